@@ -1,0 +1,250 @@
+/* rspt.h — C ABI of librspt.so: the MI355X wavefront path-tracing integrator that
+ * replaces rs_pbrt's per-tile render loop.
+ *
+ * The reference (wahn/rs_pbrt v0.9.12) has NO FFI of its own; this
+ * header is the boundary a maintainer binds from Rust (see INTEGRATION.md for the
+ * `extern "C"` block and the shim that flattens `Scene` into these structs).
+ * Each entry point cites the reference interface it stands in for; all paths are
+ * relative to the rs_pbrt source tree.
+ *
+ * Conventions
+ *   - plain C, little endian, 4-byte IEEE floats, no torch / HIP types in signatures;
+ *   - every function returns 0 on success or a negative RSPT_E_* code; the text of
+ *     the last error on the calling thread is available from rspt_last_error();
+ *   - no C++ exception and no panic crosses this boundary;
+ *   - inputs are deep-copied at rspt_scene_create (caller may free afterwards);
+ *   - calls on one scene handle are blocking and not re-entrant
+ *     (mirrors: render() is entered once from pbrt_cleanup, src/core/api.rs:2366-2369).
+ */
+#ifndef RSPT_H
+#define RSPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSPT_ABI_VERSION 1
+
+/* error codes */
+#define RSPT_OK 0
+#define RSPT_E_INVALID (-1)     /* null pointer, bad size, unsupported enum value       */
+#define RSPT_E_NODEVICE (-2)    /* no usable gfx950 device / HIP runtime failure at init  */
+#define RSPT_E_HIP (-3)         /* a HIP call failed (message has file:line + hip string) */
+#define RSPT_E_UNSUPPORTED (-4) /* scene feature outside the accelerated path (caller
+                                    falls back to the CPU loop, integrator.rs:70)           */
+#define RSPT_E_NOMEM (-5)
+
+typedef struct rspt_scene_s* rspt_scene_t;
+
+/* ---- acceleration structure ------------------------------------------------------
+ * One entry per LinearBVHNode, same order as BVHAccel.nodes
+ * (src/accelerators/bvh.rs:77-85; flatten order :358-392).  For interior nodes
+ * `offset` is the index of the second child (first child = own index + 1); for
+ * leaves it is the index of the first primitive in the BVH-ordered primitive list. */
+typedef struct {
+    float bmin[3], bmax[3];
+    int32_t offset;
+    uint16_t n_prims;
+    uint8_t axis, pad;
+} rspt_bvh_node; /* 32 B */
+
+/* One entry per element of BVHAccel.primitives (the *ordered* list, bvh.rs:144-149);
+ * each is a GeometricPrimitive wrapping a Triangle (src/core/primitive.rs:100-105,
+ * src/shapes/triangle.rs:84-96).  v[] index the global vertex arrays below. */
+typedef struct {
+    uint32_t v[3];
+    uint32_t mesh;       /* index into meshes[]                                      */
+    uint32_t material;   /* index into materials[]; 0xffffffff = no material
+                            (path.rs:109-116 passes straight through)               */
+    int32_t area_light;  /* index into lights[] or -1 (primitive.rs:193-195)         */
+} rspt_prim; /* 24 B */
+
+/* Per-TriangleMesh flags (triangle.rs:24-46).  Vertex data of all meshes is
+ * concatenated into the global arrays; a mesh without normals/tangents/uvs simply
+ * has has_* = 0 and its slots in N/S/UV are ignored. */
+typedef struct {
+    uint32_t has_n, has_s, has_uv;
+    uint32_t flip; /* reverse_orientation ^ transform_swaps_handedness (triangle.rs:324) */
+} rspt_mesh;
+
+/* ---- materials: pre-assembled BxDF lists ------------------------------------------
+ * With constant textures every Material::compute_scattering_functions
+ * (src/core/material.rs:63-113, src/materials/{matte,plastic,...}.rs) pushes the
+ * same lobes at every hit, so the shim evaluates the recipe once per material and
+ * hands over the lobe list.  Lobe order is the push order (it matters:
+ * Bsdf::sample_f picks the comp-th matching lobe, reflection.rs:307-336). */
+enum {
+    RSPT_BXDF_LAMBERT_R = 1,    /* LambertianReflection      reflection.rs:953-998   */
+    RSPT_BXDF_OREN_NAYAR = 2,   /* OrenNayar                 reflection.rs:1049-1125 */
+    RSPT_BXDF_SPECULAR_R = 3,   /* SpecularReflection        reflection.rs:711-752   */
+    RSPT_BXDF_SPECULAR_T = 4,   /* SpecularTransmission      reflection.rs:755-838   */
+    RSPT_BXDF_FRESNEL_SPEC = 5, /* FresnelSpecular           reflection.rs:841-950   */
+    RSPT_BXDF_MICROFACET_R = 6, /* MicrofacetReflection (TrowbridgeReitz, visible-area
+                                   sampling)                 reflection.rs:1128-1209 */
+    RSPT_BXDF_LAMBERT_T = 7     /* LambertianTransmission    reflection.rs:1001-1046 */
+};
+enum {
+    RSPT_FRESNEL_NOOP = 0,      /* reflection.rs:698-705 */
+    RSPT_FRESNEL_DIELECTRIC = 1,/* reflection.rs:686-696; eta_a = eta_i, eta_b = eta_t */
+    RSPT_FRESNEL_CONDUCTOR = 2  /* reflection.rs:672-684; eta_i = 1, c1 = eta_t, c2 = k */
+};
+typedef struct {
+    uint32_t type;      /* RSPT_BXDF_*                                                */
+    uint32_t fresnel;   /* RSPT_FRESNEL_* (SPECULAR_R, MICROFACET_R)                  */
+    float r[3];         /* R (reflective lobes) / T for pure transmissive lobes       */
+    float t[3];         /* T of FRESNEL_SPEC                                          */
+    float eta_a, eta_b; /* dielectric indices (SPECULAR_T, FRESNEL_SPEC, dielectric Fresnel) */
+    float alpha_x, alpha_y; /* TrowbridgeReitz alphas, already remapped and max(.,1e-3)
+                               (microfacet.rs:233-254)                                */
+    float c1[3], c2[3]; /* conductor eta_t, k                                         */
+    float on_a, on_b;   /* OrenNayar A, B (reflection.rs:1057-1065)                   */
+} rspt_bxdf; /* 80 B */
+
+typedef struct {
+    float eta;          /* Bsdf.eta (reflection.rs:224)                               */
+    uint32_t first_bxdf, n_bxdfs; /* slice of bxdfs[]; n_bxdfs <= 8 (reflection.rs:40) */
+    uint32_t pad;
+} rspt_material;
+
+/* ---- lights (Scene.lights order, src/core/scene.rs:19-24) ------------------------- */
+enum {
+    RSPT_LIGHT_DIFFUSE_AREA = 1 /* DiffuseAreaLight on one triangle, src/lights/diffuse.rs:19-27;
+                                    one per emissive triangle (api.rs:2810-2852)       */
+};
+typedef struct {
+    uint32_t kind;
+    uint32_t prim;       /* BVH-ordered primitive index of the emitting triangle      */
+    float L[3];          /* l_emit                                                    */
+    uint32_t two_sided;
+} rspt_light;
+
+typedef struct {
+    const rspt_bvh_node* nodes; uint64_t n_nodes;
+    const rspt_prim* prims;     uint64_t n_prims;     /* BVH leaf order */
+    const rspt_mesh* meshes;    uint32_t n_meshes;
+    const float* P;             /* xyz per vertex, world space (api.rs:1967-1971)     */
+    const float* N;             /* xyz per vertex or NULL                             */
+    const float* S;             /* xyz per vertex or NULL                             */
+    const float* UV;            /* uv  per vertex or NULL                             */
+    uint64_t n_vertices;
+    const rspt_material* materials; uint32_t n_materials;
+    const rspt_bxdf* bxdfs;         uint32_t n_bxdfs;
+    const rspt_light* lights;       uint32_t n_lights;
+} rspt_scene_desc;
+
+/* Sobol' generator matrices owned by the host (src/core/sobolmatrices.rs:5-7,
+ * :53463, :54155).  vdc rows are zero-padded to 52 entries. */
+typedef struct {
+    const uint32_t* sobol32;   /* [1024*52]  SOBOL_MATRICES_32          */
+    const uint64_t* vdc;       /* [25*52]    VD_C_SOBOL_MATRICES        */
+    const uint64_t* vdc_inv;   /* [26*52]    VD_C_SOBOL_MATRICES_INV    */
+} rspt_sampler_tables;
+
+enum { RSPT_SAMPLER_SOBOL = 1 };          /* src/samplers/sobol.rs                   */
+enum { RSPT_LIGHTS_UNIFORM = 0, RSPT_LIGHTS_POWER = 1, RSPT_LIGHTS_SPATIAL = 2 };
+                                           /* src/core/lightdistrib.rs:393-418         */
+
+/* Everything SamplerIntegrator::render reads from camera, film, sampler and
+ * PathIntegrator (integrator.rs:70-100; path.rs:24-34; film.rs:159-173;
+ * perspective.rs:22-43; sobol.rs:15-20). */
+typedef struct {
+    int32_t full_res[2];           /* Film.full_resolution                            */
+    int32_t crop_px[4];            /* cropped_pixel_bounds x0,y0,x1,y1 (film.rs:187-196) */
+    int32_t sample_bounds[4];      /* Film::get_sample_bounds (film.rs:266-292)       */
+    float filter_radius[2];
+    float filter_table[256];       /* film.rs:198-211                                 */
+    float max_sample_luminance;    /* film.rs:250-251; +inf by default                */
+    float raster_to_camera[16];    /* row-major Transform.m (perspective.rs:32)       */
+    float camera_to_world[16];     /* static camera_to_world.start_transform.m        */
+    float lens_radius, focal_distance;
+    float shutter_open, shutter_close;
+    uint32_t sampler_kind;         /* RSPT_SAMPLER_SOBOL                              */
+    int64_t spp;                   /* already rounded up to 2^k (sobol.rs:38-45)      */
+    uint32_t max_depth;            /* path.rs:30                                      */
+    float rr_threshold;            /* path.rs:31                                      */
+    uint32_t light_strategy;       /* RSPT_LIGHTS_*  (uniform is forced for 1 light,
+                                      lightdistrib.rs:397)                            */
+    uint32_t tile_size;            /* 16 (integrator.rs:75)                           */
+    /* multi-GPU sharding of the Morton-ordered tile list (blockqueue/mod.rs:33-36):
+     * this process renders tiles whose (morton_rank / tile_chunk) % shard_count ==
+     * shard_index.  shard_count = 1 renders everything. */
+    uint32_t shard_index, shard_count, tile_chunk;
+    rspt_sampler_tables tables;
+} rspt_render_desc;
+
+typedef struct { float o[3], d[3], t_max; uint32_t id; } rspt_ray;   /* 32 B */
+typedef struct { uint32_t prim; float t, b0, b1, b2; } rspt_hit;     /* prim = 0xffffffff on miss */
+
+typedef struct {
+    double t_render_s;      /* first launch -> film in host memory                    */
+    double t_kernels_s;     /* sum of kernel time measured with HIP events            */
+    double t_trace_s;       /* part of t_kernels_s spent in the traversal kernels     */
+    uint64_t samples;       /* camera samples rendered by this process                */
+    uint64_t rays_closest, rays_any;
+    uint64_t nodes_visited, tris_tested; /* only filled when RSPT_COUNTERS=1          */
+    uint64_t nan_samples;   /* integrator.rs:165-173                                  */
+    uint64_t trace_launches;
+    double alg_bytes;       /* SURVEY.md §8(d) B_alg over this render (needs counters) */
+} rspt_stats;
+
+/* version of this header the library was built against */
+int rspt_abi_version(void);
+
+/* Select the HIP device (ordinal among visible devices) and create streams.
+ * Must be called once per process before any other call. */
+int rspt_init(int32_t device);
+void rspt_shutdown(void);
+
+/* Replaces: RenderOptions::make_scene's hand-over of BVHAccel + lights to
+ * Scene::new (src/core/api.rs:474-485, src/core/scene.rs:27-53): uploads the
+ * flattened scene to HBM and builds the device-side triangle layout. */
+int rspt_scene_create(const rspt_scene_desc* desc, rspt_scene_t* out);
+int rspt_scene_destroy(rspt_scene_t scene);
+
+/* Replaces: SamplerIntegrator::render specialised to PathIntegrator::li
+ * (src/core/integrator.rs:70-220, src/integrators/path.rs:59-282).
+ * film_xyzw receives, for every pixel of crop_px in row-major order, exactly what
+ * Film.pixels holds after all merge_film_tile calls (film.rs:38-43,346-371):
+ * xyz[3] and filter_weight_sum.  Host memory, (x1-x0)*(y1-y0)*4 floats. */
+int rspt_render(rspt_scene_t scene, const rspt_render_desc* desc, float* film_xyzw,
+                rspt_stats* stats);
+
+/* Same, but leaves the film in device memory (for multi-GPU reduction with RCCL
+ * by the caller): film_dev is a device pointer of the same shape. */
+int rspt_render_device(rspt_scene_t scene, const rspt_render_desc* desc, void* film_dev,
+                       rspt_stats* stats);
+
+/* Debug/test hook: radiance returned by PathIntegrator::li for every camera sample,
+ * before film accumulation (integrator.rs:158-164), as rgb triples indexed
+ * [(pixel_index * spp + sample) * 3] over crop_px.  Host memory. */
+int rspt_render_samples(rspt_scene_t scene, const rspt_render_desc* desc, float* li_rgb,
+                        rspt_stats* stats);
+
+/* Stage-level hook.  Replaces: Scene::intersect / Scene::intersect_p
+ * (src/core/scene.rs:55-78) -> BVHAccel::intersect / intersect_p
+ * (src/accelerators/bvh.rs:401-514) for a batch of rays.  any_hit = 0: closest hit,
+ * out[i] = (prim, t, b0, b1, b2).  any_hit = 1: out[i].prim = 0 if occluded,
+ * 0xffffffff if not; other fields 0. */
+int rspt_trace(rspt_scene_t scene, const rspt_ray* rays, uint64_t n, rspt_hit* out,
+               int any_hit);
+
+/* Benchmark hook: same as rspt_trace on rays already resident in device memory,
+ * repeated `repeat` times; returns average kernel milliseconds per launch. */
+int rspt_trace_device(rspt_scene_t scene, const void* rays_dev, uint64_t n, void* out_dev,
+                      int any_hit, int repeat, double* ms_per_launch);
+
+/* Device memory helpers so a host without HIP bindings (tests, the Rust shim) can
+ * stage buffers for the *_device entry points. */
+int rspt_dev_alloc(uint64_t bytes, void** out);
+int rspt_dev_free(void* p);
+int rspt_dev_upload(void* dst_dev, const void* src_host, uint64_t bytes);
+int rspt_dev_download(void* dst_host, const void* src_dev, uint64_t bytes);
+
+const char* rspt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSPT_H */

@@ -1,0 +1,139 @@
+// TEST INFRASTRUCTURE — C entry points of the CPU oracle (liboracle.so), loaded with ctypes
+// by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+#include "orc_render.hpp"
+
+using namespace orc;
+
+extern "C" {
+
+// ---- leaf known-answer hooks ----
+float orc_next_float_up(float v) { return next_float_up(v); }
+float orc_next_float_down(float v) { return next_float_down(v); }
+float orc_gamma(int n) { return orc::gamma(n); }
+float orc_radical_inverse(int base_index, uint64_t a) { return radical_inverse(base_index, a); }
+uint64_t orc_sobol_index(const rspt_sampler_tables* t, uint32_t m, uint64_t frame, int32_t px, int32_t py) {
+    return sobol_interval_to_index(SobolTables{t->sobol32, t->vdc, t->vdc_inv}, m, frame, px, py);
+}
+float orc_sobol_sample(const rspt_sampler_tables* t, int64_t index, int dim) {
+    return sobol_sample_float(SobolTables{t->sobol32, t->vdc, t->vdc_inv}, index, dim, 0);
+}
+// camera samples of one pixel sample: out = p_film.xy, time, p_lens.xy
+void orc_camera_sample(const rspt_render_desc* rd, int32_t px, int32_t py, int64_t s, float out[5]) {
+    SobolSampler sp(SobolTables{rd->tables.sobol32, rd->tables.vdc, rd->tables.vdc_inv}, rd->spp, rd->sample_bounds);
+    sp.start_pixel(px, py);
+    for (int64_t i = 0; i < s; i++) sp.start_next_sample();
+    P2 f = sp.get_2d(); out[0] = (float)px + f.x; out[1] = (float)py + f.y;
+    out[2] = sp.get_1d();
+    P2 l = sp.get_2d(); out[3] = l.x; out[4] = l.y;
+}
+void orc_camera_ray(const rspt_render_desc* rd, const float cs[5], float out[7]) {
+    Ray r = camera_ray(*rd, P2{cs[0], cs[1]}, cs[2], P2{cs[3], cs[4]});
+    out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z; out[6] = r.t_max;
+}
+void orc_offset_ray_origin(const float p[3], const float pe[3], const float n[3], const float w[3], float out[3]) {
+    V3 r = offset_ray_origin(V3{p[0], p[1], p[2]}, V3{pe[0], pe[1], pe[2]}, V3{n[0], n[1], n[2]}, V3{w[0], w[1], w[2]});
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_concentric_sample_disk(float ux, float uy, float out[2]) { P2 d = concentric_sample_disk(P2{ux, uy}); out[0] = d.x; out[1] = d.y; }
+float orc_fr_dielectric(float c, float ei, float et) { return fr_dielectric(c, ei, et); }
+// Distribution1D: returns sampled offset, writes pdf and the cdf (n+1 floats)
+int64_t orc_distribution1d(const float* f, int n, float u, float* pdf, float* cdf_out, float* func_int) {
+    Distribution1D d(std::vector<Float>(f, f + n));
+    if (cdf_out) for (int i = 0; i <= n; i++) cdf_out[i] = d.cdf[i];
+    if (func_int) *func_int = d.func_int;
+    return (int64_t)d.sample_discrete(u, pdf);
+}
+
+// ---- BSDF hooks: evaluate a material in a given shading frame (n = (0,0,1), dpdu = (1,0,0)) ----
+static Interaction unit_frame() {
+    Interaction it; it.n = V3{0, 0, 1}; it.sh_n = V3{0, 0, 1}; it.sh_dpdu = V3{1, 0, 0}; it.sh_dpdv = V3{0, 1, 0};
+    it.p = V3{0, 0, 0}; it.p_error = V3{0, 0, 0};
+    return it;
+}
+void orc_bsdf_f(const rspt_material* m, const rspt_bxdf* all, const float wo[3], const float wi[3], uint32_t flags, float f_out[3], float* pdf_out) {
+    Interaction it = unit_frame();
+    Bsdf b(it, *m, all);
+    Spec f = b.f(V3{wo[0], wo[1], wo[2]}, V3{wi[0], wi[1], wi[2]}, (uint8_t)flags);
+    f_out[0] = f.c[0]; f_out[1] = f.c[1]; f_out[2] = f.c[2];
+    *pdf_out = b.pdf(V3{wo[0], wo[1], wo[2]}, V3{wi[0], wi[1], wi[2]}, (uint8_t)flags);
+}
+void orc_bsdf_sample_f(const rspt_material* m, const rspt_bxdf* all, const float wo[3], float ux, float uy, uint32_t flags,
+                       float f_out[3], float wi_out[3], float* pdf_out, uint32_t* sampled_type) {
+    Interaction it = unit_frame();
+    Bsdf b(it, *m, all);
+    V3 wi{0, 0, 0}; Float pdf = 0; uint8_t st = 255;
+    Spec f = b.sample_f(V3{wo[0], wo[1], wo[2]}, &wi, P2{ux, uy}, &pdf, (uint8_t)flags, &st);
+    f_out[0] = f.c[0]; f_out[1] = f.c[1]; f_out[2] = f.c[2];
+    wi_out[0] = wi.x; wi_out[1] = wi.y; wi_out[2] = wi.z; *pdf_out = pdf; *sampled_type = st;
+}
+
+// ---- BVH build (BVHAccel::new over triangles given by global vertex indices) ----
+// tri_idx: n*3 vertex indices; ordered_out: n entries (input index of the primitive at each
+// BVH-ordered slot).  Returns node count, or -(needed) if nodes_cap is too small.
+int64_t orc_bvh_build(const float* P, const uint32_t* tri_idx, uint64_t n, uint32_t max_prims_in_node,
+                      rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out) {
+    std::vector<Bounds3> bounds(n);
+    for (uint64_t i = 0; i < n; i++) { // Triangle::world_bound triangle.rs:126-133
+        const uint32_t* v = tri_idx + 3 * i;
+        V3 p0{P[3 * v[0]], P[3 * v[0] + 1], P[3 * v[0] + 2]}, p1{P[3 * v[1]], P[3 * v[1] + 1], P[3 * v[1] + 2]}, p2{P[3 * v[2]], P[3 * v[2] + 1], P[3 * v[2] + 2]};
+        bounds[i] = bunion(bounds_from(p0, p1), p2);
+    }
+    std::vector<rspt_bvh_node> nodes; std::vector<uint32_t> ordered;
+    bvh_build(bounds.data(), n, max_prims_in_node, nodes, ordered);
+    if (nodes.size() > nodes_cap) return -(int64_t)nodes.size();
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(rspt_bvh_node));
+    std::memcpy(ordered_out, ordered.data(), ordered.size() * sizeof(uint32_t));
+    return (int64_t)nodes.size();
+}
+
+// ---- stage hook: Scene::intersect / intersect_p over a batch ----
+// counters_out (optional): nodes_visited, tris_tested
+void orc_trace(const rspt_scene_desc* sd, const rspt_ray* rays, uint64_t n, rspt_hit* out, int any_hit, int brute, uint64_t* counters_out) {
+    Scene sc{*sd};
+    Counters c;
+    for (uint64_t i = 0; i < n; i++) {
+        Ray r{V3{rays[i].o[0], rays[i].o[1], rays[i].o[2]}, V3{rays[i].d[0], rays[i].d[1], rays[i].d[2]}, rays[i].t_max, 0.0f};
+        rspt_hit h; h.prim = 0xffffffffu; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
+        if (any_hit) { if (sc.intersect_p(r, &c)) h.prim = 0; }
+        else if (brute) { uint32_t p; Float t; if (sc.intersect_brute(r, &p, &t)) { h.prim = p; h.t = t; } }
+        else {
+            Interaction isect; Float t = 0, b[3] = {0, 0, 0};
+            if (sc.intersect(r, &isect, &c, &t, b)) { h.prim = (uint32_t)isect.prim; h.t = t; h.b0 = b[0]; h.b1 = b[1]; h.b2 = b[2]; }
+        }
+        out[i] = h;
+    }
+    if (counters_out) { counters_out[0] = c.nodes_visited; counters_out[1] = c.tris_tested; }
+}
+
+// ---- the whole path: SamplerIntegrator::render ----
+// counters_out[8]: nodes_visited, tris_tested, rays_closest, rays_any, bounces, samples, nan_samples, mis_rays
+int orc_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb,
+               uint64_t* counters_out, double* seconds_out) {
+    if (!sd || !rd) return -1;
+    Scene sc{*sd};
+    RenderOut out;
+    render(sc, *rd, num_threads, film_xyzw, li_rgb, &out);
+    if (counters_out) {
+        const Counters& c = out.counters;
+        uint64_t v[8] = {c.nodes_visited, c.tris_tested, c.rays_closest, c.rays_any, c.bounces, c.samples, c.nan_samples, c.mis_rays};
+        std::memcpy(counters_out, v, sizeof v);
+    }
+    if (seconds_out) *seconds_out = out.seconds;
+    return 0;
+}
+
+// spatial light distribution of one voxel (for differential tests of the device builder):
+// writes n_lights func values and n_lights+1 cdf values.
+void orc_spatial_voxel(const rspt_scene_desc* sd, const rspt_render_desc* rd, const int32_t pi[3], float* func_out, float* cdf_out, int32_t n_voxels_out[3]) {
+    Scene sc{*sd};
+    RenderCtx cx; cx.scene = &sc; cx.rd = rd;
+    light_distrib_init(cx);
+    if (n_voxels_out) for (int i = 0; i < 3; i++) n_voxels_out[i] = cx.strategy == RSPT_LIGHTS_SPATIAL ? cx.n_voxels[i] : 0;
+    if (cx.strategy != RSPT_LIGHTS_SPATIAL) return;
+    int p[3] = {pi[0], pi[1], pi[2]};
+    std::unique_ptr<Distribution1D> d(spatial_compute(cx, p));
+    for (size_t i = 0; i < d->func.size(); i++) func_out[i] = d->func[i];
+    for (size_t i = 0; i < d->cdf.size(); i++) cdf_out[i] = d->cdf[i];
+}
+
+} // extern "C"

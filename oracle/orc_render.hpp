@@ -1,0 +1,516 @@
+// TEST INFRASTRUCTURE — CPU oracle (see orc_math.hpp header).  Sampler, lights, light
+// distributions, PathIntegrator::li, film, tile render loop.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "orc_bsdf.hpp"
+
+namespace orc {
+
+// ---- Sobol' sampler: src/samplers/sobol.rs, src/core/lowdiscrepancy.rs:1014-1076 ----
+struct SobolTables { const uint32_t* sobol32; const uint64_t* vdc; const uint64_t* vdc_inv; };
+
+static inline uint64_t sobol_interval_to_index(const SobolTables& T, uint32_t m, uint64_t frame, int32_t px, int32_t py) {
+    if (m == 0) return 0;
+    uint32_t m2 = m << 1;
+    uint64_t index = frame << m2;
+    uint64_t delta = 0;
+    for (int c = 0; frame > 0; frame >>= 1, c++)
+        if (frame & 1) delta ^= T.vdc[(m - 1) * 52 + c];
+    uint64_t b = ((uint64_t)((uint32_t)px << m) | (uint64_t)(int64_t)py) ^ delta;
+    for (int c = 0; b > 0; b >>= 1, c++)
+        if (b & 1) index ^= T.vdc_inv[(m - 1) * 52 + c];
+    return index;
+}
+static inline Float sobol_sample_float(const SobolTables& T, int64_t a, int dimension, uint32_t scramble) {
+    uint32_t v = scramble;
+    for (size_t i = (size_t)dimension * 52; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= T.sobol32[i];
+    return std::fmin((Float)v * 0x1.0p-32f, FLOAT_ONE_MINUS_EPSILON);
+}
+static inline int32_t round_up_pow2_32(int32_t v) { // pbrt.rs:188-198
+    v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1;
+}
+static inline int log2_int(uint32_t v) { return 31 - __builtin_clz(v); } // pbrt.rs:160-163
+
+struct SobolSampler {
+    SobolTables T;
+    int64_t spp;
+    int32_t sb[4]; // sample_bounds x0,y0,x1,y1
+    int32_t resolution, log2_res;
+    int64_t dimension = 0;
+    uint64_t interval_sample_index = 0;
+    int32_t px = 0, py = 0;
+    int64_t cur_sample = 0;
+    SobolSampler(const SobolTables& t, int64_t spp_, const int32_t sb_[4]) : T(t), spp(spp_) {
+        for (int i = 0; i < 4; i++) sb[i] = sb_[i];
+        resolution = round_up_pow2_32(std::max(sb[2] - sb[0], sb[3] - sb[1])); // sobol.rs:46-47
+        log2_res = log2_int((uint32_t)resolution);
+    }
+    uint64_t get_index_for_sample(uint64_t n) const { // sobol.rs:110-117
+        return sobol_interval_to_index(T, (uint32_t)log2_res, n, px - sb[0], py - sb[1]);
+    }
+    Float sample_dimension(uint64_t index, int64_t dim) const { // sobol.rs:118-140
+        Float s = sobol_sample_float(T, (int64_t)index, (int)dim, 0);
+        if (dim == 0 || dim == 1) {
+            s = s * (Float)resolution + (Float)sb[dim];
+            s = clamp_t(s - (Float)(dim == 0 ? px : py), 0.0f, FLOAT_ONE_MINUS_EPSILON);
+        }
+        return s;
+    }
+    void start_pixel(int32_t x, int32_t y) { px = x; py = y; cur_sample = 0; dimension = 0; interval_sample_index = get_index_for_sample(0); }
+    // array_start_dim == array_end_dim == 5 for `path` (Appendix B): the skip tests never fire
+    Float get_1d() { Float r = sample_dimension(interval_sample_index, dimension); dimension += 1; return r; }
+    P2 get_2d() { // sobol.rs:190-201: y first
+        Float y = sample_dimension(interval_sample_index, dimension + 1);
+        Float x = sample_dimension(interval_sample_index, dimension);
+        dimension += 2;
+        return P2{x, y};
+    }
+    bool start_next_sample() { // sobol.rs:232-241
+        dimension = 0;
+        interval_sample_index = get_index_for_sample((uint64_t)cur_sample + 1);
+        cur_sample += 1;
+        return cur_sample < spp;
+    }
+};
+
+// ---- radical inverse: src/core/lowdiscrepancy.rs:770-787,1082-1096,1126-1135 ----
+static inline uint32_t reverse_bits_32(uint32_t n) {
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x00ff00ffu) << 8) | ((n & 0xff00ff00u) >> 8);
+    n = ((n & 0x0f0f0f0fu) << 4) | ((n & 0xf0f0f0f0u) >> 4);
+    n = ((n & 0x33333333u) << 2) | ((n & 0xccccccccu) >> 2);
+    n = ((n & 0x55555555u) << 1) | ((n & 0xaaaaaaaau) >> 1);
+    return n;
+}
+static inline uint64_t reverse_bits_64(uint64_t n) {
+    uint64_t n0 = reverse_bits_32((uint32_t)n), n1 = reverse_bits_32((uint32_t)(n >> 32));
+    return (n0 << 32) | n1;
+}
+static inline Float radical_inverse(int base_index, uint64_t a) {
+    static const int primes[5] = {2, 3, 5, 7, 11};
+    if (base_index == 0) return (Float)reverse_bits_64(a) * 0x1.0p-64f;
+    int base = primes[base_index];
+    Float inv_base = 1.0f / (Float)base;
+    uint64_t reversed = 0;
+    Float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base, digit = a - next * base;
+        reversed = reversed * base + digit;
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return std::fmin((Float)reversed * inv_base_n, FLOAT_ONE_MINUS_EPSILON);
+}
+
+// ---- Distribution1D: src/core/sampling.rs:17-147 ----
+struct Distribution1D {
+    std::vector<Float> func, cdf;
+    Float func_int = 0;
+    explicit Distribution1D(const std::vector<Float>& f) : func(f) {
+        size_t n = f.size();
+        cdf.resize(n + 1);
+        cdf[0] = 0.0f;
+        for (size_t i = 1; i <= n; i++) cdf[i] = cdf[i - 1] + f[i - 1] / (Float)n;
+        func_int = cdf[n];
+        if (func_int == 0.0f) for (size_t i = 1; i <= n; i++) cdf[i] = (Float)i / (Float)n;
+        else for (size_t i = 1; i <= n; i++) cdf[i] /= func_int;
+    }
+    size_t sample_discrete(Float u, Float* pdf) const { // :103-142
+        size_t first = 0, len = cdf.size();
+        while (len > 0) {
+            size_t half = len >> 1, middle = first + half;
+            if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; } else len = half;
+        }
+        long off = clamp_t((long)first - 1, 0L, (long)cdf.size() - 2);
+        if (pdf) *pdf = func_int > 0.0f ? func[off] / (func_int * (Float)func.size()) : 0.0f;
+        return (size_t)off;
+    }
+};
+
+struct RenderCtx {
+    const Scene* scene;
+    const rspt_render_desc* rd;
+    SobolTables T;
+    // light distribution state (src/core/lightdistrib.rs)
+    int strategy; // after the "1 light -> uniform" rule (:397)
+    std::shared_ptr<Distribution1D> fixed; // uniform / power
+    int n_voxels[3];
+    // dense grid of lazily-filled per-voxel distributions; stands in for the reference's
+    // lock-free hash table (lightdistrib.rs:296-383): same values, no probing (Q18)
+    std::unique_ptr<std::atomic<Distribution1D*>[]> voxels;
+    size_t n_vox_total = 0;
+    ~RenderCtx() { for (size_t i = 0; i < n_vox_total; i++) delete voxels[i].load(); }
+};
+
+// ---- DiffuseAreaLight: src/lights/diffuse.rs ----
+static inline Spec light_l(const rspt_light& lt, V3 n, V3 w) { // :164-170
+    if (lt.two_sided || dot(n, w) > 0.0f) return S3(lt.L);
+    return Spec(0.0f);
+}
+// sample_li :64-84
+static inline Spec light_sample_li(const Scene& sc, const rspt_light& lt, const Interaction& iref, P2 u, V3* wi, Float* pdf, Interaction* light_intr) {
+    *light_intr = sc.tri_sample_ref(sc.d.prims[lt.prim], iref, u, pdf);
+    if (*pdf == 0.0f || length_squared(light_intr->p - iref.p) == 0.0f) { *pdf = 0.0f; return Spec(); }
+    *wi = normalize(light_intr->p - iref.p);
+    return light_l(lt, light_intr->n, -*wi);
+}
+// power :85-93
+static inline Spec light_power(const Scene& sc, const rspt_light& lt) {
+    Float factor = lt.two_sided ? 2.0f : 1.0f;
+    return S3(lt.L) * factor * sc.tri_area(sc.d.prims[lt.prim]) * PI;
+}
+
+// ---- SpatialLightDistribution::compute_distribution: lightdistrib.rs:169-269 ----
+static inline Distribution1D* spatial_compute(const RenderCtx& cx, const int pi[3]) {
+    const Scene& sc = *cx.scene;
+    Bounds3 wb = sc.world_bound();
+    V3 p0{(Float)pi[0] / (Float)cx.n_voxels[0], (Float)pi[1] / (Float)cx.n_voxels[1], (Float)pi[2] / (Float)cx.n_voxels[2]};
+    V3 p1{(Float)(pi[0] + 1) / (Float)cx.n_voxels[0], (Float)(pi[1] + 1) / (Float)cx.n_voxels[1], (Float)(pi[2] + 1) / (Float)cx.n_voxels[2]};
+    Bounds3 vb; vb.p_min = wb.lerp3(p0); vb.p_max = wb.lerp3(p1);
+    const size_t n_samples = 128;
+    uint32_t nl = sc.d.n_lights;
+    std::vector<Float> contrib(nl, 0.0f);
+    for (size_t i = 0; i < n_samples; i++) {
+        V3 po = vb.lerp3(V3{radical_inverse(0, i), radical_inverse(1, i), radical_inverse(2, i)});
+        Interaction intr; intr.p = po; intr.time = 0; intr.p_error = V3{0, 0, 0}; intr.wo = V3{1, 0, 0}; intr.n = V3{0, 0, 0};
+        P2 u{radical_inverse(3, i), radical_inverse(4, i)};
+        for (uint32_t j = 0; j < nl; j++) {
+            Float pdf = 0; V3 wi{0, 0, 0}; Interaction li_intr;
+            Spec li = light_sample_li(sc, sc.d.lights[j], intr, u, &wi, &pdf, &li_intr);
+            if (pdf > 0.0f) contrib[j] += li.y() / pdf;
+        }
+    }
+    Float sum = 0.0f; for (Float c : contrib) sum += c; // iter().sum()
+    Float avg = sum / (Float)(n_samples * contrib.size());
+    Float min_contrib = avg > 0.0f ? 0.001f * avg : 1.0f;
+    for (Float& c : contrib) c = std::fmax(c, min_contrib);
+    return new Distribution1D(contrib);
+}
+// lookup: lightdistrib.rs:276-384 (hash probing replaced by an ordered map: same values, Q18)
+static inline const Distribution1D* light_lookup(RenderCtx& cx, V3 p) {
+    if (cx.strategy != RSPT_LIGHTS_SPATIAL) return cx.fixed.get();
+    V3 off = cx.scene->world_bound().offset(p);
+    int pi[3];
+    for (int i = 0; i < 3; i++) pi[i] = clamp_t(f2i(off[i] * (Float)cx.n_voxels[i]), 0, cx.n_voxels[i] - 1);
+    size_t key = ((size_t)pi[2] * cx.n_voxels[1] + pi[1]) * cx.n_voxels[0] + pi[0];
+    Distribution1D* cur = cx.voxels[key].load(std::memory_order_acquire);
+    if (cur) return cur;
+    Distribution1D* dist = spatial_compute(cx, pi);
+    Distribution1D* expected = nullptr;
+    if (cx.voxels[key].compare_exchange_strong(expected, dist, std::memory_order_acq_rel)) return dist;
+    delete dist; // another thread filled the voxel first (same value: pure function of the voxel)
+    return expected;
+}
+static inline void light_distrib_init(RenderCtx& cx) { // create_light_sample_distribution :393-418, new :127-166
+    const Scene& sc = *cx.scene;
+    uint32_t nl = sc.d.n_lights;
+    cx.strategy = (int)cx.rd->light_strategy;
+    if (cx.strategy == RSPT_LIGHTS_UNIFORM || nl == 1) {
+        cx.strategy = RSPT_LIGHTS_UNIFORM;
+        cx.fixed = std::make_shared<Distribution1D>(std::vector<Float>(nl, 1.0f));
+    } else if (cx.strategy == RSPT_LIGHTS_POWER) {
+        std::vector<Float> pw;
+        for (uint32_t i = 0; i < nl; i++) pw.push_back(light_power(sc, sc.d.lights[i]).y()); // integrator.rs:573-584
+        cx.fixed = std::make_shared<Distribution1D>(pw);
+    } else {
+        cx.strategy = RSPT_LIGHTS_SPATIAL;
+        Bounds3 b = sc.world_bound();
+        V3 diag = b.diagonal();
+        Float bmax = diag[b.maximum_extent()];
+        for (int i = 0; i < 3; i++) cx.n_voxels[i] = std::max(1, f2i(std::round(diag[i] / bmax * 64.0f)));
+        cx.n_vox_total = (size_t)cx.n_voxels[0] * cx.n_voxels[1] * cx.n_voxels[2];
+        cx.voxels.reset(new std::atomic<Distribution1D*>[cx.n_vox_total]);
+        for (size_t i = 0; i < cx.n_vox_total; i++) cx.voxels[i].store(nullptr);
+    }
+}
+
+// ---- integrator.rs:359-570 ----
+static inline Spec estimate_direct(RenderCtx& cx, const Interaction& it, const Bsdf& bsdf, P2 u_scattering, uint32_t light_num, P2 u_light, Counters* c) {
+    const Scene& sc = *cx.scene;
+    const rspt_light& light = sc.d.lights[light_num];
+    const uint8_t flags = BSDF_ALL & ~BSDF_SPECULAR;
+    Spec ld(0.0f);
+    V3 wi{0, 0, 0};
+    Float light_pdf = 0.0f, scattering_pdf = 0.0f;
+    Interaction light_intr;
+    Spec li = light_sample_li(sc, light, it, u_light, &wi, &light_pdf, &light_intr);
+    if (light_pdf > 0.0f && !li.is_black()) {
+        Spec f = bsdf.f(it.wo, wi, flags) * Spec(abs_dot(wi, it.sh_n));
+        scattering_pdf = bsdf.pdf(it.wo, wi, flags);
+        if (!f.is_black()) {
+            Ray sray = it.spawn_ray_to(light_intr); // VisibilityTester::unoccluded light.rs:199-206
+            if (sc.intersect_p(sray, c)) li = Spec(0.0f);
+            if (!li.is_black()) {
+                Float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                ld = ld + f * li * Spec(weight) / light_pdf;
+            }
+        }
+    }
+    // sample BSDF with MIS (area lights are never delta)
+    {
+        uint8_t sampled_type = 0; // Q6: stays 0 => sampled_specular always false
+        Spec f = bsdf.sample_f(it.wo, &wi, u_scattering, &scattering_pdf, flags, &sampled_type);
+        f = f * Spec(abs_dot(wi, it.sh_n));
+        bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
+        if (!f.is_black() && scattering_pdf > 0.0f) {
+            Float weight = 1.0f;
+            if (!sampled_specular) {
+                light_pdf = sc.tri_pdf_ref(sc.d.prims[light.prim], it, wi); // pdf_li diffuse.rs:100-103
+                if (light_pdf == 0.0f) return ld;
+                weight = power_heuristic(1, scattering_pdf, 1, light_pdf);
+            }
+            Ray ray = it.spawn_ray(wi);
+            Spec li2;
+            Interaction light_isect;
+            if (c) c->mis_rays++;
+            if (sc.intersect(ray, &light_isect, c)) {
+                const rspt_prim& hp = sc.d.prims[light_isect.prim];
+                if (hp.area_light >= 0 && (uint32_t)hp.area_light == light_num) // pointer compare :550-558
+                    li2 = light_l(light, light_isect.n, -wi);
+            } else {
+                li2 = Spec(); // DiffuseAreaLight::le = 0 (diffuse.rs:97-99)
+            }
+            if (!li2.is_black()) ld = ld + f * li2 * Spec(1.0f) * weight / scattering_pdf;
+        }
+    }
+    return ld;
+}
+
+static inline Spec uniform_sample_one_light(RenderCtx& cx, const Interaction& it, const Bsdf& bsdf, SobolSampler& sampler, const Distribution1D& distrib, Counters* c) {
+    uint32_t nl = cx.scene->d.n_lights;
+    if (nl == 0) return Spec();
+    Float pdf = 0.0f;
+    size_t light_num = distrib.sample_discrete(sampler.get_1d(), &pdf);
+    if (pdf == 0.0f) return Spec();
+    P2 u_light = sampler.get_2d();
+    P2 u_scattering = sampler.get_2d();
+    return estimate_direct(cx, it, bsdf, u_scattering, (uint32_t)light_num, u_light, c) / pdf;
+}
+
+// ---- PathIntegrator::li: src/integrators/path.rs:59-282 ----
+static inline Spec path_li(RenderCtx& cx, const Ray& r, SobolSampler& sampler, Counters* c) {
+    const Scene& sc = *cx.scene;
+    Spec l, beta(1.0f);
+    Ray ray = r;
+    bool specular_bounce = false;
+    uint32_t bounces = 0;
+    Float eta_scale = 1.0f;
+    for (;;) {
+        Interaction isect;
+        if (sc.intersect(ray, &isect, c)) {
+            const rspt_prim& hp = sc.d.prims[isect.prim];
+            if (bounces == 0 || specular_bounce) {
+                if (hp.area_light >= 0) l = l + beta * light_l(sc.d.lights[hp.area_light], isect.n, -ray.d); // interaction.rs:475-483
+                else l = l + beta * Spec();
+            }
+            if (bounces >= cx.rd->max_depth) break;
+            if (hp.material == 0xffffffffu) { ray = isect.spawn_ray(ray.d); continue; } // null bsdf :109-116
+            Bsdf bsdf(isect, sc.d.materials[hp.material], sc.d.bxdfs);
+            if (c) c->bounces++;
+            // lookup happens for every hit (path.rs:118); with no lights its result is never used
+            const Distribution1D* distrib = sc.d.n_lights ? light_lookup(cx, isect.p) : nullptr;
+            if (sc.d.n_lights && bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+                Spec ld = beta * uniform_sample_one_light(cx, isect, bsdf, sampler, *distrib, c);
+                l = l + ld;
+            }
+            V3 wo = -ray.d, wi{0, 0, 0};
+            Float pdf = 0.0f;
+            uint8_t sampled_type = 255;
+            Spec f = bsdf.sample_f(wo, &wi, sampler.get_2d(), &pdf, BSDF_ALL, &sampled_type);
+            if (f.is_black() || pdf == 0.0f) break;
+            beta = beta * ((f * abs_dot(wi, isect.sh_n)) / pdf);
+            specular_bounce = (sampled_type & BSDF_SPECULAR) != 0;
+            if ((sampled_type & BSDF_SPECULAR) && (sampled_type & BSDF_TRANSMISSION)) {
+                Float eta = bsdf.eta;
+                if (dot(wo, isect.n) > 0.0f) eta_scale *= eta * eta;
+                else eta_scale *= 1.0f / (eta * eta);
+            }
+            ray = isect.spawn_ray(wi);
+            // (BSSRDF branch :191-249 out of scope)
+            Spec rr_beta = beta * eta_scale;
+            if (rr_beta.max_component_value() < cx.rd->rr_threshold && bounces > 3) {
+                Float q = std::fmax(0.05f, 1.0f - rr_beta.max_component_value());
+                if (sampler.get_1d() < q) break;
+                beta = beta / (1.0f - q);
+            }
+        } else {
+            // no infinite lights in scope: `for light in &scene.infinite_lights` adds nothing
+            break;
+        }
+        bounces += 1;
+    }
+    return l;
+}
+
+// ---- PerspectiveCamera::generate_ray_differential: src/cameras/perspective.rs:190-280 ----
+static inline Ray camera_ray(const rspt_render_desc& rd, P2 p_film, Float time_s, P2 p_lens) {
+    V3 p_camera = transform_point(rd.raster_to_camera, V3{p_film.x, p_film.y, 0.0f});
+    V3 dir = normalize(p_camera);
+    Ray in_ray{V3{0, 0, 0}, dir, INF, lerp(time_s, rd.shutter_open, rd.shutter_close)};
+    if (rd.lens_radius > 0.0f) {
+        P2 pl = concentric_sample_disk(p_lens);
+        pl = P2{pl.x * rd.lens_radius, pl.y * rd.lens_radius};
+        Float ft = rd.focal_distance / in_ray.d.z;
+        V3 p_focus = in_ray.o + in_ray.d * ft;
+        in_ray.o = V3{pl.x, pl.y, 0.0f};
+        in_ray.d = normalize(p_focus - in_ray.o);
+    }
+    return transform_ray(rd.camera_to_world, in_ray);
+}
+
+// ---- film: src/core/film.rs:57-153,308-371 ----
+struct FilmTilePixel { Spec contrib_sum; Float filter_weight_sum = 0; };
+struct FilmTile {
+    int32_t pb[4]; // pixel_bounds
+    std::vector<FilmTilePixel> pixels;
+    void add_sample(const rspt_render_desc& rd, P2 p_film, Spec l, Float sample_weight) { // :94-147
+        if (l.y() > rd.max_sample_luminance) l = l * Spec(rd.max_sample_luminance / l.y());
+        P2 pd{p_film.x - 0.5f, p_film.y - 0.5f};
+        int32_t p0x = f2i(std::ceil(pd.x - rd.filter_radius[0])), p0y = f2i(std::ceil(pd.y - rd.filter_radius[1]));
+        int32_t p1x = f2i(std::floor(pd.x + rd.filter_radius[0])) + 1, p1y = f2i(std::floor(pd.y + rd.filter_radius[1])) + 1;
+        p0x = std::max(p0x, pb[0]); p0y = std::max(p0y, pb[1]);
+        p1x = std::min(p1x, pb[2]); p1y = std::min(p1y, pb[3]);
+        Float inv_rx = 1.0f / rd.filter_radius[0], inv_ry = 1.0f / rd.filter_radius[1];
+        const Float ts = 16.0f;
+        for (int32_t y = p0y; y < p1y; y++) {
+            Float fy = std::fabs(((Float)y - pd.y) * inv_ry * ts);
+            size_t ify = (size_t)f2usize(std::fmin(std::floor(fy), ts - 1.0f));
+            for (int32_t x = p0x; x < p1x; x++) {
+                Float fx = std::fabs(((Float)x - pd.x) * inv_rx * ts);
+                size_t ifx = (size_t)f2usize(std::fmin(std::floor(fx), ts - 1.0f));
+                Float w = rd.filter_table[ify * 16 + ifx];
+                FilmTilePixel& px = pixels[(size_t)(y - pb[1]) * (size_t)(pb[2] - pb[0]) + (size_t)(x - pb[0])];
+                px.contrib_sum = px.contrib_sum + l * Spec(sample_weight) * Spec(w);
+                px.filter_weight_sum += w;
+            }
+        }
+    }
+};
+static inline FilmTile get_film_tile(const rspt_render_desc& rd, const int32_t tb[4]) { // :308-345
+    FilmTile t;
+    Float pminx = (Float)tb[0] - 0.5f - rd.filter_radius[0], pminy = (Float)tb[1] - 0.5f - rd.filter_radius[1];
+    Float pmaxx = (Float)tb[2] - 0.5f + rd.filter_radius[0], pmaxy = (Float)tb[3] - 0.5f + rd.filter_radius[1];
+    int32_t p0x = f2i(std::ceil(pminx)), p0y = f2i(std::ceil(pminy));
+    int32_t p1x = f2i(std::floor(pmaxx)) + 1, p1y = f2i(std::floor(pmaxy)) + 1;
+    // bnd2_intersect_bnd2i with cropped_pixel_bounds
+    t.pb[0] = std::max(p0x, rd.crop_px[0]); t.pb[1] = std::max(p0y, rd.crop_px[1]);
+    t.pb[2] = std::min(p1x, rd.crop_px[2]); t.pb[3] = std::min(p1y, rd.crop_px[3]);
+    int64_t area = (int64_t)std::max(0, t.pb[2] - t.pb[0]) * std::max(0, t.pb[3] - t.pb[1]);
+    t.pixels.resize((size_t)area);
+    return t;
+}
+
+// blockqueue/mod.rs:100-115
+static inline uint32_t part1_by1(uint32_t x) {
+    x &= 0x0000ffff; x = (x ^ (x << 8)) & 0x00ff00ff; x = (x ^ (x << 4)) & 0x0f0f0f0f;
+    x = (x ^ (x << 2)) & 0x33333333; return (x ^ (x << 1)) & 0x55555555;
+}
+static inline uint32_t morton2(uint32_t x, uint32_t y) { return (part1_by1(y) << 1) + part1_by1(x); }
+
+struct RenderOut {
+    Counters counters;
+    double seconds = 0;
+};
+
+// ---- SamplerIntegrator::render: src/core/integrator.rs:70-220 ----
+// film_xyzw: Film.pixels after all merges (xyz + filter_weight_sum per cropped pixel);
+// li_rgb (optional): radiance per camera sample, [(pixel*spp+s)*3] over crop_px.
+static inline void render(const Scene& scene, const rspt_render_desc& rd, int num_threads, float* film_xyzw, float* li_rgb, RenderOut* out) {
+    RenderCtx cx;
+    cx.scene = &scene; cx.rd = &rd;
+    cx.T = SobolTables{rd.tables.sobol32, rd.tables.vdc, rd.tables.vdc_inv};
+    light_distrib_init(cx);
+    const int32_t* sb = rd.sample_bounds;
+    int32_t ext_x = sb[2] - sb[0], ext_y = sb[3] - sb[1];
+    int32_t ts = (int32_t)rd.tile_size;
+    int32_t ntx = (ext_x + ts - 1) / ts, nty = (ext_y + ts - 1) / ts;
+    // BlockQueue::new: Morton-sorted tile list (blockqueue/mod.rs:23-52); sort_by_key is stable
+    std::vector<std::pair<uint32_t, uint32_t>> blocks;
+    for (int32_t i = 0; i < ntx * nty; i++) blocks.push_back({(uint32_t)(i % ntx), (uint32_t)(i / ntx)});
+    std::stable_sort(blocks.begin(), blocks.end(), [](auto a, auto b) { return morton2(a.first, a.second) < morton2(b.first, b.second); });
+    // multi-GPU style sharding of the tile list (not in the reference; shard_count == 1 there)
+    std::vector<size_t> mine;
+    uint32_t chunk = rd.tile_chunk ? rd.tile_chunk : 1, sc_ = rd.shard_count ? rd.shard_count : 1;
+    for (size_t i = 0; i < blocks.size(); i++) if ((i / chunk) % sc_ == rd.shard_index) mine.push_back(i);
+    std::vector<FilmTile> tiles(mine.size());
+    std::atomic<size_t> next{0};
+    int cw = rd.crop_px[2] - rd.crop_px[0], ch = rd.crop_px[3] - rd.crop_px[1];
+    std::vector<Counters> tc((size_t)std::max(1, num_threads));
+    auto worker = [&](int tid) {
+        SobolSampler sampler(cx.T, rd.spp, rd.sample_bounds);
+        Counters& c = tc[tid];
+        for (;;) {
+            size_t k = next.fetch_add(1);
+            if (k >= mine.size()) break;
+            auto blk = blocks[mine[k]];
+            int32_t x0 = sb[0] + (int32_t)blk.first * ts, x1 = std::min(x0 + ts, sb[2]);
+            int32_t y0 = sb[1] + (int32_t)blk.second * ts, y1 = std::min(y0 + ts, sb[3]);
+            int32_t tb[4] = {x0, y0, x1, y1};
+            FilmTile ft = get_film_tile(rd, tb);
+            for (int32_t py = y0; py < y1; py++)
+                for (int32_t px = x0; px < x1; px++) {
+                    sampler.start_pixel(px, py);
+                    // pixel_bounds == sample_bounds (Q16)
+                    if (!(px >= sb[0] && px < sb[2] && py >= sb[1] && py < sb[3])) continue;
+                    bool done = false;
+                    while (!done) {
+                        P2 f2 = sampler.get_2d();
+                        P2 p_film{(Float)px + f2.x, (Float)py + f2.y}; // sampler.rs:85-95
+                        Float time_s = sampler.get_1d();
+                        P2 p_lens = sampler.get_2d();
+                        Ray ray = camera_ray(rd, p_film, time_s, p_lens);
+                        Float ray_weight = 1.0f;
+                        Spec l = path_li(cx, ray, sampler, &c);
+                        c.samples++;
+                        if (l.has_nans()) { l = Spec(0.0f); c.nan_samples++; } // integrator.rs:165-173 (Q1)
+                        if (li_rgb && px >= rd.crop_px[0] && px < rd.crop_px[2] && py >= rd.crop_px[1] && py < rd.crop_px[3]) {
+                            size_t pix = (size_t)(py - rd.crop_px[1]) * cw + (size_t)(px - rd.crop_px[0]);
+                            float* o = li_rgb + (pix * (size_t)rd.spp + (size_t)sampler.cur_sample) * 3;
+                            o[0] = l.c[0]; o[1] = l.c[1]; o[2] = l.c[2];
+                        }
+                        ft.add_sample(rd, p_film, l, ray_weight);
+                        done = !sampler.start_next_sample();
+                    }
+                }
+            tiles[k] = std::move(ft);
+        }
+    };
+    auto t0 = std::chrono::steady_clock::now();
+    if (num_threads <= 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < num_threads; i++) th.emplace_back(worker, i);
+        for (auto& t : th) t.join();
+    }
+    // merge_film_tile (film.rs:346-371), in Morton order (the reference's channel-arrival order is
+    // nondeterministic; only pixels with >=3 contributing tiles can tell the difference)
+    if (film_xyzw) {
+        std::memset(film_xyzw, 0, sizeof(float) * 4 * (size_t)cw * ch);
+        for (const FilmTile& t : tiles) {
+            int w = t.pb[2] - t.pb[0];
+            for (int32_t y = t.pb[1]; y < t.pb[3]; y++)
+                for (int32_t x = t.pb[0]; x < t.pb[2]; x++) {
+                    const FilmTilePixel& tp = t.pixels[(size_t)(y - t.pb[1]) * w + (x - t.pb[0])];
+                    float* mp = film_xyzw + 4 * ((size_t)(y - rd.crop_px[1]) * cw + (x - rd.crop_px[0]));
+                    Float xyz[3];
+                    rgb_to_xyz(tp.contrib_sum.c, xyz);
+                    for (int i = 0; i < 3; i++) mp[i] += xyz[i];
+                    mp[3] += tp.filter_weight_sum;
+                }
+        }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (out) {
+        out->seconds = std::chrono::duration<double>(t1 - t0).count();
+        for (auto& c : tc) out->counters.add(c);
+    }
+}
+
+} // namespace orc

@@ -1,0 +1,90 @@
+"""TEST INFRASTRUCTURE — ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product package (rs_pbrt_amd) never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_next_float_up.restype = C.c_float; L.orc_next_float_up.argtypes = [C.c_float]
+        L.orc_next_float_down.restype = C.c_float; L.orc_next_float_down.argtypes = [C.c_float]
+        L.orc_gamma.restype = C.c_float; L.orc_gamma.argtypes = [C.c_int]
+        L.orc_radical_inverse.restype = C.c_float; L.orc_radical_inverse.argtypes = [C.c_int, C.c_uint64]
+        L.orc_sobol_index.restype = C.c_uint64; L.orc_sobol_index.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32]
+        L.orc_sobol_sample.restype = C.c_float; L.orc_sobol_sample.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        L.orc_fr_dielectric.restype = C.c_float; L.orc_fr_dielectric.argtypes = [C.c_float] * 3
+        L.orc_distribution1d.restype = C.c_int64
+        L.orc_distribution1d.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bvh_build.restype = C.c_int64
+        L.orc_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_trace.restype = None
+        L.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_camera_sample.restype = None
+        L.orc_camera_sample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+        L.orc_camera_ray.restype = None; L.orc_camera_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_offset_ray_origin.restype = None; L.orc_offset_ray_origin.argtypes = [C.c_void_p] * 5
+        L.orc_concentric_sample_disk.restype = None; L.orc_concentric_sample_disk.argtypes = [C.c_float, C.c_float, C.c_void_p]
+        L.orc_bsdf_f.restype = None
+        L.orc_bsdf_f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_bsdf_sample_f.restype = None
+        L.orc_bsdf_sample_f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_spatial_voxel.restype = None
+        L.orc_spatial_voxel.argtypes = [C.c_void_p] * 6
+        _LIB = L
+    return _LIB
+
+
+def bvh_build(P, tri, max_prims_in_node=4):
+    """BVHAccel::new restated (oracle/orc_scene.hpp).  Returns (nodes NODE_DT[], ordered u32[])."""
+    from rs_pbrt_amd import abi  # layouts only
+    P = np.ascontiguousarray(P, np.float32); tri = np.ascontiguousarray(tri, np.uint32)
+    n = len(tri)
+    nodes = np.zeros(max(2 * n, 1), abi.NODE_DT)
+    ordered = np.zeros(n, np.uint32)
+    k = lib().orc_bvh_build(P.ctypes.data, tri.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data)
+    assert k >= 0
+    return nodes[:k].copy(), ordered
+
+
+def trace(scene, rays, any_hit=False, brute=False, counters=False):
+    from rs_pbrt_amd import abi
+    rays = np.ascontiguousarray(rays, abi.RAY_DT)
+    out = np.zeros(len(rays), abi.HIT_DT)
+    cnt = np.zeros(2, np.uint64)
+    lib().orc_trace(C.addressof(scene.desc), rays.ctypes.data, len(rays), out.ctypes.data, int(any_hit), int(brute), cnt.ctypes.data)
+    return (out, cnt) if counters else out
+
+
+COUNTER_NAMES = ("nodes_visited", "tris_tested", "rays_closest", "rays_any", "bounces", "samples", "nan_samples", "mis_rays")
+
+
+def render(scene, rd, threads=1, want_li=False):
+    """SamplerIntegrator::render restated.  Returns dict(film (npix,4), li (npix,spp,3)|None, counters, seconds)."""
+    npix = (rd.crop_px[2] - rd.crop_px[0]) * (rd.crop_px[3] - rd.crop_px[1])
+    film = np.zeros((npix, 4), np.float32)
+    li = np.zeros((npix, int(rd.spp), 3), np.float32) if want_li else None
+    cnt = np.zeros(8, np.uint64)
+    sec = C.c_double(0)
+    rc = lib().orc_render(C.addressof(scene.desc), C.addressof(rd), threads, film.ctypes.data,
+                          li.ctypes.data if want_li else None, cnt.ctypes.data, C.addressof(sec))
+    assert rc == 0
+    return dict(film=film, li=li, counters=dict(zip(COUNTER_NAMES, (int(x) for x in cnt))), seconds=sec.value)

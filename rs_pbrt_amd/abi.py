@@ -1,0 +1,109 @@
+"""ctypes mirror of include/rspt.h (the C ABI of librspt.so) — layouts only, no logic.
+
+Every struct here must stay byte-compatible with the header; tests/test_abi.py checks
+sizes against the values the library reports."""
+import ctypes as C
+
+ABI_VERSION = 1
+
+OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
+
+BXDF_LAMBERT_R, BXDF_OREN_NAYAR, BXDF_SPECULAR_R, BXDF_SPECULAR_T, BXDF_FRESNEL_SPEC, BXDF_MICROFACET_R, BXDF_LAMBERT_T = 1, 2, 3, 4, 5, 6, 7
+FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
+LIGHT_DIFFUSE_AREA = 1
+SAMPLER_SOBOL = 1
+LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
+NO_MATERIAL = 0xFFFFFFFF
+MISS = 0xFFFFFFFF
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_int32),
+                ("n_prims", C.c_uint16), ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class Prim(C.Structure):
+    _fields_ = [("v", C.c_uint32 * 3), ("mesh", C.c_uint32), ("material", C.c_uint32), ("area_light", C.c_int32)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("has_n", C.c_uint32), ("has_s", C.c_uint32), ("has_uv", C.c_uint32), ("flip", C.c_uint32)]
+
+
+class Bxdf(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("fresnel", C.c_uint32), ("r", C.c_float * 3), ("t", C.c_float * 3),
+                ("eta_a", C.c_float), ("eta_b", C.c_float), ("alpha_x", C.c_float), ("alpha_y", C.c_float),
+                ("c1", C.c_float * 3), ("c2", C.c_float * 3), ("on_a", C.c_float), ("on_b", C.c_float)]
+
+
+class Material(C.Structure):
+    _fields_ = [("eta", C.c_float), ("first_bxdf", C.c_uint32), ("n_bxdfs", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("prim", C.c_uint32), ("L", C.c_float * 3), ("two_sided", C.c_uint32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint64),
+                ("prims", C.c_void_p), ("n_prims", C.c_uint64),
+                ("meshes", C.c_void_p), ("n_meshes", C.c_uint32),
+                ("P", C.c_void_p), ("N", C.c_void_p), ("S", C.c_void_p), ("UV", C.c_void_p),
+                ("n_vertices", C.c_uint64),
+                ("materials", C.c_void_p), ("n_materials", C.c_uint32),
+                ("bxdfs", C.c_void_p), ("n_bxdfs", C.c_uint32),
+                ("lights", C.c_void_p), ("n_lights", C.c_uint32)]
+
+
+class SamplerTables(C.Structure):
+    _fields_ = [("sobol32", C.c_void_p), ("vdc", C.c_void_p), ("vdc_inv", C.c_void_p)]
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [("full_res", C.c_int32 * 2), ("crop_px", C.c_int32 * 4), ("sample_bounds", C.c_int32 * 4),
+                ("filter_radius", C.c_float * 2), ("filter_table", C.c_float * 256),
+                ("max_sample_luminance", C.c_float),
+                ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+                ("sampler_kind", C.c_uint32), ("spp", C.c_int64),
+                ("max_depth", C.c_uint32), ("rr_threshold", C.c_float), ("light_strategy", C.c_uint32),
+                ("tile_size", C.c_uint32),
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("tile_chunk", C.c_uint32),
+                ("tables", SamplerTables)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("o", C.c_float * 3), ("d", C.c_float * 3), ("t_max", C.c_float), ("id", C.c_uint32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("prim", C.c_uint32), ("t", C.c_float), ("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("t_render_s", C.c_double), ("t_kernels_s", C.c_double), ("t_trace_s", C.c_double),
+                ("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("nan_samples", C.c_uint64),
+                ("trace_launches", C.c_uint64), ("alg_bytes", C.c_double)]
+
+
+# numpy dtypes with the same layout (for bulk construction)
+import numpy as np  # noqa: E402
+
+NODE_DT = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_prims", "<u2"), ("axis", "u1"), ("pad", "u1")])
+PRIM_DT = np.dtype([("v", "<u4", 3), ("mesh", "<u4"), ("material", "<u4"), ("area_light", "<i4")])
+MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4")])
+BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
+                    ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4")])
+MATERIAL_DT = np.dtype([("eta", "<f4"), ("first_bxdf", "<u4"), ("n_bxdfs", "<u4"), ("pad", "<u4")])
+LIGHT_DT = np.dtype([("kind", "<u4"), ("prim", "<u4"), ("L", "<f4", 3), ("two_sided", "<u4")])
+RAY_DT = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("id", "<u4")])
+HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4")])
+
+assert NODE_DT.itemsize == C.sizeof(BvhNode) == 32
+assert PRIM_DT.itemsize == C.sizeof(Prim) == 24
+assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 80
+assert RAY_DT.itemsize == C.sizeof(Ray) == 32
+assert HIT_DT.itemsize == C.sizeof(Hit) == 20
+assert LIGHT_DT.itemsize == C.sizeof(Light) == 24

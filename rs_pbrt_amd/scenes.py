@@ -1,0 +1,503 @@
+"""Host-side scene set-up: what rs_pbrt's API layer (src/core/api.rs) hands to
+`integrator.render` for the BASELINE configs, flattened into the rspt.h structs.
+
+This is host plumbing (runs once per scene, numpy): triangle lists, material lobe
+recipes, camera matrices, film/sampler parameters.  It contains
+no rendering arithmetic; the BVH is built by whichever builder the caller passes in
+(`rs_pbrt_amd.lib().bvh_build` in the product, the oracle's in parity tests)."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import abi
+
+F32 = np.float32
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "sobol_tables.bin")
+
+
+# ---------------------------------------------------------------------------------------
+# Sobol' tables blob (tools/convert_sobol_tables.py)
+# ---------------------------------------------------------------------------------------
+class SobolTables:
+    def __init__(self, path=_DATA):
+        raw = np.fromfile(path, dtype=np.uint8)
+        assert raw[:4].tobytes() == b"SBL1", "bad sobol table blob"
+        n_dims, msize = np.frombuffer(raw[4:12].tobytes(), dtype="<u4")
+        assert (n_dims, msize) == (1024, 52)
+        off = 16
+        self.sobol32 = np.frombuffer(raw[off:off + 4 * 1024 * 52].tobytes(), dtype="<u4").copy()
+        off += 4 * 1024 * 52
+        self.vdc = np.frombuffer(raw[off:off + 8 * 25 * 52].tobytes(), dtype="<u8").copy()
+        off += 8 * 25 * 52
+        self.vdc_inv = np.frombuffer(raw[off:off + 8 * 26 * 52].tobytes(), dtype="<u8").copy()
+
+    def as_struct(self):
+        return abi.SamplerTables(self.sobol32.ctypes.data, self.vdc.ctypes.data, self.vdc_inv.ctypes.data)
+
+
+_TABLES = None
+
+
+def sobol_tables():
+    global _TABLES
+    if _TABLES is None:
+        _TABLES = SobolTables()
+    return _TABLES
+
+
+# ---------------------------------------------------------------------------------------
+# f32 4x4 transforms the way src/core/transform.rs builds them (m and m_inv kept in pairs)
+# ---------------------------------------------------------------------------------------
+def _mtx_mul(a, b):  # transform.rs:238-250, f32 left-to-right
+    r = np.zeros((4, 4), F32)
+    for i in range(4):
+        for j in range(4):
+            r[i, j] = F32(F32(F32(a[i, 0] * b[0, j]) + F32(a[i, 1] * b[1, j])) + F32(a[i, 2] * b[2, j])) + F32(a[i, 3] * b[3, j])
+    return r
+
+
+def _mtx_inverse(m):  # Gauss-Jordan with full pivoting in f32, transform.rs:128-197
+    minv = np.array(m, F32).copy()
+    indxc, indxr, ipiv = [0] * 4, [0] * 4, [0] * 4
+    for i in range(4):
+        irow = icol = 0
+        big = F32(0)
+        for j in range(4):
+            if ipiv[j] != 1:
+                for k in range(4):
+                    if ipiv[k] == 0 and abs(minv[j, k]) >= big:
+                        big = abs(minv[j, k]); irow = j; icol = k
+        ipiv[icol] += 1
+        if irow != icol:
+            minv[[irow, icol]] = minv[[icol, irow]]
+        indxr[i], indxc[i] = irow, icol
+        pivinv = F32(1) / minv[icol, icol]
+        minv[icol, icol] = F32(1)
+        minv[icol, :] = (minv[icol, :] * pivinv).astype(F32)
+        for j in range(4):
+            if j != icol:
+                save = minv[j, icol]
+                minv[j, icol] = F32(0)
+                minv[j, :] = (minv[j, :] - (minv[icol, :] * save).astype(F32)).astype(F32)
+    for j in (3, 2, 1, 0):
+        if indxr[j] != indxc[j]:
+            minv[:, [indxr[j], indxc[j]]] = minv[:, [indxc[j], indxr[j]]]
+    return minv
+
+
+class Transform:
+    def __init__(self, m, m_inv=None):
+        self.m = np.array(m, F32)
+        self.m_inv = np.array(m_inv, F32) if m_inv is not None else _mtx_inverse(self.m)
+
+    def __mul__(self, o):  # transform.rs:869-877
+        return Transform(_mtx_mul(self.m, o.m), _mtx_mul(o.m_inv, self.m_inv))
+
+    def inverse(self):
+        return Transform(self.m_inv, self.m)
+
+    @staticmethod
+    def translate(d):
+        m = np.eye(4, dtype=F32); mi = np.eye(4, dtype=F32)
+        m[:3, 3] = np.array(d, F32); mi[:3, 3] = -np.array(d, F32)
+        return Transform(m, mi)
+
+    @staticmethod
+    def scale(x, y, z):
+        x, y, z = F32(x), F32(y), F32(z)
+        return Transform(np.diag([x, y, z, F32(1)]).astype(F32), np.diag([F32(1) / x, F32(1) / y, F32(1) / z, F32(1)]).astype(F32))
+
+    @staticmethod
+    def perspective(fov, n, f):  # transform.rs:461-489
+        n, f = F32(n), F32(f)
+        persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], F32)
+        inv_tan = F32(1) / F32(math.tan(float(F32(F32(F32(math.pi) / F32(180)) * F32(fov)) / F32(2))))
+        return Transform.scale(inv_tan, inv_tan, 1) * Transform(persp)
+
+    @staticmethod
+    def look_at(pos, look, up):  # transform.rs:414-451 -> world_to_camera (m_inv = camera_to_world)
+        pos, look, up = (np.array(v, np.float64) for v in (pos, look, up))
+        d = (look - pos); d /= np.linalg.norm(d)
+        upn = up / np.linalg.norm(up)
+        left = np.cross(upn, d); left /= np.linalg.norm(left)
+        new_up = np.cross(d, left)
+        c2w = np.eye(4, dtype=F32)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = left.astype(F32), new_up.astype(F32), d.astype(F32), pos.astype(F32)
+        return Transform(_mtx_inverse(c2w), c2w)
+
+
+# ---------------------------------------------------------------------------------------
+# materials -> lobe lists (src/materials/*.rs with constant textures)
+# ---------------------------------------------------------------------------------------
+def tr_roughness_to_alpha(rough):  # microfacet.rs:243-254, f32
+    r = F32(max(float(rough), 1e-3))
+    x = F32(math.log(float(r)))
+    a = F32(1.62142) + F32(0.819955) * x + F32(0.1734) * x * x + F32(0.0171201) * x * x * x + F32(0.000640711) * x * x * x * x
+    return F32(a)
+
+
+def _lobe(**kw):
+    b = np.zeros((), abi.BXDF_DT)
+    for k, v in kw.items():
+        b[k] = v
+    return b
+
+
+def _alpha(a):
+    return max(float(a), 0.001)  # TrowbridgeReitzDistribution::new microfacet.rs:233-239
+
+
+def matte(kd, sigma=0.0):  # matte.rs:43-86
+    kd = np.maximum(np.array(kd, F32), 0)
+    if not kd.any():
+        return dict(eta=1.0, lobes=[])
+    sigma = min(max(float(sigma), 0.0), 90.0)
+    if sigma == 0.0:
+        return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_LAMBERT_R, r=kd)])
+    s = F32(F32(F32(math.pi) / F32(180)) * F32(sigma)); s2 = F32(s * s)  # OrenNayar::new reflection.rs:1057-1065
+    a = F32(1) - F32(s2 / F32(F32(2) * F32(s2 + F32(0.33))))
+    b = F32(F32(0.45) * s2) / F32(s2 + F32(0.09))
+    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_OREN_NAYAR, r=kd, on_a=a, on_b=b)])
+
+
+def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True):  # plastic.rs:57-125
+    lobes = []
+    kd = np.maximum(np.array(kd, F32), 0); ks = np.maximum(np.array(ks, F32), 0)
+    if kd.any():
+        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd))
+    if ks.any():
+        a = tr_roughness_to_alpha(roughness) if remap else F32(roughness)
+        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, eta_a=1.5, eta_b=1.0,
+                           alpha_x=_alpha(a), alpha_y=_alpha(a)))
+    return dict(eta=1.0, lobes=lobes)
+
+
+def mirror(kr=(0.9,) * 3):  # mirror.rs:34-70 (pushed even if black)
+    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_NOOP, r=np.maximum(np.array(kr, F32), 0))])
+
+
+def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5):  # glass.rs:83-211, smooth + allow_multiple_lobes
+    return dict(eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=np.maximum(np.array(kr, F32), 0),
+                                        t=np.maximum(np.array(kt, F32), 0), eta_a=1.0, eta_b=index)])
+
+
+def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True):  # metal.rs:144-205
+    a = tr_roughness_to_alpha(roughness) if remap else F32(roughness)
+    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_CONDUCTOR, r=(1, 1, 1), c1=eta, c2=k,
+                                      alpha_x=_alpha(a), alpha_y=_alpha(a))])
+
+
+# ---------------------------------------------------------------------------------------
+# A scene before BVH build: meshes with per-mesh material / emission
+# ---------------------------------------------------------------------------------------
+class SceneBuilder:
+    def __init__(self):
+        self.P, self.N, self.UV, self.tris, self.tri_mesh = [], [], [], [], []
+        self.meshes, self.mesh_material, self.mesh_emit = [], [], []
+        self.materials = []
+        self.nv = 0
+        self.any_n = self.any_uv = False
+
+    def add_material(self, m):
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def add_mesh(self, P, idx, material, N=None, UV=None, emit=None, two_sided=False, flip=False):
+        """P (nv,3) world-space vertices; idx (nt,3); emit = rgb L or None."""
+        P = np.asarray(P, F32).reshape(-1, 3); idx = np.asarray(idx, np.uint32).reshape(-1, 3)
+        m = len(self.meshes)
+        self.meshes.append((int(N is not None), 0, int(UV is not None), int(flip)))
+        self.mesh_material.append(material)
+        self.mesh_emit.append(None if emit is None else (np.array(emit, F32), bool(two_sided)))
+        self.P.append(P)
+        self.N.append(np.asarray(N, F32).reshape(-1, 3) if N is not None else np.zeros_like(P))
+        self.UV.append(np.asarray(UV, F32).reshape(-1, 2) if UV is not None else np.zeros((len(P), 2), F32))
+        self.any_n |= N is not None; self.any_uv |= UV is not None
+        self.tris.append(idx + np.uint32(self.nv))
+        self.tri_mesh.append(np.full(len(idx), m, np.uint32))
+        self.nv += len(P)
+        return m
+
+    def add_quad(self, p, material, **kw):
+        return self.add_mesh(np.array(p, F32), [[0, 1, 2], [0, 2, 3]], material, **kw)
+
+    def finish(self, bvh_builder, max_prims_in_node=4):
+        """bvh_builder(P (nv,3) f32, tri (nt,3) u32, max_prims) -> (nodes NODE_DT[], ordered u32[])"""
+        P = np.ascontiguousarray(np.concatenate(self.P), F32)
+        tri = np.ascontiguousarray(np.concatenate(self.tris), np.uint32)
+        tri_mesh = np.concatenate(self.tri_mesh)
+        nodes, ordered = bvh_builder(P, tri, max_prims_in_node)
+        # lights in shape-declaration order (one DiffuseAreaLight per emissive triangle, api.rs:2810-2852)
+        light_of_tri = np.full(len(tri), -1, np.int32)
+        lights_in = []
+        for t in range(len(tri)):
+            e = self.mesh_emit[tri_mesh[t]]
+            if e is not None:
+                light_of_tri[t] = len(lights_in)
+                lights_in.append((t, e))
+        inv = np.empty(len(tri), np.uint32); inv[ordered] = np.arange(len(tri), dtype=np.uint32)
+        prims = np.zeros(len(tri), abi.PRIM_DT)
+        prims["v"] = tri[ordered]
+        prims["mesh"] = tri_mesh[ordered]
+        prims["material"] = np.array(self.mesh_material, np.uint32)[tri_mesh[ordered]]
+        prims["area_light"] = light_of_tri[ordered]
+        lights = np.zeros(len(lights_in), abi.LIGHT_DT)
+        for i, (t, (L, two)) in enumerate(lights_in):
+            lights[i] = (abi.LIGHT_DIFFUSE_AREA, inv[t], L, int(two))
+        mats = np.zeros(len(self.materials), abi.MATERIAL_DT)
+        bx = []
+        for i, m in enumerate(self.materials):
+            mats[i] = (m["eta"], len(bx), len(m["lobes"]), 0)
+            bx.extend(m["lobes"])
+        bxdfs = np.array(bx, abi.BXDF_DT) if bx else np.zeros(0, abi.BXDF_DT)
+        meshes = np.array(self.meshes, np.uint32).view(abi.MESH_DT).reshape(-1)
+        return Scene(nodes=nodes, prims=prims, meshes=meshes, P=P,
+                     N=np.ascontiguousarray(np.concatenate(self.N), F32) if self.any_n else None,
+                     UV=np.ascontiguousarray(np.concatenate(self.UV), F32) if self.any_uv else None,
+                     materials=mats, bxdfs=bxdfs, lights=lights)
+
+
+class Scene:
+    """Flattened scene arrays + the ctypes rspt_scene_desc pointing at them."""
+
+    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None):
+        self.nodes, self.prims, self.meshes, self.P, self.N, self.UV, self.S = nodes, prims, meshes, P, N, UV, S
+        self.materials, self.bxdfs, self.lights = materials, bxdfs, lights
+        p = lambda a: a.ctypes.data if a is not None and a.size else None  # noqa: E731
+        self.desc = abi.SceneDesc(p(nodes), len(nodes), p(prims), len(prims), p(meshes), len(meshes),
+                                  p(P), p(N), p(S), p(UV), len(P),
+                                  p(materials), len(materials), p(bxdfs), len(bxdfs), p(lights), len(lights))
+
+    @property
+    def n_tris(self):
+        return len(self.prims)
+
+
+# ---------------------------------------------------------------------------------------
+# film / camera / sampler / integrator parameters -> rspt_render_desc
+# ---------------------------------------------------------------------------------------
+def box_filter_table(radius=(0.5, 0.5)):  # film.rs:198-211 with BoxFilter::evaluate == 1
+    return np.ones(256, F32)
+
+
+def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs, film.rs:198-211
+    rx, ry = F32(radius[0]), F32(radius[1])
+    ex, ey = F32(math.exp(-alpha * float(rx) * float(rx))), F32(math.exp(-alpha * float(ry) * float(ry)))
+    t = np.zeros(256, F32)
+    for y in range(16):
+        for x in range(16):
+            px = F32(F32(x + 0.5) * rx / F32(16)); py = F32(F32(y + 0.5) * ry / F32(16))
+            gx = max(F32(0), F32(math.exp(-alpha * float(px) * float(px))) - ex)
+            gy = max(F32(0), F32(math.exp(-alpha * float(py) * float(py))) - ey)
+            t[y * 16 + x] = F32(gx * gy)
+    return t
+
+
+def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_SPATIAL,
+                     crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
+                     focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64)):
+    rd = abi.RenderDesc()
+    rd.full_res[:] = (xres, yres)
+    # Film::new film.rs:187-196
+    cx0, cx1 = math.ceil(float(F32(xres) * F32(crop[0]))), math.ceil(float(F32(xres) * F32(crop[1])))
+    cy0, cy1 = math.ceil(float(F32(yres) * F32(crop[2]))), math.ceil(float(F32(yres) * F32(crop[3])))
+    rd.crop_px[:] = (cx0, cy0, cx1, cy1)
+    rx, ry = float(filter_radius[0]), float(filter_radius[1])
+    # Film::get_sample_bounds film.rs:266-292
+    rd.sample_bounds[:] = (math.floor(cx0 + 0.5 - rx), math.floor(cy0 + 0.5 - ry), math.ceil(cx1 - 0.5 + rx), math.ceil(cy1 - 0.5 + ry))
+    rd.filter_radius[:] = (rx, ry)
+    tbl = box_filter_table() if filter_table is None else np.asarray(filter_table, F32)
+    rd.filter_table[:] = tbl.tolist()
+    rd.max_sample_luminance = max_sample_luminance
+    # PerspectiveCamera::create / new perspective.rs:45-186
+    frame = F32(xres) / F32(yres)
+    if frame > 1.0:
+        sw = (-frame, frame, F32(-1), F32(1))
+    else:
+        sw = (F32(-1), F32(1), F32(-1) / frame, F32(1) / frame)
+    cam2screen = Transform.perspective(fov, 1e-2, 1000.0)
+    s2r = Transform.scale(xres, yres, 1) * Transform.scale(F32(1) / (sw[1] - sw[0]), F32(1) / (sw[2] - sw[3]), 1) * Transform.translate((-sw[0], -sw[3], 0))
+    r2c = cam2screen.inverse() * s2r.inverse()
+    rd.raster_to_camera[:] = r2c.m.reshape(-1).tolist()
+    w2c = Transform.look_at(*look_at)
+    rd.camera_to_world[:] = w2c.m_inv.reshape(-1).tolist()
+    rd.lens_radius, rd.focal_distance = lens_radius, focal_distance
+    rd.shutter_open, rd.shutter_close = 0.0, 1.0
+    rd.sampler_kind = abi.SAMPLER_SOBOL
+    s = 1
+    while s < spp:
+        s *= 2  # sobol.rs:38-45 rounds up to a power of two
+    rd.spp = s
+    rd.max_depth, rd.rr_threshold, rd.light_strategy, rd.tile_size = max_depth, rr_threshold, light_strategy, 16
+    rd.shard_index, rd.shard_count, rd.tile_chunk = shard
+    rd.tables = sobol_tables().as_struct()
+    return rd
+
+
+def n_pixels(rd):
+    return (rd.crop_px[2] - rd.crop_px[0]) * (rd.crop_px[3] - rd.crop_px[1])
+
+
+def film_to_rgb(film_xyzw):
+    """Film::write_image's linear value before gamma (film.rs:445-462): xyz->rgb, / weight, clamp >= 0."""
+    f = np.asarray(film_xyzw, F32).reshape(-1, 4)
+    x, y, z, w = f[:, 0], f[:, 1], f[:, 2], f[:, 3]
+    rgb = np.stack([F32(3.240479) * x - F32(1.537150) * y - F32(0.498535) * z,
+                    F32(-0.969256) * x + F32(1.875991) * y + F32(0.041556) * z,
+                    F32(0.055648) * x - F32(0.204043) * y + F32(1.057311) * z], axis=1).astype(F32)
+    nz = w != 0
+    inv = np.zeros_like(w); inv[nz] = F32(1) / w[nz]
+    rgb[nz] = np.maximum(rgb[nz] * inv[nz, None], 0)
+    return rgb
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE scenes
+# ---------------------------------------------------------------------------------------
+def cornell_box(bvh_builder, variant="matte"):
+    """C1: the public Cornell Box data (32 triangles, one quad light).  variant 'mixed' swaps the
+    blocks to mirror / glass and the floor to plastic for BSDF coverage."""
+    sb = SceneBuilder()
+    white = sb.add_material(matte((0.725, 0.71, 0.68)))
+    red = sb.add_material(matte((0.63, 0.065, 0.05)))
+    green = sb.add_material(matte((0.14, 0.45, 0.091)))
+    short_m, tall_m, floor_m = white, white, white
+    if variant == "mixed":
+        tall_m = sb.add_material(mirror())
+        short_m = sb.add_material(glass())
+        floor_m = sb.add_material(plastic((0.4, 0.4, 0.4), (0.3, 0.3, 0.3), 0.05))
+    elif variant == "rough":
+        tall_m = sb.add_material(metal(roughness=0.1))
+        short_m = sb.add_material(matte((0.5, 0.5, 0.7), sigma=30.0))
+        floor_m = sb.add_material(plastic((0.4, 0.4, 0.4), (0.3, 0.3, 0.3), 0.2))
+    q = sb.add_quad
+    q([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)], floor_m)
+    q([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)], white)
+    q([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)], white)
+    q([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)], green)
+    q([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)], red)
+    # light: emits downwards; vertex order chosen so cross(p0-p2, p1-p2) points to -y
+    q([(343, 548.7, 227), (343, 548.7, 332), (213, 548.7, 332), (213, 548.7, 227)], white, emit=(17, 12, 4))
+    for quads, m in (([[(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)],
+                       [(290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)],
+                       [(130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)],
+                       [(82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)],
+                       [(240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225)]], short_m),
+                     ([[(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)],
+                       [(423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)],
+                       [(472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)],
+                       [(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)],
+                       [(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)]], tall_m)):
+        for p in quads:
+            q(p, m)
+    return sb.finish(bvh_builder)
+
+
+CORNELL_LOOK_AT = ((278, 273, -800), (278, 273, 0), (0, 1, 0))
+CORNELL_FOV = 39.3
+
+
+def cornell_render_desc(res=400, spp=64, **kw):
+    return make_render_desc(res, res, spp, CORNELL_LOOK_AT, CORNELL_FOV, **kw)
+
+
+def _splitmix64(seed, n):
+    """n outputs of SplitMix64 started at `seed` (vectorised)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def triangle_soup(bvh_builder, n_tris=1_000_000, seed=0x5EED5EED, extent=0.01):
+    """C2: centroids U[-1,1]^3, vertices = centroid + U[-extent,extent]^3, matte 0.5,
+    one 1x1 one-sided area light at y=+1.5 facing -y with L = 40."""
+    r = _splitmix64(seed, n_tris * 12)
+    u = ((r >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).reshape(n_tris, 12)
+    c = u[:, :3] * 2.0 - 1.0
+    off = (u[:, 3:] * 2.0 - 1.0).reshape(n_tris, 3, 3) * extent
+    P = (c[:, None, :] + off).astype(F32).reshape(-1, 3)
+    idx = np.arange(n_tris * 3, dtype=np.uint32).reshape(-1, 3)
+    sb = SceneBuilder()
+    grey = sb.add_material(matte((0.5, 0.5, 0.5)))
+    sb.add_mesh(P, idx, grey)
+    sb.add_quad([(0.5, 1.5, -0.5), (0.5, 1.5, 0.5), (-0.5, 1.5, 0.5), (-0.5, 1.5, -0.5)], grey, emit=(40, 40, 40))
+    return sb.finish(bvh_builder)
+
+
+SOUP_LOOK_AT = ((0, 0, -4), (0, 0, 0), (0, 1, 0))
+SOUP_FOV = 40.0
+
+
+def soup_render_desc(res=1024, spp=256, max_depth=8, **kw):
+    return make_render_desc(res, res, spp, SOUP_LOOK_AT, SOUP_FOV, max_depth=max_depth, **kw)
+
+
+def _value_noise(p, seed, octaves=5):
+    """Smooth lattice value noise on points p (n,3) (float64), deterministic from `seed`."""
+    def h(ix, iy, iz):
+        with np.errstate(over="ignore"):
+            v = (ix.astype(np.uint64) * np.uint64(73856093)) ^ (iy.astype(np.uint64) * np.uint64(19349663)) ^ (iz.astype(np.uint64) * np.uint64(83492791)) ^ np.uint64(seed)
+            v = (v ^ (v >> np.uint64(13))) * np.uint64(0x5BD1E9955BD1E995)
+            v = v ^ (v >> np.uint64(15))
+        return (v & np.uint64(0xFFFFFF)).astype(np.float64) / float(0xFFFFFF)
+    out = np.zeros(len(p)); amp = 1.0; freq = 2.0
+    for _ in range(octaves):
+        q = p * freq + 64.0
+        i = np.floor(q); f = q - i; f = f * f * (3 - 2 * f)
+        i = i.astype(np.int64)
+        acc = 0
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                    acc = acc + w * h(i[:, 0] + dx, i[:, 1] + dy, i[:, 2] + dz)
+        out += amp * (acc - 0.5); amp *= 0.5; freq *= 2.0
+    return out
+
+
+def statue_standin(bvh_builder, grid=1466, seed=0x6A4E):
+    """C3 stand-in for the off-tree Ganesha scene: grid x grid lat-long sphere
+    (2*grid*(grid-1) ~ 4.30 M triangles at 1466) displaced by 5-octave value noise, smooth normals,
+    plastic; matte ground; three quad lights.  DECLARED STAND-IN: not the real asset."""
+    nu, nv = grid, grid
+    th = np.linspace(0, np.pi, nv + 1)[:, None]; ph = np.linspace(0, 2 * np.pi, nu + 1)[None, :]
+    d = np.stack([np.sin(th) * np.cos(ph), np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    rad = 1.0 + 0.15 * _value_noise(d, seed)
+    P = d * rad[:, None]
+    # smooth normals from finite differences of the displaced surface
+    Pg = P.reshape(nv + 1, nu + 1, 3)
+    du = np.roll(Pg, -1, 1) - np.roll(Pg, 1, 1); dv = np.zeros_like(Pg); dv[1:-1] = Pg[2:] - Pg[:-2]; dv[0] = Pg[1] - Pg[0]; dv[-1] = Pg[-1] - Pg[-2]
+    N = np.cross(du, dv).reshape(-1, 3)
+    ln = np.linalg.norm(N, axis=1); bad = ln < 1e-12
+    N[bad] = d[bad]; ln[bad] = 1.0
+    N = N / ln[:, None]
+    N[(N * d).sum(1) < 0] *= -1
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    a = (i * (nu + 1) + j).reshape(-1); b = a + 1; c = a + (nu + 1); e = c + 1
+    idx = np.concatenate([np.stack([a, c, b], 1), np.stack([b, c, e], 1)]).astype(np.uint32)
+    # drop the degenerate cap triangles
+    Pf = P.astype(F32)
+    t0, t1, t2 = Pf[idx[:, 0]], Pf[idx[:, 1]], Pf[idx[:, 2]]
+    keep = np.linalg.norm(np.cross(t1 - t0, t2 - t0), axis=1) > 0
+    idx = idx[keep]
+    sb = SceneBuilder()
+    body = sb.add_material(plastic((0.4, 0.4, 0.4), (0.1, 0.1, 0.1), 0.1))
+    ground = sb.add_material(matte((0.5, 0.5, 0.5)))
+    sb.add_mesh(Pf, idx, body, N=N.astype(F32))
+    sb.add_quad([(-6, -1.3, -6), (-6, -1.3, 6), (6, -1.3, 6), (6, -1.3, -6)], ground)
+    for (cx, cz, L) in ((-2.5, -2.0, (30, 28, 24)), (2.5, -2.0, (20, 24, 30)), (0.0, 2.5, (25, 25, 25))):
+        sb.add_quad([(cx + 0.5, 3.0, cz - 0.5), (cx + 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz - 0.5)], ground, emit=L)
+    return sb.finish(bvh_builder)
+
+
+STATUE_LOOK_AT = ((0, 0.6, -4.2), (0, 0, 0), (0, 1, 0))
+STATUE_FOV = 38.0
+
+
+def statue_render_desc(xres=1920, yres=1080, spp=1024, **kw):
+    return make_render_desc(xres, yres, spp, STATUE_LOOK_AT, STATUE_FOV, **kw)
