@@ -242,6 +242,22 @@ int rspt_dev_free(void* p);
 int rspt_dev_upload(void* dst_dev, const void* src_host, uint64_t bytes);
 int rspt_dev_download(void* dst_host, const void* src_dev, uint64_t bytes);
 
+/* Counters of the last rspt_trace_device / rspt_render when the environment has
+ * RSPT_COUNTERS=1: out[0] = BVH nodes fetched, out[1] = triangles tested. */
+int rspt_last_counters(uint64_t out[2]);
+
+/* Host-side helper for callers that do not bring rs_pbrt's own accelerator (bench, tests,
+ * tools).  Replaces: BVHAccel::new with SplitMethod::SAH over Triangle shapes
+ * (src/accelerators/bvh.rs:96-392; Triangle::world_bound src/shapes/triangle.rs:126-133) and
+ * yields the identical node array and primitive order.  tri_idx: n_tris*3 indices into P;
+ * ordered_out[k] = input index of the primitive at BVH-ordered slot k; nodes_cap >= 2*n_tris
+ * is always enough.  Returns the node count (>= 0) or an RSPT_E_* code (text from
+ * rspt_bvh_last_error).  CPU only, no GPU needed; n_threads <= 0 = all host cores. */
+int64_t rspt_bvh_build(const float* P, const uint32_t* tri_idx, uint64_t n_tris,
+                       uint32_t max_prims_in_node, rspt_bvh_node* nodes_out, uint64_t nodes_cap,
+                       uint32_t* ordered_out, int32_t n_threads);
+const char* rspt_bvh_last_error(void);
+
 const char* rspt_last_error(void);
 
 #ifdef __cplusplus

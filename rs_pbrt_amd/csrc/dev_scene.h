@@ -1,0 +1,334 @@
+// Device view of the flattened scene and the per-hit geometry / light / sampler routines of
+// the shade stage.  Layouts are private to librspt (include/rspt.h only fixes the host ABI).
+#pragma once
+#include "dev_bsdf.h"
+
+namespace rspt {
+
+#define RSPT_MISS 0xffffffffu
+// mesh flag bits packed into the 48-byte triangle record
+enum : uint32_t { MF_HAS_N = 1, MF_HAS_S = 2, MF_HAS_UV = 4, MF_FLIP = 8 };
+
+struct SceneDev {
+    // LinearBVHNode array as uploaded (bvh.rs:77-85): 2 x float4 per node
+    //   n0 = (bmin.xyz, bmax.x)  n1 = (bmax.y, bmax.z, offset:i32, n_prims:u16 | axis:u8 << 16)
+    const float4* nodes;
+    // 48-byte triangle records in BVH leaf order: 3 x float4
+    //   t0 = (p0.xyz, p1.x)  t1 = (p1.yz, p2.xy)  t2 = (p2.z, material:u32, area_light:i32, mesh flags:u32)
+    const float4* tris;
+    const rspt_prim* prims;  // vertex indices for meshes carrying N / S / UV
+    const float* N;
+    const float* S;
+    const float* UV;
+    const rspt_material* materials;
+    const rspt_bxdf* bxdfs;
+    const rspt_light* lights;
+    uint32_t n_nodes, n_prims, n_lights, pad0;
+    float wb_min[3], wb_max[3];  // BVHAccel::world_bound = nodes[0].bounds (bvh.rs:394-400)
+};
+
+// Light sampling distributions (src/core/lightdistrib.rs): one Distribution1D per voxel for
+// "spatial", a single one (n_vox = 1) for "uniform" / "power".
+struct LightDistDev {
+    const float* func;      // [n_vox][n_lights]
+    const float* cdf;       // [n_vox][n_lights + 1]
+    const float* func_int;  // [n_vox]
+    int32_t nvox[3];
+    int32_t spatial;
+};
+
+// Everything SamplerIntegrator::render reads per sample (subset of rspt_render_desc)
+struct RenderDev {
+    float raster_to_camera[16], camera_to_world[16];
+    float lens_radius, focal_distance, shutter_open, shutter_close;
+    int32_t sample_bounds[4], crop_px[4];
+    int32_t resolution, log2_res;  // sobol.rs:46-48
+    int64_t spp;
+    uint32_t max_depth;
+    float rr_threshold;
+    float filter_radius[2];
+    float max_sample_luminance;
+    uint32_t tile_size;
+    const uint32_t* sobol32;   // [1024*52]
+    const uint64_t* vdc;       // [25*52]
+    const uint64_t* vdc_inv;   // [26*52]
+    const float* filter_table; // [256]
+};
+
+// ---- Sobol' sampler (src/samplers/sobol.rs:110-140,190-201; lowdiscrepancy.rs:1014-1076) ----
+RDEV uint64_t sobol_interval_to_index(const RenderDev& rd, uint32_t m, uint64_t frame, int32_t px, int32_t py) {
+    if (m == 0) return 0;
+    uint64_t index = frame << (m << 1);
+    uint64_t delta = 0;
+    const uint64_t* M = rd.vdc + (m - 1) * 52;
+    const uint64_t* MI = rd.vdc_inv + (m - 1) * 52;
+    for (int c = 0; frame > 0; frame >>= 1, c++)
+        if (frame & 1) delta ^= M[c];
+    uint64_t b = ((uint64_t)((uint32_t)px << m) | (uint64_t)(int64_t)py) ^ delta;
+    for (int c = 0; b > 0; b >>= 1, c++)
+        if (b & 1) index ^= MI[c];
+    return index;
+}
+RDEV float sobol_dim(const RenderDev& rd, uint64_t index, uint32_t dim) {
+    uint32_t v = 0;
+    const uint32_t* row = rd.sobol32 + dim * 52;
+    int64_t a = (int64_t)index;
+    for (int i = 0; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= row[i];
+    return fminf((float)v * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+}
+// SobolSampler::sample_dimension for dim >= 2 is sobol_dim; dims 0/1 are remapped into the pixel
+RDEV float sobol_pixel_dim(const RenderDev& rd, uint64_t index, uint32_t dim, int32_t pix) {
+    float s = sobol_dim(rd, index, dim);
+    s = s * (float)rd.resolution + (float)rd.sample_bounds[dim];
+    return clampf(s - (float)pix, 0.0f, RSPT_ONE_MINUS_EPS);
+}
+struct Sampler {  // the (index, dimension) cursor a path carries between stages
+    uint64_t index;
+    uint32_t dim;
+    RDEV float get_1d(const RenderDev& rd) { return sobol_dim(rd, index, dim++); }
+    RDEV f2 get_2d(const RenderDev& rd) {  // sobol.rs:190-201: y is evaluated first (no effect on values)
+        float y = sobol_dim(rd, index, dim + 1);
+        float x = sobol_dim(rd, index, dim);
+        dim += 2;
+        return f2{x, y};
+    }
+};
+
+// ---- geometry at a hit: second half of Triangle::intersect (triangle.rs:274-448) ----
+struct Hit {
+    f3 p, p_err, n;        // point, conservative error bound, geometric normal (oriented)
+    f3 sh_n, sh_dpdu;      // shading frame inputs of Bsdf::new
+    uint32_t material;
+    int32_t area_light;
+};
+
+struct TriRec {
+    f3 p0, p1, p2;
+    uint32_t material;
+    int32_t area_light;
+    uint32_t flags;
+};
+RDEV TriRec load_tri(const SceneDev& sc, uint32_t prim) {
+    float4 a = sc.tris[3 * (size_t)prim], b = sc.tris[3 * (size_t)prim + 1], c = sc.tris[3 * (size_t)prim + 2];
+    TriRec t;
+    t.p0 = f3{a.x, a.y, a.z};
+    t.p1 = f3{a.w, b.x, b.y};
+    t.p2 = f3{b.z, b.w, c.x};
+    t.material = __float_as_uint(c.y);
+    t.area_light = (int32_t)__float_as_uint(c.z);
+    t.flags = __float_as_uint(c.w);
+    return t;
+}
+RDEV f3 ld3(const float* a, uint32_t i) { return f3{a[3 * (size_t)i], a[3 * (size_t)i + 1], a[3 * (size_t)i + 2]}; }
+
+RDEVN void tri_fill(const SceneDev& sc, uint32_t prim, const TriRec& t, float b0, float b1, float b2, Hit* h) {
+    f3 p0 = t.p0, p1 = t.p1, p2 = t.p2;
+    f2 uv0{0.0f, 0.0f}, uv1{1.0f, 0.0f}, uv2{1.0f, 1.0f};  // triangle.rs:97-112
+    const bool has_uv = (t.flags & MF_HAS_UV) && sc.UV;
+    const bool has_n = (t.flags & MF_HAS_N) && sc.N, has_s = (t.flags & MF_HAS_S) && sc.S;
+    uint32_t v0 = 0, v1 = 0, v2 = 0;
+    if (has_uv || has_n || has_s) {
+        rspt_prim pr = sc.prims[prim];
+        v0 = pr.v[0]; v1 = pr.v[1]; v2 = pr.v[2];
+    }
+    if (has_uv) {
+        uv0 = f2{sc.UV[2 * (size_t)v0], sc.UV[2 * (size_t)v0 + 1]};
+        uv1 = f2{sc.UV[2 * (size_t)v1], sc.UV[2 * (size_t)v1 + 1]};
+        uv2 = f2{sc.UV[2 * (size_t)v2], sc.UV[2 * (size_t)v2 + 1]};
+    }
+    f2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
+    f3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float det = duv02.x * duv12.y - duv02.y * duv12.x;
+    bool degenerate = fabsf(det) < 1e-8f;
+    f3 dpdu{0.0f, 0.0f, 0.0f}, dpdv{0.0f, 0.0f, 0.0f};
+    if (!degenerate) {
+        float invdet = 1.0f / det;
+        dpdu = (dp02 * duv12.y - dp12 * duv02.y) * invdet;
+        dpdv = (dp02 * -duv12.x + dp12 * duv02.x) * invdet;
+    }
+    if (degenerate || len2(cross(dpdu, dpdv)) == 0.0f) coordinate_system(normalize(cross(p2 - p0, p1 - p0)), &dpdu, &dpdv);
+    float xs = fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x);
+    float ys = fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y);
+    float zs = fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z);
+    h->p_err = f3{xs, ys, zs} * gamma_n(7);
+    h->p = p0 * b0 + p1 * b1 + p2 * b2;
+    f3 n = normalize(cross(dp02, dp12));
+    if (t.flags & MF_FLIP) n = -n;
+    f3 sh_n = n, sh_dpdu = dpdu;
+    if (has_n || has_s) {
+        f3 ns = n;
+        if (has_n) {
+            ns = ld3(sc.N, v0) * b0 + ld3(sc.N, v1) * b1 + ld3(sc.N, v2) * b2;
+            ns = len2(ns) > 0.0f ? normalize(ns) : n;
+        }
+        f3 ss;
+        if (has_s) {
+            ss = ld3(sc.S, v0) * b0 + ld3(sc.S, v1) * b1 + ld3(sc.S, v2) * b2;
+            ss = len2(ss) > 0.0f ? normalize(ss) : normalize(dpdu);
+        } else
+            ss = normalize(dpdu);
+        f3 ts = cross(ss, ns);
+        if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinate_system(ns, &ss, &ts);
+        sh_n = normalize(cross(ss, ts));  // SurfaceInteraction::set_shading_geometry
+        n = faceforward(n, sh_n);
+        sh_dpdu = ss;
+    }
+    h->n = n; h->sh_n = sh_n; h->sh_dpdu = sh_dpdu;
+    h->material = t.material; h->area_light = t.area_light;
+}
+
+// Watertight ray/triangle test shared by Triangle::intersect and ::intersect_p
+// (triangle.rs:134-273, 450-579).  The ray-dependent permutation/shear is precomputed once
+// per ray (it does not depend on the triangle), which leaves every value bit-identical.
+struct RayShear {
+    int kx, ky, kz;
+    float sx, sy, sz;
+};
+RDEV RayShear ray_shear(f3 d) {
+    f3 a = vabs(d);
+    RayShear s;
+    s.kz = a.x > a.y ? (a.x > a.z ? 0 : 2) : (a.y > a.z ? 1 : 2);  // max_dimension geometry.rs:721-733
+    s.kx = s.kz + 1; if (s.kx == 3) s.kx = 0;
+    s.ky = s.kx + 1; if (s.ky == 3) s.ky = 0;
+    float dx = comp(d, s.kx), dy = comp(d, s.ky), dz = comp(d, s.kz);
+    s.sx = -dx / dz; s.sy = -dy / dz; s.sz = 1.0f / dz;
+    return s;
+}
+RDEV f3 permute(f3 v, int kx, int ky, int kz) { return f3{comp(v, kx), comp(v, ky), comp(v, kz)}; }
+
+RDEV bool tri_test(f3 p0, f3 p1, f3 p2, f3 o, const RayShear& rs, float t_max, float* t_out, float* b0o, float* b1o, float* b2o) {
+    f3 p0t = permute(p0 - o, rs.kx, rs.ky, rs.kz), p1t = permute(p1 - o, rs.kx, rs.ky, rs.kz), p2t = permute(p2 - o, rs.kx, rs.ky, rs.kz);
+    p0t.x += rs.sx * p0t.z; p0t.y += rs.sy * p0t.z;
+    p1t.x += rs.sx * p1t.z; p1t.y += rs.sy * p1t.z;
+    p2t.x += rs.sx * p2t.z; p2t.y += rs.sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // f64 fallback, triangle.rs:189-200
+        e0 = (float)((double)p2t.y * (double)p1t.x - (double)p2t.x * (double)p1t.y);
+        e1 = (float)((double)p0t.y * (double)p2t.x - (double)p0t.x * (double)p2t.y);
+        e2 = (float)((double)p1t.y * (double)p0t.x - (double)p1t.x * (double)p0t.y);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    p0t.z *= rs.sz; p1t.z *= rs.sz; p2t.z *= rs.sz;
+    float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if ((det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det))) return false;
+    float inv_det = 1.0f / det;
+    float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det;
+    float t = t_scaled * inv_det;
+    float max_zt = max3(fabsf(p0t.z), fabsf(p1t.z), fabsf(p2t.z));
+    float delta_z = gamma_n(3) * max_zt;
+    float max_xt = max3(fabsf(p0t.x), fabsf(p1t.x), fabsf(p2t.x));
+    float max_yt = max3(fabsf(p0t.y), fabsf(p1t.y), fabsf(p2t.y));
+    float delta_x = gamma_n(5) * (max_xt + max_zt);
+    float delta_y = gamma_n(5) * (max_yt + max_zt);
+    float delta_e = 2.0f * (gamma_n(2) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+    float max_e = max3(fabsf(e0), fabsf(e1), fabsf(e2));
+    float delta_t = 3.0f * (gamma_n(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
+    if (t <= delta_t) return false;
+    *t_out = t; *b0o = b0; *b1o = b1; *b2o = b2;
+    return true;
+}
+
+// ---- DiffuseAreaLight on one triangle (src/lights/diffuse.rs, triangle.rs:667-764) ----
+RDEV rgb light_l(const rspt_light& lt, f3 n, f3 w) {  // diffuse.rs:164-170
+    if (lt.two_sided || dot(n, w) > 0.0f) return ldrgb(lt.L);
+    return mkrgb(0.0f);
+}
+RDEV float tri_area(const TriRec& t) { return 0.5f * len(cross(t.p1 - t.p0, t.p2 - t.p0)); }
+
+struct LightSample {
+    f3 p, p_err, n;
+};
+// Triangle::sample + sample_with_ref_point (triangle.rs:676-744)
+RDEV LightSample tri_sample_ref(const SceneDev& sc, uint32_t prim, const TriRec& t, f3 ref_p, f2 u, float* pdf) {
+    float su0 = sqrtf(u.x);
+    float bx = 1.0f - su0, by = u.y * su0;
+    float bz = 1.0f - bx - by;
+    LightSample s;
+    s.p = t.p0 * bx + t.p1 * by + t.p2 * bz;
+    f3 n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
+    if ((t.flags & MF_HAS_N) && sc.N) {
+        rspt_prim pr = sc.prims[prim];
+        f3 ns = ld3(sc.N, pr.v[0]) * bx + ld3(sc.N, pr.v[1]) * by + ld3(sc.N, pr.v[2]) * bz;
+        n = faceforward(n, ns);
+    } else if (t.flags & MF_FLIP)
+        n = n * -1.0f;
+    s.n = n;
+    s.p_err = (vabs(t.p0 * bx) + vabs(t.p1 * by) + vabs(t.p2 * bz)) * gamma_n(6);
+    *pdf = 1.0f / tri_area(t);
+    f3 wi = s.p - ref_p;
+    if (len2(wi) == 0.0f) *pdf = 0.0f;
+    else {
+        wi = normalize(wi);
+        *pdf *= dist2(ref_p, s.p) / absdot(s.n, -wi);
+        if (__builtin_isinf(*pdf)) *pdf = 0.0f;
+    }
+    return s;
+}
+// DiffuseAreaLight::sample_li (diffuse.rs:64-84)
+RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 u, f3* wi, float* pdf, LightSample* ls) {
+    TriRec t = load_tri(sc, lt.prim);
+    *ls = tri_sample_ref(sc, lt.prim, t, ref_p, u, pdf);
+    if (*pdf == 0.0f || len2(ls->p - ref_p) == 0.0f) { *pdf = 0.0f; return mkrgb(0.0f); }
+    *wi = normalize(ls->p - ref_p);
+    return light_l(lt, ls->n, -*wi);
+}
+
+// ---- Distribution1D::sample_discrete (sampling.rs:103-142) over a device-resident cdf ----
+RDEV uint32_t sample_discrete(const float* func, const float* cdf, float func_int, uint32_t n, float u, float* pdf) {
+    uint32_t first = 0, length = n + 1;
+    while (length > 0) {
+        uint32_t half = length >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; length -= half + 1; }
+        else length = half;
+    }
+    int64_t off = (int64_t)first - 1;
+    off = off < 0 ? 0 : (off > (int64_t)n - 1 ? (int64_t)n - 1 : off);
+    *pdf = func_int > 0.0f ? func[off] / (func_int * (float)n) : 0.0f;
+    return (uint32_t)off;
+}
+// SpatialLightDistribution::lookup voxel addressing (lightdistrib.rs:276-295)
+RDEV uint32_t light_voxel(const SceneDev& sc, const LightDistDev& ld, f3 p) {
+    if (!ld.spatial) return 0;
+    float o[3] = {p.x - sc.wb_min[0], p.y - sc.wb_min[1], p.z - sc.wb_min[2]};  // Bounds3::offset geometry.rs:2160-2173
+    int32_t pi[3];
+    for (int i = 0; i < 3; i++) {
+        if (sc.wb_max[i] > sc.wb_min[i]) o[i] /= sc.wb_max[i] - sc.wb_min[i];
+        int32_t v = f2i_sat(o[i] * (float)ld.nvox[i]);
+        pi[i] = v < 0 ? 0 : (v > ld.nvox[i] - 1 ? ld.nvox[i] - 1 : v);
+    }
+    return (uint32_t)(((int64_t)pi[2] * ld.nvox[1] + pi[1]) * ld.nvox[0] + pi[0]);
+}
+
+// ---- PerspectiveCamera::generate_ray_differential (perspective.rs:190-280), differentials dropped ----
+RDEV void camera_ray(const RenderDev& rd, f2 p_film, f2 p_lens, f3* o_out, f3* d_out, float* tmax_out) {
+    f3 p_camera = xf_point(rd.raster_to_camera, f3{p_film.x, p_film.y, 0.0f});
+    f3 o{0.0f, 0.0f, 0.0f}, d = normalize(p_camera);
+    if (rd.lens_radius > 0.0f) {
+        f2 pl = concentric_disk(p_lens);
+        pl = f2{pl.x * rd.lens_radius, pl.y * rd.lens_radius};
+        float ft = rd.focal_distance / d.z;
+        f3 p_focus = o + d * ft;
+        o = f3{pl.x, pl.y, 0.0f};
+        d = normalize(p_focus - o);
+    }
+    // Transform::transform_ray (transform.rs:538-595)
+    f3 o_err;
+    f3 ow = xf_point_err(rd.camera_to_world, o, &o_err);
+    f3 dw = xf_vector(rd.camera_to_world, d);
+    float ls = len2(dw);
+    float t_max = RSPT_INF;
+    if (ls > 0.0f) {
+        float dt = dot(vabs(dw), o_err) / ls;
+        ow = ow + dw * dt;
+        t_max -= dt;
+    }
+    *o_out = ow; *d_out = dw; *tmax_out = t_max;
+}
+
+}  // namespace rspt

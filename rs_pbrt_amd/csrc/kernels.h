@@ -1,0 +1,623 @@
+// gfx950 kernels of the wavefront path tracer.  One lane = one ray (trace stages) or one path
+// (raygen / shade) or one pixel (film); wave64 throughout, no MFMA (pointer chasing + scalar
+// f32/f64 arithmetic, HBM/L2-latency bound).  Stage inventory:
+//   k_raygen        K1  Sampler::get_camera_sample + PerspectiveCamera::generate_ray_differential
+//   k_trace<ANY>    K2/K3  BVHAccel::intersect / intersect_p + Triangle hit test, LDS-staged stack
+//   k_shade         K4+K6  PathIntegrator::li body between two intersections, incl. NEE resolve
+//   k_film          K8  FilmTile::add_sample / merge_film_tile
+//   k_ld_*          K9  light sampling distributions
+// Queues are arrays of path slots compacted with wave64 ballot + prefix popcount (K7).
+#pragma once
+#include "dev_scene.h"
+
+namespace rspt {
+
+// ---- per-path state, SoA by path slot ------------------------------------------------------
+enum : uint32_t {
+    ST_DIM_MASK = 0xffffu,       // next Sobol' dimension
+    ST_BOUNCE_SHIFT = 16,        // bounces (8 bits)
+    ST_SPECULAR = 1u << 24,      // specular_bounce
+    ST_PENDING = 1u << 25,       // a next-event estimate waits for its visibility / MIS ray
+    ST_ALIVE = 1u << 26,         // a continuation ray is in flight
+    ST_HAS_C1 = 1u << 27,        // pending light-sample term
+    ST_HAS_C2 = 1u << 28,        // pending BSDF-sample (MIS) term
+};
+#define RSPT_Q_MIS 0x80000000u   // closest-hit queue entry flag: this is the path's MIS ray
+
+struct PathBuf {
+    rspt_ray* ray_cont;   // continuation ray (o, d, t_max, slot)
+    rspt_ray* ray_mis;    // BSDF-sampled MIS ray of estimate_direct (closest hit)
+    rspt_ray* ray_sh;     // shadow ray of estimate_direct (any hit)
+    float4* hit_cont;     // (prim bits, b0, b1, b2)
+    float4* hit_mis;
+    uint32_t* occluded;   // shadow ray result
+    float4* L_eta;        // (L.rgb, eta_scale)
+    float4* beta;         // (beta.rgb, -)
+    float4* nee_c1;       // (f*Li*w/light_pdf .rgb, light choice pdf)
+    float4* nee_c2;       // (f*L*w/scattering_pdf .rgb, light index bits)
+    float4* nee_beta;     // (beta at the time of the estimate .rgb, -)
+    uint64_t* sobol_index;
+    uint32_t* state;
+    float2* p_film;
+};
+
+struct QueueCounts {  // one per wavefront iteration
+    uint32_t active, closest, any, pad;
+};
+
+struct Batch {
+    uint32_t pix0, n_pix;  // range of the shard's pixel list
+    uint32_t s0, ns;       // range of sample indices
+    uint32_t n;            // n_pix * ns paths
+};
+
+// XCD-aware virtual block index: the dispatcher places block b on XCD b % 8, so give each XCD a
+// contiguous eighth of every grid-stride stripe (neighbouring rays share BVH nodes -> same L2).
+RDEV uint32_t virtual_block() {
+    uint32_t g = gridDim.x, b = blockIdx.x;
+    return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
+}
+
+// wave64 queue append: one atomic per wave, lanes ordered by prefix popcount of the ballot.
+// Must be reached by all lanes of the wave (inactive ones with pred = false).
+RDEV uint32_t wave_append(bool pred, uint32_t* counter) {
+    uint64_t mask = __ballot(pred);
+    if (mask == 0) return 0;
+    uint32_t lane = __lane_id();
+    uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ---- K1 -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
+                                                uint32_t* __restrict__ q_active, uint32_t* __restrict__ q_closest, QueueCounts* cnt) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) { cnt->active = bt.n; cnt->closest = bt.n; cnt->any = 0; }
+    if (i >= bt.n) return;
+    uint32_t k = bt.pix0 + i / bt.ns, s = bt.s0 + i % bt.ns;
+    uint32_t pk = pix_list[k];
+    int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
+    // SobolSampler::get_index_for_sample (sobol.rs:110-117)
+    uint64_t index = sobol_interval_to_index(rd, (uint32_t)rd.log2_res, (uint64_t)s, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+    // Sampler::get_camera_sample (sampler.rs:85-95): film 2-D, time 1-D, lens 2-D
+    float fy = sobol_pixel_dim(rd, index, 1, py), fx = sobol_pixel_dim(rd, index, 0, px);
+    f2 p_film{(float)px + fx, (float)py + fy};
+    f2 p_lens{0.0f, 0.0f};
+    if (rd.lens_radius > 0.0f) p_lens = f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
+    f3 o, d;
+    float t_max;
+    camera_ray(rd, p_film, p_lens, &o, &d, &t_max);
+    rspt_ray r;
+    r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z; r.t_max = t_max; r.id = i;
+    pb.ray_cont[i] = r;
+    pb.L_eta[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    pb.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    pb.sobol_index[i] = index;
+    pb.state[i] = 5u | ST_ALIVE;  // dimensions 0..4 consumed by the camera sample
+    pb.p_film[i] = make_float2(p_film.x, p_film.y);
+    q_active[i] = i;
+    q_closest[i] = i;
+}
+
+// ---- K2 / K3 --------------------------------------------------------------------------------
+#define RSPT_TRACE_BLOCK 256
+#define RSPT_LDS_STACK 32  // entries per lane kept in LDS; deeper levels spill to scratch
+
+// Bounds3f::intersect_p with precomputed reciprocal direction (geometry.rs:2211-2269)
+RDEV bool box_hit(float4 n0, float4 n1, f3 o, f3 inv, bool ng0, bool ng1, bool ng2, float ray_tmax) {
+    const float widen = 1.0f + 2.0f * gamma_n(3);
+    float t_min = ((ng0 ? n0.w : n0.x) - o.x) * inv.x;
+    float t_max = ((ng0 ? n0.x : n0.w) - o.x) * inv.x;
+    float ty_min = ((ng1 ? n1.x : n0.y) - o.y) * inv.y;
+    float ty_max = ((ng1 ? n0.y : n1.x) - o.y) * inv.y;
+    t_max *= widen;
+    ty_max *= widen;
+    if (t_min > ty_max || ty_min > t_max) return false;
+    if (ty_min > t_min) t_min = ty_min;
+    if (ty_max < t_max) t_max = ty_max;
+    float tz_min = ((ng2 ? n1.y : n0.z) - o.z) * inv.z;
+    float tz_max = ((ng2 ? n0.z : n1.y) - o.z) * inv.z;
+    tz_max *= widen;
+    if (t_min > tz_max || tz_min > t_max) return false;
+    if (tz_min > t_min) t_min = tz_min;
+    if (tz_max < t_max) t_max = tz_max;
+    return (t_min < ray_tmax) && (t_max > 0.0f);
+}
+
+struct TraceResult {
+    uint32_t prim;
+    float t, b0, b1, b2;
+    uint32_t nodes, tris;
+};
+
+// BVHAccel::intersect (bvh.rs:401-462) / intersect_p (:463-514): ordered depth-first traversal,
+// near child first by dir_is_neg[axis], far child pushed.  Visit order is exactly the
+// reference's, so the winning primitive and (t, b) are bit-identical, ties included.
+template <bool ANY>
+RDEV TraceResult traverse(const SceneDev& sc, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */) {
+    TraceResult res;
+    res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0;
+    if (sc.n_nodes == 0) return res;
+    f3 inv{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    const bool ng0 = inv.x < 0.0f, ng1 = inv.y < 0.0f, ng2 = inv.z < 0.0f;
+    const RayShear rs = ray_shear(d);
+    uint32_t spill[64 - RSPT_LDS_STACK];
+    uint32_t sp = 0, cur = 0;
+    for (;;) {
+        float4 n0 = sc.nodes[2 * (size_t)cur], n1 = sc.nodes[2 * (size_t)cur + 1];
+        res.nodes++;
+        bool descend = false;
+        if (box_hit(n0, n1, o, inv, ng0, ng1, ng2, t_max)) {
+            uint32_t w = __float_as_uint(n1.w);
+            uint32_t n_prims = w & 0xffffu, axis = (w >> 16) & 0xffu;
+            uint32_t offset = __float_as_uint(n1.z);
+            if (n_prims > 0) {
+                for (uint32_t i = 0; i < n_prims; i++) {
+                    uint32_t pi = offset + i;
+                    float4 a = sc.tris[3 * (size_t)pi], b = sc.tris[3 * (size_t)pi + 1], c = sc.tris[3 * (size_t)pi + 2];
+                    res.tris++;
+                    float t, b0, b1, b2;
+                    if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, o, rs, t_max, &t, &b0, &b1, &b2)) {
+                        if (ANY) { res.prim = 0; return res; }
+                        t_max = t;  // GeometricPrimitive::intersect shrinks the ray (primitive.rs:155)
+                        res.prim = pi; res.t = t; res.b0 = b0; res.b1 = b1; res.b2 = b2;
+                    }
+                }
+            } else {
+                bool neg = axis == 0 ? ng0 : (axis == 1 ? ng1 : ng2);
+                uint32_t far_child = neg ? cur + 1 : offset;
+                cur = neg ? offset : cur + 1;
+                if (sp < RSPT_LDS_STACK) lds_stack[sp * RSPT_TRACE_BLOCK] = far_child;
+                else spill[sp - RSPT_LDS_STACK] = far_child;
+                sp++;
+                descend = true;
+            }
+        }
+        if (!descend) {
+            if (sp == 0) break;
+            sp--;
+            cur = sp < RSPT_LDS_STACK ? lds_stack[sp * RSPT_TRACE_BLOCK] : spill[sp - RSPT_LDS_STACK];
+        }
+    }
+    return res;
+}
+
+// out_mode 0: float4 (prim, b0, b1, b2) into hit_cont/hit_mis by slot; 1: rspt_hit AoS by queue
+// position (stage hook); ANY: occluded[slot] (mode 0) or rspt_hit.prim (mode 1).
+template <bool ANY, int OUT_MODE, bool COUNT>
+__global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
+                                                            uint32_t count_imm, const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
+                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
+                                                            rspt_hit* __restrict__ out_hits, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t stack[RSPT_LDS_STACK * RSPT_TRACE_BLOCK];
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    const uint32_t stride = gridDim.x * RSPT_TRACE_BLOCK;
+    unsigned long long c_nodes = 0, c_tris = 0;
+    for (uint32_t base = virtual_block() * RSPT_TRACE_BLOCK; base < n; base += stride) {
+        uint32_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        uint32_t e = queue ? queue[i] : i;
+        uint32_t slot = e & ~RSPT_Q_MIS;
+        bool mis = (e & RSPT_Q_MIS) != 0;
+        const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
+        float4 r0 = rp[0], r1 = rp[1];
+        TraceResult res = traverse<ANY>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        if (OUT_MODE == 0) {
+            if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
+            else (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+        } else {
+            rspt_hit h;
+            h.prim = res.prim; h.t = res.t; h.b0 = res.b0; h.b1 = res.b1; h.b2 = res.b2;
+            out_hits[i] = h;
+        }
+        if (COUNT) { c_nodes += res.nodes; c_tris += res.tris; }
+    }
+    if (COUNT) {
+        atomicAdd(&counters[0], c_nodes);
+        atomicAdd(&counters[1], c_tris);
+    }
+}
+
+// ---- K4 + K6 --------------------------------------------------------------------------------
+struct ShadeOut {
+    bool active, cont, mis, shadow;
+};
+
+RDEV void store_ray(rspt_ray* dst, f3 o, f3 d, float t_max, uint32_t id) {
+    float4* p = reinterpret_cast<float4*>(dst);
+    p[0] = make_float4(o.x, o.y, o.z, d.x);
+    p[1] = make_float4(d.y, d.z, t_max, __uint_as_float(id));
+}
+
+// One step of PathIntegrator::li (path.rs:91-280) for path slot p: fold in the previous
+// bounce's next-event estimate, then process the hit of the continuation ray.
+RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const RenderDev& rd, const PathBuf& pb, uint32_t p, unsigned long long* stats) {
+    ShadeOut out{false, false, false, false};
+    uint32_t st = pb.state[p];
+    float4 le = pb.L_eta[p];
+    rgb L{le.x, le.y, le.z};
+    float eta_scale = le.w;
+
+    if (st & ST_PENDING) {  // tail of estimate_direct (integrator.rs:461-568) + path.rs:126-139
+        float4 c1 = pb.nee_c1[p], c2 = pb.nee_c2[p], nb = pb.nee_beta[p];
+        rgb ldir = mkrgb(0.0f);
+        if ((st & ST_HAS_C1) && pb.occluded[p] == 0u) ldir = ldir + rgb{c1.x, c1.y, c1.z};
+        if (st & ST_HAS_C2) {
+            float4 hm = pb.hit_mis[p];
+            uint32_t hp = __float_as_uint(hm.x);
+            uint32_t light_num = __float_as_uint(c2.w);
+            if (hp != RSPT_MISS) {
+                TriRec t = load_tri(sc, hp);
+                if (t.area_light >= 0 && (uint32_t)t.area_light == light_num) {
+                    Hit h;
+                    tri_fill(sc, hp, t, hm.y, hm.z, hm.w, &h);
+                    const float4* mr = reinterpret_cast<const float4*>(pb.ray_mis + p);
+                    float4 m0 = mr[0], m1 = mr[1];
+                    f3 wi{m0.w, m1.x, m1.y};
+                    rgb li = light_l(sc.lights[light_num], h.n, -wi);
+                    if (!is_black(li)) ldir = ldir + rgb{c2.x, c2.y, c2.z};
+                }
+            }
+        }
+        L = L + rgb{nb.x, nb.y, nb.z} * (ldir / c1.w);
+        st &= ~(ST_PENDING | ST_HAS_C1 | ST_HAS_C2);
+    }
+    if (!(st & ST_ALIVE)) {
+        pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
+        pb.state[p] = st;
+        return out;
+    }
+    st &= ~ST_ALIVE;
+
+    float4 hc = pb.hit_cont[p];
+    uint32_t prim = __float_as_uint(hc.x);
+    uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
+    bool finished = true;
+    if (prim != RSPT_MISS) {  // a miss adds nothing: no infinite lights in scope (path.rs:267-277)
+        const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
+        float4 r0 = rp[0], r1 = rp[1];
+        f3 ray_d{r0.w, r1.x, r1.y};
+        float4 bb = pb.beta[p];
+        rgb beta{bb.x, bb.y, bb.z};
+        TriRec tri = load_tri(sc, prim);
+        Hit h;
+        tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &h);
+        f3 wo = -ray_d;  // SurfaceInteraction.wo, not normalised (triangle.rs:334)
+        if (bounces == 0 || (st & ST_SPECULAR)) {  // path.rs:97-101
+            rgb e = h.area_light >= 0 ? light_l(sc.lights[h.area_light], h.n, wo) : mkrgb(0.0f);
+            L = L + beta * e;
+        }
+        if (bounces < rd.max_depth) {  // path.rs:103
+            if (h.material == 0xffffffffu) {  // null BSDF: pass straight through (path.rs:109-116)
+                f3 o = offset_ray_origin(h.p, h.p_err, h.n, ray_d);
+                store_ray(pb.ray_cont + p, o, ray_d, RSPT_INF, p);
+                st |= ST_ALIVE;
+                out.cont = true;
+                finished = false;
+            } else {
+                finished = false;  // decided below
+                rspt_material mat = sc.materials[h.material];
+                Bsdf bsdf;  // Bsdf::new (reflection.rs:235-245)
+                bsdf.eta = mat.eta;
+                bsdf.ss = normalize(h.sh_dpdu);
+                bsdf.ns = h.sh_n;
+                bsdf.ng = h.n;
+                bsdf.ts = cross(h.sh_n, bsdf.ss);
+                bsdf.lobes = sc.bxdfs + mat.first_bxdf;
+                bsdf.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+                Sampler smp{pb.sobol_index[p], st & ST_DIM_MASK};
+                if (stats) atomicAdd(&stats[0], 1ull);
+
+                // ---- uniform_sample_one_light (integrator.rs:359-403) ----
+                const uint32_t nonspec = BX_ALL & ~BX_SPEC;
+                if (sc.n_lights > 0 && bsdf.num_components(nonspec) > 0) {
+                    uint32_t vox = light_voxel(sc, ld, h.p);
+                    float pdf_choice = 0.0f;
+                    uint32_t light_num = sample_discrete(ld.func + (size_t)vox * sc.n_lights, ld.cdf + (size_t)vox * (sc.n_lights + 1),
+                                                         ld.func_int[vox], sc.n_lights, smp.get_1d(rd), &pdf_choice);
+                    if (pdf_choice != 0.0f) {
+                        f2 u_light = smp.get_2d(rd);
+                        f2 u_scatter = smp.get_2d(rd);
+                        const rspt_light lt = sc.lights[light_num];
+                        rgb c1 = mkrgb(0.0f), c2 = mkrgb(0.0f);
+                        // light sample (integrator.rs:424-477)
+                        f3 wi{0.0f, 0.0f, 0.0f};
+                        float light_pdf = 0.0f, scattering_pdf = 0.0f;
+                        LightSample ls;
+                        rgb li = light_sample_li(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
+                        if (light_pdf > 0.0f && !is_black(li)) {
+                            rgb f = bsdf.f(wo, wi, nonspec) * mkrgb(absdot(wi, h.sh_n));
+                            scattering_pdf = bsdf.pdf(wo, wi, nonspec);
+                            if (!is_black(f)) {
+                                // VisibilityTester::unoccluded -> spawn_ray_to (interaction.rs:81-94)
+                                f3 origin = offset_ray_origin(h.p, h.p_err, h.n, ls.p - h.p);
+                                f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
+                                store_ray(pb.ray_sh + p, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, p);
+                                out.shadow = true;
+                                float weight = power_heuristic(light_pdf, scattering_pdf);
+                                c1 = f * li * mkrgb(weight) / light_pdf;
+                                st |= ST_HAS_C1;
+                            }
+                        }
+                        // BSDF sample with MIS (integrator.rs:480-568); sampled_type sentinel 0 (Q6)
+                        {
+                            uint32_t sampled_type = 0;
+                            rgb f = bsdf.sample_f(wo, &wi, u_scatter, &scattering_pdf, nonspec, &sampled_type);
+                            f = f * mkrgb(absdot(wi, h.sh_n));
+                            if (!is_black(f) && scattering_pdf > 0.0f) {
+                                // DiffuseAreaLight::pdf_li -> Triangle::pdf_with_ref_point (triangle.rs:745-764)
+                                f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
+                                TriRec lt_tri = load_tri(sc, lt.prim);
+                                float t_l, lb0, lb1, lb2;
+                                float lpdf = 0.0f;
+                                if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
+                                    Hit lh;
+                                    tri_fill(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
+                                    lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
+                                    if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+                                }
+                                if (lpdf != 0.0f) {
+                                    float weight = power_heuristic(scattering_pdf, lpdf);
+                                    store_ray(pb.ray_mis + p, ro, wi, RSPT_INF, p);
+                                    out.mis = true;
+                                    c2 = f * ldrgb(lt.L) * mkrgb(1.0f) * weight / scattering_pdf;
+                                    st |= ST_HAS_C2;
+                                }
+                            }
+                        }
+                        pb.nee_c1[p] = make_float4(c1.r, c1.g, c1.b, pdf_choice);
+                        pb.nee_c2[p] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
+                        pb.nee_beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                        st |= ST_PENDING;  // even an all-zero estimate is added (l + beta*0 == l)
+                    }
+                }
+
+                // ---- continuation (path.rs:141-188) ----
+                f3 wi{0.0f, 0.0f, 0.0f};
+                float pdf = 0.0f;
+                uint32_t sampled_type = 255;
+                rgb f = bsdf.sample_f(wo, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
+                bool go_on = !(is_black(f) || pdf == 0.0f);
+                if (go_on) {
+                    beta = beta * ((f * absdot(wi, h.sh_n)) / pdf);
+                    st = (sampled_type & BX_SPEC) ? (st | ST_SPECULAR) : (st & ~ST_SPECULAR);
+                    if ((sampled_type & BX_SPEC) && (sampled_type & BX_TRANS)) {
+                        float eta = bsdf.eta;
+                        if (dot(wo, h.n) > 0.0f) eta_scale *= eta * eta;
+                        else eta_scale *= 1.0f / (eta * eta);
+                    }
+                    f3 o = offset_ray_origin(h.p, h.p_err, h.n, wi);
+                    // Russian roulette (path.rs:251-262)
+                    rgb rr = beta * eta_scale;
+                    if (maxc(rr) < rd.rr_threshold && bounces > 3) {
+                        float q = fmaxf(0.05f, 1.0f - maxc(rr));
+                        if (smp.get_1d(rd) < q) go_on = false;
+                        else beta = beta / (1.0f - q);
+                    }
+                    if (go_on) {
+                        store_ray(pb.ray_cont + p, o, wi, RSPT_INF, p);
+                        pb.beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                        st |= ST_ALIVE;
+                        out.cont = true;
+                    }
+                }
+                bounces += 1;
+                st = (st & ~(ST_DIM_MASK | (0xffu << ST_BOUNCE_SHIFT))) | (smp.dim & ST_DIM_MASK) | ((bounces & 0xffu) << ST_BOUNCE_SHIFT);
+            }
+        }
+    }
+    (void)finished;
+    pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
+    pb.state[p] = st;
+    out.active = (st & (ST_ALIVE | ST_PENDING)) != 0;
+    return out;
+}
+
+__global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
+                                               const QueueCounts* __restrict__ cnt_in, QueueCounts* cnt_out, uint32_t* __restrict__ q_active_next,
+                                               uint32_t* __restrict__ q_closest_next, uint32_t* __restrict__ q_any_next, unsigned long long* stats) {
+    const uint32_t n = cnt_in->active;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t base = virtual_block() * 256u; base < n; base += stride) {
+        uint32_t i = base + threadIdx.x;
+        ShadeOut o{false, false, false, false};
+        uint32_t p = 0;
+        if (i < n) {
+            p = q_active[i];
+            o = shade_path(sc, ld, rd, pb, p, stats);
+        }
+        uint32_t k;
+        bool any_lane;
+        any_lane = __ballot(o.active) != 0;
+        k = wave_append(o.active, &cnt_out->active);
+        if (o.active) q_active_next[k] = p;
+        (void)any_lane;
+        k = wave_append(o.cont, &cnt_out->closest);
+        if (o.cont) q_closest_next[k] = p;
+        k = wave_append(o.mis, &cnt_out->closest);
+        if (o.mis) q_closest_next[k] = p | RSPT_Q_MIS;
+        k = wave_append(o.shadow, &cnt_out->any);
+        if (o.shadow) q_any_next[k] = p;
+    }
+}
+
+// ---- K8 -------------------------------------------------------------------------------------
+// FilmTile::add_sample (film.rs:94-147) for all samples of one pixel in this batch, in sample
+// order.  The pixel's own contributions accumulate in registers; splats into other pixels
+// (wide filters; exact-zero film offsets with the box filter) go through atomics into a
+// separate buffer that is folded in by k_film_resolve.
+__global__ __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list, float4* __restrict__ film_own,
+                                              float* __restrict__ film_splat, float* __restrict__ li_out, unsigned long long* nan_count) {
+    uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= bt.n_pix) return;
+    uint32_t pk = pix_list[bt.pix0 + k];
+    int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
+    const int32_t* sb = rd.sample_bounds;
+    const int32_t* cp = rd.crop_px;
+    const int32_t ts = (int32_t)rd.tile_size;
+    // tile of this pixel (integrator.rs:115-120) and its FilmTile pixel bounds (film.rs:308-345)
+    int32_t tx0 = sb[0] + ((px - sb[0]) / ts) * ts, ty0 = sb[1] + ((py - sb[1]) / ts) * ts;
+    int32_t tx1 = min(tx0 + ts, sb[2]), ty1 = min(ty0 + ts, sb[3]);
+    float rx = rd.filter_radius[0], ry = rd.filter_radius[1];
+    int32_t bx0 = max(f2i_sat(ceilf((float)tx0 - 0.5f - rx)), cp[0]), by0 = max(f2i_sat(ceilf((float)ty0 - 0.5f - ry)), cp[1]);
+    int32_t bx1 = min(f2i_sat(floorf((float)tx1 - 0.5f + rx)) + 1, cp[2]), by1 = min(f2i_sat(floorf((float)ty1 - 0.5f + ry)) + 1, cp[3]);
+    const int32_t cw = cp[2] - cp[0];
+    const bool own_in_crop = px >= cp[0] && px < cp[2] && py >= cp[1] && py < cp[3];
+    const size_t own_idx = own_in_crop ? (size_t)(py - cp[1]) * cw + (size_t)(px - cp[0]) : 0;
+    float4 acc = own_in_crop ? film_own[own_idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    unsigned long long nans = 0;
+    for (uint32_t j = 0; j < bt.ns; j++) {
+        uint32_t i = k * bt.ns + j;
+        float4 le = pb.L_eta[i];
+        rgb l{le.x, le.y, le.z};
+        if (has_nans(l)) { l = mkrgb(0.0f); nans++; }  // integrator.rs:165-173
+        if (li_out && own_in_crop) {
+            float* o = li_out + (own_idx * (size_t)rd.spp + (size_t)(bt.s0 + j)) * 3;
+            o[0] = l.r; o[1] = l.g; o[2] = l.b;
+        }
+        if (lum(l) > rd.max_sample_luminance) l = l * mkrgb(rd.max_sample_luminance / lum(l));
+        float2 pf = pb.p_film[i];
+        float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
+        int32_t x0 = max(f2i_sat(ceilf(dx - rx)), bx0), y0 = max(f2i_sat(ceilf(dy - ry)), by0);
+        int32_t x1 = min(f2i_sat(floorf(dx + rx)) + 1, bx1), y1 = min(f2i_sat(floorf(dy + ry)) + 1, by1);
+        for (int32_t y = y0; y < y1; y++) {
+            float fy = fabsf(((float)y - dy) * inv_ry * 16.0f);
+            int32_t ify = (int32_t)fminf(floorf(fy), 15.0f);
+            for (int32_t x = x0; x < x1; x++) {
+                float fx = fabsf(((float)x - dx) * inv_rx * 16.0f);
+                int32_t ifx = (int32_t)fminf(floorf(fx), 15.0f);
+                float w = rd.filter_table[ify * 16 + ifx];
+                rgb c = l * mkrgb(1.0f) * mkrgb(w);  // l * sample_weight * filter_weight
+                if (x == px && y == py) {
+                    acc.x += c.r; acc.y += c.g; acc.z += c.b; acc.w += w;
+                } else {
+                    float* s = film_splat + 4 * ((size_t)(y - cp[1]) * cw + (size_t)(x - cp[0]));
+                    atomicAdd(s + 0, c.r); atomicAdd(s + 1, c.g); atomicAdd(s + 2, c.b); atomicAdd(s + 3, w);
+                }
+            }
+        }
+    }
+    if (own_in_crop) film_own[own_idx] = acc;
+    if (nans) atomicAdd(nan_count, nans);
+}
+
+// Film::merge_film_tile (film.rs:346-371): contrib_sum RGB -> XYZ, plus filter weight sum.
+// `add` = 1 accumulates into film_out (multi-pass renders), 0 overwrites.
+__global__ void k_film_resolve(const float4* __restrict__ film_own, const float4* __restrict__ film_splat, float4* __restrict__ film_out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = film_own[i], s = film_splat[i];
+    float r = a.x + s.x, g = a.y + s.y, b = a.z + s.z;
+    float4 o;
+    o.x = 0.412453f * r + 0.357580f * g + 0.180423f * b;  // rgb_to_xyz spectrum.rs:1829-1835
+    o.y = 0.212671f * r + 0.715160f * g + 0.072169f * b;
+    o.z = 0.019334f * r + 0.119193f * g + 0.950227f * b;
+    o.w = a.w + s.w;
+    film_out[i] = o;
+}
+
+// ---- K9: light sampling distributions (src/core/lightdistrib.rs) ------------------------------
+RDEV uint32_t rev32(uint32_t n) {  // lowdiscrepancy.rs:770-779
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x00ff00ffu) << 8) | ((n & 0xff00ff00u) >> 8);
+    n = ((n & 0x0f0f0f0fu) << 4) | ((n & 0xf0f0f0f0u) >> 4);
+    n = ((n & 0x33333333u) << 2) | ((n & 0xccccccccu) >> 2);
+    n = ((n & 0x55555555u) << 1) | ((n & 0xaaaaaaaau) >> 1);
+    return n;
+}
+RDEV float radical_inverse(int base_index, uint64_t a) {  // lowdiscrepancy.rs:1082-1135
+    if (base_index == 0) {
+        uint64_t r = ((uint64_t)rev32((uint32_t)a) << 32) | (uint64_t)rev32((uint32_t)(a >> 32));
+        return (float)r * 0x1.0p-64f;
+    }
+    const uint64_t base = base_index == 1 ? 3 : (base_index == 2 ? 5 : (base_index == 3 ? 7 : 11));
+    float inv_base = 1.0f / (float)base;
+    uint64_t reversed = 0;
+    float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base, digit = a - next * base;
+        reversed = reversed * base + digit;
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return fminf((float)reversed * inv_base_n, RSPT_ONE_MINUS_EPS);
+}
+// SpatialLightDistribution::compute_distribution, per (voxel, light) (lightdistrib.rs:169-260)
+__global__ void k_ld_contrib(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, float* __restrict__ func) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = (uint64_t)nvx * nvy * nvz * sc.n_lights;
+    if (gid >= total) return;
+    uint32_t j = (uint32_t)(gid % sc.n_lights);
+    uint64_t v = gid / sc.n_lights;
+    int32_t ix = (int32_t)(v % nvx), iy = (int32_t)((v / nvx) % nvy), iz = (int32_t)(v / ((uint64_t)nvx * nvy));
+    f3 wmin{sc.wb_min[0], sc.wb_min[1], sc.wb_min[2]}, wmax{sc.wb_max[0], sc.wb_max[1], sc.wb_max[2]};
+    f3 p0{(float)ix / (float)nvx, (float)iy / (float)nvy, (float)iz / (float)nvz};
+    f3 p1{(float)(ix + 1) / (float)nvx, (float)(iy + 1) / (float)nvy, (float)(iz + 1) / (float)nvz};
+    f3 vmin{lerpf(p0.x, wmin.x, wmax.x), lerpf(p0.y, wmin.y, wmax.y), lerpf(p0.z, wmin.z, wmax.z)};
+    f3 vmax{lerpf(p1.x, wmin.x, wmax.x), lerpf(p1.y, wmin.y, wmax.y), lerpf(p1.z, wmin.z, wmax.z)};
+    const rspt_light lt = sc.lights[j];
+    float contrib = 0.0f;
+    for (uint64_t i = 0; i < 128; i++) {
+        f3 t{radical_inverse(0, i), radical_inverse(1, i), radical_inverse(2, i)};
+        f3 po{lerpf(t.x, vmin.x, vmax.x), lerpf(t.y, vmin.y, vmax.y), lerpf(t.z, vmin.z, vmax.z)};
+        f2 u{radical_inverse(3, i), radical_inverse(4, i)};
+        float pdf = 0.0f;
+        f3 wi{0.0f, 0.0f, 0.0f};
+        LightSample ls;
+        rgb li = light_sample_li(sc, lt, po, u, &wi, &pdf, &ls);
+        if (pdf > 0.0f) contrib += lum(li) / pdf;
+    }
+    func[gid] = contrib;
+}
+// one Distribution1D per voxel (sampling.rs:24-49) after the min-contribution clamp (:262-268);
+// mode 0: spatial (func holds raw contributions), 1: use func as is (uniform / power)
+__global__ void k_ld_build(uint32_t n_vox, uint32_t nl, int mode, float* __restrict__ func, float* __restrict__ cdf, float* __restrict__ func_int) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vox) return;
+    float* f = func + (size_t)v * nl;
+    float* c = cdf + (size_t)v * (nl + 1);
+    if (mode == 0) {
+        float sum = 0.0f;
+        for (uint32_t j = 0; j < nl; j++) sum += f[j];
+        float avg = sum / (float)(128u * nl);
+        float min_contrib = avg > 0.0f ? 0.001f * avg : 1.0f;
+        for (uint32_t j = 0; j < nl; j++) f[j] = fmaxf(f[j], min_contrib);
+    }
+    c[0] = 0.0f;
+    for (uint32_t i = 1; i <= nl; i++) c[i] = c[i - 1] + f[i - 1] / (float)nl;
+    float fi = c[nl];
+    if (fi == 0.0f) for (uint32_t i = 1; i <= nl; i++) c[i] = (float)i / (float)nl;
+    else for (uint32_t i = 1; i <= nl; i++) c[i] /= fi;
+    func_int[v] = fi;
+}
+// uniform: func = 1; power: func = Light::power().y() (integrator.rs:573-584, diffuse.rs:85-93)
+__global__ void k_ld_fixed(SceneDev sc, int power, float* __restrict__ func) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= sc.n_lights) return;
+    if (!power) { func[j] = 1.0f; return; }
+    const rspt_light lt = sc.lights[j];
+    TriRec t = load_tri(sc, lt.prim);
+    float factor = lt.two_sided ? 2.0f : 1.0f;
+    rgb pw = ldrgb(lt.L) * factor * tri_area(t) * RSPT_PI;
+    func[j] = lum(pw);
+}
+
+// scene upload helper: build the 48-byte triangle records from the indexed ABI arrays
+__global__ void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mesh* __restrict__ meshes, const float* __restrict__ P, uint32_t n,
+                             float4* __restrict__ tris) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rspt_prim pr = prims[i];
+    rspt_mesh m = meshes[pr.mesh];
+    f3 p0 = ld3(P, pr.v[0]), p1 = ld3(P, pr.v[1]), p2 = ld3(P, pr.v[2]);
+    uint32_t flags = (m.has_n ? MF_HAS_N : 0u) | (m.has_s ? MF_HAS_S : 0u) | (m.has_uv ? MF_HAS_UV : 0u) | (m.flip ? MF_FLIP : 0u);
+    tris[3 * (size_t)i] = make_float4(p0.x, p0.y, p0.z, p1.x);
+    tris[3 * (size_t)i + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
+    tris[3 * (size_t)i + 2] = make_float4(p2.z, __uint_as_float(pr.material), __uint_as_float((uint32_t)pr.area_light), __uint_as_float(flags));
+}
+
+}  // namespace rspt

@@ -1,0 +1,651 @@
+// librspt.so — host side of the C ABI in include/rspt.h: scene upload, wavefront scheduling of
+// the gfx950 kernels (kernels.h), film read-back.  gfx950 only; there is no CPU fallback: every
+// entry point that needs the GPU fails with RSPT_E_NODEVICE / RSPT_E_HIP when it is not there.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rspt.h"
+#include "kernels.h"
+
+using namespace rspt;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(RSPT_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Ctx {
+    bool inited = false;
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    // path state
+    size_t cap = 0;
+    PathBuf pb{};
+    uint32_t* q[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [parity][active, closest, any]
+    QueueCounts* cnt = nullptr;
+    uint32_t n_cnt = 0;
+    unsigned long long* totals = nullptr;  // [0] nodes [1] tris [2] bsdf hits [3] rays closest [4] rays any [5] nan samples
+    // sampler tables + filter table
+    uint32_t* sobol32 = nullptr;
+    uint64_t* vdc = nullptr;
+    uint64_t* vdc_inv = nullptr;
+    float* filter_table = nullptr;
+    // film
+    float4* film_own = nullptr;
+    float4* film_splat = nullptr;
+    float4* film_out = nullptr;
+    size_t film_px = 0;
+    uint32_t* pix_list = nullptr;
+    size_t pix_cap = 0;
+    std::vector<hipEvent_t> events;
+};
+Ctx g;
+
+struct LightDist {
+    float* func = nullptr;
+    float* cdf = nullptr;
+    float* func_int = nullptr;
+    int32_t nvox[3] = {1, 1, 1};
+    int32_t spatial = 0;
+};
+
+}  // namespace
+
+struct rspt_scene_s {
+    SceneDev dev{};
+    std::vector<void*> allocs;
+    bool has_null_material = false;
+    std::map<int, LightDist> light_dists;  // by effective strategy
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T** out, size_t n) {
+    *out = nullptr;
+    if (n == 0) return RSPT_OK;
+    HIP_TRY(hipMalloc((void**)out, n * sizeof(T)));
+    return RSPT_OK;
+}
+template <class T>
+int upload(rspt_scene_s* s, const T* host, size_t n, const T** out) {
+    *out = nullptr;
+    if (n == 0 || !host) return RSPT_OK;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, n * sizeof(T)));
+    s->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return RSPT_OK;
+}
+
+uint32_t grid_for(uint32_t waves_per_cu_blocks) { return (uint32_t)g.n_cus * waves_per_cu_blocks; }
+
+size_t env_size(const char* name, size_t dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return (size_t)strtoull(v, nullptr, 0);
+}
+
+void free_paths() {
+    void* ptrs[] = {g.pb.ray_cont, g.pb.ray_mis, g.pb.ray_sh, g.pb.hit_cont, g.pb.hit_mis, g.pb.occluded, g.pb.L_eta, g.pb.beta,
+                    g.pb.nee_c1, g.pb.nee_c2, g.pb.nee_beta, g.pb.sobol_index, g.pb.state, g.pb.p_film,
+                    g.q[0][0], g.q[0][1], g.q[0][2], g.q[1][0], g.q[1][1], g.q[1][2]};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    g.pb = PathBuf{};
+    for (auto& a : g.q) a[0] = a[1] = a[2] = nullptr;
+    g.cap = 0;
+}
+
+int ensure_paths(size_t cap) {
+    if (g.cap >= cap) return RSPT_OK;
+    free_paths();
+    int rc;
+#define A(field, n) if ((rc = dev_alloc(&field, (n))) != RSPT_OK) return rc
+    A(g.pb.ray_cont, cap); A(g.pb.ray_mis, cap); A(g.pb.ray_sh, cap);
+    A(g.pb.hit_cont, cap); A(g.pb.hit_mis, cap); A(g.pb.occluded, cap);
+    A(g.pb.L_eta, cap); A(g.pb.beta, cap); A(g.pb.nee_c1, cap); A(g.pb.nee_c2, cap); A(g.pb.nee_beta, cap);
+    A(g.pb.sobol_index, cap); A(g.pb.state, cap); A(g.pb.p_film, cap);
+    for (int par = 0; par < 2; par++) {
+        A(g.q[par][0], cap);
+        A(g.q[par][1], 2 * cap);  // continuation + MIS rays
+        A(g.q[par][2], cap);
+    }
+#undef A
+    g.cap = cap;
+    return RSPT_OK;
+}
+
+int ensure_counts(uint32_t n) {
+    if (g.n_cnt >= n) return RSPT_OK;
+    if (g.cnt) (void)hipFree(g.cnt);
+    g.cnt = nullptr;
+    int rc = dev_alloc(&g.cnt, n);
+    if (rc) return rc;
+    g.n_cnt = n;
+    return RSPT_OK;
+}
+
+hipEvent_t get_event(size_t i) {
+    while (g.events.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g.events.push_back(e);
+    }
+    return g.events[i];
+}
+
+__global__ void k_accum_counts(const QueueCounts* cnt, uint32_t n_iter, unsigned long long* totals) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long c = 0, a = 0;
+    for (uint32_t i = 0; i < n_iter; i++) { c += cnt[i].closest; a += cnt[i].any; }
+    totals[3] += c;
+    totals[4] += a;
+}
+
+// blockqueue/mod.rs:100-115
+uint32_t part1by1(uint32_t x) {
+    x &= 0x0000ffff; x = (x ^ (x << 8)) & 0x00ff00ff; x = (x ^ (x << 4)) & 0x0f0f0f0f;
+    x = (x ^ (x << 2)) & 0x33333333; return (x ^ (x << 1)) & 0x55555555;
+}
+uint32_t morton2(uint32_t x, uint32_t y) { return (part1by1(y) << 1) + part1by1(x); }
+
+int round_up_pow2_32(int32_t v) {  // pbrt.rs:188-198
+    v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    return v + 1;
+}
+
+// Light distribution for (scene, strategy): create_light_sample_distribution (lightdistrib.rs:393-418)
+int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
+    const uint32_t nl = s->dev.n_lights;
+    *out = LightDistDev{};
+    out->nvox[0] = out->nvox[1] = out->nvox[2] = 1;
+    if (nl == 0) return RSPT_OK;
+    int eff = (strategy == RSPT_LIGHTS_UNIFORM || nl == 1) ? RSPT_LIGHTS_UNIFORM : (strategy == RSPT_LIGHTS_POWER ? RSPT_LIGHTS_POWER : RSPT_LIGHTS_SPATIAL);
+    auto it = s->light_dists.find(eff);
+    if (it == s->light_dists.end()) {
+        LightDist d;
+        uint64_t n_vox = 1;
+        if (eff == RSPT_LIGHTS_SPATIAL) {  // SpatialLightDistribution::new (lightdistrib.rs:127-166)
+            float diag[3] = {s->dev.wb_max[0] - s->dev.wb_min[0], s->dev.wb_max[1] - s->dev.wb_min[1], s->dev.wb_max[2] - s->dev.wb_min[2]};
+            int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);  // maximum_extent
+            float bmax = diag[me];
+            for (int i = 0; i < 3; i++) {
+                float r = roundf(diag[i] / bmax * 64.0f);
+                int32_t v = (r != r) ? 0 : (r >= 2147483648.0f ? 2147483647 : (r <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)r));
+                d.nvox[i] = std::max(1, v);
+            }
+            n_vox = (uint64_t)d.nvox[0] * d.nvox[1] * d.nvox[2];
+            d.spatial = 1;
+            const uint64_t limit = env_size("RSPT_MAX_LIGHT_TABLE", (size_t)1 << 31);
+            if (n_vox * (nl + 1) > limit)
+                return fail(RSPT_E_UNSUPPORTED, "spatial light distribution of %llu voxels x %u lights exceeds RSPT_MAX_LIGHT_TABLE",
+                            (unsigned long long)n_vox, nl);
+        }
+        int rc;
+        if ((rc = dev_alloc(&d.func, n_vox * nl)) || (rc = dev_alloc(&d.cdf, n_vox * (nl + 1))) || (rc = dev_alloc(&d.func_int, n_vox))) return rc;
+        s->allocs.push_back(d.func); s->allocs.push_back(d.cdf); s->allocs.push_back(d.func_int);
+        if (eff == RSPT_LIGHTS_SPATIAL) {
+            uint64_t total = n_vox * nl;
+            hipLaunchKernelGGL(k_ld_contrib, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, g.stream, s->dev, d.nvox[0], d.nvox[1], d.nvox[2], d.func);
+            hipLaunchKernelGGL(k_ld_build, dim3((uint32_t)((n_vox + 255) / 256)), dim3(256), 0, g.stream, (uint32_t)n_vox, nl, 0, d.func, d.cdf, d.func_int);
+        } else {
+            hipLaunchKernelGGL(k_ld_fixed, dim3((nl + 255) / 256), dim3(256), 0, g.stream, s->dev, eff == RSPT_LIGHTS_POWER ? 1 : 0, d.func);
+            hipLaunchKernelGGL(k_ld_build, dim3(1), dim3(64), 0, g.stream, 1u, nl, 1, d.func, d.cdf, d.func_int);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        it = s->light_dists.emplace(eff, d).first;
+    }
+    const LightDist& d = it->second;
+    out->func = d.func; out->cdf = d.cdf; out->func_int = d.func_int;
+    out->nvox[0] = d.nvox[0]; out->nvox[1] = d.nvox[1]; out->nvox[2] = d.nvox[2];
+    out->spatial = d.spatial;
+    return RSPT_OK;
+}
+
+template <bool ANY, int OUT_MODE>
+void launch_trace(bool count, uint32_t grid, const SceneDev& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
+                  const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
+    if (count)
+        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
+    else
+        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
+}
+
+uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PER_CU", 5)); }
+
+int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (!s || !d) return fail(RSPT_E_INVALID, "null scene or render desc");
+    if (d->sampler_kind != RSPT_SAMPLER_SOBOL) return fail(RSPT_E_UNSUPPORTED, "sampler kind %u (only sobol)", d->sampler_kind);
+    if (d->spp <= 0 || (d->spp & (d->spp - 1)) != 0 || d->spp > (1ll << 30)) return fail(RSPT_E_INVALID, "spp must be a power of two in [1, 2^30]");
+    if (d->tile_size == 0 || d->tile_size > 4096) return fail(RSPT_E_INVALID, "bad tile_size");
+    if (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv) return fail(RSPT_E_INVALID, "null sampler tables");
+    if (!(d->filter_radius[0] > 0.0f) || !(d->filter_radius[1] > 0.0f)) return fail(RSPT_E_INVALID, "bad filter radius");
+    if (d->max_depth > 200) return fail(RSPT_E_UNSUPPORTED, "max_depth > 200");
+    const int32_t* sb = d->sample_bounds;
+    const int32_t* cp = d->crop_px;
+    if (sb[2] <= sb[0] || sb[3] <= sb[1] || cp[2] <= cp[0] || cp[3] <= cp[1]) return fail(RSPT_E_INVALID, "empty sample or crop bounds");
+    if (sb[0] < -32768 || sb[1] < -32768 || sb[2] > 32767 || sb[3] > 32767) return fail(RSPT_E_UNSUPPORTED, "sample bounds outside the 16-bit pixel range");
+    const uint32_t shard_count = d->shard_count ? d->shard_count : 1, chunk = d->tile_chunk ? d->tile_chunk : 1;
+    if (d->shard_index >= shard_count) return fail(RSPT_E_INVALID, "shard_index >= shard_count");
+    // Sobol' needs 5 + 8 dims per bounce < 1024 (sobol.rs:119-124)
+    if (5ull + 8ull * (d->max_depth + 2ull) >= 1024ull) return fail(RSPT_E_UNSUPPORTED, "max_depth exceeds the 1024 Sobol' dimensions");
+
+    auto t_start = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(g.device));
+    int rc;
+    // ---- render constants ----
+    RenderDev rd{};
+    memcpy(rd.raster_to_camera, d->raster_to_camera, sizeof rd.raster_to_camera);
+    memcpy(rd.camera_to_world, d->camera_to_world, sizeof rd.camera_to_world);
+    rd.lens_radius = d->lens_radius; rd.focal_distance = d->focal_distance;
+    rd.shutter_open = d->shutter_open; rd.shutter_close = d->shutter_close;
+    memcpy(rd.sample_bounds, sb, sizeof rd.sample_bounds);
+    memcpy(rd.crop_px, cp, sizeof rd.crop_px);
+    rd.resolution = round_up_pow2_32(std::max(sb[2] - sb[0], sb[3] - sb[1]));  // sobol.rs:46-47
+    rd.log2_res = 31 - __builtin_clz((uint32_t)rd.resolution);
+    rd.spp = d->spp; rd.max_depth = d->max_depth; rd.rr_threshold = d->rr_threshold;
+    rd.filter_radius[0] = d->filter_radius[0]; rd.filter_radius[1] = d->filter_radius[1];
+    rd.max_sample_luminance = d->max_sample_luminance;
+    rd.tile_size = d->tile_size;
+    if (!g.sobol32) {
+        if ((rc = dev_alloc(&g.sobol32, 1024 * 52)) || (rc = dev_alloc(&g.vdc, 25 * 52)) || (rc = dev_alloc(&g.vdc_inv, 26 * 52)) || (rc = dev_alloc(&g.filter_table, 256))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(g.sobol32, d->tables.sobol32, 1024 * 52 * 4, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.vdc, d->tables.vdc, 25 * 52 * 8, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.vdc_inv, d->tables.vdc_inv, 26 * 52 * 8, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.filter_table, d->filter_table, 256 * 4, hipMemcpyHostToDevice, g.stream));
+    rd.sobol32 = g.sobol32; rd.vdc = g.vdc; rd.vdc_inv = g.vdc_inv; rd.filter_table = g.filter_table;
+
+    LightDistDev ld;
+    if ((rc = get_light_dist(s, d->light_strategy, &ld))) return rc;
+
+    // ---- this shard's pixels: Morton-ordered tiles (blockqueue/mod.rs:23-52), row-major inside a tile ----
+    const int32_t ts = (int32_t)d->tile_size;
+    const int32_t ext_x = sb[2] - sb[0], ext_y = sb[3] - sb[1];
+    const int32_t ntx = (ext_x + ts - 1) / ts, nty = (ext_y + ts - 1) / ts;
+    std::vector<std::pair<uint32_t, uint32_t>> blocks((size_t)ntx * nty);
+    for (int32_t i = 0; i < ntx * nty; i++) blocks[i] = {(uint32_t)(i % ntx), (uint32_t)(i / ntx)};
+    std::stable_sort(blocks.begin(), blocks.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return morton2(a.first, a.second) < morton2(b.first, b.second); });
+    std::vector<uint32_t> pix;
+    pix.reserve((size_t)ext_x * ext_y / shard_count + 1024);
+    for (size_t i = 0; i < blocks.size(); i++) {
+        if ((i / chunk) % shard_count != d->shard_index) continue;
+        int32_t x0 = sb[0] + (int32_t)blocks[i].first * ts, x1 = std::min(x0 + ts, sb[2]);
+        int32_t y0 = sb[1] + (int32_t)blocks[i].second * ts, y1 = std::min(y0 + ts, sb[3]);
+        for (int32_t y = y0; y < y1; y++)
+            for (int32_t x = x0; x < x1; x++) pix.push_back(((uint32_t)(uint16_t)(int16_t)y << 16) | (uint32_t)(uint16_t)(int16_t)x);
+    }
+    const size_t n_pix = pix.size();
+    if (g.pix_cap < n_pix) {
+        if (g.pix_list) (void)hipFree(g.pix_list);
+        g.pix_list = nullptr; g.pix_cap = 0;
+        if ((rc = dev_alloc(&g.pix_list, n_pix))) return rc;
+        g.pix_cap = n_pix;
+    }
+    if (n_pix) HIP_TRY(hipMemcpyAsync(g.pix_list, pix.data(), n_pix * 4, hipMemcpyHostToDevice, g.stream));
+
+    // ---- film ----
+    const size_t film_px = (size_t)(cp[2] - cp[0]) * (size_t)(cp[3] - cp[1]);
+    if (g.film_px < film_px) {
+        for (float4** p : {&g.film_own, &g.film_splat, &g.film_out}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        g.film_px = 0;
+        if ((rc = dev_alloc(&g.film_own, film_px)) || (rc = dev_alloc(&g.film_splat, film_px)) || (rc = dev_alloc(&g.film_out, film_px))) return rc;
+        g.film_px = film_px;
+    }
+    HIP_TRY(hipMemsetAsync(g.film_own, 0, film_px * sizeof(float4), g.stream));
+    HIP_TRY(hipMemsetAsync(g.film_splat, 0, film_px * sizeof(float4), g.stream));
+    float* li_dev = nullptr;
+    if (li_host) {
+        HIP_TRY(hipMalloc((void**)&li_dev, film_px * (size_t)d->spp * 3 * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(li_dev, 0, film_px * (size_t)d->spp * 3 * sizeof(float), g.stream));
+    }
+
+    // ---- batches ----
+    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 22);
+    cap = std::max<size_t>(cap, 1024);
+    const bool counters = env_size("RSPT_COUNTERS", 0) != 0;
+    uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
+    while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
+    const size_t pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
+    if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1)))) { if (li_dev) (void)hipFree(li_dev); return rc; }
+    const uint32_t nominal_iters = d->max_depth + 1;
+    const uint32_t max_iters = s->has_null_material ? nominal_iters + 64 : nominal_iters;
+    if ((rc = ensure_counts(max_iters + 2))) { if (li_dev) (void)hipFree(li_dev); return rc; }
+    if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
+    HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
+
+    const uint32_t tgrid = trace_grid();
+    const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", 4));
+    size_t n_ev = 0;
+    uint64_t trace_launches = 0;
+    hipEvent_t ev_k0 = get_event(n_ev++), ev_k1 = get_event(n_ev++);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
+    HIP_TRY(hipEventRecord(ev_k0, g.stream));
+    uint64_t samples = 0;
+    for (size_t p0 = 0; p0 < n_pix; p0 += pix_per_batch) {
+        const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
+        for (uint32_t s0 = 0; s0 < (uint32_t)d->spp; s0 += ns) {
+            Batch bt{(uint32_t)p0, npx, s0, ns, npx * ns};
+            samples += bt.n;
+            HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));
+            hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
+            uint32_t it = 0;
+            for (;;) {
+                const int par = it & 1;
+                hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);
+                HIP_TRY(hipEventRecord(e0, g.stream));
+                launch_trace<false, 0>(counters, tgrid, s->dev, g.q[par][1], &g.cnt[it].closest, 0, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                if (it > 0) launch_trace<true, 0>(counters, tgrid, s->dev, g.q[par][2], &g.cnt[it].any, 0, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                HIP_TRY(hipEventRecord(e1, g.stream));
+                trace_ev.push_back({e0, e1});
+                trace_launches += it > 0 ? 2 : 1;
+                hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), 0, g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0], g.q[par ^ 1][1], g.q[par ^ 1][2],
+                                   counters ? g.totals + 2 : nullptr);
+                it++;
+                if (it < nominal_iters) continue;
+                // after max_depth + 1 bounces only pending estimates and null-material passes remain
+                bool more = true;
+                if (it >= max_iters) more = false;
+                else {
+                    QueueCounts c;
+                    HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
+                    HIP_TRY(hipStreamSynchronize(g.stream));
+                    more = c.active != 0;
+                }
+                if (!more) break;
+            }
+            if (counters) hipLaunchKernelGGL(k_accum_counts, dim3(1), dim3(1), 0, g.stream, g.cnt, it, g.totals);
+            hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
+        }
+    }
+    float4* out_dev = film_dev ? (float4*)film_dev : g.film_out;
+    hipLaunchKernelGGL(k_film_resolve, dim3((uint32_t)((film_px + 255) / 256)), dim3(256), 0, g.stream, g.film_own, g.film_splat, out_dev, (uint32_t)film_px);
+    HIP_TRY(hipEventRecord(ev_k1, g.stream));
+    HIP_TRY(hipGetLastError());
+    if (film_host) HIP_TRY(hipMemcpyAsync(film_host, out_dev, film_px * sizeof(float4), hipMemcpyDeviceToHost, g.stream));
+    if (li_host) HIP_TRY(hipMemcpyAsync(li_host, li_dev, film_px * (size_t)d->spp * 3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    hipError_t se = hipStreamSynchronize(g.stream);
+    if (li_dev) (void)hipFree(li_dev);
+    if (se != hipSuccess) return fail(RSPT_E_HIP, "render failed: %s", hipGetErrorString(se));
+    auto t_end = std::chrono::steady_clock::now();
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->t_render_s = std::chrono::duration<double>(t_end - t_start).count();
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_k0, ev_k1));
+        stats->t_kernels_s = ms * 1e-3;
+        double tr = 0;
+        for (auto& e : trace_ev) {
+            float m = 0;
+            if (hipEventElapsedTime(&m, e.first, e.second) == hipSuccess) tr += m;
+        }
+        stats->t_trace_s = tr * 1e-3;
+        stats->samples = samples;
+        stats->trace_launches = trace_launches;
+        unsigned long long tot[8];
+        HIP_TRY(hipMemcpy(tot, g.totals, sizeof tot, hipMemcpyDeviceToHost));
+        stats->nan_samples = tot[5];
+        if (counters) {
+            stats->nodes_visited = tot[0]; stats->tris_tested = tot[1];
+            stats->rays_closest = tot[3]; stats->rays_any = tot[4];
+            // B_alg = sum(32 N_node + 48 N_tri) + 96 R_closest + 72 R_any + 96 N_bounce + 32 per sample
+            stats->alg_bytes = 32.0 * (double)tot[0] + 48.0 * (double)tot[1] + 96.0 * (double)tot[3] + 72.0 * (double)tot[4] + 96.0 * (double)tot[2] + 32.0 * (double)samples;
+        }
+    }
+    return RSPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rspt_abi_version(void) { return RSPT_ABI_VERSION; }
+const char* rspt_last_error(void) { return g_err.c_str(); }
+
+int rspt_init(int32_t device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RSPT_E_NODEVICE, "no HIP device: %s", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(RSPT_E_INVALID, "device %d out of range (have %d)", device, n);
+    if (g.inited && g.device == device) return RSPT_OK;
+    if (g.inited) rspt_shutdown();
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("RSPT_ALLOW_ANY_ARCH"))
+        return fail(RSPT_E_NODEVICE, "device %d is %s; librspt is built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.device = device;
+    g.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g.inited = true;
+    return RSPT_OK;
+}
+
+void rspt_shutdown(void) {
+    if (!g.inited) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    free_paths();
+    void* ptrs[] = {g.cnt, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(g.stream);
+    g = Ctx{};
+}
+
+int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (!d || !out) return fail(RSPT_E_INVALID, "null argument");
+    *out = nullptr;
+    if (d->n_prims > 0x7fffffffull || d->n_nodes > 0x7fffffffull) return fail(RSPT_E_UNSUPPORTED, "more than 2^31 primitives / nodes");
+    if ((d->n_nodes && !d->nodes) || (d->n_prims && (!d->prims || !d->meshes || !d->P)) || (d->n_materials && !d->materials) ||
+        (d->n_bxdfs && !d->bxdfs) || (d->n_lights && !d->lights))
+        return fail(RSPT_E_INVALID, "null array with non-zero count");
+    if ((d->n_nodes == 0) != (d->n_prims == 0)) return fail(RSPT_E_INVALID, "nodes and prims must both be empty or both non-empty");
+    // ---- validate indices on the host (a bad scene must not fault the GPU) ----
+    bool has_null = false;
+    for (uint64_t i = 0; i < d->n_prims; i++) {
+        const rspt_prim& p = d->prims[i];
+        if (p.v[0] >= d->n_vertices || p.v[1] >= d->n_vertices || p.v[2] >= d->n_vertices) return fail(RSPT_E_INVALID, "prim %llu: vertex index out of range", (unsigned long long)i);
+        if (p.mesh >= d->n_meshes) return fail(RSPT_E_INVALID, "prim %llu: mesh index out of range", (unsigned long long)i);
+        if (p.material != 0xffffffffu && p.material >= d->n_materials) return fail(RSPT_E_INVALID, "prim %llu: material index out of range", (unsigned long long)i);
+        if (p.area_light >= (int64_t)d->n_lights) return fail(RSPT_E_INVALID, "prim %llu: light index out of range", (unsigned long long)i);
+        has_null |= p.material == 0xffffffffu;
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rspt_material& m = d->materials[i];
+        if (m.n_bxdfs > 8 || (uint64_t)m.first_bxdf + m.n_bxdfs > d->n_bxdfs) return fail(RSPT_E_INVALID, "material %u: bad bxdf slice", i);
+    }
+    for (uint32_t i = 0; i < d->n_bxdfs; i++)
+        if (d->bxdfs[i].type < RSPT_BXDF_LAMBERT_R || d->bxdfs[i].type > RSPT_BXDF_LAMBERT_T) return fail(RSPT_E_UNSUPPORTED, "bxdf %u: unsupported type %u", i, d->bxdfs[i].type);
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        if (d->lights[i].kind != RSPT_LIGHT_DIFFUSE_AREA) return fail(RSPT_E_UNSUPPORTED, "light %u: unsupported kind %u", i, d->lights[i].kind);
+        if (d->lights[i].prim >= d->n_prims) return fail(RSPT_E_INVALID, "light %u: prim out of range", i);
+    }
+    // BVH: child / leaf ranges in bounds, depth <= 64 (the reference's fixed traversal stack, bvh.rs:420)
+    if (d->n_nodes) {
+        std::vector<std::pair<uint32_t, uint32_t>> stack;  // node, depth
+        stack.push_back({0u, 1u});
+        uint64_t visited = 0;
+        while (!stack.empty()) {
+            auto [ni, depth] = stack.back();
+            stack.pop_back();
+            if (++visited > d->n_nodes) return fail(RSPT_E_INVALID, "BVH is not a tree");
+            if (depth > 64) return fail(RSPT_E_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
+            const rspt_bvh_node& n = d->nodes[ni];
+            if (n.n_prims > 0) {
+                if (n.offset < 0 || (uint64_t)n.offset + n.n_prims > d->n_prims) return fail(RSPT_E_INVALID, "node %u: leaf range out of bounds", ni);
+            } else {
+                if (n.axis > 2 || n.offset <= (int64_t)ni || (uint64_t)n.offset >= d->n_nodes || (uint64_t)ni + 1 >= d->n_nodes) return fail(RSPT_E_INVALID, "node %u: bad children", ni);
+                stack.push_back({(uint32_t)n.offset, depth + 1});
+                stack.push_back({ni + 1, depth + 1});
+            }
+        }
+    }
+    HIP_TRY(hipSetDevice(g.device));
+    rspt_scene_s* s = new rspt_scene_s();
+    s->has_null_material = has_null;
+    auto bail = [&](int rc) {
+        for (void* p : s->allocs) (void)hipFree(p);
+        delete s;
+        return rc;
+    };
+    int rc;
+    const rspt_bvh_node* nodes_d = nullptr;
+    const rspt_mesh* meshes_d = nullptr;
+    const float* P_d = nullptr;
+    if ((rc = upload(s, d->nodes, d->n_nodes, &nodes_d))) return bail(rc);
+    if ((rc = upload(s, d->prims, d->n_prims, &s->dev.prims))) return bail(rc);
+    if ((rc = upload(s, d->meshes, d->n_meshes, &meshes_d))) return bail(rc);
+    if ((rc = upload(s, d->P, d->n_vertices * 3, &P_d))) return bail(rc);
+    if ((rc = upload(s, d->N, d->N ? d->n_vertices * 3 : 0, &s->dev.N))) return bail(rc);
+    if ((rc = upload(s, d->S, d->S ? d->n_vertices * 3 : 0, &s->dev.S))) return bail(rc);
+    if ((rc = upload(s, d->UV, d->UV ? d->n_vertices * 2 : 0, &s->dev.UV))) return bail(rc);
+    if ((rc = upload(s, d->materials, d->n_materials, &s->dev.materials))) return bail(rc);
+    if ((rc = upload(s, d->bxdfs, d->n_bxdfs, &s->dev.bxdfs))) return bail(rc);
+    if ((rc = upload(s, d->lights, d->n_lights, &s->dev.lights))) return bail(rc);
+    s->dev.nodes = reinterpret_cast<const float4*>(nodes_d);
+    s->dev.n_nodes = (uint32_t)d->n_nodes; s->dev.n_prims = (uint32_t)d->n_prims; s->dev.n_lights = d->n_lights;
+    if (d->n_nodes) {
+        for (int i = 0; i < 3; i++) { s->dev.wb_min[i] = d->nodes[0].bmin[i]; s->dev.wb_max[i] = d->nodes[0].bmax[i]; }
+    } else {
+        for (int i = 0; i < 3; i++) { s->dev.wb_min[i] = RSPT_FLT_MAX; s->dev.wb_max[i] = -RSPT_FLT_MAX; }  // Bounds3f::default
+    }
+    if (d->n_prims) {
+        float4* tris = nullptr;
+        hipError_t e = hipMalloc((void**)&tris, d->n_prims * 3 * sizeof(float4));
+        if (e != hipSuccess) return bail(fail(RSPT_E_NOMEM, "triangle records: %s", hipGetErrorString(e)));
+        s->allocs.push_back(tris);
+        hipLaunchKernelGGL(k_build_tris, dim3((uint32_t)((d->n_prims + 255) / 256)), dim3(256), 0, g.stream, s->dev.prims, meshes_d, P_d, (uint32_t)d->n_prims, tris);
+        e = hipStreamSynchronize(g.stream);
+        if (e != hipSuccess) return bail(fail(RSPT_E_HIP, "k_build_tris: %s", hipGetErrorString(e)));
+        s->dev.tris = tris;
+    }
+    *out = s;
+    return RSPT_OK;
+}
+
+int rspt_scene_destroy(rspt_scene_t s) {
+    if (!s) return RSPT_OK;
+    if (g.inited) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(g.stream); }
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+    return RSPT_OK;
+}
+
+int rspt_render(rspt_scene_t s, const rspt_render_desc* d, float* film_xyzw, rspt_stats* stats) {
+    if (!film_xyzw) return fail(RSPT_E_INVALID, "null film");
+    return render_impl(s, d, film_xyzw, nullptr, nullptr, stats);
+}
+int rspt_render_device(rspt_scene_t s, const rspt_render_desc* d, void* film_dev, rspt_stats* stats) {
+    if (!film_dev) return fail(RSPT_E_INVALID, "null film");
+    return render_impl(s, d, nullptr, film_dev, nullptr, stats);
+}
+int rspt_render_samples(rspt_scene_t s, const rspt_render_desc* d, float* li_rgb, rspt_stats* stats) {
+    if (!li_rgb) return fail(RSPT_E_INVALID, "null li_rgb");
+    return render_impl(s, d, nullptr, nullptr, li_rgb, stats);
+}
+
+int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* out_dev, int any_hit, int repeat, double* ms_per_launch) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (!s || (n && (!rays_dev || !out_dev))) return fail(RSPT_E_INVALID, "null argument");
+    if (n > 0xfffffff0ull) return fail(RSPT_E_UNSUPPORTED, "more than 2^32 rays per call");
+    if (repeat < 1) repeat = 1;
+    HIP_TRY(hipSetDevice(g.device));
+    if (!g.totals) { int rc = dev_alloc(&g.totals, 8); if (rc) return rc; }
+    const bool counters = env_size("RSPT_COUNTERS", 0) != 0;
+    if (counters) HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
+    hipEvent_t e0 = get_event(0), e1 = get_event(1);
+    HIP_TRY(hipEventRecord(e0, g.stream));
+    for (int r = 0; r < repeat && n; r++) {
+        if (any_hit) launch_trace<true, 1>(counters, trace_grid(), s->dev, nullptr, nullptr, (uint32_t)n, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
+        else launch_trace<false, 1>(counters, trace_grid(), s->dev, nullptr, nullptr, (uint32_t)n, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
+    }
+    HIP_TRY(hipEventRecord(e1, g.stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_per_launch) *ms_per_launch = (double)ms / repeat;
+    return RSPT_OK;
+}
+
+int rspt_trace(rspt_scene_t s, const rspt_ray* rays, uint64_t n, rspt_hit* out, int any_hit) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (!s || (n && (!rays || !out))) return fail(RSPT_E_INVALID, "null argument");
+    if (n == 0) return RSPT_OK;
+    HIP_TRY(hipSetDevice(g.device));
+    rspt_ray* rd = nullptr;
+    rspt_hit* hd = nullptr;
+    HIP_TRY(hipMalloc((void**)&rd, n * sizeof(rspt_ray)));
+    hipError_t e = hipMalloc((void**)&hd, n * sizeof(rspt_hit));
+    if (e != hipSuccess) { (void)hipFree(rd); return fail(RSPT_E_NOMEM, "%s", hipGetErrorString(e)); }
+    int rc = RSPT_OK;
+    if (hipMemcpy(rd, rays, n * sizeof(rspt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RSPT_E_HIP, "upload of rays failed");
+    if (!rc) rc = rspt_trace_device(s, rd, n, hd, any_hit, 1, nullptr);
+    if (!rc && hipMemcpy(out, hd, n * sizeof(rspt_hit), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RSPT_E_HIP, "download of hits failed");
+    (void)hipFree(rd);
+    (void)hipFree(hd);
+    return rc;
+}
+
+// counters of the last rspt_trace_device / rspt_render when RSPT_COUNTERS=1: out[0] nodes visited, out[1] triangles tested
+int rspt_last_counters(uint64_t out[2]) {
+    if (!g.inited || !g.totals) return fail(RSPT_E_INVALID, "no counters");
+    unsigned long long t[2];
+    HIP_TRY(hipMemcpy(t, g.totals, sizeof t, hipMemcpyDeviceToHost));
+    out[0] = t[0]; out[1] = t[1];
+    return RSPT_OK;
+}
+
+int rspt_dev_alloc(uint64_t bytes, void** out) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (!out) return fail(RSPT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return RSPT_OK;
+}
+int rspt_dev_free(void* p) {
+    if (p) HIP_TRY(hipFree(p));
+    return RSPT_OK;
+}
+int rspt_dev_upload(void* dst, const void* src, uint64_t bytes) {
+    if (bytes && (!dst || !src)) return fail(RSPT_E_INVALID, "null argument");
+    if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return RSPT_OK;
+}
+int rspt_dev_download(void* dst, const void* src, uint64_t bytes) {
+    if (bytes && (!dst || !src)) return fail(RSPT_E_INVALID, "null argument");
+    if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return RSPT_OK;
+}
+
+}  // extern "C"

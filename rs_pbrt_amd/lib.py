@@ -1,0 +1,185 @@
+"""ctypes binding of librspt.so (include/rspt.h) — the only way the Python host mirror reaches
+the GPU.  There is no fallback: if the shared library is missing, or there is no gfx950 device,
+the calls raise RsptError.  Nothing under oracle/ is imported here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librspt.so")
+_LIB = None
+
+EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
+           "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
+           "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error")
+
+
+class RsptError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("librspt error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load librspt.so (built by __graft_entry__.build() / make -C rs_pbrt_amd/csrc)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsptError(abi.E_NODEVICE, "%s is missing: build it with `make -C rs_pbrt_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
+        L.rspt_abi_version.restype = C.c_int
+        L.rspt_last_error.restype = C.c_char_p
+        L.rspt_bvh_last_error.restype = C.c_char_p
+        L.rspt_init.argtypes = [i32]
+        L.rspt_shutdown.restype = None
+        L.rspt_scene_create.argtypes = [vp, vp]
+        L.rspt_scene_destroy.argtypes = [vp]
+        L.rspt_render.argtypes = [vp, vp, vp, vp]
+        L.rspt_render_device.argtypes = [vp, vp, vp, vp]
+        L.rspt_render_samples.argtypes = [vp, vp, vp, vp]
+        L.rspt_trace.argtypes = [vp, vp, u64, vp, C.c_int]
+        L.rspt_trace_device.argtypes = [vp, vp, u64, vp, C.c_int, C.c_int, vp]
+        L.rspt_dev_alloc.argtypes = [u64, vp]
+        L.rspt_dev_free.argtypes = [vp]
+        L.rspt_dev_upload.argtypes = [vp, vp, u64]
+        L.rspt_dev_download.argtypes = [vp, vp, u64]
+        L.rspt_last_counters.argtypes = [vp]
+        L.rspt_bvh_build.restype = C.c_int64
+        L.rspt_bvh_build.argtypes = [vp, vp, u64, u32, vp, u64, vp, i32]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise RsptError(rc, (lib().rspt_last_error() or b"").decode("utf-8", "replace"))
+
+
+def bvh_build(P, tri, max_prims_in_node=4, threads=0):
+    """BVHAccel::new (bvh.rs:96-392) on the host; returns (nodes NODE_DT[], ordered u32[])."""
+    P = np.ascontiguousarray(P, np.float32)
+    tri = np.ascontiguousarray(tri, np.uint32)
+    n = len(tri)
+    nodes = np.zeros(max(2 * n, 1), abi.NODE_DT)
+    ordered = np.zeros(n, np.uint32)
+    k = lib().rspt_bvh_build(P.ctypes.data, tri.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data, threads)
+    if k < 0:
+        raise RsptError(int(k), (lib().rspt_bvh_last_error() or b"").decode())
+    return nodes[:k].copy(), ordered
+
+
+_inited_device = None
+
+
+def init(device=0):
+    global _inited_device
+    _check(lib().rspt_init(device))
+    _inited_device = device
+
+
+def shutdown():
+    global _inited_device
+    lib().rspt_shutdown()
+    _inited_device = None
+
+
+class DeviceScene:
+    """Owner of an rspt_scene_t (the flattened Scene + BVHAccel resident in HBM)."""
+
+    def __init__(self, scene):
+        self.host = scene  # keeps the numpy arrays alive for the duration of the upload
+        h = C.c_void_p()
+        _check(lib().rspt_scene_create(C.addressof(scene.desc), C.addressof(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().rspt_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def stats_dict(st):
+    return {k: getattr(st, k) for k, _ in abi.Stats._fields_}
+
+
+def render(dscene, rd):
+    """rspt_render: returns (film (npix, 4) f32 xyz+weight, stats dict)."""
+    npix = (rd.crop_px[2] - rd.crop_px[0]) * (rd.crop_px[3] - rd.crop_px[1])
+    film = np.zeros((npix, 4), np.float32)
+    st = abi.Stats()
+    _check(lib().rspt_render(dscene.handle, C.addressof(rd), film.ctypes.data, C.addressof(st)))
+    return film, stats_dict(st)
+
+
+def render_device(dscene, rd, film_dev_ptr):
+    """rspt_render_device: film stays in HBM at film_dev_ptr (npix*4 f32)."""
+    st = abi.Stats()
+    _check(lib().rspt_render_device(dscene.handle, C.addressof(rd), C.c_void_p(film_dev_ptr), C.addressof(st)))
+    return stats_dict(st)
+
+
+def render_samples(dscene, rd):
+    """rspt_render_samples: radiance of every camera sample, (npix, spp, 3)."""
+    npix = (rd.crop_px[2] - rd.crop_px[0]) * (rd.crop_px[3] - rd.crop_px[1])
+    li = np.zeros((npix, int(rd.spp), 3), np.float32)
+    st = abi.Stats()
+    _check(lib().rspt_render_samples(dscene.handle, C.addressof(rd), li.ctypes.data, C.addressof(st)))
+    return li, stats_dict(st)
+
+
+def trace(dscene, rays, any_hit=False):
+    """rspt_trace: Scene::intersect / intersect_p over a batch of rays (RAY_DT) -> HIT_DT[]."""
+    rays = np.ascontiguousarray(rays, abi.RAY_DT)
+    out = np.zeros(len(rays), abi.HIT_DT)
+    _check(lib().rspt_trace(dscene.handle, rays.ctypes.data, len(rays), out.ctypes.data, int(any_hit)))
+    return out
+
+
+class DeviceBuffer:
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(lib().rspt_dev_alloc(nbytes, C.addressof(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().rspt_dev_upload(C.c_void_p(self.ptr), arr.ctypes.data, arr.nbytes))
+
+    def download(self, dtype, count):
+        out = np.zeros(count, dtype)
+        _check(lib().rspt_dev_download(out.ctypes.data, C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().rspt_dev_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+def trace_device(dscene, rays_buf, n, hits_buf, any_hit=False, repeat=1):
+    """rspt_trace_device: returns average kernel milliseconds per launch."""
+    ms = C.c_double(0)
+    _check(lib().rspt_trace_device(dscene.handle, C.c_void_p(rays_buf.ptr), n, C.c_void_p(hits_buf.ptr), int(any_hit), repeat, C.addressof(ms)))
+    return ms.value
+
+
+def last_counters():
+    c = (C.c_uint64 * 2)()
+    _check(lib().rspt_last_counters(C.addressof(c)))
+    return int(c[0]), int(c[1])
