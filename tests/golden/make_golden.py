@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the CPU oracle (the reference itself is Rust and
+cannot be built in this image; the oracle is its line-by-line restatement).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import pyoracle  # noqa: E402
+from rs_pbrt_amd import abi, scenes  # noqa: E402
+
+
+def main():
+    # 1. Cornell film + per-sample radiance
+    sc = scenes.cornell_box(pyoracle.bvh_build)
+    rd = scenes.cornell_render_desc(res=32, spp=8)
+    r = pyoracle.render(sc, rd, threads=1, want_li=True)
+    np.savez_compressed(os.path.join(HERE, "cornell_matte_32x32x8.npz"), film=r["film"], li=r["li"],
+                        counters=np.array([r["counters"][k] for k in pyoracle.COUNTER_NAMES], np.uint64))
+    # 2. traversal: 4096 rays against the Cornell BVH and a 2000-triangle soup
+    rng = np.random.default_rng(11)
+    for name, scene, lo, hi in (("cornell", sc, 20, 530), ("soup2k", scenes.triangle_soup(pyoracle.bvh_build, n_tris=2000, extent=0.08), -1.3, 1.3)):
+        rays = np.zeros(4096, abi.RAY_DT)
+        rays["o"] = rng.uniform(lo, hi, (4096, 3)).astype(np.float32)
+        d = rng.normal(size=(4096, 3))
+        rays["d"] = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32)
+        rays["t_max"] = np.inf
+        np.savez_compressed(os.path.join(HERE, "trace_%s.npz" % name), rays=rays, closest=pyoracle.trace(scene, rays),
+                            any=pyoracle.trace(scene, rays, any_hit=True), nodes=scene.nodes, prims=scene.prims)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+"""-m gpu: the whole path (raygen -> trace -> shade -> film) through rspt_render* against the
+oracle's restatement of SamplerIntegrator::render + PathIntegrator::li.
+
+Tolerances: the path contains sin/cos (concentric disk mapping, Trowbridge-Reitz sampling) whose
+last-ulp rounding differs between glibc (oracle, = what Rust's f32::sin calls) and the device
+library, so per-sample radiance is bit-identical for most but not all samples.  Bars:
+  * filter-weight sums: exact;
+  * per-sample radiance: >= 75 % of samples bit-identical, mean |diff| < 1e-6;
+  * film RMSE (linear RGB): < 1e-5 here; the north-star bound is 1e-3."""
+import os
+
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import abi, scenes
+from tests.util import film_rmse, small_soup
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _render_pair(gpu, oracle, sc, rd, want_li=True):
+    ds = gpu.DeviceScene(sc)
+    try:
+        film, st = gpu.render(ds, rd)
+        li = gpu.render_samples(ds, rd)[0] if want_li else None
+    finally:
+        ds.close()
+    ref = oracle.render(sc, rd, threads=8, want_li=want_li)
+    return film, li, st, ref
+
+
+@pytest.mark.parametrize("variant", ["matte", "mixed", "rough"])
+def test_cornell_matches_oracle(gpu, oracle, variant):
+    sc = scenes.cornell_box(gpu.bvh_build, variant=variant)
+    rd = scenes.cornell_render_desc(res=64, spp=16)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    same = (li == ref["li"]).all(axis=2)
+    assert same.mean() > 0.75
+    assert np.abs(li - ref["li"]).mean() < 1e-6
+    assert film_rmse(film, ref["film"]) < 1e-5
+    assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
+    assert st["samples"] == ref["counters"]["samples"] == 64 * 64 * 16
+
+
+def test_soup_matches_oracle_depth8(gpu, oracle):
+    sc = small_soup(gpu.bvh_build)
+    rd = scenes.soup_render_desc(res=96, spp=8, max_depth=8)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert (li == ref["li"]).all(axis=2).mean() > 0.9
+    assert film_rmse(film, ref["film"]) < 1e-5
+
+
+@pytest.mark.parametrize("strategy", [abi.LIGHTS_UNIFORM, abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL])
+def test_light_strategies(gpu, oracle, strategy):
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=48, spp=8, light_strategy=strategy)
+    film, _, _, ref = _render_pair(gpu, oracle, sc, rd, want_li=False)
+    assert film_rmse(film, ref["film"]) < 1e-5
+
+
+def test_smooth_normals_plastic(gpu, oracle):
+    """interpolated shading normals (has_n) + plastic (Lambert + microfacet), three area lights"""
+    sc = scenes.statue_standin(gpu.bvh_build, grid=96)
+    rd = scenes.statue_render_desc(xres=96, yres=54, spp=8)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 1e-5
+    assert (li == ref["li"]).all(axis=2).mean() > 0.75
+
+
+def test_thin_lens_and_gaussian_filter(gpu, oracle):
+    """depth of field (lens samples, concentric disk) and a radius-2 filter: every sample splats into
+    up to 16 pixels through the atomic path, so the film tolerance is f32 re-association only."""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=48, spp=8, lens_radius=8.0, focal_distance=1000.0, filter_radius=(2.0, 2.0),
+                                    filter_table=scenes.gaussian_filter_table((2.0, 2.0)))
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.allclose(film[:, 3], ref["film"][:, 3], rtol=1e-5)
+    assert film_rmse(film, ref["film"]) < 1e-5
+    assert (li == ref["li"]).all(axis=2).mean() > 0.7
+
+
+def test_crop_window_and_non_square(gpu, oracle):
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.make_render_desc(100, 60, 4, scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV, crop=(0.25, 0.8, 0.1, 0.9))
+    film, _, st, ref = _render_pair(gpu, oracle, sc, rd, want_li=False)
+    assert film.shape == ref["film"].shape
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 1e-5
+
+
+def test_null_material_and_no_lights(gpu, oracle):
+    """a primitive without material is passed through (path.rs:109-116); a scene without lights is black"""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    sc.prims["material"][sc.prims["material"] == 1] = abi.NO_MATERIAL  # red wall becomes a null boundary
+    rd = scenes.cornell_render_desc(res=48, spp=4)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert film_rmse(film, ref["film"]) < 1e-5
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_quad([(0, 0, 0), (0, 0, 559), (549, 0, 559), (549, 0, 0)], m)
+    dark = sb.finish(gpu.bvh_build)
+    film, _, _, ref = _render_pair(gpu, oracle, dark, rd, want_li=False)
+    assert np.array_equal(film, ref["film"]) and not film[:, :3].any()
+
+
+def test_tile_shards_sum_to_full_frame(gpu):
+    """multi-GPU decomposition on one device: the films of the Morton-tile shards add up to the
+    unsharded film (exactly: with the box filter every pixel's own samples come from one shard)."""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    ds = gpu.DeviceScene(sc)
+    try:
+        full, _ = gpu.render(ds, scenes.cornell_render_desc(res=80, spp=4))
+        acc = np.zeros_like(full)
+        n = 0
+        for r in range(3):
+            f, st = gpu.render(ds, scenes.cornell_render_desc(res=80, spp=4, shard=(r, 3, 2)))
+            acc += f
+            n += st["samples"]
+    finally:
+        ds.close()
+    assert n == 80 * 80 * 4
+    assert np.allclose(acc, full, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(acc[:, 3], full[:, 3])
+
+
+def test_batching_is_invisible(gpu, monkeypatch):
+    """the film must not depend on how samples are cut into wavefront batches"""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=64, spp=16)
+    ds = gpu.DeviceScene(sc)
+    try:
+        a, _ = gpu.render(ds, rd)
+        monkeypatch.setenv("RSPT_BATCH", "5000")
+        b, _ = gpu.render(ds, rd)
+        monkeypatch.setenv("RSPT_BATCH", "70000")
+        c, _ = gpu.render(ds, rd)
+    finally:
+        ds.close()
+    assert np.array_equal(a[:, 3], b[:, 3])
+    assert np.allclose(a, b, rtol=1e-6, atol=1e-7) and np.allclose(a, c, rtol=1e-6, atol=1e-7)
+
+
+def test_counters_match_oracle(gpu, oracle, monkeypatch):
+    """node / triangle / ray counts that feed the roofline's algorithmic bytes agree with the oracle's
+    (not bit-equal: a last-ulp sin/cos difference can change an individual path)"""
+    monkeypatch.setenv("RSPT_COUNTERS", "1")
+    sc = small_soup(gpu.bvh_build)
+    rd = scenes.soup_render_desc(res=64, spp=8)
+    film, _, st, ref = _render_pair(gpu, oracle, sc, rd, want_li=False)
+    c = ref["counters"]
+    for k_gpu, k_ref in (("nodes_visited", "nodes_visited"), ("tris_tested", "tris_tested"), ("rays_closest", "rays_closest"), ("rays_any", "rays_any")):
+        assert abs(st[k_gpu] - c[k_ref]) <= 1e-3 * c[k_ref] + 8, (k_gpu, st[k_gpu], c[k_ref])
+    assert st["alg_bytes"] > 0
+
+
+def test_golden_cornell_film(gpu):
+    """committed oracle output (tests/golden/make_golden.py) — no oracle build needed on the box"""
+    g = np.load(os.path.join(GOLDEN, "cornell_matte_32x32x8.npz"))
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=32, spp=8)
+    ds = gpu.DeviceScene(sc)
+    try:
+        film, _ = gpu.render(ds, rd)
+        li, _ = gpu.render_samples(ds, rd)
+    finally:
+        ds.close()
+    assert np.array_equal(film[:, 3], g["film"][:, 3])
+    assert film_rmse(film, g["film"]) < 1e-5
+    assert (li == g["li"]).all(axis=2).mean() > 0.75

@@ -1,0 +1,124 @@
+"""-m gpu: the traversal stage (k_trace) through rspt_trace against the oracle's restatement of
+BVHAccel::intersect / intersect_p + Triangle::intersect.  No transcendentals on this stage, so the
+bar is bit-exact (prim, t, b0, b1, b2)."""
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import abi, scenes
+from tests.util import random_rays, small_soup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cornell(gpu):
+    sc = scenes.cornell_box(gpu.bvh_build)
+    ds = gpu.DeviceScene(sc)
+    yield sc, ds
+    ds.close()
+
+
+@pytest.fixture(scope="module")
+def soup(gpu):
+    sc = small_soup(gpu.bvh_build)
+    ds = gpu.DeviceScene(sc)
+    yield sc, ds
+    ds.close()
+
+
+def test_closest_hit_bit_exact_cornell(gpu, oracle, cornell):
+    sc, ds = cornell
+    rays = random_rays(100000, 1, 20, 530)
+    got, ref = gpu.trace(ds, rays), oracle.trace(sc, rays)
+    assert (ref["prim"] != abi.MISS).sum() > 50000
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_any_hit_bit_exact_cornell(gpu, oracle, cornell):
+    sc, ds = cornell
+    rays = random_rays(100000, 2, 20, 530, t_max=300.0)
+    got, ref = gpu.trace(ds, rays, any_hit=True), oracle.trace(sc, rays, any_hit=True)
+    assert 1000 < (ref["prim"] == 0).sum() < 99000
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_closest_and_any_bit_exact_soup(gpu, oracle, soup):
+    sc, ds = soup
+    rays = random_rays(200000, 3, -1.3, 1.3)
+    for any_hit in (False, True):
+        got, ref = gpu.trace(ds, rays, any_hit=any_hit), oracle.trace(sc, rays, any_hit=any_hit)
+        assert got.tobytes() == ref.tobytes()
+
+
+def test_matches_brute_force(gpu, oracle, soup):
+    """BVH result == O(N) scan over all triangles in list order (structural invariant)."""
+    sc, ds = soup
+    rays = random_rays(2000, 4, -1.3, 1.3)
+    got, ref = gpu.trace(ds, rays), oracle.trace(sc, rays, brute=True)
+    hit = ref["prim"] != abi.MISS
+    assert np.array_equal(got["prim"] != abi.MISS, hit)
+    assert np.array_equal(got["t"][hit], ref["t"][hit])
+
+
+def test_axis_aligned_and_degenerate_rays(gpu, oracle, cornell):
+    """zero direction components give infinite reciprocals; rays starting on surfaces; tiny t_max"""
+    sc, ds = cornell
+    rays = random_rays(6000, 5, 20, 530)
+    rays["d"][:2000] = np.eye(3, dtype=np.float32)[np.arange(2000) % 3] * np.where(np.arange(2000) % 2, 1, -1)[:, None]
+    rays["o"][2000:3000, 1] = 0.0            # on the floor plane
+    rays["o"][3000:4000, 0] = 0.0            # on the green wall plane
+    rays["t_max"][4000:5000] = 1e-3
+    rays["d"][5000:, 2] = 0.0                # in-plane directions
+    n = np.linalg.norm(rays["d"][5000:], axis=1)[:, None]
+    rays["d"][5000:] /= n
+    for any_hit in (False, True):
+        assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
+
+
+def test_shared_edges_watertight(gpu, oracle, cornell):
+    """rays aimed exactly at triangle edge midpoints and vertices (shared diagonals, shared quad edges,
+    open boundary edges of the box): identical decisions, and the interior ones never leak through"""
+    sc, ds = cornell
+    P = sc.P[sc.prims["v"].reshape(-1)].reshape(-1, 3, 3)
+    mids = np.concatenate([(P[:, 0] + P[:, 1]) / 2, (P[:, 1] + P[:, 2]) / 2, (P[:, 0] + P[:, 2]) / 2, P[:, 0]]).astype(np.float32)
+    o = np.array([278, 273, -800], np.float32)
+    rays = np.zeros(len(mids), abi.RAY_DT)
+    rays["o"] = o
+    d = mids - o
+    rays["d"] = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32)
+    rays["t_max"] = np.inf
+    got, ref = gpu.trace(ds, rays), oracle.trace(sc, rays)
+    assert got.tobytes() == ref.tobytes()
+    assert (got["prim"] != abi.MISS).mean() > 0.9  # only open boundary edges of the box may miss
+
+
+def test_empty_inputs_and_errors(gpu, cornell):
+    sc, ds = cornell
+    assert len(gpu.trace(ds, np.zeros(0, abi.RAY_DT))) == 0
+    import ctypes as C
+    L = gpu.lib()
+    assert L.rspt_trace(None, None, 10, None, 0) == abi.E_INVALID
+    assert b"null" in L.rspt_last_error()
+    bad = scenes.cornell_box(gpu.bvh_build)
+    bad.prims["v"][0, 0] = 10 ** 6  # out-of-range vertex index must be rejected on the host
+    h = C.c_void_p()
+    assert L.rspt_scene_create(C.addressof(bad.desc), C.addressof(h)) == abi.E_INVALID
+
+
+def test_large_batch_sorted_properties(gpu, soup):
+    """full-size property check (no oracle): closest t <= any other reported hit along the same ray,
+    and any-hit == (closest-hit found something) for 4 M rays."""
+    sc, ds = soup
+    rays = random_rays(1 << 22, 6, -1.3, 1.3)
+    c = gpu.trace(ds, rays)
+    a = gpu.trace(ds, rays, any_hit=True)
+    assert np.array_equal(c["prim"] != abi.MISS, a["prim"] == 0)
+    hit = c["prim"] != abi.MISS
+    assert (c["t"][hit] > 0).all()
+    b = np.stack([c["b0"][hit], c["b1"][hit], c["b2"][hit]], 1)
+    assert np.abs(b.sum(1) - 1).max() < 1e-5 and (b >= 0).all()
+    # idempotence: shrinking t_max to just above the hit returns the same primitive
+    r2 = rays[hit][:100000].copy()
+    r2["t_max"] = np.nextafter(c["t"][hit][:100000], np.float32(np.inf))
+    c2 = gpu.trace(ds, r2)
+    assert np.array_equal(c2["prim"], c["prim"][hit][:100000])
