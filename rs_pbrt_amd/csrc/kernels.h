@@ -42,7 +42,9 @@ struct PathBuf {
 };
 
 struct QueueCounts {  // one per wavefront iteration
-    uint32_t active, closest, any, pad;
+    uint32_t active, closest, any;          // queue lengths
+    uint32_t cursor_closest, cursor_any;    // dynamic-fetch cursors of the persistent trace kernel
+    uint32_t pad[3];
 };
 
 struct Batch {

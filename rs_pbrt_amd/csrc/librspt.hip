@@ -15,6 +15,7 @@
 
 #include "../../include/rspt.h"
 #include "kernels.h"
+#include "trace_wide.h"
 
 using namespace rspt;
 
@@ -76,6 +77,7 @@ struct LightDist {
 
 struct rspt_scene_s {
     SceneDev dev{};
+    const PairNode* pairs = nullptr;  // one per interior LinearBVHNode (trace_wide.h)
     std::vector<void*> allocs;
     bool has_null_material = false;
     std::map<int, LightDist> light_dists;  // by effective strategy
@@ -228,9 +230,18 @@ int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
     return RSPT_OK;
 }
 
+// kernel choice: the persistent-wave kernel (trace_wide.h) unless RSPT_TRACE_KERNEL=0 or the
+// reference-order node / triangle counters are wanted (only k_trace counts them)
 template <bool ANY, int OUT_MODE>
-void launch_trace(bool count, uint32_t grid, const SceneDev& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
+void launch_trace(bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                   const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
+    const SceneDev& sc = s->dev;
+    static const bool use_pw = env_size("RSPT_TRACE_KERNEL", 1) != 0;
+    if (!count && use_pw) {
+        const uint32_t pgrid = grid_for((uint32_t)env_size("RSPT_PW_BLOCKS_PER_CU", 8));
+        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits);
+        return;
+    }
     if (count)
         hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
     else
@@ -361,8 +372,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 const int par = it & 1;
                 hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);
                 HIP_TRY(hipEventRecord(e0, g.stream));
-                launch_trace<false, 0>(counters, tgrid, s->dev, g.q[par][1], &g.cnt[it].closest, 0, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                if (it > 0) launch_trace<true, 0>(counters, tgrid, s->dev, g.q[par][2], &g.cnt[it].any, 0, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                launch_trace<false, 0>(counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                if (it > 0) launch_trace<true, 0>(counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
                 HIP_TRY(hipEventRecord(e1, g.stream));
                 trace_ev.push_back({e0, e1});
                 trace_launches += it > 0 ? 2 : 1;
@@ -549,6 +560,29 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         if (e != hipSuccess) return bail(fail(RSPT_E_HIP, "k_build_tris: %s", hipGetErrorString(e)));
         s->dev.tris = tris;
     }
+    if (d->n_nodes > 1) {  // pair records: both children's boxes next to each other (trace_wide.h)
+        std::vector<uint32_t> pair_of(d->n_nodes, 0u);
+        uint32_t n_pairs = 0;
+        for (uint64_t i = 0; i < d->n_nodes; i++)
+            if (d->nodes[i].n_prims == 0) pair_of[i] = n_pairs++;
+        std::vector<PairNode> pairs(n_pairs);
+        for (uint64_t i = 0; i < d->n_nodes; i++) {
+            const rspt_bvh_node& n = d->nodes[i];
+            if (n.n_prims != 0) continue;
+            const uint32_t ci[2] = {(uint32_t)i + 1u, (uint32_t)n.offset};
+            const rspt_bvh_node& a = d->nodes[ci[0]];
+            const rspt_bvh_node& b = d->nodes[ci[1]];
+            PairNode& p = pairs[pair_of[i]];
+            p.q0 = make_float4(a.bmin[0], a.bmin[1], a.bmin[2], a.bmax[0]);
+            p.q1 = make_float4(a.bmax[1], a.bmax[2], b.bmin[0], b.bmin[1]);
+            p.q2 = make_float4(b.bmin[2], b.bmax[0], b.bmax[1], b.bmax[2]);
+            p.c0 = a.n_prims ? (ci[0] | RSPT_REF_LEAF) : pair_of[ci[0]];
+            p.c1 = b.n_prims ? (ci[1] | RSPT_REF_LEAF) : pair_of[ci[1]];
+            p.self = (uint32_t)i;
+            p.axis = n.axis;
+        }
+        if ((rc = upload(s, pairs.data(), pairs.size(), &s->pairs))) return bail(rc);
+    }
     *out = s;
     return RSPT_OK;
 }
@@ -585,9 +619,13 @@ int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* ou
     if (counters) HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
     hipEvent_t e0 = get_event(0), e1 = get_event(1);
     HIP_TRY(hipEventRecord(e0, g.stream));
+    int rc0 = ensure_counts(4);
+    if (rc0) return rc0;
+    uint32_t* cursor = &g.cnt[0].cursor_closest;
     for (int r = 0; r < repeat && n; r++) {
-        if (any_hit) launch_trace<true, 1>(counters, trace_grid(), s->dev, nullptr, nullptr, (uint32_t)n, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
-        else launch_trace<false, 1>(counters, trace_grid(), s->dev, nullptr, nullptr, (uint32_t)n, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
+        HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), g.stream));
+        if (any_hit) launch_trace<true, 1>(counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
+        else launch_trace<false, 1>(counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
     }
     HIP_TRY(hipEventRecord(e1, g.stream));
     HIP_TRY(hipGetLastError());

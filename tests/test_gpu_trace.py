@@ -117,8 +117,11 @@ def test_large_batch_sorted_properties(gpu, soup):
     assert (c["t"][hit] > 0).all()
     b = np.stack([c["b0"][hit], c["b1"][hit], c["b2"][hit]], 1)
     assert np.abs(b.sum(1) - 1).max() < 1e-5 and (b >= 0).all()
-    # idempotence: shrinking t_max to just above the hit returns the same primitive
+    # idempotence: shrinking t_max to slightly beyond the hit returns the same hit; to slightly
+    # before it, a different (farther) one or none
     r2 = rays[hit][:100000].copy()
-    r2["t_max"] = np.nextafter(c["t"][hit][:100000], np.float32(np.inf))
+    r2["t_max"] = c["t"][hit][:100000] * np.float32(1.0001)
     c2 = gpu.trace(ds, r2)
-    assert np.array_equal(c2["prim"], c["prim"][hit][:100000])
+    assert np.array_equal(c2["prim"], c["prim"][hit][:100000]) and np.array_equal(c2["t"], c["t"][hit][:100000])
+    r2["t_max"] = c["t"][hit][:100000] * np.float32(0.9999)
+    assert (gpu.trace(ds, r2)["prim"] == abi.MISS).all()
