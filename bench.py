@@ -63,13 +63,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch  # first, so librspt binds to the HIP runtime torch already loaded
     import torch.distributed as dist
-    from rs_pbrt_amd import lib, scenes
+    from rs_pbrt_amd import lib, multigpu, scenes
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     lib.init(local_rank)
 
-    shard = (rank, world, 64)  # contiguous Morton chunks of 64 tiles, round-robin over ranks
+    shard = multigpu.shard_for_rank(rank, world)  # contiguous Morton chunks of 64 tiles, round-robin over ranks
     t0 = time.time()
     sc, mk_rd, spp, wl_name = build_workload(args, lib, scenes, shard)
     rd = mk_rd(spp, shard)
@@ -83,7 +83,7 @@ def main():
     def step():
         st = lib.render_device(ds, rd, film.data_ptr())
         if world > 1:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # X1: film sum over xGMI (tile borders overlap: sum, not gather)
+            multigpu.reduce_film(film)  # X1: RCCL reduce(sum) over xGMI (tile borders overlap: sum, not gather)
         return st
 
     def fence():

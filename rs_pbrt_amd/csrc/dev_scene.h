@@ -62,19 +62,17 @@ RDEV uint64_t sobol_interval_to_index(const RenderDev& rd, uint32_t m, uint64_t 
     uint64_t delta = 0;
     const uint64_t* M = rd.vdc + (m - 1) * 52;
     const uint64_t* MI = rd.vdc_inv + (m - 1) * 52;
-    for (int c = 0; frame > 0; frame >>= 1, c++)
-        if (frame & 1) delta ^= M[c];
+    for (uint64_t f = frame; f != 0; f &= f - 1) delta ^= M[__builtin_ctzll(f)];
     uint64_t b = ((uint64_t)((uint32_t)px << m) | (uint64_t)(int64_t)py) ^ delta;
-    for (int c = 0; b > 0; b >>= 1, c++)
-        if (b & 1) index ^= MI[c];
+    for (; b != 0; b &= b - 1) index ^= MI[__builtin_ctzll(b)];
     return index;
 }
 RDEV float sobol_dim(const RenderDev& rd, uint64_t index, uint32_t dim) {
     uint32_t v = 0;
     const uint32_t* row = rd.sobol32 + dim * 52;
-    int64_t a = (int64_t)index;
-    for (int i = 0; a != 0; a >>= 1, i++)
-        if (a & 1) v ^= row[i];
+    // XOR of the generator-matrix columns selected by the set bits of the index; visiting only the
+    // set bits (ctz) instead of shifting through all of them gives the same value (XOR commutes)
+    for (uint64_t a = index; a != 0; a &= a - 1) v ^= row[__builtin_ctzll(a)];
     return fminf((float)v * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
 }
 // SobolSampler::sample_dimension for dim >= 2 is sobol_dim; dims 0/1 are remapped into the pixel

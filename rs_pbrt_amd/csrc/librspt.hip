@@ -339,7 +339,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
 
     // ---- batches ----
-    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 22);
+    // paths per wavefront batch: ~350 B of state each, so 2^25 paths = 11 GB of the 288 GB HBM.
+    // Large batches keep the persistent trace kernel's queues long (measured on C2: 2^22 -> 102,
+    // 2^25 -> 195 Msamples/s).
+    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 25);
     cap = std::max<size_t>(cap, 1024);
     const bool counters = env_size("RSPT_COUNTERS", 0) != 0;
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap

@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference's operator for this path, for Python callers and tests:
+
+    PathIntegrator::new(max_depth, camera, sampler, pixel_bounds, rr_threshold, light_sample_strategy)
+                                                                    (src/integrators/path.rs:38-54)
+    Integrator::render(&mut self, scene: &Scene, num_threads: u8)   (src/core/integrator.rs:39-46,70)
+
+Same names, same defaults as CreatePathIntegrator (src/core/api.rs:285-321: maxdepth 5,
+rrthreshold 1.0, lightsamplestrategy "spatial"), same observable result: render() fills the
+film's pixels (xyz + filter_weight_sum, src/core/film.rs:38-43).  Where the reference panics
+(unknown strategy, no camera) this raises; when the GPU or librspt.so is missing it raises
+lib.RsptError — there is no CPU loop here."""
+import numpy as np
+
+from . import abi, lib, scenes
+
+_STRATEGIES = {"uniform": abi.LIGHTS_UNIFORM, "power": abi.LIGHTS_POWER, "spatial": abi.LIGHTS_SPATIAL}
+
+
+class Film:
+    """What Film.pixels holds after the render (film.rs:159-173) plus write_image's linear RGB."""
+
+    def __init__(self, rd):
+        self.full_resolution = (rd.full_res[0], rd.full_res[1])
+        self.cropped_pixel_bounds = tuple(rd.crop_px)
+        self.pixels = None  # (h, w, 4): xyz, filter_weight_sum
+
+    @property
+    def shape(self):
+        x0, y0, x1, y1 = self.cropped_pixel_bounds
+        return (y1 - y0, x1 - x0)
+
+    def rgb(self):
+        """Film::write_image before gamma / quantisation (film.rs:445-462)."""
+        h, w = self.shape
+        return scenes.film_to_rgb(self.pixels.reshape(-1, 4)).reshape(h, w, 3)
+
+
+class PathIntegrator:
+    def __init__(self, max_depth=5, camera=None, sampler=None, pixel_bounds=None, rr_threshold=1.0, light_sample_strategy="spatial"):
+        """camera: an rspt_render_desc carrying camera + film + sampler parameters
+        (scenes.make_render_desc); sampler / pixel_bounds are accepted for signature parity:
+        the sampler is the Sobol' sampler configured in the desc, pixel_bounds equal the film's
+        sample bounds (the reference ignores the "pixelbounds" parameter too, api.rs:288-304)."""
+        if camera is None:
+            raise ValueError("Unable to create camera")  # api.rs:467-483 panics the same way
+        if light_sample_strategy not in _STRATEGIES:
+            # create_light_sample_distribution (lightdistrib.rs:393-418) falls back to "spatial" with a warning
+            light_sample_strategy = "spatial"
+        self.camera = camera
+        self.max_depth = int(max_depth)
+        self.rr_threshold = float(rr_threshold)
+        self.light_sample_strategy = light_sample_strategy
+        self.stats = None
+
+    def _desc(self, shard=None):
+        rd = abi.RenderDesc.from_buffer_copy(self.camera)
+        rd.max_depth = self.max_depth
+        rd.rr_threshold = self.rr_threshold
+        rd.light_strategy = _STRATEGIES[self.light_sample_strategy]
+        if shard is not None:
+            rd.shard_index, rd.shard_count, rd.tile_chunk = shard
+        return rd
+
+    def render(self, scene, num_threads=0, shard=None):
+        """scene: scenes.Scene (flattened Scene + BVHAccel) or an already uploaded lib.DeviceScene.
+        num_threads maps to nothing on the GPU (kept for call compatibility).  Returns the Film."""
+        rd = self._desc(shard)
+        own = not isinstance(scene, lib.DeviceScene)
+        ds = lib.DeviceScene(scene) if own else scene
+        try:
+            pixels, self.stats = lib.render(ds, rd)
+        finally:
+            if own:
+                ds.close()
+        film = Film(rd)
+        h, w = film.shape
+        film.pixels = np.asarray(pixels, np.float32).reshape(h, w, 4)
+        return film

@@ -1,0 +1,22 @@
+"""Multi-GPU decomposition of one frame: the Morton-ordered 16x16 tile list of
+BlockQueue (src/blockqueue/mod.rs:23-52) is cut into chunks of TILE_CHUNK tiles that are dealt to
+the ranks round-robin; every rank renders its tiles into a full-frame film (zero elsewhere) and the
+films are SUMMED onto rank 0 — a sum, not a gather, because neighbouring tiles' pixel bounds
+overlap (film.rs:321-330).  One process per GPU; torch.distributed is only the transport
+(backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests)."""
+TILE_CHUNK = 64
+
+
+def shard_for_rank(rank, world_size, tile_chunk=TILE_CHUNK):
+    """(shard_index, shard_count, tile_chunk) for rspt_render_desc."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    return (rank, world_size, tile_chunk)
+
+
+def reduce_film(film, dst=0):
+    """Sum the per-rank film tensors onto `dst` (in place).  film: torch tensor, any device."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+    return film
