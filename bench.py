@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=4)
+    ap.add_argument("--cpu-spp", type=int, default=16)
     return ap.parse_args()
 
 

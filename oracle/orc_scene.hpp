@@ -9,7 +9,7 @@
 
 namespace orc {
 
-struct Counters {
+struct alignas(128) Counters {  // one per worker thread; padded so the hot increments never share a cache line
     uint64_t nodes_visited = 0, tris_tested = 0, rays_closest = 0, rays_any = 0, bounces = 0, samples = 0,
              nan_samples = 0, mis_rays = 0;
     void add(const Counters& o) {

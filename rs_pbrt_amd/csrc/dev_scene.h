@@ -81,6 +81,38 @@ RDEV float sobol_pixel_dim(const RenderDev& rd, uint64_t index, uint32_t dim, in
     s = s * (float)rd.resolution + (float)rd.sample_bounds[dim];
     return clampf(s - (float)pix, 0.0f, RSPT_ONE_MINUS_EPS);
 }
+// The shade stage consumes at most 8 consecutive Sobol' dimensions per bounce (light choice 1,
+// u_light 2, u_scattering 2, continuation 2, Russian roulette 1).  They are
+// evaluated together from an LDS copy of the generator matrices laid out [bit][dimension]: one pass
+// over the set bits of the index, 8 independent XOR chains, instead of 8 serial passes through
+// L2-resident global memory.  Values are identical to sobol_dim().
+struct SobolBlock {
+    float v[8];
+    uint32_t base, dim;  // first dimension held, next dimension to hand out
+    RDEV void fill(const uint32_t* __restrict__ tab, uint32_t nd, uint64_t index, uint32_t first_dim) {
+        uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint64_t a = index; a != 0; a &= a - 1) {
+            const uint32_t* row = tab + (uint32_t)__builtin_ctzll(a) * nd + first_dim;
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] ^= row[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = fminf((float)x[k] * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+        base = dim = first_dim;
+    }
+    RDEV float at(uint32_t k) const {
+        float lo = (k & 1) ? ((k & 2) ? v[3] : v[1]) : ((k & 2) ? v[2] : v[0]);
+        float hi = (k & 1) ? ((k & 2) ? v[7] : v[5]) : ((k & 2) ? v[6] : v[4]);
+        return (k & 4) ? hi : lo;
+    }
+    RDEV float get_1d() { return at((dim++) - base); }
+    RDEV f2 get_2d() {
+        f2 r{at(dim - base), at(dim + 1 - base)};
+        dim += 2;
+        return r;
+    }
+};
+
 struct Sampler {  // the (index, dimension) cursor a path carries between stages
     uint64_t index;
     uint32_t dim;

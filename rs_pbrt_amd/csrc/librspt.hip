@@ -355,6 +355,13 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
 
+    // LDS copy of the Sobol' matrices for k_shade: dimensions 0 .. 5 + 8 per bounce (+8 of read-ahead), index bits
+    // 2*log2(resolution) + log2(spp) (lowdiscrepancy.rs:1014-1043); the checks above keep this under 64 KB
+    const uint32_t sob_nd = 5u + 8u * (d->max_depth + 2u) + 8u;
+    uint32_t sob_bits = 2u * (uint32_t)rd.log2_res;
+    for (int64_t v = d->spp; v > 1; v >>= 1) sob_bits++;
+    sob_bits = std::min(52u, sob_bits + 1u);
+    if ((size_t)sob_nd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
     const uint32_t tgrid = trace_grid();
     const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", 4));
     size_t n_ev = 0;
@@ -380,8 +387,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 HIP_TRY(hipEventRecord(e1, g.stream));
                 trace_ev.push_back({e0, e1});
                 trace_launches += it > 0 ? 2 : 1;
-                hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), 0, g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0], g.q[par ^ 1][1], g.q[par ^ 1][2],
-                                   counters ? g.totals + 2 : nullptr);
+                hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
+                                   g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits);
                 it++;
                 if (it < nominal_iters) continue;
                 // after max_depth + 1 bounces only pending estimates and null-material passes remain
