@@ -239,7 +239,7 @@ void launch_trace(bool count, uint32_t grid, const rspt_scene_s* s, const uint32
     static const bool use_pw = env_size("RSPT_TRACE_KERNEL", 1) != 0;
     if (!count && use_pw) {
         const uint32_t pgrid = grid_for((uint32_t)env_size("RSPT_PW_BLOCKS_PER_CU", 8));
-        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits);
+        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
         return;
     }
     if (count)
@@ -583,9 +583,9 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             const rspt_bvh_node& a = d->nodes[ci[0]];
             const rspt_bvh_node& b = d->nodes[ci[1]];
             PairNode& p = pairs[pair_of[i]];
-            p.q0 = make_float4(a.bmin[0], a.bmin[1], a.bmin[2], a.bmax[0]);
-            p.q1 = make_float4(a.bmax[1], a.bmax[2], b.bmin[0], b.bmin[1]);
-            p.q2 = make_float4(b.bmin[2], b.bmax[0], b.bmax[1], b.bmax[2]);
+            p.q0 = make_float4(a.bmin[0], b.bmin[0], a.bmax[0], b.bmax[0]);
+            p.q1 = make_float4(a.bmin[1], b.bmin[1], a.bmax[1], b.bmax[1]);
+            p.q2 = make_float4(a.bmin[2], b.bmin[2], a.bmax[2], b.bmax[2]);
             p.c0 = a.n_prims ? (ci[0] | RSPT_REF_LEAF) : pair_of[ci[0]];
             p.c1 = b.n_prims ? (ci[1] | RSPT_REF_LEAF) : pair_of[ci[1]];
             p.self = (uint32_t)i;

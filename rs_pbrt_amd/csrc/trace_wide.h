@@ -25,9 +25,9 @@
 namespace rspt {
 
 struct PairNode {       // 64 B, 64-byte aligned
-    float4 q0;          // c0.min.xyz, c0.max.x
-    float4 q1;          // c0.max.yz,  c1.min.xy
-    float4 q2;          // c1.min.z,   c1.max.xyz
+    float4 q0;          // x slabs: c0.min.x, c1.min.x, c0.max.x, c1.max.x  (children interleaved so that
+    float4 q1;          // y slabs: c0.min.y, c1.min.y, c0.max.y, c1.max.y   each (c0, c1) pair feeds one
+    float4 q2;          // z slabs: c0.min.z, c1.min.z, c0.max.z, c1.max.z   packed-f32 instruction)
     uint32_t c0, c1;    // child refs: bit 31 = leaf; low bits = pair index (interior) / LinearBVHNode index (leaf)
     uint32_t self;      // LinearBVHNode index of this interior node
     uint32_t axis;
@@ -60,12 +60,34 @@ RDEV bool box_hit6(float lx, float ly, float lz, float hx, float hy, float hz, f
     return (t_min < ray_tmax) && (t_max > 0.0f);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Bounds3f::intersect_p (geometry.rs:2211-2269) for the two children of a pair at once, valid when
+// every reciprocal direction component is finite (no 0*inf NaNs).  With near_a = (near plane - o)*inv
+// and far_a = (far plane - o)*inv*(1+2*gamma(3)) per axis, the reference computes
+//     x/y cross checks, t_min = max(near_x, near_y), t_max = min(far_x, far_y), z cross checks,
+//     t_min = max(t_min, near_z), t_max = min(t_max, far_z), result = t_min < ray.t_max && t_max > 0.
+// The cross checks are exactly the six conditions near_a <= far_b (a != b).  They differ from
+// max3(near) <= min3(far) only in the same-axis pairs near_a <= far_a, and those can fail only when
+// far_a < 0 (widening a negative far value moves it below near), where the final t_max > 0 test
+// rejects anyway.  So hit == (max3(near) <= min3(far)) && max3(near) < ray.t_max && min3(far) > 0.
+RDEV void box_pair_hit(v2f nx, v2f fx, v2f ny, v2f fy, v2f nz, v2f fz, f3 o, f3 inv, float ray_tmax, bool* h0, bool* h1) {
+    const float widen = 1.0f + 2.0f * gamma_n(3);
+    v2f tnx = (nx - o.x) * inv.x, tny = (ny - o.y) * inv.y, tnz = (nz - o.z) * inv.z;
+    v2f tfx = (fx - o.x) * inv.x, tfy = (fy - o.y) * inv.y, tfz = (fz - o.z) * inv.z;
+    tfx = tfx * widen; tfy = tfy * widen; tfz = tfz * widen;
+    float m0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x), M0 = fminf(fminf(tfx.x, tfy.x), tfz.x);
+    float m1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y), M1 = fminf(fminf(tfx.y, tfy.y), tfz.y);
+    *h0 = (m0 <= M0) && (m0 < ray_tmax) && (M0 > 0.0f);
+    *h1 = (m1 <= M1) && (m1 < ray_tmax) && (M1 > 0.0f);
+}
+
 template <bool ANY, int OUT_MODE>
 __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const PairNode* __restrict__ pairs, const uint32_t* __restrict__ queue,
                                                            const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
-                                                           rspt_hit* __restrict__ out_hits) {
+                                                           rspt_hit* __restrict__ out_hits, int refill_thresh, int leaf_thresh) {
     __shared__ uint32_t stack[RSPT_PW_LDS * RSPT_PW_BLOCK];
     uint32_t* my = stack + threadIdx.x;
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
@@ -92,7 +114,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
     f3 o{0, 0, 0}, inv{0, 0, 0};
     RayShear rs{0, 0, 0, 0, 0, 0};
     float t_max = 0.0f;
-    bool ng0 = false, ng1 = false, ng2 = false;
+    bool ng0 = false, ng1 = false, ng2 = false, degenerate = false;
     uint32_t sp = 0, stale_sp = 0, cur = RSPT_NONE, leaf_node = RSPT_NONE;
     uint32_t best = RSPT_MISS, entry = 0, qpos = 0;
     float bt = 0.0f, bb0 = 0.0f, bb1 = 0.0f, bb2 = 0.0f;
@@ -115,7 +137,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
         // ---- refill idle lanes from the wave's chunk ----
         const uint64_t idle = __ballot(!active);
         const uint64_t busy = ~idle;
-        if (!exhausted && (__popcll(idle) >= RSPT_PW_REFILL || busy == 0)) {
+        if (!exhausted && (__popcll(idle) >= refill_thresh || busy == 0)) {
             if (chunk_lo == chunk_hi) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, (uint32_t)RSPT_PW_CHUNK);
@@ -137,6 +159,8 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                     t_max = r1.z;
                     inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
                     ng0 = inv.x < 0.0f; ng1 = inv.y < 0.0f; ng2 = inv.z < 0.0f;
+                    // zero / denormal / NaN direction components: keep the reference's literal compare chain
+                    degenerate = !(fabsf(inv.x) < RSPT_INF && fabsf(inv.y) < RSPT_INF && fabsf(inv.z) < RSPT_INF);
                     rs = ray_shear(d);
                     best = RSPT_MISS; bt = bb0 = bb1 = bb2 = 0.0f;
                     my[0] = root_ref;   // the root enters as a stale entry: its own box is tested first
@@ -187,8 +211,19 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                 }
                 cur = RSPT_NONE;
                 if (ok) {
-                    bool h0 = box_hit6(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, ng0, ng1, ng2, t_max);
-                    bool h1 = box_hit6(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, ng0, ng1, ng2, t_max);
+                    bool h0, h1;
+                    if (!degenerate) {
+                        // Both children's slab tests on packed f32 pairs (v_pk_add_f32 / v_pk_mul_f32), one
+                        // pair = (child 0, child 1).  For finite reciprocals the reference's compare-and-
+                        // select chain equals max3/min3 (see box_pair_hit): same booleans, ~40 % of the VALU.
+                        v2f nx = ng0 ? v2f{q0.z, q0.w} : v2f{q0.x, q0.y}, fx = ng0 ? v2f{q0.x, q0.y} : v2f{q0.z, q0.w};
+                        v2f ny = ng1 ? v2f{q1.z, q1.w} : v2f{q1.x, q1.y}, fy = ng1 ? v2f{q1.x, q1.y} : v2f{q1.z, q1.w};
+                        v2f nz = ng2 ? v2f{q2.z, q2.w} : v2f{q2.x, q2.y}, fz = ng2 ? v2f{q2.x, q2.y} : v2f{q2.z, q2.w};
+                        box_pair_hit(nx, fx, ny, fy, nz, fz, o, inv, t_max, &h0, &h1);
+                    } else {
+                        h0 = box_hit6(q0.x, q1.x, q2.x, q0.z, q1.z, q2.z, o, inv, ng0, ng1, ng2, t_max);
+                        h1 = box_hit6(q0.y, q1.y, q2.y, q0.w, q1.w, q2.w, o, inv, ng0, ng1, ng2, t_max);
+                    }
                     uint32_t axis = __float_as_uint(q3.w);
                     bool neg = axis == 0 ? ng0 : (axis == 1 ? ng1 : ng2);
                     uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
@@ -216,7 +251,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
         const uint64_t parked = __ballot(active && leaf_node != RSPT_NONE);
         if (parked) {
             const uint64_t running = __ballot(active && leaf_node == RSPT_NONE);
-            if (__popcll(parked) >= RSPT_PW_LEAF || running == 0) {
+            if (__popcll(parked) >= leaf_thresh || running == 0) {
                 if (active && leaf_node != RSPT_NONE) {
                     float4 n1 = sc.nodes[2 * (size_t)leaf_node + 1];
                     uint32_t w = __float_as_uint(n1.w);

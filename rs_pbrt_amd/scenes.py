@@ -232,11 +232,10 @@ class SceneBuilder:
         # lights in shape-declaration order (one DiffuseAreaLight per emissive triangle, api.rs:2810-2852)
         light_of_tri = np.full(len(tri), -1, np.int32)
         lights_in = []
-        for t in range(len(tri)):
-            e = self.mesh_emit[tri_mesh[t]]
-            if e is not None:
-                light_of_tri[t] = len(lights_in)
-                lights_in.append((t, e))
+        emissive_mesh = np.array([e is not None for e in self.mesh_emit], bool)
+        for t in np.nonzero(emissive_mesh[tri_mesh])[0]:
+            light_of_tri[t] = len(lights_in)
+            lights_in.append((int(t), self.mesh_emit[tri_mesh[t]]))
         inv = np.empty(len(tri), np.uint32); inv[ordered] = np.arange(len(tri), dtype=np.uint32)
         prims = np.zeros(len(tri), abi.PRIM_DT)
         prims["v"] = tri[ordered]
