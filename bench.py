@@ -56,6 +56,19 @@ def build_workload(args, lib, scenes, shard):
     return sc, mk, spp, name
 
 
+def measured_traffic(args):
+    """HBM-side bytes of the trace launches of one step from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE with the gfx950 correction of
+    MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so the number is
+    only reported for the exact workload it was measured on; otherwise null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    default_cfg = args.workload == "soup1m" and args.tris == 1_000_000 and not args.res and not args.spp and args.gpus == 1
+    return t["trace_traffic_bytes_per_step"] if (default_cfg and t.get("workload") == args.workload) else None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -134,7 +147,7 @@ def main():
             "config": {"workload": wl_name, "samples_per_step": samples_per_step, "tiles": "16x16 Morton, chunks of 64 dealt round-robin",
                        "film_reduce": "RCCL reduce(sum) to rank 0" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": "k_trace (BVH traversal + triangle test, closest + any launches)",
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args),
                          "alg_bytes_per_step_rank0": trace_bytes, "trace_s_per_step": t_trace, "kernels_s_per_step": t_kernels,
                          "trace_launches_per_step": stats[0]["trace_launches"],
                          "whole_path_alg_bytes_per_sample": counts["alg_bytes"] / max(counts["samples"], 1),
