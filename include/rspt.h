@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 1
+#define RSPT_ABI_VERSION 2
 
 /* error codes */
 #define RSPT_OK 0
@@ -83,7 +83,11 @@ enum {
     RSPT_BXDF_FRESNEL_SPEC = 5, /* FresnelSpecular           reflection.rs:841-950   */
     RSPT_BXDF_MICROFACET_R = 6, /* MicrofacetReflection (TrowbridgeReitz, visible-area
                                    sampling)                 reflection.rs:1128-1209 */
-    RSPT_BXDF_LAMBERT_T = 7     /* LambertianTransmission    reflection.rs:1001-1046 */
+    RSPT_BXDF_LAMBERT_T = 7,    /* LambertianTransmission    reflection.rs:1001-1046 */
+    RSPT_BXDF_MICROFACET_T = 8, /* MicrofacetTransmission (TrowbridgeReitz, radiance mode):
+                                   r = T, eta_a, eta_b, alphas  reflection.rs:1214-1371 */
+    RSPT_BXDF_FRESNEL_BLEND = 9 /* FresnelBlend: r = Rd, t = Rs, alphas
+                                                             reflection.rs:1374-1478 */
 };
 enum {
     RSPT_FRESNEL_NOOP = 0,      /* reflection.rs:698-705 */
@@ -110,15 +114,22 @@ typedef struct {
 
 /* ---- lights (Scene.lights order, src/core/scene.rs:19-24) ------------------------- */
 enum {
-    RSPT_LIGHT_DIFFUSE_AREA = 1 /* DiffuseAreaLight on one triangle, src/lights/diffuse.rs:19-27;
+    RSPT_LIGHT_DIFFUSE_AREA = 1,/* DiffuseAreaLight on one triangle, src/lights/diffuse.rs:19-27;
                                     one per emissive triangle (api.rs:2810-2852)       */
+    RSPT_LIGHT_POINT = 2,       /* PointLight   src/lights/point.rs:20-68:  p[0..2] = p_light, L = I      */
+    RSPT_LIGHT_SPOT = 3,        /* SpotLight    src/lights/spot.rs:20-110: p[0..2] = p_light, L = I,
+                                    p[3..11] = upper 3x3 of world_to_light.m (row major),
+                                    p[12] = cos_total_width, p[13] = cos_falloff_start  */
+    RSPT_LIGHT_DISTANT = 4      /* DistantLight src/lights/distant.rs:25-75: p[0..2] = w_light (normalised), L = L;
+                                    the world radius comes from the scene bounds (preprocess, :76-86)      */
 };
 typedef struct {
     uint32_t kind;
-    uint32_t prim;       /* BVH-ordered primitive index of the emitting triangle      */
-    float L[3];          /* l_emit                                                    */
+    uint32_t prim;       /* DIFFUSE_AREA: BVH-ordered primitive index of the emitting triangle */
+    float L[3];          /* l_emit / I / L                                            */
     uint32_t two_sided;
-} rspt_light;
+    float p[16];         /* kind-specific parameters, see above                       */
+} rspt_light; /* 88 B */
 
 typedef struct {
     const rspt_bvh_node* nodes; uint64_t n_nodes;

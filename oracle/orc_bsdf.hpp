@@ -148,6 +148,7 @@ struct TR {
 };
 
 static inline Spec S3(const float* p) { return Spec(p[0], p[1], p[2]); }
+static inline Float pow5(Float v) { return (v * v) * (v * v) * v; } // reflection.rs:1974-1976
 
 // One lobe = one Bxdf enum value (reflection.rs:462-633)
 struct Lobe {
@@ -160,6 +161,8 @@ struct Lobe {
         case RSPT_BXDF_SPECULAR_T: return BSDF_TRANSMISSION | BSDF_SPECULAR;
         case RSPT_BXDF_FRESNEL_SPEC: return BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
         case RSPT_BXDF_MICROFACET_R: return BSDF_REFLECTION | BSDF_GLOSSY;
+        case RSPT_BXDF_MICROFACET_T: return BSDF_TRANSMISSION | BSDF_GLOSSY; // :1319
+        case RSPT_BXDF_FRESNEL_BLEND: return BSDF_REFLECTION | BSDF_GLOSSY;  // :1475
         }
         return 0;
     }
@@ -199,6 +202,33 @@ struct Lobe {
             TR tr{b->alpha_x, b->alpha_y};
             return S3(b->r) * tr.d(wh) * tr.g(wo, wi) * fr / (4.0f * cti * cto);
         }
+        case RSPT_BXDF_MICROFACET_T: { // :1246-1317 (TransportMode::Radiance)
+            if (same_hemisphere(wo, wi)) return Spec(0.0f);
+            Float cto = cos_theta(wo), cti = cos_theta(wi);
+            if (cto == 0.0f || cti == 0.0f) return Spec(0.0f);
+            Float eta = cto > 0.0f ? b->eta_b / b->eta_a : b->eta_a / b->eta_b;
+            V3 wh = normalize(wo + wi * eta);
+            if (wh.z < 0.0f) wh = -wh;
+            if (dot(wo, wh) * dot(wi, wh) > 0.0f) return Spec(0.0f);
+            Spec f(fr_dielectric(dot(wo, wh), b->eta_a, b->eta_b));
+            Float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+            Float factor = 1.0f / eta;
+            TR tr{b->alpha_x, b->alpha_y};
+            return (Spec(1.0f) - f) * S3(b->r) *
+                   std::fabs(tr.d(wh) * tr.g(wo, wi) * eta * eta * abs_dot(wi, wh) * abs_dot(wo, wh) * factor * factor / (cti * cto * sqrt_denom * sqrt_denom));
+        }
+        case RSPT_BXDF_FRESNEL_BLEND: { // :1398-1431; rd = r, rs = t
+            Spec rd = S3(b->r), rs = S3(b->t);
+            Spec diffuse = rd * (Spec(1.0f) - rs) * (28.0f / (23.0f * PI)) * (1.0f - pow5(1.0f - 0.5f * abs_cos_theta(wi))) *
+                           (1.0f - pow5(1.0f - 0.5f * abs_cos_theta(wo)));
+            V3 wh = wi + wo;
+            if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return Spec(0.0f);
+            wh = normalize(wh);
+            TR tr{b->alpha_x, b->alpha_y};
+            Spec schlick = rs + (Spec(1.0f) - rs) * pow5(1.0f - dot(wi, wh));
+            Spec specular = schlick * (tr.d(wh) / (4.0f * std::fabs(dot(wi, wh)) * std::fmax(abs_cos_theta(wi), abs_cos_theta(wo))));
+            return diffuse + specular;
+        }
         default: return Spec(0.0f); // specular lobes :721,782,866
         }
     }
@@ -216,6 +246,24 @@ struct Lobe {
             V3 wh = normalize(wo + wi);
             TR tr{b->alpha_x, b->alpha_y};
             return tr.pdf(wo, wh) / (4.0f * dot(wo, wh));
+        }
+        case RSPT_BXDF_MICROFACET_T: { // :1350-1370
+            if (same_hemisphere(wo, wi)) return 0.0f;
+            Float eta = cos_theta(wo) > 0.0f ? b->eta_b / b->eta_a : b->eta_a / b->eta_b;
+            V3 wh = normalize(wo + wi * eta);
+            Float wo_dot_wh = dot(wo, wh), wi_dot_wh = dot(wi, wh);
+            if (wo_dot_wh * wi_dot_wh > 0.0f) return 0.0f;
+            Float sqrt_denom = wo_dot_wh + eta * wi_dot_wh;
+            Float dwh_dwi = std::fabs((eta * eta * wi_dot_wh) / (sqrt_denom * sqrt_denom));
+            TR tr{b->alpha_x, b->alpha_y};
+            return tr.pdf(wo, wh) * dwh_dwi;
+        }
+        case RSPT_BXDF_FRESNEL_BLEND: { // :1462-1474
+            if (!same_hemisphere(wo, wi)) return 0.0f;
+            V3 wh = normalize(wo + wi);
+            TR tr{b->alpha_x, b->alpha_y};
+            Float pdf_wh = tr.pdf(wo, wh);
+            return 0.5f * (abs_cos_theta(wi) * INV_PI + pdf_wh / (4.0f * dot(wo, wh)));
         }
         }
         return 0.0f;
@@ -274,6 +322,31 @@ struct Lobe {
             *wi = reflect(wo, wh);
             if (!same_hemisphere(wo, *wi)) return Spec();
             *pdf_out = tr.pdf(wo, wh) / (4.0f * dot(wo, wh));
+            return f(wo, *wi);
+        }
+        case RSPT_BXDF_MICROFACET_T: { // :1322-1349
+            if (wo.z == 0.0f) return Spec();
+            TR tr{b->alpha_x, b->alpha_y};
+            V3 wh = tr.sample_wh(wo, u);
+            Float eta = cos_theta(wo) > 0.0f ? b->eta_a / b->eta_b : b->eta_b / b->eta_a;
+            if (!refract(wo, wh, eta, wi)) return Spec();
+            *pdf_out = pdf(wo, *wi);
+            return f(wo, *wi);
+        }
+        case RSPT_BXDF_FRESNEL_BLEND: { // :1432-1461
+            P2 uu = u;
+            if (uu.x < 0.5f) {
+                uu.x = std::fmin(2.0f * uu.x, FLOAT_ONE_MINUS_EPSILON);
+                *wi = cosine_sample_hemisphere(uu);
+                if (wo.z < 0.0f) wi->z *= -1.0f;
+            } else {
+                uu.x = std::fmin(2.0f * (uu.x - 0.5f), FLOAT_ONE_MINUS_EPSILON);
+                TR tr{b->alpha_x, b->alpha_y};
+                V3 wh = tr.sample_wh(wo, uu);
+                *wi = reflect(wo, wh);
+                if (!same_hemisphere(wo, *wi)) return Spec(0.0f);
+            }
+            *pdf_out = pdf(wo, *wi);
             return f(wo, *wi);
         }
         }

@@ -154,17 +154,64 @@ static inline Spec light_l(const rspt_light& lt, V3 n, V3 w) { // :164-170
     if (lt.two_sided || dot(n, w) > 0.0f) return S3(lt.L);
     return Spec(0.0f);
 }
-// sample_li :64-84
-static inline Spec light_sample_li(const Scene& sc, const rspt_light& lt, const Interaction& iref, P2 u, V3* wi, Float* pdf, Interaction* light_intr) {
-    *light_intr = sc.tri_sample_ref(sc.d.prims[lt.prim], iref, u, pdf);
-    if (*pdf == 0.0f || length_squared(light_intr->p - iref.p) == 0.0f) { *pdf = 0.0f; return Spec(); }
-    *wi = normalize(light_intr->p - iref.p);
-    return light_l(lt, light_intr->n, -*wi);
+// Bounds3f::bounding_sphere (geometry.rs:2160-2172) of the scene bound, used by DistantLight::preprocess
+static inline Float world_radius(const Scene& sc) {
+    Bounds3 b = sc.world_bound();
+    V3 center = (b.p_min + b.p_max) / 2.0f;
+    bool inside = center.x >= b.p_min.x && center.x <= b.p_max.x && center.y >= b.p_min.y && center.y <= b.p_max.y &&
+                  center.z >= b.p_min.z && center.z <= b.p_max.z;
+    return inside ? std::sqrt(distance_squared(center, b.p_max)) : 0.0f;
 }
-// power :85-93
+static inline bool light_is_delta(const rspt_light& lt) { return lt.kind != RSPT_LIGHT_DIFFUSE_AREA; } // light.rs:178-188
+// SpotLight::falloff spot.rs:67-80
+static inline Float spot_falloff(const rspt_light& lt, V3 w) {
+    const float* m = lt.p + 3;
+    V3 wl = normalize(V3{m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z});
+    Float cos_theta_ = wl.z, cos_total = lt.p[12], cos_start = lt.p[13];
+    if (cos_theta_ < cos_total) return 0.0f;
+    if (cos_theta_ >= cos_start) return 1.0f;
+    Float delta = (cos_theta_ - cos_total) / (cos_start - cos_total);
+    return (delta * delta) * (delta * delta);
+}
+// Light::sample_li: diffuse.rs:64-84, point.rs:52-68, spot.rs:81-106, distant.rs:41-58
+static inline Spec light_sample_li(const Scene& sc, const rspt_light& lt, const Interaction& iref, P2 u, V3* wi, Float* pdf, Interaction* light_intr) {
+    if (lt.kind == RSPT_LIGHT_DIFFUSE_AREA) {
+        *light_intr = sc.tri_sample_ref(sc.d.prims[lt.prim], iref, u, pdf);
+        if (*pdf == 0.0f || length_squared(light_intr->p - iref.p) == 0.0f) { *pdf = 0.0f; return Spec(); }
+        *wi = normalize(light_intr->p - iref.p);
+        return light_l(lt, light_intr->n, -*wi);
+    }
+    Interaction li; // InteractionCommon::default(): n = 0, p_error = 0
+    li.p_error = V3{0, 0, 0}; li.n = V3{0, 0, 0}; li.wo = V3{0, 0, 0}; li.time = iref.time;
+    *pdf = 1.0f;
+    Spec out;
+    if (lt.kind == RSPT_LIGHT_DISTANT) {
+        V3 w{lt.p[0], lt.p[1], lt.p[2]};
+        *wi = w;
+        li.p = iref.p + w * (2.0f * world_radius(sc));
+        out = S3(lt.L);
+    } else {
+        V3 pl{lt.p[0], lt.p[1], lt.p[2]};
+        *wi = normalize(pl - iref.p);
+        li.p = pl;
+        Float d2 = distance_squared(pl, iref.p);
+        if (lt.kind == RSPT_LIGHT_POINT) out = S3(lt.L) / d2;
+        else out = S3(lt.L) * spot_falloff(lt, -*wi) / d2;
+    }
+    *light_intr = li;
+    return out;
+}
+// Light::power: diffuse.rs:85-93, point.rs:69-71, spot.rs:107-113, distant.rs:59-62
 static inline Spec light_power(const Scene& sc, const rspt_light& lt) {
-    Float factor = lt.two_sided ? 2.0f : 1.0f;
-    return S3(lt.L) * factor * sc.tri_area(sc.d.prims[lt.prim]) * PI;
+    switch (lt.kind) {
+    case RSPT_LIGHT_POINT: return S3(lt.L) * (4.0f * PI);
+    case RSPT_LIGHT_SPOT: return S3(lt.L) * 2.0f * PI * (1.0f - 0.5f * (lt.p[13] + lt.p[12]));
+    case RSPT_LIGHT_DISTANT: { Float r = world_radius(sc); return S3(lt.L) * PI * r * r; }
+    default: {
+        Float factor = lt.two_sided ? 2.0f : 1.0f;
+        return S3(lt.L) * factor * sc.tri_area(sc.d.prims[lt.prim]) * PI;
+    }
+    }
 }
 
 // ---- SpatialLightDistribution::compute_distribution: lightdistrib.rs:169-269 ----
@@ -248,13 +295,16 @@ static inline Spec estimate_direct(RenderCtx& cx, const Interaction& it, const B
             Ray sray = it.spawn_ray_to(light_intr); // VisibilityTester::unoccluded light.rs:199-206
             if (sc.intersect_p(sray, c)) li = Spec(0.0f);
             if (!li.is_black()) {
-                Float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
-                ld = ld + f * li * Spec(weight) / light_pdf;
+                if (light_is_delta(light)) ld = ld + f * li / light_pdf; // integrator.rs:470-471
+                else {
+                    Float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                    ld = ld + f * li * Spec(weight) / light_pdf;
+                }
             }
         }
     }
-    // sample BSDF with MIS (area lights are never delta)
-    {
+    // sample BSDF with MIS, skipped for delta lights (integrator.rs:480)
+    if (!light_is_delta(light)) {
         uint8_t sampled_type = 0; // Q6: stays 0 => sampled_specular always false
         Spec f = bsdf.sample_f(it.wo, &wi, u_scattering, &scattering_pdf, flags, &sampled_type);
         f = f * Spec(abs_dot(wi, it.sh_n));

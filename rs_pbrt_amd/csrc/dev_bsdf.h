@@ -91,6 +91,7 @@ RDEV f3 cosine_hemisphere(f2 u) {
     float z = sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return f3{d.x, d.y, z};
 }
+RDEV float pow5(float v) { return (v * v) * (v * v) * v; }  // reflection.rs:1974-1976
 RDEV float power_heuristic(float f_pdf, float g_pdf) {  // nf = ng = 1
     float f = 1.0f * f_pdf, g = 1.0f * g_pdf;
     return (f * f) / (f * f + g * g);
@@ -171,6 +172,8 @@ RDEV uint32_t lobe_type(uint32_t t) {
     case RSPT_BXDF_SPECULAR_T: return BX_TRANS | BX_SPEC;
     case RSPT_BXDF_FRESNEL_SPEC: return BX_REFL | BX_TRANS | BX_SPEC;
     case RSPT_BXDF_MICROFACET_R: return BX_REFL | BX_GLOSSY;
+    case RSPT_BXDF_MICROFACET_T: return BX_TRANS | BX_GLOSSY;
+    case RSPT_BXDF_FRESNEL_BLEND: return BX_REFL | BX_GLOSSY;
     }
     return 0;
 }
@@ -207,6 +210,31 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         rgb fr = lobe_fresnel(b, dot(wi, wh));
         return ldrgb(b.r) * tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * fr / (4.0f * cti * cto);
     }
+    case RSPT_BXDF_MICROFACET_T: {  // MicrofacetTransmission::f, TransportMode::Radiance (reflection.rs:1246-1317)
+        if (same_hemi(wo, wi)) return mkrgb(0.0f);
+        float cto = wo.z, cti = wi.z;
+        if (cto == 0.0f || cti == 0.0f) return mkrgb(0.0f);
+        float eta = cto > 0.0f ? b.eta_b / b.eta_a : b.eta_a / b.eta_b;
+        f3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0.0f) wh = -wh;
+        if (dot(wo, wh) * dot(wi, wh) > 0.0f) return mkrgb(0.0f);
+        rgb fr = mkrgb(fr_dielectric(dot(wo, wh), b.eta_a, b.eta_b));
+        float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        float factor = 1.0f / eta;
+        return (mkrgb(1.0f) - fr) * ldrgb(b.r) *
+               fabsf(tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+                     (cti * cto * sqrt_denom * sqrt_denom));
+    }
+    case RSPT_BXDF_FRESNEL_BLEND: {  // FresnelBlend::f (reflection.rs:1398-1431): r = Rd, t = Rs
+        rgb rd = ldrgb(b.r), rs = ldrgb(b.t);
+        rgb diffuse = rd * (mkrgb(1.0f) - rs) * (28.0f / (23.0f * RSPT_PI)) * (1.0f - pow5(1.0f - 0.5f * fabsf(wi.z))) * (1.0f - pow5(1.0f - 0.5f * fabsf(wo.z)));
+        f3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
+        wh = normalize(wh);
+        rgb schlick = rs + (mkrgb(1.0f) - rs) * pow5(1.0f - dot(wi, wh));
+        rgb specular = schlick * (tr_d(b.alpha_x, b.alpha_y, wh) / (4.0f * fabsf(dot(wi, wh)) * fmaxf(fabsf(wi.z), fabsf(wo.z))));
+        return diffuse + specular;
+    }
     default: return mkrgb(0.0f);
     }
 }
@@ -222,6 +250,22 @@ RDEVN float lobe_pdf(const rspt_bxdf& b, f3 wo, f3 wi) {
         if (!same_hemi(wo, wi)) return 0.0f;
         f3 wh = normalize(wo + wi);
         return tr_pdf(b.alpha_x, b.alpha_y, wo, wh) / (4.0f * dot(wo, wh));
+    }
+    case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1350-1370
+        if (same_hemi(wo, wi)) return 0.0f;
+        float eta = wo.z > 0.0f ? b.eta_b / b.eta_a : b.eta_a / b.eta_b;
+        f3 wh = normalize(wo + wi * eta);
+        float wo_wh = dot(wo, wh), wi_wh = dot(wi, wh);
+        if (wo_wh * wi_wh > 0.0f) return 0.0f;
+        float sqrt_denom = wo_wh + eta * wi_wh;
+        float dwh_dwi = fabsf((eta * eta * wi_wh) / (sqrt_denom * sqrt_denom));
+        return tr_pdf(b.alpha_x, b.alpha_y, wo, wh) * dwh_dwi;
+    }
+    case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1462-1474
+        if (!same_hemi(wo, wi)) return 0.0f;
+        f3 wh = normalize(wo + wi);
+        float pdf_wh = tr_pdf(b.alpha_x, b.alpha_y, wo, wh);
+        return 0.5f * (fabsf(wi.z) * RSPT_INV_PI + pdf_wh / (4.0f * dot(wo, wh)));
     }
     default: return 0.0f;
     }
@@ -280,6 +324,29 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
         *wi = (-wo) + wh * 2.0f * dot(wo, wh);  // reflect, reflection.rs:1889
         if (!same_hemi(wo, *wi)) return black;
         *pdf = tr_pdf(b.alpha_x, b.alpha_y, wo, wh) / (4.0f * dot(wo, wh));
+        return lobe_f(b, wo, *wi);
+    }
+    case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1322-1349
+        if (wo.z == 0.0f) return black;
+        f3 wh = tr_sample_wh(b.alpha_x, b.alpha_y, wo, u);
+        float eta = wo.z > 0.0f ? b.eta_a / b.eta_b : b.eta_b / b.eta_a;
+        if (!refract(wo, wh, eta, wi)) return black;
+        *pdf = lobe_pdf(b, wo, *wi);
+        return lobe_f(b, wo, *wi);
+    }
+    case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1432-1461
+        f2 uu = u;
+        if (uu.x < 0.5f) {
+            uu.x = fminf(2.0f * uu.x, RSPT_ONE_MINUS_EPS);
+            *wi = cosine_hemisphere(uu);
+            if (wo.z < 0.0f) wi->z *= -1.0f;
+        } else {
+            uu.x = fminf(2.0f * (uu.x - 0.5f), RSPT_ONE_MINUS_EPS);
+            f3 wh = tr_sample_wh(b.alpha_x, b.alpha_y, wo, uu);
+            *wi = (-wo) + wh * 2.0f * dot(wo, wh);
+            if (!same_hemi(wo, *wi)) return black;
+        }
+        *pdf = lobe_pdf(b, wo, *wi);
         return lobe_f(b, wo, *wi);
     }
     default: return black;

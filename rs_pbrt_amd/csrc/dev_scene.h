@@ -300,13 +300,58 @@ RDEV LightSample tri_sample_ref(const SceneDev& sc, uint32_t prim, const TriRec&
     }
     return s;
 }
-// DiffuseAreaLight::sample_li (diffuse.rs:64-84)
+RDEV bool light_is_delta(const rspt_light& lt) { return lt.kind != RSPT_LIGHT_DIFFUSE_AREA; }  // light.rs:178-188
+// Bounds3f::bounding_sphere of the scene bound (geometry.rs:2160-2172), DistantLight::preprocess
+RDEV float world_radius(const SceneDev& sc) {
+    f3 lo{sc.wb_min[0], sc.wb_min[1], sc.wb_min[2]}, hi{sc.wb_max[0], sc.wb_max[1], sc.wb_max[2]};
+    f3 c = vdiv(lo + hi, 2.0f);
+    bool inside = c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z;
+    return inside ? sqrtf(dist2(c, hi)) : 0.0f;
+}
+RDEV float spot_falloff(const rspt_light& lt, f3 w) {  // spot.rs:67-80
+    const float* m = lt.p + 3;
+    f3 wl = normalize(f3{m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z});
+    float c = wl.z, c_total = lt.p[12], c_start = lt.p[13];
+    if (c < c_total) return 0.0f;
+    if (c >= c_start) return 1.0f;
+    float delta = (c - c_total) / (c_start - c_total);
+    return (delta * delta) * (delta * delta);
+}
+// Light::sample_li: DiffuseAreaLight (diffuse.rs:64-84), PointLight (point.rs:52-68), SpotLight
+// (spot.rs:81-106), DistantLight (distant.rs:41-58).  Delta lights return pdf = 1 and a light point
+// with zero normal and zero error bounds (InteractionCommon::default()).
 RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 u, f3* wi, float* pdf, LightSample* ls) {
+    if (lt.kind == RSPT_LIGHT_DIFFUSE_AREA) {
+        TriRec t = load_tri(sc, lt.prim);
+        *ls = tri_sample_ref(sc, lt.prim, t, ref_p, u, pdf);
+        if (*pdf == 0.0f || len2(ls->p - ref_p) == 0.0f) { *pdf = 0.0f; return mkrgb(0.0f); }
+        *wi = normalize(ls->p - ref_p);
+        return light_l(lt, ls->n, -*wi);
+    }
+    ls->p_err = f3{0.0f, 0.0f, 0.0f};
+    ls->n = f3{0.0f, 0.0f, 0.0f};
+    *pdf = 1.0f;
+    if (lt.kind == RSPT_LIGHT_DISTANT) {
+        f3 w{lt.p[0], lt.p[1], lt.p[2]};
+        *wi = w;
+        ls->p = ref_p + w * (2.0f * world_radius(sc));
+        return ldrgb(lt.L);
+    }
+    f3 pl{lt.p[0], lt.p[1], lt.p[2]};
+    *wi = normalize(pl - ref_p);
+    ls->p = pl;
+    float d2 = dist2(pl, ref_p);
+    if (lt.kind == RSPT_LIGHT_POINT) return ldrgb(lt.L) / d2;
+    return ldrgb(lt.L) * spot_falloff(lt, -*wi) / d2;
+}
+// Light::power (diffuse.rs:85-93, point.rs:69-71, spot.rs:107-113, distant.rs:59-62)
+RDEV rgb light_power(const SceneDev& sc, const rspt_light& lt) {
+    if (lt.kind == RSPT_LIGHT_POINT) return ldrgb(lt.L) * (4.0f * RSPT_PI);
+    if (lt.kind == RSPT_LIGHT_SPOT) return ldrgb(lt.L) * 2.0f * RSPT_PI * (1.0f - 0.5f * (lt.p[13] + lt.p[12]));
+    if (lt.kind == RSPT_LIGHT_DISTANT) { float r = world_radius(sc); return ldrgb(lt.L) * RSPT_PI * r * r; }
     TriRec t = load_tri(sc, lt.prim);
-    *ls = tri_sample_ref(sc, lt.prim, t, ref_p, u, pdf);
-    if (*pdf == 0.0f || len2(ls->p - ref_p) == 0.0f) { *pdf = 0.0f; return mkrgb(0.0f); }
-    *wi = normalize(ls->p - ref_p);
-    return light_l(lt, ls->n, -*wi);
+    float factor = lt.two_sided ? 2.0f : 1.0f;
+    return ldrgb(lt.L) * factor * tri_area(t) * RSPT_PI;
 }
 
 // ---- Distribution1D::sample_discrete (sampling.rs:103-142) over a device-resident cdf ----

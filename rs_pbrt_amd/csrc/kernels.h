@@ -341,13 +341,13 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                                 f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
                                 store_ray(pb.ray_sh + p, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, p);
                                 out.shadow = true;
-                                float weight = power_heuristic(light_pdf, scattering_pdf);
-                                c1 = f * li * mkrgb(weight) / light_pdf;
+                                if (light_is_delta(lt)) c1 = f * li / light_pdf;  // integrator.rs:470-471
+                                else c1 = f * li * mkrgb(power_heuristic(light_pdf, scattering_pdf)) / light_pdf;
                                 st |= ST_HAS_C1;
                             }
                         }
-                        // BSDF sample with MIS (integrator.rs:480-568); sampled_type sentinel 0 (Q6)
-                        {
+                        // BSDF sample with MIS (integrator.rs:480-568), area lights only; sampled_type sentinel 0 (Q6)
+                        if (!light_is_delta(lt)) {
                             uint32_t sampled_type = 0;
                             rgb f = bsdf.sample_f(wo, &wi, u_scatter, &scattering_pdf, nonspec, &sampled_type);
                             f = f * mkrgb(absdot(wi, h.sh_n));
@@ -631,11 +631,7 @@ __global__ void k_ld_fixed(SceneDev sc, int power, float* __restrict__ func) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= sc.n_lights) return;
     if (!power) { func[j] = 1.0f; return; }
-    const rspt_light lt = sc.lights[j];
-    TriRec t = load_tri(sc, lt.prim);
-    float factor = lt.two_sided ? 2.0f : 1.0f;
-    rgb pw = ldrgb(lt.L) * factor * tri_area(t) * RSPT_PI;
-    func[j] = lum(pw);
+    func[j] = lum(light_power(sc, sc.lights[j]));
 }
 
 // scene upload helper: build the 48-byte triangle records from the indexed ABI arrays

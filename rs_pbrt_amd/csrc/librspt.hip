@@ -506,10 +506,10 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         if (m.n_bxdfs > 8 || (uint64_t)m.first_bxdf + m.n_bxdfs > d->n_bxdfs) return fail(RSPT_E_INVALID, "material %u: bad bxdf slice", i);
     }
     for (uint32_t i = 0; i < d->n_bxdfs; i++)
-        if (d->bxdfs[i].type < RSPT_BXDF_LAMBERT_R || d->bxdfs[i].type > RSPT_BXDF_LAMBERT_T) return fail(RSPT_E_UNSUPPORTED, "bxdf %u: unsupported type %u", i, d->bxdfs[i].type);
+        if (d->bxdfs[i].type < RSPT_BXDF_LAMBERT_R || d->bxdfs[i].type > RSPT_BXDF_FRESNEL_BLEND) return fail(RSPT_E_UNSUPPORTED, "bxdf %u: unsupported type %u", i, d->bxdfs[i].type);
     for (uint32_t i = 0; i < d->n_lights; i++) {
-        if (d->lights[i].kind != RSPT_LIGHT_DIFFUSE_AREA) return fail(RSPT_E_UNSUPPORTED, "light %u: unsupported kind %u", i, d->lights[i].kind);
-        if (d->lights[i].prim >= d->n_prims) return fail(RSPT_E_INVALID, "light %u: prim out of range", i);
+        if (d->lights[i].kind < RSPT_LIGHT_DIFFUSE_AREA || d->lights[i].kind > RSPT_LIGHT_DISTANT) return fail(RSPT_E_UNSUPPORTED, "light %u: unsupported kind %u", i, d->lights[i].kind);
+        if (d->lights[i].kind == RSPT_LIGHT_DIFFUSE_AREA && d->lights[i].prim >= d->n_prims) return fail(RSPT_E_INVALID, "light %u: prim out of range", i);
     }
     // BVH: child / leaf ranges in bounds, depth <= 64 (the reference's fixed traversal stack, bvh.rs:420)
     if (d->n_nodes) {

@@ -189,6 +189,79 @@ def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.
                                       alpha_x=_alpha(a), alpha_y=_alpha(a))])
 
 
+def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True):  # substrate.rs:62-114
+    kd = np.maximum(np.array(kd, F32), 0); ks = np.maximum(np.array(ks, F32), 0)
+    if not kd.any() and not ks.any():
+        return dict(eta=1.0, lobes=[])
+    au = tr_roughness_to_alpha(uroughness) if remap else F32(uroughness)
+    av = tr_roughness_to_alpha(vroughness) if remap else F32(vroughness)
+    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, alpha_x=_alpha(au), alpha_y=_alpha(av))])
+
+
+def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness=0.1, uroughness=None, vroughness=None,
+         opacity=(1.0,) * 3, index=1.5, remap=True):  # uber.rs:114-259
+    e = F32(index)
+    op = np.maximum(np.array(opacity, F32), 0)
+    t = np.maximum(F32(1) - op, 0).astype(F32)  # (-op + 1).clamp(0, inf)
+    lobes = []
+    eta = 1.0
+    if t.any():
+        lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=t, eta_a=1.0, eta_b=1.0))
+    else:
+        eta = float(e)
+    kd = (op * np.maximum(np.array(kd, F32), 0)).astype(F32)
+    if kd.any():
+        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd))
+    ks = (op * np.maximum(np.array(ks, F32), 0)).astype(F32)
+    if ks.any():
+        ru = roughness if uroughness is None else uroughness
+        rv = roughness if vroughness is None else vroughness
+        au = tr_roughness_to_alpha(ru) if remap else F32(ru)
+        av = tr_roughness_to_alpha(rv) if remap else F32(rv)
+        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, eta_a=1.0, eta_b=e, alpha_x=_alpha(au), alpha_y=_alpha(av)))
+    kr = (op * np.maximum(np.array(kr, F32), 0)).astype(F32)
+    if kr.any():
+        lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=kr, eta_a=1.0, eta_b=e))
+    kt = (op * np.maximum(np.array(kt, F32), 0)).astype(F32)
+    if kt.any():
+        lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=kt, eta_a=1.0, eta_b=e))
+    return dict(eta=eta, lobes=lobes)
+
+
+def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.5,) * 3, roughness=0.1, remap=True):  # translucent.rs:64-189
+    eta = F32(1.5)
+    r = np.maximum(np.array(reflect, F32), 0); t = np.maximum(np.array(transmit, F32), 0)
+    if not r.any() and not t.any():
+        return dict(eta=float(eta), lobes=[])
+    kd = np.maximum(np.array(kd, F32), 0); ks = np.maximum(np.array(ks, F32), 0)
+    lobes = []
+    if kd.any():
+        if r.any():
+            lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=(r * kd).astype(F32)))
+        if t.any():
+            lobes.append(_lobe(type=abi.BXDF_LAMBERT_T, r=(t * kd).astype(F32)))
+    if ks.any() and (r.any() or t.any()):
+        a = tr_roughness_to_alpha(roughness) if remap else F32(roughness)
+        if r.any():
+            lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=(r * ks).astype(F32), eta_a=1.0, eta_b=eta,
+                               alpha_x=_alpha(a), alpha_y=_alpha(a)))
+        if t.any():
+            lobes.append(_lobe(type=abi.BXDF_MICROFACET_T, r=(t * ks).astype(F32), eta_a=1.0, eta_b=eta, alpha_x=_alpha(a), alpha_y=_alpha(a)))
+    return dict(eta=float(eta), lobes=lobes)
+
+
+def rough_glass(kr=(1.0,) * 3, kt=(1.0,) * 3, uroughness=0.1, vroughness=0.1, index=1.5, remap=True):  # glass.rs:83-211, rough branch
+    au = tr_roughness_to_alpha(uroughness) if remap else F32(uroughness)
+    av = tr_roughness_to_alpha(vroughness) if remap else F32(vroughness)
+    lobes = []
+    kr = np.maximum(np.array(kr, F32), 0); kt = np.maximum(np.array(kt, F32), 0)
+    if kr.any():
+        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=kr, eta_a=1.0, eta_b=index, alpha_x=_alpha(au), alpha_y=_alpha(av)))
+    if kt.any():
+        lobes.append(_lobe(type=abi.BXDF_MICROFACET_T, r=kt, eta_a=1.0, eta_b=index, alpha_x=_alpha(au), alpha_y=_alpha(av)))
+    return dict(eta=index, lobes=lobes)
+
+
 # ---------------------------------------------------------------------------------------
 # A scene before BVH build: meshes with per-mesh material / emission
 # ---------------------------------------------------------------------------------------
@@ -199,6 +272,7 @@ class SceneBuilder:
         self.materials = []
         self.nv = 0
         self.any_n = self.any_uv = False
+        self.delta_lights = []  # appended to Scene.lights after the area lights
 
     def add_material(self, m):
         self.materials.append(m)
@@ -223,6 +297,37 @@ class SceneBuilder:
     def add_quad(self, p, material, **kw):
         return self.add_mesh(np.array(p, F32), [[0, 1, 2], [0, 2, 3]], material, **kw)
 
+    def add_point_light(self, p, I):
+        """LightSource "point" (api.rs:773-794, point.rs:30-49): p = from, I = I * scale"""
+        lt = np.zeros((), abi.LIGHT_DT)
+        lt["kind"] = abi.LIGHT_POINT; lt["L"] = np.array(I, F32); lt["p"][:3] = np.array(p, F32)
+        self.delta_lights.append(lt)
+
+    def add_spot_light(self, p_from, p_to, I, coneangle=30.0, conedelta=5.0):
+        """LightSource "spot" (api.rs:795-848, spot.rs:30-66): world_to_light rotates `to - from` onto +z"""
+        d = np.array(p_to, np.float64) - np.array(p_from, np.float64)
+        d /= np.linalg.norm(d)
+        d32 = d.astype(F32)
+        if abs(d32[0]) > abs(d32[1]):  # vec3_coordinate_system geometry.rs:779-794
+            du = np.array([-d32[2], 0, d32[0]], np.float64) / math.sqrt(float(d32[0]) ** 2 + float(d32[2]) ** 2)
+        else:
+            du = np.array([0, d32[2], -d32[1]], np.float64) / math.sqrt(float(d32[1]) ** 2 + float(d32[2]) ** 2)
+        dv = np.cross(d, du)
+        lt = np.zeros((), abi.LIGHT_DT)
+        lt["kind"] = abi.LIGHT_SPOT; lt["L"] = np.array(I, F32); lt["p"][:3] = np.array(p_from, F32)
+        lt["p"][3:12] = np.stack([du, dv, d]).astype(F32).reshape(-1)
+        lt["p"][12] = F32(math.cos(math.radians(coneangle)))
+        lt["p"][13] = F32(math.cos(math.radians(coneangle - conedelta)))
+        self.delta_lights.append(lt)
+
+    def add_distant_light(self, p_from, p_to, L):
+        """LightSource "distant" (api.rs:889-918, distant.rs:25-40): w_light = normalize(from - to)"""
+        w = np.array(p_from, np.float64) - np.array(p_to, np.float64)
+        w /= np.linalg.norm(w)
+        lt = np.zeros((), abi.LIGHT_DT)
+        lt["kind"] = abi.LIGHT_DISTANT; lt["L"] = np.array(L, F32); lt["p"][:3] = w.astype(F32)
+        self.delta_lights.append(lt)
+
     def finish(self, bvh_builder, max_prims_in_node=4):
         """bvh_builder(P (nv,3) f32, tri (nt,3) u32, max_prims) -> (nodes NODE_DT[], ordered u32[])"""
         P = np.ascontiguousarray(np.concatenate(self.P), F32)
@@ -242,9 +347,11 @@ class SceneBuilder:
         prims["mesh"] = tri_mesh[ordered]
         prims["material"] = np.array(self.mesh_material, np.uint32)[tri_mesh[ordered]]
         prims["area_light"] = light_of_tri[ordered]
-        lights = np.zeros(len(lights_in), abi.LIGHT_DT)
+        lights = np.zeros(len(lights_in) + len(self.delta_lights), abi.LIGHT_DT)
         for i, (t, (L, two)) in enumerate(lights_in):
-            lights[i] = (abi.LIGHT_DIFFUSE_AREA, inv[t], L, int(two))
+            lights[i]["kind"] = abi.LIGHT_DIFFUSE_AREA; lights[i]["prim"] = inv[t]; lights[i]["L"] = L; lights[i]["two_sided"] = int(two)
+        for i, lt in enumerate(self.delta_lights):
+            lights[len(lights_in) + i] = lt
         mats = np.zeros(len(self.materials), abi.MATERIAL_DT)
         bx = []
         for i, m in enumerate(self.materials):

@@ -171,3 +171,27 @@ def test_golden_cornell_film(gpu):
     assert np.array_equal(film[:, 3], g["film"][:, 3])
     assert film_rmse(film, g["film"]) < 1e-5
     assert (li == g["li"]).all(axis=2).mean() > 0.75
+
+
+@pytest.mark.parametrize("lights", ["all", "delta", "area"])
+def test_gallery_remaining_materials_and_delta_lights(gpu, oracle, lights):
+    """substrate (FresnelBlend), uber with opacity (specular transmission + Lambert + microfacet +
+    specular lobes), translucent (Lambertian / microfacet transmission), rough glass, Oren-Nayar;
+    point / spot / distant lights next to an area light"""
+    from tests.util import GALLERY_LOOK_AT, gallery
+    sc = gallery(gpu.bvh_build, lights)
+    rd = scenes.make_render_desc(80, 60, 16, GALLERY_LOOK_AT, 60, max_depth=6)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert (li == ref["li"]).all(axis=2).mean() > 0.6
+    assert film_rmse(film, ref["film"]) < 2e-5
+    assert st["nan_samples"] == ref["counters"]["nan_samples"]
+
+
+@pytest.mark.parametrize("strategy", [abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL])
+def test_gallery_light_strategies_with_delta_lights(gpu, oracle, strategy):
+    from tests.util import GALLERY_LOOK_AT, gallery
+    sc = gallery(gpu.bvh_build, "all")
+    rd = scenes.make_render_desc(64, 48, 8, GALLERY_LOOK_AT, 60, max_depth=4, light_strategy=strategy)
+    film, _, _, ref = _render_pair(gpu, oracle, sc, rd, want_li=False)
+    assert film_rmse(film, ref["film"]) < 2e-5

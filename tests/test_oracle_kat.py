@@ -348,3 +348,64 @@ def test_oracle_reproduces_committed_goldens(oracle):
         assert scene.nodes.tobytes() == t["nodes"].tobytes()
         assert oracle.trace(scene, t["rays"]).tobytes() == t["closest"].tobytes()
         assert oracle.trace(scene, t["rays"], any_hit=True).tobytes() == t["any"].tobytes()
+
+
+# ---------------------------------------------------------------- remaining lobes / delta lights
+@pytest.mark.parametrize("mat", ["substrate", "rough_glass", "translucent", "uber"])
+def test_new_lobes_sample_consistency_and_energy(oracle, mat):
+    """sample_f returns exactly f() and pdf() of the sampled direction (Bsdf::sample_f recomputes them,
+    reflection.rs:381-410) and the Monte Carlo albedo stays <= 1 (radiance-mode transmission is scaled
+    by 1/eta^2, so rough glass stays well below)"""
+    m = {"substrate": scenes.substrate((0.5, 0.5, 0.5), (0.4, 0.4, 0.4), 0.1, 0.3), "rough_glass": scenes.rough_glass(uroughness=0.2, vroughness=0.2),
+         "translucent": scenes.translucent(), "uber": scenes.uber(kr=(0.2,) * 3, kt=(0.2,) * 3, opacity=(0.8,) * 3)}[mat]
+    rng = np.random.default_rng(21)
+    acc, n = 0.0, 3000
+    wo = np.array([0.4, -0.1, math.sqrt(1 - 0.17)], F32)
+    for _ in range(n):
+        f, wi, pdf, st = _sample(oracle, m, wo, rng.uniform(0, 1, 2))
+        if pdf > 0:
+            acc += float(f[1]) * abs(float(wi[2])) / pdf
+            if not (st & 16):  # non-specular lobe sampled
+                f2, pdf2 = _f(oracle, m, wo, wi)
+                assert np.allclose(f, f2, rtol=1e-5, atol=1e-7) and abs(pdf - pdf2) <= 1e-4 * pdf
+    assert 0.05 < acc / n <= 1.03
+
+
+def test_fresnel_blend_reciprocity_and_microfacet_transmission_sides(oracle):
+    m = scenes.substrate((0.5, 0.3, 0.2), (0.2, 0.2, 0.2), 0.2, 0.2)
+    for wo, wi in zip(_dirs(20, 31), _dirs(20, 32)):
+        a, _ = _f(oracle, m, wo, wi); b, _ = _f(oracle, m, wi, wo)
+        assert np.allclose(a, b, rtol=3e-4, atol=1e-7)
+    g = scenes.rough_glass(kr=(0, 0, 0), uroughness=0.2, vroughness=0.2)  # MicrofacetTransmission only
+    f, pdf = _f(oracle, g, (0.1, 0.2, 0.97), (0.2, 0.1, 0.97))
+    assert not f.any() and pdf == 0                                        # same hemisphere: no transmission
+    f, pdf = _f(oracle, g, (0.1, 0.2, 0.97), (-0.05, -0.1, -0.99))
+    assert f.min() > 0 and pdf > 0
+
+
+def _light_scene(oracle, kind):
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_quad([(-10, 0, -10), (-10, 0, 10), (10, 0, 10), (10, 0, -10)], m)
+    if kind == "point":
+        sb.add_point_light((0, 2, 0), (8, 8, 8))
+    elif kind == "spot":
+        sb.add_spot_light((0, 2, 0), (0, 0, 0), (8, 8, 8), coneangle=30, conedelta=10)
+    else:
+        sb.add_distant_light((0, 1, 0), (0, 0, 0), (3, 3, 3))
+    return sb.finish(oracle.bvh_build)
+
+
+@pytest.mark.parametrize("kind", ["point", "spot", "distant"])
+def test_delta_lights_analytic_irradiance(oracle, kind):
+    """direct lighting of a diffuse floor under a delta light, max_depth 1 (no interreflection: the floor
+    is the only surface): L = rho/pi * E with E = I cos(theta)/d^2 (point), x falloff (spot), L cos (distant)"""
+    sc = _light_scene(oracle, kind)
+    rd = scenes.make_render_desc(33, 33, 4, ((0, 6, 0.001), (0, 0, 0), (0, 0, 1)), 40, max_depth=1)
+    r = oracle.render(sc, rd, threads=2)
+    rgb = scenes.film_to_rgb(r["film"]).reshape(33, 33, 3)
+    centre = float(rgb[16, 16, 1])  # looking straight down at the point below the light
+    expect = {"point": 0.5 / math.pi * 8 / 4.0, "spot": 0.5 / math.pi * 8 / 4.0, "distant": 0.5 / math.pi * 3}[kind]
+    assert abs(centre - expect) < 0.02 * expect
+    if kind == "spot":
+        assert rgb[0, 0].max() == 0.0  # outside the 30 degree cone

@@ -23,3 +23,36 @@ def film_rmse(film_a, film_b):
 
 def small_soup(builder, n=20000, seed=0x5EED5EED):
     return scenes.triangle_soup(builder, n_tris=n, seed=seed, extent=0.03)
+
+
+def gallery(builder, lights="all"):
+    """A closed room with five slabs carrying the remaining material recipes (substrate, uber with
+    opacity, translucent, rough glass, Oren-Nayar) lit by a small area light plus point / spot /
+    distant lights — exercises FresnelBlend, MicrofacetTransmission, LambertianTransmission,
+    SpecularTransmission inside uber, and the delta-light branch of estimate_direct."""
+    sb = scenes.SceneBuilder()
+    wall = sb.add_material(scenes.matte((0.6, 0.6, 0.6)))
+    mats = [sb.add_material(scenes.substrate((0.5, 0.2, 0.1), (0.3, 0.3, 0.3), 0.05, 0.2)),
+            sb.add_material(scenes.uber((0.3, 0.4, 0.2), (0.3, 0.3, 0.3), (0.1, 0.1, 0.1), (0.2, 0.2, 0.2), roughness=0.15, opacity=(0.7, 0.7, 0.7))),
+            sb.add_material(scenes.translucent((0.4, 0.4, 0.5), (0.3, 0.3, 0.3), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), 0.2)),
+            sb.add_material(scenes.rough_glass(uroughness=0.08, vroughness=0.08)),
+            sb.add_material(scenes.matte((0.5, 0.5, 0.2), sigma=40.0))]
+    q = sb.add_quad
+    q([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], wall)            # floor
+    q([(-5, 6, -5), (5, 6, -5), (5, 6, 5), (-5, 6, 5)], wall)            # ceiling
+    q([(-5, 0, 5), (-5, 6, 5), (5, 6, 5), (5, 0, 5)], wall)              # back
+    q([(-5, 0, -5), (-5, 6, -5), (-5, 6, 5), (-5, 0, 5)], wall)          # left
+    q([(5, 0, -5), (5, 0, 5), (5, 6, 5), (5, 6, -5)], wall)              # right
+    for i, m in enumerate(mats):
+        x = -4.0 + 1.8 * i
+        q([(x, 0.5, 1 + 0.3 * i), (x + 1.4, 0.5, 1 + 0.3 * i), (x + 1.4, 3.0, 2 + 0.3 * i), (x, 3.0, 2 + 0.3 * i)], m)
+    if lights in ("all", "area"):
+        q([(-1, 5.9, -1), (1, 5.9, -1), (1, 5.9, 1), (-1, 5.9, 1)], wall, emit=(6, 6, 6))
+    if lights in ("all", "delta"):
+        sb.add_point_light((3, 4, -3), (40, 30, 20))
+        sb.add_spot_light((-3, 5, -3), (0, 1, 2), (80, 80, 120), coneangle=35, conedelta=10)
+        sb.add_distant_light((1, 3, -2), (0, 0, 0), (0.6, 0.6, 0.5))
+    return sb.finish(builder)
+
+
+GALLERY_LOOK_AT = ((0, 3, -4.8), (0, 2, 2), (0, 1, 0))
