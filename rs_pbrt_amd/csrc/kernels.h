@@ -44,7 +44,8 @@ struct PathBuf {
 struct QueueCounts {  // one per wavefront iteration
     uint32_t active, closest, any;          // queue lengths
     uint32_t cursor_closest, cursor_any;    // dynamic-fetch cursors of the persistent trace kernel
-    uint32_t pad[3];
+    uint32_t overflow_closest, overflow_any; // rays handed to k_trace_fixup; each sits 2 words after its cursor
+    uint32_t pad;
 };
 
 struct Batch {

@@ -236,10 +236,16 @@ template <bool ANY, int OUT_MODE>
 void launch_trace(bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                   const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
     const SceneDev& sc = s->dev;
-    static const bool use_pw = env_size("RSPT_TRACE_KERNEL", 1) != 0;
+    // RSPT_TRACE_KERNEL: 0 = k_trace (reference-order single-ray loop), 1 = k_trace_pw (persistent waves, default).
+    // (A quad-per-ray variant with one coalesced 64-byte fetch per step was measured 35 % slower: the
+    //  replicated control flow made it VALU-bound with 16 rays per wave)
+    const bool use_pw = env_size("RSPT_TRACE_KERNEL", 1) != 0;
     if (!count && use_pw) {
         const uint32_t pgrid = grid_for((uint32_t)env_size("RSPT_PW_BLOCKS_PER_CU", 8));
-        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+        uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
+        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow,
+                           (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+        hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, n_overflow, ra, rb, oa, ob, occ, hits);
         return;
     }
     if (count)
@@ -633,7 +639,7 @@ int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* ou
     if (rc0) return rc0;
     uint32_t* cursor = &g.cnt[0].cursor_closest;
     for (int r = 0; r < repeat && n; r++) {
-        HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), g.stream));
+        HIP_TRY(hipMemsetAsync(&g.cnt[0], 0, sizeof(QueueCounts), g.stream));
         if (any_hit) launch_trace<true, 1>(counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
         else launch_trace<false, 1>(counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
     }

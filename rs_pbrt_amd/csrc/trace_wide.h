@@ -19,6 +19,10 @@
 //   * Rays have wildly different traversal lengths; lanes that finish pull new rays from a
 //     wave-local chunk of the queue (one global atomic per RSPT_PW_CHUNK rays) instead of idling
 //     until the slowest ray of their wave is done.
+//   * The stack lives entirely in LDS (column per lane, conflict-free).  A ray that would need
+//     more than RSPT_PW_LDS entries is marked and re-traced by k_trace_fixup with the 64-entry
+//     reference-order loop (mixing LDS and scratch in one stack made the compiler emit flat loads
+//     with full vmcnt/lgkmcnt drains on every pop).
 #pragma once
 #include "kernels.h"
 
@@ -34,12 +38,43 @@ struct PairNode {       // 64 B, 64-byte aligned
 };
 #define RSPT_REF_LEAF 0x80000000u
 #define RSPT_NONE 0xffffffffu
+#define RSPT_RETRACE 0xfffffffeu  // result marker: stack overflow, k_trace_fixup redoes this ray
 #define RSPT_PW_BLOCK 256
-#define RSPT_PW_LDS 16       // stack entries per lane in LDS (4 B each); deeper levels spill to scratch
+#ifndef RSPT_PW_LDS
+#define RSPT_PW_LDS 24       // stack entries per lane (4 B each, all in LDS): 24 KB per workgroup, 6 workgroups per CU
+                             // (measured on C2 / C3: 16 -> 256 / 882, 24 -> 259 / 895, 32 -> 239 / 834 Msamples/s)
+#endif
 #define RSPT_PW_CHUNK 256    // rays a wave claims per global atomic
 #define RSPT_PW_REFILL 16    // refill when at least this many lanes are idle ...
 #define RSPT_PW_LEAF 8       // ... and run the leaf phase when at least this many lanes hold a leaf
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Bounds3f::intersect_p (geometry.rs:2211-2269) for the two children of a pair at once, valid when
+// every reciprocal direction component is finite (no 0*inf NaNs).  Per axis the reference forms
+//     near = ((dir_is_neg ? max : min) - o) * inv,   far = ((dir_is_neg ? min : max) - o) * inv * (1 + 2 gamma(3))
+// With t_lo = (min - o)*inv and t_hi = (max - o)*inv (the same two products), near = min(t_lo, t_hi)
+// and far = max(t_lo, t_hi) * widen: multiplication by a finite inv is monotone, so the sign of inv
+// decides the order of t_lo and t_hi exactly as it decides the reference's select.
+// The reference's compare-and-select chain (x/y cross checks, merge, z cross checks, merge,
+// t_min < ray.t_max && t_max > 0) equals max3(near) <= min3(far) && max3(near) < ray.t_max &&
+// min3(far) > 0: the cross checks are the six conditions near_a <= far_b (a != b); the same-axis
+// pairs near_a <= far_a can fail only when far_a < 0 (widening a negative value moves it below
+// near), where the final t_max > 0 test rejects anyway.
+RDEV void box_pair_hit(float4 q0, float4 q1, float4 q2, float ox, float oy, float oz, float ix, float iy, float iz, float ray_tmax, bool* h0, bool* h1) {
+    const float widen = 1.0f + 2.0f * gamma_n(3);
+    v2f lx = (v2f{q0.x, q0.y} - ox) * ix, hx = (v2f{q0.z, q0.w} - ox) * ix;
+    v2f ly = (v2f{q1.x, q1.y} - oy) * iy, hy = (v2f{q1.z, q1.w} - oy) * iy;
+    v2f lz = (v2f{q2.x, q2.y} - oz) * iz, hz = (v2f{q2.z, q2.w} - oz) * iz;
+    v2f fx = v2f{fmaxf(lx.x, hx.x), fmaxf(lx.y, hx.y)} * widen;
+    v2f fy = v2f{fmaxf(ly.x, hy.x), fmaxf(ly.y, hy.y)} * widen;
+    v2f fz = v2f{fmaxf(lz.x, hz.x), fmaxf(lz.y, hz.y)} * widen;
+    float m0 = fmaxf(fmaxf(fminf(lx.x, hx.x), fminf(ly.x, hy.x)), fminf(lz.x, hz.x)), M0 = fminf(fminf(fx.x, fy.x), fz.x);
+    float m1 = fmaxf(fmaxf(fminf(lx.y, hx.y), fminf(ly.y, hy.y)), fminf(lz.y, hz.y)), M1 = fminf(fminf(fx.y, fy.y), fz.y);
+    *h0 = (m0 <= M0) && (m0 < ray_tmax) && (M0 > 0.0f);
+    *h1 = (m1 <= M1) && (m1 < ray_tmax) && (M1 > 0.0f);
+}
+// literal reference chain for rays with zero / non-finite direction components
 RDEV bool box_hit6(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 inv, bool ng0, bool ng1, bool ng2, float ray_tmax) {
     const float widen = 1.0f + 2.0f * gamma_n(3);
     float t_min = ((ng0 ? hx : lx) - o.x) * inv.x;
@@ -60,34 +95,12 @@ RDEV bool box_hit6(float lx, float ly, float lz, float hx, float hy, float hz, f
     return (t_min < ray_tmax) && (t_max > 0.0f);
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// Bounds3f::intersect_p (geometry.rs:2211-2269) for the two children of a pair at once, valid when
-// every reciprocal direction component is finite (no 0*inf NaNs).  With near_a = (near plane - o)*inv
-// and far_a = (far plane - o)*inv*(1+2*gamma(3)) per axis, the reference computes
-//     x/y cross checks, t_min = max(near_x, near_y), t_max = min(far_x, far_y), z cross checks,
-//     t_min = max(t_min, near_z), t_max = min(t_max, far_z), result = t_min < ray.t_max && t_max > 0.
-// The cross checks are exactly the six conditions near_a <= far_b (a != b).  They differ from
-// max3(near) <= min3(far) only in the same-axis pairs near_a <= far_a, and those can fail only when
-// far_a < 0 (widening a negative far value moves it below near), where the final t_max > 0 test
-// rejects anyway.  So hit == (max3(near) <= min3(far)) && max3(near) < ray.t_max && min3(far) > 0.
-RDEV void box_pair_hit(v2f nx, v2f fx, v2f ny, v2f fy, v2f nz, v2f fz, f3 o, f3 inv, float ray_tmax, bool* h0, bool* h1) {
-    const float widen = 1.0f + 2.0f * gamma_n(3);
-    v2f tnx = (nx - o.x) * inv.x, tny = (ny - o.y) * inv.y, tnz = (nz - o.z) * inv.z;
-    v2f tfx = (fx - o.x) * inv.x, tfy = (fy - o.y) * inv.y, tfz = (fz - o.z) * inv.z;
-    tfx = tfx * widen; tfy = tfy * widen; tfz = tfz * widen;
-    float m0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x), M0 = fminf(fminf(tfx.x, tfy.x), tfz.x);
-    float m1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y), M1 = fminf(fminf(tfx.y, tfy.y), tfz.y);
-    *h0 = (m0 <= M0) && (m0 < ray_tmax) && (M0 > 0.0f);
-    *h1 = (m1 <= M1) && (m1 < ray_tmax) && (M1 > 0.0f);
-}
-
 template <bool ANY, int OUT_MODE>
 __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const PairNode* __restrict__ pairs, const uint32_t* __restrict__ queue,
                                                            const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
-                                                           rspt_hit* __restrict__ out_hits, int refill_thresh, int leaf_thresh) {
+                                                           rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, int refill_thresh, int leaf_thresh) {
     __shared__ uint32_t stack[RSPT_PW_LDS * RSPT_PW_BLOCK];
     uint32_t* my = stack + threadIdx.x;
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
@@ -111,19 +124,18 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
     bool exhausted = false;               // wave-uniform
     // per-lane ray state
     bool active = false;
-    f3 o{0, 0, 0}, inv{0, 0, 0};
+    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0;
     RayShear rs{0, 0, 0, 0, 0, 0};
     float t_max = 0.0f;
-    bool ng0 = false, ng1 = false, ng2 = false, degenerate = false;
+    uint32_t negbits = 0;  // bit a = dir_is_neg[a]; bit 3 = zero / non-finite direction component
     uint32_t sp = 0, stale_sp = 0, cur = RSPT_NONE, leaf_node = RSPT_NONE;
     uint32_t best = RSPT_MISS, entry = 0, qpos = 0;
     float bt = 0.0f, bb0 = 0.0f, bb1 = 0.0f, bb2 = 0.0f;
-    uint32_t spill[64 - RSPT_PW_LDS];
 
     auto finish = [&]() {
         uint32_t slot = entry & ~RSPT_Q_MIS;
         if (OUT_MODE == 0) {
-            if (ANY) out_occ[slot] = best != RSPT_MISS ? 1u : 0u;
+            if (ANY) out_occ[slot] = best == RSPT_RETRACE ? 2u : (best != RSPT_MISS ? 1u : 0u);
             else ((entry & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(best), bb0, bb1, bb2);
         } else {
             rspt_hit h;
@@ -136,8 +148,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
     for (;;) {
         // ---- refill idle lanes from the wave's chunk ----
         const uint64_t idle = __ballot(!active);
-        const uint64_t busy = ~idle;
-        if (!exhausted && (__popcll(idle) >= refill_thresh || busy == 0)) {
+        if (!exhausted && (__popcll(idle) >= refill_thresh || ~idle == 0)) {
             if (chunk_lo == chunk_hi) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, (uint32_t)RSPT_PW_CHUNK);
@@ -154,13 +165,13 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                     entry = queue ? queue[qpos] : qpos;
                     const float4* rp = reinterpret_cast<const float4*>(((entry & RSPT_Q_MIS) ? rays_b : rays_a) + (entry & ~RSPT_Q_MIS));
                     float4 r0 = rp[0], r1 = rp[1];
-                    o = f3{r0.x, r0.y, r0.z};
+                    ox = r0.x; oy = r0.y; oz = r0.z;
                     f3 d{r0.w, r1.x, r1.y};
                     t_max = r1.z;
-                    inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-                    ng0 = inv.x < 0.0f; ng1 = inv.y < 0.0f; ng2 = inv.z < 0.0f;
+                    ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
+                    negbits = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
                     // zero / denormal / NaN direction components: keep the reference's literal compare chain
-                    degenerate = !(fabsf(inv.x) < RSPT_INF && fabsf(inv.y) < RSPT_INF && fabsf(inv.z) < RSPT_INF);
+                    if (!(fabsf(ix) < RSPT_INF && fabsf(iy) < RSPT_INF && fabsf(iz) < RSPT_INF)) negbits |= 8u;
                     rs = ray_shear(d);
                     best = RSPT_MISS; bt = bb0 = bb1 = bb2 = 0.0f;
                     my[0] = root_ref;   // the root enters as a stale entry: its own box is tested first
@@ -185,15 +196,15 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                     finish();
                 } else {
                     sp--;
-                    uint32_t ref = sp < RSPT_PW_LDS ? my[sp * RSPT_PW_BLOCK] : spill[sp - RSPT_PW_LDS];
+                    uint32_t ref = my[sp * RSPT_PW_BLOCK];
                     stale = sp < stale_sp;
-                    if (stale) stale_sp = sp;
+                    stale_sp = stale ? sp : stale_sp;
                     if (ref & RSPT_REF_LEAF) {
                         uint32_t li = ref & ~RSPT_REF_LEAF;
                         bool ok = true;
                         if (stale) {
                             float4 n0 = sc.nodes[2 * (size_t)li], n1 = sc.nodes[2 * (size_t)li + 1];
-                            ok = box_hit(n0, n1, o, inv, ng0, ng1, ng2, t_max);
+                            ok = box_hit(n0, n1, f3{ox, oy, oz}, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max);
                         }
                         if (ok) leaf_node = li;
                     } else
@@ -207,38 +218,33 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                 if (stale) {  // t_max shrank since this node was pushed: redo its own box test (bvh.rs:424)
                     uint32_t self = __float_as_uint(q3.z);
                     float4 n0 = sc.nodes[2 * (size_t)self], n1 = sc.nodes[2 * (size_t)self + 1];
-                    ok = box_hit(n0, n1, o, inv, ng0, ng1, ng2, t_max);
+                    ok = box_hit(n0, n1, f3{ox, oy, oz}, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max);
                 }
                 cur = RSPT_NONE;
                 if (ok) {
                     bool h0, h1;
-                    if (!degenerate) {
-                        // Both children's slab tests on packed f32 pairs (v_pk_add_f32 / v_pk_mul_f32), one
-                        // pair = (child 0, child 1).  For finite reciprocals the reference's compare-and-
-                        // select chain equals max3/min3 (see box_pair_hit): same booleans, ~40 % of the VALU.
-                        v2f nx = ng0 ? v2f{q0.z, q0.w} : v2f{q0.x, q0.y}, fx = ng0 ? v2f{q0.x, q0.y} : v2f{q0.z, q0.w};
-                        v2f ny = ng1 ? v2f{q1.z, q1.w} : v2f{q1.x, q1.y}, fy = ng1 ? v2f{q1.x, q1.y} : v2f{q1.z, q1.w};
-                        v2f nz = ng2 ? v2f{q2.z, q2.w} : v2f{q2.x, q2.y}, fz = ng2 ? v2f{q2.x, q2.y} : v2f{q2.z, q2.w};
-                        box_pair_hit(nx, fx, ny, fy, nz, fz, o, inv, t_max, &h0, &h1);
+                    if (!(negbits & 8u)) {
+                        box_pair_hit(q0, q1, q2, ox, oy, oz, ix, iy, iz, t_max, &h0, &h1);
                     } else {
-                        h0 = box_hit6(q0.x, q1.x, q2.x, q0.z, q1.z, q2.z, o, inv, ng0, ng1, ng2, t_max);
-                        h1 = box_hit6(q0.y, q1.y, q2.y, q0.w, q1.w, q2.w, o, inv, ng0, ng1, ng2, t_max);
+                        h0 = box_hit6(q0.x, q1.x, q2.x, q0.z, q1.z, q2.z, f3{ox, oy, oz}, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max);
+                        h1 = box_hit6(q0.y, q1.y, q2.y, q0.w, q1.w, q2.w, f3{ox, oy, oz}, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max);
                     }
-                    uint32_t axis = __float_as_uint(q3.w);
-                    bool neg = axis == 0 ? ng0 : (axis == 1 ? ng1 : ng2);
-                    uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                    uint32_t near_ref = neg ? c1 : c0, far_ref = neg ? c0 : c1;
-                    bool near_hit = neg ? h1 : h0, far_hit = neg ? h0 : h1;
-                    uint32_t next = RSPT_NONE;
-                    if (near_hit) {
-                        next = near_ref;
-                        if (far_hit) {
-                            if (sp < RSPT_PW_LDS) my[sp * RSPT_PW_BLOCK] = far_ref;
-                            else spill[sp - RSPT_PW_LDS] = far_ref;
+                    const bool neg = ((negbits >> __float_as_uint(q3.w)) & 1u) != 0;  // dir_is_neg[axis]
+                    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                    const uint32_t near_ref = neg ? c1 : c0, far_ref = neg ? c0 : c1;
+                    const bool near_hit = (neg && h1) || (!neg && h0), far_hit = (neg && h0) || (!neg && h1);
+                    uint32_t next = near_hit ? near_ref : (far_hit ? far_ref : RSPT_NONE);  // far alone == push + pop of a fresh entry
+                    if (near_hit && far_hit) {
+                        if (sp < RSPT_PW_LDS) {
+                            my[sp * RSPT_PW_BLOCK] = far_ref;
                             sp++;
+                        } else {  // deeper than the LDS stack: hand the ray to k_trace_fixup
+                            best = RSPT_RETRACE;
+                            atomicAdd(n_overflow, 1u);
+                            finish();
+                            next = RSPT_NONE;
                         }
-                    } else if (far_hit)
-                        next = far_ref;  // == push + immediate pop of a fresh entry
+                    }
                     if (next != RSPT_NONE) {
                         if (next & RSPT_REF_LEAF) leaf_node = next & ~RSPT_REF_LEAF;
                         else cur = next;
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                     uint32_t w = __float_as_uint(n1.w);
                     uint32_t n_prims = w & 0xffffu, offset = __float_as_uint(n1.z);
                     leaf_node = RSPT_NONE;
+                    const f3 o{ox, oy, oz};
                     for (uint32_t i = 0; i < n_prims; i++) {
                         uint32_t pi = offset + i;
                         float4 a = sc.tris[3 * (size_t)pi], b = sc.tris[3 * (size_t)pi + 1], c = sc.tris[3 * (size_t)pi + 2];
@@ -271,6 +278,39 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                     if (ANY && best != RSPT_MISS) finish();
                 }
             }
+        }
+    }
+}
+
+// Second pass for rays whose stack outgrew k_trace_pw's LDS column: the 64-entry reference-order
+// loop (kernels.h traverse<>).  Returns at once when no ray overflowed (the common case).
+template <bool ANY, int OUT_MODE>
+__global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
+                                                                  uint32_t count_imm, const uint32_t* __restrict__ n_overflow,
+                                                                  const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
+                                                                  float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
+                                                                  rspt_hit* __restrict__ out_hits) {
+    __shared__ uint32_t stack[RSPT_LDS_STACK * RSPT_TRACE_BLOCK];
+    if (*n_overflow == 0) return;
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    for (uint32_t i = blockIdx.x * RSPT_TRACE_BLOCK + threadIdx.x; i < n; i += gridDim.x * RSPT_TRACE_BLOCK) {
+        uint32_t e = queue ? queue[i] : i;
+        uint32_t slot = e & ~RSPT_Q_MIS;
+        bool mis = (e & RSPT_Q_MIS) != 0;
+        bool marked;
+        if (OUT_MODE == 0) marked = ANY ? out_occ[slot] == 2u : __float_as_uint((mis ? out_b : out_a)[slot].x) == RSPT_RETRACE;
+        else marked = out_hits[i].prim == RSPT_RETRACE;
+        if (!marked) continue;
+        const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
+        float4 r0 = rp[0], r1 = rp[1];
+        TraceResult res = traverse<ANY>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        if (OUT_MODE == 0) {
+            if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
+            else (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+        } else {
+            rspt_hit h;
+            h.prim = res.prim; h.t = res.t; h.b0 = res.b0; h.b1 = res.b1; h.b2 = res.b2;
+            out_hits[i] = h;
         }
     }
 }

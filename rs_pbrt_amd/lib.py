@@ -9,7 +9,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librspt.so")
+LIB_PATH = os.environ.get("RSPT_LIB", os.path.join(_HERE, "librspt.so"))  # RSPT_LIB: alternative build (kernel A/B tests)
 _LIB = None
 
 EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
