@@ -253,9 +253,11 @@ int rspt_dev_free(void* p);
 int rspt_dev_upload(void* dst_dev, const void* src_host, uint64_t bytes);
 int rspt_dev_download(void* dst_host, const void* src_dev, uint64_t bytes);
 
-/* Counters of the last rspt_trace_device / rspt_render when the environment has
- * RSPT_COUNTERS=1: out[0] = BVH nodes fetched, out[1] = triangles tested. */
-int rspt_last_counters(uint64_t out[2]);
+/* Diagnostics of the last rspt_trace_device call: out[0] = BVH nodes fetched, out[1] = triangles
+ * tested (both only when the environment has RSPT_COUNTERS=1; also valid after rspt_render),
+ * out[2] = rays of the last launch whose traversal stack outgrew the persistent kernel's LDS
+ * column and were redone by the 64-entry reference-order loop. */
+int rspt_last_counters(uint64_t out[3]);
 
 /* Host-side helper for callers that do not bring rs_pbrt's own accelerator (bench, tests,
  * tools).  Replaces: BVHAccel::new with SplitMethod::SAH over Triangle shapes

@@ -672,11 +672,14 @@ int rspt_trace(rspt_scene_t s, const rspt_ray* rays, uint64_t n, rspt_hit* out, 
 }
 
 // counters of the last rspt_trace_device / rspt_render when RSPT_COUNTERS=1: out[0] nodes visited, out[1] triangles tested
-int rspt_last_counters(uint64_t out[2]) {
-    if (!g.inited || !g.totals) return fail(RSPT_E_INVALID, "no counters");
+int rspt_last_counters(uint64_t out[3]) {
+    if (!g.inited || !g.totals || !g.cnt) return fail(RSPT_E_INVALID, "no counters");
     unsigned long long t[2];
     HIP_TRY(hipMemcpy(t, g.totals, sizeof t, hipMemcpyDeviceToHost));
+    QueueCounts c0;
+    HIP_TRY(hipMemcpy(&c0, g.cnt, sizeof c0, hipMemcpyDeviceToHost));
     out[0] = t[0]; out[1] = t[1];
+    out[2] = (uint64_t)c0.overflow_closest;  // rspt_trace_device keeps its counters in slot 0
     return RSPT_OK;
 }
 

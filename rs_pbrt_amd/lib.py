@@ -180,6 +180,7 @@ def trace_device(dscene, rays_buf, n, hits_buf, any_hit=False, repeat=1):
 
 
 def last_counters():
-    c = (C.c_uint64 * 2)()
+    """(nodes fetched, triangles tested, rays re-traced after LDS stack overflow) of the last trace_device"""
+    c = (C.c_uint64 * 3)()
     _check(lib().rspt_last_counters(C.addressof(c)))
-    return int(c[0]), int(c[1])
+    return int(c[0]), int(c[1]), int(c[2])

@@ -125,3 +125,48 @@ def test_large_batch_sorted_properties(gpu, soup):
     assert np.array_equal(c2["prim"], c["prim"][hit][:100000]) and np.array_equal(c2["t"], c["t"][hit][:100000])
     r2["t_max"] = c["t"][hit][:100000] * np.float32(0.9999)
     assert (gpu.trace(ds, r2)["prim"] == abi.MISS).all()
+
+
+def test_deep_bvh_stack_overflow_fixup(gpu, oracle):
+    """a chain-like BVH (exponentially spaced slabs) drives the traversal stack past the persistent
+    kernel's 24-entry LDS column: those rays are redone by the 64-entry loop and must still be
+    bit-identical to the reference order"""
+    n = 30  # ratio 16 > 12 SAH buckets: every split isolates the farthest slab, so the tree is a chain
+    xs = (16.0 ** np.arange(n)).astype(np.float32)
+    P = np.zeros((n, 3, 3), np.float32)
+    P[:, :, 0] = xs[:, None]
+    P[:, 0, 1:] = (-4, -4); P[:, 1, 1:] = (4, -4); P[:, 2, 1:] = (0, 5)
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_mesh(P.reshape(-1, 3), np.arange(3 * n).reshape(-1, 3), m)
+    sc = sb.finish(gpu.bvh_build, max_prims_in_node=1)
+    depth = 0
+    stack = [(0, 1)]
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        if sc.nodes["n_prims"][i] == 0:
+            stack += [(i + 1, d + 1), (int(sc.nodes["offset"][i]), d + 1)]
+    assert 28 <= depth <= 64
+    rng = np.random.default_rng(8)
+    k = 20000
+    rays = np.zeros(k, abi.RAY_DT)
+    rays["o"] = np.stack([np.full(k, -1.0), rng.uniform(-1, 1, k), rng.uniform(-1, 1, k)], 1).astype(np.float32)
+    rays["o"][: k // 2, 0] = xs[-1] * 1.5                      # half of them travel in -x
+    tgt = np.stack([np.where(np.arange(k) < k // 2, -1.0, xs[-1] * 1.5), rng.uniform(-1, 1, k), rng.uniform(-1, 1, k)], 1)
+    d = tgt - rays["o"]
+    rays["d"] = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32)
+    rays["t_max"] = np.inf
+    ds = gpu.DeviceScene(sc)
+    try:
+        buf = gpu.DeviceBuffer(rays.nbytes); buf.upload(rays)
+        out = gpu.DeviceBuffer(k * abi.HIT_DT.itemsize)
+        for any_hit in (False, True):
+            gpu.trace_device(ds, buf, k, out, any_hit=any_hit)
+            got = out.download(abi.HIT_DT, k)
+            assert got.tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
+            if not any_hit:
+                assert gpu.last_counters()[2] > 0  # the fix-up pass really ran
+        buf.free(); out.free()
+    finally:
+        ds.close()

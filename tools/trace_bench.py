@@ -39,7 +39,7 @@ for name, rays in sets.items():
     for any_hit in ((True,) if name == "shadow" else (False, True)):
         os.environ["RSPT_COUNTERS"] = "1"
         lib.trace_device(ds, rb, len(rays), hb, any_hit=any_hit, repeat=1)
-        nodes, tris = lib.last_counters()
+        nodes, tris, _ = lib.last_counters()
         ref = hb.download(abi.HIT_DT, len(rays)) if args.check else None
         os.environ["RSPT_COUNTERS"] = "0"
         ms = lib.trace_device(ds, rb, len(rays), hb, any_hit=any_hit, repeat=args.repeat)
