@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 2
+#define RSPT_ABI_VERSION 3
 
 /* error codes */
 #define RSPT_OK 0
@@ -145,15 +145,23 @@ typedef struct {
     const rspt_light* lights;       uint32_t n_lights;
 } rspt_scene_desc;
 
-/* Sobol' generator matrices owned by the host (src/core/sobolmatrices.rs:5-7,
- * :53463, :54155).  vdc rows are zero-padded to 52 entries. */
+/* Sampler tables owned by the host.
+ * Sobol': generator matrices (src/core/sobolmatrices.rs:5-7, :53463, :54155); vdc rows are
+ * zero-padded to 52 entries.  May be NULL when sampler_kind is not SOBOL.
+ * Halton: RADICAL_INVERSE_PERMUTATIONS (src/samplers/halton.rs:19-26, built by
+ * compute_radical_inverse_permutations, src/core/lowdiscrepancy.rs:2165-2187): the digit
+ * permutation of the i-th prime starts at the sum of the primes before it; a prefix covering
+ * the dimensions a render can reach (5 + 8 per bounce) is enough.  NULL unless HALTON. */
 typedef struct {
     const uint32_t* sobol32;   /* [1024*52]  SOBOL_MATRICES_32          */
     const uint64_t* vdc;       /* [25*52]    VD_C_SOBOL_MATRICES        */
     const uint64_t* vdc_inv;   /* [26*52]    VD_C_SOBOL_MATRICES_INV    */
+    const uint16_t* halton_perms;
+    uint64_t n_halton_perms;   /* entries available in halton_perms     */
 } rspt_sampler_tables;
 
-enum { RSPT_SAMPLER_SOBOL = 1 };          /* src/samplers/sobol.rs                   */
+enum { RSPT_SAMPLER_SOBOL = 1,            /* src/samplers/sobol.rs                   */
+       RSPT_SAMPLER_HALTON = 2 };         /* src/samplers/halton.rs (the reference's default, api.rs:526) */
 enum { RSPT_LIGHTS_UNIFORM = 0, RSPT_LIGHTS_POWER = 1, RSPT_LIGHTS_SPATIAL = 2 };
                                            /* src/core/lightdistrib.rs:393-418         */
 
@@ -171,8 +179,8 @@ typedef struct {
     float camera_to_world[16];     /* static camera_to_world.start_transform.m        */
     float lens_radius, focal_distance;
     float shutter_open, shutter_close;
-    uint32_t sampler_kind;         /* RSPT_SAMPLER_SOBOL                              */
-    int64_t spp;                   /* already rounded up to 2^k (sobol.rs:38-45)      */
+    uint32_t sampler_kind;         /* RSPT_SAMPLER_*                                  */
+    int64_t spp;                   /* Sobol': already rounded up to 2^k (sobol.rs:38-45) */
     uint32_t max_depth;            /* path.rs:30                                      */
     float rr_threshold;            /* path.rs:31                                      */
     uint32_t light_strategy;       /* RSPT_LIGHTS_*  (uniform is forced for 1 light,
@@ -182,6 +190,7 @@ typedef struct {
      * this process renders tiles whose (morton_rank / tile_chunk) % shard_count ==
      * shard_index.  shard_count = 1 renders everything. */
     uint32_t shard_index, shard_count, tile_chunk;
+    uint32_t sample_at_pixel_center; /* HaltonSampler "samplepixelcenter" (halton.rs:163-172) */
     rspt_sampler_tables tables;
 } rspt_render_desc;
 

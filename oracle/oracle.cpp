@@ -17,9 +17,26 @@ uint64_t orc_sobol_index(const rspt_sampler_tables* t, uint32_t m, uint64_t fram
 float orc_sobol_sample(const rspt_sampler_tables* t, int64_t index, int dim) {
     return sobol_sample_float(SobolTables{t->sobol32, t->vdc, t->vdc_inv}, index, dim, 0);
 }
+// RADICAL_INVERSE_PERMUTATIONS for the first n_dims primes; returns the entry count (out may be NULL)
+uint64_t orc_halton_permutations(int n_dims, uint16_t* out) {
+    std::vector<uint16_t> p = radical_inverse_permutations(n_dims);
+    if (out) std::memcpy(out, p.data(), p.size() * sizeof(uint16_t));
+    return p.size();
+}
+uint32_t orc_pcg32_next(uint64_t* state, uint64_t inc) { Rng r; r.state = *state; r.inc = inc; uint32_t v = r.uniform_uint32(); *state = r.state; return v; }
+// HaltonSampler::{get_index_for_sample, sample_dimension} for pixel (px, py)
+uint64_t orc_halton_index(const rspt_render_desc* rd, int32_t px, int32_t py, uint64_t sample_num) {
+    HaltonSampler h(rd->spp, rd->sample_bounds, rd->sample_at_pixel_center != 0, rd->tables.halton_perms, rd->tables.n_halton_perms);
+    h.px = px; h.py = py;
+    return h.get_index_for_sample(sample_num);
+}
+float orc_halton_sample(const rspt_render_desc* rd, uint64_t index, int dim) {
+    HaltonSampler h(rd->spp, rd->sample_bounds, rd->sample_at_pixel_center != 0, rd->tables.halton_perms, rd->tables.n_halton_perms);
+    return h.sample_dimension(index, dim);
+}
 // camera samples of one pixel sample: out = p_film.xy, time, p_lens.xy
 void orc_camera_sample(const rspt_render_desc* rd, int32_t px, int32_t py, int64_t s, float out[5]) {
-    SobolSampler sp(SobolTables{rd->tables.sobol32, rd->tables.vdc, rd->tables.vdc_inv}, rd->spp, rd->sample_bounds);
+    Sampler sp(*rd);
     sp.start_pixel(px, py);
     for (int64_t i = 0; i < s; i++) sp.start_next_sample();
     P2 f = sp.get_2d(); out[0] = (float)px + f.x; out[1] = (float)py + f.y;

@@ -80,6 +80,7 @@ struct SobolSampler {
     }
 };
 
+// (HaltonSampler and the sampler facade follow the radical-inverse helpers below)
 // ---- radical inverse: src/core/lowdiscrepancy.rs:770-787,1082-1096,1126-1135 ----
 static inline uint32_t reverse_bits_32(uint32_t n) {
     n = (n << 16) | (n >> 16);
@@ -93,10 +94,24 @@ static inline uint64_t reverse_bits_64(uint64_t n) {
     uint64_t n0 = reverse_bits_32((uint32_t)n), n1 = reverse_bits_32((uint32_t)(n >> 32));
     return (n0 << 32) | n1;
 }
+// PRIMES / PRIME_SUMS (lowdiscrepancy.rs:31-760): the first 1000 primes and their prefix sums
+struct PrimeTables {
+    std::vector<uint32_t> primes, sums;
+    PrimeTables() {
+        for (uint32_t v = 2; primes.size() < 1000; v++) {
+            bool is_p = true;
+            for (uint32_t d = 2; d * d <= v; d++) if (v % d == 0) { is_p = false; break; }
+            if (is_p) primes.push_back(v);
+        }
+        uint32_t acc = 0;
+        for (uint32_t p : primes) { sums.push_back(acc); acc += p; }
+    }
+};
+static inline const PrimeTables& prime_tables() { static PrimeTables t; return t; }
+// radical_inverse: lowdiscrepancy.rs:1126-2160 (base 2 via bit reversal, others radical_inverse_specialized :1082-1096)
 static inline Float radical_inverse(int base_index, uint64_t a) {
-    static const int primes[5] = {2, 3, 5, 7, 11};
     if (base_index == 0) return (Float)reverse_bits_64(a) * 0x1.0p-64f;
-    int base = primes[base_index];
+    uint64_t base = prime_tables().primes[base_index];
     Float inv_base = 1.0f / (Float)base;
     uint64_t reversed = 0;
     Float inv_base_n = 1.0f;
@@ -108,6 +123,149 @@ static inline Float radical_inverse(int base_index, uint64_t a) {
     }
     return std::fmin((Float)reversed * inv_base_n, FLOAT_ONE_MINUS_EPSILON);
 }
+// scrambled_radical_inverse_specialized: lowdiscrepancy.rs:1101-1122
+static inline Float scrambled_radical_inverse(int base_index, uint64_t a, const uint16_t* perm) {
+    uint64_t base = prime_tables().primes[base_index];
+    Float inv_base = 1.0f / (Float)base;
+    uint64_t reversed = 0;
+    Float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base, digit = a - next * base;
+        reversed = reversed * base + perm[digit];
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return std::fmin(inv_base_n * ((Float)reversed + inv_base * (Float)perm[0] / (1.0f - inv_base)), FLOAT_ONE_MINUS_EPSILON);
+}
+// inverse_radical_inverse: lowdiscrepancy.rs:788-797
+static inline uint64_t inverse_radical_inverse(uint64_t base, uint64_t inverse, uint64_t n_digits) {
+    uint64_t index = 0;
+    for (uint64_t i = 0; i < n_digits; i++) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+// PCG32: src/core/rng.rs:15-83 (default state and stream, no set_sequence: halton.rs:19-26)
+struct Rng {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    uint32_t uniform_uint32() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18) ^ old) >> 27);
+        uint32_t rot = (uint32_t)(old >> 59);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    uint32_t uniform_uint32_bounded(uint32_t b) { // Q2: threshold = lowest set bit of b, not (-b) % b
+        uint32_t threshold = (~b + 1u) & b;
+        for (;;) {
+            uint32_t r = uniform_uint32();
+            if (r >= threshold) return r % b;
+        }
+    }
+};
+// compute_radical_inverse_permutations (lowdiscrepancy.rs:2165-2187) with shuffle (sampling.rs:200-212),
+// for the first n_dims primes (the RNG stream is sequential over the primes, so a prefix is exact)
+static inline std::vector<uint16_t> radical_inverse_permutations(int n_dims) {
+    const PrimeTables& pt = prime_tables();
+    std::vector<uint16_t> perms;
+    Rng rng;
+    for (int i = 0; i < n_dims; i++) {
+        size_t p0 = perms.size();
+        uint32_t prime = pt.primes[i];
+        for (uint32_t j = 0; j < prime; j++) perms.push_back((uint16_t)j);
+        for (int32_t k = 0; k < (int32_t)prime; k++) {
+            int32_t other = k + (int32_t)rng.uniform_uint32_bounded((uint32_t)((int32_t)prime - k));
+            std::swap(perms[p0 + k], perms[p0 + other]);
+        }
+    }
+    return perms;
+}
+
+// ---- HaltonSampler: src/samplers/halton.rs ----
+static inline int64_t mod_t(int64_t a, int64_t b) { int64_t r = a - (a / b) * b; return r < 0 ? r + b : r; } // pbrt.rs:127-135
+static inline void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y) { // halton.rs:39-52
+    if (b == 0) { *x = 1; *y = 0; return; }
+    int64_t d = (int64_t)a / (int64_t)b, xp = 0, yp = 0;
+    extended_gcd(b, a % b, &xp, &yp);
+    *x = yp; *y = xp - (d * yp);
+}
+static inline uint64_t multiplicative_inverse(int64_t a, int64_t n) { int64_t x = 0, y = 0; extended_gcd((uint64_t)a, (uint64_t)n, &x, &y); return (uint64_t)mod_t(x, n); }
+struct HaltonSampler {
+    static const int32_t K_MAX_RESOLUTION = 128;
+    int64_t spp;
+    int32_t base_scales[2], base_exponents[2];
+    uint64_t sample_stride, mult_inverse[2];
+    bool sample_at_pixel_center;
+    const uint16_t* perms; uint64_t n_perms;
+    int64_t dimension = 0; uint64_t interval_sample_index = 0; int32_t px = 0, py = 0; int64_t cur_sample = 0;
+    HaltonSampler(int64_t spp_, const int32_t sb[4], bool center, const uint16_t* perms_, uint64_t n_perms_)
+        : spp(spp_), sample_at_pixel_center(center), perms(perms_), n_perms(n_perms_) { // halton.rs:80-131
+        int32_t res[2] = {sb[2] - sb[0], sb[3] - sb[1]};
+        for (int i = 0; i < 2; i++) {
+            int32_t base = i == 0 ? 2 : 3, scale = 1, exp = 0;
+            while (scale < std::min(res[i], K_MAX_RESOLUTION)) { scale *= base; exp += 1; }
+            base_scales[i] = scale; base_exponents[i] = exp;
+        }
+        sample_stride = (uint64_t)base_scales[0] * (uint64_t)base_scales[1];
+        mult_inverse[0] = multiplicative_inverse(base_scales[1], base_scales[0]);
+        mult_inverse[1] = multiplicative_inverse(base_scales[0], base_scales[1]);
+    }
+    uint64_t get_index_for_sample(uint64_t sample_num) const { // halton.rs:173-214 (the per-pixel cache recomputed)
+        uint64_t offset = 0;
+        if (sample_stride > 1) {
+            int64_t pm[2] = {mod_t(px, K_MAX_RESOLUTION), mod_t(py, K_MAX_RESOLUTION)};
+            for (int i = 0; i < 2; i++) {
+                uint64_t dim_offset = inverse_radical_inverse(i == 0 ? 2 : 3, (uint64_t)pm[i], (uint64_t)base_exponents[i]);
+                offset += dim_offset * (sample_stride / (uint64_t)base_scales[i]) * mult_inverse[i];
+            }
+            offset %= sample_stride;
+        }
+        return offset + sample_num * sample_stride;
+    }
+    Float sample_dimension(uint64_t index, int64_t dim) const { // halton.rs:215-226
+        if (sample_at_pixel_center && (dim == 0 || dim == 1)) return 0.5f;
+        if (dim == 0) return radical_inverse(0, index >> (uint64_t)base_exponents[0]);
+        if (dim == 1) return radical_inverse(1, index / (uint64_t)base_scales[1]);
+        return scrambled_radical_inverse((int)dim, index, perms + prime_tables().sums[dim]);
+    }
+};
+
+// Sampler facade (src/core/sampler.rs:18-203) over the two GlobalSamplers in scope
+struct Sampler {
+    int kind;
+    SobolSampler sobol;
+    HaltonSampler halton;
+    Sampler(const rspt_render_desc& rd)
+        : kind((int)rd.sampler_kind), sobol(SobolTables{rd.tables.sobol32, rd.tables.vdc, rd.tables.vdc_inv}, rd.spp, rd.sample_bounds),
+          halton(rd.spp, rd.sample_bounds, rd.sample_at_pixel_center != 0, rd.tables.halton_perms, rd.tables.n_halton_perms) {}
+    bool is_halton() const { return kind == RSPT_SAMPLER_HALTON; }
+    int64_t cur_sample() const { return is_halton() ? halton.cur_sample : sobol.cur_sample; }
+    void start_pixel(int32_t x, int32_t y) {
+        if (!is_halton()) { sobol.start_pixel(x, y); return; }
+        halton.px = x; halton.py = y; halton.cur_sample = 0; halton.dimension = 0;
+        halton.interval_sample_index = halton.get_index_for_sample(0);
+    }
+    Float get_1d() {
+        if (!is_halton()) return sobol.get_1d();
+        Float r = halton.sample_dimension(halton.interval_sample_index, halton.dimension); halton.dimension += 1; return r;
+    }
+    P2 get_2d() {
+        if (!is_halton()) return sobol.get_2d();
+        Float y = halton.sample_dimension(halton.interval_sample_index, halton.dimension + 1);
+        Float x = halton.sample_dimension(halton.interval_sample_index, halton.dimension);
+        halton.dimension += 2;
+        return P2{x, y};
+    }
+    bool start_next_sample() { // halton.rs:333-343
+        if (!is_halton()) return sobol.start_next_sample();
+        halton.dimension = 0;
+        halton.interval_sample_index = halton.get_index_for_sample((uint64_t)halton.cur_sample + 1);
+        halton.cur_sample += 1;
+        return halton.cur_sample < halton.spp;
+    }
+};
 
 // ---- Distribution1D: src/core/sampling.rs:17-147 ----
 struct Distribution1D {
@@ -333,7 +491,7 @@ static inline Spec estimate_direct(RenderCtx& cx, const Interaction& it, const B
     return ld;
 }
 
-static inline Spec uniform_sample_one_light(RenderCtx& cx, const Interaction& it, const Bsdf& bsdf, SobolSampler& sampler, const Distribution1D& distrib, Counters* c) {
+static inline Spec uniform_sample_one_light(RenderCtx& cx, const Interaction& it, const Bsdf& bsdf, Sampler& sampler, const Distribution1D& distrib, Counters* c) {
     uint32_t nl = cx.scene->d.n_lights;
     if (nl == 0) return Spec();
     Float pdf = 0.0f;
@@ -345,7 +503,7 @@ static inline Spec uniform_sample_one_light(RenderCtx& cx, const Interaction& it
 }
 
 // ---- PathIntegrator::li: src/integrators/path.rs:59-282 ----
-static inline Spec path_li(RenderCtx& cx, const Ray& r, SobolSampler& sampler, Counters* c) {
+static inline Spec path_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counters* c) {
     const Scene& sc = *cx.scene;
     Spec l, beta(1.0f);
     Ray ray = r;
@@ -494,7 +652,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
     int cw = rd.crop_px[2] - rd.crop_px[0], ch = rd.crop_px[3] - rd.crop_px[1];
     std::vector<Counters> tc((size_t)std::max(1, num_threads));
     auto worker = [&](int tid) {
-        SobolSampler sampler(cx.T, rd.spp, rd.sample_bounds);
+        Sampler sampler(rd);
         Counters& c = tc[tid];
         for (;;) {
             size_t k = next.fetch_add(1);
@@ -522,7 +680,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         if (l.has_nans()) { l = Spec(0.0f); c.nan_samples++; } // integrator.rs:165-173 (Q1)
                         if (li_rgb && px >= rd.crop_px[0] && px < rd.crop_px[2] && py >= rd.crop_px[1] && py < rd.crop_px[3]) {
                             size_t pix = (size_t)(py - rd.crop_px[1]) * cw + (size_t)(px - rd.crop_px[0]);
-                            float* o = li_rgb + (pix * (size_t)rd.spp + (size_t)sampler.cur_sample) * 3;
+                            float* o = li_rgb + (pix * (size_t)rd.spp + (size_t)sampler.cur_sample()) * 3;
                             o[0] = l.c[0]; o[1] = l.c[1]; o[2] = l.c[2];
                         }
                         ft.add_sample(rd, p_film, l, ray_weight);

@@ -47,6 +47,10 @@ def lib():
         L.orc_bsdf_f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_bsdf_sample_f.restype = None
         L.orc_bsdf_sample_f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_halton_permutations.restype = C.c_uint64; L.orc_halton_permutations.argtypes = [C.c_int, C.c_void_p]
+        L.orc_halton_index.restype = C.c_uint64; L.orc_halton_index.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64]
+        L.orc_halton_sample.restype = C.c_float; L.orc_halton_sample.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.orc_pcg32_next.restype = C.c_uint32; L.orc_pcg32_next.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_spatial_voxel.restype = None
         L.orc_spatial_voxel.argtypes = [C.c_void_p] * 6
         _LIB = L

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -12,7 +12,7 @@ BXDF_LAMBERT_R, BXDF_OREN_NAYAR, BXDF_SPECULAR_R, BXDF_SPECULAR_T, BXDF_FRESNEL_
 BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9
 FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT = 1, 2, 3, 4
-SAMPLER_SOBOL = 1
+SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 NO_MATERIAL = 0xFFFFFFFF
 MISS = 0xFFFFFFFF
@@ -57,7 +57,7 @@ class SceneDesc(C.Structure):
 
 
 class SamplerTables(C.Structure):
-    _fields_ = [("sobol32", C.c_void_p), ("vdc", C.c_void_p), ("vdc_inv", C.c_void_p)]
+    _fields_ = [("sobol32", C.c_void_p), ("vdc", C.c_void_p), ("vdc_inv", C.c_void_p), ("halton_perms", C.c_void_p), ("n_halton_perms", C.c_uint64)]
 
 
 class RenderDesc(C.Structure):
@@ -71,7 +71,7 @@ class RenderDesc(C.Structure):
                 ("max_depth", C.c_uint32), ("rr_threshold", C.c_float), ("light_strategy", C.c_uint32),
                 ("tile_size", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("tile_chunk", C.c_uint32),
-                ("tables", SamplerTables)]
+                ("sample_at_pixel_center", C.c_uint32), ("tables", SamplerTables)]
 
 
 class Ray(C.Structure):

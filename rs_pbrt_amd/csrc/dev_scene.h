@@ -53,6 +53,13 @@ struct RenderDev {
     const uint64_t* vdc;       // [25*52]
     const uint64_t* vdc_inv;   // [26*52]
     const float* filter_table; // [256]
+    // HaltonSampler (src/samplers/halton.rs:54-131)
+    uint32_t sampler_kind, sample_at_pixel_center;
+    int32_t base_scales[2], base_exponents[2];
+    uint64_t sample_stride, mult_inverse[2];
+    const uint16_t* halton_perms;  // RADICAL_INVERSE_PERMUTATIONS prefix
+    const uint32_t* primes;        // PRIMES [1000]
+    const uint32_t* prime_sums;    // PRIME_SUMS [1000]
 };
 
 // ---- Sobol' sampler (src/samplers/sobol.rs:110-140,190-201; lowdiscrepancy.rs:1014-1076) ----
@@ -110,6 +117,89 @@ struct SobolBlock {
         f2 r{at(dim - base), at(dim + 1 - base)};
         dim += 2;
         return r;
+    }
+};
+
+// ---- Halton sampler (src/samplers/halton.rs:173-226; lowdiscrepancy.rs:788-797, 1082-1122) ----
+// digit loops in 32-bit arithmetic whenever the index fits (it does up to ~10^5 spp): 64-bit
+// integer division is a long software sequence on the GPU
+template <class U>
+RDEV float radical_inverse_digits(U a, uint32_t base, const uint16_t* perm, float* inv_base_n_out) {
+    float inv_base = 1.0f / (float)base, inv_base_n = 1.0f;
+    uint64_t reversed = 0;
+    while (a != 0) {
+        U next = a / (U)base;
+        uint32_t digit = (uint32_t)(a - next * (U)base);
+        reversed = reversed * base + (perm ? (uint64_t)perm[digit] : (uint64_t)digit);
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    *inv_base_n_out = inv_base_n;
+    return (float)reversed;
+}
+RDEV float radical_inverse_base(uint32_t base, uint64_t a) {  // radical_inverse_specialized
+    float ibn;
+    float rev = (a >> 32) ? radical_inverse_digits<uint64_t>(a, base, nullptr, &ibn) : radical_inverse_digits<uint32_t>((uint32_t)a, base, nullptr, &ibn);
+    return fminf(rev * ibn, RSPT_ONE_MINUS_EPS);
+}
+RDEV float scrambled_radical_inverse(uint32_t base, uint64_t a, const uint16_t* perm) {  // scrambled_radical_inverse_specialized
+    float ibn;
+    float rev = (a >> 32) ? radical_inverse_digits<uint64_t>(a, base, perm, &ibn) : radical_inverse_digits<uint32_t>((uint32_t)a, base, perm, &ibn);
+    float inv_base = 1.0f / (float)base;
+    return fminf(ibn * (rev + inv_base * (float)perm[0] / (1.0f - inv_base)), RSPT_ONE_MINUS_EPS);
+}
+RDEV uint64_t inverse_radical_inverse(uint64_t base, uint64_t inverse, uint64_t n_digits) {
+    uint64_t index = 0;
+    for (uint64_t i = 0; i < n_digits; i++) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+RDEV uint64_t halton_index(const RenderDev& rd, int32_t px, int32_t py, uint64_t sample_num) {  // get_index_for_sample
+    uint64_t offset = 0;
+    if (rd.sample_stride > 1) {
+        int32_t pm0 = px % 128, pm1 = py % 128;  // mod_t(p, K_MAX_RESOLUTION)
+        if (pm0 < 0) pm0 += 128;
+        if (pm1 < 0) pm1 += 128;
+        offset += inverse_radical_inverse(2, (uint64_t)pm0, (uint64_t)rd.base_exponents[0]) * (rd.sample_stride / (uint64_t)rd.base_scales[0]) * rd.mult_inverse[0];
+        offset += inverse_radical_inverse(3, (uint64_t)pm1, (uint64_t)rd.base_exponents[1]) * (rd.sample_stride / (uint64_t)rd.base_scales[1]) * rd.mult_inverse[1];
+        offset %= rd.sample_stride;
+    }
+    return offset + sample_num * rd.sample_stride;
+}
+RDEV float halton_dim(const RenderDev& rd, uint64_t index, uint32_t dim) {  // sample_dimension
+    if (rd.sample_at_pixel_center && dim < 2) return 0.5f;
+    if (dim == 0) {
+        uint64_t a = index >> (uint64_t)rd.base_exponents[0];
+        uint64_t r = ((uint64_t)__brev((uint32_t)a) << 32) | (uint64_t)__brev((uint32_t)(a >> 32));  // reverse_bits_64
+        return (float)r * 0x1.0p-64f;
+    }
+    if (dim == 1) return radical_inverse_base(3, index / (uint64_t)rd.base_scales[1]);
+    return scrambled_radical_inverse(rd.primes[dim], index, rd.halton_perms + rd.prime_sums[dim]);
+}
+
+// the sampler cursor of the shade stage: Sobol' dimensions come from the LDS block, Halton's are
+// computed on demand (both are pure functions of (index, dimension): GlobalSampler, sampler.rs)
+struct PathSampler {
+    SobolBlock blk;
+    uint64_t index;
+    uint32_t hdim;
+    bool halton;
+    RDEV void start(const RenderDev& rd, const uint32_t* __restrict__ tab, uint32_t nd, uint64_t idx, uint32_t first_dim) {
+        halton = rd.sampler_kind == RSPT_SAMPLER_HALTON;
+        index = idx;
+        hdim = first_dim;
+        if (!halton) blk.fill(tab, nd, idx, first_dim);
+    }
+    RDEV uint32_t dim() const { return halton ? hdim : blk.dim; }
+    RDEV float get_1d(const RenderDev& rd) { return halton ? halton_dim(rd, index, hdim++) : blk.get_1d(); }
+    RDEV f2 get_2d(const RenderDev& rd) {
+        if (!halton) return blk.get_2d();
+        float y = halton_dim(rd, index, hdim + 1), x = halton_dim(rd, index, hdim);
+        hdim += 2;
+        return f2{x, y};
     }
 };
 

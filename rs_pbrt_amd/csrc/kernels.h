@@ -83,13 +83,21 @@ __global__ __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, PathBuf 
     uint32_t k = bt.pix0 + i / bt.ns, s = bt.s0 + i % bt.ns;
     uint32_t pk = pix_list[k];
     int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
-    // SobolSampler::get_index_for_sample (sobol.rs:110-117)
-    uint64_t index = sobol_interval_to_index(rd, (uint32_t)rd.log2_res, (uint64_t)s, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+    // get_index_for_sample (sobol.rs:110-117 / halton.rs:173-214), then
     // Sampler::get_camera_sample (sampler.rs:85-95): film 2-D, time 1-D, lens 2-D
-    float fy = sobol_pixel_dim(rd, index, 1, py), fx = sobol_pixel_dim(rd, index, 0, px);
-    f2 p_film{(float)px + fx, (float)py + fy};
+    uint64_t index;
+    float fx, fy;
     f2 p_lens{0.0f, 0.0f};
-    if (rd.lens_radius > 0.0f) p_lens = f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
+    if (rd.sampler_kind == RSPT_SAMPLER_HALTON) {
+        index = halton_index(rd, px, py, (uint64_t)s);
+        fy = halton_dim(rd, index, 1); fx = halton_dim(rd, index, 0);
+        if (rd.lens_radius > 0.0f) p_lens = f2{halton_dim(rd, index, 3), halton_dim(rd, index, 4)};
+    } else {
+        index = sobol_interval_to_index(rd, (uint32_t)rd.log2_res, (uint64_t)s, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+        fy = sobol_pixel_dim(rd, index, 1, py); fx = sobol_pixel_dim(rd, index, 0, px);
+        if (rd.lens_radius > 0.0f) p_lens = f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
+    }
+    f2 p_film{(float)px + fx, (float)py + fy};
     f3 o, d;
     float t_max;
     camera_ray(rd, p_film, p_lens, &o, &d, &t_max);
@@ -312,8 +320,8 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 bsdf.ts = cross(h.sh_n, bsdf.ss);
                 bsdf.lobes = sc.bxdfs + mat.first_bxdf;
                 bsdf.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
-                SobolBlock smp;
-                smp.fill(sob_tab, sob_nd, pb.sobol_index[p], st & ST_DIM_MASK);
+                PathSampler smp;
+                smp.start(rd, sob_tab, sob_nd, pb.sobol_index[p], st & ST_DIM_MASK);
                 if (stats) atomicAdd(&stats[0], 1ull);
 
                 // ---- uniform_sample_one_light (integrator.rs:359-403) ----
@@ -322,10 +330,10 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                     uint32_t vox = light_voxel(sc, ld, h.p);
                     float pdf_choice = 0.0f;
                     uint32_t light_num = sample_discrete(ld.func + (size_t)vox * sc.n_lights, ld.cdf + (size_t)vox * (sc.n_lights + 1),
-                                                         ld.func_int[vox], sc.n_lights, smp.get_1d(), &pdf_choice);
+                                                         ld.func_int[vox], sc.n_lights, smp.get_1d(rd), &pdf_choice);
                     if (pdf_choice != 0.0f) {
-                        f2 u_light = smp.get_2d();
-                        f2 u_scatter = smp.get_2d();
+                        f2 u_light = smp.get_2d(rd);
+                        f2 u_scatter = smp.get_2d(rd);
                         const rspt_light lt = sc.lights[light_num];
                         rgb c1 = mkrgb(0.0f), c2 = mkrgb(0.0f);
                         // light sample (integrator.rs:424-477)
@@ -384,7 +392,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 f3 wi{0.0f, 0.0f, 0.0f};
                 float pdf = 0.0f;
                 uint32_t sampled_type = 255;
-                rgb f = bsdf.sample_f(wo, &wi, smp.get_2d(), &pdf, BX_ALL, &sampled_type);
+                rgb f = bsdf.sample_f(wo, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
                 bool go_on = !(is_black(f) || pdf == 0.0f);
                 if (go_on) {
                     beta = beta * ((f * absdot(wi, h.sh_n)) / pdf);
@@ -399,7 +407,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                     rgb rr = beta * eta_scale;
                     if (maxc(rr) < rd.rr_threshold && bounces > 3) {
                         float q = fmaxf(0.05f, 1.0f - maxc(rr));
-                        if (smp.get_1d() < q) go_on = false;
+                        if (smp.get_1d(rd) < q) go_on = false;
                         else beta = beta / (1.0f - q);
                     }
                     if (go_on) {
@@ -410,7 +418,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                     }
                 }
                 bounces += 1;
-                st = (st & ~(ST_DIM_MASK | (0xffu << ST_BOUNCE_SHIFT))) | (smp.dim & ST_DIM_MASK) | ((bounces & 0xffu) << ST_BOUNCE_SHIFT);
+                st = (st & ~(ST_DIM_MASK | (0xffu << ST_BOUNCE_SHIFT))) | (smp.dim() & ST_DIM_MASK) | ((bounces & 0xffu) << ST_BOUNCE_SHIFT);
             }
         }
     }
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, Ren
     // Sobol' generator matrices of the dimensions this render can reach, transposed to [bit][dim]
     extern __shared__ uint32_t sob_tab[];
     __shared__ uint32_t s_wave[4][4], s_base[3];
-    for (uint32_t t = threadIdx.x; t < sob_nd * sob_bits; t += 256u) {
+    for (uint32_t t = threadIdx.x; rd.sampler_kind == RSPT_SAMPLER_SOBOL && t < sob_nd * sob_bits; t += 256u) {
         uint32_t dd = t % sob_nd;  // read-ahead columns past the last of the 1024 dimensions are never consumed
         sob_tab[t] = rd.sobol32[(dd < 1024u ? dd : 1023u) * 52u + (t / sob_nd)];
     }

@@ -54,6 +54,11 @@ struct Ctx {
     uint64_t* vdc = nullptr;
     uint64_t* vdc_inv = nullptr;
     float* filter_table = nullptr;
+    uint32_t* primes = nullptr;        // Halton: PRIMES, PRIME_SUMS, RADICAL_INVERSE_PERMUTATIONS prefix
+    uint32_t* prime_sums = nullptr;
+    uint16_t* halton_perms = nullptr;
+    uint64_t n_halton_perms = 0;
+    std::vector<uint32_t> host_primes, host_prime_sums;
     // film
     float4* film_own = nullptr;
     float4* film_splat = nullptr;
@@ -259,10 +264,12 @@ uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PE
 int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (!s || !d) return fail(RSPT_E_INVALID, "null scene or render desc");
-    if (d->sampler_kind != RSPT_SAMPLER_SOBOL) return fail(RSPT_E_UNSUPPORTED, "sampler kind %u (only sobol)", d->sampler_kind);
-    if (d->spp <= 0 || (d->spp & (d->spp - 1)) != 0 || d->spp > (1ll << 30)) return fail(RSPT_E_INVALID, "spp must be a power of two in [1, 2^30]");
+    const bool halton = d->sampler_kind == RSPT_SAMPLER_HALTON;
+    if (d->sampler_kind != RSPT_SAMPLER_SOBOL && !halton) return fail(RSPT_E_UNSUPPORTED, "sampler kind %u (sobol and halton only)", d->sampler_kind);
+    if (d->spp <= 0 || d->spp > (1ll << 30) || (!halton && (d->spp & (d->spp - 1)) != 0)) return fail(RSPT_E_INVALID, "spp must be in [1, 2^30] (a power of two for sobol)");
     if (d->tile_size == 0 || d->tile_size > 4096) return fail(RSPT_E_INVALID, "bad tile_size");
-    if (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv) return fail(RSPT_E_INVALID, "null sampler tables");
+    if (!halton && (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv)) return fail(RSPT_E_INVALID, "null sobol tables");
+    if (halton && !d->tables.halton_perms) return fail(RSPT_E_INVALID, "null halton permutation table");
     if (!(d->filter_radius[0] > 0.0f) || !(d->filter_radius[1] > 0.0f)) return fail(RSPT_E_INVALID, "bad filter radius");
     if (d->max_depth > 200) return fail(RSPT_E_UNSUPPORTED, "max_depth > 200");
     const int32_t* sb = d->sample_bounds;
@@ -294,11 +301,63 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (!g.sobol32) {
         if ((rc = dev_alloc(&g.sobol32, 1024 * 52)) || (rc = dev_alloc(&g.vdc, 25 * 52)) || (rc = dev_alloc(&g.vdc_inv, 26 * 52)) || (rc = dev_alloc(&g.filter_table, 256))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(g.sobol32, d->tables.sobol32, 1024 * 52 * 4, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.vdc, d->tables.vdc, 25 * 52 * 8, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.vdc_inv, d->tables.vdc_inv, 26 * 52 * 8, hipMemcpyHostToDevice, g.stream));
+    if (!halton) {
+        HIP_TRY(hipMemcpyAsync(g.sobol32, d->tables.sobol32, 1024 * 52 * 4, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(g.vdc, d->tables.vdc, 25 * 52 * 8, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(g.vdc_inv, d->tables.vdc_inv, 26 * 52 * 8, hipMemcpyHostToDevice, g.stream));
+    }
     HIP_TRY(hipMemcpyAsync(g.filter_table, d->filter_table, 256 * 4, hipMemcpyHostToDevice, g.stream));
     rd.sobol32 = g.sobol32; rd.vdc = g.vdc; rd.vdc_inv = g.vdc_inv; rd.filter_table = g.filter_table;
+    rd.sampler_kind = d->sampler_kind;
+    rd.sample_at_pixel_center = d->sample_at_pixel_center;
+    if (halton) {  // HaltonSampler::new (halton.rs:80-131)
+        if (!g.primes) {  // PRIMES / PRIME_SUMS (lowdiscrepancy.rs:31-760)
+            std::vector<uint32_t> primes, sums;
+            for (uint32_t v = 2; primes.size() < 1000; v++) {
+                bool is_p = true;
+                for (uint32_t q = 2; q * q <= v; q++) if (v % q == 0) { is_p = false; break; }
+                if (is_p) primes.push_back(v);
+            }
+            uint32_t acc = 0;
+            for (uint32_t p : primes) { sums.push_back(acc); acc += p; }
+            g.host_primes = primes; g.host_prime_sums = sums;
+            if ((rc = dev_alloc(&g.primes, 1000)) || (rc = dev_alloc(&g.prime_sums, 1000))) return rc;
+            HIP_TRY(hipMemcpy(g.primes, primes.data(), 4000, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(g.prime_sums, sums.data(), 4000, hipMemcpyHostToDevice));
+        }
+        const uint32_t max_dim = 5u + 8u * (d->max_depth + 2u);  // last dimension a path can consume, with slack
+        if (max_dim >= 1000u) return fail(RSPT_E_UNSUPPORTED, "max_depth exceeds the 1000 Halton dimensions");
+        const uint64_t need = (uint64_t)g.host_prime_sums[max_dim] + g.host_primes[max_dim];
+        if (d->tables.n_halton_perms < need) return fail(RSPT_E_INVALID, "halton permutation table has %llu entries, %llu needed for max_depth %u",
+                                                         (unsigned long long)d->tables.n_halton_perms, (unsigned long long)need, d->max_depth);
+        if (g.n_halton_perms < need) {
+            if (g.halton_perms) (void)hipFree(g.halton_perms);
+            g.halton_perms = nullptr; g.n_halton_perms = 0;
+            if ((rc = dev_alloc(&g.halton_perms, need))) return rc;
+            g.n_halton_perms = need;
+        }
+        HIP_TRY(hipMemcpyAsync(g.halton_perms, d->tables.halton_perms, need * sizeof(uint16_t), hipMemcpyHostToDevice, g.stream));
+        rd.halton_perms = g.halton_perms; rd.primes = g.primes; rd.prime_sums = g.prime_sums;
+        const int32_t res[2] = {sb[2] - sb[0], sb[3] - sb[1]};
+        for (int i = 0; i < 2; i++) {
+            int32_t base = i == 0 ? 2 : 3, scale = 1, exp = 0;
+            while (scale < std::min(res[i], 128)) { scale *= base; exp += 1; }
+            rd.base_scales[i] = scale; rd.base_exponents[i] = exp;
+        }
+        rd.sample_stride = (uint64_t)rd.base_scales[0] * (uint64_t)rd.base_scales[1];
+        auto mult_inv = [](int64_t a, int64_t n) {  // multiplicative_inverse via extended_gcd (halton.rs:32-52)
+            int64_t x0 = 1, x1 = 0, r0 = a, r1 = n;
+            while (r1 != 0) {
+                int64_t q = r0 / r1, t = r0 - q * r1;
+                r0 = r1; r1 = t;
+                t = x0 - q * x1; x0 = x1; x1 = t;
+            }
+            int64_t m = x0 % n;
+            return (uint64_t)(m < 0 ? m + n : m);
+        };
+        rd.mult_inverse[0] = mult_inv(rd.base_scales[1], rd.base_scales[0]);
+        rd.mult_inverse[1] = mult_inv(rd.base_scales[0], rd.base_scales[1]);
+    }
 
     LightDistDev ld;
     if ((rc = get_light_dist(s, d->light_strategy, &ld))) return rc;
@@ -379,7 +438,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     for (size_t p0 = 0; p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
         for (uint32_t s0 = 0; s0 < (uint32_t)d->spp; s0 += ns) {
-            Batch bt{(uint32_t)p0, npx, s0, ns, npx * ns};
+            const uint32_t ns_b = std::min(ns, (uint32_t)d->spp - s0);  // Halton spp need not be a power of two
+            Batch bt{(uint32_t)p0, npx, s0, ns_b, npx * ns_b};
             samples += bt.n;
             HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
@@ -480,7 +540,7 @@ void rspt_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
-    void* ptrs[] = {g.cnt, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list};
+    void* ptrs[] = {g.cnt, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);

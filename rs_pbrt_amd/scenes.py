@@ -33,11 +33,55 @@ class SobolTables:
         off += 8 * 25 * 52
         self.vdc_inv = np.frombuffer(raw[off:off + 8 * 26 * 52].tobytes(), dtype="<u8").copy()
 
-    def as_struct(self):
-        return abi.SamplerTables(self.sobol32.ctypes.data, self.vdc.ctypes.data, self.vdc_inv.ctypes.data)
+    def as_struct(self, halton_perms=None):
+        t = abi.SamplerTables(self.sobol32.ctypes.data, self.vdc.ctypes.data, self.vdc_inv.ctypes.data, None, 0)
+        if halton_perms is not None:
+            t.halton_perms, t.n_halton_perms = halton_perms.ctypes.data, len(halton_perms)
+        return t
 
 
 _TABLES = None
+_HALTON = {}
+
+
+def first_primes(n):
+    out, v = [], 2
+    while len(out) < n:
+        if all(v % d for d in range(2, int(v ** 0.5) + 1)):
+            out.append(v)
+        v += 1
+    return out
+
+
+def halton_permutations(n_dims=256):
+    """RADICAL_INVERSE_PERMUTATIONS (src/samplers/halton.rs:19-26) for the first n_dims primes: what
+    rs_pbrt's lazy_static builds with compute_radical_inverse_permutations (lowdiscrepancy.rs:2165-2187),
+    i.e. identity permutations shuffled (sampling.rs:200-212) with a default-seeded PCG32 (rng.rs:15-83),
+    including the reference's bounded-draw threshold (`(!b + 1) & b`, rng.rs:64-73).  Host-side table
+    construction, like the Sobol' matrices: the shim hands rs_pbrt's own array through the ABI."""
+    if n_dims in _HALTON:
+        return _HALTON[n_dims]
+    M = (1 << 64) - 1
+    state, inc = 0x853C49E6748FEA9B, 0xDA3E39CB94B95BDB
+    out = []
+    for prime in first_primes(n_dims):
+        perm = list(range(prime))
+        for i in range(prime):
+            b = prime - i
+            threshold = ((~b + 1) & 0xFFFFFFFF) & b
+            while True:
+                old = state
+                state = (old * 0x5851F42D4C957F2D + inc) & M
+                xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+                rot = old >> 59
+                r = ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+                if r >= threshold:
+                    break
+            other = i + r % b
+            perm[i], perm[other] = perm[other], perm[i]
+        out.extend(perm)
+    _HALTON[n_dims] = np.array(out, np.uint16)
+    return _HALTON[n_dims]
 
 
 def sobol_tables():
@@ -403,7 +447,8 @@ def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs,
 
 def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_SPATIAL,
                      crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
-                     focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64)):
+                     focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
+                     sample_at_pixel_center=False):
     rd = abi.RenderDesc()
     rd.full_res[:] = (xres, yres)
     # Film::new film.rs:187-196
@@ -431,14 +476,19 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
     rd.camera_to_world[:] = w2c.m_inv.reshape(-1).tolist()
     rd.lens_radius, rd.focal_distance = lens_radius, focal_distance
     rd.shutter_open, rd.shutter_close = 0.0, 1.0
-    rd.sampler_kind = abi.SAMPLER_SOBOL
-    s = 1
-    while s < spp:
-        s *= 2  # sobol.rs:38-45 rounds up to a power of two
-    rd.spp = s
+    if sampler == "halton":  # the reference's default sampler (api.rs:526), halton.rs:163-172
+        rd.sampler_kind = abi.SAMPLER_HALTON
+        rd.spp = spp
+        rd.sample_at_pixel_center = int(sample_at_pixel_center)
+    else:
+        rd.sampler_kind = abi.SAMPLER_SOBOL
+        s = 1
+        while s < spp:
+            s *= 2  # sobol.rs:38-45 rounds up to a power of two
+        rd.spp = s
     rd.max_depth, rd.rr_threshold, rd.light_strategy, rd.tile_size = max_depth, rr_threshold, light_strategy, 16
     rd.shard_index, rd.shard_count, rd.tile_chunk = shard
-    rd.tables = sobol_tables().as_struct()
+    rd.tables = sobol_tables().as_struct(halton_permutations(5 + 8 * (max_depth + 3)) if sampler == "halton" else None)
     return rd
 
 

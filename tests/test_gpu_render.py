@@ -195,3 +195,26 @@ def test_gallery_light_strategies_with_delta_lights(gpu, oracle, strategy):
     rd = scenes.make_render_desc(64, 48, 8, GALLERY_LOOK_AT, 60, max_depth=4, light_strategy=strategy)
     film, _, _, ref = _render_pair(gpu, oracle, sc, rd, want_li=False)
     assert film_rmse(film, ref["film"]) < 2e-5
+
+
+@pytest.mark.parametrize("variant", ["matte", "mixed"])
+def test_halton_sampler_matches_oracle(gpu, oracle, variant):
+    """HaltonSampler (the reference's default sampler, api.rs:526): index mapping, scrambled radical
+    inverses with the PCG-shuffled digit permutations, non-power-of-two spp"""
+    sc = scenes.cornell_box(gpu.bvh_build, variant=variant)
+    rd = scenes.cornell_render_desc(res=72, spp=12, sampler="halton")
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert (li == ref["li"]).all(axis=2).mean() > 0.75
+    assert film_rmse(film, ref["film"]) < 1e-5
+    assert st["samples"] == 72 * 72 * 12
+
+
+def test_halton_pixel_center_lens_and_wide_frame(gpu, oracle):
+    from tests.util import GALLERY_LOOK_AT, gallery
+    sc = gallery(gpu.bvh_build, "all")
+    rd = scenes.make_render_desc(200, 150, 5, GALLERY_LOOK_AT, 60, max_depth=4, sampler="halton", sample_at_pixel_center=True, lens_radius=0.05,
+                                 focal_distance=6.0)  # > 128 pixels wide: pixel index wraps modulo K_MAX_RESOLUTION
+    film, _, _, ref = _render_pair(gpu, oracle, sc, rd, want_li=False)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 2e-5

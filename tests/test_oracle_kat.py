@@ -409,3 +409,71 @@ def test_delta_lights_analytic_irradiance(oracle, kind):
     assert abs(centre - expect) < 0.02 * expect
     if kind == "spot":
         assert rgb[0, 0].max() == 0.0  # outside the 30 degree cone
+
+
+# ---------------------------------------------------------------- Halton sampler (the reference's default)
+def test_halton_permutations_two_implementations_agree(oracle):
+    """PCG32 + shuffle with the reference's bounded-draw threshold (Q2), written twice (Python in the host
+    mirror, C++ in the oracle); each block is a permutation of 0..p-1"""
+    n_dims = 60
+    n = oracle.lib().orc_halton_permutations(n_dims, None)
+    out = np.zeros(n, np.uint16)
+    oracle.lib().orc_halton_permutations(n_dims, out.ctypes.data)
+    assert np.array_equal(out, scenes.halton_permutations(n_dims))
+    off = 0
+    for p in scenes.first_primes(n_dims):
+        assert sorted(out[off:off + p].tolist()) == list(range(p))
+        off += p
+    assert off == n
+    # PCG32 known answer: first outputs of the default-seeded generator (O'Neill's pcg32 recurrence in big ints)
+    state, inc = 0x853C49E6748FEA9B, 0xDA3E39CB94B95BDB
+    st = C.c_uint64(state)
+    for _ in range(5):
+        old = state
+        state = (old * 0x5851F42D4C957F2D + inc) % 2 ** 64
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        expect = ((xs >> rot) | (xs << ((32 - rot) % 32))) & 0xFFFFFFFF
+        assert oracle.lib().orc_pcg32_next(C.addressof(st), inc) == expect and st.value == state
+
+
+def test_halton_index_lands_in_pixel_and_dimensions_match_rationals(oracle):
+    rd = scenes.make_render_desc(100, 60, 8, scenes.CORNELL_LOOK_AT, 40, sampler="halton")
+    L = oracle.lib()
+    perms = scenes.halton_permutations(5 + 8 * 8)
+    primes = scenes.first_primes(40)
+    sums = np.concatenate([[0], np.cumsum(primes)])
+    sx, sy = 128, 81  # base_scales: smallest 2^k >= min(100,128), 3^k >= min(60,128)
+    seen = set()
+    for (px, py) in [(0, 0), (99, 59), (17, 42), (64, 3)]:
+        for s in range(4):
+            idx = L.orc_halton_index(C.addressof(rd), px, py, s)
+            assert idx not in seen
+            seen.add(idx)
+            # defining property: the radical inverses of the index in bases 2 / 3, scaled, fall into the pixel
+            def radinv(b, a):
+                v, f = Fraction(0), Fraction(1, b)
+                while a:
+                    v += (a % b) * f; f /= b; a //= b
+                return v
+            assert int(radinv(2, idx) * sx) == px % sx and int(radinv(3, idx) * sy) == py % sy
+            # film dimensions are the remaining fractional parts; higher dimensions are scrambled radical inverses
+            assert abs(L.orc_halton_sample(C.addressof(rd), idx, 0) - float(radinv(2, idx >> 7))) < 1e-6
+            assert abs(L.orc_halton_sample(C.addressof(rd), idx, 1) - float(radinv(3, idx // 81))) < 1e-6
+            for dim in (2, 5, 11, 30):
+                b = primes[dim]; perm = perms[sums[dim]:sums[dim] + b]
+                v, f, a = Fraction(0), Fraction(1, b), idx
+                while a:
+                    v += int(perm[a % b]) * f; f /= b; a //= b
+                v += f * int(perm[0]) * Fraction(b, b - 1)  # infinite tail of perm[0] digits
+                assert abs(L.orc_halton_sample(C.addressof(rd), idx, dim) - float(v)) < 2e-6
+
+
+def test_halton_render_close_to_sobol_and_reproducible(oracle):
+    sc = scenes.cornell_box(oracle.bvh_build)
+    a = oracle.render(sc, scenes.cornell_render_desc(res=48, spp=32, sampler="halton"), threads=4)
+    b = oracle.render(sc, scenes.cornell_render_desc(res=48, spp=32, sampler="halton"), threads=1)
+    s = oracle.render(sc, scenes.cornell_render_desc(res=48, spp=32), threads=4)
+    assert np.array_equal(a["film"], b["film"])
+    ra, rs = scenes.film_to_rgb(a["film"]).mean(0), scenes.film_to_rgb(s["film"]).mean(0)
+    assert np.allclose(ra, rs, rtol=0.03)  # two different low-discrepancy estimators of the same image
