@@ -295,7 +295,6 @@ struct Distribution1D {
 struct RenderCtx {
     const Scene* scene;
     const rspt_render_desc* rd;
-    SobolTables T;
     // light distribution state (src/core/lightdistrib.rs)
     int strategy; // after the "1 light -> uniform" rule (:397)
     std::shared_ptr<Distribution1D> fixed; // uniform / power
@@ -633,7 +632,6 @@ struct RenderOut {
 static inline void render(const Scene& scene, const rspt_render_desc& rd, int num_threads, float* film_xyzw, float* li_rgb, RenderOut* out) {
     RenderCtx cx;
     cx.scene = &scene; cx.rd = &rd;
-    cx.T = SobolTables{rd.tables.sobol32, rd.tables.vdc, rd.tables.vdc_inv};
     light_distrib_init(cx);
     const int32_t* sb = rd.sample_bounds;
     int32_t ext_x = sb[2] - sb[0], ext_y = sb[3] - sb[1];

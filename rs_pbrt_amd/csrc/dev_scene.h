@@ -203,18 +203,6 @@ struct PathSampler {
     }
 };
 
-struct Sampler {  // the (index, dimension) cursor a path carries between stages
-    uint64_t index;
-    uint32_t dim;
-    RDEV float get_1d(const RenderDev& rd) { return sobol_dim(rd, index, dim++); }
-    RDEV f2 get_2d(const RenderDev& rd) {  // sobol.rs:190-201: y is evaluated first (no effect on values)
-        float y = sobol_dim(rd, index, dim + 1);
-        float x = sobol_dim(rd, index, dim);
-        dim += 2;
-        return f2{x, y};
-    }
-};
-
 // ---- geometry at a hit: second half of Triangle::intersect (triangle.rs:274-448) ----
 struct Hit {
     f3 p, p_err, n;        // point, conservative error bound, geometric normal (oriented)

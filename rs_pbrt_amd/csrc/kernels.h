@@ -6,7 +6,8 @@
 //   k_shade         K4+K6  PathIntegrator::li body between two intersections, incl. NEE resolve
 //   k_film          K8  FilmTile::add_sample / merge_film_tile
 //   k_ld_*          K9  light sampling distributions
-// Queues are arrays of path slots compacted with wave64 ballot + prefix popcount (K7).
+// Queues are arrays of path slots compacted with wave64 ballot + prefix popcount, one atomic per
+// workgroup and queue (K7, in k_shade).
 #pragma once
 #include "dev_scene.h"
 
@@ -59,19 +60,6 @@ struct Batch {
 RDEV uint32_t virtual_block() {
     uint32_t g = gridDim.x, b = blockIdx.x;
     return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
-}
-
-// wave64 queue append: one atomic per wave, lanes ordered by prefix popcount of the ballot.
-// Must be reached by all lanes of the wave (inactive ones with pred = false).
-RDEV uint32_t wave_append(bool pred, uint32_t* counter) {
-    uint64_t mask = __ballot(pred);
-    if (mask == 0) return 0;
-    uint32_t lane = __lane_id();
-    uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
 // ---- K1 -------------------------------------------------------------------------------------
@@ -287,7 +275,6 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     float4 hc = pb.hit_cont[p];
     uint32_t prim = __float_as_uint(hc.x);
     uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
-    bool finished = true;
     if (prim != RSPT_MISS) {  // a miss adds nothing: no infinite lights in scope (path.rs:267-277)
         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
         float4 r0 = rp[0], r1 = rp[1];
@@ -308,9 +295,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 store_ray(pb.ray_cont + p, o, ray_d, RSPT_INF, p);
                 st |= ST_ALIVE;
                 out.cont = true;
-                finished = false;
             } else {
-                finished = false;  // decided below
                 rspt_material mat = sc.materials[h.material];
                 Bsdf bsdf;  // Bsdf::new (reflection.rs:235-245)
                 bsdf.eta = mat.eta;
@@ -422,7 +407,6 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             }
         }
     }
-    (void)finished;
     pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
     pb.state[p] = st;
     out.active = (st & (ST_ALIVE | ST_PENDING)) != 0;
