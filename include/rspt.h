@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 3
+#define RSPT_ABI_VERSION 4
 
 /* error codes */
 #define RSPT_OK 0
@@ -120,16 +120,34 @@ enum {
     RSPT_LIGHT_SPOT = 3,        /* SpotLight    src/lights/spot.rs:20-110: p[0..2] = p_light, L = I,
                                     p[3..11] = upper 3x3 of world_to_light.m (row major),
                                     p[12] = cos_total_width, p[13] = cos_falloff_start  */
-    RSPT_LIGHT_DISTANT = 4      /* DistantLight src/lights/distant.rs:25-75: p[0..2] = w_light (normalised), L = L;
+    RSPT_LIGHT_DISTANT = 4,     /* DistantLight src/lights/distant.rs:25-75: p[0..2] = w_light (normalised), L = L;
                                     the world radius comes from the scene bounds (preprocess, :76-86)      */
+    RSPT_LIGHT_INFINITE = 5     /* InfiniteAreaLight src/lights/infinite.rs:38-392: prim = index into envmaps[]
+                                    (texels already multiplied by L), p[0..8] = upper 3x3 of light_to_world.m,
+                                    p[9..17] = upper 3x3 of world_to_light.m (row major)                    */
 };
 typedef struct {
     uint32_t kind;
     uint32_t prim;       /* DIFFUSE_AREA: BVH-ordered primitive index of the emitting triangle */
     float L[3];          /* l_emit / I / L                                            */
     uint32_t two_sided;
-    float p[16];         /* kind-specific parameters, see above                       */
-} rspt_light; /* 88 B */
+    float p[24];         /* kind-specific parameters, see above                       */
+} rspt_light; /* 120 B */
+
+/* Environment map of an InfiniteAreaLight: the MipMap<Spectrum> pyramid rs_pbrt built
+ * (src/core/mipmap.rs:56-196; power-of-two levels after its resampling, wrap mode Repeat) and the
+ * scalar image its Distribution2D was built from (infinite.rs:120-137: lookup(st, fwidth).y() *
+ * sin(theta) on a 2w x 2h grid).  The library rebuilds the conditional / marginal CDFs with
+ * Distribution1D::new's arithmetic (src/core/sampling.rs:24-49,150-170). */
+typedef struct {
+    uint32_t width, height;  /* level 0 resolution                                         */
+    uint32_t n_levels;       /* MipMap::levels(): 1 + log2(max(width, height))             */
+    uint32_t pad;
+    const float* texels;     /* rgb triples, levels concatenated; level i is
+                                max(1, width >> i) x max(1, height >> i), row major [t][s] */
+    uint32_t dist_nu, dist_nv;
+    const float* dist_func;  /* [dist_nv][dist_nu]                                         */
+} rspt_envmap;
 
 typedef struct {
     const rspt_bvh_node* nodes; uint64_t n_nodes;
@@ -143,6 +161,7 @@ typedef struct {
     const rspt_material* materials; uint32_t n_materials;
     const rspt_bxdf* bxdfs;         uint32_t n_bxdfs;
     const rspt_light* lights;       uint32_t n_lights;
+    const rspt_envmap* envmaps;     uint32_t n_envmaps;
 } rspt_scene_desc;
 
 /* Sampler tables owned by the host.

@@ -319,7 +319,104 @@ static inline Float world_radius(const Scene& sc) {
                   center.z >= b.p_min.z && center.z <= b.p_max.z;
     return inside ? std::sqrt(distance_squared(center, b.p_max)) : 0.0f;
 }
-static inline bool light_is_delta(const rspt_light& lt) { return lt.kind != RSPT_LIGHT_DIFFUSE_AREA; } // light.rs:178-188
+// ---- MipMap<Spectrum>: src/core/mipmap.rs:206-252,323-336 (wrap mode Repeat) ----
+static inline const float* env_level(const rspt_envmap& m, uint32_t level, uint32_t* w, uint32_t* h) {
+    const float* p = m.texels;
+    uint32_t lw = m.width, lh = m.height;
+    for (uint32_t i = 0; i < level; i++) { p += 3 * (size_t)lw * lh; lw = std::max(1u, lw / 2); lh = std::max(1u, lh / 2); }
+    *w = lw; *h = lh;
+    return p;
+}
+static inline Spec env_texel(const rspt_envmap& m, uint32_t level, int64_t s_, int64_t t_) { // :206-232
+    uint32_t w, h;
+    const float* p = env_level(m, level, &w, &h);
+    uint64_t ss = (uint64_t)s_ % (uint64_t)w, tt = (uint64_t)t_ % (uint64_t)h; // mod_t(s as usize, u_size)
+    return S3(p + 3 * (tt * w + ss));
+}
+static inline Spec env_triangle(const rspt_envmap& m, uint32_t level, P2 st) { // :323-336
+    if (level > m.n_levels - 1) level = m.n_levels - 1;
+    uint32_t w, h;
+    env_level(m, level, &w, &h);
+    Float s = st.x * (Float)w - 0.5f, t = st.y * (Float)h - 0.5f;
+    int64_t s0 = (int64_t)std::floor(s), t0 = (int64_t)std::floor(t);
+    Float ds = s - (Float)s0, dt = t - (Float)t0;
+    Spec tmp1 = env_texel(m, level, s0 + 1, t0 + 1) * (ds * dt);
+    Spec tmp2 = env_texel(m, level, s0 + 1, t0) * (ds * (1.0f - dt));
+    Spec tmp3 = env_texel(m, level, s0, t0 + 1) * ((1.0f - ds) * dt);
+    Spec tmp4 = env_texel(m, level, s0, t0) * ((1.0f - ds) * (1.0f - dt));
+    return tmp4 + tmp3 + tmp2 + tmp1;
+}
+static inline Spec env_lookup(const rspt_envmap& m, P2 st, Float width) { // lookup_pnt_flt :233-252
+    Float level = (Float)m.n_levels - 1.0f + std::log2(std::fmax(width, 1e-8f));
+    if (level < 0.0f) return env_triangle(m, 0, st);
+    if (level >= (Float)m.n_levels - 1.0f) return env_texel(m, m.n_levels - 1, 0, 0);
+    uint32_t il = (uint32_t)f2usize(std::floor(level));
+    Float delta = level - (Float)il;
+    Spec a = env_triangle(m, il, st), b = env_triangle(m, il + 1, st);
+    return a * (1.0f - delta) + b * delta; // lerp(delta, a, b)
+}
+// Distribution2D over the light's scalar image (sampling.rs:150-198), rebuilt per call site from dist_func
+struct Distribution2D {
+    std::vector<Distribution1D> cond;
+    std::unique_ptr<Distribution1D> marginal;
+    Distribution2D(const float* f, uint32_t nu, uint32_t nv) {
+        std::vector<Float> mf;
+        for (uint32_t v = 0; v < nv; v++) { cond.emplace_back(std::vector<Float>(f + (size_t)v * nu, f + (size_t)(v + 1) * nu)); mf.push_back(cond.back().func_int); }
+        marginal.reset(new Distribution1D(mf));
+    }
+    static Float sample_continuous_1d(const Distribution1D& d, Float u, Float* pdf, size_t* off) { // sampling.rs:53-101
+        size_t first = 0, len = d.cdf.size();
+        while (len > 0) {
+            size_t half = len >> 1, middle = first + half;
+            if (d.cdf[middle] <= u) { first = middle + 1; len -= half + 1; } else len = half;
+        }
+        long o = clamp_t((long)first - 1, 0L, (long)d.cdf.size() - 2);
+        if (off) *off = (size_t)o;
+        Float du = u - d.cdf[o];
+        if ((d.cdf[o + 1] - d.cdf[o]) > 0.0f) du /= d.cdf[o + 1] - d.cdf[o];
+        if (pdf) *pdf = d.func_int > 0.0f ? d.func[o] / d.func_int : 0.0f;
+        return ((Float)o + du) / (Float)d.func.size();
+    }
+    P2 sample_continuous(P2 u, Float* pdf) const {
+        Float pdfs[2] = {0, 0};
+        size_t v = 0;
+        Float d1 = sample_continuous_1d(*marginal, u.y, &pdfs[1], &v);
+        Float d0 = sample_continuous_1d(cond[v], u.x, &pdfs[0], nullptr);
+        *pdf = pdfs[0] * pdfs[1];
+        return P2{d0, d1};
+    }
+    Float pdf(P2 p) const {
+        size_t nu = cond[0].func.size(), nv = marginal->func.size();
+        size_t iu = std::min((size_t)f2usize(p.x * (Float)nu), nu - 1), iv = std::min((size_t)f2usize(p.y * (Float)nv), nv - 1);
+        return cond[iv].func[iu] / marginal->func_int;
+    }
+};
+static inline const Distribution2D& env_distribution(const rspt_envmap& m) { // cached per envmap pointer
+    static std::mutex mu;
+    static std::map<const float*, std::unique_ptr<Distribution2D>> cache;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(m.dist_func);
+    if (it == cache.end()) it = cache.emplace(m.dist_func, std::unique_ptr<Distribution2D>(new Distribution2D(m.dist_func, m.dist_nu, m.dist_nv))).first;
+    return *it->second;
+}
+static inline V3 mat3_mul(const float* m, V3 w) { return V3{m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z}; }
+static inline Float spherical_theta(V3 v) { return std::acos(clamp_t(v.z, -1.0f, 1.0f)); } // geometry.rs:1584-1586
+static inline Float spherical_phi(V3 v) { Float p = std::atan2(v.y, v.x); return p < 0.0f ? p + 2.0f * PI : p; } // :1589-1596
+// InfiniteAreaLight::le (infinite.rs:369-377)
+static inline Spec infinite_le(const Scene& sc, const rspt_light& lt, V3 ray_d) {
+    V3 w = normalize(mat3_mul(lt.p + 9, ray_d));
+    P2 st{spherical_phi(w) * INV_2_PI, spherical_theta(w) * INV_PI};
+    return env_lookup(sc.d.envmaps[lt.prim], st, 0.0f);
+}
+// InfiniteAreaLight::pdf_li (infinite.rs:378-392)
+static inline Float infinite_pdf_li(const Scene& sc, const rspt_light& lt, V3 w) {
+    V3 wi = mat3_mul(lt.p + 9, w);
+    Float theta = spherical_theta(wi), phi = spherical_phi(wi);
+    Float sin_theta = std::sin(theta);
+    if (sin_theta == 0.0f) return 0.0f;
+    return env_distribution(sc.d.envmaps[lt.prim]).pdf(P2{phi * INV_2_PI, theta * INV_PI}) / (2.0f * PI * PI * sin_theta);
+}
+static inline bool light_is_delta(const rspt_light& lt) { return lt.kind == RSPT_LIGHT_POINT || lt.kind == RSPT_LIGHT_SPOT || lt.kind == RSPT_LIGHT_DISTANT; } // light.rs:178-188
 // SpotLight::falloff spot.rs:67-80
 static inline Float spot_falloff(const rspt_light& lt, V3 w) {
     const float* m = lt.p + 3;
@@ -340,6 +437,20 @@ static inline Spec light_sample_li(const Scene& sc, const rspt_light& lt, const 
     }
     Interaction li; // InteractionCommon::default(): n = 0, p_error = 0
     li.p_error = V3{0, 0, 0}; li.n = V3{0, 0, 0}; li.wo = V3{0, 0, 0}; li.time = iref.time;
+    if (lt.kind == RSPT_LIGHT_INFINITE) { // infinite.rs:298-341
+        const rspt_envmap& m = sc.d.envmaps[lt.prim];
+        Float map_pdf = 0.0f;
+        P2 uv = env_distribution(m).sample_continuous(u, &map_pdf);
+        if (map_pdf == 0.0f) { *pdf = 0.0f; return Spec(); } // (the reference leaves *pdf at the caller's 0)
+        Float theta = uv.y * PI, phi = uv.x * 2.0f * PI;
+        Float cos_theta = std::cos(theta), sin_theta = std::sin(theta), sin_phi = std::sin(phi), cos_phi = std::cos(phi);
+        *wi = mat3_mul(lt.p, V3{sin_theta * cos_phi, sin_theta * sin_phi, cos_theta});
+        *pdf = map_pdf / (2.0f * PI * PI * sin_theta);
+        if (sin_theta == 0.0f) *pdf = 0.0f;
+        li.p = iref.p + *wi * (2.0f * world_radius(sc));
+        *light_intr = li;
+        return env_lookup(m, uv, 0.0f);
+    }
     *pdf = 1.0f;
     Spec out;
     if (lt.kind == RSPT_LIGHT_DISTANT) {
@@ -364,6 +475,7 @@ static inline Spec light_power(const Scene& sc, const rspt_light& lt) {
     case RSPT_LIGHT_POINT: return S3(lt.L) * (4.0f * PI);
     case RSPT_LIGHT_SPOT: return S3(lt.L) * 2.0f * PI * (1.0f - 0.5f * (lt.p[13] + lt.p[12]));
     case RSPT_LIGHT_DISTANT: { Float r = world_radius(sc); return S3(lt.L) * PI * r * r; }
+    case RSPT_LIGHT_INFINITE: { Float r = world_radius(sc); return env_lookup(sc.d.envmaps[lt.prim], P2{0.5f, 0.5f}, 0.5f) * Spec(PI * r * r); } // infinite.rs:342-346
     default: {
         Float factor = lt.two_sided ? 2.0f : 1.0f;
         return S3(lt.L) * factor * sc.tri_area(sc.d.prims[lt.prim]) * PI;
@@ -469,7 +581,8 @@ static inline Spec estimate_direct(RenderCtx& cx, const Interaction& it, const B
         if (!f.is_black() && scattering_pdf > 0.0f) {
             Float weight = 1.0f;
             if (!sampled_specular) {
-                light_pdf = sc.tri_pdf_ref(sc.d.prims[light.prim], it, wi); // pdf_li diffuse.rs:100-103
+                light_pdf = light.kind == RSPT_LIGHT_INFINITE ? infinite_pdf_li(sc, light, wi)
+                                                              : sc.tri_pdf_ref(sc.d.prims[light.prim], it, wi); // pdf_li diffuse.rs:100-103
                 if (light_pdf == 0.0f) return ld;
                 weight = power_heuristic(1, scattering_pdf, 1, light_pdf);
             }
@@ -479,10 +592,10 @@ static inline Spec estimate_direct(RenderCtx& cx, const Interaction& it, const B
             if (c) c->mis_rays++;
             if (sc.intersect(ray, &light_isect, c)) {
                 const rspt_prim& hp = sc.d.prims[light_isect.prim];
-                if (hp.area_light >= 0 && (uint32_t)hp.area_light == light_num) // pointer compare :550-558
+                if (light.kind == RSPT_LIGHT_DIFFUSE_AREA && hp.area_light >= 0 && (uint32_t)hp.area_light == light_num) // pointer compare :550-558
                     li2 = light_l(light, light_isect.n, -wi);
             } else {
-                li2 = Spec(); // DiffuseAreaLight::le = 0 (diffuse.rs:97-99)
+                li2 = light.kind == RSPT_LIGHT_INFINITE ? infinite_le(sc, light, ray.d) : Spec(); // Light::le (integrator.rs:561-563)
             }
             if (!li2.is_black()) ld = ld + f * li2 * Spec(1.0f) * weight / scattering_pdf;
         }
@@ -548,7 +661,9 @@ static inline Spec path_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counte
                 beta = beta / (1.0f - q);
             }
         } else {
-            // no infinite lights in scope: `for light in &scene.infinite_lights` adds nothing
+            if (bounces == 0 || specular_bounce) // path.rs:267-277: scene.infinite_lights in Scene.lights order (scene.rs:40-43)
+                for (uint32_t i = 0; i < sc.d.n_lights; i++)
+                    if (sc.d.lights[i].kind == RSPT_LIGHT_INFINITE) l = l + beta * infinite_le(sc, sc.d.lights[i], ray.d);
             break;
         }
         bounces += 1;

@@ -4,14 +4,14 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
 BXDF_LAMBERT_R, BXDF_OREN_NAYAR, BXDF_SPECULAR_R, BXDF_SPECULAR_T, BXDF_FRESNEL_SPEC, BXDF_MICROFACET_R, BXDF_LAMBERT_T = 1, 2, 3, 4, 5, 6, 7
 BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9
 FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
-LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT = 1, 2, 3, 4
+LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
 SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 NO_MATERIAL = 0xFFFFFFFF
@@ -42,7 +42,12 @@ class Material(C.Structure):
 
 
 class Light(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("prim", C.c_uint32), ("L", C.c_float * 3), ("two_sided", C.c_uint32), ("p", C.c_float * 16)]
+    _fields_ = [("kind", C.c_uint32), ("prim", C.c_uint32), ("L", C.c_float * 3), ("two_sided", C.c_uint32), ("p", C.c_float * 24)]
+
+
+class EnvMap(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("n_levels", C.c_uint32), ("pad", C.c_uint32), ("texels", C.c_void_p),
+                ("dist_nu", C.c_uint32), ("dist_nv", C.c_uint32), ("dist_func", C.c_void_p)]
 
 
 class SceneDesc(C.Structure):
@@ -53,7 +58,8 @@ class SceneDesc(C.Structure):
                 ("n_vertices", C.c_uint64),
                 ("materials", C.c_void_p), ("n_materials", C.c_uint32),
                 ("bxdfs", C.c_void_p), ("n_bxdfs", C.c_uint32),
-                ("lights", C.c_void_p), ("n_lights", C.c_uint32)]
+                ("lights", C.c_void_p), ("n_lights", C.c_uint32),
+                ("envmaps", C.c_void_p), ("n_envmaps", C.c_uint32)]
 
 
 class SamplerTables(C.Structure):
@@ -98,7 +104,7 @@ MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("fli
 BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
                     ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4")])
 MATERIAL_DT = np.dtype([("eta", "<f4"), ("first_bxdf", "<u4"), ("n_bxdfs", "<u4"), ("pad", "<u4")])
-LIGHT_DT = np.dtype([("kind", "<u4"), ("prim", "<u4"), ("L", "<f4", 3), ("two_sided", "<u4"), ("p", "<f4", 16)])
+LIGHT_DT = np.dtype([("kind", "<u4"), ("prim", "<u4"), ("L", "<f4", 3), ("two_sided", "<u4"), ("p", "<f4", 24)])
 RAY_DT = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("id", "<u4")])
 HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4")])
 
@@ -107,4 +113,4 @@ assert PRIM_DT.itemsize == C.sizeof(Prim) == 24
 assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 80
 assert RAY_DT.itemsize == C.sizeof(Ray) == 32
 assert HIT_DT.itemsize == C.sizeof(Hit) == 20
-assert LIGHT_DT.itemsize == C.sizeof(Light) == 88
+assert LIGHT_DT.itemsize == C.sizeof(Light) == 120

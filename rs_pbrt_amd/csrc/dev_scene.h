@@ -23,8 +23,23 @@ struct SceneDev {
     const rspt_material* materials;
     const rspt_bxdf* bxdfs;
     const rspt_light* lights;
-    uint32_t n_nodes, n_prims, n_lights, pad0;
+    const struct EnvMapDev* envmaps;    // InfiniteAreaLight maps (rspt_light.prim indexes them)
+    const uint32_t* infinite_lights;    // Scene.infinite_lights: indices into lights[] (scene.rs:40-43)
+    uint32_t n_nodes, n_prims, n_lights, n_infinite;
     float wb_min[3], wb_max[3];  // BVHAccel::world_bound = nodes[0].bounds (bvh.rs:394-400)
+};
+
+// MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)
+struct EnvMapDev {
+    const float* texels;        // rgb, levels concatenated
+    uint32_t level_offset[16];  // in texels (not floats)
+    uint32_t width, height, n_levels, nu, nv;
+    const float* cond_func;     // [nv][nu]
+    const float* cond_cdf;      // [nv][nu + 1]
+    const float* cond_int;      // [nv]
+    const float* marg_func;     // [nv]
+    const float* marg_cdf;      // [nv + 1]
+    float marg_int;
 };
 
 // Light sampling distributions (src/core/lightdistrib.rs): one Distribution1D per voxel for
@@ -378,7 +393,82 @@ RDEV LightSample tri_sample_ref(const SceneDev& sc, uint32_t prim, const TriRec&
     }
     return s;
 }
-RDEV bool light_is_delta(const rspt_light& lt) { return lt.kind != RSPT_LIGHT_DIFFUSE_AREA; }  // light.rs:178-188
+RDEV bool light_is_delta(const rspt_light& lt) { return lt.kind == RSPT_LIGHT_POINT || lt.kind == RSPT_LIGHT_SPOT || lt.kind == RSPT_LIGHT_DISTANT; }  // light.rs:178-188
+// ---- MipMap<Spectrum> lookups, wrap mode Repeat (mipmap.rs:206-252, 323-336) ----
+RDEV rgb env_texel(const EnvMapDev& m, uint32_t level, int64_t s_, int64_t t_) {
+    uint32_t w = m.width >> level, h = m.height >> level;
+    w = w ? w : 1u; h = h ? h : 1u;
+    uint64_t ss = (uint64_t)s_ % (uint64_t)w, tt = (uint64_t)t_ % (uint64_t)h;  // mod_t(s as usize, u_size)
+    return ldrgb(m.texels + 3 * ((size_t)m.level_offset[level] + tt * w + ss));
+}
+RDEV rgb env_triangle(const EnvMapDev& m, uint32_t level, f2 st) {
+    if (level > m.n_levels - 1) level = m.n_levels - 1;
+    uint32_t w = m.width >> level, h = m.height >> level;
+    w = w ? w : 1u; h = h ? h : 1u;
+    float s = st.x * (float)w - 0.5f, t = st.y * (float)h - 0.5f;
+    int64_t s0 = (int64_t)floorf(s), t0 = (int64_t)floorf(t);
+    float ds = s - (float)s0, dt = t - (float)t0;
+    rgb tmp1 = env_texel(m, level, s0 + 1, t0 + 1) * (ds * dt);
+    rgb tmp2 = env_texel(m, level, s0 + 1, t0) * (ds * (1.0f - dt));
+    rgb tmp3 = env_texel(m, level, s0, t0 + 1) * ((1.0f - ds) * dt);
+    rgb tmp4 = env_texel(m, level, s0, t0) * ((1.0f - ds) * (1.0f - dt));
+    return tmp4 + tmp3 + tmp2 + tmp1;
+}
+RDEV rgb env_lookup(const EnvMapDev& m, f2 st, float width) {  // lookup_pnt_flt
+    float level = (float)m.n_levels - 1.0f + log2f(fmaxf(width, 1e-8f));
+    if (level < 0.0f) return env_triangle(m, 0, st);
+    if (level >= (float)m.n_levels - 1.0f) return env_texel(m, m.n_levels - 1, 0, 0);
+    uint32_t il = (uint32_t)floorf(level);
+    float delta = level - (float)il;
+    rgb a = env_triangle(m, il, st), b = env_triangle(m, il + 1, st);
+    return a * (1.0f - delta) + b * delta;
+}
+// Distribution1D::sample_continuous (sampling.rs:53-101)
+RDEV float dist1d_sample_continuous(const float* func, const float* cdf, float func_int, uint32_t n, float u, float* pdf, uint32_t* off) {
+    uint32_t first = 0, length = n + 1;
+    while (length > 0) {
+        uint32_t half = length >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; length -= half + 1; }
+        else length = half;
+    }
+    int64_t o = (int64_t)first - 1;
+    o = o < 0 ? 0 : (o > (int64_t)n - 1 ? (int64_t)n - 1 : o);
+    *off = (uint32_t)o;
+    float du = u - cdf[o];
+    if ((cdf[o + 1] - cdf[o]) > 0.0f) du /= cdf[o + 1] - cdf[o];
+    *pdf = func_int > 0.0f ? func[o] / func_int : 0.0f;
+    return ((float)o + du) / (float)n;
+}
+RDEV f2 env_sample_continuous(const EnvMapDev& m, f2 u, float* pdf) {  // Distribution2D::sample_continuous
+    float pdf0, pdf1;
+    uint32_t v, dummy;
+    float d1 = dist1d_sample_continuous(m.marg_func, m.marg_cdf, m.marg_int, m.nv, u.y, &pdf1, &v);
+    float d0 = dist1d_sample_continuous(m.cond_func + (size_t)v * m.nu, m.cond_cdf + (size_t)v * (m.nu + 1), m.cond_int[v], m.nu, u.x, &pdf0, &dummy);
+    *pdf = pdf0 * pdf1;
+    return f2{d0, d1};
+}
+RDEV uint32_t f2u_sat(float x) { return (x != x || x <= 0.0f) ? 0u : (x >= 4294967296.0f ? 0xffffffffu : (uint32_t)x); }
+RDEV float env_pdf(const EnvMapDev& m, f2 p) {  // Distribution2D::pdf
+    uint32_t iu = min(f2u_sat(p.x * (float)m.nu), m.nu - 1), iv = min(f2u_sat(p.y * (float)m.nv), m.nv - 1);
+    return m.cond_func[(size_t)iv * m.nu + iu] / m.marg_int;
+}
+RDEV f3 mat3_mul(const float* m, f3 w) { return f3{m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z}; }
+RDEV float spherical_theta(f3 v) { return acosf(clampf(v.z, -1.0f, 1.0f)); }  // geometry.rs:1584-1586
+RDEV float spherical_phi(f3 v) { float p = atan2f(v.y, v.x); return p < 0.0f ? p + 2.0f * RSPT_PI : p; }
+#define RSPT_INV_2_PI 0.15915494309189533577f
+// InfiniteAreaLight::le / pdf_li (infinite.rs:369-392)
+RDEVN rgb infinite_le(const SceneDev& sc, const rspt_light& lt, f3 ray_d) {
+    f3 w = normalize(mat3_mul(lt.p + 9, ray_d));
+    f2 st{spherical_phi(w) * RSPT_INV_2_PI, spherical_theta(w) * RSPT_INV_PI};
+    return env_lookup(sc.envmaps[lt.prim], st, 0.0f);
+}
+RDEVN float infinite_pdf_li(const SceneDev& sc, const rspt_light& lt, f3 w) {
+    f3 wi = mat3_mul(lt.p + 9, w);
+    float theta = spherical_theta(wi), phi = spherical_phi(wi);
+    float sin_theta = sinf(theta);
+    if (sin_theta == 0.0f) return 0.0f;
+    return env_pdf(sc.envmaps[lt.prim], f2{phi * RSPT_INV_2_PI, theta * RSPT_INV_PI}) / (2.0f * RSPT_PI * RSPT_PI * sin_theta);
+}
 // Bounds3f::bounding_sphere of the scene bound (geometry.rs:2160-2172), DistantLight::preprocess
 RDEV float world_radius(const SceneDev& sc) {
     f3 lo{sc.wb_min[0], sc.wb_min[1], sc.wb_min[2]}, hi{sc.wb_max[0], sc.wb_max[1], sc.wb_max[2]};
@@ -408,6 +498,19 @@ RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 
     }
     ls->p_err = f3{0.0f, 0.0f, 0.0f};
     ls->n = f3{0.0f, 0.0f, 0.0f};
+    if (lt.kind == RSPT_LIGHT_INFINITE) {  // infinite.rs:298-341
+        const EnvMapDev& m = sc.envmaps[lt.prim];
+        float map_pdf = 0.0f;
+        f2 uv = env_sample_continuous(m, u, &map_pdf);
+        if (map_pdf == 0.0f) { *pdf = 0.0f; return mkrgb(0.0f); }
+        float theta = uv.y * RSPT_PI, phi = uv.x * 2.0f * RSPT_PI;
+        float cos_theta = cosf(theta), sin_theta = sinf(theta), sin_phi = sinf(phi), cos_phi = cosf(phi);
+        *wi = mat3_mul(lt.p, f3{sin_theta * cos_phi, sin_theta * sin_phi, cos_theta});
+        *pdf = map_pdf / (2.0f * RSPT_PI * RSPT_PI * sin_theta);
+        if (sin_theta == 0.0f) *pdf = 0.0f;
+        ls->p = ref_p + *wi * (2.0f * world_radius(sc));
+        return env_lookup(m, uv, 0.0f);
+    }
     *pdf = 1.0f;
     if (lt.kind == RSPT_LIGHT_DISTANT) {
         f3 w{lt.p[0], lt.p[1], lt.p[2]};
@@ -427,6 +530,7 @@ RDEV rgb light_power(const SceneDev& sc, const rspt_light& lt) {
     if (lt.kind == RSPT_LIGHT_POINT) return ldrgb(lt.L) * (4.0f * RSPT_PI);
     if (lt.kind == RSPT_LIGHT_SPOT) return ldrgb(lt.L) * 2.0f * RSPT_PI * (1.0f - 0.5f * (lt.p[13] + lt.p[12]));
     if (lt.kind == RSPT_LIGHT_DISTANT) { float r = world_radius(sc); return ldrgb(lt.L) * RSPT_PI * r * r; }
+    if (lt.kind == RSPT_LIGHT_INFINITE) { float r = world_radius(sc); return env_lookup(sc.envmaps[lt.prim], f2{0.5f, 0.5f}, 0.5f) * mkrgb(RSPT_PI * r * r); }  // infinite.rs:342-346
     TriRec t = load_tri(sc, lt.prim);
     float factor = lt.two_sided ? 2.0f : 1.0f;
     return ldrgb(lt.L) * factor * tri_area(t) * RSPT_PI;

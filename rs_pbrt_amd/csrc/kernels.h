@@ -22,6 +22,7 @@ enum : uint32_t {
     ST_ALIVE = 1u << 26,         // a continuation ray is in flight
     ST_HAS_C1 = 1u << 27,        // pending light-sample term
     ST_HAS_C2 = 1u << 28,        // pending BSDF-sample (MIS) term
+    ST_C2_ON_MISS = 1u << 29,    // ... of an infinite light: it counts when the MIS ray escapes
 };
 #define RSPT_Q_MIS 0x80000000u   // closest-hit queue entry flag: this is the path's MIS ray
 
@@ -249,7 +250,9 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             float4 hm = pb.hit_mis[p];
             uint32_t hp = __float_as_uint(hm.x);
             uint32_t light_num = __float_as_uint(c2.w);
-            if (hp != RSPT_MISS) {
+            if (st & ST_C2_ON_MISS) {  // InfiniteAreaLight: li = light.le(ray) when nothing was hit (integrator.rs:561-563)
+                if (hp == RSPT_MISS) ldir = ldir + rgb{c2.x, c2.y, c2.z};
+            } else if (hp != RSPT_MISS) {
                 TriRec t = load_tri(sc, hp);
                 if (t.area_light >= 0 && (uint32_t)t.area_light == light_num) {
                     Hit h;
@@ -263,7 +266,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             }
         }
         L = L + rgb{nb.x, nb.y, nb.z} * (ldir / c1.w);
-        st &= ~(ST_PENDING | ST_HAS_C1 | ST_HAS_C2);
+        st &= ~(ST_PENDING | ST_HAS_C1 | ST_HAS_C2 | ST_C2_ON_MISS);
     }
     if (!(st & ST_ALIVE)) {
         pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
@@ -275,7 +278,16 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     float4 hc = pb.hit_cont[p];
     uint32_t prim = __float_as_uint(hc.x);
     uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
-    if (prim != RSPT_MISS) {  // a miss adds nothing: no infinite lights in scope (path.rs:267-277)
+    if (prim == RSPT_MISS) {  // K5: escaped path picks up the infinite lights (path.rs:267-277)
+        if (sc.n_infinite && (bounces == 0 || (st & ST_SPECULAR))) {
+            const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
+            float4 r0 = rp[0], r1 = rp[1];
+            f3 ray_d{r0.w, r1.x, r1.y};
+            float4 bb = pb.beta[p];
+            rgb beta{bb.x, bb.y, bb.z};
+            for (uint32_t i = 0; i < sc.n_infinite; i++) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_lights[i]], ray_d);
+        }
+    } else {
         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
         float4 r0 = rp[0], r1 = rp[1];
         f3 ray_d{r0.w, r1.x, r1.y};
@@ -346,23 +358,30 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                             rgb f = bsdf.sample_f(wo, &wi, u_scatter, &scattering_pdf, nonspec, &sampled_type);
                             f = f * mkrgb(absdot(wi, h.sh_n));
                             if (!is_black(f) && scattering_pdf > 0.0f) {
-                                // DiffuseAreaLight::pdf_li -> Triangle::pdf_with_ref_point (triangle.rs:745-764)
                                 f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
-                                TriRec lt_tri = load_tri(sc, lt.prim);
-                                float t_l, lb0, lb1, lb2;
                                 float lpdf = 0.0f;
-                                if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
-                                    Hit lh;
-                                    tri_fill(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
-                                    lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
-                                    if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+                                rgb le_mis = ldrgb(lt.L);
+                                if (lt.kind == RSPT_LIGHT_INFINITE) {  // InfiniteAreaLight::pdf_li; Le is known from the direction alone
+                                    lpdf = infinite_pdf_li(sc, lt, wi);
+                                    if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
+                                } else {  // DiffuseAreaLight::pdf_li -> Triangle::pdf_with_ref_point (triangle.rs:745-764)
+                                    TriRec lt_tri = load_tri(sc, lt.prim);
+                                    float t_l, lb0, lb1, lb2;
+                                    if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
+                                        Hit lh;
+                                        tri_fill(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
+                                        lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
+                                        if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+                                    }
                                 }
                                 if (lpdf != 0.0f) {
                                     float weight = power_heuristic(scattering_pdf, lpdf);
-                                    store_ray(pb.ray_mis + p, ro, wi, RSPT_INF, p);
-                                    out.mis = true;
-                                    c2 = f * ldrgb(lt.L) * mkrgb(1.0f) * weight / scattering_pdf;
-                                    st |= ST_HAS_C2;
+                                    c2 = f * le_mis * mkrgb(1.0f) * weight / scattering_pdf;
+                                    if (lt.kind != RSPT_LIGHT_INFINITE || !is_black(le_mis)) {
+                                        store_ray(pb.ray_mis + p, ro, wi, RSPT_INF, p);
+                                        out.mis = true;
+                                        st |= ST_HAS_C2 | (lt.kind == RSPT_LIGHT_INFINITE ? ST_C2_ON_MISS : 0u);
+                                    }
                                 }
                             }
                         }

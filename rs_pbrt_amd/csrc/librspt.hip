@@ -574,8 +574,19 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     for (uint32_t i = 0; i < d->n_bxdfs; i++)
         if (d->bxdfs[i].type < RSPT_BXDF_LAMBERT_R || d->bxdfs[i].type > RSPT_BXDF_FRESNEL_BLEND) return fail(RSPT_E_UNSUPPORTED, "bxdf %u: unsupported type %u", i, d->bxdfs[i].type);
     for (uint32_t i = 0; i < d->n_lights; i++) {
-        if (d->lights[i].kind < RSPT_LIGHT_DIFFUSE_AREA || d->lights[i].kind > RSPT_LIGHT_DISTANT) return fail(RSPT_E_UNSUPPORTED, "light %u: unsupported kind %u", i, d->lights[i].kind);
+        if (d->lights[i].kind < RSPT_LIGHT_DIFFUSE_AREA || d->lights[i].kind > RSPT_LIGHT_INFINITE) return fail(RSPT_E_UNSUPPORTED, "light %u: unsupported kind %u", i, d->lights[i].kind);
         if (d->lights[i].kind == RSPT_LIGHT_DIFFUSE_AREA && d->lights[i].prim >= d->n_prims) return fail(RSPT_E_INVALID, "light %u: prim out of range", i);
+        if (d->lights[i].kind == RSPT_LIGHT_INFINITE && d->lights[i].prim >= d->n_envmaps) return fail(RSPT_E_INVALID, "light %u: envmap index out of range", i);
+    }
+    if (d->n_envmaps && !d->envmaps) return fail(RSPT_E_INVALID, "null envmaps");
+    for (uint32_t i = 0; i < d->n_envmaps; i++) {
+        const rspt_envmap& e = d->envmaps[i];
+        auto pow2 = [](uint32_t v) { return v && !(v & (v - 1)); };
+        if (!pow2(e.width) || !pow2(e.height) || e.width > 32768 || e.height > 32768) return fail(RSPT_E_INVALID, "envmap %u: sides must be powers of two <= 32768", i);
+        uint32_t nl = 1;
+        for (uint32_t m = std::max(e.width, e.height); m > 1; m >>= 1) nl++;
+        if (e.n_levels != nl || nl > 16) return fail(RSPT_E_INVALID, "envmap %u: n_levels %u, expected %u", i, e.n_levels, nl);
+        if (!e.texels || !e.dist_func || e.dist_nu == 0 || e.dist_nv == 0) return fail(RSPT_E_INVALID, "envmap %u: null data", i);
     }
     // BVH: child / leaf ranges in bounds, depth <= 64 (the reference's fixed traversal stack, bvh.rs:420)
     if (d->n_nodes) {
@@ -619,6 +630,43 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((rc = upload(s, d->materials, d->n_materials, &s->dev.materials))) return bail(rc);
     if ((rc = upload(s, d->bxdfs, d->n_bxdfs, &s->dev.bxdfs))) return bail(rc);
     if ((rc = upload(s, d->lights, d->n_lights, &s->dev.lights))) return bail(rc);
+    {   // Scene.infinite_lights (scene.rs:40-43) and their environment maps
+        std::vector<uint32_t> inf;
+        for (uint32_t i = 0; i < d->n_lights; i++)
+            if (d->lights[i].kind == RSPT_LIGHT_INFINITE) inf.push_back(i);
+        s->dev.n_infinite = (uint32_t)inf.size();
+        if ((rc = upload(s, inf.data(), inf.size(), &s->dev.infinite_lights))) return bail(rc);
+        std::vector<EnvMapDev> envs(d->n_envmaps);
+        for (uint32_t i = 0; i < d->n_envmaps; i++) {
+            const rspt_envmap& e = d->envmaps[i];
+            EnvMapDev& m = envs[i];
+            m.width = e.width; m.height = e.height; m.n_levels = e.n_levels; m.nu = e.dist_nu; m.nv = e.dist_nv;
+            size_t n_tex = 0;
+            for (uint32_t l = 0, w = e.width, h = e.height; l < e.n_levels; l++, w = std::max(1u, w / 2), h = std::max(1u, h / 2)) {
+                m.level_offset[l] = (uint32_t)n_tex;
+                n_tex += (size_t)w * h;
+            }
+            if ((rc = upload(s, e.texels, n_tex * 3, &m.texels))) return bail(rc);
+            // Distribution2D::new (sampling.rs:156-170) = Distribution1D::new (:24-49) per row and for the marginal
+            const uint32_t nu = e.dist_nu, nv = e.dist_nv;
+            std::vector<float> cdf((size_t)nv * (nu + 1)), fint(nv), mcdf(nv + 1);
+            auto dist1d = [](const float* f, uint32_t n, float* c) {
+                c[0] = 0.0f;
+                for (uint32_t k = 1; k <= n; k++) c[k] = c[k - 1] + f[k - 1] / (float)n;
+                float fi = c[n];
+                if (fi == 0.0f) for (uint32_t k = 1; k <= n; k++) c[k] = (float)k / (float)n;
+                else for (uint32_t k = 1; k <= n; k++) c[k] /= fi;
+                return fi;
+            };
+            for (uint32_t v = 0; v < nv; v++) fint[v] = dist1d(e.dist_func + (size_t)v * nu, nu, cdf.data() + (size_t)v * (nu + 1));
+            m.marg_int = dist1d(fint.data(), nv, mcdf.data());
+            if ((rc = upload(s, e.dist_func, (size_t)nu * nv, &m.cond_func)) || (rc = upload(s, cdf.data(), cdf.size(), &m.cond_cdf)) ||
+                (rc = upload(s, fint.data(), fint.size(), &m.cond_int)) || (rc = upload(s, fint.data(), fint.size(), &m.marg_func)) ||
+                (rc = upload(s, mcdf.data(), mcdf.size(), &m.marg_cdf)))
+                return bail(rc);
+        }
+        if ((rc = upload(s, envs.data(), envs.size(), &s->dev.envmaps))) return bail(rc);
+    }
     s->dev.nodes = reinterpret_cast<const float4*>(nodes_d);
     s->dev.n_nodes = (uint32_t)d->n_nodes; s->dev.n_prims = (uint32_t)d->n_prims; s->dev.n_lights = d->n_lights;
     if (d->n_nodes) {

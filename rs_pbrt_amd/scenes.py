@@ -307,6 +307,57 @@ def rough_glass(kr=(1.0,) * 3, kt=(1.0,) * 3, uroughness=0.1, vroughness=0.1, in
 
 
 # ---------------------------------------------------------------------------------------
+# environment maps: what InfiniteAreaLight::new builds (src/lights/infinite.rs:62-297) — host side
+# ---------------------------------------------------------------------------------------
+def _env_triangle(level_img, s_, t_):  # MipMap::triangle (mipmap.rs:323-336), wrap Repeat, vectorised in f32
+    h, w, _ = level_img.shape
+    s = (s_ * F32(w) - F32(0.5)).astype(F32); t = (t_ * F32(h) - F32(0.5)).astype(F32)
+    s0 = np.floor(s).astype(np.int64); t0 = np.floor(t).astype(np.int64)
+    ds = (s - s0.astype(F32)).astype(F32)[..., None]; dt = (t - t0.astype(F32)).astype(F32)[..., None]
+    tex = lambda a, b: level_img[np.mod(b, h), np.mod(a, w)]  # noqa: E731
+    one = F32(1)
+    tmp1 = tex(s0 + 1, t0 + 1) * (ds * dt); tmp2 = tex(s0 + 1, t0) * (ds * (one - dt))
+    tmp3 = tex(s0, t0 + 1) * ((one - ds) * dt); tmp4 = tex(s0, t0) * ((one - ds) * (one - dt))
+    return (((tmp4 + tmp3).astype(F32) + tmp2).astype(F32) + tmp1).astype(F32)
+
+
+def build_envmap(texels):
+    """texels (h, w, 3) f32, power-of-two sides (rs_pbrt resamples other sizes first, mipmap.rs:64-148).
+    Returns the MIP pyramid (mipmap.rs:154-185) and the scalar image of the sampling distribution
+    (infinite.rs:120-137)."""
+    img = np.ascontiguousarray(texels, F32)
+    h, w, _ = img.shape
+    assert w & (w - 1) == 0 and h & (h - 1) == 0, "environment map sides must be powers of two"
+    n_levels = 1 + int(math.log2(max(w, h)))
+    levels = [img]
+    for _ in range(1, n_levels):
+        p = levels[-1]
+        ph, pw, _ = p.shape
+        sh, sw = max(1, ph // 2), max(1, pw // 2)
+        ti, si = np.meshgrid(np.arange(sh), np.arange(sw), indexing="ij")
+        tex = lambda a, b: p[np.mod(b, ph), np.mod(a, pw)]  # noqa: E731
+        acc = (((tex(2 * si, 2 * ti) + tex(2 * si + 1, 2 * ti)).astype(F32) + tex(2 * si, 2 * ti + 1)).astype(F32) + tex(2 * si + 1, 2 * ti + 1)).astype(F32)
+        levels.append((acc * F32(0.25)).astype(F32))
+    nu, nv = 2 * w, 2 * h
+    fwidth = F32(0.5) / F32(min(nu, nv))
+    vv, uu = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    up = ((uu.astype(F32) + F32(0.5)) / F32(nu)).astype(F32); vp = ((vv.astype(F32) + F32(0.5)) / F32(nv)).astype(F32)
+    level = F32(n_levels) - F32(1) + F32(math.log2(max(float(fwidth), 1e-8)))
+    if level < 0:
+        val = _env_triangle(levels[0], up, vp)
+    elif level >= n_levels - 1:
+        val = np.broadcast_to(levels[-1][0, 0], up.shape + (3,)).astype(F32)
+    else:
+        il = int(math.floor(level)); delta = F32(level - F32(il))
+        val = (_env_triangle(levels[il], up, vp) * (F32(1) - delta) + _env_triangle(levels[il + 1], up, vp) * delta).astype(F32)
+    y = (F32(0.212671) * val[..., 0] + F32(0.715160) * val[..., 1]).astype(F32) + F32(0.072169) * val[..., 2]
+    sin_theta = np.sin((F32(math.pi) * (vv.astype(F32) + F32(0.5)) / F32(nv)).astype(F32)).astype(F32)
+    dist = np.ascontiguousarray((y.astype(F32) * sin_theta).astype(F32))
+    return dict(width=w, height=h, n_levels=n_levels, texels=np.ascontiguousarray(np.concatenate([l.reshape(-1) for l in levels]), F32),
+                dist_nu=nu, dist_nv=nv, dist_func=dist)
+
+
+# ---------------------------------------------------------------------------------------
 # A scene before BVH build: meshes with per-mesh material / emission
 # ---------------------------------------------------------------------------------------
 class SceneBuilder:
@@ -316,7 +367,8 @@ class SceneBuilder:
         self.materials = []
         self.nv = 0
         self.any_n = self.any_uv = False
-        self.delta_lights = []  # appended to Scene.lights after the area lights
+        self.delta_lights = []  # point / spot / distant / infinite: appended to Scene.lights after the area lights
+        self.envmaps = []
 
     def add_material(self, m):
         self.materials.append(m)
@@ -372,6 +424,17 @@ class SceneBuilder:
         lt["kind"] = abi.LIGHT_DISTANT; lt["L"] = np.array(L, F32); lt["p"][:3] = w.astype(F32)
         self.delta_lights.append(lt)
 
+    def add_infinite_light(self, L=(1.0, 1.0, 1.0), image=None, light_to_world=None):
+        """LightSource "infinite" (api.rs:855-888, infinite.rs:62-297): constant radiance L (a 1x1 map) or a
+        lat-long `image` (h, w, 3) with power-of-two sides, multiplied by L.  light_to_world: 3x3 rotation."""
+        env = build_envmap(np.array(L, F32)[None, None, :] * (np.ones((1, 1, 3), F32) if image is None else np.asarray(image, F32)))
+        self.envmaps.append(env)
+        l2w = np.eye(3, dtype=F32) if light_to_world is None else np.asarray(light_to_world, F32).reshape(3, 3)
+        lt = np.zeros((), abi.LIGHT_DT)
+        lt["kind"] = abi.LIGHT_INFINITE; lt["prim"] = len(self.envmaps) - 1; lt["L"] = np.array(L, F32)
+        lt["p"][:9] = l2w.reshape(-1); lt["p"][9:18] = np.linalg.inv(l2w.astype(np.float64)).astype(F32).reshape(-1)
+        self.delta_lights.append(lt)
+
     def finish(self, bvh_builder, max_prims_in_node=4):
         """bvh_builder(P (nv,3) f32, tri (nt,3) u32, max_prims) -> (nodes NODE_DT[], ordered u32[])"""
         P = np.ascontiguousarray(np.concatenate(self.P), F32)
@@ -406,19 +469,24 @@ class SceneBuilder:
         return Scene(nodes=nodes, prims=prims, meshes=meshes, P=P,
                      N=np.ascontiguousarray(np.concatenate(self.N), F32) if self.any_n else None,
                      UV=np.ascontiguousarray(np.concatenate(self.UV), F32) if self.any_uv else None,
-                     materials=mats, bxdfs=bxdfs, lights=lights)
+                     materials=mats, bxdfs=bxdfs, lights=lights, envmaps=self.envmaps)
 
 
 class Scene:
     """Flattened scene arrays + the ctypes rspt_scene_desc pointing at them."""
 
-    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None):
+    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=()):
         self.nodes, self.prims, self.meshes, self.P, self.N, self.UV, self.S = nodes, prims, meshes, P, N, UV, S
         self.materials, self.bxdfs, self.lights = materials, bxdfs, lights
+        self.envmaps = list(envmaps)
         p = lambda a: a.ctypes.data if a is not None and a.size else None  # noqa: E731
+        self._env_structs = (abi.EnvMap * max(len(self.envmaps), 1))()
+        for i, e in enumerate(self.envmaps):
+            self._env_structs[i] = abi.EnvMap(e["width"], e["height"], e["n_levels"], 0, e["texels"].ctypes.data, e["dist_nu"], e["dist_nv"], e["dist_func"].ctypes.data)
         self.desc = abi.SceneDesc(p(nodes), len(nodes), p(prims), len(prims), p(meshes), len(meshes),
                                   p(P), p(N), p(S), p(UV), len(P),
-                                  p(materials), len(materials), p(bxdfs), len(bxdfs), p(lights), len(lights))
+                                  p(materials), len(materials), p(bxdfs), len(bxdfs), p(lights), len(lights),
+                                  C.addressof(self._env_structs) if self.envmaps else None, len(self.envmaps))
 
     @property
     def n_tris(self):

@@ -477,3 +477,33 @@ def test_halton_render_close_to_sobol_and_reproducible(oracle):
     assert np.array_equal(a["film"], b["film"])
     ra, rs = scenes.film_to_rgb(a["film"]).mean(0), scenes.film_to_rgb(s["film"]).mean(0)
     assert np.allclose(ra, rs, rtol=0.03)  # two different low-discrepancy estimators of the same image
+
+
+# ---------------------------------------------------------------- infinite area light
+def test_uniform_sky_analytic_radiance(oracle):
+    """an unoccluded diffuse floor under a constant environment L: outgoing radiance = rho * L exactly
+    (direct only, max_depth 1); the sky itself shows L; light sampling + BSDF sampling with MIS must
+    agree with it"""
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_quad([(-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50)], m)
+    sb.add_infinite_light((2.0, 2.0, 2.0))
+    sc = sb.finish(oracle.bvh_build)
+    rd = scenes.make_render_desc(24, 24, 64, ((0, 5, 0.001), (0, 0, 0), (0, 0, 1)), 30, max_depth=1)
+    rgb = scenes.film_to_rgb(oracle.render(sc, rd, threads=4)["film"])
+    assert abs(rgb.mean() - 1.0) < 0.02
+    up = scenes.make_render_desc(8, 8, 4, ((0, 5, 0), (0, 50, 0.001), (0, 0, 1)), 30, max_depth=1)
+    sky = scenes.film_to_rgb(oracle.render(sc, up, threads=1)["film"])
+    assert np.allclose(sky, 2.0, rtol=1e-5)
+
+
+def test_envmap_pyramid_and_distribution_host_build():
+    img = np.arange(4 * 8 * 3, dtype=np.float32).reshape(4, 8, 3)
+    e = scenes.build_envmap(img)
+    assert (e["width"], e["height"], e["n_levels"]) == (8, 4, 4)
+    assert len(e["texels"]) == 3 * (32 + 8 + 2 + 1)
+    lvl1 = e["texels"][96:96 + 24].reshape(2, 4, 3)
+    assert np.allclose(lvl1[0, 0], img[:2, :2].reshape(-1, 3).mean(0))          # 2x2 box filter
+    assert np.allclose(e["texels"][-3:], img.reshape(-1, 3).mean(0), rtol=1e-6)  # top of the pyramid = mean
+    assert e["dist_func"].shape == (8, 16) and (e["dist_func"] > 0).all()
+    assert e["dist_func"][0].mean() < e["dist_func"][3].mean()                   # sin(theta) weighting towards the equator

@@ -56,3 +56,30 @@ def gallery(builder, lights="all"):
 
 
 GALLERY_LOOK_AT = ((0, 3, -4.8), (0, 2, 2), (0, 1, 0))
+
+
+def sky_scene(builder, kind="constant", with_area=False):
+    """ground + a few blocks (matte / plastic / mirror) under an InfiniteAreaLight: a constant sky or an
+    8x4 lat-long map with a bright patch, rotated about x"""
+    sb = scenes.SceneBuilder()
+    ground = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    mats = [sb.add_material(scenes.matte((0.7, 0.3, 0.2))), sb.add_material(scenes.plastic((0.3, 0.4, 0.6), (0.4, 0.4, 0.4), 0.1)), sb.add_material(scenes.mirror())]
+    sb.add_quad([(-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6)], ground)
+    for i, m in enumerate(mats):
+        x = -2.5 + 2.5 * i
+        P = np.array([(x - 0.8, 0, -0.8), (x + 0.8, 0, -0.8), (x + 0.8, 0, 0.8), (x - 0.8, 0, 0.8), (x, 1.8, 0)], np.float32)
+        sb.add_mesh(P, [[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]], m)
+    if kind == "constant":
+        sb.add_infinite_light((0.9, 1.0, 1.2))
+    else:
+        rng = np.random.default_rng(5)
+        img = rng.uniform(0.05, 0.4, (4, 8, 3)).astype(np.float32)
+        img[1, 2] = (30.0, 28.0, 20.0)  # a sun-like texel
+        c, s_ = np.cos(0.6), np.sin(0.6)
+        sb.add_infinite_light((1.0, 1.0, 1.0), image=img, light_to_world=[[1, 0, 0], [0, c, -s_], [0, s_, c]])
+    if with_area:
+        sb.add_quad([(-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1)], ground, emit=(8, 8, 8))
+    return sb.finish(builder)
+
+
+SKY_LOOK_AT = ((0, 2.5, -7), (0, 0.6, 0), (0, 1, 0))
