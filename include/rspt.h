@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 4
+#define RSPT_ABI_VERSION 5
 
 /* error codes */
 #define RSPT_OK 0
@@ -104,7 +104,10 @@ typedef struct {
                                (microfacet.rs:233-254)                                */
     float c1[3], c2[3]; /* conductor eta_t, k                                         */
     float on_a, on_b;   /* OrenNayar A, B (reflection.rs:1057-1065)                   */
-} rspt_bxdf; /* 80 B */
+    float sc[3];        /* MixMaterial scale of this lobe (sc_opt, src/materials/mixmat.rs:43-70):
+                           the reference multiplies it in front of the lobe's value       */
+    uint32_t has_sc;    /* 0 = sc_opt is None                                         */
+} rspt_bxdf; /* 96 B */
 
 typedef struct {
     float eta;          /* Bsdf.eta (reflection.rs:224)                               */

@@ -174,10 +174,12 @@ struct Lobe {
         default: return Spec(1.0f);
         }
     }
+    // sc_opt (MixMaterial): `sc * A * B ...` evaluates as ((sc * A) * B) ...; scaled(A) is that first product
+    Spec scaled(Spec a) const { return b->has_sc ? S3(b->sc) * a : a; }
     Spec f(V3 wo, V3 wi) const {
         switch (b->type) {
-        case RSPT_BXDF_LAMBERT_R: return S3(b->r) * Spec(INV_PI); // :960-966
-        case RSPT_BXDF_LAMBERT_T: return S3(b->r) * INV_PI;       // :1011-1017
+        case RSPT_BXDF_LAMBERT_R: return scaled(S3(b->r)) * Spec(INV_PI); // :960-966
+        case RSPT_BXDF_LAMBERT_T: return scaled(S3(b->r)) * INV_PI;       // :1011-1017
         case RSPT_BXDF_OREN_NAYAR: {                               // :1067-1096
             Float sti = sin_theta(wi), sto = sin_theta(wo);
             Float max_cos = 0.0f;
@@ -189,7 +191,7 @@ struct Lobe {
             Float sin_alpha, tan_beta;
             if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sin_alpha = sto; tan_beta = sti / abs_cos_theta(wi); }
             else { sin_alpha = sti; tan_beta = sto / abs_cos_theta(wo); }
-            return S3(b->r) * Spec(INV_PI * (b->on_a + b->on_b * max_cos * sin_alpha * tan_beta));
+            return scaled(S3(b->r)) * Spec(INV_PI * (b->on_a + b->on_b * max_cos * sin_alpha * tan_beta));
         }
         case RSPT_BXDF_MICROFACET_R: { // :1147-1170
             Float cto = abs_cos_theta(wo), cti = abs_cos_theta(wi);
@@ -200,7 +202,7 @@ struct Lobe {
             Float dt = dot(wi, wh);
             Spec fr = fresnel(dt);
             TR tr{b->alpha_x, b->alpha_y};
-            return S3(b->r) * tr.d(wh) * tr.g(wo, wi) * fr / (4.0f * cti * cto);
+            return scaled(S3(b->r)) * tr.d(wh) * tr.g(wo, wi) * fr / (4.0f * cti * cto);
         }
         case RSPT_BXDF_MICROFACET_T: { // :1246-1317 (TransportMode::Radiance)
             if (same_hemisphere(wo, wi)) return Spec(0.0f);
@@ -214,7 +216,7 @@ struct Lobe {
             Float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
             Float factor = 1.0f / eta;
             TR tr{b->alpha_x, b->alpha_y};
-            return (Spec(1.0f) - f) * S3(b->r) *
+            return scaled(Spec(1.0f) - f) * S3(b->r) *
                    std::fabs(tr.d(wh) * tr.g(wo, wi) * eta * eta * abs_dot(wi, wh) * abs_dot(wo, wh) * factor * factor / (cti * cto * sqrt_denom * sqrt_denom));
         }
         case RSPT_BXDF_FRESNEL_BLEND: { // :1398-1431; rd = r, rs = t
@@ -227,7 +229,7 @@ struct Lobe {
             TR tr{b->alpha_x, b->alpha_y};
             Spec schlick = rs + (Spec(1.0f) - rs) * pow5(1.0f - dot(wi, wh));
             Spec specular = schlick * (tr.d(wh) / (4.0f * std::fabs(dot(wi, wh)) * std::fmax(abs_cos_theta(wi), abs_cos_theta(wo))));
-            return diffuse + specular;
+            return b->has_sc ? S3(b->sc) * (diffuse + specular) : diffuse + specular;
         }
         default: return Spec(0.0f); // specular lobes :721,782,866
         }
@@ -285,7 +287,7 @@ struct Lobe {
         case RSPT_BXDF_SPECULAR_R: { // :724-745
             *wi = V3{-wo.x, -wo.y, wo.z};
             *pdf_out = 1.0f;
-            return fresnel(cos_theta(*wi)) * S3(b->r) / abs_cos_theta(*wi);
+            return scaled(fresnel(cos_theta(*wi))) * S3(b->r) / abs_cos_theta(*wi);
         }
         case RSPT_BXDF_SPECULAR_T: { // :785-826
             bool entering = cos_theta(wo) > 0.0f;
@@ -294,7 +296,7 @@ struct Lobe {
             *pdf_out = 1.0f;
             Spec ft = S3(b->r) * (Spec(1.0f) - Spec(fr_dielectric(cos_theta(*wi), b->eta_a, b->eta_b)));
             ft = ft * Spec((eta_i * eta_i) / (eta_t * eta_t)); // TransportMode::Radiance
-            return ft / abs_cos_theta(*wi);
+            return scaled(ft) / abs_cos_theta(*wi);
         }
         case RSPT_BXDF_FRESNEL_SPEC: { // :869-936
             Float ct = cos_theta(wo);
@@ -303,7 +305,7 @@ struct Lobe {
                 *wi = V3{-wo.x, -wo.y, wo.z};
                 if (*sampled_type != 0) *sampled_type = BSDF_REFLECTION | BSDF_SPECULAR;
                 *pdf_out = fr;
-                return S3(b->r) * fr / abs_cos_theta(*wi);
+                return scaled(S3(b->r)) * fr / abs_cos_theta(*wi);
             } else {
                 bool entering = cos_theta(wo) > 0.0f;
                 Float eta_i = entering ? b->eta_a : b->eta_b, eta_t = entering ? b->eta_b : b->eta_a;
@@ -312,7 +314,7 @@ struct Lobe {
                 ft = ft * Spec((eta_i * eta_i) / (eta_t * eta_t));
                 if (*sampled_type != 0) *sampled_type = BSDF_TRANSMISSION | BSDF_SPECULAR;
                 *pdf_out = 1.0f - fr;
-                return ft / abs_cos_theta(*wi);
+                return scaled(ft) / abs_cos_theta(*wi);
             }
         }
         case RSPT_BXDF_MICROFACET_R: { // :1172-1195

@@ -185,10 +185,13 @@ RDEV rgb lobe_fresnel(const rspt_bxdf& b, float ci) {  // Fresnel::evaluate :651
     return mkrgb(1.0f);
 }
 
+// sc_opt of MixMaterial lobes: the reference writes `sc * A * B ...`, i.e. ((sc * A) * B) ...
+RDEV rgb lobe_scaled(const rspt_bxdf& b, rgb a) { return b.has_sc ? ldrgb(b.sc) * a : a; }
+
 RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
     switch (b.type) {
-    case RSPT_BXDF_LAMBERT_R: return ldrgb(b.r) * mkrgb(RSPT_INV_PI);
-    case RSPT_BXDF_LAMBERT_T: return ldrgb(b.r) * RSPT_INV_PI;
+    case RSPT_BXDF_LAMBERT_R: return lobe_scaled(b, ldrgb(b.r)) * mkrgb(RSPT_INV_PI);
+    case RSPT_BXDF_LAMBERT_T: return lobe_scaled(b, ldrgb(b.r)) * RSPT_INV_PI;
     case RSPT_BXDF_OREN_NAYAR: {
         float sti = sin_t(wi), sto = sin_t(wo);
         float max_cos = 0.0f;
@@ -199,7 +202,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         float sin_alpha, tan_beta;
         if (fabsf(wi.z) > fabsf(wo.z)) { sin_alpha = sto; tan_beta = sti / fabsf(wi.z); }
         else { sin_alpha = sti; tan_beta = sto / fabsf(wo.z); }
-        return ldrgb(b.r) * mkrgb(RSPT_INV_PI * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta));
+        return lobe_scaled(b, ldrgb(b.r)) * mkrgb(RSPT_INV_PI * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta));
     }
     case RSPT_BXDF_MICROFACET_R: {
         float cto = fabsf(wo.z), cti = fabsf(wi.z);
@@ -208,7 +211,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
         wh = normalize(wh);
         rgb fr = lobe_fresnel(b, dot(wi, wh));
-        return ldrgb(b.r) * tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * fr / (4.0f * cti * cto);
+        return lobe_scaled(b, ldrgb(b.r)) * tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * fr / (4.0f * cti * cto);
     }
     case RSPT_BXDF_MICROFACET_T: {  // MicrofacetTransmission::f, TransportMode::Radiance (reflection.rs:1246-1317)
         if (same_hemi(wo, wi)) return mkrgb(0.0f);
@@ -221,7 +224,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         rgb fr = mkrgb(fr_dielectric(dot(wo, wh), b.eta_a, b.eta_b));
         float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = 1.0f / eta;
-        return (mkrgb(1.0f) - fr) * ldrgb(b.r) *
+        return lobe_scaled(b, mkrgb(1.0f) - fr) * ldrgb(b.r) *
                fabsf(tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                      (cti * cto * sqrt_denom * sqrt_denom));
     }
@@ -233,7 +236,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         wh = normalize(wh);
         rgb schlick = rs + (mkrgb(1.0f) - rs) * pow5(1.0f - dot(wi, wh));
         rgb specular = schlick * (tr_d(b.alpha_x, b.alpha_y, wh) / (4.0f * fabsf(dot(wi, wh)) * fmaxf(fabsf(wi.z), fabsf(wo.z))));
-        return diffuse + specular;
+        return b.has_sc ? ldrgb(b.sc) * (diffuse + specular) : diffuse + specular;
     }
     default: return mkrgb(0.0f);
     }
@@ -290,7 +293,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
     case RSPT_BXDF_SPECULAR_R: {
         *wi = f3{-wo.x, -wo.y, wo.z};
         *pdf = 1.0f;
-        return lobe_fresnel(b, wi->z) * ldrgb(b.r) / fabsf(wi->z);
+        return lobe_scaled(b, lobe_fresnel(b, wi->z)) * ldrgb(b.r) / fabsf(wi->z);
     }
     case RSPT_BXDF_SPECULAR_T: {
         bool entering = wo.z > 0.0f;
@@ -299,7 +302,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
         *pdf = 1.0f;
         rgb ft = ldrgb(b.r) * (mkrgb(1.0f) - mkrgb(fr_dielectric(wi->z, b.eta_a, b.eta_b)));
         ft = ft * mkrgb((ei * ei) / (et * et));
-        return ft / fabsf(wi->z);
+        return lobe_scaled(b, ft) / fabsf(wi->z);
     }
     case RSPT_BXDF_FRESNEL_SPEC: {
         float fr = fr_dielectric(wo.z, b.eta_a, b.eta_b);
@@ -307,7 +310,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
             *wi = f3{-wo.x, -wo.y, wo.z};
             if (*sampled_type != 0) *sampled_type = BX_REFL | BX_SPEC;
             *pdf = fr;
-            return ldrgb(b.r) * fr / fabsf(wi->z);
+            return lobe_scaled(b, ldrgb(b.r)) * fr / fabsf(wi->z);
         }
         bool entering = wo.z > 0.0f;
         float ei = entering ? b.eta_a : b.eta_b, et = entering ? b.eta_b : b.eta_a;
@@ -316,7 +319,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
         ft = ft * mkrgb((ei * ei) / (et * et));
         if (*sampled_type != 0) *sampled_type = BX_TRANS | BX_SPEC;
         *pdf = 1.0f - fr;
-        return ft / fabsf(wi->z);
+        return lobe_scaled(b, ft) / fabsf(wi->z);
     }
     case RSPT_BXDF_MICROFACET_R: {
         if (wo.z == 0.0f) return black;

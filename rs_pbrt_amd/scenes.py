@@ -294,6 +294,19 @@ def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.
     return dict(eta=float(eta), lobes=lobes)
 
 
+def mix(m1, m2, amount=(0.5, 0.5, 0.5)):  # mixmat.rs:43-305: m1 scaled by `amount`, m2 by 1 - amount, lobes concatenated
+    s1 = np.maximum(np.array(amount, F32), 0)
+    s2 = np.maximum(F32(1) - s1, 0).astype(F32)
+    lobes = []
+    for m, sc in ((m1, s1), (m2, s2)):
+        for lb in m["lobes"]:
+            lb = lb.copy()
+            lb["sc"] = sc; lb["has_sc"] = 1
+            lobes.append(lb)
+    assert len(lobes) <= 8, "Bsdf holds at most 8 BxDFs (reflection.rs:40)"
+    return dict(eta=m1["eta"], lobes=lobes)
+
+
 def rough_glass(kr=(1.0,) * 3, kt=(1.0,) * 3, uroughness=0.1, vroughness=0.1, index=1.5, remap=True):  # glass.rs:83-211, rough branch
     au = tr_roughness_to_alpha(uroughness) if remap else F32(uroughness)
     av = tr_roughness_to_alpha(vroughness) if remap else F32(vroughness)

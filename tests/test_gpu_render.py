@@ -243,3 +243,25 @@ def test_infinite_light_power_and_spatial_strategies(gpu, oracle):
         rd = scenes.make_render_desc(48, 36, 8, SKY_LOOK_AT, 50, max_depth=3, light_strategy=strategy)
         film, _, _, ref = _render_pair(gpu, oracle, sc, rd, want_li=False)
         assert film_rmse(film, ref["film"]) < 2e-4
+
+
+def test_mix_material(gpu, oracle):
+    """MixMaterial lobes with their per-lobe scale (sc_opt) through every lobe kind that can carry one"""
+    sb = scenes.SceneBuilder()
+    white = sb.add_material(scenes.matte((0.7, 0.7, 0.7)))
+    m1 = sb.add_material(scenes.mix(scenes.mirror((0.9, 0.9, 0.9)), scenes.matte((0.7, 0.2, 0.2), sigma=20.0), (0.3, 0.4, 0.5)))
+    m2 = sb.add_material(scenes.mix(scenes.glass(), scenes.plastic((0.2, 0.5, 0.3), (0.4, 0.4, 0.4), 0.15), (0.6, 0.6, 0.6)))
+    m3 = sb.add_material(scenes.mix(scenes.substrate((0.4, 0.4, 0.1), (0.2, 0.2, 0.2), 0.1, 0.1), scenes.translucent(), (0.5, 0.2, 0.8)))
+    q = sb.add_quad
+    q([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], white)
+    q([(-5, 0, 5), (-5, 6, 5), (5, 6, 5), (5, 0, 5)], white)
+    for i, m in enumerate((m1, m2, m3)):
+        x = -3.5 + 2.6 * i
+        q([(x, 0.3, 1), (x + 2, 0.3, 1), (x + 2, 3.0, 2.2), (x, 3.0, 2.2)], m)
+    q([(-1.5, 5.9, -1.5), (1.5, 5.9, -1.5), (1.5, 5.9, 1.5), (-1.5, 5.9, 1.5)], white, emit=(9, 9, 9))
+    sc = sb.finish(gpu.bvh_build)
+    rd = scenes.make_render_desc(80, 60, 16, ((0, 3, -5.5), (0, 1.8, 2), (0, 1, 0)), 55, max_depth=6)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 2e-5
+    assert (li == ref["li"]).all(axis=2).mean() > 0.6

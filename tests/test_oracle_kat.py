@@ -507,3 +507,18 @@ def test_envmap_pyramid_and_distribution_host_build():
     assert np.allclose(e["texels"][-3:], img.reshape(-1, 3).mean(0), rtol=1e-6)  # top of the pyramid = mean
     assert e["dist_func"].shape == (8, 16) and (e["dist_func"] > 0).all()
     assert e["dist_func"][0].mean() < e["dist_func"][3].mean()                   # sin(theta) weighting towards the equator
+
+
+def test_mix_material_scales_lobes(oracle):
+    """MixMaterial: lobes of both children, each carrying its scale (mixmat.rs:43-70): f = s1*f1 + s2*f2"""
+    a, b = scenes.matte((0.8, 0.2, 0.2)), scenes.plastic((0.1, 0.5, 0.1), (0.3, 0.3, 0.3), 0.2)
+    m = scenes.mix(a, b, (0.25, 0.5, 1.0))
+    assert len(m["lobes"]) == 3 and all(int(l["has_sc"]) == 1 for l in m["lobes"])
+    for wo, wi in zip(_dirs(10, 41), _dirs(10, 42)):
+        fm, _ = _f(oracle, m, wo, wi); fa, _ = _f(oracle, a, wo, wi); fb, _ = _f(oracle, b, wo, wi)
+        s1 = np.array([0.25, 0.5, 1.0], F32)
+        assert np.allclose(fm, s1 * fa + (1 - s1) * fb, rtol=1e-5, atol=1e-7)
+    # specular children: the scale multiplies the sampled value
+    ms = scenes.mix(scenes.mirror((1, 1, 1)), scenes.matte((0.5, 0.5, 0.5)), (0.3, 0.3, 0.3))
+    f, wi, pdf, st = _sample(oracle, ms, (0.3, 0.1, 0.95), (0.1, 0.5))  # u.x < 0.5 picks lobe 0 = mirror
+    assert st & 16 and abs(pdf - 0.5) < 1e-7 and np.allclose(f * abs(wi[2]), 0.3, rtol=1e-5)
