@@ -9,13 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/rspt.h"
 #include "kernels.h"
-#include "trace_wide.h"
+#include "trace_w4.h"
 
 using namespace rspt;
 
@@ -83,6 +84,9 @@ struct LightDist {
 struct rspt_scene_s {
     SceneDev dev{};
     const PairNode* pairs = nullptr;  // one per interior LinearBVHNode (trace_wide.h)
+    const Wide4Node* w4 = nullptr;    // one per interior LinearBVHNode at even depth (trace_w4.h)
+    const uint2* big_leaves = nullptr;
+    uint32_t w4_root = 0;
     std::vector<void*> allocs;
     bool has_null_material = false;
     std::map<int, LightDist> light_dists;  // by effective strategy
@@ -241,13 +245,18 @@ template <bool ANY, int OUT_MODE>
 void launch_trace(bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                   const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
     const SceneDev& sc = s->dev;
-    // RSPT_TRACE_KERNEL: 0 = k_trace (reference-order single-ray loop), 1 = k_trace_pw (persistent waves, default).
+    // RSPT_TRACE_KERNEL: 0 = k_trace (reference-order single-ray loop), 1 = k_trace_pw (persistent waves, two boxes
+    // per record), 2 = k_trace_w4 (persistent waves, four boxes per record; default).
     // (A quad-per-ray variant with one coalesced 64-byte fetch per step was measured 35 % slower: the
     //  replicated control flow made it VALU-bound with 16 rays per wave)
-    const bool use_pw = env_size("RSPT_TRACE_KERNEL", 1) != 0;
-    if (!count && use_pw) {
+    const size_t which = env_size("RSPT_TRACE_KERNEL", 2);
+    if (!count && which != 0) {
         const uint32_t pgrid = grid_for((uint32_t)env_size("RSPT_PW_BLOCKS_PER_CU", 8));
         uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
+        if (which == 2)
+            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                               ra, rb, oa, ob, occ, hits, n_overflow, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+        else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
         hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, n_overflow, ra, rb, oa, ob, occ, hits);
@@ -706,6 +715,69 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             p.axis = n.axis;
         }
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->pairs))) return bail(rc);
+    }
+    if (d->n_nodes > 0) {  // four-box records (trace_w4.h): grandchildren of every interior node at even depth
+        std::vector<uint2> big;
+        auto leaf_ref = [&](uint32_t ni) -> uint32_t {
+            const rspt_bvh_node& n = d->nodes[ni];
+            const uint32_t off = (uint32_t)n.offset, cnt = n.n_prims;
+            if (cnt <= 15u && off <= RSPT_W4_OFFSET_MASK) return RSPT_REF_LEAF | ((cnt - 1u) << RSPT_W4_COUNT_SHIFT) | off;
+            big.push_back(make_uint2(off, cnt));
+            return RSPT_REF_LEAF | (15u << RSPT_W4_COUNT_SHIFT) | (uint32_t)(big.size() - 1);
+        };
+        std::vector<Wide4Node> recs;
+        if (d->nodes[0].n_prims != 0) {
+            s->w4_root = leaf_ref(0);
+        } else {
+            const float qnan = std::numeric_limits<float>::quiet_NaN();
+            std::vector<std::pair<uint32_t, uint32_t>> todo;  // (LinearBVHNode index, record index); records in depth-first order
+            recs.emplace_back();
+            todo.emplace_back(0u, 0u);
+            while (!todo.empty()) {
+                const auto [ai, ri] = todo.back();
+                todo.pop_back();
+                const rspt_bvh_node& a = d->nodes[ai];
+                uint32_t slot_node[4] = {RSPT_NONE, RSPT_NONE, RSPT_NONE, RSPT_NONE};
+                uint32_t axes = a.axis;
+                const uint32_t child[2] = {ai + 1u, (uint32_t)a.offset};
+                for (int gi = 0; gi < 2; gi++) {
+                    const rspt_bvh_node& c = d->nodes[child[gi]];
+                    if (c.n_prims != 0) {
+                        slot_node[2 * gi] = child[gi];
+                    } else {
+                        axes |= (uint32_t)c.axis << (2 + 2 * gi);
+                        slot_node[2 * gi] = child[gi] + 1u;
+                        slot_node[2 * gi + 1] = (uint32_t)c.offset;
+                    }
+                }
+                Wide4Node w{};
+                w.axes = axes;
+                float lo[4][3], hi[4][3];
+                uint32_t pending[4], n_pending = 0;
+                for (int k = 0; k < 4; k++) {
+                    if (slot_node[k] == RSPT_NONE) {
+                        for (int c = 0; c < 3; c++) lo[k][c] = hi[k][c] = qnan;
+                        w.ref[k] = RSPT_NONE;
+                        continue;
+                    }
+                    const rspt_bvh_node& x = d->nodes[slot_node[k]];
+                    for (int c = 0; c < 3; c++) { lo[k][c] = x.bmin[c]; hi[k][c] = x.bmax[c]; }
+                    if (x.n_prims != 0) w.ref[k] = leaf_ref(slot_node[k]);
+                    else pending[n_pending++] = (uint32_t)k;
+                }
+                // children records are numbered so that the first slot's subtree follows its parent (pushed last)
+                for (uint32_t j = 0; j < n_pending; j++) { w.ref[pending[j]] = (uint32_t)recs.size(); recs.emplace_back(); }
+                for (uint32_t j = n_pending; j-- > 0;) todo.emplace_back(slot_node[pending[j]], w.ref[pending[j]]);
+                for (int c = 0; c < 3; c++) {
+                    w.b[c] = make_float4(lo[0][c], lo[1][c], hi[0][c], hi[1][c]);
+                    w.b[3 + c] = make_float4(lo[2][c], lo[3][c], hi[2][c], hi[3][c]);
+                }
+                recs[ri] = w;
+            }
+            s->w4_root = 0u;
+        }
+        if (!recs.empty() && (rc = upload(s, recs.data(), recs.size(), &s->w4))) return bail(rc);
+        if (!big.empty() && (rc = upload(s, big.data(), big.size(), &s->big_leaves))) return bail(rc);
     }
     *out = s;
     return RSPT_OK;

@@ -1,0 +1,272 @@
+// k_trace_w4 — the production traversal kernel (K2/K3): persistent waves, dynamic ray fetch,
+// four-boxes-per-record BVH nodes, entry distances on the stack, deferred leaf phase.
+//
+// Like k_trace_pw (trace_wide.h) it produces, for every ray, exactly the triangle-test sequence
+// of BVHAccel::intersect / intersect_p (bvh.rs:401-514) — near child first by dir_is_neg[axis],
+// the shrinking t_max applied to every later box and triangle test — so (prim, t, b0, b1, b2) are
+// bit-identical to the reference, ties included.  Two things are done differently from k_trace_pw:
+//
+//   * One 128-byte record per interior node A at even depth holds the boxes of A's grandchildren
+//     (or of a child that is a leaf): slots 0,1 = children of A's first child, slots 2,3 = children
+//     of A's second child.  The reference visits them in the order fixed by three sign bits
+//     (dir_is_neg[A.axis] picks the group, dir_is_neg[child.axis] the order inside a group).  The
+//     skipped intermediate box test is redundant: a grandchild's box lies inside its parent's box
+//     and Bounds3f::intersect_p (geometry.rs:2211-2269) is monotone in the box (same products,
+//     monotone rounding), so a ray that reaches a grandchild's box also passes the parent's.
+//     Halving the number of dependent fetch + pop/push rounds is what pays: the kernel is bound by
+//     VALU issue, not by bytes.
+//   * intersect_p depends on ray.t_max only through its last comparison `t_min < ray.t_max`.  The
+//     stack therefore keeps (ref, t_min) and a pop re-checks `t_min < t_max` — exactly the outcome
+//     of the reference's box test at the later moment (with the smaller t_max) — without fetching
+//     the node again.  Entries whose box failed the t_max-independent part are never pushed.
+//
+// Leaf refs carry (first primitive, count) so the leaf phase needs no LinearBVHNode fetch.
+#pragma once
+#include "trace_wide.h"
+
+namespace rspt {
+
+struct Wide4Node {      // 128 B, 128-byte aligned
+    float4 b[6];        // b[0..2]: x, y, z slabs of slots 0,1 as (s0.min, s1.min, s0.max, s1.max); b[3..5]: slots 2,3
+    uint32_t ref[4];    // bit 31 = leaf (RSPT_W4_* fields), else Wide4Node index; RSPT_NONE = empty slot (NaN box)
+    uint32_t axes;      // A.axis | first child's axis << 2 | second child's axis << 4
+    uint32_t pad[3];
+};
+// leaf ref: bit 31 | (count - 1) << 27 | first primitive; count field 15 = look the pair up in big_leaves[low bits]
+#define RSPT_W4_COUNT_SHIFT 27
+#define RSPT_W4_OFFSET_MASK 0x07ffffffu
+#ifndef RSPT_W4_LDS
+#define RSPT_W4_LDS 16       // stack entries per lane (8 B each): 32 KB per workgroup
+#endif
+
+// box_pair_hit (trace_wide.h) that also returns the entry distances
+RDEV void box_pair_hit_m(float4 q0, float4 q1, float4 q2, float ox, float oy, float oz, float ix, float iy, float iz, float ray_tmax,
+                         bool* h0, bool* h1, float* m0o, float* m1o) {
+    const float widen = 1.0f + 2.0f * gamma_n(3);
+    v2f lx = (v2f{q0.x, q0.y} - ox) * ix, hx = (v2f{q0.z, q0.w} - ox) * ix;
+    v2f ly = (v2f{q1.x, q1.y} - oy) * iy, hy = (v2f{q1.z, q1.w} - oy) * iy;
+    v2f lz = (v2f{q2.x, q2.y} - oz) * iz, hz = (v2f{q2.z, q2.w} - oz) * iz;
+    v2f fx = v2f{fmaxf(lx.x, hx.x), fmaxf(lx.y, hx.y)} * widen;
+    v2f fy = v2f{fmaxf(ly.x, hy.x), fmaxf(ly.y, hy.y)} * widen;
+    v2f fz = v2f{fmaxf(lz.x, hz.x), fmaxf(lz.y, hz.y)} * widen;
+    float m0 = fmaxf(fmaxf(fminf(lx.x, hx.x), fminf(ly.x, hy.x)), fminf(lz.x, hz.x)), M0 = fminf(fminf(fx.x, fy.x), fz.x);
+    float m1 = fmaxf(fmaxf(fminf(lx.y, hx.y), fminf(ly.y, hy.y)), fminf(lz.y, hz.y)), M1 = fminf(fminf(fx.y, fy.y), fz.y);
+    *h0 = (m0 <= M0) && (m0 < ray_tmax) && (M0 > 0.0f);
+    *h1 = (m1 <= M1) && (m1 < ray_tmax) && (M1 > 0.0f);
+    *m0o = m0; *m1o = m1;
+}
+// literal reference chain (zero / non-finite direction components), returning the final t_min
+RDEVN bool box_hit6_m(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 inv, bool ng0, bool ng1, bool ng2, float ray_tmax, float* mo) {
+    const float widen = 1.0f + 2.0f * gamma_n(3);
+    float t_min = ((ng0 ? hx : lx) - o.x) * inv.x;
+    float t_max = ((ng0 ? lx : hx) - o.x) * inv.x;
+    float ty_min = ((ng1 ? hy : ly) - o.y) * inv.y;
+    float ty_max = ((ng1 ? ly : hy) - o.y) * inv.y;
+    t_max *= widen;
+    ty_max *= widen;
+    *mo = 0.0f;
+    if (t_min > ty_max || ty_min > t_max) return false;
+    if (ty_min > t_min) t_min = ty_min;
+    if (ty_max < t_max) t_max = ty_max;
+    float tz_min = ((ng2 ? hz : lz) - o.z) * inv.z;
+    float tz_max = ((ng2 ? lz : hz) - o.z) * inv.z;
+    tz_max *= widen;
+    if (t_min > tz_max || tz_min > t_max) return false;
+    if (tz_min > t_min) t_min = tz_min;
+    if (tz_max < t_max) t_max = tz_max;
+    *mo = t_min;
+    return (t_min < ray_tmax) && (t_max > 0.0f);
+}
+
+template <bool ANY, int OUT_MODE>
+__global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
+                                                           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
+                                                           const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
+                                                           float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
+                                                           rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, int refill_thresh, int leaf_thresh) {
+    __shared__ uint2 stack[RSPT_W4_LDS * RSPT_PW_BLOCK];
+    uint2* my = stack + threadIdx.x;
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    if (sc.n_nodes == 0) {  // empty scene: every ray misses
+        for (uint32_t i = blockIdx.x * RSPT_PW_BLOCK + threadIdx.x; i < n; i += gridDim.x * RSPT_PW_BLOCK) {
+            uint32_t e = queue ? queue[i] : i, slot = e & ~RSPT_Q_MIS;
+            if (OUT_MODE == 0) {
+                if (ANY) out_occ[slot] = 0u;
+                else ((e & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(RSPT_MISS), 0.0f, 0.0f, 0.0f);
+            } else {
+                rspt_hit h; h.prim = RSPT_MISS; h.t = h.b0 = h.b1 = h.b2 = 0.0f;
+                out_hits[i] = h;
+            }
+        }
+        return;
+    }
+    const uint32_t lane = __lane_id();
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
+    uint32_t chunk_lo = 0, chunk_hi = 0;  // wave-uniform
+    bool exhausted = false;               // wave-uniform
+    // per-lane ray state
+    bool active = false;
+    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0;
+    RayShear rs{0, 0, 0, 0, 0, 0};
+    float t_max = 0.0f;
+    uint32_t negbits = 0;  // bit a = dir_is_neg[a]; bit 3 = zero / non-finite direction component
+    uint32_t sp = 0, cur = RSPT_NONE, leaf = RSPT_NONE;
+    uint32_t best = RSPT_MISS, entry = 0, qpos = 0;
+    float bt = 0.0f, bb0 = 0.0f, bb1 = 0.0f, bb2 = 0.0f;
+
+    auto finish = [&]() {
+        uint32_t slot = entry & ~RSPT_Q_MIS;
+        if (OUT_MODE == 0) {
+            if (ANY) out_occ[slot] = best == RSPT_RETRACE ? 2u : (best != RSPT_MISS ? 1u : 0u);
+            else ((entry & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(best), bb0, bb1, bb2);
+        } else {
+            rspt_hit h;
+            h.prim = best; h.t = bt; h.b0 = bb0; h.b1 = bb1; h.b2 = bb2;
+            out_hits[qpos] = h;
+        }
+        active = false;
+    };
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's chunk ----
+        const uint64_t idle = __ballot(!active);
+        if (!exhausted && (__popcll(idle) >= refill_thresh || ~idle == 0)) {
+            if (chunk_lo == chunk_hi) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (uint32_t)RSPT_PW_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                chunk_lo = base < n ? base : n;
+                chunk_hi = (base + RSPT_PW_CHUNK) < n ? (base + RSPT_PW_CHUNK) : n;
+                if (chunk_lo == chunk_hi) exhausted = true;
+            }
+            if (!exhausted) {
+                const uint32_t avail = chunk_hi - chunk_lo;
+                const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                if (!active && rank < avail) {
+                    qpos = chunk_lo + rank;
+                    entry = queue ? queue[qpos] : qpos;
+                    const float4* rp = reinterpret_cast<const float4*>(((entry & RSPT_Q_MIS) ? rays_b : rays_a) + (entry & ~RSPT_Q_MIS));
+                    float4 r0 = rp[0], r1 = rp[1];
+                    ox = r0.x; oy = r0.y; oz = r0.z;
+                    f3 d{r0.w, r1.x, r1.y};
+                    t_max = r1.z;
+                    ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
+                    negbits = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
+                    // zero / denormal / NaN direction components: keep the reference's literal compare chain
+                    if (!(fabsf(ix) < RSPT_INF && fabsf(iy) < RSPT_INF && fabsf(iz) < RSPT_INF)) negbits |= 8u;
+                    rs = ray_shear(d);
+                    best = RSPT_MISS; bt = bb0 = bb1 = bb2 = 0.0f;
+                    sp = 0; cur = RSPT_NONE; leaf = RSPT_NONE;
+                    active = true;
+                    // the root's own box (bvh.rs:424 on node 0)
+                    if (box_hit(root0, root1, f3{ox, oy, oz}, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max)) {
+                        if (root_ref & RSPT_REF_LEAF) leaf = root_ref;
+                        else cur = root_ref;
+                    } else
+                        finish();
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                chunk_lo += want < avail ? want : avail;
+            }
+        }
+        if (__ballot(active) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- node phase: one traversal step for every lane that is not parked at a leaf ----
+        if (active && leaf == RSPT_NONE) {
+            uint32_t ridx = cur;
+            if (ridx == RSPT_NONE) {
+                if (sp == 0) {
+                    finish();
+                } else {
+                    sp--;
+                    const uint2 e = my[sp * RSPT_PW_BLOCK];
+                    if (__uint_as_float(e.y) < t_max) {  // the reference's box test at this later moment (bvh.rs:424)
+                        if (e.x & RSPT_REF_LEAF) leaf = e.x;
+                        else ridx = e.x;
+                    }
+                }
+            }
+            if (ridx != RSPT_NONE) {
+                const float4* pp = reinterpret_cast<const float4*>(recs + ridx);
+                const float4 a0 = pp[0], a1 = pp[1], a2 = pp[2], a3 = pp[3], a4 = pp[4], a5 = pp[5], rf = pp[6];
+                const uint32_t axes = __float_as_uint(pp[7].x);
+                cur = RSPT_NONE;
+                bool h0, h1, h2, h3;
+                float m0, m1, m2, m3;
+                if (!(negbits & 8u)) {
+                    box_pair_hit_m(a0, a1, a2, ox, oy, oz, ix, iy, iz, t_max, &h0, &h1, &m0, &m1);
+                    box_pair_hit_m(a3, a4, a5, ox, oy, oz, ix, iy, iz, t_max, &h2, &h3, &m2, &m3);
+                } else {
+                    const f3 o{ox, oy, oz}, inv{ix, iy, iz};
+                    const bool n0 = negbits & 1u, n1 = negbits & 2u, n2 = negbits & 4u;
+                    h0 = box_hit6_m(a0.x, a1.x, a2.x, a0.z, a1.z, a2.z, o, inv, n0, n1, n2, t_max, &m0);
+                    h1 = box_hit6_m(a0.y, a1.y, a2.y, a0.w, a1.w, a2.w, o, inv, n0, n1, n2, t_max, &m1);
+                    h2 = box_hit6_m(a3.x, a4.x, a5.x, a3.z, a4.z, a5.z, o, inv, n0, n1, n2, t_max, &m2);
+                    h3 = box_hit6_m(a3.y, a4.y, a5.y, a3.w, a4.w, a5.w, o, inv, n0, n1, n2, t_max, &m3);
+                }
+                const uint32_t r0 = h0 ? __float_as_uint(rf.x) : RSPT_NONE, r1 = h1 ? __float_as_uint(rf.y) : RSPT_NONE;
+                const uint32_t r2 = h2 ? __float_as_uint(rf.z) : RSPT_NONE, r3 = h3 ? __float_as_uint(rf.w) : RSPT_NONE;
+                const bool sA = ((negbits >> (axes & 3u)) & 1u) != 0;          // dir_is_neg[A.axis]: second child's subtree first
+                const bool sB0 = ((negbits >> ((axes >> 2) & 3u)) & 1u) != 0;  // order inside the first child
+                const bool sB1 = ((negbits >> ((axes >> 4) & 3u)) & 1u) != 0;  // order inside the second child
+                const uint32_t g0n = sB0 ? r1 : r0, g0f = sB0 ? r0 : r1, g1n = sB1 ? r3 : r2, g1f = sB1 ? r2 : r3;
+                const float mg0n = sB0 ? m1 : m0, mg0f = sB0 ? m0 : m1, mg1n = sB1 ? m3 : m2, mg1f = sB1 ? m2 : m3;
+                // visiting order e0, e1, e2, e3
+                const uint32_t e0 = sA ? g1n : g0n, e1 = sA ? g1f : g0f, e2 = sA ? g0n : g1n, e3 = sA ? g0f : g1f;
+                const float me1 = sA ? mg1f : mg0f, me2 = sA ? mg0n : mg1n, me3 = sA ? mg0f : mg1f;
+                const bool v0 = e0 != RSPT_NONE, v1 = e1 != RSPT_NONE, v2 = e2 != RSPT_NONE, v3 = e3 != RSPT_NONE;
+                const bool p1 = v0, p2 = v0 || v1, p3 = p2 || v2;  // something earlier in the order is visited first
+                uint32_t next = v0 ? e0 : (v1 ? e1 : (v2 ? e2 : e3));
+                const bool push3 = v3 && p3, push2 = v2 && p2, push1 = v1 && p1;
+                if ((push3 || push2 || push1) && sp > RSPT_W4_LDS - 3) {  // (conservative) deeper than the LDS column: k_trace_fixup redoes this ray
+                    best = RSPT_RETRACE;
+                    atomicAdd(n_overflow, 1u);
+                    finish();
+                    next = RSPT_NONE;
+                } else {
+                    if (push3) { my[sp * RSPT_PW_BLOCK] = make_uint2(e3, __float_as_uint(me3)); sp++; }
+                    if (push2) { my[sp * RSPT_PW_BLOCK] = make_uint2(e2, __float_as_uint(me2)); sp++; }
+                    if (push1) { my[sp * RSPT_PW_BLOCK] = make_uint2(e1, __float_as_uint(me1)); sp++; }
+                }
+                if (next != RSPT_NONE) {
+                    if (next & RSPT_REF_LEAF) leaf = next;
+                    else cur = next;
+                }
+            }
+        }
+
+        // ---- leaf phase: watertight triangle tests for parked lanes, when enough of them wait ----
+        const uint64_t parked = __ballot(active && leaf != RSPT_NONE);
+        if (parked) {
+            const uint64_t running = __ballot(active && leaf == RSPT_NONE);
+            if (__popcll(parked) >= leaf_thresh || running == 0) {
+                if (active && leaf != RSPT_NONE) {
+                    uint32_t offset = leaf & RSPT_W4_OFFSET_MASK, n_prims = ((leaf >> RSPT_W4_COUNT_SHIFT) & 15u) + 1u;
+                    if (n_prims == 16u) {
+                        const uint2 bl = big_leaves[offset];
+                        offset = bl.x; n_prims = bl.y;
+                    }
+                    leaf = RSPT_NONE;
+                    const f3 o{ox, oy, oz};
+                    for (uint32_t i = 0; i < n_prims; i++) {
+                        uint32_t pi = offset + i;
+                        float4 a = sc.tris[3 * (size_t)pi], b = sc.tris[3 * (size_t)pi + 1], c = sc.tris[3 * (size_t)pi + 2];
+                        float t, b0, b1, b2;
+                        if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, o, rs, t_max, &t, &b0, &b1, &b2)) {
+                            if (ANY) { best = 0; break; }
+                            t_max = t;       // primitive.rs:155: later pops compare their t_min with this
+                            best = pi; bt = t; bb0 = b0; bb1 = b1; bb2 = b2;
+                        }
+                    }
+                    if (ANY && best != RSPT_MISS) finish();
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rspt
