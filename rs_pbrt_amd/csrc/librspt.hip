@@ -49,6 +49,10 @@ struct Ctx {
     uint32_t* q[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [parity][active, closest, any]
     QueueCounts* cnt = nullptr;
     uint32_t n_cnt = 0;
+    uint32_t* ovf = nullptr;           // queue entries of rays whose traversal stack overflowed (k_trace_fixup's work list)
+    size_t ovf_cap = 0;
+    uint2* spill = nullptr;            // k_trace_w4's stack rows beyond its LDS column (trace_w4.h)
+    size_t spill_threads = 0;
     unsigned long long* totals = nullptr;  // [0] nodes [1] tris [2] bsdf hits [3] rays closest [4] rays any [5] nan samples
     // sampler tables + filter table
     uint32_t* sobol32 = nullptr;
@@ -151,6 +155,27 @@ int ensure_paths(size_t cap) {
     return RSPT_OK;
 }
 
+int ensure_overflow_list(size_t n) {
+    if (g.ovf_cap >= n) return RSPT_OK;
+    if (g.ovf) (void)hipFree(g.ovf);
+    g.ovf = nullptr; g.ovf_cap = 0;
+    int rc = dev_alloc(&g.ovf, n);
+    if (rc) return rc;
+    g.ovf_cap = n;
+    return RSPT_OK;
+}
+
+int ensure_spill(size_t threads) {
+    if (g.spill_threads >= threads) return RSPT_OK;
+    if (g.spill) (void)hipFree(g.spill);
+    g.spill = nullptr; g.spill_threads = 0;
+    int rc = dev_alloc(&g.spill, threads * RSPT_W4_SPILL);
+    if (rc) return rc;
+    g.spill_threads = threads;
+    return RSPT_OK;
+}
+uint32_t pw_grid() { return grid_for((uint32_t)env_size("RSPT_PW_BLOCKS_PER_CU", 8)); }
+
 int ensure_counts(uint32_t n) {
     if (g.n_cnt >= n) return RSPT_OK;
     if (g.cnt) (void)hipFree(g.cnt);
@@ -251,15 +276,15 @@ void launch_trace(bool count, uint32_t grid, const rspt_scene_s* s, const uint32
     //  replicated control flow made it VALU-bound with 16 rays per wave)
     const size_t which = env_size("RSPT_TRACE_KERNEL", 2);
     if (!count && which != 0) {
-        const uint32_t pgrid = grid_for((uint32_t)env_size("RSPT_PW_BLOCKS_PER_CU", 8));
+        const uint32_t pgrid = pw_grid();
         uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
         if (which == 2)
             hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+                               ra, rb, oa, ob, occ, hits, n_overflow, g.ovf, g.spill, (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL), (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
         else
-        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow,
+        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, g.ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
-        hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, n_overflow, ra, rb, oa, ob, occ, hits);
+        hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, n_overflow, g.ovf, ra, rb, oa, ob, occ, hits);
         return;
     }
     if (count)
@@ -425,7 +450,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1)))) { if (li_dev) (void)hipFree(li_dev); return rc; }
     const uint32_t nominal_iters = d->max_depth + 1;
     const uint32_t max_iters = s->has_null_material ? nominal_iters + 64 : nominal_iters;
-    if ((rc = ensure_counts(max_iters + 2))) { if (li_dev) (void)hipFree(li_dev); return rc; }
+    if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(2 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK))) { if (li_dev) (void)hipFree(li_dev); return rc; }
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
 
@@ -549,7 +574,7 @@ void rspt_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
-    void* ptrs[] = {g.cnt, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
+    void* ptrs[] = {g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
@@ -816,6 +841,8 @@ int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* ou
     hipEvent_t e0 = get_event(0), e1 = get_event(1);
     HIP_TRY(hipEventRecord(e0, g.stream));
     int rc0 = ensure_counts(4);
+    if (!rc0) rc0 = ensure_overflow_list(std::max<size_t>((size_t)n, 1));
+    if (!rc0) rc0 = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK);
     if (rc0) return rc0;
     uint32_t* cursor = &g.cnt[0].cursor_closest;
     for (int r = 0; r < repeat && n; r++) {

@@ -36,8 +36,9 @@ struct Wide4Node {      // 128 B, 128-byte aligned
 #define RSPT_W4_COUNT_SHIFT 27
 #define RSPT_W4_OFFSET_MASK 0x07ffffffu
 #ifndef RSPT_W4_LDS
-#define RSPT_W4_LDS 16       // stack entries per lane (8 B each): 32 KB per workgroup
+#define RSPT_W4_LDS 16       // stack entries per lane (8 B each) kept in LDS: 32 KB per workgroup
 #endif
+#define RSPT_W4_SPILL 48     // further entries per lane in a global spill buffer (spill_rows <= this); beyond that k_trace_fixup takes over
 
 // box_pair_hit (trace_wide.h) that also returns the entry distances
 RDEV void box_pair_hit_m(float4 q0, float4 q1, float4 q2, float ox, float oy, float oz, float ix, float iy, float iz, float ray_tmax,
@@ -46,13 +47,13 @@ RDEV void box_pair_hit_m(float4 q0, float4 q1, float4 q2, float ox, float oy, fl
     v2f lx = (v2f{q0.x, q0.y} - ox) * ix, hx = (v2f{q0.z, q0.w} - ox) * ix;
     v2f ly = (v2f{q1.x, q1.y} - oy) * iy, hy = (v2f{q1.z, q1.w} - oy) * iy;
     v2f lz = (v2f{q2.x, q2.y} - oz) * iz, hz = (v2f{q2.z, q2.w} - oz) * iz;
-    v2f fx = v2f{fmaxf(lx.x, hx.x), fmaxf(lx.y, hx.y)} * widen;
-    v2f fy = v2f{fmaxf(ly.x, hy.x), fmaxf(ly.y, hy.y)} * widen;
-    v2f fz = v2f{fmaxf(lz.x, hz.x), fmaxf(lz.y, hz.y)} * widen;
-    float m0 = fmaxf(fmaxf(fminf(lx.x, hx.x), fminf(ly.x, hy.x)), fminf(lz.x, hz.x)), M0 = fminf(fminf(fx.x, fy.x), fz.x);
-    float m1 = fmaxf(fmaxf(fminf(lx.y, hx.y), fminf(ly.y, hy.y)), fminf(lz.y, hz.y)), M1 = fminf(fminf(fx.y, fy.y), fz.y);
-    *h0 = (m0 <= M0) && (m0 < ray_tmax) && (M0 > 0.0f);
-    *h1 = (m1 <= M1) && (m1 < ray_tmax) && (M1 > 0.0f);
+    // x -> x * widen is monotone, so min3 of the widened fars == widened min3 of the fars (one multiply instead of three)
+    float m0 = fmaxf(fmaxf(fminf(lx.x, hx.x), fminf(ly.x, hy.x)), fminf(lz.x, hz.x));
+    float m1 = fmaxf(fmaxf(fminf(lx.y, hx.y), fminf(ly.y, hy.y)), fminf(lz.y, hz.y));
+    v2f M = v2f{fminf(fminf(fmaxf(lx.x, hx.x), fmaxf(ly.x, hy.x)), fmaxf(lz.x, hz.x)),
+                fminf(fminf(fmaxf(lx.y, hx.y), fmaxf(ly.y, hy.y)), fmaxf(lz.y, hz.y))} * widen;
+    *h0 = (m0 <= M.x) && (m0 < ray_tmax) && (M.x > 0.0f);
+    *h1 = (m1 <= M.y) && (m1 < ray_tmax) && (M.y > 0.0f);
     *m0o = m0; *m1o = m1;
 }
 // literal reference chain (zero / non-finite direction components), returning the final t_min
@@ -83,9 +84,13 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
-                                                           rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, int refill_thresh, int leaf_thresh) {
+                                                           rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, uint32_t* __restrict__ overflow_list,
+                                                           uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh) {
     __shared__ uint2 stack[RSPT_W4_LDS * RSPT_PW_BLOCK];
     uint2* my = stack + threadIdx.x;
+    // rows RSPT_W4_LDS .. RSPT_W4_LDS + RSPT_W4_SPILL - 1 of a lane's stack live in global memory (row-major over all threads of the grid)
+    const size_t spill_stride = (size_t)gridDim.x * RSPT_PW_BLOCK;
+    uint2* my_spill = spill + (size_t)blockIdx.x * RSPT_PW_BLOCK + threadIdx.x;
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     if (sc.n_nodes == 0) {  // empty scene: every ray misses
         for (uint32_t i = blockIdx.x * RSPT_PW_BLOCK + threadIdx.x; i < n; i += gridDim.x * RSPT_PW_BLOCK) {
@@ -183,7 +188,9 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                     finish();
                 } else {
                     sp--;
-                    const uint2 e = my[sp * RSPT_PW_BLOCK];
+                    // two separate accesses (never one pointer select: that becomes a flat load with full waitcnt drains)
+                    uint2 e = my[(sp < RSPT_W4_LDS ? sp : RSPT_W4_LDS - 1u) * RSPT_PW_BLOCK];
+                    if (sp >= RSPT_W4_LDS) e = my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride];
                     if (__uint_as_float(e.y) < t_max) {  // the reference's box test at this later moment (bvh.rs:424)
                         if (e.x & RSPT_REF_LEAF) leaf = e.x;
                         else ridx = e.x;
@@ -222,15 +229,24 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                 const bool p1 = v0, p2 = v0 || v1, p3 = p2 || v2;  // something earlier in the order is visited first
                 uint32_t next = v0 ? e0 : (v1 ? e1 : (v2 ? e2 : e3));
                 const bool push3 = v3 && p3, push2 = v2 && p2, push1 = v1 && p1;
-                if ((push3 || push2 || push1) && sp > RSPT_W4_LDS - 3) {  // (conservative) deeper than the LDS column: k_trace_fixup redoes this ray
-                    best = RSPT_RETRACE;
-                    atomicAdd(n_overflow, 1u);
-                    finish();
-                    next = RSPT_NONE;
-                } else {
+                if (sp <= RSPT_W4_LDS - 3) {  // the common case: everything fits the LDS column
                     if (push3) { my[sp * RSPT_PW_BLOCK] = make_uint2(e3, __float_as_uint(me3)); sp++; }
                     if (push2) { my[sp * RSPT_PW_BLOCK] = make_uint2(e2, __float_as_uint(me2)); sp++; }
                     if (push1) { my[sp * RSPT_PW_BLOCK] = make_uint2(e1, __float_as_uint(me1)); sp++; }
+                } else if (sp + (push3 ? 1u : 0u) + (push2 ? 1u : 0u) + (push1 ? 1u : 0u) > RSPT_W4_LDS + spill_rows) {
+                    best = RSPT_RETRACE;  // deeper than LDS column + spill rows: k_trace_fixup redoes this ray
+                    overflow_list[atomicAdd(n_overflow, 1u)] = OUT_MODE == 0 ? entry : qpos;
+                    finish();
+                    next = RSPT_NONE;
+                } else {
+                    auto push = [&](uint32_t ref, float m) {
+                        if (sp < RSPT_W4_LDS) my[sp * RSPT_PW_BLOCK] = make_uint2(ref, __float_as_uint(m));
+                        else my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride] = make_uint2(ref, __float_as_uint(m));
+                        sp++;
+                    };
+                    if (push3) push(e3, me3);
+                    if (push2) push(e2, me2);
+                    if (push1) push(e1, me1);
                 }
                 if (next != RSPT_NONE) {
                     if (next & RSPT_REF_LEAF) leaf = next;

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                                                            const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
-                                                           rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, int refill_thresh, int leaf_thresh) {
+                                                           rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, uint32_t* __restrict__ overflow_list,
+                                                           int refill_thresh, int leaf_thresh) {
     __shared__ uint32_t stack[RSPT_PW_LDS * RSPT_PW_BLOCK];
     uint32_t* my = stack + threadIdx.x;
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
                             sp++;
                         } else {  // deeper than the LDS stack: hand the ray to k_trace_fixup
                             best = RSPT_RETRACE;
-                            atomicAdd(n_overflow, 1u);
+                            overflow_list[atomicAdd(n_overflow, 1u)] = OUT_MODE == 0 ? entry : qpos;
                             finish();
                             next = RSPT_NONE;
                         }
@@ -282,25 +283,20 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
     }
 }
 
-// Second pass for rays whose stack outgrew k_trace_pw's LDS column: the 64-entry reference-order
-// loop (kernels.h traverse<>).  Returns at once when no ray overflowed (the common case).
+// Second pass for the rays whose stack outgrew the persistent kernel's LDS column (their queue entries
+// were appended to overflow_list): the 64-entry reference-order loop (kernels.h traverse<>).
+// Returns at once when no ray overflowed (the common case).
 template <bool ANY, int OUT_MODE>
-__global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
-                                                                  uint32_t count_imm, const uint32_t* __restrict__ n_overflow,
+__global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, const uint32_t* __restrict__ n_overflow, const uint32_t* __restrict__ overflow_list,
                                                                   const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                                   float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
                                                                   rspt_hit* __restrict__ out_hits) {
     __shared__ uint32_t stack[RSPT_LDS_STACK * RSPT_TRACE_BLOCK];
-    if (*n_overflow == 0) return;
-    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    const uint32_t n = *n_overflow;
     for (uint32_t i = blockIdx.x * RSPT_TRACE_BLOCK + threadIdx.x; i < n; i += gridDim.x * RSPT_TRACE_BLOCK) {
-        uint32_t e = queue ? queue[i] : i;
-        uint32_t slot = e & ~RSPT_Q_MIS;
-        bool mis = (e & RSPT_Q_MIS) != 0;
-        bool marked;
-        if (OUT_MODE == 0) marked = ANY ? out_occ[slot] == 2u : __float_as_uint((mis ? out_b : out_a)[slot].x) == RSPT_RETRACE;
-        else marked = out_hits[i].prim == RSPT_RETRACE;
-        if (!marked) continue;
+        const uint32_t e = overflow_list[i];
+        const uint32_t slot = OUT_MODE == 0 ? (e & ~RSPT_Q_MIS) : e;
+        const bool mis = OUT_MODE == 0 && (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
         TraceResult res = traverse<ANY>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
@@ -310,7 +306,7 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, c
         } else {
             rspt_hit h;
             h.prim = res.prim; h.t = res.t; h.b0 = res.b0; h.b1 = res.b1; h.b2 = res.b2;
-            out_hits[i] = h;
+            out_hits[slot] = h;
         }
     }
 }

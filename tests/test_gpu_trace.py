@@ -50,6 +50,17 @@ def test_closest_and_any_bit_exact_soup(gpu, oracle, soup):
         assert got.tobytes() == ref.tobytes()
 
 
+def test_alternative_kernels_bit_exact(gpu, oracle, soup, monkeypatch):
+    """RSPT_TRACE_KERNEL=0 (reference-order loop, also the counting and fix-up kernel) and =1 (two-box records)
+    stay selectable and bit-identical to the default four-box kernel"""
+    sc, ds = soup
+    rays = random_rays(100000, 31, -1.3, 1.3)
+    for kernel in ("0", "1", "2"):
+        monkeypatch.setenv("RSPT_TRACE_KERNEL", kernel)
+        for any_hit in (False, True):
+            assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
+
+
 def test_matches_brute_force(gpu, oracle, soup):
     """BVH result == O(N) scan over all triangles in list order (structural invariant)."""
     sc, ds = soup
@@ -157,16 +168,22 @@ def test_deep_bvh_stack_overflow_fixup(gpu, oracle):
     d = tgt - rays["o"]
     rays["d"] = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32)
     rays["t_max"] = np.inf
+    import os
     ds = gpu.DeviceScene(sc)
     try:
         buf = gpu.DeviceBuffer(rays.nbytes); buf.upload(rays)
         out = gpu.DeviceBuffer(k * abi.HIT_DT.itemsize)
-        for any_hit in (False, True):
-            gpu.trace_device(ds, buf, k, out, any_hit=any_hit)
-            got = out.download(abi.HIT_DT, k)
-            assert got.tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
-            if not any_hit:
-                assert gpu.last_counters()[2] > 0  # the fix-up pass really ran
+        # (kernel, spill rows): the four-box kernel with its global spill rows (no ray left over), the same
+        # with the spill rows disabled (fix-up pass takes the deep rays), and the two-box kernel (LDS only)
+        for kernel, spill_rows, expect_fixup in (("2", "48", False), ("2", "0", True), ("1", "48", True)):
+            os.environ["RSPT_TRACE_KERNEL"], os.environ["RSPT_W4_SPILL_ROWS"] = kernel, spill_rows
+            for any_hit in (False, True):
+                gpu.trace_device(ds, buf, k, out, any_hit=any_hit)
+                got = out.download(abi.HIT_DT, k)
+                assert got.tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
+                if not any_hit:
+                    assert (gpu.last_counters()[2] > 0) == expect_fixup
         buf.free(); out.free()
     finally:
+        os.environ.pop("RSPT_TRACE_KERNEL", None); os.environ.pop("RSPT_W4_SPILL_ROWS", None)
         ds.close()
