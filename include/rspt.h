@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 5
+#define RSPT_ABI_VERSION 6
 
 /* error codes */
 #define RSPT_OK 0
@@ -107,13 +107,57 @@ typedef struct {
     float sc[3];        /* MixMaterial scale of this lobe (sc_opt, src/materials/mixmat.rs:43-70):
                            the reference multiplies it in front of the lobe's value       */
     uint32_t has_sc;    /* 0 = sc_opt is None                                         */
-} rspt_bxdf; /* 96 B */
+    uint32_t tex_r;     /* 0, or 1 + index of the texture the material binds to this lobe's colour:
+                           the lobe is built with  r * texture.evaluate(si).clamp(0, inf)  (e.g.
+                           matte.rs:59-62 with r = 1; uber.rs `op * kd`), evaluated per hit     */
+    uint32_t tex_t;     /* the same for t (FRESNEL_SPEC T, FRESNEL_BLEND Rs).  A lobe whose resulting
+                           colour(s) are black is not added, as in the reference's
+                           `if !r.is_black()` guards (matte.rs:70, plastic.rs:70,84, substrate.rs:72) */
+} rspt_bxdf; /* 104 B */
 
 typedef struct {
     float eta;          /* Bsdf.eta (reflection.rs:224)                               */
     uint32_t first_bxdf, n_bxdfs; /* slice of bxdfs[]; n_bxdfs <= 8 (reflection.rs:40) */
-    uint32_t pad;
+    uint32_t bump_tex;  /* 0, or 1 + index of the float texture of Material::bump
+                           (src/core/material.rs:116-219), applied before the lobes are built */
 } rspt_material;
+
+/* ---- textures ---------------------------------------------------- */
+/* MipMap<T> pyramid of an ImageTexture as rs_pbrt built it (src/core/mipmap.rs:56-196: power-of-two
+ * levels after its Lanczos resampling, box-filtered with the texture's wrap mode; texels already
+ * scaled / inverse-gamma-corrected by ImageTexture::new, src/textures/imagemap.rs:34-96).
+ * channels = 3 for a spectrum texture, 1 for a float texture (convert_to_float = y()). */
+typedef struct {
+    uint32_t width, height;  /* level 0 resolution                                         */
+    uint32_t n_levels;       /* MipMap::levels()                                           */
+    uint32_t channels;       /* 1 or 3                                                     */
+    const float* texels;     /* levels concatenated; level i is max(1, width >> i) x
+                                max(1, height >> i), row major [t][s], `channels` floats   */
+} rspt_image;
+enum {
+    RSPT_TEX_CONSTANT = 1,   /* ConstantTexture  src/textures/constant.rs: value            */
+    RSPT_TEX_IMAGE = 2,      /* ImageTexture     src/textures/imagemap.rs:114-149           */
+    RSPT_TEX_SCALE = 3       /* ScaleTexture     src/textures/scale.rs: tex1 * tex2 (children
+                                must be CONSTANT or IMAGE)                                 */
+};
+enum {
+    RSPT_MAP_UV = 1,         /* UVMapping2D      texture.rs:91-121: map = su, sv, du, dv    */
+    RSPT_MAP_PLANAR = 2      /* PlanarMapping2D  texture.rs:222-257: map = vs[3], vt[3], ds, dt */
+};
+enum { RSPT_WRAP_REPEAT = 0, RSPT_WRAP_BLACK = 1, RSPT_WRAP_CLAMP = 2 }; /* mipmap.rs:23-27; Black
+                                looks texels up like Clamp (mipmap.rs:217-227, "TMP" branch)   */
+typedef struct {
+    uint32_t kind;           /* RSPT_TEX_*                                                 */
+    uint32_t mapping;        /* RSPT_MAP_* (IMAGE)                                         */
+    float map[8];
+    uint32_t image;          /* index into images[] (IMAGE)                                */
+    uint32_t trilinear;      /* do_trilinear (mipmap.rs:253-262); 0 = EWA                  */
+    float max_aniso;         /* EWA eccentricity clamp (default 8)                         */
+    uint32_t wrap;           /* RSPT_WRAP_*                                                */
+    float value[3];          /* CONSTANT (float textures: value[0])                        */
+    uint32_t tex1, tex2;     /* SCALE: texture indices                                     */
+    uint32_t pad;
+} rspt_texture; /* 80 B */
 
 /* ---- lights (Scene.lights order, src/core/scene.rs:19-24) ------------------------- */
 enum {
@@ -165,6 +209,8 @@ typedef struct {
     const rspt_bxdf* bxdfs;         uint32_t n_bxdfs;
     const rspt_light* lights;       uint32_t n_lights;
     const rspt_envmap* envmaps;     uint32_t n_envmaps;
+    const rspt_texture* textures;   uint32_t n_textures;
+    const rspt_image* images;       uint32_t n_images;
 } rspt_scene_desc;
 
 /* Sampler tables owned by the host.

@@ -69,7 +69,8 @@ static Interaction unit_frame() {
 }
 void orc_bsdf_f(const rspt_material* m, const rspt_bxdf* all, const float wo[3], const float wi[3], uint32_t flags, float f_out[3], float* pdf_out) {
     Interaction it = unit_frame();
-    Bsdf b(it, *m, all);
+    Scene sc{}; sc.d.bxdfs = all;  // constant-colour lobes only: no texture tables needed
+    Bsdf b(sc, it, *m);
     Spec f = b.f(V3{wo[0], wo[1], wo[2]}, V3{wi[0], wi[1], wi[2]}, (uint8_t)flags);
     f_out[0] = f.c[0]; f_out[1] = f.c[1]; f_out[2] = f.c[2];
     *pdf_out = b.pdf(V3{wo[0], wo[1], wo[2]}, V3{wi[0], wi[1], wi[2]}, (uint8_t)flags);
@@ -77,7 +78,8 @@ void orc_bsdf_f(const rspt_material* m, const rspt_bxdf* all, const float wo[3],
 void orc_bsdf_sample_f(const rspt_material* m, const rspt_bxdf* all, const float wo[3], float ux, float uy, uint32_t flags,
                        float f_out[3], float wi_out[3], float* pdf_out, uint32_t* sampled_type) {
     Interaction it = unit_frame();
-    Bsdf b(it, *m, all);
+    Scene sc{}; sc.d.bxdfs = all;
+    Bsdf b(sc, it, *m);
     V3 wi{0, 0, 0}; Float pdf = 0; uint8_t st = 255;
     Spec f = b.sample_f(V3{wo[0], wo[1], wo[2]}, &wi, P2{ux, uy}, &pdf, (uint8_t)flags, &st);
     f_out[0] = f.c[0]; f_out[1] = f.c[1]; f_out[2] = f.c[2];

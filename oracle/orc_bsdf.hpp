@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE — CPU oracle (see orc_math.hpp header).  BSDF / BxDFs / microfacets.
 #pragma once
-#include "orc_scene.hpp"
+#include "orc_texture.hpp"
 
 namespace orc {
 
@@ -147,7 +147,6 @@ struct TR {
     }
 };
 
-static inline Spec S3(const float* p) { return Spec(p[0], p[1], p[2]); }
 static inline Float pow5(Float v) { return (v * v) * (v * v) * v; } // reflection.rs:1974-1976
 
 // One lobe = one Bxdf enum value (reflection.rs:462-633)
@@ -361,13 +360,32 @@ struct Bsdf {
     Float eta;
     V3 ns, ng, ss, ts;
     Lobe lobes[8];
+    rspt_bxdf local[8]; // lobes whose colours come from textures are built per hit
     int n = 0;
-    Bsdf(const Interaction& si, const rspt_material& m, const rspt_bxdf* all) { // Bsdf::new :235-245
+    Bsdf(const Bsdf&) = delete;
+    Bsdf& operator=(const Bsdf&) = delete;
+    // Material::compute_scattering_functions for the pre-assembled lobe list: Material::bump first
+    // (material.rs:116-219), then Bsdf::new (:235-245), then one `bsdf.add` per lobe whose
+    // (texture-modulated) colour is not black (matte.rs:59-83, plastic.rs:60-108, uber.rs, substrate.rs:60-90)
+    Bsdf(const Scene& sc, Interaction& si, const rspt_material& m) {
+        if (m.bump_tex) bump(sc, m.bump_tex - 1, &si);
         eta = m.eta;
         ss = normalize(si.sh_dpdu);
         ns = si.sh_n; ng = si.n;
         ts = cross(si.sh_n, ss); // nrm_cross_vec3
-        for (uint32_t i = 0; i < m.n_bxdfs && i < 8; i++) lobes[n++] = Lobe{&all[m.first_bxdf + i]};
+        const rspt_bxdf* all = sc.d.bxdfs;
+        for (uint32_t i = 0; i < m.n_bxdfs && i < 8; i++) {
+            const rspt_bxdf& g = all[m.first_bxdf + i];
+            if (!g.tex_r && !g.tex_t) { lobes[n++] = Lobe{&g}; continue; }
+            rspt_bxdf b = g;
+            if (g.tex_r) { Spec v = S3(g.r) * sclamp0(tex_eval(sc, g.tex_r - 1, si)); b.r[0] = v.c[0]; b.r[1] = v.c[1]; b.r[2] = v.c[2]; }
+            if (g.tex_t) { Spec v = S3(g.t) * sclamp0(tex_eval(sc, g.tex_t - 1, si)); b.t[0] = v.c[0]; b.t[1] = v.c[1]; b.t[2] = v.c[2]; }
+            bool two = g.type == RSPT_BXDF_FRESNEL_SPEC || g.type == RSPT_BXDF_FRESNEL_BLEND;
+            if (two ? (S3(b.r).is_black() && S3(b.t).is_black()) : S3(b.r).is_black()) continue;
+            local[n] = b;
+            lobes[n] = Lobe{&local[n]};
+            n++;
+        }
     }
     int num_components(uint8_t flags) const { int c = 0; for (int i = 0; i < n; i++) if (lobes[i].matches_flags(flags)) c++; return c; }
     V3 world_to_local(V3 v) const { return V3{dot(v, ss), dot(v, ts), dot(v, ns)}; }

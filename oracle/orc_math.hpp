@@ -37,6 +37,13 @@ static inline int32_t f2i(Float x) {
     if (x <= -2147483648.0f) return INT32_MIN;
     return (int32_t)x;
 }
+// Rust `x as isize` from f32
+static inline int64_t f2i64(Float x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0f) return INT64_MAX;
+    if (x <= -9223372036854775808.0f) return INT64_MIN;
+    return (int64_t)x;
+}
 // Rust `x as usize` from f32
 static inline uint64_t f2usize(Float x) {
     if (x != x || x <= 0.0f) return 0;
@@ -184,6 +191,14 @@ struct Ray {
     V3 o, d;
     mutable Float t_max; // Cell<Float>
     Float time;
+    // Option<RayDifferential> (geometry.rs:2408-2414): camera rays only
+    bool has_diff = false;
+    V3 rx_o{0, 0, 0}, ry_o{0, 0, 0}, rx_d{0, 0, 0}, ry_d{0, 0, 0};
+    void scale_differentials(Float s) { // geometry.rs:2398-2405
+        if (!has_diff) return;
+        rx_o = o + (rx_o - o) * s; ry_o = o + (ry_o - o) * s;
+        rx_d = d + (rx_d - d) * s; ry_d = d + (ry_d - d) * s;
+    }
 };
 
 // src/core/spectrum.rs:1528-1835
@@ -249,7 +264,7 @@ static inline V3 transform_point_with_error(const Float* m, V3 p, V3* p_error) {
     Float inv = 1.0f / wp;
     return V3{inv * xp, inv * yp, inv * zp};
 }
-// transform.rs:538-595 (differentials omitted)
+// transform.rs:538-595
 static inline Ray transform_ray(const Float* m, const Ray& r) {
     V3 o_error;
     V3 o = transform_point_with_error(m, r.o, &o_error);
@@ -261,7 +276,13 @@ static inline Ray transform_ray(const Float* m, const Ray& r) {
         o = o + d * dt;
         t_max -= dt;
     }
-    return Ray{o, d, t_max, r.time};
+    Ray out{o, d, t_max, r.time};
+    if (r.has_diff) { // :550-556: plain transform_point / transform_vector
+        out.has_diff = true;
+        out.rx_o = transform_point(m, r.rx_o); out.ry_o = transform_point(m, r.ry_o);
+        out.rx_d = transform_vector(m, r.rx_d); out.ry_d = transform_vector(m, r.ry_d);
+    }
+    return out;
 }
 
 } // namespace orc

@@ -632,7 +632,10 @@ static inline Spec path_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counte
             }
             if (bounces >= cx.rd->max_depth) break;
             if (hp.material == 0xffffffffu) { ray = isect.spawn_ray(ray.d); continue; } // null bsdf :109-116
-            Bsdf bsdf(isect, sc.d.materials[hp.material], sc.d.bxdfs);
+            // isect.compute_scattering_functions (interaction.rs:371-386): differentials of the camera ray
+            // (bounce rays carry none), then the material
+            compute_differentials(&isect, ray);
+            Bsdf bsdf(sc, isect, sc.d.materials[hp.material]);
             if (c) c->bounces++;
             // lookup happens for every hit (path.rs:118); with no lights its result is never used
             const Distribution1D* distrib = sc.d.n_lights ? light_lookup(cx, isect.p) : nullptr;
@@ -683,6 +686,28 @@ static inline Ray camera_ray(const rspt_render_desc& rd, P2 p_film, Float time_s
         V3 p_focus = in_ray.o + in_ray.d * ft;
         in_ray.o = V3{pl.x, pl.y, 0.0f};
         in_ray.d = normalize(p_focus - in_ray.o);
+    }
+    // offset rays (perspective.rs:205-220, 245-271); dx_camera / dy_camera as in PerspectiveCamera::new (:82-97)
+    V3 c0 = transform_point(rd.raster_to_camera, V3{0, 0, 0});
+    V3 dx_camera = transform_point(rd.raster_to_camera, V3{1, 0, 0}) - c0;
+    V3 dy_camera = transform_point(rd.raster_to_camera, V3{0, 1, 0}) - c0;
+    in_ray.has_diff = true;
+    in_ray.rx_o = in_ray.ry_o = V3{0, 0, 0};
+    in_ray.rx_d = normalize(p_camera + dx_camera);
+    in_ray.ry_d = normalize(p_camera + dy_camera);
+    if (rd.lens_radius > 0.0f) {
+        P2 pl = concentric_sample_disk(p_lens);
+        pl = P2{pl.x * rd.lens_radius, pl.y * rd.lens_radius};
+        V3 dx = normalize(p_camera + dx_camera);
+        Float ftx = rd.focal_distance / dx.z;
+        V3 pfx = V3{0, 0, 0} + dx * ftx;
+        in_ray.rx_o = V3{pl.x, pl.y, 0.0f};
+        in_ray.rx_d = normalize(pfx - in_ray.rx_o);
+        V3 dy = normalize(p_camera + dy_camera);
+        Float fty = rd.focal_distance / dy.z;
+        V3 pfy = V3{0, 0, 0} + dy * fty;
+        in_ray.ry_o = V3{pl.x, pl.y, 0.0f};
+        in_ray.ry_d = normalize(pfy - in_ray.ry_o);
     }
     return transform_ray(rd.camera_to_world, in_ray);
 }
@@ -787,6 +812,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         Float time_s = sampler.get_1d();
                         P2 p_lens = sampler.get_2d();
                         Ray ray = camera_ray(rd, p_film, time_s, p_lens);
+                        ray.scale_differentials(1.0f / std::sqrt((Float)rd.spp)); // integrator.rs:140-144 (get_samples_per_pixel)
                         Float ray_weight = 1.0f;
                         Spec l = path_li(cx, ray, sampler, &c);
                         c.samples++;

@@ -175,6 +175,11 @@ struct Interaction {
     P2 uv{0, 0};
     V3 dpdu, dpdv;
     V3 sh_n, sh_dpdu, sh_dpdv; // Shading
+    V3 sh_dndu{0, 0, 0}, sh_dndv{0, 0, 0}; // shading.dndu/dndv; isect.dndu/dndv themselves stay 0 (triangle.rs:322,433-434: the
+                                           // values computed for the shading block shadow the outer zeros)
+    // screen-space differentials (interaction.rs:388-479)
+    Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+    V3 dpdx{0, 0, 0}, dpdy{0, 0, 0};
     int64_t prim = -1;         // isect.primitive
     // interaction.rs:58-94
     Ray spawn_ray(V3 d) const { return Ray{offset_ray_origin(p, p_error, n, d), d, INF, time}; }
@@ -284,7 +289,7 @@ struct Scene {
         // (alpha masks: textures are out of scope)
         V3 surface_normal = normalize(cross(dp02, dp12));
         if (m.flip) surface_normal = -surface_normal;
-        V3 sh_n = surface_normal, sh_dpdu = dpdu, sh_dpdv = dpdv;
+        V3 sh_n = surface_normal, sh_dpdu = dpdu, sh_dpdv = dpdv, sh_dndu{0, 0, 0}, sh_dndv{0, 0, 0};
         bool has_n = m.has_n && d.N, has_s = m.has_s && d.S;
         if (has_n || has_s) {
             V3 ns;
@@ -300,16 +305,26 @@ struct Scene {
             V3 ts = cross(ss, ns);
             if (length_squared(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
             else coordinate_system(ns, &ss, &ts);
-            // dndu/dndv feed only bump mapping / texture filtering: omitted
+            // dndu / dndv of the shading geometry (triangle.rs:389-416): consumed by Material::bump
+            if (has_n) {
+                V3 dn1 = N(pr.v[0]) - N(pr.v[2]), dn2 = N(pr.v[1]) - N(pr.v[2]);
+                if (!degenerate_uv) {
+                    Float inv_det = 1.0f / determinant;
+                    sh_dndu = (dn1 * duv12.y - dn2 * duv02.y) * inv_det;
+                    sh_dndv = (dn1 * -duv12.x + dn2 * duv02.x) * inv_det;
+                }
+            }
             sh_n = normalize(cross(ss, ts));
             surface_normal = faceforward(surface_normal, sh_n);
             sh_dpdu = ss; sh_dpdv = ts;
         }
+        *isect = Interaction{};
         isect->p = p_hit; isect->time = ray.time; isect->p_error = p_error;
         isect->wo = -ray.d; // not normalised (Q8)
         isect->n = surface_normal;
         isect->uv = uv_hit; isect->dpdu = dpdu; isect->dpdv = dpdv;
         isect->sh_n = sh_n; isect->sh_dpdu = sh_dpdu; isect->sh_dpdv = sh_dpdv;
+        isect->sh_dndu = sh_dndu; isect->sh_dndv = sh_dndv;
         isect->prim = -1;
     }
 

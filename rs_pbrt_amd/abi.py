@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -14,6 +14,9 @@ FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
 SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
+TEX_CONSTANT, TEX_IMAGE, TEX_SCALE = 1, 2, 3
+MAP_UV, MAP_PLANAR = 1, 2
+WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
 NO_MATERIAL = 0xFFFFFFFF
 MISS = 0xFFFFFFFF
 
@@ -35,11 +38,21 @@ class Bxdf(C.Structure):
     _fields_ = [("type", C.c_uint32), ("fresnel", C.c_uint32), ("r", C.c_float * 3), ("t", C.c_float * 3),
                 ("eta_a", C.c_float), ("eta_b", C.c_float), ("alpha_x", C.c_float), ("alpha_y", C.c_float),
                 ("c1", C.c_float * 3), ("c2", C.c_float * 3), ("on_a", C.c_float), ("on_b", C.c_float),
-                ("sc", C.c_float * 3), ("has_sc", C.c_uint32)]
+                ("sc", C.c_float * 3), ("has_sc", C.c_uint32), ("tex_r", C.c_uint32), ("tex_t", C.c_uint32)]
 
 
 class Material(C.Structure):
-    _fields_ = [("eta", C.c_float), ("first_bxdf", C.c_uint32), ("n_bxdfs", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("eta", C.c_float), ("first_bxdf", C.c_uint32), ("n_bxdfs", C.c_uint32), ("bump_tex", C.c_uint32)]
+
+
+class Image(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("n_levels", C.c_uint32), ("channels", C.c_uint32), ("texels", C.c_void_p)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("mapping", C.c_uint32), ("map", C.c_float * 8), ("image", C.c_uint32), ("trilinear", C.c_uint32),
+                ("max_aniso", C.c_float), ("wrap", C.c_uint32), ("value", C.c_float * 3), ("tex1", C.c_uint32), ("tex2", C.c_uint32),
+                ("pad", C.c_uint32)]
 
 
 class Light(C.Structure):
@@ -60,7 +73,9 @@ class SceneDesc(C.Structure):
                 ("materials", C.c_void_p), ("n_materials", C.c_uint32),
                 ("bxdfs", C.c_void_p), ("n_bxdfs", C.c_uint32),
                 ("lights", C.c_void_p), ("n_lights", C.c_uint32),
-                ("envmaps", C.c_void_p), ("n_envmaps", C.c_uint32)]
+                ("envmaps", C.c_void_p), ("n_envmaps", C.c_uint32),
+                ("textures", C.c_void_p), ("n_textures", C.c_uint32),
+                ("images", C.c_void_p), ("n_images", C.c_uint32)]
 
 
 class SamplerTables(C.Structure):
@@ -104,15 +119,18 @@ PRIM_DT = np.dtype([("v", "<u4", 3), ("mesh", "<u4"), ("material", "<u4"), ("are
 MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4")])
 BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
                     ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4"),
-                    ("sc", "<f4", 3), ("has_sc", "<u4")])
-MATERIAL_DT = np.dtype([("eta", "<f4"), ("first_bxdf", "<u4"), ("n_bxdfs", "<u4"), ("pad", "<u4")])
+                    ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4")])
+MATERIAL_DT = np.dtype([("eta", "<f4"), ("first_bxdf", "<u4"), ("n_bxdfs", "<u4"), ("bump_tex", "<u4")])
+TEXTURE_DT = np.dtype([("kind", "<u4"), ("mapping", "<u4"), ("map", "<f4", 8), ("image", "<u4"), ("trilinear", "<u4"), ("max_aniso", "<f4"),
+                       ("wrap", "<u4"), ("value", "<f4", 3), ("tex1", "<u4"), ("tex2", "<u4"), ("pad", "<u4")])
 LIGHT_DT = np.dtype([("kind", "<u4"), ("prim", "<u4"), ("L", "<f4", 3), ("two_sided", "<u4"), ("p", "<f4", 24)])
 RAY_DT = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("id", "<u4")])
 HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4")])
 
 assert NODE_DT.itemsize == C.sizeof(BvhNode) == 32
 assert PRIM_DT.itemsize == C.sizeof(Prim) == 24
-assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 96
+assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 104
+assert TEXTURE_DT.itemsize == C.sizeof(Texture) == 80
 assert RAY_DT.itemsize == C.sizeof(Ray) == 32
 assert HIT_DT.itemsize == C.sizeof(Hit) == 20
 assert LIGHT_DT.itemsize == C.sizeof(Light) == 120

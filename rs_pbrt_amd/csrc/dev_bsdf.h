@@ -185,13 +185,30 @@ RDEV rgb lobe_fresnel(const rspt_bxdf& b, float ci) {  // Fresnel::evaluate :651
     return mkrgb(1.0f);
 }
 
+// Lobe colours bound to textures (rspt_bxdf.tex_r / tex_t): k_texture left clamp(texture value) of the
+// material's texture slots in per-path rows; the lobe's own r / t is the constant factor in front.
+struct LobeTex {
+    const float4* base;  // this path's entry of row 0 (nullptr: the material has no textured lobe)
+    size_t stride;       // paths per row
+};
+RDEV rgb lobe_r(const rspt_bxdf& b, const LobeTex& lt) {
+    rgb r = ldrgb(b.r);
+    if (lt.base && b.tex_r) { float4 v = lt.base[(size_t)(b.tex_r - 1u) * lt.stride]; r = r * rgb{v.x, v.y, v.z}; }
+    return r;
+}
+RDEV rgb lobe_t(const rspt_bxdf& b, const LobeTex& lt) {
+    rgb t = ldrgb(b.t);
+    if (lt.base && b.tex_t) { float4 v = lt.base[(size_t)(b.tex_t - 1u) * lt.stride]; t = t * rgb{v.x, v.y, v.z}; }
+    return t;
+}
+
 // sc_opt of MixMaterial lobes: the reference writes `sc * A * B ...`, i.e. ((sc * A) * B) ...
 RDEV rgb lobe_scaled(const rspt_bxdf& b, rgb a) { return b.has_sc ? ldrgb(b.sc) * a : a; }
 
-RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
+RDEVN rgb lobe_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
     switch (b.type) {
-    case RSPT_BXDF_LAMBERT_R: return lobe_scaled(b, ldrgb(b.r)) * mkrgb(RSPT_INV_PI);
-    case RSPT_BXDF_LAMBERT_T: return lobe_scaled(b, ldrgb(b.r)) * RSPT_INV_PI;
+    case RSPT_BXDF_LAMBERT_R: return lobe_scaled(b, lobe_r(b, lt)) * mkrgb(RSPT_INV_PI);
+    case RSPT_BXDF_LAMBERT_T: return lobe_scaled(b, lobe_r(b, lt)) * RSPT_INV_PI;
     case RSPT_BXDF_OREN_NAYAR: {
         float sti = sin_t(wi), sto = sin_t(wo);
         float max_cos = 0.0f;
@@ -202,7 +219,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         float sin_alpha, tan_beta;
         if (fabsf(wi.z) > fabsf(wo.z)) { sin_alpha = sto; tan_beta = sti / fabsf(wi.z); }
         else { sin_alpha = sti; tan_beta = sto / fabsf(wo.z); }
-        return lobe_scaled(b, ldrgb(b.r)) * mkrgb(RSPT_INV_PI * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta));
+        return lobe_scaled(b, lobe_r(b, lt)) * mkrgb(RSPT_INV_PI * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta));
     }
     case RSPT_BXDF_MICROFACET_R: {
         float cto = fabsf(wo.z), cti = fabsf(wi.z);
@@ -211,7 +228,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
         wh = normalize(wh);
         rgb fr = lobe_fresnel(b, dot(wi, wh));
-        return lobe_scaled(b, ldrgb(b.r)) * tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * fr / (4.0f * cti * cto);
+        return lobe_scaled(b, lobe_r(b, lt)) * tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * fr / (4.0f * cti * cto);
     }
     case RSPT_BXDF_MICROFACET_T: {  // MicrofacetTransmission::f, TransportMode::Radiance (reflection.rs:1246-1317)
         if (same_hemi(wo, wi)) return mkrgb(0.0f);
@@ -224,12 +241,12 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, f3 wo, f3 wi) {
         rgb fr = mkrgb(fr_dielectric(dot(wo, wh), b.eta_a, b.eta_b));
         float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = 1.0f / eta;
-        return lobe_scaled(b, mkrgb(1.0f) - fr) * ldrgb(b.r) *
+        return lobe_scaled(b, mkrgb(1.0f) - fr) * lobe_r(b, lt) *
                fabsf(tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                      (cti * cto * sqrt_denom * sqrt_denom));
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // FresnelBlend::f (reflection.rs:1398-1431): r = Rd, t = Rs
-        rgb rd = ldrgb(b.r), rs = ldrgb(b.t);
+        rgb rd = lobe_r(b, lt), rs = lobe_t(b, lt);
         rgb diffuse = rd * (mkrgb(1.0f) - rs) * (28.0f / (23.0f * RSPT_PI)) * (1.0f - pow5(1.0f - 0.5f * fabsf(wi.z))) * (1.0f - pow5(1.0f - 0.5f * fabsf(wo.z)));
         f3 wh = wi + wo;
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
@@ -274,7 +291,7 @@ RDEVN float lobe_pdf(const rspt_bxdf& b, f3 wo, f3 wi) {
     }
 }
 // sampled_type follows the reference's in/out sentinel convention (only written when non-zero).
-RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uint32_t* sampled_type) {
+RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2 u, float* pdf, uint32_t* sampled_type) {
     const rgb black = mkrgb(0.0f);
     switch (b.type) {
     case RSPT_BXDF_LAMBERT_R:
@@ -282,25 +299,25 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
         *wi = cosine_hemisphere(u);
         if (wo.z < 0.0f) wi->z *= -1.0f;
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, wo, *wi);
+        return lobe_f(b, lt, wo, *wi);
     }
     case RSPT_BXDF_LAMBERT_T: {
         *wi = cosine_hemisphere(u);
         if (wo.z > 0.0f) wi->z *= -1.0f;
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, wo, *wi);
+        return lobe_f(b, lt, wo, *wi);
     }
     case RSPT_BXDF_SPECULAR_R: {
         *wi = f3{-wo.x, -wo.y, wo.z};
         *pdf = 1.0f;
-        return lobe_scaled(b, lobe_fresnel(b, wi->z)) * ldrgb(b.r) / fabsf(wi->z);
+        return lobe_scaled(b, lobe_fresnel(b, wi->z)) * lobe_r(b, lt) / fabsf(wi->z);
     }
     case RSPT_BXDF_SPECULAR_T: {
         bool entering = wo.z > 0.0f;
         float ei = entering ? b.eta_a : b.eta_b, et = entering ? b.eta_b : b.eta_a;
         if (!refract(wo, faceforward(f3{0.0f, 0.0f, 1.0f}, wo), ei / et, wi)) return black;
         *pdf = 1.0f;
-        rgb ft = ldrgb(b.r) * (mkrgb(1.0f) - mkrgb(fr_dielectric(wi->z, b.eta_a, b.eta_b)));
+        rgb ft = lobe_r(b, lt) * (mkrgb(1.0f) - mkrgb(fr_dielectric(wi->z, b.eta_a, b.eta_b)));
         ft = ft * mkrgb((ei * ei) / (et * et));
         return lobe_scaled(b, ft) / fabsf(wi->z);
     }
@@ -310,12 +327,12 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
             *wi = f3{-wo.x, -wo.y, wo.z};
             if (*sampled_type != 0) *sampled_type = BX_REFL | BX_SPEC;
             *pdf = fr;
-            return lobe_scaled(b, ldrgb(b.r)) * fr / fabsf(wi->z);
+            return lobe_scaled(b, lobe_r(b, lt)) * fr / fabsf(wi->z);
         }
         bool entering = wo.z > 0.0f;
         float ei = entering ? b.eta_a : b.eta_b, et = entering ? b.eta_b : b.eta_a;
         if (!refract(wo, faceforward(f3{0.0f, 0.0f, 1.0f}, wo), ei / et, wi)) return black;
-        rgb ft = ldrgb(b.t) * (1.0f - fr);
+        rgb ft = lobe_t(b, lt) * (1.0f - fr);
         ft = ft * mkrgb((ei * ei) / (et * et));
         if (*sampled_type != 0) *sampled_type = BX_TRANS | BX_SPEC;
         *pdf = 1.0f - fr;
@@ -327,7 +344,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
         *wi = (-wo) + wh * 2.0f * dot(wo, wh);  // reflect, reflection.rs:1889
         if (!same_hemi(wo, *wi)) return black;
         *pdf = tr_pdf(b.alpha_x, b.alpha_y, wo, wh) / (4.0f * dot(wo, wh));
-        return lobe_f(b, wo, *wi);
+        return lobe_f(b, lt, wo, *wi);
     }
     case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1322-1349
         if (wo.z == 0.0f) return black;
@@ -335,7 +352,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
         float eta = wo.z > 0.0f ? b.eta_a / b.eta_b : b.eta_b / b.eta_a;
         if (!refract(wo, wh, eta, wi)) return black;
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, wo, *wi);
+        return lobe_f(b, lt, wo, *wi);
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1432-1461
         f2 uu = u;
@@ -350,7 +367,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, f3 wo, f3* wi, f2 u, float* pdf, uin
             if (!same_hemi(wo, *wi)) return black;
         }
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, wo, *wi);
+        return lobe_f(b, lt, wo, *wi);
     }
     default: return black;
     }
@@ -362,6 +379,11 @@ struct Bsdf {
     float eta;
     const rspt_bxdf* lobes;
     uint32_t n;
+    LobeTex lt;        // texture values of this hit (k_texture), or {nullptr, 0}
+    uint32_t dropped;  // bit i: lobe i's textured colour came out black, the reference never added it
+
+    // BxdfType of lobe i; a dropped lobe matches no flag set (bit 8 lies outside BSDF_ALL)
+    RDEV uint32_t ltype(uint32_t i) const { return ((dropped >> i) & 1u) ? 0x100u : lobe_type(lobes[i].type); }
 
     RDEV f3 to_local(f3 v) const { return f3{dot(v, ss), dot(v, ts), dot(v, ns)}; }
     RDEV f3 to_world(f3 v) const {
@@ -370,14 +392,14 @@ struct Bsdf {
     }
     RDEV int num_components(uint32_t flags) const {
         int c = 0;
-        for (uint32_t i = 0; i < n; i++) c += lobe_matches(lobe_type(lobes[i].type), flags) ? 1 : 0;
+        for (uint32_t i = 0; i < n; i++) c += lobe_matches(ltype(i), flags) ? 1 : 0;
         return c;
     }
     RDEVN rgb sum_f(f3 wo, f3 wi, bool refl, uint32_t flags) const {
         rgb f = mkrgb(0.0f);
         for (uint32_t i = 0; i < n; i++) {
-            uint32_t t = lobe_type(lobes[i].type);
-            if (lobe_matches(t, flags) && ((refl && (t & BX_REFL)) || (!refl && (t & BX_TRANS)))) f = f + lobe_f(lobes[i], wo, wi);
+            uint32_t t = ltype(i);
+            if (lobe_matches(t, flags) && ((refl && (t & BX_REFL)) || (!refl && (t & BX_TRANS)))) f = f + lobe_f(lobes[i], lt, wo, wi);
         }
         return f;
     }
@@ -394,7 +416,7 @@ struct Bsdf {
         float p = 0.0f;
         int matching = 0;
         for (uint32_t i = 0; i < n; i++)
-            if (lobe_matches(lobe_type(lobes[i].type), flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
+            if (lobe_matches(ltype(i), flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
         return matching > 0 ? p / (float)matching : 0.0f;
     }
     RDEVN rgb sample_f(f3 wo_w, f3* wi_w, f2 u, float* pdf_out, uint32_t flags, uint32_t* sampled_type) const {  // :298-420
@@ -406,25 +428,25 @@ struct Bsdf {
         int comp = ci < matching - 1 ? ci : matching - 1;
         int idx = -1, count = comp;
         for (uint32_t i = 0; i < n; i++) {
-            bool m = lobe_matches(lobe_type(lobes[i].type), flags);
+            bool m = lobe_matches(ltype(i), flags);
             if (m && count == 0) { idx = (int)i; break; }
             else if (m) count -= 1;
         }
         if (idx < 0) return black;
         const rspt_bxdf& bx = lobes[idx];
-        uint32_t bt = lobe_type(bx.type);
+        uint32_t bt = ltype((uint32_t)idx);
         f2 ur{fminf(u.x * (float)matching - (float)comp, RSPT_ONE_MINUS_EPS), u.y};
         f3 wi{0.0f, 0.0f, 0.0f};
         f3 wo = to_local(wo_w);
         if (wo.z == 0.0f) return black;
         *pdf_out = 0.0f;
         if (*sampled_type != 0) *sampled_type = bt;
-        rgb f = lobe_sample_f(bx, wo, &wi, ur, pdf_out, sampled_type);
+        rgb f = lobe_sample_f(bx, lt, wo, &wi, ur, pdf_out, sampled_type);
         if (*pdf_out == 0.0f) { if (*sampled_type != 0) *sampled_type = 0; return black; }
         *wi_w = to_world(wi);
         if (!(bt & BX_SPEC) && matching > 1)
             for (uint32_t i = 0; i < n; i++)
-                if ((int)i != idx && lobe_matches(lobe_type(lobes[i].type), flags)) *pdf_out += lobe_pdf(lobes[i], wo, wi);
+                if ((int)i != idx && lobe_matches(ltype(i), flags)) *pdf_out += lobe_pdf(lobes[i], wo, wi);
         if (matching > 1) *pdf_out /= (float)matching;
         if (!(bt & BX_SPEC)) {
             bool refl = dot(*wi_w, ng) * dot(wo_w, ng) > 0.0f;

@@ -27,6 +27,7 @@ struct SceneDev {
     const uint32_t* infinite_lights;    // Scene.infinite_lights: indices into lights[] (scene.rs:40-43)
     uint32_t n_nodes, n_prims, n_lights, n_infinite;
     float wb_min[3], wb_max[3];  // BVHAccel::world_bound = nodes[0].bounds (bvh.rs:394-400)
+    const uint8_t* mat_flags;    // per material: RSPT_MAT_TEXTURED | RSPT_MAT_BUMP (dev_texture.h); nullptr = no textures in the scene
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)

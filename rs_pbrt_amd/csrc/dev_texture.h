@@ -1,0 +1,313 @@
+// Textures on the device: MipMap lookups (trilinear + EWA), UV / planar mappings,
+// screen-space differentials of the camera hit, bump mapping — evaluated by k_texture, a stage of
+// its own in front of k_shade, so that scenes without textures pay nothing (k_shade only reads the
+// per-path results when the hit material is flagged as textured).
+#pragma once
+#include "dev_scene.h"
+
+namespace rspt {
+
+struct ImageDev {  // MipMap<T> pyramid (mipmap.rs:38-45)
+    const float* texels;        // `channels` floats per texel, levels concatenated
+    uint32_t level_offset[16];  // in texels
+    uint32_t width, height, n_levels, channels;
+};
+#define RSPT_TEX_SLOTS 4        // distinct textures one material may bind to lobe colours
+#define RSPT_EWA_LUT 128        // WEIGHT_LUT_SIZE (mipmap.rs:21)
+#define RSPT_EWA_MAX_SPAN 256   // guard on the EWA footprint scan (reference: unbounded)
+
+struct TexTables {
+    const rspt_texture* textures;
+    const ImageDev* images;
+    const float* ewa_lut;          // host-built with expf as MipMap::new does (mipmap.rs:186-192)
+    const uint32_t* mat_slots;     // [material][RSPT_TEX_SLOTS]: texture index or 0xffffffff
+    const uint8_t* mat_flags;      // bit 0: some lobe colour is textured; bit 1: bump map
+};
+#define RSPT_MAT_TEXTURED 1u
+#define RSPT_MAT_BUMP 2u
+// per-path results of k_texture, SoA [row][path]: rows 0..3 = clamp(texture value) of the material's
+// slots; row 4 = (bumped shading.n, flags: bit 0 = bump applied, bits 8..15 = lobes dropped as black);
+// row 5 = bumped shading.dpdu
+#define RSPT_TEX_ROWS 6
+
+// what Texture::evaluate reads of the SurfaceInteraction
+struct TexSurf {
+    f3 p;
+    f2 uv;
+    float dudx, dvdx, dudy, dvdy;
+    f3 dpdx, dpdy;
+};
+
+RDEV int64_t f2i64(float x) {  // Rust `as isize`: saturating, NaN -> 0
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0f) return INT64_MAX;
+    if (x <= -9223372036854775808.0f) return INT64_MIN;
+    return (int64_t)x;
+}
+
+// ---- MipMap<T>::texel / triangle / lookup / ewa: src/core/mipmap.rs:206-400 ----
+RDEV rgb img_texel(const ImageDev& m, uint32_t wrap, uint32_t level, int64_t s, int64_t t) {
+    uint32_t w = m.width >> level, h = m.height >> level;
+    w = w ? w : 1u; h = h ? h : 1u;
+    uint64_t ss, tt;
+    if (wrap == RSPT_WRAP_REPEAT) { ss = (uint64_t)s % (uint64_t)w; tt = (uint64_t)t % (uint64_t)h; }  // mod_t(s as usize, u_size)
+    else {  // Clamp, and Black's clamp-like branch (mipmap.rs:217-227)
+        ss = (uint64_t)(s < 0 ? 0 : (s > (int64_t)w - 1 ? (int64_t)w - 1 : s));
+        tt = (uint64_t)(t < 0 ? 0 : (t > (int64_t)h - 1 ? (int64_t)h - 1 : t));
+    }
+    const float* q = m.texels + (size_t)m.channels * ((size_t)m.level_offset[level] + tt * w + ss);
+    return m.channels == 1 ? mkrgb(q[0]) : ldrgb(q);
+}
+RDEVN rgb img_triangle(const ImageDev& m, uint32_t wrap, uint32_t level, f2 st) {
+    if (level > m.n_levels - 1) level = m.n_levels - 1;
+    uint32_t w = m.width >> level, h = m.height >> level;
+    w = w ? w : 1u; h = h ? h : 1u;
+    float s = st.x * (float)w - 0.5f, t = st.y * (float)h - 0.5f;
+    int64_t s0 = f2i64(floorf(s)), t0 = f2i64(floorf(t));
+    float ds = s - (float)s0, dt = t - (float)t0;
+    rgb tmp1 = img_texel(m, wrap, level, s0 + 1, t0 + 1) * (ds * dt);
+    rgb tmp2 = img_texel(m, wrap, level, s0 + 1, t0) * (ds * (1.0f - dt));
+    rgb tmp3 = img_texel(m, wrap, level, s0, t0 + 1) * ((1.0f - ds) * dt);
+    rgb tmp4 = img_texel(m, wrap, level, s0, t0) * ((1.0f - ds) * (1.0f - dt));
+    return tmp4 + tmp3 + tmp2 + tmp1;
+}
+RDEV rgb img_lookup_width(const ImageDev& m, uint32_t wrap, f2 st, float width) {  // lookup_pnt_flt :233-252
+    float level = (float)m.n_levels - 1.0f + log2f(fmaxf(width, 1e-8f));
+    if (level < 0.0f) return img_triangle(m, wrap, 0, st);
+    if (level >= (float)m.n_levels - 1.0f) return img_texel(m, wrap, m.n_levels - 1, 0, 0);
+    uint32_t il = (uint32_t)floorf(level);
+    float delta = level - (float)il;
+    rgb a = img_triangle(m, wrap, il, st), b = img_triangle(m, wrap, il + 1, st);
+    return a * (1.0f - delta) + b * delta;
+}
+RDEVN rgb img_ewa(const ImageDev& m, const float* lut, uint32_t wrap, uint32_t level, f2 st, f2 dst0, f2 dst1) {  // :337-400
+    if (level >= m.n_levels) return img_texel(m, wrap, m.n_levels - 1, 0, 0);
+    uint32_t w = m.width >> level, h = m.height >> level;
+    w = w ? w : 1u; h = h ? h : 1u;
+    float sx = st.x * (float)w - 0.5f, sy = st.y * (float)h - 0.5f;
+    float d0x = dst0.x * (float)w, d0y = dst0.y * (float)h, d1x = dst1.x * (float)w, d1y = dst1.y * (float)h;
+    float a = d0y * d0y + d1y * d1y + 1.0f;
+    float b = -2.0f * (d0x * d0y + d1x * d1y);
+    float c = d0x * d0x + d1x * d1x + 1.0f;
+    float inv_f = 1.0f / (a * c - b * b * 0.25f);
+    a *= inv_f; b *= inv_f; c *= inv_f;
+    float det = -b * b + 4.0f * a * c;
+    float inv_det = 1.0f / det;
+    float u_sqrt = sqrtf(det * c), v_sqrt = sqrtf(a * det);
+    int64_t s0 = f2i64(ceilf(sx - 2.0f * inv_det * u_sqrt)), s1 = f2i64(floorf(sx + 2.0f * inv_det * u_sqrt));
+    int64_t t0 = f2i64(ceilf(sy - 2.0f * inv_det * v_sqrt)), t1 = f2i64(floorf(sy + 2.0f * inv_det * v_sqrt));
+    if (s1 - s0 > RSPT_EWA_MAX_SPAN) s1 = s0 + RSPT_EWA_MAX_SPAN;
+    if (t1 - t0 > RSPT_EWA_MAX_SPAN) t1 = t0 + RSPT_EWA_MAX_SPAN;
+    rgb sum = mkrgb(0.0f);
+    float sum_wts = 0.0f;
+    for (int64_t it = t0; it <= t1; it++) {
+        float tt = (float)it - sy;
+        for (int64_t is = s0; is <= s1; is++) {
+            float ss = (float)is - sx;
+            float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+            if (r2 < 1.0f) {
+                float fi = r2 * (float)RSPT_EWA_LUT;
+                uint32_t index = (fi != fi || fi <= 0.0f) ? 0u : (fi >= (float)(RSPT_EWA_LUT - 1) ? (uint32_t)(RSPT_EWA_LUT - 1) : (uint32_t)fi);
+                float weight = lut[index];
+                sum = sum + img_texel(m, wrap, level, is, it) * weight;
+                sum_wts += weight;
+            }
+        }
+    }
+    return sum / sum_wts;
+}
+RDEV rgb img_lookup(const ImageDev& m, const float* lut, const rspt_texture& tx, f2 st, f2 dst0, f2 dst1) {  // lookup_pnt_vec_vec :253-297
+    if (tx.trilinear) {
+        float width = fmaxf(fmaxf(fabsf(dst0.x), fabsf(dst0.y)), fmaxf(fabsf(dst1.x), fabsf(dst1.y)));
+        return img_lookup_width(m, tx.wrap, st, width);
+    }
+    if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) { f2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
+    float major_length = sqrtf(dst0.x * dst0.x + dst0.y * dst0.y);
+    float minor_length = sqrtf(dst1.x * dst1.x + dst1.y * dst1.y);
+    if (minor_length * tx.max_aniso < major_length && minor_length > 0.0f) {
+        float scale = major_length / (minor_length * tx.max_aniso);
+        dst1.x *= scale; dst1.y *= scale;
+        minor_length *= scale;
+    }
+    if (minor_length == 0.0f) return img_triangle(m, tx.wrap, 0, st);
+    float lod = fmaxf(0.0f, (float)m.n_levels - 1.0f + log2f(minor_length));
+    uint32_t ilod = (uint32_t)floorf(lod);
+    rgb col2 = img_ewa(m, lut, tx.wrap, ilod + 1, st, dst0, dst1);
+    rgb col1 = img_ewa(m, lut, tx.wrap, ilod, st, dst0, dst1);
+    float t = lod - (float)ilod;
+    return col1 * (1.0f - t) + col2 * t;
+}
+
+// ---- Texture::evaluate (constant.rs, imagemap.rs:114-149, scale.rs) + mappings (texture.rs:91-121, 222-257) ----
+RDEV rgb tex_eval_leaf(const TexTables& tt, const rspt_texture& tx, const TexSurf& si) {
+    if (tx.kind == RSPT_TEX_CONSTANT) return ldrgb(tx.value);
+    f2 st, dstdx, dstdy;
+    if (tx.mapping == RSPT_MAP_PLANAR) {
+        f3 vs{tx.map[0], tx.map[1], tx.map[2]}, vt{tx.map[3], tx.map[4], tx.map[5]};
+        dstdx = f2{dot(si.dpdx, vs), dot(si.dpdx, vt)};
+        dstdy = f2{dot(si.dpdy, vs), dot(si.dpdy, vt)};
+        st = f2{tx.map[6] + dot(si.p, vs), tx.map[7] + dot(si.p, vt)};
+    } else {
+        dstdx = f2{si.dudx * tx.map[0], si.dvdx * tx.map[1]};
+        dstdy = f2{si.dudy * tx.map[0], si.dvdy * tx.map[1]};
+        st = f2{si.uv.x * tx.map[0] + tx.map[2], si.uv.y * tx.map[1] + tx.map[3]};
+    }
+    return img_lookup(tt.images[tx.image], tt.ewa_lut, tx, st, dstdx, dstdy);
+}
+RDEVN rgb tex_eval(const TexTables& tt, uint32_t ti, const TexSurf& si) {
+    const rspt_texture tx = tt.textures[ti];
+    if (tx.kind == RSPT_TEX_SCALE) return tex_eval_leaf(tt, tt.textures[tx.tex1], si) * tex_eval_leaf(tt, tt.textures[tx.tex2], si);
+    return tex_eval_leaf(tt, tx, si);
+}
+
+// Triangle::intersect's interaction (triangle.rs:274-448) with everything textures and bump mapping read
+struct TexHit {
+    f3 p, n;
+    f2 uv;
+    f3 dpdu, dpdv;                        // isect.dpdu / dpdv
+    f3 sh_n, sh_dpdu, sh_dpdv, sh_dndu, sh_dndv;  // isect.shading
+};
+RDEVN void tri_fill_tex(const SceneDev& sc, uint32_t prim, const TriRec& t, float b0, float b1, float b2, TexHit* h) {
+    f3 p0 = t.p0, p1 = t.p1, p2 = t.p2;
+    f2 uv0{0.0f, 0.0f}, uv1{1.0f, 0.0f}, uv2{1.0f, 1.0f};  // triangle.rs:97-112
+    const bool has_uv = (t.flags & MF_HAS_UV) && sc.UV;
+    const bool has_n = (t.flags & MF_HAS_N) && sc.N, has_s = (t.flags & MF_HAS_S) && sc.S;
+    uint32_t v0 = 0, v1 = 0, v2 = 0;
+    if (has_uv || has_n || has_s) {
+        rspt_prim pr = sc.prims[prim];
+        v0 = pr.v[0]; v1 = pr.v[1]; v2 = pr.v[2];
+    }
+    if (has_uv) {
+        uv0 = f2{sc.UV[2 * (size_t)v0], sc.UV[2 * (size_t)v0 + 1]};
+        uv1 = f2{sc.UV[2 * (size_t)v1], sc.UV[2 * (size_t)v1 + 1]};
+        uv2 = f2{sc.UV[2 * (size_t)v2], sc.UV[2 * (size_t)v2 + 1]};
+    }
+    f2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
+    f3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float det = duv02.x * duv12.y - duv02.y * duv12.x;
+    bool degenerate = fabsf(det) < 1e-8f;
+    f3 dpdu{0.0f, 0.0f, 0.0f}, dpdv{0.0f, 0.0f, 0.0f};
+    if (!degenerate) {
+        float invdet = 1.0f / det;
+        dpdu = (dp02 * duv12.y - dp12 * duv02.y) * invdet;
+        dpdv = (dp02 * -duv12.x + dp12 * duv02.x) * invdet;
+    }
+    if (degenerate || len2(cross(dpdu, dpdv)) == 0.0f) coordinate_system(normalize(cross(p2 - p0, p1 - p0)), &dpdu, &dpdv);
+    h->p = p0 * b0 + p1 * b1 + p2 * b2;
+    h->uv = f2{uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2};
+    f3 n = normalize(cross(dp02, dp12));
+    if (t.flags & MF_FLIP) n = -n;
+    f3 sh_n = n, sh_dpdu = dpdu, sh_dpdv = dpdv, dndu{0.0f, 0.0f, 0.0f}, dndv{0.0f, 0.0f, 0.0f};
+    if (has_n || has_s) {
+        f3 ns = n;
+        f3 n0{0.0f, 0.0f, 0.0f}, n1 = n0, n2 = n0;
+        if (has_n) {
+            n0 = ld3(sc.N, v0); n1 = ld3(sc.N, v1); n2 = ld3(sc.N, v2);
+            ns = n0 * b0 + n1 * b1 + n2 * b2;
+            ns = len2(ns) > 0.0f ? normalize(ns) : n;
+        }
+        f3 ss;
+        if (has_s) {
+            ss = ld3(sc.S, v0) * b0 + ld3(sc.S, v1) * b1 + ld3(sc.S, v2) * b2;
+            ss = len2(ss) > 0.0f ? normalize(ss) : normalize(dpdu);
+        } else
+            ss = normalize(dpdu);
+        f3 ts = cross(ss, ns);
+        if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinate_system(ns, &ss, &ts);
+        if (has_n && !degenerate) {  // triangle.rs:389-416
+            f3 dn1 = n0 - n2, dn2 = n1 - n2;
+            float inv_det = 1.0f / det;
+            dndu = (dn1 * duv12.y - dn2 * duv02.y) * inv_det;
+            dndv = (dn1 * -duv12.x + dn2 * duv02.x) * inv_det;
+        }
+        sh_n = normalize(cross(ss, ts));
+        n = faceforward(n, sh_n);
+        sh_dpdu = ss; sh_dpdv = ts;
+    }
+    h->n = n; h->dpdu = dpdu; h->dpdv = dpdv;
+    h->sh_n = sh_n; h->sh_dpdu = sh_dpdu; h->sh_dpdv = sh_dpdv; h->sh_dndu = dndu; h->sh_dndv = dndv;
+}
+
+// SurfaceInteraction::compute_differentials (interaction.rs:388-479) for a ray with differentials
+RDEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float* x0, float* x1) {  // transform.rs:219-235
+    float det = a00 * a11 - a01 * a10;
+    if (fabsf(det) < 1e-10f) return false;
+    *x0 = (a11 * b0 - a01 * b1) / det;
+    *x1 = (a00 * b1 - a10 * b0) / det;
+    return !(*x0 != *x0 || *x1 != *x1);
+}
+RDEVN void compute_differentials(const TexHit& h, f3 rx_o, f3 rx_d, f3 ry_o, f3 ry_d, TexSurf* s) {
+    s->dudx = s->dvdx = s->dudy = s->dvdy = 0.0f;
+    s->dpdx = s->dpdy = f3{0.0f, 0.0f, 0.0f};
+    float d = dot(h.n, h.p);
+    float tx = -(dot(h.n, rx_o) - d) / dot(h.n, rx_d);
+    if (__builtin_isinf(tx) || tx != tx) return;
+    f3 px = rx_o + rx_d * tx;
+    float ty = -(dot(h.n, ry_o) - d) / dot(h.n, ry_d);
+    if (__builtin_isinf(ty) || ty != ty) return;
+    f3 py = ry_o + ry_d * ty;
+    s->dpdx = px - h.p;
+    s->dpdy = py - h.p;
+    int d0, d1;
+    if (fabsf(h.n.x) > fabsf(h.n.y) && fabsf(h.n.x) > fabsf(h.n.z)) { d0 = 1; d1 = 2; }
+    else if (fabsf(h.n.y) > fabsf(h.n.z)) { d0 = 0; d1 = 2; }
+    else { d0 = 0; d1 = 1; }
+    float a00 = comp(h.dpdu, d0), a01 = comp(h.dpdv, d0), a10 = comp(h.dpdu, d1), a11 = comp(h.dpdv, d1);
+    float bx0 = comp(px, d0) - comp(h.p, d0), bx1 = comp(px, d1) - comp(h.p, d1);
+    float by0 = comp(py, d0) - comp(h.p, d0), by1 = comp(py, d1) - comp(h.p, d1);
+    if (!solve_2x2(a00, a01, a10, a11, bx0, bx1, &s->dudx, &s->dvdx)) { s->dudx = 0.0f; s->dvdx = 0.0f; }
+    if (!solve_2x2(a00, a01, a10, a11, by0, by1, &s->dudy, &s->dvdy)) { s->dudy = 0.0f; s->dvdy = 0.0f; }
+}
+
+// PerspectiveCamera::generate_ray_differential's offset rays (perspective.rs:205-220, 245-271), transformed
+// (transform.rs:550-556) and scaled by 1 / sqrt(spp) (integrator.rs:140-144; geometry.rs:2398-2405)
+RDEVN void camera_differentials(const RenderDev& rd, f2 p_film, f2 p_lens, f3 ray_o, f3 ray_d, f3* rx_o, f3* rx_d, f3* ry_o, f3* ry_d) {
+    f3 p_camera = xf_point(rd.raster_to_camera, f3{p_film.x, p_film.y, 0.0f});
+    f3 c0 = xf_point(rd.raster_to_camera, f3{0.0f, 0.0f, 0.0f});
+    f3 dx_camera = xf_point(rd.raster_to_camera, f3{1.0f, 0.0f, 0.0f}) - c0;
+    f3 dy_camera = xf_point(rd.raster_to_camera, f3{0.0f, 1.0f, 0.0f}) - c0;
+    f3 ox{0.0f, 0.0f, 0.0f}, oy = ox;
+    f3 dx = normalize(p_camera + dx_camera), dy = normalize(p_camera + dy_camera);
+    if (rd.lens_radius > 0.0f) {
+        f2 pl = concentric_disk(p_lens);
+        pl = f2{pl.x * rd.lens_radius, pl.y * rd.lens_radius};
+        float ftx = rd.focal_distance / dx.z;
+        f3 pfx = f3{0.0f, 0.0f, 0.0f} + dx * ftx;
+        ox = f3{pl.x, pl.y, 0.0f};
+        dx = normalize(pfx - ox);
+        float fty = rd.focal_distance / dy.z;
+        f3 pfy = f3{0.0f, 0.0f, 0.0f} + dy * fty;
+        oy = f3{pl.x, pl.y, 0.0f};
+        dy = normalize(pfy - oy);
+    }
+    f3 wox = xf_point(rd.camera_to_world, ox), woy = xf_point(rd.camera_to_world, oy);
+    f3 wdx = xf_vector(rd.camera_to_world, dx), wdy = xf_vector(rd.camera_to_world, dy);
+    float s = 1.0f / sqrtf((float)rd.spp);
+    *rx_o = ray_o + (wox - ray_o) * s; *ry_o = ray_o + (woy - ray_o) * s;
+    *rx_d = ray_d + (wdx - ray_d) * s; *ry_d = ray_d + (wdy - ray_d) * s;
+}
+
+// Material::bump (material.rs:116-219) followed by set_shading_geometry(.., false) (interaction.rs:345-370; si.shape is
+// None for triangles, so no orientation flip)
+RDEVN void bump_map(const TexTables& tt, uint32_t ti, const TexHit& h, const TexSurf& s, f3* sh_n_out, f3* sh_dpdu_out) {
+    TexSurf ev = s;
+    float du = 0.5f * (fabsf(s.dudx) + fabsf(s.dudy));
+    if (du == 0.0f) du = 0.0005f;
+    ev.p = h.p + h.sh_dpdu * du;
+    ev.uv = f2{s.uv.x + du, s.uv.y + 0.0f};
+    float u_displace = tex_eval(tt, ti, ev).r;
+    float dv = 0.5f * (fabsf(s.dvdx) + fabsf(s.dvdy));
+    if (dv == 0.0f) dv = 0.0005f;
+    ev.p = h.p + h.sh_dpdv * dv;
+    ev.uv = f2{s.uv.x + 0.0f, s.uv.y + dv};
+    float v_displace = tex_eval(tt, ti, ev).r;
+    float displace = tex_eval(tt, ti, s).r;
+    f3 dpdu = h.sh_dpdu + h.sh_n * ((u_displace - displace) / du) + h.sh_dndu * displace;
+    f3 dpdv = h.sh_dpdv + h.sh_n * ((v_displace - displace) / dv) + h.sh_dndv * displace;
+    f3 n = normalize(cross(dpdu, dpdv));
+    *sh_n_out = faceforward(n, h.n);
+    *sh_dpdu_out = dpdu;
+}
+
+}  // namespace rspt

@@ -9,7 +9,7 @@
 // Queues are arrays of path slots compacted with wave64 ballot + prefix popcount, one atomic per
 // workgroup and queue (K7, in k_shade).
 #pragma once
-#include "dev_scene.h"
+#include "dev_texture.h"
 
 namespace rspt {
 
@@ -41,6 +41,8 @@ struct PathBuf {
     uint64_t* sobol_index;
     uint32_t* state;
     float2* p_film;
+    float4* tex;          // k_texture results, RSPT_TEX_ROWS rows of tex_stride paths (nullptr: scene without textures)
+    uint32_t tex_stride;
 };
 
 struct QueueCounts {  // one per wavefront iteration
@@ -311,6 +313,20 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 rspt_material mat = sc.materials[h.material];
                 Bsdf bsdf;  // Bsdf::new (reflection.rs:235-245)
                 bsdf.eta = mat.eta;
+                bsdf.lt = LobeTex{nullptr, 0};
+                bsdf.dropped = 0u;
+                if (sc.mat_flags && sc.mat_flags[h.material]) {  // textured material: k_texture ran for this hit
+                    const float4* tb = pb.tex + p;
+                    bsdf.lt = LobeTex{tb, pb.tex_stride};
+                    const float4 m4 = tb[4 * (size_t)pb.tex_stride];
+                    const uint32_t tf = __float_as_uint(m4.w);
+                    bsdf.dropped = (tf >> 8) & 0xffu;
+                    if (tf & 1u) {  // Material::bump replaced the shading geometry (material.rs:116-219)
+                        const float4 d4 = tb[5 * (size_t)pb.tex_stride];
+                        h.sh_n = f3{m4.x, m4.y, m4.z};
+                        h.sh_dpdu = f3{d4.x, d4.y, d4.z};
+                    }
+                }
                 bsdf.ss = normalize(h.sh_dpdu);
                 bsdf.ns = h.sh_n;
                 bsdf.ng = h.n;
@@ -430,6 +446,85 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     pb.state[p] = st;
     out.active = (st & (ST_ALIVE | ST_PENDING)) != 0;
     return out;
+}
+
+// ---- texture stage: runs in front of k_shade when the scene has textures -------------
+// For every path whose continuation ray hit a textured material: compute_differentials (camera rays
+// only; bounce rays carry none, interaction.rs:388-479), Material::bump, and the clamped value of each
+// texture the material's lobes are bound to; k_shade picks the results up from pb.tex.
+__global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
+                                                 const QueueCounts* __restrict__ cnt_in) {
+    const uint32_t n = cnt_in->active;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t p = q_active[i];
+        const uint32_t st = pb.state[p];
+        if (!(st & ST_ALIVE)) continue;
+        const float4 hc = pb.hit_cont[p];
+        const uint32_t prim = __float_as_uint(hc.x);
+        const uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
+        if (prim == RSPT_MISS || bounces >= rd.max_depth) continue;
+        const TriRec tri = load_tri(sc, prim);
+        if (tri.material == 0xffffffffu) continue;
+        const uint32_t mf = tt.mat_flags[tri.material];
+        if (!mf) continue;
+        TexHit h;
+        tri_fill_tex(sc, prim, tri, hc.y, hc.z, hc.w, &h);
+        TexSurf s;
+        s.p = h.p; s.uv = h.uv;
+        s.dudx = s.dvdx = s.dudy = s.dvdy = 0.0f;
+        s.dpdx = s.dpdy = f3{0.0f, 0.0f, 0.0f};
+        if (bounces == 0 && !(st & ST_SPECULAR)) {  // the camera ray (a null-material pass-through re-spawns without differentials)
+            const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
+            const float4 r0 = rp[0], r1 = rp[1];
+            const float2 pf = pb.p_film[p];
+            f2 p_lens{0.0f, 0.0f};
+            if (rd.lens_radius > 0.0f) {
+                const uint64_t index = pb.sobol_index[p];
+                p_lens = rd.sampler_kind == RSPT_SAMPLER_HALTON ? f2{halton_dim(rd, index, 3), halton_dim(rd, index, 4)}
+                                                                : f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
+            }
+            f3 rx_o, rx_d, ry_o, ry_d;
+            camera_differentials(rd, f2{pf.x, pf.y}, p_lens, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, &rx_o, &rx_d, &ry_o, &ry_d);
+            compute_differentials(h, rx_o, rx_d, ry_o, ry_d, &s);
+        }
+        const rspt_material mat = sc.materials[tri.material];
+        float4* out = pb.tex + p;
+        const size_t stride = pb.tex_stride;
+        uint32_t flags = 0;
+        if (mat.bump_tex) {
+            f3 bn, bdpdu;
+            bump_map(tt, mat.bump_tex - 1u, h, s, &bn, &bdpdu);
+            out[5 * stride] = make_float4(bdpdu.x, bdpdu.y, bdpdu.z, 0.0f);
+            flags |= 1u;
+            out[4 * stride] = make_float4(bn.x, bn.y, bn.z, 0.0f);  // (.w is completed below)
+            h.sh_n = bn;
+        }
+        rgb tv[RSPT_TEX_SLOTS];
+#pragma unroll
+        for (int k = 0; k < RSPT_TEX_SLOTS; k++) {
+            tv[k] = mkrgb(0.0f);
+            const uint32_t ti = tt.mat_slots[(size_t)tri.material * RSPT_TEX_SLOTS + k];
+            if (ti != 0xffffffffu) {
+                rgb v = tex_eval(tt, ti, s);
+                tv[k] = rgb{v.r < 0.0f ? 0.0f : v.r, v.g < 0.0f ? 0.0f : v.g, v.b < 0.0f ? 0.0f : v.b};  // Spectrum::clamp(0, inf) = clamp_t per channel (pbrt.rs:108-123)
+                out[k * stride] = make_float4(tv[k].r, tv[k].g, tv[k].b, 0.0f);
+            }
+        }
+        // the reference's `if !colour.is_black()` guards around bsdf.add (matte.rs:70, plastic.rs:70,84, substrate.rs:72, uber.rs)
+        const uint32_t nl = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+        for (uint32_t l = 0; l < nl; l++) {
+            const rspt_bxdf& b = sc.bxdfs[mat.first_bxdf + l];
+            if (!b.tex_r && !b.tex_t) continue;
+            rgb r = ldrgb(b.r), t = ldrgb(b.t);
+            if (b.tex_r) r = r * (b.tex_r == 1 ? tv[0] : (b.tex_r == 2 ? tv[1] : (b.tex_r == 3 ? tv[2] : tv[3])));
+            if (b.tex_t) t = t * (b.tex_t == 1 ? tv[0] : (b.tex_t == 2 ? tv[1] : (b.tex_t == 3 ? tv[2] : tv[3])));
+            const bool two = b.type == RSPT_BXDF_FRESNEL_SPEC || b.type == RSPT_BXDF_FRESNEL_BLEND;
+            if (two ? (is_black(r) && is_black(t)) : is_black(r)) flags |= 1u << (8 + l);
+        }
+        float4 m4 = (flags & 1u) ? out[4 * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        m4.w = __uint_as_float(flags);
+        out[4 * stride] = m4;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -91,6 +92,8 @@ struct rspt_scene_s {
     const Wide4Node* w4 = nullptr;    // one per interior LinearBVHNode at even depth (trace_w4.h)
     const uint2* big_leaves = nullptr;
     uint32_t w4_root = 0;
+    TexTables tex{};                  // textures / images / per-material slots (dev_texture.h); has_textures says whether set
+    bool has_textures = false;
     std::vector<void*> allocs;
     bool has_null_material = false;
     std::map<int, LightDist> light_dists;  // by effective strategy
@@ -127,7 +130,7 @@ size_t env_size(const char* name, size_t dflt) {
 
 void free_paths() {
     void* ptrs[] = {g.pb.ray_cont, g.pb.ray_mis, g.pb.ray_sh, g.pb.hit_cont, g.pb.hit_mis, g.pb.occluded, g.pb.L_eta, g.pb.beta,
-                    g.pb.nee_c1, g.pb.nee_c2, g.pb.nee_beta, g.pb.sobol_index, g.pb.state, g.pb.p_film,
+                    g.pb.nee_c1, g.pb.nee_c2, g.pb.nee_beta, g.pb.sobol_index, g.pb.state, g.pb.p_film, g.pb.tex,
                     g.q[0][0], g.q[0][1], g.q[0][2], g.q[1][0], g.q[1][1], g.q[1][2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -152,6 +155,15 @@ int ensure_paths(size_t cap) {
     }
 #undef A
     g.cap = cap;
+    return RSPT_OK;
+}
+
+// per-path rows of k_texture's results, only for scenes with textures (6 x 16 B per path)
+int ensure_tex_rows() {
+    if (g.pb.tex) return RSPT_OK;
+    int rc = dev_alloc(&g.pb.tex, g.cap * RSPT_TEX_ROWS);
+    if (rc) return rc;
+    g.pb.tex_stride = (uint32_t)g.cap;
     return RSPT_OK;
 }
 
@@ -450,7 +462,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1)))) { if (li_dev) (void)hipFree(li_dev); return rc; }
     const uint32_t nominal_iters = d->max_depth + 1;
     const uint32_t max_iters = s->has_null_material ? nominal_iters + 64 : nominal_iters;
-    if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(2 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK))) { if (li_dev) (void)hipFree(li_dev); return rc; }
+    if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(2 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
+        (s->has_textures && (rc = ensure_tex_rows()))) { if (li_dev) (void)hipFree(li_dev); return rc; }
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
 
@@ -487,6 +500,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 HIP_TRY(hipEventRecord(e1, g.stream));
                 trace_ev.push_back({e0, e1});
                 trace_launches += it > 0 ? 2 : 1;
+                if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it]);
                 hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                    g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits);
                 it++;
@@ -612,6 +626,35 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         if (d->lights[i].kind == RSPT_LIGHT_DIFFUSE_AREA && d->lights[i].prim >= d->n_prims) return fail(RSPT_E_INVALID, "light %u: prim out of range", i);
         if (d->lights[i].kind == RSPT_LIGHT_INFINITE && d->lights[i].prim >= d->n_envmaps) return fail(RSPT_E_INVALID, "light %u: envmap index out of range", i);
     }
+    // textures: constant / imagemap / scale; each material may bind at most RSPT_TEX_SLOTS distinct ones
+    if ((d->n_textures && !d->textures) || (d->n_images && !d->images)) return fail(RSPT_E_INVALID, "null texture / image array");
+    for (uint32_t i = 0; i < d->n_images; i++) {
+        const rspt_image& im = d->images[i];
+        auto pow2 = [](uint32_t v) { return v && !(v & (v - 1)); };
+        if (!pow2(im.width) || !pow2(im.height) || im.width > 32768 || im.height > 32768) return fail(RSPT_E_INVALID, "image %u: sides must be powers of two <= 32768 (MipMap::new resamples first)", i);
+        uint32_t nl = 1;
+        for (uint32_t m = std::max(im.width, im.height); m > 1; m >>= 1) nl++;
+        if (im.n_levels != nl || nl > 16) return fail(RSPT_E_INVALID, "image %u: n_levels %u, expected %u", i, im.n_levels, nl);
+        if (!im.texels || (im.channels != 1 && im.channels != 3)) return fail(RSPT_E_INVALID, "image %u: null texels or channels not 1 / 3", i);
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rspt_texture& t = d->textures[i];
+        if (t.kind == RSPT_TEX_CONSTANT) continue;
+        if (t.kind == RSPT_TEX_IMAGE) {
+            if (t.image >= d->n_images) return fail(RSPT_E_INVALID, "texture %u: image index out of range", i);
+            if (t.mapping != RSPT_MAP_UV && t.mapping != RSPT_MAP_PLANAR) return fail(RSPT_E_UNSUPPORTED, "texture %u: mapping %u (uv and planar only)", i, t.mapping);
+            if (t.wrap > RSPT_WRAP_CLAMP) return fail(RSPT_E_INVALID, "texture %u: bad wrap mode", i);
+        } else if (t.kind == RSPT_TEX_SCALE) {
+            if (t.tex1 >= d->n_textures || t.tex2 >= d->n_textures) return fail(RSPT_E_INVALID, "texture %u: child index out of range", i);
+            if (d->textures[t.tex1].kind == RSPT_TEX_SCALE || d->textures[t.tex2].kind == RSPT_TEX_SCALE)
+                return fail(RSPT_E_UNSUPPORTED, "texture %u: nested scale textures", i);
+        } else
+            return fail(RSPT_E_UNSUPPORTED, "texture %u: unsupported kind %u", i, t.kind);
+    }
+    for (uint32_t i = 0; i < d->n_bxdfs; i++)
+        if (d->bxdfs[i].tex_r > d->n_textures || d->bxdfs[i].tex_t > d->n_textures) return fail(RSPT_E_INVALID, "bxdf %u: texture index out of range", i);
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        if (d->materials[i].bump_tex > d->n_textures) return fail(RSPT_E_INVALID, "material %u: bump texture index out of range", i);
     if (d->n_envmaps && !d->envmaps) return fail(RSPT_E_INVALID, "null envmaps");
     for (uint32_t i = 0; i < d->n_envmaps; i++) {
         const rspt_envmap& e = d->envmaps[i];
@@ -662,7 +705,57 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((rc = upload(s, d->S, d->S ? d->n_vertices * 3 : 0, &s->dev.S))) return bail(rc);
     if ((rc = upload(s, d->UV, d->UV ? d->n_vertices * 2 : 0, &s->dev.UV))) return bail(rc);
     if ((rc = upload(s, d->materials, d->n_materials, &s->dev.materials))) return bail(rc);
-    if ((rc = upload(s, d->bxdfs, d->n_bxdfs, &s->dev.bxdfs))) return bail(rc);
+    {   // lobes: texture ids become per-material slot numbers (1 + slot) for k_texture / k_shade
+        std::vector<rspt_bxdf> bx(d->bxdfs, d->bxdfs + d->n_bxdfs);
+        std::vector<uint32_t> slots((size_t)d->n_materials * RSPT_TEX_SLOTS, 0xffffffffu);
+        std::vector<uint8_t> mflags(d->n_materials, 0);
+        bool any = false;
+        for (uint32_t m = 0; m < d->n_materials; m++) {
+            const rspt_material& mat = d->materials[m];
+            uint32_t* sl = slots.data() + (size_t)m * RSPT_TEX_SLOTS;
+            uint32_t n_sl = 0;
+            auto slot_of = [&](uint32_t tex_plus_1) -> int {
+                for (uint32_t k = 0; k < n_sl; k++) if (sl[k] == tex_plus_1 - 1u) return (int)k + 1;
+                if (n_sl == RSPT_TEX_SLOTS) return -1;
+                sl[n_sl++] = tex_plus_1 - 1u;
+                return (int)n_sl;
+            };
+            for (uint32_t l = 0; l < mat.n_bxdfs; l++) {
+                rspt_bxdf& b = bx[mat.first_bxdf + l];
+                if (b.tex_r) { int k = slot_of(b.tex_r); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_r = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
+                if (b.tex_t) { int k = slot_of(b.tex_t); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_t = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
+            }
+            if (mat.bump_tex) mflags[m] |= RSPT_MAT_BUMP;
+            any |= mflags[m] != 0;
+        }
+        if ((rc = upload(s, bx.data(), bx.size(), &s->dev.bxdfs))) return bail(rc);
+        if (any) {
+            s->has_textures = true;
+            if ((rc = upload(s, d->textures, d->n_textures, &s->tex.textures)) || (rc = upload(s, slots.data(), slots.size(), &s->tex.mat_slots)) ||
+                (rc = upload(s, mflags.data(), mflags.size(), &s->tex.mat_flags)))
+                return bail(rc);
+            s->dev.mat_flags = s->tex.mat_flags;
+            std::vector<ImageDev> imgs(d->n_images);
+            for (uint32_t i = 0; i < d->n_images; i++) {
+                const rspt_image& im = d->images[i];
+                ImageDev& o = imgs[i];
+                o.width = im.width; o.height = im.height; o.n_levels = im.n_levels; o.channels = im.channels;
+                size_t n_tex = 0;
+                for (uint32_t l = 0, w = im.width, h = im.height; l < im.n_levels; l++, w = std::max(1u, w / 2), h = std::max(1u, h / 2)) {
+                    o.level_offset[l] = (uint32_t)n_tex;
+                    n_tex += (size_t)w * h;
+                }
+                if ((rc = upload(s, im.texels, n_tex * im.channels, &o.texels))) return bail(rc);
+            }
+            if ((rc = upload(s, imgs.data(), imgs.size(), &s->tex.images))) return bail(rc);
+            float lut[RSPT_EWA_LUT];  // MipMap::new's EWA weights (mipmap.rs:186-192), host expf like the reference's f32::exp
+            for (int i = 0; i < RSPT_EWA_LUT; i++) {
+                const float alpha = 2.0f, r2 = (float)i / (float)(RSPT_EWA_LUT - 1);
+                lut[i] = std::exp(-alpha * r2) - std::exp(-alpha);
+            }
+            if ((rc = upload(s, lut, (size_t)RSPT_EWA_LUT, &s->tex.ewa_lut))) return bail(rc);
+        }
+    }
     if ((rc = upload(s, d->lights, d->n_lights, &s->dev.lights))) return bail(rc);
     {   // Scene.infinite_lights (scene.rs:40-43) and their environment maps
         std::vector<uint32_t> inf;

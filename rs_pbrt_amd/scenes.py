@@ -193,29 +193,53 @@ def _alpha(a):
     return max(float(a), 0.001)  # TrowbridgeReitzDistribution::new microfacet.rs:233-239
 
 
-def matte(kd, sigma=0.0):  # matte.rs:43-86
-    kd = np.maximum(np.array(kd, F32), 0)
-    if not kd.any():
-        return dict(eta=1.0, lobes=[])
+class TexRef:
+    """A texture of the scene being built (SceneBuilder.*_texture) used where a material takes a colour:
+    the lobe stores the constant factor (1, or uber's opacity) and 1 + texture index; the
+    `is_black` test that decides whether the lobe exists moves to shade time."""
+
+    def __init__(self, index):
+        self.index = int(index)
+
+
+def _col(x, scale=None):
+    """(rgb factor, 1 + texture index or 0, may_be_nonblack) of a material colour parameter"""
+    sc = np.ones(3, F32) if scale is None else np.asarray(scale, F32)
+    if isinstance(x, TexRef):
+        return sc.astype(F32), x.index + 1, bool(sc.any())
+    c = (sc * np.maximum(np.array(x, F32), 0)).astype(F32) if scale is not None else np.maximum(np.array(x, F32), 0)
+    return c, 0, bool(c.any())
+
+
+def _with_bump(m, bump):
+    if bump is not None:
+        m["bump"] = bump.index
+    return m
+
+
+def matte(kd, sigma=0.0, bump=None):  # matte.rs:43-86
+    kd, tk, any_kd = _col(kd)
+    if not any_kd:
+        return _with_bump(dict(eta=1.0, lobes=[]), bump)
     sigma = min(max(float(sigma), 0.0), 90.0)
     if sigma == 0.0:
-        return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_LAMBERT_R, r=kd)])
+        return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_LAMBERT_R, r=kd, tex_r=tk)]), bump)
     s = F32(F32(F32(math.pi) / F32(180)) * F32(sigma)); s2 = F32(s * s)  # OrenNayar::new reflection.rs:1057-1065
     a = F32(1) - F32(s2 / F32(F32(2) * F32(s2 + F32(0.33))))
     b = F32(F32(0.45) * s2) / F32(s2 + F32(0.09))
-    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_OREN_NAYAR, r=kd, on_a=a, on_b=b)])
+    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_OREN_NAYAR, r=kd, tex_r=tk, on_a=a, on_b=b)]), bump)
 
 
-def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True):  # plastic.rs:57-125
+def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True, bump=None):  # plastic.rs:57-125
     lobes = []
-    kd = np.maximum(np.array(kd, F32), 0); ks = np.maximum(np.array(ks, F32), 0)
-    if kd.any():
-        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd))
-    if ks.any():
+    kd, tkd, any_kd = _col(kd); ks, tks, any_ks = _col(ks)
+    if any_kd:
+        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd, tex_r=tkd))
+    if any_ks:
         a = tr_roughness_to_alpha(roughness) if remap else F32(roughness)
-        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, eta_a=1.5, eta_b=1.0,
+        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, tex_r=tks, eta_a=1.5, eta_b=1.0,
                            alpha_x=_alpha(a), alpha_y=_alpha(a)))
-    return dict(eta=1.0, lobes=lobes)
+    return _with_bump(dict(eta=1.0, lobes=lobes), bump)
 
 
 def mirror(kr=(0.9,) * 3):  # mirror.rs:34-70 (pushed even if black)
@@ -233,17 +257,17 @@ def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.
                                       alpha_x=_alpha(a), alpha_y=_alpha(a))])
 
 
-def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True):  # substrate.rs:62-114
-    kd = np.maximum(np.array(kd, F32), 0); ks = np.maximum(np.array(ks, F32), 0)
-    if not kd.any() and not ks.any():
-        return dict(eta=1.0, lobes=[])
+def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True, bump=None):  # substrate.rs:62-114
+    kd, tkd, any_kd = _col(kd); ks, tks, any_ks = _col(ks)
+    if not any_kd and not any_ks:
+        return _with_bump(dict(eta=1.0, lobes=[]), bump)
     au = tr_roughness_to_alpha(uroughness) if remap else F32(uroughness)
     av = tr_roughness_to_alpha(vroughness) if remap else F32(vroughness)
-    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, alpha_x=_alpha(au), alpha_y=_alpha(av))])
+    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, tex_r=tkd, tex_t=tks, alpha_x=_alpha(au), alpha_y=_alpha(av))]), bump)
 
 
 def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness=0.1, uroughness=None, vroughness=None,
-         opacity=(1.0,) * 3, index=1.5, remap=True):  # uber.rs:114-259
+         opacity=(1.0,) * 3, index=1.5, remap=True, bump=None):  # uber.rs:114-259
     e = F32(index)
     op = np.maximum(np.array(opacity, F32), 0)
     t = np.maximum(F32(1) - op, 0).astype(F32)  # (-op + 1).clamp(0, inf)
@@ -253,23 +277,23 @@ def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=t, eta_a=1.0, eta_b=1.0))
     else:
         eta = float(e)
-    kd = (op * np.maximum(np.array(kd, F32), 0)).astype(F32)
-    if kd.any():
-        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd))
-    ks = (op * np.maximum(np.array(ks, F32), 0)).astype(F32)
-    if ks.any():
+    kd, tkd, any_kd = _col(kd, op)
+    if any_kd:
+        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd, tex_r=tkd))
+    ks, tks, any_ks = _col(ks, op)
+    if any_ks:
         ru = roughness if uroughness is None else uroughness
         rv = roughness if vroughness is None else vroughness
         au = tr_roughness_to_alpha(ru) if remap else F32(ru)
         av = tr_roughness_to_alpha(rv) if remap else F32(rv)
-        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, eta_a=1.0, eta_b=e, alpha_x=_alpha(au), alpha_y=_alpha(av)))
+        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, tex_r=tks, eta_a=1.0, eta_b=e, alpha_x=_alpha(au), alpha_y=_alpha(av)))
     kr = (op * np.maximum(np.array(kr, F32), 0)).astype(F32)
     if kr.any():
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=kr, eta_a=1.0, eta_b=e))
     kt = (op * np.maximum(np.array(kt, F32), 0)).astype(F32)
     if kt.any():
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=kt, eta_a=1.0, eta_b=e))
-    return dict(eta=eta, lobes=lobes)
+    return _with_bump(dict(eta=eta, lobes=lobes), bump)
 
 
 def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.5,) * 3, roughness=0.1, remap=True):  # translucent.rs:64-189
@@ -371,6 +395,95 @@ def build_envmap(texels):
 
 
 # ---------------------------------------------------------------------------------------
+# image textures: what ImageTexture::new + MipMap::new build (imagemap.rs:34-96, mipmap.rs:56-196) — host side
+# ---------------------------------------------------------------------------------------
+def _wrap_index(i, n, wrap):
+    """index + validity mask for the resampling / pyramid texel fetches (mipmap.rs:88-96, 206-232)"""
+    if wrap == abi.WRAP_REPEAT:
+        return np.mod(i, n), np.ones(i.shape, bool)
+    if wrap == abi.WRAP_CLAMP:
+        return np.clip(i, 0, n - 1), np.ones(i.shape, bool)
+    return np.clip(i, 0, n - 1), (i >= 0) & (i < n)  # Black: texels outside contribute nothing while resampling
+
+
+def _lanczos(x, tau=F32(2.0)):  # texture.rs:426-439 in f32
+    x = np.abs(x).astype(F32)
+    xp = (x * F32(math.pi)).astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = (np.sin((xp * tau).astype(F32)).astype(F32) / (xp * tau).astype(F32)).astype(F32)
+        lz = (np.sin(xp).astype(F32) / xp).astype(F32)
+    out = (s * lz).astype(F32)
+    out = np.where(x > F32(1.0), F32(0.0), out)
+    return np.where(x < F32(1e-5), F32(1.0), out).astype(F32)
+
+
+def _resample_weights(old_res, new_res):  # mipmap.rs:298-322
+    i = np.arange(new_res)
+    center = (((i.astype(F32) + F32(0.5)) * F32(old_res)).astype(F32) / F32(new_res)).astype(F32)
+    fw = F32(2.0)
+    first = np.floor(((center - fw).astype(F32) + F32(0.5)).astype(F32)).astype(np.int64)
+    w = np.zeros((new_res, 4), F32)
+    for j in range(4):
+        pos = ((first.astype(F32) + F32(j)).astype(F32) + F32(0.5)).astype(F32)
+        w[:, j] = _lanczos(((pos - center).astype(F32) / fw).astype(F32))
+    tot = (((w[:, 0] + w[:, 1]).astype(F32) + w[:, 2]).astype(F32) + w[:, 3]).astype(F32)
+    inv = (F32(1.0) / tot).astype(F32)
+    return first, (w * inv[:, None]).astype(F32)
+
+
+def _pyramid(img, wrap):  # mipmap.rs:154-185
+    h, w, _ = img.shape
+    n_levels = 1 + int(math.log2(max(w, h)))
+    levels = [img]
+    for _ in range(1, n_levels):
+        p = levels[-1]
+        ph, pw, _ = p.shape
+        sh, sw = max(1, ph // 2), max(1, pw // 2)
+        ti, si = np.meshgrid(np.arange(sh), np.arange(sw), indexing="ij")
+        if wrap == abi.WRAP_REPEAT:
+            tex = lambda a, b: p[np.mod(b, ph), np.mod(a, pw)]  # noqa: E731
+        else:  # Clamp, and Black's clamp-like texel()
+            tex = lambda a, b: p[np.clip(b, 0, ph - 1), np.clip(a, 0, pw - 1)]  # noqa: E731
+        acc = (((tex(2 * si, 2 * ti) + tex(2 * si + 1, 2 * ti)).astype(F32) + tex(2 * si, 2 * ti + 1)).astype(F32) + tex(2 * si + 1, 2 * ti + 1)).astype(F32)
+        levels.append((acc * F32(0.25)).astype(F32))
+    return levels
+
+
+def inverse_gamma(v):  # inverse_gamma_convert_float (spectrum.rs:1865-1871) in f32
+    v = np.asarray(v, F32)
+    lo = (v / F32(12.92)).astype(F32)
+    hi = np.power(((v + F32(0.055)).astype(F32) / F32(1.055)).astype(F32), F32(2.4)).astype(F32)
+    return np.where(v <= F32(0.04045), lo, hi).astype(F32)
+
+
+def build_image(texels, wrap=abi.WRAP_REPEAT, scale=1.0, gamma=False, channels=3):
+    """texels (h, w, 3) f32 in [0, 1] as decoded from the file, row 0 = top (the reference flips rows so that
+    t = 0 is the bottom, imagemap.rs:63-71).  Returns the pyramid dict of rspt_image.  channels=1 keeps y()
+    (float textures, convert_to_float)."""
+    img = np.ascontiguousarray(np.asarray(texels, F32)[::-1])
+    img = ((inverse_gamma(img) if gamma else img) * F32(scale)).astype(F32)
+    if channels == 1:
+        img = ((F32(0.212671) * img[..., 0] + F32(0.715160) * img[..., 1]).astype(F32) + F32(0.072169) * img[..., 2]).astype(F32)[..., None]
+    h, w, c = img.shape
+    pw, ph = 1 << (w - 1).bit_length(), 1 << (h - 1).bit_length()
+    if (pw, ph) != (w, h):  # resample to power-of-two resolution, s then t (mipmap.rs:64-148)
+        first, wt = _resample_weights(w, pw)
+        tmp = np.zeros((h, pw, c), F32)
+        for j in range(4):
+            idx, ok = _wrap_index(first + j, w, wrap)
+            tmp = (tmp + np.where(ok[None, :, None], img[:, idx, :] * wt[None, :, j, None], F32(0))).astype(F32)
+        first, wt = _resample_weights(h, ph)
+        out = np.zeros((ph, pw, c), F32)
+        for j in range(4):
+            idx, ok = _wrap_index(first + j, h, wrap)
+            out = (out + np.where(ok[:, None, None], tmp[idx, :, :] * wt[:, None, j, None], F32(0))).astype(F32)
+        img = np.maximum(out, F32(0))  # Clampable::clamp(0, inf)
+    levels = _pyramid(np.ascontiguousarray(img, F32), wrap)
+    return dict(width=img.shape[1], height=img.shape[0], n_levels=len(levels), channels=c,
+                texels=np.ascontiguousarray(np.concatenate([lv.reshape(-1) for lv in levels]), F32))
+
+
+# ---------------------------------------------------------------------------------------
 # A scene before BVH build: meshes with per-mesh material / emission
 # ---------------------------------------------------------------------------------------
 class SceneBuilder:
@@ -382,6 +495,35 @@ class SceneBuilder:
         self.any_n = self.any_uv = False
         self.delta_lights = []  # point / spot / distant / infinite: appended to Scene.lights after the area lights
         self.envmaps = []
+        self.images, self.textures = [], []
+
+    # ---- textures (api.rs make_texture; src/textures/*.rs) ----
+    def _add_texture(self, **kw):
+        t = np.zeros((), abi.TEXTURE_DT)
+        for k, v in kw.items():
+            t[k] = v
+        self.textures.append(t)
+        return TexRef(len(self.textures) - 1)
+
+    def constant_texture(self, value):
+        v = np.broadcast_to(np.asarray(value, F32), (3,))
+        return self._add_texture(kind=abi.TEX_CONSTANT, value=v)
+
+    def scale_texture(self, t1, t2):
+        return self._add_texture(kind=abi.TEX_SCALE, tex1=t1.index, tex2=t2.index)
+
+    def image_texture(self, texels, mapping="uv", su=1.0, sv=1.0, du=0.0, dv=0.0, v1=(1, 0, 0), v2=(0, 1, 0), trilinear=False,
+                      max_aniso=8.0, wrap="repeat", scale=1.0, gamma=False, channels=3):
+        """Texture "imagemap" (api.rs get_texture / imagemap.rs): texels (h, w, 3) in file order (row 0 = top)."""
+        wm = {"repeat": abi.WRAP_REPEAT, "black": abi.WRAP_BLACK, "clamp": abi.WRAP_CLAMP}[wrap]
+        self.images.append(build_image(texels, wm, scale, gamma, channels))
+        m = np.zeros(8, F32)
+        if mapping == "uv":
+            mk = abi.MAP_UV; m[:4] = (su, sv, du, dv)
+        else:
+            mk = abi.MAP_PLANAR; m[:3] = v1; m[3:6] = v2; m[6:8] = (du, dv)
+        return self._add_texture(kind=abi.TEX_IMAGE, mapping=mk, map=m, image=len(self.images) - 1, trilinear=int(trilinear),
+                                 max_aniso=max_aniso, wrap=wm)
 
     def add_material(self, m):
         self.materials.append(m)
@@ -475,23 +617,29 @@ class SceneBuilder:
         mats = np.zeros(len(self.materials), abi.MATERIAL_DT)
         bx = []
         for i, m in enumerate(self.materials):
-            mats[i] = (m["eta"], len(bx), len(m["lobes"]), 0)
+            mats[i] = (m["eta"], len(bx), len(m["lobes"]), m.get("bump", -1) + 1)
             bx.extend(m["lobes"])
         bxdfs = np.array(bx, abi.BXDF_DT) if bx else np.zeros(0, abi.BXDF_DT)
         meshes = np.array(self.meshes, np.uint32).view(abi.MESH_DT).reshape(-1)
         return Scene(nodes=nodes, prims=prims, meshes=meshes, P=P,
                      N=np.ascontiguousarray(np.concatenate(self.N), F32) if self.any_n else None,
                      UV=np.ascontiguousarray(np.concatenate(self.UV), F32) if self.any_uv else None,
-                     materials=mats, bxdfs=bxdfs, lights=lights, envmaps=self.envmaps)
+                     materials=mats, bxdfs=bxdfs, lights=lights, envmaps=self.envmaps,
+                     textures=np.array(self.textures, abi.TEXTURE_DT) if self.textures else None, images=self.images)
 
 
 class Scene:
     """Flattened scene arrays + the ctypes rspt_scene_desc pointing at them."""
 
-    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=()):
+    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=(), textures=None, images=()):
         self.nodes, self.prims, self.meshes, self.P, self.N, self.UV, self.S = nodes, prims, meshes, P, N, UV, S
         self.materials, self.bxdfs, self.lights = materials, bxdfs, lights
         self.envmaps = list(envmaps)
+        self.textures = textures if textures is not None else np.zeros(0, abi.TEXTURE_DT)
+        self.images = list(images)
+        self._img_structs = (abi.Image * max(len(self.images), 1))()
+        for i, im in enumerate(self.images):
+            self._img_structs[i] = abi.Image(im["width"], im["height"], im["n_levels"], im["channels"], im["texels"].ctypes.data)
         p = lambda a: a.ctypes.data if a is not None and a.size else None  # noqa: E731
         self._env_structs = (abi.EnvMap * max(len(self.envmaps), 1))()
         for i, e in enumerate(self.envmaps):
@@ -499,7 +647,9 @@ class Scene:
         self.desc = abi.SceneDesc(p(nodes), len(nodes), p(prims), len(prims), p(meshes), len(meshes),
                                   p(P), p(N), p(S), p(UV), len(P),
                                   p(materials), len(materials), p(bxdfs), len(bxdfs), p(lights), len(lights),
-                                  C.addressof(self._env_structs) if self.envmaps else None, len(self.envmaps))
+                                  C.addressof(self._env_structs) if self.envmaps else None, len(self.envmaps),
+                                  p(self.textures), len(self.textures),
+                                  C.addressof(self._img_structs) if self.images else None, len(self.images))
 
     @property
     def n_tris(self):

@@ -265,3 +265,56 @@ def test_mix_material(gpu, oracle):
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert film_rmse(film, ref["film"]) < 2e-5
     assert (li == ref["li"]).all(axis=2).mean() > 0.6
+
+
+@pytest.mark.parametrize("trilinear,wrap,bump", [(False, "repeat", True), (False, "repeat", False), (True, "repeat", True), (False, "clamp", True), (False, "black", False)])
+def test_textured_materials_match_oracle(gpu, oracle, trilinear, wrap, bump):
+    """image textures (EWA / trilinear MIP lookups, UV + planar mappings, scale textures), camera-ray
+    differentials, bump mapping, lobes dropped where the texture is black.  The first hit (differentials, EWA) agrees
+    to 2e-6 with 92 % of samples bit-identical.  At later hits the last-ulp sin/cos differences of the sampled
+    directions move the hit point by an ulp; a high-contrast texture turns that into ~1e-5 (bilinear weight x texel
+    contrast), and Material::bump's finite differences over du = 0.0005 (material.rs:183-189) amplify it another
+    2000x into the shading normal — hence the looser film bar with bump maps (north-star bound: 1e-3)."""
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    sc = textured_room(gpu.bvh_build, trilinear=trilinear, wrap=wrap, bump=bump)
+    rd = scenes.make_render_desc(96, 72, 16, TEXTURED_LOOK_AT, 45, max_depth=4)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    same = (li == ref["li"]).all(axis=2)
+    assert same.mean() > 0.6
+    assert np.abs(li - ref["li"]).mean() < 1e-5
+    assert film_rmse(film, ref["film"]) < (1e-4 if bump else 2e-5)
+    assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
+
+
+def test_textures_change_the_image_and_lens_differentials(gpu, oracle):
+    """thin-lens camera differentials (perspective.rs:245-271) + Halton sampler on the textured room; and the
+    textures must matter: the same room with constant colours renders a different film"""
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    sc = textured_room(gpu.bvh_build, bump=False, planar=False)
+    rd = scenes.make_render_desc(64, 48, 8, TEXTURED_LOOK_AT, 45, max_depth=3, lens_radius=0.05, focal_distance=6.0, sampler="halton")
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert film_rmse(film, ref["film"]) < 2e-5
+    assert np.abs(li - ref["li"]).mean() < 1e-5
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_quad([(-5, 0, -5), (5, 0, -5), (5, 0, 5), (-5, 0, 5)], m)
+    plain = sb.finish(gpu.bvh_build)
+    assert plain.desc.n_textures == 0 and sc.desc.n_textures > 0
+
+
+def test_texture_validation(gpu):
+    """bad texture tables are rejected on the host"""
+    import ctypes as C
+    from tests.util import textured_room
+    L = gpu.lib()
+    for breaker in ("image", "child", "slots"):
+        sc = textured_room(gpu.bvh_build)
+        if breaker == "image":
+            sc.textures["image"][0] = 99
+        elif breaker == "child":
+            k = int(np.nonzero(sc.textures["kind"] == abi.TEX_SCALE)[0][0]); sc.textures["tex1"][k] = 1000
+        else:
+            sc.bxdfs["tex_r"][0] = 77
+        h = C.c_void_p()
+        assert L.rspt_scene_create(C.addressof(sc.desc), C.addressof(h)) == abi.E_INVALID

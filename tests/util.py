@@ -83,3 +83,52 @@ def sky_scene(builder, kind="constant", with_area=False):
 
 
 SKY_LOOK_AT = ((0, 2.5, -7), (0, 0.6, 0), (0, 1, 0))
+
+
+def texture_image(h=24, w=40, seed=11):
+    """a non-power-of-two test image (so MipMap::new's Lanczos resampling runs): checker + gradient + noise"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 3), np.float32)
+    img[..., 0] = ((xx // 5 + yy // 4) % 2) * 0.8 + 0.1
+    img[..., 1] = xx / float(w)
+    img[..., 2] = 0.3 + 0.4 * rng.random((h, w))
+    return img.astype(np.float32)
+
+
+def textured_room(builder, trilinear=False, wrap="repeat", bump=True, planar=True, lens=False):
+    """floor / back wall / three slabs carrying image textures: matte Kd through a UV mapping with
+    scale + offset, plastic Kd + Ks (two slots), substrate Kd x constant (scale texture), an uber slab whose Kd
+    image is black in places (lobe dropped per hit) under a planar mapping, bump maps with and without
+    per-vertex normals; seen by camera rays (EWA / trilinear footprints) and by bounce rays (no differentials)"""
+    sb = scenes.SceneBuilder()
+    img = texture_image()
+    kd_floor = sb.image_texture(img, su=4.0, sv=3.0, du=0.15, dv=0.4, trilinear=trilinear, wrap=wrap)
+    kd_wall = sb.image_texture(img[::-1, ::-1].copy(), su=1.0, sv=1.0, trilinear=trilinear, wrap=wrap, gamma=True)
+    ks_tex = sb.image_texture(img[:, ::-1].copy(), su=2.0, sv=2.0, trilinear=True, wrap=wrap, scale=0.6)
+    tint = sb.constant_texture((0.9, 0.5, 0.3))
+    kd_scaled = sb.scale_texture(kd_wall, tint)
+    holes = img.copy(); holes[8:16, 10:30] = 0.0
+    if planar:
+        kd_holes = sb.image_texture(holes, mapping="planar", v1=(0.25, 0, 0), v2=(0, 0.3, 0.05), du=0.2, dv=0.1, trilinear=trilinear, wrap="clamp")
+    else:
+        kd_holes = sb.image_texture(holes, trilinear=trilinear, wrap="clamp")
+    height = sb.image_texture(img, channels=1, scale=0.08, su=3.0, sv=3.0, trilinear=True) if bump else None
+    floor = sb.add_material(scenes.matte(kd_floor, bump=height))
+    wall = sb.add_material(scenes.matte(kd_wall, sigma=25.0))
+    slab1 = sb.add_material(scenes.plastic(kd_floor, ks_tex, 0.12, bump=height))
+    slab2 = sb.add_material(scenes.substrate(kd_scaled, (0.25, 0.25, 0.25), 0.08, 0.15))
+    slab3 = sb.add_material(scenes.uber(kd_holes, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), roughness=0.2))
+    white = sb.add_material(scenes.matte((0.7, 0.7, 0.7)))
+    uvq = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    up = [[0, 1, 0]] * 4
+    sb.add_quad([(-5, 0, -5), (5, 0, -5), (5, 0, 5), (-5, 0, 5)], floor, UV=uvq, N=up)                       # smooth normals: dndu path of bump
+    sb.add_quad([(-5, 0, 5), (5, 0, 5), (5, 6, 5), (-5, 6, 5)], wall, UV=uvq)
+    sb.add_quad([(-4, 0.4, 1.5), (-1.8, 0.4, 1.5), (-1.8, 3.0, 2.4), (-4, 3.0, 2.4)], slab1, UV=[[0, 0], [2, 0], [2, 2], [0, 2]])
+    sb.add_quad([(-1.1, 0.4, 1.8), (1.1, 0.4, 1.8), (1.1, 3.0, 2.7), (-1.1, 3.0, 2.7)], slab2, UV=uvq)
+    sb.add_quad([(1.8, 0.4, 1.5), (4, 0.4, 1.5), (4, 3.0, 2.4), (1.8, 3.0, 2.4)], slab3)                       # no UVs: default (0,0),(1,0),(1,1)
+    sb.add_quad([(-1.5, 5.9, -1.5), (1.5, 5.9, -1.5), (1.5, 5.9, 1.5), (-1.5, 5.9, 1.5)], white, emit=(12, 12, 12))
+    return sb.finish(builder)
+
+
+TEXTURED_LOOK_AT = ((0, 2.6, -4.6), (0, 1.6, 2), (0, 1, 0))
