@@ -27,7 +27,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue"])
+    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex"])
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -50,9 +50,10 @@ def build_workload(args, lib, scenes, shard):
     else:
         xres, spp = args.res or 1920, args.spp or 1024
         yres = xres * 9 // 16
-        sc = scenes.statue_standin(lib.bvh_build)
+        tex = args.workload == "statue_tex"  # image-textured Kd + bump map + textured ground
+        sc = scenes.statue_standin(lib.bvh_build, textured=tex)
         mk = lambda s, sh: scenes.statue_render_desc(xres=xres, yres=yres, spp=s, shard=sh)  # noqa: E731
-        name = "statue stand-in (4.3 M triangles), path depth 5, sobol %d spp, %dx%d" % (spp, xres, yres)
+        name = "statue stand-in (4.3 M triangles%s), path depth 5, sobol %d spp, %dx%d" % (", image-textured + bump-mapped" if tex else "", spp, xres, yres)
     return sc, mk, spp, name
 
 

@@ -86,6 +86,47 @@ void orc_bsdf_sample_f(const rspt_material* m, const rspt_bxdf* all, const float
     wi_out[0] = wi.x; wi_out[1] = wi.y; wi_out[2] = wi.z; *pdf_out = pdf; *sampled_type = st;
 }
 
+// ---- texture hooks ----
+// surf: p[3], uv[2], dudx, dvdx, dudy, dvdy, dpdx[3], dpdy[3]
+static Interaction surf_interaction(const float* surf) {
+    Interaction it = unit_frame();
+    it.p = V3{surf[0], surf[1], surf[2]}; it.uv = P2{surf[3], surf[4]};
+    it.dudx = surf[5]; it.dvdx = surf[6]; it.dudy = surf[7]; it.dvdy = surf[8];
+    it.dpdx = V3{surf[9], surf[10], surf[11]}; it.dpdy = V3{surf[12], surf[13], surf[14]};
+    return it;
+}
+void orc_tex_eval(const rspt_scene_desc* d, uint32_t ti, const float* surf, float out[3]) {
+    Scene sc{*d};
+    Spec v = tex_eval(sc, ti, surf_interaction(surf));
+    out[0] = v.c[0]; out[1] = v.c[1]; out[2] = v.c[2];
+}
+// camera ray with its (scaled) differentials: out = o[3], d[3], rx_o[3], rx_d[3], ry_o[3], ry_d[3]
+void orc_camera_ray_diff(const rspt_render_desc* rd, const float cs[5], float out[18]) {
+    Ray r = camera_ray(*rd, P2{cs[0], cs[1]}, cs[2], P2{cs[3], cs[4]});
+    r.scale_differentials(1.0f / std::sqrt((Float)rd->spp));
+    const V3 v[6] = {r.o, r.d, r.rx_o, r.rx_d, r.ry_o, r.ry_d};
+    for (int i = 0; i < 6; i++) { out[3 * i] = v[i].x; out[3 * i + 1] = v[i].y; out[3 * i + 2] = v[i].z; }
+}
+// differentials of a hit: in = p[3], n[3], dpdu[3], dpdv[3], then the 18 floats of orc_camera_ray_diff; out = dudx, dvdx, dudy, dvdy, dpdx[3], dpdy[3]
+void orc_compute_differentials(const float* in, float out[10]) {
+    Interaction it = unit_frame();
+    it.p = V3{in[0], in[1], in[2]}; it.n = V3{in[3], in[4], in[5]}; it.dpdu = V3{in[6], in[7], in[8]}; it.dpdv = V3{in[9], in[10], in[11]};
+    const float* r = in + 12;
+    Ray ray{V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, INF, 0.0f};
+    ray.has_diff = true;
+    ray.rx_o = V3{r[6], r[7], r[8]}; ray.rx_d = V3{r[9], r[10], r[11]}; ray.ry_o = V3{r[12], r[13], r[14]}; ray.ry_d = V3{r[15], r[16], r[17]};
+    compute_differentials(&it, ray);
+    out[0] = it.dudx; out[1] = it.dvdx; out[2] = it.dudy; out[3] = it.dvdy;
+    out[4] = it.dpdx.x; out[5] = it.dpdx.y; out[6] = it.dpdx.z; out[7] = it.dpdy.x; out[8] = it.dpdy.y; out[9] = it.dpdy.z;
+}
+// Material::bump in the unit frame (n = +z, dpdu = +x, dpdv = +y): out = shading n[3], dpdu[3]
+void orc_bump(const rspt_scene_desc* d, uint32_t ti, const float* surf, float out[6]) {
+    Scene sc{*d};
+    Interaction it = surf_interaction(surf);
+    bump(sc, ti, &it);
+    out[0] = it.sh_n.x; out[1] = it.sh_n.y; out[2] = it.sh_n.z; out[3] = it.sh_dpdu.x; out[4] = it.sh_dpdu.y; out[5] = it.sh_dpdu.z;
+}
+
 // ---- BVH build (BVHAccel::new over triangles given by global vertex indices) ----
 // tri_idx: n*3 vertex indices; ordered_out: n entries (input index of the primitive at each
 // BVH-ordered slot).  Returns node count, or -(needed) if nodes_cap is too small.

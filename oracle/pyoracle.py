@@ -53,8 +53,28 @@ def lib():
         L.orc_pcg32_next.restype = C.c_uint32; L.orc_pcg32_next.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_spatial_voxel.restype = None
         L.orc_spatial_voxel.argtypes = [C.c_void_p] * 6
+        L.orc_tex_eval.restype = None; L.orc_tex_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_camera_ray_diff.restype = None; L.orc_camera_ray_diff.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_compute_differentials.restype = None; L.orc_compute_differentials.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_bump.restype = None; L.orc_bump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def tex_eval(scene, tex, uv=(0.0, 0.0), p=(0.0, 0.0, 0.0), duv=(0.0, 0.0, 0.0, 0.0), dpdx=(0.0, 0.0, 0.0), dpdy=(0.0, 0.0, 0.0)):
+    """Texture::evaluate of texture `tex` (TexRef or index) at a SurfaceInteraction given by uv, p and its differentials
+    (duv = dudx, dvdx, dudy, dvdy)"""
+    surf = np.array(list(p) + list(uv) + list(duv) + list(dpdx) + list(dpdy), np.float32)
+    out = np.zeros(3, np.float32)
+    lib().orc_tex_eval(C.addressof(scene.desc), int(getattr(tex, "index", tex)), surf.ctypes.data, out.ctypes.data)
+    return out
+
+
+def bump(scene, tex, uv=(0.0, 0.0), p=(0.0, 0.0, 0.0), duv=(0.0, 0.0, 0.0, 0.0)):
+    surf = np.array(list(p) + list(uv) + list(duv) + [0.0] * 6, np.float32)
+    out = np.zeros(6, np.float32)
+    lib().orc_bump(C.addressof(scene.desc), int(getattr(tex, "index", tex)), surf.ctypes.data, out.ctypes.data)
+    return out[:3], out[3:]
 
 
 def bvh_build(P, tri, max_prims_in_node=4):

@@ -847,10 +847,12 @@ def _value_noise(p, seed, octaves=5):
     return out
 
 
-def statue_standin(bvh_builder, grid=1466, seed=0x6A4E):
+def statue_standin(bvh_builder, grid=1466, seed=0x6A4E, textured=False):
     """C3 stand-in for the off-tree Ganesha scene: grid x grid lat-long sphere
     (2*grid*(grid-1) ~ 4.30 M triangles at 1466) displaced by 5-octave value noise, smooth normals,
-    plastic; matte ground; three quad lights.  DECLARED STAND-IN: not the real asset."""
+    plastic; matte ground; three quad lights.  DECLARED STAND-IN: not the real asset.
+    textured=True (the "textured BSDFs" axis of C4): lat-long UVs, a 1024x512 Kd image (EWA),
+    a bump map on the body and a checker image on the ground."""
     nu, nv = grid, grid
     th = np.linspace(0, np.pi, nv + 1)[:, None]; ph = np.linspace(0, 2 * np.pi, nu + 1)[None, :]
     d = np.stack([np.sin(th) * np.cos(ph), np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
@@ -873,10 +875,26 @@ def statue_standin(bvh_builder, grid=1466, seed=0x6A4E):
     keep = np.linalg.norm(np.cross(t1 - t0, t2 - t0), axis=1) > 0
     idx = idx[keep]
     sb = SceneBuilder()
-    body = sb.add_material(plastic((0.4, 0.4, 0.4), (0.1, 0.1, 0.1), 0.1))
-    ground = sb.add_material(matte((0.5, 0.5, 0.5)))
-    sb.add_mesh(Pf, idx, body, N=N.astype(F32))
-    sb.add_quad([(-6, -1.3, -6), (-6, -1.3, 6), (6, -1.3, 6), (6, -1.3, -6)], ground)
+    UV = None
+    if textured:
+        th2 = np.linspace(0, np.pi, 512)[:, None]; ph2 = np.linspace(0, 2 * np.pi, 1024, endpoint=False)[None, :]
+        d2 = np.stack([np.sin(th2) * np.cos(ph2), np.cos(th2) * np.ones_like(ph2), np.sin(th2) * np.sin(ph2)], -1).reshape(-1, 3)
+        n1 = _value_noise(d2 * 3.0, seed + 1).reshape(512, 1024); n2 = _value_noise(d2 * 9.0, seed + 2).reshape(512, 1024)
+        veins = (0.5 + 0.5 * np.sin(12.0 * n1 + 4.0 * n2)).astype(F32)
+        img = np.stack([0.25 + 0.55 * veins, 0.22 + 0.45 * veins, 0.2 + 0.35 * veins], -1).astype(F32)
+        kd = sb.image_texture(img)
+        height = sb.image_texture(np.repeat((0.5 + 0.5 * n2).astype(F32)[..., None], 3, 2), channels=1, scale=0.01, trilinear=True)
+        yy, xx = np.mgrid[0:256, 0:256]
+        chk = np.where(((xx // 32 + yy // 32) % 2)[..., None] > 0, F32(0.65), F32(0.25)) * np.ones((1, 1, 3), F32)
+        body = sb.add_material(plastic(kd, (0.1, 0.1, 0.1), 0.1, bump=height))
+        ground = sb.add_material(matte(sb.image_texture(chk.astype(F32), su=6.0, sv=6.0)))
+        vj = (np.arange((nv + 1) * (nu + 1)) % (nu + 1)) / float(nu); vi = (np.arange((nv + 1) * (nu + 1)) // (nu + 1)) / float(nv)
+        UV = np.stack([vj, 1.0 - vi], 1).astype(F32)
+    else:
+        body = sb.add_material(plastic((0.4, 0.4, 0.4), (0.1, 0.1, 0.1), 0.1))
+        ground = sb.add_material(matte((0.5, 0.5, 0.5)))
+    sb.add_mesh(Pf, idx, body, N=N.astype(F32), UV=UV)
+    sb.add_quad([(-6, -1.3, -6), (-6, -1.3, 6), (6, -1.3, 6), (6, -1.3, -6)], ground, UV=[[0, 0], [0, 1], [1, 1], [1, 0]] if textured else None)
     for (cx, cz, L) in ((-2.5, -2.0, (30, 28, 24)), (2.5, -2.0, (20, 24, 30)), (0.0, 2.5, (25, 25, 25))):
         sb.add_quad([(cx + 0.5, 3.0, cz - 0.5), (cx + 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz - 0.5)], ground, emit=L)
     return sb.finish(bvh_builder)

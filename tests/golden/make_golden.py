@@ -32,6 +32,12 @@ def main():
         rays["t_max"] = np.inf
         np.savez_compressed(os.path.join(HERE, "trace_%s.npz" % name), rays=rays, closest=pyoracle.trace(scene, rays),
                             any=pyoracle.trace(scene, rays, any_hit=True), nodes=scene.nodes, prims=scene.prims)
+    # 3. textured room: EWA + trilinear lookups, planar mapping, scale texture, bump, dropped lobes
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    sc = textured_room(pyoracle.bvh_build)
+    rd = scenes.make_render_desc(48, 36, 8, TEXTURED_LOOK_AT, 45, max_depth=3)
+    r = pyoracle.render(sc, rd, threads=1, want_li=True)
+    np.savez_compressed(os.path.join(HERE, "textured_room_48x36x8.npz"), film=r["film"], li=r["li"])
 
 
 if __name__ == "__main__":

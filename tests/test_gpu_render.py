@@ -318,3 +318,20 @@ def test_texture_validation(gpu):
             sc.bxdfs["tex_r"][0] = 77
         h = C.c_void_p()
         assert L.rspt_scene_create(C.addressof(sc.desc), C.addressof(h)) == abi.E_INVALID
+
+
+def test_golden_textured_room(gpu):
+    """committed oracle output for the textured room (tests/golden/make_golden.py)"""
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    g = np.load(os.path.join(GOLDEN, "textured_room_48x36x8.npz"))
+    sc = textured_room(gpu.bvh_build)
+    rd = scenes.make_render_desc(48, 36, 8, TEXTURED_LOOK_AT, 45, max_depth=3)
+    ds = gpu.DeviceScene(sc)
+    try:
+        film, _ = gpu.render(ds, rd)
+        li, _ = gpu.render_samples(ds, rd)
+    finally:
+        ds.close()
+    assert np.array_equal(film[:, 3], g["film"][:, 3])
+    assert film_rmse(film, g["film"]) < 1e-4
+    assert (li == g["li"]).all(axis=2).mean() > 0.6

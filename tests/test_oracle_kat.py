@@ -522,3 +522,15 @@ def test_mix_material_scales_lobes(oracle):
     ms = scenes.mix(scenes.mirror((1, 1, 1)), scenes.matte((0.5, 0.5, 0.5)), (0.3, 0.3, 0.3))
     f, wi, pdf, st = _sample(oracle, ms, (0.3, 0.1, 0.95), (0.1, 0.5))  # u.x < 0.5 picks lobe 0 = mirror
     assert st & 16 and abs(pdf - 0.5) < 1e-7 and np.allclose(f * abs(wi[2]), 0.3, rtol=1e-5)
+
+
+def test_golden_textured_room_is_reproducible(oracle):
+    """the committed textured-room fixture is what the oracle produces today (guards the fixture against drift)"""
+    import os
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "textured_room_48x36x8.npz"))
+    sc = textured_room(oracle.bvh_build)
+    rd = scenes.make_render_desc(48, 36, 8, TEXTURED_LOOK_AT, 45, max_depth=3)
+    r = oracle.render(sc, rd, threads=4, want_li=True)
+    assert np.array_equal(r["film"][:, 3], g["film"][:, 3])
+    assert np.array_equal(r["li"], g["li"])
