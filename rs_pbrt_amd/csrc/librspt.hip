@@ -44,6 +44,7 @@ struct Ctx {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // shadow-ray trace launches run beside the closest-hit launches (RSPT_TRACE_STREAMS)
     // path state
     size_t cap = 0;
     PathBuf pb{};
@@ -181,7 +182,7 @@ int ensure_spill(size_t threads) {
     if (g.spill_threads >= threads) return RSPT_OK;
     if (g.spill) (void)hipFree(g.spill);
     g.spill = nullptr; g.spill_threads = 0;
-    int rc = dev_alloc(&g.spill, threads * RSPT_W4_SPILL);
+    int rc = dev_alloc(&g.spill, 2 * threads * RSPT_W4_SPILL);  // one set of rows per trace lane
     if (rc) return rc;
     g.spill_threads = threads;
     return RSPT_OK;
@@ -278,8 +279,9 @@ int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
 
 // kernel choice: the persistent-wave kernel (trace_wide.h) unless RSPT_TRACE_KERNEL=0 or the
 // reference-order node / triangle counters are wanted (only k_trace counts them)
+// lane 0 = the library's main stream; lane 1 = the second stream with its own overflow list and spill rows
 template <bool ANY, int OUT_MODE>
-void launch_trace(bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
+void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                   const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
     const SceneDev& sc = s->dev;
     // RSPT_TRACE_KERNEL: 0 = k_trace (reference-order single-ray loop), 1 = k_trace_pw (persistent waves, two boxes
@@ -287,22 +289,25 @@ void launch_trace(bool count, uint32_t grid, const rspt_scene_s* s, const uint32
     // (A quad-per-ray variant with one coalesced 64-byte fetch per step was measured 35 % slower: the
     //  replicated control flow made it VALU-bound with 16 rays per wave)
     const size_t which = env_size("RSPT_TRACE_KERNEL", 2);
+    hipStream_t stream = lane ? g.stream2 : g.stream;
+    uint32_t* ovf = g.ovf + (lane ? 2 * g.ovf_cap / 3 : 0);
+    uint2* spill = g.spill + (lane ? g.spill_threads * RSPT_W4_SPILL : 0);
     if (!count && which != 0) {
         const uint32_t pgrid = pw_grid();
         uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
         if (which == 2)
-            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, g.ovf, g.spill, (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL), (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL), (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
         else
-        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, g.stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, g.ovf,
+        hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
-        hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, n_overflow, g.ovf, ra, rb, oa, ob, occ, hits);
+        hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits);
         return;
     }
     if (count)
-        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
+        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
     else
-        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, g.stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
+        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
 }
 
 uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PER_CU", 5)); }
@@ -462,7 +467,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1)))) { if (li_dev) (void)hipFree(li_dev); return rc; }
     const uint32_t nominal_iters = d->max_depth + 1;
     const uint32_t max_iters = s->has_null_material ? nominal_iters + 64 : nominal_iters;
-    if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(2 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
+    if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(3 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
         (s->has_textures && (rc = ensure_tex_rows()))) { if (li_dev) (void)hipFree(li_dev); return rc; }
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
@@ -477,6 +482,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const uint32_t tgrid = trace_grid();
     const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", 4));
     size_t n_ev = 0;
+    const bool two_streams = env_size("RSPT_TRACE_STREAMS", 2) >= 2 && !counters;
+    hipEvent_t ev_fork = get_event(n_ev++), ev_join = get_event(n_ev++);
     uint64_t trace_launches = 0;
     hipEvent_t ev_k0 = get_event(n_ev++), ev_k1 = get_event(n_ev++);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
@@ -495,8 +502,18 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 const int par = it & 1;
                 hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);
                 HIP_TRY(hipEventRecord(e0, g.stream));
-                launch_trace<false, 0>(counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                if (it > 0) launch_trace<true, 0>(counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                // the shadow-ray launch does not depend on the closest-hit launch: on a second stream its tail (a few
+                // long rays on an otherwise idle chip) overlaps the other launch
+                const int any_lane = (it > 0 && two_streams) ? 1 : 0;
+                if (any_lane) {
+                    HIP_TRY(hipEventRecord(ev_fork, g.stream));
+                    HIP_TRY(hipStreamWaitEvent(g.stream2, ev_fork, 0));
+                    launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                    HIP_TRY(hipEventRecord(ev_join, g.stream2));
+                }
+                launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
+                else if (it > 0) launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
                 HIP_TRY(hipEventRecord(e1, g.stream));
                 trace_ev.push_back({e0, e1});
                 trace_launches += it > 0 ? 2 : 1;
@@ -577,6 +594,7 @@ int rspt_init(int32_t device) {
         return fail(RSPT_E_NODEVICE, "device %d is %s; librspt is built for gfx950 only", device, prop.gcnArchName);
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
     g.device = device;
     g.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g.inited = true;
@@ -593,6 +611,7 @@ void rspt_shutdown(void) {
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(g.stream);
+    (void)hipStreamDestroy(g.stream2);
     g = Ctx{};
 }
 
@@ -940,8 +959,8 @@ int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* ou
     uint32_t* cursor = &g.cnt[0].cursor_closest;
     for (int r = 0; r < repeat && n; r++) {
         HIP_TRY(hipMemsetAsync(&g.cnt[0], 0, sizeof(QueueCounts), g.stream));
-        if (any_hit) launch_trace<true, 1>(counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
-        else launch_trace<false, 1>(counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
+        if (any_hit) launch_trace<true, 1>(0, counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
+        else launch_trace<false, 1>(0, counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
     }
     HIP_TRY(hipEventRecord(e1, g.stream));
     HIP_TRY(hipGetLastError());
