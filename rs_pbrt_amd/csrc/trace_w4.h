@@ -38,7 +38,14 @@ struct Wide4Node {      // 128 B, 128-byte aligned
 #ifndef RSPT_W4_LDS
 #define RSPT_W4_LDS 16       // stack entries per lane (8 B each) kept in LDS: 32 KB per workgroup
 #endif
-#define RSPT_W4_SPILL 48     // further entries per lane in a global spill buffer (spill_rows <= this); beyond that k_trace_fixup takes over
+#ifndef RSPT_W4_POP_TRIES
+#define RSPT_W4_POP_TRIES 1  // stack entries a lane may discard (t_min >= t_max) in one iteration before it gives up the slot
+#endif
+#ifndef RSPT_W4_STEPS
+#define RSPT_W4_STEPS 2      // node steps per outer iteration (refill / leaf-phase checks in between); measured on C2 / C3:
+                             // (tries, steps) = (1,1) 334.5 / 1059, (3,1) 326.9 / 1041, (1,2) 338.5 / 1073, (3,2) 333.7 / 1049 Msamples/s
+#endif
+#define RSPT_W4_SPILL 48    // further entries per lane in a global spill buffer (spill_rows <= this); beyond that k_trace_fixup takes over
 
 // box_pair_hit (trace_wide.h) that also returns the entry distances
 RDEV void box_pair_hit_m(float4 q0, float4 q1, float4 q2, float ox, float oy, float oz, float ix, float iy, float iz, float ray_tmax,
@@ -181,12 +188,18 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
         }
 
         // ---- node phase: one traversal step for every lane that is not parked at a leaf ----
+#pragma unroll 1
+        for (int step = 0; step < RSPT_W4_STEPS; step++)
         if (active && leaf == RSPT_NONE) {
             uint32_t ridx = cur;
             if (ridx == RSPT_NONE) {
-                if (sp == 0) {
-                    finish();
-                } else {
+                // pop; entries that a closer hit has meanwhile culled are skipped at once (a few per iteration)
+#pragma unroll 1
+                for (int tries = 0; tries < RSPT_W4_POP_TRIES; tries++) {
+                    if (sp == 0) {
+                        finish();
+                        break;
+                    }
                     sp--;
                     // two separate accesses (never one pointer select: that becomes a flat load with full waitcnt drains)
                     uint2 e = my[(sp < RSPT_W4_LDS ? sp : RSPT_W4_LDS - 1u) * RSPT_PW_BLOCK];
@@ -194,6 +207,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                     if (__uint_as_float(e.y) < t_max) {  // the reference's box test at this later moment (bvh.rs:424)
                         if (e.x & RSPT_REF_LEAF) leaf = e.x;
                         else ridx = e.x;
+                        break;
                     }
                 }
             }
