@@ -67,3 +67,9 @@ def test_integrator_mirror_defaults_and_desc():
     assert integrator.PathIntegrator(camera=cam, light_sample_strategy="bogus").light_sample_strategy == "spatial"
     integ2 = integrator.PathIntegrator(8, cam, None, None, 0.5, "power")
     assert integ2._desc().max_depth == 8 and integ2._desc().light_strategy == abi.LIGHTS_POWER and abs(integ2._desc().rr_threshold - 0.5) < 1e-7
+
+
+def test_graft_entry_build_runs():
+    """the driver's build check: compiles (no-op when up to date), loads the library, resolves every export"""
+    import __graft_entry__ as g
+    g.build()
