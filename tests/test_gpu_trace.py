@@ -187,3 +187,77 @@ def test_deep_bvh_stack_overflow_fixup(gpu, oracle):
     finally:
         os.environ.pop("RSPT_TRACE_KERNEL", None); os.environ.pop("RSPT_W4_SPILL_ROWS", None)
         ds.close()
+
+
+def _centroid_clusters(cluster, seed):
+    """`cluster` triangles around each of 9 centres whose bounding boxes share the centre bit-exactly (vertices
+    c + d, c - d, c + e with e inside the box, all coordinates short dyadic fractions)"""
+    rng = np.random.default_rng(seed)
+    centres = [(0, 0, 0)] + [(x, y, z) for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)]
+    tris = []
+    for c in np.array(centres, np.float32):
+        for _ in range(cluster):
+            d = rng.integers(-24, 25, 3).astype(np.float32) / np.float32(64)
+            d[d == 0] = np.float32(1 / 64)
+            e = np.abs(d) * np.float32(0.25) * rng.choice([-1, 1], 3).astype(np.float32)
+            tris.append(np.stack([c + d, c - d, c + e]))
+    return np.array(tris, np.float32)
+
+
+@pytest.mark.parametrize("cluster", [17, 40, 200])
+def test_large_leaves(gpu, oracle, cluster):
+    """triangles whose bounds share one centroid cannot be split (bvh.rs:218-229: degenerate centroid bounds -> leaf),
+    so the builder emits leaves with `cluster` primitives whatever max_prims_in_node says; more than 15 do not fit
+    the four-box kernel's packed leaf reference and go through its side table.  Every kernel must agree with the
+    oracle, including which candidate inside a leaf wins (leaf order)."""
+    import os
+    P = _centroid_clusters(cluster, 90 + cluster)
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_mesh(P.reshape(-1, 3), np.arange(3 * len(P)).reshape(-1, 3), m)
+    big = sb.finish(gpu.bvh_build, max_prims_in_node=4)
+    assert big.nodes["n_prims"].max() == cluster
+    rays = random_rays(60000, 41, -1.4, 1.4)
+    rays["d"][:30000] = -rays["o"][:30000] + rng_targets(30000)  # half of them aimed at the clusters
+    rays["d"] /= np.linalg.norm(rays["d"], axis=1)[:, None]
+    ds = gpu.DeviceScene(big)
+    try:
+        for kernel in ("2", "1", "0"):
+            os.environ["RSPT_TRACE_KERNEL"] = kernel
+            for any_hit in (False, True):
+                ref = oracle.trace(big, rays, any_hit=any_hit)
+                assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == ref.tobytes()
+        assert (ref["prim"] == 0).sum() > 3000
+    finally:
+        os.environ.pop("RSPT_TRACE_KERNEL", None)
+        ds.close()
+
+
+def rng_targets(n):
+    rng = np.random.default_rng(5)
+    centres = np.array([(0, 0, 0)] + [(x, y, z) for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32)
+    return (centres[rng.integers(0, 9, n)] + rng.normal(size=(n, 3)) * 0.1).astype(np.float32)
+
+
+def test_single_triangle_and_two_triangle_scenes(gpu, oracle):
+    """the root is a leaf (one node) / the root's children are both leaves (one four-box record with two empty slots)"""
+    for n in (1, 2):
+        sb = scenes.SceneBuilder()
+        m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+        P = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0], [2, -1, 1], [4, -1, 1], [3, 1, 1]], np.float32)[: 3 * n]
+        sb.add_mesh(P, np.arange(3 * n).reshape(-1, 3), m)
+        sc = sb.finish(gpu.bvh_build, max_prims_in_node=1)
+        assert len(sc.nodes) == (1 if n == 1 else 3)
+        rays = random_rays(20000, 42 + n, -2, 4)
+        rays["o"][:, 2] = -3.0
+        rays["d"] = np.abs(rays["d"]) * np.array([0.3, 0.3, 1.0], np.float32)
+        rays["d"] /= np.linalg.norm(rays["d"], axis=1)[:, None]
+        rays["o"][::2, :2] -= 1.5
+        ds = gpu.DeviceScene(sc)
+        try:
+            for any_hit in (False, True):
+                got, ref = gpu.trace(ds, rays, any_hit=any_hit), oracle.trace(sc, rays, any_hit=any_hit)
+                assert got.tobytes() == ref.tobytes()
+            assert (ref["prim"] == 0).sum() > 100
+        finally:
+            ds.close()
