@@ -27,6 +27,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--integrator", default="path", choices=["path", "ao"], help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample)")
     ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex"])
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
@@ -40,20 +41,22 @@ def build_workload(args, lib, scenes, shard):
     if args.workload == "soup1m":
         res, spp = args.res or 1024, args.spp or 256
         sc = scenes.triangle_soup(lib.bvh_build, n_tris=args.tris)
-        mk = lambda s, sh: scenes.soup_render_desc(res=res, spp=s, max_depth=8, shard=sh)  # noqa: E731
+        mk = lambda s, sh: scenes.soup_render_desc(res=res, spp=s, max_depth=8, shard=sh, integrator=args.integrator)  # noqa: E731
         name = "synthetic %d-triangle soup, path depth 8, sobol %d spp, %dx%d" % (args.tris, spp, res, res)
     elif args.workload == "cornell":
         res, spp = args.res or 400, args.spp or 64
         sc = scenes.cornell_box(lib.bvh_build)
-        mk = lambda s, sh: scenes.cornell_render_desc(res=res, spp=s, shard=sh)  # noqa: E731
+        mk = lambda s, sh: scenes.cornell_render_desc(res=res, spp=s, shard=sh, integrator=args.integrator)  # noqa: E731
         name = "Cornell Box, path depth 5, sobol %d spp, %dx%d" % (spp, res, res)
     else:
         xres, spp = args.res or 1920, args.spp or 1024
         yres = xres * 9 // 16
         tex = args.workload == "statue_tex"  # image-textured Kd + bump map + textured ground
         sc = scenes.statue_standin(lib.bvh_build, textured=tex)
-        mk = lambda s, sh: scenes.statue_render_desc(xres=xres, yres=yres, spp=s, shard=sh)  # noqa: E731
+        mk = lambda s, sh: scenes.statue_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=args.integrator)  # noqa: E731
         name = "statue stand-in (4.3 M triangles%s), path depth 5, sobol %d spp, %dx%d" % (", image-textured + bump-mapped" if tex else "", spp, xres, yres)
+    if args.integrator == "ao":
+        name += " [AOIntegrator, 64 shadow rays per camera sample]"
     return sc, mk, spp, name
 
 

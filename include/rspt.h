@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 6
+#define RSPT_ABI_VERSION 7
 
 /* error codes */
 #define RSPT_OK 0
@@ -259,8 +259,17 @@ typedef struct {
      * shard_index.  shard_count = 1 renders everything. */
     uint32_t shard_index, shard_count, tile_chunk;
     uint32_t sample_at_pixel_center; /* HaltonSampler "samplepixelcenter" (halton.rs:163-172) */
+    /* which `li` the shared SamplerIntegrator::render loop calls (integrator.rs:48-69).  AO:
+     * AOIntegrator::li (src/integrators/ao.rs:50-96) with its one 2-D sample array of ao_n_samples entries
+     * per pixel sample (request_2d_array in preprocess, ao.rs:47-49; GlobalSampler array dimensions 5, 6);
+     * max_depth, rr_threshold and light_strategy are ignored. */
+    uint32_t integrator;             /* RSPT_INTEGRATOR_* */
+    uint32_t ao_n_samples;           /* "nsamples" (default 64)        */
+    uint32_t ao_cos_sample;          /* "cossample" (default true)     */
+    uint32_t pad0;
     rspt_sampler_tables tables;
 } rspt_render_desc;
+enum { RSPT_INTEGRATOR_PATH = 0, RSPT_INTEGRATOR_AO = 1 };
 
 typedef struct { float o[3], d[3], t_max; uint32_t id; } rspt_ray;   /* 32 B */
 typedef struct { uint32_t prim; float t, b0, b1, b2; } rspt_hit;     /* prim = 0xffffffff on miss */

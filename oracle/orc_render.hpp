@@ -258,6 +258,14 @@ struct Sampler {
         halton.dimension += 2;
         return P2{x, y};
     }
+    // element j of the (single) 2-D sample array a GlobalSampler fills in start_pixel (sobol.rs:166-179,
+    // halton.rs:260-272): the sample of index get_index_for_sample(j) in the array dimensions; pixel sample s
+    // owns elements [s * n, (s + 1) * n) (get_2d_array, sobol.rs:214-224)
+    P2 array_2d(uint64_t j, int64_t dim) const {
+        if (!is_halton()) { uint64_t idx = sobol.get_index_for_sample(j); return P2{sobol.sample_dimension(idx, dim), sobol.sample_dimension(idx, dim + 1)}; }
+        uint64_t idx = halton.get_index_for_sample(j);
+        return P2{halton.sample_dimension(idx, dim), halton.sample_dimension(idx, dim + 1)};
+    }
     bool start_next_sample() { // halton.rs:333-343
         if (!is_halton()) return sobol.start_next_sample();
         halton.dimension = 0;
@@ -674,6 +682,37 @@ static inline Spec path_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counte
     return l;
 }
 
+// ---- AOIntegrator::li: src/integrators/ao.rs:50-96 ----
+static inline V3 uniform_sample_hemisphere(P2 u) { // sampling.rs:236-242
+    Float z = u.x;
+    Float r = std::sqrt(std::fmax(0.0f, 1.0f - z * z));
+    Float phi = 2.0f * PI * u.y;
+    return V3{r * std::cos(phi), r * std::sin(phi), z};
+}
+static inline Spec ao_li(RenderCtx& cx, const Ray& ray, Sampler& sampler, Counters* c) {
+    const Scene& sc = *cx.scene;
+    const rspt_render_desc& rd = *cx.rd;
+    Spec l;
+    Interaction isect;
+    if (sc.intersect(ray, &isect, c)) {
+        // (compute_scattering_functions only touches shading geometry and the BSDF; li reads neither)
+        V3 n = faceforward(isect.n, -ray.d);
+        V3 s = normalize(isect.dpdu);
+        V3 t = cross(isect.n, s); // nrm_cross_vec3(&isect.common.n, &s)
+        int32_t ns = (int32_t)rd.ao_n_samples;
+        uint64_t first = (uint64_t)sampler.cur_sample() * (uint64_t)ns;
+        for (int32_t k = 0; k < ns; k++) {
+            P2 u = sampler.array_2d(first + (uint64_t)k, 5); // GlobalSampler::array_start_dim = 5
+            V3 wi; Float pdf;
+            if (rd.ao_cos_sample) { wi = cosine_sample_hemisphere(u); pdf = std::fabs(wi.z) * INV_PI; }
+            else { wi = uniform_sample_hemisphere(u); pdf = INV_2_PI; }
+            wi = V3{s.x * wi.x + t.x * wi.y + n.x * wi.z, s.y * wi.x + t.y * wi.y + n.y * wi.z, s.z * wi.x + t.z * wi.y + n.z * wi.z};
+            if (pdf != 0.0f && !sc.intersect_p(isect.spawn_ray(wi), c)) l = l + Spec(dot(wi, n) / (pdf * (Float)ns));
+        }
+    }
+    return l;
+}
+
 // ---- PerspectiveCamera::generate_ray_differential: src/cameras/perspective.rs:190-280 ----
 static inline Ray camera_ray(const rspt_render_desc& rd, P2 p_film, Float time_s, P2 p_lens) {
     V3 p_camera = transform_point(rd.raster_to_camera, V3{p_film.x, p_film.y, 0.0f});
@@ -814,7 +853,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         Ray ray = camera_ray(rd, p_film, time_s, p_lens);
                         ray.scale_differentials(1.0f / std::sqrt((Float)rd.spp)); // integrator.rs:140-144 (get_samples_per_pixel)
                         Float ray_weight = 1.0f;
-                        Spec l = path_li(cx, ray, sampler, &c);
+                        Spec l = rd.integrator == RSPT_INTEGRATOR_AO ? ao_li(cx, ray, sampler, &c) : path_li(cx, ray, sampler, &c);
                         c.samples++;
                         if (l.has_nans()) { l = Spec(0.0f); c.nan_samples++; } // integrator.rs:165-173 (Q1)
                         if (li_rgb && px >= rd.crop_px[0] && px < rd.crop_px[2] && py >= rd.crop_px[1] && py < rd.crop_px[3]) {

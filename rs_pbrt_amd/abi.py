@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -13,6 +13,7 @@ BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9
 FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
 SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
+INTEGRATOR_PATH, INTEGRATOR_AO = 0, 1
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 TEX_CONSTANT, TEX_IMAGE, TEX_SCALE = 1, 2, 3
 MAP_UV, MAP_PLANAR = 1, 2
@@ -93,7 +94,8 @@ class RenderDesc(C.Structure):
                 ("max_depth", C.c_uint32), ("rr_threshold", C.c_float), ("light_strategy", C.c_uint32),
                 ("tile_size", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("tile_chunk", C.c_uint32),
-                ("sample_at_pixel_center", C.c_uint32), ("tables", SamplerTables)]
+                ("sample_at_pixel_center", C.c_uint32), ("integrator", C.c_uint32), ("ao_n_samples", C.c_uint32),
+                ("ao_cos_sample", C.c_uint32), ("pad0", C.c_uint32), ("tables", SamplerTables)]
 
 
 class Ray(C.Structure):

@@ -583,6 +583,78 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, Ren
     }
 }
 
+// ---- AOIntegrator::li (src/integrators/ao.rs:50-96) --------------------------
+// Stage 1, one lane per camera sample: frame at the hit, then the pixel sample's slice of the sampler's 2-D array
+// (GlobalSampler dimensions 5, 6 of the samples get_index_for_sample(s * n + k), sobol.rs:166-179 /
+// halton.rs:260-272) -> n shadow rays.  Ray k of path i sits at ray_sh[i * n + k]; its id field carries the
+// term dot(wi, n) / (pdf * n) that stage 2 adds when the ray is unoccluded.
+#define RSPT_AO_SKIP 0xffffffffu  // id of a ray that is not traced (pdf == 0)
+__global__ __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
+                                                  uint32_t n_samples, uint32_t cos_sample, uint32_t* __restrict__ q_any, QueueCounts* cnt) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= bt.n) return;
+    const float4 hc = pb.hit_cont[i];
+    const uint32_t prim = __float_as_uint(hc.x);
+    pb.state[i] = prim == RSPT_MISS ? 0u : 1u;
+    if (prim == RSPT_MISS) return;
+    const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + i);
+    const float4 r0 = rp[0], r1 = rp[1];
+    const f3 ray_d{r0.w, r1.x, r1.y};
+    const TriRec tri = load_tri(sc, prim);
+    TexHit h;  // the full interaction: li needs the geometric dpdu, not the shading one
+    tri_fill_tex(sc, prim, tri, hc.y, hc.z, hc.w, &h);
+    Hit hp;    // p_error for spawn_ray
+    tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &hp);
+    const f3 n = faceforward(h.n, -ray_d);
+    const f3 sv = normalize(h.dpdu);
+    const f3 tv = cross(h.n, sv);  // nrm_cross_vec3(&isect.common.n, &s)
+    const uint32_t pk = pix_list[bt.pix0 + i / bt.ns];
+    const int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
+    const uint64_t first = (uint64_t)(bt.s0 + i % bt.ns) * n_samples;
+    const uint32_t base = atomicAdd(&cnt->any, n_samples);
+    rspt_ray* out = pb.ray_sh + (size_t)i * n_samples;
+    for (uint32_t k = 0; k < n_samples; k++) {
+        f2 u;
+        if (rd.sampler_kind == RSPT_SAMPLER_HALTON) {
+            const uint64_t index = halton_index(rd, px, py, first + k);
+            u = f2{halton_dim(rd, index, 5), halton_dim(rd, index, 6)};
+        } else {
+            const uint64_t index = sobol_interval_to_index(rd, (uint32_t)rd.log2_res, first + k, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+            u = f2{sobol_dim(rd, index, 5), sobol_dim(rd, index, 6)};
+        }
+        f3 wi;
+        float pdf;
+        if (cos_sample) {
+            wi = cosine_hemisphere(u);
+            pdf = fabsf(wi.z) * RSPT_INV_PI;
+        } else {  // uniform_sample_hemisphere (sampling.rs:309-318)
+            const float z = u.x, r = sqrtf(fmaxf(0.0f, 1.0f - z * z)), phi = 2.0f * RSPT_PI * u.y;
+            wi = f3{r * cosf(phi), r * sinf(phi), z};
+            pdf = 0.15915494309189533577f;
+        }
+        wi = f3{sv.x * wi.x + tv.x * wi.y + n.x * wi.z, sv.y * wi.x + tv.y * wi.y + n.y * wi.z, sv.z * wi.x + tv.z * wi.y + n.z * wi.z};
+        uint32_t id = RSPT_AO_SKIP;
+        if (pdf != 0.0f) id = __float_as_uint(dot(wi, n) / (pdf * (float)n_samples));
+        store_ray(out + k, offset_ray_origin(hp.p, hp.p_err, hp.n, wi), wi, pdf != 0.0f ? RSPT_INF : 0.0f, id);
+        q_any[base + k] = i * n_samples + k;
+    }
+}
+// Stage 2: l += Spectrum::new(term) for the unoccluded rays, in array order (ao.rs:86-91)
+__global__ __launch_bounds__(256) void k_ao_resolve(Batch bt, PathBuf pb, uint32_t n_samples) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= bt.n) return;
+    float l = 0.0f;
+    if (pb.state[i]) {
+        const rspt_ray* rays = pb.ray_sh + (size_t)i * n_samples;
+        const uint32_t* occ = pb.occluded + (size_t)i * n_samples;
+        for (uint32_t k = 0; k < n_samples; k++) {
+            const uint32_t id = rays[k].id;
+            if (id != RSPT_AO_SKIP && occ[k] == 0u) l += __uint_as_float(id);
+        }
+    }
+    pb.L_eta[i] = make_float4(l, l, l, 1.0f);
+}
+
 // ---- K8 -------------------------------------------------------------------------------------
 // FilmTile::add_sample (film.rs:94-147) for all samples of one pixel in this batch, in sample
 // order.  The pixel's own contributions accumulate in registers; splats into other pixels

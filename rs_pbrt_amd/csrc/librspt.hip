@@ -323,6 +323,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (halton && !d->tables.halton_perms) return fail(RSPT_E_INVALID, "null halton permutation table");
     if (!(d->filter_radius[0] > 0.0f) || !(d->filter_radius[1] > 0.0f)) return fail(RSPT_E_INVALID, "bad filter radius");
     if (d->max_depth > 200) return fail(RSPT_E_UNSUPPORTED, "max_depth > 200");
+    if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO) return fail(RSPT_E_UNSUPPORTED, "integrator %u (path and ao only)", d->integrator);
+    if (d->integrator == RSPT_INTEGRATOR_AO && (d->ao_n_samples == 0 || d->ao_n_samples > 4096)) return fail(RSPT_E_INVALID, "ao_n_samples must be in [1, 4096]");
     const int32_t* sb = d->sample_bounds;
     const int32_t* cp = d->crop_px;
     if (sb[2] <= sb[0] || sb[3] <= sb[1] || cp[2] <= cp[0] || cp[3] <= cp[1]) return fail(RSPT_E_INVALID, "empty sample or crop bounds");
@@ -461,10 +463,14 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     size_t cap = env_size("RSPT_BATCH", (size_t)1 << 25);
     cap = std::max<size_t>(cap, 1024);
     const bool counters = env_size("RSPT_COUNTERS", 0) != 0;
+    // AOIntegrator: every camera sample carries ao_n_samples shadow rays through the same ray / occlusion arrays
+    const bool ao = d->integrator == RSPT_INTEGRATOR_AO;
+    const uint32_t ao_n = ao ? d->ao_n_samples : 1u;
+    if (ao) cap = std::max<size_t>(cap / ao_n, 1024);
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
     const size_t pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
-    if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1)))) { if (li_dev) (void)hipFree(li_dev); return rc; }
+    if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n))) { if (li_dev) (void)hipFree(li_dev); return rc; }
     const uint32_t nominal_iters = d->max_depth + 1;
     const uint32_t max_iters = s->has_null_material ? nominal_iters + 64 : nominal_iters;
     if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(3 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
@@ -498,6 +504,20 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
+            if (ao) {  // AOIntegrator::li: closest hit, n shadow rays per hit, sum of the unoccluded terms
+                hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++), e2 = get_event(n_ev++), e3 = get_event(n_ev++);
+                HIP_TRY(hipEventRecord(e0, g.stream));
+                launch_trace<false, 0>(0, counters, tgrid, s, g.q[0][1], &g.cnt[0].closest, 0, &g.cnt[0].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                HIP_TRY(hipEventRecord(e1, g.stream));
+                hipLaunchKernelGGL(k_ao_spawn, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, g.pix_list, ao_n, d->ao_cos_sample, g.q[0][2], &g.cnt[1]);
+                HIP_TRY(hipEventRecord(e2, g.stream));
+                launch_trace<true, 0>(0, counters, tgrid, s, g.q[0][2], &g.cnt[1].any, 0, &g.cnt[1].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                HIP_TRY(hipEventRecord(e3, g.stream));
+                trace_ev.push_back({e0, e1}); trace_ev.push_back({e2, e3});
+                trace_launches += 2;
+                hipLaunchKernelGGL(k_ao_resolve, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, ao_n);
+                it = 2;
+            } else
             for (;;) {
                 const int par = it & 1;
                 hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);

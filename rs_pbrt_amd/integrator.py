@@ -76,3 +76,20 @@ class PathIntegrator:
         h, w = film.shape
         film.pixels = np.asarray(pixels, np.float32).reshape(h, w, 4)
         return film
+
+
+class AOIntegrator(PathIntegrator):
+    """AOIntegrator::new(cos_sample, n_samples, camera, sampler, pixel_bounds) (src/integrators/ao.rs:28-45), created
+    by the "ao" / "ambientocclusion" integrator name with defaults cossample = true, nsamples = 64 (api.rs:411-440).
+    Shares SamplerIntegrator::render with the path integrator; only `li` differs."""
+
+    def __init__(self, cos_sample=True, n_samples=64, camera=None, sampler=None, pixel_bounds=None):
+        super().__init__(camera=camera, sampler=sampler, pixel_bounds=pixel_bounds)
+        self.cos_sample = bool(cos_sample)
+        self.n_samples = int(n_samples)
+
+    def _desc(self, shard=None):
+        rd = super()._desc(shard)
+        rd.integrator = abi.INTEGRATOR_AO
+        rd.ao_n_samples, rd.ao_cos_sample = self.n_samples, int(self.cos_sample)
+        return rd

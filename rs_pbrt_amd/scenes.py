@@ -679,8 +679,11 @@ def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs,
 def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_SPATIAL,
                      crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
                      focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
-                     sample_at_pixel_center=False):
+                     sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True):
     rd = abi.RenderDesc()
+    # Integrator "path" (path.rs) or "ao" / "ambientocclusion" (api.rs:411; ao.rs: nsamples 64, cossample true)
+    rd.integrator = abi.INTEGRATOR_AO if integrator == "ao" else abi.INTEGRATOR_PATH
+    rd.ao_n_samples, rd.ao_cos_sample = int(ao_samples), int(bool(ao_cos_sample))
     rd.full_res[:] = (xres, yres)
     # Film::new film.rs:187-196
     cx0, cx1 = math.ceil(float(F32(xres) * F32(crop[0]))), math.ceil(float(F32(xres) * F32(crop[1])))

@@ -335,3 +335,38 @@ def test_golden_textured_room(gpu):
     assert np.array_equal(film[:, 3], g["film"][:, 3])
     assert film_rmse(film, g["film"]) < 1e-4
     assert (li == g["li"]).all(axis=2).mean() > 0.6
+
+
+@pytest.mark.parametrize("cos_sample,sampler,n", [(True, "sobol", 16), (False, "sobol", 8), (True, "halton", 5)])
+def test_ao_integrator_matches_oracle(gpu, oracle, cos_sample, sampler, n):
+    """AOIntegrator::li through the shared render loop — closest hit, the pixel sample's slice of the
+    sampler's 2-D array (dimensions 5, 6), n shadow rays, sum of the unoccluded terms in array order"""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=48, spp=4, integrator="ao", ao_samples=n, ao_cos_sample=cos_sample, sampler=sampler)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    same = (li == ref["li"]).all(axis=2)
+    assert same.mean() > 0.75
+    assert np.abs(li - ref["li"]).mean() < 1e-5
+    assert film_rmse(film, ref["film"]) < 1e-4
+    assert 0.5 < li.mean() < 3.2 and st["nan_samples"] == 0
+
+
+def test_ao_open_plane_is_pi_and_python_mirror(gpu):
+    """cosine-sampled AO of an unoccluded point is exactly n * (cos / (cos / pi * n)) = pi; AOIntegrator mirror"""
+    from rs_pbrt_amd.integrator import AOIntegrator
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_quad([(-50, 0, -50), (50, 0, -50), (50, 0, 50), (-50, 0, 50)], m)
+    sc = sb.finish(gpu.bvh_build)
+    cam = scenes.make_render_desc(32, 32, 4, ((0, 2, -3), (0, 0, 0), (0, 1, 0)), 40.0)
+    film = AOIntegrator(camera=cam, n_samples=32).render(sc)
+    assert np.allclose(film.rgb(), np.pi, atol=1e-4)
+    import ctypes as C
+    bad = scenes.make_render_desc(8, 8, 1, ((0, 2, -3), (0, 0, 0), (0, 1, 0)), 40.0, integrator="ao", ao_samples=0)
+    ds = gpu.DeviceScene(sc)
+    try:
+        out = np.zeros((64, 4), np.float32)
+        assert gpu.lib().rspt_render(ds.handle, C.addressof(bad), out.ctypes.data, None) == abi.E_INVALID
+    finally:
+        ds.close()

@@ -534,3 +534,26 @@ def test_golden_textured_room_is_reproducible(oracle):
     r = oracle.render(sc, rd, threads=4, want_li=True)
     assert np.array_equal(r["film"][:, 3], g["film"][:, 3])
     assert np.array_equal(r["li"], g["li"])
+
+
+@pytest.mark.parametrize("sampler", ["sobol", "halton"])
+def test_ao_integrator_closed_forms(oracle, sampler):
+    """AOIntegrator::li (ao.rs:50-96): an unoccluded point gives exactly pi with cosine sampling (every term is
+    cos / (cos / pi * n)), ~pi with uniform sampling (2 pi * mean cos); under a large ceiling it is 0; the n array
+    samples of pixel sample s are elements s * n .. of the GlobalSampler array (dims 5, 6)"""
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_quad([(-50, 0, -50), (50, 0, -50), (50, 0, 50), (-50, 0, 50)], m)
+    sc = sb.finish(oracle.bvh_build)
+    look = ((0, 2, -3), (0, 0, 0), (0, 1, 0))
+    rd = scenes.make_render_desc(16, 16, 4, look, 40.0, integrator="ao", ao_samples=16, sampler=sampler)
+    r = oracle.render(sc, rd, threads=2, want_li=True)
+    assert np.allclose(r["li"], np.pi, atol=2e-6)
+    assert r["counters"]["rays_any"] == 16 * 16 * 4 * 16
+    rd = scenes.make_render_desc(16, 16, 16, look, 40.0, integrator="ao", ao_samples=64, ao_cos_sample=False, sampler=sampler)
+    r = oracle.render(sc, rd, threads=2, want_li=True)
+    assert abs(r["li"].mean() - np.pi) < 0.02
+    sb.add_quad([(-500, 5, -500), (-500, 5, 500), (500, 5, 500), (500, 5, -500)], m)  # a ceiling far larger than the view
+    sc2 = sb.finish(oracle.bvh_build)
+    rd = scenes.make_render_desc(16, 16, 4, look, 40.0, integrator="ao", ao_samples=16, sampler=sampler)
+    assert oracle.render(sc2, rd, threads=2, want_li=True)["li"].max() < 0.2
