@@ -23,6 +23,7 @@ enum : uint32_t {
     ST_HAS_C1 = 1u << 27,        // pending light-sample term
     ST_HAS_C2 = 1u << 28,        // pending BSDF-sample (MIS) term
     ST_C2_ON_MISS = 1u << 29,    // ... of an infinite light: it counts when the MIS ray escapes
+    ST_NO_DIFF = 1u << 30,       // the camera ray went through a null material: it was re-spawned without differentials (path.rs:109-116)
 };
 #define RSPT_Q_MIS 0x80000000u   // closest-hit queue entry flag: this is the path's MIS ray
 
@@ -307,7 +308,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             if (h.material == 0xffffffffu) {  // null BSDF: pass straight through (path.rs:109-116)
                 f3 o = offset_ray_origin(h.p, h.p_err, h.n, ray_d);
                 store_ray(pb.ray_cont + p, o, ray_d, RSPT_INF, p);
-                st |= ST_ALIVE;
+                st |= ST_ALIVE | ST_NO_DIFF;
                 out.cont = true;
             } else {
                 rspt_material mat = sc.materials[h.material];
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, Rend
         s.p = h.p; s.uv = h.uv;
         s.dudx = s.dvdx = s.dudy = s.dvdy = 0.0f;
         s.dpdx = s.dpdy = f3{0.0f, 0.0f, 0.0f};
-        if (bounces == 0 && !(st & ST_SPECULAR)) {  // the camera ray (a null-material pass-through re-spawns without differentials)
+        if (bounces == 0 && !(st & ST_NO_DIFF)) {  // the camera ray itself (a null-material pass-through re-spawns without differentials)
             const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
             const float4 r0 = rp[0], r1 = rp[1];
             const float2 pf = pb.p_film[p];

@@ -370,3 +370,19 @@ def test_ao_open_plane_is_pi_and_python_mirror(gpu):
         assert gpu.lib().rspt_render(ds.handle, C.addressof(bad), out.ctypes.data, None) == abi.E_INVALID
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("seed", list(range(101, 125)))
+def test_random_scenes_fuzz(gpu, oracle, seed):
+    """random rooms with every material recipe / texture binding / light kind drawn at random, both samplers and all
+    light strategies: weights exact, film within the bump-map bar (textures + bump maps appear in most of them)"""
+    from tests.util import GALLERY_LOOK_AT, random_scene
+    sc = random_scene(gpu.bvh_build, seed)
+    rd = scenes.make_render_desc(56, 40, 8, GALLERY_LOOK_AT, 55, max_depth=2 + seed % 5, sampler="halton" if seed % 2 else "sobol",
+                                 light_strategy=[abi.LIGHTS_SPATIAL, abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM][seed % 3],
+                                 lens_radius=0.03 if seed % 4 == 0 else 0.0, focal_distance=6.0)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert st["nan_samples"] == ref["counters"]["nan_samples"]
+    assert (li == ref["li"]).all(axis=2).mean() > 0.5
+    assert film_rmse(film, ref["film"]) < 3e-4

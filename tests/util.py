@@ -132,3 +132,59 @@ def textured_room(builder, trilinear=False, wrap="repeat", bump=True, planar=Tru
 
 
 TEXTURED_LOOK_AT = ((0, 2.6, -4.6), (0, 1.6, 2), (0, 1, 0))
+
+
+def random_scene(builder, seed):
+    """a random room for fuzzing the GPU path against the oracle: 6 walls + ~12 slabs with materials drawn from every
+    recipe (random parameters, some textured / bump-mapped / mixed / null), random area + delta (+ sometimes infinite) lights"""
+    rng = np.random.default_rng(seed)
+    sb = scenes.SceneBuilder()
+    col = lambda lo=0.05, hi=0.9: tuple(float(x) for x in rng.uniform(lo, hi, 3))  # noqa: E731
+    img = texture_image(seed=seed)
+    tex = [sb.image_texture(img, su=float(rng.uniform(0.5, 4)), sv=float(rng.uniform(0.5, 4)), trilinear=bool(rng.integers(2)), wrap=["repeat", "clamp", "black"][int(rng.integers(3))]),
+           sb.scale_texture(sb.image_texture(img[::-1].copy(), gamma=True), sb.constant_texture(col())),
+           sb.image_texture(img, mapping="planar", v1=col(-0.5, 0.5), v2=col(-0.5, 0.5), du=0.3, dv=0.1)]
+    height = sb.image_texture(img, channels=1, scale=0.05, trilinear=True)
+
+    def kd():
+        return tex[int(rng.integers(3))] if rng.random() < 0.4 else col()
+
+    def material():
+        k = int(rng.integers(12))
+        bump = height if rng.random() < 0.25 else None
+        if k == 0: return scenes.matte(kd(), sigma=float(rng.choice([0.0, 20.0, 60.0])), bump=bump)
+        if k == 1: return scenes.plastic(kd(), kd(), float(rng.uniform(0.01, 0.5)), bump=bump)
+        if k == 2: return scenes.mirror(col(0.5, 1.0))
+        if k == 3: return scenes.glass(col(0.5, 1.0), col(0.5, 1.0), float(rng.uniform(1.1, 2.0)))
+        if k == 4: return scenes.metal(roughness=float(rng.uniform(0.005, 0.3)))
+        if k == 5: return scenes.substrate(kd(), col(0.05, 0.4), float(rng.uniform(0.02, 0.4)), float(rng.uniform(0.02, 0.4)), bump=bump)
+        if k == 6: return scenes.uber(kd(), col(), col(0.0, 0.3), col(0.0, 0.3), roughness=float(rng.uniform(0.05, 0.4)), opacity=col(0.4, 1.0), bump=bump)
+        if k == 7: return scenes.translucent(col(), col(), col(0.2, 0.8), col(0.2, 0.8), float(rng.uniform(0.05, 0.4)))
+        if k == 8: return scenes.rough_glass(uroughness=float(rng.uniform(0.02, 0.3)), vroughness=float(rng.uniform(0.02, 0.3)))
+        if k == 9: return scenes.mix(scenes.matte(col()), scenes.plastic(col(), col(), 0.1), col(0.1, 0.9))
+        if k == 10: return scenes.mix(scenes.mirror(), scenes.substrate(col(), col(0.05, 0.3), 0.1, 0.1), col(0.1, 0.9))
+        return scenes.matte(col())
+
+    wall = sb.add_material(scenes.matte(kd()))
+    q = sb.add_quad
+    uvq = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    q([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], wall, UV=uvq)
+    q([(-5, 6, -5), (5, 6, -5), (5, 6, 5), (-5, 6, 5)], wall, UV=uvq)
+    q([(-5, 0, 5), (-5, 6, 5), (5, 6, 5), (5, 0, 5)], sb.add_material(material()), UV=uvq)
+    q([(-5, 0, -5), (-5, 6, -5), (-5, 6, 5), (-5, 0, 5)], sb.add_material(material()), UV=uvq)
+    q([(5, 0, -5), (5, 0, 5), (5, 6, 5), (5, 6, -5)], sb.add_material(material()), UV=uvq)
+    for i in range(12):
+        c = rng.uniform([-4, 0.3, -1], [4, 4.5, 4])
+        a, b = rng.normal(size=3), rng.normal(size=3)
+        a *= rng.uniform(0.4, 1.2) / np.linalg.norm(a); b -= a * (a @ b) / (a @ a); b *= rng.uniform(0.4, 1.2) / np.linalg.norm(b)
+        mat = 0xFFFFFFFF if (i == 11 and seed % 3 == 0) else sb.add_material(material())
+        P = [c - a - b, c + a - b, c + a + b, c - a + b]
+        n = np.cross(a, b); n /= np.linalg.norm(n)
+        q(P, mat, UV=uvq, N=[n] * 4 if rng.random() < 0.5 else None)
+    q([(-1.2, 5.9, -1.2), (1.2, 5.9, -1.2), (1.2, 5.9, 1.2), (-1.2, 5.9, 1.2)], wall, emit=col(4, 12))
+    if rng.random() < 0.7: q([(-4.9, 2, -1), (-4.9, 3, -1), (-4.9, 3, 0), (-4.9, 2, 0)], wall, emit=col(2, 8), two_sided=True)
+    if rng.random() < 0.6: sb.add_point_light(tuple(rng.uniform([-3, 3, -3], [3, 5, 3])), col(5, 30))
+    if rng.random() < 0.4: sb.add_spot_light((3, 5, -3), (0, 1, 1), col(30, 90), coneangle=35, conedelta=10)
+    if rng.random() < 0.3: sb.add_distant_light((1, 3, -2), (0, 0, 0), col(0.2, 0.8))
+    if rng.random() < 0.3: sb.add_infinite_light(col(0.1, 0.5))
+    return sb.finish(builder)
