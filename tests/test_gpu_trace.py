@@ -261,3 +261,47 @@ def test_single_triangle_and_two_triangle_scenes(gpu, oracle):
             assert (ref["prim"] == 0).sum() > 100
         finally:
             ds.close()
+
+
+def test_ties_duplicates_and_lattice_geometry(gpu, oracle):
+    """equal-distance candidates: every triangle of a lattice of axis-aligned quads exists three times (shuffled, so
+    the copies land in different leaves), rays start on lattice points and travel along lattice directions, so hits
+    fall on shared edges / vertices / box faces all the time.  The winner among equal t is decided by the reference's
+    visiting order and its strict `<` tests; all kernels must reproduce it bit for bit."""
+    import os
+    rng = np.random.default_rng(2024)
+    quads = []
+    for k in range(5):
+        for i in range(4):
+            for j in range(4):
+                for axis in range(3):
+                    c = np.array([i, j, k], np.float32)
+                    u = np.eye(3, dtype=np.float32)[(axis + 1) % 3]; v = np.eye(3, dtype=np.float32)[(axis + 2) % 3]
+                    quads.append([c, c + u, c + u + v]); quads.append([c, c + u + v, c + v])
+    tris = np.array(quads, np.float32)
+    tris = np.concatenate([tris, tris, tris[:, ::-1]])           # duplicates (one copy with the opposite winding)
+    tris = tris[rng.permutation(len(tris))]
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_mesh(tris.reshape(-1, 3), np.arange(3 * len(tris)).reshape(-1, 3), m)
+    sc = sb.finish(gpu.bvh_build, max_prims_in_node=2)
+    n = 80000
+    rays = np.zeros(n, abi.RAY_DT)
+    rays["o"] = rng.integers(-1, 6, (n, 3)).astype(np.float32) + rng.choice([0.0, 0.5, 0.25], (n, 3)).astype(np.float32)
+    d = rng.integers(-2, 3, (n, 3)).astype(np.float32)
+    d[(d == 0).all(1)] = (1, 1, 1)
+    rays["d"] = d / np.linalg.norm(d, axis=1)[:, None]
+    rays["d"][: n // 4] = d[: n // 4]                            # a quarter with unnormalised integer directions
+    rays["t_max"] = np.where(rng.random(n) < 0.2, rng.integers(1, 4, n), np.inf).astype(np.float32)
+    ds = gpu.DeviceScene(sc)
+    try:
+        for kernel in ("2", "1", "0"):
+            os.environ["RSPT_TRACE_KERNEL"] = kernel
+            for any_hit in (False, True):
+                ref = oracle.trace(sc, rays, any_hit=any_hit)
+                got = gpu.trace(ds, rays, any_hit=any_hit)
+                assert got.tobytes() == ref.tobytes(), (kernel, any_hit, int((got["prim"] != ref["prim"]).sum()))
+        assert (ref["prim"] == 0).mean() > 0.3
+    finally:
+        os.environ.pop("RSPT_TRACE_KERNEL", None)
+        ds.close()
