@@ -291,7 +291,9 @@ RDEVN float lobe_pdf(const rspt_bxdf& b, f3 wo, f3 wi) {
     }
 }
 // sampled_type follows the reference's in/out sentinel convention (only written when non-zero).
-RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2 u, float* pdf, uint32_t* sampled_type) {
+// want_f = false: Bsdf::sample_f replaces the value of a non-specular lobe by the sum over all matching lobes
+// (reflection.rs:393-410), so its own f() need not be evaluated (Q7: nothing else reads it)
+RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2 u, float* pdf, uint32_t* sampled_type, bool want_f) {
     const rgb black = mkrgb(0.0f);
     switch (b.type) {
     case RSPT_BXDF_LAMBERT_R:
@@ -299,13 +301,13 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
         *wi = cosine_hemisphere(u);
         if (wo.z < 0.0f) wi->z *= -1.0f;
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, lt, wo, *wi);
+        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_LAMBERT_T: {
         *wi = cosine_hemisphere(u);
         if (wo.z > 0.0f) wi->z *= -1.0f;
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, lt, wo, *wi);
+        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_SPECULAR_R: {
         *wi = f3{-wo.x, -wo.y, wo.z};
@@ -344,7 +346,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
         *wi = (-wo) + wh * 2.0f * dot(wo, wh);  // reflect, reflection.rs:1889
         if (!same_hemi(wo, *wi)) return black;
         *pdf = tr_pdf(b.alpha_x, b.alpha_y, wo, wh) / (4.0f * dot(wo, wh));
-        return lobe_f(b, lt, wo, *wi);
+        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1322-1349
         if (wo.z == 0.0f) return black;
@@ -352,7 +354,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
         float eta = wo.z > 0.0f ? b.eta_a / b.eta_b : b.eta_b / b.eta_a;
         if (!refract(wo, wh, eta, wi)) return black;
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, lt, wo, *wi);
+        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1432-1461
         f2 uu = u;
@@ -367,7 +369,7 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
             if (!same_hemi(wo, *wi)) return black;
         }
         *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, lt, wo, *wi);
+        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     default: return black;
     }
@@ -441,7 +443,7 @@ struct Bsdf {
         if (wo.z == 0.0f) return black;
         *pdf_out = 0.0f;
         if (*sampled_type != 0) *sampled_type = bt;
-        rgb f = lobe_sample_f(bx, lt, wo, &wi, ur, pdf_out, sampled_type);
+        rgb f = lobe_sample_f(bx, lt, wo, &wi, ur, pdf_out, sampled_type, false);
         if (*pdf_out == 0.0f) { if (*sampled_type != 0) *sampled_type = 0; return black; }
         *wi_w = to_world(wi);
         if (!(bt & BX_SPEC) && matching > 1)
