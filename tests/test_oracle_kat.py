@@ -557,3 +557,24 @@ def test_ao_integrator_closed_forms(oracle, sampler):
     sc2 = sb.finish(oracle.bvh_build)
     rd = scenes.make_render_desc(16, 16, 4, look, 40.0, integrator="ao", ao_samples=16, sampler=sampler)
     assert oracle.render(sc2, rd, threads=2, want_li=True)["li"].max() < 0.2
+
+
+def test_cornell_structure_matches_the_reference_illustration(oracle):
+    """The only renderer output in the reference tree is an 8-bit illustration of the Cornell box (256 spp, path),
+    whose scene file is not in the tree (tests/golden/make_reference_luma.py).  Our Cornell box is authored from the
+    public Cornell data with the same camera; the scene file evidently mirrors x (red wall on the left) and uses
+    other reflectances, so this is a structural check only: log-luminance correlation of 50x50 thumbnails after
+    mirroring, plus the ceiling light landing in the same thumbnail cells."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_cornell_256spp_luma50.npz"))["luma"]
+    sc = scenes.cornell_box(oracle.bvh_build)
+    rd = scenes.cornell_render_desc(res=500, spp=8)
+    r = oracle.render(sc, rd, threads=16)
+    rgb = scenes.film_to_rgb(r["film"]).reshape(500, 500, 3)
+    y = (0.212671 * rgb[..., 0] + 0.715160 * rgb[..., 1] + 0.072169 * rgb[..., 2]).reshape(50, 10, 50, 10).mean(axis=(1, 3))[:, ::-1]
+    corr = np.corrcoef(np.log(g.reshape(-1) + 1e-3), np.log(np.minimum(y, 1.0).reshape(-1) + 1e-3))[0, 1]
+    assert corr > 0.93, corr
+    ours = np.argwhere(y[:15] > 0.9)
+    theirs = np.argwhere(g[:15] > 0.9)
+    assert abs(ours[:, 0].mean() - theirs[:, 0].mean()) <= 1 and abs(ours[:, 1].mean() - theirs[:, 1].mean()) <= 1
+    assert y[0].max() < 0.05 and y[:, 0].max() < 0.05 and g[0].max() < 0.05  # the black frame around the open box
