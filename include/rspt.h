@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 7
+#define RSPT_ABI_VERSION 8
 
 /* error codes */
 #define RSPT_OK 0
@@ -135,29 +135,45 @@ typedef struct {
                                 max(1, height >> i), row major [t][s], `channels` floats   */
 } rspt_image;
 enum {
-    RSPT_TEX_CONSTANT = 1,   /* ConstantTexture  src/textures/constant.rs: value            */
-    RSPT_TEX_IMAGE = 2,      /* ImageTexture     src/textures/imagemap.rs:114-149           */
-    RSPT_TEX_SCALE = 3       /* ScaleTexture     src/textures/scale.rs: tex1 * tex2 (children
-                                must be CONSTANT or IMAGE)                                 */
+    RSPT_TEX_CONSTANT = 1,   /* ConstantTexture        src/textures/constant.rs: value                        */
+    RSPT_TEX_IMAGE = 2,      /* ImageTexture           src/textures/imagemap.rs:114-149 (2-D mapping)         */
+    RSPT_TEX_SCALE = 3,      /* ScaleTexture           src/textures/scale.rs: tex1 * tex2                     */
+    RSPT_TEX_MIX = 4,        /* MixTexture             src/textures/mix.rs: tex1 (1 - a) + tex2 a, a = tex3 (float) */
+    RSPT_TEX_CHECKERBOARD = 5, /* Checkerboard2DTexture src/textures/checkerboard.rs (no anti-aliasing there): tex1 / tex2,
+                                  2-D mapping                                                                */
+    RSPT_TEX_DOTS = 6,       /* DotsTexture            src/textures/dots.rs: tex1 = outside, tex2 = inside, 2-D mapping */
+    RSPT_TEX_FBM = 7,        /* FBmTexture             src/textures/fbm.rs: octaves, omega (3-D mapping)      */
+    RSPT_TEX_MARBLE = 8,     /* MarbleTexture          src/textures/marble.rs: octaves, omega, scale, variation */
+    RSPT_TEX_WINDY = 9,      /* WindyTexture           src/textures/windy.rs                                  */
+    RSPT_TEX_WRINKLED = 10   /* WrinkledTexture        src/textures/wrinkled.rs: octaves, omega               */
 };
 enum {
-    RSPT_MAP_UV = 1,         /* UVMapping2D      texture.rs:91-121: map = su, sv, du, dv    */
-    RSPT_MAP_PLANAR = 2      /* PlanarMapping2D  texture.rs:222-257: map = vs[3], vt[3], ds, dt */
+    RSPT_MAP_UV = 1,         /* UVMapping2D            texture.rs:91-121: map = su, sv, du, dv                */
+    RSPT_MAP_PLANAR = 2,     /* PlanarMapping2D        texture.rs:222-257: map = vs[3], vt[3], ds, dt         */
+    RSPT_MAP_SPHERICAL = 3,  /* SphericalMapping2D     texture.rs:123-170: world_to_texture                   */
+    RSPT_MAP_CYLINDRICAL = 4,/* CylindricalMapping2D   texture.rs:172-220: world_to_texture                   */
+    RSPT_MAP_IDENTITY3D = 5  /* IdentityMapping3D      texture.rs:259-283 (FBM / MARBLE / WINDY / WRINKLED)   */
 };
 enum { RSPT_WRAP_REPEAT = 0, RSPT_WRAP_BLACK = 1, RSPT_WRAP_CLAMP = 2 }; /* mipmap.rs:23-27; Black
                                 looks texels up like Clamp (mipmap.rs:217-227, "TMP" branch)   */
 typedef struct {
     uint32_t kind;           /* RSPT_TEX_*                                                 */
-    uint32_t mapping;        /* RSPT_MAP_* (IMAGE)                                         */
+    uint32_t mapping;        /* RSPT_MAP_*                                                 */
     float map[8];
     uint32_t image;          /* index into images[] (IMAGE)                                */
     uint32_t trilinear;      /* do_trilinear (mipmap.rs:253-262); 0 = EWA                  */
     float max_aniso;         /* EWA eccentricity clamp (default 8)                         */
     uint32_t wrap;           /* RSPT_WRAP_*                                                */
     float value[3];          /* CONSTANT (float textures: value[0])                        */
-    uint32_t tex1, tex2;     /* SCALE: texture indices                                     */
-    uint32_t pad;
-} rspt_texture; /* 80 B */
+    uint32_t tex1, tex2;     /* children: texture indices.  The graph below a texture bound to a material may
+                                be at most three levels deep                                */
+    uint32_t tex3;           /* MIX: the float `amount` texture                            */
+    float world_to_texture[16]; /* row major, for SPHERICAL / CYLINDRICAL / IDENTITY3D      */
+    int32_t octaves;         /* FBM, MARBLE, WRINKLED (default 8)                          */
+    float omega;             /* FBM, MARBLE, WRINKLED (default 0.5)                        */
+    float scale;             /* MARBLE (default 1)                                         */
+    float variation;         /* MARBLE (default 0.2)                                       */
+} rspt_texture; /* 160 B */
 
 /* ---- lights (Scene.lights order, src/core/scene.rs:19-24) ------------------------- */
 enum {

@@ -50,6 +50,12 @@ static inline uint64_t f2usize(Float x) {
     if (x >= 18446744073709551616.0f) return UINT64_MAX;
     return (uint64_t)x;
 }
+// Rust `x as u32` from f32
+static inline uint32_t f2u32(Float x) {
+    if (x != x || x <= 0.0f) return 0;
+    if (x >= 4294967296.0f) return UINT32_MAX;
+    return (uint32_t)x;
+}
 // Rust `x as u8` from f32
 static inline uint8_t f2u8(Float x) {
     if (x != x || x <= 0.0f) return 0;

@@ -408,8 +408,6 @@ static inline const Distribution2D& env_distribution(const rspt_envmap& m) { // 
     return *it->second;
 }
 static inline V3 mat3_mul(const float* m, V3 w) { return V3{m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z}; }
-static inline Float spherical_theta(V3 v) { return std::acos(clamp_t(v.z, -1.0f, 1.0f)); } // geometry.rs:1584-1586
-static inline Float spherical_phi(V3 v) { Float p = std::atan2(v.y, v.x); return p < 0.0f ? p + 2.0f * PI : p; } // :1589-1596
 // InfiniteAreaLight::le (infinite.rs:369-377)
 static inline Spec infinite_le(const Scene& sc, const rspt_light& lt, V3 ray_d) {
     V3 w = normalize(mat3_mul(lt.p + 9, ray_d));

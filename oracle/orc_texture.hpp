@@ -154,27 +154,196 @@ static inline Spec img_lookup(const rspt_image& m, const rspt_texture& tx, P2 st
     return col1 * (1.0f - t) + col2 * t;
 }
 
-// ---- Texture::evaluate: src/textures/{constant,imagemap,scale}.rs, mappings src/core/texture.rs:91-121,222-257 ----
+// ---- geometry.rs:1584-1596 ----
+static inline Float spherical_theta(V3 v) { return std::acos(clamp_t(v.z, -1.0f, 1.0f)); }
+static inline Float spherical_phi(V3 v) { Float p = std::atan2(v.y, v.x); return p < 0.0f ? p + 2.0f * PI : p; }
+
+// ---- Perlin noise: src/core/texture.rs:21-48 (Ken Perlin's reference permutation, twice), 289-425 ----
+static const uint8_t NOISE_PERM[512] = {
+#define RSPT_PERLIN_PERM \
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, 247, 120, \
+    234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, \
+    134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, \
+    161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, \
+    250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, \
+    2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, \
+    228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184, 84, \
+    204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180
+    RSPT_PERLIN_PERM, RSPT_PERLIN_PERM
+#undef RSPT_PERLIN_PERM
+};
+static inline Float smooth_step(Float mn, Float mx, Float value) { // texture.rs:289-292
+    Float v = clamp_t((value - mn) / (mx - mn), 0.0f, 1.0f);
+    return v * v * (-2.0f * v + 3.0f);
+}
+static inline Float noise_grad(int32_t x, int32_t y, int32_t z, Float dx, Float dy, Float dz) { // :342-358
+    uint8_t h = NOISE_PERM[NOISE_PERM[NOISE_PERM[x] + y] + z];
+    h &= 15;
+    Float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+    Float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+static inline Float noise_weight(Float t) { Float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; } // :360-364
+static inline Float noise_flt(Float x, Float y, Float z) { // :294-336
+    int32_t ix = f2i(std::floor(x)), iy = f2i(std::floor(y)), iz = f2i(std::floor(z));
+    Float dx = x - (Float)ix, dy = y - (Float)iy, dz = z - (Float)iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    Float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    Float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    Float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    Float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    Float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    Float x00 = lerp(wx, w000, w100), x10 = lerp(wx, w010, w110), x01 = lerp(wx, w001, w101), x11 = lerp(wx, w011, w111);
+    Float y0 = lerp(wy, x00, x10), y1 = lerp(wy, x01, x11);
+    return lerp(wz, y0, y1);
+}
+static inline Float log_2(Float x) { return std::log(x) * 1.44269504088896340736f; } // pbrt.rs:153-156 (ln * LOG2_E)
+static inline Float fbm(V3 p, V3 dpdx, V3 dpdy, Float omega, int32_t max_octaves) { // texture.rs:366-386
+    Float len2 = std::fmax(length_squared(dpdx), length_squared(dpdy));
+    Float n = clamp_t(-1.0f - 0.5f * log_2(len2), 0.0f, (Float)max_octaves);
+    int32_t n_int = f2i(std::floor(n));
+    Float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (int32_t i = 0; i < n_int; i++) {
+        sum += o * noise_flt(p.x * lambda, p.y * lambda, p.z * lambda);
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    Float n_partial = n - (Float)n_int;
+    sum += o * smooth_step(0.3f, 0.7f, n_partial) * noise_flt(p.x * lambda, p.y * lambda, p.z * lambda);
+    return sum;
+}
+static inline Float turbulence(V3 p, V3 dpdx, V3 dpdy, Float omega, int32_t max_octaves) { // texture.rs:388-424
+    Float len2 = std::fmax(length_squared(dpdx), length_squared(dpdy));
+    Float n = clamp_t(-1.0f - 0.5f * log_2(len2), 0.0f, (Float)max_octaves);
+    uint64_t n_int = f2usize(std::floor(n));
+    Float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint64_t i = 0; i < n_int; i++) {
+        sum += o * std::fabs(noise_flt(p.x * lambda, p.y * lambda, p.z * lambda));
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    Float n_partial = n - (Float)n_int;
+    sum += o * lerp(smooth_step(0.3f, 0.7f, n_partial), 0.2f, std::fabs(noise_flt(p.x * lambda, p.y * lambda, p.z * lambda)));
+    for (uint64_t i = n_int; i < (uint64_t)std::max(max_octaves, 0); i++) {
+        sum += o * 0.2f;
+        o *= omega;
+    }
+    return sum;
+}
+
+// ---- TextureMapping2D / 3D: src/core/texture.rs:51-283 ----
+static inline P2 map_sphere(const rspt_texture& tx, V3 p) { // :135-144
+    V3 v = normalize(transform_point(tx.world_to_texture, p) - V3{0, 0, 0});
+    return P2{spherical_theta(v) * INV_PI, spherical_phi(v) * INV_2_PI};
+}
+static inline P2 map_cylinder(const rspt_texture& tx, V3 p) { // :184-191
+    V3 v = normalize(transform_point(tx.world_to_texture, p) - V3{0, 0, 0});
+    return P2{PI + std::atan2(v.y, v.x) * INV_2_PI, v.z};
+}
+static inline void wrap_dt(P2* d) { // the `if dstdx[1] > 0.5 ... else if < -0.5` fix-ups (:158-167, :203-217)
+    if (d->y > 0.5f) d->y = 1.0f - d->y;
+    else if (d->y < -0.5f) d->y = -(d->y + 1.0f);
+}
+static inline P2 tex_map2d(const rspt_texture& tx, const Interaction& si, P2* dstdx, P2* dstdy) {
+    switch (tx.mapping) {
+    case RSPT_MAP_PLANAR: {
+        V3 vs{tx.map[0], tx.map[1], tx.map[2]}, vt{tx.map[3], tx.map[4], tx.map[5]};
+        *dstdx = P2{dot(si.dpdx, vs), dot(si.dpdx, vt)};
+        *dstdy = P2{dot(si.dpdy, vs), dot(si.dpdy, vt)};
+        return P2{tx.map[6] + dot(si.p, vs), tx.map[7] + dot(si.p, vt)};
+    }
+    case RSPT_MAP_SPHERICAL: {
+        P2 st = map_sphere(tx, si.p);
+        const Float delta = 0.1f;
+        P2 sx = map_sphere(tx, si.p + si.dpdx * delta);
+        *dstdx = P2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        P2 sy = map_sphere(tx, si.p + si.dpdy * delta);
+        *dstdy = P2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        wrap_dt(dstdx); wrap_dt(dstdy);
+        return st;
+    }
+    case RSPT_MAP_CYLINDRICAL: {
+        P2 st = map_cylinder(tx, si.p);
+        const Float delta = 0.01f;
+        P2 sx = map_cylinder(tx, si.p + si.dpdx * delta);
+        *dstdx = P2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        wrap_dt(dstdx);
+        P2 sy = map_cylinder(tx, si.p + si.dpdy * delta);
+        *dstdy = P2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        wrap_dt(dstdy);
+        return st;
+    }
+    default:
+        *dstdx = P2{si.dudx * tx.map[0], si.dvdx * tx.map[1]};
+        *dstdy = P2{si.dudy * tx.map[0], si.dvdy * tx.map[1]};
+        return P2{si.uv.x * tx.map[0] + tx.map[2], si.uv.y * tx.map[1] + tx.map[3]};
+    }
+}
+static inline V3 tex_map3d(const rspt_texture& tx, const Interaction& si, V3* dpdx, V3* dpdy) { // IdentityMapping3D :270-282
+    *dpdx = transform_vector(tx.world_to_texture, si.dpdx);
+    *dpdy = transform_vector(tx.world_to_texture, si.dpdy);
+    return transform_point(tx.world_to_texture, si.p);
+}
+
+// ---- Texture::evaluate: src/textures/*.rs ----
 static inline Spec tex_eval(const Scene& sc, uint32_t ti, const Interaction& si, int depth = 0) {
     const rspt_texture& tx = sc.d.textures[ti];
+    if (depth > 4) return Spec();
     switch (tx.kind) {
     case RSPT_TEX_CONSTANT: return S3(tx.value);
-    case RSPT_TEX_SCALE:
-        if (depth > 4) return Spec();
-        return tex_eval(sc, tx.tex1, si, depth + 1) * tex_eval(sc, tx.tex2, si, depth + 1); // scale.rs:24-27
+    case RSPT_TEX_SCALE: return tex_eval(sc, tx.tex1, si, depth + 1) * tex_eval(sc, tx.tex2, si, depth + 1); // scale.rs:24-27
+    case RSPT_TEX_MIX: { // mix.rs:30-35
+        Spec t1 = tex_eval(sc, tx.tex1, si, depth + 1), t2 = tex_eval(sc, tx.tex2, si, depth + 1);
+        Float amt = tex_eval(sc, tx.tex3, si, depth + 1).c[0];
+        return t1 * Spec(1.0f - amt) + t2 * Spec(amt);
+    }
     case RSPT_TEX_IMAGE: {
-        P2 st, dstdx, dstdy;
-        if (tx.mapping == RSPT_MAP_PLANAR) {
-            V3 vs{tx.map[0], tx.map[1], tx.map[2]}, vt{tx.map[3], tx.map[4], tx.map[5]};
-            dstdx = P2{dot(si.dpdx, vs), dot(si.dpdx, vt)};
-            dstdy = P2{dot(si.dpdy, vs), dot(si.dpdy, vt)};
-            st = P2{tx.map[6] + dot(si.p, vs), tx.map[7] + dot(si.p, vt)};
-        } else {
-            dstdx = P2{si.dudx * tx.map[0], si.dvdx * tx.map[1]};
-            dstdy = P2{si.dudy * tx.map[0], si.dvdy * tx.map[1]};
-            st = P2{si.uv.x * tx.map[0] + tx.map[2], si.uv.y * tx.map[1] + tx.map[3]};
-        }
+        P2 dstdx, dstdy;
+        P2 st = tex_map2d(tx, si, &dstdx, &dstdy);
         return img_lookup(sc.d.images[tx.image], tx, st, dstdx, dstdy);
+    }
+    case RSPT_TEX_CHECKERBOARD: { // checkerboard.rs:32-42: `(floor(s) as u32 + floor(t) as u32) % 2`
+        P2 dstdx, dstdy;
+        P2 st = tex_map2d(tx, si, &dstdx, &dstdy);
+        uint32_t a = f2u32(std::floor(st.x)), b = f2u32(std::floor(st.y));
+        return ((a + b) % 2u == 0u) ? tex_eval(sc, tx.tex1, si, depth + 1) : tex_eval(sc, tx.tex2, si, depth + 1);
+    }
+    case RSPT_TEX_DOTS: { // dots.rs:31-72
+        P2 dstdx, dstdy;
+        P2 st = tex_map2d(tx, si, &dstdx, &dstdy);
+        int32_t s_cell = f2i(std::floor(st.x + 0.5f)), t_cell = f2i(std::floor(st.y + 0.5f));
+        if (noise_flt((Float)s_cell + 0.5f, (Float)t_cell + 0.5f, 0.5f) > 0.0f) {
+            const Float radius = 0.35f, max_shift = 0.5f - radius;
+            Float s_center = (Float)s_cell + max_shift * noise_flt((Float)s_cell + 1.5f, (Float)t_cell + 2.8f, 0.5f);
+            Float t_center = (Float)t_cell + max_shift * noise_flt((Float)s_cell + 4.5f, (Float)t_cell + 9.8f, 0.5f);
+            Float dx = st.x - s_center, dy = st.y - t_center;
+            if (dx * dx + dy * dy < radius * radius) return tex_eval(sc, tx.tex2, si, depth + 1); // inside_dot
+        }
+        return tex_eval(sc, tx.tex1, si, depth + 1); // outside_dot
+    }
+    case RSPT_TEX_FBM: { V3 dpdx, dpdy; V3 p = tex_map3d(tx, si, &dpdx, &dpdy); return Spec(fbm(p, dpdx, dpdy, tx.omega, tx.octaves)); }
+    case RSPT_TEX_WRINKLED: { V3 dpdx, dpdy; V3 p = tex_map3d(tx, si, &dpdx, &dpdy); return Spec(turbulence(p, dpdx, dpdy, tx.omega, tx.octaves)); }
+    case RSPT_TEX_WINDY: { // windy.rs:23-37
+        V3 dpdx, dpdy; V3 p = tex_map3d(tx, si, &dpdx, &dpdy);
+        Float wind_strength = fbm(p * 0.1f, dpdx * 0.1f, dpdy * 0.1f, 0.5f, 3);
+        Float wave_height = fbm(p, dpdx, dpdy, 0.5f, 6);
+        return Spec(std::fabs(wind_strength) * wave_height);
+    }
+    case RSPT_TEX_MARBLE: { // marble.rs:43-92
+        V3 dpdx, dpdy; V3 p = tex_map3d(tx, si, &dpdx, &dpdy);
+        p = p * tx.scale;
+        Float marble = p.y + tx.variation * fbm(p, dpdx * tx.scale, dpdy * tx.scale, tx.omega, tx.octaves);
+        Float t = 0.5f + 0.5f * std::sin(marble);
+        static const Float c[9][3] = {{0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.5f, 0.5f, 0.5f}, {0.6f, 0.59f, 0.58f},
+                                      {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.2f, 0.2f, 0.33f}, {0.58f, 0.58f, 0.6f}};
+        uint64_t first = f2usize(std::floor(t * 6.0f));
+        if (first > 5) first = 5;
+        t = t * 6.0f - (Float)first;
+        Spec c0 = S3(c[first]), c1 = S3(c[first + 1]), c2 = S3(c[first + 2]), c3 = S3(c[first + 3]);
+        Spec s0 = c0 * (1.0f - t) + c1 * t, s1 = c1 * (1.0f - t) + c2 * t, s2 = c2 * (1.0f - t) + c3 * t;
+        s0 = s0 * (1.0f - t) + s1 * t;
+        s1 = s1 * (1.0f - t) + s2 * t;
+        return (s0 * (1.0f - t) + s1 * t) * 1.5f;
     }
     }
     return Spec();

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -15,8 +15,8 @@ LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 
 SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
 INTEGRATOR_PATH, INTEGRATOR_AO = 0, 1
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
-TEX_CONSTANT, TEX_IMAGE, TEX_SCALE = 1, 2, 3
-MAP_UV, MAP_PLANAR = 1, 2
+TEX_CONSTANT, TEX_IMAGE, TEX_SCALE, TEX_MIX, TEX_CHECKERBOARD, TEX_DOTS, TEX_FBM, TEX_MARBLE, TEX_WINDY, TEX_WRINKLED = range(1, 11)
+MAP_UV, MAP_PLANAR, MAP_SPHERICAL, MAP_CYLINDRICAL, MAP_IDENTITY3D = 1, 2, 3, 4, 5
 WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
 NO_MATERIAL = 0xFFFFFFFF
 MISS = 0xFFFFFFFF
@@ -53,7 +53,8 @@ class Image(C.Structure):
 class Texture(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("mapping", C.c_uint32), ("map", C.c_float * 8), ("image", C.c_uint32), ("trilinear", C.c_uint32),
                 ("max_aniso", C.c_float), ("wrap", C.c_uint32), ("value", C.c_float * 3), ("tex1", C.c_uint32), ("tex2", C.c_uint32),
-                ("pad", C.c_uint32)]
+                ("tex3", C.c_uint32), ("world_to_texture", C.c_float * 16), ("octaves", C.c_int32), ("omega", C.c_float),
+                ("scale", C.c_float), ("variation", C.c_float)]
 
 
 class Light(C.Structure):
@@ -124,7 +125,8 @@ BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", 
                     ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4")])
 MATERIAL_DT = np.dtype([("eta", "<f4"), ("first_bxdf", "<u4"), ("n_bxdfs", "<u4"), ("bump_tex", "<u4")])
 TEXTURE_DT = np.dtype([("kind", "<u4"), ("mapping", "<u4"), ("map", "<f4", 8), ("image", "<u4"), ("trilinear", "<u4"), ("max_aniso", "<f4"),
-                       ("wrap", "<u4"), ("value", "<f4", 3), ("tex1", "<u4"), ("tex2", "<u4"), ("pad", "<u4")])
+                       ("wrap", "<u4"), ("value", "<f4", 3), ("tex1", "<u4"), ("tex2", "<u4"), ("tex3", "<u4"), ("world_to_texture", "<f4", 16),
+                       ("octaves", "<i4"), ("omega", "<f4"), ("scale", "<f4"), ("variation", "<f4")])
 LIGHT_DT = np.dtype([("kind", "<u4"), ("prim", "<u4"), ("L", "<f4", 3), ("two_sided", "<u4"), ("p", "<f4", 24)])
 RAY_DT = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("id", "<u4")])
 HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4")])
@@ -132,7 +134,7 @@ HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), 
 assert NODE_DT.itemsize == C.sizeof(BvhNode) == 32
 assert PRIM_DT.itemsize == C.sizeof(Prim) == 24
 assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 104
-assert TEXTURE_DT.itemsize == C.sizeof(Texture) == 80
+assert TEXTURE_DT.itemsize == C.sizeof(Texture) == 160
 assert RAY_DT.itemsize == C.sizeof(Ray) == 32
 assert HIT_DT.itemsize == C.sizeof(Hit) == 20
 assert LIGHT_DT.itemsize == C.sizeof(Light) == 120

@@ -138,27 +138,220 @@ RDEV rgb img_lookup(const ImageDev& m, const float* lut, const rspt_texture& tx,
     return col1 * (1.0f - t) + col2 * t;
 }
 
-// ---- Texture::evaluate (constant.rs, imagemap.rs:114-149, scale.rs) + mappings (texture.rs:91-121, 222-257) ----
-RDEV rgb tex_eval_leaf(const TexTables& tt, const rspt_texture& tx, const TexSurf& si) {
-    if (tx.kind == RSPT_TEX_CONSTANT) return ldrgb(tx.value);
-    f2 st, dstdx, dstdy;
+// ---- Perlin noise (texture.rs:21-48 permutation = Ken Perlin's reference table, twice; 289-425) ----
+__device__ const uint8_t NOISE_PERM[512] = {
+#define RSPT_PERLIN_PERM \
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, 247, 120, \
+    234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, \
+    134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, \
+    161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, \
+    250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, \
+    2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, \
+    228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184, 84, \
+    204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180
+    RSPT_PERLIN_PERM, RSPT_PERLIN_PERM
+#undef RSPT_PERLIN_PERM
+};
+RDEV int32_t f2i32(float x) {  // Rust `as i32`
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+RDEV float smooth_step(float mn, float mx, float value) {
+    float v = (value - mn) / (mx - mn);
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return v * v * (-2.0f * v + 3.0f);
+}
+RDEV float noise_grad(int32_t x, int32_t y, int32_t z, float dx, float dy, float dz) {
+    uint32_t h = NOISE_PERM[NOISE_PERM[NOISE_PERM[x] + y] + z] & 15u;
+    float u = (h < 8u || h == 12u || h == 13u) ? dx : dy;
+    float v = (h < 4u || h == 12u || h == 13u) ? dy : dz;
+    return ((h & 1u) ? -u : u) + ((h & 2u) ? -v : v);
+}
+RDEV float noise_weight(float t) { float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }
+__device__ __noinline__ float noise_flt(float x, float y, float z) {
+    int32_t ix = f2i32(floorf(x)), iy = f2i32(floorf(y)), iz = f2i32(floorf(z));
+    float dx = x - (float)ix, dy = y - (float)iy, dz = z - (float)iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    float x00 = lerpf(wx, w000, w100), x10 = lerpf(wx, w010, w110), x01 = lerpf(wx, w001, w101), x11 = lerpf(wx, w011, w111);
+    float y0 = lerpf(wy, x00, x10), y1 = lerpf(wy, x01, x11);
+    return lerpf(wz, y0, y1);
+}
+RDEV float log_2(float x) { return logf(x) * 1.44269504088896340736f; }  // pbrt.rs:153-156
+__device__ __noinline__ float fbm(f3 p, f3 dpdx, f3 dpdy, float omega, int32_t max_octaves) {
+    float l2 = fmaxf(len2(dpdx), len2(dpdy));
+    float n = -1.0f - 0.5f * log_2(l2);
+    n = n < 0.0f ? 0.0f : (n > (float)max_octaves ? (float)max_octaves : n);  // clamp_t
+    int32_t n_int = f2i32(floorf(n));
+    float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (int32_t i = 0; i < n_int; i++) {
+        sum += o * noise_flt(p.x * lambda, p.y * lambda, p.z * lambda);
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    float n_partial = n - (float)n_int;
+    sum += o * smooth_step(0.3f, 0.7f, n_partial) * noise_flt(p.x * lambda, p.y * lambda, p.z * lambda);
+    return sum;
+}
+__device__ __noinline__ float turbulence(f3 p, f3 dpdx, f3 dpdy, float omega, int32_t max_octaves) {
+    float l2 = fmaxf(len2(dpdx), len2(dpdy));
+    float n = -1.0f - 0.5f * log_2(l2);
+    n = n < 0.0f ? 0.0f : (n > (float)max_octaves ? (float)max_octaves : n);
+    float fn = floorf(n);
+    uint32_t n_int = (fn != fn || fn <= 0.0f) ? 0u : (uint32_t)fn;  // `as usize` of a value in [0, max_octaves]
+    float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint32_t i = 0; i < n_int; i++) {
+        sum += o * fabsf(noise_flt(p.x * lambda, p.y * lambda, p.z * lambda));
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    float n_partial = n - (float)n_int;
+    sum += o * lerpf(smooth_step(0.3f, 0.7f, n_partial), 0.2f, fabsf(noise_flt(p.x * lambda, p.y * lambda, p.z * lambda)));
+    for (uint32_t i = n_int; i < (uint32_t)(max_octaves > 0 ? max_octaves : 0); i++) {
+        sum += o * 0.2f;
+        o *= omega;
+    }
+    return sum;
+}
+
+// ---- TextureMapping2D / 3D (texture.rs:51-283) ----
+RDEV f2 map_sphere(const rspt_texture& tx, f3 p) {
+    f3 v = normalize(xf_point(tx.world_to_texture, p) - f3{0.0f, 0.0f, 0.0f});
+    return f2{spherical_theta(v) * RSPT_INV_PI, spherical_phi(v) * 0.15915494309189533577f};
+}
+RDEV f2 map_cylinder(const rspt_texture& tx, f3 p) {
+    f3 v = normalize(xf_point(tx.world_to_texture, p) - f3{0.0f, 0.0f, 0.0f});
+    return f2{RSPT_PI + atan2f(v.y, v.x) * 0.15915494309189533577f, v.z};
+}
+RDEV void wrap_dt(f2* d) {
+    if (d->y > 0.5f) d->y = 1.0f - d->y;
+    else if (d->y < -0.5f) d->y = -(d->y + 1.0f);
+}
+__device__ __noinline__ f2 tex_map2d(const rspt_texture& tx, const TexSurf& si, f2* dstdx, f2* dstdy) {
     if (tx.mapping == RSPT_MAP_PLANAR) {
         f3 vs{tx.map[0], tx.map[1], tx.map[2]}, vt{tx.map[3], tx.map[4], tx.map[5]};
-        dstdx = f2{dot(si.dpdx, vs), dot(si.dpdx, vt)};
-        dstdy = f2{dot(si.dpdy, vs), dot(si.dpdy, vt)};
-        st = f2{tx.map[6] + dot(si.p, vs), tx.map[7] + dot(si.p, vt)};
-    } else {
-        dstdx = f2{si.dudx * tx.map[0], si.dvdx * tx.map[1]};
-        dstdy = f2{si.dudy * tx.map[0], si.dvdy * tx.map[1]};
-        st = f2{si.uv.x * tx.map[0] + tx.map[2], si.uv.y * tx.map[1] + tx.map[3]};
+        *dstdx = f2{dot(si.dpdx, vs), dot(si.dpdx, vt)};
+        *dstdy = f2{dot(si.dpdy, vs), dot(si.dpdy, vt)};
+        return f2{tx.map[6] + dot(si.p, vs), tx.map[7] + dot(si.p, vt)};
     }
-    return img_lookup(tt.images[tx.image], tt.ewa_lut, tx, st, dstdx, dstdy);
+    if (tx.mapping == RSPT_MAP_SPHERICAL) {
+        f2 st = map_sphere(tx, si.p);
+        const float delta = 0.1f;
+        f2 sx = map_sphere(tx, si.p + si.dpdx * delta);
+        *dstdx = f2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        f2 sy = map_sphere(tx, si.p + si.dpdy * delta);
+        *dstdy = f2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        wrap_dt(dstdx); wrap_dt(dstdy);
+        return st;
+    }
+    if (tx.mapping == RSPT_MAP_CYLINDRICAL) {
+        f2 st = map_cylinder(tx, si.p);
+        const float delta = 0.01f;
+        f2 sx = map_cylinder(tx, si.p + si.dpdx * delta);
+        *dstdx = f2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        wrap_dt(dstdx);
+        f2 sy = map_cylinder(tx, si.p + si.dpdy * delta);
+        *dstdy = f2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        wrap_dt(dstdy);
+        return st;
+    }
+    *dstdx = f2{si.dudx * tx.map[0], si.dvdx * tx.map[1]};
+    *dstdy = f2{si.dudy * tx.map[0], si.dvdy * tx.map[1]};
+    return f2{si.uv.x * tx.map[0] + tx.map[2], si.uv.y * tx.map[1] + tx.map[3]};
 }
-RDEVN rgb tex_eval(const TexTables& tt, uint32_t ti, const TexSurf& si) {
+RDEV f3 tex_map3d(const rspt_texture& tx, const TexSurf& si, f3* dpdx, f3* dpdy) {
+    *dpdx = xf_vector(tx.world_to_texture, si.dpdx);
+    *dpdy = xf_vector(tx.world_to_texture, si.dpdy);
+    return xf_point(tx.world_to_texture, si.p);
+}
+
+// ---- Texture::evaluate (src/textures/*.rs).  DEPTH = levels of children still allowed below this node; the host
+// rejects deeper graphs (rspt_scene_create), so the recursion is a fixed three-deep chain of functions ----
+template <int DEPTH>
+__device__ __noinline__ rgb tex_eval_d(const TexTables& tt, uint32_t ti, const TexSurf& si) {
     const rspt_texture tx = tt.textures[ti];
-    if (tx.kind == RSPT_TEX_SCALE) return tex_eval_leaf(tt, tt.textures[tx.tex1], si) * tex_eval_leaf(tt, tt.textures[tx.tex2], si);
-    return tex_eval_leaf(tt, tx, si);
+    // which children this node needs (one call site below, so the code of a level exists once)
+    uint32_t kid[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    uint32_t n_kids = 0;
+    if (tx.kind == RSPT_TEX_SCALE) { kid[0] = tx.tex1; kid[1] = tx.tex2; n_kids = 2; }
+    else if (tx.kind == RSPT_TEX_MIX) { kid[0] = tx.tex1; kid[1] = tx.tex2; kid[2] = tx.tex3; n_kids = 3; }
+    else if (tx.kind == RSPT_TEX_CHECKERBOARD) {  // checkerboard.rs:32-42
+        f2 dstdx, dstdy;
+        f2 st = tex_map2d(tx, si, &dstdx, &dstdy);
+        float fa = floorf(st.x), fb = floorf(st.y);
+        uint32_t a = (fa != fa || fa <= 0.0f) ? 0u : (fa >= 4294967296.0f ? 0xffffffffu : (uint32_t)fa);  // `as u32`
+        uint32_t b = (fb != fb || fb <= 0.0f) ? 0u : (fb >= 4294967296.0f ? 0xffffffffu : (uint32_t)fb);
+        kid[0] = ((a + b) % 2u == 0u) ? tx.tex1 : tx.tex2;
+        n_kids = 1;
+    } else if (tx.kind == RSPT_TEX_DOTS) {  // dots.rs:31-72: tex1 = outside, tex2 = inside
+        f2 dstdx, dstdy;
+        f2 st = tex_map2d(tx, si, &dstdx, &dstdy);
+        int32_t s_cell = f2i32(floorf(st.x + 0.5f)), t_cell = f2i32(floorf(st.y + 0.5f));
+        kid[0] = tx.tex1;
+        if (noise_flt((float)s_cell + 0.5f, (float)t_cell + 0.5f, 0.5f) > 0.0f) {
+            const float radius = 0.35f, max_shift = 0.5f - radius;
+            float s_center = (float)s_cell + max_shift * noise_flt((float)s_cell + 1.5f, (float)t_cell + 2.8f, 0.5f);
+            float t_center = (float)t_cell + max_shift * noise_flt((float)s_cell + 4.5f, (float)t_cell + 9.8f, 0.5f);
+            float dx = st.x - s_center, dy = st.y - t_center;
+            if (dx * dx + dy * dy < radius * radius) kid[0] = tx.tex2;
+        }
+        n_kids = 1;
+    }
+    if (n_kids) {
+        rgb v[3] = {mkrgb(0.0f), mkrgb(0.0f), mkrgb(0.0f)};
+        if constexpr (DEPTH > 0) {
+#pragma unroll 1
+            for (uint32_t k = 0; k < n_kids; k++) {
+                rgb r = tex_eval_d<DEPTH - 1>(tt, kid[k], si);
+                if (k == 0) v[0] = r; else if (k == 1) v[1] = r; else v[2] = r;
+            }
+        }
+        if (tx.kind == RSPT_TEX_SCALE) return v[0] * v[1];                                      // scale.rs:24-27
+        if (tx.kind == RSPT_TEX_MIX) return v[0] * mkrgb(1.0f - v[2].r) + v[1] * mkrgb(v[2].r);  // mix.rs:30-35
+        return v[0];
+    }
+    switch (tx.kind) {
+    case RSPT_TEX_CONSTANT: return ldrgb(tx.value);
+    case RSPT_TEX_IMAGE: {
+        f2 dstdx, dstdy;
+        f2 st = tex_map2d(tx, si, &dstdx, &dstdy);
+        return img_lookup(tt.images[tx.image], tt.ewa_lut, tx, st, dstdx, dstdy);
+    }
+    case RSPT_TEX_FBM: { f3 dpdx, dpdy; f3 p = tex_map3d(tx, si, &dpdx, &dpdy); return mkrgb(fbm(p, dpdx, dpdy, tx.omega, tx.octaves)); }
+    case RSPT_TEX_WRINKLED: { f3 dpdx, dpdy; f3 p = tex_map3d(tx, si, &dpdx, &dpdy); return mkrgb(turbulence(p, dpdx, dpdy, tx.omega, tx.octaves)); }
+    case RSPT_TEX_WINDY: {  // windy.rs:23-37
+        f3 dpdx, dpdy; f3 p = tex_map3d(tx, si, &dpdx, &dpdy);
+        float wind_strength = fbm(p * 0.1f, dpdx * 0.1f, dpdy * 0.1f, 0.5f, 3);
+        float wave_height = fbm(p, dpdx, dpdy, 0.5f, 6);
+        return mkrgb(fabsf(wind_strength) * wave_height);
+    }
+    case RSPT_TEX_MARBLE: {  // marble.rs:43-92
+        f3 dpdx, dpdy; f3 p = tex_map3d(tx, si, &dpdx, &dpdy);
+        p = p * tx.scale;
+        float marble = p.y + tx.variation * fbm(p, dpdx * tx.scale, dpdy * tx.scale, tx.omega, tx.octaves);
+        float t = 0.5f + 0.5f * sinf(marble);
+        float ff = floorf(t * 6.0f);
+        uint32_t first = (ff != ff || ff <= 0.0f) ? 0u : (ff >= 5.0f ? 5u : (uint32_t)ff);
+        t = t * 6.0f - (float)first;
+        // control points c[first .. first + 3] of {A A A G W A A B A}: A = (.58 .58 .6), G = (.5 .5 .5), W = (.6 .59 .58), B = (.2 .2 .33)
+        auto col = [](uint32_t k) { return k == 3u ? rgb{0.5f, 0.5f, 0.5f} : (k == 4u ? rgb{0.6f, 0.59f, 0.58f} : (k == 7u ? rgb{0.2f, 0.2f, 0.33f} : rgb{0.58f, 0.58f, 0.6f})); };
+        rgb c0 = col(first), c1 = col(first + 1), c2 = col(first + 2), c3 = col(first + 3);
+        rgb s0 = c0 * (1.0f - t) + c1 * t, s1 = c1 * (1.0f - t) + c2 * t, s2 = c2 * (1.0f - t) + c3 * t;
+        s0 = s0 * (1.0f - t) + s1 * t;
+        s1 = s1 * (1.0f - t) + s2 * t;
+        return (s0 * (1.0f - t) + s1 * t) * 1.5f;
+    }
+    default: return mkrgb(0.0f);
+    }
 }
+#define RSPT_TEX_MAX_DEPTH 3  // nodes on the longest path of a texture graph
+RDEV rgb tex_eval(const TexTables& tt, uint32_t ti, const TexSurf& si) { return tex_eval_d<RSPT_TEX_MAX_DEPTH - 1>(tt, ti, si); }
 
 // Triangle::intersect's interaction (triangle.rs:274-448) with everything textures and bump mapping read
 struct TexHit {

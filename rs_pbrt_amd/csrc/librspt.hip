@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <string>
@@ -676,19 +677,35 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         if (im.n_levels != nl || nl > 16) return fail(RSPT_E_INVALID, "image %u: n_levels %u, expected %u", i, im.n_levels, nl);
         if (!im.texels || (im.channels != 1 && im.channels != 3)) return fail(RSPT_E_INVALID, "image %u: null texels or channels not 1 / 3", i);
     }
-    for (uint32_t i = 0; i < d->n_textures; i++) {
-        const rspt_texture& t = d->textures[i];
-        if (t.kind == RSPT_TEX_CONSTANT) continue;
-        if (t.kind == RSPT_TEX_IMAGE) {
-            if (t.image >= d->n_images) return fail(RSPT_E_INVALID, "texture %u: image index out of range", i);
-            if (t.mapping != RSPT_MAP_UV && t.mapping != RSPT_MAP_PLANAR) return fail(RSPT_E_UNSUPPORTED, "texture %u: mapping %u (uv and planar only)", i, t.mapping);
-            if (t.wrap > RSPT_WRAP_CLAMP) return fail(RSPT_E_INVALID, "texture %u: bad wrap mode", i);
-        } else if (t.kind == RSPT_TEX_SCALE) {
-            if (t.tex1 >= d->n_textures || t.tex2 >= d->n_textures) return fail(RSPT_E_INVALID, "texture %u: child index out of range", i);
-            if (d->textures[t.tex1].kind == RSPT_TEX_SCALE || d->textures[t.tex2].kind == RSPT_TEX_SCALE)
-                return fail(RSPT_E_UNSUPPORTED, "texture %u: nested scale textures", i);
-        } else
-            return fail(RSPT_E_UNSUPPORTED, "texture %u: unsupported kind %u", i, t.kind);
+    {   // texture graph: kinds, mappings, child indices, depth (dev_texture.h evaluates at most RSPT_TEX_MAX_DEPTH levels)
+        std::vector<int> depth(d->n_textures, 0);  // 0 = not computed, -1 = on the current path (cycle)
+        std::function<int(uint32_t)> depth_of = [&](uint32_t i) -> int {
+            if (depth[i] > 0) return depth[i];
+            if (depth[i] < 0) return 1000;
+            depth[i] = -1;
+            const rspt_texture& t = d->textures[i];
+            int dmax = 0;
+            const uint32_t kids[3] = {t.tex1, t.tex2, t.tex3};
+            const int n_kids = t.kind == RSPT_TEX_MIX ? 3 : ((t.kind == RSPT_TEX_SCALE || t.kind == RSPT_TEX_CHECKERBOARD || t.kind == RSPT_TEX_DOTS) ? 2 : 0);
+            for (int k = 0; k < n_kids; k++) dmax = std::max(dmax, kids[k] < d->n_textures ? depth_of(kids[k]) : 1000);
+            return depth[i] = 1 + dmax;
+        };
+        for (uint32_t i = 0; i < d->n_textures; i++) {
+            const rspt_texture& t = d->textures[i];
+            if (t.kind < RSPT_TEX_CONSTANT || t.kind > RSPT_TEX_WRINKLED) return fail(RSPT_E_UNSUPPORTED, "texture %u: unsupported kind %u", i, t.kind);
+            const bool map2d = t.kind == RSPT_TEX_IMAGE || t.kind == RSPT_TEX_CHECKERBOARD || t.kind == RSPT_TEX_DOTS;
+            const bool map3d = t.kind == RSPT_TEX_FBM || t.kind == RSPT_TEX_MARBLE || t.kind == RSPT_TEX_WINDY || t.kind == RSPT_TEX_WRINKLED;
+            if (map2d && (t.mapping < RSPT_MAP_UV || t.mapping > RSPT_MAP_CYLINDRICAL)) return fail(RSPT_E_UNSUPPORTED, "texture %u: 2-D mapping %u", i, t.mapping);
+            if (map3d && t.mapping != RSPT_MAP_IDENTITY3D) return fail(RSPT_E_UNSUPPORTED, "texture %u: 3-D textures take the identity mapping", i);
+            if (map3d && (t.octaves < 0 || t.octaves > 64)) return fail(RSPT_E_INVALID, "texture %u: octaves out of range", i);
+            if (t.kind == RSPT_TEX_IMAGE) {
+                if (t.image >= d->n_images) return fail(RSPT_E_INVALID, "texture %u: image index out of range", i);
+                if (t.wrap > RSPT_WRAP_CLAMP) return fail(RSPT_E_INVALID, "texture %u: bad wrap mode", i);
+            }
+            const int dep = depth_of(i);
+            if (dep >= 1000) return fail(RSPT_E_INVALID, "texture %u: child index out of range or cyclic graph", i);
+            if (dep > RSPT_TEX_MAX_DEPTH) return fail(RSPT_E_UNSUPPORTED, "texture %u: graph deeper than %d levels", i, RSPT_TEX_MAX_DEPTH);
+        }
     }
     for (uint32_t i = 0; i < d->n_bxdfs; i++)
         if (d->bxdfs[i].tex_r > d->n_textures || d->bxdfs[i].tex_t > d->n_textures) return fail(RSPT_E_INVALID, "bxdf %u: texture index out of range", i);

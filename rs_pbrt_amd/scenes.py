@@ -513,17 +513,54 @@ class SceneBuilder:
         return self._add_texture(kind=abi.TEX_SCALE, tex1=t1.index, tex2=t2.index)
 
     def image_texture(self, texels, mapping="uv", su=1.0, sv=1.0, du=0.0, dv=0.0, v1=(1, 0, 0), v2=(0, 1, 0), trilinear=False,
-                      max_aniso=8.0, wrap="repeat", scale=1.0, gamma=False, channels=3):
+                      max_aniso=8.0, wrap="repeat", scale=1.0, gamma=False, channels=3, world_to_texture=None):
         """Texture "imagemap" (api.rs get_texture / imagemap.rs): texels (h, w, 3) in file order (row 0 = top)."""
         wm = {"repeat": abi.WRAP_REPEAT, "black": abi.WRAP_BLACK, "clamp": abi.WRAP_CLAMP}[wrap]
         self.images.append(build_image(texels, wm, scale, gamma, channels))
+        return self._add_texture(kind=abi.TEX_IMAGE, image=len(self.images) - 1, trilinear=int(trilinear), max_aniso=max_aniso, wrap=wm,
+                                 **self._mapping2d(mapping, su, sv, du, dv, v1, v2, world_to_texture))
+
+    @staticmethod
+    def _mapping2d(mapping, su=1.0, sv=1.0, du=0.0, dv=0.0, v1=(1, 0, 0), v2=(0, 1, 0), world_to_texture=None):
+        """TextureParams -> TextureMapping2D (api.rs get_texture_mapping_2d): "uv", "planar", "spherical", "cylindrical";
+        world_to_texture: 4x4 row-major (the CTM inverse at the Texture directive), identity if None"""
         m = np.zeros(8, F32)
+        w2t = np.eye(4, dtype=F32) if world_to_texture is None else np.asarray(world_to_texture, F32).reshape(4, 4)
         if mapping == "uv":
             mk = abi.MAP_UV; m[:4] = (su, sv, du, dv)
-        else:
+        elif mapping == "planar":
             mk = abi.MAP_PLANAR; m[:3] = v1; m[3:6] = v2; m[6:8] = (du, dv)
-        return self._add_texture(kind=abi.TEX_IMAGE, mapping=mk, map=m, image=len(self.images) - 1, trilinear=int(trilinear),
-                                 max_aniso=max_aniso, wrap=wm)
+        else:
+            mk = {"spherical": abi.MAP_SPHERICAL, "cylindrical": abi.MAP_CYLINDRICAL}[mapping]
+        return dict(mapping=mk, map=m, world_to_texture=w2t.reshape(-1))
+
+    def mix_texture(self, t1, t2, amount):
+        """MixTexture (mix.rs): amount is a float texture (TexRef) or a number"""
+        amt = amount if isinstance(amount, TexRef) else self.constant_texture(amount)
+        return self._add_texture(kind=abi.TEX_MIX, tex1=t1.index, tex2=t2.index, tex3=amt.index)
+
+    def checkerboard_texture(self, t1, t2, mapping="uv", **kw):
+        """Checkerboard2DTexture (checkerboard.rs; "dimension" 2, no anti-aliasing in the reference)"""
+        return self._add_texture(kind=abi.TEX_CHECKERBOARD, tex1=t1.index, tex2=t2.index, **self._mapping2d(mapping, **kw))
+
+    def dots_texture(self, outside, inside, mapping="uv", **kw):
+        return self._add_texture(kind=abi.TEX_DOTS, tex1=outside.index, tex2=inside.index, **self._mapping2d(mapping, **kw))
+
+    def _tex3d(self, kind, world_to_texture=None, **kw):
+        w2t = np.eye(4, dtype=F32) if world_to_texture is None else np.asarray(world_to_texture, F32).reshape(4, 4)
+        return self._add_texture(kind=kind, mapping=abi.MAP_IDENTITY3D, world_to_texture=w2t.reshape(-1), **kw)
+
+    def fbm_texture(self, octaves=8, omega=0.5, world_to_texture=None):  # fbm.rs
+        return self._tex3d(abi.TEX_FBM, world_to_texture, octaves=octaves, omega=omega)
+
+    def wrinkled_texture(self, octaves=8, omega=0.5, world_to_texture=None):  # wrinkled.rs
+        return self._tex3d(abi.TEX_WRINKLED, world_to_texture, octaves=octaves, omega=omega)
+
+    def windy_texture(self, world_to_texture=None):  # windy.rs
+        return self._tex3d(abi.TEX_WINDY, world_to_texture)
+
+    def marble_texture(self, octaves=8, omega=0.5, scale=1.0, variation=0.2, world_to_texture=None):  # marble.rs
+        return self._tex3d(abi.TEX_MARBLE, world_to_texture, octaves=octaves, omega=omega, scale=scale, variation=variation)
 
     def add_material(self, m):
         self.materials.append(m)

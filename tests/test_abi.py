@@ -48,7 +48,7 @@ int main(void) {
   O(rspt_scene_desc, P); O(rspt_scene_desc, materials); O(rspt_scene_desc, lights); O(rspt_stats, alg_bytes);
   O(rspt_bxdf, alpha_x); O(rspt_bxdf, on_a); O(rspt_bxdf, tex_r); O(rspt_bxdf, tex_t); O(rspt_material, bump_tex);
   O(rspt_scene_desc, textures); O(rspt_scene_desc, images); O(rspt_scene_desc, n_images);
-  O(rspt_texture, map); O(rspt_texture, image); O(rspt_texture, max_aniso); O(rspt_texture, value); O(rspt_texture, tex2); O(rspt_image, texels);
+  O(rspt_texture, map); O(rspt_texture, image); O(rspt_texture, max_aniso); O(rspt_texture, value); O(rspt_texture, tex2); O(rspt_texture, tex3); O(rspt_texture, world_to_texture); O(rspt_texture, octaves); O(rspt_texture, variation); O(rspt_image, texels);
   return 0; }'''
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "p.c"), "w").write(probe)

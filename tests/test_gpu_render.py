@@ -287,6 +287,22 @@ def test_textured_materials_match_oracle(gpu, oracle, trilinear, wrap, bump):
     assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
 
 
+def test_procedural_textures_and_mappings_match_oracle(gpu, oracle):
+    """checkerboard, dots, mix, fbm, marble, windy, wrinkled, spherical / cylindrical mappings, a three-level texture graph
+    and a procedural bump map.  Perlin noise is integer hashing + polynomials (bit-exact); logf of the octave count,
+    sinf of marble, acosf / atan2f of the spherical mappings carry the usual last-ulp differences, amplified by the
+    discontinuities of checker / dots edges only where a sample sits exactly on one."""
+    from tests.util import PROCEDURAL_LOOK_AT, procedural_room
+    sc = procedural_room(gpu.bvh_build)
+    rd = scenes.make_render_desc(96, 64, 16, PROCEDURAL_LOOK_AT, 50, max_depth=3)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert (li == ref["li"]).all(axis=2).mean() > 0.6
+    assert np.abs(li - ref["li"]).mean() < 2e-5
+    assert film_rmse(film, ref["film"]) < 2e-4
+    assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
+
+
 def test_textures_change_the_image_and_lens_differentials(gpu, oracle):
     """thin-lens camera differentials (perspective.rs:245-271) + Halton sampler on the textured room; and the
     textures must matter: the same room with constant colours renders a different film"""
@@ -308,16 +324,29 @@ def test_texture_validation(gpu):
     import ctypes as C
     from tests.util import textured_room
     L = gpu.lib()
-    for breaker in ("image", "child", "slots"):
+    for breaker, code in (("image", abi.E_INVALID), ("child", abi.E_INVALID), ("slots", abi.E_INVALID), ("cycle", abi.E_INVALID), ("deep", abi.E_UNSUPPORTED),
+                          ("kind", abi.E_UNSUPPORTED), ("mapping", abi.E_UNSUPPORTED)):
         sc = textured_room(gpu.bvh_build)
+        k = int(np.nonzero(sc.textures["kind"] == abi.TEX_SCALE)[0][0])
         if breaker == "image":
             sc.textures["image"][0] = 99
         elif breaker == "child":
-            k = int(np.nonzero(sc.textures["kind"] == abi.TEX_SCALE)[0][0]); sc.textures["tex1"][k] = 1000
+            sc.textures["tex1"][k] = 1000
+        elif breaker == "cycle":
+            sc.textures["tex1"][k] = k
+        elif breaker == "deep":  # scale(scale(scale(scale(...)))) four levels: make three more scale nodes point at each other in a chain
+            leaf = int(np.nonzero(sc.textures["kind"] == abi.TEX_CONSTANT)[0][0])
+            chain = [i for i in range(len(sc.textures)) if i not in (k, leaf)][:3]
+            for a, b in zip([k] + chain, chain + [leaf]):
+                sc.textures["kind"][a] = abi.TEX_SCALE; sc.textures["tex1"][a] = b; sc.textures["tex2"][a] = leaf
+        elif breaker == "kind":
+            sc.textures["kind"][0] = 42
+        elif breaker == "mapping":
+            sc.textures["mapping"][0] = abi.MAP_IDENTITY3D
         else:
             sc.bxdfs["tex_r"][0] = 77
         h = C.c_void_p()
-        assert L.rspt_scene_create(C.addressof(sc.desc), C.addressof(h)) == abi.E_INVALID
+        assert L.rspt_scene_create(C.addressof(sc.desc), C.addressof(h)) == code, breaker
 
 
 def test_golden_textured_room(gpu):

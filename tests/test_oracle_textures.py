@@ -173,3 +173,56 @@ def test_textured_lobe_is_dropped_when_black(oracle):
     # outer image columns: u < 0.25 (pure black texel under clamp) vs u > 0.75 (pure white)
     a, b = rgb[:, :5].mean(), rgb[:, -5:].mean()
     assert min(a, b) == 0.0 and max(a, b) > 0.05
+
+
+def test_procedural_textures_closed_forms(oracle):
+    """checkerboard (checkerboard.rs: floor-parity, no anti-aliasing), mix (mix.rs), Perlin noise properties
+    (texture.rs:294-364: zero on the integer lattice, within [-1, 1]), fbm / turbulence octave logic (366-424),
+    dots (dots.rs), marble range, spherical / cylindrical mappings (texture.rs:123-220)"""
+    sb = scenes.SceneBuilder()
+    a, b = sb.constant_texture((0.8, 0.1, 0.1)), sb.constant_texture((0.1, 0.1, 0.8))
+    ck = sb.checkerboard_texture(a, b, su=4.0, sv=4.0)
+    mx = sb.mix_texture(a, b, 0.25)
+    fb, wr, wi, mb = sb.fbm_texture(), sb.wrinkled_texture(octaves=4), sb.windy_texture(), sb.marble_texture(scale=2.0)
+    fb1 = sb.fbm_texture(octaves=1)
+    dt = sb.dots_texture(a, b, su=6, sv=6)
+    img = np.zeros((2, 4, 3), F32); img[:, :, 0] = np.arange(4)[None, :] / 4.0  # red = column index / 4
+    sph = sb.image_texture(img, mapping="spherical", wrap="clamp", trilinear=True)
+    cyl = sb.image_texture(img, mapping="cylindrical", wrap="clamp", trilinear=True)
+    sc = _scene(sb, oracle)
+    red, blue = np.array([0.8, 0.1, 0.1], F32), np.array([0.1, 0.1, 0.8], F32)
+    for u, v, want in ((0.1, 0.1, red), (0.3, 0.1, blue), (0.3, 0.3, red), (0.6, 0.3, blue), (0.99, 0.99, red)):
+        assert np.array_equal(oracle.tex_eval(sc, ck, uv=(u, v)), want)
+    assert np.allclose(oracle.tex_eval(sc, mx), 0.75 * red + 0.25 * blue, atol=1e-7)
+    # noise: zero on the lattice (all gradients dotted with zero offsets), so fbm with any octave count is zero there
+    assert oracle.tex_eval(sc, fb1, p=(3.0, -2.0, 7.0), dpdx=(0.3, 0, 0), dpdy=(0, 0.3, 0))[0] == 0.0
+    rng = np.random.default_rng(3)
+    vals = np.array([oracle.tex_eval(sc, fb1, p=tuple(rng.uniform(-5, 5, 3)), dpdx=(0.3, 0, 0), dpdy=(0, 0.3, 0))[0] for _ in range(300)])
+    assert np.abs(vals).max() <= 1.0 and vals.std() > 0.05 and abs(vals.mean()) < 0.1
+    # octaves: n = clamp(-1 - log2(|dp|^2) / 2, 0, max); |dp| = 1/2 gives n = 0: only the partial octave with smooth_step(0) = 0
+    assert oracle.tex_eval(sc, fb, p=(0.3, 0.4, 0.5), dpdx=(0.5, 0, 0), dpdy=(0, 0.5, 0))[0] == 0.0
+    # turbulence adds 0.2 * omega^i for the octaves beyond n (texture.rs:418-422): with n = 0 that is 0.2 * (1 + .5 + .25 + .125) + 0.2
+    w0 = oracle.tex_eval(sc, wr, p=(0.3, 0.4, 0.5), dpdx=(0.5, 0, 0), dpdy=(0, 0.5, 0))[0]
+    assert abs(w0 - (0.2 + 0.2 * (1 + 0.5 + 0.25 + 0.125))) < 1e-6
+    # no differentials: log2(0) = -inf -> all octaves; windy = |fbm(p / 10, 3 octaves)| * fbm(p, 6 octaves)
+    p = (0.37, 1.71, -2.2)
+    assert abs(oracle.tex_eval(sc, wi, p=p)[0]) < 1.0
+    m = oracle.tex_eval(sc, mb, p=p)
+    assert (m > 0.25).all() and (m < 1.0).all()  # Bezier over control points in [0.2, 0.6], times 1.5
+    inside = [oracle.tex_eval(sc, dt, uv=(u, 0.33))[0] for u in np.linspace(0, 1, 200)]
+    assert 0.02 < np.mean(np.array(inside) < 0.5) < 0.9  # some samples fall inside dots (blue = inside -> red channel 0.1)
+    # spherical: st = (theta / pi, phi / 2 pi); p on +x: theta = pi / 2, phi = 0 -> s = 0.5 -> between columns 1 and 2
+    v = oracle.tex_eval(sc, sph, p=(2.0, 0.0, 0.0))[0]
+    assert abs(v - 0.375) < 1e-6
+    # cylindrical: s = pi + atan2(y, x) / 2 pi (texture.rs:188: as written), far beyond 1 -> clamp to the last column
+    assert oracle.tex_eval(sc, cyl, p=(2.0, 0.0, 0.3))[0] == 0.75
+
+
+def test_texture_graph_depth_and_cycles_rejected():
+    """the device evaluates graphs up to three levels; deeper ones and cycles must be refused by the host (checked on the
+    GPU in test_texture_validation); here: the builder produces the depths we think"""
+    sb = scenes.SceneBuilder()
+    a, b = sb.constant_texture(0.2), sb.constant_texture(0.7)
+    l2 = sb.scale_texture(a, b)
+    l3 = sb.mix_texture(l2, a, 0.5)
+    assert [int(t["kind"]) for t in sb.textures][-1] == abi.TEX_MIX and sb.textures[l3.index]["tex1"] == l2.index

@@ -144,10 +144,15 @@ def random_scene(builder, seed):
     tex = [sb.image_texture(img, su=float(rng.uniform(0.5, 4)), sv=float(rng.uniform(0.5, 4)), trilinear=bool(rng.integers(2)), wrap=["repeat", "clamp", "black"][int(rng.integers(3))]),
            sb.scale_texture(sb.image_texture(img[::-1].copy(), gamma=True), sb.constant_texture(col())),
            sb.image_texture(img, mapping="planar", v1=col(-0.5, 0.5), v2=col(-0.5, 0.5), du=0.3, dv=0.1)]
-    height = sb.image_texture(img, channels=1, scale=0.05, trilinear=True)
+    tex += [sb.checkerboard_texture(tex[0], sb.constant_texture(col()), su=float(rng.uniform(2, 8)), sv=float(rng.uniform(2, 8))),
+            sb.marble_texture(scale=float(rng.uniform(1, 4))),
+            sb.mix_texture(sb.constant_texture(col()), sb.constant_texture(col()), sb.fbm_texture(octaves=int(rng.integers(2, 8)))),
+            sb.dots_texture(sb.constant_texture(col()), tex[1], su=6.0, sv=6.0),
+            sb.image_texture(img, mapping=["spherical", "cylindrical"][int(rng.integers(2))])]
+    height = sb.image_texture(img, channels=1, scale=0.05, trilinear=True) if rng.random() < 0.5 else sb.scale_texture(sb.wrinkled_texture(octaves=4), sb.constant_texture(0.1))
 
     def kd():
-        return tex[int(rng.integers(3))] if rng.random() < 0.4 else col()
+        return tex[int(rng.integers(len(tex)))] if rng.random() < 0.45 else col()
 
     def material():
         k = int(rng.integers(12))
@@ -188,3 +193,39 @@ def random_scene(builder, seed):
     if rng.random() < 0.3: sb.add_distant_light((1, 3, -2), (0, 0, 0), col(0.2, 0.8))
     if rng.random() < 0.3: sb.add_infinite_light(col(0.1, 0.5))
     return sb.finish(builder)
+
+
+def procedural_room(builder):
+    """every texture class of src/textures/ on its own slab: checkerboard (of an image and a constant), dots, mix with
+    an fbm amount, marble, wrinkled / windy / fbm as scale factors, spherical + cylindrical image mappings, a three-level
+    graph, a windy bump map"""
+    sb = scenes.SceneBuilder()
+    img = texture_image()
+    c1, c2, c3 = sb.constant_texture((0.8, 0.2, 0.15)), sb.constant_texture((0.15, 0.25, 0.8)), sb.constant_texture((0.9, 0.9, 0.85))
+    im = sb.image_texture(img, su=2.0, sv=2.0, trilinear=True)
+    rot = scenes.Transform.look_at((0.2, 0.3, -0.1), (1, 0.5, 2), (0, 1, 0)).m  # some world_to_texture
+    kinds = [
+        sb.checkerboard_texture(im, c2, su=5.0, sv=4.0),
+        sb.dots_texture(c3, c1, su=7.0, sv=7.0),
+        sb.mix_texture(c1, c2, sb.fbm_texture(octaves=5, omega=0.6, world_to_texture=scenes.Transform.scale(3, 3, 3).m)),
+        sb.marble_texture(scale=3.0, variation=0.3),
+        sb.scale_texture(c3, sb.wrinkled_texture(octaves=6, world_to_texture=scenes.Transform.scale(2, 2, 2).m)),
+        sb.image_texture(img, mapping="spherical", world_to_texture=rot),
+        sb.image_texture(img, mapping="cylindrical", world_to_texture=rot, trilinear=True),
+        sb.checkerboard_texture(sb.scale_texture(im, c3), sb.mix_texture(c1, c2, 0.3), mapping="planar", v1=(1.5, 0, 0), v2=(0, 1.5, 0)),  # depth 3
+    ]
+    bump = sb.scale_texture(sb.windy_texture(world_to_texture=scenes.Transform.scale(4, 4, 4).m), sb.constant_texture(0.2))
+    white = sb.add_material(scenes.matte((0.7, 0.7, 0.7)))
+    q = sb.add_quad
+    uvq = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    q([(-6, 0, -5), (6, 0, -5), (6, 0, 6), (-6, 0, 6)], sb.add_material(scenes.matte(kinds[0], bump=bump)), UV=uvq, N=[[0, 1, 0]] * 4)
+    q([(-6, 0, 6), (6, 0, 6), (6, 7, 6), (-6, 7, 6)], sb.add_material(scenes.matte(kinds[3])), UV=uvq)
+    for i, t in enumerate([kinds[1], kinds[2], kinds[4], kinds[5], kinds[6], kinds[7]]):
+        x = -5.2 + 1.8 * i
+        mat = scenes.plastic(t, (0.2, 0.2, 0.2), 0.15) if i % 2 else scenes.matte(t)
+        q([(x, 0.3, 2 + 0.2 * i), (x + 1.5, 0.3, 2 + 0.2 * i), (x + 1.5, 3.2, 2.9 + 0.2 * i), (x, 3.2, 2.9 + 0.2 * i)], sb.add_material(mat), UV=uvq)
+    q([(-1.5, 6.9, -1.5), (1.5, 6.9, -1.5), (1.5, 6.9, 1.5), (-1.5, 6.9, 1.5)], white, emit=(14, 14, 14))
+    return sb.finish(builder)
+
+
+PROCEDURAL_LOOK_AT = ((0, 3.0, -4.8), (0, 1.8, 2), (0, 1, 0))
