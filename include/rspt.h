@@ -373,6 +373,12 @@ int64_t rspt_bvh_build(const float* P, const uint32_t* tri_idx, uint64_t n_tris,
                        uint32_t* ordered_out, int32_t n_threads);
 const char* rspt_bvh_last_error(void);
 
+/* The same build on the GPU: every node of a tree level is split in one pass over the primitives
+ * (segmented bounds / bucket reductions, scan-based order-preserving partition).  Same arguments, same result bit for bit
+ * as rspt_bvh_build; n_vertices sizes the upload of P.  Needs rspt_init.  Errors through rspt_last_error. */
+int64_t rspt_bvh_build_gpu(const float* P, uint64_t n_vertices, const uint32_t* tri_idx, uint64_t n_tris,
+                           uint32_t max_prims_in_node, rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out);
+
 const char* rspt_last_error(void);
 
 #ifdef __cplusplus

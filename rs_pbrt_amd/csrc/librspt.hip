@@ -19,6 +19,7 @@
 #include "../../include/rspt.h"
 #include "kernels.h"
 #include "trace_w4.h"
+#include "bvh_device.h"
 
 using namespace rspt;
 
@@ -600,6 +601,98 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
 extern "C" {
 
 int rspt_abi_version(void) { return RSPT_ABI_VERSION; }
+// Replaces: BVHAccel::new (bvh.rs:96-392), on the device; see bvh_device.h
+int64_t rspt_bvh_build_gpu(const float* P, uint64_t n_vertices, const uint32_t* tri_idx, uint64_t n_tris, uint32_t max_prims_in_node,
+                           rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out) {
+    using namespace rspt::bvhdev;
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (n_tris == 0) return 0;
+    if (!P || !tri_idx || !nodes_out || !ordered_out) return fail(RSPT_E_INVALID, "null argument");
+    if (n_tris > 0x3fffffffull) return fail(RSPT_E_UNSUPPORTED, "too many triangles");
+    for (uint64_t i = 0; i < 3 * n_tris; i++)
+        if (tri_idx[i] >= n_vertices) return fail(RSPT_E_INVALID, "vertex index out of range");
+    HIP_TRY(hipSetDevice(g.device));
+    const uint32_t n = (uint32_t)n_tris;
+    const uint32_t max_prims = max_prims_in_node < 255 ? max_prims_in_node : 255;  // bvh.rs:102
+    std::vector<void*> allocs;
+    auto cleanup = [&]() { for (void* p : allocs) (void)hipFree(p); };
+    auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; allocs.push_back(p); return p; };
+#define BVD_ALLOC(var, type, count) type* var = (type*)dalloc(sizeof(type) * (size_t)(count)); if (!var) { cleanup(); return fail(RSPT_E_NOMEM, "hipMalloc failed in rspt_bvh_build_gpu"); }
+    BVD_ALLOC(P_d, float, 3 * n_vertices)
+    BVD_ALLOC(tri_d, uint32_t, 3 * (size_t)n)
+    Prims pr[2];
+    for (int s2 = 0; s2 < 2; s2++) {
+        for (int a = 0; a < 3; a++) {
+            BVD_ALLOC(lo, float, n) BVD_ALLOC(hi, float, n) BVD_ALLOC(cc, float, n)
+            pr[s2].lo[a] = lo; pr[s2].hi[a] = hi; pr[s2].c[a] = cc;
+        }
+        BVD_ALLOC(pid, uint32_t, n) BVD_ALLOC(pnode, uint32_t, n)
+        pr[s2].prim = pid; pr[s2].node = pnode;
+    }
+    BVD_ALLOC(nodes, Node, 2 * (size_t)n)
+    BVD_ALLOC(level_nodes, uint32_t, 2 * (size_t)n + 2)
+    BVD_ALLOC(buckets, Buckets, (size_t)n / 3 + 2)
+    BVD_ALLOC(flag, uint32_t, n)
+    BVD_ALLOC(scan, uint32_t, n)
+    const uint32_t n_scan_blocks = (n + BVD_SCAN_BLOCK * BVD_SCAN_ITEMS - 1) / (BVD_SCAN_BLOCK * BVD_SCAN_ITEMS);
+    BVD_ALLOC(block_sums, uint32_t, n_scan_blocks + 1)
+    BVD_ALLOC(counters, uint32_t, 8)  // [0] node count, [1] next level size, [2] scan total
+    BVD_ALLOC(ordered_d, uint32_t, n)
+    BVD_ALLOC(out_d, rspt_bvh_node, 2 * (size_t)n)
+#undef BVD_ALLOC
+    hipStream_t st = g.stream;
+    auto bail = [&](hipError_t e, const char* what) { cleanup(); return (int64_t)fail(RSPT_E_HIP, "%s: %s", what, hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMemcpyAsync(P_d, P, sizeof(float) * 3 * n_vertices, hipMemcpyHostToDevice, st)) != hipSuccess) return bail(e, "upload P");
+    if ((e = hipMemcpyAsync(tri_d, tri_idx, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st)) != hipSuccess) return bail(e, "upload indices");
+    const uint32_t gp = (n + 255) / 256;
+    hipLaunchKernelGGL(k_prim_info, dim3(gp), dim3(256), 0, st, P_d, tri_d, n, pr[0]);
+    Node root{};
+    root.start = 0; root.end = n; root.base = 0; root.child0 = root.child1 = BVD_NONE;
+    const uint32_t zero = 0, one = 1;
+    (void)hipMemcpyAsync(nodes, &root, sizeof root, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(level_nodes, &zero, sizeof zero, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(&counters[0], &one, sizeof one, hipMemcpyHostToDevice, st);
+    std::vector<std::pair<uint32_t, uint32_t>> levels;  // (offset into level_nodes, count)
+    uint32_t off = 0, n_level = 1;
+    int cur = 0;
+    while (n_level > 0) {
+        if (levels.size() > 4096) { cleanup(); return fail(RSPT_E_UNSUPPORTED, "BVH deeper than 4096 levels"); }
+        levels.push_back({off, n_level});
+        const uint32_t* lv = level_nodes + off;
+        const uint32_t gl = (n_level + 255) / 256;
+        hipLaunchKernelGGL(k_node_reset, dim3(gl), dim3(256), 0, st, nodes, lv, n_level);
+        hipLaunchKernelGGL(k_bounds, dim3(gp), dim3(256), 0, st, pr[cur], n, nodes);
+        (void)hipMemsetAsync(&counters[3], 0, sizeof(uint32_t), st);
+        hipLaunchKernelGGL(k_node_axis, dim3(gl), dim3(256), 0, st, nodes, lv, n_level, buckets, pr[cur], &counters[3]);
+        hipLaunchKernelGGL(k_buckets, dim3(gp), dim3(256), 0, st, pr[cur], n, nodes, buckets);
+        hipLaunchKernelGGL(k_split, dim3(gl), dim3(256), 0, st, nodes, lv, n_level, buckets, max_prims);
+        hipLaunchKernelGGL(k_flags, dim3(gp), dim3(256), 0, st, pr[cur], n, nodes, flag, ordered_d);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(n_scan_blocks), dim3(BVD_SCAN_BLOCK), 0, st, flag, scan, block_sums, n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, block_sums, n_scan_blocks, &counters[2]);
+        hipLaunchKernelGGL(k_scan_add, dim3(gp), dim3(256), 0, st, scan, block_sums, n);
+        (void)hipMemsetAsync(&counters[1], 0, sizeof(uint32_t), st);
+        uint32_t* next = level_nodes + off + n_level;
+        hipLaunchKernelGGL(k_children, dim3(gl), dim3(256), 0, st, nodes, lv, n_level, scan, &counters[2], n, &counters[0], next, &counters[1]);
+        hipLaunchKernelGGL(k_scatter, dim3(gp), dim3(256), 0, st, pr[cur], pr[cur ^ 1], n, nodes, flag, scan);
+        uint32_t n_next = 0;
+        if ((e = hipMemcpyAsync(&n_next, &counters[1], sizeof n_next, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return bail(e, "bvh level");
+        off += n_level;
+        n_level = n_next;
+        cur ^= 1;
+    }
+    uint32_t total = 0;
+    if ((e = hipMemcpy(&total, &counters[0], sizeof total, hipMemcpyDeviceToHost)) != hipSuccess) return bail(e, "node count");
+    if (total > nodes_cap) { cleanup(); return fail(RSPT_E_INVALID, "nodes_cap %llu < %u nodes", (unsigned long long)nodes_cap, total); }
+    for (size_t l = levels.size(); l-- > 0;) hipLaunchKernelGGL(k_sizes, dim3((levels[l].second + 255) / 256), dim3(256), 0, st, nodes, level_nodes + levels[l].first, levels[l].second);
+    for (size_t l = 0; l < levels.size(); l++) hipLaunchKernelGGL(k_indices, dim3((levels[l].second + 255) / 256), dim3(256), 0, st, nodes, level_nodes + levels[l].first, levels[l].second, out_d);
+    if ((e = hipMemcpyAsync(nodes_out, out_d, sizeof(rspt_bvh_node) * total, hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e, "download nodes");
+    if ((e = hipMemcpyAsync(ordered_out, ordered_d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e, "download order");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail(e, "bvh build");
+    cleanup();
+    return (int64_t)total;
+}
+
 const char* rspt_last_error(void) { return g_err.c_str(); }
 
 int rspt_init(int32_t device) {

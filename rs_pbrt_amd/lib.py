@@ -14,7 +14,8 @@ _LIB = None
 
 EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
-           "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error")
+           "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
+           "rspt_bvh_build_gpu")
 
 
 class RsptError(RuntimeError):
@@ -50,6 +51,8 @@ def lib():
         L.rspt_last_counters.argtypes = [vp]
         L.rspt_bvh_build.restype = C.c_int64
         L.rspt_bvh_build.argtypes = [vp, vp, u64, u32, vp, u64, vp, i32]
+        L.rspt_bvh_build_gpu.restype = C.c_int64
+        L.rspt_bvh_build_gpu.argtypes = [vp, u64, vp, u64, u32, vp, u64, vp]
         _LIB = L
     return _LIB
 
@@ -69,6 +72,19 @@ def bvh_build(P, tri, max_prims_in_node=4, threads=0):
     k = lib().rspt_bvh_build(P.ctypes.data, tri.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data, threads)
     if k < 0:
         raise RsptError(int(k), (lib().rspt_bvh_last_error() or b"").decode())
+    return nodes[:k].copy(), ordered
+
+
+def bvh_build_gpu(P, tri, max_prims_in_node=4):
+    """BVHAccel::new on the GPU (level-synchronous; identical output to bvh_build).  Needs init()."""
+    P = np.ascontiguousarray(P, np.float32)
+    tri = np.ascontiguousarray(tri, np.uint32)
+    n = len(tri)
+    nodes = np.zeros(max(2 * n, 1), abi.NODE_DT)
+    ordered = np.zeros(n, np.uint32)
+    k = lib().rspt_bvh_build_gpu(P.ctypes.data, len(P.reshape(-1, 3)), tri.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data)
+    if k < 0:
+        raise RsptError(int(k), (lib().rspt_last_error() or b"").decode())
     return nodes[:k].copy(), ordered
 
 
