@@ -40,19 +40,19 @@ def parse():
 def build_workload(args, lib, scenes, shard):
     if args.workload == "soup1m":
         res, spp = args.res or 1024, args.spp or 256
-        sc = scenes.triangle_soup(lib.bvh_build, n_tris=args.tris)
+        sc = scenes.triangle_soup(lib.bvh_build_gpu, n_tris=args.tris)
         mk = lambda s, sh: scenes.soup_render_desc(res=res, spp=s, max_depth=8, shard=sh, integrator=args.integrator)  # noqa: E731
         name = "synthetic %d-triangle soup, path depth 8, sobol %d spp, %dx%d" % (args.tris, spp, res, res)
     elif args.workload == "cornell":
         res, spp = args.res or 400, args.spp or 64
-        sc = scenes.cornell_box(lib.bvh_build)
+        sc = scenes.cornell_box(lib.bvh_build_gpu)
         mk = lambda s, sh: scenes.cornell_render_desc(res=res, spp=s, shard=sh, integrator=args.integrator)  # noqa: E731
         name = "Cornell Box, path depth 5, sobol %d spp, %dx%d" % (spp, res, res)
     else:
         xres, spp = args.res or 1920, args.spp or 1024
         yres = xres * 9 // 16
         tex = args.workload == "statue_tex"  # image-textured Kd + bump map + textured ground
-        sc = scenes.statue_standin(lib.bvh_build, textured=tex)
+        sc = scenes.statue_standin(lib.bvh_build_gpu, textured=tex)
         mk = lambda s, sh: scenes.statue_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=args.integrator)  # noqa: E731
         name = "statue stand-in (4.3 M triangles%s), path depth 5, sobol %d spp, %dx%d" % (", image-textured + bump-mapped" if tex else "", spp, xres, yres)
     if args.integrator == "ao":
@@ -157,7 +157,7 @@ def main():
                          "whole_path_alg_bytes_per_sample": counts["alg_bytes"] / max(counts["samples"], 1),
                          "rays_per_sample": (counts["rays_closest"] + counts["rays_any"]) / max(counts["samples"], 1),
                          "nodes_per_ray": counts["nodes_visited"] / max(counts["rays_closest"] + counts["rays_any"], 1)},
-            "setup_s": {"scene_and_bvh_build": t_scene, "upload": t_upload},
+            "setup_s": {"scene_and_bvh_build": t_scene, "upload": t_upload, "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }
         if not args.no_cpu_baseline:
             from oracle import pyoracle  # CPU baseline leg only
