@@ -233,13 +233,7 @@ RDEV void wrap_dt(f2* d) {
     if (d->y > 0.5f) d->y = 1.0f - d->y;
     else if (d->y < -0.5f) d->y = -(d->y + 1.0f);
 }
-__device__ __noinline__ f2 tex_map2d(const rspt_texture& tx, const TexSurf& si, f2* dstdx, f2* dstdy) {
-    if (tx.mapping == RSPT_MAP_PLANAR) {
-        f3 vs{tx.map[0], tx.map[1], tx.map[2]}, vt{tx.map[3], tx.map[4], tx.map[5]};
-        *dstdx = f2{dot(si.dpdx, vs), dot(si.dpdx, vt)};
-        *dstdy = f2{dot(si.dpdy, vs), dot(si.dpdy, vt)};
-        return f2{tx.map[6] + dot(si.p, vs), tx.map[7] + dot(si.p, vt)};
-    }
+__device__ __noinline__ f2 tex_map2d_round(const rspt_texture& tx, const TexSurf& si, f2* dstdx, f2* dstdy) {
     if (tx.mapping == RSPT_MAP_SPHERICAL) {
         f2 st = map_sphere(tx, si.p);
         const float delta = 0.1f;
@@ -261,9 +255,22 @@ __device__ __noinline__ f2 tex_map2d(const rspt_texture& tx, const TexSurf& si, 
         wrap_dt(dstdy);
         return st;
     }
-    *dstdx = f2{si.dudx * tx.map[0], si.dvdx * tx.map[1]};
-    *dstdy = f2{si.dudy * tx.map[0], si.dvdy * tx.map[1]};
-    return f2{si.uv.x * tx.map[0] + tx.map[2], si.uv.y * tx.map[1] + tx.map[3]};
+    *dstdx = *dstdy = f2{0.0f, 0.0f};
+    return f2{0.0f, 0.0f};
+}
+RDEV f2 tex_map2d(const rspt_texture& tx, const TexSurf& si, f2* dstdx, f2* dstdy) {
+    if (tx.mapping == RSPT_MAP_UV) {
+        *dstdx = f2{si.dudx * tx.map[0], si.dvdx * tx.map[1]};
+        *dstdy = f2{si.dudy * tx.map[0], si.dvdy * tx.map[1]};
+        return f2{si.uv.x * tx.map[0] + tx.map[2], si.uv.y * tx.map[1] + tx.map[3]};
+    }
+    if (tx.mapping == RSPT_MAP_PLANAR) {
+        f3 vs{tx.map[0], tx.map[1], tx.map[2]}, vt{tx.map[3], tx.map[4], tx.map[5]};
+        *dstdx = f2{dot(si.dpdx, vs), dot(si.dpdx, vt)};
+        *dstdy = f2{dot(si.dpdy, vs), dot(si.dpdy, vt)};
+        return f2{tx.map[6] + dot(si.p, vs), tx.map[7] + dot(si.p, vt)};
+    }
+    return tex_map2d_round(tx, si, dstdx, dstdy);
 }
 RDEV f3 tex_map3d(const rspt_texture& tx, const TexSurf& si, f3* dpdx, f3* dpdy) {
     *dpdx = xf_vector(tx.world_to_texture, si.dpdx);
@@ -275,7 +282,7 @@ RDEV f3 tex_map3d(const rspt_texture& tx, const TexSurf& si, f3* dpdx, f3* dpdy)
 // rejects deeper graphs (rspt_scene_create), so the recursion is a fixed three-deep chain of functions ----
 template <int DEPTH>
 __device__ __noinline__ rgb tex_eval_d(const TexTables& tt, uint32_t ti, const TexSurf& si) {
-    const rspt_texture tx = tt.textures[ti];
+    const rspt_texture& tx = tt.textures[ti];
     // which children this node needs (one call site below, so the code of a level exists once)
     uint32_t kid[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
     uint32_t n_kids = 0;
@@ -351,7 +358,16 @@ __device__ __noinline__ rgb tex_eval_d(const TexTables& tt, uint32_t ti, const T
     }
 }
 #define RSPT_TEX_MAX_DEPTH 3  // nodes on the longest path of a texture graph
-RDEV rgb tex_eval(const TexTables& tt, uint32_t ti, const TexSurf& si) { return tex_eval_d<RSPT_TEX_MAX_DEPTH - 1>(tt, ti, si); }
+RDEV rgb tex_eval(const TexTables& tt, uint32_t ti, const TexSurf& si) {
+    const rspt_texture& tx = tt.textures[ti];
+    if (tx.kind == RSPT_TEX_CONSTANT) return ldrgb(tx.value);
+    if (tx.kind == RSPT_TEX_IMAGE && tx.mapping <= RSPT_MAP_PLANAR) {  // the common case stays inline: no call, no scratch frame
+        f2 dstdx, dstdy;
+        f2 st = tex_map2d(tx, si, &dstdx, &dstdy);
+        return img_lookup(tt.images[tx.image], tt.ewa_lut, tx, st, dstdx, dstdy);
+    }
+    return tex_eval_d<RSPT_TEX_MAX_DEPTH - 1>(tt, ti, si);
+}
 
 // Triangle::intersect's interaction (triangle.rs:274-448) with everything textures and bump mapping read
 struct TexHit {
