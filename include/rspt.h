@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 8
+#define RSPT_ABI_VERSION 9
 
 /* error codes */
 #define RSPT_OK 0
@@ -113,7 +113,12 @@ typedef struct {
     uint32_t tex_t;     /* the same for t (FRESNEL_SPEC T, FRESNEL_BLEND Rs).  A lobe whose resulting
                            colour(s) are black is not added, as in the reference's
                            `if !r.is_black()` guards (matte.rs:70, plastic.rs:70,84, substrate.rs:72) */
-} rspt_bxdf; /* 104 B */
+    uint32_t tex_ax;    /* 0, or 1 + index of the float texture behind alpha_x: a "roughness" / "uroughness" parameter
+                           (plastic.rs:86-92, uber.rs, substrate.rs:76-85, metal.rs, translucent.rs); per hit
+                           alpha_x = max(0.001, remap ? roughness_to_alpha(v) : v) (microfacet.rs:233-254)        */
+    uint32_t tex_ay;    /* the same for alpha_y ("vroughness"; materials with one roughness bind it to both)     */
+    uint32_t remap;     /* "remaproughness" of the textured alphas                                               */
+} rspt_bxdf; /* 116 B */
 
 typedef struct {
     float eta;          /* Bsdf.eta (reflection.rs:224)                               */

@@ -376,12 +376,21 @@ struct Bsdf {
         const rspt_bxdf* all = sc.d.bxdfs;
         for (uint32_t i = 0; i < m.n_bxdfs && i < 8; i++) {
             const rspt_bxdf& g = all[m.first_bxdf + i];
-            if (!g.tex_r && !g.tex_t) { lobes[n++] = Lobe{&g}; continue; }
+            if (!g.tex_r && !g.tex_t && !g.tex_ax && !g.tex_ay) { lobes[n++] = Lobe{&g}; continue; }
             rspt_bxdf b = g;
+            // roughness textures: `rough = tex.evaluate(si); if remap { rough = roughness_to_alpha(rough) }`, then
+            // TrowbridgeReitzDistribution::new clamps to >= 0.001 (plastic.rs:86-92, microfacet.rs:233-254)
+            auto alpha_of = [&](uint32_t tex) {
+                Float v = tex_eval(sc, tex - 1, si).c[0];
+                if (g.remap) { Float r = std::fmax(v, 1e-3f), x = std::log(r); v = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
+                return std::fmax(0.001f, v);
+            };
+            if (g.tex_ax) b.alpha_x = alpha_of(g.tex_ax);
+            if (g.tex_ay) b.alpha_y = alpha_of(g.tex_ay);
             if (g.tex_r) { Spec v = S3(g.r) * sclamp0(tex_eval(sc, g.tex_r - 1, si)); b.r[0] = v.c[0]; b.r[1] = v.c[1]; b.r[2] = v.c[2]; }
             if (g.tex_t) { Spec v = S3(g.t) * sclamp0(tex_eval(sc, g.tex_t - 1, si)); b.t[0] = v.c[0]; b.t[1] = v.c[1]; b.t[2] = v.c[2]; }
             bool two = g.type == RSPT_BXDF_FRESNEL_SPEC || g.type == RSPT_BXDF_FRESNEL_BLEND;
-            if (two ? (S3(b.r).is_black() && S3(b.t).is_black()) : S3(b.r).is_black()) continue;
+            if ((g.tex_r || g.tex_t) && (two ? (S3(b.r).is_black() && S3(b.t).is_black()) : S3(b.r).is_black())) continue;
             local[n] = b;
             lobes[n] = Lobe{&local[n]};
             n++;

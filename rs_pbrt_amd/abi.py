@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -39,7 +39,8 @@ class Bxdf(C.Structure):
     _fields_ = [("type", C.c_uint32), ("fresnel", C.c_uint32), ("r", C.c_float * 3), ("t", C.c_float * 3),
                 ("eta_a", C.c_float), ("eta_b", C.c_float), ("alpha_x", C.c_float), ("alpha_y", C.c_float),
                 ("c1", C.c_float * 3), ("c2", C.c_float * 3), ("on_a", C.c_float), ("on_b", C.c_float),
-                ("sc", C.c_float * 3), ("has_sc", C.c_uint32), ("tex_r", C.c_uint32), ("tex_t", C.c_uint32)]
+                ("sc", C.c_float * 3), ("has_sc", C.c_uint32), ("tex_r", C.c_uint32), ("tex_t", C.c_uint32),
+                ("tex_ax", C.c_uint32), ("tex_ay", C.c_uint32), ("remap", C.c_uint32)]
 
 
 class Material(C.Structure):
@@ -122,7 +123,7 @@ PRIM_DT = np.dtype([("v", "<u4", 3), ("mesh", "<u4"), ("material", "<u4"), ("are
 MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4")])
 BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
                     ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4"),
-                    ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4")])
+                    ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4"), ("tex_ax", "<u4"), ("tex_ay", "<u4"), ("remap", "<u4")])
 MATERIAL_DT = np.dtype([("eta", "<f4"), ("first_bxdf", "<u4"), ("n_bxdfs", "<u4"), ("bump_tex", "<u4")])
 TEXTURE_DT = np.dtype([("kind", "<u4"), ("mapping", "<u4"), ("map", "<f4", 8), ("image", "<u4"), ("trilinear", "<u4"), ("max_aniso", "<f4"),
                        ("wrap", "<u4"), ("value", "<f4", 3), ("tex1", "<u4"), ("tex2", "<u4"), ("tex3", "<u4"), ("world_to_texture", "<f4", 16),
@@ -133,7 +134,7 @@ HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), 
 
 assert NODE_DT.itemsize == C.sizeof(BvhNode) == 32
 assert PRIM_DT.itemsize == C.sizeof(Prim) == 24
-assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 104
+assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 116
 assert TEXTURE_DT.itemsize == C.sizeof(Texture) == 160
 assert RAY_DT.itemsize == C.sizeof(Ray) == 32
 assert HIT_DT.itemsize == C.sizeof(Hit) == 20

@@ -196,6 +196,9 @@ RDEV rgb lobe_r(const rspt_bxdf& b, const LobeTex& lt) {
     if (lt.base && b.tex_r) { float4 v = lt.base[(size_t)(b.tex_r - 1u) * lt.stride]; r = r * rgb{v.x, v.y, v.z}; }
     return r;
 }
+// alphas bound to roughness textures: k_texture left the final value (remapped, clamped to >= 0.001) in the slot
+RDEV float lobe_ax(const rspt_bxdf& b, const LobeTex& lt) { return (lt.base && b.tex_ax) ? lt.base[(size_t)(b.tex_ax - 1u) * lt.stride].x : b.alpha_x; }
+RDEV float lobe_ay(const rspt_bxdf& b, const LobeTex& lt) { return (lt.base && b.tex_ay) ? lt.base[(size_t)(b.tex_ay - 1u) * lt.stride].x : b.alpha_y; }
 RDEV rgb lobe_t(const rspt_bxdf& b, const LobeTex& lt) {
     rgb t = ldrgb(b.t);
     if (lt.base && b.tex_t) { float4 v = lt.base[(size_t)(b.tex_t - 1u) * lt.stride]; t = t * rgb{v.x, v.y, v.z}; }
@@ -228,7 +231,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
         wh = normalize(wh);
         rgb fr = lobe_fresnel(b, dot(wi, wh));
-        return lobe_scaled(b, lobe_r(b, lt)) * tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * fr / (4.0f * cti * cto);
+        return lobe_scaled(b, lobe_r(b, lt)) * tr_d(lobe_ax(b, lt), lobe_ay(b, lt), wh) * tr_g(lobe_ax(b, lt), lobe_ay(b, lt), wo, wi) * fr / (4.0f * cti * cto);
     }
     case RSPT_BXDF_MICROFACET_T: {  // MicrofacetTransmission::f, TransportMode::Radiance (reflection.rs:1246-1317)
         if (same_hemi(wo, wi)) return mkrgb(0.0f);
@@ -242,7 +245,7 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
         float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = 1.0f / eta;
         return lobe_scaled(b, mkrgb(1.0f) - fr) * lobe_r(b, lt) *
-               fabsf(tr_d(b.alpha_x, b.alpha_y, wh) * tr_g(b.alpha_x, b.alpha_y, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+               fabsf(tr_d(lobe_ax(b, lt), lobe_ay(b, lt), wh) * tr_g(lobe_ax(b, lt), lobe_ay(b, lt), wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                      (cti * cto * sqrt_denom * sqrt_denom));
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // FresnelBlend::f (reflection.rs:1398-1431): r = Rd, t = Rs
@@ -252,13 +255,13 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
         wh = normalize(wh);
         rgb schlick = rs + (mkrgb(1.0f) - rs) * pow5(1.0f - dot(wi, wh));
-        rgb specular = schlick * (tr_d(b.alpha_x, b.alpha_y, wh) / (4.0f * fabsf(dot(wi, wh)) * fmaxf(fabsf(wi.z), fabsf(wo.z))));
+        rgb specular = schlick * (tr_d(lobe_ax(b, lt), lobe_ay(b, lt), wh) / (4.0f * fabsf(dot(wi, wh)) * fmaxf(fabsf(wi.z), fabsf(wo.z))));
         return b.has_sc ? ldrgb(b.sc) * (diffuse + specular) : diffuse + specular;
     }
     default: return mkrgb(0.0f);
     }
 }
-RDEVN float lobe_pdf(const rspt_bxdf& b, f3 wo, f3 wi) {
+RDEVN float lobe_pdf(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
     switch (b.type) {
     case RSPT_BXDF_LAMBERT_R:
     case RSPT_BXDF_OREN_NAYAR:
@@ -269,7 +272,7 @@ RDEVN float lobe_pdf(const rspt_bxdf& b, f3 wo, f3 wi) {
     case RSPT_BXDF_MICROFACET_R: {
         if (!same_hemi(wo, wi)) return 0.0f;
         f3 wh = normalize(wo + wi);
-        return tr_pdf(b.alpha_x, b.alpha_y, wo, wh) / (4.0f * dot(wo, wh));
+        return tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh) / (4.0f * dot(wo, wh));
     }
     case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1350-1370
         if (same_hemi(wo, wi)) return 0.0f;
@@ -279,12 +282,12 @@ RDEVN float lobe_pdf(const rspt_bxdf& b, f3 wo, f3 wi) {
         if (wo_wh * wi_wh > 0.0f) return 0.0f;
         float sqrt_denom = wo_wh + eta * wi_wh;
         float dwh_dwi = fabsf((eta * eta * wi_wh) / (sqrt_denom * sqrt_denom));
-        return tr_pdf(b.alpha_x, b.alpha_y, wo, wh) * dwh_dwi;
+        return tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh) * dwh_dwi;
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1462-1474
         if (!same_hemi(wo, wi)) return 0.0f;
         f3 wh = normalize(wo + wi);
-        float pdf_wh = tr_pdf(b.alpha_x, b.alpha_y, wo, wh);
+        float pdf_wh = tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh);
         return 0.5f * (fabsf(wi.z) * RSPT_INV_PI + pdf_wh / (4.0f * dot(wo, wh)));
     }
     default: return 0.0f;
@@ -300,13 +303,13 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
     case RSPT_BXDF_OREN_NAYAR: {
         *wi = cosine_hemisphere(u);
         if (wo.z < 0.0f) wi->z *= -1.0f;
-        *pdf = lobe_pdf(b, wo, *wi);
+        *pdf = lobe_pdf(b, lt, wo, *wi);
         return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_LAMBERT_T: {
         *wi = cosine_hemisphere(u);
         if (wo.z > 0.0f) wi->z *= -1.0f;
-        *pdf = lobe_pdf(b, wo, *wi);
+        *pdf = lobe_pdf(b, lt, wo, *wi);
         return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_SPECULAR_R: {
@@ -342,18 +345,18 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
     }
     case RSPT_BXDF_MICROFACET_R: {
         if (wo.z == 0.0f) return black;
-        f3 wh = tr_sample_wh(b.alpha_x, b.alpha_y, wo, u);
+        f3 wh = tr_sample_wh(lobe_ax(b, lt), lobe_ay(b, lt), wo, u);
         *wi = (-wo) + wh * 2.0f * dot(wo, wh);  // reflect, reflection.rs:1889
         if (!same_hemi(wo, *wi)) return black;
-        *pdf = tr_pdf(b.alpha_x, b.alpha_y, wo, wh) / (4.0f * dot(wo, wh));
+        *pdf = tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh) / (4.0f * dot(wo, wh));
         return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1322-1349
         if (wo.z == 0.0f) return black;
-        f3 wh = tr_sample_wh(b.alpha_x, b.alpha_y, wo, u);
+        f3 wh = tr_sample_wh(lobe_ax(b, lt), lobe_ay(b, lt), wo, u);
         float eta = wo.z > 0.0f ? b.eta_a / b.eta_b : b.eta_b / b.eta_a;
         if (!refract(wo, wh, eta, wi)) return black;
-        *pdf = lobe_pdf(b, wo, *wi);
+        *pdf = lobe_pdf(b, lt, wo, *wi);
         return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1432-1461
@@ -364,11 +367,11 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
             if (wo.z < 0.0f) wi->z *= -1.0f;
         } else {
             uu.x = fminf(2.0f * (uu.x - 0.5f), RSPT_ONE_MINUS_EPS);
-            f3 wh = tr_sample_wh(b.alpha_x, b.alpha_y, wo, uu);
+            f3 wh = tr_sample_wh(lobe_ax(b, lt), lobe_ay(b, lt), wo, uu);
             *wi = (-wo) + wh * 2.0f * dot(wo, wh);
             if (!same_hemi(wo, *wi)) return black;
         }
-        *pdf = lobe_pdf(b, wo, *wi);
+        *pdf = lobe_pdf(b, lt, wo, *wi);
         return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     default: return black;
@@ -418,7 +421,7 @@ struct Bsdf {
         float p = 0.0f;
         int matching = 0;
         for (uint32_t i = 0; i < n; i++)
-            if (lobe_matches(ltype(i), flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
+            if (lobe_matches(ltype(i), flags)) { matching++; p += lobe_pdf(lobes[i], lt, wo, wi); }
         return matching > 0 ? p / (float)matching : 0.0f;
     }
     RDEVN rgb sample_f(f3 wo_w, f3* wi_w, f2 u, float* pdf_out, uint32_t flags, uint32_t* sampled_type) const {  // :298-420
@@ -448,7 +451,7 @@ struct Bsdf {
         *wi_w = to_world(wi);
         if (!(bt & BX_SPEC) && matching > 1)
             for (uint32_t i = 0; i < n; i++)
-                if ((int)i != idx && lobe_matches(ltype(i), flags)) *pdf_out += lobe_pdf(lobes[i], wo, wi);
+                if ((int)i != idx && lobe_matches(ltype(i), flags)) *pdf_out += lobe_pdf(lobes[i], lt, wo, wi);
         if (matching > 1) *pdf_out /= (float)matching;
         if (!(bt & BX_SPEC)) {
             bool refl = dot(*wi_w, ng) * dot(wo_w, ng) > 0.0f;

@@ -23,6 +23,9 @@ struct TexTables {
     const uint32_t* mat_slots;     // [material][RSPT_TEX_SLOTS]: texture index or 0xffffffff
     const uint8_t* mat_flags;      // bit 0: some lobe colour is textured; bit 1: bump map
 };
+#define RSPT_SLOT_ALPHA 0x80000000u     // slot descriptor flags: the texture drives a lobe alpha ...
+#define RSPT_SLOT_REMAP 0x40000000u     // ... through roughness_to_alpha
+#define RSPT_SLOT_TEX_MASK 0x3fffffffu
 #define RSPT_MAT_TEXTURED 1u
 #define RSPT_MAT_BUMP 2u
 // per-path results of k_texture, SoA [row][path]: rows 0..3 = clamp(texture value) of the material's

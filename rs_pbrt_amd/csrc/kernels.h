@@ -505,9 +505,20 @@ __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, Rend
 #pragma unroll
         for (int k = 0; k < RSPT_TEX_SLOTS; k++) {
             tv[k] = mkrgb(0.0f);
-            const uint32_t ti = tt.mat_slots[(size_t)tri.material * RSPT_TEX_SLOTS + k];
-            if (ti != 0xffffffffu) {
+            const uint32_t sd = tt.mat_slots[(size_t)tri.material * RSPT_TEX_SLOTS + k];
+            if (sd != 0xffffffffu) {
+                const uint32_t ti = sd & RSPT_SLOT_TEX_MASK;
                 rgb v = tex_eval(tt, ti, s);
+                if (sd & RSPT_SLOT_ALPHA) {  // a roughness texture: the slot carries the lobe's alpha (plastic.rs:86-92, microfacet.rs:233-254)
+                    float a = v.r;
+                    if (sd & RSPT_SLOT_REMAP) {
+                        const float r = fmaxf(a, 1e-3f), x = logf(r);
+                        a = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+                    }
+                    a = fmaxf(0.001f, a);
+                    out[k * stride] = make_float4(a, a, a, 0.0f);
+                    continue;
+                }
                 tv[k] = rgb{v.r < 0.0f ? 0.0f : v.r, v.g < 0.0f ? 0.0f : v.g, v.b < 0.0f ? 0.0f : v.b};  // Spectrum::clamp(0, inf) = clamp_t per channel (pbrt.rs:108-123)
                 out[k * stride] = make_float4(tv[k].r, tv[k].g, tv[k].b, 0.0f);
             }

@@ -801,7 +801,8 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         }
     }
     for (uint32_t i = 0; i < d->n_bxdfs; i++)
-        if (d->bxdfs[i].tex_r > d->n_textures || d->bxdfs[i].tex_t > d->n_textures) return fail(RSPT_E_INVALID, "bxdf %u: texture index out of range", i);
+        if (d->bxdfs[i].tex_r > d->n_textures || d->bxdfs[i].tex_t > d->n_textures || d->bxdfs[i].tex_ax > d->n_textures || d->bxdfs[i].tex_ay > d->n_textures)
+            return fail(RSPT_E_INVALID, "bxdf %u: texture index out of range", i);
     for (uint32_t i = 0; i < d->n_materials; i++)
         if (d->materials[i].bump_tex > d->n_textures) return fail(RSPT_E_INVALID, "material %u: bump texture index out of range", i);
     if (d->n_envmaps && !d->envmaps) return fail(RSPT_E_INVALID, "null envmaps");
@@ -863,16 +864,20 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             const rspt_material& mat = d->materials[m];
             uint32_t* sl = slots.data() + (size_t)m * RSPT_TEX_SLOTS;
             uint32_t n_sl = 0;
-            auto slot_of = [&](uint32_t tex_plus_1) -> int {
-                for (uint32_t k = 0; k < n_sl; k++) if (sl[k] == tex_plus_1 - 1u) return (int)k + 1;
+            auto slot_of = [&](uint32_t tex_plus_1, uint32_t flags = 0u) -> int {
+                const uint32_t desc = (tex_plus_1 - 1u) | flags;
+                for (uint32_t k = 0; k < n_sl; k++) if (sl[k] == desc) return (int)k + 1;
                 if (n_sl == RSPT_TEX_SLOTS) return -1;
-                sl[n_sl++] = tex_plus_1 - 1u;
+                sl[n_sl++] = desc;
                 return (int)n_sl;
             };
             for (uint32_t l = 0; l < mat.n_bxdfs; l++) {
                 rspt_bxdf& b = bx[mat.first_bxdf + l];
                 if (b.tex_r) { int k = slot_of(b.tex_r); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_r = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
                 if (b.tex_t) { int k = slot_of(b.tex_t); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_t = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
+                const uint32_t aflags = RSPT_SLOT_ALPHA | (b.remap ? RSPT_SLOT_REMAP : 0u);
+                if (b.tex_ax) { int k = slot_of(b.tex_ax, aflags); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_ax = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
+                if (b.tex_ay) { int k = slot_of(b.tex_ay, aflags); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_ay = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
             }
             if (mat.bump_tex) mflags[m] |= RSPT_MAT_BUMP;
             any |= mflags[m] != 0;

@@ -193,6 +193,17 @@ def _alpha(a):
     return max(float(a), 0.001)  # TrowbridgeReitzDistribution::new microfacet.rs:233-239
 
 
+def _rough(ru, rv, remap):
+    """lobe fields for a pair of roughness parameters (numbers, or float textures evaluated per hit)"""
+    out = dict(remap=int(bool(remap)))
+    for key, tkey, r in (("alpha_x", "tex_ax", ru), ("alpha_y", "tex_ay", rv)):
+        if hasattr(r, "index"):  # TexRef
+            out[key], out[tkey] = 0.001, r.index + 1
+        else:
+            out[key] = _alpha(tr_roughness_to_alpha(r) if remap else F32(r))
+    return out
+
+
 class TexRef:
     """A texture of the scene being built (SceneBuilder.*_texture) used where a material takes a colour:
     the lobe stores the constant factor (1, or uber's opacity) and 1 + texture index; the
@@ -236,9 +247,8 @@ def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True, bump=None
     if any_kd:
         lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd, tex_r=tkd))
     if any_ks:
-        a = tr_roughness_to_alpha(roughness) if remap else F32(roughness)
         lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, tex_r=tks, eta_a=1.5, eta_b=1.0,
-                           alpha_x=_alpha(a), alpha_y=_alpha(a)))
+                           **_rough(roughness, roughness, remap)))
     return _with_bump(dict(eta=1.0, lobes=lobes), bump)
 
 
@@ -252,18 +262,15 @@ def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5):  # glass.rs:83-211, smooth +
 
 
 def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True):  # metal.rs:144-205
-    a = tr_roughness_to_alpha(roughness) if remap else F32(roughness)
     return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_CONDUCTOR, r=(1, 1, 1), c1=eta, c2=k,
-                                      alpha_x=_alpha(a), alpha_y=_alpha(a))])
+                                      **_rough(roughness, roughness, remap))])
 
 
 def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True, bump=None):  # substrate.rs:62-114
     kd, tkd, any_kd = _col(kd); ks, tks, any_ks = _col(ks)
     if not any_kd and not any_ks:
         return _with_bump(dict(eta=1.0, lobes=[]), bump)
-    au = tr_roughness_to_alpha(uroughness) if remap else F32(uroughness)
-    av = tr_roughness_to_alpha(vroughness) if remap else F32(vroughness)
-    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, tex_r=tkd, tex_t=tks, alpha_x=_alpha(au), alpha_y=_alpha(av))]), bump)
+    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, tex_r=tkd, tex_t=tks, **_rough(uroughness, vroughness, remap))]), bump)
 
 
 def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness=0.1, uroughness=None, vroughness=None,
@@ -284,9 +291,7 @@ def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness
     if any_ks:
         ru = roughness if uroughness is None else uroughness
         rv = roughness if vroughness is None else vroughness
-        au = tr_roughness_to_alpha(ru) if remap else F32(ru)
-        av = tr_roughness_to_alpha(rv) if remap else F32(rv)
-        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, tex_r=tks, eta_a=1.0, eta_b=e, alpha_x=_alpha(au), alpha_y=_alpha(av)))
+        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, tex_r=tks, eta_a=1.0, eta_b=e, **_rough(ru, rv, remap)))
     kr = (op * np.maximum(np.array(kr, F32), 0)).astype(F32)
     if kr.any():
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=kr, eta_a=1.0, eta_b=e))

@@ -303,6 +303,20 @@ def test_procedural_textures_and_mappings_match_oracle(gpu, oracle):
     assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
 
 
+def test_roughness_textures_match_oracle(gpu, oracle):
+    """float textures on roughness / uroughness / vroughness (plastic.rs:86-92, substrate.rs:76-85, metal.rs, uber.rs): the
+    per-hit alpha goes through roughness_to_alpha (one logf) and the 0.001 clamp of TrowbridgeReitzDistribution::new"""
+    from tests.util import PROCEDURAL_LOOK_AT, roughness_room
+    sc = roughness_room(gpu.bvh_build)
+    rd = scenes.make_render_desc(96, 64, 16, PROCEDURAL_LOOK_AT, 50, max_depth=4)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert (li == ref["li"]).all(axis=2).mean() > 0.6
+    assert np.abs(li - ref["li"]).mean() < 2e-5
+    assert film_rmse(film, ref["film"]) < 2e-4
+    assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
+
+
 def test_textures_change_the_image_and_lens_differentials(gpu, oracle):
     """thin-lens camera differentials (perspective.rs:245-271) + Halton sampler on the textured room; and the
     textures must matter: the same room with constant colours renders a different film"""
@@ -413,5 +427,8 @@ def test_random_scenes_fuzz(gpu, oracle, seed):
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert st["nan_samples"] == ref["counters"]["nan_samples"]
-    assert (li == ref["li"]).all(axis=2).mean() > 0.5
+    # (a roughness texture puts one logf in front of every microfacet term of that material: an ulp of alpha moves
+    # most of its samples by an ulp or two, so the bit-identical share drops while the differences stay tiny)
+    assert (li == ref["li"]).all(axis=2).mean() > 0.3
+    assert np.abs(li - ref["li"]).mean() < 5e-5
     assert film_rmse(film, ref["film"]) < 3e-4

@@ -154,15 +154,20 @@ def random_scene(builder, seed):
     def kd():
         return tex[int(rng.integers(len(tex)))] if rng.random() < 0.45 else col()
 
+    rough_tex = sb.image_texture(img, channels=1, scale=0.4, trilinear=True)
+
+    def rough(lo=0.01, hi=0.5):
+        return rough_tex if rng.random() < 0.3 else float(rng.uniform(lo, hi))
+
     def material():
         k = int(rng.integers(12))
         bump = height if rng.random() < 0.25 else None
         if k == 0: return scenes.matte(kd(), sigma=float(rng.choice([0.0, 20.0, 60.0])), bump=bump)
-        if k == 1: return scenes.plastic(kd(), kd(), float(rng.uniform(0.01, 0.5)), bump=bump)
+        if k == 1: return scenes.plastic(kd(), kd(), rough(), bump=bump)
         if k == 2: return scenes.mirror(col(0.5, 1.0))
         if k == 3: return scenes.glass(col(0.5, 1.0), col(0.5, 1.0), float(rng.uniform(1.1, 2.0)))
-        if k == 4: return scenes.metal(roughness=float(rng.uniform(0.005, 0.3)))
-        if k == 5: return scenes.substrate(kd(), col(0.05, 0.4), float(rng.uniform(0.02, 0.4)), float(rng.uniform(0.02, 0.4)), bump=bump)
+        if k == 4: return scenes.metal(roughness=rough(0.005, 0.3))
+        if k == 5: return scenes.substrate(kd(), col(0.05, 0.4), rough(0.02, 0.4), rough(0.02, 0.4), bump=bump)
         if k == 6: return scenes.uber(kd(), col(), col(0.0, 0.3), col(0.0, 0.3), roughness=float(rng.uniform(0.05, 0.4)), opacity=col(0.4, 1.0), bump=bump)
         if k == 7: return scenes.translucent(col(), col(), col(0.2, 0.8), col(0.2, 0.8), float(rng.uniform(0.05, 0.4)))
         if k == 8: return scenes.rough_glass(uroughness=float(rng.uniform(0.02, 0.3)), vroughness=float(rng.uniform(0.02, 0.3)))
@@ -229,3 +234,29 @@ def procedural_room(builder):
 
 
 PROCEDURAL_LOOK_AT = ((0, 3.0, -4.8), (0, 1.8, 2), (0, 1, 0))
+
+
+def roughness_room(builder):
+    """float textures behind the microfacet alphas: plastic roughness from an image, substrate u / v roughness from two
+    different textures (one through a checkerboard of constants), metal roughness without remapping, uber with a
+    roughness fbm; constant colours, so the only per-hit variation is the alpha"""
+    sb = scenes.SceneBuilder()
+    img = texture_image()
+    r_img = sb.image_texture(img, channels=1, scale=0.4, su=2.0, sv=2.0, trilinear=True)                   # 0.05 .. 0.36
+    r_chk = sb.checkerboard_texture(sb.constant_texture(0.03), sb.constant_texture(0.3), su=6.0, sv=6.0)
+    r_fbm = sb.scale_texture(sb.wrinkled_texture(octaves=4, world_to_texture=scenes.Transform.scale(3, 3, 3).m), sb.constant_texture(0.25))
+    white = sb.add_material(scenes.matte((0.7, 0.7, 0.7)))
+    mats = [scenes.plastic((0.3, 0.1, 0.1), (0.5, 0.5, 0.5), r_img),
+            scenes.substrate((0.1, 0.3, 0.1), (0.3, 0.3, 0.3), r_chk, r_img),
+            scenes.metal(roughness=r_chk, remap=False),
+            scenes.uber((0.1, 0.1, 0.4), (0.5, 0.5, 0.5), roughness=r_fbm)]
+    q = sb.add_quad
+    uvq = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    q([(-6, 0, -5), (6, 0, -5), (6, 0, 6), (-6, 0, 6)], sb.add_material(mats[0]), UV=uvq)
+    q([(-6, 0, 6), (6, 0, 6), (6, 7, 6), (-6, 7, 6)], white, UV=uvq)
+    for i, m in enumerate(mats[1:]):
+        x = -4.5 + 3.2 * i
+        q([(x, 0.3, 2), (x + 2.6, 0.3, 2), (x + 2.6, 3.6, 3.2), (x, 3.6, 3.2)], sb.add_material(m), UV=uvq)
+    q([(-1.5, 6.9, -1.5), (1.5, 6.9, -1.5), (1.5, 6.9, 1.5), (-1.5, 6.9, 1.5)], white, emit=(14, 14, 14))
+    sb.add_point_light((3, 4, -3), (30, 30, 25))
+    return sb.finish(builder)
