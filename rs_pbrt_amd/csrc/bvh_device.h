@@ -154,19 +154,49 @@ __global__ void k_node_axis(Node* nodes, const uint32_t* __restrict__ level_node
 }
 
 __global__ void k_buckets(Prims pr, uint32_t n, const Node* __restrict__ nodes, Buckets* buckets) {  // bvh.rs:247-265
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t node = pr.node[i];
-    if (node == BVD_NONE) return;
+    // A workgroup whose 256 primitives all belong to one node (the rule on the upper levels, where a handful of nodes own
+    // everything) accumulates in LDS and issues 84 global atomics instead of 1792.
+    __shared__ Buckets s_bk;
+    __shared__ uint32_t s_node;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t node = i < n ? pr.node[i] : BVD_NONE;
+    if (threadIdx.x == 0) s_node = node;
+    __syncthreads();
+    const bool uniform = __syncthreads_and(node == s_node) != 0 && s_node != BVD_NONE;
+    if (!uniform) {
+        if (node == BVD_NONE) return;
+        const Node& nd = nodes[node];
+        if (nd.state != 3) return;
+        const int dim = (int)nd.axis;
+        const uint32_t b = bucket_of(ord2f(nd.cb[dim]), ord2f(nd.cb[3 + dim]), pr.c[dim][i]);
+        Buckets& bk = buckets[nd.min_bucket];
+        atomicAdd(&bk.count[b], 1u);
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&bk.lo[b][a], f2ord(pr.lo[a][i]));
+            atomicMax(&bk.hi[b][a], f2ord(pr.hi[a][i]));
+        }
+        return;
+    }
     const Node& nd = nodes[node];
-    if (nd.state != 3) return;
+    if (nd.state != 3) return;  // (block-uniform)
+    for (uint32_t j = threadIdx.x; j < 12; j += blockDim.x) {
+        s_bk.count[j] = 0;
+        for (int a = 0; a < 3; a++) { s_bk.lo[j][a] = f2ord(BVD_FMAX); s_bk.hi[j][a] = f2ord(-BVD_FMAX); }
+    }
+    __syncthreads();
     const int dim = (int)nd.axis;
     const uint32_t b = bucket_of(ord2f(nd.cb[dim]), ord2f(nd.cb[3 + dim]), pr.c[dim][i]);
-    Buckets& bk = buckets[nd.min_bucket];
-    atomicAdd(&bk.count[b], 1u);
+    atomicAdd(&s_bk.count[b], 1u);
     for (int a = 0; a < 3; a++) {
-        atomicMin(&bk.lo[b][a], f2ord(pr.lo[a][i]));
-        atomicMax(&bk.hi[b][a], f2ord(pr.hi[a][i]));
+        atomicMin(&s_bk.lo[b][a], f2ord(pr.lo[a][i]));
+        atomicMax(&s_bk.hi[b][a], f2ord(pr.hi[a][i]));
+    }
+    __syncthreads();
+    Buckets& bk = buckets[nd.min_bucket];
+    for (uint32_t j = threadIdx.x; j < 12; j += blockDim.x) {
+        if (s_bk.count[j] == 0) continue;
+        atomicAdd(&bk.count[j], s_bk.count[j]);
+        for (int a = 0; a < 3; a++) { atomicMin(&bk.lo[j][a], s_bk.lo[j][a]); atomicMax(&bk.hi[j][a], s_bk.hi[j][a]); }
     }
 }
 
