@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--integrator", default="path", choices=["path", "ao"], help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample)")
-    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex"])
+    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex", "c4"])
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -51,10 +51,11 @@ def build_workload(args, lib, scenes, shard):
     else:
         xres, spp = args.res or 1920, args.spp or 1024
         yres = xres * 9 // 16
-        tex = args.workload == "statue_tex"  # image-textured Kd + bump map + textured ground
-        sc = scenes.statue_standin(lib.bvh_build_gpu, textured=tex)
+        tex = args.workload in ("statue_tex", "c4")  # image-textured Kd + bump map + textured ground
+        sc = scenes.statue_standin(lib.bvh_build_gpu, textured=tex, many_lights=64 if args.workload == "c4" else 0)  # c4: SURVEY 8(d) C4 stand-in
         mk = lambda s, sh: scenes.statue_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=args.integrator)  # noqa: E731
-        name = "statue stand-in (4.3 M triangles%s), path depth 5, sobol %d spp, %dx%d" % (", image-textured + bump-mapped" if tex else "", spp, xres, yres)
+        name = "statue stand-in (4.3 M triangles%s%s), path depth 5, sobol %d spp, %dx%d" % (", image-textured + bump-mapped" if tex else "",
+                                                                                                   ", 64 small area lights (C4 stand-in)" if args.workload == "c4" else "", spp, xres, yres)
     if args.integrator == "ao":
         name += " [AOIntegrator, 64 shadow rays per camera sample]"
     return sc, mk, spp, name
@@ -156,7 +157,9 @@ def main():
                          "trace_launches_per_step": stats[0]["trace_launches"],
                          "whole_path_alg_bytes_per_sample": counts["alg_bytes"] / max(counts["samples"], 1),
                          "rays_per_sample": (counts["rays_closest"] + counts["rays_any"]) / max(counts["samples"], 1),
-                         "nodes_per_ray": counts["nodes_visited"] / max(counts["rays_closest"] + counts["rays_any"], 1)},
+                         "nodes_per_ray": counts["nodes_visited"] / max(counts["rays_closest"] + counts["rays_any"], 1),
+                         "mrays_per_s": {"closest": counts["rays_closest"] / t_trace / 1e6, "any": counts["rays_any"] / t_trace / 1e6,
+                                         "note": "rays of one step / wall time of its (overlapped) trace launches"}},
             "setup_s": {"scene_and_bvh_build": t_scene, "upload": t_upload, "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }
         if not args.no_cpu_baseline:

@@ -892,7 +892,7 @@ def _value_noise(p, seed, octaves=5):
     return out
 
 
-def statue_standin(bvh_builder, grid=1466, seed=0x6A4E, textured=False):
+def statue_standin(bvh_builder, grid=1466, seed=0x6A4E, textured=False, many_lights=0):
     """C3 stand-in for the off-tree Ganesha scene: grid x grid lat-long sphere
     (2*grid*(grid-1) ~ 4.30 M triangles at 1466) displaced by 5-octave value noise, smooth normals,
     plastic; matte ground; three quad lights.  DECLARED STAND-IN: not the real asset.
@@ -940,8 +940,18 @@ def statue_standin(bvh_builder, grid=1466, seed=0x6A4E, textured=False):
         ground = sb.add_material(matte((0.5, 0.5, 0.5)))
     sb.add_mesh(Pf, idx, body, N=N.astype(F32), UV=UV)
     sb.add_quad([(-6, -1.3, -6), (-6, -1.3, 6), (6, -1.3, 6), (6, -1.3, -6)], ground, UV=[[0, 0], [0, 1], [1, 1], [1, 0]] if textured else None)
-    for (cx, cz, L) in ((-2.5, -2.0, (30, 28, 24)), (2.5, -2.0, (20, 24, 30)), (0.0, 2.5, (25, 25, 25))):
-        sb.add_quad([(cx + 0.5, 3.0, cz - 0.5), (cx + 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz - 0.5)], ground, emit=L)
+    if many_lights:  # C4 stand-in: many small area lights instead of three large ones, same total power
+        k = int(round(math.sqrt(many_lights)))
+        rng = np.random.default_rng(seed)
+        for a in range(k):
+            for b in range(k):
+                cx, cz = -3.5 + 7.0 * (a + 0.5) / k, -3.0 + 6.5 * (b + 0.5) / k
+                h = 0.5 * math.sqrt(3.0 / (k * k))  # 3 m^2 of emitter in total, like the three 1 x 1 quads
+                L = tuple(float(v) for v in rng.uniform(18, 32, 3))
+                sb.add_quad([(cx + h, 3.0, cz - h), (cx + h, 3.0, cz + h), (cx - h, 3.0, cz + h), (cx - h, 3.0, cz - h)], ground, emit=L)
+    else:
+        for (cx, cz, L) in ((-2.5, -2.0, (30, 28, 24)), (2.5, -2.0, (20, 24, 30)), (0.0, 2.5, (25, 25, 25))):
+            sb.add_quad([(cx + 0.5, 3.0, cz - 0.5), (cx + 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz - 0.5)], ground, emit=L)
     return sb.finish(bvh_builder)
 
 
