@@ -432,3 +432,30 @@ def test_random_scenes_fuzz(gpu, oracle, seed):
     assert (li == ref["li"]).all(axis=2).mean() > 0.3
     assert np.abs(li - ref["li"]).mean() < 5e-5
     assert film_rmse(film, ref["film"]) < 3e-4
+
+
+@pytest.mark.parametrize("strategy", [abi.LIGHTS_SPATIAL, abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM])
+def test_many_area_lights(gpu, oracle, strategy):
+    """the C4 axis "many lights" (SURVEY 8d): 98 emissive triangles of different power; light selection through the
+    spatial voxel tables / power / uniform distributions must pick the same light for the same sample"""
+    sb = scenes.SceneBuilder()
+    white = sb.add_material(scenes.matte((0.7, 0.7, 0.7)))
+    shiny = sb.add_material(scenes.plastic((0.3, 0.2, 0.5), (0.4, 0.4, 0.4), 0.1))
+    q = sb.add_quad
+    q([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], white)
+    q([(-5, 0, 5), (-5, 6, 5), (5, 6, 5), (5, 0, 5)], white)
+    q([(-2, 0.2, 1), (0, 0.2, 1), (0, 2.5, 2), (-2, 2.5, 2)], shiny)
+    q([(1, 0.2, 0.5), (3, 0.2, 1.5), (3, 2.0, 1.5), (1, 2.0, 0.5)], white)
+    rng = np.random.default_rng(9)
+    for a in range(7):
+        for b in range(7):
+            cx, cz, h = -4.2 + 1.4 * a, -4.2 + 1.4 * b, 0.15
+            q([(cx + h, 5.5, cz - h), (cx + h, 5.5, cz + h), (cx - h, 5.5, cz + h), (cx - h, 5.5, cz - h)], white, emit=tuple(rng.uniform(5, 60, 3)))
+    sc = sb.finish(gpu.bvh_build)
+    assert len(sc.lights) == 98
+    from tests.util import GALLERY_LOOK_AT
+    rd = scenes.make_render_desc(72, 54, 16, GALLERY_LOOK_AT, 55, max_depth=3, light_strategy=strategy)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert (li == ref["li"]).all(axis=2).mean() > 0.75
+    assert film_rmse(film, ref["film"]) < 2e-5
