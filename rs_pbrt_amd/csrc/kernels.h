@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, PathBuf 
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) { cnt->active = bt.n; cnt->closest = bt.n; cnt->any = 0; }
     if (i >= bt.n) return;
+    // path slot i = pixel-major (slot = pixel * ns + sample): the lanes of a wave start with rays through the same or
+    // neighbouring pixels (sample-major slots cost 2 % on C2: less coherent first hits and shadow rays)
     uint32_t k = bt.pix0 + i / bt.ns, s = bt.s0 + i % bt.ns;
     uint32_t pk = pix_list[k];
     int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
@@ -679,11 +681,19 @@ __global__ __launch_bounds__(256) void k_ao_resolve(Batch bt, PathBuf pb, uint32
 // order.  The pixel's own contributions accumulate in registers; splats into other pixels
 // (wide filters; exact-zero film offsets with the box filter) go through atomics into a
 // separate buffer that is folded in by k_film_resolve.
+#define RSPT_FILM_CHUNK 4
+#define RSPT_FILM_ROW (RSPT_FILM_CHUNK + 1)  // padded LDS row: the per-thread walk would otherwise hit the same banks
 __global__ __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list, float4* __restrict__ film_own,
                                               float* __restrict__ film_splat, float* __restrict__ li_out, unsigned long long* nan_count) {
-    uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= bt.n_pix) return;
-    uint32_t pk = pix_list[bt.pix0 + k];
+    // The block's 256 pixels own one contiguous range of path slots (pixel-major).  It is staged through LDS in chunks
+    // of RSPT_FILM_CHUNK samples per pixel with unit-stride loads; each thread then walks its own pixel's samples in
+    // order (a thread reading its 16 consecutive records directly touches a different cache line per lane per load).
+    __shared__ float4 s_l[256 * RSPT_FILM_ROW];
+    __shared__ float2 s_pf[256 * RSPT_FILM_ROW];
+    const uint32_t k0 = blockIdx.x * 256u;
+    uint32_t k = k0 + threadIdx.x;
+    const bool live = k < bt.n_pix;
+    uint32_t pk = live ? pix_list[bt.pix0 + k] : 0u;
     int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
     const int32_t* sb = rd.sample_bounds;
     const int32_t* cp = rd.crop_px;
@@ -695,14 +705,27 @@ __global__ __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, PathBuf pb
     int32_t bx0 = max(f2i_sat(ceilf((float)tx0 - 0.5f - rx)), cp[0]), by0 = max(f2i_sat(ceilf((float)ty0 - 0.5f - ry)), cp[1]);
     int32_t bx1 = min(f2i_sat(floorf((float)tx1 - 0.5f + rx)) + 1, cp[2]), by1 = min(f2i_sat(floorf((float)ty1 - 0.5f + ry)) + 1, cp[3]);
     const int32_t cw = cp[2] - cp[0];
-    const bool own_in_crop = px >= cp[0] && px < cp[2] && py >= cp[1] && py < cp[3];
+    const bool own_in_crop = live && px >= cp[0] && px < cp[2] && py >= cp[1] && py < cp[3];
     const size_t own_idx = own_in_crop ? (size_t)(py - cp[1]) * cw + (size_t)(px - cp[0]) : 0;
     float4 acc = own_in_crop ? film_own[own_idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
     unsigned long long nans = 0;
+    const uint32_t n_blk = min(256u, bt.n_pix - k0);  // pixels of this block
     for (uint32_t j = 0; j < bt.ns; j++) {
-        uint32_t i = k * bt.ns + j;
-        float4 le = pb.L_eta[i];
+        const uint32_t jc = j % RSPT_FILM_CHUNK;
+        if (jc == 0) {  // stage samples j .. j + chunk - 1 of all the block's pixels
+            __syncthreads();
+            const uint32_t cs = min((uint32_t)RSPT_FILM_CHUNK, bt.ns - j);
+            for (uint32_t e = threadIdx.x; e < n_blk * cs; e += 256u) {
+                const uint32_t pl = e / cs, sj = e % cs;  // consecutive e -> consecutive slots inside a pixel's run
+                const uint32_t slot = (k0 + pl) * bt.ns + j + sj;
+                s_l[pl * RSPT_FILM_ROW + sj] = pb.L_eta[slot];
+                s_pf[pl * RSPT_FILM_ROW + sj] = pb.p_film[slot];
+            }
+            __syncthreads();
+        }
+        if (!live) continue;
+        float4 le = s_l[threadIdx.x * RSPT_FILM_ROW + jc];
         rgb l{le.x, le.y, le.z};
         if (has_nans(l)) { l = mkrgb(0.0f); nans++; }  // integrator.rs:165-173
         if (li_out && own_in_crop) {
@@ -710,7 +733,7 @@ __global__ __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, PathBuf pb
             o[0] = l.r; o[1] = l.g; o[2] = l.b;
         }
         if (lum(l) > rd.max_sample_luminance) l = l * mkrgb(rd.max_sample_luminance / lum(l));
-        float2 pf = pb.p_film[i];
+        float2 pf = s_pf[threadIdx.x * RSPT_FILM_ROW + jc];
         float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
         int32_t x0 = max(f2i_sat(ceilf(dx - rx)), bx0), y0 = max(f2i_sat(ceilf(dy - ry)), by0);
         int32_t x1 = min(f2i_sat(floorf(dx + rx)) + 1, bx1), y1 = min(f2i_sat(floorf(dy + ry)) + 1, by1);
