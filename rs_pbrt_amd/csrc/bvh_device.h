@@ -100,6 +100,29 @@ __global__ void k_bounds(Prims pr, uint32_t n, Node* nodes) {  // bvh.rs:196-199
     const bool in = i < n;
     const uint32_t node = in ? pr.node[i] : BVD_NONE;
     const bool active = in && node != BVD_NONE;
+    // whole workgroup on one node (upper levels): reduce in LDS, 12 global atomics per workgroup
+    __shared__ uint32_t s_acc[12];
+    __shared__ uint32_t s_node;
+    if (threadIdx.x == 0) s_node = node;
+    if (threadIdx.x < 12) s_acc[threadIdx.x] = (threadIdx.x % 6) < 3 ? f2ord(BVD_FMAX) : f2ord(-BVD_FMAX);  // [b lo, b hi, cb lo, cb hi]
+    __syncthreads();
+    if (__syncthreads_and(active && node == s_node)) {
+        for (int a = 0; a < 3; a++) {
+            uint32_t v;
+            v = f2ord(pr.lo[a][i]); for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = o < v ? o : v; } if (__lane_id() == 0) atomicMin(&s_acc[a], v);
+            v = f2ord(pr.hi[a][i]); for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = o > v ? o : v; } if (__lane_id() == 0) atomicMax(&s_acc[3 + a], v);
+            const uint32_t c = f2ord(pr.c[a][i]);
+            v = c; for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = o < v ? o : v; } if (__lane_id() == 0) atomicMin(&s_acc[6 + a], v);
+            v = c; for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = o > v ? o : v; } if (__lane_id() == 0) atomicMax(&s_acc[9 + a], v);
+        }
+        __syncthreads();
+        Node& nb = nodes[s_node];
+        if (threadIdx.x < 3) atomicMin(&nb.b[threadIdx.x], s_acc[threadIdx.x]);
+        else if (threadIdx.x < 6) atomicMax(&nb.b[threadIdx.x], s_acc[threadIdx.x]);
+        else if (threadIdx.x < 9) atomicMin(&nb.cb[threadIdx.x - 6], s_acc[threadIdx.x]);
+        else if (threadIdx.x < 12) atomicMax(&nb.cb[threadIdx.x - 6], s_acc[threadIdx.x]);
+        return;
+    }
     const bool uni = wave_uniform(node, active);
     if (!active) return;
     Node& nd = nodes[node];
