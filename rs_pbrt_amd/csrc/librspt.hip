@@ -95,6 +95,7 @@ struct rspt_scene_s {
     const Wide4Node* w4 = nullptr;    // one per interior LinearBVHNode at even depth (trace_w4.h)
     const uint2* big_leaves = nullptr;
     uint32_t w4_root = 0;
+    bool w4_ok = false;               // false: too large for the ref fields, k_trace_pw serves the scene
     TexTables tex{};                  // textures / images / per-material slots (dev_texture.h); has_textures says whether set
     bool has_textures = false;
     std::vector<void*> allocs;
@@ -297,9 +298,10 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
     if (!count && which != 0) {
         const uint32_t pgrid = pw_grid();
         uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
-        if (which == 2)
+        const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
+        if (which >= 2 && s->w4_ok)
             hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL), (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
         else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
@@ -1023,7 +1025,6 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                     }
                 }
                 Wide4Node w{};
-                w.axes = axes;
                 float lo[4][3], hi[4][3];
                 uint32_t pending[4], n_pending = 0;
                 for (int k = 0; k < 4; k++) {
@@ -1044,11 +1045,15 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                     w.b[c] = make_float4(lo[0][c], lo[1][c], hi[0][c], hi[1][c]);
                     w.b[3 + c] = make_float4(lo[2][c], lo[3][c], hi[2][c], hi[3][c]);
                 }
+                // the three axes ride in bits 25..26 of the first three refs (an empty slot's ref is never read as a ref)
+                for (int k = 0; k < 3; k++) w.ref[k] = (w.ref[k] & ~RSPT_W4_AXIS_MASK) | (((axes >> (2 * k)) & 3u) << RSPT_W4_AXIS_SHIFT);
                 recs[ri] = w;
             }
             s->w4_root = 0u;
         }
-        if (!recs.empty() && (rc = upload(s, recs.data(), recs.size(), &s->w4))) return bail(rc);
+        // record indices and big-leaf indices must leave bits 25..30 free; larger scenes stay on the two-box kernel
+        s->w4_ok = recs.size() <= RSPT_W4_OFFSET_MASK && big.size() <= RSPT_W4_OFFSET_MASK;
+        if (s->w4_ok && !recs.empty() && (rc = upload(s, recs.data(), recs.size(), &s->w4))) return bail(rc);
         if (!big.empty() && (rc = upload(s, big.data(), big.size(), &s->big_leaves))) return bail(rc);
     }
     *out = s;

@@ -28,13 +28,17 @@ namespace rspt {
 
 struct Wide4Node {      // 128 B, 128-byte aligned
     float4 b[6];        // b[0..2]: x, y, z slabs of slots 0,1 as (s0.min, s1.min, s0.max, s1.max); b[3..5]: slots 2,3
-    uint32_t ref[4];    // bit 31 = leaf (RSPT_W4_* fields), else Wide4Node index; RSPT_NONE = empty slot (NaN box)
-    uint32_t axes;      // A.axis | first child's axis << 2 | second child's axis << 4
-    uint32_t pad[3];
+    uint32_t ref[4];    // bit 31 = leaf (RSPT_W4_* fields), else Wide4Node index; empty slots have a NaN box (ref never read).
+                        // Bits 25..26 of ref[0], ref[1], ref[2] carry A.axis, the first child's axis and the second child's
+                        // axis: the kernel is bound by the number of scattered load instructions per step (one more dword
+                        // load per step cost 10 % of the kernel's time), so the axes ride in the load that fetches the refs.
+    uint32_t pad[4];
 };
 // leaf ref: bit 31 | (count - 1) << 27 | first primitive; count field 15 = look the pair up in big_leaves[low bits]
 #define RSPT_W4_COUNT_SHIFT 27
-#define RSPT_W4_OFFSET_MASK 0x07ffffffu
+#define RSPT_W4_AXIS_SHIFT 25
+#define RSPT_W4_AXIS_MASK 0x06000000u
+#define RSPT_W4_OFFSET_MASK 0x01ffffffu
 #ifndef RSPT_W4_LDS
 #define RSPT_W4_LDS 16       // stack entries per lane (8 B each) kept in LDS: 32 KB per workgroup
 #endif
@@ -214,7 +218,6 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
             if (ridx != RSPT_NONE) {
                 const float4* pp = reinterpret_cast<const float4*>(recs + ridx);
                 const float4 a0 = pp[0], a1 = pp[1], a2 = pp[2], a3 = pp[3], a4 = pp[4], a5 = pp[5], rf = pp[6];
-                const uint32_t axes = __float_as_uint(pp[7].x);
                 cur = RSPT_NONE;
                 bool h0, h1, h2, h3;
                 float m0, m1, m2, m3;
@@ -229,11 +232,12 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                     h2 = box_hit6_m(a3.x, a4.x, a5.x, a3.z, a4.z, a5.z, o, inv, n0, n1, n2, t_max, &m2);
                     h3 = box_hit6_m(a3.y, a4.y, a5.y, a3.w, a4.w, a5.w, o, inv, n0, n1, n2, t_max, &m3);
                 }
-                const uint32_t r0 = h0 ? __float_as_uint(rf.x) : RSPT_NONE, r1 = h1 ? __float_as_uint(rf.y) : RSPT_NONE;
-                const uint32_t r2 = h2 ? __float_as_uint(rf.z) : RSPT_NONE, r3 = h3 ? __float_as_uint(rf.w) : RSPT_NONE;
-                const bool sA = ((negbits >> (axes & 3u)) & 1u) != 0;          // dir_is_neg[A.axis]: second child's subtree first
-                const bool sB0 = ((negbits >> ((axes >> 2) & 3u)) & 1u) != 0;  // order inside the first child
-                const bool sB1 = ((negbits >> ((axes >> 4) & 3u)) & 1u) != 0;  // order inside the second child
+                const uint32_t f0 = __float_as_uint(rf.x), f1 = __float_as_uint(rf.y), f2 = __float_as_uint(rf.z), f3w = __float_as_uint(rf.w);
+                const uint32_t r0 = h0 ? (f0 & ~RSPT_W4_AXIS_MASK) : RSPT_NONE, r1 = h1 ? (f1 & ~RSPT_W4_AXIS_MASK) : RSPT_NONE;
+                const uint32_t r2 = h2 ? (f2 & ~RSPT_W4_AXIS_MASK) : RSPT_NONE, r3 = h3 ? f3w : RSPT_NONE;
+                const bool sA = ((negbits >> ((f0 >> RSPT_W4_AXIS_SHIFT) & 3u)) & 1u) != 0;   // dir_is_neg[A.axis]: second child's subtree first
+                const bool sB0 = ((negbits >> ((f1 >> RSPT_W4_AXIS_SHIFT) & 3u)) & 1u) != 0;  // order inside the first child
+                const bool sB1 = ((negbits >> ((f2 >> RSPT_W4_AXIS_SHIFT) & 3u)) & 1u) != 0;  // order inside the second child
                 const uint32_t g0n = sB0 ? r1 : r0, g0f = sB0 ? r0 : r1, g1n = sB1 ? r3 : r2, g1f = sB1 ? r2 : r3;
                 const float mg0n = sB0 ? m1 : m0, mg0f = sB0 ? m0 : m1, mg1n = sB1 ? m3 : m2, mg1f = sB1 ? m2 : m3;
                 // visiting order e0, e1, e2, e3
