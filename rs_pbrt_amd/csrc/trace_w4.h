@@ -14,7 +14,8 @@
 //     and Bounds3f::intersect_p (geometry.rs:2211-2269) is monotone in the box (same products,
 //     monotone rounding), so a ray that reaches a grandchild's box also passes the parent's.
 //     Halving the number of dependent fetch + pop/push rounds is what pays: the kernel is bound by
-//     VALU issue, not by bytes.
+//     the L1 request rate of its per-lane record loads (seven per step) and VALU issue, not by
+//     bytes.
 //   * intersect_p depends on ray.t_max only through its last comparison `t_min < ray.t_max`.  The
 //     stack therefore keeps (ref, t_min) and a pop re-checks `t_min < t_max` — exactly the outcome
 //     of the reference's box test at the later moment (with the smaller t_max) — without fetching
