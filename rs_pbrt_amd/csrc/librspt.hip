@@ -95,6 +95,7 @@ struct rspt_scene_s {
     const Wide4Node* w4 = nullptr;    // one per interior LinearBVHNode at even depth (trace_w4.h)
     const uint2* big_leaves = nullptr;
     uint32_t w4_root = 0;
+    uint32_t w4_top = 0;              // records kept in LDS by k_trace_w4 (a breadth-first prefix, numbered first)
     bool w4_ok = false;               // false: too large for the ref fields, k_trace_pw serves the scene
     TexTables tex{};                  // textures / images / per-material slots (dev_texture.h); has_textures says whether set
     bool has_textures = false;
@@ -301,7 +302,7 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
         const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
         if (which >= 2 && s->w4_ok)
             hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top);
         else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
@@ -1005,6 +1006,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         } else {
             const float qnan = std::numeric_limits<float>::quiet_NaN();
             std::vector<std::pair<uint32_t, uint32_t>> todo;  // (LinearBVHNode index, record index); records in depth-first order
+            std::vector<uint32_t> rec_axes(1, 0u);
             recs.emplace_back();
             todo.emplace_back(0u, 0u);
             while (!todo.empty()) {
@@ -1039,16 +1041,38 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                     else pending[n_pending++] = (uint32_t)k;
                 }
                 // children records are numbered so that the first slot's subtree follows its parent (pushed last)
-                for (uint32_t j = 0; j < n_pending; j++) { w.ref[pending[j]] = (uint32_t)recs.size(); recs.emplace_back(); }
+                for (uint32_t j = 0; j < n_pending; j++) { w.ref[pending[j]] = (uint32_t)recs.size(); recs.emplace_back(); rec_axes.push_back(0u); }
                 for (uint32_t j = n_pending; j-- > 0;) todo.emplace_back(slot_node[pending[j]], w.ref[pending[j]]);
                 for (int c = 0; c < 3; c++) {
                     w.b[c] = make_float4(lo[0][c], lo[1][c], hi[0][c], hi[1][c]);
                     w.b[3 + c] = make_float4(lo[2][c], lo[3][c], hi[2][c], hi[3][c]);
                 }
-                // the three axes ride in bits 25..26 of the first three refs (an empty slot's ref is never read as a ref)
-                for (int k = 0; k < 3; k++) w.ref[k] = (w.ref[k] & ~RSPT_W4_AXIS_MASK) | (((axes >> (2 * k)) & 3u) << RSPT_W4_AXIS_SHIFT);
+                rec_axes[ri] = axes;
                 recs[ri] = w;
             }
+            // Renumber: a breadth-first prefix of RSPT_W4_TOP records goes first (k_trace_w4 keeps those in LDS), the others
+            // keep their depth-first order.  Then the three axes move into bits 25..26 of the first three refs (an
+            // empty slot has a NaN box, its ref is never read as a ref).
+            std::vector<uint32_t> new_of(recs.size(), RSPT_NONE), order(1, 0u);
+            for (size_t h = 0; h < order.size() && order.size() < RSPT_W4_TOP; h++)
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t r = recs[order[h]].ref[k];
+                    if (r != RSPT_NONE && !(r & RSPT_REF_LEAF) && order.size() < RSPT_W4_TOP) order.push_back(r);
+                }
+            for (size_t i = 0; i < order.size(); i++) new_of[order[i]] = (uint32_t)i;
+            uint32_t next_index = (uint32_t)order.size();
+            for (size_t i = 0; i < recs.size(); i++)
+                if (new_of[i] == RSPT_NONE) new_of[i] = next_index++;
+            std::vector<Wide4Node> renumbered(recs.size());
+            for (size_t i = 0; i < recs.size(); i++) {
+                Wide4Node w = recs[i];
+                for (int k = 0; k < 4; k++)
+                    if (w.ref[k] != RSPT_NONE && !(w.ref[k] & RSPT_REF_LEAF)) w.ref[k] = new_of[w.ref[k]];
+                for (int k = 0; k < 3; k++) w.ref[k] = (w.ref[k] & ~RSPT_W4_AXIS_MASK) | (((rec_axes[i] >> (2 * k)) & 3u) << RSPT_W4_AXIS_SHIFT);
+                renumbered[new_of[i]] = w;
+            }
+            recs.swap(renumbered);
+            s->w4_top = (uint32_t)order.size();
             s->w4_root = 0u;
         }
         // record indices and big-leaf indices must leave bits 25..30 free; larger scenes stay on the two-box kernel

@@ -41,8 +41,16 @@ struct Wide4Node {      // 128 B, 128-byte aligned
 #define RSPT_W4_AXIS_MASK 0x06000000u
 #define RSPT_W4_OFFSET_MASK 0x01ffffffu
 #ifndef RSPT_W4_LDS
-#define RSPT_W4_LDS 16       // stack entries per lane (8 B each) kept in LDS: 32 KB per workgroup
+#define RSPT_W4_LDS 12       // stack entries per lane (8 B each) kept in LDS: 24 KB per workgroup
 #endif
+#ifndef RSPT_W4_TOP
+#define RSPT_W4_TOP 56       // records nearest the root (a breadth-first prefix, numbered first by rspt_scene_create) that every
+                             // workgroup keeps in LDS: their fetches leave the L1 request path that bounds the kernel.
+                             // 2048 * RSPT_W4_LDS + 112 * RSPT_W4_TOP must stay under ~31 KB or only four workgroups fit a CU
+                             // (measured C2 / C3 Msamples/s: (16, 0) 366 / 1139; (12, 56) 379 / 1172; (11, 72) 382 / 1161;
+                             //  (10, 85) 381 / 1153; (13, 36) 378 / 1170; four workgroups (12, 72) 375 / 1137; three (16, 85) 340 / 1065)
+#endif
+static_assert(2048 * RSPT_W4_LDS + 112 * RSPT_W4_TOP <= 64 * 1024, "k_trace_w4 LDS budget (64 KB per workgroup)");
 #ifndef RSPT_W4_POP_TRIES
 #define RSPT_W4_POP_TRIES 1  // stack entries a lane may discard (t_min >= t_max) in one iteration before it gives up the slot
 #endif
@@ -97,9 +105,17 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
                                                            rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, uint32_t* __restrict__ overflow_list,
-                                                           uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh) {
+                                                           uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh, uint32_t n_top) {
     __shared__ uint2 stack[RSPT_W4_LDS * RSPT_PW_BLOCK];
     uint2* my = stack + threadIdx.x;
+#if RSPT_W4_TOP > 0
+    __shared__ float4 top[7 * RSPT_W4_TOP];  // top[j * RSPT_W4_TOP + r] = j-th 16 bytes of record r (neighbouring records in neighbouring banks)
+    for (uint32_t i = threadIdx.x; i < 7u * n_top; i += RSPT_PW_BLOCK) {
+        const uint32_t r = i / 7u, j = i - 7u * r;
+        top[j * RSPT_W4_TOP + r] = reinterpret_cast<const float4*>(recs + r)[j];
+    }
+    __syncthreads();
+#endif
     // rows RSPT_W4_LDS .. RSPT_W4_LDS + RSPT_W4_SPILL - 1 of a lane's stack live in global memory (row-major over all threads of the grid)
     const size_t spill_stride = (size_t)gridDim.x * RSPT_PW_BLOCK;
     uint2* my_spill = spill + (size_t)blockIdx.x * RSPT_PW_BLOCK + threadIdx.x;
@@ -208,6 +224,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                     sp--;
                     // two separate accesses (never one pointer select: that becomes a flat load with full waitcnt drains)
                     uint2 e = my[(sp < RSPT_W4_LDS ? sp : RSPT_W4_LDS - 1u) * RSPT_PW_BLOCK];
+                    asm volatile("" : "+v"(e.x), "+v"(e.y));  // pins the LDS read: without it the two accesses are merged into flat loads again
                     if (sp >= RSPT_W4_LDS) e = my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride];
                     if (__uint_as_float(e.y) < t_max) {  // the reference's box test at this later moment (bvh.rs:424)
                         if (e.x & RSPT_REF_LEAF) leaf = e.x;
@@ -217,8 +234,21 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                 }
             }
             if (ridx != RSPT_NONE) {
-                const float4* pp = reinterpret_cast<const float4*>(recs + ridx);
-                const float4 a0 = pp[0], a1 = pp[1], a2 = pp[2], a3 = pp[3], a4 = pp[4], a5 = pp[5], rf = pp[6];
+                float4 a0, a1, a2, a3, a4, a5, rf;
+#if RSPT_W4_TOP > 0
+                if (ridx < n_top) {
+                    const float4* lp = top + ridx;
+                    a0 = lp[0]; a1 = lp[RSPT_W4_TOP]; a2 = lp[2 * RSPT_W4_TOP]; a3 = lp[3 * RSPT_W4_TOP];
+                    a4 = lp[4 * RSPT_W4_TOP]; a5 = lp[5 * RSPT_W4_TOP]; rf = lp[6 * RSPT_W4_TOP];
+                    // keeps the two branches from being merged into one set of flat loads through a selected pointer
+                    // (flat loads of LDS drain every counter and were 2.6x slower)
+                    asm volatile("" : "+v"(rf.w));
+                } else
+#endif
+                {
+                    const float4* pp = reinterpret_cast<const float4*>(recs + ridx);
+                    a0 = pp[0]; a1 = pp[1]; a2 = pp[2]; a3 = pp[3]; a4 = pp[4]; a5 = pp[5]; rf = pp[6];
+                }
                 cur = RSPT_NONE;
                 bool h0, h1, h2, h3;
                 float m0, m1, m2, m3;
@@ -259,8 +289,11 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                     next = RSPT_NONE;
                 } else {
                     auto push = [&](uint32_t ref, float m) {
-                        if (sp < RSPT_W4_LDS) my[sp * RSPT_PW_BLOCK] = make_uint2(ref, __float_as_uint(m));
-                        else my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride] = make_uint2(ref, __float_as_uint(m));
+                        if (sp < RSPT_W4_LDS) {
+                            my[sp * RSPT_PW_BLOCK] = make_uint2(ref, __float_as_uint(m));
+                            asm volatile("");  // keeps the LDS store and the global store apart (no flat store through a selected pointer)
+                        } else
+                            my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride] = make_uint2(ref, __float_as_uint(m));
                         sp++;
                     };
                     if (push3) push(e3, me3);
