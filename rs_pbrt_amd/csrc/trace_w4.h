@@ -48,7 +48,8 @@ struct Wide4Node {      // 128 B, 128-byte aligned
                              // workgroup keeps in LDS: their fetches leave the L1 request path that bounds the kernel.
                              // 2048 * RSPT_W4_LDS + 112 * RSPT_W4_TOP must stay under ~31 KB or only four workgroups fit a CU
                              // (measured C2 / C3 Msamples/s: (16, 0) 366 / 1139; (12, 56) 379 / 1172; (11, 72) 382 / 1161;
-                             //  (10, 85) 381 / 1153; (13, 36) 378 / 1170; four workgroups (12, 72) 375 / 1137; three (16, 85) 340 / 1065)
+                             //  (10, 85) 381 / 1153; (13, 36) 378 / 1170; four workgroups (12, 72) 375 / 1137; three (16, 85) 340 / 1065;
+                             //  six waves per SIMD forced with amdgpu_waves_per_eu (80 VGPRs, 13 spilled) and (10, 56): 366 / 1141)
 #endif
 static_assert(2048 * RSPT_W4_LDS + 112 * RSPT_W4_TOP <= 64 * 1024, "k_trace_w4 LDS budget (64 KB per workgroup)");
 #ifndef RSPT_W4_POP_TRIES
