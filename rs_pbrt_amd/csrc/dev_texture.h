@@ -369,7 +369,11 @@ RDEV rgb tex_eval(const TexTables& tt, uint32_t ti, const TexSurf& si) {
         f2 st = tex_map2d(tx, si, &dstdx, &dstdy);
         return img_lookup(tt.images[tx.image], tt.ewa_lut, tx, st, dstdx, dstdy);
     }
-    return tex_eval_d<RSPT_TEX_MAX_DEPTH - 1>(tt, ti, si);
+    // the callee takes references: hand it copies, so that the caller's own tables and surface record do not escape (an
+    // escaped struct lives in scratch, and table pointers read back from scratch turn every access into a flat instruction)
+    const TexTables tt_arg = tt;
+    const TexSurf si_arg = si;
+    return tex_eval_d<RSPT_TEX_MAX_DEPTH - 1>(tt_arg, ti, si_arg);
 }
 
 // Triangle::intersect's interaction (triangle.rs:274-448) with everything textures and bump mapping read
