@@ -8,7 +8,7 @@
 namespace rspt {
 
 struct ImageDev {  // MipMap<T> pyramid (mipmap.rs:38-45)
-    const float* texels;        // `channels` floats per texel, levels concatenated
+    uint64_t texel_base;        // first float of this image in TexTables::texel_pool; `channels` floats per texel, levels concatenated
     uint32_t level_offset[16];  // in texels
     uint32_t width, height, n_levels, channels;
 };
@@ -19,6 +19,8 @@ struct ImageDev {  // MipMap<T> pyramid (mipmap.rs:38-45)
 struct TexTables {
     const rspt_texture* textures;
     const ImageDev* images;
+    const float* texel_pool;       // all pyramids in one allocation: texel addresses derive from this kernel argument, so the
+                                   // fetches are global loads (a pointer read from the image table would make them flat loads)
     const float* ewa_lut;          // host-built with expf as MipMap::new does (mipmap.rs:186-192)
     const uint32_t* mat_slots;     // [material][RSPT_TEX_SLOTS]: texture index or 0xffffffff
     const uint8_t* mat_flags;      // bit 0: some lobe colour is textured; bit 1: bump map
@@ -49,7 +51,7 @@ RDEV int64_t f2i64(float x) {  // Rust `as isize`: saturating, NaN -> 0
 }
 
 // ---- MipMap<T>::texel / triangle / lookup / ewa: src/core/mipmap.rs:206-400 ----
-RDEV rgb img_texel(const ImageDev& m, uint32_t wrap, uint32_t level, int64_t s, int64_t t) {
+RDEV rgb img_texel(const ImageDev& m, const float* texels, uint32_t wrap, uint32_t level, int64_t s, int64_t t) {
     uint32_t w = m.width >> level, h = m.height >> level;
     w = w ? w : 1u; h = h ? h : 1u;
     uint64_t ss, tt;
@@ -58,33 +60,33 @@ RDEV rgb img_texel(const ImageDev& m, uint32_t wrap, uint32_t level, int64_t s, 
         ss = (uint64_t)(s < 0 ? 0 : (s > (int64_t)w - 1 ? (int64_t)w - 1 : s));
         tt = (uint64_t)(t < 0 ? 0 : (t > (int64_t)h - 1 ? (int64_t)h - 1 : t));
     }
-    const float* q = m.texels + (size_t)m.channels * ((size_t)m.level_offset[level] + tt * w + ss);
+    const float* q = texels + (size_t)m.channels * ((size_t)m.level_offset[level] + tt * w + ss);
     return m.channels == 1 ? mkrgb(q[0]) : ldrgb(q);
 }
-RDEVN rgb img_triangle(const ImageDev& m, uint32_t wrap, uint32_t level, f2 st) {
+RDEVN rgb img_triangle(const ImageDev& m, const float* texels, uint32_t wrap, uint32_t level, f2 st) {
     if (level > m.n_levels - 1) level = m.n_levels - 1;
     uint32_t w = m.width >> level, h = m.height >> level;
     w = w ? w : 1u; h = h ? h : 1u;
     float s = st.x * (float)w - 0.5f, t = st.y * (float)h - 0.5f;
     int64_t s0 = f2i64(floorf(s)), t0 = f2i64(floorf(t));
     float ds = s - (float)s0, dt = t - (float)t0;
-    rgb tmp1 = img_texel(m, wrap, level, s0 + 1, t0 + 1) * (ds * dt);
-    rgb tmp2 = img_texel(m, wrap, level, s0 + 1, t0) * (ds * (1.0f - dt));
-    rgb tmp3 = img_texel(m, wrap, level, s0, t0 + 1) * ((1.0f - ds) * dt);
-    rgb tmp4 = img_texel(m, wrap, level, s0, t0) * ((1.0f - ds) * (1.0f - dt));
+    rgb tmp1 = img_texel(m, texels, wrap, level, s0 + 1, t0 + 1) * (ds * dt);
+    rgb tmp2 = img_texel(m, texels, wrap, level, s0 + 1, t0) * (ds * (1.0f - dt));
+    rgb tmp3 = img_texel(m, texels, wrap, level, s0, t0 + 1) * ((1.0f - ds) * dt);
+    rgb tmp4 = img_texel(m, texels, wrap, level, s0, t0) * ((1.0f - ds) * (1.0f - dt));
     return tmp4 + tmp3 + tmp2 + tmp1;
 }
-RDEV rgb img_lookup_width(const ImageDev& m, uint32_t wrap, f2 st, float width) {  // lookup_pnt_flt :233-252
+RDEV rgb img_lookup_width(const ImageDev& m, const float* texels, uint32_t wrap, f2 st, float width) {  // lookup_pnt_flt :233-252
     float level = (float)m.n_levels - 1.0f + log2f(fmaxf(width, 1e-8f));
-    if (level < 0.0f) return img_triangle(m, wrap, 0, st);
-    if (level >= (float)m.n_levels - 1.0f) return img_texel(m, wrap, m.n_levels - 1, 0, 0);
+    if (level < 0.0f) return img_triangle(m, texels, wrap, 0, st);
+    if (level >= (float)m.n_levels - 1.0f) return img_texel(m, texels, wrap, m.n_levels - 1, 0, 0);
     uint32_t il = (uint32_t)floorf(level);
     float delta = level - (float)il;
-    rgb a = img_triangle(m, wrap, il, st), b = img_triangle(m, wrap, il + 1, st);
+    rgb a = img_triangle(m, texels, wrap, il, st), b = img_triangle(m, texels, wrap, il + 1, st);
     return a * (1.0f - delta) + b * delta;
 }
-RDEVN rgb img_ewa(const ImageDev& m, const float* lut, uint32_t wrap, uint32_t level, f2 st, f2 dst0, f2 dst1) {  // :337-400
-    if (level >= m.n_levels) return img_texel(m, wrap, m.n_levels - 1, 0, 0);
+RDEVN rgb img_ewa(const ImageDev& m, const float* texels, const float* lut, uint32_t wrap, uint32_t level, f2 st, f2 dst0, f2 dst1) {  // :337-400
+    if (level >= m.n_levels) return img_texel(m, texels, wrap, m.n_levels - 1, 0, 0);
     uint32_t w = m.width >> level, h = m.height >> level;
     w = w ? w : 1u; h = h ? h : 1u;
     float sx = st.x * (float)w - 0.5f, sy = st.y * (float)h - 0.5f;
@@ -112,17 +114,17 @@ RDEVN rgb img_ewa(const ImageDev& m, const float* lut, uint32_t wrap, uint32_t l
                 float fi = r2 * (float)RSPT_EWA_LUT;
                 uint32_t index = (fi != fi || fi <= 0.0f) ? 0u : (fi >= (float)(RSPT_EWA_LUT - 1) ? (uint32_t)(RSPT_EWA_LUT - 1) : (uint32_t)fi);
                 float weight = lut[index];
-                sum = sum + img_texel(m, wrap, level, is, it) * weight;
+                sum = sum + img_texel(m, texels, wrap, level, is, it) * weight;
                 sum_wts += weight;
             }
         }
     }
     return sum / sum_wts;
 }
-RDEV rgb img_lookup(const ImageDev& m, const float* lut, const rspt_texture& tx, f2 st, f2 dst0, f2 dst1) {  // lookup_pnt_vec_vec :253-297
+RDEV rgb img_lookup(const ImageDev& m, const float* texels, const float* lut, const rspt_texture& tx, f2 st, f2 dst0, f2 dst1) {  // lookup_pnt_vec_vec :253-297
     if (tx.trilinear) {
         float width = fmaxf(fmaxf(fabsf(dst0.x), fabsf(dst0.y)), fmaxf(fabsf(dst1.x), fabsf(dst1.y)));
-        return img_lookup_width(m, tx.wrap, st, width);
+        return img_lookup_width(m, texels, tx.wrap, st, width);
     }
     if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) { f2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
     float major_length = sqrtf(dst0.x * dst0.x + dst0.y * dst0.y);
@@ -132,11 +134,11 @@ RDEV rgb img_lookup(const ImageDev& m, const float* lut, const rspt_texture& tx,
         dst1.x *= scale; dst1.y *= scale;
         minor_length *= scale;
     }
-    if (minor_length == 0.0f) return img_triangle(m, tx.wrap, 0, st);
+    if (minor_length == 0.0f) return img_triangle(m, texels, tx.wrap, 0, st);
     float lod = fmaxf(0.0f, (float)m.n_levels - 1.0f + log2f(minor_length));
     uint32_t ilod = (uint32_t)floorf(lod);
-    rgb col2 = img_ewa(m, lut, tx.wrap, ilod + 1, st, dst0, dst1);
-    rgb col1 = img_ewa(m, lut, tx.wrap, ilod, st, dst0, dst1);
+    rgb col2 = img_ewa(m, texels, lut, tx.wrap, ilod + 1, st, dst0, dst1);
+    rgb col1 = img_ewa(m, texels, lut, tx.wrap, ilod, st, dst0, dst1);
     float t = lod - (float)ilod;
     return col1 * (1.0f - t) + col2 * t;
 }
@@ -331,7 +333,8 @@ __device__ __noinline__ rgb tex_eval_d(const TexTables& tt, uint32_t ti, const T
     case RSPT_TEX_IMAGE: {
         f2 dstdx, dstdy;
         f2 st = tex_map2d(tx, si, &dstdx, &dstdy);
-        return img_lookup(tt.images[tx.image], tt.ewa_lut, tx, st, dstdx, dstdy);
+        const ImageDev& im = tt.images[tx.image];
+        return img_lookup(im, tt.texel_pool + im.texel_base, tt.ewa_lut, tx, st, dstdx, dstdy);
     }
     case RSPT_TEX_FBM: { f3 dpdx, dpdy; f3 p = tex_map3d(tx, si, &dpdx, &dpdy); return mkrgb(fbm(p, dpdx, dpdy, tx.omega, tx.octaves)); }
     case RSPT_TEX_WRINKLED: { f3 dpdx, dpdy; f3 p = tex_map3d(tx, si, &dpdx, &dpdy); return mkrgb(turbulence(p, dpdx, dpdy, tx.omega, tx.octaves)); }
@@ -367,7 +370,8 @@ RDEV rgb tex_eval(const TexTables& tt, uint32_t ti, const TexSurf& si) {
     if (tx.kind == RSPT_TEX_IMAGE && tx.mapping <= RSPT_MAP_PLANAR) {  // the common case stays inline: no call, no scratch frame
         f2 dstdx, dstdy;
         f2 st = tex_map2d(tx, si, &dstdx, &dstdy);
-        return img_lookup(tt.images[tx.image], tt.ewa_lut, tx, st, dstdx, dstdy);
+        const ImageDev& im = tt.images[tx.image];
+        return img_lookup(im, tt.texel_pool + im.texel_base, tt.ewa_lut, tx, st, dstdx, dstdy);
     }
     // the callee takes references: hand it copies, so that the caller's own tables and surface record do not escape (an
     // escaped struct lives in scratch, and table pointers read back from scratch turn every access into a flat instruction)

@@ -893,6 +893,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                 return bail(rc);
             s->dev.mat_flags = s->tex.mat_flags;
             std::vector<ImageDev> imgs(d->n_images);
+            std::vector<float> pool;  // every pyramid, back to back
             for (uint32_t i = 0; i < d->n_images; i++) {
                 const rspt_image& im = d->images[i];
                 ImageDev& o = imgs[i];
@@ -902,8 +903,10 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                     o.level_offset[l] = (uint32_t)n_tex;
                     n_tex += (size_t)w * h;
                 }
-                if ((rc = upload(s, im.texels, n_tex * im.channels, &o.texels))) return bail(rc);
+                o.texel_base = pool.size();
+                pool.insert(pool.end(), im.texels, im.texels + n_tex * im.channels);
             }
+            if ((rc = upload(s, pool.data(), pool.size(), &s->tex.texel_pool))) return bail(rc);
             if ((rc = upload(s, imgs.data(), imgs.size(), &s->tex.images))) return bail(rc);
             float lut[RSPT_EWA_LUT];  // MipMap::new's EWA weights (mipmap.rs:186-192), host expf like the reference's f32::exp
             for (int i = 0; i < RSPT_EWA_LUT; i++) {
