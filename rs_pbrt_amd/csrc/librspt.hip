@@ -493,7 +493,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     sob_bits = std::min(52u, sob_bits + 1u);
     if ((size_t)sob_nd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
     const uint32_t tgrid = trace_grid();
-    const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", 4));
+    const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", 2));
     size_t n_ev = 0;
     const bool two_streams = env_size("RSPT_TRACE_STREAMS", 2) >= 2 && !counters;
     hipEvent_t ev_fork = get_event(n_ev++), ev_join = get_event(n_ev++);
