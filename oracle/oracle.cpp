@@ -1,5 +1,8 @@
 // TEST INFRASTRUCTURE — C entry points of the CPU oracle (liboracle.so), loaded with ctypes
 // by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+// Parity unpinned: rs_pbrt ships no tests / golden vectors for this path and cannot be built here (no Rust
+// toolchain), so the restatement is pinned by first-principles known-answer tests (tests/test_oracle_*.py),
+// not by outputs of the reference itself (see orc_math.hpp and DESIGN.md §2 row (c)).
 #include "orc_render.hpp"
 
 using namespace orc;

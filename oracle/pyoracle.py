@@ -1,7 +1,10 @@
 """TEST INFRASTRUCTURE — ctypes loader for the CPU oracle (oracle/liboracle.so).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
-The product package (rs_pbrt_amd) never does."""
+The product package (rs_pbrt_amd) never does.
+
+Parity unpinned: the reference has no tests or golden vectors for this path and no Rust toolchain exists here, so
+the oracle is checked against first-principles known answers (tests/test_oracle_*.py), not against rs_pbrt output."""
 import ctypes as C
 import os
 import subprocess
