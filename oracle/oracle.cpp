@@ -158,7 +158,7 @@ void orc_trace(const rspt_scene_desc* sd, const rspt_ray* rays, uint64_t n, rspt
         Ray r{V3{rays[i].o[0], rays[i].o[1], rays[i].o[2]}, V3{rays[i].d[0], rays[i].d[1], rays[i].d[2]}, rays[i].t_max, 0.0f};
         rspt_hit h; h.prim = 0xffffffffu; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
         if (any_hit) { if (sc.intersect_p(r, &c)) h.prim = 0; }
-        else if (brute) { uint32_t p; Float t; if (sc.intersect_brute(r, &p, &t)) { h.prim = p; h.t = t; } }
+        else if (brute) { uint32_t p = RSPT_MISS; Float t = 0.0f; if (sc.intersect_brute(r, &p, &t)) { h.prim = p; h.t = t; } }
         else {
             Interaction isect; Float t = 0, b[3] = {0, 0, 0};
             if (sc.intersect(r, &isect, &c, &t, b)) { h.prim = (uint32_t)isect.prim; h.t = t; h.b0 = b[0]; h.b1 = b[1]; h.b2 = b[2]; }
