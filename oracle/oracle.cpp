@@ -158,7 +158,7 @@ void orc_trace(const rspt_scene_desc* sd, const rspt_ray* rays, uint64_t n, rspt
         Ray r{V3{rays[i].o[0], rays[i].o[1], rays[i].o[2]}, V3{rays[i].d[0], rays[i].d[1], rays[i].d[2]}, rays[i].t_max, 0.0f};
         rspt_hit h; h.prim = 0xffffffffu; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
         if (any_hit) { if (sc.intersect_p(r, &c)) h.prim = 0; }
-        else if (brute) { uint32_t p = RSPT_MISS; Float t = 0.0f; if (sc.intersect_brute(r, &p, &t)) { h.prim = p; h.t = t; } }
+        else if (brute) { uint32_t p = 0xffffffffu; Float t = 0.0f; if (sc.intersect_brute(r, &p, &t)) { h.prim = p; h.t = t; } }
         else {
             Interaction isect; Float t = 0, b[3] = {0, 0, 0};
             if (sc.intersect(r, &isect, &c, &t, b)) { h.prim = (uint32_t)isect.prim; h.t = t; h.b0 = b[0]; h.b1 = b[1]; h.b2 = b[2]; }
@@ -182,6 +182,22 @@ int orc_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_th
         std::memcpy(counters_out, v, sizeof v);
     }
     if (seconds_out) *seconds_out = out.seconds;
+    return 0;
+}
+
+// DirectLightingIntegrator (kind 2; strategy 0 = UniformSampleAll, 1 = UniformSampleOne) and WhittedIntegrator (kind 3)
+// through the same tile loop; n_light_samples: one entry per light or NULL (all 1).  No GPU counterpart yet.
+int orc_render_integrator(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb,
+                          uint64_t* counters_out, int kind, int strategy, const int32_t* n_light_samples) {
+    if (!sd || !rd || (kind != ORC_INTEGRATOR_DIRECT && kind != ORC_INTEGRATOR_WHITTED)) return -1;
+    Scene sc{*sd};
+    RenderOut out;
+    render(sc, *rd, num_threads, film_xyzw, li_rgb, &out, kind, strategy, n_light_samples);
+    if (counters_out) {
+        const Counters& c = out.counters;
+        uint64_t v[8] = {c.nodes_visited, c.tris_tested, c.rays_closest, c.rays_any, c.bounces, c.samples, c.nan_samples, c.mis_rays};
+        std::memcpy(counters_out, v, sizeof v);
+    }
     return 0;
 }
 

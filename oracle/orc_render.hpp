@@ -242,16 +242,28 @@ struct Sampler {
           halton(rd.spp, rd.sample_bounds, rd.sample_at_pixel_center != 0, rd.tables.halton_perms, rd.tables.n_halton_perms) {}
     bool is_halton() const { return kind == RSPT_SAMPLER_HALTON; }
     int64_t cur_sample() const { return is_halton() ? halton.cur_sample : sobol.cur_sample; }
+    // 2-D sample arrays requested by an integrator's preprocess (request_2d_array, sobol.rs:203-209): array i lives in
+    // dimensions 5 + 2 i, 5 + 2 i + 1 (array_start_dim = 5, no 1-D arrays on this path); get_1d / get_2d skip that
+    // range (sobol.rs:180-201, halton.rs:283-305).  round_count is the identity for both samplers (sobol.rs:210-212).
+    std::vector<int32_t> arrays_2d;
+    size_t array_2d_offset = 0;
+    static const int64_t ARRAY_START_DIM = 5;
+    int64_t array_end_dim() const { return ARRAY_START_DIM + 2 * (int64_t)arrays_2d.size(); }
+    void request_2d_array(int32_t n) { arrays_2d.push_back(n); }
+    int64_t& dimension() { return is_halton() ? halton.dimension : sobol.dimension; }
     void start_pixel(int32_t x, int32_t y) {
+        array_2d_offset = 0;
         if (!is_halton()) { sobol.start_pixel(x, y); return; }
         halton.px = x; halton.py = y; halton.cur_sample = 0; halton.dimension = 0;
         halton.interval_sample_index = halton.get_index_for_sample(0);
     }
     Float get_1d() {
+        if (dimension() >= ARRAY_START_DIM && dimension() < array_end_dim()) dimension() = array_end_dim();
         if (!is_halton()) return sobol.get_1d();
         Float r = halton.sample_dimension(halton.interval_sample_index, halton.dimension); halton.dimension += 1; return r;
     }
     P2 get_2d() {
+        if (dimension() + 1 >= ARRAY_START_DIM && dimension() < array_end_dim()) dimension() = array_end_dim();
         if (!is_halton()) return sobol.get_2d();
         Float y = halton.sample_dimension(halton.interval_sample_index, halton.dimension + 1);
         Float x = halton.sample_dimension(halton.interval_sample_index, halton.dimension);
@@ -266,7 +278,17 @@ struct Sampler {
         uint64_t idx = halton.get_index_for_sample(j);
         return P2{halton.sample_dimension(idx, dim), halton.sample_dimension(idx, dim + 1)};
     }
+    // get_2d_array_idxs (sobol.rs:225-236): false when the requested arrays are used up
+    bool get_2d_array(int32_t n, size_t* array_idx, uint64_t* start) {
+        if (array_2d_offset == arrays_2d.size()) return false;
+        // (the reference asserts samples_2d_array_sizes[offset] == n)
+        *array_idx = array_2d_offset; *start = (uint64_t)cur_sample() * (uint64_t)n;
+        array_2d_offset += 1;
+        return true;
+    }
+    P2 get_2d_sample(size_t array_idx, uint64_t j) const { return array_2d(j, ARRAY_START_DIM + 2 * (int64_t)array_idx); }
     bool start_next_sample() { // halton.rs:333-343
+        array_2d_offset = 0;
         if (!is_halton()) return sobol.start_next_sample();
         halton.dimension = 0;
         halton.interval_sample_index = halton.get_index_for_sample((uint64_t)halton.cur_sample + 1);
@@ -300,9 +322,15 @@ struct Distribution1D {
     }
 };
 
+// Integrators restated ahead of their GPU counterpart: selected through orc_render_integrator only.
+enum { ORC_INTEGRATOR_FROM_DESC = 0, ORC_INTEGRATOR_DIRECT = 2, ORC_INTEGRATOR_WHITTED = 3 };
+enum { ORC_DIRECT_SAMPLE_ALL = 0, ORC_DIRECT_SAMPLE_ONE = 1 }; // LightStrategy (directlighting.rs:17-21)
 struct RenderCtx {
     const Scene* scene;
     const rspt_render_desc* rd;
+    int ext_integrator = ORC_INTEGRATOR_FROM_DESC;
+    int direct_strategy = ORC_DIRECT_SAMPLE_ALL;
+    std::vector<int32_t> n_light_samples; // per light: Light::get_n_samples (api.rs "samples" / "nsamples", default 1)
     // light distribution state (src/core/lightdistrib.rs)
     int strategy; // after the "1 light -> uniform" rule (:397)
     std::shared_ptr<Distribution1D> fixed; // uniform / power
@@ -711,6 +739,132 @@ static inline Spec ao_li(RenderCtx& cx, const Ray& ray, Sampler& sampler, Counte
     return l;
 }
 
+// ---- DirectLightingIntegrator (src/integrators/directlighting.rs) and WhittedIntegrator (src/integrators/whitted.rs) ----
+// Both recurse through specular_reflect / specular_transmit; the sampler's dimension counter follows that depth-first
+// order.  Materials must have been flattened with allow_multiple_lobes = false (compute_scattering_functions(ray, false, ..)).
+static inline Spec uniform_sample_all_lights(RenderCtx& cx, const Interaction& it, const Bsdf& bsdf, Sampler& sampler, Counters* c) { // integrator.rs:300-355
+    const Scene& sc = *cx.scene;
+    Spec l;
+    for (uint32_t j = 0; j < sc.d.n_lights && j < cx.n_light_samples.size(); j++) {
+        int32_t n_samples = cx.n_light_samples[j];
+        size_t ia = 0, ib = 0; uint64_t sa = 0, sb = 0;
+        bool have_a = sampler.get_2d_array(n_samples, &ia, &sa);
+        bool have_b = sampler.get_2d_array(n_samples, &ib, &sb);
+        if (!have_a || !have_b) {
+            P2 u_light = sampler.get_2d();
+            P2 u_scattering = sampler.get_2d();
+            l = l + estimate_direct(cx, it, bsdf, u_scattering, j, u_light, c);
+        } else {
+            Spec ld;
+            for (int32_t k = 0; k < n_samples; k++) {
+                P2 u_scattering = sampler.get_2d_sample(ib, sb + (uint64_t)k);
+                P2 u_light = sampler.get_2d_sample(ia, sa + (uint64_t)k);
+                ld = ld + estimate_direct(cx, it, bsdf, u_scattering, j, u_light, c);
+            }
+            l = l + ld / (Float)n_samples;
+        }
+    }
+    return l;
+}
+static inline Spec uniform_sample_one_light_nodistrib(RenderCtx& cx, const Interaction& it, const Bsdf& bsdf, Sampler& sampler, Counters* c) { // integrator.rs:359-403 with light_distrib = None
+    uint32_t nl = cx.scene->d.n_lights;
+    if (nl == 0) return Spec();
+    uint32_t light_num = std::min((uint32_t)(sampler.get_1d() * (Float)nl), nl - 1u);
+    Float light_pdf = 1.0f / (Float)nl;
+    P2 u_light = sampler.get_2d();
+    P2 u_scattering = sampler.get_2d();
+    return estimate_direct(cx, it, bsdf, u_scattering, light_num, u_light, c) / light_pdf;
+}
+static inline Spec recursive_li(RenderCtx& cx, const Ray& ray, Sampler& sampler, int depth, Counters* c);
+static inline V3 differential_normal(const Interaction& si, bool x) { // dndx / dndy (directlighting.rs:164-167)
+    return x ? si.sh_dndu * si.dudx + si.sh_dndv * si.dvdx : si.sh_dndu * si.dudy + si.sh_dndv * si.dvdy;
+}
+static inline Spec specular_reflect(RenderCtx& cx, const Ray& ray, const Interaction& isect, const Bsdf& bsdf, Sampler& sampler, int depth, Counters* c) { // directlighting.rs:133-192 == whitted.rs:127-186
+    V3 wo = isect.wo, wi{0, 0, 0};
+    Float pdf = 0.0f;
+    V3 ns = isect.sh_n;
+    uint8_t sampled_type = 0;
+    Spec f = bsdf.sample_f(wo, &wi, sampler.get_2d(), &pdf, BSDF_REFLECTION | BSDF_SPECULAR, &sampled_type);
+    if (!(pdf > 0.0f && !f.is_black() && abs_dot(wi, ns) != 0.0f)) return Spec();
+    Ray rd = isect.spawn_ray(wi);
+    if (ray.has_diff) {
+        V3 dndx = differential_normal(isect, true), dndy = differential_normal(isect, false);
+        V3 dwodx = -ray.rx_d - wo, dwody = -ray.ry_d - wo;
+        Float ddndx = dot(dwodx, ns) + dot(wo, dndx);
+        Float ddndy = dot(dwody, ns) + dot(wo, dndy);
+        rd.has_diff = true;
+        rd.rx_o = isect.p + isect.dpdx; rd.ry_o = isect.p + isect.dpdy;
+        rd.rx_d = wi - dwodx + (dndx * dot(wo, ns) + ns * ddndx) * 2.0f;
+        rd.ry_d = wi - dwody + (dndy * dot(wo, ns) + ns * ddndy) * 2.0f;
+    }
+    return f * recursive_li(cx, rd, sampler, depth + 1, c) * Spec(abs_dot(wi, ns) / pdf);
+}
+static inline Spec specular_transmit(RenderCtx& cx, const Ray& ray, const Interaction& isect, const Bsdf& bsdf, Sampler& sampler, int depth, Counters* c) { // directlighting.rs:193-258 == whitted.rs:187-253
+    V3 wo = isect.wo, wi{0, 0, 0};
+    Float pdf = 0.0f;
+    V3 ns = isect.sh_n;
+    uint8_t sampled_type = 0;
+    Spec f = bsdf.sample_f(wo, &wi, sampler.get_2d(), &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR, &sampled_type);
+    if (!(pdf > 0.0f && !f.is_black() && abs_dot(wi, ns) != 0.0f)) return Spec();
+    Ray rd = isect.spawn_ray(wi);
+    if (ray.has_diff) {
+        Float eta = bsdf.eta;
+        V3 w = -wo;
+        if (dot(wo, ns) < 0.0f) eta = 1.0f / eta;
+        V3 dndx = differential_normal(isect, true), dndy = differential_normal(isect, false);
+        V3 dwodx = -ray.rx_d - wo, dwody = -ray.ry_d - wo;
+        Float ddndx = dot(dwodx, ns) + dot(wo, dndx);
+        Float ddndy = dot(dwody, ns) + dot(wo, dndy);
+        Float mu = eta * dot(w, ns) - dot(wi, ns);
+        Float dmudx = (eta - (eta * eta * dot(w, ns)) / dot(wi, ns)) * ddndx;
+        Float dmudy = (eta - (eta * eta * dot(w, ns)) / dot(wi, ns)) * ddndy;
+        rd.has_diff = true;
+        rd.rx_o = isect.p + isect.dpdx; rd.ry_o = isect.p + isect.dpdy;
+        rd.rx_d = wi + dwodx * eta - (dndx * mu + ns * dmudx);
+        rd.ry_d = wi + dwody * eta - (dndy * mu + ns * dmudy);
+    }
+    return f * recursive_li(cx, rd, sampler, depth + 1, c) * Spec(abs_dot(wi, ns) / pdf);
+}
+static inline Spec recursive_li(RenderCtx& cx, const Ray& ray, Sampler& sampler, int depth, Counters* c) { // directlighting.rs:71-123, whitted.rs:43-117
+    const Scene& sc = *cx.scene;
+    const bool whitted = cx.ext_integrator == ORC_INTEGRATOR_WHITTED;
+    Spec l;
+    Interaction isect;
+    if (!sc.intersect(ray, &isect, c)) {
+        for (uint32_t i = 0; i < sc.d.n_lights; i++) // every light's le(ray); only the infinite light's is not black
+            if (sc.d.lights[i].kind == RSPT_LIGHT_INFINITE) l = l + infinite_le(sc, sc.d.lights[i], ray.d);
+        return l;
+    }
+    const rspt_prim& hp = sc.d.prims[isect.prim];
+    V3 n_before = isect.sh_n; // whitted.rs:58: shading.n read before compute_scattering_functions (i.e. before a bump map moves it)
+    if (hp.material == 0xffffffffu) return recursive_li(cx, isect.spawn_ray(ray.d), sampler, depth, c);
+    compute_differentials(&isect, ray);
+    Bsdf bsdf(sc, isect, sc.d.materials[hp.material]);
+    if (c) c->bounces++;
+    V3 wo = isect.wo;
+    if (hp.area_light >= 0) l = l + light_l(sc.d.lights[hp.area_light], isect.n, wo); // isect.le(&wo)
+    if (whitted) {
+        for (uint32_t j = 0; j < sc.d.n_lights; j++) { // whitted.rs:74-101: one sample per light, no MIS
+            const rspt_light& light = sc.d.lights[j];
+            V3 wi{0, 0, 0};
+            Float pdf = 0.0f;
+            Interaction light_intr;
+            Spec li = light_sample_li(sc, light, isect, sampler.get_2d(), &wi, &pdf, &light_intr);
+            if (li.is_black() || pdf == 0.0f) continue;
+            Spec f = bsdf.f(wo, wi, BSDF_ALL);
+            if (!f.is_black() && !sc.intersect_p(isect.spawn_ray_to(light_intr), c)) l = l + f * li * Spec(abs_dot(wi, n_before) / pdf);
+        }
+    } else if (sc.d.n_lights) {
+        if (cx.direct_strategy == ORC_DIRECT_SAMPLE_ALL) l = l + uniform_sample_all_lights(cx, isect, bsdf, sampler, c);
+        else l = l + uniform_sample_one_light_nodistrib(cx, isect, bsdf, sampler, c);
+    }
+    if ((uint32_t)(depth + 1) < cx.rd->max_depth) {
+        l = l + specular_reflect(cx, ray, isect, bsdf, sampler, depth, c);
+        l = l + specular_transmit(cx, ray, isect, bsdf, sampler, depth, c);
+    }
+    return l;
+}
+
 // ---- PerspectiveCamera::generate_ray_differential: src/cameras/perspective.rs:190-280 ----
 static inline Ray camera_ray(const rspt_render_desc& rd, P2 p_film, Float time_s, P2 p_lens) {
     V3 p_camera = transform_point(rd.raster_to_camera, V3{p_film.x, p_film.y, 0.0f});
@@ -806,9 +960,12 @@ struct RenderOut {
 // ---- SamplerIntegrator::render: src/core/integrator.rs:70-220 ----
 // film_xyzw: Film.pixels after all merges (xyz + filter_weight_sum per cropped pixel);
 // li_rgb (optional): radiance per camera sample, [(pixel*spp+s)*3] over crop_px.
-static inline void render(const Scene& scene, const rspt_render_desc& rd, int num_threads, float* film_xyzw, float* li_rgb, RenderOut* out) {
+static inline void render(const Scene& scene, const rspt_render_desc& rd, int num_threads, float* film_xyzw, float* li_rgb, RenderOut* out,
+                          int ext_integrator = ORC_INTEGRATOR_FROM_DESC, int direct_strategy = ORC_DIRECT_SAMPLE_ALL, const int32_t* n_light_samples = nullptr) {
     RenderCtx cx;
     cx.scene = &scene; cx.rd = &rd;
+    cx.ext_integrator = ext_integrator; cx.direct_strategy = direct_strategy;
+    for (uint32_t i = 0; i < scene.d.n_lights; i++) cx.n_light_samples.push_back(n_light_samples ? n_light_samples[i] : 1);
     light_distrib_init(cx);
     const int32_t* sb = rd.sample_bounds;
     int32_t ext_x = sb[2] - sb[0], ext_y = sb[3] - sb[1];
@@ -828,6 +985,10 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
     std::vector<Counters> tc((size_t)std::max(1, num_threads));
     auto worker = [&](int tid) {
         Sampler sampler(rd);
+        if (rd.integrator == RSPT_INTEGRATOR_AO && ext_integrator == ORC_INTEGRATOR_FROM_DESC) sampler.request_2d_array((int32_t)rd.ao_n_samples); // ao.rs:44-48
+        if (ext_integrator == ORC_INTEGRATOR_DIRECT && direct_strategy == ORC_DIRECT_SAMPLE_ALL) // preprocess, directlighting.rs:54-70
+            for (uint32_t i = 0; i < rd.max_depth; i++)
+                for (uint32_t j = 0; j < scene.d.n_lights; j++) { sampler.request_2d_array(cx.n_light_samples[j]); sampler.request_2d_array(cx.n_light_samples[j]); }
         Counters& c = tc[tid];
         for (;;) {
             size_t k = next.fetch_add(1);
@@ -851,7 +1012,9 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         Ray ray = camera_ray(rd, p_film, time_s, p_lens);
                         ray.scale_differentials(1.0f / std::sqrt((Float)rd.spp)); // integrator.rs:140-144 (get_samples_per_pixel)
                         Float ray_weight = 1.0f;
-                        Spec l = rd.integrator == RSPT_INTEGRATOR_AO ? ao_li(cx, ray, sampler, &c) : path_li(cx, ray, sampler, &c);
+                        Spec l = ext_integrator != ORC_INTEGRATOR_FROM_DESC ? recursive_li(cx, ray, sampler, 0, &c)
+                                 : rd.integrator == RSPT_INTEGRATOR_AO       ? ao_li(cx, ray, sampler, &c)
+                                                                             : path_li(cx, ray, sampler, &c);
                         c.samples++;
                         if (l.has_nans()) { l = Spec(0.0f); c.nan_samples++; } // integrator.rs:165-173 (Q1)
                         if (li_rgb && px >= rd.crop_px[0] && px < rd.crop_px[2] && py >= rd.crop_px[1] && py < rd.crop_px[3]) {

@@ -41,6 +41,8 @@ def lib():
         L.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_render_integrator.restype = C.c_int
+        L.orc_render_integrator.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_camera_sample.restype = None
         L.orc_camera_sample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
         L.orc_camera_ray.restype = None; L.orc_camera_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -102,6 +104,24 @@ def trace(scene, rays, any_hit=False, brute=False, counters=False):
 
 
 COUNTER_NAMES = ("nodes_visited", "tris_tested", "rays_closest", "rays_any", "bounces", "samples", "nan_samples", "mis_rays")
+
+
+def render_integrator(scene, rd, kind, strategy="all", light_samples=None, threads=1, want_li=False):
+    """DirectLightingIntegrator ("direct"; strategy "all" = UniformSampleAll | "one" = UniformSampleOne) or
+    WhittedIntegrator ("whitted") through the oracle's tile loop (oracle-only: no GPU counterpart yet).
+    light_samples: per-light sample counts of UniformSampleAll (Light::get_n_samples), default 1 each."""
+    npix = (rd.crop_px[2] - rd.crop_px[0]) * (rd.crop_px[3] - rd.crop_px[1])
+    film = np.zeros((npix, 4), np.float32)
+    li = np.zeros((npix, int(rd.spp), 3), np.float32) if want_li else None
+    cnt = np.zeros(8, np.uint64)
+    ns = None if light_samples is None else np.ascontiguousarray(light_samples, np.int32)
+    assert ns is None or len(ns) == scene.desc.n_lights
+    rc = lib().orc_render_integrator(C.addressof(scene.desc), C.addressof(rd), threads, film.ctypes.data,
+                                     li.ctypes.data if want_li else None, cnt.ctypes.data,
+                                     {"direct": 2, "whitted": 3}[kind], {"all": 0, "one": 1}[strategy],
+                                     None if ns is None else ns.ctypes.data)
+    assert rc == 0
+    return dict(film=film, li=li, counters=dict(zip(COUNTER_NAMES, (int(x) for x in cnt))))
 
 
 def render(scene, rd, threads=1, want_li=False):
