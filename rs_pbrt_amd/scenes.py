@@ -256,9 +256,18 @@ def mirror(kr=(0.9,) * 3):  # mirror.rs:34-70 (pushed even if black)
     return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_NOOP, r=np.maximum(np.array(kr, F32), 0))])
 
 
-def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5):  # glass.rs:83-211, smooth + allow_multiple_lobes
-    return dict(eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=np.maximum(np.array(kr, F32), 0),
-                                        t=np.maximum(np.array(kt, F32), 0), eta_a=1.0, eta_b=index)])
+def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, multiple_lobes=True):  # glass.rs:83-211, smooth surface
+    """multiple_lobes: the integrator's allow_multiple_lobes — true for `path` (one FresnelSpecular lobe), false for
+    `directlighting` / `whitted` (SpecularReflection with a dielectric Fresnel + SpecularTransmission, glass.rs:136-188)"""
+    r, t = np.maximum(np.array(kr, F32), 0), np.maximum(np.array(kt, F32), 0)
+    if multiple_lobes:
+        return dict(eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=r, t=t, eta_a=1.0, eta_b=index)])
+    lobes = []
+    if r.any():
+        lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=r, eta_a=1.0, eta_b=index))
+    if t.any():
+        lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=t, eta_a=1.0, eta_b=index))
+    return dict(eta=index, lobes=lobes)
 
 
 def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True):  # metal.rs:144-205

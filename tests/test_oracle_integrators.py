@@ -66,9 +66,7 @@ def _mirror_scene(oracle, pane=None):
     sb.add_quad([(-50, -50, 4), (-50, 50, 4), (50, 50, 4), (50, -50, 4)], mir)  # normal towards -z
     sb.add_quad([(-50, -50, -2), (50, -50, -2), (50, 50, -2), (-50, 50, -2)], dark, emit=(3.0, 2.0, 1.0))  # normal towards +z
     if pane is not None:
-        lobes = [scenes._lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=np.ones(3, np.float32), eta_a=1.0, eta_b=pane),
-                 scenes._lobe(type=abi.BXDF_SPECULAR_T, r=np.ones(3, np.float32), eta_a=1.0, eta_b=pane)]
-        g = sb.add_material(dict(eta=pane, lobes=lobes))
+        g = sb.add_material(scenes.glass(index=pane, multiple_lobes=False))
         sb.add_quad([(-50, -50, 2), (-50, 50, 2), (50, 50, 2), (50, -50, 2)], g)
     return sb.finish(oracle.bvh_build)
 
