@@ -162,7 +162,7 @@ def main():
                                          "note": "rays of one step / wall time of its (overlapped) trace launches"}},
             "setup_s": {"scene_and_bvh_build": t_scene, "upload": t_upload, "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported on rank 0 at N = 1 only
             from oracle import pyoracle  # CPU baseline leg only
             ncores = os.cpu_count() or 1
             rd_cpu = mk_rd(args.cpu_spp, (0, 1, 64))
