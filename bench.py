@@ -4,22 +4,32 @@ configs[1] — synthetic 1 M random-triangle soup, PathIntegrator depth 8, Sobol
 1024x1024 (resolution fixed by SURVEY.md §8d).
 
 A "step" is one full render of that frame (1024*1024*256 = 268 M camera samples through
-raygen -> trace -> shade -> film), with the scene already resident in HBM.  With N ranks the
-Morton-ordered 16x16 tiles of the frame are dealt to the ranks (strong scaling: the frame is
-fixed) and the per-rank film buffers are summed onto rank 0 with one RCCL reduce inside the
-timed region.  Prints ONE JSON line on rank 0.
+raygen -> trace -> shade -> film), with the scene already resident in HBM and the film left in HBM.
+With N ranks the Morton-ordered 16x16 tiles of the frame are dealt to the ranks (strong scaling: the
+frame is fixed) and the per-rank films are summed onto rank 0 by one ncclReduce INSIDE librspt
+(rspt_render_desc.film_reduce, RCCL over xGMI) in the timed region.  Prints ONE JSON line on rank 0.
 
     python bench.py                       # N=1, 1 warm-up + 2 timed steps
+    python bench.py --gpus 8              # spawns 8 ranks itself (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8
-"""
+
+At N = 1 the line also carries (rank 0 only, outside the timed region of the headline):
+  roofline       the traversal kernel (k_trace_w4, closest-hit + shadow-ray launches): SURVEY §8(d) algorithmic bytes of
+                 one step / the sum of its per-launch durations (HIP events on each launch's own stream)
+  cpu_baseline   the C++ oracle's tile loop on all host cores (+ a 1-thread run) on a bounded sample of the same frame
+  extra          C3 (the 4.3 M-triangle statue stand-in at 1920x1080x1024 spp — the north-star configuration) timed the
+                 same way with its own roofline / cpu_baseline, and a 1/8-frame probe of the headline workload
+                 (what one rank of an 8-GPU node renders)"""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a streaming copy reaches)
 
 
 def parse():
@@ -27,55 +37,192 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--integrator", default="path", choices=["path", "ao"], help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample)")
-    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex", "c4"])
+    ap.add_argument("--integrator", default="path", choices=["path", "ao"],
+                    help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample)")
+    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 line and the 1/8-frame probe")
+    ap.add_argument("--no-count", action="store_true", help="skip the reference-order counting pass (no roofline block): for PMC runs")
     ap.add_argument("--cpu-spp", type=int, default=16)
     return ap.parse_args()
 
 
-def build_workload(args, lib, scenes, shard):
-    if args.workload == "soup1m":
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def build_workload(args, workload, lib, scenes):
+    """-> (scene, mk_rd(spp, shard), spp, name)"""
+    integ = args.integrator
+    if workload == "soup1m":
         res, spp = args.res or 1024, args.spp or 256
         sc = scenes.triangle_soup(lib.bvh_build_gpu, n_tris=args.tris)
-        mk = lambda s, sh: scenes.soup_render_desc(res=res, spp=s, max_depth=8, shard=sh, integrator=args.integrator)  # noqa: E731
+        mk = lambda s, sh, **kw: scenes.soup_render_desc(res=res, spp=s, max_depth=8, shard=sh, integrator=integ, **kw)  # noqa: E731
         name = "synthetic %d-triangle soup, path depth 8, sobol %d spp, %dx%d" % (args.tris, spp, res, res)
-    elif args.workload == "cornell":
+    elif workload == "cornell":
         res, spp = args.res or 400, args.spp or 64
         sc = scenes.cornell_box(lib.bvh_build_gpu)
-        mk = lambda s, sh: scenes.cornell_render_desc(res=res, spp=s, shard=sh, integrator=args.integrator)  # noqa: E731
+        mk = lambda s, sh, **kw: scenes.cornell_render_desc(res=res, spp=s, shard=sh, integrator=integ, **kw)  # noqa: E731
         name = "Cornell Box, path depth 5, sobol %d spp, %dx%d" % (spp, res, res)
+    elif workload == "c5":
+        xres, spp = args.res or 1920, args.spp or 64
+        yres = xres * 9 // 16
+        sc = scenes.landscape_standin(lib.bvh_build_gpu)
+        mk = lambda s, sh, **kw: scenes.landscape_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=integ, **kw)  # noqa: E731
+        name = "landscape stand-in (instanced trees + lat-long sky, C5 stand-in), path depth 5, sobol %d spp, %dx%d" % (spp, xres, yres)
     else:
         xres, spp = args.res or 1920, args.spp or 1024
         yres = xres * 9 // 16
-        tex = args.workload in ("statue_tex", "c4")  # image-textured Kd + bump map + textured ground
-        sc = scenes.statue_standin(lib.bvh_build_gpu, textured=tex, many_lights=64 if args.workload == "c4" else 0)  # c4: SURVEY 8(d) C4 stand-in
-        mk = lambda s, sh: scenes.statue_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=args.integrator)  # noqa: E731
-        name = "statue stand-in (4.3 M triangles%s%s), path depth 5, sobol %d spp, %dx%d" % (", image-textured + bump-mapped" if tex else "",
-                                                                                                   ", 64 small area lights (C4 stand-in)" if args.workload == "c4" else "", spp, xres, yres)
-    if args.integrator == "ao":
-        name += " [AOIntegrator, 64 shadow rays per camera sample]"
+        tex = workload in ("statue_tex", "c4")  # image-textured Kd + bump map + textured ground (SURVEY 8(f) #1)
+        sc = scenes.statue_standin(lib.bvh_build_gpu, textured=tex, many_lights=64 if workload == "c4" else 0)  # c4: SURVEY 8(d) C4 stand-in
+        mk = lambda s, sh, **kw: scenes.statue_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=integ, **kw)  # noqa: E731
+        name = "statue stand-in (4.3 M triangles%s%s; DECLARED STAND-IN for the off-tree Ganesha asset), path depth 5, sobol %d spp, %dx%d" % (
+            ", image-textured + bump-mapped" if tex else "", ", 64 small area lights (C4 stand-in)" if workload == "c4" else "", spp, xres, yres)
+    if integ != "path":
+        name += " [%s integrator]" % integ
     return sc, mk, spp, name
 
 
-def measured_traffic(args):
+def measured_traffic(lib, workload, default_cfg):
     """HBM-side bytes of the trace launches of one step from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE with the gfx950 correction of
-    MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so the number is
-    only reported for the exact workload it was measured on; otherwise null."""
+    (profiles/r02_pmc_traffic.json, written by tools/refresh_profiles.sh: FETCH_SIZE / WRITE_SIZE in separate
+    passes with the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process,
+    so the figure is only reported when the profile was taken with the same kernel sources (hash of
+    rs_pbrt_amd/csrc + include/rspt.h) and for the exact workload; otherwise null."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
     except (OSError, ValueError):
-        return None
-    default_cfg = args.workload == "soup1m" and args.tris == 1_000_000 and not args.res and not args.spp and args.gpus == 1
-    return t["trace_traffic_bytes_per_step"] if (default_cfg and t.get("workload") == args.workload) else None
+        return None, "no profiles/r02_pmc_traffic.json"
+    w = t.get("workloads", {}).get(workload)
+    if not default_cfg or not w:
+        return None, "no PMC pass for this workload / size"
+    if t.get("source_hash") != lib.source_hash():
+        return None, "PMC pass is from other kernel sources (%s, library %s)" % (t.get("source_hash"), lib.source_hash())
+    return w, None
+
+
+def roofline_block(counts, count_scale, stats, traffic, traffic_note):
+    """the dominant kernel k_trace_w4 (closest-hit + shadow-ray launches of one step, this rank):
+    SURVEY.md §8(d) bytes = 32 B per BVH node fetched + 48 B per triangle tested + ray / hit queue records
+    (96 B per closest-hit ray, 72 B per any-hit ray), counted by the reference-order COUNT kernels in the warm-up pass."""
+    n = len(stats)
+    trace_bytes = count_scale * (32.0 * counts["nodes_visited"] + 48.0 * counts["tris_tested"] + 96.0 * counts["rays_closest"] + 72.0 * counts["rays_any"])
+    t_c = sum(s["t_trace_closest_s"] for s in stats) / n
+    t_a = sum(s["t_trace_any_s"] for s in stats) / n
+    t_wall = sum(s["t_trace_s"] for s in stats) / n
+    t_sh = sum(s["t_shade_s"] for s in stats) / n
+    t_k = sum(s["t_kernels_s"] for s in stats) / n
+    launches = stats[0]["launches_closest"] + stats[0]["launches_any"]
+    dur = t_c + t_a
+    achieved = trace_bytes / dur / 1e9
+    rays = count_scale * (counts["rays_closest"] + counts["rays_any"])
+    out = {"bound": "hbm", "kernel": "k_trace_w4 (BVH traversal + triangle test; closest-hit + shadow-ray launches)",
+           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": (traffic["trace_traffic_bytes_per_step"] / max(launches, 1)) if traffic else None,
+           "launches_per_step": launches, "avg_launch_ms": dur / max(launches, 1) * 1e3, "alg_bytes_per_launch": trace_bytes / max(launches, 1),
+           "how": "algorithmic bytes of one step (SURVEY 8(d): 32 B/node visit + 48 B/triangle test + 96 B/closest ray + 72 B/any ray of the "
+                  "REFERENCE's traversal, counted in the warm-up) / sum of the per-launch durations of the step's trace launches, each "
+                  "bracketed by HIP events on the stream it runs on; the shadow-ray launch of a bounce overlaps the closest-hit launch on a "
+                  "second stream, so the sum (%.3f s) exceeds their wall time (%.3f s)" % (dur, t_wall),
+           "alg_bytes_per_step_rank0": trace_bytes,
+           "seconds_per_step": {"trace_closest_launches": t_c, "trace_any_launches": t_a, "trace_wall_overlapped": t_wall, "shade_launches": t_sh, "all_kernels_wall": t_k},
+           "whole_path_alg_bytes_per_sample": counts["alg_bytes"] / max(counts["samples"], 1),
+           "rays_per_sample": (counts["rays_closest"] + counts["rays_any"]) / max(counts["samples"], 1),
+           "nodes_per_ray": counts["nodes_visited"] / max(counts["rays_closest"] + counts["rays_any"], 1),
+           "tris_per_ray": counts["tris_tested"] / max(counts["rays_closest"] + counts["rays_any"], 1),
+           "mrays_per_s": rays / dur / 1e6}
+    if traffic:
+        tb = traffic["trace_traffic_bytes_per_step"]
+        out["traffic_frac_of_peak"] = tb / dur / 1e9 / HBM_PEAK_GBS
+        out["traffic_over_algorithmic"] = tb / trace_bytes
+        out["traffic_source"] = traffic.get("source", "profiles/r02_pmc_traffic.json")
+        out["bound_note"] = ("fabric-side traffic (L2 misses, Infinity-Cache hits included) is %.2f x the algorithmic bytes: the BVH records are served "
+                             "from L2 / Infinity Cache, so HBM bandwidth is not what limits this kernel on this scene; the limiter is the L1 request "
+                             "rate of the per-lane record loads (profiles/r02_pmc_trace_l1.md)" % (tb / trace_bytes))
+    else:
+        out["traffic_note"] = traffic_note
+    return out
+
+
+def time_steps(step, fence, n):
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(n)]
+    fence()
+    return time.perf_counter() - t0, stats
+
+
+def cpu_baseline(args, pyoracle, sc, mk_rd, spp, one_thread_crop):
+    ncores = os.cpu_count() or 1
+    rd_cpu = mk_rd(spp, (0, 1, 64))
+    r = pyoracle.render(sc, rd_cpu, threads=ncores)
+    c = r["counters"]
+    out = {"value": c["samples"] / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
+           "sample": "same scene and frame at %d spp (%d samples), C++ oracle restatement of rs_pbrt's tile loop (rs_pbrt itself cannot be built "
+                     "here: no Rust toolchain), %d threads, %.1f s" % (spp, c["samples"], ncores, r["seconds"]),
+           # SURVEY 8(d) "oracle_counters.json per config", emitted in the run: the CPU oracle's own node / triangle / ray counts
+           "oracle_counters_per_sample": {"nodes": c["nodes_visited"] / c["samples"], "tris": c["tris_tested"] / c["samples"],
+                                          "rays_closest": c["rays_closest"] / c["samples"], "rays_any": c["rays_any"] / c["samples"],
+                                          "alg_bytes": (32.0 * c["nodes_visited"] + 48.0 * c["tris_tested"] + 96.0 * c["rays_closest"] + 72.0 * c["rays_any"]
+                                                        + 96.0 * c["bounces"] + 32.0 * c["samples"]) / c["samples"]}}
+    rd1 = mk_rd(spp, (0, 1, 64), crop=one_thread_crop)
+    r1 = pyoracle.render(sc, rd1, threads=1)
+    out["one_thread"] = {"value": r1["counters"]["samples"] / r1["seconds"] / 1e6, "unit": "Msamples/s",
+                         "sample": "crop window %s of the frame at %d spp (%d samples), 1 thread, %.1f s" % (list(rd1.crop_px), spp, r1["counters"]["samples"], r1["seconds"])}
+    out["thread_scaling"] = out["value"] / out["one_thread"]["value"]
+    return out
+
+
+def measure(args, lib, scenes, workload, steps, warmup, shard, world, reduce_in_lib, torch_reduce, fence, count_spp_div=1):
+    """scene build + upload + counting pass + warm-up + timed steps for one workload on this rank"""
+    import torch
+    t0 = time.time()
+    sc, mk_rd, spp, wl_name = build_workload(args, workload, lib, scenes)
+    rd = mk_rd(spp, shard)
+    rd.film_reduce = 1 if reduce_in_lib else 0
+    t_scene = time.time() - t0
+    t0 = time.time()
+    ds = lib.DeviceScene(sc)
+    t_upload = time.time() - t0
+    film = torch.zeros(scenes.n_pixels(rd) * 4, dtype=torch.float32, device="cuda")
+
+    def step():
+        st = lib.render_device(ds, rd, film.data_ptr())  # the reduce (N > 1) runs inside, on the library's stream, before it returns
+        if torch_reduce:
+            torch_reduce(film)
+        return st
+
+    # counting pass (deterministic: identical counts in the timed passes) for the algorithmic-bytes roofline; rank-local, no reduce
+    counts = None
+    if not args.no_count:
+        rd_count = mk_rd(max(spp // count_spp_div, 1), shard)
+        os.environ["RSPT_COUNTERS"] = "1"
+        counts = lib.render_device(ds, rd_count, film.data_ptr())
+        os.environ["RSPT_COUNTERS"] = "0"
+    for _ in range(warmup):
+        step()
+    elapsed, stats = time_steps(step, fence, steps)
+    return dict(sc=sc, ds=ds, mk_rd=mk_rd, spp=spp, name=wl_name, rd=rd, counts=counts, count_scale=float(spp) / max(spp // count_spp_div, 1),
+                elapsed=elapsed, stats=stats, t_scene=t_scene, t_upload=t_upload, film=film, step=step)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -83,50 +230,39 @@ def main():
     import torch.distributed as dist
     from rs_pbrt_amd import lib, multigpu, scenes
     torch.cuda.set_device(local_rank)
+    lib.init(local_rank)
+    reduce_in_lib, torch_reduce, reduce_name = False, None, "none (1 GPU)"
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    lib.init(local_rank)
-
-    shard = multigpu.shard_for_rank(rank, world)  # contiguous Morton chunks of 64 tiles, round-robin over ranks
-    t0 = time.time()
-    sc, mk_rd, spp, wl_name = build_workload(args, lib, scenes, shard)
-    rd = mk_rd(spp, shard)
-    t_scene = time.time() - t0
-    t0 = time.time()
-    ds = lib.DeviceScene(sc)
-    t_upload = time.time() - t0
-    npix = scenes.n_pixels(rd)
-    film = torch.zeros(npix * 4, dtype=torch.float32, device="cuda")
-
-    def step():
-        st = lib.render_device(ds, rd, film.data_ptr())
-        if world > 1:
-            multigpu.reduce_film(film)  # X1: RCCL reduce(sum) over xGMI (tile borders overlap: sum, not gather)
-        return st
+        # X1 lives in the library: rank 0's id travels over the launcher's process group, then every rank joins the library's own communicator
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(lib.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            lib.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            ok = torch.ones(1, device="cuda")
+        except Exception as e:  # noqa: BLE001 — a node without a usable librccl still gets its number through torch's communicator
+            sys.stderr.write("rank %d: rspt_comm_init failed (%s); falling back to torch.distributed.reduce\n" % (rank, e))
+            ok = torch.zeros(1, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() > 0:
+            reduce_in_lib, reduce_name = True, "ncclReduce(sum) to rank 0 inside rspt_render_device (RCCL, library-owned communicator)"
+        else:
+            def torch_reduce(f):
+                torch.cuda.synchronize()  # the film was written on the library's stream
+                multigpu.reduce_film(f)
+                torch.cuda.synchronize()
+            reduce_name = "torch.distributed.reduce(sum) to rank 0 (fallback: the library's RCCL communicator could not be created)"
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # counting pass (deterministic: identical counts in the timed passes) for the algorithmic-bytes roofline
-    counts = None
-    for w in range(args.warmup):
-        if w == 0:
-            os.environ["RSPT_COUNTERS"] = "1"
-            counts = step()
-            os.environ["RSPT_COUNTERS"] = "0"
-        else:
-            step()
-    if counts is None:
-        os.environ["RSPT_COUNTERS"] = "1"
-        counts = step()
-        os.environ["RSPT_COUNTERS"] = "0"
-    fence()
-    t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
-    fence()
-    elapsed = time.perf_counter() - t0
+    shard = multigpu.shard_for_rank(rank, world)  # contiguous Morton chunks of 64 tiles, round-robin over ranks
+    m = measure(args, lib, scenes, args.workload, args.steps, args.warmup, shard, world, reduce_in_lib, torch_reduce, fence)
+    elapsed, stats = m["elapsed"], m["stats"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -138,42 +274,61 @@ def main():
         samples_per_step = float(stats[0]["samples"])
 
     if rank == 0:
-        # roofline of the dominant kernel k_trace (closest + any launches of one step, this rank):
-        # SURVEY.md §8(d) bytes: 32 B per BVH node fetched + 48 B per triangle tested + ray/hit queue
-        # records (96 B per closest-hit ray, 72 B per any-hit ray)
-        trace_bytes = 32.0 * counts["nodes_visited"] + 48.0 * counts["tris_tested"] + 96.0 * counts["rays_closest"] + 72.0 * counts["rays_any"]
-        t_trace = sum(s["t_trace_s"] for s in stats) / len(stats)
-        t_kernels = sum(s["t_kernels_s"] for s in stats) / len(stats)
-        achieved = trace_bytes / t_trace / 1e9
+        default_cfg = args.tris == 1_000_000 and not args.res and not args.spp and world == 1 and args.integrator == "path"
+        traffic, tnote = measured_traffic(lib, args.workload, default_cfg)
         out = {
             "metric": "Mpath-samples/sec (whole node)", "value": samples_per_step * args.steps / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_name, "samples_per_step": samples_per_step, "tiles": "16x16 Morton, chunks of 64 dealt round-robin",
-                       "film_reduce": "RCCL reduce(sum) to rank 0" if world > 1 else "none (1 GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "k_trace (BVH traversal + triangle test, closest + any launches)",
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args),
-                         "alg_bytes_per_step_rank0": trace_bytes, "trace_s_per_step": t_trace, "kernels_s_per_step": t_kernels,
-                         "trace_launches_per_step": stats[0]["trace_launches"],
-                         "whole_path_alg_bytes_per_sample": counts["alg_bytes"] / max(counts["samples"], 1),
-                         "rays_per_sample": (counts["rays_closest"] + counts["rays_any"]) / max(counts["samples"], 1),
-                         "nodes_per_ray": counts["nodes_visited"] / max(counts["rays_closest"] + counts["rays_any"], 1),
-                         "mrays_per_s": {"closest": counts["rays_closest"] / t_trace / 1e6, "any": counts["rays_any"] / t_trace / 1e6,
-                                         "note": "rays of one step / wall time of its (overlapped) trace launches"}},
-            "setup_s": {"scene_and_bvh_build": t_scene, "upload": t_upload, "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
+            "config": {"workload": m["name"], "samples_per_step": samples_per_step, "tiles": "16x16 Morton, chunks of 64 dealt round-robin",
+                       "film_reduce": reduce_name,
+                       "timed_region": "rspt_render_device per step: first launch -> film complete in HBM%s; SURVEY 8(d)'s t_render ends with the film in "
+                                       "host memory: + 16 B per pixel D2H once per frame (%.1f MB), not included" % (
+                                           " on rank 0 after the reduce" if world > 1 else "", scenes.n_pixels(m["rd"]) * 16 / 1e6)},
+            "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote) if m["counts"] else None,
+            "setup_s": {"scene_and_bvh_build": m["t_scene"], "upload": m["t_upload"], "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported on rank 0 at N = 1 only
+        pyoracle = None
+        if world == 1 and not args.no_cpu_baseline:  # the CPU baseline is reported on rank 0 at N = 1 only
             from oracle import pyoracle  # CPU baseline leg only
-            ncores = os.cpu_count() or 1
-            rd_cpu = mk_rd(args.cpu_spp, (0, 1, 64))
-            r = pyoracle.render(sc, rd_cpu, threads=ncores)
-            out["cpu_baseline"] = {"value": r["counters"]["samples"] / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
-                                   "sample": "same scene and frame at %d spp (%d samples), C++ oracle restatement of rs_pbrt's tile loop, %d threads"
-                                             % (args.cpu_spp, r["counters"]["samples"], ncores)}
+            rd0 = m["rd"]
+            cx, cy = (rd0.crop_px[0] + rd0.crop_px[2]) // 2, (rd0.crop_px[1] + rd0.crop_px[3]) // 2
+            fx, fy = float(rd0.full_res[0]), float(rd0.full_res[1])
+            out["cpu_baseline"] = cpu_baseline(args, pyoracle, m["sc"], m["mk_rd"], args.cpu_spp, ((cx - 24) / fx, (cx + 24) / fx, (cy - 24) / fy, (cy + 24) / fy))
+        if world == 1 and not args.no_extra and args.workload == "soup1m" and default_cfg:
+            extra = {}
+            # what one rank of an 8-GPU node renders: shard (0, 8, 64) of the same frame, same kernels, no reduce
+            rd8 = m["mk_rd"](m["spp"], (0, 8, 64))
+            lib.render_device(m["ds"], rd8, m["film"].data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st8 = [lib.render_device(m["ds"], rd8, m["film"].data_ptr()) for _ in range(3)]
+            torch.cuda.synchronize()
+            t8 = (time.perf_counter() - t0) / 3
+            t1 = elapsed / args.steps
+            extra["eighth_frame_probe"] = {"ms": t8 * 1e3, "samples": st8[0]["samples"], "full_frame_ms": t1 * 1e3,
+                                           "predicted_8gpu_speedup_before_reduce": t1 / t8,
+                                           "note": "one GPU rendering shard (0, 8, 64) of the headline frame: per-rank time of an 8-GPU run without the 16.8 MB reduce"}
+            m["ds"].close()
+            del m
+            # C3: the north-star configuration (>= 100x CPU on the 4.3 M-triangle scene), timed by the same harness
+            m3 = measure(args, lib, scenes, "statue", 2, 1, (0, 1, 64), 1, False, None, fence, count_spp_div=16)
+            s3 = float(m3["stats"][0]["samples"])
+            c3 = {"metric": "Mpath-samples/sec", "value": s3 * 2 / m3["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 2, "warmup": 1,
+                  "ms_per_step": m3["elapsed"] / 2 * 1e3, "config": {"workload": m3["name"], "samples_per_step": s3},
+                  "roofline": roofline_block(m3["counts"], m3["count_scale"], m3["stats"], *measured_traffic(lib, "statue", True)),
+                  "setup_s": {"scene_and_bvh_build": m3["t_scene"], "upload": m3["t_upload"]}}
+            c3["roofline"]["counting_pass"] = "reference-order counters at 1/16 of the spp, scaled (per-sample means; SURVEY 8(d))"
+            if pyoracle is not None:
+                c3["cpu_baseline"] = cpu_baseline(args, pyoracle, m3["sc"], m3["mk_rd"], args.cpu_spp, (0.4875, 0.5125, 0.478, 0.522))
+                c3["gpu_over_cpu"] = c3["value"] / c3["cpu_baseline"]["value"]
+            extra["c3_statue_standin"] = c3
+            m3["ds"].close()
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
-    ds.close()
     if world > 1:
         dist.barrier()
+        lib.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 9
+#define RSPT_ABI_VERSION 10
 
 /* error codes */
 #define RSPT_OK 0
@@ -287,7 +287,10 @@ typedef struct {
     uint32_t integrator;             /* RSPT_INTEGRATOR_* */
     uint32_t ao_n_samples;           /* "nsamples" (default 64)        */
     uint32_t ao_cos_sample;          /* "cossample" (default true)     */
-    uint32_t pad0;
+    uint32_t film_reduce;            /* multi-GPU (X1): 1 = before returning, sum the films of all ranks onto rank 0
+                                        with one ncclReduce over the communicator of rspt_comm_init (shard_count must equal its
+                                        world size, shard_index its rank); the other ranks' buffers keep their partial films.
+                                        0 = no collective (single GPU, or the caller reduces) */
     rspt_sampler_tables tables;
 } rspt_render_desc;
 enum { RSPT_INTEGRATOR_PATH = 0, RSPT_INTEGRATOR_AO = 1 };
@@ -305,6 +308,12 @@ typedef struct {
     uint64_t nan_samples;   /* integrator.rs:165-173                                  */
     uint64_t trace_launches;
     double alg_bytes;       /* SURVEY.md §8(d) B_alg over this render (needs counters) */
+    /* per-launch durations summed over the render, each launch bracketed by HIP events on the stream it runs on (the
+     * shadow-ray launch of a bounce runs on a second stream beside the closest-hit launch, so the two sums overlap in
+     * wall time: t_trace_s is the wall time of the pairs, these are what rocprofv3 --kernel-trace reports per kernel) */
+    double t_trace_closest_s, t_trace_any_s;
+    double t_shade_s;       /* k_shade (+ k_texture) launches                         */
+    uint64_t launches_closest, launches_any;
 } rspt_stats;
 
 /* version of this header the library was built against */
@@ -314,6 +323,16 @@ int rspt_abi_version(void);
  * Must be called once per process before any other call. */
 int rspt_init(int32_t device);
 void rspt_shutdown(void);
+
+/* Multi-GPU: one process per GPU, scene replicated, Morton tile chunks dealt by (shard_index, shard_count,
+ * tile_chunk); the only data-path collective is the final sum of the per-rank films (RCCL ncclReduce over xGMI).  The
+ * reference has no counterpart (its tiles go to threads, integrator.rs:101-217; the per-tile merge is film.rs:346-371).
+ * Rank 0 obtains an id, ships its bytes to the other ranks by any means (the Rust shim: a file or a pipe; bench.py: a
+ * torch.distributed broadcast), every rank calls rspt_comm_init (collective).  librccl.so is bound at run time. */
+#define RSPT_COMM_ID_BYTES 128
+int rspt_comm_unique_id(uint8_t id[RSPT_COMM_ID_BYTES]);
+int rspt_comm_init(int32_t rank, int32_t world, const uint8_t id[RSPT_COMM_ID_BYTES]);
+int rspt_comm_destroy(void);
 
 /* Replaces: RenderOptions::make_scene's hand-over of BVHAccel + lights to
  * Scene::new (src/core/api.rs:474-485, src/core/scene.rs:27-53): uploads the

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -97,7 +97,7 @@ class RenderDesc(C.Structure):
                 ("tile_size", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("tile_chunk", C.c_uint32),
                 ("sample_at_pixel_center", C.c_uint32), ("integrator", C.c_uint32), ("ao_n_samples", C.c_uint32),
-                ("ao_cos_sample", C.c_uint32), ("pad0", C.c_uint32), ("tables", SamplerTables)]
+                ("ao_cos_sample", C.c_uint32), ("film_reduce", C.c_uint32), ("tables", SamplerTables)]
 
 
 class Ray(C.Structure):
@@ -112,7 +112,9 @@ class Stats(C.Structure):
     _fields_ = [("t_render_s", C.c_double), ("t_kernels_s", C.c_double), ("t_trace_s", C.c_double),
                 ("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("nan_samples", C.c_uint64),
-                ("trace_launches", C.c_uint64), ("alg_bytes", C.c_double)]
+                ("trace_launches", C.c_uint64), ("alg_bytes", C.c_double),
+                ("t_trace_closest_s", C.c_double), ("t_trace_any_s", C.c_double), ("t_shade_s", C.c_double),
+                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64)]
 
 
 # numpy dtypes with the same layout (for bulk construction)

@@ -2,6 +2,8 @@
 // the gfx950 kernels (kernels.h), film read-back.  gfx950 only; there is no CPU fallback: every
 // entry point that needs the GPU fails with RSPT_E_NODEVICE / RSPT_E_HIP when it is not there.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the entry points are bound with dlopen when a communicator is asked for
 
 #include <algorithm>
 #include <chrono>
@@ -78,6 +80,46 @@ struct Ctx {
     std::vector<hipEvent_t> events;
 };
 Ctx g;
+
+// X1: the one collective of the multi-GPU decomposition, ncclReduce(sum) of the per-rank films onto rank 0
+// over xGMI.  RCCL is bound at run time so that single-GPU hosts need no librccl; a process that already has one loaded
+// (torch ships its own copy) shares it.
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 0;
+};
+Rccl rc_;
+
+int rccl_bind() {
+    if (rc_.handle) return RSPT_OK;
+    const char* names[] = {getenv("RSPT_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)  // one that is already mapped first
+        if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    for (size_t i = 0; !h && i < sizeof names / sizeof *names; i++)
+        if (names[i] && *names[i]) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(RSPT_E_UNSUPPORTED, "librccl.so not found (%s); set RSPT_RCCL_LIB", dlerror());
+    *(void**)&rc_.GetUniqueId = dlsym(h, "ncclGetUniqueId");
+    *(void**)&rc_.CommInitRank = dlsym(h, "ncclCommInitRank");
+    *(void**)&rc_.Reduce = dlsym(h, "ncclReduce");
+    *(void**)&rc_.CommDestroy = dlsym(h, "ncclCommDestroy");
+    *(void**)&rc_.GetErrorString = dlsym(h, "ncclGetErrorString");
+    if (!rc_.GetUniqueId || !rc_.CommInitRank || !rc_.Reduce || !rc_.CommDestroy || !rc_.GetErrorString)
+        return fail(RSPT_E_UNSUPPORTED, "librccl.so lacks an nccl* entry point");
+    rc_.handle = h;
+    return RSPT_OK;
+}
+#define RCCL_TRY(expr)                                                                                              \
+    do {                                                                                                           \
+        ncclResult_t r_ = (expr);                                                                                  \
+        if (r_ != ncclSuccess) return fail(RSPT_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, rc_.GetErrorString(r_)); \
+    } while (0)
 
 struct LightDist {
     float* func = nullptr;
@@ -308,7 +350,9 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
         else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
-        hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits);
+        // with every spill row in use the four-box kernel cannot overflow (RSPT_W4_MAX_STACK): no second pass to launch
+        const bool can_overflow = !(which >= 2 && s->w4_ok) || RSPT_W4_LDS + spill_rows < RSPT_W4_MAX_STACK;
+        if (can_overflow) hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits);
         return;
     }
     if (count)
@@ -500,6 +544,14 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     uint64_t trace_launches = 0;
     hipEvent_t ev_k0 = get_event(n_ev++), ev_k1 = get_event(n_ev++);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
+    // per-launch durations, each pair recorded on the stream its kernel runs on (closest-hit, shadow-ray, shade [+ texture])
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev[3];
+    auto ev_open = [&](int kind, int lane) {
+        hipEvent_t a = get_event(n_ev++), b = get_event(n_ev++);
+        (void)hipEventRecord(a, lane ? g.stream2 : g.stream);
+        kev[kind].push_back({a, b});
+    };
+    auto ev_close = [&](int kind, int lane) { (void)hipEventRecord(kev[kind].back().second, lane ? g.stream2 : g.stream); };
     HIP_TRY(hipEventRecord(ev_k0, g.stream));
     uint64_t samples = 0;
     for (size_t p0 = 0; p0 < n_pix; p0 += pix_per_batch) {
@@ -514,11 +566,15 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             if (ao) {  // AOIntegrator::li: closest hit, n shadow rays per hit, sum of the unoccluded terms
                 hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++), e2 = get_event(n_ev++), e3 = get_event(n_ev++);
                 HIP_TRY(hipEventRecord(e0, g.stream));
+                ev_open(0, 0);
                 launch_trace<false, 0>(0, counters, tgrid, s, g.q[0][1], &g.cnt[0].closest, 0, &g.cnt[0].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                ev_close(0, 0);
                 HIP_TRY(hipEventRecord(e1, g.stream));
                 hipLaunchKernelGGL(k_ao_spawn, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, g.pix_list, ao_n, d->ao_cos_sample, g.q[0][2], &g.cnt[1]);
                 HIP_TRY(hipEventRecord(e2, g.stream));
+                ev_open(1, 0);
                 launch_trace<true, 0>(0, counters, tgrid, s, g.q[0][2], &g.cnt[1].any, 0, &g.cnt[1].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                ev_close(1, 0);
                 HIP_TRY(hipEventRecord(e3, g.stream));
                 trace_ev.push_back({e0, e1}); trace_ev.push_back({e2, e3});
                 trace_launches += 2;
@@ -535,18 +591,28 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 if (any_lane) {
                     HIP_TRY(hipEventRecord(ev_fork, g.stream));
                     HIP_TRY(hipStreamWaitEvent(g.stream2, ev_fork, 0));
+                    ev_open(1, 1);
                     launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                    ev_close(1, 1);
                     HIP_TRY(hipEventRecord(ev_join, g.stream2));
                 }
+                ev_open(0, 0);
                 launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                ev_close(0, 0);
                 if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
-                else if (it > 0) launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                else if (it > 0) {
+                    ev_open(1, 0);
+                    launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                    ev_close(1, 0);
+                }
                 HIP_TRY(hipEventRecord(e1, g.stream));
                 trace_ev.push_back({e0, e1});
                 trace_launches += it > 0 ? 2 : 1;
+                ev_open(2, 0);
                 if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it]);
                 hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                    g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap);
+                ev_close(2, 0);
                 it++;
                 if (it < nominal_iters) continue;
                 // after max_depth + 1 bounces only pending estimates and null-material passes remain
@@ -566,6 +632,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
     float4* out_dev = film_dev ? (float4*)film_dev : g.film_out;
     hipLaunchKernelGGL(k_film_resolve, dim3((uint32_t)((film_px + 255) / 256)), dim3(256), 0, g.stream, g.film_own, g.film_splat, out_dev, (uint32_t)film_px);
+    if (d->film_reduce) {  // X1: sum of the ranks' films onto rank 0 (a sum, not a gather: tile pixel bounds overlap, film.rs:321-330)
+        if (!rc_.comm) return fail(RSPT_E_INVALID, "film_reduce without a communicator (rspt_comm_init)");
+        if ((uint32_t)rc_.world != shard_count || (uint32_t)rc_.rank != d->shard_index)
+            return fail(RSPT_E_INVALID, "film_reduce: shard %u of %u does not match rank %d of %d", d->shard_index, shard_count, rc_.rank, rc_.world);
+        RCCL_TRY(rc_.Reduce(out_dev, out_dev, film_px * 4, ncclFloat32, ncclSum, 0, rc_.comm, g.stream));
+    }
     HIP_TRY(hipEventRecord(ev_k1, g.stream));
     HIP_TRY(hipGetLastError());
     if (film_host) HIP_TRY(hipMemcpyAsync(film_host, out_dev, film_px * sizeof(float4), hipMemcpyDeviceToHost, g.stream));
@@ -586,6 +658,14 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             if (hipEventElapsedTime(&m, e.first, e.second) == hipSuccess) tr += m;
         }
         stats->t_trace_s = tr * 1e-3;
+        double ksum[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++)
+            for (auto& e : kev[k]) {
+                float m = 0;
+                if (hipEventElapsedTime(&m, e.first, e.second) == hipSuccess) ksum[k] += m;
+            }
+        stats->t_trace_closest_s = ksum[0] * 1e-3; stats->t_trace_any_s = ksum[1] * 1e-3; stats->t_shade_s = ksum[2] * 1e-3;
+        stats->launches_closest = kev[0].size(); stats->launches_any = kev[1].size();
         stats->samples = samples;
         stats->trace_launches = trace_launches;
         unsigned long long tot[8];
@@ -722,6 +802,7 @@ int rspt_init(int32_t device) {
 
 void rspt_shutdown(void) {
     if (!g.inited) return;
+    (void)rspt_comm_destroy();
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
@@ -732,6 +813,39 @@ void rspt_shutdown(void) {
     (void)hipStreamDestroy(g.stream);
     (void)hipStreamDestroy(g.stream2);
     g = Ctx{};
+}
+
+int rspt_comm_unique_id(uint8_t id[RSPT_COMM_ID_BYTES]) {
+    if (!id) return fail(RSPT_E_INVALID, "null argument");
+    int rc = rccl_bind();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == RSPT_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    RCCL_TRY(rc_.GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return RSPT_OK;
+}
+int rspt_comm_init(int32_t rank, int32_t world, const uint8_t id[RSPT_COMM_ID_BYTES]) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(RSPT_E_INVALID, "bad rank / world / id");
+    int rc = rccl_bind();
+    if (rc) return rc;
+    if (rc_.comm) { (void)rc_.CommDestroy(rc_.comm); rc_.comm = nullptr; }
+    HIP_TRY(hipSetDevice(g.device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    RCCL_TRY(rc_.CommInitRank(&rc_.comm, world, u, rank));
+    rc_.rank = rank; rc_.world = world;
+    return RSPT_OK;
+}
+int rspt_comm_destroy(void) {
+    if (rc_.comm) {
+        if (g.inited) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(g.stream); }
+        (void)rc_.CommDestroy(rc_.comm);
+        rc_.comm = nullptr;
+    }
+    rc_.rank = rc_.world = 0;
+    return RSPT_OK;
 }
 
 int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {

@@ -59,7 +59,12 @@ static_assert(2048 * RSPT_W4_LDS + 112 * RSPT_W4_TOP <= 64 * 1024, "k_trace_w4 L
 #define RSPT_W4_STEPS 2      // node steps per outer iteration (refill / leaf-phase checks in between); measured on C2 / C3:
                              // (tries, steps) = (1,1) 334.5 / 1059, (3,1) 326.9 / 1041, (1,2) 338.5 / 1073, (3,2) 333.7 / 1049 Msamples/s
 #endif
-#define RSPT_W4_SPILL 48    // further entries per lane in a global spill buffer (spill_rows <= this); beyond that k_trace_fixup takes over
+#define RSPT_W4_MAX_STACK 96 // deepest stack a ray can need: rspt_scene_create admits at most 64 LinearBVHNode levels (the reference's own
+                             // fixed stack, bvh.rs:420) = 32 record levels, and a step leaves at most three entries behind per level
+#define RSPT_W4_SPILL (RSPT_W4_MAX_STACK - RSPT_W4_LDS)  // further entries per lane in a global spill buffer (spill_rows <= this): with all of
+                             // them no ray can overflow, so no ray is re-traced from scratch (round 1 stopped at 48 rows and paid 132 ms
+                             // per C2 frame for a handful of deep rays redone one per lane by k_trace_fixup); fewer rows
+                             // (RSPT_W4_SPILL_ROWS) bring k_trace_fixup back
 
 // box_pair_hit (trace_wide.h) that also returns the entry distances
 RDEV void box_pair_hit_m(float4 q0, float4 q1, float4 q2, float ox, float oy, float oz, float ix, float iy, float iz, float ray_tmax,

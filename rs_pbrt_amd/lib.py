@@ -15,7 +15,20 @@ _LIB = None
 EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
            "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
-           "rspt_bvh_build_gpu")
+           "rspt_bvh_build_gpu", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy")
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel / ABI sources librspt.so is built from: profiles taken on the GPU box
+    (tools/refresh_profiles.sh) carry it, and bench.py only quotes a PMC traffic figure whose hash matches the tree it runs from"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.cpp"))
+                    + [os.path.join(_HERE, "..", "include", "rspt.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 class RsptError(RuntimeError):
@@ -53,6 +66,8 @@ def lib():
         L.rspt_bvh_build.argtypes = [vp, vp, u64, u32, vp, u64, vp, i32]
         L.rspt_bvh_build_gpu.restype = C.c_int64
         L.rspt_bvh_build_gpu.argtypes = [vp, u64, vp, u64, u32, vp, u64, vp]
+        L.rspt_comm_unique_id.argtypes = [vp]
+        L.rspt_comm_init.argtypes = [i32, i32, vp]
         _LIB = L
     return _LIB
 
@@ -101,6 +116,23 @@ def shutdown():
     global _inited_device
     lib().rspt_shutdown()
     _inited_device = None
+
+
+def comm_unique_id():
+    """rspt_comm_unique_id: the 128 bytes rank 0 hands to the other ranks"""
+    buf = (C.c_uint8 * 128)()
+    _check(lib().rspt_comm_unique_id(C.addressof(buf)))
+    return bytes(buf)
+
+
+def comm_init(rank, world, uid):
+    """rspt_comm_init (collective over the ranks): the RCCL communicator behind rspt_render_desc.film_reduce"""
+    buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+    _check(lib().rspt_comm_init(rank, world, C.addressof(buf)))
+
+
+def comm_destroy():
+    lib().rspt_comm_destroy()
 
 
 class DeviceScene:

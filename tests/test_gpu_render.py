@@ -459,3 +459,26 @@ def test_many_area_lights(gpu, oracle, strategy):
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert (li == ref["li"]).all(axis=2).mean() > 0.75
     assert film_rmse(film, ref["film"]) < 2e-5
+
+
+def test_film_reduce_runs_inside_the_library(gpu):
+    """X1 in the product: rspt_comm_unique_id / rspt_comm_init create the RCCL communicator, film_reduce = 1 makes
+    rspt_render end with ncclReduce(sum) onto rank 0.  One GPU here, so the world has one rank (the sum of one film is that film,
+    bit for bit); what is checked is that the collective is issued by librspt on its own stream, and the argument checks."""
+    from rs_pbrt_amd.lib import RsptError
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=48, spp=4)
+    with gpu.DeviceScene(sc) as ds:
+        plain, _ = gpu.render(ds, rd)
+        rd.film_reduce = 1
+        with pytest.raises(RsptError):  # no communicator yet
+            gpu.render(ds, rd)
+        gpu.comm_init(0, 1, gpu.comm_unique_id())
+        try:
+            reduced, st = gpu.render(ds, rd)
+            assert np.array_equal(plain, reduced) and st["samples"] == 48 * 48 * 4
+            rd.shard_index, rd.shard_count, rd.tile_chunk = 0, 2, 1
+            with pytest.raises(RsptError):  # shard_count must equal the communicator's world size
+                gpu.render(ds, rd)
+        finally:
+            gpu.comm_destroy()

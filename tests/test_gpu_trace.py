@@ -175,7 +175,7 @@ def test_deep_bvh_stack_overflow_fixup(gpu, oracle):
         out = gpu.DeviceBuffer(k * abi.HIT_DT.itemsize)
         # (kernel, spill rows): the four-box kernel with its global spill rows (no ray left over), the same
         # with the spill rows disabled (fix-up pass takes the deep rays), and the two-box kernel (LDS only)
-        for kernel, spill_rows, expect_fixup in (("2", "48", False), ("2", "0", True), ("1", "48", True)):
+        for kernel, spill_rows, expect_fixup in (("2", "84", False), ("2", "0", True), ("1", "84", True)):
             os.environ["RSPT_TRACE_KERNEL"], os.environ["RSPT_W4_SPILL_ROWS"] = kernel, spill_rows
             for any_hit in (False, True):
                 gpu.trace_device(ds, buf, k, out, any_hit=any_hit)

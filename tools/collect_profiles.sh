@@ -1,0 +1,11 @@
+#!/bin/bash
+# copy the judged summaries of one tools/refresh_profiles.sh run from gpurun_out/<tag>/ into profiles/<round>_*
+# usage: tools/collect_profiles.sh <tag> <round prefix, e.g. r02>
+set -u
+tag=$1; r=$2; src=gpurun_out/$tag
+cp $src/bench_soup1m.json profiles/${r}_bench_c2_soup1m_n1.json 2>/dev/null
+for w in cornell statue_tex c4 cornell_ao; do [ -s $src/bench_$w.json ] && cp $src/bench_$w.json profiles/${r}_bench_$w.json; done
+for w in soup1m statue; do [ -s $src/ks_$w.md ] && cp $src/ks_$w.md profiles/${r}_${w}_kernel_stats.md; done
+[ -s $src/pmc_traffic.json ] && cp $src/pmc_traffic.json profiles/${r}_pmc_traffic.json
+[ -s $src/pmc_trace_l1.md ] && cp $src/pmc_trace_l1.md profiles/${r}_pmc_trace_l1.md
+ls -la profiles | grep ${r}_

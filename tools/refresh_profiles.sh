@@ -1,23 +1,39 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): bench lines, rocprofv3 kernel stats and the PMC traffic passes behind profiles/.
-# usage: tools/refresh_profiles.sh <tag> [quick]   -> gpurun_out/<tag>/   (quick: no PMC passes, kernel stats of C2 and C3 only)
+# Runs on the GPU box (through gpurun): bench lines, rocprofv3 kernel stats and the PMC passes behind profiles/.
+# usage: tools/refresh_profiles.sh <tag> [quick|pmc|all]  -> gpurun_out/<tag>/
+#   quick: the default bench line (with the C3 extra) + kernel stats of C2 and C3
+#   pmc:   quick + the PMC passes (FETCH_SIZE / WRITE_SIZE / TCP / SQ, each in its own run, --kernel-trace only) -> pmc_traffic.json, pmc_trace_l1.md
+#   all:   pmc + the bench lines of the other workloads
+# Copy what is to be judged from gpurun_out/<tag>/ into profiles/ (tools/collect_profiles.sh <tag> r02).
 set -u
-tag=${1:-v5}; quick=${2:-}; out=$PWD/gpurun_out/$tag; mkdir -p $out
+tag=${1:-r02}; mode=${2:-quick}; out=$PWD/gpurun_out/$tag; mkdir -p $out; repo=$PWD
 export TMPDIR=/tmp
-for w in soup1m cornell statue statue_tex c4; do
-  timeout 200 python bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
-done
-timeout 200 python bench.py --workload cornell --integrator ao --spp 16 > $out/bench_cornell_ao.json 2> $out/bench_cornell_ao.err
-ks="soup1m statue statue_tex"; [ -n "$quick" ] && ks="soup1m statue"
-for w in $ks; do
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks_$w -- python $OLDPWD/bench.py --workload $w --steps 1 --warmup 1 --no-cpu-baseline > $out/ks_$w.log 2>&1)
-  python tools/rocprof_summary.py $out/ks_$w $out/ks_$w.md "bench.py --workload $w --steps 1 --warmup 1 --no-cpu-baseline" > /dev/null 2>&1
+timeout 600 python bench.py > $out/bench_soup1m.json 2> $out/bench_soup1m.err
+for w in soup1m statue; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks_$w -- python $repo/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $out/ks_$w.log 2>&1)
+  python tools/rocprof_summary.py $out/ks_$w $out/ks_$w.md "bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-extra" > /dev/null 2>&1
   find $out/ks_$w -name "*.db" -size +8M -delete
 done
-pmc="FETCH_SIZE WRITE_SIZE"; [ -n "$quick" ] && pmc=""
-for c in $pmc; do
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -- python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$c.log 2>&1)
-  python tools/pmc_summary.py $out/pmc_$c k_trace > $out/pmc_$c.txt 2>&1
-  find $out/pmc_$c -name "*.db" -delete
-done
-tail -n 3 $out/bench_*.json | cut -c1-400
+if [ "$mode" != quick ]; then
+  pass() {  # <workload> <name> <counters...>
+    w=$1; name=$2; shift 2
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc "$@" -d $out/pmc_${w}_$name -- python $repo/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-count > $out/pmc_${w}_$name.log 2>&1)
+    python tools/pmc_summary.py $out/pmc_${w}_$name k_ > $out/pmc_${w}_$name.txt 2>&1
+    find $out/pmc_${w}_$name -name "*.db" -delete
+  }
+  for w in soup1m statue; do
+    pass $w fetch FETCH_SIZE
+    pass $w write WRITE_SIZE
+  done
+  pass soup1m tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum
+  pass soup1m sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VALU
+  pass soup1m ta TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE
+  python tools/pmc_to_json.py $out > $out/pmc_to_json.log 2>&1
+fi
+if [ "$mode" = all ]; then
+  for w in cornell statue_tex c4; do
+    timeout 300 python bench.py --workload $w --no-extra > $out/bench_$w.json 2> $out/bench_$w.err
+  done
+  timeout 200 python bench.py --workload cornell --integrator ao --spp 16 --no-extra > $out/bench_cornell_ao.json 2> $out/bench_cornell_ao.err
+fi
+tail -c 600 $out/bench_soup1m.json
