@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 10
+#define RSPT_ABI_VERSION 11
 
 /* error codes */
 #define RSPT_OK 0
@@ -53,9 +53,10 @@ typedef struct {
 /* One entry per element of BVHAccel.primitives (the *ordered* list, bvh.rs:144-149);
  * each is a GeometricPrimitive wrapping a Triangle (src/core/primitive.rs:100-105,
  * src/shapes/triangle.rs:84-96).  v[] index the global vertex arrays below. */
+#define RSPT_MESH_INSTANCE 0xffffffffu /* rspt_prim.mesh of a TransformedPrimitive: v[0] = index into instances[] */
 typedef struct {
     uint32_t v[3];
-    uint32_t mesh;       /* index into meshes[]                                      */
+    uint32_t mesh;       /* index into meshes[], or RSPT_MESH_INSTANCE               */
     uint32_t material;   /* index into materials[]; 0xffffffff = no material
                             (path.rs:109-116 passes straight through)               */
     int32_t area_light;  /* index into lights[] or -1 (primitive.rs:193-195)         */
@@ -217,6 +218,31 @@ typedef struct {
     const float* dist_func;  /* [dist_nv][dist_nu]                                         */
 } rspt_envmap;
 
+/* ---- object instancing --------------------------------------------
+ * ObjectBegin / ObjectEnd collect the primitives of a named object; every ObjectInstance wraps them — in a BVHAccel of their
+ * own when there is more than one — in a TransformedPrimitive that sits in the scene's top-level aggregate like any other
+ * primitive (api.rs:3024-3109, primitive.rs:198-272; its bounds: primitive_to_world.motion_bounds, primitive.rs:212-215).
+ * Static transforms only (actually_animated == false), affine (last row 0 0 0 1).  The objects' nodes and primitives follow
+ * the top-level aggregate's in nodes[] / prims[]; all indices (child offsets, leaf offsets) are absolute. */
+typedef struct {
+    uint64_t first_node, n_nodes; /* this object's BVHAccel.nodes; n_nodes == 0: a single primitive, no aggregate (api.rs:3046) */
+    uint64_t first_prim, n_prims; /* its BVHAccel.primitives (BVH leaf order); triangles only, area_light = -1 ("Area lights
+                                     not supported with object instancing", api.rs:2899)                                   */
+} rspt_object;
+typedef struct {
+    uint32_t object;     /* index into objects[]                                       */
+    float to_world[16];  /* primitive_to_world.start_transform.m, row major            */
+    float from_world[16];/* ... .m_inv (the reference inverts once, Transform holds both) */
+} rspt_instance;
+/* What a hit inside an instance is:
+ * REFERENCE  what rs_pbrt v0.9.12 does: Transform::transform_surface_interaction drops isect.primitive (transform.rs:856), so
+ *            the hit has no material and no emission and PathIntegrator::li passes straight through it like a null-material
+ *            surface (path.rs:109-116) while shadow rays are blocked (primitive.rs:258-265); an instance whose transform is the
+ *            identity shrinks the ray's t_max and then reports no hit (primitive.rs:220-253).
+ * FIXED      the behaviour of the fix commented out at primitive.rs:226-250: the transformed interaction keeps its primitive
+ *            (material), identity instances report their hits. */
+enum { RSPT_INSTANCING_REFERENCE = 0, RSPT_INSTANCING_FIXED = 1 };
+
 typedef struct {
     const rspt_bvh_node* nodes; uint64_t n_nodes;
     const rspt_prim* prims;     uint64_t n_prims;     /* BVH leaf order */
@@ -232,6 +258,12 @@ typedef struct {
     const rspt_envmap* envmaps;     uint32_t n_envmaps;
     const rspt_texture* textures;   uint32_t n_textures;
     const rspt_image* images;       uint32_t n_images;
+    /* instancing: with n_instances == 0 the whole of nodes[] / prims[] is the scene's aggregate */
+    const rspt_object* objects;     uint32_t n_objects;
+    const rspt_instance* instances; uint32_t n_instances;
+    uint64_t n_top_nodes, n_top_prims; /* the top-level aggregate = nodes[0 .. n_top_nodes), prims[0 .. n_top_prims) */
+    uint32_t instancing_mode;          /* RSPT_INSTANCING_* */
+    uint32_t pad1;
 } rspt_scene_desc;
 
 /* Sampler tables owned by the host.
@@ -395,6 +427,10 @@ int rspt_last_counters(uint64_t out[3]);
 int64_t rspt_bvh_build(const float* P, const uint32_t* tri_idx, uint64_t n_tris,
                        uint32_t max_prims_in_node, rspt_bvh_node* nodes_out, uint64_t nodes_cap,
                        uint32_t* ordered_out, int32_t n_threads);
+/* The same over primitives given by their world bounds (n x (min xyz, max xyz)): the aggregate of a scene with object instances
+ * holds TransformedPrimitives (bounds: Transform::transform_bounds of the object's, transform.rs:596-660) next to triangles. */
+int64_t rspt_bvh_build_bounds(const float* bounds, uint64_t n_prims, uint32_t max_prims_in_node, rspt_bvh_node* nodes_out,
+                              uint64_t nodes_cap, uint32_t* ordered_out, int32_t n_threads);
 const char* rspt_bvh_last_error(void);
 
 /* The same build on the GPU: every node of a tree level is split in one pass over the primitives

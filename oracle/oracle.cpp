@@ -149,6 +149,33 @@ int64_t orc_bvh_build(const float* P, const uint32_t* tri_idx, uint64_t n, uint3
     return (int64_t)nodes.size();
 }
 
+// the same over primitives given by their world bounds (n x (min xyz, max xyz)): a top-level aggregate that holds TransformedPrimitives
+int64_t orc_bvh_build_bounds(const float* b6, uint64_t n, uint32_t max_prims_in_node, rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out) {
+    std::vector<Bounds3> bounds(n);
+    for (uint64_t i = 0; i < n; i++) {
+        bounds[i].p_min = V3{b6[6 * i], b6[6 * i + 1], b6[6 * i + 2]};
+        bounds[i].p_max = V3{b6[6 * i + 3], b6[6 * i + 4], b6[6 * i + 5]};
+    }
+    std::vector<rspt_bvh_node> nodes; std::vector<uint32_t> ordered;
+    bvh_build(bounds.data(), n, max_prims_in_node, nodes, ordered);
+    if (nodes.size() > nodes_cap) return -(int64_t)nodes.size();
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(rspt_bvh_node));
+    std::memcpy(ordered_out, ordered.data(), ordered.size() * sizeof(uint32_t));
+    return (int64_t)nodes.size();
+}
+// Transform::transform_bounds (transform.rs:596-660): out = min xyz, max xyz
+void orc_transform_bounds(const float m[16], const float lo[3], const float hi[3], float out[6]) {
+    Bounds3 b;
+    bool first = true;
+    const int order[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}};
+    for (auto& c : order) {
+        V3 p = transform_point(m, V3{c[0] ? hi[0] : lo[0], c[1] ? hi[1] : lo[1], c[2] ? hi[2] : lo[2]});
+        if (first) { b.p_min = b.p_max = p; first = false; }
+        else b = bunion(b, p);
+    }
+    out[0] = b.p_min.x; out[1] = b.p_min.y; out[2] = b.p_min.z; out[3] = b.p_max.x; out[4] = b.p_max.y; out[5] = b.p_max.z;
+}
+
 // ---- stage hook: Scene::intersect / intersect_p over a batch ----
 // counters_out (optional): nodes_visited, tris_tested
 void orc_trace(const rspt_scene_desc* sd, const rspt_ray* rays, uint64_t n, rspt_hit* out, int any_hit, int brute, uint64_t* counters_out) {
@@ -161,7 +188,7 @@ void orc_trace(const rspt_scene_desc* sd, const rspt_ray* rays, uint64_t n, rspt
         else if (brute) { uint32_t p = 0xffffffffu; Float t = 0.0f; if (sc.intersect_brute(r, &p, &t)) { h.prim = p; h.t = t; } }
         else {
             Interaction isect; Float t = 0, b[3] = {0, 0, 0};
-            if (sc.intersect(r, &isect, &c, &t, b)) { h.prim = (uint32_t)isect.prim; h.t = t; h.b0 = b[0]; h.b1 = b[1]; h.b2 = b[2]; }
+            if (sc.intersect(r, &isect, &c, &t, b)) { h.prim = (uint32_t)isect.geo_prim; h.t = t; h.b0 = b[0]; h.b1 = b[1]; h.b2 = b[2]; }
         }
         out[i] = h;
     }

@@ -625,7 +625,7 @@ static inline Spec estimate_direct(RenderCtx& cx, const Interaction& it, const B
             Interaction light_isect;
             if (c) c->mis_rays++;
             if (sc.intersect(ray, &light_isect, c)) {
-                const rspt_prim& hp = sc.d.prims[light_isect.prim];
+                const rspt_prim& hp = sc.hit_prim(light_isect);
                 if (light.kind == RSPT_LIGHT_DIFFUSE_AREA && hp.area_light >= 0 && (uint32_t)hp.area_light == light_num) // pointer compare :550-558
                     li2 = light_l(light, light_isect.n, -wi);
             } else {
@@ -659,7 +659,7 @@ static inline Spec path_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counte
     for (;;) {
         Interaction isect;
         if (sc.intersect(ray, &isect, c)) {
-            const rspt_prim& hp = sc.d.prims[isect.prim];
+            const rspt_prim& hp = sc.hit_prim(isect);
             if (bounces == 0 || specular_bounce) {
                 if (hp.area_light >= 0) l = l + beta * light_l(sc.d.lights[hp.area_light], isect.n, -ray.d); // interaction.rs:475-483
                 else l = l + beta * Spec();
@@ -835,7 +835,7 @@ static inline Spec recursive_li(RenderCtx& cx, const Ray& ray, Sampler& sampler,
             if (sc.d.lights[i].kind == RSPT_LIGHT_INFINITE) l = l + infinite_le(sc, sc.d.lights[i], ray.d);
         return l;
     }
-    const rspt_prim& hp = sc.d.prims[isect.prim];
+    const rspt_prim& hp = sc.hit_prim(isect);
     V3 n_before = isect.sh_n; // whitted.rs:58: shading.n read before compute_scattering_functions (i.e. before a bump map moves it)
     if (hp.material == 0xffffffffu) return recursive_li(cx, isect.spawn_ray(ray.d), sampler, depth, c);
     compute_differentials(&isect, ray);

@@ -180,7 +180,9 @@ struct Interaction {
     // screen-space differentials (interaction.rs:388-479)
     Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
     V3 dpdx{0, 0, 0}, dpdy{0, 0, 0};
-    int64_t prim = -1;         // isect.primitive
+    int64_t prim = -1;         // isect.primitive (-1: None)
+    int64_t inst = 0;          // test bookkeeping only: 1 + instance the hit lies in
+    int64_t geo_prim = -1;     // test bookkeeping only: the GeometricPrimitive that was hit, also after Q11 dropped isect.primitive
     // interaction.rs:58-94
     Ray spawn_ray(V3 d) const { return Ray{offset_ray_origin(p, p_error, n, d), d, INF, time}; }
     Ray spawn_ray_to(const Interaction& it) const {
@@ -408,14 +410,108 @@ struct Scene {
         return (t_min < ray.t_max) && (t_max > 0.0f);
     }
 
-    // ---- BVHAccel::intersect: src/accelerators/bvh.rs:401-462; GeometricPrimitive::intersect primitive.rs:150-186 ----
-    bool intersect(const Ray& ray, Interaction* isect, Counters* c, Float* t_out = nullptr, Float* b_out = nullptr) const {
-        if (c) c->rays_closest++;
-        if (d.n_nodes == 0) return false;
+    // isect.primitive -> GeometricPrimitive: a hit whose primitive was dropped (Q11) has no material and no area light
+    const rspt_prim& hit_prim(const Interaction& isect) const {
+        static const rspt_prim none = {{0, 0, 0}, 0, 0xffffffffu, -1};
+        return isect.prim < 0 ? none : d.prims[isect.prim];
+    }
+    bool instanced() const { return d.n_instances > 0; }
+    uint64_t top_nodes() const { return instanced() ? d.n_top_nodes : d.n_nodes; }
+
+    // ---- Transform::transform_surface_interaction: src/core/transform.rs:815-860 (m = to_world, mi = from_world) ----
+    static V3 transform_normal(const Float* mi, V3 n) { // :528-537: through the transposed inverse
+        return V3{mi[0] * n.x + mi[4] * n.y + mi[8] * n.z, mi[1] * n.x + mi[5] * n.y + mi[9] * n.z, mi[2] * n.x + mi[6] * n.y + mi[10] * n.z};
+    }
+    static void transform_surface_interaction(const Float* m, const Float* mi, Interaction* si) {
+        Interaction ret;
+        { // transform_point_with_abs_error :709-760
+            Float x = si->p.x, y = si->p.y, z = si->p.z;
+            const V3 pe = si->p_error;
+            ret.p = V3{m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+            ret.p_error.x = (gamma(3) + 1.0f) * (std::fabs(m[0]) * pe.x + std::fabs(m[1]) * pe.y + std::fabs(m[2]) * pe.z)
+                            + gamma(3) * (std::fabs(m[0] * x) + std::fabs(m[1] * y) + std::fabs(m[2] * z) + std::fabs(m[3]));
+            ret.p_error.y = (gamma(3) + 1.0f) * (std::fabs(m[4]) * pe.x + std::fabs(m[5]) * pe.y + std::fabs(m[6]) * pe.z)
+                            + gamma(3) * (std::fabs(m[4] * x) + std::fabs(m[5] * y) + std::fabs(m[6] * z) + std::fabs(m[7]));
+            ret.p_error.z = (gamma(3) + 1.0f) * (std::fabs(m[8]) * pe.x + std::fabs(m[9]) * pe.y + std::fabs(m[10]) * pe.z)
+                            + gamma(3) * (std::fabs(m[8] * x) + std::fabs(m[9] * y) + std::fabs(m[10] * z) + std::fabs(m[11]));
+        }
+        ret.n = normalize(transform_normal(mi, si->n));
+        ret.wo = normalize(transform_vector(m, si->wo));
+        ret.time = si->time;
+        ret.uv = si->uv;
+        ret.dpdu = transform_vector(m, si->dpdu); ret.dpdv = transform_vector(m, si->dpdv);
+        ret.sh_n = normalize(transform_normal(mi, si->sh_n));
+        ret.sh_dpdu = transform_vector(m, si->sh_dpdu); ret.sh_dpdv = transform_vector(m, si->sh_dpdv);
+        ret.sh_dndu = transform_normal(mi, si->sh_dndu); ret.sh_dndv = transform_normal(mi, si->sh_dndv);
+        ret.dudx = si->dudx; ret.dvdx = si->dvdx; ret.dudy = si->dudy; ret.dvdy = si->dvdy;
+        ret.dpdx = si->dpdx; ret.dpdy = si->dpdy;
+        ret.prim = -1; // ret.primitive = None (:856), Q11
+        ret.geo_prim = si->geo_prim;
+        ret.sh_n = faceforward(ret.sh_n, ret.n);
+        *si = ret;
+    }
+    static bool is_identity(const Float* m) { // transform.rs:291-308
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++)
+                if (m[4 * r + c] != (r == c ? 1.0f : 0.0f)) return false;
+        return true;
+    }
+
+    // ---- Primitive::intersect (primitive.rs:37-47) for entry pi of an aggregate's primitive list ----
+    bool prim_intersect(uint32_t pi, const Ray& ray, Interaction* isect, Counters* c, Float* t_out, Float* b_out) const {
+        const rspt_prim& pr = d.prims[pi];
+        if (pr.mesh == RSPT_MESH_INSTANCE) return transformed_intersect(pr.v[0], ray, isect, c, t_out, b_out);
+        Float t_hit = 0.0f; // GeometricPrimitive::intersect primitive.rs:150-186
+        if (tri_intersect(pr, ray, &t_hit, isect, b_out)) {
+            ray.t_max = t_hit; // primitive.rs:155
+            isect->prim = pi;  // primitive.rs:42
+            isect->geo_prim = pi; isect->inst = 0;
+            if (t_out) *t_out = t_hit;
+            return true;
+        }
+        return false;
+    }
+    bool prim_intersect_p(uint32_t pi, const Ray& ray, Counters* c) const {
+        const rspt_prim& pr = d.prims[pi];
+        if (pr.mesh == RSPT_MESH_INSTANCE) { // TransformedPrimitive::intersect_p primitive.rs:258-265
+            const rspt_instance& in = d.instances[pr.v[0]];
+            const rspt_object& o = d.objects[in.object];
+            Ray r2 = transform_ray(in.from_world, ray);
+            if (!o.n_nodes && c) c->tris_tested++; // (counter convention: every primitive test counts, also the lone primitive of an object)
+            return o.n_nodes ? bvh_intersect_p((uint32_t)o.first_node, r2, c) : prim_intersect_p((uint32_t)o.first_prim, r2, c);
+        }
+        Float t, b[3];
+        return tri_hit_test(pr, ray, &t, b);
+    }
+    // ---- TransformedPrimitive::intersect: primitive.rs:216-253 (static transform: interpolate() returns start_transform) ----
+    bool transformed_intersect(uint32_t k, const Ray& r, Interaction* isect, Counters* c, Float* t_out, Float* b_out) const {
+        const rspt_instance& in = d.instances[k];
+        const rspt_object& o = d.objects[in.object];
+        Ray ray = transform_ray(in.from_world, r); // Transform::inverse(&interpolated_prim_to_world).transform_ray(r)
+        ray.has_diff = false;                      // (differentials are not used below this point)
+        if (!o.n_nodes && c) c->tris_tested++;
+        bool hit = o.n_nodes ? bvh_intersect((uint32_t)o.first_node, ray, isect, c, t_out, b_out)
+                             : prim_intersect((uint32_t)o.first_prim, ray, isect, c, t_out, b_out);
+        if (!hit) return false;
+        r.t_max = ray.t_max; // :224
+        const bool fixed = d.instancing_mode == RSPT_INSTANCING_FIXED;
+        if (!is_identity(in.to_world)) {
+            const int64_t keep = isect->prim;
+            transform_surface_interaction(in.to_world, in.from_world, isect);
+            if (fixed) isect->prim = keep; // the fix commented out at :226-250: "we need to preserve the primitive pointer"
+            isect->inst = (int64_t)k + 1;
+            return true;
+        }
+        isect->inst = (int64_t)k + 1;
+        return fixed; // Q10: an identity instance has shrunk r.t_max and reports no hit
+    }
+
+    // ---- BVHAccel::intersect: src/accelerators/bvh.rs:401-462 over the aggregate whose node 0 is `root` ----
+    bool bvh_intersect(uint32_t root, const Ray& ray, Interaction* isect, Counters* c, Float* t_out, Float* b_out) const {
         bool hit = false;
         V3 inv_dir{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
         uint8_t neg[3] = {(uint8_t)(inv_dir.x < 0.0f), (uint8_t)(inv_dir.y < 0.0f), (uint8_t)(inv_dir.z < 0.0f)};
-        uint32_t to_visit = 0, cur = 0;
+        uint32_t to_visit = 0, cur = root;
         uint32_t stack[64];
         for (;;) {
             const rspt_bvh_node& node = d.nodes[cur];
@@ -423,15 +519,8 @@ struct Scene {
             if (box_hit(node, ray, inv_dir, neg)) {
                 if (node.n_prims > 0) {
                     for (uint32_t i = 0; i < node.n_prims; i++) {
-                        uint32_t pi = (uint32_t)node.offset + i;
                         if (c) c->tris_tested++;
-                        Float t_hit = 0.0f;
-                        if (tri_intersect(d.prims[pi], ray, &t_hit, isect, b_out)) {
-                            ray.t_max = t_hit; // primitive.rs:155
-                            isect->prim = pi;  // primitive.rs:42
-                            if (t_out) *t_out = t_hit;
-                            hit = true;
-                        }
+                        if (prim_intersect((uint32_t)node.offset + i, ray, isect, c, t_out, b_out)) hit = true;
                     }
                     if (to_visit == 0) break;
                     cur = stack[--to_visit];
@@ -446,13 +535,17 @@ struct Scene {
         }
         return hit;
     }
-    // ---- BVHAccel::intersect_p: bvh.rs:463-514 ----
-    bool intersect_p(const Ray& ray, Counters* c) const {
-        if (c) c->rays_any++;
+    // Scene::intersect (scene.rs:55-66)
+    bool intersect(const Ray& ray, Interaction* isect, Counters* c, Float* t_out = nullptr, Float* b_out = nullptr) const {
+        if (c) c->rays_closest++;
         if (d.n_nodes == 0) return false;
+        return bvh_intersect(0, ray, isect, c, t_out, b_out);
+    }
+    // ---- BVHAccel::intersect_p: bvh.rs:463-514 ----
+    bool bvh_intersect_p(uint32_t root, const Ray& ray, Counters* c) const {
         V3 inv_dir{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
         uint8_t neg[3] = {(uint8_t)(inv_dir.x < 0.0f), (uint8_t)(inv_dir.y < 0.0f), (uint8_t)(inv_dir.z < 0.0f)};
-        uint32_t to_visit = 0, cur = 0;
+        uint32_t to_visit = 0, cur = root;
         uint32_t stack[64];
         for (;;) {
             const rspt_bvh_node& node = d.nodes[cur];
@@ -461,8 +554,7 @@ struct Scene {
                 if (node.n_prims > 0) {
                     for (uint32_t i = 0; i < node.n_prims; i++) {
                         if (c) c->tris_tested++;
-                        Float t, b[3];
-                        if (tri_hit_test(d.prims[(uint32_t)node.offset + i], ray, &t, b)) return true;
+                        if (prim_intersect_p((uint32_t)node.offset + i, ray, c)) return true;
                     }
                     if (to_visit == 0) break;
                     cur = stack[--to_visit];
@@ -475,12 +567,17 @@ struct Scene {
         }
         return false;
     }
+    bool intersect_p(const Ray& ray, Counters* c) const {
+        if (c) c->rays_any++;
+        if (d.n_nodes == 0) return false;
+        return bvh_intersect_p(0, ray, c);
+    }
     // brute force closest hit over all primitives in list order (test helper, not in the reference)
     bool intersect_brute(const Ray& ray, uint32_t* prim, Float* t_out) const {
         bool hit = false;
         for (uint64_t i = 0; i < d.n_prims; i++) {
             Float t, b[3];
-            if (tri_hit_test(d.prims[i], ray, &t, b)) { ray.t_max = t; *prim = (uint32_t)i; *t_out = t; hit = true; }
+            if (d.prims[i].mesh != RSPT_MESH_INSTANCE && tri_hit_test(d.prims[i], ray, &t, b)) { ray.t_max = t; *prim = (uint32_t)i; *t_out = t; hit = true; }
         }
         return hit;
     }

@@ -37,6 +37,9 @@ def lib():
         L.orc_distribution1d.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bvh_build.restype = C.c_int64
         L.orc_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_bvh_build_bounds.restype = C.c_int64
+        L.orc_bvh_build_bounds.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_transform_bounds.restype = None; L.orc_transform_bounds.argtypes = [C.c_void_p] * 4
         L.orc_trace.restype = None
         L.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_render.restype = C.c_int
@@ -92,6 +95,25 @@ def bvh_build(P, tri, max_prims_in_node=4):
     k = lib().orc_bvh_build(P.ctypes.data, tri.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data)
     assert k >= 0
     return nodes[:k].copy(), ordered
+
+
+def bvh_build_bounds(bounds, max_prims_in_node=4):
+    """BVHAccel::new over primitives given by world bounds (n, 6)"""
+    from rs_pbrt_amd import abi
+    bounds = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
+    n = len(bounds)
+    nodes = np.zeros(max(2 * n, 1), abi.NODE_DT)
+    ordered = np.zeros(n, np.uint32)
+    k = lib().orc_bvh_build_bounds(bounds.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data)
+    assert k >= 0
+    return nodes[:k].copy(), ordered
+
+
+def transform_bounds(m, lo, hi):
+    m = np.ascontiguousarray(m, np.float32).reshape(16); lo = np.ascontiguousarray(lo, np.float32); hi = np.ascontiguousarray(hi, np.float32)
+    out = np.zeros(6, np.float32)
+    lib().orc_transform_bounds(m.ctypes.data, lo.ctypes.data, hi.ctypes.data, out.ctypes.data)
+    return out[:3], out[3:]
 
 
 def trace(scene, rays, any_hit=False, brute=False, counters=False):

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -18,6 +18,8 @@ LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 TEX_CONSTANT, TEX_IMAGE, TEX_SCALE, TEX_MIX, TEX_CHECKERBOARD, TEX_DOTS, TEX_FBM, TEX_MARBLE, TEX_WINDY, TEX_WRINKLED = range(1, 11)
 MAP_UV, MAP_PLANAR, MAP_SPHERICAL, MAP_CYLINDRICAL, MAP_IDENTITY3D = 1, 2, 3, 4, 5
 WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
+INSTANCING_REFERENCE, INSTANCING_FIXED = 0, 1
+MESH_INSTANCE = 0xFFFFFFFF
 NO_MATERIAL = 0xFFFFFFFF
 MISS = 0xFFFFFFFF
 
@@ -78,7 +80,11 @@ class SceneDesc(C.Structure):
                 ("lights", C.c_void_p), ("n_lights", C.c_uint32),
                 ("envmaps", C.c_void_p), ("n_envmaps", C.c_uint32),
                 ("textures", C.c_void_p), ("n_textures", C.c_uint32),
-                ("images", C.c_void_p), ("n_images", C.c_uint32)]
+                ("images", C.c_void_p), ("n_images", C.c_uint32),
+                ("objects", C.c_void_p), ("n_objects", C.c_uint32),
+                ("instances", C.c_void_p), ("n_instances", C.c_uint32),
+                ("n_top_nodes", C.c_uint64), ("n_top_prims", C.c_uint64),
+                ("instancing_mode", C.c_uint32), ("pad1", C.c_uint32)]
 
 
 class SamplerTables(C.Structure):
@@ -131,6 +137,8 @@ TEXTURE_DT = np.dtype([("kind", "<u4"), ("mapping", "<u4"), ("map", "<f4", 8), (
                        ("wrap", "<u4"), ("value", "<f4", 3), ("tex1", "<u4"), ("tex2", "<u4"), ("tex3", "<u4"), ("world_to_texture", "<f4", 16),
                        ("octaves", "<i4"), ("omega", "<f4"), ("scale", "<f4"), ("variation", "<f4")])
 LIGHT_DT = np.dtype([("kind", "<u4"), ("prim", "<u4"), ("L", "<f4", 3), ("two_sided", "<u4"), ("p", "<f4", 24)])
+OBJECT_DT = np.dtype([("first_node", "<u8"), ("n_nodes", "<u8"), ("first_prim", "<u8"), ("n_prims", "<u8")])
+INSTANCE_DT = np.dtype([("object", "<u4"), ("to_world", "<f4", 16), ("from_world", "<f4", 16)])
 RAY_DT = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("id", "<u4")])
 HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4")])
 

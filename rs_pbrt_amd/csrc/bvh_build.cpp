@@ -200,37 +200,15 @@ thread_local char g_msg[256];
 
 extern "C" const char* rspt_bvh_last_error(void) { return g_msg; }
 
-// Replaces: BVHAccel::new over Triangle shapes (src/accelerators/bvh.rs:96-152;
-// Triangle::world_bound src/shapes/triangle.rs:126-133).
-extern "C" int64_t rspt_bvh_build(const float* P, const uint32_t* tri_idx, uint64_t n_tris, uint32_t max_prims_in_node,
-                                  rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out, int32_t n_threads) {
-    g_msg[0] = 0;
-    if (n_tris == 0) return 0;
-    if (!P || !tri_idx || !nodes_out || !ordered_out) { snprintf(g_msg, sizeof g_msg, "null argument"); return RSPT_E_INVALID; }
-    if (n_tris > 0x7fffffffull) { snprintf(g_msg, sizeof g_msg, "too many triangles"); return RSPT_E_UNSUPPORTED; }
-    Builder b;
-    b.max_prims = max_prims_in_node < 255 ? max_prims_in_node : 255;  // bvh.rs:102
-    b.ordered = ordered_out;
-    b.info.resize(n_tris);
-    for (uint64_t i = 0; i < n_tris; i++) {
-        const uint32_t* v = tri_idx + 3 * i;
-        const float* p0 = P + 3 * (size_t)v[0];
-        const float* p1 = P + 3 * (size_t)v[1];
-        const float* p2 = P + 3 * (size_t)v[2];
-        Info& in = b.info[i];
-        in.prim = (uint32_t)i;
-        for (int k = 0; k < 3; k++) {
-            in.box.lo[k] = fminf(fminf(p0[k], p1[k]), p2[k]);
-            in.box.hi[k] = fmaxf(fmaxf(p0[k], p1[k]), p2[k]);
-            in.c[k] = in.box.lo[k] * 0.5f + in.box.hi[k] * 0.5f;  // bvh.rs:39
-        }
-    }
-    b.pool.resize(2 * n_tris);
+namespace {
+// shared tail of the two entry points: b.info holds every primitive's bounds and centroid
+int64_t build_from_info(Builder& b, uint64_t n_prims, rspt_bvh_node* nodes_out, uint64_t nodes_cap, int32_t n_threads) {
+    b.pool.resize(2 * n_prims);
     const uint32_t root = b.alloc_node();
     int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > 64) nt = 64;
-    b.queue.push_back(Task{root, 0, (size_t)n_tris, 0});
+    b.queue.push_back(Task{root, 0, (size_t)n_prims, 0});
     b.outstanding = 1;
     std::vector<std::thread> th;
     for (int i = 1; i < nt; i++) th.emplace_back([&b] { b.worker(); });
@@ -272,4 +250,57 @@ extern "C" int64_t rspt_bvh_build(const float* P, const uint32_t* tri_idx, uint6
         for (int k = 0; k < 3; k++) { n.bmin[k] = fminf(c0.bmin[k], c1.bmin[k]); n.bmax[k] = fmaxf(c0.bmax[k], c1.bmax[k]); }
     }
     return (int64_t)total;
+}
+}  // namespace
+
+// Replaces: BVHAccel::new over Triangle shapes (src/accelerators/bvh.rs:96-152;
+// Triangle::world_bound src/shapes/triangle.rs:126-133).
+extern "C" int64_t rspt_bvh_build(const float* P, const uint32_t* tri_idx, uint64_t n_tris, uint32_t max_prims_in_node,
+                                  rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out, int32_t n_threads) {
+    g_msg[0] = 0;
+    if (n_tris == 0) return 0;
+    if (!P || !tri_idx || !nodes_out || !ordered_out) { snprintf(g_msg, sizeof g_msg, "null argument"); return RSPT_E_INVALID; }
+    if (n_tris > 0x7fffffffull) { snprintf(g_msg, sizeof g_msg, "too many triangles"); return RSPT_E_UNSUPPORTED; }
+    Builder b;
+    b.max_prims = max_prims_in_node < 255 ? max_prims_in_node : 255;  // bvh.rs:102
+    b.ordered = ordered_out;
+    b.info.resize(n_tris);
+    for (uint64_t i = 0; i < n_tris; i++) {
+        const uint32_t* v = tri_idx + 3 * i;
+        const float* p0 = P + 3 * (size_t)v[0];
+        const float* p1 = P + 3 * (size_t)v[1];
+        const float* p2 = P + 3 * (size_t)v[2];
+        Info& in = b.info[i];
+        in.prim = (uint32_t)i;
+        for (int k = 0; k < 3; k++) {
+            in.box.lo[k] = fminf(fminf(p0[k], p1[k]), p2[k]);
+            in.box.hi[k] = fmaxf(fmaxf(p0[k], p1[k]), p2[k]);
+            in.c[k] = in.box.lo[k] * 0.5f + in.box.hi[k] * 0.5f;  // bvh.rs:39
+        }
+    }
+    return build_from_info(b, n_tris, nodes_out, nodes_cap, n_threads);
+}
+
+// The same BVHAccel::new over primitives given by their world bounds (bounds: n x (min xyz, max xyz)): the top-level
+// aggregate of a scene with object instances holds TransformedPrimitives next to triangles (primitive.rs:212-215 for their bounds).
+extern "C" int64_t rspt_bvh_build_bounds(const float* bounds, uint64_t n_prims, uint32_t max_prims_in_node,
+                                         rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out, int32_t n_threads) {
+    g_msg[0] = 0;
+    if (n_prims == 0) return 0;
+    if (!bounds || !nodes_out || !ordered_out) { snprintf(g_msg, sizeof g_msg, "null argument"); return RSPT_E_INVALID; }
+    if (n_prims > 0x7fffffffull) { snprintf(g_msg, sizeof g_msg, "too many primitives"); return RSPT_E_UNSUPPORTED; }
+    Builder b;
+    b.max_prims = max_prims_in_node < 255 ? max_prims_in_node : 255;
+    b.ordered = ordered_out;
+    b.info.resize(n_prims);
+    for (uint64_t i = 0; i < n_prims; i++) {
+        Info& in = b.info[i];
+        in.prim = (uint32_t)i;
+        for (int k = 0; k < 3; k++) {
+            in.box.lo[k] = bounds[6 * i + k];
+            in.box.hi[k] = bounds[6 * i + 3 + k];
+            in.c[k] = in.box.lo[k] * 0.5f + in.box.hi[k] * 0.5f;  // bvh.rs:39
+        }
+    }
+    return build_from_info(b, n_prims, nodes_out, nodes_cap, n_threads);
 }

@@ -7,7 +7,21 @@ namespace rspt {
 
 #define RSPT_MISS 0xffffffffu
 // mesh flag bits packed into the 48-byte triangle record
-enum : uint32_t { MF_HAS_N = 1, MF_HAS_S = 2, MF_HAS_UV = 4, MF_FLIP = 8 };
+enum : uint32_t { MF_HAS_N = 1, MF_HAS_S = 2, MF_HAS_UV = 4, MF_FLIP = 8,
+                  MF_INSTANCE = 0x100 };  // the record stands for a TransformedPrimitive: t0.x = instance index, t0.y = the four-box kernel's
+                                          // reference to the primitives that follow it in its leaf (RSPT_NONE: it is the last one)
+
+// One ObjectInstance (api.rs:3024-3109): TransformedPrimitive { primitive: the object's aggregate or single primitive,
+// primitive_to_world } (primitive.rs:198-211), static transform
+struct InstDev {
+    float m[12];          // primitive_to_world.m rows 0..2
+    float mi[12];         // .m_inv rows 0..2
+    uint32_t root_node;   // the object's BVHAccel: index of its node 0 in nodes[]; RSPT_MISS = a single primitive, no aggregate
+    uint32_t first_prim;  // the object's first primitive
+    uint32_t w4_root;     // k_trace_w4's reference to the object's root record (or leaf reference of a one-leaf aggregate)
+    uint32_t identity;    // Transform::is_identity(primitive_to_world) (transform.rs:291-308)
+    uint32_t pad[4];
+};
 
 struct SceneDev {
     // LinearBVHNode array as uploaded (bvh.rs:77-85): 2 x float4 per node
@@ -28,6 +42,9 @@ struct SceneDev {
     uint32_t n_nodes, n_prims, n_lights, n_infinite;
     float wb_min[3], wb_max[3];  // BVHAccel::world_bound = nodes[0].bounds (bvh.rs:394-400)
     const uint8_t* mat_flags;    // per material: RSPT_MAT_TEXTURED | RSPT_MAT_BUMP (dev_texture.h); nullptr = no textures in the scene
+    const InstDev* inst;         // object instances; nullptr = none
+    uint32_t n_inst;
+    uint32_t inst_fixed;         // RSPT_INSTANCING_FIXED: instanced hits keep their primitive (material)
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)
@@ -301,6 +318,49 @@ RDEVN void tri_fill(const SceneDev& sc, uint32_t prim, const TriRec& t, float b0
     }
     h->n = n; h->sh_n = sh_n; h->sh_dpdu = sh_dpdu;
     h->material = t.material; h->area_light = t.area_light;
+}
+
+// ---- TransformedPrimitive (primitive.rs:198-272) ----------------------------------------------------------------
+// Transform::transform_vector / transform_normal with a 3x4 matrix (transform.rs:518-537); the normal goes through the
+// transposed inverse
+RDEV f3 xf_normal(const float* mi, f3 n) {
+    return f3{mi[0] * n.x + mi[4] * n.y + mi[8] * n.z, mi[1] * n.x + mi[5] * n.y + mi[9] * n.z, mi[2] * n.x + mi[6] * n.y + mi[10] * n.z};
+}
+// Transform::inverse(primitive_to_world).transform_ray(r) (transform.rs:538-595 with transform_point_with_error :661-704):
+// origin and direction through m_inv, the origin pushed along d to the edge of its error bound, t_max shortened by the same dt
+RDEV void inst_ray(const InstDev& in, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) {
+    const float* m = in.mi;
+    const float x = o.x, y = o.y, z = o.z;
+    f3 op{m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+    const f3 o_err = f3{fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]), fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]),
+                        fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11])} * gamma_n(3);
+    const f3 dd = xf_vector(m, d);
+    const float l2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
+    if (l2 > 0.0f) {
+        const f3 a = vabs(dd);
+        const float dt = (a.x * o_err.x + a.y * o_err.y + a.z * o_err.z) / l2;
+        op = op + dd * dt;
+        t_max -= dt;
+    }
+    *oo = op; *od = dd; *ot = t_max;
+}
+// Transform::transform_surface_interaction (transform.rs:815-860) on the fields the path needs: p with
+// transform_point_with_abs_error (:709-760), n / shading.n normalised, shading.n face-forwarded to n, shading.dpdu as a vector
+RDEV void inst_point(const float* m, f3 p, f3 pe, f3* po, f3* peo) {
+    const float x = p.x, y = p.y, z = p.z, g3 = gamma_n(3);
+    *po = f3{m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+    *peo = f3{(g3 + 1.0f) * (fabsf(m[0]) * pe.x + fabsf(m[1]) * pe.y + fabsf(m[2]) * pe.z) + g3 * (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3])),
+              (g3 + 1.0f) * (fabsf(m[4]) * pe.x + fabsf(m[5]) * pe.y + fabsf(m[6]) * pe.z) + g3 * (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7])),
+              (g3 + 1.0f) * (fabsf(m[8]) * pe.x + fabsf(m[9]) * pe.y + fabsf(m[10]) * pe.z) + g3 * (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]))};
+}
+RDEV void inst_hit(const InstDev& in, Hit* h) {
+    f3 p, pe;
+    inst_point(in.m, h->p, h->p_err, &p, &pe);
+    h->p = p; h->p_err = pe;
+    h->n = normalize(xf_normal(in.mi, h->n));
+    f3 sn = normalize(xf_normal(in.mi, h->sh_n));
+    h->sh_dpdu = xf_vector(in.m, h->sh_dpdu);
+    h->sh_n = dot(sn, h->n) < 0.0f ? -sn : sn;  // nrm_faceforward_nrm (geometry.rs:1852-1858)
 }
 
 // Watertight ray/triangle test shared by Triangle::intersect and ::intersect_p

@@ -387,6 +387,18 @@ struct TexHit {
     f3 dpdu, dpdv;                        // isect.dpdu / dpdv
     f3 sh_n, sh_dpdu, sh_dpdv, sh_dndu, sh_dndv;  // isect.shading
 };
+// Transform::transform_surface_interaction (transform.rs:815-860) on the full interaction of the texture stage
+RDEV void inst_texhit(const InstDev& in, TexHit* h) {
+    f3 p, pe;
+    inst_point(in.m, h->p, f3{0.0f, 0.0f, 0.0f}, &p, &pe);
+    h->p = p;
+    h->n = normalize(xf_normal(in.mi, h->n));
+    h->dpdu = xf_vector(in.m, h->dpdu); h->dpdv = xf_vector(in.m, h->dpdv);
+    f3 sn = normalize(xf_normal(in.mi, h->sh_n));
+    h->sh_dpdu = xf_vector(in.m, h->sh_dpdu); h->sh_dpdv = xf_vector(in.m, h->sh_dpdv);
+    h->sh_dndu = xf_normal(in.mi, h->sh_dndu); h->sh_dndv = xf_normal(in.mi, h->sh_dndv);
+    h->sh_n = dot(sn, h->n) < 0.0f ? -sn : sn;
+}
 RDEVN void tri_fill_tex(const SceneDev& sc, uint32_t prim, const TriRec& t, float b0, float b1, float b2, TexHit* h) {
     f3 p0 = t.p0, p1 = t.p1, p2 = t.p2;
     f2 uv0{0.0f, 0.0f}, uv1{1.0f, 0.0f}, uv2{1.0f, 1.0f};  // triangle.rs:97-112

@@ -44,6 +44,7 @@ struct PathBuf {
     float2* p_film;
     float4* tex;          // k_texture results, RSPT_TEX_ROWS rows of tex_stride paths (nullptr: scene without textures)
     uint32_t tex_stride;
+    uint32_t* hit_inst;   // continuation ray's hit: 0 or 1 + instance (nullptr: scene without object instances)
 };
 
 struct QueueCounts {  // one per wavefront iteration
@@ -137,67 +138,109 @@ struct TraceResult {
     uint32_t prim;
     float t, b0, b1, b2;
     uint32_t nodes, tris;
+    uint32_t inst;  // 0: a primitive of the scene's own aggregate; k + 1: inside instance k (prim = the object's primitive, t in the object ray's parameter)
 };
 
 // BVHAccel::intersect (bvh.rs:401-462) / intersect_p (:463-514): ordered depth-first traversal,
 // near child first by dir_is_neg[axis], far child pushed.  Visit order is exactly the
 // reference's, so the winning primitive and (t, b) are bit-identical, ties included.
-template <bool ANY>
+// INST: a leaf primitive may be a TransformedPrimitive (primitive.rs:216-265): the ray goes through the instance's
+// world-to-object transform, the object's own aggregate (or single primitive) is traversed with the same loop and stack, and
+// the walk returns to the remaining primitives of the leaf.  Quirks Q10 / Q11 are reproduced unless
+// sc.inst_fixed: an identity instance shrinks t_max without reporting its hit, and its interaction survives only if some
+// other primitive of the top-level aggregate reports a hit (`hit` below is BVHAccel::intersect's flag, `res` its isect).
+template <bool ANY, bool INST>
 RDEV TraceResult traverse(const SceneDev& sc, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */) {
     TraceResult res;
-    res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0;
+    res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0;
     if (sc.n_nodes == 0) return res;
     f3 inv{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    const bool ng0 = inv.x < 0.0f, ng1 = inv.y < 0.0f, ng2 = inv.z < 0.0f;
-    const RayShear rs = ray_shear(d);
+    bool ng0 = inv.x < 0.0f, ng1 = inv.y < 0.0f, ng2 = inv.z < 0.0f;
+    RayShear rs = ray_shear(d);
     uint32_t spill[64 - RSPT_LDS_STACK];
     uint32_t sp = 0, cur = 0;
+    uint32_t leaf_i = 0, leaf_end = 0;  // primitives of the current leaf still to test
+    // instance state (INST only)
+    const f3 w_o = o, w_d = d;
+    uint32_t inst = RSPT_MISS, sp_base = 0, w_leaf_i = 0, w_leaf_end = 0;
+    float w_tmax = 0.0f;
+    bool hit = false, inst_hit = false;
     for (;;) {
+        if (leaf_i < leaf_end) {
+            const uint32_t pi = leaf_i++;
+            float4 a = sc.tris[3 * (size_t)pi], b = sc.tris[3 * (size_t)pi + 1], c = sc.tris[3 * (size_t)pi + 2];
+            res.tris++;
+            if (INST && (__float_as_uint(c.w) & MF_INSTANCE)) {  // TransformedPrimitive::intersect / intersect_p
+                inst = __float_as_uint(a.x);
+                const InstDev& in = sc.inst[inst];
+                w_leaf_i = leaf_i; w_leaf_end = leaf_end; w_tmax = t_max; sp_base = sp; inst_hit = false;
+                inst_ray(in, w_o, w_d, t_max, &o, &d, &t_max);
+                inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+                ng0 = inv.x < 0.0f; ng1 = inv.y < 0.0f; ng2 = inv.z < 0.0f;
+                rs = ray_shear(d);
+                if (in.root_node != RSPT_MISS) { cur = in.root_node; leaf_i = leaf_end = 0; }
+                else { cur = RSPT_MISS; leaf_i = in.first_prim; leaf_end = leaf_i + 1u; }  // a lone GeometricPrimitive: no box test
+                continue;
+            }
+            float t, b0, b1, b2;
+            if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, o, rs, t_max, &t, &b0, &b1, &b2)) {
+                if (ANY) { res.prim = 0; return res; }
+                t_max = t;  // GeometricPrimitive::intersect shrinks the ray (primitive.rs:155)
+                res.prim = pi; res.t = t; res.b0 = b0; res.b1 = b1; res.b2 = b2;
+                if (INST && inst != RSPT_MISS) { res.inst = inst + 1u; inst_hit = true; }
+                else { res.inst = 0; hit = true; }
+            }
+            continue;
+        }
+        if (cur == RSPT_MISS) {  // pop
+            if (INST && inst != RSPT_MISS && sp == sp_base) {  // the object's traversal is over: back to world space
+                const InstDev& in = sc.inst[inst];
+                if (inst_hit) { if (sc.inst_fixed || !in.identity) hit = true; }  // primitive.rs:226-253: r.t_max.set(ray.t_max) either way
+                else t_max = w_tmax;
+                o = w_o; d = w_d;
+                inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+                ng0 = inv.x < 0.0f; ng1 = inv.y < 0.0f; ng2 = inv.z < 0.0f;
+                rs = ray_shear(d);
+                inst = RSPT_MISS; sp_base = 0;
+                leaf_i = w_leaf_i; leaf_end = w_leaf_end;
+                continue;
+            }
+            if (sp == 0) break;
+            sp--;
+            cur = sp < RSPT_LDS_STACK ? lds_stack[sp * RSPT_TRACE_BLOCK] : spill[sp - RSPT_LDS_STACK];
+        }
         float4 n0 = sc.nodes[2 * (size_t)cur], n1 = sc.nodes[2 * (size_t)cur + 1];
         res.nodes++;
-        bool descend = false;
+        const uint32_t here = cur;
+        cur = RSPT_MISS;
         if (box_hit(n0, n1, o, inv, ng0, ng1, ng2, t_max)) {
             uint32_t w = __float_as_uint(n1.w);
             uint32_t n_prims = w & 0xffffu, axis = (w >> 16) & 0xffu;
             uint32_t offset = __float_as_uint(n1.z);
             if (n_prims > 0) {
-                for (uint32_t i = 0; i < n_prims; i++) {
-                    uint32_t pi = offset + i;
-                    float4 a = sc.tris[3 * (size_t)pi], b = sc.tris[3 * (size_t)pi + 1], c = sc.tris[3 * (size_t)pi + 2];
-                    res.tris++;
-                    float t, b0, b1, b2;
-                    if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, o, rs, t_max, &t, &b0, &b1, &b2)) {
-                        if (ANY) { res.prim = 0; return res; }
-                        t_max = t;  // GeometricPrimitive::intersect shrinks the ray (primitive.rs:155)
-                        res.prim = pi; res.t = t; res.b0 = b0; res.b1 = b1; res.b2 = b2;
-                    }
-                }
+                leaf_i = offset; leaf_end = offset + n_prims;
             } else {
                 bool neg = axis == 0 ? ng0 : (axis == 1 ? ng1 : ng2);
-                uint32_t far_child = neg ? cur + 1 : offset;
-                cur = neg ? offset : cur + 1;
+                uint32_t far_child = neg ? here + 1 : offset;
+                cur = neg ? offset : here + 1;
                 if (sp < RSPT_LDS_STACK) lds_stack[sp * RSPT_TRACE_BLOCK] = far_child;
                 else spill[sp - RSPT_LDS_STACK] = far_child;
                 sp++;
-                descend = true;
             }
         }
-        if (!descend) {
-            if (sp == 0) break;
-            sp--;
-            cur = sp < RSPT_LDS_STACK ? lds_stack[sp * RSPT_TRACE_BLOCK] : spill[sp - RSPT_LDS_STACK];
-        }
     }
+    if (INST && !ANY && !hit) { res.prim = RSPT_MISS; res.inst = 0; res.t = res.b0 = res.b1 = res.b2 = 0.0f; }  // BVHAccel::intersect returns `hit`, not "isect was written"
     return res;
 }
 
 // out_mode 0: float4 (prim, b0, b1, b2) into hit_cont/hit_mis by slot; 1: rspt_hit AoS by queue
 // position (stage hook); ANY: occluded[slot] (mode 0) or rspt_hit.prim (mode 1).
-template <bool ANY, int OUT_MODE, bool COUNT>
+// out_inst (INST, closest hit, continuation rays only): 0 or 1 + instance of the hit, by slot
+template <bool ANY, int OUT_MODE, bool COUNT, bool INST>
 __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
                                                             uint32_t count_imm, const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                             float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
-                                                            rspt_hit* __restrict__ out_hits, unsigned long long* __restrict__ counters) {
+                                                            rspt_hit* __restrict__ out_hits, unsigned long long* __restrict__ counters, uint32_t* __restrict__ out_inst) {
     __shared__ uint32_t stack[RSPT_LDS_STACK * RSPT_TRACE_BLOCK];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     const uint32_t stride = gridDim.x * RSPT_TRACE_BLOCK;
@@ -210,10 +253,13 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, const u
         bool mis = (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
-        TraceResult res = traverse<ANY>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        TraceResult res = traverse<ANY, INST>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
-            else (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+            else {
+                (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+                if (INST && !mis && out_inst) out_inst[slot] = res.inst;
+            }
         } else {
             rspt_hit h;
             h.prim = res.prim; h.t = res.t; h.b0 = res.b0; h.b1 = res.b1; h.b2 = res.b2;
@@ -303,6 +349,15 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         Hit h;
         tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &h);
         f3 wo = -ray_d;  // SurfaceInteraction.wo, not normalised (triangle.rs:334)
+        if (pb.hit_inst) {  // the hit lies inside an object instance: TransformedPrimitive::intersect (primitive.rs:216-253)
+            const uint32_t hi = pb.hit_inst[p];
+            if (hi && !sc.inst[hi - 1u].identity) {
+                const InstDev& in = sc.inst[hi - 1u];
+                inst_hit(in, &h);  // transform_surface_interaction (transform.rs:815-860)
+                wo = normalize(xf_vector(in.m, -xf_vector(in.mi, ray_d)));  // wo = -(object ray).d, transformed back and normalised
+                if (!sc.inst_fixed) { h.material = 0xffffffffu; h.area_light = -1; }  // ret.primitive = None (Q11): no material, no Le
+            }
+        }
         if (bounces == 0 || (st & ST_SPECULAR)) {  // path.rs:97-101
             rgb e = h.area_light >= 0 ? light_l(sc.lights[h.area_light], h.n, wo) : mkrgb(0.0f);
             L = L + beta * e;
@@ -416,14 +471,15 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 f3 wi{0.0f, 0.0f, 0.0f};
                 float pdf = 0.0f;
                 uint32_t sampled_type = 255;
-                rgb f = bsdf.sample_f(wo, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
+                const f3 wo_ray = -ray_d;  // path.rs:141 takes -ray.d here; estimate_direct above takes isect.wo (they differ inside instances only)
+                rgb f = bsdf.sample_f(wo_ray, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
                 bool go_on = !(is_black(f) || pdf == 0.0f);
                 if (go_on) {
                     beta = beta * ((f * absdot(wi, h.sh_n)) / pdf);
                     st = (sampled_type & BX_SPEC) ? (st | ST_SPECULAR) : (st & ~ST_SPECULAR);
                     if ((sampled_type & BX_SPEC) && (sampled_type & BX_TRANS)) {
                         float eta = bsdf.eta;
-                        if (dot(wo, h.n) > 0.0f) eta_scale *= eta * eta;
+                        if (dot(wo_ray, h.n) > 0.0f) eta_scale *= eta * eta;
                         else eta_scale *= 1.0f / (eta * eta);
                     }
                     f3 o = offset_ray_origin(h.p, h.p_err, h.n, wi);
@@ -473,6 +529,13 @@ __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, Rend
         if (!mf) continue;
         TexHit h;
         tri_fill_tex(sc, prim, tri, hc.y, hc.z, hc.w, &h);
+        if (pb.hit_inst) {
+            const uint32_t hi = pb.hit_inst[p];
+            if (hi && !sc.inst[hi - 1u].identity) {
+                if (!sc.inst_fixed) continue;  // reference behaviour: the hit has lost its primitive, nothing to texture
+                inst_texhit(sc.inst[hi - 1u], &h);
+            }
+        }
         TexSurf s;
         s.p = h.p; s.uv = h.uv;
         s.dudx = s.dvdx = s.dudy = s.dvdy = 0.0f;
@@ -626,6 +689,10 @@ __global__ __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Bat
     tri_fill_tex(sc, prim, tri, hc.y, hc.z, hc.w, &h);
     Hit hp;    // p_error for spawn_ray
     tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &hp);
+    if (pb.hit_inst) {
+        const uint32_t hi = pb.hit_inst[i];
+        if (hi && !sc.inst[hi - 1u].identity) { inst_texhit(sc.inst[hi - 1u], &h); inst_hit(sc.inst[hi - 1u], &hp); }
+    }
     const f3 n = faceforward(h.n, -ray_d);
     const f3 sv = normalize(h.dpdu);
     const f3 tv = cross(h.n, sv);  // nrm_cross_vec3(&isect.common.n, &s)
@@ -857,10 +924,16 @@ __global__ void k_ld_fixed(SceneDev sc, int power, float* __restrict__ func) {
 
 // scene upload helper: build the 48-byte triangle records from the indexed ABI arrays
 __global__ void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mesh* __restrict__ meshes, const float* __restrict__ P, uint32_t n,
-                             float4* __restrict__ tris) {
+                             float4* __restrict__ tris, const uint32_t* __restrict__ inst_cont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     rspt_prim pr = prims[i];
+    if (pr.mesh == RSPT_MESH_INSTANCE) {  // a TransformedPrimitive: instance index and (four-box kernel) the reference to the rest of its leaf
+        tris[3 * (size_t)i] = make_float4(__uint_as_float(pr.v[0]), __uint_as_float(inst_cont ? inst_cont[pr.v[0]] : 0xffffffffu), 0.0f, 0.0f);
+        tris[3 * (size_t)i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        tris[3 * (size_t)i + 2] = make_float4(0.0f, __uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu), __uint_as_float((uint32_t)MF_INSTANCE));
+        return;
+    }
     rspt_mesh m = meshes[pr.mesh];
     f3 p0 = ld3(P, pr.v[0]), p1 = ld3(P, pr.v[1]), p2 = ld3(P, pr.v[2]);
     uint32_t flags = (m.has_n ? MF_HAS_N : 0u) | (m.has_s ? MF_HAS_S : 0u) | (m.has_uv ? MF_HAS_UV : 0u) | (m.flip ? MF_FLIP : 0u);

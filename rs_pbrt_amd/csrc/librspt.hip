@@ -59,6 +59,8 @@ struct Ctx {
     size_t ovf_cap = 0;
     uint2* spill = nullptr;            // k_trace_w4's stack rows beyond its LDS column (trace_w4.h)
     size_t spill_threads = 0;
+    uint32_t* hit_inst = nullptr;      // per path slot: instance of the continuation ray's hit (scenes with object instances)
+    size_t hit_inst_cap = 0;
     unsigned long long* totals = nullptr;  // [0] nodes [1] tris [2] bsdf hits [3] rays closest [4] rays any [5] nan samples
     // sampler tables + filter table
     uint32_t* sobol32 = nullptr;
@@ -143,6 +145,7 @@ struct rspt_scene_s {
     bool has_textures = false;
     std::vector<void*> allocs;
     bool has_null_material = false;
+    bool has_instances = false;       // object instances: two-level traversal (kernels.h traverse<ANY, true>)
     std::map<int, LightDist> light_dists;  // by effective strategy
 };
 
@@ -211,6 +214,16 @@ int ensure_tex_rows() {
     int rc = dev_alloc(&g.pb.tex, g.cap * RSPT_TEX_ROWS);
     if (rc) return rc;
     g.pb.tex_stride = (uint32_t)g.cap;
+    return RSPT_OK;
+}
+
+int ensure_hit_inst(size_t n) {
+    if (g.hit_inst_cap >= n) return RSPT_OK;
+    if (g.hit_inst) (void)hipFree(g.hit_inst);
+    g.hit_inst = nullptr; g.hit_inst_cap = 0;
+    int rc = dev_alloc(&g.hit_inst, n);
+    if (rc) return rc;
+    g.hit_inst_cap = n;
     return RSPT_OK;
 }
 
@@ -340,6 +353,14 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
     hipStream_t stream = lane ? g.stream2 : g.stream;
     uint32_t* ovf = g.ovf + (lane ? 2 * g.ovf_cap / 3 : 0);
     uint2* spill = g.spill + (lane ? g.spill_threads * RSPT_W4_SPILL : 0);
+    if (s->has_instances) {  // two-level traversal: the reference-order loop (the persistent four-box kernel serves scenes without instances)
+        uint32_t* hi = (OUT_MODE == 0 && !ANY) ? g.hit_inst : nullptr;
+        if (count)
+            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
+        else
+            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
+        return;
+    }
     if (!count && which != 0) {
         const uint32_t pgrid = pw_grid();
         uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
@@ -356,9 +377,9 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
         return;
     }
     if (count)
-        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
+        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, (uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters);
+        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, (uint32_t*)nullptr);
 }
 
 uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PER_CU", 5)); }
@@ -528,6 +549,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // on them); the loop below runs until no path is left, and a scene that needs more than RSPT_NULL_PASSES extra iterations is
     // reported, not silently truncated
     const uint32_t max_iters = s->has_null_material ? nominal_iters + (uint32_t)env_size("RSPT_NULL_PASSES", 4096) : nominal_iters;
+    if (s->has_instances && (rc = ensure_hit_inst(g.cap))) return rc;
+    g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
     if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(3 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
         (s->has_textures && (rc = ensure_tex_rows()))) return rc;
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
@@ -806,7 +829,7 @@ void rspt_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
-    void* ptrs[] = {g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
+    void* ptrs[] = {g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
@@ -859,8 +882,34 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((d->n_nodes == 0) != (d->n_prims == 0)) return fail(RSPT_E_INVALID, "nodes and prims must both be empty or both non-empty");
     // ---- validate indices on the host (a bad scene must not fault the GPU) ----
     bool has_null = false;
+    const bool instanced = d->n_instances > 0;
+    const uint64_t n_top_prims = instanced ? d->n_top_prims : d->n_prims, n_top_nodes = instanced ? d->n_top_nodes : d->n_nodes;
+    if (instanced) {  // objects + instances behind the top-level aggregate
+        if (!d->instances || !d->objects || d->n_objects == 0) return fail(RSPT_E_INVALID, "instances without objects");
+        if (n_top_prims > d->n_prims || n_top_nodes > d->n_nodes || n_top_nodes == 0) return fail(RSPT_E_INVALID, "bad top-level aggregate range");
+        if (d->instancing_mode != RSPT_INSTANCING_REFERENCE && d->instancing_mode != RSPT_INSTANCING_FIXED) return fail(RSPT_E_INVALID, "bad instancing_mode");
+        for (uint32_t i = 0; i < d->n_objects; i++) {
+            const rspt_object& o = d->objects[i];
+            if (o.n_prims == 0 || o.first_prim < n_top_prims || o.first_prim + o.n_prims > d->n_prims) return fail(RSPT_E_INVALID, "object %u: primitive range", i);
+            if (o.n_nodes == 0 ? o.n_prims != 1 : (o.first_node < n_top_nodes || o.first_node + o.n_nodes > d->n_nodes)) return fail(RSPT_E_INVALID, "object %u: node range", i);
+        }
+        for (uint32_t i = 0; i < d->n_instances; i++) {
+            const rspt_instance& in = d->instances[i];
+            if (in.object >= d->n_objects) return fail(RSPT_E_INVALID, "instance %u: object index out of range", i);
+            for (int k = 0; k < 2; k++) {
+                const float* m = k ? in.from_world : in.to_world;
+                if (m[12] != 0.0f || m[13] != 0.0f || m[14] != 0.0f || m[15] != 1.0f) return fail(RSPT_E_UNSUPPORTED, "instance %u: projective transform", i);
+                for (int j = 0; j < 12; j++) if (!(fabsf(m[j]) < RSPT_INF)) return fail(RSPT_E_INVALID, "instance %u: non-finite transform", i);
+            }
+        }
+    }
     for (uint64_t i = 0; i < d->n_prims; i++) {
         const rspt_prim& p = d->prims[i];
+        if (p.mesh == RSPT_MESH_INSTANCE) {
+            if (!instanced || i >= n_top_prims || p.v[0] >= d->n_instances) return fail(RSPT_E_INVALID, "prim %llu: bad instance reference", (unsigned long long)i);
+            continue;
+        }
+        if (i >= n_top_prims && p.area_light != -1) return fail(RSPT_E_UNSUPPORTED, "prim %llu: area lights are not supported with object instancing (api.rs:2899)", (unsigned long long)i);
         if (p.v[0] >= d->n_vertices || p.v[1] >= d->n_vertices || p.v[2] >= d->n_vertices) return fail(RSPT_E_INVALID, "prim %llu: vertex index out of range", (unsigned long long)i);
         if (p.mesh >= d->n_meshes) return fail(RSPT_E_INVALID, "prim %llu: mesh index out of range", (unsigned long long)i);
         if (p.material != 0xffffffffu && p.material >= d->n_materials) return fail(RSPT_E_INVALID, "prim %llu: material index out of range", (unsigned long long)i);
@@ -875,7 +924,8 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         if (d->bxdfs[i].type < RSPT_BXDF_LAMBERT_R || d->bxdfs[i].type > RSPT_BXDF_FRESNEL_BLEND) return fail(RSPT_E_UNSUPPORTED, "bxdf %u: unsupported type %u", i, d->bxdfs[i].type);
     for (uint32_t i = 0; i < d->n_lights; i++) {
         if (d->lights[i].kind < RSPT_LIGHT_DIFFUSE_AREA || d->lights[i].kind > RSPT_LIGHT_INFINITE) return fail(RSPT_E_UNSUPPORTED, "light %u: unsupported kind %u", i, d->lights[i].kind);
-        if (d->lights[i].kind == RSPT_LIGHT_DIFFUSE_AREA && d->lights[i].prim >= d->n_prims) return fail(RSPT_E_INVALID, "light %u: prim out of range", i);
+        if (d->lights[i].kind == RSPT_LIGHT_DIFFUSE_AREA && (d->lights[i].prim >= n_top_prims || d->prims[d->lights[i].prim].mesh == RSPT_MESH_INSTANCE))
+            return fail(RSPT_E_INVALID, "light %u: prim out of range", i);
         if (d->lights[i].kind == RSPT_LIGHT_INFINITE && d->lights[i].prim >= d->n_envmaps) return fail(RSPT_E_INVALID, "light %u: envmap index out of range", i);
     }
     // textures: constant / imagemap / scale; each material may bind at most RSPT_TEX_SLOTS distinct ones
@@ -934,29 +984,50 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         if (e.n_levels != nl || nl > 16) return fail(RSPT_E_INVALID, "envmap %u: n_levels %u, expected %u", i, e.n_levels, nl);
         if (!e.texels || !e.dist_func || e.dist_nu == 0 || e.dist_nv == 0) return fail(RSPT_E_INVALID, "envmap %u: null data", i);
     }
-    // BVH: child / leaf ranges in bounds, depth <= 64 (the reference's fixed traversal stack, bvh.rs:420)
-    if (d->n_nodes) {
-        std::vector<std::pair<uint32_t, uint32_t>> stack;  // node, depth
-        stack.push_back({0u, 1u});
-        uint64_t visited = 0;
-        while (!stack.empty()) {
-            auto [ni, depth] = stack.back();
-            stack.pop_back();
-            if (++visited > d->n_nodes) return fail(RSPT_E_INVALID, "BVH is not a tree");
-            if (depth > 64) return fail(RSPT_E_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
-            const rspt_bvh_node& n = d->nodes[ni];
-            if (n.n_prims > 0) {
-                if (n.offset < 0 || (uint64_t)n.offset + n.n_prims > d->n_prims) return fail(RSPT_E_INVALID, "node %u: leaf range out of bounds", ni);
-            } else {
-                if (n.axis > 2 || n.offset <= (int64_t)ni || (uint64_t)n.offset >= d->n_nodes || (uint64_t)ni + 1 >= d->n_nodes) return fail(RSPT_E_INVALID, "node %u: bad children", ni);
-                stack.push_back({(uint32_t)n.offset, depth + 1});
-                stack.push_back({ni + 1, depth + 1});
+    // BVH: child / leaf ranges in bounds, depth <= 64 (the reference's fixed traversal stack, bvh.rs:420); with instances the
+    // object's traversal continues on the stack of the top-level one (kernels.h traverse), so the two depths add up
+    {
+        std::string err;
+        auto tree_depth = [&](uint64_t root, uint64_t node_lo, uint64_t node_hi, uint64_t prim_lo, uint64_t prim_hi) -> int {
+            std::vector<std::pair<uint32_t, uint32_t>> stack;  // node, depth
+            stack.push_back({(uint32_t)root, 1u});
+            uint64_t visited = 0;
+            uint32_t deepest = 0;
+            while (!stack.empty()) {
+                auto [ni, depth] = stack.back();
+                stack.pop_back();
+                if (++visited > node_hi - node_lo) { err = "BVH is not a tree"; return -1; }
+                deepest = std::max(deepest, depth);
+                if (depth > 64) { err = "BVH deeper than the 64-entry traversal stack"; return -2; }
+                const rspt_bvh_node& n = d->nodes[ni];
+                if (n.n_prims > 0) {
+                    if (n.offset < 0 || (uint64_t)n.offset < prim_lo || (uint64_t)n.offset + n.n_prims > prim_hi) { err = "node " + std::to_string(ni) + ": leaf range out of bounds"; return -1; }
+                } else {
+                    if (n.axis > 2 || n.offset <= (int64_t)ni || (uint64_t)n.offset >= node_hi || (uint64_t)ni + 1 >= node_hi) { err = "node " + std::to_string(ni) + ": bad children"; return -1; }
+                    stack.push_back({(uint32_t)n.offset, depth + 1});
+                    stack.push_back({ni + 1, depth + 1});
+                }
             }
+            return (int)deepest;
+        };
+        int top_depth = 0, obj_depth = 0;
+        if (d->n_nodes) {
+            top_depth = tree_depth(0, 0, n_top_nodes, 0, n_top_prims);
+            if (top_depth < 0) return fail(top_depth == -2 ? RSPT_E_UNSUPPORTED : RSPT_E_INVALID, "%s", err.c_str());
         }
+        for (uint32_t i = 0; instanced && i < d->n_objects; i++) {
+            const rspt_object& o = d->objects[i];
+            if (o.n_nodes == 0) continue;
+            const int dep = tree_depth(o.first_node, o.first_node, o.first_node + o.n_nodes, o.first_prim, o.first_prim + o.n_prims);
+            if (dep < 0) return fail(dep == -2 ? RSPT_E_UNSUPPORTED : RSPT_E_INVALID, "object %u: %s", i, err.c_str());
+            obj_depth = std::max(obj_depth, dep);
+        }
+        if (top_depth + obj_depth > 64) return fail(RSPT_E_UNSUPPORTED, "top-level BVH (%d levels) + object BVH (%d levels) deeper than the 64-entry traversal stack", top_depth, obj_depth);
     }
     HIP_TRY(hipSetDevice(g.device));
     rspt_scene_s* s = new rspt_scene_s();
-    s->has_null_material = has_null;
+    s->has_null_material = has_null || (instanced && d->instancing_mode == RSPT_INSTANCING_REFERENCE);  // instanced hits pass through like null surfaces (Q11)
+    s->has_instances = instanced;
     auto bail = [&](int rc) {
         for (void* p : s->allocs) (void)hipFree(p);
         delete s;
@@ -1082,12 +1153,33 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         hipError_t e = hipMalloc((void**)&tris, d->n_prims * 3 * sizeof(float4));
         if (e != hipSuccess) return bail(fail(RSPT_E_NOMEM, "triangle records: %s", hipGetErrorString(e)));
         s->allocs.push_back(tris);
-        hipLaunchKernelGGL(k_build_tris, dim3((uint32_t)((d->n_prims + 255) / 256)), dim3(256), 0, g.stream, s->dev.prims, meshes_d, P_d, (uint32_t)d->n_prims, tris);
+        hipLaunchKernelGGL(k_build_tris, dim3((uint32_t)((d->n_prims + 255) / 256)), dim3(256), 0, g.stream, s->dev.prims, meshes_d, P_d, (uint32_t)d->n_prims, tris, (const uint32_t*)nullptr);
         e = hipStreamSynchronize(g.stream);
         if (e != hipSuccess) return bail(fail(RSPT_E_HIP, "k_build_tris: %s", hipGetErrorString(e)));
         s->dev.tris = tris;
     }
-    if (d->n_nodes > 1) {  // pair records: both children's boxes next to each other (trace_wide.h)
+    if (instanced) {  // InstDev records
+        std::vector<InstDev> ins(d->n_instances);
+        for (uint32_t i = 0; i < d->n_instances; i++) {
+            const rspt_instance& in = d->instances[i];
+            const rspt_object& o = d->objects[in.object];
+            InstDev& x = ins[i];
+            memset(&x, 0, sizeof x);
+            memcpy(x.m, in.to_world, sizeof x.m);
+            memcpy(x.mi, in.from_world, sizeof x.mi);
+            x.root_node = o.n_nodes ? (uint32_t)o.first_node : RSPT_MISS;
+            x.first_prim = (uint32_t)o.first_prim;
+            x.w4_root = RSPT_MISS;
+            bool ident = true;  // Transform::is_identity looks at m only (transform.rs:291-308)
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) ident &= in.to_world[4 * r + c] == (r == c ? 1.0f : 0.0f);
+            x.identity = ident ? 1u : 0u;
+        }
+        if ((rc = upload(s, ins.data(), ins.size(), &s->dev.inst))) return bail(rc);
+        s->dev.n_inst = d->n_instances;
+        s->dev.inst_fixed = d->instancing_mode == RSPT_INSTANCING_FIXED ? 1u : 0u;
+    }
+    if (d->n_nodes > 1 && !instanced) {  // pair records: both children's boxes next to each other (trace_wide.h)
         std::vector<uint32_t> pair_of(d->n_nodes, 0u);
         uint32_t n_pairs = 0;
         for (uint64_t i = 0; i < d->n_nodes; i++)
@@ -1110,7 +1202,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         }
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->pairs))) return bail(rc);
     }
-    if (d->n_nodes > 0) {  // four-box records (trace_w4.h): grandchildren of every interior node at even depth
+    if (d->n_nodes > 0 && !instanced) {  // four-box records (trace_w4.h): grandchildren of every interior node at even depth
         std::vector<uint2> big;
         auto leaf_ref = [&](uint32_t ni) -> uint32_t {
             const rspt_bvh_node& n = d->nodes[ni];

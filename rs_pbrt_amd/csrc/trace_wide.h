@@ -299,7 +299,7 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, c
         const bool mis = OUT_MODE == 0 && (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
-        TraceResult res = traverse<ANY>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        TraceResult res = traverse<ANY, false>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
             else (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);

@@ -15,7 +15,7 @@ _LIB = None
 EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
            "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
-           "rspt_bvh_build_gpu", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy")
+           "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy")
 
 
 def source_hash():
@@ -64,6 +64,8 @@ def lib():
         L.rspt_last_counters.argtypes = [vp]
         L.rspt_bvh_build.restype = C.c_int64
         L.rspt_bvh_build.argtypes = [vp, vp, u64, u32, vp, u64, vp, i32]
+        L.rspt_bvh_build_bounds.restype = C.c_int64
+        L.rspt_bvh_build_bounds.argtypes = [vp, u64, u32, vp, u64, vp, i32]
         L.rspt_bvh_build_gpu.restype = C.c_int64
         L.rspt_bvh_build_gpu.argtypes = [vp, u64, vp, u64, u32, vp, u64, vp]
         L.rspt_comm_unique_id.argtypes = [vp]
@@ -85,6 +87,18 @@ def bvh_build(P, tri, max_prims_in_node=4, threads=0):
     nodes = np.zeros(max(2 * n, 1), abi.NODE_DT)
     ordered = np.zeros(n, np.uint32)
     k = lib().rspt_bvh_build(P.ctypes.data, tri.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data, threads)
+    if k < 0:
+        raise RsptError(int(k), (lib().rspt_bvh_last_error() or b"").decode())
+    return nodes[:k].copy(), ordered
+
+
+def bvh_build_bounds(bounds, max_prims_in_node=4, threads=0):
+    """BVHAccel::new over primitives given by their world bounds (n, 6): (nodes, ordered)"""
+    bounds = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
+    n = len(bounds)
+    nodes = np.zeros(max(2 * n, 1), abi.NODE_DT)
+    ordered = np.zeros(n, np.uint32)
+    k = lib().rspt_bvh_build_bounds(bounds.ctypes.data, n, max_prims_in_node, nodes.ctypes.data, len(nodes), ordered.ctypes.data, threads)
     if k < 0:
         raise RsptError(int(k), (lib().rspt_bvh_last_error() or b"").decode())
     return nodes[:k].copy(), ordered

@@ -154,6 +154,17 @@ class Transform:
         return Transform(np.diag([x, y, z, F32(1)]).astype(F32), np.diag([F32(1) / x, F32(1) / y, F32(1) / z, F32(1)]).astype(F32))
 
     @staticmethod
+    def rotate_y(theta_deg):  # transform.rs:355-367 (m_inv = transpose)
+        t = math.radians(float(F32(theta_deg)))
+        sn, cs = F32(math.sin(t)), F32(math.cos(t))
+        m = np.array([[cs, 0, sn, 0], [0, 1, 0, 0], [-sn, 0, cs, 0], [0, 0, 0, 1]], F32)
+        return Transform(m, m.T.copy())
+
+    @staticmethod
+    def identity():
+        return Transform(np.eye(4, dtype=F32), np.eye(4, dtype=F32))
+
+    @staticmethod
     def perspective(fov, n, f):  # transform.rs:461-489
         n, f = F32(n), F32(f)
         persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], F32)
@@ -510,6 +521,26 @@ class SceneBuilder:
         self.delta_lights = []  # point / spot / distant / infinite: appended to Scene.lights after the area lights
         self.envmaps = []
         self.images, self.textures = [], []
+        # object instancing (api.rs:3001-3109): meshes added between begin_object / end_object belong to that object
+        self.mesh_object = []        # per mesh: object index or -1 (top level)
+        self.objects = {}            # name -> index
+        self.cur_object = -1
+        self.instances = []          # (object index, Transform primitive_to_world)
+        self.decl = []               # render_options.primitives order: ("mesh", m) | ("inst", k)
+
+    # ---- object instancing ----
+    def begin_object(self, name):  # pbrt_object_begin api.rs:3001-3013
+        assert self.cur_object < 0, "ObjectBegin called inside of instance definition"
+        self.objects[name] = len(self.objects)
+        self.cur_object = self.objects[name]
+
+    def end_object(self):  # pbrt_object_end
+        self.cur_object = -1
+
+    def add_instance(self, name, to_world):  # pbrt_object_instance api.rs:3024-3109: TransformedPrimitive(object aggregate, CTM)
+        assert self.cur_object < 0, "ObjectInstance can't be called inside instance definition"
+        self.decl.append(("inst", len(self.instances)))
+        self.instances.append((self.objects[name], to_world))
 
     # ---- textures (api.rs make_texture; src/textures/*.rs) ----
     def _add_texture(self, **kw):
@@ -584,6 +615,10 @@ class SceneBuilder:
         """P (nv,3) world-space vertices; idx (nt,3); emit = rgb L or None."""
         P = np.asarray(P, F32).reshape(-1, 3); idx = np.asarray(idx, np.uint32).reshape(-1, 3)
         m = len(self.meshes)
+        assert self.cur_object < 0 or emit is None, "Area lights not supported with object instancing (api.rs:2899)"
+        self.mesh_object.append(self.cur_object)
+        if self.cur_object < 0:
+            self.decl.append(("mesh", m))
         self.meshes.append((int(N is not None), 0, int(UV is not None), int(flip)))
         self.mesh_material.append(material)
         self.mesh_emit.append(None if emit is None else (np.array(emit, F32), bool(two_sided)))
@@ -641,28 +676,108 @@ class SceneBuilder:
         lt["p"][:9] = l2w.reshape(-1); lt["p"][9:18] = np.linalg.inv(l2w.astype(np.float64)).astype(F32).reshape(-1)
         self.delta_lights.append(lt)
 
-    def finish(self, bvh_builder, max_prims_in_node=4):
-        """bvh_builder(P (nv,3) f32, tri (nt,3) u32, max_prims) -> (nodes NODE_DT[], ordered u32[])"""
+    def finish(self, bvh_builder, max_prims_in_node=4, instancing="reference"):
+        """bvh_builder(P (nv,3) f32, tri (nt,3) u32, max_prims) -> (nodes NODE_DT[], ordered u32[]).
+        With object instances the top-level aggregate is built over (top-level triangles in declaration order, then the
+        TransformedPrimitives in declaration order) from their world bounds by rspt_bvh_build_bounds; every object with more
+        than one triangle gets its own BVHAccel from bvh_builder (api.rs:3046-3094)."""
         P = np.ascontiguousarray(np.concatenate(self.P), F32)
         tri = np.ascontiguousarray(np.concatenate(self.tris), np.uint32)
         tri_mesh = np.concatenate(self.tri_mesh)
-        nodes, ordered = bvh_builder(P, tri, max_prims_in_node)
+        tri_obj = np.array(self.mesh_object, np.int64)[tri_mesh]
+        top = np.nonzero(tri_obj < 0)[0]          # input triangle numbers of the top-level shapes
+        objects = np.zeros(len(self.objects), abi.OBJECT_DT)
+        instances = np.zeros(len(self.instances), abi.INSTANCE_DT)
+        if not self.instances:
+            assert len(top) == len(tri), "objects without instances are dropped by the reference; not modelled"
+            nodes, ordered = bvh_builder(P, tri, max_prims_in_node)
+            top_in = ordered                       # BVH slot -> input triangle
+            n_top_nodes, n_top_prims = len(nodes), len(tri)
+            all_nodes, obj_in = [nodes], []
+        else:
+            from . import lib
+            # each object's own aggregate first (its bounds feed the instances' bounds)
+            obj_nodes, obj_in, obj_bound = [], [], []
+            for o in range(len(self.objects)):
+                t_in = np.nonzero(tri_obj == o)[0]
+                assert len(t_in) > 0, "ObjectInstance of an empty object is skipped by the reference (api.rs:3037); not modelled"
+                if len(t_in) > 1:
+                    on, oo = bvh_builder(P, tri[t_in], max_prims_in_node)
+                    lo, hi = on["bmin"][0].copy(), on["bmax"][0].copy()   # BVHAccel::world_bound = nodes[0].bounds (bvh.rs:394-400)
+                else:
+                    on, oo = np.zeros(0, abi.NODE_DT), np.zeros(1, np.uint32)
+                    v = P[tri[t_in[0]]]
+                    lo, hi = v.min(0), v.max(0)                             # Triangle::world_bound (triangle.rs:126-133)
+                obj_nodes.append(on); obj_in.append(t_in[oo]); obj_bound.append((lo.astype(F32), hi.astype(F32)))
+            # the aggregate's input list = render_options.primitives: shapes and instances in declaration order
+            first_tri_of_mesh = np.concatenate([[0], np.cumsum([len(t) for t in self.tris])])
+            in_tri, in_inst = [], []      # per input primitive: triangle number or -1, instance or -1
+            for kind, ref in self.decl:
+                if kind == "mesh":
+                    nt = len(self.tris[ref])
+                    in_tri.append(np.arange(first_tri_of_mesh[ref], first_tri_of_mesh[ref] + nt)); in_inst.append(np.full(nt, -1))
+                else:
+                    in_tri.append(np.array([-1])); in_inst.append(np.array([ref]))
+            in_tri, in_inst = np.concatenate(in_tri).astype(np.int64), np.concatenate(in_inst).astype(np.int64)
+            bounds = np.zeros((len(in_tri), 6), F32)
+            tsel = in_tri >= 0
+            tv = P[tri[in_tri[tsel]]]
+            bounds[tsel, :3], bounds[tsel, 3:] = tv.min(1), tv.max(1)
+            for k, (o, xf) in enumerate(self.instances):
+                lo, hi = _transform_bounds(xf.m, *obj_bound[o])             # TransformedPrimitive::world_bound (primitive.rs:212-215)
+                row = np.nonzero(in_inst == k)[0][0]
+                bounds[row, :3], bounds[row, 3:] = lo, hi
+                instances[k]["object"] = o
+                instances[k]["to_world"] = xf.m.reshape(-1); instances[k]["from_world"] = xf.m_inv.reshape(-1)
+            nodes, ordered = lib.bvh_build_bounds(bounds, max_prims_in_node)
+            n_top_nodes, n_top_prims = len(nodes), len(bounds)
+            top_in = ordered                       # BVH slot -> input primitive
+            all_nodes = [nodes]
+            node_base, prim_base = n_top_nodes, n_top_prims
+            for o, on in enumerate(obj_nodes):
+                on = on.copy()
+                leaf = on["n_prims"] > 0
+                on["offset"][leaf] += prim_base
+                on["offset"][~leaf] += node_base
+                objects[o] = (node_base, len(on), prim_base, len(obj_in[o]))
+                all_nodes.append(on)
+                node_base += len(on); prim_base += len(obj_in[o])
+        # prims: the top-level aggregate's (triangles and instances, BVH order), then each object's
+        n_prims_total = n_top_prims + sum(len(x) for x in obj_in)
+        prims = np.zeros(n_prims_total, abi.PRIM_DT)
+        mesh_mat = np.array(self.mesh_material, np.uint32)
+        if self.instances:
+            is_inst = in_inst[top_in] >= 0
+            slot_tri = np.where(is_inst, 0, in_tri[top_in])
+        else:
+            is_inst = np.zeros(n_top_prims, bool)
+            slot_tri = top_in
+        prims["v"][:n_top_prims] = tri[slot_tri] if len(tri) else 0
+        prims["mesh"][:n_top_prims] = tri_mesh[slot_tri]
+        prims["material"][:n_top_prims] = mesh_mat[tri_mesh[slot_tri]]
+        prims["area_light"][:n_top_prims] = -1
+        if self.instances:
+            k = np.nonzero(is_inst)[0]
+            prims["v"][k] = 0
+            prims["v"][k, 0] = in_inst[top_in[k]].astype(np.uint32)
+            prims["mesh"][k] = abi.MESH_INSTANCE; prims["material"][k] = abi.NO_MATERIAL
+        base = n_top_prims
+        for t_in in obj_in:
+            sl = slice(base, base + len(t_in))
+            prims["v"][sl] = tri[t_in]; prims["mesh"][sl] = tri_mesh[t_in]; prims["material"][sl] = mesh_mat[tri_mesh[t_in]]; prims["area_light"][sl] = -1
+            base += len(t_in)
         # lights in shape-declaration order (one DiffuseAreaLight per emissive triangle, api.rs:2810-2852)
-        light_of_tri = np.full(len(tri), -1, np.int32)
+        slot_of_tri = np.full(len(tri), -1, np.int64)
+        tri_slots = np.nonzero(~is_inst)[0]
+        slot_of_tri[slot_tri[tri_slots]] = tri_slots
         lights_in = []
         emissive_mesh = np.array([e is not None for e in self.mesh_emit], bool)
         for t in np.nonzero(emissive_mesh[tri_mesh])[0]:
-            light_of_tri[t] = len(lights_in)
+            prims["area_light"][slot_of_tri[t]] = len(lights_in)
             lights_in.append((int(t), self.mesh_emit[tri_mesh[t]]))
-        inv = np.empty(len(tri), np.uint32); inv[ordered] = np.arange(len(tri), dtype=np.uint32)
-        prims = np.zeros(len(tri), abi.PRIM_DT)
-        prims["v"] = tri[ordered]
-        prims["mesh"] = tri_mesh[ordered]
-        prims["material"] = np.array(self.mesh_material, np.uint32)[tri_mesh[ordered]]
-        prims["area_light"] = light_of_tri[ordered]
         lights = np.zeros(len(lights_in) + len(self.delta_lights), abi.LIGHT_DT)
         for i, (t, (L, two)) in enumerate(lights_in):
-            lights[i]["kind"] = abi.LIGHT_DIFFUSE_AREA; lights[i]["prim"] = inv[t]; lights[i]["L"] = L; lights[i]["two_sided"] = int(two)
+            lights[i]["kind"] = abi.LIGHT_DIFFUSE_AREA; lights[i]["prim"] = slot_of_tri[t]; lights[i]["L"] = L; lights[i]["two_sided"] = int(two)
         for i, lt in enumerate(self.delta_lights):
             lights[len(lights_in) + i] = lt
         mats = np.zeros(len(self.materials), abi.MATERIAL_DT)
@@ -672,18 +787,36 @@ class SceneBuilder:
             bx.extend(m["lobes"])
         bxdfs = np.array(bx, abi.BXDF_DT) if bx else np.zeros(0, abi.BXDF_DT)
         meshes = np.array(self.meshes, np.uint32).view(abi.MESH_DT).reshape(-1)
-        return Scene(nodes=nodes, prims=prims, meshes=meshes, P=P,
+        return Scene(nodes=np.concatenate(all_nodes), prims=prims, meshes=meshes, P=P,
                      N=np.ascontiguousarray(np.concatenate(self.N), F32) if self.any_n else None,
                      UV=np.ascontiguousarray(np.concatenate(self.UV), F32) if self.any_uv else None,
                      materials=mats, bxdfs=bxdfs, lights=lights, envmaps=self.envmaps,
-                     textures=np.array(self.textures, abi.TEXTURE_DT) if self.textures else None, images=self.images)
+                     textures=np.array(self.textures, abi.TEXTURE_DT) if self.textures else None, images=self.images,
+                     objects=objects, instances=instances, n_top=(n_top_nodes, n_top_prims),
+                     instancing={"reference": abi.INSTANCING_REFERENCE, "fixed": abi.INSTANCING_FIXED}[instancing])
+
+
+def _transform_bounds(m, lo, hi):
+    """Transform::transform_bounds (transform.rs:596-660) in f32: the eight corners through transform_point (affine: w == 1), union"""
+    m = np.asarray(m, F32)
+    out_lo, out_hi = None, None
+    for cx, cy, cz in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1), (1, 1, 0), (1, 0, 1), (1, 1, 1)):
+        x, y, z = (hi if cx else lo)[0], (hi if cy else lo)[1], (hi if cz else lo)[2]
+        p = np.array([F32(F32(F32(m[r, 0] * x) + F32(m[r, 1] * y)) + F32(m[r, 2] * z)) + m[r, 3] for r in range(3)], F32)
+        out_lo = p if out_lo is None else np.minimum(out_lo, p)
+        out_hi = p if out_hi is None else np.maximum(out_hi, p)
+    return out_lo, out_hi
 
 
 class Scene:
     """Flattened scene arrays + the ctypes rspt_scene_desc pointing at them."""
 
-    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=(), textures=None, images=()):
+    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=(), textures=None, images=(),
+                 objects=None, instances=None, n_top=None, instancing=abi.INSTANCING_REFERENCE):
         self.nodes, self.prims, self.meshes, self.P, self.N, self.UV, self.S = nodes, prims, meshes, P, N, UV, S
+        self.objects = objects if objects is not None else np.zeros(0, abi.OBJECT_DT)
+        self.instances = instances if instances is not None else np.zeros(0, abi.INSTANCE_DT)
+        self.n_top = n_top if n_top is not None else (len(nodes), len(prims))
         self.materials, self.bxdfs, self.lights = materials, bxdfs, lights
         self.envmaps = list(envmaps)
         self.textures = textures if textures is not None else np.zeros(0, abi.TEXTURE_DT)
@@ -700,7 +833,13 @@ class Scene:
                                   p(materials), len(materials), p(bxdfs), len(bxdfs), p(lights), len(lights),
                                   C.addressof(self._env_structs) if self.envmaps else None, len(self.envmaps),
                                   p(self.textures), len(self.textures),
-                                  C.addressof(self._img_structs) if self.images else None, len(self.images))
+                                  C.addressof(self._img_structs) if self.images else None, len(self.images),
+                                  p(self.objects), len(self.objects), p(self.instances), len(self.instances),
+                                  self.n_top[0], self.n_top[1], instancing, 0)
+
+    def set_instancing(self, mode):
+        """"reference" | "fixed" (rspt_scene_desc.instancing_mode); takes effect at the next DeviceScene / oracle call"""
+        self.desc.instancing_mode = {"reference": abi.INSTANCING_REFERENCE, "fixed": abi.INSTANCING_FIXED}[mode]
 
     @property
     def n_tris(self):
@@ -970,3 +1109,72 @@ STATUE_FOV = 38.0
 
 def statue_render_desc(xres=1920, yres=1080, spp=1024, **kw):
     return make_render_desc(xres, yres, spp, STATUE_LOOK_AT, STATUE_FOV, **kw)
+
+
+# ---------------------------------------------------------------------------------------
+# C5 stand-in: instanced geometry under a lat-long sky
+# ---------------------------------------------------------------------------------------
+def _tree_mesh(grid_u=100, grid_v=50, seed=0x7EE):
+    """one "tree": a noise-displaced canopy (2 * grid_u * grid_v triangles) on a thin trunk, ~10 k triangles at 100 x 50"""
+    th = np.linspace(0.02, np.pi - 0.02, grid_v + 1)[:, None]; ph = np.linspace(0, 2 * np.pi, grid_u + 1)[None, :]
+    d = np.stack([np.sin(th) * np.cos(ph), np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    rad = 0.45 + 0.2 * _value_noise(d * 2.0, seed, octaves=3)
+    P = d * rad[:, None] * np.array([1.0, 1.4, 1.0]) + np.array([0.0, 1.3, 0.0])
+    i, j = np.meshgrid(np.arange(grid_v), np.arange(grid_u), indexing="ij")
+    a = (i * (grid_u + 1) + j).reshape(-1); b = a + 1; c = a + (grid_u + 1); e = c + 1
+    idx = np.concatenate([np.stack([a, c, b], 1), np.stack([b, c, e], 1)])
+    k = 8  # trunk: an open 8-sided prism
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    ring = np.stack([0.06 * np.cos(ang), np.zeros(k), 0.06 * np.sin(ang)], 1)
+    T = np.concatenate([ring, ring + np.array([0, 0.9, 0])])
+    ti = np.array([[q, (q + 1) % k, k + q] for q in range(k)] + [[(q + 1) % k, k + (q + 1) % k, k + q] for q in range(k)])
+    return P.astype(F32), idx.astype(np.uint32), T.astype(F32), ti.astype(np.uint32)
+
+
+def landscape_standin(bvh_builder, n_side=64, terrain=256, seed=0x1A9D, instancing="reference", tree_grid=(100, 50)):
+    """C5 stand-in for the off-tree Landscape cover scene: n_side^2 ObjectInstances (4096 at 64) of one ~10 k-triangle
+    tree object (canopy + trunk, two materials) with per-instance rotation about y, non-uniform scale and translation onto a
+    terrain^2-cell height field, under a 64 x 32 lat-long sky with a sun texel (InfiniteAreaLight, importance sampled).
+    DECLARED STAND-IN: not the real asset.  instancing: "reference" = rs_pbrt v0.9.12's behaviour (instanced hits carry no
+    material: the trees are invisible to camera / bounce rays and cast shadows, Q11) | "fixed"."""
+    rng = np.random.default_rng(seed)
+    sb = SceneBuilder()
+    leaf = sb.add_material(matte((0.12, 0.35, 0.1)))
+    bark = sb.add_material(matte((0.3, 0.2, 0.12)))
+    soil = sb.add_material(matte((0.35, 0.3, 0.22)))
+    g = np.linspace(-1, 1, terrain + 1)
+    X, Z = np.meshgrid(g * 40.0, g * 40.0, indexing="xy")
+    H = 2.5 * _value_noise(np.stack([X.reshape(-1) / 20.0, np.zeros(X.size), Z.reshape(-1) / 20.0], 1), seed + 1, octaves=4).reshape(X.shape)
+    P = np.stack([X, H, Z], -1).reshape(-1, 3)
+    i, j = np.meshgrid(np.arange(terrain), np.arange(terrain), indexing="ij")
+    a = (i * (terrain + 1) + j).reshape(-1); b = a + 1; c = a + (terrain + 1); e = c + 1
+    sb.add_mesh(P.astype(F32), np.concatenate([np.stack([a, c, b], 1), np.stack([b, c, e], 1)]).astype(np.uint32), soil)
+    cp, ci, tp, ti = _tree_mesh(*tree_grid)
+    sb.begin_object("tree")
+    sb.add_mesh(cp, ci, leaf)
+    sb.add_mesh(tp, ti, bark)
+    sb.end_object()
+    cell = 70.0 / n_side
+    for r in range(n_side):
+        for q in range(n_side):
+            x = -35.0 + cell * (q + 0.5) + float(rng.uniform(-0.3, 0.3)) * cell
+            z = -35.0 + cell * (r + 0.5) + float(rng.uniform(-0.3, 0.3)) * cell
+            fx, fz = (x / 40.0 + 1) * terrain / 2, (z / 40.0 + 1) * terrain / 2
+            y = float(H[min(int(fz), terrain), min(int(fx), terrain)]) - 0.05
+            s_ = float(rng.uniform(0.7, 1.3))
+            xf = Transform.translate((x, y, z)) * Transform.rotate_y(float(rng.uniform(0, 360))) * Transform.scale(s_, s_ * float(rng.uniform(0.8, 1.4)), s_)
+            sb.add_instance("tree", xf)
+    sky = np.zeros((32, 64, 3), F32)
+    t = np.linspace(0, 1, 32)[:, None]
+    sky[..., 0] = 0.25 + 0.35 * t; sky[..., 1] = 0.4 + 0.3 * t; sky[..., 2] = 0.75 + 0.1 * t
+    sky[16:] *= 0.15                      # below the horizon
+    sky[6, 20] = (400.0, 380.0, 300.0)    # the sun
+    sb.add_infinite_light((1.0, 1.0, 1.0), image=sky)
+    return sb.finish(bvh_builder, instancing=instancing)
+
+
+LANDSCAPE_LOOK_AT = ((0, 9, -42), (0, 1.5, 0), (0, 1, 0))
+
+
+def landscape_render_desc(xres=1920, yres=1080, spp=4096, **kw):
+    return make_render_desc(xres, yres, spp, LANDSCAPE_LOOK_AT, 45.0, **kw)

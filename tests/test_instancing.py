@@ -1,0 +1,288 @@
+"""Object instancing: TransformedPrimitive (primitive.rs:198-272), Transform::transform_surface_interaction
+(transform.rs:815-860), ObjectInstance (api.rs:3024-3109).  CPU part: the host-side scene assembly and the oracle's restatement
+pinned by first principles — the reference's own behaviour (Q10 / Q11: instanced hits lose their primitive, identity instances
+report no hit) and the "fixed" behaviour are both checked against scenes with the same geometry baked into world space.
+-m gpu part: librspt's two-level traversal and shading against the oracle, bit for bit at the trace stage."""
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import abi, scenes
+from tests.util import film_rmse, random_rays
+
+LOOK = ((0, 2.5, -6), (0, 0.5, 0), (0, 1, 0))
+PYR = np.array([(-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5), (0, 1, 0)], np.float32)
+PYR_IDX = [[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]]
+
+
+def instance_transforms():
+    T = scenes.Transform
+    return [T.translate((i - 2.0, 0.2, 1.0 + 0.3 * i)) * T.rotate_y(20.0 * i + 5.0) * T.scale(0.5 + 0.1 * i, 1.0 + 0.05 * i, 0.8) for i in range(5)]
+
+
+def small_scene(builder, mode="reference", identity=True, area=True, baked=False, baked_material=None, tex=False):
+    """ground + light + five transformed instances of a 4-triangle pyramid (+ textured / bump-mapped variant), one instance of
+    a single-triangle object (no aggregate), optionally one identity instance.  baked=True: the same triangles transformed on
+    the host into world space as plain top-level meshes (material baked_material, NO_MATERIAL = null surfaces)."""
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    if tex:
+        img = np.random.default_rng(3).uniform(0.1, 0.9, (8, 8, 3)).astype(np.float32)
+        red = sb.add_material(scenes.plastic(sb.image_texture(img, su=2.0, sv=2.0), (0.3, 0.3, 0.3), 0.15,
+                                             bump=sb.image_texture(img, channels=1, scale=0.05, trilinear=True)))
+    else:
+        red = sb.add_material(scenes.plastic((0.6, 0.2, 0.15), (0.3, 0.3, 0.3), 0.15))
+    sb.add_quad([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], grey)
+    sb.add_quad([(-5, 0, 5), (-5, 5, 5), (5, 5, 5), (5, 0, 5)], grey)
+    if area:
+        sb.add_quad([(-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1)], grey, emit=(10, 10, 10))
+    sb.add_point_light((3, 4, -3), (30, 30, 25))
+    one = PYR[:3] + np.float32(0.1)
+    uv = [[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5]]
+    xfs = instance_transforms()
+    if baked:
+        mat = red if baked_material is None else baked_material
+        for xf in xfs:
+            Pw = (np.concatenate([PYR, np.ones((5, 1), np.float32)], 1).astype(np.float64) @ xf.m.astype(np.float64).T)[:, :3]
+            sb.add_mesh(Pw.astype(np.float32), PYR_IDX, mat, UV=uv if tex else None)
+        sb.add_mesh(one + np.array([0, 2, 0], np.float32), [[0, 1, 2]], mat)
+        return sb.finish(builder)
+    sb.begin_object("pyr")
+    sb.add_mesh(PYR, PYR_IDX, red, UV=uv if tex else None)
+    sb.end_object()
+    sb.begin_object("one")
+    sb.add_mesh(one, [[0, 1, 2]], red)
+    sb.end_object()
+    for xf in xfs:
+        sb.add_instance("pyr", xf)
+    sb.add_instance("one", scenes.Transform.translate((0, 2, 0)))
+    if identity:
+        sb.add_instance("pyr", scenes.Transform.identity())
+    return sb.finish(builder, instancing=mode)
+
+
+def rd_small(spp=8, res=(96, 72), **kw):
+    return scenes.make_render_desc(res[0], res[1], spp, LOOK, 40.0, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU: host assembly + oracle known answers
+# ---------------------------------------------------------------------------------------------------------------
+def test_scene_assembly_and_top_level_bvh(oracle):
+    from rs_pbrt_amd import lib
+    sc = small_scene(lib.bvh_build)
+    n_top_nodes, n_top_prims = sc.n_top
+    assert len(sc.instances) == 7 and len(sc.objects) == 2
+    assert n_top_prims == 6 + 7 and len(sc.prims) == n_top_prims + 4 + 1
+    top = sc.prims[:n_top_prims]
+    inst = top[top["mesh"] == abi.MESH_INSTANCE]
+    assert sorted(inst["v"][:, 0].tolist()) == list(range(7)) and (inst["material"] == abi.NO_MATERIAL).all()
+    o_pyr, o_one = sc.objects
+    assert (o_pyr["n_prims"], o_one["n_prims"], o_one["n_nodes"]) == (4, 1, 0) and o_pyr["n_nodes"] >= 1
+    assert o_pyr["first_prim"] == n_top_prims and o_pyr["first_node"] == n_top_nodes
+    # object nodes carry absolute indices
+    on = sc.nodes[n_top_nodes:]
+    assert (on["offset"][on["n_prims"] > 0] >= n_top_prims).all() and (on["offset"][on["n_prims"] == 0] > n_top_nodes).all()
+    # every instance's bounds = Transform::transform_bounds of the object's, and the top-level tree = BVHAccel::new over them (oracle)
+    bounds = np.zeros((n_top_prims, 6), np.float32)
+    # reconstruct the builder's input order: top-level triangles in declaration order, then instances
+    tri_in = [(np.array(q, np.float32)) for q in ()]
+    k = 0
+    decl = []
+    for p in sc.prims[:n_top_prims]:
+        decl.append(p)
+    # the builder's `ordered` is not kept; check the leaves instead: every leaf primitive's bounds lie inside its leaf box, and
+    # the root box is the union of all primitive bounds
+    lo_all, hi_all = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+    for i, p in enumerate(sc.prims[:n_top_prims]):
+        if p["mesh"] == abi.MESH_INSTANCE:
+            ins = sc.instances[p["v"][0]]
+            ob = sc.objects[ins["object"]]
+            if ob["n_nodes"]:
+                lo, hi = sc.nodes["bmin"][ob["first_node"]], sc.nodes["bmax"][ob["first_node"]]
+            else:
+                v = sc.P[sc.prims["v"][ob["first_prim"]]]
+                lo, hi = v.min(0), v.max(0)
+            lo, hi = oracle.transform_bounds(ins["to_world"], lo, hi)
+            lo2, hi2 = scenes._transform_bounds(ins["to_world"].reshape(4, 4), np.asarray(sc.nodes["bmin"][ob["first_node"]] if ob["n_nodes"] else v.min(0)),
+                                                np.asarray(sc.nodes["bmax"][ob["first_node"]] if ob["n_nodes"] else v.max(0)))
+            assert np.array_equal(lo, lo2) and np.array_equal(hi, hi2)   # host assembly == oracle's transform_bounds, bit for bit
+        else:
+            v = sc.P[p["v"]]
+            lo, hi = v.min(0), v.max(0)
+        bounds[i, :3], bounds[i, 3:] = lo, hi
+        lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
+    assert np.array_equal(sc.nodes["bmin"][0], lo_all) and np.array_equal(sc.nodes["bmax"][0], hi_all)
+    top_nodes = sc.nodes[:n_top_nodes]
+    for nd in top_nodes[top_nodes["n_prims"] > 0]:
+        sl = slice(nd["offset"], nd["offset"] + nd["n_prims"])
+        assert (bounds[sl, :3] >= nd["bmin"]).all() and (bounds[sl, 3:] <= nd["bmax"]).all()
+    # the product's bounds builder against the oracle's restatement of BVHAccel::new on the same (BVH-ordered) bounds
+    a_nodes, a_ord = lib.bvh_build_bounds(bounds)
+    b_nodes, b_ord = oracle.bvh_build_bounds(bounds)
+    assert a_nodes.tobytes() == b_nodes.tobytes() and np.array_equal(a_ord, b_ord)
+    rng = np.random.default_rng(1)
+    lo = rng.uniform(-5, 5, (3000, 3)).astype(np.float32)
+    big = np.concatenate([lo, lo + rng.uniform(0.01, 1.5, (3000, 3)).astype(np.float32)], 1)
+    a_nodes, a_ord = lib.bvh_build_bounds(big, threads=4)
+    b_nodes, b_ord = oracle.bvh_build_bounds(big)
+    assert a_nodes.tobytes() == b_nodes.tobytes() and np.array_equal(a_ord, b_ord)
+
+
+def test_oracle_fixed_mode_matches_baked_geometry(oracle):
+    """first principles: with the fix, an instanced scene is the scene whose triangles were transformed on the host — up to the
+    rounding of doing the intersection in object space (hit points move by ulps, a few samples take another branch)"""
+    from rs_pbrt_amd import lib
+    rd = rd_small(spp=16)
+    inst = oracle.render(small_scene(lib.bvh_build, mode="fixed", identity=False), rd, threads=4, want_li=True)
+    baked = oracle.render(small_scene(lib.bvh_build, baked=True), rd, threads=4, want_li=True)
+    a, b = scenes.film_to_rgb(inst["film"]), scenes.film_to_rgb(baked["film"])
+    assert np.sqrt(np.mean((a - b) ** 2)) < 0.02 and abs(a.mean() - b.mean()) < 2e-3 * b.mean()
+    close = np.isclose(inst["li"], baked["li"], rtol=1e-3, atol=1e-4).all(-1).mean()
+    assert close > 0.97
+
+
+def test_oracle_reference_mode_is_null_surfaces_that_cast_shadows(oracle):
+    """Q11: an instanced hit has no primitive => no BSDF => path.rs:109-116 passes straight through it, while shadow rays are
+    still blocked (primitive.rs:258-265).  That is what NO_MATERIAL triangles do, so the same geometry baked into world space
+    with null materials must give the same picture (up to object-space rounding)."""
+    from rs_pbrt_amd import lib
+    rd = rd_small(spp=16)
+    ref = oracle.render(small_scene(lib.bvh_build, mode="reference", identity=False), rd, threads=4, want_li=True)
+    null = oracle.render(small_scene(lib.bvh_build, baked=True, baked_material=abi.NO_MATERIAL), rd, threads=4, want_li=True)
+    fixed = oracle.render(small_scene(lib.bvh_build, mode="fixed", identity=False), rd, threads=4)
+    a, b, c = (scenes.film_to_rgb(x["film"]) for x in (ref, null, fixed))
+    assert np.sqrt(np.mean((a - b) ** 2)) < 0.02 and abs(a.mean() - b.mean()) < 2e-3 * b.mean()
+    assert np.isclose(ref["li"], null["li"], rtol=1e-3, atol=1e-4).all(-1).mean() > 0.97
+    assert np.sqrt(np.mean((a - c) ** 2)) > 0.03   # and it is not what the fixed renderer shows
+
+
+def test_oracle_identity_instance_quirk(oracle):
+    """Q10: TransformedPrimitive::intersect of an identity instance shrinks r.t_max and then returns false.  One triangle as an
+    identity instance in front of a wall: a ray reports the instance's hit only if the wall's hit was registered first (then the
+    aggregate's `hit` flag is already set and the interaction — primitive kept — survives); if the instance is visited first the
+    wall is culled by the shrunk t_max and the ray reports NO hit.  Shadow rays see the triangle either way."""
+    from rs_pbrt_amd import lib
+    for order in (0, 1):
+        sc = quirk_scene(lib.bvh_build, order)
+        assert np.array_equal(sc.nodes["n_prims"][:sc.n_top[0]], [3])   # one leaf: the primitives are tested in list order
+        rays = np.zeros(2, abi.RAY_DT)
+        rays["o"] = [(0.3, -0.5, 0), (3, 3, 0)]; rays["d"] = (0, 0, 1); rays["t_max"] = np.inf
+        for mode in ("reference", "fixed"):
+            sc.set_instancing(mode)
+            h = oracle.trace(sc, rays)
+            occ = oracle.trace(sc, rays, any_hit=True)
+            assert occ["prim"][0] == 0 and occ["prim"][1] == 0
+            assert h["prim"][1] != abi.MISS and h["t"][1] == 5.0     # the second ray only meets the wall
+            if mode == "fixed" or order == 0:
+                assert 3.0 < h["t"][0] < 4.0 and h["prim"][0] == 3  # wall first (or fixed): the instance's closer interaction is reported
+            else:
+                assert h["prim"][0] == abi.MISS                     # instance tested first: t_max shrunk, the wall culled, nothing reported
+
+
+def quirk_scene(builder, order):
+    """a wall (two triangles) and an identity instance of one slanted triangle in front of it, all three with the same bounds
+    centroid so that BVHAccel::new keeps them in ONE leaf in declaration order (bvh.rs:218-229); order 0: wall first"""
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    wall = [(-4, -4, 5), (4, -4, 5), (4, 4, 5), (-4, 4, 5)]
+    if order == 0:
+        sb.add_quad(wall, m)
+    sb.begin_object("t")
+    sb.add_mesh(np.array([(-1, -1, 2), (1, -1, 2), (0, 1, 8)], np.float32), [[0, 1, 2]], m)
+    sb.end_object()
+    sb.add_instance("t", scenes.Transform.identity())
+    if order == 1:
+        sb.add_quad(wall, m)
+    sb.add_point_light((0, 0, -3), (20, 20, 20))
+    return sb.finish(builder, max_prims_in_node=4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# -m gpu: librspt against the oracle
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["reference", "fixed"])
+def test_gpu_trace_stage_with_instances(gpu, oracle, mode):
+    sc = small_scene(gpu.bvh_build, mode=mode)
+    rays = random_rays(60000, 21, -4.0, 4.0)
+    rays["o"][:, 1] = np.abs(rays["o"][:, 1]) * 0.8
+    with gpu.DeviceScene(sc) as ds:
+        for any_hit in (False, True):
+            assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_identity_instance_quirk(gpu, oracle):
+    """Q10 on the GPU: both visiting orders, both modes, bit for bit like the oracle (see test_oracle_identity_instance_quirk)"""
+    rng = np.random.default_rng(9)
+    rays = np.zeros(4000, abi.RAY_DT)
+    rays["o"] = np.stack([rng.uniform(-2, 2, 4000), rng.uniform(-2, 2, 4000), np.zeros(4000)], 1).astype(np.float32)
+    rays["d"] = (0, 0, 1); rays["t_max"] = np.inf
+    seen = set()
+    for order in (0, 1):
+        sc = quirk_scene(gpu.bvh_build, order)
+        for mode in ("reference", "fixed"):
+            sc.set_instancing(mode)
+            with gpu.DeviceScene(sc) as ds:
+                got = gpu.trace(ds, rays)
+                assert got.tobytes() == oracle.trace(sc, rays).tobytes()
+                assert gpu.trace(ds, rays, any_hit=True).tobytes() == oracle.trace(sc, rays, any_hit=True).tobytes()
+                film, _ = gpu.render(ds, scenes.make_render_desc(32, 32, 4, ((0, 0, -4), (0, 0, 1), (0, 1, 0)), 50.0))
+            ref = oracle.render(sc, scenes.make_render_desc(32, 32, 4, ((0, 0, -4), (0, 0, 1), (0, 1, 0)), 50.0), threads=2)
+            assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-5
+            seen.add((order, mode, bool((got["prim"] == abi.MISS).any()), bool((got["prim"] == 3).any())))
+    assert (1, "reference", True, False) in seen and (0, "reference", False, True) in seen   # the quirk shows both faces
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tex", [("reference", False), ("fixed", False), ("fixed", True)])
+def test_gpu_render_with_instances_matches_oracle(gpu, oracle, mode, tex):
+    sc = small_scene(gpu.bvh_build, mode=mode, tex=tex)
+    rd = rd_small(spp=16)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+        li, _ = gpu.render_samples(ds, rd)
+    ref = oracle.render(sc, rd, threads=8, want_li=True)
+    assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == 0
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 1e-5
+    assert (li == ref["li"]).all(-1).mean() > 0.75   # most camera samples bit-identical (sinf / cosf ulps account for the rest)
+
+
+@pytest.mark.gpu
+def test_gpu_ao_and_counters_with_instances(gpu, oracle):
+    import os
+    sc = small_scene(gpu.bvh_build, mode="fixed")
+    rd = rd_small(spp=4, integrator="ao", ao_samples=16)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+        ref = oracle.render(sc, rd, threads=8)
+        assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-5
+        os.environ["RSPT_COUNTERS"] = "1"
+        try:
+            rdp = rd_small(spp=4)
+            _, stc = gpu.render(ds, rdp)
+        finally:
+            os.environ["RSPT_COUNTERS"] = "0"
+        refp = oracle.render(sc, rdp, threads=8)["counters"]
+        # node / primitive-test counters of both levels agree with the oracle's up to the few samples that take another branch
+        for k in ("nodes_visited", "tris_tested", "rays_closest", "rays_any"):
+            assert abs(stc[k] - refp[k]) <= 0.01 * refp[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["reference", "fixed"])
+def test_gpu_landscape_standin_crop_matches_oracle(gpu, oracle, mode):
+    """C5 stand-in at reduced instance count / tree resolution (the full 4096 x 10 k scene is bench.py --workload c5)"""
+    sc = scenes.landscape_standin(gpu.bvh_build_gpu, n_side=12, terrain=48, instancing=mode, tree_grid=(24, 12))
+    assert len(sc.instances) == 144
+    rd = scenes.landscape_render_desc(xres=480, yres=270, spp=16, crop=(0.35, 0.6, 0.4, 0.7))
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+        rays = random_rays(30000, 5, -30.0, 30.0)
+        rays["o"][:, 1] = np.abs(rays["o"][:, 1]) * 0.3 + 1.0
+        for any_hit in (False, True):
+            assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
+    ref = oracle.render(sc, rd, threads=8)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 1e-4   # 16 spp under a sun texel: one flipped sample moves a pixel by O(1)
