@@ -346,6 +346,9 @@ typedef struct {
     double t_trace_closest_s, t_trace_any_s;
     double t_shade_s;       /* k_shade (+ k_texture) launches                         */
     uint64_t launches_closest, launches_any;
+    uint64_t truncated_paths; /* paths cut off after RSPT_NULL_PASSES (default 1024) passes through surfaces without a BSDF (null materials;
+                                 instanced hits in RSPT_INSTANCING_REFERENCE): rs_pbrt's loop has no such limit (path.rs:109-116) and
+                                 would still be running; they keep the radiance gathered up to that point */
 } rspt_stats;
 
 /* version of this header the library was built against */

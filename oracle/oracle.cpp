@@ -195,6 +195,21 @@ void orc_trace(const rspt_scene_desc* sd, const rspt_ray* rays, uint64_t n, rspt
     if (counters_out) { counters_out[0] = c.nodes_visited; counters_out[1] = c.tris_tested; }
 }
 
+// debugging aid: follow a ray through surfaces without a BSDF the way PathIntegrator::li does (path.rs:109-116: ray = isect.spawn_ray(&ray.d))
+// for at most n steps; out[i] = (prim, t, origin xyz of the step's ray); returns the number of hits
+int orc_null_walk(const rspt_scene_desc* sd, const rspt_ray* r0, int n, rspt_hit* out) {
+    Scene sc{*sd};
+    Ray r{V3{r0->o[0], r0->o[1], r0->o[2]}, V3{r0->d[0], r0->d[1], r0->d[2]}, r0->t_max, 0.0f};
+    int k = 0;
+    for (; k < n; k++) {
+        Interaction isect; Float t = 0, b[3] = {0, 0, 0};
+        if (!sc.intersect(r, &isect, nullptr, &t, b)) break;
+        out[k].prim = (uint32_t)isect.geo_prim; out[k].t = t; out[k].b0 = r.o.x; out[k].b1 = r.o.y; out[k].b2 = r.o.z;
+        r = isect.spawn_ray(r.d);
+    }
+    return k;
+}
+
 // ---- the whole path: SamplerIntegrator::render ----
 // counters_out[8]: nodes_visited, tris_tested, rays_closest, rays_any, bounces, samples, nan_samples, mis_rays
 int orc_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb,

@@ -120,7 +120,7 @@ class Stats(C.Structure):
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("nan_samples", C.c_uint64),
                 ("trace_launches", C.c_uint64), ("alg_bytes", C.c_double),
                 ("t_trace_closest_s", C.c_double), ("t_trace_any_s", C.c_double), ("t_shade_s", C.c_double),
-                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64)]
+                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64), ("truncated_paths", C.c_uint64)]
 
 
 # numpy dtypes with the same layout (for bulk construction)

@@ -605,10 +605,88 @@ __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, Rend
     }
 }
 
+// ---- K7b: bin the active queue by what the shade stage will do with each path -------------------------------------------
+// The queue leaves k_shade in path-slot order; after the trace stage a wave's 64 paths have hit different things: nothing (an
+// escaped path costs a handful of instructions), the depth limit, surfaces of different materials (different lobe lists).  A
+// wave pays for the longest of them.  Three small kernels sort the queue into RSPT_BIN_K classes, each class padded to whole
+// waves, so that k_shade's waves are (nearly) uniform.  The order inside a class keeps the queue's.
+#define RSPT_BIN_K 16
+#define RSPT_BIN_INVALID 0xffffffffu
+struct BinInfo {  // one per wavefront iteration, zeroed with the queue counters
+    uint32_t count[RSPT_BIN_K], cursor[RSPT_BIN_K], start[RSPT_BIN_K];
+    uint32_t total;  // padded length of the sorted queue
+    uint32_t pad[15];
+};
+RDEV uint32_t bin_key(const SceneDev& sc, const PathBuf& pb, uint32_t max_depth, uint32_t p) {
+    const uint32_t st = pb.state[p];
+    const uint32_t prim = __float_as_uint(pb.hit_cont[p].x);
+    if (!(st & ST_ALIVE) || prim == RSPT_MISS) return 0u;
+    if (((st >> ST_BOUNCE_SHIFT) & 0xffu) >= max_depth) return 1u;
+    const uint32_t mat = __float_as_uint(sc.tris[3 * (size_t)prim + 2].y);
+    return mat == 0xffffffffu ? 1u : 2u + mat % (RSPT_BIN_K - 2u);
+}
+__global__ __launch_bounds__(256) void k_bin_count(SceneDev sc, PathBuf pb, uint32_t max_depth, const uint32_t* __restrict__ q_active,
+                                                   const QueueCounts* __restrict__ cnt_in, uint8_t* __restrict__ keys, BinInfo* bi) {
+    __shared__ uint32_t hist[RSPT_BIN_K];
+    if (threadIdx.x < RSPT_BIN_K) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t n = cnt_in->active;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t k = bin_key(sc, pb, max_depth, q_active[i]);
+        keys[i] = (uint8_t)k;
+        atomicAdd(&hist[k], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < RSPT_BIN_K && hist[threadIdx.x]) atomicAdd(&bi->count[threadIdx.x], hist[threadIdx.x]);
+}
+__global__ void k_bin_starts(BinInfo* bi, uint32_t* __restrict__ q_sorted) {  // one 64-thread block
+    __shared__ uint32_t start[RSPT_BIN_K];
+    if (threadIdx.x == 0) {
+        uint32_t at = 0;
+        for (int k = 0; k < RSPT_BIN_K; k++) { start[k] = at; bi->start[k] = at; at += (bi->count[k] + 63u) & ~63u; }
+        bi->total = at;
+    }
+    __syncthreads();
+    for (int k = 0; k < RSPT_BIN_K; k++) {  // the idle lanes that pad every class to whole waves
+        const uint32_t c = bi->count[k], idx = c + threadIdx.x;
+        if (idx < ((c + 63u) & ~63u)) q_sorted[start[k] + idx] = RSPT_BIN_INVALID;
+    }
+}
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt_in, const uint8_t* __restrict__ keys,
+                                                     BinInfo* bi, uint32_t* __restrict__ q_sorted) {
+    __shared__ uint32_t s_cnt[4][RSPT_BIN_K], s_base[RSPT_BIN_K];
+    const uint32_t n = cnt_in->active;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t k = i < n ? keys[i] : RSPT_BIN_K;
+        uint32_t rank = 0;
+#pragma unroll 1
+        for (uint32_t c = 0; c < RSPT_BIN_K; c++) {  // wave-level rank of this lane inside its class
+            const uint64_t m = __ballot(k == c);
+            if (k == c) rank = (uint32_t)__popcll(m & lt);
+            if (lane == 0) s_cnt[wave][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (threadIdx.x < RSPT_BIN_K) {
+            const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+            s_base[threadIdx.x] = tot ? atomicAdd(&bi->cursor[threadIdx.x], tot) : 0u;
+        }
+        __syncthreads();
+        if (k < RSPT_BIN_K) {
+            uint32_t off = bi->start[k] + s_base[k] + rank;
+            for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][k];
+            q_sorted[off] = q_active[i];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
                                                const QueueCounts* __restrict__ cnt_in, QueueCounts* cnt_out, uint32_t* __restrict__ q_active_next,
                                                uint32_t* __restrict__ q_closest_next, uint32_t* __restrict__ q_any_next, unsigned long long* stats,
-                                               uint32_t sob_nd, uint32_t sob_bits, uint32_t qcap) {
+                                               uint32_t sob_nd, uint32_t sob_bits, uint32_t qcap, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi) {
     // Sobol' generator matrices of the dimensions this render can reach, transposed to [bit][dim]
     extern __shared__ uint32_t sob_tab[];
     __shared__ uint32_t s_wave[4][5], s_base[4];
@@ -620,15 +698,16 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, Ren
     // the active queue has two ends: paths with a continuation ray in flight from the front, paths that only have a
     // pending next-event estimate left from the back (they take a fraction of the instructions), so a wave is either
     // all-alive or all-short; measured effect on C3 is small (+0.5 %) because most paths end in the same last iterations
-    const uint32_t n_front = cnt_in->active, n = n_front + cnt_in->active_tail;
+    // q_sorted (K7b): the front part binned by class and padded to whole waves (RSPT_BIN_INVALID = idle lane)
+    const uint32_t n_front = q_sorted ? bi->total : cnt_in->active, n = n_front + cnt_in->active_tail;
     const uint32_t stride = gridDim.x * 256u;
     for (uint32_t base = virtual_block() * 256u; base < n; base += stride) {
         uint32_t i = base + threadIdx.x;
         ShadeOut o{false, false, false, false};
         uint32_t p = 0;
         if (i < n) {
-            p = i < n_front ? q_active[i] : q_active[qcap - 1u - (i - n_front)];
-            o = shade_path(sc, ld, rd, pb, p, stats, sob_tab, sob_nd);
+            p = i < n_front ? (q_sorted ? q_sorted[i] : q_active[i]) : q_active[qcap - 1u - (i - n_front)];
+            if (p != RSPT_BIN_INVALID) o = shade_path(sc, ld, rd, pb, p, stats, sob_tab, sob_nd);
         }
         // queue appends, aggregated per workgroup: a single counter word sustains only ~90 M atomics/s
         // (MI355X_MICROARCH "dequeue" row), so one atomic per queue per 256 paths instead of per wave.

@@ -59,6 +59,11 @@ struct Ctx {
     size_t ovf_cap = 0;
     uint2* spill = nullptr;            // k_trace_w4's stack rows beyond its LDS column (trace_w4.h)
     size_t spill_threads = 0;
+    uint8_t* bin_keys = nullptr;       // K7b: class of every active-queue entry, the queue sorted by class, per-iteration bin bookkeeping
+    uint32_t* q_sorted = nullptr;
+    size_t bin_cap = 0;
+    BinInfo* bin_info = nullptr;
+    uint32_t n_bin_info = 0;
     uint32_t* hit_inst = nullptr;      // per path slot: instance of the continuation ray's hit (scenes with object instances)
     size_t hit_inst_cap = 0;
     unsigned long long* totals = nullptr;  // [0] nodes [1] tris [2] bsdf hits [3] rays closest [4] rays any [5] nan samples
@@ -145,6 +150,7 @@ struct rspt_scene_s {
     bool has_textures = false;
     std::vector<void*> allocs;
     bool has_null_material = false;
+    uint32_t n_materials = 0;
     bool has_instances = false;       // object instances: two-level traversal (kernels.h traverse<ANY, true>)
     std::map<int, LightDist> light_dists;  // by effective strategy
 };
@@ -214,6 +220,24 @@ int ensure_tex_rows() {
     int rc = dev_alloc(&g.pb.tex, g.cap * RSPT_TEX_ROWS);
     if (rc) return rc;
     g.pb.tex_stride = (uint32_t)g.cap;
+    return RSPT_OK;
+}
+
+int ensure_bins(size_t cap, uint32_t n_iters) {
+    int rc;
+    if (g.bin_cap < cap) {
+        if (g.bin_keys) (void)hipFree(g.bin_keys);
+        if (g.q_sorted) (void)hipFree(g.q_sorted);
+        g.bin_keys = nullptr; g.q_sorted = nullptr; g.bin_cap = 0;
+        if ((rc = dev_alloc(&g.bin_keys, cap)) || (rc = dev_alloc(&g.q_sorted, cap + 64 * RSPT_BIN_K))) return rc;
+        g.bin_cap = cap;
+    }
+    if (g.n_bin_info < n_iters) {
+        if (g.bin_info) (void)hipFree(g.bin_info);
+        g.bin_info = nullptr; g.n_bin_info = 0;
+        if ((rc = dev_alloc(&g.bin_info, n_iters))) return rc;
+        g.n_bin_info = n_iters;
+    }
     return RSPT_OK;
 }
 
@@ -338,6 +362,8 @@ int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
     return RSPT_OK;
 }
 
+bool trace_can_overflow(const rspt_scene_s* s);
+
 // kernel choice: the persistent-wave kernel (trace_wide.h) unless RSPT_TRACE_KERNEL=0 or the
 // reference-order node / triangle counters are wanted (only k_trace counts them)
 // lane 0 = the library's main stream; lane 1 = the second stream with its own overflow list and spill rows
@@ -372,8 +398,7 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
         // with every spill row in use the four-box kernel cannot overflow (RSPT_W4_MAX_STACK): no second pass to launch
-        const bool can_overflow = !(which >= 2 && s->w4_ok) || RSPT_W4_LDS + spill_rows < RSPT_W4_MAX_STACK;
-        if (can_overflow) hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits);
+        if (trace_can_overflow(s)) hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits);
         return;
     }
     if (count)
@@ -382,6 +407,12 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
         hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, (uint32_t*)nullptr);
 }
 
+// does the production trace kernel ever hand rays to k_trace_fixup?  Not the four-box kernel with all its spill rows (RSPT_W4_MAX_STACK)
+bool trace_can_overflow(const rspt_scene_s* s) {
+    const size_t which = env_size("RSPT_TRACE_KERNEL", 2);
+    const size_t rows = std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
+    return !(which >= 2 && s->w4_ok) || RSPT_W4_LDS + rows < RSPT_W4_MAX_STACK;
+}
 uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PER_CU", 5)); }
 
 int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
@@ -530,28 +561,42 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
 
     // ---- batches ----
-    // paths per wavefront batch: ~350 B of state each, so 2^25 paths = 11 GB of the 288 GB HBM.
-    // Large batches keep the persistent trace kernel's queues long (measured on C2: 2^22 -> 102,
-    // 2^25 -> 195 Msamples/s).
-    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 25);
-    cap = std::max<size_t>(cap, 1024);
+    // paths per wavefront batch: ~280 B of state each, so 2^28 paths = 75 GB of the 288 GB HBM.  Large batches keep the persistent
+    // trace kernel's queues long and its launches few (every launch ends in a tail of a few long rays): measured with these
+    // kernels, 2^25 / 2^26 / 2^27 / 2^28 paths per batch = 367 / 386 / 398 / 405 Msamples/s on C2 and 1243 / 1400 / 1472 / 1525 on
+    // the C3 stand-in.  When the device cannot give that much (other tenants), the batch is halved until it fits.
+    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 28);
+    cap = std::min<size_t>(std::max<size_t>(cap, 1024), (size_t)1 << 30);
     const bool counters = env_size("RSPT_COUNTERS", 0) != 0;
     // AOIntegrator: every camera sample carries ao_n_samples shadow rays through the same ray / occlusion arrays
     const bool ao = d->integrator == RSPT_INTEGRATOR_AO;
     const uint32_t ao_n = ao ? d->ao_n_samples : 1u;
     if (ao) cap = std::max<size_t>(cap / ao_n, 1024);
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
-    while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
-    const size_t pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
-    if ((rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n))) return rc;
+    size_t pix_per_batch = 1;
+    for (;;) {
+        ns = 1;
+        while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
+        pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
+        rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n);
+        if (rc == RSPT_OK) break;
+        (void)hipGetLastError();  // out of memory: clear the sticky error and try half the batch
+        free_paths();
+        if (cap <= ((size_t)1 << 20)) return rc;
+        cap /= 2;
+    }
     const uint32_t nominal_iters = d->max_depth + 1;
     // a pass through a null-material surface costs a wavefront iteration without counting as a bounce (path.rs:109-116 has no limit
     // on them); the loop below runs until no path is left, and a scene that needs more than RSPT_NULL_PASSES extra iterations is
     // reported, not silently truncated
-    const uint32_t max_iters = s->has_null_material ? nominal_iters + (uint32_t)env_size("RSPT_NULL_PASSES", 4096) : nominal_iters;
+    const uint32_t max_iters = s->has_null_material ? nominal_iters + (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : nominal_iters;
+    // K7b pays when a wave's paths would otherwise run different lobe lists (C3 stand-in, two materials: +4.8 %); with one material
+    // its three small kernels and the less regular slot order cost more than the escaped paths they separate (C2: -3.6 %)
+    const bool shade_bins = env_size("RSPT_SHADE_BINS", s->n_materials > 1 ? 1 : 0) != 0 && !ao;
+    if (shade_bins && (rc = ensure_bins(g.cap, max_iters + 10))) return rc;
     if (s->has_instances && (rc = ensure_hit_inst(g.cap))) return rc;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
-    if ((rc = ensure_counts(max_iters + 2)) || (rc = ensure_overflow_list(3 * g.cap)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
+    if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
         (s->has_textures && (rc = ensure_tex_rows()))) return rc;
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
@@ -580,7 +625,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     };
     auto ev_close = [&](int kind, int lane) { (void)hipEventRecord(kev[kind].back().second, lane ? g.stream2 : g.stream); };
     HIP_TRY(hipEventRecord(ev_k0, g.stream));
-    uint64_t samples = 0;
+    uint64_t samples = 0, truncated = 0;
     for (size_t p0 = 0; p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
         for (uint32_t s0 = 0; s0 < (uint32_t)d->spp; s0 += ns) {
@@ -588,6 +633,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             Batch bt{(uint32_t)p0, npx, s0, ns_b, npx * ns_b};
             samples += bt.n;
             HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));
+            if (shade_bins) HIP_TRY(hipMemsetAsync(g.bin_info, 0, (size_t)std::min<uint32_t>(g.n_bin_info, max_iters + 10) * sizeof(BinInfo), g.stream));
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
             if (ao) {  // AOIntegrator::li: closest hit, n shadow rays per hit, sum of the unoccluded terms
@@ -636,19 +682,45 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 trace_ev.push_back({e0, e1});
                 trace_launches += it > 0 ? 2 : 1;
                 ev_open(2, 0);
+                if (shade_bins) {  // K7b: whole waves of one class for k_shade
+                    const uint32_t bgrid = grid_for(4);
+                    hipLaunchKernelGGL(k_bin_count, dim3(bgrid), dim3(256), 0, g.stream, s->dev, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it]);
+                    hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, g.stream, &g.bin_info[it], g.q_sorted);
+                    hipLaunchKernelGGL(k_bin_scatter, dim3(bgrid), dim3(256), 0, g.stream, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it], g.q_sorted);
+                }
                 if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it]);
                 hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
-                                   g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap);
+                                   g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
+                                   shade_bins ? g.q_sorted : (const uint32_t*)nullptr, shade_bins ? &g.bin_info[it] : (const BinInfo*)nullptr);
                 ev_close(2, 0);
                 it++;
                 if (it < nominal_iters) continue;
                 // after max_depth + 1 bounces only pending estimates and null-material passes remain
                 if (max_iters == nominal_iters) break;
+                if (((it - nominal_iters) & 7u) != 0 && it < max_iters) continue;  // look at the queue length every 8th iteration: an empty iteration costs three idle launches, a look costs a stream sync
                 QueueCounts c;
                 HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
                 HIP_TRY(hipStreamSynchronize(g.stream));
                 if (c.active == 0 && c.active_tail == 0) break;
-                if (it >= max_iters) return fail(RSPT_E_UNSUPPORTED, "%u paths still cross null-material surfaces after %u wavefront iterations (RSPT_NULL_PASSES)", c.active + c.active_tail, it);
+                if (it >= max_iters) {  // the reference's loop would still be running (path.rs:109-116 has no limit); these paths keep the radiance gathered so far
+                    truncated += c.active + c.active_tail;
+                    if (getenv("RSPT_VERBOSE") && c.active) {  // where the endless paths are: slot, film position and the ray in flight
+                        uint32_t slots[4];
+                        const uint32_t k = std::min(c.active, 4u);
+                        HIP_TRY(hipMemcpy(slots, g.q[it & 1][0], k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                        for (uint32_t j = 0; j < k; j++) {
+                            rspt_ray r; float2 pf; float4 hc;
+                            HIP_TRY(hipMemcpy(&r, g.pb.ray_cont + slots[j], sizeof r, hipMemcpyDeviceToHost));
+                            HIP_TRY(hipMemcpy(&pf, g.pb.p_film + slots[j], sizeof pf, hipMemcpyDeviceToHost));
+                            HIP_TRY(hipMemcpy(&hc, g.pb.hit_cont + slots[j], sizeof hc, hipMemcpyDeviceToHost));
+                            uint32_t o[3], dd[3], pr;
+                            memcpy(o, r.o, 12); memcpy(dd, r.d, 12); memcpy(&pr, &hc.x, 4);
+                            fprintf(stderr, "rspt: endless null-surface path: slot %u film (%.3f, %.3f) ray o %08x %08x %08x d %08x %08x %08x last prim %u\n",
+                                    slots[j], pf.x, pf.y, o[0], o[1], o[2], dd[0], dd[1], dd[2], pr);
+                        }
+                    }
+                    break;
+                }
             }
             if (counters) hipLaunchKernelGGL(k_accum_counts, dim3(1), dim3(1), 0, g.stream, g.cnt, it, g.totals);
             hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
@@ -689,6 +761,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             }
         stats->t_trace_closest_s = ksum[0] * 1e-3; stats->t_trace_any_s = ksum[1] * 1e-3; stats->t_shade_s = ksum[2] * 1e-3;
         stats->launches_closest = kev[0].size(); stats->launches_any = kev[1].size();
+        stats->truncated_paths = truncated;
         stats->samples = samples;
         stats->trace_launches = trace_launches;
         unsigned long long tot[8];
@@ -829,7 +902,7 @@ void rspt_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
-    void* ptrs[] = {g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
+    void* ptrs[] = {g.bin_keys, g.q_sorted, g.bin_info, g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
@@ -1028,6 +1101,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     rspt_scene_s* s = new rspt_scene_s();
     s->has_null_material = has_null || (instanced && d->instancing_mode == RSPT_INSTANCING_REFERENCE);  // instanced hits pass through like null surfaces (Q11)
     s->has_instances = instanced;
+    s->n_materials = d->n_materials;
     auto bail = [&](int rc) {
         for (void* p : s->allocs) (void)hipFree(p);
         delete s;
