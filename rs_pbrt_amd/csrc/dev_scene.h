@@ -68,7 +68,15 @@ struct LightDistDev {
     const float* func_int;  // [n_vox]
     int32_t nvox[3];
     int32_t spatial;
+    // on-demand voxels (the reference fills its hash table the first time a voxel is looked up, lightdistrib.rs:297-384): table[voxel] =
+    // row of func / cdf / func_int, or < 0 while the voxel has no distribution yet; nullptr = every voxel was built up front, row = voxel
+    int32_t* table;
 };
+RDEV uint32_t light_row(const LightDistDev& ld, uint32_t vox) {
+    if (!ld.table) return vox;
+    const int32_t r = ld.table[vox];
+    return r < 0 ? 0u : (uint32_t)r;  // < 0 only after the row pool ran out: that render fails with RSPT_E_NOMEM, it must not fault
+}
 
 // Everything SamplerIntegrator::render reads per sample (subset of rspt_render_desc)
 struct RenderDev {

@@ -399,7 +399,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 // ---- uniform_sample_one_light (integrator.rs:359-403) ----
                 const uint32_t nonspec = BX_ALL & ~BX_SPEC;
                 if (sc.n_lights > 0 && bsdf.num_components(nonspec) > 0) {
-                    uint32_t vox = light_voxel(sc, ld, h.p);
+                    uint32_t vox = light_row(ld, light_voxel(sc, ld, h.p));
                     float pdf_choice = 0.0f;
                     uint32_t light_num = sample_discrete(ld.func + (size_t)vox * sc.n_lights, ld.cdf + (size_t)vox * (sc.n_lights + 1),
                                                          ld.func_int[vox], sc.n_lights, smp.get_1d(rd), &pdf_choice);
@@ -946,12 +946,7 @@ RDEV float radical_inverse(int base_index, uint64_t a) {  // lowdiscrepancy.rs:1
     return fminf((float)reversed * inv_base_n, RSPT_ONE_MINUS_EPS);
 }
 // SpatialLightDistribution::compute_distribution, per (voxel, light) (lightdistrib.rs:169-260)
-__global__ void k_ld_contrib(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, float* __restrict__ func) {
-    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t total = (uint64_t)nvx * nvy * nvz * sc.n_lights;
-    if (gid >= total) return;
-    uint32_t j = (uint32_t)(gid % sc.n_lights);
-    uint64_t v = gid / sc.n_lights;
+RDEV float ld_voxel_light_contrib(const SceneDev& sc, int32_t nvx, int32_t nvy, int32_t nvz, uint64_t v, uint32_t j) {
     int32_t ix = (int32_t)(v % nvx), iy = (int32_t)((v / nvx) % nvy), iz = (int32_t)(v / ((uint64_t)nvx * nvy));
     f3 wmin{sc.wb_min[0], sc.wb_min[1], sc.wb_min[2]}, wmax{sc.wb_max[0], sc.wb_max[1], sc.wb_max[2]};
     f3 p0{(float)ix / (float)nvx, (float)iy / (float)nvy, (float)iz / (float)nvz};
@@ -970,15 +965,17 @@ __global__ void k_ld_contrib(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz,
         rgb li = light_sample_li(sc, lt, po, u, &wi, &pdf, &ls);
         if (pdf > 0.0f) contrib += lum(li) / pdf;
     }
-    func[gid] = contrib;
+    return contrib;
+}
+__global__ void k_ld_contrib(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, float* __restrict__ func) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = (uint64_t)nvx * nvy * nvz * sc.n_lights;
+    if (gid >= total) return;
+    func[gid] = ld_voxel_light_contrib(sc, nvx, nvy, nvz, gid / sc.n_lights, (uint32_t)(gid % sc.n_lights));
 }
 // one Distribution1D per voxel (sampling.rs:24-49) after the min-contribution clamp (:262-268);
 // mode 0: spatial (func holds raw contributions), 1: use func as is (uniform / power)
-__global__ void k_ld_build(uint32_t n_vox, uint32_t nl, int mode, float* __restrict__ func, float* __restrict__ cdf, float* __restrict__ func_int) {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_vox) return;
-    float* f = func + (size_t)v * nl;
-    float* c = cdf + (size_t)v * (nl + 1);
+RDEV void ld_build_row(uint32_t nl, int mode, float* f, float* c, float* func_int) {
     if (mode == 0) {
         float sum = 0.0f;
         for (uint32_t j = 0; j < nl; j++) sum += f[j];
@@ -991,7 +988,12 @@ __global__ void k_ld_build(uint32_t n_vox, uint32_t nl, int mode, float* __restr
     float fi = c[nl];
     if (fi == 0.0f) for (uint32_t i = 1; i <= nl; i++) c[i] = (float)i / (float)nl;
     else for (uint32_t i = 1; i <= nl; i++) c[i] /= fi;
-    func_int[v] = fi;
+    *func_int = fi;
+}
+__global__ void k_ld_build(uint32_t n_vox, uint32_t nl, int mode, float* __restrict__ func, float* __restrict__ cdf, float* __restrict__ func_int) {
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vox) return;
+    ld_build_row(nl, mode, func + (size_t)v * nl, cdf + (size_t)v * (nl + 1), func_int + v);
 }
 // uniform: func = 1; power: func = Light::power().y() (integrator.rs:573-584, diffuse.rs:85-93)
 __global__ void k_ld_fixed(SceneDev sc, int power, float* __restrict__ func) {
@@ -999,6 +1001,71 @@ __global__ void k_ld_fixed(SceneDev sc, int power, float* __restrict__ func) {
     if (j >= sc.n_lights) return;
     if (!power) { func[j] = 1.0f; return; }
     func[j] = lum(light_power(sc, sc.lights[j]));
+}
+
+// ---- on-demand voxels of the spatial distribution (the eager table is n_vox x n_lights) ---------------------------
+// Before a shade launch: every path about to look a voxel up (a surface hit below the depth limit, with a material) claims the
+// voxel if nobody has; the claimed voxels get their rows built by the kernels above (same arithmetic as the eager build, so the
+// values do not depend on when a voxel is built, Q18) and are published in the table.
+struct LightLazy {
+    uint32_t n_new;      // voxels claimed in this round
+    uint32_t n_rows;     // rows handed out so far
+    uint32_t max_rows;
+    uint32_t overflow;   // a voxel could not get a row: the render fails with RSPT_E_NOMEM
+};
+__global__ __launch_bounds__(256) void k_ld_mark(SceneDev sc, LightDistDev ld, PathBuf pb, uint32_t max_depth, const uint32_t* __restrict__ q_active,
+                                                 const QueueCounts* __restrict__ cnt_in, LightLazy* lz, uint32_t* __restrict__ new_list) {
+    const uint32_t n = cnt_in->active;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t p = q_active[i];
+        const uint32_t st = pb.state[p];
+        const float4 hc = pb.hit_cont[p];
+        const uint32_t prim = __float_as_uint(hc.x);
+        if (!(st & ST_ALIVE) || prim == RSPT_MISS || ((st >> ST_BOUNCE_SHIFT) & 0xffu) >= max_depth) continue;
+        const TriRec t = load_tri(sc, prim);
+        if (t.material == 0xffffffffu) continue;
+        f3 hp = t.p0 * hc.y + t.p1 * hc.z + t.p2 * hc.w;  // the hit point as tri_fill forms it
+        if (pb.hit_inst) {
+            const uint32_t hi = pb.hit_inst[p];
+            if (hi && !sc.inst[hi - 1u].identity) {
+                if (!sc.inst_fixed) continue;
+                f3 pe;
+                inst_point(sc.inst[hi - 1u].m, hp, f3{0.0f, 0.0f, 0.0f}, &hp, &pe);
+            }
+        }
+        const uint32_t vox = light_voxel(sc, ld, hp);
+        if (ld.table[vox] == -1 && atomicCAS(&ld.table[vox], -1, -2) == -1) {
+            const uint32_t k = atomicAdd(&lz->n_new, 1u);
+            if (lz->n_rows + k < lz->max_rows) new_list[k] = vox;
+            else { lz->overflow = 1u; ld.table[vox] = -1; }
+        }
+    }
+}
+// contributions of every light to the claimed voxels: the body of k_ld_contrib with (row, voxel) from the list
+__global__ void k_ld_contrib_list(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, const LightLazy* lz, const uint32_t* __restrict__ new_list, float* __restrict__ func) {
+    const uint64_t n_new = lz->n_new < lz->max_rows - lz->n_rows ? lz->n_new : lz->max_rows - lz->n_rows;
+    const uint64_t total = n_new * sc.n_lights;
+    for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)(gid % sc.n_lights);
+        const uint64_t k = gid / sc.n_lights;
+        const uint64_t v = new_list[k];
+        func[((uint64_t)lz->n_rows + k) * sc.n_lights + j] = ld_voxel_light_contrib(sc, nvx, nvy, nvz, v, j);
+    }
+}
+__global__ void k_ld_build_list(uint32_t nl, const LightLazy* lz, const uint32_t* __restrict__ new_list, float* __restrict__ func, float* __restrict__ cdf,
+                                float* __restrict__ func_int, int32_t* __restrict__ table) {
+    const uint32_t n_new = lz->n_new < lz->max_rows - lz->n_rows ? lz->n_new : lz->max_rows - lz->n_rows;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_new; k += gridDim.x * blockDim.x) {
+        const uint32_t row = lz->n_rows + k;
+        ld_build_row(nl, 0, func + (size_t)row * nl, cdf + (size_t)row * (nl + 1), func_int + row);
+        table[new_list[k]] = (int32_t)row;
+    }
+}
+__global__ void k_ld_commit(LightLazy* lz) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t n_new = lz->n_new < lz->max_rows - lz->n_rows ? lz->n_new : lz->max_rows - lz->n_rows;
+    lz->n_rows += n_new;
+    lz->n_new = 0u;
 }
 
 // scene upload helper: build the 48-byte triangle records from the indexed ABI arrays

@@ -134,6 +134,11 @@ struct LightDist {
     float* func_int = nullptr;
     int32_t nvox[3] = {1, 1, 1};
     int32_t spatial = 0;
+    // on-demand voxels: table (one int32 per voxel), the list of voxels claimed in the current round, the counters
+    int32_t* table = nullptr;
+    uint32_t* new_list = nullptr;
+    LightLazy* lazy = nullptr;
+    uint32_t max_rows = 0;
 };
 
 }  // namespace
@@ -314,7 +319,7 @@ int round_up_pow2_32(int32_t v) {  // pbrt.rs:188-198
 }
 
 // Light distribution for (scene, strategy): create_light_sample_distribution (lightdistrib.rs:393-418)
-int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
+int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out, const LightDist** lazy_out = nullptr) {
     const uint32_t nl = s->dev.n_lights;
     *out = LightDistDev{};
     out->nvox[0] = out->nvox[1] = out->nvox[2] = 1;
@@ -324,6 +329,8 @@ int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
     if (it == s->light_dists.end()) {
         LightDist d;
         uint64_t n_vox = 1;
+        uint64_t n_rows = 1;
+        bool lazy = false;
         if (eff == RSPT_LIGHTS_SPATIAL) {  // SpatialLightDistribution::new (lightdistrib.rs:127-166)
             float diag[3] = {s->dev.wb_max[0] - s->dev.wb_min[0], s->dev.wb_max[1] - s->dev.wb_min[1], s->dev.wb_max[2] - s->dev.wb_min[2]};
             int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);  // maximum_extent
@@ -335,15 +342,26 @@ int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
             }
             n_vox = (uint64_t)d.nvox[0] * d.nvox[1] * d.nvox[2];
             d.spatial = 1;
-            const uint64_t limit = env_size("RSPT_MAX_LIGHT_TABLE", (size_t)1 << 31);
-            if (n_vox * (nl + 1) > limit)
-                return fail(RSPT_E_UNSUPPORTED, "spatial light distribution of %llu voxels x %u lights exceeds RSPT_MAX_LIGHT_TABLE",
-                            (unsigned long long)n_vox, nl);
+            // Every emissive triangle is a light, so the full table is n_vox x n_lights (64^3 voxels x 10^4 lights = 21 GB and 3 x 10^11
+            // light samples before the first pixel).  The reference fills a voxel the first time a path looks it up
+            // (lightdistrib.rs:297-384); above RSPT_LIGHT_TABLE_EAGER_BYTES the same is done here, with rows handed out from a pool.
+            const uint64_t row_bytes = (2ull * nl + 2ull) * sizeof(float);
+            lazy = n_vox * row_bytes > env_size("RSPT_LIGHT_TABLE_EAGER_BYTES", (size_t)1 << 30);
+            n_rows = n_vox;
+            if (lazy) n_rows = std::max<uint64_t>(1, std::min<uint64_t>(n_vox, env_size("RSPT_LIGHT_TABLE_POOL_BYTES", (size_t)16 << 30) / row_bytes));
+            if (n_rows > 0x7fffffffull || n_vox > 0x7fffffffull) return fail(RSPT_E_UNSUPPORTED, "spatial light distribution: %llu voxels", (unsigned long long)n_vox);
         }
         int rc;
-        if ((rc = dev_alloc(&d.func, n_vox * nl)) || (rc = dev_alloc(&d.cdf, n_vox * (nl + 1))) || (rc = dev_alloc(&d.func_int, n_vox))) return rc;
-        s->allocs.push_back(d.func); s->allocs.push_back(d.cdf); s->allocs.push_back(d.func_int);
-        if (eff == RSPT_LIGHTS_SPATIAL) {
+        // every allocation is owned by the scene as soon as it exists (a later failure must not leak the earlier ones)
+        auto owned = [&](auto** p, size_t n) { int r = dev_alloc(p, n); if (!r && *p) s->allocs.push_back(*p); return r; };
+        if ((rc = owned(&d.func, n_rows * nl)) || (rc = owned(&d.cdf, n_rows * (nl + 1))) || (rc = owned(&d.func_int, n_rows))) return rc;
+        if (lazy) {
+            if ((rc = owned(&d.table, n_vox)) || (rc = owned(&d.new_list, n_rows)) || (rc = owned(&d.lazy, 1))) return rc;
+            d.max_rows = (uint32_t)n_rows;
+            HIP_TRY(hipMemsetAsync(d.table, 0xff, n_vox * sizeof(int32_t), g.stream));  // -1: no distribution yet
+            LightLazy lz{0u, 0u, d.max_rows, 0u};
+            HIP_TRY(hipMemcpyAsync(d.lazy, &lz, sizeof lz, hipMemcpyHostToDevice, g.stream));
+        } else if (eff == RSPT_LIGHTS_SPATIAL) {
             uint64_t total = n_vox * nl;
             hipLaunchKernelGGL(k_ld_contrib, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, g.stream, s->dev, d.nvox[0], d.nvox[1], d.nvox[2], d.func);
             hipLaunchKernelGGL(k_ld_build, dim3((uint32_t)((n_vox + 255) / 256)), dim3(256), 0, g.stream, (uint32_t)n_vox, nl, 0, d.func, d.cdf, d.func_int);
@@ -359,6 +377,8 @@ int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out) {
     out->func = d.func; out->cdf = d.cdf; out->func_int = d.func_int;
     out->nvox[0] = d.nvox[0]; out->nvox[1] = d.nvox[1]; out->nvox[2] = d.nvox[2];
     out->spatial = d.spatial;
+    out->table = d.table;
+    if (lazy_out) *lazy_out = d.table ? &d : nullptr;
     return RSPT_OK;
 }
 
@@ -516,7 +536,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
 
     LightDistDev ld;
-    if ((rc = get_light_dist(s, d->light_strategy, &ld))) return rc;
+    const LightDist* ld_lazy = nullptr;  // on-demand voxels: a mark / build round in front of every shade launch
+    if ((rc = get_light_dist(s, d->light_strategy, &ld, &ld_lazy))) return rc;
 
     // ---- this shard's pixels: Morton-ordered tiles (blockqueue/mod.rs:23-52), row-major inside a tile ----
     const int32_t ts = (int32_t)d->tile_size;
@@ -688,6 +709,13 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, g.stream, &g.bin_info[it], g.q_sorted);
                     hipLaunchKernelGGL(k_bin_scatter, dim3(bgrid), dim3(256), 0, g.stream, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it], g.q_sorted);
                 }
+                if (ld_lazy && d->integrator == RSPT_INTEGRATOR_PATH) {
+                    const uint32_t lgrid = grid_for(4);
+                    hipLaunchKernelGGL(k_ld_mark, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], ld_lazy->lazy, ld_lazy->new_list);
+                    hipLaunchKernelGGL(k_ld_contrib_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld.nvox[0], ld.nvox[1], ld.nvox[2], ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func);
+                    hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
+                    hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
+                }
                 if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it]);
                 hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                    g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
@@ -740,6 +768,15 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (li_host) HIP_TRY(hipMemcpyAsync(li_host, li_dev, film_px * (size_t)d->spp * 3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
     hipError_t se = hipStreamSynchronize(g.stream);
     if (se != hipSuccess) return fail(RSPT_E_HIP, "render failed: %s", hipGetErrorString(se));
+    if (ld_lazy) {
+        LightLazy lz;
+        HIP_TRY(hipMemcpy(&lz, ld_lazy->lazy, sizeof lz, hipMemcpyDeviceToHost));
+        if (lz.overflow) {
+            LightLazy reset{0u, lz.n_rows, lz.max_rows, 0u};
+            (void)hipMemcpy(ld_lazy->lazy, &reset, sizeof reset, hipMemcpyHostToDevice);
+            return fail(RSPT_E_NOMEM, "spatial light distribution: more than %u voxels were touched; raise RSPT_LIGHT_TABLE_POOL_BYTES", lz.max_rows);
+        }
+    }
     auto t_end = std::chrono::steady_clock::now();
     if (stats) {
         memset(stats, 0, sizeof *stats);

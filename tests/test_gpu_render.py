@@ -13,9 +13,10 @@ import numpy as np
 import pytest
 
 from rs_pbrt_amd import abi, scenes
-from tests.util import film_rmse, small_soup
+from tests.util import GALLERY_LOOK_AT, film_rmse, gallery, small_soup
 
 pytestmark = pytest.mark.gpu
+THREADS_ALL = __import__("os").cpu_count() or 8
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -482,3 +483,55 @@ def test_film_reduce_runs_inside_the_library(gpu):
                 gpu.render(ds, rd)
         finally:
             gpu.comm_destroy()
+
+
+def test_spatial_light_distribution_on_demand_voxels(gpu, oracle):
+    """the spatial distribution is built voxel by voxel as paths look voxels up (what the reference's lazily filled hash
+    table does, lightdistrib.rs:297-384) once the full table would be large; a voxel's distribution is a pure function of
+    (voxel, lights) (Q18), so the film must equal the eager build's bit for bit.  A pool that is too small fails loudly."""
+    import os
+    from rs_pbrt_amd.lib import RsptError
+    sc = gallery(gpu.bvh_build)
+    rd = scenes.make_render_desc(64, 48, 8, GALLERY_LOOK_AT, 60.0, max_depth=5)
+    with gpu.DeviceScene(sc) as ds:
+        eager, _ = gpu.render(ds, rd)
+    try:
+        os.environ["RSPT_LIGHT_TABLE_EAGER_BYTES"] = "0"
+        with gpu.DeviceScene(sc) as ds:
+            lazy, st = gpu.render(ds, rd)
+            again, _ = gpu.render(ds, rd)    # second render: every voxel it needs is already there
+        assert np.array_equal(eager, lazy) and np.array_equal(lazy, again)
+        ref = oracle.render(sc, rd, threads=8)
+        assert np.array_equal(lazy[:, 3], ref["film"][:, 3]) and film_rmse(lazy, ref["film"]) < 1e-5
+        os.environ["RSPT_LIGHT_TABLE_POOL_BYTES"] = "64"   # room for a single row
+        with gpu.DeviceScene(sc) as ds:
+            with pytest.raises(RsptError) as e:
+                gpu.render(ds, rd)
+            assert e.value.code == abi.E_NOMEM
+    finally:
+        os.environ.pop("RSPT_LIGHT_TABLE_EAGER_BYTES", None); os.environ.pop("RSPT_LIGHT_TABLE_POOL_BYTES", None)
+
+
+def test_scene_with_ten_thousand_emissive_triangles_renders(gpu, oracle):
+    """the case the eager table refused in round 1 (64^3 voxels x 10 082 lights): an emissive 71 x 71 grid (10 082 light triangles)
+    over a room; only the voxels paths actually reach are built"""
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.6, 0.6, 0.6)))
+    sb.add_quad([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], grey)
+    sb.add_quad([(-5, 0, 5), (-5, 6, 5), (5, 6, 5), (5, 0, 5)], grey)
+    sb.add_quad([(-1, 0.0, 1), (1, 0.0, 1), (1, 2.0, 2), (-1, 2.0, 2)], sb.add_material(scenes.plastic((0.5, 0.3, 0.2), (0.3, 0.3, 0.3), 0.1)))
+    k = 71
+    g = np.linspace(-2, 2, k + 1, dtype=np.float32)
+    X, Z = np.meshgrid(g, g, indexing="xy")
+    P = np.stack([X, np.full_like(X, 5.9), Z], -1).reshape(-1, 3)
+    i, j = np.meshgrid(np.arange(k), np.arange(k), indexing="ij")
+    a = (i * (k + 1) + j).reshape(-1); b = a + 1; c = a + (k + 1); e = c + 1
+    sb.add_mesh(P, np.concatenate([np.stack([a, b, c], 1), np.stack([b, e, c], 1)]), grey, emit=(6, 6, 6))
+    sc = sb.finish(gpu.bvh_build)
+    assert sc.desc.n_lights == 2 * k * k
+    rd = scenes.make_render_desc(32, 24, 4, GALLERY_LOOK_AT, 60.0, max_depth=3)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    assert st["nan_samples"] == 0 and np.isfinite(film).all() and film[:, 1].mean() > 0.05
+    ref = oracle.render(sc, rd, threads=THREADS_ALL)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-4
