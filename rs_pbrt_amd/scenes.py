@@ -239,7 +239,23 @@ def _with_bump(m, bump):
     return m
 
 
+def _pbrt_rgb(name, v):
+    v = np.broadcast_to(np.asarray(v, F32), (3,))
+    return '"rgb %s" [%.9g %.9g %.9g]' % (name, v[0], v[1], v[2])
+
+
+def _pbrt(m, text, *params):
+    """the `Material` directive that makes rs_pbrt build this recipe (tools/export_pbrt.py); None when a parameter is a texture"""
+    m["pbrt"] = None if any(isinstance(p, TexRef) for p in params) else text
+    return m
+
+
 def matte(kd, sigma=0.0, bump=None):  # matte.rs:43-86
+    return _pbrt(_matte(kd, sigma, bump), None if isinstance(kd, TexRef) or bump is not None else
+                 'Material "matte" %s "float sigma" [%.9g]' % (_pbrt_rgb("Kd", kd), float(sigma)), kd)
+
+
+def _matte(kd, sigma=0.0, bump=None):
     kd, tk, any_kd = _col(kd)
     if not any_kd:
         return _with_bump(dict(eta=1.0, lobes=[]), bump)
@@ -253,6 +269,12 @@ def matte(kd, sigma=0.0, bump=None):  # matte.rs:43-86
 
 
 def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True, bump=None):  # plastic.rs:57-125
+    tex = any(isinstance(x, TexRef) for x in (kd, ks, roughness)) or bump is not None
+    return _pbrt(_plastic(kd, ks, roughness, remap, bump), None if tex else 'Material "plastic" %s %s "float roughness" [%.9g] "bool remaproughness" ["%s"]'
+                 % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), float(roughness), "true" if remap else "false"))
+
+
+def _plastic(kd, ks, roughness, remap, bump):
     lobes = []
     kd, tkd, any_kd = _col(kd); ks, tks, any_ks = _col(ks)
     if any_kd:
@@ -264,7 +286,7 @@ def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True, bump=None
 
 
 def mirror(kr=(0.9,) * 3):  # mirror.rs:34-70 (pushed even if black)
-    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_NOOP, r=np.maximum(np.array(kr, F32), 0))])
+    return dict(pbrt='Material "mirror" %s' % _pbrt_rgb("Kr", kr), eta=1.0, lobes=[_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_NOOP, r=np.maximum(np.array(kr, F32), 0))])
 
 
 def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, multiple_lobes=True):  # glass.rs:83-211, smooth surface
@@ -272,7 +294,7 @@ def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, multiple_lobes=True):  # glas
     `directlighting` / `whitted` (SpecularReflection with a dielectric Fresnel + SpecularTransmission, glass.rs:136-188)"""
     r, t = np.maximum(np.array(kr, F32), 0), np.maximum(np.array(kt, F32), 0)
     if multiple_lobes:
-        return dict(eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=r, t=t, eta_a=1.0, eta_b=index)])
+        return dict(pbrt='Material "glass" %s %s "float index" [%.9g]' % (_pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), float(index)), eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=r, t=t, eta_a=1.0, eta_b=index)])
     lobes = []
     if r.any():
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=r, eta_a=1.0, eta_b=index))
@@ -282,7 +304,8 @@ def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, multiple_lobes=True):  # glas
 
 
 def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True):  # metal.rs:144-205
-    return dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_CONDUCTOR, r=(1, 1, 1), c1=eta, c2=k,
+    return dict(pbrt=None if isinstance(roughness, TexRef) else 'Material "metal" %s %s "float roughness" [%.9g] "bool remaproughness" ["%s"]'
+                % (_pbrt_rgb("eta", eta), _pbrt_rgb("k", k), float(roughness), "true" if remap else "false"), eta=1.0, lobes=[_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_CONDUCTOR, r=(1, 1, 1), c1=eta, c2=k,
                                       **_rough(roughness, roughness, remap))])
 
 
@@ -793,7 +816,7 @@ class SceneBuilder:
                      materials=mats, bxdfs=bxdfs, lights=lights, envmaps=self.envmaps,
                      textures=np.array(self.textures, abi.TEXTURE_DT) if self.textures else None, images=self.images,
                      objects=objects, instances=instances, n_top=(n_top_nodes, n_top_prims),
-                     instancing={"reference": abi.INSTANCING_REFERENCE, "fixed": abi.INSTANCING_FIXED}[instancing])
+                     instancing={"reference": abi.INSTANCING_REFERENCE, "fixed": abi.INSTANCING_FIXED}[instancing], builder=self)
 
 
 def _transform_bounds(m, lo, hi):
@@ -812,7 +835,8 @@ class Scene:
     """Flattened scene arrays + the ctypes rspt_scene_desc pointing at them."""
 
     def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=(), textures=None, images=(),
-                 objects=None, instances=None, n_top=None, instancing=abi.INSTANCING_REFERENCE):
+                 objects=None, instances=None, n_top=None, instancing=abi.INSTANCING_REFERENCE, builder=None):
+        self.builder = builder  # declaration-order view of the scene (tools/export_pbrt.py)
         self.nodes, self.prims, self.meshes, self.P, self.N, self.UV, self.S = nodes, prims, meshes, P, N, UV, S
         self.objects = objects if objects is not None else np.zeros(0, abi.OBJECT_DT)
         self.instances = instances if instances is not None else np.zeros(0, abi.INSTANCE_DT)

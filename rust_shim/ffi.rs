@@ -1,0 +1,85 @@
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 11) one to one.
+//! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
+//! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
+#![allow(dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const RSPT_ABI_VERSION: c_int = 11;
+pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
+pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptBvhNode { pub bmin: [f32; 3], pub bmax: [f32; 3], pub offset: i32, pub n_prims: u16, pub axis: u8, pub pad: u8 } // 32 B
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptPrim { pub v: [u32; 3], pub mesh: u32, pub material: u32, pub area_light: i32 } // 24 B
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptMesh { pub has_n: u32, pub has_s: u32, pub has_uv: u32, pub flip: u32 }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptBxdf { // 116 B
+    pub kind: u32, pub fresnel: u32, pub r: [f32; 3], pub t: [f32; 3], pub eta_a: f32, pub eta_b: f32, pub alpha_x: f32, pub alpha_y: f32,
+    pub c1: [f32; 3], pub c2: [f32; 3], pub on_a: f32, pub on_b: f32, pub sc: [f32; 3], pub has_sc: u32,
+    pub tex_r: u32, pub tex_t: u32, pub tex_ax: u32, pub tex_ay: u32, pub remap: u32,
+}
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptMaterial { pub eta: f32, pub first_bxdf: u32, pub n_bxdfs: u32, pub bump_tex: u32 }
+#[repr(C)] pub struct RsptImage { pub width: u32, pub height: u32, pub n_levels: u32, pub channels: u32, pub texels: *const f32 }
+#[repr(C)] pub struct RsptTexture { // 160 B
+    pub kind: u32, pub mapping: u32, pub map: [f32; 8], pub image: u32, pub trilinear: u32, pub max_aniso: f32, pub wrap: u32,
+    pub value: [f32; 3], pub tex1: u32, pub tex2: u32, pub tex3: u32, pub world_to_texture: [f32; 16], pub octaves: i32,
+    pub omega: f32, pub scale: f32, pub variation: f32,
+}
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct RsptLight { pub kind: u32, pub prim: u32, pub l: [f32; 3], pub two_sided: u32, pub p: [f32; 24] } // 120 B
+#[repr(C)] pub struct RsptEnvMap { pub width: u32, pub height: u32, pub n_levels: u32, pub pad: u32, pub texels: *const f32,
+                                   pub dist_nu: u32, pub dist_nv: u32, pub dist_func: *const f32 }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptObject { pub first_node: u64, pub n_nodes: u64, pub first_prim: u64, pub n_prims: u64 }
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_world: [f32; 16] }
+#[repr(C)] pub struct RsptSceneDesc {
+    pub nodes: *const RsptBvhNode, pub n_nodes: u64, pub prims: *const RsptPrim, pub n_prims: u64,
+    pub meshes: *const RsptMesh, pub n_meshes: u32, pub p: *const f32, pub n: *const f32, pub s: *const f32, pub uv: *const f32,
+    pub n_vertices: u64, pub materials: *const RsptMaterial, pub n_materials: u32, pub bxdfs: *const RsptBxdf, pub n_bxdfs: u32,
+    pub lights: *const RsptLight, pub n_lights: u32, pub envmaps: *const RsptEnvMap, pub n_envmaps: u32,
+    pub textures: *const RsptTexture, pub n_textures: u32, pub images: *const RsptImage, pub n_images: u32,
+    pub objects: *const RsptObject, pub n_objects: u32, pub instances: *const RsptInstance, pub n_instances: u32,
+    pub n_top_nodes: u64, pub n_top_prims: u64, pub instancing_mode: u32, pub pad1: u32,
+}
+#[repr(C)] pub struct RsptSamplerTables { pub sobol32: *const u32, pub vdc: *const u64, pub vdc_inv: *const u64,
+                                            pub halton_perms: *const u16, pub n_halton_perms: u64 }
+#[repr(C)] pub struct RsptRenderDesc {
+    pub full_res: [i32; 2], pub crop_px: [i32; 4], pub sample_bounds: [i32; 4], pub filter_radius: [f32; 2], pub filter_table: [f32; 256],
+    pub max_sample_luminance: f32, pub raster_to_camera: [f32; 16], pub camera_to_world: [f32; 16], pub lens_radius: f32,
+    pub focal_distance: f32, pub shutter_open: f32, pub shutter_close: f32, pub sampler_kind: u32, pub spp: i64, pub max_depth: u32,
+    pub rr_threshold: f32, pub light_strategy: u32, pub tile_size: u32, pub shard_index: u32, pub shard_count: u32, pub tile_chunk: u32,
+    pub sample_at_pixel_center: u32, pub integrator: u32, pub ao_n_samples: u32, pub ao_cos_sample: u32, pub film_reduce: u32,
+    pub tables: RsptSamplerTables,
+}
+#[repr(C)] #[derive(Default)]
+pub struct RsptStats {
+    pub t_render_s: f64, pub t_kernels_s: f64, pub t_trace_s: f64, pub samples: u64, pub rays_closest: u64, pub rays_any: u64,
+    pub nodes_visited: u64, pub tris_tested: u64, pub nan_samples: u64, pub trace_launches: u64, pub alg_bytes: f64,
+    pub t_trace_closest_s: f64, pub t_trace_any_s: f64, pub t_shade_s: f64, pub launches_closest: u64, pub launches_any: u64,
+    pub truncated_paths: u64,
+}
+pub enum RsptSceneOpaque {}
+
+#[link(name = "rspt")]
+extern "C" {
+    pub fn rspt_abi_version() -> c_int;
+    pub fn rspt_init(device: i32) -> c_int;
+    pub fn rspt_shutdown();
+    pub fn rspt_scene_create(desc: *const RsptSceneDesc, out: *mut *mut RsptSceneOpaque) -> c_int;
+    pub fn rspt_scene_destroy(scene: *mut RsptSceneOpaque) -> c_int;
+    pub fn rspt_render(scene: *mut RsptSceneOpaque, desc: *const RsptRenderDesc, film_xyzw: *mut f32, stats: *mut RsptStats) -> c_int;
+    pub fn rspt_render_device(scene: *mut RsptSceneOpaque, desc: *const RsptRenderDesc, film_dev: *mut c_void, stats: *mut RsptStats) -> c_int;
+    pub fn rspt_dev_alloc(bytes: u64, out: *mut *mut c_void) -> c_int;
+    pub fn rspt_dev_free(p: *mut c_void) -> c_int;
+    pub fn rspt_dev_download(dst_host: *mut c_void, src_dev: *const c_void, bytes: u64) -> c_int;
+    pub fn rspt_comm_unique_id(id: *mut u8) -> c_int;                              // 128 bytes
+    pub fn rspt_comm_init(rank: i32, world: i32, id: *const u8) -> c_int;
+    pub fn rspt_comm_destroy() -> c_int;
+    pub fn rspt_last_error() -> *const c_char;
+    pub fn rspt_bvh_build_gpu(p: *const f32, n_vertices: u64, tri_idx: *const u32, n_tris: u64, max_prims_in_node: u32,
+                              nodes_out: *mut RsptBvhNode, nodes_cap: u64, ordered_out: *mut u32) -> i64;
+}

@@ -1,0 +1,298 @@
+//! src/gpu/mod.rs — the whole Rust side of the MI355X path: flatten `Scene` + `PathIntegrator` into the POD arrays of
+//! include/rspt.h, call librspt.so, write the film back.  Uncompiled source for a maintainer (no Rust toolchain in the image this
+//! repo is built in); it is written against rs_pbrt v0.9.12 plus the getters of rust_shim/rs_pbrt.patch.  Everything not covered
+//! returns Err and `SamplerIntegrator::render` keeps its CPU tile loop (src/core/integrator.rs:70-220).
+//!
+//! Covered: triangle meshes (Shape::Trngl) under a BVHAccel aggregate, object instances (Primitive::Transformed, static),
+//! matte / plastic / mirror / glass / metal with constant textures (Texture::as_constant, added by the patch), diffuse area /
+//! point / spot / distant lights, PerspectiveCamera, Sobol' and Halton samplers, any filter (through Film.filter_table).
+//! Image / procedural textures, the other materials, infinite lights: the ABI has them (rspt_texture, rspt_envmap; see
+//! rs_pbrt_amd/scenes.py for the field-by-field recipe), this file does not flatten them yet.
+pub mod ffi;
+pub mod refdump;
+
+use self::ffi::*;
+use crate::accelerators::bvh::BVHAccel;
+use crate::core::camera::Camera;
+use crate::core::integrator::SamplerIntegrator;
+use crate::core::light::Light;
+use crate::core::material::Material;
+use crate::core::pbrt::{Float, Spectrum};
+use crate::core::primitive::Primitive;
+use crate::core::sampler::Sampler;
+use crate::core::scene::Scene;
+use crate::core::shape::Shape;
+use crate::core::sobolmatrices::{SOBOL_MATRICES_32, VD_C_SOBOL_MATRICES, VD_C_SOBOL_MATRICES_INV};
+use crate::core::transform::Transform;
+use crate::samplers::halton::RADICAL_INVERSE_PERMUTATIONS;
+use crate::shapes::triangle::TriangleMesh;
+use std::collections::HashMap;
+use std::ffi::CStr;
+use std::sync::Arc;
+
+fn m16(t: &crate::core::transform::Matrix4x4) -> [f32; 16] {
+    let mut o = [0.0f32; 16];
+    for r in 0..4 { for c in 0..4 { o[4 * r + c] = t.m[r][c]; } }
+    o
+}
+fn rgb(s: &Spectrum) -> [f32; 3] { [s.c[0].max(0.0), s.c[1].max(0.0), s.c[2].max(0.0)] } // Spectrum::clamp_t(0, inf)
+fn err() -> String { unsafe { CStr::from_ptr(rspt_last_error()).to_string_lossy().into_owned() } }
+
+/// TrowbridgeReitzDistribution::roughness_to_alpha (microfacet.rs:243-254) + the 0.001 floor of ::new (:233-239)
+fn alpha(roughness: Float, remap: bool) -> f32 {
+    let a = if remap {
+        let x = roughness.max(1e-3 as Float).ln();
+        1.62142 + 0.819955 * x + 0.1734 * x * x + 0.0171201 * x * x * x + 0.000640711 * x * x * x * x
+    } else { roughness };
+    a.max(0.001)
+}
+
+/// Everything that has to stay alive until rspt_scene_create has copied it.
+#[derive(Default)]
+struct Flat {
+    nodes: Vec<RsptBvhNode>, prims: Vec<RsptPrim>, meshes: Vec<RsptMesh>,
+    p: Vec<f32>, n: Vec<f32>, s: Vec<f32>, uv: Vec<f32>, any_n: bool, any_s: bool, any_uv: bool,
+    materials: Vec<RsptMaterial>, bxdfs: Vec<RsptBxdf>, lights: Vec<RsptLight>,
+    objects: Vec<RsptObject>, instances: Vec<RsptInstance>,
+    mesh_of: HashMap<*const TriangleMesh, (u32, u32)>,     // mesh -> (mesh index, first vertex)
+    material_of: HashMap<*const Material, u32>,
+    object_of: HashMap<*const Primitive, u32>,               // instanced aggregate / primitive -> object index
+}
+
+impl Flat {
+    fn mesh(&mut self, m: &Arc<TriangleMesh>) -> (u32, u32) {
+        let key = Arc::as_ptr(m);
+        if let Some(v) = self.mesh_of.get(&key) { return *v; }
+        let first = (self.p.len() / 3) as u32;
+        for q in &m.p { self.p.extend_from_slice(&[q.x, q.y, q.z]); }          // world space already (api.rs:1967-1971)
+        for i in 0..m.p.len() {
+            if m.n.is_empty() { self.n.extend_from_slice(&[0.0; 3]); } else { self.n.extend_from_slice(&[m.n[i].x, m.n[i].y, m.n[i].z]); }
+            if m.s.is_empty() { self.s.extend_from_slice(&[0.0; 3]); } else { self.s.extend_from_slice(&[m.s[i].x, m.s[i].y, m.s[i].z]); }
+            if m.uv.is_empty() { self.uv.extend_from_slice(&[0.0; 2]); } else { self.uv.extend_from_slice(&[m.uv[i].x, m.uv[i].y]); }
+        }
+        self.any_n |= !m.n.is_empty(); self.any_s |= !m.s.is_empty(); self.any_uv |= !m.uv.is_empty();
+        self.meshes.push(RsptMesh { has_n: !m.n.is_empty() as u32, has_s: !m.s.is_empty() as u32, has_uv: !m.uv.is_empty() as u32,
+                                    flip: (m.reverse_orientation ^ m.transform_swaps_handedness) as u32 }); // triangle.rs:324
+        let v = ((self.meshes.len() - 1) as u32, first);
+        self.mesh_of.insert(key, v);
+        v
+    }
+
+    /// Material::compute_scattering_functions with constant textures, evaluated once: the lobes in push order
+    fn material(&mut self, m: &Option<Arc<Material>>) -> Result<u32, String> {
+        let m = match m { Some(m) => m, None => return Ok(RSPT_NO_MATERIAL) };   // path.rs:109-116 passes straight through
+        let key = Arc::as_ptr(m);
+        if let Some(i) = self.material_of.get(&key) { return Ok(*i); }
+        let cs = |t: &Arc<dyn crate::core::texture::Texture<Spectrum> + Sync + Send>| t.as_constant().map(|s| rgb(&s)).ok_or("non-constant spectrum texture".to_string());
+        let cf = |t: &Arc<dyn crate::core::texture::Texture<Float> + Sync + Send>| t.as_constant().ok_or("non-constant float texture".to_string());
+        let black = |c: &[f32; 3]| c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0;
+        let first = self.bxdfs.len() as u32;
+        let mut eta = 1.0f32;
+        let lobe = RsptBxdf::default();
+        match &**m {
+            Material::Matte(mm) => {                                               // matte.rs:43-86
+                if mm.bump_map.is_some() { return Err("bump map".into()); }
+                let r = cs(&mm.kd)?; let sig = cf(&mm.sigma)?.max(0.0).min(90.0);
+                if !black(&r) {
+                    if sig == 0.0 { self.bxdfs.push(RsptBxdf { kind: 1, r, ..lobe }); }
+                    else {                                                          // OrenNayar::new reflection.rs:1057-1065
+                        let s = (std::f32::consts::PI / 180.0) * sig; let s2 = s * s;
+                        self.bxdfs.push(RsptBxdf { kind: 2, r, on_a: 1.0 - s2 / (2.0 * (s2 + 0.33)), on_b: 0.45 * s2 / (s2 + 0.09), ..lobe });
+                    }
+                }
+            }
+            Material::Plastic(pm) => {                                             // plastic.rs:57-125
+                if pm.bump_map.is_some() { return Err("bump map".into()); }
+                let kd = cs(&pm.kd)?; let ks = cs(&pm.ks)?; let a = alpha(cf(&pm.roughness)?, pm.remap_roughness);
+                if !black(&kd) { self.bxdfs.push(RsptBxdf { kind: 1, r: kd, ..lobe }); }
+                if !black(&ks) { self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 1, r: ks, eta_a: 1.5, eta_b: 1.0, alpha_x: a, alpha_y: a, ..lobe }); }
+            }
+            Material::Mirror(mm) => { self.bxdfs.push(RsptBxdf { kind: 3, fresnel: 0, r: cs(&mm.kr)?, ..lobe }); } // mirror.rs:34-70, pushed even if black
+            Material::Glass(gm) => {                                               // glass.rs:83-211, smooth surface, allow_multiple_lobes = true (path)
+                if gm.bump_map.is_some() || cf(&gm.u_roughness)? != 0.0 || cf(&gm.v_roughness)? != 0.0 { return Err("rough / bumped glass".into()); }
+                eta = cf(&gm.index)?;
+                let r = cs(&gm.kr)?; let t = cs(&gm.kt)?;
+                if !(black(&r) && black(&t)) { self.bxdfs.push(RsptBxdf { kind: 5, r, t, eta_a: 1.0, eta_b: eta, ..lobe }); }
+            }
+            Material::Metal(mm) => {                                               // metal.rs:144-205
+                if mm.bump_map.is_some() || mm.u_roughness.is_some() || mm.v_roughness.is_some() { return Err("anisotropic / bumped metal".into()); }
+                let a = alpha(cf(&mm.roughness)?, mm.remap_roughness);
+                self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 2, r: [1.0; 3], c1: cs(&mm.eta)?, c2: cs(&mm.k)?, alpha_x: a, alpha_y: a, ..lobe });
+            }
+            _ => return Err("material not flattened by the shim yet (substrate / uber / translucent / mix: see rs_pbrt_amd/scenes.py)".into()),
+        }
+        self.materials.push(RsptMaterial { eta, first_bxdf: first, n_bxdfs: self.bxdfs.len() as u32 - first, bump_tex: 0 });
+        let i = (self.materials.len() - 1) as u32;
+        self.material_of.insert(key, i);
+        Ok(i)
+    }
+
+    /// One BVHAccel: its LinearBVHNodes (offsets made absolute) and its ordered primitives; returns (first node, n nodes, first prim, n prims)
+    fn aggregate(&mut self, bvh: &BVHAccel, lights: &[Arc<Light>], top: bool) -> Result<(u64, u64, u64, u64), String> {
+        let node_base = self.nodes.len() as i32; let prim_base = self.prims.len() as i32;
+        for n in &bvh.nodes {                                                      // LinearBVHNode getters: rs_pbrt.patch (bvh.rs:77-85)
+            let b = n.bounds();
+            let leaf = n.n_primitives() > 0;
+            self.nodes.push(RsptBvhNode { bmin: [b.p_min.x, b.p_min.y, b.p_min.z], bmax: [b.p_max.x, b.p_max.y, b.p_max.z],
+                                          offset: n.offset() + if leaf { prim_base } else { node_base }, n_prims: n.n_primitives(), axis: n.axis(), pad: 0 });
+        }
+        let mut pending: Vec<(usize, Arc<Primitive>, Transform)> = Vec::new();     // instances: flattened after this aggregate
+        for prim in &bvh.primitives {                                              // BVH leaf order (bvh.rs:144-149)
+            match &**prim {
+                Primitive::Geometric(g) => {
+                    let tri = match &*g.shape { Shape::Trngl(t) => t, _ => return Err("non-triangle shape".into()) };
+                    let (mesh, first) = self.mesh(tri.mesh());                     // Triangle.mesh getter: rs_pbrt.patch (triangle.rs:85)
+                    let vi = &tri.mesh().vertex_indices[3 * tri.id as usize..3 * tri.id as usize + 3];
+                    let area_light = match &g.area_light {                         // the reference compares these pointers (integrator.rs:540-543)
+                        Some(al) if top => lights.iter().position(|l| Arc::ptr_eq(l, al)).map(|i| i as i32).unwrap_or(-1),
+                        Some(_) => return Err("area light inside an object instance".into()),
+                        None => -1,
+                    };
+                    let material = self.material(&g.material)?;
+                    self.prims.push(RsptPrim { v: [first + vi[0], first + vi[1], first + vi[2]], mesh, material, area_light });
+                }
+                Primitive::Transformed(tp) if top => {
+                    if tp.primitive_to_world.is_animated() { return Err("animated instance".into()); }   // getter: rs_pbrt.patch
+                    pending.push((self.prims.len(), tp.primitive.clone(), tp.primitive_to_world.start_transform()));
+                    self.prims.push(RsptPrim { v: [0; 3], mesh: RSPT_MESH_INSTANCE, material: RSPT_NO_MATERIAL, area_light: -1 });
+                }
+                _ => return Err("nested aggregate".into()),
+            }
+        }
+        let me = (node_base as u64, bvh.nodes.len() as u64, prim_base as u64, bvh.primitives.len() as u64);
+        for (slot, obj, xf) in pending {
+            let key = Arc::as_ptr(&obj);
+            let oi = match self.object_of.get(&key) {
+                Some(i) => *i,
+                None => {
+                    let o = match &*obj {
+                        Primitive::BVH(b) => { let (fnod, nn, fp, np) = self.aggregate(b, lights, false)?; RsptObject { first_node: fnod, n_nodes: nn, first_prim: fp, n_prims: np } }
+                        Primitive::Geometric(_) => {                               // a single primitive: no aggregate (api.rs:3046)
+                            let fp = self.prims.len() as u64;
+                            let one = BVHAccel::single_for_shim(obj.clone());      // helper in rs_pbrt.patch: primitives = [obj], nodes = []
+                            self.aggregate(&one, lights, false)?;
+                            RsptObject { first_node: 0, n_nodes: 0, first_prim: fp, n_prims: 1 }
+                        }
+                        _ => return Err("unsupported instanced primitive".into()),
+                    };
+                    self.objects.push(o);
+                    let i = (self.objects.len() - 1) as u32;
+                    self.object_of.insert(key, i);
+                    i
+                }
+            };
+            self.prims[slot].v[0] = self.instances.len() as u32;
+            self.instances.push(RsptInstance { object: oi, to_world: m16(&xf.m), from_world: m16(&xf.m_inv) });
+        }
+        Ok(me)
+    }
+}
+
+fn light_record(l: &Light, prims: &[RsptPrim], index: usize) -> Result<RsptLight, String> {
+    let mut o = RsptLight { kind: 0, prim: 0, l: [0.0; 3], two_sided: 0, p: [0.0; 24] };
+    match l {
+        Light::DiffuseArea(a) => {                                                 // diffuse.rs:19-27
+            o.kind = 1; o.l = a.l_emit.c; o.two_sided = a.two_sided as u32;
+            o.prim = prims.iter().position(|p| p.area_light == index as i32).ok_or("area light without primitive")? as u32;
+        }
+        Light::Point(p) => { o.kind = 2; o.l = p.i.c; o.p[..3].copy_from_slice(&[p.p_light.x, p.p_light.y, p.p_light.z]); }   // point.rs:20-68
+        Light::Spot(s) => {                                                        // spot.rs:20-110
+            o.kind = 3; o.l = s.i.c; o.p[..3].copy_from_slice(&[s.p_light.x, s.p_light.y, s.p_light.z]);
+            let w = &s.world_to_light.m.m;
+            for r in 0..3 { for c in 0..3 { o.p[3 + 3 * r + c] = w[r][c]; } }
+            o.p[12] = s.cos_total_width; o.p[13] = s.cos_falloff_start;
+        }
+        Light::Distant(d) => { o.kind = 4; o.l = d.l.c; o.p[..3].copy_from_slice(&[d.w_light.x, d.w_light.y, d.w_light.z]); } // distant.rs:25-75
+        _ => return Err("light not flattened by the shim yet (infinite / projection / goniometric)".into()),
+    }
+    Ok(o)
+}
+
+/// What `SamplerIntegrator::render` calls first when RSPT_GPU is set.  Ok(()) = Film.pixels hold the finished frame.
+pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), String> {
+    let (max_depth, rr_threshold, strategy, integrator_kind, ao_n, ao_cos) = match integ {
+        SamplerIntegrator::Path(p) => (p.max_depth(), p.rr_threshold(), p.light_sample_strategy().to_string(), 0u32, 0u32, 0u32), // getters: rs_pbrt.patch (path.rs:30-32)
+        SamplerIntegrator::AO(a) => (0, 1.0, "spatial".to_string(), 1u32, a.n_samples as u32, a.cos_sample as u32),
+        _ => return Err("integrator without a GPU path".into()),
+    };
+    let bvh = match &*scene.aggregate { Primitive::BVH(b) => b, _ => return Err("aggregate is not a BVH".into()) };
+    let mut f = Flat::default();
+    let (_, n_top_nodes, _, n_top_prims) = f.aggregate(bvh, &scene.lights, true)?;
+    let lights: Vec<RsptLight> = scene.lights.iter().enumerate().map(|(i, l)| light_record(l, &f.prims, i)).collect::<Result<_, _>>()?;
+    f.lights = lights;
+
+    // ---- camera / film / sampler (perspective.rs:22-43, film.rs:159-173, sobol.rs:15-20, halton.rs:54-78) ----
+    let cam = match &*integ.get_camera() { Camera::Perspective(c) => c.clone_for_shim(), _ => return Err("camera is not perspective".into()) };
+    if cam.camera_to_world.is_animated() { return Err("animated camera".into()); }
+    let film = cam.film.clone();
+    let sb = film.get_sample_bounds(); let cb = film.cropped_pixel_bounds;
+    let radius = film.filter.get_radius();
+    let mut filter_table = [0.0f32; 256];
+    filter_table.copy_from_slice(film.filter_table());                             // getter: rs_pbrt.patch (film.rs:170)
+    let (sampler_kind, spp, at_center) = match integ.get_sampler() {
+        Sampler::Sobol(s) => (1u32, s.samples_per_pixel, 0u32),
+        Sampler::Halton(h) => (2u32, h.samples_per_pixel, h.sample_at_pixel_center() as u32),
+        _ => return Err("sampler with per-tile RNG state (02sequence / random / stratified / maxmindist)".into()),
+    };
+    let mut vdc = vec![0u64; 25 * 52]; let mut vdc_inv = vec![0u64; 26 * 52];       // rows zero-padded to 52 entries
+    for (i, row) in VD_C_SOBOL_MATRICES.iter().enumerate() { vdc[i * 52..i * 52 + row.len()].copy_from_slice(row); }
+    for (i, row) in VD_C_SOBOL_MATRICES_INV.iter().enumerate() { vdc_inv[i * 52..i * 52 + row.len()].copy_from_slice(row); }
+    let rank: u32 = std::env::var("RSPT_RANK").ok().and_then(|v| v.parse().ok()).unwrap_or(0);   // one process per GPU, INTEGRATION.md §5
+    let world: u32 = std::env::var("RSPT_WORLD").ok().and_then(|v| v.parse().ok()).unwrap_or(1);
+    let rd = RsptRenderDesc {
+        full_res: [film.full_resolution.x, film.full_resolution.y],
+        crop_px: [cb.p_min.x, cb.p_min.y, cb.p_max.x, cb.p_max.y], sample_bounds: [sb.p_min.x, sb.p_min.y, sb.p_max.x, sb.p_max.y],
+        filter_radius: [radius.x, radius.y], filter_table, max_sample_luminance: film.max_sample_luminance(),
+        raster_to_camera: m16(&cam.raster_to_camera.m), camera_to_world: m16(&cam.camera_to_world.start_transform().m),
+        lens_radius: cam.lens_radius, focal_distance: cam.focal_distance, shutter_open: cam.shutter_open, shutter_close: cam.shutter_close,
+        sampler_kind, spp, max_depth, rr_threshold,
+        light_strategy: match strategy.as_str() { "uniform" => 0, "power" => 1, _ => 2 },    // lightdistrib.rs:393-418 falls back to spatial
+        tile_size: 16, shard_index: rank, shard_count: world, tile_chunk: 64, sample_at_pixel_center: at_center,
+        integrator: integrator_kind, ao_n_samples: ao_n, ao_cos_sample: ao_cos, film_reduce: (world > 1) as u32,
+        tables: RsptSamplerTables { sobol32: SOBOL_MATRICES_32.as_ptr(), vdc: vdc.as_ptr(), vdc_inv: vdc_inv.as_ptr(),
+                                    halton_perms: RADICAL_INVERSE_PERMUTATIONS.as_ptr(), n_halton_perms: RADICAL_INVERSE_PERMUTATIONS.len() as u64 },
+    };
+    let sd = RsptSceneDesc {
+        nodes: f.nodes.as_ptr(), n_nodes: f.nodes.len() as u64, prims: f.prims.as_ptr(), n_prims: f.prims.len() as u64,
+        meshes: f.meshes.as_ptr(), n_meshes: f.meshes.len() as u32, p: f.p.as_ptr(),
+        n: if f.any_n { f.n.as_ptr() } else { std::ptr::null() }, s: if f.any_s { f.s.as_ptr() } else { std::ptr::null() },
+        uv: if f.any_uv { f.uv.as_ptr() } else { std::ptr::null() }, n_vertices: (f.p.len() / 3) as u64,
+        materials: f.materials.as_ptr(), n_materials: f.materials.len() as u32, bxdfs: f.bxdfs.as_ptr(), n_bxdfs: f.bxdfs.len() as u32,
+        lights: f.lights.as_ptr(), n_lights: f.lights.len() as u32, envmaps: std::ptr::null(), n_envmaps: 0,
+        textures: std::ptr::null(), n_textures: 0, images: std::ptr::null(), n_images: 0,
+        objects: f.objects.as_ptr(), n_objects: f.objects.len() as u32, instances: f.instances.as_ptr(), n_instances: f.instances.len() as u32,
+        n_top_nodes, n_top_prims, instancing_mode: (std::env::var_os("RSPT_INSTANCING_FIXED").is_some()) as u32, pad1: 0,
+    };
+    unsafe {
+        if rspt_abi_version() != RSPT_ABI_VERSION { return Err("librspt.so ABI version mismatch".into()); }
+        if rspt_init(std::env::var("RSPT_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(rank as i32)) != 0 { return Err(err()); }
+        if world > 1 {                                                             // X1: the id travels through a file the launcher names
+            let path = std::env::var("RSPT_COMM_ID_FILE").map_err(|_| "RSPT_COMM_ID_FILE unset")?;
+            let mut id = [0u8; 128];
+            if rank == 0 {
+                if rspt_comm_unique_id(id.as_mut_ptr()) != 0 { return Err(err()); }
+                std::fs::write(format!("{}.tmp", path), &id[..]).and_then(|_| std::fs::rename(format!("{}.tmp", path), &path)).map_err(|e| e.to_string())?;
+            } else {
+                loop { if let Ok(b) = std::fs::read(&path) { if b.len() == 128 { id.copy_from_slice(&b); break; } } std::thread::sleep(std::time::Duration::from_millis(20)); }
+            }
+            if rspt_comm_init(rank as i32, world as i32, id.as_ptr()) != 0 { return Err(err()); }
+        }
+        let mut handle: *mut RsptSceneOpaque = std::ptr::null_mut();
+        if rspt_scene_create(&sd, &mut handle) != 0 { return Err(err()); }
+        let npix = ((cb.p_max.x - cb.p_min.x) * (cb.p_max.y - cb.p_min.y)) as usize;
+        let mut xyzw = vec![0.0f32; 4 * npix];
+        let mut stats = RsptStats::default();
+        let rc = rspt_render(handle, &rd, xyzw.as_mut_ptr(), &mut stats);          // with film_reduce the sum arrives on rank 0
+        let msg = if rc != 0 { err() } else { String::new() };
+        rspt_scene_destroy(handle);
+        if rc != 0 { return Err(msg); }
+        if rank != 0 { std::process::exit(0); }                                    // ranks > 0 have delivered their tiles
+        // Film.pixels exactly as merge_film_tile leaves them (film.rs:346-371): xyz is ALREADY XYZ (the library applied rgb_to_xyz
+        // once per pixel), so write_image must not convert again on the way in — it only reads xyz / filter_weight_sum (film.rs:445-462)
+        let mut px = film.pixels.write().unwrap();
+        for i in 0..npix { px[i].set_xyz_weight([xyzw[4 * i], xyzw[4 * i + 1], xyzw[4 * i + 2]], xyzw[4 * i + 3]); } // setter: rs_pbrt.patch (film.rs:38-43)
+        eprintln!("rspt: {} samples in {:.3} s ({:.1} Msamples/s), {} NaN samples, {} truncated paths", stats.samples, stats.t_render_s,
+                  stats.samples as f64 / stats.t_render_s / 1e6, stats.nan_samples, stats.truncated_paths);
+    }
+    Ok(())
+}
