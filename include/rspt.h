@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 11
+#define RSPT_ABI_VERSION 12
 
 /* error codes */
 #define RSPT_OK 0
@@ -324,8 +324,15 @@ typedef struct {
                                         world size, shard_index its rank); the other ranks' buffers keep their partial films.
                                         0 = no collective (single GPU, or the caller reduces) */
     rspt_sampler_tables tables;
+    /* DirectLightingIntegrator (src/integrators/directlighting.rs:17-70): max_depth bounds the specular recursion
+     * (default 5, api.rs:322-349); rr_threshold and light_strategy are ignored (uniform_sample_one_light gets no distribution) */
+    uint32_t direct_strategy;        /* RSPT_DIRECT_SAMPLE_ALL (default, "all") | RSPT_DIRECT_SAMPLE_ONE ("one")                   */
+    uint32_t pad2;
+    const int32_t* n_light_samples;  /* SAMPLE_ALL: Light::get_n_samples() per light ("samples" / "nsamples", default 1), after
+                                        Sampler::round_count (the identity for Sobol' and Halton); NULL = 1 each                   */
 } rspt_render_desc;
-enum { RSPT_INTEGRATOR_PATH = 0, RSPT_INTEGRATOR_AO = 1 };
+enum { RSPT_INTEGRATOR_PATH = 0, RSPT_INTEGRATOR_AO = 1, RSPT_INTEGRATOR_DIRECT = 2 };
+enum { RSPT_DIRECT_SAMPLE_ALL = 0, RSPT_DIRECT_SAMPLE_ONE = 1 };
 
 typedef struct { float o[3], d[3], t_max; uint32_t id; } rspt_ray;   /* 32 B */
 typedef struct { uint32_t prim; float t, b0, b1, b2; } rspt_hit;     /* prim = 0xffffffff on miss */

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -13,7 +13,8 @@ BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9
 FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
 SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
-INTEGRATOR_PATH, INTEGRATOR_AO = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_AO, INTEGRATOR_DIRECT = 0, 1, 2
+DIRECT_SAMPLE_ALL, DIRECT_SAMPLE_ONE = 0, 1
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 TEX_CONSTANT, TEX_IMAGE, TEX_SCALE, TEX_MIX, TEX_CHECKERBOARD, TEX_DOTS, TEX_FBM, TEX_MARBLE, TEX_WINDY, TEX_WRINKLED = range(1, 11)
 MAP_UV, MAP_PLANAR, MAP_SPHERICAL, MAP_CYLINDRICAL, MAP_IDENTITY3D = 1, 2, 3, 4, 5
@@ -103,7 +104,8 @@ class RenderDesc(C.Structure):
                 ("tile_size", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("tile_chunk", C.c_uint32),
                 ("sample_at_pixel_center", C.c_uint32), ("integrator", C.c_uint32), ("ao_n_samples", C.c_uint32),
-                ("ao_cos_sample", C.c_uint32), ("film_reduce", C.c_uint32), ("tables", SamplerTables)]
+                ("ao_cos_sample", C.c_uint32), ("film_reduce", C.c_uint32), ("tables", SamplerTables),
+                ("direct_strategy", C.c_uint32), ("pad2", C.c_uint32), ("n_light_samples", C.c_void_p)]
 
 
 class Ray(C.Structure):

@@ -1,0 +1,379 @@
+// DirectLightingIntegrator::li on the GPU (src/integrators/directlighting.rs:71-258).
+//
+// `li` recurses into specular reflection AND transmission, and the sampler's dimensions / 2-D sample arrays are consumed in
+// that depth-first order, so a node's dimensions depend on how many nodes its earlier siblings' subtrees hold.  The wavefront
+// form rests on one observation: the direction of a specular bounce does not depend on a sample value (a material with more
+// than one specular-reflective or more than one specular-transmissive lobe is refused), so
+//   1. the whole specular tree of every camera sample is traced first, level by level (k_dl_hit), in heap order: node h of
+//      sample s lives in slot s * H + h, H = 2^max_depth, children 2h (reflection) and 2h + 1 (transmission);
+//   2. one lane per camera sample walks its tree in the reference's order and gives every shading node its index among the
+//      sample's shading nodes (which sample arrays it gets, sampler.rs get_2d_array) and its position in the dimension stream
+//      (k_dl_assign);
+//   3. the light estimates of all nodes run as wavefront rounds — one (light, array element) per round, shadow + MIS rays through
+//      the same trace kernels as the path integrator — and are added in the reference's order (k_dl_nee / k_dl_nee_resolve);
+//   4. one lane per camera sample folds the tree bottom-up: l = le + lights + f_r * li(reflected) * |cos| / pdf + ... (k_dl_gather).
+// Null-BSDF hits continue inside their node (directlighting.rs:90-92).  Textured materials are not handled here yet
+// (rspt_render refuses the combination).
+#pragma once
+#include "kernels.h"
+
+namespace rspt {
+
+enum : uint32_t { DL_EMPTY = 0, DL_SHADING = 1, DL_LEAF = 2, DL_PENDING = 3 };
+enum : uint32_t { DLF_HAS_C1 = 1, DLF_HAS_C2 = 2, DLF_C2_ON_MISS = 4 };
+
+struct DlBuf {          // per node slot
+    float4* le_kind;    // (emitted radiance of a shading node | radiance of an escaped ray, kind)
+    float4* w_r;        // edge to the reflection child: (f.rgb, |wi . ns| / pdf); all zero = no child
+    float4* w_t;        // edge to the transmission child
+    float4* l_all;      // running sum of uniform_sample_all_lights / _one_light; after k_dl_gather: li of the node
+    float4* ld_acc;     // running `ld` of the current light (sample arrays)
+    uint32_t* dim;      // dimension at which the node's lighting starts in the regular stream
+    uint32_t* kidx;     // index among the camera sample's shading nodes, depth first
+    uint32_t* nflags;   // DLF_* of the estimate in flight
+    uint32_t H;         // slots per camera sample
+    uint32_t* error;    // != 0: a material with several specular lobes of one kind was met
+};
+
+// per-wave aggregated queue append
+RDEV void dl_push(bool want, uint32_t value, uint32_t* __restrict__ queue, uint32_t* counter) {
+    const uint64_t m = __ballot(want);
+    if (!m) return;
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, __builtin_ctzll(m));
+    if (want) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+// the interaction of a node's hit and its BSDF (Triangle::intersect second half + compute_scattering_functions with constant textures)
+struct DlHit {
+    Hit h;
+    f3 wo;      // isect.common.wo
+    Bsdf bsdf;
+};
+RDEV void dl_interaction(const SceneDev& sc, const PathBuf& pb, uint32_t slot, uint32_t prim, float4 hc, f3 ray_d, DlHit* o) {
+    TriRec tri = load_tri(sc, prim);
+    tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &o->h);
+    o->wo = -ray_d;
+    if (pb.hit_inst) {
+        const uint32_t hi = pb.hit_inst[slot];
+        if (hi && !sc.inst[hi - 1u].identity) {
+            const InstDev& in = sc.inst[hi - 1u];
+            inst_hit(in, &o->h);
+            o->wo = normalize(xf_vector(in.m, -xf_vector(in.mi, ray_d)));
+            if (!sc.inst_fixed) { o->h.material = 0xffffffffu; o->h.area_light = -1; }
+        }
+    }
+    if (o->h.material != 0xffffffffu) {
+        const rspt_material mat = sc.materials[o->h.material];
+        Bsdf& b = o->bsdf;
+        b.eta = mat.eta; b.lt = LobeTex{nullptr, 0}; b.dropped = 0u;
+        b.ss = normalize(o->h.sh_dpdu); b.ns = o->h.sh_n; b.ng = o->h.n; b.ts = cross(o->h.sh_n, b.ss);
+        b.lobes = sc.bxdfs + mat.first_bxdf;
+        b.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+    }
+}
+
+// roots: the camera rays (k_raygen left them in src_rays by sample slot)
+__global__ __launch_bounds__(256) void k_dl_init(Batch bt, PathBuf pb, DlBuf dl, const rspt_ray* __restrict__ src_rays, uint32_t* __restrict__ q_level0, uint32_t* cnt_level0) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) *cnt_level0 = bt.n;
+    if (i >= bt.n) return;
+    const uint32_t slot = i * dl.H + 1u;
+    pb.ray_cont[slot] = src_rays[i];
+    dl.le_kind[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)DL_PENDING));
+    q_level0[i] = slot;
+}
+
+// one level of the specular tree: classify every traced node, spawn its children into the next level's queue; null-BSDF hits
+// re-enter the same level (q_retrace)
+__global__ __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
+                                                uint32_t* __restrict__ q_retrace, uint32_t* cnt_retrace, uint32_t* __restrict__ q_next, uint32_t* cnt_next, uint32_t level) {
+    const uint32_t n = *count_in;
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        bool retrace = false, kid_r = false, kid_t = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            const float4 hc = pb.hit_cont[slot];
+            const uint32_t prim = __float_as_uint(hc.x);
+            const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
+            const float4 r0 = rp[0], r1 = rp[1];
+            const f3 ray_d{r0.w, r1.x, r1.y};
+            if (prim == RSPT_MISS) {  // for light in &scene.lights { l += light.le(ray) } (directlighting.rs:117-121): only infinite lights emit there
+                rgb l = mkrgb(0.0f);
+                for (uint32_t k = 0; k < sc.n_infinite; k++) l = l + infinite_le(sc, sc.lights[sc.infinite_lights[k]], ray_d);
+                dl.le_kind[slot] = make_float4(l.r, l.g, l.b, __uint_as_float((uint32_t)DL_LEAF));
+            } else {
+                DlHit d;
+                dl_interaction(sc, pb, slot, prim, hc, ray_d, &d);
+                if (d.h.material == 0xffffffffu) {  // isect.bsdf.is_none(): return self.li(&isect.spawn_ray(&ray.d), ..., depth) (:90-92)
+                    store_ray(pb.ray_cont + slot, offset_ray_origin(d.h.p, d.h.p_err, d.h.n, ray_d), ray_d, RSPT_INF, slot);
+                    retrace = true;
+                } else {
+                    const rgb le = d.h.area_light >= 0 ? light_l(sc.lights[d.h.area_light], d.h.n, d.wo) : mkrgb(0.0f);  // l += isect.le(&wo)
+                    dl.le_kind[slot] = make_float4(le.r, le.g, le.b, __uint_as_float((uint32_t)DL_SHADING));
+                    float4 wr = make_float4(0.0f, 0.0f, 0.0f, 0.0f), wt = wr;
+                    if (level + 1u < rd.max_depth) {  // specular_reflect / specular_transmit (:124-258), ray differentials left out
+                        if (d.bsdf.num_components(BX_REFL | BX_SPEC) > 1 || d.bsdf.num_components(BX_TRANS | BX_SPEC) > 1) *dl.error = 1u;
+                        const uint32_t h = slot % dl.H, s = slot / dl.H;
+                        for (int side = 0; side < 2; side++) {
+                            f3 wi{0.0f, 0.0f, 0.0f};
+                            float pdf = 0.0f;
+                            uint32_t st = 0;
+                            const rgb f = d.bsdf.sample_f(d.wo, &wi, f2{0.0f, 0.0f}, &pdf, (side ? BX_TRANS : BX_REFL) | BX_SPEC, &st);
+                            if (pdf > 0.0f && !is_black(f) && absdot(wi, d.h.sh_n) != 0.0f) {
+                                const uint32_t child = s * dl.H + 2u * h + (uint32_t)side;
+                                store_ray(pb.ray_cont + child, offset_ray_origin(d.h.p, d.h.p_err, d.h.n, wi), wi, RSPT_INF, child);
+                                dl.le_kind[child] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)DL_PENDING));
+                                const float4 w = make_float4(f.r, f.g, f.b, absdot(wi, d.h.sh_n) / pdf);
+                                if (side) { wt = w; kid_t = true; } else { wr = w; kid_r = true; }
+                            }
+                        }
+                    }
+                    dl.w_r[slot] = wr; dl.w_t[slot] = wt;
+                }
+            }
+        }
+        dl_push(retrace, slot, q_retrace, cnt_retrace);
+        const uint32_t h = slot % dl.H, s = slot / dl.H;
+        dl_push(kid_r, s * dl.H + 2u * h, q_next, cnt_next);
+        dl_push(kid_t, s * dl.H + 2u * h + 1u, q_next, cnt_next);
+    }
+}
+
+// the reference's depth-first order: which sample arrays and which dimensions every shading node gets
+// n_arrays = 2 * max_depth * n_lights with LightStrategy::UniformSampleAll (preprocess, directlighting.rs:54-70), else 0
+__global__ __launch_bounds__(256) void k_dl_assign(Batch bt, DlBuf dl, uint32_t n_lights, uint32_t n_arrays, uint32_t sample_all, uint32_t max_depth) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= bt.n) return;
+    uint32_t k = 0;
+    uint32_t dim = 5u + 2u * n_arrays;  // get_1d / get_2d jump over the array dimensions, two per array (sobol.rs:180-201): the regular stream starts behind them
+    uint32_t stack[32];            // (heap index << 1) | stage
+    int sp = 0;
+    stack[sp++] = 1u << 1;
+    while (sp > 0) {
+        const uint32_t e = stack[--sp], h = e >> 1, stage = e & 1u;
+        const uint32_t slot = s * dl.H + h;
+        if (stage == 0u) {
+            if (__float_as_uint(dl.le_kind[slot].w) != DL_SHADING) continue;
+            dl.kidx[slot] = k; dl.dim[slot] = dim;
+            if (n_lights) {
+                if (sample_all) {  // lights whose array pair is used up fall back to get_2d() x 2 (integrator.rs:316-329)
+                    const uint32_t pairs = n_arrays / 2u, first = k * n_lights;
+                    const uint32_t with_arrays = first >= pairs ? 0u : (pairs - first < n_lights ? pairs - first : n_lights);
+                    dim += 4u * (n_lights - with_arrays);
+                } else dim += 5u;  // get_1d (light choice), get_2d, get_2d (integrator.rs:378-392)
+            }
+            k++;
+            const uint32_t depth = 31u - (uint32_t)__builtin_clz(h);
+            if (depth + 1u < max_depth) {
+                dim += 2u;                                            // specular_reflect's sampler.get_2d()
+                stack[sp++] = (h << 1) | 1u;                          // after the reflection subtree: the transmission side
+                if (__float_as_uint(dl.le_kind[s * dl.H + 2u * h].w) != DL_EMPTY) stack[sp++] = (2u * h) << 1;
+            }
+        } else {
+            dim += 2u;                                                // specular_transmit's sampler.get_2d()
+            if (__float_as_uint(dl.le_kind[s * dl.H + 2u * h + 1u].w) != DL_EMPTY) stack[sp++] = (2u * h + 1u) << 1;
+        }
+    }
+}
+
+RDEV f2 dl_dims(const RenderDev& rd, uint64_t index, uint32_t d) {
+    return rd.sampler_kind == RSPT_SAMPLER_HALTON ? f2{halton_dim(rd, index, d), halton_dim(rd, index, d + 1u)} : f2{sobol_dim(rd, index, d), sobol_dim(rd, index, d + 1u)};
+}
+
+// one round of estimate_direct (integrator.rs:406-570) for every shading node of a level: light j, element kk of its sample arrays
+// (sample_all), or the one light uniform_sample_one_light picks (j, kk = 0)
+__global__ __launch_bounds__(256) void k_dl_nee(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ pix_list,
+                                                const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in, uint32_t j, uint32_t kk, uint32_t n_j,
+                                                uint32_t n_arrays, uint32_t sample_all, uint32_t* __restrict__ q_any, uint32_t* cnt_any,
+                                                uint32_t* __restrict__ q_mis, uint32_t* cnt_mis) {
+    const uint32_t n = *count_in;
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        bool want_sh = false, want_mis = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            uint32_t fl = 0;
+            if (__float_as_uint(dl.le_kind[slot].w) == DL_SHADING) {
+                const uint32_t s = slot / dl.H;
+                const uint32_t nl = sc.n_lights;
+                // ---- the sample values of this estimate ----
+                f2 u_light, u_scatter;
+                uint32_t light_num = j;
+                float choice_pdf = 1.0f;
+                bool active = true;
+                const uint64_t index = pb.sobol_index[s];
+                if (sample_all) {
+                    const uint32_t pair = dl.kidx[slot] * nl + j;
+                    if (pair < n_arrays / 2u) {  // get_2d_array_idxs -> get_2d_sample (sobol.rs:214-236): element cur_sample * n + kk of arrays 2 pair, 2 pair + 1
+                        const uint32_t pk = pix_list[bt.pix0 + s / bt.ns];
+                        const int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
+                        const uint64_t elem = (uint64_t)(bt.s0 + s % bt.ns) * n_j + kk;
+                        const uint64_t ei = rd.sampler_kind == RSPT_SAMPLER_HALTON ? halton_index(rd, px, py, elem)
+                                                                                  : sobol_interval_to_index(rd, (uint32_t)rd.log2_res, elem, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+                        u_light = dl_dims(rd, ei, 5u + 4u * pair);
+                        u_scatter = dl_dims(rd, ei, 5u + 4u * pair + 2u);
+                    } else if (kk == 0u) {       // a single estimate from the regular stream
+                        const uint32_t pairs = n_arrays / 2u, first = dl.kidx[slot] * nl;
+                        const uint32_t j0 = first >= pairs ? 0u : pairs - first;  // first light of this node without arrays
+                        const uint32_t d = dl.dim[slot] + 4u * (j - j0);
+                        u_light = dl_dims(rd, index, d); u_scatter = dl_dims(rd, index, d + 2u);
+                    } else active = false;
+                } else {                          // uniform_sample_one_light with light_distrib = None (integrator.rs:359-403)
+                    const uint32_t d = dl.dim[slot];
+                    const float u1 = rd.sampler_kind == RSPT_SAMPLER_HALTON ? halton_dim(rd, index, d) : sobol_dim(rd, index, d);
+                    const uint32_t pick = (uint32_t)(u1 * (float)nl);
+                    light_num = pick < nl - 1u ? pick : nl - 1u;
+                    choice_pdf = 1.0f / (float)nl;
+                    u_light = dl_dims(rd, index, d + 1u); u_scatter = dl_dims(rd, index, d + 3u);
+                }
+                if (active) {
+                    const float4 hc = pb.hit_cont[slot];
+                    const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
+                    const float4 r0 = rp[0], r1 = rp[1];
+                    DlHit d;
+                    dl_interaction(sc, pb, slot, __float_as_uint(hc.x), hc, f3{r0.w, r1.x, r1.y}, &d);
+                    const Hit& h = d.h;
+                    const uint32_t flags = BX_ALL & ~BX_SPEC;  // estimate_direct(.., specular = false): bsdf_flags = BsdfAll & !BsdfSpecular (integrator.rs:419-423)
+                    const rspt_light lt = sc.lights[light_num];
+                    rgb c1 = mkrgb(0.0f), c2 = mkrgb(0.0f);
+                    f3 wi{0.0f, 0.0f, 0.0f};
+                    float light_pdf = 0.0f, scattering_pdf = 0.0f;
+                    LightSample ls;
+                    const rgb li = light_sample_li(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
+                    if (light_pdf > 0.0f && !is_black(li)) {
+                        const rgb f = d.bsdf.f(d.wo, wi, flags) * mkrgb(absdot(wi, h.sh_n));
+                        scattering_pdf = d.bsdf.pdf(d.wo, wi, flags);
+                        if (!is_black(f)) {
+                            const f3 origin = offset_ray_origin(h.p, h.p_err, h.n, ls.p - h.p);
+                            const f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
+                            store_ray(pb.ray_sh + slot, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, slot);
+                            want_sh = true;
+                            if (light_is_delta(lt)) c1 = f * li / light_pdf;
+                            else c1 = f * li * mkrgb(power_heuristic(light_pdf, scattering_pdf)) / light_pdf;
+                            fl |= DLF_HAS_C1;
+                        }
+                    }
+                    if (!light_is_delta(lt)) {
+                        uint32_t sampled_type = 0;
+                        rgb f = d.bsdf.sample_f(d.wo, &wi, u_scatter, &scattering_pdf, flags, &sampled_type);
+                        f = f * mkrgb(absdot(wi, h.sh_n));
+                        if (!is_black(f) && scattering_pdf > 0.0f) {
+                            const f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
+                            float lpdf = 0.0f;
+                            rgb le_mis = ldrgb(lt.L);
+                            if (lt.kind == RSPT_LIGHT_INFINITE) {
+                                lpdf = infinite_pdf_li(sc, lt, wi);
+                                if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
+                            } else {
+                                const TriRec lt_tri = load_tri(sc, lt.prim);
+                                float t_l, lb0, lb1, lb2;
+                                if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
+                                    Hit lh;
+                                    tri_fill(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
+                                    lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
+                                    if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+                                }
+                            }
+                            if (lpdf != 0.0f) {
+                                c2 = f * le_mis * mkrgb(1.0f) * power_heuristic(scattering_pdf, lpdf) / scattering_pdf;
+                                if (lt.kind != RSPT_LIGHT_INFINITE || !is_black(le_mis)) {
+                                    store_ray(pb.ray_mis + slot, ro, wi, RSPT_INF, slot);
+                                    want_mis = true;
+                                    fl |= DLF_HAS_C2 | (lt.kind == RSPT_LIGHT_INFINITE ? DLF_C2_ON_MISS : 0u);
+                                }
+                            }
+                        }
+                    }
+                    pb.nee_c1[slot] = make_float4(c1.r, c1.g, c1.b, choice_pdf);
+                    pb.nee_c2[slot] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
+                    fl |= 0x100u;  // an estimate is in flight
+                }
+            }
+            dl.nflags[slot] = fl;
+        }
+        dl_push(want_sh, slot, q_any, cnt_any);
+        dl_push(want_mis, slot | RSPT_Q_MIS, q_mis, cnt_mis);
+    }
+}
+
+// fold the round's estimate into the node, in the reference's order (integrator.rs:309-353)
+__global__ __launch_bounds__(256) void k_dl_nee_resolve(SceneDev sc, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
+                                                        uint32_t j, uint32_t kk, uint32_t n_j, uint32_t n_arrays, uint32_t sample_all) {
+    const uint32_t n = *count_in;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t slot = queue[i];
+        const uint32_t fl = dl.nflags[slot];
+        if (!(fl & 0x100u)) continue;
+        const float4 c1 = pb.nee_c1[slot], c2 = pb.nee_c2[slot];
+        rgb ld = mkrgb(0.0f);
+        if ((fl & DLF_HAS_C1) && pb.occluded[slot] == 0u) ld = ld + rgb{c1.x, c1.y, c1.z};
+        if (fl & DLF_HAS_C2) {
+            const float4 hm = pb.hit_mis[slot];
+            const uint32_t hp = __float_as_uint(hm.x), light_num = __float_as_uint(c2.w);
+            if (fl & DLF_C2_ON_MISS) {
+                if (hp == RSPT_MISS) ld = ld + rgb{c2.x, c2.y, c2.z};
+            } else if (hp != RSPT_MISS) {
+                const TriRec t = load_tri(sc, hp);
+                if (t.area_light >= 0 && (uint32_t)t.area_light == light_num) {
+                    Hit h;
+                    tri_fill(sc, hp, t, hm.y, hm.z, hm.w, &h);
+                    const float4* mr = reinterpret_cast<const float4*>(pb.ray_mis + slot);
+                    const float4 m0 = mr[0], m1 = mr[1];
+                    if (!is_black(light_l(sc.lights[light_num], h.n, -f3{m0.w, m1.x, m1.y}))) ld = ld + rgb{c2.x, c2.y, c2.z};
+                }
+            }
+        }
+        const float4 la = dl.l_all[slot];
+        rgb l = rgb{la.x, la.y, la.z};
+        if (!sample_all) l = l + ld / c1.w;  // estimate_direct(..) / light_pdf
+        else if (dl.kidx[slot] * sc.n_lights + j < n_arrays / 2u) {
+            const float4 a4 = dl.ld_acc[slot];
+            const rgb acc = rgb{a4.x, a4.y, a4.z} + ld;
+            if (kk + 1u == n_j) { l = l + acc / (float)n_j; dl.ld_acc[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            else dl.ld_acc[slot] = make_float4(acc.r, acc.g, acc.b, 0.0f);
+        } else l = l + ld;
+        dl.l_all[slot] = make_float4(l.r, l.g, l.b, 0.0f);
+    }
+}
+
+// li of every node, bottom-up; the root's goes to the camera sample
+__global__ __launch_bounds__(256) void k_dl_gather(Batch bt, PathBuf pb, DlBuf dl, uint32_t n_lights, uint32_t max_depth) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= bt.n) return;
+    for (uint32_t h = dl.H - 1u; h >= 1u; h--) {
+        const uint32_t slot = s * dl.H + h;
+        const float4 lk = dl.le_kind[slot];
+        const uint32_t kind = __float_as_uint(lk.w);
+        if (kind == DL_EMPTY) continue;
+        rgb l = mkrgb(0.0f);
+        if (kind == DL_LEAF) l = rgb{lk.x, lk.y, lk.z};
+        else if (kind == DL_SHADING) {
+            l = l + rgb{lk.x, lk.y, lk.z};                                   // l += isect.le(&wo)
+            if (n_lights) { const float4 la = dl.l_all[slot]; l = l + rgb{la.x, la.y, la.z}; }
+            const uint32_t depth = 31u - (uint32_t)__builtin_clz(h);
+            if (depth + 1u < max_depth) {
+                for (int side = 0; side < 2; side++) {                        // l += specular_reflect(..); l += specular_transmit(..)
+                    const float4 w = side ? dl.w_t[slot] : dl.w_r[slot];
+                    rgb term = mkrgb(0.0f);
+                    const uint32_t child = s * dl.H + 2u * h + (uint32_t)side;
+                    if (__float_as_uint(dl.le_kind[child].w) != DL_EMPTY) {
+                        const float4 lc = dl.l_all[child];
+                        term = rgb{w.x, w.y, w.z} * rgb{lc.x, lc.y, lc.z} * mkrgb(w.w);  // f * self.li(..) * Spectrum::new(|cos| / pdf)
+                    }
+                    l = l + term;
+                }
+            }
+        }
+        dl.l_all[slot] = make_float4(l.r, l.g, l.b, 0.0f);
+    }
+    const float4 root = dl.l_all[s * dl.H + 1u];
+    pb.L_eta[s] = make_float4(root.x, root.y, root.z, 1.0f);
+}
+
+}  // namespace rspt

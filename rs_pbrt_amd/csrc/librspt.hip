@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "trace_w4.h"
 #include "bvh_device.h"
+#include "direct.h"
 
 using namespace rspt;
 
@@ -59,6 +60,9 @@ struct Ctx {
     size_t ovf_cap = 0;
     uint2* spill = nullptr;            // k_trace_w4's stack rows beyond its LDS column (trace_w4.h)
     size_t spill_threads = 0;
+    DlBuf dl{};                        // directlighting: per-node arrays (direct.h) + level queues
+    uint32_t* dl_queue = nullptr;
+    size_t dl_cap = 0;
     uint8_t* bin_keys = nullptr;       // K7b: class of every active-queue entry, the queue sorted by class, per-iteration bin bookkeeping
     uint32_t* q_sorted = nullptr;
     size_t bin_cap = 0;
@@ -225,6 +229,20 @@ int ensure_tex_rows() {
     int rc = dev_alloc(&g.pb.tex, g.cap * RSPT_TEX_ROWS);
     if (rc) return rc;
     g.pb.tex_stride = (uint32_t)g.cap;
+    return RSPT_OK;
+}
+
+int ensure_direct(size_t cap) {
+    if (g.dl_cap >= cap) return RSPT_OK;
+    void* old[] = {g.dl.le_kind, g.dl.w_r, g.dl.w_t, g.dl.l_all, g.dl.ld_acc, g.dl.dim, g.dl.kidx, g.dl.nflags, g.dl.error, g.dl_queue};
+    for (void* p : old) if (p) (void)hipFree(p);
+    g.dl = DlBuf{}; g.dl_queue = nullptr; g.dl_cap = 0;
+    int rc;
+    if ((rc = dev_alloc(&g.dl.le_kind, cap)) || (rc = dev_alloc(&g.dl.w_r, cap)) || (rc = dev_alloc(&g.dl.w_t, cap)) || (rc = dev_alloc(&g.dl.l_all, cap)) ||
+        (rc = dev_alloc(&g.dl.ld_acc, cap)) || (rc = dev_alloc(&g.dl.dim, cap)) || (rc = dev_alloc(&g.dl.kidx, cap)) || (rc = dev_alloc(&g.dl.nflags, cap)) ||
+        (rc = dev_alloc(&g.dl.error, 1)) || (rc = dev_alloc(&g.dl_queue, cap)))
+        return rc;
+    g.dl_cap = cap;
     return RSPT_OK;
 }
 
@@ -446,7 +464,16 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (halton && !d->tables.halton_perms) return fail(RSPT_E_INVALID, "null halton permutation table");
     if (!(d->filter_radius[0] > 0.0f) || !(d->filter_radius[1] > 0.0f)) return fail(RSPT_E_INVALID, "bad filter radius");
     if (d->max_depth > 200) return fail(RSPT_E_UNSUPPORTED, "max_depth > 200");
-    if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO) return fail(RSPT_E_UNSUPPORTED, "integrator %u (path and ao only)", d->integrator);
+    if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO && d->integrator != RSPT_INTEGRATOR_DIRECT)
+        return fail(RSPT_E_UNSUPPORTED, "integrator %u (path, ao and directlighting only)", d->integrator);
+    const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
+    if (direct) {
+        if (d->max_depth < 1 || d->max_depth > 8) return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, 8] (the specular tree has 2^max_depth slots per camera sample)");
+        if (d->direct_strategy > RSPT_DIRECT_SAMPLE_ONE) return fail(RSPT_E_INVALID, "bad direct_strategy");
+        if (s && s->has_textures) return fail(RSPT_E_UNSUPPORTED, "directlighting with textured materials");
+        for (uint32_t i = 0; s && d->n_light_samples && i < s->dev.n_lights; i++)
+            if (d->n_light_samples[i] < 1 || d->n_light_samples[i] > 4096) return fail(RSPT_E_INVALID, "n_light_samples[%u] out of range", i);
+    }
     if (d->integrator == RSPT_INTEGRATOR_AO && (d->ao_n_samples == 0 || d->ao_n_samples > 4096)) return fail(RSPT_E_INVALID, "ao_n_samples must be in [1, 4096]");
     const int32_t* sb = d->sample_bounds;
     const int32_t* cp = d->crop_px;
@@ -501,7 +528,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             HIP_TRY(hipMemcpy(g.primes, primes.data(), 4000, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(g.prime_sums, sums.data(), 4000, hipMemcpyHostToDevice));
         }
-        const uint32_t max_dim = 5u + 8u * (d->max_depth + 2u);  // last dimension a path can consume, with slack
+        uint32_t max_dim = 5u + 8u * (d->max_depth + 2u);  // last dimension a path can consume, with slack
+        if (direct) max_dim = 5u + 4u * d->max_depth * s->dev.n_lights + ((1u << d->max_depth) - 1u) * (4u * s->dev.n_lights + 4u) + 2u;  // arrays + every node on the fall-back stream
         if (max_dim >= 1000u) return fail(RSPT_E_UNSUPPORTED, "max_depth exceeds the 1000 Halton dimensions");
         const uint64_t need = (uint64_t)g.host_prime_sums[max_dim] + g.host_primes[max_dim];
         if (d->tables.n_halton_perms < need) return fail(RSPT_E_INVALID, "halton permutation table has %llu entries, %llu needed for max_depth %u",
@@ -593,13 +621,16 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const bool ao = d->integrator == RSPT_INTEGRATOR_AO;
     const uint32_t ao_n = ao ? d->ao_n_samples : 1u;
     if (ao) cap = std::max<size_t>(cap / ao_n, 1024);
+    const uint32_t dl_H = direct ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h)
+    if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << 26) / dl_H, 1024);
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     size_t pix_per_batch = 1;
     for (;;) {
         ns = 1;
         while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
         pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
-        rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n);
+        rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H);
+        if (rc == RSPT_OK && direct) rc = ensure_direct(g.cap);
         if (rc == RSPT_OK) break;
         (void)hipGetLastError();  // out of memory: clear the sticky error and try half the batch
         free_paths();
@@ -613,7 +644,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const uint32_t max_iters = s->has_null_material ? nominal_iters + (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : nominal_iters;
     // K7b pays when a wave's paths would otherwise run different lobe lists (C3 stand-in, two materials: +4.8 %); with one material
     // its three small kernels and the less regular slot order cost more than the escaped paths they separate (C2: -3.6 %)
-    const bool shade_bins = env_size("RSPT_SHADE_BINS", s->n_materials > 1 ? 1 : 0) != 0 && !ao;
+    const bool shade_bins = env_size("RSPT_SHADE_BINS", s->n_materials > 1 ? 1 : 0) != 0 && !ao && !direct;
     if (shade_bins && (rc = ensure_bins(g.cap, max_iters + 10))) return rc;
     if (s->has_instances && (rc = ensure_hit_inst(g.cap))) return rc;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
@@ -657,6 +688,83 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             if (shade_bins) HIP_TRY(hipMemsetAsync(g.bin_info, 0, (size_t)std::min<uint32_t>(g.n_bin_info, max_iters + 10) * sizeof(BinInfo), g.stream));
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
+            if (direct) {  // DirectLightingIntegrator::li (direct.h): specular tree, dimension assignment, light rounds, gather
+                const uint32_t nl = s->dev.n_lights, H = dl_H, md = d->max_depth;
+                const bool all = d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL;
+                const uint32_t n_arrays = all ? 2u * md * nl : 0u;
+                if (5ull + 2ull * n_arrays + ((1ull << md) - 1ull) * (4ull * nl + 4ull) + 2ull >= 1000ull)  // the reference panics past NUM_SOBOL_DIMENSIONS / the prime table
+                    return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays + the dimension stream of a full specular tree exceed the sampler's dimensions", n_arrays);
+                DlBuf dl = g.dl;
+                dl.H = H;
+                const size_t n_slots = (size_t)bt.n * H;
+                HIP_TRY(hipMemsetAsync(dl.le_kind, 0, n_slots * sizeof(float4), g.stream));
+                HIP_TRY(hipMemsetAsync(dl.l_all, 0, n_slots * sizeof(float4), g.stream));
+                HIP_TRY(hipMemsetAsync(dl.ld_acc, 0, n_slots * sizeof(float4), g.stream));
+                HIP_TRY(hipMemsetAsync(dl.error, 0, sizeof(uint32_t), g.stream));
+                // the camera rays were left in ray_cont[sample]; node slots overlay that array, so move them aside first
+                HIP_TRY(hipMemcpyAsync(g.pb.ray_sh, g.pb.ray_cont, (size_t)bt.n * sizeof(rspt_ray), hipMemcpyDeviceToDevice, g.stream));
+                // counters: g.cnt[level].closest = nodes of the level, .any = re-trace queue; rounds use g.cnt[md + 1 ..]
+                auto level_q = [&](uint32_t l) { return g.dl_queue + (size_t)bt.n * ((1u << l) - 1u); };
+                hipLaunchKernelGGL(k_dl_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, dl, g.pb.ray_sh, level_q(0), &g.cnt[0].closest);
+                const uint32_t dgrid = grid_for(4);
+                for (uint32_t l = 0; l < md; l++) {
+                    const uint32_t* queue = level_q(l);
+                    const uint32_t* qcount = &g.cnt[l].closest;
+                    for (uint32_t round = 0;; round++) {
+                        QueueCounts* rc_ = &g.cnt[md + 1 + (round & 1u)];  // re-trace queue of this round (null-BSDF hits), double buffered
+                        HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
+                        HIP_TRY(hipMemsetAsync((void*)&g.cnt[l].cursor_closest, 0, 3 * sizeof(uint32_t), g.stream));
+                        ev_open(0, 0);
+                        launch_trace<false, 0>(0, false, tgrid, s, queue, qcount, 0, round == 0 ? &g.cnt[l].cursor_closest : &g.cnt[md + 1 + ((round - 1) & 1u)].cursor_closest,
+                                               g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                        ev_close(0, 0);
+                        trace_launches++;
+                        ev_open(2, 0);
+                        hipLaunchKernelGGL(k_dl_hit, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, g.pb, dl, queue, qcount, g.q[round & 1u][0], &rc_->closest,
+                                           level_q(l + 1 < md ? l + 1 : l), &g.cnt[l + 1].closest, l);
+                        ev_close(2, 0);
+                        if (!s->has_null_material) break;
+                        QueueCounts c;
+                        HIP_TRY(hipMemcpyAsync(&c, rc_, sizeof c, hipMemcpyDeviceToHost, g.stream));
+                        HIP_TRY(hipStreamSynchronize(g.stream));
+                        if (c.closest == 0) break;
+                        if (round >= env_size("RSPT_NULL_PASSES", 1024)) { truncated += c.closest; break; }
+                        queue = g.q[round & 1u][0];
+                        qcount = &rc_->closest;
+                    }
+                }
+                hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md);
+                if (nl) {
+                    QueueCounts* rc_ = &g.cnt[md + 3];
+                    for (uint32_t l = 0; l < md; l++) {
+                        const uint32_t n_lights_round = all ? nl : 1u;
+                        for (uint32_t j = 0; j < n_lights_round; j++) {
+                            const uint32_t n_j = all ? (uint32_t)(d->n_light_samples ? d->n_light_samples[j] : 1) : 1u;
+                            for (uint32_t kk = 0; kk < n_j; kk++) {
+                                HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
+                                ev_open(2, 0);
+                                hipLaunchKernelGGL(k_dl_nee, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, j, kk, n_j,
+                                                   n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest);
+                                ev_close(2, 0);
+                                ev_open(1, 0);
+                                launch_trace<true, 0>(0, false, tgrid, s, g.q[0][2], &rc_->any, 0, &rc_->cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                                ev_close(1, 0);
+                                ev_open(0, 0);
+                                launch_trace<false, 0>(0, false, tgrid, s, g.q[0][1], &rc_->closest, 0, &rc_->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                                ev_close(0, 0);
+                                trace_launches += 2;
+                                hipLaunchKernelGGL(k_dl_nee_resolve, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, dl, level_q(l), &g.cnt[l].closest, j, kk, n_j, n_arrays, all ? 1u : 0u);
+                            }
+                        }
+                    }
+                }
+                hipLaunchKernelGGL(k_dl_gather, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, dl, nl, md);
+                uint32_t dl_err = 0;
+                HIP_TRY(hipMemcpyAsync(&dl_err, dl.error, sizeof dl_err, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                if (dl_err) return fail(RSPT_E_UNSUPPORTED, "directlighting: a material with several specular lobes of one kind (the lobe choice would depend on a sample value)");
+                it = md + 4;
+            } else
             if (ao) {  // AOIntegrator::li: closest hit, n shadow rays per hit, sum of the unoccluded terms
                 hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++), e2 = get_event(n_ev++), e3 = get_event(n_ev++);
                 HIP_TRY(hipEventRecord(e0, g.stream));
@@ -939,7 +1047,7 @@ void rspt_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
-    void* ptrs[] = {g.bin_keys, g.q_sorted, g.bin_info, g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
+    void* ptrs[] = {g.dl.le_kind, g.dl.w_r, g.dl.w_t, g.dl.l_all, g.dl.ld_acc, g.dl.dim, g.dl.kidx, g.dl.nflags, g.dl.error, g.dl_queue, g.bin_keys, g.q_sorted, g.bin_info, g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);

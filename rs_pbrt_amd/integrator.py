@@ -7,7 +7,7 @@
 Same names, same defaults as CreatePathIntegrator (src/core/api.rs:285-321: maxdepth 5,
 rrthreshold 1.0, lightsamplestrategy "spatial"), same observable result: render() fills the
 film's pixels (xyz + filter_weight_sum, src/core/film.rs:38-43).  Where the reference panics
-(unknown strategy, no camera) this raises; when the GPU or librspt.so is missing it raises
+(no camera) this raises, where it only warns (an unknown light sample strategy falls back to "spatial") this does the same; when the GPU or librspt.so is missing it raises
 lib.RsptError — there is no CPU loop here."""
 import numpy as np
 
@@ -44,7 +44,7 @@ class PathIntegrator:
         if camera is None:
             raise ValueError("Unable to create camera")  # api.rs:467-483 panics the same way
         if light_sample_strategy not in _STRATEGIES:
-            # create_light_sample_distribution (lightdistrib.rs:393-418) falls back to "spatial" with a warning
+            # an unknown name does not raise: create_light_sample_distribution (lightdistrib.rs:393-418) warns and falls back to "spatial"
             light_sample_strategy = "spatial"
         self.camera = camera
         self.max_depth = int(max_depth)
@@ -92,4 +92,25 @@ class AOIntegrator(PathIntegrator):
         rd = super()._desc(shard)
         rd.integrator = abi.INTEGRATOR_AO
         rd.ao_n_samples, rd.ao_cos_sample = self.n_samples, int(self.cos_sample)
+        return rd
+
+
+class DirectLightingIntegrator(PathIntegrator):
+    """DirectLightingIntegrator::new(strategy, max_depth, camera, sampler, pixel_bounds) (src/integrators/directlighting.rs:38-53), created
+    by the "directlighting" integrator name with defaults strategy "all", maxdepth 5 (api.rs:322-349).  Materials must have been
+    flattened with allow_multiple_lobes = false (scenes.glass(multiple_lobes=False)): `li` calls compute_scattering_functions(ray, false, ..).
+    light_samples: Light::get_n_samples() per light (UniformSampleAll's sample arrays), default 1 each."""
+
+    def __init__(self, strategy="all", max_depth=5, camera=None, sampler=None, pixel_bounds=None, light_samples=None):
+        super().__init__(max_depth=max_depth, camera=camera, sampler=sampler, pixel_bounds=pixel_bounds)
+        if strategy not in ("all", "one"):
+            strategy = "all"  # api.rs:332-341: unknown strategy -> warning, UniformSampleAll
+        self.strategy = strategy
+        self.light_samples = None if light_samples is None else np.ascontiguousarray(light_samples, np.int32)
+
+    def _desc(self, shard=None):
+        rd = super()._desc(shard)
+        rd.integrator = abi.INTEGRATOR_DIRECT
+        rd.direct_strategy = abi.DIRECT_SAMPLE_ALL if self.strategy == "all" else abi.DIRECT_SAMPLE_ONE
+        rd.n_light_samples = self.light_samples.ctypes.data if self.light_samples is not None else None
         return rd

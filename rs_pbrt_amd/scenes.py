@@ -893,10 +893,15 @@ def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs,
 def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_SPATIAL,
                      crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
                      focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
-                     sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True):
+                     sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True, direct_strategy="all", light_samples=None):
     rd = abi.RenderDesc()
-    # Integrator "path" (path.rs) or "ao" / "ambientocclusion" (api.rs:411; ao.rs: nsamples 64, cossample true)
-    rd.integrator = abi.INTEGRATOR_AO if integrator == "ao" else abi.INTEGRATOR_PATH
+    # Integrator "path" (path.rs), "ao" / "ambientocclusion" (api.rs:411; ao.rs: nsamples 64, cossample true) or
+    # "directlighting" (api.rs:322-349: strategy "all" | "one", maxdepth 5; light_samples = Light::get_n_samples per light)
+    rd.integrator = {"ao": abi.INTEGRATOR_AO, "directlighting": abi.INTEGRATOR_DIRECT}.get(integrator, abi.INTEGRATOR_PATH)
+    rd.direct_strategy = {"all": abi.DIRECT_SAMPLE_ALL, "one": abi.DIRECT_SAMPLE_ONE}[direct_strategy]
+    if light_samples is not None:
+        rd._light_samples = np.ascontiguousarray(light_samples, np.int32)  # kept alive by the desc object
+        rd.n_light_samples = rd._light_samples.ctypes.data
     rd.ao_n_samples, rd.ao_cos_sample = int(ao_samples), int(bool(ao_cos_sample))
     rd.full_res[:] = (xres, yres)
     # Film::new film.rs:187-196
@@ -936,7 +941,11 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
         rd.spp = s
     rd.max_depth, rd.rr_threshold, rd.light_strategy, rd.tile_size = max_depth, rr_threshold, light_strategy, 16
     rd.shard_index, rd.shard_count, rd.tile_chunk = shard
-    rd.tables = sobol_tables().as_struct(halton_permutations(5 + 8 * (max_depth + 3)) if sampler == "halton" else None)
+    n_halton_dims = 5 + 8 * (max_depth + 3)
+    if integrator == "directlighting":  # sample arrays + a full specular tree on the fall-back stream (rs_pbrt_amd/csrc/direct.h)
+        nl = len(light_samples) if light_samples is not None else 16
+        n_halton_dims = min(999, 5 + 4 * max_depth * nl + ((1 << max_depth) - 1) * (4 * nl + 4) + 4)
+    rd.tables = sobol_tables().as_struct(halton_permutations(n_halton_dims) if sampler == "halton" else None)
     return rd
 
 
