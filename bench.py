@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--instancing", default="reference", choices=["reference", "fixed"], help="c5: what a hit inside an object instance is (rspt_scene_desc.instancing_mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 line and the 1/8-frame probe")
     ap.add_argument("--no-count", action="store_true", help="skip the reference-order counting pass (no roofline block): for PMC runs")
@@ -80,9 +81,9 @@ def build_workload(args, workload, lib, scenes):
     elif workload == "c5":
         xres, spp = args.res or 1920, args.spp or 64
         yres = xres * 9 // 16
-        sc = scenes.landscape_standin(lib.bvh_build_gpu)
+        sc = scenes.landscape_standin(lib.bvh_build_gpu, instancing=args.instancing)
         mk = lambda s, sh, **kw: scenes.landscape_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=integ, **kw)  # noqa: E731
-        name = "landscape stand-in (instanced trees + lat-long sky, C5 stand-in), path depth 5, sobol %d spp, %dx%d" % (spp, xres, yres)
+        name = "landscape stand-in (4096 instances of a 10 k-triangle tree + lat-long sky; DECLARED STAND-IN for the off-tree Landscape scene; instancing mode %s), path depth 5, sobol %d spp, %dx%d" % (args.instancing, spp, xres, yres)
     else:
         xres, spp = args.res or 1920, args.spp or 1024
         yres = xres * 9 // 16
@@ -286,6 +287,7 @@ def main():
                                        "host memory: + 16 B per pixel D2H once per frame (%.1f MB), not included" % (
                                            " on rank 0 after the reduce" if world > 1 else "", scenes.n_pixels(m["rd"]) * 16 / 1e6)},
             "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote) if m["counts"] else None,
+            "stats": {k: sum(s_[k] for s_ in stats) / len(stats) for k in ("t_trace_closest_s", "t_trace_any_s", "t_trace_s", "t_shade_s", "t_kernels_s", "trace_launches", "truncated_paths", "nan_samples")},
             "setup_s": {"scene_and_bvh_build": m["t_scene"], "upload": m["t_upload"], "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }
         pyoracle = None

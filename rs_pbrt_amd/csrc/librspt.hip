@@ -401,6 +401,15 @@ int get_light_dist(rspt_scene_s* s, uint32_t strategy, LightDistDev* out, const 
 }
 
 bool trace_can_overflow(const rspt_scene_s* s);
+// upper bound of the queue lengths of the launches that follow, when the host knows one (the null-surface tail of a render looks at
+// its queue every 8th iteration and the queues only shrink): a few hundred paths do not need 1280 persistent workgroups each copying
+// the root-side records into LDS
+uint32_t g_queue_hint = 0xffffffffu;
+uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
+    if (g_queue_hint == 0xffffffffu) return full;
+    const uint64_t need = (2ull * g_queue_hint + per_block - 1) / per_block + 1;
+    return (uint32_t)std::min<uint64_t>(full, need);
+}
 
 // kernel choice: the persistent-wave kernel (trace_wide.h) unless RSPT_TRACE_KERNEL=0 or the
 // reference-order node / triangle counters are wanted (only k_trace counts them)
@@ -417,7 +426,8 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
     hipStream_t stream = lane ? g.stream2 : g.stream;
     uint32_t* ovf = g.ovf + (lane ? 2 * g.ovf_cap / 3 : 0);
     uint2* spill = g.spill + (lane ? g.spill_threads * RSPT_W4_SPILL : 0);
-    if (s->has_instances) {  // two-level traversal: the reference-order loop (the persistent four-box kernel serves scenes without instances)
+    const bool inst_slow = s->has_instances && (count || which == 0 || !s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0);
+    if (inst_slow) {  // two-level traversal by the reference-order loop: counters, or RSPT_INSTANCE_KERNEL=0
         uint32_t* hi = (OUT_MODE == 0 && !ANY) ? g.hit_inst : nullptr;
         if (count)
             hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
@@ -426,17 +436,25 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
         return;
     }
     if (!count && which != 0) {
-        const uint32_t pgrid = pw_grid();
+        const uint32_t pgrid = hinted_grid(pw_grid(), RSPT_PW_BLOCK);
+        grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
         uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
         const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
+        uint32_t* hi = (OUT_MODE == 0 && !ANY) ? g.hit_inst : nullptr;
+        if (s->has_instances) {  // the four-box kernel with the instance switch; overflowing rays (stack beyond LDS + spill rows) go to the two-level fix-up
+            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, true>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi);
+            hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
+            return;
+        }
         if (which >= 2 && s->w4_ok)
-            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top);
+            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, false>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, (uint32_t*)nullptr);
         else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
         // with every spill row in use the four-box kernel cannot overflow (RSPT_W4_MAX_STACK): no second pass to launch
-        if (trace_can_overflow(s)) hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits);
+        if (trace_can_overflow(s)) hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits, (uint32_t*)nullptr);
         return;
     }
     if (count)
@@ -449,7 +467,7 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
 bool trace_can_overflow(const rspt_scene_s* s) {
     const size_t which = env_size("RSPT_TRACE_KERNEL", 2);
     const size_t rows = std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
-    return !(which >= 2 && s->w4_ok) || RSPT_W4_LDS + rows < RSPT_W4_MAX_STACK;
+    return s->has_instances || !(which >= 2 && s->w4_ok) || RSPT_W4_LDS + rows < RSPT_W4_MAX_STACK;  // (two stacked aggregates + leaf continuations can pass the bound)
 }
 uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PER_CU", 5)); }
 
@@ -688,6 +706,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             if (shade_bins) HIP_TRY(hipMemsetAsync(g.bin_info, 0, (size_t)std::min<uint32_t>(g.n_bin_info, max_iters + 10) * sizeof(BinInfo), g.stream));
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
+            g_queue_hint = 0xffffffffu;
             if (direct) {  // DirectLightingIntegrator::li (direct.h): specular tree, dimension assignment, light rounds, gather
                 const uint32_t nl = s->dev.n_lights, H = dl_H, md = d->max_depth;
                 const bool all = d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL;
@@ -812,20 +831,20 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 trace_launches += it > 0 ? 2 : 1;
                 ev_open(2, 0);
                 if (shade_bins) {  // K7b: whole waves of one class for k_shade
-                    const uint32_t bgrid = grid_for(4);
+                    const uint32_t bgrid = hinted_grid(grid_for(4), 256);
                     hipLaunchKernelGGL(k_bin_count, dim3(bgrid), dim3(256), 0, g.stream, s->dev, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it]);
                     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, g.stream, &g.bin_info[it], g.q_sorted);
                     hipLaunchKernelGGL(k_bin_scatter, dim3(bgrid), dim3(256), 0, g.stream, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it], g.q_sorted);
                 }
                 if (ld_lazy && d->integrator == RSPT_INTEGRATOR_PATH) {
-                    const uint32_t lgrid = grid_for(4);
+                    const uint32_t lgrid = hinted_grid(grid_for(4), 256);
                     hipLaunchKernelGGL(k_ld_mark, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], ld_lazy->lazy, ld_lazy->new_list);
                     hipLaunchKernelGGL(k_ld_contrib_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld.nvox[0], ld.nvox[1], ld.nvox[2], ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func);
                     hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
                     hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
                 }
                 if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it]);
-                hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
+                hipLaunchKernelGGL(k_shade, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                    g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
                                    shade_bins ? g.q_sorted : (const uint32_t*)nullptr, shade_bins ? &g.bin_info[it] : (const BinInfo*)nullptr);
                 ev_close(2, 0);
@@ -838,6 +857,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
                 HIP_TRY(hipStreamSynchronize(g.stream));
                 if (c.active == 0 && c.active_tail == 0) break;
+                g_queue_hint = c.active + c.active_tail;
                 if (it >= max_iters) {  // the reference's loop would still be running (path.rs:109-116 has no limit); these paths keep the radiance gathered so far
                     truncated += c.active + c.active_tail;
                     if (getenv("RSPT_VERBOSE") && c.active) {  // where the endless paths are: slot, film position and the ray in flight
@@ -862,6 +882,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
         }
     }
+    g_queue_hint = 0xffffffffu;
     float4* out_dev = film_dev ? (float4*)film_dev : g.film_out;
     hipLaunchKernelGGL(k_film_resolve, dim3((uint32_t)((film_px + 255) / 256)), dim3(256), 0, g.stream, g.film_own, g.film_splat, out_dev, (uint32_t)film_px);
     if (d->film_reduce) {  // X1: sum of the ranks' films onto rank 0 (a sum, not a gather: tile pixel bounds overlap, film.rs:321-330)
@@ -1367,78 +1388,32 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     } else {
         for (int i = 0; i < 3; i++) { s->dev.wb_min[i] = RSPT_FLT_MAX; s->dev.wb_max[i] = -RSPT_FLT_MAX; }  // Bounds3f::default
     }
-    if (d->n_prims) {
-        float4* tris = nullptr;
-        hipError_t e = hipMalloc((void**)&tris, d->n_prims * 3 * sizeof(float4));
-        if (e != hipSuccess) return bail(fail(RSPT_E_NOMEM, "triangle records: %s", hipGetErrorString(e)));
-        s->allocs.push_back(tris);
-        hipLaunchKernelGGL(k_build_tris, dim3((uint32_t)((d->n_prims + 255) / 256)), dim3(256), 0, g.stream, s->dev.prims, meshes_d, P_d, (uint32_t)d->n_prims, tris, (const uint32_t*)nullptr);
-        e = hipStreamSynchronize(g.stream);
-        if (e != hipSuccess) return bail(fail(RSPT_E_HIP, "k_build_tris: %s", hipGetErrorString(e)));
-        s->dev.tris = tris;
-    }
-    if (instanced) {  // InstDev records
-        std::vector<InstDev> ins(d->n_instances);
-        for (uint32_t i = 0; i < d->n_instances; i++) {
-            const rspt_instance& in = d->instances[i];
-            const rspt_object& o = d->objects[in.object];
-            InstDev& x = ins[i];
-            memset(&x, 0, sizeof x);
-            memcpy(x.m, in.to_world, sizeof x.m);
-            memcpy(x.mi, in.from_world, sizeof x.mi);
-            x.root_node = o.n_nodes ? (uint32_t)o.first_node : RSPT_MISS;
-            x.first_prim = (uint32_t)o.first_prim;
-            x.w4_root = RSPT_MISS;
-            bool ident = true;  // Transform::is_identity looks at m only (transform.rs:291-308)
-            for (int r = 0; r < 4; r++)
-                for (int c = 0; c < 4; c++) ident &= in.to_world[4 * r + c] == (r == c ? 1.0f : 0.0f);
-            x.identity = ident ? 1u : 0u;
-        }
-        if ((rc = upload(s, ins.data(), ins.size(), &s->dev.inst))) return bail(rc);
-        s->dev.n_inst = d->n_instances;
-        s->dev.inst_fixed = d->instancing_mode == RSPT_INSTANCING_FIXED ? 1u : 0u;
-    }
-    if (d->n_nodes > 1 && !instanced) {  // pair records: both children's boxes next to each other (trace_wide.h)
-        std::vector<uint32_t> pair_of(d->n_nodes, 0u);
-        uint32_t n_pairs = 0;
-        for (uint64_t i = 0; i < d->n_nodes; i++)
-            if (d->nodes[i].n_prims == 0) pair_of[i] = n_pairs++;
-        std::vector<PairNode> pairs(n_pairs);
-        for (uint64_t i = 0; i < d->n_nodes; i++) {
-            const rspt_bvh_node& n = d->nodes[i];
-            if (n.n_prims != 0) continue;
-            const uint32_t ci[2] = {(uint32_t)i + 1u, (uint32_t)n.offset};
-            const rspt_bvh_node& a = d->nodes[ci[0]];
-            const rspt_bvh_node& b = d->nodes[ci[1]];
-            PairNode& p = pairs[pair_of[i]];
-            p.q0 = make_float4(a.bmin[0], b.bmin[0], a.bmax[0], b.bmax[0]);
-            p.q1 = make_float4(a.bmin[1], b.bmin[1], a.bmax[1], b.bmax[1]);
-            p.q2 = make_float4(a.bmin[2], b.bmin[2], a.bmax[2], b.bmax[2]);
-            p.c0 = a.n_prims ? (ci[0] | RSPT_REF_LEAF) : pair_of[ci[0]];
-            p.c1 = b.n_prims ? (ci[1] | RSPT_REF_LEAF) : pair_of[ci[1]];
-            p.self = (uint32_t)i;
-            p.axis = n.axis;
-        }
-        if ((rc = upload(s, pairs.data(), pairs.size(), &s->pairs))) return bail(rc);
-    }
-    if (d->n_nodes > 0 && !instanced) {  // four-box records (trace_w4.h): grandchildren of every interior node at even depth
+    // ---- four-box records (trace_w4.h): grandchildren of every interior node at even depth; with object instances every object's
+    // aggregate gets its own records behind the top-level ones, and every instance primitive the reference to the rest of its leaf ----
+    std::vector<uint32_t> obj_root(d->n_objects, RSPT_NONE), inst_cont_h(d->n_instances, RSPT_NONE);
+    if (d->n_nodes > 0) {
         std::vector<uint2> big;
-        auto leaf_ref = [&](uint32_t ni) -> uint32_t {
-            const rspt_bvh_node& n = d->nodes[ni];
-            const uint32_t off = (uint32_t)n.offset, cnt = n.n_prims;
+        auto range_ref = [&](uint32_t off, uint32_t cnt) -> uint32_t {
             if (cnt <= 15u && off <= RSPT_W4_OFFSET_MASK) return RSPT_REF_LEAF | ((cnt - 1u) << RSPT_W4_COUNT_SHIFT) | off;
             big.push_back(make_uint2(off, cnt));
             return RSPT_REF_LEAF | (15u << RSPT_W4_COUNT_SHIFT) | (uint32_t)(big.size() - 1);
         };
-        std::vector<Wide4Node> recs;
-        if (d->nodes[0].n_prims != 0) {
-            s->w4_root = leaf_ref(0);
-        } else {
+        auto leaf_ref = [&](uint32_t ni) -> uint32_t {
+            const rspt_bvh_node& n = d->nodes[ni];
+            if (instanced && ni < n_top_nodes)  // an instance in this leaf: the primitives behind it are reached again through its continuation reference
+                for (uint32_t i = 0; i + 1u < n.n_prims; i++) {
+                    const rspt_prim& p = d->prims[(uint32_t)n.offset + i];
+                    if (p.mesh == RSPT_MESH_INSTANCE) inst_cont_h[p.v[0]] = range_ref((uint32_t)n.offset + i + 1u, n.n_prims - i - 1u);
+                }
+            return range_ref((uint32_t)n.offset, n.n_prims);
+        };
+        // the records of the tree rooted at LinearBVHNode `root` (an interior node), depth first, with record-local indices
+        auto build_tree = [&](uint32_t root, std::vector<Wide4Node>& recs, std::vector<uint32_t>& rec_axes) {
             const float qnan = std::numeric_limits<float>::quiet_NaN();
-            std::vector<std::pair<uint32_t, uint32_t>> todo;  // (LinearBVHNode index, record index); records in depth-first order
-            std::vector<uint32_t> rec_axes(1, 0u);
+            std::vector<std::pair<uint32_t, uint32_t>> todo;  // (LinearBVHNode index, record index)
+            recs.clear(); rec_axes.assign(1, 0u);
             recs.emplace_back();
-            todo.emplace_back(0u, 0u);
+            todo.emplace_back(root, 0u);
             while (!todo.empty()) {
                 const auto [ai, ri] = todo.back();
                 todo.pop_back();
@@ -1480,35 +1455,109 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                 rec_axes[ri] = axes;
                 recs[ri] = w;
             }
+        };
+        // final form of a record: child indices through `new_of` (+ base), the three axes in bits 25..26 of the first three refs (an
+        // empty slot has a NaN box, its ref is never read as a ref)
+        auto finish_rec = [&](Wide4Node w, uint32_t axes, const std::vector<uint32_t>* new_of, uint32_t base) {
+            for (int k = 0; k < 4; k++)
+                if (w.ref[k] != RSPT_NONE && !(w.ref[k] & RSPT_REF_LEAF)) w.ref[k] = (new_of ? (*new_of)[w.ref[k]] : w.ref[k]) + base;
+            for (int k = 0; k < 3; k++) w.ref[k] = (w.ref[k] & ~RSPT_W4_AXIS_MASK) | (((axes >> (2 * k)) & 3u) << RSPT_W4_AXIS_SHIFT);
+            return w;
+        };
+        std::vector<Wide4Node> recs, local;
+        std::vector<uint32_t> axes;
+        if (d->nodes[0].n_prims != 0) {
+            s->w4_root = leaf_ref(0);
+        } else {
+            build_tree(0u, local, axes);
             // Renumber: a breadth-first prefix of RSPT_W4_TOP records goes first (k_trace_w4 keeps those in LDS), the others
-            // keep their depth-first order.  Then the three axes move into bits 25..26 of the first three refs (an
-            // empty slot has a NaN box, its ref is never read as a ref).
-            std::vector<uint32_t> new_of(recs.size(), RSPT_NONE), order(1, 0u);
+            // keep their depth-first order.
+            std::vector<uint32_t> new_of(local.size(), RSPT_NONE), order(1, 0u);
             for (size_t h = 0; h < order.size() && order.size() < RSPT_W4_TOP; h++)
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t r = recs[order[h]].ref[k];
+                    const uint32_t r = local[order[h]].ref[k];
                     if (r != RSPT_NONE && !(r & RSPT_REF_LEAF) && order.size() < RSPT_W4_TOP) order.push_back(r);
                 }
             for (size_t i = 0; i < order.size(); i++) new_of[order[i]] = (uint32_t)i;
             uint32_t next_index = (uint32_t)order.size();
-            for (size_t i = 0; i < recs.size(); i++)
+            for (size_t i = 0; i < local.size(); i++)
                 if (new_of[i] == RSPT_NONE) new_of[i] = next_index++;
-            std::vector<Wide4Node> renumbered(recs.size());
-            for (size_t i = 0; i < recs.size(); i++) {
-                Wide4Node w = recs[i];
-                for (int k = 0; k < 4; k++)
-                    if (w.ref[k] != RSPT_NONE && !(w.ref[k] & RSPT_REF_LEAF)) w.ref[k] = new_of[w.ref[k]];
-                for (int k = 0; k < 3; k++) w.ref[k] = (w.ref[k] & ~RSPT_W4_AXIS_MASK) | (((rec_axes[i] >> (2 * k)) & 3u) << RSPT_W4_AXIS_SHIFT);
-                renumbered[new_of[i]] = w;
-            }
-            recs.swap(renumbered);
+            recs.resize(local.size());
+            for (size_t i = 0; i < local.size(); i++) recs[new_of[i]] = finish_rec(local[i], axes[i], &new_of, 0u);
             s->w4_top = (uint32_t)order.size();
             s->w4_root = 0u;
+        }
+        for (uint32_t o = 0; instanced && o < d->n_objects; o++) {
+            const rspt_object& ob = d->objects[o];
+            if (ob.n_nodes == 0) obj_root[o] = range_ref((uint32_t)ob.first_prim, 1u);                       // a lone primitive: no box, no aggregate
+            else if (d->nodes[ob.first_node].n_prims != 0) obj_root[o] = leaf_ref((uint32_t)ob.first_node);  // a one-leaf aggregate
+            else {
+                build_tree((uint32_t)ob.first_node, local, axes);
+                const uint32_t base = (uint32_t)recs.size();
+                for (size_t i = 0; i < local.size(); i++) recs.push_back(finish_rec(local[i], axes[i], nullptr, base));
+                obj_root[o] = base;
+            }
         }
         // record indices and big-leaf indices must leave bits 25..30 free; larger scenes stay on the two-box kernel
         s->w4_ok = recs.size() <= RSPT_W4_OFFSET_MASK && big.size() <= RSPT_W4_OFFSET_MASK;
         if (s->w4_ok && !recs.empty() && (rc = upload(s, recs.data(), recs.size(), &s->w4))) return bail(rc);
         if (!big.empty() && (rc = upload(s, big.data(), big.size(), &s->big_leaves))) return bail(rc);
+    }
+    if (d->n_prims) {
+        float4* tris = nullptr;
+        hipError_t e = hipMalloc((void**)&tris, d->n_prims * 3 * sizeof(float4));
+        if (e != hipSuccess) return bail(fail(RSPT_E_NOMEM, "triangle records: %s", hipGetErrorString(e)));
+        s->allocs.push_back(tris);
+        const uint32_t* inst_cont_d = nullptr;
+        if ((rc = upload(s, inst_cont_h.data(), inst_cont_h.size(), &inst_cont_d))) return bail(rc);
+        hipLaunchKernelGGL(k_build_tris, dim3((uint32_t)((d->n_prims + 255) / 256)), dim3(256), 0, g.stream, s->dev.prims, meshes_d, P_d, (uint32_t)d->n_prims, tris, inst_cont_d);
+        e = hipStreamSynchronize(g.stream);
+        if (e != hipSuccess) return bail(fail(RSPT_E_HIP, "k_build_tris: %s", hipGetErrorString(e)));
+        s->dev.tris = tris;
+    }
+    if (instanced) {  // InstDev records
+        std::vector<InstDev> ins(d->n_instances);
+        for (uint32_t i = 0; i < d->n_instances; i++) {
+            const rspt_instance& in = d->instances[i];
+            const rspt_object& o = d->objects[in.object];
+            InstDev& x = ins[i];
+            memset(&x, 0, sizeof x);
+            memcpy(x.m, in.to_world, sizeof x.m);
+            memcpy(x.mi, in.from_world, sizeof x.mi);
+            x.root_node = o.n_nodes ? (uint32_t)o.first_node : RSPT_MISS;
+            x.first_prim = (uint32_t)o.first_prim;
+            x.w4_root = obj_root[in.object];
+            bool ident = true;  // Transform::is_identity looks at m only (transform.rs:291-308)
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) ident &= in.to_world[4 * r + c] == (r == c ? 1.0f : 0.0f);
+            x.identity = ident ? 1u : 0u;
+        }
+        if ((rc = upload(s, ins.data(), ins.size(), &s->dev.inst))) return bail(rc);
+        s->dev.n_inst = d->n_instances;
+        s->dev.inst_fixed = d->instancing_mode == RSPT_INSTANCING_FIXED ? 1u : 0u;
+    }
+    if (d->n_nodes > 1 && !instanced) {  // pair records: both children's boxes next to each other (trace_wide.h)
+        std::vector<uint32_t> pair_of(d->n_nodes, 0u);
+        uint32_t n_pairs = 0;
+        for (uint64_t i = 0; i < d->n_nodes; i++)
+            if (d->nodes[i].n_prims == 0) pair_of[i] = n_pairs++;
+        std::vector<PairNode> pairs(n_pairs);
+        for (uint64_t i = 0; i < d->n_nodes; i++) {
+            const rspt_bvh_node& n = d->nodes[i];
+            if (n.n_prims != 0) continue;
+            const uint32_t ci[2] = {(uint32_t)i + 1u, (uint32_t)n.offset};
+            const rspt_bvh_node& a = d->nodes[ci[0]];
+            const rspt_bvh_node& b = d->nodes[ci[1]];
+            PairNode& p = pairs[pair_of[i]];
+            p.q0 = make_float4(a.bmin[0], b.bmin[0], a.bmax[0], b.bmax[0]);
+            p.q1 = make_float4(a.bmin[1], b.bmin[1], a.bmax[1], b.bmax[1]);
+            p.q2 = make_float4(a.bmin[2], b.bmin[2], a.bmax[2], b.bmax[2]);
+            p.c0 = a.n_prims ? (ci[0] | RSPT_REF_LEAF) : pair_of[ci[0]];
+            p.c1 = b.n_prims ? (ci[1] | RSPT_REF_LEAF) : pair_of[ci[1]];
+            p.self = (uint32_t)i;
+            p.axis = n.axis;
+        }
+        if ((rc = upload(s, pairs.data(), pairs.size(), &s->pairs))) return bail(rc);
     }
     *out = s;
     return RSPT_OK;

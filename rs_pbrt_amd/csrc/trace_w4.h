@@ -105,13 +105,19 @@ RDEVN bool box_hit6_m(float lx, float ly, float lz, float hx, float hy, float hz
     return (t_min < ray_tmax) && (t_max > 0.0f);
 }
 
-template <bool ANY, int OUT_MODE>
+// INST (scenes with object instances): a leaf primitive may be a TransformedPrimitive (primitive.rs:216-265).  The lane
+// then pushes the reference to the rest of that leaf, switches to the instance's object-space ray (Transform::transform_ray with
+// m_inv), runs the object's own records on top of the same stack, and on coming back down to that stack level reloads the world
+// ray from its queue record.  t_max is carried over as the reference does (r.t_max.set(ray.t_max), quirks Q10 / Q11 in kernels.h
+// traverse<>).  Without INST the code is the one measured in DESIGN.md (the flag is a template parameter, not a branch).
+template <bool ANY, int OUT_MODE, bool INST>
 __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
                                                            rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, uint32_t* __restrict__ overflow_list,
-                                                           uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh, uint32_t n_top) {
+                                                           uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh, uint32_t n_top,
+                                                           uint32_t* __restrict__ out_inst) {
     __shared__ uint2 stack[RSPT_W4_LDS * RSPT_PW_BLOCK];
     uint2* my = stack + threadIdx.x;
 #if RSPT_W4_TOP > 0
@@ -153,9 +159,16 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
     uint32_t sp = 0, cur = RSPT_NONE, leaf = RSPT_NONE;
     uint32_t best = RSPT_MISS, entry = 0, qpos = 0;
     float bt = 0.0f, bb0 = 0.0f, bb1 = 0.0f, bb2 = 0.0f;
+    // INST: instance being traversed, stack level at which its traversal ends, 1 + instance of the best hit, the world ray's t_max at
+    // entry, BVHAccel::intersect's `hit` flag of the top-level aggregate, "the object reported a hit"
+    uint32_t inst = RSPT_NONE, sp_base = 0, best_inst = 0;
+    float w_tmax = 0.0f;
+    bool hitflag = false, inst_hit = false;
 
     auto finish = [&]() {
         uint32_t slot = entry & ~RSPT_Q_MIS;
+        if (INST && !ANY && !hitflag && best != RSPT_RETRACE) { best = RSPT_MISS; best_inst = 0; bt = bb0 = bb1 = bb2 = 0.0f; }  // `hit`, not "isect was written" (Q10)
+        if (INST && !ANY && OUT_MODE == 0 && !(entry & RSPT_Q_MIS) && out_inst) out_inst[slot] = best_inst;
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = best == RSPT_RETRACE ? 2u : (best != RSPT_MISS ? 1u : 0u);
             else ((entry & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(best), bb0, bb1, bb2);
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                     rs = ray_shear(d);
                     best = RSPT_MISS; bt = bb0 = bb1 = bb2 = 0.0f;
                     sp = 0; cur = RSPT_NONE; leaf = RSPT_NONE;
+                    if (INST) { inst = RSPT_NONE; sp_base = 0; best_inst = 0; hitflag = false; inst_hit = false; }
                     active = true;
                     // the root's own box (bvh.rs:424 on node 0)
                     if (box_hit(root0, root1, f3{ox, oy, oz}, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max)) {
@@ -223,7 +237,22 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                 // pop; entries that a closer hit has meanwhile culled are skipped at once (a few per iteration)
 #pragma unroll 1
                 for (int tries = 0; tries < RSPT_W4_POP_TRIES; tries++) {
-                    if (sp == 0) {
+                    if (sp == sp_base) {
+                        if (INST && inst != RSPT_NONE) {  // the object's traversal is over: back to world space (primitive.rs:224-253)
+                            const InstDev& in = sc.inst[inst];
+                            if (inst_hit) { if (sc.inst_fixed || !in.identity) hitflag = true; }
+                            else t_max = w_tmax;
+                            const float4* rp = reinterpret_cast<const float4*>(((entry & RSPT_Q_MIS) ? rays_b : rays_a) + (entry & ~RSPT_Q_MIS));
+                            const float4 r0 = rp[0], r1 = rp[1];
+                            ox = r0.x; oy = r0.y; oz = r0.z;
+                            const f3 d{r0.w, r1.x, r1.y};
+                            ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
+                            negbits = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
+                            if (!(fabsf(ix) < RSPT_INF && fabsf(iy) < RSPT_INF && fabsf(iz) < RSPT_INF)) negbits |= 8u;
+                            rs = ray_shear(d);
+                            inst = RSPT_NONE; sp_base = 0;
+                            break;  // the next pop finds the rest of the instance's leaf (if any), then the world-space entries
+                        }
                         finish();
                         break;
                     }
@@ -329,11 +358,53 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                     for (uint32_t i = 0; i < n_prims; i++) {
                         uint32_t pi = offset + i;
                         float4 a = sc.tris[3 * (size_t)pi], b = sc.tris[3 * (size_t)pi + 1], c = sc.tris[3 * (size_t)pi + 2];
+                        if (INST && (__float_as_uint(c.w) & MF_INSTANCE)) {  // TransformedPrimitive::intersect / intersect_p
+                            const uint32_t cont = __float_as_uint(a.y);
+                            if (cont != RSPT_NONE) {  // the rest of this leaf waits on the stack below the object's entries; -inf: it is always due
+                                if (sp >= RSPT_W4_LDS + spill_rows) {
+                                    best = RSPT_RETRACE;
+                                    overflow_list[atomicAdd(n_overflow, 1u)] = OUT_MODE == 0 ? entry : qpos;
+                                    finish();
+                                    break;
+                                }
+                                if (sp < RSPT_W4_LDS) {
+                                    my[sp * RSPT_PW_BLOCK] = make_uint2(cont, 0xff800000u);
+                                    asm volatile("");
+                                } else
+                                    my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride] = make_uint2(cont, 0xff800000u);
+                                sp++;
+                            }
+                            inst = __float_as_uint(a.x);
+                            const InstDev& in = sc.inst[inst];
+                            const float4* rp = reinterpret_cast<const float4*>(((entry & RSPT_Q_MIS) ? rays_b : rays_a) + (entry & ~RSPT_Q_MIS));
+                            const float4 r0 = rp[0], r1 = rp[1];
+                            f3 no, nd;
+                            w_tmax = t_max; sp_base = sp; inst_hit = false;
+                            inst_ray(in, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, t_max, &no, &nd, &t_max);
+                            ox = no.x; oy = no.y; oz = no.z;
+                            ix = 1.0f / nd.x; iy = 1.0f / nd.y; iz = 1.0f / nd.z;
+                            negbits = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
+                            if (!(fabsf(ix) < RSPT_INF && fabsf(iy) < RSPT_INF && fabsf(iz) < RSPT_INF)) negbits |= 8u;
+                            rs = ray_shear(nd);
+                            if (in.root_node == RSPT_MISS) leaf = in.w4_root;  // a lone GeometricPrimitive: no box test (api.rs:3046)
+                            else {                                            // the object aggregate's node 0 (bvh.rs:424)
+                                const float4 q0 = sc.nodes[2 * (size_t)in.root_node], q1 = sc.nodes[2 * (size_t)in.root_node + 1];
+                                if (box_hit(q0, q1, no, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max)) {
+                                    if (in.w4_root & RSPT_REF_LEAF) leaf = in.w4_root;
+                                    else cur = in.w4_root;
+                                }
+                            }
+                            break;
+                        }
                         float t, b0, b1, b2;
-                        if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, o, rs, t_max, &t, &b0, &b1, &b2)) {
+                        if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, INST ? f3{ox, oy, oz} : o, rs, t_max, &t, &b0, &b1, &b2)) {
                             if (ANY) { best = 0; break; }
                             t_max = t;       // primitive.rs:155: later pops compare their t_min with this
                             best = pi; bt = t; bb0 = b0; bb1 = b1; bb2 = b2;
+                            if (INST) {
+                                if (inst != RSPT_NONE) { best_inst = inst + 1u; inst_hit = true; }
+                                else { best_inst = 0; hitflag = true; }
+                            }
                         }
                     }
                     if (ANY && best != RSPT_MISS) finish();

@@ -286,11 +286,11 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
 // Second pass for the rays whose stack outgrew the persistent kernel's LDS column (their queue entries
 // were appended to overflow_list): the 64-entry reference-order loop (kernels.h traverse<>).
 // Returns at once when no ray overflowed (the common case).
-template <bool ANY, int OUT_MODE>
+template <bool ANY, int OUT_MODE, bool INST>
 __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, const uint32_t* __restrict__ n_overflow, const uint32_t* __restrict__ overflow_list,
                                                                   const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                                   float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
-                                                                  rspt_hit* __restrict__ out_hits) {
+                                                                  rspt_hit* __restrict__ out_hits, uint32_t* __restrict__ out_inst) {
     __shared__ uint32_t stack[RSPT_LDS_STACK * RSPT_TRACE_BLOCK];
     const uint32_t n = *n_overflow;
     for (uint32_t i = blockIdx.x * RSPT_TRACE_BLOCK + threadIdx.x; i < n; i += gridDim.x * RSPT_TRACE_BLOCK) {
@@ -299,10 +299,13 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, c
         const bool mis = OUT_MODE == 0 && (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
-        TraceResult res = traverse<ANY, false>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        TraceResult res = traverse<ANY, INST>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
-            else (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+            else {
+                (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+                if (INST && !mis && out_inst) out_inst[slot] = res.inst;
+            }
         } else {
             rspt_hit h;
             h.prim = res.prim; h.t = res.t; h.b0 = res.b0; h.b1 = res.b1; h.b2 = res.b2;
