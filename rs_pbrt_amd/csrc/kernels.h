@@ -661,12 +661,17 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t* __restrict_
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t k = i < n ? keys[i] : RSPT_BIN_K;
+        if (threadIdx.x < 4 * RSPT_BIN_K) (&s_cnt[0][0])[threadIdx.x] = 0u;
+        __syncthreads();
+        // rank of this lane among the wave's lanes of the same class: one ballot per class that is present (a wave rarely holds more than three)
         uint32_t rank = 0;
-#pragma unroll 1
-        for (uint32_t c = 0; c < RSPT_BIN_K; c++) {  // wave-level rank of this lane inside its class
+        uint64_t todo = __ballot(k < RSPT_BIN_K);
+        while (todo) {
+            const uint32_t c = (uint32_t)__shfl((int)k, (int)__builtin_ctzll(todo));
             const uint64_t m = __ballot(k == c);
             if (k == c) rank = (uint32_t)__popcll(m & lt);
-            if (lane == 0) s_cnt[wave][c] = (uint32_t)__popcll(m);
+            if (lane == (uint32_t)__builtin_ctzll(todo)) s_cnt[wave][c] = (uint32_t)__popcll(m);
+            todo &= ~m;
         }
         __syncthreads();
         if (threadIdx.x < RSPT_BIN_K) {

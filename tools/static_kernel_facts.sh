@@ -1,6 +1,6 @@
 #!/bin/bash
 # Register / LDS / scratch budget and the instruction mix of the final kernels, from the compiler (no GPU needed):
-# writes profiles/r01_static_kernel_facts.md.  usage: tools/static_kernel_facts.sh
+# writes profiles/r02_static_kernel_facts.md.  usage: tools/static_kernel_facts.sh
 set -eu
 repo=$(cd "$(dirname "$0")/.." && pwd); work=$(mktemp -d)
 F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -I$repo/include --cuda-device-only"
