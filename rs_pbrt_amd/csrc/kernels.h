@@ -652,37 +652,43 @@ __global__ void k_bin_starts(BinInfo* bi, uint32_t* __restrict__ q_sorted) {  //
         if (idx < ((c + 63u) & ~63u)) q_sorted[start[k] + idx] = RSPT_BIN_INVALID;
     }
 }
+#define RSPT_BIN_E 8  // queue entries per thread and round of k_bin_scatter: one global atomic per class per 2048 entries (its round trip is what a round waits for)
 __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt_in, const uint8_t* __restrict__ keys,
                                                      BinInfo* bi, uint32_t* __restrict__ q_sorted) {
-    __shared__ uint32_t s_cnt[4][RSPT_BIN_K], s_base[RSPT_BIN_K];
+    __shared__ uint32_t s_cnt[RSPT_BIN_E * 4][RSPT_BIN_K], s_base[RSPT_BIN_K];
     const uint32_t n = cnt_in->active;
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t k = i < n ? keys[i] : RSPT_BIN_K;
-        if (threadIdx.x < 4 * RSPT_BIN_K) (&s_cnt[0][0])[threadIdx.x] = 0u;
+    for (uint32_t base = blockIdx.x * (256u * RSPT_BIN_E); base < n; base += gridDim.x * (256u * RSPT_BIN_E)) {
+        for (uint32_t t = threadIdx.x; t < RSPT_BIN_E * 4 * RSPT_BIN_K; t += 256u) (&s_cnt[0][0])[t] = 0u;
         __syncthreads();
-        // rank of this lane among the wave's lanes of the same class: one ballot per class that is present (a wave rarely holds more than three)
-        uint32_t rank = 0;
-        uint64_t todo = __ballot(k < RSPT_BIN_K);
-        while (todo) {
-            const uint32_t c = (uint32_t)__shfl((int)k, (int)__builtin_ctzll(todo));
-            const uint64_t m = __ballot(k == c);
-            if (k == c) rank = (uint32_t)__popcll(m & lt);
-            if (lane == (uint32_t)__builtin_ctzll(todo)) s_cnt[wave][c] = (uint32_t)__popcll(m);
-            todo &= ~m;
+        uint32_t key[RSPT_BIN_E], rank[RSPT_BIN_E];
+#pragma unroll
+        for (uint32_t j = 0; j < RSPT_BIN_E; j++) {  // slice j: entries base + 256 j + thread (coalesced); rank inside (slice, wave, class)
+            const uint32_t i = base + 256u * j + threadIdx.x;
+            const uint32_t k = i < n ? keys[i] : RSPT_BIN_K;
+            uint32_t r = 0;
+            uint64_t todo = __ballot(k < RSPT_BIN_K);
+            while (todo) {  // one ballot per class present in the wave (rarely more than three)
+                const uint32_t c = (uint32_t)__shfl((int)k, (int)__builtin_ctzll(todo));
+                const uint64_t m = __ballot(k == c);
+                if (k == c) r = (uint32_t)__popcll(m & lt);
+                if (lane == (uint32_t)__builtin_ctzll(todo)) s_cnt[4u * j + wave][c] = (uint32_t)__popcll(m);
+                todo &= ~m;
+            }
+            key[j] = k; rank[j] = r;
         }
         __syncthreads();
-        if (threadIdx.x < RSPT_BIN_K) {
-            const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
-            s_base[threadIdx.x] = tot ? atomicAdd(&bi->cursor[threadIdx.x], tot) : 0u;
+        if (threadIdx.x < RSPT_BIN_K) {  // exclusive prefix over (slice, wave) per class, then one atomic for the class
+            uint32_t run = 0;
+            for (uint32_t u = 0; u < RSPT_BIN_E * 4; u++) { const uint32_t c = s_cnt[u][threadIdx.x]; s_cnt[u][threadIdx.x] = run; run += c; }
+            s_base[threadIdx.x] = run ? bi->start[threadIdx.x] + atomicAdd(&bi->cursor[threadIdx.x], run) : 0u;
         }
         __syncthreads();
-        if (k < RSPT_BIN_K) {
-            uint32_t off = bi->start[k] + s_base[k] + rank;
-            for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][k];
-            q_sorted[off] = q_active[i];
+#pragma unroll
+        for (uint32_t j = 0; j < RSPT_BIN_E; j++) {
+            const uint32_t i = base + 256u * j + threadIdx.x;
+            if (key[j] < RSPT_BIN_K) q_sorted[s_base[key[j]] + s_cnt[4u * j + wave][key[j]] + rank[j]] = q_active[i];
         }
         __syncthreads();
     }

@@ -660,9 +660,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // on them); the loop below runs until no path is left, and a scene that needs more than RSPT_NULL_PASSES extra iterations is
     // reported, not silently truncated
     const uint32_t max_iters = s->has_null_material ? nominal_iters + (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : nominal_iters;
-    // K7b pays when a wave's paths would otherwise run different lobe lists (C3 stand-in, two materials: +4.8 %); with one material
-    // its three small kernels and the less regular slot order cost more than the escaped paths they separate (C2: -3.6 %)
-    const bool shade_bins = env_size("RSPT_SHADE_BINS", s->n_materials > 1 ? 1 : 0) != 0 && !ao && !direct;
+    // K7b: whole waves of one class (escaped | depth limit | material) for k_shade.  C3 stand-in (two materials): 1396 -> 1686 Msamples/s;
+    // C2 (one material: only the escaped paths are separated): 423 -> 425
+    const bool shade_bins = env_size("RSPT_SHADE_BINS", 1) != 0 && !ao && !direct;
     if (shade_bins && (rc = ensure_bins(g.cap, max_iters + 10))) return rc;
     if (s->has_instances && (rc = ensure_hit_inst(g.cap))) return rc;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
