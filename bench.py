@@ -231,6 +231,10 @@ def main():
     import torch.distributed as dist
     from rs_pbrt_amd import lib, multigpu, scenes
     torch.cuda.set_device(local_rank)
+    # one RCCL per process: librspt binds the copy torch has already mapped (rspt_comm_* dlopen it by this path)
+    torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(torch_rccl):
+        os.environ.setdefault("RSPT_RCCL_LIB", torch_rccl)
     lib.init(local_rank)
     reduce_in_lib, torch_reduce, reduce_name = False, None, "none (1 GPU)"
     if world > 1:
