@@ -37,8 +37,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--integrator", default="path", choices=["path", "ao"],
-                    help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample)")
+    ap.add_argument("--integrator", default="path", choices=["path", "ao", "directlighting"],
+                    help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample); directlighting: DirectLightingIntegrator, strategy all, maxdepth 5")
     ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
@@ -169,7 +169,15 @@ def time_steps(step, fence, n):
 def cpu_baseline(args, pyoracle, sc, mk_rd, spp, one_thread_crop):
     ncores = os.cpu_count() or 1
     rd_cpu = mk_rd(spp, (0, 1, 64))
-    r = pyoracle.render(sc, rd_cpu, threads=ncores)
+    def cpu_render(rd_, threads):
+        if args.integrator != "directlighting":
+            return pyoracle.render(sc, rd_, threads=threads)
+        t0 = time.perf_counter()  # the oracle's recursive_li (directlighting.rs), strategy all, one sample per light
+        r_ = pyoracle.render_integrator(sc, rd_, "direct", threads=threads)
+        r_["seconds"] = time.perf_counter() - t0
+        return r_
+
+    r = cpu_render(rd_cpu, ncores)
     c = r["counters"]
     out = {"value": c["samples"] / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
            "sample": "same scene and frame at %d spp (%d samples), C++ oracle restatement of rs_pbrt's tile loop (rs_pbrt itself cannot be built "
@@ -180,7 +188,7 @@ def cpu_baseline(args, pyoracle, sc, mk_rd, spp, one_thread_crop):
                                           "alg_bytes": (32.0 * c["nodes_visited"] + 48.0 * c["tris_tested"] + 96.0 * c["rays_closest"] + 72.0 * c["rays_any"]
                                                         + 96.0 * c["bounces"] + 32.0 * c["samples"]) / c["samples"]}}
     rd1 = mk_rd(spp, (0, 1, 64), crop=one_thread_crop)
-    r1 = pyoracle.render(sc, rd1, threads=1)
+    r1 = cpu_render(rd1, 1)
     out["one_thread"] = {"value": r1["counters"]["samples"] / r1["seconds"] / 1e6, "unit": "Msamples/s",
                          "sample": "crop window %s of the frame at %d spp (%d samples), 1 thread, %.1f s" % (list(rd1.crop_px), spp, r1["counters"]["samples"], r1["seconds"])}
     out["thread_scaling"] = out["value"] / out["one_thread"]["value"]
