@@ -273,7 +273,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    shard = multigpu.shard_for_rank(rank, world)  # contiguous Morton chunks of 64 tiles, round-robin over ranks
+    shard = multigpu.shard_for_rank(rank, world)  # Morton-ordered tiles dealt round-robin over the ranks
     m = measure(args, lib, scenes, args.workload, args.steps, args.warmup, shard, world, reduce_in_lib, torch_reduce, fence)
     elapsed, stats = m["elapsed"], m["stats"]
     if world > 1:
@@ -293,7 +293,7 @@ def main():
             "metric": "Mpath-samples/sec (whole node)", "value": samples_per_step * args.steps / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": m["name"], "samples_per_step": samples_per_step, "tiles": "16x16 Morton, chunks of 64 dealt round-robin",
+            "config": {"workload": m["name"], "samples_per_step": samples_per_step, "tiles": "16x16 tiles in Morton order dealt round-robin to the ranks (tile_chunk %d)" % multigpu.TILE_CHUNK,
                        "film_reduce": reduce_name,
                        "timed_region": "rspt_render_device per step: first launch -> film complete in HBM%s; SURVEY 8(d)'s t_render ends with the film in "
                                        "host memory: + 16 B per pixel D2H once per frame (%.1f MB), not included" % (
@@ -311,18 +311,23 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, pyoracle, m["sc"], m["mk_rd"], args.cpu_spp, ((cx - 24) / fx, (cx + 24) / fx, (cy - 24) / fy, (cy + 24) / fy))
         if world == 1 and not args.no_extra and args.workload == "soup1m" and default_cfg:
             extra = {}
-            # what one rank of an 8-GPU node renders: shard (0, 8, 64) of the same frame, same kernels, no reduce
-            rd8 = m["mk_rd"](m["spp"], (0, 8, 64))
-            lib.render_device(m["ds"], rd8, m["film"].data_ptr())
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            st8 = [lib.render_device(m["ds"], rd8, m["film"].data_ptr()) for _ in range(3)]
-            torch.cuda.synchronize()
-            t8 = (time.perf_counter() - t0) / 3
-            t1 = elapsed / args.steps
-            extra["eighth_frame_probe"] = {"ms": t8 * 1e3, "samples": st8[0]["samples"], "full_frame_ms": t1 * 1e3,
-                                           "predicted_8gpu_speedup_before_reduce": t1 / t8,
-                                           "note": "one GPU rendering shard (0, 8, 64) of the headline frame: per-rank time of an 8-GPU run without the 16.8 MB reduce"}
+            # what the ranks of an 8-GPU node render: every shard (r, 8, tile_chunk) of the same frame on this one GPU, same kernels, no reduce;
+            # the slowest shard bounds the 8-GPU frame time (static deal of interleaved Morton chunks: how even is it?)
+            shard_ms = []
+            for r in range(8):
+                rd8 = m["mk_rd"](m["spp"], multigpu.shard_for_rank(r, 8))
+                if r == 0:
+                    lib.render_device(m["ds"], rd8, m["film"].data_ptr())  # warm-up (allocations sized for the shard)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st8 = [lib.render_device(m["ds"], rd8, m["film"].data_ptr()) for _ in range(2)]
+                torch.cuda.synchronize()
+                shard_ms.append((time.perf_counter() - t0) / 2 * 1e3)
+            t1 = elapsed / args.steps * 1e3
+            extra["eighth_frame_probe"] = {"ms": shard_ms[0], "samples": st8[0]["samples"], "full_frame_ms": t1, "shard_ms": shard_ms,
+                                           "predicted_8gpu_speedup_before_reduce": t1 / max(shard_ms),
+                                           "imbalance_max_over_mean": max(shard_ms) / (sum(shard_ms) / 8),
+                                           "note": "one GPU rendering each shard (r, 8, tile_chunk) of the headline frame in turn: per-rank times of an 8-GPU run without the 16.8 MB reduce"}
             m["ds"].close()
             del m
             # C3: the north-star configuration (>= 100x CPU on the 4.3 M-triangle scene), timed by the same harness

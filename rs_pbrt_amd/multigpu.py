@@ -1,10 +1,12 @@
 """Multi-GPU decomposition of one frame: the Morton-ordered 16x16 tile list of
 BlockQueue (src/blockqueue/mod.rs:23-52) is cut into chunks of TILE_CHUNK tiles that are dealt to
-the ranks round-robin; every rank renders its tiles into a full-frame film (zero elsewhere) and the
+the ranks round-robin (TILE_CHUNK = 1: tile by tile — measured on one GPU rendering the 8 shards in turn, tools/c5_shard_balance.py:
+chunks of 64 / 16 / 4 / 1 tiles give max / mean shard times of 1.16 / 1.08 / 1.02 / 1.01 on C2 and 1.14 / 1.09 / 1.05 / 1.01 on the
+C5 stand-in, at the same mean); every rank renders its tiles into a full-frame film (zero elsewhere) and the
 films are SUMMED onto rank 0 — a sum, not a gather, because neighbouring tiles' pixel bounds
 overlap (film.rs:321-330).  One process per GPU; torch.distributed is only the transport
 (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests)."""
-TILE_CHUNK = 64
+TILE_CHUNK = 1
 
 
 def shard_for_rank(rank, world_size, tile_chunk=TILE_CHUNK):

@@ -247,7 +247,7 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
         lens_radius: cam.lens_radius, focal_distance: cam.focal_distance, shutter_open: cam.shutter_open, shutter_close: cam.shutter_close,
         sampler_kind, spp, max_depth, rr_threshold,
         light_strategy: match strategy.as_str() { "uniform" => 0, "power" => 1, _ => 2 },    // lightdistrib.rs:393-418 falls back to spatial
-        tile_size: 16, shard_index: rank, shard_count: world, tile_chunk: 64, sample_at_pixel_center: at_center,
+        tile_size: 16, shard_index: rank, shard_count: world, tile_chunk: 1, sample_at_pixel_center: at_center,
         integrator: integrator_kind, ao_n_samples: ao_n, ao_cos_sample: ao_cos, film_reduce: (world > 1) as u32,
         tables: RsptSamplerTables { sobol32: SOBOL_MATRICES_32.as_ptr(), vdc: vdc.as_ptr(), vdc_inv: vdc_inv.as_ptr(),
                                     halton_perms: RADICAL_INVERSE_PERMUTATIONS.as_ptr(), n_halton_perms: RADICAL_INVERSE_PERMUTATIONS.len() as u64 },

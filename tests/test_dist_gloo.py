@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_for_rank():
-    assert multigpu.shard_for_rank(0, 1) == (0, 1, 64)
-    assert multigpu.shard_for_rank(3, 8) == (3, 8, 64)
+    assert multigpu.shard_for_rank(0, 1) == (0, 1, multigpu.TILE_CHUNK)
+    assert multigpu.shard_for_rank(3, 8) == (3, 8, multigpu.TILE_CHUNK) and multigpu.shard_for_rank(3, 8, 64) == (3, 8, 64)
     with pytest.raises(ValueError):
         multigpu.shard_for_rank(2, 2)
 
