@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 12
+#define RSPT_ABI_VERSION 13
 
 /* error codes */
 #define RSPT_OK 0
@@ -68,6 +68,11 @@ typedef struct {
 typedef struct {
     uint32_t has_n, has_s, has_uv;
     uint32_t flip; /* reverse_orientation ^ transform_swaps_handedness (triangle.rs:324) */
+    /* TriangleMesh.alpha_mask / shadow_alpha_mask (triangle.rs:39-40; "alpha" / "shadowalpha" shape parameters, api.rs:1920-1965):
+     * 0, or 1 + index of a float texture (its first channel).  A candidate hit where the texture evaluates to exactly 0 — at the hit's
+     * uv / p, without ray differentials — is no hit: Triangle::intersect tests alpha_mask (triangle.rs:313-330), Triangle::intersect_p
+     * both (:593-655).  Meshes that emit light may not carry masks (the pdf of a light's own triangle would need them). */
+    uint32_t alpha_tex, shadow_alpha_tex;
 } rspt_mesh;
 
 /* ---- materials: pre-assembled BxDF lists ------------------------------------------
@@ -408,6 +413,14 @@ int rspt_render_samples(rspt_scene_t scene, const rspt_render_desc* desc, float*
  * 0xffffffff if not; other fields 0. */
 int rspt_trace(rspt_scene_t scene, const rspt_ray* rays, uint64_t n, rspt_hit* out,
                int any_hit);
+
+/* Stage-level hook.  Replaces: LightDistribution::lookup(p) (src/core/lightdistrib.rs:33-39) of the distribution
+ * create_light_sample_distribution(strategy) builds (:393-418; "uniform" is forced for a single light): the Distribution1D the path
+ * integrator samples a light from at point p — func_out[n_lights], cdf_out[n_lights + 1] (sampling.rs:24-49), and for the spatial
+ * strategy the voxel grid's resolution in nvox_out[3] (else 1 1 1) and p's voxel in voxel_out[3].  Spatial voxels that are built on
+ * demand are built by this call. */
+int rspt_light_distribution(rspt_scene_t scene, uint32_t light_strategy, const float p[3], float* func_out, float* cdf_out,
+                            int32_t nvox_out[3], int32_t voxel_out[3]);
 
 /* Benchmark hook: same as rspt_trace on rays already resident in device memory,
  * repeated `repeat` times; returns average kernel milliseconds per launch. */

@@ -193,6 +193,10 @@ struct Interaction {
     }
 };
 
+struct Scene;
+// Texture::evaluate of float texture `ti` at an interaction (orc_texture.hpp): TriangleMesh.alpha_mask / shadow_alpha_mask
+static inline Float alpha_texture_value(const Scene& sc, uint32_t ti, const Interaction& si);
+
 struct Scene {
     rspt_scene_desc d;
     Bounds3 world_bound() const { // bvh.rs:394-400
@@ -330,10 +334,41 @@ struct Scene {
         isect->prim = -1;
     }
 
+    // the alpha tests of Triangle::intersect (triangle.rs:313-330: alpha_mask only) and ::intersect_p (:593-655: both masks, and the
+    // degenerate-triangle rejection that only exists on that branch): false = the candidate is no hit
+    bool alpha_pass(const rspt_prim& pr, const Ray& ray, const Float b[3], bool shadow) const {
+        const rspt_mesh& m = d.meshes[pr.mesh];
+        if (!m.alpha_tex && !(shadow && m.shadow_alpha_tex)) return true;
+        V3 p0 = P(pr.v[0]), p1 = P(pr.v[1]), p2 = P(pr.v[2]);
+        P2 uv[3]; get_uvs(pr, uv);
+        P2 duv02{uv[0].x - uv[2].x, uv[0].y - uv[2].y}, duv12{uv[1].x - uv[2].x, uv[1].y - uv[2].y};
+        V3 dp02 = p0 - p2, dp12 = p1 - p2;
+        Float determinant = duv02.x * duv12.y - duv02.y * duv12.x;
+        bool degenerate_uv = std::fabs(determinant) < 1e-8f;
+        V3 dpdu{0, 0, 0}, dpdv{0, 0, 0};
+        if (!degenerate_uv) {
+            Float invdet = 1.0f / determinant;
+            dpdu = (dp02 * duv12.y - dp12 * duv02.y) * invdet;
+            dpdv = (dp02 * -duv12.x + dp12 * duv02.x) * invdet;
+        }
+        if (degenerate_uv || length_squared(cross(dpdu, dpdv)) == 0.0f) {
+            V3 ng = cross(p2 - p0, p1 - p0);
+            if (shadow && length_squared(ng) == 0.0f) return false; // triangle.rs:617-621 (intersect_p only)
+            coordinate_system(normalize(ng), &dpdu, &dpdv);
+        }
+        Interaction local; // SurfaceInteraction::new(p_hit, 0, uv_hit, wo, dpdu, dpdv, 0, 0, time): no differentials
+        local.p = p0 * b[0] + p1 * b[1] + p2 * b[2];
+        local.uv = P2{uv[0].x * b[0] + uv[1].x * b[1] + uv[2].x * b[2], uv[0].y * b[0] + uv[1].y * b[1] + uv[2].y * b[2]};
+        local.wo = -ray.d; local.dpdu = dpdu; local.dpdv = dpdv;
+        if (m.alpha_tex && alpha_texture_value(*this, m.alpha_tex - 1u, local) == 0.0f) return false;
+        if (shadow && m.shadow_alpha_tex && alpha_texture_value(*this, m.shadow_alpha_tex - 1u, local) == 0.0f) return false;
+        return true;
+    }
     // Triangle::intersect (triangle.rs:134-449)
     bool tri_intersect(const rspt_prim& pr, const Ray& ray, Float* t_hit, Interaction* isect, Float bout[3] = nullptr) const {
         Float b[3], t;
         if (!tri_hit_test(pr, ray, &t, b)) return false;
+        if (!alpha_pass(pr, ray, b, false)) return false;
         tri_fill(pr, ray, b, isect);
         *t_hit = t;
         if (bout) { bout[0] = b[0]; bout[1] = b[1]; bout[2] = b[2]; }
@@ -481,7 +516,7 @@ struct Scene {
             return o.n_nodes ? bvh_intersect_p((uint32_t)o.first_node, r2, c) : prim_intersect_p((uint32_t)o.first_prim, r2, c);
         }
         Float t, b[3];
-        return tri_hit_test(pr, ray, &t, b);
+        return tri_hit_test(pr, ray, &t, b) && alpha_pass(pr, ray, b, true);
     }
     // ---- TransformedPrimitive::intersect: primitive.rs:216-253 (static transform: interpolate() returns start_transform) ----
     bool transformed_intersect(uint32_t k, const Ray& r, Interaction* isect, Counters* c, Float* t_out, Float* b_out) const {

@@ -376,4 +376,6 @@ static inline void bump(const Scene& sc, uint32_t ti, Interaction* si) {
     si->sh_dpdu = dpdu; si->sh_dpdv = dpdv;
 }
 
+static inline Float alpha_texture_value(const Scene& sc, uint32_t ti, const Interaction& si) { return tex_eval(sc, ti, si).c[0]; }
+
 } // namespace orc

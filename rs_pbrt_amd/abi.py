@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -35,7 +35,7 @@ class Prim(C.Structure):
 
 
 class Mesh(C.Structure):
-    _fields_ = [("has_n", C.c_uint32), ("has_s", C.c_uint32), ("has_uv", C.c_uint32), ("flip", C.c_uint32)]
+    _fields_ = [("has_n", C.c_uint32), ("has_s", C.c_uint32), ("has_uv", C.c_uint32), ("flip", C.c_uint32), ("alpha_tex", C.c_uint32), ("shadow_alpha_tex", C.c_uint32)]
 
 
 class Bxdf(C.Structure):
@@ -130,7 +130,7 @@ import numpy as np  # noqa: E402
 
 NODE_DT = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_prims", "<u2"), ("axis", "u1"), ("pad", "u1")])
 PRIM_DT = np.dtype([("v", "<u4", 3), ("mesh", "<u4"), ("material", "<u4"), ("area_light", "<i4")])
-MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4")])
+MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4"), ("alpha_tex", "<u4"), ("shadow_alpha_tex", "<u4")])
 BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
                     ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4"),
                     ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4"), ("tex_ax", "<u4"), ("tex_ay", "<u4"), ("remap", "<u4")])

@@ -8,6 +8,7 @@ namespace rspt {
 #define RSPT_MISS 0xffffffffu
 // mesh flag bits packed into the 48-byte triangle record
 enum : uint32_t { MF_HAS_N = 1, MF_HAS_S = 2, MF_HAS_UV = 4, MF_FLIP = 8,
+                  MF_ALPHA = 16,          // the mesh has an alpha_mask or a shadow_alpha_mask (triangle.rs:39-40)
                   MF_INSTANCE = 0x100 };  // the record stands for a TransformedPrimitive: t0.x = instance index, t0.y = the four-box kernel's
                                           // reference to the primitives that follow it in its leaf (RSPT_NONE: it is the last one)
 
@@ -42,6 +43,7 @@ struct SceneDev {
     uint32_t n_nodes, n_prims, n_lights, n_infinite;
     float wb_min[3], wb_max[3];  // BVHAccel::world_bound = nodes[0].bounds (bvh.rs:394-400)
     const uint8_t* mat_flags;    // per material: RSPT_MAT_TEXTURED | RSPT_MAT_BUMP (dev_texture.h); nullptr = no textures in the scene
+    const rspt_mesh* meshes;     // per-mesh flags and alpha-mask textures (alpha tests only)
     const InstDev* inst;         // object instances; nullptr = none
     uint32_t n_inst;
     uint32_t inst_fixed;         // RSPT_INSTANCING_FIXED: instanced hits keep their primitive (material)

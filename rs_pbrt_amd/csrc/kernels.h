@@ -134,6 +134,44 @@ RDEV bool box_hit(float4 n0, float4 n1, f3 o, f3 inv, bool ng0, bool ng1, bool n
     return (t_min < ray_tmax) && (t_max > 0.0f);
 }
 
+// The alpha tests of Triangle::intersect (triangle.rs:313-330: alpha_mask) and Triangle::intersect_p (:593-655: alpha_mask and
+// shadow_alpha_mask, plus the degenerate-triangle rejection that exists only on that branch).  Called for a candidate that passed the
+// watertight test on a mesh with MF_ALPHA; the texture is evaluated at the hit's p / uv without ray differentials
+// (SurfaceInteraction::new).  false = no hit, and the ray's t_max stays as it was.
+template <bool SHADOW>
+__device__ __noinline__ bool alpha_pass(const SceneDev& sc, const TexTables& tt, uint32_t pi, f3 p0, f3 p1, f3 p2, float b0, float b1, float b2) {
+    const rspt_prim pr = sc.prims[pi];
+    const rspt_mesh m = sc.meshes[pr.mesh];
+    if (!m.alpha_tex && !(SHADOW && m.shadow_alpha_tex)) return true;
+    f2 uv0{0.0f, 0.0f}, uv1{1.0f, 0.0f}, uv2{1.0f, 1.0f};  // triangle.rs:97-112
+    if (m.has_uv && sc.UV) {
+        uv0 = f2{sc.UV[2 * (size_t)pr.v[0]], sc.UV[2 * (size_t)pr.v[0] + 1]};
+        uv1 = f2{sc.UV[2 * (size_t)pr.v[1]], sc.UV[2 * (size_t)pr.v[1] + 1]};
+        uv2 = f2{sc.UV[2 * (size_t)pr.v[2]], sc.UV[2 * (size_t)pr.v[2] + 1]};
+    }
+    if (SHADOW) {  // "the triangle is actually degenerate; the intersection is bogus" (triangle.rs:611-621)
+        const f2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
+        const f3 dp02 = p0 - p2, dp12 = p1 - p2;
+        const float det = duv02.x * duv12.y - duv02.y * duv12.x;
+        const bool degenerate = fabsf(det) < 1e-8f;
+        f3 dpdu{0.0f, 0.0f, 0.0f}, dpdv{0.0f, 0.0f, 0.0f};
+        if (!degenerate) {
+            const float invdet = 1.0f / det;
+            dpdu = (dp02 * duv12.y - dp12 * duv02.y) * invdet;
+            dpdv = (dp02 * -duv12.x + dp12 * duv02.x) * invdet;
+        }
+        if ((degenerate || len2(cross(dpdu, dpdv)) == 0.0f) && len2(cross(p2 - p0, p1 - p0)) == 0.0f) return false;
+    }
+    TexSurf su;
+    su.p = p0 * b0 + p1 * b1 + p2 * b2;
+    su.uv = f2{uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2};
+    su.dudx = su.dvdx = su.dudy = su.dvdy = 0.0f;
+    su.dpdx = su.dpdy = f3{0.0f, 0.0f, 0.0f};
+    if (m.alpha_tex && tex_eval(tt, m.alpha_tex - 1u, su).r == 0.0f) return false;
+    if (SHADOW && m.shadow_alpha_tex && tex_eval(tt, m.shadow_alpha_tex - 1u, su).r == 0.0f) return false;
+    return true;
+}
+
 struct TraceResult {
     uint32_t prim;
     float t, b0, b1, b2;
@@ -149,8 +187,8 @@ struct TraceResult {
 // the walk returns to the remaining primitives of the leaf.  Quirks Q10 / Q11 are reproduced unless
 // sc.inst_fixed: an identity instance shrinks t_max without reporting its hit, and its interaction survives only if some
 // other primitive of the top-level aggregate reports a hit (`hit` below is BVHAccel::intersect's flag, `res` its isect).
-template <bool ANY, bool INST>
-RDEV TraceResult traverse(const SceneDev& sc, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */) {
+template <bool ANY, bool INST, bool ALPHA>
+RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */) {
     TraceResult res;
     res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0;
     if (sc.n_nodes == 0) return res;
@@ -184,6 +222,7 @@ RDEV TraceResult traverse(const SceneDev& sc, f3 o, f3 d, float t_max, uint32_t*
             }
             float t, b0, b1, b2;
             if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, o, rs, t_max, &t, &b0, &b1, &b2)) {
+                if (ALPHA && (__float_as_uint(c.w) & MF_ALPHA) && !alpha_pass<ANY>(sc, tt, pi, f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, b0, b1, b2)) continue;
                 if (ANY) { res.prim = 0; return res; }
                 t_max = t;  // GeometricPrimitive::intersect shrinks the ray (primitive.rs:155)
                 res.prim = pi; res.t = t; res.b0 = b0; res.b1 = b1; res.b2 = b2;
@@ -236,8 +275,8 @@ RDEV TraceResult traverse(const SceneDev& sc, f3 o, f3 d, float t_max, uint32_t*
 // out_mode 0: float4 (prim, b0, b1, b2) into hit_cont/hit_mis by slot; 1: rspt_hit AoS by queue
 // position (stage hook); ANY: occluded[slot] (mode 0) or rspt_hit.prim (mode 1).
 // out_inst (INST, closest hit, continuation rays only): 0 or 1 + instance of the hit, by slot
-template <bool ANY, int OUT_MODE, bool COUNT, bool INST>
-__global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
+template <bool ANY, int OUT_MODE, bool COUNT, bool INST, bool ALPHA>
+__global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTables tt, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
                                                             uint32_t count_imm, const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                             float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
                                                             rspt_hit* __restrict__ out_hits, unsigned long long* __restrict__ counters, uint32_t* __restrict__ out_inst) {
@@ -253,7 +292,7 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, const u
         bool mis = (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
-        TraceResult res = traverse<ANY, INST>(sc, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        TraceResult res = traverse<ANY, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
             else {
@@ -1093,7 +1132,8 @@ __global__ void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mes
     }
     rspt_mesh m = meshes[pr.mesh];
     f3 p0 = ld3(P, pr.v[0]), p1 = ld3(P, pr.v[1]), p2 = ld3(P, pr.v[2]);
-    uint32_t flags = (m.has_n ? MF_HAS_N : 0u) | (m.has_s ? MF_HAS_S : 0u) | (m.has_uv ? MF_HAS_UV : 0u) | (m.flip ? MF_FLIP : 0u);
+    uint32_t flags = (m.has_n ? MF_HAS_N : 0u) | (m.has_s ? MF_HAS_S : 0u) | (m.has_uv ? MF_HAS_UV : 0u) | (m.flip ? MF_FLIP : 0u) |
+                     ((m.alpha_tex || m.shadow_alpha_tex) ? MF_ALPHA : 0u);
     tris[3 * (size_t)i] = make_float4(p0.x, p0.y, p0.z, p1.x);
     tris[3 * (size_t)i + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
     tris[3 * (size_t)i + 2] = make_float4(p2.z, __uint_as_float(pr.material), __uint_as_float((uint32_t)pr.area_light), __uint_as_float(flags));

@@ -160,6 +160,7 @@ struct rspt_scene_s {
     std::vector<void*> allocs;
     bool has_null_material = false;
     uint32_t n_materials = 0;
+    bool has_alpha = false;           // some mesh carries an alpha / shadow-alpha mask (Triangle::intersect's alpha tests)
     bool has_instances = false;       // object instances: two-level traversal (kernels.h traverse<ANY, true>)
     std::map<int, LightDist> light_dists;  // by effective strategy
 };
@@ -414,9 +415,12 @@ uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
 // kernel choice: the persistent-wave kernel (trace_wide.h) unless RSPT_TRACE_KERNEL=0 or the
 // reference-order node / triangle counters are wanted (only k_trace counts them)
 // lane 0 = the library's main stream; lane 1 = the second stream with its own overflow list and spill rows
-template <bool ANY, int OUT_MODE>
-void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
-                  const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
+// One launch of the traversal stage.  Kernel choice: scenes with object instances or alpha-masked meshes take the <INST, ALPHA>
+// instantiations (template flags, so that the plain kernels stay the ones measured in DESIGN.md); counters and RSPT_TRACE_KERNEL=0
+// use the reference-order loop; a scene whose records outgrow the four-box reference fields stays on the two-box kernel.
+template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
+void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
+                    const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
     const SceneDev& sc = s->dev;
     // RSPT_TRACE_KERNEL: 0 = k_trace (reference-order single-ray loop), 1 = k_trace_pw (persistent waves, two boxes
     // per record), 2 = k_trace_w4 (persistent waves, four boxes per record; default).
@@ -426,48 +430,44 @@ void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, co
     hipStream_t stream = lane ? g.stream2 : g.stream;
     uint32_t* ovf = g.ovf + (lane ? 2 * g.ovf_cap / 3 : 0);
     uint2* spill = g.spill + (lane ? g.spill_threads * RSPT_W4_SPILL : 0);
-    const bool inst_slow = s->has_instances && (count || which == 0 || !s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0);
-    if (inst_slow) {  // two-level traversal by the reference-order loop: counters, or RSPT_INSTANCE_KERNEL=0
-        uint32_t* hi = (OUT_MODE == 0 && !ANY) ? g.hit_inst : nullptr;
+    uint32_t* hi = (INST && OUT_MODE == 0 && !ANY) ? g.hit_inst : nullptr;
+    const bool special = INST || ALPHA;
+    const bool slow = count || which == 0 || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
+    if (slow) {
         if (count)
-            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
+            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
         else
-            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
+            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
         return;
     }
-    if (!count && which != 0) {
-        const uint32_t pgrid = hinted_grid(pw_grid(), RSPT_PW_BLOCK);
-        grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
-        uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
-        const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
-        uint32_t* hi = (OUT_MODE == 0 && !ANY) ? g.hit_inst : nullptr;
-        if (s->has_instances) {  // the four-box kernel with the instance switch; overflowing rays (stack beyond LDS + spill rows) go to the two-level fix-up
-            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, true>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi);
-            hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
-            return;
-        }
-        if (which >= 2 && s->w4_ok)
-            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, false>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, (uint32_t*)nullptr);
-        else
+    const uint32_t pgrid = hinted_grid(pw_grid(), RSPT_PW_BLOCK);
+    grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
+    uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
+    const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
+    if (special || (which >= 2 && s->w4_ok))
+        hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi);
+    else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
-        // with every spill row in use the four-box kernel cannot overflow (RSPT_W4_MAX_STACK): no second pass to launch
-        if (trace_can_overflow(s)) hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, n_overflow, ovf, ra, rb, oa, ob, occ, hits, (uint32_t*)nullptr);
-        return;
-    }
-    if (count)
-        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, (uint32_t*)nullptr);
-    else
-        hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, false>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, (uint32_t*)nullptr);
+    // with every spill row in use the plain four-box kernel cannot overflow (RSPT_W4_MAX_STACK): no second pass to launch
+    if (trace_can_overflow(s))
+        hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
+}
+template <bool ANY, int OUT_MODE>
+void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
+                  const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
+#define RSPT_LT(I, A) launch_trace_v<ANY, OUT_MODE, I, A>(lane, count, grid, s, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, counters)
+    if (s->has_instances) { if (s->has_alpha) RSPT_LT(true, true); else RSPT_LT(true, false); }
+    else { if (s->has_alpha) RSPT_LT(false, true); else RSPT_LT(false, false); }
+#undef RSPT_LT
 }
 
 // does the production trace kernel ever hand rays to k_trace_fixup?  Not the four-box kernel with all its spill rows (RSPT_W4_MAX_STACK)
 bool trace_can_overflow(const rspt_scene_s* s) {
     const size_t which = env_size("RSPT_TRACE_KERNEL", 2);
     const size_t rows = std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
-    return s->has_instances || !(which >= 2 && s->w4_ok) || RSPT_W4_LDS + rows < RSPT_W4_MAX_STACK;  // (two stacked aggregates + leaf continuations can pass the bound)
+    return s->has_instances || (s->has_alpha && !s->w4_ok) || !(which >= 2 && s->w4_ok) || RSPT_W4_LDS + rows < RSPT_W4_MAX_STACK;  // (two stacked aggregates + leaf continuations can pass the bound)
 }
 uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PER_CU", 5)); }
 
@@ -1155,6 +1155,18 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         if (p.area_light >= (int64_t)d->n_lights) return fail(RSPT_E_INVALID, "prim %llu: light index out of range", (unsigned long long)i);
         has_null |= p.material == 0xffffffffu;
     }
+    bool any_alpha = false;
+    for (uint32_t i = 0; i < d->n_meshes; i++) {
+        const rspt_mesh& m = d->meshes[i];
+        if (m.alpha_tex > d->n_textures || m.shadow_alpha_tex > d->n_textures) return fail(RSPT_E_INVALID, "mesh %u: alpha texture index out of range", i);
+        any_alpha |= m.alpha_tex != 0 || m.shadow_alpha_tex != 0;
+    }
+    if (any_alpha)
+        for (uint64_t i = 0; i < d->n_prims; i++) {
+            const rspt_prim& p = d->prims[i];
+            if (p.mesh != RSPT_MESH_INSTANCE && p.mesh < d->n_meshes && p.area_light >= 0 && (d->meshes[p.mesh].alpha_tex || d->meshes[p.mesh].shadow_alpha_tex))
+                return fail(RSPT_E_UNSUPPORTED, "prim %llu: an emissive mesh with an alpha mask", (unsigned long long)i);
+        }
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const rspt_material& m = d->materials[i];
         if (m.n_bxdfs > 8 || (uint64_t)m.first_bxdf + m.n_bxdfs > d->n_bxdfs) return fail(RSPT_E_INVALID, "material %u: bad bxdf slice", i);
@@ -1267,6 +1279,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     rspt_scene_s* s = new rspt_scene_s();
     s->has_null_material = has_null || (instanced && d->instancing_mode == RSPT_INSTANCING_REFERENCE);  // instanced hits pass through like null surfaces (Q11)
     s->has_instances = instanced;
+    s->has_alpha = any_alpha;
     s->n_materials = d->n_materials;
     auto bail = [&](int rc) {
         for (void* p : s->allocs) (void)hipFree(p);
@@ -1280,6 +1293,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((rc = upload(s, d->nodes, d->n_nodes, &nodes_d))) return bail(rc);
     if ((rc = upload(s, d->prims, d->n_prims, &s->dev.prims))) return bail(rc);
     if ((rc = upload(s, d->meshes, d->n_meshes, &meshes_d))) return bail(rc);
+    s->dev.meshes = meshes_d;
     if ((rc = upload(s, d->P, d->n_vertices * 3, &P_d))) return bail(rc);
     if ((rc = upload(s, d->N, d->N ? d->n_vertices * 3 : 0, &s->dev.N))) return bail(rc);
     if ((rc = upload(s, d->S, d->S ? d->n_vertices * 3 : 0, &s->dev.S))) return bail(rc);
@@ -1313,12 +1327,12 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             any |= mflags[m] != 0;
         }
         if ((rc = upload(s, bx.data(), bx.size(), &s->dev.bxdfs))) return bail(rc);
-        if (any) {
-            s->has_textures = true;
+        if (any || any_alpha) {
+            s->has_textures = any;  // k_texture / per-path texture rows only when a material is textured; alpha masks just need the tables
             if ((rc = upload(s, d->textures, d->n_textures, &s->tex.textures)) || (rc = upload(s, slots.data(), slots.size(), &s->tex.mat_slots)) ||
                 (rc = upload(s, mflags.data(), mflags.size(), &s->tex.mat_flags)))
                 return bail(rc);
-            s->dev.mat_flags = s->tex.mat_flags;
+            if (any) s->dev.mat_flags = s->tex.mat_flags;
             std::vector<ImageDev> imgs(d->n_images);
             std::vector<float> pool;  // every pyramid, back to back
             for (uint32_t i = 0; i < d->n_images; i++) {
@@ -1582,6 +1596,55 @@ int rspt_render_device(rspt_scene_t s, const rspt_render_desc* d, void* film_dev
 int rspt_render_samples(rspt_scene_t s, const rspt_render_desc* d, float* li_rgb, rspt_stats* stats) {
     if (!li_rgb) return fail(RSPT_E_INVALID, "null li_rgb");
     return render_impl(s, d, nullptr, nullptr, li_rgb, stats);
+}
+
+int rspt_light_distribution(rspt_scene_t s, uint32_t strategy, const float p[3], float* func_out, float* cdf_out, int32_t nvox_out[3], int32_t voxel_out[3]) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (!s || !p || !func_out || !cdf_out) return fail(RSPT_E_INVALID, "null argument");
+    const uint32_t nl = s->dev.n_lights;
+    if (nl == 0) return fail(RSPT_E_INVALID, "the scene has no lights");
+    HIP_TRY(hipSetDevice(g.device));
+    LightDistDev ld;
+    const LightDist* lazy = nullptr;
+    int rc = get_light_dist(s, strategy, &ld, &lazy);
+    if (rc) return rc;
+    // SpatialLightDistribution::lookup's voxel addressing (lightdistrib.rs:276-295), as dev_scene.h light_voxel does it
+    int32_t pi[3] = {0, 0, 0};
+    uint64_t vox = 0;
+    if (ld.spatial) {
+        for (int i = 0; i < 3; i++) {
+            float o = p[i] - s->dev.wb_min[i];
+            if (s->dev.wb_max[i] > s->dev.wb_min[i]) o /= s->dev.wb_max[i] - s->dev.wb_min[i];
+            const float f = o * (float)ld.nvox[i];
+            const int32_t v = (f != f) ? 0 : (f >= 2147483648.0f ? 2147483647 : (f <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)f));
+            pi[i] = v < 0 ? 0 : (v > ld.nvox[i] - 1 ? ld.nvox[i] - 1 : v);
+        }
+        vox = ((uint64_t)pi[2] * ld.nvox[1] + pi[1]) * ld.nvox[0] + pi[0];
+    }
+    uint64_t row = vox;
+    if (lazy) {  // build the voxel if no path has asked for it yet: one round of the on-demand kernels with a one-entry list
+        int32_t r = -1;
+        HIP_TRY(hipMemcpy(&r, lazy->table + vox, sizeof r, hipMemcpyDeviceToHost));
+        if (r < 0) {
+            LightLazy lz;
+            HIP_TRY(hipMemcpy(&lz, lazy->lazy, sizeof lz, hipMemcpyDeviceToHost));
+            if (lz.n_rows >= lz.max_rows) return fail(RSPT_E_NOMEM, "spatial light distribution: row pool exhausted; raise RSPT_LIGHT_TABLE_POOL_BYTES");
+            lz.n_new = 1;
+            const uint32_t v32 = (uint32_t)vox;
+            HIP_TRY(hipMemcpy(lazy->lazy, &lz, sizeof lz, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(lazy->new_list, &v32, sizeof v32, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_ld_contrib_list, dim3(4), dim3(256), 0, g.stream, s->dev, ld.nvox[0], ld.nvox[1], ld.nvox[2], lazy->lazy, lazy->new_list, lazy->func);
+            hipLaunchKernelGGL(k_ld_build_list, dim3(1), dim3(64), 0, g.stream, nl, lazy->lazy, lazy->new_list, lazy->func, lazy->cdf, lazy->func_int, lazy->table);
+            hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, lazy->lazy);
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            HIP_TRY(hipMemcpy(&r, lazy->table + vox, sizeof r, hipMemcpyDeviceToHost));
+        }
+        row = (uint64_t)r;
+    }
+    HIP_TRY(hipMemcpy(func_out, ld.func + row * nl, nl * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cdf_out, ld.cdf + row * (nl + 1), (nl + 1) * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) { if (nvox_out) nvox_out[i] = ld.nvox[i]; if (voxel_out) voxel_out[i] = pi[i]; }
+    return RSPT_OK;
 }
 
 int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* out_dev, int any_hit, int repeat, double* ms_per_launch) {

@@ -110,8 +110,10 @@ RDEVN bool box_hit6_m(float lx, float ly, float lz, float hx, float hy, float hz
 // m_inv), runs the object's own records on top of the same stack, and on coming back down to that stack level reloads the world
 // ray from its queue record.  t_max is carried over as the reference does (r.t_max.set(ray.t_max), quirks Q10 / Q11 in kernels.h
 // traverse<>).  Without INST the code is the one measured in DESIGN.md (the flag is a template parameter, not a branch).
-template <bool ANY, int OUT_MODE, bool INST>
-__global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
+// ALPHA (scenes with alpha-masked meshes): a candidate that passed the watertight test on such a mesh is checked by alpha_pass
+// (kernels.h) before it counts — a call into the texture code, which is why this too is a template flag.
+template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
+__global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, const W
                         }
                         float t, b0, b1, b2;
                         if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, INST ? f3{ox, oy, oz} : o, rs, t_max, &t, &b0, &b1, &b2)) {
+                            if (ALPHA && (__float_as_uint(c.w) & MF_ALPHA) && !alpha_pass<ANY>(sc, tt, pi, f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, b0, b1, b2)) continue;
                             if (ANY) { best = 0; break; }
                             t_max = t;       // primitive.rs:155: later pops compare their t_min with this
                             best = pi; bt = t; bb0 = b0; bb1 = b1; bb2 = b2;

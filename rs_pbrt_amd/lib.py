@@ -15,7 +15,7 @@ _LIB = None
 EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
            "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
-           "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy")
+           "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy", "rspt_light_distribution")
 
 
 def source_hash():
@@ -68,6 +68,7 @@ def lib():
         L.rspt_bvh_build_bounds.argtypes = [vp, u64, u32, vp, u64, vp, i32]
         L.rspt_bvh_build_gpu.restype = C.c_int64
         L.rspt_bvh_build_gpu.argtypes = [vp, u64, vp, u64, u32, vp, u64, vp]
+        L.rspt_light_distribution.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         L.rspt_comm_unique_id.argtypes = [vp]
         L.rspt_comm_init.argtypes = [i32, i32, vp]
         _LIB = L
@@ -130,6 +131,16 @@ def shutdown():
     global _inited_device
     lib().rspt_shutdown()
     _inited_device = None
+
+
+def light_distribution(dscene, strategy, p):
+    """rspt_light_distribution: LightDistribution::lookup(p) -> (func[n_lights], cdf[n_lights + 1], n_voxels[3], voxel[3])"""
+    n = int(dscene.host.desc.n_lights)
+    func, cdf = np.zeros(n, np.float32), np.zeros(n + 1, np.float32)
+    nv, vx = np.zeros(3, np.int32), np.zeros(3, np.int32)
+    pp = np.ascontiguousarray(p, np.float32)
+    _check(lib().rspt_light_distribution(dscene.handle, int(strategy), pp.ctypes.data, func.ctypes.data, cdf.ctypes.data, nv.ctypes.data, vx.ctypes.data))
+    return func, cdf, nv, vx
 
 
 def comm_unique_id():

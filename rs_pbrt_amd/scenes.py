@@ -634,15 +634,17 @@ class SceneBuilder:
         self.materials.append(m)
         return len(self.materials) - 1
 
-    def add_mesh(self, P, idx, material, N=None, UV=None, emit=None, two_sided=False, flip=False):
-        """P (nv,3) world-space vertices; idx (nt,3); emit = rgb L or None."""
+    def add_mesh(self, P, idx, material, N=None, UV=None, emit=None, two_sided=False, flip=False, alpha=None, shadow_alpha=None):
+        """P (nv,3) world-space vertices; idx (nt,3); emit = rgb L or None; alpha / shadow_alpha: float textures (TexRef) of the
+        shape's "alpha" / "shadowalpha" parameters (api.rs:1920-1965): where they evaluate to 0 the surface is not there."""
         P = np.asarray(P, F32).reshape(-1, 3); idx = np.asarray(idx, np.uint32).reshape(-1, 3)
         m = len(self.meshes)
         assert self.cur_object < 0 or emit is None, "Area lights not supported with object instancing (api.rs:2899)"
         self.mesh_object.append(self.cur_object)
         if self.cur_object < 0:
             self.decl.append(("mesh", m))
-        self.meshes.append((int(N is not None), 0, int(UV is not None), int(flip)))
+        assert emit is None or (alpha is None and shadow_alpha is None), "alpha masks on emissive meshes are not supported"
+        self.meshes.append((int(N is not None), 0, int(UV is not None), int(flip), 0 if alpha is None else alpha.index + 1, 0 if shadow_alpha is None else shadow_alpha.index + 1))
         self.mesh_material.append(material)
         self.mesh_emit.append(None if emit is None else (np.array(emit, F32), bool(two_sided)))
         self.P.append(P)

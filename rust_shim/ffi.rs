@@ -1,10 +1,10 @@
-//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 12) one to one.
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 13) one to one.
 //! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
 //! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RSPT_ABI_VERSION: c_int = 12;
+pub const RSPT_ABI_VERSION: c_int = 13;
 pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
 pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
 
@@ -13,7 +13,7 @@ pub struct RsptBvhNode { pub bmin: [f32; 3], pub bmax: [f32; 3], pub offset: i32
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptPrim { pub v: [u32; 3], pub mesh: u32, pub material: u32, pub area_light: i32 } // 24 B
 #[repr(C)] #[derive(Clone, Copy, Default)]
-pub struct RsptMesh { pub has_n: u32, pub has_s: u32, pub has_uv: u32, pub flip: u32 }
+pub struct RsptMesh { pub has_n: u32, pub has_s: u32, pub has_uv: u32, pub flip: u32, pub alpha_tex: u32, pub shadow_alpha_tex: u32 }
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptBxdf { // 116 B
     pub kind: u32, pub fresnel: u32, pub r: [f32; 3], pub t: [f32; 3], pub eta_a: f32, pub eta_b: f32, pub alpha_x: f32, pub alpha_y: f32,

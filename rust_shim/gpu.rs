@@ -72,7 +72,8 @@ impl Flat {
         }
         self.any_n |= !m.n.is_empty(); self.any_s |= !m.s.is_empty(); self.any_uv |= !m.uv.is_empty();
         self.meshes.push(RsptMesh { has_n: !m.n.is_empty() as u32, has_s: !m.s.is_empty() as u32, has_uv: !m.uv.is_empty() as u32,
-                                    flip: (m.reverse_orientation ^ m.transform_swaps_handedness) as u32 }); // triangle.rs:324
+                                    flip: (m.reverse_orientation ^ m.transform_swaps_handedness) as u32, // triangle.rs:324
+                                    alpha_tex: 0, shadow_alpha_tex: 0 });   // masks need the texture flattening this file does not have yet: checked in aggregate()
         let v = ((self.meshes.len() - 1) as u32, first);
         self.mesh_of.insert(key, v);
         v
@@ -141,6 +142,7 @@ impl Flat {
             match &**prim {
                 Primitive::Geometric(g) => {
                     let tri = match &*g.shape { Shape::Trngl(t) => t, _ => return Err("non-triangle shape".into()) };
+                    if tri.mesh().alpha_mask.is_some() || tri.mesh().shadow_alpha_mask.is_some() { return Err("alpha-masked mesh (textures are not flattened by the shim yet)".into()); }
                     let (mesh, first) = self.mesh(tri.mesh());                     // Triangle.mesh getter: rs_pbrt.patch (triangle.rs:85)
                     let vi = &tri.mesh().vertex_indices[3 * tri.id as usize..3 * tri.id as usize + 3];
                     let area_light = match &g.area_light {                         // the reference compares these pointers (integrator.rs:540-543)

@@ -512,6 +512,38 @@ def test_spatial_light_distribution_on_demand_voxels(gpu, oracle):
         os.environ.pop("RSPT_LIGHT_TABLE_EAGER_BYTES", None); os.environ.pop("RSPT_LIGHT_TABLE_POOL_BYTES", None)
 
 
+def test_light_distribution_hook_equals_oracle_voxel_by_voxel(gpu, oracle):
+    """rspt_light_distribution = LightDistribution::lookup(p) (lightdistrib.rs:33-39): func / cdf of p's voxel, bit for bit the
+    oracle's spatial_compute (128 Halton points per voxel x every light, :297-384), from the eager table and from on-demand rows;
+    uniform and power are one row for every p"""
+    import ctypes as C, os
+    sc = gallery(gpu.bvh_build)
+    rd = scenes.make_render_desc(64, 48, 1, GALLERY_LOOK_AT, 60.0)
+    nl = int(sc.desc.n_lights)
+    lo, hi = sc.nodes["bmin"][0], sc.nodes["bmax"][0]   # BVHAccel::world_bound (bvh.rs:394-400)
+    pts = np.random.default_rng(4).uniform(lo - 0.5, hi + 0.5, (60, 3)).astype(np.float32)   # some outside: clamped to the border voxels
+
+    def check(ds):
+        for p in pts:
+            f, c, nv, vx = gpu.light_distribution(ds, abi.LIGHTS_SPATIAL, p)
+            of, oc, onv = np.zeros(nl, np.float32), np.zeros(nl + 1, np.float32), (C.c_int32 * 3)()
+            oracle.lib().orc_spatial_voxel(C.addressof(sc.desc), C.addressof(rd), (C.c_int32 * 3)(*map(int, vx)), of.ctypes.data, oc.ctypes.data, onv)
+            assert list(nv) == list(onv) and np.array_equal(f, of) and np.array_equal(c, oc)
+    with gpu.DeviceScene(sc) as ds:
+        check(ds)
+        f, c, nv, _ = gpu.light_distribution(ds, abi.LIGHTS_UNIFORM, pts[0])
+        assert list(nv) == [1, 1, 1] and np.all(f == 1.0) and np.allclose(c, np.arange(nl + 1) / nl, atol=1e-6)
+        f, c, _, _ = gpu.light_distribution(ds, abi.LIGHTS_POWER, pts[0])
+        assert f.min() > 0 and c[0] == 0 and abs(c[-1] - 1) < 1e-6 and np.all(np.diff(c) > 0)
+    try:
+        os.environ["RSPT_LIGHT_TABLE_EAGER_BYTES"] = "0"
+        with gpu.DeviceScene(sc) as ds:
+            check(ds)   # every voxel is built by the hook itself
+            check(ds)   # and found the second time
+    finally:
+        os.environ.pop("RSPT_LIGHT_TABLE_EAGER_BYTES", None)
+
+
 def test_scene_with_ten_thousand_emissive_triangles_renders(gpu, oracle):
     """the case the eager table refused in round 1 (64^3 voxels x 10 082 lights): an emissive 71 x 71 grid (10 082 light triangles)
     over a room; only the voxels paths actually reach are built"""
