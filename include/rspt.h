@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 13
+#define RSPT_ABI_VERSION 14
 
 /* error codes */
 #define RSPT_OK 0
@@ -73,7 +73,21 @@ typedef struct {
      * uv / p, without ray differentials — is no hit: Triangle::intersect tests alpha_mask (triangle.rs:313-330), Triangle::intersect_p
      * both (:593-655).  Meshes that emit light may not carry masks (the pdf of a light's own triangle would need them). */
     uint32_t alpha_tex, shadow_alpha_tex;
-} rspt_mesh;
+    /* GeometricPrimitive.medium_interface (primitive.rs:103, filled from the graphics state's MediumInterface, api.rs:734-767,
+     * 2858-2870): 0 = no medium, else 1 + index into media[].  Only VolPathIntegrator looks at it; a surface is a medium transition
+     * when the two differ (medium.rs:340-362), otherwise rays keep the medium they travel in (primitive.rs:160-170). */
+    uint32_t medium_inside, medium_outside;
+} rspt_mesh; /* 32 B */
+
+/* ---- participating media (src/core/medium.rs, src/media/homogeneous.rs; MakeNamedMedium api.rs:953-1037) ----
+ * sigma_a / sigma_s already multiplied by "scale"; sigma_t = sigma_s + sigma_a is formed by the library as HomogeneousMedium::new does.
+ * The phase function is HenyeyGreenstein { g } (medium.rs:296-331).  GridDensityMedium ("heterogeneous") is not accelerated. */
+enum { RSPT_MEDIUM_HOMOGENEOUS = 1 };
+typedef struct {
+    uint32_t kind;
+    float sigma_a[3], sigma_s[3];
+    float g;
+} rspt_medium; /* 32 B */
 
 /* ---- materials: pre-assembled BxDF lists ------------------------------------------
  * With constant textures every Material::compute_scattering_functions
@@ -268,7 +282,8 @@ typedef struct {
     const rspt_instance* instances; uint32_t n_instances;
     uint64_t n_top_nodes, n_top_prims; /* the top-level aggregate = nodes[0 .. n_top_nodes), prims[0 .. n_top_prims) */
     uint32_t instancing_mode;          /* RSPT_INSTANCING_* */
-    uint32_t pad1;
+    uint32_t n_media;
+    const rspt_medium* media;          /* RenderOptions.named_media, referenced by rspt_mesh.medium_inside / _outside */
 } rspt_scene_desc;
 
 /* Sampler tables owned by the host.
@@ -336,7 +351,12 @@ typedef struct {
     const int32_t* n_light_samples;  /* SAMPLE_ALL: Light::get_n_samples() per light ("samples" / "nsamples", default 1), after
                                         Sampler::round_count (the identity for Sobol' and Halton); NULL = 1 each                   */
 } rspt_render_desc;
-enum { RSPT_INTEGRATOR_PATH = 0, RSPT_INTEGRATOR_AO = 1, RSPT_INTEGRATOR_DIRECT = 2 };
+/* RSPT_INTEGRATOR_VOLPATH: VolPathIntegrator::li (src/integrators/volpath.rs:60-347) with max_depth, rr_threshold and
+ * light_strategy as for "path" (api.rs:350-380).  Camera rays start outside every medium (make_camera passes
+ * MediumInterface::default().outside, api.rs:1638-1645).  As in v0.9.12: the BSDF- / phase-sampled half of estimate_direct is
+ * multiplied by a transmittance that starts at Spectrum::default() = 0 (integrator.rs:531-536, scene.rs:79-106) and so adds nothing;
+ * a ray that leaves the scene ends its path even after scattering in a medium (volpath.rs:288-345). */
+enum { RSPT_INTEGRATOR_PATH = 0, RSPT_INTEGRATOR_AO = 1, RSPT_INTEGRATOR_DIRECT = 2, RSPT_INTEGRATOR_VOLPATH = 3 };
 enum { RSPT_DIRECT_SAMPLE_ALL = 0, RSPT_DIRECT_SAMPLE_ONE = 1 };
 
 typedef struct { float o[3], d[3], t_max; uint32_t id; } rspt_ray;   /* 32 B */

@@ -243,6 +243,34 @@ int orc_render_integrator(const rspt_scene_desc* sd, const rspt_render_desc* rd,
     return 0;
 }
 
+// media (VolPathIntegrator): leaf functions for known-answer tests
+float orc_phase_hg(float cos_theta, float g) { return phase_hg(cos_theta, g); }
+float orc_hg_sample_p(float g, const float wo[3], float ux, float uy, float wi_out[3]) {
+    V3 wi{0, 0, 0};
+    float p = hg_sample_p(g, V3{wo[0], wo[1], wo[2]}, &wi, P2{ux, uy});
+    wi_out[0] = wi.x; wi_out[1] = wi.y; wi_out[2] = wi.z;
+    return p;
+}
+// HomogeneousMedium::sample for the ray (o, d, t_max): out = (beta factor rgb, sampled 0/1, p xyz)
+void orc_homogeneous_sample(const rspt_medium* m, const float o[3], const float d[3], float t_max, float u_channel, float u_dist, float out[7]) {
+    Ray ray{V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, t_max, 0.0f};
+    ray.medium = 1;
+    Interaction mi = Interaction{}; mi.p = V3{0, 0, 0}; bool sampled = false;
+    Spec b = homogeneous_sample(*m, 1, ray, u_channel, u_dist, &mi, &sampled);
+    out[0] = b.c[0]; out[1] = b.c[1]; out[2] = b.c[2]; out[3] = sampled ? 1.0f : 0.0f;
+    out[4] = mi.p.x; out[5] = mi.p.y; out[6] = mi.p.z;
+}
+// VisibilityTester::tr between two free points (MediumInteraction-like ends: n = 0, p_error = 0) that start in medium `medium0`
+void orc_visibility_tr(const rspt_scene_desc* sd, const float p0[3], uint32_t medium0, const float p1[3], float tr_out[3]) {
+    Scene sc{*sd};
+    Interaction a = Interaction{}, b = Interaction{};
+    a.p_error = a.n = a.wo = b.p_error = b.n = b.wo = V3{0, 0, 0};
+    a.p = V3{p0[0], p0[1], p0[2]}; a.med_in = a.med_out = medium0; a.is_medium = true;
+    b.p = V3{p1[0], p1[1], p1[2]};
+    Spec tr = visibility_tr(sc, a, b, nullptr);
+    tr_out[0] = tr.c[0]; tr_out[1] = tr.c[1]; tr_out[2] = tr.c[2];
+}
+
 // spatial light distribution of one voxel (for differential tests of the device builder):
 // writes n_lights func values and n_lights+1 cdf values.
 void orc_spatial_voxel(const rspt_scene_desc* sd, const rspt_render_desc* rd, const int32_t pi[3], float* func_out, float* cdf_out, int32_t n_voxels_out[3]) {

@@ -24,6 +24,7 @@ static const Float SHADOW_EPSILON = 0.0001f;
 static const Float PI = 3.14159265358979323846f; // std::f32::consts::PI
 static const Float INV_PI = 0.31830988618379067154f;
 static const Float INV_2_PI = 0.15915494309189533577f;
+static const Float INV_4_PI = 0.07957747154594766788f; // pbrt.rs:20
 static const Float PI_OVER_2 = 1.57079632679489661923f;
 static const Float PI_OVER_4 = 0.78539816339744830961f;
 // src/core/rng.rs:13
@@ -200,6 +201,7 @@ struct Ray {
     // Option<RayDifferential> (geometry.rs:2408-2414): camera rays only
     bool has_diff = false;
     V3 rx_o{0, 0, 0}, ry_o{0, 0, 0}, rx_d{0, 0, 0}, ry_d{0, 0, 0};
+    uint32_t medium = 0; // Option<Arc<Medium>>: 0 = None, else 1 + index into rspt_scene_desc.media
     void scale_differentials(Float s) { // geometry.rs:2398-2405
         if (!has_diff) return;
         rx_o = o + (rx_o - o) * s; ry_o = o + (ry_o - o) * s;
@@ -283,6 +285,7 @@ static inline Ray transform_ray(const Float* m, const Ray& r) {
         t_max -= dt;
     }
     Ray out{o, d, t_max, r.time};
+    out.medium = r.medium; // :591
     if (r.has_diff) { // :550-556: plain transform_point / transform_vector
         out.has_diff = true;
         out.rx_o = transform_point(m, r.rx_o); out.ry_o = transform_point(m, r.ry_o);

@@ -708,6 +708,259 @@ static inline Spec path_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counte
     return l;
 }
 
+// ---- participating media: src/media/homogeneous.rs, src/core/medium.rs (VolPathIntegrator) ----
+static inline Spec spec_exp(Spec a) { return Spec(std::exp(a.c[0]), std::exp(a.c[1]), std::exp(a.c[2])); } // Spectrum::exp spectrum.rs:1620-1622
+static inline Spec medium_sigma_t(const rspt_medium& m) { // HomogeneousMedium::new homogeneous.rs:24-31: sigma_s + sigma_a
+    return Spec(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) + Spec(m.sigma_a[0], m.sigma_a[1], m.sigma_a[2]);
+}
+static inline Spec medium_tr(const Scene& sc, const Ray& ray) { // Medium::tr medium.rs:277-283 -> HomogeneousMedium::tr homogeneous.rs:33-36
+    const rspt_medium& m = sc.d.media[ray.medium - 1];
+    Spec st = medium_sigma_t(m);
+    Spec nst(-st.c[0], -st.c[1], -st.c[2]);
+    return spec_exp(nst * std::fmin(ray.t_max * length(ray.d), std::numeric_limits<Float>::max()));
+}
+// Medium::sample -> HomogeneousMedium::sample (homogeneous.rs:37-91): returns the path-throughput factor; *mi is filled (and
+// *sampled set) when the sampled distance ends before ray.t_max
+static inline Spec homogeneous_sample(const rspt_medium& m, uint32_t medium, const Ray& ray, Float u_channel, Float u_dist, Interaction* mi, bool* sampled) {
+    const Spec sigma_t = medium_sigma_t(m), sigma_s(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]);
+    size_t channel = (size_t)(u_channel * 3.0f);
+    if (channel > 2) channel = 2;
+    const Float dist = -std::log(1.0f - u_dist) / sigma_t.c[channel];
+    const Float len = length(ray.d);
+    const Float t = std::fmin(dist / len, ray.t_max);
+    const bool sampled_medium = t < ray.t_max;
+    if (sampled_medium) { // MediumInteraction::new (interaction.rs:128-151): n = 0, p_error = 0, interface (medium, medium)
+        *mi = Interaction{};
+        mi->p = ray.o + ray.d * t; // Ray::position geometry.rs:2392-2394
+        mi->wo = -ray.d;
+        mi->time = ray.time;
+        mi->med_in = mi->med_out = medium;
+        mi->is_medium = true;
+        mi->phase_g = m.g;
+    }
+    *sampled = sampled_medium;
+    const Spec nst(-sigma_t.c[0], -sigma_t.c[1], -sigma_t.c[2]);
+    const Spec tr = spec_exp(nst * std::fmin(t, std::numeric_limits<Float>::max()) * len);
+    const Spec density = sampled_medium ? sigma_t * tr : tr;
+    Float pdf = 0.0f;
+    for (int i = 0; i < 3; i++) pdf += density.c[i];
+    pdf *= 1.0f / 3.0f;
+    if (pdf == 0.0f) pdf = 1.0f; // (assert!(tr.is_black()))
+    return sampled_medium ? tr * sigma_s / pdf : tr / pdf;
+}
+static inline Spec medium_sample(const Scene& sc, const Ray& ray, Sampler& sampler, Interaction* mi, bool* sampled) {
+    const Float u_channel = sampler.get_1d(); // :43
+    const Float u_dist = sampler.get_1d();    // :49
+    return homogeneous_sample(sc.d.media[ray.medium - 1], ray.medium, ray, u_channel, u_dist, mi, sampled);
+}
+static inline Float phase_hg(Float cos_theta, Float g) { // medium.rs:389-392
+    const Float denom = 1.0f + g * g + 2.0f * g * cos_theta;
+    return INV_4_PI * (1.0f - g * g) / (denom * std::sqrt(denom));
+}
+static inline Float hg_sample_p(Float g, V3 wo, V3* wi, P2 u) { // HenyeyGreenstein::sample_p medium.rs:306-331
+    Float cos_theta;
+    if (std::fabs(g) < 1e-3f) cos_theta = 1.0f - 2.0f * u.x;
+    else {
+        const Float sqr_term = (1.0f - g * g) / (1.0f + g - 2.0f * g * u.x);
+        cos_theta = -(1.0f + g * g - sqr_term * sqr_term) / (2.0f * g);
+    }
+    const Float sin_theta = std::sqrt(std::fmax(0.0f, 1.0f - cos_theta * cos_theta));
+    const Float phi = 2.0f * PI * u.y;
+    V3 v1, v2;
+    coordinate_system(wo, &v1, &v2);
+    *wi = v1 * (sin_theta * std::cos(phi)) + v2 * (sin_theta * std::sin(phi)) + wo * cos_theta; // spherical_direction_vec3 geometry.rs:1570-1579
+    return phase_hg(cos_theta, g);
+}
+// VisibilityTester::tr (light.rs:207-239)
+static inline Spec visibility_tr(const Scene& sc, const Interaction& p0, const Interaction& p1, Counters* c) {
+    Ray ray = p0.spawn_ray_to(p1);
+    Spec tr(1.0f);
+    for (;;) {
+        Interaction isect;
+        if (sc.intersect(ray, &isect, c)) {
+            if (isect.prim >= 0) { // isect.primitive is Some (an instanced hit has lost it, Q11: then neither branch runs)
+                if (sc.d.prims[isect.prim].material != 0xffffffffu) return Spec();
+                if (ray.medium) tr = tr * medium_tr(sc, ray);
+            }
+        } else {
+            if (ray.medium) tr = tr * medium_tr(sc, ray);
+            break;
+        }
+        ray = isect.spawn_ray_to(p1);
+    }
+    return tr;
+}
+// Scene::intersect_tr (scene.rs:79-106)
+static inline bool intersect_tr(const Scene& sc, Ray* ray, Interaction* isect, Spec* tr, Counters* c) {
+    for (;;) {
+        const bool hit_surface = sc.intersect(*ray, isect, c);
+        if (ray->medium) *tr = *tr * medium_tr(sc, *ray);
+        if (!hit_surface) return false;
+        if (isect->prim >= 0 && sc.d.prims[isect->prim].material != 0xffffffffu) return true;
+        *ray = isect->spawn_ray(ray->d);
+    }
+}
+// estimate_direct (integrator.rs:406-570) with handle_media = true, specular = false; `bsdf` is null for a medium interaction
+static inline Spec estimate_direct_media(RenderCtx& cx, const Interaction& it, const Bsdf* bsdf, P2 u_scattering, uint32_t light_num, P2 u_light, Counters* c) {
+    const Scene& sc = *cx.scene;
+    const rspt_light& light = sc.d.lights[light_num];
+    const uint8_t flags = BSDF_ALL & ~BSDF_SPECULAR;
+    Spec ld(0.0f);
+    V3 wi{0, 0, 0};
+    Float light_pdf = 0.0f, scattering_pdf = 0.0f;
+    Interaction light_intr;
+    Spec li = light_sample_li(sc, light, it, u_light, &wi, &light_pdf, &light_intr);
+    if (light_pdf > 0.0f && !li.is_black()) {
+        Spec f(0.0f);
+        if (!it.is_medium) { // is_surface_interaction: n != 0
+            f = bsdf->f(it.wo, wi, flags) * Spec(abs_dot(wi, it.sh_n));
+            scattering_pdf = bsdf->pdf(it.wo, wi, flags);
+        } else {
+            const Float p = phase_hg(dot(it.wo, wi), it.phase_g); // HenyeyGreenstein::p medium.rs:302-305
+            f = Spec(p);
+            scattering_pdf = p;
+        }
+        if (!f.is_black()) {
+            li = li * visibility_tr(sc, it, light_intr, c); // handle_media (:462-463)
+            if (!li.is_black()) {
+                if (light_is_delta(light)) ld = ld + f * li / light_pdf;
+                else {
+                    Float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                    ld = ld + f * li * Spec(weight) / light_pdf;
+                }
+            }
+        }
+    }
+    if (!light_is_delta(light)) {
+        Spec f(0.0f);
+        bool sampled_specular = false;
+        if (!it.is_medium) {
+            uint8_t sampled_type = 0;
+            f = bsdf->sample_f(it.wo, &wi, u_scattering, &scattering_pdf, flags, &sampled_type);
+            f = f * Spec(abs_dot(wi, it.sh_n));
+            sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
+        } else {
+            const Float p = hg_sample_p(it.phase_g, it.wo, &wi, u_scattering);
+            f = Spec(p);
+            scattering_pdf = p;
+        }
+        if (!f.is_black() && scattering_pdf > 0.0f) {
+            Float weight = 1.0f;
+            if (!sampled_specular) {
+                light_pdf = light.kind == RSPT_LIGHT_INFINITE ? infinite_pdf_li(sc, light, wi) : sc.tri_pdf_ref(sc.d.prims[light.prim], it, wi);
+                if (light_pdf == 0.0f) return ld;
+                weight = power_heuristic(1, scattering_pdf, 1, light_pdf);
+            }
+            Ray ray = it.spawn_ray(wi);
+            bool found_surface_interaction = false;
+            Spec li2;
+            Interaction light_isect;
+            Spec tr_spectrum; // Spectrum::default(): the transmittance intersect_tr multiplies into starts at ZERO (integrator.rs:531, scene.rs:86)
+            if (c) c->mis_rays++;
+            const bool hit_surface = intersect_tr(sc, &ray, &light_isect, &tr_spectrum, c);
+            const Spec tr = tr_spectrum;
+            if (hit_surface) {
+                found_surface_interaction = true;
+                const rspt_prim& hp = sc.hit_prim(light_isect);
+                if (light.kind == RSPT_LIGHT_DIFFUSE_AREA && hp.area_light >= 0 && (uint32_t)hp.area_light == light_num) li2 = light_l(light, light_isect.n, -wi);
+            }
+            if (!found_surface_interaction) li2 = light.kind == RSPT_LIGHT_INFINITE ? infinite_le(sc, light, ray.d) : Spec();
+            if (!li2.is_black()) ld = ld + f * li2 * tr * weight / scattering_pdf;
+        }
+    }
+    return ld;
+}
+static inline Spec uniform_sample_one_light_media(RenderCtx& cx, const Interaction& it, const Bsdf* bsdf, Sampler& sampler, const Distribution1D& distrib, Counters* c) {
+    if (cx.scene->d.n_lights == 0) return Spec();
+    Float pdf = 0.0f;
+    size_t light_num = distrib.sample_discrete(sampler.get_1d(), &pdf);
+    if (pdf == 0.0f) return Spec();
+    P2 u_light = sampler.get_2d();
+    P2 u_scattering = sampler.get_2d();
+    return estimate_direct_media(cx, it, bsdf, u_scattering, (uint32_t)light_num, u_light, c) / pdf;
+}
+
+// ---- VolPathIntegrator::li: src/integrators/volpath.rs:60-347 ----
+static inline Spec volpath_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counters* c) {
+    const Scene& sc = *cx.scene;
+    Spec l, beta(1.0f);
+    Ray ray = r;
+    bool specular_bounce = false;
+    uint32_t bounces = 0;
+    Float eta_scale = 1.0f;
+    // the block both branches run for a medium interaction (:101-127 / :304-330)
+    auto scatter_in_medium = [&](const Interaction& mi) {
+        if (sc.d.n_lights) { // (light_distribution is Some only with lights; lookup panics on an empty scene otherwise)
+            const Distribution1D* distrib = light_lookup(cx, mi.p);
+            l = l + beta * uniform_sample_one_light_media(cx, mi, nullptr, sampler, *distrib, c);
+        }
+        V3 wi{0, 0, 0};
+        hg_sample_p(mi.phase_g, -ray.d, &wi, sampler.get_2d());
+        ray = mi.spawn_ray(wi);
+        specular_bounce = false;
+    };
+    for (;;) {
+        Interaction isect, mi;
+        bool have_mi = false;
+        if (sc.intersect(ray, &isect, c)) {
+            if (ray.medium) beta = beta * medium_sample(sc, ray, sampler, &mi, &have_mi);
+            if (beta.is_black()) break;
+            if (have_mi) {
+                if (bounces >= cx.rd->max_depth) break;
+                scatter_in_medium(mi);
+            } else {
+                const rspt_prim& hp = sc.hit_prim(isect);
+                if (bounces == 0 || specular_bounce) {
+                    if (hp.area_light >= 0) l = l + beta * light_l(sc.d.lights[hp.area_light], isect.n, -ray.d);
+                    else l = l + beta * Spec();
+                }
+                if (bounces >= cx.rd->max_depth) break;
+                if (hp.material == 0xffffffffu) { ray = isect.spawn_ray(ray.d); continue; } // :141-145: `continue` skips `bounces += 1`
+                compute_differentials(&isect, ray);
+                Bsdf bsdf(sc, isect, sc.d.materials[hp.material]);
+                if (c) c->bounces++;
+                if (sc.d.n_lights) {
+                    const Distribution1D* distrib = light_lookup(cx, isect.p);
+                    l = l + beta * uniform_sample_one_light_media(cx, isect, &bsdf, sampler, *distrib, c); // no non-specular-lobe test here (:146-161)
+                }
+                V3 wo = -ray.d, wi{0, 0, 0};
+                Float pdf = 0.0f;
+                uint8_t sampled_type = 255;
+                Spec f = bsdf.sample_f(wo, &wi, sampler.get_2d(), &pdf, BSDF_ALL, &sampled_type);
+                if (f.is_black() || pdf == 0.0f) break;
+                beta = beta * ((f * abs_dot(wi, isect.sh_n)) / pdf);
+                specular_bounce = (sampled_type & BSDF_SPECULAR) != 0;
+                if ((sampled_type & BSDF_SPECULAR) && (sampled_type & BSDF_TRANSMISSION)) {
+                    Float eta = bsdf.eta;
+                    if (dot(wo, isect.n) > 0.0f) eta_scale *= eta * eta;
+                    else eta_scale *= 1.0f / (eta * eta);
+                }
+                ray = isect.spawn_ray(wi);
+                // (BSSRDF branch :193-270 out of scope)
+            }
+            Spec rr_beta = beta * eta_scale; // :275-285: also after scattering in a medium
+            if (rr_beta.max_component_value() < cx.rd->rr_threshold && bounces > 3) {
+                Float q = std::fmax(0.05f, 1.0f - rr_beta.max_component_value());
+                if (sampler.get_1d() < q) break;
+                beta = beta / (1.0f - q);
+            }
+        } else {
+            if (ray.medium) beta = beta * medium_sample(sc, ray, sampler, &mi, &have_mi);
+            if (beta.is_black()) break;
+            if (have_mi) {
+                if (bounces >= cx.rd->max_depth) break;
+                scatter_in_medium(mi);
+            }
+            if (bounces == 0 || specular_bounce) // :332-337: with the ray as it is NOW (after a scattering event: the scattered ray)
+                for (uint32_t i = 0; i < sc.d.n_lights; i++)
+                    if (sc.d.lights[i].kind == RSPT_LIGHT_INFINITE) l = l + beta * infinite_le(sc, sc.d.lights[i], ray.d);
+            break; // :338-339: the path ends here even if it has just scattered
+        }
+        bounces += 1;
+    }
+    return l;
+}
+
 // ---- AOIntegrator::li: src/integrators/ao.rs:50-96 ----
 static inline V3 uniform_sample_hemisphere(P2 u) { // sampling.rs:236-242
     Float z = u.x;
@@ -1014,6 +1267,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         Float ray_weight = 1.0f;
                         Spec l = ext_integrator != ORC_INTEGRATOR_FROM_DESC ? recursive_li(cx, ray, sampler, 0, &c)
                                  : rd.integrator == RSPT_INTEGRATOR_AO       ? ao_li(cx, ray, sampler, &c)
+                                 : rd.integrator == RSPT_INTEGRATOR_VOLPATH  ? volpath_li(cx, ray, sampler, &c)
                                                                              : path_li(cx, ray, sampler, &c);
                         c.samples++;
                         if (l.has_nans()) { l = Spec(0.0f); c.nan_samples++; } // integrator.rs:165-173 (Q1)

@@ -183,13 +183,25 @@ struct Interaction {
     int64_t prim = -1;         // isect.primitive (-1: None)
     int64_t inst = 0;          // test bookkeeping only: 1 + instance the hit lies in
     int64_t geo_prim = -1;     // test bookkeeping only: the GeometricPrimitive that was hit, also after Q11 dropped isect.primitive
+    // InteractionCommon.medium_interface (interaction.rs:54): inside / outside as 0 = None or 1 + medium index.  (0, 0) stands for
+    // both `None` and `Some(MediumInterface { None, None })`: get_medium cannot tell them apart.
+    uint32_t med_in = 0, med_out = 0;
+    bool is_medium = false;    // a MediumInteraction (n == 0, interaction.rs:174-180)
+    Float phase_g = 0;         // its HenyeyGreenstein { g }
+    uint32_t get_medium(V3 w) const { return dot(w, n) > 0.0f ? med_out : med_in; } // interaction.rs:95-107
     // interaction.rs:58-94
-    Ray spawn_ray(V3 d) const { return Ray{offset_ray_origin(p, p_error, n, d), d, INF, time}; }
+    Ray spawn_ray(V3 d) const {
+        Ray r{offset_ray_origin(p, p_error, n, d), d, INF, time};
+        r.medium = get_medium(d);
+        return r;
+    }
     Ray spawn_ray_to(const Interaction& it) const {
         V3 origin = offset_ray_origin(p, p_error, n, it.p - p);
         V3 target = offset_ray_origin(it.p, it.p_error, it.n, origin - it.p);
         V3 d = target - origin;
-        return Ray{origin, d, 1.0f - SHADOW_EPSILON, time};
+        Ray r{origin, d, 1.0f - SHADOW_EPSILON, time};
+        r.medium = get_medium(d);
+        return r;
     }
 };
 
@@ -501,6 +513,10 @@ struct Scene {
             ray.t_max = t_hit; // primitive.rs:155
             isect->prim = pi;  // primitive.rs:42
             isect->geo_prim = pi; isect->inst = 0;
+            // primitive.rs:160-170: the primitive's MediumInterface at a medium transition, else the medium the ray travels in
+            const rspt_mesh& me = d.meshes[pr.mesh];
+            if (me.medium_inside != me.medium_outside) { isect->med_in = me.medium_inside; isect->med_out = me.medium_outside; }
+            else isect->med_in = isect->med_out = ray.medium;
             if (t_out) *t_out = t_hit;
             return true;
         }

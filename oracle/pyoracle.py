@@ -59,6 +59,11 @@ def lib():
         L.orc_halton_index.restype = C.c_uint64; L.orc_halton_index.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64]
         L.orc_halton_sample.restype = C.c_float; L.orc_halton_sample.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.orc_pcg32_next.restype = C.c_uint32; L.orc_pcg32_next.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_phase_hg.restype = C.c_float; L.orc_phase_hg.argtypes = [C.c_float, C.c_float]
+        L.orc_hg_sample_p.restype = C.c_float; L.orc_hg_sample_p.argtypes = [C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.orc_homogeneous_sample.restype = None
+        L.orc_homogeneous_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_visibility_tr.restype = None; L.orc_visibility_tr.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_spatial_voxel.restype = None
         L.orc_spatial_voxel.argtypes = [C.c_void_p] * 6
         L.orc_tex_eval.restype = None; L.orc_tex_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]

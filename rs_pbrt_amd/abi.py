@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -13,7 +13,8 @@ BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9
 FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
 SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
-INTEGRATOR_PATH, INTEGRATOR_AO, INTEGRATOR_DIRECT = 0, 1, 2
+INTEGRATOR_PATH, INTEGRATOR_AO, INTEGRATOR_DIRECT, INTEGRATOR_VOLPATH = 0, 1, 2, 3
+MEDIUM_HOMOGENEOUS = 1
 DIRECT_SAMPLE_ALL, DIRECT_SAMPLE_ONE = 0, 1
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 TEX_CONSTANT, TEX_IMAGE, TEX_SCALE, TEX_MIX, TEX_CHECKERBOARD, TEX_DOTS, TEX_FBM, TEX_MARBLE, TEX_WINDY, TEX_WRINKLED = range(1, 11)
@@ -35,7 +36,12 @@ class Prim(C.Structure):
 
 
 class Mesh(C.Structure):
-    _fields_ = [("has_n", C.c_uint32), ("has_s", C.c_uint32), ("has_uv", C.c_uint32), ("flip", C.c_uint32), ("alpha_tex", C.c_uint32), ("shadow_alpha_tex", C.c_uint32)]
+    _fields_ = [("has_n", C.c_uint32), ("has_s", C.c_uint32), ("has_uv", C.c_uint32), ("flip", C.c_uint32), ("alpha_tex", C.c_uint32), ("shadow_alpha_tex", C.c_uint32),
+                ("medium_inside", C.c_uint32), ("medium_outside", C.c_uint32)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float)]
 
 
 class Bxdf(C.Structure):
@@ -85,7 +91,7 @@ class SceneDesc(C.Structure):
                 ("objects", C.c_void_p), ("n_objects", C.c_uint32),
                 ("instances", C.c_void_p), ("n_instances", C.c_uint32),
                 ("n_top_nodes", C.c_uint64), ("n_top_prims", C.c_uint64),
-                ("instancing_mode", C.c_uint32), ("pad1", C.c_uint32)]
+                ("instancing_mode", C.c_uint32), ("n_media", C.c_uint32), ("media", C.c_void_p)]
 
 
 class SamplerTables(C.Structure):
@@ -130,7 +136,9 @@ import numpy as np  # noqa: E402
 
 NODE_DT = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_prims", "<u2"), ("axis", "u1"), ("pad", "u1")])
 PRIM_DT = np.dtype([("v", "<u4", 3), ("mesh", "<u4"), ("material", "<u4"), ("area_light", "<i4")])
-MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4"), ("alpha_tex", "<u4"), ("shadow_alpha_tex", "<u4")])
+MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4"), ("alpha_tex", "<u4"), ("shadow_alpha_tex", "<u4"),
+                    ("medium_inside", "<u4"), ("medium_outside", "<u4")])
+MEDIUM_DT = np.dtype([("kind", "<u4"), ("sigma_a", "<f4", 3), ("sigma_s", "<f4", 3), ("g", "<f4")])
 BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
                     ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4"),
                     ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4"), ("tex_ax", "<u4"), ("tex_ay", "<u4"), ("remap", "<u4")])

@@ -47,6 +47,8 @@ struct SceneDev {
     const InstDev* inst;         // object instances; nullptr = none
     uint32_t n_inst;
     uint32_t inst_fixed;         // RSPT_INSTANCING_FIXED: instanced hits keep their primitive (material)
+    const rspt_medium* media;    // RenderOptions.named_media (VolPathIntegrator only; meshes[] carry the medium interfaces)
+    uint32_t n_media;
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)

@@ -23,6 +23,7 @@
 #include "trace_w4.h"
 #include "bvh_device.h"
 #include "direct.h"
+#include "vol.h"
 
 using namespace rspt;
 
@@ -60,6 +61,8 @@ struct Ctx {
     size_t ovf_cap = 0;
     uint2* spill = nullptr;            // k_trace_w4's stack rows beyond its LDS column (trace_w4.h)
     size_t spill_threads = 0;
+    VolBuf vol{};                      // volpath: per-path medium / shadow-ray state (vol.h)
+    size_t vol_cap = 0;
     DlBuf dl{};                        // directlighting: per-node arrays (direct.h) + level queues
     uint32_t* dl_queue = nullptr;
     size_t dl_cap = 0;
@@ -244,6 +247,19 @@ int ensure_direct(size_t cap) {
         (rc = dev_alloc(&g.dl.error, 1)) || (rc = dev_alloc(&g.dl_queue, cap)))
         return rc;
     g.dl_cap = cap;
+    return RSPT_OK;
+}
+
+int ensure_vol(size_t cap) {
+    if (g.vol_cap >= cap) return RSPT_OK;
+    void* old[] = {g.vol.medium, g.vol.sh, g.vol.p1_p, g.vol.p1_e, g.vol.p1_n, g.vol.post, g.vol.truncated};
+    for (void* p : old) if (p) (void)hipFree(p);
+    g.vol = VolBuf{}; g.vol_cap = 0;
+    int rc;
+    if ((rc = dev_alloc(&g.vol.medium, cap)) || (rc = dev_alloc(&g.vol.sh, cap)) || (rc = dev_alloc(&g.vol.p1_p, cap)) || (rc = dev_alloc(&g.vol.p1_e, cap)) ||
+        (rc = dev_alloc(&g.vol.p1_n, cap)) || (rc = dev_alloc(&g.vol.post, cap)) || (rc = dev_alloc(&g.vol.truncated, 1)))
+        return rc;
+    g.vol_cap = cap;
     return RSPT_OK;
 }
 
@@ -482,9 +498,14 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (halton && !d->tables.halton_perms) return fail(RSPT_E_INVALID, "null halton permutation table");
     if (!(d->filter_radius[0] > 0.0f) || !(d->filter_radius[1] > 0.0f)) return fail(RSPT_E_INVALID, "bad filter radius");
     if (d->max_depth > 200) return fail(RSPT_E_UNSUPPORTED, "max_depth > 200");
-    if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO && d->integrator != RSPT_INTEGRATOR_DIRECT)
-        return fail(RSPT_E_UNSUPPORTED, "integrator %u (path, ao and directlighting only)", d->integrator);
+    if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO && d->integrator != RSPT_INTEGRATOR_DIRECT && d->integrator != RSPT_INTEGRATOR_VOLPATH)
+        return fail(RSPT_E_UNSUPPORTED, "integrator %u (path, ao, directlighting and volpath only)", d->integrator);
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
+    const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
+    if (volpath && s) {
+        if (s->has_textures) return fail(RSPT_E_UNSUPPORTED, "volpath with textured materials");
+        if (s->has_instances) return fail(RSPT_E_UNSUPPORTED, "volpath with object instances (transform_surface_interaction drops the medium interface)");
+    }
     if (direct) {
         if (d->max_depth < 1 || d->max_depth > 8) return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, 8] (the specular tree has 2^max_depth slots per camera sample)");
         if (d->direct_strategy > RSPT_DIRECT_SAMPLE_ONE) return fail(RSPT_E_INVALID, "bad direct_strategy");
@@ -500,7 +521,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const uint32_t shard_count = d->shard_count ? d->shard_count : 1, chunk = d->tile_chunk ? d->tile_chunk : 1;
     if (d->shard_index >= shard_count) return fail(RSPT_E_INVALID, "shard_index >= shard_count");
     // Sobol' needs 5 + 8 dims per bounce < 1024 (sobol.rs:119-124)
-    if (5ull + 8ull * (d->max_depth + 2ull) >= 1024ull) return fail(RSPT_E_UNSUPPORTED, "max_depth exceeds the 1024 Sobol' dimensions");
+    if (5ull + (volpath ? 10ull : 8ull) * (d->max_depth + 2ull) >= 1024ull) return fail(RSPT_E_UNSUPPORTED, "max_depth exceeds the 1024 Sobol' dimensions");
 
     auto t_start = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(g.device));
@@ -531,6 +552,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     rd.sobol32 = g.sobol32; rd.vdc = g.vdc; rd.vdc_inv = g.vdc_inv; rd.filter_table = g.filter_table;
     rd.sampler_kind = d->sampler_kind;
     rd.sample_at_pixel_center = d->sample_at_pixel_center;
+    uint32_t vol_dim_limit = 1024u;  // NUM_SOBOL_DIMENSIONS (sobol.rs:119-124) or the Halton permutation table the caller brought
     if (halton) {  // HaltonSampler::new (halton.rs:80-131)
         if (!g.primes) {  // PRIMES / PRIME_SUMS (lowdiscrepancy.rs:31-760)
             std::vector<uint32_t> primes, sums;
@@ -547,6 +569,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             HIP_TRY(hipMemcpy(g.prime_sums, sums.data(), 4000, hipMemcpyHostToDevice));
         }
         uint32_t max_dim = 5u + 8u * (d->max_depth + 2u);  // last dimension a path can consume, with slack
+        if (volpath) max_dim = std::min(990u, 5u + 10u * (d->max_depth + 2u) + 64u);  // 10 per counted bounce, 2 per uncounted pass through a medium boundary (slack for 32; vol.h cuts a path that needs more)
         if (direct) max_dim = 5u + 4u * d->max_depth * s->dev.n_lights + ((1u << d->max_depth) - 1u) * (4u * s->dev.n_lights + 4u) + 2u;  // arrays + every node on the fall-back stream
         if (max_dim >= 1000u) return fail(RSPT_E_UNSUPPORTED, "max_depth exceeds the 1000 Halton dimensions");
         const uint64_t need = (uint64_t)g.host_prime_sums[max_dim] + g.host_primes[max_dim];
@@ -560,6 +583,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         }
         HIP_TRY(hipMemcpyAsync(g.halton_perms, d->tables.halton_perms, need * sizeof(uint16_t), hipMemcpyHostToDevice, g.stream));
         rd.halton_perms = g.halton_perms; rd.primes = g.primes; rd.prime_sums = g.prime_sums;
+        vol_dim_limit = max_dim;
         const int32_t res[2] = {sb[2] - sb[0], sb[3] - sb[1]};
         for (int i = 0; i < 2; i++) {
             int32_t base = i == 0 ? 2 : 3, scale = 1, exp = 0;
@@ -584,6 +608,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     LightDistDev ld;
     const LightDist* ld_lazy = nullptr;  // on-demand voxels: a mark / build round in front of every shade launch
     if ((rc = get_light_dist(s, d->light_strategy, &ld, &ld_lazy))) return rc;
+    if (volpath && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "volpath with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
 
     // ---- this shard's pixels: Morton-ordered tiles (blockqueue/mod.rs:23-52), row-major inside a tile ----
     const int32_t ts = (int32_t)d->tile_size;
@@ -649,6 +674,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
         rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H);
         if (rc == RSPT_OK && direct) rc = ensure_direct(g.cap);
+        if (rc == RSPT_OK && volpath) rc = ensure_vol(g.cap);
         if (rc == RSPT_OK) break;
         (void)hipGetLastError();  // out of memory: clear the sticky error and try half the batch
         free_paths();
@@ -660,9 +686,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // on them); the loop below runs until no path is left, and a scene that needs more than RSPT_NULL_PASSES extra iterations is
     // reported, not silently truncated
     const uint32_t max_iters = s->has_null_material ? nominal_iters + (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : nominal_iters;
+    if (volpath) HIP_TRY(hipMemsetAsync(g.vol.truncated, 0, sizeof(uint32_t), g.stream));
     // K7b: whole waves of one class (escaped | depth limit | material) for k_shade.  C3 stand-in (two materials): 1396 -> 1686 Msamples/s;
     // C2 (one material: only the escaped paths are separated): 423 -> 425
-    const bool shade_bins = env_size("RSPT_SHADE_BINS", 1) != 0 && !ao && !direct;
+    const bool shade_bins = env_size("RSPT_SHADE_BINS", 1) != 0 && !ao && !direct && !volpath;
     if (shade_bins && (rc = ensure_bins(g.cap, max_iters + 10))) return rc;
     if (s->has_instances && (rc = ensure_hit_inst(g.cap))) return rc;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
@@ -707,6 +734,50 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
             g_queue_hint = 0xffffffffu;
+            if (volpath) {  // VolPathIntegrator::li (vol.h): the continuation queue doubles as the list of live paths
+                const uint32_t dgrid = grid_for(4);
+                const uint32_t null_passes = (uint32_t)env_size("RSPT_NULL_PASSES", 1024);
+                hipLaunchKernelGGL(k_vol_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, g.vol, bt.n);
+                // counters: g.cnt[0 / 1] = the continuation queue of this / the next pass, g.cnt[2 / 3] = the shadow-ray segments
+                uint32_t live = bt.n;
+                for (uint32_t pass = 0; live > 0; pass++) {
+                    const int par = pass & 1;
+                    QueueCounts* cur = &g.cnt[par];
+                    QueueCounts* nxt = &g.cnt[par ^ 1];
+                    HIP_TRY(hipMemsetAsync(nxt, 0, sizeof(QueueCounts), g.stream));
+                    HIP_TRY(hipMemsetAsync(&g.cnt[2], 0, sizeof(QueueCounts), g.stream));
+                    ev_open(0, 0);
+                    launch_trace<false, 0>(0, false, tgrid, s, g.q[par][1], &cur->closest, 0, &cur->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                    ev_close(0, 0);
+                    trace_launches++;
+                    ev_open(2, 0);
+                    hipLaunchKernelGGL(k_vol_shade, dim3(dgrid), dim3(256), 0, g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest, g.q[par ^ 1][1], &nxt->closest,
+                                       g.q[0][2], &g.cnt[2].closest, vol_dim_limit);
+                    ev_close(2, 0);
+                    // VisibilityTester::tr: segments until every shadow ray has arrived or is blocked
+                    for (uint32_t seg = 0;; seg++) {
+                        QueueCounts* tc = &g.cnt[2 + (seg & 1u)];
+                        QueueCounts* tn = &g.cnt[2 + ((seg + 1u) & 1u)];
+                        QueueCounts c;
+                        HIP_TRY(hipMemcpyAsync(&c, tc, sizeof c, hipMemcpyDeviceToHost, g.stream));
+                        HIP_TRY(hipStreamSynchronize(g.stream));
+                        if (c.closest == 0) break;
+                        if (seg > null_passes) { truncated += c.closest; break; }
+                        HIP_TRY(hipMemsetAsync(tn, 0, sizeof(QueueCounts), g.stream));
+                        ev_open(1, 0);
+                        launch_trace<false, 0>(0, false, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                        ev_close(1, 0);
+                        trace_launches++;
+                        hipLaunchKernelGGL(k_vol_tr, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
+                    }
+                    QueueCounts c;
+                    HIP_TRY(hipMemcpyAsync(&c, nxt, sizeof c, hipMemcpyDeviceToHost, g.stream));
+                    HIP_TRY(hipStreamSynchronize(g.stream));
+                    live = c.closest;
+                    if (live && pass >= nominal_iters + null_passes) { truncated += live; break; }
+                }
+                it = 4;
+            } else
             if (direct) {  // DirectLightingIntegrator::li (direct.h): specular tree, dimension assignment, light rounds, gather
                 const uint32_t nl = s->dev.n_lights, H = dl_H, md = d->max_depth;
                 const bool all = d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL;
@@ -927,6 +998,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             }
         stats->t_trace_closest_s = ksum[0] * 1e-3; stats->t_trace_any_s = ksum[1] * 1e-3; stats->t_shade_s = ksum[2] * 1e-3;
         stats->launches_closest = kev[0].size(); stats->launches_any = kev[1].size();
+        if (volpath) {  // paths vol.h cut because the sampler ran out of dimensions
+            uint32_t tv = 0;
+            HIP_TRY(hipMemcpy(&tv, g.vol.truncated, sizeof tv, hipMemcpyDeviceToHost));
+            truncated += tv;
+        }
         stats->truncated_paths = truncated;
         stats->samples = samples;
         stats->trace_launches = trace_launches;
@@ -1160,6 +1236,15 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         const rspt_mesh& m = d->meshes[i];
         if (m.alpha_tex > d->n_textures || m.shadow_alpha_tex > d->n_textures) return fail(RSPT_E_INVALID, "mesh %u: alpha texture index out of range", i);
         any_alpha |= m.alpha_tex != 0 || m.shadow_alpha_tex != 0;
+        if (m.medium_inside > d->n_media || m.medium_outside > d->n_media) return fail(RSPT_E_INVALID, "mesh %u: medium index out of range", i);
+    }
+    if (d->n_media && !d->media) return fail(RSPT_E_INVALID, "null media");
+    for (uint32_t i = 0; i < d->n_media; i++) {
+        const rspt_medium& m = d->media[i];
+        if (m.kind != RSPT_MEDIUM_HOMOGENEOUS) return fail(RSPT_E_UNSUPPORTED, "medium %u: kind %u (homogeneous media only)", i, m.kind);
+        for (int c = 0; c < 3; c++)
+            if (!(m.sigma_a[c] >= 0.0f) || !(m.sigma_s[c] >= 0.0f) || !std::isfinite(m.sigma_a[c]) || !std::isfinite(m.sigma_s[c])) return fail(RSPT_E_INVALID, "medium %u: bad sigma_a / sigma_s", i);
+        if (!(m.g > -1.0f && m.g < 1.0f)) return fail(RSPT_E_INVALID, "medium %u: g outside (-1, 1)", i);
     }
     if (any_alpha)
         for (uint64_t i = 0; i < d->n_prims; i++) {
@@ -1294,6 +1379,8 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((rc = upload(s, d->prims, d->n_prims, &s->dev.prims))) return bail(rc);
     if ((rc = upload(s, d->meshes, d->n_meshes, &meshes_d))) return bail(rc);
     s->dev.meshes = meshes_d;
+    if ((rc = upload(s, d->media, d->n_media, &s->dev.media))) return bail(rc);
+    s->dev.n_media = d->n_media;
     if ((rc = upload(s, d->P, d->n_vertices * 3, &P_d))) return bail(rc);
     if ((rc = upload(s, d->N, d->N ? d->n_vertices * 3 : 0, &s->dev.N))) return bail(rc);
     if ((rc = upload(s, d->S, d->S ? d->n_vertices * 3 : 0, &s->dev.S))) return bail(rc);

@@ -114,3 +114,14 @@ class DirectLightingIntegrator(PathIntegrator):
         rd.direct_strategy = abi.DIRECT_SAMPLE_ALL if self.strategy == "all" else abi.DIRECT_SAMPLE_ONE
         rd.n_light_samples = self.light_samples.ctypes.data if self.light_samples is not None else None
         return rd
+
+
+class VolPathIntegrator(PathIntegrator):
+    """VolPathIntegrator::new(max_depth, camera, sampler, pixel_bounds, rr_threshold, light_sample_strategy) (src/integrators/volpath.rs:38-55),
+    created by the "volpath" integrator name with the path integrator's defaults (api.rs:350-380).  Media come with the scene
+    (SceneBuilder.add_medium, add_mesh(medium=(inside, outside))); materials are flattened with allow_multiple_lobes = true as for "path"."""
+
+    def _desc(self, shard=None):
+        rd = super()._desc(shard)
+        rd.integrator = abi.INTEGRATOR_VOLPATH
+        return rd

@@ -538,6 +538,7 @@ class SceneBuilder:
     def __init__(self):
         self.P, self.N, self.UV, self.tris, self.tri_mesh = [], [], [], [], []
         self.meshes, self.mesh_material, self.mesh_emit = [], [], []
+        self.media = []
         self.materials = []
         self.nv = 0
         self.any_n = self.any_uv = False
@@ -634,9 +635,22 @@ class SceneBuilder:
         self.materials.append(m)
         return len(self.materials) - 1
 
-    def add_mesh(self, P, idx, material, N=None, UV=None, emit=None, two_sided=False, flip=False, alpha=None, shadow_alpha=None):
+    def add_medium(self, sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77), g=0.0, scale=1.0):
+        """MakeNamedMedium "homogeneous" (api.rs:953-1037; the defaults are the ones at :959-960): returns the handle add_mesh's
+        `medium=(inside, outside)` takes (None = no medium)"""
+        md = np.zeros((), abi.MEDIUM_DT)
+        md["kind"] = abi.MEDIUM_HOMOGENEOUS; md["g"] = F32(g)
+        md["sigma_a"] = np.array(sigma_a, F32) * F32(scale); md["sigma_s"] = np.array(sigma_s, F32) * F32(scale)
+        self.media.append(md)
+        return len(self.media)   # 1 + index, what rspt_mesh.medium_inside / _outside hold
+
+    def add_mesh(self, P, idx, material, N=None, UV=None, emit=None, two_sided=False, flip=False, alpha=None, shadow_alpha=None, medium=(None, None)):
         """P (nv,3) world-space vertices; idx (nt,3); emit = rgb L or None; alpha / shadow_alpha: float textures (TexRef) of the
-        shape's "alpha" / "shadowalpha" parameters (api.rs:1920-1965): where they evaluate to 0 the surface is not there."""
+        shape's "alpha" / "shadowalpha" parameters (api.rs:1920-1965): where they evaluate to 0 the surface is not there.
+        material None: Material "" / "none" (a surface without BSDF: a medium boundary); medium = the graphics state's
+        MediumInterface (inside, outside) when the shape is declared (api.rs:2618-2640)."""
+        if material is None:
+            material = abi.NO_MATERIAL
         P = np.asarray(P, F32).reshape(-1, 3); idx = np.asarray(idx, np.uint32).reshape(-1, 3)
         m = len(self.meshes)
         assert self.cur_object < 0 or emit is None, "Area lights not supported with object instancing (api.rs:2899)"
@@ -644,7 +658,8 @@ class SceneBuilder:
         if self.cur_object < 0:
             self.decl.append(("mesh", m))
         assert emit is None or (alpha is None and shadow_alpha is None), "alpha masks on emissive meshes are not supported"
-        self.meshes.append((int(N is not None), 0, int(UV is not None), int(flip), 0 if alpha is None else alpha.index + 1, 0 if shadow_alpha is None else shadow_alpha.index + 1))
+        self.meshes.append((int(N is not None), 0, int(UV is not None), int(flip), 0 if alpha is None else alpha.index + 1, 0 if shadow_alpha is None else shadow_alpha.index + 1,
+                            medium[0] or 0, medium[1] or 0))
         self.mesh_material.append(material)
         self.mesh_emit.append(None if emit is None else (np.array(emit, F32), bool(two_sided)))
         self.P.append(P)
@@ -658,6 +673,15 @@ class SceneBuilder:
 
     def add_quad(self, p, material, **kw):
         return self.add_mesh(np.array(p, F32), [[0, 1, 2], [0, 2, 3]], material, **kw)
+
+    def add_box(self, lo, hi, material, **kw):
+        """an axis-aligned box as one mesh of 12 triangles whose geometric normals (cross(p0 - p2, p1 - p2), triangle.rs:293) point
+        outwards: what a medium boundary needs (Interaction::get_medium picks `outside` for directions on the normal's side)"""
+        x0, y0, z0 = lo; x1, y1, z1 = hi
+        P = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+        quads = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (3, 7, 6, 2), (0, 4, 7, 3), (1, 2, 6, 5)]   # -z +z -y +y -x +x, counter-clockwise seen from outside
+        idx = [t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))]
+        return self.add_mesh(np.array(P, F32), idx, material, **kw)
 
     def add_point_light(self, p, I):
         """LightSource "point" (api.rs:773-794, point.rs:30-49): p = from, I = I * scale"""
@@ -817,7 +841,7 @@ class SceneBuilder:
                      UV=np.ascontiguousarray(np.concatenate(self.UV), F32) if self.any_uv else None,
                      materials=mats, bxdfs=bxdfs, lights=lights, envmaps=self.envmaps,
                      textures=np.array(self.textures, abi.TEXTURE_DT) if self.textures else None, images=self.images,
-                     objects=objects, instances=instances, n_top=(n_top_nodes, n_top_prims),
+                     objects=objects, instances=instances, n_top=(n_top_nodes, n_top_prims), media=np.array(self.media, abi.MEDIUM_DT) if self.media else None,
                      instancing={"reference": abi.INSTANCING_REFERENCE, "fixed": abi.INSTANCING_FIXED}[instancing], builder=self)
 
 
@@ -837,7 +861,8 @@ class Scene:
     """Flattened scene arrays + the ctypes rspt_scene_desc pointing at them."""
 
     def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=(), textures=None, images=(),
-                 objects=None, instances=None, n_top=None, instancing=abi.INSTANCING_REFERENCE, builder=None):
+                 objects=None, instances=None, n_top=None, instancing=abi.INSTANCING_REFERENCE, builder=None, media=None):
+        self.media = media if media is not None else np.zeros(0, abi.MEDIUM_DT)
         self.builder = builder  # declaration-order view of the scene (tools/export_pbrt.py)
         self.nodes, self.prims, self.meshes, self.P, self.N, self.UV, self.S = nodes, prims, meshes, P, N, UV, S
         self.objects = objects if objects is not None else np.zeros(0, abi.OBJECT_DT)
@@ -861,7 +886,7 @@ class Scene:
                                   p(self.textures), len(self.textures),
                                   C.addressof(self._img_structs) if self.images else None, len(self.images),
                                   p(self.objects), len(self.objects), p(self.instances), len(self.instances),
-                                  self.n_top[0], self.n_top[1], instancing, 0)
+                                  self.n_top[0], self.n_top[1], instancing, len(self.media), p(self.media))
 
     def set_instancing(self, mode):
         """"reference" | "fixed" (rspt_scene_desc.instancing_mode); takes effect at the next DeviceScene / oracle call"""
@@ -899,7 +924,7 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
     rd = abi.RenderDesc()
     # Integrator "path" (path.rs), "ao" / "ambientocclusion" (api.rs:411; ao.rs: nsamples 64, cossample true) or
     # "directlighting" (api.rs:322-349: strategy "all" | "one", maxdepth 5; light_samples = Light::get_n_samples per light)
-    rd.integrator = {"ao": abi.INTEGRATOR_AO, "directlighting": abi.INTEGRATOR_DIRECT}.get(integrator, abi.INTEGRATOR_PATH)
+    rd.integrator = {"ao": abi.INTEGRATOR_AO, "directlighting": abi.INTEGRATOR_DIRECT, "volpath": abi.INTEGRATOR_VOLPATH}.get(integrator, abi.INTEGRATOR_PATH)
     rd.direct_strategy = {"all": abi.DIRECT_SAMPLE_ALL, "one": abi.DIRECT_SAMPLE_ONE}[direct_strategy]
     if light_samples is not None:
         rd._light_samples = np.ascontiguousarray(light_samples, np.int32)  # kept alive by the desc object

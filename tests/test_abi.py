@@ -42,12 +42,12 @@ def test_struct_layouts_match_the_header():
 #define O(t, f) printf(#t "." #f " %zu\n", offsetof(t, f))
 int main(void) {
   S(rspt_bvh_node); S(rspt_prim); S(rspt_mesh); S(rspt_bxdf); S(rspt_material); S(rspt_light);
-  S(rspt_scene_desc); S(rspt_envmap); S(rspt_image); S(rspt_texture); S(rspt_sampler_tables); S(rspt_render_desc); S(rspt_ray); S(rspt_hit); S(rspt_stats);
+  S(rspt_scene_desc); S(rspt_medium); S(rspt_envmap); S(rspt_image); S(rspt_texture); S(rspt_sampler_tables); S(rspt_render_desc); S(rspt_ray); S(rspt_hit); S(rspt_stats);
   O(rspt_render_desc, filter_table); O(rspt_render_desc, raster_to_camera); O(rspt_render_desc, spp);
   O(rspt_render_desc, max_depth); O(rspt_render_desc, shard_index); O(rspt_render_desc, tables);
   O(rspt_scene_desc, P); O(rspt_scene_desc, materials); O(rspt_scene_desc, lights); O(rspt_stats, alg_bytes);
   O(rspt_bxdf, alpha_x); O(rspt_bxdf, on_a); O(rspt_bxdf, tex_r); O(rspt_bxdf, tex_t); O(rspt_material, bump_tex);
-  O(rspt_scene_desc, textures); O(rspt_scene_desc, images); O(rspt_scene_desc, n_images);
+  O(rspt_scene_desc, textures); O(rspt_scene_desc, images); O(rspt_scene_desc, n_images); O(rspt_scene_desc, n_media); O(rspt_scene_desc, media); O(rspt_mesh, medium_inside); O(rspt_medium, g);
   O(rspt_texture, map); O(rspt_texture, image); O(rspt_texture, max_aniso); O(rspt_texture, value); O(rspt_texture, tex2); O(rspt_texture, tex3); O(rspt_texture, world_to_texture); O(rspt_texture, octaves); O(rspt_texture, variation); O(rspt_image, texels);
   return 0; }'''
     with tempfile.TemporaryDirectory() as td:
@@ -55,7 +55,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "p"), os.path.join(td, "p.c")])
         out = dict(l.split() for l in subprocess.check_output([os.path.join(td, "p")]).decode().splitlines())
     ct = {"rspt_bvh_node": abi.BvhNode, "rspt_prim": abi.Prim, "rspt_mesh": abi.Mesh, "rspt_bxdf": abi.Bxdf, "rspt_material": abi.Material,
-          "rspt_light": abi.Light, "rspt_scene_desc": abi.SceneDesc, "rspt_envmap": abi.EnvMap, "rspt_image": abi.Image, "rspt_texture": abi.Texture, "rspt_sampler_tables": abi.SamplerTables, "rspt_render_desc": abi.RenderDesc,
+          "rspt_light": abi.Light, "rspt_scene_desc": abi.SceneDesc, "rspt_medium": abi.Medium, "rspt_envmap": abi.EnvMap, "rspt_image": abi.Image, "rspt_texture": abi.Texture, "rspt_sampler_tables": abi.SamplerTables, "rspt_render_desc": abi.RenderDesc,
           "rspt_ray": abi.Ray, "rspt_hit": abi.Hit, "rspt_stats": abi.Stats}
     for k, v in out.items():
         if "." in k:
@@ -63,7 +63,7 @@ int main(void) {
             assert getattr(ct[t], f).offset == int(v), k
         else:
             assert C.sizeof(ct[k]) == int(v), k
-    for dt, t in ((abi.NODE_DT, abi.BvhNode), (abi.PRIM_DT, abi.Prim), (abi.MESH_DT, abi.Mesh), (abi.BXDF_DT, abi.Bxdf),
+    for dt, t in ((abi.NODE_DT, abi.BvhNode), (abi.PRIM_DT, abi.Prim), (abi.MESH_DT, abi.Mesh), (abi.MEDIUM_DT, abi.Medium), (abi.BXDF_DT, abi.Bxdf),
                   (abi.MATERIAL_DT, abi.Material), (abi.TEXTURE_DT, abi.Texture), (abi.LIGHT_DT, abi.Light), (abi.RAY_DT, abi.Ray), (abi.HIT_DT, abi.Hit)):
         assert dt.itemsize == C.sizeof(t)
 

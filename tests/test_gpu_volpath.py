@@ -1,0 +1,104 @@
+"""VolPathIntegrator::li on the GPU (rs_pbrt_amd/csrc/vol.h) against the oracle (volpath.rs:60-347, homogeneous.rs, medium.rs).
+Radiance goes through expf / logf (the medium) and sinf / cosf (phase function and BSDF sampling), whose last ulp differs between glibc
+and the device library for a few per cent of the arguments: the bar is the film RMSE of DESIGN.md section 3 (1e-5 at 16+ spp, weights exact)."""
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import abi, scenes
+from tests.test_volpath import slab_scene
+from tests.util import film_rmse
+
+pytestmark = pytest.mark.gpu
+LOOK = ((0, 1.0, -6.0), (0, 1.0, 0), (0, 1, 0))
+
+
+def fog_room(builder, g=0.4, area_light=True, glass=False, thin=1.0):
+    """a room with a box of fog in it (a medium boundary without material), a diffuse block inside the fog, a point light outside it and
+    an area light above: paths scatter in the medium, on surfaces inside and outside it, and shadow rays cross its boundary"""
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.6, 0.6, 0.6)))
+    red = sb.add_material(scenes.matte((0.7, 0.25, 0.2)))
+    fog = sb.add_medium(sigma_a=(0.02, 0.03, 0.05), sigma_s=(0.35, 0.3, 0.25), g=g, scale=thin)
+    sb.add_quad([(-4, 0, -4.03), (-4, 0, 4.03), (4, 0, 4.03), (4, 0, -4.03)], grey)
+    sb.add_quad([(-4, 0, 2.97), (-4, 5.03, 2.97), (4, 5.03, 2.97), (4, 0, 2.97)], grey)
+    sb.add_box((-1.53, 0.07, -1.51), (1.49, 2.53, 1.52), None, medium=(fog, None))
+    sb.add_box((-0.52, 0.31, -0.49), (0.51, 1.27, 0.53), red, medium=(fog, fog))            # inside the fog: not a transition, rays keep their medium
+    if glass:
+        sb.add_box((1.93, 0.09, -0.8), (2.87, 1.1, 0.1), sb.add_material(scenes.glass((1, 1, 1), (1, 1, 1), 1.5)))
+    if area_light:
+        sb.add_quad([(-1, 4.47, -1), (1, 4.47, -1), (1, 4.47, 1), (-1, 4.47, 1)], grey, emit=(14, 13, 12))
+    sb.add_point_light((2.5, 3.1, -3.2), (22, 22, 25))
+    return sb.finish(builder)
+
+
+@pytest.mark.parametrize("case", ["fog", "fog-isotropic", "fog-glass", "fog-delta-only", "fog-dense", "fog-halton", "fog-uniform-lights"])
+def test_gpu_volpath_matches_oracle(gpu, oracle, case):
+    sc = fog_room(gpu.bvh_build, g=0.0 if case == "fog-isotropic" else (-0.3 if case == "fog-dense" else 0.4), glass=case == "fog-glass",
+                  area_light=case != "fog-delta-only", thin=6.0 if case == "fog-dense" else 1.0)
+    kw = dict(sampler="halton") if case == "fog-halton" else {}
+    if case == "fog-uniform-lights":
+        kw["light_strategy"] = abi.LIGHTS_UNIFORM
+    rd = scenes.make_render_desc(64, 48, 16, LOOK, 55.0, integrator="volpath", max_depth=7 if case == "fog-dense" else 5, **kw)
+    ref = oracle.render(sc, rd, threads=8)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    assert st["samples"] == ref["counters"]["samples"] and st["truncated_paths"] == 0
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 1e-5
+    assert scenes.film_to_rgb(film).mean() > 0.02
+
+
+def test_gpu_beer_lambert_and_media_free_scenes(gpu, oracle):
+    """the absorbing slab of tests/test_volpath.py (closed form) and a scene without media, where volpath and path differ only by the
+    estimate's BSDF-sampled half"""
+    sc = slab_scene(gpu.bvh_build, (0.7, 0.7, 0.7), (0, 0, 0))
+    rd = scenes.make_render_desc(48, 48, 64, ((0, 0, -6.0), (0, 0, 0), (0, 1, 0)), 12.0, integrator="volpath")
+    with gpu.DeviceScene(sc) as ds:
+        film, _ = gpu.render(ds, rd)
+        rdp = scenes.make_render_desc(48, 48, 4, ((0, 0, -6.0), (0, 0, 0), (0, 1, 0)), 12.0)
+        plain, _ = gpu.render(ds, rdp)   # the path integrator ignores the medium
+    assert np.allclose(scenes.film_to_rgb(film).reshape(-1, 3).mean(0), np.array([3.0, 2.0, 1.0]) * np.exp(-0.7), rtol=0.01)
+    assert np.allclose(scenes.film_to_rgb(plain).reshape(-1, 3).mean(0), [3.0, 2.0, 1.0], rtol=1e-5)
+    ref = oracle.render(sc, rd, threads=8)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-5
+    cb = scenes.cornell_box(gpu.bvh_build)
+    rdc = scenes.cornell_render_desc(res=64, spp=16)
+    rdc.integrator = abi.INTEGRATOR_VOLPATH
+    refc = oracle.render(cb, rdc, threads=8)
+    with gpu.DeviceScene(cb) as ds:
+        fc, _ = gpu.render(ds, rdc)
+    assert np.array_equal(fc[:, 3], refc["film"][:, 3]) and film_rmse(fc, refc["film"]) < 1e-5
+
+
+def test_gpu_volpath_escaping_paths_and_infinite_light(gpu, oracle):
+    """no walls: most scattered rays leave the scene, which ends the path (volpath.rs:338-339) after the infinite light was added for
+    bounces == 0 along the SCATTERED ray (:332-337)"""
+    sb = scenes.SceneBuilder()
+    fog = sb.add_medium(sigma_a=(0.05, 0.05, 0.05), sigma_s=(0.5, 0.6, 0.7), g=0.6)
+    sb.add_box((-1.53, -1.07, -1.51), (1.49, 1.53, 1.52), None, medium=(fog, None))
+    sb.add_box((-0.4, -0.4, -0.4), (0.45, 0.35, 0.4), sb.add_material(scenes.matte((0.5, 0.5, 0.5))), medium=(fog, fog))
+    sb.add_infinite_light(L=(0.6, 0.7, 0.9))
+    sb.add_point_light((3, 3, -3), (30, 30, 30))
+    sc = sb.finish(gpu.bvh_build)
+    rd = scenes.make_render_desc(64, 48, 16, ((0, 0.5, -6.0), (0, 0, 0), (0, 1, 0)), 40.0, integrator="volpath")
+    ref = oracle.render(sc, rd, threads=8)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-5 and st["truncated_paths"] == 0
+
+
+def test_gpu_volpath_refusals(gpu):
+    from rs_pbrt_amd.lib import RsptError
+    sb = scenes.SceneBuilder()
+    m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    sb.add_quad([(-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1)], m)
+    sc = sb.finish(gpu.bvh_build)
+    sc.meshes["medium_inside"][0] = 3   # no such medium
+    with pytest.raises(RsptError) as e:
+        gpu.DeviceScene(sc)
+    assert e.value.code == abi.E_INVALID
+    from tests.test_instancing import small_scene
+    with gpu.DeviceScene(small_scene(gpu.bvh_build)) as ds:
+        with pytest.raises(RsptError) as e:
+            gpu.render(ds, scenes.make_render_desc(16, 16, 1, LOOK, 50.0, integrator="volpath"))
+        assert e.value.code == abi.E_UNSUPPORTED
