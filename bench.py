@@ -37,8 +37,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--integrator", default="path", choices=["path", "ao", "directlighting"],
-                    help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample); directlighting: DirectLightingIntegrator, strategy all, maxdepth 5")
+    ap.add_argument("--integrator", default="path", choices=["path", "ao", "directlighting", "volpath"],
+                    help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample); directlighting: DirectLightingIntegrator, strategy all, maxdepth 5; "
+                         "volpath: VolPathIntegrator (with --workload cornell the room is filled with a homogeneous medium)")
     ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
@@ -75,9 +76,9 @@ def build_workload(args, workload, lib, scenes):
         name = "synthetic %d-triangle soup, path depth 8, sobol %d spp, %dx%d" % (args.tris, spp, res, res)
     elif workload == "cornell":
         res, spp = args.res or 400, args.spp or 64
-        sc = scenes.cornell_box(lib.bvh_build_gpu)
+        sc = scenes.cornell_box(lib.bvh_build_gpu, fog=scenes.CORNELL_FOG if integ == "volpath" else None)
         mk = lambda s, sh, **kw: scenes.cornell_render_desc(res=res, spp=s, shard=sh, integrator=integ, **kw)  # noqa: E731
-        name = "Cornell Box, path depth 5, sobol %d spp, %dx%d" % (spp, res, res)
+        name = "Cornell Box%s, path depth 5, sobol %d spp, %dx%d" % (" filled with a homogeneous medium (optical depth ~1 across the room)" if integ == "volpath" else "", spp, res, res)
     elif workload == "c5":
         xres, spp = args.res or 1920, args.spp or 64
         yres = xres * 9 // 16

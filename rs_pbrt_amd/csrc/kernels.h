@@ -552,8 +552,8 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
 // only; bounce rays carry none, interaction.rs:388-479), Material::bump, and the clamped value of each
 // texture the material's lobes are bound to; k_shade picks the results up from pb.tex.
 __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
-                                                 const QueueCounts* __restrict__ cnt_in) {
-    const uint32_t n = cnt_in->active;
+                                                 const uint32_t* __restrict__ count_in) {
+    const uint32_t n = *count_in;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const uint32_t p = q_active[i];
         const uint32_t st = pb.state[p];

@@ -503,7 +503,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
     const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
     if (volpath && s) {
-        if (s->has_textures) return fail(RSPT_E_UNSUPPORTED, "volpath with textured materials");
         if (s->has_instances) return fail(RSPT_E_UNSUPPORTED, "volpath with object instances (transform_surface_interaction drops the medium interface)");
     }
     if (direct) {
@@ -722,7 +721,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     };
     auto ev_close = [&](int kind, int lane) { (void)hipEventRecord(kev[kind].back().second, lane ? g.stream2 : g.stream); };
     HIP_TRY(hipEventRecord(ev_k0, g.stream));
-    uint64_t samples = 0, truncated = 0;
+    uint64_t samples = 0, truncated = 0, vol_rays = 0;
     for (size_t p0 = 0; p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
         for (uint32_t s0 = 0; s0 < (uint32_t)d->spp; s0 += ns) {
@@ -737,6 +736,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             if (volpath) {  // VolPathIntegrator::li (vol.h): the continuation queue doubles as the list of live paths
                 const uint32_t dgrid = grid_for(4);
                 const uint32_t null_passes = (uint32_t)env_size("RSPT_NULL_PASSES", 1024);
+                // LDS table: 10 dimensions per counted pass, 2 per pass through a medium boundary (room for 64 of those), 8 of read-ahead;
+                // a path that needs more is cut and counted (rspt_stats.truncated_paths); the reference's own limit is 1024
+                const uint32_t vnd = std::min(1024u, 5u + 10u * (d->max_depth + 2u) + 128u) + 8u;
+                if ((size_t)vnd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "volpath: max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
+                const uint32_t vlimit = halton ? vol_dim_limit : std::min(1024u, vnd - 8u);
                 hipLaunchKernelGGL(k_vol_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, g.vol, bt.n);
                 // counters: g.cnt[0 / 1] = the continuation queue of this / the next pass, g.cnt[2 / 3] = the shadow-ray segments
                 uint32_t live = bt.n;
@@ -747,12 +751,14 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                     HIP_TRY(hipMemsetAsync(nxt, 0, sizeof(QueueCounts), g.stream));
                     HIP_TRY(hipMemsetAsync(&g.cnt[2], 0, sizeof(QueueCounts), g.stream));
                     ev_open(0, 0);
-                    launch_trace<false, 0>(0, false, tgrid, s, g.q[par][1], &cur->closest, 0, &cur->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                    launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &cur->closest, 0, &cur->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
                     ev_close(0, 0);
                     trace_launches++;
+                    vol_rays += live;
                     ev_open(2, 0);
-                    hipLaunchKernelGGL(k_vol_shade, dim3(dgrid), dim3(256), 0, g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest, g.q[par ^ 1][1], &nxt->closest,
-                                       g.q[0][2], &g.cnt[2].closest, vol_dim_limit);
+                    if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][1], &cur->closest);
+                    hipLaunchKernelGGL(k_vol_shade, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest,
+                                       g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits);
                     ev_close(2, 0);
                     // VisibilityTester::tr: segments until every shadow ray has arrived or is blocked
                     for (uint32_t seg = 0;; seg++) {
@@ -765,9 +771,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                         if (seg > null_passes) { truncated += c.closest; break; }
                         HIP_TRY(hipMemsetAsync(tn, 0, sizeof(QueueCounts), g.stream));
                         ev_open(1, 0);
-                        launch_trace<false, 0>(0, false, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                        launch_trace<false, 0>(0, counters, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
                         ev_close(1, 0);
                         trace_launches++;
+                        vol_rays += c.closest;
                         hipLaunchKernelGGL(k_vol_tr, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
                     }
                     QueueCounts c;
@@ -914,7 +921,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                     hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
                     hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
                 }
-                if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it]);
+                if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active);
                 hipLaunchKernelGGL(k_shade, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                    g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
                                    shade_bins ? g.q_sorted : (const uint32_t*)nullptr, shade_bins ? &g.bin_info[it] : (const BinInfo*)nullptr);
@@ -1009,6 +1016,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         unsigned long long tot[8];
         HIP_TRY(hipMemcpy(tot, g.totals, sizeof tot, hipMemcpyDeviceToHost));
         stats->nan_samples = tot[5];
+        if (volpath) { tot[3] = vol_rays; tot[4] = 0; }  // every volpath ray is a closest-hit ray (shadow rays walk segment by segment); counted from the queue lengths the host reads
         if (counters) {
             stats->nodes_visited = tot[0]; stats->tris_tested = tot[1];
             stats->rays_closest = tot[3]; stats->rays_any = tot[4];

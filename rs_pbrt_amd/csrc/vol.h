@@ -30,11 +30,31 @@ struct VolBuf {         // per path slot, next to PathBuf
 // pb.nee_c1 = (f.rgb, light_pdf)   pb.nee_c2 = (li.rgb, MIS weight | < 0 for a delta light)   pb.nee_beta = (beta.rgb, light choice pdf)
 // pb.ray_mis / pb.hit_mis = the shadow ray's current segment and its closest hit
 
-struct VolSampler {  // GlobalSampler::get_1d / get_2d (sobol.rs:180-201, halton.rs) without sample arrays: dimensions in order
+struct VolSampler {  // GlobalSampler::get_1d / get_2d (sobol.rs:180-201, halton.rs) without sample arrays: dimensions in order.
+                     // Sobol': eight dimensions at a time from the LDS copy of the generator matrices (SobolBlock, as k_shade), refilled
+                     // when a pass needs more (a pass can draw 2 + 5 + 2 + 1)
+    SobolBlock blk;
+    const uint32_t* tab;
+    uint32_t nd;
     uint64_t index;
-    uint32_t dim;
-    RDEV float get_1d(const RenderDev& rd) { return rd.sampler_kind == RSPT_SAMPLER_HALTON ? halton_dim(rd, index, dim++) : sobol_dim(rd, index, dim++); }
-    RDEV f2 get_2d(const RenderDev& rd) { const f2 v = dl_dims(rd, index, dim); dim += 2u; return v; }
+    uint32_t hdim;
+    bool halton;
+    RDEV void start(const RenderDev& rd, const uint32_t* t, uint32_t n, uint64_t idx, uint32_t first_dim) {
+        halton = rd.sampler_kind == RSPT_SAMPLER_HALTON;
+        tab = t; nd = n; index = idx; hdim = first_dim;
+        if (!halton) blk.fill(tab, nd, idx, first_dim);
+    }
+    RDEV uint32_t dim() const { return halton ? hdim : blk.dim; }
+    RDEV float get_1d(const RenderDev& rd) {
+        if (halton) return halton_dim(rd, index, hdim++);
+        if (blk.dim + 1u > blk.base + 8u) blk.fill(tab, nd, index, blk.dim);
+        return blk.get_1d();
+    }
+    RDEV f2 get_2d(const RenderDev& rd) {
+        if (halton) { const f2 v = dl_dims(rd, index, hdim); hdim += 2u; return v; }
+        if (blk.dim + 2u > blk.base + 8u) blk.fill(tab, nd, index, blk.dim);
+        return blk.get_2d();
+    }
 };
 
 RDEV rgb med_sigma_t(const rspt_medium& m) { return ldrgb(m.sigma_s) + ldrgb(m.sigma_a); }  // HomogeneousMedium::new (homogeneous.rs:24-31)
@@ -119,7 +139,13 @@ RDEV bool vol_estimate(const SceneDev& sc, const LightDistDev& ld, const RenderD
 // one pass of the loop body of VolPathIntegrator::li for every live path
 __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ q_next, uint32_t* cnt_next,
-                                                   uint32_t* __restrict__ q_tr, uint32_t* cnt_tr, uint32_t dim_limit) {
+                                                   uint32_t* __restrict__ q_tr, uint32_t* cnt_tr, uint32_t dim_limit, uint32_t sob_nd, uint32_t sob_bits) {
+    extern __shared__ uint32_t sob_tab[];  // Sobol' generator matrices of the dimensions a path can reach, transposed to [bit][dim] (as k_shade)
+    for (uint32_t t = threadIdx.x; rd.sampler_kind == RSPT_SAMPLER_SOBOL && t < sob_nd * sob_bits; t += 256u) {
+        const uint32_t dd = t % sob_nd;
+        sob_tab[t] = rd.sobol32[(dd < 1024u ? dd : 1023u) * 52u + (t / sob_nd)];
+    }
+    __syncthreads();
     const uint32_t n = *count_in;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
@@ -141,14 +167,15 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
             const bool hit = prim != RSPT_MISS;
             uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
             const uint32_t medium = vb.medium[p];
-            VolSampler smp{pb.sobol_index[p], st & ST_DIM_MASK};
+            VolSampler smp;
+            smp.start(rd, sob_tab, sob_nd, pb.sobol_index[p], st & ST_DIM_MASK);
             bool specular = (st & ST_SPECULAR) != 0;
             rgb post = mkrgb(0.0f);
             bool have_post = false, counted = true;   // counted: this pass ends with `bounces += 1`
             f3 new_o = ray_o, new_d = ray_d;
             uint32_t new_medium = medium;
 
-            if (smp.dim + 12u > dim_limit) {  // the reference's sampler panics past its last dimension (sobol.rs:119-124): cut and report
+            if (smp.dim() + 12u > dim_limit) {  // the reference's sampler panics past its last dimension (sobol.rs:119-124): cut and report
                 atomicAdd(vb.truncated, 1u);
             } else {
                 TriRec tri{};
@@ -213,10 +240,23 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                                 new_o = offset_ray_origin(h.p, h.p_err, h.n, ray_d);
                                 new_medium = surface_medium(sc, prim, medium, h.n, ray_d);
                                 go_on = true; counted = false;
+                                st |= ST_NO_DIFF;   // the re-spawned ray carries no differentials (k_texture)
                             } else {
                                 const rspt_material mat = sc.materials[h.material];
-                                Bsdf b;  // Bsdf::new (reflection.rs:235-245), constant textures
+                                Bsdf b;  // Bsdf::new (reflection.rs:235-245)
                                 b.eta = mat.eta; b.lt = LobeTex{nullptr, 0}; b.dropped = 0u;
+                                if (sc.mat_flags && sc.mat_flags[h.material]) {  // textured material: k_texture ran for this hit (as in shade_path)
+                                    const float4* tb = pb.tex + p;
+                                    b.lt = LobeTex{tb, pb.tex_stride};
+                                    const float4 m4 = tb[4 * (size_t)pb.tex_stride];
+                                    const uint32_t tf = __float_as_uint(m4.w);
+                                    b.dropped = (tf >> 8) & 0xffu;
+                                    if (tf & 1u) {
+                                        const float4 d4 = tb[5 * (size_t)pb.tex_stride];
+                                        h.sh_n = f3{m4.x, m4.y, m4.z};
+                                        h.sh_dpdu = f3{d4.x, d4.y, d4.z};
+                                    }
+                                }
                                 b.ss = normalize(h.sh_dpdu); b.ns = h.sh_n; b.ng = h.n; b.ts = cross(h.sh_n, b.ss);
                                 b.lobes = sc.bxdfs + mat.first_bxdf;
                                 b.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
@@ -274,7 +314,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
             vb.post[p] = make_float4(post.r, post.g, post.b, have_post ? 1.0f : 0.0f);
             if (!shadow && have_post) L = L + post;   // nothing in flight: the estimate added 0
             pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
-            st = (st & ~(ST_DIM_MASK | (0xffu << ST_BOUNCE_SHIFT) | ST_SPECULAR)) | (smp.dim & ST_DIM_MASK) | ((bounces & 0xffu) << ST_BOUNCE_SHIFT) | (specular ? ST_SPECULAR : 0u);
+            st = (st & ~(ST_DIM_MASK | (0xffu << ST_BOUNCE_SHIFT) | ST_SPECULAR)) | (smp.dim() & ST_DIM_MASK) | ((bounces & 0xffu) << ST_BOUNCE_SHIFT) | (specular ? ST_SPECULAR : 0u);
             pb.state[p] = st;
         }
         dl_push(go_on, p, q_next, cnt_next);

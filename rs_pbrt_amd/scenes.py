@@ -969,6 +969,8 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
     rd.max_depth, rd.rr_threshold, rd.light_strategy, rd.tile_size = max_depth, rr_threshold, light_strategy, 16
     rd.shard_index, rd.shard_count, rd.tile_chunk = shard
     n_halton_dims = 5 + 8 * (max_depth + 3)
+    if integrator == "volpath":   # 10 dimensions per counted bounce, 2 per pass through a medium boundary (librspt cuts and reports a path that needs more)
+        n_halton_dims = min(999, 5 + 10 * (max_depth + 2) + 64 + 8)
     if integrator == "directlighting":  # sample arrays + a full specular tree on the fall-back stream (rs_pbrt_amd/csrc/direct.h)
         nl = len(light_samples) if light_samples is not None else 16
         n_halton_dims = min(999, 5 + 4 * max_depth * nl + ((1 << max_depth) - 1) * (4 * nl + 4) + 4)
@@ -996,10 +998,13 @@ def film_to_rgb(film_xyzw):
 # ---------------------------------------------------------------------------------------
 # BASELINE scenes
 # ---------------------------------------------------------------------------------------
-def cornell_box(bvh_builder, variant="matte"):
+def cornell_box(bvh_builder, variant="matte", fog=None):
     """C1: the public Cornell Box data (32 triangles, one quad light).  variant 'mixed' swaps the
-    blocks to mirror / glass and the floor to plastic for BSDF coverage."""
+    blocks to mirror / glass and the floor to plastic for BSDF coverage.  fog = (sigma_a, sigma_s, g): a homogeneous medium
+    fills the room (a box without material just inside the walls, MediumInterface inside = the fog) — a workload for "volpath";
+    the two blocks stand inside it (MediumInterface fog / fog: no transition, rays keep their medium)."""
     sb = SceneBuilder()
+    med = sb.add_medium(sigma_a=fog[0], sigma_s=fog[1], g=fog[2]) if fog else None
     white = sb.add_material(matte((0.725, 0.71, 0.68)))
     red = sb.add_material(matte((0.63, 0.065, 0.05)))
     green = sb.add_material(matte((0.14, 0.45, 0.091)))
@@ -1031,10 +1036,13 @@ def cornell_box(bvh_builder, variant="matte"):
                        [(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)],
                        [(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)]], tall_m)):
         for p in quads:
-            q(p, m)
+            q(p, m, medium=(med, med))
+    if fog:
+        sb.add_box((1.3, 0.7, 0.9), (548.1, 547.9, 558.3), None, medium=(med, None))
     return sb.finish(bvh_builder)
 
 
+CORNELL_FOG = ((0.0002, 0.0002, 0.0003), (0.0016, 0.0016, 0.0014), 0.3)   # per scene unit (the room is 550 units wide): optical depth ~1 across it
 CORNELL_LOOK_AT = ((278, 273, -800), (278, 273, 0), (0, 1, 0))
 CORNELL_FOV = 39.3
 

@@ -1,10 +1,10 @@
-//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 13) one to one.
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 14) one to one.
 //! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
 //! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RSPT_ABI_VERSION: c_int = 13;
+pub const RSPT_ABI_VERSION: c_int = 14;
 pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
 pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
 
@@ -13,7 +13,10 @@ pub struct RsptBvhNode { pub bmin: [f32; 3], pub bmax: [f32; 3], pub offset: i32
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptPrim { pub v: [u32; 3], pub mesh: u32, pub material: u32, pub area_light: i32 } // 24 B
 #[repr(C)] #[derive(Clone, Copy, Default)]
-pub struct RsptMesh { pub has_n: u32, pub has_s: u32, pub has_uv: u32, pub flip: u32, pub alpha_tex: u32, pub shadow_alpha_tex: u32 }
+pub struct RsptMesh { pub has_n: u32, pub has_s: u32, pub has_uv: u32, pub flip: u32, pub alpha_tex: u32, pub shadow_alpha_tex: u32,
+                      pub medium_inside: u32, pub medium_outside: u32 }   // 0 = none, else 1 + index into media
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptMedium { pub kind: u32, pub sigma_a: [f32; 3], pub sigma_s: [f32; 3], pub g: f32 }   // kind 1 = HomogeneousMedium
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptBxdf { // 116 B
     pub kind: u32, pub fresnel: u32, pub r: [f32; 3], pub t: [f32; 3], pub eta_a: f32, pub eta_b: f32, pub alpha_x: f32, pub alpha_y: f32,
@@ -43,7 +46,7 @@ pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_wor
     pub lights: *const RsptLight, pub n_lights: u32, pub envmaps: *const RsptEnvMap, pub n_envmaps: u32,
     pub textures: *const RsptTexture, pub n_textures: u32, pub images: *const RsptImage, pub n_images: u32,
     pub objects: *const RsptObject, pub n_objects: u32, pub instances: *const RsptInstance, pub n_instances: u32,
-    pub n_top_nodes: u64, pub n_top_prims: u64, pub instancing_mode: u32, pub pad1: u32,
+    pub n_top_nodes: u64, pub n_top_prims: u64, pub instancing_mode: u32, pub n_media: u32, pub media: *const RsptMedium,
 }
 #[repr(C)] pub struct RsptSamplerTables { pub sobol32: *const u32, pub vdc: *const u64, pub vdc_inv: *const u64,
                                             pub halton_perms: *const u16, pub n_halton_perms: u64 }

@@ -17,6 +17,7 @@ use crate::core::camera::Camera;
 use crate::core::integrator::SamplerIntegrator;
 use crate::core::light::Light;
 use crate::core::material::Material;
+use crate::core::medium::{Medium, MediumInterface};
 use crate::core::pbrt::{Float, Spectrum};
 use crate::core::primitive::Primitive;
 use crate::core::sampler::Sampler;
@@ -57,12 +58,30 @@ struct Flat {
     mesh_of: HashMap<*const TriangleMesh, (u32, u32)>,     // mesh -> (mesh index, first vertex)
     material_of: HashMap<*const Material, u32>,
     object_of: HashMap<*const Primitive, u32>,               // instanced aggregate / primitive -> object index
+    media: Vec<RsptMedium>,
+    medium_of: HashMap<*const Medium, u32>,                  // named medium -> 1 + index (the reference compares these pointers, medium.rs:340-362)
 }
 
 impl Flat {
-    fn mesh(&mut self, m: &Arc<TriangleMesh>) -> (u32, u32) {
+    /// 0 = None, else 1 + index into media (MakeNamedMedium api.rs:953-1037 leaves sigma_a / sigma_s already scaled)
+    fn medium(&mut self, m: &Option<Arc<Medium>>) -> Result<u32, String> {
+        let m = match m { Some(m) => m, None => return Ok(0) };
         let key = Arc::as_ptr(m);
-        if let Some(v) = self.mesh_of.get(&key) { return *v; }
+        if let Some(i) = self.medium_of.get(&key) { return Ok(*i); }
+        let md = match &**m {
+            Medium::Homogeneous(h) => RsptMedium { kind: 1, sigma_a: rgb(&h.sigma_a), sigma_s: rgb(&h.sigma_s), g: h.g },
+            _ => return Err("heterogeneous medium".into()),
+        };
+        self.media.push(md);
+        self.medium_of.insert(key, self.media.len() as u32);
+        Ok(self.media.len() as u32)
+    }
+
+    /// all triangles of a mesh come from one Shape statement and share its MediumInterface (api.rs:2858-2870)
+    fn mesh(&mut self, m: &Arc<TriangleMesh>, mi: &Option<Arc<MediumInterface>>) -> Result<(u32, u32), String> {
+        let key = Arc::as_ptr(m);
+        if let Some(v) = self.mesh_of.get(&key) { return Ok(*v); }
+        let (medium_inside, medium_outside) = match mi { Some(i) => (self.medium(&i.inside)?, self.medium(&i.outside)?), None => (0, 0) };
         let first = (self.p.len() / 3) as u32;
         for q in &m.p { self.p.extend_from_slice(&[q.x, q.y, q.z]); }          // world space already (api.rs:1967-1971)
         for i in 0..m.p.len() {
@@ -73,10 +92,11 @@ impl Flat {
         self.any_n |= !m.n.is_empty(); self.any_s |= !m.s.is_empty(); self.any_uv |= !m.uv.is_empty();
         self.meshes.push(RsptMesh { has_n: !m.n.is_empty() as u32, has_s: !m.s.is_empty() as u32, has_uv: !m.uv.is_empty() as u32,
                                     flip: (m.reverse_orientation ^ m.transform_swaps_handedness) as u32, // triangle.rs:324
-                                    alpha_tex: 0, shadow_alpha_tex: 0 });   // masks need the texture flattening this file does not have yet: checked in aggregate()
+                                    alpha_tex: 0, shadow_alpha_tex: 0,      // masks need the texture flattening this file does not have yet: checked in aggregate()
+                                    medium_inside, medium_outside });
         let v = ((self.meshes.len() - 1) as u32, first);
         self.mesh_of.insert(key, v);
-        v
+        Ok(v)
     }
 
     /// Material::compute_scattering_functions with constant textures, evaluated once: the lobes in push order
@@ -143,7 +163,7 @@ impl Flat {
                 Primitive::Geometric(g) => {
                     let tri = match &*g.shape { Shape::Trngl(t) => t, _ => return Err("non-triangle shape".into()) };
                     if tri.mesh().alpha_mask.is_some() || tri.mesh().shadow_alpha_mask.is_some() { return Err("alpha-masked mesh (textures are not flattened by the shim yet)".into()); }
-                    let (mesh, first) = self.mesh(tri.mesh());                     // Triangle.mesh getter: rs_pbrt.patch (triangle.rs:85)
+                    let (mesh, first) = self.mesh(tri.mesh(), &g.medium_interface)?; // Triangle.mesh getter: rs_pbrt.patch (triangle.rs:85)
                     let vi = &tri.mesh().vertex_indices[3 * tri.id as usize..3 * tri.id as usize + 3];
                     let area_light = match &g.area_light {                         // the reference compares these pointers (integrator.rs:540-543)
                         Some(al) if top => lights.iter().position(|l| Arc::ptr_eq(l, al)).map(|i| i as i32).unwrap_or(-1),
@@ -215,6 +235,7 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
     let (max_depth, rr_threshold, strategy, integrator_kind, ao_n, ao_cos) = match integ {
         SamplerIntegrator::Path(p) => (p.max_depth(), p.rr_threshold(), p.light_sample_strategy().to_string(), 0u32, 0u32, 0u32), // getters: rs_pbrt.patch (path.rs:30-32)
         SamplerIntegrator::AO(a) => (0, 1.0, "spatial".to_string(), 1u32, a.n_samples as u32, a.cos_sample as u32),
+        SamplerIntegrator::VolPath(v) => (v.max_depth, v.rr_threshold, v.light_sample_strategy.clone(), 3u32, 0u32, 0u32),   // pub fields (volpath.rs:25-35)
         _ => return Err("integrator without a GPU path".into()),
     };
     let bvh = match &*scene.aggregate { Primitive::BVH(b) => b, _ => return Err("aggregate is not a BVH".into()) };
@@ -264,7 +285,8 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
         lights: f.lights.as_ptr(), n_lights: f.lights.len() as u32, envmaps: std::ptr::null(), n_envmaps: 0,
         textures: std::ptr::null(), n_textures: 0, images: std::ptr::null(), n_images: 0,
         objects: f.objects.as_ptr(), n_objects: f.objects.len() as u32, instances: f.instances.as_ptr(), n_instances: f.instances.len() as u32,
-        n_top_nodes, n_top_prims, instancing_mode: (std::env::var_os("RSPT_INSTANCING_FIXED").is_some()) as u32, pad1: 0,
+        n_top_nodes, n_top_prims, instancing_mode: (std::env::var_os("RSPT_INSTANCING_FIXED").is_some()) as u32,
+        n_media: f.media.len() as u32, media: if f.media.is_empty() { std::ptr::null() } else { f.media.as_ptr() },
     };
     unsafe {
         if rspt_abi_version() != RSPT_ABI_VERSION { return Err("librspt.so ABI version mismatch".into()); }

@@ -87,6 +87,24 @@ def test_gpu_volpath_escaping_paths_and_infinite_light(gpu, oracle):
     assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-5 and st["truncated_paths"] == 0
 
 
+def test_gpu_volpath_with_textured_materials(gpu, oracle):
+    """the texture stage in front of k_vol_shade (image textures with camera-ray differentials, scale textures, dropped lobes): the room of
+    test_textured_materials_match_oracle with a box of fog in front of the slabs; the camera ray loses its differentials when it
+    crosses the fog's boundary (isect.spawn_ray, volpath.rs:141-145), so the slabs behind the fog are filtered without footprint"""
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    sb = textured_room(gpu.bvh_build, bump=False).builder
+    fog = sb.add_medium(sigma_a=(0.02, 0.02, 0.03), sigma_s=(0.12, 0.1, 0.08), g=0.2)
+    sb.add_box((-1.03, 0.21, -0.97), (2.51, 3.07, 1.03), None, medium=(fog, None))
+    sb.add_point_light((-3.1, 4.2, -2.2), (20, 20, 20))
+    sc = sb.finish(gpu.bvh_build)
+    rd = scenes.make_render_desc(96, 72, 16, TEXTURED_LOOK_AT, 45, max_depth=4, integrator="volpath")
+    ref = oracle.render(sc, rd, threads=8)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and st["truncated_paths"] == 0
+    assert film_rmse(film, ref["film"]) < 2e-5
+
+
 def test_gpu_volpath_refusals(gpu):
     from rs_pbrt_amd.lib import RsptError
     sb = scenes.SceneBuilder()
