@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 14
+#define RSPT_ABI_VERSION 15
 
 /* error codes */
 #define RSPT_OK 0
@@ -302,7 +302,15 @@ typedef struct {
 } rspt_sampler_tables;
 
 enum { RSPT_SAMPLER_SOBOL = 1,            /* src/samplers/sobol.rs                   */
-       RSPT_SAMPLER_HALTON = 2 };         /* src/samplers/halton.rs (the reference's default, api.rs:526) */
+       RSPT_SAMPLER_HALTON = 2,           /* src/samplers/halton.rs (the reference's default, api.rs:526) */
+       /* The pixel samplers: their PCG32 state runs through all pixels and samples of a 16x16 tile (reseeded per
+        * tile with tile.y * n_tiles.x + tile.x, integrator.rs:113-114; start_pixel before the pixel-bounds test, Q9) and every
+        * dimension past `pixel_dimensions` is drawn from it on demand — a tile is one serial chain.  librspt runs one lane per
+        * tile (tile_serial.h); `path` only. */
+       RSPT_SAMPLER_RANDOM = 3,           /* src/samplers/random.rs                  */
+       RSPT_SAMPLER_ZEROTWO = 4,          /* src/samplers/zerotwosequence.rs ("lowdiscrepancy" / "02sequence", api.rs:1694) */
+       RSPT_SAMPLER_STRATIFIED = 5,       /* src/samplers/stratified.rs: spp must equal strat_x * strat_y */
+       RSPT_SAMPLER_MAXMINDIST = 6 };     /* src/samplers/maxmin.rs: spp a power of two <= 65536, maxmin_c_pixel = C_MAX_MIN_DIST[log2 spp] */
 enum { RSPT_LIGHTS_UNIFORM = 0, RSPT_LIGHTS_POWER = 1, RSPT_LIGHTS_SPATIAL = 2 };
                                            /* src/core/lightdistrib.rs:393-418         */
 
@@ -347,9 +355,13 @@ typedef struct {
     /* DirectLightingIntegrator (src/integrators/directlighting.rs:17-70): max_depth bounds the specular recursion
      * (default 5, api.rs:322-349); rr_threshold and light_strategy are ignored (uniform_sample_one_light gets no distribution) */
     uint32_t direct_strategy;        /* RSPT_DIRECT_SAMPLE_ALL (default, "all") | RSPT_DIRECT_SAMPLE_ONE ("one")                   */
-    uint32_t pad2;
+    uint32_t pixel_dimensions;       /* pixel samplers: "dimensions" (default 4) = number of precomputed 1-D and 2-D sample vectors  */
     const int32_t* n_light_samples;  /* SAMPLE_ALL: Light::get_n_samples() per light ("samples" / "nsamples", default 1), after
                                         Sampler::round_count (the identity for Sobol' and Halton); NULL = 1 each                   */
+    uint32_t strat_x, strat_y;       /* StratifiedSampler "xsamples" / "ysamples" (default 4 x 4)                                    */
+    uint32_t strat_jitter;           /* "jitter" (default true)                                                                      */
+    uint32_t pad3;
+    const uint32_t* maxmin_c_pixel;  /* MaxMinDistSampler: the 32 columns of its generator matrix (lowdiscrepancy.rs:187-760, row log2 spp)  */
 } rspt_render_desc;
 /* RSPT_INTEGRATOR_VOLPATH: VolPathIntegrator::li (src/integrators/volpath.rs:60-347) with max_depth, rr_threshold and
  * light_strategy as for "path" (api.rs:350-380).  Camera rays start outside every medium (make_camera passes

@@ -243,6 +243,29 @@ int orc_render_integrator(const rspt_scene_desc* sd, const rspt_render_desc* rd,
     return 0;
 }
 
+// the pixel samplers: reseed(seed), then n_pixels x start_pixel (+ a full round of start_next_sample, as a rendered pixel has);
+// out1d [dims][spp], out2d [dims][spp][2] = the vectors of the last pixel; draws[0..3] = get_1d, get_2d.x, get_2d.y, get_1d taken
+// after every precomputed dimension of sample 0 has been handed out (the on-demand stream)
+void orc_pixel_sampler(const rspt_render_desc* rd, uint64_t seed, int n_pixels, float* out1d, float* out2d, float* draws) {
+    Sampler s(*rd);
+    s.reseed(seed);
+    for (int k = 0; k < n_pixels; k++) {
+        s.start_pixel(0, 0);
+        if (k + 1 < n_pixels) while (s.start_next_sample()) {}
+    }
+    const PixelSampler& p = s.pix;
+    for (size_t d = 0; d < p.samples_1d.size(); d++)
+        for (int64_t i = 0; i < p.spp; i++) out1d[d * (size_t)p.spp + (size_t)i] = p.samples_1d[d][(size_t)i];
+    for (size_t d = 0; d < p.samples_2d.size(); d++)
+        for (int64_t i = 0; i < p.spp; i++) { out2d[(d * (size_t)p.spp + (size_t)i) * 2] = p.samples_2d[d][(size_t)i].x; out2d[(d * (size_t)p.spp + (size_t)i) * 2 + 1] = p.samples_2d[d][(size_t)i].y; }
+    for (size_t d = 0; d < p.samples_1d.size(); d++) (void)s.get_1d();
+    for (size_t d = 0; d < p.samples_2d.size(); d++) (void)s.get_2d();
+    draws[0] = s.get_1d();
+    P2 v = s.get_2d();
+    draws[1] = v.x; draws[2] = v.y;
+    draws[3] = s.get_1d();
+}
+
 // media (VolPathIntegrator): leaf functions for known-answer tests
 float orc_phase_hg(float cos_theta, float g) { return phase_hg(cos_theta, g); }
 float orc_hg_sample_p(float g, const float wo[3], float ux, float uy, float wi_out[3]) {

@@ -157,6 +157,14 @@ struct Rng {
         uint32_t rot = (uint32_t)(old >> 59);
         return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
     }
+    void set_sequence(uint64_t initseq) { // rng.rs:31-39
+        state = 0;
+        inc = (initseq << 1) | 1;
+        uniform_uint32();
+        state += 0x853c49e6748fea9bULL;
+        uniform_uint32();
+    }
+    Float uniform_float() { return std::fmin((Float)uniform_uint32() * 0x1.0p-32f, FLOAT_ONE_MINUS_EPSILON); } // rng.rs:74-82
     uint32_t uniform_uint32_bounded(uint32_t b) { // Q2: threshold = lowest set bit of b, not (-b) % b
         uint32_t threshold = (~b + 1u) & b;
         for (;;) {
@@ -233,15 +241,142 @@ struct HaltonSampler {
 };
 
 // Sampler facade (src/core/sampler.rs:18-203) over the two GlobalSamplers in scope
+// ---- the pixel samplers: src/samplers/{random,zerotwosequence,stratified,maxmin}.rs ----
+// sampling.rs:202-212
+template <class T>
+static inline void shuffle(T* samp, int32_t count, int32_t n_dimensions, Rng& rng) {
+    for (int32_t i = 0; i < count; i++) {
+        int32_t other = i + (int32_t)rng.uniform_uint32_bounded((uint32_t)(count - i));
+        for (int32_t j = 0; j < n_dimensions; j++) std::swap(samp[n_dimensions * i + j], samp[n_dimensions * other + j]);
+    }
+}
+static inline uint32_t c_van_der_corput(int i) { return 0x80000000u >> i; } // lowdiscrepancy.rs:864-897: the identity matrix, reversed
+static inline uint32_t c_sobol1(int i) { // lowdiscrepancy.rs:959-992: column i of the second Sobol' generator matrix = row i of Pascal's triangle mod 2, bit-reversed
+    uint32_t v = 0x80000000u;            // v_0; v_{i} = v_{i-1} ^ (v_{i-1} >> 1)
+    for (int k = 0; k < i; k++) v ^= v >> 1;
+    return v;
+}
+// lowdiscrepancy.rs:857-916
+static inline void van_der_corput(int32_t n_per, int32_t n_pixel_samples, Float* samples, Rng& rng) {
+    const uint32_t scramble = rng.uniform_uint32();
+    const int32_t total = n_per * n_pixel_samples;
+    uint32_t v = scramble; // gray_code_sample_1d :824-835
+    for (int32_t i = 0; i < total; i++) {
+        samples[i] = std::fmin((Float)v * 0x1.0p-32f, FLOAT_ONE_MINUS_EPSILON);
+        v ^= c_van_der_corput(__builtin_ctz((uint32_t)(i + 1)));
+    }
+    for (int32_t i = 0; i < n_pixel_samples; i++) shuffle(samples + (size_t)i * n_per, n_per, 1, rng);
+    shuffle(samples, n_pixel_samples, n_per, rng);
+}
+// lowdiscrepancy.rs:920-1010.  Q3: the per-sample shuffles all start at samples[0]
+static inline void sobol_2d(int32_t n_per, int32_t n_pixel_samples, P2* samples, Rng& rng) {
+    uint32_t v0 = rng.uniform_uint32(), v1 = rng.uniform_uint32(); // scramble.x, scramble.y
+    const int32_t total = n_per * n_pixel_samples;
+    for (int32_t i = 0; i < total; i++) { // gray_code_sample_2d :840-853
+        samples[i].x = std::fmin((Float)v0 * 0x1.0p-32f, FLOAT_ONE_MINUS_EPSILON);
+        samples[i].y = std::fmin((Float)v1 * 0x1.0p-32f, FLOAT_ONE_MINUS_EPSILON);
+        const int tz = __builtin_ctz((uint32_t)(i + 1));
+        v0 ^= c_van_der_corput(tz);
+        v1 ^= c_sobol1(tz);
+    }
+    for (int32_t i = 0; i < n_pixel_samples; i++) shuffle(samples, n_per, 1, rng);
+    shuffle(samples, n_pixel_samples, n_per, rng);
+}
+// sampling.rs:237-271
+static inline void stratified_sample_1d(Float* samp, int32_t n, Rng& rng, bool jitter) {
+    const Float inv_n = 1.0f / (Float)n;
+    for (int32_t i = 0; i < n; i++) {
+        const Float delta = jitter ? rng.uniform_float() : 0.5f;
+        samp[i] = std::fmin(((Float)i + delta) * inv_n, FLOAT_ONE_MINUS_EPSILON);
+    }
+}
+static inline void stratified_sample_2d(P2* samp, int32_t nx, int32_t ny, Rng& rng, bool jitter) {
+    const Float dx = 1.0f / (Float)nx, dy = 1.0f / (Float)ny;
+    size_t k = 0;
+    for (int32_t y = 0; y < ny; y++)
+        for (int32_t x = 0; x < nx; x++) {
+            const Float jx = jitter ? rng.uniform_float() : 0.5f;
+            const Float jy = jitter ? rng.uniform_float() : 0.5f;
+            samp[k].x = std::fmin(((Float)x + jx) * dx, FLOAT_ONE_MINUS_EPSILON);
+            samp[k].y = std::fmin(((Float)y + jy) * dy, FLOAT_ONE_MINUS_EPSILON);
+            k++;
+        }
+}
+static inline uint32_t multiply_generator(const uint32_t* c, uint32_t a) { // lowdiscrepancy.rs:799-814
+    uint32_t v = 0;
+    for (int i = 0; a != 0; i++, a >>= 1) if (a & 1u) v ^= c[i];
+    return v;
+}
+struct PixelSampler {
+    int kind = 0;
+    int64_t spp = 1;
+    int32_t n_dims = 4, nx = 1, ny = 1;
+    bool jitter = true;
+    const uint32_t* c_pixel = nullptr;
+    std::vector<std::vector<Float>> samples_1d;
+    std::vector<std::vector<P2>> samples_2d;
+    int32_t current_1d_dimension = 0, current_2d_dimension = 0;
+    int64_t cur_sample = 0;
+    Rng rng;
+    void init(const rspt_render_desc& rd) {
+        kind = (int)rd.sampler_kind; spp = rd.spp; n_dims = (int32_t)rd.pixel_dimensions;
+        nx = (int32_t)rd.strat_x; ny = (int32_t)rd.strat_y; jitter = rd.strat_jitter != 0; c_pixel = rd.maxmin_c_pixel;
+        rng.state = 0; rng.inc = 0; // Rng::default() (derive(Default)): the samplers' `new` do not call Rng::new()
+        if (kind != RSPT_SAMPLER_RANDOM) { // RandomSampler keeps no per-dimension vectors (random.rs:10-22)
+            samples_1d.assign((size_t)n_dims, std::vector<Float>((size_t)spp));
+            samples_2d.assign((size_t)n_dims, std::vector<P2>((size_t)spp));
+        }
+    }
+    void reseed(uint64_t seed) { rng.set_sequence(seed); }
+    void start_pixel() {
+        const int32_t n = (int32_t)spp;
+        if (kind == RSPT_SAMPLER_ZEROTWO) { // zerotwosequence.rs:127-163
+            for (auto& v : samples_1d) van_der_corput(1, n, v.data(), rng);
+            for (auto& v : samples_2d) sobol_2d(1, n, v.data(), rng);
+        } else if (kind == RSPT_SAMPLER_STRATIFIED) { // stratified.rs:101-161
+            for (auto& v : samples_1d) { stratified_sample_1d(v.data(), nx * ny, rng, jitter); shuffle(v.data(), nx * ny, 1, rng); }
+            for (auto& v : samples_2d) { stratified_sample_2d(v.data(), nx, ny, rng, jitter); shuffle(v.data(), nx * ny, 1, rng); }
+        } else if (kind == RSPT_SAMPLER_MAXMINDIST) { // maxmin.rs:116-159
+            const Float inv_spp = 1.0f / (Float)spp;
+            if (!samples_2d.empty()) {
+                for (int32_t i = 0; i < n; i++)
+                    samples_2d[0][(size_t)i] = P2{(Float)i * inv_spp, std::fmin((Float)(multiply_generator(c_pixel, (uint32_t)i) ^ 0u) * 0x1.0p-32f, FLOAT_ONE_MINUS_EPSILON)};
+                shuffle(samples_2d[0].data(), n, 1, rng);
+            }
+            for (auto& v : samples_1d) van_der_corput(1, n, v.data(), rng);
+            for (size_t i = 1; i < samples_2d.size(); i++) sobol_2d(1, n, samples_2d[i].data(), rng);
+        }
+        cur_sample = 0; // (current_*_dimension are reset by start_next_sample only; they are 0 here: every pixel ends with one)
+    }
+    Float get_1d() {
+        if (kind != RSPT_SAMPLER_RANDOM && current_1d_dimension < (int32_t)samples_1d.size()) return samples_1d[(size_t)current_1d_dimension++][(size_t)cur_sample];
+        return rng.uniform_float();
+    }
+    P2 get_2d() {
+        if (kind == RSPT_SAMPLER_RANDOM) { Float x = rng.uniform_float(); Float y = rng.uniform_float(); return P2{x, y}; } // random.rs:86-92: x first
+        if (current_2d_dimension < (int32_t)samples_2d.size()) return samples_2d[(size_t)current_2d_dimension++][(size_t)cur_sample];
+        Float y = rng.uniform_float(); Float x = rng.uniform_float(); // Q4: y first (zerotwosequence.rs:178-181, stratified.rs, maxmin.rs)
+        return P2{x, y};
+    }
+    bool start_next_sample() {
+        current_1d_dimension = 0; current_2d_dimension = 0;
+        cur_sample += 1;
+        return cur_sample < spp;
+    }
+};
+
 struct Sampler {
     int kind;
     SobolSampler sobol;
     HaltonSampler halton;
+    PixelSampler pix;
+    bool is_pixel() const { return kind >= RSPT_SAMPLER_RANDOM; }
+    void reseed(uint64_t seed) { if (is_pixel()) pix.reseed(seed); } // Sampler::reseed: a no-op for Sobol' / Halton
     Sampler(const rspt_render_desc& rd)
         : kind((int)rd.sampler_kind), sobol(SobolTables{rd.tables.sobol32, rd.tables.vdc, rd.tables.vdc_inv}, rd.spp, rd.sample_bounds),
-          halton(rd.spp, rd.sample_bounds, rd.sample_at_pixel_center != 0, rd.tables.halton_perms, rd.tables.n_halton_perms) {}
+          halton(rd.spp, rd.sample_bounds, rd.sample_at_pixel_center != 0, rd.tables.halton_perms, rd.tables.n_halton_perms) { if (is_pixel()) pix.init(rd); }
     bool is_halton() const { return kind == RSPT_SAMPLER_HALTON; }
-    int64_t cur_sample() const { return is_halton() ? halton.cur_sample : sobol.cur_sample; }
+    int64_t cur_sample() const { return is_pixel() ? pix.cur_sample : (is_halton() ? halton.cur_sample : sobol.cur_sample); }
     // 2-D sample arrays requested by an integrator's preprocess (request_2d_array, sobol.rs:203-209): array i lives in
     // dimensions 5 + 2 i, 5 + 2 i + 1 (array_start_dim = 5, no 1-D arrays on this path); get_1d / get_2d skip that
     // range (sobol.rs:180-201, halton.rs:283-305).  round_count is the identity for both samplers (sobol.rs:210-212).
@@ -253,16 +388,19 @@ struct Sampler {
     int64_t& dimension() { return is_halton() ? halton.dimension : sobol.dimension; }
     void start_pixel(int32_t x, int32_t y) {
         array_2d_offset = 0;
+        if (is_pixel()) { pix.start_pixel(); return; }
         if (!is_halton()) { sobol.start_pixel(x, y); return; }
         halton.px = x; halton.py = y; halton.cur_sample = 0; halton.dimension = 0;
         halton.interval_sample_index = halton.get_index_for_sample(0);
     }
     Float get_1d() {
+        if (is_pixel()) return pix.get_1d();
         if (dimension() >= ARRAY_START_DIM && dimension() < array_end_dim()) dimension() = array_end_dim();
         if (!is_halton()) return sobol.get_1d();
         Float r = halton.sample_dimension(halton.interval_sample_index, halton.dimension); halton.dimension += 1; return r;
     }
     P2 get_2d() {
+        if (is_pixel()) return pix.get_2d();
         if (dimension() + 1 >= ARRAY_START_DIM && dimension() < array_end_dim()) dimension() = array_end_dim();
         if (!is_halton()) return sobol.get_2d();
         Float y = halton.sample_dimension(halton.interval_sample_index, halton.dimension + 1);
@@ -289,6 +427,7 @@ struct Sampler {
     P2 get_2d_sample(size_t array_idx, uint64_t j) const { return array_2d(j, ARRAY_START_DIM + 2 * (int64_t)array_idx); }
     bool start_next_sample() { // halton.rs:333-343
         array_2d_offset = 0;
+        if (is_pixel()) return pix.start_next_sample();
         if (!is_halton()) return sobol.start_next_sample();
         halton.dimension = 0;
         halton.interval_sample_index = halton.get_index_for_sample((uint64_t)halton.cur_sample + 1);
@@ -1251,6 +1390,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
             int32_t y0 = sb[1] + (int32_t)blk.second * ts, y1 = std::min(y0 + ts, sb[3]);
             int32_t tb[4] = {x0, y0, x1, y1};
             FilmTile ft = get_film_tile(rd, tb);
+            sampler.reseed((uint64_t)(int64_t)(int32_t)((int32_t)blk.second * ntx + (int32_t)blk.first)); // integrator.rs:113-114: seed = tile.y * n_tiles.x + tile.x
             for (int32_t py = y0; py < y1; py++)
                 for (int32_t px = x0; px < x1; px++) {
                     sampler.start_pixel(px, py);

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -12,7 +12,7 @@ BXDF_LAMBERT_R, BXDF_OREN_NAYAR, BXDF_SPECULAR_R, BXDF_SPECULAR_T, BXDF_FRESNEL_
 BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9
 FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
-SAMPLER_SOBOL, SAMPLER_HALTON = 1, 2
+SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_RANDOM, SAMPLER_ZEROTWO, SAMPLER_STRATIFIED, SAMPLER_MAXMINDIST = 1, 2, 3, 4, 5, 6
 INTEGRATOR_PATH, INTEGRATOR_AO, INTEGRATOR_DIRECT, INTEGRATOR_VOLPATH = 0, 1, 2, 3
 MEDIUM_HOMOGENEOUS = 1
 DIRECT_SAMPLE_ALL, DIRECT_SAMPLE_ONE = 0, 1
@@ -111,7 +111,8 @@ class RenderDesc(C.Structure):
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("tile_chunk", C.c_uint32),
                 ("sample_at_pixel_center", C.c_uint32), ("integrator", C.c_uint32), ("ao_n_samples", C.c_uint32),
                 ("ao_cos_sample", C.c_uint32), ("film_reduce", C.c_uint32), ("tables", SamplerTables),
-                ("direct_strategy", C.c_uint32), ("pad2", C.c_uint32), ("n_light_samples", C.c_void_p)]
+                ("direct_strategy", C.c_uint32), ("pixel_dimensions", C.c_uint32), ("n_light_samples", C.c_void_p),
+                ("strat_x", C.c_uint32), ("strat_y", C.c_uint32), ("strat_jitter", C.c_uint32), ("pad3", C.c_uint32), ("maxmin_c_pixel", C.c_void_p)]
 
 
 class Ray(C.Structure):

@@ -10,6 +10,7 @@
 // workgroup and queue (K7, in k_shade).
 #pragma once
 #include "dev_texture.h"
+#include "pixel_sampler.h"
 
 namespace rspt {
 
@@ -325,8 +326,9 @@ RDEV void store_ray(rspt_ray* dst, f3 o, f3 d, float t_max, uint32_t id) {
 
 // One step of PathIntegrator::li (path.rs:91-280) for path slot p: fold in the previous
 // bounce's next-event estimate, then process the hit of the continuation ray.
+template <bool PIX>
 RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const RenderDev& rd, const PathBuf& pb, uint32_t p, unsigned long long* stats,
-                          const uint32_t* __restrict__ sob_tab, uint32_t sob_nd) {
+                          const uint32_t* __restrict__ sob_tab, uint32_t sob_nd, PixSampler* px) {
     ShadeOut out{false, false, false, false};
     uint32_t st = pb.state[p];
     float4 le = pb.L_eta[p];
@@ -431,7 +433,8 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 bsdf.ts = cross(h.sh_n, bsdf.ss);
                 bsdf.lobes = sc.bxdfs + mat.first_bxdf;
                 bsdf.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
-                PathSampler smp;
+                ShadeSampler<PIX> smp;
+                smp.bind(px);
                 smp.start(rd, sob_tab, sob_nd, pb.sobol_index[p], st & ST_DIM_MASK);
                 if (stats) atomicAdd(&stats[0], 1ull);
 
@@ -757,7 +760,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, Ren
         uint32_t p = 0;
         if (i < n) {
             p = i < n_front ? (q_sorted ? q_sorted[i] : q_active[i]) : q_active[qcap - 1u - (i - n_front)];
-            if (p != RSPT_BIN_INVALID) o = shade_path(sc, ld, rd, pb, p, stats, sob_tab, sob_nd);
+            if (p != RSPT_BIN_INVALID) o = shade_path<false>(sc, ld, rd, pb, p, stats, sob_tab, sob_nd, nullptr);
         }
         // queue appends, aggregated per workgroup: a single counter word sustains only ~90 M atomics/s
         // (MI355X_MICROARCH "dequeue" row), so one atomic per queue per 256 paths instead of per wave.

@@ -24,6 +24,7 @@
 #include "bvh_device.h"
 #include "direct.h"
 #include "vol.h"
+#include "tile_serial.h"
 
 using namespace rspt;
 
@@ -491,10 +492,21 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (!s || !d) return fail(RSPT_E_INVALID, "null scene or render desc");
     const bool halton = d->sampler_kind == RSPT_SAMPLER_HALTON;
-    if (d->sampler_kind != RSPT_SAMPLER_SOBOL && !halton) return fail(RSPT_E_UNSUPPORTED, "sampler kind %u (sobol and halton only)", d->sampler_kind);
-    if (d->spp <= 0 || d->spp > (1ll << 30) || (!halton && (d->spp & (d->spp - 1)) != 0)) return fail(RSPT_E_INVALID, "spp must be in [1, 2^30] (a power of two for sobol)");
+    const bool sobol = d->sampler_kind == RSPT_SAMPLER_SOBOL;
+    const bool pixel_sampler = d->sampler_kind >= RSPT_SAMPLER_RANDOM && d->sampler_kind <= RSPT_SAMPLER_MAXMINDIST;  // one serial chain per tile: tile_serial.h
+    if (!sobol && !halton && !pixel_sampler) return fail(RSPT_E_UNSUPPORTED, "sampler kind %u", d->sampler_kind);
+    if (d->spp <= 0 || d->spp > (1ll << 30) || (sobol && (d->spp & (d->spp - 1)) != 0)) return fail(RSPT_E_INVALID, "spp must be in [1, 2^30] (a power of two for sobol)");
     if (d->tile_size == 0 || d->tile_size > 4096) return fail(RSPT_E_INVALID, "bad tile_size");
-    if (!halton && (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv)) return fail(RSPT_E_INVALID, "null sobol tables");
+    if (sobol && (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv)) return fail(RSPT_E_INVALID, "null sobol tables");
+    if (pixel_sampler) {
+        if (d->integrator != RSPT_INTEGRATOR_PATH) return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path integrator only");
+        if (s->has_textures) return fail(RSPT_E_UNSUPPORTED, "the pixel samplers with textured materials");
+        if (d->tile_size != 16 && d->tile_size > 255) return fail(RSPT_E_UNSUPPORTED, "tile_size > 255 with a pixel sampler");
+        if (d->spp > 65536 || d->pixel_dimensions > 64) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: spp > 65536 or more than 64 sampled dimensions");
+        if (d->sampler_kind == RSPT_SAMPLER_STRATIFIED && (d->strat_x == 0 || d->strat_y == 0 || (int64_t)d->strat_x * d->strat_y != d->spp))
+            return fail(RSPT_E_INVALID, "stratified sampler: spp must equal strat_x * strat_y");
+        if (d->sampler_kind == RSPT_SAMPLER_MAXMINDIST && (!d->maxmin_c_pixel || (d->spp & (d->spp - 1)) != 0)) return fail(RSPT_E_INVALID, "maxmindist sampler: spp must be a power of two and maxmin_c_pixel given");
+    }
     if (halton && !d->tables.halton_perms) return fail(RSPT_E_INVALID, "null halton permutation table");
     if (!(d->filter_radius[0] > 0.0f) || !(d->filter_radius[1] > 0.0f)) return fail(RSPT_E_INVALID, "bad filter radius");
     if (d->max_depth > 200) return fail(RSPT_E_UNSUPPORTED, "max_depth > 200");
@@ -542,7 +554,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (!g.sobol32) {
         if ((rc = dev_alloc(&g.sobol32, 1024 * 52)) || (rc = dev_alloc(&g.vdc, 25 * 52)) || (rc = dev_alloc(&g.vdc_inv, 26 * 52)) || (rc = dev_alloc(&g.filter_table, 256))) return rc;
     }
-    if (!halton) {
+    if (sobol) {
         HIP_TRY(hipMemcpyAsync(g.sobol32, d->tables.sobol32, 1024 * 52 * 4, hipMemcpyHostToDevice, g.stream));
         HIP_TRY(hipMemcpyAsync(g.vdc, d->tables.vdc, 25 * 52 * 8, hipMemcpyHostToDevice, g.stream));
         HIP_TRY(hipMemcpyAsync(g.vdc_inv, d->tables.vdc_inv, 26 * 52 * 8, hipMemcpyHostToDevice, g.stream));
@@ -607,6 +619,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     LightDistDev ld;
     const LightDist* ld_lazy = nullptr;  // on-demand voxels: a mark / build round in front of every shade launch
     if ((rc = get_light_dist(s, d->light_strategy, &ld, &ld_lazy))) return rc;
+    if (pixel_sampler && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
     if (volpath && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "volpath with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
 
     // ---- this shard's pixels: Morton-ordered tiles (blockqueue/mod.rs:23-52), row-major inside a tile ----
@@ -665,6 +678,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (ao) cap = std::max<size_t>(cap / ao_n, 1024);
     const uint32_t dl_H = direct ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h)
     if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << 26) / dl_H, 1024);
+    if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     size_t pix_per_batch = 1;
     for (;;) {
@@ -722,7 +736,72 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     auto ev_close = [&](int kind, int lane) { (void)hipEventRecord(kev[kind].back().second, lane ? g.stream2 : g.stream); };
     HIP_TRY(hipEventRecord(ev_k0, g.stream));
     uint64_t samples = 0, truncated = 0, vol_rays = 0;
-    for (size_t p0 = 0; p0 < n_pix; p0 += pix_per_batch) {
+    if (pixel_sampler) {
+        // ---- one lane per tile (tile_serial.h) ----
+        std::vector<TileRec> tiles;
+        for (size_t i = 0; i < blocks.size(); i++) {
+            if ((i / chunk) % shard_count != d->shard_index) continue;
+            const int32_t x0 = sb[0] + (int32_t)blocks[i].first * ts, x1 = std::min(x0 + ts, sb[2]);
+            const int32_t y0 = sb[1] + (int32_t)blocks[i].second * ts, y1 = std::min(y0 + ts, sb[3]);
+            tiles.push_back(TileRec{(int16_t)x0, (int16_t)y0, (int16_t)x1, (int16_t)y1, (uint32_t)((int32_t)blocks[i].second * ntx + (int32_t)blocks[i].first), 0u, 0u});
+        }
+        const uint32_t n_tiles = (uint32_t)tiles.size();
+        const uint32_t spp = (uint32_t)d->spp, nd = d->pixel_dimensions;
+        // rows of every tile per pass: as many as the sample-result arrays (24 B per sample) allow
+        const size_t samp_cap = std::max<size_t>(env_size("RSPT_SERIAL_SAMPLES", (size_t)1 << 28), (size_t)ts * spp);
+        int32_t rows = ts;
+        while (rows > 1 && (size_t)n_tiles * rows * ts * spp > samp_cap) rows--;
+        if ((size_t)n_tiles * rows * ts * spp > ((size_t)1 << 31)) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: %u tiles x %u spp do not fit one pass", n_tiles, spp);
+        struct Guard { std::vector<void*> p; ~Guard() { for (void* q : p) (void)hipFree(q); } } guard;
+        auto tmp = [&](auto** p, size_t n) { int r = dev_alloc(p, std::max<size_t>(n, 1)); if (!r) guard.p.push_back(*p); return r; };
+        TileRec* tiles_d = nullptr; float4* samp_L = nullptr; float2* samp_pf = nullptr; float* a1 = nullptr; float2* a2 = nullptr; uint64_t* rng_state = nullptr;
+        uint32_t* c_pixel_d = nullptr; uint32_t* trunc_d = nullptr; uint32_t* pass_pix = nullptr;
+        const size_t max_samples = (size_t)n_tiles * rows * ts * spp;
+        if ((rc = tmp(&tiles_d, n_tiles)) || (rc = tmp(&samp_L, max_samples)) || (rc = tmp(&samp_pf, max_samples)) || (rc = tmp(&a1, (size_t)nd * spp * n_tiles)) ||
+            (rc = tmp(&a2, (size_t)nd * spp * n_tiles)) || (rc = tmp(&rng_state, 2 * (size_t)n_tiles)) || (rc = tmp(&c_pixel_d, 32)) || (rc = tmp(&trunc_d, 1)) ||
+            (rc = tmp(&pass_pix, (size_t)n_tiles * rows * ts)))
+            return rc;
+        HIP_TRY(hipMemsetAsync(trunc_d, 0, sizeof(uint32_t), g.stream));
+        if (d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) HIP_TRY(hipMemcpyAsync(c_pixel_d, d->maxmin_c_pixel, 32 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state};
+        // lanes per wave: a lane that shares its wave waits whenever the others diverge, so spread the tiles over as many waves
+        // as the chip holds (256 CUs x 4 SIMDs x 2) before doubling up
+        uint32_t lanes = 1;
+        while (lanes < 64 && (n_tiles + lanes - 1) / lanes > (uint32_t)env_size("RSPT_SERIAL_WAVES", 2048)) lanes *= 2;
+        PathBuf fpb = g.pb;
+        fpb.L_eta = samp_L; fpb.p_film = samp_pf;
+        const uint32_t serial_iters = nominal_iters + 1u + (s->has_null_material ? (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : 0u);
+        std::vector<uint32_t> pl;
+        for (int32_t r0 = 0; r0 < ts; r0 += rows) {
+            const int32_t r1 = std::min(r0 + rows, ts);
+            pl.clear();
+            for (TileRec& t : tiles) {
+                t.pix0 = (uint32_t)pl.size();
+                for (int32_t y = t.y0 + r0; y < t.y0 + r1 && y < t.y1; y++)
+                    for (int32_t x = t.x0; x < t.x1; x++) pl.push_back(((uint32_t)(uint16_t)(int16_t)y << 16) | (uint32_t)(uint16_t)(int16_t)x);
+            }
+            if (pl.empty()) continue;
+            HIP_TRY(hipStreamSynchronize(g.stream));  // the previous pass still reads tiles_d / pass_pix
+            HIP_TRY(hipMemcpyAsync(tiles_d, tiles.data(), n_tiles * sizeof(TileRec), hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipMemcpyAsync(pass_pix, pl.data(), pl.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+            const dim3 grid((n_tiles + lanes - 1) / lanes);
+            ev_open(2, 0);
+#define RSPT_TS(I, A) hipLaunchKernelGGL((k_tile_serial<I, A>), grid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, g.pb, pd, tiles_d, n_tiles, lanes, r0, r1, samp_L, samp_pf, serial_iters, trunc_d)
+            if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true); else RSPT_TS(true, false); }
+            else { if (s->has_alpha) RSPT_TS(false, true); else RSPT_TS(false, false); }
+#undef RSPT_TS
+            ev_close(2, 0);
+            const uint32_t npx = (uint32_t)pl.size();
+            Batch bt{0u, npx, 0u, spp, npx * spp};
+            samples += bt.n;
+            hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, fpb, pass_pix, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
+        }
+        uint32_t tv = 0;
+        HIP_TRY(hipMemcpyAsync(&tv, trunc_d, sizeof tv, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        truncated += tv;
+    }
+    for (size_t p0 = 0; !pixel_sampler && p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
         for (uint32_t s0 = 0; s0 < (uint32_t)d->spp; s0 += ns) {
             const uint32_t ns_b = std::min(ns, (uint32_t)d->spp - s0);  // Halton spp need not be a power of two

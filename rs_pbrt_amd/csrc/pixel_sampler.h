@@ -1,0 +1,158 @@
+// The PCG-backed pixel samplers on the device: RandomSampler, ZeroTwoSequenceSampler, StratifiedSampler,
+// MaxMinDistSampler (src/samplers/*.rs) over one PCG32 stream per 16x16 tile (src/core/rng.rs).  State lives with the lane that
+// renders the tile (tile_serial.h); the per-pixel sample vectors live in global memory, element (d, i) of lane l at
+// [(d * spp + i) * stride + l].
+#pragma once
+#include "dev_scene.h"
+
+namespace rspt {
+
+struct PcgRng {  // rng.rs:15-83
+    uint64_t state, inc;
+    RDEV uint32_t u32() {
+        const uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        const uint32_t xorshifted = (uint32_t)(((old >> 18) ^ old) >> 27);
+        const uint32_t rot = (uint32_t)(old >> 59);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
+    }
+    RDEV void set_sequence(uint64_t initseq) {
+        state = 0;
+        inc = (initseq << 1) | 1ull;
+        (void)u32();
+        state += 0x853c49e6748fea9bULL;
+        (void)u32();
+    }
+    RDEV uint32_t bounded(uint32_t b) {  // Q2: threshold = (!b + 1) & b, the lowest set bit of b
+        const uint32_t threshold = (~b + 1u) & b;
+        for (;;) {
+            const uint32_t r = u32();
+            if (r >= threshold) return r % b;
+        }
+    }
+    RDEV float f32() { return fminf((float)u32() * 0x1.0p-32f, RSPT_ONE_MINUS_EPS); }
+};
+
+struct PixSampler {
+    uint32_t kind, spp, n_dims, nx, ny, jitter;
+    const uint32_t* c_pixel;
+    float* a1;
+    float2* a2;
+    uint32_t stride;
+    uint32_t cur1, cur2, cur_s;
+    PcgRng rng;
+
+    RDEV float& v1(uint32_t d, uint32_t i) const { return a1[((size_t)d * spp + i) * stride]; }
+    RDEV float2& v2(uint32_t d, uint32_t i) const { return a2[((size_t)d * spp + i) * stride]; }
+    // shuffle(samp, count, 1, rng) (sampling.rs:202-212) on vector d
+    RDEV void shuffle1(uint32_t d, uint32_t count) {
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t other = i + rng.bounded(count - i);
+            const float t = v1(d, i); v1(d, i) = v1(d, other); v1(d, other) = t;
+        }
+    }
+    RDEV void shuffle2(uint32_t d, uint32_t count) {
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t other = i + rng.bounded(count - i);
+            const float2 t = v2(d, i); v2(d, i) = v2(d, other); v2(d, other) = t;
+        }
+    }
+    // van_der_corput(1, spp, ..) (lowdiscrepancy.rs:857-916): Gray-code enumeration of the scrambled radical inverse, one
+    // single-element shuffle per pixel sample (each draws from the stream and swaps an element with itself), one over all
+    RDEV void van_der_corput(uint32_t d) {
+        uint32_t v = rng.u32();
+        for (uint32_t i = 0; i < spp; i++) {
+            v1(d, i) = fminf((float)v * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+            v ^= 0x80000000u >> __builtin_ctz(i + 1u);
+        }
+        for (uint32_t i = 0; i < spp; i++) (void)rng.bounded(1u);
+        shuffle1(d, spp);
+    }
+    // sobol_2d(1, spp, ..) (lowdiscrepancy.rs:920-1010); column k of the second generator matrix is v_k = v_{k-1} ^ (v_{k-1} >> 1)
+    RDEV void sobol_2d(uint32_t d) {
+        uint32_t x = rng.u32(), y = rng.u32();
+        for (uint32_t i = 0; i < spp; i++) {
+            v2(d, i) = make_float2(fminf((float)x * 0x1.0p-32f, RSPT_ONE_MINUS_EPS), fminf((float)y * 0x1.0p-32f, RSPT_ONE_MINUS_EPS));
+            const uint32_t tz = (uint32_t)__builtin_ctz(i + 1u);
+            x ^= 0x80000000u >> tz;
+            uint32_t c = 0x80000000u;
+            for (uint32_t k = 0; k < tz; k++) c ^= c >> 1;
+            y ^= c;
+        }
+        for (uint32_t i = 0; i < spp; i++) (void)rng.bounded(1u);  // Q3: shuffle(samples, 1, 1) spp times, all on element 0
+        shuffle2(d, spp);
+    }
+    RDEV void start_pixel() {
+        if (kind == RSPT_SAMPLER_ZEROTWO) {  // zerotwosequence.rs:127-163
+            for (uint32_t d = 0; d < n_dims; d++) van_der_corput(d);
+            for (uint32_t d = 0; d < n_dims; d++) sobol_2d(d);
+        } else if (kind == RSPT_SAMPLER_STRATIFIED) {  // stratified.rs:101-161, sampling.rs:237-271
+            const uint32_t n = nx * ny;
+            const float inv_n = 1.0f / (float)n;
+            for (uint32_t d = 0; d < n_dims; d++) {
+                for (uint32_t i = 0; i < n; i++) v1(d, i) = fminf(((float)i + (jitter ? rng.f32() : 0.5f)) * inv_n, RSPT_ONE_MINUS_EPS);
+                shuffle1(d, n);
+            }
+            const float dx = 1.0f / (float)nx, dy = 1.0f / (float)ny;
+            for (uint32_t d = 0; d < n_dims; d++) {
+                uint32_t k = 0;
+                for (uint32_t y = 0; y < ny; y++)
+                    for (uint32_t x = 0; x < nx; x++) {
+                        const float jx = jitter ? rng.f32() : 0.5f;
+                        const float jy = jitter ? rng.f32() : 0.5f;
+                        v2(d, k++) = make_float2(fminf(((float)x + jx) * dx, RSPT_ONE_MINUS_EPS), fminf(((float)y + jy) * dy, RSPT_ONE_MINUS_EPS));
+                    }
+                shuffle2(d, n);
+            }
+        } else if (kind == RSPT_SAMPLER_MAXMINDIST) {  // maxmin.rs:116-159
+            const float inv_spp = 1.0f / (float)spp;
+            if (n_dims > 0) {
+                for (uint32_t i = 0; i < spp; i++) {
+                    uint32_t v = 0;  // multiply_generator (lowdiscrepancy.rs:799-814)
+                    for (uint32_t a = i, k = 0; a != 0; a >>= 1, k++) if (a & 1u) v ^= c_pixel[k];
+                    v2(0, i) = make_float2((float)i * inv_spp, fminf((float)v * 0x1.0p-32f, RSPT_ONE_MINUS_EPS));
+                }
+                shuffle2(0, spp);
+            }
+            for (uint32_t d = 0; d < n_dims; d++) van_der_corput(d);
+            for (uint32_t d = 1; d < n_dims; d++) sobol_2d(d);
+        }
+        cur_s = 0;
+    }
+    RDEV float get_1d() {
+        if (kind != RSPT_SAMPLER_RANDOM && cur1 < n_dims) return v1(cur1++, cur_s);
+        return rng.f32();
+    }
+    RDEV f2 get_2d() {
+        if (kind == RSPT_SAMPLER_RANDOM) { const float x = rng.f32(); const float y = rng.f32(); return f2{x, y}; }  // random.rs:86-92: x first
+        if (cur2 < n_dims) { const float2 v = v2(cur2++, cur_s); return f2{v.x, v.y}; }
+        const float y = rng.f32(); const float x = rng.f32();  // Q4: y first (zerotwosequence.rs:178-181, stratified.rs:187-190, maxmin.rs:185-188)
+        return f2{x, y};
+    }
+    RDEV void start_next_sample() { cur1 = 0; cur2 = 0; cur_s += 1; }
+};
+
+// what shade_path draws its samples from: the global samplers' dimension stream (k_shade: PIX = false, identical code to before)
+// or the tile's pixel sampler
+template <bool PIX>
+struct ShadeSampler;
+template <>
+struct ShadeSampler<false> {
+    PathSampler g;
+    RDEV void bind(PixSampler*) {}
+    RDEV void start(const RenderDev& rd, const uint32_t* __restrict__ tab, uint32_t nd, uint64_t idx, uint32_t first_dim) { g.start(rd, tab, nd, idx, first_dim); }
+    RDEV uint32_t dim() const { return g.dim(); }
+    RDEV float get_1d(const RenderDev& rd) { return g.get_1d(rd); }
+    RDEV f2 get_2d(const RenderDev& rd) { return g.get_2d(rd); }
+};
+template <>
+struct ShadeSampler<true> {
+    PixSampler* px;
+    RDEV void bind(PixSampler* p) { px = p; }
+    RDEV void start(const RenderDev&, const uint32_t* __restrict__, uint32_t, uint64_t, uint32_t) {}
+    RDEV uint32_t dim() const { return 0u; }
+    RDEV float get_1d(const RenderDev&) { return px->get_1d(); }
+    RDEV f2 get_2d(const RenderDev&) { return px->get_2d(); }
+};
+
+}  // namespace rspt

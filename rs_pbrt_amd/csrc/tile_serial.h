@@ -1,0 +1,100 @@
+// SamplerIntegrator::render's tile loop (integrator.rs:101-217) for the PCG-backed pixel samplers.
+//
+// With these samplers a tile is one serial chain: the tile's PCG32 state runs through start_pixel of every pixel (Q9) and through
+// every dimension a path draws past the precomputed ones — how many that is depends on where the path ends — so sample k's position
+// in the stream is known only when samples 0 .. k-1 of the tile are done.  The chain cannot be cut (PCG's jump-ahead needs the
+// offset) and the only parallelism the reference's definition leaves is across tiles.  One lane renders one tile: camera sample,
+// PathIntegrator::li by the same shade_path the wavefront kernels use (its pending-estimate state machine runs on the lane's own
+// path slot), the reference-order traversal loop for its rays, then the next sample.  Lanes are spread thinly over waves
+// (lanes_per_wave, host-chosen: few tiles -> one lane per wave, so that no lane waits for a diverged neighbour).
+// Radiance and film position of every sample go to arrays that k_film then splats exactly as it does for the wavefront batches.
+#pragma once
+#include "kernels.h"
+
+namespace rspt {
+
+struct TileRec {
+    int16_t x0, y0, x1, y1;   // pixel bounds of the tile
+    uint32_t seed;            // tile.y * n_tiles.x + tile.x (integrator.rs:113)
+    uint32_t pix0;            // first entry of this tile's pixels in the pass's pixel list
+    uint32_t pad;
+};
+struct PixDesc {              // the sampler's parameters and this render's vectors
+    uint32_t kind, spp, n_dims, nx, ny, jitter;
+    const uint32_t* c_pixel;
+    float* a1;
+    float2* a2;
+    uint64_t* rng_state;      // [2 * n_tiles]: PCG state / inc between passes over the tile's rows
+};
+
+template <bool INST, bool ALPHA>
+__global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
+                                                    uint32_t n_tiles, uint32_t lanes_per_wave, int32_t row0, int32_t row1, float4* __restrict__ samp_L,
+                                                    float2* __restrict__ samp_pf, uint32_t max_iters, uint32_t* __restrict__ truncated) {
+    __shared__ uint32_t stack[RSPT_LDS_STACK * RSPT_TRACE_BLOCK];
+    if (threadIdx.x >= lanes_per_wave) return;
+    const uint32_t t = blockIdx.x * lanes_per_wave + threadIdx.x;
+    if (t >= n_tiles) return;
+    const TileRec tr = tiles[t];
+    PixSampler px;
+    px.kind = pd.kind; px.spp = pd.spp; px.n_dims = pd.n_dims; px.nx = pd.nx; px.ny = pd.ny; px.jitter = pd.jitter; px.c_pixel = pd.c_pixel;
+    px.a1 = pd.a1 + t; px.a2 = pd.a2 + t; px.stride = n_tiles;
+    px.cur1 = px.cur2 = px.cur_s = 0;
+    if (row0 == 0) px.rng.set_sequence((uint64_t)tr.seed);  // tile_sampler.reseed(seed) (integrator.rs:114)
+    else { px.rng.state = pd.rng_state[2 * (size_t)t]; px.rng.inc = pd.rng_state[2 * (size_t)t + 1]; }
+    const uint32_t slot = t;   // the lane's own path slot
+    uint32_t k = tr.pix0;
+    uint32_t* lds = stack + threadIdx.x;
+    for (int32_t y = tr.y0 + row0; y < tr.y0 + row1 && y < tr.y1; y++)
+        for (int32_t x = tr.x0; x < tr.x1; x++, k++) {
+            px.start_pixel();   // before any bounds test (Q9); pixel_bounds == sample_bounds here (Q16)
+            for (uint32_t s = 0; s < pd.spp; s++) {
+                // Sampler::get_camera_sample (sampler.rs:85-95)
+                const f2 fs = px.get_2d();
+                const f2 p_film{(float)x + fs.x, (float)y + fs.y};
+                (void)px.get_1d();   // time
+                const f2 p_lens = px.get_2d();
+                f3 o, d;
+                float t_max;
+                camera_ray(rd, p_film, p_lens, &o, &d, &t_max);
+                store_ray(pb.ray_cont + slot, o, d, t_max, slot);
+                pb.L_eta[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+                pb.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                pb.state[slot] = ST_ALIVE;
+                pb.p_film[slot] = make_float2(p_film.x, p_film.y);
+                ShadeOut so{true, true, false, false};
+                for (uint32_t it = 0; so.active; it++) {
+                    if (it >= max_iters) { atomicAdd(truncated, 1u); break; }   // the reference's loop over BSDF-less surfaces has no limit (path.rs:109-116)
+                    if (so.cont) {
+                        const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
+                        const float4 r0 = rp[0], r1 = rp[1];
+                        const TraceResult res = traverse<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        pb.hit_cont[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+                        if (INST && pb.hit_inst) pb.hit_inst[slot] = res.inst;
+                    }
+                    if (so.mis) {
+                        const float4* rp = reinterpret_cast<const float4*>(pb.ray_mis + slot);
+                        const float4 r0 = rp[0], r1 = rp[1];
+                        const TraceResult res = traverse<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        pb.hit_mis[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+                    }
+                    if (so.shadow) {
+                        const float4* rp = reinterpret_cast<const float4*>(pb.ray_sh + slot);
+                        const float4 r0 = rp[0], r1 = rp[1];
+                        const TraceResult res = traverse<true, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        pb.occluded[slot] = res.prim != RSPT_MISS ? 1u : 0u;
+                    }
+                    so = shade_path<true>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
+                }
+                const size_t out = (size_t)k * pd.spp + s;
+                samp_L[out] = pb.L_eta[slot];
+                samp_pf[out] = make_float2(p_film.x, p_film.y);
+                px.start_next_sample();
+            }
+            px.cur_s = 0;
+        }
+    pd.rng_state[2 * (size_t)t] = px.rng.state;
+    pd.rng_state[2 * (size_t)t + 1] = px.rng.inc;
+}
+
+}  // namespace rspt

@@ -84,6 +84,17 @@ def halton_permutations(n_dims=256):
     return _HALTON[n_dims]
 
 
+_MAXMIN = None
+
+
+def maxmin_tables():
+    """C_MAX_MIN_DIST (lowdiscrepancy.rs:187): 17 generator matrices of 32 columns (tools/convert_maxmin_table.py)"""
+    global _MAXMIN
+    if _MAXMIN is None:
+        _MAXMIN = np.fromfile(os.path.join(os.path.dirname(_DATA), "maxmin_tables.bin"), dtype="<u4").reshape(17, 32)
+    return _MAXMIN
+
+
 def sobol_tables():
     global _TABLES
     if _TABLES is None:
@@ -920,7 +931,8 @@ def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs,
 def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_SPATIAL,
                      crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
                      focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
-                     sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True, direct_strategy="all", light_samples=None):
+                     sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True, direct_strategy="all", light_samples=None,
+                     dimensions=4, strat=(4, 4), jitter=True):
     rd = abi.RenderDesc()
     # Integrator "path" (path.rs), "ao" / "ambientocclusion" (api.rs:411; ao.rs: nsamples 64, cossample true) or
     # "directlighting" (api.rs:322-349: strategy "all" | "one", maxdepth 5; light_samples = Light::get_n_samples per light)
@@ -960,6 +972,27 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
         rd.sampler_kind = abi.SAMPLER_HALTON
         rd.spp = spp
         rd.sample_at_pixel_center = int(sample_at_pixel_center)
+    elif sampler in ("random", "02sequence", "lowdiscrepancy", "stratified", "maxmindist"):   # the pixel samplers (make_sampler, api.rs:1690-1720)
+        rd.pixel_dimensions = int(dimensions)
+        rd.spp = spp
+        if sampler == "random":                       # random.rs:53-58
+            rd.sampler_kind = abi.SAMPLER_RANDOM
+        elif sampler == "stratified":                 # stratified.rs:89-99: spp = xsamples * ysamples
+            rd.sampler_kind = abi.SAMPLER_STRATIFIED
+            rd.strat_x, rd.strat_y = (int(v) for v in strat)
+            rd.strat_jitter = int(bool(jitter))
+            rd.spp = rd.strat_x * rd.strat_y
+        elif sampler == "maxmindist":                 # maxmin.rs:32-59: spp rounded up to a power of two, at most 2^16
+            rd.sampler_kind = abi.SAMPLER_MAXMINDIST
+            s = 1
+            while s < spp:
+                s *= 2
+            assert s <= 65536, "No more than 65536 samples per pixel are supported with MaxMinDistSampler"
+            rd.spp = s
+            rd._c_pixel = np.ascontiguousarray(maxmin_tables()[s.bit_length() - 1])   # kept alive by the desc object
+            rd.maxmin_c_pixel = rd._c_pixel.ctypes.data
+        else:                                         # zerotwosequence.rs:117-126 (no rounding of spp here, unlike pbrt-v3)
+            rd.sampler_kind = abi.SAMPLER_ZEROTWO
     else:
         rd.sampler_kind = abi.SAMPLER_SOBOL
         s = 1

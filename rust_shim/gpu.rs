@@ -274,7 +274,8 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
         integrator: integrator_kind, ao_n_samples: ao_n, ao_cos_sample: ao_cos, film_reduce: (world > 1) as u32,
         tables: RsptSamplerTables { sobol32: SOBOL_MATRICES_32.as_ptr(), vdc: vdc.as_ptr(), vdc_inv: vdc_inv.as_ptr(),
                                     halton_perms: RADICAL_INVERSE_PERMUTATIONS.as_ptr(), n_halton_perms: RADICAL_INVERSE_PERMUTATIONS.len() as u64 },
-        direct_strategy: 0, pad2: 0, n_light_samples: std::ptr::null(),
+        direct_strategy: 0, pixel_dimensions: 0, n_light_samples: std::ptr::null(),
+        strat_x: 0, strat_y: 0, strat_jitter: 0, pad3: 0, maxmin_c_pixel: std::ptr::null(),   // pixel samplers: §3 of INTEGRATION.md
     };
     let sd = RsptSceneDesc {
         nodes: f.nodes.as_ptr(), n_nodes: f.nodes.len() as u64, prims: f.prims.as_ptr(), n_prims: f.prims.len() as u64,

@@ -1,0 +1,97 @@
+"""The PCG-backed pixel samplers on the GPU: librspt's one-lane-per-tile kernel (rs_pbrt_amd/csrc/tile_serial.h)
+against the oracle.  The sample values are integer arithmetic (PCG32, Gray-code nets, shuffles) and must agree exactly: film weights
+bit for bit; radiance within the sinf / cosf tolerance of DESIGN.md section 3."""
+import os
+
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import abi, scenes
+from tests.util import film_rmse
+
+pytestmark = pytest.mark.gpu
+SAMPLERS = ("random", "02sequence", "stratified", "maxmindist")
+
+
+def _pair(gpu, oracle, sc, rd):
+    ref = oracle.render(sc, rd, threads=8)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    assert st["samples"] == ref["counters"]["samples"]
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])   # which pixel got which sample positions: the sampler streams, exactly
+    return film, st, ref
+
+
+@pytest.mark.parametrize("sampler", SAMPLERS)
+def test_cornell_matches_oracle(gpu, oracle, sampler):
+    sc = scenes.cornell_box(gpu.bvh_build, variant="mixed")
+    rd = scenes.cornell_render_desc(res=72, spp=16, sampler=sampler, strat=(4, 4))   # 72 = 4.5 tiles: partial tiles on two sides
+    film, st, ref = _pair(gpu, oracle, sc, rd)
+    assert film_rmse(film, ref["film"]) < 1e-5 and st["truncated_paths"] == 0
+    # Monte-Carlo sanity: close to the Sobol' picture
+    sob = scenes.film_to_rgb(oracle.render(sc, scenes.cornell_render_desc(res=72, spp=16), threads=8)["film"])
+    assert abs(scenes.film_to_rgb(film).mean() - sob.mean()) < 0.05 * sob.mean()
+
+
+def test_passes_lanes_and_shards_do_not_change_the_frame(gpu, oracle):
+    """rows-per-pass (RSPT_SERIAL_SAMPLES: the PCG state is carried from pass to pass), lanes per wave (RSPT_SERIAL_WAVES) and the
+    multi-GPU tile deal are scheduling only"""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=64, spp=8, sampler="02sequence", dimensions=3)
+    base, _, ref = _pair(gpu, oracle, sc, rd)
+    assert film_rmse(base, ref["film"]) < 1e-5
+    try:
+        for k, v in (("RSPT_SERIAL_SAMPLES", str(16 * 8 * 16 * 3)), ("RSPT_SERIAL_WAVES", "1"), ("RSPT_SERIAL_WAVES", "5")):   # 3 rows per pass; 64 / 4 lanes per wave
+            os.environ[k] = v
+            with gpu.DeviceScene(sc) as ds:
+                f, _ = gpu.render(ds, rd)
+            os.environ.pop(k)
+            assert np.array_equal(f, base), k
+    finally:
+        os.environ.pop("RSPT_SERIAL_SAMPLES", None); os.environ.pop("RSPT_SERIAL_WAVES", None)
+    total = np.zeros_like(base)
+    with gpu.DeviceScene(sc) as ds:
+        for r in range(3):
+            rds = scenes.cornell_render_desc(res=64, spp=8, sampler="02sequence", dimensions=3, shard=(r, 3, 1))
+            f, _ = gpu.render(ds, rds)
+            assert np.array_equal(f[:, 3], oracle.render(sc, rds, threads=4)["film"][:, 3])
+            total += f
+    assert np.array_equal(total[:, 3], base[:, 3]) and np.allclose(total, base, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("sampler", ("random", "02sequence"))
+def test_gallery_materials_lights_and_null_surfaces(gpu, oracle, sampler):
+    from tests.util import GALLERY_LOOK_AT, gallery
+    sc = gallery(gpu.bvh_build)
+    rd = scenes.make_render_desc(64, 48, 8, GALLERY_LOOK_AT, 60.0, max_depth=5, sampler=sampler, crop=(0.1, 0.9, 0.2, 1.0))
+    film, st, ref = _pair(gpu, oracle, sc, rd)
+    assert film_rmse(film, ref["film"]) < 2e-5
+    cb = scenes.cornell_box(gpu.bvh_build)
+    cb.prims["material"][cb.prims["material"] == 1] = abi.NO_MATERIAL   # the red wall becomes a null boundary: uncounted passes (path.rs:109-116)
+    rd = scenes.cornell_render_desc(res=48, spp=8, sampler=sampler)
+    film, st, ref = _pair(gpu, oracle, cb, rd)
+    assert film_rmse(film, ref["film"]) < 1e-5
+
+
+def test_instances_and_alpha_masks(gpu, oracle):
+    from tests.test_alpha_masks import LOOK, masked_scene
+    for kw in (dict(), dict(instanced=True, mode="fixed"), dict(instanced=True, mode="reference")):
+        sc = masked_scene(gpu.bvh_build, **kw)
+        rd = scenes.make_render_desc(64, 48, 4, LOOK, 50.0, sampler="02sequence")
+        film, st, ref = _pair(gpu, oracle, sc, rd)
+        assert film_rmse(film, ref["film"]) < 2e-5 and st["truncated_paths"] == 0
+
+
+def test_refusals(gpu):
+    from rs_pbrt_amd.lib import RsptError
+    sc = scenes.cornell_box(gpu.bvh_build)
+    with gpu.DeviceScene(sc) as ds:
+        for kw in (dict(integrator="ao"), dict(integrator="volpath"), dict(integrator="directlighting")):
+            with pytest.raises(RsptError) as e:
+                gpu.render(ds, scenes.cornell_render_desc(res=32, spp=4, sampler="random", **kw))
+            assert e.value.code == abi.E_UNSUPPORTED
+        rd = scenes.cornell_render_desc(res=32, spp=4, sampler="stratified", strat=(2, 2))
+        rd.spp = 5
+        with pytest.raises(RsptError) as e:
+            gpu.render(ds, rd)
+        assert e.value.code == abi.E_INVALID
