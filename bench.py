@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sampler", default="sobol", choices=["sobol", "halton", "random", "02sequence", "stratified", "maxmindist"],
+                    help="the four PCG-backed pixel samplers run one lane per 16x16 tile (a tile is one serial chain): a latency-bound workload")
     ap.add_argument("--integrator", default="path", choices=["path", "ao", "directlighting", "volpath"],
                     help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample); directlighting: DirectLightingIntegrator, strategy all, maxdepth 5; "
                          "volpath: VolPathIntegrator (with --workload cornell the room is filled with a homogeneous medium)")
@@ -95,6 +97,18 @@ def build_workload(args, workload, lib, scenes):
             ", image-textured + bump-mapped" if tex else "", ", 64 small area lights (C4 stand-in)" if workload == "c4" else "", spp, xres, yres)
     if integ != "path":
         name += " [%s integrator]" % integ
+    if args.sampler != "sobol":   # the default of every workload above
+        base_mk = mk
+
+        def mk(s, sh, **kw):  # noqa: E731
+            extra = {}
+            if args.sampler == "stratified":   # xsamples x ysamples = the (power-of-two) sample count
+                k = max(int(s).bit_length() - 1, 0)
+                extra["strat"] = (1 << ((k + 1) // 2), 1 << (k // 2))
+            return base_mk(s, sh, sampler=args.sampler, **extra, **kw)
+        name = name.replace("sobol", args.sampler)
+        if args.sampler not in ("sobol", "halton"):
+            name += " [pixel sampler: one lane per 16x16 tile, a tile is one serial chain of its PCG32 stream]"
     return sc, mk, spp, name
 
 
@@ -217,7 +231,7 @@ def measure(args, lib, scenes, workload, steps, warmup, shard, world, reduce_in_
 
     # counting pass (deterministic: identical counts in the timed passes) for the algorithmic-bytes roofline; rank-local, no reduce
     counts = None
-    if not args.no_count:
+    if not args.no_count and args.sampler in ("sobol", "halton"):   # (the tile-serial kernel of the pixel samplers has no counting variant)
         rd_count = mk_rd(max(spp // count_spp_div, 1), shard)
         os.environ["RSPT_COUNTERS"] = "1"
         counts = lib.render_device(ds, rd_count, film.data_ptr())
@@ -288,7 +302,7 @@ def main():
         samples_per_step = float(stats[0]["samples"])
 
     if rank == 0:
-        default_cfg = args.tris == 1_000_000 and not args.res and not args.spp and world == 1 and args.integrator == "path"
+        default_cfg = args.tris == 1_000_000 and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
         traffic, tnote = measured_traffic(lib, args.workload, default_cfg)
         out = {
             "metric": "Mpath-samples/sec (whole node)", "value": samples_per_step * args.steps / elapsed / 1e6, "unit": "Msamples/s",
@@ -299,7 +313,11 @@ def main():
                        "timed_region": "rspt_render_device per step: first launch -> film complete in HBM%s; SURVEY 8(d)'s t_render ends with the film in "
                                        "host memory: + 16 B per pixel D2H once per frame (%.1f MB), not included" % (
                                            " on rank 0 after the reduce" if world > 1 else "", scenes.n_pixels(m["rd"]) * 16 / 1e6)},
-            "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote) if m["counts"] else None,
+            "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote) if m["counts"] else (
+                {"bound": "latency", "kernel": "k_tile_serial (one lane per tile: camera sample, reference-order traversal and shade_path in turn)", "achieved": None, "peak": None,
+                 "unit": None, "frac": None, "traffic": None,
+                 "note": "the pixel samplers make a tile one serial chain (DESIGN.md section 5.7): the bound is the dependent-load latency of one lane, "
+                         "not bandwidth or issue rate; what is reported is the rate next to the CPU's"} if args.sampler not in ("sobol", "halton") else None),
             "stats": {k: sum(s_[k] for s_ in stats) / len(stats) for k in ("t_trace_closest_s", "t_trace_any_s", "t_trace_s", "t_shade_s", "t_kernels_s", "trace_launches", "truncated_paths", "nan_samples")},
             "setup_s": {"scene_and_bvh_build": m["t_scene"], "upload": m["t_upload"], "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }

@@ -252,11 +252,19 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
     let radius = film.filter.get_radius();
     let mut filter_table = [0.0f32; 256];
     filter_table.copy_from_slice(film.filter_table());                             // getter: rs_pbrt.patch (film.rs:170)
-    let (sampler_kind, spp, at_center) = match integ.get_sampler() {
-        Sampler::Sobol(s) => (1u32, s.samples_per_pixel, 0u32),
-        Sampler::Halton(h) => (2u32, h.samples_per_pixel, h.sample_at_pixel_center() as u32),
-        _ => return Err("sampler with per-tile RNG state (02sequence / random / stratified / maxmindist)".into()),
+    // (kind, spp, samplepixelcenter, dimensions, xsamples, ysamples, jitter, c_pixel): the pixel samplers' private fields through
+    // pub(crate) getters of rs_pbrt.patch; n_sampled_dimensions = samples_1d.len()
+    let mut c_pixel = [0u32; 32];
+    let (sampler_kind, spp, at_center, pix_dims, sx, sy, jit) = match integ.get_sampler() {
+        Sampler::Sobol(s) => (1u32, s.samples_per_pixel, 0u32, 0u32, 0u32, 0u32, 0u32),
+        Sampler::Halton(h) => (2u32, h.samples_per_pixel, h.sample_at_pixel_center() as u32, 0, 0, 0, 0),
+        Sampler::Random(r) => (3u32, r.samples_per_pixel, 0, 0, 0, 0, 0),
+        Sampler::ZeroTwoSequence(z) => (4u32, z.samples_per_pixel, 0, z.n_sampled_dimensions as u32, 0, 0, 0),
+        Sampler::Stratified(t) => { let (x, y, j, dims) = t.shim_params(); (5u32, t.samples_per_pixel, 0, dims, x as u32, y as u32, j as u32) }
+        Sampler::MaxMinDist(m) => { let (c, dims) = m.shim_params(); c_pixel = c; (6u32, m.samples_per_pixel, 0, dims, 0, 0, 0) }
+        _ => return Err("MLT sampler".into()),
     };
+    if sampler_kind >= 3 && integrator_kind != 0 { return Err("pixel sampler with an integrator other than path".into()); }
     let mut vdc = vec![0u64; 25 * 52]; let mut vdc_inv = vec![0u64; 26 * 52];       // rows zero-padded to 52 entries
     for (i, row) in VD_C_SOBOL_MATRICES.iter().enumerate() { vdc[i * 52..i * 52 + row.len()].copy_from_slice(row); }
     for (i, row) in VD_C_SOBOL_MATRICES_INV.iter().enumerate() { vdc_inv[i * 52..i * 52 + row.len()].copy_from_slice(row); }
@@ -274,8 +282,8 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
         integrator: integrator_kind, ao_n_samples: ao_n, ao_cos_sample: ao_cos, film_reduce: (world > 1) as u32,
         tables: RsptSamplerTables { sobol32: SOBOL_MATRICES_32.as_ptr(), vdc: vdc.as_ptr(), vdc_inv: vdc_inv.as_ptr(),
                                     halton_perms: RADICAL_INVERSE_PERMUTATIONS.as_ptr(), n_halton_perms: RADICAL_INVERSE_PERMUTATIONS.len() as u64 },
-        direct_strategy: 0, pixel_dimensions: 0, n_light_samples: std::ptr::null(),
-        strat_x: 0, strat_y: 0, strat_jitter: 0, pad3: 0, maxmin_c_pixel: std::ptr::null(),   // pixel samplers: §3 of INTEGRATION.md
+        direct_strategy: 0, pixel_dimensions: pix_dims, n_light_samples: std::ptr::null(),
+        strat_x: sx, strat_y: sy, strat_jitter: jit, pad3: 0, maxmin_c_pixel: if sampler_kind == 6 { c_pixel.as_ptr() } else { std::ptr::null() },
     };
     let sd = RsptSceneDesc {
         nodes: f.nodes.as_ptr(), n_nodes: f.nodes.len() as u64, prims: f.prims.as_ptr(), n_prims: f.prims.len() as u64,
