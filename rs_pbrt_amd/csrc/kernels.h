@@ -554,97 +554,100 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
 // For every path whose continuation ray hit a textured material: compute_differentials (camera rays
 // only; bounce rays carry none, interaction.rs:388-479), Material::bump, and the clamped value of each
 // texture the material's lobes are bound to; k_shade picks the results up from pb.tex.
+// the texture stage for path slot p (see above); lens: the camera sample's lens position when it cannot be recomputed from the
+// sample index (pixel samplers), else nullptr
+RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev& rd, const PathBuf& pb, uint32_t p, const f2* lens) {
+    const uint32_t st = pb.state[p];
+    if (!(st & ST_ALIVE)) return;
+    const float4 hc = pb.hit_cont[p];
+    const uint32_t prim = __float_as_uint(hc.x);
+    const uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
+    if (prim == RSPT_MISS || bounces >= rd.max_depth) return;
+    const TriRec tri = load_tri(sc, prim);
+    if (tri.material == 0xffffffffu) return;
+    const uint32_t mf = tt.mat_flags[tri.material];
+    if (!mf) return;
+    TexHit h;
+    tri_fill_tex(sc, prim, tri, hc.y, hc.z, hc.w, &h);
+    if (pb.hit_inst) {
+        const uint32_t hi = pb.hit_inst[p];
+        if (hi && !sc.inst[hi - 1u].identity) {
+            if (!sc.inst_fixed) return;  // reference behaviour: the hit has lost its primitive, nothing to texture
+            inst_texhit(sc.inst[hi - 1u], &h);
+        }
+    }
+    TexSurf s;
+    s.p = h.p; s.uv = h.uv;
+    s.dudx = s.dvdx = s.dudy = s.dvdy = 0.0f;
+    s.dpdx = s.dpdy = f3{0.0f, 0.0f, 0.0f};
+    if (bounces == 0 && !(st & ST_NO_DIFF)) {  // the camera ray itself (a null-material pass-through re-spawns without differentials)
+        const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
+        const float4 r0 = rp[0], r1 = rp[1];
+        const float2 pf = pb.p_film[p];
+        f2 p_lens{0.0f, 0.0f};
+        if (lens) p_lens = *lens;   // a pixel sampler's lens sample (tile_serial.h): not a function of (index, dimension)
+        else if (rd.lens_radius > 0.0f) {
+            const uint64_t index = pb.sobol_index[p];
+            p_lens = rd.sampler_kind == RSPT_SAMPLER_HALTON ? f2{halton_dim(rd, index, 3), halton_dim(rd, index, 4)}
+                                                            : f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
+        }
+        f3 rx_o, rx_d, ry_o, ry_d;
+        camera_differentials(rd, f2{pf.x, pf.y}, p_lens, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, &rx_o, &rx_d, &ry_o, &ry_d);
+        compute_differentials(h, rx_o, rx_d, ry_o, ry_d, &s);
+    }
+    const rspt_material mat = sc.materials[tri.material];
+    float4* out = pb.tex + p;
+    const size_t stride = pb.tex_stride;
+    uint32_t flags = 0;
+    if (mat.bump_tex) {
+        f3 bn, bdpdu;
+        bump_map(tt, mat.bump_tex - 1u, h, s, &bn, &bdpdu);
+        out[5 * stride] = make_float4(bdpdu.x, bdpdu.y, bdpdu.z, 0.0f);
+        flags |= 1u;
+        out[4 * stride] = make_float4(bn.x, bn.y, bn.z, 0.0f);  // (.w is completed below)
+        h.sh_n = bn;
+    }
+    rgb tv[RSPT_TEX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < RSPT_TEX_SLOTS; k++) {
+        tv[k] = mkrgb(0.0f);
+        const uint32_t sd = tt.mat_slots[(size_t)tri.material * RSPT_TEX_SLOTS + k];
+        if (sd != 0xffffffffu) {
+            const uint32_t ti = sd & RSPT_SLOT_TEX_MASK;
+            rgb v = tex_eval(tt, ti, s);
+            if (sd & RSPT_SLOT_ALPHA) {  // a roughness texture: the slot carries the lobe's alpha (plastic.rs:86-92, microfacet.rs:233-254)
+                float a = v.r;
+                if (sd & RSPT_SLOT_REMAP) {
+                    const float r = fmaxf(a, 1e-3f), x = logf(r);
+                    a = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+                }
+                a = fmaxf(0.001f, a);
+                out[k * stride] = make_float4(a, a, a, 0.0f);
+                continue;
+            }
+            tv[k] = rgb{v.r < 0.0f ? 0.0f : v.r, v.g < 0.0f ? 0.0f : v.g, v.b < 0.0f ? 0.0f : v.b};  // Spectrum::clamp(0, inf) = clamp_t per channel (pbrt.rs:108-123)
+            out[k * stride] = make_float4(tv[k].r, tv[k].g, tv[k].b, 0.0f);
+        }
+    }
+    // the reference's `if !colour.is_black()` guards around bsdf.add (matte.rs:70, plastic.rs:70,84, substrate.rs:72, uber.rs)
+    const uint32_t nl = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+    for (uint32_t l = 0; l < nl; l++) {
+        const rspt_bxdf& b = sc.bxdfs[mat.first_bxdf + l];
+        if (!b.tex_r && !b.tex_t) continue;
+        rgb r = ldrgb(b.r), t = ldrgb(b.t);
+        if (b.tex_r) r = r * (b.tex_r == 1 ? tv[0] : (b.tex_r == 2 ? tv[1] : (b.tex_r == 3 ? tv[2] : tv[3])));
+        if (b.tex_t) t = t * (b.tex_t == 1 ? tv[0] : (b.tex_t == 2 ? tv[1] : (b.tex_t == 3 ? tv[2] : tv[3])));
+        const bool two = b.type == RSPT_BXDF_FRESNEL_SPEC || b.type == RSPT_BXDF_FRESNEL_BLEND;
+        if (two ? (is_black(r) && is_black(t)) : is_black(r)) flags |= 1u << (8 + l);
+    }
+    float4 m4 = (flags & 1u) ? out[4 * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    m4.w = __uint_as_float(flags);
+    out[4 * stride] = m4;
+}
 __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
                                                  const uint32_t* __restrict__ count_in) {
     const uint32_t n = *count_in;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t p = q_active[i];
-        const uint32_t st = pb.state[p];
-        if (!(st & ST_ALIVE)) continue;
-        const float4 hc = pb.hit_cont[p];
-        const uint32_t prim = __float_as_uint(hc.x);
-        const uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
-        if (prim == RSPT_MISS || bounces >= rd.max_depth) continue;
-        const TriRec tri = load_tri(sc, prim);
-        if (tri.material == 0xffffffffu) continue;
-        const uint32_t mf = tt.mat_flags[tri.material];
-        if (!mf) continue;
-        TexHit h;
-        tri_fill_tex(sc, prim, tri, hc.y, hc.z, hc.w, &h);
-        if (pb.hit_inst) {
-            const uint32_t hi = pb.hit_inst[p];
-            if (hi && !sc.inst[hi - 1u].identity) {
-                if (!sc.inst_fixed) continue;  // reference behaviour: the hit has lost its primitive, nothing to texture
-                inst_texhit(sc.inst[hi - 1u], &h);
-            }
-        }
-        TexSurf s;
-        s.p = h.p; s.uv = h.uv;
-        s.dudx = s.dvdx = s.dudy = s.dvdy = 0.0f;
-        s.dpdx = s.dpdy = f3{0.0f, 0.0f, 0.0f};
-        if (bounces == 0 && !(st & ST_NO_DIFF)) {  // the camera ray itself (a null-material pass-through re-spawns without differentials)
-            const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
-            const float4 r0 = rp[0], r1 = rp[1];
-            const float2 pf = pb.p_film[p];
-            f2 p_lens{0.0f, 0.0f};
-            if (rd.lens_radius > 0.0f) {
-                const uint64_t index = pb.sobol_index[p];
-                p_lens = rd.sampler_kind == RSPT_SAMPLER_HALTON ? f2{halton_dim(rd, index, 3), halton_dim(rd, index, 4)}
-                                                                : f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
-            }
-            f3 rx_o, rx_d, ry_o, ry_d;
-            camera_differentials(rd, f2{pf.x, pf.y}, p_lens, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, &rx_o, &rx_d, &ry_o, &ry_d);
-            compute_differentials(h, rx_o, rx_d, ry_o, ry_d, &s);
-        }
-        const rspt_material mat = sc.materials[tri.material];
-        float4* out = pb.tex + p;
-        const size_t stride = pb.tex_stride;
-        uint32_t flags = 0;
-        if (mat.bump_tex) {
-            f3 bn, bdpdu;
-            bump_map(tt, mat.bump_tex - 1u, h, s, &bn, &bdpdu);
-            out[5 * stride] = make_float4(bdpdu.x, bdpdu.y, bdpdu.z, 0.0f);
-            flags |= 1u;
-            out[4 * stride] = make_float4(bn.x, bn.y, bn.z, 0.0f);  // (.w is completed below)
-            h.sh_n = bn;
-        }
-        rgb tv[RSPT_TEX_SLOTS];
-#pragma unroll
-        for (int k = 0; k < RSPT_TEX_SLOTS; k++) {
-            tv[k] = mkrgb(0.0f);
-            const uint32_t sd = tt.mat_slots[(size_t)tri.material * RSPT_TEX_SLOTS + k];
-            if (sd != 0xffffffffu) {
-                const uint32_t ti = sd & RSPT_SLOT_TEX_MASK;
-                rgb v = tex_eval(tt, ti, s);
-                if (sd & RSPT_SLOT_ALPHA) {  // a roughness texture: the slot carries the lobe's alpha (plastic.rs:86-92, microfacet.rs:233-254)
-                    float a = v.r;
-                    if (sd & RSPT_SLOT_REMAP) {
-                        const float r = fmaxf(a, 1e-3f), x = logf(r);
-                        a = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
-                    }
-                    a = fmaxf(0.001f, a);
-                    out[k * stride] = make_float4(a, a, a, 0.0f);
-                    continue;
-                }
-                tv[k] = rgb{v.r < 0.0f ? 0.0f : v.r, v.g < 0.0f ? 0.0f : v.g, v.b < 0.0f ? 0.0f : v.b};  // Spectrum::clamp(0, inf) = clamp_t per channel (pbrt.rs:108-123)
-                out[k * stride] = make_float4(tv[k].r, tv[k].g, tv[k].b, 0.0f);
-            }
-        }
-        // the reference's `if !colour.is_black()` guards around bsdf.add (matte.rs:70, plastic.rs:70,84, substrate.rs:72, uber.rs)
-        const uint32_t nl = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
-        for (uint32_t l = 0; l < nl; l++) {
-            const rspt_bxdf& b = sc.bxdfs[mat.first_bxdf + l];
-            if (!b.tex_r && !b.tex_t) continue;
-            rgb r = ldrgb(b.r), t = ldrgb(b.t);
-            if (b.tex_r) r = r * (b.tex_r == 1 ? tv[0] : (b.tex_r == 2 ? tv[1] : (b.tex_r == 3 ? tv[2] : tv[3])));
-            if (b.tex_t) t = t * (b.tex_t == 1 ? tv[0] : (b.tex_t == 2 ? tv[1] : (b.tex_t == 3 ? tv[2] : tv[3])));
-            const bool two = b.type == RSPT_BXDF_FRESNEL_SPEC || b.type == RSPT_BXDF_FRESNEL_BLEND;
-            if (two ? (is_black(r) && is_black(t)) : is_black(r)) flags |= 1u << (8 + l);
-        }
-        float4 m4 = (flags & 1u) ? out[4 * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        m4.w = __uint_as_float(flags);
-        out[4 * stride] = m4;
-    }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) texture_path(sc, tt, rd, pb, q_active[i], nullptr);
 }
 
 // ---- K7b: bin the active queue by what the shade stage will do with each path -------------------------------------------

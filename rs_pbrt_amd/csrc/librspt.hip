@@ -500,7 +500,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (sobol && (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv)) return fail(RSPT_E_INVALID, "null sobol tables");
     if (pixel_sampler) {
         if (d->integrator != RSPT_INTEGRATOR_PATH) return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path integrator only");
-        if (s->has_textures) return fail(RSPT_E_UNSUPPORTED, "the pixel samplers with textured materials");
         if (d->tile_size != 16 && d->tile_size > 255) return fail(RSPT_E_UNSUPPORTED, "tile_size > 255 with a pixel sampler");
         if (d->spp > 65536 || d->pixel_dimensions > 64) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: spp > 65536 or more than 64 sampled dimensions");
         if (d->sampler_kind == RSPT_SAMPLER_STRATIFIED && (d->strat_x == 0 || d->strat_y == 0 || (int64_t)d->strat_x * d->strat_y != d->spp))

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                         const TraceResult res = traverse<true, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
                         pb.occluded[slot] = res.prim != RSPT_MISS ? 1u : 0u;
                     }
+                    if (sc.mat_flags && so.cont) texture_path(sc, tt, rd, pb, slot, &p_lens);   // the texture stage k_texture runs in front of k_shade
                     so = shade_path<true>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
                 }
                 const size_t out = (size_t)k * pd.spp + s;

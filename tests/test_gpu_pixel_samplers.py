@@ -82,6 +82,20 @@ def test_instances_and_alpha_masks(gpu, oracle):
         assert film_rmse(film, ref["film"]) < 2e-5 and st["truncated_paths"] == 0
 
 
+@pytest.mark.parametrize("seed", [301, 302, 303, 304, 305, 306])
+def test_random_scenes_fuzz(gpu, oracle, seed):
+    """the random rooms of tests/test_gpu_render.py (every material recipe, image / procedural textures with the camera ray's
+    differentials, bump maps, null surfaces, all light kinds, thin lens) under the pixel samplers"""
+    from tests.util import GALLERY_LOOK_AT, random_scene
+    sc = random_scene(gpu.bvh_build, seed)
+    rd = scenes.make_render_desc(56, 40, 4, GALLERY_LOOK_AT, 55, max_depth=2 + seed % 5, sampler=SAMPLERS[seed % 4], strat=(2, 2), dimensions=2 + seed % 4,
+                                 light_strategy=[abi.LIGHTS_SPATIAL, abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM][seed % 3],
+                                 lens_radius=0.03 if seed % 2 == 0 else 0.0, focal_distance=6.0)
+    film, st, ref = _pair(gpu, oracle, sc, rd)
+    assert st["nan_samples"] == ref["counters"]["nan_samples"]
+    assert film_rmse(film, ref["film"]) < 3e-4
+
+
 def test_refusals(gpu):
     from rs_pbrt_amd.lib import RsptError
     sc = scenes.cornell_box(gpu.bvh_build)

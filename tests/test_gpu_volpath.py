@@ -105,6 +105,29 @@ def test_gpu_volpath_with_textured_materials(gpu, oracle):
     assert film_rmse(film, ref["film"]) < 2e-5
 
 
+@pytest.mark.parametrize("seed", list(range(201, 213)))
+def test_volpath_random_scenes_fuzz(gpu, oracle, seed):
+    """the random rooms of test_random_scenes_fuzz (every material recipe, textures, bump maps, null surfaces, area / delta / sometimes
+    infinite lights) with one or two overlapping boxes of fog, both samplers, all light strategies.  Where two media overlap, the
+    boundary a ray crossed last decides its medium (Interaction::get_medium), whatever that means physically."""
+    from tests.util import GALLERY_LOOK_AT, random_scene
+    sb = random_scene(gpu.bvh_build, seed).builder
+    rng = np.random.default_rng(seed)
+    for k in range(1 + seed % 2):
+        fog = sb.add_medium(sigma_a=tuple(rng.uniform(0.0, 0.08, 3)), sigma_s=tuple(rng.uniform(0.05, 0.5, 3)), g=float(rng.uniform(-0.5, 0.8)))
+        lo = rng.uniform([-3.5, 0.3, -2.5], [-0.5, 1.5, 0.5])
+        sb.add_box(tuple(lo), tuple(lo + rng.uniform([1.5, 1.5, 1.5], [4.0, 3.5, 4.0])), None, medium=(fog, None))
+    sc = sb.finish(gpu.bvh_build)
+    rd = scenes.make_render_desc(56, 40, 8, GALLERY_LOOK_AT, 55, max_depth=2 + seed % 5, sampler="halton" if seed % 2 else "sobol", integrator="volpath",
+                                 light_strategy=[abi.LIGHTS_SPATIAL, abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM][seed % 3])
+    ref = oracle.render(sc, rd, threads=8)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and st["truncated_paths"] == 0
+    assert st["nan_samples"] == ref["counters"]["nan_samples"]
+    assert film_rmse(film, ref["film"]) < 3e-4
+
+
 def test_gpu_volpath_refusals(gpu):
     from rs_pbrt_amd.lib import RsptError
     sb = scenes.SceneBuilder()
