@@ -18,21 +18,24 @@ from rs_pbrt_amd import multigpu, scenes  # noqa: E402
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    sc = scenes.cornell_box(pyoracle.bvh_build)
-    mk = lambda shard: scenes.cornell_render_desc(res=80, spp=2, shard=shard)  # noqa: E731
-    shard = multigpu.shard_for_rank(rank, world, tile_chunk=3)
-    mine = pyoracle.render(sc, mk(shard), threads=2)
-    n_mine = mine["counters"]["samples"]
-    film = torch.from_numpy(mine["film"].copy())
-    multigpu.reduce_film(film, dst=0)
-    counts = torch.tensor([float(n_mine)], dtype=torch.float64)
-    dist.all_reduce(counts)
     ok = True
+    # the Sobol' wavefront configuration, a fogged room under volpath, and a pixel sampler (tiles reseed by position: the deal must not matter)
+    for fog, kw in ((None, {}), (scenes.CORNELL_FOG, dict(integrator="volpath")), (None, dict(sampler="02sequence"))):
+        sc = scenes.cornell_box(pyoracle.bvh_build, fog=fog)
+        mk = lambda shard: scenes.cornell_render_desc(res=80, spp=2, shard=shard, **kw)  # noqa: E731,B023
+        shard = multigpu.shard_for_rank(rank, world, tile_chunk=3 if not kw else 1)
+        mine = pyoracle.render(sc, mk(shard), threads=2)
+        n_mine = mine["counters"]["samples"]
+        film = torch.from_numpy(mine["film"].copy())
+        multigpu.reduce_film(film, dst=0)
+        counts = torch.tensor([float(n_mine)], dtype=torch.float64)
+        dist.all_reduce(counts)
+        if rank == 0:
+            full = pyoracle.render(sc, mk((0, 1, 3)), threads=2)
+            ok = ok and bool(np.allclose(film.numpy(), full["film"], rtol=1e-6, atol=1e-7)) and np.array_equal(film.numpy()[:, 3], full["film"][:, 3])
+            ok = ok and int(counts.item()) == full["counters"]["samples"] == 80 * 80 * 2
+            ok = ok and 0 < n_mine < 80 * 80 * 2  # a strict subset of the frame per rank
     if rank == 0:
-        full = pyoracle.render(sc, mk((0, 1, 3)), threads=2)
-        ok = bool(np.allclose(film.numpy(), full["film"], rtol=1e-6, atol=1e-7)) and np.array_equal(film.numpy()[:, 3], full["film"][:, 3])
-        ok = ok and int(counts.item()) == full["counters"]["samples"] == 80 * 80 * 2
-        ok = ok and 0 < n_mine < 80 * 80 * 2  # a strict subset of the frame per rank
         print("GLOO_RESULT", "OK" if ok else "MISMATCH", flush=True)
     dist.barrier()
     dist.destroy_process_group()
