@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 15
+#define RSPT_ABI_VERSION 16
 
 /* error codes */
 #define RSPT_OK 0
@@ -362,6 +362,12 @@ typedef struct {
     uint32_t strat_jitter;           /* "jitter" (default true)                                                                      */
     uint32_t pad3;
     const uint32_t* maxmin_c_pixel;  /* MaxMinDistSampler: the 32 columns of its generator matrix (lowdiscrepancy.rs:187-760, row log2 spp)  */
+    /* Checkpoint / resume and progressive refinement (not in the reference, whose render loop is one-shot): render only
+     * the pixel samples [sample_begin, sample_begin + sample_count) of every pixel; sample_count = 0 means all of spp.  With the
+     * Sobol' and Halton samplers a sample's values depend on (pixel, sample index) alone, so the films of disjoint ranges add up to the
+     * full frame's (xyz and filter_weight_sum alike): a caller that keeps the summed film and the next sample index can stop and
+     * resume, show intermediate results, or re-render a lost rank's shard elsewhere.  The pixel samplers accept the full range only. */
+    uint64_t sample_begin, sample_count;
 } rspt_render_desc;
 /* RSPT_INTEGRATOR_VOLPATH: VolPathIntegrator::li (src/integrators/volpath.rs:60-347) with max_depth, rr_threshold and
  * light_strategy as for "path" (api.rs:350-380).  Camera rays start outside every medium (make_camera passes

@@ -1405,6 +1405,10 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         Ray ray = camera_ray(rd, p_film, time_s, p_lens);
                         ray.scale_differentials(1.0f / std::sqrt((Float)rd.spp)); // integrator.rs:140-144 (get_samples_per_pixel)
                         Float ray_weight = 1.0f;
+                        if (rd.sample_count && ((uint64_t)sampler.cur_sample() < rd.sample_begin || (uint64_t)sampler.cur_sample() >= rd.sample_begin + rd.sample_count)) {
+                            done = !sampler.start_next_sample(); // checkpoint / resume (not in the reference): this sample belongs to another range
+                            continue;
+                        }
                         Spec l = ext_integrator != ORC_INTEGRATOR_FROM_DESC ? recursive_li(cx, ray, sampler, 0, &c)
                                  : rd.integrator == RSPT_INTEGRATOR_AO       ? ao_li(cx, ray, sampler, &c)
                                  : rd.integrator == RSPT_INTEGRATOR_VOLPATH  ? volpath_li(cx, ray, sampler, &c)

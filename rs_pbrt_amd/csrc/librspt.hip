@@ -524,6 +524,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             if (d->n_light_samples[i] < 1 || d->n_light_samples[i] > 4096) return fail(RSPT_E_INVALID, "n_light_samples[%u] out of range", i);
     }
     if (d->integrator == RSPT_INTEGRATOR_AO && (d->ao_n_samples == 0 || d->ao_n_samples > 4096)) return fail(RSPT_E_INVALID, "ao_n_samples must be in [1, 4096]");
+    // checkpoint / resume: the pixel samples [smp_begin, smp_end) of every pixel
+    const uint64_t smp_begin = d->sample_begin, smp_end = d->sample_count ? d->sample_begin + d->sample_count : (uint64_t)d->spp;
+    if (smp_begin >= smp_end || smp_end > (uint64_t)d->spp) return fail(RSPT_E_INVALID, "sample range [%llu, %llu) outside [0, spp)", (unsigned long long)smp_begin, (unsigned long long)smp_end);
+    if (pixel_sampler && (smp_begin != 0 || smp_end != (uint64_t)d->spp)) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler renders all samples of a tile in one chain: partial sample ranges are not possible");
     const int32_t* sb = d->sample_bounds;
     const int32_t* cp = d->crop_px;
     if (sb[2] <= sb[0] || sb[3] <= sb[1] || cp[2] <= cp[0] || cp[3] <= cp[1]) return fail(RSPT_E_INVALID, "empty sample or crop bounds");
@@ -802,8 +806,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
     for (size_t p0 = 0; !pixel_sampler && p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
-        for (uint32_t s0 = 0; s0 < (uint32_t)d->spp; s0 += ns) {
-            const uint32_t ns_b = std::min(ns, (uint32_t)d->spp - s0);  // Halton spp need not be a power of two
+        for (uint32_t s0 = (uint32_t)smp_begin; s0 < (uint32_t)smp_end; s0 += ns) {
+            const uint32_t ns_b = std::min(ns, (uint32_t)smp_end - s0);  // Halton spp need not be a power of two
             Batch bt{(uint32_t)p0, npx, s0, ns_b, npx * ns_b};
             samples += bt.n;
             HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));

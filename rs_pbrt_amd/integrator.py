@@ -125,3 +125,52 @@ class VolPathIntegrator(PathIntegrator):
         rd = super()._desc(shard)
         rd.integrator = abi.INTEGRATOR_VOLPATH
         return rd
+
+
+class Checkpoint:
+    """Checkpoint / resume around any of the integrators above ("film buffer + next-sample-index is the whole
+    state"; the reference's render loop is one-shot).  Renders the frame in slices of the per-pixel sample index through
+    rspt_render_desc.sample_begin / sample_count and keeps the running sum of the films, which IS the film of the samples done so
+    far (xyz and filter_weight_sum are sums over samples).  save() / load() carry the state across processes: a run that died at
+    sample k resumes at k; a multi-GPU driver re-renders a lost rank's shard the same way (tiles and sample ranges are idempotent).
+    Sobol' and Halton only: the pixel samplers chain all samples of a tile."""
+
+    def __init__(self, integrator, shard=None):
+        self.integrator, self.shard = integrator, shard
+        self.rd = integrator._desc(shard)
+        self.next_sample = 0
+        npix = (self.rd.crop_px[2] - self.rd.crop_px[0]) * (self.rd.crop_px[3] - self.rd.crop_px[1])
+        self.sum = np.zeros((npix, 4), np.float64)   # accumulate wider than the slices so that many small slices do not drift
+
+    @property
+    def done(self):
+        return self.next_sample >= int(self.rd.spp)
+
+    def step(self, dscene, n_samples):
+        """render the next n_samples samples of every pixel (fewer at the end); returns how many were rendered"""
+        n = min(int(n_samples), int(self.rd.spp) - self.next_sample)
+        if n <= 0:
+            return 0
+        rd = abi.RenderDesc.from_buffer_copy(self.rd)
+        rd.sample_begin, rd.sample_count = self.next_sample, n
+        pixels, self.integrator.stats = lib.render(dscene, rd)
+        self.sum += pixels
+        self.next_sample += n
+        return n
+
+    def film(self):
+        f = Film(self.rd)
+        h, w = f.shape
+        f.pixels = self.sum.astype(np.float32).reshape(h, w, 4)
+        return f
+
+    def save(self, path):
+        np.savez(path, sum=self.sum, next_sample=self.next_sample, spp=int(self.rd.spp), crop=np.array(self.rd.crop_px[:], np.int32),
+                 shard=np.array([self.rd.shard_index, self.rd.shard_count, self.rd.tile_chunk], np.uint32))
+
+    def load(self, path):
+        z = np.load(path)
+        if int(z["spp"]) != int(self.rd.spp) or list(z["crop"]) != list(self.rd.crop_px[:]) or z["sum"].shape != self.sum.shape or \
+                list(z["shard"]) != [self.rd.shard_index, self.rd.shard_count, self.rd.tile_chunk]:
+            raise ValueError("checkpoint belongs to another frame (spp / crop window / shard differ)")
+        self.sum, self.next_sample = z["sum"].astype(np.float64), int(z["next_sample"])

@@ -932,7 +932,7 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
                      crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
                      focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
                      sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True, direct_strategy="all", light_samples=None,
-                     dimensions=4, strat=(4, 4), jitter=True):
+                     dimensions=4, strat=(4, 4), jitter=True, sample_range=None):
     rd = abi.RenderDesc()
     # Integrator "path" (path.rs), "ao" / "ambientocclusion" (api.rs:411; ao.rs: nsamples 64, cossample true) or
     # "directlighting" (api.rs:322-349: strategy "all" | "one", maxdepth 5; light_samples = Light::get_n_samples per light)
@@ -999,6 +999,8 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
         while s < spp:
             s *= 2  # sobol.rs:38-45 rounds up to a power of two
         rd.spp = s
+    if sample_range is not None:   # checkpoint / resume: (first sample, number of samples) of every pixel; films of disjoint ranges add up
+        rd.sample_begin, rd.sample_count = int(sample_range[0]), int(sample_range[1])
     rd.max_depth, rd.rr_threshold, rd.light_strategy, rd.tile_size = max_depth, rr_threshold, light_strategy, 16
     rd.shard_index, rd.shard_count, rd.tile_chunk = shard
     n_halton_dims = 5 + 8 * (max_depth + 3)

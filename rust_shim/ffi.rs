@@ -1,10 +1,10 @@
-//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 15) one to one.
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 16) one to one.
 //! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
 //! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RSPT_ABI_VERSION: c_int = 15;
+pub const RSPT_ABI_VERSION: c_int = 16;
 pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
 pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
 
@@ -59,6 +59,7 @@ pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_wor
     pub tables: RsptSamplerTables,
     pub direct_strategy: u32, pub pixel_dimensions: u32, pub n_light_samples: *const i32,
     pub strat_x: u32, pub strat_y: u32, pub strat_jitter: u32, pub pad3: u32, pub maxmin_c_pixel: *const u32,   // pixel samplers
+    pub sample_begin: u64, pub sample_count: u64,   // checkpoint / resume: 0, 0 = the whole frame
 }
 #[repr(C)] #[derive(Default)]
 pub struct RsptStats {

@@ -284,6 +284,7 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
                                     halton_perms: RADICAL_INVERSE_PERMUTATIONS.as_ptr(), n_halton_perms: RADICAL_INVERSE_PERMUTATIONS.len() as u64 },
         direct_strategy: 0, pixel_dimensions: pix_dims, n_light_samples: std::ptr::null(),
         strat_x: sx, strat_y: sy, strat_jitter: jit, pad3: 0, maxmin_c_pixel: if sampler_kind == 6 { c_pixel.as_ptr() } else { std::ptr::null() },
+        sample_begin: 0, sample_count: 0,
     };
     let sd = RsptSceneDesc {
         nodes: f.nodes.as_ptr(), n_nodes: f.nodes.len() as u64, prims: f.prims.as_ptr(), n_prims: f.prims.len() as u64,

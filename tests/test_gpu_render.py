@@ -435,6 +435,54 @@ def test_random_scenes_fuzz(gpu, oracle, seed):
     assert film_rmse(film, ref["film"]) < 3e-4
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(sampler="halton"), dict(integrator="volpath"), dict(integrator="ao", ao_samples=4), dict(integrator="directlighting")])
+def test_sample_ranges_add_up_to_the_frame(gpu, oracle, kw):
+    """checkpoint / resume (rspt_render_desc.sample_begin / sample_count): films of disjoint sample ranges sum to the full
+    film — weights exactly, radiance up to the order of the additions — and each partial film is the oracle's for that range"""
+    sc = scenes.cornell_box(gpu.bvh_build, variant="matte" if kw.get("integrator") == "directlighting" else "mixed", fog=scenes.CORNELL_FOG if kw.get("integrator") == "volpath" else None)
+    full_rd = scenes.cornell_render_desc(res=48, spp=12 if kw.get("sampler") == "halton" else 16, **kw)
+    spp = int(full_rd.spp)
+    with gpu.DeviceScene(sc) as ds:
+        full, st = gpu.render(ds, full_rd)
+        total = np.zeros_like(full)
+        n = 0
+        for begin, count in ((0, 5), (5, 1), (6, spp - 6)):
+            rd = scenes.cornell_render_desc(res=48, spp=spp, sample_range=(begin, count), **kw)
+            part, pst = gpu.render(ds, rd)
+            ref = oracle.render(sc, rd, threads=8) if kw.get("integrator") != "directlighting" else oracle.render_integrator(sc, rd, "direct", threads=8)
+            assert np.array_equal(part[:, 3], ref["film"][:, 3]) and film_rmse(part, ref["film"]) < (1e-5 if count > 1 else 1e-4)
+            total += part
+            n += pst["samples"]
+        from rs_pbrt_amd.lib import RsptError
+        with pytest.raises(RsptError):
+            gpu.render(ds, scenes.cornell_render_desc(res=48, spp=spp, sample_range=(spp - 2, 3), **kw))
+    assert n == st["samples"] and np.array_equal(total[:, 3], full[:, 3])
+    assert np.allclose(total[:, :3], full[:, :3], rtol=2e-6, atol=1e-6)
+
+
+def test_checkpoint_resume(gpu, tmp_path):
+    """integrator.Checkpoint: a render interrupted after 5 of 16 samples, saved, and finished by a fresh object equals the one-shot
+    frame; a checkpoint of another frame is refused"""
+    from rs_pbrt_amd import integrator
+    sc = scenes.cornell_box(gpu.bvh_build, variant="rough")
+    pi = integrator.PathIntegrator(camera=scenes.cornell_render_desc(res=48, spp=16))
+    with gpu.DeviceScene(sc) as ds:
+        whole = pi.render(ds).pixels.reshape(-1, 4)
+        a = integrator.Checkpoint(pi)
+        assert a.step(ds, 5) == 5 and not a.done
+        a.save(tmp_path / "ckpt.npz")
+        b = integrator.Checkpoint(integrator.PathIntegrator(camera=scenes.cornell_render_desc(res=48, spp=16)))
+        b.load(tmp_path / "ckpt.npz")
+        assert b.next_sample == 5
+        while not b.done:
+            b.step(ds, 4)
+        got = b.film().pixels.reshape(-1, 4)
+        other = integrator.Checkpoint(integrator.PathIntegrator(camera=scenes.cornell_render_desc(res=48, spp=32)))
+        with pytest.raises(ValueError):
+            other.load(tmp_path / "ckpt.npz")
+    assert np.array_equal(got[:, 3], whole[:, 3]) and np.allclose(got[:, :3], whole[:, :3], rtol=2e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("strategy", [abi.LIGHTS_SPATIAL, abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM])
 def test_many_area_lights(gpu, oracle, strategy):
     """the C4 axis "many lights" (SURVEY 8d): 98 emissive triangles of different power; light selection through the
