@@ -188,7 +188,7 @@ struct TraceResult {
 // the walk returns to the remaining primitives of the leaf.  Quirks Q10 / Q11 are reproduced unless
 // sc.inst_fixed: an identity instance shrinks t_max without reporting its hit, and its interaction survives only if some
 // other primitive of the top-level aggregate reports a hit (`hit` below is BVHAccel::intersect's flag, `res` its isect).
-template <bool ANY, bool INST, bool ALPHA>
+template <bool ANY, bool INST, bool ALPHA, int STRIDE = RSPT_TRACE_BLOCK /* words between two levels of the LDS stack = columns (threads per block) */>
 RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */) {
     TraceResult res;
     res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0;
@@ -247,7 +247,7 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
             }
             if (sp == 0) break;
             sp--;
-            cur = sp < RSPT_LDS_STACK ? lds_stack[sp * RSPT_TRACE_BLOCK] : spill[sp - RSPT_LDS_STACK];
+            cur = sp < RSPT_LDS_STACK ? lds_stack[sp * STRIDE] : spill[sp - RSPT_LDS_STACK];
         }
         float4 n0 = sc.nodes[2 * (size_t)cur], n1 = sc.nodes[2 * (size_t)cur + 1];
         res.nodes++;
@@ -263,7 +263,7 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
                 bool neg = axis == 0 ? ng0 : (axis == 1 ? ng1 : ng2);
                 uint32_t far_child = neg ? here + 1 : offset;
                 cur = neg ? offset : here + 1;
-                if (sp < RSPT_LDS_STACK) lds_stack[sp * RSPT_TRACE_BLOCK] = far_child;
+                if (sp < RSPT_LDS_STACK) lds_stack[sp * STRIDE] = far_child;
                 else spill[sp - RSPT_LDS_STACK] = far_child;
                 sp++;
             }

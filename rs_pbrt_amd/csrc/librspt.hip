@@ -843,26 +843,38 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                                        g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits);
                     ev_close(2, 0);
                     // VisibilityTester::tr: segments until every shadow ray has arrived or is blocked
+                    // (the first two segments are launched without looking at the queue: most shadow rays cross at most one boundary, an
+                    //  empty launch costs microseconds, a look costs a stream synchronisation; the look that follows also brings the
+                    //  next pass's path count)
+                    QueueCounts look[4];
+                    bool have_live = false;
                     for (uint32_t seg = 0;; seg++) {
                         QueueCounts* tc = &g.cnt[2 + (seg & 1u)];
                         QueueCounts* tn = &g.cnt[2 + ((seg + 1u) & 1u)];
-                        QueueCounts c;
-                        HIP_TRY(hipMemcpyAsync(&c, tc, sizeof c, hipMemcpyDeviceToHost, g.stream));
-                        HIP_TRY(hipStreamSynchronize(g.stream));
-                        if (c.closest == 0) break;
+                        QueueCounts c{};
+                        c.closest = live;   // upper bound while not looking (every live path has at most one shadow ray)
+                        const bool looked = seg >= 2 || counters;   // (the counting pass wants every queue length)
+                        if (looked) {
+                            HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
+                            HIP_TRY(hipStreamSynchronize(g.stream));
+                            c = look[2 + (seg & 1u)];
+                            have_live = true;
+                            if (c.closest == 0) break;
+                        }
                         if (seg > null_passes) { truncated += c.closest; break; }
                         HIP_TRY(hipMemsetAsync(tn, 0, sizeof(QueueCounts), g.stream));
                         ev_open(1, 0);
                         launch_trace<false, 0>(0, counters, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
                         ev_close(1, 0);
                         trace_launches++;
-                        vol_rays += c.closest;
+                        if (looked) vol_rays += c.closest;
                         hipLaunchKernelGGL(k_vol_tr, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
                     }
-                    QueueCounts c;
-                    HIP_TRY(hipMemcpyAsync(&c, nxt, sizeof c, hipMemcpyDeviceToHost, g.stream));
-                    HIP_TRY(hipStreamSynchronize(g.stream));
-                    live = c.closest;
+                    if (!have_live) {
+                        HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
+                        HIP_TRY(hipStreamSynchronize(g.stream));
+                    }
+                    live = look[par ^ 1].closest;
                     if (live && pass >= nominal_iters + null_passes) { truncated += live; break; }
                 }
                 it = 4;

@@ -31,7 +31,7 @@ template <bool INST, bool ALPHA>
 __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
                                                     uint32_t n_tiles, uint32_t lanes_per_wave, int32_t row0, int32_t row1, float4* __restrict__ samp_L,
                                                     float2* __restrict__ samp_pf, uint32_t max_iters, uint32_t* __restrict__ truncated) {
-    __shared__ uint32_t stack[RSPT_LDS_STACK * RSPT_TRACE_BLOCK];
+    __shared__ uint32_t stack[RSPT_LDS_STACK * 64];   // 32 levels x the block's 64 columns
     if (threadIdx.x >= lanes_per_wave) return;
     const uint32_t t = blockIdx.x * lanes_per_wave + threadIdx.x;
     if (t >= n_tiles) return;
@@ -68,20 +68,20 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                     if (so.cont) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = traverse<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = traverse<false, INST, ALPHA, 64>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
                         pb.hit_cont[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
                         if (INST && pb.hit_inst) pb.hit_inst[slot] = res.inst;
                     }
                     if (so.mis) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_mis + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = traverse<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = traverse<false, INST, ALPHA, 64>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
                         pb.hit_mis[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
                     }
                     if (so.shadow) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_sh + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = traverse<true, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = traverse<true, INST, ALPHA, 64>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
                         pb.occluded[slot] = res.prim != RSPT_MISS ? 1u : 0u;
                     }
                     if (sc.mat_flags && so.cont) texture_path(sc, tt, rd, pb, slot, &p_lens);   // the texture stage k_texture runs in front of k_shade
