@@ -739,7 +739,250 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     auto ev_close = [&](int kind, int lane) { (void)hipEventRecord(kev[kind].back().second, lane ? g.stream2 : g.stream); };
     HIP_TRY(hipEventRecord(ev_k0, g.stream));
     uint64_t samples = 0, truncated = 0, vol_rays = 0;
-    if (pixel_sampler) {
+    // ---- one batch of each integrator (the wavefront schedules); `it` leaves with the number of queue-counter records used ----
+    auto batch_volpath = [&](const Batch& bt, uint32_t& it) -> int {  // VolPathIntegrator::li (vol.h): the continuation queue doubles as the list of live paths
+        const uint32_t dgrid = grid_for(4);
+        const uint32_t null_passes = (uint32_t)env_size("RSPT_NULL_PASSES", 1024);
+        // LDS table: 10 dimensions per counted pass, 2 per pass through a medium boundary (room for 64 of those), 8 of read-ahead;
+        // a path that needs more is cut and counted (rspt_stats.truncated_paths); the reference's own limit is 1024
+        const uint32_t vnd = std::min(1024u, 5u + 10u * (d->max_depth + 2u) + 128u) + 8u;
+        if ((size_t)vnd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "volpath: max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
+        const uint32_t vlimit = halton ? vol_dim_limit : std::min(1024u, vnd - 8u);
+        hipLaunchKernelGGL(k_vol_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, g.vol, bt.n);
+        // counters: g.cnt[0 / 1] = the continuation queue of this / the next pass, g.cnt[2 / 3] = the shadow-ray segments
+        uint32_t live = bt.n;
+        for (uint32_t pass = 0; live > 0; pass++) {
+            const int par = pass & 1;
+            QueueCounts* cur = &g.cnt[par];
+            QueueCounts* nxt = &g.cnt[par ^ 1];
+            HIP_TRY(hipMemsetAsync(nxt, 0, sizeof(QueueCounts), g.stream));
+            HIP_TRY(hipMemsetAsync(&g.cnt[2], 0, sizeof(QueueCounts), g.stream));
+            ev_open(0, 0);
+            launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &cur->closest, 0, &cur->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+            ev_close(0, 0);
+            trace_launches++;
+            vol_rays += live;
+            ev_open(2, 0);
+            if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][1], &cur->closest);
+            hipLaunchKernelGGL(k_vol_shade, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest,
+                               g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits);
+            ev_close(2, 0);
+            // VisibilityTester::tr: segments until every shadow ray has arrived or is blocked
+            // (the first two segments are launched without looking at the queue: most shadow rays cross at most one boundary, an
+            //  empty launch costs microseconds, a look costs a stream synchronisation; the look that follows also brings the
+            //  next pass's path count)
+            QueueCounts look[4];
+            bool have_live = false;
+            for (uint32_t seg = 0;; seg++) {
+                QueueCounts* tc = &g.cnt[2 + (seg & 1u)];
+                QueueCounts* tn = &g.cnt[2 + ((seg + 1u) & 1u)];
+                QueueCounts c{};
+                c.closest = live;   // upper bound while not looking (every live path has at most one shadow ray)
+                const bool looked = seg >= 2 || counters;   // (the counting pass wants every queue length)
+                if (looked) {
+                    HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
+                    HIP_TRY(hipStreamSynchronize(g.stream));
+                    c = look[2 + (seg & 1u)];
+                    have_live = true;
+                    if (c.closest == 0) break;
+                }
+                if (seg > null_passes) { truncated += c.closest; break; }
+                HIP_TRY(hipMemsetAsync(tn, 0, sizeof(QueueCounts), g.stream));
+                ev_open(1, 0);
+                launch_trace<false, 0>(0, counters, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                ev_close(1, 0);
+                trace_launches++;
+                if (looked) vol_rays += c.closest;
+                hipLaunchKernelGGL(k_vol_tr, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
+            }
+            if (!have_live) {
+                HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+            }
+            live = look[par ^ 1].closest;
+            if (live && pass >= nominal_iters + null_passes) { truncated += live; break; }
+        }
+        it = 4;
+        return RSPT_OK;
+    };
+    auto batch_direct = [&](const Batch& bt, uint32_t& it) -> int {  // DirectLightingIntegrator::li (direct.h): specular tree, dimension assignment, light rounds, gather
+        const uint32_t nl = s->dev.n_lights, H = dl_H, md = d->max_depth;
+        const bool all = d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL;
+        const uint32_t n_arrays = all ? 2u * md * nl : 0u;
+        if (5ull + 2ull * n_arrays + ((1ull << md) - 1ull) * (4ull * nl + 4ull) + 2ull >= 1000ull)  // the reference panics past NUM_SOBOL_DIMENSIONS / the prime table
+            return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays + the dimension stream of a full specular tree exceed the sampler's dimensions", n_arrays);
+        DlBuf dl = g.dl;
+        dl.H = H;
+        const size_t n_slots = (size_t)bt.n * H;
+        HIP_TRY(hipMemsetAsync(dl.le_kind, 0, n_slots * sizeof(float4), g.stream));
+        HIP_TRY(hipMemsetAsync(dl.l_all, 0, n_slots * sizeof(float4), g.stream));
+        HIP_TRY(hipMemsetAsync(dl.ld_acc, 0, n_slots * sizeof(float4), g.stream));
+        HIP_TRY(hipMemsetAsync(dl.error, 0, sizeof(uint32_t), g.stream));
+        // the camera rays were left in ray_cont[sample]; node slots overlay that array, so move them aside first
+        HIP_TRY(hipMemcpyAsync(g.pb.ray_sh, g.pb.ray_cont, (size_t)bt.n * sizeof(rspt_ray), hipMemcpyDeviceToDevice, g.stream));
+        // counters: g.cnt[level].closest = nodes of the level, .any = re-trace queue; rounds use g.cnt[md + 1 ..]
+        auto level_q = [&](uint32_t l) { return g.dl_queue + (size_t)bt.n * ((1u << l) - 1u); };
+        hipLaunchKernelGGL(k_dl_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, dl, g.pb.ray_sh, level_q(0), &g.cnt[0].closest);
+        const uint32_t dgrid = grid_for(4);
+        for (uint32_t l = 0; l < md; l++) {
+            const uint32_t* queue = level_q(l);
+            const uint32_t* qcount = &g.cnt[l].closest;
+            for (uint32_t round = 0;; round++) {
+                QueueCounts* rc_ = &g.cnt[md + 1 + (round & 1u)];  // re-trace queue of this round (null-BSDF hits), double buffered
+                HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
+                HIP_TRY(hipMemsetAsync((void*)&g.cnt[l].cursor_closest, 0, 3 * sizeof(uint32_t), g.stream));
+                ev_open(0, 0);
+                launch_trace<false, 0>(0, false, tgrid, s, queue, qcount, 0, round == 0 ? &g.cnt[l].cursor_closest : &g.cnt[md + 1 + ((round - 1) & 1u)].cursor_closest,
+                                       g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                ev_close(0, 0);
+                trace_launches++;
+                ev_open(2, 0);
+                hipLaunchKernelGGL(k_dl_hit, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, g.pb, dl, queue, qcount, g.q[round & 1u][0], &rc_->closest,
+                                   level_q(l + 1 < md ? l + 1 : l), &g.cnt[l + 1].closest, l);
+                ev_close(2, 0);
+                if (!s->has_null_material) break;
+                QueueCounts c;
+                HIP_TRY(hipMemcpyAsync(&c, rc_, sizeof c, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                if (c.closest == 0) break;
+                if (round >= env_size("RSPT_NULL_PASSES", 1024)) { truncated += c.closest; break; }
+                queue = g.q[round & 1u][0];
+                qcount = &rc_->closest;
+            }
+        }
+        hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md);
+        if (nl) {
+            QueueCounts* rc_ = &g.cnt[md + 3];
+            for (uint32_t l = 0; l < md; l++) {
+                const uint32_t n_lights_round = all ? nl : 1u;
+                for (uint32_t j = 0; j < n_lights_round; j++) {
+                    const uint32_t n_j = all ? (uint32_t)(d->n_light_samples ? d->n_light_samples[j] : 1) : 1u;
+                    for (uint32_t kk = 0; kk < n_j; kk++) {
+                        HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
+                        ev_open(2, 0);
+                        hipLaunchKernelGGL(k_dl_nee, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, j, kk, n_j,
+                                           n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest);
+                        ev_close(2, 0);
+                        ev_open(1, 0);
+                        launch_trace<true, 0>(0, false, tgrid, s, g.q[0][2], &rc_->any, 0, &rc_->cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                        ev_close(1, 0);
+                        ev_open(0, 0);
+                        launch_trace<false, 0>(0, false, tgrid, s, g.q[0][1], &rc_->closest, 0, &rc_->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                        ev_close(0, 0);
+                        trace_launches += 2;
+                        hipLaunchKernelGGL(k_dl_nee_resolve, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, dl, level_q(l), &g.cnt[l].closest, j, kk, n_j, n_arrays, all ? 1u : 0u);
+                    }
+                }
+            }
+        }
+        hipLaunchKernelGGL(k_dl_gather, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, dl, nl, md);
+        uint32_t dl_err = 0;
+        HIP_TRY(hipMemcpyAsync(&dl_err, dl.error, sizeof dl_err, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (dl_err) return fail(RSPT_E_UNSUPPORTED, "directlighting: a material with several specular lobes of one kind (the lobe choice would depend on a sample value)");
+        it = md + 4;
+        return RSPT_OK;
+    };
+    auto batch_ao = [&](const Batch& bt, uint32_t& it) -> int {  // AOIntegrator::li: closest hit, n shadow rays per hit, sum of the unoccluded terms
+        hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++), e2 = get_event(n_ev++), e3 = get_event(n_ev++);
+        HIP_TRY(hipEventRecord(e0, g.stream));
+        ev_open(0, 0);
+        launch_trace<false, 0>(0, counters, tgrid, s, g.q[0][1], &g.cnt[0].closest, 0, &g.cnt[0].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+        ev_close(0, 0);
+        HIP_TRY(hipEventRecord(e1, g.stream));
+        hipLaunchKernelGGL(k_ao_spawn, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, g.pix_list, ao_n, d->ao_cos_sample, g.q[0][2], &g.cnt[1]);
+        HIP_TRY(hipEventRecord(e2, g.stream));
+        ev_open(1, 0);
+        launch_trace<true, 0>(0, counters, tgrid, s, g.q[0][2], &g.cnt[1].any, 0, &g.cnt[1].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+        ev_close(1, 0);
+        HIP_TRY(hipEventRecord(e3, g.stream));
+        trace_ev.push_back({e0, e1}); trace_ev.push_back({e2, e3});
+        trace_launches += 2;
+        hipLaunchKernelGGL(k_ao_resolve, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, ao_n);
+        it = 2;
+        return RSPT_OK;
+    };
+    auto batch_path = [&](const Batch& bt, uint32_t& it) -> int {  // PathIntegrator::li: trace (closest || any) -> [light voxels] -> [bins] -> [textures] -> shade, per bounce
+        for (;;) {
+            const int par = it & 1;
+            hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);
+            HIP_TRY(hipEventRecord(e0, g.stream));
+            // the shadow-ray launch does not depend on the closest-hit launch: on a second stream its tail (a few
+            // long rays on an otherwise idle chip) overlaps the other launch
+            const int any_lane = (it > 0 && two_streams) ? 1 : 0;
+            if (any_lane) {
+                HIP_TRY(hipEventRecord(ev_fork, g.stream));
+                HIP_TRY(hipStreamWaitEvent(g.stream2, ev_fork, 0));
+                ev_open(1, 1);
+                launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                ev_close(1, 1);
+                HIP_TRY(hipEventRecord(ev_join, g.stream2));
+            }
+            ev_open(0, 0);
+            launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+            ev_close(0, 0);
+            if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
+            else if (it > 0) {
+                ev_open(1, 0);
+                launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                ev_close(1, 0);
+            }
+            HIP_TRY(hipEventRecord(e1, g.stream));
+            trace_ev.push_back({e0, e1});
+            trace_launches += it > 0 ? 2 : 1;
+            ev_open(2, 0);
+            if (shade_bins) {  // K7b: whole waves of one class for k_shade
+                const uint32_t bgrid = hinted_grid(grid_for(4), 256);
+                hipLaunchKernelGGL(k_bin_count, dim3(bgrid), dim3(256), 0, g.stream, s->dev, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it]);
+                hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, g.stream, &g.bin_info[it], g.q_sorted);
+                hipLaunchKernelGGL(k_bin_scatter, dim3(bgrid), dim3(256), 0, g.stream, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it], g.q_sorted);
+            }
+            if (ld_lazy && d->integrator == RSPT_INTEGRATOR_PATH) {
+                const uint32_t lgrid = hinted_grid(grid_for(4), 256);
+                hipLaunchKernelGGL(k_ld_mark, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], ld_lazy->lazy, ld_lazy->new_list);
+                hipLaunchKernelGGL(k_ld_contrib_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld.nvox[0], ld.nvox[1], ld.nvox[2], ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func);
+                hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
+                hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
+            }
+            if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active);
+            hipLaunchKernelGGL(k_shade, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
+                               g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
+                               shade_bins ? g.q_sorted : (const uint32_t*)nullptr, shade_bins ? &g.bin_info[it] : (const BinInfo*)nullptr);
+            ev_close(2, 0);
+            it++;
+            if (it < nominal_iters) continue;
+            // after max_depth + 1 bounces only pending estimates and null-material passes remain
+            if (max_iters == nominal_iters) break;
+            if (((it - nominal_iters) & 7u) != 0 && it < max_iters) continue;  // look at the queue length every 8th iteration: an empty iteration costs three idle launches, a look costs a stream sync
+            QueueCounts c;
+            HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            if (c.active == 0 && c.active_tail == 0) break;
+            g_queue_hint = c.active + c.active_tail;
+            if (it >= max_iters) {  // the reference's loop would still be running (path.rs:109-116 has no limit); these paths keep the radiance gathered so far
+                truncated += c.active + c.active_tail;
+                if (getenv("RSPT_VERBOSE") && c.active) {  // where the endless paths are: slot, film position and the ray in flight
+                    uint32_t slots[4];
+                    const uint32_t k = std::min(c.active, 4u);
+                    HIP_TRY(hipMemcpy(slots, g.q[it & 1][0], k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                    for (uint32_t j = 0; j < k; j++) {
+                        rspt_ray r; float2 pf; float4 hc;
+                        HIP_TRY(hipMemcpy(&r, g.pb.ray_cont + slots[j], sizeof r, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(&pf, g.pb.p_film + slots[j], sizeof pf, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(&hc, g.pb.hit_cont + slots[j], sizeof hc, hipMemcpyDeviceToHost));
+                        uint32_t o[3], dd[3], pr;
+                        memcpy(o, r.o, 12); memcpy(dd, r.d, 12); memcpy(&pr, &hc.x, 4);
+                        fprintf(stderr, "rspt: endless null-surface path: slot %u film (%.3f, %.3f) ray o %08x %08x %08x d %08x %08x %08x last prim %u\n",
+                                slots[j], pf.x, pf.y, o[0], o[1], o[2], dd[0], dd[1], dd[2], pr);
+                    }
+                }
+                break;
+            }
+        }
+        return RSPT_OK;
+    };
+    auto run_tile_serial = [&]() -> int {  // the pixel samplers: one lane per tile (tile_serial.h)
+
         // ---- one lane per tile (tile_serial.h) ----
         std::vector<TileRec> tiles;
         for (size_t i = 0; i < blocks.size(); i++) {
@@ -803,7 +1046,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         HIP_TRY(hipMemcpyAsync(&tv, trunc_d, sizeof tv, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         truncated += tv;
-    }
+        return RSPT_OK;
+    };
+    if (pixel_sampler && (rc = run_tile_serial())) return rc;
     for (size_t p0 = 0; !pixel_sampler && p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
         for (uint32_t s0 = (uint32_t)smp_begin; s0 < (uint32_t)smp_end; s0 += ns) {
@@ -815,241 +1060,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
             g_queue_hint = 0xffffffffu;
-            if (volpath) {  // VolPathIntegrator::li (vol.h): the continuation queue doubles as the list of live paths
-                const uint32_t dgrid = grid_for(4);
-                const uint32_t null_passes = (uint32_t)env_size("RSPT_NULL_PASSES", 1024);
-                // LDS table: 10 dimensions per counted pass, 2 per pass through a medium boundary (room for 64 of those), 8 of read-ahead;
-                // a path that needs more is cut and counted (rspt_stats.truncated_paths); the reference's own limit is 1024
-                const uint32_t vnd = std::min(1024u, 5u + 10u * (d->max_depth + 2u) + 128u) + 8u;
-                if ((size_t)vnd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "volpath: max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
-                const uint32_t vlimit = halton ? vol_dim_limit : std::min(1024u, vnd - 8u);
-                hipLaunchKernelGGL(k_vol_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, g.vol, bt.n);
-                // counters: g.cnt[0 / 1] = the continuation queue of this / the next pass, g.cnt[2 / 3] = the shadow-ray segments
-                uint32_t live = bt.n;
-                for (uint32_t pass = 0; live > 0; pass++) {
-                    const int par = pass & 1;
-                    QueueCounts* cur = &g.cnt[par];
-                    QueueCounts* nxt = &g.cnt[par ^ 1];
-                    HIP_TRY(hipMemsetAsync(nxt, 0, sizeof(QueueCounts), g.stream));
-                    HIP_TRY(hipMemsetAsync(&g.cnt[2], 0, sizeof(QueueCounts), g.stream));
-                    ev_open(0, 0);
-                    launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &cur->closest, 0, &cur->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                    ev_close(0, 0);
-                    trace_launches++;
-                    vol_rays += live;
-                    ev_open(2, 0);
-                    if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][1], &cur->closest);
-                    hipLaunchKernelGGL(k_vol_shade, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest,
-                                       g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits);
-                    ev_close(2, 0);
-                    // VisibilityTester::tr: segments until every shadow ray has arrived or is blocked
-                    // (the first two segments are launched without looking at the queue: most shadow rays cross at most one boundary, an
-                    //  empty launch costs microseconds, a look costs a stream synchronisation; the look that follows also brings the
-                    //  next pass's path count)
-                    QueueCounts look[4];
-                    bool have_live = false;
-                    for (uint32_t seg = 0;; seg++) {
-                        QueueCounts* tc = &g.cnt[2 + (seg & 1u)];
-                        QueueCounts* tn = &g.cnt[2 + ((seg + 1u) & 1u)];
-                        QueueCounts c{};
-                        c.closest = live;   // upper bound while not looking (every live path has at most one shadow ray)
-                        const bool looked = seg >= 2 || counters;   // (the counting pass wants every queue length)
-                        if (looked) {
-                            HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
-                            HIP_TRY(hipStreamSynchronize(g.stream));
-                            c = look[2 + (seg & 1u)];
-                            have_live = true;
-                            if (c.closest == 0) break;
-                        }
-                        if (seg > null_passes) { truncated += c.closest; break; }
-                        HIP_TRY(hipMemsetAsync(tn, 0, sizeof(QueueCounts), g.stream));
-                        ev_open(1, 0);
-                        launch_trace<false, 0>(0, counters, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                        ev_close(1, 0);
-                        trace_launches++;
-                        if (looked) vol_rays += c.closest;
-                        hipLaunchKernelGGL(k_vol_tr, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
-                    }
-                    if (!have_live) {
-                        HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
-                        HIP_TRY(hipStreamSynchronize(g.stream));
-                    }
-                    live = look[par ^ 1].closest;
-                    if (live && pass >= nominal_iters + null_passes) { truncated += live; break; }
-                }
-                it = 4;
-            } else
-            if (direct) {  // DirectLightingIntegrator::li (direct.h): specular tree, dimension assignment, light rounds, gather
-                const uint32_t nl = s->dev.n_lights, H = dl_H, md = d->max_depth;
-                const bool all = d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL;
-                const uint32_t n_arrays = all ? 2u * md * nl : 0u;
-                if (5ull + 2ull * n_arrays + ((1ull << md) - 1ull) * (4ull * nl + 4ull) + 2ull >= 1000ull)  // the reference panics past NUM_SOBOL_DIMENSIONS / the prime table
-                    return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays + the dimension stream of a full specular tree exceed the sampler's dimensions", n_arrays);
-                DlBuf dl = g.dl;
-                dl.H = H;
-                const size_t n_slots = (size_t)bt.n * H;
-                HIP_TRY(hipMemsetAsync(dl.le_kind, 0, n_slots * sizeof(float4), g.stream));
-                HIP_TRY(hipMemsetAsync(dl.l_all, 0, n_slots * sizeof(float4), g.stream));
-                HIP_TRY(hipMemsetAsync(dl.ld_acc, 0, n_slots * sizeof(float4), g.stream));
-                HIP_TRY(hipMemsetAsync(dl.error, 0, sizeof(uint32_t), g.stream));
-                // the camera rays were left in ray_cont[sample]; node slots overlay that array, so move them aside first
-                HIP_TRY(hipMemcpyAsync(g.pb.ray_sh, g.pb.ray_cont, (size_t)bt.n * sizeof(rspt_ray), hipMemcpyDeviceToDevice, g.stream));
-                // counters: g.cnt[level].closest = nodes of the level, .any = re-trace queue; rounds use g.cnt[md + 1 ..]
-                auto level_q = [&](uint32_t l) { return g.dl_queue + (size_t)bt.n * ((1u << l) - 1u); };
-                hipLaunchKernelGGL(k_dl_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, dl, g.pb.ray_sh, level_q(0), &g.cnt[0].closest);
-                const uint32_t dgrid = grid_for(4);
-                for (uint32_t l = 0; l < md; l++) {
-                    const uint32_t* queue = level_q(l);
-                    const uint32_t* qcount = &g.cnt[l].closest;
-                    for (uint32_t round = 0;; round++) {
-                        QueueCounts* rc_ = &g.cnt[md + 1 + (round & 1u)];  // re-trace queue of this round (null-BSDF hits), double buffered
-                        HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
-                        HIP_TRY(hipMemsetAsync((void*)&g.cnt[l].cursor_closest, 0, 3 * sizeof(uint32_t), g.stream));
-                        ev_open(0, 0);
-                        launch_trace<false, 0>(0, false, tgrid, s, queue, qcount, 0, round == 0 ? &g.cnt[l].cursor_closest : &g.cnt[md + 1 + ((round - 1) & 1u)].cursor_closest,
-                                               g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                        ev_close(0, 0);
-                        trace_launches++;
-                        ev_open(2, 0);
-                        hipLaunchKernelGGL(k_dl_hit, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, g.pb, dl, queue, qcount, g.q[round & 1u][0], &rc_->closest,
-                                           level_q(l + 1 < md ? l + 1 : l), &g.cnt[l + 1].closest, l);
-                        ev_close(2, 0);
-                        if (!s->has_null_material) break;
-                        QueueCounts c;
-                        HIP_TRY(hipMemcpyAsync(&c, rc_, sizeof c, hipMemcpyDeviceToHost, g.stream));
-                        HIP_TRY(hipStreamSynchronize(g.stream));
-                        if (c.closest == 0) break;
-                        if (round >= env_size("RSPT_NULL_PASSES", 1024)) { truncated += c.closest; break; }
-                        queue = g.q[round & 1u][0];
-                        qcount = &rc_->closest;
-                    }
-                }
-                hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md);
-                if (nl) {
-                    QueueCounts* rc_ = &g.cnt[md + 3];
-                    for (uint32_t l = 0; l < md; l++) {
-                        const uint32_t n_lights_round = all ? nl : 1u;
-                        for (uint32_t j = 0; j < n_lights_round; j++) {
-                            const uint32_t n_j = all ? (uint32_t)(d->n_light_samples ? d->n_light_samples[j] : 1) : 1u;
-                            for (uint32_t kk = 0; kk < n_j; kk++) {
-                                HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
-                                ev_open(2, 0);
-                                hipLaunchKernelGGL(k_dl_nee, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, j, kk, n_j,
-                                                   n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest);
-                                ev_close(2, 0);
-                                ev_open(1, 0);
-                                launch_trace<true, 0>(0, false, tgrid, s, g.q[0][2], &rc_->any, 0, &rc_->cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
-                                ev_close(1, 0);
-                                ev_open(0, 0);
-                                launch_trace<false, 0>(0, false, tgrid, s, g.q[0][1], &rc_->closest, 0, &rc_->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                                ev_close(0, 0);
-                                trace_launches += 2;
-                                hipLaunchKernelGGL(k_dl_nee_resolve, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, dl, level_q(l), &g.cnt[l].closest, j, kk, n_j, n_arrays, all ? 1u : 0u);
-                            }
-                        }
-                    }
-                }
-                hipLaunchKernelGGL(k_dl_gather, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, dl, nl, md);
-                uint32_t dl_err = 0;
-                HIP_TRY(hipMemcpyAsync(&dl_err, dl.error, sizeof dl_err, hipMemcpyDeviceToHost, g.stream));
-                HIP_TRY(hipStreamSynchronize(g.stream));
-                if (dl_err) return fail(RSPT_E_UNSUPPORTED, "directlighting: a material with several specular lobes of one kind (the lobe choice would depend on a sample value)");
-                it = md + 4;
-            } else
-            if (ao) {  // AOIntegrator::li: closest hit, n shadow rays per hit, sum of the unoccluded terms
-                hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++), e2 = get_event(n_ev++), e3 = get_event(n_ev++);
-                HIP_TRY(hipEventRecord(e0, g.stream));
-                ev_open(0, 0);
-                launch_trace<false, 0>(0, counters, tgrid, s, g.q[0][1], &g.cnt[0].closest, 0, &g.cnt[0].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                ev_close(0, 0);
-                HIP_TRY(hipEventRecord(e1, g.stream));
-                hipLaunchKernelGGL(k_ao_spawn, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, g.pix_list, ao_n, d->ao_cos_sample, g.q[0][2], &g.cnt[1]);
-                HIP_TRY(hipEventRecord(e2, g.stream));
-                ev_open(1, 0);
-                launch_trace<true, 0>(0, counters, tgrid, s, g.q[0][2], &g.cnt[1].any, 0, &g.cnt[1].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
-                ev_close(1, 0);
-                HIP_TRY(hipEventRecord(e3, g.stream));
-                trace_ev.push_back({e0, e1}); trace_ev.push_back({e2, e3});
-                trace_launches += 2;
-                hipLaunchKernelGGL(k_ao_resolve, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, ao_n);
-                it = 2;
-            } else
-            for (;;) {
-                const int par = it & 1;
-                hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);
-                HIP_TRY(hipEventRecord(e0, g.stream));
-                // the shadow-ray launch does not depend on the closest-hit launch: on a second stream its tail (a few
-                // long rays on an otherwise idle chip) overlaps the other launch
-                const int any_lane = (it > 0 && two_streams) ? 1 : 0;
-                if (any_lane) {
-                    HIP_TRY(hipEventRecord(ev_fork, g.stream));
-                    HIP_TRY(hipStreamWaitEvent(g.stream2, ev_fork, 0));
-                    ev_open(1, 1);
-                    launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
-                    ev_close(1, 1);
-                    HIP_TRY(hipEventRecord(ev_join, g.stream2));
-                }
-                ev_open(0, 0);
-                launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
-                ev_close(0, 0);
-                if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
-                else if (it > 0) {
-                    ev_open(1, 0);
-                    launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
-                    ev_close(1, 0);
-                }
-                HIP_TRY(hipEventRecord(e1, g.stream));
-                trace_ev.push_back({e0, e1});
-                trace_launches += it > 0 ? 2 : 1;
-                ev_open(2, 0);
-                if (shade_bins) {  // K7b: whole waves of one class for k_shade
-                    const uint32_t bgrid = hinted_grid(grid_for(4), 256);
-                    hipLaunchKernelGGL(k_bin_count, dim3(bgrid), dim3(256), 0, g.stream, s->dev, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it]);
-                    hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, g.stream, &g.bin_info[it], g.q_sorted);
-                    hipLaunchKernelGGL(k_bin_scatter, dim3(bgrid), dim3(256), 0, g.stream, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it], g.q_sorted);
-                }
-                if (ld_lazy && d->integrator == RSPT_INTEGRATOR_PATH) {
-                    const uint32_t lgrid = hinted_grid(grid_for(4), 256);
-                    hipLaunchKernelGGL(k_ld_mark, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], ld_lazy->lazy, ld_lazy->new_list);
-                    hipLaunchKernelGGL(k_ld_contrib_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld.nvox[0], ld.nvox[1], ld.nvox[2], ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func);
-                    hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
-                    hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
-                }
-                if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active);
-                hipLaunchKernelGGL(k_shade, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
-                                   g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
-                                   shade_bins ? g.q_sorted : (const uint32_t*)nullptr, shade_bins ? &g.bin_info[it] : (const BinInfo*)nullptr);
-                ev_close(2, 0);
-                it++;
-                if (it < nominal_iters) continue;
-                // after max_depth + 1 bounces only pending estimates and null-material passes remain
-                if (max_iters == nominal_iters) break;
-                if (((it - nominal_iters) & 7u) != 0 && it < max_iters) continue;  // look at the queue length every 8th iteration: an empty iteration costs three idle launches, a look costs a stream sync
-                QueueCounts c;
-                HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
-                HIP_TRY(hipStreamSynchronize(g.stream));
-                if (c.active == 0 && c.active_tail == 0) break;
-                g_queue_hint = c.active + c.active_tail;
-                if (it >= max_iters) {  // the reference's loop would still be running (path.rs:109-116 has no limit); these paths keep the radiance gathered so far
-                    truncated += c.active + c.active_tail;
-                    if (getenv("RSPT_VERBOSE") && c.active) {  // where the endless paths are: slot, film position and the ray in flight
-                        uint32_t slots[4];
-                        const uint32_t k = std::min(c.active, 4u);
-                        HIP_TRY(hipMemcpy(slots, g.q[it & 1][0], k * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                        for (uint32_t j = 0; j < k; j++) {
-                            rspt_ray r; float2 pf; float4 hc;
-                            HIP_TRY(hipMemcpy(&r, g.pb.ray_cont + slots[j], sizeof r, hipMemcpyDeviceToHost));
-                            HIP_TRY(hipMemcpy(&pf, g.pb.p_film + slots[j], sizeof pf, hipMemcpyDeviceToHost));
-                            HIP_TRY(hipMemcpy(&hc, g.pb.hit_cont + slots[j], sizeof hc, hipMemcpyDeviceToHost));
-                            uint32_t o[3], dd[3], pr;
-                            memcpy(o, r.o, 12); memcpy(dd, r.d, 12); memcpy(&pr, &hc.x, 4);
-                            fprintf(stderr, "rspt: endless null-surface path: slot %u film (%.3f, %.3f) ray o %08x %08x %08x d %08x %08x %08x last prim %u\n",
-                                    slots[j], pf.x, pf.y, o[0], o[1], o[2], dd[0], dd[1], dd[2], pr);
-                        }
-                    }
-                    break;
-                }
-            }
+            if (volpath) rc = batch_volpath(bt, it);
+            else if (direct) rc = batch_direct(bt, it);
+            else if (ao) rc = batch_ao(bt, it);
+            else rc = batch_path(bt, it);
+            if (rc) return rc;
             if (counters) hipLaunchKernelGGL(k_accum_counts, dim3(1), dim3(1), 0, g.stream, g.cnt, it, g.totals);
             hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
         }
