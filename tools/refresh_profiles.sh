@@ -35,5 +35,18 @@ if [ "$mode" = all ]; then
     timeout 300 python bench.py --workload $w --no-extra > $out/bench_$w.json 2> $out/bench_$w.err
   done
   timeout 200 python bench.py --workload cornell --integrator ao --spp 16 --no-extra > $out/bench_cornell_ao.json 2> $out/bench_cornell_ao.err
+  timeout 200 python bench.py --workload cornell --integrator directlighting --no-extra > $out/bench_cornell_directlighting.json 2> $out/bench_cornell_directlighting.err
+  timeout 200 python bench.py --workload cornell --integrator volpath --no-extra > $out/bench_cornell_volpath.json 2> $out/bench_cornell_volpath.err
+  timeout 300 python bench.py --workload cornell --sampler 02sequence --steps 2 --warmup 1 --no-extra > $out/bench_cornell_02sequence.json 2> $out/bench_cornell_02sequence.err
+  timeout 300 python bench.py --workload statue --sampler 02sequence --spp 16 --steps 1 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_02sequence.json 2> $out/bench_statue_02sequence.err
+  for m in fixed reference; do
+    timeout 300 python bench.py --workload c5 --instancing $m --steps 3 --warmup 1 --no-extra > $out/bench_c5_$m.json 2> $out/bench_c5_$m.err
+  done
+  for w in volpath 02sequence; do   # kernel stats of the two schedules that are not the wavefront path loop
+    if [ $w = volpath ]; then a="--integrator volpath"; else a="--sampler 02sequence --spp 8"; fi
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks_cornell_$w -- python $repo/bench.py --workload cornell $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $out/ks_cornell_$w.log 2>&1)
+    python tools/rocprof_summary.py $out/ks_cornell_$w $out/ks_cornell_$w.md "bench.py --workload cornell $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra" > /dev/null 2>&1
+    find $out/ks_cornell_$w -name "*.db" -size +8M -delete
+  done
 fi
 tail -c 600 $out/bench_soup1m.json
