@@ -124,3 +124,62 @@ def test_python_mirror_and_refusals(gpu):
     with pytest.raises(RsptError) as e:  # textured materials: not on the GPU for this integrator yet
         DirectLightingIntegrator(camera=scenes.make_render_desc(16, 16, 2, GALLERY_LOOK_AT, 60.0)).render(textured_room(gpu.bvh_build))
     assert e.value.code == abi.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("seed", list(range(501, 513)))
+def test_directlighting_random_scenes_fuzz(gpu, oracle, seed):
+    """random rooms restricted to what directlighting takes (constant textures, at most one specular lobe of a kind per material): slabs
+    of matte / Oren-Nayar / plastic / mirror / two-lobe glass / metal / substrate / null surfaces, an instanced object (either
+    behaviour), an alpha-masked quad, area + delta + sometimes infinite lights, both strategies with random per-light sample counts,
+    both samplers, depths 1-5"""
+    rng = np.random.default_rng(seed)
+    sb = scenes.SceneBuilder()
+    col = lambda lo=0.05, hi=0.9: tuple(float(x) for x in rng.uniform(lo, hi, 3))  # noqa: E731
+
+    def material():
+        k = int(rng.integers(8))
+        if k == 0: return scenes.matte(col(), sigma=float(rng.choice([0.0, 25.0])))
+        if k == 1: return scenes.plastic(col(), col(), float(rng.uniform(0.02, 0.4)))
+        if k == 2: return scenes.mirror(col(0.5, 1.0))
+        if k == 3: return scenes.glass(col(0.5, 1.0), col(0.5, 1.0), float(rng.uniform(1.1, 1.9)), multiple_lobes=False)
+        if k == 4: return scenes.metal(roughness=float(rng.uniform(0.01, 0.3)))
+        if k == 5: return scenes.substrate(col(), col(0.05, 0.4), 0.1, 0.2)
+        return scenes.matte(col())
+    wall = sb.add_material(scenes.matte(col(0.3, 0.8)))
+    q = sb.add_quad
+    q([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], wall)
+    q([(-5, 6, -5), (5, 6, -5), (5, 6, 5), (-5, 6, 5)], wall)
+    q([(-5, 0, 5), (-5, 6, 5), (5, 6, 5), (5, 0, 5)], sb.add_material(material()))
+    q([(-5, 0, -5), (-5, 6, -5), (-5, 6, 5), (-5, 0, 5)], sb.add_material(material()))
+    q([(5, 0, -5), (5, 0, 5), (5, 6, 5), (5, 6, -5)], sb.add_material(material()))
+    for i in range(9):
+        c = rng.uniform([-4, 0.3, -1], [4, 4.5, 4])
+        a, b = rng.normal(size=3), rng.normal(size=3)
+        a *= rng.uniform(0.4, 1.2) / np.linalg.norm(a); b -= a * (a @ b) / (a @ a); b *= rng.uniform(0.4, 1.2) / np.linalg.norm(b)
+        q([c - a - b, c + a - b, c + a + b, c - a + b], abi.NO_MATERIAL if (i == 8 and seed % 3 == 0) else sb.add_material(material()))
+    mode = ["fixed", "reference"][seed % 2]
+    if seed % 4 != 3:
+        sb.begin_object("thing")
+        sb.add_box((-0.3, 0.0, -0.3), (0.3, 0.7, 0.3), sb.add_material(material()))
+        sb.end_object()
+        for _ in range(2):
+            sb.add_instance("thing", scenes.Transform.translate(tuple(rng.uniform([-3, 0, -1], [3, 2, 3]))) * scenes.Transform.rotate_y(float(rng.uniform(0, 360))))
+    if seed % 2:
+        mask = sb.checkerboard_texture(sb.constant_texture(0.0), sb.constant_texture(1.0), su=4.0, sv=3.0)
+        q([(-1, 0.5, 1.0), (1, 0.5, 1.1), (1, 1.8, 1.1), (-1, 1.8, 1.0)], sb.add_material(scenes.matte(col())), UV=[[0, 0], [1, 0], [1, 1], [0, 1]], alpha=mask)
+    q([(-1.2, 5.9, -1.2), (1.2, 5.9, -1.2), (1.2, 5.9, 1.2), (-1.2, 5.9, 1.2)], wall, emit=col(4, 12))
+    if rng.random() < 0.6: q([(-4.9, 2, -1), (-4.9, 3, -1), (-4.9, 3, 0), (-4.9, 2, 0)], wall, emit=col(2, 8), two_sided=True)
+    if rng.random() < 0.6: sb.add_point_light(tuple(rng.uniform([-3, 3, -3], [3, 5, 3])), col(5, 30))
+    if rng.random() < 0.4: sb.add_spot_light((3, 5, -3), (0, 1, 1), col(30, 90), coneangle=35, conedelta=10)
+    if rng.random() < 0.3: sb.add_infinite_light(col(0.1, 0.5))
+    sc = sb.finish(gpu.bvh_build, instancing=mode)
+    strategy = ["all", "one"][(seed // 2) % 2]
+    ns = [int(v) for v in rng.integers(1, 4, int(sc.desc.n_lights))]
+    rd = scenes.make_render_desc(56, 40, 4, GALLERY_LOOK_AT, 55, max_depth=1 + seed % 5, sampler="halton" if seed % 3 == 0 else "sobol", integrator="directlighting",
+                                 direct_strategy=strategy, light_samples=ns)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    ref = oracle.render_integrator(sc, rd, "direct", strategy=strategy, light_samples=ns if strategy == "all" else None, threads=8)
+    assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == 0
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 2e-5
