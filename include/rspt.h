@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 16
+#define RSPT_ABI_VERSION 17
 
 /* error codes */
 #define RSPT_OK 0
@@ -459,6 +459,14 @@ int rspt_trace(rspt_scene_t scene, const rspt_ray* rays, uint64_t n, rspt_hit* o
  * demand are built by this call. */
 int rspt_light_distribution(rspt_scene_t scene, uint32_t light_strategy, const float p[3], float* func_out, float* cdf_out,
                             int32_t nvox_out[3], int32_t voxel_out[3]);
+
+/* Stage-level hook.  Replaces: f32::sin / cos / ln / log2 / exp / acos / atan2 as the path uses them (concentric_sample_disk
+ * sampling.rs:360-382, Trowbridge-Reitz sampling microfacet.rs:475-531, spherical directions and mappings, MIP level selection, roughness
+ * remapping, medium transmittance) = the host libm's sinf / cosf / logf / log2f / expf / acosf / atan2f.  The device evaluates glibc's
+ * algorithms operation by operation (rs_pbrt_amd/csrc/glibc_libm.h); this entry point runs one of them over an array so that a test can
+ * compare it with the host's libm bit for bit.  y is read by RSPT_LIBM_ATAN2 only (out = atan2f(x[i], y[i])), else may be NULL. */
+enum { RSPT_LIBM_SIN = 0, RSPT_LIBM_COS = 1, RSPT_LIBM_LOG = 2, RSPT_LIBM_LOG2 = 3, RSPT_LIBM_EXP = 4, RSPT_LIBM_ACOS = 5, RSPT_LIBM_ATAN2 = 6 };
+int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out);
 
 /* Benchmark hook: same as rspt_trace on rays already resident in device memory,
  * repeated `repeat` times; returns average kernel milliseconds per launch. */

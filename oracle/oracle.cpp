@@ -266,6 +266,14 @@ void orc_pixel_sampler(const rspt_render_desc* rd, uint64_t seed, int n_pixels, 
     draws[3] = s.get_1d();
 }
 
+// f32::sin / cos / ln / log2 / exp / acos / atan2 = the host libm's functions, over an array (to compare the device's restatements with, bit for bit)
+void orc_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float v = x[i];
+        out[i] = fn == 0 ? std::sin(v) : fn == 1 ? std::cos(v) : fn == 2 ? std::log(v) : fn == 3 ? std::log2(v) : fn == 4 ? std::exp(v) : fn == 5 ? std::acos(v) : std::atan2(v, y[i]);
+    }
+}
+
 // media (VolPathIntegrator): leaf functions for known-answer tests
 float orc_phase_hg(float cos_theta, float g) { return phase_hg(cos_theta, g); }
 float orc_hg_sample_p(float g, const float wo[3], float ux, float uy, float wi_out[3]) {

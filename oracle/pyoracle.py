@@ -64,6 +64,7 @@ def lib():
         L.orc_homogeneous_sample.restype = None
         L.orc_homogeneous_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.orc_visibility_tr.restype = None; L.orc_visibility_tr.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_libm.restype = None; L.orc_libm.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_pixel_sampler.restype = None
         L.orc_pixel_sampler.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_spatial_voxel.restype = None

@@ -84,7 +84,7 @@ RDEV f2 concentric_disk(f2 u) {
         r = oy;
         theta = RSPT_PI_OVER_2 - RSPT_PI_OVER_4 * (ox / oy);
     }
-    return f2{cosf(theta) * r, sinf(theta) * r};
+    return f2{rspt_cosf(theta) * r, rspt_sinf(theta) * r};
 }
 RDEV f3 cosine_hemisphere(f2 u) {
     f2 d = concentric_disk(u);
@@ -122,8 +122,8 @@ RDEV void tr_sample11(float cos_th, float u1, float u2, float* sx, float* sy) {
     if (cos_th > 0.9999f) {
         float r = sqrtf(u1 / (1.0f - u1));
         float phi = RSPT_TAU * u2;
-        *sx = r * cosf(phi);
-        *sy = r * sinf(phi);
+        *sx = r * rspt_cosf(phi);
+        *sy = r * rspt_sinf(phi);
         return;
     }
     float sin_th = sqrtf(fmaxf(0.0f, 1.0f - cos_th * cos_th));

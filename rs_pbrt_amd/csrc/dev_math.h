@@ -44,6 +44,16 @@ RDEV f3 vdiv(f3 a, float s) {
 }
 RDEV float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 RDEV f3 vabs(f3 a) { return f3{fabsf(a.x), fabsf(a.y), fabsf(a.z)}; }
+// ---- libm as the reference's host computes it: sinf, cosf, logf, log2f, expf, acosf, atanf, atan2f (glibc_libm.h) ----
+#define GL_FN RDEV
+#define GL_FN_COLD __device__ __noinline__
+#define GL_TABLE static __device__ const
+#define GL_F2U(x) __float_as_uint(x)
+#define GL_U2F(x) __uint_as_float(x)
+#define GL_D2U(x) ((uint64_t)__double_as_longlong(x))
+#define GL_U2D(x) __longlong_as_double((long long)(x))
+#include "glibc_libm.h"
+
 RDEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // geometry.rs:630
 RDEV float absdot(f3 a, f3 b) { return fabsf(dot(a, b)); }
 RDEV float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }

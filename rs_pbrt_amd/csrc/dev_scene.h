@@ -488,7 +488,7 @@ RDEV rgb env_triangle(const EnvMapDev& m, uint32_t level, f2 st) {
     return tmp4 + tmp3 + tmp2 + tmp1;
 }
 RDEV rgb env_lookup(const EnvMapDev& m, f2 st, float width) {  // lookup_pnt_flt
-    float level = (float)m.n_levels - 1.0f + log2f(fmaxf(width, 1e-8f));
+    float level = (float)m.n_levels - 1.0f + rspt_log2f(fmaxf(width, 1e-8f));
     if (level < 0.0f) return env_triangle(m, 0, st);
     if (level >= (float)m.n_levels - 1.0f) return env_texel(m, m.n_levels - 1, 0, 0);
     uint32_t il = (uint32_t)floorf(level);
@@ -526,8 +526,8 @@ RDEV float env_pdf(const EnvMapDev& m, f2 p) {  // Distribution2D::pdf
     return m.cond_func[(size_t)iv * m.nu + iu] / m.marg_int;
 }
 RDEV f3 mat3_mul(const float* m, f3 w) { return f3{m[0] * w.x + m[1] * w.y + m[2] * w.z, m[3] * w.x + m[4] * w.y + m[5] * w.z, m[6] * w.x + m[7] * w.y + m[8] * w.z}; }
-RDEV float spherical_theta(f3 v) { return acosf(clampf(v.z, -1.0f, 1.0f)); }  // geometry.rs:1584-1586
-RDEV float spherical_phi(f3 v) { float p = atan2f(v.y, v.x); return p < 0.0f ? p + 2.0f * RSPT_PI : p; }
+RDEV float spherical_theta(f3 v) { return rspt_acosf(clampf(v.z, -1.0f, 1.0f)); }  // geometry.rs:1584-1586
+RDEV float spherical_phi(f3 v) { float p = rspt_atan2f(v.y, v.x); return p < 0.0f ? p + 2.0f * RSPT_PI : p; }
 #define RSPT_INV_2_PI 0.15915494309189533577f
 // InfiniteAreaLight::le / pdf_li (infinite.rs:369-392)
 RDEVN rgb infinite_le(const SceneDev& sc, const rspt_light& lt, f3 ray_d) {
@@ -538,7 +538,7 @@ RDEVN rgb infinite_le(const SceneDev& sc, const rspt_light& lt, f3 ray_d) {
 RDEVN float infinite_pdf_li(const SceneDev& sc, const rspt_light& lt, f3 w) {
     f3 wi = mat3_mul(lt.p + 9, w);
     float theta = spherical_theta(wi), phi = spherical_phi(wi);
-    float sin_theta = sinf(theta);
+    float sin_theta = rspt_sinf(theta);
     if (sin_theta == 0.0f) return 0.0f;
     return env_pdf(sc.envmaps[lt.prim], f2{phi * RSPT_INV_2_PI, theta * RSPT_INV_PI}) / (2.0f * RSPT_PI * RSPT_PI * sin_theta);
 }
@@ -577,7 +577,7 @@ RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 
         f2 uv = env_sample_continuous(m, u, &map_pdf);
         if (map_pdf == 0.0f) { *pdf = 0.0f; return mkrgb(0.0f); }
         float theta = uv.y * RSPT_PI, phi = uv.x * 2.0f * RSPT_PI;
-        float cos_theta = cosf(theta), sin_theta = sinf(theta), sin_phi = sinf(phi), cos_phi = cosf(phi);
+        float cos_theta = rspt_cosf(theta), sin_theta = rspt_sinf(theta), sin_phi = rspt_sinf(phi), cos_phi = rspt_cosf(phi);
         *wi = mat3_mul(lt.p, f3{sin_theta * cos_phi, sin_theta * sin_phi, cos_theta});
         *pdf = map_pdf / (2.0f * RSPT_PI * RSPT_PI * sin_theta);
         if (sin_theta == 0.0f) *pdf = 0.0f;

@@ -77,7 +77,7 @@ RDEVN rgb img_triangle(const ImageDev& m, const float* texels, uint32_t wrap, ui
     return tmp4 + tmp3 + tmp2 + tmp1;
 }
 RDEV rgb img_lookup_width(const ImageDev& m, const float* texels, uint32_t wrap, f2 st, float width) {  // lookup_pnt_flt :233-252
-    float level = (float)m.n_levels - 1.0f + log2f(fmaxf(width, 1e-8f));
+    float level = (float)m.n_levels - 1.0f + rspt_log2f(fmaxf(width, 1e-8f));
     if (level < 0.0f) return img_triangle(m, texels, wrap, 0, st);
     if (level >= (float)m.n_levels - 1.0f) return img_texel(m, texels, wrap, m.n_levels - 1, 0, 0);
     uint32_t il = (uint32_t)floorf(level);
@@ -135,7 +135,7 @@ RDEV rgb img_lookup(const ImageDev& m, const float* texels, const float* lut, co
         minor_length *= scale;
     }
     if (minor_length == 0.0f) return img_triangle(m, texels, tx.wrap, 0, st);
-    float lod = fmaxf(0.0f, (float)m.n_levels - 1.0f + log2f(minor_length));
+    float lod = fmaxf(0.0f, (float)m.n_levels - 1.0f + rspt_log2f(minor_length));
     uint32_t ilod = (uint32_t)floorf(lod);
     rgb col2 = img_ewa(m, texels, lut, tx.wrap, ilod + 1, st, dst0, dst1);
     rgb col1 = img_ewa(m, texels, lut, tx.wrap, ilod, st, dst0, dst1);
@@ -188,7 +188,7 @@ __device__ __noinline__ float noise_flt(float x, float y, float z) {
     float y0 = lerpf(wy, x00, x10), y1 = lerpf(wy, x01, x11);
     return lerpf(wz, y0, y1);
 }
-RDEV float log_2(float x) { return logf(x) * 1.44269504088896340736f; }  // pbrt.rs:153-156
+RDEV float log_2(float x) { return rspt_logf(x) * 1.44269504088896340736f; }  // pbrt.rs:153-156
 __device__ __noinline__ float fbm(f3 p, f3 dpdx, f3 dpdy, float omega, int32_t max_octaves) {
     float l2 = fmaxf(len2(dpdx), len2(dpdy));
     float n = -1.0f - 0.5f * log_2(l2);
@@ -232,7 +232,7 @@ RDEV f2 map_sphere(const rspt_texture& tx, f3 p) {
 }
 RDEV f2 map_cylinder(const rspt_texture& tx, f3 p) {
     f3 v = normalize(xf_point(tx.world_to_texture, p) - f3{0.0f, 0.0f, 0.0f});
-    return f2{RSPT_PI + atan2f(v.y, v.x) * 0.15915494309189533577f, v.z};
+    return f2{RSPT_PI + rspt_atan2f(v.y, v.x) * 0.15915494309189533577f, v.z};
 }
 RDEV void wrap_dt(f2* d) {
     if (d->y > 0.5f) d->y = 1.0f - d->y;
@@ -348,7 +348,7 @@ __device__ __noinline__ rgb tex_eval_d(const TexTables& tt, uint32_t ti, const T
         f3 dpdx, dpdy; f3 p = tex_map3d(tx, si, &dpdx, &dpdy);
         p = p * tx.scale;
         float marble = p.y + tx.variation * fbm(p, dpdx * tx.scale, dpdy * tx.scale, tx.omega, tx.octaves);
-        float t = 0.5f + 0.5f * sinf(marble);
+        float t = 0.5f + 0.5f * rspt_sinf(marble);
         float ff = floorf(t * 6.0f);
         uint32_t first = (ff != ff || ff <= 0.0f) ? 0u : (ff >= 5.0f ? 5u : (uint32_t)ff);
         t = t * 6.0f - (float)first;

@@ -618,7 +618,7 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
             if (sd & RSPT_SLOT_ALPHA) {  // a roughness texture: the slot carries the lobe's alpha (plastic.rs:86-92, microfacet.rs:233-254)
                 float a = v.r;
                 if (sd & RSPT_SLOT_REMAP) {
-                    const float r = fmaxf(a, 1e-3f), x = logf(r);
+                    const float r = fmaxf(a, 1e-3f), x = rspt_logf(r);
                     a = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
                 }
                 a = fmaxf(0.001f, a);
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Bat
             pdf = fabsf(wi.z) * RSPT_INV_PI;
         } else {  // uniform_sample_hemisphere (sampling.rs:309-318)
             const float z = u.x, r = sqrtf(fmaxf(0.0f, 1.0f - z * z)), phi = 2.0f * RSPT_PI * u.y;
-            wi = f3{r * cosf(phi), r * sinf(phi), z};
+            wi = f3{r * rspt_cosf(phi), r * rspt_sinf(phi), z};
             pdf = 0.15915494309189533577f;
         }
         wi = f3{sv.x * wi.x + tv.x * wi.y + n.x * wi.z, sv.y * wi.x + tv.y * wi.y + n.y * wi.z, sv.z * wi.x + tv.z * wi.y + n.z * wi.z};
@@ -1143,6 +1143,14 @@ __global__ void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mes
     tris[3 * (size_t)i] = make_float4(p0.x, p0.y, p0.z, p1.x);
     tris[3 * (size_t)i + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
     tris[3 * (size_t)i + 2] = make_float4(p2.z, __uint_as_float(pr.material), __uint_as_float((uint32_t)pr.area_light), __uint_as_float(flags));
+}
+
+// stage hook rspt_libm: one of the device's libm restatements (glibc_libm.h) over an array
+__global__ void k_libm(uint32_t fn, const float* __restrict__ x, const float* __restrict__ y, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    out[i] = fn == 0 ? rspt_sinf(v) : fn == 1 ? rspt_cosf(v) : fn == 2 ? rspt_logf(v) : fn == 3 ? rspt_log2f(v) : fn == 4 ? rspt_expf(v) : fn == 5 ? rspt_acosf(v) : rspt_atan2f(v, y[i]);
 }
 
 }  // namespace rspt

@@ -1802,6 +1802,24 @@ int rspt_render_samples(rspt_scene_t s, const rspt_render_desc* d, float* li_rgb
     return render_impl(s, d, nullptr, nullptr, li_rgb, stats);
 }
 
+int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {
+    if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
+    if (n == 0) return RSPT_OK;
+    if (fn > RSPT_LIBM_ATAN2 || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (1ull << 31)) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values");
+    HIP_TRY(hipSetDevice(g.device));
+    float *xd = nullptr, *yd = nullptr, *od = nullptr;
+    struct Guard { float **a, **b, **c; ~Guard() { for (float** p : {a, b, c}) if (*p) (void)hipFree(*p); } } guard{&xd, &yd, &od};
+    int rc;
+    if ((rc = dev_alloc(&xd, n)) || (rc = dev_alloc(&od, n)) || (y && (rc = dev_alloc(&yd, n)))) return rc;
+    HIP_TRY(hipMemcpyAsync(xd, x, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    if (y) HIP_TRY(hipMemcpyAsync(yd, y, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_libm, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, yd, n, od);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, od, n * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RSPT_OK;
+}
+
 int rspt_light_distribution(rspt_scene_t s, uint32_t strategy, const float p[3], float* func_out, float* cdf_out, int32_t nvox_out[3], int32_t voxel_out[3]) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (!s || !p || !func_out || !cdf_out) return fail(RSPT_E_INVALID, "null argument");

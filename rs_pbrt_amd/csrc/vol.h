@@ -58,7 +58,7 @@ struct VolSampler {  // GlobalSampler::get_1d / get_2d (sobol.rs:180-201, halton
 };
 
 RDEV rgb med_sigma_t(const rspt_medium& m) { return ldrgb(m.sigma_s) + ldrgb(m.sigma_a); }  // HomogeneousMedium::new (homogeneous.rs:24-31)
-RDEV rgb rgb_exp(rgb a) { return rgb{expf(a.r), expf(a.g), expf(a.b)}; }
+RDEV rgb rgb_exp(rgb a) { return rgb{rspt_expf(a.r), rspt_expf(a.g), rspt_expf(a.b)}; }
 // HomogeneousMedium::tr (homogeneous.rs:33-36) over a ray of parametric length t_max and direction length len
 RDEV rgb med_tr(const rspt_medium& m, float t_max, float len) {
     const rgb st = med_sigma_t(m);
@@ -79,7 +79,7 @@ RDEV float hg_sample_p(float g, f3 wo, f3* wi, f2 u) {  // HenyeyGreenstein::sam
     const float phi = 2.0f * RSPT_PI * u.y;
     f3 v1, v2;
     coordinate_system(wo, &v1, &v2);
-    *wi = v1 * (sin_theta * cosf(phi)) + v2 * (sin_theta * sinf(phi)) + wo * cos_theta;
+    *wi = v1 * (sin_theta * rspt_cosf(phi)) + v2 * (sin_theta * rspt_sinf(phi)) + wo * cos_theta;
     return phase_hg(cos_theta, g);
 }
 // GeometricPrimitive::intersect's medium interface (primitive.rs:160-170) + Interaction::get_medium (interaction.rs:95-107)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                     const rgb sigma_t = med_sigma_t(m);
                     uint32_t channel = (uint32_t)(smp.get_1d(rd) * 3.0f);
                     channel = channel < 2u ? channel : 2u;
-                    const float dist = -logf(1.0f - smp.get_1d(rd)) / (channel == 0u ? sigma_t.r : (channel == 1u ? sigma_t.g : sigma_t.b));
+                    const float dist = -rspt_logf(1.0f - smp.get_1d(rd)) / (channel == 0u ? sigma_t.r : (channel == 1u ? sigma_t.g : sigma_t.b));
                     const float dlen = len(ray_d);
                     const float t = fminf(dist / dlen, t_hit);
                     have_mi = t < t_hit;

@@ -15,7 +15,7 @@ _LIB = None
 EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
            "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
-           "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy", "rspt_light_distribution")
+           "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy", "rspt_light_distribution", "rspt_libm")
 
 
 def source_hash():
@@ -69,6 +69,7 @@ def lib():
         L.rspt_bvh_build_gpu.restype = C.c_int64
         L.rspt_bvh_build_gpu.argtypes = [vp, u64, vp, u64, u32, vp, u64, vp]
         L.rspt_light_distribution.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.rspt_libm.argtypes = [u32, vp, vp, C.c_uint64, vp]
         L.rspt_comm_unique_id.argtypes = [vp]
         L.rspt_comm_init.argtypes = [i32, i32, vp]
         _LIB = L
@@ -131,6 +132,18 @@ def shutdown():
     global _inited_device
     lib().rspt_shutdown()
     _inited_device = None
+
+
+LIBM = {"sin": 0, "cos": 1, "log": 2, "log2": 3, "exp": 4, "acos": 5, "atan2": 6}
+
+
+def libm(fn, x, y=None):
+    """rspt_libm: the device's restatement of the host libm's sinf / cosf / logf / log2f / expf / acosf / atan2f(x, y), element by element"""
+    x = np.ascontiguousarray(x, np.float32)
+    y = None if y is None else np.ascontiguousarray(y, np.float32)
+    out = np.empty_like(x)
+    _check(lib().rspt_libm(LIBM[fn], x.ctypes.data, None if y is None else y.ctypes.data, x.size, out.ctypes.data))
+    return out
 
 
 def light_distribution(dscene, strategy, p):

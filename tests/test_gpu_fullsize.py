@@ -205,3 +205,33 @@ def test_c4_standin_crop_at_depth_16_matches_oracle(gpu, oracle):
             assert film_rmse(film, ref["film"]) < 1e-5
     finally:
         ds.close()
+
+
+def test_c1_fogged_volpath_at_full_size_matches_oracle(gpu, oracle):
+    """the bench workload of `--integrator volpath` (Cornell box filled with a medium of optical depth ~1, 400x400x64): two crop
+    windows of the full-resolution frame at the full sample count against the oracle, and frame-level bookkeeping"""
+    sc = scenes.cornell_box(gpu.bvh_build, fog=scenes.CORNELL_FOG)
+    with gpu.DeviceScene(sc) as ds:
+        full, st = gpu.render(ds, scenes.cornell_render_desc(res=400, spp=64, integrator="volpath"))
+        assert st["samples"] == 400 * 400 * 64 and st["truncated_paths"] == 0 and st["nan_samples"] == 0
+        extra = float(full[:, 3].astype(np.float64).sum()) - 400 * 400 * 64   # box filter: a pixel owns its 64 samples; a film offset of exactly 0 also counts next door (Q22)
+        assert 0 <= extra < 1e-3 * 400 * 400 * 64
+        for crop in ((0.30, 0.40, 0.55, 0.65), (0.62, 0.70, 0.12, 0.20)):   # a block in the fog with the light above it; a wall corner
+            rd = scenes.cornell_render_desc(res=400, spp=64, integrator="volpath", crop=crop)
+            film, _ = gpu.render(ds, rd)
+            ref = oracle.render(sc, rd, threads=THREADS)
+            assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-5
+    rgb = scenes.film_to_rgb(full)
+    assert 0.05 < rgb.mean() < 0.5
+
+
+def test_c1_pixel_sampler_at_full_size_matches_oracle(gpu, oracle):
+    """Cornell 400x400 (625 tiles, the last row and column partial) x 64 spp under the 02sequence sampler: the whole frame against the
+    oracle (a crop window would change the tiling and with it every tile's PCG stream)"""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=400, spp=64, sampler="02sequence")
+    ref = oracle.render(sc, rd, threads=THREADS)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+    assert st["samples"] == ref["counters"]["samples"] == 400 * 400 * 64 and st["truncated_paths"] == 0
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-5

@@ -305,3 +305,35 @@ def test_ties_duplicates_and_lattice_geometry(gpu, oracle):
     finally:
         os.environ.pop("RSPT_TRACE_KERNEL", None)
         ds.close()
+
+
+def test_device_libm_equals_host_libm(gpu, oracle):
+    """rspt_libm (the device's sinf / cosf / logf / log2f / expf / acosf / atan2f: glibc's algorithms restated, glibc_libm.h) against the libm
+    of THIS host — the one the oracle's values come from — bit for bit: dense sets over the ranges the path produces, 2^24 random arguments
+    of the wider domain, and the edge cases (zeros, denormals, quadrant boundaries, domain ends, infinities, NaN)"""
+    rng = np.random.default_rng(11)
+    dense = lambda lo, hi, step: np.arange(int(np.float32(lo).view(np.uint32)), int(np.float32(hi).view(np.uint32)) + 1, step, dtype=np.uint32).view(np.float32)  # noqa: E731
+    rnd = lambda lo, hi: (rng.random(1 << 24, dtype=np.float32) * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)  # noqa: E731
+    bits = rng.integers(0, 1 << 32, 1 << 22, dtype=np.uint64).astype(np.uint32).view(np.float32)   # raw bit patterns: every exponent, NaNs, infinities
+    edge = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 2.4e-4, 0.5, 0.78539816, 0.7853982, 1.0, -1.0, 1.5707964, 3.1415927, 4.712389, 6.2831855, -3.1415927,
+                     88.0, 88.8, -87.4, -103.9, -104.1, 100.0, -119.5, np.inf, -np.inf, np.nan], np.float32)
+    args = {"sin": np.concatenate([dense(0.0, 6.2831855, 16), -dense(0.0, 6.2831855, 112), rnd(-119.9, 119.9), edge]),
+            "cos": np.concatenate([dense(0.0, 6.2831855, 16), -dense(0.0, 6.2831855, 112), rnd(-119.9, 119.9), edge]),
+            "log": np.concatenate([dense(1e-30, 1e30, 64), bits, edge]),
+            "log2": np.concatenate([dense(1e-30, 1e30, 64), bits, edge]),
+            "exp": np.concatenate([-dense(1e-30, 110.0, 32), dense(1e-30, 90.0, 64), bits, edge]),
+            "acos": np.concatenate([dense(0.0, 1.0, 8), -dense(0.0, 1.0, 8), bits, edge])}
+    for fn, x in args.items():
+        got = gpu.libm(fn, x)
+        ref = np.empty_like(x)
+        oracle.lib().orc_libm(gpu.LIBM[fn], x.ctypes.data, None, x.size, ref.ctypes.data)
+        ok = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        assert ok.all(), (fn, x[~ok][:4], got[~ok][:4], ref[~ok][:4])
+    n = 1 << 25
+    y = np.concatenate([rnd(-3.0, 3.0), rnd(-3.0, 3.0)[::-1] * np.float32(1e-6), bits, edge])
+    x = np.concatenate([rnd(-3.0, 3.0)[::-1], rnd(-3.0, 3.0), bits[::-1], edge[::-1]])
+    got = gpu.libm("atan2", y, x)
+    ref = np.empty_like(y)
+    oracle.lib().orc_libm(gpu.LIBM["atan2"], y.ctypes.data, x.ctypes.data, y.size, ref.ctypes.data)
+    ok = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert ok.all(), ("atan2", y[~ok][:4], x[~ok][:4], got[~ok][:4], ref[~ok][:4])

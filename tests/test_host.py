@@ -1,10 +1,13 @@
 """CPU: host-side logic of the Python mirror — render-desc construction (film / camera / sampler
 parameters as rs_pbrt's API layer computes them), material lobe recipes, scene flattening."""
 import math
+import os
 
 import numpy as np
 
 from rs_pbrt_amd import abi, integrator, lib, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_film_bounds_match_film_rs():
@@ -73,3 +76,14 @@ def test_graft_entry_build_runs():
     """the driver's build check: compiles (no-op when up to date), loads the library, resolves every export"""
     import __graft_entry__ as g
     g.build()
+
+
+def test_glibc_restatements_are_exhaustively_exact(tmp_path):
+    """tools/libm_exhaustive.c compiles rs_pbrt_amd/csrc/glibc_libm.h — the source text every kernel includes for sinf, cosf, logf, log2f,
+    expf, acosf, atanf, atan2f — for the host and compares it with the host libm (what Rust's f32 methods call) over all 2^32 floats
+    (2^30 pairs for atan2f): 0 mismatches.  The device side of the chain is tests/test_gpu_trace.py::test_device_libm_equals_host_libm."""
+    import subprocess
+    exe = tmp_path / "libm_exhaustive"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe), "-x", "c++", os.path.join(ROOT, "tools", "libm_exhaustive.c"), "-lm", "-lpthread"])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=1800)
+    assert out.returncode == 0 and b"all eight functions equal the host libm" in out.stdout, out.stdout.decode()
