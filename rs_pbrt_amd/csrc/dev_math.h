@@ -2,7 +2,7 @@
 //
 // Everything here is f32 with NO fused multiply-add (the translation unit is built with
 // -ffp-contract=off) so that results are bit-identical to rs_pbrt's scalar Rust code, which
-// LLVM never contracts.  Each helper names the rs_pbrt function whose arithmetic it has to
+// LLVM never contracts; the libm functions Rust calls are restated from glibc (glibc_libm.h).  Each helper names the rs_pbrt function whose arithmetic it has to
 // reproduce (paths relative to the rs_pbrt tree).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -13,8 +13,8 @@ LOOK = ((0, 2.0, -5.0), (0, 1.0, 0), (0, 1, 0))
 
 def masked_scene(builder, cut=False, shadow_only=False, instanced=False, mode="fixed", plain=False):
     """a wall, a floor, a light, and a 2 x 2 m panel in front of the wall whose 4 x 4 checker alpha texture (constants 0 / 1) removes every
-    other cell.  (No surface lies on a boundary of the 64-voxel light-distribution grid: a bounce ray's hit point carries the sinf / cosf
-    ulps of its sampled direction, and on a boundary one ulp picks the neighbouring voxel's distribution — DESIGN.md §3.)  cut=True: the same panel modelled as the eight remaining cells (no texture) — the first-principles twin.
+    other cell.  (No surface lies on a boundary of the 64-voxel light-distribution grid: chosen when the device library's sinf / cosf still moved bounce-ray
+    hit points by an ulp, which on a boundary picks the neighbouring voxel's distribution — DESIGN.md §3; no longer needed.)  cut=True: the same panel modelled as the eight remaining cells (no texture) — the first-principles twin.
     shadow_only: the mask sits in shadow_alpha_mask (camera rays see the whole panel, shadow rays go through the holes)."""
     sb = scenes.SceneBuilder()
     grey = sb.add_material(scenes.matte((0.6, 0.6, 0.6)))

@@ -1,6 +1,6 @@
 """The PCG-backed pixel samplers on the GPU: librspt's one-lane-per-tile kernel (rs_pbrt_amd/csrc/tile_serial.h)
 against the oracle.  The sample values are integer arithmetic (PCG32, Gray-code nets, shuffles) and must agree exactly: film weights
-bit for bit; radiance within the sinf / cosf tolerance of DESIGN.md section 3."""
+bit for bit; so does the radiance (glibc_libm.h), which is what keeps a tile's chain from ever drifting away from the reference's."""
 import os
 
 import numpy as np

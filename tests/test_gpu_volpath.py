@@ -1,6 +1,6 @@
 """VolPathIntegrator::li on the GPU (rs_pbrt_amd/csrc/vol.h) against the oracle (volpath.rs:60-347, homogeneous.rs, medium.rs).
-Radiance goes through expf / logf (the medium) and sinf / cosf (phase function and BSDF sampling), whose last ulp differs between glibc
-and the device library for a few per cent of the arguments: the bar is the film RMSE of DESIGN.md section 3 (1e-5 at 16+ spp, weights exact)."""
+Radiance goes through expf / logf (the medium) and sinf / cosf (phase function and BSDF sampling), which glibc_libm.h evaluates exactly as
+the host libm does: per-sample radiance is bit-identical (tests/test_gpu_render.py); the bars here are the film's (weights exact, RMSE 1e-5)."""
 import numpy as np
 import pytest
 
