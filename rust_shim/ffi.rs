@@ -86,6 +86,7 @@ extern "C" {
     pub fn rspt_comm_init(rank: i32, world: i32, id: *const u8) -> c_int;
     pub fn rspt_comm_destroy() -> c_int;
     pub fn rspt_last_error() -> *const c_char;
+    pub fn rspt_libm(func: u32, x: *const f32, y: *const f32, n: u64, out: *mut f32) -> c_int;   // 0 sin 1 cos 2 ln 3 log2 4 exp 5 acos 6 atan2(x, y)
     pub fn rspt_bvh_build_gpu(p: *const f32, n_vertices: u64, tri_idx: *const u32, n_tris: u64, max_prims_in_node: u32,
                               nodes_out: *mut RsptBvhNode, nodes_cap: u64, ordered_out: *mut u32) -> i64;
 }
