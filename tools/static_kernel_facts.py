@@ -40,6 +40,6 @@ out += ["", "Reading: the traversal step of `k_trace_w4` is the block with the s
 "`ds_read_b128` of an LDS-resident root-side record), the stack pop is the `ds_read_b64` (+ a conditional `global_load_dwordx2` from",
 "the spill rows), and there is no flat instruction in the kernel (DESIGN.md §5). `k_shade`'s correctly rounded divisions",
 "(`v_div_scale/fmas/fixup` + `v_rcp`) and square roots are what bit-exact parity with Rust's IEEE `/` and `sqrt` costs; its",
-"211 VGPRs (2 waves/SIMD) are the first open end of DESIGN.md §8. Template arguments of `k_trace_w4`: <any-hit, output mode, object instances, alpha masks>; the `true` variants are only launched for scenes with instances (SURVEY 8(f) #2) / alpha-masked meshes."]
+"register count (2 waves/SIMD) is the first open end of DESIGN.md §9. Template arguments of `k_trace_w4`: <any-hit, output mode, object instances, alpha masks>; the `true` variants are only launched for scenes with instances (SURVEY 8(f) #2) / alpha-masked meshes."]
 open(repo+'/profiles/r02_static_kernel_facts.md','w').write("\n".join(out)+"\n")
 print("\n".join(out))
