@@ -19,7 +19,7 @@ def check(gpu, oracle, sc, rd, strategy, light_samples=None, min_same=0.75):
     assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == 0
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert film_rmse(film, ref["film"]) < 1e-5
-    assert (li == ref["li"]).all(-1).mean() > min_same
+    assert np.array_equal(li, ref["li"])   # (min_same dates from the device library's sinf / cosf; glibc_libm.h made the radiance exact)
     return film
 
 

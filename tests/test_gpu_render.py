@@ -28,6 +28,8 @@ def _render_pair(gpu, oracle, sc, rd, want_li=True):
     finally:
         ds.close()
     ref = oracle.render(sc, rd, threads=8, want_li=want_li)
+    if want_li:   # every sample's radiance, bit for bit (glibc_libm.h): the looser per-test bars below are all met with zero difference
+        assert np.array_equal(li, ref["li"]), "per-sample radiance differs from the oracle in %d of %d samples" % (int((li != ref["li"]).any(axis=2).sum()), li.shape[0] * li.shape[1])
     return film, li, st, ref
 
 
