@@ -22,3 +22,25 @@ def reduce_film(film, dst=0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
+
+
+def shards_after_failures(rank, world_size, dead, tile_chunk=TILE_CHUNK):
+    """Losing GPUs mid-frame ("per-GPU failure => re-queue its tiles on survivors (tiles are idempotent)").
+    The frame keeps its decomposition into `world_size` shards; the shards of the ranks in `dead` are handed to the survivors round
+    robin, in rank order.  Returns the list of (shard_index, shard_count, tile_chunk) that `rank` renders — its own first — or [] for
+    a dead rank.  Every survivor computes the same assignment from (world_size, dead) alone; the films of all listed shards are
+    summed (on the rank, then by the usual reduce over the survivors' communicator): shards are disjoint sets of tiles, so the sum
+    is the frame whatever the assignment."""
+    dead = sorted(set(int(d) for d in dead))
+    if any(not 0 <= d < world_size for d in dead):
+        raise ValueError("dead rank outside world of %d" % world_size)
+    alive = [r for r in range(world_size) if r not in dead]
+    if not alive:
+        raise ValueError("no surviving rank")
+    if rank in dead:
+        return []
+    mine = [shard_for_rank(rank, world_size, tile_chunk)]
+    for k, d in enumerate(dead):
+        if alive[k % len(alive)] == rank:
+            mine.append((d, world_size, tile_chunk))
+    return mine
