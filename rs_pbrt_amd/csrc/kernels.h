@@ -647,7 +647,9 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
 __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
                                                  const uint32_t* __restrict__ count_in) {
     const uint32_t n = *count_in;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) texture_path(sc, tt, rd, pb, q_active[i], nullptr);
+    // inlined at this call site: as a call (the compiler's choice once the stage had a second caller) the launch runs 28 % longer — 248 VGPRs and
+    // 1056 B of scratch against 209 and 368; the tile-serial kernel, at its register ceiling, keeps calling it
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) [[clang::always_inline]] texture_path(sc, tt, rd, pb, q_active[i], nullptr);
 }
 
 // ---- K7b: bin the active queue by what the shade stage will do with each path -------------------------------------------

@@ -52,18 +52,26 @@ def main():
     json.dump(out, open(d + "/pmc_traffic.json", "w"), indent=1)
     lines = ["# L1 / issue-side PMC counters of one C2 step (soup1m), per kernel — rocprofv3 --kernel-trace --pmc <one block per run>", "",
              "source hash %s; command: `python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-count`" % out["source_hash"], ""]
-    for name in ("tcp", "sq", "ta"):
+    for name in ("tcp", "sq", "ta", "lds"):
         rows = parse("%s/pmc_soup1m_%s.txt" % (d, name))
         if not rows:
             continue
         ctrs = sorted({c for k in rows for c in rows[k]})
         lines += ["## pass `%s`" % name, "", "| kernel | launches | " + " | ".join(ctrs) + " |", "|---|---|" + "---|" * len(ctrs)]
         for k in sorted(rows):
-            if not (k.startswith("k_trace") or k.startswith("k_shade") or k.startswith("k_raygen") or k.startswith("k_film")):
+            if k.startswith("bvhdev::"):
+                continue
+            if name != "lds" and not (k.startswith("k_trace") or k.startswith("k_shade") or k.startswith("k_raygen") or k.startswith("k_film")):
                 continue
             n = max((rows[k][c][0] for c in rows[k]), default=0)
             lines.append("| %s | %d | " % (k, n) + " | ".join("%.4g" % rows[k].get(c, (0, 0.0))[1] for c in ctrs) + " |")
         lines.append("")
+        if name == "lds":
+            fr = sorted(rows[k]["SQ_LDS_BANK_CONFLICT"][1] / max(rows[k]["SQ_LDS_IDX_ACTIVE"][1], 1.0) for k in rows
+                        if k.startswith("k_trace_w4") and "SQ_LDS_BANK_CONFLICT" in rows[k] and "SQ_LDS_IDX_ACTIVE" in rows[k])
+            if fr:
+                lines += ["`SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` of the traversal launches = %.1f-%.1f %%: the `stack[level][lane]` columns and the SoA copy of the"
+                          % (100.0 * fr[0], 100.0 * fr[-1]), "root-side records are read without bank conflicts to speak of (DESIGN.md section 5).", ""]
     open(d + "/pmc_trace_l1.md", "w").write("\n".join(lines) + "\n")
     print(json.dumps(out["workloads"], indent=1)[:2000])
 

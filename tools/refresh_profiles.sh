@@ -28,6 +28,7 @@ if [ "$mode" != quick ]; then
   pass soup1m tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum
   pass soup1m sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VALU
   pass soup1m ta TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE
+  pass soup1m lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
   python tools/pmc_to_json.py $out > $out/pmc_to_json.log 2>&1
 fi
 if [ "$mode" = all ]; then
@@ -40,6 +41,7 @@ if [ "$mode" = all ]; then
   timeout 300 python bench.py --workload cornell --sampler 02sequence --steps 2 --warmup 1 --no-extra > $out/bench_cornell_02sequence.json 2> $out/bench_cornell_02sequence.err
   timeout 300 python bench.py --workload statue --sampler 02sequence --spp 16 --steps 1 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_02sequence.json 2> $out/bench_statue_02sequence.err
   for m in fixed reference; do
+    [ -n "${SKIP_C5:-}" ] && continue   # the C5 stand-in lines take six minutes (host-side scene generation); skip when the change cannot touch them
     timeout 300 python bench.py --workload c5 --instancing $m --steps 3 --warmup 1 --no-extra > $out/bench_c5_$m.json 2> $out/bench_c5_$m.err
   done
   for w in volpath 02sequence; do   # kernel stats of the two schedules that are not the wavefront path loop
