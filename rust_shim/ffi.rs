@@ -26,7 +26,8 @@ pub struct RsptBxdf { // 116 B
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptMaterial { pub eta: f32, pub first_bxdf: u32, pub n_bxdfs: u32, pub bump_tex: u32 }
 #[repr(C)] pub struct RsptImage { pub width: u32, pub height: u32, pub n_levels: u32, pub channels: u32, pub texels: *const f32 }
-#[repr(C)] pub struct RsptTexture { // 160 B
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RsptTexture { // 160 B
     pub kind: u32, pub mapping: u32, pub map: [f32; 8], pub image: u32, pub trilinear: u32, pub max_aniso: f32, pub wrap: u32,
     pub value: [f32; 3], pub tex1: u32, pub tex2: u32, pub tex3: u32, pub world_to_texture: [f32; 16], pub octaves: i32,
     pub omega: f32, pub scale: f32, pub variation: f32,

@@ -8,9 +8,10 @@
 //! (Texture::as_constant, added by the patch), diffuse area / point / spot / distant / infinite lights (the light's own MIP
 //! pyramid and Distribution2D image are handed over), homogeneous media, PerspectiveCamera, the Sobol', Halton and the four
 //! PCG-backed pixel samplers, the path / ao / directlighting / volpath integrators, any filter (through Film.filter_table).
-//! Image / procedural textures, bump maps and alpha masks: the ABI has them (rspt_texture, rspt_image; see rs_pbrt_amd/scenes.py
-//! for the field-by-field recipe), but rs_pbrt's textures are trait objects and this file has no way to look inside one yet
-//! beyond as_constant — such scenes keep the CPU loop.
+//! Image / procedural textures (every class of src/textures/, through Texture::describe of rs_pbrt.patch) where the library
+//! takes them: Kd / Ks / roughness of matte, plastic, substrate, uber, the roughness of metal, bump maps of those materials,
+//! the alpha / shadowalpha masks of a mesh.  A textured parameter anywhere else (sigma, opacity, index, Kr, Kt, eta, k,
+//! reflect, transmit, a mix amount) returns Err and the scene keeps the CPU loop.
 pub mod ffi;
 pub mod refdump;
 
@@ -27,6 +28,8 @@ use crate::core::sampler::Sampler;
 use crate::core::scene::Scene;
 use crate::core::shape::Shape;
 use crate::core::sobolmatrices::{SOBOL_MATRICES_32, VD_C_SOBOL_MATRICES, VD_C_SOBOL_MATRICES_INV};
+use crate::core::texture::{TexDesc, Texture, TextureMapping2D, TextureMapping3D};
+use crate::core::mipmap::{ImageWrap, MipMap};
 use crate::core::transform::Transform;
 use crate::samplers::halton::RADICAL_INVERSE_PERMUTATIONS;
 use crate::shapes::triangle::TriangleMesh;
@@ -41,6 +44,14 @@ fn m16(t: &crate::core::transform::Matrix4x4) -> [f32; 16] {
 }
 fn rgb(s: &Spectrum) -> [f32; 3] { [s.c[0].max(0.0), s.c[1].max(0.0), s.c[2].max(0.0)] } // Spectrum::clamp_t(0, inf)
 fn err() -> String { unsafe { CStr::from_ptr(rspt_last_error()).to_string_lossy().into_owned() } }
+
+/// Float or Spectrum as the ABI stores them (rspt_texture.value, rspt_image.channels)
+trait ShimValue { const CHANNELS: u32; fn rgb3(&self) -> [f32; 3]; fn push(&self, out: &mut Vec<f32>); }
+impl ShimValue for Float { const CHANNELS: u32 = 1; fn rgb3(&self) -> [f32; 3] { [*self; 3] } fn push(&self, out: &mut Vec<f32>) { out.push(*self); } }
+impl ShimValue for Spectrum { const CHANNELS: u32 = 3; fn rgb3(&self) -> [f32; 3] { self.c } fn push(&self, out: &mut Vec<f32>) { out.extend_from_slice(&self.c); } }
+const IDENTITY16: [f32; 16] = [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0];
+type SpecTex = Arc<dyn Texture<Spectrum> + Sync + Send>;
+type FloatTex = Arc<dyn Texture<Float> + Sync + Send>;
 
 /// TrowbridgeReitzDistribution::roughness_to_alpha (microfacet.rs:243-254) + the 0.001 floor of ::new (:233-239)
 fn alpha(roughness: Float, remap: bool) -> f32 {
@@ -60,6 +71,8 @@ struct Flat {
     objects: Vec<RsptObject>, instances: Vec<RsptInstance>,
     envmaps: Vec<RsptEnvMap>, env_texels: Vec<Vec<f32>>, env_dist: Vec<Vec<f32>>,   // the Vecs own what the RsptEnvMap pointers refer to
     multi_lobes: bool,                                       // allow_multiple_lobes of the integrator (true for path / volpath)
+    textures: Vec<RsptTexture>, images: Vec<RsptImage>, image_texels: Vec<Vec<f32>>,   // image_texels owns what RsptImage.texels points to
+    texture_of: HashMap<*const u8, u32>, image_of: HashMap<*const u8, u32>,           // texture / MipMap object -> index (named textures are shared)
     mesh_of: HashMap<*const TriangleMesh, (u32, u32)>,     // mesh -> (mesh index, first vertex)
     material_of: HashMap<*const Material, u32>,
     object_of: HashMap<*const Primitive, u32>,               // instanced aggregate / primitive -> object index
@@ -82,11 +95,83 @@ impl Flat {
         Ok(self.media.len() as u32)
     }
 
+    /// One MipMap pyramid as rs_pbrt built it (mipmap.rs:56-196; texels already scaled / inverse-gamma-corrected and flipped by
+    /// ImageTexture::new, imagemap.rs:34-96), un-blocked: levels concatenated, row major [t][s]
+    fn image<T: ShimValue + num::Zero + Clone + std::ops::Add<T, Output = T>>(&mut self, mip: &Arc<MipMap<T>>) -> u32 {
+        let key = Arc::as_ptr(mip) as *const u8;
+        if let Some(i) = self.image_of.get(&key) { return *i; }
+        let mut tex: Vec<f32> = Vec::new();
+        for lvl in &mip.pyramid {
+            for t in 0..lvl.v_size() { for s in 0..lvl.u_size() { lvl[(s, t)].push(&mut tex); } }
+        }
+        self.image_texels.push(tex);
+        let tp = self.image_texels.last().unwrap().as_ptr();
+        self.images.push(RsptImage { width: mip.width() as u32, height: mip.height() as u32, n_levels: mip.levels() as u32, channels: T::CHANNELS, texels: tp });
+        let i = (self.images.len() - 1) as u32;
+        self.image_of.insert(key, i);
+        i
+    }
+
+    /// A texture graph as rspt_texture records (children first; indices are 0-based here, 1-based where a lobe / material / mesh refers to one)
+    fn texture<T: ShimValue + num::Zero + Clone + std::ops::Add<T, Output = T>>(&mut self, t: &Arc<dyn Texture<T> + Sync + Send>) -> Result<u32, String> {
+        let key = Arc::as_ptr(t) as *const u8;
+        if let Some(i) = self.texture_of.get(&key) { return Ok(*i); }
+        let mut rec = RsptTexture { world_to_texture: IDENTITY16, max_aniso: 8.0, ..RsptTexture::default() };
+        fn map2d(m: &TextureMapping2D, rec: &mut RsptTexture) {
+            match m {
+                TextureMapping2D::UV(u) => { rec.mapping = 1; rec.map[..4].copy_from_slice(&[u.su, u.sv, u.du, u.dv]); }          // texture.rs:91-121
+                TextureMapping2D::Planar(p) => { rec.mapping = 2; rec.map = [p.vs.x, p.vs.y, p.vs.z, p.vt.x, p.vt.y, p.vt.z, p.ds, p.dt]; } // :222-257
+                TextureMapping2D::Spherical(sp) => { rec.mapping = 3; rec.world_to_texture = m16(&sp.world_to_texture.m); }       // :123-170
+                TextureMapping2D::Cylindrical(c) => { rec.mapping = 4; rec.world_to_texture = m16(&c.world_to_texture.m); }       // :172-220
+            }
+        }
+        fn map3d(m: &TextureMapping3D, rec: &mut RsptTexture) {
+            match m { TextureMapping3D::Identity(i) => { rec.mapping = 5; rec.world_to_texture = m16(&i.world_to_texture.m); } }   // :259-283
+        }
+        match t.describe().ok_or("texture class without a GPU form")? {
+            TexDesc::Constant(v) => { rec.kind = 1; rec.value = v.rgb3(); }
+            TexDesc::Image(m, mip) => {
+                rec.kind = 2; map2d(m, &mut rec);
+                rec.image = self.image(mip); rec.trilinear = mip.do_trilinear as u32; rec.max_aniso = mip.max_anisotropy;
+                rec.wrap = match mip.wrap_mode { ImageWrap::Repeat => 0, ImageWrap::Black => 1, ImageWrap::Clamp => 2 };
+            }
+            TexDesc::Scale(a, b) => { rec.kind = 3; rec.tex1 = self.texture(a)?; rec.tex2 = self.texture(b)?; }
+            TexDesc::Mix(a, b, amount) => { rec.kind = 4; rec.tex1 = self.texture(a)?; rec.tex2 = self.texture(b)?; rec.tex3 = self.texture::<Float>(amount)?; }
+            TexDesc::Checkerboard(m, a, b) => { rec.kind = 5; map2d(m, &mut rec); rec.tex1 = self.texture(a)?; rec.tex2 = self.texture(b)?; }
+            TexDesc::Dots(m, outside, inside) => { rec.kind = 6; map2d(m, &mut rec); rec.tex1 = self.texture(outside)?; rec.tex2 = self.texture(inside)?; }
+            TexDesc::FBm(m, octaves, omega) => { rec.kind = 7; map3d(m, &mut rec); rec.octaves = octaves; rec.omega = omega; }
+            TexDesc::Marble(m, octaves, omega, scale, variation) => { rec.kind = 8; map3d(m, &mut rec); rec.octaves = octaves; rec.omega = omega; rec.scale = scale; rec.variation = variation; }
+            TexDesc::Windy(m) => { rec.kind = 9; map3d(m, &mut rec); }
+            TexDesc::Wrinkled(m, octaves, omega) => { rec.kind = 10; map3d(m, &mut rec); rec.octaves = octaves; rec.omega = omega; }
+        }
+        self.textures.push(rec);
+        let i = (self.textures.len() - 1) as u32;
+        self.texture_of.insert(key, i);
+        Ok(i)
+    }
+
+    /// A colour parameter a lobe is built from (rs_pbrt_amd/scenes.py `_col`): (constant factor, 0 or 1 + texture index, can be
+    /// non-black).  With a texture the factor is `scale` (uber's opacity) or 1 and the `is_black` test moves to shade time.
+    fn col(&mut self, t: &SpecTex, scale: Option<[f32; 3]>) -> Result<([f32; 3], u32, bool), String> {
+        let sc = scale.unwrap_or([1.0; 3]);
+        let some = |c: &[f32; 3]| c[0] != 0.0 || c[1] != 0.0 || c[2] != 0.0;
+        if let Some(v) = t.as_constant() { let c = rgb(&v); let r = [sc[0] * c[0], sc[1] * c[1], sc[2] * c[2]]; return Ok((r, 0, some(&r))); }
+        let ti = self.texture(t)?;
+        Ok((sc, ti + 1, some(&sc)))
+    }
+    /// A roughness parameter (scenes.py `_rough`): (alpha, 0) for a constant, (0.001, 1 + texture index) for a texture evaluated per hit
+    fn rough(&mut self, t: &FloatTex, remap: bool) -> Result<(f32, u32), String> {
+        if let Some(v) = t.as_constant() { return Ok((alpha(v, remap), 0)); }
+        Ok((0.001, self.texture(t)? + 1))
+    }
+    fn bump(&mut self, b: &Option<FloatTex>) -> Result<u32, String> { match b { Some(t) => Ok(self.texture(t)? + 1), None => Ok(0) } }
+
     /// all triangles of a mesh come from one Shape statement and share its MediumInterface (api.rs:2858-2870)
     fn mesh(&mut self, m: &Arc<TriangleMesh>, mi: &Option<Arc<MediumInterface>>) -> Result<(u32, u32), String> {
         let key = Arc::as_ptr(m);
         if let Some(v) = self.mesh_of.get(&key) { return Ok(*v); }
         let (medium_inside, medium_outside) = match mi { Some(i) => (self.medium(&i.inside)?, self.medium(&i.outside)?), None => (0, 0) };
+        let alpha_tex = self.bump(&m.alpha_mask)?; let shadow_alpha_tex = self.bump(&m.shadow_alpha_mask)?;   // same encoding as a bump map: 0 or 1 + index
         let first = (self.p.len() / 3) as u32;
         for q in &m.p { self.p.extend_from_slice(&[q.x, q.y, q.z]); }          // world space already (api.rs:1967-1971)
         for i in 0..m.p.len() {
@@ -97,43 +182,49 @@ impl Flat {
         self.any_n |= !m.n.is_empty(); self.any_s |= !m.s.is_empty(); self.any_uv |= !m.uv.is_empty();
         self.meshes.push(RsptMesh { has_n: !m.n.is_empty() as u32, has_s: !m.s.is_empty() as u32, has_uv: !m.uv.is_empty() as u32,
                                     flip: (m.reverse_orientation ^ m.transform_swaps_handedness) as u32, // triangle.rs:324
-                                    alpha_tex: 0, shadow_alpha_tex: 0,      // masks need the texture flattening this file does not have yet: checked in aggregate()
+                                    alpha_tex, shadow_alpha_tex,            // "alpha" / "shadowalpha" float textures (triangle.rs:39-40), 1-based
                                     medium_inside, medium_outside });
         let v = ((self.meshes.len() - 1) as u32, first);
         self.mesh_of.insert(key, v);
         Ok(v)
     }
 
-    /// Material::compute_scattering_functions with constant textures, evaluated once: the lobes in push order (SURVEY Appendix F,
-    /// the same recipes as rs_pbrt_amd/scenes.py).  `sc`: MixMaterial's scale for this side (mixmat.rs:52-56).  Returns the Bsdf's eta.
-    fn lobes_of(&mut self, m: &Material, sc: Option<[f32; 3]>) -> Result<f32, String> {
-        let cs = |t: &Arc<dyn crate::core::texture::Texture<Spectrum> + Sync + Send>| t.as_constant().map(|s| rgb(&s)).ok_or("non-constant spectrum texture".to_string());
-        let cf = |t: &Arc<dyn crate::core::texture::Texture<Float> + Sync + Send>| t.as_constant().ok_or("non-constant float texture".to_string());
+    /// Material::compute_scattering_functions evaluated once per material: the lobes in push order (the same
+    /// recipes as rs_pbrt_amd/scenes.py); parameters the library evaluates per hit keep their texture (col / rough / bump above).
+    /// `sc`: MixMaterial's scale for this side (mixmat.rs:52-56).  Returns (Bsdf.eta, bump_tex).
+    fn lobes_of(&mut self, m: &Material, sc: Option<[f32; 3]>) -> Result<(f32, u32), String> {
+        let cs = |t: &SpecTex| t.as_constant().map(|s| rgb(&s)).ok_or("textured parameter the library takes as a constant (spectrum)".to_string());
+        let cf = |t: &FloatTex| t.as_constant().ok_or("textured parameter the library takes as a constant (float)".to_string());
         let black = |c: &[f32; 3]| c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0;
         let mul = |a: &[f32; 3], b: &[f32; 3]| [a[0] * b[0], a[1] * b[1], a[2] * b[2]];
-        let mut eta = 1.0f32;
+        let no_bump = |b: &Option<FloatTex>| if b.is_some() { Err("bump map on a material the library takes without one".to_string()) } else { Ok(()) };
+        let mut eta = 1.0f32; let mut bump_tex = 0u32;
         let lobe = match sc { Some(v) => RsptBxdf { sc: v, has_sc: 1, ..RsptBxdf::default() }, None => RsptBxdf::default() };
         match m {
             Material::Matte(mm) => {                                               // matte.rs:43-86
-                if mm.bump_map.is_some() { return Err("bump map".into()); }
-                let r = cs(&mm.kd)?; let sig = cf(&mm.sigma)?.max(0.0).min(90.0);
-                if !black(&r) {
-                    if sig == 0.0 { self.bxdfs.push(RsptBxdf { kind: 1, r, ..lobe }); }
+                bump_tex = self.bump(&mm.bump_map)?;
+                let (r, tex_r, any) = self.col(&mm.kd, None)?; let sig = cf(&mm.sigma)?.max(0.0).min(90.0);
+                if any {
+                    if sig == 0.0 { self.bxdfs.push(RsptBxdf { kind: 1, r, tex_r, ..lobe }); }
                     else {                                                          // OrenNayar::new reflection.rs:1057-1065
                         let s = (std::f32::consts::PI / 180.0) * sig; let s2 = s * s;
-                        self.bxdfs.push(RsptBxdf { kind: 2, r, on_a: 1.0 - s2 / (2.0 * (s2 + 0.33)), on_b: 0.45 * s2 / (s2 + 0.09), ..lobe });
+                        self.bxdfs.push(RsptBxdf { kind: 2, r, tex_r, on_a: 1.0 - s2 / (2.0 * (s2 + 0.33)), on_b: 0.45 * s2 / (s2 + 0.09), ..lobe });
                     }
                 }
             }
             Material::Plastic(pm) => {                                             // plastic.rs:57-125
-                if pm.bump_map.is_some() { return Err("bump map".into()); }
-                let kd = cs(&pm.kd)?; let ks = cs(&pm.ks)?; let a = alpha(cf(&pm.roughness)?, pm.remap_roughness);
-                if !black(&kd) { self.bxdfs.push(RsptBxdf { kind: 1, r: kd, ..lobe }); }
-                if !black(&ks) { self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 1, r: ks, eta_a: 1.5, eta_b: 1.0, alpha_x: a, alpha_y: a, ..lobe }); }
+                bump_tex = self.bump(&pm.bump_map)?;
+                let (kd, tkd, any_kd) = self.col(&pm.kd, None)?; let (ks, tks, any_ks) = self.col(&pm.ks, None)?;
+                if any_kd { self.bxdfs.push(RsptBxdf { kind: 1, r: kd, tex_r: tkd, ..lobe }); }
+                if any_ks {
+                    let (a, ta) = self.rough(&pm.roughness, pm.remap_roughness)?;
+                    self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 1, r: ks, tex_r: tks, eta_a: 1.5, eta_b: 1.0, alpha_x: a, alpha_y: a, tex_ax: ta, tex_ay: ta,
+                                               remap: pm.remap_roughness as u32, ..lobe });
+                }
             }
-            Material::Mirror(mm) => { self.bxdfs.push(RsptBxdf { kind: 3, fresnel: 0, r: cs(&mm.kr)?, ..lobe }); } // mirror.rs:34-70, pushed even if black
+            Material::Mirror(mm) => { no_bump(&mm.bump_map)?; self.bxdfs.push(RsptBxdf { kind: 3, fresnel: 0, r: cs(&mm.kr)?, ..lobe }); } // mirror.rs:34-70, pushed even if black
             Material::Glass(gm) => {                                               // glass.rs:83-211
-                if gm.bump_map.is_some() { return Err("bump map".into()); }
+                no_bump(&gm.bump_map)?;
                 eta = cf(&gm.index)?;
                 let (ur, vr) = (cf(&gm.u_roughness)?, cf(&gm.v_roughness)?);
                 let r = cs(&gm.kr)?; let t = cs(&gm.kt)?;
@@ -153,32 +244,34 @@ impl Flat {
                 }
             }
             Material::Metal(mm) => {                                               // metal.rs:144-205
-                if mm.bump_map.is_some() { return Err("bump map".into()); }
-                let ru = match &mm.u_roughness { Some(t) => cf(t)?, None => cf(&mm.roughness)? };
-                let rv = match &mm.v_roughness { Some(t) => cf(t)?, None => cf(&mm.roughness)? };
-                self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 2, r: [1.0; 3], c1: cs(&mm.eta)?, c2: cs(&mm.k)?,
-                                           alpha_x: alpha(ru, mm.remap_roughness), alpha_y: alpha(rv, mm.remap_roughness), ..lobe });
+                no_bump(&mm.bump_map)?;
+                let (ax, tax) = self.rough(match &mm.u_roughness { Some(t) => t, None => &mm.roughness }, mm.remap_roughness)?;
+                let (ay, tay) = self.rough(match &mm.v_roughness { Some(t) => t, None => &mm.roughness }, mm.remap_roughness)?;
+                self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 2, r: [1.0; 3], c1: cs(&mm.eta)?, c2: cs(&mm.k)?, alpha_x: ax, alpha_y: ay, tex_ax: tax, tex_ay: tay,
+                                           remap: mm.remap_roughness as u32, ..lobe });
             }
             Material::Substrate(sm) => {                                           // substrate.rs:62-114: one FresnelBlend lobe
-                if sm.bump_map.is_some() { return Err("bump map".into()); }
-                let d = cs(&sm.kd)?; let sp = cs(&sm.ks)?;
-                if !(black(&d) && black(&sp)) {
-                    self.bxdfs.push(RsptBxdf { kind: 9, r: d, t: sp, alpha_x: alpha(cf(&sm.nu)?, sm.remap_roughness), alpha_y: alpha(cf(&sm.nv)?, sm.remap_roughness), ..lobe });
+                bump_tex = self.bump(&sm.bump_map)?;
+                let (d, td, any_d) = self.col(&sm.kd, None)?; let (sp, ts, any_s) = self.col(&sm.ks, None)?;
+                if any_d || any_s {
+                    let (ax, tax) = self.rough(&sm.nu, sm.remap_roughness)?; let (ay, tay) = self.rough(&sm.nv, sm.remap_roughness)?;
+                    self.bxdfs.push(RsptBxdf { kind: 9, r: d, t: sp, tex_r: td, tex_t: ts, alpha_x: ax, alpha_y: ay, tex_ax: tax, tex_ay: tay, remap: sm.remap_roughness as u32, ..lobe });
                 }
             }
             Material::Uber(um) => {                                                // uber.rs:114-259
-                if um.bump_map.is_some() { return Err("bump map".into()); }
+                bump_tex = self.bump(&um.bump_map)?;
                 let e = cf(&um.eta)?;
                 let op = cs(&um.opacity)?;
                 let t = [(1.0 - op[0]).max(0.0), (1.0 - op[1]).max(0.0), (1.0 - op[2]).max(0.0)];
                 if !black(&t) { self.bxdfs.push(RsptBxdf { kind: 4, r: t, eta_a: 1.0, eta_b: 1.0, ..lobe }); } else { eta = e; }
-                let kd = mul(&op, &cs(&um.kd)?);
-                if !black(&kd) { self.bxdfs.push(RsptBxdf { kind: 1, r: kd, ..lobe }); }
-                let ks = mul(&op, &cs(&um.ks)?);
-                if !black(&ks) {
-                    let ru = match &um.u_roughness { Some(t) => cf(t)?, None => cf(&um.roughness)? };
-                    let rv = match &um.v_roughness { Some(t) => cf(t)?, None => cf(&um.roughness)? };
-                    self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 1, r: ks, eta_a: 1.0, eta_b: e, alpha_x: alpha(ru, um.remap_roughness), alpha_y: alpha(rv, um.remap_roughness), ..lobe });
+                let (kd, tkd, any_kd) = self.col(&um.kd, Some(op))?;
+                if any_kd { self.bxdfs.push(RsptBxdf { kind: 1, r: kd, tex_r: tkd, ..lobe }); }
+                let (ks, tks, any_ks) = self.col(&um.ks, Some(op))?;
+                if any_ks {
+                    let (ax, tax) = self.rough(match &um.u_roughness { Some(t) => t, None => &um.roughness }, um.remap_roughness)?;
+                    let (ay, tay) = self.rough(match &um.v_roughness { Some(t) => t, None => &um.roughness }, um.remap_roughness)?;
+                    self.bxdfs.push(RsptBxdf { kind: 6, fresnel: 1, r: ks, tex_r: tks, eta_a: 1.0, eta_b: e, alpha_x: ax, alpha_y: ay, tex_ax: tax, tex_ay: tay,
+                                               remap: um.remap_roughness as u32, ..lobe });
                 }
                 let kr = mul(&op, &cs(&um.kr)?);
                 if !black(&kr) { self.bxdfs.push(RsptBxdf { kind: 3, fresnel: 1, r: kr, eta_a: 1.0, eta_b: e, ..lobe }); }
@@ -186,7 +279,7 @@ impl Flat {
                 if !black(&kt) { self.bxdfs.push(RsptBxdf { kind: 4, r: kt, eta_a: 1.0, eta_b: e, ..lobe }); }
             }
             Material::Translucent(tm) => {                                         // translucent.rs:64-189
-                if tm.bump_map.is_some() { return Err("bump map".into()); }
+                no_bump(&tm.bump_map)?;
                 eta = 1.5;
                 let r = cs(&tm.reflect)?; let t = cs(&tm.transmit)?;
                 if !(black(&r) && black(&t)) {
@@ -206,12 +299,14 @@ impl Flat {
                 if sc.is_some() { return Err("nested mix material".into()); }      // (an inner MixMaterial ignores the scale it is handed, :50)
                 let s1 = cs(&mx.scale)?;
                 let s2 = [(1.0 - s1[0]).max(0.0), (1.0 - s1[1]).max(0.0), (1.0 - s1[2]).max(0.0)];
-                eta = self.lobes_of(&mx.m1, Some(s1))?;                            // si.bsdf is m1's, with its eta (:71-76)
-                self.lobes_of(&mx.m2, Some(s2))?;
+                let (e1, b1) = self.lobes_of(&mx.m1, Some(s1))?;                   // si.bsdf is m1's, with its eta (:71-76)
+                let (_, b2) = self.lobes_of(&mx.m2, Some(s2))?;
+                if b1 != 0 || b2 != 0 { return Err("bump map under a mix material (each side bumps its own copy of the interaction, :58-76)".into()); }
+                eta = e1;
             }
             _ => return Err("material without a recipe (disney / hair / fourier / subsurface / kdsubsurface)".into()),
         }
-        Ok(eta)
+        Ok((eta, bump_tex))
     }
 
     fn material(&mut self, m: &Option<Arc<Material>>) -> Result<u32, String> {
@@ -219,10 +314,10 @@ impl Flat {
         let key = Arc::as_ptr(m);
         if let Some(i) = self.material_of.get(&key) { return Ok(*i); }
         let first = self.bxdfs.len() as u32;
-        let eta = self.lobes_of(m, None)?;
+        let (eta, bump_tex) = self.lobes_of(m, None)?;
         let n = self.bxdfs.len() as u32 - first;
         if n > 8 { return Err("more than 8 lobes (reflection.rs:40)".into()); }
-        self.materials.push(RsptMaterial { eta, first_bxdf: first, n_bxdfs: n, bump_tex: 0 });
+        self.materials.push(RsptMaterial { eta, first_bxdf: first, n_bxdfs: n, bump_tex });
         let i = (self.materials.len() - 1) as u32;
         self.material_of.insert(key, i);
         Ok(i)
@@ -242,7 +337,6 @@ impl Flat {
             match &**prim {
                 Primitive::Geometric(g) => {
                     let tri = match &*g.shape { Shape::Trngl(t) => t, _ => return Err("non-triangle shape".into()) };
-                    if tri.mesh().alpha_mask.is_some() || tri.mesh().shadow_alpha_mask.is_some() { return Err("alpha-masked mesh (textures are not flattened by the shim yet)".into()); }
                     let (mesh, first) = self.mesh(tri.mesh(), &g.medium_interface)?; // Triangle.mesh getter: rs_pbrt.patch (triangle.rs:85)
                     let vi = &tri.mesh().vertex_indices[3 * tri.id as usize..3 * tri.id as usize + 3];
                     let area_light = match &g.area_light {                         // the reference compares these pointers (integrator.rs:540-543)
@@ -403,7 +497,8 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
         materials: f.materials.as_ptr(), n_materials: f.materials.len() as u32, bxdfs: f.bxdfs.as_ptr(), n_bxdfs: f.bxdfs.len() as u32,
         lights: f.lights.as_ptr(), n_lights: f.lights.len() as u32,
         envmaps: if f.envmaps.is_empty() { std::ptr::null() } else { f.envmaps.as_ptr() }, n_envmaps: f.envmaps.len() as u32,
-        textures: std::ptr::null(), n_textures: 0, images: std::ptr::null(), n_images: 0,
+        textures: if f.textures.is_empty() { std::ptr::null() } else { f.textures.as_ptr() }, n_textures: f.textures.len() as u32,
+        images: if f.images.is_empty() { std::ptr::null() } else { f.images.as_ptr() }, n_images: f.images.len() as u32,
         objects: f.objects.as_ptr(), n_objects: f.objects.len() as u32, instances: f.instances.as_ptr(), n_instances: f.instances.len() as u32,
         n_top_nodes, n_top_prims, instancing_mode: (std::env::var_os("RSPT_INSTANCING_FIXED").is_some()) as u32,
         n_media: f.media.len() as u32, media: if f.media.is_empty() { std::ptr::null() } else { f.media.as_ptr() },
