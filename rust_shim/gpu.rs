@@ -4,8 +4,8 @@
 //! returns Err and `SamplerIntegrator::render` keeps its CPU tile loop (src/core/integrator.rs:70-220).
 //!
 //! Covered: triangle meshes (Shape::Trngl) under a BVHAccel aggregate, object instances (Primitive::Transformed, static),
-//! matte / plastic / mirror / glass (smooth and rough) / metal / substrate / uber / translucent / mix with constant textures
-//! (Texture::as_constant, added by the patch), diffuse area / point / spot / distant / infinite lights (the light's own MIP
+//! matte / plastic / mirror / glass (smooth and rough) / metal / substrate / uber / translucent / mix (recipes evaluated once per
+//! material through Texture::as_constant, added by the patch), diffuse area / point / spot / distant / infinite lights (the light's own MIP
 //! pyramid and Distribution2D image are handed over), homogeneous media, PerspectiveCamera, the Sobol', Halton and the four
 //! PCG-backed pixel samplers, the path / ao / directlighting / volpath integrators, any filter (through Film.filter_table).
 //! Image / procedural textures (every class of src/textures/, through Texture::describe of rs_pbrt.patch) where the library
