@@ -251,19 +251,30 @@ def _with_bump(m, bump):
 
 
 def _pbrt_rgb(name, v):
+    """a colour parameter of a Material directive: an rgb triple, or a reference to the named texture tools/export_pbrt.py declares
+    for texture record `index` ("tex<index>")"""
+    if isinstance(v, TexRef):
+        return '"texture %s" "tex%d"' % (name, v.index)
     v = np.broadcast_to(np.asarray(v, F32), (3,))
     return '"rgb %s" [%.9g %.9g %.9g]' % (name, v[0], v[1], v[2])
 
 
+def _pbrt_float(name, v):
+    return '"texture %s" "tex%d"' % (name, v.index) if isinstance(v, TexRef) else '"float %s" [%.9g]' % (name, float(v))
+
+
+def _pbrt_bump(bump):
+    return "" if bump is None else ' "texture bumpmap" "tex%d"' % bump.index
+
+
 def _pbrt(m, text, *params):
-    """the `Material` directive that makes rs_pbrt build this recipe (tools/export_pbrt.py); None when a parameter is a texture"""
-    m["pbrt"] = None if any(isinstance(p, TexRef) for p in params) else text
+    """the `Material` directive that makes rs_pbrt build this recipe (tools/export_pbrt.py)"""
+    m["pbrt"] = text
     return m
 
 
 def matte(kd, sigma=0.0, bump=None):  # matte.rs:43-86
-    return _pbrt(_matte(kd, sigma, bump), None if isinstance(kd, TexRef) or bump is not None else
-                 'Material "matte" %s "float sigma" [%.9g]' % (_pbrt_rgb("Kd", kd), float(sigma)), kd)
+    return _pbrt(_matte(kd, sigma, bump), 'Material "matte" %s "float sigma" [%.9g]%s' % (_pbrt_rgb("Kd", kd), float(sigma), _pbrt_bump(bump)), kd)
 
 
 def _matte(kd, sigma=0.0, bump=None):
@@ -280,9 +291,8 @@ def _matte(kd, sigma=0.0, bump=None):
 
 
 def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True, bump=None):  # plastic.rs:57-125
-    tex = any(isinstance(x, TexRef) for x in (kd, ks, roughness)) or bump is not None
-    return _pbrt(_plastic(kd, ks, roughness, remap, bump), None if tex else 'Material "plastic" %s %s "float roughness" [%.9g] "bool remaproughness" ["%s"]'
-                 % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), float(roughness), "true" if remap else "false"))
+    return _pbrt(_plastic(kd, ks, roughness, remap, bump), 'Material "plastic" %s %s %s "bool remaproughness" ["%s"]%s'
+                 % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_float("roughness", roughness), "true" if remap else "false", _pbrt_bump(bump)))
 
 
 def _plastic(kd, ks, roughness, remap, bump):
@@ -315,16 +325,18 @@ def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, multiple_lobes=True):  # glas
 
 
 def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True):  # metal.rs:144-205
-    return dict(pbrt=None if isinstance(roughness, TexRef) else 'Material "metal" %s %s "float roughness" [%.9g] "bool remaproughness" ["%s"]'
-                % (_pbrt_rgb("eta", eta), _pbrt_rgb("k", k), float(roughness), "true" if remap else "false"), eta=1.0, lobes=[_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_CONDUCTOR, r=(1, 1, 1), c1=eta, c2=k,
+    return dict(pbrt='Material "metal" %s %s %s "bool remaproughness" ["%s"]'
+                % (_pbrt_rgb("eta", eta), _pbrt_rgb("k", k), _pbrt_float("roughness", roughness), "true" if remap else "false"), eta=1.0, lobes=[_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_CONDUCTOR, r=(1, 1, 1), c1=eta, c2=k,
                                       **_rough(roughness, roughness, remap))])
 
 
 def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True, bump=None):  # substrate.rs:62-114
+    text = 'Material "substrate" %s %s %s %s "bool remaproughness" ["%s"]%s' % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_float("uroughness", uroughness),
+                                                                             _pbrt_float("vroughness", vroughness), "true" if remap else "false", _pbrt_bump(bump))
     kd, tkd, any_kd = _col(kd); ks, tks, any_ks = _col(ks)
     if not any_kd and not any_ks:
-        return _with_bump(dict(eta=1.0, lobes=[]), bump)
-    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, tex_r=tkd, tex_t=tks, **_rough(uroughness, vroughness, remap))]), bump)
+        return _with_bump(dict(eta=1.0, lobes=[], pbrt=text), bump)
+    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, tex_r=tkd, tex_t=tks, **_rough(uroughness, vroughness, remap))], pbrt=text), bump)
 
 
 def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness=0.1, uroughness=None, vroughness=None,
@@ -1052,12 +1064,28 @@ def cornell_box(bvh_builder, variant="matte", fog=None):
         tall_m = sb.add_material(metal(roughness=0.1))
         short_m = sb.add_material(matte((0.5, 0.5, 0.7), sigma=30.0))
         floor_m = sb.add_material(plastic((0.4, 0.4, 0.4), (0.3, 0.3, 0.3), 0.2))
-    q = sb.add_quad
+    back_m, left_m, right_m = white, green, red
+    if variant == "procedural":
+        # every procedural texture class of src/textures/ (no image files: tools/export_pbrt.py can hand the scene to rs_pbrt as text):
+        # 2-D mappings on the quads' uv, 3-D noise in world space scaled to the room, float textures behind roughness and bump
+        c = sb.constant_texture
+        w2t = lambda k: Transform.scale(k, k, k).m  # noqa: E731
+        floor_m = sb.add_material(matte(sb.checkerboard_texture(c((0.725, 0.71, 0.68)), c((0.2, 0.2, 0.25)), su=6.0, sv=6.0),
+                                        bump=sb.scale_texture(sb.windy_texture(world_to_texture=w2t(0.02)), c(3.0))))
+        back_m = sb.add_material(matte(sb.marble_texture(octaves=6, omega=0.5, scale=3.0, variation=0.3, world_to_texture=w2t(0.01))))
+        left_m = sb.add_material(matte(sb.mix_texture(c((0.14, 0.45, 0.091)), c((0.7, 0.65, 0.1)), sb.fbm_texture(octaves=5, omega=0.6, world_to_texture=w2t(0.02)))))
+        right_m = sb.add_material(matte(sb.dots_texture(c((0.63, 0.065, 0.05)), c((0.725, 0.71, 0.68)), su=7.0, sv=7.0)))
+        short_m = sb.add_material(plastic(sb.scale_texture(c((0.8, 0.8, 0.75)), sb.wrinkled_texture(octaves=6, omega=0.5, world_to_texture=w2t(0.03))), (0.3, 0.3, 0.3),
+                                          sb.scale_texture(sb.wrinkled_texture(octaves=4, omega=0.5, world_to_texture=w2t(0.05)), c(0.25))))
+        tall_m = sb.add_material(substrate(sb.checkerboard_texture(c((0.1, 0.3, 0.6)), c((0.6, 0.5, 0.1)), mapping="planar", v1=(0.02, 0, 0), v2=(0, 0.02, 0)),
+                                           (0.25, 0.25, 0.25), sb.dots_texture(c(0.05), c(0.3), su=4.0, sv=4.0), 0.1))
+    uvq = dict(UV=[[0, 0], [1, 0], [1, 1], [0, 1]]) if variant == "procedural" else {}
+    q = lambda p, m, **kw: sb.add_quad(p, m, **dict(uvq, **kw))  # noqa: E731
     q([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)], floor_m)
     q([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)], white)
-    q([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)], white)
-    q([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)], green)
-    q([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)], red)
+    q([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)], back_m)
+    q([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)], left_m)
+    q([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)], right_m)
     # light: emits downwards; vertex order chosen so cross(p0-p2, p1-p2) points to -y
     q([(343, 548.7, 227), (343, 548.7, 332), (213, 548.7, 332), (213, 548.7, 227)], white, emit=(17, 12, 4))
     for quads, m in (([[(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)],

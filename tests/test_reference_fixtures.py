@@ -28,6 +28,27 @@ def test_scene_files_for_the_reference_are_current():
     assert before == after and any(f.endswith(".pbrt") for f in after)
 
 
+def test_exported_texture_directives_follow_make_texture(oracle):
+    """the procedural Cornell variant as text for rs_pbrt: float / spectrum namespaces by use, the dots argument swap of api.rs:1228 /
+    :1531, a 3-D mapping's world_to_texture as the CTM (Transform reads columns), materials referring to textures by name — and the
+    scene itself renders in the oracle with every texture class contributing"""
+    text = open(os.path.join(HERE, "golden", "ref_scenes", "cornell_procedural.pbrt")).read()
+    for cls in ("constant", "scale", "mix", "checkerboard", "dots", "fbm", "wrinkled", "windy", "marble"):
+        assert '" "%s"' % cls in text, cls
+    assert 'Texture "tex3" "float" "windy"' in text and '"spectrum" "marble"' in text and '"float" "checkerboard"' not in text
+    dots = [l for l in text.splitlines() if '"spectrum" "dots"' in l][0]
+    assert dots.index('"rgb inside" [0.629999995') < dots.index('"rgb outside" [0.725000024')   # scenes: dots_texture(outside = red, inside = white)
+    assert "Transform [0.0199999996 0 0 0 0 0.0199999996 0 0 0 0 0.0199999996 0 0 0 0 1]" in text
+    assert 'Material "matte" "texture Kd" "tex2" "float sigma" [0] "texture bumpmap" "tex5"' in text
+    assert '"texture roughness" "tex' in text and '"texture uroughness" "tex' in text and '"float uv" [0 0 1 0 1 1 0 1]' in text
+    from rs_pbrt_amd import lib
+    sc = scenes.cornell_box(lib.bvh_build, "procedural")
+    a = oracle.render(sc, scenes.cornell_render_desc(res=32, spp=4), threads=4)
+    b = oracle.render(scenes.cornell_box(lib.bvh_build, "matte"), scenes.cornell_render_desc(res=32, spp=4), threads=4)
+    assert a["counters"]["nan_samples"] == 0 and np.isfinite(a["film"]).all()
+    assert np.array_equal(a["film"][:, 3], b["film"][:, 3]) and not np.allclose(a["film"][:, :3], b["film"][:, :3], atol=1e-3)
+
+
 @pytest.mark.skipif(not FIXTURES, reason="parity unpinned: no tests/golden/ref_*.npz (made from real rs_pbrt by rust_shim/refdump.rs) is committed yet")
 @pytest.mark.parametrize("path", FIXTURES or ["-"])
 def test_oracle_against_rs_pbrt_output(oracle, path):

@@ -4,10 +4,17 @@ reference fixtures for the oracle (rust_shim/refdump.rs -> tools/ref_to_npz.py -
 
     python tools/export_pbrt.py            # (re)writes tests/golden/ref_scenes/*.pbrt and their rays.bin
 
-Covers what rs_pbrt's own parser + API produce for: triangle meshes in world space, the constant-parameter materials that carry a
-"pbrt" string (rs_pbrt_amd/scenes.py), diffuse area lights, point / spot / distant lights, a LookAt + perspective camera, box
-filter, every sampler the library takes (Sobol', Halton, random, 02sequence, stratified, maxmindist), homogeneous media with
-MediumInterface per shape, `path` / `volpath`."""
+Covers what rs_pbrt's own parser + API produce for: triangle meshes in world space (with uv / normals), the materials that carry a
+"pbrt" string (rs_pbrt_amd/scenes.py: matte, plastic, mirror, glass, metal, substrate — colour / roughness / bump parameters may be
+textures), the procedural texture classes (constant, scale, mix, checkerboard, dots, fbm, wrinkled, windy, marble; image textures
+are left out: an 8-bit file would not carry the generator's float texels), diffuse area lights, point lights, a LookAt + perspective
+camera, box filter, every sampler the library takes (Sobol', Halton, random, 02sequence, stratified, maxmindist), homogeneous media
+with MediumInterface per shape, `path` / `volpath`.
+
+Texture directives follow make_texture (api.rs:1039-1600), quirks included: the float namespace has no checkerboard and no marble
+(":1175 TODO", ":1263 TODO"); `DotsTexture::new(mapping, inside, outside)` is called with the arguments of a constructor declared
+`(mapping, outside_dot, inside_dot)` (api.rs:1228, :1531 vs dots.rs:19-23), so the directive's "inside" is the record's outside;
+a 3-D mapping's world_to_texture is the CTM at the directive (IdentityMapping3D::new(tex_2_world), :1242)."""
 import os
 import sys
 
@@ -31,9 +38,86 @@ def sampler_directive(sampler, spp, dimensions=4, strat=(4, 4), jitter=True):
     return 'Sampler "%s" "integer pixelsamples" [%d] "integer dimensions" [%d]' % (sampler, spp, dimensions)   # 02sequence / lowdiscrepancy / maxmindist
 
 
+def texture_directives(sb):
+    """Texture directives for the builder's texture records, children first; float or spectrum by how each record is used"""
+    from rs_pbrt_amd import abi
+    T = sb.textures
+    kind_of = {}   # index -> "float" | "spectrum"
+
+    def mark(i, ty):
+        assert kind_of.get(i, ty) == ty, "texture %d is used both as a float and as a spectrum texture: declare it twice" % i
+        if i in kind_of:
+            return
+        kind_of[i] = ty
+        k = int(T[i]["kind"])
+        if k in (abi.TEX_SCALE, abi.TEX_MIX, abi.TEX_CHECKERBOARD, abi.TEX_DOTS):
+            mark(int(T[i]["tex1"]), ty); mark(int(T[i]["tex2"]), ty)
+        if k == abi.TEX_MIX:
+            mark(int(T[i]["tex3"]), "float")
+    for m in sb.materials:
+        if m.get("bump") is not None:
+            mark(int(m["bump"]), "float")
+        for lb in m["lobes"]:
+            for key, ty in (("tex_r", "spectrum"), ("tex_t", "spectrum"), ("tex_ax", "float"), ("tex_ay", "float")):
+                if int(lb[key]):
+                    mark(int(lb[key]) - 1, ty)
+    for fl in sb.meshes:
+        for a in (fl[4], fl[5]):
+            if a:
+                mark(int(a) - 1, "float")
+
+    def child(name, i, ty):   # a constant child is written inline, anything else by name
+        if int(T[i]["kind"]) == abi.TEX_CONSTANT:
+            return '"rgb %s" [%s]' % (name, f(T[i]["value"])) if ty == "spectrum" else '"float %s" [%.9g]' % (name, float(T[i]["value"][0]))
+        return '"texture %s" "tex%d"' % (name, i)
+
+    def mapping2d(t):
+        mk = int(t["mapping"])
+        if mk == abi.MAP_UV:
+            return '"string mapping" ["uv"] "float uscale" [%.9g] "float vscale" [%.9g] "float udelta" [%.9g] "float vdelta" [%.9g]' % tuple(float(x) for x in t["map"][:4])
+        if mk == abi.MAP_PLANAR:
+            return '"string mapping" ["planar"] "vector v1" [%s] "vector v2" [%s] "float udelta" [%.9g] "float vdelta" [%.9g]' % (
+                f(t["map"][:3]), f(t["map"][3:6]), float(t["map"][6]), float(t["map"][7]))
+        return '"string mapping" ["%s"]' % {abi.MAP_SPHERICAL: "spherical", abi.MAP_CYLINDRICAL: "cylindrical"}[mk]
+
+    out = []
+    for i in sorted(kind_of):   # records are appended children first (SceneBuilder), so index order is declaration order
+        t, ty = T[i], kind_of[i]
+        k = int(t["kind"])
+        head = 'Texture "tex%d" "%s"' % (i, ty)
+        uses_ctm = k in (abi.TEX_FBM, abi.TEX_WRINKLED, abi.TEX_WINDY, abi.TEX_MARBLE) or int(t["mapping"]) in (abi.MAP_SPHERICAL, abi.MAP_CYLINDRICAL)
+        if k == abi.TEX_CONSTANT:
+            line = head + ' "constant" ' + ('"rgb value" [%s]' % f(t["value"]) if ty == "spectrum" else '"float value" [%.9g]' % float(t["value"][0]))
+        elif k == abi.TEX_SCALE:
+            line = head + ' "scale" %s %s' % (child("tex1", int(t["tex1"]), ty), child("tex2", int(t["tex2"]), ty))
+        elif k == abi.TEX_MIX:
+            line = head + ' "mix" %s %s %s' % (child("tex1", int(t["tex1"]), ty), child("tex2", int(t["tex2"]), ty), child("amount", int(t["tex3"]), "float"))
+        elif k == abi.TEX_CHECKERBOARD:
+            assert ty == "spectrum", "rs_pbrt has no float checkerboard (api.rs:1175)"
+            line = head + ' "checkerboard" "integer dimension" [2] %s %s %s' % (child("tex1", int(t["tex1"]), ty), child("tex2", int(t["tex2"]), ty), mapping2d(t))
+        elif k == abi.TEX_DOTS:   # record: tex1 = outside_dot, tex2 = inside_dot; the API hands "inside" to the outside_dot slot
+            line = head + ' "dots" %s %s %s' % (child("inside", int(t["tex1"]), ty), child("outside", int(t["tex2"]), ty), mapping2d(t))
+        elif k in (abi.TEX_FBM, abi.TEX_WRINKLED):
+            line = head + ' "%s" "integer octaves" [%d] "float roughness" [%.9g]' % ("fbm" if k == abi.TEX_FBM else "wrinkled", int(t["octaves"]), float(t["omega"]))
+        elif k == abi.TEX_WINDY:
+            line = head + ' "windy"'
+        elif k == abi.TEX_MARBLE:
+            assert ty == "spectrum", "rs_pbrt has no float marble (api.rs:1263)"
+            line = head + ' "marble" "integer octaves" [%d] "float roughness" [%.9g] "float scale" [%.9g] "float variation" [%.9g]' % (
+                int(t["octaves"]), float(t["omega"]), float(t["scale"]), float(t["variation"]))
+        else:
+            raise NotImplementedError("exporter: texture kind %d (image textures need a file format that keeps float texels)" % k)
+        if uses_ctm:   # the Transform directive reads its 16 numbers column by column (bin/rs_pbrt.rs:729-748)
+            w = np.asarray(t["world_to_texture"], np.float32).reshape(4, 4)
+            out += ["TransformBegin", "  Transform [%s]" % f(w.T), "  " + line, "TransformEnd"]
+        else:
+            out.append(line)
+    return out
+
+
 def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **sampler_kw):
     sb = sc.builder
-    assert sb is not None and not sb.instances and not sb.textures and not sb.envmaps, "not covered by the exporter"
+    assert sb is not None and not sb.instances and not sb.images and not sb.envmaps, "not covered by the exporter"
     out = ["# generated by tools/export_pbrt.py from rs_pbrt_amd/scenes.py — do not edit",
            "LookAt %s  %s  %s" % tuple(f(v) for v in look_at),
            'Camera "perspective" "float fov" [%.9g]' % fov,
@@ -45,6 +129,7 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
     for k, md in enumerate(sb.media):   # MakeNamedMedium (api.rs:953-1037): sigma_a / sigma_s are already scaled in the builder
         out.append('MakeNamedMedium "medium%d" "string type" ["homogeneous"] "rgb sigma_a" [%s] "rgb sigma_s" [%s] "float g" [%.9g] "float scale" [1]' % (
             k + 1, f(md["sigma_a"]), f(md["sigma_s"]), float(md["g"])))
+    out += texture_directives(sb)
     for lt in sb.delta_lights:
         from rs_pbrt_amd import abi
         if lt["kind"] == abi.LIGHT_POINT:
@@ -65,7 +150,15 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
             out.append("  ReverseOrientation")
         first = sum(len(p) for p in sb.P[:m])
         idx = sb.tris[m].astype(np.int64) - first
-        out.append('  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]' % (" ".join(str(int(i)) for i in idx.reshape(-1)), f(sb.P[m])))
+        extra = ""
+        if flags[0]:
+            extra += ' "normal N" [%s]' % f(sb.N[m])
+        if flags[2]:
+            extra += ' "float uv" [%s]' % f(sb.UV[m])
+        for key, a in (("alpha", flags[4]), ("shadowalpha", flags[5])):   # float textures by name (api.rs:1920-1965)
+            if a:
+                extra += ' "texture %s" "tex%d"' % (key, a - 1)
+        out.append('  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]%s' % (" ".join(str(int(i)) for i in idx.reshape(-1)), f(sb.P[m]), extra))
         out.append("AttributeEnd")
     out.append("WorldEnd")
     open(path, "w").write("\n".join(out) + "\n")
@@ -82,6 +175,8 @@ SCENES = {
     "cornell_random": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 80, 80, 16, 5),
     "cornell_stratified": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 80, 80, 16, 5),
     "cornell_maxmindist": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 80, 80, 16, 5),
+    # the texture stage: every procedural texture class, 2-D and 3-D mappings, float textures behind roughness and bump
+    "cornell_procedural": (lambda b, s: s.cornell_box(b, "procedural"), "CORNELL", 64, 64, 16, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
