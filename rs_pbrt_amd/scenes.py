@@ -560,6 +560,7 @@ def build_image(texels, wrap=abi.WRAP_REPEAT, scale=1.0, gamma=False, channels=3
 class SceneBuilder:
     def __init__(self):
         self.P, self.N, self.UV, self.tris, self.tri_mesh = [], [], [], [], []
+        self.image_src = {}   # image index -> the 8-bit source of an image_texture_u8
         self.meshes, self.mesh_material, self.mesh_emit = [], [], []
         self.media = []
         self.materials = []
@@ -611,6 +612,14 @@ class SceneBuilder:
         self.images.append(build_image(texels, wm, scale, gamma, channels))
         return self._add_texture(kind=abi.TEX_IMAGE, image=len(self.images) - 1, trilinear=int(trilinear), max_aniso=max_aniso, wrap=wm,
                                  **self._mapping2d(mapping, su, sv, du, dv, v1, v2, world_to_texture))
+
+    def image_texture_u8(self, rgb8, **kw):
+        """An image texture whose texels are what ImageTexture::new reads from an 8-bit file: Float::from(u8) / 255 (imagemap.rs:55-62).
+        The bytes are kept (image_src) so that tools/export_pbrt.py can write the file for rs_pbrt."""
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        t = self.image_texture((rgb8.astype(F32) / F32(255.0)).astype(F32), **kw)
+        self.image_src[len(self.images) - 1] = dict(u8=rgb8, scale=float(kw.get("scale", 1.0)), gamma=bool(kw.get("gamma", False)), channels=int(kw.get("channels", 3)))
+        return t
 
     @staticmethod
     def _mapping2d(mapping, su=1.0, sv=1.0, du=0.0, dv=0.0, v1=(1, 0, 0), v2=(0, 1, 0), world_to_texture=None):
@@ -1079,7 +1088,23 @@ def cornell_box(bvh_builder, variant="matte", fog=None):
                                           sb.scale_texture(sb.wrinkled_texture(octaves=4, omega=0.5, world_to_texture=w2t(0.05)), c(0.25))))
         tall_m = sb.add_material(substrate(sb.checkerboard_texture(c((0.1, 0.3, 0.6)), c((0.6, 0.5, 0.1)), mapping="planar", v1=(0.02, 0, 0), v2=(0, 0.02, 0)),
                                            (0.25, 0.25, 0.25), sb.dots_texture(c(0.05), c(0.3), su=4.0, sv=4.0), 0.1))
-    uvq = dict(UV=[[0, 0], [1, 0], [1, 1], [0, 1]]) if variant == "procedural" else {}
+    if variant == "imagemap":
+        # image textures from 8-bit sources (so that the same texels reach rs_pbrt through a PNG): EWA and trilinear lookups, a
+        # resolution that is not a power of two (MipMap::new's Lanczos resampling), the three wrap modes, uv and planar mappings,
+        # float images (y()) behind roughness and bump
+        rng = np.random.default_rng(7)
+        yy, xx = np.mgrid[0:24, 0:40]
+        a8 = np.stack([((xx // 5 + yy // 4) % 2) * 200 + 30, xx * 6, 80 + rng.integers(0, 100, (24, 40))], -1).astype(np.uint8)
+        b8 = rng.integers(0, 256, (32, 32, 3)).astype(np.uint8)
+        floor_m = sb.add_material(matte(sb.image_texture_u8(a8, su=4.0, sv=3.0, du=0.15, dv=0.4)))
+        back_m = sb.add_material(matte(sb.image_texture_u8(a8[::-1, ::-1], trilinear=True, wrap="clamp", scale=0.8), sigma=20.0))
+        left_m = sb.add_material(matte(sb.scale_texture(sb.image_texture_u8(b8, mapping="planar", v1=(0, 0.004, 0), v2=(0, 0, 0.004), du=0.1, dv=0.2, wrap="black"),
+                                                        sb.constant_texture((0.3, 0.9, 0.4)))))
+        short_m = sb.add_material(plastic((0.5, 0.45, 0.4), sb.image_texture_u8(b8, su=2.0, sv=2.0, trilinear=True, scale=0.6),
+                                          sb.image_texture_u8(a8, channels=1, scale=0.4, su=2.0, sv=2.0, trilinear=True)))
+        tall_m = sb.add_material(substrate(sb.image_texture_u8(a8, su=2.0, sv=3.0), (0.2, 0.2, 0.2), 0.1, 0.2,
+                                           bump=sb.image_texture_u8(b8, channels=1, scale=4.0, su=3.0, sv=3.0, trilinear=True)))
+    uvq = dict(UV=[[0, 0], [1, 0], [1, 1], [0, 1]]) if variant in ("procedural", "imagemap") else {}
     q = lambda p, m, **kw: sb.add_quad(p, m, **dict(uvq, **kw))  # noqa: E731
     q([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)], floor_m)
     q([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)], white)

@@ -49,6 +49,30 @@ def test_exported_texture_directives_follow_make_texture(oracle):
     assert np.array_equal(a["film"][:, 3], b["film"][:, 3]) and not np.allclose(a["film"][:, :3], b["film"][:, :3], atol=1e-3)
 
 
+def test_exported_image_textures_carry_the_generators_texels(oracle):
+    """cornell_imagemap: the PNGs next to the scene file decode (8-bit RGB, stored) to the bytes the generator divided by 255, every
+    imagemap directive spells out gamma false / scale / filter / wrap / mapping, float images are declared in the float namespace"""
+    import struct
+    import zlib
+    d = os.path.join(HERE, "golden", "ref_scenes")
+    text = open(os.path.join(d, "cornell_imagemap.pbrt")).read()
+    lines = [l for l in text.splitlines() if '"imagemap"' in l]
+    assert len(lines) == 7 and all('"bool gamma" ["false"]' in l and '"float maxanisotropy" [8]' in l for l in lines)
+    assert sum('"float" "imagemap"' in l for l in lines) == 2 and {w for l in lines for w in ("repeat", "clamp", "black") if '["%s"]' % w in l} == {"repeat", "clamp", "black"}
+    from rs_pbrt_amd import lib
+    sc = scenes.cornell_box(lib.bvh_build, "imagemap")
+    for k, src in sc.builder.image_src.items():
+        raw = open(os.path.join(d, "cornell_imagemap_img%d.png" % k), "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        w, h, depth, ctype = struct.unpack(">IIBB", raw[16:26])
+        i = raw.index(b"IDAT")
+        n = struct.unpack(">I", raw[i - 4:i])[0]
+        px = np.frombuffer(zlib.decompress(raw[i + 4:i + 4 + n]), np.uint8).reshape(h, 1 + 3 * w)[:, 1:].reshape(h, w, 3)
+        assert (depth, ctype) == (8, 2) and np.array_equal(px, src["u8"])
+    a = oracle.render(sc, scenes.cornell_render_desc(res=32, spp=4), threads=4)
+    assert a["counters"]["nan_samples"] == 0 and np.isfinite(a["film"]).all() and a["film"][:, :3].max() > 0.1
+
+
 @pytest.mark.skipif(not FIXTURES, reason="parity unpinned: no tests/golden/ref_*.npz (made from real rs_pbrt by rust_shim/refdump.rs) is committed yet")
 @pytest.mark.parametrize("path", FIXTURES or ["-"])
 def test_oracle_against_rs_pbrt_output(oracle, path):

@@ -22,6 +22,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def f(v):
@@ -80,7 +81,7 @@ def texture_directives(sb):
                 f(t["map"][:3]), f(t["map"][3:6]), float(t["map"][6]), float(t["map"][7]))
         return '"string mapping" ["%s"]' % {abi.MAP_SPHERICAL: "spherical", abi.MAP_CYLINDRICAL: "cylindrical"}[mk]
 
-    out = []
+    out, files = [], []
     for i in sorted(kind_of):   # records are appended children first (SceneBuilder), so index order is declaration order
         t, ty = T[i], kind_of[i]
         k = int(t["kind"])
@@ -105,19 +106,27 @@ def texture_directives(sb):
             assert ty == "spectrum", "rs_pbrt has no float marble (api.rs:1263)"
             line = head + ' "marble" "integer octaves" [%d] "float roughness" [%.9g] "float scale" [%.9g] "float variation" [%.9g]' % (
                 int(t["octaves"]), float(t["omega"]), float(t["scale"]), float(t["variation"]))
+        elif k == abi.TEX_IMAGE:   # CreateImage{Float,Spectrum}Texture (api.rs:1095-1170, :1320-1405): every parameter spelled out
+            src = sb.image_src.get(int(t["image"]))
+            assert src is not None and not src["gamma"] and src["channels"] == (1 if ty == "float" else 3), \
+                "exporter: an image texture needs an 8-bit source (SceneBuilder.image_texture_u8) without gamma: the file must carry the generator's texels"
+            files.append(("img%d.png" % int(t["image"]), src["u8"]))
+            line = head + ' "imagemap" "string filename" ["%s_img%d.png"] "bool gamma" ["false"] "float scale" [%.9g] "bool trilinear" ["%s"] "float maxanisotropy" [%.9g] "string wrap" ["%s"] %s' % (
+                "%s", int(t["image"]), src["scale"], "true" if int(t["trilinear"]) else "false", float(t["max_aniso"]),
+                {abi.WRAP_REPEAT: "repeat", abi.WRAP_BLACK: "black", abi.WRAP_CLAMP: "clamp"}[int(t["wrap"])], mapping2d(t))
         else:
-            raise NotImplementedError("exporter: texture kind %d (image textures need a file format that keeps float texels)" % k)
+            raise NotImplementedError("exporter: texture kind %d" % k)
         if uses_ctm:   # the Transform directive reads its 16 numbers column by column (bin/rs_pbrt.rs:729-748)
             w = np.asarray(t["world_to_texture"], np.float32).reshape(4, 4)
             out += ["TransformBegin", "  Transform [%s]" % f(w.T), "  " + line, "TransformEnd"]
         else:
             out.append(line)
-    return out
+    return out, files
 
 
 def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **sampler_kw):
     sb = sc.builder
-    assert sb is not None and not sb.instances and not sb.images and not sb.envmaps, "not covered by the exporter"
+    assert sb is not None and not sb.instances and not sb.envmaps, "not covered by the exporter"
     out = ["# generated by tools/export_pbrt.py from rs_pbrt_amd/scenes.py — do not edit",
            "LookAt %s  %s  %s" % tuple(f(v) for v in look_at),
            'Camera "perspective" "float fov" [%.9g]' % fov,
@@ -129,7 +138,12 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
     for k, md in enumerate(sb.media):   # MakeNamedMedium (api.rs:953-1037): sigma_a / sigma_s are already scaled in the builder
         out.append('MakeNamedMedium "medium%d" "string type" ["homogeneous"] "rgb sigma_a" [%s] "rgb sigma_s" [%s] "float g" [%.9g] "float scale" [1]' % (
             k + 1, f(md["sigma_a"]), f(md["sigma_s"]), float(md["g"])))
-    out += texture_directives(sb)
+    tex, files = texture_directives(sb)
+    stem = os.path.splitext(os.path.basename(path))[0]
+    out += [l.replace("%s_img", stem + "_img") if '"imagemap"' in l else l for l in tex]   # image files sit next to the scene file (api.rs:1381-1388)
+    from imgio import write_png_u8
+    for name, u8 in files:
+        write_png_u8(os.path.join(os.path.dirname(path), "%s_%s" % (stem, name)), u8)
     for lt in sb.delta_lights:
         from rs_pbrt_amd import abi
         if lt["kind"] == abi.LIGHT_POINT:
@@ -177,6 +191,8 @@ SCENES = {
     "cornell_maxmindist": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 80, 80, 16, 5),
     # the texture stage: every procedural texture class, 2-D and 3-D mappings, float textures behind roughness and bump
     "cornell_procedural": (lambda b, s: s.cornell_box(b, "procedural"), "CORNELL", 64, 64, 16, 5),
+    # image textures read from 8-bit PNGs written next to the scene (the generator's texels are u8 / 255, as ImageTexture::new computes them)
+    "cornell_imagemap": (lambda b, s: s.cornell_box(b, "imagemap"), "CORNELL", 64, 64, 16, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
