@@ -78,7 +78,7 @@ def test_exported_image_textures_carry_the_generators_texels(oracle):
 def test_oracle_against_rs_pbrt_output(oracle, path):
     import sys
     sys.path.insert(0, os.path.join(HERE, "..", "tools"))
-    from export_pbrt import EXTRA, SCENES
+    from export_pbrt import EXTRA, SCENES, camera_of
     from rs_pbrt_amd import lib
     z = np.load(path, allow_pickle=False)
     name = str(z["name"]); meta = json.loads(str(z["meta"]))
@@ -99,7 +99,8 @@ def test_oracle_against_rs_pbrt_output(oracle, path):
         assert np.array_equal(sc.P[sc.prims["v"][h["prim"][hit]]].reshape(-1, 9), ref[hit, 8:17])
         assert np.array_equal(oracle.trace(sc, rays, any_hit=True)["prim"] == 0, z["occluded"] == 1)
     # 3. the frame: filter weights exact; radiance per camera sample bit for bit where the dump has it, else film RMSE
-    rd = scenes.make_render_desc(xres, yres, spp, scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV, max_depth=depth, **EXTRA.get(name, {}))
+    look_at, fov = camera_of(name, scenes)
+    rd = scenes.make_render_desc(xres, yres, spp, look_at, fov, max_depth=depth, **EXTRA.get(name, {}))
     assert list(rd.crop_px) == meta["crop_px"] and list(rd.sample_bounds) == meta["sample_bounds"] and int(rd.spp) == meta["spp"]
     r = oracle.render(sc, rd, threads=4, want_li=True)
     assert np.array_equal(r["film"][:, 3], z["film"][:, 3])

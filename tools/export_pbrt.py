@@ -126,7 +126,7 @@ def texture_directives(sb):
 
 def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **sampler_kw):
     sb = sc.builder
-    assert sb is not None and not sb.instances and not sb.envmaps, "not covered by the exporter"
+    assert sb is not None and not sb.envmaps, "not covered by the exporter"
     out = ["# generated by tools/export_pbrt.py from rs_pbrt_amd/scenes.py — do not edit",
            "LookAt %s  %s  %s" % tuple(f(v) for v in look_at),
            'Camera "perspective" "float fov" [%.9g]' % fov,
@@ -144,24 +144,21 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
     from imgio import write_png_u8
     for name, u8 in files:
         write_png_u8(os.path.join(os.path.dirname(path), "%s_%s" % (stem, name)), u8)
-    for lt in sb.delta_lights:
-        from rs_pbrt_amd import abi
-        if lt["kind"] == abi.LIGHT_POINT:
-            out.append('LightSource "point" "point from" [%s] "rgb I" [%s]' % (f(lt["p"][:3]), f(lt["L"])))
-        else:
-            raise NotImplementedError("exporter: light kind %d" % int(lt["kind"]))
-    for m, (flags, mat, emit) in enumerate(zip(sb.meshes, sb.mesh_material, sb.mesh_emit)):
-        from rs_pbrt_amd import abi as _abi
+    from rs_pbrt_amd import abi as _abi
+
+    def mesh_block(m, indent=""):
+        blk = []
+        flags, mat, emit = sb.meshes[m], sb.mesh_material[m], sb.mesh_emit[m]
         text = 'Material ""' if mat == _abi.NO_MATERIAL else sb.materials[mat].get("pbrt")   # Material "" / "none": no BSDF (a medium boundary)
         assert text, "material %d has no pbrt directive (textured parameter?)" % mat
-        out.append("AttributeBegin")
+        blk.append(indent + "AttributeBegin")
         if flags[6] or flags[7]:   # the shape's MediumInterface: inside, outside ("" = no medium)
-            out.append('  MediumInterface "%s" "%s"' % ("medium%d" % flags[6] if flags[6] else "", "medium%d" % flags[7] if flags[7] else ""))
+            blk.append(indent + '  MediumInterface "%s" "%s"' % ("medium%d" % flags[6] if flags[6] else "", "medium%d" % flags[7] if flags[7] else ""))
         if emit is not None:
-            out.append('  AreaLightSource "diffuse" "rgb L" [%s] "bool twosided" ["%s"]' % (f(emit[0]), "true" if emit[1] else "false"))
-        out.append("  " + text)
+            blk.append(indent + '  AreaLightSource "diffuse" "rgb L" [%s] "bool twosided" ["%s"]' % (f(emit[0]), "true" if emit[1] else "false"))
+        blk.append(indent + "  " + text)
         if flags[3]:
-            out.append("  ReverseOrientation")
+            blk.append(indent + "  ReverseOrientation")
         first = sum(len(p) for p in sb.P[:m])
         idx = sb.tris[m].astype(np.int64) - first
         extra = ""
@@ -172,14 +169,77 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
         for key, a in (("alpha", flags[4]), ("shadowalpha", flags[5])):   # float textures by name (api.rs:1920-1965)
             if a:
                 extra += ' "texture %s" "tex%d"' % (key, a - 1)
-        out.append('  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]%s' % (" ".join(str(int(i)) for i in idx.reshape(-1)), f(sb.P[m]), extra))
-        out.append("AttributeEnd")
+        blk.append(indent + '  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]%s' % (" ".join(str(int(i)) for i in idx.reshape(-1)), f(sb.P[m]), extra))
+        blk.append(indent + "AttributeEnd")
+        return blk
+
+    # ObjectBegin / ObjectEnd first (their order does not reach render_options.primitives), then the top-level declarations in order.
+    # An instance's transform is written as one Transform directive, so rs_pbrt derives m_inv by Matrix4x4::inverse — the scene must
+    # have been built with Transform(m) (scenes.py computes the same Gauss-Jordan inverse), not with a product of (m, m_inv) pairs.
+    names = {v: k for k, v in sb.objects.items()}
+    for o in sorted(names):
+        out.append('ObjectBegin "%s"' % names[o])
+        for m in range(len(sb.meshes)):
+            if sb.mesh_object[m] == o:
+                out += mesh_block(m, "  ")
+        out.append("ObjectEnd")
+    for what, k in sb.decl:
+        if what == "mesh":
+            out += mesh_block(k)
+        else:
+            obj, xf = sb.instances[k]
+            from rs_pbrt_amd import scenes as _sc
+            assert np.array_equal(np.asarray(xf.m_inv, np.float32), np.asarray(_sc.Transform(xf.m).m_inv, np.float32)), "instance transform was not built as Transform(m)"
+            out += ["TransformBegin", "  Transform [%s]" % f(np.asarray(xf.m, np.float32).reshape(4, 4).T), '  ObjectInstance "%s"' % names[obj], "TransformEnd"]
+    # point lights after the shapes: the builder lists Scene.lights as area lights (declaration order) then the others
+    for lt in sb.delta_lights:
+        from rs_pbrt_amd import abi
+        if lt["kind"] == abi.LIGHT_POINT:
+            out.append('LightSource "point" "point from" [%s] "rgb I" [%s]' % (f(lt["p"][:3]), f(lt["L"])))
+        else:
+            raise NotImplementedError("exporter: light kind %d" % int(lt["kind"]))
     out.append("WorldEnd")
     open(path, "w").write("\n".join(out) + "\n")
 
 
+def instanced_room(bvh_builder, scenes):
+    """ground, wall, an area light and a point light; five transformed instances of a four-triangle pyramid object, one instance of
+    a single-triangle object (no aggregate of its own, api.rs:3046), one identity instance (the quirk of primitive.rs:226-250) — the
+    scene of tests/test_instancing.py with every instance transform built as Transform(m), which is what one Transform directive
+    gives rs_pbrt (m_inv by Matrix4x4::inverse)"""
+    T = scenes.Transform
+    pyr = np.array([(-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5), (0, 1, 0)], np.float32)
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    red = sb.add_material(scenes.plastic((0.6, 0.2, 0.15), (0.3, 0.3, 0.3), 0.15))
+    sb.add_quad([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], grey)
+    sb.add_quad([(-5, 0, 5), (-5, 5, 5), (5, 5, 5), (5, 0, 5)], grey)
+    sb.add_quad([(-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1)], grey, emit=(10, 10, 10))
+    sb.add_point_light((3, 4, -3), (30, 30, 25))
+    sb.begin_object("pyr")
+    sb.add_mesh(pyr, [[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]], red)
+    sb.end_object()
+    sb.begin_object("one")
+    sb.add_mesh(pyr[:3] + np.float32(0.1), [[0, 1, 2]], red)
+    sb.end_object()
+    for i in range(5):
+        sb.add_instance("pyr", T((T.translate((i - 2.0, 0.2, 1.0 + 0.3 * i)) * T.rotate_y(20.0 * i + 5.0) * T.scale(0.5 + 0.1 * i, 1.0 + 0.05 * i, 0.8)).m))
+    sb.add_instance("one", T(T.translate((0, 2, 0)).m))
+    sb.add_instance("pyr", T.identity())
+    return sb.finish(bvh_builder, instancing="reference")
+
+
+INSTANCED_CAMERA = (((0, 2.5, -6), (0, 0.5, 0), (0, 1, 0)), 40.0)
+
+
+def camera_of(name, scenes):
+    """(look_at, fov) of a scene of SCENES"""
+    cam = SCENES[name][1]
+    return (scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV) if cam == "CORNELL" else cam
+
+
 SCENES = {
-    # name: (scene factory(builder), look_at, fov, xres, yres, spp, max_depth)
+    # name: (scene factory(builder), "CORNELL" | (look_at, fov), xres, yres, spp, max_depth)
     "cornell_matte": (lambda b, s: s.cornell_box(b), "CORNELL", 64, 64, 16, 5),
     "cornell_mixed": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 64, 64, 16, 5),
     "cornell_rough": (lambda b, s: s.cornell_box(b, "rough"), "CORNELL", 64, 64, 16, 5),
@@ -193,6 +253,11 @@ SCENES = {
     "cornell_procedural": (lambda b, s: s.cornell_box(b, "procedural"), "CORNELL", 64, 64, 16, 5),
     # image textures read from 8-bit PNGs written next to the scene (the generator's texels are u8 / 255, as ImageTexture::new computes them)
     "cornell_imagemap": (lambda b, s: s.cornell_box(b, "imagemap"), "CORNELL", 64, 64, 16, 5),
+    # ObjectBegin / ObjectInstance: v0.9.12's behaviour (instanced hits lose their primitive, identity instances report nothing) is what
+    # the fixture will record; the oracle's RSPT_INSTANCING_REFERENCE mode claims to reproduce it
+    "instanced_room": (instanced_room, INSTANCED_CAMERA, 96, 72, 8, 5),
+    # the other samplers / integrators that share the loop
+    "cornell_halton": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 64, 64, 16, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
@@ -201,6 +266,7 @@ EXTRA = {
     "cornell_random": dict(sampler="random"),
     "cornell_stratified": dict(sampler="stratified", strat=(4, 4), jitter=True, dimensions=4),
     "cornell_maxmindist": dict(sampler="maxmindist", dimensions=4),
+    "cornell_halton": dict(sampler="halton"),
 }
 
 
@@ -210,7 +276,8 @@ def main():
     os.makedirs(d, exist_ok=True)
     for name, (mk, cam, xres, yres, spp, depth) in SCENES.items():
         sc = mk(lib.bvh_build, scenes)
-        export(sc, os.path.join(d, name + ".pbrt"), scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV, xres, yres, spp, depth, **EXTRA.get(name, {}))
+        look_at, fov = camera_of(name, scenes)
+        export(sc, os.path.join(d, name + ".pbrt"), look_at, fov, xres, yres, spp, depth, **EXTRA.get(name, {}))
     rng = np.random.default_rng(1234)   # the stage-level fixture: rays through the Cornell box, RAY_DT records
     rays = np.zeros(4096, abi.RAY_DT)
     rays["o"] = rng.uniform(20, 530, (4096, 3)).astype(np.float32)
