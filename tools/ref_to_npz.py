@@ -10,8 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
-    d, name = sys.argv[1], sys.argv[2]
+def pack(d, name, dst):
     meta = json.load(open(os.path.join(d, "meta.json")))
     node_dt = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_prims", "<u2"), ("axis", "u1"), ("pad", "u1")])
     out = dict(meta=json.dumps(meta), name=name,
@@ -25,8 +24,14 @@ def main():
     p = os.path.join(d, "occluded.bin")
     if os.path.exists(p):
         out["occluded"] = np.fromfile(p, np.uint8)
-    dst = os.path.join(ROOT, "tests", "golden", "ref_%s.npz" % name)
     np.savez_compressed(dst, **out)
+    return out
+
+
+def main():
+    d, name = sys.argv[1], sys.argv[2]
+    dst = os.path.join(ROOT, "tests", "golden", "ref_%s.npz" % name)
+    out = pack(d, name, dst)
     print("wrote", dst, {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
