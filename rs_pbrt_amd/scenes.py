@@ -314,14 +314,15 @@ def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, multiple_lobes=True):  # glas
     """multiple_lobes: the integrator's allow_multiple_lobes — true for `path` (one FresnelSpecular lobe), false for
     `directlighting` / `whitted` (SpecularReflection with a dielectric Fresnel + SpecularTransmission, glass.rs:136-188)"""
     r, t = np.maximum(np.array(kr, F32), 0), np.maximum(np.array(kt, F32), 0)
+    text = 'Material "glass" %s %s "float index" [%.9g]' % (_pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), float(index))   # the same directive: the integrator decides the form
     if multiple_lobes:
-        return dict(pbrt='Material "glass" %s %s "float index" [%.9g]' % (_pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), float(index)), eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=r, t=t, eta_a=1.0, eta_b=index)])
+        return dict(pbrt=text, eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=r, t=t, eta_a=1.0, eta_b=index)])
     lobes = []
     if r.any():
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=r, eta_a=1.0, eta_b=index))
     if t.any():
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=t, eta_a=1.0, eta_b=index))
-    return dict(eta=index, lobes=lobes)
+    return dict(pbrt=text, eta=index, lobes=lobes)
 
 
 def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True):  # metal.rs:144-205
@@ -1065,9 +1066,9 @@ def cornell_box(bvh_builder, variant="matte", fog=None):
     red = sb.add_material(matte((0.63, 0.065, 0.05)))
     green = sb.add_material(matte((0.14, 0.45, 0.091)))
     short_m, tall_m, floor_m = white, white, white
-    if variant == "mixed":
+    if variant in ("mixed", "mixed_two_lobes"):   # _two_lobes: the glass as directlighting / whitted see it (allow_multiple_lobes = false)
         tall_m = sb.add_material(mirror())
-        short_m = sb.add_material(glass())
+        short_m = sb.add_material(glass(multiple_lobes=variant == "mixed"))
         floor_m = sb.add_material(plastic((0.4, 0.4, 0.4), (0.3, 0.3, 0.3), 0.05))
     elif variant == "rough":
         tall_m = sb.add_material(metal(roughness=0.1))

@@ -80,7 +80,7 @@ def test_oracle_against_rs_pbrt_output(oracle, path):
     check_fixture(oracle, path)
 
 
-@pytest.mark.parametrize("name", ["cornell_mixed", "instanced_room", "cornell_fog_volpath", "cornell_02sequence"])
+@pytest.mark.parametrize("name", ["cornell_mixed", "instanced_room", "cornell_fog_volpath", "cornell_02sequence", "cornell_directlighting", "cornell_ao"])
 def test_fixture_pipeline_end_to_end_with_a_fabricated_dump(oracle, tmp_path, name):
     """NOT a pin: the oracle's own output written in refdump.rs's file layout, packed by tools/ref_to_npz.py and run through the very
     checks a real fixture gets — so that the day a dump from rs_pbrt arrives, a failure means the oracle, not the plumbing"""
@@ -92,6 +92,13 @@ def test_fixture_pipeline_end_to_end_with_a_fabricated_dump(oracle, tmp_path, na
     dst = str(tmp_path / ("ref_%s.npz" % name))
     pack(str(tmp_path / "dump"), name, dst)
     check_fixture(oracle, dst)
+
+
+def render_as(oracle, sc, rd, extra):
+    """the oracle's render for a scene of export_pbrt.SCENES (DirectLightingIntegrator has its own entry point there)"""
+    if extra.get("integrator") == "directlighting":
+        return oracle.render_integrator(sc, rd, "direct", strategy=extra.get("direct_strategy", "all"), threads=4, want_li=True)
+    return oracle.render(sc, rd, threads=4, want_li=True)
 
 
 def check_fixture(oracle, path):
@@ -126,7 +133,7 @@ def check_fixture(oracle, path):
     look_at, fov = camera_of(name, scenes)
     rd = scenes.make_render_desc(xres, yres, spp, look_at, fov, max_depth=depth, **EXTRA.get(name, {}))
     assert list(rd.crop_px) == meta["crop_px"] and list(rd.sample_bounds) == meta["sample_bounds"] and int(rd.spp) == meta["spp"]
-    r = oracle.render(sc, rd, threads=4, want_li=True)
+    r = render_as(oracle, sc, rd, EXTRA.get(name, {}))
     assert np.array_equal(r["film"][:, 3], z["film"][:, 3])
     a, b = scenes.film_to_rgb(r["film"]), scenes.film_to_rgb(z["film"])
     assert np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)) < 1e-6

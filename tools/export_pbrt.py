@@ -124,14 +124,25 @@ def texture_directives(sb):
     return out, files
 
 
-def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **sampler_kw):
+def integrator_directive(integrator, max_depth, direct_strategy="all", ao_samples=64, ao_cos_sample=True):
+    """make_integrator (api.rs:246-435): the parameters each integrator reads"""
+    if integrator == "directlighting":
+        return 'Integrator "directlighting" "integer maxdepth" [%d] "string strategy" ["%s"]' % (max_depth, direct_strategy)
+    if integrator == "ao":
+        return 'Integrator "ambientocclusion" "integer nsamples" [%d] "bool cossample" ["%s"]' % (ao_samples, "true" if ao_cos_sample else "false")
+    return 'Integrator "%s" "integer maxdepth" [%d]' % (integrator, max_depth)
+
+
+def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **kw):
+    integ_kw = {k: kw.pop(k) for k in ("direct_strategy", "ao_samples", "ao_cos_sample") if k in kw}
+    sampler_kw = kw
     sb = sc.builder
     assert sb is not None and not sb.envmaps, "not covered by the exporter"
     out = ["# generated by tools/export_pbrt.py from rs_pbrt_amd/scenes.py — do not edit",
            "LookAt %s  %s  %s" % tuple(f(v) for v in look_at),
            'Camera "perspective" "float fov" [%.9g]' % fov,
            sampler_directive(sampler, spp, **sampler_kw),
-           'Integrator "%s" "integer maxdepth" [%d]' % (integrator, max_depth),
+           integrator_directive(integrator, max_depth, **integ_kw),
            'PixelFilter "box" "float xwidth" [0.5] "float ywidth" [0.5]',
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d] "string filename" ["ref.png"]' % (xres, yres),
            "WorldBegin"]
@@ -258,6 +269,11 @@ SCENES = {
     "instanced_room": (instanced_room, INSTANCED_CAMERA, 96, 72, 8, 5),
     # the other samplers / integrators that share the loop
     "cornell_halton": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 64, 64, 16, 5),
+    # DirectLightingIntegrator (both strategies; the glass block in its two-lobe form, allow_multiple_lobes = false: the specular tree
+    # of reflection + transmission) and AOIntegrator
+    "cornell_directlighting": (lambda b, s: s.cornell_box(b, "mixed_two_lobes"), "CORNELL", 64, 64, 8, 5),
+    "cornell_directlighting_one": (lambda b, s: s.cornell_box(b, "mixed_two_lobes"), "CORNELL", 64, 64, 8, 5),
+    "cornell_ao": (lambda b, s: s.cornell_box(b), "CORNELL", 64, 64, 4, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
@@ -267,6 +283,9 @@ EXTRA = {
     "cornell_stratified": dict(sampler="stratified", strat=(4, 4), jitter=True, dimensions=4),
     "cornell_maxmindist": dict(sampler="maxmindist", dimensions=4),
     "cornell_halton": dict(sampler="halton"),
+    "cornell_directlighting": dict(integrator="directlighting", direct_strategy="all"),
+    "cornell_directlighting_one": dict(integrator="directlighting", direct_strategy="one"),
+    "cornell_ao": dict(integrator="ao", ao_samples=16, ao_cos_sample=True),
 }
 
 

@@ -28,7 +28,10 @@ def write_dump(oracle, name, d):
     tri = sc.P[sc.prims["v"][:nt_prims]].reshape(-1, 9).astype(np.float32)
     tri[sc.prims["mesh"][:nt_prims] == abi.MESH_INSTANCE] = np.nan           # refdump.rs tri_vertices: a TransformedPrimitive has no triangle
     tri.tofile(os.path.join(d, "bvh_prims.bin"))
-    r = oracle.render(sc, rd, threads=4, want_li=True)
+    if EXTRA.get(name, {}).get("integrator") == "directlighting":
+        r = oracle.render_integrator(sc, rd, "direct", strategy=EXTRA[name].get("direct_strategy", "all"), threads=4, want_li=True)
+    else:
+        r = oracle.render(sc, rd, threads=4, want_li=True)
     r["film"].astype("<f4").tofile(os.path.join(d, "film.bin"))
     w = rd.crop_px[2] - rd.crop_px[0]
     npix, nspp = r["li"].shape[:2]
