@@ -342,6 +342,7 @@ def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, rema
 
 def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness=0.1, uroughness=None, vroughness=None,
          opacity=(1.0,) * 3, index=1.5, remap=True, bump=None):  # uber.rs:114-259
+    kd_in, ks_in, kr_in, kt_in = kd, ks, kr, kt
     e = F32(index)
     op = np.maximum(np.array(opacity, F32), 0)
     t = np.maximum(F32(1) - op, 0).astype(F32)  # (-op + 1).clamp(0, inf)
@@ -365,14 +366,22 @@ def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness
     kt = (op * np.maximum(np.array(kt, F32), 0)).astype(F32)
     if kt.any():
         lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=kt, eta_a=1.0, eta_b=e))
-    return _with_bump(dict(eta=eta, lobes=lobes), bump)
+    text = None
+    if not any(isinstance(x, TexRef) for x in (opacity, kr, kt)):   # the export names what the library takes: Kd / Ks / roughness may be textures
+        text = 'Material "uber" %s %s %s %s %s%s%s %s "float index" [%.9g] "bool remaproughness" ["%s"]%s' % (
+            _pbrt_rgb("Kd", kd_in), _pbrt_rgb("Ks", ks_in), _pbrt_rgb("Kr", kr_in), _pbrt_rgb("Kt", kt_in), _pbrt_float("roughness", roughness),
+            "" if uroughness is None else " " + _pbrt_float("uroughness", uroughness), "" if vroughness is None else " " + _pbrt_float("vroughness", vroughness),
+            _pbrt_rgb("opacity", opacity), float(index), "true" if remap else "false", _pbrt_bump(bump))
+    return _with_bump(dict(eta=eta, lobes=lobes, pbrt=text), bump)
 
 
 def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.5,) * 3, roughness=0.1, remap=True):  # translucent.rs:64-189
     eta = F32(1.5)
+    text = 'Material "translucent" %s %s %s %s "float roughness" [%.9g] "bool remaproughness" ["%s"]' % (
+        _pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_rgb("reflect", reflect), _pbrt_rgb("transmit", transmit), float(roughness), "true" if remap else "false")
     r = np.maximum(np.array(reflect, F32), 0); t = np.maximum(np.array(transmit, F32), 0)
     if not r.any() and not t.any():
-        return dict(eta=float(eta), lobes=[])
+        return dict(eta=float(eta), lobes=[], pbrt=text)
     kd = np.maximum(np.array(kd, F32), 0); ks = np.maximum(np.array(ks, F32), 0)
     lobes = []
     if kd.any():
@@ -387,7 +396,7 @@ def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.
                                alpha_x=_alpha(a), alpha_y=_alpha(a)))
         if t.any():
             lobes.append(_lobe(type=abi.BXDF_MICROFACET_T, r=(t * ks).astype(F32), eta_a=1.0, eta_b=eta, alpha_x=_alpha(a), alpha_y=_alpha(a)))
-    return dict(eta=float(eta), lobes=lobes)
+    return dict(eta=float(eta), lobes=lobes, pbrt=text)
 
 
 def mix(m1, m2, amount=(0.5, 0.5, 0.5)):  # mixmat.rs:43-305: m1 scaled by `amount`, m2 by 1 - amount, lobes concatenated
@@ -412,7 +421,8 @@ def rough_glass(kr=(1.0,) * 3, kt=(1.0,) * 3, uroughness=0.1, vroughness=0.1, in
         lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=kr, eta_a=1.0, eta_b=index, alpha_x=_alpha(au), alpha_y=_alpha(av)))
     if kt.any():
         lobes.append(_lobe(type=abi.BXDF_MICROFACET_T, r=kt, eta_a=1.0, eta_b=index, alpha_x=_alpha(au), alpha_y=_alpha(av)))
-    return dict(eta=index, lobes=lobes)
+    return dict(eta=index, lobes=lobes, pbrt='Material "glass" %s %s "float uroughness" [%.9g] "float vroughness" [%.9g] "float index" [%.9g] "bool remaproughness" ["%s"]' % (
+        _pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), float(uroughness), float(vroughness), float(index), "true" if remap else "false"))
 
 
 # ---------------------------------------------------------------------------------------
@@ -1075,6 +1085,11 @@ def cornell_box(bvh_builder, variant="matte", fog=None):
         short_m = sb.add_material(matte((0.5, 0.5, 0.7), sigma=30.0))
         floor_m = sb.add_material(plastic((0.4, 0.4, 0.4), (0.3, 0.3, 0.3), 0.2))
     back_m, left_m, right_m = white, green, red
+    if variant == "layered":   # the recipes the other variants leave out: substrate, uber (partly transparent, with Kr and Kt), translucent, rough glass
+        floor_m = sb.add_material(substrate((0.4, 0.35, 0.3), (0.3, 0.3, 0.3), 0.05, 0.2))
+        short_m = sb.add_material(uber((0.3, 0.4, 0.6), (0.2, 0.2, 0.2), (0.1, 0.1, 0.1), (0.2, 0.2, 0.2), roughness=0.1, uroughness=0.05, opacity=(0.8, 0.8, 0.8), index=1.33))
+        tall_m = sb.add_material(rough_glass((0.9, 0.9, 0.9), (0.9, 0.9, 0.9), 0.05, 0.1, 1.5))
+        back_m = sb.add_material(translucent((0.4, 0.4, 0.4), (0.2, 0.2, 0.2), (0.6, 0.6, 0.6), (0.3, 0.3, 0.3), 0.15))
     if variant == "procedural":
         # every procedural texture class of src/textures/ (no image files: tools/export_pbrt.py can hand the scene to rs_pbrt as text):
         # 2-D mappings on the quads' uv, 3-D noise in world space scaled to the room, float textures behind roughness and bump

@@ -33,7 +33,7 @@ def _render_pair(gpu, oracle, sc, rd, want_li=True):
     return film, li, st, ref
 
 
-@pytest.mark.parametrize("variant", ["matte", "mixed", "rough", "procedural", "imagemap"])
+@pytest.mark.parametrize("variant", ["matte", "mixed", "rough", "procedural", "imagemap", "layered"])
 def test_cornell_matches_oracle(gpu, oracle, variant):
     sc = scenes.cornell_box(gpu.bvh_build, variant=variant)
     rd = scenes.cornell_render_desc(res=64, spp=16)

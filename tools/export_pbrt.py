@@ -274,6 +274,8 @@ SCENES = {
     "cornell_directlighting": (lambda b, s: s.cornell_box(b, "mixed_two_lobes"), "CORNELL", 64, 64, 8, 5),
     "cornell_directlighting_one": (lambda b, s: s.cornell_box(b, "mixed_two_lobes"), "CORNELL", 64, 64, 8, 5),
     "cornell_ao": (lambda b, s: s.cornell_box(b), "CORNELL", 64, 64, 4, 5),
+    # the material recipes the other scenes leave out: substrate, uber (opacity < 1, Kr, Kt), translucent, rough glass
+    "cornell_layered": (lambda b, s: s.cornell_box(b, "layered"), "CORNELL", 64, 64, 16, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
