@@ -80,7 +80,7 @@ def test_oracle_against_rs_pbrt_output(oracle, path):
     check_fixture(oracle, path)
 
 
-@pytest.mark.parametrize("name", ["cornell_mixed", "instanced_room", "cornell_fog_volpath", "cornell_02sequence", "cornell_directlighting", "cornell_ao"])
+@pytest.mark.parametrize("name", ["cornell_mixed", "instanced_room", "cornell_fog_volpath", "cornell_02sequence", "cornell_directlighting", "cornell_ao", "sky_blocks", "cornell_imagemap"])
 def test_fixture_pipeline_end_to_end_with_a_fabricated_dump(oracle, tmp_path, name):
     """NOT a pin: the oracle's own output written in refdump.rs's file layout, packed by tools/ref_to_npz.py and run through the very
     checks a real fixture gets — so that the day a dump from rs_pbrt arrives, a failure means the oracle, not the plumbing"""

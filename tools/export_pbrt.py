@@ -137,7 +137,7 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
     integ_kw = {k: kw.pop(k) for k in ("direct_strategy", "ao_samples", "ao_cos_sample") if k in kw}
     sampler_kw = kw
     sb = sc.builder
-    assert sb is not None and not sb.envmaps, "not covered by the exporter"
+    assert sb is not None, "the scene was not made by a SceneBuilder"
     out = ["# generated by tools/export_pbrt.py from rs_pbrt_amd/scenes.py — do not edit",
            "LookAt %s  %s  %s" % tuple(f(v) for v in look_at),
            'Camera "perspective" "float fov" [%.9g]' % fov,
@@ -207,6 +207,10 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
         from rs_pbrt_amd import abi
         if lt["kind"] == abi.LIGHT_POINT:
             out.append('LightSource "point" "point from" [%s] "rgb I" [%s]' % (f(lt["p"][:3]), f(lt["L"])))
+        elif lt["kind"] == abi.LIGHT_INFINITE:   # constant radiance only: the 1x1 map InfiniteAreaLight::new makes of L (api.rs:918-950); a file would have to be .hdr
+            env = sb.envmaps[int(lt["prim"])]
+            assert env["width"] == env["height"] == 1 and np.array_equal(np.asarray(lt["p"][:9], np.float32).reshape(3, 3), np.eye(3, dtype=np.float32))
+            out.append('LightSource "infinite" "rgb L" [%s] "integer nsamples" [1]' % f(lt["L"]))
         else:
             raise NotImplementedError("exporter: light kind %d" % int(lt["kind"]))
     out.append("WorldEnd")
@@ -238,6 +242,23 @@ def instanced_room(bvh_builder, scenes):
     sb.add_instance("one", T(T.translate((0, 2, 0)).m))
     sb.add_instance("pyr", T.identity())
     return sb.finish(bvh_builder, instancing="reference")
+
+
+def sky_blocks(bvh_builder, scenes):
+    """an open scene under a constant sky (InfiniteAreaLight: le on escape, importance sampling of a 1x1 map, the world radius) plus a
+    point light; two boxes on a ground plane behind a screen perforated by an alpha mask (a float dots texture that is exactly 0 inside
+    the dots: Triangle::intersect / intersect_p drop those hits, triangle.rs:313-330, :593-655)"""
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    blue = sb.add_material(scenes.plastic((0.2, 0.3, 0.6), (0.3, 0.3, 0.3), 0.1))
+    sb.add_quad([(-200, 0, -400), (-200, 0, 900), (800, 0, 900), (800, 0, -400)], grey)
+    sb.add_box((130, 0, 65), (290, 165, 230), blue)
+    sb.add_box((265, 0, 296), (430, 330, 456), grey)
+    holes = sb.dots_texture(sb.constant_texture(1.0), sb.constant_texture(0.0), su=6.0, sv=6.0)
+    sb.add_quad([(60, 0, 20), (500, 0, 20), (500, 300, 20), (60, 300, 20)], grey, UV=[[0, 0], [1, 0], [1, 1], [0, 1]], alpha=holes, shadow_alpha=holes)
+    sb.add_infinite_light((0.6, 0.7, 0.9))
+    sb.add_point_light((278, 500, -200), (4e5, 4e5, 3.5e5))
+    return sb.finish(bvh_builder)
 
 
 INSTANCED_CAMERA = (((0, 2.5, -6), (0, 0.5, 0), (0, 1, 0)), 40.0)
@@ -276,6 +297,8 @@ SCENES = {
     "cornell_ao": (lambda b, s: s.cornell_box(b), "CORNELL", 64, 64, 4, 5),
     # the material recipes the other scenes leave out: substrate, uber (opacity < 1, Kr, Kt), translucent, rough glass
     "cornell_layered": (lambda b, s: s.cornell_box(b, "layered"), "CORNELL", 64, 64, 16, 5),
+    # InfiniteAreaLight (constant L) + a point light, alpha / shadowalpha masks
+    "sky_blocks": (sky_blocks, "CORNELL", 64, 64, 16, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
