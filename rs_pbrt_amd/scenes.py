@@ -409,7 +409,9 @@ def mix(m1, m2, amount=(0.5, 0.5, 0.5)):  # mixmat.rs:43-305: m1 scaled by `amou
             lb["sc"] = sc; lb["has_sc"] = 1
             lobes.append(lb)
     assert len(lobes) <= 8, "Bsdf holds at most 8 BxDFs (reflection.rs:40)"
-    return dict(eta=m1["eta"], lobes=lobes)
+    # for tools/export_pbrt.py: two MakeNamedMaterial directives + Material "mix" (api.rs:678-704; the texture parameter is called "amount")
+    named = None if isinstance(amount, TexRef) or not (isinstance(m1.get("pbrt"), str) and isinstance(m2.get("pbrt"), str)) else ("mix", m1["pbrt"], m2["pbrt"], _pbrt_rgb("amount", amount))
+    return dict(eta=m1["eta"], lobes=lobes, pbrt=named)
 
 
 def rough_glass(kr=(1.0,) * 3, kt=(1.0,) * 3, uroughness=0.1, vroughness=0.1, index=1.5, remap=True):  # glass.rs:83-211, rough branch
@@ -1090,6 +1092,7 @@ def cornell_box(bvh_builder, variant="matte", fog=None):
         short_m = sb.add_material(uber((0.3, 0.4, 0.6), (0.2, 0.2, 0.2), (0.1, 0.1, 0.1), (0.2, 0.2, 0.2), roughness=0.1, uroughness=0.05, opacity=(0.8, 0.8, 0.8), index=1.33))
         tall_m = sb.add_material(rough_glass((0.9, 0.9, 0.9), (0.9, 0.9, 0.9), 0.05, 0.1, 1.5))
         back_m = sb.add_material(translucent((0.4, 0.4, 0.4), (0.2, 0.2, 0.2), (0.6, 0.6, 0.6), (0.3, 0.3, 0.3), 0.15))
+        right_m = sb.add_material(mix(matte((0.63, 0.065, 0.05)), plastic((0.1, 0.2, 0.5), (0.4, 0.4, 0.4), 0.08), (0.3, 0.5, 0.7)))
     if variant == "procedural":
         # every procedural texture class of src/textures/ (no image files: tools/export_pbrt.py can hand the scene to rs_pbrt as text):
         # 2-D mappings on the quads' uv, 3-D noise in world space scaled to the room, float textures behind roughness and bump

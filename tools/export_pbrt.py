@@ -162,6 +162,8 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
         flags, mat, emit = sb.meshes[m], sb.mesh_material[m], sb.mesh_emit[m]
         text = 'Material ""' if mat == _abi.NO_MATERIAL else sb.materials[mat].get("pbrt")   # Material "" / "none": no BSDF (a medium boundary)
         assert text, "material %d has no pbrt directive (textured parameter?)" % mat
+        if isinstance(text, tuple):   # a mix of the two named materials declared before the shapes
+            text = 'Material "mix" "string namedmaterial1" ["mat%d_1"] "string namedmaterial2" ["mat%d_2"] %s' % (mat, mat, text[3])
         blk.append(indent + "AttributeBegin")
         if flags[6] or flags[7]:   # the shape's MediumInterface: inside, outside ("" = no medium)
             blk.append(indent + '  MediumInterface "%s" "%s"' % ("medium%d" % flags[6] if flags[6] else "", "medium%d" % flags[7] if flags[7] else ""))
@@ -184,6 +186,12 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
         blk.append(indent + "AttributeEnd")
         return blk
 
+    import re
+    for k, m in enumerate(sb.materials):   # MakeNamedMaterial "name" "string type" ["matte"] <the parameters of the Material directive> (api.rs:2740-2770)
+        if isinstance(m.get("pbrt"), tuple):
+            for side in (1, 2):
+                mm = re.match(r'Material "(\w+)" (.*)$', m["pbrt"][side])
+                out.append('MakeNamedMaterial "mat%d_%d" "string type" ["%s"] %s' % (k, side, mm.group(1), mm.group(2)))
     # ObjectBegin / ObjectEnd first (their order does not reach render_options.primitives), then the top-level declarations in order.
     # An instance's transform is written as one Transform directive, so rs_pbrt derives m_inv by Matrix4x4::inverse — the scene must
     # have been built with Transform(m) (scenes.py computes the same Gauss-Jordan inverse), not with a product of (m, m_inv) pairs.
