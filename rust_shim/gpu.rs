@@ -97,7 +97,7 @@ impl Flat {
 
     /// One MipMap pyramid as rs_pbrt built it (mipmap.rs:56-196; texels already scaled / inverse-gamma-corrected and flipped by
     /// ImageTexture::new, imagemap.rs:34-96), un-blocked: levels concatenated, row major [t][s]
-    fn image<T: ShimValue + num::Zero + Clone + std::ops::Add<T, Output = T>>(&mut self, mip: &Arc<MipMap<T>>) -> u32 {
+    fn image<T: ShimValue + num::Zero + Clone + std::ops::Add<T, Output = T> + 'static>(&mut self, mip: &Arc<MipMap<T>>) -> u32 {
         let key = Arc::as_ptr(mip) as *const u8;
         if let Some(i) = self.image_of.get(&key) { return *i; }
         let mut tex: Vec<f32> = Vec::new();
@@ -113,7 +113,7 @@ impl Flat {
     }
 
     /// A texture graph as rspt_texture records (children first; indices are 0-based here, 1-based where a lobe / material / mesh refers to one)
-    fn texture<T: ShimValue + num::Zero + Clone + std::ops::Add<T, Output = T>>(&mut self, t: &Arc<dyn Texture<T> + Sync + Send>) -> Result<u32, String> {
+    fn texture<T: ShimValue + num::Zero + Clone + std::ops::Add<T, Output = T> + 'static>(&mut self, t: &Arc<dyn Texture<T> + Sync + Send>) -> Result<u32, String> {
         let key = Arc::as_ptr(t) as *const u8;
         if let Some(i) = self.texture_of.get(&key) { return Ok(*i); }
         let mut rec = RsptTexture { world_to_texture: IDENTITY16, max_aniso: 8.0, ..RsptTexture::default() };
