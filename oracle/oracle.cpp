@@ -291,6 +291,34 @@ void orc_homogeneous_sample(const rspt_medium* m, const float o[3], const float 
     out[0] = b.c[0]; out[1] = b.c[1]; out[2] = b.c[2]; out[3] = sampled ? 1.0f : 0.0f;
     out[4] = mi.p.x; out[5] = mi.p.y; out[6] = mi.p.z;
 }
+// GridDensityMedium leaf functions (orc_render.hpp; not part of the render path yet).  grid = (sigma_a[3], sigma_s[3], g, n[3], world_to_medium[16], density);
+// `u` is the stream sampler.get_1d() would deliver; *used = how many values were drawn; returns -1 if the stream ran out.
+void orc_grid_density(const int32_t n[3], const float* density, const float* pts, uint64_t npts, float* out) {
+    const float zero[3] = {0, 0, 0}, ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    GridMedium m = grid_medium_new(zero, zero, 0.0f, n[0], n[1], n[2], ident, density);
+    for (uint64_t i = 0; i < npts; i++) out[i] = grid_density(m, V3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]});
+}
+int orc_grid_tr(const float sigma_a[3], const float sigma_s[3], const int32_t n[3], const float w2m[16], const float* density, const float o[3], const float d[3], float t_max,
+                const float* u, uint64_t nu, float out[3], uint64_t* used) {
+    GridMedium m = grid_medium_new(sigma_a, sigma_s, 0.0f, n[0], n[1], n[2], w2m, density);
+    Ray ray{V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, t_max, 0.0f};
+    uint64_t k = 0; bool dry = false;
+    Spec tr = grid_tr(m, ray, [&]() -> Float { if (k >= nu) { dry = true; return 0.5f; } return u[k++]; });
+    out[0] = tr.c[0]; out[1] = tr.c[1]; out[2] = tr.c[2]; *used = k;
+    return dry ? -1 : 0;
+}
+// out = (beta rgb, sampled 0/1, p xyz, wo xyz)
+int orc_grid_sample(const float sigma_a[3], const float sigma_s[3], float g, const int32_t n[3], const float w2m[16], const float* density, const float o[3], const float d[3], float t_max,
+                    const float* u, uint64_t nu, float out[10], uint64_t* used) {
+    GridMedium m = grid_medium_new(sigma_a, sigma_s, g, n[0], n[1], n[2], w2m, density);
+    Ray ray{V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, t_max, 0.0f};
+    uint64_t k = 0; bool dry = false, sampled = false;
+    Interaction mi = Interaction{}; mi.p = mi.wo = V3{0, 0, 0};
+    Spec b = grid_sample(m, 1, ray, [&]() -> Float { if (k >= nu) { dry = true; return 0.5f; } return u[k++]; }, &mi, &sampled);
+    out[0] = b.c[0]; out[1] = b.c[1]; out[2] = b.c[2]; out[3] = sampled ? 1.0f : 0.0f;
+    out[4] = mi.p.x; out[5] = mi.p.y; out[6] = mi.p.z; out[7] = mi.wo.x; out[8] = mi.wo.y; out[9] = mi.wo.z; *used = k;
+    return dry ? -1 : 0;
+}
 // VisibilityTester::tr between two free points (MediumInteraction-like ends: n = 0, p_error = 0) that start in medium `medium0`
 void orc_visibility_tr(const rspt_scene_desc* sd, const float p0[3], uint32_t medium0, const float p1[3], float tr_out[3]) {
     Scene sc{*sd};

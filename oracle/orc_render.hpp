@@ -892,6 +892,109 @@ static inline Spec medium_sample(const Scene& sc, const Ray& ray, Sampler& sampl
     const Float u_dist = sampler.get_1d();    // :49
     return homogeneous_sample(sc.d.media[ray.medium - 1], ray.medium, ray, u_channel, u_dist, mi, sampled);
 }
+// ---- GridDensityMedium (src/media/grid.rs): LEAF FUNCTIONS ONLY.  Not wired into volpath_li and not in the ABI yet: its tr / sample
+// draw a data-dependent number of sampler values inside estimate_direct, which only the pixel samplers' serial streams can follow
+// (DESIGN.md section 10 A).  `next_1d` stands for sampler.get_1d(). ----
+struct GridMedium {
+    Spec sigma_a, sigma_s;
+    Float g;
+    int32_t nx, ny, nz;
+    const Float* density;
+    Float world_to_medium[16];
+    Float sigma_t, inv_max_density;
+};
+static inline GridMedium grid_medium_new(const Float sigma_a[3], const Float sigma_s[3], Float g, int32_t nx, int32_t ny, int32_t nz, const Float world_to_medium[16], const Float* d) { // grid.rs:30-56
+    GridMedium m;
+    m.sigma_a = Spec(sigma_a[0], sigma_a[1], sigma_a[2]); m.sigma_s = Spec(sigma_s[0], sigma_s[1], sigma_s[2]);
+    m.g = g; m.nx = nx; m.ny = ny; m.nz = nz; m.density = d;
+    for (int i = 0; i < 16; i++) m.world_to_medium[i] = world_to_medium[i];
+    Float max_density = 0.0f;
+    for (int64_t i = 0; i < (int64_t)nx * ny * nz; i++) max_density = std::fmax(max_density, d[i]); // f32::max
+    m.sigma_t = (m.sigma_s + m.sigma_a).c[0]; // [RGBEnum::Red]
+    m.inv_max_density = 1.0f / max_density;
+    return m;
+}
+static inline Float grid_d(const GridMedium& m, int32_t x, int32_t y, int32_t z) { // :57-75 (pnt3i_inside_exclusive)
+    if (!(x >= 0 && x < m.nx && y >= 0 && y < m.ny && z >= 0 && z < m.nz)) return 0.0f;
+    return m.density[((size_t)z * m.ny + y) * m.nx + x];
+}
+static inline Float grid_density(const GridMedium& m, V3 p) { // :76-153
+    const V3 ps{p.x * (Float)m.nx - 0.5f, p.y * (Float)m.ny - 0.5f, p.z * (Float)m.nz - 0.5f};
+    const int32_t ix = f2i(std::floor(ps.x)), iy = f2i(std::floor(ps.y)), iz = f2i(std::floor(ps.z));
+    const V3 d{ps.x - (Float)ix, ps.y - (Float)iy, ps.z - (Float)iz};
+    const Float d00 = lerp(d.x, grid_d(m, ix, iy, iz), grid_d(m, ix + 1, iy, iz));
+    const Float d10 = lerp(d.x, grid_d(m, ix, iy + 1, iz), grid_d(m, ix + 1, iy + 1, iz));
+    const Float d01 = lerp(d.x, grid_d(m, ix, iy, iz + 1), grid_d(m, ix + 1, iy, iz + 1));
+    const Float d11 = lerp(d.x, grid_d(m, ix, iy + 1, iz + 1), grid_d(m, ix + 1, iy + 1, iz + 1));
+    const Float d0 = lerp(d.y, d00, d10), d1 = lerp(d.y, d01, d11);
+    return lerp(d.z, d0, d1);
+}
+// Bounds3f::intersect_b (geometry.rs:2183-2210) against the unit cube the medium lives in
+static inline bool unit_cube_intersect_b(const Ray& ray, Float* hitt0, Float* hitt1) {
+    Float t0 = 0.0f, t1 = ray.t_max;
+    const Float o[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
+    for (int i = 0; i < 3; i++) {
+        const Float inv_ray_dir = 1.0f / dd[i];
+        Float t_near = (0.0f - o[i]) * inv_ray_dir, t_far = (1.0f - o[i]) * inv_ray_dir;
+        if (t_near > t_far) std::swap(t_near, t_far);
+        t_far *= 1.0f + 2.0f * gamma(3);
+        if (t_near > t0) t0 = t_near;
+        if (t_far < t1) t1 = t_far;
+        if (t0 > t1) return false;
+    }
+    *hitt0 = t0; *hitt1 = t1;
+    return true;
+}
+// the prelude tr and sample share (:158-176, :216-235): the world ray normalised (t_max scaled), then taken to medium space
+static inline Ray grid_medium_ray(const GridMedium& m, const Ray& r_world) {
+    Ray in_ray{r_world.o, normalize(r_world.d), r_world.t_max * length(r_world.d), 0.0f}; // ..Default::default(): time 0, no differential, no medium
+    return transform_ray(m.world_to_medium, in_ray);
+}
+template <class Next1D>
+static inline Spec grid_tr(const GridMedium& m, const Ray& r_world, Next1D&& next_1d) { // GridDensityMedium::tr :155-208: ratio tracking
+    const Ray ray = grid_medium_ray(m, r_world);
+    Float t_min = 0.0f, t_max = 0.0f;
+    if (!unit_cube_intersect_b(ray, &t_min, &t_max)) return Spec(1.0f);
+    Float tr = 1.0f, t = t_min;
+    for (;;) {
+        t -= std::log(1.0f - next_1d()) * m.inv_max_density / m.sigma_t;
+        if (t >= t_max) break;
+        const Float density = grid_density(m, ray.o + ray.d * t);
+        tr *= 1.0f - std::fmax(0.0f, density * m.inv_max_density);
+        const Float rr_threshold = 0.1f; // "added after book publication"
+        if (tr < rr_threshold) {
+            const Float q = std::fmax(0.05f, 1.0f - tr);
+            if (next_1d() < q) return Spec(0.0f);
+            tr /= 1.0f - q;
+        }
+    }
+    return Spec(tr);
+}
+template <class Next1D>
+static inline Spec grid_sample(const GridMedium& m, uint32_t medium, const Ray& r_world, Next1D&& next_1d, Interaction* mi, bool* sampled) { // ::sample :209-270: delta tracking
+    *sampled = false;
+    const Ray ray = grid_medium_ray(m, r_world);
+    Float t_min = 0.0f, t_max = 0.0f;
+    if (!unit_cube_intersect_b(ray, &t_min, &t_max)) return Spec(1.0f);
+    Float t = t_min;
+    for (;;) {
+        t -= std::log(1.0f - next_1d()) * m.inv_max_density / m.sigma_t;
+        if (t >= t_max) break;
+        if (grid_density(m, ray.o + ray.d * t) * m.inv_max_density > next_1d()) {
+            *mi = Interaction{};
+            mi->p = r_world.o + r_world.d * t; // r_world.position(t): the WORLD ray as given (not normalised) at the normalised ray's parameter (:243)
+            mi->wo = -r_world.d;
+            mi->time = r_world.time;
+            mi->med_in = mi->med_out = medium;
+            mi->is_medium = true;
+            mi->phase_g = m.g;
+            *sampled = true;
+            return m.sigma_s / m.sigma_t;
+        }
+    }
+    return Spec(1.0f);
+}
+
 static inline Float phase_hg(Float cos_theta, Float g) { // medium.rs:389-392
     const Float denom = 1.0f + g * g + 2.0f * g * cos_theta;
     return INV_4_PI * (1.0f - g * g) / (denom * std::sqrt(denom));

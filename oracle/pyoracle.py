@@ -64,6 +64,11 @@ def lib():
         L.orc_homogeneous_sample.restype = None
         L.orc_homogeneous_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.orc_visibility_tr.restype = None; L.orc_visibility_tr.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_grid_density.restype = None; L.orc_grid_density.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_grid_tr.restype = C.c_int
+        L.orc_grid_tr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_grid_sample.restype = C.c_int
+        L.orc_grid_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.orc_libm.restype = None; L.orc_libm.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_pixel_sampler.restype = None
         L.orc_pixel_sampler.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -165,3 +170,36 @@ def render(scene, rd, threads=1, want_li=False):
                           li.ctypes.data if want_li else None, cnt.ctypes.data, C.addressof(sec))
     assert rc == 0
     return dict(film=film, li=li, counters=dict(zip(COUNTER_NAMES, (int(x) for x in cnt))), seconds=sec.value)
+
+
+# ---- GridDensityMedium leaf functions (src/media/grid.rs; oracle only) ----
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def grid_density(density, pts):
+    """GridDensityMedium::density at medium-space points; density[z][y][x]"""
+    d = _f32(density); n = np.array(d.shape[::-1], np.int32); p = _f32(pts).reshape(-1, 3); out = np.zeros(len(p), np.float32)
+    lib().orc_grid_density(n.ctypes.data, d.ctypes.data, p.ctypes.data, len(p), out.ctypes.data)
+    return out
+
+
+def grid_tr(density, sigma_a, sigma_s, o, d, t_max, u, world_to_medium=None):
+    """GridDensityMedium::tr with the 1-D sample stream u: (tr rgb, values used)"""
+    dn = _f32(density); n = np.array(dn.shape[::-1], np.int32); w = _f32(np.eye(4) if world_to_medium is None else world_to_medium)
+    sa, ss, oo, dd, uu = _f32(np.broadcast_to(sigma_a, 3)), _f32(np.broadcast_to(sigma_s, 3)), _f32(o), _f32(d), _f32(u)
+    out = np.zeros(3, np.float32); used = C.c_uint64(0)
+    rc = lib().orc_grid_tr(sa.ctypes.data, ss.ctypes.data, n.ctypes.data, w.ctypes.data, dn.ctypes.data, oo.ctypes.data, dd.ctypes.data, float(t_max), uu.ctypes.data, len(uu), out.ctypes.data, C.addressof(used))
+    assert rc == 0, "sample stream too short"
+    return out, used.value
+
+
+def grid_sample(density, sigma_a, sigma_s, g, o, d, t_max, u, world_to_medium=None):
+    """GridDensityMedium::sample: dict(beta rgb, sampled, p, wo, used)"""
+    dn = _f32(density); n = np.array(dn.shape[::-1], np.int32); w = _f32(np.eye(4) if world_to_medium is None else world_to_medium)
+    sa, ss, oo, dd, uu = _f32(np.broadcast_to(sigma_a, 3)), _f32(np.broadcast_to(sigma_s, 3)), _f32(o), _f32(d), _f32(u)
+    out = np.zeros(10, np.float32); used = C.c_uint64(0)
+    rc = lib().orc_grid_sample(sa.ctypes.data, ss.ctypes.data, float(g), n.ctypes.data, w.ctypes.data, dn.ctypes.data, oo.ctypes.data, dd.ctypes.data, float(t_max), uu.ctypes.data, len(uu),
+                               out.ctypes.data, C.addressof(used))
+    assert rc == 0, "sample stream too short"
+    return dict(beta=out[:3].copy(), sampled=bool(out[3]), p=out[4:7].copy(), wo=out[7:10].copy(), used=used.value)

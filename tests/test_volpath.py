@@ -127,3 +127,78 @@ def test_single_scattering_adds_light_and_a_path_that_leaves_the_scene_ends(orac
     m5 = scenes.film_to_rgb(oracle.render(sc, rd5, threads=8)["film"]).reshape(-1, 3).mean(0)
     assert m1.min() > 1e-3 and m1[0] > m1[1] > m1[2]          # sigma_s red > green > blue
     assert np.all(m5 >= m1 * 0.999) and np.all(m5 < 3.0 * m1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GridDensityMedium (src/media/grid.rs): leaf functions of the oracle only — not on the render path yet
+# ---------------------------------------------------------------------------------------------------------------
+def test_grid_density_is_trilinear_between_voxel_centres_and_zero_outside(oracle):
+    d = np.arange(1, 9, dtype=np.float32).reshape(2, 2, 2)          # density[z][y][x]
+    c = np.array([[(x + 0.5) / 2, (y + 0.5) / 2, (z + 0.5) / 2] for z in range(2) for y in range(2) for x in range(2)], np.float32)
+    assert np.array_equal(oracle.grid_density(d, c), d.reshape(-1))                                   # a voxel centre returns its voxel (grid.rs:76-153)
+    mid = oracle.grid_density(d, [[0.5, 0.25, 0.25], [0.25, 0.5, 0.25], [0.25, 0.25, 0.5], [0.5, 0.5, 0.5]])
+    assert np.array_equal(mid, np.float32([1.5, 2.0, 3.0, 4.5]))                                       # halfway: exact averages
+    assert np.array_equal(oracle.grid_density(d, [[0.0, 0.25, 0.25], [1.0, 0.75, 0.75], [-1, 0.5, 0.5], [0.5, 0.5, 2.0]]), np.float32([0.5, 4.0, 0.0, 0.0]))   # samples outside the grid read 0 (:57-75)
+    big = np.random.default_rng(1).random((5, 4, 3)).astype(np.float32)
+    p = np.random.default_rng(2).random((200, 3)).astype(np.float32)
+    got = oracle.grid_density(big, p)
+    pad = np.zeros((7, 6, 5), np.float32); pad[1:-1, 1:-1, 1:-1] = big                                 # the same interpolation written independently (f64)
+    ps = p.astype(np.float64) * [3, 4, 5] - 0.5
+    i0 = np.floor(ps).astype(int); f = ps - i0
+    ref = np.zeros(len(p))
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                w = np.where(dx, f[:, 0], 1 - f[:, 0]) * np.where(dy, f[:, 1], 1 - f[:, 1]) * np.where(dz, f[:, 2], 1 - f[:, 2])
+                ref += w * pad[i0[:, 2] + dz + 1, i0[:, 1] + dy + 1, i0[:, 0] + dx + 1]
+    assert np.allclose(got, ref, rtol=0, atol=2e-6)
+
+
+def test_grid_ratio_and_delta_tracking_match_beer_lambert_in_expectation(oracle):
+    """a grid that is uniform along the ray (density 0.5 in every voxel it crosses, maximum 1 in a corner it never sees): ratio tracking (tr, with its
+    Russian roulette) and delta tracking (sample) are unbiased estimators of exp(-sigma_t * 0.5 * length) and of its complement"""
+    d = np.full((4, 4, 4), 0.5, np.float32); d[3, 3, 3] = 1.0
+    sigma_a, sigma_s = 0.6, 1.8                                                                      # sigma_t = 2.4
+    o, dr, t_max = (0.2, 0.3, -1.0), (0.0, 0.0, 1.0), 5.0                                            # crosses z in [0, 1]: length 1 inside
+    rng = np.random.default_rng(5)
+    n = 6000
+    trs, hits, betas, used_tr = [], 0, set(), 0
+    for _ in range(n):
+        u = rng.random(64).astype(np.float32)
+        tr, k = oracle.grid_tr(d, sigma_a, sigma_s, o, dr, t_max, u)
+        assert tr[0] == tr[1] == tr[2]; trs.append(tr[0]); used_tr += k
+        r = oracle.grid_sample(d, sigma_a, sigma_s, 0.3, o, dr, t_max, u)
+        hits += r["sampled"]; betas.add(tuple(r["beta"]))
+        if r["sampled"]:
+            assert 0.0 <= r["p"][2] <= 1.0 + 1e-5 and np.array_equal(r["p"][:2], np.float32(o[:2])) and np.array_equal(r["wo"], -np.float32(dr))
+    # optical depth: density 0.5 along the ray except in the outer half voxels, where the trilinear lookup blends with the zeros outside
+    # the grid (0.25 at the faces): integral of the density over z in [0, 1] = 0.5 - 2 * (0.125 * 0.25 / 2) = 0.46875
+    expect = np.exp(-2.4 * 0.46875)
+    assert abs(np.mean(trs) - expect) < 4 * np.std(trs) / np.sqrt(n) + 1e-3
+    assert abs(hits / n - (1 - expect)) < 4 * np.sqrt(expect * (1 - expect) / n)
+    assert betas == {(1.0, 1.0, 1.0), tuple(np.float32([1.8, 1.8, 1.8]) / np.float32(2.4))}            # sigma_s / sigma_t[Red] when scattered, 1 otherwise (:263, :269)
+    assert used_tr / n > 1.5                                                                        # steps + roulette draws really come from the stream
+
+
+def test_grid_medium_edge_cases_and_the_unnormalised_ray_quirk(oracle):
+    d = np.full((2, 2, 2), 0.7, np.float32)
+    u = np.float32([0.3, 0.6, 0.2, 0.9, 0.5, 0.5, 0.5, 0.5])
+    tr, k = oracle.grid_tr(d, 0.5, 0.5, (2.0, 2.0, 2.0), (1.0, 0.0, 0.0), 10.0, u)                   # misses the unit cube: 1, nothing drawn (:177-179)
+    assert np.array_equal(tr, np.float32([1, 1, 1])) and k == 0
+    tr, k = oracle.grid_tr(np.zeros((2, 2, 2), np.float32), 0.5, 0.5, (0.5, 0.5, -1.0), (0, 0, 1.0), 10.0, u)   # empty grid: inv_max_density = inf, the first step leaves the cube
+    assert np.array_equal(tr, np.float32([1, 1, 1])) and k == 1
+    # a uniform grid at its own maximum: the first collision multiplies tr by 1 - 1 = 0, the roulette (q = 1) ends it (:190-203)
+    # (the first step, -ln(1 - 0.2953) / 0.7 = 0.5, lands in the middle of the cube, where the density is the maximum)
+    tr, k = oracle.grid_tr(d, 0.5, 0.5, (0.5, 0.5, -1.0), (0, 0, 1.0), 10.0, np.float32([0.2953, 0.5, 0.5, 0.5]))
+    assert np.array_equal(tr, np.float32([0, 0, 0])) and k == 2
+    # the interaction point is taken on the ray AS GIVEN at the normalised ray's parameter (r_world.position(t), :243): with |d| = 2 it
+    # lies twice as far from the origin as the collision that was found
+    a = oracle.grid_sample(d, 0.5, 0.5, 0.0, (0.5, 0.5, -1.0), (0, 0, 1.0), 10.0, np.float32([0.5, 0.0, 0.5, 0.5]))
+    b = oracle.grid_sample(d, 0.5, 0.5, 0.0, (0.5, 0.5, -1.0), (0, 0, 2.0), 5.0, np.float32([0.5, 0.0, 0.5, 0.5]))
+    assert a["sampled"] and b["sampled"] and a["used"] == b["used"] == 2
+    ta, tb = a["p"][2] + 1.0, b["p"][2] + 1.0
+    assert abs(tb - 2.0 * ta) < 1e-5 and 1.0 < ta < 2.0
+    # a scaled world_to_medium: the medium occupies [0, 4]^3 in the world; the same collision statistics at 4x the world distance
+    w2m = np.diag([0.25, 0.25, 0.25, 1.0]).astype(np.float32)
+    c = oracle.grid_sample(d, 0.5, 0.5, 0.0, (2.0, 2.0, -4.0), (0, 0, 1.0), 40.0, np.float32([0.5, 0.0, 0.5, 0.5]), world_to_medium=w2m)
+    assert c["sampled"] and abs((c["p"][2] + 4.0) - 4.0 - (ta - 1.0)) < 1e-4   # entry at world distance 4; then the same free flight as in the unit medium (t is a world-ray parameter)
