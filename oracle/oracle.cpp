@@ -243,11 +243,20 @@ int orc_render_integrator(const rspt_scene_desc* sd, const rspt_render_desc* rd,
     return 0;
 }
 
+void orc_pixel_sampler_arrays(const rspt_render_desc* rd, uint64_t seed, int n_pixels, float* out1d, float* out2d, float* draws, const int32_t* array_sizes, int n_arrays,
+                              float* out_arrays);
 // the pixel samplers: reseed(seed), then n_pixels x start_pixel (+ a full round of start_next_sample, as a rendered pixel has);
 // out1d [dims][spp], out2d [dims][spp][2] = the vectors of the last pixel; draws[0..3] = get_1d, get_2d.x, get_2d.y, get_1d taken
 // after every precomputed dimension of sample 0 has been handed out (the on-demand stream)
 void orc_pixel_sampler(const rspt_render_desc* rd, uint64_t seed, int n_pixels, float* out1d, float* out2d, float* draws) {
+    orc_pixel_sampler_arrays(rd, seed, n_pixels, out1d, out2d, draws, nullptr, 0, nullptr);
+}
+// the same with 2-D sample arrays requested first (what ao / directlighting's preprocess does): array_sizes[n_arrays];
+// out_arrays = the arrays of the last pixel, concatenated, [size * spp][2] each
+void orc_pixel_sampler_arrays(const rspt_render_desc* rd, uint64_t seed, int n_pixels, float* out1d, float* out2d, float* draws, const int32_t* array_sizes, int n_arrays,
+                              float* out_arrays) {
     Sampler s(*rd);
+    for (int i = 0; i < n_arrays; i++) s.request_2d_array(array_sizes[i]);
     s.reseed(seed);
     for (int k = 0; k < n_pixels; k++) {
         s.start_pixel(0, 0);
@@ -264,7 +273,11 @@ void orc_pixel_sampler(const rspt_render_desc* rd, uint64_t seed, int n_pixels, 
     P2 v = s.get_2d();
     draws[1] = v.x; draws[2] = v.y;
     draws[3] = s.get_1d();
+    size_t k = 0;
+    for (int i = 0; i < n_arrays; i++)
+        for (const P2& q : p.sample_array_2d[(size_t)i]) { out_arrays[k++] = q.x; out_arrays[k++] = q.y; }
 }
+int32_t orc_round_count(const rspt_render_desc* rd, int32_t n) { Sampler s(*rd); return s.round_count(n); }
 
 // f32::sin / cos / ln / log2 / exp / acos / atan2 = the host libm's functions, over an array (to compare the device's restatements with, bit for bit)
 void orc_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {

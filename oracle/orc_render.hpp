@@ -307,6 +307,22 @@ static inline uint32_t multiply_generator(const uint32_t* c, uint32_t a) { // lo
     for (int i = 0; a != 0; i++, a >>= 1) if (a & 1u) v ^= c[i];
     return v;
 }
+// sampling.rs:273-306 (the two-dimensional instance the stratified sampler's arrays use)
+static inline void latin_hypercube(P2* samples, uint32_t n_samples, Rng& rng) {
+    const Float inv_n_samples = 1.0f / (Float)n_samples;
+    for (uint32_t i = 0; i < n_samples; i++) {
+        const Float sx = ((Float)i + rng.uniform_float()) * inv_n_samples;
+        samples[i].x = std::fmin(sx, FLOAT_ONE_MINUS_EPSILON);
+        const Float sy = ((Float)i + rng.uniform_float()) * inv_n_samples;
+        samples[i].y = std::fmin(sy, FLOAT_ONE_MINUS_EPSILON);
+    }
+    for (int dim = 0; dim < 2; dim++)
+        for (uint32_t j = 0; j < n_samples; j++) {
+            const uint32_t other = j + rng.uniform_uint32_bounded(n_samples - j);
+            if (dim == 0) std::swap(samples[j].x, samples[other].x); else std::swap(samples[j].y, samples[other].y);
+        }
+}
+
 struct PixelSampler {
     int kind = 0;
     int64_t spp = 1;
@@ -318,6 +334,25 @@ struct PixelSampler {
     int32_t current_1d_dimension = 0, current_2d_dimension = 0;
     int64_t cur_sample = 0;
     Rng rng;
+    // 2-D sample arrays an integrator's preprocess requested (ao, directlighting): n x spp points each, refilled by every start_pixel
+    // AFTER the plain vectors, from the same stream (zerotwosequence.rs:131-148, maxmin.rs:137-152, stratified.rs:137-160, random.rs:64-77)
+    std::vector<int32_t> samples_2d_array_sizes;
+    std::vector<std::vector<P2>> sample_array_2d;
+    void request_2d_array(int32_t n) { samples_2d_array_sizes.push_back(n); sample_array_2d.emplace_back((size_t)n * (size_t)spp); } // (asserts round_count(n) == n, e.g. zerotwosequence.rs:187-193)
+    int32_t round_count(int32_t n) const { // zerotwosequence.rs:194, maxmin.rs:198: round_up_pow2_32; stratified.rs:200, random.rs:107: the identity
+        if (kind != RSPT_SAMPLER_ZEROTWO && kind != RSPT_SAMPLER_MAXMINDIST) return n;
+        int32_t v = n - 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; // pbrt.rs round_up_pow2_32
+    }
+    void fill_arrays() {
+        const int32_t n = (int32_t)spp;
+        for (size_t i = 0; i < sample_array_2d.size(); i++) {
+            const int32_t count = samples_2d_array_sizes[i];
+            P2* a = sample_array_2d[i].data();
+            if (kind == RSPT_SAMPLER_ZEROTWO || kind == RSPT_SAMPLER_MAXMINDIST) sobol_2d(count, n, a, rng);
+            else if (kind == RSPT_SAMPLER_STRATIFIED) { for (int64_t j = 0; j < spp; j++) latin_hypercube(a + (size_t)j * (size_t)count, (uint32_t)count, rng); }
+            else for (size_t j = 0; j < sample_array_2d[i].size(); j++) { const Float x = rng.uniform_float(); const Float y = rng.uniform_float(); a[j] = P2{x, y}; } // random.rs:70-76: x first
+        }
+    }
     void init(const rspt_render_desc& rd) {
         kind = (int)rd.sampler_kind; spp = rd.spp; n_dims = (int32_t)rd.pixel_dimensions;
         nx = (int32_t)rd.strat_x; ny = (int32_t)rd.strat_y; jitter = rd.strat_jitter != 0; c_pixel = rd.maxmin_c_pixel;
@@ -346,6 +381,7 @@ struct PixelSampler {
             for (auto& v : samples_1d) van_der_corput(1, n, v.data(), rng);
             for (size_t i = 1; i < samples_2d.size(); i++) sobol_2d(1, n, samples_2d[i].data(), rng);
         }
+        fill_arrays();
         cur_sample = 0; // (current_*_dimension are reset by start_next_sample only; they are 0 here: every pixel ends with one)
     }
     Float get_1d() {
@@ -384,7 +420,8 @@ struct Sampler {
     size_t array_2d_offset = 0;
     static const int64_t ARRAY_START_DIM = 5;
     int64_t array_end_dim() const { return ARRAY_START_DIM + 2 * (int64_t)arrays_2d.size(); }
-    void request_2d_array(int32_t n) { arrays_2d.push_back(n); }
+    void request_2d_array(int32_t n) { arrays_2d.push_back(n); if (is_pixel()) pix.request_2d_array(n); }
+    int32_t round_count(int32_t n) const { return is_pixel() ? pix.round_count(n) : n; }
     int64_t& dimension() { return is_halton() ? halton.dimension : sobol.dimension; }
     void start_pixel(int32_t x, int32_t y) {
         array_2d_offset = 0;
@@ -424,7 +461,10 @@ struct Sampler {
         array_2d_offset += 1;
         return true;
     }
-    P2 get_2d_sample(size_t array_idx, uint64_t j) const { return array_2d(j, ARRAY_START_DIM + 2 * (int64_t)array_idx); }
+    P2 get_2d_sample(size_t array_idx, uint64_t j) const {
+        if (is_pixel()) return pix.sample_array_2d[array_idx][(size_t)j];
+        return array_2d(j, ARRAY_START_DIM + 2 * (int64_t)array_idx);
+    }
     bool start_next_sample() { // halton.rs:333-343
         array_2d_offset = 0;
         if (is_pixel()) return pix.start_next_sample();

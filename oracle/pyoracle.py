@@ -72,6 +72,9 @@ def lib():
         L.orc_libm.restype = None; L.orc_libm.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_pixel_sampler.restype = None
         L.orc_pixel_sampler.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pixel_sampler_arrays.restype = None
+        L.orc_pixel_sampler_arrays.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_round_count.restype = C.c_int32; L.orc_round_count.argtypes = [C.c_void_p, C.c_int32]
         L.orc_spatial_voxel.restype = None
         L.orc_spatial_voxel.argtypes = [C.c_void_p] * 6
         L.orc_tex_eval.restype = None; L.orc_tex_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]

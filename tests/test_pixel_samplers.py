@@ -183,3 +183,105 @@ def test_tiles_are_seeded_by_position_and_thread_count_does_not_matter(oracle):
     for name in ("random", "02sequence", "stratified", "maxmindist"):   # the same picture within Monte-Carlo noise
         img = scenes.film_to_rgb(oracle.render(sc, scenes.cornell_render_desc(res=48, spp=64, sampler=name, strat=(8, 8)), threads=8)["film"])
         assert abs(img.mean() - ref.mean()) < 0.03 * ref.mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 2-D sample ARRAYS (request_2d_array: what ao / directlighting's preprocess asks for) — oracle only so far
+# ---------------------------------------------------------------------------------------------------------------
+def oracle_arrays(oracle, rd, seed, sizes, n_pixels=1):
+    nd, spp = rd.pixel_dimensions, rd.spp
+    o1, o2, dr = np.zeros((nd, spp), F32), np.zeros((nd, spp, 2), F32), np.zeros(4, F32)
+    sz = np.array(sizes, np.int32)
+    arr = np.zeros((int(sz.sum()) * spp, 2), F32)
+    oracle.lib().orc_pixel_sampler_arrays(C.addressof(rd), seed, n_pixels, o1.ctypes.data, o2.ctypes.data, dr.ctypes.data, sz.ctypes.data, len(sz), arr.ctypes.data)
+    out, k = [], 0
+    for n in sizes:
+        out.append(arr[k:k + n * spp]); k += n * spp
+    return o1, o2, dr, out
+
+
+def py_latin_hypercube(n, rng):   # sampling.rs:273-306
+    inv = F32(1) / F32(n)
+    pts = []
+    for i in range(n):
+        x = min(F32(F32(i) + rng.f32()) * inv, ONE_MINUS_EPS)
+        y = min(F32(F32(i) + rng.f32()) * inv, ONE_MINUS_EPS)
+        pts.append([x, y])
+    for dim in range(2):
+        for j in range(n):
+            other = j + rng.bounded(n - j)
+            pts[j][dim], pts[other][dim] = pts[other][dim], pts[j][dim]
+    return [tuple(p) for p in pts]
+
+
+def test_sample_arrays_follow_the_vectors_in_the_tile_stream(oracle):
+    """every start_pixel refills the requested arrays AFTER the plain vectors, from the same PCG stream, so requesting arrays shifts
+    everything drawn later; each sampler fills them its own way (zerotwosequence.rs:131-148, maxmin.rs:137-152, stratified.rs:137-160,
+    random.rs:64-77), and round_count is a power of two for the two (0, 2)-sequence samplers only"""
+    sizes = [4, 8]
+    # 02sequence: sobol_2d(size, spp) per array
+    rd = desc("02sequence", 8, dimensions=2)
+    o1, o2, dr, arrs = oracle_arrays(oracle, rd, 21, sizes, n_pixels=2)
+    rng = PyRng(); rng.set_sequence(21)
+    for _ in range(2):
+        p1 = [py_van_der_corput(1, 8, rng) for _ in range(2)]
+        p2 = [py_sobol_2d(1, 8, rng) for _ in range(2)]
+        pa = [py_sobol_2d(n, 8, rng) for n in sizes]
+    assert np.array_equal(o1, np.array(p1, F32)) and np.array_equal(o2, np.array(p2, F32))
+    for got, exp in zip(arrs, pa):
+        assert np.array_equal(got, np.array(exp, F32))
+    a = rng.f32(); y = rng.f32(); x = rng.f32(); b = rng.f32()
+    assert np.array_equal(dr, np.array([a, x, y, b], F32))
+    # each pixel sample's slice of an array [s * n, (s + 1) * n) is a (0, 2)-net of n points (power-of-two n)
+    for got, n in zip(arrs, sizes):
+        for s in range(8):
+            sl = got[s * n:(s + 1) * n]
+            assert sorted((sl[:, 0] * n).astype(int)) == list(range(n)) and sorted((sl[:, 1] * n).astype(int)) == list(range(n))
+    # random: x first, straight from the stream
+    rd = desc("random", 4)
+    _, _, dr, arrs = oracle_arrays(oracle, rd, 5, [3])
+    rng = PyRng(); rng.set_sequence(5)
+    exp = [(rng.f32(), rng.f32()) for _ in range(3 * 4)]
+    assert np.array_equal(arrs[0], np.array(exp, F32))
+    a = rng.f32(); x = rng.f32(); y = rng.f32(); b = rng.f32()
+    assert np.array_equal(dr, np.array([a, x, y, b], F32))
+    # stratified: one latin hypercube of `size` points per pixel sample
+    rd = desc("stratified", strat=(2, 2), dimensions=1)
+    o1, o2, _, arrs = oracle_arrays(oracle, rd, 9, [5])
+    rng = PyRng(); rng.set_sequence(9)
+    v = [min(F32(F32(i) + rng.f32()) * F32(F32(1) / F32(4)), ONE_MINUS_EPS) for i in range(4)]; py_shuffle(v, 0, 4, 1, rng)
+    assert np.array_equal(o1[0], np.array(v, F32))
+    pts = []                                                    # stratified_sample_2d(2, 2) + shuffle (stratified.rs:118-135)
+    for yy in range(2):
+        for xx in range(2):
+            jx = rng.f32(); jy = rng.f32()
+            pts.append((min(F32(F32(xx) + jx) * F32(0.5), ONE_MINUS_EPS), min(F32(F32(yy) + jy) * F32(0.5), ONE_MINUS_EPS)))
+    py_shuffle(pts, 0, 4, 1, rng)
+    assert np.array_equal(o2[0], np.array(pts, F32))
+    exp = [p for _ in range(4) for p in py_latin_hypercube(5, rng)]
+    assert np.array_equal(arrs[0], np.array(exp, F32))
+    for s in range(4):                                           # a latin hypercube: one point per row and per column of the 5 x 5 grid
+        sl = arrs[0][s * 5:(s + 1) * 5]
+        assert sorted((sl[:, 0] * 5).astype(int)) == list(range(5)) and sorted((sl[:, 1] * 5).astype(int)) == list(range(5))
+    # maxmindist: arrays by sobol_2d like 02sequence, after its own vectors
+    rd = desc("maxmindist", 16, dimensions=2)
+    o1, o2, _, arrs = oracle_arrays(oracle, rd, 3, [2])
+    for s in range(16):
+        sl = arrs[0][s * 2:(s + 1) * 2]
+        assert sorted((sl[:, 0] * 2).astype(int)) == [0, 1] and sorted((sl[:, 1] * 2).astype(int)) == [0, 1]
+    rc = lambda name, n: oracle.lib().orc_round_count(C.addressof(desc(name, 16)), n)   # noqa: E731
+    assert [rc("02sequence", n) for n in (1, 3, 4, 5, 64, 65)] == [1, 4, 4, 8, 64, 128] and rc("maxmindist", 6) == 8 and rc("random", 6) == 6 and rc("stratified", 6) == 6
+
+
+def test_ao_renders_under_the_pixel_samplers_in_the_oracle(oracle):
+    """AOIntegrator with its 2-D array coming from a pixel sampler: thread-count invariant (tiles reseed by position) and the same
+    picture as under Sobol' within Monte-Carlo noise"""
+    sc = scenes.cornell_box(lib.bvh_build)
+    ref = oracle.render(sc, scenes.cornell_render_desc(res=32, spp=16, integrator="ao", ao_samples=16), threads=8)["film"]
+    for name in ("random", "02sequence", "stratified", "maxmindist"):
+        rd = scenes.cornell_render_desc(res=32, spp=16, sampler=name, strat=(4, 4), integrator="ao", ao_samples=16)
+        a = oracle.render(sc, rd, threads=1, want_li=True)
+        b = oracle.render(sc, rd, threads=5, want_li=True)
+        assert np.array_equal(a["li"], b["li"]) and a["counters"]["nan_samples"] == 0
+        m, r = scenes.film_to_rgb(a["film"]).mean(), scenes.film_to_rgb(ref).mean()
+        assert abs(m - r) < 0.03 * r, (name, m, r)
