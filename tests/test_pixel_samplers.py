@@ -285,3 +285,17 @@ def test_ao_renders_under_the_pixel_samplers_in_the_oracle(oracle):
         assert np.array_equal(a["li"], b["li"]) and a["counters"]["nan_samples"] == 0
         m, r = scenes.film_to_rgb(a["film"]).mean(), scenes.film_to_rgb(ref).mean()
         assert abs(m - r) < 0.03 * r, (name, m, r)
+
+
+def test_directlighting_renders_under_the_pixel_samplers_in_the_oracle(oracle):
+    """DirectLightingIntegrator with its per-light 2-D arrays (2 samples per light and bounce level: 2 x max_depth x n_lights arrays)
+    from a pixel sampler: thread-count invariant, both strategies, close to the Sobol' picture"""
+    sc = scenes.cornell_box(lib.bvh_build, "mixed_two_lobes")
+    ref = scenes.film_to_rgb(oracle.render_integrator(sc, scenes.cornell_render_desc(res=32, spp=64), "direct", threads=8)["film"]).mean()
+    for name in ("random", "02sequence", "stratified", "maxmindist"):
+        rd = scenes.cornell_render_desc(res=32, spp=64, sampler=name, strat=(8, 8))
+        for strategy in ("all", "one"):
+            a = oracle.render_integrator(sc, rd, "direct", strategy=strategy, light_samples=[2, 2], threads=1, want_li=True)
+            b = oracle.render_integrator(sc, rd, "direct", strategy=strategy, light_samples=[2, 2], threads=6, want_li=True)
+            assert np.array_equal(a["li"], b["li"]) and a["counters"]["nan_samples"] == 0
+            assert abs(scenes.film_to_rgb(a["film"]).mean() - ref) < 0.08 * ref, (name, strategy)
