@@ -14,9 +14,10 @@ frame is fixed) and the per-rank films are summed onto rank 0 by one ncclReduce 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8
 
 At N = 1 the line also carries (rank 0 only, outside the timed region of the headline):
-  roofline       the traversal kernel (k_trace_w4, closest-hit + shadow-ray launches): SURVEY §8(d) algorithmic bytes of
-                 one step / the sum of its per-launch durations (HIP events on each launch's own stream)
-  cpu_baseline   the C++ oracle's tile loop on all host cores (+ a 1-thread run) on a bounded sample of the same frame
+  roofline       the traversal kernel (k_trace_w4, closest-hit + shadow-ray launches): its measured limiter (L1 request rate, from the
+                 hash-matched PMC profile), its fabric-side traffic / the wall time of its launches against the 8 TB/s HBM peak, and
+                 SURVEY 8(d)'s algorithmic bytes as a rate (not a fraction); the same for the shade stage under roofline.shade
+  cpu_baseline   the C++ oracle's tile loop on all host cores on a bounded sample of the same frame (+ its 1-thread / all-thread scaling on one window)
   extra          C3 (the 4.3 M-triangle statue stand-in at 1920x1080x1024 spp — the north-star configuration) timed the
                  same way with its own roofline / cpu_baseline, and a 1/8-frame probe of the headline workload
                  (what one rank of an 8-GPU node renders)"""
@@ -113,27 +114,43 @@ def build_workload(args, workload, lib, scenes):
 
 
 def measured_traffic(lib, workload, default_cfg):
-    """HBM-side bytes of the trace launches of one step from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_traffic.json, written by tools/refresh_profiles.sh: FETCH_SIZE / WRITE_SIZE in separate
-    passes with the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process,
-    so the figure is only reported when the profile was taken with the same kernel sources (hash of
-    rs_pbrt_amd/csrc + include/rspt.h) and for the exact workload; otherwise null."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-    except (OSError, ValueError):
-        return None, "no profiles/r02_pmc_traffic.json"
-    w = t.get("workloads", {}).get(workload)
-    if not default_cfg or not w:
-        return None, "no PMC pass for this workload / size"
-    if t.get("source_hash") != lib.source_hash():
-        return None, "PMC pass is from other kernel sources (%s, library %s)" % (t.get("source_hash"), lib.source_hash())
-    return w, None
+    """PMC figures of one step from the committed rocprofv3 passes (profiles/rNN_pmc_traffic.json, written by tools/refresh_profiles.sh +
+    tools/pmc_to_json.py: FETCH_SIZE / WRITE_SIZE in separate passes with the gfx950 correction of MI355X_MICROARCH.md; TCP / SQ / TA passes
+    for the limiter ratios).  PMC counters cannot be read from inside this process, so the figures are only quoted as current when the
+    profile was taken with the same kernel sources (hash of rs_pbrt_amd/csrc + include/rspt.h) and for the exact workload; a profile of
+    other sources is passed on marked stale and never enters a ratio.  -> (record | None, note | None, stale record | None)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
+        return None, "no profiles/rNN_pmc_traffic.json", None
+    stale = None
+    for f in reversed(files):
+        try:
+            t = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        w = t.get("workloads", {}).get(workload)
+        if not default_cfg or not w:
+            continue
+        w = dict(w, file=os.path.relpath(f, ROOT), source_hash=t.get("source_hash"))
+        if t.get("source_hash") == lib.source_hash():
+            return w, None, None
+        stale = stale or w
+    if stale:
+        return None, "newest PMC pass (%s) is from other kernel sources (%s, library %s)" % (stale["file"], stale["source_hash"], lib.source_hash()), stale
+    return None, "no PMC pass for this workload / size", None
 
 
-def roofline_block(counts, count_scale, stats, traffic, traffic_note):
-    """the dominant kernel k_trace_w4 (closest-hit + shadow-ray launches of one step, this rank):
-    SURVEY.md §8(d) bytes = 32 B per BVH node fetched + 48 B per triangle tested + ray / hit queue records
-    (96 B per closest-hit ray, 72 B per any-hit ray), counted by the reference-order COUNT kernels in the warm-up pass."""
+def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_per_step):
+    """The dominant kernel k_trace_w4 (closest-hit + shadow-ray launches of one step, this rank) and, under "shade", the second one.
+
+    `bound` is the MEASURED limiter: the per-lane record loads saturate the CU's L1 request path
+    (l1_request_frac = TCP line probes per CU per cycle, ceiling 1) with VALU issue close behind; HBM is not it.  The HBM figures
+    (`achieved`, `frac`, `traffic`) are what the contract asks to see next to that: fabric-side bytes from the PMC passes (an upper bound of
+    HBM bytes: Infinity-Cache hits included) / the WALL time of the trace launches (closest-hit and shadow-ray launches overlap on two streams;
+    their summed durations would count that time twice).  SURVEY 8(d)'s algorithmic bytes (32 B per node visit + 48 B per triangle test of
+    the REFERENCE's traversal + queue records) are reported as `alg_bytes_per_launch` / `alg_rate_gbs`, NOT as a fraction of the HBM peak:
+    the four-box kernel fetches half as many, larger records and most of them from L2 / Infinity Cache, so that rate may exceed 8 TB/s."""
     n = len(stats)
     trace_bytes = count_scale * (32.0 * counts["nodes_visited"] + 48.0 * counts["tris_tested"] + 96.0 * counts["rays_closest"] + 72.0 * counts["rays_any"])
     t_c = sum(s["t_trace_closest_s"] for s in stats) / n
@@ -142,34 +159,55 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note):
     t_sh = sum(s["t_shade_s"] for s in stats) / n
     t_k = sum(s["t_kernels_s"] for s in stats) / n
     launches = stats[0]["launches_closest"] + stats[0]["launches_any"]
-    dur = t_c + t_a
-    achieved = trace_bytes / dur / 1e9
     rays = count_scale * (counts["rays_closest"] + counts["rays_any"])
-    out = {"bound": "hbm", "kernel": "k_trace_w4 (BVH traversal + triangle test; closest-hit + shadow-ray launches)",
-           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": (traffic["trace_traffic_bytes_per_step"] / max(launches, 1)) if traffic else None,
-           "launches_per_step": launches, "avg_launch_ms": dur / max(launches, 1) * 1e3, "alg_bytes_per_launch": trace_bytes / max(launches, 1),
-           "how": "algorithmic bytes of one step (SURVEY 8(d): 32 B/node visit + 48 B/triangle test + 96 B/closest ray + 72 B/any ray of the "
-                  "REFERENCE's traversal, counted in the warm-up) / sum of the per-launch durations of the step's trace launches, each "
-                  "bracketed by HIP events on the stream it runs on; the shadow-ray launch of a bounce overlaps the closest-hit launch on a "
-                  "second stream, so the sum (%.3f s) exceeds their wall time (%.3f s)" % (dur, t_wall),
-           "alg_bytes_per_step_rank0": trace_bytes,
+    # every duration that enters a ratio below is a wall time inside the step
+    assert t_wall <= ms_per_step * 1e-3 * 1.02 and t_sh <= ms_per_step * 1e-3 * 1.02 and t_wall + t_sh <= t_k * 1.02, (t_wall, t_sh, t_k, ms_per_step)
+    lim = (traffic or {}).get("limiters", {})
+    out = {"bound": "l1", "bound_detail": "L1 request rate of the per-lane BVH record loads (TA / TCP path), VALU issue close behind; not HBM, not MFMA",
+           "kernel": "k_trace_w4 (BVH traversal + triangle test; closest-hit + shadow-ray launches)",
+           "l1_request_frac": lim.get("trace_closest", {}).get("l1_request_frac"), "ta_busy": lim.get("trace_closest", {}).get("ta_busy"),
+           "valu_busy": lim.get("trace_closest", {}).get("valu_busy"),
+           "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+           "launches_per_step": launches, "avg_launch_ms": t_wall / max(launches, 1) * 1e3,
+           "alg_bytes_per_launch": trace_bytes / max(launches, 1), "alg_rate_gbs": trace_bytes / t_wall / 1e9, "alg_bytes_per_step_rank0": trace_bytes,
+           "how": "achieved = PMC fabric-side bytes of the step's trace launches (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) / their wall time (%.3f s; "
+                  "per-launch HIP-event durations sum to %.3f s because the shadow-ray launch of a bounce overlaps the closest-hit launch on a second stream); "
+                  "frac = achieved / 8 TB/s; l1_request_frac / ta_busy / valu_busy from the TCP / TA / SQ passes of the same profile" % (t_wall, t_c + t_a),
            "seconds_per_step": {"trace_closest_launches": t_c, "trace_any_launches": t_a, "trace_wall_overlapped": t_wall, "shade_launches": t_sh, "all_kernels_wall": t_k},
            "whole_path_alg_bytes_per_sample": counts["alg_bytes"] / max(counts["samples"], 1),
            "rays_per_sample": (counts["rays_closest"] + counts["rays_any"]) / max(counts["samples"], 1),
            "nodes_per_ray": counts["nodes_visited"] / max(counts["rays_closest"] + counts["rays_any"], 1),
            "tris_per_ray": counts["tris_tested"] / max(counts["rays_closest"] + counts["rays_any"], 1),
-           "mrays_per_s": rays / dur / 1e6}
+           "mrays_per_s": rays / t_wall / 1e6}
+    # the shade stage (k_bin_* + k_texture + k_shade): SURVEY 8(d) prices it at 48 B per closest-hit ray (32 B ray record written + 16 B hit record
+    # read) + 36 B per shadow ray (32 B written + 4 B flag read) + 96 B of path state per bounce
+    n_bounce = count_scale * (counts["alg_bytes"] - 32.0 * counts["samples"]) / 96.0 - trace_bytes / 96.0
+    shade_alg = 48.0 * count_scale * counts["rays_closest"] + 36.0 * count_scale * counts["rays_any"] + 96.0 * n_bounce
+    sh = {"bound": "latency", "bound_detail": "2 waves / SIMD (VGPRs): dependent loads of the interaction fill, light sample and BSDF evaluation are not hidden",
+          "kernel": "k_shade (+ k_bin_*, k_texture)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+          "alg_bytes_per_step": shade_alg, "alg_rate_gbs": shade_alg / t_sh / 1e9 if t_sh > 0 else None, "seconds_per_step": t_sh,
+          "valu_busy": lim.get("shade", {}).get("valu_busy"), "wait_frac": lim.get("shade", {}).get("wait_frac"), "waves_per_simd": lim.get("shade", {}).get("waves_per_simd")}
     if traffic:
         tb = traffic["trace_traffic_bytes_per_step"]
-        out["traffic_frac_of_peak"] = tb / dur / 1e9 / HBM_PEAK_GBS
+        out["achieved"] = tb / t_wall / 1e9
+        out["frac"] = out["achieved"] / HBM_PEAK_GBS
+        out["traffic"] = tb / max(launches, 1)
         out["traffic_over_algorithmic"] = tb / trace_bytes
-        out["traffic_source"] = traffic.get("source", "profiles/r02_pmc_traffic.json")
-        out["bound_note"] = ("fabric-side traffic (L2 misses, Infinity-Cache hits included) is %.2f x the algorithmic bytes: the BVH records are served "
-                             "from L2 / Infinity Cache, so HBM bandwidth is not what limits this kernel on this scene; the limiter is the L1 request "
-                             "rate of the per-lane record loads (profiles/r02_pmc_trace_l1.md)" % (tb / trace_bytes))
+        out["traffic_source"] = "%s (source hash %s = this library)" % (traffic["file"], traffic["source_hash"])
+        sb = traffic.get("shade_traffic_bytes_per_step")
+        if sb and t_sh > 0:
+            sh["achieved"] = sb / t_sh / 1e9
+            sh["frac"] = sh["achieved"] / HBM_PEAK_GBS
+            sh["traffic"] = sb
+            sh["traffic_over_algorithmic"] = sb / shade_alg
+        for fr in (out["frac"], sh["frac"], out["l1_request_frac"], out["ta_busy"], out["valu_busy"]):
+            assert fr is None or 0.0 <= fr <= 1.0, "a printed fraction left [0, 1]: %r" % fr
     else:
         out["traffic_note"] = traffic_note
+        if stale:   # shown, marked, in no ratio
+            out["stale_profile"] = {"file": stale["file"], "source_hash": stale["source_hash"], "trace_traffic_bytes_per_step": stale["trace_traffic_bytes_per_step"],
+                                    "limiters": stale.get("limiters")}
+    out["shade"] = sh
     return out
 
 
@@ -181,7 +219,7 @@ def time_steps(step, fence, n):
     return time.perf_counter() - t0, stats
 
 
-def cpu_baseline(args, pyoracle, sc, mk_rd, spp, one_thread_crop):
+def cpu_baseline(args, pyoracle, sc, mk_rd, spp, scaling_crop):
     ncores = os.cpu_count() or 1
     rd_cpu = mk_rd(spp, (0, 1, 64))
     def cpu_render(rd_, threads):
@@ -202,15 +240,18 @@ def cpu_baseline(args, pyoracle, sc, mk_rd, spp, one_thread_crop):
                                           "rays_closest": c["rays_closest"] / c["samples"], "rays_any": c["rays_any"] / c["samples"],
                                           "alg_bytes": (32.0 * c["nodes_visited"] + 48.0 * c["tris_tested"] + 96.0 * c["rays_closest"] + 72.0 * c["rays_any"]
                                                         + 96.0 * c["bounces"] + 32.0 * c["samples"]) / c["samples"]}}
-    rd1 = mk_rd(spp, (0, 1, 64), crop=one_thread_crop)
-    r1 = cpu_render(rd1, 1)
-    out["one_thread"] = {"value": r1["counters"]["samples"] / r1["seconds"] / 1e6, "unit": "Msamples/s",
-                         "sample": "crop window %s of the frame at %d spp (%d samples), 1 thread, %.1f s" % (list(rd1.crop_px), spp, r1["counters"]["samples"], r1["seconds"])}
-    out["thread_scaling"] = out["value"] / out["one_thread"]["value"]
+    # how the port scales with threads, on ONE sample for both runs: a crop window of 256 tiles (one per hardware thread of the box) at 1/4 of the spp
+    rd_s = mk_rd(max(spp // 4, 1), (0, 1, 64), crop=scaling_crop)
+    r1, rn = cpu_render(rd_s, 1), cpu_render(rd_s, ncores)
+    v1, vn = r1["counters"]["samples"] / r1["seconds"] / 1e6, rn["counters"]["samples"] / rn["seconds"] / 1e6
+    out["thread_scaling"] = {"ratio": vn / v1, "one_thread": v1, "all_threads": vn, "unit": "Msamples/s",
+                             "sample": "crop window %s of the frame at %d spp (%d samples) for BOTH runs: 1 thread %.1f s, %d threads %.1f s (the tile loop hands out 16x16 tiles: "
+                                       "%d tiles in this window)" % (list(rd_s.crop_px), max(spp // 4, 1), r1["counters"]["samples"], r1["seconds"], ncores, rn["seconds"],
+                                                                     ((rd_s.crop_px[2] - rd_s.crop_px[0] + 15) // 16) * ((rd_s.crop_px[3] - rd_s.crop_px[1] + 15) // 16))}
     return out
 
 
-def measure(args, lib, scenes, workload, steps, warmup, shard, world, reduce_in_lib, torch_reduce, fence, count_spp_div=1):
+def measure(args, lib, scenes, workload, steps, warmup, shard, world, reduce_in_lib, torch_reduce, fence, count_spp_div=1, rank0=True):
     """scene build + upload + counting pass + warm-up + timed steps for one workload on this rank"""
     import torch
     t0 = time.time()
@@ -222,11 +263,14 @@ def measure(args, lib, scenes, workload, steps, warmup, shard, world, reduce_in_
     ds = lib.DeviceScene(sc)
     t_upload = time.time() - t0
     film = torch.zeros(scenes.n_pixels(rd) * 4, dtype=torch.float32, device="cuda")
+    film_host = torch.zeros(scenes.n_pixels(rd) * 4, dtype=torch.float32).pin_memory() if rank0 else None
 
     def step():
         st = lib.render_device(ds, rd, film.data_ptr())  # the reduce (N > 1) runs inside, on the library's stream, before it returns
         if torch_reduce:
             torch_reduce(film)
+        if film_host is not None:   # t_render ends with the film in host memory (rank 0 holds the frame)
+            film_host.copy_(film)
         return st
 
     # counting pass (deterministic: identical counts in the timed passes) for the algorithmic-bytes roofline; rank-local, no reduce
@@ -289,7 +333,7 @@ def main():
         torch.cuda.synchronize()
 
     shard = multigpu.shard_for_rank(rank, world)  # Morton-ordered tiles dealt round-robin over the ranks
-    m = measure(args, lib, scenes, args.workload, args.steps, args.warmup, shard, world, reduce_in_lib, torch_reduce, fence)
+    m = measure(args, lib, scenes, args.workload, args.steps, args.warmup, shard, world, reduce_in_lib, torch_reduce, fence, rank0=rank == 0)
     elapsed, stats = m["elapsed"], m["stats"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -303,17 +347,18 @@ def main():
 
     if rank == 0:
         default_cfg = args.tris == 1_000_000 and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
-        traffic, tnote = measured_traffic(lib, args.workload, default_cfg)
+        traffic, tnote, stale = measured_traffic(lib, args.workload, default_cfg)
+        ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "Mpath-samples/sec (whole node)", "value": samples_per_step * args.steps / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": m["name"], "samples_per_step": samples_per_step, "tiles": "16x16 tiles in Morton order dealt round-robin to the ranks (tile_chunk %d)" % multigpu.TILE_CHUNK,
                        "film_reduce": reduce_name,
-                       "timed_region": "rspt_render_device per step: first launch -> film complete in HBM%s; SURVEY 8(d)'s t_render ends with the film in "
-                                       "host memory: + 16 B per pixel D2H once per frame (%.1f MB), not included" % (
+                       "timed_region": "per step: rspt_render_device (first launch -> film complete in HBM%s) + the copy of the film to pinned host memory "
+                                       "(%.1f MB): SURVEY 8(d)'s t_render, first launch -> film in host memory" % (
                                            " on rank 0 after the reduce" if world > 1 else "", scenes.n_pixels(m["rd"]) * 16 / 1e6)},
-            "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote) if m["counts"] else (
+            "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote, stale, ms_per_step) if m["counts"] else (
                 {"bound": "latency", "kernel": "k_tile_serial (one lane per tile: camera sample, reference-order traversal and shade_path in turn)", "achieved": None, "peak": None,
                  "unit": None, "frac": None, "traffic": None,
                  "note": "the pixel samplers make a tile one serial chain (DESIGN.md section 5.7): the bound is the dependent-load latency of one lane, "
@@ -327,7 +372,7 @@ def main():
             rd0 = m["rd"]
             cx, cy = (rd0.crop_px[0] + rd0.crop_px[2]) // 2, (rd0.crop_px[1] + rd0.crop_px[3]) // 2
             fx, fy = float(rd0.full_res[0]), float(rd0.full_res[1])
-            out["cpu_baseline"] = cpu_baseline(args, pyoracle, m["sc"], m["mk_rd"], args.cpu_spp, ((cx - 24) / fx, (cx + 24) / fx, (cy - 24) / fy, (cy + 24) / fy))
+            out["cpu_baseline"] = cpu_baseline(args, pyoracle, m["sc"], m["mk_rd"], args.cpu_spp, ((cx - 128) / fx, (cx + 128) / fx, (cy - 128) / fy, (cy + 128) / fy))
         if world == 1 and not args.no_extra and args.workload == "soup1m" and default_cfg:
             extra = {}
             # what the ranks of an 8-GPU node render: every shard (r, 8, tile_chunk) of the same frame on this one GPU, same kernels, no reduce;
@@ -354,11 +399,11 @@ def main():
             s3 = float(m3["stats"][0]["samples"])
             c3 = {"metric": "Mpath-samples/sec", "value": s3 * 2 / m3["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 2, "warmup": 1,
                   "ms_per_step": m3["elapsed"] / 2 * 1e3, "config": {"workload": m3["name"], "samples_per_step": s3},
-                  "roofline": roofline_block(m3["counts"], m3["count_scale"], m3["stats"], *measured_traffic(lib, "statue", True)),
+                  "roofline": roofline_block(m3["counts"], m3["count_scale"], m3["stats"], *measured_traffic(lib, "statue", True), m3["elapsed"] / 2 * 1e3),
                   "setup_s": {"scene_and_bvh_build": m3["t_scene"], "upload": m3["t_upload"]}}
             c3["roofline"]["counting_pass"] = "reference-order counters at 1/16 of the spp, scaled (per-sample means; SURVEY 8(d))"
             if pyoracle is not None:
-                c3["cpu_baseline"] = cpu_baseline(args, pyoracle, m3["sc"], m3["mk_rd"], args.cpu_spp, (0.4875, 0.5125, 0.478, 0.522))
+                c3["cpu_baseline"] = cpu_baseline(args, pyoracle, m3["sc"], m3["mk_rd"], args.cpu_spp, (832 / 1920, 1088 / 1920, 412 / 1080, 668 / 1080))
                 c3["gpu_over_cpu"] = c3["value"] / c3["cpu_baseline"]["value"]
             extra["c3_statue_standin"] = c3
             m3["ds"].close()

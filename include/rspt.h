@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 17
+#define RSPT_ABI_VERSION 18
 
 /* error codes */
 #define RSPT_OK 0
@@ -89,12 +89,48 @@ typedef struct {
     float g;
 } rspt_medium; /* 32 B */
 
-/* ---- materials: pre-assembled BxDF lists ------------------------------------------
- * With constant textures every Material::compute_scattering_functions
- * (src/core/material.rs:63-113, src/materials/{matte,plastic,...}.rs) pushes the
- * same lobes at every hit, so the shim evaluates the recipe once per material and
- * hands over the lobe list.  Lobe order is the push order (it matters:
- * Bsdf::sample_f picks the comp-th matching lobe, reflection.rs:307-336). */
+/* ---- materials: the parameters of Material::create, assembled into BxDF lists by the library --------------------
+ * Every parameter of a reference material is a texture (TextureParams::get_spectrum_texture / get_float_texture wrap a literal
+ * value in a ConstantTexture, src/core/paramset.rs:622-735), so a material record is the material's kind plus one texture
+ * reference per parameter: 1 + index into textures[], 0 = parameter absent (possible only for the *_or_null parameters:
+ * bumpmap; metal / uber uroughness, vroughness).  Float parameters read the first channel of their texture.  The shim passes
+ * what the reference's material structs hold and nothing else; Material::compute_scattering_functions
+ * (src/core/material.rs:63-113, src/materials/{matte,plastic,mirror,glass,metal,substrate,uber,translucent,mixmat}.rs) is
+ * restated by the library (rs_pbrt_amd/csrc/material_assembly.h): parameters bound to constant textures are folded into the
+ * lobe list once per material (clamp, `is_black` guards, roughness remapping, OrenNayar A / B), parameters bound to other
+ * textures are evaluated per hit by the texture stage.  Which parameters may be non-constant: Kd, Ks, roughness / uroughness /
+ * vroughness of matte, plastic, substrate, uber and metal, and bumpmap; anything else is answered with RSPT_E_UNSUPPORTED by
+ * rspt_scene_create and the caller keeps its CPU loop. */
+enum {
+    RSPT_MAT_MATTE = 1,       /* matte.rs:43-86:       kd, sigma, bumpmap                                               */
+    RSPT_MAT_PLASTIC = 2,     /* plastic.rs:57-125:    kd, ks, roughness, remap_roughness, bumpmap                      */
+    RSPT_MAT_MIRROR = 3,      /* mirror.rs:34-70:      kr, bumpmap                                                      */
+    RSPT_MAT_GLASS = 4,       /* glass.rs:83-211:      kr, kt, uroughness, vroughness, index, remap_roughness, bumpmap  */
+    RSPT_MAT_METAL = 5,       /* metal.rs:144-205:     eta, k, roughness, [uroughness], [vroughness], remap_roughness, bumpmap */
+    RSPT_MAT_SUBSTRATE = 6,   /* substrate.rs:62-114:  kd, ks, uroughness, vroughness, remap_roughness, bumpmap         */
+    RSPT_MAT_UBER = 7,        /* uber.rs:114-259:      kd, ks, kr, kt, roughness, [uroughness], [vroughness], opacity, index, remap_roughness, bumpmap */
+    RSPT_MAT_TRANSLUCENT = 8, /* translucent.rs:64-189: kd, ks, reflect, transmit, roughness, remap_roughness, bumpmap  */
+    RSPT_MAT_MIX = 9          /* mixmat.rs:43-305:     m1, m2 (material indices), amount                                */
+};
+typedef struct {
+    uint32_t kind;            /* RSPT_MAT_*                                                                              */
+    uint32_t kd, ks, kr, kt;  /* spectrum parameters "Kd" "Ks" "Kr" "Kt"                                                */
+    uint32_t reflect, transmit; /* translucent                                                                           */
+    uint32_t opacity;         /* uber                                                                                    */
+    uint32_t eta, k;          /* metal: spectrum "eta", "k"                                                              */
+    uint32_t amount;          /* mix: spectrum "amount" (MixMaterial.scale)                                              */
+    uint32_t sigma;           /* matte: float, degrees                                                                   */
+    uint32_t roughness, uroughness, vroughness; /* float                                                                 */
+    uint32_t index;           /* glass / uber: float "index" (uber.rs calls it eta)                                      */
+    uint32_t bumpmap;         /* float, or 0                                                                             */
+    uint32_t remap_roughness; /* "remaproughness" (default true)                                                         */
+    uint32_t m1, m2;          /* mix: indices into materials[]; neither may be a mix itself (the reference drops the outer
+                                 scale of a nested mix, mixmat.rs:50: `_scale`)                                          */
+} rspt_material_desc; /* 80 B */
+
+/* What the library assembles from a material record: the BxDF list of Bsdf.bxdfs in push order (it matters: Bsdf::sample_f
+ * picks the comp-th matching lobe, reflection.rs:307-336).  Not an input of the ABI; rspt_material_lobes returns it so that a
+ * test can compare the assembly with a restatement of the reference's recipes. */
 enum {
     RSPT_BXDF_LAMBERT_R = 1,    /* LambertianReflection      reflection.rs:953-998   */
     RSPT_BXDF_OREN_NAYAR = 2,   /* OrenNayar                 reflection.rs:1049-1125 */
@@ -127,7 +163,7 @@ typedef struct {
     float sc[3];        /* MixMaterial scale of this lobe (sc_opt, src/materials/mixmat.rs:43-70):
                            the reference multiplies it in front of the lobe's value       */
     uint32_t has_sc;    /* 0 = sc_opt is None                                         */
-    uint32_t tex_r;     /* 0, or 1 + index of the texture the material binds to this lobe's colour:
+    uint32_t tex_r;     /* 0, or 1 + index of the texture bound to this lobe's colour:
                            the lobe is built with  r * texture.evaluate(si).clamp(0, inf)  (e.g.
                            matte.rs:59-62 with r = 1; uber.rs `op * kd`), evaluated per hit     */
     uint32_t tex_t;     /* the same for t (FRESNEL_SPEC T, FRESNEL_BLEND Rs).  A lobe whose resulting
@@ -137,12 +173,16 @@ typedef struct {
                            (plastic.rs:86-92, uber.rs, substrate.rs:76-85, metal.rs, translucent.rs); per hit
                            alpha_x = max(0.001, remap ? roughness_to_alpha(v) : v) (microfacet.rs:233-254)        */
     uint32_t tex_ay;    /* the same for alpha_y ("vroughness"; materials with one roughness bind it to both)     */
-    uint32_t remap;     /* "remaproughness" of the textured alphas                                               */
+    uint32_t remap;     /* "remaproughness" of the textured alphas; bit 1 (RSPT_LOBE_NODIFF): the lobe came from the m2 side of a
+                           MixMaterial, whose textures are evaluated at an interaction rebuilt without ray differentials
+                           (mixmat.rs:58-69: SurfaceInteraction::new)                                              */
 } rspt_bxdf; /* 116 B */
+#define RSPT_LOBE_REMAP 1u
+#define RSPT_LOBE_NODIFF 2u
 
 typedef struct {
     float eta;          /* Bsdf.eta (reflection.rs:224)                               */
-    uint32_t first_bxdf, n_bxdfs; /* slice of bxdfs[]; n_bxdfs <= 8 (reflection.rs:40) */
+    uint32_t first_bxdf, n_bxdfs; /* slice of the lobe list; n_bxdfs <= 8 (reflection.rs:40) */
     uint32_t bump_tex;  /* 0, or 1 + index of the float texture of Material::bump
                            (src/core/material.rs:116-219), applied before the lobes are built */
 } rspt_material;
@@ -271,8 +311,7 @@ typedef struct {
     const float* S;             /* xyz per vertex or NULL                             */
     const float* UV;            /* uv  per vertex or NULL                             */
     uint64_t n_vertices;
-    const rspt_material* materials; uint32_t n_materials;
-    const rspt_bxdf* bxdfs;         uint32_t n_bxdfs;
+    const rspt_material_desc* materials; uint32_t n_materials;
     const rspt_light* lights;       uint32_t n_lights;
     const rspt_envmap* envmaps;     uint32_t n_envmaps;
     const rspt_texture* textures;   uint32_t n_textures;
@@ -459,6 +498,15 @@ int rspt_trace(rspt_scene_t scene, const rspt_ray* rays, uint64_t n, rspt_hit* o
  * demand are built by this call. */
 int rspt_light_distribution(rspt_scene_t scene, uint32_t light_strategy, const float p[3], float* func_out, float* cdf_out,
                             int32_t nvox_out[3], int32_t voxel_out[3]);
+
+/* Stage-level hook, host only (no device, may be called without rspt_init).  Replaces: Material::compute_scattering_functions
+ * (src/core/material.rs:63-113) for material `material` of a scene description, with the integrator's allow_multiple_lobes
+ * (true for path / volpath / ao, false for directlighting): out_material / out_bxdfs (room for 8) receive the
+ * lobe list the library assembles for that material — what Bsdf.bxdfs holds after the call wherever the material's textures are
+ * constant; tex_* fields carry 1 + the index of the texture that completes a lobe per hit.  Returns the number of lobes, or an
+ * RSPT_E_* code (RSPT_E_UNSUPPORTED names the parameter that may not be textured). */
+int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t allow_multiple_lobes, rspt_material* out_material,
+                        rspt_bxdf out_bxdfs[8]);
 
 /* Stage-level hook.  Replaces: f32::sin / cos / ln / log2 / exp / acos / atan2 as the path uses them (concentric_sample_disk
  * sampling.rs:360-382, Trowbridge-Reitz sampling microfacet.rs:475-531, spherical directions and mappings, MIP level selection, roughness

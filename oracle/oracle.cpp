@@ -70,27 +70,41 @@ static Interaction unit_frame() {
     it.p = V3{0, 0, 0}; it.p_error = V3{0, 0, 0};
     return it;
 }
-void orc_bsdf_f(const rspt_material* m, const rspt_bxdf* all, const float wo[3], const float wi[3], uint32_t flags, float f_out[3], float* pdf_out) {
+// surf (may be NULL = the unit frame at the origin): p[3], uv[2], dudx, dvdx, dudy, dvdy, dpdx[3], dpdy[3]
+static Interaction surf_interaction(const float* surf);
+void orc_bsdf_f(const rspt_scene_desc* d, uint32_t material, int allow_multiple_lobes, const float wo[3], const float wi[3], uint32_t flags, float f_out[3], float* pdf_out) {
     Interaction it = unit_frame();
-    Scene sc{}; sc.d.bxdfs = all;  // constant-colour lobes only: no texture tables needed
-    Bsdf b(sc, it, *m);
+    Scene sc{*d};
+    Bsdf b;
+    make_bsdf(sc, it, material, allow_multiple_lobes != 0, &b);
     Spec f = b.f(V3{wo[0], wo[1], wo[2]}, V3{wi[0], wi[1], wi[2]}, (uint8_t)flags);
     f_out[0] = f.c[0]; f_out[1] = f.c[1]; f_out[2] = f.c[2];
     *pdf_out = b.pdf(V3{wo[0], wo[1], wo[2]}, V3{wi[0], wi[1], wi[2]}, (uint8_t)flags);
 }
-void orc_bsdf_sample_f(const rspt_material* m, const rspt_bxdf* all, const float wo[3], float ux, float uy, uint32_t flags,
+void orc_bsdf_sample_f(const rspt_scene_desc* d, uint32_t material, int allow_multiple_lobes, const float wo[3], float ux, float uy, uint32_t flags,
                        float f_out[3], float wi_out[3], float* pdf_out, uint32_t* sampled_type) {
     Interaction it = unit_frame();
-    Scene sc{}; sc.d.bxdfs = all;
-    Bsdf b(sc, it, *m);
+    Scene sc{*d};
+    Bsdf b;
+    make_bsdf(sc, it, material, allow_multiple_lobes != 0, &b);
     V3 wi{0, 0, 0}; Float pdf = 0; uint8_t st = 255;
     Spec f = b.sample_f(V3{wo[0], wo[1], wo[2]}, &wi, P2{ux, uy}, &pdf, (uint8_t)flags, &st);
     f_out[0] = f.c[0]; f_out[1] = f.c[1]; f_out[2] = f.c[2];
     wi_out[0] = wi.x; wi_out[1] = wi.y; wi_out[2] = wi.z; *pdf_out = pdf; *sampled_type = st;
 }
+// Material::compute_scattering_functions at one surface point: Bsdf.eta and Bsdf.bxdfs (values only: every texture evaluated).
+// Returns the number of BxDFs; out_bxdfs has room for 8.
+int orc_material_lobes(const rspt_scene_desc* d, uint32_t material, int allow_multiple_lobes, const float* surf, float* eta_out, rspt_bxdf* out_bxdfs) {
+    Interaction it = surf ? surf_interaction(surf) : unit_frame();
+    Scene sc{*d};
+    Bsdf b;
+    make_bsdf(sc, it, material, allow_multiple_lobes != 0, &b);
+    *eta_out = b.eta;
+    for (int i = 0; i < b.n; i++) out_bxdfs[i] = *b.lobes[i].b;
+    return b.n;
+}
 
 // ---- texture hooks ----
-// surf: p[3], uv[2], dudx, dvdx, dudy, dvdy, dpdx[3], dpdy[3]
 static Interaction surf_interaction(const float* surf) {
     Interaction it = unit_frame();
     it.p = V3{surf[0], surf[1], surf[2]}; it.uv = P2{surf[3], surf[4]};

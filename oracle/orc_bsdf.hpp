@@ -360,41 +360,25 @@ struct Bsdf {
     Float eta;
     V3 ns, ng, ss, ts;
     Lobe lobes[8];
-    rspt_bxdf local[8]; // lobes whose colours come from textures are built per hit
+    rspt_bxdf local[8]; // Bsdf.bxdfs: Vec<Bxdf> with capacity 8
     int n = 0;
+    Bsdf() = default;
     Bsdf(const Bsdf&) = delete;
     Bsdf& operator=(const Bsdf&) = delete;
-    // Material::compute_scattering_functions for the pre-assembled lobe list: Material::bump first
-    // (material.rs:116-219), then Bsdf::new (:235-245), then one `bsdf.add` per lobe whose
-    // (texture-modulated) colour is not black (matte.rs:59-83, plastic.rs:60-108, uber.rs, substrate.rs:60-90)
-    Bsdf(const Scene& sc, Interaction& si, const rspt_material& m) {
-        if (m.bump_tex) bump(sc, m.bump_tex - 1, &si);
-        eta = m.eta;
+    // Bsdf::new (reflection.rs:235-245)
+    void init(const Interaction& si, Float eta_) {
+        eta = eta_;
         ss = normalize(si.sh_dpdu);
         ns = si.sh_n; ng = si.n;
         ts = cross(si.sh_n, ss); // nrm_cross_vec3
-        const rspt_bxdf* all = sc.d.bxdfs;
-        for (uint32_t i = 0; i < m.n_bxdfs && i < 8; i++) {
-            const rspt_bxdf& g = all[m.first_bxdf + i];
-            if (!g.tex_r && !g.tex_t && !g.tex_ax && !g.tex_ay) { lobes[n++] = Lobe{&g}; continue; }
-            rspt_bxdf b = g;
-            // roughness textures: `rough = tex.evaluate(si); if remap { rough = roughness_to_alpha(rough) }`, then
-            // TrowbridgeReitzDistribution::new clamps to >= 0.001 (plastic.rs:86-92, microfacet.rs:233-254)
-            auto alpha_of = [&](uint32_t tex) {
-                Float v = tex_eval(sc, tex - 1, si).c[0];
-                if (g.remap) { Float r = std::fmax(v, 1e-3f), x = std::log(r); v = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; }
-                return std::fmax(0.001f, v);
-            };
-            if (g.tex_ax) b.alpha_x = alpha_of(g.tex_ax);
-            if (g.tex_ay) b.alpha_y = alpha_of(g.tex_ay);
-            if (g.tex_r) { Spec v = S3(g.r) * sclamp0(tex_eval(sc, g.tex_r - 1, si)); b.r[0] = v.c[0]; b.r[1] = v.c[1]; b.r[2] = v.c[2]; }
-            if (g.tex_t) { Spec v = S3(g.t) * sclamp0(tex_eval(sc, g.tex_t - 1, si)); b.t[0] = v.c[0]; b.t[1] = v.c[1]; b.t[2] = v.c[2]; }
-            bool two = g.type == RSPT_BXDF_FRESNEL_SPEC || g.type == RSPT_BXDF_FRESNEL_BLEND;
-            if ((g.tex_r || g.tex_t) && (two ? (S3(b.r).is_black() && S3(b.t).is_black()) : S3(b.r).is_black())) continue;
-            local[n] = b;
-            lobes[n] = Lobe{&local[n]};
-            n++;
-        }
+        n = 0;
+    }
+    // Bsdf::add (reflection.rs:246-249)
+    void add(const rspt_bxdf& b) {
+        if (n >= 8) { std::fprintf(stderr, "oracle: assertion failed: self.bxdfs.len() < MAX_BXDFS (reflection.rs:247)\n"); std::abort(); }
+        local[n] = b;
+        lobes[n] = Lobe{&local[n]};
+        n++;
     }
     int num_components(uint8_t flags) const { int c = 0; for (int i = 0; i < n; i++) if (lobes[i].matches_flags(flags)) c++; return c; }
     V3 world_to_local(V3 v) const { return V3{dot(v, ss), dot(v, ts), dot(v, ns)}; }

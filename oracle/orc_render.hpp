@@ -8,7 +8,7 @@
 #include <mutex>
 #include <thread>
 
-#include "orc_bsdf.hpp"
+#include "orc_material.hpp"
 
 namespace orc {
 
@@ -848,7 +848,8 @@ static inline Spec path_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Counte
             // isect.compute_scattering_functions (interaction.rs:371-386): differentials of the camera ray
             // (bounce rays carry none), then the material
             compute_differentials(&isect, ray);
-            Bsdf bsdf(sc, isect, sc.d.materials[hp.material]);
+            Bsdf bsdf;
+            make_bsdf(sc, isect, hp.material, true, &bsdf); // path.rs:108: allow_multiple_lobes = true
             if (c) c->bounces++;
             // lookup happens for every hit (path.rs:118); with no lights its result is never used
             const Distribution1D* distrib = sc.d.n_lights ? light_lookup(cx, isect.p) : nullptr;
@@ -1199,7 +1200,8 @@ static inline Spec volpath_li(RenderCtx& cx, const Ray& r, Sampler& sampler, Cou
                 if (bounces >= cx.rd->max_depth) break;
                 if (hp.material == 0xffffffffu) { ray = isect.spawn_ray(ray.d); continue; } // :141-145: `continue` skips `bounces += 1`
                 compute_differentials(&isect, ray);
-                Bsdf bsdf(sc, isect, sc.d.materials[hp.material]);
+                Bsdf bsdf;
+                make_bsdf(sc, isect, hp.material, true, &bsdf); // volpath.rs:146
                 if (c) c->bounces++;
                 if (sc.d.n_lights) {
                     const Distribution1D* distrib = light_lookup(cx, isect.p);
@@ -1374,7 +1376,8 @@ static inline Spec recursive_li(RenderCtx& cx, const Ray& ray, Sampler& sampler,
     V3 n_before = isect.sh_n; // whitted.rs:58: shading.n read before compute_scattering_functions (i.e. before a bump map moves it)
     if (hp.material == 0xffffffffu) return recursive_li(cx, isect.spawn_ray(ray.d), sampler, depth, c);
     compute_differentials(&isect, ray);
-    Bsdf bsdf(sc, isect, sc.d.materials[hp.material]);
+    Bsdf bsdf;
+    make_bsdf(sc, isect, hp.material, false, &bsdf); // directlighting.rs:86 / whitted.rs:63: allow_multiple_lobes = false
     if (c) c->bounces++;
     V3 wo = isect.wo;
     if (hp.area_light >= 0) l = l + light_l(sc.d.lights[hp.area_light], isect.n, wo); // isect.le(&wo)

@@ -52,9 +52,11 @@ def lib():
         L.orc_offset_ray_origin.restype = None; L.orc_offset_ray_origin.argtypes = [C.c_void_p] * 5
         L.orc_concentric_sample_disk.restype = None; L.orc_concentric_sample_disk.argtypes = [C.c_float, C.c_float, C.c_void_p]
         L.orc_bsdf_f.restype = None
-        L.orc_bsdf_f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_bsdf_f.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_bsdf_sample_f.restype = None
-        L.orc_bsdf_sample_f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bsdf_sample_f.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_material_lobes.restype = C.c_int
+        L.orc_material_lobes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_halton_permutations.restype = C.c_uint64; L.orc_halton_permutations.argtypes = [C.c_int, C.c_void_p]
         L.orc_halton_index.restype = C.c_uint64; L.orc_halton_index.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64]
         L.orc_halton_sample.restype = C.c_float; L.orc_halton_sample.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
@@ -83,6 +85,17 @@ def lib():
         L.orc_bump.restype = None; L.orc_bump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def material_lobes(scene, material, allow_multiple_lobes=True, uv=(0.0, 0.0), p=(0.0, 0.0, 0.0), duv=(0.0, 0.0, 0.0, 0.0)):
+    """Material::compute_scattering_functions of material `material` of a scenes.Scene at a surface point: (Bsdf.eta, Bsdf.bxdfs as
+    BXDF_DT records with every parameter texture evaluated)"""
+    from rs_pbrt_amd import abi  # layouts only
+    surf = np.array(list(p) + list(uv) + list(duv) + [0.0] * 6, np.float32)
+    bx = np.zeros(8, abi.BXDF_DT)
+    eta = C.c_float(0)
+    n = lib().orc_material_lobes(C.addressof(scene.desc), int(material), int(bool(allow_multiple_lobes)), surf.ctypes.data, C.addressof(eta), bx.ctypes.data)
+    return float(eta.value), bx[:n].copy()
 
 
 def tex_eval(scene, tex, uv=(0.0, 0.0), p=(0.0, 0.0, 0.0), duv=(0.0, 0.0, 0.0, 0.0), dpdx=(0.0, 0.0, 0.0), dpdy=(0.0, 0.0, 0.0)):

@@ -4,13 +4,15 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
 
 BXDF_LAMBERT_R, BXDF_OREN_NAYAR, BXDF_SPECULAR_R, BXDF_SPECULAR_T, BXDF_FRESNEL_SPEC, BXDF_MICROFACET_R, BXDF_LAMBERT_T = 1, 2, 3, 4, 5, 6, 7
 BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9
 FRESNEL_NOOP, FRESNEL_DIELECTRIC, FRESNEL_CONDUCTOR = 0, 1, 2
+MAT_MATTE, MAT_PLASTIC, MAT_MIRROR, MAT_GLASS, MAT_METAL, MAT_SUBSTRATE, MAT_UBER, MAT_TRANSLUCENT, MAT_MIX = range(1, 10)
+LOBE_REMAP, LOBE_NODIFF = 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
 SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_RANDOM, SAMPLER_ZEROTWO, SAMPLER_STRATIFIED, SAMPLER_MAXMINDIST = 1, 2, 3, 4, 5, 6
 INTEGRATOR_PATH, INTEGRATOR_AO, INTEGRATOR_DIRECT, INTEGRATOR_VOLPATH = 0, 1, 2, 3
@@ -52,6 +54,14 @@ class Bxdf(C.Structure):
                 ("tex_ax", C.c_uint32), ("tex_ay", C.c_uint32), ("remap", C.c_uint32)]
 
 
+MATERIAL_DESC_FIELDS = ("kind", "kd", "ks", "kr", "kt", "reflect", "transmit", "opacity", "eta", "k", "amount", "sigma", "roughness", "uroughness", "vroughness",
+                        "index", "bumpmap", "remap_roughness", "m1", "m2")
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [(f, C.c_uint32) for f in MATERIAL_DESC_FIELDS]
+
+
 class Material(C.Structure):
     _fields_ = [("eta", C.c_float), ("first_bxdf", C.c_uint32), ("n_bxdfs", C.c_uint32), ("bump_tex", C.c_uint32)]
 
@@ -83,7 +93,6 @@ class SceneDesc(C.Structure):
                 ("P", C.c_void_p), ("N", C.c_void_p), ("S", C.c_void_p), ("UV", C.c_void_p),
                 ("n_vertices", C.c_uint64),
                 ("materials", C.c_void_p), ("n_materials", C.c_uint32),
-                ("bxdfs", C.c_void_p), ("n_bxdfs", C.c_uint32),
                 ("lights", C.c_void_p), ("n_lights", C.c_uint32),
                 ("envmaps", C.c_void_p), ("n_envmaps", C.c_uint32),
                 ("textures", C.c_void_p), ("n_textures", C.c_uint32),
@@ -144,6 +153,7 @@ MEDIUM_DT = np.dtype([("kind", "<u4"), ("sigma_a", "<f4", 3), ("sigma_s", "<f4",
 BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
                     ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4"),
                     ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4"), ("tex_ax", "<u4"), ("tex_ay", "<u4"), ("remap", "<u4")])
+MATERIAL_DESC_DT = np.dtype([(f, "<u4") for f in MATERIAL_DESC_FIELDS])
 MATERIAL_DT = np.dtype([("eta", "<f4"), ("first_bxdf", "<u4"), ("n_bxdfs", "<u4"), ("bump_tex", "<u4")])
 TEXTURE_DT = np.dtype([("kind", "<u4"), ("mapping", "<u4"), ("map", "<f4", 8), ("image", "<u4"), ("trilinear", "<u4"), ("max_aniso", "<f4"),
                        ("wrap", "<u4"), ("value", "<f4", 3), ("tex1", "<u4"), ("tex2", "<u4"), ("tex3", "<u4"), ("world_to_texture", "<f4", 16),
@@ -157,6 +167,7 @@ HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), 
 assert NODE_DT.itemsize == C.sizeof(BvhNode) == 32
 assert PRIM_DT.itemsize == C.sizeof(Prim) == 24
 assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 116
+assert MATERIAL_DESC_DT.itemsize == C.sizeof(MaterialDesc) == 80
 assert TEXTURE_DT.itemsize == C.sizeof(Texture) == 160
 assert RAY_DT.itemsize == C.sizeof(Ray) == 32
 assert HIT_DT.itemsize == C.sizeof(Hit) == 20

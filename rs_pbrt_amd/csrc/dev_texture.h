@@ -27,7 +27,8 @@ struct TexTables {
 };
 #define RSPT_SLOT_ALPHA 0x80000000u     // slot descriptor flags: the texture drives a lobe alpha ...
 #define RSPT_SLOT_REMAP 0x40000000u     // ... through roughness_to_alpha
-#define RSPT_SLOT_TEX_MASK 0x3fffffffu
+#define RSPT_SLOT_NODIFF 0x20000000u    // the m2 side of a MixMaterial: evaluated at an interaction without ray differentials (mixmat.rs:58-69)
+#define RSPT_SLOT_TEX_MASK 0x1fffffffu
 #define RSPT_MAT_TEXTURED 1u
 #define RSPT_MAT_BUMP 2u
 // per-path results of k_texture, SoA [row][path]: rows 0..3 = clamp(texture value) of the material's

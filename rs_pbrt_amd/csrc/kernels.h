@@ -614,7 +614,13 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
         const uint32_t sd = tt.mat_slots[(size_t)tri.material * RSPT_TEX_SLOTS + k];
         if (sd != 0xffffffffu) {
             const uint32_t ti = sd & RSPT_SLOT_TEX_MASK;
-            rgb v = tex_eval(tt, ti, s);
+            rgb v;
+            if (sd & RSPT_SLOT_NODIFF) {  // MixMaterial hands m2 a SurfaceInteraction::new(p, uv, ..): no dudx .. dpdy (mixmat.rs:58-69)
+                TexSurf s2 = s;
+                s2.dudx = s2.dvdx = s2.dudy = s2.dvdy = 0.0f;
+                s2.dpdx = s2.dpdy = f3{0.0f, 0.0f, 0.0f};
+                v = tex_eval(tt, ti, s2);
+            } else v = tex_eval(tt, ti, s);
             if (sd & RSPT_SLOT_ALPHA) {  // a roughness texture: the slot carries the lobe's alpha (plastic.rs:86-92, microfacet.rs:233-254)
                 float a = v.r;
                 if (sd & RSPT_SLOT_REMAP) {

@@ -3,7 +3,6 @@
 // entry point that needs the GPU fails with RSPT_E_NODEVICE / RSPT_E_HIP when it is not there.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: the entry points are bound with dlopen when a communicator is asked for
 
 #include <algorithm>
 #include <chrono>
@@ -19,6 +18,7 @@
 #include <vector>
 
 #include "../../include/rspt.h"
+#include "material_assembly.h"
 #include "kernels.h"
 #include "trace_w4.h"
 #include "bvh_device.h"
@@ -99,6 +99,13 @@ Ctx g;
 // X1: the one collective of the multi-GPU decomposition, ncclReduce(sum) of the per-rank films onto rank 0
 // over xGMI.  RCCL is bound at run time so that single-GPU hosts need no librccl; a process that already has one loaded
 // (torch ships its own copy) shares it.
+// The handful of RCCL types the dlopen'ed entry points take, declared here with rccl.h's values (ncclFloat32 = 7, ncclSum = 0,
+// NCCL_UNIQUE_ID_BYTES = 128) so that a host without the RCCL development headers still builds the library.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
 struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -161,6 +168,23 @@ struct rspt_scene_s {
     bool w4_ok = false;               // false: too large for the ref fields, k_trace_pw serves the scene
     TexTables tex{};                  // textures / images / per-material slots (dev_texture.h); has_textures says whether set
     bool has_textures = false;
+    // Lobe lists as material_assembly.h built them, once per value of the integrator's allow_multiple_lobes ([0]: true — path,
+    // volpath, ao; [1]: false — directlighting: glass as SpecularReflection + SpecularTransmission, glass.rs:136-188).
+    // select_materials() points dev / tex at the set a render needs.
+    struct MatSet {
+        const rspt_material* materials = nullptr;
+        const rspt_bxdf* bxdfs = nullptr;
+        const uint32_t* mat_slots = nullptr;
+        const uint8_t* mat_flags = nullptr;
+        bool textured = false;
+    } mat_set[2];
+    void select_materials(bool allow_multiple_lobes) {
+        const MatSet& m = mat_set[allow_multiple_lobes ? 0 : 1];
+        dev.materials = m.materials; dev.bxdfs = m.bxdfs;
+        tex.mat_slots = m.mat_slots; tex.mat_flags = m.mat_flags;
+        dev.mat_flags = m.textured ? m.mat_flags : nullptr;
+        has_textures = m.textured;
+    }
     std::vector<void*> allocs;
     bool has_null_material = false;
     uint32_t n_materials = 0;
@@ -491,6 +515,7 @@ uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PE
 int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (!s || !d) return fail(RSPT_E_INVALID, "null scene or render desc");
+    s->select_materials(d->integrator != RSPT_INTEGRATOR_DIRECT);  // allow_multiple_lobes: false in DirectLightingIntegrator::li only (directlighting.rs:86)
     const bool halton = d->sampler_kind == RSPT_SAMPLER_HALTON;
     const bool sobol = d->sampler_kind == RSPT_SAMPLER_SOBOL;
     const bool pixel_sampler = d->sampler_kind >= RSPT_SAMPLER_RANDOM && d->sampler_kind <= RSPT_SAMPLER_MAXMINDIST;  // one serial chain per tile: tile_serial.h
@@ -1309,7 +1334,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     *out = nullptr;
     if (d->n_prims > 0x7fffffffull || d->n_nodes > 0x7fffffffull) return fail(RSPT_E_UNSUPPORTED, "more than 2^31 primitives / nodes");
     if ((d->n_nodes && !d->nodes) || (d->n_prims && (!d->prims || !d->meshes || !d->P)) || (d->n_materials && !d->materials) ||
-        (d->n_bxdfs && !d->bxdfs) || (d->n_lights && !d->lights))
+        (d->n_lights && !d->lights))
         return fail(RSPT_E_INVALID, "null array with non-zero count");
     if ((d->n_nodes == 0) != (d->n_prims == 0)) return fail(RSPT_E_INVALID, "nodes and prims must both be empty or both non-empty");
     // ---- validate indices on the host (a bad scene must not fault the GPU) ----
@@ -1369,12 +1394,6 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             if (p.mesh != RSPT_MESH_INSTANCE && p.mesh < d->n_meshes && p.area_light >= 0 && (d->meshes[p.mesh].alpha_tex || d->meshes[p.mesh].shadow_alpha_tex))
                 return fail(RSPT_E_UNSUPPORTED, "prim %llu: an emissive mesh with an alpha mask", (unsigned long long)i);
         }
-    for (uint32_t i = 0; i < d->n_materials; i++) {
-        const rspt_material& m = d->materials[i];
-        if (m.n_bxdfs > 8 || (uint64_t)m.first_bxdf + m.n_bxdfs > d->n_bxdfs) return fail(RSPT_E_INVALID, "material %u: bad bxdf slice", i);
-    }
-    for (uint32_t i = 0; i < d->n_bxdfs; i++)
-        if (d->bxdfs[i].type < RSPT_BXDF_LAMBERT_R || d->bxdfs[i].type > RSPT_BXDF_FRESNEL_BLEND) return fail(RSPT_E_UNSUPPORTED, "bxdf %u: unsupported type %u", i, d->bxdfs[i].type);
     for (uint32_t i = 0; i < d->n_lights; i++) {
         if (d->lights[i].kind < RSPT_LIGHT_DIFFUSE_AREA || d->lights[i].kind > RSPT_LIGHT_INFINITE) return fail(RSPT_E_UNSUPPORTED, "light %u: unsupported kind %u", i, d->lights[i].kind);
         if (d->lights[i].kind == RSPT_LIGHT_DIFFUSE_AREA && (d->lights[i].prim >= n_top_prims || d->prims[d->lights[i].prim].mesh == RSPT_MESH_INSTANCE))
@@ -1422,11 +1441,20 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             if (dep > RSPT_TEX_MAX_DEPTH) return fail(RSPT_E_UNSUPPORTED, "texture %u: graph deeper than %d levels", i, RSPT_TEX_MAX_DEPTH);
         }
     }
-    for (uint32_t i = 0; i < d->n_bxdfs; i++)
-        if (d->bxdfs[i].tex_r > d->n_textures || d->bxdfs[i].tex_t > d->n_textures || d->bxdfs[i].tex_ax > d->n_textures || d->bxdfs[i].tex_ay > d->n_textures)
-            return fail(RSPT_E_INVALID, "bxdf %u: texture index out of range", i);
-    for (uint32_t i = 0; i < d->n_materials; i++)
-        if (d->materials[i].bump_tex > d->n_textures) return fail(RSPT_E_INVALID, "material %u: bump texture index out of range", i);
+    // materials: Material::compute_scattering_functions restated on the host (material_assembly.h), once per allow_multiple_lobes
+    std::vector<rspt_material> asm_mats[2];
+    std::vector<rspt_bxdf> asm_bx[2];
+    for (int v = 0; v < 2; v++) {
+        rspt_mat::Assembler as(d, v == 0);
+        rspt_mat::Lobes lb;
+        asm_mats[v].resize(d->n_materials);
+        for (uint32_t i = 0; i < d->n_materials; i++) {
+            if (rspt_mat::Error e = as.assemble(i, &lb)) return fail(e.code, "%s", e.text.c_str());
+            lb.mat.first_bxdf = (uint32_t)asm_bx[v].size();
+            asm_mats[v][i] = lb.mat;
+            asm_bx[v].insert(asm_bx[v].end(), lb.lobes.begin(), lb.lobes.end());
+        }
+    }
     if (d->n_envmaps && !d->envmaps) return fail(RSPT_E_INVALID, "null envmaps");
     for (uint32_t i = 0; i < d->n_envmaps; i++) {
         const rspt_envmap& e = d->envmaps[i];
@@ -1502,41 +1530,48 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((rc = upload(s, d->N, d->N ? d->n_vertices * 3 : 0, &s->dev.N))) return bail(rc);
     if ((rc = upload(s, d->S, d->S ? d->n_vertices * 3 : 0, &s->dev.S))) return bail(rc);
     if ((rc = upload(s, d->UV, d->UV ? d->n_vertices * 2 : 0, &s->dev.UV))) return bail(rc);
-    if ((rc = upload(s, d->materials, d->n_materials, &s->dev.materials))) return bail(rc);
     {   // lobes: texture ids become per-material slot numbers (1 + slot) for k_texture / k_shade
-        std::vector<rspt_bxdf> bx(d->bxdfs, d->bxdfs + d->n_bxdfs);
-        std::vector<uint32_t> slots((size_t)d->n_materials * RSPT_TEX_SLOTS, 0xffffffffu);
-        std::vector<uint8_t> mflags(d->n_materials, 0);
         bool any = false;
-        for (uint32_t m = 0; m < d->n_materials; m++) {
-            const rspt_material& mat = d->materials[m];
-            uint32_t* sl = slots.data() + (size_t)m * RSPT_TEX_SLOTS;
-            uint32_t n_sl = 0;
-            auto slot_of = [&](uint32_t tex_plus_1, uint32_t flags = 0u) -> int {
-                const uint32_t desc = (tex_plus_1 - 1u) | flags;
-                for (uint32_t k = 0; k < n_sl; k++) if (sl[k] == desc) return (int)k + 1;
-                if (n_sl == RSPT_TEX_SLOTS) return -1;
-                sl[n_sl++] = desc;
-                return (int)n_sl;
-            };
-            for (uint32_t l = 0; l < mat.n_bxdfs; l++) {
-                rspt_bxdf& b = bx[mat.first_bxdf + l];
-                if (b.tex_r) { int k = slot_of(b.tex_r); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_r = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
-                if (b.tex_t) { int k = slot_of(b.tex_t); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_t = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
-                const uint32_t aflags = RSPT_SLOT_ALPHA | (b.remap ? RSPT_SLOT_REMAP : 0u);
-                if (b.tex_ax) { int k = slot_of(b.tex_ax, aflags); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_ax = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
-                if (b.tex_ay) { int k = slot_of(b.tex_ay, aflags); if (k < 0) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS)); b.tex_ay = (uint32_t)k; mflags[m] |= RSPT_MAT_TEXTURED; }
+        for (int v = 0; v < 2; v++) {
+            std::vector<rspt_bxdf>& bx = asm_bx[v];
+            std::vector<uint32_t> slots((size_t)d->n_materials * RSPT_TEX_SLOTS, 0xffffffffu);
+            std::vector<uint8_t> mflags(d->n_materials, 0);
+            bool any_v = false;
+            for (uint32_t m = 0; m < d->n_materials; m++) {
+                const rspt_material& mat = asm_mats[v][m];
+                uint32_t* sl = slots.data() + (size_t)m * RSPT_TEX_SLOTS;
+                uint32_t n_sl = 0;
+                bool full = false;
+                auto slot_of = [&](uint32_t tex_plus_1, uint32_t flags) -> uint32_t {
+                    const uint32_t desc = (tex_plus_1 - 1u) | flags;
+                    for (uint32_t k = 0; k < n_sl; k++) if (sl[k] == desc) return k + 1u;
+                    if (n_sl == RSPT_TEX_SLOTS) { full = true; return 1u; }
+                    sl[n_sl++] = desc;
+                    return n_sl;
+                };
+                for (uint32_t l = 0; l < mat.n_bxdfs; l++) {
+                    rspt_bxdf& b = bx[mat.first_bxdf + l];
+                    const uint32_t nd = (b.remap & RSPT_LOBE_NODIFF) ? RSPT_SLOT_NODIFF : 0u;  // the m2 side of a mix (mixmat.rs:58-69)
+                    const uint32_t aflags = RSPT_SLOT_ALPHA | ((b.remap & RSPT_LOBE_REMAP) ? RSPT_SLOT_REMAP : 0u) | nd;
+                    if (b.tex_r) { b.tex_r = slot_of(b.tex_r, nd); mflags[m] |= RSPT_MAT_TEXTURED; }
+                    if (b.tex_t) { b.tex_t = slot_of(b.tex_t, nd); mflags[m] |= RSPT_MAT_TEXTURED; }
+                    if (b.tex_ax) { b.tex_ax = slot_of(b.tex_ax, aflags); mflags[m] |= RSPT_MAT_TEXTURED; }
+                    if (b.tex_ay) { b.tex_ay = slot_of(b.tex_ay, aflags); mflags[m] |= RSPT_MAT_TEXTURED; }
+                }
+                if (full) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS));
+                if (mat.bump_tex) mflags[m] |= RSPT_MAT_BUMP;
+                any_v |= mflags[m] != 0;
             }
-            if (mat.bump_tex) mflags[m] |= RSPT_MAT_BUMP;
-            any |= mflags[m] != 0;
-        }
-        if ((rc = upload(s, bx.data(), bx.size(), &s->dev.bxdfs))) return bail(rc);
-        if (any || any_alpha) {
-            s->has_textures = any;  // k_texture / per-path texture rows only when a material is textured; alpha masks just need the tables
-            if ((rc = upload(s, d->textures, d->n_textures, &s->tex.textures)) || (rc = upload(s, slots.data(), slots.size(), &s->tex.mat_slots)) ||
-                (rc = upload(s, mflags.data(), mflags.size(), &s->tex.mat_flags)))
+            rspt_scene_s::MatSet& ms = s->mat_set[v];
+            ms.textured = any_v;
+            any |= any_v;
+            if ((rc = upload(s, asm_mats[v].data(), asm_mats[v].size(), &ms.materials)) || (rc = upload(s, bx.data(), bx.size(), &ms.bxdfs)) ||
+                (rc = upload(s, slots.data(), slots.size(), &ms.mat_slots)) || (rc = upload(s, mflags.data(), mflags.size(), &ms.mat_flags)))
                 return bail(rc);
-            if (any) s->dev.mat_flags = s->tex.mat_flags;
+        }
+        s->select_materials(true);
+        if (any || any_alpha) {  // k_texture / per-path texture rows only when a material is textured; alpha masks just need the tables
+            if ((rc = upload(s, d->textures, d->n_textures, &s->tex.textures))) return bail(rc);
             std::vector<ImageDev> imgs(d->n_images);
             std::vector<float> pool;  // every pyramid, back to back
             for (uint32_t i = 0; i < d->n_images; i++) {
@@ -1800,6 +1835,16 @@ int rspt_render_device(rspt_scene_t s, const rspt_render_desc* d, void* film_dev
 int rspt_render_samples(rspt_scene_t s, const rspt_render_desc* d, float* li_rgb, rspt_stats* stats) {
     if (!li_rgb) return fail(RSPT_E_INVALID, "null li_rgb");
     return render_impl(s, d, nullptr, nullptr, li_rgb, stats);
+}
+
+int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t allow_multiple_lobes, rspt_material* out_material, rspt_bxdf out_bxdfs[8]) {
+    if (!desc || !out_material || !out_bxdfs) return fail(RSPT_E_INVALID, "null argument");
+    rspt_mat::Assembler as(desc, allow_multiple_lobes != 0);
+    rspt_mat::Lobes lb;
+    if (rspt_mat::Error e = as.assemble(material, &lb)) return fail(e.code, "%s", e.text.c_str());
+    *out_material = lb.mat;
+    for (size_t i = 0; i < lb.lobes.size(); i++) out_bxdfs[i] = lb.lobes[i];
+    return (int)lb.lobes.size();
 }
 
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {

@@ -15,7 +15,8 @@ _LIB = None
 EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create", "rspt_scene_destroy", "rspt_render",
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
            "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
-           "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy", "rspt_light_distribution", "rspt_libm")
+           "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy", "rspt_light_distribution", "rspt_libm",
+           "rspt_material_lobes")
 
 
 def source_hash():
@@ -70,6 +71,7 @@ def lib():
         L.rspt_bvh_build_gpu.argtypes = [vp, u64, vp, u64, u32, vp, u64, vp]
         L.rspt_light_distribution.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         L.rspt_libm.argtypes = [u32, vp, vp, C.c_uint64, vp]
+        L.rspt_material_lobes.argtypes = [vp, u32, u32, vp, vp]
         L.rspt_comm_unique_id.argtypes = [vp]
         L.rspt_comm_init.argtypes = [i32, i32, vp]
         _LIB = L
@@ -79,6 +81,17 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise RsptError(rc, (lib().rspt_last_error() or b"").decode("utf-8", "replace"))
+
+
+def material_lobes(scene, material, allow_multiple_lobes=True):
+    """The lobe list librspt assembles for material `material` of a scenes.Scene (rspt_material_lobes; host only, no device):
+    (eta, bump_tex, lobes BXDF_DT[]) — tex_* fields are 1 + texture index."""
+    mat = abi.Material()
+    bx = np.zeros(8, abi.BXDF_DT)
+    n = lib().rspt_material_lobes(C.addressof(scene.desc), int(material), int(bool(allow_multiple_lobes)), C.addressof(mat), bx.ctypes.data)
+    if n < 0:
+        _check(n)
+    return float(mat.eta), int(mat.bump_tex), bx[:n].copy()
 
 
 def bvh_build(P, tri, max_prims_in_node=4, threads=0):

@@ -195,59 +195,19 @@ class Transform:
 
 
 # ---------------------------------------------------------------------------------------
-# materials -> lobe lists (src/materials/*.rs with constant textures)
+# materials: the parameters of src/materials/*.rs `create`, handed to the library as they are (rspt_material_desc).
+# No recipe lives here any more: which lobes a material pushes is decided by librspt (csrc/material_assembly.h) and,
+# independently, by the oracle's restatement of compute_scattering_functions (oracle/orc_material.hpp).
 # ---------------------------------------------------------------------------------------
-def tr_roughness_to_alpha(rough):  # microfacet.rs:243-254, f32
-    r = F32(max(float(rough), 1e-3))
-    x = F32(math.log(float(r)))
-    a = F32(1.62142) + F32(0.819955) * x + F32(0.1734) * x * x + F32(0.0171201) * x * x * x + F32(0.000640711) * x * x * x * x
-    return F32(a)
-
-
-def _lobe(**kw):
-    b = np.zeros((), abi.BXDF_DT)
-    for k, v in kw.items():
-        b[k] = v
-    return b
-
-
-def _alpha(a):
-    return max(float(a), 0.001)  # TrowbridgeReitzDistribution::new microfacet.rs:233-239
-
-
-def _rough(ru, rv, remap):
-    """lobe fields for a pair of roughness parameters (numbers, or float textures evaluated per hit)"""
-    out = dict(remap=int(bool(remap)))
-    for key, tkey, r in (("alpha_x", "tex_ax", ru), ("alpha_y", "tex_ay", rv)):
-        if hasattr(r, "index"):  # TexRef
-            out[key], out[tkey] = 0.001, r.index + 1
-        else:
-            out[key] = _alpha(tr_roughness_to_alpha(r) if remap else F32(r))
-    return out
-
-
 class TexRef:
-    """A texture of the scene being built (SceneBuilder.*_texture) used where a material takes a colour:
-    the lobe stores the constant factor (1, or uber's opacity) and 1 + texture index; the
-    `is_black` test that decides whether the lobe exists moves to shade time."""
+    """A texture of the scene being built (SceneBuilder.*_texture) bound to a material parameter."""
 
     def __init__(self, index):
         self.index = int(index)
 
 
-def _col(x, scale=None):
-    """(rgb factor, 1 + texture index or 0, may_be_nonblack) of a material colour parameter"""
-    sc = np.ones(3, F32) if scale is None else np.asarray(scale, F32)
-    if isinstance(x, TexRef):
-        return sc.astype(F32), x.index + 1, bool(sc.any())
-    c = (sc * np.maximum(np.array(x, F32), 0)).astype(F32) if scale is not None else np.maximum(np.array(x, F32), 0)
-    return c, 0, bool(c.any())
-
-
-def _with_bump(m, bump):
-    if bump is not None:
-        m["bump"] = bump.index
-    return m
+SPECTRUM_PARAMS = ("kd", "ks", "kr", "kt", "reflect", "transmit", "opacity", "eta", "k", "amount")
+FLOAT_PARAMS = ("sigma", "roughness", "uroughness", "vroughness", "index", "bumpmap")
 
 
 def _pbrt_rgb(name, v):
@@ -267,164 +227,90 @@ def _pbrt_bump(bump):
     return "" if bump is None else ' "texture bumpmap" "tex%d"' % bump.index
 
 
-def _pbrt(m, text, *params):
-    """the `Material` directive that makes rs_pbrt build this recipe (tools/export_pbrt.py)"""
-    m["pbrt"] = text
-    return m
+def _pbrt_bool(name, v):
+    return '"bool %s" ["%s"]' % (name, "true" if v else "false")
 
 
-def matte(kd, sigma=0.0, bump=None):  # matte.rs:43-86
-    return _pbrt(_matte(kd, sigma, bump), 'Material "matte" %s "float sigma" [%.9g]%s' % (_pbrt_rgb("Kd", kd), float(sigma), _pbrt_bump(bump)), kd)
+def _material(kind, text, remap=True, **params):
+    """a material record: kind, the Material directive that makes rs_pbrt build it (tools/export_pbrt.py), and its parameters
+    (a number / rgb triple = the ConstantTexture TextureParams would make of it, a TexRef, or None for an absent *_or_null one)"""
+    return dict(kind=kind, pbrt=text, remap=bool(remap), params=params)
 
 
-def _matte(kd, sigma=0.0, bump=None):
-    kd, tk, any_kd = _col(kd)
-    if not any_kd:
-        return _with_bump(dict(eta=1.0, lobes=[]), bump)
-    sigma = min(max(float(sigma), 0.0), 90.0)
-    if sigma == 0.0:
-        return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_LAMBERT_R, r=kd, tex_r=tk)]), bump)
-    s = F32(F32(F32(math.pi) / F32(180)) * F32(sigma)); s2 = F32(s * s)  # OrenNayar::new reflection.rs:1057-1065
-    a = F32(1) - F32(s2 / F32(F32(2) * F32(s2 + F32(0.33))))
-    b = F32(F32(0.45) * s2) / F32(s2 + F32(0.09))
-    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_OREN_NAYAR, r=kd, tex_r=tk, on_a=a, on_b=b)]), bump)
+def material_texrefs(m):
+    """(TexRef, "float" | "spectrum") of every parameter of material record m that is bound to a texture of the scene"""
+    for name, v in m["params"].items():
+        if isinstance(v, TexRef):
+            yield v, ("spectrum" if name in SPECTRUM_PARAMS else "float")
 
 
-def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True, bump=None):  # plastic.rs:57-125
-    return _pbrt(_plastic(kd, ks, roughness, remap, bump), 'Material "plastic" %s %s %s "bool remaproughness" ["%s"]%s'
-                 % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_float("roughness", roughness), "true" if remap else "false", _pbrt_bump(bump)))
+def material_scene(m):
+    """(geometry-free Scene, material index) for one material record built from literals"""
+    sb = SceneBuilder()
+    i = sb.add_material(m)
+    return sb.materials_only(), i
 
 
-def _plastic(kd, ks, roughness, remap, bump):
-    lobes = []
-    kd, tkd, any_kd = _col(kd); ks, tks, any_ks = _col(ks)
-    if any_kd:
-        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd, tex_r=tkd))
-    if any_ks:
-        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, tex_r=tks, eta_a=1.5, eta_b=1.0,
-                           **_rough(roughness, roughness, remap)))
-    return _with_bump(dict(eta=1.0, lobes=lobes), bump)
+def matte(kd, sigma=0.0, bump=None):  # matte.rs:26-42
+    return _material(abi.MAT_MATTE, 'Material "matte" %s %s%s' % (_pbrt_rgb("Kd", kd), _pbrt_float("sigma", sigma), _pbrt_bump(bump)), kd=kd, sigma=sigma, bumpmap=bump)
 
 
-def mirror(kr=(0.9,) * 3):  # mirror.rs:34-70 (pushed even if black)
-    return dict(pbrt='Material "mirror" %s' % _pbrt_rgb("Kr", kr), eta=1.0, lobes=[_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_NOOP, r=np.maximum(np.array(kr, F32), 0))])
+def plastic(kd=(0.25,) * 3, ks=(0.25,) * 3, roughness=0.1, remap=True, bump=None):  # plastic.rs:42-56
+    return _material(abi.MAT_PLASTIC, 'Material "plastic" %s %s %s %s%s' % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_float("roughness", roughness),
+                                                                        _pbrt_bool("remaproughness", remap), _pbrt_bump(bump)), remap, kd=kd, ks=ks, roughness=roughness, bumpmap=bump)
 
 
-def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, multiple_lobes=True):  # glass.rs:83-211, smooth surface
-    """multiple_lobes: the integrator's allow_multiple_lobes — true for `path` (one FresnelSpecular lobe), false for
-    `directlighting` / `whitted` (SpecularReflection with a dielectric Fresnel + SpecularTransmission, glass.rs:136-188)"""
-    r, t = np.maximum(np.array(kr, F32), 0), np.maximum(np.array(kt, F32), 0)
-    text = 'Material "glass" %s %s "float index" [%.9g]' % (_pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), float(index))   # the same directive: the integrator decides the form
-    if multiple_lobes:
-        return dict(pbrt=text, eta=index, lobes=[_lobe(type=abi.BXDF_FRESNEL_SPEC, r=r, t=t, eta_a=1.0, eta_b=index)])
-    lobes = []
-    if r.any():
-        lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=r, eta_a=1.0, eta_b=index))
-    if t.any():
-        lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=t, eta_a=1.0, eta_b=index))
-    return dict(pbrt=text, eta=index, lobes=lobes)
+def mirror(kr=(0.9,) * 3, bump=None):  # mirror.rs:24-33
+    return _material(abi.MAT_MIRROR, 'Material "mirror" %s%s' % (_pbrt_rgb("Kr", kr), _pbrt_bump(bump)), kr=kr, bumpmap=bump)
 
 
-def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True):  # metal.rs:144-205
-    return dict(pbrt='Material "metal" %s %s %s "bool remaproughness" ["%s"]'
-                % (_pbrt_rgb("eta", eta), _pbrt_rgb("k", k), _pbrt_float("roughness", roughness), "true" if remap else "false"), eta=1.0, lobes=[_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_CONDUCTOR, r=(1, 1, 1), c1=eta, c2=k,
-                                      **_rough(roughness, roughness, remap))])
-
-
-def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True, bump=None):  # substrate.rs:62-114
-    text = 'Material "substrate" %s %s %s %s "bool remaproughness" ["%s"]%s' % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_float("uroughness", uroughness),
-                                                                             _pbrt_float("vroughness", vroughness), "true" if remap else "false", _pbrt_bump(bump))
-    kd, tkd, any_kd = _col(kd); ks, tks, any_ks = _col(ks)
-    if not any_kd and not any_ks:
-        return _with_bump(dict(eta=1.0, lobes=[], pbrt=text), bump)
-    return _with_bump(dict(eta=1.0, lobes=[_lobe(type=abi.BXDF_FRESNEL_BLEND, r=kd, t=ks, tex_r=tkd, tex_t=tks, **_rough(uroughness, vroughness, remap))], pbrt=text), bump)
-
-
-def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness=0.1, uroughness=None, vroughness=None,
-         opacity=(1.0,) * 3, index=1.5, remap=True, bump=None):  # uber.rs:114-259
-    kd_in, ks_in, kr_in, kt_in = kd, ks, kr, kt
-    e = F32(index)
-    op = np.maximum(np.array(opacity, F32), 0)
-    t = np.maximum(F32(1) - op, 0).astype(F32)  # (-op + 1).clamp(0, inf)
-    lobes = []
-    eta = 1.0
-    if t.any():
-        lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=t, eta_a=1.0, eta_b=1.0))
-    else:
-        eta = float(e)
-    kd, tkd, any_kd = _col(kd, op)
-    if any_kd:
-        lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=kd, tex_r=tkd))
-    ks, tks, any_ks = _col(ks, op)
-    if any_ks:
-        ru = roughness if uroughness is None else uroughness
-        rv = roughness if vroughness is None else vroughness
-        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=ks, tex_r=tks, eta_a=1.0, eta_b=e, **_rough(ru, rv, remap)))
-    kr = (op * np.maximum(np.array(kr, F32), 0)).astype(F32)
-    if kr.any():
-        lobes.append(_lobe(type=abi.BXDF_SPECULAR_R, fresnel=abi.FRESNEL_DIELECTRIC, r=kr, eta_a=1.0, eta_b=e))
-    kt = (op * np.maximum(np.array(kt, F32), 0)).astype(F32)
-    if kt.any():
-        lobes.append(_lobe(type=abi.BXDF_SPECULAR_T, r=kt, eta_a=1.0, eta_b=e))
-    text = None
-    if not any(isinstance(x, TexRef) for x in (opacity, kr, kt)):   # the export names what the library takes: Kd / Ks / roughness may be textures
-        text = 'Material "uber" %s %s %s %s %s%s%s %s "float index" [%.9g] "bool remaproughness" ["%s"]%s' % (
-            _pbrt_rgb("Kd", kd_in), _pbrt_rgb("Ks", ks_in), _pbrt_rgb("Kr", kr_in), _pbrt_rgb("Kt", kt_in), _pbrt_float("roughness", roughness),
-            "" if uroughness is None else " " + _pbrt_float("uroughness", uroughness), "" if vroughness is None else " " + _pbrt_float("vroughness", vroughness),
-            _pbrt_rgb("opacity", opacity), float(index), "true" if remap else "false", _pbrt_bump(bump))
-    return _with_bump(dict(eta=eta, lobes=lobes, pbrt=text), bump)
-
-
-def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.5,) * 3, roughness=0.1, remap=True):  # translucent.rs:64-189
-    eta = F32(1.5)
-    text = 'Material "translucent" %s %s %s %s "float roughness" [%.9g] "bool remaproughness" ["%s"]' % (
-        _pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_rgb("reflect", reflect), _pbrt_rgb("transmit", transmit), float(roughness), "true" if remap else "false")
-    r = np.maximum(np.array(reflect, F32), 0); t = np.maximum(np.array(transmit, F32), 0)
-    if not r.any() and not t.any():
-        return dict(eta=float(eta), lobes=[], pbrt=text)
-    kd = np.maximum(np.array(kd, F32), 0); ks = np.maximum(np.array(ks, F32), 0)
-    lobes = []
-    if kd.any():
-        if r.any():
-            lobes.append(_lobe(type=abi.BXDF_LAMBERT_R, r=(r * kd).astype(F32)))
-        if t.any():
-            lobes.append(_lobe(type=abi.BXDF_LAMBERT_T, r=(t * kd).astype(F32)))
-    if ks.any() and (r.any() or t.any()):
-        a = tr_roughness_to_alpha(roughness) if remap else F32(roughness)
-        if r.any():
-            lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=(r * ks).astype(F32), eta_a=1.0, eta_b=eta,
-                               alpha_x=_alpha(a), alpha_y=_alpha(a)))
-        if t.any():
-            lobes.append(_lobe(type=abi.BXDF_MICROFACET_T, r=(t * ks).astype(F32), eta_a=1.0, eta_b=eta, alpha_x=_alpha(a), alpha_y=_alpha(a)))
-    return dict(eta=float(eta), lobes=lobes, pbrt=text)
-
-
-def mix(m1, m2, amount=(0.5, 0.5, 0.5)):  # mixmat.rs:43-305: m1 scaled by `amount`, m2 by 1 - amount, lobes concatenated
-    s1 = np.maximum(np.array(amount, F32), 0)
-    s2 = np.maximum(F32(1) - s1, 0).astype(F32)
-    lobes = []
-    for m, sc in ((m1, s1), (m2, s2)):
-        for lb in m["lobes"]:
-            lb = lb.copy()
-            lb["sc"] = sc; lb["has_sc"] = 1
-            lobes.append(lb)
-    assert len(lobes) <= 8, "Bsdf holds at most 8 BxDFs (reflection.rs:40)"
-    # for tools/export_pbrt.py: two MakeNamedMaterial directives + Material "mix" (api.rs:678-704; the texture parameter is called "amount")
-    named = None if isinstance(amount, TexRef) or not (isinstance(m1.get("pbrt"), str) and isinstance(m2.get("pbrt"), str)) else ("mix", m1["pbrt"], m2["pbrt"], _pbrt_rgb("amount", amount))
-    return dict(eta=m1["eta"], lobes=lobes, pbrt=named)
+def glass(kr=(1.0,) * 3, kt=(1.0,) * 3, index=1.5, uroughness=0.0, vroughness=0.0, remap=True, bump=None, multiple_lobes=None):  # glass.rs:44-82
+    """multiple_lobes is ignored (kept for old call sites): the integrator decides (allow_multiple_lobes — true for `path` / `volpath`: one
+    FresnelSpecular lobe; false for `directlighting` / `whitted`: SpecularReflection + SpecularTransmission, glass.rs:136-188)"""
+    return _material(abi.MAT_GLASS, 'Material "glass" %s %s %s %s %s %s%s' % (_pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), _pbrt_float("uroughness", uroughness),
+                                                                          _pbrt_float("vroughness", vroughness), _pbrt_float("index", index), _pbrt_bool("remaproughness", remap), _pbrt_bump(bump)),
+                     remap, kr=kr, kt=kt, uroughness=uroughness, vroughness=vroughness, index=index, bumpmap=bump)
 
 
 def rough_glass(kr=(1.0,) * 3, kt=(1.0,) * 3, uroughness=0.1, vroughness=0.1, index=1.5, remap=True):  # glass.rs:83-211, rough branch
-    au = tr_roughness_to_alpha(uroughness) if remap else F32(uroughness)
-    av = tr_roughness_to_alpha(vroughness) if remap else F32(vroughness)
-    lobes = []
-    kr = np.maximum(np.array(kr, F32), 0); kt = np.maximum(np.array(kt, F32), 0)
-    if kr.any():
-        lobes.append(_lobe(type=abi.BXDF_MICROFACET_R, fresnel=abi.FRESNEL_DIELECTRIC, r=kr, eta_a=1.0, eta_b=index, alpha_x=_alpha(au), alpha_y=_alpha(av)))
-    if kt.any():
-        lobes.append(_lobe(type=abi.BXDF_MICROFACET_T, r=kt, eta_a=1.0, eta_b=index, alpha_x=_alpha(au), alpha_y=_alpha(av)))
-    return dict(eta=index, lobes=lobes, pbrt='Material "glass" %s %s "float uroughness" [%.9g] "float vroughness" [%.9g] "float index" [%.9g] "bool remaproughness" ["%s"]' % (
-        _pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), float(uroughness), float(vroughness), float(index), "true" if remap else "false"))
+    return glass(kr, kt, index, uroughness, vroughness, remap)
+
+
+def metal(eta=(0.2004, 0.9240, 1.1022), k=(3.9129, 2.4528, 2.1421), roughness=0.01, remap=True, uroughness=None, vroughness=None, bump=None):  # metal.rs:117-143
+    return _material(abi.MAT_METAL, 'Material "metal" %s %s %s%s%s %s%s' % (
+        _pbrt_rgb("eta", eta), _pbrt_rgb("k", k), _pbrt_float("roughness", roughness), "" if uroughness is None else " " + _pbrt_float("uroughness", uroughness),
+        "" if vroughness is None else " " + _pbrt_float("vroughness", vroughness), _pbrt_bool("remaproughness", remap), _pbrt_bump(bump)),
+        remap, eta=eta, k=k, roughness=roughness, uroughness=uroughness, vroughness=vroughness, bumpmap=bump)
+
+
+def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True, bump=None):  # substrate.rs:41-61
+    return _material(abi.MAT_SUBSTRATE, 'Material "substrate" %s %s %s %s %s%s' % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_float("uroughness", uroughness),
+                                                                               _pbrt_float("vroughness", vroughness), _pbrt_bool("remaproughness", remap), _pbrt_bump(bump)),
+                     remap, kd=kd, ks=ks, uroughness=uroughness, vroughness=vroughness, bumpmap=bump)
+
+
+def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0.0,) * 3, kt=(0.0,) * 3, roughness=0.1, uroughness=None, vroughness=None,
+         opacity=(1.0,) * 3, index=1.5, remap=True, bump=None):  # uber.rs:60-113
+    text = 'Material "uber" %s %s %s %s %s%s%s %s %s %s%s' % (
+        _pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_rgb("Kr", kr), _pbrt_rgb("Kt", kt), _pbrt_float("roughness", roughness),
+        "" if uroughness is None else " " + _pbrt_float("uroughness", uroughness), "" if vroughness is None else " " + _pbrt_float("vroughness", vroughness),
+        _pbrt_rgb("opacity", opacity), _pbrt_float("index", index), _pbrt_bool("remaproughness", remap), _pbrt_bump(bump))
+    return _material(abi.MAT_UBER, text, remap, kd=kd, ks=ks, kr=kr, kt=kt, roughness=roughness, uroughness=uroughness, vroughness=vroughness,
+                     opacity=opacity, index=index, bumpmap=bump)
+
+
+def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.5,) * 3, roughness=0.1, remap=True, bump=None):  # translucent.rs:40-63
+    text = 'Material "translucent" %s %s %s %s %s %s%s' % (_pbrt_rgb("Kd", kd), _pbrt_rgb("Ks", ks), _pbrt_rgb("reflect", reflect), _pbrt_rgb("transmit", transmit),
+                                                        _pbrt_float("roughness", roughness), _pbrt_bool("remaproughness", remap), _pbrt_bump(bump))
+    return _material(abi.MAT_TRANSLUCENT, text, remap, kd=kd, ks=ks, reflect=reflect, transmit=transmit, roughness=roughness, bumpmap=bump)
+
+
+def mix(m1, m2, amount=(0.5, 0.5, 0.5)):  # api.rs:678-704 (MakeNamedMaterial x 2 + Material "mix", the texture parameter is called "amount"), mixmat.rs:28-41
+    named = ("mix", m1["pbrt"], m2["pbrt"], _pbrt_rgb("amount", amount)) if isinstance(m1.get("pbrt"), str) and isinstance(m2.get("pbrt"), str) else None
+    m = _material(abi.MAT_MIX, named, amount=amount)
+    m["m1"], m["m2"] = m1, m2
+    return m
+
 
 
 # ---------------------------------------------------------------------------------------
@@ -582,6 +468,7 @@ class SceneBuilder:
         self.delta_lights = []  # point / spot / distant / infinite: appended to Scene.lights after the area lights
         self.envmaps = []
         self.images, self.textures = [], []
+        self._const_tex = {}         # literal material parameter -> its ConstantTexture record
         # object instancing (api.rs:3001-3109): meshes added between begin_object / end_object belong to that object
         self.mesh_object = []        # per mesh: object index or -1 (top level)
         self.objects = {}            # name -> index
@@ -677,8 +564,41 @@ class SceneBuilder:
         return self._tex3d(abi.TEX_MARBLE, world_to_texture, octaves=octaves, omega=omega, scale=scale, variation=variation)
 
     def add_material(self, m):
+        """m: a record of matte() .. mix(); returns its index.  The two sides of a mix are added in front of it (MakeNamedMaterial)."""
+        if m["kind"] == abi.MAT_MIX:
+            m = dict(m, m1_index=self.add_material(m["m1"]), m2_index=self.add_material(m["m2"]))
         self.materials.append(m)
         return len(self.materials) - 1
+
+    def _param_texture(self, v, spectrum):
+        """1 + texture index of a material parameter: a literal becomes the ConstantTexture TextureParams::get_*_texture builds"""
+        if v is None:
+            return 0
+        if isinstance(v, TexRef):
+            return v.index + 1
+        val = np.broadcast_to(np.asarray(v, F32), (3,)).astype(F32) if spectrum else np.array([F32(v), 0, 0], F32)
+        key = (bool(spectrum), val.tobytes())
+        if key not in self._const_tex:
+            self._const_tex[key] = self._add_texture(kind=abi.TEX_CONSTANT, value=val).index
+        return self._const_tex[key] + 1
+
+    def materials_only(self):
+        """a Scene without geometry carrying this builder's materials, textures and images: what rspt_material_lobes and the oracle's
+        material hooks read"""
+        mats = self.material_descs()
+        return Scene(nodes=np.zeros(0, abi.NODE_DT), prims=np.zeros(0, abi.PRIM_DT), meshes=np.zeros(0, abi.MESH_DT), P=np.zeros((0, 3), F32), N=None, UV=None,
+                     materials=mats, lights=np.zeros(0, abi.LIGHT_DT), textures=np.array(self.textures, abi.TEXTURE_DT) if self.textures else None,
+                     images=self.images, builder=self)
+
+    def material_descs(self):
+        out = np.zeros(len(self.materials), abi.MATERIAL_DESC_DT)
+        for i, m in enumerate(self.materials):
+            out[i]["kind"] = m["kind"]; out[i]["remap_roughness"] = int(m["remap"])
+            for name, v in m["params"].items():
+                out[i][name] = self._param_texture(v, name in SPECTRUM_PARAMS)
+            if m["kind"] == abi.MAT_MIX:
+                out[i]["m1"], out[i]["m2"] = m["m1_index"], m["m2_index"]
+        return out
 
     def add_medium(self, sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77), g=0.0, scale=1.0):
         """MakeNamedMedium "homogeneous" (api.rs:953-1037; the defaults are the ones at :959-960): returns the handle add_mesh's
@@ -874,17 +794,12 @@ class SceneBuilder:
             lights[i]["kind"] = abi.LIGHT_DIFFUSE_AREA; lights[i]["prim"] = slot_of_tri[t]; lights[i]["L"] = L; lights[i]["two_sided"] = int(two)
         for i, lt in enumerate(self.delta_lights):
             lights[len(lights_in) + i] = lt
-        mats = np.zeros(len(self.materials), abi.MATERIAL_DT)
-        bx = []
-        for i, m in enumerate(self.materials):
-            mats[i] = (m["eta"], len(bx), len(m["lobes"]), m.get("bump", -1) + 1)
-            bx.extend(m["lobes"])
-        bxdfs = np.array(bx, abi.BXDF_DT) if bx else np.zeros(0, abi.BXDF_DT)
+        mats = self.material_descs()   # (appends the ConstantTextures of literal parameters to self.textures)
         meshes = np.array(self.meshes, np.uint32).view(abi.MESH_DT).reshape(-1)
         return Scene(nodes=np.concatenate(all_nodes), prims=prims, meshes=meshes, P=P,
                      N=np.ascontiguousarray(np.concatenate(self.N), F32) if self.any_n else None,
                      UV=np.ascontiguousarray(np.concatenate(self.UV), F32) if self.any_uv else None,
-                     materials=mats, bxdfs=bxdfs, lights=lights, envmaps=self.envmaps,
+                     materials=mats, lights=lights, envmaps=self.envmaps,
                      textures=np.array(self.textures, abi.TEXTURE_DT) if self.textures else None, images=self.images,
                      objects=objects, instances=instances, n_top=(n_top_nodes, n_top_prims), media=np.array(self.media, abi.MEDIUM_DT) if self.media else None,
                      instancing={"reference": abi.INSTANCING_REFERENCE, "fixed": abi.INSTANCING_FIXED}[instancing], builder=self)
@@ -905,7 +820,7 @@ def _transform_bounds(m, lo, hi):
 class Scene:
     """Flattened scene arrays + the ctypes rspt_scene_desc pointing at them."""
 
-    def __init__(self, nodes, prims, meshes, P, N, UV, materials, bxdfs, lights, S=None, envmaps=(), textures=None, images=(),
+    def __init__(self, nodes, prims, meshes, P, N, UV, materials, lights, S=None, envmaps=(), textures=None, images=(),
                  objects=None, instances=None, n_top=None, instancing=abi.INSTANCING_REFERENCE, builder=None, media=None):
         self.media = media if media is not None else np.zeros(0, abi.MEDIUM_DT)
         self.builder = builder  # declaration-order view of the scene (tools/export_pbrt.py)
@@ -913,7 +828,7 @@ class Scene:
         self.objects = objects if objects is not None else np.zeros(0, abi.OBJECT_DT)
         self.instances = instances if instances is not None else np.zeros(0, abi.INSTANCE_DT)
         self.n_top = n_top if n_top is not None else (len(nodes), len(prims))
-        self.materials, self.bxdfs, self.lights = materials, bxdfs, lights
+        self.materials, self.lights = materials, lights
         self.envmaps = list(envmaps)
         self.textures = textures if textures is not None else np.zeros(0, abi.TEXTURE_DT)
         self.images = list(images)
@@ -926,7 +841,7 @@ class Scene:
             self._env_structs[i] = abi.EnvMap(e["width"], e["height"], e["n_levels"], 0, e["texels"].ctypes.data, e["dist_nu"], e["dist_nv"], e["dist_func"].ctypes.data)
         self.desc = abi.SceneDesc(p(nodes), len(nodes), p(prims), len(prims), p(meshes), len(meshes),
                                   p(P), p(N), p(S), p(UV), len(P),
-                                  p(materials), len(materials), p(bxdfs), len(bxdfs), p(lights), len(lights),
+                                  p(materials), len(materials), p(lights), len(lights),
                                   C.addressof(self._env_structs) if self.envmaps else None, len(self.envmaps),
                                   p(self.textures), len(self.textures),
                                   C.addressof(self._img_structs) if self.images else None, len(self.images),

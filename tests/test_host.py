@@ -32,20 +32,20 @@ def test_camera_matrices_are_consistent():
     assert np.allclose(c2w[:3, 3], (278, 273, -800)) and np.allclose(c2w[:3, 2], (0, 0, 1))
 
 
-def test_material_recipes_follow_appendix_f():
-    m = scenes.matte((0.5, 0.5, 0.5))
-    assert [int(l["type"]) for l in m["lobes"]] == [abi.BXDF_LAMBERT_R]
-    assert scenes.matte((0, 0, 0))["lobes"] == []                                    # black Kd: no lobe (matte.rs:60)
-    assert int(scenes.matte((0.5,) * 3, sigma=20)["lobes"][0]["type"]) == abi.BXDF_OREN_NAYAR
-    p = scenes.plastic()
-    assert [int(l["type"]) for l in p["lobes"]] == [abi.BXDF_LAMBERT_R, abi.BXDF_MICROFACET_R]
-    assert int(p["lobes"][1]["fresnel"]) == abi.FRESNEL_DIELECTRIC and float(p["lobes"][1]["eta_a"]) == 1.5
-    a = float(scenes.tr_roughness_to_alpha(0.1))
-    x = math.log(0.1)
-    assert abs(a - (1.62142 + 0.819955 * x + 0.1734 * x * x + 0.0171201 * x ** 3 + 0.000640711 * x ** 4)) < 1e-5
-    g = scenes.glass()
-    assert g["eta"] == 1.5 and int(g["lobes"][0]["type"]) == abi.BXDF_FRESNEL_SPEC
-    assert int(scenes.mirror((0, 0, 0))["lobes"][0]["type"]) == abi.BXDF_SPECULAR_R  # pushed even if black (mirror.rs)
+def test_material_records_carry_parameters_not_recipes():
+    """scenes.py hands the reference's material parameters through as texture references (literals become ConstantTextures, as
+    TextureParams does); which lobes they make is the library's business (tests/test_materials.py)"""
+    sb = scenes.SceneBuilder()
+    t = sb.image_texture(np.ones((2, 2, 3), np.float32))
+    i = sb.add_material(scenes.plastic(kd=t, ks=(0.25,) * 3, roughness=0.1, bump=None))
+    j = sb.add_material(scenes.mix(scenes.matte((0.5,) * 3), scenes.mirror(), (0.3,) * 3))
+    d = sb.material_descs()
+    assert d[i]["kind"] == abi.MAT_PLASTIC and d[i]["kd"] == t.index + 1 and d[i]["bumpmap"] == 0 and d[i]["remap_roughness"] == 1
+    ks = sb.textures[d[i]["ks"] - 1]
+    assert ks["kind"] == abi.TEX_CONSTANT and tuple(ks["value"]) == (0.25, 0.25, 0.25)
+    assert sb.textures[d[i]["roughness"] - 1]["value"][0] == np.float32(0.1)
+    assert d[j]["kind"] == abi.MAT_MIX and d[d[j]["m1"]]["kind"] == abi.MAT_MATTE and d[d[j]["m2"]]["kind"] == abi.MAT_MIRROR
+    assert len(sb.textures) == len({bytes(x.tobytes()) for x in sb.textures})   # literals are shared, not repeated
 
 
 def test_scene_flattening_orders_lights_by_declaration_and_prims_by_bvh():

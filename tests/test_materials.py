@@ -1,0 +1,177 @@
+"""Material::compute_scattering_functions, twice: the library's host-side assembly (rspt_material_lobes, rs_pbrt_amd/csrc/
+material_assembly.h: constant parameters folded once per material) against the oracle's restatement of src/materials/*.rs
+(oracle/orc_material.hpp: every parameter texture evaluated per hit, the reference's guards in the reference's order).  Both read the
+same RAW parameters (rspt_material_desc); neither sees the other's lobes.  CPU only: the hook needs no device."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import abi, lib, scenes
+
+F32 = np.float32
+VALUE_FIELDS = ("type", "fresnel", "r", "t", "eta_a", "eta_b", "alpha_x", "alpha_y", "c1", "c2", "on_a", "on_b", "sc", "has_sc")
+BLACK, GREY, RED = (0.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.6, 0.0, 0.0)
+NEG = (-0.5, 0.3, -0.0)   # clamp(0, inf) makes (0, 0.3, -0): not black... -0.0 == 0, so black needs all three == 0
+
+
+def _used_fields(b):
+    """the fields of a lobe record that its BxDF type reads (others are don't-care)"""
+    t = int(b["type"])
+    f = ["type", "r", "sc", "has_sc"]
+    if t in (abi.BXDF_SPECULAR_R, abi.BXDF_MICROFACET_R):
+        f.append("fresnel")
+        if int(b["fresnel"]) == abi.FRESNEL_DIELECTRIC: f += ["eta_a", "eta_b"]
+        if int(b["fresnel"]) == abi.FRESNEL_CONDUCTOR: f += ["c1", "c2"]
+    if t in (abi.BXDF_SPECULAR_T, abi.BXDF_FRESNEL_SPEC, abi.BXDF_MICROFACET_T): f += ["eta_a", "eta_b"]
+    if t in (abi.BXDF_FRESNEL_SPEC, abi.BXDF_FRESNEL_BLEND): f.append("t")
+    if t in (abi.BXDF_MICROFACET_R, abi.BXDF_MICROFACET_T, abi.BXDF_FRESNEL_BLEND): f += ["alpha_x", "alpha_y"]
+    if t == abi.BXDF_OREN_NAYAR: f += ["on_a", "on_b"]
+    return f
+
+
+def _same(oracle, m, multi):
+    sc, mi = scenes.material_scene(m)
+    eta_l, bump_l, lobes_l = lib.material_lobes(sc, mi, multi)
+    eta_o, lobes_o = oracle.material_lobes(sc, mi, multi)
+    assert len(lobes_l) == len(lobes_o), "%s: library pushes %d lobes, the reference %d" % (m["pbrt"], len(lobes_l), len(lobes_o))
+    assert F32(eta_l).tobytes() == F32(eta_o).tobytes(), "%s: Bsdf.eta %r vs %r" % (m["pbrt"], eta_l, eta_o)
+    for a, b in zip(lobes_l, lobes_o):
+        assert int(a["type"]) == int(b["type"]), m["pbrt"]
+        assert not (int(a["tex_r"]) or int(a["tex_t"]) or int(a["tex_ax"]) or int(a["tex_ay"])), "constant parameters must be folded"
+        for f in _used_fields(b):
+            assert np.asarray(a[f]).tobytes() == np.asarray(b[f]).tobytes(), "%s: lobe field %s: %r vs %r" % (m["pbrt"], f, a[f], b[f])
+    return lobes_l
+
+
+COLOURS = (BLACK, GREY, RED, NEG)
+ROUGH = (0.0, 0.0005, 0.1, 1.7)
+
+
+def _recipes():
+    for kd, sigma in itertools.product(COLOURS, (0.0, -3.0, 20.0, 90.0, 120.0)):
+        yield scenes.matte(kd, sigma)
+    for kd, ks, r, remap in itertools.product(COLOURS, COLOURS, ROUGH, (True, False)):
+        yield scenes.plastic(kd, ks, r, remap)
+    for kr in COLOURS:
+        yield scenes.mirror(kr)
+    for kr, kt, (ru, rv), remap in itertools.product((BLACK, GREY), (BLACK, RED), ((0.0, 0.0), (0.0, 0.2), (0.3, 0.05)), (True, False)):
+        yield scenes.glass(kr, kt, 1.33, ru, rv, remap)
+    for r, remap, uv in itertools.product(ROUGH, (True, False), ((None, None), (0.3, None), (None, 0.02), (0.2, 0.4))):
+        yield scenes.metal(roughness=r, remap=remap, uroughness=uv[0], vroughness=uv[1])
+    yield scenes.metal(eta=(-1.0, 0.5, 2.0), k=(3.0, -2.0, 0.0))   # eta / k are not clamped (metal.rs:183-187)
+    for kd, ks, ru, remap in itertools.product(COLOURS, COLOURS, ROUGH, (True, False)):
+        yield scenes.substrate(kd, ks, ru, 0.2, remap)
+    for kd, ks, kr, kt, op in itertools.product((BLACK, GREY), (BLACK, RED), (BLACK, GREY), (BLACK, GREY), ((1.0,) * 3, (0.0,) * 3, (0.3, 1.0, 1.5), (1.0, 1.0, 0.999))):
+        yield scenes.uber(kd, ks, kr, kt, 0.1, None, None, op, 1.4)
+    yield scenes.uber(GREY, GREY, roughness=0.3, uroughness=0.05, vroughness=None, remap=False)
+    yield scenes.uber(GREY, GREY, roughness=0.3, uroughness=None, vroughness=0.7)
+    for kd, ks, rf, tm in itertools.product((BLACK, GREY), (BLACK, RED), (BLACK, GREY), (BLACK, (0.2, 0.4, 0.0))):
+        yield scenes.translucent(kd, ks, rf, tm, 0.2, True)
+    yield scenes.translucent(GREY, GREY, GREY, GREY, 0.0005, False)
+
+
+def test_every_recipe_and_every_guard_matches_the_reference_restatement(oracle):
+    n = 0
+    for m in _recipes():
+        for multi in (True, False):
+            _same(oracle, m, multi)
+            n += 1
+    assert n >= 800
+
+
+def test_mix_concatenates_scaled_children_and_keeps_the_first_bsdf(oracle):
+    kids = [scenes.matte(GREY), scenes.matte(BLACK), scenes.plastic(RED, GREY, 0.2), scenes.mirror(), scenes.glass(), scenes.glass(uroughness=0.2, vroughness=0.1),
+            scenes.metal(), scenes.substrate(), scenes.uber(opacity=(0.5,) * 3, kr=GREY), scenes.translucent()]
+    for a, b in itertools.product(kids, kids):
+        for amount in ((0.5,) * 3, (0.0, 0.3, 1.0), (1.7, -0.2, 0.5)):
+            for multi in (True, False):
+                sc, mi = scenes.material_scene(scenes.mix(a, b, amount))
+                la = lib.material_lobes(sc, mi - 2, multi)[2]; lb = lib.material_lobes(sc, mi - 1, multi)[2]
+                if len(la) + len(lb) > 8:
+                    with pytest.raises(lib.RsptError):
+                        lib.material_lobes(sc, mi, multi)   # Bsdf::add asserts in the reference
+                    continue
+                lobes = _same(oracle, scenes.mix(a, b, amount), multi)
+                assert len(lobes) == len(la) + len(lb) and all(int(l["has_sc"]) for l in lobes)
+                s1 = np.maximum(np.array(amount, F32), 0)
+                for l in lobes[:len(la)]:
+                    assert np.array_equal(l["sc"], s1)
+                for l in lobes[len(la):]:
+                    assert np.array_equal(l["sc"], np.maximum(F32(1) - s1, 0)) and int(l["remap"]) & abi.LOBE_NODIFF
+                assert lib.material_lobes(sc, mi, multi)[0] == lib.material_lobes(sc, mi - 2, multi)[0]   # Bsdf.eta is m1's
+
+
+def test_known_answers_of_the_recipes(oracle):
+    """first principles, independent of both implementations"""
+    _, _, l = lib.material_lobes(*scenes.material_scene(scenes.matte(GREY, 20.0)))
+    s2 = math.radians(20.0) ** 2
+    assert int(l[0]["type"]) == abi.BXDF_OREN_NAYAR and abs(l[0]["on_a"] - (1 - s2 / (2 * (s2 + 0.33)))) < 1e-6 and abs(l[0]["on_b"] - 0.45 * s2 / (s2 + 0.09)) < 1e-6
+    _, _, l = lib.material_lobes(*scenes.material_scene(scenes.plastic(GREY, GREY, 0.1)))
+    x = math.log(0.1)
+    assert [int(b["type"]) for b in l] == [abi.BXDF_LAMBERT_R, abi.BXDF_MICROFACET_R] and float(l[1]["eta_a"]) == 1.5 and float(l[1]["eta_b"]) == 1.0
+    assert abs(l[1]["alpha_x"] - (1.62142 + 0.819955 * x + 0.1734 * x * x + 0.0171201 * x ** 3 + 0.000640711 * x ** 4)) < 1e-5
+    eta, _, l = lib.material_lobes(*scenes.material_scene(scenes.glass()), True)
+    assert eta == 1.5 and [int(b["type"]) for b in l] == [abi.BXDF_FRESNEL_SPEC]
+    eta, _, l = lib.material_lobes(*scenes.material_scene(scenes.glass()), False)
+    assert [int(b["type"]) for b in l] == [abi.BXDF_SPECULAR_R, abi.BXDF_SPECULAR_T] and int(l[0]["fresnel"]) == abi.FRESNEL_DIELECTRIC
+    assert [int(b["type"]) for b in lib.material_lobes(*scenes.material_scene(scenes.mirror(BLACK)))[2]] == [abi.BXDF_SPECULAR_R]   # pushed even if black
+    assert len(lib.material_lobes(*scenes.material_scene(scenes.matte(BLACK)))[2]) == 0
+    eta, _, l = lib.material_lobes(*scenes.material_scene(scenes.uber(opacity=(0.4,) * 3, index=1.7)))
+    assert eta == 1.0 and int(l[0]["type"]) == abi.BXDF_SPECULAR_T and np.allclose(l[0]["r"], 0.6) and float(l[0]["eta_b"]) == 1.0
+    assert lib.material_lobes(*scenes.material_scene(scenes.uber(index=1.7)))[0] == F32(1.7)
+
+
+def test_textured_parameters_are_deferred_or_refused(oracle):
+    """a varying Kd / Ks / roughness stays a texture reference on the lobe, evaluated per hit by the texture stage, and the lobe list agrees
+    with the reference's at sample points; a varying parameter that shapes the lobe list is refused (the caller keeps its CPU loop)"""
+    sb = scenes.SceneBuilder()
+    rng = np.random.default_rng(5)
+    img = sb.image_texture(rng.uniform(0.0, 1.0, (8, 8, 3)).astype(F32), trilinear=True)
+    chk = sb.checkerboard_texture(sb.constant_texture(BLACK), sb.constant_texture(GREY), su=4, sv=4)
+    rgh = sb.image_texture(rng.uniform(0.01, 0.6, (8, 8, 3)).astype(F32), channels=1, trilinear=True)
+    ok = [sb.add_material(m) for m in (scenes.matte(img), scenes.matte(chk, 30.0), scenes.plastic(chk, img, rgh), scenes.substrate(img, chk, rgh, 0.2),
+                                       scenes.uber(chk, img, GREY, BLACK, rgh, opacity=(0.5, 1.0, 0.25)), scenes.metal(roughness=rgh),
+                                       scenes.translucent(roughness=rgh), scenes.mix(scenes.matte(chk), scenes.plastic(img, GREY, rgh), (0.3,) * 3))]
+    sc = sb.materials_only()
+    for mi in ok:
+        eta_l, _, ll = lib.material_lobes(sc, mi)
+        for uv in rng.uniform(0, 1, (16, 2)):
+            eta_o, lo = oracle.material_lobes(sc, mi, uv=uv)
+            # complete the library's lobes the way the texture stage does: clamp(texture) * factor, alpha from the roughness texture, black -> dropped
+            done = []
+            for b in ll:
+                b = b.copy()
+                two = int(b["type"]) in (abi.BXDF_FRESNEL_SPEC, abi.BXDF_FRESNEL_BLEND)
+                for key, tk in (("r", "tex_r"), ("t", "tex_t")):
+                    if int(b[tk]):
+                        b[key] = b[key] * np.maximum(oracle.tex_eval(sc, int(b[tk]) - 1, uv=uv), 0)
+                for key, tk in (("alpha_x", "tex_ax"), ("alpha_y", "tex_ay")):
+                    if int(b[tk]):
+                        v = oracle.tex_eval(sc, int(b[tk]) - 1, uv=uv)[0]
+                        if int(b["remap"]) & abi.LOBE_REMAP:
+                            x = F32(math.log(max(float(v), 1e-3)))
+                            v = F32(1.62142) + F32(0.819955) * x + F32(0.1734) * x * x + F32(0.0171201) * x * x * x + F32(0.000640711) * x * x * x * x
+                        b[key] = max(F32(0.001), F32(v))
+                textured = int(b["tex_r"]) or int(b["tex_t"])
+                if textured and (not b["r"].any() and (not two or not b["t"].any())):
+                    continue
+                done.append(b)
+            assert len(done) == len(lo) and eta_l == eta_o
+            for a, b in zip(done, lo):
+                for f in _used_fields(b):
+                    if f in ("alpha_x", "alpha_y"):
+                        assert abs(float(a[f]) - float(b[f])) <= 2e-7 * abs(float(b[f]))   # (numpy's log vs libm's logf in this test's own remap)
+                    else:
+                        assert np.asarray(a[f]).tobytes() == np.asarray(b[f]).tobytes(), (mi, f, a[f], b[f])
+    f1 = sb.image_texture(rng.uniform(0.0, 1.0, (4, 4, 3)).astype(F32), channels=1, trilinear=True)
+    for bad in (scenes.matte(GREY, f1), scenes.mirror(img), scenes.glass(img), scenes.glass(index=f1), scenes.glass(uroughness=f1), scenes.metal(eta=img), scenes.uber(opacity=img),
+                scenes.uber(kr=img), scenes.uber(index=f1), scenes.translucent(kd=img), scenes.translucent(reflect=img), scenes.mix(scenes.matte(GREY), scenes.mirror(), img),
+                scenes.mix(scenes.matte(GREY), scenes.mix(scenes.matte(RED), scenes.mirror()))):
+        sb2 = scenes.SceneBuilder()
+        sb2.textures, sb2.images = list(sb.textures), list(sb.images)
+        i = sb2.add_material(bad)
+        with pytest.raises(lib.RsptError) as e:
+            lib.material_lobes(sb2.materials_only(), i)
+        assert e.value.code == abi.E_UNSUPPORTED

@@ -153,22 +153,20 @@ def test_concentric_disk_known_points_and_area(oracle):
 
 # ---------------------------------------------------------------- BSDFs
 def _mat(m):
-    bx = np.array(m["lobes"], abi.BXDF_DT) if m["lobes"] else np.zeros(1, abi.BXDF_DT)
-    mt = np.zeros(1, abi.MATERIAL_DT); mt[0] = (m["eta"], 0, len(m["lobes"]), 0)
-    return mt, bx
+    return scenes.material_scene(m) if isinstance(m, dict) else m   # (Scene, material index); callers with textures bring their own
 
 
-def _f(oracle, m, wo, wi, flags=31):
-    mt, bx = _mat(m)
+def _f(oracle, m, wo, wi, flags=31, multi=True):
+    sc, mi = _mat(m)
     wo = np.asarray(wo, F32); wi = np.asarray(wi, F32); f = np.zeros(3, F32); pdf = C.c_float()
-    oracle.lib().orc_bsdf_f(mt.ctypes.data, bx.ctypes.data, wo.ctypes.data, wi.ctypes.data, flags, f.ctypes.data, C.addressof(pdf))
+    oracle.lib().orc_bsdf_f(C.addressof(sc.desc), mi, int(multi), wo.ctypes.data, wi.ctypes.data, flags, f.ctypes.data, C.addressof(pdf))
     return f, pdf.value
 
 
-def _sample(oracle, m, wo, u, flags=31):
-    mt, bx = _mat(m)
+def _sample(oracle, m, wo, u, flags=31, multi=True):
+    sc, mi = _mat(m)
     wo = np.asarray(wo, F32); f = np.zeros(3, F32); wi = np.zeros(3, F32); pdf = C.c_float(); st = C.c_uint32()
-    oracle.lib().orc_bsdf_sample_f(mt.ctypes.data, bx.ctypes.data, wo.ctypes.data, float(u[0]), float(u[1]), flags, f.ctypes.data, wi.ctypes.data,
+    oracle.lib().orc_bsdf_sample_f(C.addressof(sc.desc), mi, int(multi), wo.ctypes.data, float(u[0]), float(u[1]), flags, f.ctypes.data, wi.ctypes.data,
                                    C.addressof(pdf), C.addressof(st))
     return f, wi, pdf.value, st.value
 
@@ -513,7 +511,8 @@ def test_mix_material_scales_lobes(oracle):
     """MixMaterial: lobes of both children, each carrying its scale (mixmat.rs:43-70): f = s1*f1 + s2*f2"""
     a, b = scenes.matte((0.8, 0.2, 0.2)), scenes.plastic((0.1, 0.5, 0.1), (0.3, 0.3, 0.3), 0.2)
     m = scenes.mix(a, b, (0.25, 0.5, 1.0))
-    assert len(m["lobes"]) == 3 and all(int(l["has_sc"]) == 1 for l in m["lobes"])
+    _, lobes = oracle.material_lobes(*scenes.material_scene(m))
+    assert len(lobes) == 3 and all(int(l["has_sc"]) == 1 for l in lobes)
     for wo, wi in zip(_dirs(10, 41), _dirs(10, 42)):
         fm, _ = _f(oracle, m, wo, wi); fa, _ = _f(oracle, a, wo, wi); fb, _ = _f(oracle, b, wo, wi)
         s1 = np.array([0.25, 0.5, 1.0], F32)

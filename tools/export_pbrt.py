@@ -55,13 +55,10 @@ def texture_directives(sb):
             mark(int(T[i]["tex1"]), ty); mark(int(T[i]["tex2"]), ty)
         if k == abi.TEX_MIX:
             mark(int(T[i]["tex3"]), "float")
+    from rs_pbrt_amd import scenes as _sc
     for m in sb.materials:
-        if m.get("bump") is not None:
-            mark(int(m["bump"]), "float")
-        for lb in m["lobes"]:
-            for key, ty in (("tex_r", "spectrum"), ("tex_t", "spectrum"), ("tex_ax", "float"), ("tex_ay", "float")):
-                if int(lb[key]):
-                    mark(int(lb[key]) - 1, ty)
+        for ref, ty in _sc.material_texrefs(m):
+            mark(ref.index, ty)
     for fl in sb.meshes:
         for a in (fl[4], fl[5]):
             if a:

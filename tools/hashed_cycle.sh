@@ -1,15 +1,15 @@
 #!/bin/bash
 # One cycle after a change under rs_pbrt_amd/csrc or include/rspt.h (which changes lib.source_hash() and so unties profiles/ from the build),
 # to be run on the GPU box: GPU tests (without the full-size file), profile refresh, collect into profiles/, the driver's bench line last so
-# that it quotes the fresh PMC traffic.  usage: gpurun --timeout 540 -- 'bash tools/hashed_cycle.sh <tag>'   (≈ 5 GPU-minutes with SKIP_C5=1)
-# Afterwards, here: tools/collect_profiles.sh <tag> r02; cp gpurun_out/<tag>/bench_final.json profiles/r02_bench_c2_soup1m_n1.json;
+# that it quotes the fresh PMC traffic.  usage: gpurun --timeout 540 -- 'bash tools/hashed_cycle.sh <tag> [round prefix, default r03]'   (≈ 5 GPU-minutes with SKIP_C5=1)
+# Afterwards, here: tools/collect_profiles.sh <tag> r03; cp gpurun_out/<tag>/bench_final.json profiles/r03_bench_c2_soup1m_n1.json;
 # tools/static_kernel_facts.sh
 set -u
-tag=$1; out=$PWD/gpurun_out/$tag; mkdir -p $out
+tag=$1; round=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p $out
 timeout 240 python -m pytest tests -m gpu -x -q --ignore=tests/test_gpu_fullsize.py > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log
 tail -2 $out/pytest.log
 SKIP_C5=${SKIP_C5-1} bash tools/refresh_profiles.sh $tag all > $out/refresh.log 2>&1
-bash tools/collect_profiles.sh $tag r02 > /dev/null 2>&1
+bash tools/collect_profiles.sh $tag $round > /dev/null 2>&1
 timeout 200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_final.json 2> $out/bench_final.err
 for f in $out/bench_*.json; do echo "$(basename $f) $(grep -o '"value": [0-9.]*' $f | head -1)"; done
 grep -o '"traffic": [0-9.a-z]*' $out/bench_final.json
