@@ -32,7 +32,7 @@ struct DlBuf {          // per node slot
     uint32_t* kidx;     // index among the camera sample's shading nodes, depth first
     uint32_t* nflags;   // DLF_* of the estimate in flight
     uint32_t H;         // slots per camera sample
-    uint32_t* error;    // != 0: a material with several specular lobes of one kind was met
+    uint32_t* error;    // 1: a material with several specular lobes of one kind was met; 2: a camera sample ran out of sampler dimensions
 };
 
 // per-wave aggregated queue append
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd, PathB
                     dl.le_kind[slot] = make_float4(le.r, le.g, le.b, __uint_as_float((uint32_t)DL_SHADING));
                     float4 wr = make_float4(0.0f, 0.0f, 0.0f, 0.0f), wt = wr;
                     if (level + 1u < rd.max_depth) {  // specular_reflect / specular_transmit (:124-258), ray differentials left out
-                        if (d.bsdf.num_components(BX_REFL | BX_SPEC) > 1 || d.bsdf.num_components(BX_TRANS | BX_SPEC) > 1) *dl.error = 1u;
+                        if (d.bsdf.num_components(BX_REFL | BX_SPEC) > 1 || d.bsdf.num_components(BX_TRANS | BX_SPEC) > 1) atomicMax(dl.error, 1u);
                         const uint32_t h = slot % dl.H, s = slot / dl.H;
                         for (int side = 0; side < 2; side++) {
                             f3 wi{0.0f, 0.0f, 0.0f};
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd, PathB
 
 // the reference's depth-first order: which sample arrays and which dimensions every shading node gets
 // n_arrays = 2 * max_depth * n_lights with LightStrategy::UniformSampleAll (preprocess, directlighting.rs:54-70), else 0
-__global__ __launch_bounds__(256) void k_dl_assign(Batch bt, DlBuf dl, uint32_t n_lights, uint32_t n_arrays, uint32_t sample_all, uint32_t max_depth) {
+// dim_limit: the sampler's dimension count (NUM_SOBOL_DIMENSIONS, or what the Halton permutation table covers); the reference panics when a
+// dimension past it is asked for (sobol.rs:119-124), so a camera sample whose stream ends beyond it is reported (dl.error = 2), not rendered
+__global__ __launch_bounds__(256) void k_dl_assign(Batch bt, DlBuf dl, uint32_t n_lights, uint32_t n_arrays, uint32_t sample_all, uint32_t max_depth, uint32_t dim_limit) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= bt.n) return;
     uint32_t k = 0;
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void k_dl_assign(Batch bt, DlBuf dl, uint32_t 
             if (__float_as_uint(dl.le_kind[s * dl.H + 2u * h + 1u].w) != DL_EMPTY) stack[sp++] = (2u * h + 1u) << 1;
         }
     }
+    if (dim > dim_limit) atomicMax(dl.error, 2u);
 }
 
 RDEV f2 dl_dims(const RenderDev& rd, uint64_t index, uint32_t d) {

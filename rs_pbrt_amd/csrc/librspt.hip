@@ -609,7 +609,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         }
         uint32_t max_dim = 5u + 8u * (d->max_depth + 2u);  // last dimension a path can consume, with slack
         if (volpath) max_dim = std::min(990u, 5u + 10u * (d->max_depth + 2u) + 64u);  // 10 per counted bounce, 2 per uncounted pass through a medium boundary (slack for 32; vol.h cuts a path that needs more)
-        if (direct) max_dim = 5u + 4u * d->max_depth * s->dev.n_lights + ((1u << d->max_depth) - 1u) * (4u * s->dev.n_lights + 4u) + 2u;  // arrays + every node on the fall-back stream
+        if (direct) {  // every dimension the caller's table covers: k_dl_assign reports a camera sample whose stream really ends beyond it
+            max_dim = 0;
+            while (max_dim + 1u < 1000u && (uint64_t)g.host_prime_sums[max_dim + 1u] + g.host_primes[max_dim + 1u] <= d->tables.n_halton_perms) max_dim++;
+        }
         if (max_dim >= 1000u) return fail(RSPT_E_UNSUPPORTED, "max_depth exceeds the 1000 Halton dimensions");
         const uint64_t need = (uint64_t)g.host_prime_sums[max_dim] + g.host_primes[max_dim];
         if (d->tables.n_halton_perms < need) return fail(RSPT_E_INVALID, "halton permutation table has %llu entries, %llu needed for max_depth %u",
@@ -834,8 +837,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         const uint32_t nl = s->dev.n_lights, H = dl_H, md = d->max_depth;
         const bool all = d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL;
         const uint32_t n_arrays = all ? 2u * md * nl : 0u;
-        if (5ull + 2ull * n_arrays + ((1ull << md) - 1ull) * (4ull * nl + 4ull) + 2ull >= 1000ull)  // the reference panics past NUM_SOBOL_DIMENSIONS / the prime table
-            return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays + the dimension stream of a full specular tree exceed the sampler's dimensions", n_arrays);
+        // the sample arrays are filled for every pixel sample whether a node uses them or not (GlobalSampler::start_pixel), so they must fit;
+        // the regular stream behind them is checked per camera sample by k_dl_assign against what each tree really draws
+        const uint32_t dim_limit = halton ? vol_dim_limit + 1u : 1024u;
+        if (5ull + 2ull * n_arrays > dim_limit)
+            return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays exceed the sampler's %u dimensions", n_arrays, dim_limit);
         DlBuf dl = g.dl;
         dl.H = H;
         const size_t n_slots = (size_t)bt.n * H;
@@ -875,7 +881,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 qcount = &rc_->closest;
             }
         }
-        hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md);
+        hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md, dim_limit);
         if (nl) {
             QueueCounts* rc_ = &g.cnt[md + 3];
             for (uint32_t l = 0; l < md; l++) {
@@ -904,7 +910,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         uint32_t dl_err = 0;
         HIP_TRY(hipMemcpyAsync(&dl_err, dl.error, sizeof dl_err, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        if (dl_err) return fail(RSPT_E_UNSUPPORTED, "directlighting: a material with several specular lobes of one kind (the lobe choice would depend on a sample value)");
+        if (dl_err == 1u) return fail(RSPT_E_UNSUPPORTED, "directlighting: a material with several specular lobes of one kind (the lobe choice would depend on a sample value)");
+        if (dl_err) return fail(RSPT_E_UNSUPPORTED, "directlighting: a camera sample draws more than the sampler's %u dimensions (the reference panics there, sobol.rs:119-124)", dim_limit);
         it = md + 4;
         return RSPT_OK;
     };

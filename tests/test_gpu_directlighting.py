@@ -183,3 +183,38 @@ def test_directlighting_random_scenes_fuzz(gpu, oracle, seed):
     assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == 0
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert film_rmse(film, ref["film"]) < 2e-5
+
+
+@pytest.mark.parametrize("strategy", ["one", "all"])
+def test_many_lights_at_default_depth_are_not_refused(gpu, oracle, strategy):
+    """the dimension guard used to price a full 2^max_depth specular tree with every node on the fall-back stream, so the
+    default max_depth 5 was refused from 7-8 emitter triangles up.  Now the sample arrays must fit (5 + 4 x max_depth x n_lights
+    dimensions) and k_dl_assign reports only a camera sample whose tree really draws past the sampler's dimensions.  The mirror /
+    glass Cornell box with 24 emitter triangles, depth 5."""
+    from rs_pbrt_amd.lib import RsptError
+    sb = scenes.SceneBuilder()
+    white = sb.add_material(scenes.matte((0.725, 0.71, 0.68)))
+    mir = sb.add_material(scenes.mirror())
+    gls = sb.add_material(scenes.glass())
+    q = sb.add_quad
+    q([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)], white)
+    q([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)], white)
+    q([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)], white)
+    q([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)], mir)
+    q([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)], gls)
+    for a in range(4):
+        for b in range(3):
+            x0, z0 = 150 + 70 * a, 180 + 70 * b
+            q([(x0 + 40, 548.7, z0), (x0 + 40, 548.7, z0 + 40), (x0, 548.7, z0 + 40), (x0, 548.7, z0)], white, emit=(10 + 3 * a, 8 + b, 4))
+    sc = sb.finish(gpu.bvh_build)
+    assert len(sc.lights) == 24
+    rd = scenes.cornell_render_desc(res=40, spp=4, integrator="directlighting", direct_strategy=strategy, max_depth=5)
+    check(gpu, oracle, sc, rd, strategy)
+    # 60 lights x depth 5 = 600 array pairs: 5 + 1200 dimensions do not fit the 1024 of the Sobol' sampler (the reference panics in start_pixel)
+    if strategy == "all":
+        for a in range(6):
+            for b in range(3):
+                q([(60 + 80 * a, 10, 60 + 80 * b), (60 + 80 * a, 10, 90 + 80 * b), (90 + 80 * a, 10, 90 + 80 * b), (90 + 80 * a, 10, 60 + 80 * b)], white, emit=(5, 5, 5))
+        with gpu.DeviceScene(sb.finish(gpu.bvh_build)) as ds, pytest.raises(RsptError) as e:
+            gpu.render(ds, rd)
+        assert e.value.code == abi.E_UNSUPPORTED

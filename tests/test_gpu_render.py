@@ -563,6 +563,39 @@ def test_film_reduce_runs_inside_the_library(gpu):
             gpu.comm_destroy()
 
 
+def test_film_reduce_with_two_ranks_on_one_gpu(gpu, tmp_path):
+    """X1 with a world of two: two processes on the one GPU of this box join the library's RCCL communicator, render the shards
+    (0, 2, 1) / (1, 2, 1) with film_reduce = 1; rank 0's buffer must hold the whole frame (= the single-rank render: weights bit for
+    bit, radiance up to the order of the sum).  RCCL may refuse two ranks on one device ("Duplicate GPU detected"): then the test says so
+    and skips — the multi-device run is the driver's."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0].decode("utf-8", "replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank reduce hung")
+    errs = [open(os.path.join(tmp_path, f)).read() for f in os.listdir(tmp_path) if f.startswith("init_error")]
+    if errs:
+        pytest.skip("RCCL refused two ranks on one device: %s | %s" % (errs[0], outs[0][-300:]))
+    assert [p.returncode for p in procs] == [0, 0], outs
+    sc = scenes.cornell_box(gpu.bvh_build)
+    with gpu.DeviceScene(sc) as ds:
+        whole, st = gpu.render(ds, scenes.cornell_render_desc(res=80, spp=4))
+    reduced = np.load(os.path.join(tmp_path, "film_0.npy"))
+    part1 = np.load(os.path.join(tmp_path, "film_1.npy"))
+    n = int(np.load(os.path.join(tmp_path, "samples_0.npy"))[0]) + int(np.load(os.path.join(tmp_path, "samples_1.npy"))[0])
+    assert n == st["samples"] == 80 * 80 * 4
+    assert np.array_equal(reduced[:, 3], whole[:, 3]) and np.allclose(reduced, whole, rtol=1e-6, atol=1e-7)
+    assert 0 < part1[:, 3].sum() < whole[:, 3].sum()   # the other rank keeps its partial film
+
+
 def test_spatial_light_distribution_on_demand_voxels(gpu, oracle):
     """the spatial distribution is built voxel by voxel as paths look voxels up (what the reference's lazily filled hash
     table does, lightdistrib.rs:297-384) once the full table would be large; a voxel's distribution is a pure function of

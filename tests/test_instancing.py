@@ -285,4 +285,4 @@ def test_gpu_landscape_standin_crop_matches_oracle(gpu, oracle, mode):
             assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
     ref = oracle.render(sc, rd, threads=8)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    assert film_rmse(film, ref["film"]) < 1e-4   # 16 spp under a sun texel: one flipped sample moves a pixel by O(1)
+    assert film_rmse(film, ref["film"]) < 1e-7   # per-sample radiance is bit-identical; the full-size frame is tests/test_gpu_fullsize.py
