@@ -12,6 +12,24 @@ namespace rspt {
 
 enum : uint32_t { BX_REFL = 1, BX_TRANS = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX_SPEC = 16, BX_ALL = 31 };
 
+// Feature set of a shade-stage instantiation (kernels.h k_shade<F>): what the scene being rendered can put in front of the stage.
+// rspt_scene_create knows every lobe type, light kind and mesh attribute of the scene; the host launches the narrowest compiled
+// instantiation that covers them (librspt.hip shade_variant), and code for anything outside F folds away at compile time — the
+// arithmetic of what remains is untouched, so the results are bit for bit those of the generic instantiation (SF_ALL).
+enum : uint32_t {
+    // bits 1 .. 9: 1 << RSPT_BXDF_*
+    SF_CONDUCTOR = 1u << 10,   // a MicrofacetReflection / SpecularReflection with a conductor Fresnel (metal)
+    SF_SC = 1u << 11,          // MixMaterial lobes (sc_opt)
+    SF_L_AREA = 1u << 12, SF_L_POINT = 1u << 13, SF_L_SPOT = 1u << 14, SF_L_DISTANT = 1u << 15, SF_L_INFINITE = 1u << 16,
+    SF_TEX = 1u << 17,         // textured materials (the texture stage ran)
+    SF_INST = 1u << 18,        // object instances
+    SF_NULL = 1u << 19,        // surfaces without a BSDF
+    SF_HALTON = 1u << 20,      // the Halton sampler (else Sobol' from the LDS block)
+    SF_VERTEX = 1u << 21,      // meshes with per-vertex normals / tangents / uvs
+    SF_ALL = 0xffffffffu
+};
+#define RSPT_SF_LOBE(T) (1u << (T))
+
 // trigonometry in the shading frame, reflection.rs:1801-1886
 RDEV float cos2_t(f3 w) { return w.z * w.z; }
 RDEV float sin2_t(f3 w) { return fmaxf(0.0f, 1.0f - cos2_t(w)); }
@@ -179,9 +197,10 @@ RDEV uint32_t lobe_type(uint32_t t) {
 }
 RDEV bool lobe_matches(uint32_t type_bits, uint32_t flags) { return (type_bits & flags) == type_bits; }
 
+template <uint32_t F = SF_ALL>
 RDEV rgb lobe_fresnel(const rspt_bxdf& b, float ci) {  // Fresnel::evaluate :651-705
     if (b.fresnel == RSPT_FRESNEL_DIELECTRIC) return mkrgb(fr_dielectric(ci, b.eta_a, b.eta_b));
-    if (b.fresnel == RSPT_FRESNEL_CONDUCTOR) return fr_conductor(ci, ldrgb(b.c1), ldrgb(b.c2));
+    if ((F & SF_CONDUCTOR) && b.fresnel == RSPT_FRESNEL_CONDUCTOR) return fr_conductor(ci, ldrgb(b.c1), ldrgb(b.c2));
     return mkrgb(1.0f);
 }
 
@@ -191,28 +210,35 @@ struct LobeTex {
     const float4* base;  // this path's entry of row 0 (nullptr: the material has no textured lobe)
     size_t stride;       // paths per row
 };
+template <uint32_t F = SF_ALL>
 RDEV rgb lobe_r(const rspt_bxdf& b, const LobeTex& lt) {
     rgb r = ldrgb(b.r);
-    if (lt.base && b.tex_r) { float4 v = lt.base[(size_t)(b.tex_r - 1u) * lt.stride]; r = r * rgb{v.x, v.y, v.z}; }
+    if ((F & SF_TEX) && lt.base && b.tex_r) { float4 v = lt.base[(size_t)(b.tex_r - 1u) * lt.stride]; r = r * rgb{v.x, v.y, v.z}; }
     return r;
 }
 // alphas bound to roughness textures: k_texture left the final value (remapped, clamped to >= 0.001) in the slot
-RDEV float lobe_ax(const rspt_bxdf& b, const LobeTex& lt) { return (lt.base && b.tex_ax) ? lt.base[(size_t)(b.tex_ax - 1u) * lt.stride].x : b.alpha_x; }
-RDEV float lobe_ay(const rspt_bxdf& b, const LobeTex& lt) { return (lt.base && b.tex_ay) ? lt.base[(size_t)(b.tex_ay - 1u) * lt.stride].x : b.alpha_y; }
+template <uint32_t F = SF_ALL>
+RDEV float lobe_ax(const rspt_bxdf& b, const LobeTex& lt) { return ((F & SF_TEX) && lt.base && b.tex_ax) ? lt.base[(size_t)(b.tex_ax - 1u) * lt.stride].x : b.alpha_x; }
+template <uint32_t F = SF_ALL>
+RDEV float lobe_ay(const rspt_bxdf& b, const LobeTex& lt) { return ((F & SF_TEX) && lt.base && b.tex_ay) ? lt.base[(size_t)(b.tex_ay - 1u) * lt.stride].x : b.alpha_y; }
+template <uint32_t F = SF_ALL>
 RDEV rgb lobe_t(const rspt_bxdf& b, const LobeTex& lt) {
     rgb t = ldrgb(b.t);
-    if (lt.base && b.tex_t) { float4 v = lt.base[(size_t)(b.tex_t - 1u) * lt.stride]; t = t * rgb{v.x, v.y, v.z}; }
+    if ((F & SF_TEX) && lt.base && b.tex_t) { float4 v = lt.base[(size_t)(b.tex_t - 1u) * lt.stride]; t = t * rgb{v.x, v.y, v.z}; }
     return t;
 }
 
 // sc_opt of MixMaterial lobes: the reference writes `sc * A * B ...`, i.e. ((sc * A) * B) ...
-RDEV rgb lobe_scaled(const rspt_bxdf& b, rgb a) { return b.has_sc ? ldrgb(b.sc) * a : a; }
+template <uint32_t F = SF_ALL>
+RDEV rgb lobe_scaled(const rspt_bxdf& b, rgb a) { return ((F & SF_SC) && b.has_sc) ? ldrgb(b.sc) * a : a; }
 
+template <uint32_t F = SF_ALL>
 RDEVN rgb lobe_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
     switch (b.type) {
-    case RSPT_BXDF_LAMBERT_R: return lobe_scaled(b, lobe_r(b, lt)) * mkrgb(RSPT_INV_PI);
-    case RSPT_BXDF_LAMBERT_T: return lobe_scaled(b, lobe_r(b, lt)) * RSPT_INV_PI;
+    case RSPT_BXDF_LAMBERT_R: return lobe_scaled<F>(b, lobe_r<F>(b, lt)) * mkrgb(RSPT_INV_PI);
+    case RSPT_BXDF_LAMBERT_T: return lobe_scaled<F>(b, lobe_r<F>(b, lt)) * RSPT_INV_PI;
     case RSPT_BXDF_OREN_NAYAR: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_OREN_NAYAR))) break;
         float sti = sin_t(wi), sto = sin_t(wo);
         float max_cos = 0.0f;
         if (sti > 1.0e-4f && sto > 1.0e-4f) {
@@ -222,18 +248,20 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
         float sin_alpha, tan_beta;
         if (fabsf(wi.z) > fabsf(wo.z)) { sin_alpha = sto; tan_beta = sti / fabsf(wi.z); }
         else { sin_alpha = sti; tan_beta = sto / fabsf(wo.z); }
-        return lobe_scaled(b, lobe_r(b, lt)) * mkrgb(RSPT_INV_PI * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta));
+        return lobe_scaled<F>(b, lobe_r<F>(b, lt)) * mkrgb(RSPT_INV_PI * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta));
     }
     case RSPT_BXDF_MICROFACET_R: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R))) break;
         float cto = fabsf(wo.z), cti = fabsf(wi.z);
         f3 wh = wi + wo;
         if (cti == 0.0f || cto == 0.0f) return mkrgb(0.0f);
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
         wh = normalize(wh);
-        rgb fr = lobe_fresnel(b, dot(wi, wh));
-        return lobe_scaled(b, lobe_r(b, lt)) * tr_d(lobe_ax(b, lt), lobe_ay(b, lt), wh) * tr_g(lobe_ax(b, lt), lobe_ay(b, lt), wo, wi) * fr / (4.0f * cti * cto);
+        rgb fr = lobe_fresnel<F>(b, dot(wi, wh));
+        return lobe_scaled<F>(b, lobe_r<F>(b, lt)) * tr_d(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wh) * tr_g(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, wi) * fr / (4.0f * cti * cto);
     }
     case RSPT_BXDF_MICROFACET_T: {  // MicrofacetTransmission::f, TransportMode::Radiance (reflection.rs:1246-1317)
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_T))) break;
         if (same_hemi(wo, wi)) return mkrgb(0.0f);
         float cto = wo.z, cti = wi.z;
         if (cto == 0.0f || cti == 0.0f) return mkrgb(0.0f);
@@ -244,23 +272,26 @@ RDEVN rgb lobe_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
         rgb fr = mkrgb(fr_dielectric(dot(wo, wh), b.eta_a, b.eta_b));
         float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = 1.0f / eta;
-        return lobe_scaled(b, mkrgb(1.0f) - fr) * lobe_r(b, lt) *
-               fabsf(tr_d(lobe_ax(b, lt), lobe_ay(b, lt), wh) * tr_g(lobe_ax(b, lt), lobe_ay(b, lt), wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+        return lobe_scaled<F>(b, mkrgb(1.0f) - fr) * lobe_r<F>(b, lt) *
+               fabsf(tr_d(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wh) * tr_g(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                      (cti * cto * sqrt_denom * sqrt_denom));
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // FresnelBlend::f (reflection.rs:1398-1431): r = Rd, t = Rs
-        rgb rd = lobe_r(b, lt), rs = lobe_t(b, lt);
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_BLEND))) break;
+        rgb rd = lobe_r<F>(b, lt), rs = lobe_t<F>(b, lt);
         rgb diffuse = rd * (mkrgb(1.0f) - rs) * (28.0f / (23.0f * RSPT_PI)) * (1.0f - pow5(1.0f - 0.5f * fabsf(wi.z))) * (1.0f - pow5(1.0f - 0.5f * fabsf(wo.z)));
         f3 wh = wi + wo;
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkrgb(0.0f);
         wh = normalize(wh);
         rgb schlick = rs + (mkrgb(1.0f) - rs) * pow5(1.0f - dot(wi, wh));
-        rgb specular = schlick * (tr_d(lobe_ax(b, lt), lobe_ay(b, lt), wh) / (4.0f * fabsf(dot(wi, wh)) * fmaxf(fabsf(wi.z), fabsf(wo.z))));
+        rgb specular = schlick * (tr_d(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wh) / (4.0f * fabsf(dot(wi, wh)) * fmaxf(fabsf(wi.z), fabsf(wo.z))));
         return b.has_sc ? ldrgb(b.sc) * (diffuse + specular) : diffuse + specular;
     }
-    default: return mkrgb(0.0f);
+    default: break;
     }
+    return mkrgb(0.0f);
 }
+template <uint32_t F = SF_ALL>
 RDEVN float lobe_pdf(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
     switch (b.type) {
     case RSPT_BXDF_LAMBERT_R:
@@ -270,11 +301,13 @@ RDEVN float lobe_pdf(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
         return same_hemi(wo, wi) ? fabsf(wi.z) * RSPT_INV_PI : 0.0f;
     case RSPT_BXDF_LAMBERT_T: return !same_hemi(wo, wi) ? fabsf(wi.z) * RSPT_INV_PI : 0.0f;
     case RSPT_BXDF_MICROFACET_R: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R))) break;
         if (!same_hemi(wo, wi)) return 0.0f;
         f3 wh = normalize(wo + wi);
-        return tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh) / (4.0f * dot(wo, wh));
+        return tr_pdf(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, wh) / (4.0f * dot(wo, wh));
     }
     case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1350-1370
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_T))) break;
         if (same_hemi(wo, wi)) return 0.0f;
         float eta = wo.z > 0.0f ? b.eta_b / b.eta_a : b.eta_a / b.eta_b;
         f3 wh = normalize(wo + wi * eta);
@@ -282,20 +315,23 @@ RDEVN float lobe_pdf(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3 wi) {
         if (wo_wh * wi_wh > 0.0f) return 0.0f;
         float sqrt_denom = wo_wh + eta * wi_wh;
         float dwh_dwi = fabsf((eta * eta * wi_wh) / (sqrt_denom * sqrt_denom));
-        return tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh) * dwh_dwi;
+        return tr_pdf(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, wh) * dwh_dwi;
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1462-1474
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_BLEND))) break;
         if (!same_hemi(wo, wi)) return 0.0f;
         f3 wh = normalize(wo + wi);
-        float pdf_wh = tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh);
+        float pdf_wh = tr_pdf(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, wh);
         return 0.5f * (fabsf(wi.z) * RSPT_INV_PI + pdf_wh / (4.0f * dot(wo, wh)));
     }
-    default: return 0.0f;
+    default: break;
     }
+    return 0.0f;
 }
 // sampled_type follows the reference's in/out sentinel convention (only written when non-zero).
 // want_f = false: Bsdf::sample_f replaces the value of a non-specular lobe by the sum over all matching lobes
 // (reflection.rs:393-410), so its own f() need not be evaluated (Q7: nothing else reads it)
+template <uint32_t F = SF_ALL>
 RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2 u, float* pdf, uint32_t* sampled_type, bool want_f) {
     const rgb black = mkrgb(0.0f);
     switch (b.type) {
@@ -303,63 +339,70 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
     case RSPT_BXDF_OREN_NAYAR: {
         *wi = cosine_hemisphere(u);
         if (wo.z < 0.0f) wi->z *= -1.0f;
-        *pdf = lobe_pdf(b, lt, wo, *wi);
-        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
+        *pdf = lobe_pdf<F>(b, lt, wo, *wi);
+        return want_f ? lobe_f<F>(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_LAMBERT_T: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_LAMBERT_T))) break;
         *wi = cosine_hemisphere(u);
         if (wo.z > 0.0f) wi->z *= -1.0f;
-        *pdf = lobe_pdf(b, lt, wo, *wi);
-        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
+        *pdf = lobe_pdf<F>(b, lt, wo, *wi);
+        return want_f ? lobe_f<F>(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_SPECULAR_R: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_R))) break;
         *wi = f3{-wo.x, -wo.y, wo.z};
         *pdf = 1.0f;
-        return lobe_scaled(b, lobe_fresnel(b, wi->z)) * lobe_r(b, lt) / fabsf(wi->z);
+        return lobe_scaled<F>(b, lobe_fresnel<F>(b, wi->z)) * lobe_r<F>(b, lt) / fabsf(wi->z);
     }
     case RSPT_BXDF_SPECULAR_T: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_T))) break;
         bool entering = wo.z > 0.0f;
         float ei = entering ? b.eta_a : b.eta_b, et = entering ? b.eta_b : b.eta_a;
         if (!refract(wo, faceforward(f3{0.0f, 0.0f, 1.0f}, wo), ei / et, wi)) return black;
         *pdf = 1.0f;
-        rgb ft = lobe_r(b, lt) * (mkrgb(1.0f) - mkrgb(fr_dielectric(wi->z, b.eta_a, b.eta_b)));
+        rgb ft = lobe_r<F>(b, lt) * (mkrgb(1.0f) - mkrgb(fr_dielectric(wi->z, b.eta_a, b.eta_b)));
         ft = ft * mkrgb((ei * ei) / (et * et));
-        return lobe_scaled(b, ft) / fabsf(wi->z);
+        return lobe_scaled<F>(b, ft) / fabsf(wi->z);
     }
     case RSPT_BXDF_FRESNEL_SPEC: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_SPEC))) break;
         float fr = fr_dielectric(wo.z, b.eta_a, b.eta_b);
         if (u.x < fr) {
             *wi = f3{-wo.x, -wo.y, wo.z};
             if (*sampled_type != 0) *sampled_type = BX_REFL | BX_SPEC;
             *pdf = fr;
-            return lobe_scaled(b, lobe_r(b, lt)) * fr / fabsf(wi->z);
+            return lobe_scaled<F>(b, lobe_r<F>(b, lt)) * fr / fabsf(wi->z);
         }
         bool entering = wo.z > 0.0f;
         float ei = entering ? b.eta_a : b.eta_b, et = entering ? b.eta_b : b.eta_a;
         if (!refract(wo, faceforward(f3{0.0f, 0.0f, 1.0f}, wo), ei / et, wi)) return black;
-        rgb ft = lobe_t(b, lt) * (1.0f - fr);
+        rgb ft = lobe_t<F>(b, lt) * (1.0f - fr);
         ft = ft * mkrgb((ei * ei) / (et * et));
         if (*sampled_type != 0) *sampled_type = BX_TRANS | BX_SPEC;
         *pdf = 1.0f - fr;
-        return lobe_scaled(b, ft) / fabsf(wi->z);
+        return lobe_scaled<F>(b, ft) / fabsf(wi->z);
     }
     case RSPT_BXDF_MICROFACET_R: {
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R))) break;
         if (wo.z == 0.0f) return black;
-        f3 wh = tr_sample_wh(lobe_ax(b, lt), lobe_ay(b, lt), wo, u);
+        f3 wh = tr_sample_wh(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, u);
         *wi = (-wo) + wh * 2.0f * dot(wo, wh);  // reflect, reflection.rs:1889
         if (!same_hemi(wo, *wi)) return black;
-        *pdf = tr_pdf(lobe_ax(b, lt), lobe_ay(b, lt), wo, wh) / (4.0f * dot(wo, wh));
-        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
+        *pdf = tr_pdf(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, wh) / (4.0f * dot(wo, wh));
+        return want_f ? lobe_f<F>(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_MICROFACET_T: {  // reflection.rs:1322-1349
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_T))) break;
         if (wo.z == 0.0f) return black;
-        f3 wh = tr_sample_wh(lobe_ax(b, lt), lobe_ay(b, lt), wo, u);
+        f3 wh = tr_sample_wh(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, u);
         float eta = wo.z > 0.0f ? b.eta_a / b.eta_b : b.eta_b / b.eta_a;
         if (!refract(wo, wh, eta, wi)) return black;
-        *pdf = lobe_pdf(b, lt, wo, *wi);
-        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
+        *pdf = lobe_pdf<F>(b, lt, wo, *wi);
+        return want_f ? lobe_f<F>(b, lt, wo, *wi) : mkrgb(0.0f);
     }
     case RSPT_BXDF_FRESNEL_BLEND: {  // reflection.rs:1432-1461
+        if (!(F & RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_BLEND))) break;
         f2 uu = u;
         if (uu.x < 0.5f) {
             uu.x = fminf(2.0f * uu.x, RSPT_ONE_MINUS_EPS);
@@ -367,15 +410,16 @@ RDEVN rgb lobe_sample_f(const rspt_bxdf& b, const LobeTex& lt, f3 wo, f3* wi, f2
             if (wo.z < 0.0f) wi->z *= -1.0f;
         } else {
             uu.x = fminf(2.0f * (uu.x - 0.5f), RSPT_ONE_MINUS_EPS);
-            f3 wh = tr_sample_wh(lobe_ax(b, lt), lobe_ay(b, lt), wo, uu);
+            f3 wh = tr_sample_wh(lobe_ax<F>(b, lt), lobe_ay<F>(b, lt), wo, uu);
             *wi = (-wo) + wh * 2.0f * dot(wo, wh);
             if (!same_hemi(wo, *wi)) return black;
         }
-        *pdf = lobe_pdf(b, lt, wo, *wi);
-        return want_f ? lobe_f(b, lt, wo, *wi) : mkrgb(0.0f);
+        *pdf = lobe_pdf<F>(b, lt, wo, *wi);
+        return want_f ? lobe_f<F>(b, lt, wo, *wi) : mkrgb(0.0f);
     }
-    default: return black;
+    default: break;
     }
+    return black;
 }
 
 // Bsdf (reflection.rs:223-446): frame + lobe slice
@@ -400,20 +444,23 @@ struct Bsdf {
         for (uint32_t i = 0; i < n; i++) c += lobe_matches(ltype(i), flags) ? 1 : 0;
         return c;
     }
+    template <uint32_t F = SF_ALL>
     RDEVN rgb sum_f(f3 wo, f3 wi, bool refl, uint32_t flags) const {
         rgb f = mkrgb(0.0f);
         for (uint32_t i = 0; i < n; i++) {
             uint32_t t = ltype(i);
-            if (lobe_matches(t, flags) && ((refl && (t & BX_REFL)) || (!refl && (t & BX_TRANS)))) f = f + lobe_f(lobes[i], lt, wo, wi);
+            if (lobe_matches(t, flags) && ((refl && (t & BX_REFL)) || (!refl && (t & BX_TRANS)))) f = f + lobe_f<F>(lobes[i], lt, wo, wi);
         }
         return f;
     }
+    template <uint32_t F = SF_ALL>
     RDEVN rgb f(f3 wo_w, f3 wi_w, uint32_t flags) const {  // :274-297
         f3 wi = to_local(wi_w), wo = to_local(wo_w);
         if (wo.z == 0.0f) return mkrgb(0.0f);
         bool refl = (dot(wi_w, ng) * dot(wo_w, ng)) > 0.0f;
-        return sum_f(wo, wi, refl, flags);
+        return sum_f<F>(wo, wi, refl, flags);
     }
+    template <uint32_t F = SF_ALL>
     RDEVN float pdf(f3 wo_w, f3 wi_w, uint32_t flags) const {  // :421-446
         if (n == 0) return 0.0f;
         f3 wo = to_local(wo_w), wi = to_local(wi_w);
@@ -421,9 +468,10 @@ struct Bsdf {
         float p = 0.0f;
         int matching = 0;
         for (uint32_t i = 0; i < n; i++)
-            if (lobe_matches(ltype(i), flags)) { matching++; p += lobe_pdf(lobes[i], lt, wo, wi); }
+            if (lobe_matches(ltype(i), flags)) { matching++; p += lobe_pdf<F>(lobes[i], lt, wo, wi); }
         return matching > 0 ? p / (float)matching : 0.0f;
     }
+    template <uint32_t F = SF_ALL>
     RDEVN rgb sample_f(f3 wo_w, f3* wi_w, f2 u, float* pdf_out, uint32_t flags, uint32_t* sampled_type) const {  // :298-420
         const rgb black = mkrgb(0.0f);
         int matching = num_components(flags);
@@ -446,16 +494,16 @@ struct Bsdf {
         if (wo.z == 0.0f) return black;
         *pdf_out = 0.0f;
         if (*sampled_type != 0) *sampled_type = bt;
-        rgb f = lobe_sample_f(bx, lt, wo, &wi, ur, pdf_out, sampled_type, false);
+        rgb f = lobe_sample_f<F>(bx, lt, wo, &wi, ur, pdf_out, sampled_type, false);
         if (*pdf_out == 0.0f) { if (*sampled_type != 0) *sampled_type = 0; return black; }
         *wi_w = to_world(wi);
         if (!(bt & BX_SPEC) && matching > 1)
             for (uint32_t i = 0; i < n; i++)
-                if ((int)i != idx && lobe_matches(ltype(i), flags)) *pdf_out += lobe_pdf(lobes[i], lt, wo, wi);
+                if ((int)i != idx && lobe_matches(ltype(i), flags)) *pdf_out += lobe_pdf<F>(lobes[i], lt, wo, wi);
         if (matching > 1) *pdf_out /= (float)matching;
         if (!(bt & BX_SPEC)) {
             bool refl = dot(*wi_w, ng) * dot(wo_w, ng) > 0.0f;
-            f = sum_f(wo, wi, refl, flags);
+            f = sum_f<F>(wo, wi, refl, flags);
         }
         return f;
     }

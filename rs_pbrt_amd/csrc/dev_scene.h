@@ -227,26 +227,28 @@ RDEV float halton_dim(const RenderDev& rd, uint64_t index, uint32_t dim) {  // s
 
 // the sampler cursor of the shade stage: Sobol' dimensions come from the LDS block, Halton's are
 // computed on demand (both are pure functions of (index, dimension): GlobalSampler, sampler.rs)
-struct PathSampler {
+template <bool HALTON_POSSIBLE = true>
+struct PathSamplerT {
     SobolBlock blk;
     uint64_t index;
     uint32_t hdim;
     bool halton;
     RDEV void start(const RenderDev& rd, const uint32_t* __restrict__ tab, uint32_t nd, uint64_t idx, uint32_t first_dim) {
-        halton = rd.sampler_kind == RSPT_SAMPLER_HALTON;
+        halton = HALTON_POSSIBLE && rd.sampler_kind == RSPT_SAMPLER_HALTON;
         index = idx;
         hdim = first_dim;
         if (!halton) blk.fill(tab, nd, idx, first_dim);
     }
-    RDEV uint32_t dim() const { return halton ? hdim : blk.dim; }
-    RDEV float get_1d(const RenderDev& rd) { return halton ? halton_dim(rd, index, hdim++) : blk.get_1d(); }
+    RDEV uint32_t dim() const { return (HALTON_POSSIBLE && halton) ? hdim : blk.dim; }
+    RDEV float get_1d(const RenderDev& rd) { return (HALTON_POSSIBLE && halton) ? halton_dim(rd, index, hdim++) : blk.get_1d(); }
     RDEV f2 get_2d(const RenderDev& rd) {
-        if (!halton) return blk.get_2d();
+        if (!(HALTON_POSSIBLE && halton)) return blk.get_2d();
         float y = halton_dim(rd, index, hdim + 1), x = halton_dim(rd, index, hdim);
         hdim += 2;
         return f2{x, y};
     }
 };
+using PathSampler = PathSamplerT<true>;
 
 // ---- geometry at a hit: second half of Triangle::intersect (triangle.rs:274-448) ----
 struct Hit {
@@ -275,11 +277,13 @@ RDEV TriRec load_tri(const SceneDev& sc, uint32_t prim) {
 }
 RDEV f3 ld3(const float* a, uint32_t i) { return f3{a[3 * (size_t)i], a[3 * (size_t)i + 1], a[3 * (size_t)i + 2]}; }
 
+// VERTEX = false: the scene has no mesh with per-vertex normals / tangents / uvs (SF_VERTEX, dev_bsdf.h)
+template <bool VERTEX = true>
 RDEVN void tri_fill(const SceneDev& sc, uint32_t prim, const TriRec& t, float b0, float b1, float b2, Hit* h) {
     f3 p0 = t.p0, p1 = t.p1, p2 = t.p2;
     f2 uv0{0.0f, 0.0f}, uv1{1.0f, 0.0f}, uv2{1.0f, 1.0f};  // triangle.rs:97-112
-    const bool has_uv = (t.flags & MF_HAS_UV) && sc.UV;
-    const bool has_n = (t.flags & MF_HAS_N) && sc.N, has_s = (t.flags & MF_HAS_S) && sc.S;
+    const bool has_uv = VERTEX && (t.flags & MF_HAS_UV) && sc.UV;
+    const bool has_n = VERTEX && (t.flags & MF_HAS_N) && sc.N, has_s = VERTEX && (t.flags & MF_HAS_S) && sc.S;
     uint32_t v0 = 0, v1 = 0, v2 = 0;
     if (has_uv || has_n || has_s) {
         rspt_prim pr = sc.prims[prim];
@@ -466,7 +470,10 @@ RDEV LightSample tri_sample_ref(const SceneDev& sc, uint32_t prim, const TriRec&
     }
     return s;
 }
-RDEV bool light_is_delta(const rspt_light& lt) { return lt.kind == RSPT_LIGHT_POINT || lt.kind == RSPT_LIGHT_SPOT || lt.kind == RSPT_LIGHT_DISTANT; }  // light.rs:178-188
+template <uint32_t F = 0xffffffffu>
+RDEV bool light_is_delta(const rspt_light& lt) {  // light.rs:178-188
+    return ((F & SF_L_POINT) && lt.kind == RSPT_LIGHT_POINT) || ((F & SF_L_SPOT) && lt.kind == RSPT_LIGHT_SPOT) || ((F & SF_L_DISTANT) && lt.kind == RSPT_LIGHT_DISTANT);
+}
 // ---- MipMap<Spectrum> lookups, wrap mode Repeat (mipmap.rs:206-252, 323-336) ----
 RDEV rgb env_texel(const EnvMapDev& m, uint32_t level, int64_t s_, int64_t t_) {
     uint32_t w = m.width >> level, h = m.height >> level;
@@ -561,8 +568,9 @@ RDEV float spot_falloff(const rspt_light& lt, f3 w) {  // spot.rs:67-80
 // Light::sample_li: DiffuseAreaLight (diffuse.rs:64-84), PointLight (point.rs:52-68), SpotLight
 // (spot.rs:81-106), DistantLight (distant.rs:41-58).  Delta lights return pdf = 1 and a light point
 // with zero normal and zero error bounds (InteractionCommon::default()).
+template <uint32_t F = 0xffffffffu>
 RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 u, f3* wi, float* pdf, LightSample* ls) {
-    if (lt.kind == RSPT_LIGHT_DIFFUSE_AREA) {
+    if (!(F & (SF_L_POINT | SF_L_SPOT | SF_L_DISTANT | SF_L_INFINITE)) || lt.kind == RSPT_LIGHT_DIFFUSE_AREA) {
         TriRec t = load_tri(sc, lt.prim);
         *ls = tri_sample_ref(sc, lt.prim, t, ref_p, u, pdf);
         if (*pdf == 0.0f || len2(ls->p - ref_p) == 0.0f) { *pdf = 0.0f; return mkrgb(0.0f); }
@@ -571,7 +579,7 @@ RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 
     }
     ls->p_err = f3{0.0f, 0.0f, 0.0f};
     ls->n = f3{0.0f, 0.0f, 0.0f};
-    if (lt.kind == RSPT_LIGHT_INFINITE) {  // infinite.rs:298-341
+    if ((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) {  // infinite.rs:298-341
         const EnvMapDev& m = sc.envmaps[lt.prim];
         float map_pdf = 0.0f;
         f2 uv = env_sample_continuous(m, u, &map_pdf);
@@ -585,7 +593,7 @@ RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 
         return env_lookup(m, uv, 0.0f);
     }
     *pdf = 1.0f;
-    if (lt.kind == RSPT_LIGHT_DISTANT) {
+    if ((F & SF_L_DISTANT) && lt.kind == RSPT_LIGHT_DISTANT) {
         f3 w{lt.p[0], lt.p[1], lt.p[2]};
         *wi = w;
         ls->p = ref_p + w * (2.0f * world_radius(sc));
@@ -595,7 +603,7 @@ RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 
     *wi = normalize(pl - ref_p);
     ls->p = pl;
     float d2 = dist2(pl, ref_p);
-    if (lt.kind == RSPT_LIGHT_POINT) return ldrgb(lt.L) / d2;
+    if (!(F & SF_L_SPOT) || lt.kind == RSPT_LIGHT_POINT) return ldrgb(lt.L) / d2;
     return ldrgb(lt.L) * spot_falloff(lt, -*wi) / d2;
 }
 // Light::power (diffuse.rs:85-93, point.rs:69-71, spot.rs:107-113, distant.rs:59-62)
