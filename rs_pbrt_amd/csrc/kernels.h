@@ -326,7 +326,8 @@ RDEV void store_ray(rspt_ray* dst, f3 o, f3 d, float t_max, uint32_t id) {
 
 // One step of PathIntegrator::li (path.rs:91-280) for path slot p: fold in the previous
 // bounce's next-event estimate, then process the hit of the continuation ray.
-template <bool PIX>
+// F: the feature set the instantiation is compiled for (dev_bsdf.h SF_*): everything a scene outside F could bring folds away
+template <bool PIX, uint32_t F = SF_ALL>
 RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const RenderDev& rd, const PathBuf& pb, uint32_t p, unsigned long long* stats,
                           const uint32_t* __restrict__ sob_tab, uint32_t sob_nd, PixSampler* px) {
     ShadeOut out{false, false, false, false};
@@ -343,13 +344,13 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             float4 hm = pb.hit_mis[p];
             uint32_t hp = __float_as_uint(hm.x);
             uint32_t light_num = __float_as_uint(c2.w);
-            if (st & ST_C2_ON_MISS) {  // InfiniteAreaLight: li = light.le(ray) when nothing was hit (integrator.rs:561-563)
+            if ((F & SF_L_INFINITE) && (st & ST_C2_ON_MISS)) {  // InfiniteAreaLight: li = light.le(ray) when nothing was hit (integrator.rs:561-563)
                 if (hp == RSPT_MISS) ldir = ldir + rgb{c2.x, c2.y, c2.z};
             } else if (hp != RSPT_MISS) {
                 TriRec t = load_tri(sc, hp);
                 if (t.area_light >= 0 && (uint32_t)t.area_light == light_num) {
                     Hit h;
-                    tri_fill(sc, hp, t, hm.y, hm.z, hm.w, &h);
+                    tri_fill<(F & SF_VERTEX) != 0>(sc, hp, t, hm.y, hm.z, hm.w, &h);
                     const float4* mr = reinterpret_cast<const float4*>(pb.ray_mis + p);
                     float4 m0 = mr[0], m1 = mr[1];
                     f3 wi{m0.w, m1.x, m1.y};
@@ -372,7 +373,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     uint32_t prim = __float_as_uint(hc.x);
     uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
     if (prim == RSPT_MISS) {  // K5: escaped path picks up the infinite lights (path.rs:267-277)
-        if (sc.n_infinite && (bounces == 0 || (st & ST_SPECULAR))) {
+        if ((F & SF_L_INFINITE) && sc.n_infinite && (bounces == 0 || (st & ST_SPECULAR))) {
             const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
             float4 r0 = rp[0], r1 = rp[1];
             f3 ray_d{r0.w, r1.x, r1.y};
@@ -388,9 +389,9 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         rgb beta{bb.x, bb.y, bb.z};
         TriRec tri = load_tri(sc, prim);
         Hit h;
-        tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &h);
+        tri_fill<(F & SF_VERTEX) != 0>(sc, prim, tri, hc.y, hc.z, hc.w, &h);
         f3 wo = -ray_d;  // SurfaceInteraction.wo, not normalised (triangle.rs:334)
-        if (pb.hit_inst) {  // the hit lies inside an object instance: TransformedPrimitive::intersect (primitive.rs:216-253)
+        if ((F & SF_INST) && pb.hit_inst) {  // the hit lies inside an object instance: TransformedPrimitive::intersect (primitive.rs:216-253)
             const uint32_t hi = pb.hit_inst[p];
             if (hi && !sc.inst[hi - 1u].identity) {
                 const InstDev& in = sc.inst[hi - 1u];
@@ -404,7 +405,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             L = L + beta * e;
         }
         if (bounces < rd.max_depth) {  // path.rs:103
-            if (h.material == 0xffffffffu) {  // null BSDF: pass straight through (path.rs:109-116)
+            if ((F & SF_NULL) && h.material == 0xffffffffu) {  // null BSDF: pass straight through (path.rs:109-116)
                 f3 o = offset_ray_origin(h.p, h.p_err, h.n, ray_d);
                 store_ray(pb.ray_cont + p, o, ray_d, RSPT_INF, p);
                 st |= ST_ALIVE | ST_NO_DIFF;
@@ -415,7 +416,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 bsdf.eta = mat.eta;
                 bsdf.lt = LobeTex{nullptr, 0};
                 bsdf.dropped = 0u;
-                if (sc.mat_flags && sc.mat_flags[h.material]) {  // textured material: k_texture ran for this hit
+                if ((F & SF_TEX) && sc.mat_flags && sc.mat_flags[h.material]) {  // textured material: k_texture ran for this hit
                     const float4* tb = pb.tex + p;
                     bsdf.lt = LobeTex{tb, pb.tex_stride};
                     const float4 m4 = tb[4 * (size_t)pb.tex_stride];
@@ -433,7 +434,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 bsdf.ts = cross(h.sh_n, bsdf.ss);
                 bsdf.lobes = sc.bxdfs + mat.first_bxdf;
                 bsdf.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
-                ShadeSampler<PIX> smp;
+                typename ShadeSamplerFor<PIX, F>::type smp;
                 smp.bind(px);
                 smp.start(rd, sob_tab, sob_nd, pb.sobol_index[p], st & ST_DIM_MASK);
                 if (stats) atomicAdd(&stats[0], 1ull);
@@ -454,31 +455,31 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                         f3 wi{0.0f, 0.0f, 0.0f};
                         float light_pdf = 0.0f, scattering_pdf = 0.0f;
                         LightSample ls;
-                        rgb li = light_sample_li(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
+                        rgb li = light_sample_li<F>(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
                         if (light_pdf > 0.0f && !is_black(li)) {
-                            rgb f = bsdf.f(wo, wi, nonspec) * mkrgb(absdot(wi, h.sh_n));
-                            scattering_pdf = bsdf.pdf(wo, wi, nonspec);
+                            rgb f = bsdf.template f<F>(wo, wi, nonspec) * mkrgb(absdot(wi, h.sh_n));
+                            scattering_pdf = bsdf.template pdf<F>(wo, wi, nonspec);
                             if (!is_black(f)) {
                                 // VisibilityTester::unoccluded -> spawn_ray_to (interaction.rs:81-94)
                                 f3 origin = offset_ray_origin(h.p, h.p_err, h.n, ls.p - h.p);
                                 f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
                                 store_ray(pb.ray_sh + p, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, p);
                                 out.shadow = true;
-                                if (light_is_delta(lt)) c1 = f * li / light_pdf;  // integrator.rs:470-471
+                                if (light_is_delta<F>(lt)) c1 = f * li / light_pdf;  // integrator.rs:470-471
                                 else c1 = f * li * mkrgb(power_heuristic(light_pdf, scattering_pdf)) / light_pdf;
                                 st |= ST_HAS_C1;
                             }
                         }
                         // BSDF sample with MIS (integrator.rs:480-568), area lights only; sampled_type sentinel 0 (Q6)
-                        if (!light_is_delta(lt)) {
+                        if (!light_is_delta<F>(lt)) {
                             uint32_t sampled_type = 0;
-                            rgb f = bsdf.sample_f(wo, &wi, u_scatter, &scattering_pdf, nonspec, &sampled_type);
+                            rgb f = bsdf.template sample_f<F>(wo, &wi, u_scatter, &scattering_pdf, nonspec, &sampled_type);
                             f = f * mkrgb(absdot(wi, h.sh_n));
                             if (!is_black(f) && scattering_pdf > 0.0f) {
                                 f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
                                 float lpdf = 0.0f;
                                 rgb le_mis = ldrgb(lt.L);
-                                if (lt.kind == RSPT_LIGHT_INFINITE) {  // InfiniteAreaLight::pdf_li; Le is known from the direction alone
+                                if ((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) {  // InfiniteAreaLight::pdf_li; Le is known from the direction alone
                                     lpdf = infinite_pdf_li(sc, lt, wi);
                                     if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
                                 } else {  // DiffuseAreaLight::pdf_li -> Triangle::pdf_with_ref_point (triangle.rs:745-764)
@@ -486,7 +487,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                                     float t_l, lb0, lb1, lb2;
                                     if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
                                         Hit lh;
-                                        tri_fill(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
+                                        tri_fill<(F & SF_VERTEX) != 0>(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
                                         lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
                                         if (__builtin_isinf(lpdf)) lpdf = 0.0f;
                                     }
@@ -494,10 +495,10 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                                 if (lpdf != 0.0f) {
                                     float weight = power_heuristic(scattering_pdf, lpdf);
                                     c2 = f * le_mis * mkrgb(1.0f) * weight / scattering_pdf;
-                                    if (lt.kind != RSPT_LIGHT_INFINITE || !is_black(le_mis)) {
+                                    if (!((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) || !is_black(le_mis)) {
                                         store_ray(pb.ray_mis + p, ro, wi, RSPT_INF, p);
                                         out.mis = true;
-                                        st |= ST_HAS_C2 | (lt.kind == RSPT_LIGHT_INFINITE ? ST_C2_ON_MISS : 0u);
+                                        st |= ST_HAS_C2 | (((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) ? ST_C2_ON_MISS : 0u);
                                     }
                                 }
                             }
@@ -514,7 +515,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 float pdf = 0.0f;
                 uint32_t sampled_type = 255;
                 const f3 wo_ray = -ray_d;  // path.rs:141 takes -ray.d here; estimate_direct above takes isect.wo (they differ inside instances only)
-                rgb f = bsdf.sample_f(wo_ray, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
+                rgb f = bsdf.template sample_f<F>(wo_ray, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
                 bool go_on = !(is_black(f) || pdf == 0.0f);
                 if (go_on) {
                     beta = beta * ((f * absdot(wi, h.sh_n)) / pdf);
@@ -747,14 +748,16 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
-                                               const QueueCounts* __restrict__ cnt_in, QueueCounts* cnt_out, uint32_t* __restrict__ q_active_next,
-                                               uint32_t* __restrict__ q_closest_next, uint32_t* __restrict__ q_any_next, unsigned long long* stats,
-                                               uint32_t sob_nd, uint32_t sob_bits, uint32_t qcap, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi) {
-    // Sobol' generator matrices of the dimensions this render can reach, transposed to [bit][dim]
-    extern __shared__ uint32_t sob_tab[];
-    __shared__ uint32_t s_wave[4][5], s_base[4];
-    for (uint32_t t = threadIdx.x; rd.sampler_kind == RSPT_SAMPLER_SOBOL && t < sob_nd * sob_bits; t += 256u) {
+// The shade kernel's body; F = the feature set (dev_bsdf.h SF_*) the instantiation is compiled for.  k_shade<F> leaves the register budget
+// to the compiler, k_shade_w<F, W> asks for W waves per SIMD (the allocator spills what does not fit 512 / W registers).
+template <uint32_t F>
+__device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDistDev& ld, const RenderDev& rd, const PathBuf& pb, const uint32_t* __restrict__ q_active,
+                                             const QueueCounts* __restrict__ cnt_in, QueueCounts* cnt_out, uint32_t* __restrict__ q_active_next,
+                                             uint32_t* __restrict__ q_closest_next, uint32_t* __restrict__ q_any_next, unsigned long long* stats,
+                                             uint32_t sob_nd, uint32_t sob_bits, uint32_t qcap, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi,
+                                             uint32_t* sob_tab, uint32_t (*s_wave)[5], uint32_t* s_base) {
+    // sob_tab: Sobol' generator matrices of the dimensions this render can reach, transposed to [bit][dim]
+    for (uint32_t t = threadIdx.x; (!(F & SF_HALTON) || rd.sampler_kind == RSPT_SAMPLER_SOBOL) && t < sob_nd * sob_bits; t += 256u) {
         uint32_t dd = t % sob_nd;  // read-ahead columns past the last of the 1024 dimensions are never consumed
         sob_tab[t] = rd.sobol32[(dd < 1024u ? dd : 1023u) * 52u + (t / sob_nd)];
     }
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, Ren
         uint32_t p = 0;
         if (i < n) {
             p = i < n_front ? (q_sorted ? q_sorted[i] : q_active[i]) : q_active[qcap - 1u - (i - n_front)];
-            if (p != RSPT_BIN_INVALID) o = shade_path<false>(sc, ld, rd, pb, p, stats, sob_tab, sob_nd, nullptr);
+            if (p != RSPT_BIN_INVALID) o = shade_path<false, F>(sc, ld, rd, pb, p, stats, sob_tab, sob_nd, nullptr);
         }
         // queue appends, aggregated per workgroup: a single counter word sustains only ~90 M atomics/s
         // (MI355X_MICROARCH "dequeue" row), so one atomic per queue per 256 paths instead of per wave.
@@ -808,6 +811,23 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, LightDistDev ld, Ren
         if (o.shadow) q_any_next[off_sh + (uint32_t)__popcll(m_sh & lt)] = p;
         __syncthreads();  // s_wave / s_base are reused by the next stripe
     }
+}
+
+#define RSPT_SHADE_ARGS SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt_in, QueueCounts* cnt_out, \
+                        uint32_t* __restrict__ q_active_next, uint32_t* __restrict__ q_closest_next, uint32_t* __restrict__ q_any_next, unsigned long long* stats, uint32_t sob_nd, \
+                        uint32_t sob_bits, uint32_t qcap, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi
+#define RSPT_SHADE_CALL shade_kernel<F>(sc, ld, rd, pb, q_active, cnt_in, cnt_out, q_active_next, q_closest_next, q_any_next, stats, sob_nd, sob_bits, qcap, q_sorted, bi, sob_tab, s_wave, s_base)
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_shade(RSPT_SHADE_ARGS) {
+    extern __shared__ uint32_t sob_tab[];
+    __shared__ uint32_t s_wave[4][5], s_base[4];
+    RSPT_SHADE_CALL;
+}
+template <uint32_t F, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void k_shade_w(RSPT_SHADE_ARGS) {
+    extern __shared__ uint32_t sob_tab[];
+    __shared__ uint32_t s_wave[4][5], s_base[4];
+    RSPT_SHADE_CALL;
 }
 
 // ---- AOIntegrator::li (src/integrators/ao.rs:50-96) --------------------------

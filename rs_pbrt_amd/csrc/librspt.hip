@@ -178,6 +178,7 @@ struct rspt_scene_s {
         const uint8_t* mat_flags = nullptr;
         bool textured = false;
     } mat_set[2];
+    uint32_t shade_features = 0;      // SF_* (dev_bsdf.h) of everything the scene can put in front of the shade stage
     void select_materials(bool allow_multiple_lobes) {
         const MatSet& m = mat_set[allow_multiple_lobes ? 0 : 1];
         dev.materials = m.materials; dev.bxdfs = m.bxdfs;
@@ -512,6 +513,34 @@ bool trace_can_overflow(const rspt_scene_s* s) {
 }
 uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PER_CU", 5)); }
 
+// ---- the shade stage's instantiations (kernels.h k_shade<F>) ----
+// A scene is served by the narrowest compiled feature set that covers what it can put in front of the stage (rspt_scene_s.shade_features
+// + the sampler): the code for every other lobe type, light kind, texture slot, instance transform and the Halton sampler folds away,
+// and with it registers (generic: 212 VGPRs = 2 waves / SIMD).  The arithmetic that remains is the same, so results do not change.
+constexpr uint32_t SV_DIFFUSE = RSPT_SF_LOBE(RSPT_BXDF_LAMBERT_R) | SF_L_AREA;                      // matte scenes under area lights: C1, C2
+constexpr uint32_t SV_PLASTIC = SV_DIFFUSE | RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R) | SF_VERTEX;      // + plastic, smooth-shaded meshes: the C3 stand-in
+constexpr uint32_t SV_TEXTURED = SV_PLASTIC | RSPT_SF_LOBE(RSPT_BXDF_OREN_NAYAR) | SF_TEX;          // + textured materials: the C4 stand-in
+typedef void (*ShadeKernel)(RSPT_SHADE_ARGS);
+struct ShadeVariant { uint32_t features; const char* name; ShadeKernel natural, w3, w4; };
+const ShadeVariant g_shade_variants[] = {
+    {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>},
+    {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>},
+    {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>},
+    {SF_ALL, "generic", k_shade<SF_ALL>, k_shade_w<SF_ALL, 3>, k_shade_w<SF_ALL, 4>},
+};
+// RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 3 | 4 the forced-occupancy builds (A/B)
+ShadeKernel shade_kernel_for(uint32_t need, const char** name_out) {
+    const char* force = getenv("RSPT_SHADE_VARIANT");
+    const size_t waves = env_size("RSPT_SHADE_WAVES", 0);
+    for (const ShadeVariant& v : g_shade_variants) {
+        if ((need & ~v.features) != 0) continue;
+        if (force && *force && strcmp(force, v.name) != 0 && v.features != SF_ALL) continue;
+        if (name_out) *name_out = v.name;
+        return waves == 3 ? v.w3 : (waves == 4 ? v.w4 : v.natural);
+    }
+    return k_shade<SF_ALL>;
+}
+
 int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (!s || !d) return fail(RSPT_E_INVALID, "null scene or render desc");
@@ -750,7 +779,17 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     sob_bits = std::min(52u, sob_bits + 1u);
     if ((size_t)sob_nd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
     const uint32_t tgrid = trace_grid();
-    const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", 2));
+    const char* shade_name = "generic";
+    const ShadeKernel shade_k = shade_kernel_for(s->shade_features | (halton ? (uint32_t)SF_HALTON : 0u), &shade_name);
+    if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shade stage instantiation '%s' (scene features %#x)\n", shade_name, s->shade_features);
+    // one launch fills the chip once: as many 256-thread blocks per CU as the instantiation's registers and the LDS table allow
+    int shade_blocks = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_blocks, reinterpret_cast<const void*>(shade_k), 256, sob_nd * sob_bits * sizeof(uint32_t)) != hipSuccess || shade_blocks < 1) {
+        (void)hipGetLastError();
+        shade_blocks = 2;
+    }
+    const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", (size_t)shade_blocks));
+    if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shade stage: %d blocks of 256 per CU\n", shade_blocks);
     size_t n_ev = 0;
     const bool two_streams = env_size("RSPT_TRACE_STREAMS", 2) >= 2 && !counters;
     hipEvent_t ev_fork = get_event(n_ev++), ev_join = get_event(n_ev++);
@@ -977,7 +1016,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
             }
             if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active);
-            hipLaunchKernelGGL(k_shade, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
+            hipLaunchKernelGGL(shade_k, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
                                shade_bins ? g.q_sorted : (const uint32_t*)nullptr, shade_bins ? &g.bin_info[it] : (const BinInfo*)nullptr);
             ev_close(2, 0);
@@ -1462,6 +1501,24 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             asm_bx[v].insert(asm_bx[v].end(), lb.lobes.begin(), lb.lobes.end());
         }
     }
+    uint32_t shade_features = 0;
+    for (int v = 0; v < 2; v++)
+        for (const rspt_bxdf& b : asm_bx[v]) {
+            shade_features |= RSPT_SF_LOBE(b.type);
+            if (b.fresnel == RSPT_FRESNEL_CONDUCTOR) shade_features |= SF_CONDUCTOR;
+            if (b.has_sc) shade_features |= SF_SC;
+            if (b.tex_r || b.tex_t || b.tex_ax || b.tex_ay) shade_features |= SF_TEX;
+        }
+    for (int v = 0; v < 2; v++)
+        for (const rspt_material& m : asm_mats[v]) if (m.bump_tex) shade_features |= SF_TEX;
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        const uint32_t k = d->lights[i].kind;
+        shade_features |= k == RSPT_LIGHT_DIFFUSE_AREA ? SF_L_AREA : (k == RSPT_LIGHT_POINT ? SF_L_POINT : (k == RSPT_LIGHT_SPOT ? SF_L_SPOT : (k == RSPT_LIGHT_DISTANT ? SF_L_DISTANT : SF_L_INFINITE)));
+    }
+    for (uint32_t i = 0; i < d->n_meshes; i++)
+        if (d->meshes[i].has_n || d->meshes[i].has_s || d->meshes[i].has_uv) shade_features |= SF_VERTEX;
+    if (instanced) shade_features |= SF_INST;
+    if (has_null || (instanced && d->instancing_mode == RSPT_INSTANCING_REFERENCE)) shade_features |= SF_NULL;
     if (d->n_envmaps && !d->envmaps) return fail(RSPT_E_INVALID, "null envmaps");
     for (uint32_t i = 0; i < d->n_envmaps; i++) {
         const rspt_envmap& e = d->envmaps[i];
@@ -1518,6 +1575,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     s->has_instances = instanced;
     s->has_alpha = any_alpha;
     s->n_materials = d->n_materials;
+    s->shade_features = shade_features;
     auto bail = [&](int rc) {
         for (void* p : s->allocs) (void)hipFree(p);
         delete s;

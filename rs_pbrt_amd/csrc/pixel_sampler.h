@@ -136,15 +136,17 @@ struct PixSampler {
 // or the tile's pixel sampler
 template <bool PIX>
 struct ShadeSampler;
-template <>
-struct ShadeSampler<false> {
-    PathSampler g;
+template <bool HALTON_POSSIBLE>
+struct ShadeSamplerG {
+    PathSamplerT<HALTON_POSSIBLE> g;
     RDEV void bind(PixSampler*) {}
     RDEV void start(const RenderDev& rd, const uint32_t* __restrict__ tab, uint32_t nd, uint64_t idx, uint32_t first_dim) { g.start(rd, tab, nd, idx, first_dim); }
     RDEV uint32_t dim() const { return g.dim(); }
     RDEV float get_1d(const RenderDev& rd) { return g.get_1d(rd); }
     RDEV f2 get_2d(const RenderDev& rd) { return g.get_2d(rd); }
 };
+template <>
+struct ShadeSampler<false> : ShadeSamplerG<true> {};
 template <>
 struct ShadeSampler<true> {
     PixSampler* px;
@@ -154,5 +156,10 @@ struct ShadeSampler<true> {
     RDEV float get_1d(const RenderDev&) { return px->get_1d(); }
     RDEV f2 get_2d(const RenderDev&) { return px->get_2d(); }
 };
+// the sample source of shade_path<PIX, F>: a pixel sampler's stream, or the global samplers with the Halton code only where F has it
+template <bool PIX, uint32_t F>
+struct ShadeSamplerFor { using type = ShadeSampler<true>; };
+template <uint32_t F>
+struct ShadeSamplerFor<false, F> { using type = ShadeSamplerG<(F & SF_HALTON) != 0>; };
 
 }  // namespace rspt
