@@ -521,21 +521,25 @@ constexpr uint32_t SV_DIFFUSE = RSPT_SF_LOBE(RSPT_BXDF_LAMBERT_R) | SF_L_AREA;  
 constexpr uint32_t SV_PLASTIC = SV_DIFFUSE | RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R) | SF_VERTEX;      // + plastic, smooth-shaded meshes: the C3 stand-in
 constexpr uint32_t SV_TEXTURED = SV_PLASTIC | RSPT_SF_LOBE(RSPT_BXDF_OREN_NAYAR) | SF_TEX;          // + textured materials: the C4 stand-in
 typedef void (*ShadeKernel)(RSPT_SHADE_ARGS);
-struct ShadeVariant { uint32_t features; const char* name; ShadeKernel natural, w3, w4; };
+// natural = the compiler's own register budget; w3 / w4 = built for 3 / 4 waves per SIMD (amdgpu_waves_per_eu: what does not fit 168 / 128
+// VGPRs is spilled); dflt = which of the three runs.  Measured on one box (profiles/r03_ab_shade.md; Msamples/s of C2 / the C3 stand-in,
+// k_shade seconds per step): generic 212 VGPRs 423 / 1685 (0.161 / 0.578 s); diffuse 158 VGPRs = 3 waves as compiled 459 (0.111 s), forced to
+// 4 waves 455; plastic 173 VGPRs as compiled 1749 (0.531 s), 168 + 24 B of spills = 3 waves 1841 (0.470 s), 128 + 152 B = 4 waves 1791.
+struct ShadeVariant { uint32_t features; const char* name; ShadeKernel natural, w3, w4; int dflt; };
 const ShadeVariant g_shade_variants[] = {
-    {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>},
-    {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>},
-    {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>},
-    {SF_ALL, "generic", k_shade<SF_ALL>, k_shade_w<SF_ALL, 3>, k_shade_w<SF_ALL, 4>},
+    {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 0},
+    {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
+    {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 3},
+    {SF_ALL, "generic", k_shade<SF_ALL>, k_shade_w<SF_ALL, 3>, k_shade_w<SF_ALL, 4>, 0},
 };
-// RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 3 | 4 the forced-occupancy builds (A/B)
+// RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 0 | 3 | 4 one of its builds (A/B)
 ShadeKernel shade_kernel_for(uint32_t need, const char** name_out) {
     const char* force = getenv("RSPT_SHADE_VARIANT");
-    const size_t waves = env_size("RSPT_SHADE_WAVES", 0);
     for (const ShadeVariant& v : g_shade_variants) {
         if ((need & ~v.features) != 0) continue;
         if (force && *force && strcmp(force, v.name) != 0 && v.features != SF_ALL) continue;
         if (name_out) *name_out = v.name;
+        const size_t waves = env_size("RSPT_SHADE_WAVES", (size_t)v.dflt);
         return waves == 3 ? v.w3 : (waves == 4 ? v.w4 : v.natural);
     }
     return k_shade<SF_ALL>;

@@ -1,10 +1,10 @@
-//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 17) one to one.
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 18) one to one.
 //! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
 //! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RSPT_ABI_VERSION: c_int = 17;
+pub const RSPT_ABI_VERSION: c_int = 18;
 pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
 pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
 
@@ -17,14 +17,14 @@ pub struct RsptMesh { pub has_n: u32, pub has_s: u32, pub has_uv: u32, pub flip:
                       pub medium_inside: u32, pub medium_outside: u32 }   // 0 = none, else 1 + index into media
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptMedium { pub kind: u32, pub sigma_a: [f32; 3], pub sigma_s: [f32; 3], pub g: f32 }   // kind 1 = HomogeneousMedium
+/// rspt_material_desc: kind (1 matte 2 plastic 3 mirror 4 glass 5 metal 6 substrate 7 uber 8 translucent 9 mix) and, per parameter,
+/// 0 (absent) or 1 + index of its texture record — a ConstantTexture for a literal value, as TextureParams builds one
 #[repr(C)] #[derive(Clone, Copy, Default)]
-pub struct RsptBxdf { // 116 B
-    pub kind: u32, pub fresnel: u32, pub r: [f32; 3], pub t: [f32; 3], pub eta_a: f32, pub eta_b: f32, pub alpha_x: f32, pub alpha_y: f32,
-    pub c1: [f32; 3], pub c2: [f32; 3], pub on_a: f32, pub on_b: f32, pub sc: [f32; 3], pub has_sc: u32,
-    pub tex_r: u32, pub tex_t: u32, pub tex_ax: u32, pub tex_ay: u32, pub remap: u32,
+pub struct RsptMaterialDesc { // 80 B
+    pub kind: u32, pub kd: u32, pub ks: u32, pub kr: u32, pub kt: u32, pub reflect: u32, pub transmit: u32, pub opacity: u32, pub eta: u32, pub k: u32,
+    pub amount: u32, pub sigma: u32, pub roughness: u32, pub uroughness: u32, pub vroughness: u32, pub index: u32, pub bumpmap: u32,
+    pub remap_roughness: u32, pub m1: u32, pub m2: u32,
 }
-#[repr(C)] #[derive(Clone, Copy, Default)]
-pub struct RsptMaterial { pub eta: f32, pub first_bxdf: u32, pub n_bxdfs: u32, pub bump_tex: u32 }
 #[repr(C)] pub struct RsptImage { pub width: u32, pub height: u32, pub n_levels: u32, pub channels: u32, pub texels: *const f32 }
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptTexture { // 160 B
@@ -43,7 +43,7 @@ pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_wor
 #[repr(C)] pub struct RsptSceneDesc {
     pub nodes: *const RsptBvhNode, pub n_nodes: u64, pub prims: *const RsptPrim, pub n_prims: u64,
     pub meshes: *const RsptMesh, pub n_meshes: u32, pub p: *const f32, pub n: *const f32, pub s: *const f32, pub uv: *const f32,
-    pub n_vertices: u64, pub materials: *const RsptMaterial, pub n_materials: u32, pub bxdfs: *const RsptBxdf, pub n_bxdfs: u32,
+    pub n_vertices: u64, pub materials: *const RsptMaterialDesc, pub n_materials: u32,
     pub lights: *const RsptLight, pub n_lights: u32, pub envmaps: *const RsptEnvMap, pub n_envmaps: u32,
     pub textures: *const RsptTexture, pub n_textures: u32, pub images: *const RsptImage, pub n_images: u32,
     pub objects: *const RsptObject, pub n_objects: u32, pub instances: *const RsptInstance, pub n_instances: u32,
