@@ -121,7 +121,7 @@ class RenderDesc(C.Structure):
                 ("sample_at_pixel_center", C.c_uint32), ("integrator", C.c_uint32), ("ao_n_samples", C.c_uint32),
                 ("ao_cos_sample", C.c_uint32), ("film_reduce", C.c_uint32), ("tables", SamplerTables),
                 ("direct_strategy", C.c_uint32), ("pixel_dimensions", C.c_uint32), ("n_light_samples", C.c_void_p),
-                ("strat_x", C.c_uint32), ("strat_y", C.c_uint32), ("strat_jitter", C.c_uint32), ("pad3", C.c_uint32), ("maxmin_c_pixel", C.c_void_p),
+                ("strat_x", C.c_uint32), ("strat_y", C.c_uint32), ("strat_jitter", C.c_uint32), ("allow_slow_paths", C.c_uint32), ("maxmin_c_pixel", C.c_void_p),
                 ("sample_begin", C.c_uint64), ("sample_count", C.c_uint64)]
 
 

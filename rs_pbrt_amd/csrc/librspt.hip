@@ -93,6 +93,8 @@ struct Ctx {
     uint32_t* pix_list = nullptr;
     size_t pix_cap = 0;
     std::vector<hipEvent_t> events;
+    QueueCounts* look = nullptr;       // pinned host words the render loops read queue lengths into: a device-to-host copy into pageable memory
+                                       // goes through a staging buffer and costs milliseconds per look (volpath looks once per pass)
 };
 Ctx g;
 
@@ -529,7 +531,7 @@ struct ShadeVariant { uint32_t features; const char* name; ShadeKernel natural, 
 const ShadeVariant g_shade_variants[] = {
     {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 0},
     {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
-    {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 3},
+    {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0},
     {SF_ALL, "generic", k_shade<SF_ALL>, k_shade_w<SF_ALL, 3>, k_shade_w<SF_ALL, 4>, 0},
 };
 // RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 0 | 3 | 4 one of its builds (A/B)
@@ -842,7 +844,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             // (the first two segments are launched without looking at the queue: most shadow rays cross at most one boundary, an
             //  empty launch costs microseconds, a look costs a stream synchronisation; the look that follows also brings the
             //  next pass's path count)
-            QueueCounts look[4];
+            QueueCounts* look = g.look;   // (pinned: see Ctx::look)
             bool have_live = false;
             for (uint32_t seg = 0;; seg++) {
                 QueueCounts* tc = &g.cnt[2 + (seg & 1u)];
@@ -851,7 +853,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 c.closest = live;   // upper bound while not looking (every live path has at most one shadow ray)
                 const bool looked = seg >= 2 || counters;   // (the counting pass wants every queue length)
                 if (looked) {
-                    HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
+                    HIP_TRY(hipMemcpyAsync(look, g.cnt, 4 * sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
                     HIP_TRY(hipStreamSynchronize(g.stream));
                     c = look[2 + (seg & 1u)];
                     have_live = true;
@@ -867,7 +869,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 hipLaunchKernelGGL(k_vol_tr, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
             }
             if (!have_live) {
-                HIP_TRY(hipMemcpyAsync(look, g.cnt, sizeof look, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipMemcpyAsync(look, g.cnt, 4 * sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
                 HIP_TRY(hipStreamSynchronize(g.stream));
             }
             live = look[par ^ 1].closest;
@@ -915,9 +917,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                                    level_q(l + 1 < md ? l + 1 : l), &g.cnt[l + 1].closest, l);
                 ev_close(2, 0);
                 if (!s->has_null_material) break;
-                QueueCounts c;
-                HIP_TRY(hipMemcpyAsync(&c, rc_, sizeof c, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipMemcpyAsync(g.look, rc_, sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
                 HIP_TRY(hipStreamSynchronize(g.stream));
+                const QueueCounts c = g.look[0];
                 if (c.closest == 0) break;
                 if (round >= env_size("RSPT_NULL_PASSES", 1024)) { truncated += c.closest; break; }
                 queue = g.q[round & 1u][0];
@@ -1029,9 +1031,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             // after max_depth + 1 bounces only pending estimates and null-material passes remain
             if (max_iters == nominal_iters) break;
             if (((it - nominal_iters) & 7u) != 0 && it < max_iters) continue;  // look at the queue length every 8th iteration: an empty iteration costs three idle launches, a look costs a stream sync
-            QueueCounts c;
-            HIP_TRY(hipMemcpyAsync(&c, &g.cnt[it], sizeof c, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipMemcpyAsync(g.look, &g.cnt[it], sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipStreamSynchronize(g.stream));
+            const QueueCounts c = g.look[0];
             if (c.active == 0 && c.active_tail == 0) break;
             g_queue_hint = c.active + c.active_tail;
             if (it >= max_iters) {  // the reference's loop would still be running (path.rs:109-116 has no limit); these paths keep the radiance gathered so far
@@ -1123,6 +1125,13 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         truncated += tv;
         return RSPT_OK;
     };
+    if (pixel_sampler) {
+        size_t my_tiles = 0;
+        for (size_t i = 0; i < blocks.size(); i++) my_tiles += (i / chunk) % shard_count == d->shard_index;
+        const size_t min_tiles = env_size("RSPT_SERIAL_MIN_TILES", 8192);
+        if (!d->allow_slow_paths && my_tiles < min_tiles)
+            return fail(RSPT_E_UNSUPPORTED, "a pixel sampler over %zu tiles: one lane per tile is slower than the host's tile loop below ~%zu tiles (set allow_slow_paths to run it anyway)", my_tiles, min_tiles);
+    }
     if (pixel_sampler && (rc = run_tile_serial())) return rc;
     for (size_t p0 = 0; !pixel_sampler && p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
@@ -1324,6 +1333,7 @@ int rspt_init(int32_t device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void**)&g.look, 8 * sizeof(QueueCounts), hipHostMallocDefault));
     g.device = device;
     g.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g.inited = true;
@@ -1340,6 +1350,7 @@ void rspt_shutdown(void) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
+    if (g.look) (void)hipHostFree(g.look);
     (void)hipStreamDestroy(g.stream);
     (void)hipStreamDestroy(g.stream2);
     g = Ctx{};

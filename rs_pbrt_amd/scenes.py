@@ -881,8 +881,11 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
                      crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
                      focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
                      sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True, direct_strategy="all", light_samples=None,
-                     dimensions=4, strat=(4, 4), jitter=True, sample_range=None):
+                     dimensions=4, strat=(4, 4), jitter=True, sample_range=None, allow_slow_paths=True):
+    """allow_slow_paths: True here (tests and bench want the device path whatever its speed); the Rust shim passes 0, so that a pixel-sampler
+    frame of few tiles — which the device renders slower than the host's tile loop — comes back as RSPT_E_UNSUPPORTED (include/rspt.h)"""
     rd = abi.RenderDesc()
+    rd.allow_slow_paths = int(bool(allow_slow_paths))
     # Integrator "path" (path.rs), "ao" / "ambientocclusion" (api.rs:411; ao.rs: nsamples 64, cossample true) or
     # "directlighting" (api.rs:322-349: strategy "all" | "one", maxdepth 5; light_samples = Light::get_n_samples per light)
     rd.integrator = {"ao": abi.INTEGRATOR_AO, "directlighting": abi.INTEGRATOR_DIRECT, "volpath": abi.INTEGRATOR_VOLPATH}.get(integrator, abi.INTEGRATOR_PATH)

@@ -59,7 +59,7 @@ pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_wor
     pub sample_at_pixel_center: u32, pub integrator: u32, pub ao_n_samples: u32, pub ao_cos_sample: u32, pub film_reduce: u32,
     pub tables: RsptSamplerTables,
     pub direct_strategy: u32, pub pixel_dimensions: u32, pub n_light_samples: *const i32,
-    pub strat_x: u32, pub strat_y: u32, pub strat_jitter: u32, pub pad3: u32, pub maxmin_c_pixel: *const u32,   // pixel samplers
+    pub strat_x: u32, pub strat_y: u32, pub strat_jitter: u32, pub allow_slow_paths: u32, pub maxmin_c_pixel: *const u32,   // pixel samplers
     pub sample_begin: u64, pub sample_count: u64,   // checkpoint / resume: 0, 0 = the whole frame
 }
 #[repr(C)] #[derive(Default)]

@@ -365,7 +365,7 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
         tables: RsptSamplerTables { sobol32: SOBOL_MATRICES_32.as_ptr(), vdc: vdc.as_ptr(), vdc_inv: vdc_inv.as_ptr(),
                                     halton_perms: RADICAL_INVERSE_PERMUTATIONS.as_ptr(), n_halton_perms: RADICAL_INVERSE_PERMUTATIONS.len() as u64 },
         direct_strategy, pixel_dimensions: pix_dims, n_light_samples: if n_light_samples.is_empty() { std::ptr::null() } else { n_light_samples.as_ptr() },
-        strat_x: sx, strat_y: sy, strat_jitter: jit, pad3: 0, maxmin_c_pixel: if sampler_kind == 6 { c_pixel.as_ptr() } else { std::ptr::null() },
+        strat_x: sx, strat_y: sy, strat_jitter: jit, allow_slow_paths: 0 /* a scene the device would render slower than the tile loop comes back as Err: keep the CPU loop */, maxmin_c_pixel: if sampler_kind == 6 { c_pixel.as_ptr() } else { std::ptr::null() },
         sample_begin: 0, sample_count: 0,
     };
     let sd = RsptSceneDesc {

@@ -109,3 +109,21 @@ def test_refusals(gpu):
         with pytest.raises(RsptError) as e:
             gpu.render(ds, rd)
         assert e.value.code == abi.E_INVALID
+
+
+def test_few_tiles_are_handed_back_to_the_cpu_loop_unless_asked(gpu):
+    """with few tiles the one-lane-per-tile kernel is slower than the host's tile loop (Cornell 625 tiles: 3.2 vs 7.1
+    Msamples/s), so the library answers RSPT_E_UNSUPPORTED unless the caller sets allow_slow_paths (what every other test here does)"""
+    from rs_pbrt_amd.lib import RsptError
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=64, spp=4, sampler="02sequence", allow_slow_paths=False)
+    with gpu.DeviceScene(sc) as ds:
+        with pytest.raises(RsptError) as e:
+            gpu.render(ds, rd)
+        assert e.value.code == abi.E_UNSUPPORTED and "tile" in str(e.value)
+        rd.allow_slow_paths = 1
+        film, st = gpu.render(ds, rd)
+        assert st["samples"] == 64 * 64 * 4
+        rd.allow_slow_paths = 0
+        rd2 = scenes.cornell_render_desc(res=64, spp=4, allow_slow_paths=False)   # the Sobol' wavefront path is not affected
+        assert gpu.render(ds, rd2)[1]["samples"] == 64 * 64 * 4
