@@ -98,9 +98,11 @@ typedef struct {
  * (src/core/material.rs:63-113, src/materials/{matte,plastic,mirror,glass,metal,substrate,uber,translucent,mixmat}.rs) is
  * restated by the library (rs_pbrt_amd/csrc/material_assembly.h): parameters bound to constant textures are folded into the
  * lobe list once per material (clamp, `is_black` guards, roughness remapping, OrenNayar A / B), parameters bound to other
- * textures are evaluated per hit by the texture stage.  Which parameters may be non-constant: Kd, Ks, roughness / uroughness /
- * vroughness of matte, plastic, substrate, uber and metal, and bumpmap; anything else is answered with RSPT_E_UNSUPPORTED by
- * rspt_scene_create and the caller keeps its CPU loop. */
+ * textures are evaluated per hit by the texture stage: Kd, Ks and the roughnesses leave the lobe list's shape alone and only
+ * scale lobes (the fast path); a non-constant texture on any other parameter (sigma, index, opacity, Kr, Kt, reflect, transmit, eta, k,
+ * a glass roughness, a mix amount) makes the material "dynamic" — its lobe list is built per hit on the device.  Refused with
+ * RSPT_E_UNSUPPORTED: a mix of a mix, more than 12 varying textures on a dynamic material, dynamic materials under volpath /
+ * directlighting / the pixel samplers. */
 enum {
     RSPT_MAT_MATTE = 1,       /* matte.rs:43-86:       kd, sigma, bumpmap                                               */
     RSPT_MAT_PLASTIC = 2,     /* plastic.rs:57-125:    kd, ks, roughness, remap_roughness, bumpmap                      */
@@ -507,8 +509,11 @@ int rspt_light_distribution(rspt_scene_t scene, uint32_t light_strategy, const f
  * (src/core/material.rs:63-113) for material `material` of a scene description, with the integrator's allow_multiple_lobes
  * (true for path / volpath / ao, false for directlighting): out_material / out_bxdfs (room for 8) receive the
  * lobe list the library assembles for that material — what Bsdf.bxdfs holds after the call wherever the material's textures are
- * constant; tex_* fields carry 1 + the index of the texture that completes a lobe per hit.  Returns the number of lobes, or an
- * RSPT_E_* code (RSPT_E_UNSUPPORTED names the parameter that may not be textured). */
+ * constant; tex_* fields carry 1 + the index of the texture that completes a lobe per hit.  Returns the number of lobes;
+ * RSPT_MATERIAL_DYNAMIC when a parameter that decides the SHAPE of the list (sigma, index, opacity, Kr, Kt, reflect, transmit, the
+ * conductor's eta / k, a glass roughness, a mix amount) is bound to a non-constant texture — the list is then built per hit on the
+ * device, from the texture values there, by the same assembly function; or an RSPT_E_* code. */
+#define RSPT_MATERIAL_DYNAMIC 1000
 int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t allow_multiple_lobes, rspt_material* out_material,
                         rspt_bxdf out_bxdfs[8]);
 

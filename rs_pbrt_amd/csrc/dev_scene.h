@@ -2,6 +2,7 @@
 // the shade stage.  Layouts are private to librspt (include/rspt.h only fixes the host ABI).
 #pragma once
 #include "dev_bsdf.h"
+#include "material_assembly.h"
 
 namespace rspt {
 
@@ -49,6 +50,7 @@ struct SceneDev {
     uint32_t inst_fixed;         // RSPT_INSTANCING_FIXED: instanced hits keep their primitive (material)
     const rspt_medium* media;    // RenderOptions.named_media (VolPathIntegrator only; meshes[] carry the medium interfaces)
     uint32_t n_media;
+    const rspt_mat::DynMaterial* dyn;  // per material, valid where mat_flags has RSPT_MAT_DYNAMIC (material_assembly.h); nullptr = none
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)

@@ -23,7 +23,8 @@ struct TexTables {
                                    // fetches are global loads (a pointer read from the image table would make them flat loads)
     const float* ewa_lut;          // host-built with expf as MipMap::new does (mipmap.rs:186-192)
     const uint32_t* mat_slots;     // [material][RSPT_TEX_SLOTS]: texture index or 0xffffffff
-    const uint8_t* mat_flags;      // bit 0: some lobe colour is textured; bit 1: bump map
+    const uint8_t* mat_flags;      // bit 0: some lobe colour is textured; bit 1: bump map; bit 2: dynamic
+    const rspt_mat::DynMaterial* dyn;  // [material], where bit 2 is set
 };
 #define RSPT_SLOT_ALPHA 0x80000000u     // slot descriptor flags: the texture drives a lobe alpha ...
 #define RSPT_SLOT_REMAP 0x40000000u     // ... through roughness_to_alpha
@@ -31,6 +32,7 @@ struct TexTables {
 #define RSPT_SLOT_TEX_MASK 0x1fffffffu
 #define RSPT_MAT_TEXTURED 1u
 #define RSPT_MAT_BUMP 2u
+#define RSPT_MAT_DYNAMIC 4u             // the lobe list is built per hit from the raw parameter values in rows RSPT_TEX_ROWS .. (material_assembly.h)
 // per-path results of k_texture, SoA [row][path]: rows 0..3 = clamp(texture value) of the material's
 // slots; row 4 = (bumped shading.n, flags: bit 0 = bump applied, bits 8..15 = lobes dropped as black);
 // row 5 = bumped shading.dpdu

@@ -46,6 +46,8 @@ struct PathBuf {
     float4* tex;          // k_texture results, RSPT_TEX_ROWS rows of tex_stride paths (nullptr: scene without textures)
     uint32_t tex_stride;
     uint32_t* hit_inst;   // continuation ray's hit: 0 or 1 + instance (nullptr: scene without object instances)
+    rspt_mat::Built* dyn_built;  // one per thread of the shade launch: where a dynamic material's lobes are built (nullptr: no dynamic material)
+    uint32_t dyn_threads;
 };
 
 struct QueueCounts {  // one per wavefront iteration
@@ -324,6 +326,31 @@ RDEV void store_ray(rspt_ray* dst, f3 o, f3 d, float t_max, uint32_t id) {
     p[1] = make_float4(d.y, d.z, t_max, __uint_as_float(id));
 }
 
+// A dynamic material's Bsdf.bxdfs at this hit: the raw values the texture stage left in the path's rows go through the parameter clamps
+// and build_part — the function the host folds constant materials with (material_assembly.h).  Returns the thread's Built record.
+RDEVN const rspt_mat::Built* dynamic_lobes(const rspt_mat::DynMaterial& dm, const float4* rows, size_t stride, bool allow_multiple_lobes, rspt_mat::Built* out) {
+    using namespace rspt_mat;
+    out->n = 0u; out->overflow = 0u; out->shape_varies = 0u; out->eta = 1.0f;
+    auto fetch = [&](const DynParam& q, uint32_t id) {
+        Param r;
+        r.present = q.present; r.tex = 0u; r.v[0] = q.v[0]; r.v[1] = q.v[1]; r.v[2] = q.v[2];
+        if (q.row) { const float4 v = rows[(size_t)(RSPT_TEX_ROWS + q.row - 1u) * stride]; r = param_value(id, v.x, v.y, v.z); }
+        return r;
+    };
+    float s1[3] = {0.0f, 0.0f, 0.0f}, s2[3] = {0.0f, 0.0f, 0.0f};
+    if (dm.n_parts == 2u) {
+        const Param am = fetch(dm.amount, P_KD);  // a colour: clamp(0, inf) (mixmat.rs:52-56)
+        for (int c = 0; c < 3; c++) { s1[c] = am.v[c]; s2[c] = clamp0(1.0f - s1[c]); }
+    }
+    for (uint32_t k = 0; k < dm.n_parts; k++) {
+        Param p[P_COUNT];
+#pragma unroll 1
+        for (uint32_t i = 0; i < P_COUNT; i++) p[i] = fetch(dm.part[k].p[i], i);
+        build_part(dm.part[k].kind, p, dm.part[k].remap != 0u, allow_multiple_lobes, dm.n_parts == 2u ? (k ? s2 : s1) : nullptr, k == 1u, out);
+    }
+    return out;
+}
+
 // One step of PathIntegrator::li (path.rs:91-280) for path slot p: fold in the previous
 // bounce's next-event estimate, then process the hit of the continuation ray.
 // F: the feature set the instantiation is compiled for (dev_bsdf.h SF_*): everything a scene outside F could bring folds away
@@ -416,8 +443,15 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 bsdf.eta = mat.eta;
                 bsdf.lt = LobeTex{nullptr, 0};
                 bsdf.dropped = 0u;
+                const rspt_bxdf* lobes = sc.bxdfs + mat.first_bxdf;
+                uint32_t n_lobes = mat.n_bxdfs;
                 if ((F & SF_TEX) && sc.mat_flags && sc.mat_flags[h.material]) {  // textured material: k_texture ran for this hit
                     const float4* tb = pb.tex + p;
+                    if ((F & SF_DYNAMIC) && (sc.mat_flags[h.material] & RSPT_MAT_DYNAMIC)) {  // the lobe list itself depends on texture values at the hit
+                        const rspt_mat::Built* bl = dynamic_lobes(sc.dyn[h.material], tb, pb.tex_stride, true /* path.rs:108 */, pb.dyn_built + (blockIdx.x * blockDim.x + threadIdx.x));
+                        lobes = bl->l; n_lobes = bl->n;
+                        bsdf.eta = bl->eta;
+                    }
                     bsdf.lt = LobeTex{tb, pb.tex_stride};
                     const float4 m4 = tb[4 * (size_t)pb.tex_stride];
                     const uint32_t tf = __float_as_uint(m4.w);
@@ -432,8 +466,8 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 bsdf.ns = h.sh_n;
                 bsdf.ng = h.n;
                 bsdf.ts = cross(h.sh_n, bsdf.ss);
-                bsdf.lobes = sc.bxdfs + mat.first_bxdf;
-                bsdf.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+                bsdf.lobes = lobes;
+                bsdf.n = n_lobes < 8u ? n_lobes : 8u;
                 typename ShadeSamplerFor<PIX, F>::type smp;
                 smp.bind(px);
                 smp.start(rd, sob_tab, sob_nd, pb.sobol_index[p], st & ST_DIM_MASK);
@@ -634,6 +668,20 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
             }
             tv[k] = rgb{v.r < 0.0f ? 0.0f : v.r, v.g < 0.0f ? 0.0f : v.g, v.b < 0.0f ? 0.0f : v.b};  // Spectrum::clamp(0, inf) = clamp_t per channel (pbrt.rs:108-123)
             out[k * stride] = make_float4(tv[k].r, tv[k].g, tv[k].b, 0.0f);
+        }
+    }
+    if (mf & RSPT_MAT_DYNAMIC) {  // raw values of every varying parameter: the shade stage builds the lobe list from them (dynamic_lobes)
+        const rspt_mat::DynMaterial& dm = tt.dyn[tri.material];
+        for (uint32_t r = 0; r < dm.n_rows; r++) {
+            const uint32_t sd = dm.row_tex[r];
+            rgb v;
+            if (sd & RSPT_SLOT_NODIFF) {
+                TexSurf s2 = s;
+                s2.dudx = s2.dvdx = s2.dudy = s2.dvdy = 0.0f;
+                s2.dpdx = s2.dpdy = f3{0.0f, 0.0f, 0.0f};
+                v = tex_eval(tt, sd & RSPT_SLOT_TEX_MASK, s2);
+            } else v = tex_eval(tt, sd & RSPT_SLOT_TEX_MASK, s);
+            out[(size_t)(RSPT_TEX_ROWS + r) * stride] = make_float4(v.r, v.g, v.b, 0.0f);
         }
     }
     // the reference's `if !colour.is_black()` guards around bsdf.add (matte.rs:70, plastic.rs:70,84, substrate.rs:72, uber.rs)

@@ -93,6 +93,7 @@ struct Ctx {
     uint32_t* pix_list = nullptr;
     size_t pix_cap = 0;
     std::vector<hipEvent_t> events;
+    uint32_t tex_rows = 0;             // rows of g.pb.tex per path: RSPT_TEX_ROWS, + RSPT_DYN_ROWS once a scene with dynamic materials was rendered
     QueueCounts* look = nullptr;       // pinned host words the render loops read queue lengths into: a device-to-host copy into pageable memory
                                        // goes through a staging buffer and costs milliseconds per look (volpath looks once per pass)
 };
@@ -178,15 +179,19 @@ struct rspt_scene_s {
         const rspt_bxdf* bxdfs = nullptr;
         const uint32_t* mat_slots = nullptr;
         const uint8_t* mat_flags = nullptr;
-        bool textured = false;
+        const rspt_mat::DynMaterial* dyn = nullptr;
+        bool textured = false, dynamic = false;
     } mat_set[2];
+    bool has_dynamic = false;         // (in the selected set) some material's lobe list is built per hit
     uint32_t shade_features = 0;      // SF_* (dev_bsdf.h) of everything the scene can put in front of the shade stage
     void select_materials(bool allow_multiple_lobes) {
         const MatSet& m = mat_set[allow_multiple_lobes ? 0 : 1];
         dev.materials = m.materials; dev.bxdfs = m.bxdfs;
         tex.mat_slots = m.mat_slots; tex.mat_flags = m.mat_flags;
         dev.mat_flags = m.textured ? m.mat_flags : nullptr;
+        dev.dyn = m.dyn; tex.dyn = m.dyn;
         has_textures = m.textured;
+        has_dynamic = m.dynamic;
     }
     std::vector<void*> allocs;
     bool has_null_material = false;
@@ -227,11 +232,12 @@ size_t env_size(const char* name, size_t dflt) {
 
 void free_paths() {
     void* ptrs[] = {g.pb.ray_cont, g.pb.ray_mis, g.pb.ray_sh, g.pb.hit_cont, g.pb.hit_mis, g.pb.occluded, g.pb.L_eta, g.pb.beta,
-                    g.pb.nee_c1, g.pb.nee_c2, g.pb.nee_beta, g.pb.sobol_index, g.pb.state, g.pb.p_film, g.pb.tex,
+                    g.pb.nee_c1, g.pb.nee_c2, g.pb.nee_beta, g.pb.sobol_index, g.pb.state, g.pb.p_film, g.pb.tex, g.pb.dyn_built,
                     g.q[0][0], g.q[0][1], g.q[0][2], g.q[1][0], g.q[1][1], g.q[1][2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g.pb = PathBuf{};
+    g.tex_rows = 0;
     for (auto& a : g.q) a[0] = a[1] = a[2] = nullptr;
     g.cap = 0;
 }
@@ -256,11 +262,25 @@ int ensure_paths(size_t cap) {
 }
 
 // per-path rows of k_texture's results, only for scenes with textures (6 x 16 B per path)
-int ensure_tex_rows() {
-    if (g.pb.tex) return RSPT_OK;
-    int rc = dev_alloc(&g.pb.tex, g.cap * RSPT_TEX_ROWS);
+int ensure_tex_rows(bool dynamic) {
+    const uint32_t rows = RSPT_TEX_ROWS + (dynamic ? RSPT_DYN_ROWS : 0);
+    if (g.pb.tex && g.tex_rows >= rows) return RSPT_OK;
+    if (g.pb.tex) (void)hipFree(g.pb.tex);
+    g.pb.tex = nullptr; g.tex_rows = 0;
+    int rc = dev_alloc(&g.pb.tex, g.cap * rows);
     if (rc) return rc;
     g.pb.tex_stride = (uint32_t)g.cap;
+    g.tex_rows = rows;
+    return RSPT_OK;
+}
+// dynamic materials: one Built record (8 lobes) per thread of the widest shade-stage launch
+int ensure_dyn_built(uint32_t threads) {
+    if (g.pb.dyn_built && g.pb.dyn_threads >= threads) return RSPT_OK;
+    if (g.pb.dyn_built) (void)hipFree(g.pb.dyn_built);
+    g.pb.dyn_built = nullptr; g.pb.dyn_threads = 0;
+    int rc = dev_alloc(&g.pb.dyn_built, threads);
+    if (rc) return rc;
+    g.pb.dyn_threads = threads;
     return RSPT_OK;
 }
 
@@ -532,14 +552,15 @@ const ShadeVariant g_shade_variants[] = {
     {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 0},
     {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
     {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0},
-    {SF_ALL, "generic", k_shade<SF_ALL>, k_shade_w<SF_ALL, 3>, k_shade_w<SF_ALL, 4>, 0},
+    {SF_ALL & ~SF_DYNAMIC, "generic", k_shade<SF_ALL & ~SF_DYNAMIC>, k_shade_w<SF_ALL & ~SF_DYNAMIC, 3>, k_shade_w<SF_ALL & ~SF_DYNAMIC, 4>, 0},
+    {SF_ALL, "dynamic", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0},   // + lobe lists built per hit (material_assembly.h)
 };
 // RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 0 | 3 | 4 one of its builds (A/B)
 ShadeKernel shade_kernel_for(uint32_t need, const char** name_out) {
     const char* force = getenv("RSPT_SHADE_VARIANT");
     for (const ShadeVariant& v : g_shade_variants) {
         if ((need & ~v.features) != 0) continue;
-        if (force && *force && strcmp(force, v.name) != 0 && v.features != SF_ALL) continue;
+        if (force && *force && strcmp(force, v.name) != 0 && (v.features | SF_DYNAMIC) != SF_ALL) continue;
         if (name_out) *name_out = v.name;
         const size_t waves = env_size("RSPT_SHADE_WAVES", (size_t)v.dflt);
         return waves == 3 ? v.w3 : (waves == 4 ? v.w4 : v.natural);
@@ -685,6 +706,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     LightDistDev ld;
     const LightDist* ld_lazy = nullptr;  // on-demand voxels: a mark / build round in front of every shade launch
     if ((rc = get_light_dist(s, d->light_strategy, &ld, &ld_lazy))) return rc;
+    if (pixel_sampler && s->has_dynamic) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with a material whose lobe list depends on a texture");
     if (pixel_sampler && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
     if (volpath && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "volpath with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
 
@@ -773,7 +795,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (s->has_instances && (rc = ensure_hit_inst(g.cap))) return rc;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
     if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
-        (s->has_textures && (rc = ensure_tex_rows()))) return rc;
+        (s->has_textures && (rc = ensure_tex_rows(s->has_dynamic)))) return rc;
+    if (s->has_dynamic) {
+        if (volpath) return fail(RSPT_E_UNSUPPORTED, "volpath with a material whose lobe list depends on a texture (sigma / index / opacity / Kr / Kt / reflect / transmit / eta / k / a mix amount bound to a non-constant texture)");
+        if ((rc = ensure_dyn_built(grid_for(8) * 256u))) return rc;
+    }
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
 
@@ -1505,15 +1531,23 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     // materials: Material::compute_scattering_functions restated on the host (material_assembly.h), once per allow_multiple_lobes
     std::vector<rspt_material> asm_mats[2];
     std::vector<rspt_bxdf> asm_bx[2];
+    std::vector<rspt_mat::DynMaterial> asm_dyn[2];   // [material] when the variant has a dynamic material, else empty
+    std::vector<uint8_t> asm_is_dyn[2];
     for (int v = 0; v < 2; v++) {
         rspt_mat::Assembler as(d, v == 0);
         rspt_mat::Lobes lb;
         asm_mats[v].resize(d->n_materials);
+        asm_is_dyn[v].assign(d->n_materials, 0);
         for (uint32_t i = 0; i < d->n_materials; i++) {
             if (rspt_mat::Error e = as.assemble(i, &lb)) return fail(e.code, "%s", e.text.c_str());
             lb.mat.first_bxdf = (uint32_t)asm_bx[v].size();
             asm_mats[v][i] = lb.mat;
             asm_bx[v].insert(asm_bx[v].end(), lb.lobes.begin(), lb.lobes.end());
+            if (lb.dynamic) {
+                if (asm_dyn[v].empty()) asm_dyn[v].resize(d->n_materials);
+                asm_dyn[v][i] = lb.dyn;
+                asm_is_dyn[v][i] = 1;
+            }
         }
     }
     uint32_t shade_features = 0;
@@ -1526,6 +1560,8 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         }
     for (int v = 0; v < 2; v++)
         for (const rspt_material& m : asm_mats[v]) if (m.bump_tex) shade_features |= SF_TEX;
+    if (!asm_dyn[0].empty() || !asm_dyn[1].empty())  // a list built per hit may hold any lobe its material kind can push
+        shade_features |= SF_DYNAMIC | SF_TEX | 0x3feu | SF_CONDUCTOR | SF_SC;
     for (uint32_t i = 0; i < d->n_lights; i++) {
         const uint32_t k = d->lights[i].kind;
         shade_features |= k == RSPT_LIGHT_DIFFUSE_AREA ? SF_L_AREA : (k == RSPT_LIGHT_POINT ? SF_L_POINT : (k == RSPT_LIGHT_SPOT ? SF_L_SPOT : (k == RSPT_LIGHT_DISTANT ? SF_L_DISTANT : SF_L_INFINITE)));
@@ -1639,11 +1675,14 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                     if (b.tex_ay) { b.tex_ay = slot_of(b.tex_ay, aflags); mflags[m] |= RSPT_MAT_TEXTURED; }
                 }
                 if (full) return bail(fail(RSPT_E_UNSUPPORTED, "material %u binds more than %d distinct textures", m, RSPT_TEX_SLOTS));
+                if (asm_is_dyn[v][m]) mflags[m] |= RSPT_MAT_DYNAMIC | RSPT_MAT_TEXTURED;
                 if (mat.bump_tex) mflags[m] |= RSPT_MAT_BUMP;
                 any_v |= mflags[m] != 0;
             }
             rspt_scene_s::MatSet& ms = s->mat_set[v];
             ms.textured = any_v;
+            ms.dynamic = !asm_dyn[v].empty();
+            if (ms.dynamic && (rc = upload(s, asm_dyn[v].data(), asm_dyn[v].size(), &ms.dyn))) return bail(rc);
             any |= any_v;
             if ((rc = upload(s, asm_mats[v].data(), asm_mats[v].size(), &ms.materials)) || (rc = upload(s, bx.data(), bx.size(), &ms.bxdfs)) ||
                 (rc = upload(s, slots.data(), slots.size(), &ms.mat_slots)) || (rc = upload(s, mflags.data(), mflags.size(), &ms.mat_flags)))
@@ -1923,6 +1962,7 @@ int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t
     rspt_mat::Lobes lb;
     if (rspt_mat::Error e = as.assemble(material, &lb)) return fail(e.code, "%s", e.text.c_str());
     *out_material = lb.mat;
+    if (lb.dynamic) return RSPT_MATERIAL_DYNAMIC;
     for (size_t i = 0; i < lb.lobes.size(); i++) out_bxdfs[i] = lb.lobes[i];
     return (int)lb.lobes.size();
 }

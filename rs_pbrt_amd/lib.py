@@ -83,6 +83,9 @@ def _check(rc):
         raise RsptError(rc, (lib().rspt_last_error() or b"").decode("utf-8", "replace"))
 
 
+MATERIAL_DYNAMIC = 1000
+
+
 def material_lobes(scene, material, allow_multiple_lobes=True):
     """The lobe list librspt assembles for material `material` of a scenes.Scene (rspt_material_lobes; host only, no device):
     (eta, bump_tex, lobes BXDF_DT[]) — tex_* fields are 1 + texture index."""
@@ -91,6 +94,8 @@ def material_lobes(scene, material, allow_multiple_lobes=True):
     n = lib().rspt_material_lobes(C.addressof(scene.desc), int(material), int(bool(allow_multiple_lobes)), C.addressof(mat), bx.ctypes.data)
     if n < 0:
         _check(n)
+    if n == MATERIAL_DYNAMIC:   # the lobe list depends on texture values at the hit: built per hit on the device
+        return float(mat.eta), int(mat.bump_tex), None
     return float(mat.eta), int(mat.bump_tex), bx[:n].copy()
 
 

@@ -540,6 +540,35 @@ def test_many_area_lights(gpu, oracle, strategy):
     assert film_rmse(film, ref["film"]) < 2e-5
 
 
+@pytest.mark.parametrize("sampler", ["sobol", "halton"])
+def test_materials_whose_lobe_list_depends_on_textures(gpu, oracle, sampler):
+    """Dynamic materials (material_assembly.h): sigma / index / opacity / Kr / Kt / reflect / transmit / eta / k / a glass roughness / a mix
+    amount bound to image and checker textures — the texture stage leaves the raw values in the path's rows, the shade stage runs the
+    host's own assembly function per hit.  The oracle evaluates compute_scattering_functions at every hit as the reference does; every
+    camera sample's radiance must be equal bit for bit."""
+    from tests.util import DYNAMIC_LOOK_AT, dynamic_gallery
+    sc = dynamic_gallery(gpu.bvh_build)
+    from rs_pbrt_amd import lib as _lib
+    assert sum(_lib.material_lobes(sc, i)[2] is None for i in range(len(sc.materials))) >= 8   # the slabs' materials are dynamic
+    rd = scenes.make_render_desc(96, 40, 16, DYNAMIC_LOOK_AT, 75.0, max_depth=6, sampler=sampler)
+    film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+    assert st["nan_samples"] == 0 and np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert film_rmse(film, ref["film"]) < 1e-6
+    rgb = scenes.film_to_rgb(film).reshape(40, 96, 3)
+    assert rgb[10:30].std() > 0.02   # the slabs are in view and differ
+
+
+def test_dynamic_materials_are_refused_where_the_stage_is_not_built(gpu):
+    from rs_pbrt_amd.lib import RsptError
+    from tests.util import DYNAMIC_LOOK_AT, dynamic_gallery
+    sc = dynamic_gallery(gpu.bvh_build)
+    with gpu.DeviceScene(sc) as ds:
+        for kw in (dict(integrator="volpath"), dict(integrator="directlighting"), dict(sampler="02sequence")):
+            with pytest.raises(RsptError) as e:
+                gpu.render(ds, scenes.make_render_desc(32, 16, 4, DYNAMIC_LOOK_AT, 75.0, **kw))
+            assert e.value.code == abi.E_UNSUPPORTED
+
+
 def test_film_reduce_runs_inside_the_library(gpu):
     """X1 in the product: rspt_comm_unique_id / rspt_comm_init create the RCCL communicator, film_reduce = 1 makes
     rspt_render end with ncclReduce(sum) onto rank 0.  One GPU here, so the world has one rank (the sum of one film is that film,
