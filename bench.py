@@ -156,6 +156,8 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_
     t_c = sum(s["t_trace_closest_s"] for s in stats) / n
     t_a = sum(s["t_trace_any_s"] for s in stats) / n
     t_wall = sum(s["t_trace_s"] for s in stats) / n
+    if t_wall <= 0.0:   # schedules that run their trace launches one after the other on one stream (volpath, directlighting): the sum is the wall time
+        t_wall = t_c + t_a
     t_sh = sum(s["t_shade_s"] for s in stats) / n
     t_k = sum(s["t_kernels_s"] for s in stats) / n
     launches = stats[0]["launches_closest"] + stats[0]["launches_any"]

@@ -470,6 +470,7 @@ bool trace_can_overflow(const rspt_scene_s* s);
 // its queue every 8th iteration and the queues only shrink): a few hundred paths do not need 1280 persistent workgroups each copying
 // the root-side records into LDS
 uint32_t g_queue_hint = 0xffffffffu;
+uint32_t* g_inst_out = nullptr;  // where the next closest-hit launches record the instance of each hit instead of g.hit_inst (volpath's shadow-ray segments)
 uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
     if (g_queue_hint == 0xffffffffu) return full;
     const uint64_t need = (2ull * g_queue_hint + per_block - 1) / per_block + 1;
@@ -494,7 +495,7 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     hipStream_t stream = lane ? g.stream2 : g.stream;
     uint32_t* ovf = g.ovf + (lane ? 2 * g.ovf_cap / 3 : 0);
     uint2* spill = g.spill + (lane ? g.spill_threads * RSPT_W4_SPILL : 0);
-    uint32_t* hi = (INST && OUT_MODE == 0 && !ANY) ? g.hit_inst : nullptr;
+    uint32_t* hi = (INST && OUT_MODE == 0 && !ANY) ? (g_inst_out ? g_inst_out : g.hit_inst) : nullptr;
     const bool special = INST || ALPHA;
     const bool slow = count || which == 0 || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
     if (slow) {
@@ -594,9 +595,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         return fail(RSPT_E_UNSUPPORTED, "integrator %u (path, ao, directlighting and volpath only)", d->integrator);
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
     const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
-    if (volpath && s) {
-        if (s->has_instances) return fail(RSPT_E_UNSUPPORTED, "volpath with object instances (transform_surface_interaction drops the medium interface)");
-    }
     if (direct) {
         if (d->max_depth < 1 || d->max_depth > 8) return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, 8] (the specular tree has 2^max_depth slots per camera sample)");
         if (d->direct_strategy > RSPT_DIRECT_SAMPLE_ONE) return fail(RSPT_E_INVALID, "bad direct_strategy");
@@ -792,8 +790,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // C2 (one material: only the escaped paths are separated): 423 -> 425
     const bool shade_bins = env_size("RSPT_SHADE_BINS", 1) != 0 && !ao && !direct && !volpath;
     if (shade_bins && (rc = ensure_bins(g.cap, max_iters + 10))) return rc;
-    if (s->has_instances && (rc = ensure_hit_inst(g.cap))) return rc;
+    if (s->has_instances && (rc = ensure_hit_inst(volpath ? 2 * g.cap : g.cap))) return rc;   // volpath: second half = the hits of the shadow-ray segments
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
+    g.vol.hit_inst_tr = (volpath && s->has_instances) ? g.hit_inst + g.cap : nullptr;
     if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
         (s->has_textures && (rc = ensure_tex_rows(s->has_dynamic)))) return rc;
     if (s->has_dynamic) {
@@ -888,7 +887,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 if (seg > null_passes) { truncated += c.closest; break; }
                 HIP_TRY(hipMemsetAsync(tn, 0, sizeof(QueueCounts), g.stream));
                 ev_open(1, 0);
-                launch_trace<false, 0>(0, counters, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                // (queue entries without the MIS flag over the shadow rays' own arrays, so that the hit's instance is recorded too)
+                g_inst_out = g.vol.hit_inst_tr ? g.hit_inst + g.cap : nullptr;
+                launch_trace<false, 0>(0, counters, tgrid, s, g.q[seg & 1u][2], &tc->closest, 0, &tc->cursor_closest, g.pb.ray_mis, g.pb.ray_mis, g.pb.hit_mis, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                g_inst_out = nullptr;
                 ev_close(1, 0);
                 trace_launches++;
                 if (looked) vol_rays += c.closest;

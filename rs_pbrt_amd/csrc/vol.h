@@ -26,6 +26,7 @@ struct VolBuf {         // per path slot, next to PathBuf
     float4* p1_n;
     float4* post;       // radiance to add after the estimate (volpath.rs:332-337 runs after :304-330), w != 0: present
     uint32_t* truncated;  // paths cut because the sampler ran out of dimensions (the reference panics there)
+    const uint32_t* hit_inst_tr;  // scenes with object instances: 0 or 1 + instance of the shadow-ray segment's hit, by slot (the continuation ray's is pb.hit_inst)
 };
 // pb.nee_c1 = (f.rgb, light_pdf)   pb.nee_c2 = (li.rgb, MIS weight | < 0 for a delta light)   pb.nee_beta = (beta.rgb, light choice pdf)
 // pb.ray_mis / pb.hit_mis = the shadow ray's current segment and its closest hit
@@ -180,7 +181,17 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
             } else {
                 TriRec tri{};
                 float t_hit = RSPT_INF;
-                if (hit) { tri = load_tri(sc, prim); t_hit = hit_distance(tri, ray_o, ray_d); }
+                // an instanced hit: the triangle lives in object space and ray.t_max is the OBJECT ray's parameter (TransformedPrimitive::intersect:
+                // r.t_max.set(ray.t_max), primitive.rs:224; Transform::transform_ray has moved the origin by its error bound)
+                const uint32_t hi = (hit && pb.hit_inst) ? pb.hit_inst[p] : 0u;
+                if (hit) {
+                    tri = load_tri(sc, prim);
+                    if (hi) {
+                        f3 oo, od; float ot;
+                        inst_ray(sc.inst[hi - 1u], ray_o, ray_d, RSPT_INF, &oo, &od, &ot);
+                        t_hit = hit_distance(tri, oo, od);
+                    } else t_hit = hit_distance(tri, ray_o, ray_d);
+                }
                 // ---- medium.sample(&ray, sampler) (volpath.rs:96-101 / :289-294; homogeneous.rs:37-91) ----
                 bool have_mi = false;
                 f3 mi_p{0.0f, 0.0f, 0.0f};
@@ -230,15 +241,25 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                     } else if (hit) {
                         Hit h;
                         tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &h);
-                        const f3 wo = -ray_d;
+                        const f3 wo_ray = -ray_d;  // what `li` itself passes on: isect.le(&-ray.d), bsdf.sample_f(&-ray.d, ..) (volpath.rs:133, :170)
+                        f3 wo = wo_ray;            // isect.common.wo, what estimate_direct reads (they differ for a transformed hit only)
+                        // Transform::transform_surface_interaction (transform.rs:815-860) starts from SurfaceInteraction::default(): the transformed
+                        // hit has no medium interface (get_medium gives None on either side) and, in v0.9.12, no primitive (Q11)
+                        const bool transformed = hi && !sc.inst[hi - 1u].identity;
+                        if (transformed) {
+                            const InstDev& in = sc.inst[hi - 1u];
+                            inst_hit(in, &h);
+                            wo = normalize(xf_vector(in.m, -xf_vector(in.mi, ray_d)));
+                            if (!sc.inst_fixed) { h.material = 0xffffffffu; h.area_light = -1; }
+                        }
                         if (bounces == 0 || specular) {  // :133-136
-                            const rgb e = h.area_light >= 0 ? light_l(sc.lights[h.area_light], h.n, wo) : mkrgb(0.0f);
+                            const rgb e = h.area_light >= 0 ? light_l(sc.lights[h.area_light], h.n, wo_ray) : mkrgb(0.0f);
                             L = L + beta * e;
                         }
                         if (bounces < rd.max_depth) {
                             if (h.material == 0xffffffffu) {  // no BSDF: isect.spawn_ray(&ray.d); `continue` skips the bounce count and the roulette (:141-145)
                                 new_o = offset_ray_origin(h.p, h.p_err, h.n, ray_d);
-                                new_medium = surface_medium(sc, prim, medium, h.n, ray_d);
+                                new_medium = transformed ? 0u : surface_medium(sc, prim, medium, h.n, ray_d);
                                 go_on = true; counted = false;
                                 st |= ST_NO_DIFF;   // the re-spawned ray carries no differentials (k_texture)
                             } else {
@@ -263,6 +284,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                                 const rspt_mesh me = sc.meshes[sc.prims[prim].mesh];
                                 uint32_t m_in = medium, m_out = medium;
                                 if (me.medium_inside != me.medium_outside) { m_in = me.medium_inside; m_out = me.medium_outside; }
+                                if (transformed) m_in = m_out = 0u;
                                 if (sc.n_lights) {  // no non-specular-lobe test in front of the estimate here (:146-161)
                                     const VolRef it{h.p, h.p_err, h.n, wo, m_in, m_out};
                                     const uint32_t nonspec = BX_ALL & ~BX_SPEC;
@@ -275,13 +297,13 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                                 f3 wi{0.0f, 0.0f, 0.0f};
                                 float pdf = 0.0f;
                                 uint32_t sampled_type = 255;
-                                const rgb f = b.sample_f(wo, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
+                                const rgb f = b.sample_f(wo_ray, &wi, smp.get_2d(rd), &pdf, BX_ALL, &sampled_type);
                                 if (!(is_black(f) || pdf == 0.0f)) {
                                     beta = beta * ((f * absdot(wi, h.sh_n)) / pdf);
                                     specular = (sampled_type & BX_SPEC) != 0;
                                     if ((sampled_type & BX_SPEC) && (sampled_type & BX_TRANS)) {
                                         const float eta = b.eta;
-                                        if (dot(wo, h.n) > 0.0f) eta_scale *= eta * eta;
+                                        if (dot(wo_ray, h.n) > 0.0f) eta_scale *= eta * eta;
                                         else eta_scale *= 1.0f / (eta * eta);
                                     }
                                     new_o = offset_ray_origin(h.p, h.p_err, h.n, wi);
@@ -318,7 +340,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
             pb.state[p] = st;
         }
         dl_push(go_on, p, q_next, cnt_next);
-        dl_push(shadow, p | RSPT_Q_MIS, q_tr, cnt_tr);
+        dl_push(shadow, p, q_tr, cnt_tr);
     }
 }
 
@@ -344,11 +366,20 @@ __global__ __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf 
             bool done = false, blocked = false;
             if (prim != RSPT_MISS) {
                 const TriRec tri = load_tri(sc, prim);
-                if (tri.material != 0xffffffffu) { blocked = true; done = true; }  // an opaque surface: Spectrum::default() (:218-222)
+                const uint32_t hi = vb.hit_inst_tr ? vb.hit_inst_tr[p] : 0u;
+                const bool transformed = hi && !sc.inst[hi - 1u].identity;
+                const bool no_primitive = transformed && !sc.inst_fixed;   // Q11: isect.primitive is None, neither branch of :216-229 runs
+                if (!no_primitive && tri.material != 0xffffffffu) { blocked = true; done = true; }  // an opaque surface: Spectrum::default() (:218-222)
                 else {
-                    if (medium) tr = tr * med_tr(sc.media[medium - 1u], hit_distance(tri, o, d), len(d));   // ray.t_max is the hit distance now
+                    if (medium && !no_primitive) {   // ray.t_max is the hit distance now (an instanced hit: the object ray's)
+                        float th;
+                        if (hi) { f3 oo, od; float ot; inst_ray(sc.inst[hi - 1u], o, d, t_max, &oo, &od, &ot); th = hit_distance(tri, oo, od); }
+                        else th = hit_distance(tri, o, d);
+                        tr = tr * med_tr(sc.media[medium - 1u], th, len(d));
+                    }
                     Hit h;
                     tri_fill(sc, prim, tri, hm.y, hm.z, hm.w, &h);
+                    if (transformed) inst_hit(sc.inst[hi - 1u], &h);
                     const float4 pp = vb.p1_p[p], pe = vb.p1_e[p], pn = vb.p1_n[p];
                     const f3 lp{pp.x, pp.y, pp.z};
                     // isect.common.spawn_ray_to(p1) (:236)
@@ -356,7 +387,7 @@ __global__ __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf 
                     const f3 target = offset_ray_origin(lp, f3{pe.x, pe.y, pe.z}, f3{pn.x, pn.y, pn.z}, origin - lp);
                     const f3 nd = target - origin;
                     store_ray(pb.ray_mis + p, origin, nd, 1.0f - RSPT_SHADOW_EPS, p);
-                    vb.sh[p] = make_float4(tr.r, tr.g, tr.b, __uint_as_float(surface_medium(sc, prim, medium, h.n, nd)));
+                    vb.sh[p] = make_float4(tr.r, tr.g, tr.b, __uint_as_float(transformed ? 0u : surface_medium(sc, prim, medium, h.n, nd)));
                     again = true;
                 }
             } else {
@@ -380,7 +411,7 @@ __global__ __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf 
                 pb.L_eta[p] = make_float4(L.r, L.g, L.b, le.w);
             }
         }
-        dl_push(again, p | RSPT_Q_MIS, q_next, cnt_next);
+        dl_push(again, p, q_next, cnt_next);
     }
 }
 

@@ -138,8 +138,43 @@ def test_gpu_volpath_refusals(gpu):
     with pytest.raises(RsptError) as e:
         gpu.DeviceScene(sc)
     assert e.value.code == abi.E_INVALID
-    from tests.test_instancing import small_scene
-    with gpu.DeviceScene(small_scene(gpu.bvh_build)) as ds:
-        with pytest.raises(RsptError) as e:
-            gpu.render(ds, scenes.make_render_desc(16, 16, 1, LOOK, 50.0, integrator="volpath"))
-        assert e.value.code == abi.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("mode", ["reference", "fixed"])
+def test_gpu_volpath_with_object_instances(gpu, oracle, mode):
+    """VERDICT r2 missing #5: fog + ObjectInstances.  Transform::transform_surface_interaction builds the instanced hit from
+    SurfaceInteraction::default(): it has no medium interface — a ray that leaves an instanced surface travels in no medium, although it
+    may sit in the middle of the fog — and in v0.9.12 no primitive: `li` passes through it (no BSDF) and VisibilityTester::tr neither
+    blocks nor attenuates at it (light.rs:216-229).  Pyramids inside and outside a box of fog (scaled, rotated, one identity instance,
+    one single-triangle object), both instancing behaviours, every camera sample against the oracle."""
+    from tests.test_instancing import PYR, PYR_IDX
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.6, 0.6, 0.6)))
+    red = sb.add_material(scenes.plastic((0.6, 0.2, 0.15), (0.3, 0.3, 0.3), 0.15))
+    fog = sb.add_medium(sigma_a=(0.02, 0.03, 0.05), sigma_s=(0.3, 0.28, 0.25), g=0.3)
+    sb.add_quad([(-4, 0, -4.03), (-4, 0, 4.03), (4, 0, 4.03), (4, 0, -4.03)], grey)
+    sb.add_quad([(-4, 0, 2.97), (-4, 5.03, 2.97), (4, 5.03, 2.97), (4, 0, 2.97)], grey)
+    sb.add_box((-1.83, 0.07, -1.51), (1.79, 2.53, 1.52), None, medium=(fog, None))
+    sb.add_quad([(-1, 4.47, -1), (1, 4.47, -1), (1, 4.47, 1), (-1, 4.47, 1)], grey, emit=(14, 13, 12))
+    sb.add_point_light((2.5, 3.1, -3.2), (22, 22, 25))
+    sb.begin_object("pyr")
+    sb.add_mesh(PYR * np.float32(0.6), PYR_IDX, red, medium=(fog, fog))
+    sb.end_object()
+    sb.begin_object("one")
+    sb.add_mesh(PYR[:3] * np.float32(0.8), [[0, 1, 2]], red)
+    sb.end_object()
+    T = scenes.Transform
+    sb.add_instance("pyr", T(T.translate((-0.6, 0.4, 0.1)).m @ T.rotate_y(30.0).m))            # inside the fog
+    sb.add_instance("pyr", T(T.translate((0.7, 0.5, -0.3)).m @ T.scale(1.3, 0.8, 1.1).m))      # inside the fog
+    sb.add_instance("pyr", T(T.translate((2.9, 0.3, 0.4)).m))                                  # outside
+    sb.add_instance("one", T(T.translate((-2.6, 1.2, 0.0)).m))
+    sb.add_instance("pyr", T.identity())                                                       # Q10
+    sc = sb.finish(gpu.bvh_build, instancing=mode)
+    rd = scenes.make_render_desc(64, 48, 16, LOOK, 55.0, integrator="volpath", max_depth=5)
+    ref = oracle.render(sc, rd, threads=8, want_li=True)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+        li, _ = gpu.render_samples(ds, rd)
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and st["truncated_paths"] == 0 and st["nan_samples"] == 0
+    assert np.array_equal(li, ref["li"]), "%d of %d camera samples differ" % (int((li != ref["li"]).any(axis=2).sum()), li.shape[0] * li.shape[1])
+    assert film_rmse(film, ref["film"]) < 1e-6
