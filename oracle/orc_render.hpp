@@ -1263,9 +1263,11 @@ static inline Spec ao_li(RenderCtx& cx, const Ray& ray, Sampler& sampler, Counte
         V3 s = normalize(isect.dpdu);
         V3 t = cross(isect.n, s); // nrm_cross_vec3(&isect.common.n, &s)
         int32_t ns = (int32_t)rd.ao_n_samples;
-        uint64_t first = (uint64_t)sampler.cur_sample() * (uint64_t)ns;
-        for (int32_t k = 0; k < ns; k++) {
-            P2 u = sampler.array_2d(first + (uint64_t)k, 5); // GlobalSampler::array_start_dim = 5
+        size_t which = 0;
+        uint64_t first = 0;
+        const bool have = sampler.get_2d_array(ns, &which, &first); // ao.rs:75: the pixel sample's slice of the array preprocess requested
+        for (int32_t k = 0; have && k < ns; k++) {
+            P2 u = sampler.get_2d_sample(which, first + (uint64_t)k); // GlobalSampler: array dimensions 5, 6 (array_start_dim = 5); PixelSampler: its own array
             V3 wi; Float pdf;
             if (rd.ao_cos_sample) { wi = cosine_sample_hemisphere(u); pdf = std::fabs(wi.z) * INV_PI; }
             else { wi = uniform_sample_hemisphere(u); pdf = INV_2_PI; }

@@ -581,7 +581,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (d->tile_size == 0 || d->tile_size > 4096) return fail(RSPT_E_INVALID, "bad tile_size");
     if (sobol && (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv)) return fail(RSPT_E_INVALID, "null sobol tables");
     if (pixel_sampler) {
-        if (d->integrator != RSPT_INTEGRATOR_PATH) return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path integrator only");
+        if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO)
+            return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path and ao integrators only");
+        if (d->integrator == RSPT_INTEGRATOR_AO && (d->sampler_kind == RSPT_SAMPLER_ZEROTWO || d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) && (d->ao_n_samples & (d->ao_n_samples - 1)) != 0)
+            return fail(RSPT_E_INVALID, "ao: nsamples must be a power of two with the 02sequence / maxmindist samplers (request_2d_array asserts round_count(n) == n, zerotwosequence.rs:187-193)");
         if (d->tile_size != 16 && d->tile_size > 255) return fail(RSPT_E_UNSUPPORTED, "tile_size > 255 with a pixel sampler");
         if (d->spp > 65536 || d->pixel_dimensions > 64) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: spp > 65536 or more than 64 sampled dimensions");
         if (d->sampler_kind == RSPT_SAMPLER_STRATIFIED && (d->strat_x == 0 || d->strat_y == 0 || (int64_t)d->strat_x * d->strat_y != d->spp))
@@ -1106,6 +1109,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         struct Guard { std::vector<void*> p; ~Guard() { for (void* q : p) (void)hipFree(q); } } guard;
         auto tmp = [&](auto** p, size_t n) { int r = dev_alloc(p, std::max<size_t>(n, 1)); if (!r) guard.p.push_back(*p); return r; };
         TileRec* tiles_d = nullptr; float4* samp_L = nullptr; float2* samp_pf = nullptr; float* a1 = nullptr; float2* a2 = nullptr; uint64_t* rng_state = nullptr;
+        float2* arr = nullptr;
+        const uint32_t arr_n = ao ? d->ao_n_samples : 0u;   // AOIntegrator::preprocess: request_2d_array(n_samples) (ao.rs:47-49)
+        if (arr_n && (rc = tmp(&arr, (size_t)arr_n * spp * n_tiles))) return rc;
         uint32_t* c_pixel_d = nullptr; uint32_t* trunc_d = nullptr; uint32_t* pass_pix = nullptr;
         const size_t max_samples = (size_t)n_tiles * rows * ts * spp;
         if ((rc = tmp(&tiles_d, n_tiles)) || (rc = tmp(&samp_L, max_samples)) || (rc = tmp(&samp_pf, max_samples)) || (rc = tmp(&a1, (size_t)nd * spp * n_tiles)) ||
@@ -1114,7 +1120,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             return rc;
         HIP_TRY(hipMemsetAsync(trunc_d, 0, sizeof(uint32_t), g.stream));
         if (d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) HIP_TRY(hipMemcpyAsync(c_pixel_d, d->maxmin_c_pixel, 32 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state};
+        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_n, d->ao_cos_sample};
         // lanes per wave: a lane that shares its wave waits whenever the others diverge, so spread the tiles over as many waves
         // as the chip holds (256 CUs x 4 SIMDs x 2) before doubling up
         uint32_t lanes = 1;
@@ -1137,9 +1143,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             HIP_TRY(hipMemcpyAsync(pass_pix, pl.data(), pl.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
             const dim3 grid((n_tiles + lanes - 1) / lanes);
             ev_open(2, 0);
-#define RSPT_TS(I, A) hipLaunchKernelGGL((k_tile_serial<I, A>), grid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, g.pb, pd, tiles_d, n_tiles, lanes, r0, r1, samp_L, samp_pf, serial_iters, trunc_d)
-            if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true); else RSPT_TS(true, false); }
-            else { if (s->has_alpha) RSPT_TS(false, true); else RSPT_TS(false, false); }
+#define RSPT_TS(I, A, O) hipLaunchKernelGGL((k_tile_serial<I, A, O>), grid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, g.pb, pd, tiles_d, n_tiles, lanes, r0, r1, samp_L, samp_pf, serial_iters, trunc_d)
+            if (ao) {
+                if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, true); else RSPT_TS(true, false, true); }
+                else { if (s->has_alpha) RSPT_TS(false, true, true); else RSPT_TS(false, false, true); }
+            } else if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, false); else RSPT_TS(true, false, false); }
+            else { if (s->has_alpha) RSPT_TS(false, true, false); else RSPT_TS(false, false, false); }
 #undef RSPT_TS
             ev_close(2, 0);
             const uint32_t npx = (uint32_t)pl.size();

@@ -82,7 +82,62 @@ struct PixSampler {
         for (uint32_t i = 0; i < spp; i++) (void)rng.bounded(1u);  // Q3: shuffle(samples, 1, 1) spp times, all on element 0
         shuffle2(d, spp);
     }
+    // ---- the 2-D sample ARRAY an integrator's preprocess asked for (request_2d_array; AOIntegrator: one array of arr_n points per pixel
+    // sample, ao.rs:47-49): flat element e = sample * arr_n + j at arr[e * stride]; refilled by every start_pixel after the vectors, from
+    // the same stream (zerotwosequence.rs:131-148, maxmin.rs:137-152, stratified.rs:137-160, random.rs:64-77) ----
+    float2* arr;
+    uint32_t arr_n;
+    RDEV float2& va(uint32_t e) const { return arr[(size_t)e * stride]; }
+    RDEV void fill_array() {
+        if (!arr_n) return;
+        const uint32_t total = arr_n * spp;
+        if (kind == RSPT_SAMPLER_ZEROTWO || kind == RSPT_SAMPLER_MAXMINDIST) {  // sobol_2d(arr_n, spp, ..) (lowdiscrepancy.rs:919-1010)
+            uint32_t x = rng.u32(), y = rng.u32();
+            for (uint32_t i = 0; i < total; i++) {
+                va(i) = make_float2(fminf((float)x * 0x1.0p-32f, RSPT_ONE_MINUS_EPS), fminf((float)y * 0x1.0p-32f, RSPT_ONE_MINUS_EPS));
+                const uint32_t tz = (uint32_t)__builtin_ctz(i + 1u);
+                x ^= 0x80000000u >> tz;
+                uint32_t c = 0x80000000u;
+                for (uint32_t k = 0; k < tz; k++) c ^= c >> 1;
+                y ^= c;
+            }
+            for (uint32_t i = 0; i < spp; i++)   // Q3: shuffle(samples, arr_n, 1) spp times, every time on the FIRST arr_n elements
+                for (uint32_t k = 0; k < arr_n; k++) {
+                    const uint32_t other = k + rng.bounded(arr_n - k);
+                    const float2 t = va(k); va(k) = va(other); va(other) = t;
+                }
+            for (uint32_t i = 0; i < spp; i++) {   // shuffle(samples, spp, arr_n): whole blocks
+                const uint32_t other = i + rng.bounded(spp - i);
+                for (uint32_t j = 0; j < arr_n; j++) { const float2 t = va(arr_n * i + j); va(arr_n * i + j) = va(arr_n * other + j); va(arr_n * other + j) = t; }
+            }
+        } else if (kind == RSPT_SAMPLER_STRATIFIED) {  // latin_hypercube per pixel sample (stratified.rs:150-159, sampling.rs:273-306)
+            const float inv_n = 1.0f / (float)arr_n;
+            for (uint32_t s = 0; s < spp; s++) {
+                const uint32_t b = s * arr_n;
+                for (uint32_t i = 0; i < arr_n; i++) {
+                    const float sx = ((float)i + rng.f32()) * inv_n;
+                    const float sy = ((float)i + rng.f32()) * inv_n;
+                    va(b + i) = make_float2(fminf(sx, RSPT_ONE_MINUS_EPS), fminf(sy, RSPT_ONE_MINUS_EPS));
+                }
+                for (uint32_t dim = 0; dim < 2; dim++)
+                    for (uint32_t j = 0; j < arr_n; j++) {
+                        const uint32_t other = j + rng.bounded(arr_n - j);
+                        float2 a = va(b + j), o = va(b + other);
+                        if (dim == 0) { const float t = a.x; a.x = o.x; o.x = t; } else { const float t = a.y; a.y = o.y; o.y = t; }
+                        va(b + j) = a;
+                        if (other != j) va(b + other) = o;
+                    }
+            }
+        } else {  // random.rs:70-76: x first
+            for (uint32_t i = 0; i < total; i++) { const float x = rng.f32(); const float y = rng.f32(); va(i) = make_float2(x, y); }
+        }
+    }
     RDEV void start_pixel() {
+        start_pixel_vectors();
+        fill_array();
+        cur_s = 0;
+    }
+    RDEV void start_pixel_vectors() {
         if (kind == RSPT_SAMPLER_ZEROTWO) {  // zerotwosequence.rs:127-163
             for (uint32_t d = 0; d < n_dims; d++) van_der_corput(d);
             for (uint32_t d = 0; d < n_dims; d++) sobol_2d(d);

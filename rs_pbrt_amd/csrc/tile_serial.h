@@ -25,9 +25,14 @@ struct PixDesc {              // the sampler's parameters and this render's vect
     float* a1;
     float2* a2;
     uint64_t* rng_state;      // [2 * n_tiles]: PCG state / inc between passes over the tile's rows
+    float2* arr;              // the integrator's 2-D sample array (AOIntegrator: arr_n points per pixel sample), nullptr / 0 for `path`
+    uint32_t arr_n;
+    uint32_t ao_cos_sample;
 };
 
-template <bool INST, bool ALPHA>
+// AO = false: PathIntegrator::li.  AO = true: AOIntegrator::li (ao.rs:50-96) with its sample array from the pixel sampler: closest hit, frame on
+// the true geometry, arr_n hemisphere directions from get_2d_array, one any-hit traversal each, the unoccluded terms added in array order.
+template <bool INST, bool ALPHA, bool AO = false>
 __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
                                                     uint32_t n_tiles, uint32_t lanes_per_wave, int32_t row0, int32_t row1, float4* __restrict__ samp_L,
                                                     float2* __restrict__ samp_pf, uint32_t max_iters, uint32_t* __restrict__ truncated) {
@@ -40,6 +45,7 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
     px.kind = pd.kind; px.spp = pd.spp; px.n_dims = pd.n_dims; px.nx = pd.nx; px.ny = pd.ny; px.jitter = pd.jitter; px.c_pixel = pd.c_pixel;
     px.a1 = pd.a1 + t; px.a2 = pd.a2 + t; px.stride = n_tiles;
     px.cur1 = px.cur2 = px.cur_s = 0;
+    px.arr = pd.arr ? pd.arr + t : nullptr; px.arr_n = pd.arr_n;
     if (row0 == 0) px.rng.set_sequence((uint64_t)tr.seed);  // tile_sampler.reseed(seed) (integrator.rs:114)
     else { px.rng.state = pd.rng_state[2 * (size_t)t]; px.rng.inc = pd.rng_state[2 * (size_t)t + 1]; }
     const uint32_t slot = t;   // the lane's own path slot
@@ -62,6 +68,44 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                 pb.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                 pb.state[slot] = ST_ALIVE;
                 pb.p_film[slot] = make_float2(p_film.x, p_film.y);
+                if (AO) {
+                    const TraceResult res = traverse<false, INST, ALPHA, 64>(sc, tt, o, d, t_max, lds);
+                    float l = 0.0f;
+                    if (res.prim != RSPT_MISS) {
+                        const TriRec tri = load_tri(sc, res.prim);
+                        TexHit h;   // the full interaction: li needs the geometric dpdu
+                        tri_fill_tex(sc, res.prim, tri, res.b0, res.b1, res.b2, &h);
+                        Hit hp;     // p_error for spawn_ray
+                        tri_fill(sc, res.prim, tri, res.b0, res.b1, res.b2, &hp);
+                        if (INST && res.inst && !sc.inst[res.inst - 1u].identity) { inst_texhit(sc.inst[res.inst - 1u], &h); inst_hit(sc.inst[res.inst - 1u], &hp); }
+                        const f3 n = faceforward(h.n, -d);
+                        const f3 sv = normalize(h.dpdu);
+                        const f3 tv = cross(h.n, sv);  // nrm_cross_vec3(&isect.common.n, &s)
+                        const uint32_t first = px.cur_s * px.arr_n;   // get_2d_array: the pixel sample's slice
+                        for (uint32_t j = 0; j < px.arr_n; j++) {
+                            const float2 uu = px.va(first + j);
+                            const f2 u{uu.x, uu.y};
+                            f3 wi;
+                            float pdf;
+                            if (pd.ao_cos_sample) { wi = cosine_hemisphere(u); pdf = fabsf(wi.z) * RSPT_INV_PI; }
+                            else {  // uniform_sample_hemisphere (sampling.rs:309-318)
+                                const float z = u.x, r = sqrtf(fmaxf(0.0f, 1.0f - z * z)), phi = 2.0f * RSPT_PI * u.y;
+                                wi = f3{r * rspt_cosf(phi), r * rspt_sinf(phi), z};
+                                pdf = 0.15915494309189533577f;
+                            }
+                            wi = f3{sv.x * wi.x + tv.x * wi.y + n.x * wi.z, sv.y * wi.x + tv.y * wi.y + n.y * wi.z, sv.z * wi.x + tv.z * wi.y + n.z * wi.z};
+                            if (pdf != 0.0f) {
+                                const TraceResult occ = traverse<true, INST, ALPHA, 64>(sc, tt, offset_ray_origin(hp.p, hp.p_err, hp.n, wi), wi, RSPT_INF, lds);
+                                if (occ.prim == RSPT_MISS) l += dot(wi, n) / (pdf * (float)px.arr_n);
+                            }
+                        }
+                    }
+                    const size_t out = (size_t)k * pd.spp + s;
+                    samp_L[out] = make_float4(l, l, l, 1.0f);
+                    samp_pf[out] = make_float2(p_film.x, p_film.y);
+                    px.start_next_sample();
+                    continue;
+                }
                 ShadeOut so{true, true, false, false};
                 for (uint32_t it = 0; so.active; it++) {
                     if (it >= max_iters) { atomicAdd(truncated, 1u); break; }   // the reference's loop over BSDF-less surfaces has no limit (path.rs:109-116)

@@ -164,10 +164,10 @@ def test_gpu_volpath_with_object_instances(gpu, oracle, mode):
     sb.add_mesh(PYR[:3] * np.float32(0.8), [[0, 1, 2]], red)
     sb.end_object()
     T = scenes.Transform
-    sb.add_instance("pyr", T(T.translate((-0.6, 0.4, 0.1)).m @ T.rotate_y(30.0).m))            # inside the fog
-    sb.add_instance("pyr", T(T.translate((0.7, 0.5, -0.3)).m @ T.scale(1.3, 0.8, 1.1).m))      # inside the fog
-    sb.add_instance("pyr", T(T.translate((2.9, 0.3, 0.4)).m))                                  # outside
-    sb.add_instance("one", T(T.translate((-2.6, 1.2, 0.0)).m))
+    sb.add_instance("pyr", T.translate((-0.6, 0.4, 0.1)) * T.rotate_y(30.0))                  # inside the fog
+    sb.add_instance("pyr", T.translate((0.7, 0.5, -0.3)) * T.scale(1.3, 0.8, 1.1))            # inside the fog
+    sb.add_instance("pyr", T.translate((2.9, 0.3, 0.4)))                                      # outside
+    sb.add_instance("one", T.translate((-2.6, 1.2, 0.0)))
     sb.add_instance("pyr", T.identity())                                                       # Q10
     sc = sb.finish(gpu.bvh_build, instancing=mode)
     rd = scenes.make_render_desc(64, 48, 16, LOOK, 55.0, integrator="volpath", max_depth=5)
