@@ -180,6 +180,8 @@ struct TraceResult {
     float t, b0, b1, b2;
     uint32_t nodes, tris;
     uint32_t inst;  // 0: a primitive of the scene's own aggregate; k + 1: inside instance k (prim = the object's primitive, t in the object ray's parameter)
+    float t_end;    // INST, closest hit: ray.t_max when the traversal ended — on a miss it can be shorter than it started: an identity instance
+                    // shrinks it without reporting its hit (Q10), and VolPathIntegrator::li samples the medium up to ray.t_max (volpath.rs:96-101)
 };
 
 // BVHAccel::intersect (bvh.rs:401-462) / intersect_p (:463-514): ordered depth-first traversal,
@@ -193,7 +195,7 @@ struct TraceResult {
 template <bool ANY, bool INST, bool ALPHA, int STRIDE = RSPT_TRACE_BLOCK /* words between two levels of the LDS stack = columns (threads per block) */>
 RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */) {
     TraceResult res;
-    res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0;
+    res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0; res.t_end = t_max;
     if (sc.n_nodes == 0) return res;
     f3 inv{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     bool ng0 = inv.x < 0.0f, ng1 = inv.y < 0.0f, ng2 = inv.z < 0.0f;
@@ -272,6 +274,7 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
         }
     }
     if (INST && !ANY && !hit) { res.prim = RSPT_MISS; res.inst = 0; res.t = res.b0 = res.b1 = res.b2 = 0.0f; }  // BVHAccel::intersect returns `hit`, not "isect was written"
+    res.t_end = t_max;
     return res;
 }
 
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTabl
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
             else {
-                (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+                (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), (INST && res.prim == RSPT_MISS) ? res.t_end : res.b0, res.b1, res.b2);  // a miss: .y = the ray's final t_max
                 if (INST && !mis && out_inst) out_inst[slot] = res.inst;
             }
         } else {

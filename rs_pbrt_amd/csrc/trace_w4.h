@@ -173,7 +173,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
         if (INST && !ANY && OUT_MODE == 0 && !(entry & RSPT_Q_MIS) && out_inst) out_inst[slot] = best_inst;
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = best == RSPT_RETRACE ? 2u : (best != RSPT_MISS ? 1u : 0u);
-            else ((entry & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(best), bb0, bb1, bb2);
+            else ((entry & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(best), (INST && best == RSPT_MISS) ? t_max : bb0, bb1, bb2);  // a miss: .y = the ray's final t_max (Q10)
         } else {
             rspt_hit h;
             h.prim = best; h.t = bt; h.b0 = bb0; h.b1 = bb1; h.b2 = bb2;

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, T
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
             else {
-                (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
+                (mis ? out_b : out_a)[slot] = make_float4(__uint_as_float(res.prim), (INST && res.prim == RSPT_MISS) ? res.t_end : res.b0, res.b1, res.b2);
                 if (INST && !mis && out_inst) out_inst[slot] = res.inst;
             }
         } else {

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                 // an instanced hit: the triangle lives in object space and ray.t_max is the OBJECT ray's parameter (TransformedPrimitive::intersect:
                 // r.t_max.set(ray.t_max), primitive.rs:224; Transform::transform_ray has moved the origin by its error bound)
                 const uint32_t hi = (hit && pb.hit_inst) ? pb.hit_inst[p] : 0u;
+                if (!hit && pb.hit_inst) t_hit = hc.y;   // no hit reported, but an identity instance may have shortened ray.t_max (Q10): the medium is sampled up to there
                 if (hit) {
                     tri = load_tri(sc, prim);
                     if (hi) {
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf 
                     again = true;
                 }
             } else {
-                if (medium) tr = tr * med_tr(sc.media[medium - 1u], t_max, len(d));
+                if (medium) tr = tr * med_tr(sc.media[medium - 1u], vb.hit_inst_tr ? hm.y : t_max, len(d));   // (with instances: ray.t_max as the traversal left it, Q10)
                 done = true;
             }
             if (done) {  // the tail of estimate_direct's first half (integrator.rs:461-476), uniform_sample_one_light's / pdf, l += beta * ..
