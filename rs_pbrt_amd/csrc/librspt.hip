@@ -184,6 +184,7 @@ struct rspt_scene_s {
     } mat_set[2];
     bool has_dynamic = false;         // (in the selected set) some material's lobe list is built per hit
     uint32_t shade_features = 0;      // SF_* (dev_bsdf.h) of everything the scene can put in front of the shade stage
+    uint32_t shade_classes = 1;       // distinct lobe-list shapes among the materials: K7b sorts the shade queue by material only when waves would differ
     void select_materials(bool allow_multiple_lobes) {
         const MatSet& m = mat_set[allow_multiple_lobes ? 0 : 1];
         dev.materials = m.materials; dev.bxdfs = m.bxdfs;
@@ -585,7 +586,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path and ao integrators only");
         if (d->integrator == RSPT_INTEGRATOR_AO && (d->sampler_kind == RSPT_SAMPLER_ZEROTWO || d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) && (d->ao_n_samples & (d->ao_n_samples - 1)) != 0)
             return fail(RSPT_E_INVALID, "ao: nsamples must be a power of two with the 02sequence / maxmindist samplers (request_2d_array asserts round_count(n) == n, zerotwosequence.rs:187-193)");
-        if (d->tile_size != 16 && d->tile_size > 255) return fail(RSPT_E_UNSUPPORTED, "tile_size > 255 with a pixel sampler");
+        if (d->tile_size > 255) return fail(RSPT_E_UNSUPPORTED, "tile_size > 255 with a pixel sampler");
         if (d->spp > 65536 || d->pixel_dimensions > 64) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: spp > 65536 or more than 64 sampled dimensions");
         if (d->sampler_kind == RSPT_SAMPLER_STRATIFIED && (d->strat_x == 0 || d->strat_y == 0 || (int64_t)d->strat_x * d->strat_y != d->spp))
             return fail(RSPT_E_INVALID, "stratified sampler: spp must equal strat_x * strat_y");
@@ -791,7 +792,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (volpath) HIP_TRY(hipMemsetAsync(g.vol.truncated, 0, sizeof(uint32_t), g.stream));
     // K7b: whole waves of one class (escaped | depth limit | material) for k_shade.  C3 stand-in (two materials): 1396 -> 1686 Msamples/s;
     // C2 (one material: only the escaped paths are separated): 423 -> 425
-    const bool shade_bins = env_size("RSPT_SHADE_BINS", 1) != 0 && !ao && !direct && !volpath;
+    // (measured with the specialised shade instantiations, profiles/r03_ab_shade.md: C3 stand-in — plastic statue on a matte ground — 1640 -> 1830
+    //  Msamples/s with the bins; C2 — one material, only escaped paths to separate — 468 -> 456: the sort runs when lobe lists differ)
+    const bool shade_bins = env_size("RSPT_SHADE_BINS", s->shade_classes > 1 ? 1 : 0) != 0 && !ao && !direct && !volpath;
     if (shade_bins && (rc = ensure_bins(g.cap, max_iters + 10))) return rc;
     if (s->has_instances && (rc = ensure_hit_inst(volpath ? 2 * g.cap : g.cap))) return rc;   // volpath: second half = the hits of the shadow-ray segments
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
@@ -1571,6 +1574,21 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         }
     for (int v = 0; v < 2; v++)
         for (const rspt_material& m : asm_mats[v]) if (m.bump_tex) shade_features |= SF_TEX;
+    uint32_t shade_classes = 0;
+    {   // materials whose lobe lists have the same types in the same order (and the same textured-ness) cost a wave the same
+        std::vector<std::string> seen;
+        for (uint32_t i = 0; i < d->n_materials; i++) {
+            const rspt_material& m = asm_mats[0][i];
+            std::string sig = asm_is_dyn[0][i] ? "dyn" : "";
+            for (uint32_t l = 0; l < m.n_bxdfs; l++) {
+                const rspt_bxdf& b = asm_bx[0][m.first_bxdf + l];
+                sig += (char)('a' + b.type); sig += (char)('0' + b.fresnel); sig += (b.tex_r || b.tex_t || b.tex_ax || b.tex_ay) ? 't' : 'c';
+            }
+            if (m.bump_tex) sig += 'B';
+            if (std::find(seen.begin(), seen.end(), sig) == seen.end()) seen.push_back(sig);
+        }
+        shade_classes = (uint32_t)seen.size();
+    }
     if (!asm_dyn[0].empty() || !asm_dyn[1].empty())  // a list built per hit may hold any lobe its material kind can push
         shade_features |= SF_DYNAMIC | SF_TEX | 0x3feu | SF_CONDUCTOR | SF_SC;
     for (uint32_t i = 0; i < d->n_lights; i++) {
@@ -1638,6 +1656,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     s->has_alpha = any_alpha;
     s->n_materials = d->n_materials;
     s->shade_features = shade_features;
+    s->shade_classes = shade_classes;
     auto bail = [&](int rc) {
         for (void* p : s->allocs) (void)hipFree(p);
         delete s;

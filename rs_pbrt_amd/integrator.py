@@ -164,13 +164,37 @@ class Checkpoint:
         f.pixels = self.sum.astype(np.float32).reshape(h, w, 4)
         return f
 
-    def save(self, path):
-        np.savez(path, sum=self.sum, next_sample=self.next_sample, spp=int(self.rd.spp), crop=np.array(self.rd.crop_px[:], np.int32),
-                 shard=np.array([self.rd.shard_index, self.rd.shard_count, self.rd.tile_chunk], np.uint32))
+    def _identity(self, scene_id):
+        """what the partial film is a film OF: every render parameter except the sample slice (pointer fields excluded: they are
+        per-process), plus the caller's scene identifier — a checkpoint of another scene, integrator, sampler, depth or camera must not
+        be summed with this one's samples"""
+        import ctypes as C
+        import hashlib
+        rd = abi.RenderDesc.from_buffer_copy(self.rd)
+        rd.sample_begin = rd.sample_count = 0
+        rd.n_light_samples = None; rd.maxmin_c_pixel = None
+        rd.tables = abi.SamplerTables()
+        h = hashlib.sha256(bytes(memoryview(rd).cast("B")))
+        ls = getattr(self.rd, "_light_samples", None)
+        if ls is not None:
+            h.update(ls.tobytes())
+        h.update(str(scene_id).encode())
+        return h.hexdigest()
 
-    def load(self, path):
-        z = np.load(path)
-        if int(z["spp"]) != int(self.rd.spp) or list(z["crop"]) != list(self.rd.crop_px[:]) or z["sum"].shape != self.sum.shape or \
-                list(z["shard"]) != [self.rd.shard_index, self.rd.shard_count, self.rd.tile_chunk]:
-            raise ValueError("checkpoint belongs to another frame (spp / crop window / shard differ)")
+    @staticmethod
+    def _path(path):
+        return str(path) if str(path).endswith(".npz") else str(path) + ".npz"
+
+    def save(self, path, scene_id=""):
+        """atomic (written beside the target, then renamed over it): a crash during save leaves the previous checkpoint intact"""
+        import os
+        path = self._path(path)
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, sum=self.sum, next_sample=self.next_sample, identity=self._identity(scene_id))
+        os.replace(tmp, path)
+
+    def load(self, path, scene_id=""):
+        z = np.load(self._path(path))
+        if str(z["identity"]) != self._identity(scene_id) or z["sum"].shape != self.sum.shape:
+            raise ValueError("checkpoint belongs to another render (scene / integrator / sampler / camera / film / shard differ)")
         self.sum, self.next_sample = z["sum"].astype(np.float64), int(z["next_sample"])
