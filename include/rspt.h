@@ -79,15 +79,25 @@ typedef struct {
     uint32_t medium_inside, medium_outside;
 } rspt_mesh; /* 32 B */
 
-/* ---- participating media (src/core/medium.rs, src/media/homogeneous.rs; MakeNamedMedium api.rs:953-1037) ----
- * sigma_a / sigma_s already multiplied by "scale"; sigma_t = sigma_s + sigma_a is formed by the library as HomogeneousMedium::new does.
- * The phase function is HenyeyGreenstein { g } (medium.rs:296-331).  GridDensityMedium ("heterogeneous") is not accelerated. */
-enum { RSPT_MEDIUM_HOMOGENEOUS = 1 };
+/* ---- participating media (src/core/medium.rs, src/media/{homogeneous,grid}.rs; MakeNamedMedium api.rs:953-1037) ----
+ * sigma_a / sigma_s already multiplied by "scale".  The phase function is HenyeyGreenstein { g } (medium.rs:296-331).
+ * HOMOGENEOUS: sigma_t = sigma_s + sigma_a is formed by the library as HomogeneousMedium::new does.
+ * GRID (GridDensityMedium, "heterogeneous"): density[nz][ny][nx] over the unit cube of medium space, world_to_medium = the
+ *   inverse of the medium's medium_to_world (Transform.m, row major).  sigma_t is the RED channel of sigma_a + sigma_s and the
+ *   majorant 1 / max(density), as GridDensityMedium::new computes them (grid.rs:30-56).  Its tr / sample draw one or two sampler
+ *   values per tracking step, so it is rendered under the pixel samplers only (each lane follows its tile's stream in program
+ *   order); with Sobol' / Halton — whose 1024 / 1000 dimensions such a walk exhausts within a bounce or two, where the reference
+ *   panics — rspt_render answers RSPT_E_UNSUPPORTED. */
+enum { RSPT_MEDIUM_HOMOGENEOUS = 1, RSPT_MEDIUM_GRID = 2 };
 typedef struct {
     uint32_t kind;
     float sigma_a[3], sigma_s[3];
     float g;
-} rspt_medium; /* 32 B */
+    int32_t nx, ny, nz;      /* GRID */
+    uint32_t pad;
+    const float* density;    /* GRID: nx * ny * nz floats, x fastest */
+    float world_to_medium[16];
+} rspt_medium; /* 120 B */
 
 /* ---- materials: the parameters of Material::create, assembled into BxDF lists by the library --------------------
  * Every parameter of a reference material is a texture (TextureParams::get_spectrum_texture / get_float_texture wrap a literal

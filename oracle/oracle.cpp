@@ -353,7 +353,11 @@ void orc_visibility_tr(const rspt_scene_desc* sd, const float p0[3], uint32_t me
     a.p_error = a.n = a.wo = b.p_error = b.n = b.wo = V3{0, 0, 0};
     a.p = V3{p0[0], p0[1], p0[2]}; a.med_in = a.med_out = medium0; a.is_medium = true;
     b.p = V3{p1[0], p1[1], p1[2]};
-    Spec tr = visibility_tr(sc, a, b, nullptr);
+    sc.prepare_media();
+    rspt_render_desc rd0{};            // (homogeneous media draw nothing; a grid medium would draw from this Sobol' sampler's dimension stream)
+    rd0.sampler_kind = RSPT_SAMPLER_SOBOL; rd0.spp = 1; rd0.sample_bounds[2] = rd0.sample_bounds[3] = 1;
+    Sampler smp(rd0);
+    Spec tr = visibility_tr(sc, a, b, smp, nullptr);
     tr_out[0] = tr.c[0]; tr_out[1] = tr.c[1]; tr_out[2] = tr.c[2];
 }
 

@@ -893,8 +893,7 @@ static inline Spec spec_exp(Spec a) { return Spec(std::exp(a.c[0]), std::exp(a.c
 static inline Spec medium_sigma_t(const rspt_medium& m) { // HomogeneousMedium::new homogeneous.rs:24-31: sigma_s + sigma_a
     return Spec(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) + Spec(m.sigma_a[0], m.sigma_a[1], m.sigma_a[2]);
 }
-static inline Spec medium_tr(const Scene& sc, const Ray& ray) { // Medium::tr medium.rs:277-283 -> HomogeneousMedium::tr homogeneous.rs:33-36
-    const rspt_medium& m = sc.d.media[ray.medium - 1];
+static inline Spec homogeneous_tr(const rspt_medium& m, const Ray& ray) { // HomogeneousMedium::tr homogeneous.rs:33-36
     Spec st = medium_sigma_t(m);
     Spec nst(-st.c[0], -st.c[1], -st.c[2]);
     return spec_exp(nst * std::fmin(ray.t_max * length(ray.d), std::numeric_limits<Float>::max()));
@@ -928,33 +927,9 @@ static inline Spec homogeneous_sample(const rspt_medium& m, uint32_t medium, con
     if (pdf == 0.0f) pdf = 1.0f; // (assert!(tr.is_black()))
     return sampled_medium ? tr * sigma_s / pdf : tr / pdf;
 }
-static inline Spec medium_sample(const Scene& sc, const Ray& ray, Sampler& sampler, Interaction* mi, bool* sampled) {
-    const Float u_channel = sampler.get_1d(); // :43
-    const Float u_dist = sampler.get_1d();    // :49
-    return homogeneous_sample(sc.d.media[ray.medium - 1], ray.medium, ray, u_channel, u_dist, mi, sampled);
-}
-// ---- GridDensityMedium (src/media/grid.rs): LEAF FUNCTIONS ONLY.  Not wired into volpath_li and not in the ABI yet: its tr / sample
-// draw a data-dependent number of sampler values inside estimate_direct, which only the pixel samplers' serial streams can follow
-// (DESIGN.md section 10 A).  `next_1d` stands for sampler.get_1d(). ----
-struct GridMedium {
-    Spec sigma_a, sigma_s;
-    Float g;
-    int32_t nx, ny, nz;
-    const Float* density;
-    Float world_to_medium[16];
-    Float sigma_t, inv_max_density;
-};
-static inline GridMedium grid_medium_new(const Float sigma_a[3], const Float sigma_s[3], Float g, int32_t nx, int32_t ny, int32_t nz, const Float world_to_medium[16], const Float* d) { // grid.rs:30-56
-    GridMedium m;
-    m.sigma_a = Spec(sigma_a[0], sigma_a[1], sigma_a[2]); m.sigma_s = Spec(sigma_s[0], sigma_s[1], sigma_s[2]);
-    m.g = g; m.nx = nx; m.ny = ny; m.nz = nz; m.density = d;
-    for (int i = 0; i < 16; i++) m.world_to_medium[i] = world_to_medium[i];
-    Float max_density = 0.0f;
-    for (int64_t i = 0; i < (int64_t)nx * ny * nz; i++) max_density = std::fmax(max_density, d[i]); // f32::max
-    m.sigma_t = (m.sigma_s + m.sigma_a).c[0]; // [RGBEnum::Red]
-    m.inv_max_density = 1.0f / max_density;
-    return m;
-}
+// ---- GridDensityMedium (src/media/grid.rs).  Its tr / sample draw a data-dependent number of sampler values — also in the middle of
+// estimate_direct — which only the pixel samplers' serial streams can follow for long (the dimension-indexed samplers panic past their
+// last dimension, sobol.rs:119-124).  `next_1d` stands for sampler.get_1d(). ----
 static inline Float grid_d(const GridMedium& m, int32_t x, int32_t y, int32_t z) { // :57-75 (pnt3i_inside_exclusive)
     if (!(x >= 0 && x < m.nx && y >= 0 && y < m.ny && z >= 0 && z < m.nz)) return 0.0f;
     return m.density[((size_t)z * m.ny + y) * m.nx + x];
@@ -1036,6 +1011,20 @@ static inline Spec grid_sample(const GridMedium& m, uint32_t medium, const Ray& 
     return Spec(1.0f);
 }
 
+// Medium::tr / Medium::sample (medium.rs:268-294): dispatch on the medium's kind
+static inline Spec medium_tr(const Scene& sc, const Ray& ray, Sampler& sampler) {
+    const rspt_medium& m = sc.d.media[ray.medium - 1];
+    if (m.kind == RSPT_MEDIUM_GRID) return grid_tr(sc.grid(ray.medium), ray, [&]() { return sampler.get_1d(); });
+    return homogeneous_tr(m, ray);
+}
+static inline Spec medium_sample(const Scene& sc, const Ray& ray, Sampler& sampler, Interaction* mi, bool* sampled) {
+    const rspt_medium& m = sc.d.media[ray.medium - 1];
+    if (m.kind == RSPT_MEDIUM_GRID) return grid_sample(sc.grid(ray.medium), ray.medium, ray, [&]() { return sampler.get_1d(); }, mi, sampled);
+    const Float u_channel = sampler.get_1d(); // homogeneous.rs:43
+    const Float u_dist = sampler.get_1d();    // :49
+    return homogeneous_sample(m, ray.medium, ray, u_channel, u_dist, mi, sampled);
+}
+
 static inline Float phase_hg(Float cos_theta, Float g) { // medium.rs:389-392
     const Float denom = 1.0f + g * g + 2.0f * g * cos_theta;
     return INV_4_PI * (1.0f - g * g) / (denom * std::sqrt(denom));
@@ -1055,7 +1044,7 @@ static inline Float hg_sample_p(Float g, V3 wo, V3* wi, P2 u) { // HenyeyGreenst
     return phase_hg(cos_theta, g);
 }
 // VisibilityTester::tr (light.rs:207-239)
-static inline Spec visibility_tr(const Scene& sc, const Interaction& p0, const Interaction& p1, Counters* c) {
+static inline Spec visibility_tr(const Scene& sc, const Interaction& p0, const Interaction& p1, Sampler& sampler, Counters* c) {
     Ray ray = p0.spawn_ray_to(p1);
     Spec tr(1.0f);
     for (;;) {
@@ -1063,10 +1052,10 @@ static inline Spec visibility_tr(const Scene& sc, const Interaction& p0, const I
         if (sc.intersect(ray, &isect, c)) {
             if (isect.prim >= 0) { // isect.primitive is Some (an instanced hit has lost it, Q11: then neither branch runs)
                 if (sc.d.prims[isect.prim].material != 0xffffffffu) return Spec();
-                if (ray.medium) tr = tr * medium_tr(sc, ray);
+                if (ray.medium) tr = tr * medium_tr(sc, ray, sampler);
             }
         } else {
-            if (ray.medium) tr = tr * medium_tr(sc, ray);
+            if (ray.medium) tr = tr * medium_tr(sc, ray, sampler);
             break;
         }
         ray = isect.spawn_ray_to(p1);
@@ -1074,17 +1063,17 @@ static inline Spec visibility_tr(const Scene& sc, const Interaction& p0, const I
     return tr;
 }
 // Scene::intersect_tr (scene.rs:79-106)
-static inline bool intersect_tr(const Scene& sc, Ray* ray, Interaction* isect, Spec* tr, Counters* c) {
+static inline bool intersect_tr(const Scene& sc, Ray* ray, Interaction* isect, Spec* tr, Sampler& sampler, Counters* c) {
     for (;;) {
         const bool hit_surface = sc.intersect(*ray, isect, c);
-        if (ray->medium) *tr = *tr * medium_tr(sc, *ray);
+        if (ray->medium) *tr = *tr * medium_tr(sc, *ray, sampler);
         if (!hit_surface) return false;
         if (isect->prim >= 0 && sc.d.prims[isect->prim].material != 0xffffffffu) return true;
         *ray = isect->spawn_ray(ray->d);
     }
 }
 // estimate_direct (integrator.rs:406-570) with handle_media = true, specular = false; `bsdf` is null for a medium interaction
-static inline Spec estimate_direct_media(RenderCtx& cx, const Interaction& it, const Bsdf* bsdf, P2 u_scattering, uint32_t light_num, P2 u_light, Counters* c) {
+static inline Spec estimate_direct_media(RenderCtx& cx, const Interaction& it, const Bsdf* bsdf, P2 u_scattering, uint32_t light_num, P2 u_light, Sampler& sampler, Counters* c) {
     const Scene& sc = *cx.scene;
     const rspt_light& light = sc.d.lights[light_num];
     const uint8_t flags = BSDF_ALL & ~BSDF_SPECULAR;
@@ -1104,7 +1093,7 @@ static inline Spec estimate_direct_media(RenderCtx& cx, const Interaction& it, c
             scattering_pdf = p;
         }
         if (!f.is_black()) {
-            li = li * visibility_tr(sc, it, light_intr, c); // handle_media (:462-463)
+            li = li * visibility_tr(sc, it, light_intr, sampler, c); // handle_media (:462-463)
             if (!li.is_black()) {
                 if (light_is_delta(light)) ld = ld + f * li / light_pdf;
                 else {
@@ -1140,7 +1129,7 @@ static inline Spec estimate_direct_media(RenderCtx& cx, const Interaction& it, c
             Interaction light_isect;
             Spec tr_spectrum; // Spectrum::default(): the transmittance intersect_tr multiplies into starts at ZERO (integrator.rs:531, scene.rs:86)
             if (c) c->mis_rays++;
-            const bool hit_surface = intersect_tr(sc, &ray, &light_isect, &tr_spectrum, c);
+            const bool hit_surface = intersect_tr(sc, &ray, &light_isect, &tr_spectrum, sampler, c);
             const Spec tr = tr_spectrum;
             if (hit_surface) {
                 found_surface_interaction = true;
@@ -1160,7 +1149,7 @@ static inline Spec uniform_sample_one_light_media(RenderCtx& cx, const Interacti
     if (pdf == 0.0f) return Spec();
     P2 u_light = sampler.get_2d();
     P2 u_scattering = sampler.get_2d();
-    return estimate_direct_media(cx, it, bsdf, u_scattering, (uint32_t)light_num, u_light, c) / pdf;
+    return estimate_direct_media(cx, it, bsdf, u_scattering, (uint32_t)light_num, u_light, sampler, c) / pdf;
 }
 
 // ---- VolPathIntegrator::li: src/integrators/volpath.rs:60-347 ----
@@ -1502,6 +1491,7 @@ struct RenderOut {
 // li_rgb (optional): radiance per camera sample, [(pixel*spp+s)*3] over crop_px.
 static inline void render(const Scene& scene, const rspt_render_desc& rd, int num_threads, float* film_xyzw, float* li_rgb, RenderOut* out,
                           int ext_integrator = ORC_INTEGRATOR_FROM_DESC, int direct_strategy = ORC_DIRECT_SAMPLE_ALL, const int32_t* n_light_samples = nullptr) {
+    scene.prepare_media();
     RenderCtx cx;
     cx.scene = &scene; cx.rd = &rd;
     cx.ext_integrator = ext_integrator; cx.direct_strategy = direct_strategy;

@@ -209,8 +209,40 @@ struct Scene;
 // Texture::evaluate of float texture `ti` at an interaction (orc_texture.hpp): TriangleMesh.alpha_mask / shadow_alpha_mask
 static inline Float alpha_texture_value(const Scene& sc, uint32_t ti, const Interaction& si);
 
+// GridDensityMedium (src/media/grid.rs:17-56) as built by ::new; the functions on it are in orc_render.hpp
+struct GridMedium {
+    Spec sigma_a, sigma_s;
+    Float g;
+    int32_t nx, ny, nz;
+    const Float* density;
+    Float world_to_medium[16];
+    Float sigma_t, inv_max_density;
+};
+static inline GridMedium grid_medium_new(const Float sigma_a[3], const Float sigma_s[3], Float g, int32_t nx, int32_t ny, int32_t nz, const Float world_to_medium[16], const Float* d) { // grid.rs:30-56
+    GridMedium m;
+    m.sigma_a = Spec(sigma_a[0], sigma_a[1], sigma_a[2]); m.sigma_s = Spec(sigma_s[0], sigma_s[1], sigma_s[2]);
+    m.g = g; m.nx = nx; m.ny = ny; m.nz = nz; m.density = d;
+    for (int i = 0; i < 16; i++) m.world_to_medium[i] = world_to_medium[i];
+    Float max_density = 0.0f;
+    for (int64_t i = 0; i < (int64_t)nx * ny * nz; i++) max_density = std::fmax(max_density, d[i]); // f32::max
+    m.sigma_t = (m.sigma_s + m.sigma_a).c[0]; // [RGBEnum::Red]
+    m.inv_max_density = 1.0f / max_density;
+    return m;
+}
+
 struct Scene {
     rspt_scene_desc d;
+    // GridDensityMedium::new runs once per medium when the scene is made (api.rs:1016-1030); prepare_media() before the first render / hook call
+    mutable std::vector<GridMedium> grids;
+    void prepare_media() const {
+        grids.clear();
+        for (uint32_t i = 0; i < d.n_media; i++) {
+            const rspt_medium& m = d.media[i];
+            if (m.kind == RSPT_MEDIUM_GRID) grids.push_back(grid_medium_new(m.sigma_a, m.sigma_s, m.g, m.nx, m.ny, m.nz, m.world_to_medium, m.density));
+            else grids.push_back(GridMedium{});
+        }
+    }
+    const GridMedium& grid(uint32_t medium) const { return grids[medium - 1]; }
     Bounds3 world_bound() const { // bvh.rs:394-400
         Bounds3 b;
         if (d.n_nodes) {

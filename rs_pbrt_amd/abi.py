@@ -16,7 +16,7 @@ LOBE_REMAP, LOBE_NODIFF = 1, 2
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 1, 2, 3, 4, 5
 SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_RANDOM, SAMPLER_ZEROTWO, SAMPLER_STRATIFIED, SAMPLER_MAXMINDIST = 1, 2, 3, 4, 5, 6
 INTEGRATOR_PATH, INTEGRATOR_AO, INTEGRATOR_DIRECT, INTEGRATOR_VOLPATH = 0, 1, 2, 3
-MEDIUM_HOMOGENEOUS = 1
+MEDIUM_HOMOGENEOUS, MEDIUM_GRID = 1, 2
 DIRECT_SAMPLE_ALL, DIRECT_SAMPLE_ONE = 0, 1
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 TEX_CONSTANT, TEX_IMAGE, TEX_SCALE, TEX_MIX, TEX_CHECKERBOARD, TEX_DOTS, TEX_FBM, TEX_MARBLE, TEX_WINDY, TEX_WRINKLED = range(1, 11)
@@ -43,7 +43,8 @@ class Mesh(C.Structure):
 
 
 class Medium(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float)]
+    _fields_ = [("kind", C.c_uint32), ("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float),
+                ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("pad", C.c_uint32), ("density", C.c_void_p), ("world_to_medium", C.c_float * 16)]
 
 
 class Bxdf(C.Structure):
@@ -149,7 +150,8 @@ NODE_DT = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), (
 PRIM_DT = np.dtype([("v", "<u4", 3), ("mesh", "<u4"), ("material", "<u4"), ("area_light", "<i4")])
 MESH_DT = np.dtype([("has_n", "<u4"), ("has_s", "<u4"), ("has_uv", "<u4"), ("flip", "<u4"), ("alpha_tex", "<u4"), ("shadow_alpha_tex", "<u4"),
                     ("medium_inside", "<u4"), ("medium_outside", "<u4")])
-MEDIUM_DT = np.dtype([("kind", "<u4"), ("sigma_a", "<f4", 3), ("sigma_s", "<f4", 3), ("g", "<f4")])
+MEDIUM_DT = np.dtype([("kind", "<u4"), ("sigma_a", "<f4", 3), ("sigma_s", "<f4", 3), ("g", "<f4"), ("nx", "<i4"), ("ny", "<i4"), ("nz", "<i4"), ("pad", "<u4"),
+                      ("density", "<u8"), ("world_to_medium", "<f4", 16)])
 BXDF_DT = np.dtype([("type", "<u4"), ("fresnel", "<u4"), ("r", "<f4", 3), ("t", "<f4", 3), ("eta_a", "<f4"), ("eta_b", "<f4"),
                     ("alpha_x", "<f4"), ("alpha_y", "<f4"), ("c1", "<f4", 3), ("c2", "<f4", 3), ("on_a", "<f4"), ("on_b", "<f4"),
                     ("sc", "<f4", 3), ("has_sc", "<u4"), ("tex_r", "<u4"), ("tex_t", "<u4"), ("tex_ax", "<u4"), ("tex_ay", "<u4"), ("remap", "<u4")])
@@ -165,6 +167,7 @@ RAY_DT = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("id", "<
 HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4")])
 
 assert NODE_DT.itemsize == C.sizeof(BvhNode) == 32
+assert MEDIUM_DT.itemsize == C.sizeof(Medium) == 120
 assert PRIM_DT.itemsize == C.sizeof(Prim) == 24
 assert BXDF_DT.itemsize == C.sizeof(Bxdf) == 116
 assert MATERIAL_DESC_DT.itemsize == C.sizeof(MaterialDesc) == 80

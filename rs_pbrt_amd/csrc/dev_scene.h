@@ -51,6 +51,7 @@ struct SceneDev {
     const rspt_medium* media;    // RenderOptions.named_media (VolPathIntegrator only; meshes[] carry the medium interfaces)
     uint32_t n_media;
     const rspt_mat::DynMaterial* dyn;  // per material, valid where mat_flags has RSPT_MAT_DYNAMIC (material_assembly.h); nullptr = none
+    uint32_t n_grid_media;       // GridDensityMedium records among media[] (their density pointers are device pointers, pad = 1 / max density as float bits)
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)
@@ -346,8 +347,7 @@ RDEV f3 xf_normal(const float* mi, f3 n) {
 }
 // Transform::inverse(primitive_to_world).transform_ray(r) (transform.rs:538-595 with transform_point_with_error :661-704):
 // origin and direction through m_inv, the origin pushed along d to the edge of its error bound, t_max shortened by the same dt
-RDEV void inst_ray(const InstDev& in, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) {
-    const float* m = in.mi;
+RDEV void xf_ray(const float* m /* 3 x 4, row major */, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) {
     const float x = o.x, y = o.y, z = o.z;
     f3 op{m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
     const f3 o_err = f3{fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]), fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]),
@@ -362,6 +362,7 @@ RDEV void inst_ray(const InstDev& in, f3 o, f3 d, float t_max, f3* oo, f3* od, f
     }
     *oo = op; *od = dd; *ot = t_max;
 }
+RDEV void inst_ray(const InstDev& in, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) { xf_ray(in.mi, o, d, t_max, oo, od, ot); }
 // Transform::transform_surface_interaction (transform.rs:815-860) on the fields the path needs: p with
 // transform_point_with_abs_error (:709-760), n / shading.n normalised, shading.n face-forwarded to n, shading.dpdu as a vector
 RDEV void inst_point(const float* m, f3 p, f3 pe, f3* po, f3* peo) {

@@ -582,8 +582,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (d->tile_size == 0 || d->tile_size > 4096) return fail(RSPT_E_INVALID, "bad tile_size");
     if (sobol && (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv)) return fail(RSPT_E_INVALID, "null sobol tables");
     if (pixel_sampler) {
-        if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO)
-            return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path and ao integrators only");
+        if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO && d->integrator != RSPT_INTEGRATOR_VOLPATH)
+            return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path, ao and volpath integrators only");
         if (d->integrator == RSPT_INTEGRATOR_AO && (d->sampler_kind == RSPT_SAMPLER_ZEROTWO || d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) && (d->ao_n_samples & (d->ao_n_samples - 1)) != 0)
             return fail(RSPT_E_INVALID, "ao: nsamples must be a power of two with the 02sequence / maxmindist samplers (request_2d_array asserts round_count(n) == n, zerotwosequence.rs:187-193)");
         if (d->tile_size > 255) return fail(RSPT_E_UNSUPPORTED, "tile_size > 255 with a pixel sampler");
@@ -708,6 +708,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     LightDistDev ld;
     const LightDist* ld_lazy = nullptr;  // on-demand voxels: a mark / build round in front of every shade launch
     if ((rc = get_light_dist(s, d->light_strategy, &ld, &ld_lazy))) return rc;
+    if (volpath && s->dev.n_grid_media && !pixel_sampler)
+        return fail(RSPT_E_UNSUPPORTED, "volpath with a grid-density medium under the Sobol' / Halton sampler: every tracking step draws sampler dimensions (the reference panics past "
+                                        "dimension 1024 / 1000 within a bounce or two); render it with a pixel sampler (random / 02sequence / stratified / maxmindist)");
     if (pixel_sampler && s->has_dynamic) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with a material whose lobe list depends on a texture");
     if (pixel_sampler && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
     if (volpath && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "volpath with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
@@ -1148,10 +1151,13 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             ev_open(2, 0);
 #define RSPT_TS(I, A, O) hipLaunchKernelGGL((k_tile_serial<I, A, O>), grid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, g.pb, pd, tiles_d, n_tiles, lanes, r0, r1, samp_L, samp_pf, serial_iters, trunc_d)
             if (ao) {
-                if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, true); else RSPT_TS(true, false, true); }
-                else { if (s->has_alpha) RSPT_TS(false, true, true); else RSPT_TS(false, false, true); }
-            } else if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, false); else RSPT_TS(true, false, false); }
-            else { if (s->has_alpha) RSPT_TS(false, true, false); else RSPT_TS(false, false, false); }
+                if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 1); else RSPT_TS(true, false, 1); }
+                else { if (s->has_alpha) RSPT_TS(false, true, 1); else RSPT_TS(false, false, 1); }
+            } else if (volpath) {
+                if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 2); else RSPT_TS(true, false, 2); }
+                else { if (s->has_alpha) RSPT_TS(false, true, 2); else RSPT_TS(false, false, 2); }
+            } else if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 0); else RSPT_TS(true, false, 0); }
+            else { if (s->has_alpha) RSPT_TS(false, true, 0); else RSPT_TS(false, false, 0); }
 #undef RSPT_TS
             ev_close(2, 0);
             const uint32_t npx = (uint32_t)pl.size();
@@ -1484,7 +1490,12 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if (d->n_media && !d->media) return fail(RSPT_E_INVALID, "null media");
     for (uint32_t i = 0; i < d->n_media; i++) {
         const rspt_medium& m = d->media[i];
-        if (m.kind != RSPT_MEDIUM_HOMOGENEOUS) return fail(RSPT_E_UNSUPPORTED, "medium %u: kind %u (homogeneous media only)", i, m.kind);
+        if (m.kind != RSPT_MEDIUM_HOMOGENEOUS && m.kind != RSPT_MEDIUM_GRID) return fail(RSPT_E_UNSUPPORTED, "medium %u: kind %u (homogeneous and grid-density media)", i, m.kind);
+        if (m.kind == RSPT_MEDIUM_GRID) {
+            if (m.nx < 1 || m.ny < 1 || m.nz < 1 || (uint64_t)m.nx * m.ny * m.nz > (1ull << 31) || !m.density) return fail(RSPT_E_INVALID, "medium %u: bad density grid", i);
+            const float* w = m.world_to_medium;
+            if (w[12] != 0.0f || w[13] != 0.0f || w[14] != 0.0f || w[15] != 1.0f) return fail(RSPT_E_UNSUPPORTED, "medium %u: projective world_to_medium", i);
+        }
         for (int c = 0; c < 3; c++)
             if (!(m.sigma_a[c] >= 0.0f) || !(m.sigma_s[c] >= 0.0f) || !std::isfinite(m.sigma_a[c]) || !std::isfinite(m.sigma_s[c])) return fail(RSPT_E_INVALID, "medium %u: bad sigma_a / sigma_s", i);
         if (!(m.g > -1.0f && m.g < 1.0f)) return fail(RSPT_E_INVALID, "medium %u: g outside (-1, 1)", i);
@@ -1670,7 +1681,22 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((rc = upload(s, d->prims, d->n_prims, &s->dev.prims))) return bail(rc);
     if ((rc = upload(s, d->meshes, d->n_meshes, &meshes_d))) return bail(rc);
     s->dev.meshes = meshes_d;
-    if ((rc = upload(s, d->media, d->n_media, &s->dev.media))) return bail(rc);
+    {   // media: a grid medium's density goes to the device, its record gets the device pointer and 1 / max(density) (GridDensityMedium::new, grid.rs:44-55)
+        std::vector<rspt_medium> media(d->media, d->media + d->n_media);
+        for (rspt_medium& m : media) {
+            if (m.kind != RSPT_MEDIUM_GRID) continue;
+            const size_t n = (size_t)m.nx * m.ny * m.nz;
+            float max_density = 0.0f;
+            for (size_t k = 0; k < n; k++) max_density = std::fmax(max_density, m.density[k]);   // f32::max
+            const float inv_max = 1.0f / max_density;
+            memcpy(&m.pad, &inv_max, sizeof inv_max);
+            const float* dens_d = nullptr;
+            if ((rc = upload(s, m.density, n, &dens_d))) return bail(rc);
+            m.density = dens_d;
+            s->dev.n_grid_media++;
+        }
+        if ((rc = upload(s, media.data(), media.size(), &s->dev.media))) return bail(rc);
+    }
     s->dev.n_media = d->n_media;
     if ((rc = upload(s, d->P, d->n_vertices * 3, &P_d))) return bail(rc);
     if ((rc = upload(s, d->N, d->N ? d->n_vertices * 3 : 0, &s->dev.N))) return bail(rc);

@@ -9,7 +9,7 @@
 // (lanes_per_wave, host-chosen: few tiles -> one lane per wave, so that no lane waits for a diverged neighbour).
 // Radiance and film position of every sample go to arrays that k_film then splats exactly as it does for the wavefront batches.
 #pragma once
-#include "kernels.h"
+#include "vol_serial.h"
 
 namespace rspt {
 
@@ -30,9 +30,10 @@ struct PixDesc {              // the sampler's parameters and this render's vect
     uint32_t ao_cos_sample;
 };
 
-// AO = false: PathIntegrator::li.  AO = true: AOIntegrator::li (ao.rs:50-96) with its sample array from the pixel sampler: closest hit, frame on
-// the true geometry, arr_n hemisphere directions from get_2d_array, one any-hit traversal each, the unoccluded terms added in array order.
-template <bool INST, bool ALPHA, bool AO = false>
+// MODE 0: PathIntegrator::li.  1: AOIntegrator::li (ao.rs:50-96) with its sample array from the pixel sampler: closest hit, frame on the true
+// geometry, arr_n hemisphere directions from get_2d_array, one any-hit traversal each, the unoccluded terms added in array order.
+// 2: VolPathIntegrator::li (vol_serial.h), homogeneous and grid media.
+template <bool INST, bool ALPHA, int MODE = 0>
 __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
                                                     uint32_t n_tiles, uint32_t lanes_per_wave, int32_t row0, int32_t row1, float4* __restrict__ samp_L,
                                                     float2* __restrict__ samp_pf, uint32_t max_iters, uint32_t* __restrict__ truncated) {
@@ -68,7 +69,17 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                 pb.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                 pb.state[slot] = ST_ALIVE;
                 pb.p_film[slot] = make_float2(p_film.x, p_film.y);
-                if (AO) {
+                if (MODE == 2) {
+                    VolSerial<INST, ALPHA> vs{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false};
+                    const rgb l = vs.li(o, d, t_max, p_film, p_lens);
+                    if (vs.truncated) atomicAdd(truncated, 1u);
+                    const size_t out = (size_t)k * pd.spp + s;
+                    samp_L[out] = make_float4(l.r, l.g, l.b, 1.0f);
+                    samp_pf[out] = make_float2(p_film.x, p_film.y);
+                    px.start_next_sample();
+                    continue;
+                }
+                if (MODE == 1) {
                     const TraceResult res = traverse<false, INST, ALPHA, 64>(sc, tt, o, d, t_max, lds);
                     float l = 0.0f;
                     if (res.prim != RSPT_MISS) {

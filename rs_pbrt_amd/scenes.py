@@ -609,6 +609,24 @@ class SceneBuilder:
         self.media.append(md)
         return len(self.media)   # 1 + index, what rspt_mesh.medium_inside / _outside hold
 
+    def add_grid_medium(self, density, p0=(0.0, 0.0, 0.0), p1=(1.0, 1.0, 1.0), sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77), g=0.0, scale=1.0,
+                        medium_to_world=None):
+        """MakeNamedMedium "heterogeneous" (api.rs:980-1030): density[nz][ny][nx] between p0 and p1 of medium space; GridDensityMedium::new gets
+        medium_to_world * (translate(p0) * scale(p1 - p0)) and keeps its inverse.  Returns the handle add_mesh's `medium=` takes."""
+        d = np.ascontiguousarray(density, F32)
+        assert d.ndim == 3
+        data_to_medium = Transform.translate(p0) * Transform.scale(F32(p1[0]) - F32(p0[0]), F32(p1[1]) - F32(p0[1]), F32(p1[2]) - F32(p0[2]))
+        m2w = (Transform.identity() if medium_to_world is None else medium_to_world) * data_to_medium
+        md = np.zeros((), abi.MEDIUM_DT)
+        md["kind"] = abi.MEDIUM_GRID; md["g"] = F32(g)
+        md["sigma_a"] = np.array(sigma_a, F32) * F32(scale); md["sigma_s"] = np.array(sigma_s, F32) * F32(scale)
+        md["nz"], md["ny"], md["nx"] = d.shape
+        md["density"] = d.ctypes.data
+        md["world_to_medium"] = m2w.inverse().m.reshape(-1)
+        self._grid_keep = getattr(self, "_grid_keep", []) + [d]   # the ABI copies at rspt_scene_create; until then the array must live
+        self.media.append(md)
+        return len(self.media)
+
     def add_mesh(self, P, idx, material, N=None, UV=None, emit=None, two_sided=False, flip=False, alpha=None, shadow_alpha=None, medium=(None, None)):
         """P (nv,3) world-space vertices; idx (nt,3); emit = rgb L or None; alpha / shadow_alpha: float textures (TexRef) of the
         shape's "alpha" / "shadowalpha" parameters (api.rs:1920-1965): where they evaluate to 0 the surface is not there.

@@ -15,8 +15,9 @@ pub struct RsptPrim { pub v: [u32; 3], pub mesh: u32, pub material: u32, pub are
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptMesh { pub has_n: u32, pub has_s: u32, pub has_uv: u32, pub flip: u32, pub alpha_tex: u32, pub shadow_alpha_tex: u32,
                       pub medium_inside: u32, pub medium_outside: u32 }   // 0 = none, else 1 + index into media
-#[repr(C)] #[derive(Clone, Copy, Default)]
-pub struct RsptMedium { pub kind: u32, pub sigma_a: [f32; 3], pub sigma_s: [f32; 3], pub g: f32 }   // kind 1 = HomogeneousMedium
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct RsptMedium { pub kind: u32, pub sigma_a: [f32; 3], pub sigma_s: [f32; 3], pub g: f32,                 // kind 1 = HomogeneousMedium
+                        pub nx: i32, pub ny: i32, pub nz: i32, pub pad: u32, pub density: *const f32, pub world_to_medium: [f32; 16] }   // kind 2 = GridDensityMedium
 /// rspt_material_desc: kind (1 matte 2 plastic 3 mirror 4 glass 5 metal 6 substrate 7 uber 8 translucent 9 mix) and, per parameter,
 /// 0 (absent) or 1 + index of its texture record — a ConstantTexture for a literal value, as TextureParams builds one
 #[repr(C)] #[derive(Clone, Copy, Default)]

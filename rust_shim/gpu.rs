@@ -77,8 +77,11 @@ impl Flat {
         let key = Arc::as_ptr(m);
         if let Some(i) = self.medium_of.get(&key) { return Ok(*i); }
         let md = match &**m {
-            Medium::Homogeneous(h) => RsptMedium { kind: 1, sigma_a: rgb(&h.sigma_a), sigma_s: rgb(&h.sigma_s), g: h.g },
-            _ => return Err("heterogeneous medium".into()),
+            Medium::Homogeneous(h) => RsptMedium { kind: 1, sigma_a: rgb(&h.sigma_a), sigma_s: rgb(&h.sigma_s), g: h.g,
+                                                   nx: 0, ny: 0, nz: 0, pad: 0, density: std::ptr::null(), world_to_medium: [0.0; 16] },
+            // GridDensityMedium (grid.rs:17-56): the density Arc stays alive in the scene for the duration of the call; the library copies it
+            Medium::GridDensity(gd) => RsptMedium { kind: 2, sigma_a: rgb(&gd.sigma_a), sigma_s: rgb(&gd.sigma_s), g: gd.g, nx: gd.nx, ny: gd.ny, nz: gd.nz, pad: 0,
+                                                    density: gd.density.as_ptr(), world_to_medium: m16(&gd.world_to_medium.m) },
         };
         self.media.push(md);
         self.medium_of.insert(key, self.media.len() as u32);
