@@ -582,8 +582,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (d->tile_size == 0 || d->tile_size > 4096) return fail(RSPT_E_INVALID, "bad tile_size");
     if (sobol && (!d->tables.sobol32 || !d->tables.vdc || !d->tables.vdc_inv)) return fail(RSPT_E_INVALID, "null sobol tables");
     if (pixel_sampler) {
-        if (d->integrator != RSPT_INTEGRATOR_PATH && d->integrator != RSPT_INTEGRATOR_AO && d->integrator != RSPT_INTEGRATOR_VOLPATH)
-            return fail(RSPT_E_UNSUPPORTED, "the pixel samplers (random / 02sequence / stratified / maxmindist) are built for the path, ao and volpath integrators only");
+        if (d->integrator == RSPT_INTEGRATOR_DIRECT && d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL && (d->sampler_kind == RSPT_SAMPLER_ZEROTWO || d->sampler_kind == RSPT_SAMPLER_MAXMINDIST))
+            for (uint32_t i = 0; s && d->n_light_samples && i < s->dev.n_lights; i++)
+                if (d->n_light_samples[i] < 1 || (d->n_light_samples[i] & (d->n_light_samples[i] - 1)) != 0)
+                    return fail(RSPT_E_INVALID, "directlighting: n_light_samples[%u] must be a power of two with the 02sequence / maxmindist samplers (preprocess passes it through round_count, directlighting.rs:58-60)", i);
         if (d->integrator == RSPT_INTEGRATOR_AO && (d->sampler_kind == RSPT_SAMPLER_ZEROTWO || d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) && (d->ao_n_samples & (d->ao_n_samples - 1)) != 0)
             return fail(RSPT_E_INVALID, "ao: nsamples must be a power of two with the 02sequence / maxmindist samplers (request_2d_array asserts round_count(n) == n, zerotwosequence.rs:187-193)");
         if (d->tile_size > 255) return fail(RSPT_E_UNSUPPORTED, "tile_size > 255 with a pixel sampler");
@@ -600,7 +602,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
     const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
     if (direct) {
-        if (d->max_depth < 1 || d->max_depth > 8) return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, 8] (the specular tree has 2^max_depth slots per camera sample)");
+        if (d->max_depth < 1 || d->max_depth > (pixel_sampler ? (uint32_t)RSPT_DL_SERIAL_DEPTH : 8u))
+            return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, 8] under Sobol' / Halton (the specular tree has 2^max_depth slots per camera sample), [1, %d] under a pixel sampler (one lane walks the tree)", RSPT_DL_SERIAL_DEPTH);
         if (d->direct_strategy > RSPT_DIRECT_SAMPLE_ONE) return fail(RSPT_E_INVALID, "bad direct_strategy");
         if (s && s->has_textures) return fail(RSPT_E_UNSUPPORTED, "directlighting with textured materials");
         for (uint32_t i = 0; s && d->n_light_samples && i < s->dev.n_lights; i++)
@@ -769,7 +772,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const bool ao = d->integrator == RSPT_INTEGRATOR_AO;
     const uint32_t ao_n = ao ? d->ao_n_samples : 1u;
     if (ao) cap = std::max<size_t>(cap / ao_n, 1024);
-    const uint32_t dl_H = direct ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h)
+    const uint32_t dl_H = (direct && !pixel_sampler) ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h; a pixel sampler's lane walks the tree itself)
     if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << 26) / dl_H, 1024);
     if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
@@ -779,7 +782,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
         pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
         rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H);
-        if (rc == RSPT_OK && direct) rc = ensure_direct(g.cap);
+        if (rc == RSPT_OK && direct && !pixel_sampler) rc = ensure_direct(g.cap);
         if (rc == RSPT_OK && volpath) rc = ensure_vol(g.cap);
         if (rc == RSPT_OK) break;
         (void)hipGetLastError();  // out of memory: clear the sticky error and try half the batch
@@ -1115,9 +1118,28 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         struct Guard { std::vector<void*> p; ~Guard() { for (void* q : p) (void)hipFree(q); } } guard;
         auto tmp = [&](auto** p, size_t n) { int r = dev_alloc(p, std::max<size_t>(n, 1)); if (!r) guard.p.push_back(*p); return r; };
         TileRec* tiles_d = nullptr; float4* samp_L = nullptr; float2* samp_pf = nullptr; float* a1 = nullptr; float2* a2 = nullptr; uint64_t* rng_state = nullptr;
-        float2* arr = nullptr;
-        const uint32_t arr_n = ao ? d->ao_n_samples : 0u;   // AOIntegrator::preprocess: request_2d_array(n_samples) (ao.rs:47-49)
-        if (arr_n && (rc = tmp(&arr, (size_t)arr_n * spp * n_tiles))) return rc;
+        // the integrator's 2-D sample arrays (request_2d_array in preprocess): ao one of n_samples (ao.rs:47-49); directlighting, strategy all,
+        // two per light and recursion level (directlighting.rs:54-70)
+        float2* arr = nullptr; uint32_t* arr_sz_d = nullptr; uint32_t* arr_base_d = nullptr; int32_t* nls_d = nullptr;
+        std::vector<uint32_t> arr_sz;
+        if (ao) arr_sz.push_back(d->ao_n_samples);
+        if (direct && d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL)
+            for (uint32_t lvl = 0; lvl < d->max_depth; lvl++)
+                for (uint32_t j = 0; j < s->dev.n_lights; j++) { const uint32_t n = d->n_light_samples ? (uint32_t)d->n_light_samples[j] : 1u; arr_sz.push_back(n); arr_sz.push_back(n); }
+        std::vector<uint32_t> arr_base(arr_sz.size());
+        uint32_t arr_total = 0;
+        for (size_t a = 0; a < arr_sz.size(); a++) { arr_base[a] = arr_total * spp; arr_total += arr_sz[a]; }
+        if ((size_t)arr_total * spp * n_tiles > ((size_t)1 << 31)) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: %u sample-array points x %u spp x %u tiles", arr_total, spp, n_tiles);
+        if (!arr_sz.empty()) {
+            if ((rc = tmp(&arr, (size_t)arr_total * spp * n_tiles)) || (rc = tmp(&arr_sz_d, arr_sz.size())) || (rc = tmp(&arr_base_d, arr_sz.size()))) return rc;
+            HIP_TRY(hipMemcpyAsync(arr_sz_d, arr_sz.data(), arr_sz.size() * 4, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipMemcpyAsync(arr_base_d, arr_base.data(), arr_base.size() * 4, hipMemcpyHostToDevice, g.stream));
+        }
+        if (direct && d->n_light_samples && s->dev.n_lights) {
+            if ((rc = tmp(&nls_d, s->dev.n_lights))) return rc;
+            HIP_TRY(hipMemcpyAsync(nls_d, d->n_light_samples, s->dev.n_lights * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));   // (the caller's array, and the vectors above, must outlive the copies)
+        }
         uint32_t* c_pixel_d = nullptr; uint32_t* trunc_d = nullptr; uint32_t* pass_pix = nullptr;
         const size_t max_samples = (size_t)n_tiles * rows * ts * spp;
         if ((rc = tmp(&tiles_d, n_tiles)) || (rc = tmp(&samp_L, max_samples)) || (rc = tmp(&samp_pf, max_samples)) || (rc = tmp(&a1, (size_t)nd * spp * n_tiles)) ||
@@ -1126,7 +1148,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             return rc;
         HIP_TRY(hipMemsetAsync(trunc_d, 0, sizeof(uint32_t), g.stream));
         if (d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) HIP_TRY(hipMemcpyAsync(c_pixel_d, d->maxmin_c_pixel, 32 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_n, d->ao_cos_sample};
+        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_sz_d, arr_base_d, (uint32_t)arr_sz.size(), arr_total, d->ao_cos_sample, nls_d, d->direct_strategy};
         // lanes per wave: a lane that shares its wave waits whenever the others diverge, so spread the tiles over as many waves
         // as the chip holds (256 CUs x 4 SIMDs x 2) before doubling up
         uint32_t lanes = 1;
@@ -1156,6 +1178,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             } else if (volpath) {
                 if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 2); else RSPT_TS(true, false, 2); }
                 else { if (s->has_alpha) RSPT_TS(false, true, 2); else RSPT_TS(false, false, 2); }
+            } else if (direct) {
+                if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 3); else RSPT_TS(true, false, 3); }
+                else { if (s->has_alpha) RSPT_TS(false, true, 3); else RSPT_TS(false, false, 3); }
             } else if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 0); else RSPT_TS(true, false, 0); }
             else { if (s->has_alpha) RSPT_TS(false, true, 0); else RSPT_TS(false, false, 0); }
 #undef RSPT_TS

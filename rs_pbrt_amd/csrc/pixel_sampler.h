@@ -82,19 +82,35 @@ struct PixSampler {
         for (uint32_t i = 0; i < spp; i++) (void)rng.bounded(1u);  // Q3: shuffle(samples, 1, 1) spp times, all on element 0
         shuffle2(d, spp);
     }
-    // ---- the 2-D sample ARRAY an integrator's preprocess asked for (request_2d_array; AOIntegrator: one array of arr_n points per pixel
-    // sample, ao.rs:47-49): flat element e = sample * arr_n + j at arr[e * stride]; refilled by every start_pixel after the vectors, from
-    // the same stream (zerotwosequence.rs:131-148, maxmin.rs:137-152, stratified.rs:137-160, random.rs:64-77) ----
+    // ---- the 2-D sample ARRAYS an integrator's preprocess asked for (request_2d_array; AOIntegrator: one array of n points per pixel sample,
+    // ao.rs:47-49; DirectLightingIntegrator, strategy all: two per light and recursion level, directlighting.rs:54-70).  Array a holds
+    // arr_sz[a] points per pixel sample: its flat element e = sample * arr_sz[a] + j lives at arr[(arr_base[a] + e) * stride], arr_base[a] =
+    // spp * (sizes before a).  All arrays are refilled by every start_pixel after the vectors, in request order, from the same stream
+    // (zerotwosequence.rs:131-148, maxmin.rs:137-152, stratified.rs:137-160, random.rs:64-77) ----
     float2* arr;
-    uint32_t arr_n;
+    const uint32_t* arr_sz;    // [n_arr]
+    const uint32_t* arr_base;  // [n_arr]
+    uint32_t n_arr, arr_cur;   // arr_cur: array_2d_offset (get_2d_array hands the arrays out in order, start_next_sample rewinds)
     RDEV float2& va(uint32_t e) const { return arr[(size_t)e * stride]; }
-    RDEV void fill_array() {
+    // get_2d_array_idxs (zerotwosequence.rs:208-218): false when the requested arrays are used up; *first = the pixel sample's slice
+    RDEV bool get_2d_array(uint32_t* first, uint32_t* count) {
+        if (arr_cur == n_arr) return false;
+        *count = arr_sz[arr_cur];
+        *first = arr_base[arr_cur] + cur_s * arr_sz[arr_cur];
+        arr_cur++;
+        return true;
+    }
+    RDEV void fill_arrays() {
+        for (uint32_t a = 0; a < n_arr; a++) fill_array(arr_base[a], arr_sz[a]);
+        arr_cur = 0;
+    }
+    RDEV void fill_array(uint32_t base, uint32_t arr_n) {
         if (!arr_n) return;
         const uint32_t total = arr_n * spp;
         if (kind == RSPT_SAMPLER_ZEROTWO || kind == RSPT_SAMPLER_MAXMINDIST) {  // sobol_2d(arr_n, spp, ..) (lowdiscrepancy.rs:919-1010)
             uint32_t x = rng.u32(), y = rng.u32();
             for (uint32_t i = 0; i < total; i++) {
-                va(i) = make_float2(fminf((float)x * 0x1.0p-32f, RSPT_ONE_MINUS_EPS), fminf((float)y * 0x1.0p-32f, RSPT_ONE_MINUS_EPS));
+                va(base + i) = make_float2(fminf((float)x * 0x1.0p-32f, RSPT_ONE_MINUS_EPS), fminf((float)y * 0x1.0p-32f, RSPT_ONE_MINUS_EPS));
                 const uint32_t tz = (uint32_t)__builtin_ctz(i + 1u);
                 x ^= 0x80000000u >> tz;
                 uint32_t c = 0x80000000u;
@@ -104,16 +120,18 @@ struct PixSampler {
             for (uint32_t i = 0; i < spp; i++)   // Q3: shuffle(samples, arr_n, 1) spp times, every time on the FIRST arr_n elements
                 for (uint32_t k = 0; k < arr_n; k++) {
                     const uint32_t other = k + rng.bounded(arr_n - k);
-                    const float2 t = va(k); va(k) = va(other); va(other) = t;
+                    const float2 t = va(base + k); va(base + k) = va(base + other); va(base + other) = t;
                 }
             for (uint32_t i = 0; i < spp; i++) {   // shuffle(samples, spp, arr_n): whole blocks
                 const uint32_t other = i + rng.bounded(spp - i);
-                for (uint32_t j = 0; j < arr_n; j++) { const float2 t = va(arr_n * i + j); va(arr_n * i + j) = va(arr_n * other + j); va(arr_n * other + j) = t; }
+                for (uint32_t j = 0; j < arr_n; j++) {
+                    const float2 t = va(base + arr_n * i + j); va(base + arr_n * i + j) = va(base + arr_n * other + j); va(base + arr_n * other + j) = t;
+                }
             }
         } else if (kind == RSPT_SAMPLER_STRATIFIED) {  // latin_hypercube per pixel sample (stratified.rs:150-159, sampling.rs:273-306)
             const float inv_n = 1.0f / (float)arr_n;
             for (uint32_t s = 0; s < spp; s++) {
-                const uint32_t b = s * arr_n;
+                const uint32_t b = base + s * arr_n;
                 for (uint32_t i = 0; i < arr_n; i++) {
                     const float sx = ((float)i + rng.f32()) * inv_n;
                     const float sy = ((float)i + rng.f32()) * inv_n;
@@ -129,12 +147,12 @@ struct PixSampler {
                     }
             }
         } else {  // random.rs:70-76: x first
-            for (uint32_t i = 0; i < total; i++) { const float x = rng.f32(); const float y = rng.f32(); va(i) = make_float2(x, y); }
+            for (uint32_t i = 0; i < total; i++) { const float x = rng.f32(); const float y = rng.f32(); va(base + i) = make_float2(x, y); }
         }
     }
     RDEV void start_pixel() {
         start_pixel_vectors();
-        fill_array();
+        fill_arrays();
         cur_s = 0;
     }
     RDEV void start_pixel_vectors() {
@@ -184,7 +202,7 @@ struct PixSampler {
         const float y = rng.f32(); const float x = rng.f32();  // Q4: y first (zerotwosequence.rs:178-181, stratified.rs:187-190, maxmin.rs:185-188)
         return f2{x, y};
     }
-    RDEV void start_next_sample() { cur1 = 0; cur2 = 0; cur_s += 1; }
+    RDEV void start_next_sample() { cur1 = 0; cur2 = 0; arr_cur = 0; cur_s += 1; }
 };
 
 // what shade_path draws its samples from: the global samplers' dimension stream (k_shade: PIX = false, identical code to before)

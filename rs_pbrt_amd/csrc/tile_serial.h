@@ -9,7 +9,7 @@
 // (lanes_per_wave, host-chosen: few tiles -> one lane per wave, so that no lane waits for a diverged neighbour).
 // Radiance and film position of every sample go to arrays that k_film then splats exactly as it does for the wavefront batches.
 #pragma once
-#include "vol_serial.h"
+#include "dl_serial.h"
 
 namespace rspt {
 
@@ -25,14 +25,18 @@ struct PixDesc {              // the sampler's parameters and this render's vect
     float* a1;
     float2* a2;
     uint64_t* rng_state;      // [2 * n_tiles]: PCG state / inc between passes over the tile's rows
-    float2* arr;              // the integrator's 2-D sample array (AOIntegrator: arr_n points per pixel sample), nullptr / 0 for `path`
-    uint32_t arr_n;
+    float2* arr;              // the integrator's 2-D sample arrays (pixel_sampler.h), nullptr / 0 for `path` and `volpath`
+    const uint32_t* arr_sz;
+    const uint32_t* arr_base;
+    uint32_t n_arr, arr_total;   // arr_total: points per pixel sample over all arrays
     uint32_t ao_cos_sample;
+    const int32_t* n_light_samples;   // directlighting, strategy all: per light (device copy), nullptr = 1 each
+    uint32_t direct_strategy;
 };
 
 // MODE 0: PathIntegrator::li.  1: AOIntegrator::li (ao.rs:50-96) with its sample array from the pixel sampler: closest hit, frame on the true
 // geometry, arr_n hemisphere directions from get_2d_array, one any-hit traversal each, the unoccluded terms added in array order.
-// 2: VolPathIntegrator::li (vol_serial.h), homogeneous and grid media.
+// 2: VolPathIntegrator::li (vol_serial.h), homogeneous and grid media.  3: DirectLightingIntegrator::li (dl_serial.h).
 template <bool INST, bool ALPHA, int MODE = 0>
 __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
                                                     uint32_t n_tiles, uint32_t lanes_per_wave, int32_t row0, int32_t row1, float4* __restrict__ samp_L,
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
     px.kind = pd.kind; px.spp = pd.spp; px.n_dims = pd.n_dims; px.nx = pd.nx; px.ny = pd.ny; px.jitter = pd.jitter; px.c_pixel = pd.c_pixel;
     px.a1 = pd.a1 + t; px.a2 = pd.a2 + t; px.stride = n_tiles;
     px.cur1 = px.cur2 = px.cur_s = 0;
-    px.arr = pd.arr ? pd.arr + t : nullptr; px.arr_n = pd.arr_n;
+    px.arr = pd.arr ? pd.arr + t : nullptr; px.arr_sz = pd.arr_sz; px.arr_base = pd.arr_base; px.n_arr = pd.n_arr; px.arr_cur = 0;
     if (row0 == 0) px.rng.set_sequence((uint64_t)tr.seed);  // tile_sampler.reseed(seed) (integrator.rs:114)
     else { px.rng.state = pd.rng_state[2 * (size_t)t]; px.rng.inc = pd.rng_state[2 * (size_t)t + 1]; }
     const uint32_t slot = t;   // the lane's own path slot
@@ -69,6 +73,16 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                 pb.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                 pb.state[slot] = ST_ALIVE;
                 pb.p_film[slot] = make_float2(p_film.x, p_film.y);
+                if (MODE == 3) {
+                    DlSerial<INST, ALPHA> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false}, &px, pd.n_light_samples, pd.direct_strategy == RSPT_DIRECT_SAMPLE_ALL};
+                    const rgb l = dl.li(o, d, t_max);
+                    if (dl.base.truncated) atomicAdd(truncated, 1u);
+                    const size_t out = (size_t)k * pd.spp + s;
+                    samp_L[out] = make_float4(l.r, l.g, l.b, 1.0f);
+                    samp_pf[out] = make_float2(p_film.x, p_film.y);
+                    px.start_next_sample();
+                    continue;
+                }
                 if (MODE == 2) {
                     VolSerial<INST, ALPHA> vs{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false};
                     const rgb l = vs.li(o, d, t_max, p_film, p_lens);
@@ -92,8 +106,9 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                         const f3 n = faceforward(h.n, -d);
                         const f3 sv = normalize(h.dpdu);
                         const f3 tv = cross(h.n, sv);  // nrm_cross_vec3(&isect.common.n, &s)
-                        const uint32_t first = px.cur_s * px.arr_n;   // get_2d_array: the pixel sample's slice
-                        for (uint32_t j = 0; j < px.arr_n; j++) {
+                        uint32_t first = 0, arr_n = 0;
+                        const bool have = px.get_2d_array(&first, &arr_n);   // ao.rs:75: the pixel sample's slice of the array preprocess requested
+                        for (uint32_t j = 0; have && j < arr_n; j++) {
                             const float2 uu = px.va(first + j);
                             const f2 u{uu.x, uu.y};
                             f3 wi;
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                             wi = f3{sv.x * wi.x + tv.x * wi.y + n.x * wi.z, sv.y * wi.x + tv.y * wi.y + n.y * wi.z, sv.z * wi.x + tv.z * wi.y + n.z * wi.z};
                             if (pdf != 0.0f) {
                                 const TraceResult occ = traverse<true, INST, ALPHA, 64>(sc, tt, offset_ray_origin(hp.p, hp.p_err, hp.n, wi), wi, RSPT_INF, lds);
-                                if (occ.prim == RSPT_MISS) l += dot(wi, n) / (pdf * (float)px.arr_n);
+                                if (occ.prim == RSPT_MISS) l += dot(wi, n) / (pdf * (float)arr_n);
                             }
                         }
                     }
