@@ -6,7 +6,7 @@
 # tools/static_kernel_facts.sh
 set -u
 tag=$1; round=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p $out
-timeout 240 python -m pytest tests -m gpu -x -q --ignore=tests/test_gpu_fullsize.py > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log
+timeout ${PYTEST_TIMEOUT:-480} python -m pytest tests -m gpu -x -q --ignore=tests/test_gpu_fullsize.py > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log
 tail -2 $out/pytest.log
 SKIP_C5=${SKIP_C5-1} bash tools/refresh_profiles.sh $tag all > $out/refresh.log 2>&1
 bash tools/collect_profiles.sh $tag $round > /dev/null 2>&1
