@@ -171,6 +171,8 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_
            "valu_busy": lim.get("trace_closest", {}).get("valu_busy"),
            "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
            "launches_per_step": launches, "avg_launch_ms": t_wall / max(launches, 1) * 1e3,
+           # per-launch HIP-event durations, the figures rocprofv3 --kernel-trace --stats reports as "avg" for the two instantiations (profiles/rNN_soup1m_kernel_stats.md)
+           "avg_launch_ms_by_kernel": {"k_trace_w4<closest>": t_c / max(stats[0]["launches_closest"], 1) * 1e3, "k_trace_w4<any>": t_a / max(stats[0]["launches_any"], 1) * 1e3},
            "alg_bytes_per_launch": trace_bytes / max(launches, 1), "alg_rate_gbs": trace_bytes / t_wall / 1e9, "alg_bytes_per_step_rank0": trace_bytes,
            "how": "achieved = PMC fabric-side bytes of the step's trace launches (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) / their wall time (%.3f s; "
                   "per-launch HIP-event durations sum to %.3f s because the shadow-ray launch of a bounce overlaps the closest-hit launch on a second stream); "
@@ -185,7 +187,7 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_
     # read) + 36 B per shadow ray (32 B written + 4 B flag read) + 96 B of path state per bounce
     n_bounce = count_scale * (counts["alg_bytes"] - 32.0 * counts["samples"]) / 96.0 - trace_bytes / 96.0
     shade_alg = 48.0 * count_scale * counts["rays_closest"] + 36.0 * count_scale * counts["rays_any"] + 96.0 * n_bounce
-    sh = {"bound": "latency", "bound_detail": "2 waves / SIMD (VGPRs): dependent loads of the interaction fill, light sample and BSDF evaluation are not hidden",
+    sh = {"bound": "latency", "bound_detail": "2 - 3 waves / SIMD (VGPRs; waves_per_simd is the measured figure): dependent loads of the interaction fill, light sample and BSDF evaluation are not hidden",
           "kernel": "k_shade (+ k_bin_*, k_texture)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
           "alg_bytes_per_step": shade_alg, "alg_rate_gbs": shade_alg / t_sh / 1e9 if t_sh > 0 else None, "seconds_per_step": t_sh,
           "valu_busy": lim.get("shade", {}).get("valu_busy"), "wait_frac": lim.get("shade", {}).get("wait_frac"), "waves_per_simd": lim.get("shade", {}).get("waves_per_simd")}

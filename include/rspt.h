@@ -35,6 +35,7 @@ extern "C" {
 #define RSPT_E_UNSUPPORTED (-4) /* scene feature outside the accelerated path (caller
                                     falls back to the CPU loop, integrator.rs:70)           */
 #define RSPT_E_NOMEM (-5)
+#define RSPT_E_PEER (-6)        /* film_reduce: another rank of the communicator failed its render (see film_reduce) */
 
 typedef struct rspt_scene_s* rspt_scene_t;
 
@@ -401,6 +402,11 @@ typedef struct {
     uint32_t film_reduce;            /* multi-GPU (X1): 1 = before returning, sum the films of all ranks onto rank 0
                                         with one ncclReduce over the communicator of rspt_comm_init (shard_count must equal its
                                         world size, shard_index its rank); the other ranks' buffers keep their partial films.
+                                        The ranks first agree (one ncclAllReduce of a status word) that all of them reached the
+                                        reduce: if one failed — it returns its own error — the others return RSPT_E_PEER and no
+                                        film is summed; nobody waits in the collective.  Every rank of the communicator must
+                                        call rspt_render with film_reduce = 1 for the same frame (a rank that does not call at
+                                        all is the communicator's time-out, not this library's).
                                         0 = no collective (single GPU, or the caller reduces) */
     rspt_sampler_tables tables;
     /* DirectLightingIntegrator (src/integrators/directlighting.rs:17-70): max_depth bounds the specular recursion

@@ -6,7 +6,7 @@ import ctypes as C
 
 ABI_VERSION = 18
 
-OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
+OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM, E_PEER = 0, -1, -2, -3, -4, -5, -6
 
 BXDF_LAMBERT_R, BXDF_OREN_NAYAR, BXDF_SPECULAR_R, BXDF_SPECULAR_T, BXDF_FRESNEL_SPEC, BXDF_MICROFACET_R, BXDF_LAMBERT_T = 1, 2, 3, 4, 5, 6, 7
 BXDF_MICROFACET_T, BXDF_FRESNEL_BLEND = 8, 9

@@ -588,6 +588,81 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     return out;
 }
 
+// The part of the texture stage that does not depend on where the hit and its differentials come from: Material::bump, the material's
+// texture slots, the raw rows of a dynamic material, the mask of lobes whose colour came out black.  `h` is the interaction in world
+// space, `s` carries compute_differentials' results (zeros for a ray without differentials); rows go to out[row * stride].
+// Always inlined: k_texture's launch time depends on it (see the comment at its call site); the per-lane integrators call it through
+// texture_path / texture_hit_call.
+__device__ __attribute__((always_inline)) inline void texture_hit(const SceneDev& sc, const TexTables& tt, TexHit& h, const TexSurf& s, uint32_t material, float4* out, size_t stride) {
+    const rspt_material mat = sc.materials[material];
+    const uint32_t mf = tt.mat_flags[material];
+    uint32_t flags = 0;
+    if (mat.bump_tex) {
+        f3 bn, bdpdu;
+        bump_map(tt, mat.bump_tex - 1u, h, s, &bn, &bdpdu);
+        out[5 * stride] = make_float4(bdpdu.x, bdpdu.y, bdpdu.z, 0.0f);
+        flags |= 1u;
+        out[4 * stride] = make_float4(bn.x, bn.y, bn.z, 0.0f);  // (.w is completed below)
+        h.sh_n = bn;
+    }
+    rgb tv[RSPT_TEX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < RSPT_TEX_SLOTS; k++) {
+        tv[k] = mkrgb(0.0f);
+        const uint32_t sd = tt.mat_slots[(size_t)material * RSPT_TEX_SLOTS + k];
+        if (sd != 0xffffffffu) {
+            const uint32_t ti = sd & RSPT_SLOT_TEX_MASK;
+            rgb v;
+            if (sd & RSPT_SLOT_NODIFF) {  // MixMaterial hands m2 a SurfaceInteraction::new(p, uv, ..): no dudx .. dpdy (mixmat.rs:58-69)
+                TexSurf s2 = s;
+                s2.dudx = s2.dvdx = s2.dudy = s2.dvdy = 0.0f;
+                s2.dpdx = s2.dpdy = f3{0.0f, 0.0f, 0.0f};
+                v = tex_eval(tt, ti, s2);
+            } else v = tex_eval(tt, ti, s);
+            if (sd & RSPT_SLOT_ALPHA) {  // a roughness texture: the slot carries the lobe's alpha (plastic.rs:86-92, microfacet.rs:233-254)
+                float a = v.r;
+                if (sd & RSPT_SLOT_REMAP) {
+                    const float r = fmaxf(a, 1e-3f), x = rspt_logf(r);
+                    a = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+                }
+                a = fmaxf(0.001f, a);
+                out[k * stride] = make_float4(a, a, a, 0.0f);
+                continue;
+            }
+            tv[k] = rgb{v.r < 0.0f ? 0.0f : v.r, v.g < 0.0f ? 0.0f : v.g, v.b < 0.0f ? 0.0f : v.b};  // Spectrum::clamp(0, inf) = clamp_t per channel (pbrt.rs:108-123)
+            out[k * stride] = make_float4(tv[k].r, tv[k].g, tv[k].b, 0.0f);
+        }
+    }
+    if (mf & RSPT_MAT_DYNAMIC) {  // raw values of every varying parameter: the shade stage builds the lobe list from them (dynamic_lobes)
+        const rspt_mat::DynMaterial& dm = tt.dyn[material];
+        for (uint32_t r = 0; r < dm.n_rows; r++) {
+            const uint32_t sd = dm.row_tex[r];
+            rgb v;
+            if (sd & RSPT_SLOT_NODIFF) {
+                TexSurf s2 = s;
+                s2.dudx = s2.dvdx = s2.dudy = s2.dvdy = 0.0f;
+                s2.dpdx = s2.dpdy = f3{0.0f, 0.0f, 0.0f};
+                v = tex_eval(tt, sd & RSPT_SLOT_TEX_MASK, s2);
+            } else v = tex_eval(tt, sd & RSPT_SLOT_TEX_MASK, s);
+            out[(size_t)(RSPT_TEX_ROWS + r) * stride] = make_float4(v.r, v.g, v.b, 0.0f);
+        }
+    }
+    // the reference's `if !colour.is_black()` guards around bsdf.add (matte.rs:70, plastic.rs:70,84, substrate.rs:72, uber.rs)
+    const uint32_t nl = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+    for (uint32_t l = 0; l < nl; l++) {
+        const rspt_bxdf& b = sc.bxdfs[mat.first_bxdf + l];
+        if (!b.tex_r && !b.tex_t) continue;
+        rgb r = ldrgb(b.r), t = ldrgb(b.t);
+        if (b.tex_r) r = r * (b.tex_r == 1 ? tv[0] : (b.tex_r == 2 ? tv[1] : (b.tex_r == 3 ? tv[2] : tv[3])));
+        if (b.tex_t) t = t * (b.tex_t == 1 ? tv[0] : (b.tex_t == 2 ? tv[1] : (b.tex_t == 3 ? tv[2] : tv[3])));
+        const bool two = b.type == RSPT_BXDF_FRESNEL_SPEC || b.type == RSPT_BXDF_FRESNEL_BLEND;
+        if (two ? (is_black(r) && is_black(t)) : is_black(r)) flags |= 1u << (8 + l);
+    }
+    float4 m4 = (flags & 1u) ? out[4 * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    m4.w = __uint_as_float(flags);
+    out[4 * stride] = m4;
+}
+RDEVN void texture_hit_call(const SceneDev& sc, const TexTables& tt, TexHit& h, const TexSurf& s, uint32_t material, float4* out, size_t stride) { texture_hit(sc, tt, h, s, material, out, stride); }
 // ---- texture stage: runs in front of k_shade when the scene has textures -------------
 // For every path whose continuation ray hit a textured material: compute_differentials (camera rays
 // only; bounce rays carry none, interaction.rs:388-479), Material::bump, and the clamped value of each
@@ -633,74 +708,7 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
         camera_differentials(rd, f2{pf.x, pf.y}, p_lens, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, &rx_o, &rx_d, &ry_o, &ry_d);
         compute_differentials(h, rx_o, rx_d, ry_o, ry_d, &s);
     }
-    const rspt_material mat = sc.materials[tri.material];
-    float4* out = pb.tex + p;
-    const size_t stride = pb.tex_stride;
-    uint32_t flags = 0;
-    if (mat.bump_tex) {
-        f3 bn, bdpdu;
-        bump_map(tt, mat.bump_tex - 1u, h, s, &bn, &bdpdu);
-        out[5 * stride] = make_float4(bdpdu.x, bdpdu.y, bdpdu.z, 0.0f);
-        flags |= 1u;
-        out[4 * stride] = make_float4(bn.x, bn.y, bn.z, 0.0f);  // (.w is completed below)
-        h.sh_n = bn;
-    }
-    rgb tv[RSPT_TEX_SLOTS];
-#pragma unroll
-    for (int k = 0; k < RSPT_TEX_SLOTS; k++) {
-        tv[k] = mkrgb(0.0f);
-        const uint32_t sd = tt.mat_slots[(size_t)tri.material * RSPT_TEX_SLOTS + k];
-        if (sd != 0xffffffffu) {
-            const uint32_t ti = sd & RSPT_SLOT_TEX_MASK;
-            rgb v;
-            if (sd & RSPT_SLOT_NODIFF) {  // MixMaterial hands m2 a SurfaceInteraction::new(p, uv, ..): no dudx .. dpdy (mixmat.rs:58-69)
-                TexSurf s2 = s;
-                s2.dudx = s2.dvdx = s2.dudy = s2.dvdy = 0.0f;
-                s2.dpdx = s2.dpdy = f3{0.0f, 0.0f, 0.0f};
-                v = tex_eval(tt, ti, s2);
-            } else v = tex_eval(tt, ti, s);
-            if (sd & RSPT_SLOT_ALPHA) {  // a roughness texture: the slot carries the lobe's alpha (plastic.rs:86-92, microfacet.rs:233-254)
-                float a = v.r;
-                if (sd & RSPT_SLOT_REMAP) {
-                    const float r = fmaxf(a, 1e-3f), x = rspt_logf(r);
-                    a = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
-                }
-                a = fmaxf(0.001f, a);
-                out[k * stride] = make_float4(a, a, a, 0.0f);
-                continue;
-            }
-            tv[k] = rgb{v.r < 0.0f ? 0.0f : v.r, v.g < 0.0f ? 0.0f : v.g, v.b < 0.0f ? 0.0f : v.b};  // Spectrum::clamp(0, inf) = clamp_t per channel (pbrt.rs:108-123)
-            out[k * stride] = make_float4(tv[k].r, tv[k].g, tv[k].b, 0.0f);
-        }
-    }
-    if (mf & RSPT_MAT_DYNAMIC) {  // raw values of every varying parameter: the shade stage builds the lobe list from them (dynamic_lobes)
-        const rspt_mat::DynMaterial& dm = tt.dyn[tri.material];
-        for (uint32_t r = 0; r < dm.n_rows; r++) {
-            const uint32_t sd = dm.row_tex[r];
-            rgb v;
-            if (sd & RSPT_SLOT_NODIFF) {
-                TexSurf s2 = s;
-                s2.dudx = s2.dvdx = s2.dudy = s2.dvdy = 0.0f;
-                s2.dpdx = s2.dpdy = f3{0.0f, 0.0f, 0.0f};
-                v = tex_eval(tt, sd & RSPT_SLOT_TEX_MASK, s2);
-            } else v = tex_eval(tt, sd & RSPT_SLOT_TEX_MASK, s);
-            out[(size_t)(RSPT_TEX_ROWS + r) * stride] = make_float4(v.r, v.g, v.b, 0.0f);
-        }
-    }
-    // the reference's `if !colour.is_black()` guards around bsdf.add (matte.rs:70, plastic.rs:70,84, substrate.rs:72, uber.rs)
-    const uint32_t nl = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
-    for (uint32_t l = 0; l < nl; l++) {
-        const rspt_bxdf& b = sc.bxdfs[mat.first_bxdf + l];
-        if (!b.tex_r && !b.tex_t) continue;
-        rgb r = ldrgb(b.r), t = ldrgb(b.t);
-        if (b.tex_r) r = r * (b.tex_r == 1 ? tv[0] : (b.tex_r == 2 ? tv[1] : (b.tex_r == 3 ? tv[2] : tv[3])));
-        if (b.tex_t) t = t * (b.tex_t == 1 ? tv[0] : (b.tex_t == 2 ? tv[1] : (b.tex_t == 3 ? tv[2] : tv[3])));
-        const bool two = b.type == RSPT_BXDF_FRESNEL_SPEC || b.type == RSPT_BXDF_FRESNEL_BLEND;
-        if (two ? (is_black(r) && is_black(t)) : is_black(r)) flags |= 1u << (8 + l);
-    }
-    float4 m4 = (flags & 1u) ? out[4 * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    m4.w = __uint_as_float(flags);
-    out[4 * stride] = m4;
+    texture_hit(sc, tt, h, s, tri.material, pb.tex + p, pb.tex_stride);
 }
 __global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
                                                  const uint32_t* __restrict__ count_in) {

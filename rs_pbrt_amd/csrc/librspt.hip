@@ -102,22 +102,28 @@ Ctx g;
 // X1: the one collective of the multi-GPU decomposition, ncclReduce(sum) of the per-rank films onto rank 0
 // over xGMI.  RCCL is bound at run time so that single-GPU hosts need no librccl; a process that already has one loaded
 // (torch ships its own copy) shares it.
-// The handful of RCCL types the dlopen'ed entry points take, declared here with rccl.h's values (ncclFloat32 = 7, ncclSum = 0,
-// NCCL_UNIQUE_ID_BYTES = 128) so that a host without the RCCL development headers still builds the library.
+// Before that reduce the ranks agree on whether every one of them got that far (ncclAllReduce(max) of one status word): a rank whose
+// render failed contributes 1 from rspt_render's exit path, and all ranks return (RSPT_E_PEER for the healthy ones) instead of
+// waiting in a collective that one member never enters.
+// The handful of RCCL types the dlopen'ed entry points take, declared here with rccl.h's values (ncclInt32 = 2, ncclFloat32 = 7,
+// ncclSum = 0, ncclMax = 2, NCCL_UNIQUE_ID_BYTES = 128) so that a host without the RCCL development headers still builds the library.
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclFloat32 = 7 } ncclDataType_t;
-typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclInt32 = 2, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
 struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
+    int32_t* status = nullptr;      // device word of the status agreement
+    bool status_exchanged = false;  // this rspt_render call has taken part in the agreement
 };
 Rccl rc_;
 
@@ -133,9 +139,10 @@ int rccl_bind() {
     *(void**)&rc_.GetUniqueId = dlsym(h, "ncclGetUniqueId");
     *(void**)&rc_.CommInitRank = dlsym(h, "ncclCommInitRank");
     *(void**)&rc_.Reduce = dlsym(h, "ncclReduce");
+    *(void**)&rc_.AllReduce = dlsym(h, "ncclAllReduce");
     *(void**)&rc_.CommDestroy = dlsym(h, "ncclCommDestroy");
     *(void**)&rc_.GetErrorString = dlsym(h, "ncclGetErrorString");
-    if (!rc_.GetUniqueId || !rc_.CommInitRank || !rc_.Reduce || !rc_.CommDestroy || !rc_.GetErrorString)
+    if (!rc_.GetUniqueId || !rc_.CommInitRank || !rc_.Reduce || !rc_.AllReduce || !rc_.CommDestroy || !rc_.GetErrorString)
         return fail(RSPT_E_UNSUPPORTED, "librccl.so lacks an nccl* entry point");
     rc_.handle = h;
     return RSPT_OK;
@@ -145,6 +152,17 @@ int rccl_bind() {
         ncclResult_t r_ = (expr);                                                                                  \
         if (r_ != ncclSuccess) return fail(RSPT_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, rc_.GetErrorString(r_)); \
     } while (0)
+
+// The status agreement in front of the film reduce: every rank contributes 0 (ready to reduce) or 1 (failed); returns the maximum.
+int film_reduce_agree(int32_t mine, int32_t* all) {
+    if (!rc_.status) HIP_TRY(hipMalloc((void**)&rc_.status, sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(rc_.status, &mine, sizeof mine, hipMemcpyHostToDevice, g.stream));
+    rc_.status_exchanged = true;
+    RCCL_TRY(rc_.AllReduce(rc_.status, rc_.status, 1, ncclInt32, ncclMax, rc_.comm, g.stream));
+    HIP_TRY(hipMemcpyAsync(all, rc_.status, sizeof *all, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RSPT_OK;
+}
 
 struct LightDist {
     float* func = nullptr;
@@ -1231,6 +1249,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         if (!rc_.comm) return fail(RSPT_E_INVALID, "film_reduce without a communicator (rspt_comm_init)");
         if ((uint32_t)rc_.world != shard_count || (uint32_t)rc_.rank != d->shard_index)
             return fail(RSPT_E_INVALID, "film_reduce: shard %u of %u does not match rank %d of %d", d->shard_index, shard_count, rc_.rank, rc_.world);
+        hipError_t pe = hipStreamSynchronize(g.stream);   // a kernel fault of this rank must surface before the agreement, not inside the collective
+        if (pe != hipSuccess) return fail(RSPT_E_HIP, "render failed: %s", hipGetErrorString(pe));
+        int32_t any_failed = 0;
+        if (int rc = film_reduce_agree(0, &any_failed)) return rc;
+        if (any_failed) return fail(RSPT_E_PEER, "film_reduce: another rank of the communicator failed its render; no film was summed");
         RCCL_TRY(rc_.Reduce(out_dev, out_dev, film_px * 4, ncclFloat32, ncclSum, 0, rc_.comm, g.stream));
     }
     HIP_TRY(hipEventRecord(ev_k1, g.stream));
@@ -2024,17 +2047,33 @@ int rspt_scene_destroy(rspt_scene_t s) {
     return RSPT_OK;
 }
 
+namespace {
+// A render that asked for the film reduce and failed before reaching it still takes part in the status agreement, so that the other
+// ranks return RSPT_E_PEER instead of waiting for it; its own error code and message are kept.
+int render_entry(rspt_scene_t s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
+    rc_.status_exchanged = false;
+    const int rc = render_impl(s, d, film_host, film_dev, li_host, stats);
+    if (rc != RSPT_OK && d && d->film_reduce && rc_.comm && g.inited && !rc_.status_exchanged) {
+        const std::string kept = rspt_last_error();
+        int32_t all = 0;
+        (void)film_reduce_agree(1, &all);
+        fail(rc, "%s", kept.c_str());
+    }
+    return rc;
+}
+}  // namespace
+
 int rspt_render(rspt_scene_t s, const rspt_render_desc* d, float* film_xyzw, rspt_stats* stats) {
     if (!film_xyzw) return fail(RSPT_E_INVALID, "null film");
-    return render_impl(s, d, film_xyzw, nullptr, nullptr, stats);
+    return render_entry(s, d, film_xyzw, nullptr, nullptr, stats);
 }
 int rspt_render_device(rspt_scene_t s, const rspt_render_desc* d, void* film_dev, rspt_stats* stats) {
     if (!film_dev) return fail(RSPT_E_INVALID, "null film");
-    return render_impl(s, d, nullptr, film_dev, nullptr, stats);
+    return render_entry(s, d, nullptr, film_dev, nullptr, stats);
 }
 int rspt_render_samples(rspt_scene_t s, const rspt_render_desc* d, float* li_rgb, rspt_stats* stats) {
     if (!li_rgb) return fail(RSPT_E_INVALID, "null li_rgb");
-    return render_impl(s, d, nullptr, nullptr, li_rgb, stats);
+    return render_entry(s, d, nullptr, nullptr, li_rgb, stats);
 }
 
 int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t allow_multiple_lobes, rspt_material* out_material, rspt_bxdf out_bxdfs[8]) {

@@ -1,6 +1,7 @@
 """world_size-2 worker for tests/test_gpu_render.py::test_film_reduce_with_two_ranks_on_one_gpu: two processes, both on GPU 0, join the
 LIBRARY's communicator (rspt_comm_init(rank, 2, id)), each renders its shard of the Morton tile deal with film_reduce = 1, rank 0 saves the
-reduced frame.  The id travels through a file (what the Rust shim does)."""
+reduced frame.  The id travels through a file (what the Rust shim does).  A second frame fails on rank 1 only: the status agreement in
+front of the reduce (librspt.hip film_reduce_agree) must bring rank 0 back with RSPT_E_PEER."""
 import os
 import sys
 import time
@@ -14,7 +15,8 @@ from rs_pbrt_amd import lib, scenes  # noqa: E402
 
 def main():
     rank, workdir = int(sys.argv[1]), sys.argv[2]
-    lib.init(0)
+    import torch
+    lib.init(rank % max(torch.cuda.device_count(), 1))   # one device per rank where the box has them, both on device 0 otherwise
     idf = os.path.join(workdir, "id.bin")
     if rank == 0:
         uid = lib.comm_unique_id()
@@ -38,8 +40,18 @@ def main():
     rd.film_reduce = 1
     with lib.DeviceScene(sc) as ds:
         film, st = lib.render(ds, rd)
+        # second frame: rank 1's render is refused before it reaches the reduce; rank 0 must come back with RSPT_E_PEER, not wait
+        rd2 = scenes.cornell_render_desc(res=80, spp=4, shard=(rank, 2, 1), integrator="directlighting", max_depth=9 if rank == 1 else 5)
+        rd2.film_reduce = 1
+        code = 0
+        try:
+            lib.render(ds, rd2)
+        except lib.RsptError as e:
+            code = e.code
+        film3, _ = lib.render(ds, rd)   # and the communicator is still usable
     np.save(os.path.join(workdir, "film_%d.npy" % rank), film)
-    np.save(os.path.join(workdir, "samples_%d.npy" % rank), np.array([st["samples"]]))
+    np.save(os.path.join(workdir, "film3_%d.npy" % rank), film3)
+    np.save(os.path.join(workdir, "samples_%d.npy" % rank), np.array([st["samples"], code]))
     lib.comm_destroy()
 
 

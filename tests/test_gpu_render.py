@@ -586,8 +586,19 @@ def test_film_reduce_runs_inside_the_library(gpu):
             reduced, st = gpu.render(ds, rd)
             assert np.array_equal(plain, reduced) and st["samples"] == 48 * 48 * 4
             rd.shard_index, rd.shard_count, rd.tile_chunk = 0, 2, 1
-            with pytest.raises(RsptError):  # shard_count must equal the communicator's world size
+            with pytest.raises(RsptError) as e:  # shard_count must equal the communicator's world size
                 gpu.render(ds, rd)
+            assert e.value.code == abi.E_INVALID and "shard" in str(e.value)   # ... and the failed call took part in the status agreement
+            # (a rank that fails before the reduce must not leave the others waiting in it) keeping its own error; the next frame runs
+            rd.shard_index, rd.shard_count = 0, 1
+            again, _ = gpu.render(ds, rd)
+            assert np.array_equal(again, plain)
+            bad = scenes.cornell_render_desc(res=48, spp=4, integrator="directlighting", max_depth=9)
+            bad.film_reduce = 1
+            with pytest.raises(RsptError) as e:
+                gpu.render(ds, bad)
+            assert e.value.code == abi.E_UNSUPPORTED
+            assert np.array_equal(gpu.render(ds, rd)[0], plain)
         finally:
             gpu.comm_destroy()
 
@@ -623,6 +634,9 @@ def test_film_reduce_with_two_ranks_on_one_gpu(gpu, tmp_path):
     assert n == st["samples"] == 80 * 80 * 4
     assert np.array_equal(reduced[:, 3], whole[:, 3]) and np.allclose(reduced, whole, rtol=1e-6, atol=1e-7)
     assert 0 < part1[:, 3].sum() < whole[:, 3].sum()   # the other rank keeps its partial film
+    codes = [int(np.load(os.path.join(tmp_path, "samples_%d.npy" % r))[1]) for r in range(2)]
+    assert codes == [abi.E_PEER, abi.E_UNSUPPORTED], codes   # the failed rank keeps its own error, the healthy one is told
+    assert np.array_equal(np.load(os.path.join(tmp_path, "film3_0.npy")), reduced)
 
 
 def test_spatial_light_distribution_on_demand_voxels(gpu, oracle):
