@@ -50,7 +50,7 @@ struct Buckets {
     uint32_t lo[12][3], hi[12][3];
 };
 
-__global__ void k_prim_info(const float* __restrict__ P, const uint32_t* __restrict__ tri, uint32_t n, Prims pr) {
+RSPT_PLAIN_KERNEL void k_prim_info(const float* __restrict__ P, const uint32_t* __restrict__ tri, uint32_t n, Prims pr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p0 = P + 3 * (size_t)tri[3 * (size_t)i];
@@ -65,7 +65,7 @@ __global__ void k_prim_info(const float* __restrict__ P, const uint32_t* __restr
     pr.node[i] = 0u;
 }
 
-__global__ void k_node_reset(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level) {
+RSPT_PLAIN_KERNEL void k_node_reset(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_level) return;
     Node& nd = nodes[level_nodes[k]];
@@ -95,7 +95,7 @@ __device__ __forceinline__ bool wave_uniform(uint32_t node, bool active) {
     return __ballot(node == first) == ~0ull;
 }
 
-__global__ void k_bounds(Prims pr, uint32_t n, Node* nodes) {  // bvh.rs:196-199, 211-216
+RSPT_PLAIN_KERNEL void k_bounds(Prims pr, uint32_t n, Node* nodes) {  // bvh.rs:196-199, 211-216
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n;
     const uint32_t node = in ? pr.node[i] : BVD_NONE;
@@ -149,7 +149,7 @@ __device__ __forceinline__ uint32_t bucket_of(float lo, float hi, float c) {  //
 }
 
 // per node: axis, the early outs of recursive_build (n == 1; all centroids equal), n == 2
-__global__ void k_node_axis(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, Buckets* buckets, Prims pr, uint32_t* n_sah) {
+RSPT_PLAIN_KERNEL void k_node_axis(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, Buckets* buckets, Prims pr, uint32_t* n_sah) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_level) return;
     Node& nd = nodes[level_nodes[k]];
@@ -176,7 +176,7 @@ __global__ void k_node_axis(Node* nodes, const uint32_t* __restrict__ level_node
     }
 }
 
-__global__ void k_buckets(Prims pr, uint32_t n, const Node* __restrict__ nodes, Buckets* buckets) {  // bvh.rs:247-265
+RSPT_PLAIN_KERNEL void k_buckets(Prims pr, uint32_t n, const Node* __restrict__ nodes, Buckets* buckets) {  // bvh.rs:247-265
     // A workgroup whose 256 primitives all belong to one node (the rule on the upper levels, where a handful of nodes own
     // everything) accumulates in LDS and issues 84 global atomics instead of 1792.
     __shared__ Buckets s_bk;
@@ -224,7 +224,7 @@ __global__ void k_buckets(Prims pr, uint32_t n, const Node* __restrict__ nodes, 
 }
 
 // SAH decision per node (bvh.rs:266-296)
-__global__ void k_split(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, const Buckets* __restrict__ buckets, uint32_t max_prims) {
+RSPT_PLAIN_KERNEL void k_split(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, const Buckets* __restrict__ buckets, uint32_t max_prims) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_level) return;
     Node& nd = nodes[level_nodes[k]];
@@ -255,7 +255,7 @@ __global__ void k_split(Node* nodes, const uint32_t* __restrict__ level_nodes, u
 }
 
 // leaves emit their primitives; everyone else marks who goes to the first child
-__global__ void k_flags(Prims pr, uint32_t n, Node* nodes, uint32_t* __restrict__ flag, uint32_t* __restrict__ ordered) {
+RSPT_PLAIN_KERNEL void k_flags(Prims pr, uint32_t n, Node* nodes, uint32_t* __restrict__ flag, uint32_t* __restrict__ ordered) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t f = 0;
@@ -279,7 +279,7 @@ __global__ void k_flags(Prims pr, uint32_t n, Node* nodes, uint32_t* __restrict_
 // ---- exclusive scan of n uint32 (three passes, 1024 elements per block) ----
 #define BVD_SCAN_BLOCK 256
 #define BVD_SCAN_ITEMS 4
-__global__ void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums, uint32_t n) {
+RSPT_PLAIN_KERNEL void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums, uint32_t n) {
     __shared__ uint32_t s[BVD_SCAN_BLOCK];
     const uint32_t base = (blockIdx.x * BVD_SCAN_BLOCK + threadIdx.x) * BVD_SCAN_ITEMS;
     uint32_t v[BVD_SCAN_ITEMS], sum = 0;
@@ -296,7 +296,7 @@ __global__ void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restr
     for (int k = 0; k < BVD_SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
     if (threadIdx.x == BVD_SCAN_BLOCK - 1) block_sums[blockIdx.x] = s[threadIdx.x];
 }
-__global__ void k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t* __restrict__ total) {  // one block
+RSPT_PLAIN_KERNEL void k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t* __restrict__ total) {  // one block
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -319,13 +319,13 @@ __global__ void k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t n_blocks
     }
     if (threadIdx.x == 0) *total = carry;
 }
-__global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sums, uint32_t n) {
+RSPT_PLAIN_KERNEL void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sums, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] += block_sums[i / (BVD_SCAN_BLOCK * BVD_SCAN_ITEMS)];
 }
 
 // children of the nodes that split: their ranges follow from the scan (mid = start + number of "first child" flags)
-__global__ void k_children(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, const uint32_t* __restrict__ scan,
+RSPT_PLAIN_KERNEL void k_children(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, const uint32_t* __restrict__ scan,
                            const uint32_t* __restrict__ scan_total, uint32_t n, uint32_t* n_nodes, uint32_t* __restrict__ next_level, uint32_t* n_next) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_level) return;
@@ -345,7 +345,7 @@ __global__ void k_children(Node* nodes, const uint32_t* __restrict__ level_nodes
     nd.min_bucket = mid;  // (now: the split position, for k_scatter)
 }
 
-__global__ void k_scatter(Prims src, Prims dst, uint32_t n, const Node* __restrict__ nodes, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan) {
+RSPT_PLAIN_KERNEL void k_scatter(Prims src, Prims dst, uint32_t n, const Node* __restrict__ nodes, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t node = src.node[i];
@@ -360,13 +360,13 @@ __global__ void k_scatter(Prims src, Prims dst, uint32_t n, const Node* __restri
 }
 
 // ---- flattening (bvh.rs:358-392): subtree sizes bottom-up, depth-first indices top-down, one level per launch ----
-__global__ void k_sizes(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level) {
+RSPT_PLAIN_KERNEL void k_sizes(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_level) return;
     Node& nd = nodes[level_nodes[k]];
     nd.size = nd.leaf ? 1u : 1u + nodes[nd.child0].size + nodes[nd.child1].size;
 }
-__global__ void k_indices(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, rspt_bvh_node* __restrict__ out) {
+RSPT_PLAIN_KERNEL void k_indices(Node* nodes, const uint32_t* __restrict__ level_nodes, uint32_t n_level, rspt_bvh_node* __restrict__ out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_level) return;
     Node& nd = nodes[level_nodes[k]];

@@ -10,6 +10,14 @@
 
 #define RDEV __device__ __forceinline__
 #define RDEVN __device__ inline
+// A kernel that is not a template.  librspt.so is several translation units (tu_decl.h): the units that exist only to carry
+// instantiations of the heavy kernel templates (RSPT_TU_TEMPLATES_ONLY) see the plain kernels as templates nobody instantiates,
+// so that each of those has exactly one definition — in librspt.hip, which launches them.
+#ifdef RSPT_TU_TEMPLATES_ONLY
+#define RSPT_PLAIN_KERNEL template <int RSPT_NEVER_INSTANTIATED = 0> __global__
+#else
+#define RSPT_PLAIN_KERNEL __global__
+#endif
 
 namespace rspt {
 

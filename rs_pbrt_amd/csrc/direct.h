@@ -76,7 +76,7 @@ RDEV void dl_interaction(const SceneDev& sc, const PathBuf& pb, uint32_t slot, u
 }
 
 // roots: the camera rays (k_raygen left them in src_rays by sample slot)
-__global__ __launch_bounds__(256) void k_dl_init(Batch bt, PathBuf pb, DlBuf dl, const rspt_ray* __restrict__ src_rays, uint32_t* __restrict__ q_level0, uint32_t* cnt_level0) {
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_init(Batch bt, PathBuf pb, DlBuf dl, const rspt_ray* __restrict__ src_rays, uint32_t* __restrict__ q_level0, uint32_t* cnt_level0) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) *cnt_level0 = bt.n;
     if (i >= bt.n) return;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_dl_init(Batch bt, PathBuf pb, DlBuf dl,
 
 // one level of the specular tree: classify every traced node, spawn its children into the next level's queue; null-BSDF hits
 // re-enter the same level (q_retrace)
-__global__ __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
                                                 uint32_t* __restrict__ q_retrace, uint32_t* cnt_retrace, uint32_t* __restrict__ q_next, uint32_t* cnt_next, uint32_t level) {
     const uint32_t n = *count_in;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd, PathB
 // n_arrays = 2 * max_depth * n_lights with LightStrategy::UniformSampleAll (preprocess, directlighting.rs:54-70), else 0
 // dim_limit: the sampler's dimension count (NUM_SOBOL_DIMENSIONS, or what the Halton permutation table covers); the reference panics when a
 // dimension past it is asked for (sobol.rs:119-124), so a camera sample whose stream ends beyond it is reported (dl.error = 2), not rendered
-__global__ __launch_bounds__(256) void k_dl_assign(Batch bt, DlBuf dl, uint32_t n_lights, uint32_t n_arrays, uint32_t sample_all, uint32_t max_depth, uint32_t dim_limit) {
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_assign(Batch bt, DlBuf dl, uint32_t n_lights, uint32_t n_arrays, uint32_t sample_all, uint32_t max_depth, uint32_t dim_limit) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= bt.n) return;
     uint32_t k = 0;
@@ -190,7 +190,7 @@ RDEV f2 dl_dims(const RenderDev& rd, uint64_t index, uint32_t d) {
 
 // one round of estimate_direct (integrator.rs:406-570) for every shading node of a level: light j, element kk of its sample arrays
 // (sample_all), or the one light uniform_sample_one_light picks (j, kk = 0)
-__global__ __launch_bounds__(256) void k_dl_nee(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ pix_list,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ pix_list,
                                                 const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in, uint32_t j, uint32_t kk, uint32_t n_j,
                                                 uint32_t n_arrays, uint32_t sample_all, uint32_t* __restrict__ q_any, uint32_t* cnt_any,
                                                 uint32_t* __restrict__ q_mis, uint32_t* cnt_mis) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_dl_nee(SceneDev sc, RenderDev rd, Batch
 }
 
 // fold the round's estimate into the node, in the reference's order (integrator.rs:309-353)
-__global__ __launch_bounds__(256) void k_dl_nee_resolve(SceneDev sc, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_resolve(SceneDev sc, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
                                                         uint32_t j, uint32_t kk, uint32_t n_j, uint32_t n_arrays, uint32_t sample_all) {
     const uint32_t n = *count_in;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_dl_nee_resolve(SceneDev sc, PathBuf pb,
 }
 
 // li of every node, bottom-up; the root's goes to the camera sample
-__global__ __launch_bounds__(256) void k_dl_gather(Batch bt, PathBuf pb, DlBuf dl, uint32_t n_lights, uint32_t max_depth) {
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_gather(Batch bt, PathBuf pb, DlBuf dl, uint32_t n_lights, uint32_t max_depth) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= bt.n) return;
     for (uint32_t h = dl.H - 1u; h >= 1u; h--) {

@@ -3,8 +3,13 @@
 // reference's own depth-first order on an explicit stack of at most max_depth frames: no 2^max_depth tree of node slots (direct.h, the
 // wavefront form under Sobol' / Halton, is bounded by max_depth 8 for that reason; this one by RSPT_DL_SERIAL_DEPTH), and the sampler
 // — dimensions and the 2-D sample arrays of uniform_sample_all_lights alike — is simply read in program order.
-// Not handled here (rspt_render refuses): textured materials (the specular bounces' ray differentials, directlighting.rs:150-191, exist
-// only to filter their textures).
+// The sample source is a template parameter read in program order: a pixel sampler's stream (tile_serial.h) or, one lane per camera
+// sample, the Sobol' / Halton dimensions (lane_serial.h) — the form rspt_render takes under those samplers when the wavefront form
+// cannot serve the render (textured materials, max_depth > 8, a material with several specular lobes of one kind).
+// Textured materials: every activation carries its ray's differentials — the camera's at the root, specular_reflect's / _transmit's
+// (directlighting.rs:150-191, :215-250) below it, none behind a BSDF-less surface (isect.spawn_ray) — through
+// SurfaceInteraction::compute_differentials into the texture stage (kernels.h texture_hit), whose rows this activation keeps for as
+// long as its BSDF lives (level L of the lane: tex + L * tex_rows * tex_stride).
 #pragma once
 #include "vol_serial.h"
 
@@ -12,12 +17,15 @@ namespace rspt {
 
 #define RSPT_DL_SERIAL_DEPTH 32
 
-template <bool INST, bool ALPHA>
+template <bool INST, bool ALPHA, class SMP>
 struct DlSerial {
     VolSerial<INST, ALPHA> base;      // closest(), surface()
-    PixSampler* px;
+    SMP* px;                          // get_1d / get_2d / get_2d_array / va
     const int32_t* n_light_samples;   // strategy all: Light::get_n_samples after round_count, per light (nullptr: 1 each)
     bool sample_all;
+    float4* tex;                      // this lane's column of texture-stage rows (nullptr: the scene has no textured material)
+    uint32_t tex_stride, tex_rows;    // lanes per row; rows per activation
+    f2 p_film, p_lens;                // the camera sample (differentials of the camera ray)
 
     const SceneDev& sc() const { return base.sc; }
     RDEV bool occluded(f3 o, f3 d, float t_max) { return traverse<true, INST, ALPHA, 64>(base.sc, base.tt, o, d, t_max, base.lds).prim != RSPT_MISS; }
@@ -84,12 +92,12 @@ struct DlSerial {
         rgb l = mkrgb(0.0f);
         if (S.n_lights == 0u) return l;
         if (!sample_all) {
-            const float fl = base.smp.get_1d() * (float)S.n_lights;
+            const float fl = px->get_1d() * (float)S.n_lights;
             uint32_t light_num = (fl != fl || fl <= 0.0f) ? 0u : (fl >= 4294967296.0f ? 0xffffffffu : (uint32_t)fl);   // `as usize`
             light_num = light_num < S.n_lights - 1u ? light_num : S.n_lights - 1u;
             const float light_pdf = 1.0f / (float)S.n_lights;
-            const f2 u_light = base.smp.get_2d();
-            const f2 u_scattering = base.smp.get_2d();
+            const f2 u_light = px->get_2d();
+            const f2 u_scattering = px->get_2d();
             return estimate_direct(it, bsdf, u_scattering, light_num, u_light) / light_pdf;
         }
         for (uint32_t j = 0; j < S.n_lights; j++) {
@@ -98,8 +106,8 @@ struct DlSerial {
             const bool have_a = px->get_2d_array(&fa, &ca);
             const bool have_b = px->get_2d_array(&fb, &cb);
             if (!have_a || !have_b) {   // the arrays are used up: one sample from the regular stream
-                const f2 u_light = base.smp.get_2d();
-                const f2 u_scattering = base.smp.get_2d();
+                const f2 u_light = px->get_2d();
+                const f2 u_scattering = px->get_2d();
                 l = l + estimate_direct(it, bsdf, u_scattering, j, u_light);
             } else {
                 rgb ld = mkrgb(0.0f);
@@ -119,18 +127,45 @@ struct DlSerial {
         uint32_t stage;   // 1: the reflection child is in flight, 2: the transmission child
         SerialHit it;
         Bsdf bsdf;
+        // the ray that reached this activation had differentials (only kept when the scene has textures): its offset directions, and
+        // what compute_differentials made of them here — dpdx / dpdy, dndx = shading.dndu * dudx + shading.dndv * dvdx, dndy
+        bool has_diff;
+        f3 in_rx_d, in_ry_d, dpdx, dpdy, dndx, dndy;
     };
+    struct RayDiff { bool has; f3 rx_o, rx_d, ry_o, ry_d; };
     // specular_reflect / specular_transmit (:133-258) up to the recursive call: draws its get_2d, returns whether a child ray was spawned
-    RDEV bool specular(const Frame& fr, bool transmit, f3* o, f3* d, rgb* f_out, float* s_out) {
+    RDEV bool specular(const Frame& fr, bool transmit, f3* o, f3* d, rgb* f_out, float* s_out, RayDiff* rdiff) {
         f3 wi{0.0f, 0.0f, 0.0f};
         float pdf = 0.0f;
         uint32_t st = 0;
-        const rgb f = fr.bsdf.sample_f(fr.it.wo, &wi, base.smp.get_2d(), &pdf, (transmit ? BX_TRANS : BX_REFL) | BX_SPEC, &st);
+        const rgb f = fr.bsdf.sample_f(fr.it.wo, &wi, px->get_2d(), &pdf, (transmit ? BX_TRANS : BX_REFL) | BX_SPEC, &st);
         const f3 ns = fr.it.h.sh_n;
         if (!(pdf > 0.0f && !is_black(f) && absdot(wi, ns) != 0.0f)) return false;
         *o = offset_ray_origin(fr.it.h.p, fr.it.h.p_err, fr.it.h.n, wi);
         *d = wi;
         *f_out = f; *s_out = absdot(wi, ns) / pdf;
+        rdiff->has = false;
+        if (tex && fr.has_diff) {   // the child's differentials (directlighting.rs:150-191 reflection, :215-250 transmission)
+            const f3 wo = fr.it.wo;
+            const f3 dwodx = -fr.in_rx_d - wo, dwody = -fr.in_ry_d - wo;
+            const float ddndx = dot(dwodx, ns) + dot(wo, fr.dndx);
+            const float ddndy = dot(dwody, ns) + dot(wo, fr.dndy);
+            rdiff->has = true;
+            rdiff->rx_o = fr.it.h.p + fr.dpdx; rdiff->ry_o = fr.it.h.p + fr.dpdy;
+            if (!transmit) {
+                rdiff->rx_d = wi - dwodx + (fr.dndx * dot(wo, ns) + ns * ddndx) * 2.0f;
+                rdiff->ry_d = wi - dwody + (fr.dndy * dot(wo, ns) + ns * ddndy) * 2.0f;
+            } else {
+                float eta = fr.bsdf.eta;
+                const f3 w = -wo;
+                if (dot(wo, ns) < 0.0f) eta = 1.0f / eta;
+                const float mu = eta * dot(w, ns) - dot(wi, ns);
+                const float dmudx = (eta - (eta * eta * dot(w, ns)) / dot(wi, ns)) * ddndx;
+                const float dmudy = (eta - (eta * eta * dot(w, ns)) / dot(wi, ns)) * ddndy;
+                rdiff->rx_d = wi + dwodx * eta - (fr.dndx * mu + ns * dmudx);
+                rdiff->ry_d = wi + dwody * eta - (fr.dndy * mu + ns * dmudy);
+            }
+        }
         return true;
     }
 
@@ -140,6 +175,8 @@ struct DlSerial {
         uint32_t sp = 0;          // = depth of the activation being entered
         rgb ret = mkrgb(0.0f);
         uint32_t walked = 0;
+        RayDiff cur{false, f3{0.0f, 0.0f, 0.0f}, f3{0.0f, 0.0f, 0.0f}, f3{0.0f, 0.0f, 0.0f}, f3{0.0f, 0.0f, 0.0f}};   // the differentials of the ray being traced
+        if (tex) { cur.has = true; camera_differentials(base.rd, p_film, p_lens, ray_o, ray_d, &cur.rx_o, &cur.rx_d, &cur.ry_o, &cur.ry_d); }
         for (;;) {
             // ---- enter li(ray, depth = sp) ----
             rgb l = mkrgb(0.0f);
@@ -156,12 +193,42 @@ struct DlSerial {
                         if (++walked > base.max_walk) { base.truncated = true; }
                         else {
                             ray_o = offset_ray_origin(fr.it.h.p, fr.it.h.p_err, fr.it.h.n, ray_d);
+                            cur.has = false;   // isect.spawn_ray(&ray.d): no differentials
                             continue;
                         }
                     } else {
                         const rspt_material mat = S.materials[fr.it.h.material];
                         Bsdf& b = fr.bsdf;
                         b.eta = mat.eta; b.lt = LobeTex{nullptr, 0}; b.dropped = 0u;
+                        fr.has_diff = false;
+                        if (tex) {   // compute_scattering_functions: compute_differentials(ray), then the material's textures / bump map
+                            TexHit th;
+                            tri_fill_tex(S, r.prim, load_tri(S, r.prim), r.b0, r.b1, r.b2, &th);
+                            if (INST && r.inst && !S.inst[r.inst - 1u].identity) inst_texhit(S.inst[r.inst - 1u], &th);
+                            TexSurf ts;
+                            ts.p = th.p; ts.uv = th.uv;
+                            ts.dudx = ts.dvdx = ts.dudy = ts.dvdy = 0.0f;
+                            ts.dpdx = ts.dpdy = f3{0.0f, 0.0f, 0.0f};
+                            if (cur.has) compute_differentials(th, cur.rx_o, cur.rx_d, cur.ry_o, cur.ry_d, &ts);
+                            fr.has_diff = cur.has;
+                            fr.in_rx_d = cur.rx_d; fr.in_ry_d = cur.ry_d;
+                            fr.dpdx = ts.dpdx; fr.dpdy = ts.dpdy;
+                            fr.dndx = th.sh_dndu * ts.dudx + th.sh_dndv * ts.dvdx;
+                            fr.dndy = th.sh_dndu * ts.dudy + th.sh_dndv * ts.dvdy;
+                            if (S.mat_flags && S.mat_flags[fr.it.h.material]) {
+                                float4* rows = tex + (size_t)sp * tex_rows * tex_stride;
+                                texture_hit_call(S, base.tt, th, ts, fr.it.h.material, rows, tex_stride);
+                                b.lt = LobeTex{rows, tex_stride};
+                                const float4 m4 = rows[4 * (size_t)tex_stride];
+                                const uint32_t tf = __float_as_uint(m4.w);
+                                b.dropped = (tf >> 8) & 0xffu;
+                                if (tf & 1u) {   // Material::bump replaced the shading geometry
+                                    const float4 d4 = rows[5 * (size_t)tex_stride];
+                                    fr.it.h.sh_n = f3{m4.x, m4.y, m4.z};
+                                    fr.it.h.sh_dpdu = f3{d4.x, d4.y, d4.z};
+                                }
+                            }
+                        }
                         b.ss = normalize(fr.it.h.sh_dpdu); b.ns = fr.it.h.sh_n; b.ng = fr.it.h.n; b.ts = cross(fr.it.h.sh_n, b.ss);
                         b.lobes = S.bxdfs + mat.first_bxdf;
                         b.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
@@ -170,8 +237,8 @@ struct DlSerial {
                         if (sp + 1u < base.rd.max_depth && sp + 1u < RSPT_DL_SERIAL_DEPTH) {
                             fr.l = l;
                             f3 co, cd;
-                            if (specular(fr, false, &co, &cd, &fr.f, &fr.s)) { fr.stage = 1u; ray_o = co; ray_d = cd; sp++; spawned = true; }
-                            else if (specular(fr, true, &co, &cd, &fr.f, &fr.s)) { fr.stage = 2u; ray_o = co; ray_d = cd; sp++; spawned = true; }
+                            if (specular(fr, false, &co, &cd, &fr.f, &fr.s, &cur)) { fr.stage = 1u; ray_o = co; ray_d = cd; sp++; spawned = true; }
+                            else if (specular(fr, true, &co, &cd, &fr.f, &fr.s, &cur)) { fr.stage = 2u; ray_o = co; ray_d = cd; sp++; spawned = true; }
                         }
                     }
                 }
@@ -185,7 +252,7 @@ struct DlSerial {
                 fr.l = fr.l + fr.f * ret * mkrgb(fr.s);   // f * li(child) * Spectrum(|wi . ns| / pdf)
                 if (fr.stage == 1u) {   // the reflection subtree is done: now the transmission side draws its sample
                     f3 co, cd;
-                    if (specular(fr, true, &co, &cd, &fr.f, &fr.s)) { fr.stage = 2u; ray_o = co; ray_d = cd; break; }
+                    if (specular(fr, true, &co, &cd, &fr.f, &fr.s, &cur)) { fr.stage = 2u; ray_o = co; ray_d = cd; break; }
                 }
                 ret = fr.l;
                 sp--;

@@ -72,7 +72,7 @@ RDEV uint32_t virtual_block() {
 }
 
 // ---- K1 -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
                                                 uint32_t* __restrict__ q_active, uint32_t* __restrict__ q_closest, QueueCounts* cnt) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) { cnt->active = bt.n; cnt->closest = bt.n; cnt->any = 0; }
@@ -710,7 +710,7 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
     }
     texture_hit(sc, tt, h, s, tri.material, pb.tex + p, pb.tex_stride);
 }
-__global__ __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
                                                  const uint32_t* __restrict__ count_in) {
     const uint32_t n = *count_in;
     // inlined at this call site: as a call (the compiler's choice once the stage had a second caller) the launch runs 28 % longer — 248 VGPRs and
@@ -738,7 +738,7 @@ RDEV uint32_t bin_key(const SceneDev& sc, const PathBuf& pb, uint32_t max_depth,
     const uint32_t mat = __float_as_uint(sc.tris[3 * (size_t)prim + 2].y);
     return mat == 0xffffffffu ? 1u : 2u + mat % (RSPT_BIN_K - 2u);
 }
-__global__ __launch_bounds__(256) void k_bin_count(SceneDev sc, PathBuf pb, uint32_t max_depth, const uint32_t* __restrict__ q_active,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_bin_count(SceneDev sc, PathBuf pb, uint32_t max_depth, const uint32_t* __restrict__ q_active,
                                                    const QueueCounts* __restrict__ cnt_in, uint8_t* __restrict__ keys, BinInfo* bi) {
     __shared__ uint32_t hist[RSPT_BIN_K];
     if (threadIdx.x < RSPT_BIN_K) hist[threadIdx.x] = 0u;
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void k_bin_count(SceneDev sc, PathBuf pb, uint
     __syncthreads();
     if (threadIdx.x < RSPT_BIN_K && hist[threadIdx.x]) atomicAdd(&bi->count[threadIdx.x], hist[threadIdx.x]);
 }
-__global__ void k_bin_starts(BinInfo* bi, uint32_t* __restrict__ q_sorted) {  // one 64-thread block
+RSPT_PLAIN_KERNEL void k_bin_starts(BinInfo* bi, uint32_t* __restrict__ q_sorted) {  // one 64-thread block
     __shared__ uint32_t start[RSPT_BIN_K];
     if (threadIdx.x == 0) {
         uint32_t at = 0;
@@ -766,7 +766,7 @@ __global__ void k_bin_starts(BinInfo* bi, uint32_t* __restrict__ q_sorted) {  //
     }
 }
 #define RSPT_BIN_E 8  // queue entries per thread and round of k_bin_scatter: one global atomic per class per 2048 entries (its round trip is what a round waits for)
-__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt_in, const uint8_t* __restrict__ keys,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_bin_scatter(const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt_in, const uint8_t* __restrict__ keys,
                                                      BinInfo* bi, uint32_t* __restrict__ q_sorted) {
     __shared__ uint32_t s_cnt[RSPT_BIN_E * 4][RSPT_BIN_K], s_base[RSPT_BIN_K];
     const uint32_t n = cnt_in->active;
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
 // halton.rs:260-272) -> n shadow rays.  Ray k of path i sits at ray_sh[i * n + k]; its id field carries the
 // term dot(wi, n) / (pdf * n) that stage 2 adds when the ray is unoccluded.
 #define RSPT_AO_SKIP 0xffffffffu  // id of a ray that is not traced (pdf == 0)
-__global__ __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
                                                   uint32_t n_samples, uint32_t cos_sample, uint32_t* __restrict__ q_any, QueueCounts* cnt) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= bt.n) return;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Bat
     }
 }
 // Stage 2: l += Spectrum::new(term) for the unoccluded rays, in array order (ao.rs:86-91)
-__global__ __launch_bounds__(256) void k_ao_resolve(Batch bt, PathBuf pb, uint32_t n_samples) {
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_ao_resolve(Batch bt, PathBuf pb, uint32_t n_samples) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= bt.n) return;
     float l = 0.0f;
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_ao_resolve(Batch bt, PathBuf pb, uint32
 // separate buffer that is folded in by k_film_resolve.
 #define RSPT_FILM_CHUNK 4
 #define RSPT_FILM_ROW (RSPT_FILM_CHUNK + 1)  // padded LDS row: the per-thread walk would otherwise hit the same banks
-__global__ __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list, float4* __restrict__ film_own,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list, float4* __restrict__ film_own,
                                               float* __restrict__ film_splat, float* __restrict__ li_out, unsigned long long* nan_count) {
     // The block's 256 pixels own one contiguous range of path slots (pixel-major).  It is staged through LDS in chunks
     // of RSPT_FILM_CHUNK samples per pixel with unit-stride loads; each thread then walks its own pixel's samples in
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, PathBuf pb
 
 // Film::merge_film_tile (film.rs:346-371): contrib_sum RGB -> XYZ, plus filter weight sum.
 // `add` = 1 accumulates into film_out (multi-pass renders), 0 overwrites.
-__global__ void k_film_resolve(const float4* __restrict__ film_own, const float4* __restrict__ film_splat, float4* __restrict__ film_out, uint32_t n) {
+RSPT_PLAIN_KERNEL void k_film_resolve(const float4* __restrict__ film_own, const float4* __restrict__ film_splat, float4* __restrict__ film_out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 a = film_own[i], s = film_splat[i];
@@ -1110,7 +1110,7 @@ RDEV float ld_voxel_light_contrib(const SceneDev& sc, int32_t nvx, int32_t nvy, 
     }
     return contrib;
 }
-__global__ void k_ld_contrib(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, float* __restrict__ func) {
+RSPT_PLAIN_KERNEL void k_ld_contrib(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, float* __restrict__ func) {
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t total = (uint64_t)nvx * nvy * nvz * sc.n_lights;
     if (gid >= total) return;
@@ -1133,13 +1133,13 @@ RDEV void ld_build_row(uint32_t nl, int mode, float* f, float* c, float* func_in
     else for (uint32_t i = 1; i <= nl; i++) c[i] /= fi;
     *func_int = fi;
 }
-__global__ void k_ld_build(uint32_t n_vox, uint32_t nl, int mode, float* __restrict__ func, float* __restrict__ cdf, float* __restrict__ func_int) {
+RSPT_PLAIN_KERNEL void k_ld_build(uint32_t n_vox, uint32_t nl, int mode, float* __restrict__ func, float* __restrict__ cdf, float* __restrict__ func_int) {
     uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_vox) return;
     ld_build_row(nl, mode, func + (size_t)v * nl, cdf + (size_t)v * (nl + 1), func_int + v);
 }
 // uniform: func = 1; power: func = Light::power().y() (integrator.rs:573-584, diffuse.rs:85-93)
-__global__ void k_ld_fixed(SceneDev sc, int power, float* __restrict__ func) {
+RSPT_PLAIN_KERNEL void k_ld_fixed(SceneDev sc, int power, float* __restrict__ func) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= sc.n_lights) return;
     if (!power) { func[j] = 1.0f; return; }
@@ -1156,7 +1156,7 @@ struct LightLazy {
     uint32_t max_rows;
     uint32_t overflow;   // a voxel could not get a row: the render fails with RSPT_E_NOMEM
 };
-__global__ __launch_bounds__(256) void k_ld_mark(SceneDev sc, LightDistDev ld, PathBuf pb, uint32_t max_depth, const uint32_t* __restrict__ q_active,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_ld_mark(SceneDev sc, LightDistDev ld, PathBuf pb, uint32_t max_depth, const uint32_t* __restrict__ q_active,
                                                  const QueueCounts* __restrict__ cnt_in, LightLazy* lz, uint32_t* __restrict__ new_list) {
     const uint32_t n = cnt_in->active;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_ld_mark(SceneDev sc, LightDistDev ld, P
     }
 }
 // contributions of every light to the claimed voxels: the body of k_ld_contrib with (row, voxel) from the list
-__global__ void k_ld_contrib_list(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, const LightLazy* lz, const uint32_t* __restrict__ new_list, float* __restrict__ func) {
+RSPT_PLAIN_KERNEL void k_ld_contrib_list(SceneDev sc, int32_t nvx, int32_t nvy, int32_t nvz, const LightLazy* lz, const uint32_t* __restrict__ new_list, float* __restrict__ func) {
     const uint64_t n_new = lz->n_new < lz->max_rows - lz->n_rows ? lz->n_new : lz->max_rows - lz->n_rows;
     const uint64_t total = n_new * sc.n_lights;
     for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
@@ -1195,7 +1195,7 @@ __global__ void k_ld_contrib_list(SceneDev sc, int32_t nvx, int32_t nvy, int32_t
         func[((uint64_t)lz->n_rows + k) * sc.n_lights + j] = ld_voxel_light_contrib(sc, nvx, nvy, nvz, v, j);
     }
 }
-__global__ void k_ld_build_list(uint32_t nl, const LightLazy* lz, const uint32_t* __restrict__ new_list, float* __restrict__ func, float* __restrict__ cdf,
+RSPT_PLAIN_KERNEL void k_ld_build_list(uint32_t nl, const LightLazy* lz, const uint32_t* __restrict__ new_list, float* __restrict__ func, float* __restrict__ cdf,
                                 float* __restrict__ func_int, int32_t* __restrict__ table) {
     const uint32_t n_new = lz->n_new < lz->max_rows - lz->n_rows ? lz->n_new : lz->max_rows - lz->n_rows;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_new; k += gridDim.x * blockDim.x) {
@@ -1204,7 +1204,7 @@ __global__ void k_ld_build_list(uint32_t nl, const LightLazy* lz, const uint32_t
         table[new_list[k]] = (int32_t)row;
     }
 }
-__global__ void k_ld_commit(LightLazy* lz) {
+RSPT_PLAIN_KERNEL void k_ld_commit(LightLazy* lz) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t n_new = lz->n_new < lz->max_rows - lz->n_rows ? lz->n_new : lz->max_rows - lz->n_rows;
     lz->n_rows += n_new;
@@ -1212,7 +1212,7 @@ __global__ void k_ld_commit(LightLazy* lz) {
 }
 
 // scene upload helper: build the 48-byte triangle records from the indexed ABI arrays
-__global__ void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mesh* __restrict__ meshes, const float* __restrict__ P, uint32_t n,
+RSPT_PLAIN_KERNEL void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mesh* __restrict__ meshes, const float* __restrict__ P, uint32_t n,
                              float4* __restrict__ tris, const uint32_t* __restrict__ inst_cont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1233,7 +1233,7 @@ __global__ void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mes
 }
 
 // stage hook rspt_libm: one of the device's libm restatements (glibc_libm.h) over an array
-__global__ void k_libm(uint32_t fn, const float* __restrict__ x, const float* __restrict__ y, uint64_t n, float* __restrict__ out) {
+RSPT_PLAIN_KERNEL void k_libm(uint32_t fn, const float* __restrict__ x, const float* __restrict__ y, uint64_t n, float* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];

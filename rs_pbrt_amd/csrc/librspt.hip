@@ -25,6 +25,11 @@
 #include "direct.h"
 #include "vol.h"
 #include "tile_serial.h"
+#include "lane_serial.h"
+// the heavy kernel templates are compiled in tu_*.hip; here they are only declared (tu_decl.h)
+#define RSPT_TU_X extern
+#define RSPT_TU_ALL
+#include "tu_decl.h"
 
 using namespace rspt;
 
@@ -559,9 +564,7 @@ uint32_t trace_grid() { return grid_for((uint32_t)env_size("RSPT_TRACE_BLOCKS_PE
 // A scene is served by the narrowest compiled feature set that covers what it can put in front of the stage (rspt_scene_s.shade_features
 // + the sampler): the code for every other lobe type, light kind, texture slot, instance transform and the Halton sampler folds away,
 // and with it registers (generic: 212 VGPRs = 2 waves / SIMD).  The arithmetic that remains is the same, so results do not change.
-constexpr uint32_t SV_DIFFUSE = RSPT_SF_LOBE(RSPT_BXDF_LAMBERT_R) | SF_L_AREA;                      // matte scenes under area lights: C1, C2
-constexpr uint32_t SV_PLASTIC = SV_DIFFUSE | RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R) | SF_VERTEX;      // + plastic, smooth-shaded meshes: the C3 stand-in
-constexpr uint32_t SV_TEXTURED = SV_PLASTIC | RSPT_SF_LOBE(RSPT_BXDF_OREN_NAYAR) | SF_TEX;          // + textured materials: the C4 stand-in
+// (the feature sets SV_DIFFUSE / SV_PLASTIC / SV_TEXTURED / SV_GENERIC: tu_decl.h, next to the instantiations they name)
 typedef void (*ShadeKernel)(RSPT_SHADE_ARGS);
 // natural = the compiler's own register budget; w3 / w4 = built for 3 / 4 waves per SIMD (amdgpu_waves_per_eu: what does not fit 168 / 128
 // VGPRs is spilled); dflt = which of the three runs.  Measured on one box (profiles/r03_ab_shade.md; Msamples/s of C2 / the C3 stand-in,
@@ -572,7 +575,7 @@ const ShadeVariant g_shade_variants[] = {
     {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 0},
     {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
     {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0},
-    {SF_ALL & ~SF_DYNAMIC, "generic", k_shade<SF_ALL & ~SF_DYNAMIC>, k_shade_w<SF_ALL & ~SF_DYNAMIC, 3>, k_shade_w<SF_ALL & ~SF_DYNAMIC, 4>, 0},
+    {SV_GENERIC, "generic", k_shade<SV_GENERIC>, k_shade_w<SV_GENERIC, 3>, k_shade_w<SV_GENERIC, 4>, 0},
     {SF_ALL, "dynamic", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0},   // + lobe lists built per hit (material_assembly.h)
 };
 // RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 0 | 3 | 4 one of its builds (A/B)
@@ -588,6 +591,7 @@ ShadeKernel shade_kernel_for(uint32_t need, const char** name_out) {
     return k_shade<SF_ALL>;
 }
 
+constexpr int RSPT_DL_RETRY_LANE = -1000;   // batch_direct -> the batch loop: redo this batch with the per-lane form (never leaves render_impl)
 int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (!s || !d) return fail(RSPT_E_INVALID, "null scene or render desc");
@@ -620,10 +624,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
     const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
     if (direct) {
-        if (d->max_depth < 1 || d->max_depth > (pixel_sampler ? (uint32_t)RSPT_DL_SERIAL_DEPTH : 8u))
-            return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, 8] under Sobol' / Halton (the specular tree has 2^max_depth slots per camera sample), [1, %d] under a pixel sampler (one lane walks the tree)", RSPT_DL_SERIAL_DEPTH);
+        if (d->max_depth < 1 || d->max_depth > (uint32_t)RSPT_DL_SERIAL_DEPTH)
+            return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, %d] (the explicit recursion stack of the per-lane form, dl_serial.h)", RSPT_DL_SERIAL_DEPTH);
         if (d->direct_strategy > RSPT_DIRECT_SAMPLE_ONE) return fail(RSPT_E_INVALID, "bad direct_strategy");
-        if (s && s->has_textures) return fail(RSPT_E_UNSUPPORTED, "directlighting with textured materials");
+        if (s && s->has_dynamic) return fail(RSPT_E_UNSUPPORTED, "directlighting with a material whose lobe list depends on a texture");
         for (uint32_t i = 0; s && d->n_light_samples && i < s->dev.n_lights; i++)
             if (d->n_light_samples[i] < 1 || d->n_light_samples[i] > 4096) return fail(RSPT_E_INVALID, "n_light_samples[%u] out of range", i);
     }
@@ -790,8 +794,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const bool ao = d->integrator == RSPT_INTEGRATOR_AO;
     const uint32_t ao_n = ao ? d->ao_n_samples : 1u;
     if (ao) cap = std::max<size_t>(cap / ao_n, 1024);
-    const uint32_t dl_H = (direct && !pixel_sampler) ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h; a pixel sampler's lane walks the tree itself)
-    if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << 26) / dl_H, 1024);
+    // directlighting under Sobol' / Halton: the wavefront form (direct.h) unless the render needs what only the per-lane form has
+    // (lane_serial.h): textured materials, more than 8 recursion levels; RSPT_DL_FORM=lane forces it (A/B, tests)
+    const char* dl_form_env = getenv("RSPT_DL_FORM");
+    bool dl_lane = direct && !pixel_sampler && (s->has_textures || d->max_depth > 8 || (dl_form_env && !strcmp(dl_form_env, "lane")));
+    const uint32_t dl_H = (direct && !pixel_sampler && !dl_lane) ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h; in the per-lane forms a lane walks the tree itself)
+    if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? 22 : 26)) / dl_H, 1024);
     if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     size_t pix_per_batch = 1;
@@ -800,13 +808,33 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
         pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
         rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H);
-        if (rc == RSPT_OK && direct && !pixel_sampler) rc = ensure_direct(g.cap);
+        if (rc == RSPT_OK && direct && !pixel_sampler && !dl_lane) rc = ensure_direct(g.cap);
         if (rc == RSPT_OK && volpath) rc = ensure_vol(g.cap);
         if (rc == RSPT_OK) break;
         (void)hipGetLastError();  // out of memory: clear the sticky error and try half the batch
         free_paths();
         if (cap <= ((size_t)1 << 20)) return rc;
         cap /= 2;
+    }
+    // the per-lane directlighting forms: per-level texture rows, the light sample counts on the device, error / truncation words
+    struct TmpGuard { std::vector<void*> p; ~TmpGuard() { for (void* q : p) (void)hipFree(q); } } dl_guard;
+    float4* dl_tex = nullptr; int32_t* dl_nls = nullptr; uint32_t* dl_words = nullptr;
+    const uint32_t dl_tex_rows = RSPT_TEX_ROWS;
+    const size_t dl_lanes = pixel_sampler ? blocks.size() : pix_per_batch * ns;
+    if (direct) {
+        if (s->has_textures) {
+            if ((rc = dev_alloc(&dl_tex, (size_t)d->max_depth * dl_tex_rows * std::max<size_t>(dl_lanes, 1)))) return rc;
+            dl_guard.p.push_back(dl_tex);
+        }
+        if (!pixel_sampler) {
+            if ((rc = dev_alloc(&dl_words, 2))) return rc;
+            dl_guard.p.push_back(dl_words);
+            if (d->n_light_samples && s->dev.n_lights) {
+                if ((rc = dev_alloc(&dl_nls, s->dev.n_lights))) return rc;
+                dl_guard.p.push_back(dl_nls);
+                HIP_TRY(hipMemcpy(dl_nls, d->n_light_samples, s->dev.n_lights * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+        }
     }
     const uint32_t nominal_iters = d->max_depth + 1;
     // a pass through a null-material surface costs a wavefront iteration without counting as a bounce (path.rs:109-116 has no limit
@@ -1013,9 +1041,34 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         uint32_t dl_err = 0;
         HIP_TRY(hipMemcpyAsync(&dl_err, dl.error, sizeof dl_err, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        if (dl_err == 1u) return fail(RSPT_E_UNSUPPORTED, "directlighting: a material with several specular lobes of one kind (the lobe choice would depend on a sample value)");
+        if (dl_err == 1u) return RSPT_DL_RETRY_LANE;   // a material with several specular lobes of one kind: the lobe choice depends on a sample value, the tree cannot be traced ahead
         if (dl_err) return fail(RSPT_E_UNSUPPORTED, "directlighting: a camera sample draws more than the sampler's %u dimensions (the reference panics there, sobol.rs:119-124)", dim_limit);
         it = md + 4;
+        return RSPT_OK;
+    };
+    auto batch_direct_lane = [&](const Batch& bt, uint32_t& it) -> int {  // the same integrator, one lane per camera sample (lane_serial.h)
+        const uint32_t nl = s->dev.n_lights, md = d->max_depth;
+        const bool all = d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL;
+        const uint32_t n_arrays = all ? 2u * md * nl : 0u;
+        const uint32_t dim_limit = halton ? vol_dim_limit + 1u : 1024u;
+        if (5ull + 2ull * n_arrays > dim_limit)
+            return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays exceed the sampler's %u dimensions", n_arrays, dim_limit);
+        HIP_TRY(hipMemsetAsync(dl_words, 0, 2 * sizeof(uint32_t), g.stream));
+        const LaneDesc ln{all ? dl_nls : nullptr, n_arrays, all ? 1u : 0u, dim_limit, dl_tex, (uint32_t)dl_lanes, dl_tex_rows,
+                          s->has_null_material ? (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : 0u, dl_words, dl_words + 1};
+        const dim3 lgrid((bt.n + 63u) / 64u);
+        ev_open(2, 0);
+#define RSPT_LN(I, A) hipLaunchKernelGGL((k_lane_dl<I, A>), lgrid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, bt, g.pb, g.pix_list, ln)
+        if (s->has_instances) { if (s->has_alpha) RSPT_LN(true, true); else RSPT_LN(true, false); }
+        else { if (s->has_alpha) RSPT_LN(false, true); else RSPT_LN(false, false); }
+#undef RSPT_LN
+        ev_close(2, 0);
+        uint32_t w[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(w, dl_words, sizeof w, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (w[0]) return fail(RSPT_E_UNSUPPORTED, "directlighting: a camera sample draws more than the sampler's %u dimensions (the reference panics there, sobol.rs:119-124)", dim_limit);
+        truncated += w[1];
+        it = 1;
         return RSPT_OK;
     };
     auto batch_ao = [&](const Batch& bt, uint32_t& it) -> int {  // AOIntegrator::li: closest hit, n shadow rays per hit, sum of the unoccluded terms
@@ -1166,7 +1219,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             return rc;
         HIP_TRY(hipMemsetAsync(trunc_d, 0, sizeof(uint32_t), g.stream));
         if (d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) HIP_TRY(hipMemcpyAsync(c_pixel_d, d->maxmin_c_pixel, 32 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_sz_d, arr_base_d, (uint32_t)arr_sz.size(), arr_total, d->ao_cos_sample, nls_d, d->direct_strategy};
+        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_sz_d, arr_base_d, (uint32_t)arr_sz.size(), arr_total, d->ao_cos_sample, nls_d, d->direct_strategy, dl_tex, dl_tex_rows};
         // lanes per wave: a lane that shares its wave waits whenever the others diverge, so spread the tiles over as many waves
         // as the chip holds (256 CUs x 4 SIMDs x 2) before doubling up
         uint32_t lanes = 1;
@@ -1234,7 +1287,15 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             uint32_t it = 0;
             g_queue_hint = 0xffffffffu;
             if (volpath) rc = batch_volpath(bt, it);
-            else if (direct) rc = batch_direct(bt, it);
+            else if (direct) {
+                rc = dl_lane ? batch_direct_lane(bt, it) : batch_direct(bt, it);
+                if (rc == RSPT_DL_RETRY_LANE) {   // from here on the per-lane form serves this render; this batch starts over
+                    dl_lane = true;
+                    HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));
+                    hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
+                    rc = batch_direct_lane(bt, it);
+                }
+            }
             else if (ao) rc = batch_ao(bt, it);
             else rc = batch_path(bt, it);
             if (rc) return rc;

@@ -32,6 +32,8 @@ struct PixDesc {              // the sampler's parameters and this render's vect
     uint32_t ao_cos_sample;
     const int32_t* n_light_samples;   // directlighting, strategy all: per light (device copy), nullptr = 1 each
     uint32_t direct_strategy;
+    float4* dl_tex;                   // directlighting over textured materials: texture-stage rows per recursion level (dl_serial.h), [level][row][tile]
+    uint32_t dl_tex_rows;
 };
 
 // MODE 0: PathIntegrator::li.  1: AOIntegrator::li (ao.rs:50-96) with its sample array from the pixel sampler: closest hit, frame on the true
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                 pb.state[slot] = ST_ALIVE;
                 pb.p_film[slot] = make_float2(p_film.x, p_film.y);
                 if (MODE == 3) {
-                    DlSerial<INST, ALPHA> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false}, &px, pd.n_light_samples, pd.direct_strategy == RSPT_DIRECT_SAMPLE_ALL};
+                    DlSerial<INST, ALPHA, PixSampler> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false}, &px, pd.n_light_samples, pd.direct_strategy == RSPT_DIRECT_SAMPLE_ALL,
+                                                         pd.dl_tex ? pd.dl_tex + t : nullptr, n_tiles, pd.dl_tex_rows, p_film, p_lens};
                     const rgb l = dl.li(o, d, t_max);
                     if (dl.base.truncated) atomicAdd(truncated, 1u);
                     const size_t out = (size_t)k * pd.spp + s;

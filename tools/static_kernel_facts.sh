@@ -4,7 +4,11 @@
 set -eu
 repo=$(cd "$(dirname "$0")/.." && pwd); work=$(mktemp -d)
 F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -I$repo/include --cuda-device-only"
-/opt/rocm/bin/hipcc $F -S $repo/rs_pbrt_amd/csrc/librspt.hip -o $work/final.s
-/opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage -c $repo/rs_pbrt_amd/csrc/librspt.hip -o $work/x.o 2> $work/ru.txt
+# every translation unit of the library (rs_pbrt_amd/csrc/Makefile: librspt.hip + the tu_*.hip instantiation groups)
+: > $work/final.s; : > $work/ru.txt
+for tu in $repo/rs_pbrt_amd/csrc/*.hip; do
+  /opt/rocm/bin/hipcc $F -S $tu -o $work/one.s && cat $work/one.s >> $work/final.s
+  /opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage -c $tu -o $work/x.o 2>> $work/ru.txt
+done
 python3 $repo/tools/static_kernel_facts.py $work $repo
 rm -rf $work
