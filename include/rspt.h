@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 18
+#define RSPT_ABI_VERSION 19
 
 /* error codes */
 #define RSPT_OK 0
@@ -377,7 +377,7 @@ typedef struct {
     float filter_table[256];       /* film.rs:198-211                                 */
     float max_sample_luminance;    /* film.rs:250-251; +inf by default                */
     float raster_to_camera[16];    /* row-major Transform.m (perspective.rs:32)       */
-    float camera_to_world[16];     /* static camera_to_world.start_transform.m        */
+    float camera_to_world[16];     /* camera_to_world.start_transform.m (the only one unless camera_animated, below) */
     float lens_radius, focal_distance;
     float shutter_open, shutter_close;
     uint32_t sampler_kind;         /* RSPT_SAMPLER_*                                  */
@@ -429,6 +429,16 @@ typedef struct {
      * full frame's (xyz and filter_weight_sum alike): a caller that keeps the summed film and the next sample index can stop and
      * resume, show intermediate results, or re-render a lost rank's shard elsewhere.  The pixel samplers accept the full range only. */
     uint64_t sample_begin, sample_count;
+    /* A moving camera (CameraBase.camera_to_world is an AnimatedTransform, core/transform.rs:894-2124; perspective.rs:261-279
+     * transforms every camera ray — and its differentials — with the matrix interpolated at the ray's time,
+     * lerp(CameraSample.time, shutter_open, shutter_close)).  camera_animated = 0: camera_to_world for every ray.  1: camera_to_world is
+     * start_transform.m at camera_time[0], camera_to_world_end is end_transform.m at camera_time[1] (api.rs transform_start_time /
+     * transform_end_time); the library decomposes both (AnimatedTransform::decompose: translation, rotation quaternion, scale) and
+     * interpolates per ray (translation and scale linearly, rotation by slerp), start / end matrix outside the interval.  Object
+     * instances and lights do not move in this ABI (rspt_instance carries one matrix). */
+    uint32_t camera_animated;
+    float camera_to_world_end[16];
+    float camera_time[2];
 } rspt_render_desc;
 /* RSPT_INTEGRATOR_VOLPATH: VolPathIntegrator::li (src/integrators/volpath.rs:60-347) with max_depth, rr_threshold and
  * light_strategy as for "path" (api.rs:350-380).  Camera rays start outside every medium (make_camera passes

@@ -50,6 +50,19 @@ void orc_camera_ray(const rspt_render_desc* rd, const float cs[5], float out[7])
     Ray r = camera_ray(*rd, P2{cs[0], cs[1]}, cs[2], P2{cs[3], cs[4]});
     out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z; out[6] = r.t_max;
 }
+// AnimatedTransform of the camera: the decomposition (t[2][3], r[2][4] xyzw, s[2][16]) and the matrix interpolated at `time`
+void orc_camera_matrix(const rspt_render_desc* rd, float time, float m_out[16], float* trs_out) {
+    AnimatedTransform at = camera_animation(*rd);
+    M44 m = at.interpolate(time);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m_out[4 * i + j] = m.m[i][j];
+    if (trs_out) {
+        for (int k = 0; k < 2; k++) {
+            trs_out[3 * k] = at.t[k].x; trs_out[3 * k + 1] = at.t[k].y; trs_out[3 * k + 2] = at.t[k].z;
+            trs_out[6 + 4 * k] = at.r[k].v.x; trs_out[6 + 4 * k + 1] = at.r[k].v.y; trs_out[6 + 4 * k + 2] = at.r[k].v.z; trs_out[6 + 4 * k + 3] = at.r[k].w;
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) trs_out[14 + 16 * k + 4 * i + j] = at.s[k].m[i][j];
+        }
+    }
+}
 void orc_offset_ray_origin(const float p[3], const float pe[3], const float n[3], const float w[3], float out[3]) {
     V3 r = offset_ray_origin(V3{p[0], p[1], p[2]}, V3{pe[0], pe[1], pe[2]}, V3{n[0], n[1], n[2]}, V3{w[0], w[1], w[2]});
     out[0] = r.x; out[1] = r.y; out[2] = r.z;

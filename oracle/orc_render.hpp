@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "orc_material.hpp"
+#include "orc_animated.hpp"
 
 namespace orc {
 
@@ -1395,7 +1396,12 @@ static inline Spec recursive_li(RenderCtx& cx, const Ray& ray, Sampler& sampler,
 }
 
 // ---- PerspectiveCamera::generate_ray_differential: src/cameras/perspective.rs:190-280 ----
-static inline Ray camera_ray(const rspt_render_desc& rd, P2 p_film, Float time_s, P2 p_lens) {
+// CameraBase.camera_to_world (an AnimatedTransform): the key matrices of a moving camera, or the one matrix twice
+static inline AnimatedTransform camera_animation(const rspt_render_desc& rd) {
+    return rd.camera_animated ? AnimatedTransform(rd.camera_to_world, rd.camera_time[0], rd.camera_to_world_end, rd.camera_time[1])
+                              : AnimatedTransform(rd.camera_to_world, 0.0f, rd.camera_to_world, 1.0f);
+}
+static inline Ray camera_ray(const rspt_render_desc& rd, const AnimatedTransform& c2w, P2 p_film, Float time_s, P2 p_lens) {
     V3 p_camera = transform_point(rd.raster_to_camera, V3{p_film.x, p_film.y, 0.0f});
     V3 dir = normalize(p_camera);
     Ray in_ray{V3{0, 0, 0}, dir, INF, lerp(time_s, rd.shutter_open, rd.shutter_close)};
@@ -1429,8 +1435,9 @@ static inline Ray camera_ray(const rspt_render_desc& rd, P2 p_film, Float time_s
         in_ray.ry_o = V3{pl.x, pl.y, 0.0f};
         in_ray.ry_d = normalize(pfy - in_ray.ry_o);
     }
-    return transform_ray(rd.camera_to_world, in_ray);
+    return c2w.transform_ray(in_ray); // perspective.rs:279
 }
+static inline Ray camera_ray(const rspt_render_desc& rd, P2 p_film, Float time_s, P2 p_lens) { return camera_ray(rd, camera_animation(rd), p_film, time_s, p_lens); }
 
 // ---- film: src/core/film.rs:57-153,308-371 ----
 struct FilmTilePixel { Spec contrib_sum; Float filter_weight_sum = 0; };
@@ -1513,6 +1520,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
     std::atomic<size_t> next{0};
     int cw = rd.crop_px[2] - rd.crop_px[0], ch = rd.crop_px[3] - rd.crop_px[1];
     std::vector<Counters> tc((size_t)std::max(1, num_threads));
+    const AnimatedTransform cam_c2w = camera_animation(rd);
     auto worker = [&](int tid) {
         Sampler sampler(rd);
         if (rd.integrator == RSPT_INTEGRATOR_AO && ext_integrator == ORC_INTEGRATOR_FROM_DESC) sampler.request_2d_array((int32_t)rd.ao_n_samples); // ao.rs:44-48
@@ -1540,7 +1548,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         P2 p_film{(Float)px + f2.x, (Float)py + f2.y}; // sampler.rs:85-95
                         Float time_s = sampler.get_1d();
                         P2 p_lens = sampler.get_2d();
-                        Ray ray = camera_ray(rd, p_film, time_s, p_lens);
+                        Ray ray = camera_ray(rd, cam_c2w, p_film, time_s, p_lens);
                         ray.scale_differentials(1.0f / std::sqrt((Float)rd.spp)); // integrator.rs:140-144 (get_samples_per_pixel)
                         Float ray_weight = 1.0f;
                         if (rd.sample_count && ((uint64_t)sampler.cur_sample() < rd.sample_begin || (uint64_t)sampler.cur_sample() >= rd.sample_begin + rd.sample_count)) {

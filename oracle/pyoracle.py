@@ -49,6 +49,7 @@ def lib():
         L.orc_camera_sample.restype = None
         L.orc_camera_sample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
         L.orc_camera_ray.restype = None; L.orc_camera_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_camera_matrix.restype = None; L.orc_camera_matrix.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.orc_offset_ray_origin.restype = None; L.orc_offset_ray_origin.argtypes = [C.c_void_p] * 5
         L.orc_concentric_sample_disk.restype = None; L.orc_concentric_sample_disk.argtypes = [C.c_float, C.c_float, C.c_void_p]
         L.orc_bsdf_f.restype = None

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM, E_PEER = 0, -1, -2, -3, -4, -5, -6
 
@@ -123,7 +123,8 @@ class RenderDesc(C.Structure):
                 ("ao_cos_sample", C.c_uint32), ("film_reduce", C.c_uint32), ("tables", SamplerTables),
                 ("direct_strategy", C.c_uint32), ("pixel_dimensions", C.c_uint32), ("n_light_samples", C.c_void_p),
                 ("strat_x", C.c_uint32), ("strat_y", C.c_uint32), ("strat_jitter", C.c_uint32), ("allow_slow_paths", C.c_uint32), ("maxmin_c_pixel", C.c_void_p),
-                ("sample_begin", C.c_uint64), ("sample_count", C.c_uint64)]
+                ("sample_begin", C.c_uint64), ("sample_count", C.c_uint64),
+                ("camera_animated", C.c_uint32), ("camera_to_world_end", C.c_float * 16), ("camera_time", C.c_float * 2)]
 
 
 class Ray(C.Structure):

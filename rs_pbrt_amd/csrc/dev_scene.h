@@ -86,7 +86,18 @@ RDEV uint32_t light_row(const LightDistDev& ld, uint32_t vox) {
 }
 
 // Everything SamplerIntegrator::render reads per sample (subset of rspt_render_desc)
+// A moving camera (AnimatedTransform, core/transform.rs:894-2124): what AnimatedTransform::new leaves for interpolate — the end matrix and
+// the two decompositions (translation, rotation quaternion xyzw, 4x4 scale matrix) — computed by rspt_render on the host (librspt.hip
+// decompose_camera) and read by every lane from device memory.
+struct CamAnim {
+    float end[16];
+    float t[2][3];
+    float r[2][4];
+    float s[2][16];
+    float time[2];   // start_time, end_time
+};
 struct RenderDev {
+    const CamAnim* cam_anim;   // nullptr: camera_to_world holds for every ray (rspt_render_desc.camera_animated = 0, or equal key matrices)
     float raster_to_camera[16], camera_to_world[16];
     float lens_radius, focal_distance, shutter_open, shutter_close;
     int32_t sample_bounds[4], crop_px[4];
@@ -646,12 +657,78 @@ RDEV uint32_t light_voxel(const SceneDev& sc, const LightDistDev& ld, f3 p) {
     return (uint32_t)(((int64_t)pi[2] * ld.nvox[1] + pi[1]) * ld.nvox[0] + pi[0]);
 }
 
+// ---- the camera_to_world matrix of a ray: AnimatedTransform::transform_ray / interpolate (transform.rs:2081-2124) at
+// ray.time = lerp(CameraSample.time, shutter_open, shutter_close) (perspective.rs:226) ----
+RDEV void mat4_mul(const float* a, const float* b, float* r) {  // mtx_mul (transform.rs:238-249): all four products of every element, in this order
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[4 * i + j] = a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j] + a[4 * i + 2] * b[8 + j] + a[4 * i + 3] * b[12 + j];
+}
+RDEVN void camera_to_world_at(const RenderDev& rd, float time_sample, float* m) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = rd.camera_to_world[i];
+    const CamAnim* ca = rd.cam_anim;
+    if (!ca) return;
+    const float time = rd.shutter_open * (1.0f - time_sample) + rd.shutter_close * time_sample;  // pbrt.rs lerp
+    if (time <= ca->time[0]) return;
+    if (time >= ca->time[1]) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i] = ca->end[i];
+        return;
+    }
+    const float dt = (time - ca->time[0]) / (ca->time[1] - ca->time[0]);
+    const f3 t0{ca->t[0][0], ca->t[0][1], ca->t[0][2]}, t1{ca->t[1][0], ca->t[1][1], ca->t[1][2]};
+    const f3 trans = t0 * (1.0f - dt) + t1 * dt;
+    // quat_slerp (quaternion.rs:168-180)
+    const float q1[4] = {ca->r[0][0], ca->r[0][1], ca->r[0][2], ca->r[0][3]}, q2[4] = {ca->r[1][0], ca->r[1][1], ca->r[1][2], ca->r[1][3]};
+    const float cos_theta = (q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2]) + q1[3] * q2[3];
+    float q[4];
+    if (cos_theta > 0.9995f) {
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) u[i] = q1[i] * (1.0f - dt) + q2[i] * dt;
+        const float n = sqrtf((u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) + u[3] * u[3]), inv = 1.0f / n;  // quat_normalize: v * (1 / n), w / n
+        q[0] = u[0] * inv; q[1] = u[1] * inv; q[2] = u[2] * inv; q[3] = u[3] / n;
+    } else {
+        const float theta = rspt_acosf(cos_theta < -1.0f ? -1.0f : (cos_theta > 1.0f ? 1.0f : cos_theta));
+        const float thetap = theta * dt;
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) u[i] = q2[i] - q1[i] * cos_theta;
+        const float n = sqrtf((u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) + u[3] * u[3]), inv = 1.0f / n;
+        const float qp[4] = {u[0] * inv, u[1] * inv, u[2] * inv, u[3] / n};
+        const float c = rspt_cosf(thetap), sn = rspt_sinf(thetap);
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = q1[i] * c + qp[i] * sn;
+    }
+    // Quaternion::to_transform().m (quaternion.rs:80-109): the transpose of the matrix written there
+    const float xx = q[0] * q[0], yy = q[1] * q[1], zz = q[2] * q[2], xy = q[0] * q[1], xz = q[0] * q[2], yz = q[1] * q[2];
+    const float wx = q[0] * q[3], wy = q[1] * q[3], wz = q[2] * q[3];
+    const float rot[16] = {1.0f - 2.0f * (yy + zz), 2.0f * (xy - wz), 2.0f * (xz + wy), 0.0f,
+                           2.0f * (xy + wz), 1.0f - 2.0f * (xx + zz), 2.0f * (yz - wx), 0.0f,
+                           2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (xx + yy), 0.0f,
+                           0.0f, 0.0f, 0.0f, 1.0f};
+    float scale[16] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) scale[4 * i + j] = ca->s[0][4 * i + j] * (1.0f - dt) + ca->s[1][4 * i + j] * dt;
+    const float tr[16] = {1.0f, 0.0f, 0.0f, trans.x, 0.0f, 1.0f, 0.0f, trans.y, 0.0f, 0.0f, 1.0f, trans.z, 0.0f, 0.0f, 0.0f, 1.0f};
+    float tmp[16];
+    mat4_mul(tr, rot, tmp);      // Transform::translate(&trans) * rotate.to_transform()
+    mat4_mul(tmp, scale, m);     //   * Transform { m: scale, .. }
+}
+
 // ---- PerspectiveCamera::generate_ray_differential (perspective.rs:190-280), differentials dropped ----
-RDEV void camera_ray(const RenderDev& rd, f2 p_film, f2 p_lens, f3* o_out, f3* d_out, float* tmax_out) {
+// p_lens: (CameraSample.p_lens, CameraSample.time) — the time value matters to a moving camera only
+RDEV void camera_ray(const RenderDev& rd, f2 p_film, f3 p_lens, f3* o_out, f3* d_out, float* tmax_out) {
     f3 p_camera = xf_point(rd.raster_to_camera, f3{p_film.x, p_film.y, 0.0f});
     f3 o{0.0f, 0.0f, 0.0f}, d = normalize(p_camera);
+    float c2w[16];
+    camera_to_world_at(rd, p_lens.z, c2w);
     if (rd.lens_radius > 0.0f) {
-        f2 pl = concentric_disk(p_lens);
+        f2 pl = concentric_disk(f2{p_lens.x, p_lens.y});
         pl = f2{pl.x * rd.lens_radius, pl.y * rd.lens_radius};
         float ft = rd.focal_distance / d.z;
         f3 p_focus = o + d * ft;
@@ -660,8 +737,8 @@ RDEV void camera_ray(const RenderDev& rd, f2 p_film, f2 p_lens, f3* o_out, f3* d
     }
     // Transform::transform_ray (transform.rs:538-595)
     f3 o_err;
-    f3 ow = xf_point_err(rd.camera_to_world, o, &o_err);
-    f3 dw = xf_vector(rd.camera_to_world, d);
+    f3 ow = xf_point_err(c2w, o, &o_err);
+    f3 dw = xf_vector(c2w, d);
     float ls = len2(dw);
     float t_max = RSPT_INF;
     if (ls > 0.0f) {

@@ -497,7 +497,9 @@ RDEVN void compute_differentials(const TexHit& h, f3 rx_o, f3 rx_d, f3 ry_o, f3 
 
 // PerspectiveCamera::generate_ray_differential's offset rays (perspective.rs:205-220, 245-271), transformed
 // (transform.rs:550-556) and scaled by 1 / sqrt(spp) (integrator.rs:140-144; geometry.rs:2398-2405)
-RDEVN void camera_differentials(const RenderDev& rd, f2 p_film, f2 p_lens, f3 ray_o, f3 ray_d, f3* rx_o, f3* rx_d, f3* ry_o, f3* ry_d) {
+RDEVN void camera_differentials(const RenderDev& rd, f2 p_film, f3 p_lens, f3 ray_o, f3 ray_d, f3* rx_o, f3* rx_d, f3* ry_o, f3* ry_d) {
+    float c2w[16];
+    camera_to_world_at(rd, p_lens.z, c2w);   // the matrix the ray itself was transformed with (Transform::transform_ray, transform.rs:550-556)
     f3 p_camera = xf_point(rd.raster_to_camera, f3{p_film.x, p_film.y, 0.0f});
     f3 c0 = xf_point(rd.raster_to_camera, f3{0.0f, 0.0f, 0.0f});
     f3 dx_camera = xf_point(rd.raster_to_camera, f3{1.0f, 0.0f, 0.0f}) - c0;
@@ -505,7 +507,7 @@ RDEVN void camera_differentials(const RenderDev& rd, f2 p_film, f2 p_lens, f3 ra
     f3 ox{0.0f, 0.0f, 0.0f}, oy = ox;
     f3 dx = normalize(p_camera + dx_camera), dy = normalize(p_camera + dy_camera);
     if (rd.lens_radius > 0.0f) {
-        f2 pl = concentric_disk(p_lens);
+        f2 pl = concentric_disk(f2{p_lens.x, p_lens.y});
         pl = f2{pl.x * rd.lens_radius, pl.y * rd.lens_radius};
         float ftx = rd.focal_distance / dx.z;
         f3 pfx = f3{0.0f, 0.0f, 0.0f} + dx * ftx;
@@ -516,8 +518,8 @@ RDEVN void camera_differentials(const RenderDev& rd, f2 p_film, f2 p_lens, f3 ra
         oy = f3{pl.x, pl.y, 0.0f};
         dy = normalize(pfy - oy);
     }
-    f3 wox = xf_point(rd.camera_to_world, ox), woy = xf_point(rd.camera_to_world, oy);
-    f3 wdx = xf_vector(rd.camera_to_world, dx), wdy = xf_vector(rd.camera_to_world, dy);
+    f3 wox = xf_point(c2w, ox), woy = xf_point(c2w, oy);
+    f3 wdx = xf_vector(c2w, dx), wdy = xf_vector(c2w, dy);
     float s = 1.0f / sqrtf((float)rd.spp);
     *rx_o = ray_o + (wox - ray_o) * s; *ry_o = ray_o + (woy - ray_o) * s;
     *rx_d = ray_d + (wdx - ray_d) * s; *ry_d = ray_d + (wdy - ray_d) * s;

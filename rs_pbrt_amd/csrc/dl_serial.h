@@ -25,7 +25,7 @@ struct DlSerial {
     bool sample_all;
     float4* tex;                      // this lane's column of texture-stage rows (nullptr: the scene has no textured material)
     uint32_t tex_stride, tex_rows;    // lanes per row; rows per activation
-    f2 p_film, p_lens;                // the camera sample (differentials of the camera ray)
+    f2 p_film; f3 p_lens;             // the camera sample: film position, (lens x, lens y, time) — differentials of the camera ray
 
     const SceneDev& sc() const { return base.sc; }
     RDEV bool occluded(f3 o, f3 d, float t_max) { return traverse<true, INST, ALPHA, 64>(base.sc, base.tt, o, d, t_max, base.lds).prim != RSPT_MISS; }

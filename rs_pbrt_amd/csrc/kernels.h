@@ -86,15 +86,17 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
     // Sampler::get_camera_sample (sampler.rs:85-95): film 2-D, time 1-D, lens 2-D
     uint64_t index;
     float fx, fy;
-    f2 p_lens{0.0f, 0.0f};
+    f3 p_lens{0.0f, 0.0f, 0.0f};   // (lens x, lens y, time): the time value only for a moving camera
     if (rd.sampler_kind == RSPT_SAMPLER_HALTON) {
         index = halton_index(rd, px, py, (uint64_t)s);
         fy = halton_dim(rd, index, 1); fx = halton_dim(rd, index, 0);
-        if (rd.lens_radius > 0.0f) p_lens = f2{halton_dim(rd, index, 3), halton_dim(rd, index, 4)};
+        if (rd.cam_anim) p_lens.z = halton_dim(rd, index, 2);
+        if (rd.lens_radius > 0.0f) { p_lens.x = halton_dim(rd, index, 3); p_lens.y = halton_dim(rd, index, 4); }
     } else {
         index = sobol_interval_to_index(rd, (uint32_t)rd.log2_res, (uint64_t)s, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
         fy = sobol_pixel_dim(rd, index, 1, py); fx = sobol_pixel_dim(rd, index, 0, px);
-        if (rd.lens_radius > 0.0f) p_lens = f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
+        if (rd.cam_anim) p_lens.z = sobol_dim(rd, index, 2);
+        if (rd.lens_radius > 0.0f) { p_lens.x = sobol_dim(rd, index, 3); p_lens.y = sobol_dim(rd, index, 4); }
     }
     f2 p_film{(float)px + fx, (float)py + fy};
     f3 o, d;
@@ -669,7 +671,7 @@ RDEVN void texture_hit_call(const SceneDev& sc, const TexTables& tt, TexHit& h, 
 // texture the material's lobes are bound to; k_shade picks the results up from pb.tex.
 // the texture stage for path slot p (see above); lens: the camera sample's lens position when it cannot be recomputed from the
 // sample index (pixel samplers), else nullptr
-RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev& rd, const PathBuf& pb, uint32_t p, const f2* lens) {
+RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev& rd, const PathBuf& pb, uint32_t p, const f3* lens) {
     const uint32_t st = pb.state[p];
     if (!(st & ST_ALIVE)) return;
     const float4 hc = pb.hit_cont[p];
@@ -697,12 +699,13 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
         const float4 r0 = rp[0], r1 = rp[1];
         const float2 pf = pb.p_film[p];
-        f2 p_lens{0.0f, 0.0f};
-        if (lens) p_lens = *lens;   // a pixel sampler's lens sample (tile_serial.h): not a function of (index, dimension)
-        else if (rd.lens_radius > 0.0f) {
+        f3 p_lens{0.0f, 0.0f, 0.0f};
+        if (lens) p_lens = *lens;   // a pixel sampler's lens / time sample (tile_serial.h): not a function of (index, dimension)
+        else {
             const uint64_t index = pb.sobol_index[p];
-            p_lens = rd.sampler_kind == RSPT_SAMPLER_HALTON ? f2{halton_dim(rd, index, 3), halton_dim(rd, index, 4)}
-                                                            : f2{sobol_dim(rd, index, 3), sobol_dim(rd, index, 4)};
+            const bool hal = rd.sampler_kind == RSPT_SAMPLER_HALTON;
+            if (rd.lens_radius > 0.0f) { p_lens.x = hal ? halton_dim(rd, index, 3) : sobol_dim(rd, index, 3); p_lens.y = hal ? halton_dim(rd, index, 4) : sobol_dim(rd, index, 4); }
+            if (rd.cam_anim) p_lens.z = hal ? halton_dim(rd, index, 2) : sobol_dim(rd, index, 2);
         }
         f3 rx_o, rx_d, ry_o, ry_d;
         camera_differentials(rd, f2{pf.x, pf.y}, p_lens, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, &rx_o, &rx_d, &ry_o, &ry_d);

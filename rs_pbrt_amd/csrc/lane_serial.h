@@ -81,8 +81,9 @@ __global__ __launch_bounds__(64) void k_lane_dl(SceneDev sc, TexTables tt, Light
     LaneSampler smp{rd, index, 5u, 5u + 2u * ln.n_arr, (int32_t)(int16_t)(pk & 0xffffu), (int32_t)(int16_t)(pk >> 16), bt.s0 + i % bt.ns,
                     ln.n_light_samples, sc.n_lights, ln.n_arr, 0u, ln.dim_limit, false};
     const float2 pf = pb.p_film[i];
-    f2 p_lens{0.0f, 0.0f};
-    if (rd.lens_radius > 0.0f) p_lens = f2{smp.dimv(index, 3u), smp.dimv(index, 4u)};
+    f3 p_lens{0.0f, 0.0f, 0.0f};
+    if (rd.lens_radius > 0.0f) { p_lens.x = smp.dimv(index, 3u); p_lens.y = smp.dimv(index, 4u); }
+    if (rd.cam_anim) p_lens.z = smp.dimv(index, 2u);
     DlSerial<INST, ALPHA, LaneSampler> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, i, SerialSampler{nullptr}, stack + threadIdx.x, ln.max_walk, false}, &smp, ln.n_light_samples,
                                           ln.sample_all != 0u, ln.tex ? ln.tex + i : nullptr, ln.tex_stride, ln.tex_rows, f2{pf.x, pf.y}, p_lens};
     const rgb l = dl.li(f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z);

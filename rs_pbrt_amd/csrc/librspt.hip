@@ -19,6 +19,7 @@
 
 #include "../../include/rspt.h"
 #include "material_assembly.h"
+#include "camera_anim.h"
 #include "kernels.h"
 #include "trace_w4.h"
 #include "bvh_device.h"
@@ -69,6 +70,7 @@ struct Ctx {
     size_t spill_threads = 0;
     VolBuf vol{};                      // volpath: per-path medium / shadow-ray state (vol.h)
     size_t vol_cap = 0;
+    CamAnim* cam_anim = nullptr;       // a moving camera's key decompositions (dev_scene.h), written per render
     DlBuf dl{};                        // directlighting: per-node arrays (direct.h) + level queues
     uint32_t* dl_queue = nullptr;
     size_t dl_cap = 0;
@@ -653,6 +655,15 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     memcpy(rd.raster_to_camera, d->raster_to_camera, sizeof rd.raster_to_camera);
     memcpy(rd.camera_to_world, d->camera_to_world, sizeof rd.camera_to_world);
     rd.lens_radius = d->lens_radius; rd.focal_distance = d->focal_distance;
+    rd.cam_anim = nullptr;
+    if (d->camera_animated) {   // AnimatedTransform::new (camera_anim.h); equal key matrices = a camera that does not move
+        CamAnim ca;
+        if (camanim::camera_keys(d->camera_to_world, d->camera_time[0], d->camera_to_world_end, d->camera_time[1], &ca)) {
+            if (!g.cam_anim && (rc = dev_alloc(&g.cam_anim, 1))) return rc;
+            HIP_TRY(hipMemcpy(g.cam_anim, &ca, sizeof ca, hipMemcpyHostToDevice));
+            rd.cam_anim = g.cam_anim;
+        }
+    }
     rd.shutter_open = d->shutter_open; rd.shutter_close = d->shutter_close;
     memcpy(rd.sample_bounds, sb, sizeof rd.sample_bounds);
     memcpy(rd.crop_px, cp, sizeof rd.crop_px);
@@ -1501,7 +1512,7 @@ void rspt_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
-    void* ptrs[] = {g.dl.le_kind, g.dl.w_r, g.dl.w_t, g.dl.l_all, g.dl.ld_acc, g.dl.dim, g.dl.kidx, g.dl.nflags, g.dl.error, g.dl_queue, g.bin_keys, g.q_sorted, g.bin_info, g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms};
+    void* ptrs[] = {g.dl.le_kind, g.dl.w_r, g.dl.w_t, g.dl.l_all, g.dl.ld_acc, g.dl.dim, g.dl.kidx, g.dl.nflags, g.dl.error, g.dl_queue, g.bin_keys, g.q_sorted, g.bin_info, g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms, g.cam_anim};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);

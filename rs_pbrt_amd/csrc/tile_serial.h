@@ -65,8 +65,9 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                 // Sampler::get_camera_sample (sampler.rs:85-95)
                 const f2 fs = px.get_2d();
                 const f2 p_film{(float)x + fs.x, (float)y + fs.y};
-                (void)px.get_1d();   // time
-                const f2 p_lens = px.get_2d();
+                const float time_s = px.get_1d();   // time: a moving camera interpolates its matrix there
+                const f2 lens2 = px.get_2d();
+                const f3 p_lens{lens2.x, lens2.y, time_s};
                 f3 o, d;
                 float t_max;
                 camera_ray(rd, p_film, p_lens, &o, &d, &t_max);

@@ -244,7 +244,7 @@ struct VolSerial {
     }
 
     // VolPathIntegrator::li; p_film / p_lens: the camera sample (the texture stage rebuilds the camera ray's differentials from them)
-    RDEVN rgb li(f3 ray_o, f3 ray_d, float ray_tmax0, f2 p_film, f2 p_lens) {
+    RDEVN rgb li(f3 ray_o, f3 ray_d, float ray_tmax0, f2 p_film, f3 p_lens) {
         rgb L = mkrgb(0.0f), beta = mkrgb(1.0f);
         uint32_t medium = 0u;   // camera rays start outside every medium (api.rs:1638-1645)
         bool specular = false, no_diff = false;

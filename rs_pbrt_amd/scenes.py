@@ -899,7 +899,8 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
                      crop=(0.0, 1.0, 0.0, 1.0), filter_radius=(0.5, 0.5), filter_table=None, lens_radius=0.0,
                      focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
                      sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True, direct_strategy="all", light_samples=None,
-                     dimensions=4, strat=(4, 4), jitter=True, sample_range=None, allow_slow_paths=True):
+                     dimensions=4, strat=(4, 4), jitter=True, sample_range=None, allow_slow_paths=True, look_at_end=None, camera_times=(0.0, 1.0),
+                     shutter=(0.0, 1.0)):
     """allow_slow_paths: True here (tests and bench want the device path whatever its speed); the Rust shim passes 0, so that a pixel-sampler
     frame of few tiles — which the device renders slower than the host's tile loop — comes back as RSPT_E_UNSUPPORTED (include/rspt.h)"""
     rd = abi.RenderDesc()
@@ -937,7 +938,11 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
     w2c = Transform.look_at(*look_at)
     rd.camera_to_world[:] = w2c.m_inv.reshape(-1).tolist()
     rd.lens_radius, rd.focal_distance = lens_radius, focal_distance
-    rd.shutter_open, rd.shutter_close = 0.0, 1.0
+    rd.shutter_open, rd.shutter_close = float(shutter[0]), float(shutter[1])
+    if look_at_end is not None:   # a moving camera (ActiveTransform / TransformTimes blocks around LookAt): AnimatedTransform's two key matrices
+        rd.camera_animated = 1
+        rd.camera_to_world_end[:] = Transform.look_at(*look_at_end).m_inv.reshape(-1).tolist()
+        rd.camera_time[:] = (float(camera_times[0]), float(camera_times[1]))
     if sampler == "halton":  # the reference's default sampler (api.rs:526), halton.rs:163-172
         rd.sampler_kind = abi.SAMPLER_HALTON
         rd.spp = spp

@@ -4,7 +4,7 @@
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RSPT_ABI_VERSION: c_int = 18;
+pub const RSPT_ABI_VERSION: c_int = 19;
 pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
 pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
 
@@ -62,6 +62,7 @@ pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_wor
     pub direct_strategy: u32, pub pixel_dimensions: u32, pub n_light_samples: *const i32,
     pub strat_x: u32, pub strat_y: u32, pub strat_jitter: u32, pub allow_slow_paths: u32, pub maxmin_c_pixel: *const u32,   // pixel samplers
     pub sample_begin: u64, pub sample_count: u64,   // checkpoint / resume: 0, 0 = the whole frame
+    pub camera_animated: u32, pub camera_to_world_end: [f32; 16], pub camera_time: [f32; 2],   // AnimatedTransform camera (transform.rs:894-2124)
 }
 #[repr(C)] #[derive(Default)]
 pub struct RsptStats {

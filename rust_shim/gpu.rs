@@ -331,7 +331,8 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
 
     // ---- camera / film / sampler (perspective.rs:22-43, film.rs:159-173, sobol.rs:15-20, halton.rs:54-78) ----
     let cam = match &*integ.get_camera() { Camera::Perspective(c) => c.clone_for_shim(), _ => return Err("camera is not perspective".into()) };
-    if cam.camera_to_world.is_animated() { return Err("animated camera".into()); }
+    // a moving camera goes over as its two key matrices and their times; the library decomposes and interpolates (AnimatedTransform::interpolate)
+    let cam_anim = cam.camera_to_world.is_animated();                               // getter: rs_pbrt.patch (actually_animated)
     let film = cam.film.clone();
     let sb = film.get_sample_bounds(); let cb = film.cropped_pixel_bounds;
     let radius = film.filter.get_radius();
@@ -370,6 +371,8 @@ pub fn render_path(integ: &SamplerIntegrator, scene: &Scene) -> Result<(), Strin
         direct_strategy, pixel_dimensions: pix_dims, n_light_samples: if n_light_samples.is_empty() { std::ptr::null() } else { n_light_samples.as_ptr() },
         strat_x: sx, strat_y: sy, strat_jitter: jit, allow_slow_paths: 0 /* a scene the device would render slower than the tile loop comes back as Err: keep the CPU loop */, maxmin_c_pixel: if sampler_kind == 6 { c_pixel.as_ptr() } else { std::ptr::null() },
         sample_begin: 0, sample_count: 0,
+        camera_animated: cam_anim as u32, camera_to_world_end: m16(&cam.camera_to_world.end_transform().m),
+        camera_time: [cam.camera_to_world.start_time(), cam.camera_to_world.end_time()],
     };
     let sd = RsptSceneDesc {
         nodes: f.nodes.as_ptr(), n_nodes: f.nodes.len() as u64, prims: f.prims.as_ptr(), n_prims: f.prims.len() as u64,

@@ -44,7 +44,7 @@ int main(void) {
   S(rspt_bvh_node); S(rspt_prim); S(rspt_mesh); S(rspt_bxdf); S(rspt_material); S(rspt_light);
   S(rspt_scene_desc); S(rspt_medium); S(rspt_envmap); S(rspt_image); S(rspt_texture); S(rspt_sampler_tables); S(rspt_render_desc); S(rspt_ray); S(rspt_hit); S(rspt_stats);
   O(rspt_render_desc, filter_table); O(rspt_render_desc, raster_to_camera); O(rspt_render_desc, spp);
-  O(rspt_render_desc, max_depth); O(rspt_render_desc, shard_index); O(rspt_render_desc, tables); O(rspt_render_desc, pixel_dimensions); O(rspt_render_desc, n_light_samples); O(rspt_render_desc, strat_x); O(rspt_render_desc, maxmin_c_pixel); O(rspt_render_desc, sample_begin);
+  O(rspt_render_desc, max_depth); O(rspt_render_desc, shard_index); O(rspt_render_desc, tables); O(rspt_render_desc, pixel_dimensions); O(rspt_render_desc, n_light_samples); O(rspt_render_desc, strat_x); O(rspt_render_desc, maxmin_c_pixel); O(rspt_render_desc, sample_begin); O(rspt_render_desc, camera_animated); O(rspt_render_desc, camera_time);
   O(rspt_scene_desc, P); O(rspt_scene_desc, materials); O(rspt_scene_desc, lights); O(rspt_stats, alg_bytes);
   O(rspt_bxdf, alpha_x); O(rspt_bxdf, on_a); O(rspt_bxdf, tex_r); O(rspt_bxdf, tex_t); O(rspt_material, bump_tex);
   O(rspt_scene_desc, textures); O(rspt_scene_desc, images); O(rspt_scene_desc, n_images); O(rspt_scene_desc, n_media); O(rspt_scene_desc, media); O(rspt_mesh, medium_inside); O(rspt_medium, g);

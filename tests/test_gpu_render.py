@@ -593,7 +593,7 @@ def test_film_reduce_runs_inside_the_library(gpu):
             rd.shard_index, rd.shard_count = 0, 1
             again, _ = gpu.render(ds, rd)
             assert np.array_equal(again, plain)
-            bad = scenes.cornell_render_desc(res=48, spp=4, integrator="directlighting", max_depth=9)
+            bad = scenes.cornell_render_desc(res=48, spp=4, integrator="directlighting", max_depth=33)   # (past the recursion stack of the per-lane form)
             bad.film_reduce = 1
             with pytest.raises(RsptError) as e:
                 gpu.render(ds, bad)
@@ -721,3 +721,30 @@ def test_scene_with_ten_thousand_emissive_triangles_renders(gpu, oracle):
     assert st["nan_samples"] == 0 and np.isfinite(film).all() and film[:, 1].mean() > 0.05
     ref = oracle.render(sc, rd, threads=THREADS_ALL)
     assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-4
+
+
+@pytest.mark.parametrize("sampler,integrator", [("sobol", "path"), ("halton", "path"), ("02sequence", "path"), ("sobol", "directlighting"), ("stratified", "volpath"), ("sobol", "ao")])
+def test_moving_camera(gpu, oracle, sampler, integrator):
+    """SURVEY a4 / VERDICT r2 missing #7: CameraBase.camera_to_world as an AnimatedTransform (transform.rs:894-2124).  The camera turns and
+    travels during the exposure: every camera ray — and the differentials the textures are filtered with — goes through the matrix
+    interpolated at its own time sample (translation and scale linearly, rotation by slerp); times before / after the key times use the
+    key matrices.  Thin lens on, so that the lens and the time values of a sample are both in play.  Per-sample radiance bit-identical."""
+    from tests.util import TEXTURED_LOOK_AT, textured_room
+    sc = textured_room(gpu.bvh_build, specular=(integrator == "directlighting"))
+    la1 = ((1.2, 3.1, -4.2), (0.4, 1.3, 2.0), (0.2, 1.0, 0.05))
+    rd = scenes.make_render_desc(48, 36, 8 if sampler != "stratified" else 16, TEXTURED_LOOK_AT, 55.0, max_depth=3, sampler=sampler, integrator=integrator, ao_samples=4,
+                                 light_samples=[1] * sc.desc.n_lights, look_at_end=la1, camera_times=(0.2, 0.85), shutter=(0.0, 1.0), lens_radius=0.03, focal_distance=6.0)
+    if integrator == "directlighting":   # (the oracle's DirectLightingIntegrator has its own entry point)
+        from tests.test_gpu_directlighting import check
+        film = check(gpu, oracle, sc, rd, "all", [1] * sc.desc.n_lights)
+    else:
+        film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+        assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-6
+    rd_static = scenes.make_render_desc(48, 36, 8 if sampler != "stratified" else 16, TEXTURED_LOOK_AT, 55.0, max_depth=3, sampler=sampler, integrator=integrator, ao_samples=4,
+                                        light_samples=[1] * sc.desc.n_lights, lens_radius=0.03, focal_distance=6.0)
+    with gpu.DeviceScene(sc) as ds:
+        still = gpu.render(ds, rd_static)[0]
+        rd_static.camera_animated = 1          # equal key matrices: the camera does not move (actually_animated = false)
+        rd_static.camera_to_world_end[:] = list(rd_static.camera_to_world)
+        assert np.array_equal(gpu.render(ds, rd_static)[0], still)
+    assert film_rmse(film, still) > 1e-3       # the motion is in the picture

@@ -272,6 +272,52 @@ def test_camera_center_ray_points_at_lookat(oracle):
     assert np.allclose(out[3:6], (0, 0, 1), atol=1e-5)  # y flips on the film but the centre looks down +z
 
 
+def test_moving_camera_decomposition_and_interpolation(oracle):
+    """AnimatedTransform (transform.rs:894-2124) from first principles: look_at matrices are rigid, so the decomposition must return the
+    camera position, a unit quaternion of the rotation block and an identity scale; the interpolated matrix must be the scipy slerp of the
+    two rotations with the linearly interpolated position; outside [start_time, end_time] the key matrices themselves."""
+    from scipy.spatial.transform import Rotation, Slerp
+    la0, la1 = ((278, 273, -800), (278, 273, 0), (0, 1, 0)), ((400, 300, -700), (250, 200, 0), (0.2, 1, 0))
+    rd = scenes.make_render_desc(64, 64, 1, la0, 40.0, look_at_end=la1, camera_times=(0.25, 0.75))
+    m = np.zeros(16, F32); trs = np.zeros(46, F32)
+    L = oracle.lib()
+    L.orc_camera_matrix(C.addressof(rd), 0.1, m.ctypes.data, trs.ctypes.data)
+    m0, m1 = np.array(rd.camera_to_world, F32), np.array(rd.camera_to_world_end, F32)
+    assert np.array_equal(m, m0)                                     # time <= start_time: start_transform
+    L.orc_camera_matrix(C.addressof(rd), 0.75, m.ctypes.data, None)
+    assert np.array_equal(m, m1)                                     # time >= end_time: end_transform
+    t, q, s = trs[:6].reshape(2, 3), trs[6:14].reshape(2, 4), trs[14:].reshape(2, 4, 4)
+    assert np.allclose(t[0], la0[0], atol=1e-3) and np.allclose(t[1], la1[0], atol=1e-3)
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-5) and np.allclose(s[:, :3, :3], np.eye(3), atol=1e-4)   # (s = R^-1 m with m's translation column still in it, transform.rs:2079: only the 3x3 block is interpolated)
+    rot = [Rotation.from_matrix(np.asarray(k, np.float64).reshape(4, 4)[:3, :3]) for k in (m0, m1)]
+    for k in range(2):   # Quaternion::new(Transform): the quaternion of the rotation block (to_transform writes the transposed formula and transposes it back)
+        assert np.allclose(Rotation.from_quat(q[k].astype(np.float64)).as_matrix(), rot[k].as_matrix(), atol=1e-5)
+    sl = Slerp([0.0, 1.0], Rotation.concatenate(rot))
+    for time in (0.3, 0.5, 0.6999):
+        L.orc_camera_matrix(C.addressof(rd), time, m.ctypes.data, None)
+        dt = (time - 0.25) / 0.5
+        want = np.eye(4)
+        want[:3, :3] = sl([dt])[0].as_matrix()
+        want[:3, 3] = (1 - dt) * np.asarray(la0[0], np.float64) + dt * np.asarray(la1[0], np.float64)
+        assert np.abs(m.reshape(4, 4) - want)[:3, :3].max() < 2e-5 and np.abs(m.reshape(4, 4) - want)[:3, 3].max() < 2e-3
+    # a scaled, sheared key matrix: T R S must multiply back to it
+    rd2 = scenes.make_render_desc(64, 64, 1, la0, 40.0, look_at_end=la1)
+    a = np.asarray(rd2.camera_to_world_end, np.float64).reshape(4, 4) @ np.array([[1.5, 0.2, 0, 0], [0, 0.7, 0.1, 0], [0, 0, 2.0, 0], [0, 0, 0, 1]])
+    rd2.camera_to_world_end[:] = a.astype(F32).reshape(-1).tolist()
+    L.orc_camera_matrix(C.addressof(rd2), 0.5, m.ctypes.data, trs.ctypes.data)
+    q1, s1, t1 = trs[10:14].astype(np.float64), trs[30:46].reshape(4, 4).astype(np.float64), trs[3:6].astype(np.float64)
+    r1 = np.eye(4); r1[:3, :3] = Rotation.from_quat(q1).as_matrix()
+    tr = np.eye(4); tr[:3, 3] = t1
+    s1[:3, 3] = 0.0
+    assert np.abs(tr @ r1 @ s1 - a).max() < 1e-3 * np.abs(a).max()
+    # the static description is the same camera as an animated one whose key matrices are equal
+    rd3 = scenes.make_render_desc(64, 64, 1, la0, 40.0, look_at_end=la0)
+    cs = np.array([20.3, 41.7, 0.37, 0.5, 0.5], F32); o_a = np.zeros(7, F32); o_b = np.zeros(7, F32)
+    L.orc_camera_ray(C.addressof(rd3), cs.ctypes.data, o_a.ctypes.data)
+    L.orc_camera_ray(C.addressof(scenes.make_render_desc(64, 64, 1, la0, 40.0)), cs.ctypes.data, o_b.ctypes.data)
+    assert np.array_equal(o_a, o_b)
+
+
 def test_spatial_light_distribution_favours_the_near_light(oracle):
     sb = scenes.SceneBuilder()
     m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))

@@ -132,12 +132,22 @@ def integrator_directive(integrator, max_depth, direct_strategy="all", ao_sample
 
 def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **kw):
     integ_kw = {k: kw.pop(k) for k in ("direct_strategy", "ao_samples", "ao_cos_sample") if k in kw}
+    cam_kw = {k: kw.pop(k) for k in ("look_at_end", "camera_times", "shutter", "lens_radius", "focal_distance") if k in kw}
     sampler_kw = kw
     sb = sc.builder
     assert sb is not None, "the scene was not made by a SceneBuilder"
-    out = ["# generated by tools/export_pbrt.py from rs_pbrt_amd/scenes.py — do not edit",
-           "LookAt %s  %s  %s" % tuple(f(v) for v in look_at),
-           'Camera "perspective" "float fov" [%.9g]' % fov,
+    cam_xf = ["LookAt %s  %s  %s" % tuple(f(v) for v in look_at)]
+    cam_par = ""
+    if cam_kw.get("look_at_end") is not None:   # a moving camera: the CTM's two slots (api.rs active_transform_bits), AnimatedTransform::new in make_camera
+        t0, t1 = cam_kw.get("camera_times", (0.0, 1.0))
+        so, sc_ = cam_kw.get("shutter", (0.0, 1.0))
+        cam_xf = ["TransformTimes %.9g %.9g" % (t0, t1), "ActiveTransform StartTime", cam_xf[0], "ActiveTransform EndTime",
+                  "LookAt %s  %s  %s" % tuple(f(v) for v in cam_kw["look_at_end"]), "ActiveTransform All"]
+        cam_par += ' "float shutteropen" [%.9g] "float shutterclose" [%.9g]' % (so, sc_)
+    if cam_kw.get("lens_radius"):
+        cam_par += ' "float lensradius" [%.9g] "float focaldistance" [%.9g]' % (cam_kw["lens_radius"], cam_kw.get("focal_distance", 1e6))
+    out = ["# generated by tools/export_pbrt.py from rs_pbrt_amd/scenes.py — do not edit"] + cam_xf + [
+           'Camera "perspective" "float fov" [%.9g]%s' % (fov, cam_par),
            sampler_directive(sampler, spp, **sampler_kw),
            integrator_directive(integrator, max_depth, **integ_kw),
            'PixelFilter "box" "float xwidth" [0.5] "float ywidth" [0.5]',
@@ -304,6 +314,9 @@ SCENES = {
     "cornell_layered": (lambda b, s: s.cornell_box(b, "layered"), "CORNELL", 64, 64, 16, 5),
     # InfiniteAreaLight (constant L) + a point light, alpha / shadowalpha masks
     "sky_blocks": (sky_blocks, "CORNELL", 64, 64, 16, 5),
+    # a camera that turns and travels while the shutter is open (TransformTimes / ActiveTransform): AnimatedTransform decompose + slerp per ray,
+    # with a thin lens, over the image-textured box (the differentials go through the interpolated matrix too)
+    "cornell_moving_camera": (lambda b, s: s.cornell_box(b, "imagemap"), "CORNELL", 64, 64, 16, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
@@ -316,6 +329,7 @@ EXTRA = {
     "cornell_directlighting": dict(integrator="directlighting", direct_strategy="all"),
     "cornell_directlighting_one": dict(integrator="directlighting", direct_strategy="one"),
     "cornell_ao": dict(integrator="ao", ao_samples=16, ao_cos_sample=True),
+    "cornell_moving_camera": dict(look_at_end=((340.0, 300.0, -760.0), (250.0, 260.0, 0.0), (0.1, 1.0, 0.0)), camera_times=(0.2, 0.9), shutter=(0.0, 1.0), lens_radius=4.0, focal_distance=1000.0),
 }
 
 
