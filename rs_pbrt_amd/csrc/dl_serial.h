@@ -26,6 +26,8 @@ struct DlSerial {
     float4* tex;                      // this lane's column of texture-stage rows (nullptr: the scene has no textured material)
     uint32_t tex_stride, tex_rows;    // lanes per row; rows per activation
     f2 p_film; f3 p_lens;             // the camera sample: film position, (lens x, lens y, time) — differentials of the camera ray
+    rspt_mat::Built* dyn;             // dynamic materials: this lane's column of per-activation lobe records (level L: dyn + L * dyn_stride); nullptr = none
+    uint32_t dyn_stride;
 
     const SceneDev& sc() const { return base.sc; }
     RDEV bool occluded(f3 o, f3 d, float t_max) { return traverse<true, INST, ALPHA, 64>(base.sc, base.tt, o, d, t_max, base.lds).prim != RSPT_MISS; }
@@ -200,6 +202,8 @@ struct DlSerial {
                         const rspt_material mat = S.materials[fr.it.h.material];
                         Bsdf& b = fr.bsdf;
                         b.eta = mat.eta; b.lt = LobeTex{nullptr, 0}; b.dropped = 0u;
+                        const rspt_bxdf* dyn_l = nullptr;
+                        uint32_t dyn_n = 0u;
                         fr.has_diff = false;
                         if (tex) {   // compute_scattering_functions: compute_differentials(ray), then the material's textures / bump map
                             TexHit th;
@@ -218,6 +222,11 @@ struct DlSerial {
                             if (S.mat_flags && S.mat_flags[fr.it.h.material]) {
                                 float4* rows = tex + (size_t)sp * tex_rows * tex_stride;
                                 texture_hit_call(S, base.tt, th, ts, fr.it.h.material, rows, tex_stride);
+                                if (S.mat_flags[fr.it.h.material] & RSPT_MAT_DYNAMIC) {   // the lobe list is built from this hit's texture values; the activation keeps its own record
+                                    const rspt_mat::Built* bl = dynamic_lobes(S.dyn[fr.it.h.material], rows, tex_stride, false /* directlighting.rs:86 */, dyn + (size_t)sp * dyn_stride);
+                                    dyn_l = bl->l; dyn_n = bl->n;
+                                    b.eta = bl->eta;
+                                }
                                 b.lt = LobeTex{rows, tex_stride};
                                 const float4 m4 = rows[4 * (size_t)tex_stride];
                                 const uint32_t tf = __float_as_uint(m4.w);
@@ -230,8 +239,8 @@ struct DlSerial {
                             }
                         }
                         b.ss = normalize(fr.it.h.sh_dpdu); b.ns = fr.it.h.sh_n; b.ng = fr.it.h.n; b.ts = cross(fr.it.h.sh_n, b.ss);
-                        b.lobes = S.bxdfs + mat.first_bxdf;
-                        b.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+                        b.lobes = dyn_l ? dyn_l : S.bxdfs + mat.first_bxdf;
+                        b.n = dyn_l ? (dyn_n < 8u ? dyn_n : 8u) : (mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u);
                         if (fr.it.h.area_light >= 0) l = l + light_l(S.lights[fr.it.h.area_light], fr.it.h.n, fr.it.wo);   // isect.le(&wo)
                         l = l + direct(fr.it, b);
                         if (sp + 1u < base.rd.max_depth && sp + 1u < RSPT_DL_SERIAL_DEPTH) {

@@ -342,16 +342,21 @@ RDEVN const rspt_mat::Built* dynamic_lobes(const rspt_mat::DynMaterial& dm, cons
         if (q.row) { const float4 v = rows[(size_t)(RSPT_TEX_ROWS + q.row - 1u) * stride]; r = param_value(id, v.x, v.y, v.z); }
         return r;
     };
-    float s1[3] = {0.0f, 0.0f, 0.0f}, s2[3] = {0.0f, 0.0f, 0.0f};
+    // the mix amount s1 and, for the second side, s2 = clamp(1 - s1) (mixmat.rs:52-56), kept in scalars and copied into one array per
+    // side: a choice between two arrays by pointer — `k ? s2 : s1` — came out as s2 for BOTH sides in the per-lane kernels (every m1 lobe
+    // scaled by 1 - amount; the wavefront instantiation of the same source was right), found by the linearity of the frame in the scales
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
     if (dm.n_parts == 2u) {
-        const Param am = fetch(dm.amount, P_KD);  // a colour: clamp(0, inf) (mixmat.rs:52-56)
-        for (int c = 0; c < 3; c++) { s1[c] = am.v[c]; s2[c] = clamp0(1.0f - s1[c]); }
+        const Param am = fetch(dm.amount, P_KD);  // a colour: clamp(0, inf)
+        a0 = am.v[0]; a1 = am.v[1]; a2 = am.v[2];
     }
     for (uint32_t k = 0; k < dm.n_parts; k++) {
         Param p[P_COUNT];
 #pragma unroll 1
         for (uint32_t i = 0; i < P_COUNT; i++) p[i] = fetch(dm.part[k].p[i], i);
-        build_part(dm.part[k].kind, p, dm.part[k].remap != 0u, allow_multiple_lobes, dm.n_parts == 2u ? (k ? s2 : s1) : nullptr, k == 1u, out);
+        float side[3];
+        side[0] = k ? clamp0(1.0f - a0) : a0; side[1] = k ? clamp0(1.0f - a1) : a1; side[2] = k ? clamp0(1.0f - a2) : a2;
+        build_part(dm.part[k].kind, p, dm.part[k].remap != 0u, allow_multiple_lobes, dm.n_parts == 2u ? side : nullptr, k == 1u, out);
     }
     return out;
 }

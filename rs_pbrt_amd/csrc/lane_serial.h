@@ -63,6 +63,7 @@ struct LaneDesc {
     uint32_t dim_limit;
     float4* tex;                      // [level][row][lane] texture-stage rows, nullptr = no textured material
     uint32_t tex_stride, tex_rows;
+    rspt_mat::Built* dyn;             // [level][lane] lobe records of dynamic materials, nullptr = none
     uint32_t max_walk;
     uint32_t* error;                  // 2: a camera sample drew past the sampler's dimensions
     uint32_t* truncated;
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(64) void k_lane_dl(SceneDev sc, TexTables tt, Light
     if (rd.lens_radius > 0.0f) { p_lens.x = smp.dimv(index, 3u); p_lens.y = smp.dimv(index, 4u); }
     if (rd.cam_anim) p_lens.z = smp.dimv(index, 2u);
     DlSerial<INST, ALPHA, LaneSampler> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, i, SerialSampler{nullptr}, stack + threadIdx.x, ln.max_walk, false}, &smp, ln.n_light_samples,
-                                          ln.sample_all != 0u, ln.tex ? ln.tex + i : nullptr, ln.tex_stride, ln.tex_rows, f2{pf.x, pf.y}, p_lens};
+                                          ln.sample_all != 0u, ln.tex ? ln.tex + i : nullptr, ln.tex_stride, ln.tex_rows, f2{pf.x, pf.y}, p_lens,
+                                          ln.dyn ? ln.dyn + i : nullptr, ln.tex_stride};
     const rgb l = dl.li(f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z);
     pb.L_eta[i] = make_float4(l.r, l.g, l.b, 1.0f);
     if (dl.base.truncated) atomicAdd(ln.truncated, 1u);

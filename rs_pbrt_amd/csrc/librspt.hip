@@ -629,7 +629,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         if (d->max_depth < 1 || d->max_depth > (uint32_t)RSPT_DL_SERIAL_DEPTH)
             return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, %d] (the explicit recursion stack of the per-lane form, dl_serial.h)", RSPT_DL_SERIAL_DEPTH);
         if (d->direct_strategy > RSPT_DIRECT_SAMPLE_ONE) return fail(RSPT_E_INVALID, "bad direct_strategy");
-        if (s && s->has_dynamic) return fail(RSPT_E_UNSUPPORTED, "directlighting with a material whose lobe list depends on a texture");
         for (uint32_t i = 0; s && d->n_light_samples && i < s->dev.n_lights; i++)
             if (d->n_light_samples[i] < 1 || d->n_light_samples[i] > 4096) return fail(RSPT_E_INVALID, "n_light_samples[%u] out of range", i);
     }
@@ -747,7 +746,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (volpath && s->dev.n_grid_media && !pixel_sampler)
         return fail(RSPT_E_UNSUPPORTED, "volpath with a grid-density medium under the Sobol' / Halton sampler: every tracking step draws sampler dimensions (the reference panics past "
                                         "dimension 1024 / 1000 within a bounce or two); render it with a pixel sampler (random / 02sequence / stratified / maxmindist)");
-    if (pixel_sampler && s->has_dynamic) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with a material whose lobe list depends on a texture");
     if (pixel_sampler && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
     if (volpath && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "volpath with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
 
@@ -810,7 +808,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const char* dl_form_env = getenv("RSPT_DL_FORM");
     bool dl_lane = direct && !pixel_sampler && (s->has_textures || d->max_depth > 8 || (dl_form_env && !strcmp(dl_form_env, "lane")));
     const uint32_t dl_H = (direct && !pixel_sampler && !dl_lane) ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h; in the per-lane forms a lane walks the tree itself)
-    if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? 22 : 26)) / dl_H, 1024);
+    if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? (s->has_dynamic ? 20 : 22) : 26)) / dl_H, 1024);   // (per-lane form: texture rows and lobe records per recursion level)
     if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     size_t pix_per_batch = 1;
@@ -829,13 +827,17 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
     // the per-lane directlighting forms: per-level texture rows, the light sample counts on the device, error / truncation words
     struct TmpGuard { std::vector<void*> p; ~TmpGuard() { for (void* q : p) (void)hipFree(q); } } dl_guard;
-    float4* dl_tex = nullptr; int32_t* dl_nls = nullptr; uint32_t* dl_words = nullptr;
-    const uint32_t dl_tex_rows = RSPT_TEX_ROWS;
+    float4* dl_tex = nullptr; int32_t* dl_nls = nullptr; uint32_t* dl_words = nullptr; rspt_mat::Built* dl_dyn = nullptr;
+    const uint32_t dl_tex_rows = RSPT_TEX_ROWS + (s->has_dynamic ? RSPT_DYN_ROWS : 0);
     const size_t dl_lanes = pixel_sampler ? blocks.size() : pix_per_batch * ns;
     if (direct) {
         if (s->has_textures) {
             if ((rc = dev_alloc(&dl_tex, (size_t)d->max_depth * dl_tex_rows * std::max<size_t>(dl_lanes, 1)))) return rc;
             dl_guard.p.push_back(dl_tex);
+            if (s->has_dynamic) {
+                if ((rc = dev_alloc(&dl_dyn, (size_t)d->max_depth * std::max<size_t>(dl_lanes, 1)))) return rc;
+                dl_guard.p.push_back(dl_dyn);
+            }
         }
         if (!pixel_sampler) {
             if ((rc = dev_alloc(&dl_words, 2))) return rc;
@@ -865,7 +867,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
         (s->has_textures && (rc = ensure_tex_rows(s->has_dynamic)))) return rc;
     if (s->has_dynamic) {
-        if (volpath) return fail(RSPT_E_UNSUPPORTED, "volpath with a material whose lobe list depends on a texture (sigma / index / opacity / Kr / Kt / reflect / transmit / eta / k / a mix amount bound to a non-constant texture)");
         if ((rc = ensure_dyn_built(grid_for(8) * 256u))) return rc;
     }
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
@@ -931,7 +932,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             vol_rays += live;
             ev_open(2, 0);
             if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][1], &cur->closest);
-            hipLaunchKernelGGL(k_vol_shade, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest,
+            hipLaunchKernelGGL(s->has_dynamic ? k_vol_shade<true> : k_vol_shade<false>, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest,
                                g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits);
             ev_close(2, 0);
             // VisibilityTester::tr: segments until every shadow ray has arrived or is blocked
@@ -1065,7 +1066,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         if (5ull + 2ull * n_arrays > dim_limit)
             return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays exceed the sampler's %u dimensions", n_arrays, dim_limit);
         HIP_TRY(hipMemsetAsync(dl_words, 0, 2 * sizeof(uint32_t), g.stream));
-        const LaneDesc ln{all ? dl_nls : nullptr, n_arrays, all ? 1u : 0u, dim_limit, dl_tex, (uint32_t)dl_lanes, dl_tex_rows,
+        const LaneDesc ln{all ? dl_nls : nullptr, n_arrays, all ? 1u : 0u, dim_limit, dl_tex, (uint32_t)dl_lanes, dl_tex_rows, dl_dyn,
                           s->has_null_material ? (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : 0u, dl_words, dl_words + 1};
         const dim3 lgrid((bt.n + 63u) / 64u);
         ev_open(2, 0);
@@ -1230,11 +1231,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             return rc;
         HIP_TRY(hipMemsetAsync(trunc_d, 0, sizeof(uint32_t), g.stream));
         if (d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) HIP_TRY(hipMemcpyAsync(c_pixel_d, d->maxmin_c_pixel, 32 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_sz_d, arr_base_d, (uint32_t)arr_sz.size(), arr_total, d->ao_cos_sample, nls_d, d->direct_strategy, dl_tex, dl_tex_rows};
+        const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_sz_d, arr_base_d, (uint32_t)arr_sz.size(), arr_total, d->ao_cos_sample, nls_d, d->direct_strategy, dl_tex, dl_tex_rows, dl_dyn};
         // lanes per wave: a lane that shares its wave waits whenever the others diverge, so spread the tiles over as many waves
         // as the chip holds (256 CUs x 4 SIMDs x 2) before doubling up
         uint32_t lanes = 1;
         while (lanes < 64 && (n_tiles + lanes - 1) / lanes > (uint32_t)env_size("RSPT_SERIAL_WAVES", 2048)) lanes *= 2;
+        if (s->has_dynamic && (rc = ensure_dyn_built(((n_tiles + lanes - 1) / lanes) * 64u))) return rc;   // one lobe record per thread of the launch
         PathBuf fpb = g.pb;
         fpb.L_eta = samp_L; fpb.p_film = samp_pf;
         const uint32_t serial_iters = nominal_iters + 1u + (s->has_null_material ? (uint32_t)env_size("RSPT_NULL_PASSES", 1024) : 0u);
@@ -1263,6 +1265,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             } else if (direct) {
                 if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 3); else RSPT_TS(true, false, 3); }
                 else { if (s->has_alpha) RSPT_TS(false, true, 3); else RSPT_TS(false, false, 3); }
+            } else if (s->has_dynamic) {
+                if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 4); else RSPT_TS(true, false, 4); }
+                else { if (s->has_alpha) RSPT_TS(false, true, 4); else RSPT_TS(false, false, 4); }
             } else if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 0); else RSPT_TS(true, false, 0); }
             else { if (s->has_alpha) RSPT_TS(false, true, 0); else RSPT_TS(false, false, 0); }
 #undef RSPT_TS

@@ -34,11 +34,13 @@ struct PixDesc {              // the sampler's parameters and this render's vect
     uint32_t direct_strategy;
     float4* dl_tex;                   // directlighting over textured materials: texture-stage rows per recursion level (dl_serial.h), [level][row][tile]
     uint32_t dl_tex_rows;
+    rspt_mat::Built* dl_dyn;          // ... and, with dynamic materials, the lobe record of every level, [level][tile]
 };
 
 // MODE 0: PathIntegrator::li.  1: AOIntegrator::li (ao.rs:50-96) with its sample array from the pixel sampler: closest hit, frame on the true
 // geometry, arr_n hemisphere directions from get_2d_array, one any-hit traversal each, the unoccluded terms added in array order.
 // 2: VolPathIntegrator::li (vol_serial.h), homogeneous and grid media.  3: DirectLightingIntegrator::li (dl_serial.h).
+// 4: PathIntegrator::li over a scene with dynamic materials (shade_path<.., SF_ALL>: lobe lists built per hit, material_assembly.h).
 template <bool INST, bool ALPHA, int MODE = 0>
 __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
                                                     uint32_t n_tiles, uint32_t lanes_per_wave, int32_t row0, int32_t row1, float4* __restrict__ samp_L,
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                 pb.p_film[slot] = make_float2(p_film.x, p_film.y);
                 if (MODE == 3) {
                     DlSerial<INST, ALPHA, PixSampler> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false}, &px, pd.n_light_samples, pd.direct_strategy == RSPT_DIRECT_SAMPLE_ALL,
-                                                         pd.dl_tex ? pd.dl_tex + t : nullptr, n_tiles, pd.dl_tex_rows, p_film, p_lens};
+                                                         pd.dl_tex ? pd.dl_tex + t : nullptr, n_tiles, pd.dl_tex_rows, p_film, p_lens,
+                                                         pd.dl_dyn ? pd.dl_dyn + t : nullptr, n_tiles};
                     const rgb l = dl.li(o, d, t_max);
                     if (dl.base.truncated) atomicAdd(truncated, 1u);
                     const size_t out = (size_t)k * pd.spp + s;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                         pb.occluded[slot] = res.prim != RSPT_MISS ? 1u : 0u;
                     }
                     if (sc.mat_flags && so.cont) texture_path(sc, tt, rd, pb, slot, &p_lens);   // the texture stage k_texture runs in front of k_shade
-                    so = shade_path<true, SF_ALL & ~SF_DYNAMIC>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
+                    so = shade_path<true, MODE == 4 ? SF_ALL : (SF_ALL & ~SF_DYNAMIC)>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
                 }
                 const size_t out = (size_t)k * pd.spp + s;
                 samp_L[out] = pb.L_eta[slot];

@@ -58,9 +58,18 @@ RSPT_TU_TS2(false, 3)
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS3B)
 RSPT_TU_TS2(true, 3)
 #endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS4A)
+RSPT_TU_TS2(false, 4)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS4B)
+RSPT_TU_TS2(true, 4)
+#endif
 #define RSPT_TU_LANE(I, A) RSPT_TU_X template __global__ void k_lane_dl<I, A>(SceneDev, TexTables, LightDistDev, RenderDev, Batch, PathBuf, const uint32_t*, LaneDesc);
-#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_LANE)
-RSPT_TU_LANE(false, false) RSPT_TU_LANE(false, true) RSPT_TU_LANE(true, false) RSPT_TU_LANE(true, true)
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_LANE_A)
+RSPT_TU_LANE(false, false) RSPT_TU_LANE(false, true)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_LANE_B)
+RSPT_TU_LANE(true, false) RSPT_TU_LANE(true, true)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_A)
 RSPT_TU_SHADE(SV_DIFFUSE) RSPT_TU_SHADE_W(SV_DIFFUSE, 3) RSPT_TU_SHADE_W(SV_DIFFUSE, 4)

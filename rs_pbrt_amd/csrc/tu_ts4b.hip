@@ -3,5 +3,5 @@
 #include "../../include/rspt.h"
 #define RSPT_TU_TEMPLATES_ONLY
 #define RSPT_TU_X
-#define RSPT_TU_GROUP_LANE
+#define RSPT_TU_GROUP_TS4B
 #include "tu_decl.h"

@@ -138,7 +138,9 @@ RDEV bool vol_estimate(const SceneDev& sc, const LightDistDev& ld, const RenderD
 }
 
 // one pass of the loop body of VolPathIntegrator::li for every live path
-RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue,
+// DYN: the scene has a material whose lobe list is built per hit (material_assembly.h; shade_path<.., SF_DYNAMIC> is the `path` counterpart)
+template <bool DYN>
+__global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ q_next, uint32_t* cnt_next,
                                                    uint32_t* __restrict__ q_tr, uint32_t* cnt_tr, uint32_t dim_limit, uint32_t sob_nd, uint32_t sob_bits) {
     extern __shared__ uint32_t sob_tab[];  // Sobol' generator matrices of the dimensions a path can reach, transposed to [bit][dim] (as k_shade)
@@ -267,8 +269,15 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDist
                                 const rspt_material mat = sc.materials[h.material];
                                 Bsdf b;  // Bsdf::new (reflection.rs:235-245)
                                 b.eta = mat.eta; b.lt = LobeTex{nullptr, 0}; b.dropped = 0u;
+                                const rspt_bxdf* lobes = sc.bxdfs + mat.first_bxdf;
+                                uint32_t n_lobes = mat.n_bxdfs;
                                 if (sc.mat_flags && sc.mat_flags[h.material]) {  // textured material: k_texture ran for this hit (as in shade_path)
                                     const float4* tb = pb.tex + p;
+                                    if (DYN && (sc.mat_flags[h.material] & RSPT_MAT_DYNAMIC)) {
+                                        const rspt_mat::Built* bl = dynamic_lobes(sc.dyn[h.material], tb, pb.tex_stride, true /* volpath.rs:146 */, pb.dyn_built + (blockIdx.x * blockDim.x + threadIdx.x));
+                                        lobes = bl->l; n_lobes = bl->n;
+                                        b.eta = bl->eta;
+                                    }
                                     b.lt = LobeTex{tb, pb.tex_stride};
                                     const float4 m4 = tb[4 * (size_t)pb.tex_stride];
                                     const uint32_t tf = __float_as_uint(m4.w);
@@ -280,8 +289,8 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDist
                                     }
                                 }
                                 b.ss = normalize(h.sh_dpdu); b.ns = h.sh_n; b.ng = h.n; b.ts = cross(h.sh_n, b.ss);
-                                b.lobes = sc.bxdfs + mat.first_bxdf;
-                                b.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+                                b.lobes = lobes;
+                                b.n = n_lobes < 8u ? n_lobes : 8u;
                                 const rspt_mesh me = sc.meshes[sc.prims[prim].mesh];
                                 uint32_t m_in = medium, m_out = medium;
                                 if (me.medium_inside != me.medium_outside) { m_in = me.medium_inside; m_out = me.medium_outside; }

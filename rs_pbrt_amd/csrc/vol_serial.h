@@ -314,6 +314,8 @@ struct VolSerial {
                 const rspt_material mat = sc.materials[s.h.material];
                 Bsdf b;  // Bsdf::new (reflection.rs:235-245)
                 b.eta = mat.eta; b.lt = LobeTex{nullptr, 0}; b.dropped = 0u;
+                const rspt_bxdf* dyn_l = nullptr;
+                uint32_t dyn_n = 0u;
                 if (sc.mat_flags && sc.mat_flags[s.h.material]) {  // textured material: the texture stage, called for this hit (texture_path reads the path slot)
                     store_ray(pb.ray_cont + slot, ray_o, ray_d, RSPT_INF, slot);
                     pb.hit_cont[slot] = make_float4(__uint_as_float(r.prim), r.b0, r.b1, r.b2);
@@ -322,6 +324,11 @@ struct VolSerial {
                     pb.p_film[slot] = make_float2(p_film.x, p_film.y);
                     texture_path(sc, tt, rd, pb, slot, &p_lens);
                     const float4* tb = pb.tex + slot;
+                    if (sc.mat_flags[s.h.material] & RSPT_MAT_DYNAMIC) {   // the lobe list itself is built from the hit's texture values (material_assembly.h)
+                        const rspt_mat::Built* bl = dynamic_lobes(sc.dyn[s.h.material], tb, pb.tex_stride, true /* volpath.rs:146 */, pb.dyn_built + (blockIdx.x * blockDim.x + threadIdx.x));
+                        dyn_l = bl->l; dyn_n = bl->n;
+                        b.eta = bl->eta;
+                    }
                     b.lt = LobeTex{tb, pb.tex_stride};
                     const float4 m4 = tb[4 * (size_t)pb.tex_stride];
                     const uint32_t tf = __float_as_uint(m4.w);
@@ -333,8 +340,8 @@ struct VolSerial {
                     }
                 }
                 b.ss = normalize(s.h.sh_dpdu); b.ns = s.h.sh_n; b.ng = s.h.n; b.ts = cross(s.h.sh_n, b.ss);
-                b.lobes = sc.bxdfs + mat.first_bxdf;
-                b.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
+                b.lobes = dyn_l ? dyn_l : sc.bxdfs + mat.first_bxdf;
+                b.n = dyn_l ? (dyn_n < 8u ? dyn_n : 8u) : (mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u);
                 L = L + beta * one_light(s.h.p, s.h.p_err, s.h.n, s.wo, s.m_in, s.m_out, &b, s.h.sh_n, 0.0f);   // no non-specular-lobe test in front (:146-161)
                 f3 wi{0.0f, 0.0f, 0.0f};
                 float pdf = 0.0f;

@@ -558,15 +558,23 @@ def test_materials_whose_lobe_list_depends_on_textures(gpu, oracle, sampler):
     assert rgb[10:30].std() > 0.02   # the slabs are in view and differ
 
 
-def test_dynamic_materials_are_refused_where_the_stage_is_not_built(gpu):
-    from rs_pbrt_amd.lib import RsptError
+@pytest.mark.parametrize("kw", [dict(integrator="volpath"), dict(integrator="volpath", sampler="stratified"), dict(integrator="directlighting"),
+                                dict(integrator="directlighting", sampler="halton", direct_strategy="one"), dict(integrator="directlighting", sampler="random"),
+                                dict(sampler="02sequence"), dict(sampler="maxmindist")])
+def test_dynamic_materials_under_every_integrator_and_sampler(gpu, oracle, kw):
+    """the same gallery through the forms that used to refuse it: VolPathIntegrator (wavefront k_vol_shade<DYN> and per lane),
+    DirectLightingIntegrator (allow_multiple_lobes = false: the lists are assembled for that; per lane with one lobe record per
+    recursion level), PathIntegrator under the pixel samplers (k_tile_serial mode 4)"""
     from tests.util import DYNAMIC_LOOK_AT, dynamic_gallery
     sc = dynamic_gallery(gpu.bvh_build)
-    with gpu.DeviceScene(sc) as ds:
-        for kw in (dict(integrator="volpath"), dict(integrator="directlighting"), dict(sampler="02sequence")):
-            with pytest.raises(RsptError) as e:
-                gpu.render(ds, scenes.make_render_desc(32, 16, 4, DYNAMIC_LOOK_AT, 75.0, **kw))
-            assert e.value.code == abi.E_UNSUPPORTED
+    ls = [1] * sc.desc.n_lights
+    rd = scenes.make_render_desc(64, 28, 16 if kw.get("sampler") in ("stratified", "maxmindist") else 8, DYNAMIC_LOOK_AT, 75.0, max_depth=4, light_samples=ls, **kw)
+    if kw.get("integrator") == "directlighting":
+        from tests.test_gpu_directlighting import check
+        check(gpu, oracle, sc, rd, kw.get("direct_strategy", "all"), ls if kw.get("direct_strategy", "all") == "all" else None)
+    else:
+        film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+        assert st["nan_samples"] == 0 and np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-6
 
 
 def test_film_reduce_runs_inside_the_library(gpu):
