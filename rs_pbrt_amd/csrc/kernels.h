@@ -76,6 +76,18 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
                                                 uint32_t* __restrict__ q_active, uint32_t* __restrict__ q_closest, QueueCounts* cnt) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) { cnt->active = bt.n; cnt->closest = bt.n; cnt->any = 0; }
+    // Sobol': the block's copy of the tables a camera sample reads — the two van der Corput matrices of this resolution (index of the
+    // sample in its pixel, lowdiscrepancy.rs:1014-1043) and generator-matrix rows 0..4 — so that the ~50 dependent table reads per sample
+    // are LDS reads (the kernel took 8 % of a C3 stand-in step reading them through L1 / L2)
+    __shared__ uint64_t s_vdc[2][52];
+    __shared__ uint32_t s_gen[5][52];
+    const bool sobol = rd.sampler_kind != RSPT_SAMPLER_HALTON;
+    const uint32_t m = (uint32_t)rd.log2_res;
+    if (sobol) {
+        for (uint32_t t = threadIdx.x; t < 5u * 52u; t += 256u) s_gen[t / 52u][t % 52u] = rd.sobol32[t];
+        if (m > 0u && threadIdx.x < 104u) s_vdc[threadIdx.x / 52u][threadIdx.x % 52u] = (threadIdx.x < 52u ? rd.vdc : rd.vdc_inv)[(m - 1u) * 52u + threadIdx.x % 52u];
+        __syncthreads();
+    }
     if (i >= bt.n) return;
     // path slot i = pixel-major (slot = pixel * ns + sample): the lanes of a wave start with rays through the same or
     // neighbouring pixels (sample-major slots cost 2 % on C2: less coherent first hits and shadow rays)
@@ -87,16 +99,33 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
     uint64_t index;
     float fx, fy;
     f3 p_lens{0.0f, 0.0f, 0.0f};   // (lens x, lens y, time): the time value only for a moving camera
-    if (rd.sampler_kind == RSPT_SAMPLER_HALTON) {
+    if (!sobol) {
         index = halton_index(rd, px, py, (uint64_t)s);
         fy = halton_dim(rd, index, 1); fx = halton_dim(rd, index, 0);
         if (rd.cam_anim) p_lens.z = halton_dim(rd, index, 2);
         if (rd.lens_radius > 0.0f) { p_lens.x = halton_dim(rd, index, 3); p_lens.y = halton_dim(rd, index, 4); }
     } else {
-        index = sobol_interval_to_index(rd, (uint32_t)rd.log2_res, (uint64_t)s, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
-        fy = sobol_pixel_dim(rd, index, 1, py); fx = sobol_pixel_dim(rd, index, 0, px);
-        if (rd.cam_anim) p_lens.z = sobol_dim(rd, index, 2);
-        if (rd.lens_radius > 0.0f) { p_lens.x = sobol_dim(rd, index, 3); p_lens.y = sobol_dim(rd, index, 4); }
+        // sobol_interval_to_index / sobol_dim / sobol_pixel_dim (dev_scene.h) over the LDS copies: the same XORs
+        index = 0;
+        if (m > 0u) {
+            index = (uint64_t)s << (m << 1);
+            uint64_t delta = 0;
+            for (uint64_t f = (uint64_t)s; f != 0; f &= f - 1) delta ^= s_vdc[0][__builtin_ctzll(f)];
+            uint64_t b = ((uint64_t)((uint32_t)(px - rd.sample_bounds[0]) << m) | (uint64_t)(int64_t)(py - rd.sample_bounds[1])) ^ delta;
+            for (; b != 0; b &= b - 1) index ^= s_vdc[1][__builtin_ctzll(b)];
+        }
+        auto dim = [&](uint32_t dnum) {
+            uint32_t v = 0;
+            for (uint64_t a = index; a != 0; a &= a - 1) v ^= s_gen[dnum][__builtin_ctzll(a)];
+            return fminf((float)v * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+        };
+        auto pixel_dim = [&](uint32_t dnum, int32_t pix) {
+            const float sv = dim(dnum) * (float)rd.resolution + (float)rd.sample_bounds[dnum];
+            return clampf(sv - (float)pix, 0.0f, RSPT_ONE_MINUS_EPS);
+        };
+        fy = pixel_dim(1, py); fx = pixel_dim(0, px);
+        if (rd.cam_anim) p_lens.z = dim(2);
+        if (rd.lens_radius > 0.0f) { p_lens.x = dim(3); p_lens.y = dim(4); }
     }
     f2 p_film{(float)px + fx, (float)py + fy};
     f3 o, d;
