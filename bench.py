@@ -362,11 +362,15 @@ def main():
                        "timed_region": "per step: rspt_render_device (first launch -> film complete in HBM%s) + the copy of the film to pinned host memory "
                                        "(%.1f MB): SURVEY 8(d)'s t_render, first launch -> film in host memory" % (
                                            " on rank 0 after the reduce" if world > 1 else "", scenes.n_pixels(m["rd"]) * 16 / 1e6)},
-            "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote, stale, ms_per_step) if m["counts"] else (
+            "roofline": roofline_block(m["counts"], m["count_scale"], stats, traffic, tnote, stale, ms_per_step) if (m["counts"] and stats[0]["launches_closest"] + stats[0]["launches_any"] > 0) else (
                 {"bound": "latency", "kernel": "k_tile_serial (one lane per tile: camera sample, reference-order traversal and shade_path in turn)", "achieved": None, "peak": None,
                  "unit": None, "frac": None, "traffic": None,
                  "note": "the pixel samplers make a tile one serial chain (DESIGN.md section 5.7): the bound is the dependent-load latency of one lane, "
-                         "not bandwidth or issue rate; what is reported is the rate next to the CPU's"} if args.sampler not in ("sobol", "halton") else None),
+                         "not bandwidth or issue rate; what is reported is the rate next to the CPU's"} if args.sampler not in ("sobol", "halton") else
+                {"bound": "latency", "kernel": "k_lane_dl (DirectLightingIntegrator::li, one lane per camera sample: the specular tree, its light estimates and the texture stage in one kernel)",
+                 "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                 "note": "the per-lane form of directlighting (DESIGN.md section 5.4: textured materials / max_depth > 8 / several specular lobes of one kind); "
+                         "no separate trace launches, the reference-order traversal runs inside the lane"}),
             "stats": {k: sum(s_[k] for s_ in stats) / len(stats) for k in ("t_trace_closest_s", "t_trace_any_s", "t_trace_s", "t_shade_s", "t_kernels_s", "trace_launches", "truncated_paths", "nan_samples")},
             "setup_s": {"scene_and_bvh_build": m["t_scene"], "upload": m["t_upload"], "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }

@@ -38,6 +38,8 @@ if [ "$mode" = all ]; then
   timeout 200 python bench.py --workload cornell --integrator ao --spp 16 --no-extra > $out/bench_cornell_ao.json 2> $out/bench_cornell_ao.err
   timeout 200 python bench.py --workload cornell --integrator directlighting --no-extra > $out/bench_cornell_directlighting.json 2> $out/bench_cornell_directlighting.err
   timeout 200 python bench.py --workload cornell --integrator volpath --no-extra > $out/bench_cornell_volpath.json 2> $out/bench_cornell_volpath.err
+  # directlighting over textured materials: the per-lane form under Sobol' (lane_serial.h), one lane per camera sample
+  timeout 300 python bench.py --workload statue_tex --integrator directlighting --spp 64 --steps 2 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_tex_directlighting.json 2> $out/bench_statue_tex_directlighting.err
   timeout 300 python bench.py --workload cornell --sampler 02sequence --steps 2 --warmup 1 --no-extra > $out/bench_cornell_02sequence.json 2> $out/bench_cornell_02sequence.err
   timeout 300 python bench.py --workload statue --sampler 02sequence --spp 16 --steps 1 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_02sequence.json 2> $out/bench_statue_02sequence.err
   for m in fixed reference; do
