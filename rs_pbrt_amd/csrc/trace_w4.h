@@ -173,7 +173,11 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
         if (INST && !ANY && OUT_MODE == 0 && !(entry & RSPT_Q_MIS) && out_inst) out_inst[slot] = best_inst;
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = best == RSPT_RETRACE ? 2u : (best != RSPT_MISS ? 1u : 0u);
-            else ((entry & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(best), (INST && best == RSPT_MISS) ? t_max : bb0, bb1, bb2);  // a miss: .y = the ray's final t_max (Q10)
+            else if (INST) {   // (two stores, not one store through a selected pointer: with the instance state live the select sent the kernel's pointer arguments — and with them the per-lane instance state — to scratch)
+                const float4 v = make_float4(__uint_as_float(best), best == RSPT_MISS ? t_max : bb0, bb1, bb2);  // a miss: .y = the ray's final t_max (Q10)
+                if (entry & RSPT_Q_MIS) { out_b[slot] = v; asm volatile(""); }   // (the empty asm keeps the compiler from merging the two stores back into one)
+                else out_a[slot] = v;
+            } else ((entry & RSPT_Q_MIS) ? out_b : out_a)[slot] = make_float4(__uint_as_float(best), bb0, bb1, bb2);
         } else {
             rspt_hit h;
             h.prim = best; h.t = bt; h.b0 = bb0; h.b1 = bb1; h.b2 = bb2;
