@@ -153,22 +153,26 @@ RDEV float sobol_pixel_dim(const RenderDev& rd, uint64_t index, uint32_t dim, in
 // over the set bits of the index, 8 independent XOR chains, instead of 8 serial passes through
 // L2-resident global memory.  Values are identical to sobol_dim().
 struct SobolBlock {
-    float v[8];
+    float v0, v1, v2, v3, v4, v5, v6, v7;   // eight scalars, not an array: selecting between array elements became a selected ADDRESS into a
+                                            // scratch copy of the array (two scratch loads per draw in every k_shade instantiation)
     uint32_t base, dim;  // first dimension held, next dimension to hand out
     RDEV void fill(const uint32_t* __restrict__ tab, uint32_t nd, uint64_t index, uint32_t first_dim) {
-        uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0, x5 = 0, x6 = 0, x7 = 0;
         for (uint64_t a = index; a != 0; a &= a - 1) {
             const uint32_t* row = tab + (uint32_t)__builtin_ctzll(a) * nd + first_dim;
-#pragma unroll
-            for (int k = 0; k < 8; k++) x[k] ^= row[k];
+            x0 ^= row[0]; x1 ^= row[1]; x2 ^= row[2]; x3 ^= row[3]; x4 ^= row[4]; x5 ^= row[5]; x6 ^= row[6]; x7 ^= row[7];
         }
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = fminf((float)x[k] * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+        v0 = fminf((float)x0 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS); v1 = fminf((float)x1 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+        v2 = fminf((float)x2 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS); v3 = fminf((float)x3 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+        v4 = fminf((float)x4 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS); v5 = fminf((float)x5 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
+        v6 = fminf((float)x6 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS); v7 = fminf((float)x7 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS);
         base = dim = first_dim;
     }
     RDEV float at(uint32_t k) const {
-        float lo = (k & 1) ? ((k & 2) ? v[3] : v[1]) : ((k & 2) ? v[2] : v[0]);
-        float hi = (k & 1) ? ((k & 2) ? v[7] : v[5]) : ((k & 2) ? v[6] : v[4]);
+        float a0 = v0, a1 = v1, a2 = v2, a3 = v3, a4 = v4, a5 = v5, a6 = v6, a7 = v7;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));   // values, not addresses, go into the selects
+        float lo = (k & 1) ? ((k & 2) ? a3 : a1) : ((k & 2) ? a2 : a0);
+        float hi = (k & 1) ? ((k & 2) ? a7 : a5) : ((k & 2) ? a6 : a4);
         return (k & 4) ? hi : lo;
     }
     RDEV float get_1d() { return at((dim++) - base); }
