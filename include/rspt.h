@@ -543,6 +543,13 @@ int rspt_light_distribution(rspt_scene_t scene, uint32_t light_strategy, const f
 int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t allow_multiple_lobes, rspt_material* out_material,
                         rspt_bxdf out_bxdfs[8]);
 
+/* Stage-level hook, host only (no device needed).  Replaces: AnimatedTransform::new up to the rotation test (core/transform.rs:912-943) for the
+ * camera's two key matrices — what rspt_render computes before its first launch when rspt_render_desc.camera_animated is set.  *animated_out:
+ * 0 when the keys are equal (actually_animated = false: nothing else is written), else 1 and trs_out[46] = the two translations t[2][3], the two
+ * rotation quaternions r[2][4] (x, y, z, w; the second one flipped onto the shorter arc), the two scale matrices s[2][16] (row-major; with
+ * the key's translation column still in it, transform.rs:2079 — only the 3x3 block is interpolated). */
+int rspt_camera_decompose(const float start_m[16], float start_time, const float end_m[16], float end_time, int32_t* animated_out, float trs_out[46]);
+
 /* Stage-level hook.  Replaces: f32::sin / cos / ln / log2 / exp / acos / atan2 as the path uses them (concentric_sample_disk
  * sampling.rs:360-382, Trowbridge-Reitz sampling microfacet.rs:475-531, spherical directions and mappings, MIP level selection, roughness
  * remapping, medium transmittance) = the host libm's sinf / cosf / logf / log2f / expf / acosf / atan2f.  The device evaluates glibc's

@@ -2164,6 +2164,17 @@ int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t
     return (int)lb.lobes.size();
 }
 
+int rspt_camera_decompose(const float start_m[16], float start_time, const float end_m[16], float end_time, int32_t* animated_out, float trs_out[46]) {
+    if (!start_m || !end_m || !animated_out || !trs_out) return fail(RSPT_E_INVALID, "null argument");
+    CamAnim ca;
+    *animated_out = camanim::camera_keys(start_m, start_time, end_m, end_time, &ca) ? 1 : 0;
+    if (*animated_out) {
+        memcpy(trs_out, ca.t, sizeof ca.t);
+        memcpy(trs_out + 6, ca.r, sizeof ca.r);
+        memcpy(trs_out + 14, ca.s, sizeof ca.s);
+    }
+    return RSPT_OK;
+}
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (n == 0) return RSPT_OK;

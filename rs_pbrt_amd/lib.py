@@ -16,7 +16,7 @@ EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create"
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
            "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
            "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy", "rspt_light_distribution", "rspt_libm",
-           "rspt_material_lobes")
+           "rspt_material_lobes", "rspt_camera_decompose")
 
 
 def source_hash():
@@ -72,6 +72,7 @@ def lib():
         L.rspt_light_distribution.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         L.rspt_libm.argtypes = [u32, vp, vp, C.c_uint64, vp]
         L.rspt_material_lobes.argtypes = [vp, u32, u32, vp, vp]
+        L.rspt_camera_decompose.argtypes = [vp, C.c_float, vp, C.c_float, vp, vp]
         L.rspt_comm_unique_id.argtypes = [vp]
         L.rspt_comm_init.argtypes = [i32, i32, vp]
         _LIB = L
@@ -84,6 +85,17 @@ def _check(rc):
 
 
 MATERIAL_DYNAMIC = 1000
+
+
+def camera_decompose(rd):
+    """What rspt_render makes of a moving camera's two key matrices (rspt_camera_decompose; host only): None when they are equal, else
+    (t (2, 3), r (2, 4) xyzw, s (2, 4, 4)) — AnimatedTransform::new's translations, quaternions (second on the shorter arc), scale matrices."""
+    a = np.asarray(list(rd.camera_to_world), np.float32); b = np.asarray(list(rd.camera_to_world_end), np.float32)
+    animated = C.c_int32(0); trs = np.zeros(46, np.float32)
+    _check(lib().rspt_camera_decompose(a.ctypes.data, float(rd.camera_time[0]), b.ctypes.data, float(rd.camera_time[1]), C.addressof(animated), trs.ctypes.data))
+    if not animated.value:
+        return None
+    return trs[:6].reshape(2, 3).copy(), trs[6:14].reshape(2, 4).copy(), trs[14:].reshape(2, 4, 4).copy()
 
 
 def material_lobes(scene, material, allow_multiple_lobes=True):

@@ -88,3 +88,38 @@ def test_glibc_restatements_equal_the_host_libm(tmp_path):
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe), "-x", "c++", os.path.join(ROOT, "tools", "libm_exhaustive.c"), "-lm", "-lpthread"])
     out = subprocess.run([str(exe), "5"], stdout=subprocess.PIPE, timeout=1800)
     assert out.returncode == 0 and b"all eight functions equal the host libm" in out.stdout, out.stdout.decode()
+
+
+def test_moving_camera_keys_decompose_like_the_oracle(oracle):
+    """rspt_camera_decompose (host only: what rspt_render does with a moving camera's key matrices, camera_anim.h) against the oracle's
+    restatement of AnimatedTransform::new / decompose (orc_animated.hpp, pinned from first principles in test_oracle_kat.py): translations,
+    quaternions and scale matrices bit for bit — they are inputs of every camera ray — over look-at keys, sheared / scaled / mirrored keys, keys a
+    hair apart (the polar iteration's exit), and equal keys (no animation)."""
+    import ctypes as C
+    from rs_pbrt_amd import lib, scenes
+    rng = np.random.default_rng(19)
+    la0 = ((278, 273, -800), (278, 273, 0), (0, 1, 0))
+    cases = []
+    for i in range(24):
+        pos = rng.uniform(-900, 900, 3); look = rng.uniform(-200, 200, 3); up = rng.normal(size=3) + (0, 2, 0)
+        rd = scenes.make_render_desc(32, 32, 1, la0, 40.0, look_at_end=(tuple(pos), tuple(look), tuple(up)), camera_times=(float(rng.uniform(0, 0.4)), float(rng.uniform(0.6, 1.0))))
+        if i % 3 == 1:     # scale / shear / mirror in front of the end key (and of the start key for every sixth)
+            a = np.asarray(list(rd.camera_to_world_end), np.float64).reshape(4, 4) @ np.array([[rng.uniform(0.3, 3), rng.uniform(-0.5, 0.5), 0, 0], [0, rng.uniform(0.3, 3), rng.uniform(-0.5, 0.5), 0],
+                                                                                                [0, 0, rng.uniform(0.3, 3) * (-1 if i % 2 else 1), 0], [0, 0, 0, 1]])
+            rd.camera_to_world_end[:] = a.astype(np.float32).reshape(-1).tolist()
+            if i % 6 == 1:
+                rd.camera_to_world[:] = (np.asarray(list(rd.camera_to_world), np.float64).reshape(4, 4) @ np.diag([2.0, 0.5, 1.5, 1.0])).astype(np.float32).reshape(-1).tolist()
+        if i % 3 == 2:     # the end key a hair away from the start key
+            rd.camera_to_world_end[:] = (np.asarray(list(rd.camera_to_world), np.float32) * np.float32(1.0 + 1e-6 * (i + 1))).tolist()
+            rd.camera_to_world_end[15] = 1.0
+        cases.append(rd)
+    for rd in cases:
+        got = lib.camera_decompose(rd)
+        m = np.zeros(16, np.float32); trs = np.zeros(46, np.float32)
+        oracle.lib().orc_camera_matrix(C.addressof(rd), 0.5, m.ctypes.data, trs.ctypes.data)
+        assert got is not None
+        t, r, s = got
+        assert t.tobytes() == trs[:6].tobytes() and r.tobytes() == trs[6:14].tobytes() and s.tobytes() == trs[14:].tobytes()
+        assert np.isfinite(r).all() and abs(float((r[0] * r[1]).sum())) <= 1.0 + 1e-5 and float((r[0] * r[1]).sum()) >= 0.0   # the shorter arc
+    same = scenes.make_render_desc(32, 32, 1, la0, 40.0, look_at_end=la0)
+    assert lib.camera_decompose(same) is None
