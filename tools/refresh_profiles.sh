@@ -42,10 +42,15 @@ if [ "$mode" = all ]; then
   timeout 300 python bench.py --workload statue_tex --integrator directlighting --spp 64 --steps 2 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_tex_directlighting.json 2> $out/bench_statue_tex_directlighting.err
   timeout 300 python bench.py --workload cornell --sampler 02sequence --steps 2 --warmup 1 --no-extra > $out/bench_cornell_02sequence.json 2> $out/bench_cornell_02sequence.err
   timeout 300 python bench.py --workload statue --sampler 02sequence --spp 16 --steps 1 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_02sequence.json 2> $out/bench_statue_02sequence.err
-  for m in fixed reference; do
-    [ -n "${SKIP_C5:-}" ] && continue   # the C5 stand-in lines take six minutes (host-side scene generation); skip when the change cannot touch them
-    timeout 300 python bench.py --workload c5 --instancing $m --steps 3 --warmup 1 --no-extra > $out/bench_c5_$m.json 2> $out/bench_c5_$m.err
-  done
+  # the C5 stand-in: both instancing modes from one host-side scene build (tools/c5_both_modes.py); FULL_C5=1 runs the two bench.py lines with
+  # their CPU legs instead (six minutes each, most of it scene generation)
+  if [ -z "${SKIP_C5:-}" ]; then
+    if [ -n "${FULL_C5:-}" ]; then
+      for m in fixed reference; do timeout 600 python bench.py --workload c5 --instancing $m --steps 3 --warmup 1 --no-extra > $out/bench_c5_$m.json 2> $out/bench_c5_$m.err; done
+    else
+      timeout 900 python tools/c5_both_modes.py 3 > $out/c5_both_modes.txt 2> $out/c5_both_modes.err
+    fi
+  fi
   for w in volpath 02sequence; do   # kernel stats of the two schedules that are not the wavefront path loop
     if [ $w = volpath ]; then a="--integrator volpath"; else a="--sampler 02sequence --spp 8"; fi
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks_cornell_$w -- python $repo/bench.py --workload cornell $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $out/ks_cornell_$w.log 2>&1)
