@@ -747,13 +747,6 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
     }
     texture_hit(sc, tt, h, s, tri.material, pb.tex + p, pb.tex_stride);
 }
-RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
-                                                 const uint32_t* __restrict__ count_in) {
-    const uint32_t n = *count_in;
-    // inlined at this call site: as a call (the compiler's choice once the stage had a second caller) the launch runs 28 % longer — 248 VGPRs and
-    // 1056 B of scratch against 209 and 368 (DESIGN.md section 5.4); the tile-serial kernel, at its register ceiling, keeps calling it
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) [[clang::always_inline]] texture_path(sc, tt, rd, pb, q_active[i], nullptr);
-}
 
 // ---- K7b: bin the active queue by what the shade stage will do with each path -------------------------------------------
 // The queue leaves k_shade in path-slot order; after the trace stage a wave's 64 paths have hit different things: nothing (an
@@ -767,6 +760,18 @@ struct BinInfo {  // one per wavefront iteration, zeroed with the queue counters
     uint32_t total;  // padded length of the sorted queue
     uint32_t pad[15];
 };
+// q_sorted / bi (K7b, when the shade queue is binned): the same entries sorted by class and padded to whole waves, so that a wave of this
+// kernel too evaluates ONE material's texture graph (escaped paths and the depth limit have waves of their own and return at once)
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
+                                                 const uint32_t* __restrict__ count_in, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi) {
+    const uint32_t n = q_sorted ? bi->total : *count_in;
+    // inlined at this call site: as a call (the compiler's choice once the stage had a second caller) the launch runs 28 % longer — 248 VGPRs and
+    // 1056 B of scratch against 209 and 368 (DESIGN.md section 5.4); the tile-serial kernel, at its register ceiling, keeps calling it
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t p = q_sorted ? q_sorted[i] : q_active[i];
+        if (p != RSPT_BIN_INVALID) [[clang::always_inline]] texture_path(sc, tt, rd, pb, p, nullptr);
+    }
+}
 RDEV uint32_t bin_key(const SceneDev& sc, const PathBuf& pb, uint32_t max_depth, uint32_t p) {
     const uint32_t st = pb.state[p];
     const uint32_t prim = __float_as_uint(pb.hit_cont[p].x);

@@ -931,7 +931,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             trace_launches++;
             vol_rays += live;
             ev_open(2, 0);
-            if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][1], &cur->closest);
+            if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][1], &cur->closest, (const uint32_t*)nullptr, (const BinInfo*)nullptr);
             hipLaunchKernelGGL(s->has_dynamic ? k_vol_shade<true> : k_vol_shade<false>, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest,
                                g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits);
             ev_close(2, 0);
@@ -1144,7 +1144,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
                 hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
             }
-            if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active);
+            if (s->has_textures) {
+                const bool tex_sorted = shade_bins && env_size("RSPT_TEXTURE_SORTED", 1) != 0;
+                hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active,
+                                   tex_sorted ? g.q_sorted : (const uint32_t*)nullptr, tex_sorted ? &g.bin_info[it] : (const BinInfo*)nullptr);
+            }
             hipLaunchKernelGGL(shade_k, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
                                shade_bins ? g.q_sorted : (const uint32_t*)nullptr, shade_bins ? &g.bin_info[it] : (const BinInfo*)nullptr);
