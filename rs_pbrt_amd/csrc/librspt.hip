@@ -792,13 +792,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
 
     // ---- batches ----
-    // paths per wavefront batch: ~280 B of state each, so 2^29 paths = 150 GB of the 288 GB HBM (+ 51 GB of texture rows in a textured
-    // scene).  Large batches keep the persistent trace kernel's queues long and its launches few (every launch ends in a tail of a few
-    // long rays): measured in round 2, 2^25 / 2^26 / 2^27 / 2^28 paths per batch = 367 / 386 / 398 / 405 Msamples/s on C2 and
-    // 1243 / 1400 / 1472 / 1525 on the C3 stand-in; round 3, same box: 2^28 -> 2^29 = 1900 -> 1952 on the C3 stand-in (C2's frame is one
-    // batch of 2^28 either way).  When the device cannot give that much (other tenants, dynamic materials' 18 rows), the batch is halved
-    // until everything that scales with it fits.
-    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 29);
+    // paths per wavefront batch: ~280 B of state each, so 2^28 paths = 75 GB of the 288 GB HBM.  Large batches keep the persistent
+    // trace kernel's queues long and its launches few (every launch ends in a tail of a few long rays): measured with these
+    // kernels, 2^25 / 2^26 / 2^27 / 2^28 paths per batch = 367 / 386 / 398 / 405 Msamples/s on C2 and 1243 / 1400 / 1472 / 1525 on
+    // the C3 stand-in.  When the device cannot give that much (other tenants), the batch is halved until it fits.
+    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 28);
     cap = std::min<size_t>(std::max<size_t>(cap, 1024), (size_t)1 << 30);
     const bool counters = env_size("RSPT_COUNTERS", 0) != 0;
     // AOIntegrator: every camera sample carries ao_n_samples shadow rays through the same ray / occlusion arrays
@@ -821,7 +819,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H);
         if (rc == RSPT_OK && direct && !pixel_sampler && !dl_lane) rc = ensure_direct(g.cap);
         if (rc == RSPT_OK && volpath) rc = ensure_vol(g.cap);
-        if (rc == RSPT_OK && s->has_textures) rc = ensure_tex_rows(s->has_dynamic);
         if (rc == RSPT_OK) break;
         (void)hipGetLastError();  // out of memory: clear the sticky error and try half the batch
         free_paths();
