@@ -1090,6 +1090,83 @@ def cornell_box(bvh_builder, variant="matte", fog=None):
     return sb.finish(bvh_builder)
 
 
+# ---- the Cornell box of the reference's documentation (docs/source/getting_started.rst:150-209), recovered from its two renders ----
+# rs_pbrt ships two renders of rs-pbrt-test-scenes/pbrt/cornell_box/cornell_box.pbrt (Sampler "sobol" 8 and 256 spp, Integrator "path",
+# 500 x 500) but not the scene file.  What the file must say was recovered from the images (tools/recover_cornell_docs.py is the procedure,
+# tests/test_reference_pin.py the evidence: with this scene the oracle's 8-spp render has 94 % of its pixels byte for byte equal to the
+# reference's PNG).  Every value below sits on a sharp optimum of that agreement:
+#  * camera: `Scale -1 1 1` in front of `LookAt 278 273 -800  278 273 -799  0 1 0`, fov 39.146 (the frame edges of the 256-spp image give
+#    39.149 +- 0.003; at 39.1445 and 39.148 the byte agreement is already lower).  The mirror is on the camera, not the world: the same
+#    picture from a mirrored world has other BSDF frames (ts = cross(ns, ss)) and 16 % equal pixels;
+#  * room: the public Cornell data; blocks: exact squares of side 165 — centre (185, 169) turned by 0.29 rad, centre (368, 351) turned by
+#    1.27 rad (found as free corners, then as squares with 0.02 steps: 185.0, 169.0, 164.99..165.01, 16.616 deg = 0.2900 rad, ...);
+#  * every quad a fan (k, k+1, k+2), (k, k+2, k+3) of its vertex cycle — a triangle's first edge is its dpdu (default uv, triangle.rs:330-345),
+#    the axis every cosine-sampled bounce is built on; found per visible triangle among 2 diagonals x 3 rotations x 2 windings;
+#  * light: the public rectangle at y = 547.8 (+- 0.05 is worse), fan from its last vertex, L = 100; walls 0.4, red / green / blocks 0.5
+#    (+- 0.5 % of any of them halves the number of equal pixels).
+CORNELL_DOCS_LOOK_AT = ((278, 273, -800), (278, 273, -799), (0, 1, 0))
+CORNELL_DOCS_FOV = 39.14625166082039
+_DOCS_ROOM = [([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)], "white", 2),            # floor
+              ([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)], "white", 1),   # ceiling
+              ([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)], "white", 3),  # back
+              ([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)], "green", 1),
+              ([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)], "red", 1)]
+_DOCS_SHORT = ((185.0, 169.0, 165.0, 0.29), 165.0, (1, 2, 0, 2, 0))   # (centre x, centre z, side, angle of the edge a->d in rad), height, fan starts of top + 4 sides
+_DOCS_TALL = ((368.0, 351.0, 165.0, 1.27), 330.0, (1, 0, 2, 0, 2))
+_DOCS_LIGHT = [(343, 547.8, 227), (343, 547.8, 332), (213, 547.8, 332), (213, 547.8, 227)]
+
+
+def _docs_fan(k, rev=False):
+    c = [(k + i) % 4 for i in range(4)]
+    if rev:
+        c = [c[0], c[3], c[2], c[1]]
+    return [[c[0], c[1], c[2]], [c[0], c[2], c[3]]]
+
+
+def _docs_square(cx, cz, side, angle):
+    """corners a, b, c, d in the order the public data lists a block's top (a->d along `angle`, a->b a quarter turn on)"""
+    e = np.array([math.cos(angle), math.sin(angle)]) * side
+    f = np.array([-e[1], e[0]])
+    a = np.array([cx, cz]) - (e + f) / 2
+    return [tuple(a), tuple(a + f), tuple(a + e + f), tuple(a + e)]
+
+
+def _docs_block_quads(corners, h, tall):
+    a, b, c, d = corners
+    side = lambda u, v: [(u[0], 0, u[1]), (u[0], h, u[1]), (v[0], h, v[1]), (v[0], 0, v[1])]  # noqa: E731
+    order = ((a, d), (d, c), (c, b), (b, a)) if tall else ((d, c), (a, d), (b, a), (c, b))   # the public data lists the two blocks' sides in different orders
+    return [[(p[0], h, p[1]) for p in (a, b, c, d)]] + [side(u, v) for u, v in order]
+
+
+def cornell_box_docs(bvh_builder, mirror_world=False, L=100.0, white=0.4, colour=0.5):
+    """The scene behind docs/source/cornell_box_{8,256}_pixelsamples.png as recovered from those images (see above); render it with
+    cornell_docs_render_desc().  mirror_world=True negates x and turns the light's cycle round so that it still faces down: with
+    cornell_docs_render_desc(mirror_camera=False) that is the same picture with other BSDF frames — the negative control of
+    tests/test_reference_pin.py."""
+    sb = SceneBuilder()
+    m = dict(white=sb.add_material(matte((white,) * 3)), red=sb.add_material(matte((colour, 0, 0))), green=sb.add_material(matte((0, colour, 0))),
+             block=sb.add_material(matte((colour,) * 3)))
+    sx = -1.0 if mirror_world else 1.0
+    quads = [(q, m[k], kf) for q, k, kf in _DOCS_ROOM]
+    for sq, h, kfs in (_DOCS_SHORT, _DOCS_TALL):
+        quads += [(q, m["block"], kf) for q, kf in zip(_docs_block_quads(_docs_square(*sq), h, h > 200), kfs)]
+    for q, mat, kf in quads:
+        sb.add_mesh(np.array([(sx * p[0], p[1], p[2]) for p in q], F32), _docs_fan(kf), mat)
+    sb.add_mesh(np.array([(sx * p[0], p[1], p[2]) for p in _DOCS_LIGHT], F32), _docs_fan(3, rev=mirror_world), m["white"], emit=(L,) * 3)
+    return sb.finish(bvh_builder)
+
+
+def cornell_docs_render_desc(spp=8, res=500, mirror_camera=True, **kw):
+    """Film 500 x 500, Sampler "sobol", Integrator "path" (maxdepth 5), box filter: getting_started.rst:166-172; `Scale -1 1 1` in front of
+    LookAt unless mirror_camera=False (then the camera stands at x = -278, for cornell_box_docs(mirror_world=True))."""
+    look = CORNELL_DOCS_LOOK_AT if mirror_camera else ((-278, 273, -800), (-278, 273, -799), (0, 1, 0))
+    rd = make_render_desc(res, res, spp, look, CORNELL_DOCS_FOV, **kw)
+    if mirror_camera:   # CTM = Scale * LookAt is world-to-camera, so camera-to-world = LookAt^-1 * Scale(-1, 1, 1)
+        c2w = np.array(rd.camera_to_world[:], np.float64).reshape(4, 4) @ np.diag([-1.0, 1.0, 1.0, 1.0])
+        rd.camera_to_world[:] = c2w.astype(F32).reshape(-1).tolist()
+    return rd
+
+
 CORNELL_FOG = ((0.0002, 0.0002, 0.0003), (0.0016, 0.0016, 0.0014), 0.3)   # per scene unit (the room is 550 units wide): optical depth ~1 across it
 CORNELL_LOOK_AT = ((278, 273, -800), (278, 273, 0), (0, 1, 0))
 CORNELL_FOV = 39.3
