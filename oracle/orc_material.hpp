@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE — CPU oracle (see orc_math.hpp header).  Material::compute_scattering_functions
 // (src/core/material.rs:63-113) restated material by material from src/materials/*.rs: every parameter texture is evaluated at
 // the hit, clamped, and the BxDFs are pushed in the reference's order behind the reference's `is_black` guards.  Parity unpinned
-// (no reference output exists here); what this file pins is the LIBRARY's host-side assembly (rs_pbrt_amd/csrc/
+// (the reference output that exists here, tests/test_reference_pin.py, reaches MatteMaterial with sigma = 0 only); what this file pins is the LIBRARY's host-side assembly (rs_pbrt_amd/csrc/
 // material_assembly.h), which folds constant parameters once per material: the two are written independently from the same Rust
 // and compared lobe by lobe in tests/test_materials.py and sample by sample in the GPU render tests.
 #pragma once

@@ -3,8 +3,10 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 The product package (rs_pbrt_amd) never does.
 
-Parity unpinned: the reference has no tests or golden vectors for this path and no Rust toolchain exists here, so
-the oracle is checked against first-principles known answers (tests/test_oracle_*.py), not against rs_pbrt output."""
+Parity: pinned by real rs_pbrt output on one scene family only — the reference's two documentation renders of the Cornell box
+(tests/test_reference_pin.py: path, Sobol', matte, area light, spatial light distribution, film).  For everything else the
+reference has no tests or golden vectors and no Rust toolchain exists here: unpinned, checked against first-principles known
+answers (tests/test_oracle_*.py), not against rs_pbrt output."""
 import ctypes as C
 import os
 import subprocess

@@ -5,7 +5,7 @@ docs/source/cornell_box_256_pixelsamples.png (500 x 500, 8-bit sRGB; `rs_pbrt --
 tests/golden/reference_cornell_docs.npz (the reference tree does not exist on the GPU box).  Needs PIL; run where /root/reference exists:
 
     python tests/golden/make_reference_cornell.py            # writes the fixture
-    python tests/golden/make_reference_cornell.py --recover  # re-runs the searches below and prints what they find (minutes)
+    python tests/golden/make_reference_cornell.py --recover  # = python tools/recover_cornell_docs.py: re-runs the searches and prints what they find (minutes)
 
 The scene FILE of those renders (rs-pbrt-test-scenes/pbrt/cornell_box/cornell_box.pbrt) is not in the tree.  rs_pbrt_amd/scenes.py
 `cornell_box_docs` is that scene as recovered from the two images, in this order (every step is a search whose objective is agreement
