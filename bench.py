@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--integrator", default="path", choices=["path", "ao", "directlighting", "volpath"],
                     help="ao: AOIntegrator (64 cosine-sampled shadow rays per camera sample); directlighting: DirectLightingIntegrator, strategy all, maxdepth 5; "
                          "volpath: VolPathIntegrator (with --workload cornell the room is filled with a homogeneous medium)")
-    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "statue", "statue_tex", "c4", "c5"])
+    ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "cornell_docs", "statue", "statue_tex", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -69,6 +69,9 @@ def self_spawn(args):
     return subprocess.call(cmd, env=env)
 
 
+PUBLISHED_CORNELL_MSAMPLES = 500 * 500 * 8 / (1024 / 1828.38) / 1e6   # 3.57
+
+
 def build_workload(args, workload, lib, scenes):
     """-> (scene, mk_rd(spp, shard), spp, name)"""
     integ = args.integrator
@@ -82,6 +85,13 @@ def build_workload(args, workload, lib, scenes):
         sc = scenes.cornell_box(lib.bvh_build_gpu, fog=scenes.CORNELL_FOG if integ == "volpath" else None)
         mk = lambda s, sh, **kw: scenes.cornell_render_desc(res=res, spp=s, shard=sh, integrator=integ, **kw)  # noqa: E731
         name = "Cornell Box%s, path depth 5, sobol %d spp, %dx%d" % (" filled with a homogeneous medium (optical depth ~1 across the room)" if integ == "volpath" else "", spp, res, res)
+    elif workload == "cornell_docs":
+        # the ONE configuration the reference publishes a rate for (docs/source/getting_started.rst:161-175, 500 x 500, sobol 8 spp, path,
+        # 1828.38 tiles/s on 28 threads = 3.57 Msamples/s), on the scene recovered from the reference's own renders of it
+        res, spp = args.res or 500, args.spp or 8
+        sc = scenes.cornell_box_docs(lib.bvh_build_gpu)
+        mk = lambda s, sh, **kw: scenes.cornell_docs_render_desc(s, res, shard=sh, integrator=integ, **kw)  # noqa: E731
+        name = "the Cornell box of the reference's documentation (scene recovered from its renders, 94 %% of the 8-spp PNG reproduced byte for byte), path depth 5, sobol %d spp, %dx%d" % (spp, res, res)
     elif workload == "c5":
         xres, spp = args.res or 1920, args.spp or 64
         yres = xres * 9 // 16
@@ -374,6 +384,10 @@ def main():
             "stats": {k: sum(s_[k] for s_ in stats) / len(stats) for k in ("t_trace_closest_s", "t_trace_any_s", "t_trace_s", "t_shade_s", "t_kernels_s", "trace_launches", "truncated_paths", "nan_samples")},
             "setup_s": {"scene_and_bvh_build": m["t_scene"], "upload": m["t_upload"], "bvh_builder": "rspt_bvh_build_gpu (device, bit-identical to BVHAccel::new)"},
         }
+        if args.workload == "cornell_docs" and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol":
+            out["vs_baseline"] = out["value"] / PUBLISHED_CORNELL_MSAMPLES
+            out["baseline"] = ("%.2f Msamples/s = 500 * 500 * 8 samples / (1024 tiles / 1828.38 tiles/s): the reference's console transcript of this very render on 28 threads of an unnamed CPU "
+                               "(docs/source/getting_started.rst:161-175; BASELINE.md section 1) — the only rate the reference publishes" % PUBLISHED_CORNELL_MSAMPLES)
         pyoracle = None
         if world == 1 and not args.no_cpu_baseline:  # the CPU baseline is reported on rank 0 at N = 1 only
             from oracle import pyoracle  # CPU baseline leg only

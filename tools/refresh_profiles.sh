@@ -32,7 +32,7 @@ if [ "$mode" != quick ]; then
   python tools/pmc_to_json.py $out > $out/pmc_to_json.log 2>&1
 fi
 if [ "$mode" = all ]; then
-  for w in cornell statue_tex c4; do
+  for w in cornell cornell_docs statue_tex c4; do
     timeout 300 python bench.py --workload $w --no-extra > $out/bench_$w.json 2> $out/bench_$w.err
   done
   timeout 200 python bench.py --workload cornell --integrator ao --spp 16 --no-extra > $out/bench_cornell_ao.json 2> $out/bench_cornell_ao.err
