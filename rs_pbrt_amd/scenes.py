@@ -900,7 +900,7 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
                      focal_distance=1e6, max_sample_luminance=float("inf"), shard=(0, 1, 64), sampler="sobol",
                      sample_at_pixel_center=False, integrator="path", ao_samples=64, ao_cos_sample=True, direct_strategy="all", light_samples=None,
                      dimensions=4, strat=(4, 4), jitter=True, sample_range=None, allow_slow_paths=True, look_at_end=None, camera_times=(0.0, 1.0),
-                     shutter=(0.0, 1.0)):
+                     shutter=(0.0, 1.0), mirror_x=False):
     """allow_slow_paths: True here (tests and bench want the device path whatever its speed); the Rust shim passes 0, so that a pixel-sampler
     frame of few tiles — which the device renders slower than the host's tile loop — comes back as RSPT_E_UNSUPPORTED (include/rspt.h)"""
     rd = abi.RenderDesc()
@@ -937,6 +937,9 @@ def make_render_desc(xres, yres, spp, look_at, fov, max_depth=5, rr_threshold=1.
     rd.raster_to_camera[:] = r2c.m.reshape(-1).tolist()
     w2c = Transform.look_at(*look_at)
     rd.camera_to_world[:] = w2c.m_inv.reshape(-1).tolist()
+    if mirror_x:   # `Scale -1 1 1` in front of LookAt: the CTM Scale * LookAt is world-to-camera, so camera-to-world = LookAt^-1 * Scale(-1, 1, 1)
+        assert look_at_end is None
+        rd.camera_to_world[:] = (w2c.m_inv.astype(np.float64) @ np.diag([-1.0, 1.0, 1.0, 1.0])).astype(F32).reshape(-1).tolist()
     rd.lens_radius, rd.focal_distance = lens_radius, focal_distance
     rd.shutter_open, rd.shutter_close = float(shutter[0]), float(shutter[1])
     if look_at_end is not None:   # a moving camera (ActiveTransform / TransformTimes blocks around LookAt): AnimatedTransform's two key matrices
@@ -1160,11 +1163,7 @@ def cornell_docs_render_desc(spp=8, res=500, mirror_camera=True, **kw):
     """Film 500 x 500, Sampler "sobol", Integrator "path" (maxdepth 5), box filter: getting_started.rst:166-172; `Scale -1 1 1` in front of
     LookAt unless mirror_camera=False (then the camera stands at x = -278, for cornell_box_docs(mirror_world=True))."""
     look = CORNELL_DOCS_LOOK_AT if mirror_camera else ((-278, 273, -800), (-278, 273, -799), (0, 1, 0))
-    rd = make_render_desc(res, res, spp, look, CORNELL_DOCS_FOV, **kw)
-    if mirror_camera:   # CTM = Scale * LookAt is world-to-camera, so camera-to-world = LookAt^-1 * Scale(-1, 1, 1)
-        c2w = np.array(rd.camera_to_world[:], np.float64).reshape(4, 4) @ np.diag([-1.0, 1.0, 1.0, 1.0])
-        rd.camera_to_world[:] = c2w.astype(F32).reshape(-1).tolist()
-    return rd
+    return make_render_desc(res, res, spp, look, CORNELL_DOCS_FOV, mirror_x=mirror_camera, **kw)
 
 
 CORNELL_FOG = ((0.0002, 0.0002, 0.0003), (0.0016, 0.0016, 0.0014), 0.3)   # per scene unit (the room is 550 units wide): optical depth ~1 across it

@@ -132,12 +132,14 @@ def integrator_directive(integrator, max_depth, direct_strategy="all", ao_sample
 
 def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **kw):
     integ_kw = {k: kw.pop(k) for k in ("direct_strategy", "ao_samples", "ao_cos_sample") if k in kw}
-    cam_kw = {k: kw.pop(k) for k in ("look_at_end", "camera_times", "shutter", "lens_radius", "focal_distance") if k in kw}
+    cam_kw = {k: kw.pop(k) for k in ("look_at_end", "camera_times", "shutter", "lens_radius", "focal_distance", "mirror_x") if k in kw}
     sampler_kw = kw
     sb = sc.builder
     assert sb is not None, "the scene was not made by a SceneBuilder"
     cam_xf = ["LookAt %s  %s  %s" % tuple(f(v) for v in look_at)]
     cam_par = ""
+    if cam_kw.get("mirror_x"):
+        cam_xf = ["Scale -1 1 1"] + cam_xf
     if cam_kw.get("look_at_end") is not None:   # a moving camera: the CTM's two slots (api.rs active_transform_bits), AnimatedTransform::new in make_camera
         t0, t1 = cam_kw.get("camera_times", (0.0, 1.0))
         so, sc_ = cam_kw.get("shutter", (0.0, 1.0))
@@ -282,6 +284,8 @@ INSTANCED_CAMERA = (((0, 2.5, -6), (0, 0.5, 0), (0, 1, 0)), 40.0)
 def camera_of(name, scenes):
     """(look_at, fov) of a scene of SCENES"""
     cam = SCENES[name][1]
+    if cam == "CORNELL_DOCS":
+        return scenes.CORNELL_DOCS_LOOK_AT, scenes.CORNELL_DOCS_FOV
     return (scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV) if cam == "CORNELL" else cam
 
 
@@ -317,9 +321,13 @@ SCENES = {
     # a camera that turns and travels while the shutter is open (TransformTimes / ActiveTransform): AnimatedTransform decompose + slerp per ray,
     # with a thin lens, over the image-textured box (the differentials go through the interpolated matrix too)
     "cornell_moving_camera": (lambda b, s: s.cornell_box(b, "imagemap"), "CORNELL", 64, 64, 16, 5),
+    # the scene of the reference's own documentation renders as recovered from them (scenes.cornell_box_docs, tests/test_reference_pin.py): rs_pbrt's
+    # ref.png of this file should BE docs/source/cornell_box_8_pixelsamples.png (the oracle's render equals it byte for byte in 94 % of the pixels)
+    "cornell_docs": (lambda b, s: s.cornell_box_docs(b), "CORNELL_DOCS", 500, 500, 8, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
+    "cornell_docs": dict(mirror_x=True),
     "cornell_fog_volpath": dict(integrator="volpath"),
     "cornell_02sequence": dict(sampler="02sequence", dimensions=4),
     "cornell_random": dict(sampler="random"),
