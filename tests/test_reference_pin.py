@@ -10,8 +10,10 @@ camera ray, the triangle and BVH code, the shading frame, the cosine sampling, t
 emitter's two triangles, the triangle sampling, the shadow rays, the MIS weights, the film's box filter and write_image's gamma — so a byte
 match is a sample-for-sample match of all of those (what it does not cover: every other material, texture, light, sampler, integrator,
 media, instancing: for those the oracle is still pinned by first-principles tests only).
-The 6 % of pixels that differ are scattered evenly (no face, edge or shadow stands out): the rotated blocks' vertices are known to
-~0.02 units only (the file's decimals are not), and the docs' renders came from another machine's libm.
+The 6 % of pixels that differ are scattered evenly (no face, edge or shadow stands out), 1.7 % by one byte step, 4.2 % by more: about one path
+vertex in a thousand goes another way.  Not explained: every scalar of the scene is a strict optimum at steps of 0.005 units / 0.0002 rad
+(moving the light by 0.01 changes 0.6 % of the pixels), so it is not the recovery's resolution in those; what is left are the file's
+decimals vertex by vertex, the libm of the machine that rendered the pictures, and whatever the oracle may still get wrong.
 """
 import os
 
