@@ -10,10 +10,15 @@ camera ray, the triangle and BVH code, the shading frame, the cosine sampling, t
 emitter's two triangles, the triangle sampling, the shadow rays, the MIS weights, the film's box filter and write_image's gamma — so a byte
 match is a sample-for-sample match of all of those (what it does not cover: every other material, texture, light, sampler, integrator,
 media, instancing: for those the oracle is still pinned by first-principles tests only).
-The 6 % of pixels that differ are scattered evenly (no face, edge or shadow stands out), 1.7 % by one byte step, 4.2 % by more: about one path
-vertex in a thousand goes another way.  Not explained: every scalar of the scene is a strict optimum at steps of 0.005 units / 0.0002 rad
-(moving the light by 0.01 changes 0.6 % of the pixels), so it is not the recovery's resolution in those; what is left are the file's
-decimals vertex by vertex, the libm of the machine that rendered the pictures, and whatever the oracle may still get wrong.
+The 6 % of pixels that differ are scattered evenly (no face, edge or shadow stands out), 1.7 % by one byte step, 4.2 % by more — and they
+are ONE-SIDED: the reference is the brighter one in all of them (test_the_open_remainder...).  It holds 0.33 % more energy than the oracle,
+in single samples (about one path in 130) that carry an extra contribution of the size of an ordinary light sample, often of a pure wall
+colour (a path that has been to the red or the green wall).  0.33 % is what this scene's paths carry beyond five bounces (with
+`maxdepth` 100 the oracle's total equals the reference's to 4e-5) — but none of the ways to let paths run on that were tried (maxdepth
+6 .. 100, Russian roulette by luminance / from the throughput of the previous bounce / from bounce 3 or 5 / with its sample from a
+neighbouring dimension) puts the extra energy into the pixels where the reference has it: each LOWERS the share of equal pixels.  Every
+scalar of the scene is a strict optimum at steps of 0.005 units / 0.0002 rad, so it is not the recovery's resolution.  Open: an rs_pbrt
+of another vintage behind the documentation's pictures, or something this oracle (and the GPU with it) still gets wrong.
 """
 import os
 
@@ -83,3 +88,13 @@ def test_oracle_reproduces_the_references_256spp_png_in_every_sixth_tile(oracle)
     d = np.abs(to_u8(scenes.film_to_rgb(r["film"])) - G["spp256"].reshape(-1, 3).astype(np.int32)).max(-1)[mine]
     exact, w1, w4 = float((d == 0).mean()), float((d <= 1).mean()), float((d <= 4).mean())
     assert exact > 0.65 and w1 > 0.98 and w4 > 0.998, (exact, w1, w4)   # measured on these tiles: 0.703, 0.989, 0.9992
+
+
+def test_the_open_remainder_is_one_sided(oracle):
+    """What is known about the pixels that do not match (module docstring): the reference is brighter in every one of them, by 0.33 % of the
+    picture's energy in total — a record of the open end, so that whoever closes it sees the numbers move."""
+    sc = scenes.cornell_box_docs(oracle.bvh_build)
+    ours = to_u8(scenes.film_to_rgb(oracle.render(sc, scenes.cornell_docs_render_desc(8), threads=THREADS)["film"])).reshape(500, 500, 3)
+    ref = G["spp8"].astype(np.int32)
+    assert ((ours - ref).max(-1) > 0).mean() < 0.001          # measured: 0.0001 of the pixels have a byte above the reference's
+    assert 0.04 < ((ref - ours).max(-1) > 0).mean() < 0.07    # 0.058 have one below
