@@ -8,6 +8,7 @@ set -u
 tag=$1; round=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p $out
 timeout ${PYTEST_TIMEOUT:-480} python -m pytest tests -m gpu -x -q --ignore=tests/test_gpu_fullsize.py > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log
 tail -2 $out/pytest.log
+timeout 120 python tools/reference_pin_gpu.py > $out/reference_pin_gpu.txt 2>&1   # the product against the reference's own PNGs
 SKIP_C5=${SKIP_C5-1} bash tools/refresh_profiles.sh $tag all > $out/refresh.log 2>&1
 bash tools/collect_profiles.sh $tag $round > /dev/null 2>&1
 timeout 200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_final.json 2> $out/bench_final.err
