@@ -1,0 +1,13 @@
+import os, sys, numpy as np
+mode, start = sys.argv[1], sys.argv[2]
+os.environ['ORC_RR_MODE'] = mode; os.environ['ORC_RR_START'] = start
+sys.path.insert(0, '/tmp/orc2'); sys.path.insert(1, '/root/repo'); sys.path.insert(2, '/root/repo/tools')
+from oracle import pyoracle
+assert pyoracle.__file__.startswith('/tmp/orc2'), pyoracle.__file__
+import recover_cornell_docs as r
+assert r.oracle is pyoracle
+sc = r.build(r.FROZEN_TRIS, r.FROZEN_LIGHT, quads=r.FROZEN_QUADS)
+unsat = r.U8[8].max(-1) < 250
+for depth in [int(a) for a in sys.argv[3:]]:
+    img = r.render(sc, 8, max_depth=depth); s = r.to_u8(img) - r.U8[8]
+    print('mode', mode, 'start', start, 'depth', depth, r.byte_stats(img), 'signed %.3f' % s[unsat].mean(), 'ours/ref %.5f' % (np.minimum(img,1)[unsat].mean() / r.R8[unsat].mean()), flush=True)
