@@ -1,6 +1,7 @@
 import os, sys, numpy as np
 mode = sys.argv[1]; os.environ['ORC_RR_MODE'] = mode; os.environ['ORC_RR_START'] = '3'
-sys.path.insert(0, '/tmp/orc2'); sys.path.insert(1, '/root/repo'); sys.path.insert(2, '/root/repo/tools')
+HERE = os.path.dirname(os.path.abspath(__file__)); REPO = os.environ.get('REPO', '/root/repo')   # run from the scratch copy (README.md)
+sys.path.insert(0, HERE); sys.path.insert(1, REPO); sys.path.insert(2, os.path.join(REPO, 'tools'))
 from oracle import pyoracle
 import recover_cornell_docs as r
 sc = r.build(r.FROZEN_TRIS, r.FROZEN_LIGHT, quads=r.FROZEN_QUADS)

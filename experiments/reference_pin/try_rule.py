@@ -1,9 +1,10 @@
 import os, sys, numpy as np
 mode, start = sys.argv[1], sys.argv[2]
 os.environ['ORC_RR_MODE'] = mode; os.environ['ORC_RR_START'] = start
-sys.path.insert(0, '/tmp/orc2'); sys.path.insert(1, '/root/repo'); sys.path.insert(2, '/root/repo/tools')
+HERE = os.path.dirname(os.path.abspath(__file__)); REPO = os.environ.get('REPO', '/root/repo')   # run from the scratch copy (README.md)
+sys.path.insert(0, HERE); sys.path.insert(1, REPO); sys.path.insert(2, os.path.join(REPO, 'tools'))
 from oracle import pyoracle
-assert pyoracle.__file__.startswith('/tmp/orc2'), pyoracle.__file__
+assert pyoracle.__file__.startswith(HERE), pyoracle.__file__
 import recover_cornell_docs as r
 assert r.oracle is pyoracle
 sc = r.build(r.FROZEN_TRIS, r.FROZEN_LIGHT, quads=r.FROZEN_QUADS)
