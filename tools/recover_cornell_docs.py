@@ -27,7 +27,7 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-from rs_pbrt_amd import abi, scenes  # noqa: E402
+from rs_pbrt_amd import scenes  # noqa: E402
 from rs_pbrt_amd.scenes import F32, SceneBuilder, matte  # noqa: E402
 from oracle import pyoracle as oracle  # noqa: E402
 
