@@ -35,6 +35,16 @@ def main():
             ok = ok and bool(np.allclose(film.numpy(), full["film"], rtol=1e-6, atol=1e-7)) and np.array_equal(film.numpy()[:, 3], full["film"][:, 3])
             ok = ok and int(counts.item()) == full["counters"]["samples"] == 80 * 80 * 2
             ok = ok and 0 < n_mine < 80 * 80 * 2  # a strict subset of the frame per rank
+    # the same deal + sum against REAL rs_pbrt output: the two ranks' shard films of the documentation's Cornell box at 8 spp add up to a film whose bytes
+    # equal the reference's PNG in 94 % of the pixels (tests/test_reference_pin.py) — the N > 1 path loses nothing of that
+    sc = scenes.cornell_box_docs(pyoracle.bvh_build)
+    film = torch.from_numpy(pyoracle.render(sc, scenes.cornell_docs_render_desc(8, shard=multigpu.shard_for_rank(rank, world)), threads=2)["film"].copy())
+    multigpu.reduce_film(film, dst=0)
+    if rank == 0:
+        from tests.test_reference_pin import G, agreement
+        exact, w1, w4 = agreement(film.numpy(), G["spp8"])
+        ok = ok and exact > 0.93 and w1 > 0.95 and w4 > 0.98
+        print("GLOO_REFERENCE_PIN %.4f %.4f %.4f" % (exact, w1, w4), flush=True)
     if rank == 0:
         print("GLOO_RESULT", "OK" if ok else "MISMATCH", flush=True)
     dist.barrier()

@@ -24,7 +24,7 @@ def test_two_ranks_reduce_to_the_full_frame(oracle):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode("utf-8", "replace")
-    assert p.returncode == 0 and "GLOO_RESULT OK" in out, out[-3000:]
+    assert p.returncode == 0 and "GLOO_RESULT OK" in out and "GLOO_REFERENCE_PIN 0.94" in out, out[-3000:]
 
 
 def test_shards_of_lost_ranks_are_adopted_by_the_survivors(oracle):
