@@ -1,5 +1,5 @@
-"""world_size-2 worker for tests/test_gpu_render.py::test_film_reduce_with_two_ranks_on_one_gpu: two processes, both on GPU 0, join the
-LIBRARY's communicator (rspt_comm_init(rank, 2, id)), each renders its shard of the Morton tile deal with film_reduce = 1, rank 0 saves the
+"""world_size-2 worker for tests/test_gpu_render.py::test_film_reduce_with_two_ranks: two processes (one device each where the box has two,
+both on GPU 0 otherwise) join the LIBRARY's communicator (rspt_comm_init(rank, 2, id)), each renders its shard of the Morton tile deal with film_reduce = 1, rank 0 saves the
 reduced frame.  The id travels through a file (what the Rust shim does).  A second frame fails on rank 1 only: the status agreement in
 front of the reduce (librspt.hip film_reduce_agree) must bring rank 0 back with RSPT_E_PEER."""
 import os
@@ -41,7 +41,7 @@ def main():
     with lib.DeviceScene(sc) as ds:
         film, st = lib.render(ds, rd)
         # second frame: rank 1's render is refused before it reaches the reduce; rank 0 must come back with RSPT_E_PEER, not wait
-        rd2 = scenes.cornell_render_desc(res=80, spp=4, shard=(rank, 2, 1), integrator="directlighting", max_depth=9 if rank == 1 else 5)
+        rd2 = scenes.cornell_render_desc(res=80, spp=4, shard=(rank, 2, 1), integrator="directlighting", max_depth=33 if rank == 1 else 5)   # 33 > RSPT_DL_SERIAL_DEPTH: the only depth directlighting still refuses
         rd2.film_reduce = 1
         code = 0
         try:

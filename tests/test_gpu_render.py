@@ -611,8 +611,8 @@ def test_film_reduce_runs_inside_the_library(gpu):
             gpu.comm_destroy()
 
 
-def test_film_reduce_with_two_ranks_on_one_gpu(gpu, tmp_path):
-    """X1 with a world of two: two processes on the one GPU of this box join the library's RCCL communicator, render the shards
+def test_film_reduce_with_two_ranks(gpu, tmp_path):
+    """X1 with a world of two: two processes (one device each where the box has two devices, both on device 0 otherwise) join the library's RCCL communicator, render the shards
     (0, 2, 1) / (1, 2, 1) with film_reduce = 1; rank 0's buffer must hold the whole frame (= the single-rank render: weights bit for
     bit, radiance up to the order of the sum).  RCCL may refuse two ranks on one device ("Duplicate GPU detected"): then the test says so
     and skips — the multi-device run is the driver's."""
