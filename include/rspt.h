@@ -111,9 +111,11 @@ typedef struct {
  * lobe list once per material (clamp, `is_black` guards, roughness remapping, OrenNayar A / B), parameters bound to other
  * textures are evaluated per hit by the texture stage: Kd, Ks and the roughnesses leave the lobe list's shape alone and only
  * scale lobes (the fast path); a non-constant texture on any other parameter (sigma, index, opacity, Kr, Kt, reflect, transmit, eta, k,
- * a glass roughness, a mix amount) makes the material "dynamic" — its lobe list is built per hit on the device.  Refused with
- * RSPT_E_UNSUPPORTED: a mix of a mix, more than 12 varying textures on a dynamic material, dynamic materials under volpath /
- * directlighting / the pixel samplers. */
+ * a glass roughness, a mix amount) makes the material "dynamic" — its lobe list is built per hit on the device, under every
+ * integrator and sampler.  A mix may contain mixes: the tree is flattened into its non-mix materials, each scaled by its immediate
+ * parent's amount only (a MixMaterial ignores the scale it is handed itself, mixmat.rs:50).  Refused with RSPT_E_UNSUPPORTED: a
+ * tree of mixes with more than 8 non-mix materials, more than 12 varying textures on a dynamic material, a material that can push
+ * more than 8 BxDFs (Bsdf::add asserts there, reflection.rs:247). */
 enum {
     RSPT_MAT_MATTE = 1,       /* matte.rs:43-86:       kd, sigma, bumpmap                                               */
     RSPT_MAT_PLASTIC = 2,     /* plastic.rs:57-125:    kd, ks, roughness, remap_roughness, bumpmap                      */
@@ -137,8 +139,8 @@ typedef struct {
     uint32_t index;           /* glass / uber: float "index" (uber.rs calls it eta)                                      */
     uint32_t bumpmap;         /* float, or 0                                                                             */
     uint32_t remap_roughness; /* "remaproughness" (default true)                                                         */
-    uint32_t m1, m2;          /* mix: indices into materials[]; neither may be a mix itself (the reference drops the outer
-                                 scale of a nested mix, mixmat.rs:50: `_scale`)                                          */
+    uint32_t m1, m2;          /* mix: indices into materials[]; either may be a mix itself (which then ignores the scale
+                                 this one hands it, mixmat.rs:50: `_scale`)                                              */
 } rspt_material_desc; /* 80 B */
 
 /* What the library assembles from a material record: the BxDF list of Bsdf.bxdfs in push order (it matters: Bsdf::sample_f

@@ -371,21 +371,22 @@ RDEVN const rspt_mat::Built* dynamic_lobes(const rspt_mat::DynMaterial& dm, cons
         if (q.row) { const float4 v = rows[(size_t)(RSPT_TEX_ROWS + q.row - 1u) * stride]; r = param_value(id, v.x, v.y, v.z); }
         return r;
     };
-    // the mix amount s1 and, for the second side, s2 = clamp(1 - s1) (mixmat.rs:52-56), kept in scalars and copied into one array per
-    // side: a choice between two arrays by pointer — `k ? s2 : s1` — came out as s2 for BOTH sides in the per-lane kernels (every m1 lobe
-    // scaled by 1 - amount; the wavefront instantiation of the same source was right), found by the linearity of the frame in the scales
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    if (dm.n_parts == 2u) {
-        const Param am = fetch(dm.amount, P_KD);  // a colour: clamp(0, inf)
-        a0 = am.v[0]; a1 = am.v[1]; a2 = am.v[2];
-    }
+    // a part under a mix is scaled by its parent's s1 = clamp(amount) or s2 = clamp(1 - s1) (mixmat.rs:52-56).  The scale is computed into
+    // scalars and copied into one array: a choice between two arrays by pointer — `k ? s2 : s1` — came out as s2 for BOTH sides in the
+    // per-lane kernels (every m1 lobe scaled by 1 - amount; the wavefront instantiation of the same source was right), found by the linearity
+    // of the frame in the scales
     for (uint32_t k = 0; k < dm.n_parts; k++) {
+        const DynPart& part = dm.part[k];
         Param p[P_COUNT];
 #pragma unroll 1
-        for (uint32_t i = 0; i < P_COUNT; i++) p[i] = fetch(dm.part[k].p[i], i);
-        float side[3];
-        side[0] = k ? clamp0(1.0f - a0) : a0; side[1] = k ? clamp0(1.0f - a1) : a1; side[2] = k ? clamp0(1.0f - a2) : a2;
-        build_part(dm.part[k].kind, p, dm.part[k].remap != 0u, allow_multiple_lobes, dm.n_parts == 2u ? side : nullptr, k == 1u, out);
+        for (uint32_t i = 0; i < P_COUNT; i++) p[i] = fetch(part.p[i], i);
+        float side[3] = {0.0f, 0.0f, 0.0f};
+        if (part.side) {
+            const Param am = fetch(part.amount, P_KD);  // a colour: clamp(0, inf)
+            const bool s2 = part.side == 2u;
+            side[0] = s2 ? clamp0(1.0f - am.v[0]) : am.v[0]; side[1] = s2 ? clamp0(1.0f - am.v[1]) : am.v[1]; side[2] = s2 ? clamp0(1.0f - am.v[2]) : am.v[2];
+        }
+        build_part(part.kind, p, part.remap != 0u, allow_multiple_lobes, part.side ? side : nullptr, part.second != 0u, out);
     }
     return out;
 }

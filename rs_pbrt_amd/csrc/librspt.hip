@@ -130,6 +130,7 @@ struct Rccl {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
     int32_t* status = nullptr;      // device word of the status agreement
+    int32_t* status_host = nullptr; // its pinned host twin
     bool status_exchanged = false;  // this rspt_render call has taken part in the agreement
 };
 Rccl rc_;
@@ -161,13 +162,20 @@ int rccl_bind() {
     } while (0)
 
 // The status agreement in front of the film reduce: every rank contributes 0 (ready to reduce) or 1 (failed); returns the maximum.
+// The device word and its pinned host twin are allocated by rspt_comm_init, so that a rank that reports a failure allocates nothing on the
+// way.  What the agreement covers: every failure that leaves the device usable (argument validation, UNSUPPORTED, out of memory).  After a
+// sticky HIP error (a kernel fault) the copies below fail too and this rank cannot enter the collective: its peers are then released by the
+// communicator's own time-out / abort, not by this word.
 int film_reduce_agree(int32_t mine, int32_t* all) {
     if (!rc_.status) HIP_TRY(hipMalloc((void**)&rc_.status, sizeof(int32_t)));
-    HIP_TRY(hipMemcpyAsync(rc_.status, &mine, sizeof mine, hipMemcpyHostToDevice, g.stream));
+    if (!rc_.status_host) HIP_TRY(hipHostMalloc((void**)&rc_.status_host, sizeof(int32_t), hipHostMallocDefault));
+    *rc_.status_host = mine;
+    HIP_TRY(hipMemcpyAsync(rc_.status, rc_.status_host, sizeof mine, hipMemcpyHostToDevice, g.stream));
     rc_.status_exchanged = true;
     RCCL_TRY(rc_.AllReduce(rc_.status, rc_.status, 1, ncclInt32, ncclMax, rc_.comm, g.stream));
-    HIP_TRY(hipMemcpyAsync(all, rc_.status, sizeof *all, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(rc_.status_host, rc_.status, sizeof *all, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    *all = *rc_.status_host;
     return RSPT_OK;
 }
 
@@ -870,9 +878,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     g.vol.hit_inst_tr = (volpath && s->has_instances) ? g.hit_inst + g.cap : nullptr;
     if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
         (s->has_textures && (rc = ensure_tex_rows(s->has_dynamic)))) return rc;
-    if (s->has_dynamic) {
-        if ((rc = ensure_dyn_built(grid_for(8) * 256u))) return rc;
-    }
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
 
@@ -895,6 +900,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
     const uint32_t sgrid = grid_for((uint32_t)env_size("RSPT_SHADE_BLOCKS_PER_CU", (size_t)shade_blocks));
     if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shade stage: %d blocks of 256 per CU\n", shade_blocks);
+    // dynamic materials: one Built record per thread of the widest shade-stage launch (k_shade's grid; k_vol_shade runs grid_for(4))
+    if (s->has_dynamic && (rc = ensure_dyn_built(std::max(sgrid, grid_for(8)) * 256u))) return rc;
     size_t n_ev = 0;
     const bool two_streams = env_size("RSPT_TRACE_STREAMS", 2) >= 2 && !counters;
     hipEvent_t ev_fork = get_event(n_ev++), ev_join = get_event(n_ev++);
@@ -1557,6 +1564,8 @@ int rspt_comm_init(int32_t rank, int32_t world, const uint8_t id[RSPT_COMM_ID_BY
     memcpy(&u, id, sizeof u);
     RCCL_TRY(rc_.CommInitRank(&rc_.comm, world, u, rank));
     rc_.rank = rank; rc_.world = world;
+    if (!rc_.status) HIP_TRY(hipMalloc((void**)&rc_.status, sizeof(int32_t)));   // the status agreement's words (film_reduce_agree)
+    if (!rc_.status_host) HIP_TRY(hipHostMalloc((void**)&rc_.status_host, sizeof(int32_t), hipHostMallocDefault));
     return RSPT_OK;
 }
 int rspt_comm_destroy(void) {
@@ -2138,7 +2147,7 @@ namespace {
 // ranks return RSPT_E_PEER instead of waiting for it; its own error code and message are kept.
 int render_entry(rspt_scene_t s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     rc_.status_exchanged = false;
-    const int rc = render_impl(s, d, film_host, film_dev, li_host, stats);
+    const int rc = (!film_host && !film_dev && !li_host) ? fail(RSPT_E_INVALID, "null output buffer") : render_impl(s, d, film_host, film_dev, li_host, stats);
     if (rc != RSPT_OK && d && d->film_reduce && rc_.comm && g.inited && !rc_.status_exchanged) {
         const std::string kept = rspt_last_error();
         int32_t all = 0;
@@ -2150,15 +2159,12 @@ int render_entry(rspt_scene_t s, const rspt_render_desc* d, float* film_host, vo
 }  // namespace
 
 int rspt_render(rspt_scene_t s, const rspt_render_desc* d, float* film_xyzw, rspt_stats* stats) {
-    if (!film_xyzw) return fail(RSPT_E_INVALID, "null film");
     return render_entry(s, d, film_xyzw, nullptr, nullptr, stats);
 }
 int rspt_render_device(rspt_scene_t s, const rspt_render_desc* d, void* film_dev, rspt_stats* stats) {
-    if (!film_dev) return fail(RSPT_E_INVALID, "null film");
     return render_entry(s, d, nullptr, film_dev, nullptr, stats);
 }
 int rspt_render_samples(rspt_scene_t s, const rspt_render_desc* d, float* li_rgb, rspt_stats* stats) {
-    if (!li_rgb) return fail(RSPT_E_INVALID, "null li_rgb");
     return render_entry(s, d, nullptr, nullptr, li_rgb, stats);
 }
 

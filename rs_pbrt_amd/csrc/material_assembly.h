@@ -13,6 +13,7 @@
 // Plain C++ where the host uses it (rspt_material_lobes runs without a device: tests/test_materials.py compares every recipe with the
 // oracle's line-by-line restatement of the reference); build_part is also compiled for the device.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -271,11 +272,17 @@ struct DynParam {         // a parameter of a dynamic material: a constant, or t
     uint32_t row;         // 0: constant v; else 1 + row
     float v[3];
 };
-struct DynPart { uint32_t kind, remap; DynParam p[P_COUNT]; };
+#define RSPT_MIX_PARTS 8  // non-mix materials one (possibly nested) mix may bring together: Bsdf.bxdfs holds 8 lobes (reflection.rs:243-248)
+struct DynPart {          // one non-mix material of the (flattened) tree, in the order its lobes arrive on the surviving Bsdf
+    uint32_t kind, remap;
+    uint32_t side;        // 0: no scale (the material is not under a mix); 1: its parent mix's s1 = clamp(amount); 2: s2 = clamp(1 - s1)
+    uint32_t second;      // reached through some m2 edge: built on a SurfaceInteraction::new without differentials (mixmat.rs:58-69)
+    DynParam amount;      // the PARENT mix's MixMaterial.scale (the only scale a material sees: a mix ignores the one it is handed, mixmat.rs:50)
+    DynParam p[P_COUNT];
+};
 struct DynMaterial {      // one per material (valid where the material is flagged RSPT_MAT_DYNAMIC)
-    uint32_t n_parts;     // 1, or 2 for a mix
-    DynParam amount;      // mix: MixMaterial.scale
-    DynPart part[2];
+    uint32_t n_parts;
+    DynPart part[RSPT_MIX_PARTS];
     uint32_t n_rows;
     uint32_t row_tex[RSPT_DYN_ROWS];  // texture index | RSPT_SLOT_NODIFF of every row
 };
@@ -305,25 +312,19 @@ public:
         out->dynamic = false;
         memset(&out->dyn, 0, sizeof out->dyn);
         if (!d_ || index >= d_->n_materials || !d_->materials) return fail(RSPT_E_INVALID, index, "material index out of range");
-        const rspt_material_desc& m = d_->materials[index];
-        const rspt_material_desc* parts[2] = {&m, nullptr};
-        uint32_t part_index[2] = {index, 0};
-        Param amount = Param{0u, 0u, {0, 0, 0}};
-        if (m.kind == RSPT_MAT_MIX) {  // m1 scaled by `amount`, m2 by 1 - amount, lobes concatenated on m1's Bsdf (mixmat.rs:43-305)
-            if (m.m1 >= d_->n_materials || m.m2 >= d_->n_materials) return fail(RSPT_E_INVALID, index, "mix: material index out of range");
-            parts[0] = &d_->materials[m.m1]; parts[1] = &d_->materials[m.m2];
-            part_index[0] = m.m1; part_index[1] = m.m2;
-            if (parts[0]->kind == RSPT_MAT_MIX || parts[1]->kind == RSPT_MAT_MIX)
-                return fail(RSPT_E_UNSUPPORTED, index, "mix of a mix (MixMaterial ignores the scale it is handed, mixmat.rs:50)");
-            amount = bind(index, m.amount, "amount", PM_COLOUR, false);
-            if (err_) return err_;
-        }
-        const int n_parts = parts[1] ? 2 : 1;
-        Param p[2][P_COUNT];
+        // MixMaterial (mixmat.rs:43-305): m1 builds the Bsdf of `si` under Some(s1), m2 builds one on a SurfaceInteraction::new (no ray
+        // differentials) under Some(s2), and m2's BxDFs are re-created on m1's Bsdf in order.  A mix that is itself handed a scale ignores it
+        // (`_scale`, :50) and hands its OWN s1 / s2 down — so a tree of mixes flattens into its non-mix leaves, left to right, each scaled by
+        // its immediate parent's amount only; the surviving Bsdf (eta, bump-mapped shading frame) is the leftmost leaf's.
+        std::vector<Leaf> leaves;
+        flatten(index, 0, Param{0u, 0u, {0, 0, 0}}, false, false, 0, &leaves);
+        if (err_) return err_;
+        const int n_parts = (int)leaves.size();
+        Param p[RSPT_MIX_PARTS][P_COUNT];
         for (int k = 0; k < n_parts; k++) {
-            const rspt_material_desc& q = *parts[k];
+            const rspt_material_desc& q = *leaves[k].m;
             if (q.kind < RSPT_MAT_MATTE || q.kind > RSPT_MAT_TRANSLUCENT)
-                return fail(RSPT_E_UNSUPPORTED, part_index[k], "material kind " + std::to_string(q.kind) + " (matte, plastic, mirror, glass, metal, substrate, uber, translucent, mix)");
+                return fail(RSPT_E_UNSUPPORTED, leaves[k].index, "material kind " + std::to_string(q.kind) + " (matte, plastic, mirror, glass, metal, substrate, uber, translucent, mix)");
             const uint32_t refs[P_COUNT] = {q.kd, q.ks, q.kr, q.kt, q.reflect, q.transmit, q.opacity, q.eta, q.k, q.sigma, q.roughness, q.uroughness, q.vroughness, q.index};
             static const char* const names[P_COUNT] = {"Kd", "Ks", "Kr", "Kt", "reflect", "transmit", "opacity", "eta", "k", "sigma", "roughness", "uroughness", "vroughness", "index"};
             const uint32_t used = params_of(q.kind), optional = (1u << P_UROUGH) | (1u << P_VROUGH);
@@ -331,28 +332,38 @@ public:
                 p[k][i] = Param{0u, 0u, {0, 0, 0}};
                 if (!((used >> i) & 1u)) continue;
                 const bool opt = ((optional >> i) & 1u) && (q.kind == RSPT_MAT_METAL || q.kind == RSPT_MAT_UBER);
-                p[k][i] = bind(part_index[k], refs[i], names[i], param_mode(i), opt);
+                p[k][i] = bind(leaves[k].index, refs[i], names[i], param_mode(i), opt);
             }
-            if (q.bumpmap > d_->n_textures) return fail(RSPT_E_INVALID, part_index[k], "parameter \"bumpmap\": texture index out of range");
+            if (q.bumpmap > d_->n_textures) return fail(RSPT_E_INVALID, leaves[k].index, "parameter \"bumpmap\": texture index out of range");
             if (err_) return err_;
         }
         // static attempt: everything that shapes the list constant
         Built bl;
         memset(&bl, 0, sizeof bl);
         bl.eta = 1.0f;
-        float s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
-        for (int c = 0; c < 3; c++) { s1[c] = amount.v[c]; s2[c] = clamp0(1.0f - s1[c]); }
-        build_part(parts[0]->kind, p[0], parts[0]->remap_roughness != 0, multi_, n_parts == 2 ? s1 : nullptr, false, &bl);
-        if (n_parts == 2) build_part(parts[1]->kind, p[1], parts[1]->remap_roughness != 0, multi_, s2, true, &bl);
-        out->mat.bump_tex = parts[0]->bumpmap;  // m1's (also a ConstantTexture displaces: displace * shading.dndu, material.rs:150-170); m2 bumps a copy of the interaction that is dropped
-        if (!bl.shape_varies && !(n_parts == 2 && amount.tex)) {
+        bool amount_varies = false;
+        for (int k = 0; k < n_parts; k++) {
+            float sc[3] = {0, 0, 0};
+            for (int c = 0; c < 3; c++) sc[c] = leaves[k].side == 2 ? clamp0(1.0f - leaves[k].amount.v[c]) : leaves[k].amount.v[c];
+            if (leaves[k].side && leaves[k].amount.tex) amount_varies = true;
+            build_part(leaves[k].m->kind, p[k], leaves[k].m->remap_roughness != 0, multi_, leaves[k].side ? sc : nullptr, leaves[k].second, &bl);
+        }
+        out->mat.bump_tex = leaves[0].m->bumpmap;  // the leftmost leaf's (also a ConstantTexture displaces: displace * shading.dndu, material.rs:150-170); every m2 bumps a copy of the interaction that is dropped
+        if (!bl.shape_varies && !amount_varies) {
             if (bl.overflow) return fail(RSPT_E_UNSUPPORTED, index, "more than 8 BxDFs (Bsdf::add asserts, reflection.rs:247)");
             out->mat.eta = bl.eta;
             out->lobes.assign(bl.l, bl.l + bl.n);
             out->mat.n_bxdfs = bl.n;
             return err_;
         }
-        // dynamic: every varying parameter gets a row of the path's texture rows; build_part runs per hit on the device
+        // dynamic: every varying parameter gets a row of the path's texture rows; build_part runs per hit on the device.  Its Built record
+        // holds 8 lobes like Bsdf.bxdfs (reflection.rs:243-248: Bsdf::add asserts on the ninth), and nothing on the device could report a
+        // ninth push — so the list is bounded here from what can be non-black at SOME hit, and a material that could pass 8 is refused
+        // like its static counterpart above
+        uint32_t worst = 0;
+        for (int k = 0; k < n_parts; k++) worst += max_lobes(leaves[k].m->kind, p[k], multi_);
+        if (worst > 8u)
+            return fail(RSPT_E_UNSUPPORTED, index, "up to " + std::to_string(worst) + " BxDFs where the varying parameters are all non-black (Bsdf::add asserts past 8, reflection.rs:247)");
         out->dynamic = true;
         DynMaterial& dm = out->dyn;
         dm.n_parts = (uint32_t)n_parts;
@@ -369,10 +380,11 @@ public:
             r.v[0] = q.v[0]; r.v[1] = q.v[1]; r.v[2] = q.v[2];
             return r;
         };
-        dm.amount = dyn_param(amount, false);
         for (int k = 0; k < n_parts; k++) {
-            dm.part[k].kind = parts[k]->kind; dm.part[k].remap = parts[k]->remap_roughness != 0;
-            for (uint32_t i = 0; i < P_COUNT; i++) dm.part[k].p[i] = dyn_param(p[k][i], k == 1);
+            dm.part[k].kind = leaves[k].m->kind; dm.part[k].remap = leaves[k].m->remap_roughness != 0;
+            dm.part[k].side = (uint32_t)leaves[k].side; dm.part[k].second = leaves[k].second ? 1u : 0u;
+            dm.part[k].amount = dyn_param(leaves[k].amount, leaves[k].amount_second);   // evaluated on the interaction the parent mix was handed
+            for (uint32_t i = 0; i < P_COUNT; i++) dm.part[k].p[i] = dyn_param(p[k][i], leaves[k].second);
         }
         return err_;
     }
@@ -382,9 +394,62 @@ private:
     bool multi_;
     Error err_;
 
+    // a non-mix material of the flattened tree (see assemble)
+    struct Leaf {
+        const rspt_material_desc* m;
+        uint32_t index;
+        int side;             // 0: not under a mix; 1 / 2: the m1 / m2 side of its parent
+        bool second;          // some m2 edge on the way down: no ray differentials
+        Param amount;         // the parent's MixMaterial.scale ...
+        bool amount_second;   // ... evaluated on the interaction the PARENT was handed
+    };
+    void flatten(uint32_t index, int side, const Param& amount, bool amount_second, bool second, int depth, std::vector<Leaf>* out) {
+        if (err_) return;
+        if (!d_ || index >= d_->n_materials || !d_->materials) { fail(RSPT_E_INVALID, index, "material index out of range"); return; }
+        const rspt_material_desc& m = d_->materials[index];
+        if (m.kind != RSPT_MAT_MIX) {
+            if (out->size() == RSPT_MIX_PARTS) { fail(RSPT_E_UNSUPPORTED, index, "a tree of mixes with more than " + std::to_string(RSPT_MIX_PARTS) + " non-mix materials"); return; }
+            out->push_back(Leaf{&m, index, side, second, amount, amount_second});
+            return;
+        }
+        if (depth >= RSPT_MIX_PARTS) { fail(RSPT_E_INVALID, index, "mixes nested deeper than " + std::to_string(RSPT_MIX_PARTS) + " (a mix that contains itself?)"); return; }
+        if (m.m1 >= d_->n_materials || m.m2 >= d_->n_materials) { fail(RSPT_E_INVALID, index, "mix: material index out of range"); return; }
+        const Param a = bind(index, m.amount, "amount", PM_COLOUR, false);
+        if (err_) return;
+        flatten(m.m1, 1, a, second, second, depth + 1, out);
+        flatten(m.m2, 2, a, second, true, depth + 1, out);
+    }
+
     Error fail(int code, uint32_t index, const std::string& what) {
         if (!err_) { err_.code = code; err_.text = "material " + std::to_string(index) + ": " + what; }
         return err_;
+    }
+    // upper bound of the lobes build_part can push for one part at any hit: a factor counts as possibly non-black when it is a texture
+    // or a non-black constant (the guards of build_part, evaluated on what is known at scene creation)
+    static uint32_t max_lobes(uint32_t kind, const Param* p, bool multi) {
+        auto may = [](const Param& q) { return q.tex != 0u || !black(q.v); };
+        auto may_be_nonzero = [](const Param& q) { return q.tex != 0u || q.v[0] != 0.0f; };
+        switch (kind) {
+        case RSPT_MAT_MATTE: return may(p[P_KD]) ? 1u : 0u;
+        case RSPT_MAT_PLASTIC: return (may(p[P_KD]) ? 1u : 0u) + (may(p[P_KS]) ? 1u : 0u);
+        case RSPT_MAT_MIRROR: case RSPT_MAT_METAL: return 1u;
+        case RSPT_MAT_GLASS:
+            if (multi && !may_be_nonzero(p[P_UROUGH]) && !may_be_nonzero(p[P_VROUGH])) return 1u;
+            return std::max(multi ? 1u : 0u, (may(p[P_KR]) ? 1u : 0u) + (may(p[P_KT]) ? 1u : 0u));
+        case RSPT_MAT_SUBSTRATE: return (may(p[P_KD]) || may(p[P_KS])) ? 1u : 0u;
+        case RSPT_MAT_UBER: {
+            const Param& op = p[P_OPACITY];
+            float through[3] = {clamp0(1.0f - op.v[0]), clamp0(1.0f - op.v[1]), clamp0(1.0f - op.v[2])};
+            const uint32_t pass = (op.tex != 0u || !black(through)) ? 1u : 0u;
+            if (!may(op)) return pass;
+            return pass + (may(p[P_KD]) ? 1u : 0u) + (may(p[P_KS]) ? 1u : 0u) + (may(p[P_KR]) ? 1u : 0u) + (may(p[P_KT]) ? 1u : 0u);
+        }
+        case RSPT_MAT_TRANSLUCENT: {
+            const uint32_t sides = (may(p[P_REFLECT]) ? 1u : 0u) + (may(p[P_TRANSMIT]) ? 1u : 0u);
+            return sides * ((may(p[P_KD]) ? 1u : 0u) + (may(p[P_KS]) ? 1u : 0u));
+        }
+        }
+        return 0u;
     }
     // which parameters a material kind reads
     static uint32_t params_of(uint32_t kind) {

@@ -172,6 +172,7 @@ class Checkpoint:
         import hashlib
         rd = abi.RenderDesc.from_buffer_copy(self.rd)
         rd.sample_begin = rd.sample_count = 0
+        rd.film_reduce = 0; rd.allow_slow_paths = 0   # options of HOW the frame is rendered, not of which frame: a resumed run may differ in them
         rd.n_light_samples = None; rd.maxmin_c_pixel = None
         rd.tables = abi.SamplerTables()
         h = hashlib.sha256(bytes(memoryview(rd).cast("B")))
@@ -195,6 +196,6 @@ class Checkpoint:
 
     def load(self, path, scene_id=""):
         z = np.load(self._path(path))
-        if str(z["identity"]) != self._identity(scene_id) or z["sum"].shape != self.sum.shape:
+        if "identity" not in z.files or str(z["identity"]) != self._identity(scene_id) or z["sum"].shape != self.sum.shape:   # (no identity: a file of the first checkpoint format)
             raise ValueError("checkpoint belongs to another render (scene / integrator / sampler / camera / film / shard differ)")
         self.sum, self.next_sample = z["sum"].astype(np.float64), int(z["next_sample"])

@@ -1,4 +1,4 @@
-//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 18) one to one.
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 19) one to one.
 //! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
 //! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
 #![allow(dead_code)]

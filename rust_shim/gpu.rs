@@ -9,9 +9,10 @@
 //! pyramid and Distribution2D image are handed over), homogeneous media, PerspectiveCamera, the Sobol', Halton and the four
 //! PCG-backed pixel samplers, the path / ao / directlighting / volpath integrators, any filter (through Film.filter_table).
 //! Image / procedural textures (every class of src/textures/, through Texture::describe of rs_pbrt.patch) go over as texture
-//! graphs wherever a material or mesh refers to one; which parameters may vary over a surface is the library's decision
-//! (include/rspt.h: Kd / Ks / roughness, bump maps, alpha masks; anything else comes back as RSPT_E_UNSUPPORTED from
-//! rspt_scene_create) and the scene then keeps the CPU loop.
+//! graphs wherever a material or mesh refers to one; any parameter may vary over a surface (include/rspt.h: Kd / Ks / roughness
+//! scale the lobes of a list folded once per material, any other varying parameter has the library build the lobe list per hit;
+//! mixes may nest).  What the library refuses (more than 8 non-mix materials under one mix, more than 12 varying textures on such a
+//! material, more than 8 BxDFs) comes back as RSPT_E_UNSUPPORTED from rspt_scene_create and the scene then keeps the CPU loop.
 pub mod ffi;
 pub mod refdump;
 

@@ -577,6 +577,28 @@ def test_dynamic_materials_under_every_integrator_and_sampler(gpu, oracle, kw):
         assert st["nan_samples"] == 0 and np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-6
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(sampler="halton"), dict(integrator="volpath"), dict(integrator="directlighting"), dict(sampler="02sequence")])
+def test_mixes_of_mixes(gpu, oracle, kw):
+    """MixMaterial inside MixMaterial (mixmat.rs:43-76): the library flattens the tree into its non-mix materials, each under its immediate
+    parent's scale only (a mix ignores the `_scale` it is handed, :50); the oracle recurses through compute_scattering_functions as the
+    reference does.  Static trees (constant amounts) and dynamic ones (image / checker amounts, also behind an m2 edge), every integrator
+    form: per-sample radiance bit for bit."""
+    from tests.util import DYNAMIC_LOOK_AT, nested_mix_gallery
+    sc = nested_mix_gallery(gpu.bvh_build)
+    from rs_pbrt_amd import lib as _lib
+    dyn = [_lib.material_lobes(sc, i)[2] is None for i in range(len(sc.materials))]
+    assert sum(dyn) >= 2 and not all(dyn)
+    ls = [1] * sc.desc.n_lights
+    rd = scenes.make_render_desc(64, 28, 8, DYNAMIC_LOOK_AT, 75.0, max_depth=5, light_samples=ls, **kw)
+    if kw.get("integrator") == "directlighting":
+        from tests.test_gpu_directlighting import check
+        check(gpu, oracle, sc, rd, "all", ls)
+    else:
+        film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
+        assert st["nan_samples"] == 0 and np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-6
+        assert scenes.film_to_rgb(film).reshape(28, 64, 3)[8:22].std() > 0.02   # the slabs are in view and differ
+
+
 def test_film_reduce_runs_inside_the_library(gpu):
     """X1 in the product: rspt_comm_unique_id / rspt_comm_init create the RCCL communicator, film_reduce = 1 makes
     rspt_render end with ncclReduce(sum) onto rank 0.  One GPU here, so the world has one rank (the sum of one film is that film,

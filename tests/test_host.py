@@ -123,3 +123,24 @@ def test_moving_camera_keys_decompose_like_the_oracle(oracle):
         assert np.isfinite(r).all() and abs(float((r[0] * r[1]).sum())) <= 1.0 + 1e-5 and float((r[0] * r[1]).sum()) >= 0.0   # the shorter arc
     same = scenes.make_render_desc(32, 32, 1, la0, 40.0, look_at_end=la0)
     assert lib.camera_decompose(same) is None
+
+
+def test_checkpoint_identity_covers_the_frame_not_the_way_it_is_rendered(tmp_path):
+    """a checkpoint of the first file format (no identity) is "another render" (ValueError, not KeyError); film_reduce and
+    allow_slow_paths do not define the frame, spp does"""
+    import pytest
+    a = integrator.Checkpoint(integrator.PathIntegrator(camera=scenes.cornell_render_desc(res=16, spp=8)))
+    a.sum += 1.0
+    a.next_sample = 3
+    a.save(tmp_path / "c.npz", scene_id="cornell")
+    b = integrator.Checkpoint(integrator.PathIntegrator(camera=scenes.cornell_render_desc(res=16, spp=8)))
+    b.rd.film_reduce = 1
+    b.rd.allow_slow_paths = 1
+    b.load(tmp_path / "c.npz", scene_id="cornell")
+    assert b.next_sample == 3 and np.array_equal(b.sum, a.sum)
+    for other, sid in ((integrator.Checkpoint(integrator.PathIntegrator(camera=scenes.cornell_render_desc(res=16, spp=16))), "cornell"), (b, "another scene")):
+        with pytest.raises(ValueError):
+            other.load(tmp_path / "c.npz", scene_id=sid)
+    np.savez(tmp_path / "old.npz", sum=a.sum, next_sample=3)   # the first format: sum / next_sample only
+    with pytest.raises(ValueError):
+        b.load(tmp_path / "old.npz", scene_id="cornell")

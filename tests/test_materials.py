@@ -103,6 +103,34 @@ def test_mix_concatenates_scaled_children_and_keeps_the_first_bsdf(oracle):
                 assert lib.material_lobes(sc, mi, multi)[0] == lib.material_lobes(sc, mi - 2, multi)[0]   # Bsdf.eta is m1's
 
 
+def test_a_mix_of_mixes_keeps_only_the_innermost_scale(oracle):
+    """mixmat.rs:50: MixMaterial::compute_scattering_functions names its scale argument `_scale` and never reads it — a mix inside a mix
+    is not scaled by the outer amount; its own s1 / s2 go to its children.  The library flattens the tree (material_assembly.h), the oracle
+    recurses as the reference does (orc_material.hpp mix_csf): same lobes, same order, same scales, NODIFF on everything behind an m2 edge,
+    Bsdf.eta of the leftmost leaf."""
+    A, B, C, D = scenes.glass(index=1.33), scenes.plastic(RED, GREY, 0.2), scenes.matte(GREY, 20.0), scenes.mirror()
+    a_in, a_out, a_3 = (0.25, 0.5, 1.5), (0.6, 0.1, 0.9), (0.0, 1.0, 0.3)
+    for multi in (True, False):
+        # ((A, B), C): A under the inner s1 (with differentials), B under the inner s2, C under the OUTER s2
+        lobes = _same(oracle, scenes.mix(scenes.mix(A, B, a_in), C, a_out), multi)
+        na = 1 if multi else 2
+        s_in, s_out = np.maximum(np.array(a_in, F32), 0), np.maximum(np.array(a_out, F32), 0)
+        assert len(lobes) == na + 2 + 1
+        for l in lobes[:na]:
+            assert np.array_equal(l["sc"], s_in) and not int(l["remap"]) & abi.LOBE_NODIFF
+        for l in lobes[na:na + 2]:
+            assert np.array_equal(l["sc"], np.maximum(F32(1) - s_in, 0)) and int(l["remap"]) & abi.LOBE_NODIFF
+        assert np.array_equal(lobes[-1]["sc"], np.maximum(F32(1) - s_out, 0)) and int(lobes[-1]["remap"]) & abi.LOBE_NODIFF
+        sc, mi = scenes.material_scene(scenes.mix(scenes.mix(A, B, a_in), C, a_out))
+        assert lib.material_lobes(sc, mi, multi)[0] == F32(1.33)   # the leftmost leaf's Bsdf survives
+        # (C, (B, D)): everything under the inner mix sits behind the outer m2 edge; the outer s2 reaches nobody
+        lobes = _same(oracle, scenes.mix(C, scenes.mix(B, D, a_in), a_out), multi)
+        assert len(lobes) == 4 and np.array_equal(lobes[0]["sc"], s_out) and not int(lobes[0]["remap"]) & abi.LOBE_NODIFF
+        assert all(int(l["remap"]) & abi.LOBE_NODIFF for l in lobes[1:]) and np.array_equal(lobes[1]["sc"], s_in) and np.array_equal(lobes[3]["sc"], np.maximum(F32(1) - s_in, 0))
+        # three levels, mixes on both sides
+        _same(oracle, scenes.mix(scenes.mix(scenes.mix(D, C, a_3), B, a_in), scenes.mix(C, D, a_out), a_3), multi)
+
+
 def test_known_answers_of_the_recipes(oracle):
     """first principles, independent of both implementations"""
     _, _, l = lib.material_lobes(*scenes.material_scene(scenes.matte(GREY, 20.0)))
@@ -173,8 +201,19 @@ def test_textured_parameters_are_deferred_or_dynamic(oracle):
         sb2.textures, sb2.images = list(sb.textures), list(sb.images)
         i = sb2.add_material(dyn)
         assert lib.material_lobes(sb2.materials_only(), i)[2] is None
+    # what stays refused: a dynamic material that could push a ninth BxDF at some hit (Bsdf::add asserts, reflection.rs:247) and a tree of
+    # mixes with more than 8 non-mix materials
     sb2 = scenes.SceneBuilder()
-    i = sb2.add_material(scenes.mix(scenes.matte(GREY), scenes.mix(scenes.matte(RED), scenes.mirror())))
-    with pytest.raises(lib.RsptError) as e:   # a mix of a mix: the reference drops the outer scale (mixmat.rs:50)
+    sb2.textures, sb2.images = list(sb.textures), list(sb.images)
+    i = sb2.add_material(scenes.mix(scenes.uber(kr=GREY, kt=GREY, opacity=img), scenes.uber(kr=GREY, kt=GREY, opacity=(0.5,) * 3), img))
+    with pytest.raises(lib.RsptError) as e:
+        lib.material_lobes(sb2.materials_only(), i)
+    assert e.value.code == abi.E_UNSUPPORTED and "BxDFs" in str(e.value)
+    sb2 = scenes.SceneBuilder()
+    deep = scenes.matte(GREY)
+    for _ in range(8):
+        deep = scenes.mix(deep, scenes.matte(RED))
+    i = sb2.add_material(deep)
+    with pytest.raises(lib.RsptError) as e:
         lib.material_lobes(sb2.materials_only(), i)
     assert e.value.code == abi.E_UNSUPPORTED

@@ -103,6 +103,36 @@ def dynamic_gallery(builder):
 DYNAMIC_LOOK_AT = ((0, 2.6, -4.9), (0, 1.9, 2), (0, 1, 0))
 
 
+def nested_mix_gallery(builder):
+    """The gallery room with slabs of MixMaterials that contain MixMaterials (mixmat.rs:43-76: a mix ignores the scale it is handed and
+    hands its own s1 / s2 down): constant amounts (the tree folds into one static lobe list), an image amount on an inner mix that sits
+    behind an outer m2 edge (evaluated without ray differentials), textured leaves on both sides, three levels."""
+    sb = scenes.SceneBuilder()
+    img = texture_image()
+    wall = sb.add_material(scenes.matte((0.6, 0.6, 0.6)))
+    rgb_t = sb.image_texture(img, su=2.0, sv=2.0)
+    rgb_b = sb.image_texture((img * (img[..., :1] > 0.5)).astype(np.float32), su=1.0, sv=3.0, trilinear=True)
+    chk = sb.checkerboard_texture(sb.constant_texture((1.0, 0.2, 0.6)), sb.constant_texture((0.0, 0.9, 0.3)), su=5, sv=4)
+    glass, plastic, matte, mirror = scenes.glass(index=1.33), scenes.plastic((0.2, 0.5, 0.3), (0.4, 0.4, 0.4), 0.1), scenes.matte((0.5, 0.3, 0.2), 20.0), scenes.mirror((0.8, 0.8, 0.9))
+    mats = [sb.add_material(scenes.mix(scenes.mix(glass, plastic, (0.25, 0.5, 1.5)), matte, (0.6, 0.1, 0.9))),
+            sb.add_material(scenes.mix(matte, scenes.mix(plastic, mirror, (0.3, 0.3, 0.3)), (0.7, 0.7, 0.2))),
+            sb.add_material(scenes.mix(scenes.matte(rgb_t), scenes.mix(scenes.plastic(rgb_t, (0.3, 0.3, 0.3), 0.2), mirror, rgb_b), chk)),
+            sb.add_material(scenes.mix(scenes.mix(scenes.mix(mirror, scenes.matte(rgb_b), chk), plastic, (0.5, 0.4, 0.3)), scenes.mix(matte, glass, rgb_t), (0.4, 0.5, 0.6)))]
+    q = sb.add_quad
+    uv = np.array([(0, 0), (1, 0), (1, 1), (0, 1)], np.float32)
+    q([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], wall)
+    q([(-5, 6, -5), (5, 6, -5), (5, 6, 5), (-5, 6, 5)], wall)
+    q([(-5, 0, 5), (-5, 6, 5), (5, 6, 5), (5, 0, 5)], wall)
+    q([(-5, 0, -5), (-5, 6, -5), (-5, 6, 5), (-5, 0, 5)], wall)
+    q([(5, 0, -5), (5, 0, 5), (5, 6, 5), (5, 6, -5)], wall)
+    for i, m in enumerate(mats):
+        x = -4.2 + 2.2 * i
+        q([(x, 0.5, 1 + 0.2 * i), (x + 1.8, 0.5, 1 + 0.2 * i), (x + 1.8, 3.2, 2 + 0.2 * i), (x, 3.2, 2 + 0.2 * i)], m, UV=uv)
+    q([(-1.5, 5.9, -1), (1.5, 5.9, -1), (1.5, 5.9, 1), (-1.5, 5.9, 1)], wall, emit=(7, 7, 6))
+    sb.add_point_light((3, 4, -3), (50, 40, 30))
+    return sb.finish(builder)
+
+
 def sky_scene(builder, kind="constant", with_area=False):
     """ground + a few blocks (matte / plastic / mirror) under an InfiniteAreaLight: a constant sky or an
     8x4 lat-long map with a bright patch, rotated about x"""
