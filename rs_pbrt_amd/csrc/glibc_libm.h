@@ -7,6 +7,14 @@
 // The file is compiled twice: by hipcc into every kernel (included from dev_math.h; no contraction, correctly rounded / and sqrt), and by
 // gcc into tools/libm_exhaustive.c, which compares every function with the host's libm over all 2^32 floats (2^30 pairs for atan2f):
 // 0 mismatches (tests/test_host.py).  tests/test_gpu_trace.py then compares the device's results with the GPU box's libm.
+// Third-party algorithms restated here (not the reference's code), with their upstream licences:
+//   * sinf / cosf / logf / log2f / expf follow glibc 2.35 sysdeps/ieee754/flt-32/{s_sincosf.h, s_sincosf_data.c, e_logf.c, e_log2f.c, e_expf.c},
+//     which glibc took from ARM's Optimized Routines — Copyright (c) Arm Limited, MIT OR Apache-2.0 WITH LLVM-exception upstream; distributed by
+//     glibc under the GNU Lesser General Public License v2.1 or later (Copyright (C) Free Software Foundation, Inc.).  The polynomial
+//     coefficients below are those routines'; the lookup tables are NOT copied: they are read at run time from the installed libm.so.6.
+//   * acosf / atanf / atan2f follow fdlibm's e_acosf.c / s_atanf.c / e_atan2f.c as shipped in glibc — Copyright (C) 1993 by Sun Microsystems,
+//     Inc. All rights reserved.  Developed at SunPro, a Sun Microsystems, Inc. business.  Permission to use, copy, modify, and distribute this
+//     software is freely granted, provided that this notice is preserved.
 // The includer defines GL_FN / GL_FN_COLD (function qualifiers: sinf and cosf sit on the shading path and are inlined, the others are called),
 // GL_TABLE (table qualifiers) and the bit casts GL_F2U / GL_U2F / GL_D2U / GL_U2D.
 #pragma once

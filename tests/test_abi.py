@@ -117,3 +117,19 @@ def test_bvh_build_argument_errors():
     nodes = np.zeros(0, abi.NODE_DT); order = np.zeros(1, np.uint32)
     assert L.rspt_bvh_build(P.ctypes.data, tri.ctypes.data, 1, 4, nodes.ctypes.data if nodes.size else order.ctypes.data, 0, order.ctypes.data, 1) == abi.E_INVALID
     assert b"nodes_cap" in L.rspt_bvh_last_error()
+
+
+def test_rust_shim_layouts_match_the_header_without_a_rust_compiler():
+    """rust_shim/ffi.rs is never compiled here (no cargo / rustc in the image): its #[repr(C)] structs are laid out by the repr(C) rules in
+    tools/ffi_layout.py and compared with gcc's sizeof / offsetof of include/rspt.h, field by field in declaration order; its ABI constant
+    and every `pub fn` of its extern block must exist in the library."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ffi_layout
+    assert ffi_layout.compare() == []
+    src = open(os.path.join(ROOT, "rust_shim", "ffi.rs")).read()
+    assert int(re.search(r"RSPT_ABI_VERSION: c_int = (\d+);", src).group(1)) == abi.ABI_VERSION
+    assert "ABI version %d" % abi.ABI_VERSION in src.splitlines()[0]
+    fns = re.findall(r"pub fn (rspt_\w+)\(", src)
+    assert len(fns) >= 15 and all(f in lib.EXPORTS for f in fns), [f for f in fns if f not in lib.EXPORTS]

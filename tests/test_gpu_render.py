@@ -28,7 +28,8 @@ def _render_pair(gpu, oracle, sc, rd, want_li=True):
     finally:
         ds.close()
     ref = oracle.render(sc, rd, threads=8, want_li=want_li)
-    if want_li:   # every sample's radiance, bit for bit (glibc_libm.h): the looser per-test bars below are all met with zero difference
+    if want_li:   # THE bar of these tests: every sample's radiance, bit for bit (glibc_libm.h).  Films are compared after it by RMSE only because
+                  # a pixel's f32 sum over its samples is taken in another order (weights, being sums of equal terms, are compared bit for bit)
         assert np.array_equal(li, ref["li"]), "per-sample radiance differs from the oracle in %d of %d samples" % (int((li != ref["li"]).any(axis=2).sum()), li.shape[0] * li.shape[1])
     return film, li, st, ref
 
@@ -39,9 +40,6 @@ def test_cornell_matches_oracle(gpu, oracle, variant):
     rd = scenes.cornell_render_desc(res=64, spp=16)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    same = (li == ref["li"]).all(axis=2)
-    assert same.mean() > 0.75
-    assert np.abs(li - ref["li"]).mean() < 1e-6
     assert film_rmse(film, ref["film"]) < 1e-5
     assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
     assert st["samples"] == ref["counters"]["samples"] == 64 * 64 * 16
@@ -52,7 +50,6 @@ def test_soup_matches_oracle_depth8(gpu, oracle):
     rd = scenes.soup_render_desc(res=96, spp=8, max_depth=8)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    assert (li == ref["li"]).all(axis=2).mean() > 0.9
     assert film_rmse(film, ref["film"]) < 1e-5
 
 
@@ -71,7 +68,6 @@ def test_smooth_normals_plastic(gpu, oracle):
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert film_rmse(film, ref["film"]) < 1e-5
-    assert (li == ref["li"]).all(axis=2).mean() > 0.75
 
 
 def test_thin_lens_and_gaussian_filter(gpu, oracle):
@@ -83,7 +79,6 @@ def test_thin_lens_and_gaussian_filter(gpu, oracle):
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.allclose(film[:, 3], ref["film"][:, 3], rtol=1e-5)
     assert film_rmse(film, ref["film"]) < 1e-5
-    assert (li == ref["li"]).all(axis=2).mean() > 0.7
 
 
 def test_crop_window_and_non_square(gpu, oracle):
@@ -173,7 +168,7 @@ def test_golden_cornell_film(gpu):
         ds.close()
     assert np.array_equal(film[:, 3], g["film"][:, 3])
     assert film_rmse(film, g["film"]) < 1e-5
-    assert (li == g["li"]).all(axis=2).mean() > 0.75
+    assert np.array_equal(li, g["li"])   # the committed fixture (= today's oracle, tests/test_oracle_kat.py), every sample bit for bit
 
 
 @pytest.mark.parametrize("lights", ["all", "delta", "area"])
@@ -186,7 +181,6 @@ def test_gallery_remaining_materials_and_delta_lights(gpu, oracle, lights):
     rd = scenes.make_render_desc(80, 60, 16, GALLERY_LOOK_AT, 60, max_depth=6)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    assert (li == ref["li"]).all(axis=2).mean() > 0.6
     assert film_rmse(film, ref["film"]) < 2e-5
     assert st["nan_samples"] == ref["counters"]["nan_samples"]
 
@@ -208,7 +202,6 @@ def test_halton_sampler_matches_oracle(gpu, oracle, variant):
     rd = scenes.cornell_render_desc(res=72, spp=12, sampler="halton")
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    assert (li == ref["li"]).all(axis=2).mean() > 0.75
     assert film_rmse(film, ref["film"]) < 1e-5
     assert st["samples"] == 72 * 72 * 12
 
@@ -235,7 +228,6 @@ def test_infinite_area_light(gpu, oracle, kind, with_area):
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert film_rmse(film, ref["film"]) < (2e-5 if kind == "constant" else 2e-4)
-    assert np.abs(li - ref["li"]).mean() < 1e-5
     assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
 
 
@@ -267,7 +259,6 @@ def test_mix_material(gpu, oracle):
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert film_rmse(film, ref["film"]) < 2e-5
-    assert (li == ref["li"]).all(axis=2).mean() > 0.6
 
 
 @pytest.mark.parametrize("trilinear,wrap,bump", [(False, "repeat", True), (False, "repeat", False), (True, "repeat", True), (False, "clamp", True), (False, "black", False)])
@@ -283,9 +274,6 @@ def test_textured_materials_match_oracle(gpu, oracle, trilinear, wrap, bump):
     rd = scenes.make_render_desc(96, 72, 16, TEXTURED_LOOK_AT, 45, max_depth=4)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    same = (li == ref["li"]).all(axis=2)
-    assert same.mean() > 0.6
-    assert np.abs(li - ref["li"]).mean() < 1e-5
     assert film_rmse(film, ref["film"]) < (1e-4 if bump else 2e-5)
     assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
 
@@ -300,8 +288,6 @@ def test_procedural_textures_and_mappings_match_oracle(gpu, oracle):
     rd = scenes.make_render_desc(96, 64, 16, PROCEDURAL_LOOK_AT, 50, max_depth=3)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    assert (li == ref["li"]).all(axis=2).mean() > 0.6
-    assert np.abs(li - ref["li"]).mean() < 2e-5
     assert film_rmse(film, ref["film"]) < 2e-4
     assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
 
@@ -314,8 +300,6 @@ def test_roughness_textures_match_oracle(gpu, oracle):
     rd = scenes.make_render_desc(96, 64, 16, PROCEDURAL_LOOK_AT, 50, max_depth=4)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    assert (li == ref["li"]).all(axis=2).mean() > 0.6
-    assert np.abs(li - ref["li"]).mean() < 2e-5
     assert film_rmse(film, ref["film"]) < 2e-4
     assert st["nan_samples"] == ref["counters"]["nan_samples"] == 0
 
@@ -328,7 +312,6 @@ def test_textures_change_the_image_and_lens_differentials(gpu, oracle):
     rd = scenes.make_render_desc(64, 48, 8, TEXTURED_LOOK_AT, 45, max_depth=3, lens_radius=0.05, focal_distance=6.0, sampler="halton")
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert film_rmse(film, ref["film"]) < 2e-5
-    assert np.abs(li - ref["li"]).mean() < 1e-5
     sb = scenes.SceneBuilder()
     m = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
     sb.add_quad([(-5, 0, -5), (5, 0, -5), (5, 0, 5), (-5, 0, 5)], m)
@@ -380,7 +363,7 @@ def test_golden_textured_room(gpu):
         ds.close()
     assert np.array_equal(film[:, 3], g["film"][:, 3])
     assert film_rmse(film, g["film"]) < 1e-4
-    assert (li == g["li"]).all(axis=2).mean() > 0.6
+    assert np.array_equal(li, g["li"])   # the committed fixture (= today's oracle, tests/test_oracle_kat.py), every sample bit for bit
 
 
 @pytest.mark.parametrize("cos_sample,sampler,n", [(True, "sobol", 16), (False, "sobol", 8), (True, "halton", 5)])
@@ -391,9 +374,6 @@ def test_ao_integrator_matches_oracle(gpu, oracle, cos_sample, sampler, n):
     rd = scenes.cornell_render_desc(res=48, spp=4, integrator="ao", ao_samples=n, ao_cos_sample=cos_sample, sampler=sampler)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    same = (li == ref["li"]).all(axis=2)
-    assert same.mean() > 0.75
-    assert np.abs(li - ref["li"]).mean() < 1e-5
     assert film_rmse(film, ref["film"]) < 1e-4
     assert 0.5 < li.mean() < 3.2 and st["nan_samples"] == 0
 
@@ -432,8 +412,6 @@ def test_random_scenes_fuzz(gpu, oracle, seed):
     assert st["nan_samples"] == ref["counters"]["nan_samples"]
     # (a roughness texture puts one logf in front of every microfacet term of that material: an ulp of alpha moves
     # most of its samples by an ulp or two, so the bit-identical share drops while the differences stay tiny)
-    assert (li == ref["li"]).all(axis=2).mean() > 0.3
-    assert np.abs(li - ref["li"]).mean() < 5e-5
     assert film_rmse(film, ref["film"]) < 3e-4
 
 
@@ -536,7 +514,6 @@ def test_many_area_lights(gpu, oracle, strategy):
     rd = scenes.make_render_desc(72, 54, 16, GALLERY_LOOK_AT, 55, max_depth=3, light_strategy=strategy)
     film, li, st, ref = _render_pair(gpu, oracle, sc, rd)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
-    assert (li == ref["li"]).all(axis=2).mean() > 0.75
     assert film_rmse(film, ref["film"]) < 2e-5
 
 
