@@ -800,11 +800,14 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
 
     // ---- batches ----
-    // paths per wavefront batch: ~280 B of state each, so 2^28 paths = 75 GB of the 288 GB HBM.  Large batches keep the persistent
-    // trace kernel's queues long and its launches few (every launch ends in a tail of a few long rays): measured with these
+    // paths per wavefront batch: ~280 B of state each, so 2^29 paths = 150 GB of the 288 GB HBM.  Large batches keep the persistent
+    // trace kernel's queues long and its launches few (every launch ends in a tail of a few long rays): measured with round 1's
     // kernels, 2^25 / 2^26 / 2^27 / 2^28 paths per batch = 367 / 386 / 398 / 405 Msamples/s on C2 and 1243 / 1400 / 1472 / 1525 on
-    // the C3 stand-in.  When the device cannot give that much (other tenants), the batch is halved until it fits.
-    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 28);
+    // the C3 stand-in; with round 4's, 2^28 -> 2^29 on the C3 stand-in: 1929 -> 1966 (same box; C2's frame is 2^28 paths, one batch
+    // either way).  Halving the number of launch tails bought 1.9 %: what is left of them is what a second pipeline of half batches
+    // on other streams could still fill — less than that again, which is why shade / trace overlap across batches was not built
+    // (DESIGN.md section 10).  When the device cannot give that much (other tenants), the batch is halved until it fits.
+    size_t cap = env_size("RSPT_BATCH", (size_t)1 << 29);
     cap = std::min<size_t>(std::max<size_t>(cap, 1024), (size_t)1 << 30);
     const bool counters = env_size("RSPT_COUNTERS", 0) != 0;
     // AOIntegrator: every camera sample carries ao_n_samples shadow rays through the same ray / occlusion arrays

@@ -1299,6 +1299,99 @@ STATUE_LOOK_AT = ((0, 0.6, -4.2), (0, 0, 0), (0, 1, 0))
 STATUE_FOV = 38.0
 
 
+def read_ply(path):
+    """vertices (n, 3) f32, optional normals (n, 3) f32, triangles (m, 3) u32 of a PLY file — ascii or binary_little_endian / big_endian, faces of
+    any size triangulated as fans.  What rs_pbrt's `Shape "plymesh"` reads (src/shapes/plymesh.rs:45-340 through ply-rs): x y z [nx ny nz] [u v]
+    per vertex, vertex_indices per face.  Only for bench.py's $RSPT_GANESHA_DIR: in the product the mesh arrives flattened from rs_pbrt."""
+    f = open(path, "rb")
+    if f.readline().strip() != b"ply":
+        raise ValueError("%s: not a PLY file" % path)
+    fmt, elements = None, []
+    while True:
+        line = f.readline()
+        if not line:
+            raise ValueError("%s: header without end_header" % path)
+        t = line.decode("ascii", "replace").split()
+        if not t or t[0] == "comment" or t[0] == "obj_info":
+            continue
+        if t[0] == "format":
+            fmt = t[1]
+        elif t[0] == "element":
+            elements.append((t[1], int(t[2]), []))
+        elif t[0] == "property":
+            elements[-1][2].append(tuple(t[1:]))
+        elif t[0] == "end_header":
+            break
+    types = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4",
+             "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+    end = ">" if fmt == "binary_big_endian" else "<"
+    P = N = tri = None
+    for name, count, props in elements:
+        scalar = all(pr[0] != "list" for pr in props)
+        if fmt == "ascii":
+            rows = [f.readline().split() for _ in range(count)]
+            if name == "vertex":
+                cols = {pr[-1]: i for i, pr in enumerate(props)}
+                a = np.array(rows, np.float64)
+                P = a[:, [cols["x"], cols["y"], cols["z"]]].astype(F32)
+                if all(k in cols for k in ("nx", "ny", "nz")):
+                    N = a[:, [cols["nx"], cols["ny"], cols["nz"]]].astype(F32)
+            elif name == "face":
+                faces = [[int(v) for v in r[1:1 + int(r[0])]] for r in rows]
+                tri = np.array([[fc[0], fc[i], fc[i + 1]] for fc in faces for i in range(1, len(fc) - 1)], np.uint32)
+            continue
+        if scalar:
+            dt = np.dtype([(pr[-1], end + types[pr[0]]) for pr in props])
+            a = np.frombuffer(f.read(dt.itemsize * count), dt, count)
+            if name == "vertex":
+                P = np.stack([a["x"], a["y"], a["z"]], 1).astype(F32)
+                if all(k in a.dtype.names for k in ("nx", "ny", "nz")):
+                    N = np.stack([a["nx"], a["ny"], a["nz"]], 1).astype(F32)
+            continue
+        if name != "face" or len(props) != 1:   # an element with a list property that is not the face list: walk it record by record
+            raise ValueError("%s: element %s mixes list and scalar properties" % (path, name))
+        ct, it = end + types[props[0][1]], end + types[props[0][2]]
+        raw = f.read()
+        csz, isz = np.dtype(ct).itemsize, np.dtype(it).itemsize
+        first = int(np.frombuffer(raw[:csz], ct)[0])
+        rec = csz + first * isz
+        if len(raw) >= rec * count and (np.frombuffer(raw[:rec * count], "u1").reshape(count, rec)[:, :csz] == np.frombuffer(raw[:csz], "u1")).all():   # all faces the same size (the usual case): one reshape
+            idx = np.frombuffer(np.ascontiguousarray(np.frombuffer(raw[:rec * count], "u1").reshape(count, rec)[:, csz:]).tobytes(), it).reshape(count, first).astype(np.uint32)
+            tri = np.concatenate([idx[:, [0, i, i + 1]] for i in range(1, first - 1)], 0)
+            f.seek(-(len(raw) - rec * count), 1) if len(raw) > rec * count else None
+        else:
+            out, off = [], 0
+            for _ in range(count):
+                k = int(np.frombuffer(raw[off:off + csz], ct)[0]); off += csz
+                v = np.frombuffer(raw[off:off + k * isz], it); off += k * isz
+                out += [[v[0], v[i], v[i + 1]] for i in range(1, k - 1)]
+            tri = np.array(out, np.uint32)
+    if P is None or tri is None:
+        raise ValueError("%s: no vertex / face element" % path)
+    return P, N, tri
+
+
+def statue_from_ply(bvh_builder, path):
+    """C3 with the REAL mesh when $RSPT_GANESHA_DIR holds it: the PLY's triangles, centred and scaled into the
+    stand-in's frame (bounding-sphere radius 1.15 at the origin, as the displaced sphere), its normals if it has them, under the stand-in's
+    camera, ground, three quad lights and plastic — the asset's own .pbrt (camera, lights, materials) is rs_pbrt's to parse, not this tool's."""
+    P, N, tri = read_ply(path)
+    lo, hi = P.min(0), P.max(0)
+    c = (0.5 * (lo + hi)).astype(F32)
+    r = float(np.linalg.norm(P - c, axis=1).max())
+    Pf = ((P - c) * F32(1.15 / r)).astype(F32)
+    t0, t1, t2 = Pf[tri[:, 0]], Pf[tri[:, 1]], Pf[tri[:, 2]]
+    tri = tri[np.linalg.norm(np.cross(t1 - t0, t2 - t0), axis=1) > 0]
+    sb = SceneBuilder()
+    body = sb.add_material(plastic((0.4, 0.4, 0.4), (0.1, 0.1, 0.1), 0.1))
+    ground = sb.add_material(matte((0.5, 0.5, 0.5)))
+    sb.add_mesh(Pf, tri, body, N=N)
+    sb.add_quad([(-6, -1.3, -6), (-6, -1.3, 6), (6, -1.3, 6), (6, -1.3, -6)], ground)
+    for (cx, cz, L) in ((-2.5, -2.0, (30, 28, 24)), (2.5, -2.0, (20, 24, 30)), (0.0, 2.5, (25, 25, 25))):
+        sb.add_quad([(cx + 0.5, 3.0, cz - 0.5), (cx + 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz + 0.5), (cx - 0.5, 3.0, cz - 0.5)], ground, emit=L)
+    return sb.finish(bvh_builder), len(tri)
+
+
 def statue_render_desc(xres=1920, yres=1080, spp=1024, **kw):
     return make_render_desc(xres, yres, spp, STATUE_LOOK_AT, STATUE_FOV, **kw)
 

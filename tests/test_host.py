@@ -144,3 +144,35 @@ def test_checkpoint_identity_covers_the_frame_not_the_way_it_is_rendered(tmp_pat
     np.savez(tmp_path / "old.npz", sum=a.sum, next_sample=3)   # the first format: sum / next_sample only
     with pytest.raises(ValueError):
         b.load(tmp_path / "old.npz", scene_id="cornell")
+
+
+def test_ply_reader_and_the_ganesha_pickup(tmp_path, monkeypatch):
+    """bench.py's $RSPT_GANESHA_DIR: scenes.read_ply reads what `Shape "plymesh"` reads (ascii and binary, faces of any
+    size as fans, optional normals); statue_from_ply puts the mesh into the C3 stand-in's frame"""
+    import struct
+    import sys
+    P = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]], np.float32)
+    faces = [[0, 1, 2, 3], [0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]]
+    hdr = "ply\nformat %s 1.0\ncomment made by a test\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\nelement face 5\nproperty list uchar int vertex_indices\nend_header\n"
+    with open(tmp_path / "a.ply", "w") as f:
+        f.write(hdr % "ascii")
+        f.writelines(" ".join(str(float(v)) for v in p) + "\n" for p in P)
+        f.writelines("%d %s\n" % (len(fc), " ".join(map(str, fc))) for fc in faces)
+    for name, end in (("l.ply", "<"), ("b.ply", ">")):
+        with open(tmp_path / name, "wb") as f:
+            f.write((hdr % ("binary_little_endian" if end == "<" else "binary_big_endian")).encode())
+            f.write(P.astype(end + "f4").tobytes())
+            for fc in faces:
+                f.write(struct.pack(end + "B%di" % len(fc), len(fc), *fc))
+    want = [[0, 1, 2], [0, 2, 3], [0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]]
+    for name in ("a.ply", "l.ply", "b.ply"):
+        Pr, Nr, tri = scenes.read_ply(str(tmp_path / name))
+        assert np.array_equal(Pr, P) and Nr is None and tri.tolist() == want, name
+    sc, n = scenes.statue_from_ply(lib.bvh_build, str(tmp_path / "l.ply"))
+    assert n == 6 and len(sc.prims) == 6 + 2 + 6 and len(sc.lights) == 6
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setenv("RSPT_GANESHA_DIR", str(tmp_path))
+    assert bench.ganesha_ply() in (str(tmp_path / "l.ply"), str(tmp_path / "b.ply"), str(tmp_path / "a.ply"))
+    monkeypatch.delenv("RSPT_GANESHA_DIR")
+    assert bench.ganesha_ply() is None

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build a VARIANT of librspt.so next to the committed one, for A/B runs on the GPU box (tools/ab_run.sh) — without touching
 # rs_pbrt_amd/csrc, so lib.source_hash() and the profiles tied to it stay valid until a variant is adopted.
+# (AB_DEFS="-DX=1 ..." adds compiler flags to the variant)
 # usage: tools/ab_build.sh <name> [patch file applying to the repo root with -p1 | "-"]   ("-" or nothing: the committed sources)
 #   -> exp/librspt_<name>.so (git-ignored, travels with gpurun) and exp/<name>.ru.txt (register / scratch / occupancy per kernel);
 #   prints the kernels whose resource usage differs from the committed build's (exp/base.ru.txt, built on first use).
@@ -9,7 +10,7 @@ name=$1; patch=${2:--}; repo=$(cd "$(dirname "$0")/.." && pwd); work=$(mktemp -d
 mkdir -p $work/rs_pbrt_amd $work/include; cp -r $repo/rs_pbrt_amd/csrc $work/rs_pbrt_amd/; cp $repo/include/rspt.h $work/include/
 if [ "$patch" != "-" ]; then patch=$(cd "$(dirname "$patch")" && pwd)/$(basename "$patch"); (cd $work && patch -p1 --no-backup-if-mismatch < "$patch"); fi
 # the library's own Makefile (several translation units side by side), with the resource-usage remarks switched on
-make -s -j8 -C $work/rs_pbrt_amd/csrc OUT=$repo/exp/librspt_$name.so OBJDIR=$work/obj EXTRA=-Rpass-analysis=kernel-resource-usage 2> $work/ru.raw || { grep -E "error" $work/ru.raw | head; exit 1; }
+make -s -j8 -C $work/rs_pbrt_amd/csrc OUT=$repo/exp/librspt_$name.so OBJDIR=$work/obj EXTRA="-Rpass-analysis=kernel-resource-usage ${AB_DEFS:-}" 2> $work/ru.raw || { grep -E "error" $work/ru.raw | head; exit 1; }
 python3 - $work/ru.raw > $repo/exp/$name.ru.txt <<'PY'
 import re, subprocess, sys
 t = open(sys.argv[1]).read()

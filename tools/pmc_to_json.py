@@ -49,46 +49,48 @@ def main():
             out["workloads"][w] = {"kernels": kernels, "trace_traffic_bytes_per_step": total,
                                    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --workload %s --steps 1 --warmup 0 "
                                              "--no-cpu-baseline --no-extra --no-count; sums over the k_trace_w4 launches of the one step" % w}
-    # limiter-side ratios of the C2 step (what bench.py leads its roofline block with).  Per kernel class:
+    # limiter-side ratios of a C2 / C3 step (what bench.py leads its roofline blocks with).  Per kernel class:
     #   cycles            GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8
     #   l1_request_frac   TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / cycles     (one L1 line probe per CU per cycle is the ceiling)
     #   ta_busy           TA_TA_BUSY_sum / 256 TAs / cycles;  ta_busy_avr = TA_BUSY_avr / cycles
     #   valu_busy         SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / 1024 SIMDs / cycles
     #   wait_frac         SQ_WAIT_ANY / SQ_WAVE_CYCLES;  waves_per_simd = SQ_WAVE_CYCLES * 4 / 1024 / cycles
-    tcp, sq, ta = (parse("%s/pmc_soup1m_%s.txt" % (d, n)) for n in ("tcp", "sq", "ta"))
-    derived = {}
-    for label, key in (("trace_closest", "k_trace_w4<false"), ("trace_any", "k_trace_w4<true"), ("shade", "k_shade")):
-        def pick(rows, ctr):
-            return sum(v[ctr][1] for k, v in rows.items() if k.startswith(key) and ctr in v)
-        cyc = pick(ta, "GRBM_GUI_ACTIVE") / 8.0
-        if cyc <= 0:
-            continue
-        e = {"cycles": cyc, "ta_busy": pick(ta, "TA_TA_BUSY_sum") / 256.0 / cyc, "ta_busy_avr": pick(ta, "TA_BUSY_avr") / cyc}
-        if pick(tcp, "TCP_TOTAL_CACHE_ACCESSES_sum"):
-            e["l1_request_frac"] = pick(tcp, "TCP_TOTAL_CACHE_ACCESSES_sum") / 256.0 / cyc
-            e["l1_to_l2_read_latency_cycles"] = pick(tcp, "TCP_TCC_READ_REQ_LATENCY_sum") / max(pick(tcp, "TCP_TCC_READ_REQ_sum"), 1.0)
-        if pick(sq, "SQ_WAVE_CYCLES"):
-            e["valu_busy"] = pick(sq, "SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / cyc
-            e["wait_frac"] = pick(sq, "SQ_WAIT_ANY") / pick(sq, "SQ_WAVE_CYCLES")
-            e["waves_per_simd"] = pick(sq, "SQ_WAVE_CYCLES") * 4.0 / 1024.0 / cyc
-        derived[label] = e
-    if derived and "soup1m" in out["workloads"]:
-        out["workloads"]["soup1m"]["limiters"] = derived
+    for wname in ("soup1m", "statue"):
+        tcp, sq, ta = (parse("%s/pmc_%s_%s.txt" % (d, wname, n)) for n in ("tcp", "sq", "ta"))
+        derived = {}
+        for label, key in (("trace_closest", "k_trace_w4<false"), ("trace_any", "k_trace_w4<true"), ("shade", "k_shade")):
+            def pick(rows, ctr):
+                return sum(v[ctr][1] for k, v in rows.items() if k.startswith(key) and ctr in v)
+            cyc = pick(ta, "GRBM_GUI_ACTIVE") / 8.0
+            if cyc <= 0:
+                continue
+            e = {"cycles": cyc, "ta_busy": pick(ta, "TA_TA_BUSY_sum") / 256.0 / cyc, "ta_busy_avr": pick(ta, "TA_BUSY_avr") / cyc}
+            if pick(tcp, "TCP_TOTAL_CACHE_ACCESSES_sum"):
+                e["l1_request_frac"] = pick(tcp, "TCP_TOTAL_CACHE_ACCESSES_sum") / 256.0 / cyc
+                e["l1_to_l2_read_latency_cycles"] = pick(tcp, "TCP_TCC_READ_REQ_LATENCY_sum") / max(pick(tcp, "TCP_TCC_READ_REQ_sum"), 1.0)
+            if pick(sq, "SQ_WAVE_CYCLES"):
+                e["valu_busy"] = pick(sq, "SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / cyc
+                e["wait_frac"] = pick(sq, "SQ_WAIT_ANY") / pick(sq, "SQ_WAVE_CYCLES")
+                e["waves_per_simd"] = pick(sq, "SQ_WAVE_CYCLES") * 4.0 / 1024.0 / cyc
+            derived[label] = e
+        if derived and wname in out["workloads"]:
+            out["workloads"][wname]["limiters"] = derived
     for w in out["workloads"].values():   # the shade stage's fabric-side traffic, for its own roofline block
         w["shade_traffic_bytes_per_step"] = sum(v["bytes_corrected"] for k, v in w["kernels"].items() if k.startswith("k_shade") or k.startswith("k_texture") or k.startswith("k_bin_"))
     json.dump(out, open(d + "/pmc_traffic.json", "w"), indent=1)
-    lines = ["# L1 / issue-side PMC counters of one C2 step (soup1m), per kernel — rocprofv3 --kernel-trace --pmc <one block per run>", "",
-             "source hash %s; command: `python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-count`" % out["source_hash"], ""]
-    for name in ("tcp", "sq", "ta", "lds"):
-        rows = parse("%s/pmc_soup1m_%s.txt" % (d, name))
+    lines = ["# L1 / issue-side PMC counters of one step, per kernel — rocprofv3 --kernel-trace --pmc <one block per run>", "",
+             "source hash %s; command: `python bench.py --workload <w> --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-count`" % out["source_hash"], ""]
+    for wname, title in (("soup1m", "C2 (soup1m)"), ("statue", "C3 stand-in (statue)")):
+      for name in ("tcp", "sq", "ta", "lds"):
+        rows = parse("%s/pmc_%s_%s.txt" % (d, wname, name))
         if not rows:
             continue
         ctrs = sorted({c for k in rows for c in rows[k]})
-        lines += ["## pass `%s`" % name, "", "| kernel | launches | " + " | ".join(ctrs) + " |", "|---|---|" + "---|" * len(ctrs)]
+        lines += ["## %s, pass `%s`" % (title, name), "", "| kernel | launches | " + " | ".join(ctrs) + " |", "|---|---|" + "---|" * len(ctrs)]
         for k in sorted(rows):
             if k.startswith("bvhdev::"):
                 continue
-            if name != "lds" and not (k.startswith("k_trace") or k.startswith("k_shade") or k.startswith("k_raygen") or k.startswith("k_film")):
+            if name != "lds" and not (k.startswith("k_trace") or k.startswith("k_shade") or k.startswith("k_raygen") or k.startswith("k_film") or k.startswith("k_bin")):
                 continue
             n = max((rows[k][c][0] for c in rows[k]), default=0)
             lines.append("| %s | %d | " % (k, n) + " | ".join("%.4g" % rows[k].get(c, (0, 0.0))[1] for c in ctrs) + " |")
