@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from rs_pbrt_amd import scenes
-from tests.test_reference_pin import G, agreement
+from tests.test_reference_pin import G, agreement, to_u8
 from tests.util import film_rmse
 
 pytestmark = pytest.mark.gpu
@@ -21,7 +21,11 @@ def test_gpu_reproduces_the_references_8spp_png(gpu, oracle):
     finally:
         ds.close()
     exact, w1, w4 = agreement(film, G["spp8"])
-    assert exact > 0.93 and w1 > 0.95 and w4 > 0.98, (exact, w1, w4)
+    assert exact > 0.94 and w1 > 0.957 and w4 > 0.985, (exact, w1, w4)
+    # the strict bar (tests/test_reference_pin.py, last test): where the reference's picture carries no extra contribution the PRODUCT's bytes are the reference's
+    ours, refpng = to_u8(scenes.film_to_rgb(film)).reshape(500, 500, 3), G["spp8"].astype(np.int32)
+    no_extra = (refpng - ours).max(-1) <= 0
+    assert no_extra.mean() > 0.94 and (ours == refpng).all(-1)[no_extra].mean() >= 0.998 and ((ours - refpng).max(-1) > 1).mean() < 0.0005
     ref = oracle.render(sc, rd, threads=8, want_li=True)
     assert np.array_equal(li, ref["li"])                       # a camera with a mirror in it (`Scale -1 1 1`): every sample bit for bit as the oracle's
     assert np.array_equal(film[:, 3], ref["film"][:, 3]) and film_rmse(film, ref["film"]) < 1e-7

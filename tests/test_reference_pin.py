@@ -11,7 +11,7 @@ emitter's two triangles, the triangle sampling, the shadow rays, the MIS weights
 match is a sample-for-sample match of all of those (what it does not cover: every other material, texture, light, sampler, integrator,
 media, instancing: for those the oracle is still pinned by first-principles tests only).
 The 6 % of pixels that differ are scattered evenly (no face, edge or shadow stands out), 1.7 % by one byte step, 4.2 % by more — and they
-are ONE-SIDED: the reference is the brighter one in all of them (test_the_open_remainder...).  It holds 0.33 % more energy than the oracle,
+are ONE-SIDED: the reference is the brighter one in all of them (the last test of this file).  It holds 0.33 % more energy than the oracle,
 in single samples (about one path in 130) that carry an extra contribution of the size of an ordinary light sample, often of a pure wall
 colour (a path that has been to the red or the green wall).  0.33 % is what this scene's paths carry beyond five bounces (with
 `maxdepth` 100 the oracle's total equals the reference's to 4e-5) — but none of the ways to let paths run on that were tried (maxdepth
@@ -49,7 +49,7 @@ def test_oracle_reproduces_the_references_8spp_png(oracle):
     sc = scenes.cornell_box_docs(oracle.bvh_build)
     r = oracle.render(sc, scenes.cornell_docs_render_desc(8), threads=THREADS)
     exact, w1, w4 = agreement(r["film"], G["spp8"])
-    assert exact > 0.93 and w1 > 0.95 and w4 > 0.98, (exact, w1, w4)   # measured: 0.9408, 0.9579, 0.9853
+    assert exact > 0.94 and w1 > 0.957 and w4 > 0.985, (exact, w1, w4)   # measured: 0.9408, 0.9579, 0.9853 (the strict bar is the last test of this file)
 
 
 @pytest.mark.parametrize("what, bar", [("mirrored world instead of mirrored camera", 0.25), ("uniform light choice", 0.40), ("power light choice", 0.40),
@@ -91,11 +91,17 @@ def test_oracle_reproduces_the_references_256spp_png_in_every_sixth_tile(oracle)
     assert exact > 0.65 and w1 > 0.98 and w4 > 0.998, (exact, w1, w4)   # measured on these tiles: 0.703, 0.989, 0.9992
 
 
-def test_the_open_remainder_is_one_sided(oracle):
-    """What is known about the pixels that do not match (module docstring): the reference is brighter in every one of them, by 0.33 % of the
-    picture's energy in total — a record of the open end, so that whoever closes it sees the numbers move."""
+def test_outside_the_references_extra_contributions_every_pixel_is_byte_identical(oracle):
+    """The strict form of the pin.  The reference's 8-spp picture carries extra, strictly positive contributions in about
+    one path of 130 that v0.9.12's source does not explain (module docstring; experiments/reference_pin/README.md) — wherever it does NOT
+    (no byte of the reference above the oracle's), the two must agree byte for byte: measured 99.85 % of those pixels, the rest one byte step
+    with the oracle the brighter one (0.14 % of the picture).  A regression anywhere in the sampler / camera / traversal / shading / light
+    selection / film shows up two-sided and fails this at once (every ingredient test above falls to 9 - 69 % exact)."""
     sc = scenes.cornell_box_docs(oracle.bvh_build)
     ours = to_u8(scenes.film_to_rgb(oracle.render(sc, scenes.cornell_docs_render_desc(8), threads=THREADS)["film"])).reshape(500, 500, 3)
     ref = G["spp8"].astype(np.int32)
-    assert ((ours - ref).max(-1) > 0).mean() < 0.003 and ((ours - ref).max(-1) > 1).mean() < 0.0005   # measured: 0.0014 of the pixels have a byte above the reference's, 0.0001 by more than one step
-    assert 0.04 < ((ref - ours).max(-1) > 0).mean() < 0.07 and ((ref - ours).max(-1) > 1).mean() > 0.03   # 0.058 have one below, 0.042 by more than one step
+    no_extra = (ref - ours).max(-1) <= 0
+    exact = (ours == ref).all(-1)
+    assert no_extra.mean() > 0.94                                   # measured 0.9422
+    assert exact[no_extra].mean() >= 0.998, exact[no_extra].mean()   # measured 0.9985
+    assert ((ours - ref).max(-1) > 1).mean() < 0.0005               # the oracle above the reference by more than one byte step: 0.0001 of the pixels
