@@ -17,15 +17,19 @@ L = lib.lib()
 if wl == "soup1m":
     sc = scenes.triangle_soup(lib.bvh_build, n_tris=1_000_000)
     rd = scenes.soup_render_desc(res=1024, spp=spp, max_depth=8)
+elif wl.startswith("c5"):   # c5 (instancing as the reference has it) / c5fixed
+    sc = scenes.landscape_standin(lib.bvh_build_gpu, instancing="fixed" if wl == "c5fixed" else "reference")
+    rd = scenes.landscape_render_desc(xres=1920, yres=1080, spp=spp)
 else:
     sc = scenes.statue_standin(lib.bvh_build)
     rd = scenes.statue_render_desc(spp=spp)
 out = (C.c_uint64 * 16)()
 with lib.DeviceScene(sc) as ds:
+    prof = L.rspt_debug_w4q_prof if os.environ.get("RSPT_TRACE_KERNEL") == "3" else L.rspt_debug_w4_prof   # (one copy of the counters per translation unit)
     lib.render(ds, rd)
-    L.rspt_debug_w4_prof(out, 1)
+    prof(out, 1)
     film, st = lib.render(ds, rd)
-    L.rspt_debug_w4_prof(out, 1)
+    prof(out, 1)
 p = [int(v) for v in out]
 iters, idle, steps, step_lanes, fetches, fetch_lanes, top_lanes, leafs, leaf_lanes, leaf_trips, leaf_tris = p[:11]
 print("workload %s, %d spp: %.1f M samples, %.3f s in trace launches" % (wl, spp, st["samples"] / 1e6, st["t_trace_closest_s"] + st["t_trace_any_s"]))
@@ -35,5 +39,10 @@ print("node steps %d: lanes in the step %.1f / 64 (%.0f %%); record fetches: %.1
 print("leaf phases %d (one per %.2f node steps): parked lanes %.1f / 64 (%.0f %%); triangles per lane %.2f, loop trips per phase %.2f (lane utilisation inside the loop %.0f %%)"
       % (leafs, steps / max(leafs, 1), leaf_lanes / max(leafs, 1), 100 * leaf_lanes / max(64 * leafs, 1), leaf_tris / max(leaf_lanes, 1), leaf_trips / max(leafs, 1),
          100 * leaf_tris / max(64 * leaf_trips, 1)))
-rays = (st.get("rays_closest", 0) + st.get("rays_any", 0)) or None
-print("raw:", p[:11])
+print("raw:", p[:12], " Q kernel: leaves stopped by the exact box test %d (%.1f %% of the leaf arrivals)" % (p[11], 100.0 * p[11] / max(leaf_lanes, 1)))
+os.environ["RSPT_COUNTERS"] = "1"
+with lib.DeviceScene(sc) as ds:
+    film, st = lib.render(ds, rd)
+rays = st["rays_closest"] + st["rays_any"]
+print("reference-order counters: %.2f rays per sample (%.2f closest, %.2f any), %.1f nodes and %.2f triangle tests per ray; record fetches per ray (profile) %.1f"
+      % (rays / st["samples"], st["rays_closest"] / st["samples"], st["rays_any"] / st["samples"], st["nodes_visited"] / rays, st["tris_tested"] / rays, fetch_lanes / rays))
