@@ -190,10 +190,19 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_
     # every duration that enters a ratio below is a wall time inside the step
     assert t_wall <= ms_per_step * 1e-3 * 1.02 and t_sh <= ms_per_step * 1e-3 * 1.02 and t_wall + t_sh <= t_k * 1.02, (t_wall, t_sh, t_k, ms_per_step)
     lim = (traffic or {}).get("limiters", {})
-    out = {"bound": "l1", "bound_detail": "L1 request rate of the per-lane BVH record loads (TA / TCP path), VALU issue close behind; not HBM, not MFMA",
+    lc, la = lim.get("trace_closest", {}), lim.get("trace_any", {})
+    miss_lines = (lc.get("l1_miss_lines") or 0.0) + (la.get("l1_miss_lines") or 0.0)
+    out = {"bound": "l2", "bound_detail": "rate and latency of the kernel's L1 MISSES (128-byte lines of BVH records and triangles fetched from L2 / Infinity Cache per lane), VALU issue "
+                                          "right behind; not the L1 probe rate (a variant with a third fewer probes per ray is no faster: experiments/README.md round 4), not HBM, not MFMA",
            "kernel": "k_trace_w4 (BVH traversal + triangle test; closest-hit + shadow-ray launches)",
            "l1_request_frac": lim.get("trace_closest", {}).get("l1_request_frac"), "ta_busy": lim.get("trace_closest", {}).get("ta_busy"),
            "valu_busy": lim.get("trace_closest", {}).get("valu_busy"),
+           # the L1-miss side (TCP_TCC_READ_REQ of the same PMC pass): lines per ray, their mean latency, how many a CU keeps in flight, and the line rate over
+           # the launches' wall time; a random walk with this kernel's shape reaches ~60 G lines/s on this GPU (profiles/r04_step_model.txt)
+           "l1_miss_lines_per_ray": (miss_lines / rays) if miss_lines else None,
+           "l1_miss_latency_cycles": lc.get("l1_to_l2_read_latency_cycles"), "l1_misses_in_flight_per_cu": lc.get("l1_misses_in_flight_per_cu"),
+           "l1_hit_rate": lc.get("l1_hit_rate"), "l2_hit_rate": lc.get("l2_hit_rate"),
+           "l1_miss_g_lines_per_s": (miss_lines / t_wall / 1e9) if miss_lines else None,
            "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
            "launches_per_step": launches, "avg_launch_ms": t_wall / max(launches, 1) * 1e3,
            # per-launch HIP-event durations, the figures rocprofv3 --kernel-trace --stats reports as "avg" for the two instantiations (profiles/rNN_soup1m_kernel_stats.md)
@@ -212,7 +221,8 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_
     # read) + 36 B per shadow ray (32 B written + 4 B flag read) + 96 B of path state per bounce
     n_bounce = count_scale * (counts["alg_bytes"] - 32.0 * counts["samples"]) / 96.0 - trace_bytes / 96.0
     shade_alg = 48.0 * count_scale * counts["rays_closest"] + 36.0 * count_scale * counts["rays_any"] + 96.0 * n_bounce
-    sh = {"bound": "latency", "bound_detail": "2 - 3 waves / SIMD (VGPRs; waves_per_simd is the measured figure): dependent loads of the interaction fill, light sample and BSDF evaluation are not hidden",
+    sh = {"bound": "hbm", "bound_detail": "bytes of path state moved per path and bounce (scattered 16 - 32-byte records of the SoA slot, ~3.2 x SURVEY 8(d)'s budget) at 2 - 3 waves / SIMD; "
+                                          "issuing every slot load up front (fewer dependent round trips, 68 more bytes per path) lost 4 %: experiments/README.md round 4",
           "kernel": "k_shade (+ k_bin_*, k_texture)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
           "alg_bytes_per_step": shade_alg, "alg_rate_gbs": shade_alg / t_sh / 1e9 if t_sh > 0 else None, "seconds_per_step": t_sh,
           "valu_busy": lim.get("shade", {}).get("valu_busy"), "wait_frac": lim.get("shade", {}).get("wait_frac"), "waves_per_simd": lim.get("shade", {}).get("waves_per_simd")}

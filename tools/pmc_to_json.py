@@ -68,6 +68,12 @@ def main():
             if pick(tcp, "TCP_TOTAL_CACHE_ACCESSES_sum"):
                 e["l1_request_frac"] = pick(tcp, "TCP_TOTAL_CACHE_ACCESSES_sum") / 256.0 / cyc
                 e["l1_to_l2_read_latency_cycles"] = pick(tcp, "TCP_TCC_READ_REQ_LATENCY_sum") / max(pick(tcp, "TCP_TCC_READ_REQ_sum"), 1.0)
+                # round 4 (experiments/README.md): what the traversal kernel's time follows is its L1 MISSES — lines requested from L2 — and their latency
+                e["l1_miss_lines"] = pick(tcp, "TCP_TCC_READ_REQ_sum")
+                e["l1_hit_rate"] = 1.0 - pick(tcp, "TCP_TCC_READ_REQ_sum") / pick(tcp, "TCP_TOTAL_CACHE_ACCESSES_sum")
+                e["l2_hit_rate"] = pick(tcp, "TCC_HIT_sum") / max(pick(tcp, "TCC_HIT_sum") + pick(tcp, "TCC_MISS_sum"), 1.0)
+                # Little's law: misses in flight per CU = (lines / cycles) x latency / 256 CUs
+                e["l1_misses_in_flight_per_cu"] = pick(tcp, "TCP_TCC_READ_REQ_LATENCY_sum") / cyc / 256.0
             if pick(sq, "SQ_WAVE_CYCLES"):
                 e["valu_busy"] = pick(sq, "SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / cyc
                 e["wait_frac"] = pick(sq, "SQ_WAIT_ANY") / pick(sq, "SQ_WAVE_CYCLES")
