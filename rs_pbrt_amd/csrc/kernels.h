@@ -25,6 +25,7 @@ enum : uint32_t {
     ST_HAS_C2 = 1u << 28,        // pending BSDF-sample (MIS) term
     ST_C2_ON_MISS = 1u << 29,    // ... of an infinite light: it counts when the MIS ray escapes
     ST_NO_DIFF = 1u << 30,       // the camera ray went through a null material: it was re-spawned without differentials (path.rs:109-116)
+    ST_COMPACT = 1u << 31,       // the pending estimate is kept as ONE vector: what the resolve adds if the shadow ray arrives (shade_path)
 };
 #define RSPT_Q_MIS 0x80000000u   // closest-hit queue entry flag: this is the path's MIS ray
 
@@ -403,6 +404,11 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     rgb L{le.x, le.y, le.z};
     float eta_scale = le.w;
 
+    if ((st & ST_PENDING) && (st & ST_COMPACT)) {   // the estimate without a BSDF-sampled term (almost all of them): nee_c1 holds beta * ((0 + c1) / pdf), already
+        const float4 k = pb.nee_c1[p];                // formed with the operations of the general resolve below; a blocked shadow ray adds beta * (0 / pdf) = +-0
+        if (pb.occluded[p] == 0u) L = L + rgb{k.x, k.y, k.z};
+        st &= ~(ST_PENDING | ST_HAS_C1 | ST_COMPACT);
+    }
     if (st & ST_PENDING) {  // tail of estimate_direct (integrator.rs:461-568) + path.rs:126-139
         float4 c1 = pb.nee_c1[p], c2 = pb.nee_c2[p], nb = pb.nee_beta[p];
         rgb ldir = mkrgb(0.0f);
@@ -577,10 +583,25 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                                 }
                             }
                         }
-                        pb.nee_c1[p] = make_float4(c1.r, c1.g, c1.b, pdf_choice);
-                        pb.nee_c2[p] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
-                        pb.nee_beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
-                        st |= ST_PENDING;  // even an all-zero estimate is added (l + beta*0 == l)
+                        // What the resolve at the top of this function will add (path.rs:126-139): beta * (ldir / pdf) with ldir = 0 [+ c1 if the shadow ray
+                        // arrives] [+ c2 if the MIS ray ends on the light].  Without a BSDF-sampled term — the rule: that term exists only when the sampled
+                        // direction meets the light's triangle — the two possible results are known now: beta * (0 / pdf), which is +-0 unless beta or
+                        // pdf is not finite, and beta * ((0 + c1) / pdf).  Then only the second is kept (16 bytes written and read instead of 48 + 48:
+                        // the stage is bound by its slot bytes, experiments/README.md round 4), formed by the very operations of the resolve, and a path
+                        // without a light term at all has nothing pending.  Anything else takes the general form.
+                        const rgb k_occ = beta * (mkrgb(0.0f) / pdf_choice);
+                        if (!(st & ST_HAS_C2) && k_occ.r == 0.0f && k_occ.g == 0.0f && k_occ.b == 0.0f) {
+                            if (st & ST_HAS_C1) {
+                                const rgb k = beta * ((mkrgb(0.0f) + c1) / pdf_choice);
+                                pb.nee_c1[p] = make_float4(k.r, k.g, k.b, 0.0f);
+                                st |= ST_PENDING | ST_COMPACT;
+                            }
+                        } else {
+                            pb.nee_c1[p] = make_float4(c1.r, c1.g, c1.b, pdf_choice);
+                            pb.nee_c2[p] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
+                            pb.nee_beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                            st |= ST_PENDING;  // even an all-zero estimate is added (l + beta*0 == l)
+                        }
                     }
                 }
 

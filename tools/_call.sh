@@ -1,29 +1,9 @@
 set -u
-export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/c12; mkdir -p $out
-cat > /tmp/tb.py <<'PY'
-import os, sys
-import numpy as np
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-from rs_pbrt_amd import scenes, lib, abi
-lib.init(0)
-sc = scenes.triangle_soup(lib.bvh_build, n_tris=1_000_000)
-ds = lib.DeviceScene(sc)
-n = 1 << 22
-rng = np.random.default_rng(5)
-r = np.zeros(n, abi.RAY_DT)
-r["o"] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
-d = rng.normal(size=(n, 3)); r["d"] = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32); r["t_max"] = np.inf
-rb = lib.DeviceBuffer(r.nbytes); rb.upload(r)
-hb = lib.DeviceBuffer(n * abi.HIT_DT.itemsize)
-for k in ("2", "3"):
-    os.environ["RSPT_TRACE_KERNEL"] = k
-    print(k, lib.trace_device(ds, rb, n, hb, any_hit=False, repeat=2))
-PY
-pass() { name=$1; shift
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $out/pmc_$name -- python /tmp/tb.py > $out/pmc_$name.log 2>&1)
-  python tools/pmc_summary.py $out/pmc_$name k_trace_w4 > $out/pmc_$name.txt 2>&1; find $out/pmc_$name -name "*.db" -delete; cat $out/pmc_$name.txt; }
-pass sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU
-pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum
-pass ta TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE
-pass fetch FETCH_SIZE
+mkdir -p gpurun_out/c13
+timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_fuzz.py tests/test_gpu_pixel_samplers.py tests/test_gpu_reference_pin.py -m gpu -x -q -k "not two_ranks" > gpurun_out/c13/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/c13/pytest.log | tail -3
+bash tools/ab_run.sh -r 2 -- "--workload statue --steps 3 --warmup 1 --no-count" before compact 2>&1 | tail -3
+cp gpurun_out/ab/values.txt gpurun_out/c13/ab_statue.txt
+bash tools/ab_run.sh -r 2 -- "--workload soup1m --steps 4 --warmup 1 --no-count" before compact 2>&1 | tail -3
+cp gpurun_out/ab/values.txt gpurun_out/c13/ab_soup.txt
+bash tools/ab_run.sh -r 1 -- "--workload statue_tex --steps 3 --warmup 1 --no-count" before compact 2>&1 | tail -3
+cp gpurun_out/ab/values.txt gpurun_out/c13/ab_statue_tex.txt
