@@ -78,11 +78,28 @@ struct LightDistDev {
     // on-demand voxels (the reference fills its hash table the first time a voxel is looked up, lightdistrib.rs:297-384): table[voxel] =
     // row of func / cdf / func_int, or < 0 while the voxel has no distribution yet; nullptr = every voxel was built up front, row = voxel
     int32_t* table;
+    // Kernels that meet their lookup points only while they run (volpath: a point in a medium is sampled inside the kernel; the pixel samplers:
+    // a whole tile is one serial chain) claim a missing voxel themselves — the words k_ld_mark uses — and the host builds the claimed rows and
+    // runs the step again (librspt.hip).  nullptr for the kernels whose lookup points are known before the launch (`path`: k_ld_mark).
+    struct LightLazyWords* lazy;
+    uint32_t* new_list;
 };
-RDEV uint32_t light_row(const LightDistDev& ld, uint32_t vox) {
-    if (!ld.table) return vox;
+struct LightLazyWords { uint32_t n_new, n_rows, max_rows, overflow; };   // = LightLazy (kernels.h)
+// the voxel's row, or -1 when it has no distribution yet (after claiming it for the next build round where the kernel may do that)
+RDEV int32_t light_row_try(const LightDistDev& ld, uint32_t vox) {
+    if (!ld.table) return (int32_t)vox;
     const int32_t r = ld.table[vox];
-    return r < 0 ? 0u : (uint32_t)r;  // < 0 only after the row pool ran out: that render fails with RSPT_E_NOMEM, it must not fault
+    if (r >= 0) return r;
+    if (ld.lazy && r == -1 && atomicCAS(&ld.table[vox], -1, -2) == -1) {
+        const uint32_t k = atomicAdd(&ld.lazy->n_new, 1u);
+        if (ld.lazy->n_rows + k < ld.lazy->max_rows) ld.new_list[k] = vox;
+        else { ld.lazy->overflow = 1u; ld.table[vox] = -1; }
+    }
+    return -1;
+}
+RDEV uint32_t light_row(const LightDistDev& ld, uint32_t vox) {
+    const int32_t r = light_row_try(ld, vox);
+    return r < 0 ? 0u : (uint32_t)r;  // < 0: the row pool ran out (that render fails with RSPT_E_NOMEM) or the step is run again once the row exists; it must not fault
 }
 
 // Everything SamplerIntegrator::render reads per sample (subset of rspt_render_desc)

@@ -754,8 +754,26 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (volpath && s->dev.n_grid_media && !pixel_sampler)
         return fail(RSPT_E_UNSUPPORTED, "volpath with a grid-density medium under the Sobol' / Halton sampler: every tracking step draws sampler dimensions (the reference panics past "
                                         "dimension 1024 / 1000 within a bounce or two); render it with a pixel sampler (random / 02sequence / stratified / maxmindist)");
-    if (pixel_sampler && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "a pixel sampler with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
-    if (volpath && ld_lazy) return fail(RSPT_E_UNSUPPORTED, "volpath with an on-demand spatial light distribution (raise RSPT_LIGHT_TABLE_EAGER_BYTES)");
+    // on-demand voxels under volpath and the pixel samplers: their kernels meet the lookup points only while they run, so they claim missing
+    // voxels themselves (dev_scene.h light_row_try) and the step runs again once the claimed rows are built (lightdistrib.rs:276-384 builds on
+    // first touch too; a row is a pure function of (voxel, lights), Q18, so when it is built cannot show)
+    if (ld_lazy && (volpath || pixel_sampler)) { ld.lazy = reinterpret_cast<LightLazyWords*>(ld_lazy->lazy); ld.new_list = ld_lazy->new_list; }
+    static_assert(sizeof(LightLazyWords) == sizeof(LightLazy), "LightLazyWords mirrors LightLazy");
+    // the claimed voxels' rows: contributions of every light, the row's distribution, the table entries; returns how many were claimed
+    auto build_claimed_rows = [&](uint32_t* n_claimed) -> int {
+        LightLazy lz;
+        HIP_TRY(hipMemcpyAsync(g.look, ld_lazy->lazy, sizeof lz, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        memcpy(&lz, g.look, sizeof lz);
+        *n_claimed = lz.n_new;
+        if (lz.overflow) return fail(RSPT_E_NOMEM, "spatial light distribution: more than %u voxels were touched; raise RSPT_LIGHT_TABLE_POOL_BYTES", lz.max_rows);
+        if (lz.n_new == 0) return RSPT_OK;
+        const uint32_t lgrid = grid_for(4);
+        hipLaunchKernelGGL(k_ld_contrib_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld.nvox[0], ld.nvox[1], ld.nvox[2], ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func);
+        hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
+        hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
+        return RSPT_OK;
+    };
 
     // ---- this shard's pixels: Morton-ordered tiles (blockqueue/mod.rs:23-52), row-major inside a tile ----
     const int32_t ts = (int32_t)d->tile_size;
@@ -946,8 +964,25 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             vol_rays += live;
             ev_open(2, 0);
             if (s->has_textures) hipLaunchKernelGGL(k_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][1], &cur->closest, (const uint32_t*)nullptr, (const BinInfo*)nullptr);
+            if (ld.lazy) HIP_TRY(hipMemsetAsync(&cur->active, 0, sizeof(uint32_t), g.stream));   // (k_raygen leaves the batch size there; volpath itself does not use the active queues)
             hipLaunchKernelGGL(s->has_dynamic ? k_vol_shade<true> : k_vol_shade<false>, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol, g.q[par][1], &cur->closest,
-                               g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits);
+                               g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits, ld.lazy ? g.q[par][0] : (uint32_t*)nullptr, &cur->active);
+            // on-demand light voxels: paths whose voxel had no row were put back (q[par][0], counted in cur->active, zero until here); build the rows, run those paths
+            for (uint32_t round = 0; ld.lazy; round++) {
+                uint32_t claimed = 0;
+                if ((rc = build_claimed_rows(&claimed))) return rc;
+                HIP_TRY(hipMemcpyAsync(g.look, cur, sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                const uint32_t n_retry = g.look[0].active;
+                if (n_retry == 0) break;
+                if (round > 64) return fail(RSPT_E_HIP, "volpath: on-demand light voxels did not settle");
+                // the retry queue becomes the input (copied to the other parity's active queue, which volpath does not use either), its counter starts again
+                HIP_TRY(hipMemcpyAsync(g.q[par ^ 1][0], g.q[par][0], (size_t)n_retry * sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
+                HIP_TRY(hipMemcpyAsync(&cur->any, &cur->active, sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));   // (cur->any: the retry run's input length)
+                HIP_TRY(hipMemsetAsync(&cur->active, 0, sizeof(uint32_t), g.stream));
+                hipLaunchKernelGGL(s->has_dynamic ? k_vol_shade<true> : k_vol_shade<false>, dim3(dgrid), dim3(256), halton ? 0 : vnd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.vol,
+                                   g.q[par ^ 1][0], &cur->any, g.q[par ^ 1][1], &nxt->closest, g.q[0][2], &g.cnt[2].closest, vlimit, vnd, sob_bits, g.q[par][0], &cur->active);
+            }
             ev_close(2, 0);
             // VisibilityTester::tr: segments until every shadow ray has arrived or is blocked
             // (the first two segments are launched without looking at the queue: most shadow rays cross at most one boundary, an
@@ -1219,7 +1254,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         if ((size_t)n_tiles * rows * ts * spp > ((size_t)1 << 31)) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: %u tiles x %u spp do not fit one pass", n_tiles, spp);
         struct Guard { std::vector<void*> p; ~Guard() { for (void* q : p) (void)hipFree(q); } } guard;
         auto tmp = [&](auto** p, size_t n) { int r = dev_alloc(p, std::max<size_t>(n, 1)); if (!r) guard.p.push_back(*p); return r; };
-        TileRec* tiles_d = nullptr; float4* samp_L = nullptr; float2* samp_pf = nullptr; float* a1 = nullptr; float2* a2 = nullptr; uint64_t* rng_state = nullptr;
+        TileRec* tiles_d = nullptr; float4* samp_L = nullptr; float2* samp_pf = nullptr; float* a1 = nullptr; float2* a2 = nullptr; uint64_t* rng_state = nullptr; uint64_t* rng_saved = nullptr;
         // the integrator's 2-D sample arrays (request_2d_array in preprocess): ao one of n_samples (ao.rs:47-49); directlighting, strategy all,
         // two per light and recursion level (directlighting.rs:54-70)
         float2* arr = nullptr; uint32_t* arr_sz_d = nullptr; uint32_t* arr_base_d = nullptr; int32_t* nls_d = nullptr;
@@ -1245,7 +1280,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         uint32_t* c_pixel_d = nullptr; uint32_t* trunc_d = nullptr; uint32_t* pass_pix = nullptr;
         const size_t max_samples = (size_t)n_tiles * rows * ts * spp;
         if ((rc = tmp(&tiles_d, n_tiles)) || (rc = tmp(&samp_L, max_samples)) || (rc = tmp(&samp_pf, max_samples)) || (rc = tmp(&a1, (size_t)nd * spp * n_tiles)) ||
-            (rc = tmp(&a2, (size_t)nd * spp * n_tiles)) || (rc = tmp(&rng_state, 2 * (size_t)n_tiles)) || (rc = tmp(&c_pixel_d, 32)) || (rc = tmp(&trunc_d, 1)) ||
+            (rc = tmp(&a2, (size_t)nd * spp * n_tiles)) || (rc = tmp(&rng_state, 2 * (size_t)n_tiles)) || (rc = tmp(&rng_saved, ld.lazy ? 2 * (size_t)n_tiles : 1)) || (rc = tmp(&c_pixel_d, 32)) || (rc = tmp(&trunc_d, 2)) ||
             (rc = tmp(&pass_pix, (size_t)n_tiles * rows * ts)))
             return rc;
         HIP_TRY(hipMemsetAsync(trunc_d, 0, sizeof(uint32_t), g.stream));
@@ -1273,6 +1308,19 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             HIP_TRY(hipMemcpyAsync(tiles_d, tiles.data(), n_tiles * sizeof(TileRec), hipMemcpyHostToDevice, g.stream));
             HIP_TRY(hipMemcpyAsync(pass_pix, pl.data(), pl.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
             const dim3 grid((n_tiles + lanes - 1) / lanes);
+            // on-demand light voxels: a lane claims the voxels it finds without a row (dev_scene.h light_row_try) and goes on with row 0; the claimed rows are
+            // built and the rows of the tiles rendered again from the saved generator states, until a run claims nothing — only that run's samples are kept
+            // (a wrong row can change how many dimensions an estimate draws, so a run may leave the true paths after its first missing voxel: each
+            // round completes at least the first one along every true chain)
+            if (ld.lazy) {
+                HIP_TRY(hipMemcpyAsync(rng_saved, rng_state, 2 * (size_t)n_tiles * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+                HIP_TRY(hipMemcpyAsync(trunc_d + 1, trunc_d, sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
+            }
+            for (uint32_t lazy_round = 0;; lazy_round++) {
+            if (ld.lazy && lazy_round > 0) {
+                HIP_TRY(hipMemcpyAsync(rng_state, rng_saved, 2 * (size_t)n_tiles * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+                HIP_TRY(hipMemcpyAsync(trunc_d, trunc_d + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
+            }
             ev_open(2, 0);
 #define RSPT_TS(I, A, O) hipLaunchKernelGGL((k_tile_serial<I, A, O>), grid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, g.pb, pd, tiles_d, n_tiles, lanes, r0, r1, samp_L, samp_pf, serial_iters, trunc_d)
             if (ao) {
@@ -1291,6 +1339,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             else { if (s->has_alpha) RSPT_TS(false, true, 0); else RSPT_TS(false, false, 0); }
 #undef RSPT_TS
             ev_close(2, 0);
+            if (!ld.lazy) break;
+            uint32_t claimed = 0;
+            if ((rc = build_claimed_rows(&claimed))) return rc;
+            if (claimed == 0) break;
+            if (lazy_round > 64) return fail(RSPT_E_HIP, "pixel sampler: on-demand light voxels did not settle");
+            }
             const uint32_t npx = (uint32_t)pl.size();
             Batch bt{0u, npx, 0u, spp, npx * spp};
             samples += bt.n;

@@ -105,8 +105,12 @@ struct VolRef {        // Interaction::get_common of the reference point
 };
 template <typename F>
 RDEV bool vol_estimate(const SceneDev& sc, const LightDistDev& ld, const RenderDev& rd, const PathBuf& pb, const VolBuf& vb, uint32_t p, VolSampler& smp,
-                       const VolRef& it, rgb beta, F&& scatter /* (wi, &pdf) -> f */) {
-    const uint32_t vox = light_row(ld, light_voxel(sc, ld, it.p));
+                       const VolRef& it, rgb beta, bool* retry, F&& scatter /* (wi, &pdf) -> f */) {
+    // on-demand spatial distribution: a voxel without a row yet is claimed (light_row_try) and the path is put back, untouched, for the run
+    // that follows the build of the claimed rows (librspt.hip batch_volpath) — nothing of this pass has been written for it at this point
+    const int32_t row = light_row_try(ld, light_voxel(sc, ld, it.p));
+    if (row < 0 && ld.lazy) { *retry = true; return false; }
+    const uint32_t vox = row < 0 ? 0u : (uint32_t)row;
     float pdf_choice = 0.0f;
     const uint32_t light_num = sample_discrete(ld.func + (size_t)vox * sc.n_lights, ld.cdf + (size_t)vox * (sc.n_lights + 1), ld.func_int[vox], sc.n_lights, smp.get_1d(rd), &pdf_choice);
     if (pdf_choice == 0.0f) return false;
@@ -142,7 +146,8 @@ RDEV bool vol_estimate(const SceneDev& sc, const LightDistDev& ld, const RenderD
 template <bool DYN>
 __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ q_next, uint32_t* cnt_next,
-                                                   uint32_t* __restrict__ q_tr, uint32_t* cnt_tr, uint32_t dim_limit, uint32_t sob_nd, uint32_t sob_bits) {
+                                                   uint32_t* __restrict__ q_tr, uint32_t* cnt_tr, uint32_t dim_limit, uint32_t sob_nd, uint32_t sob_bits,
+                                                   uint32_t* __restrict__ q_retry, uint32_t* cnt_retry) {
     extern __shared__ uint32_t sob_tab[];  // Sobol' generator matrices of the dimensions a path can reach, transposed to [bit][dim] (as k_shade)
     for (uint32_t t = threadIdx.x; rd.sampler_kind == RSPT_SAMPLER_SOBOL && t < sob_nd * sob_bits; t += 256u) {
         const uint32_t dd = t % sob_nd;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
     const uint32_t n = *count_in;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
-        bool go_on = false, shadow = false;
+        bool go_on = false, shadow = false, retry = false;
         uint32_t p = 0;
         if (i < n) {
             p = queue[i];
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                             const f3 wo = -ray_d;
                             if (sc.n_lights) {
                                 const VolRef it{mi_p, f3{0.0f, 0.0f, 0.0f}, f3{0.0f, 0.0f, 0.0f}, wo, medium, medium};
-                                shadow = vol_estimate(sc, ld, rd, pb, vb, p, smp, it, beta, [&](f3 wi, float* pdf) {
+                                shadow = vol_estimate(sc, ld, rd, pb, vb, p, smp, it, beta, &retry, [&](f3 wi, float* pdf) {
                                     const float ph = phase_hg(dot(wo, wi), g);  // HenyeyGreenstein::p (medium.rs:302-305)
                                     *pdf = ph;
                                     return mkrgb(ph);
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                                 if (sc.n_lights) {  // no non-specular-lobe test in front of the estimate here (:146-161)
                                     const VolRef it{h.p, h.p_err, h.n, wo, m_in, m_out};
                                     const uint32_t nonspec = BX_ALL & ~BX_SPEC;
-                                    shadow = vol_estimate(sc, ld, rd, pb, vb, p, smp, it, beta, [&](f3 wi, float* pdf) {
+                                    shadow = vol_estimate(sc, ld, rd, pb, vb, p, smp, it, beta, &retry, [&](f3 wi, float* pdf) {
                                         const rgb f = b.f(wo, wi, nonspec) * mkrgb(absdot(wi, h.sh_n));
                                         *pdf = b.pdf(wo, wi, nonspec);
                                         return f;
@@ -338,6 +343,8 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                     }
                 }
             }
+            if (retry) { go_on = false; shadow = false; }   // the voxel of this path's light estimate is being built: the path runs again, from the state it came with
+            else {
             if (go_on) {
                 store_ray(pb.ray_cont + p, new_o, new_d, RSPT_INF, p);
                 pb.beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
@@ -348,9 +355,11 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
             pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
             st = (st & ~(ST_DIM_MASK | (0xffu << ST_BOUNCE_SHIFT) | ST_SPECULAR)) | (smp.dim() & ST_DIM_MASK) | ((bounces & 0xffu) << ST_BOUNCE_SHIFT) | (specular ? ST_SPECULAR : 0u);
             pb.state[p] = st;
+            }
         }
         dl_push(go_on, p, q_next, cnt_next);
         dl_push(shadow, p, q_tr, cnt_tr);
+        if (q_retry) dl_push(retry, p, q_retry, cnt_retry);
     }
 }
 
