@@ -52,6 +52,11 @@ struct SceneDev {
     uint32_t n_media;
     const rspt_mat::DynMaterial* dyn;  // per material, valid where mat_flags has RSPT_MAT_DYNAMIC (material_assembly.h); nullptr = none
     uint32_t n_grid_media;       // GridDensityMedium records among media[] (their density pointers are device pointers, pad = 1 / max density as float bits)
+    // the four-box records of trace_w4.h for the per-lane kernels (trace_serial.h traverse_w4): Wide4Node array, the big-leaf table, the root
+    // reference; w4 = nullptr where the scene has none in the plain form (object instances, alpha masks, more records than a reference holds)
+    const void* w4;
+    const uint2* w4_big;
+    uint32_t w4_root;
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)

@@ -30,7 +30,7 @@ struct DlSerial {
     uint32_t dyn_stride;
 
     const SceneDev& sc() const { return base.sc; }
-    RDEV bool occluded(f3 o, f3 d, float t_max) { return traverse<true, INST, ALPHA, 64>(base.sc, base.tt, o, d, t_max, base.lds).prim != RSPT_MISS; }
+    RDEV bool occluded(f3 o, f3 d, float t_max) { return serial_trace<true, INST, ALPHA>(base.sc, base.tt, o, d, t_max, base.lds).prim != RSPT_MISS; }
 
     // estimate_direct (integrator.rs:406-570), handle_media = false, specular = false
     RDEVN rgb estimate_direct(const SerialHit& it, const Bsdf& bsdf, f2 u_scattering, uint32_t light_num, f2 u_light) {

@@ -2130,6 +2130,11 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         s->w4_ok = recs.size() <= RSPT_W4_OFFSET_MASK && big.size() <= RSPT_W4_OFFSET_MASK;
         if (s->w4_ok && !recs.empty() && (rc = upload(s, recs.data(), recs.size(), &s->w4))) return bail(rc);
         if (!big.empty() && (rc = upload(s, big.data(), big.size(), &s->big_leaves))) return bail(rc);
+        bool any_alpha = false;
+        for (uint32_t i = 0; i < d->n_meshes; i++) any_alpha = any_alpha || d->meshes[i].alpha_tex || d->meshes[i].shadow_alpha_tex;
+        if (s->w4_ok && !instanced && !any_alpha && env_size("RSPT_SERIAL_W4", 1) != 0) {   // the per-lane kernels' traversal (trace_serial.h)
+            s->dev.w4 = s->w4; s->dev.w4_big = s->big_leaves; s->dev.w4_root = s->w4_root;
+        }
     }
     if (d->n_prims) {
         float4* tris = nullptr;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                     continue;
                 }
                 if (MODE == 1) {
-                    const TraceResult res = traverse<false, INST, ALPHA, 64>(sc, tt, o, d, t_max, lds);
+                    const TraceResult res = serial_trace<false, INST, ALPHA>(sc, tt, o, d, t_max, lds);
                     float l = 0.0f;
                     if (res.prim != RSPT_MISS) {
                         const TriRec tri = load_tri(sc, res.prim);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                             }
                             wi = f3{sv.x * wi.x + tv.x * wi.y + n.x * wi.z, sv.y * wi.x + tv.y * wi.y + n.y * wi.z, sv.z * wi.x + tv.z * wi.y + n.z * wi.z};
                             if (pdf != 0.0f) {
-                                const TraceResult occ = traverse<true, INST, ALPHA, 64>(sc, tt, offset_ray_origin(hp.p, hp.p_err, hp.n, wi), wi, RSPT_INF, lds);
+                                const TraceResult occ = serial_trace<true, INST, ALPHA>(sc, tt, offset_ray_origin(hp.p, hp.p_err, hp.n, wi), wi, RSPT_INF, lds);
                                 if (occ.prim == RSPT_MISS) l += dot(wi, n) / (pdf * (float)arr_n);
                             }
                         }
@@ -145,20 +145,20 @@ __global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, L
                     if (so.cont) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = traverse<false, INST, ALPHA, 64>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = serial_trace<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
                         pb.hit_cont[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
                         if (INST && pb.hit_inst) pb.hit_inst[slot] = res.inst;
                     }
                     if (so.mis) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_mis + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = traverse<false, INST, ALPHA, 64>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = serial_trace<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
                         pb.hit_mis[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
                     }
                     if (so.shadow) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_sh + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = traverse<true, INST, ALPHA, 64>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = serial_trace<true, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
                         pb.occluded[slot] = res.prim != RSPT_MISS ? 1u : 0u;
                     }
                     if (sc.mat_flags && so.cont) texture_path(sc, tt, rd, pb, slot, &p_lens);   // the texture stage k_texture runs in front of k_shade

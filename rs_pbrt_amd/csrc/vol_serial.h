@@ -11,6 +11,7 @@
 // media in the scene the walk is made); then the direction sample get_2d and the roulette's get_1d.
 #pragma once
 #include "vol.h"
+#include "trace_serial.h"
 
 namespace rspt {
 
@@ -120,7 +121,7 @@ struct VolSerial {
     uint32_t max_walk;     // cap on passes through BSDF-less surfaces / shadow-ray segments (the reference has none)
     bool truncated;
 
-    RDEV TraceResult closest(f3 o, f3 d, float t_max) { return traverse<false, INST, ALPHA, 64>(sc, tt, o, d, t_max, lds); }
+    RDEV TraceResult closest(f3 o, f3 d, float t_max) { return serial_trace<false, INST, ALPHA>(sc, tt, o, d, t_max, lds); }
     // Medium::tr over a ray whose t_max is where its traversal left it
     RDEV rgb medium_tr(uint32_t medium, f3 o, f3 d, float t_max) {
         const rspt_medium& m = sc.media[medium - 1u];
