@@ -1286,10 +1286,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         HIP_TRY(hipMemsetAsync(trunc_d, 0, sizeof(uint32_t), g.stream));
         if (d->sampler_kind == RSPT_SAMPLER_MAXMINDIST) HIP_TRY(hipMemcpyAsync(c_pixel_d, d->maxmin_c_pixel, 32 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
         const PixDesc pd{d->sampler_kind, spp, d->sampler_kind == RSPT_SAMPLER_RANDOM ? 0u : nd, d->strat_x, d->strat_y, d->strat_jitter, c_pixel_d, a1, a2, rng_state, arr, arr_sz_d, arr_base_d, (uint32_t)arr_sz.size(), arr_total, d->ao_cos_sample, nls_d, d->direct_strategy, dl_tex, dl_tex_rows, dl_dyn};
-        // lanes per wave: a lane that shares its wave waits whenever the others diverge, so spread the tiles over as many waves
-        // as the chip holds (256 CUs x 4 SIMDs x 2) before doubling up
+        // lanes per wave: a lane that shares its wave waits whenever the others diverge (measured: four lanes of a wave take four times one lane's
+        // time — no overlap at all), so the tiles are spread over waves, up to twice what the chip holds at these kernels' 2 waves / SIMD
+        // (256 CUs x 4 SIMDs x 2 = 2048) before doubling up: C3 frame, 8160 tiles, 02sequence — 2048: 21.9, 4096: 24.7, 8192: 21.7 Msamples/s;
+        // builds forced to 3 / 4 waves per SIMD (168 / 128 VGPRs, 2.3 / 2.5 KB of scratch) lose to the spills: 17.8 - 21.5
         uint32_t lanes = 1;
-        while (lanes < 64 && (n_tiles + lanes - 1) / lanes > (uint32_t)env_size("RSPT_SERIAL_WAVES", 2048)) lanes *= 2;
+        while (lanes < 64 && (n_tiles + lanes - 1) / lanes > (uint32_t)env_size("RSPT_SERIAL_WAVES", 4096)) lanes *= 2;
         if (s->has_dynamic && (rc = ensure_dyn_built(((n_tiles + lanes - 1) / lanes) * 64u))) return rc;   // one lobe record per thread of the launch
         PathBuf fpb = g.pb;
         fpb.L_eta = samp_L; fpb.p_film = samp_pf;

@@ -41,8 +41,13 @@ struct PixDesc {              // the sampler's parameters and this render's vect
 // geometry, arr_n hemisphere directions from get_2d_array, one any-hit traversal each, the unoccluded terms added in array order.
 // 2: VolPathIntegrator::li (vol_serial.h), homogeneous and grid media.  3: DirectLightingIntegrator::li (dl_serial.h).
 // 4: PathIntegrator::li over a scene with dynamic materials (shade_path<.., SF_ALL>: lobe lists built per hit, material_assembly.h).
+#ifdef RSPT_TS_WAVES   // A/B: the per-tile kernels built for that many waves per SIMD (what does not fit the budget is spilled)
+#define RSPT_TS_ATTR __attribute__((amdgpu_waves_per_eu(RSPT_TS_WAVES, RSPT_TS_WAVES)))
+#else
+#define RSPT_TS_ATTR
+#endif
 template <bool INST, bool ALPHA, int MODE = 0>
-__global__ __launch_bounds__(64) void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
+__global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, PathBuf pb, PixDesc pd, const TileRec* __restrict__ tiles,
                                                     uint32_t n_tiles, uint32_t lanes_per_wave, int32_t row0, int32_t row1, float4* __restrict__ samp_L,
                                                     float2* __restrict__ samp_pf, uint32_t max_iters, uint32_t* __restrict__ truncated) {
     __shared__ uint32_t stack[RSPT_LDS_STACK * 64];   // 32 levels x the block's 64 columns
