@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 19
+#define RSPT_ABI_VERSION 20
 
 /* error codes */
 #define RSPT_OK 0
@@ -307,7 +307,20 @@ typedef struct {
     uint32_t object;     /* index into objects[]                                       */
     float to_world[16];  /* primitive_to_world.start_transform.m, row major            */
     float from_world[16];/* ... .m_inv (the reference inverts once, Transform holds both) */
-} rspt_instance;
+    /* A moving instance (ABI 20): TransformedPrimitive.primitive_to_world is an AnimatedTransform (primitive.rs:198-201,
+     * transform.rs:894-943).  animated = its actually_animated (the two key matrices differ); then to_world / from_world are
+     * start_transform at time[0], to_world_end / from_world_end are end_transform at time[1].  intersect / intersect_p
+     * interpolate at the ray's time (primitive.rs:216-222, :258-262; transform.rs:2081-2113: translation and scale linearly,
+     * rotation by slerp between the decomposed keys, m_inv as inverse(scale) * rotation^T * translate(-t)); the library does the
+     * same per instance visit.  The top-level aggregate's bounds of such a primitive are the reference's
+     * AnimatedTransform::motion_bounds (the shim passes the BVH rs_pbrt built; the library never computes them).
+     * Served by the `path` integrator under the Sobol' / Halton samplers; other integrators and the pixel samplers answer
+     * RSPT_E_UNSUPPORTED for a scene with a moving instance. */
+    uint32_t animated;
+    float to_world_end[16];
+    float from_world_end[16];
+    float time[2];
+} rspt_instance; /* 272 B */
 /* What a hit inside an instance is:
  * REFERENCE  what rs_pbrt v0.9.12 does: Transform::transform_surface_interaction drops isect.primitive (transform.rs:856), so
  *            the hit has no material and no emission and PathIntegrator::li passes straight through it like a null-material
@@ -436,8 +449,8 @@ typedef struct {
      * lerp(CameraSample.time, shutter_open, shutter_close)).  camera_animated = 0: camera_to_world for every ray.  1: camera_to_world is
      * start_transform.m at camera_time[0], camera_to_world_end is end_transform.m at camera_time[1] (api.rs transform_start_time /
      * transform_end_time); the library decomposes both (AnimatedTransform::decompose: translation, rotation quaternion, scale) and
-     * interpolates per ray (translation and scale linearly, rotation by slerp), start / end matrix outside the interval.  Object
-     * instances and lights do not move in this ABI (rspt_instance carries one matrix). */
+     * interpolates per ray (translation and scale linearly, rotation by slerp), start / end matrix outside the interval.  Lights
+     * do not move in this ABI; object instances do (rspt_instance, ABI 20). */
     uint32_t camera_animated;
     float camera_to_world_end[16];
     float camera_time[2];

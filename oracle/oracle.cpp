@@ -133,6 +133,14 @@ void orc_tex_eval(const rspt_scene_desc* d, uint32_t ti, const float* surf, floa
     out[0] = v.c[0]; out[1] = v.c[1]; out[2] = v.c[2];
 }
 // camera ray with its (scaled) differentials: out = o[3], d[3], rx_o[3], rx_d[3], ry_o[3], ry_d[3]
+// AnimatedTransform::interpolate (transform.rs:2081-2113) of a moving TransformedPrimitive at `time`: m and m_inv of the resulting Transform
+void orc_interpolate_transform(const float start_m[16], const float start_inv[16], float t0, const float end_m[16], const float end_inv[16], float t1, float time,
+                               float m_out[16], float inv_out[16]) {
+    const AnimatedTransform a(start_m, t0, end_m, t1);
+    M44 m, mi;
+    a.interpolate_full(time, m44_from(start_inv), m44_from(end_inv), &m, &mi);
+    std::memcpy(m_out, &m.m[0][0], 64); std::memcpy(inv_out, &mi.m[0][0], 64);
+}
 void orc_camera_ray_diff(const rspt_render_desc* rd, const float cs[5], float out[18]) {
     Ray r = camera_ray(*rd, P2{cs[0], cs[1]}, cs[2], P2{cs[3], cs[4]});
     r.scale_differentials(1.0f / std::sqrt((Float)rd->spp));

@@ -154,6 +154,25 @@ struct AnimatedTransform {
         tr.m[0][3] = trans.x; tr.m[1][3] = trans.y; tr.m[2][3] = trans.z;
         return m44_mul(m44_mul(tr, quat_to_matrix(rotate)), scale); // Transform::translate(&trans) * rotate.to_transform() * Transform { m: scale, .. }
     }
+    // the whole Transform interpolate leaves (:2106-2112): m as above, m_inv as the reverse product of the factors' inverses
+    // (Transform * Transform = { mtx_mul(a.m, b.m), mtx_mul(b.m_inv, a.m_inv) }, transform.rs:869-877): translate's is translate(-t)
+    // (:316-327), the quaternion's the transpose of its m (quaternion.rs:102-106), the scale's Matrix4x4::inverse(&scale) (:2111).
+    // Outside the interval the key Transforms themselves come back, with the inverses they were built with (start_inv / end_inv).
+    void interpolate_full(Float time, const M44& start_inv, const M44& end_inv, M44* m, M44* m_inv) const {
+        if (!actually_animated || time <= start_time) { *m = start; *m_inv = start_inv; return; }
+        if (time >= end_time) { *m = end; *m_inv = end_inv; return; }
+        Float dt = (time - start_time) / (end_time - start_time);
+        V3 trans = t[0] * (1.0f - dt) + t[1] * dt;
+        Quat rotate = quat_slerp(dt, r[0], r[1]);
+        M44 scale = m44_identity();
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) scale.m[i][j] = lerp(dt, s[0].m[i][j], s[1].m[i][j]);
+        M44 tr = m44_identity(), tr_inv = m44_identity();
+        tr.m[0][3] = trans.x; tr.m[1][3] = trans.y; tr.m[2][3] = trans.z;
+        tr_inv.m[0][3] = -trans.x; tr_inv.m[1][3] = -trans.y; tr_inv.m[2][3] = -trans.z;
+        const M44 rot = quat_to_matrix(rotate), rot_inv = m44_transpose(rot);
+        *m = m44_mul(m44_mul(tr, rot), scale);
+        *m_inv = m44_mul(m44_inverse(scale), m44_mul(rot_inv, tr_inv));
+    }
     Ray transform_ray(const Ray& r) const { // :2114-2124
         M44 m = interpolate(r.time);
         return orc::transform_ray(&m.m[0][0], r);

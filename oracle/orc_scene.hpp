@@ -6,6 +6,7 @@
 
 #include "../include/rspt.h" // POD scene structs only (interface header, no product code)
 #include "orc_math.hpp"
+#include "orc_animated.hpp"
 
 namespace orc {
 
@@ -559,7 +560,9 @@ struct Scene {
         if (pr.mesh == RSPT_MESH_INSTANCE) { // TransformedPrimitive::intersect_p primitive.rs:258-265
             const rspt_instance& in = d.instances[pr.v[0]];
             const rspt_object& o = d.objects[in.object];
-            Ray r2 = transform_ray(in.from_world, ray);
+            Float to_world[16], from_world[16];
+            instance_transform(in, ray.time, to_world, from_world);   // primitive_to_world.interpolate(r.time), then its inverse (:259-262)
+            Ray r2 = transform_ray(from_world, ray);
             if (!o.n_nodes && c) c->tris_tested++; // (counter convention: every primitive test counts, also the lone primitive of an object)
             return o.n_nodes ? bvh_intersect_p((uint32_t)o.first_node, r2, c) : prim_intersect_p((uint32_t)o.first_prim, r2, c);
         }
@@ -567,9 +570,20 @@ struct Scene {
         return tri_hit_test(pr, ray, &t, b) && alpha_pass(pr, ray, b, true);
     }
     // ---- TransformedPrimitive::intersect: primitive.rs:216-253 (static transform: interpolate() returns start_transform) ----
+    // AnimatedTransform::interpolate (transform.rs:2081-2113) of a TransformedPrimitive's primitive_to_world at the ray's time: the start
+    // Transform for a static instance (and before the interval), the end Transform after it, the product of the interpolated factors inside
+    static void instance_transform(const rspt_instance& in, Float time, Float* to_world, Float* from_world) {
+        if (!in.animated) { std::memcpy(to_world, in.to_world, 64); std::memcpy(from_world, in.from_world, 64); return; }
+        const AnimatedTransform a(in.to_world, in.time[0], in.to_world_end, in.time[1]);
+        M44 m, mi;
+        a.interpolate_full(time, m44_from(in.from_world), m44_from(in.from_world_end), &m, &mi);
+        std::memcpy(to_world, &m.m[0][0], 64); std::memcpy(from_world, &mi.m[0][0], 64);
+    }
     bool transformed_intersect(uint32_t k, const Ray& r, Interaction* isect, Counters* c, Float* t_out, Float* b_out) const {
-        const rspt_instance& in = d.instances[k];
-        const rspt_object& o = d.objects[in.object];
+        const rspt_instance& in0 = d.instances[k];
+        const rspt_object& o = d.objects[in0.object];
+        struct { Float to_world[16], from_world[16]; } in;
+        instance_transform(in0, r.time, in.to_world, in.from_world);
         Ray ray = transform_ray(in.from_world, r); // Transform::inverse(&interpolated_prim_to_world).transform_ray(r)
         ray.has_diff = false;                      // (differentials are not used below this point)
         if (!o.n_nodes && c) c->tris_tested++;

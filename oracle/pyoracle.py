@@ -84,6 +84,8 @@ def lib():
         L.orc_spatial_voxel.argtypes = [C.c_void_p] * 6
         L.orc_tex_eval.restype = None; L.orc_tex_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_camera_ray_diff.restype = None; L.orc_camera_ray_diff.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_interpolate_transform.restype = None
+        L.orc_interpolate_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orc_compute_differentials.restype = None; L.orc_compute_differentials.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_bump.restype = None; L.orc_bump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _LIB = L
@@ -222,3 +224,13 @@ def grid_sample(density, sigma_a, sigma_s, g, o, d, t_max, u, world_to_medium=No
                                out.ctypes.data, C.addressof(used))
     assert rc == 0, "sample stream too short"
     return dict(beta=out[:3].copy(), sampled=bool(out[3]), p=out[4:7].copy(), wo=out[7:10].copy(), used=used.value)
+
+
+def interpolate_transform(start_m, t0, end_m, t1, time, start_inv=None, end_inv=None, want_inverse=False):
+    """AnimatedTransform::interpolate (transform.rs:2081-2113) between two key matrices (4 x 4, row major): the Transform's m (and m_inv)"""
+    a = np.ascontiguousarray(start_m, np.float32).reshape(16); b = np.ascontiguousarray(end_m, np.float32).reshape(16)
+    ai = np.ascontiguousarray(np.linalg.inv(a.reshape(4, 4).astype(np.float64)) if start_inv is None else start_inv, np.float32).reshape(16)
+    bi = np.ascontiguousarray(np.linalg.inv(b.reshape(4, 4).astype(np.float64)) if end_inv is None else end_inv, np.float32).reshape(16)
+    m, mi = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    lib().orc_interpolate_transform(a.ctypes.data, ai.ctypes.data, float(t0), b.ctypes.data, bi.ctypes.data, float(t1), float(time), m.ctypes.data, mi.ctypes.data)
+    return (m.reshape(4, 4), mi.reshape(4, 4)) if want_inverse else m.reshape(4, 4)

@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM, E_PEER = 0, -1, -2, -3, -4, -5, -6
 
@@ -163,7 +163,7 @@ TEXTURE_DT = np.dtype([("kind", "<u4"), ("mapping", "<u4"), ("map", "<f4", 8), (
                        ("octaves", "<i4"), ("omega", "<f4"), ("scale", "<f4"), ("variation", "<f4")])
 LIGHT_DT = np.dtype([("kind", "<u4"), ("prim", "<u4"), ("L", "<f4", 3), ("two_sided", "<u4"), ("p", "<f4", 24)])
 OBJECT_DT = np.dtype([("first_node", "<u8"), ("n_nodes", "<u8"), ("first_prim", "<u8"), ("n_prims", "<u8")])
-INSTANCE_DT = np.dtype([("object", "<u4"), ("to_world", "<f4", 16), ("from_world", "<f4", 16)])
+INSTANCE_DT = np.dtype([("object", "<u4"), ("to_world", "<f4", 16), ("from_world", "<f4", 16), ("animated", "<u4"), ("to_world_end", "<f4", 16), ("from_world_end", "<f4", 16), ("time", "<f4", 2)])
 RAY_DT = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("id", "<u4")])
 HIT_DT = np.dtype([("prim", "<u4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4")])
 

@@ -22,7 +22,8 @@ struct InstDev {
     uint32_t first_prim;  // the object's first primitive
     uint32_t w4_root;     // k_trace_w4's reference to the object's root record (or leaf reference of a one-leaf aggregate)
     uint32_t identity;    // Transform::is_identity(primitive_to_world) (transform.rs:291-308)
-    uint32_t pad[4];
+    uint32_t anim;        // a moving instance: index into SceneDev::inst_anim (m / mi / identity above are then the START key's); RSPT_MISS = static
+    uint32_t pad[3];
 };
 
 struct SceneDev {
@@ -57,6 +58,9 @@ struct SceneDev {
     const void* w4;
     const uint2* w4_big;
     uint32_t w4_root;
+    const struct InstAnim* inst_anim;   // the keys of the moving instances (inst_at); nullptr = none
+    const float* ray_time;              // [path slot] Ray.time of the path's rays (the camera sample's time, perspective.rs:226), set by rspt_render while a
+                                        // scene with moving instances is rendered; nullptr = time 0 (rspt_trace)
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)
@@ -691,19 +695,9 @@ RDEV void mat4_mul(const float* a, const float* b, float* r) {  // mtx_mul (tran
 #pragma unroll
         for (int j = 0; j < 4; j++) r[4 * i + j] = a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j] + a[4 * i + 2] * b[8 + j] + a[4 * i + 3] * b[12 + j];
 }
-RDEVN void camera_to_world_at(const RenderDev& rd, float time_sample, float* m) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) m[i] = rd.camera_to_world[i];
-    const CamAnim* ca = rd.cam_anim;
-    if (!ca) return;
-    const float time = rd.shutter_open * (1.0f - time_sample) + rd.shutter_close * time_sample;  // pbrt.rs lerp
-    if (time <= ca->time[0]) return;
-    if (time >= ca->time[1]) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) m[i] = ca->end[i];
-        return;
-    }
-    const float dt = (time - ca->time[0]) / (ca->time[1] - ca->time[0]);
+// the factors AnimatedTransform::interpolate multiplies for a time inside the interval (transform.rs:2091-2105), dt in (0, 1): translate(trans).m,
+// rotate.to_transform().m, the scale matrix
+RDEVN void anim_factors(const CamAnim* ca, float dt, float* tr, float* rot, float* scale) {
     const f3 t0{ca->t[0][0], ca->t[0][1], ca->t[0][2]}, t1{ca->t[1][0], ca->t[1][1], ca->t[1][2]};
     const f3 trans = t0 * (1.0f - dt) + t1 * dt;
     // quat_slerp (quaternion.rs:168-180)
@@ -731,19 +725,106 @@ RDEVN void camera_to_world_at(const RenderDev& rd, float time_sample, float* m) 
     // Quaternion::to_transform().m (quaternion.rs:80-109): the transpose of the matrix written there
     const float xx = q[0] * q[0], yy = q[1] * q[1], zz = q[2] * q[2], xy = q[0] * q[1], xz = q[0] * q[2], yz = q[1] * q[2];
     const float wx = q[0] * q[3], wy = q[1] * q[3], wz = q[2] * q[3];
-    const float rot[16] = {1.0f - 2.0f * (yy + zz), 2.0f * (xy - wz), 2.0f * (xz + wy), 0.0f,
-                           2.0f * (xy + wz), 1.0f - 2.0f * (xx + zz), 2.0f * (yz - wx), 0.0f,
-                           2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (xx + yy), 0.0f,
-                           0.0f, 0.0f, 0.0f, 1.0f};
-    float scale[16] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    const float rot_[16] = {1.0f - 2.0f * (yy + zz), 2.0f * (xy - wz), 2.0f * (xz + wy), 0.0f,
+                            2.0f * (xy + wz), 1.0f - 2.0f * (xx + zz), 2.0f * (yz - wx), 0.0f,
+                            2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (xx + yy), 0.0f,
+                            0.0f, 0.0f, 0.0f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 16; i++) { rot[i] = rot_[i]; scale[i] = (i % 5 == 0) ? 1.0f : 0.0f; tr[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) scale[4 * i + j] = ca->s[0][4 * i + j] * (1.0f - dt) + ca->s[1][4 * i + j] * dt;
-    const float tr[16] = {1.0f, 0.0f, 0.0f, trans.x, 0.0f, 1.0f, 0.0f, trans.y, 0.0f, 0.0f, 1.0f, trans.z, 0.0f, 0.0f, 0.0f, 1.0f};
-    float tmp[16];
+    tr[3] = trans.x; tr[7] = trans.y; tr[11] = trans.z;
+}
+RDEVN void camera_to_world_at(const RenderDev& rd, float time_sample, float* m) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = rd.camera_to_world[i];
+    const CamAnim* ca = rd.cam_anim;
+    if (!ca) return;
+    const float time = rd.shutter_open * (1.0f - time_sample) + rd.shutter_close * time_sample;  // pbrt.rs lerp
+    if (time <= ca->time[0]) return;
+    if (time >= ca->time[1]) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i] = ca->end[i];
+        return;
+    }
+    const float dt = (time - ca->time[0]) / (ca->time[1] - ca->time[0]);
+    float tr[16], rot[16], scale[16], tmp[16];
+    anim_factors(ca, dt, tr, rot, scale);
     mat4_mul(tr, rot, tmp);      // Transform::translate(&trans) * rotate.to_transform()
     mat4_mul(tmp, scale, m);     //   * Transform { m: scale, .. }
+}
+
+// ---- a moving TransformedPrimitive (primitive.rs:198-265) at a ray's time ----
+struct InstAnim {        // per moving instance: what AnimatedTransform::new leaves (as for the camera) + the end key's stored inverse
+    CamAnim keys;        // keys.end = end_transform.m
+    float mi_end[12];    // end_transform.m_inv rows 0..2
+    uint32_t identity_end;
+    uint32_t pad[3];
+};
+// Matrix4x4::inverse (transform.rs:128-200): Gauss-Jordan elimination, the pivot the largest remaining element (later candidates win ties)
+RDEVN void mat4_inverse(const float* src, float* out) {
+    int col_of[4] = {0, 0, 0, 0}, row_of[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+    float a[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) a[i][j] = src[4 * i + j];
+    for (int step = 0; step < 4; step++) {
+        int pr = 0, pc = 0;
+        float best = 0.0f;
+        for (int r = 0; r < 4; r++) {
+            if (used[r] == 1) continue;
+            for (int c = 0; c < 4; c++) {
+                if (used[c] != 0) continue;
+                const float v = fabsf(a[r][c]);
+                if (v >= best) { best = v; pr = r; pc = c; }
+            }
+        }
+        used[pc] += 1;
+        if (pr != pc) for (int k = 0; k < 4; k++) { const float t = a[pr][k]; a[pr][k] = a[pc][k]; a[pc][k] = t; }
+        row_of[step] = pr; col_of[step] = pc;
+        const float pivinv = 1.0f / a[pc][pc];
+        a[pc][pc] = 1.0f;
+        for (int k = 0; k < 4; k++) a[pc][k] *= pivinv;
+        for (int r = 0; r < 4; r++) {
+            if (r == pc) continue;
+            const float save = a[r][pc];
+            a[r][pc] = 0.0f;
+            for (int k = 0; k < 4; k++) a[r][k] -= a[pc][k] * save;
+        }
+    }
+    for (int step = 3; step >= 0; step--)
+        if (row_of[step] != col_of[step])
+            for (int k = 0; k < 4; k++) { const float t = a[k][row_of[step]]; a[k][row_of[step]] = a[k][col_of[step]]; a[k][col_of[step]] = t; }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out[4 * i + j] = a[i][j];
+}
+// primitive_to_world.interpolate(r.time) (transform.rs:2081-2113) as an InstDev: the start Transform up to the start time (and for a static
+// instance), the end Transform from the end time on, in between translate(trans) * rotate.to_transform() * Transform { scale, inverse(scale) }
+// — m the product of the m's, m_inv the reverse product of the inverses (Transform * Transform, :869-877)
+RDEVN InstDev inst_at(const SceneDev& sc, uint32_t index, float time) {
+    InstDev in = sc.inst[index];
+    if (in.anim == RSPT_MISS || !sc.inst_anim) return in;
+    const InstAnim& an = sc.inst_anim[in.anim];
+    if (time <= an.keys.time[0]) return in;
+    if (time >= an.keys.time[1]) {
+        for (int i = 0; i < 12; i++) { in.m[i] = an.keys.end[i]; in.mi[i] = an.mi_end[i]; }
+        in.identity = an.identity_end;
+        return in;
+    }
+    const float dt = (time - an.keys.time[0]) / (an.keys.time[1] - an.keys.time[0]);
+    float tr[16], rot[16], scale[16], tmp[16], m[16], rot_t[16], tr_inv[16], scale_inv[16], mi[16];
+    anim_factors(&an.keys, dt, tr, rot, scale);
+    mat4_mul(tr, rot, tmp);
+    mat4_mul(tmp, scale, m);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { rot_t[4 * i + j] = rot[4 * j + i]; tr_inv[4 * i + j] = i == j ? 1.0f : 0.0f; }
+    tr_inv[3] = -tr[3]; tr_inv[7] = -tr[7]; tr_inv[11] = -tr[11];
+    mat4_inverse(scale, scale_inv);
+    mat4_mul(rot_t, tr_inv, tmp);        // (T * R).m_inv = R.m_inv * T.m_inv
+    mat4_mul(scale_inv, tmp, mi);        // ((T * R) * S).m_inv = S.m_inv * (T * R).m_inv
+    bool ident = true;                   // Transform::is_identity (transform.rs:291-308): m against the identity, element by element
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (m[4 * i + j] != (i == j ? 1.0f : 0.0f)) ident = false;
+    for (int i = 0; i < 12; i++) { in.m[i] = m[i]; in.mi[i] = mi[i]; }
+    in.identity = ident ? 1u : 0u;
+    return in;
 }
 
 // ---- PerspectiveCamera::generate_ray_differential (perspective.rs:190-280), differentials dropped ----

@@ -49,6 +49,7 @@ struct PathBuf {
     uint32_t* hit_inst;   // continuation ray's hit: 0 or 1 + instance (nullptr: scene without object instances)
     rspt_mat::Built* dyn_built;  // one per thread of the shade launch: where a dynamic material's lobes are built (nullptr: no dynamic material)
     uint32_t dyn_threads;
+    float* time;          // Ray.time of the path (perspective.rs:226), kept only while a scene with moving instances is rendered (nullptr otherwise)
 };
 
 struct QueueCounts {  // one per wavefront iteration
@@ -103,7 +104,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
     if (!sobol) {
         index = halton_index(rd, px, py, (uint64_t)s);
         fy = halton_dim(rd, index, 1); fx = halton_dim(rd, index, 0);
-        if (rd.cam_anim) p_lens.z = halton_dim(rd, index, 2);
+        if (rd.cam_anim || pb.time) p_lens.z = halton_dim(rd, index, 2);
         if (rd.lens_radius > 0.0f) { p_lens.x = halton_dim(rd, index, 3); p_lens.y = halton_dim(rd, index, 4); }
     } else {
         // sobol_interval_to_index / sobol_dim / sobol_pixel_dim (dev_scene.h) over the LDS copies: the same XORs
@@ -125,7 +126,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
             return clampf(sv - (float)pix, 0.0f, RSPT_ONE_MINUS_EPS);
         };
         fy = pixel_dim(1, py); fx = pixel_dim(0, px);
-        if (rd.cam_anim) p_lens.z = dim(2);
+        if (rd.cam_anim || pb.time) p_lens.z = dim(2);
         if (rd.lens_radius > 0.0f) { p_lens.x = dim(3); p_lens.y = dim(4); }
     }
     f2 p_film{(float)px + fx, (float)py + fy};
@@ -140,6 +141,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
     pb.sobol_index[i] = index;
     pb.state[i] = 5u | ST_ALIVE;  // dimensions 0..4 consumed by the camera sample
     pb.p_film[i] = make_float2(p_film.x, p_film.y);
+    if (pb.time) pb.time[i] = rd.shutter_open * (1.0f - p_lens.z) + rd.shutter_close * p_lens.z;   // lerp(sample.time, shutter_open, shutter_close)
     q_active[i] = i;
     q_closest[i] = i;
 }
@@ -225,7 +227,7 @@ struct TraceResult {
 // sc.inst_fixed: an identity instance shrinks t_max without reporting its hit, and its interaction survives only if some
 // other primitive of the top-level aggregate reports a hit (`hit` below is BVHAccel::intersect's flag, `res` its isect).
 template <bool ANY, bool INST, bool ALPHA, int STRIDE = RSPT_TRACE_BLOCK /* words between two levels of the LDS stack = columns (threads per block) */>
-RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */) {
+RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */, float time = 0.0f /* Ray.time: moving instances */) {
     TraceResult res;
     res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0; res.t_end = t_max;
     if (sc.n_nodes == 0) return res;
@@ -239,7 +241,7 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
     const f3 w_o = o, w_d = d;
     uint32_t inst = RSPT_MISS, sp_base = 0, w_leaf_i = 0, w_leaf_end = 0;
     float w_tmax = 0.0f;
-    bool hit = false, inst_hit = false;
+    bool hit = false, inst_hit = false, inst_ident = false;
     for (;;) {
         if (leaf_i < leaf_end) {
             const uint32_t pi = leaf_i++;
@@ -249,7 +251,14 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
                 inst = __float_as_uint(a.x);
                 const InstDev& in = sc.inst[inst];
                 w_leaf_i = leaf_i; w_leaf_end = leaf_end; w_tmax = t_max; sp_base = sp; inst_hit = false;
-                inst_ray(in, w_o, w_d, t_max, &o, &d, &t_max);
+                if (in.anim != RSPT_MISS) {   // a moving instance: primitive_to_world.interpolate(r.time) and its inverse (primitive.rs:218-222)
+                    const InstDev at = inst_at(sc, inst, time);
+                    inst_ident = at.identity != 0u;
+                    inst_ray(at, w_o, w_d, t_max, &o, &d, &t_max);
+                } else {
+                    inst_ident = in.identity != 0u;
+                    inst_ray(in, w_o, w_d, t_max, &o, &d, &t_max);
+                }
                 inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
                 ng0 = inv.x < 0.0f; ng1 = inv.y < 0.0f; ng2 = inv.z < 0.0f;
                 rs = ray_shear(d);
@@ -270,8 +279,7 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
         }
         if (cur == RSPT_MISS) {  // pop
             if (INST && inst != RSPT_MISS && sp == sp_base) {  // the object's traversal is over: back to world space
-                const InstDev& in = sc.inst[inst];
-                if (inst_hit) { if (sc.inst_fixed || !in.identity) hit = true; }  // primitive.rs:226-253: r.t_max.set(ray.t_max) either way
+                if (inst_hit) { if (sc.inst_fixed || !inst_ident) hit = true; }  // primitive.rs:226-253: r.t_max.set(ray.t_max) either way
                 else t_max = w_tmax;
                 o = w_o; d = w_d;
                 inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
@@ -330,7 +338,8 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTabl
         bool mis = (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
-        TraceResult res = traverse<ANY, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        const float time = (INST && OUT_MODE == 0 && sc.ray_time) ? sc.ray_time[slot] : 0.0f;
+        TraceResult res = traverse<ANY, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x, time);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
             else {
@@ -466,8 +475,12 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         f3 wo = -ray_d;  // SurfaceInteraction.wo, not normalised (triangle.rs:334)
         if ((F & SF_INST) && pb.hit_inst) {  // the hit lies inside an object instance: TransformedPrimitive::intersect (primitive.rs:216-253)
             const uint32_t hi = pb.hit_inst[p];
-            if (hi && !sc.inst[hi - 1u].identity) {
-                const InstDev& in = sc.inst[hi - 1u];
+            const bool moving = hi && sc.inst[hi - 1u].anim != RSPT_MISS;   // (rare: the interpolated Transform of the path's time, as the traversal used it)
+            InstDev moved;
+            if (moving) moved = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f);
+            const InstDev& in_ref = moving ? moved : sc.inst[hi ? hi - 1u : 0u];
+            if (hi && !in_ref.identity) {
+                const InstDev& in = in_ref;
                 inst_hit(in, &h);  // transform_surface_interaction (transform.rs:815-860)
                 wo = normalize(xf_vector(in.m, -xf_vector(in.mi, ray_d)));  // wo = -(object ray).d, transformed back and normalised
                 if (!sc.inst_fixed) { h.material = 0xffffffffu; h.area_light = -1; }  // ret.primitive = None (Q11): no material, no Le
@@ -742,7 +755,13 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
     tri_fill_tex(sc, prim, tri, hc.y, hc.z, hc.w, &h);
     if (pb.hit_inst) {
         const uint32_t hi = pb.hit_inst[p];
-        if (hi && !sc.inst[hi - 1u].identity) {
+        if (hi && sc.inst[hi - 1u].anim != RSPT_MISS) {   // a moving instance: its Transform at the path's time (inst_at)
+            const InstDev at = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f);
+            if (!at.identity) {
+                if (!sc.inst_fixed) return;
+                inst_texhit(at, &h);
+            }
+        } else if (hi && !sc.inst[hi - 1u].identity) {
             if (!sc.inst_fixed) return;  // reference behaviour: the hit has lost its primitive, nothing to texture
             inst_texhit(sc.inst[hi - 1u], &h);
         }
@@ -1234,7 +1253,14 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_ld_mark(SceneDev sc, LightDistDe
         f3 hp = t.p0 * hc.y + t.p1 * hc.z + t.p2 * hc.w;  // the hit point as tri_fill forms it
         if (pb.hit_inst) {
             const uint32_t hi = pb.hit_inst[p];
-            if (hi && !sc.inst[hi - 1u].identity) {
+            if (hi && sc.inst[hi - 1u].anim != RSPT_MISS) {
+                const InstDev at = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f);
+                if (!at.identity) {
+                    if (!sc.inst_fixed) continue;
+                    f3 pe;
+                    inst_point(at.m, hp, f3{0.0f, 0.0f, 0.0f}, &hp, &pe);
+                }
+            } else if (hi && !sc.inst[hi - 1u].identity) {
                 if (!sc.inst_fixed) continue;
                 f3 pe;
                 inst_point(sc.inst[hi - 1u].m, hp, f3{0.0f, 0.0f, 0.0f}, &hp, &pe);

@@ -81,6 +81,8 @@ struct Ctx {
     uint32_t n_bin_info = 0;
     uint32_t* hit_inst = nullptr;      // per path slot: instance of the continuation ray's hit (scenes with object instances)
     size_t hit_inst_cap = 0;
+    float* path_time = nullptr;        // per path slot: Ray.time (scenes with moving instances)
+    size_t time_cap = 0;
     unsigned long long* totals = nullptr;  // [0] nodes [1] tris [2] bsdf hits [3] rays closest [4] rays any [5] nan samples
     // sampler tables + filter table
     uint32_t* sobol32 = nullptr;
@@ -232,6 +234,7 @@ struct rspt_scene_s {
     uint32_t n_materials = 0;
     bool has_alpha = false;           // some mesh carries an alpha / shadow-alpha mask (Triangle::intersect's alpha tests)
     bool has_instances = false;       // object instances: two-level traversal (kernels.h traverse<ANY, true>)
+    bool has_animated = false;        // ... some of them moving (dev_scene.h inst_at): the reference-order kernel serves the scene, `path` under Sobol' / Halton only
     std::map<int, LightDist> light_dists;  // by effective strategy
 };
 
@@ -531,7 +534,7 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     uint2* spill = g.spill + (lane ? g.spill_threads * RSPT_W4_SPILL : 0);
     uint32_t* hi = (INST && OUT_MODE == 0 && !ANY) ? (g_inst_out ? g_inst_out : g.hit_inst) : nullptr;
     const bool special = INST || ALPHA;
-    const bool slow = count || which == 0 || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
+    const bool slow = count || which == 0 || s->has_animated || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
     if (slow) {
         if (count)
             hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
@@ -633,6 +636,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         return fail(RSPT_E_UNSUPPORTED, "integrator %u (path, ao, directlighting and volpath only)", d->integrator);
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
     const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
+    if (s->has_animated && (d->integrator != RSPT_INTEGRATOR_PATH || pixel_sampler))
+        return fail(RSPT_E_UNSUPPORTED, "a scene with a moving object instance is served by the path integrator under the Sobol' / Halton samplers only");
     if (direct) {
         if (d->max_depth < 1 || d->max_depth > (uint32_t)RSPT_DL_SERIAL_DEPTH)
             return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, %d] (the explicit recursion stack of the per-lane form, dl_serial.h)", RSPT_DL_SERIAL_DEPTH);
@@ -895,6 +900,17 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // 1319 -> 1339; RSPT_BIN_FIRST=1 sorts it as before)
     const bool bins_first = env_size("RSPT_BIN_FIRST", 0) != 0;
     if (s->has_instances && (rc = ensure_hit_inst(volpath ? 2 * g.cap : g.cap))) return rc;   // volpath: second half = the hits of the shadow-ray segments
+    // moving instances: every path keeps its ray time (the camera sample's), read where an instance's Transform is interpolated
+    if (s->has_animated) {
+        if (g.time_cap < g.cap) {
+            if (g.path_time) (void)hipFree(g.path_time);
+            g.path_time = nullptr; g.time_cap = 0;
+            if ((rc = dev_alloc(&g.path_time, g.cap))) return rc;
+            g.time_cap = g.cap;
+        }
+    }
+    g.pb.time = s->has_animated ? g.path_time : nullptr;
+    s->dev.ray_time = g.pb.time;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
     g.vol.hit_inst_tr = (volpath && s->has_instances) ? g.hit_inst + g.cap : nullptr;
     if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
@@ -2152,6 +2168,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     }
     if (instanced) {  // InstDev records
         std::vector<InstDev> ins(d->n_instances);
+        std::vector<InstAnim> anims;
         for (uint32_t i = 0; i < d->n_instances; i++) {
             const rspt_instance& in = d->instances[i];
             const rspt_object& o = d->objects[in.object];
@@ -2166,6 +2183,25 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             for (int r = 0; r < 4; r++)
                 for (int c = 0; c < 4; c++) ident &= in.to_world[4 * r + c] == (r == c ? 1.0f : 0.0f);
             x.identity = ident ? 1u : 0u;
+            x.anim = RSPT_MISS;
+            if (in.animated) {   // a moving instance (ABI 20): AnimatedTransform::new's decomposition of the two keys, as for a moving camera
+                if (!(in.time[1] > in.time[0])) return bail(fail(RSPT_E_INVALID, "instance %u: animated with time[1] <= time[0]", i));
+                InstAnim an;
+                memset(&an, 0, sizeof an);
+                if (camanim::camera_keys(in.to_world, in.time[0], in.to_world_end, in.time[1], &an.keys)) {   // false: equal keys = not actually animated
+                    memcpy(an.mi_end, in.from_world_end, sizeof an.mi_end);
+                    bool ie = true;
+                    for (int r = 0; r < 4; r++)
+                        for (int c = 0; c < 4; c++) ie &= in.to_world_end[4 * r + c] == (r == c ? 1.0f : 0.0f);
+                    an.identity_end = ie ? 1u : 0u;
+                    x.anim = (uint32_t)anims.size();
+                    anims.push_back(an);
+                }
+            }
+        }
+        if (!anims.empty()) {
+            if ((rc = upload(s, anims.data(), anims.size(), &s->dev.inst_anim))) return bail(rc);
+            s->has_animated = true;
         }
         if ((rc = upload(s, ins.data(), ins.size(), &s->dev.inst))) return bail(rc);
         s->dev.n_inst = d->n_instances;

@@ -485,10 +485,15 @@ class SceneBuilder:
     def end_object(self):  # pbrt_object_end
         self.cur_object = -1
 
-    def add_instance(self, name, to_world):  # pbrt_object_instance api.rs:3024-3109: TransformedPrimitive(object aggregate, CTM)
+    def add_instance(self, name, to_world, to_world_end=None, time=(0.0, 1.0)):
+        """pbrt_object_instance (api.rs:3024-3109): TransformedPrimitive(object aggregate, AnimatedTransform(CTM[0], start time, CTM[1], end time)).
+        to_world_end: the second key of a MOVING instance (ActiveTransform EndTime ... ObjectInstance); its top-level bounds are then
+        AnimatedTransform::motion_bounds — the union of the two keys' bounds when the keys differ by translation / scale only
+        (transform.rs:2147-2160); with a rotation between the keys the reference bounds the motion of every corner (bound_point_motion, :2164-2210),
+        for which this scaffolding takes the corners at 256 times and pads by 5 % of the extent — a test scene's BVH only has to contain the motion"""
         assert self.cur_object < 0, "ObjectInstance can't be called inside instance definition"
         self.decl.append(("inst", len(self.instances)))
-        self.instances.append((self.objects[name], to_world))
+        self.instances.append((self.objects[name], to_world, to_world_end, (float(time[0]), float(time[1]))))
 
     # ---- textures (api.rs make_texture; src/textures/*.rs) ----
     def _add_texture(self, **kw):
@@ -755,12 +760,26 @@ class SceneBuilder:
             tsel = in_tri >= 0
             tv = P[tri[in_tri[tsel]]]
             bounds[tsel, :3], bounds[tsel, 3:] = tv.min(1), tv.max(1)
-            for k, (o, xf) in enumerate(self.instances):
+            for k, (o, xf, xf_end, times) in enumerate(self.instances):
                 lo, hi = _transform_bounds(xf.m, *obj_bound[o])             # TransformedPrimitive::world_bound (primitive.rs:212-215)
-                row = np.nonzero(in_inst == k)[0][0]
-                bounds[row, :3], bounds[row, 3:] = lo, hi
                 instances[k]["object"] = o
                 instances[k]["to_world"] = xf.m.reshape(-1); instances[k]["from_world"] = xf.m_inv.reshape(-1)
+                instances[k]["to_world_end"] = xf.m.reshape(-1); instances[k]["from_world_end"] = xf.m_inv.reshape(-1); instances[k]["time"] = times
+                if xf_end is not None and not np.array_equal(xf_end.m, xf.m):   # actually_animated (transform.rs:923)
+                    instances[k]["animated"] = 1
+                    instances[k]["to_world_end"] = xf_end.m.reshape(-1); instances[k]["from_world_end"] = xf_end.m_inv.reshape(-1)
+                    lo2, hi2 = _transform_bounds(xf_end.m, *obj_bound[o])
+                    lo, hi = np.minimum(lo, lo2), np.maximum(hi, hi2)           # motion_bounds without rotation: the union of the keys' bounds
+                    ra, rb = xf.m[:3, :3] / np.linalg.norm(xf.m[:3, :3], axis=0), xf_end.m[:3, :3] / np.linalg.norm(xf_end.m[:3, :3], axis=0)
+                    if not np.allclose(ra, rb, atol=1e-6):                      # a rotation between the keys (see add_instance)
+                        from oracle import pyoracle                             # (test scaffolding: the oracle's AnimatedTransform::interpolate)
+                        for tt in np.linspace(times[0], times[1], 256):
+                            l3, h3 = _transform_bounds(pyoracle.interpolate_transform(xf.m, times[0], xf_end.m, times[1], float(tt)), *obj_bound[o])
+                            lo, hi = np.minimum(lo, l3), np.maximum(hi, h3)
+                        pad = F32(0.05) * (hi - lo)
+                        lo, hi = (lo - pad).astype(F32), (hi + pad).astype(F32)
+                row = np.nonzero(in_inst == k)[0][0]
+                bounds[row, :3], bounds[row, 3:] = lo, hi
             nodes, ordered = lib.bvh_build_bounds(bounds, max_prims_in_node)
             n_top_nodes, n_top_prims = len(nodes), len(bounds)
             top_in = ordered                       # BVH slot -> input primitive

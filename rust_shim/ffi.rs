@@ -1,10 +1,10 @@
-//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 19) one to one.
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 20) one to one.
 //! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
 //! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RSPT_ABI_VERSION: c_int = 19;
+pub const RSPT_ABI_VERSION: c_int = 20;
 pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
 pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
 
@@ -40,7 +40,7 @@ pub struct RsptLight { pub kind: u32, pub prim: u32, pub l: [f32; 3], pub two_si
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RsptObject { pub first_node: u64, pub n_nodes: u64, pub first_prim: u64, pub n_prims: u64 }
 #[repr(C)] #[derive(Clone, Copy)]
-pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_world: [f32; 16] }
+pub struct RsptInstance { pub object: u32, pub to_world: [f32; 16], pub from_world: [f32; 16], pub animated: u32, pub to_world_end: [f32; 16], pub from_world_end: [f32; 16], pub time: [f32; 2] } // 272 B
 #[repr(C)] pub struct RsptSceneDesc {
     pub nodes: *const RsptBvhNode, pub n_nodes: u64, pub prims: *const RsptPrim, pub n_prims: u64,
     pub meshes: *const RsptMesh, pub n_meshes: u32, pub p: *const f32, pub n: *const f32, pub s: *const f32, pub uv: *const f32,

@@ -3,7 +3,7 @@
 //! repo is built in); it is written against rs_pbrt v0.9.12 plus the getters of rust_shim/rs_pbrt.patch.  Everything not covered
 //! returns Err and `SamplerIntegrator::render` keeps its CPU tile loop (src/core/integrator.rs:70-220).
 //!
-//! Covered: triangle meshes (Shape::Trngl) under a BVHAccel aggregate, object instances (Primitive::Transformed, static),
+//! Covered: triangle meshes (Shape::Trngl) under a BVHAccel aggregate, object instances (Primitive::Transformed, static or moving),
 //! matte / plastic / mirror / glass (smooth and rough) / metal / substrate / uber / translucent / mix (handed over as their
 //! parameters — one texture reference each, rspt_material_desc; the library assembles the lobes), diffuse area / point / spot / distant / infinite lights (the light's own MIP
 //! pyramid and Distribution2D image are handed over), homogeneous media, PerspectiveCamera, the Sobol', Halton and the four
@@ -232,15 +232,17 @@ impl Flat {
                     self.prims.push(RsptPrim { v: [first + vi[0], first + vi[1], first + vi[2]], mesh, material, area_light });
                 }
                 Primitive::Transformed(tp) if top => {
-                    if tp.primitive_to_world.is_animated() { return Err("animated instance".into()); }   // getter: rs_pbrt.patch
-                    pending.push((self.prims.len(), tp.primitive.clone(), tp.primitive_to_world.start_transform()));
+                    // a moving instance goes over with both keys (ABI 20); getters of rs_pbrt.patch: is_animated = actually_animated,
+                    // start_transform / end_transform, start_time / end_time (transform.rs:894-911)
+                    let a = &tp.primitive_to_world;
+                    pending.push((self.prims.len(), tp.primitive.clone(), a.start_transform(), a.end_transform(), a.is_animated(), [a.start_time(), a.end_time()]));
                     self.prims.push(RsptPrim { v: [0; 3], mesh: RSPT_MESH_INSTANCE, material: RSPT_NO_MATERIAL, area_light: -1 });
                 }
                 _ => return Err("nested aggregate".into()),
             }
         }
         let me = (node_base as u64, bvh.nodes.len() as u64, prim_base as u64, bvh.primitives.len() as u64);
-        for (slot, obj, xf) in pending {
+        for (slot, obj, xf, xf_end, animated, times) in pending {
             let key = Arc::as_ptr(&obj);
             let oi = match self.object_of.get(&key) {
                 Some(i) => *i,
@@ -262,7 +264,8 @@ impl Flat {
                 }
             };
             self.prims[slot].v[0] = self.instances.len() as u32;
-            self.instances.push(RsptInstance { object: oi, to_world: m16(&xf.m), from_world: m16(&xf.m_inv) });
+            self.instances.push(RsptInstance { object: oi, to_world: m16(&xf.m), from_world: m16(&xf.m_inv), animated: animated as u32,
+                                               to_world_end: m16(&xf_end.m), from_world_end: m16(&xf_end.m_inv), time: times });
         }
         Ok(me)
     }

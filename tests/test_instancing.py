@@ -64,6 +64,37 @@ def rd_small(spp=8, res=(96, 72), **kw):
     return scenes.make_render_desc(res[0], res[1], spp, LOOK, 40.0, **kw)
 
 
+def moving_scene(builder, mode="fixed", rotation=True, tex=False):
+    """small_scene with MOVING instances (AnimatedTransform primitive_to_world, primitive.rs:198-265): a pyramid that slides and grows, one that
+    also turns (slerp), one whose keys are equal (actually_animated = false), one whose interval ends inside the shutter, a moving
+    single-triangle object, static ones next to them.  Shutter 0 .. 1, keys at 0 / 1 unless noted."""
+    T = scenes.Transform
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    if tex:
+        img = np.random.default_rng(3).uniform(0.1, 0.9, (8, 8, 3)).astype(np.float32)
+        red = sb.add_material(scenes.plastic(sb.image_texture(img, su=2.0, sv=2.0), (0.3, 0.3, 0.3), 0.15, bump=sb.image_texture(img, channels=1, scale=0.05, trilinear=True)))
+    else:
+        red = sb.add_material(scenes.plastic((0.6, 0.2, 0.15), (0.3, 0.3, 0.3), 0.15))
+    sb.add_quad([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], grey)
+    sb.add_quad([(-5, 0, 5), (-5, 5, 5), (5, 5, 5), (5, 0, 5)], grey)
+    sb.add_quad([(-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1)], grey, emit=(10, 10, 10))
+    sb.add_point_light((3, 4, -3), (30, 30, 25))
+    uv = [[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5]]
+    sb.begin_object("pyr"); sb.add_mesh(PYR, PYR_IDX, red, UV=uv if tex else None); sb.end_object()
+    sb.begin_object("one"); sb.add_mesh(PYR[:3] + np.float32(0.1), [[0, 1, 2]], red); sb.end_object()
+    sb.add_instance("pyr", T.translate((-2.2, 0.1, 1.0)) * T.scale(0.6, 0.8, 0.6), T.translate((-1.4, 0.5, 1.6)) * T.scale(0.9, 1.3, 0.7))          # slides and grows
+    if rotation:
+        sb.add_instance("pyr", T.translate((-0.3, 0.2, 0.6)) * T.rotate_y(10.0), T.translate((0.2, 0.2, 1.0)) * T.rotate_y(75.0) * T.scale(1.0, 1.2, 1.0))   # turns
+    same = T.translate((1.2, 0.1, 1.4)) * T.rotate_y(30.0)
+    sb.add_instance("pyr", same, T(same.m, same.m_inv))                                                                                    # equal keys
+    sb.add_instance("pyr", T.translate((2.2, 0.1, 0.8)), T.translate((2.6, 0.9, 0.8)), time=(0.25, 0.6))                                   # stands still, moves, stands still
+    sb.add_instance("one", T.translate((0, 2.0, 0)), T.translate((0.4, 2.4, 0.3)))
+    sb.add_instance("pyr", T.translate((-0.8, 0.0, 2.6)) * T.scale(0.7, 0.7, 0.7))                                                         # static
+    sb.add_instance("pyr", T.identity(), T.translate((0.0, 0.3, 0.0)), time=(0.5, 1.0))                                                    # the identity for half of the shutter (Q10 while it lasts)
+    return sb.finish(builder, instancing=mode)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # CPU: host assembly + oracle known answers
 # ---------------------------------------------------------------------------------------------------------------
@@ -286,3 +317,77 @@ def test_gpu_landscape_standin_crop_matches_oracle(gpu, oracle, mode):
     ref = oracle.render(sc, rd, threads=8)
     assert np.array_equal(film[:, 3], ref["film"][:, 3])
     assert film_rmse(film, ref["film"]) < 1e-7   # per-sample radiance is bit-identical; the full-size frame is tests/test_gpu_fullsize.py
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# moving instances (ABI 20)
+
+def test_interpolated_instance_transform_known_answers(oracle):
+    """AnimatedTransform::interpolate (transform.rs:2081-2113) as the oracle restates it for TransformedPrimitive: the keys themselves outside the
+    interval, in between translate(lerp) * slerp * lerp(scale) with m_inv its inverse (as the reverse product of the factors' inverses)"""
+    T = scenes.Transform
+    a, b = T.translate((1, 2, 3)) * T.rotate_y(10.0) * T.scale(1, 2, 1), T.translate((3, 2, -1)) * T.rotate_y(100.0) * T.scale(2, 2, 0.5)
+    for time, want in ((-1.0, a), (0.0, a), (1.0, b), (7.0, b)):
+        m, mi = oracle.interpolate_transform(a.m, 0.0, b.m, 1.0, time, a.m_inv, b.m_inv, want_inverse=True)
+        assert np.array_equal(m, want.m) and np.array_equal(mi, want.m_inv)
+    m, mi = oracle.interpolate_transform(a.m, 0.0, b.m, 1.0, 0.5, a.m_inv, b.m_inv, want_inverse=True)
+    assert np.allclose(m[:3, 3], (2, 2, 1), atol=1e-6)                                   # translation: linear
+    assert np.allclose(m.astype(np.float64) @ mi.astype(np.float64), np.eye(4), atol=1e-5)
+    r = m[:3, :3] / np.linalg.norm(m[:3, :3], axis=0)
+    ang = np.degrees(np.arctan2(r[0, 2], r[0, 0]))
+    assert abs(ang - 55.0) < 1e-3                                                        # rotation: halfway along the arc
+    assert np.allclose(np.linalg.norm(m[:3, :3], axis=0), (1.5, 2.0, 0.75), atol=1e-5)   # scale: linear
+    # equal keys: not animated, the start Transform at every time
+    m = oracle.interpolate_transform(a.m, 0.0, a.m, 1.0, 0.3)
+    assert np.array_equal(m, a.m)
+
+
+def test_oracle_moving_instances_blur_and_reduce_to_static_ones(oracle):
+    """a closed shutter at time t renders the static scene of that time's interpolated transforms (the host bakes them); an open shutter differs
+    from both ends (motion blur) and moving instances keep Q10 / Q11 (reference mode: null surfaces that cast shadows)"""
+    T = scenes.Transform
+    sc = moving_scene(oracle.bvh_build, mode="fixed", rotation=False)
+    frames = {}
+    for name, shutter in (("open", (0.0, 1.0)), ("start", (0.0, 0.0)), ("end", (1.0, 1.0))):
+        rd = rd_small(spp=8, res=(64, 48), shutter=shutter)
+        frames[name] = scenes.film_to_rgb(oracle.render(sc, rd, threads=8)["film"])
+    assert np.abs(frames["start"] - frames["end"]).mean() > 1e-3 and np.abs(frames["open"] - frames["start"]).mean() > 5e-4 and np.abs(frames["open"] - frames["end"]).mean() > 5e-4
+    # the start-of-shutter frame = the same scene with every instance static at its first key
+    sc0 = moving_scene(oracle.bvh_build, mode="fixed", rotation=False)
+    for k in range(len(sc0.instances)):
+        sc0.instances[k]["animated"] = 0
+    f0 = scenes.film_to_rgb(oracle.render(sc0, rd_small(spp=8, res=(64, 48), shutter=(0.0, 0.0)), threads=8)["film"])
+    assert np.array_equal(f0, frames["start"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tex,sampler", [("fixed", False, "sobol"), ("reference", False, "sobol"), ("fixed", True, "sobol"), ("fixed", False, "halton")])
+def test_gpu_moving_instances_match_oracle(gpu, oracle, mode, tex, sampler):
+    """TransformedPrimitive with an AnimatedTransform (ABI 20): the library interpolates the instance's Transform at the path's ray time at every
+    instance visit and at the hit (dev_scene.h inst_at); per-sample radiance bit for bit, with rotation between the keys, in both instancing modes"""
+    sc = moving_scene(gpu.bvh_build, mode=mode, tex=tex)
+    assert int(sc.instances["animated"].sum()) >= 5
+    rd = rd_small(spp=16, shutter=(0.0, 1.0), sampler=sampler)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+        li, _ = gpu.render_samples(ds, rd)
+    ref = oracle.render(sc, rd, threads=8, want_li=True)
+    assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == 0
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert np.array_equal(li, ref["li"])
+    assert film_rmse(film, ref["film"]) < 1e-5
+    closed = oracle.render(sc, rd_small(spp=16, shutter=(0.0, 0.0), sampler=sampler), threads=8)
+    assert film_rmse(film, closed["film"]) > 1e-3   # the motion is in the picture
+
+
+@pytest.mark.gpu
+def test_gpu_moving_instances_are_refused_where_not_served(gpu):
+    from rs_pbrt_amd.lib import RsptError
+    sc = moving_scene(gpu.bvh_build, rotation=False)
+    with gpu.DeviceScene(sc) as ds:
+        for kw in (dict(integrator="volpath"), dict(integrator="directlighting"), dict(integrator="ao"), dict(sampler="02sequence")):
+            rd = rd_small(spp=4, **kw)
+            rd.allow_slow_paths = 1
+            with pytest.raises(RsptError) as e:
+                gpu.render(ds, rd)
+            assert e.value.code == abi.E_UNSUPPORTED

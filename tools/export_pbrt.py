@@ -215,7 +215,8 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
         if what == "mesh":
             out += mesh_block(k)
         else:
-            obj, xf = sb.instances[k]
+            obj, xf, xf_end, _times = sb.instances[k]
+            assert xf_end is None, "moving instances are not exported (ActiveTransform blocks): add them when a reference dump needs one"
             from rs_pbrt_amd import scenes as _sc
             assert np.array_equal(np.asarray(xf.m_inv, np.float32), np.asarray(_sc.Transform(xf.m).m_inv, np.float32)), "instance transform was not built as Transform(m)"
             out += ["TransformBegin", "  Transform [%s]" % f(np.asarray(xf.m, np.float32).reshape(4, 4).T), '  ObjectInstance "%s"' % names[obj], "TransformEnd"]
