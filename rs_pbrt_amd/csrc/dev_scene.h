@@ -58,6 +58,11 @@ struct SceneDev {
     const void* w4;
     const uint2* w4_big;
     uint32_t w4_root;
+    // per-primitive copies of the vertex attributes the interaction fill interpolates (round 4): tri_nuv[5 * prim ..] = the three normals (9 floats),
+    // the three uvs (6), 5 of padding = 80 bytes next to each other instead of a 24-byte index record and three scattered 12-byte + three 8-byte
+    // vertex reads (a dependent round trip and up to seven 64-byte sectors per hit: the shade stage is bound by the bytes it moves).  nullptr = the
+    // scene has no per-vertex normals or uvs (or too many primitives for the copy: the gathers remain)
+    const float4* tri_nuv;
     const struct InstAnim* inst_anim;   // the keys of the moving instances (inst_at); nullptr = none
     const float* ray_time;              // [path slot] Ray.time of the path's rays (the camera sample's time, perspective.rs:226), set by rspt_render while a
                                         // scene with moving instances is rendered; nullptr = time 0 (rspt_trace)
@@ -329,15 +334,23 @@ RDEVN void tri_fill(const SceneDev& sc, uint32_t prim, const TriRec& t, float b0
     const bool has_uv = VERTEX && (t.flags & MF_HAS_UV) && sc.UV;
     const bool has_n = VERTEX && (t.flags & MF_HAS_N) && sc.N, has_s = VERTEX && (t.flags & MF_HAS_S) && sc.S;
     uint32_t v0 = 0, v1 = 0, v2 = 0;
-    if (has_uv || has_n || has_s) {
+    f3 vn0{0.0f, 0.0f, 0.0f}, vn1 = vn0, vn2 = vn0;
+    const bool packed = sc.tri_nuv != nullptr && (has_uv || has_n);   // the primitive's own copy of its normals / uvs (SceneDev::tri_nuv)
+    if (packed) {
+        const float4* q = sc.tri_nuv + 5 * (size_t)prim;
+        if (has_n) { const float4 a = q[0], b = q[1]; const float c = q[2].x; vn0 = f3{a.x, a.y, a.z}; vn1 = f3{a.w, b.x, b.y}; vn2 = f3{b.z, b.w, c}; }
+        if (has_uv) { const float4 c = q[2], d = q[3]; uv0 = f2{c.y, c.z}; uv1 = f2{c.w, d.x}; uv2 = f2{d.y, d.z}; }
+    }
+    if (((has_uv || has_n) && !packed) || has_s) {
         rspt_prim pr = sc.prims[prim];
         v0 = pr.v[0]; v1 = pr.v[1]; v2 = pr.v[2];
     }
-    if (has_uv) {
+    if (has_uv && !packed) {
         uv0 = f2{sc.UV[2 * (size_t)v0], sc.UV[2 * (size_t)v0 + 1]};
         uv1 = f2{sc.UV[2 * (size_t)v1], sc.UV[2 * (size_t)v1 + 1]};
         uv2 = f2{sc.UV[2 * (size_t)v2], sc.UV[2 * (size_t)v2 + 1]};
     }
+    if (has_n && !packed) { vn0 = ld3(sc.N, v0); vn1 = ld3(sc.N, v1); vn2 = ld3(sc.N, v2); }
     f2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
     f3 dp02 = p0 - p2, dp12 = p1 - p2;
     float det = duv02.x * duv12.y - duv02.y * duv12.x;
@@ -360,7 +373,7 @@ RDEVN void tri_fill(const SceneDev& sc, uint32_t prim, const TriRec& t, float b0
     if (has_n || has_s) {
         f3 ns = n;
         if (has_n) {
-            ns = ld3(sc.N, v0) * b0 + ld3(sc.N, v1) * b1 + ld3(sc.N, v2) * b2;
+            ns = vn0 * b0 + vn1 * b1 + vn2 * b2;
             ns = len2(ns) > 0.0f ? normalize(ns) : n;
         }
         f3 ss;

@@ -408,15 +408,23 @@ RDEVN void tri_fill_tex(const SceneDev& sc, uint32_t prim, const TriRec& t, floa
     const bool has_uv = (t.flags & MF_HAS_UV) && sc.UV;
     const bool has_n = (t.flags & MF_HAS_N) && sc.N, has_s = (t.flags & MF_HAS_S) && sc.S;
     uint32_t v0 = 0, v1 = 0, v2 = 0;
-    if (has_uv || has_n || has_s) {
+    f3 pn0{0.0f, 0.0f, 0.0f}, pn1 = pn0, pn2 = pn0;
+    const bool packed = sc.tri_nuv != nullptr && (has_uv || has_n);   // the primitive's own copy of its normals / uvs (SceneDev::tri_nuv)
+    if (packed) {
+        const float4* q = sc.tri_nuv + 5 * (size_t)prim;
+        if (has_n) { const float4 a = q[0], b = q[1]; const float c = q[2].x; pn0 = f3{a.x, a.y, a.z}; pn1 = f3{a.w, b.x, b.y}; pn2 = f3{b.z, b.w, c}; }
+        if (has_uv) { const float4 c = q[2], d = q[3]; uv0 = f2{c.y, c.z}; uv1 = f2{c.w, d.x}; uv2 = f2{d.y, d.z}; }
+    }
+    if (((has_uv || has_n) && !packed) || has_s) {
         rspt_prim pr = sc.prims[prim];
         v0 = pr.v[0]; v1 = pr.v[1]; v2 = pr.v[2];
     }
-    if (has_uv) {
+    if (has_uv && !packed) {
         uv0 = f2{sc.UV[2 * (size_t)v0], sc.UV[2 * (size_t)v0 + 1]};
         uv1 = f2{sc.UV[2 * (size_t)v1], sc.UV[2 * (size_t)v1 + 1]};
         uv2 = f2{sc.UV[2 * (size_t)v2], sc.UV[2 * (size_t)v2 + 1]};
     }
+    if (has_n && !packed) { pn0 = ld3(sc.N, v0); pn1 = ld3(sc.N, v1); pn2 = ld3(sc.N, v2); }
     f2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
     f3 dp02 = p0 - p2, dp12 = p1 - p2;
     float det = duv02.x * duv12.y - duv02.y * duv12.x;
@@ -437,7 +445,7 @@ RDEVN void tri_fill_tex(const SceneDev& sc, uint32_t prim, const TriRec& t, floa
         f3 ns = n;
         f3 n0{0.0f, 0.0f, 0.0f}, n1 = n0, n2 = n0;
         if (has_n) {
-            n0 = ld3(sc.N, v0); n1 = ld3(sc.N, v1); n2 = ld3(sc.N, v2);
+            n0 = pn0; n1 = pn1; n2 = pn2;
             ns = n0 * b0 + n1 * b1 + n2 * b2;
             ns = len2(ns) > 0.0f ? normalize(ns) : n;
         }

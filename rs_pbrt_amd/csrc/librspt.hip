@@ -1920,6 +1920,26 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     if ((rc = upload(s, d->N, d->N ? d->n_vertices * 3 : 0, &s->dev.N))) return bail(rc);
     if ((rc = upload(s, d->S, d->S ? d->n_vertices * 3 : 0, &s->dev.S))) return bail(rc);
     if ((rc = upload(s, d->UV, d->UV ? d->n_vertices * 2 : 0, &s->dev.UV))) return bail(rc);
+    {   // SceneDev::tri_nuv: every primitive's normals and uvs next to each other (80 B per primitive; skipped beyond 16 GB)
+        bool any = false;
+        for (uint32_t i = 0; i < d->n_meshes; i++) any = any || (d->meshes[i].has_n && d->N) || (d->meshes[i].has_uv && d->UV);
+        if (any && d->n_prims && d->n_prims * 80ull <= env_size("RSPT_TRI_NUV_MAX_BYTES", (size_t)16 << 30) && env_size("RSPT_TRI_NUV", 1) != 0) {
+            std::vector<float> nuv((size_t)d->n_prims * 20, 0.0f);
+            for (uint64_t i = 0; i < d->n_prims; i++) {
+                const rspt_prim& pr = d->prims[i];
+                if (pr.mesh == RSPT_MESH_INSTANCE) continue;
+                const rspt_mesh& me = d->meshes[pr.mesh];
+                float* q = nuv.data() + 20 * i;
+                for (int k = 0; k < 3; k++) {
+                    if (me.has_n && d->N) for (int c = 0; c < 3; c++) q[3 * k + c] = d->N[3 * (size_t)pr.v[k] + c];
+                    if (me.has_uv && d->UV) for (int c = 0; c < 2; c++) q[9 + 2 * k + c] = d->UV[2 * (size_t)pr.v[k] + c];
+                }
+            }
+            const float* dev_nuv = nullptr;
+            if ((rc = upload(s, nuv.data(), nuv.size(), &dev_nuv))) return bail(rc);
+            s->dev.tri_nuv = reinterpret_cast<const float4*>(dev_nuv);
+        }
+    }
     {   // lobes: texture ids become per-material slot numbers (1 + slot) for k_texture / k_shade
         bool any = false;
         for (int v = 0; v < 2; v++) {
