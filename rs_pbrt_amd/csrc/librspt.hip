@@ -585,7 +585,8 @@ typedef void (*ShadeKernel)(RSPT_SHADE_ARGS);
 // 4 waves 455; plastic 173 VGPRs as compiled 1749 (0.531 s), 168 + 24 B of spills = 3 waves 1841 (0.470 s), 128 + 152 B = 4 waves 1791.
 struct ShadeVariant { uint32_t features; const char* name; ShadeKernel natural, w3, w4; int dflt; };
 const ShadeVariant g_shade_variants[] = {
-    {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 0},
+    {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 3},   // (round 4: as compiled it now takes 169 VGPRs = 2 waves — the in-kernel voxel claim of light_row_try
+                                                                                                           //  cost the four registers; the 3-wave build fits 168 without scratch: Cornell 875 -> see profiles/r04_*)
     {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
     {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0},
     {SV_GENERIC, "generic", k_shade<SV_GENERIC>, k_shade_w<SV_GENERIC, 3>, k_shade_w<SV_GENERIC, 4>, 0},

@@ -1,9 +1,5 @@
 set -u
-mkdir -p gpurun_out/c19
-timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_volpath.py tests/test_gpu_pixel_samplers.py tests/test_gpu_directlighting.py tests/test_gpu_fuzz.py -m gpu -x -q -k "not two_ranks" > gpurun_out/c19/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error|Error|assert" gpurun_out/c19/pytest.log | tail -5
-bash tools/ab_run.sh -r 2 -- "--workload statue --steps 3 --warmup 1 --no-count" nuv core 2>&1 | tail -3
-cp gpurun_out/ab/values.txt gpurun_out/c19/ab_statue.txt
-bash tools/ab_run.sh -r 2 -- "--workload soup1m --steps 4 --warmup 1 --no-count" nuv core 2>&1 | tail -3
-cp gpurun_out/ab/values.txt gpurun_out/c19/ab_soup.txt
-bash tools/ab_run.sh -r 1 -- "--workload statue_tex --steps 3 --warmup 1 --no-count" nuv core 2>&1 | tail -3
-cp gpurun_out/ab/values.txt gpurun_out/c19/ab_statue_tex.txt
+mkdir -p gpurun_out/c20
+for w in cornell soup1m; do for v in 0 3; do
+echo "$w RSPT_SHADE_WAVES=$v: $(RSPT_SHADE_WAVES=$v timeout 300 python bench.py --workload $w --steps 6 --warmup 2 --no-count --no-extra --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*')"
+done; done | tee gpurun_out/c20/diffuse_waves.txt
