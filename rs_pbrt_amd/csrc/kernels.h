@@ -226,7 +226,9 @@ struct TraceResult {
 // the walk returns to the remaining primitives of the leaf.  Quirks Q10 / Q11 are reproduced unless
 // sc.inst_fixed: an identity instance shrinks t_max without reporting its hit, and its interaction survives only if some
 // other primitive of the top-level aggregate reports a hit (`hit` below is BVHAccel::intersect's flag, `res` its isect).
-template <bool ANY, bool INST, bool ALPHA, int STRIDE = RSPT_TRACE_BLOCK /* words between two levels of the LDS stack = columns (threads per block) */>
+// ANIM: the scene has moving instances (their Transform is interpolated at the ray's time, dev_scene.h inst_at) — its own instantiation, so that the kernels
+// of every other instanced scene keep their register budget (with the interpolation inlined k_trace_fixup<.., INST> went from 97 to 172 VGPRs)
+template <bool ANY, bool INST, bool ALPHA, int STRIDE = RSPT_TRACE_BLOCK /* words between two levels of the LDS stack = columns (threads per block) */, bool ANIM = false>
 RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column */, float time = 0.0f /* Ray.time: moving instances */) {
     TraceResult res;
     res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0; res.t_end = t_max;
@@ -251,7 +253,7 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
                 inst = __float_as_uint(a.x);
                 const InstDev& in = sc.inst[inst];
                 w_leaf_i = leaf_i; w_leaf_end = leaf_end; w_tmax = t_max; sp_base = sp; inst_hit = false;
-                if (in.anim != RSPT_MISS) {   // a moving instance: primitive_to_world.interpolate(r.time) and its inverse (primitive.rs:218-222)
+                if (ANIM && in.anim != RSPT_MISS) {   // a moving instance: primitive_to_world.interpolate(r.time) and its inverse (primitive.rs:218-222)
                     const InstDev at = inst_at(sc, inst, time);
                     inst_ident = at.identity != 0u;
                     inst_ray(at, w_o, w_d, t_max, &o, &d, &t_max);
@@ -321,7 +323,7 @@ RDEV TraceResult traverse(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, f
 // out_mode 0: float4 (prim, b0, b1, b2) into hit_cont/hit_mis by slot; 1: rspt_hit AoS by queue
 // position (stage hook); ANY: occluded[slot] (mode 0) or rspt_hit.prim (mode 1).
 // out_inst (INST, closest hit, continuation rays only): 0 or 1 + instance of the hit, by slot
-template <bool ANY, int OUT_MODE, bool COUNT, bool INST, bool ALPHA>
+template <bool ANY, int OUT_MODE, bool COUNT, bool INST, bool ALPHA, bool ANIM = false>
 __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTables tt, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
                                                             uint32_t count_imm, const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                             float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTabl
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
         const float time = (INST && OUT_MODE == 0 && sc.ray_time) ? sc.ray_time[slot] : 0.0f;
-        TraceResult res = traverse<ANY, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x, time);
+        TraceResult res = traverse<ANY, INST, ALPHA, RSPT_TRACE_BLOCK, ANIM>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x, time);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
             else {
@@ -475,7 +477,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         f3 wo = -ray_d;  // SurfaceInteraction.wo, not normalised (triangle.rs:334)
         if ((F & SF_INST) && pb.hit_inst) {  // the hit lies inside an object instance: TransformedPrimitive::intersect (primitive.rs:216-253)
             const uint32_t hi = pb.hit_inst[p];
-            const bool moving = hi && sc.inst[hi - 1u].anim != RSPT_MISS;   // (rare: the interpolated Transform of the path's time, as the traversal used it)
+            const bool moving = (F & SF_ANIM) && hi && sc.inst[hi - 1u].anim != RSPT_MISS;   // (rare: the interpolated Transform of the path's time, as the traversal used it)
             InstDev moved;
             if (moving) moved = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f);
             const InstDev& in_ref = moving ? moved : sc.inst[hi ? hi - 1u : 0u];

@@ -536,7 +536,9 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     const bool special = INST || ALPHA;
     const bool slow = count || which == 0 || s->has_animated || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
     if (slow) {
-        if (count)
+        if (INST && !ALPHA && s->has_animated)   // moving instances: the reference-order loop with the interpolation (its own instantiation; no node / triangle counters)
+            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, true, false, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
+        else if (count)
             hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
         else
             hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
@@ -590,14 +592,15 @@ const ShadeVariant g_shade_variants[] = {
     {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
     {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0},
     {SV_GENERIC, "generic", k_shade<SV_GENERIC>, k_shade_w<SV_GENERIC, 3>, k_shade_w<SV_GENERIC, 4>, 0},
-    {SF_ALL, "dynamic", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0},   // + lobe lists built per hit (material_assembly.h)
+    {SV_DYNAMIC, "dynamic", k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, 0},   // + lobe lists built per hit (material_assembly.h)
+    {SF_ALL, "moving", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0},                     // + moving object instances (dev_scene.h inst_at)
 };
 // RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 0 | 3 | 4 one of its builds (A/B)
 ShadeKernel shade_kernel_for(uint32_t need, const char** name_out) {
     const char* force = getenv("RSPT_SHADE_VARIANT");
     for (const ShadeVariant& v : g_shade_variants) {
         if ((need & ~v.features) != 0) continue;
-        if (force && *force && strcmp(force, v.name) != 0 && (v.features | SF_DYNAMIC) != SF_ALL) continue;
+        if (force && *force && strcmp(force, v.name) != 0 && (v.features | SF_DYNAMIC | SF_ANIM) != SF_ALL) continue;
         if (name_out) *name_out = v.name;
         const size_t waves = env_size("RSPT_SHADE_WAVES", (size_t)v.dflt);
         return waves == 3 ? v.w3 : (waves == 4 ? v.w4 : v.natural);
@@ -2221,8 +2224,10 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             }
         }
         if (!anims.empty()) {
+            if (s->has_alpha) return bail(fail(RSPT_E_UNSUPPORTED, "moving object instances together with alpha-masked meshes"));
             if ((rc = upload(s, anims.data(), anims.size(), &s->dev.inst_anim))) return bail(rc);
             s->has_animated = true;
+            s->shade_features |= SF_ANIM;
         }
         if ((rc = upload(s, ins.data(), ins.size(), &s->dev.inst))) return bail(rc);
         s->dev.n_inst = d->n_instances;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
                         pb.occluded[slot] = res.prim != RSPT_MISS ? 1u : 0u;
                     }
                     if (sc.mat_flags && so.cont) texture_path(sc, tt, rd, pb, slot, &p_lens);   // the texture stage k_texture runs in front of k_shade
-                    so = shade_path<true, MODE == 4 ? SF_ALL : (SF_ALL & ~SF_DYNAMIC)>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
+                    so = shade_path<true, MODE == 4 ? (SF_ALL & ~SF_ANIM) : (SF_ALL & ~SF_DYNAMIC & ~SF_ANIM)>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
                 }
                 const size_t out = (size_t)k * pd.spp + s;
                 samp_L[out] = pb.L_eta[slot];

@@ -13,7 +13,8 @@ namespace rspt {
 constexpr uint32_t SV_DIFFUSE = RSPT_SF_LOBE(RSPT_BXDF_LAMBERT_R) | SF_L_AREA;                      // matte scenes under area lights: C1, C2
 constexpr uint32_t SV_PLASTIC = SV_DIFFUSE | RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R) | SF_VERTEX;      // + plastic, smooth-shaded meshes: the C3 stand-in
 constexpr uint32_t SV_TEXTURED = SV_PLASTIC | RSPT_SF_LOBE(RSPT_BXDF_OREN_NAYAR) | SF_TEX;          // + textured materials: the C4 stand-in
-constexpr uint32_t SV_GENERIC = SF_ALL & ~SF_DYNAMIC;
+constexpr uint32_t SV_GENERIC = SF_ALL & ~SF_DYNAMIC & ~SF_ANIM;
+constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                                                  // + per-hit lobe lists; SF_ALL itself: + moving instances
 
 #define RSPT_TU_TS(I, A, M) \
     RSPT_TU_X template __global__ void k_tile_serial<I, A, M>(SceneDev, TexTables, LightDistDev, RenderDev, PathBuf, PixDesc, const TileRec*, uint32_t, uint32_t, int32_t, int32_t, float4*, float2*, uint32_t, uint32_t*);
@@ -27,6 +28,9 @@ constexpr uint32_t SV_GENERIC = SF_ALL & ~SF_DYNAMIC;
 #define RSPT_TU_REF(ANY, OM, C, I, A) \
     RSPT_TU_X template __global__ void k_trace<ANY, OM, C, I, A>(SceneDev, TexTables, const uint32_t*, const uint32_t*, uint32_t, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, \
                                                                  unsigned long long*, uint32_t*);
+#define RSPT_TU_REFA(ANY, OM) \
+    RSPT_TU_X template __global__ void k_trace<ANY, OM, false, true, false, true>(SceneDev, TexTables, const uint32_t*, const uint32_t*, uint32_t, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, \
+                                                                                  unsigned long long*, uint32_t*);   /* moving instances (traverse<.., ANIM>) */
 #define RSPT_TU_REF8(ANY, OM) \
     RSPT_TU_REF(ANY, OM, false, false, false) RSPT_TU_REF(ANY, OM, false, false, true) RSPT_TU_REF(ANY, OM, false, true, false) RSPT_TU_REF(ANY, OM, false, true, true) \
     RSPT_TU_REF(ANY, OM, true, false, false) RSPT_TU_REF(ANY, OM, true, false, true) RSPT_TU_REF(ANY, OM, true, true, false) RSPT_TU_REF(ANY, OM, true, true, true)
@@ -80,7 +84,7 @@ RSPT_TU_SHADE(SV_TEXTURED) RSPT_TU_SHADE_W(SV_TEXTURED, 3) RSPT_TU_SHADE_W(SV_TE
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_C)
 RSPT_TU_SHADE(SV_GENERIC) RSPT_TU_SHADE_W(SV_GENERIC, 3) RSPT_TU_SHADE_W(SV_GENERIC, 4)
-RSPT_TU_SHADE(SF_ALL)
+RSPT_TU_SHADE(SV_DYNAMIC) RSPT_TU_SHADE(SF_ALL)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4)
 RSPT_TU_W4_4(false, 0) RSPT_TU_W4_4(false, 1) RSPT_TU_W4_4(true, 0) RSPT_TU_W4_4(true, 1)
@@ -88,6 +92,7 @@ RSPT_TU_W4_4(false, 0) RSPT_TU_W4_4(false, 1) RSPT_TU_W4_4(true, 0) RSPT_TU_W4_4
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_REF)
 RSPT_TU_REF8(false, 0) RSPT_TU_REF8(false, 1) RSPT_TU_REF8(true, 0) RSPT_TU_REF8(true, 1)
 RSPT_TU_FIX4(false, 0) RSPT_TU_FIX4(false, 1) RSPT_TU_FIX4(true, 0) RSPT_TU_FIX4(true, 1)
+RSPT_TU_REFA(false, 0) RSPT_TU_REFA(false, 1) RSPT_TU_REFA(true, 0) RSPT_TU_REFA(true, 1)
 #endif
 
 }  // namespace rspt

@@ -18,7 +18,7 @@ for f in sorted(glob.glob(work + "/*.ru")):
 with open(out, "w") as o:
     o.write("# Static budgets of every kernel of librspt.so (hipcc -Rpass-analysis=kernel-resource-usage, gfx950; source hash %s)\n\n" % h)
     o.write("Generated on the build host by `tools/kernel_budgets.sh` (no GPU needed). Feature masks of `k_shade<F>`: 4098 = diffuse, 2101314 = plastic, 2232390 = textured, "
-            "4290772991 = generic, 4294967295 = dynamic; `k_shade_w<F, W>` = built for W waves per SIMD. `k_tile_serial<INST, ALPHA, MODE>`: 0 path, 1 ao, 2 volpath, 3 directlighting, "
+            "4282384383 = generic, 4286578687 = dynamic (lobe lists built per hit), 4294967295 = + moving instances"
             "4 path with dynamic materials. `k_trace_w4<ANY, OUT_MODE, INST, ALPHA>`.\n\n| unit | kernel | VGPRs | scratch B/lane | LDS B/workgroup | waves/SIMD |\n|---|---|---|---|---|---|\n")
     for r in rows:
         o.write("| %s | `%s` | %d | %d | %d | %d |\n" % r)
