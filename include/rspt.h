@@ -434,8 +434,9 @@ typedef struct {
     uint32_t strat_jitter;           /* "jitter" (default true)                                                                      */
     uint32_t allow_slow_paths;       /* 0: configurations this library is known to run SLOWER than the host's own tile loop are answered with
                                         RSPT_E_UNSUPPORTED so that the caller keeps the faster CPU path — today: a pixel sampler (one lane per
-                                        16x16 tile, a tile is one serial PCG chain) with fewer than 8192 tiles in this shard (measured: 625 tiles
-                                        3.2 vs 7.1 Msamples/s on 256 host threads, 8160 tiles 11.9 vs 8.5; RSPT_SERIAL_MIN_TILES overrides).
+                                        16x16 tile, a tile is one serial PCG chain) with fewer than 2048 tiles in this shard (measured against 256
+                                        host threads, Msamples/s: 920 tiles 5.6 vs 8.9, 2040 tiles 11.2 vs 8.0, 8160 tiles 26.7 vs 7.3;
+                                        RSPT_SERIAL_MIN_TILES overrides).
                                         1: run them anyway (tests; a caller that wants the device's bit-identical sample values regardless) */
     const uint32_t* maxmin_c_pixel;  /* MaxMinDistSampler: the 32 columns of its generator matrix (lowdiscrepancy.rs:187-760, row log2 spp)  */
     /* Checkpoint / resume and progressive refinement (not in the reference, whose render loop is one-shot): render only

@@ -805,7 +805,12 @@ struct BinInfo {  // one per wavefront iteration, zeroed with the queue counters
 };
 // q_sorted / bi (K7b, when the shade queue is binned): the same entries sorted by class and padded to whole waves, so that a wave of this
 // kernel too evaluates ONE material's texture graph (escaped paths and the depth limit have waves of their own and return at once)
-RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
+#ifdef RSPT_TEX_WAVES   // A/B knob (tools/ab_build.sh AB_DEFS=-DRSPT_TEX_WAVES=3): the stage built for 3 / 4 waves per SIMD
+#define RSPT_TEX_OCC __attribute__((amdgpu_waves_per_eu(RSPT_TEX_WAVES, RSPT_TEX_WAVES)))
+#else
+#define RSPT_TEX_OCC
+#endif
+RSPT_PLAIN_KERNEL __launch_bounds__(256) RSPT_TEX_OCC void k_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active,
                                                  const uint32_t* __restrict__ count_in, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi) {
     const uint32_t n = q_sorted ? bi->total : *count_in;
     // inlined at this call site: as a call (the compiler's choice once the stage had a second caller) the launch runs 28 % longer — 248 VGPRs and

@@ -1381,7 +1381,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if (pixel_sampler) {
         size_t my_tiles = 0;
         for (size_t i = 0; i < blocks.size(); i++) my_tiles += (i / chunk) % shard_count == d->shard_index;
-        const size_t min_tiles = env_size("RSPT_SERIAL_MIN_TILES", 8192);
+        const size_t min_tiles = env_size("RSPT_SERIAL_MIN_TILES", 2048);   // (round 4, statue frame under 02sequence, GPU vs 256 host threads, Msamples/s: 920 tiles 5.6 / 8.9, 2040: 11.2 / 8.0, 4080: 19.3 / 7.8, 8160: 26.7 / 7.3)
         if (!d->allow_slow_paths && my_tiles < min_tiles)
             return fail(RSPT_E_UNSUPPORTED, "a pixel sampler over %zu tiles: one lane per tile is slower than the host's tile loop below ~%zu tiles (set allow_slow_paths to run it anyway)", my_tiles, min_tiles);
     }
