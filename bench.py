@@ -45,6 +45,7 @@ def parse():
                          "volpath: VolPathIntegrator (with --workload cornell the room is filled with a homogeneous medium)")
     ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "cornell_docs", "statue", "statue_tex", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--alpha-mask", action="store_true", help="soup1m: every triangle carries an image alpha mask (the foliage case: k_trace_w4<.., ALPHA>)")
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--instancing", default="reference", choices=["reference", "fixed"], help="c5: what a hit inside an object instance is (rspt_scene_desc.instancing_mode)")
@@ -86,9 +87,9 @@ def build_workload(args, workload, lib, scenes):
     integ = args.integrator
     if workload == "soup1m":
         res, spp = args.res or 1024, args.spp or 256
-        sc = scenes.triangle_soup(lib.bvh_build_gpu, n_tris=args.tris)
+        sc = scenes.triangle_soup(lib.bvh_build_gpu, n_tris=args.tris, alpha_mask=args.alpha_mask)
         mk = lambda s, sh, **kw: scenes.soup_render_desc(res=res, spp=s, max_depth=8, shard=sh, integrator=integ, **kw)  # noqa: E731
-        name = "synthetic %d-triangle soup, path depth 8, sobol %d spp, %dx%d" % (args.tris, spp, res, res)
+        name = "synthetic %d-triangle soup%s, path depth 8, sobol %d spp, %dx%d" % (args.tris, ", every triangle under an image alpha mask" if args.alpha_mask else "", spp, res, res)
     elif workload == "cornell":
         res, spp = args.res or 400, args.spp or 64
         sc = scenes.cornell_box(lib.bvh_build_gpu, fog=scenes.CORNELL_FOG if integ == "volpath" else None)
@@ -385,7 +386,7 @@ def main():
         samples_per_step = float(stats[0]["samples"])
 
     if rank == 0:
-        default_cfg = args.tris == 1_000_000 and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
+        default_cfg = args.tris == 1_000_000 and not args.alpha_mask and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
         traffic, tnote, stale = measured_traffic(lib, args.workload, default_cfg)
         ms_per_step = elapsed / args.steps * 1e3
         out = {

@@ -10,8 +10,21 @@ namespace rspt {
 // mesh flag bits packed into the 48-byte triangle record
 enum : uint32_t { MF_HAS_N = 1, MF_HAS_S = 2, MF_HAS_UV = 4, MF_FLIP = 8,
                   MF_ALPHA = 16,          // the mesh has an alpha_mask or a shadow_alpha_mask (triangle.rs:39-40)
-                  MF_INSTANCE = 0x100 };  // the record stands for a TransformedPrimitive: t0.x = instance index, t0.y = the four-box kernel's
+                  MF_INSTANCE = 0x100,
+                  MF_MASK_SHIFT = 12 };   // bits 12 .. 31: the mesh's entry in SceneDev::alpha_masks (scenes whose masks all have the simple form)  // the record stands for a TransformedPrimitive: t0.x = instance index, t0.y = the four-box kernel's
                                           // reference to the primitives that follow it in its leaf (RSPT_NONE: it is the last one)
+
+// A float texture used as alpha mask, in the two forms that cover what scene files use ("float imagemap" cut-outs and constants): at the alpha test
+// the interaction has no ray differentials (SurfaceInteraction::new), so an ImageTexture lookup is MipMap::triangle at level 0 whatever its filter
+// (mipmap.rs:233-262: width 0 -> level < 0; :268-275: minor axis 0) and only the texel's first channel is compared with 0.
+struct AlphaMask {
+    uint32_t kind;               // 0: no mask, 1: ConstantTexture (value), 2: ImageTexture under a UVMapping2D
+    float value;
+    float su, sv, du, dv;        // UVMapping2D (texture.rs:64-83)
+    uint32_t width, height, wrap, channels;
+    uint64_t base;               // level 0's first float in TexTables::texel_pool
+};
+struct AlphaEntry { AlphaMask alpha, shadow; };   // TriangleMesh.alpha_mask / shadow_alpha_mask (triangle.rs:39-40)
 
 // One ObjectInstance (api.rs:3024-3109): TransformedPrimitive { primitive: the object's aggregate or single primitive,
 // primitive_to_world } (primitive.rs:198-211), static transform
@@ -63,6 +76,9 @@ struct SceneDev {
     // vertex reads (a dependent round trip and up to seven 64-byte sectors per hit: the shade stage is bound by the bytes it moves).  nullptr = the
     // scene has no per-vertex normals or uvs (or too many primitives for the copy: the gathers remain)
     const float4* tri_nuv;
+    // alpha masks in the form k_trace_w4<.., ALPHA = 2> evaluates in line (kernels.h alpha_simple): one entry per distinct (alpha, shadowalpha) pair,
+    // addressed by the triangle record's flag bits; nullptr = some mask of the scene is a texture graph only alpha_pass / tex_eval can evaluate
+    const struct AlphaEntry* alpha_masks;
     const struct InstAnim* inst_anim;   // the keys of the moving instances (inst_at); nullptr = none
     const float* ray_time;              // [path slot] Ray.time of the path's rays (the camera sample's time, perspective.rs:226), set by rspt_render while a
                                         // scene with moving instances is rendered; nullptr = time 0 (rspt_trace)

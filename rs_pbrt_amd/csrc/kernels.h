@@ -209,6 +209,62 @@ __device__ __noinline__ bool alpha_pass(const SceneDev& sc, const TexTables& tt,
     return true;
 }
 
+// The same tests for scenes whose masks all have AlphaMask's form (SceneDev::alpha_masks), in line: no call, no texture-graph interpreter in the
+// traversal kernel's register budget (k_trace_w4<.., ALPHA = 1> carries tex_eval's: 178 - 200 VGPRs + 624 B of scratch = 2 waves / SIMD).
+// Operation for operation what alpha_pass -> tex_eval -> img_lookup -> img_triangle(level 0) computes for the first channel.
+RDEV float alpha_mask_value(const AlphaMask& m, const float* __restrict__ texel_pool, f2 uv) {
+    if (m.kind == 1u) return m.value;
+    const f2 st{uv.x * m.su + m.du, uv.y * m.sv + m.dv};
+    const uint32_t w = m.width ? m.width : 1u, h = m.height ? m.height : 1u;
+    const float s = st.x * (float)w - 0.5f, t = st.y * (float)h - 0.5f;
+    const int64_t s0 = f2i64(floorf(s)), t0 = f2i64(floorf(t));
+    const float ds = s - (float)s0, dt = t - (float)t0;
+    auto texel = [&](int64_t si, int64_t ti) {
+        uint64_t ss, tt;
+        if (m.wrap == RSPT_WRAP_REPEAT) { ss = (uint64_t)si % (uint64_t)w; tt = (uint64_t)ti % (uint64_t)h; }
+        else {
+            ss = (uint64_t)(si < 0 ? 0 : (si > (int64_t)w - 1 ? (int64_t)w - 1 : si));
+            tt = (uint64_t)(ti < 0 ? 0 : (ti > (int64_t)h - 1 ? (int64_t)h - 1 : ti));
+        }
+        return texel_pool[m.base + (size_t)m.channels * (tt * w + ss)];
+    };
+    const float tmp1 = texel(s0 + 1, t0 + 1) * (ds * dt);
+    const float tmp2 = texel(s0 + 1, t0) * (ds * (1.0f - dt));
+    const float tmp3 = texel(s0, t0 + 1) * ((1.0f - ds) * dt);
+    const float tmp4 = texel(s0, t0) * ((1.0f - ds) * (1.0f - dt));
+    return tmp4 + tmp3 + tmp2 + tmp1;
+}
+template <bool SHADOW>
+RDEV bool alpha_simple(const SceneDev& sc, const TexTables& tt, uint32_t pi, uint32_t flags, f3 p0, f3 p1, f3 p2, float b0, float b1, float b2) {
+    const AlphaEntry& e = sc.alpha_masks[flags >> MF_MASK_SHIFT];
+    const AlphaMask ma = e.alpha;
+    const uint32_t shadow_kind = SHADOW ? e.shadow.kind : 0u;
+    if (!ma.kind && !shadow_kind) return true;
+    f2 uv0{0.0f, 0.0f}, uv1{1.0f, 0.0f}, uv2{1.0f, 1.0f};  // triangle.rs:97-112
+    if ((flags & MF_HAS_UV) && sc.UV) {   // (the scene has its per-primitive copies: rspt_scene_create builds alpha_masks only then)
+        const float4* q = sc.tri_nuv + 5 * (size_t)pi;
+        const float4 q2 = q[2], q3 = q[3];
+        uv0 = f2{q2.y, q2.z}; uv1 = f2{q2.w, q3.x}; uv2 = f2{q3.y, q3.z};
+    }
+    if (SHADOW) {  // "the triangle is actually degenerate; the intersection is bogus" (triangle.rs:611-621)
+        const f2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
+        const f3 dp02 = p0 - p2, dp12 = p1 - p2;
+        const float det = duv02.x * duv12.y - duv02.y * duv12.x;
+        const bool degenerate = fabsf(det) < 1e-8f;
+        f3 dpdu{0.0f, 0.0f, 0.0f}, dpdv{0.0f, 0.0f, 0.0f};
+        if (!degenerate) {
+            const float invdet = 1.0f / det;
+            dpdu = (dp02 * duv12.y - dp12 * duv02.y) * invdet;
+            dpdv = (dp02 * -duv12.x + dp12 * duv02.x) * invdet;
+        }
+        if ((degenerate || len2(cross(dpdu, dpdv)) == 0.0f) && len2(cross(p2 - p0, p1 - p0)) == 0.0f) return false;
+    }
+    const f2 uv{uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2};
+    if (ma.kind && alpha_mask_value(ma, tt.texel_pool, uv) == 0.0f) return false;
+    if (SHADOW && shadow_kind) { const AlphaMask ms = e.shadow; if (alpha_mask_value(ms, tt.texel_pool, uv) == 0.0f) return false; }
+    return true;
+}
+
 struct TraceResult {
     uint32_t prim;
     float t, b0, b1, b2;
@@ -1310,7 +1366,7 @@ RSPT_PLAIN_KERNEL void k_ld_commit(LightLazy* lz) {
 
 // scene upload helper: build the 48-byte triangle records from the indexed ABI arrays
 RSPT_PLAIN_KERNEL void k_build_tris(const rspt_prim* __restrict__ prims, const rspt_mesh* __restrict__ meshes, const float* __restrict__ P, uint32_t n,
-                             float4* __restrict__ tris, const uint32_t* __restrict__ inst_cont) {
+                             float4* __restrict__ tris, const uint32_t* __restrict__ inst_cont, const uint32_t* __restrict__ mesh_mask) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     rspt_prim pr = prims[i];
@@ -1323,7 +1379,7 @@ RSPT_PLAIN_KERNEL void k_build_tris(const rspt_prim* __restrict__ prims, const r
     rspt_mesh m = meshes[pr.mesh];
     f3 p0 = ld3(P, pr.v[0]), p1 = ld3(P, pr.v[1]), p2 = ld3(P, pr.v[2]);
     uint32_t flags = (m.has_n ? MF_HAS_N : 0u) | (m.has_s ? MF_HAS_S : 0u) | (m.has_uv ? MF_HAS_UV : 0u) | (m.flip ? MF_FLIP : 0u) |
-                     ((m.alpha_tex || m.shadow_alpha_tex) ? MF_ALPHA : 0u);
+                     ((m.alpha_tex || m.shadow_alpha_tex) ? MF_ALPHA : 0u) | (mesh_mask ? mesh_mask[pr.mesh] << MF_MASK_SHIFT : 0u);
     tris[3 * (size_t)i] = make_float4(p0.x, p0.y, p0.z, p1.x);
     tris[3 * (size_t)i + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
     tris[3 * (size_t)i + 2] = make_float4(p2.z, __uint_as_float(pr.material), __uint_as_float((uint32_t)pr.area_light), __uint_as_float(flags));

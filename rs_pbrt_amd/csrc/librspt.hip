@@ -233,6 +233,8 @@ struct rspt_scene_s {
     bool has_null_material = false;
     uint32_t n_materials = 0;
     bool has_alpha = false;           // some mesh carries an alpha / shadow-alpha mask (Triangle::intersect's alpha tests)
+    bool alpha_simple = false;        // ... and every mask is a constant or a uv-mapped image (dev_scene.h AlphaMask): k_trace_w4<.., ALPHA = 2>
+    std::vector<uint64_t> image_base; // per image: its first float in the texel pool
     bool has_instances = false;       // object instances: two-level traversal (kernels.h traverse<ANY, true>)
     bool has_animated = false;        // ... some of them moving (dev_scene.h inst_at): the reference-order kernel serves the scene, `path` under Sobol' / Halton only
     std::map<int, LightDist> light_dists;  // by effective strategy
@@ -548,8 +550,11 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
     uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
     const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
-    if (special || (which >= 2 && s->w4_ok))
-        hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+    if (ALPHA && s->alpha_simple)   // every mask of the scene is evaluated in line (kernels.h alpha_simple): the traversal keeps its register budget
+        hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 2 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi);
+    else if (special || (which >= 2 && s->w4_ok))
+        hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 1 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
                            ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi);
     else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
@@ -2001,6 +2006,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                     n_tex += (size_t)w * h;
                 }
                 o.texel_base = pool.size();
+                s->image_base.push_back(o.texel_base);
                 pool.insert(pool.end(), im.texels, im.texels + n_tex * im.channels);
             }
             if ((rc = upload(s, pool.data(), pool.size(), &s->tex.texel_pool))) return bail(rc);
@@ -2172,11 +2178,6 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         s->w4_ok = recs.size() <= RSPT_W4_OFFSET_MASK && big.size() <= RSPT_W4_OFFSET_MASK;
         if (s->w4_ok && !recs.empty() && (rc = upload(s, recs.data(), recs.size(), &s->w4))) return bail(rc);
         if (!big.empty() && (rc = upload(s, big.data(), big.size(), &s->big_leaves))) return bail(rc);
-        bool any_alpha = false;
-        for (uint32_t i = 0; i < d->n_meshes; i++) any_alpha = any_alpha || d->meshes[i].alpha_tex || d->meshes[i].shadow_alpha_tex;
-        if (s->w4_ok && !instanced && !any_alpha && env_size("RSPT_SERIAL_W4", 1) != 0) {   // the per-lane kernels' traversal (trace_serial.h)
-            s->dev.w4 = s->w4; s->dev.w4_big = s->big_leaves; s->dev.w4_root = s->w4_root;
-        }
     }
     if (d->n_prims) {
         float4* tris = nullptr;
@@ -2185,10 +2186,53 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         s->allocs.push_back(tris);
         const uint32_t* inst_cont_d = nullptr;
         if ((rc = upload(s, inst_cont_h.data(), inst_cont_h.size(), &inst_cont_d))) return bail(rc);
-        hipLaunchKernelGGL(k_build_tris, dim3((uint32_t)((d->n_prims + 255) / 256)), dim3(256), 0, g.stream, s->dev.prims, meshes_d, P_d, (uint32_t)d->n_prims, tris, inst_cont_d);
+        // alpha masks in the in-line form (dev_scene.h AlphaMask; kernels.h alpha_simple): possible when every mask of the scene is a ConstantTexture or an
+        // ImageTexture under a UVMapping2D with finite parameters, and meshes with uvs have their per-primitive copies (tri_nuv)
+        const uint32_t* mesh_mask_d = nullptr;
+        if (s->has_alpha && env_size("RSPT_ALPHA_SIMPLE", 1) != 0) {
+            std::vector<AlphaEntry> entries;
+            std::vector<uint32_t> mesh_mask(d->n_meshes, 0u);
+            std::map<std::pair<uint32_t, uint32_t>, uint32_t> seen;
+            bool simple = s->image_base.size() == d->n_images;
+            auto mask_of = [&](uint32_t tex_plus_1, AlphaMask* m) {
+                memset(m, 0, sizeof *m);
+                if (!tex_plus_1) return true;
+                const rspt_texture& tx = d->textures[tex_plus_1 - 1u];
+                if (tx.kind == RSPT_TEX_CONSTANT) { m->kind = 1u; m->value = tx.value[0]; return true; }
+                if (tx.kind != RSPT_TEX_IMAGE || tx.mapping != RSPT_MAP_UV || tx.image >= d->n_images) return false;
+                for (int k = 0; k < 4; k++) if (!std::isfinite(tx.map[k])) return false;   // (0 * su must be 0: the lookup's zero differentials)
+                const rspt_image& im = d->images[tx.image];
+                if (!im.n_levels || im.n_levels > 27u) return false;   // (level = n_levels - 1 + log2(1e-8) must be negative: mipmap.rs:236-239)
+                m->kind = 2u; m->su = tx.map[0]; m->sv = tx.map[1]; m->du = tx.map[2]; m->dv = tx.map[3];
+                m->width = im.width; m->height = im.height; m->wrap = tx.wrap; m->channels = im.channels; m->base = s->image_base[tx.image];
+                return true;
+            };
+            for (uint32_t i = 0; i < d->n_meshes && simple; i++) {
+                const rspt_mesh& me = d->meshes[i];
+                if (!me.alpha_tex && !me.shadow_alpha_tex) continue;
+                if (me.has_uv && d->UV && !s->dev.tri_nuv) { simple = false; break; }
+                const auto key = std::make_pair(me.alpha_tex, me.shadow_alpha_tex);
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    AlphaEntry e;
+                    if (!mask_of(me.alpha_tex, &e.alpha) || !mask_of(me.shadow_alpha_tex, &e.shadow) || entries.size() >= (1u << (32 - MF_MASK_SHIFT))) { simple = false; break; }
+                    it = seen.emplace(key, (uint32_t)entries.size()).first;
+                    entries.push_back(e);
+                }
+                mesh_mask[i] = it->second;
+            }
+            if (simple && !entries.empty()) {
+                if ((rc = upload(s, entries.data(), entries.size(), &s->dev.alpha_masks)) || (rc = upload(s, mesh_mask.data(), mesh_mask.size(), &mesh_mask_d))) return bail(rc);
+                s->alpha_simple = true;
+            }
+        }
+        hipLaunchKernelGGL(k_build_tris, dim3((uint32_t)((d->n_prims + 255) / 256)), dim3(256), 0, g.stream, s->dev.prims, meshes_d, P_d, (uint32_t)d->n_prims, tris, inst_cont_d, mesh_mask_d);
         e = hipStreamSynchronize(g.stream);
         if (e != hipSuccess) return bail(fail(RSPT_E_HIP, "k_build_tris: %s", hipGetErrorString(e)));
         s->dev.tris = tris;
+        if (s->w4_ok && s->w4 && !instanced && (!s->has_alpha || s->alpha_simple) && env_size("RSPT_SERIAL_W4", 1) != 0) {   // the per-lane kernels' traversal (trace_serial.h)
+            s->dev.w4 = s->w4; s->dev.w4_big = s->big_leaves; s->dev.w4_root = s->w4_root;
+        }
     }
     if (instanced) {  // InstDev records
         std::vector<InstDev> ins(d->n_instances);

@@ -7,7 +7,7 @@
 // of the tree per fetch and its entries carry their entry distances, so a popped subtree that a closer hit has culled costs no fetch at all:
 // about a fifth of the round trips.  Same visiting order, same boxes, same arithmetic as k_trace_w4's node step (the argument of trace_w4.h's
 // header: a grandchild's box implies its parent's; `t_min < t_max` is re-checked on pop), triangles tested the moment a lane reaches a leaf —
-// so (prim, t, b0, b1, b2) and the final t_max are the reference's, bit for bit.  Scenes with object instances or alpha masks keep traverse<>.
+// so (prim, t, b0, b1, b2) and the final t_max are the reference's, bit for bit.  Scenes with object instances, or with alpha masks outside the in-line form (dev_scene.h AlphaMask), keep traverse<>.
 #pragma once
 #include "trace_w4.h"
 
@@ -15,8 +15,8 @@ namespace rspt {
 
 #define RSPT_SERIAL_LDS 16   // stack entries (8 B) per lane in the block's 8 KB of LDS (the 32 four-byte levels traverse<> uses); the rest in scratch
 
-template <bool ANY>
-RDEVN TraceResult traverse_w4(const SceneDev& sc, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column of the block's 32 x 64 words */) {
+template <bool ANY, bool ALPHA = false /* alpha masks in the in-line form (kernels.h alpha_simple) */>
+RDEVN TraceResult traverse_w4(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds_stack /* this lane's column of the block's 32 x 64 words */) {
     TraceResult res;
     res.prim = RSPT_MISS; res.t = 0.0f; res.b0 = res.b1 = res.b2 = 0.0f; res.nodes = 0; res.tris = 0; res.inst = 0; res.t_end = t_max;
     if (sc.n_nodes == 0) return res;
@@ -46,6 +46,8 @@ RDEVN TraceResult traverse_w4(const SceneDev& sc, f3 o, f3 d, float t_max, uint3
                 res.tris++;
                 float t, b0, b1, b2;
                 if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, o, rs, t_max, &t, &b0, &b1, &b2)) {
+                    if (ALPHA && (__float_as_uint(c.w) & MF_ALPHA) &&
+                        !alpha_simple<ANY>(sc, tt, pi, __float_as_uint(c.w), f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, b0, b1, b2)) continue;
                     if (ANY) { res.prim = 0; return res; }
                     t_max = t;   // primitive.rs:155
                     res.prim = pi; res.t = t; res.b0 = b0; res.b1 = b1; res.b2 = b2;
@@ -120,7 +122,7 @@ RDEVN TraceResult traverse_w4(const SceneDev& sc, f3 o, f3 d, float t_max, uint3
 // the traversal a per-lane kernel runs for one ray: the four-box records where the scene has them in the plain form
 template <bool ANY, bool INST, bool ALPHA>
 RDEV TraceResult serial_trace(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds) {
-    if (!INST && !ALPHA && sc.w4) return traverse_w4<ANY>(sc, o, d, t_max, lds);
+    if (!INST && sc.w4) return traverse_w4<ANY, ALPHA>(sc, tt, o, d, t_max, lds);   // (with alpha masks: rspt_scene_create sets w4 only when they have the in-line form)
     return traverse<ANY, INST, ALPHA, 64>(sc, tt, o, d, t_max, lds);
 }
 

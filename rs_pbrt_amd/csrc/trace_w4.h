@@ -112,7 +112,7 @@ RDEVN bool box_hit6_m(float lx, float ly, float lz, float hx, float hy, float hz
 // traverse<>).  Without INST the code is the one measured in DESIGN.md (the flag is a template parameter, not a branch).
 // ALPHA (scenes with alpha-masked meshes): a candidate that passed the watertight test on such a mesh is checked by alpha_pass
 // (kernels.h) before it counts — a call into the texture code, which is why this too is a template flag.
-template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
+template <bool ANY, int OUT_MODE, bool INST, int ALPHA /* 0: no masks, 1: alpha_pass (any texture graph, a call), 2: alpha_simple (in line) */>
 __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
@@ -404,13 +404,23 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                         }
                         float t, b0, b1, b2;
                         if (tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, INST ? f3{ox, oy, oz} : o, rs, t_max, &t, &b0, &b1, &b2)) {
-                            if (ALPHA && (__float_as_uint(c.w) & MF_ALPHA) && !alpha_pass<ANY>(sc, tt, pi, f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, b0, b1, b2)) continue;
-                            if (ANY) { best = 0; break; }
-                            t_max = t;       // primitive.rs:155: later pops compare their t_min with this
-                            best = pi; bt = t; bb0 = b0; bb1 = b1; bb2 = b2;
-                            if (INST) {
-                                if (inst != RSPT_NONE) { best_inst = inst + 1u; inst_hit = true; }
-                                else { best_inst = 0; hitflag = true; }
+                            bool there = true;
+                            if (ALPHA && (__float_as_uint(c.w) & MF_ALPHA)) {
+                                // (in line, the test must not see through (t, b): without this pin the <closest, INST> instantiations came out of hipcc 7.2 keeping
+                                //  the PREVIOUS hit's (t, b0, b1, b2) next to the new primitive index — tests/test_alpha_masks.py [instanced] catches it; the
+                                //  not-inlined build of alpha_simple was right but 4 % slower on the masked soup)
+                                if constexpr (ALPHA == 2) asm volatile("" : "+v"(t), "+v"(b0), "+v"(b1), "+v"(b2));
+                                if constexpr (ALPHA == 2) there = alpha_simple<ANY>(sc, tt, pi, __float_as_uint(c.w), f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, b0, b1, b2);
+                                else there = alpha_pass<ANY>(sc, tt, pi, f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, b0, b1, b2);
+                            }
+                            if (there) {
+                                if (ANY) { best = 0; break; }
+                                t_max = t;       // primitive.rs:155: later pops compare their t_min with this
+                                best = pi; bt = t; bb0 = b0; bb1 = b1; bb2 = b2;
+                                if (INST) {
+                                    if (inst != RSPT_NONE) { best_inst = inst + 1u; inst_hit = true; }
+                                    else { best_inst = 0; hitflag = true; }
+                                }
                             }
                         }
                     }

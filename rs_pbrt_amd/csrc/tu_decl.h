@@ -24,7 +24,8 @@ constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                              
 #define RSPT_TU_W4(ANY, OM, I, A) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, I, A>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
                                                                   const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*);
-#define RSPT_TU_W4_4(ANY, OM) RSPT_TU_W4(ANY, OM, false, false) RSPT_TU_W4(ANY, OM, false, true) RSPT_TU_W4(ANY, OM, true, false) RSPT_TU_W4(ANY, OM, true, true)
+#define RSPT_TU_W4_4(ANY, OM) RSPT_TU_W4(ANY, OM, false, 0) RSPT_TU_W4(ANY, OM, false, 1) RSPT_TU_W4(ANY, OM, true, 0) RSPT_TU_W4(ANY, OM, true, 1)
+#define RSPT_TU_W4_S(ANY, OM) RSPT_TU_W4(ANY, OM, false, 2) RSPT_TU_W4(ANY, OM, true, 2)   /* alpha masks evaluated in line (alpha_simple) */
 #define RSPT_TU_REF(ANY, OM, C, I, A) \
     RSPT_TU_X template __global__ void k_trace<ANY, OM, C, I, A>(SceneDev, TexTables, const uint32_t*, const uint32_t*, uint32_t, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, \
                                                                  unsigned long long*, uint32_t*);
@@ -88,6 +89,9 @@ RSPT_TU_SHADE(SV_DYNAMIC) RSPT_TU_SHADE(SF_ALL)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4)
 RSPT_TU_W4_4(false, 0) RSPT_TU_W4_4(false, 1) RSPT_TU_W4_4(true, 0) RSPT_TU_W4_4(true, 1)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4S)
+RSPT_TU_W4_S(false, 0) RSPT_TU_W4_S(false, 1) RSPT_TU_W4_S(true, 0) RSPT_TU_W4_S(true, 1)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_REF)
 RSPT_TU_REF8(false, 0) RSPT_TU_REF8(false, 1) RSPT_TU_REF8(true, 0) RSPT_TU_REF8(true, 1)

@@ -1204,9 +1204,11 @@ def _splitmix64(seed, n):
         return z ^ (z >> np.uint64(31))
 
 
-def triangle_soup(bvh_builder, n_tris=1_000_000, seed=0x5EED5EED, extent=0.01):
+def triangle_soup(bvh_builder, n_tris=1_000_000, seed=0x5EED5EED, extent=0.01, alpha_mask=False):
     """C2: centroids U[-1,1]^3, vertices = centroid + U[-extent,extent]^3, matte 0.5,
-    one 1x1 one-sided area light at y=+1.5 facing -y with L = 40."""
+    one 1x1 one-sided area light at y=+1.5 facing -y with L = 40.
+    alpha_mask: every triangle of the soup carries a "float imagemap" alpha texture (a 64 x 64 disc cut-out over the default uv of a mesh
+    without uvs, triangle.rs:97-112) — the foliage case: a candidate hit costs a texture lookup inside the traversal."""
     r = _splitmix64(seed, n_tris * 12)
     u = ((r >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).reshape(n_tris, 12)
     c = u[:, :3] * 2.0 - 1.0
@@ -1215,7 +1217,12 @@ def triangle_soup(bvh_builder, n_tris=1_000_000, seed=0x5EED5EED, extent=0.01):
     idx = np.arange(n_tris * 3, dtype=np.uint32).reshape(-1, 3)
     sb = SceneBuilder()
     grey = sb.add_material(matte((0.5, 0.5, 0.5)))
-    sb.add_mesh(P, idx, grey)
+    mask = None
+    if alpha_mask:
+        g = (np.arange(64, dtype=np.float64) + 0.5) / 64.0
+        disc = (((g[None, :] - 0.62) ** 2 + (g[:, None] - 0.38) ** 2) < 0.33 ** 2).astype(F32)   # centred on the uv triangle (0,0) (1,0) (1,1): about half of it stays
+        mask = sb.image_texture(np.repeat(disc[:, :, None], 3, axis=2), channels=1)
+    sb.add_mesh(P, idx, grey, alpha=mask)
     sb.add_quad([(0.5, 1.5, -0.5), (0.5, 1.5, 0.5), (-0.5, 1.5, 0.5), (-0.5, 1.5, -0.5)], grey, emit=(40, 40, 40))
     return sb.finish(bvh_builder)
 

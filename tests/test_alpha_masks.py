@@ -136,3 +136,108 @@ def test_gpu_image_alpha_mask_and_refusal(gpu, oracle):
     with pytest.raises(RsptError) as e:
         gpu.DeviceScene(sc2)
     assert e.value.code == abi.E_UNSUPPORTED
+
+
+def image_masked_scene(builder, form):
+    """the panel scene with masks in the forms rspt_scene_create turns into in-line records (dev_scene.h AlphaMask): "float imagemap" cut-outs under a
+    UVMapping2D and constants — and one form it must leave to the general evaluator (a checkerboard next to image masks)"""
+    rng = np.random.default_rng(11)
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.6, 0.6, 0.6)))
+    green = sb.add_material(scenes.matte((0.2, 0.55, 0.2)))
+    sb.add_quad([(-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4)], grey)
+    sb.add_quad([(-4, 0, 2.97), (-4, 5, 2.97), (4, 5, 2.97), (4, 0, 2.97)], grey)
+    sb.add_quad([(-1, 4.47, -1), (1, 4.47, -1), (1, 4.47, 1), (-1, 4.47, 1)], grey, emit=(12, 12, 12))
+    sb.add_point_light((0, 2, -4), (25, 25, 25))
+    img1 = (rng.random((16, 16, 3)) > 0.45).astype(np.float32)
+    img3 = (rng.random((8, 12, 3)) > 0.4).astype(np.float32) * rng.random((8, 12, 3)).astype(np.float32)   # three channels: only the first one counts
+    panel = np.array([(-1.0, 0.2, 0.97), (1.0, 0.2, 0.97), (1.0, 2.2, 0.97), (-1.0, 2.2, 0.97)], np.float32)
+    uv = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    leaf = np.array([(-2.6, 0.3, 0.2), (-1.4, 0.5, 0.4), (-2.0, 1.9, 0.3)], np.float32)   # a mesh without uvs: (0,0) (1,0) (1,1), triangle.rs:97-112
+    if form == "repeat":       # EWA filter (the default), repeat wrap, scaled and shifted uvs
+        m = sb.image_texture(img1, channels=1, su=2.0, sv=3.0, du=0.25, dv=-0.4)
+        sb.add_quad(panel, green, UV=uv, alpha=m)
+        sb.add_mesh(leaf, [[0, 1, 2]], green, alpha=m)
+    elif form == "clamp-trilinear":
+        m = sb.image_texture(img1, channels=1, su=1.5, sv=1.5, du=-0.2, dv=-0.2, wrap="clamp", trilinear=True)
+        sb.add_quad(panel, green, UV=uv, alpha=m)
+        sb.add_mesh(leaf, [[0, 1, 2]], green, alpha=sb.image_texture(img3, channels=3, wrap="black", su=1.3, sv=0.8))
+    elif form == "shadow":     # alpha and shadowalpha are different textures; a second mesh has the shadow mask only
+        m = sb.image_texture(img1, channels=1, su=2.0, sv=2.0)
+        ms = sb.image_texture(img3, channels=3, su=1.0, sv=2.0)
+        sb.add_quad(panel, green, UV=uv, alpha=m, shadow_alpha=ms)
+        sb.add_mesh(leaf, [[0, 1, 2]], green, shadow_alpha=m)
+    elif form == "constants":  # "float alpha 0" removes a mesh, 1 keeps it; a degenerate uv set under a shadow mask (triangle.rs:611-621)
+        sb.add_quad(panel, green, UV=uv, alpha=sb.constant_texture(0.0))
+        sb.add_mesh(leaf, [[0, 1, 2]], green, alpha=sb.constant_texture(1.0))
+        sb.add_mesh(leaf + np.float32(0.8), [[0, 1, 2]], green, UV=[[0.5, 0.5], [0.5, 0.5], [0.5, 0.5]], shadow_alpha=sb.constant_texture(1.0))
+    elif form == "instanced":
+        m = sb.image_texture(img1, channels=1, su=2.0, sv=2.0)
+        sb.begin_object("panel")
+        sb.add_mesh(panel - np.array([0, 0, 0.97], np.float32), [[0, 1, 2], [0, 2, 3]], green, UV=uv, alpha=m)
+        sb.add_mesh(np.array([(-0.2, 0, 0.3), (0.2, 0, 0.3), (0, 0.4, 0.3)], np.float32), [[0, 1, 2]], green, shadow_alpha=m)
+        sb.end_object()
+        sb.add_instance("panel", scenes.Transform.translate((0, 0, 0.97)) * scenes.Transform.rotate_y(8.0))
+        sb.add_instance("panel", scenes.Transform.translate((2.6, 0.3, 0.5)) * scenes.Transform.scale(0.6, 0.8, 1.0))
+        return sb.finish(builder, instancing="fixed")
+    elif form == "mixed-with-a-graph":   # one mask is a checkerboard: the whole scene stays with the general evaluator
+        sb.add_quad(panel, green, UV=uv, alpha=sb.image_texture(img1, channels=1, su=2.0, sv=2.0))
+        sb.add_mesh(leaf, [[0, 1, 2]], green, alpha=sb.checkerboard_texture(sb.constant_texture(0.0), sb.constant_texture(1.0), su=3.0, sv=3.0))
+    else:
+        raise ValueError(form)
+    return sb.finish(builder)
+
+
+def test_oracle_image_alpha_masks_remove_light_blockers(oracle):
+    """CPU: the forms above change what the oracle renders (masks are really applied), "float alpha 0" equals leaving the mesh out"""
+    sc = image_masked_scene(oracle.bvh_build, "constants")
+    rays = rays_at_panel(4000, 9)
+    hit = oracle.trace(sc, rays, any_hit=False)
+    assert (hit["prim"][np.abs(rays["o"][:, 0] + rays["d"][:, 0] * 2.97 / rays["d"][:, 2]) < 0.9] != 0xffffffff).all()   # they reach the wall behind the removed panel
+    sb = image_masked_scene(oracle.bvh_build, "repeat")
+    a = oracle.render(sb, scenes.make_render_desc(32, 24, 4, LOOK, 50.0), threads=8)["film"]
+    b = oracle.render(masked_scene(oracle.bvh_build, plain=True), scenes.make_render_desc(32, 24, 4, LOOK, 50.0), threads=8)["film"]
+    assert not np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["repeat", "clamp-trilinear", "shadow", "constants", "instanced", "mixed-with-a-graph"])
+def test_gpu_inline_alpha_masks_match_oracle_and_the_general_evaluator(gpu, oracle, form, monkeypatch):
+    """k_trace_w4<.., ALPHA = 2> (kernels.h alpha_simple: masks as in-line records, no texture-graph interpreter in the traversal) against the oracle and
+    against the general path (RSPT_ALPHA_SIMPLE=0: alpha_pass -> tex_eval): hit records byte for byte, every sample's radiance bit for bit"""
+    sc = image_masked_scene(gpu.bvh_build, form)
+    rays = np.concatenate([rays_at_panel(30000, 5), random_rays(30000, 6, -3.0, 3.0)])
+    rd = scenes.make_render_desc(64, 48, 8, LOOK, 50.0)
+    ref = oracle.render(sc, rd, threads=8, want_li=True)
+    ref_hits = {a: oracle.trace(sc, rays, any_hit=a).tobytes() for a in (False, True)}
+    for simple in ("1", "0"):
+        monkeypatch.setenv("RSPT_ALPHA_SIMPLE", simple)
+        with gpu.DeviceScene(sc) as ds:
+            for any_hit in (False, True):
+                assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == ref_hits[any_hit], (simple, any_hit)
+            li = gpu.render_samples(ds, rd)[0]
+            film, st = gpu.render(ds, rd)
+        assert np.array_equal(li, ref["li"]), (simple, int((li != ref["li"]).any(axis=2).sum()))
+        assert st["samples"] == ref["counters"]["samples"] and np.array_equal(film[:, 3], ref["film"][:, 3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(sampler="02sequence"), dict(sampler="random", integrator="directlighting", max_depth=3),
+                                dict(sampler="stratified", strat=(2, 2), integrator="ao", ao_samples=4), dict(integrator="directlighting", max_depth=12)],
+                         ids=["02sequence-path", "random-directlighting", "stratified-ao", "sobol-directlighting-per-lane"])
+def test_gpu_per_lane_kernels_with_inline_alpha_masks(gpu, oracle, kw, monkeypatch):
+    """the per-lane kernels (k_tile_serial, k_lane_dl) on a scene whose masks have the in-line form: they take the four-box traversal
+    (trace_serial.h traverse_w4<.., ALPHA>) instead of the reference-order loop — same films as the oracle's and as the general evaluator's"""
+    films = []
+    for form in ("repeat", "shadow"):
+        sc = image_masked_scene(gpu.bvh_build, form)
+        rd = scenes.make_render_desc(64, 48, 4, LOOK, 50.0, **kw)
+        ref = oracle.render_integrator(sc, rd, "direct", threads=8) if kw.get("integrator") == "directlighting" else oracle.render(sc, rd, threads=8)
+        for simple in ("1", "0"):
+            monkeypatch.setenv("RSPT_ALPHA_SIMPLE", simple)
+            with gpu.DeviceScene(sc) as ds:
+                film, st = gpu.render(ds, rd)
+            assert st["samples"] == ref["counters"]["samples"] and np.array_equal(film[:, 3], ref["film"][:, 3])
+            assert film_rmse(film, ref["film"]) < 2e-5, (form, simple)
+            films.append(film)
+        assert np.array_equal(films[-1], films[-2]), form   # one lane per tile / per camera sample: the accumulation order is fixed, the two evaluators agree bit for bit
