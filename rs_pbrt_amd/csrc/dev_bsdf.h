@@ -27,6 +27,7 @@ enum : uint32_t {
     SF_HALTON = 1u << 20,      // the Halton sampler (else Sobol' from the LDS block)
     SF_VERTEX = 1u << 21,      // meshes with per-vertex normals / tangents / uvs
     SF_DYNAMIC = 1u << 22,     // materials whose lobe list is built per hit (material_assembly.h build_part)
+    SF_SOBOL = 1u << 24,       // the Sobol' sampler; an instantiation with SF_HALTON and without this bit serves Halton renders only (no Sobol' block, no LDS tables)
     SF_ANIM = 1u << 23,        // moving object instances (dev_scene.h inst_at): only the all-features instantiation carries the interpolation
     SF_ALL = 0xffffffffu
 };

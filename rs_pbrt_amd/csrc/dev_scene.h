@@ -292,14 +292,14 @@ RDEV float halton_dim(const RenderDev& rd, uint64_t index, uint32_t dim) {  // s
 
 // the sampler cursor of the shade stage: Sobol' dimensions come from the LDS block, Halton's are
 // computed on demand (both are pure functions of (index, dimension): GlobalSampler, sampler.rs)
-template <bool HALTON_POSSIBLE = true>
+template <bool HALTON_POSSIBLE = true, bool SOBOL_POSSIBLE = true>
 struct PathSamplerT {
     SobolBlock blk;
     uint64_t index;
     uint32_t hdim;
     bool halton;
     RDEV void start(const RenderDev& rd, const uint32_t* __restrict__ tab, uint32_t nd, uint64_t idx, uint32_t first_dim) {
-        halton = HALTON_POSSIBLE && rd.sampler_kind == RSPT_SAMPLER_HALTON;
+        halton = HALTON_POSSIBLE && (!SOBOL_POSSIBLE || rd.sampler_kind == RSPT_SAMPLER_HALTON);
         index = idx;
         hdim = first_dim;
         if (!halton) blk.fill(tab, nd, idx, first_dim);

@@ -962,7 +962,7 @@ __device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDist
                                              uint32_t sob_nd, uint32_t sob_bits, uint32_t qcap, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi,
                                              uint32_t* sob_tab, uint32_t (*s_wave)[5], uint32_t* s_base) {
     // sob_tab: Sobol' generator matrices of the dimensions this render can reach, transposed to [bit][dim]
-    for (uint32_t t = threadIdx.x; (!(F & SF_HALTON) || rd.sampler_kind == RSPT_SAMPLER_SOBOL) && t < sob_nd * sob_bits; t += 256u) {
+    for (uint32_t t = threadIdx.x; ((F & SF_SOBOL) || !(F & SF_HALTON)) && (!(F & SF_HALTON) || rd.sampler_kind == RSPT_SAMPLER_SOBOL) && t < sob_nd * sob_bits; t += 256u) {
         uint32_t dd = t % sob_nd;  // read-ahead columns past the last of the 1024 dimensions are never consumed
         sob_tab[t] = rd.sobol32[(dd < 1024u ? dd : 1023u) * 52u + (t / sob_nd)];
     }

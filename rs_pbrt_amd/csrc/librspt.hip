@@ -596,6 +596,9 @@ const ShadeVariant g_shade_variants[] = {
                                                                                                            //  cost the four registers; the 3-wave build fits 168 without scratch: Cornell 875 -> see profiles/r04_*)
     {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
     {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0},
+    {SV_DIFFUSE_H, "diffuse-halton", k_shade<SV_DIFFUSE_H>, k_shade_w<SV_DIFFUSE_H, 3>, k_shade_w<SV_DIFFUSE_H, 3>, 3},   // (tu_decl.h: the reference's default sampler gets the narrow builds too)
+    {SV_PLASTIC_H, "plastic-halton", k_shade<SV_PLASTIC_H>, k_shade_w<SV_PLASTIC_H, 3>, k_shade_w<SV_PLASTIC_H, 3>, 3},
+    {SV_TEXTURED_H, "textured-halton", k_shade<SV_TEXTURED_H>, k_shade_w<SV_TEXTURED_H, 3>, k_shade_w<SV_TEXTURED_H, 3>, 3},   // (textured C3 stand-in: 1343 as compiled, 1358 at 3 waves)
     {SV_GENERIC, "generic", k_shade<SV_GENERIC>, k_shade_w<SV_GENERIC, 3>, k_shade_w<SV_GENERIC, 4>, 0},
     {SV_DYNAMIC, "dynamic", k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, 0},   // + lobe lists built per hit (material_assembly.h)
     {SF_ALL, "moving", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0},                     // + moving object instances (dev_scene.h inst_at)
@@ -936,7 +939,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     if ((size_t)sob_nd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
     const uint32_t tgrid = trace_grid();
     const char* shade_name = "generic";
-    const ShadeKernel shade_k = shade_kernel_for(s->shade_features | (halton ? (uint32_t)SF_HALTON : 0u), &shade_name);
+    const ShadeKernel shade_k = shade_kernel_for(s->shade_features | (halton ? (uint32_t)SF_HALTON : (uint32_t)SF_SOBOL), &shade_name);
     if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shade stage instantiation '%s' (scene features %#x)\n", shade_name, s->shade_features);
     // one launch fills the chip once: as many 256-thread blocks per CU as the instantiation's registers and the LDS table allow
     int shade_blocks = 2;

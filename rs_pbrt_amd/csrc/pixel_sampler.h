@@ -209,9 +209,9 @@ struct PixSampler {
 // or the tile's pixel sampler
 template <bool PIX>
 struct ShadeSampler;
-template <bool HALTON_POSSIBLE>
+template <bool HALTON_POSSIBLE, bool SOBOL_POSSIBLE = true>
 struct ShadeSamplerG {
-    PathSamplerT<HALTON_POSSIBLE> g;
+    PathSamplerT<HALTON_POSSIBLE, SOBOL_POSSIBLE> g;
     RDEV void bind(PixSampler*) {}
     RDEV void start(const RenderDev& rd, const uint32_t* __restrict__ tab, uint32_t nd, uint64_t idx, uint32_t first_dim) { g.start(rd, tab, nd, idx, first_dim); }
     RDEV uint32_t dim() const { return g.dim(); }
@@ -233,6 +233,6 @@ struct ShadeSampler<true> {
 template <bool PIX, uint32_t F>
 struct ShadeSamplerFor { using type = ShadeSampler<true>; };
 template <uint32_t F>
-struct ShadeSamplerFor<false, F> { using type = ShadeSamplerG<(F & SF_HALTON) != 0>; };
+struct ShadeSamplerFor<false, F> { using type = ShadeSamplerG<(F & SF_HALTON) != 0, (F & SF_SOBOL) != 0 || (F & SF_HALTON) == 0>; };
 
 }  // namespace rspt

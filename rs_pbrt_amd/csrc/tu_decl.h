@@ -10,10 +10,13 @@
 namespace rspt {
 
 // ---- the shade stage's feature sets (kernels.h k_shade<F>; librspt.hip g_shade_variants) ----
-constexpr uint32_t SV_DIFFUSE = RSPT_SF_LOBE(RSPT_BXDF_LAMBERT_R) | SF_L_AREA;                      // matte scenes under area lights: C1, C2
+constexpr uint32_t SV_DIFFUSE = RSPT_SF_LOBE(RSPT_BXDF_LAMBERT_R) | SF_L_AREA | SF_SOBOL;           // matte scenes under area lights: C1, C2
 constexpr uint32_t SV_PLASTIC = SV_DIFFUSE | RSPT_SF_LOBE(RSPT_BXDF_MICROFACET_R) | SF_VERTEX;      // + plastic, smooth-shaded meshes: the C3 stand-in
 constexpr uint32_t SV_TEXTURED = SV_PLASTIC | RSPT_SF_LOBE(RSPT_BXDF_OREN_NAYAR) | SF_TEX;          // + textured materials: the C4 stand-in
 constexpr uint32_t SV_GENERIC = SF_ALL & ~SF_DYNAMIC & ~SF_ANIM;
+// the same three under the Halton sampler (the reference's default, api.rs:526): without them a Halton render took the generic instantiation
+// (212 VGPRs = 2 waves: C2 403 against Sobol's 473 M samples/s, the C3 stand-in 1705 against 2018)
+constexpr uint32_t SV_DIFFUSE_H = (SV_DIFFUSE & ~SF_SOBOL) | SF_HALTON, SV_PLASTIC_H = (SV_PLASTIC & ~SF_SOBOL) | SF_HALTON, SV_TEXTURED_H = (SV_TEXTURED & ~SF_SOBOL) | SF_HALTON;
 constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                                                  // + per-hit lobe lists; SF_ALL itself: + moving instances
 
 #define RSPT_TU_TS(I, A, M) \
@@ -86,6 +89,9 @@ RSPT_TU_SHADE(SV_TEXTURED) RSPT_TU_SHADE_W(SV_TEXTURED, 3) RSPT_TU_SHADE_W(SV_TE
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_C)
 RSPT_TU_SHADE(SV_GENERIC) RSPT_TU_SHADE_W(SV_GENERIC, 3) RSPT_TU_SHADE_W(SV_GENERIC, 4)
 RSPT_TU_SHADE(SV_DYNAMIC) RSPT_TU_SHADE(SF_ALL)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_H)
+RSPT_TU_SHADE(SV_DIFFUSE_H) RSPT_TU_SHADE_W(SV_DIFFUSE_H, 3) RSPT_TU_SHADE(SV_PLASTIC_H) RSPT_TU_SHADE_W(SV_PLASTIC_H, 3) RSPT_TU_SHADE(SV_TEXTURED_H) RSPT_TU_SHADE_W(SV_TEXTURED_H, 3)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4)
 RSPT_TU_W4_4(false, 0) RSPT_TU_W4_4(false, 1) RSPT_TU_W4_4(true, 0) RSPT_TU_W4_4(true, 1)
