@@ -45,6 +45,7 @@ def parse():
                          "volpath: VolPathIntegrator (with --workload cornell the room is filled with a homogeneous medium)")
     ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "cornell_docs", "statue", "statue_tex", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--filter", default="box", choices=["box", "gaussian"], help="pixel filter: the reference's default box 0.5 x 0.5, or gaussian radius 2 alpha 2 (every sample lands in ~16 pixels: k_film's splat path)")
     ap.add_argument("--alpha-mask", action="store_true", help="soup1m: every triangle carries an image alpha mask (the foliage case: k_trace_w4<.., ALPHA>)")
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -124,6 +125,12 @@ def build_workload(args, workload, lib, scenes):
                 ", image-textured + bump-mapped" if tex else "", ", 64 small area lights (C4 stand-in)" if workload == "c4" else "", spp, xres, yres)
     if integ != "path":
         name += " [%s integrator]" % integ
+    if args.filter == "gaussian":
+        plain_mk = mk
+
+        def mk(s, sh, **kw):  # noqa: E731
+            return plain_mk(s, sh, filter_radius=(2.0, 2.0), filter_table=scenes.gaussian_filter_table((2.0, 2.0), 2.0), **kw)
+        name += " [gaussian filter, radius 2]"
     if args.sampler != "sobol":   # the default of every workload above
         base_mk = mk
 
@@ -386,7 +393,7 @@ def main():
         samples_per_step = float(stats[0]["samples"])
 
     if rank == 0:
-        default_cfg = args.tris == 1_000_000 and not args.alpha_mask and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
+        default_cfg = args.tris == 1_000_000 and not args.alpha_mask and args.filter == "box" and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
         traffic, tnote, stale = measured_traffic(lib, args.workload, default_cfg)
         ms_per_step = elapsed / args.steps * 1e3
         out = {

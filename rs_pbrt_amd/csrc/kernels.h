@@ -1193,6 +1193,115 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_film(RenderDev rd, Batch bt, Pat
     if (nans) atomicAdd(nan_count, nans);
 }
 
+// ---- K8 for filters wider than a pixel (gaussian / mitchell / triangle / sinc scene files): a gather -------------------------------
+// k_film above adds a sample to its own pixel in registers and to every other pixel of its footprint through four atomics: with a radius-2
+// filter that is 60 atomics per sample, and the stage took 309 ms of a C2 step (2.4 ms under the box filter) and two thirds of a C3 step.
+// Here a block owns 16 x 16 pixels of the sample-bounds grid; it stages the samples of those pixels and of a K-pixel halo (K = floor(radius + 0.5):
+// the pixels whose samples can reach the block) through LDS, RSPT_FG chunk samples per pixel at a time — NaN test, luminance clamp and the
+// footprint box (film.rs:94-147) are done once per sample there — and every thread sums what reaches ITS pixel: the arithmetic per (sample,
+// pixel) pair is add_sample's, the order of a pixel's additions is fixed (source pixels row by row, samples in order; the reference's own
+// order depends on which thread finishes a tile first), nothing is atomic and nothing lands in film_splat.
+// pix_index[(y - sb1) * sbw + (x - sb0)] = position of pixel (x, y) in the pixel list the batch indexes, 0xffffffff = not in it.
+#define RSPT_FG_T 16u
+#define RSPT_FG_NONE 0xffffffffu
+RSPT_PLAIN_KERNEL void k_pix_index(const uint32_t* __restrict__ pix_list, uint32_t n, int32_t sb0, int32_t sb1, int32_t sbw, uint32_t* __restrict__ pix_index) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pk = pix_list[i];
+    const int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
+    pix_index[(size_t)(py - sb1) * sbw + (size_t)(px - sb0)] = i;
+}
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_film_gather(RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_index, int32_t K, uint32_t chunk,
+                                                     float4* __restrict__ film_own, float* __restrict__ li_out, unsigned long long* nan_count) {
+    extern __shared__ float4 fg_smem[];
+    const int32_t* sb = rd.sample_bounds;
+    const int32_t* cp = rd.crop_px;
+    const int32_t S = (int32_t)RSPT_FG_T + 2 * K, sbw = sb[2] - sb[0];
+    const uint32_t row = chunk + 1u;   // padded sample row of a source pixel
+    float4* s_a = fg_smem;                                                   // [S * S][row]: clamped L rgb, dx
+    float2* s_b = reinterpret_cast<float2*>(s_a + (size_t)S * S * row);      // [S * S][row]: dy, footprint box (4 x int8 relative to the block's origin)
+    uint32_t* s_pos = reinterpret_cast<uint32_t*>(s_b + (size_t)S * S * row);  // [S * S]: the source pixel's position in this batch, or NONE
+    float* s_tab = reinterpret_cast<float*>(s_pos + S * S);                  // the 16 x 16 filter table
+    const int32_t bx = sb[0] + (int32_t)(blockIdx.x * RSPT_FG_T), by = sb[1] + (int32_t)(blockIdx.y * RSPT_FG_T);
+    int any = 0;
+    for (int32_t e = (int32_t)threadIdx.x; e < S * S; e += 256) {
+        const int32_t sx = bx - K + e % S, sy = by - K + e / S;
+        uint32_t pos = RSPT_FG_NONE;
+        if (sx >= sb[0] && sx < sb[2] && sy >= sb[1] && sy < sb[3]) pos = pix_index[(size_t)(sy - sb[1]) * sbw + (size_t)(sx - sb[0])];
+        const bool in_batch = pos != RSPT_FG_NONE && pos >= bt.pix0 && pos - bt.pix0 < bt.n_pix;
+        s_pos[e] = in_batch ? pos - bt.pix0 : RSPT_FG_NONE;
+        any |= in_batch ? 1 : 0;
+    }
+    s_tab[threadIdx.x] = rd.filter_table[threadIdx.x];
+    if (!__syncthreads_or(any)) return;   // none of this batch's samples can reach the block
+    const int32_t tx = (int32_t)(threadIdx.x % RSPT_FG_T), ty = (int32_t)(threadIdx.x / RSPT_FG_T);
+    const int32_t x = bx + tx, y = by + ty;
+    const int32_t cw = cp[2] - cp[0];
+    const bool in_crop = x >= cp[0] && x < cp[2] && y >= cp[1] && y < cp[3];
+    const size_t idx = in_crop ? (size_t)(y - cp[1]) * cw + (size_t)(x - cp[0]) : 0;
+    float4 acc = in_crop ? film_own[idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float rx = rd.filter_radius[0], ry = rd.filter_radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    unsigned long long nans = 0;
+    for (uint32_t j0 = 0; j0 < bt.ns; j0 += chunk) {
+        const uint32_t cs = min(chunk, bt.ns - j0);
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < (uint32_t)(S * S) * cs; e += 256u) {
+            const uint32_t pl = e / cs, sj = e % cs;   // consecutive e -> consecutive slots of one pixel's run
+            const uint32_t p = s_pos[pl];
+            float4 oa = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float2 ob = make_float2(0.0f, __uint_as_float(0x00000000u));   // an empty box (x1 = x0)
+            if (p != RSPT_FG_NONE) {
+                const uint32_t slot = p * bt.ns + j0 + sj;
+                const float4 le = pb.L_eta[slot];
+                const float2 pf = pb.p_film[slot];
+                rgb l{le.x, le.y, le.z};
+                const int32_t sx = bx - K + (int32_t)pl % S, sy = by - K + (int32_t)pl / S;   // the sample's own pixel
+                const bool mine = sx >= bx && sx < bx + (int32_t)RSPT_FG_T && sy >= by && sy < by + (int32_t)RSPT_FG_T;   // counted / reported by exactly one block
+                if (has_nans(l)) { l = mkrgb(0.0f); if (mine) nans++; }  // integrator.rs:165-173
+                if (li_out && mine && sx >= cp[0] && sx < cp[2] && sy >= cp[1] && sy < cp[3]) {
+                    float* o = li_out + (((size_t)(sy - cp[1]) * cw + (size_t)(sx - cp[0])) * (size_t)rd.spp + (size_t)(bt.s0 + j0 + sj)) * 3;
+                    o[0] = l.r; o[1] = l.g; o[2] = l.b;
+                }
+                if (lum(l) > rd.max_sample_luminance) l = l * mkrgb(rd.max_sample_luminance / lum(l));
+                const float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
+                // the footprint (film.rs:104-116); a FilmTile's own pixel bounds never cut it (they are the tile's sample bounds grown by the radius), the crop window does
+                const int32_t x0 = max(f2i_sat(ceilf(dx - rx)), cp[0]) - bx, y0 = max(f2i_sat(ceilf(dy - ry)), cp[1]) - by;
+                const int32_t x1 = min(f2i_sat(floorf(dx + rx)) + 1, cp[2]) - bx, y1 = min(f2i_sat(floorf(dy + ry)) + 1, cp[3]) - by;
+                auto b8 = [](int32_t v) { return (uint32_t)(v < -128 ? -128 : (v > 127 ? 127 : v)) & 0xffu; };
+                oa = make_float4(l.r, l.g, l.b, dx);
+                ob = make_float2(dy, __uint_as_float(b8(x0) | (b8(x1) << 8) | (b8(y0) << 16) | (b8(y1) << 24)));
+            }
+            s_a[pl * row + sj] = oa;
+            s_b[pl * row + sj] = ob;
+        }
+        __syncthreads();
+        if (!in_crop) continue;
+        for (int32_t dyy = -K; dyy <= K; dyy++)
+            for (int32_t dxx = -K; dxx <= K; dxx++) {
+                const uint32_t pl = (uint32_t)((ty + K + dyy) * S + (tx + K + dxx));
+                if (s_pos[pl] == RSPT_FG_NONE) continue;
+                for (uint32_t sj = 0; sj < cs; sj++) {
+                    const float2 b = s_b[pl * row + sj];
+                    const uint32_t box = __float_as_uint(b.y);
+                    const int32_t x0 = (int32_t)(int8_t)(box & 0xffu), x1 = (int32_t)(int8_t)((box >> 8) & 0xffu);
+                    const int32_t y0 = (int32_t)(int8_t)((box >> 16) & 0xffu), y1 = (int32_t)(int8_t)(box >> 24);
+                    if (tx < x0 || tx >= x1 || ty < y0 || ty >= y1) continue;
+                    const float4 a = s_a[pl * row + sj];
+                    const float fy = fabsf(((float)y - b.x) * inv_ry * 16.0f);
+                    const int32_t ify = (int32_t)fminf(floorf(fy), 15.0f);
+                    const float fx = fabsf(((float)x - a.w) * inv_rx * 16.0f);
+                    const int32_t ifx = (int32_t)fminf(floorf(fx), 15.0f);
+                    const float w = s_tab[ify * 16 + ifx];
+                    const rgb c = rgb{a.x, a.y, a.z} * mkrgb(1.0f) * mkrgb(w);  // l * sample_weight * filter_weight
+                    acc.x += c.r; acc.y += c.g; acc.z += c.b; acc.w += w;
+                }
+            }
+    }
+    if (in_crop) film_own[idx] = acc;
+    if (nans) atomicAdd(nan_count, nans);
+}
+
 // Film::merge_film_tile (film.rs:346-371): contrib_sum RGB -> XYZ, plus filter weight sum.
 // `add` = 1 accumulates into film_out (multi-pass renders), 0 overwrites.
 RSPT_PLAIN_KERNEL void k_film_resolve(const float4* __restrict__ film_own, const float4* __restrict__ film_splat, float4* __restrict__ film_out, uint32_t n) {

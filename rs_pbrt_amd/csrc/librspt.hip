@@ -101,6 +101,8 @@ struct Ctx {
     size_t film_px = 0;
     uint32_t* pix_list = nullptr;
     size_t pix_cap = 0;
+    uint32_t* pix_index = nullptr;     // k_film_gather: pixel of the sample-bounds grid -> its position in the pixel list
+    size_t pix_index_cap = 0;
     std::vector<hipEvent_t> events;
     uint32_t tex_rows = 0;             // rows of g.pb.tex per path: RSPT_TEX_ROWS, + RSPT_DYN_ROWS once a scene with dynamic materials was rendered
     QueueCounts* look = nullptr;       // pinned host words the render loops read queue lengths into: a device-to-host copy into pageable memory
@@ -827,7 +829,35 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
     HIP_TRY(hipMemsetAsync(g.film_own, 0, film_px * sizeof(float4), g.stream));
     HIP_TRY(hipMemsetAsync(g.film_splat, 0, film_px * sizeof(float4), g.stream));
+    // the film stage: k_film, or for filters wider than a pixel the gather form (kernels.h k_film_gather; RSPT_FILM_GATHER=0: the atomic form)
+    const int film_k = (int)std::floor(std::max(d->filter_radius[0], d->filter_radius[1]) + 0.5f);
+    const bool film_gather = (d->filter_radius[0] > 0.5f || d->filter_radius[1] > 0.5f) && film_k <= 8 && env_size("RSPT_FILM_GATHER", 1) != 0;
+    const size_t sb_px = (size_t)(sb[2] - sb[0]) * (size_t)(sb[3] - sb[1]);
+    if (film_gather && g.pix_index_cap < sb_px) {
+        if (g.pix_index) (void)hipFree(g.pix_index);
+        g.pix_index = nullptr; g.pix_index_cap = 0;
+        if ((rc = dev_alloc(&g.pix_index, sb_px))) return rc;
+        g.pix_index_cap = sb_px;
+    }
+    auto film_index = [&](const uint32_t* list, uint32_t n) -> int {   // (the list a batch indexes: the render's, or one pass of the pixel samplers)
+        if (!film_gather) return RSPT_OK;
+        HIP_TRY(hipMemsetAsync(g.pix_index, 0xff, sb_px * sizeof(uint32_t), g.stream));
+        if (n) hipLaunchKernelGGL(k_pix_index, dim3((n + 255) / 256), dim3(256), 0, g.stream, list, n, sb[0], sb[1], sb[2] - sb[0], g.pix_index);
+        return RSPT_OK;
+    };
     float* li_dev = nullptr;
+    auto film_stage = [&](const RenderDev& rd_, const Batch& bt, const PathBuf& fpb, const uint32_t* list) {
+        if (!film_gather) {
+            hipLaunchKernelGGL(k_film, dim3((bt.n_pix + 255) / 256), dim3(256), 0, g.stream, rd_, bt, fpb, list, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
+            return;
+        }
+        const size_t s2 = (size_t)(RSPT_FG_T + 2 * film_k) * (RSPT_FG_T + 2 * film_k);
+        const size_t fit = (60000 - s2 * 4 - 1024) / (s2 * 24);   // sample rows of (chunk + 1) x 24 bytes per source pixel in < 64 KB of LDS
+        const uint32_t chunk = (uint32_t)std::min<size_t>(std::max<size_t>(fit, 2) - 1, 8);
+        const size_t lds = s2 * (chunk + 1) * 24 + s2 * 4 + 1024;
+        hipLaunchKernelGGL(k_film_gather, dim3((uint32_t)((sb[2] - sb[0] + RSPT_FG_T - 1) / RSPT_FG_T), (uint32_t)((sb[3] - sb[1] + RSPT_FG_T - 1) / RSPT_FG_T)), dim3(256), lds, g.stream,
+                           rd_, bt, fpb, g.pix_index, film_k, chunk, g.film_own, li_dev, g.totals + 5);
+    };
     struct LiGuard { float** p; ~LiGuard() { if (*p) (void)hipFree(*p); } } li_guard{&li_dev};  // also on the early error returns below
     if (li_host) {
         HIP_TRY(hipMalloc((void**)&li_dev, film_px * (size_t)d->spp * 3 * sizeof(float)));
@@ -1378,7 +1408,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             const uint32_t npx = (uint32_t)pl.size();
             Batch bt{0u, npx, 0u, spp, npx * spp};
             samples += bt.n;
-            hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, fpb, pass_pix, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
+            if ((rc = film_index(pass_pix, npx))) return rc;
+            film_stage(rd, bt, fpb, pass_pix);
         }
         uint32_t tv = 0;
         HIP_TRY(hipMemcpyAsync(&tv, trunc_d, sizeof tv, hipMemcpyDeviceToHost, g.stream));
@@ -1394,6 +1425,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             return fail(RSPT_E_UNSUPPORTED, "a pixel sampler over %zu tiles: one lane per tile is slower than the host's tile loop below ~%zu tiles (set allow_slow_paths to run it anyway)", my_tiles, min_tiles);
     }
     if (pixel_sampler && (rc = run_tile_serial())) return rc;
+    if (!pixel_sampler && (rc = film_index(g.pix_list, (uint32_t)n_pix))) return rc;
     for (size_t p0 = 0; !pixel_sampler && p0 < n_pix; p0 += pix_per_batch) {
         const uint32_t npx = (uint32_t)std::min(pix_per_batch, n_pix - p0);
         for (uint32_t s0 = (uint32_t)smp_begin; s0 < (uint32_t)smp_end; s0 += ns) {
@@ -1419,7 +1451,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             else rc = batch_path(bt, it);
             if (rc) return rc;
             if (counters) hipLaunchKernelGGL(k_accum_counts, dim3(1), dim3(1), 0, g.stream, g.cnt, it, g.totals);
-            hipLaunchKernelGGL(k_film, dim3((npx + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.film_own, (float*)g.film_splat, li_dev, g.totals + 5);
+            film_stage(rd, bt, g.pb, g.pix_list);
         }
     }
     g_queue_hint = 0xffffffffu;
@@ -1620,7 +1652,7 @@ void rspt_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     free_paths();
-    void* ptrs[] = {g.dl.le_kind, g.dl.w_r, g.dl.w_t, g.dl.l_all, g.dl.ld_acc, g.dl.dim, g.dl.kidx, g.dl.nflags, g.dl.error, g.dl_queue, g.bin_keys, g.q_sorted, g.bin_info, g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.primes, g.prime_sums, g.halton_perms, g.cam_anim};
+    void* ptrs[] = {g.dl.le_kind, g.dl.w_r, g.dl.w_t, g.dl.l_all, g.dl.ld_acc, g.dl.dim, g.dl.kidx, g.dl.nflags, g.dl.error, g.dl_queue, g.bin_keys, g.q_sorted, g.bin_info, g.hit_inst, g.cnt, g.ovf, g.spill, g.totals, g.sobol32, g.vdc, g.vdc_inv, g.filter_table, g.film_own, g.film_splat, g.film_out, g.pix_list, g.pix_index, g.primes, g.prime_sums, g.halton_perms, g.cam_anim};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g.events) (void)hipEventDestroy(e);

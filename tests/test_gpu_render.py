@@ -81,6 +81,49 @@ def test_thin_lens_and_gaussian_filter(gpu, oracle):
     assert film_rmse(film, ref["film"]) < 1e-5
 
 
+@pytest.mark.parametrize("case", ["gaussian-2", "anisotropic", "wide-4", "crop-shards-ranges", "02sequence", "halton-clamped"])
+def test_wide_pixel_filters_gather_form(gpu, oracle, case, monkeypatch):
+    """filters wider than a pixel take the gather form of the film stage (kernels.h k_film_gather: every pixel sums what reaches it, no atomics): against the
+    oracle's film, against the atomic form (RSPT_FILM_GATHER=0), per-sample radiance through the same kernel, shards / sample slices / crop windows adding up"""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    kw = dict(res=56, spp=8)
+    if case == "gaussian-2":
+        kw.update(filter_radius=(2.0, 2.0), filter_table=scenes.gaussian_filter_table((2.0, 2.0)))
+    elif case == "anisotropic":
+        kw.update(filter_radius=(1.5, 2.75), filter_table=scenes.gaussian_filter_table((1.5, 2.75), alpha=1.0))
+    elif case == "wide-4":
+        kw.update(filter_radius=(4.0, 3.5), filter_table=scenes.gaussian_filter_table((4.0, 3.5), alpha=0.5))
+    elif case == "crop-shards-ranges":
+        kw.update(filter_radius=(2.0, 2.0), filter_table=scenes.gaussian_filter_table((2.0, 2.0)), crop=(0.2, 0.83, 0.1, 0.7))
+    elif case == "02sequence":
+        kw.update(filter_radius=(2.0, 2.0), filter_table=scenes.gaussian_filter_table((2.0, 2.0)), sampler="02sequence")
+    elif case == "halton-clamped":
+        kw.update(spp=6, filter_radius=(2.5, 2.5), filter_table=scenes.gaussian_filter_table((2.5, 2.5)), sampler="halton", max_sample_luminance=1.5)
+    rd = scenes.cornell_render_desc(**kw)
+    ref = oracle.render(sc, rd, threads=8, want_li=case != "02sequence")
+    films = {}
+    with gpu.DeviceScene(sc) as ds:
+        for form in ("1", "0"):
+            monkeypatch.setenv("RSPT_FILM_GATHER", form)
+            film, st = gpu.render(ds, rd)
+            assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == ref["counters"]["nan_samples"]
+            assert np.allclose(film[:, 3], ref["film"][:, 3], rtol=1e-5) and film_rmse(film, ref["film"]) < 1e-5, form
+            films[form] = film
+            if case != "02sequence":
+                assert np.array_equal(gpu.render_samples(ds, rd)[0], ref["li"]), form
+        assert np.allclose(films["1"], films["0"], rtol=2e-5, atol=1e-6)
+        monkeypatch.setenv("RSPT_FILM_GATHER", "1")
+        again, _ = gpu.render(ds, rd)
+        assert np.array_equal(again, films["1"])   # the gather form adds in a fixed order: the same film every time
+        if case == "crop-shards-ranges":
+            total = np.zeros_like(films["1"])
+            for r in range(3):
+                for rng in ((0, 3), (3, 5)):
+                    f, _ = gpu.render(ds, scenes.cornell_render_desc(shard=(r, 3, 1), sample_range=rng, **kw))
+                    total += f
+            assert np.allclose(total, films["1"], rtol=2e-5, atol=1e-6)
+
+
 def test_crop_window_and_non_square(gpu, oracle):
     sc = scenes.cornell_box(gpu.bvh_build)
     rd = scenes.make_render_desc(100, 60, 4, scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV, crop=(0.25, 0.8, 0.1, 0.9))
