@@ -31,8 +31,12 @@ struct DlBuf {          // per node slot
     uint32_t* dim;      // dimension at which the node's lighting starts in the regular stream
     uint32_t* kidx;     // index among the camera sample's shading nodes, depth first
     uint32_t* nflags;   // DLF_* of the estimate in flight
-    uint32_t H;         // slots per camera sample
-    uint32_t* error;    // 1: a material with several specular lobes of one kind was met; 2: a camera sample ran out of sampler dimensions
+    uint32_t H;         // slots per camera sample = 2^levels
+    uint32_t levels;    // levels of the tree that can hold nodes: max_depth, or 1 for a scene without specular lobes (no node ever has a child: the
+                        // recursion's two sample_f calls return black and only consume their dimensions) — the slots, the level loops and the
+                        // batch size follow it (untextured directlighting at depth 8 ran 1024 batches of 2^18 samples before)
+    uint32_t* error;    // 1: a material with several specular lobes of one kind was met; 2: a camera sample ran out of sampler dimensions;
+                        // 3: a specular bounce below the last level (the host's `levels` was wrong: never expected)
 };
 
 // per-wave aggregated queue append
@@ -125,6 +129,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd
                             uint32_t st = 0;
                             const rgb f = d.bsdf.sample_f(d.wo, &wi, f2{0.0f, 0.0f}, &pdf, (side ? BX_TRANS : BX_REFL) | BX_SPEC, &st);
                             if (pdf > 0.0f && !is_black(f) && absdot(wi, d.h.sh_n) != 0.0f) {
+                                if (level + 1u >= dl.levels) { atomicMax(dl.error, 3u); continue; }
                                 const uint32_t child = s * dl.H + 2u * h + (uint32_t)side;
                                 store_ray(pb.ray_cont + child, offset_ray_origin(d.h.p, d.h.p_err, d.h.n, wi), wi, RSPT_INF, child);
                                 dl.le_kind[child] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)DL_PENDING));
@@ -174,11 +179,12 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_assign(Batch bt, DlBuf dl, ui
             if (depth + 1u < max_depth) {
                 dim += 2u;                                            // specular_reflect's sampler.get_2d()
                 stack[sp++] = (h << 1) | 1u;                          // after the reflection subtree: the transmission side
-                if (__float_as_uint(dl.le_kind[s * dl.H + 2u * h].w) != DL_EMPTY) stack[sp++] = (2u * h) << 1;
+                if (depth + 1u < dl.levels && __float_as_uint(dl.le_kind[s * dl.H + 2u * h].w) != DL_EMPTY) stack[sp++] = (2u * h) << 1;
             }
         } else {
             dim += 2u;                                                // specular_transmit's sampler.get_2d()
-            if (__float_as_uint(dl.le_kind[s * dl.H + 2u * h + 1u].w) != DL_EMPTY) stack[sp++] = (2u * h + 1u) << 1;
+            const uint32_t depth = 31u - (uint32_t)__builtin_clz(h);
+            if (depth + 1u < dl.levels && __float_as_uint(dl.le_kind[s * dl.H + 2u * h + 1u].w) != DL_EMPTY) stack[sp++] = (2u * h + 1u) << 1;
         }
     }
     if (dim > dim_limit) atomicMax(dl.error, 2u);
@@ -365,7 +371,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_gather(Batch bt, PathBuf pb, 
                     const float4 w = side ? dl.w_t[slot] : dl.w_r[slot];
                     rgb term = mkrgb(0.0f);
                     const uint32_t child = s * dl.H + 2u * h + (uint32_t)side;
-                    if (__float_as_uint(dl.le_kind[child].w) != DL_EMPTY) {
+                    if (depth + 1u < dl.levels && __float_as_uint(dl.le_kind[child].w) != DL_EMPTY) {
                         const float4 lc = dl.l_all[child];
                         term = rgb{w.x, w.y, w.z} * rgb{lc.x, lc.y, lc.z} * mkrgb(w.w);  // f * self.li(..) * Spectrum::new(|cos| / pdf)
                     }

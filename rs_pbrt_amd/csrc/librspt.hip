@@ -883,7 +883,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // (lane_serial.h): textured materials, more than 8 recursion levels; RSPT_DL_FORM=lane forces it (A/B, tests)
     const char* dl_form_env = getenv("RSPT_DL_FORM");
     bool dl_lane = direct && !pixel_sampler && (s->has_textures || d->max_depth > 8 || (dl_form_env && !strcmp(dl_form_env, "lane")));
-    const uint32_t dl_H = (direct && !pixel_sampler && !dl_lane) ? (1u << d->max_depth) : 1u;   // node slots per camera sample (direct.h; in the per-lane forms a lane walks the tree itself)
+    // levels of the specular tree that can hold nodes (direct.h DlBuf::levels): a scene without specular lobes has the root only
+    const bool dl_specular = s->has_dynamic || (s->shade_features & (RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_R) | RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_T) | RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_SPEC))) != 0;
+    const uint32_t dl_levels = (dl_specular || env_size("RSPT_DL_FULL_TREE", 0) != 0) ? (uint32_t)d->max_depth : std::min<uint32_t>((uint32_t)d->max_depth, 1u);
+    const uint32_t dl_H = (direct && !pixel_sampler && !dl_lane) ? (1u << dl_levels) : 1u;   // node slots per camera sample (direct.h; in the per-lane forms a lane walks the tree itself)
     if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? (s->has_dynamic ? 20 : 22) : 26)) / dl_H, 1024);   // (per-lane form: texture rows and lobe records per recursion level)
     if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
@@ -1093,7 +1096,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         if (5ull + 2ull * n_arrays > dim_limit)
             return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays exceed the sampler's %u dimensions", n_arrays, dim_limit);
         DlBuf dl = g.dl;
-        dl.H = H;
+        dl.H = H; dl.levels = dl_levels;
         const size_t n_slots = (size_t)bt.n * H;
         HIP_TRY(hipMemsetAsync(dl.le_kind, 0, n_slots * sizeof(float4), g.stream));
         HIP_TRY(hipMemsetAsync(dl.l_all, 0, n_slots * sizeof(float4), g.stream));
@@ -1105,7 +1108,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         auto level_q = [&](uint32_t l) { return g.dl_queue + (size_t)bt.n * ((1u << l) - 1u); };
         hipLaunchKernelGGL(k_dl_init, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, g.pb, dl, g.pb.ray_sh, level_q(0), &g.cnt[0].closest);
         const uint32_t dgrid = grid_for(4);
-        for (uint32_t l = 0; l < md; l++) {
+        for (uint32_t l = 0; l < dl_levels; l++) {
             const uint32_t* queue = level_q(l);
             const uint32_t* qcount = &g.cnt[l].closest;
             for (uint32_t round = 0;; round++) {
@@ -1119,7 +1122,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 trace_launches++;
                 ev_open(2, 0);
                 hipLaunchKernelGGL(k_dl_hit, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, g.pb, dl, queue, qcount, g.q[round & 1u][0], &rc_->closest,
-                                   level_q(l + 1 < md ? l + 1 : l), &g.cnt[l + 1].closest, l);
+                                   level_q(l + 1 < dl_levels ? l + 1 : l), &g.cnt[l + 1].closest, l);
                 ev_close(2, 0);
                 if (!s->has_null_material) break;
                 HIP_TRY(hipMemcpyAsync(g.look, rc_, sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
@@ -1134,7 +1137,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md, dim_limit);
         if (nl) {
             QueueCounts* rc_ = &g.cnt[md + 3];
-            for (uint32_t l = 0; l < md; l++) {
+            for (uint32_t l = 0; l < dl_levels; l++) {
                 const uint32_t n_lights_round = all ? nl : 1u;
                 for (uint32_t j = 0; j < n_lights_round; j++) {
                     const uint32_t n_j = all ? (uint32_t)(d->n_light_samples ? d->n_light_samples[j] : 1) : 1u;
@@ -1161,6 +1164,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         HIP_TRY(hipMemcpyAsync(&dl_err, dl.error, sizeof dl_err, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         if (dl_err == 1u) return RSPT_DL_RETRY_LANE;   // a material with several specular lobes of one kind: the lobe choice depends on a sample value, the tree cannot be traced ahead
+        if (dl_err == 3u) return fail(RSPT_E_HIP, "directlighting: a specular bounce in a scene classified as having none");
         if (dl_err) return fail(RSPT_E_UNSUPPORTED, "directlighting: a camera sample draws more than the sampler's %u dimensions (the reference panics there, sobol.rs:119-124)", dim_limit);
         it = md + 4;
         return RSPT_OK;

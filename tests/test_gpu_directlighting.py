@@ -251,3 +251,18 @@ def test_per_lane_form_under_the_global_samplers(gpu, oracle, sampler, monkeypat
     monkeypatch.delenv("RSPT_DL_FORM")
     rd = scenes.cornell_render_desc(res=32, spp=4, max_depth=12, integrator="directlighting", direct_strategy="one", sampler=sampler)
     check(gpu, oracle, sc, rd, "one")
+
+
+@pytest.mark.parametrize("strategy", ["all", "one"])
+def test_scene_without_specular_lobes_keeps_only_the_root_level(gpu, oracle, strategy, monkeypatch):
+    """direct.h DlBuf::levels: with no specular lobe in the scene no node of the recursion can have a child, so the wavefront form keeps one slot level
+    per camera sample (the batch is 2^(max_depth - 1) times larger) — the same radiance, bit for bit, as with the full tree (RSPT_DL_FULL_TREE=1)
+    and as the oracle's recursion, whose two specular sample_f calls still consume their dimensions at every depth"""
+    sc = scenes.cornell_box(gpu.bvh_build)   # matte only
+    ls = [3, 2] if strategy == "all" else None
+    rd = scenes.cornell_render_desc(res=40, spp=8, integrator="directlighting", direct_strategy=strategy, max_depth=6, light_samples=ls)
+    films = []
+    for full in ("0", "1"):
+        monkeypatch.setenv("RSPT_DL_FULL_TREE", full)
+        films.append(check(gpu, oracle, sc, rd, strategy, ls))
+    assert np.array_equal(films[0], films[1])
