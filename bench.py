@@ -45,6 +45,7 @@ def parse():
                          "volpath: VolPathIntegrator (with --workload cornell the room is filled with a homogeneous medium)")
     ap.add_argument("--workload", default="soup1m", choices=["soup1m", "cornell", "cornell_docs", "statue", "statue_tex", "c4", "c5"])
     ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--lights", type=int, default=64, help="c4: number of small area lights (a square number; 64 = the C4 stand-in)")
     ap.add_argument("--filter", default="box", choices=["box", "gaussian"], help="pixel filter: the reference's default box 0.5 x 0.5, or gaussian radius 2 alpha 2 (every sample lands in ~16 pixels: k_film's splat path)")
     ap.add_argument("--alpha-mask", action="store_true", help="soup1m: every triangle carries an image alpha mask (the foliage case: k_trace_w4<.., ALPHA>)")
     ap.add_argument("--res", type=int, default=0)
@@ -120,9 +121,9 @@ def build_workload(args, workload, lib, scenes):
             name = "Ganesha mesh %s (%d triangles, from $RSPT_GANESHA_DIR) in the stand-in's frame: its camera, ground, three quad lights, plastic; path depth 5, sobol %d spp, %dx%d" % (
                 os.path.basename(ply), n_tri, spp, xres, yres)
         else:
-            sc = scenes.statue_standin(lib.bvh_build_gpu, textured=tex, many_lights=64 if workload == "c4" else 0)  # c4: SURVEY 8(d) C4 stand-in
+            sc = scenes.statue_standin(lib.bvh_build_gpu, textured=tex, many_lights=args.lights if workload == "c4" else 0)  # c4: SURVEY 8(d) C4 stand-in
             name = "statue stand-in (4.3 M triangles%s%s; DECLARED STAND-IN for the off-tree Ganesha asset), path depth 5, sobol %d spp, %dx%d" % (
-                ", image-textured + bump-mapped" if tex else "", ", 64 small area lights (C4 stand-in)" if workload == "c4" else "", spp, xres, yres)
+                ", image-textured + bump-mapped" if tex else "", ", %d small area lights (C4 stand-in)" % args.lights if workload == "c4" else "", spp, xres, yres)
     if integ != "path":
         name += " [%s integrator]" % integ
     if args.filter == "gaussian":

@@ -44,6 +44,22 @@ if [ "$mode" = all ]; then
   timeout 300 python bench.py --workload statue_tex --integrator directlighting --spp 64 --steps 2 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_tex_directlighting.json 2> $out/bench_statue_tex_directlighting.err
   timeout 300 python bench.py --workload cornell --sampler 02sequence --steps 2 --warmup 1 --no-extra > $out/bench_cornell_02sequence.json 2> $out/bench_cornell_02sequence.err
   timeout 300 python bench.py --workload statue --sampler 02sequence --spp 16 --steps 1 --warmup 1 --cpu-spp 4 --no-extra > $out/bench_statue_02sequence.json 2> $out/bench_statue_02sequence.err
+  # round 4, second half: the configurations scene files actually use — one line each, no CPU legs
+  : > $out/variants.txt
+  variant() {  # <name> <bench.py args...>
+    n=$1; shift
+    v=$(timeout 300 python bench.py "$@" --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-count 2> $out/variant_$n.err | tee $out/variant_$n.json | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f Msamples/s  %.1f ms/step  %s' % (d['value'], d['ms_per_step'], d['config']['workload']))")
+    echo "$n: ${v:-FAILED}" | tee -a $out/variants.txt
+  }
+  variant c2_gaussian --workload soup1m --filter gaussian
+  variant c3_gaussian --workload statue --filter gaussian
+  variant c2_halton --workload soup1m --sampler halton
+  variant c3_halton --workload statue --sampler halton
+  variant c3tex_halton --workload statue_tex --sampler halton
+  variant c2_alpha_mask --workload soup1m --alpha-mask
+  variant c2_directlighting --workload soup1m --integrator directlighting
+  variant c3_directlighting --workload statue --integrator directlighting
+  variant c3_volpath --workload statue --integrator volpath
   # the C5 stand-in: both instancing modes from one host-side scene build (tools/c5_both_modes.py); FULL_C5=1 runs the two bench.py lines with
   # their CPU legs instead (six minutes each, most of it scene generation)
   if [ -z "${SKIP_C5:-}" ]; then
