@@ -514,6 +514,8 @@ struct Scene {
                             + gamma(3) * (std::fabs(m[4] * x) + std::fabs(m[5] * y) + std::fabs(m[6] * z) + std::fabs(m[7]));
             ret.p_error.z = (gamma(3) + 1.0f) * (std::fabs(m[8]) * pe.x + std::fabs(m[9]) * pe.y + std::fabs(m[10]) * pe.z)
                             + gamma(3) * (std::fabs(m[8] * x) + std::fabs(m[9] * y) + std::fabs(m[10] * z) + std::fabs(m[11]));
+            const Float wp = m[12] * x + m[13] * y + m[14] * z + m[15];   // :747-760 (the reference asserts wp != 0)
+            if (wp != 1.0f) { const Float inv = 1.0f / wp; ret.p = V3{inv * ret.p.x, inv * ret.p.y, inv * ret.p.z}; }
         }
         ret.n = normalize(transform_normal(mi, si->n));
         ret.wo = normalize(transform_vector(m, si->wo));

@@ -37,6 +37,9 @@ struct InstDev {
     uint32_t identity;    // Transform::is_identity(primitive_to_world) (transform.rs:291-308)
     uint32_t anim;        // a moving instance: index into SceneDev::inst_anim (m / mi / identity above are then the START key's); RSPT_MISS = static
     uint32_t pad[3];
+    float m3[4], mi3[4];  // rows 3 of m and m_inv.  A CTM made of Translate / Rotate / Scale has (0 0 0 1) there in both; the inverse that Transform::new computes
+                          // for a `Transform [..]` / `ConcatTransform` matrix (Matrix4x4::inverse, Gauss-Jordan) does not — a few 1e-8 — and transform_point
+                          // divides by the homogeneous weight whenever it is not exactly 1 (transform.rs:490-516, :661-760): so do inst_ray / inst_point
 };
 
 struct SceneDev {
@@ -417,9 +420,13 @@ RDEV f3 xf_normal(const float* mi, f3 n) {
 }
 // Transform::inverse(primitive_to_world).transform_ray(r) (transform.rs:538-595 with transform_point_with_error :661-704):
 // origin and direction through m_inv, the origin pushed along d to the edge of its error bound, t_max shortened by the same dt
-RDEV void xf_ray(const float* m /* 3 x 4, row major */, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) {
+RDEV void xf_ray(const float* m /* rows 0..2, row major */, const float* m3 /* row 3; nullptr = (0 0 0 1) */, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) {
     const float x = o.x, y = o.y, z = o.z;
     f3 op{m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+    if (m3) {   // transform_point_with_error's homogeneous divide (transform.rs:694-707)
+        const float wp = m3[0] * x + m3[1] * y + m3[2] * z + m3[3];
+        if (wp != 1.0f) { const float inv = 1.0f / wp; op = f3{inv * op.x, inv * op.y, inv * op.z}; }
+    }
     const f3 o_err = f3{fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]), fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]),
                         fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11])} * gamma_n(3);
     const f3 dd = xf_vector(m, d);
@@ -432,19 +439,21 @@ RDEV void xf_ray(const float* m /* 3 x 4, row major */, f3 o, f3 d, float t_max,
     }
     *oo = op; *od = dd; *ot = t_max;
 }
-RDEV void inst_ray(const InstDev& in, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) { xf_ray(in.mi, o, d, t_max, oo, od, ot); }
+RDEV void inst_ray(const InstDev& in, f3 o, f3 d, float t_max, f3* oo, f3* od, float* ot) { xf_ray(in.mi, in.mi3, o, d, t_max, oo, od, ot); }
 // Transform::transform_surface_interaction (transform.rs:815-860) on the fields the path needs: p with
 // transform_point_with_abs_error (:709-760), n / shading.n normalised, shading.n face-forwarded to n, shading.dpdu as a vector
-RDEV void inst_point(const float* m, f3 p, f3 pe, f3* po, f3* peo) {
+RDEV void inst_point(const float* m, const float* m3 /* row 3 */, f3 p, f3 pe, f3* po, f3* peo) {
     const float x = p.x, y = p.y, z = p.z, g3 = gamma_n(3);
     *po = f3{m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+    const float wp = m3[0] * x + m3[1] * y + m3[2] * z + m3[3];   // transform_point_with_abs_error's homogeneous divide (transform.rs:748-760)
+    if (wp != 1.0f) { const float inv = 1.0f / wp; *po = f3{inv * po->x, inv * po->y, inv * po->z}; }
     *peo = f3{(g3 + 1.0f) * (fabsf(m[0]) * pe.x + fabsf(m[1]) * pe.y + fabsf(m[2]) * pe.z) + g3 * (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3])),
               (g3 + 1.0f) * (fabsf(m[4]) * pe.x + fabsf(m[5]) * pe.y + fabsf(m[6]) * pe.z) + g3 * (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7])),
               (g3 + 1.0f) * (fabsf(m[8]) * pe.x + fabsf(m[9]) * pe.y + fabsf(m[10]) * pe.z) + g3 * (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]))};
 }
 RDEV void inst_hit(const InstDev& in, Hit* h) {
     f3 p, pe;
-    inst_point(in.m, h->p, h->p_err, &p, &pe);
+    inst_point(in.m, in.m3, h->p, h->p_err, &p, &pe);
     h->p = p; h->p_err = pe;
     h->n = normalize(xf_normal(in.mi, h->n));
     f3 sn = normalize(xf_normal(in.mi, h->sh_n));
@@ -788,7 +797,7 @@ RDEVN void camera_to_world_at(const RenderDev& rd, float time_sample, float* m) 
 // ---- a moving TransformedPrimitive (primitive.rs:198-265) at a ray's time ----
 struct InstAnim {        // per moving instance: what AnimatedTransform::new leaves (as for the camera) + the end key's stored inverse
     CamAnim keys;        // keys.end = end_transform.m
-    float mi_end[12];    // end_transform.m_inv rows 0..2
+    float mi_end[16];    // end_transform.m_inv
     uint32_t identity_end;
     uint32_t pad[3];
 };
@@ -836,6 +845,7 @@ RDEVN InstDev inst_at(const SceneDev& sc, uint32_t index, float time) {
     if (time <= an.keys.time[0]) return in;
     if (time >= an.keys.time[1]) {
         for (int i = 0; i < 12; i++) { in.m[i] = an.keys.end[i]; in.mi[i] = an.mi_end[i]; }
+        for (int i = 0; i < 4; i++) { in.m3[i] = an.keys.end[12 + i]; in.mi3[i] = an.mi_end[12 + i]; }
         in.identity = an.identity_end;
         return in;
     }
@@ -852,6 +862,7 @@ RDEVN InstDev inst_at(const SceneDev& sc, uint32_t index, float time) {
     bool ident = true;                   // Transform::is_identity (transform.rs:291-308): m against the identity, element by element
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (m[4 * i + j] != (i == j ? 1.0f : 0.0f)) ident = false;
     for (int i = 0; i < 12; i++) { in.m[i] = m[i]; in.mi[i] = mi[i]; }
+    for (int i = 0; i < 4; i++) { in.m3[i] = m[12 + i]; in.mi3[i] = mi[12 + i]; }
     in.identity = ident ? 1u : 0u;
     return in;
 }

@@ -393,7 +393,7 @@ struct TexHit {
 // Transform::transform_surface_interaction (transform.rs:815-860) on the full interaction of the texture stage
 RDEV void inst_texhit(const InstDev& in, TexHit* h) {
     f3 p, pe;
-    inst_point(in.m, h->p, f3{0.0f, 0.0f, 0.0f}, &p, &pe);
+    inst_point(in.m, in.m3, h->p, f3{0.0f, 0.0f, 0.0f}, &p, &pe);
     h->p = p;
     h->n = normalize(xf_normal(in.mi, h->n));
     h->dpdu = xf_vector(in.m, h->dpdu); h->dpdv = xf_vector(in.m, h->dpdv);

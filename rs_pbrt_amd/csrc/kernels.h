@@ -1430,12 +1430,12 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_ld_mark(SceneDev sc, LightDistDe
                 if (!at.identity) {
                     if (!sc.inst_fixed) continue;
                     f3 pe;
-                    inst_point(at.m, hp, f3{0.0f, 0.0f, 0.0f}, &hp, &pe);
+                    inst_point(at.m, at.m3, hp, f3{0.0f, 0.0f, 0.0f}, &hp, &pe);
                 }
             } else if (hi && !sc.inst[hi - 1u].identity) {
                 if (!sc.inst_fixed) continue;
                 f3 pe;
-                inst_point(sc.inst[hi - 1u].m, hp, f3{0.0f, 0.0f, 0.0f}, &hp, &pe);
+                inst_point(sc.inst[hi - 1u].m, sc.inst[hi - 1u].m3, hp, f3{0.0f, 0.0f, 0.0f}, &hp, &pe);
             }
         }
         const uint32_t vox = light_voxel(sc, ld, hp);

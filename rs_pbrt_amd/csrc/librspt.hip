@@ -1726,9 +1726,9 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         for (uint32_t i = 0; i < d->n_instances; i++) {
             const rspt_instance& in = d->instances[i];
             if (in.object >= d->n_objects) return fail(RSPT_E_INVALID, "instance %u: object index out of range", i);
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < 2; k++) {   // (rows 3 other than (0 0 0 1) are served: InstDev::m3 / mi3; a weight of 0 is where the reference asserts, transform.rs:747)
                 const float* m = k ? in.from_world : in.to_world;
-                if (m[12] != 0.0f || m[13] != 0.0f || m[14] != 0.0f || m[15] != 1.0f) return fail(RSPT_E_UNSUPPORTED, "instance %u: projective transform", i);
+                if (!std::isfinite(m[12]) || !std::isfinite(m[13]) || !std::isfinite(m[14]) || !std::isfinite(m[15])) return fail(RSPT_E_INVALID, "instance %u: non-finite transform", i);
                 for (int j = 0; j < 12; j++) if (!(fabsf(m[j]) < RSPT_INF)) return fail(RSPT_E_INVALID, "instance %u: non-finite transform", i);
             }
         }
@@ -2283,6 +2283,8 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             memset(&x, 0, sizeof x);
             memcpy(x.m, in.to_world, sizeof x.m);
             memcpy(x.mi, in.from_world, sizeof x.mi);
+            memcpy(x.m3, in.to_world + 12, sizeof x.m3);
+            memcpy(x.mi3, in.from_world + 12, sizeof x.mi3);
             x.root_node = o.n_nodes ? (uint32_t)o.first_node : RSPT_MISS;
             x.first_prim = (uint32_t)o.first_prim;
             x.w4_root = obj_root[in.object];

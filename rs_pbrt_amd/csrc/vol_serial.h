@@ -52,7 +52,7 @@ RDEV bool unit_cube_intersect_b(f3 o, f3 d, float ray_tmax, float* hitt0, float*
 }
 // the prelude tr and sample share (:158-176, :216-235): the world ray normalised (t_max scaled by its length), then to medium space
 RDEV void grid_ray(const rspt_medium& m, f3 o, f3 d, float t_max, f3* mo, f3* md, float* mt) {
-    xf_ray(m.world_to_medium, o, normalize(d), t_max * len(d), mo, md, mt);
+    xf_ray(m.world_to_medium, nullptr, o, normalize(d), t_max * len(d), mo, md, mt);   // (rspt_scene_create refuses a world_to_medium whose row 3 is not (0 0 0 1))
 }
 template <class S>
 RDEVN rgb grid_tr(const rspt_medium& m, f3 o, f3 d, float ray_tmax, S& smp) {  // GridDensityMedium::tr :155-208: ratio tracking

@@ -843,12 +843,16 @@ class SceneBuilder:
 
 
 def _transform_bounds(m, lo, hi):
-    """Transform::transform_bounds (transform.rs:596-660) in f32: the eight corners through transform_point (affine: w == 1), union"""
+    """Transform::transform_bounds (transform.rs:596-660) in f32: the eight corners through transform_point (with its divide by the homogeneous
+    weight where that is not exactly 1, :490-516), union"""
     m = np.asarray(m, F32)
     out_lo, out_hi = None, None
     for cx, cy, cz in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1), (1, 1, 0), (1, 0, 1), (1, 1, 1)):
         x, y, z = (hi if cx else lo)[0], (hi if cy else lo)[1], (hi if cz else lo)[2]
         p = np.array([F32(F32(F32(m[r, 0] * x) + F32(m[r, 1] * y)) + F32(m[r, 2] * z)) + m[r, 3] for r in range(3)], F32)
+        wp = F32(F32(F32(m[3, 0] * x) + F32(m[3, 1] * y)) + F32(m[3, 2] * z)) + m[3, 3]
+        if wp != F32(1.0):
+            p = (F32(F32(1.0) / wp) * p).astype(F32)
         out_lo = p if out_lo is None else np.minimum(out_lo, p)
         out_hi = p if out_hi is None else np.maximum(out_hi, p)
     return out_lo, out_hi

@@ -391,3 +391,57 @@ def test_gpu_moving_instances_are_refused_where_not_served(gpu):
             with pytest.raises(RsptError) as e:
                 gpu.render(ds, rd)
             assert e.value.code == abi.E_UNSUPPORTED
+
+
+def matrix_scene(builder, mode, tex=False):
+    """small_scene with its instance CTMs given the way `Transform [..]` / `ConcatTransform` give them: the 16 numbers, the inverse by Transform::new's Gauss-Jordan
+    (scenes.Transform(m)) — rows 3 of those inverses are (a few 1e-8, .., 1), not (0 0 0 1), and Transform::transform_point divides by the homogeneous weight
+    whenever it is not exactly 1 (transform.rs:490-516).  One instance also carries a to_world whose own row 3 is off (a mildly projective matrix)."""
+    sc0 = small_scene(builder, mode=mode, tex=tex)
+    sb = sc0.builder
+    T = scenes.Transform
+    new = []
+    for k, (obj, xf, xf_end, tm) in enumerate(sb.instances):
+        m = np.array(xf.m, np.float32)
+        if k == 1:
+            m[3] = np.array([2e-3, -1e-3, 5e-4, 1.001], np.float32)
+        new.append((obj, T(m) if k < 5 else xf, xf_end, tm))   # (the lone-triangle and identity instances keep their exact pairs)
+    sb.instances[:] = new
+    sc = sb.finish(builder, instancing=mode)
+    rows3 = np.asarray(sc.instances["from_world"]).reshape(-1, 4, 4)[:, 3]
+    assert (rows3[:5] != np.array([0, 0, 0, 1], np.float32)).any(), "the scene no longer exercises the homogeneous divide"
+    return sc
+
+
+def test_oracle_divides_by_the_homogeneous_weight(oracle):
+    """CPU: known answer of Transform::transform_point's divide through the oracle's instance path — a ray into an instance whose from_world row 3 is not
+    (0 0 0 1) hits where the divided origin says, and the interaction's point goes back through to_world's own row 3"""
+    sc = matrix_scene(oracle.bvh_build, "fixed")
+    rays = random_rays(20000, 23, -4.0, 4.0)
+    a = oracle.trace(sc, rays)
+    b = oracle.trace(small_scene(oracle.bvh_build, mode="fixed"), rays)
+    assert (a["prim"] != 0xffffffff).sum() > 1000
+    assert (a["t"] != b["t"]).any()   # the perturbed rows move hits (last bits for the Gauss-Jordan rows, visibly for the projective instance)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tex", [("reference", False), ("fixed", False), ("fixed", True)])
+def test_gpu_instances_given_as_matrices_match_oracle(gpu, oracle, mode, tex):
+    """InstDev::m3 / mi3: hit records byte for byte, every sample's radiance bit for bit, under path / volpath-free ao / a pixel sampler"""
+    sc = matrix_scene(gpu.bvh_build, mode, tex=tex)
+    rays = random_rays(60000, 21, -4.0, 4.0)
+    rays["o"][:, 1] = np.abs(rays["o"][:, 1]) * 0.8
+    rd = rd_small(spp=8)
+    ref = oracle.render(sc, rd, threads=8, want_li=True)
+    with gpu.DeviceScene(sc) as ds:
+        for any_hit in (False, True):
+            assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
+        li = gpu.render_samples(ds, rd)[0]
+        film, st = gpu.render(ds, rd)
+        assert np.array_equal(li, ref["li"]), int((li != ref["li"]).any(axis=2).sum())
+        assert np.array_equal(film[:, 3], ref["film"][:, 3])
+        for kw in (dict(integrator="ao", ao_samples=8), dict(sampler="02sequence")):
+            rdk = rd_small(spp=4, **kw)
+            fk, _ = gpu.render(ds, rdk)
+            rk = oracle.render(sc, rdk, threads=8)
+            assert np.array_equal(fk[:, 3], rk["film"][:, 3]) and film_rmse(fk, rk["film"]) < 2e-5, kw

@@ -133,6 +133,7 @@ def integrator_directive(integrator, max_depth, direct_strategy="all", ao_sample
 def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol", integrator="path", **kw):
     integ_kw = {k: kw.pop(k) for k in ("direct_strategy", "ao_samples", "ao_cos_sample") if k in kw}
     cam_kw = {k: kw.pop(k) for k in ("look_at_end", "camera_times", "shutter", "lens_radius", "focal_distance", "mirror_x") if k in kw}
+    filt = kw.pop("filter", None)   # ("gaussian", (xwidth, ywidth), alpha): GaussianFilter::create (filters/gaussian.rs); None = the box filter the library's default table restates
     sampler_kw = kw
     sb = sc.builder
     assert sb is not None, "the scene was not made by a SceneBuilder"
@@ -152,7 +153,8 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
            'Camera "perspective" "float fov" [%.9g]%s' % (fov, cam_par),
            sampler_directive(sampler, spp, **sampler_kw),
            integrator_directive(integrator, max_depth, **integ_kw),
-           'PixelFilter "box" "float xwidth" [0.5] "float ywidth" [0.5]',
+           ('PixelFilter "box" "float xwidth" [0.5] "float ywidth" [0.5]' if filt is None else
+            'PixelFilter "%s" "float xwidth" [%.9g] "float ywidth" [%.9g] "float alpha" [%.9g]' % (filt[0], filt[1][0], filt[1][1], filt[2])),
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d] "string filename" ["ref.png"]' % (xres, yres),
            "WorldBegin"]
     for k, md in enumerate(sb.media):   # MakeNamedMedium (api.rs:953-1037): sigma_a / sigma_s are already scaled in the builder
@@ -279,6 +281,27 @@ def sky_blocks(bvh_builder, scenes):
     return sb.finish(bvh_builder)
 
 
+def alpha_cutouts(bvh_builder, scenes):
+    """the Cornell room with a panel and a uv-less triangle in front of the back wall whose "float imagemap" alpha / shadowalpha textures cut holes into them
+    (8-bit images: exactly 0 or 1; the lookups at the alpha test have no ray differentials, so they are bilinear at level 0 whatever the filter — the form the
+    library's traversal kernels evaluate in line)"""
+    rng = np.random.default_rng(5)
+    sb = scenes.SceneBuilder()
+    white = sb.add_material(scenes.matte((0.725, 0.71, 0.68)))
+    green = sb.add_material(scenes.matte((0.14, 0.45, 0.091)))
+    sb.add_quad([(0, 0, 0), (0, 0, 560), (556, 0, 560), (556, 0, 0)], white)
+    sb.add_quad([(0, 549, 0), (556, 549, 0), (556, 549, 560), (0, 549, 560)], white)
+    sb.add_quad([(0, 0, 560), (0, 549, 560), (556, 549, 560), (556, 0, 560)], white)
+    sb.add_quad([(213, 548.7, 227), (343, 548.7, 227), (343, 548.7, 332), (213, 548.7, 332)], white, emit=(17, 12, 4))
+    a8 = (rng.random((16, 16)) > 0.45).astype(np.uint8) * 255
+    b8 = (rng.random((8, 12)) > 0.4).astype(np.uint8) * 255
+    m = sb.image_texture_u8(np.repeat(a8[:, :, None], 3, 2), channels=1, su=2.0, sv=3.0, du=0.25, dv=-0.4)
+    ms = sb.image_texture_u8(np.repeat(b8[:, :, None], 3, 2), channels=1, su=1.0, sv=2.0, wrap="clamp", trilinear=True)
+    sb.add_quad([(100, 60, 300), (460, 60, 300), (460, 420, 300), (100, 420, 300)], green, UV=[[0, 0], [1, 0], [1, 1], [0, 1]], alpha=m, shadow_alpha=ms)
+    sb.add_mesh(np.array([(60, 300, 200), (260, 330, 220), (140, 520, 210)], np.float32), [[0, 1, 2]], green, alpha=m)
+    return sb.finish(bvh_builder)
+
+
 INSTANCED_CAMERA = (((0, 2.5, -6), (0, 0.5, 0), (0, 1, 0)), 40.0)
 
 
@@ -325,10 +348,14 @@ SCENES = {
     # the scene of the reference's own documentation renders as recovered from them (scenes.cornell_box_docs, tests/test_reference_pin.py): rs_pbrt's
     # ref.png of this file should BE docs/source/cornell_box_8_pixelsamples.png (the oracle's render equals it byte for byte in 94 % of the pixels)
     "cornell_docs": (lambda b, s: s.cornell_box_docs(b), "CORNELL_DOCS", 500, 500, 8, 5),
+    # round 4: a pixel filter wider than a pixel (the film stage's gather form) and image alpha masks (evaluated in line in the traversal)
+    "cornell_gaussian": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 64, 64, 16, 5),
+    "alpha_cutouts": (alpha_cutouts, "CORNELL", 64, 64, 16, 5),
 }
 # what make_render_desc / export take beyond the table above, per scene
 EXTRA = {
     "cornell_docs": dict(mirror_x=True),
+    "cornell_gaussian": dict(filter=("gaussian", (2.0, 2.0), 2.0)),
     "cornell_fog_volpath": dict(integrator="volpath"),
     "cornell_02sequence": dict(sampler="02sequence", dimensions=4),
     "cornell_random": dict(sampler="random"),
@@ -340,6 +367,16 @@ EXTRA = {
     "cornell_ao": dict(integrator="ao", ao_samples=16, ao_cos_sample=True),
     "cornell_moving_camera": dict(look_at_end=((340.0, 300.0, -760.0), (250.0, 260.0, 0.0), (0.1, 1.0, 0.0)), camera_times=(0.2, 0.9), shutter=(0.0, 1.0), lens_radius=4.0, focal_distance=1000.0),
 }
+
+
+def render_kwargs(name, scenes):
+    """EXTRA[name] as make_render_desc takes it: a "filter" entry becomes the radius and the 16 x 16 table Film::new tabulates (film.rs:198-211)"""
+    kw = dict(EXTRA.get(name, {}))
+    filt = kw.pop("filter", None)
+    if filt is not None:
+        assert filt[0] == "gaussian"
+        kw.update(filter_radius=filt[1], filter_table=scenes.gaussian_filter_table(filt[1], filt[2]))
+    return kw
 
 
 def main():

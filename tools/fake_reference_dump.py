@@ -16,13 +16,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def write_dump(oracle, name, d):
-    from export_pbrt import EXTRA, SCENES, camera_of
+    from export_pbrt import EXTRA, SCENES, camera_of, render_kwargs
     from rs_pbrt_amd import abi, lib, scenes
     os.makedirs(d, exist_ok=True)
     mk, _cam, xres, yres, spp, depth = SCENES[name]
     sc = mk(lib.bvh_build, scenes)
     look_at, fov = camera_of(name, scenes)
-    rd = scenes.make_render_desc(xres, yres, spp, look_at, fov, max_depth=depth, **EXTRA.get(name, {}))
+    rd = scenes.make_render_desc(xres, yres, spp, look_at, fov, max_depth=depth, **render_kwargs(name, scenes))
     nt_nodes, nt_prims = sc.n_top
     sc.nodes[:nt_nodes].tofile(os.path.join(d, "bvh_nodes.bin"))          # LinearBVHNode == rspt_bvh_node, 32 B
     tri = sc.P[sc.prims["v"][:nt_prims]].reshape(-1, 9).astype(np.float32)
