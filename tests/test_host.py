@@ -176,3 +176,18 @@ def test_ply_reader_and_the_ganesha_pickup(tmp_path, monkeypatch):
     assert bench.ganesha_ply() in (str(tmp_path / "l.ply"), str(tmp_path / "b.ply"), str(tmp_path / "a.ply"))
     monkeypatch.delenv("RSPT_GANESHA_DIR")
     assert bench.ganesha_ply() is None
+
+
+def test_transform_bounds_divides_by_the_homogeneous_weight():
+    """scenes._transform_bounds = Transform::transform_bounds (transform.rs:596-660): the eight corners go through transform_point, which divides by the
+    homogeneous weight whenever it is not exactly 1 (:490-516) — an affine matrix is untouched, a last row (0 0 0 2) halves the box"""
+    lo, hi = np.array([1, 2, 3], np.float32), np.array([2, 4, 6], np.float32)
+    m = np.eye(4, dtype=np.float32)
+    a_lo, a_hi = scenes._transform_bounds(m, lo, hi)
+    assert np.array_equal(a_lo, lo) and np.array_equal(a_hi, hi)
+    m[3, 3] = 2.0
+    b_lo, b_hi = scenes._transform_bounds(m, lo, hi)
+    assert np.array_equal(b_lo, lo / 2) and np.array_equal(b_hi, hi / 2)
+    m[3] = [1e-3, 0, 0, 1]   # the weight grows with x: the far corners shrink more than the near ones
+    c_lo, c_hi = scenes._transform_bounds(m, lo, hi)
+    assert np.allclose(c_lo, lo / np.float32(1.001), rtol=1e-6) and np.allclose(c_hi[0], 2 / np.float32(1.002), rtol=1e-6)
