@@ -190,4 +190,4 @@ def test_transform_bounds_divides_by_the_homogeneous_weight():
     assert np.array_equal(b_lo, lo / 2) and np.array_equal(b_hi, hi / 2)
     m[3] = [1e-3, 0, 0, 1]   # the weight grows with x: the far corners shrink more than the near ones
     c_lo, c_hi = scenes._transform_bounds(m, lo, hi)
-    assert np.allclose(c_lo, lo / np.float32(1.001), rtol=1e-6) and np.allclose(c_hi[0], 2 / np.float32(1.002), rtol=1e-6)
+    assert np.allclose(c_lo, [1 / 1.001, 2 / 1.002, 3 / 1.002], rtol=1e-6) and np.allclose(c_hi, [2 / 1.002, 4 / 1.001, 6 / 1.001], rtol=1e-6)
