@@ -124,6 +124,20 @@ def test_wide_pixel_filters_gather_form(gpu, oracle, case, monkeypatch):
             assert np.allclose(total, films["1"], rtol=2e-5, atol=1e-6)
 
 
+def test_wide_filter_under_a_pixel_sampler_in_several_passes(gpu, oracle, monkeypatch):
+    """the pixel samplers hand their samples to the film stage pass by pass (RSPT_SERIAL_SAMPLES rows of pixels at a time), each pass with its own pixel list:
+    the gather form rebuilds its position index per pass — the frame must not depend on how many passes there were"""
+    sc = scenes.cornell_box(gpu.bvh_build)
+    rd = scenes.cornell_render_desc(res=64, spp=4, sampler="02sequence", filter_radius=(2.0, 2.0), filter_table=scenes.gaussian_filter_table((2.0, 2.0)))
+    ref = oracle.render(sc, rd, threads=8)
+    with gpu.DeviceScene(sc) as ds:
+        one, _ = gpu.render(ds, rd)
+        monkeypatch.setenv("RSPT_SERIAL_SAMPLES", str(16 * 4 * 16 * 3))   # three rows of pixels per pass
+        many, _ = gpu.render(ds, rd)
+    assert np.allclose(one[:, 3], ref["film"][:, 3], rtol=1e-5) and film_rmse(one, ref["film"]) < 1e-5
+    assert np.allclose(many, one, rtol=2e-5, atol=1e-6)
+
+
 def test_crop_window_and_non_square(gpu, oracle):
     sc = scenes.cornell_box(gpu.bvh_build)
     rd = scenes.make_render_desc(100, 60, 4, scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV, crop=(0.25, 0.8, 0.1, 0.9))
