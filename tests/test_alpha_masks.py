@@ -171,7 +171,7 @@ def image_masked_scene(builder, form):
         sb.add_quad(panel, green, UV=uv, alpha=sb.constant_texture(0.0))
         sb.add_mesh(leaf, [[0, 1, 2]], green, alpha=sb.constant_texture(1.0))
         sb.add_mesh(leaf + np.float32(0.8), [[0, 1, 2]], green, UV=[[0.5, 0.5], [0.5, 0.5], [0.5, 0.5]], shadow_alpha=sb.constant_texture(1.0))
-    elif form == "instanced":
+    elif form in ("instanced", "instanced-reference"):
         m = sb.image_texture(img1, channels=1, su=2.0, sv=2.0)
         sb.begin_object("panel")
         sb.add_mesh(panel - np.array([0, 0, 0.97], np.float32), [[0, 1, 2], [0, 2, 3]], green, UV=uv, alpha=m)
@@ -179,7 +179,7 @@ def image_masked_scene(builder, form):
         sb.end_object()
         sb.add_instance("panel", scenes.Transform.translate((0, 0, 0.97)) * scenes.Transform.rotate_y(8.0))
         sb.add_instance("panel", scenes.Transform.translate((2.6, 0.3, 0.5)) * scenes.Transform.scale(0.6, 0.8, 1.0))
-        return sb.finish(builder, instancing="fixed")
+        return sb.finish(builder, instancing="reference" if form.endswith("reference") else "fixed")
     elif form == "mixed-with-a-graph":   # one mask is a checkerboard: the whole scene stays with the general evaluator
         sb.add_quad(panel, green, UV=uv, alpha=sb.image_texture(img1, channels=1, su=2.0, sv=2.0))
         sb.add_mesh(leaf, [[0, 1, 2]], green, alpha=sb.checkerboard_texture(sb.constant_texture(0.0), sb.constant_texture(1.0), su=3.0, sv=3.0))
@@ -201,7 +201,7 @@ def test_oracle_image_alpha_masks_remove_light_blockers(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["repeat", "clamp-trilinear", "shadow", "constants", "instanced", "mixed-with-a-graph"])
+@pytest.mark.parametrize("form", ["repeat", "clamp-trilinear", "shadow", "constants", "instanced", "instanced-reference", "mixed-with-a-graph"])
 def test_gpu_inline_alpha_masks_match_oracle_and_the_general_evaluator(gpu, oracle, form, monkeypatch):
     """k_trace_w4<.., ALPHA = 2> (kernels.h alpha_simple: masks as in-line records, no texture-graph interpreter in the traversal) against the oracle and
     against the general path (RSPT_ALPHA_SIMPLE=0: alpha_pass -> tex_eval): hit records byte for byte, every sample's radiance bit for bit"""
