@@ -440,8 +440,8 @@ def test_gpu_instances_given_as_matrices_match_oracle(gpu, oracle, mode, tex):
         film, st = gpu.render(ds, rd)
         assert np.array_equal(li, ref["li"]), int((li != ref["li"]).any(axis=2).sum())
         assert np.array_equal(film[:, 3], ref["film"][:, 3])
-        for kw in (dict(integrator="ao", ao_samples=8), dict(sampler="02sequence")):
+        for kw in (dict(integrator="ao", ao_samples=8), dict(sampler="02sequence"), dict(integrator="volpath"), dict(integrator="directlighting", max_depth=3)):
             rdk = rd_small(spp=4, **kw)
             fk, _ = gpu.render(ds, rdk)
-            rk = oracle.render(sc, rdk, threads=8)
+            rk = oracle.render_integrator(sc, rdk, "direct", threads=8) if kw.get("integrator") == "directlighting" else oracle.render(sc, rdk, threads=8)
             assert np.array_equal(fk[:, 3], rk["film"][:, 3]) and film_rmse(fk, rk["film"]) < 2e-5, kw
