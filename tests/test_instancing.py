@@ -64,7 +64,7 @@ def rd_small(spp=8, res=(96, 72), **kw):
     return scenes.make_render_desc(res[0], res[1], spp, LOOK, 40.0, **kw)
 
 
-def moving_scene(builder, mode="fixed", rotation=True, tex=False):
+def moving_scene(builder, mode="fixed", rotation=True, tex=False, matrices=False):
     """small_scene with MOVING instances (AnimatedTransform primitive_to_world, primitive.rs:198-265): a pyramid that slides and grows, one that
     also turns (slerp), one whose keys are equal (actually_animated = false), one whose interval ends inside the shutter, a moving
     single-triangle object, static ones next to them.  Shutter 0 .. 1, keys at 0 / 1 unless noted."""
@@ -92,6 +92,8 @@ def moving_scene(builder, mode="fixed", rotation=True, tex=False):
     sb.add_instance("one", T.translate((0, 2.0, 0)), T.translate((0.4, 2.4, 0.3)))
     sb.add_instance("pyr", T.translate((-0.8, 0.0, 2.6)) * T.scale(0.7, 0.7, 0.7))                                                         # static
     sb.add_instance("pyr", T.identity(), T.translate((0.0, 0.3, 0.0)), time=(0.5, 1.0))                                                    # the identity for half of the shutter (Q10 while it lasts)
+    if matrices:   # the keys as `Transform [..]` gives them: the inverses by Gauss-Jordan, rows 3 not exactly (0 0 0 1) (matrix_scene below)
+        sb.instances[:] = [(o, T(a.m) if k < 2 else a, (T(e.m) if k < 2 else e) if e is not None else None, tm) for k, (o, a, e, tm) in enumerate(sb.instances)]
     return sb.finish(builder, instancing=mode)
 
 
@@ -361,11 +363,11 @@ def test_oracle_moving_instances_blur_and_reduce_to_static_ones(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,tex,sampler", [("fixed", False, "sobol"), ("reference", False, "sobol"), ("fixed", True, "sobol"), ("fixed", False, "halton")])
+@pytest.mark.parametrize("mode,tex,sampler", [("fixed", False, "sobol"), ("reference", False, "sobol"), ("fixed", True, "sobol"), ("fixed", False, "halton"), ("fixed-matrices", False, "sobol")])
 def test_gpu_moving_instances_match_oracle(gpu, oracle, mode, tex, sampler):
     """TransformedPrimitive with an AnimatedTransform (ABI 20): the library interpolates the instance's Transform at the path's ray time at every
     instance visit and at the hit (dev_scene.h inst_at); per-sample radiance bit for bit, with rotation between the keys, in both instancing modes"""
-    sc = moving_scene(gpu.bvh_build, mode=mode, tex=tex)
+    sc = moving_scene(gpu.bvh_build, mode=mode.split("-")[0], tex=tex, matrices=mode.endswith("matrices"))
     assert int(sc.instances["animated"].sum()) >= 5
     rd = rd_small(spp=16, shutter=(0.0, 1.0), sampler=sampler)
     with gpu.DeviceScene(sc) as ds:
