@@ -115,6 +115,11 @@ def test_wide_pixel_filters_gather_form(gpu, oracle, case, monkeypatch):
         monkeypatch.setenv("RSPT_FILM_GATHER", "1")
         again, _ = gpu.render(ds, rd)
         assert np.array_equal(again, films["1"])   # the gather form adds in a fixed order: the same film every time
+        if case == "gaussian-2":   # several batches per frame (pixels and sample slices): a block's halo pixels then sit in other batches, which add their share when they run
+            monkeypatch.setenv("RSPT_BATCH", "4096")
+            split, st2 = gpu.render(ds, rd)
+            monkeypatch.delenv("RSPT_BATCH")
+            assert st2["samples"] == st["samples"] and np.allclose(split, films["1"], rtol=2e-5, atol=1e-6)
         if case == "crop-shards-ranges":
             total = np.zeros_like(films["1"])
             for r in range(3):
