@@ -266,3 +266,19 @@ def test_scene_without_specular_lobes_keeps_only_the_root_level(gpu, oracle, str
         monkeypatch.setenv("RSPT_DL_FULL_TREE", full)
         films.append(check(gpu, oracle, sc, rd, strategy, ls))
     assert np.array_equal(films[0], films[1])
+
+
+def test_root_only_tree_with_a_null_surface_in_the_way(gpu, oracle):
+    """DlBuf::levels = 1 and BSDF-less surfaces together: a camera ray that meets a material-less pane continues inside its (only) node
+    (directlighting.rs:90-92) — the re-trace rounds of level 0 — while no node ever gets a child"""
+    sb = scenes.SceneBuilder()
+    white = sb.add_material(scenes.matte((0.7, 0.7, 0.7)))
+    sb.add_quad([(-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4)], white)
+    sb.add_quad([(-4, 0, 3), (-4, 5, 3), (4, 5, 3), (4, 0, 3)], white)
+    sb.add_quad([(-1, 4.5, -1), (1, 4.5, -1), (1, 4.5, 1), (-1, 4.5, 1)], white, emit=(15, 15, 15))
+    sb.add_quad([(-2, 0.2, 0.5), (2, 0.2, 0.5), (2, 3.0, 0.5), (-2, 3.0, 0.5)], abi.NO_MATERIAL)    # two panes behind each other
+    sb.add_quad([(-1.5, 0.4, 1.5), (1.5, 0.4, 1.5), (1.5, 2.5, 1.5), (-1.5, 2.5, 1.5)], abi.NO_MATERIAL)
+    sb.add_point_light((2, 3, -3), (20, 20, 20))
+    sc = sb.finish(gpu.bvh_build)
+    rd = scenes.make_render_desc(48, 36, 8, ((0, 2.0, -6.0), (0, 1.5, 0), (0, 1, 0)), 45.0, max_depth=5, integrator="directlighting", light_samples=[2, 2, 1])
+    check(gpu, oracle, sc, rd, "all", [2, 2, 1])
