@@ -55,11 +55,17 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 line and the 1/8-frame probe")
     ap.add_argument("--no-count", action="store_true", help="skip the reference-order counting pass (no roofline block): for PMC runs")
     ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--dump-film", default="", help="rank 0 writes the frame of the last timed step (float32 [pixels, 4], after the reduce) to this .npy file")
+    ap.add_argument("--watchdog", type=int, default=1500, help="seconds after which a rank that is still running dumps its stack and exits 1 (a hung collective "
+                                                               "then ends the job with a non-zero code instead of holding the box); 0 = off")
     return ap.parse_args()
 
 
 def self_spawn(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU)."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU; on a box with fewer devices than
+    ranks the ranks share devices and fall back to gloo — main()).  The launcher runs in its own process group under a time limit: a
+    hung rank ends the run with a non-zero code."""
+    import signal
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -69,7 +75,17 @@ def self_spawn(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    p = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return p.wait(timeout=(args.watchdog + 120) if args.watchdog > 0 else None)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: the %d-rank job did not finish within %d s; killing its process group\n" % (args.gpus, args.watchdog + 120))
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.wait()
+        return 124
 
 
 PUBLISHED_CORNELL_MSAMPLES = 500 * 500 * 8 / (1024 / 1828.38) / 1e6   # 3.57
@@ -226,6 +242,20 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_
            "nodes_per_ray": counts["nodes_visited"] / max(counts["rays_closest"] + counts["rays_any"], 1),
            "tris_per_ray": counts["tris_tested"] / max(counts["rays_closest"] + counts["rays_any"], 1),
            "mrays_per_s": rays / t_wall / 1e6}
+    # three more fractions, each against the ceiling it names:
+    #   alg_frac       SURVEY 8(d)'s algorithmic bytes / SUM of the per-launch durations / 8 TB/s — the contract's literal "achieved / peak".  It can
+    #                  exceed 1 and does: the model prices every node visit of the REFERENCE's traversal as a fresh 32-byte HBM fetch, the kernel
+    #                  fetches half as many 128-byte records and nearly all of them from L2 / Infinity Cache — it is not a bound, it is printed as asked
+    #   l2_line_frac   L1-miss lines x 128 B / wall time of the launches / 34.5 TB/s (aggregate L2 -> L1 bandwidth, MI355X_MICROARCH.md: 2048 B/clk/XCD)
+    #   latency_bound_g_lines_per_s   misses in flight per CU x 256 CUs / mean miss latency: the rate Little's law allows at THIS latency and THIS
+    #                  number of outstanding misses; l1_miss_g_lines_per_s sits on it by construction over the kernels' busy cycles — what can move is
+    #                  the latency (the L2 hit rate) and the number in flight (occupancy), which is what profiles/r05_w8_sweeps.txt varies
+    L2_PEAK_GBS, CLOCK_GHZ = 34500.0, 2.4
+    out["alg_frac"] = trace_bytes / (t_c + t_a) / 1e9 / HBM_PEAK_GBS if (t_c + t_a) > 0 else None
+    out["alg_frac_note"] = "SURVEY 8(d) bytes / summed launch durations / 8 TB/s; > 1 means the byte model over-counts (L2 / Infinity-Cache residency, four-box records), not that HBM is saturated"
+    out["l2_line_frac"] = (miss_lines * 128.0 / t_wall / 1e9 / L2_PEAK_GBS) if miss_lines else None
+    lat, infl = lc.get("l1_to_l2_read_latency_cycles"), lc.get("l1_misses_in_flight_per_cu")
+    out["latency_bound_g_lines_per_s"] = (infl * 256.0 / lat * CLOCK_GHZ) if (lat and infl) else None
     # the shade stage (k_bin_* + k_texture + k_shade): SURVEY 8(d) prices it at 48 B per closest-hit ray (32 B ray record written + 16 B hit record
     # read) + 36 B per shadow ray (32 B written + 4 B flag read) + 96 B of path state per bounce
     n_bounce = count_scale * (counts["alg_bytes"] - 32.0 * counts["samples"]) / 96.0 - trace_bytes / 96.0
@@ -267,8 +297,24 @@ def time_steps(step, fence, n):
     return time.perf_counter() - t0, stats
 
 
+def host_cpu_facts():
+    """what the box gives this process: logical CPUs, the affinity mask, the cgroup CPU quota (a container may see 256 CPUs and be allowed 32)"""
+    facts = {"logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": None, "model": None}
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            facts["cgroup_cpu_max"] = open(f).read().strip()
+            break
+        except OSError:
+            pass
+    try:
+        facts["model"] = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return facts
+
+
 def cpu_baseline(args, pyoracle, sc, mk_rd, spp, scaling_crop):
-    ncores = os.cpu_count() or 1
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     rd_cpu = mk_rd(spp, (0, 1, 64))
     def cpu_render(rd_, threads):
         if args.integrator != "directlighting":
@@ -288,14 +334,25 @@ def cpu_baseline(args, pyoracle, sc, mk_rd, spp, scaling_crop):
                                           "rays_closest": c["rays_closest"] / c["samples"], "rays_any": c["rays_any"] / c["samples"],
                                           "alg_bytes": (32.0 * c["nodes_visited"] + 48.0 * c["tris_tested"] + 96.0 * c["rays_closest"] + 72.0 * c["rays_any"]
                                                         + 96.0 * c["bounces"] + 32.0 * c["samples"]) / c["samples"]}}
-    # how the port scales with threads, on ONE sample for both runs: a crop window of 256 tiles (one per hardware thread of the box) at 1/4 of the spp
-    rd_s = mk_rd(max(spp // 4, 1), (0, 1, 64), crop=scaling_crop)
-    r1, rn = cpu_render(rd_s, 1), cpu_render(rd_s, ncores)
+    # how the port scales with threads, on ONE sample for both runs: a crop window of 256 tiles (one per hardware thread of the box) at an spp chosen so
+    # that the all-thread leg runs for >= 2 s at the rate just measured (legs of 0.0 - 0.4 s measured thread start-up, not rendering);
+    # the one-thread leg is then that many seconds x the ratio
+    crop_px = 256 * 256
+    spp_s = 1
+    while crop_px * spp_s < 2.2e6 * out["value"] and spp_s < 4096:
+        spp_s *= 2
+    rp = cpu_render(mk_rd(1, (0, 1, 64), crop=scaling_crop), 1)                      # probe: bounds the one-thread leg to ~40 s
+    v1_probe = rp["counters"]["samples"] / max(rp["seconds"], 1e-6)
+    while spp_s > 1 and crop_px * spp_s > 40.0 * v1_probe:
+        spp_s //= 2
+    rd_s = mk_rd(spp_s, (0, 1, 64), crop=scaling_crop)
+    rn, r1 = cpu_render(rd_s, ncores), cpu_render(rd_s, 1)
     v1, vn = r1["counters"]["samples"] / r1["seconds"] / 1e6, rn["counters"]["samples"] / rn["seconds"] / 1e6
     out["thread_scaling"] = {"ratio": vn / v1, "one_thread": v1, "all_threads": vn, "unit": "Msamples/s",
                              "sample": "crop window %s of the frame at %d spp (%d samples) for BOTH runs: 1 thread %.1f s, %d threads %.1f s (the tile loop hands out 16x16 tiles: "
-                                       "%d tiles in this window)" % (list(rd_s.crop_px), max(spp // 4, 1), r1["counters"]["samples"], r1["seconds"], ncores, rn["seconds"],
+                                       "%d tiles in this window)" % (list(rd_s.crop_px), spp_s, r1["counters"]["samples"], r1["seconds"], ncores, rn["seconds"],
                                                                      ((rd_s.crop_px[2] - rd_s.crop_px[0] + 15) // 16) * ((rd_s.crop_px[3] - rd_s.crop_px[1] + 15) // 16))}
+    out["host"] = host_cpu_facts()
     return out
 
 
@@ -332,7 +389,7 @@ def measure(args, lib, scenes, workload, steps, warmup, shard, world, reduce_in_
         step()
     elapsed, stats = time_steps(step, fence, steps)
     return dict(sc=sc, ds=ds, mk_rd=mk_rd, spp=spp, name=wl_name, rd=rd, counts=counts, count_scale=float(spp) / max(spp // count_spp_div, 1),
-                elapsed=elapsed, stats=stats, t_scene=t_scene, t_upload=t_upload, film=film, step=step)
+                elapsed=elapsed, stats=stats, t_scene=t_scene, t_upload=t_upload, film=film, step=step, film_host=film_host)
 
 
 def main():
@@ -342,32 +399,62 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.watchdog > 0:   # a rank that is still here after this long is hung (a collective one member never entered): stack to stderr, exit 1 —
+        import faulthandler  # torch.distributed.run then stops the other ranks and the job ends with a non-zero code
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     import torch  # first, so librspt binds to the HIP runtime torch already loaded
     import torch.distributed as dist
     from rs_pbrt_amd import lib, multigpu, scenes
-    torch.cuda.set_device(local_rank)
-    # one RCCL per process: librspt binds the copy torch has already mapped (rspt_comm_* dlopen it by this path)
-    torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-    if os.path.exists(torch_rccl):
-        os.environ.setdefault("RSPT_RCCL_LIB", torch_rccl)
-    lib.init(local_rank)
+    n_dev = max(torch.cuda.device_count(), 1)
+    # fewer devices than ranks (a one-GPU box running the N > 1 control flow): ranks share devices, and the transport is gloo over host
+    # memory — RCCL refuses two ranks on one device ("Duplicate GPU detected").  Same spawn, uid exchange, tile deal, film sum, max-over-ranks
+    # time and JSON line as on a full node; the rate it prints is that of one oversubscribed GPU and says so.
+    shared_devices = world > n_dev
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    # ONE librccl per process and one policy everywhere (rspt_comm_library, include/rspt.h): the copy the process has mapped already — torch's,
+    # since torch is imported first here and in the tests — else $RSPT_RCCL_LIB, else the loader's.  The path that was bound is printed in the line.
+    lib.init(device_index)
     reduce_in_lib, torch_reduce, reduce_name = False, None, "none (1 GPU)"
+    coll_dev = "cpu" if shared_devices else "cuda"    # where the tensors of this script's own collectives live
+    rccl_path = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        if shared_devices:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=600))
         # X1 lives in the library: rank 0's id travels over the launcher's process group, then every rank joins the library's own communicator
         try:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            rccl_path = lib.comm_library()
+            uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(lib.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, src=0)
+            if shared_devices:
+                raise RuntimeError("%d ranks on %d device(s): RCCL takes one rank per device" % (world, n_dev))
             lib.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-            ok = torch.ones(1, device="cuda")
+            ok = torch.ones(1, device=coll_dev)
         except Exception as e:  # noqa: BLE001 — a node without a usable librccl still gets its number through torch's communicator
-            sys.stderr.write("rank %d: rspt_comm_init failed (%s); falling back to torch.distributed.reduce\n" % (rank, e))
-            ok = torch.zeros(1, device="cuda")
+            sys.stderr.write("rank %d: no library communicator (%s); the films are summed by torch.distributed.reduce\n" % (rank, e))
+            ok = torch.zeros(1, device=coll_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() > 0:
             reduce_in_lib, reduce_name = True, "ncclReduce(sum) to rank 0 inside rspt_render_device (RCCL, library-owned communicator)"
+        elif shared_devices:
+            stage = torch.zeros(1, dtype=torch.float32).pin_memory()
+
+            def torch_reduce(f):
+                nonlocal stage
+                torch.cuda.synchronize()  # the film was written on the library's stream
+                if stage.numel() != f.numel():
+                    stage = torch.zeros(f.numel(), dtype=torch.float32).pin_memory()
+                stage.copy_(f)
+                multigpu.reduce_film(stage)
+                if rank == 0:
+                    f.copy_(stage)
+                torch.cuda.synchronize()
+            reduce_name = "torch.distributed.reduce(sum) to rank 0 over gloo through host memory (%d ranks share %d device(s): RCCL takes one rank per device)" % (world, n_dev)
         else:
             def torch_reduce(f):
                 torch.cuda.synchronize()  # the film was written on the library's stream
@@ -383,11 +470,12 @@ def main():
     shard = multigpu.shard_for_rank(rank, world)  # Morton-ordered tiles dealt round-robin over the ranks
     m = measure(args, lib, scenes, args.workload, args.steps, args.warmup, shard, world, reduce_in_lib, torch_reduce, fence, rank0=rank == 0)
     elapsed, stats = m["elapsed"], m["stats"]
+    m_film_host = m["film_host"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        samples_t = torch.tensor([float(stats[0]["samples"])], dtype=torch.float64, device="cuda")
+        samples_t = torch.tensor([float(stats[0]["samples"])], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(samples_t, op=dist.ReduceOp.SUM)
         samples_per_step = float(samples_t.item())
     else:
@@ -402,7 +490,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": m["name"], "samples_per_step": samples_per_step, "tiles": "16x16 tiles in Morton order dealt round-robin to the ranks (tile_chunk %d)" % multigpu.TILE_CHUNK,
-                       "film_reduce": reduce_name,
+                       "film_reduce": reduce_name, "librccl": rccl_path, "devices_visible": n_dev,
                        "timed_region": "per step: rspt_render_device (first launch -> film complete in HBM%s) + the copy of the film to pinned host memory "
                                        "(%.1f MB): SURVEY 8(d)'s t_render, first launch -> film in host memory" % (
                                            " on rank 0 after the reduce" if world > 1 else "", scenes.n_pixels(m["rd"]) * 16 / 1e6)},
@@ -465,11 +553,20 @@ def main():
             extra["c3_statue_standin"] = c3
             m3["ds"].close()
             out["extra"] = extra
+        if shared_devices:
+            out["config"]["note"] = ("%d ranks on %d device(s): a run of the N > 1 CONTROL FLOW (spawn, id exchange, tile deal, film sum, max-over-ranks timing), "
+                                     "not a scaling measurement" % (world, n_dev))
+        if args.dump_film:
+            import numpy as np
+            np.save(args.dump_film, m_film_host.numpy().reshape(-1, 4))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        lib.comm_destroy()
+        if reduce_in_lib:
+            lib.comm_destroy()
         dist.destroy_process_group()
+    if args.watchdog > 0:
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

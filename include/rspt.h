@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSPT_ABI_VERSION 20
+#define RSPT_ABI_VERSION 21
 
 /* error codes */
 #define RSPT_OK 0
@@ -505,6 +505,11 @@ void rspt_shutdown(void);
 int rspt_comm_unique_id(uint8_t id[RSPT_COMM_ID_BYTES]);
 int rspt_comm_init(int32_t rank, int32_t world, const uint8_t id[RSPT_COMM_ID_BYTES]);
 int rspt_comm_destroy(void);
+/* Which librccl the calls above are bound to: the copy the process has ALREADY mapped if there is one (a host that imported torch has torch's),
+ * else $RSPT_RCCL_LIB, else librccl.so / librccl.so.1 by the loader's search, else /opt/rocm/lib/librccl.so.1 — one policy for every caller.
+ * Binds on first use; the returned path (dladdr of ncclGetUniqueId) stays valid for the life of the process; NULL + RSPT_E_UNSUPPORTED in
+ * rspt_last_error when no librccl can be loaded. */
+const char* rspt_comm_library(void);
 
 /* Replaces: RenderOptions::make_scene's hand-over of BVHAccel + lights to
  * Scene::new (src/core/api.rs:474-485, src/core/scene.rs:27-53): uploads the
@@ -565,6 +570,22 @@ int rspt_material_lobes(const rspt_scene_desc* desc, uint32_t material, uint32_t
  * rotation quaternions r[2][4] (x, y, z, w; the second one flipped onto the shorter arc), the two scale matrices s[2][16] (row-major; with
  * the key's translation column still in it, transform.rs:2079 — only the 3x3 block is interpolated). */
 int rspt_camera_decompose(const float start_m[16], float start_time, const float end_m[16], float end_time, int32_t* animated_out, float trs_out[46]);
+
+/* The hash of the kernel / ABI sources this binary was built from (16 hex digits; csrc/Makefile SRC_HASH): rocprofv3 summaries under
+ * profiles/ carry it, and a measurement quotes a profile only when the LIBRARY that is running reports the same hash. */
+const char* rspt_source_hash(void);
+
+/* Host only (no device needed).  Replaces: AnimatedTransform::motion_bounds (core/transform.rs:2147-2163) with bound_point_motion
+ * (:2164-2210) and interval_find_zeros (:2281-2350) — TransformedPrimitive::world_bound (core/primitive.rs:212-215) of a moving instance,
+ * the box its caller hands rspt_bvh_build_bounds for the top-level tree.  [box_min, box_max] is the instanced object's own bound, the keys
+ * are primitive_to_world's start / end matrices and times.  Equal keys: the start transform's transform_bounds; no rotation between the keys
+ * (quaternion dot >= 0.9995): the union of the two keys' boxes; else per corner the union of the two end points and of the point at every
+ * zero of the motion derivative (root isolation as the reference does it, in f32; the derivative's coefficients come from a matrix form
+ * of the reference's expanded DerivativeTerm polynomials, :944-2030, evaluated in double precision — csrc/motion_bounds.h).
+ * *flags_out (may be NULL): bit 0 = actually_animated, bit 1 = has_rotation.  RSPT_E_UNSUPPORTED where the reference would panic (a ninth
+ * zero for one point and component), RSPT_E_INVALID for non-finite input. */
+int rspt_motion_bounds(const float start_m[16], float start_time, const float end_m[16], float end_time, const float box_min[3],
+                       const float box_max[3], float out_min[3], float out_max[3], int32_t* flags_out);
 
 /* Stage-level hook.  Replaces: f32::sin / cos / ln / log2 / exp / acos / atan2 as the path uses them (concentric_sample_disk
  * sampling.rs:360-382, Trowbridge-Reitz sampling microfacet.rs:475-531, spherical directions and mappings, MIP level selection, roughness

@@ -6,6 +6,7 @@
 // rs_pbrt ships no tests / golden vectors and cannot be built here (no Rust toolchain), so those parts rest on first-principles
 // known-answer tests (tests/test_oracle_*.py) until a dump of real rs_pbrt is committed (oracle/REFERENCE_FIXTURES.md).
 #include "orc_render.hpp"
+#include "orc_motion.hpp"
 
 using namespace orc;
 
@@ -140,6 +141,35 @@ void orc_interpolate_transform(const float start_m[16], const float start_inv[16
     M44 m, mi;
     a.interpolate_full(time, m44_from(start_inv), m44_from(end_inv), &m, &mi);
     std::memcpy(m_out, &m.m[0][0], 64); std::memcpy(inv_out, &mi.m[0][0], 64);
+}
+// AnimatedTransform::motion_bounds (transform.rs:2147-2210) of box [lo, hi] under the keys (start_m, t0) / (end_m, t1).
+// terms_in: NULL = this oracle's own coefficients, else 60 floats c[5][3][4] (kc, kx, ky, kz) to use instead (the fixture generator passes the
+// reference's literal expressions); terms_out (may be NULL): the 60 coefficients + theta that were used.  Returns 0, or 1 where the reference panics.
+int orc_motion_bounds(const float start_m[16], float t0, const float end_m[16], float t1, const float lo[3], const float hi[3], const float* terms_in,
+                      float out_lo[3], float out_hi[3], float* terms_out, int32_t* flags_out) {
+    const AnimatedTransform a(start_m, t0, end_m, t1);
+    MotionTerms mt{};
+    if (a.actually_animated && a.has_rotation) {
+        mt = motion_terms(a);
+        if (terms_in) std::memcpy(mt.c, terms_in, sizeof mt.c);
+    }
+    Bounds3 b, r;
+    b.p_min = V3{lo[0], lo[1], lo[2]}; b.p_max = V3{hi[0], hi[1], hi[2]};
+    if (!motion_bounds(a, b, &mt, &r)) return 1;
+    out_lo[0] = r.p_min.x; out_lo[1] = r.p_min.y; out_lo[2] = r.p_min.z; out_hi[0] = r.p_max.x; out_hi[1] = r.p_max.y; out_hi[2] = r.p_max.z;
+    if (terms_out) { std::memcpy(terms_out, mt.c, sizeof mt.c); terms_out[60] = mt.theta; }
+    if (flags_out) *flags_out = (a.actually_animated ? 1 : 0) | (a.has_rotation ? 2 : 0);
+    return 0;
+}
+// what AnimatedTransform::new leaves (transform.rs:912-943): t[2][3], r[2][4] (x, y, z, w; second on the shorter arc), s[2][16] — the inputs of the
+// reference's derivative-term expressions (the fixture generator feeds them to the machine-converted text)
+void orc_animated_keys(const float start_m[16], float t0, const float end_m[16], float t1, float trs_out[46]) {
+    const AnimatedTransform a(start_m, t0, end_m, t1);
+    for (int k = 0; k < 2; k++) {
+        trs_out[3 * k] = a.t[k].x; trs_out[3 * k + 1] = a.t[k].y; trs_out[3 * k + 2] = a.t[k].z;
+        trs_out[6 + 4 * k] = a.r[k].v.x; trs_out[6 + 4 * k + 1] = a.r[k].v.y; trs_out[6 + 4 * k + 2] = a.r[k].v.z; trs_out[6 + 4 * k + 3] = a.r[k].w;
+        std::memcpy(trs_out + 14 + 16 * k, &a.s[k].m[0][0], 64);
+    }
 }
 void orc_camera_ray_diff(const rspt_render_desc* rd, const float cs[5], float out[18]) {
     Ray r = camera_ray(*rd, P2{cs[0], cs[1]}, cs[2], P2{cs[3], cs[4]});

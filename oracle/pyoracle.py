@@ -226,6 +226,32 @@ def grid_sample(density, sigma_a, sigma_s, g, o, d, t_max, u, world_to_medium=No
     return dict(beta=out[:3].copy(), sampled=bool(out[3]), p=out[4:7].copy(), wo=out[7:10].copy(), used=used.value)
 
 
+def motion_bounds(start_m, t0, end_m, t1, lo, hi, terms=None):
+    """AnimatedTransform::motion_bounds (transform.rs:2147-2210): (lo, hi, terms (5, 3, 4), theta, actually_animated, has_rotation);
+    terms: use this coefficient table instead of the oracle's own (orc_motion.hpp)"""
+    a = np.ascontiguousarray(start_m, np.float32).reshape(16); b = np.ascontiguousarray(end_m, np.float32).reshape(16)
+    l = np.ascontiguousarray(lo, np.float32).reshape(3); h = np.ascontiguousarray(hi, np.float32).reshape(3)
+    ti = None if terms is None else np.ascontiguousarray(terms, np.float32).reshape(60)
+    ol, oh, to, fl = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(61, np.float32), C.c_int32(0)
+    L = lib()
+    L.orc_motion_bounds.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_float] + [C.c_void_p] * 7
+    rc = L.orc_motion_bounds(a.ctypes.data, float(t0), b.ctypes.data, float(t1), l.ctypes.data, h.ctypes.data, None if ti is None else ti.ctypes.data,
+                             ol.ctypes.data, oh.ctypes.data, to.ctypes.data, C.addressof(fl))
+    assert rc == 0, "more than eight zeros: the reference panics here"
+    return ol, oh, to[:60].reshape(5, 3, 4).copy(), float(to[60]), bool(fl.value & 1), bool(fl.value & 2)
+
+
+def animated_keys(start_m, t0, end_m, t1):
+    """AnimatedTransform::new's decomposition (transform.rs:912-943): t (2, 3), r (2, 4) xyzw, s (2, 4, 4)"""
+    a = np.ascontiguousarray(start_m, np.float32).reshape(16); b = np.ascontiguousarray(end_m, np.float32).reshape(16)
+    trs = np.zeros(46, np.float32)
+    L = lib()
+    L.orc_animated_keys.restype = None
+    L.orc_animated_keys.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_animated_keys(a.ctypes.data, float(t0), b.ctypes.data, float(t1), trs.ctypes.data)
+    return trs[:6].reshape(2, 3).copy(), trs[6:14].reshape(2, 4).copy(), trs[14:].reshape(2, 4, 4).copy()
+
+
 def interpolate_transform(start_m, t0, end_m, t1, time, start_inv=None, end_inv=None, want_inverse=False):
     """AnimatedTransform::interpolate (transform.rs:2081-2113) between two key matrices (4 x 4, row major): the Transform's m (and m_inv)"""
     a = np.ascontiguousarray(start_m, np.float32).reshape(16); b = np.ascontiguousarray(end_m, np.float32).reshape(16)

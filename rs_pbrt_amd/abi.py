@@ -4,7 +4,7 @@ Every struct here must stay byte-compatible with the header; tests/test_abi.py c
 sizes against the values the library reports."""
 import ctypes as C
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM, E_PEER = 0, -1, -2, -3, -4, -5, -6
 

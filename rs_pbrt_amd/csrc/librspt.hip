@@ -20,6 +20,7 @@
 #include "../../include/rspt.h"
 #include "material_assembly.h"
 #include "camera_anim.h"
+#include "motion_bounds.h"
 #include "kernels.h"
 #include "trace_w4.h"
 #include "bvh_device.h"
@@ -143,8 +144,20 @@ int rccl_bind() {
     if (rc_.handle) return RSPT_OK;
     const char* names[] = {getenv("RSPT_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (const char* n : names)  // one that is already mapped first
-        if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    // one policy for every caller (rspt_comm_library): a librccl the process has mapped ALREADY wins — a second copy of RCCL in one process
+    // means two sets of bootstrap threads and IPC state.  /proc/self/maps names it whatever name it was loaded by (torch ships its own copy).
+    if (FILE* maps = fopen("/proc/self/maps", "r")) {
+        char line[4096];
+        while (!h && fgets(line, sizeof line, maps)) {
+            char* path = strchr(line, '/');
+            if (!path || !strstr(path, "librccl.so")) continue;
+            path[strcspn(path, "\n")] = 0;
+            h = dlopen(path, RTLD_NOW | RTLD_NOLOAD);
+        }
+        fclose(maps);
+    }
+    for (const char* n : names)
+        if (!h && n && *n && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     for (size_t i = 0; !h && i < sizeof names / sizeof *names; i++)
         if (names[i] && *names[i]) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(RSPT_E_UNSUPPORTED, "librccl.so not found (%s); set RSPT_RCCL_LIB", dlerror());
@@ -277,6 +290,8 @@ void free_paths() {
                     g.q[0][0], g.q[0][1], g.q[0][2], g.q[1][0], g.q[1][1], g.q[1][2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (g.path_time) (void)hipFree(g.path_time);   // sized with the path buffers (render_impl), freed with them
+    g.path_time = nullptr; g.time_cap = 0;
     g.pb = PathBuf{};
     g.tex_rows = 0;
     for (auto& a : g.q) a[0] = a[1] = a[2] = nullptr;
@@ -1036,7 +1051,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 HIP_TRY(hipStreamSynchronize(g.stream));
                 const uint32_t n_retry = g.look[0].active;
                 if (n_retry == 0) break;
-                if (round > 64) return fail(RSPT_E_HIP, "volpath: on-demand light voxels did not settle");
+                if (round > 64) return fail(RSPT_E_UNSUPPORTED, "volpath: on-demand light voxels did not settle in 64 rounds (not a device fault: the caller keeps its CPU loop, or asks for the eager table)");
                 // the retry queue becomes the input (copied to the other parity's active queue, which volpath does not use either), its counter starts again
                 HIP_TRY(hipMemcpyAsync(g.q[par ^ 1][0], g.q[par][0], (size_t)n_retry * sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
                 HIP_TRY(hipMemcpyAsync(&cur->any, &cur->active, sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));   // (cur->any: the retry run's input length)
@@ -1407,7 +1422,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             uint32_t claimed = 0;
             if ((rc = build_claimed_rows(&claimed))) return rc;
             if (claimed == 0) break;
-            if (lazy_round > 64) return fail(RSPT_E_HIP, "pixel sampler: on-demand light voxels did not settle");
+            if (lazy_round > 64) return fail(RSPT_E_UNSUPPORTED, "pixel sampler: on-demand light voxels did not settle in 64 rounds (not a device fault: the caller keeps its CPU loop, or asks for the eager table)");
             }
             const uint32_t npx = (uint32_t)pl.size();
             Batch bt{0u, npx, 0u, spp, npx * spp};
@@ -1675,6 +1690,13 @@ int rspt_comm_unique_id(uint8_t id[RSPT_COMM_ID_BYTES]) {
     RCCL_TRY(rc_.GetUniqueId(&u));
     memcpy(id, &u, sizeof u);
     return RSPT_OK;
+}
+const char* rspt_comm_library(void) {
+    static std::string path;
+    if (rccl_bind() != RSPT_OK) return nullptr;
+    Dl_info info;
+    if (path.empty()) path = (dladdr((void*)rc_.GetUniqueId, &info) && info.dli_fname) ? info.dli_fname : "(unknown)";
+    return path.c_str();
 }
 int rspt_comm_init(int32_t rank, int32_t world, const uint8_t id[RSPT_COMM_ID_BYTES]) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
@@ -2294,7 +2316,17 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             x.identity = ident ? 1u : 0u;
             x.anim = RSPT_MISS;
             if (in.animated) {   // a moving instance (ABI 20): AnimatedTransform::new's decomposition of the two keys, as for a moving camera
-                if (!(in.time[1] > in.time[0])) return bail(fail(RSPT_E_INVALID, "instance %u: animated with time[1] <= time[0]", i));
+                if (!std::isfinite(in.time[0]) || !std::isfinite(in.time[1]) || !(in.time[1] > in.time[0]))
+                    return bail(fail(RSPT_E_INVALID, "instance %u: animated with time[1] <= time[0] or a non-finite key time", i));
+                for (int k = 0; k < 16; k++)
+                    if (!std::isfinite(in.to_world_end[k]) || !std::isfinite(in.from_world_end[k]))
+                        return bail(fail(RSPT_E_INVALID, "instance %u: non-finite end key matrix", i));
+                // transform_point divides by the homogeneous weight and the reference asserts it is not zero (transform.rs:505): an end key whose
+                // rows 3 are all zero can only produce such weights
+                if (in.to_world_end[12] == 0.0f && in.to_world_end[13] == 0.0f && in.to_world_end[14] == 0.0f && in.to_world_end[15] == 0.0f)
+                    return bail(fail(RSPT_E_INVALID, "instance %u: end key with a zero homogeneous row", i));
+                if (in.from_world_end[12] == 0.0f && in.from_world_end[13] == 0.0f && in.from_world_end[14] == 0.0f && in.from_world_end[15] == 0.0f)
+                    return bail(fail(RSPT_E_INVALID, "instance %u: end key inverse with a zero homogeneous row", i));
                 InstAnim an;
                 memset(&an, 0, sizeof an);
                 if (camanim::camera_keys(in.to_world, in.time[0], in.to_world_end, in.time[1], &an.keys)) {   // false: equal keys = not actually animated
@@ -2359,6 +2391,7 @@ namespace {
 int render_entry(rspt_scene_t s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     rc_.status_exchanged = false;
     const int rc = (!film_host && !film_dev && !li_host) ? fail(RSPT_E_INVALID, "null output buffer") : render_impl(s, d, film_host, film_dev, li_host, stats);
+    if (s && g.inited) s->dev.ray_time = nullptr;   // the per-path times belong to the render that just ended (the buffer is the library's, not the scene's)
     if (rc != RSPT_OK && d && d->film_reduce && rc_.comm && g.inited && !rc_.status_exchanged) {
         const std::string kept = rspt_last_error();
         int32_t all = 0;
@@ -2399,6 +2432,23 @@ int rspt_camera_decompose(const float start_m[16], float start_time, const float
         memcpy(trs_out + 6, ca.r, sizeof ca.r);
         memcpy(trs_out + 14, ca.s, sizeof ca.s);
     }
+    return RSPT_OK;
+}
+int rspt_motion_bounds(const float start_m[16], float start_time, const float end_m[16], float end_time, const float box_min[3], const float box_max[3],
+                       float out_min[3], float out_max[3], int32_t* flags_out) {
+    if (!start_m || !end_m || !box_min || !box_max || !out_min || !out_max) return fail(RSPT_E_INVALID, "null argument");
+    for (int i = 0; i < 16; i++) if (!std::isfinite(start_m[i]) || !std::isfinite(end_m[i])) return fail(RSPT_E_INVALID, "non-finite key matrix");
+    for (int i = 0; i < 3; i++) if (!std::isfinite(box_min[i]) || !std::isfinite(box_max[i])) return fail(RSPT_E_INVALID, "non-finite box");
+    if (!std::isfinite(start_time) || !std::isfinite(end_time)) return fail(RSPT_E_INVALID, "non-finite key time");
+    motion::Keys keys;
+    motion::make_keys(start_m, start_time, end_m, end_time, &keys);
+    motion::Box b;
+    for (int i = 0; i < 3; i++) { b.lo[i] = box_min[i]; b.hi[i] = box_max[i]; }
+    bool overflow = false;
+    const motion::Box r = motion::motion_bounds(keys, b, &overflow);
+    if (overflow) return fail(RSPT_E_UNSUPPORTED, "more than eight motion-derivative zeros for one point: the reference's interval_find_zeros indexes past its array here (transform.rs:2346)");
+    for (int i = 0; i < 3; i++) { out_min[i] = r.lo[i]; out_max[i] = r.hi[i]; }
+    if (flags_out) *flags_out = (keys.animated ? 1 : 0) | (keys.has_rotation ? 2 : 0);
     return RSPT_OK;
 }
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {

@@ -16,20 +16,29 @@ EXPORTS = ("rspt_abi_version", "rspt_init", "rspt_shutdown", "rspt_scene_create"
            "rspt_render_device", "rspt_render_samples", "rspt_trace", "rspt_trace_device", "rspt_dev_alloc", "rspt_dev_free",
            "rspt_dev_upload", "rspt_dev_download", "rspt_last_error", "rspt_last_counters", "rspt_bvh_build", "rspt_bvh_last_error",
            "rspt_bvh_build_gpu", "rspt_bvh_build_bounds", "rspt_comm_unique_id", "rspt_comm_init", "rspt_comm_destroy", "rspt_light_distribution", "rspt_libm",
-           "rspt_material_lobes", "rspt_camera_decompose")
+           "rspt_material_lobes", "rspt_camera_decompose", "rspt_motion_bounds", "rspt_source_hash", "rspt_comm_library")
 
 
-def source_hash():
-    """sha256 (first 16 hex digits) over the kernel / ABI sources librspt.so is built from: profiles taken on the GPU box
-    (tools/refresh_profiles.sh) carry it, and bench.py only quotes a PMC traffic figure whose hash matches the tree it runs from"""
+def tree_source_hash():
+    """sha256 (first 16 hex digits) over the kernel / ABI sources under rs_pbrt_amd/csrc + include/rspt.h as they are ON DISK — the recipe
+    of csrc/Makefile's SRC_HASH, which compiles the same digest into librspt.so.  Equal to source_hash() exactly when the library was
+    built from this tree (tests/test_abi.py checks that)."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.cpp"))
-                    + [os.path.join(_HERE, "..", "include", "rspt.h")]):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    names = sorted(os.path.basename(f).encode() for pat in ("*.h", "*.hip", "*.cpp") for f in glob.glob(os.path.join(_HERE, "csrc", pat)))
+    for n in names:
+        h.update(n)
+        h.update(open(os.path.join(_HERE, "csrc", n.decode()), "rb").read())
+    h.update(b"rspt.h")
+    h.update(open(os.path.join(_HERE, "..", "include", "rspt.h"), "rb").read())
     return h.hexdigest()[:16]
+
+
+def source_hash():
+    """The source hash compiled into the librspt.so that is LOADED (rspt_source_hash): profiles taken on the GPU box
+    (tools/refresh_profiles.sh) carry it, and bench.py only quotes a PMC traffic figure whose hash equals the running library's."""
+    return lib().rspt_source_hash().decode()
 
 
 class RsptError(RuntimeError):
@@ -73,6 +82,9 @@ def lib():
         L.rspt_libm.argtypes = [u32, vp, vp, C.c_uint64, vp]
         L.rspt_material_lobes.argtypes = [vp, u32, u32, vp, vp]
         L.rspt_camera_decompose.argtypes = [vp, C.c_float, vp, C.c_float, vp, vp]
+        L.rspt_motion_bounds.argtypes = [vp, C.c_float, vp, C.c_float, vp, vp, vp, vp, vp]
+        L.rspt_source_hash.restype = C.c_char_p
+        L.rspt_comm_library.restype = C.c_char_p
         L.rspt_comm_unique_id.argtypes = [vp]
         L.rspt_comm_init.argtypes = [i32, i32, vp]
         _LIB = L
@@ -96,6 +108,17 @@ def camera_decompose(rd):
     if not animated.value:
         return None
     return trs[:6].reshape(2, 3).copy(), trs[6:14].reshape(2, 4).copy(), trs[14:].reshape(2, 4, 4).copy()
+
+
+def motion_bounds(start_m, start_time, end_m, end_time, box_min, box_max):
+    """AnimatedTransform::motion_bounds (transform.rs:2147-2210) of a box under a moving instance's two keys (rspt_motion_bounds; host only):
+    (lo (3,), hi (3,), actually_animated, has_rotation)"""
+    a = np.ascontiguousarray(start_m, np.float32).reshape(16); b = np.ascontiguousarray(end_m, np.float32).reshape(16)
+    lo = np.ascontiguousarray(box_min, np.float32).reshape(3); hi = np.ascontiguousarray(box_max, np.float32).reshape(3)
+    out_lo, out_hi, flags = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_int32(0)
+    _check(lib().rspt_motion_bounds(a.ctypes.data, float(start_time), b.ctypes.data, float(end_time), lo.ctypes.data, hi.ctypes.data,
+                                    out_lo.ctypes.data, out_hi.ctypes.data, C.addressof(flags)))
+    return out_lo, out_hi, bool(flags.value & 1), bool(flags.value & 2)
 
 
 def material_lobes(scene, material, allow_multiple_lobes=True):
@@ -201,6 +224,15 @@ def comm_init(rank, world, uid):
 
 def comm_destroy():
     lib().rspt_comm_destroy()
+
+
+def comm_library():
+    """the librccl.so rspt_comm_* are bound to (rspt_comm_library): the one the process had mapped already (torch's, where torch was imported
+    first), else $RSPT_RCCL_LIB, else the loader's"""
+    p = lib().rspt_comm_library()
+    if p is None:
+        _check(abi.E_UNSUPPORTED)
+    return p.decode()
 
 
 class DeviceScene:

@@ -489,8 +489,8 @@ class SceneBuilder:
         """pbrt_object_instance (api.rs:3024-3109): TransformedPrimitive(object aggregate, AnimatedTransform(CTM[0], start time, CTM[1], end time)).
         to_world_end: the second key of a MOVING instance (ActiveTransform EndTime ... ObjectInstance); its top-level bounds are then
         AnimatedTransform::motion_bounds — the union of the two keys' bounds when the keys differ by translation / scale only
-        (transform.rs:2147-2160); with a rotation between the keys the reference bounds the motion of every corner (bound_point_motion, :2164-2210),
-        for which this scaffolding takes the corners at 256 times and pads by 5 % of the extent — a test scene's BVH only has to contain the motion"""
+        (transform.rs:2147-2160); with a rotation between the keys the motion of every corner is bounded at the zeros of its velocity
+        (bound_point_motion, :2164-2210) — both by librspt's rspt_motion_bounds (csrc/motion_bounds.h)"""
         assert self.cur_object < 0, "ObjectInstance can't be called inside instance definition"
         self.decl.append(("inst", len(self.instances)))
         self.instances.append((self.objects[name], to_world, to_world_end, (float(time[0]), float(time[1]))))
@@ -768,16 +768,9 @@ class SceneBuilder:
                 if xf_end is not None and not np.array_equal(xf_end.m, xf.m):   # actually_animated (transform.rs:923)
                     instances[k]["animated"] = 1
                     instances[k]["to_world_end"] = xf_end.m.reshape(-1); instances[k]["from_world_end"] = xf_end.m_inv.reshape(-1)
-                    lo2, hi2 = _transform_bounds(xf_end.m, *obj_bound[o])
-                    lo, hi = np.minimum(lo, lo2), np.maximum(hi, hi2)           # motion_bounds without rotation: the union of the keys' bounds
-                    ra, rb = xf.m[:3, :3] / np.linalg.norm(xf.m[:3, :3], axis=0), xf_end.m[:3, :3] / np.linalg.norm(xf_end.m[:3, :3], axis=0)
-                    if not np.allclose(ra, rb, atol=1e-6):                      # a rotation between the keys (see add_instance)
-                        from oracle import pyoracle                             # (test scaffolding: the oracle's AnimatedTransform::interpolate)
-                        for tt in np.linspace(times[0], times[1], 256):
-                            l3, h3 = _transform_bounds(pyoracle.interpolate_transform(xf.m, times[0], xf_end.m, times[1], float(tt)), *obj_bound[o])
-                            lo, hi = np.minimum(lo, l3), np.maximum(hi, h3)
-                        pad = F32(0.05) * (hi - lo)
-                        lo, hi = (lo - pad).astype(F32), (hi + pad).astype(F32)
+                    # AnimatedTransform::motion_bounds (transform.rs:2147-2210): the keys' boxes joined, and with a rotation between the keys
+                    # the corners' paths bounded at the zeros of their velocity — librspt's host function, as the C caller would use it
+                    lo, hi, _, _ = lib.motion_bounds(xf.m, times[0], xf_end.m, times[1], *obj_bound[o])
                 row = np.nonzero(in_inst == k)[0][0]
                 bounds[row, :3], bounds[row, 3:] = lo, hi
             nodes, ordered = lib.bvh_build_bounds(bounds, max_prims_in_node)

@@ -1,10 +1,10 @@
-//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 20) one to one.
+//! src/gpu/ffi.rs — the `extern "C"` block for librspt.so, mirroring include/rspt.h (ABI version 21) one to one.
 //! Uncompiled source for a maintainer (the image this repo is built in has no Rust toolchain); struct layouts are checked
 //! from the C side by tests/test_abi.py, so a mismatch here shows up as a wrong `size_of` against the table in INTEGRATION.md §2.
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RSPT_ABI_VERSION: c_int = 20;
+pub const RSPT_ABI_VERSION: c_int = 21;
 pub const RSPT_MESH_INSTANCE: u32 = 0xffff_ffff;
 pub const RSPT_NO_MATERIAL: u32 = 0xffff_ffff;
 

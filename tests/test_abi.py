@@ -133,3 +133,10 @@ def test_rust_shim_layouts_match_the_header_without_a_rust_compiler():
     assert "ABI version %d" % abi.ABI_VERSION in src.splitlines()[0]
     fns = re.findall(r"pub fn (rspt_\w+)\(", src)
     assert len(fns) >= 15 and all(f in lib.EXPORTS for f in fns), [f for f in fns if f not in lib.EXPORTS]
+
+
+def test_the_loaded_library_was_built_from_this_tree():
+    """profiles/ are tied to the hash the LIBRARY reports (compiled in by csrc/Makefile); a stale librspt.so — it is git-ignored and shipped prebuilt to the GPU
+    box — would report another hash than the sources next to it"""
+    assert lib.source_hash() == lib.tree_source_hash(), "librspt.so is stale: rebuild with make -C rs_pbrt_amd/csrc"
+    assert len(lib.source_hash()) == 16 and int(lib.source_hash(), 16) >= 0
