@@ -58,6 +58,7 @@ struct QueueCounts {  // one per wavefront iteration
     uint32_t overflow_closest, overflow_any; // rays handed to k_trace_fixup; each sits 2 words after its cursor
     uint32_t active_tail;                   // paths that only wait for their last next-event estimate: stored from the END of the
                                             // active queue, so that the waves of k_shade are either all-alive or all-short
+    uint32_t xcd_closest[8], xcd_any[8];    // k_trace_w4's per-XCD fetch cursors (XCD-affine dealing, trace_w4.h); zeroed with the rest
 };
 
 struct Batch {

@@ -541,7 +541,7 @@ uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
 // use the reference-order loop; a scene whose records outgrow the four-box reference fields stays on the two-box kernel.
 template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
 void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
-                    const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
+                    const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters, uint32_t* xcur) {
     const SceneDev& sc = s->dev;
     // RSPT_TRACE_KERNEL: 0 = k_trace (reference-order single-ray loop), 1 = k_trace_pw (persistent waves, two boxes
     // per record), 2 = k_trace_w4 (persistent waves, four boxes per record; default).
@@ -569,10 +569,10 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
     if (ALPHA && s->alpha_simple)   // every mask of the scene is evaluated in line (kernels.h alpha_simple): the traversal keeps its register budget
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 2 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi);
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
     else if (special || (which >= 2 && s->w4_ok))
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 1 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi);
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
     else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
@@ -582,8 +582,10 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
 }
 template <bool ANY, int OUT_MODE>
 void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
-                  const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters) {
-#define RSPT_LT(I, A) launch_trace_v<ANY, OUT_MODE, I, A>(lane, count, grid, s, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, counters)
+                  const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters, uint32_t* xcd_cursors = nullptr) {
+    // XCD-affine dealing (trace_w4.h): on where the caller hands eight zeroed cursor words (the path integrator's loop, the trace hook); RSPT_XCD_DEAL=0 switches it off
+    uint32_t* xcur = (xcd_cursors && env_size("RSPT_XCD_DEAL", 1) != 0) ? xcd_cursors : nullptr;
+#define RSPT_LT(I, A) launch_trace_v<ANY, OUT_MODE, I, A>(lane, count, grid, s, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, counters, xcur)
     if (s->has_instances) { if (s->has_alpha) RSPT_LT(true, true); else RSPT_LT(true, false); }
     else { if (s->has_alpha) RSPT_LT(false, true); else RSPT_LT(false, false); }
 #undef RSPT_LT
@@ -1240,17 +1242,17 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 HIP_TRY(hipEventRecord(ev_fork, g.stream));
                 HIP_TRY(hipStreamWaitEvent(g.stream2, ev_fork, 0));
                 ev_open(1, 1);
-                launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals, g.cnt[it].xcd_any);
                 ev_close(1, 1);
                 HIP_TRY(hipEventRecord(ev_join, g.stream2));
             }
             ev_open(0, 0);
-            launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+            launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals, g.cnt[it].xcd_closest);
             ev_close(0, 0);
             if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
             else if (it > 0) {
                 ev_open(1, 0);
-                launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals, g.cnt[it].xcd_any);
                 ev_close(1, 0);
             }
             HIP_TRY(hipEventRecord(e1, g.stream));
@@ -2536,8 +2538,8 @@ int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* ou
     uint32_t* cursor = &g.cnt[0].cursor_closest;
     for (int r = 0; r < repeat && n; r++) {
         HIP_TRY(hipMemsetAsync(&g.cnt[0], 0, sizeof(QueueCounts), g.stream));
-        if (any_hit) launch_trace<true, 1>(0, counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
-        else launch_trace<false, 1>(0, counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals);
+        if (any_hit) launch_trace<true, 1>(0, counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals, g.cnt[0].xcd_any);
+        else launch_trace<false, 1>(0, counters, trace_grid(), s, nullptr, nullptr, (uint32_t)n, cursor, (const rspt_ray*)rays_dev, (const rspt_ray*)rays_dev, nullptr, nullptr, nullptr, (rspt_hit*)out_dev, g.totals, g.cnt[0].xcd_closest);
     }
     HIP_TRY(hipEventRecord(e1, g.stream));
     HIP_TRY(hipGetLastError());

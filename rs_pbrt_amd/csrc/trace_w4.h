@@ -119,7 +119,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
                                                            rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, uint32_t* __restrict__ overflow_list,
                                                            uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh, uint32_t n_top,
-                                                           uint32_t* __restrict__ out_inst) {
+                                                           uint32_t* __restrict__ out_inst, uint32_t* xcd_cursors) {
     __shared__ uint2 stack[RSPT_W4_LDS * RSPT_PW_BLOCK];
     uint2* my = stack + threadIdx.x;
 #if RSPT_W4_TOP > 0
@@ -152,6 +152,18 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
     const float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
     uint32_t chunk_lo = 0, chunk_hi = 0;  // wave-uniform
     bool exhausted = false;               // wave-uniform
+    // XCD-affine dealing (xcd_cursors != nullptr): the queue is cut into eight contiguous ranges, one per XCD; a wave draws its chunks from the
+    // range of the XCD it runs on (HW_REG_XCC_ID — placement is read, not assumed) and, once that is empty, from the others' in turn.  Neighbouring
+    // queue entries are neighbouring path slots = neighbouring pixels, whose rays walk the same part of the tree: with one cursor the eight XCDs
+    // drain the queue interleaved in 256-ray chunks and every XCD's 4 MB L2 sees the whole tree; with eight, each L2 sees its own region.
+    // Which rays a wave traces changes, nothing about any ray's result does.
+    uint32_t xcc = 0, victim = 0, per_xcd = 0;   // wave-uniform
+    if (xcd_cursors) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcc = id & 7u;
+        per_xcd = (uint32_t)((((uint64_t)n + 8ull * RSPT_PW_CHUNK - 1ull) / (8ull * RSPT_PW_CHUNK)) * RSPT_PW_CHUNK);
+    }
     // per-lane ray state
     bool active = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0;
@@ -191,12 +203,30 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
         const uint64_t idle = __ballot(!active);
         if (!exhausted && (__popcll(idle) >= refill_thresh || ~idle == 0)) {
             if (chunk_lo == chunk_hi) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (uint32_t)RSPT_PW_CHUNK);
-                base = __builtin_amdgcn_readfirstlane(base);
-                chunk_lo = base < n ? base : n;
-                chunk_hi = (base + RSPT_PW_CHUNK) < n ? (base + RSPT_PW_CHUNK) : n;
-                if (chunk_lo == chunk_hi) exhausted = true;
+                if (xcd_cursors) {
+                    for (; victim < 8u; victim++) {
+                        const uint32_t x = (xcc + victim) & 7u;
+                        const uint64_t lo64 = (uint64_t)x * per_xcd, hi64 = lo64 + per_xcd;
+                        const uint32_t lo = lo64 < n ? (uint32_t)lo64 : n, hi = hi64 < n ? (uint32_t)hi64 : n;
+                        if (lo == hi) continue;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(xcd_cursors + x, (uint32_t)RSPT_PW_CHUNK);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base < hi - lo) {
+                            chunk_lo = lo + base;
+                            chunk_hi = (hi - lo - base) > RSPT_PW_CHUNK ? chunk_lo + RSPT_PW_CHUNK : hi;
+                            break;
+                        }
+                    }
+                    if (victim == 8u) exhausted = true;
+                } else {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, (uint32_t)RSPT_PW_CHUNK);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    chunk_lo = base < n ? base : n;
+                    chunk_hi = (base + RSPT_PW_CHUNK) < n ? (base + RSPT_PW_CHUNK) : n;
+                    if (chunk_lo == chunk_hi) exhausted = true;
+                }
             }
             if (!exhausted) {
                 const uint32_t avail = chunk_hi - chunk_lo;

@@ -26,7 +26,7 @@ constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                              
 #define RSPT_TU_SHADE_W(F, W) RSPT_TU_X template __global__ void k_shade_w<F, W>(RSPT_SHADE_ARGS);
 #define RSPT_TU_W4(ANY, OM, I, A) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, I, A>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
-                                                                  const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*);
+                                                                  const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);
 #define RSPT_TU_W4_4(ANY, OM) RSPT_TU_W4(ANY, OM, false, 0) RSPT_TU_W4(ANY, OM, false, 1) RSPT_TU_W4(ANY, OM, true, 0) RSPT_TU_W4(ANY, OM, true, 1)
 #define RSPT_TU_W4_S(ANY, OM) RSPT_TU_W4(ANY, OM, false, 2) RSPT_TU_W4(ANY, OM, true, 2)   /* alpha masks evaluated in line (alpha_simple) */
 #define RSPT_TU_REF(ANY, OM, C, I, A) \
