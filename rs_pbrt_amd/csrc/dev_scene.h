@@ -85,6 +85,8 @@ struct SceneDev {
     const struct InstAnim* inst_anim;   // the keys of the moving instances (inst_at); nullptr = none
     const float* ray_time;              // [path slot] Ray.time of the path's rays (the camera sample's time, perspective.rs:226), set by rspt_render while a
                                         // scene with moving instances is rendered; nullptr = time 0 (rspt_trace)
+    uint32_t time_div;                  // ray slots per entry of ray_time: 1 for path / volpath (a ray's slot is its path's), ao_n_samples for the AO
+                                        // integrator's shadow rays (slot = sample * n + k), nodes per camera sample for directlighting's tree; never 0
 };
 
 // MipMap<Spectrum> pyramid + Distribution2D of one InfiniteAreaLight (mipmap.rs, sampling.rs:150-198)

@@ -50,6 +50,8 @@ struct PathBuf {
     rspt_mat::Built* dyn_built;  // one per thread of the shade launch: where a dynamic material's lobes are built (nullptr: no dynamic material)
     uint32_t dyn_threads;
     float* time;          // Ray.time of the path (perspective.rs:226), kept only while a scene with moving instances is rendered (nullptr otherwise)
+    uint32_t fresh;       // 1 in the path integrator's k_raygen and its FIRST shade launch of a batch: every slot's (L, eta_scale) is (0, 0, 0, 1) and beta (1, 1, 1)
+                          // by construction, so k_raygen does not write the two 16-byte fields and shade_path does not read them (64 of ~1200 bytes per C3 sample)
 };
 
 struct QueueCounts {  // one per wavefront iteration
@@ -137,8 +139,10 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
     rspt_ray r;
     r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z; r.t_max = t_max; r.id = i;
     pb.ray_cont[i] = r;
-    pb.L_eta[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-    pb.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    if (!pb.fresh) {
+        pb.L_eta[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        pb.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    }
     pb.sobol_index[i] = index;
     pb.state[i] = 5u | ST_ALIVE;  // dimensions 0..4 consumed by the camera sample
     pb.p_film[i] = make_float2(p_film.x, p_film.y);
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTabl
         bool mis = (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
-        const float time = (INST && OUT_MODE == 0 && sc.ray_time) ? sc.ray_time[slot] : 0.0f;
+        const float time = (INST && OUT_MODE == 0 && sc.ray_time) ? sc.ray_time[slot / sc.time_div] : 0.0f;
         TraceResult res = traverse<ANY, INST, ALPHA, RSPT_TRACE_BLOCK, ANIM>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x, time);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
@@ -468,7 +472,9 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                           const uint32_t* __restrict__ sob_tab, uint32_t sob_nd, PixSampler* px) {
     ShadeOut out{false, false, false, false};
     uint32_t st = pb.state[p];
-    float4 le = pb.L_eta[p];
+    const bool fresh = !PIX && pb.fresh != 0u;   // the first shade launch of a path-integrator batch (PathBuf::fresh)
+    float4 le = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (!fresh) le = pb.L_eta[p];
     rgb L{le.x, le.y, le.z};
     float eta_scale = le.w;
 
@@ -518,7 +524,8 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
             float4 r0 = rp[0], r1 = rp[1];
             f3 ray_d{r0.w, r1.x, r1.y};
-            float4 bb = pb.beta[p];
+            float4 bb = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            if (!fresh) bb = pb.beta[p];
             rgb beta{bb.x, bb.y, bb.z};
             for (uint32_t i = 0; i < sc.n_infinite; i++) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_lights[i]], ray_d);
         }
@@ -526,7 +533,8 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
         float4 r0 = rp[0], r1 = rp[1];
         f3 ray_d{r0.w, r1.x, r1.y};
-        float4 bb = pb.beta[p];
+        float4 bb = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        if (!fresh) bb = pb.beta[p];
         rgb beta{bb.x, bb.y, bb.z};
         TriRec tri = load_tri(sc, prim);
         Hit h;
@@ -553,6 +561,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             if ((F & SF_NULL) && h.material == 0xffffffffu) {  // null BSDF: pass straight through (path.rs:109-116)
                 f3 o = offset_ray_origin(h.p, h.p_err, h.n, ray_d);
                 store_ray(pb.ray_cont + p, o, ray_d, RSPT_INF, p);
+                if (fresh) pb.beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);   // (k_raygen left it unwritten, and the path goes on)
                 st |= ST_ALIVE | ST_NO_DIFF;
                 out.cont = true;
             } else {

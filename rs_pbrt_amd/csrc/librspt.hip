@@ -553,7 +553,9 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     uint2* spill = g.spill + (lane ? g.spill_threads * RSPT_W4_SPILL : 0);
     uint32_t* hi = (INST && OUT_MODE == 0 && !ANY) ? (g_inst_out ? g_inst_out : g.hit_inst) : nullptr;
     const bool special = INST || ALPHA;
-    const bool slow = count || which == 0 || s->has_animated || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
+    // moving instances: k_trace_w4<.., INST, 0, ANIM> (round 5; RSPT_ANIM_W4=0: the reference-order loop with the interpolation, as before)
+    const bool anim_w4 = s->has_animated && s->w4_ok && which >= 2 && env_size("RSPT_ANIM_W4", 1) != 0 && env_size("RSPT_INSTANCE_KERNEL", 1) != 0;
+    const bool slow = count || which == 0 || (s->has_animated && !anim_w4) || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
     if (slow) {
         if (INST && !ALPHA && s->has_animated)   // moving instances: the reference-order loop with the interpolation (its own instantiation; no node / triangle counters)
             hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, true, false, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
@@ -567,6 +569,14 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
     uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
     const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
+    if constexpr (INST && !ALPHA) {
+        if (anim_w4) {
+            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, true, 0, true>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
+            hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, true, false, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
+            return;
+        }
+    }
     if (ALPHA && s->alpha_simple)   // every mask of the scene is evaluated in line (kernels.h alpha_simple): the traversal keeps its register budget
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 2 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
                            ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
@@ -973,6 +983,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
     g.pb.time = s->has_animated ? g.path_time : nullptr;
     s->dev.ray_time = g.pb.time;
+    s->dev.time_div = 1u;
+    g.pb.fresh = 0u;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
     g.vol.hit_inst_tr = (volpath && s->has_instances) ? g.hit_inst + g.cap : nullptr;
     if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
@@ -1278,6 +1290,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active,
                                    tex_sorted ? g.q_sorted : (const uint32_t*)nullptr, tex_sorted ? &g.bin_info[it] : (const BinInfo*)nullptr);
             }
+            if (it > 0) g.pb.fresh = 0u;   // (PathBuf travels by value: the first launch of the batch has carried the flag k_raygen ran with)
             hipLaunchKernelGGL(shade_k, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
                                bins_now ? g.q_sorted : (const uint32_t*)nullptr, bins_now ? &g.bin_info[it] : (const BinInfo*)nullptr);
@@ -1455,6 +1468,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             samples += bt.n;
             HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));
             if (shade_bins) HIP_TRY(hipMemsetAsync(g.bin_info, 0, (size_t)std::min<uint32_t>(g.n_bin_info, max_iters + 10) * sizeof(BinInfo), g.stream));
+            // the path integrator's first shade launch knows what k_raygen would have written into L_eta / beta (PathBuf::fresh); RSPT_FRESH=0: written and read as before
+            const bool fresh_ok = !volpath && !direct && !ao && env_size("RSPT_FRESH", 1) != 0;
+            g.pb.fresh = fresh_ok ? 1u : 0u;
             hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
             g_queue_hint = 0xffffffffu;
@@ -1464,6 +1480,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 if (rc == RSPT_DL_RETRY_LANE) {   // from here on the per-lane form serves this render; this batch starts over
                     dl_lane = true;
                     HIP_TRY(hipMemsetAsync(g.cnt, 0, (size_t)g.n_cnt * sizeof(QueueCounts), g.stream));
+                    g.pb.fresh = 0u;
                     hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
                     rc = batch_direct_lane(bt, it);
                 }
@@ -1952,6 +1969,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
     }
     HIP_TRY(hipSetDevice(g.device));
     rspt_scene_s* s = new rspt_scene_s();
+    s->dev.time_div = 1u;
     s->has_null_material = has_null || (instanced && d->instancing_mode == RSPT_INSTANCING_REFERENCE);  // instanced hits pass through like null surfaces (Q11)
     s->has_instances = instanced;
     s->has_alpha = any_alpha;
@@ -2393,7 +2411,7 @@ namespace {
 int render_entry(rspt_scene_t s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     rc_.status_exchanged = false;
     const int rc = (!film_host && !film_dev && !li_host) ? fail(RSPT_E_INVALID, "null output buffer") : render_impl(s, d, film_host, film_dev, li_host, stats);
-    if (s && g.inited) s->dev.ray_time = nullptr;   // the per-path times belong to the render that just ended (the buffer is the library's, not the scene's)
+    if (s && g.inited) { s->dev.ray_time = nullptr; s->dev.time_div = 1u; }   // the per-path times belong to the render that just ended (the buffer is the library's, not the scene's)
     if (rc != RSPT_OK && d && d->film_reduce && rc_.comm && g.inited && !rc_.status_exchanged) {
         const std::string kept = rspt_last_error();
         int32_t all = 0;

@@ -112,7 +112,10 @@ RDEVN bool box_hit6_m(float lx, float ly, float lz, float hx, float hy, float hz
 // traverse<>).  Without INST the code is the one measured in DESIGN.md (the flag is a template parameter, not a branch).
 // ALPHA (scenes with alpha-masked meshes): a candidate that passed the watertight test on such a mesh is checked by alpha_pass
 // (kernels.h) before it counts — a call into the texture code, which is why this too is a template flag.
-template <bool ANY, int OUT_MODE, bool INST, int ALPHA /* 0: no masks, 1: alpha_pass (any texture graph, a call), 2: alpha_simple (in line) */>
+// ANIM (with INST): some instances move (AnimatedTransform primitive_to_world, primitive.rs:198-222): entering such an instance interpolates its Transform at the
+// ray's time (dev_scene.h inst_at — two key decompositions blended, a 4x4 inverse: ~100 live values for a moment), so it is its own instantiation and every
+// other instanced scene keeps the register budget it was measured with.
+template <bool ANY, int OUT_MODE, bool INST, int ALPHA /* 0: no masks, 1: alpha_pass (any texture graph, a call), 2: alpha_simple (in line) */, bool ANIM = false>
 __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
     // entry, BVHAccel::intersect's `hit` flag of the top-level aggregate, "the object reported a hit"
     uint32_t inst = RSPT_NONE, sp_base = 0, best_inst = 0;
     float w_tmax = 0.0f;
-    bool hitflag = false, inst_hit = false;
+    bool hitflag = false, inst_hit = false, inst_ident = false;   // inst_ident: Transform::is_identity of the Transform the instance was entered with
 
     auto finish = [&]() {
         uint32_t slot = entry & ~RSPT_Q_MIS;
@@ -275,8 +278,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                 for (int tries = 0; tries < RSPT_W4_POP_TRIES; tries++) {
                     if (sp == sp_base) {
                         if (INST && inst != RSPT_NONE) {  // the object's traversal is over: back to world space (primitive.rs:224-253)
-                            const InstDev& in = sc.inst[inst];
-                            if (inst_hit) { if (sc.inst_fixed || !in.identity) hitflag = true; }
+                            if (inst_hit) { if (sc.inst_fixed || !inst_ident) hitflag = true; }
                             else t_max = w_tmax;
                             const float4* rp = reinterpret_cast<const float4*>(((entry & RSPT_Q_MIS) ? rays_b : rays_a) + (entry & ~RSPT_Q_MIS));
                             const float4 r0 = rp[0], r1 = rp[1];
@@ -416,7 +418,16 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                             const float4 r0 = rp[0], r1 = rp[1];
                             f3 no, nd;
                             w_tmax = t_max; sp_base = sp; inst_hit = false;
-                            inst_ray(in, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, t_max, &no, &nd, &t_max);
+                            if (ANIM && in.anim != RSPT_MISS) {   // primitive_to_world.interpolate(r.time) and its inverse (primitive.rs:218-222)
+                                const uint32_t slot = entry & ~RSPT_Q_MIS;
+                                const float time = (OUT_MODE == 0 && sc.ray_time) ? sc.ray_time[slot / sc.time_div] : 0.0f;
+                                const InstDev at = inst_at(sc, inst, time);
+                                inst_ident = at.identity != 0u;
+                                inst_ray(at, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, t_max, &no, &nd, &t_max);
+                            } else {
+                                inst_ident = in.identity != 0u;
+                                inst_ray(in, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, t_max, &no, &nd, &t_max);
+                            }
                             ox = no.x; oy = no.y; oz = no.z;
                             ix = 1.0f / nd.x; iy = 1.0f / nd.y; iz = 1.0f / nd.z;
                             negbits = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_pw(SceneDev sc, const P
 // Second pass for the rays whose stack outgrew the persistent kernel's LDS column (their queue entries
 // were appended to overflow_list): the 64-entry reference-order loop (kernels.h traverse<>).
 // Returns at once when no ray overflowed (the common case).
-template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
+template <bool ANY, int OUT_MODE, bool INST, bool ALPHA, bool ANIM = false>
 __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, TexTables tt, const uint32_t* __restrict__ n_overflow, const uint32_t* __restrict__ overflow_list,
                                                                   const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                                   float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace_fixup(SceneDev sc, T
         const bool mis = OUT_MODE == 0 && (e & RSPT_Q_MIS) != 0;
         const float4* rp = reinterpret_cast<const float4*>((mis ? rays_b : rays_a) + slot);
         float4 r0 = rp[0], r1 = rp[1];
-        TraceResult res = traverse<ANY, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x);
+        const float time = (ANIM && OUT_MODE == 0 && sc.ray_time) ? sc.ray_time[slot / sc.time_div] : 0.0f;
+        TraceResult res = traverse<ANY, INST, ALPHA, RSPT_TRACE_BLOCK, ANIM>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, stack + threadIdx.x, time);
         if (OUT_MODE == 0) {
             if (ANY) out_occ[slot] = res.prim != RSPT_MISS ? 1u : 0u;
             else {

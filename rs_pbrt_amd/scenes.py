@@ -1439,12 +1439,13 @@ def _tree_mesh(grid_u=100, grid_v=50, seed=0x7EE):
     return P.astype(F32), idx.astype(np.uint32), T.astype(F32), ti.astype(np.uint32)
 
 
-def landscape_standin(bvh_builder, n_side=64, terrain=256, seed=0x1A9D, instancing="reference", tree_grid=(100, 50)):
+def landscape_standin(bvh_builder, n_side=64, terrain=256, seed=0x1A9D, instancing="reference", tree_grid=(100, 50), moving=False):
     """C5 stand-in for the off-tree Landscape cover scene: n_side^2 ObjectInstances (4096 at 64) of one ~10 k-triangle
     tree object (canopy + trunk, two materials) with per-instance rotation about y, non-uniform scale and translation onto a
     terrain^2-cell height field, under a 64 x 32 lat-long sky with a sun texel (InfiniteAreaLight, importance sampled).
     DECLARED STAND-IN: not the real asset.  instancing: "reference" = rs_pbrt v0.9.12's behaviour (instanced hits carry no
-    material: the trees are invisible to camera / bounce rays and cast shadows, Q11) | "fixed"."""
+    material: the trees are invisible to camera / bounce rays and cast shadows, Q11) | "fixed".  moving: every instance is a MOVING TransformedPrimitive
+    (two keys over the shutter interval 0 .. 1; the render desc then wants shutter=(0, 1))."""
     rng = np.random.default_rng(seed)
     sb = SceneBuilder()
     leaf = sb.add_material(matte((0.12, 0.35, 0.1)))
@@ -1471,7 +1472,12 @@ def landscape_standin(bvh_builder, n_side=64, terrain=256, seed=0x1A9D, instanci
             y = float(H[min(int(fz), terrain), min(int(fx), terrain)]) - 0.05
             s_ = float(rng.uniform(0.7, 1.3))
             xf = Transform.translate((x, y, z)) * Transform.rotate_y(float(rng.uniform(0, 360))) * Transform.scale(s_, s_ * float(rng.uniform(0.8, 1.4)), s_)
-            sb.add_instance("tree", xf)
+            if moving:   # every tree sways over the shutter: the end key is turned 6 degrees about its own axis and shifted by a hand's width — keys that differ by a
+                # rotation, so the top-level box of every instance is AnimatedTransform::motion_bounds' per-corner form (rspt_motion_bounds)
+                xf_end = Transform.translate((0.1 * s_, 0.0, 0.05 * s_)) * xf * Transform.rotate_y(6.0)
+                sb.add_instance("tree", xf, xf_end)
+            else:
+                sb.add_instance("tree", xf)
     sky = np.zeros((32, 64, 3), F32)
     t = np.linspace(0, 1, 32)[:, None]
     sky[..., 0] = 0.25 + 0.35 * t; sky[..., 1] = 0.4 + 0.3 * t; sky[..., 2] = 0.75 + 0.1 * t

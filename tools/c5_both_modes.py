@@ -22,3 +22,21 @@ for mode, flag in (("fixed", abi.INSTANCING_FIXED), ("reference", abi.INSTANCING
             best = max(best, st["samples"] / st["t_render_s"] / 1e6)
         print("c5 stand-in, instancing %-9s: %.1f Msamples/s (best of %d; closest-hit launches %.3f s, shadow-ray launches %.3f s, shade %.3f s, truncated paths %d)" % (
             mode, best, steps, st["t_trace_closest_s"], st["t_trace_any_s"], st["t_shade_s"], st["truncated_paths"]), flush=True)
+
+# round 5: every tree a MOVING instance (two keys that differ by a rotation; top-level boxes from rspt_motion_bounds): through k_trace_w4<INST, ANIM>
+# (RSPT_ANIM_W4=1, default) and through the reference-order loop with the interpolation that served such scenes until round 4 (RSPT_ANIM_W4=0)
+if os.environ.get("C5_MOVING", "1") != "0":
+    t0 = time.time()
+    scm = scenes.landscape_standin(lib.bvh_build_gpu, instancing="fixed", moving=True)
+    print("moving scene build %.1f s (%d instances, each with two keys)" % (time.time() - t0, len(scm.instances)), flush=True)
+    for w4 in ("1", "0"):
+        os.environ["RSPT_ANIM_W4"] = w4
+        with lib.DeviceScene(scm) as ds:
+            lib.render(ds, rd)
+            best = 0.0
+            for _ in range(steps):
+                film, st = lib.render(ds, rd)
+                best = max(best, st["samples"] / st["t_render_s"] / 1e6)
+            print("c5 stand-in, every instance moving, %s: %.1f Msamples/s (best of %d; closest-hit launches %.3f s, shadow-ray launches %.3f s, shade %.3f s)" % (
+                "k_trace_w4<INST, ANIM>       " if w4 == "1" else "reference-order k_trace<ANIM>", best, steps, st["t_trace_closest_s"], st["t_trace_any_s"], st["t_shade_s"]), flush=True)
+    os.environ.pop("RSPT_ANIM_W4", None)
