@@ -577,6 +577,27 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
             return;
         }
     }
+    if constexpr (!INST && !ALPHA) {
+        // RSPT_W4_SHAPE: 0 = five 256-thread workgroups per CU, 56 root-side records in LDS each; 1 = ONE 1024-thread workgroup per CU with 512 records;
+        // 2 = two 512-thread workgroups with 256 records each (trace_w4.h BLOCK / TOPCAP; dynamic LDS, 152 KB per CU either way)
+        const size_t shape = which >= 2 && s->w4_ok ? env_size("RSPT_W4_SHAPE", RSPT_W4_SHAPE_DEFAULT) : 0;
+        if (shape == 1 || shape == 2) {
+            auto go = [&](auto kern, uint32_t block, uint32_t topcap, uint32_t per_cu) {
+                const size_t lds = (size_t)8 * RSPT_W4_LDS * block + (size_t)112 * topcap;
+                static bool attr_set[2][2][2][3] = {};
+                bool& done = attr_set[ANY ? 1 : 0][OUT_MODE ? 1 : 0][0][shape];
+                if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+                const uint32_t bgrid = hinted_grid(grid_for(per_cu), block);
+                hipLaunchKernelGGL(kern, dim3(bgrid), dim3(block), lds, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
+            };
+            if (shape == 1) go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 1024, 512>, 1024u, 512u, 1u);
+            else go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 512, 256>, 512u, 256u, 2u);
+            if (trace_can_overflow(s))
+                hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
+            return;
+        }
+    }
     if (ALPHA && s->alpha_simple)   // every mask of the scene is evaluated in line (kernels.h alpha_simple): the traversal keeps its register budget
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 2 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
                            ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
@@ -593,8 +614,10 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
 template <bool ANY, int OUT_MODE>
 void launch_trace(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                   const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters, uint32_t* xcd_cursors = nullptr) {
-    // XCD-affine dealing (trace_w4.h): on where the caller hands eight zeroed cursor words (the path integrator's loop, the trace hook); RSPT_XCD_DEAL=0 switches it off
-    uint32_t* xcur = (xcd_cursors && env_size("RSPT_XCD_DEAL", 1) != 0) ? xcd_cursors : nullptr;
+    // XCD-affine dealing (trace_w4.h), RSPT_XCD_DEAL=1: available where the caller hands eight zeroed cursor words (the path integrator's loop, the trace hook).
+    // OFF by default: measured neutral to slightly negative (C2 474.0 -> 471.5 Msamples/s, C3 stand-in 2015.6 -> 2014.7; L2 hit rate of the closest-hit
+    // launches 0.624 -> 0.620 by TCC_HIT / TCC_MISS — profiles/r05_xcd_affine_ab.txt): the tree's L2 hits are its root side, which every XCD holds anyway
+    uint32_t* xcur = (xcd_cursors && env_size("RSPT_XCD_DEAL", 0) != 0) ? xcd_cursors : nullptr;
 #define RSPT_LT(I, A) launch_trace_v<ANY, OUT_MODE, I, A>(lane, count, grid, s, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, counters, xcur)
     if (s->has_instances) { if (s->has_alpha) RSPT_LT(true, true); else RSPT_LT(true, false); }
     else { if (s->has_alpha) RSPT_LT(false, true); else RSPT_LT(false, false); }
@@ -2227,13 +2250,13 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             s->w4_root = leaf_ref(0);
         } else {
             build_tree(0u, local, axes);
-            // Renumber: a breadth-first prefix of RSPT_W4_TOP records goes first (k_trace_w4 keeps those in LDS), the others
-            // keep their depth-first order.
+            // Renumber: a breadth-first prefix of RSPT_W4_TOP_MAX records goes first (k_trace_w4 keeps its first TOPCAP in LDS: any prefix of a
+            // breadth-first order is one), the others keep their depth-first order.
             std::vector<uint32_t> new_of(local.size(), RSPT_NONE), order(1, 0u);
-            for (size_t h = 0; h < order.size() && order.size() < RSPT_W4_TOP; h++)
+            for (size_t h = 0; h < order.size() && order.size() < RSPT_W4_TOP_MAX; h++)
                 for (int k = 0; k < 4; k++) {
                     const uint32_t r = local[order[h]].ref[k];
-                    if (r != RSPT_NONE && !(r & RSPT_REF_LEAF) && order.size() < RSPT_W4_TOP) order.push_back(r);
+                    if (r != RSPT_NONE && !(r & RSPT_REF_LEAF) && order.size() < RSPT_W4_TOP_MAX) order.push_back(r);
                 }
             for (size_t i = 0; i < order.size(); i++) new_of[order[i]] = (uint32_t)i;
             uint32_t next_index = (uint32_t)order.size();

@@ -52,6 +52,10 @@ struct Wide4Node {      // 128 B, 128-byte aligned
                              //  six waves per SIMD forced with amdgpu_waves_per_eu (80 VGPRs, 13 spilled) and (10, 56): 366 / 1141)
 #endif
 static_assert(2048 * RSPT_W4_LDS + 112 * RSPT_W4_TOP <= 64 * 1024, "k_trace_w4 LDS budget (64 KB per workgroup)");
+#define RSPT_W4_TOP_MAX 512  // the breadth-first prefix rspt_scene_create numbers first: the largest TOPCAP any instantiation keeps in LDS
+#ifndef RSPT_W4_SHAPE_DEFAULT
+#define RSPT_W4_SHAPE_DEFAULT 0
+#endif
 #ifndef RSPT_W4_POP_TRIES
 #define RSPT_W4_POP_TRIES 1  // stack entries a lane may discard (t_min >= t_max) in one iteration before it gives up the slot
 #endif
@@ -115,30 +119,45 @@ RDEVN bool box_hit6_m(float lx, float ly, float lz, float hx, float hy, float hz
 // ANIM (with INST): some instances move (AnimatedTransform primitive_to_world, primitive.rs:198-222): entering such an instance interpolates its Transform at the
 // ray's time (dev_scene.h inst_at — two key decompositions blended, a 4x4 inverse: ~100 live values for a moment), so it is its own instantiation and every
 // other instanced scene keeps the register budget it was measured with.
-template <bool ANY, int OUT_MODE, bool INST, int ALPHA /* 0: no masks, 1: alpha_pass (any texture graph, a call), 2: alpha_simple (in line) */, bool ANIM = false>
-__global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
+// BLOCK / TOPCAP (round 5): threads per workgroup and the number of root-side records a workgroup keeps in LDS.  The measured default is five 256-thread
+// workgroups per CU with 56 records each (30 KB); ONE 1024-thread workgroup per CU has room for 512 (96 KB of stack columns + 56 KB of records = the CU's
+// 160 KB, declared as dynamic LDS): a ninth of the record fetches of an incoherent ray come from the first 56 records, about a quarter from the first 512 —
+// fetches that leave the L1 request path the kernel is bound by.
+template <bool ANY, int OUT_MODE, bool INST, int ALPHA /* 0: no masks, 1: alpha_pass (any texture graph, a call), 2: alpha_simple (in line) */, bool ANIM = false,
+          int BLOCK = RSPT_PW_BLOCK, int TOPCAP = RSPT_W4_TOP>
+__global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
                                                            rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, uint32_t* __restrict__ overflow_list,
                                                            uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh, uint32_t n_top,
                                                            uint32_t* __restrict__ out_inst, uint32_t* xcd_cursors) {
-    __shared__ uint2 stack[RSPT_W4_LDS * RSPT_PW_BLOCK];
-    uint2* my = stack + threadIdx.x;
-#if RSPT_W4_TOP > 0
-    __shared__ float4 top[7 * RSPT_W4_TOP];  // top[j * RSPT_W4_TOP + r] = j-th 16 bytes of record r (neighbouring records in neighbouring banks)
-    for (uint32_t i = threadIdx.x; i < 7u * n_top; i += RSPT_PW_BLOCK) {
-        const uint32_t r = i / 7u, j = i - 7u * r;
-        top[j * RSPT_W4_TOP + r] = reinterpret_cast<const float4*>(recs + r)[j];
+    uint2* stack;
+    float4* top;   // top[j * TOPCAP + r] = j-th 16 bytes of record r (neighbouring records in neighbouring banks)
+    if constexpr (8 * RSPT_W4_LDS * BLOCK + 112 * TOPCAP <= 64 * 1024) {   // the static form (the kernels measured since round 2 keep their code)
+        __shared__ uint2 stack_s[RSPT_W4_LDS * BLOCK];
+        __shared__ float4 top_s[7 * (TOPCAP > 0 ? TOPCAP : 1)];
+        stack = stack_s; top = top_s;
+    } else {
+        extern __shared__ uint4 w4_dyn_lds[];
+        stack = reinterpret_cast<uint2*>(w4_dyn_lds);
+        top = reinterpret_cast<float4*>(stack + RSPT_W4_LDS * BLOCK);
     }
-    __syncthreads();
-#endif
+    uint2* my = stack + threadIdx.x;
+    if (n_top > (uint32_t)TOPCAP) n_top = (uint32_t)TOPCAP;   // (the scene numbers a longer breadth-first prefix first than the small form keeps)
+    if constexpr (TOPCAP > 0) {
+        for (uint32_t i = threadIdx.x; i < 7u * n_top; i += BLOCK) {
+            const uint32_t r = i / 7u, j = i - 7u * r;
+            top[j * TOPCAP + r] = reinterpret_cast<const float4*>(recs + r)[j];
+        }
+        __syncthreads();
+    }
     // rows RSPT_W4_LDS .. RSPT_W4_LDS + RSPT_W4_SPILL - 1 of a lane's stack live in global memory (row-major over all threads of the grid)
-    const size_t spill_stride = (size_t)gridDim.x * RSPT_PW_BLOCK;
-    uint2* my_spill = spill + (size_t)blockIdx.x * RSPT_PW_BLOCK + threadIdx.x;
+    const size_t spill_stride = (size_t)gridDim.x * BLOCK;
+    uint2* my_spill = spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     if (sc.n_nodes == 0) {  // empty scene: every ray misses
-        for (uint32_t i = blockIdx.x * RSPT_PW_BLOCK + threadIdx.x; i < n; i += gridDim.x * RSPT_PW_BLOCK) {
+        for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
             uint32_t e = queue ? queue[i] : i, slot = e & ~RSPT_Q_MIS;
             if (OUT_MODE == 0) {
                 if (ANY) out_occ[slot] = 0u;
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                     }
                     sp--;
                     // two separate accesses (never one pointer select: that becomes a flat load with full waitcnt drains)
-                    uint2 e = my[(sp < RSPT_W4_LDS ? sp : RSPT_W4_LDS - 1u) * RSPT_PW_BLOCK];
+                    uint2 e = my[(sp < RSPT_W4_LDS ? sp : RSPT_W4_LDS - 1u) * BLOCK];
                     asm volatile("" : "+v"(e.x), "+v"(e.y));  // pins the LDS read: without it the two accesses are merged into flat loads again
                     if (sp >= RSPT_W4_LDS) e = my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride];
                     if (__uint_as_float(e.y) < t_max) {  // the reference's box test at this later moment (bvh.rs:424)
@@ -308,17 +327,14 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
             }
             if (ridx != RSPT_NONE) {
                 float4 a0, a1, a2, a3, a4, a5, rf;
-#if RSPT_W4_TOP > 0
-                if (ridx < n_top) {
+                if (TOPCAP > 0 && ridx < n_top) {
                     const float4* lp = top + ridx;
-                    a0 = lp[0]; a1 = lp[RSPT_W4_TOP]; a2 = lp[2 * RSPT_W4_TOP]; a3 = lp[3 * RSPT_W4_TOP];
-                    a4 = lp[4 * RSPT_W4_TOP]; a5 = lp[5 * RSPT_W4_TOP]; rf = lp[6 * RSPT_W4_TOP];
+                    a0 = lp[0]; a1 = lp[TOPCAP]; a2 = lp[2 * TOPCAP]; a3 = lp[3 * TOPCAP];
+                    a4 = lp[4 * TOPCAP]; a5 = lp[5 * TOPCAP]; rf = lp[6 * TOPCAP];
                     // keeps the two branches from being merged into one set of flat loads through a selected pointer
                     // (flat loads of LDS drain every counter and were 2.6x slower)
                     asm volatile("" : "+v"(rf.w));
-                } else
-#endif
-                {
+                } else {
                     const float4* pp = reinterpret_cast<const float4*>(recs + ridx);
                     a0 = pp[0]; a1 = pp[1]; a2 = pp[2]; a3 = pp[3]; a4 = pp[4]; a5 = pp[5]; rf = pp[6];
                 }
@@ -352,9 +368,9 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                 uint32_t next = v0 ? e0 : (v1 ? e1 : (v2 ? e2 : e3));
                 const bool push3 = v3 && p3, push2 = v2 && p2, push1 = v1 && p1;
                 if (sp <= RSPT_W4_LDS - 3) {  // the common case: everything fits the LDS column
-                    if (push3) { my[sp * RSPT_PW_BLOCK] = make_uint2(e3, __float_as_uint(me3)); sp++; }
-                    if (push2) { my[sp * RSPT_PW_BLOCK] = make_uint2(e2, __float_as_uint(me2)); sp++; }
-                    if (push1) { my[sp * RSPT_PW_BLOCK] = make_uint2(e1, __float_as_uint(me1)); sp++; }
+                    if (push3) { my[sp * BLOCK] = make_uint2(e3, __float_as_uint(me3)); sp++; }
+                    if (push2) { my[sp * BLOCK] = make_uint2(e2, __float_as_uint(me2)); sp++; }
+                    if (push1) { my[sp * BLOCK] = make_uint2(e1, __float_as_uint(me1)); sp++; }
                 } else if (sp + (push3 ? 1u : 0u) + (push2 ? 1u : 0u) + (push1 ? 1u : 0u) > RSPT_W4_LDS + spill_rows) {
                     best = RSPT_RETRACE;  // deeper than LDS column + spill rows: k_trace_fixup redoes this ray
                     overflow_list[atomicAdd(n_overflow, 1u)] = OUT_MODE == 0 ? entry : qpos;
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                 } else {
                     auto push = [&](uint32_t ref, float m) {
                         if (sp < RSPT_W4_LDS) {
-                            my[sp * RSPT_PW_BLOCK] = make_uint2(ref, __float_as_uint(m));
+                            my[sp * BLOCK] = make_uint2(ref, __float_as_uint(m));
                             asm volatile("");  // keeps the LDS store and the global store apart (no flat store through a selected pointer)
                         } else
                             my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride] = make_uint2(ref, __float_as_uint(m));
@@ -406,7 +422,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4(SceneDev sc, TexTabl
                                     break;
                                 }
                                 if (sp < RSPT_W4_LDS) {
-                                    my[sp * RSPT_PW_BLOCK] = make_uint2(cont, 0xff800000u);
+                                    my[sp * BLOCK] = make_uint2(cont, 0xff800000u);
                                     asm volatile("");
                                 } else
                                     my_spill[(size_t)(sp - RSPT_W4_LDS) * spill_stride] = make_uint2(cont, 0xff800000u);

@@ -31,6 +31,9 @@ constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                              
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, true, 0, true>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
                                                                            const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*); \
     RSPT_TU_X template __global__ void k_trace_fixup<ANY, OM, true, false, true>(SceneDev, TexTables, const uint32_t*, const uint32_t*, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*);   /* moving instances */
+#define RSPT_TU_W4B(ANY, OM, B, T) \
+    RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, false, 0, false, B, T>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
+                                                                                   const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);   /* big workgroups, big LDS top */
 #define RSPT_TU_W4_4(ANY, OM) RSPT_TU_W4(ANY, OM, false, 0) RSPT_TU_W4(ANY, OM, false, 1) RSPT_TU_W4(ANY, OM, true, 0) RSPT_TU_W4(ANY, OM, true, 1)
 #define RSPT_TU_W4_S(ANY, OM) RSPT_TU_W4(ANY, OM, false, 2) RSPT_TU_W4(ANY, OM, true, 2)   /* alpha masks evaluated in line (alpha_simple) */
 #define RSPT_TU_REF(ANY, OM, C, I, A) \
@@ -105,6 +108,10 @@ RSPT_TU_W4_S(false, 0) RSPT_TU_W4_S(false, 1) RSPT_TU_W4_S(true, 0) RSPT_TU_W4_S
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4A)
 RSPT_TU_W4A(false, 0) RSPT_TU_W4A(false, 1) RSPT_TU_W4A(true, 0) RSPT_TU_W4A(true, 1)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4B)
+RSPT_TU_W4B(false, 0, 1024, 512) RSPT_TU_W4B(false, 1, 1024, 512) RSPT_TU_W4B(true, 0, 1024, 512) RSPT_TU_W4B(true, 1, 1024, 512)
+RSPT_TU_W4B(false, 0, 512, 256) RSPT_TU_W4B(false, 1, 512, 256) RSPT_TU_W4B(true, 0, 512, 256) RSPT_TU_W4B(true, 1, 512, 256)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_REF)
 RSPT_TU_REF8(false, 0) RSPT_TU_REF8(false, 1) RSPT_TU_REF8(true, 0) RSPT_TU_REF8(true, 1)
