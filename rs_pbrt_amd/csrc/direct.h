@@ -351,6 +351,202 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_resolve(SceneDev sc, Path
     }
 }
 
+// ---- round 5: ALL light estimates of a node in ONE round ---------------------------------------------------------------------------------------
+// uniform_sample_all_lights (integrator.rs:300-357) makes R = sum_j n_j estimates per shading node.  The round-per-estimate form above launches
+// (k_dl_nee, two traces, k_dl_nee_resolve) R times per tree level and rebuilds the node's interaction in each — on the C3 stand-in (six light triangles)
+// k_dl_nee alone was 48 % of the step.  Here the interaction is built once, estimate r of node slot n lives in the VIRTUAL slot v = n * R + r of the ray /
+// result arrays (ray_sh, ray_mis, occluded, hit_mis, nee_c1, nee_c2, nflags: the trace kernels index by queue entry, so nothing changes for them), one
+// any-hit launch and one closest-hit launch serve all of them, and k_dl_nee_resolve_all adds them in the reference's order (`ld += ..` over a light's
+// elements, `l += ld / n`).  Same operations on the same values as the rounds: bit-identical radiance; the batch shrinks by R.
+
+// the (u_light, u_scatter, light, choice pdf) of estimate (j, kk) of a node — the sample-value part of k_dl_nee, unchanged
+RDEV bool dl_estimate_samples(const RenderDev& rd, const Batch& bt, const PathBuf& pb, const DlBuf& dl, const uint32_t* __restrict__ pix_list, uint32_t slot, uint32_t nl,
+                              uint32_t j, uint32_t kk, uint32_t n_j, uint32_t n_arrays, uint32_t sample_all, f2* u_light, f2* u_scatter, uint32_t* light_num, float* choice_pdf) {
+    const uint32_t s = slot / dl.H;
+    const uint64_t index = pb.sobol_index[s];
+    *light_num = j; *choice_pdf = 1.0f;
+    if (sample_all) {
+        const uint32_t pair = dl.kidx[slot] * nl + j;
+        if (pair < n_arrays / 2u) {
+            const uint32_t pk = pix_list[bt.pix0 + s / bt.ns];
+            const int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
+            const uint64_t elem = (uint64_t)(bt.s0 + s % bt.ns) * n_j + kk;
+            const uint64_t ei = rd.sampler_kind == RSPT_SAMPLER_HALTON ? halton_index(rd, px, py, elem)
+                                                                      : sobol_interval_to_index(rd, (uint32_t)rd.log2_res, elem, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+            *u_light = dl_dims(rd, ei, 5u + 4u * pair);
+            *u_scatter = dl_dims(rd, ei, 5u + 4u * pair + 2u);
+            return true;
+        }
+        if (kk != 0u) return false;
+        const uint32_t pairs = n_arrays / 2u, first = dl.kidx[slot] * nl;
+        const uint32_t j0 = first >= pairs ? 0u : pairs - first;
+        const uint32_t d = dl.dim[slot] + 4u * (j - j0);
+        *u_light = dl_dims(rd, index, d); *u_scatter = dl_dims(rd, index, d + 2u);
+        return true;
+    }
+    const uint32_t d = dl.dim[slot];
+    const float u1 = rd.sampler_kind == RSPT_SAMPLER_HALTON ? halton_dim(rd, index, d) : sobol_dim(rd, index, d);
+    const uint32_t pick = (uint32_t)(u1 * (float)nl);
+    *light_num = pick < nl - 1u ? pick : nl - 1u;
+    *choice_pdf = 1.0f / (float)nl;
+    *u_light = dl_dims(rd, index, d + 1u); *u_scatter = dl_dims(rd, index, d + 3u);
+    return true;
+}
+
+// estimate_direct (integrator.rs:406-570) of one light for a built interaction; rays and terms go to virtual slot v.  Returns the DLF_* flags | 0x100.
+RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d, uint32_t light_num, float choice_pdf, f2 u_light, f2 u_scatter, uint32_t v, bool* want_sh, bool* want_mis) {
+    const Hit& h = d.h;
+    uint32_t fl = 0;
+    const uint32_t flags = BX_ALL & ~BX_SPEC;
+    const rspt_light lt = sc.lights[light_num];
+    rgb c1 = mkrgb(0.0f), c2 = mkrgb(0.0f);
+    f3 wi{0.0f, 0.0f, 0.0f};
+    float light_pdf = 0.0f, scattering_pdf = 0.0f;
+    LightSample ls;
+    const rgb li = light_sample_li(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
+    if (light_pdf > 0.0f && !is_black(li)) {
+        const rgb f = d.bsdf.f(d.wo, wi, flags) * mkrgb(absdot(wi, h.sh_n));
+        scattering_pdf = d.bsdf.pdf(d.wo, wi, flags);
+        if (!is_black(f)) {
+            const f3 origin = offset_ray_origin(h.p, h.p_err, h.n, ls.p - h.p);
+            const f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
+            store_ray(pb.ray_sh + v, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, v);
+            *want_sh = true;
+            if (light_is_delta(lt)) c1 = f * li / light_pdf;
+            else c1 = f * li * mkrgb(power_heuristic(light_pdf, scattering_pdf)) / light_pdf;
+            fl |= DLF_HAS_C1;
+        }
+    }
+    if (!light_is_delta(lt)) {
+        uint32_t sampled_type = 0;
+        rgb f = d.bsdf.sample_f(d.wo, &wi, u_scatter, &scattering_pdf, flags, &sampled_type);
+        f = f * mkrgb(absdot(wi, h.sh_n));
+        if (!is_black(f) && scattering_pdf > 0.0f) {
+            const f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
+            float lpdf = 0.0f;
+            rgb le_mis = ldrgb(lt.L);
+            if (lt.kind == RSPT_LIGHT_INFINITE) {
+                lpdf = infinite_pdf_li(sc, lt, wi);
+                if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
+            } else {
+                const TriRec lt_tri = load_tri(sc, lt.prim);
+                float t_l, lb0, lb1, lb2;
+                if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
+                    Hit lh;
+                    tri_fill(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
+                    lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
+                    if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+                }
+            }
+            if (lpdf != 0.0f) {
+                c2 = f * le_mis * mkrgb(1.0f) * power_heuristic(scattering_pdf, lpdf) / scattering_pdf;
+                if (lt.kind != RSPT_LIGHT_INFINITE || !is_black(le_mis)) {
+                    store_ray(pb.ray_mis + v, ro, wi, RSPT_INF, v);
+                    *want_mis = true;
+                    fl |= DLF_HAS_C2 | (lt.kind == RSPT_LIGHT_INFINITE ? DLF_C2_ON_MISS : 0u);
+                }
+            }
+        }
+    }
+    pb.nee_c1[v] = make_float4(c1.r, c1.g, c1.b, choice_pdf);
+    pb.nee_c2[v] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
+    return fl | 0x100u;
+}
+
+// nls: n_light_samples per light on the device (nullptr: one each); R = the number of estimates per node = sum_j n_j (sample_all) or 1
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_all(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ pix_list,
+                                                    const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in, const int32_t* __restrict__ nls, uint32_t R,
+                                                    uint32_t n_arrays, uint32_t sample_all, uint32_t* __restrict__ q_any, uint32_t* cnt_any,
+                                                    uint32_t* __restrict__ q_mis, uint32_t* cnt_mis) {
+    const uint32_t n = *count_in;
+    const uint32_t nl = sc.n_lights, n_lights_round = sample_all ? nl : 1u;
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t slot = 0;
+        bool shading = false;
+        DlHit d;
+        if (i < n) {
+            slot = queue[i];
+            shading = __float_as_uint(dl.le_kind[slot].w) == DL_SHADING;
+            if (shading) {
+                const float4 hc = pb.hit_cont[slot];
+                const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
+                const float4 r0 = rp[0], r1 = rp[1];
+                dl_interaction(sc, pb, slot, __float_as_uint(hc.x), hc, f3{r0.w, r1.x, r1.y}, &d);
+            }
+        }
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n_lights_round; j++) {          // (wave-uniform trip counts: dl_push ballots inside)
+            const uint32_t n_j = sample_all ? (uint32_t)(nls ? nls[j] : 1) : 1u;
+            for (uint32_t kk = 0; kk < n_j; kk++, r++) {
+                bool want_sh = false, want_mis = false;
+                const uint32_t v = slot * R + r;
+                if (i < n) {
+                    uint32_t fl = 0;
+                    if (shading) {
+                        f2 u_light, u_scatter;
+                        uint32_t light_num;
+                        float choice_pdf;
+                        if (dl_estimate_samples(rd, bt, pb, dl, pix_list, slot, nl, j, kk, n_j, n_arrays, sample_all, &u_light, &u_scatter, &light_num, &choice_pdf))
+                            fl = dl_estimate(sc, pb, d, light_num, choice_pdf, u_light, u_scatter, v, &want_sh, &want_mis);
+                    }
+                    dl.nflags[v] = fl;
+                }
+                dl_push(want_sh, v, q_any, cnt_any);
+                dl_push(want_mis, v | RSPT_Q_MIS, q_mis, cnt_mis);
+            }
+        }
+    }
+}
+
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_resolve_all(SceneDev sc, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
+                                                            const int32_t* __restrict__ nls, uint32_t R, uint32_t n_arrays, uint32_t sample_all) {
+    const uint32_t n = *count_in;
+    const uint32_t nl = sc.n_lights, n_lights_round = sample_all ? nl : 1u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t slot = queue[i];
+        const float4 la = dl.l_all[slot];
+        rgb l = rgb{la.x, la.y, la.z};
+        const float4 a4 = dl.ld_acc[slot];
+        rgb acc = rgb{a4.x, a4.y, a4.z};
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n_lights_round; j++) {
+            const uint32_t n_j = sample_all ? (uint32_t)(nls ? nls[j] : 1) : 1u;
+            for (uint32_t kk = 0; kk < n_j; kk++, r++) {
+                const uint32_t v = slot * R + r;
+                const uint32_t fl = dl.nflags[v];
+                if (!(fl & 0x100u)) continue;
+                const float4 c1 = pb.nee_c1[v], c2 = pb.nee_c2[v];
+                rgb ld = mkrgb(0.0f);
+                if ((fl & DLF_HAS_C1) && pb.occluded[v] == 0u) ld = ld + rgb{c1.x, c1.y, c1.z};
+                if (fl & DLF_HAS_C2) {
+                    const float4 hm = pb.hit_mis[v];
+                    const uint32_t hp = __float_as_uint(hm.x), light_num = __float_as_uint(c2.w);
+                    if (fl & DLF_C2_ON_MISS) {
+                        if (hp == RSPT_MISS) ld = ld + rgb{c2.x, c2.y, c2.z};
+                    } else if (hp != RSPT_MISS) {
+                        const TriRec t = load_tri(sc, hp);
+                        if (t.area_light >= 0 && (uint32_t)t.area_light == light_num) {
+                            Hit h;
+                            tri_fill(sc, hp, t, hm.y, hm.z, hm.w, &h);
+                            const float4* mr = reinterpret_cast<const float4*>(pb.ray_mis + v);
+                            const float4 m0 = mr[0], m1 = mr[1];
+                            if (!is_black(light_l(sc.lights[light_num], h.n, -f3{m0.w, m1.x, m1.y}))) ld = ld + rgb{c2.x, c2.y, c2.z};
+                        }
+                    }
+                }
+                if (!sample_all) l = l + ld / c1.w;  // estimate_direct(..) / light_pdf
+                else if (dl.kidx[slot] * nl + j < n_arrays / 2u) {
+                    acc = acc + ld;
+                    if (kk + 1u == n_j) { l = l + acc / (float)n_j; acc = mkrgb(0.0f); }
+                } else l = l + ld;
+            }
+        }
+        dl.l_all[slot] = make_float4(l.r, l.g, l.b, 0.0f);
+        dl.ld_acc[slot] = make_float4(acc.r, acc.g, acc.b, 0.0f);
+    }
+}
+
 // li of every node, bottom-up; the root's goes to the camera sample
 RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_gather(Batch bt, PathBuf pb, DlBuf dl, uint32_t n_lights, uint32_t max_depth) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;

@@ -937,7 +937,16 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const bool dl_specular = s->has_dynamic || (s->shade_features & (RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_R) | RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_T) | RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_SPEC))) != 0;
     const uint32_t dl_levels = (dl_specular || env_size("RSPT_DL_FULL_TREE", 0) != 0) ? (uint32_t)d->max_depth : std::min<uint32_t>((uint32_t)d->max_depth, 1u);
     const uint32_t dl_H = (direct && !pixel_sampler && !dl_lane) ? (1u << dl_levels) : 1u;   // node slots per camera sample (direct.h; in the per-lane forms a lane walks the tree itself)
-    if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? (s->has_dynamic ? 20 : 22) : 26)) / dl_H, 1024);   // (per-lane form: texture rows and lobe records per recursion level)
+    // all light estimates of a node in one round (direct.h k_dl_nee_all): R = sum_j n_j virtual slots per node slot in the ray / result arrays; RSPT_DL_ROUNDS=1 = one
+    // round per estimate as before (R = 1 for the sizing)
+    uint32_t dl_R = 1;
+    if (direct && !pixel_sampler && !dl_lane && env_size("RSPT_DL_ROUNDS", 0) == 0 && d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL && s->dev.n_lights) {
+        uint64_t r = 0;
+        for (uint32_t j = 0; j < s->dev.n_lights; j++) r += d->n_light_samples ? (uint64_t)d->n_light_samples[j] : 1u;
+        dl_R = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r, 1u), 1u << 20);
+    }
+    const bool dl_one_round = direct && !pixel_sampler && !dl_lane && env_size("RSPT_DL_ROUNDS", 0) == 0;
+    if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? (s->has_dynamic ? 20 : 22) : (dl_R > 1 ? 28 : 26))) / dl_H / dl_R, 1024);   // (per-lane form: texture rows and lobe records per recursion level)
     if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     size_t pix_per_batch = 1;
@@ -945,7 +954,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         ns = 1;
         while ((uint64_t)ns * 2 <= (uint64_t)d->spp && (uint64_t)n_pix * ns * 2 <= cap) ns *= 2;
         pix_per_batch = std::max<size_t>(1, std::min(n_pix, cap / ns));
-        rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H);
+        rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H * dl_R);
         if (rc == RSPT_OK && direct && !pixel_sampler && !dl_lane) rc = ensure_direct(g.cap);
         if (rc == RSPT_OK && volpath) rc = ensure_vol(g.cap);
         if (rc == RSPT_OK) break;
@@ -1187,7 +1196,24 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             }
         }
         hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md, dim_limit);
-        if (nl) {
+        if (nl && dl_one_round) {   // every estimate of a level's nodes in one round: 4 launches per level (direct.h k_dl_nee_all)
+            QueueCounts* rc_ = &g.cnt[md + 3];
+            for (uint32_t l = 0; l < dl_levels; l++) {
+                HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
+                ev_open(2, 0);
+                hipLaunchKernelGGL(k_dl_nee_all, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R,
+                                   n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest);
+                ev_close(2, 0);
+                ev_open(1, 0);
+                launch_trace<true, 0>(0, false, tgrid, s, g.q[0][2], &rc_->any, 0, &rc_->cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                ev_close(1, 0);
+                ev_open(0, 0);
+                launch_trace<false, 0>(0, false, tgrid, s, g.q[0][1], &rc_->closest, 0, &rc_->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                ev_close(0, 0);
+                trace_launches += 2;
+                hipLaunchKernelGGL(k_dl_nee_resolve_all, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, dl, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R, n_arrays, all ? 1u : 0u);
+            }
+        } else if (nl) {
             QueueCounts* rc_ = &g.cnt[md + 3];
             for (uint32_t l = 0; l < dl_levels; l++) {
                 const uint32_t n_lights_round = all ? nl : 1u;
