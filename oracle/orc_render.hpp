@@ -202,7 +202,7 @@ static inline void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y) 
 }
 static inline uint64_t multiplicative_inverse(int64_t a, int64_t n) { int64_t x = 0, y = 0; extended_gcd((uint64_t)a, (uint64_t)n, &x, &y); return (uint64_t)mod_t(x, n); }
 struct HaltonSampler {
-    static const int32_t K_MAX_RESOLUTION = 128;
+    static constexpr int32_t K_MAX_RESOLUTION = 128;
     int64_t spp;
     int32_t base_scales[2], base_exponents[2];
     uint64_t sample_stride, mult_inverse[2];

@@ -24,7 +24,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # ORACLE_LIB: the sanitizer build (make -C oracle san; tests/test_oracle_sanitizers.py)
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

@@ -314,7 +314,8 @@ def test_moving_camera_decomposition_and_interpolation(oracle):
     rd3 = scenes.make_render_desc(64, 64, 1, la0, 40.0, look_at_end=la0)
     cs = np.array([20.3, 41.7, 0.37, 0.5, 0.5], F32); o_a = np.zeros(7, F32); o_b = np.zeros(7, F32)
     L.orc_camera_ray(C.addressof(rd3), cs.ctypes.data, o_a.ctypes.data)
-    L.orc_camera_ray(C.addressof(scenes.make_render_desc(64, 64, 1, la0, 40.0)), cs.ctypes.data, o_b.ctypes.data)
+    rd4 = scenes.make_render_desc(64, 64, 1, la0, 40.0)   # (kept alive across the call: the address of a temporary was a use after free — found by the ASan run)
+    L.orc_camera_ray(C.addressof(rd4), cs.ctypes.data, o_b.ctypes.data)
     assert np.array_equal(o_a, o_b)
 
 

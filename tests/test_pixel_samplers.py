@@ -269,7 +269,9 @@ def test_sample_arrays_follow_the_vectors_in_the_tile_stream(oracle):
     for s in range(16):
         sl = arrs[0][s * 2:(s + 1) * 2]
         assert sorted((sl[:, 0] * 2).astype(int)) == [0, 1] and sorted((sl[:, 1] * 2).astype(int)) == [0, 1]
-    rc = lambda name, n: oracle.lib().orc_round_count(C.addressof(desc(name, 16)), n)   # noqa: E731
+    def rc(name, n):
+        rd_ = desc(name, 16)   # (kept alive across the call: the address of a temporary was a use after free — found by the ASan run)
+        return oracle.lib().orc_round_count(C.addressof(rd_), n)
     assert [rc("02sequence", n) for n in (1, 3, 4, 5, 64, 65)] == [1, 4, 4, 8, 64, 128] and rc("maxmindist", 6) == 8 and rc("random", 6) == 6 and rc("stratified", 6) == 6
 
 
