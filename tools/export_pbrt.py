@@ -218,10 +218,15 @@ def export(sc, path, look_at, fov, xres, yres, spp, max_depth=5, sampler="sobol"
             out += mesh_block(k)
         else:
             obj, xf, xf_end, _times = sb.instances[k]
-            assert xf_end is None, "moving instances are not exported (ActiveTransform blocks): add them when a reference dump needs one"
             from rs_pbrt_amd import scenes as _sc
             assert np.array_equal(np.asarray(xf.m_inv, np.float32), np.asarray(_sc.Transform(xf.m).m_inv, np.float32)), "instance transform was not built as Transform(m)"
-            out += ["TransformBegin", "  Transform [%s]" % f(np.asarray(xf.m, np.float32).reshape(4, 4).T), '  ObjectInstance "%s"' % names[obj], "TransformEnd"]
+            if xf_end is None:
+                out += ["TransformBegin", "  Transform [%s]" % f(np.asarray(xf.m, np.float32).reshape(4, 4).T), '  ObjectInstance "%s"' % names[obj], "TransformEnd"]
+            else:   # a MOVING instance: the CTM's two slots set apart (api.rs active_transform_bits), pbrt_object_instance makes AnimatedTransform(ctm[0], start, ctm[1], end)
+                assert np.array_equal(np.asarray(xf_end.m_inv, np.float32), np.asarray(_sc.Transform(xf_end.m).m_inv, np.float32)), "instance end key was not built as Transform(m)"
+                out += ["TransformBegin", "  ActiveTransform StartTime", "  Transform [%s]" % f(np.asarray(xf.m, np.float32).reshape(4, 4).T),
+                        "  ActiveTransform EndTime", "  Transform [%s]" % f(np.asarray(xf_end.m, np.float32).reshape(4, 4).T), "  ActiveTransform All",
+                        '  ObjectInstance "%s"' % names[obj], "TransformEnd"]
     # point lights after the shapes: the builder lists Scene.lights as area lights (declaration order) then the others
     for lt in sb.delta_lights:
         from rs_pbrt_amd import abi
@@ -261,6 +266,31 @@ def instanced_room(bvh_builder, scenes):
         sb.add_instance("pyr", T((T.translate((i - 2.0, 0.2, 1.0 + 0.3 * i)) * T.rotate_y(20.0 * i + 5.0) * T.scale(0.5 + 0.1 * i, 1.0 + 0.05 * i, 0.8)).m))
     sb.add_instance("one", T(T.translate((0, 2, 0)).m))
     sb.add_instance("pyr", T.identity())
+    return sb.finish(bvh_builder, instancing="reference")
+
+
+def instanced_moving(bvh_builder, scenes):
+    """instanced_room with MOVING instances (AnimatedTransform primitive_to_world, primitive.rs:198-265): one that slides and grows (no rotation between its
+    keys: motion_bounds = the union of the keys' boxes), one that also turns (slerp; motion_bounds per corner, transform.rs:2164-2210), one whose keys are
+    equal, a static one.  Every key is Transform(m) — what a `Transform [..]` directive gives rs_pbrt.  The keys hold for the whole shutter (TransformTimes 0 1,
+    the file's default): per-instance key times other than the global TransformTimes cannot be written in a .pbrt file."""
+    T = scenes.Transform
+    pyr = np.array([(-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5), (0, 1, 0)], np.float32)
+    sb = scenes.SceneBuilder()
+    grey = sb.add_material(scenes.matte((0.5, 0.5, 0.5)))
+    red = sb.add_material(scenes.plastic((0.6, 0.2, 0.15), (0.3, 0.3, 0.3), 0.15))
+    sb.add_quad([(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)], grey)
+    sb.add_quad([(-5, 0, 5), (-5, 5, 5), (5, 5, 5), (5, 0, 5)], grey)
+    sb.add_quad([(-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1)], grey, emit=(10, 10, 10))
+    sb.begin_object("pyr")
+    sb.add_mesh(pyr, [[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]], red)
+    sb.end_object()
+    K = lambda t: T(t.m)   # noqa: E731
+    sb.add_instance("pyr", K(T.translate((-2.2, 0.1, 1.0)) * T.scale(0.6, 0.8, 0.6)), K(T.translate((-1.4, 0.5, 1.6)) * T.scale(0.9, 1.3, 0.7)))
+    sb.add_instance("pyr", K(T.translate((-0.3, 0.2, 0.6)) * T.rotate_y(10.0)), K(T.translate((0.2, 0.2, 1.0)) * T.rotate_y(75.0) * T.scale(1.0, 1.2, 1.0)))
+    same = K(T.translate((1.2, 0.1, 1.4)) * T.rotate_y(30.0))
+    sb.add_instance("pyr", same, T(same.m))
+    sb.add_instance("pyr", K(T.translate((2.4, 0.0, 2.2)) * T.scale(0.7, 0.7, 0.7)))
     return sb.finish(bvh_builder, instancing="reference")
 
 
@@ -331,6 +361,8 @@ SCENES = {
     # ObjectBegin / ObjectInstance: v0.9.12's behaviour (instanced hits lose their primitive, identity instances report nothing) is what
     # the fixture will record; the oracle's RSPT_INSTANCING_REFERENCE mode claims to reproduce it
     "instanced_room": (instanced_room, INSTANCED_CAMERA, 96, 72, 8, 5),
+    # round 5: MOVING instances — AnimatedTransform::new's decomposition, interpolate per ray, and (in the dump's BVH node array) motion_bounds of the top-level boxes
+    "instanced_moving": (instanced_moving, INSTANCED_CAMERA, 96, 72, 8, 5),
     # the other samplers / integrators that share the loop
     "cornell_halton": (lambda b, s: s.cornell_box(b, "mixed"), "CORNELL", 64, 64, 16, 5),
     # DirectLightingIntegrator (both strategies; the glass block in its two-lobe form, allow_multiple_lobes = false: the specular tree
