@@ -314,8 +314,10 @@ typedef struct {
      * rotation by slerp between the decomposed keys, m_inv as inverse(scale) * rotation^T * translate(-t)); the library does the
      * same per instance visit.  The top-level aggregate's bounds of such a primitive are the reference's
      * AnimatedTransform::motion_bounds (the shim passes the BVH rs_pbrt built; the library never computes them).
-     * Served by the `path` integrator under the Sobol' / Halton samplers; other integrators and the pixel samplers answer
-     * RSPT_E_UNSUPPORTED for a scene with a moving instance. */
+     * (A caller that builds the top-level tree itself gets them from rspt_motion_bounds.)
+     * Served by all four integrators under the Sobol' / Halton samplers (ABI 21 builds).  RSPT_E_UNSUPPORTED: under the PCG-backed pixel
+     * samplers, under the per-lane form of directlighting (textured materials, max_depth > 8), and — at rspt_scene_create — for a scene that
+     * has both a moving instance and an alpha-masked mesh. */
     uint32_t animated;
     float to_world_end[16];
     float from_world_end[16];

@@ -62,8 +62,9 @@ RDEV void dl_interaction(const SceneDev& sc, const PathBuf& pb, uint32_t slot, u
     o->wo = -ray_d;
     if (pb.hit_inst) {
         const uint32_t hi = pb.hit_inst[slot];
-        if (hi && !sc.inst[hi - 1u].identity) {
-            const InstDev& in = sc.inst[hi - 1u];
+        InstDev in{};   // the instance's Transform, a moving one's at the camera sample's time (node slots per sample = sc.time_div while the tree is traced)
+        if (hi) in = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[slot / sc.time_div] : 0.0f);
+        if (hi && !in.identity) {
             inst_hit(in, &o->h);
             o->wo = normalize(xf_vector(in.m, -xf_vector(in.mi, ray_d)));
             if (!sc.inst_fixed) { o->h.material = 0xffffffffu; o->h.area_light = -1; }

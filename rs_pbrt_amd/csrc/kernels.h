@@ -1051,7 +1051,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
 // halton.rs:260-272) -> n shadow rays.  Ray k of path i sits at ray_sh[i * n + k]; its id field carries the
 // term dot(wi, n) / (pdf * n) that stage 2 adds when the ray is unoccluded.
 #define RSPT_AO_SKIP 0xffffffffu  // id of a ray that is not traced (pdf == 0)
-RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
+template <bool ANIM>   // ANIM: the scene has moving instances (their Transform at the camera sample's time, inst_at)
+__global__ __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list,
                                                   uint32_t n_samples, uint32_t cos_sample, uint32_t* __restrict__ q_any, QueueCounts* cnt) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= bt.n) return;
@@ -1069,7 +1070,10 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_ao_spawn(SceneDev sc, RenderDev 
     tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &hp);
     if (pb.hit_inst) {
         const uint32_t hi = pb.hit_inst[i];
-        if (hi && !sc.inst[hi - 1u].identity) { inst_texhit(sc.inst[hi - 1u], &h); inst_hit(sc.inst[hi - 1u], &hp); }
+        InstDev moved{};   // (a moving instance: its Transform at the camera sample's time)
+        if (ANIM && hi) moved = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[i] : 0.0f);
+        const InstDev& in = ANIM ? moved : sc.inst[hi ? hi - 1u : 0u];
+        if (hi && !in.identity) { inst_texhit(in, &h); inst_hit(in, &hp); }
     }
     const f3 n = faceforward(h.n, -ray_d);
     const f3 sv = normalize(h.dpdu);

@@ -700,8 +700,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         return fail(RSPT_E_UNSUPPORTED, "integrator %u (path, ao, directlighting and volpath only)", d->integrator);
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
     const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
-    if (s->has_animated && (d->integrator != RSPT_INTEGRATOR_PATH || pixel_sampler))
-        return fail(RSPT_E_UNSUPPORTED, "a scene with a moving object instance is served by the path integrator under the Sobol' / Halton samplers only");
+    if (s->has_animated && pixel_sampler)   // (the per-lane kernels carry no interpolation; round 5 lifted the refusal for volpath / directlighting / ao under Sobol' / Halton)
+        return fail(RSPT_E_UNSUPPORTED, "a scene with a moving object instance is served under the Sobol' / Halton samplers only");
     if (direct) {
         if (d->max_depth < 1 || d->max_depth > (uint32_t)RSPT_DL_SERIAL_DEPTH)
             return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, %d] (the explicit recursion stack of the per-lane form, dl_serial.h)", RSPT_DL_SERIAL_DEPTH);
@@ -933,6 +933,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // (lane_serial.h): textured materials, more than 8 recursion levels; RSPT_DL_FORM=lane forces it (A/B, tests)
     const char* dl_form_env = getenv("RSPT_DL_FORM");
     bool dl_lane = direct && !pixel_sampler && (s->has_textures || d->max_depth > 8 || (dl_form_env && !strcmp(dl_form_env, "lane")));
+    if (s->has_animated && dl_lane) return fail(RSPT_E_UNSUPPORTED, "directlighting in its per-lane form (textured materials / max_depth > 8) over a scene with a moving object instance");
     // levels of the specular tree that can hold nodes (direct.h DlBuf::levels): a scene without specular lobes has the root only
     const bool dl_specular = s->has_dynamic || (s->shade_features & (RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_R) | RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_T) | RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_SPEC))) != 0;
     const uint32_t dl_levels = (dl_specular || env_size("RSPT_DL_FULL_TREE", 0) != 0) ? (uint32_t)d->max_depth : std::min<uint32_t>((uint32_t)d->max_depth, 1u);
@@ -1135,7 +1136,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 ev_close(1, 0);
                 trace_launches++;
                 if (looked) vol_rays += c.closest;
-                hipLaunchKernelGGL(k_vol_tr, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
+                hipLaunchKernelGGL(s->has_animated ? k_vol_tr<true> : k_vol_tr<false>, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, g.vol, g.q[seg & 1u][2], &tc->closest, g.q[(seg + 1u) & 1u][2], &tn->closest);
             }
             if (!have_live) {
                 HIP_TRY(hipMemcpyAsync(look, g.cnt, 4 * sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
@@ -1158,6 +1159,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             return fail(RSPT_E_UNSUPPORTED, "directlighting: %u sample arrays exceed the sampler's %u dimensions", n_arrays, dim_limit);
         DlBuf dl = g.dl;
         dl.H = H; dl.levels = dl_levels;
+        s->dev.time_div = H;   // node h of camera sample s lives in slot s * H + h: its rays carry the sample's time (moving instances); estimate rays: below
+        struct TimeDivReset { rspt_scene_s* s; ~TimeDivReset() { s->dev.time_div = 1u; } } time_div_reset{s};
         const size_t n_slots = (size_t)bt.n * H;
         HIP_TRY(hipMemsetAsync(dl.le_kind, 0, n_slots * sizeof(float4), g.stream));
         HIP_TRY(hipMemsetAsync(dl.l_all, 0, n_slots * sizeof(float4), g.stream));
@@ -1205,10 +1208,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                                    n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest);
                 ev_close(2, 0);
                 ev_open(1, 0);
+                s->dev.time_div = H * dl_R;   // estimate r of node slot n sits in virtual slot n * R + r
                 launch_trace<true, 0>(0, false, tgrid, s, g.q[0][2], &rc_->any, 0, &rc_->cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
                 ev_close(1, 0);
                 ev_open(0, 0);
                 launch_trace<false, 0>(0, false, tgrid, s, g.q[0][1], &rc_->closest, 0, &rc_->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
+                s->dev.time_div = H;
                 ev_close(0, 0);
                 trace_launches += 2;
                 hipLaunchKernelGGL(k_dl_nee_resolve_all, dim3(dgrid), dim3(256), 0, g.stream, s->dev, g.pb, dl, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R, n_arrays, all ? 1u : 0u);
@@ -1279,10 +1284,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         launch_trace<false, 0>(0, counters, tgrid, s, g.q[0][1], &g.cnt[0].closest, 0, &g.cnt[0].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
         ev_close(0, 0);
         HIP_TRY(hipEventRecord(e1, g.stream));
-        hipLaunchKernelGGL(k_ao_spawn, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, g.pix_list, ao_n, d->ao_cos_sample, g.q[0][2], &g.cnt[1]);
+        hipLaunchKernelGGL(s->has_animated ? k_ao_spawn<true> : k_ao_spawn<false>, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, g.pix_list, ao_n, d->ao_cos_sample, g.q[0][2], &g.cnt[1]);
         HIP_TRY(hipEventRecord(e2, g.stream));
         ev_open(1, 0);
+        s->dev.time_div = ao_n;   // shadow ray k of camera sample i sits in slot i * n + k: its Ray.time is the sample's (moving instances)
         launch_trace<true, 0>(0, counters, tgrid, s, g.q[0][2], &g.cnt[1].any, 0, &g.cnt[1].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+        s->dev.time_div = 1u;
         ev_close(1, 0);
         HIP_TRY(hipEventRecord(e3, g.stream));
         trace_ev.push_back({e0, e1}); trace_ev.push_back({e2, e3});

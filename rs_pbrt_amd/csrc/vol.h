@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                 if (!hit && pb.hit_inst) t_hit = hc.y;   // no hit reported, but an identity instance may have shortened ray.t_max (Q10): the medium is sampled up to there
                 if (hit) {
                     tri = load_tri(sc, prim);
-                    if (hi) {
+                    if (hi) {   // (inst_at: the instance's own Transform, or for a moving instance the one interpolated at the path's time — as the traversal used it)
                         f3 oo, od; float ot;
-                        inst_ray(sc.inst[hi - 1u], ray_o, ray_d, RSPT_INF, &oo, &od, &ot);
+                        inst_ray(inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f), ray_o, ray_d, RSPT_INF, &oo, &od, &ot);
                         t_hit = hit_distance(tri, oo, od);
                     } else t_hit = hit_distance(tri, ray_o, ray_d);
                 }
@@ -253,9 +253,10 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
                         f3 wo = wo_ray;            // isect.common.wo, what estimate_direct reads (they differ for a transformed hit only)
                         // Transform::transform_surface_interaction (transform.rs:815-860) starts from SurfaceInteraction::default(): the transformed
                         // hit has no medium interface (get_medium gives None on either side) and, in v0.9.12, no primitive (Q11)
-                        const bool transformed = hi && !sc.inst[hi - 1u].identity;
+                        InstDev in{};
+                        if (hi) in = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f);
+                        const bool transformed = hi && !in.identity;
                         if (transformed) {
-                            const InstDev& in = sc.inst[hi - 1u];
                             inst_hit(in, &h);
                             wo = normalize(xf_vector(in.m, -xf_vector(in.mi, ray_d)));
                             if (!sc.inst_fixed) { h.material = 0xffffffffu; h.area_light = -1; }
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(256) void k_vol_shade(SceneDev sc, LightDistDev ld,
 }
 
 // one segment of VisibilityTester::tr (light.rs:207-239) for every shadow ray in flight
-RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
+template <bool ANIM>   // ANIM: the scene has moving instances (inst_at's interpolation costs this kernel two waves of occupancy: 92 -> 147 VGPRs)
+__global__ __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, VolBuf vb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
                                                 uint32_t* __restrict__ q_next, uint32_t* cnt_next) {
     const uint32_t n = *count_in;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
@@ -386,19 +388,22 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_vol_tr(SceneDev sc, PathBuf pb, 
             if (prim != RSPT_MISS) {
                 const TriRec tri = load_tri(sc, prim);
                 const uint32_t hi = vb.hit_inst_tr ? vb.hit_inst_tr[p] : 0u;
-                const bool transformed = hi && !sc.inst[hi - 1u].identity;
+                InstDev moved{};
+                if (ANIM && hi) moved = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f);
+                const InstDev& in = ANIM ? moved : sc.inst[hi ? hi - 1u : 0u];   // (a reference, not a copy: the static case keeps reading the record's fields from memory as it needs them)
+                const bool transformed = hi && !in.identity;
                 const bool no_primitive = transformed && !sc.inst_fixed;   // Q11: isect.primitive is None, neither branch of :216-229 runs
                 if (!no_primitive && tri.material != 0xffffffffu) { blocked = true; done = true; }  // an opaque surface: Spectrum::default() (:218-222)
                 else {
                     if (medium && !no_primitive) {   // ray.t_max is the hit distance now (an instanced hit: the object ray's)
                         float th;
-                        if (hi) { f3 oo, od; float ot; inst_ray(sc.inst[hi - 1u], o, d, t_max, &oo, &od, &ot); th = hit_distance(tri, oo, od); }
+                        if (hi) { f3 oo, od; float ot; inst_ray(in, o, d, t_max, &oo, &od, &ot); th = hit_distance(tri, oo, od); }
                         else th = hit_distance(tri, o, d);
                         tr = tr * med_tr(sc.media[medium - 1u], th, len(d));
                     }
                     Hit h;
                     tri_fill(sc, prim, tri, hm.y, hm.z, hm.w, &h);
-                    if (transformed) inst_hit(sc.inst[hi - 1u], &h);
+                    if (transformed) inst_hit(in, &h);
                     const float4 pp = vb.p1_p[p], pe = vb.p1_e[p], pn = vb.p1_n[p];
                     const f3 lp{pp.x, pp.y, pp.z};
                     // isect.common.spawn_ray_to(p1) (:236)

@@ -383,16 +383,57 @@ def test_gpu_moving_instances_match_oracle(gpu, oracle, mode, tex, sampler):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("integrator,mode,sampler", [("volpath", "fixed", "sobol"), ("volpath", "reference", "halton"), ("ao", "fixed", "sobol"), ("ao", "reference", "sobol"),
+                                                     ("directlighting", "fixed", "sobol"), ("directlighting", "reference", "sobol"), ("directlighting-one", "fixed", "halton")])
+def test_gpu_moving_instances_under_the_other_integrators(gpu, oracle, integrator, mode, sampler):
+    """round 5: moving TransformedPrimitives under VolPathIntegrator, AOIntegrator and DirectLightingIntegrator (primitive.rs:198-272 is integrator-agnostic: every
+    Scene::intersect / intersect_p interpolates at the ray's time) — the traversal through k_trace_w4<INST, ANIM> with the ray's slot mapped back to its camera
+    sample's time (SceneDev::time_div: 1 / ao_n_samples / nodes per sample), the hit's interaction through the same interpolated Transform.  Per-sample
+    radiance bit for bit, with a rotation between the keys."""
+    sc = moving_scene(gpu.bvh_build, mode=mode)
+    kw = dict(integrator=integrator.split("-")[0], sampler=sampler)
+    if integrator.startswith("directlighting"):
+        kw.update(direct_strategy="one" if integrator.endswith("one") else "all", light_samples=[2, 1, 1] if sc.desc.n_lights == 3 else None)
+    if integrator == "ao":
+        kw.update(ao_samples=8)
+    rd = rd_small(spp=8, shutter=(0.0, 1.0), **kw)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+        li, _ = gpu.render_samples(ds, rd)
+    if integrator.startswith("directlighting"):
+        strat = kw["direct_strategy"]
+        ref = oracle.render_integrator(sc, rd, "direct", strategy=strat, light_samples=kw["light_samples"] if strat == "all" else None, threads=8, want_li=True)
+    else:
+        ref = oracle.render(sc, rd, threads=8, want_li=True)
+    assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == 0
+    assert np.array_equal(film[:, 3], ref["film"][:, 3])
+    assert np.array_equal(li, ref["li"])
+    assert film_rmse(film, ref["film"]) < 1e-5
+    closed = dict(kw)
+    rd0 = rd_small(spp=8, shutter=(0.0, 0.0), **closed)
+    ref0 = (oracle.render_integrator(sc, rd0, "direct", strategy=kw["direct_strategy"], light_samples=kw["light_samples"] if kw["direct_strategy"] == "all" else None, threads=8)
+            if integrator.startswith("directlighting") else oracle.render(sc, rd0, threads=8))
+    assert film_rmse(film, ref0["film"]) > 2e-4   # the motion is in the picture
+
+
+@pytest.mark.gpu
 def test_gpu_moving_instances_are_refused_where_not_served(gpu):
+    """the per-lane kernels carry no interpolation: the PCG-backed pixel samplers and the per-lane form of directlighting (textured materials) answer
+    RSPT_E_UNSUPPORTED for a scene with a moving instance, as do moving instances next to alpha-masked meshes (rspt_scene_create)"""
     from rs_pbrt_amd.lib import RsptError
     sc = moving_scene(gpu.bvh_build, rotation=False)
     with gpu.DeviceScene(sc) as ds:
-        for kw in (dict(integrator="volpath"), dict(integrator="directlighting"), dict(integrator="ao"), dict(sampler="02sequence")):
+        for kw in (dict(sampler="02sequence"), dict(sampler="random", integrator="volpath")):
             rd = rd_small(spp=4, **kw)
             rd.allow_slow_paths = 1
             with pytest.raises(RsptError) as e:
                 gpu.render(ds, rd)
             assert e.value.code == abi.E_UNSUPPORTED
+    sct = moving_scene(gpu.bvh_build, rotation=False, tex=True)
+    with gpu.DeviceScene(sct) as ds:
+        with pytest.raises(RsptError) as e:
+            gpu.render(ds, rd_small(spp=4, integrator="directlighting"))
+        assert e.value.code == abi.E_UNSUPPORTED
 
 
 def matrix_scene(builder, mode, tex=False):
