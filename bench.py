@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--instancing", default="reference", choices=["reference", "fixed"], help="c5: what a hit inside an object instance is (rspt_scene_desc.instancing_mode)")
+    ap.add_argument("--moving", action="store_true", help="c5: every instance is a MOVING TransformedPrimitive (two keys that differ by a rotation; k_trace_w4<INST, ANIM>)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 line and the 1/8-frame probe")
     ap.add_argument("--no-count", action="store_true", help="skip the reference-order counting pass (no roofline block): for PMC runs")
@@ -123,9 +124,9 @@ def build_workload(args, workload, lib, scenes):
     elif workload == "c5":
         xres, spp = args.res or 1920, args.spp or 64
         yres = xres * 9 // 16
-        sc = scenes.landscape_standin(lib.bvh_build_gpu, instancing=args.instancing)
+        sc = scenes.landscape_standin(lib.bvh_build_gpu, instancing=args.instancing, moving=args.moving)
         mk = lambda s, sh, **kw: scenes.landscape_render_desc(xres=xres, yres=yres, spp=s, shard=sh, integrator=integ, **kw)  # noqa: E731
-        name = "landscape stand-in (4096 instances of a 10 k-triangle tree + lat-long sky; DECLARED STAND-IN for the off-tree Landscape scene; instancing mode %s), path depth 5, sobol %d spp, %dx%d" % (args.instancing, spp, xres, yres)
+        name = "landscape stand-in (4096 instances of a 10 k-triangle tree + lat-long sky; DECLARED STAND-IN for the off-tree Landscape scene; instancing mode %s%s), path depth 5, sobol %d spp, %dx%d" % (args.instancing, "; every instance moving over the shutter" if args.moving else "", spp, xres, yres)
     else:
         xres, spp = args.res or 1920, args.spp or 1024
         yres = xres * 9 // 16
@@ -217,8 +218,12 @@ def roofline_block(counts, count_scale, stats, traffic, traffic_note, stale, ms_
     lim = (traffic or {}).get("limiters", {})
     lc, la = lim.get("trace_closest", {}), lim.get("trace_any", {})
     miss_lines = (lc.get("l1_miss_lines") or 0.0) + (la.get("l1_miss_lines") or 0.0)
-    out = {"bound": "l2", "bound_detail": "rate and latency of the kernel's L1 MISSES (128-byte lines of BVH records and triangles fetched from L2 / Infinity Cache per lane), VALU issue "
-                                          "right behind; not the L1 probe rate (a variant with a third fewer probes per ray is no faster: experiments/README.md round 4), not HBM, not MFMA",
+    out = {"bound": "l1", "bound_detail": "the CU's L1 request path: every lane of a node step reads its own 128-byte record with seven 16-byte loads, and a CU's L1 takes ONE such divergent lane "
+                                          "request per clock (l1_request_frac = TCP_TOTAL_CACHE_ACCESSES / CU / clock, ceiling 1) — with VALU issue right behind (valu_busy).  Round 5's model sweeps "
+                                          "(profiles/r05_w8_sweeps.txt) settle what the walk is NOT bound by: occupancy (1 workgroup per CU runs as fast as 8: not latency x misses in flight), the L2 hit "
+                                          "rate short of 1 (0.63 -> 0.85 is +4 %), per-XCD locality (no faster than a shared hot set; XCD-affine dealing measured neutral, profiles/r05_xcd_affine_ab.txt), "
+                                          "HBM (frac below), MFMA (none)",
+           "binding_frac": lim.get("trace_closest", {}).get("l1_request_frac"),
            "kernel": "k_trace_w4 (BVH traversal + triangle test; closest-hit + shadow-ray launches)",
            "l1_request_frac": lim.get("trace_closest", {}).get("l1_request_frac"), "ta_busy": lim.get("trace_closest", {}).get("ta_busy"),
            "valu_busy": lim.get("trace_closest", {}).get("valu_busy"),
@@ -482,7 +487,7 @@ def main():
         samples_per_step = float(stats[0]["samples"])
 
     if rank == 0:
-        default_cfg = args.tris == 1_000_000 and not args.alpha_mask and args.filter == "box" and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
+        default_cfg = args.tris == 1_000_000 and not args.alpha_mask and not args.moving and args.filter == "box" and not args.res and not args.spp and world == 1 and args.integrator == "path" and args.sampler == "sobol"
         traffic, tnote, stale = measured_traffic(lib, args.workload, default_cfg)
         ms_per_step = elapsed / args.steps * 1e3
         out = {

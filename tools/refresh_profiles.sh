@@ -69,6 +69,10 @@ if [ "$mode" = all ]; then
       timeout 900 python tools/c5_both_modes.py 3 > $out/c5_both_modes.txt 2> $out/c5_both_modes.err
     fi
   fi
+  # round 5: the wavefront directlighting schedule with all light estimates of a node in one round (direct.h k_dl_nee_all), on the C3 stand-in
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks_statue_directlighting -- python $repo/bench.py --workload statue --integrator directlighting --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-count > $out/ks_statue_directlighting.log 2>&1)
+  python tools/rocprof_summary.py $out/ks_statue_directlighting $out/ks_statue_directlighting.md "bench.py --workload statue --integrator directlighting --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-count" > /dev/null 2>&1
+  find $out/ks_statue_directlighting -name "*.db" -size +8M -delete
   for w in volpath 02sequence; do   # kernel stats of the two schedules that are not the wavefront path loop
     if [ $w = volpath ]; then a="--integrator volpath"; else a="--sampler 02sequence --spp 8"; fi
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $out/ks_cornell_$w -- python $repo/bench.py --workload cornell $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $out/ks_cornell_$w.log 2>&1)
