@@ -318,8 +318,26 @@ def host_cpu_facts():
     return facts
 
 
+def effective_cores():
+    """the cores this process may actually use: the affinity mask, cut by the cgroup CPU quota (the GPU boxes show 256 logical CPUs to a container that is
+    allowed 16 CPUs' worth of time — 256 threads then run at 16 cores' speed, which is what rounds 1-4 reported as "256 cores")"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(args, pyoracle, sc, mk_rd, spp, scaling_crop):
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores = effective_cores()
     rd_cpu = mk_rd(spp, (0, 1, 64))
     def cpu_render(rd_, threads):
         if args.integrator != "directlighting":
@@ -333,7 +351,7 @@ def cpu_baseline(args, pyoracle, sc, mk_rd, spp, scaling_crop):
     c = r["counters"]
     out = {"value": c["samples"] / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
            "sample": "same scene and frame at %d spp (%d samples), C++ oracle restatement of rs_pbrt's tile loop (rs_pbrt itself cannot be built "
-                     "here: no Rust toolchain), %d threads, %.1f s" % (spp, c["samples"], ncores, r["seconds"]),
+                     "here: no Rust toolchain), %d threads = the cores this container may use (affinity cut by the cgroup CPU quota; cpu_baseline.host), %.1f s" % (spp, c["samples"], ncores, r["seconds"]),
            # SURVEY 8(d) "oracle_counters.json per config", emitted in the run: the CPU oracle's own node / triangle / ray counts
            "oracle_counters_per_sample": {"nodes": c["nodes_visited"] / c["samples"], "tris": c["tris_tested"] / c["samples"],
                                           "rays_closest": c["rays_closest"] / c["samples"], "rays_any": c["rays_any"] / c["samples"],
@@ -426,7 +444,17 @@ def main():
     if world > 1:
         import datetime
         if shared_devices:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            # (gloo announces its peers on STDOUT; this script's stdout carries exactly one JSON line, so the announcement goes to stderr)
+            sys.stdout.flush()
+            saved_out = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_out, 1)
+                os.close(saved_out)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=600))
         # X1 lives in the library: rank 0's id travels over the launcher's process group, then every rank joins the library's own communicator
