@@ -150,3 +150,11 @@ def test_no_module_of_the_package_mentions_an_oracle_import():
     for f in glob.glob(os.path.join(ROOT, "rs_pbrt_amd", "*.py")):
         for ln, line in enumerate(open(f), 1):
             assert not re.search(r"^\s*(from\s+oracle|import\s+oracle|from\s+\.\.?oracle)", line), "%s:%d imports the oracle" % (f, ln)
+
+
+def test_committed_fixture_is_what_the_references_text_gives():
+    """where /root/reference exists (this container, not the GPU box): the fixture's literal coefficients regenerated from transform.rs:944-2030 as it lies there, bit for bit"""
+    if not os.path.exists("/root/reference/src/core/transform.rs"):
+        pytest.skip("the reference tree is not on this machine: the committed fixture is what travels")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_motion_fixture.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
