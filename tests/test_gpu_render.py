@@ -714,6 +714,22 @@ def test_film_reduce_with_two_ranks(gpu, tmp_path):
     assert np.array_equal(np.load(os.path.join(tmp_path, "film3_0.npy")), reduced)
 
 
+def test_round5_schedule_switches_leave_the_film_bit_identical(gpu, monkeypatch):
+    """RSPT_FRESH=0 (k_raygen writes L / beta, the first shade launch reads them back), RSPT_XCD_DEAL=1 and RSPT_W4_SHAPE=1 change which bytes move and which wave
+    traces which ray, never a sample: the film of a gallery frame (every material recipe, four light kinds) is bit-identical under each"""
+    sc = gallery(gpu.bvh_build)
+    rd = scenes.make_render_desc(96, 72, 16, GALLERY_LOOK_AT, 60.0, max_depth=5)
+    with gpu.DeviceScene(sc) as ds:
+        base, _ = gpu.render(ds, rd)
+        for env in (dict(RSPT_FRESH="0"), dict(RSPT_XCD_DEAL="1"), dict(RSPT_W4_SHAPE="1")):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            film, _ = gpu.render(ds, rd)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.array_equal(film, base), env
+
+
 def test_bench_two_ranks_share_one_device(tmp_path):
     """`python bench.py --gpus 2` end to end on whatever the box has — self_spawn (torch.distributed.run, two ranks), the unique-id broadcast,
     the Morton tile deal (rank, 2, 1), the film sum onto rank 0 (the library's ncclReduce where there are two devices; gloo through host memory where the

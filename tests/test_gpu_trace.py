@@ -61,6 +61,21 @@ def test_alternative_kernels_bit_exact(gpu, oracle, soup, monkeypatch):
             assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == oracle.trace(sc, rays, any_hit=any_hit).tobytes()
 
 
+def test_round5_kernel_shapes_and_xcd_dealing_bit_exact(gpu, oracle, soup, monkeypatch):
+    """the selectable forms of k_trace_w4 that round 5 measured and left off by default stay bit-identical: XCD-affine ray dealing (RSPT_XCD_DEAL=1: which wave
+    traces which ray changes, no ray's result does), one 1024-thread / two 512-thread workgroups per CU with 512 / 256 root-side records in LDS (RSPT_W4_SHAPE=1 / 2)"""
+    sc, ds = soup
+    rays = random_rays(200000, 77, -1.3, 1.3)
+    ref = {a: oracle.trace(sc, rays, any_hit=a).tobytes() for a in (False, True)}
+    for env in (dict(RSPT_XCD_DEAL="1"), dict(RSPT_W4_SHAPE="1"), dict(RSPT_W4_SHAPE="2"), dict(RSPT_W4_SHAPE="1", RSPT_XCD_DEAL="1")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for any_hit in (False, True):
+            assert gpu.trace(ds, rays, any_hit=any_hit).tobytes() == ref[any_hit], env
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_matches_brute_force(gpu, oracle, soup):
     """BVH result == O(N) scan over all triangles in list order (structural invariant)."""
     sc, ds = soup
