@@ -56,11 +56,12 @@ struct DlHit {
     f3 wo;      // isect.common.wo
     Bsdf bsdf;
 };
+template <uint32_t F = SF_ALL>
 RDEV void dl_interaction(const SceneDev& sc, const PathBuf& pb, uint32_t slot, uint32_t prim, float4 hc, f3 ray_d, DlHit* o) {
     TriRec tri = load_tri(sc, prim);
-    tri_fill(sc, prim, tri, hc.y, hc.z, hc.w, &o->h);
+    tri_fill<(F & SF_VERTEX) != 0>(sc, prim, tri, hc.y, hc.z, hc.w, &o->h);
     o->wo = -ray_d;
-    if (pb.hit_inst) {
+    if ((F & SF_INST) && pb.hit_inst) {
         const uint32_t hi = pb.hit_inst[slot];
         InstDev in{};   // the instance's Transform, a moving one's at the camera sample's time (node slots per sample = sc.time_div while the tree is traced)
         if (hi) in = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[slot / sc.time_div] : 0.0f);
@@ -395,6 +396,7 @@ RDEV bool dl_estimate_samples(const RenderDev& rd, const Batch& bt, const PathBu
 }
 
 // estimate_direct (integrator.rs:406-570) of one light for a built interaction; rays and terms go to virtual slot v.  Returns the DLF_* flags | 0x100.
+template <uint32_t F>   // the feature set the instantiation is compiled for (dev_bsdf.h SF_*: lobe kinds, light kinds, per-vertex normals), as k_shade<F>
 RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d, uint32_t light_num, float choice_pdf, f2 u_light, f2 u_scatter, uint32_t v, bool* want_sh, bool* want_mis) {
     const Hit& h = d.h;
     uint32_t fl = 0;
@@ -404,29 +406,29 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
     f3 wi{0.0f, 0.0f, 0.0f};
     float light_pdf = 0.0f, scattering_pdf = 0.0f;
     LightSample ls;
-    const rgb li = light_sample_li(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
+    const rgb li = light_sample_li<F>(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
     if (light_pdf > 0.0f && !is_black(li)) {
-        const rgb f = d.bsdf.f(d.wo, wi, flags) * mkrgb(absdot(wi, h.sh_n));
-        scattering_pdf = d.bsdf.pdf(d.wo, wi, flags);
+        const rgb f = d.bsdf.template f<F>(d.wo, wi, flags) * mkrgb(absdot(wi, h.sh_n));
+        scattering_pdf = d.bsdf.template pdf<F>(d.wo, wi, flags);
         if (!is_black(f)) {
             const f3 origin = offset_ray_origin(h.p, h.p_err, h.n, ls.p - h.p);
             const f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
             store_ray(pb.ray_sh + v, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, v);
             *want_sh = true;
-            if (light_is_delta(lt)) c1 = f * li / light_pdf;
+            if (light_is_delta<F>(lt)) c1 = f * li / light_pdf;
             else c1 = f * li * mkrgb(power_heuristic(light_pdf, scattering_pdf)) / light_pdf;
             fl |= DLF_HAS_C1;
         }
     }
-    if (!light_is_delta(lt)) {
+    if (!light_is_delta<F>(lt)) {
         uint32_t sampled_type = 0;
-        rgb f = d.bsdf.sample_f(d.wo, &wi, u_scatter, &scattering_pdf, flags, &sampled_type);
+        rgb f = d.bsdf.template sample_f<F>(d.wo, &wi, u_scatter, &scattering_pdf, flags, &sampled_type);
         f = f * mkrgb(absdot(wi, h.sh_n));
         if (!is_black(f) && scattering_pdf > 0.0f) {
             const f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
             float lpdf = 0.0f;
             rgb le_mis = ldrgb(lt.L);
-            if (lt.kind == RSPT_LIGHT_INFINITE) {
+            if ((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) {
                 lpdf = infinite_pdf_li(sc, lt, wi);
                 if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
             } else {
@@ -434,17 +436,17 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
                 float t_l, lb0, lb1, lb2;
                 if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
                     Hit lh;
-                    tri_fill(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
+                    tri_fill<(F & SF_VERTEX) != 0>(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
                     lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
                     if (__builtin_isinf(lpdf)) lpdf = 0.0f;
                 }
             }
             if (lpdf != 0.0f) {
                 c2 = f * le_mis * mkrgb(1.0f) * power_heuristic(scattering_pdf, lpdf) / scattering_pdf;
-                if (lt.kind != RSPT_LIGHT_INFINITE || !is_black(le_mis)) {
+                if (!((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) || !is_black(le_mis)) {
                     store_ray(pb.ray_mis + v, ro, wi, RSPT_INF, v);
                     *want_mis = true;
-                    fl |= DLF_HAS_C2 | (lt.kind == RSPT_LIGHT_INFINITE ? DLF_C2_ON_MISS : 0u);
+                    fl |= DLF_HAS_C2 | (((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) ? DLF_C2_ON_MISS : 0u);
                 }
             }
         }
@@ -455,10 +457,14 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
 }
 
 // nls: n_light_samples per light on the device (nullptr: one each); R = the number of estimates per node = sum_j n_j (sample_all) or 1
-RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_all(SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ pix_list,
-                                                    const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in, const int32_t* __restrict__ nls, uint32_t R,
-                                                    uint32_t n_arrays, uint32_t sample_all, uint32_t* __restrict__ q_any, uint32_t* cnt_any,
-                                                    uint32_t* __restrict__ q_mis, uint32_t* cnt_mis) {
+#define RSPT_DL_NEE_ARGS SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ pix_list, const uint32_t* __restrict__ queue, \
+                         const uint32_t* __restrict__ count_in, const int32_t* __restrict__ nls, uint32_t R, uint32_t n_arrays, uint32_t sample_all,            \
+                         uint32_t* __restrict__ q_any, uint32_t* cnt_any, uint32_t* __restrict__ q_mis, uint32_t* cnt_mis
+template <uint32_t F>
+__device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& rd, const Batch& bt, const PathBuf& pb, const DlBuf& dl, const uint32_t* __restrict__ pix_list,
+                                           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in, const int32_t* __restrict__ nls, uint32_t R,
+                                           uint32_t n_arrays, uint32_t sample_all, uint32_t* __restrict__ q_any, uint32_t* cnt_any,
+                                           uint32_t* __restrict__ q_mis, uint32_t* cnt_mis) {
     const uint32_t n = *count_in;
     const uint32_t nl = sc.n_lights, n_lights_round = sample_all ? nl : 1u;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
@@ -473,7 +479,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_all(SceneDev sc, RenderDe
                 const float4 hc = pb.hit_cont[slot];
                 const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
                 const float4 r0 = rp[0], r1 = rp[1];
-                dl_interaction(sc, pb, slot, __float_as_uint(hc.x), hc, f3{r0.w, r1.x, r1.y}, &d);
+                dl_interaction<F>(sc, pb, slot, __float_as_uint(hc.x), hc, f3{r0.w, r1.x, r1.y}, &d);
             }
         }
         uint32_t r = 0;
@@ -489,7 +495,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_all(SceneDev sc, RenderDe
                         uint32_t light_num;
                         float choice_pdf;
                         if (dl_estimate_samples(rd, bt, pb, dl, pix_list, slot, nl, j, kk, n_j, n_arrays, sample_all, &u_light, &u_scatter, &light_num, &choice_pdf))
-                            fl = dl_estimate(sc, pb, d, light_num, choice_pdf, u_light, u_scatter, v, &want_sh, &want_mis);
+                            fl = dl_estimate<F>(sc, pb, d, light_num, choice_pdf, u_light, u_scatter, v, &want_sh, &want_mis);
                     }
                     dl.nflags[v] = fl;
                 }
@@ -498,6 +504,13 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_all(SceneDev sc, RenderDe
             }
         }
     }
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_dl_nee_all(RSPT_DL_NEE_ARGS) { dl_nee_all<F>(sc, rd, bt, pb, dl, pix_list, queue, count_in, nls, R, n_arrays, sample_all, q_any, cnt_any, q_mis, cnt_mis); }
+template <uint32_t F, int W>   // the same built for W waves per SIMD (a register budget of 512 / W; the compiler spills what does not fit)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void k_dl_nee_all_w(RSPT_DL_NEE_ARGS) {
+    dl_nee_all<F>(sc, rd, bt, pb, dl, pix_list, queue, count_in, nls, R, n_arrays, sample_all, q_any, cnt_any, q_mis, cnt_mis);
 }
 
 RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_resolve_all(SceneDev sc, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,

@@ -668,6 +668,9 @@ ShadeKernel shade_kernel_for(uint32_t need, const char** name_out) {
     return k_shade<SF_ALL>;
 }
 
+#ifndef RSPT_DL_WAVES_DEFAULT
+#define RSPT_DL_WAVES_DEFAULT 0
+#endif
 constexpr int RSPT_DL_RETRY_LANE = -1000;   // batch_direct -> the batch loop: redo this batch with the per-lane form (never leaves render_impl)
 int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, void* film_dev, float* li_host, rspt_stats* stats) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
@@ -1204,7 +1207,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             for (uint32_t l = 0; l < dl_levels; l++) {
                 HIP_TRY(hipMemsetAsync(rc_, 0, sizeof(QueueCounts), g.stream));
                 ev_open(2, 0);
-                hipLaunchKernelGGL(k_dl_nee_all, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R,
+                // the estimate kernel per feature set, as k_shade<F>: scenes of Lambert / microfacet-reflection lobes under area lights without instances (C1 - C3) take the
+                // narrow build (RSPT_DL_VARIANT=generic forces the other)
+                constexpr uint32_t DLV_PLASTIC = SV_PLASTIC | SF_SOBOL | SF_HALTON;
+                const bool dl_narrow = (s->shade_features & ~DLV_PLASTIC) == 0 && !(getenv("RSPT_DL_VARIANT") && !strcmp(getenv("RSPT_DL_VARIANT"), "generic"));
+                const size_t dl_waves = env_size("RSPT_DL_WAVES", RSPT_DL_WAVES_DEFAULT);   // 3: the narrow build forced to 3 waves per SIMD
+                hipLaunchKernelGGL(dl_narrow ? (dl_waves == 3 ? k_dl_nee_all_w<DLV_PLASTIC, 3> : k_dl_nee_all<DLV_PLASTIC>) : k_dl_nee_all<SF_ALL>, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R,
                                    n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest);
                 ev_close(2, 0);
                 ev_open(1, 0);
