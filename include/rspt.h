@@ -316,8 +316,7 @@ typedef struct {
      * AnimatedTransform::motion_bounds (the shim passes the BVH rs_pbrt built; the library never computes them).
      * (A caller that builds the top-level tree itself gets them from rspt_motion_bounds.)
      * Served by all four integrators under the Sobol' / Halton samplers (ABI 21 builds).  RSPT_E_UNSUPPORTED: under the PCG-backed pixel
-     * samplers, under the per-lane form of directlighting (textured materials, max_depth > 8), and — at rspt_scene_create — for a scene that
-     * has both a moving instance and an alpha-masked mesh. */
+     * samplers, under the per-lane form of directlighting (textured materials, max_depth > 8).  Moving instances next to alpha-masked meshes are served. */
     uint32_t animated;
     float to_world_end[16];
     float from_world_end[16];

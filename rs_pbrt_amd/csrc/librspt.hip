@@ -554,7 +554,7 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     uint32_t* hi = (INST && OUT_MODE == 0 && !ANY) ? (g_inst_out ? g_inst_out : g.hit_inst) : nullptr;
     const bool special = INST || ALPHA;
     // moving instances: k_trace_w4<.., INST, 0, ANIM> (round 5; RSPT_ANIM_W4=0: the reference-order loop with the interpolation, as before)
-    const bool anim_w4 = s->has_animated && s->w4_ok && which >= 2 && env_size("RSPT_ANIM_W4", 1) != 0 && env_size("RSPT_INSTANCE_KERNEL", 1) != 0;
+    const bool anim_w4 = s->has_animated && s->w4_ok && ((which >= 2 && env_size("RSPT_ANIM_W4", 1) != 0 && env_size("RSPT_INSTANCE_KERNEL", 1) != 0) || (ALPHA && !count));   // (with masks: the only form)
     const bool slow = count || which == 0 || (s->has_animated && !anim_w4) || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
     if (slow) {
         if (INST && !ALPHA && s->has_animated)   // moving instances: the reference-order loop with the interpolation (its own instantiation; no node / triangle counters)
@@ -569,11 +569,15 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
     uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
     const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
-    if constexpr (INST && !ALPHA) {
-        if (anim_w4) {
-            hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, true, 0, true>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
-            hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, true, false, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
+    if constexpr (INST) {
+        if (anim_w4) {   // moving instances; next to alpha-masked meshes the masks in line (ALPHA = 2) where every mask allows it, else through alpha_pass
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
+            };
+            if constexpr (ALPHA) { if (s->alpha_simple) go(k_trace_w4<ANY, OUT_MODE, true, 2, true>); else go(k_trace_w4<ANY, OUT_MODE, true, 1, true>); }
+            else go(k_trace_w4<ANY, OUT_MODE, true, 0, true>);
+            hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, true, ALPHA, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
             return;
         }
     }
@@ -2425,7 +2429,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
             }
         }
         if (!anims.empty()) {
-            if (s->has_alpha) return bail(fail(RSPT_E_UNSUPPORTED, "moving object instances together with alpha-masked meshes"));
+            if (s->has_alpha && !s->w4_ok) return bail(fail(RSPT_E_UNSUPPORTED, "moving object instances together with alpha-masked meshes in a scene whose records outgrow the four-box kernel"));
             if ((rc = upload(s, anims.data(), anims.size(), &s->dev.inst_anim))) return bail(rc);
             s->has_animated = true;
             s->shade_features |= SF_ANIM;

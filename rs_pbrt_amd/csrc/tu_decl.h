@@ -27,10 +27,13 @@ constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                              
 #define RSPT_TU_W4(ANY, OM, I, A) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, I, A>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
                                                                   const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);
-#define RSPT_TU_W4A(ANY, OM) \
-    RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, true, 0, true>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
-                                                                           const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*); \
-    RSPT_TU_X template __global__ void k_trace_fixup<ANY, OM, true, false, true>(SceneDev, TexTables, const uint32_t*, const uint32_t*, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*);   /* moving instances */
+#define RSPT_TU_W4A1(ANY, OM, A) \
+    RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, true, A, true>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
+                                                                           const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);
+#define RSPT_TU_W4AF(ANY, OM, A) \
+    RSPT_TU_X template __global__ void k_trace_fixup<ANY, OM, true, A, true>(SceneDev, TexTables, const uint32_t*, const uint32_t*, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*);
+#define RSPT_TU_W4A(ANY, OM) RSPT_TU_W4A1(ANY, OM, 0) RSPT_TU_W4AF(ANY, OM, false)   /* moving instances */
+#define RSPT_TU_W4AM(ANY, OM) RSPT_TU_W4A1(ANY, OM, 1) RSPT_TU_W4A1(ANY, OM, 2) RSPT_TU_W4AF(ANY, OM, true)   /* moving instances next to alpha-masked meshes */
 #define RSPT_TU_W4B(ANY, OM, B, T) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, false, 0, false, B, T>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
                                                                                    const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);   /* big workgroups, big LDS top */
@@ -108,6 +111,9 @@ RSPT_TU_W4_S(false, 0) RSPT_TU_W4_S(false, 1) RSPT_TU_W4_S(true, 0) RSPT_TU_W4_S
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4A)
 RSPT_TU_W4A(false, 0) RSPT_TU_W4A(false, 1) RSPT_TU_W4A(true, 0) RSPT_TU_W4A(true, 1)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4AM)
+RSPT_TU_W4AM(false, 0) RSPT_TU_W4AM(false, 1) RSPT_TU_W4AM(true, 0) RSPT_TU_W4AM(true, 1)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4B)
 RSPT_TU_W4B(false, 0, 1024, 512) RSPT_TU_W4B(false, 1, 1024, 512) RSPT_TU_W4B(true, 0, 1024, 512) RSPT_TU_W4B(true, 1, 1024, 512)

@@ -11,7 +11,7 @@ from tests.util import film_rmse, random_rays
 LOOK = ((0, 2.0, -5.0), (0, 1.0, 0), (0, 1, 0))
 
 
-def masked_scene(builder, cut=False, shadow_only=False, instanced=False, mode="fixed", plain=False):
+def masked_scene(builder, cut=False, shadow_only=False, instanced=False, mode="fixed", plain=False, moving=False):
     """a wall, a floor, a light, and a 2 x 2 m panel in front of the wall whose 4 x 4 checker alpha texture (constants 0 / 1) removes every
     other cell.  (No surface lies on a boundary of the 64-voxel light-distribution grid: chosen when the device library's sinf / cosf still moved bounce-ray
     hit points by an ulp, which on a boundary picks the neighbouring voxel's distribution — DESIGN.md §3; no longer needed.)  cut=True: the same panel modelled as the eight remaining cells (no texture) — the first-principles twin.
@@ -41,6 +41,11 @@ def masked_scene(builder, cut=False, shadow_only=False, instanced=False, mode="f
         sb.add_mesh(np.array(panel, np.float32) - np.array([0, 0, z], np.float32), [[0, 1, 2], [0, 2, 3]], red, UV=uv, **kw)
         sb.add_mesh(np.array([(-0.2, 0, 0.3), (0.2, 0, 0.3), (0, 0.4, 0.3)], np.float32), [[0, 1, 2]], red)
         sb.end_object()
+        if moving:   # (round 5) the masked panels MOVE over the shutter: one turns (slerp), one slides and grows
+            T = scenes.Transform
+            sb.add_instance("panel", T.translate((0, 0, z)) * T.rotate_y(8.0), T.translate((0.3, 0.1, z)) * T.rotate_y(40.0))
+            sb.add_instance("panel", T.translate((2.6, 0.3, 0.5)) * T.scale(0.6, 0.8, 1.0), T.translate((2.2, 0.5, 0.7)) * T.scale(0.8, 0.9, 1.0))
+            return sb.finish(builder, instancing=mode)
         sb.add_instance("panel", scenes.Transform.translate((0, 0, z)) * scenes.Transform.rotate_y(8.0))
         sb.add_instance("panel", scenes.Transform.translate((2.6, 0.3, 0.5)) * scenes.Transform.scale(0.6, 0.8, 1.0))
         return sb.finish(builder, instancing=mode)
@@ -241,3 +246,26 @@ def test_gpu_per_lane_kernels_with_inline_alpha_masks(gpu, oracle, kw, monkeypat
             assert film_rmse(film, ref["film"]) < 2e-5, (form, simple)
             films.append(film)
         assert np.array_equal(films[-1], films[-2]), form   # one lane per tile / per camera sample: the accumulation order is fixed, the two evaluators agree bit for bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,integrator", [("fixed", "path"), ("reference", "path"), ("fixed", "volpath"), ("fixed", "directlighting")])
+def test_moving_instances_of_alpha_masked_meshes(gpu, oracle, mode, integrator):
+    """round 5: a moving TransformedPrimitive whose object carries an alpha mask (primitive.rs:216-265 around triangle.rs:313-330): k_trace_w4<INST, ALPHA, ANIM> — the mask
+    test is a function of the hit's uv, whatever Transform the instance was entered with.  Per-sample radiance bit for bit; rspt_scene_create used to refuse the scene."""
+    sc = masked_scene(gpu.bvh_build, instanced=True, mode=mode, moving=True)
+    assert int(sc.instances["animated"].sum()) == 2
+    kw = dict(integrator=integrator)
+    if integrator == "directlighting":
+        kw.update(direct_strategy="all", light_samples=[1] * sc.desc.n_lights)
+    rd = scenes.make_render_desc(80, 60, 8, LOOK, 45.0, shutter=(0.0, 1.0), **kw)
+    with gpu.DeviceScene(sc) as ds:
+        film, st = gpu.render(ds, rd)
+        li, _ = gpu.render_samples(ds, rd)
+    ref = (oracle.render_integrator(sc, rd, "direct", strategy="all", light_samples=kw["light_samples"], threads=8, want_li=True) if integrator == "directlighting"
+           else oracle.render(sc, rd, threads=8, want_li=True))
+    assert st["samples"] == ref["counters"]["samples"] and st["nan_samples"] == 0
+    assert np.array_equal(film[:, 3], ref["film"][:, 3]) and np.array_equal(li, ref["li"])
+    still = oracle.render(sc, scenes.make_render_desc(80, 60, 8, LOOK, 45.0, shutter=(0.0, 0.0)), threads=8) if integrator == "path" else None
+    if still is not None:
+        assert np.abs(scenes.film_to_rgb(film) - scenes.film_to_rgb(still["film"])).mean() > 1e-4   # the motion is in the picture

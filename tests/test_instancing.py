@@ -419,7 +419,7 @@ def test_gpu_moving_instances_under_the_other_integrators(gpu, oracle, integrato
 @pytest.mark.gpu
 def test_gpu_moving_instances_are_refused_where_not_served(gpu):
     """the per-lane kernels carry no interpolation: the PCG-backed pixel samplers and the per-lane form of directlighting (textured materials) answer
-    RSPT_E_UNSUPPORTED for a scene with a moving instance, as do moving instances next to alpha-masked meshes (rspt_scene_create)"""
+    RSPT_E_UNSUPPORTED for a scene with a moving instance (moving instances next to alpha-masked meshes are served since round 5: tests/test_alpha_masks.py)"""
     from rs_pbrt_amd.lib import RsptError
     sc = moving_scene(gpu.bvh_build, rotation=False)
     with gpu.DeviceScene(sc) as ds:
