@@ -539,6 +539,11 @@ uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
 // One launch of the traversal stage.  Kernel choice: scenes with object instances or alpha-masked meshes take the <INST, ALPHA>
 // instantiations (template flags, so that the plain kernels stay the ones measured in DESIGN.md); counters and RSPT_TRACE_KERNEL=0
 // use the reference-order loop; a scene whose records outgrow the four-box reference fields stays on the two-box kernel.
+#ifndef RSPT_PW_CHUNK_CAMERA_DEFAULT
+#define RSPT_PW_CHUNK_CAMERA_DEFAULT 1024   // measured on the C3 stand-in, same box, alternating: 256 -> 2025 / 2029, 1024 -> 2075 / 2070, 4096 -> 2024 / 2030, 16384 -> 1900 Msamples/s
+                                            // (C2: 473.9 / 473.3 / 471.1 at 256 / 1024 / 4096); the incoherent launches keep 256 (512: C3 2061 with the camera launch at 1024)
+#endif
+bool g_camera_launch = false;
 template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
 void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                     const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters, uint32_t* xcur) {
@@ -566,6 +571,9 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
         return;
     }
     const uint32_t pgrid = hinted_grid(pw_grid(), RSPT_PW_BLOCK);
+    // rays a wave claims per global atomic: 256 for the incoherent launches; the camera-ray launch of a batch (pixel-major queue: a chunk is a run of samples of one pixel
+    // or its neighbours) takes RSPT_PW_CHUNK_CAMERA (g_camera_launch is set around that launch by the path integrator's loop)
+    const uint32_t pw_chunk = (uint32_t)std::min<size_t>(std::max<size_t>((g_camera_launch ? env_size("RSPT_PW_CHUNK_CAMERA", RSPT_PW_CHUNK_CAMERA_DEFAULT) : env_size("RSPT_PW_CHUNK", RSPT_PW_CHUNK)) & ~(size_t)63, 64), 1u << 20);
     grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
     uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
     const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
@@ -573,7 +581,7 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
         if (anim_w4) {   // moving instances; next to alpha-masked meshes the masks in line (ALPHA = 2) where every mask allows it, else through alpha_pass
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
+                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
             };
             if constexpr (ALPHA) { if (s->alpha_simple) go(k_trace_w4<ANY, OUT_MODE, true, 2, true>); else go(k_trace_w4<ANY, OUT_MODE, true, 1, true>); }
             else go(k_trace_w4<ANY, OUT_MODE, true, 0, true>);
@@ -593,7 +601,7 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
                 if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
                 const uint32_t bgrid = hinted_grid(grid_for(per_cu), block);
                 hipLaunchKernelGGL(kern, dim3(bgrid), dim3(block), lds, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
+                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
             };
             if (shape == 1) go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 1024, 512>, 1024u, 512u, 1u);
             else go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 512, 256>, 512u, 256u, 2u);
@@ -604,10 +612,10 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     }
     if (ALPHA && s->alpha_simple)   // every mask of the scene is evaluated in line (kernels.h alpha_simple): the traversal keeps its register budget
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 2 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
     else if (special || (which >= 2 && s->w4_ok))
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 1 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur);
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
     else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
                            (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
@@ -1327,7 +1335,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 HIP_TRY(hipEventRecord(ev_join, g.stream2));
             }
             ev_open(0, 0);
+            g_camera_launch = it == 0;
             launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals, g.cnt[it].xcd_closest);
+            g_camera_launch = false;
             ev_close(0, 0);
             if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
             else if (it > 0) {

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
                                                            rspt_hit* __restrict__ out_hits, uint32_t* n_overflow, uint32_t* __restrict__ overflow_list,
                                                            uint2* __restrict__ spill, uint32_t spill_rows, int refill_thresh, int leaf_thresh, uint32_t n_top,
-                                                           uint32_t* __restrict__ out_inst, uint32_t* xcd_cursors) {
+                                                           uint32_t* __restrict__ out_inst, uint32_t* xcd_cursors, uint32_t chunk /* rays a wave claims per global atomic (a multiple of 64) */) {
     uint2* stack;
     float4* top;   // top[j * TOPCAP + r] = j-th 16 bytes of record r (neighbouring records in neighbouring banks)
     if constexpr (8 * RSPT_W4_LDS * BLOCK + 112 * TOPCAP <= 64 * 1024) {   // the static form (the kernels measured since round 2 keep their code)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
         uint32_t id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
         xcc = id & 7u;
-        per_xcd = (uint32_t)((((uint64_t)n + 8ull * RSPT_PW_CHUNK - 1ull) / (8ull * RSPT_PW_CHUNK)) * RSPT_PW_CHUNK);
+        per_xcd = (uint32_t)((((uint64_t)n + 8ull * chunk - 1ull) / (8ull * chunk)) * chunk);
     }
     // per-lane ray state
     bool active = false;
@@ -232,21 +232,21 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
                         const uint32_t lo = lo64 < n ? (uint32_t)lo64 : n, hi = hi64 < n ? (uint32_t)hi64 : n;
                         if (lo == hi) continue;
                         uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(xcd_cursors + x, (uint32_t)RSPT_PW_CHUNK);
+                        if (lane == 0) base = atomicAdd(xcd_cursors + x, chunk);
                         base = __builtin_amdgcn_readfirstlane(base);
                         if (base < hi - lo) {
                             chunk_lo = lo + base;
-                            chunk_hi = (hi - lo - base) > RSPT_PW_CHUNK ? chunk_lo + RSPT_PW_CHUNK : hi;
+                            chunk_hi = (hi - lo - base) > chunk ? chunk_lo + chunk : hi;
                             break;
                         }
                     }
                     if (victim == 8u) exhausted = true;
                 } else {
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(cursor, (uint32_t)RSPT_PW_CHUNK);
+                    if (lane == 0) base = atomicAdd(cursor, chunk);
                     base = __builtin_amdgcn_readfirstlane(base);
                     chunk_lo = base < n ? base : n;
-                    chunk_hi = (base + RSPT_PW_CHUNK) < n ? (base + RSPT_PW_CHUNK) : n;
+                    chunk_hi = (base + chunk) < n ? (base + chunk) : n;
                     if (chunk_lo == chunk_hi) exhausted = true;
                 }
             }

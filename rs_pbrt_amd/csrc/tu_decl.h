@@ -26,17 +26,17 @@ constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                              
 #define RSPT_TU_SHADE_W(F, W) RSPT_TU_X template __global__ void k_shade_w<F, W>(RSPT_SHADE_ARGS);
 #define RSPT_TU_W4(ANY, OM, I, A) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, I, A>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
-                                                                  const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);
+                                                                  const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*, uint32_t);
 #define RSPT_TU_W4A1(ANY, OM, A) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, true, A, true>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
-                                                                           const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);
+                                                                           const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*, uint32_t);
 #define RSPT_TU_W4AF(ANY, OM, A) \
     RSPT_TU_X template __global__ void k_trace_fixup<ANY, OM, true, A, true>(SceneDev, TexTables, const uint32_t*, const uint32_t*, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*);
 #define RSPT_TU_W4A(ANY, OM) RSPT_TU_W4A1(ANY, OM, 0) RSPT_TU_W4AF(ANY, OM, false)   /* moving instances */
 #define RSPT_TU_W4AM(ANY, OM) RSPT_TU_W4A1(ANY, OM, 1) RSPT_TU_W4A1(ANY, OM, 2) RSPT_TU_W4AF(ANY, OM, true)   /* moving instances next to alpha-masked meshes */
 #define RSPT_TU_W4B(ANY, OM, B, T) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, false, 0, false, B, T>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
-                                                                                   const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*);   /* big workgroups, big LDS top */
+                                                                                   const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*, uint32_t);   /* big workgroups, big LDS top */
 #define RSPT_TU_W4_4(ANY, OM) RSPT_TU_W4(ANY, OM, false, 0) RSPT_TU_W4(ANY, OM, false, 1) RSPT_TU_W4(ANY, OM, true, 0) RSPT_TU_W4(ANY, OM, true, 1)
 #define RSPT_TU_W4_S(ANY, OM) RSPT_TU_W4(ANY, OM, false, 2) RSPT_TU_W4(ANY, OM, true, 2)   /* alpha masks evaluated in line (alpha_simple) */
 #define RSPT_TU_REF(ANY, OM, C, I, A) \
