@@ -543,6 +543,9 @@ uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
 #define RSPT_PW_CHUNK_CAMERA_DEFAULT 1024   // measured on the C3 stand-in, same box, alternating: 256 -> 2025 / 2029, 1024 -> 2075 / 2070, 4096 -> 2024 / 2030, 16384 -> 1900 Msamples/s
                                             // (C2: 473.9 / 473.3 / 471.1 at 256 / 1024 / 4096); the incoherent launches keep 256 (512: C3 2061 with the camera launch at 1024)
 #endif
+#ifndef RSPT_PW_REFILL_CAMERA_DEFAULT
+#define RSPT_PW_REFILL_CAMERA_DEFAULT 48   // a wave of coherent camera rays refills when three quarters of its lanes are idle (the incoherent launches: RSPT_PW_REFILL = 16)
+#endif
 bool g_camera_launch = false;
 template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
 void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
@@ -573,6 +576,10 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     const uint32_t pgrid = hinted_grid(pw_grid(), RSPT_PW_BLOCK);
     // rays a wave claims per global atomic: 256 for the incoherent launches; the camera-ray launch of a batch (pixel-major queue: a chunk is a run of samples of one pixel
     // or its neighbours) takes RSPT_PW_CHUNK_CAMERA (g_camera_launch is set around that launch by the path integrator's loop)
+    // refill / leaf-phase thresholds; the camera-ray launch may take its own (RSPT_PW_REFILL_CAMERA / RSPT_PW_LEAF_CAMERA: coherent rays reach their leaves together)
+    // (camera launch, C3 stand-in, one box, alternating: refill 16 -> 2079 / 2067 Msamples/s, 32 -> 2083 / 2083, 48 -> 2114 / 2113, 64 -> 2105 / 2101; leaf 16 / 24 / 32 at refill 16: 2061 / 2059 / 2046)
+    const int pw_refill = (int)(g_camera_launch ? env_size("RSPT_PW_REFILL_CAMERA", RSPT_PW_REFILL_CAMERA_DEFAULT) : env_size("RSPT_PW_REFILL", RSPT_PW_REFILL));
+    const int pw_leaf = (int)(g_camera_launch ? env_size("RSPT_PW_LEAF_CAMERA", env_size("RSPT_PW_LEAF", RSPT_PW_LEAF)) : env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
     const uint32_t pw_chunk = (uint32_t)std::min<size_t>(std::max<size_t>((g_camera_launch ? env_size("RSPT_PW_CHUNK_CAMERA", RSPT_PW_CHUNK_CAMERA_DEFAULT) : env_size("RSPT_PW_CHUNK", RSPT_PW_CHUNK)) & ~(size_t)63, 64), 1u << 20);
     grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
     uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
@@ -581,7 +588,7 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
         if (anim_w4) {   // moving instances; next to alpha-masked meshes the masks in line (ALPHA = 2) where every mask allows it, else through alpha_pass
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
+                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, pw_refill, pw_leaf, s->w4_top, hi, xcur, pw_chunk);
             };
             if constexpr (ALPHA) { if (s->alpha_simple) go(k_trace_w4<ANY, OUT_MODE, true, 2, true>); else go(k_trace_w4<ANY, OUT_MODE, true, 1, true>); }
             else go(k_trace_w4<ANY, OUT_MODE, true, 0, true>);
@@ -601,7 +608,7 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
                 if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
                 const uint32_t bgrid = hinted_grid(grid_for(per_cu), block);
                 hipLaunchKernelGGL(kern, dim3(bgrid), dim3(block), lds, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
+                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, pw_refill, pw_leaf, s->w4_top, hi, xcur, pw_chunk);
             };
             if (shape == 1) go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 1024, 512>, 1024u, 512u, 1u);
             else go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 512, 256>, 512u, 256u, 2u);
@@ -612,13 +619,13 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     }
     if (ALPHA && s->alpha_simple)   // every mask of the scene is evaluated in line (kernels.h alpha_simple): the traversal keeps its register budget
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 2 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, pw_refill, pw_leaf, s->w4_top, hi, xcur, pw_chunk);
     else if (special || (which >= 2 && s->w4_ok))
         hipLaunchKernelGGL((k_trace_w4<ANY, OUT_MODE, INST, ALPHA ? 1 : 0>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF), s->w4_top, hi, xcur, pw_chunk);
+                           ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, pw_refill, pw_leaf, s->w4_top, hi, xcur, pw_chunk);
     else
         hipLaunchKernelGGL((k_trace_pw<ANY, OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->pairs, queue, count_ptr, count_imm, cursor, ra, rb, oa, ob, occ, hits, n_overflow, ovf,
-                           (int)env_size("RSPT_PW_REFILL", RSPT_PW_REFILL), (int)env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
+                           pw_refill, pw_leaf);
     // with every spill row in use the plain four-box kernel cannot overflow (RSPT_W4_MAX_STACK): no second pass to launch
     if (trace_can_overflow(s))
         hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
