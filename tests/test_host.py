@@ -191,3 +191,58 @@ def test_transform_bounds_divides_by_the_homogeneous_weight():
     m[3] = [1e-3, 0, 0, 1]   # the weight grows with x: the far corners shrink more than the near ones
     c_lo, c_hi = scenes._transform_bounds(m, lo, hi)
     assert np.allclose(c_lo, [1 / 1.001, 2 / 1.002, 3 / 1.002], rtol=1e-6) and np.allclose(c_hi, [2 / 1.002, 4 / 1.001, 6 / 1.001], rtol=1e-6)
+
+
+def test_bench_cpu_legs_use_the_cores_the_container_may_use(tmp_path, monkeypatch):
+    """bench.effective_cores: the affinity mask cut by the cgroup CPU quota (the GPU boxes show 256 logical CPUs to a container allowed 16 CPUs' worth of time;
+    rounds 1 - 4 reported the 256).  The function is checked against made-up cgroup files through the paths it reads."""
+    import builtins
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n_aff = len(os.sched_getaffinity(0))
+    real_open = builtins.open
+    fake = {}
+
+    def fake_open(path, *a, **kw):
+        if path in fake:
+            if fake[path] is None:
+                raise OSError(path)
+            p = tmp_path / ("f%d" % (abs(hash(path)) % 10**8))
+            p.write_text(fake[path])
+            return real_open(p, *a, **kw)
+        return real_open(path, *a, **kw)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    fake["/sys/fs/cgroup/cpu.max"] = "1600000 100000\n"
+    assert bench.effective_cores() == min(16, n_aff)
+    fake["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert bench.effective_cores() == n_aff
+    fake["/sys/fs/cgroup/cpu.max"] = "150000 100000\n"           # a quota of 1.5 CPUs: two threads
+    assert bench.effective_cores() == min(2, n_aff)
+    fake["/sys/fs/cgroup/cpu.max"] = None                        # cgroup v1
+    fake["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "-1\n"; fake["/sys/fs/cgroup/cpu/cpu.cfs_period_us"] = "100000\n"
+    assert bench.effective_cores() == n_aff
+    fake["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "400000\n"
+    assert bench.effective_cores() == min(4, n_aff)
+
+
+def test_bench_with_ranks_fails_loudly_without_a_device():
+    """`python bench.py --gpus 2` on a host without a gfx950 device: every rank's rspt_init fails, the launcher returns non-zero within seconds (no hang, no
+    JSON line, no fallback to anything) — the watchdog and the self-spawn path on the failure side"""
+    import subprocess
+    import sys
+    import time
+    from rs_pbrt_amd import lib
+    try:
+        lib.init(0)
+        lib.shutdown()
+        pytest.skip("a GPU is present")
+    except lib.RsptError:
+        pass
+    bench_py = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--workload", "cornell", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--no-count", "--watchdog", "100"],
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0 and time.time() - t0 < 200
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
+    assert "failed" in r.stderr.lower() or "error" in r.stderr.lower(), r.stderr[-2000:]   # (the ranks die at the first device call: torch's or librspt's)
