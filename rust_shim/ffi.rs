@@ -88,6 +88,12 @@ extern "C" {
     pub fn rspt_comm_unique_id(id: *mut u8) -> c_int;                              // 128 bytes
     pub fn rspt_comm_init(rank: i32, world: i32, id: *const u8) -> c_int;
     pub fn rspt_comm_destroy() -> c_int;
+    pub fn rspt_comm_library() -> *const c_char;                                   // which librccl the calls above are bound to (ABI 21)
+    pub fn rspt_source_hash() -> *const c_char;                                    // hash of the kernel sources compiled into the library (ABI 21)
+    // AnimatedTransform::motion_bounds (transform.rs:2147-2210) on the host, for a caller that builds the top-level tree itself; the shim passes rs_pbrt's own BVH and
+    // does not need it (ABI 21)
+    pub fn rspt_motion_bounds(start_m: *const f32, start_time: f32, end_m: *const f32, end_time: f32, box_min: *const f32, box_max: *const f32,
+                              out_min: *mut f32, out_max: *mut f32, flags_out: *mut i32) -> c_int;
     pub fn rspt_last_error() -> *const c_char;
     pub fn rspt_libm(func: u32, x: *const f32, y: *const f32, n: u64, out: *mut f32) -> c_int;   // 0 sin 1 cos 2 ln 3 log2 4 exp 5 acos 6 atan2(x, y)
     pub fn rspt_bvh_build_gpu(p: *const f32, n_vertices: u64, tri_idx: *const u32, n_tris: u64, max_prims_in_node: u32,
