@@ -158,3 +158,59 @@ def test_committed_fixture_is_what_the_references_text_gives():
         pytest.skip("the reference tree is not on this machine: the committed fixture is what travels")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_motion_fixture.py"), "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_fuzz_product_against_oracle_and_against_the_motion(oracle):
+    """400 seeded key pairs beyond the fixture's families — tiny and half-turn rotations, mirrored and sheared scales, far translations, key times anywhere, thin boxes:
+    librspt's box equals the oracle's within the edge tolerance (both follow the reference's root isolation; the coefficients come from f64 there, f32 here) and contains
+    the corners' motion sampled through the oracle's interpolate.  A refusal (a ninth zero: the reference panics there) must be shared by both."""
+    rng = np.random.default_rng(0xF022)
+
+    def rot(axis, ang):
+        x, y, z = axis / np.linalg.norm(axis)
+        c, s = np.cos(ang), np.sin(ang)
+        return np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s], [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                         [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+    refused = 0
+    worst = 0.0
+    for it in range(400):
+        def key():
+            m = np.eye(4)
+            kind = rng.integers(0, 5)
+            ang = [rng.uniform(0, 1e-3), rng.uniform(0.01, 0.05), rng.uniform(0.05, 3.1), np.pi - rng.uniform(0, 1e-3), rng.uniform(0, 6.28)][kind]
+            sc = np.diag(rng.uniform(0.05, 20.0, 3) * (rng.choice([-1.0, 1.0], 3) if it % 11 == 0 else 1.0))
+            if it % 4 == 1:
+                sc = sc + rng.uniform(-0.5, 0.5, (3, 3))
+            m[:3, :3] = rot(rng.normal(size=3), ang) @ sc
+            m[:3, 3] = rng.uniform(-1, 1, 3) * (10.0 ** rng.integers(0, 4))
+            return m.astype(np.float32)
+        a, b = key(), key()
+        if it % 9 == 0:
+            b[:3, :3] = a[:3, :3]                                   # the same rotation and scale, another place: "no rotation"
+        lo = rng.uniform(-3, 1, 3).astype(np.float32)
+        hi = (lo + rng.uniform(0, 4, 3) * (rng.uniform(0, 1, 3) > 0.15)).astype(np.float32)   # some boxes are flat
+        t0 = float(np.float32(rng.uniform(-2, 1))); t1 = float(np.float32(t0 + rng.uniform(0.1, 3)))
+        try:
+            plo, phi, animated, has_rot = lib.motion_bounds(a, t0, b, t1, lo, hi)
+        except lib.RsptError as e:
+            assert e.code == -4, e      # RSPT_E_UNSUPPORTED: a ninth zero
+            with pytest.raises(AssertionError):
+                oracle.motion_bounds(a, t0, b, t1, lo, hi)
+            refused += 1
+            continue
+        olo, ohi, _, _, oa, orot = oracle.motion_bounds(a, t0, b, t1, lo, hi)
+        assert (animated, has_rot) == (oa, orot)
+        e = max(_extent(olo, ohi), 1e-30)
+        d = max(float(np.abs(plo - olo).max()), float(np.abs(phi - ohi).max())) / e
+        worst = max(worst, d)
+        assert d <= 2e-5, (it, d, plo, olo, phi, ohi)
+        # (keys with a reflection — the reference's `XXX TODO FIXME deal with flip` in decompose, transform.rs:2067 — decompose into an improper "rotation" whose quaternion does
+        #  not reproduce it: interpolate() then jumps at the key times and the reference's own motion_bounds does not bound it; there only product == oracle is asked for)
+        if it % 8 == 0 and it % 11 != 0:
+            corners = np.array([[(hi if c & 1 else lo)[0], (hi if c & 2 else lo)[1], (hi if c & 4 else lo)[2], 1.0] for c in range(8)])
+            for tt in np.linspace(t0, t1, 60):
+                m = oracle.interpolate_transform(a, t0, b, t1, float(tt)).astype(np.float64)
+                p = corners @ m.T
+                p = p[:, :3] / p[:, 3:4]
+                assert (p.min(0) >= plo - 1e-4 * e).all() and (p.max(0) <= phi + 1e-4 * e).all(), (it, tt)
+    assert refused <= 4, refused
