@@ -583,6 +583,11 @@ const char* rspt_source_hash(void);
  * (quaternion dot >= 0.9995): the union of the two keys' boxes; else per corner the union of the two end points and of the point at every
  * zero of the motion derivative (root isolation as the reference does it, in f32; the derivative's coefficients come from a matrix form
  * of the reference's expanded DerivativeTerm polynomials, :944-2030, evaluated in double precision — csrc/motion_bounds.h).
+ * TOLERANCE (not bit-exact): edges that come from a key position equal the reference's bit for bit; an edge pushed out by a velocity zero
+ * is located from coefficients that differ from the reference's f32 sums in their last bits (within 5e-7 of the box's largest extent,
+ * either way round) and is then moved OUTWARD by 1e-6 of that extent (RSPT_MOTION_PAD): the result always CONTAINS the reference's box and
+ * exceeds it by at most 1.5e-6 of the extent.  A top-level BVH built from these boxes may therefore split differently from rs_pbrt's own
+ * (SAH bucket edges); a caller that needs rs_pbrt's exact tree passes the tree rs_pbrt built (rust_shim/gpu.rs does).
  * *flags_out (may be NULL): bit 0 = actually_animated, bit 1 = has_rotation.  RSPT_E_UNSUPPORTED where the reference would panic (a ninth
  * zero for one point and component), RSPT_E_INVALID for non-finite input. */
 int rspt_motion_bounds(const float start_m[16], float start_time, const float end_m[16], float end_time, const float box_min[3],

@@ -417,6 +417,9 @@ int ensure_spill(size_t threads) {
 // persistent trace grid = what is resident: k_trace_w4 fits five 256-thread workgroups per CU (93 VGPRs, 30 KB LDS); more only
 // adds workgroups that start at the tail, copy the root-side records and find the queue empty (8 -> 5: C3 +0.6 %)
 uint32_t pw_grid() { return grid_for((uint32_t)env_size("RSPT_PW_BLOCKS_PER_CU", 5)); }
+// threads of the widest persistent trace launch any selectable shape can make (spill rows are addressed [row][thread]): the default shape's pw_grid() x 256, or the
+// 1024 threads per CU of RSPT_W4_SHAPE = 1 / 2 — whichever is larger (with RSPT_PW_BLOCKS_PER_CU < 4 the big shapes indexed past the rows sized for the default)
+size_t pw_spill_threads() { return std::max<size_t>((size_t)pw_grid() * RSPT_PW_BLOCK, (size_t)grid_for(1) * 1024u); }
 
 int ensure_counts(uint32_t n) {
     if (g.n_cnt >= n) return RSPT_OK;
@@ -562,11 +565,11 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     uint32_t* hi = (INST && OUT_MODE == 0 && !ANY) ? (g_inst_out ? g_inst_out : g.hit_inst) : nullptr;
     const bool special = INST || ALPHA;
     // moving instances: k_trace_w4<.., INST, 0, ANIM> (round 5; RSPT_ANIM_W4=0: the reference-order loop with the interpolation, as before)
-    const bool anim_w4 = s->has_animated && s->w4_ok && ((which >= 2 && env_size("RSPT_ANIM_W4", 1) != 0 && env_size("RSPT_INSTANCE_KERNEL", 1) != 0) || (ALPHA && !count));   // (with masks: the only form)
+    const bool anim_w4 = s->has_animated && s->w4_ok && which >= 2 && env_size("RSPT_ANIM_W4", 1) != 0 && env_size("RSPT_INSTANCE_KERNEL", 1) != 0;   // (round 6: the reference-order loop serves moving instances next to masks too, so every A/B switch stays bit-exact)
     const bool slow = count || which == 0 || (s->has_animated && !anim_w4) || (special && (!s->w4_ok || env_size("RSPT_INSTANCE_KERNEL", 1) == 0));
     if (slow) {
-        if (INST && !ALPHA && s->has_animated)   // moving instances: the reference-order loop with the interpolation (its own instantiation; no node / triangle counters)
-            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, true, false, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
+        if (INST && s->has_animated)   // moving instances (alone or next to alpha-masked meshes): the reference-order loop with the interpolation (its own instantiations; no node / triangle counters)
+            hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, false, true, ALPHA, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
         else if (count)
             hipLaunchKernelGGL((k_trace<ANY, OUT_MODE, true, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, queue, count_ptr, count_imm, ra, rb, oa, ob, occ, hits, counters, hi);
         else
@@ -601,20 +604,25 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
         // 2 = two 512-thread workgroups with 256 records each (trace_w4.h BLOCK / TOPCAP; dynamic LDS, 152 KB per CU either way)
         const size_t shape = which >= 2 && s->w4_ok ? env_size("RSPT_W4_SHAPE", RSPT_W4_SHAPE_DEFAULT) : 0;
         if (shape == 1 || shape == 2) {
-            auto go = [&](auto kern, uint32_t block, uint32_t topcap, uint32_t per_cu) {
+            auto go = [&](auto kern, uint32_t block, uint32_t topcap, uint32_t per_cu) -> bool {
                 const size_t lds = (size_t)8 * RSPT_W4_LDS * block + (size_t)112 * topcap;
                 static bool attr_set[2][2][2][3] = {};
                 bool& done = attr_set[ANY ? 1 : 0][OUT_MODE ? 1 : 0][0][shape];
-                if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+                static bool attr_bad[2][2][2][3] = {};
+                bool& bad = attr_bad[ANY ? 1 : 0][OUT_MODE ? 1 : 0][0][shape];
+                if (!done) { bad = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess; (void)hipGetLastError(); done = true; }
+                if (bad) return false;   // the device refuses that much dynamic LDS: the default shape serves the launch
                 const uint32_t bgrid = hinted_grid(grid_for(per_cu), block);
                 hipLaunchKernelGGL(kern, dim3(bgrid), dim3(block), lds, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
                                    ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, pw_refill, pw_leaf, s->w4_top, hi, xcur, pw_chunk);
+                return true;
             };
-            if (shape == 1) go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 1024, 512>, 1024u, 512u, 1u);
-            else go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 512, 256>, 512u, 256u, 2u);
-            if (trace_can_overflow(s))
-                hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
-            return;
+            const bool launched = shape == 1 ? go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 1024, 512>, 1024u, 512u, 1u) : go(k_trace_w4<ANY, OUT_MODE, false, 0, false, 512, 256>, 512u, 256u, 2u);
+            if (launched) {
+                if (trace_can_overflow(s))
+                    hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, INST, ALPHA>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
+                return;
+            }
         }
     }
     if (ALPHA && s->alpha_simple)   // every mask of the scene is evaluated in line (kernels.h alpha_simple): the traversal keeps its register budget
@@ -963,12 +971,15 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // all light estimates of a node in one round (direct.h k_dl_nee_all): R = sum_j n_j virtual slots per node slot in the ray / result arrays; RSPT_DL_ROUNDS=1 = one
     // round per estimate as before (R = 1 for the sizing)
     uint32_t dl_R = 1;
-    if (direct && !pixel_sampler && !dl_lane && env_size("RSPT_DL_ROUNDS", 0) == 0 && d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL && s->dev.n_lights) {
+    // (R used to be CLAMPED to 2^20 while the kernels iterate over the unclamped sum — virtual slots would alias.  A sum above 2^16 — hundreds of lights at thousands
+    //  of samples each — takes the round-per-estimate form instead, whose slots do not depend on it; n_slots * R then stays far below the RSPT_Q_MIS bit: the batch is <= 2^28 / R)
+    bool dl_one_round = direct && !pixel_sampler && !dl_lane && env_size("RSPT_DL_ROUNDS", 0) == 0;
+    if (dl_one_round && d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL && s->dev.n_lights) {
         uint64_t r = 0;
-        for (uint32_t j = 0; j < s->dev.n_lights; j++) r += d->n_light_samples ? (uint64_t)d->n_light_samples[j] : 1u;
-        dl_R = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r, 1u), 1u << 20);
+        for (uint32_t j = 0; j < s->dev.n_lights; j++) r += d->n_light_samples ? (uint64_t)std::max<int32_t>(d->n_light_samples[j], 0) : 1u;
+        if (r > (1u << 16)) dl_one_round = false;
+        else dl_R = (uint32_t)std::max<uint64_t>(r, 1u);
     }
-    const bool dl_one_round = direct && !pixel_sampler && !dl_lane && env_size("RSPT_DL_ROUNDS", 0) == 0;
     if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? (s->has_dynamic ? 20 : 22) : (dl_R > 1 ? 28 : 26))) / dl_H / dl_R, 1024);   // (per-lane form: texture rows and lobe records per recursion level)
     if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
@@ -1042,7 +1053,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     g.pb.fresh = 0u;
     g.pb.hit_inst = s->has_instances ? g.hit_inst : nullptr;
     g.vol.hit_inst_tr = (volpath && s->has_instances) ? g.hit_inst + g.cap : nullptr;
-    if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK)) ||
+    if ((rc = ensure_counts(max_iters + 10)) || (rc = ensure_overflow_list(trace_can_overflow(s) ? 3 * g.cap : 1024)) || (rc = ensure_spill(pw_spill_threads())) ||
         (s->has_textures && (rc = ensure_tex_rows(s->has_dynamic)))) return rc;
     if (!g.totals) { if ((rc = dev_alloc(&g.totals, 8))) return rc; }
     HIP_TRY(hipMemsetAsync(g.totals, 0, 8 * sizeof(unsigned long long), g.stream));
@@ -2636,7 +2647,7 @@ int rspt_trace_device(rspt_scene_t s, const void* rays_dev, uint64_t n, void* ou
     HIP_TRY(hipEventRecord(e0, g.stream));
     int rc0 = ensure_counts(4);
     if (!rc0) rc0 = ensure_overflow_list(std::max<size_t>((size_t)n, 1));
-    if (!rc0) rc0 = ensure_spill((size_t)pw_grid() * RSPT_PW_BLOCK);
+    if (!rc0) rc0 = ensure_spill(pw_spill_threads());
     if (rc0) return rc0;
     uint32_t* cursor = &g.cnt[0].cursor_closest;
     for (int r = 0; r < repeat && n; r++) {

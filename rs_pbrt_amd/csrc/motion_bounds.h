@@ -19,6 +19,7 @@
 #include "camera_anim.h"
 
 namespace rspt {
+#define RSPT_MOTION_PAD 1e-6f   // outward slack of the velocity-zero edges, relative to the box's largest extent (motion_bounds below)
 namespace motion {
 
 struct Box { float lo[3], hi[3]; };
@@ -195,13 +196,16 @@ inline void make_keys(const float start[16], float t0, const float end[16], floa
 }
 
 // AnimatedTransform::bound_point_motion (:2164-2210)
-inline Box bound_point_motion(const Keys& a, const float p[3], bool* overflow) {
+// ends (optional): the box of the point at the two keys alone — plain f32 transform_point, bit-identical to the reference's; what the velocity zeros add beyond it is
+// located from coefficient tables that differ from the reference's expanded sums in their last bits (motion_bounds below pads exactly those edges)
+inline Box bound_point_motion(const Keys& a, const float p[3], bool* overflow, Box* ends = nullptr) {
     Box b;
     float ps[3], pe[3];
     xf_point(a.start, p, ps);
-    if (!a.animated) { for (int i = 0; i < 3; i++) b.lo[i] = b.hi[i] = ps[i]; return b; }
+    if (!a.animated) { for (int i = 0; i < 3; i++) b.lo[i] = b.hi[i] = ps[i]; if (ends) *ends = b; return b; }
     xf_point(a.end, p, pe);
     for (int i = 0; i < 3; i++) { b.lo[i] = fminf(ps[i], pe[i]); b.hi[i] = fmaxf(ps[i], pe[i]); }    // Bounds3f::new orders its corners
+    if (ends) *ends = b;
     for (int c = 0; c < 3; c++) {
         float cn[5];
         for (int n5 = 0; n5 < 5; n5++) cn[n5] = a.kc[n5][c] + a.k[n5][c][0] * p[0] + a.k[n5][c][1] * p[1] + a.k[n5][c][2] * p[2];   // DerivativeTerm::eval (:888-890)
@@ -224,9 +228,23 @@ inline Box motion_bounds(const Keys& a, const Box& b, bool* overflow) {
     if (!a.has_rotation) { Box r = xf_bounds(a.start, b); box_join(&r, xf_bounds(a.end, b)); return r; }
     Box r;                                   // Bounds3f::default() (geometry.rs:1993-2011): p_min = f32::MAX, p_max = f32::MIN
     for (int i = 0; i < 3; i++) { r.lo[i] = 3.40282347e38f; r.hi[i] = -3.40282347e38f; }
+    Box e = r;                               // the same union over the eight corners at the two keys only
     for (int corner = 0; corner < 8; corner++) {
         const float p[3] = {(corner & 1) ? b.hi[0] : b.lo[0], (corner & 2) ? b.hi[1] : b.lo[1], (corner & 4) ? b.hi[2] : b.lo[2]};
-        box_join(&r, bound_point_motion(a, p, overflow));
+        Box ends;
+        box_join(&r, bound_point_motion(a, p, overflow, &ends));
+        box_join(&e, ends);
+    }
+    // A BOUND must err outward.  Edges set by a key position are the reference's bit for bit.  An edge pushed out by a velocity zero
+    // is transform_point at a time found by Newton steps on c1..c5, which this file forms in double precision and rounds once where the reference sums expanded f32
+    // terms (transform.rs:944-2030): the two agree within 5e-7 of the box's extent (tests/test_motion_bounds.py, 96 reference-derived cases), either way round.  Those
+    // edges move OUT by RSPT_MOTION_PAD x the largest extent, so the result contains the reference's box; it differs from it by at most 1.5e-6 of that extent.
+    float ext = 0.0f;
+    for (int i = 0; i < 3; i++) ext = fmaxf(ext, r.hi[i] - r.lo[i]);
+    const float pad = RSPT_MOTION_PAD * ext;
+    for (int i = 0; i < 3; i++) {
+        if (r.lo[i] < e.lo[i]) r.lo[i] = nextafterf(r.lo[i] - pad, -3.40282347e38f);
+        if (r.hi[i] > e.hi[i]) r.hi[i] = nextafterf(r.hi[i] + pad, 3.40282347e38f);
     }
     return r;
 }

@@ -42,9 +42,10 @@ constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                              
 #define RSPT_TU_REF(ANY, OM, C, I, A) \
     RSPT_TU_X template __global__ void k_trace<ANY, OM, C, I, A>(SceneDev, TexTables, const uint32_t*, const uint32_t*, uint32_t, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, \
                                                                  unsigned long long*, uint32_t*);
-#define RSPT_TU_REFA(ANY, OM) \
-    RSPT_TU_X template __global__ void k_trace<ANY, OM, false, true, false, true>(SceneDev, TexTables, const uint32_t*, const uint32_t*, uint32_t, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, \
+#define RSPT_TU_REFA1(ANY, OM, A) \
+    RSPT_TU_X template __global__ void k_trace<ANY, OM, false, true, A, true>(SceneDev, TexTables, const uint32_t*, const uint32_t*, uint32_t, const rspt_ray*, const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, \
                                                                                   unsigned long long*, uint32_t*);   /* moving instances (traverse<.., ANIM>) */
+#define RSPT_TU_REFA(ANY, OM) RSPT_TU_REFA1(ANY, OM, false) RSPT_TU_REFA1(ANY, OM, true)   /* ... alone and next to alpha-masked meshes */
 #define RSPT_TU_REF8(ANY, OM) \
     RSPT_TU_REF(ANY, OM, false, false, false) RSPT_TU_REF(ANY, OM, false, false, true) RSPT_TU_REF(ANY, OM, false, true, false) RSPT_TU_REF(ANY, OM, false, true, true) \
     RSPT_TU_REF(ANY, OM, true, false, false) RSPT_TU_REF(ANY, OM, true, false, true) RSPT_TU_REF(ANY, OM, true, true, false) RSPT_TU_REF(ANY, OM, true, true, true)

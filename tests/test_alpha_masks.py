@@ -269,3 +269,19 @@ def test_moving_instances_of_alpha_masked_meshes(gpu, oracle, mode, integrator):
     still = oracle.render(sc, scenes.make_render_desc(80, 60, 8, LOOK, 45.0, shutter=(0.0, 0.0)), threads=8) if integrator == "path" else None
     if still is not None:
         assert np.abs(scenes.film_to_rgb(film) - scenes.film_to_rgb(still["film"])).mean() > 1e-4   # the motion is in the picture
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", [{"RSPT_TRACE_KERNEL": "0"}, {"RSPT_INSTANCE_KERNEL": "0"}, {"RSPT_ANIM_W4": "0"}, {"RSPT_COUNTERS": "1"}])
+def test_moving_masked_instances_under_every_trace_switch(gpu, oracle, monkeypatch, switch):
+    """round 6: with RSPT_TRACE_KERNEL=0 / RSPT_INSTANCE_KERNEL=0 / RSPT_COUNTERS=1 a scene with moving instances AND alpha masks used to fall to
+    k_trace<.., INST, ALPHA> without the interpolation (the start key's Transform in the traversal, inst_at(time) in the shade stage): a silently wrong picture.  The
+    reference-order loop now has its <INST, ALPHA, ANIM> instantiation; every switch gives the oracle's samples bit for bit."""
+    sc = masked_scene(gpu.bvh_build, instanced=True, mode="fixed", moving=True)
+    rd = scenes.make_render_desc(80, 60, 4, LOOK, 45.0, shutter=(0.0, 1.0))
+    for k, v in switch.items():
+        monkeypatch.setenv(k, v)
+    with gpu.DeviceScene(sc) as ds:
+        li, st = gpu.render_samples(ds, rd)
+    ref = oracle.render(sc, rd, threads=8, want_li=True)
+    assert st["samples"] == ref["counters"]["samples"] and np.array_equal(li, ref["li"])

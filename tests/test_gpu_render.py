@@ -675,8 +675,8 @@ def test_film_reduce_runs_inside_the_library(gpu):
 def test_film_reduce_with_two_ranks(gpu, tmp_path):
     """X1 with a world of two: two processes (one device each where the box has two devices, both on device 0 otherwise) join the library's RCCL communicator, render the shards
     (0, 2, 1) / (1, 2, 1) with film_reduce = 1; rank 0's buffer must hold the whole frame (= the single-rank render: weights bit for
-    bit, radiance up to the order of the sum).  RCCL may refuse two ranks on one device ("Duplicate GPU detected"): then the test says so
-    and skips — the multi-device run is the driver's."""
+    bit, radiance up to the order of the sum).  RCCL refuses two ranks on one device ("Duplicate GPU detected"): on a one-GPU box the test checks that both ranks come back
+    with an error code and a message (no hang) and then reports XFAIL — the reduce itself did not run there, and the report must say so (VERDICT r5 #9)."""
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
@@ -698,7 +698,7 @@ def test_film_reduce_with_two_ranks(gpu, tmp_path):
         assert torch.cuda.device_count() < 2, "RCCL refused two ranks although the box has %d devices: %s" % (torch.cuda.device_count(), errs[0])
         assert len(errs) == 2 and [p.returncode for p in procs] == [2, 2], (errs, outs)
         assert all("librspt error" in e for e in errs), errs
-        return
+        pytest.xfail("one device: RCCL refuses two ranks on it (%s) — ncclReduce with a world of two did NOT run; only rspt_comm_init's error path was checked" % errs[0].strip().splitlines()[-1][:120])
     assert [p.returncode for p in procs] == [0, 0], outs
     sc = scenes.cornell_box(gpu.bvh_build)
     with gpu.DeviceScene(sc) as ds:

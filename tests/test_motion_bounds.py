@@ -5,7 +5,8 @@ restatement (oracle/orc_motion.hpp), and tests/golden/motion_bounds.npz — boxe
 expressions (transform.rs:944-2030, machine-converted where they lie by oracle/make_motion_fixture.py; the fixture travels, the reference does not).
 Tolerances: a box edge is transform_point at a velocity zero, found by four f32 Newton steps — product, oracle and fixture locate it from coefficient
 tables that differ in their last bits, and the position there is stationary in time, so edges agree to a few ulps of the box's size: 4e-6 relative
-to the box's largest extent, asserted below (measured: < 5e-7)."""
+to the box's largest extent, asserted below (measured: < 5e-7).  Round 6: the product pads its velocity-zero edges outward by 1e-6 of the extent, so that its box
+always contains the reference's (asserted below) — at most 1.5e-6 larger."""
 import os
 import subprocess
 import sys
@@ -55,15 +56,19 @@ def test_oracle_boxes_equal_the_fixture(oracle):
     assert exact >= N // 2, "only %d of %d boxes bit-identical" % (exact, N)
 
 
-def test_product_boxes_equal_the_fixture():
-    exact = 0
+def test_product_boxes_contain_the_fixture_and_stay_within_tolerance():
+    """round 6: a bound errs OUTWARD.  Edges set by a key position are the reference's bit for bit; an edge pushed out by a velocity zero is padded by
+    1e-6 of the box's extent (csrc/motion_bounds.h RSPT_MOTION_PAD) over a location that agrees with the reference's within 5e-7: product >= fixture on every edge, and
+    within EDGE_TOL of it."""
+    same = total = 0
     for i in range(N):
         lo, hi, animated, has_rot = lib.motion_bounds(G["start"][i], G["time"][i][0], G["end"][i], G["time"][i][1], G["box_lo"][i], G["box_hi"][i])
         assert animated and has_rot
         e = _extent(G["out_lo"][i], G["out_hi"][i])
+        assert np.all(lo <= G["out_lo"][i]) and np.all(hi >= G["out_hi"][i]), (i, lo - G["out_lo"][i], hi - G["out_hi"][i])   # superset
         assert np.abs(lo - G["out_lo"][i]).max() <= EDGE_TOL * e and np.abs(hi - G["out_hi"][i]).max() <= EDGE_TOL * e, i
-        exact += int(np.array_equal(lo, G["out_lo"][i]) and np.array_equal(hi, G["out_hi"][i]))
-    assert exact >= N // 2, "only %d of %d boxes bit-identical" % (exact, N)
+        same += int((lo == G["out_lo"][i]).sum() + (hi == G["out_hi"][i]).sum()); total += 6
+    assert same >= total // 4, "only %d of %d edges bit-identical (the ones a key position sets)" % (same, total)
 
 
 def test_product_box_contains_the_motion(oracle):
