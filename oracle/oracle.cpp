@@ -428,4 +428,24 @@ void orc_spatial_voxel(const rspt_scene_desc* sd, const rspt_render_desc* rd, co
     for (size_t i = 0; i < d->cdf.size(); i++) cdf_out[i] = d->cdf[i];
 }
 
+// ---- the oracle's restatements of the leaf functions that tests/golden/leaf_functions.npz pins by the reference's own text (oracle/make_leaf_fixtures.py) ----
+// fn: 0 fr_dielectric (c, eta_i, eta_t -> 1)   1 fr_conductor (c, eta_i[3], eta_t[3], k[3] -> 3)   2 TrowbridgeReitz sample_11 (cos, u1, u2 -> 2)
+//     3 trowbridge_reitz_sample (wi[3], ax, ay, u1, u2 -> 3)   4 sobol_sample_float (index, dim; words -> 1)   5 concentric_sample_disk (u[2] -> 2)   6 Matrix4x4::inverse (16 -> 16)
+void orc_leaf(int fn, const float* a, const float* b, const float* c, const float* d, const float* e, const int64_t* ia, const int32_t* ib, const uint32_t* words, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: out[i] = fr_dielectric(a[i], b[i], c[i]); break;
+        case 1: { Spec r = fr_conductor(a[i], Spec(b[3 * i], b[3 * i + 1], b[3 * i + 2]), Spec(c[3 * i], c[3 * i + 1], c[3 * i + 2]), Spec(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+                  out[3 * i] = r.c[0]; out[3 * i + 1] = r.c[1]; out[3 * i + 2] = r.c[2]; break; }
+        case 2: { Float sx = 0, sy = 0; TR::sample_11(a[i], b[i], c[i], &sx, &sy); out[2 * i] = sx; out[2 * i + 1] = sy; break; }
+        case 3: { V3 r = TR::sample(V3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, b[i], c[i], d[i], e[i]); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+        case 4: out[i] = sobol_sample_float(SobolTables{words, nullptr, nullptr}, ia[i], ib[i], 0); break;
+        case 5: { P2 r = concentric_sample_disk(P2{a[2 * i], a[2 * i + 1]}); out[2 * i] = r.x; out[2 * i + 1] = r.y; break; }
+        case 6: { M44 m; for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) m.m[r][k] = a[16 * i + 4 * r + k];
+                  const M44 v = m44_inverse(m); for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) out[16 * i + 4 * r + k] = v.m[r][k]; break; }
+        default: break;
+        }
+    }
+}
+
 } // extern "C"

@@ -260,3 +260,14 @@ def interpolate_transform(start_m, t0, end_m, t1, time, start_inv=None, end_inv=
     m, mi = np.zeros(16, np.float32), np.zeros(16, np.float32)
     lib().orc_interpolate_transform(a.ctypes.data, ai.ctypes.data, float(t0), b.ctypes.data, bi.ctypes.data, float(t1), float(time), m.ctypes.data, mi.ctypes.data)
     return (m.reshape(4, 4), mi.reshape(4, 4)) if want_inverse else m.reshape(4, 4)
+
+
+def leaf(fn, n, out_shape, a=None, b=None, c=None, d=None, e=None, ia=None, ib=None, words=None):
+    """the oracle's restatement of leaf function `fn` (oracle.cpp orc_leaf) over n inputs — what tests/golden/leaf_functions.npz pins by the reference's text"""
+    L = lib()
+    L.orc_leaf.restype = None
+    L.orc_leaf.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_uint64, C.c_void_p]
+    keep = [None if x is None else np.ascontiguousarray(x) for x in (a, b, c, d, e, ia, ib, words)]
+    out = np.zeros(out_shape, np.float32)
+    L.orc_leaf(fn, *[None if x is None else x.ctypes.data for x in keep], n, out.ctypes.data)
+    return out

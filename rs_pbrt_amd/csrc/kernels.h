@@ -52,6 +52,17 @@ struct PathBuf {
     float* time;          // Ray.time of the path (perspective.rs:226), kept only while a scene with moving instances is rendered (nullptr otherwise)
     uint32_t fresh;       // 1 in the path integrator's k_raygen and its FIRST shade launch of a batch: every slot's (L, eta_scale) is (0, 0, 0, 1) and beta (1, 1, 1)
                           // by construction, so k_raygen does not write the two 16-byte fields and shade_path does not read them (64 of ~1200 bytes per C3 sample)
+    // ---- round 6: MOVING path state (the path integrator's schedule, k_shade<F, MOVE>) ----
+    // A path no longer keeps its slot for life.  The index of a live path is its POSITION in the current iteration's active queue: k_shade reads the state at position p
+    // and writes what the path carries on (ray, beta, L, state, Sobol' index, its pending estimate, its shadow ray) at the position it gets in the NEXT queue — dense,
+    // unit-stride stores, and next iteration's loads are unit-stride too (a 16-byte field read from a sparse slot costs a whole 128-byte line from the fabric:
+    // profiles/r06_pmc_calibration.md).  The fields above are the set the iteration READS (the host swaps the two sets between iterations); the o_* fields the set it
+    // WRITES.  What stays indexed by the path's ORIGINAL slot: p_film, the final radiance (L_final, what k_film reads) and the general (BSDF-sampled / MIS) form of a
+    // pending estimate — ray_mis, hit_mis, nee_c2, nee_beta — which only light-hitting samples and infinite lights use.
+    uint32_t move;        // 1: positions (MOVE instantiations); 0: slots for life (every other schedule)
+    uint32_t* orig;       // original slot of the path at position p (not read in the fresh launch: position = slot there)
+    rspt_ray* o_ray_cont; float4* o_L_eta; float4* o_beta; float4* o_nee_c1; uint64_t* o_sobol_index; uint32_t* o_state; uint32_t* o_orig;
+    float4* L_final;      // (L.rgb, -) by original slot, written once when the path ends
 };
 
 struct QueueCounts {  // one per wavefront iteration
@@ -144,6 +155,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
         pb.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     }
     pb.sobol_index[i] = index;
+    if (pb.move && !pb.fresh) pb.orig[i] = i;   // (MOVE: the first shade launch takes position = slot without reading this; only RSPT_FRESH=0 reads it back)
     pb.state[i] = 5u | ST_ALIVE;  // dimensions 0..4 consumed by the camera sample
     pb.p_film[i] = make_float2(p_film.x, p_film.y);
     if (pb.time) pb.time[i] = rd.shutter_open * (1.0f - p_lens.z) + rd.shutter_close * p_lens.z;   // lerp(sample.time, shutter_open, shutter_close)
@@ -426,6 +438,19 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTabl
 struct ShadeOut {
     bool active, cont, mis, shadow;
 };
+// MOVE: what shade_path hands back instead of storing it at the path's own index — the kernel stores it at the path's next position (shade_kernel)
+struct ShadeMove {
+    f3 o, d;              // continuation ray (cont)
+    rgb beta;
+    float4 L;             // (L.rgb, eta_scale)
+    float4* s_c1;         // this thread's LDS cells: the pending estimate's nee_c1 record (ST_PENDING in st) and the shadow ray (o.xyz, d.x | d.y, d.z) — staged there, not in
+    float4* s_sh0;        // registers: both are made in the next-event block and would stay live through the continuation sampling, the kernel's register peak
+    float2* s_sh1;
+    uint32_t st;          // packed state
+    bool valid;           // the lane held a path
+    // (the Sobol' index and the original slot are NOT carried here: shade_kernel reads them again at the commit — two L1 / L2 hits against three registers held
+    //  through the whole of shade_path, which runs at its register ceiling)
+};
 
 RDEV void store_ray(rspt_ray* dst, f3 o, f3 d, float t_max, uint32_t id) {
     float4* p = reinterpret_cast<float4*>(dst);
@@ -467,9 +492,11 @@ RDEVN const rspt_mat::Built* dynamic_lobes(const rspt_mat::DynMaterial& dm, cons
 // One step of PathIntegrator::li (path.rs:91-280) for path slot p: fold in the previous
 // bounce's next-event estimate, then process the hit of the continuation ray.
 // F: the feature set the instantiation is compiled for (dev_bsdf.h SF_*): everything a scene outside F could bring folds away
-template <bool PIX, uint32_t F = SF_ALL>
+// MOVE (round 6, PathBuf::move): p is the path's POSITION in this iteration's queue; nothing the path carries on is stored here — it comes back in *mv and
+// shade_kernel stores it at the path's next position.  Indexed by the original slot `og` instead: the general form of a pending estimate.
+template <bool PIX, uint32_t F = SF_ALL, bool MOVE = false>
 RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const RenderDev& rd, const PathBuf& pb, uint32_t p, unsigned long long* stats,
-                          const uint32_t* __restrict__ sob_tab, uint32_t sob_nd, PixSampler* px) {
+                          const uint32_t* __restrict__ sob_tab, uint32_t sob_nd, PixSampler* px, ShadeMove* mv = nullptr) {
     ShadeOut out{false, false, false, false};
     uint32_t st = pb.state[p];
     const bool fresh = !PIX && pb.fresh != 0u;   // the first shade launch of a path-integrator batch (PathBuf::fresh)
@@ -477,6 +504,11 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     if (!fresh) le = pb.L_eta[p];
     rgb L{le.x, le.y, le.z};
     float eta_scale = le.w;
+    uint32_t og = p;      // where the slot-for-life arrays of this path live
+    if (MOVE) {
+        if (!fresh) og = pb.orig[p];
+        mv->valid = true;
+    }
 
     if ((st & ST_PENDING) && (st & ST_COMPACT)) {   // the estimate without a BSDF-sampled term (almost all of them): nee_c1 holds beta * ((0 + c1) / pdf), already
         const float4 k = pb.nee_c1[p];                // formed with the operations of the general resolve below; a blocked shadow ray adds beta * (0 / pdf) = +-0
@@ -484,11 +516,11 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         st &= ~(ST_PENDING | ST_HAS_C1 | ST_COMPACT);
     }
     if (st & ST_PENDING) {  // tail of estimate_direct (integrator.rs:461-568) + path.rs:126-139
-        float4 c1 = pb.nee_c1[p], c2 = pb.nee_c2[p], nb = pb.nee_beta[p];
+        float4 c1 = pb.nee_c1[p], c2 = pb.nee_c2[og], nb = pb.nee_beta[og];
         rgb ldir = mkrgb(0.0f);
         if ((st & ST_HAS_C1) && pb.occluded[p] == 0u) ldir = ldir + rgb{c1.x, c1.y, c1.z};
         if (st & ST_HAS_C2) {
-            float4 hm = pb.hit_mis[p];
+            float4 hm = pb.hit_mis[og];
             uint32_t hp = __float_as_uint(hm.x);
             uint32_t light_num = __float_as_uint(c2.w);
             if ((F & SF_L_INFINITE) && (st & ST_C2_ON_MISS)) {  // InfiniteAreaLight: li = light.le(ray) when nothing was hit (integrator.rs:561-563)
@@ -498,7 +530,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                 if (t.area_light >= 0 && (uint32_t)t.area_light == light_num) {
                     Hit h;
                     tri_fill<(F & SF_VERTEX) != 0>(sc, hp, t, hm.y, hm.z, hm.w, &h);
-                    const float4* mr = reinterpret_cast<const float4*>(pb.ray_mis + p);
+                    const float4* mr = reinterpret_cast<const float4*>(pb.ray_mis + og);
                     float4 m0 = mr[0], m1 = mr[1];
                     f3 wi{m0.w, m1.x, m1.y};
                     rgb li = light_l(sc.lights[light_num], h.n, -wi);
@@ -510,6 +542,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         st &= ~(ST_PENDING | ST_HAS_C1 | ST_HAS_C2 | ST_C2_ON_MISS);
     }
     if (!(st & ST_ALIVE)) {
+        if (MOVE) { mv->L = make_float4(L.r, L.g, L.b, eta_scale); mv->st = st; return out; }
         pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
         pb.state[p] = st;
         return out;
@@ -560,8 +593,11 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
         if (bounces < rd.max_depth) {  // path.rs:103
             if ((F & SF_NULL) && h.material == 0xffffffffu) {  // null BSDF: pass straight through (path.rs:109-116)
                 f3 o = offset_ray_origin(h.p, h.p_err, h.n, ray_d);
-                store_ray(pb.ray_cont + p, o, ray_d, RSPT_INF, p);
-                if (fresh) pb.beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);   // (k_raygen left it unwritten, and the path goes on)
+                if (MOVE) { mv->o = o; mv->d = ray_d; mv->beta = beta; }
+                else {
+                    store_ray(pb.ray_cont + p, o, ray_d, RSPT_INF, p);
+                    if (fresh) pb.beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);   // (k_raygen left it unwritten, and the path goes on)
+                }
                 st |= ST_ALIVE | ST_NO_DIFF;
                 out.cont = true;
             } else {
@@ -624,7 +660,8 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                                 // VisibilityTester::unoccluded -> spawn_ray_to (interaction.rs:81-94)
                                 f3 origin = offset_ray_origin(h.p, h.p_err, h.n, ls.p - h.p);
                                 f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
-                                store_ray(pb.ray_sh + p, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, p);
+                                if (MOVE) { const f3 sd = target - origin; *mv->s_sh0 = make_float4(origin.x, origin.y, origin.z, sd.x); *mv->s_sh1 = make_float2(sd.y, sd.z); }
+                                else store_ray(pb.ray_sh + p, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, p);
                                 out.shadow = true;
                                 if (light_is_delta<F>(lt)) c1 = f * li / light_pdf;  // integrator.rs:470-471
                                 else c1 = f * li * mkrgb(power_heuristic(light_pdf, scattering_pdf)) / light_pdf;
@@ -657,7 +694,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                                     float weight = power_heuristic(scattering_pdf, lpdf);
                                     c2 = f * le_mis * mkrgb(1.0f) * weight / scattering_pdf;
                                     if (!((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) || !is_black(le_mis)) {
-                                        store_ray(pb.ray_mis + p, ro, wi, RSPT_INF, p);
+                                        store_ray(pb.ray_mis + og, ro, wi, RSPT_INF, og);
                                         out.mis = true;
                                         st |= ST_HAS_C2 | (((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) ? ST_C2_ON_MISS : 0u);
                                     }
@@ -674,13 +711,15 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                         if (!(st & ST_HAS_C2) && k_occ.r == 0.0f && k_occ.g == 0.0f && k_occ.b == 0.0f) {
                             if (st & ST_HAS_C1) {
                                 const rgb k = beta * ((mkrgb(0.0f) + c1) / pdf_choice);
-                                pb.nee_c1[p] = make_float4(k.r, k.g, k.b, 0.0f);
+                                if (MOVE) *mv->s_c1 = make_float4(k.r, k.g, k.b, 0.0f);
+                                else pb.nee_c1[p] = make_float4(k.r, k.g, k.b, 0.0f);
                                 st |= ST_PENDING | ST_COMPACT;
                             }
                         } else {
-                            pb.nee_c1[p] = make_float4(c1.r, c1.g, c1.b, pdf_choice);
-                            pb.nee_c2[p] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
-                            pb.nee_beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                            if (MOVE) *mv->s_c1 = make_float4(c1.r, c1.g, c1.b, pdf_choice);
+                            else pb.nee_c1[p] = make_float4(c1.r, c1.g, c1.b, pdf_choice);
+                            pb.nee_c2[og] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
+                            pb.nee_beta[og] = make_float4(beta.r, beta.g, beta.b, 0.0f);
                             st |= ST_PENDING;  // even an all-zero estimate is added (l + beta*0 == l)
                         }
                     }
@@ -710,8 +749,11 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                         else beta = beta / (1.0f - q);
                     }
                     if (go_on) {
-                        store_ray(pb.ray_cont + p, o, wi, RSPT_INF, p);
-                        pb.beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                        if (MOVE) { mv->o = o; mv->d = wi; mv->beta = beta; }
+                        else {
+                            store_ray(pb.ray_cont + p, o, wi, RSPT_INF, p);
+                            pb.beta[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                        }
                         st |= ST_ALIVE;
                         out.cont = true;
                     }
@@ -721,8 +763,11 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
             }
         }
     }
-    pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
-    pb.state[p] = st;
+    if (MOVE) { mv->L = make_float4(L.r, L.g, L.b, eta_scale); mv->st = st; }
+    else {
+        pb.L_eta[p] = make_float4(L.r, L.g, L.b, eta_scale);
+        pb.state[p] = st;
+    }
     out.active = (st & (ST_ALIVE | ST_PENDING)) != 0;
     return out;
 }
@@ -965,12 +1010,14 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_bin_scatter(const uint32_t* __re
 
 // The shade kernel's body; F = the feature set (dev_bsdf.h SF_*) the instantiation is compiled for.  k_shade<F> leaves the register budget
 // to the compiler, k_shade_w<F, W> asks for W waves per SIMD (the allocator spills what does not fit 512 / W registers).
-template <uint32_t F>
+// MOVE (round 6): queue entries are positions; what a path carries on is stored at its position in the next queue (PathBuf, ShadeMove)
+struct ShadeStage { float4 c1[256]; float4 sh0[256]; float2 sh1[256]; };   // 10 KB of LDS per workgroup (MOVE instantiations only)
+template <uint32_t F, bool MOVE>
 __device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDistDev& ld, const RenderDev& rd, const PathBuf& pb, const uint32_t* __restrict__ q_active,
                                              const QueueCounts* __restrict__ cnt_in, QueueCounts* cnt_out, uint32_t* __restrict__ q_active_next,
                                              uint32_t* __restrict__ q_closest_next, uint32_t* __restrict__ q_any_next, unsigned long long* stats,
                                              uint32_t sob_nd, uint32_t sob_bits, uint32_t qcap, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi,
-                                             uint32_t* sob_tab, uint32_t (*s_wave)[5], uint32_t* s_base) {
+                                             uint32_t* sob_tab, uint32_t (*s_wave)[5], uint32_t* s_base, ShadeStage* stage) {
     // sob_tab: Sobol' generator matrices of the dimensions this render can reach, transposed to [bit][dim]
     for (uint32_t t = threadIdx.x; ((F & SF_SOBOL) || !(F & SF_HALTON)) && (!(F & SF_HALTON) || rd.sampler_kind == RSPT_SAMPLER_SOBOL) && t < sob_nd * sob_bits; t += 256u) {
         uint32_t dd = t % sob_nd;  // read-ahead columns past the last of the 1024 dimensions are never consumed
@@ -986,10 +1033,12 @@ __device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDist
     for (uint32_t base = virtual_block() * 256u; base < n; base += stride) {
         uint32_t i = base + threadIdx.x;
         ShadeOut o{false, false, false, false};
+        ShadeMove mv;
+        if (MOVE) { mv.valid = false; mv.s_c1 = &stage->c1[threadIdx.x]; mv.s_sh0 = &stage->sh0[threadIdx.x]; mv.s_sh1 = &stage->sh1[threadIdx.x]; }
         uint32_t p = 0;
         if (i < n) {
             p = i < n_front ? (q_sorted ? q_sorted[i] : q_active[i]) : q_active[qcap - 1u - (i - n_front)];
-            if (p != RSPT_BIN_INVALID) o = shade_path<false, F>(sc, ld, rd, pb, p, stats, sob_tab, sob_nd, nullptr);
+            if (p != RSPT_BIN_INVALID) o = shade_path<false, F, MOVE>(sc, ld, rd, pb, p, stats, sob_tab, sob_nd, nullptr, MOVE ? &mv : nullptr);
         }
         // queue appends, aggregated per workgroup: a single counter word sustains only ~90 M atomics/s
         // (MI355X_MICROARCH "dequeue" row), so one atomic per queue per 256 paths instead of per wave.
@@ -1019,11 +1068,38 @@ __device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDist
             if (w < wave) { off_act += s_wave[w][0]; off_cont += s_wave[w][1]; off_mis += s_wave[w][2]; off_sh += s_wave[w][3]; off_tail += s_wave[w][4]; }
             off_mis += s_wave[w][1];  // MIS entries follow all continuation entries of the workgroup
         }
-        if (o.cont) q_active_next[off_act + (uint32_t)__popcll(m_act & lt)] = p;
-        if (tail) q_active_next[qcap - 1u - (off_tail + (uint32_t)__popcll(m_tail & lt))] = p;
-        if (o.cont) q_closest_next[off_cont + (uint32_t)__popcll(m_cont & lt)] = p;
-        if (o.mis) q_closest_next[off_mis + (uint32_t)__popcll(m_mis & lt)] = p | RSPT_Q_MIS;
-        if (o.shadow) q_any_next[off_sh + (uint32_t)__popcll(m_sh & lt)] = p;
+        if (MOVE) {
+            const uint32_t og = (mv.valid && !pb.fresh) ? pb.orig[p] : p;   // the original slot (the fresh launch: position = slot)
+            // the path's next position: its place in the next active queue (front: a continuation ray is in flight; back: only an estimate is pending)
+            const uint32_t p2 = o.cont ? off_act + (uint32_t)__popcll(m_act & lt) : qcap - 1u - (off_tail + (uint32_t)__popcll(m_tail & lt));
+            if (o.cont) {
+                q_active_next[p2] = p2;
+                q_closest_next[off_cont + (uint32_t)__popcll(m_cont & lt)] = p2;
+                store_ray(pb.o_ray_cont + p2, mv.o, mv.d, RSPT_INF, p2);
+                pb.o_beta[p2] = make_float4(mv.beta.r, mv.beta.g, mv.beta.b, 0.0f);
+                pb.o_sobol_index[p2] = pb.sobol_index[p];
+            }
+            if (tail) q_active_next[p2] = p2;
+            if (o.cont || tail) {
+                pb.o_L_eta[p2] = mv.L;
+                pb.o_state[p2] = mv.st;
+                pb.o_orig[p2] = og;
+                if (mv.st & ST_PENDING) pb.o_nee_c1[p2] = *mv.s_c1;
+            } else if (mv.valid)
+                pb.L_final[og] = mv.L;   // the path ends here: its radiance goes where k_film reads it
+            if (o.mis) q_closest_next[off_mis + (uint32_t)__popcll(m_mis & lt)] = og | RSPT_Q_MIS;   // (the general form of an estimate stays with the original slot)
+            if (o.shadow) {
+                const float4 a = *mv.s_sh0; const float2 b = *mv.s_sh1;
+                store_ray(pb.ray_sh + p2, f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, 1.0f - RSPT_SHADOW_EPS, p2);
+                q_any_next[off_sh + (uint32_t)__popcll(m_sh & lt)] = p2;
+            }
+        } else {
+            if (o.cont) q_active_next[off_act + (uint32_t)__popcll(m_act & lt)] = p;
+            if (tail) q_active_next[qcap - 1u - (off_tail + (uint32_t)__popcll(m_tail & lt))] = p;
+            if (o.cont) q_closest_next[off_cont + (uint32_t)__popcll(m_cont & lt)] = p;
+            if (o.mis) q_closest_next[off_mis + (uint32_t)__popcll(m_mis & lt)] = p | RSPT_Q_MIS;
+            if (o.shadow) q_any_next[off_sh + (uint32_t)__popcll(m_sh & lt)] = p;
+        }
         __syncthreads();  // s_wave / s_base are reused by the next stripe
     }
 }
@@ -1031,18 +1107,41 @@ __device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDist
 #define RSPT_SHADE_ARGS SceneDev sc, LightDistDev ld, RenderDev rd, PathBuf pb, const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt_in, QueueCounts* cnt_out, \
                         uint32_t* __restrict__ q_active_next, uint32_t* __restrict__ q_closest_next, uint32_t* __restrict__ q_any_next, unsigned long long* stats, uint32_t sob_nd, \
                         uint32_t sob_bits, uint32_t qcap, const uint32_t* __restrict__ q_sorted, const BinInfo* __restrict__ bi
-#define RSPT_SHADE_CALL shade_kernel<F>(sc, ld, rd, pb, q_active, cnt_in, cnt_out, q_active_next, q_closest_next, q_any_next, stats, sob_nd, sob_bits, qcap, q_sorted, bi, sob_tab, s_wave, s_base)
+#define RSPT_SHADE_CALL(MOVE, STAGE) shade_kernel<F, MOVE>(sc, ld, rd, pb, q_active, cnt_in, cnt_out, q_active_next, q_closest_next, q_any_next, stats, sob_nd, sob_bits, qcap, q_sorted, bi, sob_tab, s_wave, s_base, STAGE)
 template <uint32_t F>
 __global__ __launch_bounds__(256) void k_shade(RSPT_SHADE_ARGS) {
     extern __shared__ uint32_t sob_tab[];
     __shared__ uint32_t s_wave[4][5], s_base[4];
-    RSPT_SHADE_CALL;
+    RSPT_SHADE_CALL(false, nullptr);
 }
 template <uint32_t F, int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void k_shade_w(RSPT_SHADE_ARGS) {
     extern __shared__ uint32_t sob_tab[];
     __shared__ uint32_t s_wave[4][5], s_base[4];
-    RSPT_SHADE_CALL;
+    RSPT_SHADE_CALL(false, nullptr);
+}
+// the MOVE forms (W = 0: the compiler's own register budget)
+template <uint32_t F, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void k_shade_mw(RSPT_SHADE_ARGS) {
+    extern __shared__ uint32_t sob_tab[];
+    __shared__ uint32_t s_wave[4][5], s_base[4];
+    __shared__ ShadeStage stage;
+    RSPT_SHADE_CALL(true, &stage);
+}
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_shade_m(RSPT_SHADE_ARGS) {
+    extern __shared__ uint32_t sob_tab[];
+    __shared__ uint32_t s_wave[4][5], s_base[4];
+    __shared__ ShadeStage stage;
+    RSPT_SHADE_CALL(true, &stage);
+}
+// MOVE: after the last iteration of a batch, whatever is still in the queue (paths cut by RSPT_NULL_PASSES; normally nothing) hands its radiance to the film
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_move_flush(PathBuf pb, const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt, uint32_t qcap) {
+    const uint32_t n_front = cnt->active, n = n_front + cnt->active_tail;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t p = i < n_front ? q_active[i] : q_active[qcap - 1u - (i - n_front)];
+        pb.L_final[pb.orig[p]] = pb.L_eta[p];
+    }
 }
 
 // ---- AOIntegrator::li (src/integrators/ao.rs:50-96) --------------------------

@@ -62,6 +62,10 @@ struct Ctx {
     // path state
     size_t cap = 0;
     PathBuf pb{};
+    // round 6, MOVING path state (kernels.h PathBuf::move): the second set of the fields a path carries from position to position (iteration it reads set it & 1: set 0 =
+    // pb's own arrays, set 1 = these), the original-slot words of both sets, and the radiance of ended paths by original slot
+    struct MoveSet { rspt_ray* ray_cont = nullptr; float4* L_eta = nullptr; float4* beta = nullptr; float4* nee_c1 = nullptr; uint64_t* sobol_index = nullptr;
+                     uint32_t* state = nullptr; uint32_t* orig[2] = {nullptr, nullptr}; float4* L_final = nullptr; size_t cap = 0; } mv;
     uint32_t* q[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [parity][active, closest, any]
     QueueCounts* cnt = nullptr;
     uint32_t n_cnt = 0;
@@ -284,7 +288,14 @@ size_t env_size(const char* name, size_t dflt) {
     return (size_t)strtoull(v, nullptr, 0);
 }
 
+void free_move() {
+    void* ptrs[] = {g.mv.ray_cont, g.mv.L_eta, g.mv.beta, g.mv.nee_c1, g.mv.sobol_index, g.mv.state, g.mv.orig[0], g.mv.orig[1], g.mv.L_final};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    g.mv = Ctx::MoveSet{};
+}
 void free_paths() {
+    free_move();
     void* ptrs[] = {g.pb.ray_cont, g.pb.ray_mis, g.pb.ray_sh, g.pb.hit_cont, g.pb.hit_mis, g.pb.occluded, g.pb.L_eta, g.pb.beta,
                     g.pb.nee_c1, g.pb.nee_c2, g.pb.nee_beta, g.pb.sobol_index, g.pb.state, g.pb.p_film, g.pb.tex, g.pb.dyn_built,
                     g.q[0][0], g.q[0][1], g.q[0][2], g.q[1][0], g.q[1][1], g.q[1][2]};
@@ -315,6 +326,32 @@ int ensure_paths(size_t cap) {
 #undef A
     g.cap = cap;
     return RSPT_OK;
+}
+
+// the second set of the MOVE schedule (116 B per path on top of ensure_paths' 280), sized like the first
+int ensure_move(size_t cap) {
+    if (g.mv.cap >= cap) return RSPT_OK;
+    free_move();
+    int rc;
+    if ((rc = dev_alloc(&g.mv.ray_cont, cap)) || (rc = dev_alloc(&g.mv.L_eta, cap)) || (rc = dev_alloc(&g.mv.beta, cap)) || (rc = dev_alloc(&g.mv.nee_c1, cap)) ||
+        (rc = dev_alloc(&g.mv.sobol_index, cap)) || (rc = dev_alloc(&g.mv.state, cap)) || (rc = dev_alloc(&g.mv.orig[0], cap)) || (rc = dev_alloc(&g.mv.orig[1], cap)) ||
+        (rc = dev_alloc(&g.mv.L_final, cap)))
+        return rc;
+    g.mv.cap = cap;
+    return RSPT_OK;
+}
+// the PathBuf of wavefront iteration `it` under the MOVE schedule: reads set it & 1, writes the other
+PathBuf move_pathbuf(uint32_t it) {
+    PathBuf b = g.pb;
+    const Ctx::MoveSet& m = g.mv;
+    b.move = 1u;
+    b.L_final = m.L_final;
+    rspt_ray* rc[2] = {g.pb.ray_cont, m.ray_cont}; float4* le[2] = {g.pb.L_eta, m.L_eta}; float4* be[2] = {g.pb.beta, m.beta}; float4* c1[2] = {g.pb.nee_c1, m.nee_c1};
+    uint64_t* so[2] = {g.pb.sobol_index, m.sobol_index}; uint32_t* st[2] = {g.pb.state, m.state};
+    const int r = (int)(it & 1u), w = r ^ 1;
+    b.ray_cont = rc[r]; b.L_eta = le[r]; b.beta = be[r]; b.nee_c1 = c1[r]; b.sobol_index = so[r]; b.state = st[r]; b.orig = m.orig[r];
+    b.o_ray_cont = rc[w]; b.o_L_eta = le[w]; b.o_beta = be[w]; b.o_nee_c1 = c1[w]; b.o_sobol_index = so[w]; b.o_state = st[w]; b.o_orig = m.orig[w];
+    return b;
 }
 
 // per-path rows of k_texture's results, only for scenes with textures (6 x 16 B per path)
@@ -669,27 +706,30 @@ typedef void (*ShadeKernel)(RSPT_SHADE_ARGS);
 // VGPRs is spilled); dflt = which of the three runs.  Measured on one box (profiles/r03_ab_shade.md; Msamples/s of C2 / the C3 stand-in,
 // k_shade seconds per step): generic 212 VGPRs 423 / 1685 (0.161 / 0.578 s); diffuse 158 VGPRs = 3 waves as compiled 459 (0.111 s), forced to
 // 4 waves 455; plastic 173 VGPRs as compiled 1749 (0.531 s), 168 + 24 B of spills = 3 waves 1841 (0.470 s), 128 + 152 B = 4 waves 1791.
-struct ShadeVariant { uint32_t features; const char* name; ShadeKernel natural, w3, w4; int dflt; };
+struct ShadeVariant { uint32_t features; const char* name; ShadeKernel natural, w3, w4; int dflt; ShadeKernel move; /* the MOVE form (kernels.h PathBuf::move), built as this set's default is; nullptr: none */ };
 const ShadeVariant g_shade_variants[] = {
-    {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 3},   // (round 4: as compiled it now takes 169 VGPRs = 2 waves — the in-kernel voxel claim of light_row_try
+    {SV_DIFFUSE, "diffuse", k_shade<SV_DIFFUSE>, k_shade_w<SV_DIFFUSE, 3>, k_shade_w<SV_DIFFUSE, 4>, 3, k_shade_mw<SV_DIFFUSE, 3>},   // (round 4: as compiled it now takes 169 VGPRs = 2 waves — the in-kernel voxel claim of light_row_try
                                                                                                            //  cost the four registers; the 3-wave build fits 168 without scratch: Cornell 875 -> see profiles/r04_*)
-    {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3},
-    {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0},
-    {SV_DIFFUSE_H, "diffuse-halton", k_shade<SV_DIFFUSE_H>, k_shade_w<SV_DIFFUSE_H, 3>, k_shade_w<SV_DIFFUSE_H, 3>, 3},   // (tu_decl.h: the reference's default sampler gets the narrow builds too)
-    {SV_PLASTIC_H, "plastic-halton", k_shade<SV_PLASTIC_H>, k_shade_w<SV_PLASTIC_H, 3>, k_shade_w<SV_PLASTIC_H, 3>, 3},
-    {SV_TEXTURED_H, "textured-halton", k_shade<SV_TEXTURED_H>, k_shade_w<SV_TEXTURED_H, 3>, k_shade_w<SV_TEXTURED_H, 3>, 3},   // (textured C3 stand-in: 1343 as compiled, 1358 at 3 waves)
-    {SV_GENERIC, "generic", k_shade<SV_GENERIC>, k_shade_w<SV_GENERIC, 3>, k_shade_w<SV_GENERIC, 4>, 0},
-    {SV_DYNAMIC, "dynamic", k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, 0},   // + lobe lists built per hit (material_assembly.h)
-    {SF_ALL, "moving", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0},                     // + moving object instances (dev_scene.h inst_at)
+    {SV_PLASTIC, "plastic", k_shade<SV_PLASTIC>, k_shade_w<SV_PLASTIC, 3>, k_shade_w<SV_PLASTIC, 4>, 3, k_shade_mw<SV_PLASTIC, 3>},
+    {SV_TEXTURED, "textured", k_shade<SV_TEXTURED>, k_shade_w<SV_TEXTURED, 3>, k_shade_w<SV_TEXTURED, 4>, 0, k_shade_m<SV_TEXTURED>},
+    {SV_DIFFUSE_H, "diffuse-halton", k_shade<SV_DIFFUSE_H>, k_shade_w<SV_DIFFUSE_H, 3>, k_shade_w<SV_DIFFUSE_H, 3>, 3, k_shade_mw<SV_DIFFUSE_H, 3>},   // (tu_decl.h: the reference's default sampler gets the narrow builds too)
+    {SV_PLASTIC_H, "plastic-halton", k_shade<SV_PLASTIC_H>, k_shade_w<SV_PLASTIC_H, 3>, k_shade_w<SV_PLASTIC_H, 3>, 3, k_shade_mw<SV_PLASTIC_H, 3>},
+    {SV_TEXTURED_H, "textured-halton", k_shade<SV_TEXTURED_H>, k_shade_w<SV_TEXTURED_H, 3>, k_shade_w<SV_TEXTURED_H, 3>, 3, k_shade_mw<SV_TEXTURED_H, 3>},   // (textured C3 stand-in: 1343 as compiled, 1358 at 3 waves)
+    {SV_GENERIC, "generic", k_shade<SV_GENERIC>, k_shade_w<SV_GENERIC, 3>, k_shade_w<SV_GENERIC, 4>, 0, k_shade_m<SV_GENERIC>},
+    {SV_DYNAMIC, "dynamic", k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, 0, k_shade_m<SV_DYNAMIC>},   // + lobe lists built per hit (material_assembly.h)
+    {SF_ALL, "moving", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0, nullptr},                     // + moving object instances (dev_scene.h inst_at)
 };
 // RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 0 | 3 | 4 one of its builds (A/B)
-ShadeKernel shade_kernel_for(uint32_t need, const char** name_out) {
+// move_out (may be null): the MOVE form of the chosen set when it has one and the build asked for is its default (RSPT_SHADE_WAVES A/B runs stay on the slot-for-life kernels)
+ShadeKernel shade_kernel_for(uint32_t need, const char** name_out, ShadeKernel* move_out = nullptr) {
     const char* force = getenv("RSPT_SHADE_VARIANT");
+    if (move_out) *move_out = nullptr;
     for (const ShadeVariant& v : g_shade_variants) {
         if ((need & ~v.features) != 0) continue;
         if (force && *force && strcmp(force, v.name) != 0 && (v.features | SF_DYNAMIC | SF_ANIM) != SF_ALL) continue;
         if (name_out) *name_out = v.name;
         const size_t waves = env_size("RSPT_SHADE_WAVES", (size_t)v.dflt);
+        if (move_out && waves == (size_t)v.dflt) *move_out = v.move;
         return waves == 3 ? v.w3 : (waves == 4 ? v.w4 : v.natural);
     }
     return k_shade<SF_ALL>;
@@ -982,6 +1022,13 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     }
     if (direct) cap = std::max<size_t>(std::min<size_t>(cap, (size_t)1 << (dl_lane ? (s->has_dynamic ? 20 : 22) : (dl_R > 1 ? 28 : 26))) / dl_H / dl_R, 1024);   // (per-lane form: texture rows and lobe records per recursion level)
     if (pixel_sampler) cap = std::max<size_t>(blocks.size(), 1024);   // one path slot per tile (tile_serial.h); the samples' results have their own arrays
+    // round 6: the path integrator's MOVING path state (kernels.h PathBuf::move) — wherever the scene's shade instantiation has a MOVE form; not with moving instances
+    // (their ray times are kept by original slot) and not under the pixel samplers / the other integrators, which keep slots for life.  RSPT_MOVE=0: slots, as before.
+    const char* shade_name = "generic";
+    ShadeKernel shade_move_k = nullptr;
+    const ShadeKernel shade_slot_k = shade_kernel_for(s->shade_features | (halton ? (uint32_t)SF_HALTON : (uint32_t)SF_SOBOL), &shade_name, &shade_move_k);
+    const bool move = !volpath && !direct && !ao && !pixel_sampler && !s->has_animated && shade_move_k != nullptr && env_size("RSPT_MOVE", 1) != 0;
+    if (!move) free_move();   // (213 GB at the default batch: the second set is not kept for renders that do not use it)
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     size_t pix_per_batch = 1;
     for (;;) {
@@ -991,6 +1038,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         rc = ensure_paths(std::max<size_t>(pix_per_batch * ns, 1) * ao_n * dl_H * dl_R);
         if (rc == RSPT_OK && direct && !pixel_sampler && !dl_lane) rc = ensure_direct(g.cap);
         if (rc == RSPT_OK && volpath) rc = ensure_vol(g.cap);
+        if (rc == RSPT_OK && move) rc = ensure_move(g.cap);
         if (rc == RSPT_OK) break;
         (void)hipGetLastError();  // out of memory: clear the sticky error and try half the batch
         free_paths();
@@ -1066,9 +1114,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     sob_bits = std::min(52u, sob_bits + 1u);
     if ((size_t)sob_nd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
     const uint32_t tgrid = trace_grid();
-    const char* shade_name = "generic";
-    const ShadeKernel shade_k = shade_kernel_for(s->shade_features | (halton ? (uint32_t)SF_HALTON : (uint32_t)SF_SOBOL), &shade_name);
-    if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shade stage instantiation '%s' (scene features %#x)\n", shade_name, s->shade_features);
+    const ShadeKernel shade_k = move ? shade_move_k : shade_slot_k;
+    if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shade stage instantiation '%s'%s (scene features %#x)\n", shade_name, move ? ", moving path state" : "", s->shade_features);
     // one launch fills the chip once: as many 256-thread blocks per CU as the instantiation's registers and the LDS table allow
     int shade_blocks = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_blocks, reinterpret_cast<const void*>(shade_k), 256, sob_nd * sob_bits * sizeof(uint32_t)) != hipSuccess || shade_blocks < 1) {
@@ -1339,6 +1386,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     auto batch_path = [&](const Batch& bt, uint32_t& it) -> int {  // PathIntegrator::li: trace (closest || any) -> [light voxels] -> [bins] -> [textures] -> shade, per bounce
         for (;;) {
             const int par = it & 1;
+            if (it > 0) g.pb.fresh = 0u;   // (PathBuf travels by value: the first launches of the batch have carried the flag k_raygen ran with)
+            const PathBuf P = move ? move_pathbuf(it) : g.pb;   // MOVE: the set this iteration reads (written by the previous one's shade launch) and the set it writes
             hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);
             HIP_TRY(hipEventRecord(e0, g.stream));
             // the shadow-ray launch does not depend on the closest-hit launch: on a second stream its tail (a few
@@ -1348,19 +1397,19 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 HIP_TRY(hipEventRecord(ev_fork, g.stream));
                 HIP_TRY(hipStreamWaitEvent(g.stream2, ev_fork, 0));
                 ev_open(1, 1);
-                launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals, g.cnt[it].xcd_any);
+                launch_trace<true, 0>(1, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, P.ray_sh, P.ray_sh, nullptr, nullptr, P.occluded, nullptr, g.totals, g.cnt[it].xcd_any);
                 ev_close(1, 1);
                 HIP_TRY(hipEventRecord(ev_join, g.stream2));
             }
             ev_open(0, 0);
             g_camera_launch = it == 0;
-            launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals, g.cnt[it].xcd_closest);
+            launch_trace<false, 0>(0, counters, tgrid, s, g.q[par][1], &g.cnt[it].closest, 0, &g.cnt[it].cursor_closest, P.ray_cont, P.ray_mis, P.hit_cont, P.hit_mis, nullptr, nullptr, g.totals, g.cnt[it].xcd_closest);
             g_camera_launch = false;
             ev_close(0, 0);
             if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
             else if (it > 0) {
                 ev_open(1, 0);
-                launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals, g.cnt[it].xcd_any);
+                launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, P.ray_sh, P.ray_sh, nullptr, nullptr, P.occluded, nullptr, g.totals, g.cnt[it].xcd_any);
                 ev_close(1, 0);
             }
             HIP_TRY(hipEventRecord(e1, g.stream));
@@ -1370,24 +1419,23 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             const bool bins_now = shade_bins && (it > 0 || bins_first);
             if (bins_now) {  // K7b: whole waves of one class for k_shade
                 const uint32_t bgrid = hinted_grid(grid_for(4), 256);
-                hipLaunchKernelGGL(k_bin_count, dim3(bgrid), dim3(256), 0, g.stream, s->dev, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it]);
+                hipLaunchKernelGGL(k_bin_count, dim3(bgrid), dim3(256), 0, g.stream, s->dev, P, d->max_depth, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it]);
                 hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, g.stream, &g.bin_info[it], g.q_sorted);
                 hipLaunchKernelGGL(k_bin_scatter, dim3(bgrid), dim3(256), 0, g.stream, g.q[par][0], &g.cnt[it], g.bin_keys, &g.bin_info[it], g.q_sorted);
             }
             if (ld_lazy && d->integrator == RSPT_INTEGRATOR_PATH) {
                 const uint32_t lgrid = hinted_grid(grid_for(4), 256);
-                hipLaunchKernelGGL(k_ld_mark, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld, g.pb, d->max_depth, g.q[par][0], &g.cnt[it], ld_lazy->lazy, ld_lazy->new_list);
+                hipLaunchKernelGGL(k_ld_mark, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld, P, d->max_depth, g.q[par][0], &g.cnt[it], ld_lazy->lazy, ld_lazy->new_list);
                 hipLaunchKernelGGL(k_ld_contrib_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev, ld.nvox[0], ld.nvox[1], ld.nvox[2], ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func);
                 hipLaunchKernelGGL(k_ld_build_list, dim3(lgrid), dim3(256), 0, g.stream, s->dev.n_lights, ld_lazy->lazy, ld_lazy->new_list, ld_lazy->func, ld_lazy->cdf, ld_lazy->func_int, ld_lazy->table);
                 hipLaunchKernelGGL(k_ld_commit, dim3(1), dim3(1), 0, g.stream, ld_lazy->lazy);
             }
             if (s->has_textures) {
                 const bool tex_sorted = bins_now && env_size("RSPT_TEXTURE_SORTED", 1) != 0;
-                hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, g.q[par][0], &g.cnt[it].active,
+                hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, P, g.q[par][0], &g.cnt[it].active,
                                    tex_sorted ? g.q_sorted : (const uint32_t*)nullptr, tex_sorted ? &g.bin_info[it] : (const BinInfo*)nullptr);
             }
-            if (it > 0) g.pb.fresh = 0u;   // (PathBuf travels by value: the first launch of the batch has carried the flag k_raygen ran with)
-            hipLaunchKernelGGL(shade_k, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, g.pb, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
+            hipLaunchKernelGGL(shade_k, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, P, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
                                bins_now ? g.q_sorted : (const uint32_t*)nullptr, bins_now ? &g.bin_info[it] : (const BinInfo*)nullptr);
             ev_close(2, 0);
@@ -1409,9 +1457,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                     HIP_TRY(hipMemcpy(slots, g.q[it & 1][0], k * sizeof(uint32_t), hipMemcpyDeviceToHost));
                     for (uint32_t j = 0; j < k; j++) {
                         rspt_ray r; float2 pf; float4 hc;
-                        HIP_TRY(hipMemcpy(&r, g.pb.ray_cont + slots[j], sizeof r, hipMemcpyDeviceToHost));
-                        HIP_TRY(hipMemcpy(&pf, g.pb.p_film + slots[j], sizeof pf, hipMemcpyDeviceToHost));
-                        HIP_TRY(hipMemcpy(&hc, g.pb.hit_cont + slots[j], sizeof hc, hipMemcpyDeviceToHost));
+                        const PathBuf D = move ? move_pathbuf(it) : g.pb;   // (MOVE: queue entries are positions; the film position lives at the original slot)
+                        uint32_t og = slots[j];
+                        if (move) HIP_TRY(hipMemcpy(&og, D.orig + slots[j], sizeof og, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(&r, D.ray_cont + slots[j], sizeof r, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(&pf, D.p_film + og, sizeof pf, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(&hc, D.hit_cont + slots[j], sizeof hc, hipMemcpyDeviceToHost));
                         uint32_t o[3], dd[3], pr;
                         memcpy(o, r.o, 12); memcpy(dd, r.d, 12); memcpy(&pr, &hc.x, 4);
                         fprintf(stderr, "rspt: endless null-surface path: slot %u film (%.3f, %.3f) ray o %08x %08x %08x d %08x %08x %08x last prim %u\n",
@@ -1421,6 +1472,8 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 break;
             }
         }
+        // MOVE: whatever is still queued (paths cut at max_iters; normally nothing) hands its radiance to the film's array
+        if (move) hipLaunchKernelGGL(k_move_flush, dim3(grid_for(1)), dim3(256), 0, g.stream, move_pathbuf(it), g.q[it & 1][0], &g.cnt[it], (uint32_t)g.cap);
         return RSPT_OK;
     };
     auto run_tile_serial = [&]() -> int {  // the pixel samplers: one lane per tile (tile_serial.h)
@@ -1567,7 +1620,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             // the path integrator's first shade launch knows what k_raygen would have written into L_eta / beta (PathBuf::fresh); RSPT_FRESH=0: written and read as before
             const bool fresh_ok = !volpath && !direct && !ao && env_size("RSPT_FRESH", 1) != 0;
             g.pb.fresh = fresh_ok ? 1u : 0u;
-            hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
+            hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, move ? move_pathbuf(0) : g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
             uint32_t it = 0;
             g_queue_hint = 0xffffffffu;
             if (volpath) rc = batch_volpath(bt, it);
@@ -1585,7 +1638,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             else rc = batch_path(bt, it);
             if (rc) return rc;
             if (counters) hipLaunchKernelGGL(k_accum_counts, dim3(1), dim3(1), 0, g.stream, g.cnt, it, g.totals);
-            film_stage(rd, bt, g.pb, g.pix_list);
+            if (move) {   // the film reads the radiance of ended paths by original slot
+                PathBuf fpb = g.pb;
+                fpb.L_eta = g.mv.L_final;
+                film_stage(rd, bt, fpb, g.pix_list);
+            } else
+                film_stage(rd, bt, g.pb, g.pix_list);
         }
     }
     g_queue_hint = 0xffffffffu;

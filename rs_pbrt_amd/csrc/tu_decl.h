@@ -24,6 +24,8 @@ constexpr uint32_t SV_DYNAMIC = SF_ALL & ~SF_ANIM;                              
 #define RSPT_TU_TS2(I, M) RSPT_TU_TS(I, false, M) RSPT_TU_TS(I, true, M)
 #define RSPT_TU_SHADE(F) RSPT_TU_X template __global__ void k_shade<F>(RSPT_SHADE_ARGS);
 #define RSPT_TU_SHADE_W(F, W) RSPT_TU_X template __global__ void k_shade_w<F, W>(RSPT_SHADE_ARGS);
+#define RSPT_TU_SHADE_M(F) RSPT_TU_X template __global__ void k_shade_m<F>(RSPT_SHADE_ARGS);          /* the MOVE forms (kernels.h PathBuf::move): one per feature set, */
+#define RSPT_TU_SHADE_MW(F, W) RSPT_TU_X template __global__ void k_shade_mw<F, W>(RSPT_SHADE_ARGS);  /* built the way that set's default is built */
 #define RSPT_TU_W4(ANY, OM, I, A) \
     RSPT_TU_X template __global__ void k_trace_w4<ANY, OM, I, A>(SceneDev, TexTables, const Wide4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, \
                                                                   const rspt_ray*, float4*, float4*, uint32_t*, rspt_hit*, uint32_t*, uint32_t*, uint2*, uint32_t, int, int, uint32_t, uint32_t*, uint32_t*, uint32_t);
@@ -103,6 +105,18 @@ RSPT_TU_SHADE(SV_DYNAMIC) RSPT_TU_SHADE(SF_ALL)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_H)
 RSPT_TU_SHADE(SV_DIFFUSE_H) RSPT_TU_SHADE_W(SV_DIFFUSE_H, 3) RSPT_TU_SHADE(SV_PLASTIC_H) RSPT_TU_SHADE_W(SV_PLASTIC_H, 3) RSPT_TU_SHADE(SV_TEXTURED_H) RSPT_TU_SHADE_W(SV_TEXTURED_H, 3)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_MA)
+RSPT_TU_SHADE_MW(SV_DIFFUSE, 3) RSPT_TU_SHADE_MW(SV_PLASTIC, 3) RSPT_TU_SHADE_M(SV_DIFFUSE) RSPT_TU_SHADE_M(SV_PLASTIC)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_MB)
+RSPT_TU_SHADE_M(SV_TEXTURED) RSPT_TU_SHADE_MW(SV_TEXTURED_H, 3)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_MC)
+RSPT_TU_SHADE_M(SV_GENERIC) RSPT_TU_SHADE_M(SV_DYNAMIC)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_MH)
+RSPT_TU_SHADE_MW(SV_DIFFUSE_H, 3) RSPT_TU_SHADE_MW(SV_PLASTIC_H, 3)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4)
 RSPT_TU_W4_4(false, 0) RSPT_TU_W4_4(false, 1) RSPT_TU_W4_4(true, 0) RSPT_TU_W4_4(true, 1)
