@@ -60,6 +60,7 @@ struct PathBuf {
     // WRITES.  What stays indexed by the path's ORIGINAL slot: p_film, the final radiance (L_final, what k_film reads) and the general (BSDF-sampled / MIS) form of a
     // pending estimate — ray_mis, hit_mis, nee_c2, nee_beta — which only light-hitting samples and infinite lights use.
     uint32_t move;        // 1: positions (MOVE instantiations); 0: slots for life (every other schedule)
+    uint32_t orig_is_p;   // 1 in the first MOVE launch of a batch: the queue still holds original slots (position = slot), pb.orig is not read
     uint32_t* orig;       // original slot of the path at position p (not read in the fresh launch: position = slot there)
     rspt_ray* o_ray_cont; float4* o_L_eta; float4* o_beta; float4* o_nee_c1; uint64_t* o_sobol_index; uint32_t* o_state; uint32_t* o_orig;
     float4* L_final;      // (L.rgb, -) by original slot, written once when the path ends
@@ -155,7 +156,6 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_raygen(RenderDev rd, Batch bt, P
         pb.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     }
     pb.sobol_index[i] = index;
-    if (pb.move && !pb.fresh) pb.orig[i] = i;   // (MOVE: the first shade launch takes position = slot without reading this; only RSPT_FRESH=0 reads it back)
     pb.state[i] = 5u | ST_ALIVE;  // dimensions 0..4 consumed by the camera sample
     pb.p_film[i] = make_float2(p_film.x, p_film.y);
     if (pb.time) pb.time[i] = rd.shutter_open * (1.0f - p_lens.z) + rd.shutter_close * p_lens.z;   // lerp(sample.time, shutter_open, shutter_close)
@@ -435,6 +435,9 @@ __global__ __launch_bounds__(RSPT_TRACE_BLOCK) void k_trace(SceneDev sc, TexTabl
 }
 
 // ---- K4 + K6 --------------------------------------------------------------------------------
+#ifndef RSPT_MIS_EARLY_OUT
+#define RSPT_MIS_EARLY_OUT 1   // A/B knob (tools/ab_build.sh AB_DEFS=-DRSPT_MIS_EARLY_OUT=0): the light-triangle test of estimate_direct's BSDF-sampled term before the lobes' values
+#endif
 struct ShadeOut {
     bool active, cont, mis, shadow;
 };
@@ -506,7 +509,7 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
     float eta_scale = le.w;
     uint32_t og = p;      // where the slot-for-life arrays of this path live
     if (MOVE) {
-        if (!fresh) og = pb.orig[p];
+        if (!pb.orig_is_p) og = pb.orig[p];
         mv->valid = true;
     }
 
@@ -671,7 +674,19 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                         // BSDF sample with MIS (integrator.rs:480-568), area lights only; sampled_type sentinel 0 (Q6)
                         if (!light_is_delta<F>(lt)) {
                             uint32_t sampled_type = 0;
-                            rgb f = bsdf.template sample_f<F>(wo, &wi, u_scatter, &scattering_pdf, nonspec, &sampled_type);
+                            // An area light's BSDF-sampled term exists only when the sampled direction meets the light's own triangle (pdf_li = 0 otherwise, and with it the
+                            // whole term: integrator.rs:520-566): that test needs the direction alone, so it runs as soon as the lobe has chosen one, and a miss — all but a
+                            // few in 10^4 samples — skips the other lobes' pdfs and the sum of the lobes' values.  Nothing a miss would have computed is read afterwards.
+                            const bool area_mis = !((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) && RSPT_MIS_EARLY_OUT;
+                            TriRec lt_tri;
+                            float t_l = 0.0f, lb0 = 0.0f, lb1 = 0.0f, lb2 = 0.0f;
+                            bool on_light = false;
+                            if (area_mis) lt_tri = load_tri(sc, lt.prim);
+                            rgb f = bsdf.template sample_f_if<F>(wo, &wi, u_scatter, &scattering_pdf, nonspec, &sampled_type, [&](f3 w) {
+                                if (!area_mis) return false;
+                                on_light = tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, offset_ray_origin(h.p, h.p_err, h.n, w), ray_shear(w), RSPT_INF, &t_l, &lb0, &lb1, &lb2);
+                                return !on_light;
+                            });
                             f = f * mkrgb(absdot(wi, h.sh_n));
                             if (!is_black(f) && scattering_pdf > 0.0f) {
                                 f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
@@ -681,9 +696,11 @@ RDEVN ShadeOut shade_path(const SceneDev& sc, const LightDistDev& ld, const Rend
                                     lpdf = infinite_pdf_li(sc, lt, wi);
                                     if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
                                 } else {  // DiffuseAreaLight::pdf_li -> Triangle::pdf_with_ref_point (triangle.rs:745-764)
-                                    TriRec lt_tri = load_tri(sc, lt.prim);
-                                    float t_l, lb0, lb1, lb2;
-                                    if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
+                                    if (!area_mis) {
+                                        lt_tri = load_tri(sc, lt.prim);
+                                        on_light = tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2);
+                                    }
+                                    if (on_light) {
                                         Hit lh;
                                         tri_fill<(F & SF_VERTEX) != 0>(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
                                         lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));
@@ -1069,7 +1086,7 @@ __device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDist
             off_mis += s_wave[w][1];  // MIS entries follow all continuation entries of the workgroup
         }
         if (MOVE) {
-            const uint32_t og = (mv.valid && !pb.fresh) ? pb.orig[p] : p;   // the original slot (the fresh launch: position = slot)
+            const uint32_t og = (mv.valid && !pb.orig_is_p) ? pb.orig[p] : p;   // the original slot (the first MOVE launch of a batch: position = slot)
             // the path's next position: its place in the next active queue (front: a continuation ray is in flight; back: only an estimate is pending)
             const uint32_t p2 = o.cont ? off_act + (uint32_t)__popcll(m_act & lt) : qcap - 1u - (off_tail + (uint32_t)__popcll(m_tail & lt));
             if (o.cont) {
@@ -1136,11 +1153,12 @@ __global__ __launch_bounds__(256) void k_shade_m(RSPT_SHADE_ARGS) {
     RSPT_SHADE_CALL(true, &stage);
 }
 // MOVE: after the last iteration of a batch, whatever is still in the queue (paths cut by RSPT_NULL_PASSES; normally nothing) hands its radiance to the film
-RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_move_flush(PathBuf pb, const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt, uint32_t qcap) {
+// moved = 0: no MOVE launch has run in this batch (max_depth below RSPT_MOVE_FROM): every slot's radiance is still in L_eta by slot, copied over as a whole
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_move_flush(PathBuf pb, const uint32_t* __restrict__ q_active, const QueueCounts* __restrict__ cnt, uint32_t qcap, uint32_t moved) {
     const uint32_t n_front = cnt->active, n = n_front + cnt->active_tail;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const uint32_t p = i < n_front ? q_active[i] : q_active[qcap - 1u - (i - n_front)];
-        pb.L_final[pb.orig[p]] = pb.L_eta[p];
+        pb.L_final[moved ? pb.orig[p] : p] = pb.L_eta[p];
     }
 }
 

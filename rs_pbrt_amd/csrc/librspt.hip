@@ -23,6 +23,7 @@
 #include "motion_bounds.h"
 #include "kernels.h"
 #include "trace_w4.h"
+#include "trace_w4q.h"
 #include "bvh_device.h"
 #include "direct.h"
 #include "vol.h"
@@ -65,7 +66,7 @@ struct Ctx {
     // round 6, MOVING path state (kernels.h PathBuf::move): the second set of the fields a path carries from position to position (iteration it reads set it & 1: set 0 =
     // pb's own arrays, set 1 = these), the original-slot words of both sets, and the radiance of ended paths by original slot
     struct MoveSet { rspt_ray* ray_cont = nullptr; float4* L_eta = nullptr; float4* beta = nullptr; float4* nee_c1 = nullptr; uint64_t* sobol_index = nullptr;
-                     uint32_t* state = nullptr; uint32_t* orig[2] = {nullptr, nullptr}; float4* L_final = nullptr; size_t cap = 0; } mv;
+                     uint32_t* state = nullptr; uint32_t* orig[2] = {nullptr, nullptr}; float4* L_final = nullptr /* the second carried-radiance array (move_pathbuf) */; size_t cap = 0; } mv;
     uint32_t* q[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [parity][active, closest, any]
     QueueCounts* cnt = nullptr;
     uint32_t n_cnt = 0;
@@ -223,6 +224,8 @@ struct rspt_scene_s {
     uint32_t w4_root = 0;
     uint32_t w4_top = 0;              // records kept in LDS by k_trace_w4 (a breadth-first prefix, numbered first)
     bool w4_ok = false;               // false: too large for the ref fields, k_trace_pw serves the scene
+    const Quad4Node* w4q = nullptr;   // the same records on an 8-bit grid, for the shadow-ray kernel k_trace_w4q (trace_w4q.h): plain scenes only (no instances, no alpha masks)
+    const float4* leaf_boxes = nullptr;  // [2 * first primitive of a leaf]: the leaf's LinearBVHNode bounds, for that kernel's exact leaf test
     TexTables tex{};                  // textures / images / per-material slots (dev_texture.h); has_textures says whether set
     bool has_textures = false;
     // Lobe lists as material_assembly.h built them, once per value of the integrator's allow_multiple_lobes ([0]: true — path,
@@ -340,17 +343,24 @@ int ensure_move(size_t cap) {
     g.mv.cap = cap;
     return RSPT_OK;
 }
-// the PathBuf of wavefront iteration `it` under the MOVE schedule: reads set it & 1, writes the other
-PathBuf move_pathbuf(uint32_t it) {
+// the PathBuf of wavefront iteration `it` under the MOVE schedule, which starts at iteration `first` (RSPT_MOVE_FROM: the iterations before it run the slot-for-life
+// kernel on set 0 = pb's own arrays): iteration it >= first reads set (it - first) & 1 and writes the other; at it == first the queue still holds original slots.
+// The radiance is the exception: pb.L_eta — by original slot — is what k_film reads (L_final), so the carried radiance alternates between the two arrays of the
+// second set and only the first MOVE launch reads it from pb.L_eta, where the slot-for-life launches (or nothing: a fresh batch) left it.
+PathBuf move_pathbuf(uint32_t it, uint32_t first) {
     PathBuf b = g.pb;
     const Ctx::MoveSet& m = g.mv;
+    b.L_final = g.pb.L_eta;
+    if (it < first) return b;
     b.move = 1u;
-    b.L_final = m.L_final;
-    rspt_ray* rc[2] = {g.pb.ray_cont, m.ray_cont}; float4* le[2] = {g.pb.L_eta, m.L_eta}; float4* be[2] = {g.pb.beta, m.beta}; float4* c1[2] = {g.pb.nee_c1, m.nee_c1};
-    uint64_t* so[2] = {g.pb.sobol_index, m.sobol_index}; uint32_t* st[2] = {g.pb.state, m.state};
+    b.orig_is_p = it == first ? 1u : 0u;
+    it -= first;
+    rspt_ray* rc[2] = {g.pb.ray_cont, m.ray_cont}; float4* be[2] = {g.pb.beta, m.beta}; float4* c1[2] = {g.pb.nee_c1, m.nee_c1};
+    uint64_t* so[2] = {g.pb.sobol_index, m.sobol_index}; uint32_t* st[2] = {g.pb.state, m.state}; float4* le[2] = {m.L_eta, m.L_final};
     const int r = (int)(it & 1u), w = r ^ 1;
-    b.ray_cont = rc[r]; b.L_eta = le[r]; b.beta = be[r]; b.nee_c1 = c1[r]; b.sobol_index = so[r]; b.state = st[r]; b.orig = m.orig[r];
-    b.o_ray_cont = rc[w]; b.o_L_eta = le[w]; b.o_beta = be[w]; b.o_nee_c1 = c1[w]; b.o_sobol_index = so[w]; b.o_state = st[w]; b.o_orig = m.orig[w];
+    b.ray_cont = rc[r]; b.beta = be[r]; b.nee_c1 = c1[r]; b.sobol_index = so[r]; b.state = st[r]; b.orig = m.orig[r];
+    b.L_eta = it == 0 ? g.pb.L_eta : le[w];   // (written by iteration it - 1 into le[(it - 1) & 1] = le[w])
+    b.o_ray_cont = rc[w]; b.o_L_eta = le[r]; b.o_beta = be[w]; b.o_nee_c1 = c1[w]; b.o_sobol_index = so[w]; b.o_state = st[w]; b.o_orig = m.orig[w];
     return b;
 }
 
@@ -587,6 +597,9 @@ uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
 #define RSPT_PW_REFILL_CAMERA_DEFAULT 48   // a wave of coherent camera rays refills when three quarters of its lanes are idle (the incoherent launches: RSPT_PW_REFILL = 16)
 #endif
 bool g_camera_launch = false;
+#ifndef RSPT_ANY_Q_DEFAULT
+#define RSPT_ANY_Q_DEFAULT 1
+#endif
 template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
 void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                     const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters, uint32_t* xcur) {
@@ -633,6 +646,15 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
             if constexpr (ALPHA) { if (s->alpha_simple) go(k_trace_w4<ANY, OUT_MODE, true, 2, true>); else go(k_trace_w4<ANY, OUT_MODE, true, 1, true>); }
             else go(k_trace_w4<ANY, OUT_MODE, true, 0, true>);
             hipLaunchKernelGGL((k_trace_fixup<ANY, OUT_MODE, true, ALPHA, true>), dim3(grid), dim3(RSPT_TRACE_BLOCK), 0, stream, sc, s->tex, n_overflow, ovf, ra, rb, oa, ob, occ, hits, hi);
+            return;
+        }
+    }
+    if constexpr (ANY && !INST && !ALPHA) {
+        // round 6: shadow rays of plain scenes walk the 64-byte quantised records (trace_w4q.h; RSPT_ANY_Q=0: the plain kernel).  Occlusion flags byte-identical.
+        if (which >= 2 && s->w4q && !(s->w4_root & RSPT_REF_LEAF) && ra == rb && env_size("RSPT_ANY_Q", RSPT_ANY_Q_DEFAULT) != 0 && env_size("RSPT_W4_SHAPE", RSPT_W4_SHAPE_DEFAULT) == 0 && !xcur &&
+            spill_rows == RSPT_W4_SPILL) {
+            hipLaunchKernelGGL((k_trace_w4q<OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4q, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
+                               ra, occ, hits, reinterpret_cast<uint32_t*>(spill), pw_refill, pw_leaf, s->w4_top, pw_chunk, s->leaf_boxes);
             return;
         }
     }
@@ -716,7 +738,7 @@ const ShadeVariant g_shade_variants[] = {
     {SV_PLASTIC_H, "plastic-halton", k_shade<SV_PLASTIC_H>, k_shade_w<SV_PLASTIC_H, 3>, k_shade_w<SV_PLASTIC_H, 3>, 3, k_shade_mw<SV_PLASTIC_H, 3>},
     {SV_TEXTURED_H, "textured-halton", k_shade<SV_TEXTURED_H>, k_shade_w<SV_TEXTURED_H, 3>, k_shade_w<SV_TEXTURED_H, 3>, 3, k_shade_mw<SV_TEXTURED_H, 3>},   // (textured C3 stand-in: 1343 as compiled, 1358 at 3 waves)
     {SV_GENERIC, "generic", k_shade<SV_GENERIC>, k_shade_w<SV_GENERIC, 3>, k_shade_w<SV_GENERIC, 4>, 0, k_shade_m<SV_GENERIC>},
-    {SV_DYNAMIC, "dynamic", k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, 0, k_shade_m<SV_DYNAMIC>},   // + lobe lists built per hit (material_assembly.h)
+    {SV_DYNAMIC, "dynamic", k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, k_shade<SV_DYNAMIC>, 0, nullptr},   // (its MOVE form needs 256 VGPRs = one wave per SIMD: dynamic materials keep slots for life)   // + lobe lists built per hit (material_assembly.h)
     {SF_ALL, "moving", k_shade<SF_ALL>, k_shade<SF_ALL>, k_shade<SF_ALL>, 0, nullptr},                     // + moving object instances (dev_scene.h inst_at)
 };
 // RSPT_SHADE_VARIANT = name forces an instantiation (it must cover the scene), RSPT_SHADE_WAVES = 0 | 3 | 4 one of its builds (A/B)
@@ -1028,6 +1050,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     ShadeKernel shade_move_k = nullptr;
     const ShadeKernel shade_slot_k = shade_kernel_for(s->shade_features | (halton ? (uint32_t)SF_HALTON : (uint32_t)SF_SOBOL), &shade_name, &shade_move_k);
     const bool move = !volpath && !direct && !ao && !pixel_sampler && !s->has_animated && shade_move_k != nullptr && env_size("RSPT_MOVE", 1) != 0;
+    // the first iteration that runs the MOVE kernel.  Iteration 0 reads a dense pixel-major queue whatever the schedule and its stores are dense too (every slot is
+    // written): the slot-for-life kernel serves it (the MOVE form is 4 % slower there: 120 B of scratch against 36 at the same 168 VGPRs, profiles/r06_move_ab.txt),
+    // and the first MOVE launch reads what it left in place
+    const uint32_t move_first = (uint32_t)env_size("RSPT_MOVE_FROM", 1);
     if (!move) free_move();   // (213 GB at the default batch: the second set is not kept for renders that do not use it)
     uint32_t ns = 1;  // samples per pixel per batch: largest power of two with n_pix * ns <= cap
     size_t pix_per_batch = 1;
@@ -1114,7 +1140,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     sob_bits = std::min(52u, sob_bits + 1u);
     if ((size_t)sob_nd * sob_bits * 4 > 64 * 1024) return fail(RSPT_E_UNSUPPORTED, "max_depth %u x %u index bits exceed the LDS Sobol' table", d->max_depth, sob_bits);
     const uint32_t tgrid = trace_grid();
-    const ShadeKernel shade_k = move ? shade_move_k : shade_slot_k;
+    const ShadeKernel shade_k = shade_slot_k;   // (iterations >= move_first of a MOVE render launch shade_move_k)
     if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shade stage instantiation '%s'%s (scene features %#x)\n", shade_name, move ? ", moving path state" : "", s->shade_features);
     // one launch fills the chip once: as many 256-thread blocks per CU as the instantiation's registers and the LDS table allow
     int shade_blocks = 2;
@@ -1387,7 +1413,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         for (;;) {
             const int par = it & 1;
             if (it > 0) g.pb.fresh = 0u;   // (PathBuf travels by value: the first launches of the batch have carried the flag k_raygen ran with)
-            const PathBuf P = move ? move_pathbuf(it) : g.pb;   // MOVE: the set this iteration reads (written by the previous one's shade launch) and the set it writes
+            const PathBuf P = move ? move_pathbuf(it, move_first) : g.pb;   // MOVE: the set this iteration reads (written by the previous one's shade launch) and the set it writes
             hipEvent_t e0 = get_event(n_ev++), e1 = get_event(n_ev++);
             HIP_TRY(hipEventRecord(e0, g.stream));
             // the shadow-ray launch does not depend on the closest-hit launch: on a second stream its tail (a few
@@ -1435,7 +1461,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 hipLaunchKernelGGL(k_texture, dim3(sgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, P, g.q[par][0], &g.cnt[it].active,
                                    tex_sorted ? g.q_sorted : (const uint32_t*)nullptr, tex_sorted ? &g.bin_info[it] : (const BinInfo*)nullptr);
             }
-            hipLaunchKernelGGL(shade_k, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, P, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
+            hipLaunchKernelGGL((move && it >= move_first) ? shade_move_k : shade_k, dim3(hinted_grid(sgrid, 256)), dim3(256), sob_nd * sob_bits * sizeof(uint32_t), g.stream, s->dev, ld, rd, P, g.q[par][0], &g.cnt[it], &g.cnt[it + 1], g.q[par ^ 1][0],
                                g.q[par ^ 1][1], g.q[par ^ 1][2], counters ? g.totals + 2 : nullptr, sob_nd, sob_bits, (uint32_t)g.cap,
                                bins_now ? g.q_sorted : (const uint32_t*)nullptr, bins_now ? &g.bin_info[it] : (const BinInfo*)nullptr);
             ev_close(2, 0);
@@ -1457,9 +1483,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                     HIP_TRY(hipMemcpy(slots, g.q[it & 1][0], k * sizeof(uint32_t), hipMemcpyDeviceToHost));
                     for (uint32_t j = 0; j < k; j++) {
                         rspt_ray r; float2 pf; float4 hc;
-                        const PathBuf D = move ? move_pathbuf(it) : g.pb;   // (MOVE: queue entries are positions; the film position lives at the original slot)
+                        const PathBuf D = move ? move_pathbuf(it, move_first) : g.pb;   // (MOVE: queue entries are positions; the film position lives at the original slot)
                         uint32_t og = slots[j];
-                        if (move) HIP_TRY(hipMemcpy(&og, D.orig + slots[j], sizeof og, hipMemcpyDeviceToHost));
+                        if (move && it > move_first) HIP_TRY(hipMemcpy(&og, D.orig + slots[j], sizeof og, hipMemcpyDeviceToHost));
                         HIP_TRY(hipMemcpy(&r, D.ray_cont + slots[j], sizeof r, hipMemcpyDeviceToHost));
                         HIP_TRY(hipMemcpy(&pf, D.p_film + og, sizeof pf, hipMemcpyDeviceToHost));
                         HIP_TRY(hipMemcpy(&hc, D.hit_cont + slots[j], sizeof hc, hipMemcpyDeviceToHost));
@@ -1473,7 +1499,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             }
         }
         // MOVE: whatever is still queued (paths cut at max_iters; normally nothing) hands its radiance to the film's array
-        if (move) hipLaunchKernelGGL(k_move_flush, dim3(grid_for(1)), dim3(256), 0, g.stream, move_pathbuf(it), g.q[it & 1][0], &g.cnt[it], (uint32_t)g.cap);
+        if (move) hipLaunchKernelGGL(k_move_flush, dim3(grid_for(1)), dim3(256), 0, g.stream, move_pathbuf(it, move_first), g.q[it & 1][0], &g.cnt[it], (uint32_t)g.cap, it > move_first ? 1u : 0u);
         return RSPT_OK;
     };
     auto run_tile_serial = [&]() -> int {  // the pixel samplers: one lane per tile (tile_serial.h)
@@ -1620,7 +1646,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             // the path integrator's first shade launch knows what k_raygen would have written into L_eta / beta (PathBuf::fresh); RSPT_FRESH=0: written and read as before
             const bool fresh_ok = !volpath && !direct && !ao && env_size("RSPT_FRESH", 1) != 0;
             g.pb.fresh = fresh_ok ? 1u : 0u;
-            hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, move ? move_pathbuf(0) : g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);
+            hipLaunchKernelGGL(k_raygen, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, rd, bt, g.pb, g.pix_list, g.q[0][0], g.q[0][1], g.cnt);   // (MOVE or not: iteration 0 lives in set 0 = pb's own arrays, by slot)
             uint32_t it = 0;
             g_queue_hint = 0xffffffffu;
             if (volpath) rc = batch_volpath(bt, it);
@@ -1637,13 +1663,15 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             else if (ao) rc = batch_ao(bt, it);
             else rc = batch_path(bt, it);
             if (rc) return rc;
+            if (getenv("RSPT_QUEUE_LOG") && p0 == 0 && s0 == (uint32_t)smp_begin) {   // the queue lengths of the render's first batch, per wavefront iteration (profiles/rNN_shade_ledger.md)
+                std::vector<QueueCounts> qc(it + 1);
+                HIP_TRY(hipMemcpyAsync(qc.data(), g.cnt, (it + 1) * sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                for (uint32_t k = 0; k <= it; k++)
+                    fprintf(stderr, "rspt: queue it %u: active %u (+ %u that only wait for an estimate) closest %u any %u of %u paths\n", k, qc[k].active, qc[k].active_tail, qc[k].closest, qc[k].any, bt.n);
+            }
             if (counters) hipLaunchKernelGGL(k_accum_counts, dim3(1), dim3(1), 0, g.stream, g.cnt, it, g.totals);
-            if (move) {   // the film reads the radiance of ended paths by original slot
-                PathBuf fpb = g.pb;
-                fpb.L_eta = g.mv.L_final;
-                film_stage(rd, bt, fpb, g.pix_list);
-            } else
-                film_stage(rd, bt, g.pb, g.pix_list);
+            film_stage(rd, bt, g.pb, g.pix_list);   // (MOVE: ended paths have written their radiance to pb.L_eta by original slot, move_pathbuf)
         }
     }
     g_queue_hint = 0xffffffffu;
@@ -2413,6 +2441,58 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
         s->w4_ok = recs.size() <= RSPT_W4_OFFSET_MASK && big.size() <= RSPT_W4_OFFSET_MASK;
         if (s->w4_ok && !recs.empty() && (rc = upload(s, recs.data(), recs.size(), &s->w4))) return bail(rc);
         if (!big.empty() && (rc = upload(s, big.data(), big.size(), &s->big_leaves))) return bail(rc);
+        // ---- the quantised form of the records (trace_w4q.h) for the shadow rays of scenes without instances and alpha masks ----
+        bool any_alpha = false;
+        for (uint32_t i = 0; i < d->n_meshes; i++) any_alpha = any_alpha || d->meshes[i].alpha_tex || d->meshes[i].shadow_alpha_tex;
+        if (s->w4_ok && !recs.empty() && !instanced && !any_alpha && env_size("RSPT_W4Q_BUILD", 1) != 0) {
+            std::vector<Quad4Node> q(recs.size());
+            bool ok = true;
+            for (size_t i = 0; i < recs.size() && ok; i++) {
+                const Wide4Node& w = recs[i];
+                Quad4Node& o = q[i];
+                memset(&o, 0, sizeof o);
+                memcpy(o.ref, w.ref, sizeof o.ref);
+                uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, meta = 0;
+                for (int c = 0; c < 3 && ok; c++) {
+                    const float lo4[4] = {w.b[c].x, w.b[c].y, w.b[3 + c].x, w.b[3 + c].y}, hi4[4] = {w.b[c].z, w.b[c].w, w.b[3 + c].z, w.b[3 + c].w};
+                    double org = 0.0, top = 0.0;
+                    bool have = false;
+                    for (int k = 0; k < 4; k++) {
+                        if (lo4[k] != lo4[k]) { if (c == 0) meta |= 1u << (24 + k); continue; }   // an empty slot: a NaN box
+                        org = have ? std::min(org, (double)lo4[k]) : (double)lo4[k];
+                        top = have ? std::max(top, (double)hi4[k]) : (double)hi4[k];
+                        have = true;
+                    }
+                    if (!have) { o.org[c] = 0.0f; meta |= 100u << (8 * c); continue; }
+                    if (!std::isfinite(org) || !std::isfinite(top)) { ok = false; break; }
+                    // cell = 2^(e - 127), the smallest power of two with 255 cells covering the extent (never below 2^-67, never above 2^60)
+                    int e = 60;
+                    while (e < 187 && std::ceil((top - org) / std::ldexp(1.0, e - 127)) > 255.0) e++;
+                    if (std::ceil((top - org) / std::ldexp(1.0, e - 127)) > 255.0) { ok = false; break; }
+                    const double cell = std::ldexp(1.0, e - 127);
+                    o.org[c] = (float)org;   // (org is one of the f32 planes: exact)
+                    meta |= (uint32_t)e << (8 * c);
+                    for (int k = 0; k < 4; k++) {
+                        if (lo4[k] != lo4[k]) { qlo[c] |= 255u << (8 * k); continue; }   // empty: lower plane above the upper one (and the empty bit)
+                        const double fl = std::floor(((double)lo4[k] - org) / cell), ce = std::ceil(((double)hi4[k] - org) / cell);
+                        const uint32_t a = (uint32_t)std::min(255.0, std::max(0.0, fl)), b = (uint32_t)std::min(255.0, std::max(0.0, ce));
+                        if (org + a * cell > (double)lo4[k] || org + b * cell < (double)hi4[k]) { ok = false; break; }   // outward, in exact arithmetic
+                        qlo[c] |= a << (8 * k); qhi[c] |= b << (8 * k);
+                    }
+                }
+                o.meta = meta; o.qlo[0] = qlo[0]; o.qlo[1] = qlo[1]; o.qlo[2] = qlo[2]; o.qhi_x = qhi[0]; o.qhi_y = qhi[1]; o.qhi_z = qhi[2];
+            }
+            if (ok) {
+                std::vector<float4> lb(2 * (size_t)d->n_prims, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                for (uint64_t ni = 0; ni < d->n_nodes; ni++) {
+                    const rspt_bvh_node& n = d->nodes[ni];
+                    if (n.n_prims == 0) continue;
+                    lb[2 * (size_t)n.offset] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0]);   // the layout box_hit reads (sc.nodes)
+                    lb[2 * (size_t)n.offset + 1] = make_float4(n.bmax[1], n.bmax[2], 0.0f, 0.0f);
+                }
+                if ((rc = upload(s, q.data(), q.size(), &s->w4q)) || (rc = upload(s, lb.data(), lb.size(), &s->leaf_boxes))) return bail(rc);
+            }
+        }
     }
     if (d->n_prims) {
         float4* tris = nullptr;

@@ -6,6 +6,7 @@
 #include "tile_serial.h"
 #include "lane_serial.h"
 #include "trace_w4.h"
+#include "trace_w4q.h"
 
 namespace rspt {
 
@@ -113,10 +114,14 @@ RSPT_TU_SHADE_MW(SV_DIFFUSE, 3) RSPT_TU_SHADE_MW(SV_PLASTIC, 3) RSPT_TU_SHADE_M(
 RSPT_TU_SHADE_M(SV_TEXTURED) RSPT_TU_SHADE_MW(SV_TEXTURED_H, 3)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_MC)
-RSPT_TU_SHADE_M(SV_GENERIC) RSPT_TU_SHADE_M(SV_DYNAMIC)
+RSPT_TU_SHADE_M(SV_GENERIC)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_MH)
 RSPT_TU_SHADE_MW(SV_DIFFUSE_H, 3) RSPT_TU_SHADE_MW(SV_PLASTIC_H, 3)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4Q)
+RSPT_TU_X template __global__ void k_trace_w4q<0>(SceneDev, const Quad4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, uint32_t*, rspt_hit*, uint32_t*, int, int, uint32_t, uint32_t, const float4*);
+RSPT_TU_X template __global__ void k_trace_w4q<1>(SceneDev, const Quad4Node*, const uint2*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, const rspt_ray*, uint32_t*, rspt_hit*, uint32_t*, int, int, uint32_t, uint32_t, const float4*);
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_W4)
 RSPT_TU_W4_4(false, 0) RSPT_TU_W4_4(false, 1) RSPT_TU_W4_4(true, 0) RSPT_TU_W4_4(true, 1)
