@@ -422,7 +422,18 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
     }
     if (!light_is_delta<F>(lt)) {
         uint32_t sampled_type = 0;
-        rgb f = d.bsdf.template sample_f<F>(d.wo, &wi, u_scatter, &scattering_pdf, flags, &sampled_type);
+        // (round 6, as kernels.h shade_path: an area light's BSDF-sampled term needs the sampled direction to meet the light's own triangle — tested as soon as the
+        //  lobe has chosen the direction; a miss skips the other lobes' pdfs and the lobes' values)
+        const bool area_mis = !((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) && RSPT_MIS_EARLY_OUT;
+        TriRec lt_tri;
+        float t_l = 0.0f, lb0 = 0.0f, lb1 = 0.0f, lb2 = 0.0f;
+        bool on_light = false;
+        if (area_mis) lt_tri = load_tri(sc, lt.prim);
+        rgb f = d.bsdf.template sample_f_if<F>(d.wo, &wi, u_scatter, &scattering_pdf, flags, &sampled_type, [&](f3 w) {
+            if (!area_mis) return false;
+            on_light = tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, offset_ray_origin(h.p, h.p_err, h.n, w), ray_shear(w), RSPT_INF, &t_l, &lb0, &lb1, &lb2);
+            return !on_light;
+        });
         f = f * mkrgb(absdot(wi, h.sh_n));
         if (!is_black(f) && scattering_pdf > 0.0f) {
             const f3 ro = offset_ray_origin(h.p, h.p_err, h.n, wi);
@@ -432,9 +443,11 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
                 lpdf = infinite_pdf_li(sc, lt, wi);
                 if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
             } else {
-                const TriRec lt_tri = load_tri(sc, lt.prim);
-                float t_l, lb0, lb1, lb2;
-                if (tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2)) {
+                if (!area_mis) {
+                    lt_tri = load_tri(sc, lt.prim);
+                    on_light = tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2);
+                }
+                if (on_light) {
                     Hit lh;
                     tri_fill<(F & SF_VERTEX) != 0>(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
                     lpdf = dist2(h.p, lh.p) / (absdot(lh.n, -wi) * tri_area(lt_tri));

@@ -226,6 +226,8 @@ struct rspt_scene_s {
     bool w4_ok = false;               // false: too large for the ref fields, k_trace_pw serves the scene
     const Quad4Node* w4q = nullptr;   // the same records on an 8-bit grid, for the shadow-ray kernel k_trace_w4q (trace_w4q.h): plain scenes only (no instances, no alpha masks)
     const float4* leaf_boxes = nullptr;  // [2 * first primitive of a leaf]: the leaf's LinearBVHNode bounds, for that kernel's exact leaf test
+    int any_q_choice = -1;            // which kernel serves this scene's shadow rays: -1 not measured yet (the plain one until then), 0 k_trace_w4<true>, 1 k_trace_w4q — set by
+                                      // the first large shadow-ray launch of a render, which runs both on the same rays and keeps the faster (render_impl tune_any)
     TexTables tex{};                  // textures / images / per-material slots (dev_texture.h); has_textures says whether set
     bool has_textures = false;
     // Lobe lists as material_assembly.h built them, once per value of the integrator's allow_multiple_lobes ([0]: true — path,
@@ -597,9 +599,7 @@ uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
 #define RSPT_PW_REFILL_CAMERA_DEFAULT 48   // a wave of coherent camera rays refills when three quarters of its lanes are idle (the incoherent launches: RSPT_PW_REFILL = 16)
 #endif
 bool g_camera_launch = false;
-#ifndef RSPT_ANY_Q_DEFAULT
-#define RSPT_ANY_Q_DEFAULT 1
-#endif
+int g_any_q_force = -1;   // render_impl's measurement of the two shadow-ray kernels (tune_any): 0 / 1 forces the plain / the quantised one for the launches in between
 template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
 void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm, uint32_t* cursor,
                     const rspt_ray* ra, const rspt_ray* rb, float4* oa, float4* ob, uint32_t* occ, rspt_hit* hits, unsigned long long* counters, uint32_t* xcur) {
@@ -651,8 +651,12 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     }
     if constexpr (ANY && !INST && !ALPHA) {
         // round 6: shadow rays of plain scenes walk the 64-byte quantised records (trace_w4q.h; RSPT_ANY_Q=0: the plain kernel).  Occlusion flags byte-identical.
-        if (which >= 2 && s->w4q && !(s->w4_root & RSPT_REF_LEAF) && ra == rb && env_size("RSPT_ANY_Q", RSPT_ANY_Q_DEFAULT) != 0 && env_size("RSPT_W4_SHAPE", RSPT_W4_SHAPE_DEFAULT) == 0 && !xcur &&
-            spill_rows == RSPT_W4_SPILL) {
+        // Which of the two is faster depends on the rays, not on the scene's size: the quantised records win where the plain kernel is bound by L1 lane requests (C2's incoherent
+        // shadow rays through a dense soup: +6 % on the frame) and lose where it is bound by VALU issue with half its fetches in LDS (the C3 stand-in's coherent ones: -2.5 %;
+        // profiles/r06_any_q_ab.txt).  RSPT_ANY_Q=0 / 1 forces one; otherwise the scene's measured choice (rspt_scene_s::any_q_choice), the plain kernel until it exists.
+        const char* q_env = getenv("RSPT_ANY_Q");
+        const bool use_q = g_any_q_force >= 0 ? g_any_q_force != 0 : (q_env && *q_env ? atoi(q_env) != 0 : s->any_q_choice > 0);
+        if (use_q && which >= 2 && s->w4q && !(s->w4_root & RSPT_REF_LEAF) && ra == rb && env_size("RSPT_W4_SHAPE", RSPT_W4_SHAPE_DEFAULT) == 0 && !xcur && spill_rows == RSPT_W4_SPILL) {
             hipLaunchKernelGGL((k_trace_w4q<OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4q, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
                                ra, occ, hits, reinterpret_cast<uint32_t*>(spill), pw_refill, pw_leaf, s->w4_top, pw_chunk, s->leaf_boxes);
             return;
@@ -1169,6 +1173,29 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     HIP_TRY(hipEventRecord(ev_k0, g.stream));
     uint64_t samples = 0, truncated = 0, vol_rays = 0;
     // ---- one batch of each integrator (the wavefront schedules); `it` leaves with the number of queue-counter records used ----
+    // Which kernel serves this scene's shadow rays (trace_w4q.h; launch_trace_v): measured once per scene, by the first shadow-ray launch of a batch of >= 2^22 paths — both kernels
+    // run on the same rays (their flags are identical), the faster one is kept in rspt_scene_s::any_q_choice.  Returns 1 if it made the launch (twice), 0 if there was nothing to
+    // measure (the caller launches as usual), -code on an error.
+    auto tune_any = [&](uint32_t batch_n, const uint32_t* queue, uint32_t* count_ptr, uint32_t* cursor, const rspt_ray* rays, uint32_t* occ, uint32_t* xcd) -> int {
+        if (!s->w4q || s->any_q_choice >= 0 || getenv("RSPT_ANY_Q") || counters || batch_n < (1u << 22) || env_size("RSPT_ANY_Q_TUNE", 1) == 0) return 0;
+        hipEvent_t t0 = get_event(n_ev++), t1 = get_event(n_ev++), t2 = get_event(n_ev++);
+        if (hipEventRecord(t0, g.stream) != hipSuccess) return RSPT_E_HIP;
+        g_any_q_force = 0;
+        launch_trace<true, 0>(0, false, tgrid, s, queue, count_ptr, 0, cursor, rays, rays, nullptr, nullptr, occ, nullptr, g.totals, xcd);
+        (void)hipEventRecord(t1, g.stream);
+        (void)hipMemsetAsync(cursor, 0, sizeof(uint32_t), g.stream);   // (the persistent kernel's fetch cursor: the second run starts over)
+        g_any_q_force = 1;
+        launch_trace<true, 0>(0, false, tgrid, s, queue, count_ptr, 0, cursor, rays, rays, nullptr, nullptr, occ, nullptr, g.totals, xcd);
+        g_any_q_force = -1;
+        (void)hipEventRecord(t2, g.stream);
+        if (hipEventSynchronize(t2) != hipSuccess) return RSPT_E_HIP;
+        float ms_plain = 0.0f, ms_q = 0.0f;
+        (void)hipEventElapsedTime(&ms_plain, t0, t1);
+        (void)hipEventElapsedTime(&ms_q, t1, t2);
+        s->any_q_choice = ms_q < ms_plain ? 1 : 0;
+        if (getenv("RSPT_VERBOSE")) fprintf(stderr, "rspt: shadow rays of this scene: k_trace_w4<any> %.2f ms, k_trace_w4q %.2f ms on the same launch -> %s\n", ms_plain, ms_q, s->any_q_choice ? "the quantised records" : "the plain records");
+        return 1;
+    };
     auto batch_volpath = [&](const Batch& bt, uint32_t& it) -> int {  // VolPathIntegrator::li (vol.h): the continuation queue doubles as the list of live paths
         const uint32_t dgrid = grid_for(4);
         const uint32_t null_passes = (uint32_t)env_size("RSPT_NULL_PASSES", 1024);
@@ -1320,7 +1347,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 ev_close(2, 0);
                 ev_open(1, 0);
                 s->dev.time_div = H * dl_R;   // estimate r of node slot n sits in virtual slot n * R + r
-                launch_trace<true, 0>(0, false, tgrid, s, g.q[0][2], &rc_->any, 0, &rc_->cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                {
+                    const int tuned = tune_any(bt.n, g.q[0][2], &rc_->any, &rc_->cursor_any, g.pb.ray_sh, g.pb.occluded, nullptr);   // (the scene's first large shadow-ray launch measures the two kernels)
+                    if (tuned < 0) return fail(tuned, "the shadow-ray kernel measurement failed");
+                    if (!tuned) launch_trace<true, 0>(0, false, tgrid, s, g.q[0][2], &rc_->any, 0, &rc_->cursor_any, g.pb.ray_sh, g.pb.ray_sh, nullptr, nullptr, g.pb.occluded, nullptr, g.totals);
+                }
                 ev_close(1, 0);
                 ev_open(0, 0);
                 launch_trace<false, 0>(0, false, tgrid, s, g.q[0][1], &rc_->closest, 0, &rc_->cursor_closest, g.pb.ray_cont, g.pb.ray_mis, g.pb.hit_cont, g.pb.hit_mis, nullptr, nullptr, g.totals);
@@ -1418,7 +1449,15 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             HIP_TRY(hipEventRecord(e0, g.stream));
             // the shadow-ray launch does not depend on the closest-hit launch: on a second stream its tail (a few
             // long rays on an otherwise idle chip) overlaps the other launch
-            const int any_lane = (it > 0 && two_streams) ? 1 : 0;
+            int any_lane = (it > 0 && two_streams) ? 1 : 0;
+            bool any_done = false;
+            if (it == 1) {   // (the scene's first large shadow-ray launch measures the two kernels: tune_any above)
+                ev_open(1, 0);
+                const int tuned = tune_any(bt.n, g.q[par][2], &g.cnt[it].any, &g.cnt[it].cursor_any, P.ray_sh, P.occluded, g.cnt[it].xcd_any);
+                ev_close(1, 0);
+                if (tuned < 0) return fail(tuned, "the shadow-ray kernel measurement failed");
+                if (tuned) { any_done = true; any_lane = 0; }
+            }
             if (any_lane) {
                 HIP_TRY(hipEventRecord(ev_fork, g.stream));
                 HIP_TRY(hipStreamWaitEvent(g.stream2, ev_fork, 0));
@@ -1433,7 +1472,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             g_camera_launch = false;
             ev_close(0, 0);
             if (any_lane) HIP_TRY(hipStreamWaitEvent(g.stream, ev_join, 0));
-            else if (it > 0) {
+            else if (it > 0 && !any_done) {
                 ev_open(1, 0);
                 launch_trace<true, 0>(0, counters, tgrid, s, g.q[par][2], &g.cnt[it].any, 0, &g.cnt[it].cursor_any, P.ray_sh, P.ray_sh, nullptr, nullptr, P.occluded, nullptr, g.totals, g.cnt[it].xcd_any);
                 ev_close(1, 0);
@@ -1663,6 +1702,13 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             else if (ao) rc = batch_ao(bt, it);
             else rc = batch_path(bt, it);
             if (rc) return rc;
+            if (getenv("RSPT_QUEUE_LOG") && p0 == 0 && s0 == (uint32_t)smp_begin) {   // the queue lengths of the render's first batch, per wavefront iteration (profiles/rNN_shade_ledger.md)
+                std::vector<QueueCounts> qc(it + 1);
+                HIP_TRY(hipMemcpyAsync(qc.data(), g.cnt, (it + 1) * sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                for (uint32_t k = 0; k <= it; k++)
+                    fprintf(stderr, "rspt: queue it %u: active %u (+ %u that only wait for an estimate) closest %u any %u of %u paths\n", k, qc[k].active, qc[k].active_tail, qc[k].closest, qc[k].any, bt.n);
+            }
             if (getenv("RSPT_QUEUE_LOG") && p0 == 0 && s0 == (uint32_t)smp_begin) {   // the queue lengths of the render's first batch, per wavefront iteration (profiles/rNN_shade_ledger.md)
                 std::vector<QueueCounts> qc(it + 1);
                 HIP_TRY(hipMemcpyAsync(qc.data(), g.cnt, (it + 1) * sizeof(QueueCounts), hipMemcpyDeviceToHost, g.stream));
@@ -2467,6 +2513,7 @@ int rspt_scene_create(const rspt_scene_desc* d, rspt_scene_t* out) {
                     if (!std::isfinite(org) || !std::isfinite(top)) { ok = false; break; }
                     // cell = 2^(e - 127), the smallest power of two with 255 cells covering the extent (never below 2^-67, never above 2^60)
                     int e = 60;
+                    if (top > org) { int ex = 0; (void)std::frexp((top - org) / 255.0, &ex); e = std::max(60, std::min(187, ex + 127 - 2)); }   // (start two below the answer: the loop then takes <= 3 steps)
                     while (e < 187 && std::ceil((top - org) / std::ldexp(1.0, e - 127)) > 255.0) e++;
                     if (std::ceil((top - org) / std::ldexp(1.0, e - 127)) > 255.0) { ok = false; break; }
                     const double cell = std::ldexp(1.0, e - 127);

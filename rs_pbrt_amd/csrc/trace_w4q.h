@@ -36,6 +36,9 @@ static_assert(sizeof(Quad4Node) == 64, "Quad4Node is four 16-byte loads");
 #define RSPT_W4Q_TOP 216     // root-side records in LDS: 64 * 216 = 13.5 KB; with the stack columns 29.5 KB = five workgroups per CU, as k_trace_w4
 #endif
 #define RSPT_W4Q_SPILL (RSPT_W4_MAX_STACK - RSPT_W4Q_LDS)
+#ifndef RSPT_W4Q_ORDERED
+#define RSPT_W4Q_ORDERED 0   // 1: the four slots of a record in the reference's near-first order (A/B, tools/ab_build.sh AB_DEFS=-DRSPT_W4Q_ORDERED=1)
+#endif
 
 template <int OUT_MODE>
 __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4q(SceneDev sc, const Quad4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
@@ -197,9 +200,32 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4q(SceneDev sc, const 
                     }
                     h0 = h0 && in[0]; h1 = h1 && in[1]; h2 = h2 && in[2]; h3 = h3 && in[3];
                 }
-                const uint32_t f0 = __float_as_uint(rf.x) & ~RSPT_W4_AXIS_MASK, f1 = __float_as_uint(rf.y) & ~RSPT_W4_AXIS_MASK, f2 = __float_as_uint(rf.z) & ~RSPT_W4_AXIS_MASK, f3w = __float_as_uint(rf.w);
-                // stored order: the first slot that passes is walked next, the others wait on the stack (occlusion does not depend on the order)
+                const uint32_t g0 = __float_as_uint(rf.x), g1 = __float_as_uint(rf.y), g2 = __float_as_uint(rf.z);
+                const uint32_t f0 = g0 & ~RSPT_W4_AXIS_MASK, f1 = g1 & ~RSPT_W4_AXIS_MASK, f2 = g2 & ~RSPT_W4_AXIS_MASK, f3w = __float_as_uint(rf.w);
                 uint32_t next = RSPT_NONE;
+#if RSPT_W4Q_ORDERED
+                {   // the reference's near-first order of the four (trace_w4.h: three sign bits): an occluder near the origin is found before the far side of the tree is walked
+                    const bool sA = ((negbits >> ((g0 >> RSPT_W4_AXIS_SHIFT) & 3u)) & 1u) != 0, sB0 = ((negbits >> ((g1 >> RSPT_W4_AXIS_SHIFT) & 3u)) & 1u) != 0,
+                               sB1 = ((negbits >> ((g2 >> RSPT_W4_AXIS_SHIFT) & 3u)) & 1u) != 0;
+                    const uint32_t r0 = h0 ? f0 : RSPT_NONE, r1 = h1 ? f1 : RSPT_NONE, r2 = h2 ? f2 : RSPT_NONE, r3 = h3 ? f3w : RSPT_NONE;
+                    const uint32_t g0n = sB0 ? r1 : r0, g0f = sB0 ? r0 : r1, g1n = sB1 ? r3 : r2, g1f = sB1 ? r2 : r3;
+                    const uint32_t e0 = sA ? g1n : g0n, e1 = sA ? g1f : g0f, e2 = sA ? g0n : g1n, e3 = sA ? g0f : g1f;
+                    auto put = [&](uint32_t ref) {
+                        if (sp < RSPT_W4Q_LDS) {
+                            my[sp * BLOCK] = ref;
+                            asm volatile("");
+                        } else
+                            my_spill[(size_t)(sp - RSPT_W4Q_LDS) * spill_stride] = ref;
+                        sp++;
+                    };
+                    next = e0 != RSPT_NONE ? e0 : (e1 != RSPT_NONE ? e1 : (e2 != RSPT_NONE ? e2 : e3));
+                    const bool p1 = e0 != RSPT_NONE, p2 = p1 || e1 != RSPT_NONE, p3 = p2 || e2 != RSPT_NONE;
+                    if (e3 != RSPT_NONE && p3) put(e3);
+                    if (e2 != RSPT_NONE && p2) put(e2);
+                    if (e1 != RSPT_NONE && p1) put(e1);
+                }
+#else
+                // stored order: the first slot that passes is walked next, the others wait on the stack (occlusion does not depend on the order)
                 auto take = [&](bool h, uint32_t ref) {
                     if (!h) return;
                     if (next == RSPT_NONE) { next = ref; return; }
@@ -211,6 +237,7 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4q(SceneDev sc, const 
                     sp++;
                 };
                 take(h0, f0); take(h1, f1); take(h2, f2); take(h3, f3w);
+#endif
                 if (next != RSPT_NONE) {
                     if (next & RSPT_REF_LEAF) leaf = next;
                     else cur = next;

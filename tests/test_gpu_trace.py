@@ -352,3 +352,29 @@ def test_device_libm_equals_host_libm(gpu, oracle):
     oracle.lib().orc_libm(gpu.LIBM["atan2"], y.ctypes.data, x.ctypes.data, y.size, ref.ctypes.data)
     ok = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
     assert ok.all(), ("atan2", y[~ok][:4], x[~ok][:4], got[~ok][:4], ref[~ok][:4])
+
+
+def test_quantised_shadow_ray_kernel_flags_are_the_references(gpu, oracle, soup, cornell, monkeypatch):
+    """round 6: k_trace_w4q (trace_w4q.h: 64-byte records on an 8-bit grid, conservative box tests, the reference's exact test on every leaf box) forced by RSPT_ANY_Q=1 —
+    occlusion flags byte-identical to the oracle's BVHAccel::intersect_p on random rays, short shadow-like segments, axis-parallel rays (a zero direction component: the
+    axis leaves the grid test and becomes a containment test), rays that start on a triangle's plane, and rays with a huge / tiny direction (reciprocals beyond 2^60)."""
+    monkeypatch.setenv("RSPT_ANY_Q", "1")
+    for (sc, ds), lo, hi in ((soup, -1.3, 1.3), (cornell, 20.0, 530.0)):
+        rng = np.random.default_rng(606)
+        sets = [random_rays(150000, 61, lo, hi), random_rays(150000, 62, lo, hi, t_max=0.35 * (hi - lo))]
+        ax = random_rays(60000, 63, lo, hi)
+        k = rng.integers(0, 3, len(ax))
+        d = ax["d"].copy(); d[np.arange(len(ax)), k] = 0.0; d[::3, (k[::3] + 1) % 3] = 0.0    # one zero component, every third ray two
+        ax["d"] = d
+        sets.append(ax)
+        sc_rays = random_rays(60000, 64, lo, hi)
+        sc_rays["d"] = (sc_rays["d"] * np.where(rng.uniform(size=(len(sc_rays), 1)) < 0.5, 1e-25, 1e25)).astype(np.float32)   # |1 / d| far beyond 2^60 / far below
+        sc_rays["d"][::2, 0] = np.float32(1.0)
+        sets.append(sc_rays)
+        for rays in sets:
+            got, ref = gpu.trace(ds, rays, any_hit=True), oracle.trace(sc, rays, any_hit=True)
+            assert got.tobytes() == ref.tobytes()
+    monkeypatch.setenv("RSPT_ANY_Q", "0")
+    sc, ds = soup
+    rays = random_rays(50000, 65, -1.3, 1.3)
+    assert gpu.trace(ds, rays, any_hit=True).tobytes() == oracle.trace(sc, rays, any_hit=True).tobytes()
