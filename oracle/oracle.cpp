@@ -5,6 +5,9 @@
 // byte).  Everything else (other materials, textures, lights, samplers, integrators, media, instances) is UNPINNED by the reference:
 // rs_pbrt ships no tests / golden vectors and cannot be built here (no Rust toolchain), so those parts rest on first-principles
 // known-answer tests (tests/test_oracle_*.py) until a dump of real rs_pbrt is committed (oracle/REFERENCE_FIXTURES.md).
+// Pinned by the reference's own TEXT since round 6 (compiled from the Rust sources by committed rewrite rules, oracle/make_leaf_fixtures.py; bit for bit):
+// fr_dielectric, fr_conductor, trowbridge_reitz_sample_11 / _sample, sobol_sample_float, concentric_sample_disk, Matrix4x4::inverse; since round 5
+// AnimatedTransform's derivative polynomials (oracle/make_motion_fixture.py).  Control flow (dispatch, loops, traversal order) remains unpinned.
 #include "orc_render.hpp"
 #include "orc_motion.hpp"
 

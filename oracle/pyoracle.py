@@ -6,7 +6,10 @@ The product package (rs_pbrt_amd) never does.
 Parity: pinned by real rs_pbrt output on one scene family only — the reference's two documentation renders of the Cornell box
 (tests/test_reference_pin.py: path, Sobol', matte, area light, spatial light distribution, film).  For everything else the
 reference has no tests or golden vectors and no Rust toolchain exists here: unpinned, checked against first-principles known
-answers (tests/test_oracle_*.py), not against rs_pbrt output."""
+answers (tests/test_oracle_*.py), not against rs_pbrt output.  Round 6 adds pins by the reference's own TEXT: seven scalar leaf functions
+(fr_dielectric, fr_conductor, trowbridge_reitz_sample_11 / _sample, sobol_sample_float, concentric_sample_disk, Matrix4x4::inverse) compiled from the Rust
+sources by oracle/make_leaf_fixtures.py and equal to this oracle bit for bit (tests/test_reference_leaf_functions.py), AnimatedTransform's derivative
+polynomials (oracle/make_motion_fixture.py, round 5), and the Sobol' / max-min-distance / prime tables (tests/test_reference_tables.py).  Control flow stays unpinned."""
 import ctypes as C
 import os
 import subprocess

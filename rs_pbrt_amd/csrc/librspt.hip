@@ -633,7 +633,8 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     // (camera launch, C3 stand-in, one box, alternating: refill 16 -> 2079 / 2067 Msamples/s, 32 -> 2083 / 2083, 48 -> 2114 / 2113, 64 -> 2105 / 2101; leaf 16 / 24 / 32 at refill 16: 2061 / 2059 / 2046)
     const int pw_refill = (int)(g_camera_launch ? env_size("RSPT_PW_REFILL_CAMERA", RSPT_PW_REFILL_CAMERA_DEFAULT) : env_size("RSPT_PW_REFILL", RSPT_PW_REFILL));
     const int pw_leaf = (int)(g_camera_launch ? env_size("RSPT_PW_LEAF_CAMERA", env_size("RSPT_PW_LEAF", RSPT_PW_LEAF)) : env_size("RSPT_PW_LEAF", RSPT_PW_LEAF));
-    const uint32_t pw_chunk = (uint32_t)std::min<size_t>(std::max<size_t>((g_camera_launch ? env_size("RSPT_PW_CHUNK_CAMERA", RSPT_PW_CHUNK_CAMERA_DEFAULT) : env_size("RSPT_PW_CHUNK", RSPT_PW_CHUNK)) & ~(size_t)63, 64), 1u << 20);
+    const uint32_t pw_chunk = (uint32_t)std::min<size_t>(std::max<size_t>((g_camera_launch ? env_size("RSPT_PW_CHUNK_CAMERA", RSPT_PW_CHUNK_CAMERA_DEFAULT) : env_size("RSPT_PW_CHUNK", RSPT_PW_CHUNK)) & ~(size_t)63, 64), 1u << 20) |
+                              (env_size("RSPT_PW_ADAPT", 1) != 0 ? 0u : 1u);   // (bit 0: the kernels do not shrink the claim on short queues — trace_w4.h)
     grid = hinted_grid(grid, RSPT_TRACE_BLOCK);
     uint32_t* n_overflow = cursor + 2;  // QueueCounts layout: overflow word sits two after its cursor
     const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);

@@ -156,6 +156,17 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
     const size_t spill_stride = (size_t)gridDim.x * BLOCK;
     uint2* my_spill = spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    // A short queue (the late iterations of a batch, a shard of a frame): with 256 rays per claim a few waves hold all of it and run their rays 64 at a time, one
+    // round after the other, while the rest of the chip idles — the launch then lasts four dependent walks instead of one.  The claim shrinks to the queue's share per
+    // wave (wave-uniform; which wave traces which ray changes, no ray's result does).  Queues of more than chunk x waves entries keep the launch parameter.
+    {
+        const bool adapt = !(chunk & 1u);   // (bit 0 of the launch parameter: RSPT_PW_ADAPT=0, the A/B switch; the claim itself is a multiple of 64)
+        chunk &= ~63u;
+        const uint32_t waves = gridDim.x * (uint32_t)(BLOCK / 64);
+        uint32_t per = ((n + waves - 1u) / waves + 63u) & ~63u;
+        if (per < 64u) per = 64u;
+        if (adapt && per < chunk) chunk = per;
+    }
     if (sc.n_nodes == 0) {  // empty scene: every ray misses
         for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
             uint32_t e = queue ? queue[i] : i, slot = e & ~RSPT_Q_MIS;

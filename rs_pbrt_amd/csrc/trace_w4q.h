@@ -59,6 +59,14 @@ __global__ __launch_bounds__(RSPT_PW_BLOCK) void k_trace_w4q(SceneDev sc, const 
     const size_t spill_stride = (size_t)gridDim.x * BLOCK;
     uint32_t* my_spill = spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    {   // a short queue is spread over all waves (trace_w4.h: the claim shrinks to the queue's share per wave)
+        const bool adapt = !(chunk & 1u);   // (bit 0 of the launch parameter: RSPT_PW_ADAPT=0, the A/B switch; the claim itself is a multiple of 64)
+        chunk &= ~63u;
+        const uint32_t waves = gridDim.x * (uint32_t)(BLOCK / 64);
+        uint32_t per = ((n + waves - 1u) / waves + 63u) & ~63u;
+        if (per < 64u) per = 64u;
+        if (adapt && per < chunk) chunk = per;
+    }
     const uint32_t lane = __lane_id();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
