@@ -315,8 +315,8 @@ typedef struct {
      * same per instance visit.  The top-level aggregate's bounds of such a primitive are the reference's
      * AnimatedTransform::motion_bounds (the shim passes the BVH rs_pbrt built; the library never computes them).
      * (A caller that builds the top-level tree itself gets them from rspt_motion_bounds.)
-     * Served by all four integrators under the Sobol' / Halton samplers (ABI 21 builds).  RSPT_E_UNSUPPORTED: under the PCG-backed pixel
-     * samplers, under the per-lane form of directlighting (textured materials, max_depth > 8).  Moving instances next to alpha-masked meshes are served. */
+     * Served by all four integrators under every sampler (Sobol' / Halton: ABI 21 builds; the PCG-backed pixel samplers and the per-lane form of
+     * directlighting: round 6), also next to alpha-masked meshes.  RSPT_E_UNSUPPORTED: next to a dynamic material under a pixel sampler. */
     uint32_t animated;
     float to_world_end[16];
     float from_world_end[16];

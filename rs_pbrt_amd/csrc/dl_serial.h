@@ -17,9 +17,9 @@ namespace rspt {
 
 #define RSPT_DL_SERIAL_DEPTH 32
 
-template <bool INST, bool ALPHA, class SMP>
+template <bool INST, bool ALPHA, class SMP, bool ANIM = false>
 struct DlSerial {
-    VolSerial<INST, ALPHA> base;      // closest(), surface()
+    VolSerial<INST, ALPHA, ANIM> base;      // closest(), surface()
     SMP* px;                          // get_1d / get_2d / get_2d_array / va
     const int32_t* n_light_samples;   // strategy all: Light::get_n_samples after round_count, per light (nullptr: 1 each)
     bool sample_all;
@@ -30,7 +30,7 @@ struct DlSerial {
     uint32_t dyn_stride;
 
     const SceneDev& sc() const { return base.sc; }
-    RDEV bool occluded(f3 o, f3 d, float t_max) { return serial_trace<true, INST, ALPHA>(base.sc, base.tt, o, d, t_max, base.lds).prim != RSPT_MISS; }
+    RDEV bool occluded(f3 o, f3 d, float t_max) { return serial_trace<true, INST, ALPHA, ANIM>(base.sc, base.tt, o, d, t_max, base.lds, base.time).prim != RSPT_MISS; }
 
     // estimate_direct (integrator.rs:406-570), handle_media = false, specular = false
     RDEVN rgb estimate_direct(const SerialHit& it, const Bsdf& bsdf, f2 u_scattering, uint32_t light_num, f2 u_light) {
@@ -208,7 +208,13 @@ struct DlSerial {
                         if (tex) {   // compute_scattering_functions: compute_differentials(ray), then the material's textures / bump map
                             TexHit th;
                             tri_fill_tex(S, r.prim, load_tri(S, r.prim), r.b0, r.b1, r.b2, &th);
-                            if (INST && r.inst && !S.inst[r.inst - 1u].identity) inst_texhit(S.inst[r.inst - 1u], &th);
+                            if (INST && r.inst) {
+                                const bool moving = ANIM && S.inst[r.inst - 1u].anim != RSPT_MISS;
+                                InstDev moved;
+                                if (moving) moved = inst_at(S, r.inst - 1u, base.time);
+                                const InstDev& in = moving ? moved : S.inst[r.inst - 1u];
+                                if (!in.identity) inst_texhit(in, &th);
+                            }
                             TexSurf ts;
                             ts.p = th.p; ts.uv = th.uv;
                             ts.dudx = ts.dvdx = ts.dudy = ts.dvdy = 0.0f;

@@ -70,7 +70,8 @@ struct LaneDesc {
 };
 
 // k_raygen has left the camera ray, the sample's index and film position in slot i
-template <bool INST, bool ALPHA>
+// ANIM (round 6): moving instances — the sample's ray time is what k_raygen left in pb.time[i]
+template <bool INST, bool ALPHA, bool ANIM = false>
 __global__ __launch_bounds__(64) void k_lane_dl(SceneDev sc, TexTables tt, LightDistDev ld, RenderDev rd, Batch bt, PathBuf pb, const uint32_t* __restrict__ pix_list, LaneDesc ln) {
     __shared__ uint32_t stack[RSPT_LDS_STACK * 64];
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64) void k_lane_dl(SceneDev sc, TexTables tt, Light
     f3 p_lens{0.0f, 0.0f, 0.0f};
     if (rd.lens_radius > 0.0f) { p_lens.x = smp.dimv(index, 3u); p_lens.y = smp.dimv(index, 4u); }
     if (rd.cam_anim) p_lens.z = smp.dimv(index, 2u);
-    DlSerial<INST, ALPHA, LaneSampler> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, i, SerialSampler{nullptr}, stack + threadIdx.x, ln.max_walk, false}, &smp, ln.n_light_samples,
+    DlSerial<INST, ALPHA, LaneSampler, ANIM> dl{VolSerial<INST, ALPHA, ANIM>{sc, tt, ld, rd, pb, i, SerialSampler{nullptr}, stack + threadIdx.x, ln.max_walk, false, (ANIM && pb.time) ? pb.time[i] : 0.0f}, &smp, ln.n_light_samples,
                                           ln.sample_all != 0u, ln.tex ? ln.tex + i : nullptr, ln.tex_stride, ln.tex_rows, f2{pf.x, pf.y}, p_lens,
                                           ln.dyn ? ln.dyn + i : nullptr, ln.tex_stride};
     const rgb l = dl.li(f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z);

@@ -797,8 +797,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         return fail(RSPT_E_UNSUPPORTED, "integrator %u (path, ao, directlighting and volpath only)", d->integrator);
     const bool direct = d->integrator == RSPT_INTEGRATOR_DIRECT;
     const bool volpath = d->integrator == RSPT_INTEGRATOR_VOLPATH;
-    if (s->has_animated && pixel_sampler)   // (the per-lane kernels carry no interpolation; round 5 lifted the refusal for volpath / directlighting / ao under Sobol' / Halton)
-        return fail(RSPT_E_UNSUPPORTED, "a scene with a moving object instance is served under the Sobol' / Halton samplers only");
+    // moving instances under the pixel samplers and in the per-lane directlighting: round 6 (k_tile_serial modes 5 - 8, k_lane_dl<.., ANIM>); dynamic materials next to them under a
+    // pixel sampler are the one combination left without an instantiation
+    if (s->has_animated && pixel_sampler && s->has_dynamic)
+        return fail(RSPT_E_UNSUPPORTED, "a scene with a moving object instance AND a dynamic material (a lobe list that depends on a texture value) under a pixel sampler");
     if (direct) {
         if (d->max_depth < 1 || d->max_depth > (uint32_t)RSPT_DL_SERIAL_DEPTH)
             return fail(RSPT_E_UNSUPPORTED, "directlighting: max_depth must be in [1, %d] (the explicit recursion stack of the per-lane form, dl_serial.h)", RSPT_DL_SERIAL_DEPTH);
@@ -1030,7 +1032,6 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // (lane_serial.h): textured materials, more than 8 recursion levels; RSPT_DL_FORM=lane forces it (A/B, tests)
     const char* dl_form_env = getenv("RSPT_DL_FORM");
     bool dl_lane = direct && !pixel_sampler && (s->has_textures || d->max_depth > 8 || (dl_form_env && !strcmp(dl_form_env, "lane")));
-    if (s->has_animated && dl_lane) return fail(RSPT_E_UNSUPPORTED, "directlighting in its per-lane form (textured materials / max_depth > 8) over a scene with a moving object instance");
     // levels of the specular tree that can hold nodes (direct.h DlBuf::levels): a scene without specular lobes has the root only
     const bool dl_specular = s->has_dynamic || (s->shade_features & (RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_R) | RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_T) | RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_SPEC))) != 0;
     const uint32_t dl_levels = (dl_specular || env_size("RSPT_DL_FULL_TREE", 0) != 0) ? (uint32_t)d->max_depth : std::min<uint32_t>((uint32_t)d->max_depth, 1u);
@@ -1408,7 +1409,10 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         const dim3 lgrid((bt.n + 63u) / 64u);
         ev_open(2, 0);
 #define RSPT_LN(I, A) hipLaunchKernelGGL((k_lane_dl<I, A>), lgrid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, bt, g.pb, g.pix_list, ln)
-        if (s->has_instances) { if (s->has_alpha) RSPT_LN(true, true); else RSPT_LN(true, false); }
+        if (s->has_animated) {   // (round 6: the walk interpolates the instances it enters at the sample's ray time, pb.time)
+            if (s->has_alpha) hipLaunchKernelGGL((k_lane_dl<true, true, true>), lgrid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, bt, g.pb, g.pix_list, ln);
+            else hipLaunchKernelGGL((k_lane_dl<true, false, true>), lgrid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, bt, g.pb, g.pix_list, ln);
+        } else if (s->has_instances) { if (s->has_alpha) RSPT_LN(true, true); else RSPT_LN(true, false); }
         else { if (s->has_alpha) RSPT_LN(false, true); else RSPT_LN(false, false); }
 #undef RSPT_LN
         ev_close(2, 0);
@@ -1632,7 +1636,12 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             }
             ev_open(2, 0);
 #define RSPT_TS(I, A, O) hipLaunchKernelGGL((k_tile_serial<I, A, O>), grid, dim3(64), 0, g.stream, s->dev, s->tex, ld, rd, g.pb, pd, tiles_d, n_tiles, lanes, r0, r1, samp_L, samp_pf, serial_iters, trunc_d)
-            if (ao) {
+            if (s->has_animated) {   // (round 6: modes 5 - 8 = path / ao / volpath / directlighting with the instances' Transforms interpolated at the camera sample's time)
+                if (ao) { if (s->has_alpha) RSPT_TS(true, true, 6); else RSPT_TS(true, false, 6); }
+                else if (volpath) { if (s->has_alpha) RSPT_TS(true, true, 7); else RSPT_TS(true, false, 7); }
+                else if (direct) { if (s->has_alpha) RSPT_TS(true, true, 8); else RSPT_TS(true, false, 8); }
+                else { if (s->has_alpha) RSPT_TS(true, true, 5); else RSPT_TS(true, false, 5); }
+            } else if (ao) {
                 if (s->has_instances) { if (s->has_alpha) RSPT_TS(true, true, 1); else RSPT_TS(true, false, 1); }
                 else { if (s->has_alpha) RSPT_TS(false, true, 1); else RSPT_TS(false, false, 1); }
             } else if (volpath) {

@@ -41,6 +41,8 @@ struct PixDesc {              // the sampler's parameters and this render's vect
 // geometry, arr_n hemisphere directions from get_2d_array, one any-hit traversal each, the unoccluded terms added in array order.
 // 2: VolPathIntegrator::li (vol_serial.h), homogeneous and grid media.  3: DirectLightingIntegrator::li (dl_serial.h).
 // 4: PathIntegrator::li over a scene with dynamic materials (shade_path<.., SF_ALL>: lobe lists built per hit, material_assembly.h).
+// 5 / 6 / 7 / 8 (round 6): modes 0 / 1 / 2 / 3 over a scene with MOVING object instances (AnimatedTransform primitive_to_world, primitive.rs:198-272): the camera sample's time
+// (sampler.rs:88, lerp over the shutter) rides in pb.time[slot] — where shade_path / texture_path read it — and every traversal interpolates the instances it enters.
 #ifdef RSPT_TS_WAVES   // A/B: the per-tile kernels built for that many waves per SIMD (what does not fit the budget is spilled)
 #define RSPT_TS_ATTR __attribute__((amdgpu_waves_per_eu(RSPT_TS_WAVES, RSPT_TS_WAVES)))
 #else
@@ -62,6 +64,9 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
     px.arr = pd.arr ? pd.arr + t : nullptr; px.arr_sz = pd.arr_sz; px.arr_base = pd.arr_base; px.n_arr = pd.n_arr; px.arr_cur = 0;
     if (row0 == 0) px.rng.set_sequence((uint64_t)tr.seed);  // tile_sampler.reseed(seed) (integrator.rs:114)
     else { px.rng.state = pd.rng_state[2 * (size_t)t]; px.rng.inc = pd.rng_state[2 * (size_t)t + 1]; }
+    constexpr bool ANIM = MODE >= 5 && MODE <= 8;
+    constexpr int M = MODE == 5 ? 0 : (MODE == 6 ? 1 : (MODE == 7 ? 2 : (MODE == 8 ? 3 : MODE)));
+    static_assert(!ANIM || INST, "moving instances are instances");
     const uint32_t slot = t;   // the lane's own path slot
     uint32_t k = tr.pix0;
     uint32_t* lds = stack + threadIdx.x;
@@ -83,8 +88,10 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
                 pb.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                 pb.state[slot] = ST_ALIVE;
                 pb.p_film[slot] = make_float2(p_film.x, p_film.y);
-                if (MODE == 3) {
-                    DlSerial<INST, ALPHA, PixSampler> dl{VolSerial<INST, ALPHA>{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false}, &px, pd.n_light_samples, pd.direct_strategy == RSPT_DIRECT_SAMPLE_ALL,
+                const float ray_time = ANIM ? rd.shutter_open * (1.0f - time_s) + rd.shutter_close * time_s : 0.0f;   // lerp(sample.time, shutter_open, shutter_close) (perspective.rs:226)
+                if (ANIM) pb.time[slot] = ray_time;
+                if (M == 3) {
+                    DlSerial<INST, ALPHA, PixSampler, ANIM> dl{VolSerial<INST, ALPHA, ANIM>{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false, ray_time}, &px, pd.n_light_samples, pd.direct_strategy == RSPT_DIRECT_SAMPLE_ALL,
                                                          pd.dl_tex ? pd.dl_tex + t : nullptr, n_tiles, pd.dl_tex_rows, p_film, p_lens,
                                                          pd.dl_dyn ? pd.dl_dyn + t : nullptr, n_tiles};
                     const rgb l = dl.li(o, d, t_max);
@@ -95,8 +102,8 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
                     px.start_next_sample();
                     continue;
                 }
-                if (MODE == 2) {
-                    VolSerial<INST, ALPHA> vs{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false};
+                if (M == 2) {
+                    VolSerial<INST, ALPHA, ANIM> vs{sc, tt, ld, rd, pb, slot, SerialSampler{&px}, lds, max_iters, false, ray_time};
                     const rgb l = vs.li(o, d, t_max, p_film, p_lens);
                     if (vs.truncated) atomicAdd(truncated, 1u);
                     const size_t out = (size_t)k * pd.spp + s;
@@ -105,8 +112,8 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
                     px.start_next_sample();
                     continue;
                 }
-                if (MODE == 1) {
-                    const TraceResult res = serial_trace<false, INST, ALPHA>(sc, tt, o, d, t_max, lds);
+                if (M == 1) {
+                    const TraceResult res = serial_trace<false, INST, ALPHA, ANIM>(sc, tt, o, d, t_max, lds, ray_time);
                     float l = 0.0f;
                     if (res.prim != RSPT_MISS) {
                         const TriRec tri = load_tri(sc, res.prim);
@@ -114,7 +121,13 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
                         tri_fill_tex(sc, res.prim, tri, res.b0, res.b1, res.b2, &h);
                         Hit hp;     // p_error for spawn_ray
                         tri_fill(sc, res.prim, tri, res.b0, res.b1, res.b2, &hp);
-                        if (INST && res.inst && !sc.inst[res.inst - 1u].identity) { inst_texhit(sc.inst[res.inst - 1u], &h); inst_hit(sc.inst[res.inst - 1u], &hp); }
+                        if (INST && res.inst) {
+                            const bool moving = ANIM && sc.inst[res.inst - 1u].anim != RSPT_MISS;
+                            InstDev moved;
+                            if (moving) moved = inst_at(sc, res.inst - 1u, ray_time);
+                            const InstDev& in = moving ? moved : sc.inst[res.inst - 1u];
+                            if (!in.identity) { inst_texhit(in, &h); inst_hit(in, &hp); }
+                        }
                         const f3 n = faceforward(h.n, -d);
                         const f3 sv = normalize(h.dpdu);
                         const f3 tv = cross(h.n, sv);  // nrm_cross_vec3(&isect.common.n, &s)
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
                             }
                             wi = f3{sv.x * wi.x + tv.x * wi.y + n.x * wi.z, sv.y * wi.x + tv.y * wi.y + n.y * wi.z, sv.z * wi.x + tv.z * wi.y + n.z * wi.z};
                             if (pdf != 0.0f) {
-                                const TraceResult occ = serial_trace<true, INST, ALPHA>(sc, tt, offset_ray_origin(hp.p, hp.p_err, hp.n, wi), wi, RSPT_INF, lds);
+                                const TraceResult occ = serial_trace<true, INST, ALPHA, ANIM>(sc, tt, offset_ray_origin(hp.p, hp.p_err, hp.n, wi), wi, RSPT_INF, lds, ray_time);
                                 if (occ.prim == RSPT_MISS) l += dot(wi, n) / (pdf * (float)arr_n);
                             }
                         }
@@ -150,24 +163,24 @@ __global__ __launch_bounds__(64) RSPT_TS_ATTR void k_tile_serial(SceneDev sc, Te
                     if (so.cont) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = serial_trace<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = serial_trace<false, INST, ALPHA, ANIM>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds, ray_time);
                         pb.hit_cont[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
                         if (INST && pb.hit_inst) pb.hit_inst[slot] = res.inst;
                     }
                     if (so.mis) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_mis + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = serial_trace<false, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = serial_trace<false, INST, ALPHA, ANIM>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds, ray_time);
                         pb.hit_mis[slot] = make_float4(__uint_as_float(res.prim), res.b0, res.b1, res.b2);
                     }
                     if (so.shadow) {
                         const float4* rp = reinterpret_cast<const float4*>(pb.ray_sh + slot);
                         const float4 r0 = rp[0], r1 = rp[1];
-                        const TraceResult res = serial_trace<true, INST, ALPHA>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds);
+                        const TraceResult res = serial_trace<true, INST, ALPHA, ANIM>(sc, tt, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, r1.z, lds, ray_time);
                         pb.occluded[slot] = res.prim != RSPT_MISS ? 1u : 0u;
                     }
                     if (sc.mat_flags && so.cont) texture_path(sc, tt, rd, pb, slot, &p_lens);   // the texture stage k_texture runs in front of k_shade
-                    so = shade_path<true, MODE == 4 ? (SF_ALL & ~SF_ANIM) : (SF_ALL & ~SF_DYNAMIC & ~SF_ANIM)>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
+                    so = shade_path<true, MODE == 4 ? (SF_ALL & ~SF_ANIM) : (ANIM ? (SF_ALL & ~SF_DYNAMIC) : (SF_ALL & ~SF_DYNAMIC & ~SF_ANIM))>(sc, ld, rd, pb, slot, nullptr, nullptr, 0u, &px);
                 }
                 const size_t out = (size_t)k * pd.spp + s;
                 samp_L[out] = pb.L_eta[slot];

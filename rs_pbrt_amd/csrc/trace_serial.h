@@ -120,10 +120,11 @@ RDEVN TraceResult traverse_w4(const SceneDev& sc, const TexTables& tt, f3 o, f3 
 }
 
 // the traversal a per-lane kernel runs for one ray: the four-box records where the scene has them in the plain form
-template <bool ANY, bool INST, bool ALPHA>
-RDEV TraceResult serial_trace(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds) {
+// ANIM (round 6: moving instances under the pixel samplers): the reference-order loop with primitive_to_world interpolated at the ray's time (kernels.h traverse<.., ANIM>)
+template <bool ANY, bool INST, bool ALPHA, bool ANIM = false>
+RDEV TraceResult serial_trace(const SceneDev& sc, const TexTables& tt, f3 o, f3 d, float t_max, uint32_t* lds, float time = 0.0f) {
     if (!INST && sc.w4) return traverse_w4<ANY, ALPHA>(sc, tt, o, d, t_max, lds);   // (with alpha masks: rspt_scene_create sets w4 only when they have the in-line form)
-    return traverse<ANY, INST, ALPHA, 64>(sc, tt, o, d, t_max, lds);
+    return traverse<ANY, INST, ALPHA, 64, ANIM>(sc, tt, o, d, t_max, lds, time);
 }
 
 }  // namespace rspt

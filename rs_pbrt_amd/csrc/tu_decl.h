@@ -86,12 +86,28 @@ RSPT_TU_TS2(false, 4)
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS4B)
 RSPT_TU_TS2(true, 4)
 #endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS5)
+RSPT_TU_TS2(true, 5)   /* path / ao under the pixel samplers over moving instances */
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS6)
+RSPT_TU_TS2(true, 6)
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS7)
+RSPT_TU_TS2(true, 7)   /* volpath / directlighting per tile over moving instances */
+#endif
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_TS8)
+RSPT_TU_TS2(true, 8)
+#endif
 #define RSPT_TU_LANE(I, A) RSPT_TU_X template __global__ void k_lane_dl<I, A>(SceneDev, TexTables, LightDistDev, RenderDev, Batch, PathBuf, const uint32_t*, LaneDesc);
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_LANE_A)
 RSPT_TU_LANE(false, false) RSPT_TU_LANE(false, true)
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_LANE_B)
 RSPT_TU_LANE(true, false) RSPT_TU_LANE(true, true)
+#endif
+#define RSPT_TU_LANE_ANIM(A) RSPT_TU_X template __global__ void k_lane_dl<true, A, true>(SceneDev, TexTables, LightDistDev, RenderDev, Batch, PathBuf, const uint32_t*, LaneDesc);
+#if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_LANE_C)
+RSPT_TU_LANE_ANIM(false) RSPT_TU_LANE_ANIM(true)   /* the per-lane directlighting over moving instances */
 #endif
 #if defined(RSPT_TU_ALL) || defined(RSPT_TU_GROUP_SHADE_A)
 RSPT_TU_SHADE(SV_DIFFUSE) RSPT_TU_SHADE_W(SV_DIFFUSE, 3) RSPT_TU_SHADE_W(SV_DIFFUSE, 4)

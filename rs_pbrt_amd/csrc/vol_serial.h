@@ -112,7 +112,8 @@ struct SerialHit {
     uint32_t m_in, m_out;  // the interaction's medium interface (0 = None)
 };
 
-template <bool INST, bool ALPHA>
+// ANIM (round 6): the scene has moving instances — every traversal interpolates the instances it enters at `time`, the camera sample's ray time, and so does the hit's interaction
+template <bool INST, bool ALPHA, bool ANIM = false>
 struct VolSerial {
     const SceneDev& sc; const TexTables& tt; const LightDistDev& ld; const RenderDev& rd; const PathBuf& pb;
     uint32_t slot;
@@ -120,8 +121,9 @@ struct VolSerial {
     uint32_t* lds;
     uint32_t max_walk;     // cap on passes through BSDF-less surfaces / shadow-ray segments (the reference has none)
     bool truncated;
+    float time;            // Ray.time of the camera sample (ANIM)
 
-    RDEV TraceResult closest(f3 o, f3 d, float t_max) { return serial_trace<false, INST, ALPHA>(sc, tt, o, d, t_max, lds); }
+    RDEV TraceResult closest(f3 o, f3 d, float t_max) { return serial_trace<false, INST, ALPHA, ANIM>(sc, tt, o, d, t_max, lds, time); }
     // Medium::tr over a ray whose t_max is where its traversal left it
     RDEV rgb medium_tr(uint32_t medium, f3 o, f3 d, float t_max) {
         const rspt_medium& m = sc.media[medium - 1u];
@@ -137,8 +139,11 @@ struct VolSerial {
         const rspt_mesh me = sc.meshes[sc.prims[r.prim].mesh];
         s->m_in = s->m_out = ray_medium;
         if (me.medium_inside != me.medium_outside) { s->m_in = me.medium_inside; s->m_out = me.medium_outside; }
-        if (INST && r.inst && !sc.inst[r.inst - 1u].identity) {  // transform_surface_interaction: no medium interface, (v0.9.12) no primitive
-            const InstDev& in = sc.inst[r.inst - 1u];
+        const bool moving = INST && ANIM && r.inst && sc.inst[r.inst - 1u].anim != RSPT_MISS;
+        InstDev moved;
+        if (moving) moved = inst_at(sc, r.inst - 1u, time);   // primitive_to_world.interpolate(ray.time) (primitive.rs:218-222)
+        if (INST && r.inst && !(moving ? moved : sc.inst[r.inst - 1u]).identity) {  // transform_surface_interaction: no medium interface, (v0.9.12) no primitive
+            const InstDev& in = moving ? moved : sc.inst[r.inst - 1u];
             inst_hit(in, &s->h);
             s->wo = normalize(xf_vector(in.m, -xf_vector(in.mi, ray_d)));
             s->m_in = s->m_out = 0u;
