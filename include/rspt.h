@@ -597,8 +597,11 @@ int rspt_motion_bounds(const float start_m[16], float start_time, const float en
  * sampling.rs:360-382, Trowbridge-Reitz sampling microfacet.rs:475-531, spherical directions and mappings, MIP level selection, roughness
  * remapping, medium transmittance) = the host libm's sinf / cosf / logf / log2f / expf / acosf / atan2f.  The device evaluates glibc's
  * algorithms operation by operation (rs_pbrt_amd/csrc/glibc_libm.h); this entry point runs one of them over an array so that a test can
- * compare it with the host's libm bit for bit.  y is read by RSPT_LIBM_ATAN2 only (out = atan2f(x[i], y[i])), else may be NULL. */
-enum { RSPT_LIBM_SIN = 0, RSPT_LIBM_COS = 1, RSPT_LIBM_LOG = 2, RSPT_LIBM_LOG2 = 3, RSPT_LIBM_EXP = 4, RSPT_LIBM_ACOS = 5, RSPT_LIBM_ATAN2 = 6 };
+ * compare it with the host's libm bit for bit.  y is read by RSPT_LIBM_ATAN2 only (out = atan2f(x[i], y[i])), else may be NULL.
+ * RSPT_LIBM_MAT4_INVERSE (round 6): not libm but the same kind of hook — Matrix4x4::inverse (transform.rs:128-200) as the device evaluates it at every visit of a
+ * moving instance (rs_pbrt_amd/csrc/mat4_inverse.h: the reference's Gauss-Jordan elimination with static indices); x and out then hold n row-major 4x4 matrices
+ * (16 n floats). */
+enum { RSPT_LIBM_SIN = 0, RSPT_LIBM_COS = 1, RSPT_LIBM_LOG = 2, RSPT_LIBM_LOG2 = 3, RSPT_LIBM_EXP = 4, RSPT_LIBM_ACOS = 5, RSPT_LIBM_ATAN2 = 6, RSPT_LIBM_MAT4_INVERSE = 7 };
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out);
 
 /* Benchmark hook: same as rspt_trace on rays already resident in device memory,

@@ -803,40 +803,10 @@ struct InstAnim {        // per moving instance: what AnimatedTransform::new lea
     uint32_t identity_end;
     uint32_t pad[3];
 };
-// Matrix4x4::inverse (transform.rs:128-200): Gauss-Jordan elimination, the pivot the largest remaining element (later candidates win ties)
-RDEVN void mat4_inverse(const float* src, float* out) {
-    int col_of[4] = {0, 0, 0, 0}, row_of[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
-    float a[4][4];
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) a[i][j] = src[4 * i + j];
-    for (int step = 0; step < 4; step++) {
-        int pr = 0, pc = 0;
-        float best = 0.0f;
-        for (int r = 0; r < 4; r++) {
-            if (used[r] == 1) continue;
-            for (int c = 0; c < 4; c++) {
-                if (used[c] != 0) continue;
-                const float v = fabsf(a[r][c]);
-                if (v >= best) { best = v; pr = r; pc = c; }
-            }
-        }
-        used[pc] += 1;
-        if (pr != pc) for (int k = 0; k < 4; k++) { const float t = a[pr][k]; a[pr][k] = a[pc][k]; a[pc][k] = t; }
-        row_of[step] = pr; col_of[step] = pc;
-        const float pivinv = 1.0f / a[pc][pc];
-        a[pc][pc] = 1.0f;
-        for (int k = 0; k < 4; k++) a[pc][k] *= pivinv;
-        for (int r = 0; r < 4; r++) {
-            if (r == pc) continue;
-            const float save = a[r][pc];
-            a[r][pc] = 0.0f;
-            for (int k = 0; k < 4; k++) a[r][k] -= a[pc][k] * save;
-        }
-    }
-    for (int step = 3; step >= 0; step--)
-        if (row_of[step] != col_of[step])
-            for (int k = 0; k < 4; k++) { const float t = a[k][row_of[step]]; a[k][row_of[step]] = a[k][col_of[step]]; a[k][col_of[step]] = t; }
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out[4 * i + j] = a[i][j];
-}
+// Matrix4x4::inverse (transform.rs:128-200): Gauss-Jordan elimination, the pivot the largest remaining element (later candidates win ties) — mat4_inverse.h
+}  // namespace rspt
+#include "mat4_inverse.h"
+namespace rspt {
 // primitive_to_world.interpolate(r.time) (transform.rs:2081-2113) as an InstDev: the start Transform up to the start time (and for a static
 // instance), the end Transform from the end time on, in between translate(trans) * rotate.to_transform() * Transform { scale, inverse(scale) }
 // — m the product of the m's, m_inv the reverse product of the inverses (Transform * Transform, :869-877)
@@ -867,6 +837,57 @@ RDEVN InstDev inst_at(const SceneDev& sc, uint32_t index, float time) {
     for (int i = 0; i < 4; i++) { in.m3[i] = m[12 + i]; in.mi3[i] = mi[12 + i]; }
     in.identity = ident ? 1u : 0u;
     return in;
+}
+
+// What a TRAVERSAL needs of primitive_to_world.interpolate(r.time): the inverse's matrix (Transform::transform_ray with m_inv, primitive.rs:218-222) and, in the
+// reference's instancing mode only, Transform::is_identity of the interpolated Transform (want_ident).  Same values as inst_at's; what it leaves out is the product
+// m = T * R * S, needed only for that flag: row i of m ends in ((+-0 + +-0) + +-0) + trans[i] * 1 (the fourth columns of R and S are (0 0 0 1) by construction), so a
+// translation with a non-zero (or NaN) component cannot be the identity and m is formed only when all three are zero.
+RDEVN void inst_inverse_at(const SceneDev& sc, const InstDev& in, float time, bool want_ident, float* mi /* rows 0..2 */, float* mi3, bool* ident) {
+    const InstAnim& an = sc.inst_anim[in.anim];
+    if (time <= an.keys.time[0]) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) mi[i] = in.mi[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) mi3[i] = in.mi3[i];
+        *ident = in.identity != 0u;
+        return;
+    }
+    if (time >= an.keys.time[1]) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) mi[i] = an.mi_end[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) mi3[i] = an.mi_end[12 + i];
+        *ident = an.identity_end != 0u;
+        return;
+    }
+    const float dt = (time - an.keys.time[0]) / (an.keys.time[1] - an.keys.time[0]);
+    float tr[16], rot[16], scale[16], tmp[16], rot_t[16], tr_inv[16], scale_inv[16], full[16];
+    anim_factors(&an.keys, dt, tr, rot, scale);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { rot_t[4 * i + j] = rot[4 * j + i]; tr_inv[4 * i + j] = i == j ? 1.0f : 0.0f; }
+    tr_inv[3] = -tr[3]; tr_inv[7] = -tr[7]; tr_inv[11] = -tr[11];
+    mat4_inverse(scale, scale_inv);
+    mat4_mul(rot_t, tr_inv, tmp);        // (T * R).m_inv = R.m_inv * T.m_inv
+    mat4_mul(scale_inv, tmp, full);      // ((T * R) * S).m_inv = S.m_inv * (T * R).m_inv
+#pragma unroll
+    for (int i = 0; i < 12; i++) mi[i] = full[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) mi3[i] = full[12 + i];
+    bool id = false;
+    if (want_ident && !(tr[3] != 0.0f || tr[7] != 0.0f || tr[11] != 0.0f)) {
+        float m[16];
+        mat4_mul(tr, rot, tmp);
+        mat4_mul(tmp, scale, m);
+        id = true;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (m[4 * i + j] != (i == j ? 1.0f : 0.0f)) id = false;
+    }
+    *ident = id;
 }
 
 // ---- PerspectiveCamera::generate_ray_differential (perspective.rs:190-280), differentials dropped ----

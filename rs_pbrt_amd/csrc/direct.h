@@ -31,6 +31,11 @@ struct DlBuf {          // per node slot
     uint32_t* dim;      // dimension at which the node's lighting starts in the regular stream
     uint32_t* kidx;     // index among the camera sample's shading nodes, depth first
     uint32_t* nflags;   // DLF_* of the estimate in flight
+    uint32_t vs, vr;    // k_dl_nee_all: estimate r of node slot n lives in the virtual slot v = n * vs + r * vr.  Round 6: planes — (vs, vr) = (1, node slots of the batch):
+                        // the lanes of a wave, which hold neighbouring node slots, then store their rays / terms / flags of estimate r side by side (at stride R every 16-byte
+                        // store of the wave met its own line: profiles/r06_pmc_calibration.md, "scattered stores are slow beyond their bytes") and the trace kernels and the
+                        // resolve read them back the same way.  (R, 1) = round 5's interleaved layout, kept where a ray's slot must give its camera sample by ONE division
+                        // (moving instances: SceneDev::time_div)
     uint32_t H;         // slots per camera sample = 2^levels
     uint32_t levels;    // levels of the tree that can hold nodes: max_depth, or 1 for a scene without specular lobes (no node ever has a child: the
                         // recursion's two sample_f calls return black and only consume their dimensions) — the slots, the level loops and the
@@ -361,8 +366,44 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_resolve(SceneDev sc, Path
 // any-hit launch and one closest-hit launch serve all of them, and k_dl_nee_resolve_all adds them in the reference's order (`ld += ..` over a light's
 // elements, `l += ld / n`).  Same operations on the same values as the rounds: bit-identical radiance; the batch shrinks by R.
 
+// Sobol' tables of the estimate kernel in LDS (round 6).  Every estimate draws FOUR dimensions (u_light, u_scatter) at an index of its own — the sample arrays of
+// uniform_sample_all_lights have one element per (pixel sample, kk), sampler.rs request_2d_array / sobol.rs:110-140 — and sobol_dim walks the set bits of that index once
+// per dimension through the 213 KB generator table in global memory (~25 dependent L2 round trips each), after sobol_interval_to_index's two walks through the van der
+// Corput matrices: ~130 serial cache misses per estimate, six estimates per node on the C3 stand-in — k_dl_nee_all spent its time there, not in estimate_direct.  The
+// kernel now keeps, per workgroup, the generator columns of the dimensions this render can reach, transposed to [bit][dimension] as the shade stage's (kernels.h
+// shade_kernel), and the two van der Corput matrices of the film's resolution: ONE walk over the index's bits yields the four values.  Same XORs, same values.
+struct DlSob {
+    const uint32_t* tab;   // [bits][nd] in LDS; nullptr: Halton, or the tables do not fit — the global walks
+    uint32_t nd, bits;
+    const uint64_t* m;     // vdc rows of log2_res [52], then vdc_inv rows [52], in LDS
+};
+RDEV uint64_t dl_interval_to_index(const RenderDev& rd, const DlSob& sb, uint32_t m, uint64_t frame, int32_t px, int32_t py) {
+    if (!sb.tab) return sobol_interval_to_index(rd, m, frame, px, py);
+    if (m == 0) return 0;
+    uint64_t index = frame << (m << 1);
+    uint64_t delta = 0;
+    for (uint64_t f = frame; f != 0; f &= f - 1) delta ^= sb.m[__builtin_ctzll(f)];
+    uint64_t b = ((uint64_t)((uint32_t)px << m) | (uint64_t)(int64_t)py) ^ delta;
+    for (; b != 0; b &= b - 1) index ^= sb.m[52 + __builtin_ctzll(b)];
+    return index;
+}
+// dimensions d .. d + 3 at `index`
+RDEV void dl_dims4(const RenderDev& rd, const DlSob& sb, uint64_t index, uint32_t d, f2* a, f2* b) {
+    if (sb.tab && d + 4u <= sb.nd && (index >> sb.bits) == 0) {
+        uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+        for (uint64_t i = index; i != 0; i &= i - 1) {
+            const uint32_t* row = sb.tab + (uint32_t)__builtin_ctzll(i) * sb.nd + d;
+            x0 ^= row[0]; x1 ^= row[1]; x2 ^= row[2]; x3 ^= row[3];
+        }
+        *a = f2{fminf((float)x0 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS), fminf((float)x1 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS)};
+        *b = f2{fminf((float)x2 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS), fminf((float)x3 * 0x1.0p-32f, RSPT_ONE_MINUS_EPS)};
+        return;
+    }
+    *a = dl_dims(rd, index, d); *b = dl_dims(rd, index, d + 2u);
+}
+
 // the (u_light, u_scatter, light, choice pdf) of estimate (j, kk) of a node — the sample-value part of k_dl_nee, unchanged
-RDEV bool dl_estimate_samples(const RenderDev& rd, const Batch& bt, const PathBuf& pb, const DlBuf& dl, const uint32_t* __restrict__ pix_list, uint32_t slot, uint32_t nl,
+RDEV bool dl_estimate_samples(const RenderDev& rd, const DlSob& sb, const Batch& bt, const PathBuf& pb, const DlBuf& dl, const uint32_t* __restrict__ pix_list, uint32_t slot, uint32_t nl,
                               uint32_t j, uint32_t kk, uint32_t n_j, uint32_t n_arrays, uint32_t sample_all, f2* u_light, f2* u_scatter, uint32_t* light_num, float* choice_pdf) {
     const uint32_t s = slot / dl.H;
     const uint64_t index = pb.sobol_index[s];
@@ -374,16 +415,15 @@ RDEV bool dl_estimate_samples(const RenderDev& rd, const Batch& bt, const PathBu
             const int32_t px = (int32_t)(int16_t)(pk & 0xffffu), py = (int32_t)(int16_t)(pk >> 16);
             const uint64_t elem = (uint64_t)(bt.s0 + s % bt.ns) * n_j + kk;
             const uint64_t ei = rd.sampler_kind == RSPT_SAMPLER_HALTON ? halton_index(rd, px, py, elem)
-                                                                      : sobol_interval_to_index(rd, (uint32_t)rd.log2_res, elem, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
-            *u_light = dl_dims(rd, ei, 5u + 4u * pair);
-            *u_scatter = dl_dims(rd, ei, 5u + 4u * pair + 2u);
+                                                                      : dl_interval_to_index(rd, sb, (uint32_t)rd.log2_res, elem, px - rd.sample_bounds[0], py - rd.sample_bounds[1]);
+            dl_dims4(rd, sb, ei, 5u + 4u * pair, u_light, u_scatter);
             return true;
         }
         if (kk != 0u) return false;
         const uint32_t pairs = n_arrays / 2u, first = dl.kidx[slot] * nl;
         const uint32_t j0 = first >= pairs ? 0u : pairs - first;
         const uint32_t d = dl.dim[slot] + 4u * (j - j0);
-        *u_light = dl_dims(rd, index, d); *u_scatter = dl_dims(rd, index, d + 2u);
+        dl_dims4(rd, sb, index, d, u_light, u_scatter);
         return true;
     }
     const uint32_t d = dl.dim[slot];
@@ -391,7 +431,7 @@ RDEV bool dl_estimate_samples(const RenderDev& rd, const Batch& bt, const PathBu
     const uint32_t pick = (uint32_t)(u1 * (float)nl);
     *light_num = pick < nl - 1u ? pick : nl - 1u;
     *choice_pdf = 1.0f / (float)nl;
-    *u_light = dl_dims(rd, index, d + 1u); *u_scatter = dl_dims(rd, index, d + 3u);
+    dl_dims4(rd, sb, index, d + 1u, u_light, u_scatter);
     return true;
 }
 
@@ -472,14 +512,29 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
 // nls: n_light_samples per light on the device (nullptr: one each); R = the number of estimates per node = sum_j n_j (sample_all) or 1
 #define RSPT_DL_NEE_ARGS SceneDev sc, RenderDev rd, Batch bt, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ pix_list, const uint32_t* __restrict__ queue, \
                          const uint32_t* __restrict__ count_in, const int32_t* __restrict__ nls, uint32_t R, uint32_t n_arrays, uint32_t sample_all,            \
-                         uint32_t* __restrict__ q_any, uint32_t* cnt_any, uint32_t* __restrict__ q_mis, uint32_t* cnt_mis
+                         uint32_t* __restrict__ q_any, uint32_t* cnt_any, uint32_t* __restrict__ q_mis, uint32_t* cnt_mis, uint32_t sob_nd, uint32_t sob_bits
 template <uint32_t F>
 __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& rd, const Batch& bt, const PathBuf& pb, const DlBuf& dl, const uint32_t* __restrict__ pix_list,
                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in, const int32_t* __restrict__ nls, uint32_t R,
                                            uint32_t n_arrays, uint32_t sample_all, uint32_t* __restrict__ q_any, uint32_t* cnt_any,
-                                           uint32_t* __restrict__ q_mis, uint32_t* cnt_mis) {
+                                           uint32_t* __restrict__ q_mis, uint32_t* cnt_mis, uint32_t sob_nd, uint32_t sob_bits) {
     const uint32_t n = *count_in;
     const uint32_t nl = sc.n_lights, n_lights_round = sample_all ? nl : 1u;
+    // the Sobol' tables of this render's dimensions in LDS (DlSob; sob_nd = 0: Halton, or they do not fit)
+    extern __shared__ uint64_t dl_lds[];
+    DlSob sb{nullptr, 0u, 0u, nullptr};
+    if (sob_nd) {
+        uint64_t* vm = dl_lds;
+        uint32_t* tab = reinterpret_cast<uint32_t*>(dl_lds + 104);
+        const uint32_t m = (uint32_t)rd.log2_res;
+        for (uint32_t t = threadIdx.x; t < 104u; t += 256u) vm[t] = m == 0 ? 0ull : (t < 52u ? rd.vdc[(m - 1u) * 52u + t] : rd.vdc_inv[(m - 1u) * 52u + (t - 52u)]);
+        for (uint32_t t = threadIdx.x; t < sob_nd * sob_bits; t += 256u) {
+            const uint32_t dd = t % sob_nd;
+            tab[t] = rd.sobol32[(dd < 1024u ? dd : 1023u) * 52u + (t / sob_nd)];
+        }
+        __syncthreads();
+        sb = DlSob{tab, sob_nd, sob_bits, vm};
+    }
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
         uint32_t slot = 0;
@@ -500,14 +555,14 @@ __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& 
             const uint32_t n_j = sample_all ? (uint32_t)(nls ? nls[j] : 1) : 1u;
             for (uint32_t kk = 0; kk < n_j; kk++, r++) {
                 bool want_sh = false, want_mis = false;
-                const uint32_t v = slot * R + r;
+                const uint32_t v = slot * dl.vs + r * dl.vr;
                 if (i < n) {
                     uint32_t fl = 0;
                     if (shading) {
                         f2 u_light, u_scatter;
                         uint32_t light_num;
                         float choice_pdf;
-                        if (dl_estimate_samples(rd, bt, pb, dl, pix_list, slot, nl, j, kk, n_j, n_arrays, sample_all, &u_light, &u_scatter, &light_num, &choice_pdf))
+                        if (dl_estimate_samples(rd, sb, bt, pb, dl, pix_list, slot, nl, j, kk, n_j, n_arrays, sample_all, &u_light, &u_scatter, &light_num, &choice_pdf))
                             fl = dl_estimate<F>(sc, pb, d, light_num, choice_pdf, u_light, u_scatter, v, &want_sh, &want_mis);
                     }
                     dl.nflags[v] = fl;
@@ -520,10 +575,10 @@ __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& 
 }
 
 template <uint32_t F>
-__global__ __launch_bounds__(256) void k_dl_nee_all(RSPT_DL_NEE_ARGS) { dl_nee_all<F>(sc, rd, bt, pb, dl, pix_list, queue, count_in, nls, R, n_arrays, sample_all, q_any, cnt_any, q_mis, cnt_mis); }
+__global__ __launch_bounds__(256) void k_dl_nee_all(RSPT_DL_NEE_ARGS) { dl_nee_all<F>(sc, rd, bt, pb, dl, pix_list, queue, count_in, nls, R, n_arrays, sample_all, q_any, cnt_any, q_mis, cnt_mis, sob_nd, sob_bits); }
 template <uint32_t F, int W>   // the same built for W waves per SIMD (a register budget of 512 / W; the compiler spills what does not fit)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void k_dl_nee_all_w(RSPT_DL_NEE_ARGS) {
-    dl_nee_all<F>(sc, rd, bt, pb, dl, pix_list, queue, count_in, nls, R, n_arrays, sample_all, q_any, cnt_any, q_mis, cnt_mis);
+    dl_nee_all<F>(sc, rd, bt, pb, dl, pix_list, queue, count_in, nls, R, n_arrays, sample_all, q_any, cnt_any, q_mis, cnt_mis, sob_nd, sob_bits);
 }
 
 RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_resolve_all(SceneDev sc, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in,
@@ -540,7 +595,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_nee_resolve_all(SceneDev sc, 
         for (uint32_t j = 0; j < n_lights_round; j++) {
             const uint32_t n_j = sample_all ? (uint32_t)(nls ? nls[j] : 1) : 1u;
             for (uint32_t kk = 0; kk < n_j; kk++, r++) {
-                const uint32_t v = slot * R + r;
+                const uint32_t v = slot * dl.vs + r * dl.vr;
                 const uint32_t fl = dl.nflags[v];
                 if (!(fl & 0x100u)) continue;
                 const float4 c1 = pb.nee_c1[v], c2 = pb.nee_c2[v];

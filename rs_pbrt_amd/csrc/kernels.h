@@ -1629,6 +1629,15 @@ RSPT_PLAIN_KERNEL void k_build_tris(const rspt_prim* __restrict__ prims, const r
 RSPT_PLAIN_KERNEL void k_libm(uint32_t fn, const float* __restrict__ x, const float* __restrict__ y, uint64_t n, float* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (fn == 7u) {   // RSPT_LIBM_MAT4_INVERSE: Matrix4x4::inverse (mat4_inverse.h) of the i-th 4x4 matrix
+        float a[16], b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[k] = x[16 * i + k];
+        mat4_inverse(a, b);
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[16 * i + k] = b[k];
+        return;
+    }
     const float v = x[i];
     out[i] = fn == 0 ? rspt_sinf(v) : fn == 1 ? rspt_cosf(v) : fn == 2 ? rspt_logf(v) : fn == 3 ? rspt_log2f(v) : fn == 4 ? rspt_expf(v) : fn == 5 ? rspt_acosf(v) : rspt_atan2f(v, y[i]);
 }

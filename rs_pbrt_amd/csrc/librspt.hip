@@ -598,6 +598,9 @@ uint32_t hinted_grid(uint32_t full, uint32_t per_block) {
 #ifndef RSPT_PW_REFILL_CAMERA_DEFAULT
 #define RSPT_PW_REFILL_CAMERA_DEFAULT 48   // a wave of coherent camera rays refills when three quarters of its lanes are idle (the incoherent launches: RSPT_PW_REFILL = 16)
 #endif
+#ifndef RSPT_PW_ENTER
+#define RSPT_PW_ENTER 24   // C5 stand-in, every instance moving (profiles/r06_c5_enter_sweep.txt): 1 -> 142, 8 -> 170, 16 -> 182, 24 -> 183, 32 -> 180 Msamples/s
+#endif
 bool g_camera_launch = false;
 int g_any_q_force = -1;   // render_impl's measurement of the two shadow-ray kernels (tune_any): 0 / 1 forces the plain / the quantised one for the launches in between
 template <bool ANY, int OUT_MODE, bool INST, bool ALPHA>
@@ -640,9 +643,11 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
     const uint32_t spill_rows = (uint32_t)std::min<size_t>(env_size("RSPT_W4_SPILL_ROWS", RSPT_W4_SPILL), RSPT_W4_SPILL);
     if constexpr (INST) {
         if (anim_w4) {   // moving instances; next to alpha-masked meshes the masks in line (ALPHA = 2) where every mask allows it, else through alpha_pass
+            // RSPT_PW_ENTER: lanes in front of an instance wait until that many of a wave do (trace_w4.h, the entry phase); it rides in bits 8.. of the leaf threshold
+            const int pw_enter = (int)std::min<size_t>(std::max<size_t>(env_size("RSPT_PW_ENTER", RSPT_PW_ENTER), 1), 64);
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->tex, s->w4, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, pw_refill, pw_leaf, s->w4_top, hi, xcur, pw_chunk);
+                                   ra, rb, oa, ob, occ, hits, n_overflow, ovf, spill, spill_rows, pw_refill, (pw_leaf & 0xff) | (pw_enter << 8), s->w4_top, hi, xcur, pw_chunk);
             };
             if constexpr (ALPHA) { if (s->alpha_simple) go(k_trace_w4<ANY, OUT_MODE, true, 2, true>); else go(k_trace_w4<ANY, OUT_MODE, true, 1, true>); }
             else go(k_trace_w4<ANY, OUT_MODE, true, 0, true>);
@@ -659,7 +664,8 @@ void launch_trace_v(int lane, bool count, uint32_t grid, const rspt_scene_s* s, 
         const bool use_q = g_any_q_force >= 0 ? g_any_q_force != 0 : (q_env && *q_env ? atoi(q_env) != 0 : s->any_q_choice > 0);
         if (use_q && which >= 2 && s->w4q && !(s->w4_root & RSPT_REF_LEAF) && ra == rb && env_size("RSPT_W4_SHAPE", RSPT_W4_SHAPE_DEFAULT) == 0 && !xcur && spill_rows == RSPT_W4_SPILL) {
             hipLaunchKernelGGL((k_trace_w4q<OUT_MODE>), dim3(pgrid), dim3(RSPT_PW_BLOCK), 0, stream, sc, s->w4q, s->big_leaves, s->w4_root, queue, count_ptr, count_imm, cursor,
-                               ra, occ, hits, reinterpret_cast<uint32_t*>(spill), pw_refill, pw_leaf, s->w4_top, pw_chunk, s->leaf_boxes);
+                               ra, occ, hits, reinterpret_cast<uint32_t*>(spill), pw_refill, pw_leaf, s->w4_top,
+                               pw_chunk | (env_size("RSPT_ANY_Q_LATE", 1) != 0 ? 2u : 0u) /* bit 1: the exact leaf-box test only behind a triangle hit (trace_w4q.h) */, s->leaf_boxes);
             return;
         }
     }
@@ -1297,6 +1303,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         s->dev.time_div = H;   // node h of camera sample s lives in slot s * H + h: its rays carry the sample's time (moving instances); estimate rays: below
         struct TimeDivReset { rspt_scene_s* s; ~TimeDivReset() { s->dev.time_div = 1u; } } time_div_reset{s};
         const size_t n_slots = (size_t)bt.n * H;
+        // virtual slots of the estimates (direct.h DlBuf::vs / vr): planes of n_slots, unless a moving instance needs slot -> camera sample by one division (RSPT_DL_PLANES=0: A/B)
+        const bool dl_planes = !s->has_animated && env_size("RSPT_DL_PLANES", 1) != 0;
+        dl.vs = dl_planes ? 1u : dl_R; dl.vr = dl_planes ? (uint32_t)n_slots : 1u;
         HIP_TRY(hipMemsetAsync(dl.le_kind, 0, n_slots * sizeof(float4), g.stream));
         HIP_TRY(hipMemsetAsync(dl.l_all, 0, n_slots * sizeof(float4), g.stream));
         HIP_TRY(hipMemsetAsync(dl.ld_acc, 0, n_slots * sizeof(float4), g.stream));
@@ -1344,8 +1353,22 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                 constexpr uint32_t DLV_PLASTIC = SV_PLASTIC | SF_SOBOL | SF_HALTON;
                 const bool dl_narrow = (s->shade_features & ~DLV_PLASTIC) == 0 && !(getenv("RSPT_DL_VARIANT") && !strcmp(getenv("RSPT_DL_VARIANT"), "generic"));
                 const size_t dl_waves = env_size("RSPT_DL_WAVES", RSPT_DL_WAVES_DEFAULT);   // 3: the narrow build forced to 3 waves per SIMD
-                hipLaunchKernelGGL(dl_narrow ? (dl_waves == 3 ? k_dl_nee_all_w<DLV_PLASTIC, 3> : k_dl_nee_all<DLV_PLASTIC>) : k_dl_nee_all<SF_ALL>, dim3(dgrid), dim3(256), 0, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R,
-                                   n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest);
+                // the Sobol' tables the estimates read, in LDS (direct.h DlSob): the sample arrays' dimensions 5 .. 5 + 2 n_arrays and what the regular stream adds behind them,
+                // for indices of 2 log2_res + log2(spp x the longest array) bits; cut to 40 KB (the rest falls back to the global walks); RSPT_DL_LDS_SOBOL=0: as before
+                uint32_t dsn = 0, dsb = 0;
+                if (!halton && env_size("RSPT_DL_LDS_SOBOL", 1) != 0) {
+                    uint64_t longest = 1;
+                    for (uint32_t j = 0; all && d->n_light_samples && j < nl; j++) longest = std::max<uint64_t>(longest, (uint64_t)std::max<int32_t>(d->n_light_samples[j], 1));
+                    dsb = 2u * (uint32_t)rd.log2_res + 1u;
+                    for (uint64_t v = (uint64_t)std::max<int64_t>(d->spp, 1) * longest; v > 1; v >>= 1) dsb++;
+                    dsb = std::min(52u, dsb);
+                    dsn = std::min<uint32_t>(1024u, 5u + 2u * n_arrays + 8u * (md + 2u));
+                    dsn = std::min<uint32_t>(dsn, (40u * 1024u) / (4u * dsb));
+                    if (dsn < 16u) dsn = dsb = 0;
+                }
+                const size_t dl_lds = dsn ? 104 * sizeof(uint64_t) + (size_t)dsn * dsb * sizeof(uint32_t) : 0;
+                hipLaunchKernelGGL(dl_narrow ? (dl_waves == 3 ? k_dl_nee_all_w<DLV_PLASTIC, 3> : k_dl_nee_all<DLV_PLASTIC>) : k_dl_nee_all<SF_ALL>, dim3(dgrid), dim3(256), dl_lds, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R,
+                                   n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest, dsn, dsb);
                 ev_close(2, 0);
                 ev_open(1, 0);
                 s->dev.time_div = H * dl_R;   // estimate r of node slot n sits in virtual slot n * R + r
@@ -2765,17 +2788,18 @@ int rspt_motion_bounds(const float start_m[16], float start_time, const float en
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (n == 0) return RSPT_OK;
-    if (fn > RSPT_LIBM_ATAN2 || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (1ull << 31)) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values");
+    if (fn > RSPT_LIBM_MAT4_INVERSE || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (1ull << 31)) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values");
     HIP_TRY(hipSetDevice(g.device));
     float *xd = nullptr, *yd = nullptr, *od = nullptr;
     struct Guard { float **a, **b, **c; ~Guard() { for (float** p : {a, b, c}) if (*p) (void)hipFree(*p); } } guard{&xd, &yd, &od};
     int rc;
-    if ((rc = dev_alloc(&xd, n)) || (rc = dev_alloc(&od, n)) || (y && (rc = dev_alloc(&yd, n)))) return rc;
-    HIP_TRY(hipMemcpyAsync(xd, x, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    const uint64_t per = fn == RSPT_LIBM_MAT4_INVERSE ? 16u : 1u;   // values per element
+    if ((rc = dev_alloc(&xd, n * per)) || (rc = dev_alloc(&od, n * per)) || (y && (rc = dev_alloc(&yd, n)))) return rc;
+    HIP_TRY(hipMemcpyAsync(xd, x, n * per * sizeof(float), hipMemcpyHostToDevice, g.stream));
     if (y) HIP_TRY(hipMemcpyAsync(yd, y, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
     hipLaunchKernelGGL(k_libm, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, yd, n, od);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, od, n * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(out, od, n * per * sizeof(float), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     return RSPT_OK;
 }

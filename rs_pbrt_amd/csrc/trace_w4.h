@@ -40,6 +40,7 @@ struct Wide4Node {      // 128 B, 128-byte aligned
 #define RSPT_W4_AXIS_SHIFT 25
 #define RSPT_W4_AXIS_MASK 0x06000000u
 #define RSPT_W4_OFFSET_MASK 0x01ffffffu
+#define RSPT_W4_ENTER 0xfffffffeu   // k_trace_w4<.., ANIM>: "parked in front of an instance" in the lane's leaf word (no leaf reference carries the axis bits)
 #ifndef RSPT_W4_LDS
 #define RSPT_W4_LDS 12       // stack entries per lane (8 B each) kept in LDS: 24 KB per workgroup
 #endif
@@ -144,6 +145,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
         top = reinterpret_cast<float4*>(stack + RSPT_W4_LDS * BLOCK);
     }
     uint2* my = stack + threadIdx.x;
+    // ANIM: entering a moving instance costs ~1 400 instructions (inst_inverse_at), ten node steps' worth, and a leaf phase runs with a fifth of the wave: lanes that
+    // reach an instance are parked (leaf = RSPT_W4_ENTER) until enter_thresh of them wait — bits 8.. of the leaf_thresh parameter — or nothing else can run
+    int enter_thresh = 1;
+    if constexpr (ANIM) { enter_thresh = leaf_thresh >> 8; leaf_thresh &= 0xff; if (enter_thresh < 1) enter_thresh = 1; }
     if (n_top > (uint32_t)TOPCAP) n_top = (uint32_t)TOPCAP;   // (the scene numbers a longer breadth-first prefix first than the small form keeps)
     if constexpr (TOPCAP > 0) {
         for (uint32_t i = threadIdx.x; i < 7u * n_top; i += BLOCK) {
@@ -408,11 +413,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
         }
 
         // ---- leaf phase: watertight triangle tests for parked lanes, when enough of them wait ----
-        const uint64_t parked = __ballot(active && leaf != RSPT_NONE);
+        const uint64_t parked = __ballot(active && leaf != RSPT_NONE && (!ANIM || leaf != RSPT_W4_ENTER));
         if (parked) {
             const uint64_t running = __ballot(active && leaf == RSPT_NONE);
             if (__popcll(parked) >= leaf_thresh || running == 0) {
-                if (active && leaf != RSPT_NONE) {
+                if (active && leaf != RSPT_NONE && (!ANIM || leaf != RSPT_W4_ENTER)) {
                     uint32_t offset = leaf & RSPT_W4_OFFSET_MASK, n_prims = ((leaf >> RSPT_W4_COUNT_SHIFT) & 15u) + 1u;
                     if (n_prims == 16u) {
                         const uint2 bl = big_leaves[offset];
@@ -440,34 +445,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
                                 sp++;
                             }
                             inst = __float_as_uint(a.x);
-                            const InstDev& in = sc.inst[inst];
-                            const float4* rp = reinterpret_cast<const float4*>(((entry & RSPT_Q_MIS) ? rays_b : rays_a) + (entry & ~RSPT_Q_MIS));
-                            const float4 r0 = rp[0], r1 = rp[1];
-                            f3 no, nd;
-                            w_tmax = t_max; sp_base = sp; inst_hit = false;
-                            if (ANIM && in.anim != RSPT_MISS) {   // primitive_to_world.interpolate(r.time) and its inverse (primitive.rs:218-222)
-                                const uint32_t slot = entry & ~RSPT_Q_MIS;
-                                const float time = (OUT_MODE == 0 && sc.ray_time) ? sc.ray_time[slot / sc.time_div] : 0.0f;
-                                const InstDev at = inst_at(sc, inst, time);
-                                inst_ident = at.identity != 0u;
-                                inst_ray(at, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, t_max, &no, &nd, &t_max);
-                            } else {
-                                inst_ident = in.identity != 0u;
-                                inst_ray(in, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, t_max, &no, &nd, &t_max);
-                            }
-                            ox = no.x; oy = no.y; oz = no.z;
-                            ix = 1.0f / nd.x; iy = 1.0f / nd.y; iz = 1.0f / nd.z;
-                            negbits = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
-                            if (!(fabsf(ix) < RSPT_INF && fabsf(iy) < RSPT_INF && fabsf(iz) < RSPT_INF)) negbits |= 8u;
-                            rs = ray_shear(nd);
-                            if (in.root_node == RSPT_MISS) leaf = in.w4_root;  // a lone GeometricPrimitive: no box test (api.rs:3046)
-                            else {                                            // the object aggregate's node 0 (bvh.rs:424)
-                                const float4 q0 = sc.nodes[2 * (size_t)in.root_node], q1 = sc.nodes[2 * (size_t)in.root_node + 1];
-                                if (box_hit(q0, q1, no, f3{ix, iy, iz}, negbits & 1u, negbits & 2u, negbits & 4u, t_max)) {
-                                    if (in.w4_root & RSPT_REF_LEAF) leaf = in.w4_root;
-                                    else cur = in.w4_root;
-                                }
-                            }
+                            if constexpr (ANIM) leaf = RSPT_W4_ENTER;   // (the entry phase below)
+                            else
+#include "trace_w4_enter.h"
                             break;
                         }
                         float t, b0, b1, b2;
@@ -493,6 +473,20 @@ __global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, c
                         }
                     }
                     if (ANY && best != RSPT_MISS) finish();
+                }
+            }
+        }
+
+        // ---- entry phase (ANIM): lanes parked in front of an instance, when enough of them wait or no other lane can move ----
+        if constexpr (ANIM) {
+            const uint64_t waiting = __ballot(active && leaf == RSPT_W4_ENTER);
+            if (waiting) {
+                const uint64_t others = __ballot(active && leaf != RSPT_W4_ENTER);
+                if (__popcll(waiting) >= enter_thresh || others == 0) {
+                    if (active && leaf == RSPT_W4_ENTER) {
+                        leaf = RSPT_NONE;
+#include "trace_w4_enter.h"
+                    }
                 }
             }
         }

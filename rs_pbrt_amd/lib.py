@@ -199,6 +199,14 @@ def libm(fn, x, y=None):
     return out
 
 
+def mat4_inverse(m):
+    """rspt_libm(RSPT_LIBM_MAT4_INVERSE): Matrix4x4::inverse (transform.rs:128-200) of n row-major 4x4 matrices as the device evaluates it (csrc/mat4_inverse.h)"""
+    m = np.ascontiguousarray(m, np.float32).reshape(-1, 16)
+    out = np.empty_like(m)
+    _check(lib().rspt_libm(7, m.ctypes.data, None, len(m), out.ctypes.data))
+    return out
+
+
 def light_distribution(dscene, strategy, p):
     """rspt_light_distribution: LightDistribution::lookup(p) -> (func[n_lights], cdf[n_lights + 1], n_voxels[3], voxel[3])"""
     n = int(dscene.host.desc.n_lights)
