@@ -652,10 +652,11 @@ RDEV float spot_falloff(const rspt_light& lt, f3 w) {  // spot.rs:67-80
 // Light::sample_li: DiffuseAreaLight (diffuse.rs:64-84), PointLight (point.rs:52-68), SpotLight
 // (spot.rs:81-106), DistantLight (distant.rs:41-58).  Delta lights return pdf = 1 and a light point
 // with zero normal and zero error bounds (InteractionCommon::default()).
+// pre: the light's triangle record where the caller already holds it (direct.h keeps the lights and their triangles in LDS), else nullptr
 template <uint32_t F = 0xffffffffu>
-RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 u, f3* wi, float* pdf, LightSample* ls) {
+RDEV rgb light_sample_li(const SceneDev& sc, const rspt_light& lt, f3 ref_p, f2 u, f3* wi, float* pdf, LightSample* ls, const TriRec* pre = nullptr) {
     if (!(F & (SF_L_POINT | SF_L_SPOT | SF_L_DISTANT | SF_L_INFINITE)) || lt.kind == RSPT_LIGHT_DIFFUSE_AREA) {
-        TriRec t = load_tri(sc, lt.prim);
+        TriRec t = pre ? *pre : load_tri(sc, lt.prim);
         *ls = tri_sample_ref(sc, lt.prim, t, ref_p, u, pdf);
         if (*pdf == 0.0f || len2(ls->p - ref_p) == 0.0f) { *pdf = 0.0f; return mkrgb(0.0f); }
         *wi = normalize(ls->p - ref_p);

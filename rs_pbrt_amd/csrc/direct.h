@@ -376,7 +376,35 @@ struct DlSob {
     const uint32_t* tab;   // [bits][nd] in LDS; nullptr: Halton, or the tables do not fit — the global walks
     uint32_t nd, bits;
     const uint64_t* m;     // vdc rows of log2_res [52], then vdc_inv rows [52], in LDS
+    // The scene's lights and the triangle records of the area lights, in LDS (nullptr: more lights than DL_LDS_LIGHTS).  Not for their bytes — every lane of a wave reads
+    // the SAME record, an L1 hit — but for the counter they wait on: gfx950 has one vmcnt for loads and stores, so a global load issued behind an estimate's five stores
+    // (shadow ray, two term vectors, flags) is waited for with vmcnt(0), i.e. until those stores are acknowledged by L2 — once per estimate, at two waves per SIMD:
+    // SQ_WAIT_ANY 0.69 of the kernel's wave cycles, VALU busy 0.20 (profiles/r06_directlighting_pmc.txt).  LDS reads count on lgkmcnt and pass the stores.
+    const uint32_t* lights;   // rspt_light[n] as words
+    const float4* tris;       // [3 * n]: the triangle record of light j (area lights; zeros for the others)
 };
+#define DL_LDS_LIGHTS 64u
+#ifndef RSPT_DL_EXP
+#define RSPT_DL_EXP 0   // timing experiments on k_dl_nee_all (tools/ab_build.sh with AB_DEFS=-DRSPT_DL_EXP=n; WRONG PICTURES, never the shipped build): 1 = no result stores,
+                        // 2 = no queue appends, 3 = no BSDF-sampled half of estimate_direct
+#endif
+RDEV rspt_light dl_light(const SceneDev& sc, const DlSob& sb, uint32_t j) {
+    if (!sb.lights) return sc.lights[j];
+    rspt_light lt;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&lt);
+    const uint32_t* src = sb.lights + j * (uint32_t)(sizeof(rspt_light) / 4);
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(rspt_light) / 4; k++) w[k] = src[k];
+    return lt;
+}
+RDEV TriRec dl_light_tri(const SceneDev& sc, const DlSob& sb, const rspt_light& lt, uint32_t j) {
+    if (!sb.lights) return load_tri(sc, lt.prim);
+    const float4 a = sb.tris[3u * j], b = sb.tris[3u * j + 1u], c = sb.tris[3u * j + 2u];
+    TriRec t;
+    t.p0 = f3{a.x, a.y, a.z}; t.p1 = f3{a.w, b.x, b.y}; t.p2 = f3{b.z, b.w, c.x};
+    t.material = __float_as_uint(c.y); t.area_light = (int32_t)__float_as_uint(c.z); t.flags = __float_as_uint(c.w);
+    return t;
+}
 RDEV uint64_t dl_interval_to_index(const RenderDev& rd, const DlSob& sb, uint32_t m, uint64_t frame, int32_t px, int32_t py) {
     if (!sb.tab) return sobol_interval_to_index(rd, m, frame, px, py);
     if (m == 0) return 0;
@@ -437,38 +465,39 @@ RDEV bool dl_estimate_samples(const RenderDev& rd, const DlSob& sb, const Batch&
 
 // estimate_direct (integrator.rs:406-570) of one light for a built interaction; rays and terms go to virtual slot v.  Returns the DLF_* flags | 0x100.
 template <uint32_t F>   // the feature set the instantiation is compiled for (dev_bsdf.h SF_*: lobe kinds, light kinds, per-vertex normals), as k_shade<F>
-RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d, uint32_t light_num, float choice_pdf, f2 u_light, f2 u_scatter, uint32_t v, bool* want_sh, bool* want_mis) {
+RDEVN uint32_t dl_estimate(const SceneDev& sc, const DlSob& sb, const PathBuf& pb, const DlHit& d, uint32_t light_num, float choice_pdf, f2 u_light, f2 u_scatter, uint32_t v, bool* want_sh, bool* want_mis) {
     const Hit& h = d.h;
     uint32_t fl = 0;
     const uint32_t flags = BX_ALL & ~BX_SPEC;
-    const rspt_light lt = sc.lights[light_num];
+    const rspt_light lt = dl_light(sc, sb, light_num);
+    const bool is_area = !(F & (SF_L_POINT | SF_L_SPOT | SF_L_DISTANT | SF_L_INFINITE)) || lt.kind == RSPT_LIGHT_DIFFUSE_AREA;
+    TriRec lt_tri{};
+    if (is_area) lt_tri = dl_light_tri(sc, sb, lt, light_num);
     rgb c1 = mkrgb(0.0f), c2 = mkrgb(0.0f);
     f3 wi{0.0f, 0.0f, 0.0f};
     float light_pdf = 0.0f, scattering_pdf = 0.0f;
     LightSample ls;
-    const rgb li = light_sample_li<F>(sc, lt, h.p, u_light, &wi, &light_pdf, &ls);
+    const rgb li = light_sample_li<F>(sc, lt, h.p, u_light, &wi, &light_pdf, &ls, is_area ? &lt_tri : nullptr);
     if (light_pdf > 0.0f && !is_black(li)) {
         const rgb f = d.bsdf.template f<F>(d.wo, wi, flags) * mkrgb(absdot(wi, h.sh_n));
         scattering_pdf = d.bsdf.template pdf<F>(d.wo, wi, flags);
         if (!is_black(f)) {
             const f3 origin = offset_ray_origin(h.p, h.p_err, h.n, ls.p - h.p);
             const f3 target = offset_ray_origin(ls.p, ls.p_err, ls.n, origin - ls.p);
-            store_ray(pb.ray_sh + v, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, v);
+            if (RSPT_DL_EXP != 1) store_ray(pb.ray_sh + v, origin, target - origin, 1.0f - RSPT_SHADOW_EPS, v);
             *want_sh = true;
             if (light_is_delta<F>(lt)) c1 = f * li / light_pdf;
             else c1 = f * li * mkrgb(power_heuristic(light_pdf, scattering_pdf)) / light_pdf;
             fl |= DLF_HAS_C1;
         }
     }
-    if (!light_is_delta<F>(lt)) {
+    if (RSPT_DL_EXP != 3 && !light_is_delta<F>(lt)) {
         uint32_t sampled_type = 0;
         // (round 6, as kernels.h shade_path: an area light's BSDF-sampled term needs the sampled direction to meet the light's own triangle — tested as soon as the
         //  lobe has chosen the direction; a miss skips the other lobes' pdfs and the lobes' values)
         const bool area_mis = !((F & SF_L_INFINITE) && lt.kind == RSPT_LIGHT_INFINITE) && RSPT_MIS_EARLY_OUT;
-        TriRec lt_tri;
         float t_l = 0.0f, lb0 = 0.0f, lb1 = 0.0f, lb2 = 0.0f;
         bool on_light = false;
-        if (area_mis) lt_tri = load_tri(sc, lt.prim);
         rgb f = d.bsdf.template sample_f_if<F>(d.wo, &wi, u_scatter, &scattering_pdf, flags, &sampled_type, [&](f3 w) {
             if (!area_mis) return false;
             on_light = tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, offset_ray_origin(h.p, h.p_err, h.n, w), ray_shear(w), RSPT_INF, &t_l, &lb0, &lb1, &lb2);
@@ -483,10 +512,7 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
                 lpdf = infinite_pdf_li(sc, lt, wi);
                 if (lpdf != 0.0f) le_mis = infinite_le(sc, lt, wi);
             } else {
-                if (!area_mis) {
-                    lt_tri = load_tri(sc, lt.prim);
-                    on_light = tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2);
-                }
+                if (!area_mis) on_light = tri_test(lt_tri.p0, lt_tri.p1, lt_tri.p2, ro, ray_shear(wi), RSPT_INF, &t_l, &lb0, &lb1, &lb2);
                 if (on_light) {
                     Hit lh;
                     tri_fill<(F & SF_VERTEX) != 0>(sc, lt.prim, lt_tri, lb0, lb1, lb2, &lh);
@@ -504,6 +530,7 @@ RDEVN uint32_t dl_estimate(const SceneDev& sc, const PathBuf& pb, const DlHit& d
             }
         }
     }
+    if (RSPT_DL_EXP == 1) { if (c1.r + c2.r == 1e30f) pb.nee_c1[v] = make_float4(c1.r, c1.g, c1.b, choice_pdf); return fl | 0x100u; }
     pb.nee_c1[v] = make_float4(c1.r, c1.g, c1.b, choice_pdf);
     pb.nee_c2[v] = make_float4(c2.r, c2.g, c2.b, __uint_as_float(light_num));
     return fl | 0x100u;
@@ -521,11 +548,29 @@ __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& 
     const uint32_t n = *count_in;
     const uint32_t nl = sc.n_lights, n_lights_round = sample_all ? nl : 1u;
     // the Sobol' tables of this render's dimensions in LDS (DlSob; sob_nd = 0: Halton, or they do not fit)
-    extern __shared__ uint64_t dl_lds[];
-    DlSob sb{nullptr, 0u, 0u, nullptr};
+    extern __shared__ __attribute__((aligned(16))) uint64_t dl_lds[];
+    DlSob sb{nullptr, 0u, 0u, nullptr, nullptr, nullptr};
+    // [lights: 3 x float4 of triangles + rspt_light words per light][vdc rows 104 x u64][Sobol' columns]; the host sizes the launch's dynamic LDS to match (lds_lights = the
+    // number of lights staged, 0 = none)
+    const uint32_t lds_lights = sob_bits >> 16;
+    sob_bits &= 0xffffu;
+    uint64_t* after_lights = dl_lds;
+    if (lds_lights) {
+        float4* lt_tris = reinterpret_cast<float4*>(dl_lds);
+        uint32_t* lt_words = reinterpret_cast<uint32_t*>(lt_tris + 3u * lds_lights);
+        constexpr uint32_t LW = (uint32_t)(sizeof(rspt_light) / 4);
+        for (uint32_t t = threadIdx.x; t < lds_lights * LW; t += 256u) lt_words[t] = reinterpret_cast<const uint32_t*>(sc.lights)[t];
+        for (uint32_t t = threadIdx.x; t < 3u * lds_lights; t += 256u) {
+            const rspt_light& l = sc.lights[t / 3u];
+            lt_tris[t] = l.kind == RSPT_LIGHT_DIFFUSE_AREA ? sc.tris[3 * (size_t)l.prim + t % 3u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        sb.lights = lt_words; sb.tris = lt_tris;
+        after_lights = dl_lds + (lds_lights * (48u + 4u * LW) + 7u) / 8u;
+        if (!sob_nd) __syncthreads();
+    }
     if (sob_nd) {
-        uint64_t* vm = dl_lds;
-        uint32_t* tab = reinterpret_cast<uint32_t*>(dl_lds + 104);
+        uint64_t* vm = after_lights;
+        uint32_t* tab = reinterpret_cast<uint32_t*>(after_lights + 104);
         const uint32_t m = (uint32_t)rd.log2_res;
         for (uint32_t t = threadIdx.x; t < 104u; t += 256u) vm[t] = m == 0 ? 0ull : (t < 52u ? rd.vdc[(m - 1u) * 52u + t] : rd.vdc_inv[(m - 1u) * 52u + (t - 52u)]);
         for (uint32_t t = threadIdx.x; t < sob_nd * sob_bits; t += 256u) {
@@ -533,7 +578,7 @@ __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& 
             tab[t] = rd.sobol32[(dd < 1024u ? dd : 1023u) * 52u + (t / sob_nd)];
         }
         __syncthreads();
-        sb = DlSob{tab, sob_nd, sob_bits, vm};
+        sb.tab = tab; sb.nd = sob_nd; sb.bits = sob_bits; sb.m = vm;
     }
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
@@ -550,8 +595,37 @@ __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& 
                 dl_interaction<F>(sc, pb, slot, __float_as_uint(hc.x), hc, f3{r0.w, r1.x, r1.y}, &d);
             }
         }
+        // Queue appends, gathered over up to 32 estimates: one atomicAdd per wave, queue and chunk instead of one per estimate.  With an append after every estimate (dl_push)
+        // the kernel spent 43 % of its time on them — 10.6 -> 6.1 ms per launch with the appends compiled out (RSPT_DL_EXP=2), against 10.4 without the result stores
+        // (profiles/r06_directlighting_experiments.txt): every append is an atomic round trip that the wave waits for with its stores in flight, on one address for the
+        // whole chip.  A lane notes what its estimates want in two bit masks; flush() counts the chunk's entries by ballots, claims them at once and writes them estimate by
+        // estimate, so that the rays of one estimate — neighbouring virtual slots of a plane — stay neighbours in the queue.
+        uint32_t sh_bits = 0, mis_bits = 0, r0 = 0;
+        auto flush_one = [&](uint32_t bits, uint32_t cnt, uint32_t tag, uint32_t* __restrict__ q, uint32_t* counter) {
+            uint32_t total = 0;   // wave-uniform
+            for (uint32_t k = 0; k < cnt; k++) total += (uint32_t)__popcll(__ballot((bits >> k) & 1u));
+            if (!total) return;
+            const uint32_t lane = __lane_id();
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(counter, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            for (uint32_t k = 0; k < cnt; k++) {
+                const bool mine = (bits >> k) & 1u;
+                const uint64_t m = __ballot(mine);
+                if (mine) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (slot * dl.vs + (r0 + k) * dl.vr) | tag;
+                base += (uint32_t)__popcll(m);
+            }
+        };
+        auto flush = [&](uint32_t cnt) {
+            if (RSPT_DL_EXP != 2) {
+                flush_one(sh_bits, cnt, 0u, q_any, cnt_any);
+                flush_one(mis_bits, cnt, RSPT_Q_MIS, q_mis, cnt_mis);
+            }
+            sh_bits = mis_bits = 0;
+            r0 += cnt;
+        };
         uint32_t r = 0;
-        for (uint32_t j = 0; j < n_lights_round; j++) {          // (wave-uniform trip counts: dl_push ballots inside)
+        for (uint32_t j = 0; j < n_lights_round; j++) {          // (wave-uniform trip counts: flush() ballots)
             const uint32_t n_j = sample_all ? (uint32_t)(nls ? nls[j] : 1) : 1u;
             for (uint32_t kk = 0; kk < n_j; kk++, r++) {
                 bool want_sh = false, want_mis = false;
@@ -563,14 +637,16 @@ __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& 
                         uint32_t light_num;
                         float choice_pdf;
                         if (dl_estimate_samples(rd, sb, bt, pb, dl, pix_list, slot, nl, j, kk, n_j, n_arrays, sample_all, &u_light, &u_scatter, &light_num, &choice_pdf))
-                            fl = dl_estimate<F>(sc, pb, d, light_num, choice_pdf, u_light, u_scatter, v, &want_sh, &want_mis);
+                            fl = dl_estimate<F>(sc, sb, pb, d, light_num, choice_pdf, u_light, u_scatter, v, &want_sh, &want_mis);
                     }
-                    dl.nflags[v] = fl;
+                    if (RSPT_DL_EXP != 1 || fl == 0x7fffffffu) dl.nflags[v] = fl;
                 }
-                dl_push(want_sh, v, q_any, cnt_any);
-                dl_push(want_mis, v | RSPT_Q_MIS, q_mis, cnt_mis);
+                if (want_sh) sh_bits |= 1u << (r - r0);
+                if (want_mis) mis_bits |= 1u << (r - r0);
+                if (r - r0 == 31u) flush(32u);
             }
         }
+        if (r != r0) flush(r - r0);
     }
 }
 

@@ -1077,7 +1077,12 @@ __device__ __forceinline__ void shade_kernel(const SceneDev& sc, const LightDist
             uint32_t tot = 0;
             for (int w = 0; w < 4; w++) tot += q == 0 ? s_wave[w][0] : (q == 1 ? s_wave[w][1] + s_wave[w][2] : (q == 2 ? s_wave[w][3] : s_wave[w][4]));
             uint32_t* ctr = q == 0 ? &cnt_out->active : (q == 1 ? &cnt_out->closest : (q == 2 ? &cnt_out->any : &cnt_out->active_tail));
+#if defined(RSPT_SHADE_EXP) && RSPT_SHADE_EXP == 1   // timing experiment (tools/ab_build.sh, WRONG pictures): what the queue-counter atomics cost the first shade launch
+            s_base[q] = base;
+            if (tot == 0xffffffffu) *ctr = tot;
+#else
             s_base[q] = tot ? atomicAdd(ctr, tot) : 0u;
+#endif
         }
         __syncthreads();
         uint32_t off_act = s_base[0], off_cont = s_base[1], off_mis = s_base[1], off_sh = s_base[2], off_tail = s_base[3];

@@ -1366,7 +1366,11 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
                     dsn = std::min<uint32_t>(dsn, (40u * 1024u) / (4u * dsb));
                     if (dsn < 16u) dsn = dsb = 0;
                 }
-                const size_t dl_lds = dsn ? 104 * sizeof(uint64_t) + (size_t)dsn * dsb * sizeof(uint32_t) : 0;
+                // the lights and the area lights' triangle records in LDS too (direct.h DlSob::lights: their loads must not queue behind the estimates' stores); the count
+                // rides in bits 16.. of the index-bits argument.  RSPT_DL_LDS_LIGHTS=0: from global memory as before
+                const uint32_t dll = (nl <= DL_LDS_LIGHTS && env_size("RSPT_DL_LDS_LIGHTS", 1) != 0) ? nl : 0u;
+                const size_t dl_lds = (dll ? (((size_t)dll * (48 + sizeof(rspt_light)) + 7) / 8) * 8 : 0) + (dsn ? 104 * sizeof(uint64_t) + (size_t)dsn * dsb * sizeof(uint32_t) : 0);
+                dsb |= dll << 16;
                 hipLaunchKernelGGL(dl_narrow ? (dl_waves == 3 ? k_dl_nee_all_w<DLV_PLASTIC, 3> : k_dl_nee_all<DLV_PLASTIC>) : k_dl_nee_all<SF_ALL>, dim3(dgrid), dim3(256), dl_lds, g.stream, s->dev, rd, bt, g.pb, dl, g.pix_list, level_q(l), &g.cnt[l].closest, (const int32_t*)dl_nls, dl_R,
                                    n_arrays, all ? 1u : 0u, g.q[0][2], &rc_->any, g.q[0][1], &rc_->closest, dsn, dsb);
                 ev_close(2, 0);

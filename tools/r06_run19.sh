@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+tag=${1:-r06t}; out=$PWD/gpurun_out/$tag; mkdir -p $out; repo=$PWD; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_directlighting.py tests/test_instancing.py tests/test_gpu_pixel_samplers.py -m gpu -q -x > $out/pytest_dl.log 2>&1; echo "pytest rc=$?" >> $out/pytest_dl.log; tail -3 $out/pytest_dl.log
+for r in 1 2; do for w in statue soup1m cornell; do
+  v=$(timeout 600 python bench.py --workload $w --integrator directlighting --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-count 2> $out/dl.err | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f Msamples/s %.2f ms' % (d['value'], d['ms_per_step']))")
+  echo "round $r batched appends, $w directlighting: $v" | tee -a $out/dl_appends.txt
+done; done
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/kt_dl -- python $repo/bench.py --workload statue --integrator directlighting --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-count > $out/kt_dl.log 2>&1)
+python3 tools/rocprof_summary.py $out/kt_dl $out/statue_directlighting_kernel_stats.md "bench.py --workload statue --integrator directlighting --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-count" > /dev/null 2>&1; head -14 $out/statue_directlighting_kernel_stats.md; rm -rf $out/kt_dl
