@@ -61,7 +61,10 @@ struct DlHit {
     f3 wo;      // isect.common.wo
     Bsdf bsdf;
 };
-template <uint32_t F = SF_ALL>
+// TEX: the node's texture results are in pb.tex (k_dl_texture ran for it): the material's lobes are bound to them and Material::bump's shading geometry replaces the
+// interpolated one, as in shade_path (kernels.h).  k_dl_hit, which runs before the texture stage, passes false: what it reads of the BSDF — specular lobes — does not exist in
+// the scenes the wavefront form serves with textures (the host routes textures + specular lobes to the per-lane form).
+template <uint32_t F = SF_ALL, bool TEX = false>
 RDEV void dl_interaction(const SceneDev& sc, const PathBuf& pb, uint32_t slot, uint32_t prim, float4 hc, f3 ray_d, DlHit* o) {
     TriRec tri = load_tri(sc, prim);
     tri_fill<(F & SF_VERTEX) != 0>(sc, prim, tri, hc.y, hc.z, hc.w, &o->h);
@@ -80,6 +83,18 @@ RDEV void dl_interaction(const SceneDev& sc, const PathBuf& pb, uint32_t slot, u
         const rspt_material mat = sc.materials[o->h.material];
         Bsdf& b = o->bsdf;
         b.eta = mat.eta; b.lt = LobeTex{nullptr, 0}; b.dropped = 0u;
+        if (TEX && (F & SF_TEX) && pb.tex && sc.mat_flags && sc.mat_flags[o->h.material]) {   // (shade_path's textured assembly; dynamic lobe lists take the per-lane form)
+            const float4* tb = pb.tex + slot;
+            b.lt = LobeTex{tb, pb.tex_stride};
+            const float4 m4 = tb[4 * (size_t)pb.tex_stride];
+            const uint32_t tf = __float_as_uint(m4.w);
+            b.dropped = (tf >> 8) & 0xffu;
+            if (tf & 1u) {   // Material::bump replaced the shading geometry (material.rs:116-219)
+                const float4 d4 = tb[5 * (size_t)pb.tex_stride];
+                o->h.sh_n = f3{m4.x, m4.y, m4.z};
+                o->h.sh_dpdu = f3{d4.x, d4.y, d4.z};
+            }
+        }
         b.ss = normalize(o->h.sh_dpdu); b.ns = o->h.sh_n; b.ng = o->h.n; b.ts = cross(o->h.sh_n, b.ss);
         b.lobes = sc.bxdfs + mat.first_bxdf;
         b.n = mat.n_bxdfs < 8u ? mat.n_bxdfs : 8u;
@@ -122,6 +137,7 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd
                 dl_interaction(sc, pb, slot, prim, hc, ray_d, &d);
                 if (d.h.material == 0xffffffffu) {  // isect.bsdf.is_none(): return self.li(&isect.spawn_ray(&ray.d), ..., depth) (:90-92)
                     store_ray(pb.ray_cont + slot, offset_ray_origin(d.h.p, d.h.p_err, d.h.n, ray_d), ray_d, RSPT_INF, slot);
+                    pb.state[slot] = ST_NO_DIFF;   // isect.spawn_ray: no differentials (k_dl_texture; the host zeroes the node slots' words per batch)
                     retrace = true;
                 } else {
                     const rgb le = d.h.area_light >= 0 ? light_l(sc.lights[d.h.area_light], d.h.n, d.wo) : mkrgb(0.0f);  // l += isect.le(&wo)
@@ -153,6 +169,18 @@ RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_hit(SceneDev sc, RenderDev rd
         const uint32_t h = slot % dl.H, s = slot / dl.H;
         dl_push(kid_r, s * dl.H + 2u * h, q_next, cnt_next);
         dl_push(kid_t, s * dl.H + 2u * h + 1u, q_next, cnt_next);
+    }
+}
+
+// round 6: the texture stage of the wavefront form — scenes with textured materials and NO specular lobes (the tree is its roots: every node's ray is a camera ray, whose
+// differentials compute_differentials takes from the camera, directlighting.rs:86 -> compute_scattering_functions).  Textures next to specular lobes keep the per-lane form,
+// which carries the reflected / refracted differentials down the tree (dl_serial.h).
+RSPT_PLAIN_KERNEL __launch_bounds__(256) void k_dl_texture(SceneDev sc, TexTables tt, RenderDev rd, PathBuf pb, DlBuf dl, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_in) {
+    const uint32_t n = *count_in;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t slot = queue[i];
+        if (__float_as_uint(dl.le_kind[slot].w) != DL_SHADING) continue;
+        [[clang::always_inline]] texture_slot(sc, tt, rd, pb, slot, slot / dl.H, slot / sc.time_div, pb.state[slot] != ST_NO_DIFF, nullptr);
     }
 }
 
@@ -592,7 +620,7 @@ __device__ __forceinline__ void dl_nee_all(const SceneDev& sc, const RenderDev& 
                 const float4 hc = pb.hit_cont[slot];
                 const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + slot);
                 const float4 r0 = rp[0], r1 = rp[1];
-                dl_interaction<F>(sc, pb, slot, __float_as_uint(hc.x), hc, f3{r0.w, r1.x, r1.y}, &d);
+                dl_interaction<F, true>(sc, pb, slot, __float_as_uint(hc.x), hc, f3{r0.w, r1.x, r1.y}, &d);
             }
         }
         // Queue appends, gathered over up to 32 estimates: one atomicAdd per wave, queue and chunk instead of one per estimate.  With an append after every estimate (dl_push)

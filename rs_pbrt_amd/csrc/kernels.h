@@ -870,13 +870,12 @@ RDEVN void texture_hit_call(const SceneDev& sc, const TexTables& tt, TexHit& h, 
 // texture the material's lobes are bound to; k_shade picks the results up from pb.tex.
 // the texture stage for path slot p (see above); lens: the camera sample's lens position when it cannot be recomputed from the
 // sample index (pixel samplers), else nullptr
-RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev& rd, const PathBuf& pb, uint32_t p, const f3* lens) {
-    const uint32_t st = pb.state[p];
-    if (!(st & ST_ALIVE)) return;
+// The stage for ONE hit: p = the slot that holds the hit record, its ray, the instance word and the result rows; smp = the camera sample's slot (film position, sampler
+// index: the same slot for the path integrator, slot / H for directlighting's node slots); tix = index of the ray's time (moving instances); with_diff: the ray is the camera
+// ray itself (bounce rays and rays re-spawned behind a null material carry no differentials)
+RDEV void texture_slot(const SceneDev& sc, const TexTables& tt, const RenderDev& rd, const PathBuf& pb, uint32_t p, uint32_t smp, uint32_t tix, bool with_diff, const f3* lens) {
     const float4 hc = pb.hit_cont[p];
     const uint32_t prim = __float_as_uint(hc.x);
-    const uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
-    if (prim == RSPT_MISS || bounces >= rd.max_depth) return;
     const TriRec tri = load_tri(sc, prim);
     if (tri.material == 0xffffffffu) return;
     const uint32_t mf = tt.mat_flags[tri.material];
@@ -886,7 +885,7 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
     if (pb.hit_inst) {
         const uint32_t hi = pb.hit_inst[p];
         if (hi && sc.inst[hi - 1u].anim != RSPT_MISS) {   // a moving instance: its Transform at the path's time (inst_at)
-            const InstDev at = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[p] : 0.0f);
+            const InstDev at = inst_at(sc, hi - 1u, sc.ray_time ? sc.ray_time[tix] : 0.0f);
             if (!at.identity) {
                 if (!sc.inst_fixed) return;
                 inst_texhit(at, &h);
@@ -900,14 +899,14 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
     s.p = h.p; s.uv = h.uv;
     s.dudx = s.dvdx = s.dudy = s.dvdy = 0.0f;
     s.dpdx = s.dpdy = f3{0.0f, 0.0f, 0.0f};
-    if (bounces == 0 && !(st & ST_NO_DIFF)) {  // the camera ray itself (a null-material pass-through re-spawns without differentials)
+    if (with_diff) {
         const float4* rp = reinterpret_cast<const float4*>(pb.ray_cont + p);
         const float4 r0 = rp[0], r1 = rp[1];
-        const float2 pf = pb.p_film[p];
+        const float2 pf = pb.p_film[smp];
         f3 p_lens{0.0f, 0.0f, 0.0f};
         if (lens) p_lens = *lens;   // a pixel sampler's lens / time sample (tile_serial.h): not a function of (index, dimension)
         else {
-            const uint64_t index = pb.sobol_index[p];
+            const uint64_t index = pb.sobol_index[smp];
             const bool hal = rd.sampler_kind == RSPT_SAMPLER_HALTON;
             if (rd.lens_radius > 0.0f) { p_lens.x = hal ? halton_dim(rd, index, 3) : sobol_dim(rd, index, 3); p_lens.y = hal ? halton_dim(rd, index, 4) : sobol_dim(rd, index, 4); }
             if (rd.cam_anim) p_lens.z = hal ? halton_dim(rd, index, 2) : sobol_dim(rd, index, 2);
@@ -917,6 +916,14 @@ RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev
         compute_differentials(h, rx_o, rx_d, ry_o, ry_d, &s);
     }
     texture_hit(sc, tt, h, s, tri.material, pb.tex + p, pb.tex_stride);
+}
+RDEVN void texture_path(const SceneDev& sc, const TexTables& tt, const RenderDev& rd, const PathBuf& pb, uint32_t p, const f3* lens) {
+    const uint32_t st = pb.state[p];
+    if (!(st & ST_ALIVE)) return;
+    const uint32_t prim = __float_as_uint(pb.hit_cont[p].x);
+    const uint32_t bounces = (st >> ST_BOUNCE_SHIFT) & 0xffu;
+    if (prim == RSPT_MISS || bounces >= rd.max_depth) return;
+    texture_slot(sc, tt, rd, pb, p, p, p, bounces == 0 && !(st & ST_NO_DIFF) /* the camera ray itself (a null-material pass-through re-spawns without differentials) */, lens);
 }
 
 // ---- K7b: bin the active queue by what the shade stage will do with each path -------------------------------------------

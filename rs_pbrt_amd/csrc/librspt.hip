@@ -1037,9 +1037,19 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     // directlighting under Sobol' / Halton: the wavefront form (direct.h) unless the render needs what only the per-lane form has
     // (lane_serial.h): textured materials, more than 8 recursion levels; RSPT_DL_FORM=lane forces it (A/B, tests)
     const char* dl_form_env = getenv("RSPT_DL_FORM");
-    bool dl_lane = direct && !pixel_sampler && (s->has_textures || d->max_depth > 8 || (dl_form_env && !strcmp(dl_form_env, "lane")));
     // levels of the specular tree that can hold nodes (direct.h DlBuf::levels): a scene without specular lobes has the root only
     const bool dl_specular = s->has_dynamic || (s->shade_features & (RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_R) | RSPT_SF_LOBE(RSPT_BXDF_SPECULAR_T) | RSPT_SF_LOBE(RSPT_BXDF_FRESNEL_SPEC))) != 0;
+    // round 6: textured materials WITHOUT specular lobes stay in the wavefront form (every node is a camera hit: k_dl_texture); with specular lobes the children's rays carry
+    // reflected / refracted differentials, which only the per-lane form tracks.  RSPT_DL_TEX_WAVEFRONT=0: textures always per lane, as before.  (The estimate kernel of the
+    // one-round form is the one that reads the texture results: RSPT_DL_ROUNDS=1 or more than 2^16 estimates per node also send a textured scene to the per-lane form.)
+    bool dl_rounds_one = env_size("RSPT_DL_ROUNDS", 0) == 0;
+    if (dl_rounds_one && d->direct_strategy == RSPT_DIRECT_SAMPLE_ALL && s->dev.n_lights) {
+        uint64_t r = 0;
+        for (uint32_t j = 0; j < s->dev.n_lights; j++) r += d->n_light_samples ? (uint64_t)std::max<int32_t>(d->n_light_samples[j], 0) : 1u;
+        if (r > (1u << 16)) dl_rounds_one = false;
+    }
+    const bool dl_tex_wave = s->has_textures && !dl_specular && dl_rounds_one && env_size("RSPT_DL_TEX_WAVEFRONT", 1) != 0;
+    bool dl_lane = direct && !pixel_sampler && ((s->has_textures && !dl_tex_wave) || d->max_depth > 8 || (dl_form_env && !strcmp(dl_form_env, "lane")));
     const uint32_t dl_levels = (dl_specular || env_size("RSPT_DL_FULL_TREE", 0) != 0) ? (uint32_t)d->max_depth : std::min<uint32_t>((uint32_t)d->max_depth, 1u);
     const uint32_t dl_H = (direct && !pixel_sampler && !dl_lane) ? (1u << dl_levels) : 1u;   // node slots per camera sample (direct.h; in the per-lane forms a lane walks the tree itself)
     // all light estimates of a node in one round (direct.h k_dl_nee_all): R = sum_j n_j virtual slots per node slot in the ray / result arrays; RSPT_DL_ROUNDS=1 = one
@@ -1089,7 +1099,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
     const uint32_t dl_tex_rows = RSPT_TEX_ROWS + (s->has_dynamic ? RSPT_DYN_ROWS : 0);
     const size_t dl_lanes = pixel_sampler ? blocks.size() : pix_per_batch * ns;
     if (direct) {
-        if (s->has_textures) {
+        if (s->has_textures && (dl_lane || pixel_sampler)) {   // (the wavefront form over textures keeps its results in g.pb.tex; it cannot fall back to the per-lane form: that needs a specular lobe)
             if ((rc = dev_alloc(&dl_tex, (size_t)d->max_depth * dl_tex_rows * std::max<size_t>(dl_lanes, 1)))) return rc;
             dl_guard.p.push_back(dl_tex);
             if (s->has_dynamic) {
@@ -1306,6 +1316,7 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
         // virtual slots of the estimates (direct.h DlBuf::vs / vr): planes of n_slots, unless a moving instance needs slot -> camera sample by one division (RSPT_DL_PLANES=0: A/B)
         const bool dl_planes = !s->has_animated && env_size("RSPT_DL_PLANES", 1) != 0;
         dl.vs = dl_planes ? 1u : dl_R; dl.vr = dl_planes ? (uint32_t)n_slots : 1u;
+        if (s->has_textures) HIP_TRY(hipMemsetAsync(g.pb.state, 0, n_slots * sizeof(uint32_t), g.stream));   // (ST_NO_DIFF marks of k_dl_hit, read by k_dl_texture)
         HIP_TRY(hipMemsetAsync(dl.le_kind, 0, n_slots * sizeof(float4), g.stream));
         HIP_TRY(hipMemsetAsync(dl.l_all, 0, n_slots * sizeof(float4), g.stream));
         HIP_TRY(hipMemsetAsync(dl.ld_acc, 0, n_slots * sizeof(float4), g.stream));
@@ -1343,6 +1354,9 @@ int render_impl(rspt_scene_s* s, const rspt_render_desc* d, float* film_host, vo
             }
         }
         hipLaunchKernelGGL(k_dl_assign, dim3((bt.n + 255) / 256), dim3(256), 0, g.stream, bt, dl, nl, n_arrays, all ? 1u : 0u, md, dim_limit);
+        if (s->has_textures)   // (dl_tex_wave: one level, the roots) the texture stage in front of the estimates
+            for (uint32_t l = 0; l < dl_levels; l++)
+                hipLaunchKernelGGL(k_dl_texture, dim3(dgrid), dim3(256), 0, g.stream, s->dev, s->tex, rd, g.pb, dl, level_q(l), &g.cnt[l].closest);
         if (nl && dl_one_round) {   // every estimate of a level's nodes in one round: 4 launches per level (direct.h k_dl_nee_all)
             QueueCounts* rc_ = &g.cnt[md + 3];
             for (uint32_t l = 0; l < dl_levels; l++) {

@@ -124,9 +124,16 @@ RDEVN bool box_hit6_m(float lx, float ly, float lz, float hx, float hy, float hz
 // workgroups per CU with 56 records each (30 KB); ONE 1024-thread workgroup per CU has room for 512 (96 KB of stack columns + 56 KB of records = the CU's
 // 160 KB, declared as dynamic LDS): a ninth of the record fetches of an incoherent ray come from the first 56 records, about a quarter from the first 512 —
 // fetches that leave the L1 request path the kernel is bound by.
+#ifdef RSPT_W4_WAVES   // A/B (tools/ab_build.sh AB_DEFS=-DRSPT_W4_WAVES=n): every instantiation built for n waves per SIMD (what does not fit the budget is spilled)
+#define RSPT_W4_ATTR __attribute__((amdgpu_waves_per_eu(RSPT_W4_WAVES, RSPT_W4_WAVES)))
+#else
+// the closest-hit kernel over moving instances is built for FOUR waves per SIMD: 147 -> 128 VGPRs + 64 B of scratch around the entry phase; all-moving C5 stand-in 183.2 -> 199.4
+// Msamples/s (two alternating rounds, profiles/r06_c5_anim_waves_ab.txt).  (1, 8) is the backend's own default: every other instantiation keeps the budget it was measured with.
+#define RSPT_W4_ATTR __attribute__((amdgpu_waves_per_eu((ANIM && !ANY) ? 4 : 1, (ANIM && !ANY) ? 4 : 8)))
+#endif
 template <bool ANY, int OUT_MODE, bool INST, int ALPHA /* 0: no masks, 1: alpha_pass (any texture graph, a call), 2: alpha_simple (in line) */, bool ANIM = false,
           int BLOCK = RSPT_PW_BLOCK, int TOPCAP = RSPT_W4_TOP>
-__global__ __launch_bounds__(BLOCK) void k_trace_w4(SceneDev sc, TexTables tt, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
+__global__ __launch_bounds__(BLOCK) RSPT_W4_ATTR void k_trace_w4(SceneDev sc, TexTables tt, const Wide4Node* __restrict__ recs, const uint2* __restrict__ big_leaves, uint32_t root_ref,
                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm, uint32_t* cursor,
                                                            const rspt_ray* __restrict__ rays_a, const rspt_ray* __restrict__ rays_b,
                                                            float4* __restrict__ out_a, float4* __restrict__ out_b, uint32_t* __restrict__ out_occ,
