@@ -1,0 +1,621 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — second batch of hot-path functions pinned by the reference's OWN TEXT (round 6, third session): the geometry of a traversal step, the sampling
+helpers, the Trowbridge-Reitz terms and the PCG32 generator.  Same route as oracle/make_leaf_fixtures.py (whose prelude, rules and functions this script builds on):
+the Rust text is read from /root/reference where it lies, its SYNTAX is rewritten by the committed rules below, the result is compiled as C++ into
+oracle/_ref/libgeomref.so (git-ignored), and tests/golden/geom_functions.npz holds seeded inputs with that code's outputs.  No function body is edited by hand.
+
+Pinned here (file:line of the compiled text is printed by the script and asserted by the test):
+    gamma, next_float_up, next_float_down                         core/pbrt.rs
+    Vector3f::abs, vec3_max_componentf, vec3_max_dimensionf, vec3_permutef, pnt3_permutef, vec3_dot_vec3f, vec3_abs_dot_vec3f, vec3_dot_nrmf, nrm_dot_vec3f,
+    nrm_absf, vec3_cross_vec3, vec3_coordinate_system, pnt3_offset_ray_origin, Point3f -/+ Vector3f, Point3f - Point3f, Vector3f + Vector3f, Vector3f * Float
+                                                                  core/geometry.rs
+    Bounds3f::intersect_p (the traversal's box test)              core/geometry.rs:2211-2269
+    Triangle::intersect / Triangle::intersect_p, the watertight test: from the `fn` line to the `t <= delta_t` rejection (the text in front of "compute triangle
+        partial derivatives" / the alpha-mask block; what follows builds the SurfaceInteraction and is checked through the renders)   shapes/triangle.rs:134-273, 450-591
+    power_heuristic, cosine_sample_hemisphere, uniform_sample_hemisphere                                          core/sampling.rs
+    abs_cos_theta, tan_theta, tan_2_theta, cos_2_phi, sin_2_phi, reflect, refract                                 core/reflection.rs
+    TrowbridgeReitzDistribution::roughness_to_alpha, d, lambda, g1, g, pdf                                        core/microfacet.rs
+    phase_hg                                                      core/medium.rs
+    RGBSpectrum::y                                                core/spectrum.rs
+    Rng::set_sequence, uniform_uint32, uniform_uint32_bounded, uniform_float                                     core/rng.rs
+Hand-written here: the CARRIERS (structs with Rust's field names, index / negation / conversion selectors that move values and never compute), the named constants,
+the C wrappers that marshal arrays — and for the two triangle tests the signature and the three lines that hand t, b0, b1, b2 back (the text is cut before it fills
+the SurfaceInteraction).  usage: python oracle/make_geom_fixtures.py [--build-only | --check]
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import make_leaf_fixtures as base  # noqa: E402
+
+REF = "/root/reference/src/"
+OUT_DIR = base.OUT_DIR
+FIXTURE = os.path.join(ROOT, "tests", "golden", "geom_functions.npz")
+
+# ---- carriers added to the base prelude (no arithmetic: selectors, bit casts, constants) ----
+FLOAT_EXTRA = """    explicit operator double() const { return (double)v; }      // `x as f64`
+    Float ln() const { return Float(logf(v)); }                  // f32::ln is the platform libm's logf
+"""
+VEC3_EXTRA = """    Vector3f abs() const;            // body: the reference's text (geometry.rs:397-403)
+    Float& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }                 // impl Index<XYZEnum> (geometry.rs:574-583): a selector
+    const Float& operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+"""
+PRELUDE2 = r"""
+#include <cstring>
+static const Float MACHINE_EPSILON(5.9604644775390625e-8f);                     // core/pbrt.rs:16: f32::EPSILON * 0.5 = 2^-24
+static const Float PI(3.14159265358979323846f), INV_PI(0.31830988618379067154f), INV_4_PI(0.07957747154594766788f);   // core/pbrt.rs:17-20
+static inline uint32_t float_to_bits(Float f) { uint32_t u; std::memcpy(&u, &f.v, 4); return u; }   // pbrt.rs:30-57: transmute_copy
+static inline Float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return Float(f); }
+struct Normal3f { Float x, y, z; };
+struct Point3f {
+    Float x, y, z;
+    Float& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }                 // impl Index / IndexMut<XYZEnum> (geometry.rs:1417-1440)
+    const Float& operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+static inline Vector3f operator-(const Vector3f& a) { return Vector3f{Float(-a.x.v), Float(-a.y.v), Float(-a.z.v)}; }   // impl Neg (a sign flip)
+static inline Vector3f Vector3f_from(const Normal3f& n) { return Vector3f{n.x, n.y, n.z}; }                                // impl From<Normal3f> (geometry.rs:616-624)
+struct Cell { Float v; Float get() const { return v; } };                           // Cell<Float>
+struct Ray { Point3f o; Vector3f d; Cell t_max; };
+enum class MinMaxEnum { Min, Max };
+struct Bounds3f {
+    Point3f p_min, p_max;
+    const Point3f& operator[](MinMaxEnum i) const { return i == MinMaxEnum::Min ? p_min : p_max; }   // impl Index<MinMaxEnum> (geometry.rs:2271-2279)
+    bool intersect_p(const Ray& ray, const Vector3f& inv_dir, const uint8_t* dir_is_neg) const;
+};
+struct TriangleMesh { const uint32_t* vertex_indices; const Point3f* p; };
+struct Triangle {
+    uint32_t id; TriangleMesh mesh;
+    bool intersect(const Ray& ray, Float* t_out, Float* b_out) const;
+    bool intersect_p(const Ray& ray, Float* t_out, Float* b_out) const;
+};
+struct TrowbridgeReitzDistribution {
+    Float alpha_x, alpha_y; bool sample_visible_area;
+    bool get_sample_visible_area() const { return sample_visible_area; }
+    static Float roughness_to_alpha(Float roughness);
+    Float d(const Vector3f& wh) const; Float lambda(const Vector3f& w) const; Float g1(const Vector3f& w) const;
+    Float g(const Vector3f& wo, const Vector3f& wi) const; Float pdf(const Vector3f& wo, const Vector3f& wh) const;
+};
+struct RGBSpectrum { Float c[3]; Float y() const; };
+static const uint64_t PCG32_DEFAULT_STATE = 0x853c49e6748fea9bull, PCG32_DEFAULT_STREAM = 0xda3e39cb94b95bdbull, PCG32_MULT = 0x5851f42d4c957f2dull;   // rng.rs:8-10
+struct Rng {
+    uint64_t state = PCG32_DEFAULT_STATE, inc = PCG32_DEFAULT_STREAM;
+    void set_sequence(uint64_t initseq); uint32_t uniform_uint32(); uint32_t uniform_uint32_bounded(uint32_t b); Float uniform_float();
+};
+// forward declarations (Rust resolves names in any order)
+Float gamma(int32_t n); Float next_float_up(Float v); Float next_float_down(Float v);
+Float vec3_max_componentf(const Vector3f& v); size_t vec3_max_dimensionf(const Vector3f& v);
+Vector3f vec3_permutef(const Vector3f& v, size_t x, size_t y, size_t z); Point3f pnt3_permutef(const Point3f& v, size_t x, size_t y, size_t z);
+Float vec3_dot_vec3f(const Vector3f& v1, const Vector3f& v2); Float vec3_abs_dot_vec3f(const Vector3f& v1, const Vector3f& v2);
+Float vec3_dot_nrmf(const Vector3f& v1, const Normal3f& n2); Float nrm_dot_vec3f(const Normal3f& n1, const Vector3f& v2); Normal3f nrm_absf(const Normal3f& n);
+Vector3f vec3_cross_vec3(const Vector3f& v1, const Vector3f& v2);
+Float abs_cos_theta(const Vector3f& w); Float tan_theta(const Vector3f& w); Float tan_2_theta(const Vector3f& w); Float cos_2_phi(const Vector3f& w); Float sin_2_phi(const Vector3f& w);
+Point3f operator-(const Point3f& a, const Vector3f& b); Point3f operator+(const Point3f& a, const Vector3f& b); Vector3f operator-(const Point3f& a, const Point3f& b);
+Vector3f operator+(const Vector3f& a, const Vector3f& b); Vector3f operator*(const Vector3f& a, Float b);
+"""
+
+TYPES = dict(base.TYPES)
+TYPES.update({"f32": "Float", "f64": "double", "u8": "uint8_t", "Point3f": "Point3f", "Normal3f": "Normal3f", "&Point3f": "const Point3f&", "&Normal3f": "const Normal3f&",
+              "&Ray": "const Ray&", "&mut Vector3f": "Vector3f*", "&[u8; 3]": "const uint8_t*", "RGBSpectrum": "RGBSpectrum"})
+
+# (file, search-from regex or None, first-line regex, name, class or None, cut-before regex or None, explicit signature or None, appended epilogue or None, extra rule set)
+TRI_SIG = "bool Triangle::%s(const Ray& ray, Float* t_out, Float* b_out) const {\n"
+TRI_END = "    *t_out = t; b_out[0] = b0; b_out[1] = b1; b_out[2] = b2;   // (hand-written: the values the cut text has computed, handed back)\n    return true;\n}\n"
+SOURCES = [
+    ("core/pbrt.rs", None, r"^pub fn gamma\(", "gamma", None, None, None, None, ()),
+    ("core/pbrt.rs", None, r"^pub fn next_float_up\(", "next_float_up", None, None, None, None, ()),
+    ("core/pbrt.rs", None, r"^pub fn next_float_down\(", "next_float_down", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^    pub fn abs\(&self\) -> Vector3f \{", "abs", "Vector3f", None, None, None, ()),
+    ("core/geometry.rs", None, r"^impl_op_ex!\(\+\|a: &Vector3f, b: &Vector3f\| -> Vector3f \{", "operator+", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^impl_op_ex!\(\+\|a: &Point3f, b: &Vector3f\| -> Point3f \{", "operator+", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^impl_op_ex!\(-\|a: &Point3f, b: &Point3f\| -> Vector3f \{", "operator-", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^impl_op_ex!\(-\|a: &Point3f, b: &Vector3f\| -> Point3f \{", "operator-", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^impl_op_ex!\(\*\|a: &Vector3f, b: Float\| -> Vector3f \{", "operator*", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_dot_vec3f\(", "vec3_dot_vec3f", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_dot_nrmf\(", "vec3_dot_nrmf", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_abs_dot_vec3f\(", "vec3_abs_dot_vec3f", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_cross_vec3\(", "vec3_cross_vec3", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_max_componentf\(", "vec3_max_componentf", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_max_dimensionf\(", "vec3_max_dimensionf", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_permutef\(", "vec3_permutef", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn vec3_coordinate_system\(", "vec3_coordinate_system", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn pnt3_permutef\(", "pnt3_permutef", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn nrm_dot_vec3f\(", "nrm_dot_vec3f", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn nrm_absf\(", "nrm_absf", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^pub fn pnt3_offset_ray_origin\(", "pnt3_offset_ray_origin", None, None, None, None, ()),
+    ("core/geometry.rs", None, r"^    pub fn intersect_p\(&self, ray: &Ray, inv_dir: &Vector3f, dir_is_neg: &\[u8; 3\]\) -> bool \{", "intersect_p", "Bounds3f", None, None, None, ()),
+    ("shapes/triangle.rs", None, r"^    pub fn intersect\(&self, ray: &Ray, t_hit: &mut Float, isect: &mut SurfaceInteraction\) -> bool \{", "intersect", "Triangle",
+     r"^\s*// compute triangle partial derivatives", TRI_SIG % "intersect", TRI_END, ()),
+    ("shapes/triangle.rs", None, r"^    pub fn intersect_p\(&self, ray: &Ray\) -> bool \{", "intersect_p", "Triangle",
+     r"^\s*// TODO: if \(testAlphaTexture", TRI_SIG % "intersect_p", TRI_END, ()),
+    ("core/sampling.rs", None, r"^pub fn power_heuristic\(", "power_heuristic", None, None, None, None, ()),
+    ("core/sampling.rs", None, r"^pub fn cosine_sample_hemisphere\(", "cosine_sample_hemisphere", None, None, None, None, ()),
+    ("core/sampling.rs", None, r"^pub fn uniform_sample_hemisphere\(", "uniform_sample_hemisphere", None, None, None, None, ()),
+    ("core/reflection.rs", None, r"^pub fn abs_cos_theta\(", "abs_cos_theta", None, None, None, None, ()),
+    ("core/reflection.rs", None, r"^pub fn tan_theta\(", "tan_theta", None, None, None, None, ()),
+    ("core/reflection.rs", None, r"^pub fn tan_2_theta\(", "tan_2_theta", None, None, None, None, ()),
+    ("core/reflection.rs", None, r"^pub fn cos_2_phi\(", "cos_2_phi", None, None, None, None, ()),
+    ("core/reflection.rs", None, r"^pub fn sin_2_phi\(", "sin_2_phi", None, None, None, None, ()),
+    ("core/reflection.rs", None, r"^pub fn reflect\(", "reflect", None, None, None, None, ()),
+    ("core/reflection.rs", None, r"^pub fn refract\(", "refract", None, None, None, None, ()),
+    ("core/microfacet.rs", r"^impl TrowbridgeReitzDistribution \{", r"^    pub fn roughness_to_alpha\(", "roughness_to_alpha", "TrowbridgeReitzDistribution", None, None, None, ()),
+    ("core/microfacet.rs", r"^impl TrowbridgeReitzDistribution \{", r"^    pub fn d\(&self", "d", "TrowbridgeReitzDistribution", None, None, None, ()),
+    ("core/microfacet.rs", r"^impl TrowbridgeReitzDistribution \{", r"^    pub fn lambda\(&self", "lambda", "TrowbridgeReitzDistribution", None, None, None, ()),
+    ("core/microfacet.rs", r"^impl TrowbridgeReitzDistribution \{", r"^    pub fn g1\(&self", "g1", "TrowbridgeReitzDistribution", None, None, None, ()),
+    ("core/microfacet.rs", r"^impl TrowbridgeReitzDistribution \{", r"^    pub fn g\(&self", "g", "TrowbridgeReitzDistribution", None, None, None, ()),
+    ("core/microfacet.rs", r"^impl TrowbridgeReitzDistribution \{", r"^    pub fn pdf\(&self", "pdf", "TrowbridgeReitzDistribution", None, None, None, ()),
+    ("core/medium.rs", None, r"^pub fn phase_hg\(", "phase_hg", None, None, None, None, ()),
+    ("core/spectrum.rs", r"^impl RGBSpectrum \{", r"^    pub fn y\(&self\) -> Float \{", "y", "RGBSpectrum", None, None, None, ()),
+    ("core/rng.rs", None, r"^    pub fn set_sequence\(&mut self", "set_sequence", "Rng", None, None, None, ("rng",)),
+    ("core/rng.rs", None, r"^    pub fn uniform_uint32\(&mut self\)", "uniform_uint32", "Rng", None, None, None, ("rng",)),
+    ("core/rng.rs", None, r"^    pub fn uniform_uint32_bounded\(&mut self", "uniform_uint32_bounded", "Rng", None, None, None, ("rng",)),
+    ("core/rng.rs", None, r"^    pub fn uniform_float\(&mut self\)", "uniform_float", "Rng", None, None, None, ("rng",)),
+]
+FN_NAMES = [s[3] for s in SOURCES] + base.FN_NAMES
+
+
+def extract(fname, after_re, first_re, cut_re):
+    """the text from the `fn` line to its closing brace (or, with cut_re, to the line in front of the first line matching it)"""
+    lines = open(REF + fname).read().split("\n")
+    k0 = 0 if after_re is None else next(k for k, l in enumerate(lines) if re.match(after_re, l))
+    i = next(k for k in range(k0, len(lines)) if re.match(first_re, lines[k]))
+    indent = len(lines[i]) - len(lines[i].lstrip())
+    j = next(k for k in range(i + 1, len(lines)) if lines[k].rstrip() in (" " * indent + "}", " " * indent + "});"))
+    if cut_re is not None:
+        j = next(k for k in range(i + 1, j) if re.match(cut_re, lines[k])) - 1
+    return "\n".join(l[indent:] for l in lines[i:j + 1]), i + 1, j + 1
+
+
+def matching(s, i, open_ch="(", close_ch=")"):
+    """index of the bracket that closes the one at s[i]"""
+    depth = 0
+    for k in range(i, len(s)):
+        if s[k] == open_ch:
+            depth += 1
+        elif s[k] == close_ch:
+            depth -= 1
+            if depth == 0:
+                return k
+    raise ValueError("unbalanced")
+
+
+def cast_after_parens(body, rust_ty, fmt):
+    """G1: `( EXPR ) as T` (the cast applies to the whole parenthesis) -> fmt % EXPR, innermost first"""
+    pat = ") as " + rust_ty
+    while True:
+        k = body.find(pat)
+        if k < 0:
+            return body
+        depth, i = 0, k
+        while True:
+            if body[i] == ")":
+                depth += 1
+            elif body[i] == "(":
+                depth -= 1
+                if depth == 0:
+                    break
+            i -= 1
+        body = body[:i] + fmt % body[i + 1:k] + body[k + len(pat):]
+
+
+RULES_PRE = [
+    # G0  rustfmt's line breaks:  `let x: T =\n    E;` and `if C\n    || D\n{`  ->  one logical line each
+    (r"(let (?:mut )?\w+(?:: \w+)?) =\n\s*", r"\1 = ", 0),
+    (r"^(\s*)if ([^{};]*?)\n\s*\{$", lambda m: "%sif (%s) {" % (m.group(1), re.sub(r"\s*\n\s*", " ", m.group(2))), re.M),
+    # G0b a float literal with an exponent under a cast:  `1e-3 as Float` -> Float(1e-3)  (an f64 literal converted, as in Rust)
+    (r"\b(\d+e-?\d+) as Float\b", r"Float(\1)", 0),
+    # G2  what is decided at compile time in the reference: Float IS f32
+    (r"mem::size_of::<Float>\(\) == mem::size_of::<f32>\(\)", "true", 0),
+    (r"^\s*// TODO.*$", "", re.M),
+    (r";\s*//.*$", ";", re.M),                                  # a comment behind a statement
+    (r'hexf32!\("([^"]+)"\) as Float', r"Float(\1f)", 0),       # (the base's R3, needed in front of G1)
+    # G3  suffixed literals
+    (r"\b(\d+)_i32\b", r"\1", 0), (r"\b(\d+)_u64\b", r"\1ull", 0), (r"\b(\d+)_u32\b", r"\1u", 0),
+    # G4  casts of a place expression:  `p.x as f64` -> (double)(p.x);  `idx[0] as usize` -> (size_t)idx[0];  `x as u32` -> (uint32_t)x;  `nf as Float` is the base's R3
+    (r"\b([\w.]+) as f64\b", r"(double)(\1)", 0),
+    (r"\b(\w+\[\d\]) as usize\b", r"(size_t)\1", 0),
+    (r"\b(\w+) as u32\b", r"(uint32_t)\1", 0),
+    (r"(this->\w+\(\)) as Float", r"Float(\1)", 0),
+    # G5  slices and borrows of elements:  `&A[i..(i + 3)]` -> &A[i];  `let p: &T = &E;` -> const T* p = &E;   `&*v` (re-borrow) -> *v
+    (r"&([\w.>\-]+)\[(\w+)\.\.\([^)]*\)\]", r"&\1[\2]", 0),
+    (r"let (\w+): &(\w+) = &", r"const \2* \1 = &", 0),
+    (r"&\*(\w+)", r"*\1", 0),
+    # G6  fixed arrays:  `let v: [T; 3] = [a, b, c];` -> T v[3] = {a, b, c};
+    (r"let (\w+): \[(\w+); (\d)\] = \[(.*?)\];", lambda m: "%s %s[%s] = {%s};" % (TYPES[m.group(2)], m.group(1), m.group(3), m.group(4)), 0),
+    # G7  two-armed match on 0:  `let n: T = match E {\n 0 => A,\n _ => B,\n };` -> T n = (E == 0) ? A : B;
+    (r"let (\w+): (\w+) = match (.*?) \{\s*0 => (.*?),\s*_ => (.*?),\s*\};", r"\2 \1 = (\3 == 0) ? \4 : \5;", re.S),
+    # G8  index selectors:  `u[XYEnum::X]` -> u.x;  `for i in XYZEnum::iter() {` -> the three indices;  `self[E]` -> (*this)[E]
+    (r"\[XYEnum::X\]", ".x", 0), (r"\[XYEnum::Y\]", ".y", 0),
+    (r"for (\w+) in XYZEnum::iter\(\) \{", r"for (int \1 = 0; \1 < 3; \1++) {", 0),
+    (r"\bself\[", "(*this)[", 0),
+    # G9  struct literals of the point / normal carriers (the base's R6 knows Vector3f), and the field-init shorthand `z,` / `z }`
+    (r"\b(Vector3f|Point3f|Normal3f) \{\s*x: ([^{}]*?),\s*y: ([^{}]*?),\s*z,?\s*\}", r"\1{\2, \3, z}", re.S),
+    (r"\b(Point3f|Normal3f) \{\s*x: ([^{}]*?),\s*y: ([^{}]*?),\s*z: ([^{}]*?),?\s*\}", r"\1{\2, \3, \4}", re.S),
+    (r"Vector3f::from\(\*?(\w+)\)", r"Vector3f_from(\1)", 0),
+    # G10 one-line conditional value:  `let x = if C { A } else { B };` -> auto x = (C) ? (A) : (B);
+    (r"let (\w+) = if ([^{}]*?) \{ ([^{};]*?) \} else \{ ([^{};]*?) \};", r"auto \1 = (\2) ? Float(\3) : Float(\4);", 0),
+    (r"\bloop \{", "for (;;) {", 0),
+    (r"\bmut self\b", "self", 0),
+]
+RULES_RNG = [
+    # G11 wrapping integer arithmetic (rng.rs):  `let (x, _overflow) = A.overflowing_OP(B);`  — C++ unsigned arithmetic wraps; Rust's overflowing shifts mask the count
+    (r"let \((\w+), _overflow\) = ([\w.>\-]+)\.overflowing_mul\((.*?)\);", r"auto \1 = (\2) * (\3);", 0),
+    (r"let \((\w+), _overflow\) = ([\w.>\-]+)\.overflowing_add\((.*?)\);", r"auto \1 = (\2) + (\3);", 0),
+    (r"let \((\w+), _overflow\) = ([\w.>\-]+)\.overflowing_shl\((.*?)\);", r"auto \1 = (\2) << ((\3) & (sizeof(\2) * 8 - 1));", 0),
+    (r"let \((\w+), _overflow\) = ([\w.>\-]+)\.overflowing_shr\((.*?)\);", r"auto \1 = (\2) >> ((\3) & (sizeof(\2) * 8 - 1));", 0),
+    # G12 `!x` on an integer is the bitwise complement
+    (r"= !(\w+);", r"= ~\1;", 0), (r"\(!(\w+) \+", r"(~\1 +", 0),
+]
+
+
+def signature(text, name, cls):
+    m = re.match(r"(?:pub )?fn (\w+)\((.*?)\)(?: -> ([\w:]+))?\s*\{\n", text, re.S)
+    args, ret = m.group(2), m.group(3)
+    out, params, const, refs = [], [], "", []
+    is_static = True
+    for a in [x.strip() for x in args.replace("\n", " ").split(",") if x.strip()]:
+        if a in ("&self", "&mut self"):
+            const = " const" if a == "&self" else ""
+            is_static = False
+            continue
+        n, t = [x.strip() for x in a.split(":", 1)]
+        out.append("%s %s" % (TYPES.get(t, "void*"), n))      # (a type this batch has no carrier for only occurs in signatures that are overridden below)
+        params.append(n)
+        if t.startswith("&") and not t.startswith("&mut"):
+            refs.append(n)
+    body = text[m.end():]
+    for n in refs:                                              # G14: a shared borrow is a C++ reference: `*n` (no blank after the star) reads through it
+        body = re.sub(r"(?<![\w)\]])\*%s\b" % n, n, body)
+    if cls:
+        body = body.replace("*self", "(*this)").replace("self.", "this->")
+    return "%s %s%s(%s)%s {\n" % (TYPES[ret] if ret else "void", (cls + "::") if cls else "", name, ", ".join(out), const), body, params
+
+
+def tail_value(body):
+    """G13: a block's value is its last expression.  Applied to the function body and, recursively, to the blocks of a trailing if / else chain: the last expression
+    statement (no `;`) becomes `return (..);`."""
+    b = body.rstrip()
+    assert b.endswith("}"), b[-80:]
+    inner = b[:-1].rstrip()
+    if inner.endswith(";"):
+        return b + "\n"
+    is_chain = False
+    if inner.endswith("}") and re.search(r"for \(;;\) \{(?:[^{}]|\{[^{}]*\})*\}$", inner):
+        return b + "\n"            # an endless loop that returns from inside
+    if inner.endswith("}"):
+        i = len(inner) - 1
+        depth = 0
+        while True:
+            if inner[i] == "}":
+                depth += 1
+            elif inner[i] == "{":
+                depth -= 1
+                if depth == 0:
+                    break
+            i -= 1
+        head = inner[:i].rstrip()
+        is_chain = head.endswith("else") or re.search(r"\bif \((?:[^{}])*\)$", head) is not None
+    if is_chain:
+        # a trailing `if (C) { .. } else if (D) { .. } else { .. }`: find the chain's blocks from the end
+        blocks, end = [], len(inner) - 1
+        while True:
+            depth, i = 0, end
+            while True:
+                if inner[i] == "}":
+                    depth += 1
+                elif inner[i] == "{":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                i -= 1
+            blocks.append((i, end))
+            head = inner[:i].rstrip()
+            if head.endswith("else"):
+                j = head.rindex("}")
+                end = j
+                continue
+            mm = re.search(r"(\} else )?if \((?:[^{}])*\)$", head)
+            assert mm, head[-120:]
+            if mm.group(1):
+                end = mm.start()
+                continue
+            break
+        out = inner
+        for (i, end) in blocks:      # blocks are listed from the last to the first: positions in front stay valid
+            blk = tail_value(out[i + 1:end] + "}")      # (re-uses the closing brace convention)
+            out = out[:i + 1] + blk.rstrip()[:-1] + out[end:]
+        return out + "\n}\n"
+    lines = inner.split("\n")
+    j = len(lines) - 1
+    while j > 0 and not (lines[j - 1].rstrip().endswith(";") or lines[j - 1].rstrip().endswith("{") or (lines[j - 1].rstrip().endswith("}") and not lines[j].lstrip().startswith("."))):
+        j -= 1
+    expr = "\n".join(lines[j:]).strip()
+    return "\n".join(lines[:j]) + "\n    return (" + expr + ");\n}\n"
+
+
+def convert_parts():
+    parts, where = base.convert_parts()
+    pre = parts[0]
+    anchor = "    Float sin() const { return Float(sinf(v)); }\n"
+    assert anchor in pre
+    pre = pre.replace(anchor, anchor + FLOAT_EXTRA)
+    anchor = "struct Vector3f {\n    Float x, y, z;\n"
+    assert anchor in pre
+    pre = pre.replace(anchor, anchor + VEC3_EXTRA)
+    # the base prelude ends with the Sobol' words; the carriers of this batch go between the base prelude and the base functions
+    parts = [pre, PRELUDE2] + parts[1:]
+    base.TYPES.update(TYPES)          # (the base's declaration rule R11 looks types up in its own table; the base functions are already converted)
+    TYPES["MinMaxEnum"] = base.TYPES["MinMaxEnum"] = "MinMaxEnum"
+    for fname, after_re, first_re, name, cls, cut_re, sig_override, epilogue, extra in SOURCES:
+        text, l0, l1 = extract(fname, after_re, first_re, cut_re)
+        if text.startswith("impl_op_ex!"):
+            mo = re.match(r"impl_op_ex!\((.)\|(.*?)\| -> (\w+) \{\n", text)
+            args = [x.strip().split(":") for x in mo.group(2).split(",")]
+            sig = "%s operator%s(%s) {\n" % (TYPES[mo.group(3)], mo.group(1), ", ".join("%s %s" % (TYPES[t.strip()], n.strip()) for n, t in args))
+            body = text[mo.end():].rstrip()[:-3] + "}\n"
+            params = [n.strip() for n, _ in args]
+        else:
+            sig, body, params = signature(text + ("\n}" if cut_re else ""), name, cls)
+            if cut_re:
+                body = body.rstrip()[:-1]      # the brace added for the signature parser
+        if sig_override:
+            sig = sig_override
+        for pat, rep, flags in RULES_PRE + (RULES_RNG if "rng" in extra else []):
+            body = re.sub(pat, rep, body, flags=flags)
+        body = cast_after_parens(body, "Float", "Float(%s)")
+        body = cast_after_parens(body, "usize", "(size_t)(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = re.sub(r"\blet (?:mut )?(\w+): (f64|f32|u32|u8|Point3f|Normal3f|MinMaxEnum) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+        body = base.shadowing(body, set(params) | set(FN_NAMES))
+        if epilogue:
+            body = body.rstrip() + "\n" + epilogue
+        elif not sig.startswith("void"):
+            body = tail_value(body)
+        parts.append("// %s%s:%d-%d\n%s%s" % (REF, fname, l0, l1, sig, body))
+        where.append("%s%s %s:%d-%d" % ((cls + "::") if cls else "", name, fname, l0, l1))
+    return parts, where
+
+
+WRAPPERS = r"""
+extern "C" {
+static inline Vector3f V(const float* p) { return Vector3f{p[0], p[1], p[2]}; }
+static inline void S3(float* o, const Vector3f& v) { o[0] = v.x.v; o[1] = v.y.v; o[2] = v.z.v; }
+void g_scalar(int fn, const float* a, const float* b, const float* c, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) switch (fn) {
+        case 0: out[i] = gamma((int32_t)a[i]).v; break;
+        case 1: out[i] = next_float_up(a[i]).v; break;
+        case 2: out[i] = next_float_down(a[i]).v; break;
+        case 3: out[i] = power_heuristic((uint8_t)a[i], b[i], (uint8_t)1, c[i]).v; break;
+        case 5: out[i] = TrowbridgeReitzDistribution::roughness_to_alpha(a[i]).v; break;
+        case 6: out[i] = phase_hg(a[i], b[i]).v; break;
+        case 7: { RGBSpectrum s; s.c[0] = a[i]; s.c[1] = b[i]; s.c[2] = c[i]; out[i] = s.y().v; break; }
+    }
+}
+void g_sample(int fn, const float* u, uint64_t n, float* out) {   // u: n x 2 -> out n x 3
+    for (uint64_t i = 0; i < n; i++) {
+        const Point2f p{u[2 * i], u[2 * i + 1]};
+        S3(out + 3 * i, fn == 0 ? cosine_sample_hemisphere(p) : uniform_sample_hemisphere(p));
+    }
+}
+void g_vec(int fn, const float* a, const float* b, uint64_t n, float* out) {   // a, b: n x 3
+    for (uint64_t i = 0; i < n; i++) {
+        const Vector3f x = V(a + 3 * i), y = V(b + 3 * i);
+        switch (fn) {
+            case 0: S3(out + 3 * i, vec3_cross_vec3(x, y)); break;
+            case 1: { Vector3f v2, v3; vec3_coordinate_system(x, &v2, &v3); S3(out + 6 * i, v2); S3(out + 6 * i + 3, v3); break; }
+            case 2: S3(out + 3 * i, reflect(x, y)); break;
+            case 3: { Vector3f wt{Float(0.0f), Float(0.0f), Float(0.0f)}; const bool ok = refract(x, Normal3f{y.x, y.y, y.z}, Float(b[3 * n + i]), &wt);
+                      S3(out + 4 * i, wt); out[4 * i + 3] = ok ? 1.0f : 0.0f; break; }
+            case 4: out[i] = vec3_abs_dot_vec3f(x, y).v; break;
+        }
+    }
+}
+void g_offset_ray_origin(const float* p, const float* e, const float* nn, const float* w, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const Point3f r = pnt3_offset_ray_origin(Point3f{p[3 * i], p[3 * i + 1], p[3 * i + 2]}, V(e + 3 * i), Normal3f{nn[3 * i], nn[3 * i + 1], nn[3 * i + 2]}, V(w + 3 * i));
+        out[3 * i] = r.x.v; out[3 * i + 1] = r.y.v; out[3 * i + 2] = r.z.v;
+    }
+}
+void g_box(const float* box, const float* o, const float* inv, const uint8_t* neg, const float* tmax, uint64_t n, float* out) {   // box: n x 6 (min, max)
+    for (uint64_t i = 0; i < n; i++) {
+        const Bounds3f b{Point3f{box[6 * i], box[6 * i + 1], box[6 * i + 2]}, Point3f{box[6 * i + 3], box[6 * i + 4], box[6 * i + 5]}};
+        Ray r; r.o = Point3f{o[3 * i], o[3 * i + 1], o[3 * i + 2]}; r.d = Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)}; r.t_max.v = tmax[i];
+        out[i] = b.intersect_p(r, V(inv + 3 * i), neg + 3 * i) ? 1.0f : 0.0f;
+    }
+}
+void g_triangle(int any, const float* tri, const float* o, const float* d, const float* tmax, uint64_t n, float* out) {   // tri: n x 9; out: n x 5 (hit, t, b0, b1, b2)
+    static const uint32_t idx[3] = {0, 1, 2};
+    for (uint64_t i = 0; i < n; i++) {
+        Point3f p[3];
+        for (int k = 0; k < 3; k++) p[k] = Point3f{tri[9 * i + 3 * k], tri[9 * i + 3 * k + 1], tri[9 * i + 3 * k + 2]};
+        Triangle t; t.id = 0; t.mesh.vertex_indices = idx; t.mesh.p = p;
+        Ray r; r.o = Point3f{o[3 * i], o[3 * i + 1], o[3 * i + 2]}; r.d = V(d + 3 * i); r.t_max.v = tmax[i];
+        Float th(0.0f), b[3] = {Float(0.0f), Float(0.0f), Float(0.0f)};
+        const bool hit = any ? t.intersect_p(r, &th, b) : t.intersect(r, &th, b);
+        out[5 * i] = hit ? 1.0f : 0.0f; out[5 * i + 1] = hit ? th.v : 0.0f;
+        for (int k = 0; k < 3; k++) out[5 * i + 2 + k] = hit ? b[k].v : 0.0f;
+    }
+}
+void g_microfacet(const float* wo, const float* wh, const float* ax, const float* ay, uint64_t n, float* out) {   // out: n x 5 (d(wh), lambda(wo), g1(wo), g(wo, wh), pdf(wo, wh))
+    for (uint64_t i = 0; i < n; i++) {
+        const TrowbridgeReitzDistribution t{Float(ax[i]), Float(ay[i]), true};
+        const Vector3f a = V(wo + 3 * i), h = V(wh + 3 * i);
+        out[5 * i] = t.d(h).v; out[5 * i + 1] = t.lambda(a).v; out[5 * i + 2] = t.g1(a).v; out[5 * i + 3] = t.g(a, h).v; out[5 * i + 4] = t.pdf(a, h).v;
+    }
+}
+void g_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {   // per sequence: 4 words, 2 floats, 2 bounded draws
+    for (uint64_t i = 0; i < n; i++) {
+        Rng r; r.set_sequence(seq[i]);
+        for (int k = 0; k < 4; k++) out_u[6 * i + k] = r.uniform_uint32();
+        for (int k = 0; k < 2; k++) out_f[2 * i + k] = r.uniform_float().v;
+        for (int k = 0; k < 2; k++) out_u[6 * i + 4 + k] = r.uniform_uint32_bounded(bound[i]);
+    }
+}
+}
+"""
+
+
+def convert():
+    parts, where = convert_parts()
+    parts.append(WRAPPERS)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cpp = os.path.join(OUT_DIR, "geom_functions.cpp")
+    open(cpp, "w").write("\n".join(parts))
+    so = os.path.join(OUT_DIR, "libgeomref.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-o", so, cpp])
+    return C.CDLL(so), where
+
+
+def unit(rng, n):
+    v = rng.normal(size=(n, 3))
+    return (v / np.linalg.norm(v, axis=1)[:, None]).astype(np.float32)
+
+
+def inputs(n=1 << 12, seed=0x6E0A):
+    """seeded inputs incl. the regions each function branches on.  The box / triangle cases are made the way a traversal meets them: rays through and next to the
+    primitive, rays along an edge or through a vertex (the f64 fall-back of the watertight test), axis-parallel rays (infinite reciprocals), t_max in front of / behind
+    the hit."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    d = {}
+    d["gam_n"] = rng.integers(1, 12, n).astype(f32)
+    x = rng.normal(size=n) * np.exp(rng.uniform(-40, 40, n))
+    x[:16] = [0.0, -0.0, np.inf, -np.inf, 1.0, -1.0, 3.4028235e38, -3.4028235e38, 1e-45, -1e-45, 1.1754944e-38, -1.1754944e-38, 0.5, 2.0, 1e-10, -1e-10]
+    d["nf_x"] = x.astype(f32)
+    d["ph_nf"] = rng.integers(1, 5, n).astype(f32); d["ph_f"] = np.exp(rng.uniform(-12, 12, n)).astype(f32); d["ph_g"] = np.exp(rng.uniform(-12, 12, n)).astype(f32)
+    d["ph_g"][:8] = 0.0
+    d["rta_r"] = np.concatenate([rng.uniform(0, 1.2, n - 4), [0.0, 1e-3, 1e-4, 1.0]]).astype(f32)
+    d["hg_c"] = rng.uniform(-1, 1, n).astype(f32); d["hg_g"] = rng.uniform(-0.99, 0.99, n).astype(f32)
+    d["y_rgb"] = np.exp(rng.uniform(-8, 8, (n, 3))).astype(f32)
+    u = rng.uniform(0, 1, (n, 2)).astype(f32).clip(0, np.nextafter(f32(1), f32(0)))
+    u[:32] = f32(0.5); u[32:64, 0] = 0.0
+    d["smp_u"] = u
+    # vectors: cross / coordinate_system / reflect / refract / abs_dot
+    d["vec_a"] = unit(rng, n); d["vec_b"] = unit(rng, n)
+    d["vec_a"][:8] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [0.70710677, 0.70710677, 0], [0, 0.70710677, -0.70710677]]
+    d["rfr_eta"] = rng.choice(np.array([1 / 1.5, 1.5, 1 / 1.33, 1.33, 1.0], f32), n)
+    # offset_ray_origin
+    d["oro_p"] = (rng.normal(size=(n, 3)) * np.exp(rng.uniform(-3, 8, (n, 1)))).astype(f32)
+    d["oro_e"] = (np.abs(d["oro_p"]) * rng.uniform(0, 4e-7, (n, 3))).astype(f32)
+    d["oro_n"] = unit(rng, n); d["oro_n"][:6] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]
+    d["oro_w"] = unit(rng, n)
+    # Bounds3f::intersect_p: boxes and rays of a scene of extent ~10
+    c = rng.uniform(-5, 5, (n, 3)); h = np.exp(rng.uniform(-6, 1.5, (n, 3)))
+    h[: n // 16, rng.integers(0, 3)] = 0.0                               # flat boxes (axis-aligned triangles)
+    lo, hi = (c - h).astype(f32), (c + h).astype(f32)
+    o = rng.uniform(-8, 8, (n, 3))
+    tgt = c + rng.uniform(-1.6, 1.6, (n, 3)) * h                          # through, grazing and next to the box
+    dirs = tgt - o
+    ax = rng.integers(0, 3, n // 8)
+    dirs[np.arange(n // 8), ax] = 0.0                                     # axis-parallel: an infinite reciprocal
+    o[: n // 32] = c[: n // 32]                                           # origin inside the box
+    dirs = (dirs / np.maximum(np.linalg.norm(dirs, axis=1), 1e-30)[:, None]).astype(f32)
+    o = o.astype(f32)
+    o[n // 8: n // 8 + n // 32, 0] = lo[n // 8: n // 8 + n // 32, 0]      # origin ON a slab plane
+    with np.errstate(divide="ignore"):
+        inv = (f32(1.0) / dirs).astype(f32)                               # bvh.rs:409-413: inv_dir = 1 / d, dir_is_neg = inv_dir < 0
+    d["box_b"] = np.concatenate([lo, hi], 1); d["box_o"] = o; d["box_inv"] = inv; d["box_neg"] = (inv < 0).astype(np.uint8)
+    tm = np.where(rng.uniform(size=n) < 0.3, np.exp(rng.uniform(-2, 3, n)), np.inf)
+    d["box_tmax"] = tm.astype(f32)
+    # Triangle::intersect / intersect_p
+    P0 = rng.uniform(-5, 5, (n, 3)); e1 = rng.normal(size=(n, 3)) * np.exp(rng.uniform(-5, 1, (n, 1))); e2 = rng.normal(size=(n, 3)) * np.exp(rng.uniform(-5, 1, (n, 1)))
+    tri = np.stack([P0, P0 + e1, P0 + e2], 1).astype(f32)                 # (n, 3, 3)
+    tri[: n // 32, :, 2] = tri[: n // 32, :1, 2]                          # axis-aligned triangles
+    bc = rng.dirichlet([1, 1, 1], n) * rng.choice([1.0, 1.0, 1.0, 1.3], (n, 1))   # a quarter of the targets fall outside
+    k = n // 8
+    bc[:k, 0] = 0.0; bc[:k, 1] = rng.uniform(0, 1, k); bc[:k, 2] = 1 - bc[:k, 1]   # ON an edge: exact zeros of an edge function, the f64 fall-back
+    bc[k: k + k // 2] = np.eye(3)[rng.integers(0, 3, k // 2)]                       # THROUGH a vertex
+    tgt = (tri.astype(np.float64) * bc[:, :, None]).sum(1)
+    o = tgt + unit(rng, n).astype(np.float64) * np.exp(rng.uniform(-3, 3, (n, 1)))
+    o[k: 2 * k] = np.round(o[k: 2 * k] * 4) / 4                           # origins and targets on a coarse grid: many exactly representable products
+    dirs = tgt - o
+    ax = rng.integers(0, 3, n // 16)
+    dirs[-(n // 16):][np.arange(n // 16), ax] = 0.0
+    nrm = np.maximum(np.linalg.norm(dirs, axis=1), 1e-30)
+    dirs = (dirs / nrm[:, None]).astype(f32)
+    d["tri_p"] = tri.reshape(n, 9); d["tri_o"] = o.astype(f32); d["tri_d"] = dirs
+    tm = np.where(rng.uniform(size=n) < 0.4, nrm * rng.uniform(0.5, 1.5, n), np.inf)      # t_max in front of / behind the hit
+    d["tri_tmax"] = tm.astype(f32)
+    # Trowbridge-Reitz terms
+    wo = unit(rng, n); wo[:, 2] = np.abs(wo[:, 2]); wh = unit(rng, n); wh[:, 2] = np.abs(wh[:, 2])
+    wh[:16] = [0, 0, 1]; wo[16:24] = [[1, 0, 0]] * 8                       # normal incidence, grazing (infinite tangent)
+    d["mf_wo"] = wo; d["mf_wh"] = wh
+    d["mf_ax"] = rng.uniform(0.001, 1.6, n).astype(f32)
+    d["mf_ay"] = np.where(rng.uniform(size=n) < 0.5, d["mf_ax"], rng.uniform(0.001, 1.6, n).astype(f32)).astype(f32)
+    # PCG32
+    d["rng_seq"] = rng.integers(0, 1 << 63, n, dtype=np.uint64); d["rng_seq"][:4] = [0, 1, 2, (1 << 64) - 1]
+    b = rng.integers(1, 1 << 31, n).astype(np.uint32); b[: n // 2] = rng.integers(1, 4096, n // 2); b[:8] = [1, 2, 3, 4, 5, 7, 8, 4096]
+    d["rng_bound"] = b
+    return d
+
+
+def run_reference(L, d):
+    n = len(d["gam_n"])
+    P = lambda a: np.ascontiguousarray(a).ctypes.data
+    keep = []
+
+    def call(fn, ins, shape, dtype=np.float32, pre=()):
+        o = np.zeros(shape, dtype)
+        f = getattr(L, fn)
+        f.restype = None
+        arrs = [np.ascontiguousarray(a) for a in ins]
+        keep.extend(arrs)
+        f.argtypes = [C.c_int] * len(pre) + [C.c_void_p] * len(arrs) + [C.c_uint64, C.c_void_p]
+        f(*pre, *[a.ctypes.data for a in arrs], n, o.ctypes.data)
+        return o
+    z = np.zeros(n, np.float32)
+    out = {}
+    out["gam_out"] = call("g_scalar", [d["gam_n"], z, z], n, pre=(0,))
+    out["nfu_out"] = call("g_scalar", [d["nf_x"], z, z], n, pre=(1,))
+    out["nfd_out"] = call("g_scalar", [d["nf_x"], z, z], n, pre=(2,))
+    out["ph_out"] = call("g_scalar", [d["ph_nf"], d["ph_f"], d["ph_g"]], n, pre=(3,))
+    out["rta_out"] = call("g_scalar", [d["rta_r"], z, z], n, pre=(5,))
+    out["hg_out"] = call("g_scalar", [d["hg_c"], d["hg_g"], z], n, pre=(6,))
+    out["y_out"] = call("g_scalar", [d["y_rgb"][:, 0], d["y_rgb"][:, 1], d["y_rgb"][:, 2]], n, pre=(7,))
+    for k, name in enumerate(["csh", "ush"]):
+        out[name + "_out"] = call("g_sample", [d["smp_u"]], (n, 3), pre=(k,))
+    out["crs_out"] = call("g_vec", [d["vec_a"], d["vec_b"]], (n, 3), pre=(0,))
+    out["cs_out"] = call("g_vec", [d["vec_a"], d["vec_b"]], (n, 6), pre=(1,))
+    out["rfl_out"] = call("g_vec", [d["vec_a"], d["vec_b"]], (n, 3), pre=(2,))
+    out["rfr_out"] = call("g_vec", [d["vec_a"], np.concatenate([d["vec_b"].reshape(-1), d["rfr_eta"]])], (n, 4), pre=(3,))
+    out["adt_out"] = call("g_vec", [d["vec_a"], d["vec_b"]], n, pre=(4,))
+    out["oro_out"] = call("g_offset_ray_origin", [d["oro_p"], d["oro_e"], d["oro_n"], d["oro_w"]], (n, 3))
+    out["box_out"] = call("g_box", [d["box_b"], d["box_o"], d["box_inv"], d["box_neg"], d["box_tmax"]], n)
+    out["tri_out"] = call("g_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5), pre=(0,))
+    out["trp_out"] = call("g_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5), pre=(1,))
+    out["mf_out"] = call("g_microfacet", [d["mf_wo"], d["mf_wh"], d["mf_ax"], d["mf_ay"]], (n, 5))
+    ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
+    L.g_rng.restype = None
+    L.g_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.g_rng(P(d["rng_seq"]), P(d["rng_bound"]), n, ou.ctypes.data, of.ctypes.data)
+    out["rng_u_out"] = ou; out["rng_f_out"] = of
+    return out
+
+
+def main():
+    L, where = convert()
+    for w in where[18:]:
+        print("compiled from", w)
+    if len(sys.argv) > 1 and sys.argv[1] == "--build-only":
+        return 0
+    d = inputs()
+    out = run_reference(L, d)
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        g = np.load(FIXTURE)
+        bad = [k for k in list(d) + list(out) if not np.array_equal(g[k].view(np.uint8), (d[k] if k in d else out[k]).view(np.uint8))]
+        print("committed fixture %s the reference's text%s" % ("equals" if not bad else "DIFFERS from", "" if not bad else ": " + ", ".join(bad)))
+        return 1 if bad else 0
+    np.savez_compressed(FIXTURE, **d, **out)
+    print("wrote", FIXTURE, os.path.getsize(FIXTURE), "bytes;", len(d["gam_n"]), "cases per function;",
+          "box hits %.2f, triangle hits %.2f" % (out["box_out"].mean(), out["tri_out"][:, 0].mean()))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

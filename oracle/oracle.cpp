@@ -7,7 +7,10 @@
 // known-answer tests (tests/test_oracle_*.py) until a dump of real rs_pbrt is committed (oracle/REFERENCE_FIXTURES.md).
 // Pinned by the reference's own TEXT since round 6 (compiled from the Rust sources by committed rewrite rules, oracle/make_leaf_fixtures.py; bit for bit):
 // fr_dielectric, fr_conductor, trowbridge_reitz_sample_11 / _sample, sobol_sample_float, concentric_sample_disk, Matrix4x4::inverse; since round 5
-// AnimatedTransform's derivative polynomials (oracle/make_motion_fixture.py).  Control flow (dispatch, loops, traversal order) remains unpinned.
+// AnimatedTransform's derivative polynomials (oracle/make_motion_fixture.py); third session of round 6 (oracle/make_geom_fixtures.py): Bounds3f::intersect_p, the
+// watertight test of Triangle::intersect / intersect_p, pnt3_offset_ray_origin (+ next_float_up / _down, gamma), vec3_cross_vec3, vec3_coordinate_system, reflect,
+// refract, power_heuristic, cosine_ / uniform_sample_hemisphere, TrowbridgeReitzDistribution::{roughness_to_alpha, d, lambda, g1, g, pdf}, phase_hg, RGBSpectrum::y,
+// Rng::{set_sequence, uniform_uint32, uniform_uint32_bounded, uniform_float}.  Control flow (dispatch, loops, traversal order) remains unpinned.
 #include "orc_render.hpp"
 #include "orc_motion.hpp"
 
@@ -448,6 +451,84 @@ void orc_leaf(int fn, const float* a, const float* b, const float* c, const floa
                   const M44 v = m44_inverse(m); for (int r = 0; r < 4; r++) for (int k = 0; k < 4; k++) out[16 * i + 4 * r + k] = v.m[r][k]; break; }
         default: break;
         }
+    }
+}
+
+// ---- the oracle's restatements of what tests/golden/geom_functions.npz pins by the reference's own text (oracle/make_geom_fixtures.py): same argument layout as
+// that script's g_* wrappers ----
+void orc_geom_scalar(int fn, const float* a, const float* b, const float* c, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) switch (fn) {
+        case 0: out[i] = orc::gamma((int)a[i]); break;
+        case 1: out[i] = next_float_up(a[i]); break;
+        case 2: out[i] = next_float_down(a[i]); break;
+        case 3: out[i] = power_heuristic((int)a[i], b[i], 1, c[i]); break;
+        case 5: out[i] = tr_roughness_to_alpha(a[i]); break;
+        case 6: out[i] = phase_hg(a[i], b[i]); break;
+        case 7: out[i] = Spec(a[i], b[i], c[i]).y(); break;
+        default: break;
+    }
+}
+void orc_geom_sample(int fn, const float* u, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const P2 p{u[2 * i], u[2 * i + 1]};
+        const V3 r = fn == 0 ? cosine_sample_hemisphere(p) : uniform_sample_hemisphere(p);
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+void orc_geom_vec(int fn, const float* a, const float* b, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const V3 x{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, y{b[3 * i], b[3 * i + 1], b[3 * i + 2]};
+        switch (fn) {
+            case 0: { const V3 r = cross(x, y); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+            case 1: { V3 v2{0, 0, 0}, v3{0, 0, 0}; coordinate_system(x, &v2, &v3); out[6 * i] = v2.x; out[6 * i + 1] = v2.y; out[6 * i + 2] = v2.z;
+                      out[6 * i + 3] = v3.x; out[6 * i + 4] = v3.y; out[6 * i + 5] = v3.z; break; }
+            case 2: { const V3 r = reflect(x, y); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+            case 3: { V3 wt{0, 0, 0}; const bool ok = refract(x, y, b[3 * n + i], &wt); out[4 * i] = wt.x; out[4 * i + 1] = wt.y; out[4 * i + 2] = wt.z; out[4 * i + 3] = ok ? 1.0f : 0.0f; break; }
+            case 4: out[i] = abs_dot(x, y); break;
+            default: break;
+        }
+    }
+}
+void orc_geom_offset_ray_origin(const float* p, const float* e, const float* nn, const float* w, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const V3 r = offset_ray_origin(V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}, V3{e[3 * i], e[3 * i + 1], e[3 * i + 2]}, V3{nn[3 * i], nn[3 * i + 1], nn[3 * i + 2]},
+                                       V3{w[3 * i], w[3 * i + 1], w[3 * i + 2]});
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+void orc_geom_box(const float* box, const float* o, const float* inv, const uint8_t* neg, const float* tmax, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        rspt_bvh_node nd{};
+        for (int k = 0; k < 3; k++) { nd.bmin[k] = box[6 * i + k]; nd.bmax[k] = box[6 * i + 3 + k]; }
+        Ray r{}; r.o = V3{o[3 * i], o[3 * i + 1], o[3 * i + 2]}; r.d = V3{0, 0, 0}; r.t_max = tmax[i];
+        out[i] = Scene::box_hit(nd, r, V3{inv[3 * i], inv[3 * i + 1], inv[3 * i + 2]}, neg + 3 * i) ? 1.0f : 0.0f;
+    }
+}
+void orc_geom_triangle(const float* tri, const float* o, const float* d, const float* tmax, uint64_t n, float* out) {   // the watertight test shared by intersect / intersect_p
+    Scene sc{};
+    rspt_prim pr{}; pr.v[0] = 0; pr.v[1] = 1; pr.v[2] = 2;
+    for (uint64_t i = 0; i < n; i++) {
+        sc.d.P = tri + 9 * i;
+        Ray r{}; r.o = V3{o[3 * i], o[3 * i + 1], o[3 * i + 2]}; r.d = V3{d[3 * i], d[3 * i + 1], d[3 * i + 2]}; r.t_max = tmax[i];
+        Float t = 0.0f, b[3] = {0.0f, 0.0f, 0.0f};
+        const bool hit = sc.tri_hit_test(pr, r, &t, b);
+        out[5 * i] = hit ? 1.0f : 0.0f; out[5 * i + 1] = hit ? t : 0.0f;
+        for (int k = 0; k < 3; k++) out[5 * i + 2 + k] = hit ? b[k] : 0.0f;
+    }
+}
+void orc_geom_microfacet(const float* wo, const float* wh, const float* ax, const float* ay, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const TR t{ax[i], ay[i]};
+        const V3 a{wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]}, h{wh[3 * i], wh[3 * i + 1], wh[3 * i + 2]};
+        out[5 * i] = t.d(h); out[5 * i + 1] = t.lambda(a); out[5 * i + 2] = t.g1(a); out[5 * i + 3] = t.g(a, h); out[5 * i + 4] = t.pdf(a, h);
+    }
+}
+void orc_geom_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {
+    for (uint64_t i = 0; i < n; i++) {
+        Rng r; r.set_sequence(seq[i]);
+        for (int k = 0; k < 4; k++) out_u[6 * i + k] = r.uniform_uint32();
+        for (int k = 0; k < 2; k++) out_f[2 * i + k] = r.uniform_float();
+        for (int k = 0; k < 2; k++) out_u[6 * i + 4 + k] = r.uniform_uint32_bounded(bound[i]);
     }
 }
 

@@ -9,7 +9,10 @@ reference has no tests or golden vectors and no Rust toolchain exists here: unpi
 answers (tests/test_oracle_*.py), not against rs_pbrt output.  Round 6 adds pins by the reference's own TEXT: seven scalar leaf functions
 (fr_dielectric, fr_conductor, trowbridge_reitz_sample_11 / _sample, sobol_sample_float, concentric_sample_disk, Matrix4x4::inverse) compiled from the Rust
 sources by oracle/make_leaf_fixtures.py and equal to this oracle bit for bit (tests/test_reference_leaf_functions.py), AnimatedTransform's derivative
-polynomials (oracle/make_motion_fixture.py, round 5), and the Sobol' / max-min-distance / prime tables (tests/test_reference_tables.py).  Control flow stays unpinned."""
+polynomials (oracle/make_motion_fixture.py, round 5), the Sobol' / max-min-distance / prime tables (tests/test_reference_tables.py), and — second batch,
+oracle/make_geom_fixtures.py / tests/test_reference_geom_functions.py — the traversal's box test (Bounds3f::intersect_p), the watertight test of Triangle::intersect /
+intersect_p, pnt3_offset_ray_origin, vec3_cross_vec3, vec3_coordinate_system, reflect / refract, power_heuristic, the hemisphere samplers, the Trowbridge-Reitz terms,
+phase_hg, RGBSpectrum::y and the PCG32 generator.  Control flow stays unpinned."""
 import ctypes as C
 import os
 import subprocess
@@ -273,4 +276,46 @@ def leaf(fn, n, out_shape, a=None, b=None, c=None, d=None, e=None, ia=None, ib=N
     keep = [None if x is None else np.ascontiguousarray(x) for x in (a, b, c, d, e, ia, ib, words)]
     out = np.zeros(out_shape, np.float32)
     L.orc_leaf(fn, *[None if x is None else x.ctypes.data for x in keep], n, out.ctypes.data)
+    return out
+
+
+def geom(d):
+    """the oracle's restatements of everything tests/golden/geom_functions.npz pins by the reference's text (oracle.cpp orc_geom_*; oracle/make_geom_fixtures.py's
+    input dictionary in, its output dictionary out)"""
+    L = lib()
+    n = len(d["gam_n"])
+    keep = []
+
+    def call(fn, ins, shape, pre=(), dtype=np.float32):
+        o = np.zeros(shape, dtype)
+        f = getattr(L, fn)
+        f.restype = None
+        arrs = [np.ascontiguousarray(a) for a in ins]
+        keep.extend(arrs)
+        f.argtypes = [C.c_int] * len(pre) + [C.c_void_p] * len(arrs) + [C.c_uint64, C.c_void_p]
+        f(*pre, *[a.ctypes.data for a in arrs], n, o.ctypes.data)
+        return o
+    z = np.zeros(n, np.float32)
+    out = {
+        "gam_out": call("orc_geom_scalar", [d["gam_n"], z, z], n, (0,)), "nfu_out": call("orc_geom_scalar", [d["nf_x"], z, z], n, (1,)),
+        "nfd_out": call("orc_geom_scalar", [d["nf_x"], z, z], n, (2,)), "ph_out": call("orc_geom_scalar", [d["ph_nf"], d["ph_f"], d["ph_g"]], n, (3,)),
+        "rta_out": call("orc_geom_scalar", [d["rta_r"], z, z], n, (5,)), "hg_out": call("orc_geom_scalar", [d["hg_c"], d["hg_g"], z], n, (6,)),
+        "y_out": call("orc_geom_scalar", [d["y_rgb"][:, 0], d["y_rgb"][:, 1], d["y_rgb"][:, 2]], n, (7,)),
+        "csh_out": call("orc_geom_sample", [d["smp_u"]], (n, 3), (0,)), "ush_out": call("orc_geom_sample", [d["smp_u"]], (n, 3), (1,)),
+        "crs_out": call("orc_geom_vec", [d["vec_a"], d["vec_b"]], (n, 3), (0,)), "cs_out": call("orc_geom_vec", [d["vec_a"], d["vec_b"]], (n, 6), (1,)),
+        "rfl_out": call("orc_geom_vec", [d["vec_a"], d["vec_b"]], (n, 3), (2,)),
+        "rfr_out": call("orc_geom_vec", [d["vec_a"], np.concatenate([np.asarray(d["vec_b"]).reshape(-1), d["rfr_eta"]])], (n, 4), (3,)),
+        "adt_out": call("orc_geom_vec", [d["vec_a"], d["vec_b"]], n, (4,)),
+        "oro_out": call("orc_geom_offset_ray_origin", [d["oro_p"], d["oro_e"], d["oro_n"], d["oro_w"]], (n, 3)),
+        "box_out": call("orc_geom_box", [d["box_b"], d["box_o"], d["box_inv"], d["box_neg"], d["box_tmax"]], n),
+        "tri_out": call("orc_geom_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5)),
+        "mf_out": call("orc_geom_microfacet", [d["mf_wo"], d["mf_wh"], d["mf_ax"], d["mf_ay"]], (n, 5)),
+    }
+    out["trp_out"] = out["tri_out"]      # Triangle::intersect_p repeats intersect's watertight test (triangle.rs:450-591); the oracle shares one function
+    ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
+    L.orc_geom_rng.restype = None
+    L.orc_geom_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    seq, bound = np.ascontiguousarray(d["rng_seq"], np.uint64), np.ascontiguousarray(d["rng_bound"], np.uint32)
+    L.orc_geom_rng(seq.ctypes.data, bound.ctypes.data, n, ou.ctypes.data, of.ctypes.data)
+    out["rng_u_out"], out["rng_f_out"] = ou, of
     return out

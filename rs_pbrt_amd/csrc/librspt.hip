@@ -2803,19 +2803,69 @@ int rspt_motion_bounds(const float start_m[16], float start_time, const float en
     if (flags_out) *flags_out = (keys.animated ? 1 : 0) | (keys.has_rotation ? 2 : 0);
     return RSPT_OK;
 }
+}  // extern "C" (reopened below)
+namespace {
+// stage hook rspt_libm, codes 8 .. 12: the device's traversal / shading geometry AS THE KERNELS CALL IT, one element = 16 floats in, 16 floats out (include/rspt.h) —
+// what tests/golden/geom_functions.npz pins by the reference's own text
+__global__ void k_leaf_geom(uint32_t fn, const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a[16], r[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { a[k] = x[16 * i + k]; r[k] = 0.0f; }
+    if (fn == RSPT_LIBM_TRIANGLE) {              // Triangle::intersect's watertight test: ray_shear once per ray + tri_test per triangle (dev_scene.h), as traverse<> / k_trace_w4 run it
+        const f3 d{a[12], a[13], a[14]};
+        const RayShear rs = ray_shear(d);
+        float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+        const bool hit = tri_test(f3{a[0], a[1], a[2]}, f3{a[3], a[4], a[5]}, f3{a[6], a[7], a[8]}, f3{a[9], a[10], a[11]}, rs, a[15], &t, &b0, &b1, &b2);
+        r[0] = hit ? 1.0f : 0.0f; r[1] = hit ? t : 0.0f; r[2] = hit ? b0 : 0.0f; r[3] = hit ? b1 : 0.0f; r[4] = hit ? b2 : 0.0f;
+    } else if (fn == RSPT_LIBM_BOX) {            // Bounds3f::intersect_p: k_trace's box_hit (kernels.h), and k_trace_w4's choice (trace_w4.h): the pair form for finite reciprocals, else the literal chain
+        const f3 o{a[6], a[7], a[8]}, inv{a[9], a[10], a[11]};
+        const bool n0 = a[12] != 0.0f, n1 = a[13] != 0.0f, n2 = a[14] != 0.0f;
+        r[0] = box_hit(float4{a[0], a[1], a[2], a[3]}, float4{a[4], a[5], 0.0f, 0.0f}, o, inv, n0, n1, n2, a[15]) ? 1.0f : 0.0f;
+        if (fabsf(inv.x) < RSPT_INF && fabsf(inv.y) < RSPT_INF && fabsf(inv.z) < RSPT_INF) {
+            bool h0, h1; float m0, m1;
+            box_pair_hit_m(float4{a[0], a[0], a[3], a[3]}, float4{a[1], a[1], a[4], a[4]}, float4{a[2], a[2], a[5], a[5]}, o.x, o.y, o.z, inv.x, inv.y, inv.z, a[15], &h0, &h1, &m0, &m1);
+            r[1] = h0 ? 1.0f : 0.0f; r[2] = h1 ? 1.0f : 0.0f; r[3] = 1.0f;
+        } else {
+            float m0;
+            r[1] = r[2] = box_hit6_m(a[0], a[1], a[2], a[3], a[4], a[5], o, inv, n0, n1, n2, a[15], &m0) ? 1.0f : 0.0f; r[3] = 0.0f;
+        }
+    } else if (fn == RSPT_LIBM_OFFSET_RAY_ORIGIN) {   // pnt3_offset_ray_origin (dev_math.h): every spawned ray
+        const f3 po = offset_ray_origin(f3{a[0], a[1], a[2]}, f3{a[3], a[4], a[5]}, f3{a[6], a[7], a[8]}, f3{a[9], a[10], a[11]});
+        r[0] = po.x; r[1] = po.y; r[2] = po.z;
+    } else if (fn == RSPT_LIBM_MICROFACET) {     // TrowbridgeReitzDistribution::d / lambda / g1 / g / pdf (dev_bsdf.h)
+        const f3 wo{a[0], a[1], a[2]}, wh{a[3], a[4], a[5]};
+        r[0] = tr_d(a[6], a[7], wh); r[1] = tr_lambda(a[6], a[7], wo); r[2] = tr_g1(a[6], a[7], wo); r[3] = tr_g(a[6], a[7], wo, wh); r[4] = tr_pdf(a[6], a[7], wo, wh);
+    } else {                                     // RSPT_LIBM_VECTORS: vec3_cross_vec3, vec3_coordinate_system, refract, cosine_sample_hemisphere (dev_math.h, dev_bsdf.h)
+        const f3 u{a[0], a[1], a[2]}, v{a[3], a[4], a[5]};
+        const f3 c = cross(u, v);
+        f3 v2{0.0f, 0.0f, 0.0f}, v3{0.0f, 0.0f, 0.0f}, wt{0.0f, 0.0f, 0.0f};
+        coordinate_system(u, &v2, &v3);
+        const bool ok = refract(u, v, a[6], &wt);
+        const f3 h = cosine_hemisphere(f2{a[7], a[8]});
+        r[0] = c.x; r[1] = c.y; r[2] = c.z; r[3] = v2.x; r[4] = v2.y; r[5] = v2.z; r[6] = v3.x; r[7] = v3.y; r[8] = v3.z;
+        r[9] = ok ? wt.x : 0.0f; r[10] = ok ? wt.y : 0.0f; r[11] = ok ? wt.z : 0.0f; r[12] = ok ? 1.0f : 0.0f; r[13] = h.x; r[14] = h.y; r[15] = h.z;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[16 * i + k] = r[k];
+}
+}  // namespace
+extern "C" {
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (n == 0) return RSPT_OK;
-    if (fn > RSPT_LIBM_MAT4_INVERSE || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (1ull << 31)) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values");
+    if (fn > RSPT_LIBM_VECTORS || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (fn >= RSPT_LIBM_MAT4_INVERSE ? (1ull << 27) : (1ull << 31))) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values (2^27 sixteen-float elements)");
     HIP_TRY(hipSetDevice(g.device));
     float *xd = nullptr, *yd = nullptr, *od = nullptr;
     struct Guard { float **a, **b, **c; ~Guard() { for (float** p : {a, b, c}) if (*p) (void)hipFree(*p); } } guard{&xd, &yd, &od};
     int rc;
-    const uint64_t per = fn == RSPT_LIBM_MAT4_INVERSE ? 16u : 1u;   // values per element
+    const uint64_t per = fn >= RSPT_LIBM_MAT4_INVERSE ? 16u : 1u;   // values per element
     if ((rc = dev_alloc(&xd, n * per)) || (rc = dev_alloc(&od, n * per)) || (y && (rc = dev_alloc(&yd, n)))) return rc;
     HIP_TRY(hipMemcpyAsync(xd, x, n * per * sizeof(float), hipMemcpyHostToDevice, g.stream));
     if (y) HIP_TRY(hipMemcpyAsync(yd, y, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
-    hipLaunchKernelGGL(k_libm, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, yd, n, od);
+    if (fn > RSPT_LIBM_MAT4_INVERSE) hipLaunchKernelGGL(k_leaf_geom, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, n, od);
+    else hipLaunchKernelGGL(k_libm, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, yd, n, od);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, od, n * per * sizeof(float), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));

@@ -95,7 +95,7 @@ extern "C" {
     pub fn rspt_motion_bounds(start_m: *const f32, start_time: f32, end_m: *const f32, end_time: f32, box_min: *const f32, box_max: *const f32,
                               out_min: *mut f32, out_max: *mut f32, flags_out: *mut i32) -> c_int;
     pub fn rspt_last_error() -> *const c_char;
-    pub fn rspt_libm(func: u32, x: *const f32, y: *const f32, n: u64, out: *mut f32) -> c_int;   // 0 sin 1 cos 2 ln 3 log2 4 exp 5 acos 6 atan2(x, y) 7 Matrix4x4::inverse of n 4x4 matrices (x, out: 16 n floats)
+    pub fn rspt_libm(func: u32, x: *const f32, y: *const f32, n: u64, out: *mut f32) -> c_int;   // 0 sin 1 cos 2 ln 3 log2 4 exp 5 acos 6 atan2(x, y) 7 Matrix4x4::inverse of n 4x4 matrices (x, out: 16 n floats); 8 .. 12: the triangle / box / offset_ray_origin / microfacet / vector hooks of rspt.h (16 floats per element)
     pub fn rspt_bvh_build_gpu(p: *const f32, n_vertices: u64, tri_idx: *const u32, n_tris: u64, max_prims_in_node: u32,
                               nodes_out: *mut RsptBvhNode, nodes_cap: u64, ordered_out: *mut u32) -> i64;
 }

@@ -1,0 +1,76 @@
+"""The DEVICE's traversal and shading geometry against the REFERENCE'S OWN TEXT, with no oracle in between (round 6, third session).
+
+tests/golden/geom_functions.npz holds what the Rust text of Bounds3f::intersect_p, Triangle::intersect's watertight test, pnt3_offset_ray_origin, the Trowbridge-Reitz
+terms, vec3_cross_vec3, vec3_coordinate_system, refract and cosine_sample_hemisphere computes on 2^12 seeded cases each (oracle/make_geom_fixtures.py compiles that text
+by committed rewrite rules).  rspt_libm's codes 8 .. 12 run the functions the kernels call (dev_scene.h tri_test, kernels.h box_hit, trace_w4.h box_pair_hit_m /
+box_hit6_m, dev_math.h, dev_bsdf.h) over the same inputs: every output must be the same BITS."""
+import os
+
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import lib
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def g():
+    lib.init(0)
+    return np.load(os.path.join(HERE, "golden", "geom_functions.npz"))
+
+
+def pack(n, *cols):
+    x = np.zeros((n, 16), np.float32)
+    k = 0
+    for c in cols:
+        c = np.asarray(c, np.float32).reshape(n, -1)
+        x[:, k:k + c.shape[1]] = c
+        k += c.shape[1]
+    return x
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_the_watertight_triangle_test_is_the_references_text(g):
+    n = len(g["tri_p"])
+    x = pack(n, g["tri_p"], g["tri_o"], g["tri_d"])
+    x[:, 15] = g["tri_tmax"]
+    out = lib.leaf_geom("triangle", x)
+    assert same_bits(out[:, :5], g["tri_out"]), "Triangle::intersect: %d of %d cases differ" % (int((out[:, :5].view(np.uint32) != g["tri_out"].view(np.uint32)).any(axis=1).sum()), n)
+    assert same_bits(out[:, :5], g["trp_out"])          # Triangle::intersect_p repeats the test
+    assert (out[:, 5:] == 0).all() and 0.3 < out[:, 0].mean() < 0.8
+
+
+def test_the_box_test_is_the_references_text_in_every_form_the_kernels_use(g):
+    n = len(g["box_b"])
+    x = pack(n, g["box_b"], g["box_o"], g["box_inv"], g["box_neg"].astype(np.float32))
+    x[:, 15] = g["box_tmax"]
+    out = lib.leaf_geom("box", x)
+    ref = g["box_out"]
+    assert np.array_equal(out[:, 0], ref), "k_trace's box_hit: %d of %d differ" % (int((out[:, 0] != ref).sum()), n)
+    assert np.array_equal(out[:, 1], ref) and np.array_equal(out[:, 2], ref), "k_trace_w4's forms: %d / %d of %d differ" % (int((out[:, 1] != ref).sum()), int((out[:, 2] != ref).sum()), n)
+    finite = np.isfinite(g["box_inv"]).all(axis=1)
+    assert np.array_equal(out[:, 3] == 1, finite) and 100 < (~finite).sum() < n - 100      # both of the w4 kernel's forms were exercised
+
+
+def test_offset_ray_origin_and_the_microfacet_terms_are_the_references_text(g):
+    n = len(g["oro_p"])
+    out = lib.leaf_geom("offset_ray_origin", pack(n, g["oro_p"], g["oro_e"], g["oro_n"], g["oro_w"]))
+    assert same_bits(out[:, :3], g["oro_out"])
+    out = lib.leaf_geom("microfacet", pack(n, g["mf_wo"], g["mf_wh"], g["mf_ax"], g["mf_ay"]))
+    assert same_bits(out[:, :5], g["mf_out"]), "Trowbridge-Reitz d / lambda / g1 / g / pdf: columns differing %s" % (out[:, :5].view(np.uint32) != g["mf_out"].view(np.uint32)).sum(axis=0)
+
+
+def test_cross_coordinate_system_refract_and_the_cosine_hemisphere_are_the_references_text(g):
+    n = len(g["vec_a"])
+    out = lib.leaf_geom("vectors", pack(n, g["vec_a"], g["vec_b"], g["rfr_eta"], g["smp_u"]))
+    assert same_bits(out[:, 0:3], g["crs_out"])
+    assert same_bits(out[:, 3:9], g["cs_out"])
+    ok = g["rfr_out"][:, 3] == 1
+    assert np.array_equal(out[:, 12] == 1, ok) and same_bits(out[ok, 9:12], g["rfr_out"][ok, :3])
+    assert same_bits(out[:, 13:16], g["csh_out"])

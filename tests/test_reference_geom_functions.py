@@ -1,0 +1,76 @@
+"""The geometry of a traversal step, the sampling helpers, the Trowbridge-Reitz terms and the PCG32 generator held to the REFERENCE'S OWN TEXT (round 6, third session;
+the route of tests/test_reference_leaf_functions.py, second batch).
+
+oracle/make_geom_fixtures.py compiles — syntax rewritten by committed rules, no hand-edited body — Bounds3f::intersect_p (geometry.rs:2211-2268), the watertight test of
+Triangle::intersect / intersect_p (triangle.rs:134-273, 450-591: everything in front of the SurfaceInteraction), pnt3_offset_ray_origin with next_float_up / _down and
+gamma, vec3_cross_vec3 (its f64 products), vec3_coordinate_system, reflect / refract, power_heuristic, cosine_ / uniform_sample_hemisphere,
+TrowbridgeReitzDistribution::{roughness_to_alpha, d, lambda, g1, g, pdf}, phase_hg, RGBSpectrum::y and Rng::{set_sequence, uniform_uint32, uniform_uint32_bounded,
+uniform_float} from the Rust text where it lies; tests/golden/geom_functions.npz holds 2^12 seeded cases per function with that code's outputs.  The ORACLE's
+restatements (and through tests/test_gpu_*.py the HIP kernels, sample for sample) must give the same BITS.  Where /root/reference exists the fixture is regenerated
+and compared, and 2^17 fresh cases per function run through both side by side."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HAVE_REF = os.path.exists("/root/reference/src/shapes/triangle.rs")
+NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_down", "ph_out": "power_heuristic", "rta_out": "roughness_to_alpha", "hg_out": "phase_hg",
+         "y_out": "RGBSpectrum::y", "csh_out": "cosine_sample_hemisphere", "ush_out": "uniform_sample_hemisphere", "crs_out": "vec3_cross_vec3", "cs_out": "vec3_coordinate_system",
+         "rfl_out": "reflect", "rfr_out": "refract", "adt_out": "vec3_abs_dot_vec3f", "oro_out": "pnt3_offset_ray_origin", "box_out": "Bounds3f::intersect_p",
+         "tri_out": "Triangle::intersect (watertight test)", "trp_out": "Triangle::intersect_p (watertight test)", "mf_out": "TrowbridgeReitzDistribution d / lambda / g1 / g / pdf",
+         "rng_u_out": "Rng uniform_uint32 / _bounded", "rng_f_out": "Rng::uniform_float"}
+
+
+def differing(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.dtype == np.float32:
+        return int(((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))).sum())   # (a NaN has many encodings)
+    return int((a != b).sum())
+
+
+def generator():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_geom_fixtures
+    return make_geom_fixtures
+
+
+def test_oracle_equals_the_references_text_on_the_committed_fixture(oracle):
+    g = np.load(os.path.join(HERE, "golden", "geom_functions.npz"))
+    assert len(g["gam_n"]) == 1 << 12
+    got = oracle.geom(g)
+    assert set(got) == set(NAMES)
+    for k, name in NAMES.items():
+        assert differing(got[k], g[k]) == 0, "%s: the oracle's restatement differs from the reference's text in %d of %d outputs" % (name, differing(got[k], g[k]), g[k].size)
+    # the fixture exercises the branches it is there for
+    tri, box = g["tri_out"], g["box_out"]
+    assert 0.3 < tri[:, 0].mean() < 0.8 and 0.15 < box.mean() < 0.7                       # hits and misses
+    assert ((tri[:, 0] == 1) & ((tri[:, 2:] == 0).any(axis=1))).sum() > 50                # hits ON an edge / through a vertex: the f64 fall-back decides them
+    assert (np.isinf(g["box_inv"]).any(axis=1) & (box == 1)).sum() > 20                   # axis-parallel rays that pass a box (infinite reciprocals)
+    assert np.isfinite(g["tri_tmax"]).sum() > 1000 and ((tri[:, 0] == 0) & np.isfinite(g["tri_tmax"])).sum() > 200   # t_max in front of the hit
+    assert (g["rfr_out"][:, 3] == 0).sum() > 50                                           # total internal reflection
+    assert (g["mf_out"][:16, 0] > 0).all() and (g["mf_out"][16:24, 1] == 0).all()         # D at normal incidence, lambda at grazing incidence (infinite tangent)
+    assert (g["oro_out"] != g["oro_p"]).any(axis=1).mean() > 0.9                          # the offset moved the origin, rounded away from it
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference tree is not on this machine: the committed fixture is what travels")
+def test_committed_fixture_is_what_the_references_text_gives():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_geom_fixtures.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs /root/reference to compile the reference's text")
+def test_oracle_equals_the_compiled_reference_text_on_131072_fresh_cases_per_function(oracle):
+    mk = generator()
+    L, where = mk.convert()
+    assert len(where) == 18 + len(mk.SOURCES)
+    lines = dict(w.rsplit(" ", 1) for w in where)
+    assert lines["Bounds3f::intersect_p"] == "core/geometry.rs:2211-2268" and lines["Triangle::intersect"] == "shapes/triangle.rs:134-273"
+    d = mk.inputs(n=1 << 17, seed=0x5EED7)
+    ref = mk.run_reference(L, d)
+    got = oracle.geom(d)
+    for k, name in NAMES.items():
+        assert differing(got[k], ref[k]) == 0, "%s: %d of %d outputs differ" % (name, differing(got[k], ref[k]), ref[k].size)
