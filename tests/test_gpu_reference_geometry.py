@@ -74,3 +74,23 @@ def test_cross_coordinate_system_refract_and_the_cosine_hemisphere_are_the_refer
     ok = g["rfr_out"][:, 3] == 1
     assert np.array_equal(out[:, 12] == 1, ok) and same_bits(out[ok, 9:12], g["rfr_out"][ok, :3])
     assert same_bits(out[:, 13:16], g["csh_out"])
+
+
+def test_the_traversal_kernels_walk_the_tree_as_the_references_text_does(g):
+    """rspt_trace (k_trace_w4 closest / any, and with it the four-box records, the persistent waves, the deferred leaf phase) against BVHAccel::intersect / intersect_p
+    compiled from the reference's text (bvh.rs:401-514 over primitive.rs:150-156, geometry.rs:2211-2268, triangle.rs:134-273): the hit record and the occlusion flag of
+    every committed ray — incoherent, axis-parallel, leaving a triangle along its own edge, segments ending on a surface — bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import make_geom_fixtures as mk
+    from rs_pbrt_amd import abi
+    sc = mk.traversal_scene(lib.bvh_build)
+    assert np.array_equal(mk.tree_digest(sc), g["trv_tree"]), "the library's host builder gives another tree than the one the fixture was walked on"
+    rays = np.zeros(len(g["trv_o"]), abi.RAY_DT)
+    rays["o"], rays["d"], rays["t_max"] = g["trv_o"], g["trv_d"], g["trv_tmax"]
+    with lib.DeviceScene(sc) as ds:
+        h = lib.trace(ds, rays)
+        a = lib.trace(ds, rays, any_hit=True)
+    assert np.array_equal(h["prim"], g["trv_prim"]), "%d of %d rays end on another primitive" % (int((h["prim"] != g["trv_prim"]).sum()), len(rays))
+    assert same_bits(np.stack([h["t"], h["b0"], h["b1"], h["b2"]], 1), g["trv_tb"])
+    assert np.array_equal((a["prim"] != abi.MISS).astype(np.uint8), g["trv_any"])
