@@ -49,6 +49,7 @@ VEC3_EXTRA = """    Vector3f abs() const;            // body: the reference's te
 """
 PRELUDE2 = r"""
 #include <cstring>
+#include <vector>
 static const Float MACHINE_EPSILON(5.9604644775390625e-8f);                     // core/pbrt.rs:16: f32::EPSILON * 0.5 = 2^-24
 static const Float PI(3.14159265358979323846f), INV_PI(0.31830988618379067154f), INV_4_PI(0.07957747154594766788f);   // core/pbrt.rs:17-20
 static inline uint32_t float_to_bits(Float f) { uint32_t u; std::memcpy(&u, &f.v, 4); return u; }   // pbrt.rs:30-57: transmute_copy
@@ -104,6 +105,43 @@ struct GeometricPrimitive { Shape shape; bool intersect(const Ray& ray, SurfaceI
 struct LinearBVHNode { Bounds3f bounds; int32_t offset; uint16_t n_primitives; uint8_t axis; };   // bvh.rs:77-85
 template <class T> struct Slice { const T* p; size_t n; bool is_empty() const { return n == 0; } const T& operator[](size_t i) const { return p[i]; } };
 struct BVHAccel { Slice<LinearBVHNode> nodes; Slice<GeometricPrimitive> primitives; bool intersect(const Ray& ray, SurfaceInteraction* isect) const; bool intersect_p(const Ray& ray) const; };
+// the Sobol' sampler's carriers (samplers/sobol.rs, core/sampler.rs, core/lowdiscrepancy.rs:1014-1050)
+enum class XYEnum { X, Y };
+struct Vector2i { int32_t x, y; };
+struct Point2i {
+    int32_t x, y;
+    static Point2i default_() { return Point2i{0, 0}; }
+    int32_t operator[](XYEnum i) const { return i == XYEnum::X ? x : y; }      // impl Index<XYEnum> for Point2i (geometry.rs:914-923)
+};
+Vector2i operator-(const Point2i& a, const Point2i& b);
+Point2f operator+(const Point2f& a, const Point2f& b);
+struct Bounds2i { Point2i p_min, p_max; Vector2i diagonal() const; };
+struct TableRows { const uint64_t* p; const uint64_t* operator[](size_t k) const { return p + 52 * k; } };   // [&[u64]; 25 / 26]: rows of at most 52 words (the committed blob pads them)
+static TableRows VD_C_SOBOL_MATRICES{nullptr}, VD_C_SOBOL_MATRICES_INV{nullptr};
+static inline int32_t rs_leading_zeros(uint32_t v) { return v == 0 ? 32 : __builtin_clz(v); }                 // u32::leading_zeros
+static inline int32_t rs_max(int32_t a, int32_t b) { return a > b ? a : b; }                                   // Ord::max on i32
+template <class T> struct Vec : std::vector<T> { size_t len() const { return this->size(); } };
+struct CameraSample { Point2f p_film; Float time; Point2f p_lens; };
+int32_t round_up_pow2_32(int32_t v); int32_t log_2_int_u32(uint32_t v);
+uint64_t sobol_interval_to_index(uint32_t m, uint64_t frame, Point2i p); Float sobol_sample(int64_t index, int32_t dimension, uint64_t scramble);
+struct SobolSampler {
+    int64_t samples_per_pixel; Bounds2i sample_bounds; int32_t resolution, log_2_resolution;
+    int64_t dimension; uint64_t interval_sample_index; int64_t array_start_dim, array_end_dim;
+    Point2i current_pixel; int64_t current_pixel_sample_index;
+    Vec<int32_t> samples_1d_array_sizes, samples_2d_array_sizes; Vec<Vec<Float>> sample_array_1d; Vec<Vec<Point2f>> sample_array_2d;
+    size_t array_1d_offset, array_2d_offset;
+    // SobolSampler::new (sobol.rs:37-78): its field list; the two computed fields through the reference's own round_up_pow2_32 / log_2_int_u32 (sobol.rs:46-48)
+    static SobolSampler make(int64_t spp, const Bounds2i& sb) {
+        SobolSampler s{};
+        s.samples_per_pixel = spp; s.sample_bounds = sb;
+        s.resolution = round_up_pow2_32(rs_max(sb.diagonal().x, sb.diagonal().y)); s.log_2_resolution = log_2_int_u32((uint32_t)s.resolution);
+        s.array_start_dim = 5;
+        return s;
+    }
+    uint64_t get_index_for_sample(uint64_t sample_num) const; Float sample_dimension(uint64_t index, int64_t dim) const;
+    void start_pixel(Point2i p); Float get_1d(); Point2f get_2d(); bool start_next_sample(); bool set_sample_number(int64_t sample_num);
+    CameraSample get_camera_sample(Point2i p_raster);      // Sampler::get_camera_sample (sampler.rs:85-95); the enum's Sobol arm forwards get_1d / get_2d
+};
 // forward declarations (Rust resolves names in any order)
 Float gamma(int32_t n); Float next_float_up(Float v); Float next_float_down(Float v);
 Float vec3_max_componentf(const Vector3f& v); size_t vec3_max_dimensionf(const Vector3f& v);
@@ -117,9 +155,10 @@ Vector3f operator+(const Vector3f& a, const Vector3f& b); Vector3f operator*(con
 """
 
 TYPES = dict(base.TYPES)
-TYPES.update({"f32": "Float", "f64": "double", "u8": "uint8_t", "Point3f": "Point3f", "Normal3f": "Normal3f", "&Point3f": "const Point3f&", "&Normal3f": "const Normal3f&",
+TYPES.update({"i64": "int64_t", "i32": "int32_t", "u64": "uint64_t", "usize": "size_t", "f32": "Float", "f64": "double", "u8": "uint8_t", "Point3f": "Point3f", "Normal3f": "Normal3f", "&Point3f": "const Point3f&", "&Normal3f": "const Normal3f&",
               "&Ray": "const Ray&", "&mut Vector3f": "Vector3f*", "&[u8; 3]": "const uint8_t*", "RGBSpectrum": "RGBSpectrum",
-              "&mut SurfaceInteraction": "SurfaceInteraction*", "u32": "uint32_t", "LinearBVHNode": "LinearBVHNode"})
+              "&mut SurfaceInteraction": "SurfaceInteraction*", "u32": "uint32_t", "LinearBVHNode": "LinearBVHNode",
+              "Point2i": "Point2i", "&Point2i": "const Point2i&", "Vector2i": "Vector2i", "CameraSample": "CameraSample", "XYEnum": "XYEnum", "&Point2f": "const Point2f&"})
 
 # (file, search-from regex or None, first-line regex, name, class or None, cut-before regex or None, explicit signature or None, appended epilogue or None, extra rule set)
 TRI_SIG = "bool Triangle::%s(const Ray& ray, Float* t_out, Float* b_out) const {\n"
@@ -157,6 +196,21 @@ SOURCES = [
     ("core/primitive.rs", r"^impl GeometricPrimitive \{", r"^    pub fn intersect_p\(&self, r: &Ray\) -> bool \{", "intersect_p", "GeometricPrimitive", None, None, None, ()),
     ("accelerators/bvh.rs", None, r"^    pub fn intersect\(&self, ray: &Ray, isect: &mut SurfaceInteraction\) -> bool \{", "intersect", "BVHAccel", None, None, None, ()),
     ("accelerators/bvh.rs", None, r"^    pub fn intersect_p\(&self, ray: &Ray\) -> bool \{", "intersect_p", "BVHAccel", None, None, None, ()),
+    ("core/pbrt.rs", None, r"^pub fn round_up_pow2_32\(", "round_up_pow2_32", None, None, None, None, ("int",)),
+    ("core/pbrt.rs", None, r"^pub fn log_2_int_u32\(", "log_2_int_u32", None, None, None, None, ("int",)),
+    ("core/geometry.rs", None, r"^impl_op_ex!\(-\|a: &Point2i, b: &Point2i\| -> Vector2i \{", "operator-", None, None, None, None, ("int",)),
+    ("core/geometry.rs", None, r"^impl_op_ex!\(\+\|a: &Point2f, b: &Point2f\| -> Point2f \{", "operator+", None, None, None, None, ("int",)),
+    ("core/geometry.rs", r"^impl Bounds2i \{", r"^    pub fn diagonal\(&self\) -> Vector2i \{", "diagonal", "Bounds2i", None, None, None, ()),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn sobol_interval_to_index\(", "sobol_interval_to_index", None, None, None, None, ("int",)),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn sobol_sample\(", "sobol_sample", None, None, None, None, ("int",)),
+    ("samplers/sobol.rs", None, r"^    pub fn get_index_for_sample\(&self", "get_index_for_sample", "SobolSampler", None, None, None, ("int",)),
+    ("samplers/sobol.rs", None, r"^    pub fn sample_dimension\(&self", "sample_dimension", "SobolSampler", None, None, None, ("int",)),
+    ("samplers/sobol.rs", None, r"^    pub fn start_pixel\(&mut self", "start_pixel", "SobolSampler", None, None, None, ("int",)),
+    ("samplers/sobol.rs", None, r"^    pub fn get_1d\(&mut self", "get_1d", "SobolSampler", None, None, None, ("int",)),
+    ("samplers/sobol.rs", None, r"^    pub fn get_2d\(&mut self", "get_2d", "SobolSampler", None, None, None, ("int",)),
+    ("samplers/sobol.rs", None, r"^    pub fn start_next_sample\(&mut self", "start_next_sample", "SobolSampler", None, None, None, ("int",)),
+    ("samplers/sobol.rs", None, r"^    pub fn set_sample_number\(&mut self", "set_sample_number", "SobolSampler", None, None, None, ("int",)),
+    ("core/sampler.rs", None, r"^    pub fn get_camera_sample\(&mut self", "get_camera_sample", "SobolSampler", None, None, None, ("int",)),
     ("core/sampling.rs", None, r"^pub fn power_heuristic\(", "power_heuristic", None, None, None, None, ()),
     ("core/sampling.rs", None, r"^pub fn cosine_sample_hemisphere\(", "cosine_sample_hemisphere", None, None, None, None, ()),
     ("core/sampling.rs", None, r"^pub fn uniform_sample_hemisphere\(", "uniform_sample_hemisphere", None, None, None, None, ()),
@@ -270,6 +324,25 @@ RULES_PRE = [
     (r"let (\w+) = if ([^{}]*?) \{ ([^{};]*?) \} else \{ ([^{};]*?) \};", r"auto \1 = (\2) ? Float(\3) : Float(\4);", 0),
     (r"\bloop \{", "for (;;) {", 0),
     (r"\bmut self\b", "self", 0),
+]
+RULES_INT = [
+    # G15 integer casts, suffixes and methods of the sampler code:  `x as i64` / `f() as i64` / `(e) as i64` (the last by G1), `31_i32`, `v.leading_zeros()`, `a.max(b)` on i32
+    (r"\b(\w+) & (\w+) > 0_u64", r"((\1 & \2) > 0)", 0),
+    (r"(this->[\w.]+) as Float\b", r"Float(\1)", 0),
+    (r"\b(\d+)_i64\b", r"\1ll", 0), (r"\b(\d+)_usize\b", r"\1", 0),
+    (r"((?:this->)?[\w.]+(?:\[\w+\])?(?:\(\))?) as (i64|i32|u64|u32|usize)\b", lambda m: "(%s)(%s)" % (TYPES[m.group(2)], m.group(1)), 0),
+    (r"((?:this->)?[\w.]+\[\w+\]) as Float\b", r"Float(\1)", 0),
+    (r"(\w+)\.leading_zeros\(\)", r"rs_leading_zeros(\1)", 0),
+    (r"\bpanic!\(.*?\);", "", re.S),
+    # G16 counted loops up to an expression:  `for i in 0..E {`
+    (r"for (\w+) in 0\.\.([^{]+?) \{", r"for (auto \1 = decltype(\2)(0); \1 < (\2); \1++) {", 0),
+    # G17 struct literals of the integer points, the field-init shorthand `Point2f { x, y }`, and CameraSample's three fields in their written order
+    (r"\b(Point2i|Vector2i) \{\s*x: ([^{}]*?),\s*y: ([^{}]*?),?\s*\}", r"\1{\2, \3}", re.S),
+    (r"\bPoint2f \{ x, y \}", "Point2f{x, y}", 0),
+    (r"let (\w+): XYEnum = match (\w+) \{\s*0 => (.*?),\s*_ => (.*?),\s*\};", r"XYEnum \1 = (\2 == 0) ? \3 : \4;", re.S),
+]
+RULES_POST = [
+    (r"CameraSample \{\s*p_film: (.*?),\s*time: (.*?),\s*p_lens: (.*?),?\s*\};", r"CameraSample{\1, \2, \3};", re.S),
 ]
 RULES_RNG = [
     # G11 wrapping integer arithmetic (rng.rs):  `let (x, _overflow) = A.overflowing_OP(B);`  — C++ unsigned arithmetic wraps; Rust's overflowing shifts mask the count
@@ -394,14 +467,19 @@ def convert_parts():
                 body = body.rstrip()[:-1]      # the brace added for the signature parser
         if sig_override:
             sig = sig_override
-        for pat, rep, flags in RULES_PRE + (RULES_RNG if "rng" in extra else []):
+        for pat, rep, flags in (RULES_INT if "int" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
             body = re.sub(pat, rep, body, flags=flags)
         body = cast_after_parens(body, "Float", "Float(%s)")
         body = cast_after_parens(body, "usize", "(size_t)(%s)")
         body = cast_after_parens(body, "u8", "(uint8_t)(%s)")
+        if "int" in extra:
+            for ty in ("i64", "i32", "u64", "u32"):
+                body = cast_after_parens(body, ty, "(" + TYPES[ty] + ")(%s)")
         for pat, rep, flags in base.RULES:
             body = re.sub(pat, rep, body, flags=flags)
-        body = re.sub(r"\blet (?:mut )?(\w+): (f64|f32|u32|u8|Point3f|Normal3f|MinMaxEnum) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+        for pat, rep, flags in RULES_POST:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = re.sub(r"\blet (?:mut )?(\w+): (f64|f32|u32|u8|u64|i64|i32|usize|Point3f|Normal3f|MinMaxEnum|Point2i|Vector2i|CameraSample|Point2f) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
         body = base.shadowing(body, set(params) | set(FN_NAMES))
         if epilogue:
             body = body.rstrip() + "\n" + epilogue
@@ -502,6 +580,26 @@ void g_bvh(int any, const float* bounds, const int32_t* offset, const int32_t* n
     }
     delete[] nodes; delete[] pts; delete[] prims;
 }
+void g_set_tables(const uint32_t* sobol32, const uint64_t* vdc, const uint64_t* vdc_inv) { SOBOL_MATRICES_32 = sobol32; VD_C_SOBOL_MATRICES.p = vdc; VD_C_SOBOL_MATRICES_INV.p = vdc_inv; }
+// the render loop's use of the sampler (integrator.rs:134-175): start_pixel, then per sample get_camera_sample, the path's draws (get_1d, get_2d, get_2d per bounce), start_next_sample
+void g_sobol(const int64_t* spp, const int32_t* bounds, const int32_t* pixel, uint64_t n, float* out) {   // out: n x 4 samples x 26
+    for (uint64_t i = 0; i < n; i++) {
+        SobolSampler s = SobolSampler::make(spp[i], Bounds2i{Point2i{bounds[4 * i], bounds[4 * i + 1]}, Point2i{bounds[4 * i + 2], bounds[4 * i + 3]}});
+        const Point2i p{pixel[2 * i], pixel[2 * i + 1]};
+        s.start_pixel(p);
+        for (int k = 0; k < 4; k++) {
+            float* o = out + (4 * i + k) * 26;
+            const CameraSample cs = s.get_camera_sample(p);
+            o[0] = cs.p_film.x.v; o[1] = cs.p_film.y.v; o[2] = cs.time.v; o[3] = cs.p_lens.x.v; o[4] = cs.p_lens.y.v;
+            for (int b = 0; b < 4; b++) {
+                o[5 + 5 * b] = s.get_1d().v;
+                const Point2f u = s.get_2d(), w = s.get_2d();
+                o[6 + 5 * b] = u.x.v; o[7 + 5 * b] = u.y.v; o[8 + 5 * b] = w.x.v; o[9 + 5 * b] = w.y.v;
+            }
+            o[25] = s.start_next_sample() ? 1.0f : 0.0f;
+        }
+    }
+}
 void g_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {   // per sequence: 4 words, 2 floats, 2 bounded draws
     for (uint64_t i = 0; i < n; i++) {
         Rng r; r.set_sequence(seq[i]);
@@ -601,6 +699,16 @@ def inputs(n=1 << 12, seed=0x6E0A):
     d["mf_wo"] = wo; d["mf_wh"] = wh
     d["mf_ax"] = rng.uniform(0.001, 1.6, n).astype(f32)
     d["mf_ay"] = np.where(rng.uniform(size=n) < 0.5, d["mf_ax"], rng.uniform(0.001, 1.6, n).astype(f32)).astype(f32)
+    # the Sobol' sampler as the render loop drives it: power-of-two spp, full-frame and cropped sample bounds (p_min != 0), pixels incl. the bounds' corners
+    n_all, n = n, max(n // 4, 16)          # (104 floats per case: a quarter of the cases keeps the committed file small)
+    d["sob_spp"] = rng.choice(np.array([1, 4, 64, 1024, 4096], np.int64), n)
+    x0 = rng.integers(0, 64, n) * (rng.uniform(size=n) < 0.5); y0 = rng.integers(0, 64, n) * (rng.uniform(size=n) < 0.5)
+    w = rng.choice([1, 16, 400, 1024, 1920], n); h = rng.choice([1, 16, 400, 1024, 1080], n)
+    d["sob_bounds"] = np.stack([x0, y0, x0 + w, y0 + h], 1).astype(np.int32)
+    px = x0 + rng.integers(0, 1 << 30, n) % w; py = y0 + rng.integers(0, 1 << 30, n) % h
+    px[:8] = x0[:8]; py[:8] = y0[:8]; px[8:16] = (x0 + w - 1)[8:16]; py[8:16] = (y0 + h - 1)[8:16]
+    d["sob_pixel"] = np.stack([px, py], 1).astype(np.int32)
+    n = n_all
     # PCG32
     d["rng_seq"] = rng.integers(0, 1 << 63, n, dtype=np.uint64); d["rng_seq"][:4] = [0, 1, 2, (1 << 64) - 1]
     b = rng.integers(1, 1 << 31, n).astype(np.uint32); b[: n // 2] = rng.integers(1, 4096, n // 2); b[:8] = [1, 2, 3, 4, 5, 7, 8, 4096]
@@ -677,7 +785,7 @@ def run_reference(L, d):
     P = lambda a: np.ascontiguousarray(a).ctypes.data
     keep = []
 
-    def call(fn, ins, shape, dtype=np.float32, pre=()):
+    def call(fn, ins, shape, dtype=np.float32, pre=(), n=n):
         o = np.zeros(shape, dtype)
         f = getattr(L, fn)
         f.restype = None
@@ -707,6 +815,15 @@ def run_reference(L, d):
     out["tri_out"] = call("g_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5), pre=(0,))
     out["trp_out"] = call("g_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5), pre=(1,))
     out["mf_out"] = call("g_microfacet", [d["mf_wo"], d["mf_wh"], d["mf_ax"], d["mf_ay"]], (n, 5))
+    blob = open(os.path.join(ROOT, "rs_pbrt_amd", "data", "sobol_tables.bin"), "rb").read()     # tests/test_reference_tables.py holds this file to sobolmatrices.rs byte for byte
+    words = np.frombuffer(blob, "<u4", 1024 * 52, 16).copy(); vdc = np.frombuffer(blob, "<u8", 25 * 52, 16 + 4 * 1024 * 52).copy()
+    vdc_inv = np.frombuffer(blob, "<u8", 26 * 52, 16 + 4 * 1024 * 52 + 8 * 25 * 52).copy()
+    keep.extend([words, vdc, vdc_inv])
+    L.g_set_tables.restype = None
+    L.g_set_tables.argtypes = [C.c_void_p] * 3
+    L.g_set_tables(words.ctypes.data, vdc.ctypes.data, vdc_inv.ctypes.data)
+    L.keep_alive = keep
+    out["sob_out"] = call("g_sobol", [d["sob_spp"], d["sob_bounds"], d["sob_pixel"]], (len(d["sob_spp"]), 4, 26), n=len(d["sob_spp"]))
     ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
     L.g_rng.restype = None
     L.g_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]

@@ -523,6 +523,27 @@ void orc_geom_microfacet(const float* wo, const float* wh, const float* ax, cons
         out[5 * i] = t.d(h); out[5 * i + 1] = t.lambda(a); out[5 * i + 2] = t.g1(a); out[5 * i + 3] = t.g(a, h); out[5 * i + 4] = t.pdf(a, h);
     }
 }
+void orc_geom_sobol(const rspt_sampler_tables* t, const int64_t* spp, const int32_t* bounds, const int32_t* pixel, uint64_t n, float* out) {   // the tile loop's draws (orc_render.hpp render)
+    for (uint64_t i = 0; i < n; i++) {
+        SobolSampler s(SobolTables{t->sobol32, t->vdc, t->vdc_inv}, spp[i], bounds + 4 * i);
+        const int32_t px = pixel[2 * i], py = pixel[2 * i + 1];
+        s.start_pixel(px, py);
+        for (int k = 0; k < 4; k++) {
+            float* o = out + (4 * i + k) * 26;
+            const P2 f2 = s.get_2d();
+            o[0] = (Float)px + f2.x; o[1] = (Float)py + f2.y;   // sampler.rs:85-95
+            o[2] = s.get_1d();
+            const P2 lens = s.get_2d();
+            o[3] = lens.x; o[4] = lens.y;
+            for (int b = 0; b < 4; b++) {
+                o[5 + 5 * b] = s.get_1d();
+                const P2 u = s.get_2d(), w = s.get_2d();
+                o[6 + 5 * b] = u.x; o[7 + 5 * b] = u.y; o[8 + 5 * b] = w.x; o[9 + 5 * b] = w.y;
+            }
+            o[25] = s.start_next_sample() ? 1.0f : 0.0f;
+        }
+    }
+}
 void orc_geom_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {
     for (uint64_t i = 0; i < n; i++) {
         Rng r; r.set_sequence(seq[i]);

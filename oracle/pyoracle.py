@@ -311,6 +311,15 @@ def geom(d):
         "tri_out": call("orc_geom_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5)),
         "mf_out": call("orc_geom_microfacet", [d["mf_wo"], d["mf_wh"], d["mf_ax"], d["mf_ay"]], (n, 5)),
     }
+    from rs_pbrt_amd import scenes
+    tables = scenes.sobol_tables().as_struct(None)
+    L.orc_geom_sobol.restype = None
+    L.orc_geom_sobol.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
+    ns = len(d["sob_spp"])
+    so = np.zeros((ns, 4, 26), np.float32)
+    spp, bounds, pixel = np.ascontiguousarray(d["sob_spp"], np.int64), np.ascontiguousarray(d["sob_bounds"], np.int32), np.ascontiguousarray(d["sob_pixel"], np.int32)
+    L.orc_geom_sobol(C.addressof(tables), spp.ctypes.data, bounds.ctypes.data, pixel.ctypes.data, ns, so.ctypes.data)
+    out["sob_out"] = so
     out["trp_out"] = out["tri_out"]      # Triangle::intersect_p repeats intersect's watertight test (triangle.rs:450-591); the oracle shares one function
     ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
     L.orc_geom_rng.restype = None

@@ -22,7 +22,8 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "y_out": "RGBSpectrum::y", "csh_out": "cosine_sample_hemisphere", "ush_out": "uniform_sample_hemisphere", "crs_out": "vec3_cross_vec3", "cs_out": "vec3_coordinate_system",
          "rfl_out": "reflect", "rfr_out": "refract", "adt_out": "vec3_abs_dot_vec3f", "oro_out": "pnt3_offset_ray_origin", "box_out": "Bounds3f::intersect_p",
          "tri_out": "Triangle::intersect (watertight test)", "trp_out": "Triangle::intersect_p (watertight test)", "mf_out": "TrowbridgeReitzDistribution d / lambda / g1 / g / pdf",
-         "rng_u_out": "Rng uniform_uint32 / _bounded", "rng_f_out": "Rng::uniform_float"}
+         "rng_u_out": "Rng uniform_uint32 / _bounded", "rng_f_out": "Rng::uniform_float",
+         "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample"}
 
 
 def differing(a, b):
@@ -55,6 +56,9 @@ def test_oracle_equals_the_references_text_on_the_committed_fixture(oracle):
     assert (g["rfr_out"][:, 3] == 0).sum() > 50                                           # total internal reflection
     assert (g["mf_out"][:16, 0] > 0).all() and (g["mf_out"][16:24, 1] == 0).all()         # D at normal incidence, lambda at grazing incidence (infinite tangent)
     assert (g["oro_out"] != g["oro_p"]).any(axis=1).mean() > 0.9                          # the offset moved the origin, rounded away from it
+    sob = g["sob_out"]
+    assert ((sob[:, :, 0] >= g["sob_pixel"][:, None, 0]) & (sob[:, :, 0] < g["sob_pixel"][:, None, 0] + 1)).all()     # the film sample lies in its pixel (the remap of dimensions 0 / 1)
+    assert (sob[:, :, 25] == 0).any() and (sob[:, :, 25] == 1).any() and (g["sob_bounds"][:, :2] != 0).any()           # the last sample of a pixel; cropped sample bounds
 
 
 def oracle_traversal(oracle, sc, o, d, tmax):
