@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — the CONTROL FLOW of the path integrator pinned by the reference's OWN TEXT (round 6, third session).
+
+oracle/make_leaf_fixtures.py and oracle/make_geom_fixtures.py pin leaf arithmetic, the traversal and the sampler.  What they cannot reach is the body of
+`PathIntegrator::li` (integrators/path.rs:59-282) and of `uniform_sample_one_light` (core/integrator.rs:359-403): which terms a path adds in which order, when it stops,
+what it draws from the sampler and when, how Russian roulette is decided — trait objects and containers all the way down.  This script compiles THAT text too, by the
+same committed rewrite rules, over CARRIERS that give the reference's method names (scene.intersect, isect.le, isect.compute_scattering_functions, bsdf.sample_f,
+light_distribution.lookup, estimate_direct, sampler.get_1d ..) to the ORACLE's leaf functions (oracle/orc_*.hpp, header-only, included by the generated file).  The result,
+oracle/_ref/libflowref.so (git-ignored), renders through the oracle's own tile loop with `li` = the reference's text.  tests/test_reference_flow.py: the radiance of
+every camera sample equals the oracle's own li bit for bit on scenes with area / point / infinite lights, specular and rough transmission (eta_scale), null-material
+surfaces (the `continue` that skips `bounces += 1`), depths past the roulette threshold.
+
+One block of li is dropped by rule F1, not compiled: the subsurface branch (path.rs:195-259: `if let Some(ref bssrdf) = isect.bssrdf`) — no material in scope creates a
+BSSRDF, and the oracle has none to delegate to.  usage: python oracle/make_flow_fixtures.py [--build-only]
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+import make_leaf_fixtures as base  # noqa: E402
+import make_geom_fixtures as geom  # noqa: E402
+
+REF = geom.REF
+OUT_DIR = base.OUT_DIR
+
+CARRIERS = r"""
+// ---- carriers of the path integrator's control flow: the reference's names over the oracle's leaf functions (namespace orc, oracle/orc_*.hpp).  No arithmetic here
+// beyond element-wise Spectrum operators (core/spectrum.rs: every operator of RGBSpectrum is element-wise) ----
+static inline Spectrum& operator+=(Spectrum& a, const Spectrum& b) { a = a + b; return a; }
+static inline Spectrum& operator*=(Spectrum& a, const Spectrum& b) { a = a * b; return a; }
+static inline Spectrum& operator/=(Spectrum& a, Float b) { a = a / b; return a; }
+static inline Spectrum spectrum_default() { return Spectrum::new_(Float(0.0f)); }                     // #[derive(Default)]: zeros
+static inline Vector3f vector3f_default() { return Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
+static inline bool spectrum_is_black(const Spectrum& s) { return !(s.c[0] != Float(0.0f) || s.c[1] != Float(0.0f) || s.c[2] != Float(0.0f)); }   // spectrum.rs is_black
+static inline Float spectrum_max_component_value(const Spectrum& s) { return s.c[0].max(s.c[1].max(s.c[2])); }                                  // spectrum.rs max_component_value
+Float vec3_abs_dot_nrmf(const Vector3f& v1, const Normal3f& n2);
+namespace flow {
+static inline orc::V3 V(const Vector3f& v) { return orc::V3{v.x.v, v.y.v, v.z.v}; }
+static inline orc::V3 V(const Point3f& v) { return orc::V3{v.x.v, v.y.v, v.z.v}; }
+static inline Vector3f Vf(orc::V3 v) { return Vector3f{Float(v.x), Float(v.y), Float(v.z)}; }
+static inline Point3f Pf(orc::V3 v) { return Point3f{Float(v.x), Float(v.y), Float(v.z)}; }
+static inline Normal3f Nf(orc::V3 v) { return Normal3f{Float(v.x), Float(v.y), Float(v.z)}; }
+static inline Spectrum Sf(const orc::Spec& s) { Spectrum r; for (int i = 0; i < 3; i++) r.c[i] = Float(s.c[i]); return r; }
+static inline orc::Spec So(const Spectrum& s) { return orc::Spec(s.c[0].v, s.c[1].v, s.c[2].v); }
+static inline Ray to_ref(const orc::Ray& r) {
+    Ray o; o.o = Pf(r.o); o.d = Vf(r.d); o.t_max.v = Float(r.t_max); o.time = Float(r.time);
+    o.differential = RayDifferential{r.has_diff, Pf(r.rx_o), Pf(r.ry_o), Vf(r.rx_d), Vf(r.ry_d)}; o.medium = MediumRef{r.medium};
+    return o;
+}
+static inline orc::Ray to_orc(const Ray& r) {
+    orc::Ray o{V(r.o), V(r.d), r.t_max.get().v, r.time.v};
+    o.has_diff = r.differential.some; o.rx_o = V(r.differential.rx_origin); o.ry_o = V(r.differential.ry_origin); o.rx_d = V(r.differential.rx_direction); o.ry_d = V(r.differential.ry_direction);
+    o.medium = r.medium.id;
+    return o;
+}
+template <class T> struct Option { bool some; T v; bool is_some() const { return some; } T& unwrap() { return v; } const T& unwrap() const { return v; } };
+template <class T> static inline Option<T> Some(const T& v) { return Option<T>{true, v}; }
+enum class TransportMode { Radiance, Importance };
+enum class BxdfType : uint8_t { BsdfReflection = 1, BsdfTransmission = 2, BsdfDiffuse = 4, BsdfGlossy = 8, BsdfSpecular = 16, BsdfAll = 31 };   // reflection.rs:57-64
+struct Scene;
+struct Bsdf {                                   // reflection.rs Bsdf: the oracle's lobe list behind the reference's method names
+    const orc::Bsdf* b; Float eta;
+    uint8_t num_components(uint8_t flags) const { return (uint8_t)b->num_components(flags); }
+    Spectrum sample_f(const Vector3f& wo, Vector3f* wi, const Point2f& u, Float* pdf, uint8_t flags, uint8_t* sampled_type) const {
+        orc::V3 w{0, 0, 0}; float p = pdf->v;
+        const orc::Spec f = b->sample_f(V(wo), &w, orc::P2{u.x.v, u.y.v}, &p, flags, sampled_type);
+        *wi = Vf(w); *pdf = Float(p);
+        return Sf(f);
+    }
+};
+struct Bssrdf {};
+struct Common { Point3f p; Normal3f n; };
+struct Shading { Normal3f n; };
+struct SurfaceInteraction {
+    orc::Interaction it; orc::Bsdf store; const Scene* scene = nullptr;
+    Option<Bsdf> bsdf{false, Bsdf{nullptr, Float(0.0f)}}; Option<Bssrdf> bssrdf{false, Bssrdf{}}; Common common; Shading shading;
+    static SurfaceInteraction default_() { return SurfaceInteraction{}; }
+    void refresh() { common.p = Pf(it.p); common.n = Nf(it.n); shading.n = Nf(it.sh_n); }
+    Spectrum le(const Vector3f& w) const;                                                    // interaction.rs:475-483
+    void compute_scattering_functions(const Ray& ray, bool allow_multiple_lobes, TransportMode mode);   // interaction.rs:371-386
+    Ray spawn_ray(const Vector3f& d) const { return to_ref(it.spawn_ray(V(d))); }             // interaction.rs:58-94
+};
+struct LightRef { const Scene* scene; uint32_t index; Spectrum le(const Ray& ray) const; };
+struct LightList { std::vector<LightRef> v; size_t len() const { return v.size(); } const LightRef& operator[](size_t i) const { return v[i]; } auto begin() const { return v.begin(); } auto end() const { return v.end(); } };
+struct Scene {
+    orc::RenderCtx* cx; orc::Counters* c; LightList lights, infinite_lights;
+    bool intersect(const Ray& ray, SurfaceInteraction* isect) const {
+        const orc::Ray r = to_orc(ray);
+        const bool hit = cx->scene->intersect(r, &isect->it, c);
+        ray.t_max.set(Float(r.t_max));                 // the Cell the reference's primitives write through
+        isect->scene = this;
+        if (hit) isect->refresh();
+        return hit;
+    }
+};
+inline Spectrum SurfaceInteraction::le(const Vector3f& w) const {
+    const rspt_prim& hp = scene->cx->scene->hit_prim(it);
+    return hp.area_light >= 0 ? Sf(orc::light_l(scene->cx->scene->d.lights[hp.area_light], it.n, V(w))) : spectrum_default();
+}
+inline void SurfaceInteraction::compute_scattering_functions(const Ray& ray, bool allow_multiple_lobes, TransportMode) {
+    const orc::Scene& sc = *scene->cx->scene;
+    const rspt_prim& hp = sc.hit_prim(it);
+    if (hp.material == 0xffffffffu) { bsdf.some = false; return; }       // a primitive without a material: no BSDF (primitive.rs:230-243)
+    orc::compute_differentials(&it, to_orc(ray));
+    orc::make_bsdf(sc, it, hp.material, allow_multiple_lobes, &store);
+    if (scene->c) scene->c->bounces++;
+    bsdf = Option<Bsdf>{true, Bsdf{&store, Float(store.eta)}};
+    refresh();
+}
+inline Spectrum LightRef::le(const Ray& ray) const { return Sf(orc::infinite_le(*scene->cx->scene, scene->cx->scene->d.lights[index], V(ray.d))); }
+struct Distribution1D {
+    const orc::Distribution1D* d;
+    size_t sample_discrete(Float u, Option<Float*> pdf) const { float p = 0.0f; const size_t i = d->sample_discrete(u.v, &p); if (pdf.some) *pdf.v = Float(p); return i; }
+};
+struct OptFloat { bool some; Float v; Option<Float*> as_mut() { return Option<Float*>{some, &v}; } Float unwrap() const { return v; } };
+static inline OptFloat SomeFloat(Float v) { return OptFloat{true, v}; }
+struct LightDistribution { orc::RenderCtx* cx; Distribution1D lookup(const Point3f& p) const { return Distribution1D{cx->scene->d.n_lights ? orc::light_lookup(*cx, V(p)) : nullptr}; } };
+struct Sampler {
+    orc::Sampler* s;
+    Float get_1d() { return Float(s->get_1d()); }
+    Point2f get_2d() { const orc::P2 p = s->get_2d(); return Point2f{Float(p.x), Float(p.y)}; }
+};
+// estimate_direct (integrator.rs:406-570) is the oracle's here: the MIS estimate for the chosen light
+static inline Spectrum estimate_direct(const SurfaceInteraction& it, Point2f u_scattering, const LightRef& light, Point2f u_light, const Scene& scene, Sampler&, bool, bool) {
+    return Sf(orc::estimate_direct(*scene.cx, it.it, it.store, orc::P2{u_scattering.x.v, u_scattering.y.v}, light.index, orc::P2{u_light.x.v, u_light.y.v}, scene.c));
+}
+Spectrum uniform_sample_one_light(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, bool handle_media, Option<Distribution1D> light_distrib);
+struct PathIntegrator {
+    uint32_t max_depth; Float rr_threshold; Option<LightDistribution> light_distribution;
+    Spectrum li(const Ray& r, const Scene& scene, Sampler& sampler, int32_t _depth) const;
+};
+}  // namespace flow
+"""
+
+TYPES = dict(geom.TYPES)
+TYPES.update({"&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
+              "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
+
+RULES_FLOW = [
+    # F2  generic containers in a declaration:  `let x: Arc<T> = E;` / `let mut x: Option<Float> = Some(E);`  ->  auto (the carrier's type decides)
+    (r"let (?:mut )?(\w+): Arc<\w+> = ", r"auto \1 = ", 0),
+    (r"let mut (\w+): Option<Float> = Some\((.*?)\);", r"auto \1 = SomeFloat(\2);", 0),
+    # F3  `if let Some([ref] x) = E {`  ->  `if (E.is_some()) { auto& x = E.unwrap();`   (E a place expression);  `Some(&x)` at a call site -> Some(x)
+    (r"if let Some\((?:ref )?(\w+)\) = ((?:this->)?[\w.]+) \{", r"if (\2.is_some()) { const auto& \1 = \2.unwrap();", 0),
+    (r"Some\(&(\w+)\)", r"Some(\1)", 0),
+    # F4  enum values under a cast, integer `!`, u8::max_value()
+    (r"(BxdfType::\w+) as u8", r"(uint8_t)(\1)", 0),
+    (r"& !\(", "& ~(", 0),
+    (r"u8::max_value\(\)", "255", 0),
+    # F5  borrows of temporaries and iteration over a borrowed list
+    (r"&-(\w)", r"-\1", 0),
+    (r"for (\w+) in &([\w.]+) \{", r"for (const auto& \1 : \2) {", 0),
+    (r"let (\w+) = &([\w.]+\[\w+\]);", r"const auto& \1 = \2;", 0),
+    # F6  the six-field copy of a Ray, Spectrum's associated functions and methods (carried as free functions: the base prelude's Spectrum is a plain aggregate)
+    (r"Ray \{\s*o: (.*?),\s*d: (.*?),\s*t_max: (.*?),\s*time: (.*?),\s*differential: (.*?),\s*medium: (.*?),\s*\}", r"Ray{\1, \2, \3, \4, \5, \6}", re.S),
+    (r"Spectrum::default\(\)", "spectrum_default()", 0),
+    (r"Vector3f::default\(\)", "vector3f_default()", 0),
+    (r"\b([\w.]+)\.is_black\(\)", r"spectrum_is_black(\1)", 0),
+    (r"\b([\w.]+)\.max_component_value\(\)", r"spectrum_max_component_value(\1)", 0),
+    (r"std::cmp::min\(", "std::min<size_t>(", 0),
+    (r"\b(\d+)_usize\b", r"\1", 0),
+]
+
+
+def drop_block(body, head):
+    """F1: remove the statement `head { .. }` (to its matching brace); comment lines are gone by then"""
+    i = body.index(head)
+    j = geom.matching(body, body.index("{", i), "{", "}")
+    return body[:body.rfind("\n", 0, i)] + body[j + 1:]
+
+
+SOURCES = [
+    ("core/geometry.rs", r"^pub fn vec3_abs_dot_nrmf\(", "vec3_abs_dot_nrmf", None, False),
+    ("core/integrator.rs", r"^pub fn uniform_sample_one_light\(", "uniform_sample_one_light", None, True),
+    ("integrators/path.rs", r"^    pub fn li\(", "li", "PathIntegrator", True),
+]
+
+
+def convert_parts():
+    parts, where = geom.convert_parts()
+    parts.insert(0, '#include "../orc_render.hpp"   // the oracle (header-only, namespace orc): the leaf functions the carriers below delegate to\n')
+    parts.append(CARRIERS)
+    geom.TYPES.update(TYPES); base.TYPES.update(TYPES)
+    for fname, first_re, name, cls, in_flow in SOURCES:
+        text, l0, l1 = geom.extract(fname, None, first_re, None)
+        text = re.sub(r"^\s*//.*\n", "", text, flags=re.M)                      # (comment lines sit inside li's argument list)
+        sig, body, params = geom.signature(text, name, cls)
+        if name == "li":
+            body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
+        for pat, rep, flags in RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = geom.cast_after_parens(body, "Float", "Float(%s)")
+        body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|usize|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+        body = re.sub(r"\blet (\w+): (usize|Float);", lambda m: "%s %s;" % (TYPES[m.group(2)], m.group(1)), body)
+        body = base.shadowing(body, set(params) | set(geom.FN_NAMES) | {"li"})
+        body = geom.tail_value(body)
+        code = "// %s%s:%d-%d\n%s%s" % (REF, fname, l0, l1, sig, body)
+        parts.append("namespace flow {\n%s}\n" % code if in_flow else code)
+        where.append("%s%s %s:%d-%d" % ((cls + "::") if cls else "", name, fname, l0, l1))
+    parts.append(r"""
+namespace flow {
+static orc::Spec li_from_the_references_text(orc::RenderCtx& cx, const orc::Ray& ray, orc::Sampler& sampler, orc::Counters* c) {
+    Scene scene{&cx, c, {}, {}};
+    for (uint32_t i = 0; i < cx.scene->d.n_lights; i++) {
+        scene.lights.v.push_back(LightRef{&scene, i});
+        if (cx.scene->d.lights[i].kind == RSPT_LIGHT_INFINITE) scene.infinite_lights.v.push_back(LightRef{&scene, i});      // Scene::new scene.rs:40-43
+    }
+    const PathIntegrator integrator{cx.rd->max_depth, Float(cx.rd->rr_threshold), Option<LightDistribution>{true, LightDistribution{&cx}}};
+    Sampler s{&sampler};
+    return So(integrator.li(to_ref(ray), scene, s, 0));
+}
+}
+extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {
+    if (!sd || !rd) return -1;
+    orc::g_li_override = use_text ? flow::li_from_the_references_text : nullptr;
+    orc::Scene sc{*sd};
+    orc::RenderOut out;
+    orc::render(sc, *rd, num_threads, film_xyzw, li_rgb, &out);
+    return 0;
+}
+""")
+    return parts, where
+
+
+def convert():
+    parts, where = convert_parts()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cpp = os.path.join(OUT_DIR, "flow_functions.cpp")
+    open(cpp, "w").write("\n".join(parts))
+    so = os.path.join(OUT_DIR, "libflowref.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-function",
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-o", so, cpp])
+    return C.CDLL(so), where
+
+
+def render(L, scene, rd, use_text, threads=4):
+    """per-sample radiance (cropped pixels x spp x 3) of the oracle's tile loop with li = the reference's text (use_text) or the oracle's own path_li"""
+    import numpy as np
+    cw, ch = rd.crop_px[2] - rd.crop_px[0], rd.crop_px[3] - rd.crop_px[1]
+    film = np.zeros((cw * ch, 4), np.float32)
+    li = np.zeros((cw * ch, int(rd.spp), 3), np.float32)
+    L.flow_render.restype = C.c_int
+    L.flow_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    rc = L.flow_render(C.addressof(scene.desc), C.addressof(rd), threads, film.ctypes.data, li.ctypes.data, int(use_text))
+    assert rc == 0
+    return film, li
+
+
+def main():
+    L, where = convert()
+    for w in where[-3:]:
+        print("compiled from", w)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -40,7 +40,9 @@ OUT_DIR = base.OUT_DIR
 FIXTURE = os.path.join(ROOT, "tests", "golden", "geom_functions.npz")
 
 # ---- carriers added to the base prelude (no arithmetic: selectors, bit casts, constants) ----
-FLOAT_EXTRA = """    explicit operator double() const { return (double)v; }      // `x as f64`
+FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                             // `n as Float` from usize
+    explicit operator size_t() const { return (size_t)v; }       // `x as usize` (only met with small non-negative values here)
+    explicit operator double() const { return (double)v; }      // `x as f64`
     Float ln() const { return Float(logf(v)); }                  // f32::ln is the platform libm's logf
 """
 VEC3_EXTRA = """    Vector3f abs() const;            // body: the reference's text (geometry.rs:397-403)
@@ -62,8 +64,10 @@ struct Point3f {
 };
 static inline Vector3f operator-(const Vector3f& a) { return Vector3f{Float(-a.x.v), Float(-a.y.v), Float(-a.z.v)}; }   // impl Neg (a sign flip)
 static inline Vector3f Vector3f_from(const Normal3f& n) { return Vector3f{n.x, n.y, n.z}; }                                // impl From<Normal3f> (geometry.rs:616-624)
-struct Cell { mutable Float v; Float get() const { return v; } void set(Float x) const { v = x; } };   // Cell<Float>
-struct Ray { Point3f o; Vector3f d; Cell t_max; };
+struct Cell { mutable Float v; Float get() const { return v; } void set(Float x) const { v = x; } static Cell new_(Float x) { return Cell{x}; } };   // Cell<Float>
+struct RayDifferential { bool some; Point3f rx_origin, ry_origin; Vector3f rx_direction, ry_direction; };   // Option<RayDifferential> (geometry.rs:2408-2414): Copy
+struct MediumRef { uint32_t id; MediumRef clone() const { return *this; } };                               // Option<Arc<Medium>>
+struct Ray { Point3f o; Vector3f d; Cell t_max; Float time; RayDifferential differential; MediumRef medium; };   // geometry.rs:2378-2390
 enum class MinMaxEnum { Min, Max };
 struct Bounds3f {
     Point3f p_min, p_max;

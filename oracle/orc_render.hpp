@@ -1494,6 +1494,9 @@ struct RenderOut {
 };
 
 // ---- SamplerIntegrator::render: src/core/integrator.rs:70-220 ----
+// PathIntegrator::li from somewhere else: oracle/make_flow_fixtures.py compiles the REFERENCE'S TEXT of li (path.rs:59-282) over this oracle's leaf functions and runs it
+// through this tile loop (oracle/_ref/libflowref.so sets the pointer in its own copy of this header-only code; liboracle.so never does)
+inline Spec (*g_li_override)(RenderCtx&, const Ray&, Sampler&, Counters*) = nullptr;
 // film_xyzw: Film.pixels after all merges (xyz + filter_weight_sum per cropped pixel);
 // li_rgb (optional): radiance per camera sample, [(pixel*spp+s)*3] over crop_px.
 static inline void render(const Scene& scene, const rspt_render_desc& rd, int num_threads, float* film_xyzw, float* li_rgb, RenderOut* out,
@@ -1558,6 +1561,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         Spec l = ext_integrator != ORC_INTEGRATOR_FROM_DESC ? recursive_li(cx, ray, sampler, 0, &c)
                                  : rd.integrator == RSPT_INTEGRATOR_AO       ? ao_li(cx, ray, sampler, &c)
                                  : rd.integrator == RSPT_INTEGRATOR_VOLPATH  ? volpath_li(cx, ray, sampler, &c)
+                                 : g_li_override                             ? g_li_override(cx, ray, sampler, &c)
                                                                              : path_li(cx, ray, sampler, &c);
                         c.samples++;
                         if (l.has_nans()) { l = Spec(0.0f); c.nan_samples++; } // integrator.rs:165-173 (Q1)

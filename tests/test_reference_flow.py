@@ -1,0 +1,89 @@
+"""The CONTROL FLOW of the path integrator held to the REFERENCE'S OWN TEXT (round 6, third session).
+
+oracle/make_flow_fixtures.py compiles `PathIntegrator::li` (integrators/path.rs:59-282) and `uniform_sample_one_light` (core/integrator.rs:359-403) from the Rust text —
+syntax rewritten by committed rules, the subsurface block dropped by rule — over carriers that hand the reference's method names to the oracle's leaf functions, and
+renders through the oracle's tile loop with that li.  The oracle's own restatement of li (oracle/orc_render.hpp path_li, which every GPU test is held to sample for
+sample) must give the same radiance for EVERY camera sample, bit for bit: which terms a path adds in which order, when it stops (max_depth, a black f, a zero pdf),
+what it draws from the sampler and when, the null-material `continue` that skips `bounces += 1`, the eta_scale of refraction, Russian roulette from bounce 4 on.
+Needs /root/reference (the text is compiled here; nothing of it is committed): skipped elsewhere — the GPU box holds the HIP path to the oracle, this file holds the
+oracle to the reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from rs_pbrt_amd import abi, scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HAVE_REF = os.path.exists("/root/reference/src/integrators/path.rs")
+pytestmark = pytest.mark.skipif(not HAVE_REF, reason="needs /root/reference to compile the reference's text")
+
+
+@pytest.fixture(scope="module")
+def flow():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_flow_fixtures as mk
+    L, where = mk.convert()
+    assert where[-1] == "PathIntegrator::li integrators/path.rs:59-282" and where[-2] == "uniform_sample_one_light core/integrator.rs:359-403"
+    return mk, L
+
+
+def both(flow, sc, rd):
+    mk, L = flow
+    film_t, li_t = mk.render(L, sc, rd, True)
+    film_o, li_o = mk.render(L, sc, rd, False)
+    return film_t, li_t, film_o, li_o
+
+
+def assert_same(li_t, li_o):
+    a, b = li_t.view(np.uint32), li_o.view(np.uint32)
+    nan = np.isnan(li_t) & np.isnan(li_o)
+    assert np.all((a == b) | nan), "%d of %d camera samples differ" % (int(((a != b) & ~nan).any(axis=-1).sum()), li_t.shape[0] * li_t.shape[1])
+
+
+def test_li_text_equals_the_oracles_li_on_the_cornell_box_past_the_roulette_threshold(flow, oracle):
+    sc = scenes.cornell_box(oracle.bvh_build)
+    rd = scenes.cornell_render_desc(res=48, spp=16, max_depth=12)          # roulette from bounce 4 on (rr_threshold 1)
+    film_t, li_t, film_o, li_o = both(flow, sc, rd)
+    assert_same(li_t, li_o)
+    assert np.array_equal(film_t, film_o) and li_t.mean() > 0.05
+    ref = oracle.render(sc, rd, threads=4, want_li=True)                   # and the library every other test uses gives the same samples
+    assert np.array_equal(ref["li"].reshape(li_o.shape).view(np.uint32), li_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("lights", ["all", "delta", "area"])
+def test_li_text_equals_the_oracles_li_on_the_gallery(flow, oracle, lights):
+    """every material recipe (specular and rough transmission: eta_scale; mixes), area + point + spot + distant lights, all three light strategies"""
+    from tests.util import GALLERY_LOOK_AT, gallery
+    sc = gallery(oracle.bvh_build, lights)
+    for strategy in (abi.LIGHTS_SPATIAL, abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM):
+        rd = scenes.make_render_desc(64, 48, 8, GALLERY_LOOK_AT, 60, max_depth=7, light_strategy=strategy)
+        _, li_t, _, li_o = both(flow, sc, rd)
+        assert_same(li_t, li_o)
+
+
+def test_li_text_equals_the_oracles_li_with_null_surfaces_and_an_infinite_light(flow, oracle):
+    from tests.util import sky_scene
+    cb = scenes.cornell_box(oracle.bvh_build)
+    cb.prims["material"][cb.prims["material"] == 1] = abi.NO_MATERIAL     # a null boundary: passes do not count as bounces (path.rs:109-116)
+    rd = scenes.cornell_render_desc(res=40, spp=8, max_depth=3)
+    _, li_t, _, li_o = both(flow, cb, rd)
+    assert_same(li_t, li_o)
+    for kind in ("constant", "image"):
+        sc = sky_scene(oracle.bvh_build, kind, with_area=True)             # escaped rays add the environment on bounce 0 / after a specular bounce only
+        from tests.util import GALLERY_LOOK_AT
+        rd = scenes.make_render_desc(48, 36, 8, GALLERY_LOOK_AT, 60, max_depth=5)
+        _, li_t, _, li_o = both(flow, sc, rd)
+        assert_same(li_t, li_o)
+
+
+@pytest.mark.parametrize("seed", list(range(101, 117)))
+def test_li_text_equals_the_oracles_li_on_random_scenes(flow, oracle, seed):
+    from tests.util import GALLERY_LOOK_AT, random_scene
+    sc = random_scene(oracle.bvh_build, seed)
+    rd = scenes.make_render_desc(48, 36, 8, GALLERY_LOOK_AT, 55, max_depth=2 + seed % 9, sampler="halton" if seed % 2 else "sobol",
+                                 light_strategy=[abi.LIGHTS_SPATIAL, abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM][seed % 3])
+    _, li_t, _, li_o = both(flow, sc, rd)
+    assert_same(li_t, li_o)
