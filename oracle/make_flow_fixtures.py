@@ -2,7 +2,7 @@
 """TEST INFRASTRUCTURE — the CONTROL FLOW of the path integrator pinned by the reference's OWN TEXT (round 6, third session).
 
 oracle/make_leaf_fixtures.py and oracle/make_geom_fixtures.py pin leaf arithmetic, the traversal and the sampler.  What they cannot reach is the body of
-`PathIntegrator::li` (integrators/path.rs:59-282) and of `uniform_sample_one_light` (core/integrator.rs:359-403): which terms a path adds in which order, when it stops,
+`PathIntegrator::li` (integrators/path.rs:59-282), `uniform_sample_one_light` and `estimate_direct` (core/integrator.rs:359-570): which terms a path adds in which order, when it stops,
 what it draws from the sampler and when, how Russian roulette is decided — trait objects and containers all the way down.  This script compiles THAT text too, by the
 same committed rewrite rules, over CARRIERS that give the reference's method names (scene.intersect, isect.le, isect.compute_scattering_functions, bsdf.sample_f,
 light_distribution.lookup, estimate_direct, sampler.get_1d ..) to the ORACLE's leaf functions (oracle/orc_*.hpp, header-only, included by the generated file).  The result,
@@ -63,29 +63,81 @@ template <class T> static inline Option<T> Some(const T& v) { return Option<T>{t
 enum class TransportMode { Radiance, Importance };
 enum class BxdfType : uint8_t { BsdfReflection = 1, BsdfTransmission = 2, BsdfDiffuse = 4, BsdfGlossy = 8, BsdfSpecular = 16, BsdfAll = 31 };   // reflection.rs:57-64
 struct Scene;
-struct Bsdf {                                   // reflection.rs Bsdf: the oracle's lobe list behind the reference's method names
-    const orc::Bsdf* b; Float eta;
-    uint8_t num_components(uint8_t flags) const { return (uint8_t)b->num_components(flags); }
-    Spectrum sample_f(const Vector3f& wo, Vector3f* wi, const Point2f& u, Float* pdf, uint8_t flags, uint8_t* sampled_type) const {
+struct Bxdf {                                   // one lobe: the oracle's (orc::Lobe) behind Bxdf's method names (reflection.rs:470-560)
+    const orc::Lobe* l;
+    bool matches_flags(uint8_t t) const { return l->matches_flags(t); }
+    uint8_t get_type() const { return l->get_type(); }
+    Spectrum f(const Vector3f& wo, const Vector3f& wi) const { return Sf(l->f(V(wo), V(wi))); }
+    Float pdf(const Vector3f& wo, const Vector3f& wi) const { return Float(l->pdf(V(wo), V(wi))); }
+    Spectrum sample_f(const Vector3f& wo, Vector3f* wi, const Point2f& u, Float* pdf, uint8_t* sampled_type) const {
         orc::V3 w{0, 0, 0}; float p = pdf->v;
-        const orc::Spec f = b->sample_f(V(wo), &w, orc::P2{u.x.v, u.y.v}, &p, flags, sampled_type);
+        const orc::Spec f = l->sample_f(V(wo), &w, orc::P2{u.x.v, u.y.v}, &p, sampled_type);
         *wi = Vf(w); *pdf = Float(p);
         return Sf(f);
     }
 };
+struct BxdfRef {                                // `&Bxdf`
+    const Bxdf* p;
+    uint8_t get_type() const { return p->get_type(); }
+    Spectrum sample_f(const Vector3f& wo, Vector3f* wi, const Point2f& u, Float* pdf, uint8_t* sampled_type) const { return p->sample_f(wo, wi, u, pdf, sampled_type); }
+};
+struct BxdfList {                               // Vec<Bxdf> with capacity 8
+    Bxdf v[8]; size_t n = 0;
+    size_t len() const { return n; } const Bxdf& operator[](size_t i) const { return v[i]; }
+    Option<BxdfRef> get(size_t i) const { return Option<BxdfRef>{i < n, BxdfRef{&v[i]}}; }
+};
+static inline uint8_t rs_f2u8(Float x) { return x.v != x.v ? 0 : (x.v >= 255.0f ? 255 : (x.v <= 0.0f ? 0 : (uint8_t)x.v)); }   // `as u8` from a float: saturating, NaN -> 0
+struct Bsdf {                                   // reflection.rs:216-232; the methods below are the reference's text (reflection.rs:250-446)
+    Float eta; Normal3f ns, ng; Vector3f ss, ts; BxdfList bxdfs;
+    static Bsdf from(const orc::Bsdf& b) {
+        Bsdf r; r.eta = Float(b.eta); r.ns = Nf(b.ns); r.ng = Nf(b.ng); r.ss = Vf(b.ss); r.ts = Vf(b.ts);
+        r.bxdfs.n = (size_t)b.n; for (int i = 0; i < b.n; i++) r.bxdfs.v[i] = Bxdf{&b.lobes[i]};
+        return r;
+    }
+    uint8_t num_components(uint8_t flags) const; Vector3f world_to_local(const Vector3f& v) const; Vector3f local_to_world(const Vector3f& v) const;
+    Spectrum f(const Vector3f& wo_w, const Vector3f& wi_w, uint8_t flags) const;
+    Spectrum sample_f(const Vector3f& wo_world, Vector3f* wi_world, const Point2f& u, Float* pdf, uint8_t bsdf_flags, uint8_t* sampled_type) const;
+    Float pdf(const Vector3f& wo_world, const Vector3f& wi_world, uint8_t bsdf_flags) const;
+};
 struct Bssrdf {};
+struct Phase { Float p(const Vector3f&, const Vector3f&) const { abort(); } Float sample_p(const Vector3f&, Vector3f*, Point2f) const { abort(); } };   // media: VolPathIntegrator's, not on this path
+struct LightRef; struct PrimRef;
 struct Common { Point3f p; Normal3f n; };
 struct Shading { Normal3f n; };
 struct SurfaceInteraction {
     orc::Interaction it; orc::Bsdf store; const Scene* scene = nullptr;
-    Option<Bsdf> bsdf{false, Bsdf{nullptr, Float(0.0f)}}; Option<Bssrdf> bssrdf{false, Bssrdf{}}; Common common; Shading shading;
+    Option<Bsdf> bsdf{false, Bsdf{}}; Option<Bssrdf> bssrdf{false, Bssrdf{}}; Common common; Shading shading; Option<const SurfaceInteraction*> primitive{false, nullptr};
+    // the `&dyn Interaction` view of estimate_direct (interaction.rs:20-50)
+    const SurfaceInteraction& get_common() const { return *this; }
+    bool is_surface_interaction() const { return true; }
+    Option<Bsdf> get_bsdf() const { return bsdf; }
+    Option<Normal3f> get_shading_n() const { return Option<Normal3f>{true, shading.n}; }
+    Vector3f get_wo() const { return Vf(it.wo); }
+    Option<Phase> get_phase() const { return Option<Phase>{false, Phase{}}; }
+    Option<LightRef> get_area_light() const;      // Primitive::get_area_light of the primitive that was hit
     static SurfaceInteraction default_() { return SurfaceInteraction{}; }
     void refresh() { common.p = Pf(it.p); common.n = Nf(it.n); shading.n = Nf(it.sh_n); }
     Spectrum le(const Vector3f& w) const;                                                    // interaction.rs:475-483
     void compute_scattering_functions(const Ray& ray, bool allow_multiple_lobes, TransportMode mode);   // interaction.rs:371-386
     Ray spawn_ray(const Vector3f& d) const { return to_ref(it.spawn_ray(V(d))); }             // interaction.rs:58-94
 };
-struct LightRef { const Scene* scene; uint32_t index; Spectrum le(const Ray& ray) const; };
+struct InteractionCommon { orc::Interaction it; static InteractionCommon default_() { return InteractionCommon{}; } };
+struct VisibilityTester {                       // light.rs:190-230
+    const SurfaceInteraction* p0 = nullptr; const InteractionCommon* p1 = nullptr;
+    static VisibilityTester default_() { return VisibilityTester{}; }
+    bool unoccluded(const Scene& scene) const;
+    Spectrum tr(const Scene&, const struct Sampler&) const { abort(); }
+};
+struct LightFlags { bool delta; };
+static inline bool is_delta_light(LightFlags f) { return f.delta; }                   // light.rs:178-188
+struct LightRef {
+    const Scene* scene; uint32_t index;
+    Spectrum le(const Ray& ray) const;                                              // Light::le: the environment's radiance, black for every other light
+    Spectrum sample_li(const SurfaceInteraction& iref, InteractionCommon* light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester* vis) const;
+    Float pdf_li(const SurfaceInteraction& iref, const Vector3f& wi) const;
+    LightFlags get_flags() const;
+    uint32_t address() const { return index; }                                       // (the reference compares Arc pointers: integrator.rs:550-558)
+};
 struct LightList { std::vector<LightRef> v; size_t len() const { return v.size(); } const LightRef& operator[](size_t i) const { return v[i]; } auto begin() const { return v.begin(); } auto end() const { return v.end(); } };
 struct Scene {
     orc::RenderCtx* cx; orc::Counters* c; LightList lights, infinite_lights;
@@ -94,9 +146,10 @@ struct Scene {
         const bool hit = cx->scene->intersect(r, &isect->it, c);
         ray.t_max.set(Float(r.t_max));                 // the Cell the reference's primitives write through
         isect->scene = this;
-        if (hit) isect->refresh();
+        if (hit) { isect->refresh(); isect->primitive = Option<const SurfaceInteraction*>{isect->it.prim >= 0, isect}; }   // isect.primitive: None after Q11 dropped it
         return hit;
     }
+    bool intersect_tr(Ray*, struct Sampler&, SurfaceInteraction*, Spectrum*) const { abort(); }
 };
 inline Spectrum SurfaceInteraction::le(const Vector3f& w) const {
     const rspt_prim& hp = scene->cx->scene->hit_prim(it);
@@ -109,10 +162,29 @@ inline void SurfaceInteraction::compute_scattering_functions(const Ray& ray, boo
     orc::compute_differentials(&it, to_orc(ray));
     orc::make_bsdf(sc, it, hp.material, allow_multiple_lobes, &store);
     if (scene->c) scene->c->bounces++;
-    bsdf = Option<Bsdf>{true, Bsdf{&store, Float(store.eta)}};
+    bsdf = Option<Bsdf>{true, Bsdf::from(store)};
     refresh();
 }
-inline Spectrum LightRef::le(const Ray& ray) const { return Sf(orc::infinite_le(*scene->cx->scene, scene->cx->scene->d.lights[index], V(ray.d))); }
+inline Spectrum LightRef::le(const Ray& ray) const {
+    const rspt_light& lt = scene->cx->scene->d.lights[index];
+    return lt.kind == RSPT_LIGHT_INFINITE ? Sf(orc::infinite_le(*scene->cx->scene, lt, V(ray.d))) : spectrum_default();
+}
+inline Spectrum LightRef::sample_li(const SurfaceInteraction& iref, InteractionCommon* light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester* vis) const {
+    orc::V3 w{0, 0, 0}; float p = 0.0f;
+    const orc::Spec li = orc::light_sample_li(*scene->cx->scene, scene->cx->scene->d.lights[index], iref.it, orc::P2{u.x.v, u.y.v}, &w, &p, &light_intr->it);
+    *wi = Vf(w); *pdf = Float(p); vis->p0 = &iref; vis->p1 = light_intr;
+    return Sf(li);
+}
+inline Float LightRef::pdf_li(const SurfaceInteraction& iref, const Vector3f& wi) const {
+    const orc::Scene& sc = *scene->cx->scene; const rspt_light& lt = sc.d.lights[index];
+    return Float(lt.kind == RSPT_LIGHT_INFINITE ? orc::infinite_pdf_li(sc, lt, V(wi)) : sc.tri_pdf_ref(sc.d.prims[lt.prim], iref.it, V(wi)));   // diffuse.rs:100-103
+}
+inline LightFlags LightRef::get_flags() const { return LightFlags{orc::light_is_delta(scene->cx->scene->d.lights[index])}; }
+inline bool VisibilityTester::unoccluded(const Scene& scene) const { return !scene.cx->scene->intersect_p(p0->it.spawn_ray_to(p1->it), scene.c); }   // light.rs:199-206
+inline Option<LightRef> SurfaceInteraction::get_area_light() const {
+    const rspt_prim& hp = scene->cx->scene->hit_prim(it);
+    return Option<LightRef>{hp.area_light >= 0, LightRef{scene, (uint32_t)(hp.area_light >= 0 ? hp.area_light : 0)}};
+}
 struct Distribution1D {
     const orc::Distribution1D* d;
     size_t sample_discrete(Float u, Option<Float*> pdf) const { float p = 0.0f; const size_t i = d->sample_discrete(u.v, &p); if (pdf.some) *pdf.v = Float(p); return i; }
@@ -125,10 +197,7 @@ struct Sampler {
     Float get_1d() { return Float(s->get_1d()); }
     Point2f get_2d() { const orc::P2 p = s->get_2d(); return Point2f{Float(p.x), Float(p.y)}; }
 };
-// estimate_direct (integrator.rs:406-570) is the oracle's here: the MIS estimate for the chosen light
-static inline Spectrum estimate_direct(const SurfaceInteraction& it, Point2f u_scattering, const LightRef& light, Point2f u_light, const Scene& scene, Sampler&, bool, bool) {
-    return Sf(orc::estimate_direct(*scene.cx, it.it, it.store, orc::P2{u_scattering.x.v, u_scattering.y.v}, light.index, orc::P2{u_light.x.v, u_light.y.v}, scene.c));
-}
+Spectrum estimate_direct(const SurfaceInteraction& it, Point2f u_scattering, const LightRef& light, Point2f u_light, const Scene& scene, Sampler& sampler, bool handle_media, bool specular);
 Spectrum uniform_sample_one_light(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, bool handle_media, Option<Distribution1D> light_distrib);
 struct PathIntegrator {
     uint32_t max_depth; Float rr_threshold; Option<LightDistribution> light_distribution;
@@ -138,15 +207,24 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
+TYPES.update({"i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
 RULES_FLOW = [
+    # F0  Rust's `&` binds tighter than a comparison, C's does not (the base's R4, for a method call and an enum value):  `x.t() & E as u8 > 0_u8` -> ((x.t() & E) > 0)
+    (r"([\w.\[\]>\-]+\(\)) & (BxdfType::\w+) as u8 (>|==) 0_u8", r"((\1 & (uint8_t)(\2)) \3 0)", 0),
+    (r"(\([^()]*(?:\([^()]*\))*[^()]*\)\.floor\(\)) as u8", r"rs_f2u8(\1)", 0),
+    (r"let mut (\w+): Option<&Bxdf> = None;", r"Option<BxdfRef> \1{false, BxdfRef{nullptr}};", 0),
+    (r"Vector3f::from\(((?:self\.|this->)[\w.]+)\)", r"Vector3f_from(\1)", 0),
+    (r"\b(\d+)_i8\b", r"\1", 0), (r"\b(\w+) as i8\b", r"(int8_t)(\1)", 0),
     # F2  generic containers in a declaration:  `let x: Arc<T> = E;` / `let mut x: Option<Float> = Some(E);`  ->  auto (the carrier's type decides)
     (r"let (?:mut )?(\w+): Arc<\w+> = ", r"auto \1 = ", 0),
     (r"let mut (\w+): Option<Float> = Some\((.*?)\);", r"auto \1 = SomeFloat(\2);", 0),
     # F3  `if let Some([ref] x) = E {`  ->  `if (E.is_some()) { auto& x = E.unwrap();`   (E a place expression);  `Some(&x)` at a call site -> Some(x)
-    (r"if let Some\((?:ref )?(\w+)\) = ((?:this->)?[\w.]+) \{", r"if (\2.is_some()) { const auto& \1 = \2.unwrap();", 0),
+    (r"if let Some\((?:ref )?(\w+)\) = ((?:this->)?[\w.]+(?:\(\))?) \{", r"if (\2.is_some()) { const auto \1 = \2.unwrap();", 0),
+    # F3b the reference's pointer identity of two lights (integrator.rs:550-558):  `unsafe { &*p }` -> p;  `x as *const _ as *const usize` -> x.address()
+    (r"let (\w+) = unsafe \{ &\*(\w+) \};", r"const auto& \1 = *\2;", 0),
+    (r"let (\w+) = (?:&\*)?(\w+) as \*const _ as \*const usize;", r"auto \1 = \2.address();", 0),
     (r"Some\(&(\w+)\)", r"Some(\1)", 0),
     # F4  enum values under a cast, integer `!`, u8::max_value()
     (r"(BxdfType::\w+) as u8", r"(uint8_t)(\1)", 0),
@@ -176,6 +254,13 @@ def drop_block(body, head):
 
 SOURCES = [
     ("core/geometry.rs", r"^pub fn vec3_abs_dot_nrmf\(", "vec3_abs_dot_nrmf", None, False),
+    ("core/reflection.rs", r"^    pub fn num_components\(&self, flags: u8\) -> u8 \{", "num_components", "Bsdf", True),
+    ("core/reflection.rs", r"^    pub fn world_to_local\(&self, v: &Vector3f\) -> Vector3f \{", "world_to_local", "Bsdf", True),
+    ("core/reflection.rs", r"^    pub fn local_to_world\(&self, v: &Vector3f\) -> Vector3f \{", "local_to_world", "Bsdf", True),
+    ("core/reflection.rs", r"^    pub fn f\(&self, wo_w: &Vector3f, wi_w: &Vector3f, flags: u8\) -> Spectrum \{", "f", "Bsdf", True),
+    ("core/reflection.rs", r"^    pub fn sample_f\($", "sample_f", "Bsdf", True),
+    ("core/reflection.rs", r"^    pub fn pdf\(&self, wo_world: &Vector3f, wi_world: &Vector3f, bsdf_flags: u8\) -> Float \{", "pdf", "Bsdf", True),
+    ("core/integrator.rs", r"^pub fn estimate_direct\(", "estimate_direct", None, True),
     ("core/integrator.rs", r"^pub fn uniform_sample_one_light\(", "uniform_sample_one_light", None, True),
     ("integrators/path.rs", r"^    pub fn li\(", "li", "PathIntegrator", True),
 ]
@@ -198,7 +283,7 @@ def convert_parts():
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
         for pat, rep, flags in base.RULES:
             body = re.sub(pat, rep, body, flags=flags)
-        body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|usize|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+        body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|i8|usize|bool|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f|VisibilityTester|InteractionCommon) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
         body = re.sub(r"\blet (\w+): (usize|Float);", lambda m: "%s %s;" % (TYPES[m.group(2)], m.group(1)), body)
         body = base.shadowing(body, set(params) | set(geom.FN_NAMES) | {"li"})
         body = geom.tail_value(body)

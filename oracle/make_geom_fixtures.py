@@ -44,6 +44,8 @@ FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                           
     explicit operator size_t() const { return (size_t)v; }       // `x as usize` (only met with small non-negative values here)
     explicit operator double() const { return (double)v; }      // `x as f64`
     Float ln() const { return Float(logf(v)); }                  // f32::ln is the platform libm's logf
+    Float floor() const { return Float(floorf(v)); }
+    Float& operator/=(Float o) { v = v / o.v; return *this; }
 """
 VEC3_EXTRA = """    Vector3f abs() const;            // body: the reference's text (geometry.rs:397-403)
     Float& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }                 // impl Index<XYZEnum> (geometry.rs:574-583): a selector
