@@ -26,7 +26,7 @@ def flow():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import make_flow_fixtures as mk
     L, where = mk.convert()
-    assert where[-3:] == ["estimate_direct core/integrator.rs:406-570", "uniform_sample_one_light core/integrator.rs:359-403", "PathIntegrator::li integrators/path.rs:59-282"] and "Bsdf::sample_f core/reflection.rs:299-420" in where
+    assert where[-3:] == ["estimate_direct core/integrator.rs:406-570", "uniform_sample_one_light core/integrator.rs:359-403", "PathIntegrator::li integrators/path.rs:59-282"] and "Bsdf::sample_f core/reflection.rs:298-420" in where
     return mk, L
 
 
