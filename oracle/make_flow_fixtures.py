@@ -34,11 +34,13 @@ CARRIERS = r"""
 static inline Spectrum& operator+=(Spectrum& a, const Spectrum& b) { a = a + b; return a; }
 static inline Spectrum& operator*=(Spectrum& a, const Spectrum& b) { a = a * b; return a; }
 static inline Spectrum& operator/=(Spectrum& a, Float b) { a = a / b; return a; }
+static inline Float rs_fmax(Float a, Float b) { return a.max(b); } static inline Float rs_fmin(Float a, Float b) { return a.min(b); } static inline Float rs_fabs(Float a) { return a.abs(); }
 static inline Spectrum spectrum_default() { return Spectrum::new_(Float(0.0f)); }                     // #[derive(Default)]: zeros
 static inline Vector3f vector3f_default() { return Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
 static inline bool spectrum_is_black(const Spectrum& s) { return !(s.c[0] != Float(0.0f) || s.c[1] != Float(0.0f) || s.c[2] != Float(0.0f)); }   // spectrum.rs is_black
 static inline Float spectrum_max_component_value(const Spectrum& s) { return s.c[0].max(s.c[1].max(s.c[2])); }                                  // spectrum.rs max_component_value
-Float vec3_abs_dot_nrmf(const Vector3f& v1, const Normal3f& n2);
+Float vec3_abs_dot_nrmf(const Vector3f& v1, const Normal3f& n2); bool vec3_same_hemisphere_vec3(const Vector3f& w, const Vector3f& wp); Float pow5(Float v);
+Normal3f nrm_faceforward_vec3(const Normal3f& n, const Vector3f& v); Vector3f spherical_direction(Float sin_theta, Float cos_theta, Float phi);
 namespace flow {
 static inline orc::V3 V(const Vector3f& v) { return orc::V3{v.x.v, v.y.v, v.z.v}; }
 static inline orc::V3 V(const Point3f& v) { return orc::V3{v.x.v, v.y.v, v.z.v}; }
@@ -63,6 +65,32 @@ template <class T> static inline Option<T> Some(const T& v) { return Option<T>{t
 enum class TransportMode { Radiance, Importance };
 enum class BxdfType : uint8_t { BsdfReflection = 1, BsdfTransmission = 2, BsdfDiffuse = 4, BsdfGlossy = 8, BsdfSpecular = 16, BsdfAll = 31 };   // reflection.rs:57-64
 struct Scene;
+// ---- the lobes themselves (reflection.rs:711-1478): structs with the reference's field names; every method body below is the reference's text ----
+struct FresnelConductor { Spectrum eta_i, eta_t, k; Spectrum evaluate(Float cos_theta_i) const; };
+struct FresnelDielectric { Float eta_i, eta_t; Spectrum evaluate(Float cos_theta_i) const; };
+struct FresnelNoOp { Spectrum evaluate(Float _cos_theta_i) const; };
+struct Fresnel {                                // enum Fresnel (reflection.rs:636-655): evaluate forwards to the arm that is set
+    int kind; FresnelNoOp noop; FresnelConductor conductor; FresnelDielectric dielectric;
+    Spectrum evaluate(Float c) const { return kind == 2 ? conductor.evaluate(c) : (kind == 1 ? dielectric.evaluate(c) : noop.evaluate(c)); }
+};
+struct MicrofacetDistribution {                 // enum MicrofacetDistribution (microfacet.rs:16-75): the TrowbridgeReitz arm (Beckmann cannot be constructed by any material)
+    TrowbridgeReitzDistribution tr;
+    Float d(const Vector3f& wh) const { return tr.d(wh); } Float g(const Vector3f& wo, const Vector3f& wi) const { return tr.g(wo, wi); }
+    Float pdf(const Vector3f& wo, const Vector3f& wh) const { return tr.pdf(wo, wh); } Vector3f sample_wh(const Vector3f& wo, const Point2f& u) const;
+};
+Vector3f tr_sample_wh(const TrowbridgeReitzDistribution& self, const Vector3f& wo, const Point2f& u);
+inline Vector3f MicrofacetDistribution::sample_wh(const Vector3f& wo, const Point2f& u) const { return tr_sample_wh(tr, wo, u); }
+typedef Option<Spectrum> OptSpectrum;
+#define LOBE_METHODS Spectrum f(const Vector3f& wo, const Vector3f& wi) const; Float pdf(const Vector3f& wo, const Vector3f& wi) const; uint8_t get_type() const; \
+    Spectrum sample_f(const Vector3f& wo, Vector3f* wi, const Point2f& u, Float* pdf, uint8_t* sampled_type) const;
+struct LambertianReflection { Spectrum r; OptSpectrum sc_opt; LOBE_METHODS };
+struct LambertianTransmission { Spectrum t; OptSpectrum sc_opt; LOBE_METHODS };
+struct OrenNayar { Spectrum r; Float a, b; OptSpectrum sc_opt; LOBE_METHODS };
+struct SpecularReflection { Spectrum r; Fresnel fresnel; OptSpectrum sc_opt; LOBE_METHODS };
+struct SpecularTransmission { Spectrum t; Float eta_a, eta_b; FresnelDielectric fresnel; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
+struct FresnelSpecular { Spectrum r, t; Float eta_a, eta_b; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
+struct MicrofacetReflection { Spectrum r; MicrofacetDistribution distribution; Fresnel fresnel; OptSpectrum sc_opt; LOBE_METHODS };
+struct FresnelBlend { Spectrum rd, rs; Option<MicrofacetDistribution> distribution; OptSpectrum sc_opt; Spectrum schlick_fresnel(Float cos_theta) const; LOBE_METHODS };
 struct Bxdf {                                   // one lobe: the oracle's (orc::Lobe) behind Bxdf's method names (reflection.rs:470-560)
     const orc::Lobe* l;
     bool matches_flags(uint8_t t) const { return l->matches_flags(t); }
@@ -207,10 +235,20 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
+TYPES.update({"&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
 RULES_FLOW = [
+    # F8  lobes: `} else if let Some(x) = E {`;  an assignment that ends a block without `;`;  associated functions of f32;  untyped `let x;`;  Spectrum::zero()
+    (r"\} else if let Some\((?:ref )?(\w+)\) = ((?:this->)?[\w.]+) \{", r"} else if (\2.is_some()) { const auto \1 = \2.unwrap();", 0),
+    (r"(\*sampled_type = [^;{}\n]*(?:\n\s*\|[^;{}\n]*)*)\n(\s*)\}", r"\1;\n\2}", 0),
+    (r"\b(?:f32|Float)::(max|min)\(", r"rs_f\1(", 0),
+    (r"Float::abs\(", "rs_fabs(", 0),
+    (r"let (\w+);", r"Float \1;", 0),
+    (r"Spectrum::zero\(\)", "spectrum_default()", 0),
+    (r"let mut (\w+): Point2f = \*(\w+);", r"Point2f \1 = \2;", 0),
+    (r"&-\(\*?(\w+)\)", r"-\1", 0),
+    (r"&(\w+)\.into\(\)", r"Normal3f_from(\1)", 0),
     # F0  Rust's `&` binds tighter than a comparison, C's does not (the base's R4, for a method call and an enum value):  `x.t() & E as u8 > 0_u8` -> ((x.t() & E) > 0)
     (r"([\w.\[\]>\-]+\(\)) & (BxdfType::\w+) as u8 (>|==) 0_u8", r"((\1 & (uint8_t)(\2)) \3 0)", 0),
     (r"(\([^()]*(?:\([^()]*\))*[^()]*\)\.floor\(\)) as u8", r"rs_f2u8(\1)", 0),
@@ -245,6 +283,33 @@ RULES_FLOW = [
 ]
 
 
+def join_multiline_if(body):
+    """F7: rustfmt breaks a long condition over lines (`if !refract(\n    wo,\n    ..\n) {`): one logical line.  The `{` that opens the block is the first one outside
+    every parenthesis."""
+    out, i = [], 0
+    for m in re.finditer(r"^(\s*)((?:\} else )?if )", body, re.M):
+        if m.start() < i:
+            continue
+        j, depth = m.end(), 0
+        while j < len(body):
+            ch = body[j]
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+            elif ch == "{" and depth == 0:
+                break
+            elif ch == "{":
+                j = geom.matching(body, j, "{", "}")
+            j += 1
+        cond = body[m.end():j]
+        if "\n" in cond:
+            out.append(body[i:m.end()] + re.sub(r"\s*\n\s*", " ", cond).replace("( ", "(").replace(" )", ")"))
+            i = j
+    out.append(body[i:])
+    return "".join(out)
+
+
 def drop_block(body, head):
     """F1: remove the statement `head { .. }` (to its matching brace); comment lines are gone by then"""
     i = body.index(head)
@@ -254,6 +319,19 @@ def drop_block(body, head):
 
 SOURCES = [
     ("core/geometry.rs", r"^pub fn vec3_abs_dot_nrmf\(", "vec3_abs_dot_nrmf", None, False),
+    ("core/reflection.rs", r"^pub fn vec3_same_hemisphere_vec3\(", "vec3_same_hemisphere_vec3", None, False),
+    ("core/reflection.rs", r"^fn pow5\(", "pow5", None, False),
+    ("core/geometry.rs", r"^pub fn nrm_faceforward_vec3\(", "nrm_faceforward_vec3", None, False),
+    ("core/geometry.rs", r"^pub fn spherical_direction\(", "spherical_direction", None, False),
+    ("core/microfacet.rs", ("^impl TrowbridgeReitzDistribution \\{", r"^    pub fn sample_wh\(&self, wo: &Vector3f, u: &Point2f\) -> Vector3f \{"), "tr_sample_wh", "@TrowbridgeReitzDistribution", True),
+    ("core/reflection.rs", ("^impl FresnelConductor \\{", r"^    pub fn evaluate\("), "evaluate", "FresnelConductor", True),
+    ("core/reflection.rs", ("^impl FresnelDielectric \\{", r"^    pub fn evaluate\("), "evaluate", "FresnelDielectric", True),
+    ("core/reflection.rs", ("^impl FresnelNoOp \\{", r"^    pub fn evaluate\("), "evaluate", "FresnelNoOp", True),
+] + [
+    ("core/reflection.rs", ("^impl %s \\{" % cls, r"^    pub fn %s\(" % m), m, cls, True)
+    for cls in ("LambertianReflection", "LambertianTransmission", "OrenNayar", "SpecularReflection", "SpecularTransmission", "FresnelSpecular", "MicrofacetReflection", "FresnelBlend")
+    for m in (("schlick_fresnel",) if cls == "FresnelBlend" else ()) + ("f", "sample_f", "pdf", "get_type")
+] + [
     ("core/reflection.rs", r"^    pub fn num_components\(&self, flags: u8\) -> u8 \{", "num_components", "Bsdf", True),
     ("core/reflection.rs", r"^    pub fn world_to_local\(&self, v: &Vector3f\) -> Vector3f \{", "world_to_local", "Bsdf", True),
     ("core/reflection.rs", r"^    pub fn local_to_world\(&self, v: &Vector3f\) -> Vector3f \{", "local_to_world", "Bsdf", True),
@@ -272,9 +350,19 @@ def convert_parts():
     parts.append(CARRIERS)
     geom.TYPES.update(TYPES); base.TYPES.update(TYPES)
     for fname, first_re, name, cls, in_flow in SOURCES:
-        text, l0, l1 = geom.extract(fname, None, first_re, None)
+        after_re, first_re = first_re if isinstance(first_re, tuple) else (None, first_re)
+        text, l0, l1 = geom.extract(fname, after_re, first_re, None)
+        self_type = None
+        if cls and cls.startswith("@"):            # a method compiled as a free function over the carrier of another batch: `&self` -> an explicit `self`
+            self_type, cls = cls[1:], None
+            text = text.replace("&self,", "self_: &%s," % self_type)
         text = re.sub(r"^\s*//.*\n", "", text, flags=re.M)                      # (comment lines sit inside li's argument list)
         sig, body, params = geom.signature(text, name, cls)
+        if self_type:
+            body = body.replace("self.", "self_.")
+        body = join_multiline_if(body)
+        for nm in re.findall(r"Vector3f\* (\w+)", sig):        # F9: field access through a `&mut Vector3f` auto-dereferences
+            body = re.sub(r"(?<![\w>.])%s\.(?=[xyz]\b)" % nm, nm + "->", body)
         if name == "li":
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
         for pat, rep, flags in RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
@@ -302,6 +390,47 @@ static orc::Spec li_from_the_references_text(orc::RenderCtx& cx, const orc::Ray&
     Sampler s{&sampler};
     return So(integrator.li(to_ref(ray), scene, s, 0));
 }
+}
+namespace flow {
+static inline Spectrum S3f(const float* p) { Spectrum r; for (int i = 0; i < 3; i++) r.c[i] = Float(p[i]); return r; }
+template <class L> static void run_lobe(const L& l, const Vector3f& wo, const Vector3f& wi, const Point2f& u, float* o) {
+    const Spectrum f = l.f(wo, wi);
+    o[0] = f.c[0].v; o[1] = f.c[1].v; o[2] = f.c[2].v; o[3] = l.pdf(wo, wi).v;
+    Vector3f w = vector3f_default(); Float pdf(0.0f); uint8_t st = 255;
+    const Spectrum s = l.sample_f(wo, &w, u, &pdf, &st);
+    o[4] = s.c[0].v; o[5] = s.c[1].v; o[6] = s.c[2].v; o[7] = w.x.v; o[8] = w.y.v; o[9] = w.z.v; o[10] = pdf.v; o[11] = (float)st; o[12] = (float)l.get_type();
+}
+}
+// every lobe of the reference (its text, over the struct a material would build from the record) next to the oracle's restatement (orc::Lobe) on the same record
+extern "C" void flow_lobes(const rspt_bxdf* recs, const float* wo, const float* wi, const float* u, uint64_t n, float* out_text, float* out_oracle) {
+    using namespace flow;
+    for (uint64_t i = 0; i < n; i++) {
+        const rspt_bxdf& b = recs[i];
+        const Vector3f o{Float(wo[3 * i]), Float(wo[3 * i + 1]), Float(wo[3 * i + 2])}, w{Float(wi[3 * i]), Float(wi[3 * i + 1]), Float(wi[3 * i + 2])};
+        const Point2f uu{Float(u[2 * i]), Float(u[2 * i + 1])};
+        float* t = out_text + 16 * i; float* q = out_oracle + 16 * i;
+        for (int k = 0; k < 16; k++) t[k] = q[k] = 0.0f;
+        const OptSpectrum sc{b.has_sc != 0, S3f(b.sc)};
+        Fresnel fr{(int)b.fresnel, FresnelNoOp{}, FresnelConductor{Spectrum::new_(Float(1.0f)), S3f(b.c1), S3f(b.c2)}, FresnelDielectric{Float(b.eta_a), Float(b.eta_b)}};
+        const MicrofacetDistribution md{TrowbridgeReitzDistribution{Float(b.alpha_x), Float(b.alpha_y), true}};
+        switch (b.type) {
+            case RSPT_BXDF_LAMBERT_R: run_lobe(LambertianReflection{S3f(b.r), sc}, o, w, uu, t); break;
+            case RSPT_BXDF_LAMBERT_T: run_lobe(LambertianTransmission{S3f(b.r), sc}, o, w, uu, t); break;
+            case RSPT_BXDF_OREN_NAYAR: run_lobe(OrenNayar{S3f(b.r), Float(b.on_a), Float(b.on_b), sc}, o, w, uu, t); break;
+            case RSPT_BXDF_SPECULAR_R: run_lobe(SpecularReflection{S3f(b.r), fr, sc}, o, w, uu, t); break;
+            case RSPT_BXDF_SPECULAR_T: run_lobe(SpecularTransmission{S3f(b.r), Float(b.eta_a), Float(b.eta_b), FresnelDielectric{Float(b.eta_a), Float(b.eta_b)}, TransportMode::Radiance, sc}, o, w, uu, t); break;
+            case RSPT_BXDF_FRESNEL_SPEC: run_lobe(FresnelSpecular{S3f(b.r), S3f(b.t), Float(b.eta_a), Float(b.eta_b), TransportMode::Radiance, sc}, o, w, uu, t); break;
+            case RSPT_BXDF_MICROFACET_R: run_lobe(MicrofacetReflection{S3f(b.r), md, fr, sc}, o, w, uu, t); break;
+            case RSPT_BXDF_FRESNEL_BLEND: run_lobe(FresnelBlend{S3f(b.r), S3f(b.t), Option<MicrofacetDistribution>{true, md}, sc}, o, w, uu, t); break;
+            default: break;
+        }
+        const orc::Lobe l{&b};
+        const orc::Spec f = l.f(V(o), V(w));
+        q[0] = f.c[0]; q[1] = f.c[1]; q[2] = f.c[2]; q[3] = l.pdf(V(o), V(w));
+        orc::V3 sw{0, 0, 0}; float pdf = 0.0f; uint8_t st = 255;
+        const orc::Spec sf = l.sample_f(V(o), &sw, orc::P2{uu.x.v, uu.y.v}, &pdf, &st);
+        q[4] = sf.c[0]; q[5] = sf.c[1]; q[6] = sf.c[2]; q[7] = sw.x; q[8] = sw.y; q[9] = sw.z; q[10] = pdf; q[11] = (float)st; q[12] = (float)l.get_type();
+    }
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {
     if (!sd || !rd) return -1;

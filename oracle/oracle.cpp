@@ -544,6 +544,23 @@ void orc_geom_sobol(const rspt_sampler_tables* t, const int64_t* spp, const int3
         }
     }
 }
+void orc_geom_area_light(const float* tri, const float* nrm, const int32_t* flags, const float* L, const float* ref_p, const float* u, uint64_t n, float* out) {   // light_sample_li on one emitting triangle
+    for (uint64_t i = 0; i < n; i++) {
+        Scene sc{};
+        rspt_prim pr{}; pr.v[0] = 0; pr.v[1] = 1; pr.v[2] = 2; pr.mesh = 0; pr.area_light = 0;
+        rspt_mesh m{}; m.has_n = (flags[i] & 1) ? 1u : 0u; m.flip = (flags[i] & 2) ? 1u : 0u;
+        rspt_light lt{}; lt.kind = RSPT_LIGHT_DIFFUSE_AREA; lt.prim = 0; lt.two_sided = (flags[i] & 4) ? 1u : 0u;
+        for (int k = 0; k < 3; k++) lt.L[k] = L[3 * i + k];
+        sc.d.P = tri + 9 * i; sc.d.N = nrm + 9 * i; sc.d.prims = &pr; sc.d.n_prims = 1; sc.d.meshes = &m; sc.d.n_meshes = 1; sc.d.lights = &lt; sc.d.n_lights = 1;
+        Interaction iref; iref.p = V3{ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]}; iref.p_error = V3{0, 0, 0}; iref.n = V3{0, 0, 0}; iref.wo = V3{0, 0, 0};
+        Interaction li = iref; V3 wi{0, 0, 0}; Float pdf = 0.0f;
+        const Spec s = light_sample_li(sc, lt, iref, P2{u[2 * i], u[2 * i + 1]}, &wi, &pdf, &li);
+        float* o = out + 16 * i;
+        o[0] = pdf; o[1] = wi.x; o[2] = wi.y; o[3] = wi.z; o[4] = s.c[0]; o[5] = s.c[1]; o[6] = s.c[2];
+        o[7] = li.p.x; o[8] = li.p.y; o[9] = li.p.z; o[10] = li.n.x; o[11] = li.n.y; o[12] = li.n.z; o[13] = li.p_error.x; o[14] = li.p_error.y; o[15] = li.p_error.z;
+        if (pdf == 0.0f) for (int k = 1; k < 7; k++) o[k] = 0.0f;
+    }
+}
 void orc_geom_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {
     for (uint64_t i = 0; i < n; i++) {
         Rng r; r.set_sequence(seq[i]);

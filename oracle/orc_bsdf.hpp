@@ -269,19 +269,24 @@ struct Lobe {
         }
         return 0.0f;
     }
+    // The non-specular lobes end their sample_f with `if let Some(sc) = self.sc_opt { sc * self.f(wo, wi) } else { self.f(wo, wi) }` (reflection.rs:982-986, 1030-1034,
+    // 1109-1113, 1190-1194, 1339-1343, 1456-1460) while f already carries sc: inside a MixMaterial the scale enters the value of a lobe's OWN sample_f twice.  Bsdf::sample_f
+    // discards that value for every non-specular lobe (it re-sums f over the matching lobes, :393-412), so no radiance depends on it; kept because the lobe-level pin
+    // (oracle/make_flow_fixtures.py flow_lobes, found by it) holds this function to the reference's text bit for bit.
+    Spec sampled_value(V3 wo, V3 wi) const { return b->has_sc ? S3(b->sc) * f(wo, wi) : f(wo, wi); }
     Spec sample_f(V3 wo, V3* wi, P2 u, Float* pdf_out, uint8_t* sampled_type) const {
         switch (b->type) {
         case RSPT_BXDF_LAMBERT_R: case RSPT_BXDF_OREN_NAYAR: { // :968-987, :1097-1114
             *wi = cosine_sample_hemisphere(u);
             if (wo.z < 0.0f) wi->z *= -1.0f;
             *pdf_out = pdf(wo, *wi);
-            return f(wo, *wi);
+            return sampled_value(wo, *wi);
         }
         case RSPT_BXDF_LAMBERT_T: { // :1018-1035
             *wi = cosine_sample_hemisphere(u);
             if (wo.z > 0.0f) wi->z *= -1.0f;
             *pdf_out = pdf(wo, *wi);
-            return f(wo, *wi);
+            return sampled_value(wo, *wi);
         }
         case RSPT_BXDF_SPECULAR_R: { // :724-745
             *wi = V3{-wo.x, -wo.y, wo.z};
@@ -323,7 +328,7 @@ struct Lobe {
             *wi = reflect(wo, wh);
             if (!same_hemisphere(wo, *wi)) return Spec();
             *pdf_out = tr.pdf(wo, wh) / (4.0f * dot(wo, wh));
-            return f(wo, *wi);
+            return sampled_value(wo, *wi);
         }
         case RSPT_BXDF_MICROFACET_T: { // :1322-1349
             if (wo.z == 0.0f) return Spec();
@@ -332,7 +337,7 @@ struct Lobe {
             Float eta = cos_theta(wo) > 0.0f ? b->eta_a / b->eta_b : b->eta_b / b->eta_a;
             if (!refract(wo, wh, eta, wi)) return Spec();
             *pdf_out = pdf(wo, *wi);
-            return f(wo, *wi);
+            return sampled_value(wo, *wi);
         }
         case RSPT_BXDF_FRESNEL_BLEND: { // :1432-1461
             P2 uu = u;
@@ -348,7 +353,7 @@ struct Lobe {
                 if (!same_hemisphere(wo, *wi)) return Spec(0.0f);
             }
             *pdf_out = pdf(wo, *wi);
-            return f(wo, *wi);
+            return sampled_value(wo, *wi);
         }
         }
         return Spec();

@@ -2837,6 +2837,16 @@ __global__ void k_leaf_geom(uint32_t fn, const float* __restrict__ x, uint64_t n
     } else if (fn == RSPT_LIBM_MICROFACET) {     // TrowbridgeReitzDistribution::d / lambda / g1 / g / pdf (dev_bsdf.h)
         const f3 wo{a[0], a[1], a[2]}, wh{a[3], a[4], a[5]};
         r[0] = tr_d(a[6], a[7], wh); r[1] = tr_lambda(a[6], a[7], wo); r[2] = tr_g1(a[6], a[7], wo); r[3] = tr_g(a[6], a[7], wo, wh); r[4] = tr_pdf(a[6], a[7], wo, wh);
+    } else if (fn == RSPT_LIBM_AREA_LIGHT) {     // DiffuseAreaLight::sample_li on one emitting triangle without vertex normals (dev_scene.h light_sample_li / tri_sample_ref), radiance (1, 1, 1)
+        SceneDev sc{};
+        TriRec t; t.p0 = f3{a[0], a[1], a[2]}; t.p1 = f3{a[3], a[4], a[5]}; t.p2 = f3{a[6], a[7], a[8]}; t.material = 0; t.area_light = 0;
+        const uint32_t fl = (uint32_t)a[14];
+        t.flags = (fl & 2u) ? MF_FLIP : 0u;
+        rspt_light lt{}; lt.kind = RSPT_LIGHT_DIFFUSE_AREA; lt.prim = 0; lt.L[0] = lt.L[1] = lt.L[2] = 1.0f; lt.two_sided = (fl & 4u) ? 1u : 0u;
+        f3 wi{0.0f, 0.0f, 0.0f}; float pdf = 0.0f; LightSample ls; ls.p = ls.p_err = ls.n = f3{0.0f, 0.0f, 0.0f};
+        const rgb li = light_sample_li(sc, lt, f3{a[9], a[10], a[11]}, f2{a[12], a[13]}, &wi, &pdf, &ls, &t);
+        r[0] = pdf; r[1] = pdf == 0.0f ? 0.0f : wi.x; r[2] = pdf == 0.0f ? 0.0f : wi.y; r[3] = pdf == 0.0f ? 0.0f : wi.z; r[4] = pdf == 0.0f ? 0.0f : li.r;
+        r[5] = ls.p.x; r[6] = ls.p.y; r[7] = ls.p.z; r[8] = ls.n.x; r[9] = ls.n.y; r[10] = ls.n.z; r[11] = ls.p_err.x; r[12] = ls.p_err.y; r[13] = ls.p_err.z;
     } else {                                     // RSPT_LIBM_VECTORS: vec3_cross_vec3, vec3_coordinate_system, refract, cosine_sample_hemisphere (dev_math.h, dev_bsdf.h)
         const f3 u{a[0], a[1], a[2]}, v{a[3], a[4], a[5]};
         const f3 c = cross(u, v);
@@ -2855,7 +2865,7 @@ extern "C" {
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (n == 0) return RSPT_OK;
-    if (fn > RSPT_LIBM_VECTORS || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (fn >= RSPT_LIBM_MAT4_INVERSE ? (1ull << 27) : (1ull << 31))) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values (2^27 sixteen-float elements)");
+    if (fn > RSPT_LIBM_AREA_LIGHT || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (fn >= RSPT_LIBM_MAT4_INVERSE ? (1ull << 27) : (1ull << 31))) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values (2^27 sixteen-float elements)");
     HIP_TRY(hipSetDevice(g.device));
     float *xd = nullptr, *yd = nullptr, *od = nullptr;
     struct Guard { float **a, **b, **c; ~Guard() { for (float** p : {a, b, c}) if (*p) (void)hipFree(*p); } } guard{&xd, &yd, &od};

@@ -207,11 +207,11 @@ def mat4_inverse(m):
     return out
 
 
-LEAF_GEOM = {"triangle": 8, "box": 9, "offset_ray_origin": 10, "microfacet": 11, "vectors": 12}
+LEAF_GEOM = {"triangle": 8, "box": 9, "offset_ray_origin": 10, "microfacet": 11, "vectors": 12, "area_light": 13}
 
 
 def leaf_geom(fn, x):
-    """rspt_libm codes 8 .. 12 (include/rspt.h): the traversal / shading geometry as the kernels call it — n elements of 16 floats in, 16 floats out"""
+    """rspt_libm codes 8 .. 13 (include/rspt.h): the traversal / shading geometry as the kernels call it — n elements of 16 floats in, 16 floats out"""
     x = np.ascontiguousarray(x, np.float32).reshape(-1, 16)
     out = np.empty_like(x)
     _check(lib().rspt_libm(LEAF_GEOM[fn], x.ctypes.data, None, len(x), out.ctypes.data))

@@ -76,6 +76,20 @@ def test_cross_coordinate_system_refract_and_the_cosine_hemisphere_are_the_refer
     assert same_bits(out[:, 13:16], g["csh_out"])
 
 
+def test_area_light_sampling_is_the_references_text(g):
+    """DiffuseAreaLight::sample_li over Triangle::sample / sample_with_ref_point as the shade and directlighting kernels call it (dev_scene.h light_sample_li): pdf, wi,
+    radiance, the sampled point, its normal and error bound — the cases of the fixture without vertex normals (the hook carries one triangle, no scene)"""
+    sel = (g["al_flags"] & 1) == 0
+    n = int(sel.sum())
+    assert n > 1500
+    x = pack(n, g["al_tri"][sel], g["al_ref"][sel], g["al_u"][sel], g["al_flags"][sel].astype(np.float32))
+    out = lib.leaf_geom("area_light", x)
+    ref = g["al_out"][sel]
+    lit = ref[:, 4:7].sum(axis=1) > 0                                  # the fixture's radiance is L or 0; the hook's light has L = 1
+    assert same_bits(out[:, 0:4], ref[:, 0:4]) and np.array_equal(out[:, 4] == 1, lit)
+    assert same_bits(out[:, 5:14], ref[:, 7:16])
+
+
 def test_the_traversal_kernels_walk_the_tree_as_the_references_text_does(g):
     """rspt_trace (k_trace_w4 closest / any, and with it the four-box records, the persistent waves, the deferred leaf phase) against BVHAccel::intersect / intersect_p
     compiled from the reference's text (bvh.rs:401-514 over primitive.rs:150-156, geometry.rs:2211-2268, triangle.rs:134-273): the hit record and the occlusion flag of

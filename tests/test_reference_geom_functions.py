@@ -23,6 +23,7 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "rfl_out": "reflect", "rfr_out": "refract", "adt_out": "vec3_abs_dot_vec3f", "oro_out": "pnt3_offset_ray_origin", "box_out": "Bounds3f::intersect_p",
          "tri_out": "Triangle::intersect (watertight test)", "trp_out": "Triangle::intersect_p (watertight test)", "mf_out": "TrowbridgeReitzDistribution d / lambda / g1 / g / pdf",
          "rng_u_out": "Rng uniform_uint32 / _bounded", "rng_f_out": "Rng::uniform_float",
+         "al_out": "DiffuseAreaLight::sample_li / l over Triangle::sample / sample_with_ref_point",
          "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample"}
 
 
@@ -56,6 +57,8 @@ def test_oracle_equals_the_references_text_on_the_committed_fixture(oracle):
     assert (g["rfr_out"][:, 3] == 0).sum() > 50                                           # total internal reflection
     assert (g["mf_out"][:16, 0] > 0).all() and (g["mf_out"][16:24, 1] == 0).all()         # D at normal incidence, lambda at grazing incidence (infinite tangent)
     assert (g["oro_out"] != g["oro_p"]).any(axis=1).mean() > 0.9                          # the offset moved the origin, rounded away from it
+    al = g["al_out"]
+    assert (al[:, 0] == 0).sum() > 10 and (al[:, 0] > 0).sum() > 3000 and ((al[:, 0] > 0) & (al[:, 4:7] == 0).all(axis=1)).sum() > 300     # zero / infinite pdf -> 0; one-sided lights seen from behind
     sob = g["sob_out"]
     assert ((sob[:, :, 0] >= g["sob_pixel"][:, None, 0]) & (sob[:, :, 0] < g["sob_pixel"][:, None, 0] + 1)).all()     # the film sample lies in its pixel (the remap of dimensions 0 / 1)
     assert (sob[:, :, 25] == 0).any() and (sob[:, :, 25] == 1).any() and (g["sob_bounds"][:, :2] != 0).any()           # the last sample of a pixel; cropped sample bounds
