@@ -90,6 +90,7 @@ struct SpecularReflection { Spectrum r; Fresnel fresnel; OptSpectrum sc_opt; LOB
 struct SpecularTransmission { Spectrum t; Float eta_a, eta_b; FresnelDielectric fresnel; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
 struct FresnelSpecular { Spectrum r, t; Float eta_a, eta_b; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
 struct MicrofacetReflection { Spectrum r; MicrofacetDistribution distribution; Fresnel fresnel; OptSpectrum sc_opt; LOBE_METHODS };
+struct MicrofacetTransmission { Spectrum t; MicrofacetDistribution distribution; Float eta_a, eta_b; FresnelDielectric fresnel; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
 struct FresnelBlend { Spectrum rd, rs; Option<MicrofacetDistribution> distribution; OptSpectrum sc_opt; Spectrum schlick_fresnel(Float cos_theta) const; LOBE_METHODS };
 struct Bxdf {                                   // one lobe: the oracle's (orc::Lobe) behind Bxdf's method names (reflection.rs:470-560)
     const orc::Lobe* l;
@@ -246,6 +247,7 @@ RULES_FLOW = [
     (r"Float::abs\(", "rs_fabs(", 0),
     (r"let (\w+);", r"Float \1;", 0),
     (r"Spectrum::zero\(\)", "spectrum_default()", 0),
+    (r"let (\w+) = match ([\w.>\-]+) \{\s*([\w:]+) => (.*?),\s*_ => (.*?),\s*\};", r"auto \1 = (\2 == \3) ? Float(\4) : Float(\5);", re.S),
     (r"let mut (\w+): Point2f = \*(\w+);", r"Point2f \1 = \2;", 0),
     (r"&-\(\*?(\w+)\)", r"-\1", 0),
     (r"&(\w+)\.into\(\)", r"Normal3f_from(\1)", 0),
@@ -329,7 +331,7 @@ SOURCES = [
     ("core/reflection.rs", ("^impl FresnelNoOp \\{", r"^    pub fn evaluate\("), "evaluate", "FresnelNoOp", True),
 ] + [
     ("core/reflection.rs", ("^impl %s \\{" % cls, r"^    pub fn %s\(" % m), m, cls, True)
-    for cls in ("LambertianReflection", "LambertianTransmission", "OrenNayar", "SpecularReflection", "SpecularTransmission", "FresnelSpecular", "MicrofacetReflection", "FresnelBlend")
+    for cls in ("LambertianReflection", "LambertianTransmission", "OrenNayar", "SpecularReflection", "SpecularTransmission", "FresnelSpecular", "MicrofacetReflection", "MicrofacetTransmission", "FresnelBlend")
     for m in (("schlick_fresnel",) if cls == "FresnelBlend" else ()) + ("f", "sample_f", "pdf", "get_type")
 ] + [
     ("core/reflection.rs", r"^    pub fn num_components\(&self, flags: u8\) -> u8 \{", "num_components", "Bsdf", True),
@@ -361,8 +363,9 @@ def convert_parts():
         if self_type:
             body = body.replace("self.", "self_.")
         body = join_multiline_if(body)
-        for nm in re.findall(r"Vector3f\* (\w+)", sig):        # F9: field access through a `&mut Vector3f` auto-dereferences
+        for nm in re.findall(r"Vector3f\* (\w+)", sig):        # F9: field access through a `&mut Vector3f` auto-dereferences; handing it on as `&Vector3f` re-borrows
             body = re.sub(r"(?<![\w>.])%s\.(?=[xyz]\b)" % nm, nm + "->", body)
+            body = re.sub(r"(this->(?:f|pdf)\(\w+, )%s\)" % nm, r"\1*%s)" % nm, body)
         if name == "li":
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
         for pat, rep, flags in RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
@@ -421,6 +424,7 @@ extern "C" void flow_lobes(const rspt_bxdf* recs, const float* wo, const float* 
             case RSPT_BXDF_SPECULAR_T: run_lobe(SpecularTransmission{S3f(b.r), Float(b.eta_a), Float(b.eta_b), FresnelDielectric{Float(b.eta_a), Float(b.eta_b)}, TransportMode::Radiance, sc}, o, w, uu, t); break;
             case RSPT_BXDF_FRESNEL_SPEC: run_lobe(FresnelSpecular{S3f(b.r), S3f(b.t), Float(b.eta_a), Float(b.eta_b), TransportMode::Radiance, sc}, o, w, uu, t); break;
             case RSPT_BXDF_MICROFACET_R: run_lobe(MicrofacetReflection{S3f(b.r), md, fr, sc}, o, w, uu, t); break;
+            case RSPT_BXDF_MICROFACET_T: run_lobe(MicrofacetTransmission{S3f(b.r), md, Float(b.eta_a), Float(b.eta_b), FresnelDielectric{Float(b.eta_a), Float(b.eta_b)}, TransportMode::Radiance, sc}, o, w, uu, t); break;
             case RSPT_BXDF_FRESNEL_BLEND: run_lobe(FresnelBlend{S3f(b.r), S3f(b.t), Option<MicrofacetDistribution>{true, md}, sc}, o, w, uu, t); break;
             default: break;
         }

@@ -90,11 +90,11 @@ def test_li_text_equals_the_oracles_li_on_random_scenes(flow, oracle, seed):
 
 
 def lobe_cases(n, seed):
-    """random lobe records of every kind a material can build (except MicrofacetTransmission), with and without a MixMaterial scale, and directions over both hemispheres
+    """random lobe records of every kind a material can build, with and without a MixMaterial scale, and directions over both hemispheres
     incl. the degenerate ones the lobes test for (z = 0, wi = -wo, normal incidence)"""
     rng = np.random.default_rng(seed)
     f32 = np.float32
-    kinds = np.array([abi.BXDF_LAMBERT_R, abi.BXDF_LAMBERT_T, abi.BXDF_OREN_NAYAR, abi.BXDF_SPECULAR_R, abi.BXDF_SPECULAR_T, abi.BXDF_FRESNEL_SPEC, abi.BXDF_MICROFACET_R, abi.BXDF_FRESNEL_BLEND], np.uint32)
+    kinds = np.array([abi.BXDF_LAMBERT_R, abi.BXDF_LAMBERT_T, abi.BXDF_OREN_NAYAR, abi.BXDF_SPECULAR_R, abi.BXDF_SPECULAR_T, abi.BXDF_FRESNEL_SPEC, abi.BXDF_MICROFACET_R, abi.BXDF_MICROFACET_T, abi.BXDF_FRESNEL_BLEND], np.uint32)
     b = np.zeros(n, abi.BXDF_DT)
     b["type"] = kinds[np.arange(n) % len(kinds)]
     b["fresnel"] = rng.integers(0, 3, n)
@@ -118,7 +118,7 @@ def lobe_cases(n, seed):
 
 
 def test_every_lobes_f_pdf_and_sample_f_text_equals_the_oracles(flow):
-    """LambertianReflection / Transmission, OrenNayar, SpecularReflection / Transmission, FresnelSpecular, MicrofacetReflection and FresnelBlend (reflection.rs:711-1478:
+    """LambertianReflection / Transmission, OrenNayar, SpecularReflection / Transmission, FresnelSpecular, MicrofacetReflection / Transmission and FresnelBlend (reflection.rs:711-1478:
     f, pdf, sample_f, get_type of each, over Fresnel::evaluate, TrowbridgeReitzDistribution::sample_wh / d / g / pdf, reflect, refract, cosine_sample_hemisphere — all
     compiled from the reference's text) against the oracle's lobe evaluator on the same records: 2^17 cases, every bit.  Includes the reference's own quirk that a
     MixMaterial scale enters sample_f's value twice where a lobe's sample_f calls its f."""
@@ -135,4 +135,4 @@ def test_every_lobes_f_pdf_and_sample_f_text_equals_the_oracles(flow):
     for kind in np.unique(b["type"]):
         sel = b["type"] == kind
         assert not bad[sel].any(), "lobe kind %d: %s differ in %d of %d cases" % (kind, [names[c] for c in np.nonzero(bad[sel].any(axis=0))[0]], int(bad[sel].any(axis=1).sum()), int(sel.sum()))
-        assert (t[sel, 12] != 0).all() and (t[sel, 10] > 0).mean() > 0.3         # every kind was evaluated and mostly sampled with a positive pdf
+        assert (t[sel, 12] != 0).all() and (t[sel, 10] > 0).mean() > 0.25         # every kind was evaluated and mostly sampled with a positive pdf
