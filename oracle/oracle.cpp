@@ -544,6 +544,23 @@ void orc_geom_sobol(const rspt_sampler_tables* t, const int64_t* spp, const int3
         }
     }
 }
+void orc_geom_triangle_full(const float* tri, const float* nrm, const float* tan, const float* uvs, const int32_t* flags, const float* o, const float* d, const float* tmax, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        Scene sc{};
+        rspt_prim pr{}; pr.v[0] = 0; pr.v[1] = 1; pr.v[2] = 2; pr.mesh = 0; pr.area_light = -1;
+        rspt_mesh m{}; m.has_n = (flags[i] & 1) ? 1u : 0u; m.flip = (flags[i] & 2) ? 1u : 0u; m.has_s = (flags[i] & 4) ? 1u : 0u; m.has_uv = (flags[i] & 8) ? 1u : 0u;
+        sc.d.P = tri + 9 * i; sc.d.N = nrm + 9 * i; sc.d.S = tan + 9 * i; sc.d.UV = uvs + 6 * i; sc.d.prims = &pr; sc.d.n_prims = 1; sc.d.meshes = &m; sc.d.n_meshes = 1;
+        Ray r{}; r.o = V3{o[3 * i], o[3 * i + 1], o[3 * i + 2]}; r.d = V3{d[3 * i], d[3 * i + 1], d[3 * i + 2]}; r.t_max = tmax[i]; r.time = 0.0f;
+        float* q = out + 48 * i;
+        for (int k = 0; k < 48; k++) q[k] = 0.0f;
+        Float t = 0.0f; Interaction si;
+        if (!sc.tri_intersect(pr, r, &t, &si)) continue;
+        auto put = [&](int k, V3 v) { q[k] = v.x; q[k + 1] = v.y; q[k + 2] = v.z; };
+        q[0] = 1.0f; q[1] = t; put(2, si.p); put(5, si.p_error); put(8, si.wo); put(11, si.n); q[14] = si.uv.x; q[15] = si.uv.y; put(16, si.dpdu); put(19, si.dpdv);
+        // q[22 .. 27]: isect.dndu / dndv stay zero in the reference (triangle.rs:322-323, 433-434: the shading block's values shadow them)
+        put(28, si.sh_n); put(31, si.sh_dpdu); put(34, si.sh_dpdv); put(37, si.sh_dndu); put(40, si.sh_dndv);
+    }
+}
 void orc_geom_area_light(const float* tri, const float* nrm, const int32_t* flags, const float* L, const float* ref_p, const float* u, uint64_t n, float* out) {   // light_sample_li on one emitting triangle
     for (uint64_t i = 0; i < n; i++) {
         Scene sc{};

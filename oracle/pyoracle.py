@@ -310,6 +310,7 @@ def geom(d):
         "box_out": call("orc_geom_box", [d["box_b"], d["box_o"], d["box_inv"], d["box_neg"], d["box_tmax"]], n),
         "tri_out": call("orc_geom_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5)),
         "mf_out": call("orc_geom_microfacet", [d["mf_wo"], d["mf_wh"], d["mf_ax"], d["mf_ay"]], (n, 5)),
+        "trf_out": call("orc_geom_triangle_full", [d["tri_p"], d["trf_n"], d["trf_s"], d["trf_uv"], d["trf_flags"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 48)),
         "al_out": call("orc_geom_area_light", [d["al_tri"], d["al_nrm"], d["al_flags"], d["al_L"], d["al_ref"], d["al_u"]], (n, 16)),
     }
     from rs_pbrt_amd import scenes

@@ -23,6 +23,7 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "rfl_out": "reflect", "rfr_out": "refract", "adt_out": "vec3_abs_dot_vec3f", "oro_out": "pnt3_offset_ray_origin", "box_out": "Bounds3f::intersect_p",
          "tri_out": "Triangle::intersect (watertight test)", "trp_out": "Triangle::intersect_p (watertight test)", "mf_out": "TrowbridgeReitzDistribution d / lambda / g1 / g / pdf",
          "rng_u_out": "Rng uniform_uint32 / _bounded", "rng_f_out": "Rng::uniform_float",
+         "trf_out": "the whole Triangle::intersect: hit point, error bound, normals, uv, dpdu / dpdv, the shading frame and dndu / dndv",
          "al_out": "DiffuseAreaLight::sample_li / l over Triangle::sample / sample_with_ref_point",
          "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample"}
 
