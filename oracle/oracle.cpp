@@ -561,6 +561,24 @@ void orc_geom_triangle_full(const float* tri, const float* nrm, const float* tan
         put(28, si.sh_n); put(31, si.sh_dpdu); put(34, si.sh_dpdv); put(37, si.sh_dndu); put(40, si.sh_dndv);
     }
 }
+// Film::get_film_tile + FilmTile::add_sample + Film::merge_film_tile: per case a 16 x 16 film (crop window = the frame), one tile of samples.  geo: n x 8 ints = tile x0 y0 x1 y1, n_samples, 3 unused;
+// flt: n x 260 = filter radius x / y, max_sample_luminance, unused, the 16 x 16 filter table;  smp: n x 64 x 5 = p_film, L;  out: n x 256 x 4
+void orc_geom_film(const int32_t* geo, const float* flt, const float* smp, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        rspt_render_desc rd{};
+        rd.crop_px[0] = rd.crop_px[1] = 0; rd.crop_px[2] = rd.crop_px[3] = 16;
+        rd.filter_radius[0] = flt[260 * i]; rd.filter_radius[1] = flt[260 * i + 1]; rd.max_sample_luminance = flt[260 * i + 2];
+        for (int k = 0; k < 256; k++) rd.filter_table[k] = flt[260 * i + 4 + k];
+        FilmTile t = get_film_tile(rd, geo + 8 * i);
+        for (int k = 0; k < geo[8 * i + 4]; k++) {
+            const float* q = smp + (64 * i + k) * 5;
+            t.add_sample(rd, P2{q[0], q[1]}, Spec(q[2], q[3], q[4]), 1.0f);
+        }
+        float* film = out + 1024 * i;
+        for (int k = 0; k < 1024; k++) film[k] = 0.0f;
+        merge_film_tile(rd, t, film);
+    }
+}
 void orc_geom_area_light(const float* tri, const float* nrm, const int32_t* flags, const float* L, const float* ref_p, const float* u, uint64_t n, float* out) {   // light_sample_li on one emitting triangle
     for (uint64_t i = 0; i < n; i++) {
         Scene sc{};

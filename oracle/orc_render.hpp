@@ -1481,6 +1481,21 @@ static inline FilmTile get_film_tile(const rspt_render_desc& rd, const int32_t t
     return t;
 }
 
+// Film::merge_film_tile (film.rs:346-371) into film_xyzw = Film.pixels over crop_px (xyz + filter_weight_sum per pixel)
+static inline void merge_film_tile(const rspt_render_desc& rd, const FilmTile& t, float* film_xyzw) {
+    const int cw = rd.crop_px[2] - rd.crop_px[0];
+    const int w = t.pb[2] - t.pb[0];
+    for (int32_t y = t.pb[1]; y < t.pb[3]; y++)
+        for (int32_t x = t.pb[0]; x < t.pb[2]; x++) {
+            const FilmTilePixel& tp = t.pixels[(size_t)(y - t.pb[1]) * w + (x - t.pb[0])];
+            float* mp = film_xyzw + 4 * ((size_t)(y - rd.crop_px[1]) * cw + (x - rd.crop_px[0]));
+            Float xyz[3];
+            rgb_to_xyz(tp.contrib_sum.c, xyz);
+            for (int i = 0; i < 3; i++) mp[i] += xyz[i];
+            mp[3] += tp.filter_weight_sum;
+        }
+}
+
 // blockqueue/mod.rs:100-115
 static inline uint32_t part1_by1(uint32_t x) {
     x &= 0x0000ffff; x = (x ^ (x << 8)) & 0x00ff00ff; x = (x ^ (x << 4)) & 0x0f0f0f0f;
@@ -1588,18 +1603,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
     // nondeterministic; only pixels with >=3 contributing tiles can tell the difference)
     if (film_xyzw) {
         std::memset(film_xyzw, 0, sizeof(float) * 4 * (size_t)cw * ch);
-        for (const FilmTile& t : tiles) {
-            int w = t.pb[2] - t.pb[0];
-            for (int32_t y = t.pb[1]; y < t.pb[3]; y++)
-                for (int32_t x = t.pb[0]; x < t.pb[2]; x++) {
-                    const FilmTilePixel& tp = t.pixels[(size_t)(y - t.pb[1]) * w + (x - t.pb[0])];
-                    float* mp = film_xyzw + 4 * ((size_t)(y - rd.crop_px[1]) * cw + (x - rd.crop_px[0]));
-                    Float xyz[3];
-                    rgb_to_xyz(tp.contrib_sum.c, xyz);
-                    for (int i = 0; i < 3; i++) mp[i] += xyz[i];
-                    mp[3] += tp.filter_weight_sum;
-                }
-        }
+        for (const FilmTile& t : tiles) merge_film_tile(rd, t, film_xyzw);
     }
     auto t1 = std::chrono::steady_clock::now();
     if (out) {

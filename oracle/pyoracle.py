@@ -313,6 +313,13 @@ def geom(d):
         "trf_out": call("orc_geom_triangle_full", [d["tri_p"], d["trf_n"], d["trf_s"], d["trf_uv"], d["trf_flags"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 48)),
         "al_out": call("orc_geom_area_light", [d["al_tri"], d["al_nrm"], d["al_flags"], d["al_L"], d["al_ref"], d["al_u"]], (n, 16)),
     }
+    nf = len(d["flm_geo"])
+    L.orc_geom_film.restype = None
+    L.orc_geom_film.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p]
+    fo = np.zeros((nf, 256, 4), np.float32)
+    fg, ff, fs = np.ascontiguousarray(d["flm_geo"], np.int32), np.ascontiguousarray(d["flm_flt"], np.float32), np.ascontiguousarray(d["flm_smp"], np.float32)
+    L.orc_geom_film(fg.ctypes.data, ff.ctypes.data, fs.ctypes.data, nf, fo.ctypes.data)
+    out["flm_out"] = fo
     from rs_pbrt_amd import scenes
     tables = scenes.sobol_tables().as_struct(None)
     L.orc_geom_sobol.restype = None

@@ -24,6 +24,7 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "tri_out": "Triangle::intersect (watertight test)", "trp_out": "Triangle::intersect_p (watertight test)", "mf_out": "TrowbridgeReitzDistribution d / lambda / g1 / g / pdf",
          "rng_u_out": "Rng uniform_uint32 / _bounded", "rng_f_out": "Rng::uniform_float",
          "trf_out": "the whole Triangle::intersect: hit point, error bound, normals, uv, dpdu / dpdv, the shading frame and dndu / dndv",
+         "flm_out": "Film::get_film_tile, FilmTile::add_sample, Film::merge_film_tile (box and gaussian filter tables, tiles across the frame's border, the luminance clamp)",
          "al_out": "DiffuseAreaLight::sample_li / l over Triangle::sample / sample_with_ref_point",
          "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample"}
 
@@ -60,6 +61,8 @@ def test_oracle_equals_the_references_text_on_the_committed_fixture(oracle):
     assert (g["oro_out"] != g["oro_p"]).any(axis=1).mean() > 0.9                          # the offset moved the origin, rounded away from it
     al = g["al_out"]
     assert (al[:, 0] == 0).sum() > 10 and (al[:, 0] > 0).sum() > 3000 and ((al[:, 0] > 0) & (al[:, 4:7] == 0).all(axis=1)).sum() > 300     # zero / infinite pdf -> 0; one-sided lights seen from behind
+    flm = g["flm_out"]
+    assert (flm[:, :, 3] > 0).any(axis=1).mean() > 0.8 and (flm[:, :, 3] == 0).any()             # every tile reached the film; pixels no sample reached stay zero
     sob = g["sob_out"]
     assert ((sob[:, :, 0] >= g["sob_pixel"][:, None, 0]) & (sob[:, :, 0] < g["sob_pixel"][:, None, 0] + 1)).all()     # the film sample lies in its pixel (the remap of dimensions 0 / 1)
     assert (sob[:, :, 25] == 0).any() and (sob[:, :, 25] == 1).any() and (g["sob_bounds"][:, :2] != 0).any()           # the last sample of a pixel; cropped sample bounds
