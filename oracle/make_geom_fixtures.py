@@ -206,7 +206,7 @@ static inline Spectrum& operator+=(Spectrum& a, const Spectrum& b) { a = a + b; 
 static inline Spectrum& operator*=(Spectrum& a, const Spectrum& b) { a = a * b; return a; }
 Point2f pnt2_floor(Point2f p); Point2f pnt2_ceil(Point2f p); Point2i pnt2_min_pnt2i(Point2i pa, Point2i pb); Point2i pnt2_max_pnt2i(Point2i pa, Point2i pb);
 Bounds2i bnd2_intersect_bnd2i(const Bounds2i& b1, const Bounds2i& b2); Point2f operator+(const Point2f& a, const Vector2f& b); Point2i operator+(const Point2i& a, const Point2i& b);
-void rgb_to_xyz(const Float* rgb, Float* xyz);
+void rgb_to_xyz(const Float* rgb, Float* xyz); uint32_t part1_by1(uint32_t x); uint32_t morton2(std::pair<uint32_t, uint32_t> p);
 // forward declarations (Rust resolves names in any order)
 Float gamma(int32_t n); Float next_float_up(Float v); Float next_float_down(Float v);
 Float vec3_max_componentf(const Vector3f& v); size_t vec3_max_dimensionf(const Vector3f& v);
@@ -223,7 +223,7 @@ TYPES = dict(base.TYPES)
 TYPES.update({"i64": "int64_t", "i32": "int32_t", "u64": "uint64_t", "usize": "size_t", "f32": "Float", "f64": "double", "u8": "uint8_t", "Point3f": "Point3f", "Normal3f": "Normal3f", "&Point3f": "const Point3f&", "&Normal3f": "const Normal3f&",
               "&Ray": "const Ray&", "&mut Vector3f": "Vector3f*", "&[u8; 3]": "const uint8_t*", "RGBSpectrum": "RGBSpectrum",
               "&mut SurfaceInteraction": "SurfaceInteraction*", "u32": "uint32_t", "LinearBVHNode": "LinearBVHNode",
-              "&Vector2f": "const Vector2f&", "Bounds2i": "Bounds2i", "&Bounds2i": "const Bounds2i&", "Bounds2f": "Bounds2f", "&mut Spectrum": "Spectrum&", "&[Float; 3]": "const Float*", "&mut [Float; 3]": "Float*",
+              "PairU32": "std::pair<uint32_t, uint32_t>", "&Vector2f": "const Vector2f&", "Bounds2i": "Bounds2i", "&Bounds2i": "const Bounds2i&", "Bounds2f": "Bounds2f", "&mut Spectrum": "Spectrum&", "&[Float; 3]": "const Float*", "&mut [Float; 3]": "Float*",
               "&[Float; FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH]": "const Float*", "Self": "FilmTile", "FilmTile": "FilmTile", "&FilmTile": "const FilmTile&",
               "Vector2f": "Vector2f", "Shading": "Shading", "Point2fArray3": "std::array<Point2f, 3>",
               "InteractionCommon": "InteractionCommon", "&InteractionCommon": "const InteractionCommon&", "&mut InteractionCommon": "InteractionCommon&",
@@ -292,6 +292,8 @@ SOURCES = [
     ("shapes/triangle.rs", None, r"^    pub fn sample_with_ref_point\($", "sample_with_ref_point", "Triangle", None, None, None, ("light",)),
     ("lights/diffuse.rs", None, r"^    pub fn sample_li<'a, 'b>\($", "sample_li", "DiffuseAreaLight", None, None, None, ("light",)),
     ("lights/diffuse.rs", None, r"^    pub fn l\(&self, intr: &InteractionCommon, w: &Vector3f\) -> Spectrum \{", "l", "DiffuseAreaLight", None, None, None, ("light",)),
+    ("blockqueue/mod.rs", None, r"^fn part1_by1\(", "part1_by1", None, None, None, None, ("int", "morton")),
+    ("blockqueue/mod.rs", None, r"^fn morton2\(", "morton2", None, None, None, None, ("int", "morton")),
     ("core/pbrt.rs", None, r"^pub fn round_up_pow2_32\(", "round_up_pow2_32", None, None, None, None, ("int",)),
     ("core/pbrt.rs", None, r"^pub fn log_2_int_u32\(", "log_2_int_u32", None, None, None, None, ("int",)),
     ("core/geometry.rs", None, r"^impl_op_ex!\(-\|a: &Point2i, b: &Point2i\| -> Vector2i \{", "operator-", None, None, None, None, ("int",)),
@@ -514,6 +516,11 @@ RULES_FULL = [
     (r"let (?:mut )?(\w+): (Normal3f|Vector3f);", r"\2 \1;", 0),
     (r"^(\s*)let (n[012]|s[012]) = ", r"\1auto \2 = ", re.M),
 ]
+RULES_MORTON = [
+    # G25 hexadecimal literals with digit separators; the fields of a pair
+    (r"0x[0-9a-fA-F_]+", lambda m: m.group(0).replace("_", "") + "u", 0),
+    (r"\bp\.0\b", "p.first", 0), (r"\bp\.1\b", "p.second", 0),
+]
 RULES_FILM = [
     # G23 the film: ranges `a..b`, SmallVec, mutable element borrows, min / max on i32, zero-filled float arrays, `for (i, item) in xyz.iter().enumerate()`
     (r"for (\w+) in ([\w.]+)\.\.([\w.]+) \{", r"for (auto \1 = \2; \1 < \3; \1++) {", 0),
@@ -547,7 +554,7 @@ RULES_RNG = [
 
 
 def signature(text, name, cls):
-    text = re.sub(r"<'a, 'b>", "", re.sub(r"&'[ab] ", "&", text)).replace("-> [Point2f; 3] {", "-> Point2fArray3 {")
+    text = re.sub(r"<'a, 'b>", "", re.sub(r"&'[ab] ", "&", text)).replace("-> [Point2f; 3] {", "-> Point2fArray3 {").replace("p: (u32, u32)", "p: PairU32")
     m = re.match(r"(?:pub )?fn (\w+)\((.*?)\)(?: -> ([\w:]+))?\s*\{\n", text, re.S)
     args, ret = m.group(2), m.group(3)
     out, params, const, refs = [], [], "", []
@@ -558,6 +565,7 @@ def signature(text, name, cls):
             is_static = False
             continue
         n, t = [x.strip() for x in a.split(":", 1)]
+        n = n[4:] if n.startswith("mut ") else n                # `mut x: T`: a by-value parameter the body assigns to
         out.append("%s %s" % (TYPES.get(t, "void*"), n))      # (a type this batch has no carrier for only occurs in signatures that are overridden below)
         params.append(n)
         if (t.startswith("&") and not t.startswith("&mut")) or TYPES.get(t, "").endswith("&"):
@@ -662,7 +670,7 @@ def convert_parts():
         if "full" in extra and name == "intersect_full":
             i0 = body.index("if let Some(alpha_mask) = &self.mesh.alpha_mask {") if "if let Some(alpha_mask) = &self.mesh.alpha_mask {" in body else body.index("if let Some(alpha_mask) = &this->mesh.alpha_mask {")
             body = body[:body.rfind("\n", 0, i0)] + body[matching(body, body.index("{", i0), "{", "}") + 1:]      # G22: the alpha-mask block (triangle.rs:313-331) is dropped
-        for pat, rep, flags in (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
+        for pat, rep, flags in (RULES_MORTON if "morton" in extra else []) + (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
             body = re.sub(pat, rep, body, flags=flags)
         body = cast_after_parens(body, "Float", "Float(%s)")
         body = cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -861,6 +869,7 @@ void g_sobol(const int64_t* spp, const int32_t* bounds, const int32_t* pixel, ui
         }
     }
 }
+void g_morton(const uint32_t* xy, uint64_t n, uint32_t* out) { for (uint64_t i = 0; i < n; i++) out[i] = morton2(std::pair<uint32_t, uint32_t>{xy[2 * i], xy[2 * i + 1]}); }
 void g_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {   // per sequence: 4 words, 2 floats, 2 bounded draws
     for (uint64_t i = 0; i < n; i++) {
         Rng r; r.set_sequence(seq[i]);
@@ -1016,6 +1025,7 @@ def inputs(n=1 << 12, seed=0x6E0A):
     smp[:, :8, 0] = np.floor(smp[:, :8, 0]) + 0.5; smp[:, 8:16, 1] = np.floor(smp[:, 8:16, 1]); smp[:, 16:20, 0] = np.floor(smp[:, 16:20, 0])      # pixel centres (a zero offset), pixel borders
     smp[:, :, 2:] = np.exp(rng.uniform(-3, 3, (nf, 64, 3)))
     d["flm_geo"], d["flm_flt"], d["flm_smp"] = geo, flt, smp
+    d["mor_xy"] = np.concatenate([rng.integers(0, 1 << 16, (n - 8, 2)), [[0, 0], [1, 0], [0, 1], [65535, 65535], [65535, 0], [0, 65535], [255, 256], [119, 67]]]).astype(np.uint32)   # tile coordinates (blockqueue/mod.rs)
     # PCG32
     d["rng_seq"] = rng.integers(0, 1 << 63, n, dtype=np.uint64); d["rng_seq"][:4] = [0, 1, 2, (1 << 64) - 1]
     b = rng.integers(1, 1 << 31, n).astype(np.uint32); b[: n // 2] = rng.integers(1, 4096, n // 2); b[:8] = [1, 2, 3, 4, 5, 7, 8, 4096]
@@ -1135,6 +1145,7 @@ def run_reference(L, d):
     L.g_set_tables(words.ctypes.data, vdc.ctypes.data, vdc_inv.ctypes.data)
     L.keep_alive = keep
     out["sob_out"] = call("g_sobol", [d["sob_spp"], d["sob_bounds"], d["sob_pixel"]], (len(d["sob_spp"]), 4, 26), n=len(d["sob_spp"]))
+    out["mor_out"] = call("g_morton", [d["mor_xy"]], n, dtype=np.uint32)
     ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
     L.g_rng.restype = None
     L.g_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]

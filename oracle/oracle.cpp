@@ -579,6 +579,7 @@ void orc_geom_film(const int32_t* geo, const float* flt, const float* smp, uint6
         merge_film_tile(rd, t, film);
     }
 }
+void orc_geom_morton(const uint32_t* xy, uint64_t n, uint32_t* out) { for (uint64_t i = 0; i < n; i++) out[i] = morton2(xy[2 * i], xy[2 * i + 1]); }
 void orc_geom_area_light(const float* tri, const float* nrm, const int32_t* flags, const float* L, const float* ref_p, const float* u, uint64_t n, float* out) {   // light_sample_li on one emitting triangle
     for (uint64_t i = 0; i < n; i++) {
         Scene sc{};

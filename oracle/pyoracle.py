@@ -313,6 +313,7 @@ def geom(d):
         "trf_out": call("orc_geom_triangle_full", [d["tri_p"], d["trf_n"], d["trf_s"], d["trf_uv"], d["trf_flags"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 48)),
         "al_out": call("orc_geom_area_light", [d["al_tri"], d["al_nrm"], d["al_flags"], d["al_L"], d["al_ref"], d["al_u"]], (n, 16)),
     }
+    out["mor_out"] = call("orc_geom_morton", [np.ascontiguousarray(d["mor_xy"], np.uint32)], n, dtype=np.uint32)
     nf = len(d["flm_geo"])
     L.orc_geom_film.restype = None
     L.orc_geom_film.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p]

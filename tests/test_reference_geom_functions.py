@@ -25,6 +25,7 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "rng_u_out": "Rng uniform_uint32 / _bounded", "rng_f_out": "Rng::uniform_float",
          "trf_out": "the whole Triangle::intersect: hit point, error bound, normals, uv, dpdu / dpdv, the shading frame and dndu / dndv",
          "flm_out": "Film::get_film_tile, FilmTile::add_sample, Film::merge_film_tile (box and gaussian filter tables, tiles across the frame's border, the luminance clamp)",
+         "mor_out": "morton2 / part1_by1 (the tile order of BlockQueue)",
          "al_out": "DiffuseAreaLight::sample_li / l over Triangle::sample / sample_with_ref_point",
          "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample"}
 
