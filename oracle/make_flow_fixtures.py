@@ -31,9 +31,7 @@ OUT_DIR = base.OUT_DIR
 CARRIERS = r"""
 // ---- carriers of the path integrator's control flow: the reference's names over the oracle's leaf functions (namespace orc, oracle/orc_*.hpp).  No arithmetic here
 // beyond element-wise Spectrum operators (core/spectrum.rs: every operator of RGBSpectrum is element-wise) ----
-static inline Spectrum& operator+=(Spectrum& a, const Spectrum& b) { a = a + b; return a; }
-static inline Spectrum& operator*=(Spectrum& a, const Spectrum& b) { a = a * b; return a; }
-static inline Spectrum& operator/=(Spectrum& a, Float b) { a = a / b; return a; }
+static inline Spectrum& operator/=(Spectrum& a, Float b) { a = a / b; return a; }      // (+= and *= come with the film's carriers, oracle/make_geom_fixtures.py)
 static inline Float rs_fmax(Float a, Float b) { return a.max(b); } static inline Float rs_fmin(Float a, Float b) { return a.min(b); } static inline Float rs_fabs(Float a) { return a.abs(); }
 static inline Spectrum spectrum_default() { return Spectrum::new_(Float(0.0f)); }                     // #[derive(Default)]: zeros
 static inline Vector3f vector3f_default() { return Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
@@ -62,6 +60,7 @@ static inline orc::Ray to_orc(const Ray& r) {
 }
 template <class T> struct Option { bool some; T v; bool is_some() const { return some; } T& unwrap() { return v; } const T& unwrap() const { return v; } };
 template <class T> static inline Option<T> Some(const T& v) { return Option<T>{true, v}; }
+template <class T> static inline Option<T*> SomeMut(T& v) { return Option<T*>{true, &v}; }      // Some(&mut x)
 enum class TransportMode { Radiance, Importance };
 enum class BxdfType : uint8_t { BsdfReflection = 1, BsdfTransmission = 2, BsdfDiffuse = 4, BsdfGlossy = 8, BsdfSpecular = 16, BsdfAll = 31 };   // reflection.rs:57-64
 struct Scene;
@@ -214,13 +213,25 @@ inline Option<LightRef> SurfaceInteraction::get_area_light() const {
     const rspt_prim& hp = scene->cx->scene->hit_prim(it);
     return Option<LightRef>{hp.area_light >= 0, LightRef{scene, (uint32_t)(hp.area_light >= 0 ? hp.area_light : 0)}};
 }
-struct Distribution1D {
-    const orc::Distribution1D* d;
-    size_t sample_discrete(Float u, Option<Float*> pdf) const { float p = 0.0f; const size_t i = d->sample_discrete(u.v, &p); if (pdf.some) *pdf.v = Float(p); return i; }
+struct NoneAny { template <class T> operator Option<T>() const { return Option<T>{false, T{}}; } };
+static const NoneAny NoneOpt{};
+struct Distribution1D {                          // sampling.rs:17-21; every method below is the reference's text (sampling.rs:24-147)
+    Vec<Float> func, cdf; Float func_int;
+    static Distribution1D new_(Vec<Float> f);
+    size_t count() const; Float sample_continuous(Float u, Option<Float*> pdf, Option<size_t*> off) const; size_t sample_discrete(Float u, Option<Float*> pdf) const; Float discrete_pdf(size_t index) const;
+    static Distribution1D from(const orc::Distribution1D& d) { Distribution1D r; for (float v : d.func) r.func.push(Float(v)); for (float v : d.cdf) r.cdf.push(Float(v)); r.func_int = Float(d.func_int); return r; }
 };
+struct Distribution2D {                          // sampling.rs:150-153
+    Vec<Distribution1D> p_conditional_v; Distribution1D p_marginal;
+    Point2f sample_continuous(Point2f u, Float* pdf) const; Float pdf(Point2f p) const;
+};
+int64_t clamp_t(int64_t val, int64_t low, int64_t high); size_t clamp_t(size_t val, size_t low, size_t high);
 struct OptFloat { bool some; Float v; Option<Float*> as_mut() { return Option<Float*>{some, &v}; } Float unwrap() const { return v; } };
 static inline OptFloat SomeFloat(Float v) { return OptFloat{true, v}; }
-struct LightDistribution { orc::RenderCtx* cx; Distribution1D lookup(const Point3f& p) const { return Distribution1D{cx->scene->d.n_lights ? orc::light_lookup(*cx, V(p)) : nullptr}; } };
+struct LightDistribution {                      // LightDistribution::lookup: the oracle's table (uniform / power / spatial), handed on as the reference's Distribution1D
+    orc::RenderCtx* cx;
+    Distribution1D lookup(const Point3f& p) const { return cx->scene->d.n_lights ? Distribution1D::from(*orc::light_lookup(*cx, V(p))) : Distribution1D{}; }
+};
 struct Sampler {
     orc::Sampler* s;
     Float get_1d() { return Float(s->get_1d()); }
@@ -236,10 +247,20 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
+TYPES.update({"Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
 RULES_FLOW = [
+    # F11 Distribution1D / 2D: inclusive ranges, Vec::with_capacity, the two iter_mut().skip(1).take(n) loops, isize arithmetic, the struct literal, Some(&mut (x)), None
+    (r"for (\w+) in 1\.\.=(\w+) \{", r"for (size_t \1 = 1; \1 <= \2; \1++) {", 0),
+    (r"let mut (\w+): Vec<Float> = Vec::with_capacity\(.*?\);", r"Vec<Float> \1;", 0),
+    (r"for \((\w+), (\w+)\) in (\w+)\.iter_mut\(\)\.enumerate\(\)\.skip\(1\)\.take\((\w+)\) \{", r"for (size_t \1 = 1; \1 < 1 + \4 && \1 < \3.len(); \1++) { Float* \2 = &\3[\1];", 0),
+    (r"for (\w+) in (\w+)\.iter_mut\(\)\.skip\(1\)\.take\((\w+)\) \{", r"for (size_t i_ = 1; i_ < 1 + \3 && i_ < \2.len(); i_++) { Float* \1 = &\2[i_];", 0),
+    (r"\b(\w+) as isize\b", r"(int64_t)(\1)", 0), (r"((?:this->|self\.)[\w.]+\(\)) as isize", r"(int64_t)(\1)", 0), (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
+    (r"((?:this->|self\.)[\w.\[\]]+\(\)) as Float", r"Float(\1)", 0),
+    (r"Distribution1D \{\s*func: f,\s*cdf,\s*func_int,\s*\}", "Distribution1D{f, cdf, func_int}", re.S),
+    (r"Some\(&mut \((\w+\[\d\])\)\)", r"SomeMut(\1)", 0), (r"Some\(&mut (\w+)\)", r"SomeMut(\1)", 0),
+    (r"let mut (\w+): \[Float; 2\] = \[Float\(0\.0\); 2\];|let mut (\w+): \[Float; 2\] = \[0\.0 as Float; 2\];", lambda m: "Float %s[2] = {};" % (m.group(1) or m.group(2)), 0),
     # F8  lobes: `} else if let Some(x) = E {`;  an assignment that ends a block without `;`;  associated functions of f32;  untyped `let x;`;  Spectrum::zero()
     (r"\} else if let Some\((?:ref )?(\w+)\) = ((?:this->)?[\w.]+) \{", r"} else if (\2.is_some()) { const auto \1 = \2.unwrap();", 0),
     (r"(\*sampled_type = [^;{}\n]*(?:\n\s*\|[^;{}\n]*)*)\n(\s*)\}", r"\1;\n\2}", 0),
@@ -282,6 +303,7 @@ RULES_FLOW = [
     (r"\b([\w.]+)\.max_component_value\(\)", r"spectrum_max_component_value(\1)", 0),
     (r"std::cmp::min\(", "std::min<size_t>(", 0),
     (r"\b(\d+)_usize\b", r"\1", 0),
+    (r"\bNone\b", "NoneOpt", 0),
 ]
 
 
@@ -321,6 +343,15 @@ def drop_block(body, head):
 
 SOURCES = [
     ("core/geometry.rs", r"^pub fn vec3_abs_dot_nrmf\(", "vec3_abs_dot_nrmf", None, False),
+    ("core/pbrt.rs", r"^pub fn clamp_t<T>", "clamp_t@int64_t", None, True),
+    ("core/pbrt.rs", r"^pub fn clamp_t<T>", "clamp_t@size_t", None, True),
+    ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn new\(f: Vec<Float>\) -> Self \{"), "new_", "Distribution1D", True),
+    ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn count\(&self\)"), "count", "Distribution1D", True),
+    ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn sample_continuous\($"), "sample_continuous", "Distribution1D", True),
+    ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn sample_discrete\($"), "sample_discrete", "Distribution1D", True),
+    ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn discrete_pdf\("), "discrete_pdf", "Distribution1D", True),
+    ("core/sampling.rs", ("^impl Distribution2D \\{", r"^    pub fn sample_continuous\(&self, u: Point2f, pdf: &mut Float\) -> Point2f \{"), "sample_continuous", "Distribution2D", True),
+    ("core/sampling.rs", ("^impl Distribution2D \\{", r"^    pub fn pdf\(&self, p: Point2f\) -> Float \{"), "pdf", "Distribution2D", True),
     ("core/reflection.rs", r"^pub fn vec3_same_hemisphere_vec3\(", "vec3_same_hemisphere_vec3", None, False),
     ("core/reflection.rs", r"^fn pow5\(", "pow5", None, False),
     ("core/geometry.rs", r"^pub fn nrm_faceforward_vec3\(", "nrm_faceforward_vec3", None, False),
@@ -359,7 +390,13 @@ def convert_parts():
             self_type, cls = cls[1:], None
             text = text.replace("&self,", "self_: &%s," % self_type)
         text = re.sub(r"^\s*//.*\n", "", text, flags=re.M)                      # (comment lines sit inside li's argument list)
-        sig, body, params = geom.signature(text, name, cls)
+        if name.startswith("clamp_t@"):             # the generic clamp_t (pbrt.rs:108-121) instantiated at another T: the base's signature rule with its type table switched
+            ty = name.split("@")[1]
+            saved_t = base.TYPES["T"]; base.TYPES["T"] = ty
+            sig, body, params = base.signature(text)
+            name = "clamp_t"
+        else:
+            sig, body, params = geom.signature(text.replace("/* TODO: Float *uRemapped = nullptr */", ""), name, cls)
         if self_type:
             body = body.replace("self.", "self_.")
         body = join_multiline_if(body)
@@ -374,8 +411,9 @@ def convert_parts():
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
         for pat, rep, flags in base.RULES:
             body = re.sub(pat, rep, body, flags=flags)
-        body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|i8|usize|bool|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f|VisibilityTester|InteractionCommon) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+        body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|i8|usize|bool|Float|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f|VisibilityTester|InteractionCommon) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
         body = re.sub(r"\blet (\w+): (usize|Float);", lambda m: "%s %s;" % (TYPES[m.group(2)], m.group(1)), body)
+        base.TYPES["T"] = "Float"
         body = base.shadowing(body, set(params) | set(geom.FN_NAMES) | {"li"})
         body = geom.tail_value(body)
         code = "// %s%s:%d-%d\n%s%s" % (REF, fname, l0, l1, sig, body)
@@ -434,6 +472,34 @@ extern "C" void flow_lobes(const rspt_bxdf* recs, const float* wo, const float* 
         orc::V3 sw{0, 0, 0}; float pdf = 0.0f; uint8_t st = 255;
         const orc::Spec sf = l.sample_f(V(o), &sw, orc::P2{uu.x.v, uu.y.v}, &pdf, &st);
         q[4] = sf.c[0]; q[5] = sf.c[1]; q[6] = sf.c[2]; q[7] = sw.x; q[8] = sw.y; q[9] = sw.z; q[10] = pdf; q[11] = (float)st; q[12] = (float)l.get_type();
+    }
+}
+// Distribution1D::new / sample_discrete / sample_continuous / discrete_pdf and Distribution2D::sample_continuous / pdf (the environment light's image), text next to oracle.
+// func: nv rows of nu values; u: n x 2.  out (per side): [cdf of row 0 (nu + 1), func_int] then per sample 10 floats
+extern "C" void flow_distributions(const float* func, uint32_t nu, uint32_t nv, const float* u, uint64_t n, float* head_text, float* head_oracle, float* out_text, float* out_oracle) {
+    using namespace flow;
+    Vec<Float> f0; for (uint32_t k = 0; k < nu; k++) f0.push(Float(func[k]));
+    const Distribution1D d1 = Distribution1D::new_(f0);
+    const orc::Distribution1D o1(std::vector<float>(func, func + nu));
+    for (uint32_t k = 0; k <= nu; k++) { head_text[k] = d1.cdf[k].v; head_oracle[k] = o1.cdf[k]; }
+    head_text[nu + 1] = d1.func_int.v; head_oracle[nu + 1] = o1.func_int;
+    Distribution2D d2; Vec<Float> marg;
+    for (uint32_t v = 0; v < nv; v++) { Vec<Float> row; for (uint32_t k = 0; k < nu; k++) row.push(Float(func[v * nu + k])); d2.p_conditional_v.push(Distribution1D::new_(row)); marg.push(d2.p_conditional_v[v].func_int); }
+    d2.p_marginal = Distribution1D::new_(marg);                      // Distribution2D::new (sampling.rs:156-171): its rows and the marginal over their integrals
+    const orc::Distribution2D o2(func, nu, nv);
+    for (uint64_t i = 0; i < n; i++) {
+        float* t = out_text + 10 * i; float* q = out_oracle + 10 * i;
+        const Float ux(u[2 * i]), uy(u[2 * i + 1]);
+        Float pdf(0.0f); size_t off = 0;
+        t[0] = (float)d1.sample_discrete(ux, SomeMut(pdf)); t[1] = pdf.v;
+        t[2] = d1.sample_continuous(ux, SomeMut(pdf), SomeMut(off)).v; t[3] = pdf.v; t[4] = (float)off; t[5] = d1.discrete_pdf(off).v;
+        Float p2(0.0f); const Point2f s = d2.sample_continuous(Point2f{ux, uy}, &p2);
+        t[6] = s.x.v; t[7] = s.y.v; t[8] = p2.v; t[9] = d2.pdf(Point2f{ux, uy}).v;
+        float op = 0.0f; size_t oo = 0;
+        q[0] = (float)o1.sample_discrete(ux.v, &op); q[1] = op;
+        q[2] = orc::Distribution2D::sample_continuous_1d(o1, ux.v, &op, &oo); q[3] = op; q[4] = (float)oo; q[5] = o1.func[oo] / (o1.func_int * (float)o1.func.size());
+        float op2 = 0.0f; const orc::P2 os = o2.sample_continuous(orc::P2{ux.v, uy.v}, &op2);
+        q[6] = os.x; q[7] = os.y; q[8] = op2; q[9] = o2.pdf(orc::P2{ux.v, uy.v});
     }
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {

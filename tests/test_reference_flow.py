@@ -136,3 +136,30 @@ def test_every_lobes_f_pdf_and_sample_f_text_equals_the_oracles(flow):
         sel = b["type"] == kind
         assert not bad[sel].any(), "lobe kind %d: %s differ in %d of %d cases" % (kind, [names[c] for c in np.nonzero(bad[sel].any(axis=0))[0]], int(bad[sel].any(axis=1).sum()), int(sel.sum()))
         assert (t[sel, 12] != 0).all() and (t[sel, 10] > 0).mean() > 0.25         # every kind was evaluated and mostly sampled with a positive pdf
+
+
+@pytest.mark.parametrize("shape,kind", [((7, 1), "lights"), ((64, 32), "image"), ((5, 3), "zeros"), ((1, 1), "single")])
+def test_distribution_text_equals_the_oracles(flow, shape, kind):
+    """Distribution1D::new / sample_discrete / sample_continuous / discrete_pdf (sampling.rs:24-147: the table behind every light choice) and Distribution2D's
+    sample_continuous / pdf (the environment light's image, sampling.rs:172-198) from the reference's text against the oracle's: cdf, integral, and 2^15 samples each —
+    over a handful of light powers, a 64 x 32 image with black rows, an all-zero function (the uniform fall-back), a single entry"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(hash(kind) & 0xffff)
+    nu, nv = shape
+    f = np.exp(rng.uniform(-3, 3, (nv, nu))).astype(np.float32)
+    if kind == "image":
+        f[5] = 0.0; f[:, 7] = 0.0
+    if kind == "zeros":
+        f[:] = 0.0
+    n = 1 << 15
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32).clip(0, np.nextafter(np.float32(1), np.float32(0)))
+    u[:4] = [[0, 0], [0.99999994, 0.99999994], [0.5, 0.5], [0, 0.99999994]]
+    ht, ho = np.zeros(nu + 2, np.float32), np.zeros(nu + 2, np.float32)
+    t, o = np.zeros((n, 10), np.float32), np.zeros((n, 10), np.float32)
+    L.flow_distributions.restype = None
+    L.flow_distributions.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
+    L.flow_distributions(f.ctypes.data, nu, nv, u.ctypes.data, n, ht.ctypes.data, ho.ctypes.data, t.ctypes.data, o.ctypes.data)
+    assert np.array_equal(ht.view(np.uint32), ho.view(np.uint32)), "cdf / integral differ"
+    bad = (t.view(np.uint32) != o.view(np.uint32)) & ~(np.isnan(t) & np.isnan(o))
+    assert not bad.any(), "columns %s differ in %d samples" % (np.nonzero(bad.any(axis=0))[0], int(bad.any(axis=1).sum()))
