@@ -601,7 +601,7 @@ int rspt_motion_bounds(const float start_m[16], float start_time, const float en
  * RSPT_LIBM_MAT4_INVERSE (round 6): not libm but the same kind of hook — Matrix4x4::inverse (transform.rs:128-200) as the device evaluates it at every visit of a
  * moving instance (rs_pbrt_amd/csrc/mat4_inverse.h: the reference's Gauss-Jordan elimination with static indices); x and out then hold n row-major 4x4 matrices
  * (16 n floats).
- * Codes 8 .. 13 (round 6, still ABI 21: an older library answers RSPT_E_INVALID): the geometry of a traversal / shading step as the kernels call it, one element =
+ * Codes 8 .. 14 (round 6, still ABI 21: an older library answers RSPT_E_INVALID): the geometry of a traversal / shading step as the kernels call it, one element =
  * 16 floats in x and 16 floats in out (unused values 0), so that a test can hold the DEVICE functions to the reference's own text (tests/golden/geom_functions.npz):
  *   RSPT_LIBM_TRIANGLE           x = p0 p1 p2 o d t_max -> out = hit t b0 b1 b2: the watertight test of Triangle::intersect / intersect_p (triangle.rs:134-273, 450-591)
  *   RSPT_LIBM_BOX                x = p_min p_max o inv_dir dir_is_neg[3] t_max -> out[0] = Bounds3f::intersect_p (geometry.rs:2211-2268) as k_trace evaluates it,
@@ -610,9 +610,11 @@ int rspt_motion_bounds(const float start_m[16], float start_time, const float en
  *   RSPT_LIBM_MICROFACET         x = wo wh alpha_x alpha_y -> out = TrowbridgeReitzDistribution d(wh) lambda(wo) g1(wo) g(wo, wh) pdf(wo, wh) (microfacet.rs:256-297)
  *   RSPT_LIBM_VECTORS            x = a b eta u[2] -> out = vec3_cross_vec3(a, b) | vec3_coordinate_system(a)'s v2, v3 | refract(a, b, eta)'s wt, ok | cosine_sample_hemisphere(u)
  *   RSPT_LIBM_AREA_LIGHT         x = p0 p1 p2 ref_p u[2] flags (2: reversed orientation, 4: two-sided) -> out = pdf wi radiance(of L = 1) p n p_error: DiffuseAreaLight::sample_li
- *                                over Triangle::sample / sample_with_ref_point (lights/diffuse.rs:64-84, triangle.rs:676-744) on a triangle without vertex normals */
+ *                                over Triangle::sample / sample_with_ref_point (lights/diffuse.rs:64-84, triangle.rs:676-744) on a triangle without vertex normals
+ *   RSPT_LIBM_LOBE (48 floats per element, in and out)  x = the 29 words of one rspt_bxdf, wo, wi, u[2] -> out = f(wo, wi) pdf(wo, wi) | sample_f(wo, u): value wi pdf sampled_type | get_type:
+ *                                one lobe of reflection.rs:711-1478 as the shade kernels evaluate it (the sampled value of a NON-specular lobe is what lobe_f gives: Bsdf::sample_f re-sums it) */
 enum { RSPT_LIBM_SIN = 0, RSPT_LIBM_COS = 1, RSPT_LIBM_LOG = 2, RSPT_LIBM_LOG2 = 3, RSPT_LIBM_EXP = 4, RSPT_LIBM_ACOS = 5, RSPT_LIBM_ATAN2 = 6, RSPT_LIBM_MAT4_INVERSE = 7,
-       RSPT_LIBM_TRIANGLE = 8, RSPT_LIBM_BOX = 9, RSPT_LIBM_OFFSET_RAY_ORIGIN = 10, RSPT_LIBM_MICROFACET = 11, RSPT_LIBM_VECTORS = 12, RSPT_LIBM_AREA_LIGHT = 13 };
+       RSPT_LIBM_TRIANGLE = 8, RSPT_LIBM_BOX = 9, RSPT_LIBM_OFFSET_RAY_ORIGIN = 10, RSPT_LIBM_MICROFACET = 11, RSPT_LIBM_VECTORS = 12, RSPT_LIBM_AREA_LIGHT = 13, RSPT_LIBM_LOBE = 14 };
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out);
 
 /* Benchmark hook: same as rspt_trace on rays already resident in device memory,

@@ -538,10 +538,66 @@ def render(L, scene, rd, use_text, threads=4):
     return film, li
 
 
+LOBE_FIXTURE = os.path.join(ROOT, "tests", "golden", "lobe_functions.npz")
+
+
+def lobe_cases(n, seed):
+    """random lobe records of every kind a material can build, with and without a MixMaterial scale, and directions over both hemispheres incl. the degenerate ones the
+    lobes test for (z = 0, wi = -wo, normal incidence)"""
+    import numpy as np
+    from rs_pbrt_amd import abi
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    kinds = np.array([abi.BXDF_LAMBERT_R, abi.BXDF_LAMBERT_T, abi.BXDF_OREN_NAYAR, abi.BXDF_SPECULAR_R, abi.BXDF_SPECULAR_T, abi.BXDF_FRESNEL_SPEC, abi.BXDF_MICROFACET_R, abi.BXDF_MICROFACET_T,
+                      abi.BXDF_FRESNEL_BLEND], np.uint32)
+    b = np.zeros(n, abi.BXDF_DT)
+    b["type"] = kinds[np.arange(n) % len(kinds)]
+    b["fresnel"] = rng.integers(0, 3, n)
+    b["r"] = rng.uniform(0, 1, (n, 3)); b["t"] = rng.uniform(0, 1, (n, 3))
+    b["eta_a"] = rng.choice(np.array([1.0, 1.33, 1.5], f32), n); b["eta_b"] = rng.choice(np.array([1.0, 1.33, 1.5, 2.4], f32), n)
+    b["alpha_x"] = rng.uniform(0.001, 1.2, n); b["alpha_y"] = np.where(rng.uniform(size=n) < 0.5, b["alpha_x"], rng.uniform(0.001, 1.2, n))
+    b["c1"] = rng.uniform(0.1, 3.5, (n, 3)); b["c2"] = rng.uniform(0, 7, (n, 3))
+    sigma = np.radians(rng.uniform(0, 40, n)); s2 = sigma * sigma
+    b["on_a"] = 1.0 - s2 / (2.0 * (s2 + 0.33)); b["on_b"] = 0.45 * s2 / (s2 + 0.09)
+    b["has_sc"] = rng.uniform(size=n) < 0.3; b["sc"] = rng.uniform(0, 1, (n, 3))
+
+    def unit(k):
+        v = rng.normal(size=(k, 3))
+        return v / np.linalg.norm(v, axis=1)[:, None]
+    wo, wi = unit(n), unit(n)
+    k = n // 32
+    wo[:k, 2] = 0.0; wi[k:2 * k, 2] = 0.0; wi[2 * k:3 * k] = -wo[2 * k:3 * k]; wo[3 * k:4 * k] = [0, 0, 1]; wo[4 * k:5 * k] = [0, 0, -1]
+    u = rng.uniform(0, 1, (n, 2)).astype(f32).clip(0, np.nextafter(f32(1), f32(0)))
+    u[5 * k:6 * k, 0] = 0.0
+    return b, wo.astype(f32), wi.astype(f32), u
+
+
+def run_lobes(L, b, wo, wi, u):
+    import numpy as np
+    n = len(b)
+    t, o = np.zeros((n, 16), np.float32), np.zeros((n, 16), np.float32)
+    L.flow_lobes.restype = None
+    L.flow_lobes.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.flow_lobes(b.ctypes.data, wo.ctypes.data, wi.ctypes.data, u.ctypes.data, n, t.ctypes.data, o.ctypes.data)
+    return t[:, :13], o[:, :13]
+
+
 def main():
+    import numpy as np
     L, where = convert()
     for w in where[-3:]:
         print("compiled from", w)
+    if len(sys.argv) > 1 and sys.argv[1] == "--build-only":
+        return 0
+    b, wo, wi, u = lobe_cases(1 << 12, 0xF17)
+    t, _ = run_lobes(L, b, wo, wi, u)
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        g = np.load(LOBE_FIXTURE)
+        same = g["records"].tobytes() == b.tobytes() and all(np.array_equal(g[k].view(np.uint32), v.view(np.uint32)) for k, v in (("wo", wo), ("wi", wi), ("u", u), ("text", t)))
+        print("committed lobe fixture %s the reference's text" % ("equals" if same else "DIFFERS from"))
+        return 0 if same else 1
+    np.savez_compressed(LOBE_FIXTURE, records=b, wo=wo, wi=wi, u=u, text=t)
+    print("wrote", LOBE_FIXTURE, os.path.getsize(LOBE_FIXTURE), "bytes")
     return 0
 
 

@@ -71,7 +71,7 @@ struct Point3f {
 };
 static inline Vector3f operator-(const Vector3f& a) { return Vector3f{Float(-a.x.v), Float(-a.y.v), Float(-a.z.v)}; }   // impl Neg (a sign flip)
 static inline Vector3f Vector3f_from(const Normal3f& n) { return Vector3f{n.x, n.y, n.z}; }                                // impl From<Normal3f> (geometry.rs:616-624)
-struct Cell { mutable Float v; Float get() const { return v; } void set(Float x) const { v = x; } static Cell new_(Float x) { return Cell{x}; } };   // Cell<Float>
+struct Cell { mutable Float v; Float get() const { return v; } void set(Float x) const { v = x; } static Cell new_(Float x) { return Cell{x}; } Float* get_mut() { return &v; } };   // Cell<Float>
 struct RayDifferential { bool some; Point3f rx_origin, ry_origin; Vector3f rx_direction, ry_direction; };   // Option<RayDifferential> (geometry.rs:2408-2414): Copy
 struct MediumRef { uint32_t id; MediumRef clone() const { return *this; } };                               // Option<Arc<Medium>>
 struct Ray { Point3f o; Vector3f d; Cell t_max; Float time; RayDifferential differential; MediumRef medium; };   // geometry.rs:2378-2390
@@ -87,11 +87,14 @@ struct InteractionCommon { Point3f p; Float time; Vector3f p_error; Vector3f wo;
 struct NoneOpt { bool is_some() const { return false; } };                                                       // an Option that is None in every case of this batch
 struct TriangleMesh { const uint32_t* vertex_indices; const Point3f* p; Slice<Normal3f> n{nullptr, 0}; bool reverse_orientation = false, transform_swaps_handedness = false;
                       Slice<Vector3f> s{nullptr, 0}; Slice<Point2f> uv{nullptr, 0}; NoneOpt alpha_mask; };
-struct CellV { Vector3f v; static CellV new_(const Vector3f& x) { return CellV{x}; } };
+struct CellV { mutable Vector3f v; static CellV new_(const Vector3f& x) { return CellV{x}; } void set(const Vector3f& x) const { v = x; } };
 struct Shading { Normal3f n; Vector3f dpdu, dpdv; Normal3f dndu, dndv; };                                            // interaction.rs:120-127
 struct FullInteraction {                                                                                             // SurfaceInteraction (interaction.rs:129-170): what Triangle::intersect fills
     InteractionCommon common; Point2f uv; Vector3f dpdu, dpdv; Normal3f dndu, dndv; CellV dpdx, dpdy; Cell dudx, dvdx, dudy, dvdy; NoneT primitive; Shading shading; NoneT bsdf, shape;
+    void compute_differentials(const Ray& ray);
 };
+static inline Vector3f Vector3f_from(const Point3f& p) { return Vector3f{p.x, p.y, p.z}; }                     // impl From<Point3f> for Vector3f (geometry.rs:606-614)
+bool solve_linear_system_2x2(std::array<std::array<Float, 2>, 2> a, std::array<Float, 2> b, Float* x0, Float* x1);
 struct Triangle {
     uint32_t id; TriangleMesh mesh;
     bool intersect(const Ray& ray, Float* t_out, Float* b_out) const;
@@ -223,6 +226,7 @@ TYPES = dict(base.TYPES)
 TYPES.update({"i64": "int64_t", "i32": "int32_t", "u64": "uint64_t", "usize": "size_t", "f32": "Float", "f64": "double", "u8": "uint8_t", "Point3f": "Point3f", "Normal3f": "Normal3f", "&Point3f": "const Point3f&", "&Normal3f": "const Normal3f&",
               "&Ray": "const Ray&", "&mut Vector3f": "Vector3f*", "&[u8; 3]": "const uint8_t*", "RGBSpectrum": "RGBSpectrum",
               "&mut SurfaceInteraction": "SurfaceInteraction*", "u32": "uint32_t", "LinearBVHNode": "LinearBVHNode",
+              "[[Float; 2]; 2]": "std::array<std::array<Float, 2>, 2>", "[Float; 2]": "std::array<Float, 2>",
               "PairU32": "std::pair<uint32_t, uint32_t>", "&Vector2f": "const Vector2f&", "Bounds2i": "Bounds2i", "&Bounds2i": "const Bounds2i&", "Bounds2f": "Bounds2f", "&mut Spectrum": "Spectrum&", "&[Float; 3]": "const Float*", "&mut [Float; 3]": "Float*",
               "&[Float; FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH]": "const Float*", "Self": "FilmTile", "FilmTile": "FilmTile", "&FilmTile": "const FilmTile&",
               "Vector2f": "Vector2f", "Shading": "Shading", "Point2fArray3": "std::array<Point2f, 3>",
@@ -287,6 +291,8 @@ SOURCES = [
     # the WHOLE of Triangle::intersect: the watertight test and everything it fills into the SurfaceInteraction (the alpha-mask block is dropped by rule: the mesh of this batch has none)
     ("shapes/triangle.rs", None, r"^    pub fn intersect\(&self, ray: &Ray, t_hit: &mut Float, isect: &mut SurfaceInteraction\) -> bool \{", "intersect_full", "Triangle", None,
      "bool Triangle::intersect_full(const Ray& ray, Float* t_hit, FullInteraction& isect) const {\n", None, ("light", "full")),
+    ("core/transform.rs", None, r"^pub fn solve_linear_system_2x2\($", "solve_linear_system_2x2", None, None, None, None, ("diff",)),
+    ("core/interaction.rs", None, r"^    pub fn compute_differentials\(&mut self, ray: &Ray\) \{", "compute_differentials", "FullInteraction", None, None, None, ("diff", "light")),
     ("shapes/triangle.rs", None, r"^    pub fn area\(&self\) -> Float \{", "area", "Triangle", None, None, None, ("light",)),
     ("shapes/triangle.rs", None, r"^    pub fn sample\(&self, u: Point2f, pdf: &mut Float\) -> InteractionCommon \{", "sample", "Triangle", None, None, None, ("light",)),
     ("shapes/triangle.rs", None, r"^    pub fn sample_with_ref_point\($", "sample_with_ref_point", "Triangle", None, None, None, ("light",)),
@@ -516,6 +522,15 @@ RULES_FULL = [
     (r"let (?:mut )?(\w+): (Normal3f|Vector3f);", r"\2 \1;", 0),
     (r"^(\s*)let (n[012]|s[012]) = ", r"\1auto \2 = ", re.M),
 ]
+RULES_DIFF = [
+    # G26 SurfaceInteraction::compute_differentials: the optional differential of the ray, fixed arrays passed by value, the axis enum as an index
+    (r"if let Some\(ref (\w+)\) = ray\.differential \{", r"if (ray.differential.some) { const RayDifferential& \1 = ray.differential;", 0),
+    (r"let mut (\w+): \[XYZEnum; 2\] = \[XYZEnum::X; 2\];", r"int \1[2] = {0, 0};", 0),
+    (r"XYZEnum::X", "0", 0), (r"XYZEnum::Y", "1", 0), (r"XYZEnum::Z", "2", 0),
+    (r"let (\w+): \[\[Float; 2\]; 2\] = \[(\w+), (\w+)\];", r"std::array<std::array<Float, 2>, 2> \1 = {\2, \3};", 0),
+    (r"let (\w+): \[Float; 2\] = \[(.*?),?\s*\];", r"std::array<Float, 2> \1 = {\2};", re.S),
+    (r"Vector3f::from\(((?:\w+\.)+\w+)\)", r"Vector3f_from(\1)", 0),
+]
 RULES_MORTON = [
     # G25 hexadecimal literals with digit separators; the fields of a pair
     (r"0x[0-9a-fA-F_]+", lambda m: m.group(0).replace("_", "") + "u", 0),
@@ -670,7 +685,7 @@ def convert_parts():
         if "full" in extra and name == "intersect_full":
             i0 = body.index("if let Some(alpha_mask) = &self.mesh.alpha_mask {") if "if let Some(alpha_mask) = &self.mesh.alpha_mask {" in body else body.index("if let Some(alpha_mask) = &this->mesh.alpha_mask {")
             body = body[:body.rfind("\n", 0, i0)] + body[matching(body, body.index("{", i0), "{", "}") + 1:]      # G22: the alpha-mask block (triangle.rs:313-331) is dropped
-        for pat, rep, flags in (RULES_MORTON if "morton" in extra else []) + (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
+        for pat, rep, flags in (RULES_DIFF if "diff" in extra else []) + (RULES_MORTON if "morton" in extra else []) + (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
             body = re.sub(pat, rep, body, flags=flags)
         body = cast_after_parens(body, "Float", "Float(%s)")
         body = cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -828,6 +843,19 @@ void g_film(const int32_t* geo, const float* flt, const float* smp, uint64_t n, 
         }
         film.merge_film_tile(t);
         for (int k = 0; k < 256; k++) { const Pixel& p = film.pixels.v[k]; float* o = out + 1024 * i + 4 * k; o[0] = p.xyz[0].v; o[1] = p.xyz[1].v; o[2] = p.xyz[2].v; o[3] = p.filter_weight_sum.v; }
+    }
+}
+// SurfaceInteraction::compute_differentials: x = p n dpdu dpdv (12) | rx_origin ry_origin rx_direction ry_direction (12) | has differential; out: dudx dvdx dudy dvdy dpdx dpdy
+void g_differentials(const float* x, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = x + 25 * i;
+        FullInteraction si{};
+        si.common.p = Point3f{q[0], q[1], q[2]}; si.common.n = Normal3f{q[3], q[4], q[5]}; si.dpdu = V(q + 6); si.dpdv = V(q + 9);
+        si.dudx.v = si.dvdx.v = si.dudy.v = si.dvdy.v = Float(7.0f); si.dpdx.v = si.dpdy.v = Vector3f{Float(7.0f), Float(7.0f), Float(7.0f)};      // (every path of the function writes all six)
+        Ray r; r.differential = RayDifferential{q[24] != 0.0f, Point3f{q[12], q[13], q[14]}, Point3f{q[15], q[16], q[17]}, V(q + 18), V(q + 21)};
+        si.compute_differentials(r);
+        float* o = out + 10 * i;
+        o[0] = si.dudx.v.v; o[1] = si.dvdx.v.v; o[2] = si.dudy.v.v; o[3] = si.dvdy.v.v; S3(o + 4, si.dpdx.v); S3(o + 7, si.dpdy.v);
     }
 }
 // DiffuseAreaLight::sample_li over one emitting triangle: flags bit 0 = the mesh carries normals (nrm: 3 per case), bit 1 = reverse_orientation ^ transform_swaps_handedness, bit 2 = two_sided
@@ -1026,6 +1054,19 @@ def inputs(n=1 << 12, seed=0x6E0A):
     smp[:, :, 2:] = np.exp(rng.uniform(-3, 3, (nf, 64, 3)))
     d["flm_geo"], d["flm_flt"], d["flm_smp"] = geo, flt, smp
     d["mor_xy"] = np.concatenate([rng.integers(0, 1 << 16, (n - 8, 2)), [[0, 0], [1, 0], [0, 1], [65535, 65535], [65535, 0], [0, 65535], [255, 256], [119, 67]]]).astype(np.uint32)   # tile coordinates (blockqueue/mod.rs)
+    # compute_differentials: a hit seen by a camera ray with its two offset rays; grazing planes (an infinite tx), dpdu parallel to dpdv (a singular system), no differential
+    pp = rng.uniform(-5, 5, (n, 3)); nn = unit(rng, n).astype(np.float64)
+    du = np.cross(nn, unit(rng, n)); du *= np.exp(rng.uniform(-2, 2, (n, 1))); dv = np.cross(nn, du) * np.exp(rng.uniform(-2, 2, (n, 1)))
+    dv[: n // 32] = du[: n // 32] * 2.0
+    eye = pp + unit(rng, n) * np.exp(rng.uniform(0, 3, (n, 1)))
+    dirs = pp - eye; dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    rxd = dirs + rng.normal(size=(n, 3)) * 1e-3; ryd = dirs + rng.normal(size=(n, 3)) * 1e-3
+    rxd /= np.linalg.norm(rxd, axis=1)[:, None]; ryd /= np.linalg.norm(ryd, axis=1)[:, None]
+    k = n // 32
+    rxd[k: 2 * k] = np.cross(nn[k: 2 * k], unit(rng, k)); ryd[2 * k: 3 * k] = np.cross(nn[2 * k: 3 * k], unit(rng, k))     # an offset ray in the tangent plane
+    nn[3 * k: 4 * k] = np.eye(3)[rng.integers(0, 3, k)] * rng.choice([1.0, -1.0], (k, 1))                                 # axis-aligned normals: the dimension choice
+    has = (rng.uniform(size=n) > 0.1).astype(np.float64)
+    d["dif_x"] = np.concatenate([pp, nn, du, dv, eye, eye, rxd, ryd, has[:, None]], 1).astype(f32)
     # PCG32
     d["rng_seq"] = rng.integers(0, 1 << 63, n, dtype=np.uint64); d["rng_seq"][:4] = [0, 1, 2, (1 << 64) - 1]
     b = rng.integers(1, 1 << 31, n).astype(np.uint32); b[: n // 2] = rng.integers(1, 4096, n // 2); b[:8] = [1, 2, 3, 4, 5, 7, 8, 4096]
@@ -1133,6 +1174,7 @@ def run_reference(L, d):
     out["trp_out"] = call("g_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5), pre=(1,))
     out["mf_out"] = call("g_microfacet", [d["mf_wo"], d["mf_wh"], d["mf_ax"], d["mf_ay"]], (n, 5))
     out["trf_out"] = call("g_triangle_full", [d["tri_p"], d["trf_n"], d["trf_s"], d["trf_uv"], d["trf_flags"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 48))
+    out["dif_out"] = call("g_differentials", [d["dif_x"]], (n, 10))
     nf = len(d["flm_geo"])
     out["flm_out"] = call("g_film", [d["flm_geo"], d["flm_flt"], d["flm_smp"]], (nf, 256, 4), n=nf)
     out["al_out"] = call("g_area_light", [d["al_tri"], d["al_nrm"], d["al_flags"], d["al_L"], d["al_ref"], d["al_u"]], (n, 16))

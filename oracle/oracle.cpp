@@ -579,6 +579,16 @@ void orc_geom_film(const int32_t* geo, const float* flt, const float* smp, uint6
         merge_film_tile(rd, t, film);
     }
 }
+void orc_geom_differentials(const float* x, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = x + 25 * i;
+        Interaction si; si.p = V3{q[0], q[1], q[2]}; si.n = V3{q[3], q[4], q[5]}; si.dpdu = V3{q[6], q[7], q[8]}; si.dpdv = V3{q[9], q[10], q[11]};
+        Ray r{}; r.has_diff = q[24] != 0.0f; r.rx_o = V3{q[12], q[13], q[14]}; r.ry_o = V3{q[15], q[16], q[17]}; r.rx_d = V3{q[18], q[19], q[20]}; r.ry_d = V3{q[21], q[22], q[23]};
+        compute_differentials(&si, r);
+        float* o = out + 10 * i;
+        o[0] = si.dudx; o[1] = si.dvdx; o[2] = si.dudy; o[3] = si.dvdy; o[4] = si.dpdx.x; o[5] = si.dpdx.y; o[6] = si.dpdx.z; o[7] = si.dpdy.x; o[8] = si.dpdy.y; o[9] = si.dpdy.z;
+    }
+}
 void orc_geom_morton(const uint32_t* xy, uint64_t n, uint32_t* out) { for (uint64_t i = 0; i < n; i++) out[i] = morton2(xy[2 * i], xy[2 * i + 1]); }
 void orc_geom_area_light(const float* tri, const float* nrm, const int32_t* flags, const float* L, const float* ref_p, const float* u, uint64_t n, float* out) {   // light_sample_li on one emitting triangle
     for (uint64_t i = 0; i < n; i++) {

@@ -311,6 +311,7 @@ def geom(d):
         "tri_out": call("orc_geom_triangle", [d["tri_p"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 5)),
         "mf_out": call("orc_geom_microfacet", [d["mf_wo"], d["mf_wh"], d["mf_ax"], d["mf_ay"]], (n, 5)),
         "trf_out": call("orc_geom_triangle_full", [d["tri_p"], d["trf_n"], d["trf_s"], d["trf_uv"], d["trf_flags"], d["tri_o"], d["tri_d"], d["tri_tmax"]], (n, 48)),
+        "dif_out": call("orc_geom_differentials", [d["dif_x"]], (n, 10)),
         "al_out": call("orc_geom_area_light", [d["al_tri"], d["al_nrm"], d["al_flags"], d["al_L"], d["al_ref"], d["al_u"]], (n, 16)),
     }
     out["mor_out"] = call("orc_geom_morton", [np.ascontiguousarray(d["mor_xy"], np.uint32)], n, dtype=np.uint32)

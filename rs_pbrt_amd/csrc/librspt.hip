@@ -2860,21 +2860,42 @@ __global__ void k_leaf_geom(uint32_t fn, const float* __restrict__ x, uint64_t n
 #pragma unroll
     for (int k = 0; k < 16; k++) out[16 * i + k] = r[k];
 }
+// rspt_libm code 14: one lobe record (the 116 bytes of an rspt_bxdf, as 29 floats) + wo, wi, u -> lobe_f, lobe_pdf, lobe_sample_f (dev_bsdf.h) as the shade kernels call them;
+// 48 floats in, 48 floats out per element
+__global__ void k_leaf_lobe(const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rspt_bxdf b;
+    static_assert(sizeof(rspt_bxdf) == 116, "rspt_bxdf is 29 words");
+    uint32_t* bw = reinterpret_cast<uint32_t*>(&b);
+    for (int k = 0; k < 29; k++) bw[k] = __float_as_uint(x[48 * i + k]);
+    const float* q = x + 48 * i + 29;
+    const f3 wo{q[0], q[1], q[2]}, wi{q[3], q[4], q[5]};
+    const LobeTex lt{nullptr, 0};
+    float* o = out + 48 * i;
+    for (int k = 0; k < 48; k++) o[k] = 0.0f;
+    const rgb f = lobe_f<SF_ALL>(b, lt, wo, wi);
+    o[0] = f.r; o[1] = f.g; o[2] = f.b; o[3] = lobe_pdf<SF_ALL>(b, lt, wo, wi);
+    f3 w{0.0f, 0.0f, 0.0f}; float pdf = 0.0f; uint32_t st = 255u;
+    const rgb sf = lobe_sample_f<SF_ALL>(b, lt, wo, &w, f2{q[6], q[7]}, &pdf, &st, true);
+    o[4] = sf.r; o[5] = sf.g; o[6] = sf.b; o[7] = w.x; o[8] = w.y; o[9] = w.z; o[10] = pdf; o[11] = (float)st; o[12] = (float)lobe_type(b.type);
+}
 }  // namespace
 extern "C" {
 int rspt_libm(uint32_t fn, const float* x, const float* y, uint64_t n, float* out) {
     if (!g.inited) return fail(RSPT_E_NODEVICE, "rspt_init has not been called");
     if (n == 0) return RSPT_OK;
-    if (fn > RSPT_LIBM_AREA_LIGHT || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (fn >= RSPT_LIBM_MAT4_INVERSE ? (1ull << 27) : (1ull << 31))) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values (2^27 sixteen-float elements)");
+    if (fn > RSPT_LIBM_LOBE || !x || !out || (fn == RSPT_LIBM_ATAN2 && !y) || n > (fn >= RSPT_LIBM_MAT4_INVERSE ? (1ull << 27) : (1ull << 31))) return fail(RSPT_E_INVALID, "bad function, null argument or more than 2^31 values (2^27 sixteen-float elements)");
     HIP_TRY(hipSetDevice(g.device));
     float *xd = nullptr, *yd = nullptr, *od = nullptr;
     struct Guard { float **a, **b, **c; ~Guard() { for (float** p : {a, b, c}) if (*p) (void)hipFree(*p); } } guard{&xd, &yd, &od};
     int rc;
-    const uint64_t per = fn >= RSPT_LIBM_MAT4_INVERSE ? 16u : 1u;   // values per element
+    const uint64_t per = fn == RSPT_LIBM_LOBE ? 48u : (fn >= RSPT_LIBM_MAT4_INVERSE ? 16u : 1u);   // values per element
     if ((rc = dev_alloc(&xd, n * per)) || (rc = dev_alloc(&od, n * per)) || (y && (rc = dev_alloc(&yd, n)))) return rc;
     HIP_TRY(hipMemcpyAsync(xd, x, n * per * sizeof(float), hipMemcpyHostToDevice, g.stream));
     if (y) HIP_TRY(hipMemcpyAsync(yd, y, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
-    if (fn > RSPT_LIBM_MAT4_INVERSE) hipLaunchKernelGGL(k_leaf_geom, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, n, od);
+    if (fn == RSPT_LIBM_LOBE) hipLaunchKernelGGL(k_leaf_lobe, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, xd, n, od);
+    else if (fn > RSPT_LIBM_MAT4_INVERSE) hipLaunchKernelGGL(k_leaf_geom, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, n, od);
     else hipLaunchKernelGGL(k_libm, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, g.stream, fn, xd, yd, n, od);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, od, n * per * sizeof(float), hipMemcpyDeviceToHost, g.stream));

@@ -218,6 +218,17 @@ def leaf_geom(fn, x):
     return out
 
 
+def leaf_lobe(records, wo, wi, u):
+    """rspt_libm code 14: lobe_f / lobe_pdf / lobe_sample_f of BXDF_DT records at (wo, wi, u) -> (n, 13): f(3) pdf | sample value(3) wi(3) pdf sampled_type | get_type"""
+    n = len(records)
+    x = np.zeros((n, 48), np.float32)
+    x[:, :29] = np.ascontiguousarray(records).view(np.float32).reshape(n, 29)
+    x[:, 29:32], x[:, 32:35], x[:, 35:37] = wo, wi, u
+    out = np.empty_like(x)
+    _check(lib().rspt_libm(14, x.ctypes.data, None, n, out.ctypes.data))
+    return out[:, :13]
+
+
 def light_distribution(dscene, strategy, p):
     """rspt_light_distribution: LightDistribution::lookup(p) -> (func[n_lights], cdf[n_lights + 1], n_voxels[3], voxel[3])"""
     n = int(dscene.host.desc.n_lights)

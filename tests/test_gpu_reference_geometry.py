@@ -108,3 +108,24 @@ def test_the_traversal_kernels_walk_the_tree_as_the_references_text_does(g):
     assert np.array_equal(h["prim"], g["trv_prim"]), "%d of %d rays end on another primitive" % (int((h["prim"] != g["trv_prim"]).sum()), len(rays))
     assert same_bits(np.stack([h["t"], h["b0"], h["b1"], h["b2"]], 1), g["trv_tb"])
     assert np.array_equal((a["prim"] != abi.MISS).astype(np.uint8), g["trv_any"])
+
+
+def test_the_device_lobes_are_the_references_text():
+    """lobe_f / lobe_pdf / lobe_sample_f (dev_bsdf.h, every one of the nine lobe kinds, with and without a MixMaterial scale) as the shade kernels call them against
+    reflection.rs:711-1478 compiled from the reference's text (tests/golden/lobe_functions.npz, oracle/make_flow_fixtures.py): f, pdf, the sampled direction, its pdf,
+    sampled_type and get_type of every case; the sampled VALUE for the specular lobes (a non-specular lobe's own value is never read: Bsdf::sample_f re-sums f over the
+    matching lobes, and the reference's text carries a MixMaterial scale twice there — DESIGN.md section 3a)"""
+    lib.init(0)
+    g = np.load(os.path.join(HERE, "golden", "lobe_functions.npz"))
+    from rs_pbrt_amd import abi
+    rec = g["records"].view(abi.BXDF_DT).reshape(-1) if g["records"].dtype != abi.BXDF_DT else g["records"]
+    out = lib.leaf_lobe(rec, g["wo"], g["wi"], g["u"])
+    ref = g["text"]
+    for cols, name in (((0, 1, 2), "f"), ((3,), "pdf"), ((7, 8, 9), "sampled wi"), ((10,), "sampled pdf"), ((11,), "sampled_type"), ((12,), "get_type")):
+        c = list(cols)
+        live = np.ones(len(rec), bool) if name not in ("sampled wi",) else ref[:, 10] > 0          # (a direction is only defined where the sample has a pdf)
+        assert same_bits(out[live][:, c], ref[live][:, c]), "%s: %d of %d cases differ" % (name, int((out[live][:, c].view(np.uint32) != ref[live][:, c].view(np.uint32)).any(axis=1).sum()), int(live.sum()))
+    spec = np.isin(rec["type"], [abi.BXDF_SPECULAR_R, abi.BXDF_SPECULAR_T, abi.BXDF_FRESNEL_SPEC])
+    assert same_bits(out[spec][:, 4:7], ref[spec][:, 4:7])
+    plain = ~spec & (rec["has_sc"] == 0)
+    assert same_bits(out[plain][:, 4:7], ref[plain][:, 4:7])              # without a scale the value of a non-specular lobe's own sample_f agrees too

@@ -89,53 +89,23 @@ def test_li_text_equals_the_oracles_li_on_random_scenes(flow, oracle, seed):
     assert_same(li_t, li_o)
 
 
-def lobe_cases(n, seed):
-    """random lobe records of every kind a material can build, with and without a MixMaterial scale, and directions over both hemispheres
-    incl. the degenerate ones the lobes test for (z = 0, wi = -wo, normal incidence)"""
-    rng = np.random.default_rng(seed)
-    f32 = np.float32
-    kinds = np.array([abi.BXDF_LAMBERT_R, abi.BXDF_LAMBERT_T, abi.BXDF_OREN_NAYAR, abi.BXDF_SPECULAR_R, abi.BXDF_SPECULAR_T, abi.BXDF_FRESNEL_SPEC, abi.BXDF_MICROFACET_R, abi.BXDF_MICROFACET_T, abi.BXDF_FRESNEL_BLEND], np.uint32)
-    b = np.zeros(n, abi.BXDF_DT)
-    b["type"] = kinds[np.arange(n) % len(kinds)]
-    b["fresnel"] = rng.integers(0, 3, n)
-    b["r"] = rng.uniform(0, 1, (n, 3)); b["t"] = rng.uniform(0, 1, (n, 3))
-    b["eta_a"] = rng.choice(np.array([1.0, 1.33, 1.5], f32), n); b["eta_b"] = rng.choice(np.array([1.0, 1.33, 1.5, 2.4], f32), n)
-    b["alpha_x"] = rng.uniform(0.001, 1.2, n); b["alpha_y"] = np.where(rng.uniform(size=n) < 0.5, b["alpha_x"], rng.uniform(0.001, 1.2, n))
-    b["c1"] = rng.uniform(0.1, 3.5, (n, 3)); b["c2"] = rng.uniform(0, 7, (n, 3))
-    sigma = np.radians(rng.uniform(0, 40, n)); s2 = sigma * sigma
-    b["on_a"] = 1.0 - s2 / (2.0 * (s2 + 0.33)); b["on_b"] = 0.45 * s2 / (s2 + 0.09)
-    b["has_sc"] = rng.uniform(size=n) < 0.3; b["sc"] = rng.uniform(0, 1, (n, 3))
-
-    def unit(k):
-        v = rng.normal(size=(k, 3))
-        return v / np.linalg.norm(v, axis=1)[:, None]
-    wo, wi = unit(n), unit(n)
-    k = n // 32
-    wo[:k, 2] = 0.0; wi[k:2 * k, 2] = 0.0; wi[2 * k:3 * k] = -wo[2 * k:3 * k]; wo[3 * k:4 * k] = [0, 0, 1]; wo[4 * k:5 * k] = [0, 0, -1]
-    u = rng.uniform(0, 1, (n, 2)).astype(f32).clip(0, np.nextafter(f32(1), f32(0)))
-    u[5 * k:6 * k, 0] = 0.0
-    return b, wo.astype(f32), wi.astype(f32), u
-
-
 def test_every_lobes_f_pdf_and_sample_f_text_equals_the_oracles(flow):
     """LambertianReflection / Transmission, OrenNayar, SpecularReflection / Transmission, FresnelSpecular, MicrofacetReflection / Transmission and FresnelBlend (reflection.rs:711-1478:
     f, pdf, sample_f, get_type of each, over Fresnel::evaluate, TrowbridgeReitzDistribution::sample_wh / d / g / pdf, reflect, refract, cosine_sample_hemisphere — all
     compiled from the reference's text) against the oracle's lobe evaluator on the same records: 2^17 cases, every bit.  Includes the reference's own quirk that a
     MixMaterial scale enters sample_f's value twice where a lobe's sample_f calls its f."""
-    import ctypes as C
     mk, L = flow
     n = 1 << 17
-    b, wo, wi, u = lobe_cases(n, 0x10BE5)
-    t, o = np.zeros((n, 16), np.float32), np.zeros((n, 16), np.float32)
-    L.flow_lobes.restype = None
-    L.flow_lobes.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_void_p]
-    L.flow_lobes(b.ctypes.data, wo.ctypes.data, wi.ctypes.data, u.ctypes.data, n, t.ctypes.data, o.ctypes.data)
+    b, wo, wi, u = mk.lobe_cases(n, 0x10BE5)
+    t, o = mk.run_lobes(L, b, wo, wi, u)
     names = ["f.r", "f.g", "f.b", "pdf", "sample_f.r", "sample_f.g", "sample_f.b", "wi.x", "wi.y", "wi.z", "sample pdf", "sampled_type", "get_type"]
     bad = (t.view(np.uint32) != o.view(np.uint32)) & ~(np.isnan(t) & np.isnan(o))
     for kind in np.unique(b["type"]):
         sel = b["type"] == kind
         assert not bad[sel].any(), "lobe kind %d: %s differ in %d of %d cases" % (kind, [names[c] for c in np.nonzero(bad[sel].any(axis=0))[0]], int(bad[sel].any(axis=1).sum()), int(sel.sum()))
-        assert (t[sel, 12] != 0).all() and (t[sel, 10] > 0).mean() > 0.25         # every kind was evaluated and mostly sampled with a positive pdf
+        assert (t[sel, 12] != 0).all() and (t[sel, 10] > 0).mean() > 0.25
+    r = __import__("subprocess").run([sys.executable, os.path.join(ROOT, "oracle", "make_flow_fixtures.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]          # tests/golden/lobe_functions.npz (what the GPU test holds the device's lobes to) is what the text gives         # every kind was evaluated and mostly sampled with a positive pdf
 
 
 @pytest.mark.parametrize("shape,kind", [((7, 1), "lights"), ((64, 32), "image"), ((5, 3), "zeros"), ((1, 1), "single")])

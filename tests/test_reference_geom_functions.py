@@ -26,6 +26,7 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "trf_out": "the whole Triangle::intersect: hit point, error bound, normals, uv, dpdu / dpdv, the shading frame and dndu / dndv",
          "flm_out": "Film::get_film_tile, FilmTile::add_sample, Film::merge_film_tile (box and gaussian filter tables, tiles across the frame's border, the luminance clamp)",
          "mor_out": "morton2 / part1_by1 (the tile order of BlockQueue)",
+         "dif_out": "SurfaceInteraction::compute_differentials over solve_linear_system_2x2",
          "al_out": "DiffuseAreaLight::sample_li / l over Triangle::sample / sample_with_ref_point",
          "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample"}
 
@@ -62,6 +63,8 @@ def test_oracle_equals_the_references_text_on_the_committed_fixture(oracle):
     assert (g["oro_out"] != g["oro_p"]).any(axis=1).mean() > 0.9                          # the offset moved the origin, rounded away from it
     al = g["al_out"]
     assert (al[:, 0] == 0).sum() > 10 and (al[:, 0] > 0).sum() > 3000 and ((al[:, 0] > 0) & (al[:, 4:7] == 0).all(axis=1)).sum() > 300     # zero / infinite pdf -> 0; one-sided lights seen from behind
+    dif = g["dif_out"]
+    assert (dif == 0).all(axis=1).sum() > 300 and (dif[:, :4] != 0).all(axis=1).sum() > 2500 and ((dif[:, :2] == 0).all(axis=1) & (dif[:, 4:] != 0).any(axis=1)).sum() > 50   # no differential / a grazing offset ray; the regular case; a singular 2 x 2 system
     flm = g["flm_out"]
     assert (flm[:, :, 3] > 0).any(axis=1).mean() > 0.8 and (flm[:, :, 3] == 0).any()             # every tile reached the film; pixels no sample reached stay zero
     sob = g["sob_out"]
