@@ -37,6 +37,24 @@ static inline Spectrum spectrum_default() { return Spectrum::new_(Float(0.0f)); 
 static inline Vector3f vector3f_default() { return Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
 static inline bool spectrum_is_black(const Spectrum& s) { return !(s.c[0] != Float(0.0f) || s.c[1] != Float(0.0f) || s.c[2] != Float(0.0f)); }   // spectrum.rs is_black
 static inline Float spectrum_max_component_value(const Spectrum& s) { return s.c[0].max(s.c[1].max(s.c[2])); }                                  // spectrum.rs max_component_value
+// ---- the camera's carriers (cameras/perspective.rs, core/transform.rs): field names; the methods' bodies are the reference's text ----
+struct Transform {
+    Matrix4x4 m, m_inv;
+    Point3f transform_point(const Point3f& p) const; Vector3f transform_vector(const Vector3f& v) const; Point3f transform_point_with_error(const Point3f& p, Vector3f* p_error) const; Ray transform_ray(const Ray& r) const;
+    static Transform default_() { return Transform{}; }
+};
+struct AnimatedTransform {                      // transform.rs:894-930: a camera that does not move has actually_animated = false
+    Transform start_transform, end_transform; Float start_time, end_time; bool actually_animated;
+    void interpolate(Float, Transform*) const { abort(); }
+    Ray transform_ray(const Ray& r) const;
+};
+struct PerspectiveCamera {                      // perspective.rs:21-47 (with CameraBase's fields)
+    AnimatedTransform camera_to_world; Float shutter_open, shutter_close; MediumRef medium; Transform raster_to_camera; Float lens_radius, focal_distance; Vector3f dx_camera, dy_camera;
+    Float generate_ray_differential(const CameraSample& sample, Ray& ray) const;
+};
+static inline Point3f& operator+=(Point3f& a, const Vector3f& b) { a = a + b; return a; }          // impl AddAssign<Vector3f> for Point3f
+static inline Point3f point3f_default() { return Point3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
+Point3f ray_position(const Ray& self_, Float t); Float lerp(Float t, Float a, Float b);
 Float vec3_abs_dot_nrmf(const Vector3f& v1, const Normal3f& n2); bool vec3_same_hemisphere_vec3(const Vector3f& w, const Vector3f& wp); Float pow5(Float v);
 Normal3f nrm_faceforward_vec3(const Normal3f& n, const Vector3f& v); Vector3f spherical_direction(Float sin_theta, Float cos_theta, Float phi);
 namespace flow {
@@ -247,9 +265,25 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
+TYPES.update({"&mut Ray": "Ray&", "&CameraSample": "const CameraSample&", "Transform": "Transform", "&mut Transform": "Transform*", "Point3f": "Point3f", "Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
+RULES_CAM = [
+    # F13 the camera and Transform::transform_ray: the optional differential / medium of a Ray (carried as a flag / an id), the Ray and RayDifferential literals in either written order
+    (r"if let Some\((\w+)\) = r\.differential \{", r"if (r.differential.some) { const RayDifferential \1 = r.differential;", 0),
+    (r"if let Some\(ref (\w+)\) = ((?:r\.|self\.|this->)medium) \{", r"if (\2.id != 0) { const MediumRef& \1 = \2;", 0),
+    (r"\} else if let Some\(ref (\w+)\) = (r\.medium) \{", r"} else if (\2.id != 0) { const MediumRef& \1 = \2;", 0),
+    (r"Some\(medium_arc\.clone\(\)\)", "medium_arc.clone()", 0), (r"Some\(diff\)", "diff", 0),
+    (r"(medium: |\.medium = )None", r"\1MediumRef{0}", 0), (r"differential: None", "differential: RayDifferential{}", 0),
+    (r"RayDifferential \{\s*rx_origin: (.*?),\s*ry_origin: (.*?),\s*rx_direction: (.*?),\s*ry_direction: (.*?),\s*\};", r"RayDifferential{true, \1, \2, \3, \4};", re.S),
+    (r"Ray \{\s*o,\s*d,\s*t_max: (.*?),\s*time: (.*?),\s*differential: (.*?),\s*medium: (.*?),\s*\}", r"Ray{o, d, \1, \2, \3, \4}", re.S),
+    (r"Ray \{\s*o: (.*?),\s*d: (.*?),\s*t_max: (.*?),\s*time: (.*?),\s*medium: (.*?),\s*differential: (.*?),\s*\};", r"Ray{\1, \2, \3, \4, \6, \5};", re.S),
+    (r"Point3f::default\(\)", "point3f_default()", 0), (r"std::f32::INFINITY", "Float(INFINITY)", 0), (r"\b(\d+)i32\b", r"\1", 0),
+    (r"\b(\w+)\.position\(", r"ray_position(\1, ", 0),
+    (r"Vector3f::from\(([^()]+)\)", r"Vector3f_from(\1)", 0),
+    (r"let (?:mut )?(\w+): (RayDifferential|Ray|Transform|Point3f|Point2f) = ", r"\2 \1 = ", 0),
+    (r"Transform::default\(\)", "Transform::default_()", 0),
+]
 RULES_FLOW = [
     # F11 Distribution1D / 2D: inclusive ranges, Vec::with_capacity, the two iter_mut().skip(1).take(n) loops, isize arithmetic, the struct literal, Some(&mut (x)), None
     (r"for (\w+) in 1\.\.=(\w+) \{", r"for (size_t \1 = 1; \1 <= \2; \1++) {", 0),
@@ -343,6 +377,14 @@ def drop_block(body, head):
 
 SOURCES = [
     ("core/geometry.rs", r"^pub fn vec3_abs_dot_nrmf\(", "vec3_abs_dot_nrmf", None, False),
+    ("core/pbrt.rs", r"^pub fn lerp<S, T>", "lerp", "#cam", False),
+    ("core/geometry.rs", ("^impl Ray \\{", r"^    pub fn position\(&self, t: Float\) -> Point3f \{"), "ray_position", "@Ray#cam", False),
+    ("core/transform.rs", ("^impl Transform \\{", r"^    pub fn transform_point\(&self, p: &Point3f\) -> Point3f \{"), "transform_point", "Transform#cam", False),
+    ("core/transform.rs", ("^impl Transform \\{", r"^    pub fn transform_vector\(&self, v: &Vector3f\) -> Vector3f \{"), "transform_vector", "Transform#cam", False),
+    ("core/transform.rs", ("^impl Transform \\{", r"^    pub fn transform_point_with_error\("), "transform_point_with_error", "Transform#cam", False),
+    ("core/transform.rs", ("^impl Transform \\{", r"^    pub fn transform_ray\(&self, r: &Ray\) -> Ray \{"), "transform_ray", "Transform#cam", False),
+    ("core/transform.rs", ("^impl AnimatedTransform \\{", r"^    pub fn transform_ray\(&self, r: &Ray\) -> Ray \{"), "transform_ray", "AnimatedTransform#cam", False),
+    ("cameras/perspective.rs", r"^    pub fn generate_ray_differential\(", "generate_ray_differential", "PerspectiveCamera#cam", False),
     ("core/pbrt.rs", r"^pub fn clamp_t<T>", "clamp_t@int64_t", None, True),
     ("core/pbrt.rs", r"^pub fn clamp_t<T>", "clamp_t@size_t", None, True),
     ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn new\(f: Vec<Float>\) -> Self \{"), "new_", "Distribution1D", True),
@@ -385,6 +427,10 @@ def convert_parts():
     for fname, first_re, name, cls, in_flow in SOURCES:
         after_re, first_re = first_re if isinstance(first_re, tuple) else (None, first_re)
         text, l0, l1 = geom.extract(fname, after_re, first_re, None)
+        cam = bool(cls) and cls.endswith("#cam")
+        cls = (cls[:-4] or None) if cam else cls
+        if name == "lerp":                          # F12: the generic lerp (pbrt.rs:235-245) instantiated at S = T = Float; num::One::one() at Float is 1
+            text = re.sub(r"pub fn lerp<S, T>\(t: S, a: T, b: T\) -> T\nwhere.*?\{\n", "pub fn lerp(t: Float, a: Float, b: Float) -> Float {\n", text, flags=re.S).replace("let one: S = num::One::one();", "let one: Float = 1.0 as Float;")
         self_type = None
         if cls and cls.startswith("@"):            # a method compiled as a free function over the carrier of another batch: `&self` -> an explicit `self`
             self_type, cls = cls[1:], None
@@ -405,7 +451,7 @@ def convert_parts():
             body = re.sub(r"(this->(?:f|pdf)\(\w+, )%s\)" % nm, r"\1*%s)" % nm, body)
         if name == "li":
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
-        for pat, rep, flags in RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+        for pat, rep, flags in (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -500,6 +546,33 @@ extern "C" void flow_distributions(const float* func, uint32_t nu, uint32_t nv, 
         q[2] = orc::Distribution2D::sample_continuous_1d(o1, ux.v, &op, &oo); q[3] = op; q[4] = (float)oo; q[5] = o1.func[oo] / (o1.func_int * (float)o1.func.size());
         float op2 = 0.0f; const orc::P2 os = o2.sample_continuous(orc::P2{ux.v, uy.v}, &op2);
         q[6] = os.x; q[7] = os.y; q[8] = op2; q[9] = o2.pdf(orc::P2{ux.v, uy.v});
+    }
+}
+// PerspectiveCamera::generate_ray_differential over Transform::transform_ray (a camera that does not move), text next to the oracle's camera_ray: n samples of (p_film, time, p_lens) -> 20 floats each
+extern "C" void flow_camera(const rspt_render_desc* rd, const float* smp, uint64_t n, float* out_text, float* out_oracle) {
+    PerspectiveCamera cam{};
+    auto M = [](const float* m) { Matrix4x4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = Float(m[4 * i + j]); return r; };
+    cam.camera_to_world.start_transform.m = M(rd->camera_to_world); cam.camera_to_world.end_transform.m = M(rd->camera_to_world); cam.camera_to_world.actually_animated = false;
+    cam.camera_to_world.start_time = Float(0.0f); cam.camera_to_world.end_time = Float(1.0f);
+    cam.shutter_open = Float(rd->shutter_open); cam.shutter_close = Float(rd->shutter_close); cam.medium = MediumRef{0};
+    cam.raster_to_camera.m = M(rd->raster_to_camera); cam.lens_radius = Float(rd->lens_radius); cam.focal_distance = Float(rd->focal_distance);
+    // PerspectiveCamera::new (perspective.rs:82-97): dx_camera / dy_camera through the reference's own transform_point and Point3f - Point3f
+    const Point3f c0 = cam.raster_to_camera.transform_point(Point3f{Float(0.0f), Float(0.0f), Float(0.0f)});
+    cam.dx_camera = cam.raster_to_camera.transform_point(Point3f{Float(1.0f), Float(0.0f), Float(0.0f)}) - c0;
+    cam.dy_camera = cam.raster_to_camera.transform_point(Point3f{Float(0.0f), Float(1.0f), Float(0.0f)}) - c0;
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = smp + 5 * i;
+        const CameraSample cs{Point2f{Float(q[0]), Float(q[1])}, Float(q[2]), Point2f{Float(q[3]), Float(q[4])}};
+        Ray r{}; r.medium = MediumRef{0};
+        cam.generate_ray_differential(cs, r);
+        float* t = out_text + 20 * i; float* o = out_oracle + 20 * i;
+        auto put = [](float* d, const Ray& r) {
+            d[0] = r.o.x.v; d[1] = r.o.y.v; d[2] = r.o.z.v; d[3] = r.d.x.v; d[4] = r.d.y.v; d[5] = r.d.z.v; d[6] = r.t_max.get().v; d[7] = r.time.v;
+            d[8] = r.differential.rx_origin.x.v; d[9] = r.differential.rx_origin.y.v; d[10] = r.differential.rx_origin.z.v; d[11] = r.differential.ry_origin.x.v; d[12] = r.differential.ry_origin.y.v; d[13] = r.differential.ry_origin.z.v;
+            d[14] = r.differential.rx_direction.x.v; d[15] = r.differential.rx_direction.y.v; d[16] = r.differential.rx_direction.z.v; d[17] = r.differential.ry_direction.x.v; d[18] = r.differential.ry_direction.y.v; d[19] = r.differential.ry_direction.z.v;
+        };
+        put(t, r);
+        put(o, flow::to_ref(orc::camera_ray(*rd, orc::P2{q[0], q[1]}, q[2], orc::P2{q[3], q[4]})));
     }
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {

@@ -133,3 +133,29 @@ def test_distribution_text_equals_the_oracles(flow, shape, kind):
     assert np.array_equal(ht.view(np.uint32), ho.view(np.uint32)), "cdf / integral differ"
     bad = (t.view(np.uint32) != o.view(np.uint32)) & ~(np.isnan(t) & np.isnan(o))
     assert not bad.any(), "columns %s differ in %d samples" % (np.nonzero(bad.any(axis=0))[0], int(bad.any(axis=1).sum()))
+
+
+@pytest.mark.parametrize("lens", [0.0, 0.05])
+def test_camera_text_equals_the_oracles_camera_ray(flow, lens):
+    """PerspectiveCamera::generate_ray_differential (perspective.rs:190-280) over Transform::{transform_point, transform_vector, transform_point_with_error, transform_ray}
+    (transform.rs:490-595, 662-708), Ray::position and lerp — the reference's text — against the oracle's camera_ray: origin, direction, t_max, time and the two offset rays
+    of 2^15 camera samples per camera (pinhole and thin lens; a camera that does not move), bit for bit"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(77 + int(lens * 100))
+    L.flow_camera.restype = None
+    L.flow_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    n = 1 << 15
+    for k in range(6):
+        eye = rng.uniform(-20, 20, 3); look = eye + rng.normal(size=3) * 5; up = [(0, 1, 0), (0, 0, 1), (1, 0, 0)][k % 3]
+        res = [(400, 400), (1920, 1080), (64, 48)][k % 3]
+        rd = scenes.make_render_desc(res[0], res[1], 4, (tuple(eye), tuple(look), up), float(rng.uniform(20, 90)), lens_radius=lens, focal_distance=float(rng.uniform(1, 20)),
+                                     shutter=(0.0, 1.0) if k % 2 else (0.25, 0.75))
+        smp = np.zeros((n, 5), np.float32)
+        smp[:, 0] = rng.uniform(0, res[0], n); smp[:, 1] = rng.uniform(0, res[1], n); smp[:, 2:] = rng.uniform(0, 1, (n, 3))
+        smp[:4, :2] = [[0, 0], [res[0], res[1]], [res[0] / 2, res[1] / 2], [0.5, 0.5]]; smp[:8, 3:] = 0.5
+        t, o = np.zeros((n, 20), np.float32), np.zeros((n, 20), np.float32)
+        L.flow_camera(C.addressof(rd), smp.ctypes.data, n, t.ctypes.data, o.ctypes.data)
+        bad = (t.view(np.uint32) != o.view(np.uint32)) & ~(np.isnan(t) & np.isnan(o))
+        assert not bad.any(), "camera %d: columns %s differ in %d samples" % (k, np.nonzero(bad.any(axis=0))[0], int(bad.any(axis=1).sum()))
+        assert np.abs(np.linalg.norm(t[:, 3:6], axis=1) - 1).max() < 1e-5 and (t[:, 6] > 1e30).all()
