@@ -52,6 +52,11 @@ struct PerspectiveCamera {                      // perspective.rs:21-47 (with Ca
     AnimatedTransform camera_to_world; Float shutter_open, shutter_close; MediumRef medium; Transform raster_to_camera; Float lens_radius, focal_distance; Vector3f dx_camera, dy_camera;
     Float generate_ray_differential(const CameraSample& sample, Ray& ray) const;
 };
+struct PointLight { Point3f p_light; Spectrum i; Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f _u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const; };   // lights/point.rs
+struct SpotLight { Point3f p_light; Spectrum i; Float cos_total_width, cos_falloff_start; Transform world_to_light;                                                                         // lights/spot.rs
+    Float falloff(const Vector3f& w) const; Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f _u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const; };
+struct DistantLight { Spectrum l; Vector3f w_light; Float world_radius;                                                                                                                  // lights/distant.rs (world_radius: what preprocess stored)
+    Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f _u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const; };
 static inline Point3f& operator+=(Point3f& a, const Vector3f& b) { a = a + b; return a; }          // impl AddAssign<Vector3f> for Point3f
 static inline Point3f point3f_default() { return Point3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
 Point3f ray_position(const Ray& self_, Float t); Float lerp(Float t, Float a, Float b);
@@ -385,6 +390,10 @@ SOURCES = [
     ("core/transform.rs", ("^impl Transform \\{", r"^    pub fn transform_ray\(&self, r: &Ray\) -> Ray \{"), "transform_ray", "Transform#cam", False),
     ("core/transform.rs", ("^impl AnimatedTransform \\{", r"^    pub fn transform_ray\(&self, r: &Ray\) -> Ray \{"), "transform_ray", "AnimatedTransform#cam", False),
     ("cameras/perspective.rs", r"^    pub fn generate_ray_differential\(", "generate_ray_differential", "PerspectiveCamera#cam", False),
+    ("lights/point.rs", r"^    pub fn sample_li<'a, 'b>\($", "sample_li", "PointLight#cam", False),
+    ("lights/spot.rs", r"^    pub fn falloff\(&self, w: &Vector3f\) -> Float \{", "falloff", "SpotLight#cam", False),
+    ("lights/spot.rs", r"^    pub fn sample_li<'a, 'b>\($", "sample_li", "SpotLight#cam", False),
+    ("lights/distant.rs", r"^    pub fn sample_li<'a, 'b>\($", "sample_li", "DistantLight#cam", False),
     ("core/pbrt.rs", r"^pub fn clamp_t<T>", "clamp_t@int64_t", None, True),
     ("core/pbrt.rs", r"^pub fn clamp_t<T>", "clamp_t@size_t", None, True),
     ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn new\(f: Vec<Float>\) -> Self \{"), "new_", "Distribution1D", True),
@@ -431,6 +440,9 @@ def convert_parts():
         cls = (cls[:-4] or None) if cam else cls
         if name == "lerp":                          # F12: the generic lerp (pbrt.rs:235-245) instantiated at S = T = Float; num::One::one() at Float is 1
             text = re.sub(r"pub fn lerp<S, T>\(t: S, a: T, b: T\) -> T\nwhere.*?\{\n", "pub fn lerp(t: Float, a: Float, b: Float) -> Float {\n", text, flags=re.S).replace("let one: S = num::One::one();", "let one: Float = 1.0 as Float;")
+        if "lights/" in fname:                      # F14: the lights of this batch sit in no medium (the block that clones the spot light's MediumInterface is dropped); DistantLight reads the radius its preprocess stored
+            text = re.sub(r"\n\s*let mut inside: Option<Arc<Medium>> = None;.*?Arc::new\(MediumInterface::new\(inside, outside\)\);", "", text, flags=re.S)
+            text = re.sub(r"\n\s*light_intr\.medium_interface = Some\(medium_interface2_arc\);", "", text).replace("*self.world_radius.read().unwrap()", "self.world_radius")
         self_type = None
         if cls and cls.startswith("@"):            # a method compiled as a free function over the carrier of another batch: `&self` -> an explicit `self`
             self_type, cls = cls[1:], None
@@ -451,7 +463,7 @@ def convert_parts():
             body = re.sub(r"(this->(?:f|pdf)\(\w+, )%s\)" % nm, r"\1*%s)" % nm, body)
         if name == "li":
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
-        for pat, rep, flags in (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+        for pat, rep, flags in (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -573,6 +585,31 @@ extern "C" void flow_camera(const rspt_render_desc* rd, const float* smp, uint64
         };
         put(t, r);
         put(o, flow::to_ref(orc::camera_ray(*rd, orc::P2{q[0], q[1]}, q[2], orc::P2{q[3], q[4]})));
+    }
+}
+// PointLight / SpotLight / DistantLight::sample_li (+ SpotLight::falloff), text next to the oracle's light_sample_li: lt = the records, ref = reference points; out: pdf wi(3) li(3) p(3)
+extern "C" void flow_delta_lights(const rspt_scene_desc* sd, const rspt_light* lt, const float* ref, uint64_t n, float* out_text, float* out_oracle) {
+    orc::Scene sc{*sd};
+    const float radius = orc::world_radius(sc);
+    for (uint64_t i = 0; i < n; i++) {
+        const rspt_light& l = lt[i];
+        const InteractionCommon iref{Point3f{Float(ref[3 * i]), Float(ref[3 * i + 1]), Float(ref[3 * i + 2])}, Float(0.25f), Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)}, Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)},
+                                     Normal3f{Float(0.0f), Float(0.0f), Float(0.0f)}, None};
+        InteractionCommon li = iref; li.time = Float(0.0f); Vector3f wi{Float(0.0f), Float(0.0f), Float(0.0f)}; Float pdf(0.0f); VisibilityTester vis{nullptr, nullptr};
+        const Point3f pl{Float(l.p[0]), Float(l.p[1]), Float(l.p[2])};
+        Spectrum s = Spectrum::new_(Float(0.0f));
+        if (l.kind == RSPT_LIGHT_POINT) s = PointLight{pl, flow::S3f(l.L)}.sample_li(iref, li, Point2f{Float(0.5f), Float(0.5f)}, &wi, &pdf, vis);
+        else if (l.kind == RSPT_LIGHT_SPOT) {
+            Transform w2l{}; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) w2l.m.m[r][c] = Float(l.p[3 + 3 * r + c]);
+            w2l.m.m[3][3] = Float(1.0f);
+            s = SpotLight{pl, flow::S3f(l.L), Float(l.p[12]), Float(l.p[13]), w2l}.sample_li(iref, li, Point2f{Float(0.5f), Float(0.5f)}, &wi, &pdf, vis);
+        } else s = DistantLight{flow::S3f(l.L), Vector3f{Float(l.p[0]), Float(l.p[1]), Float(l.p[2])}, Float(radius)}.sample_li(iref, li, Point2f{Float(0.5f), Float(0.5f)}, &wi, &pdf, vis);
+        float* t = out_text + 11 * i; float* q = out_oracle + 11 * i;
+        t[0] = pdf.v; t[1] = wi.x.v; t[2] = wi.y.v; t[3] = wi.z.v; t[4] = s.c[0].v; t[5] = s.c[1].v; t[6] = s.c[2].v; t[7] = li.p.x.v; t[8] = li.p.y.v; t[9] = li.p.z.v; t[10] = li.time.v;
+        orc::Interaction oref; oref.p = orc::V3{ref[3 * i], ref[3 * i + 1], ref[3 * i + 2]}; oref.time = 0.25f;
+        orc::Interaction oli; orc::V3 owi{0, 0, 0}; float opdf = 0.0f;
+        const orc::Spec os = orc::light_sample_li(sc, l, oref, orc::P2{0.5f, 0.5f}, &owi, &opdf, &oli);
+        q[0] = opdf; q[1] = owi.x; q[2] = owi.y; q[3] = owi.z; q[4] = os.c[0]; q[5] = os.c[1]; q[6] = os.c[2]; q[7] = oli.p.x; q[8] = oli.p.y; q[9] = oli.p.z; q[10] = oli.time;
     }
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {

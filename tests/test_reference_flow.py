@@ -159,3 +159,28 @@ def test_camera_text_equals_the_oracles_camera_ray(flow, lens):
         bad = (t.view(np.uint32) != o.view(np.uint32)) & ~(np.isnan(t) & np.isnan(o))
         assert not bad.any(), "camera %d: columns %s differ in %d samples" % (k, np.nonzero(bad.any(axis=0))[0], int(bad.any(axis=1).sum()))
         assert np.abs(np.linalg.norm(t[:, 3:6], axis=1) - 1).max() < 1e-5 and (t[:, 6] > 1e30).all()
+
+
+def test_delta_light_text_equals_the_oracles_light_sample_li(flow, oracle):
+    """PointLight / SpotLight (with falloff through world_to_light) / DistantLight::sample_li (lights/point.rs, spot.rs, distant.rs) from the reference's text against the
+    oracle's light_sample_li: wi, pdf, radiance, the light-side point and its time for 2^15 reference points per light kind"""
+    import ctypes as C
+    from tests.util import gallery
+    mk, L = flow
+    sc = gallery(oracle.bvh_build, "delta")
+    lights = sc.lights[np.isin(sc.lights["kind"], [abi.LIGHT_POINT, abi.LIGHT_SPOT, abi.LIGHT_DISTANT])]
+    assert set(lights["kind"]) == {abi.LIGHT_POINT, abi.LIGHT_SPOT, abi.LIGHT_DISTANT}
+    rng = np.random.default_rng(5)
+    n = 1 << 15
+    lt = np.ascontiguousarray(lights[rng.integers(0, len(lights), n)])
+    ref = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    t, o = np.zeros((n, 11), np.float32), np.zeros((n, 11), np.float32)
+    L.flow_delta_lights.restype = None
+    L.flow_delta_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.flow_delta_lights(C.addressof(sc.desc), lt.ctypes.data, ref.ctypes.data, n, t.ctypes.data, o.ctypes.data)
+    bad = (t.view(np.uint32) != o.view(np.uint32)) & ~(np.isnan(t) & np.isnan(o))
+    for kind in (abi.LIGHT_POINT, abi.LIGHT_SPOT, abi.LIGHT_DISTANT):
+        sel = lt["kind"] == kind
+        assert not bad[sel].any(), "light kind %d: columns %s differ in %d cases" % (kind, np.nonzero(bad[sel].any(axis=0))[0], int(bad[sel].any(axis=1).sum()))
+    spot = lt["kind"] == abi.LIGHT_SPOT
+    assert (t[spot, 4:7] == 0).all(axis=1).any() and (t[spot, 4:7] > 0).all(axis=1).any()     # outside and inside the cone
