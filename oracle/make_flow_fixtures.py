@@ -172,7 +172,13 @@ struct SurfaceInteraction {
     void compute_scattering_functions(const Ray& ray, bool allow_multiple_lobes, TransportMode mode);   // interaction.rs:371-386
     Ray spawn_ray(const Vector3f& d) const { return to_ref(it.spawn_ray(V(d))); }             // interaction.rs:58-94
 };
-struct InteractionCommon { orc::Interaction it; static InteractionCommon default_() { return InteractionCommon{}; } };
+struct InteractionCommon {
+    orc::Interaction it;
+    static InteractionCommon default_() { return InteractionCommon{}; }
+    static InteractionCommon make(const Point3f& p, Float time, const Vector3f& p_error, const Vector3f& wo, const Normal3f& n) {     // the struct literal of lightdistrib.rs:213-225
+        InteractionCommon r; r.it.p = V(p); r.it.time = time.v; r.it.p_error = V(p_error); r.it.wo = V(wo); r.it.n = orc::V3{n.x.v, n.y.v, n.z.v}; return r;
+    }
+};
 struct VisibilityTester {                       // light.rs:190-230
     const SurfaceInteraction* p0 = nullptr; const InteractionCommon* p1 = nullptr;
     static VisibilityTester default_() { return VisibilityTester{}; }
@@ -260,6 +266,25 @@ struct Sampler {
     Float get_1d() { return Float(s->get_1d()); }
     Point2f get_2d() { const orc::P2 p = s->get_2d(); return Point2f{Float(p.x), Float(p.y)}; }
 };
+// SpatialLightDistribution::compute_distribution (lightdistrib.rs:180-275): the voxel's light weights.  Carriers: the scene's bound and lights, the oracle's radical_inverse and light samplers
+struct Point3i { int32_t x, y, z; int32_t operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); } };
+struct Bounds3fL { Point3f p_min, p_max; Point3f lerp(const Point3f& t) const; };
+struct SpatialScene {
+    const Scene* s;
+    Bounds3fL world_bound() const { const orc::Bounds3 b = s->cx->scene->world_bound(); return Bounds3fL{Pf(b.p_min), Pf(b.p_max)}; }
+    struct Lights { const Scene* s; size_t len() const { return s->lights.len(); }
+        struct L { const Scene* s; uint32_t index;
+            Spectrum sample_li(const InteractionCommon& iref, InteractionCommon* light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester*) const {
+                orc::V3 w{0, 0, 0}; float p = 0.0f;
+                const orc::Spec li = orc::light_sample_li(*s->cx->scene, s->cx->scene->d.lights[index], iref.it, orc::P2{u.x.v, u.y.v}, &w, &p, &light_intr->it);
+                *wi = Vf(w); *pdf = Float(p);
+                return Sf(li);
+            } };
+        L operator[](size_t j) const { return L{s, (uint32_t)j}; } } lights;
+};
+static inline Float radical_inverse(uint16_t base_index, uint64_t a) { return Float(orc::radical_inverse((int)base_index, a)); }      // lowdiscrepancy.rs radical_inverse: the oracle's
+static inline Float spectrum_y(const Spectrum& s) { return s.y(); }
+struct SpatialLightDistribution { SpatialScene scene; int32_t n_voxels[3]; Distribution1D compute_distribution(const Point3i& pi) const; };
 Spectrum estimate_direct(const SurfaceInteraction& it, Point2f u_scattering, const LightRef& light, Point2f u_light, const Scene& scene, Sampler& sampler, bool handle_media, bool specular);
 Spectrum uniform_sample_one_light(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, bool handle_media, Option<Distribution1D> light_distrib);
 struct PathIntegrator {
@@ -270,7 +295,7 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"&mut Ray": "Ray&", "&CameraSample": "const CameraSample&", "Transform": "Transform", "&mut Transform": "Transform*", "Point3f": "Point3f", "Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
+TYPES.update({"&Point3i": "const Point3i&", "Distribution1D": "Distribution1D", "&mut Ray": "Ray&", "&CameraSample": "const CameraSample&", "Transform": "Transform", "&mut Transform": "Transform*", "Point3f": "Point3f", "Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
 RULES_CAM = [
@@ -290,6 +315,21 @@ RULES_CAM = [
     (r"Transform::default\(\)", "Transform::default_()", 0),
 ]
 RULES_FLOW = [
+    # F15 SpatialLightDistribution::compute_distribution: the axis enum as an index, Bounds3f / InteractionCommon literals, Rc, vec![0; n], the enumerate().take(n) loop, iter().sum(), `for item in &mut v`
+    (r"\[XYZEnum::X\]", "[0]", 0), (r"\[XYZEnum::Y\]", "[1]", 0), (r"\[XYZEnum::Z\]", "[2]", 0),
+    (r"let (\w+): Bounds3f = Bounds3f \{\s*p_min: (.*?),\s*p_max: (.*?),\s*\};", r"Bounds3fL \1 = Bounds3fL{\2, \3};", re.S),
+    (r"let mut (\w+): Vec<Float> = vec!\[0\.0 as Float; (.*?)\];", r"Vec<Float> \1 = Vec<Float>::filled(\2);", 0),
+    (r"let (\w+): Rc<InteractionCommon> = Rc::new\(InteractionCommon \{\s*p: (.*?),\s*time,\s*p_error: (.*?),\s*wo: (Vector3f \{.*?\}),\s*n: (.*?),\s*medium_interface: None,\s*\}\);",
+     r"InteractionCommon \1 = InteractionCommon::make(\2, time, \3, \4, \5);", re.S),
+    (r"for \((\w+), (\w+)\) in (\w+)\s*\.iter_mut\(\)\s*\.enumerate\(\)\s*\.take\((.*?)\)\s*\{", r"for (size_t \1 = 0; \1 < (\4) && \1 < \3.len(); \1++) { Float* \2 = &\3[\1];", re.S),
+    (r"let (\w+): Float = (\w+)\.iter\(\)\.sum\(\);", r"Float \1 = Float(0.0f); for (size_t i_ = 0; i_ < \2.len(); i_++) \1 += \2[i_];", 0),
+    (r"for (\w+) in &mut (\w+) \{", r"for (size_t i_ = 0; i_ < \2.len(); i_++) { Float* \1 = &\2[i_];", 0),
+    (r"\*item = item\.max\(", "*item = (*item).max(", 0),
+    (r"\bli\.y\(\)", "spectrum_y(li)", 0),
+    (r"Normal3f::default\(\)", "Normal3f_default()", 0),
+    (r"Distribution1D::new\(", "Distribution1D::new_(", 0),
+    (r"let (\w+): usize = 128;", r"size_t \1 = 128;", 0),
+    (r"\(n_samples \* light_contrib\.len\(\)\) as Float", "Float(n_samples * light_contrib.len())", 0),
     # F11 Distribution1D / 2D: inclusive ranges, Vec::with_capacity, the two iter_mut().skip(1).take(n) loops, isize arithmetic, the struct literal, Some(&mut (x)), None
     (r"for (\w+) in 1\.\.=(\w+) \{", r"for (size_t \1 = 1; \1 <= \2; \1++) {", 0),
     (r"let mut (\w+): Vec<Float> = Vec::with_capacity\(.*?\);", r"Vec<Float> \1;", 0),
@@ -403,6 +443,8 @@ SOURCES = [
     ("core/sampling.rs", ("^impl Distribution1D \\{", r"^    pub fn discrete_pdf\("), "discrete_pdf", "Distribution1D", True),
     ("core/sampling.rs", ("^impl Distribution2D \\{", r"^    pub fn sample_continuous\(&self, u: Point2f, pdf: &mut Float\) -> Point2f \{"), "sample_continuous", "Distribution2D", True),
     ("core/sampling.rs", ("^impl Distribution2D \\{", r"^    pub fn pdf\(&self, p: Point2f\) -> Float \{"), "pdf", "Distribution2D", True),
+    ("core/geometry.rs", r"^    pub fn lerp\(&self, t: &Point3f\) -> Point3f \{", "lerp", "Bounds3fL", True),
+    ("core/lightdistrib.rs", r"^    pub fn compute_distribution\(&self, pi: &Point3i\) -> Distribution1D \{", "compute_distribution", "SpatialLightDistribution", True),
     ("core/reflection.rs", r"^pub fn vec3_same_hemisphere_vec3\(", "vec3_same_hemisphere_vec3", None, False),
     ("core/reflection.rs", r"^fn pow5\(", "pow5", None, False),
     ("core/geometry.rs", r"^pub fn nrm_faceforward_vec3\(", "nrm_faceforward_vec3", None, False),
@@ -458,6 +500,8 @@ def convert_parts():
         if self_type:
             body = body.replace("self.", "self_.")
         body = join_multiline_if(body)
+        if cls and name == "lerp":                  # (Rust's free function `lerp` inside a method of the same name: C++ needs the scope spelled out)
+            body = re.sub(r"(?<![\w.>:])lerp\(", "::lerp(", body)
         for nm in re.findall(r"Vector3f\* (\w+)", sig):        # F9: field access through a `&mut Vector3f` auto-dereferences; handing it on as `&Vector3f` re-borrows
             body = re.sub(r"(?<![\w>.])%s\.(?=[xyz]\b)" % nm, nm + "->", body)
             body = re.sub(r"(this->(?:f|pdf)\(\w+, )%s\)" % nm, r"\1*%s)" % nm, body)
@@ -469,7 +513,7 @@ def convert_parts():
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
         for pat, rep, flags in base.RULES:
             body = re.sub(pat, rep, body, flags=flags)
-        body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|i8|usize|bool|Float|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f|VisibilityTester|InteractionCommon) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+        body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|i8|usize|bool|Float|Point3f|Point2f|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f|VisibilityTester|InteractionCommon) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
         body = re.sub(r"\blet (\w+): (usize|Float);", lambda m: "%s %s;" % (TYPES[m.group(2)], m.group(1)), body)
         base.TYPES["T"] = "Float"
         body = base.shadowing(body, set(params) | set(geom.FN_NAMES) | {"li"})
@@ -611,6 +655,26 @@ extern "C" void flow_delta_lights(const rspt_scene_desc* sd, const rspt_light* l
         const orc::Spec os = orc::light_sample_li(sc, l, oref, orc::P2{0.5f, 0.5f}, &owi, &opdf, &oli);
         q[0] = opdf; q[1] = owi.x; q[2] = owi.y; q[3] = owi.z; q[4] = os.c[0]; q[5] = os.c[1]; q[6] = os.c[2]; q[7] = oli.p.x; q[8] = oli.p.y; q[9] = oli.p.z; q[10] = oli.time;
     }
+}
+// SpatialLightDistribution::compute_distribution for voxels pi (n x 3), text next to the oracle's spatial_compute: func (n_lights per voxel)
+extern "C" int flow_spatial(const rspt_scene_desc* sd, const rspt_render_desc* rd, const int32_t* pi, uint64_t n, float* out_text, float* out_oracle) {
+    orc::Scene sc{*sd};
+    sc.prepare_media();
+    orc::RenderCtx cx; cx.scene = &sc; cx.rd = rd;
+    for (uint32_t i = 0; i < sc.d.n_lights; i++) cx.n_light_samples.push_back(1);
+    orc::light_distrib_init(cx);
+    if (cx.strategy != RSPT_LIGHTS_SPATIAL) return -1;
+    flow::Scene scene{&cx, nullptr, {}, {}};
+    for (uint32_t i = 0; i < sc.d.n_lights; i++) scene.lights.v.push_back(flow::LightRef{&scene, i});
+    const flow::SpatialLightDistribution sd_{flow::SpatialScene{&scene, {&scene}}, {cx.n_voxels[0], cx.n_voxels[1], cx.n_voxels[2]}};
+    const uint32_t nl = sc.d.n_lights;
+    for (uint64_t i = 0; i < n; i++) {
+        const flow::Distribution1D d = sd_.compute_distribution(flow::Point3i{pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]});
+        const int p[3] = {pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]};
+        std::unique_ptr<orc::Distribution1D> o(orc::spatial_compute(cx, p));
+        for (uint32_t j = 0; j < nl; j++) { out_text[nl * i + j] = d.func[j].v; out_oracle[nl * i + j] = o->func[j]; }
+    }
+    return (int)nl;
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {
     if (!sd || !rd) return -1;

@@ -184,3 +184,24 @@ def test_delta_light_text_equals_the_oracles_light_sample_li(flow, oracle):
         assert not bad[sel].any(), "light kind %d: columns %s differ in %d cases" % (kind, np.nonzero(bad[sel].any(axis=0))[0], int(bad[sel].any(axis=1).sum()))
     spot = lt["kind"] == abi.LIGHT_SPOT
     assert (t[spot, 4:7] == 0).all(axis=1).any() and (t[spot, 4:7] > 0).all(axis=1).any()     # outside and inside the cone
+
+
+@pytest.mark.parametrize("lights", ["all", "area"])
+def test_spatial_light_distribution_text_equals_the_oracles(flow, oracle, lights):
+    """SpatialLightDistribution::compute_distribution (lightdistrib.rs:180-275: the voxel's bounds, 128 Halton points, every light sampled at each, the floor of a
+    thousandth of the average, Distribution1D::new) from the reference's text against the oracle's spatial_compute: the weights of every light in 64 voxels"""
+    import ctypes as C
+    from tests.util import GALLERY_LOOK_AT, gallery
+    mk, L = flow
+    sc = gallery(oracle.bvh_build, lights)
+    rd = scenes.make_render_desc(32, 24, 1, GALLERY_LOOK_AT, 60, light_strategy=abi.LIGHTS_SPATIAL)
+    rng = np.random.default_rng(3)
+    pi = rng.integers(0, 6, (64, 3)).astype(np.int32)
+    pi[:2] = [[0, 0, 0], [1, 0, 2]]
+    nl = int(sc.desc.n_lights)
+    t, o = np.zeros((64, nl), np.float32), np.zeros((64, nl), np.float32)
+    L.flow_spatial.restype = C.c_int
+    L.flow_spatial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    assert L.flow_spatial(C.addressof(sc.desc), C.addressof(rd), pi.ctypes.data, 64, t.ctypes.data, o.ctypes.data) == nl
+    assert np.array_equal(t.view(np.uint32), o.view(np.uint32)), "%d of %d weights differ" % (int((t.view(np.uint32) != o.view(np.uint32)).sum()), t.size)
+    assert (t > 0).all() and len(np.unique(t)) > nl
