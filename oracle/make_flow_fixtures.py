@@ -471,6 +471,14 @@ SOURCES = [
 
 
 def convert_parts():
+    saved = (dict(geom.TYPES), dict(base.TYPES))      # (the type tables are module state shared with the other two scripts: a test process runs all three)
+    try:
+        return _convert_parts()
+    finally:
+        geom.TYPES.clear(); geom.TYPES.update(saved[0]); base.TYPES.clear(); base.TYPES.update(saved[1])
+
+
+def _convert_parts():
     parts, where = geom.convert_parts()
     parts.insert(0, '#include "../orc_render.hpp"   // the oracle (header-only, namespace orc): the leaf functions the carriers below delegate to\n')
     parts.append(CARRIERS)

@@ -656,6 +656,14 @@ def tail_value(body):
 
 
 def convert_parts():
+    saved = dict(base.TYPES)
+    try:
+        return _convert_parts()
+    finally:
+        base.TYPES.clear(); base.TYPES.update(saved)
+
+
+def _convert_parts():
     parts, where = base.convert_parts()
     pre = parts[0]
     anchor = "    Float sin() const { return Float(sinf(v)); }\n"
