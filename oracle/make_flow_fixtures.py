@@ -60,6 +60,7 @@ struct DistantLight { Spectrum l; Vector3f w_light; Float world_radius;         
 static inline Point3f& operator+=(Point3f& a, const Vector3f& b) { a = a + b; return a; }          // impl AddAssign<Vector3f> for Point3f
 static inline Point3f point3f_default() { return Point3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
 Point3f ray_position(const Ray& self_, Float t); Float lerp(Float t, Float a, Float b);
+Bounds3f bnd3_union_bnd3f(const Bounds3f& b1, const Bounds3f& b2); Bounds3f bnd3_union_pnt3f(const Bounds3f& b, const Point3f& p);
 Float vec3_abs_dot_nrmf(const Vector3f& v1, const Normal3f& n2); bool vec3_same_hemisphere_vec3(const Vector3f& w, const Vector3f& wp); Float pow5(Float v);
 Normal3f nrm_faceforward_vec3(const Normal3f& n, const Vector3f& v); Vector3f spherical_direction(Float sin_theta, Float cos_theta, Float phi);
 namespace flow {
@@ -285,6 +286,22 @@ struct SpatialScene {
 static inline Float radical_inverse(uint16_t base_index, uint64_t a) { return Float(orc::radical_inverse((int)base_index, a)); }      // lowdiscrepancy.rs radical_inverse: the oracle's
 static inline Float spectrum_y(const Spectrum& s) { return s.y(); }
 struct SpatialLightDistribution { SpatialScene scene; int32_t n_voxels[3]; Distribution1D compute_distribution(const Point3i& pi) const; };
+// ---- the BVH BUILDER's carriers (accelerators/bvh.rs:27-75, 171-392): containers and the arena; every function body below them is the reference's text ----
+Bounds3f bounds3f_default();
+struct BVHPrimitiveInfo { size_t primitive_number; Bounds3f bounds; Point3f centroid; static BVHPrimitiveInfo new_(size_t primitive_number, Bounds3f bounds); };
+struct BVHBuildNode {
+    Bounds3f bounds; Option<const BVHBuildNode*> child1{false, nullptr}, child2{false, nullptr}; uint8_t split_axis = 0; size_t first_prim_offset = 0, n_primitives = 0;
+    static BVHBuildNode default_() { BVHBuildNode n; n.bounds = bounds3f_default(); return n; }
+    void init_leaf(size_t first, size_t n, const Bounds3f& b); void init_interior(uint8_t axis, const BVHBuildNode* c0, const BVHBuildNode* c1);
+};
+struct BucketInfo { size_t count = 0; Bounds3f bounds = bounds3f_default(); };
+struct Arena { std::deque<BVHBuildNode> v; BVHBuildNode* alloc(const BVHBuildNode& n) { v.push_back(n); return &v.back(); } };
+struct PrimHandle { size_t i; size_t clone() const { return i; } };
+struct PrimHandles { PrimHandle operator[](size_t i) const { return PrimHandle{i}; } };
+struct BvhArc { size_t max_prims_in_node; PrimHandles primitives; BvhArc clone() const { return *this; } };      // Arc<BVHAccel> as recursive_build reads it
+template <class T> struct BVec : Vec<T> { void clear() { std::vector<T>::clear(); } void append(BVec* o) { for (const T& x : *o) this->push_back(x); o->clear(); } };
+BVHBuildNode* recursive_build(BvhArc bvh, Arena& arena, BVec<BVHPrimitiveInfo>& primitive_info, size_t start, size_t end, size_t& total_nodes, Vec<size_t>& ordered_prims);
+size_t flatten_bvh_tree(const BVHBuildNode* node, Vec<LinearBVHNode>& nodes, size_t& offset);
 Spectrum estimate_direct(const SurfaceInteraction& it, Point2f u_scattering, const LightRef& light, Point2f u_light, const Scene& scene, Sampler& sampler, bool handle_media, bool specular);
 Spectrum uniform_sample_one_light(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, bool handle_media, Option<Distribution1D> light_distrib);
 struct PathIntegrator {
@@ -295,9 +312,42 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"&Point3i": "const Point3i&", "Distribution1D": "Distribution1D", "&mut Ray": "Ray&", "&CameraSample": "const CameraSample&", "Transform": "Transform", "&mut Transform": "Transform*", "Point3f": "Point3f", "Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
+TYPES.update({"Bounds3f": "Bounds3f", "&Bounds3f": "const Bounds3f&", "BVHBuildNodePtr": "BVHBuildNode*", "&BVHBuildNode": "const BVHBuildNode*", "Arc<BVHAccel>": "BvhArc", "&Arena<BVHBuildNode>": "Arena&",
+              "&mut Vec<BVHPrimitiveInfo>": "BVec<BVHPrimitiveInfo>&", "&mut usize": "size_t&", "&mut Vec<Arc<Primitive>>": "Vec<size_t>&", "&mut Vec<LinearBVHNode>": "Vec<LinearBVHNode>&", "usize": "size_t",
+              "&Point3i": "const Point3i&", "Distribution1D": "Distribution1D", "&mut Ray": "Ray&", "&CameraSample": "const CameraSample&", "Transform": "Transform", "&mut Transform": "Transform*", "Point3f": "Point3f", "Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
+RULES_BVH = [
+    # F17 the BVH builder: iterator windows, fixed arrays of carriers, the arena, the one reachable arm of `match split_method`, the stable partition by a closure, splice / append
+    (r"for (\w+) in (\w+)\.iter\(\)\.take\((\w+)\)\.skip\((\w+)\) \{", r"for (size_t i_ = \4; i_ < \3; i_++) { const auto& \1 = \2[i_];", 0),
+    (r"for (\w+) in (\w+)\.iter\(\)\.take\(([^{}]+?)\)\.skip\(([^{}]+?)\) \{", r"for (size_t i_ = (\4); i_ < (\3); i_++) { const auto& \1 = \2[i_];", 0),
+    (r"for (\w+) in (\w+)\.iter\(\)\.take\(([^{}]+?)\) \{", r"for (size_t i_ = 0; i_ < (\3); i_++) { const auto& \1 = \2[i_];", 0),
+    (r"for \((\w+), (\w+)\) in (\w+)\.iter_mut\(\)\.enumerate\(\)\.take\(([^{}]+?)\) \{", r"for (size_t \1 = 0; \1 < (\4); \1++) { Float* \2 = &\3[\1];", 0),
+    (r"for \((\w+), (\w+)\) in (\w+)\.iter\(\)\.enumerate\(\)\.take\(([^{}]+?)\) \{", r"for (size_t \1 = 0; \1 < (\4); \1++) { const Float* \2 = &\3[\1];", 0),
+    (r"item < &min_cost", "*item < min_cost", 0),
+    (r"let mut (\w+): \[Float; (\d+)\] = \[0\.0; \d+\];", r"Float \1[\2] = {};", 0),
+    (r"let mut (\w+): \[BucketInfo; 12\] = \[BucketInfo::default\(\); 12\];", r"BucketInfo \1[12];", 0),
+    (r"let node: &mut BVHBuildNode = arena\.alloc\(BVHBuildNode::default\(\)\);", "BVHBuildNode* node = arena.alloc(BVHBuildNode::default_());", 0),
+    (r"let (\w+): XYZEnum = match (\w+) \{\s*0 => XYZEnum::X,\s*1 => XYZEnum::Y,\s*_ => XYZEnum::Z,\s*\};", r"int \1 = (int)\2;", re.S),
+    (r"match bvh\.split_method \{\s*SplitMethod::Middle => \{\s*\}\s*SplitMethod::EqualCounts => \{\s*\}\s*SplitMethod::SAH \| SplitMethod::HLBVH => \{", "{ {", re.S),
+    (r"let \(mut left, mut right\): \(\s*Vec<BVHPrimitiveInfo>,\s*Vec<BVHPrimitiveInfo>,\s*\) = primitive_info\[start\.\.end\]\.iter\(\)\.partition\(\|&pi\| \{(.*?)\n(\s*)(b <= min_cost_split_bucket)\s*\}\);",
+     lambda m: "BVec<BVHPrimitiveInfo> left, right;\n%sfor (size_t i_ = start; i_ < end; i_++) { const BVHPrimitiveInfo& pi = primitive_info[i_]; const bool keep_ = ({%s\n%s%s; }); if (keep_) left.push(pi); else right.push(pi); }" % (m.group(2), m.group(1), m.group(2), m.group(3)), re.S),
+    (r"(\w+)\.splice\((\w+)\.\.(\w+), (\w+)\.iter\(\)\.cloned\(\)\);", r"for (size_t i_ = 0; i_ < \4.len(); i_++) \1[\2 + i_] = \4[i_];", 0),
+    (r"BVHAccel::(recursive_build|flatten_bvh_tree)\(", r"\1(", 0),
+    (r"std::f32::MIN", "Float(-FLT_MAX)", 0), (r"std::f32::MAX", "Float(FLT_MAX)", 0),
+    (r"Bounds3f::default\(\)", "bounds3f_default()", 0),
+    (r"LinearBVHNode \{\s*bounds: (.*?),\s*offset: (.*?),\s*n_primitives: (.*?),\s*axis: (.*?),\s*\};", r"LinearBVHNode{\1, \2, \3, \4};", re.S),
+    (r"BVHPrimitiveInfo \{\s*primitive_number,\s*bounds,\s*centroid: (.*?),\s*\}", r"BVHPrimitiveInfo{primitive_number, bounds, \1}", re.S),
+    (r"let (?:mut )?(\w+): (Bounds3f|Point3f|Vector3f) = ", r"\2 \1 = ", 0),
+    (r"((?:\w+->)\w+) as (i32|u16)\b", lambda m: "(%s)(%s)" % ({"i32": "int32_t", "u16": "uint16_t"}[m.group(2)], m.group(1)), 0), (r"(?<!>)\b(\w+) as u16\b", r"(uint16_t)(\1)", 0),
+    (r"(\w+)\.swap\((\w+), ([^()]+)\);", r"std::swap(\1[\2], \1[\3]);", 0),
+    (r"\b(\d+)_u16\b", r"\1", 0),
+    (r"\b(\w+) as Float \* ", r"Float(\1) * ", 0),
+]
+RULES_BVH_POST = [
+    (r"Bounds3f \{\s*p_min: (.*?),\s*p_max: (.*?),?\s*\}(?=[;,)\n])", r"Bounds3f{\1, \2}", re.S),
+    (r"Bounds3f \{ p_min, p_max \}", "Bounds3f{p_min, p_max}", 0),
+]
 RULES_CAM = [
     # F13 the camera and Transform::transform_ray: the optional differential / medium of a Ray (carried as a flag / an id), the Ray and RayDifferential literals in either written order
     (r"if let Some\((\w+)\) = r\.differential \{", r"if (r.differential.some) { const RayDifferential \1 = r.differential;", 0),
@@ -361,7 +411,7 @@ RULES_FLOW = [
     (r"let (?:mut )?(\w+): Arc<\w+> = ", r"auto \1 = ", 0),
     (r"let mut (\w+): Option<Float> = Some\((.*?)\);", r"auto \1 = SomeFloat(\2);", 0),
     # F3  `if let Some([ref] x) = E {`  ->  `if (E.is_some()) { auto& x = E.unwrap();`   (E a place expression);  `Some(&x)` at a call site -> Some(x)
-    (r"if let Some\((?:ref )?(\w+)\) = ((?:this->)?[\w.]+(?:\(\))?) \{", r"if (\2.is_some()) { const auto \1 = \2.unwrap();", 0),
+    (r"if let Some\((?:ref )?(\w+)\) = ((?:this->)?[\w.]+(?:->\w+)?(?:\(\))?) \{", r"if (\2.is_some()) { const auto \1 = \2.unwrap();", 0),
     # F3b the reference's pointer identity of two lights (integrator.rs:550-558):  `unsafe { &*p }` -> p;  `x as *const _ as *const usize` -> x.address()
     (r"let (\w+) = unsafe \{ &\*(\w+) \};", r"const auto& \1 = *\2;", 0),
     (r"let (\w+) = (?:&\*)?(\w+) as \*const _ as \*const usize;", r"auto \1 = \2.address();", 0),
@@ -445,6 +495,18 @@ SOURCES = [
     ("core/sampling.rs", ("^impl Distribution2D \\{", r"^    pub fn pdf\(&self, p: Point2f\) -> Float \{"), "pdf", "Distribution2D", True),
     ("core/geometry.rs", r"^    pub fn lerp\(&self, t: &Point3f\) -> Point3f \{", "lerp", "Bounds3fL", True),
     ("core/lightdistrib.rs", r"^    pub fn compute_distribution\(&self, pi: &Point3i\) -> Distribution1D \{", "compute_distribution", "SpatialLightDistribution", True),
+    ("core/geometry.rs", ("^impl Default for Bounds3f \\{", r"^    fn default\(\) -> Bounds3f \{"), "bounds3f_default", "#bvh", True),
+    ("core/geometry.rs", r"^pub fn bnd3_union_pnt3f\(", "bnd3_union_pnt3f", "#bvh", False),
+    ("core/geometry.rs", r"^pub fn bnd3_union_bnd3f\(", "bnd3_union_bnd3f", "#bvh", False),
+    ("core/geometry.rs", ("^impl Bounds3f \\{", r"^    pub fn diagonal\(&self\) -> Vector3f \{"), "diagonal", "Bounds3f#bvh", False),
+    ("core/geometry.rs", ("^impl Bounds3f \\{", r"^    pub fn surface_area\(&self\) -> Float \{"), "surface_area", "Bounds3f#bvh", False),
+    ("core/geometry.rs", ("^impl Bounds3f \\{", r"^    pub fn maximum_extent\(&self\) -> u8 \{"), "maximum_extent", "Bounds3f#bvh", False),
+    ("core/geometry.rs", ("^impl Bounds3f \\{", r"^    pub fn offset\(&self, p: &Point3f\) -> Vector3f \{"), "offset", "Bounds3f#bvh", False),
+    ("accelerators/bvh.rs", ("^impl BVHPrimitiveInfo \\{", r"^    pub fn new\(primitive_number: usize, bounds: Bounds3f\) -> Self \{"), "new_", "BVHPrimitiveInfo#bvh", True),
+    ("accelerators/bvh.rs", r"^    pub fn init_leaf\(", "init_leaf", "BVHBuildNode#bvh", True),
+    ("accelerators/bvh.rs", r"^    pub fn init_interior\(", "init_interior", "BVHBuildNode#bvh", True),
+    ("accelerators/bvh.rs", r"^    pub fn recursive_build<'a>\($", "recursive_build", "#bvh", True),
+    ("accelerators/bvh.rs", r"^    pub fn flatten_bvh_tree\($", "flatten_bvh_tree", "#bvh", True),
     ("core/reflection.rs", r"^pub fn vec3_same_hemisphere_vec3\(", "vec3_same_hemisphere_vec3", None, False),
     ("core/reflection.rs", r"^fn pow5\(", "pow5", None, False),
     ("core/geometry.rs", r"^pub fn nrm_faceforward_vec3\(", "nrm_faceforward_vec3", None, False),
@@ -480,14 +542,19 @@ def convert_parts():
 
 def _convert_parts():
     parts, where = geom.convert_parts()
-    parts.insert(0, '#include "../orc_render.hpp"   // the oracle (header-only, namespace orc): the leaf functions the carriers below delegate to\n')
+    parts.insert(0, '#include <deque>\n#include "../orc_render.hpp"   // the oracle (header-only, namespace orc): the leaf functions the carriers below delegate to\n')
     parts.append(CARRIERS)
     geom.TYPES.update(TYPES); base.TYPES.update(TYPES)
     for fname, first_re, name, cls, in_flow in SOURCES:
         after_re, first_re = first_re if isinstance(first_re, tuple) else (None, first_re)
         text, l0, l1 = geom.extract(fname, after_re, first_re, None)
         cam = bool(cls) and cls.endswith("#cam")
-        cls = (cls[:-4] or None) if cam else cls
+        bvh = bool(cls) and cls.endswith("#bvh")
+        cls = (cls[:-4] or None) if (cam or bvh) else cls
+        if bvh:                                     # F16: lifetimes; the borrowed return type; `Self`
+            text = re.sub(r"<'a>", "", text.replace("&'a ", "&").replace("-> &BVHBuildNode<'a>", "-> BVHBuildNodePtr").replace("-> &'a BVHBuildNode<'a>", "-> BVHBuildNodePtr"))
+            text = text.replace("&BVHBuildNode<'a>", "&BVHBuildNode").replace("&mut BVHBuildNode<'a>", "&mut BVHBuildNode").replace("Arena<BVHBuildNode<'a>>", "Arena<BVHBuildNode>")
+            TYPES["Self"] = geom.TYPES["Self"] = base.TYPES["Self"] = "BVHPrimitiveInfo" if name == "new_" else "Bounds3f"
         if name == "lerp":                          # F12: the generic lerp (pbrt.rs:235-245) instantiated at S = T = Float; num::One::one() at Float is 1
             text = re.sub(r"pub fn lerp<S, T>\(t: S, a: T, b: T\) -> T\nwhere.*?\{\n", "pub fn lerp(t: Float, a: Float, b: Float) -> Float {\n", text, flags=re.S).replace("let one: S = num::One::one();", "let one: Float = 1.0 as Float;")
         if "lights/" in fname:                      # F14: the lights of this batch sit in no medium (the block that clones the spot light's MediumInterface is dropped); DistantLight reads the radius its preprocess stored
@@ -498,6 +565,9 @@ def _convert_parts():
             self_type, cls = cls[1:], None
             text = text.replace("&self,", "self_: &%s," % self_type)
         text = re.sub(r"^\s*//.*\n", "", text, flags=re.M)                      # (comment lines sit inside li's argument list)
+        if "accelerators/bvh.rs" in fname or "geometry.rs" in fname:
+            text = re.sub(r"\s+// .*$", "", text, flags=re.M)                    # a comment behind an expression
+            text = re.sub(r"\)\s*\n\s*as usize", ") as usize", text)
         if name.startswith("clamp_t@"):             # the generic clamp_t (pbrt.rs:108-121) instantiated at another T: the base's signature rule with its type table switched
             ty = name.split("@")[1]
             saved_t = base.TYPES["T"]; base.TYPES["T"] = ty
@@ -515,11 +585,15 @@ def _convert_parts():
             body = re.sub(r"(this->(?:f|pdf)\(\w+, )%s\)" % nm, r"\1*%s)" % nm, body)
         if name == "li":
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
-        for pat, rep, flags in (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+        if bvh and name in ("recursive_build", "flatten_bvh_tree", "init_interior"):
+            body = re.sub(r"\b(node|c0|c1)\.", r"\1->", body)          # (these are `&BVHBuildNode` / `&mut BVHBuildNode`: pointers into the arena)
+        for pat, rep, flags in (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
-        for pat, rep, flags in base.RULES:
+        if bvh:
+            body = geom.cast_after_parens(body, "i32", "(int32_t)(%s)")
+        for pat, rep, flags in base.RULES + (RULES_BVH_POST if bvh else []):
             body = re.sub(pat, rep, body, flags=flags)
         body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|i8|usize|bool|Float|Point3f|Point2f|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f|VisibilityTester|InteractionCommon) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
         body = re.sub(r"\blet (\w+): (usize|Float);", lambda m: "%s %s;" % (TYPES[m.group(2)], m.group(1)), body)
@@ -683,6 +757,29 @@ extern "C" int flow_spatial(const rspt_scene_desc* sd, const rspt_render_desc* r
         for (uint32_t j = 0; j < nl; j++) { out_text[nl * i + j] = d.func[j].v; out_oracle[nl * i + j] = o->func[j]; }
     }
     return (int)nl;
+}
+// BVHAccel::new's work (bvh.rs:96-152) through the reference's recursive_build + flatten_bvh_tree: bounds (n x 6) -> flattened nodes (32-byte records) + the primitive order; returns the node count
+extern "C" int64_t flow_bvh_build(const float* b6, uint64_t n, uint32_t max_prims_in_node, rspt_bvh_node* nodes_out, uint64_t nodes_cap, uint32_t* ordered_out) {
+    using namespace flow;
+    if (n == 0) return 0;
+    BVec<BVHPrimitiveInfo> info;
+    for (uint64_t i = 0; i < n; i++)     // bvh.rs:113-117: BVHPrimitiveInfo::new(i, world_bound) — its centroid is the reference's text
+        info.push(BVHPrimitiveInfo::new_(i, Bounds3f{Point3f{Float(b6[6 * i]), Float(b6[6 * i + 1]), Float(b6[6 * i + 2])}, Point3f{Float(b6[6 * i + 3]), Float(b6[6 * i + 4]), Float(b6[6 * i + 5])}}));
+    Arena arena; size_t total_nodes = 0; Vec<size_t> ordered;
+    const BvhArc bvh{std::min<size_t>(max_prims_in_node, 255), PrimHandles{}};
+    const BVHBuildNode* root = recursive_build(bvh, arena, info, 0, n, total_nodes, ordered);
+    Vec<LinearBVHNode> nodes = Vec<LinearBVHNode>::filled(total_nodes);
+    size_t offset = 0;
+    flatten_bvh_tree(root, nodes, offset);
+    if (total_nodes > nodes_cap) return -(int64_t)total_nodes;
+    for (size_t k = 0; k < total_nodes; k++) {
+        rspt_bvh_node o{}; const LinearBVHNode& ln = nodes[k];
+        o.bmin[0] = ln.bounds.p_min.x.v; o.bmin[1] = ln.bounds.p_min.y.v; o.bmin[2] = ln.bounds.p_min.z.v; o.bmax[0] = ln.bounds.p_max.x.v; o.bmax[1] = ln.bounds.p_max.y.v; o.bmax[2] = ln.bounds.p_max.z.v;
+        o.offset = ln.offset; o.n_prims = ln.n_primitives; o.axis = ln.axis;
+        nodes_out[k] = o;
+    }
+    for (size_t k = 0; k < ordered.len(); k++) ordered_out[k] = (uint32_t)ordered[k];
+    return (int64_t)total_nodes;
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {
     if (!sd || !rd) return -1;

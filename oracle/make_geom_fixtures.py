@@ -80,6 +80,7 @@ struct Bounds3f {
     Point3f p_min, p_max;
     const Point3f& operator[](MinMaxEnum i) const { return i == MinMaxEnum::Min ? p_min : p_max; }   // impl Index<MinMaxEnum> (geometry.rs:2271-2279)
     bool intersect_p(const Ray& ray, const Vector3f& inv_dir, const uint8_t* dir_is_neg) const;
+    Vector3f diagonal() const; Float surface_area() const; uint8_t maximum_extent() const; Vector3f offset(const Point3f& p) const;      // bodies: the reference's text where a batch compiles them (geometry.rs:2047-2078)
 };
 template <class T> struct Slice { const T* p; size_t n; bool is_empty() const { return n == 0; } const T& operator[](size_t i) const { return p[i]; } };
 struct NoneT {}; static const NoneT None{};

@@ -205,3 +205,29 @@ def test_spatial_light_distribution_text_equals_the_oracles(flow, oracle, lights
     assert L.flow_spatial(C.addressof(sc.desc), C.addressof(rd), pi.ctypes.data, 64, t.ctypes.data, o.ctypes.data) == nl
     assert np.array_equal(t.view(np.uint32), o.view(np.uint32)), "%d of %d weights differ" % (int((t.view(np.uint32) != o.view(np.uint32)).sum()), t.size)
     assert (t > 0).all() and len(np.unique(t)) > nl
+
+
+@pytest.mark.parametrize("kind", ["soup", "dense", "coincident", "grid", "tiny"])
+def test_bvh_builder_text_equals_the_oracles_tree(flow, oracle, kind):
+    """BVHAccel::recursive_build (SAH with 12 buckets, the two-primitive case, coincident centroids, the leaf rule, the stable partition; the RIGHT child is built first) and
+    flatten_bvh_tree (bvh.rs:171-392) with BVHPrimitiveInfo::new, BVHBuildNode::init_leaf / init_interior, Bounds3f::{default, diagonal, surface_area, maximum_extent, offset},
+    bnd3_union_* from the reference's text: the flattened nodes (bounds, offsets, counts, axes) and the primitive order equal the oracle's builder byte for byte"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng({"soup": 1, "dense": 2, "coincident": 3, "grid": 4, "tiny": 5}[kind])
+    n = {"soup": 50000, "dense": 20000, "coincident": 3000, "grid": 4096, "tiny": 3}[kind]
+    c = rng.uniform(-1, 1, (n, 3)); h = rng.uniform(0, 0.01 if kind != "dense" else 0.3, (n, 3))
+    if kind == "coincident":
+        c[: n // 2] = c[0]; c[n // 2:, 1:] = 0.25                     # half of the centroids in one point, the rest on a line
+    if kind == "grid":
+        g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3); c = g / 16.0; h[:] = 0.03     # equal costs: ties in the bucket search
+    b6 = np.concatenate([c - h, c + h], 1).astype(np.float32)
+    L.flow_bvh_build.restype = C.c_int64
+    L.flow_bvh_build.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    for max_prims in (1, 4, 255):
+        nodes_t = np.zeros(2 * n, abi.NODE_DT); order_t = np.zeros(n, np.uint32)
+        nn = L.flow_bvh_build(b6.ctypes.data, n, max_prims, nodes_t.ctypes.data, len(nodes_t), order_t.ctypes.data)
+        nodes_o, order_o = oracle.bvh_build_bounds(b6, max_prims)
+        assert nn == len(nodes_o) > 0
+        assert nodes_t[:nn].tobytes() == nodes_o.tobytes(), "%s, max_prims %d: %d of %d nodes differ" % (kind, max_prims, int((nodes_t[:nn] != nodes_o).sum()), nn)
+        assert np.array_equal(order_t, order_o) and sorted(order_t.tolist()) == list(range(n))
