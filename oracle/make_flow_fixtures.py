@@ -82,7 +82,7 @@ static inline orc::Ray to_orc(const Ray& r) {
     o.medium = r.medium.id;
     return o;
 }
-template <class T> struct Option { bool some; T v; bool is_some() const { return some; } T& unwrap() { return v; } const T& unwrap() const { return v; } };
+template <class T> struct Option { bool some; T v; bool is_some() const { return some; } bool is_none() const { return !some; } T& unwrap() { return v; } const T& unwrap() const { return v; } };
 template <class T> static inline Option<T> Some(const T& v) { return Option<T>{true, v}; }
 template <class T> static inline Option<T*> SomeMut(T& v) { return Option<T*>{true, &v}; }      // Some(&mut x)
 enum class TransportMode { Radiance, Importance };
@@ -154,11 +154,14 @@ struct Bsdf {                                   // reflection.rs:216-232; the me
 struct Bssrdf {};
 struct Phase { Float p(const Vector3f&, const Vector3f&) const { abort(); } Float sample_p(const Vector3f&, Vector3f*, Point2f) const { abort(); } };   // media: VolPathIntegrator's, not on this path
 struct LightRef; struct PrimRef;
-struct Common { Point3f p; Normal3f n; };
-struct Shading { Normal3f n; };
+struct Common { Point3f p; Normal3f n; Vector3f wo; };
+struct Shading { Normal3f n, dndu, dndv; };
+struct CellF { Float v; Float get() const { return v; } };
+struct CellV3 { Vector3f v; Vector3f get() const { return v; } };
 struct SurfaceInteraction {
     orc::Interaction it; orc::Bsdf store; const Scene* scene = nullptr;
     Option<Bsdf> bsdf{false, Bsdf{}}; Option<Bssrdf> bssrdf{false, Bssrdf{}}; Common common; Shading shading; Option<const SurfaceInteraction*> primitive{false, nullptr};
+    CellF dudx, dvdx, dudy, dvdy; CellV3 dpdx, dpdy;
     // the `&dyn Interaction` view of estimate_direct (interaction.rs:20-50)
     const SurfaceInteraction& get_common() const { return *this; }
     bool is_surface_interaction() const { return true; }
@@ -168,7 +171,10 @@ struct SurfaceInteraction {
     Option<Phase> get_phase() const { return Option<Phase>{false, Phase{}}; }
     Option<LightRef> get_area_light() const;      // Primitive::get_area_light of the primitive that was hit
     static SurfaceInteraction default_() { return SurfaceInteraction{}; }
-    void refresh() { common.p = Pf(it.p); common.n = Nf(it.n); shading.n = Nf(it.sh_n); }
+    void refresh() {
+        common.p = Pf(it.p); common.n = Nf(it.n); common.wo = Vf(it.wo); shading.n = Nf(it.sh_n); shading.dndu = Nf(it.sh_dndu); shading.dndv = Nf(it.sh_dndv);
+        dudx.v = Float(it.dudx); dvdx.v = Float(it.dvdx); dudy.v = Float(it.dudy); dvdy.v = Float(it.dvdy); dpdx.v = Vf(it.dpdx); dpdy.v = Vf(it.dpdy);
+    }
     Spectrum le(const Vector3f& w) const;                                                    // interaction.rs:475-483
     void compute_scattering_functions(const Ray& ray, bool allow_multiple_lobes, TransportMode mode);   // interaction.rs:371-386
     Ray spawn_ray(const Vector3f& d) const { return to_ref(it.spawn_ray(V(d))); }             // interaction.rs:58-94
@@ -196,7 +202,7 @@ struct LightRef {
     LightFlags get_flags() const;
     uint32_t address() const { return index; }                                       // (the reference compares Arc pointers: integrator.rs:550-558)
 };
-struct LightList { std::vector<LightRef> v; size_t len() const { return v.size(); } const LightRef& operator[](size_t i) const { return v[i]; } auto begin() const { return v.begin(); } auto end() const { return v.end(); } };
+struct LightList { std::vector<LightRef> v; bool is_empty() const { return v.empty(); } size_t len() const { return v.size(); } const LightRef& operator[](size_t i) const { return v[i]; } auto begin() const { return v.begin(); } auto end() const { return v.end(); } };
 struct Scene {
     orc::RenderCtx* cx; orc::Counters* c; LightList lights, infinite_lights;
     bool intersect(const Ray& ray, SurfaceInteraction* isect) const {
@@ -266,6 +272,18 @@ struct Sampler {
     orc::Sampler* s;
     Float get_1d() { return Float(s->get_1d()); }
     Point2f get_2d() { const orc::P2 p = s->get_2d(); return Point2f{Float(p.x), Float(p.y)}; }
+    // the 2-D sample arrays an integrator's preprocess requested (sobol.rs:203-236, halton.rs): (used up, array, first element of this pixel sample)
+    std::tuple<bool, size_t, size_t> get_2d_array_idxs(int32_t n) { size_t idx = 0; uint64_t start = 0; const bool ok = s->get_2d_array(n, &idx, &start); return {!ok, idx, (size_t)start}; }
+    Point2f get_2d_sample(size_t array_idx, size_t j) const { const orc::P2 p = s->get_2d_sample(array_idx, (uint64_t)j); return Point2f{Float(p.x), Float(p.y)}; }
+};
+struct IntSlice { const int32_t* p; size_t n; size_t len() const { return n; } const int32_t& operator[](size_t i) const { return p[i]; } };
+enum class LightStrategy { UniformSampleAll, UniformSampleOne };
+Spectrum uniform_sample_all_lights(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, IntSlice n_light_samples, bool handle_media);
+struct DirectLightingIntegrator {               // integrators/directlighting.rs:26-40
+    LightStrategy strategy; uint32_t max_depth; IntSlice n_light_samples;
+    Spectrum li(const Ray& ray, const Scene& scene, Sampler& sampler, int32_t depth) const;
+    Spectrum specular_reflect(const Ray& ray, const SurfaceInteraction& isect, const Scene& scene, Sampler& sampler, int32_t depth) const;
+    Spectrum specular_transmit(const Ray& ray, const SurfaceInteraction& isect, const Scene& scene, Sampler& sampler, int32_t depth) const;
 };
 // SpatialLightDistribution::compute_distribution (lightdistrib.rs:180-275): the voxel's light weights.  Carriers: the scene's bound and lights, the oracle's radical_inverse and light samplers
 struct Point3i { int32_t x, y, z; int32_t operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); } };
@@ -312,11 +330,23 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"Bounds3f": "Bounds3f", "&Bounds3f": "const Bounds3f&", "BVHBuildNodePtr": "BVHBuildNode*", "&BVHBuildNode": "const BVHBuildNode*", "Arc<BVHAccel>": "BvhArc", "&Arena<BVHBuildNode>": "Arena&",
+TYPES.update({"&SurfaceInteraction": "const SurfaceInteraction&", "&[i32]": "IntSlice", "Bounds3f": "Bounds3f", "&Bounds3f": "const Bounds3f&", "BVHBuildNodePtr": "BVHBuildNode*", "&BVHBuildNode": "const BVHBuildNode*", "Arc<BVHAccel>": "BvhArc", "&Arena<BVHBuildNode>": "Arena&",
               "&mut Vec<BVHPrimitiveInfo>": "BVec<BVHPrimitiveInfo>&", "&mut usize": "size_t&", "&mut Vec<Arc<Primitive>>": "Vec<size_t>&", "&mut Vec<LinearBVHNode>": "Vec<LinearBVHNode>&", "usize": "size_t",
               "&Point3i": "const Point3i&", "Distribution1D": "Distribution1D", "&mut Ray": "Ray&", "&CameraSample": "const CameraSample&", "Transform": "Transform", "&mut Transform": "Transform*", "Point3f": "Point3f", "Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
+RULES_DL = [
+    # F18 DirectLightingIntegrator: the sample arrays (a tuple of three), the per-light sample counts, the optional differential of the incoming ray
+    (r"let \((\w+), (\w+), (\w+)\) =\s*(sampler\.get_2d_array_idxs\(.*?\));", r"auto [\1, \2, \3] = \4;", re.S),
+    (r"for \((\w+), (\w+)\) in (\w+)\.iter\(\)\.enumerate\(\)\.take\(([^{}]+?)\) \{", r"for (size_t \1 = 0; \1 < (\4) && \1 < \3.len(); \1++) { const int32_t* \2 = &\3[\1];", 0),
+    (r"for (\w+) in 0\.\.\*(\w+) \{", r"for (int32_t \1 = 0; \1 < *\2; \1++) {", 0),
+    (r"\*(n_samples) as Float", r"Float(*\1)", 0),
+    (r"if let Some\((\w+)\) = ray\.differential\.iter\(\)\.next\(\) \{", r"if (ray.differential.some) { const RayDifferential& \1 = ray.differential;", 0),
+    (r"Vector3f::from\(", "Vector3f_from(", 0),
+    (r"let (\w+): Spectrum;", r"Spectrum \1;", 0),
+    (r"&this->n_light_samples|&self\.n_light_samples", "this->n_light_samples", 0),
+    (r"let (?:mut )?(\w+): (Normal3f) = ", r"\2 \1 = ", 0),
+]
 RULES_BVH = [
     # F17 the BVH builder: iterator windows, fixed arrays of carriers, the arena, the one reachable arm of `match split_method`, the stable partition by a closure, splice / append
     (r"for (\w+) in (\w+)\.iter\(\)\.take\((\w+)\)\.skip\((\w+)\) \{", r"for (size_t i_ = \4; i_ < \3; i_++) { const auto& \1 = \2[i_];", 0),
@@ -529,6 +559,10 @@ SOURCES = [
     ("core/integrator.rs", r"^pub fn estimate_direct\(", "estimate_direct", None, True),
     ("core/integrator.rs", r"^pub fn uniform_sample_one_light\(", "uniform_sample_one_light", None, True),
     ("integrators/path.rs", r"^    pub fn li\(", "li", "PathIntegrator", True),
+    ("core/integrator.rs", r"^pub fn uniform_sample_all_lights\(", "uniform_sample_all_lights", "#dl", True),
+    ("integrators/directlighting.rs", r"^    pub fn li\(", "li", "DirectLightingIntegrator#dl", True),
+    ("integrators/directlighting.rs", r"^    pub fn specular_reflect\(", "specular_reflect", "DirectLightingIntegrator#dl", True),
+    ("integrators/directlighting.rs", r"^    pub fn specular_transmit\(", "specular_transmit", "DirectLightingIntegrator#dl", True),
 ]
 
 
@@ -550,7 +584,10 @@ def _convert_parts():
         text, l0, l1 = geom.extract(fname, after_re, first_re, None)
         cam = bool(cls) and cls.endswith("#cam")
         bvh = bool(cls) and cls.endswith("#bvh")
-        cls = (cls[:-4] or None) if (cam or bvh) else cls
+        dl = bool(cls) and cls.endswith("#dl")
+        cls = (cls[:-4] or None) if (cam or bvh) else ((cls[:-3] or None) if dl else cls)
+        if dl:
+            text = re.sub(r"\s+// arena,$", "", text, flags=re.M)                 # a comment behind an argument
         if bvh:                                     # F16: lifetimes; the borrowed return type; `Self`
             text = re.sub(r"<'a>", "", text.replace("&'a ", "&").replace("-> &BVHBuildNode<'a>", "-> BVHBuildNodePtr").replace("-> &'a BVHBuildNode<'a>", "-> BVHBuildNodePtr"))
             text = text.replace("&BVHBuildNode<'a>", "&BVHBuildNode").replace("&mut BVHBuildNode<'a>", "&mut BVHBuildNode").replace("Arena<BVHBuildNode<'a>>", "Arena<BVHBuildNode>")
@@ -583,16 +620,18 @@ def _convert_parts():
         for nm in re.findall(r"Vector3f\* (\w+)", sig):        # F9: field access through a `&mut Vector3f` auto-dereferences; handing it on as `&Vector3f` re-borrows
             body = re.sub(r"(?<![\w>.])%s\.(?=[xyz]\b)" % nm, nm + "->", body)
             body = re.sub(r"(this->(?:f|pdf)\(\w+, )%s\)" % nm, r"\1*%s)" % nm, body)
-        if name == "li":
+        if name == "li" and cls == "PathIntegrator":
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
         if bvh and name in ("recursive_build", "flatten_bvh_tree", "init_interior"):
             body = re.sub(r"\b(node|c0|c1)\.", r"\1->", body)          # (these are `&BVHBuildNode` / `&mut BVHBuildNode`: pointers into the arena)
-        for pat, rep, flags in (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+        for pat, rep, flags in (RULES_DL + RULES_CAM if dl else []) + (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
         if bvh:
             body = geom.cast_after_parens(body, "i32", "(int32_t)(%s)")
+        if dl:
+            body = geom.cast_after_parens(body, "u32", "(uint32_t)(%s)")
         for pat, rep, flags in base.RULES + (RULES_BVH_POST if bvh else []):
             body = re.sub(pat, rep, body, flags=flags)
         body = re.sub(r"\blet (?:mut )?(\w+): (u32|u8|i8|usize|bool|Float|Point3f|Point2f|Spectrum|SurfaceInteraction|TransportMode|Ray|Vector3f|Point2f|VisibilityTester|InteractionCommon) = ", lambda m: "%s %s = " % (TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
@@ -780,6 +819,27 @@ extern "C" int64_t flow_bvh_build(const float* b6, uint64_t n, uint32_t max_prim
     }
     for (size_t k = 0; k < ordered.len(); k++) ordered_out[k] = (uint32_t)ordered[k];
     return (int64_t)total_nodes;
+}
+namespace flow {
+static const int32_t* g_n_light_samples = nullptr; static int g_direct_strategy = 0;
+static orc::Spec direct_li_from_the_references_text(orc::RenderCtx& cx, const orc::Ray& ray, orc::Sampler& sampler, orc::Counters* c) {
+    Scene scene{&cx, c, {}, {}};
+    for (uint32_t i = 0; i < cx.scene->d.n_lights; i++) scene.lights.v.push_back(LightRef{&scene, i});
+    const DirectLightingIntegrator integrator{g_direct_strategy == 0 ? LightStrategy::UniformSampleAll : LightStrategy::UniformSampleOne, cx.rd->max_depth, IntSlice{cx.n_light_samples.data(), cx.n_light_samples.size()}};
+    Sampler s{&sampler};
+    return So(integrator.li(to_ref(ray), scene, s, 0));
+}
+}
+// DirectLightingIntegrator through the oracle's tile loop: strategy 0 = UniformSampleAll, 1 = UniformSampleOne; li = the reference's text (use_text) or the oracle's recursive_li
+extern "C" int flow_render_direct(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int strategy, const int32_t* n_light_samples, int use_text) {
+    if (!sd || !rd) return -1;
+    flow::g_direct_strategy = strategy;
+    orc::g_direct_li_override = use_text ? flow::direct_li_from_the_references_text : nullptr;
+    orc::Scene sc{*sd};
+    orc::RenderOut out;
+    orc::render(sc, *rd, num_threads, film_xyzw, li_rgb, &out, orc::ORC_INTEGRATOR_DIRECT, strategy, n_light_samples);
+    orc::g_direct_li_override = nullptr;
+    return 0;
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {
     if (!sd || !rd) return -1;

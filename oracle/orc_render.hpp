@@ -1512,6 +1512,7 @@ struct RenderOut {
 // PathIntegrator::li from somewhere else: oracle/make_flow_fixtures.py compiles the REFERENCE'S TEXT of li (path.rs:59-282) over this oracle's leaf functions and runs it
 // through this tile loop (oracle/_ref/libflowref.so sets the pointer in its own copy of this header-only code; liboracle.so never does)
 inline Spec (*g_li_override)(RenderCtx&, const Ray&, Sampler&, Counters*) = nullptr;
+inline Spec (*g_direct_li_override)(RenderCtx&, const Ray&, Sampler&, Counters*) = nullptr;     // the same for DirectLightingIntegrator::li (directlighting.rs:71-131)
 // film_xyzw: Film.pixels after all merges (xyz + filter_weight_sum per cropped pixel);
 // li_rgb (optional): radiance per camera sample, [(pixel*spp+s)*3] over crop_px.
 static inline void render(const Scene& scene, const rspt_render_desc& rd, int num_threads, float* film_xyzw, float* li_rgb, RenderOut* out,
@@ -1573,7 +1574,8 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                             done = !sampler.start_next_sample(); // checkpoint / resume (not in the reference): this sample belongs to another range
                             continue;
                         }
-                        Spec l = ext_integrator != ORC_INTEGRATOR_FROM_DESC ? recursive_li(cx, ray, sampler, 0, &c)
+                        Spec l = (ext_integrator == ORC_INTEGRATOR_DIRECT && g_direct_li_override) ? g_direct_li_override(cx, ray, sampler, &c)
+                                 : ext_integrator != ORC_INTEGRATOR_FROM_DESC ? recursive_li(cx, ray, sampler, 0, &c)
                                  : rd.integrator == RSPT_INTEGRATOR_AO       ? ao_li(cx, ray, sampler, &c)
                                  : rd.integrator == RSPT_INTEGRATOR_VOLPATH  ? volpath_li(cx, ray, sampler, &c)
                                  : g_li_override                             ? g_li_override(cx, ray, sampler, &c)

@@ -26,7 +26,9 @@ def flow():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import make_flow_fixtures as mk
     L, where = mk.convert()
-    assert where[-3:] == ["estimate_direct core/integrator.rs:406-570", "uniform_sample_one_light core/integrator.rs:359-403", "PathIntegrator::li integrators/path.rs:59-282"] and "Bsdf::sample_f core/reflection.rs:298-420" in where
+    for w in ("estimate_direct core/integrator.rs:406-570", "uniform_sample_one_light core/integrator.rs:359-403", "PathIntegrator::li integrators/path.rs:59-282", "Bsdf::sample_f core/reflection.rs:298-420",
+              "uniform_sample_all_lights core/integrator.rs:300-355", "DirectLightingIntegrator::li integrators/directlighting.rs:71-123", "recursive_build accelerators/bvh.rs:178-357"):
+        assert w in where, (w, [x for x in where if w.split(" ")[0] in x])
     return mk, L
 
 
@@ -231,3 +233,39 @@ def test_bvh_builder_text_equals_the_oracles_tree(flow, oracle, kind):
         assert nn == len(nodes_o) > 0
         assert nodes_t[:nn].tobytes() == nodes_o.tobytes(), "%s, max_prims %d: %d of %d nodes differ" % (kind, max_prims, int((nodes_t[:nn] != nodes_o).sum()), nn)
         assert np.array_equal(order_t, order_o) and sorted(order_t.tolist()) == list(range(n))
+
+
+def render_direct(flow, sc, rd, strategy, use_text, n_light_samples=None):
+    import ctypes as C
+    mk, L = flow
+    cw, ch = rd.crop_px[2] - rd.crop_px[0], rd.crop_px[3] - rd.crop_px[1]
+    film = np.zeros((cw * ch, 4), np.float32)
+    li = np.zeros((cw * ch, int(rd.spp), 3), np.float32)
+    L.flow_render_direct.restype = C.c_int
+    L.flow_render_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    ns = None if n_light_samples is None else np.ascontiguousarray(n_light_samples, np.int32)
+    assert L.flow_render_direct(C.addressof(sc.desc), C.addressof(rd), 4, film.ctypes.data, li.ctypes.data, strategy, None if ns is None else ns.ctypes.data, int(use_text)) == 0
+    return li
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_directlighting_li_text_equals_the_oracles(flow, oracle, strategy):
+    """DirectLightingIntegrator::li with specular_reflect / specular_transmit (the reflected and refracted rays' differentials; directlighting.rs:71-258) and
+    uniform_sample_all_lights (the per-light 2-D sample arrays; integrator.rs:299-354) / uniform_sample_one_light without a distribution, compiled from the reference's
+    text, against the oracle's recursive_li for every camera sample: the gallery (mirror, glass, every light kind), several samples per light, both samplers, a
+    null-material wall, an infinite light"""
+    from tests.util import GALLERY_LOOK_AT, gallery, sky_scene
+    sc = gallery(oracle.bvh_build, "all")
+    nl = int(sc.desc.n_lights)
+    for sampler, samples in (("sobol", None), ("halton", [1 + (j % 3) * 2 for j in range(nl)]), ("sobol", [4] * nl)):
+        rd = scenes.make_render_desc(48, 36, 4, GALLERY_LOOK_AT, 60, max_depth=5, sampler=sampler, integrator="directlighting", direct_strategy="all" if strategy == 0 else "one", light_samples=samples)
+        t = render_direct(flow, sc, rd, strategy, True, samples); o = render_direct(flow, sc, rd, strategy, False, samples)
+        assert_same(t, o)
+        assert t.mean() > 0.01
+    cb = scenes.cornell_box(oracle.bvh_build)
+    cb.prims["material"][cb.prims["material"] == 1] = abi.NO_MATERIAL
+    rd = scenes.cornell_render_desc(res=32, spp=4, integrator="directlighting", direct_strategy="all" if strategy == 0 else "one")
+    assert_same(render_direct(flow, cb, rd, strategy, True), render_direct(flow, cb, rd, strategy, False))
+    sky = sky_scene(oracle.bvh_build, "image", with_area=True)
+    rd = scenes.make_render_desc(40, 30, 4, GALLERY_LOOK_AT, 60, max_depth=4, integrator="directlighting", direct_strategy="all" if strategy == 0 else "one")
+    assert_same(render_direct(flow, sky, rd, strategy, True), render_direct(flow, sky, rd, strategy, False))
