@@ -60,6 +60,8 @@ struct DistantLight { Spectrum l; Vector3f w_light; Float world_radius;         
 static inline Point3f& operator+=(Point3f& a, const Vector3f& b) { a = a + b; return a; }          // impl AddAssign<Vector3f> for Point3f
 static inline Point3f point3f_default() { return Point3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
 Point3f ray_position(const Ray& self_, Float t); Float lerp(Float t, Float a, Float b);
+Vector3f nrm_cross_vec3(const Normal3f& n1, const Vector3f& v2); Float cosine_hemisphere_pdf(Float cos_theta); Float uniform_hemisphere_pdf();
+static const Float INV_2_PI(0.15915494309189533577f);                      // core/pbrt.rs:19
 Bounds3f bnd3_union_bnd3f(const Bounds3f& b1, const Bounds3f& b2); Bounds3f bnd3_union_pnt3f(const Bounds3f& b, const Point3f& p);
 Float vec3_abs_dot_nrmf(const Vector3f& v1, const Normal3f& n2); bool vec3_same_hemisphere_vec3(const Vector3f& w, const Vector3f& wp); Float pow5(Float v);
 Normal3f nrm_faceforward_vec3(const Normal3f& n, const Vector3f& v); Vector3f spherical_direction(Float sin_theta, Float cos_theta, Float phi);
@@ -161,7 +163,7 @@ struct CellV3 { Vector3f v; Vector3f get() const { return v; } };
 struct SurfaceInteraction {
     orc::Interaction it; orc::Bsdf store; const Scene* scene = nullptr;
     Option<Bsdf> bsdf{false, Bsdf{}}; Option<Bssrdf> bssrdf{false, Bssrdf{}}; Common common; Shading shading; Option<const SurfaceInteraction*> primitive{false, nullptr};
-    CellF dudx, dvdx, dudy, dvdy; CellV3 dpdx, dpdy;
+    CellF dudx, dvdx, dudy, dvdy; CellV3 dpdx, dpdy; Vector3f dpdu;
     // the `&dyn Interaction` view of estimate_direct (interaction.rs:20-50)
     const SurfaceInteraction& get_common() const { return *this; }
     bool is_surface_interaction() const { return true; }
@@ -172,7 +174,7 @@ struct SurfaceInteraction {
     Option<LightRef> get_area_light() const;      // Primitive::get_area_light of the primitive that was hit
     static SurfaceInteraction default_() { return SurfaceInteraction{}; }
     void refresh() {
-        common.p = Pf(it.p); common.n = Nf(it.n); common.wo = Vf(it.wo); shading.n = Nf(it.sh_n); shading.dndu = Nf(it.sh_dndu); shading.dndv = Nf(it.sh_dndv);
+        dpdu = Vf(it.dpdu); common.p = Pf(it.p); common.n = Nf(it.n); common.wo = Vf(it.wo); shading.n = Nf(it.sh_n); shading.dndu = Nf(it.sh_dndu); shading.dndv = Nf(it.sh_dndv);
         dudx.v = Float(it.dudx); dvdx.v = Float(it.dvdx); dudy.v = Float(it.dudy); dvdy.v = Float(it.dvdy); dpdx.v = Vf(it.dpdx); dpdy.v = Vf(it.dpdy);
     }
     Spectrum le(const Vector3f& w) const;                                                    // interaction.rs:475-483
@@ -214,6 +216,7 @@ struct Scene {
         return hit;
     }
     bool intersect_tr(Ray*, struct Sampler&, SurfaceInteraction*, Spectrum*) const { abort(); }
+    bool intersect_p(Ray ray) const { return cx->scene->intersect_p(to_orc(ray), c); }
 };
 inline Spectrum SurfaceInteraction::le(const Vector3f& w) const {
     const rspt_prim& hp = scene->cx->scene->hit_prim(it);
@@ -274,9 +277,17 @@ struct Sampler {
     Point2f get_2d() { const orc::P2 p = s->get_2d(); return Point2f{Float(p.x), Float(p.y)}; }
     // the 2-D sample arrays an integrator's preprocess requested (sobol.rs:203-236, halton.rs): (used up, array, first element of this pixel sample)
     std::tuple<bool, size_t, size_t> get_2d_array_idxs(int32_t n) { size_t idx = 0; uint64_t start = 0; const bool ok = s->get_2d_array(n, &idx, &start); return {!ok, idx, (size_t)start}; }
+    struct Slice2 { std::vector<Point2f> v; const Point2f& operator[](size_t i) const { return v[i]; } };
+    Option<Slice2> get_2d_array(int32_t n) {                              // sobol.rs:214-224: this pixel sample's n elements of the next requested array
+        size_t idx = 0; uint64_t start = 0; Slice2 r;
+        if (!s->get_2d_array(n, &idx, &start)) return Option<Slice2>{false, r};
+        for (int32_t k = 0; k < n; k++) r.v.push_back(get_2d_sample(idx, (size_t)start + (size_t)k));
+        return Option<Slice2>{true, r};
+    }
     Point2f get_2d_sample(size_t array_idx, size_t j) const { const orc::P2 p = s->get_2d_sample(array_idx, (uint64_t)j); return Point2f{Float(p.x), Float(p.y)}; }
 };
 struct IntSlice { const int32_t* p; size_t n; size_t len() const { return n; } const int32_t& operator[](size_t i) const { return p[i]; } };
+struct AOIntegrator { bool cos_sample; int32_t n_samples; Spectrum li(Ray& ray, const Scene& scene, Sampler& sampler, int32_t _depth) const; };     // integrators/ao.rs:20-26
 enum class LightStrategy { UniformSampleAll, UniformSampleOne };
 Spectrum uniform_sample_all_lights(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, IntSlice n_light_samples, bool handle_media);
 struct DirectLightingIntegrator {               // integrators/directlighting.rs:26-40
@@ -336,6 +347,10 @@ TYPES.update({"&SurfaceInteraction": "const SurfaceInteraction&", "&[i32]": "Int
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
 RULES_DL = [
+    # F19 AOIntegrator: the pixel sample's slice of the 2-D array, a temporary ray handed to intersect_p
+    (r"let (\w+): Option<&\[Point2f\]> = ", r"auto \1 = ", 0),
+    (r"for (\w+) in (\w+)\.iter\(\)\.take\(([^{}]+?)\) \{", r"for (size_t i_ = 0; i_ < (\3); i_++) { const auto& \1 = \2[i_];", 0),
+    (r"&mut (isect\.spawn_ray\()", r"\1", 0),
     # F18 DirectLightingIntegrator: the sample arrays (a tuple of three), the per-light sample counts, the optional differential of the incoming ray
     (r"let \((\w+), (\w+), (\w+)\) =\s*(sampler\.get_2d_array_idxs\(.*?\));", r"auto [\1, \2, \3] = \4;", re.S),
     (r"for \((\w+), (\w+)\) in (\w+)\.iter\(\)\.enumerate\(\)\.take\(([^{}]+?)\) \{", r"for (size_t \1 = 0; \1 < (\4) && \1 < \3.len(); \1++) { const int32_t* \2 = &\3[\1];", 0),
@@ -559,6 +574,10 @@ SOURCES = [
     ("core/integrator.rs", r"^pub fn estimate_direct\(", "estimate_direct", None, True),
     ("core/integrator.rs", r"^pub fn uniform_sample_one_light\(", "uniform_sample_one_light", None, True),
     ("integrators/path.rs", r"^    pub fn li\(", "li", "PathIntegrator", True),
+    ("core/geometry.rs", r"^pub fn nrm_cross_vec3\(", "nrm_cross_vec3", None, False),
+    ("core/sampling.rs", r"^pub fn cosine_hemisphere_pdf\(", "cosine_hemisphere_pdf", None, False),
+    ("core/sampling.rs", r"^pub fn uniform_hemisphere_pdf\(", "uniform_hemisphere_pdf", None, False),
+    ("integrators/ao.rs", r"^    pub fn li\($", "li", "AOIntegrator#dl", True),
     ("core/integrator.rs", r"^pub fn uniform_sample_all_lights\(", "uniform_sample_all_lights", "#dl", True),
     ("integrators/directlighting.rs", r"^    pub fn li\(", "li", "DirectLightingIntegrator#dl", True),
     ("integrators/directlighting.rs", r"^    pub fn specular_reflect\(", "specular_reflect", "DirectLightingIntegrator#dl", True),
@@ -821,6 +840,13 @@ extern "C" int64_t flow_bvh_build(const float* b6, uint64_t n, uint32_t max_prim
     return (int64_t)total_nodes;
 }
 namespace flow {
+static orc::Spec ao_li_from_the_references_text(orc::RenderCtx& cx, const orc::Ray& ray, orc::Sampler& sampler, orc::Counters* c) {
+    Scene scene{&cx, c, {}, {}};
+    const AOIntegrator integrator{cx.rd->ao_cos_sample != 0, (int32_t)cx.rd->ao_n_samples};
+    Sampler s{&sampler};
+    Ray r = to_ref(ray);
+    return So(integrator.li(r, scene, s, 0));
+}
 static const int32_t* g_n_light_samples = nullptr; static int g_direct_strategy = 0;
 static orc::Spec direct_li_from_the_references_text(orc::RenderCtx& cx, const orc::Ray& ray, orc::Sampler& sampler, orc::Counters* c) {
     Scene scene{&cx, c, {}, {}};
@@ -844,6 +870,7 @@ extern "C" int flow_render_direct(const rspt_scene_desc* sd, const rspt_render_d
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {
     if (!sd || !rd) return -1;
     orc::g_li_override = use_text ? flow::li_from_the_references_text : nullptr;
+    orc::g_ao_li_override = use_text ? flow::ao_li_from_the_references_text : nullptr;
     orc::Scene sc{*sd};
     orc::RenderOut out;
     orc::render(sc, *rd, num_threads, film_xyzw, li_rgb, &out);

@@ -1512,6 +1512,7 @@ struct RenderOut {
 // PathIntegrator::li from somewhere else: oracle/make_flow_fixtures.py compiles the REFERENCE'S TEXT of li (path.rs:59-282) over this oracle's leaf functions and runs it
 // through this tile loop (oracle/_ref/libflowref.so sets the pointer in its own copy of this header-only code; liboracle.so never does)
 inline Spec (*g_li_override)(RenderCtx&, const Ray&, Sampler&, Counters*) = nullptr;
+inline Spec (*g_ao_li_override)(RenderCtx&, const Ray&, Sampler&, Counters*) = nullptr;         // AOIntegrator::li (ao.rs:53-110)
 inline Spec (*g_direct_li_override)(RenderCtx&, const Ray&, Sampler&, Counters*) = nullptr;     // the same for DirectLightingIntegrator::li (directlighting.rs:71-131)
 // film_xyzw: Film.pixels after all merges (xyz + filter_weight_sum per cropped pixel);
 // li_rgb (optional): radiance per camera sample, [(pixel*spp+s)*3] over crop_px.
@@ -1576,7 +1577,7 @@ static inline void render(const Scene& scene, const rspt_render_desc& rd, int nu
                         }
                         Spec l = (ext_integrator == ORC_INTEGRATOR_DIRECT && g_direct_li_override) ? g_direct_li_override(cx, ray, sampler, &c)
                                  : ext_integrator != ORC_INTEGRATOR_FROM_DESC ? recursive_li(cx, ray, sampler, 0, &c)
-                                 : rd.integrator == RSPT_INTEGRATOR_AO       ? ao_li(cx, ray, sampler, &c)
+                                 : rd.integrator == RSPT_INTEGRATOR_AO       ? (g_ao_li_override ? g_ao_li_override(cx, ray, sampler, &c) : ao_li(cx, ray, sampler, &c))
                                  : rd.integrator == RSPT_INTEGRATOR_VOLPATH  ? volpath_li(cx, ray, sampler, &c)
                                  : g_li_override                             ? g_li_override(cx, ray, sampler, &c)
                                                                              : path_li(cx, ray, sampler, &c);

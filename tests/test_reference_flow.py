@@ -269,3 +269,14 @@ def test_directlighting_li_text_equals_the_oracles(flow, oracle, strategy):
     sky = sky_scene(oracle.bvh_build, "image", with_area=True)
     rd = scenes.make_render_desc(40, 30, 4, GALLERY_LOOK_AT, 60, max_depth=4, integrator="directlighting", direct_strategy="all" if strategy == 0 else "one")
     assert_same(render_direct(flow, sky, rd, strategy, True), render_direct(flow, sky, rd, strategy, False))
+
+
+@pytest.mark.parametrize("cos_sample,sampler,n", [(True, "sobol", 16), (False, "sobol", 8), (True, "halton", 5)])
+def test_ao_li_text_equals_the_oracles(flow, oracle, cos_sample, sampler, n):
+    """AOIntegrator::li (ao.rs:53-110: the frame from the true geometry, this pixel sample's slice of the 2-D array, cosine / uniform hemisphere directions, the unoccluded
+    terms summed in array order) from the reference's text against the oracle's ao_li, every camera sample"""
+    sc = scenes.cornell_box(oracle.bvh_build)
+    rd = scenes.cornell_render_desc(res=40, spp=4, integrator="ao", ao_samples=n, ao_cos_sample=cos_sample, sampler=sampler)
+    _, li_t, _, li_o = both(flow, sc, rd)
+    assert_same(li_t, li_o)
+    assert 0.3 < li_t.mean() < 3.2
