@@ -106,16 +106,18 @@ struct MicrofacetDistribution {                 // enum MicrofacetDistribution (
 Vector3f tr_sample_wh(const TrowbridgeReitzDistribution& self, const Vector3f& wo, const Point2f& u);
 inline Vector3f MicrofacetDistribution::sample_wh(const Vector3f& wo, const Point2f& u) const { return tr_sample_wh(tr, wo, u); }
 typedef Option<Spectrum> OptSpectrum;
+Float radians(Float deg); TrowbridgeReitzDistribution tr_new(Float alpha_x, Float alpha_y, bool sample_visible_area);
 #define LOBE_METHODS Spectrum f(const Vector3f& wo, const Vector3f& wi) const; Float pdf(const Vector3f& wo, const Vector3f& wi) const; uint8_t get_type() const; \
     Spectrum sample_f(const Vector3f& wo, Vector3f* wi, const Point2f& u, Float* pdf, uint8_t* sampled_type) const;
 struct LambertianReflection { Spectrum r; OptSpectrum sc_opt; LOBE_METHODS };
 struct LambertianTransmission { Spectrum t; OptSpectrum sc_opt; LOBE_METHODS };
-struct OrenNayar { Spectrum r; Float a, b; OptSpectrum sc_opt; LOBE_METHODS };
+struct OrenNayar { Spectrum r; Float a, b; OptSpectrum sc_opt; static OrenNayar new_(Spectrum r, Float sigma, OptSpectrum sc_opt); LOBE_METHODS };
 struct SpecularReflection { Spectrum r; Fresnel fresnel; OptSpectrum sc_opt; LOBE_METHODS };
-struct SpecularTransmission { Spectrum t; Float eta_a, eta_b; FresnelDielectric fresnel; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
+struct SpecularTransmission { Spectrum t; Float eta_a, eta_b; FresnelDielectric fresnel; TransportMode mode; OptSpectrum sc_opt; static SpecularTransmission new_(Spectrum t, Float eta_a, Float eta_b, TransportMode mode, OptSpectrum sc_opt); LOBE_METHODS };
 struct FresnelSpecular { Spectrum r, t; Float eta_a, eta_b; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
 struct MicrofacetReflection { Spectrum r; MicrofacetDistribution distribution; Fresnel fresnel; OptSpectrum sc_opt; LOBE_METHODS };
-struct MicrofacetTransmission { Spectrum t; MicrofacetDistribution distribution; Float eta_a, eta_b; FresnelDielectric fresnel; TransportMode mode; OptSpectrum sc_opt; LOBE_METHODS };
+struct MicrofacetTransmission { Spectrum t; MicrofacetDistribution distribution; Float eta_a, eta_b; FresnelDielectric fresnel; TransportMode mode; OptSpectrum sc_opt;
+    static MicrofacetTransmission new_(Spectrum t, MicrofacetDistribution distribution, Float eta_a, Float eta_b, TransportMode mode, OptSpectrum sc_opt); LOBE_METHODS };
 struct FresnelBlend { Spectrum rd, rs; Option<MicrofacetDistribution> distribution; OptSpectrum sc_opt; Spectrum schlick_fresnel(Float cos_theta) const; LOBE_METHODS };
 struct Bxdf {                                   // one lobe: the oracle's (orc::Lobe) behind Bxdf's method names (reflection.rs:470-560)
     const orc::Lobe* l;
@@ -331,6 +333,36 @@ struct BvhArc { size_t max_prims_in_node; PrimHandles primitives; BvhArc clone()
 template <class T> struct BVec : Vec<T> { void clear() { std::vector<T>::clear(); } void append(BVec* o) { for (const T& x : *o) this->push_back(x); o->clear(); } };
 BVHBuildNode* recursive_build(BvhArc bvh, Arena& arena, BVec<BVHPrimitiveInfo>& primitive_info, size_t start, size_t end, size_t& total_nodes, Vec<size_t>& ordered_prims);
 size_t flatten_bvh_tree(const BVHBuildNode* node, Vec<LinearBVHNode>& nodes, size_t& offset);
+// ---- the material recipes (materials/*.rs compute_scattering_functions): constant textures, no bump map; the Bsdf here collects the reference's own lobe structs ----
+namespace mat {
+struct Bxdf {                                   // enum Bxdf (reflection.rs:462-484): the arm that is set
+    uint32_t kind = 0; LambertianReflection lr; OrenNayar on; SpecularReflection sr; SpecularTransmission st; FresnelSpecular fs; MicrofacetReflection mr; MicrofacetTransmission mt;
+    static Bxdf LambertianRefl(const LambertianReflection& x) { Bxdf b; b.kind = RSPT_BXDF_LAMBERT_R; b.lr = x; return b; }
+    static Bxdf OrenNayarRefl(const OrenNayar& x) { Bxdf b; b.kind = RSPT_BXDF_OREN_NAYAR; b.on = x; return b; }
+    static Bxdf SpecRefl(const SpecularReflection& x) { Bxdf b; b.kind = RSPT_BXDF_SPECULAR_R; b.sr = x; return b; }
+    static Bxdf SpecTrans(const SpecularTransmission& x) { Bxdf b; b.kind = RSPT_BXDF_SPECULAR_T; b.st = x; return b; }
+    static Bxdf FresnelSpec(const FresnelSpecular& x) { Bxdf b; b.kind = RSPT_BXDF_FRESNEL_SPEC; b.fs = x; return b; }
+    static Bxdf MicrofacetRefl(const MicrofacetReflection& x) { Bxdf b; b.kind = RSPT_BXDF_MICROFACET_R; b.mr = x; return b; }
+    static Bxdf MicrofacetTrans(const MicrofacetTransmission& x) { Bxdf b; b.kind = RSPT_BXDF_MICROFACET_T; b.mt = x; return b; }
+};
+struct MShading { Normal3f n; Vector3f dpdu; }; struct MCommon { Normal3f n; };
+struct Bsdf;
+struct SurfaceInteraction { MCommon common; MShading shading; std::shared_ptr<Bsdf> store; Option<Bsdf*> bsdf{false, nullptr}; };
+struct Bsdf { Float eta; Normal3f ns, ng; Vector3f ss, ts; Vec<Bxdf> bxdfs; static Bsdf new_(const SurfaceInteraction& si, Float eta); void add(Bxdf b); };
+template <class T> struct Tex { T value; T evaluate(const SurfaceInteraction&) const { return value; } };      // Arc<dyn Texture<T>>: a ConstantTexture
+struct NoBump { bool is_some() const { return false; } int unwrap() const { return 0; } };
+struct Material { static void bump(int, SurfaceInteraction&) {} };
+static inline Fresnel Fresnel_Dielectric(const FresnelDielectric& d) { return Fresnel{1, FresnelNoOp{}, FresnelConductor{}, d}; }
+static inline Fresnel Fresnel_Conductor(const FresnelConductor& c) { return Fresnel{2, FresnelNoOp{}, c, FresnelDielectric{}}; }
+static inline Fresnel Fresnel_NoOp(const FresnelNoOp&) { return Fresnel{0, FresnelNoOp{}, FresnelConductor{}, FresnelDielectric{}}; }
+static inline MicrofacetDistribution MicrofacetDistribution_TrowbridgeReitz(const TrowbridgeReitzDistribution& t) { return MicrofacetDistribution{t}; }
+#define CSF void compute_scattering_functions(SurfaceInteraction& si, TransportMode mode, bool allow_multiple_lobes, NoneAny _material, OptSpectrum scale_opt) const;
+struct MatteMaterial { Tex<Spectrum> kd; Tex<Float> sigma; NoBump bump_map; CSF };
+struct PlasticMaterial { Tex<Spectrum> kd, ks; Tex<Float> roughness; NoBump bump_map; bool remap_roughness; CSF };
+struct MirrorMaterial { Tex<Spectrum> kr; NoBump bump_map; CSF };
+struct GlassMaterial { Tex<Spectrum> kr, kt; Tex<Float> u_roughness, v_roughness, index; NoBump bump_map; bool remap_roughness; CSF };
+struct MetalMaterial { Tex<Spectrum> eta, k; Tex<Float> roughness; Option<Tex<Float>> u_roughness, v_roughness; NoBump bump_map; bool remap_roughness; CSF };
+}
 Spectrum estimate_direct(const SurfaceInteraction& it, Point2f u_scattering, const LightRef& light, Point2f u_light, const Scene& scene, Sampler& sampler, bool handle_media, bool specular);
 Spectrum uniform_sample_one_light(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, bool handle_media, Option<Distribution1D> light_distrib);
 struct PathIntegrator {
@@ -341,11 +373,34 @@ struct PathIntegrator {
 """
 
 TYPES = dict(geom.TYPES)
-TYPES.update({"&SurfaceInteraction": "const SurfaceInteraction&", "&[i32]": "IntSlice", "Bounds3f": "Bounds3f", "&Bounds3f": "const Bounds3f&", "BVHBuildNodePtr": "BVHBuildNode*", "&BVHBuildNode": "const BVHBuildNode*", "Arc<BVHAccel>": "BvhArc", "&Arena<BVHBuildNode>": "Arena&",
+TYPES.update({"Option<Spectrum>": "OptSpectrum", "Option<Arc<Material>>": "NoneAny", "MicrofacetDistribution": "MicrofacetDistribution", "Bxdf": "Bxdf", "RGBSpectrum": "Spectrum", "&Spectrum": "const Spectrum&", "&SurfaceInteraction": "const SurfaceInteraction&", "&[i32]": "IntSlice", "Bounds3f": "Bounds3f", "&Bounds3f": "const Bounds3f&", "BVHBuildNodePtr": "BVHBuildNode*", "&BVHBuildNode": "const BVHBuildNode*", "Arc<BVHAccel>": "BvhArc", "&Arena<BVHBuildNode>": "Arena&",
               "&mut Vec<BVHPrimitiveInfo>": "BVec<BVHPrimitiveInfo>&", "&mut usize": "size_t&", "&mut Vec<Arc<Primitive>>": "Vec<size_t>&", "&mut Vec<LinearBVHNode>": "Vec<LinearBVHNode>&", "usize": "size_t",
               "&Point3i": "const Point3i&", "Distribution1D": "Distribution1D", "&mut Ray": "Ray&", "&CameraSample": "const CameraSample&", "Transform": "Transform", "&mut Transform": "Transform*", "Point3f": "Point3f", "Vec<Float>": "Vec<Float>", "Option<&mut Float>": "Option<Float*>", "Option<&mut usize>": "Option<size_t*>", "Self": "Distribution1D", "&TrowbridgeReitzDistribution": "const TrowbridgeReitzDistribution&", "Normal3f": "Normal3f", "&Normal3f": "const Normal3f&", "i8": "int8_t", "&mut u8": "uint8_t*", "&Light": "const LightRef&", "VisibilityTester": "VisibilityTester", "InteractionCommon": "InteractionCommon", "&Scene": "const Scene&", "&mut Sampler": "Sampler&", "&dyn Interaction": "const SurfaceInteraction&", "Option<&Distribution1D>": "Option<Distribution1D>",
               "Spectrum": "Spectrum", "SurfaceInteraction": "SurfaceInteraction", "TransportMode": "TransportMode", "Ray": "Ray", "Vector3f": "Vector3f"})
 
+RULES_MAT = [
+    # F20 the material recipes: enum constructors, struct literals of the lobes' pieces, `si.bsdf = Some(Bsdf::new(..))` (the Bsdf lives behind the interaction), constant textures
+    (r"Bxdf::(LambertianRefl|OrenNayarRefl|SpecRefl|SpecTrans|FresnelSpec|MicrofacetRefl|MicrofacetTrans)\(", r"Bxdf::\1(", 0),
+    (r"Fresnel::(Dielectric|Conductor|NoOp)\(", r"Fresnel_\1(", 0),
+    (r"MicrofacetDistribution::TrowbridgeReitz\(", "MicrofacetDistribution_TrowbridgeReitz(", 0),
+    (r"TrowbridgeReitzDistribution::new\(", "tr_new(", 0),
+    (r"FresnelDielectric \{\s*eta_i: (.*?),\s*eta_t: (.*?),\s*\}", r"FresnelDielectric{\1, \2}", re.S),
+    (r"FresnelConductor \{\s*eta_i: (.*?),\s*eta_t: (.*?),\s*k: (.*?),\s*\}", r"FresnelConductor{\1, \2, \3}", re.S),
+    (r"FresnelNoOp \{\}", "FresnelNoOp{}", 0),
+    (r"si\.bsdf = Some\(Bsdf::new\(si, (.*?)\)\);", r"si.store = std::make_shared<Bsdf>(Bsdf::new_(si, \1)); si.bsdf = Option<Bsdf*>{true, si.store.get()};", 0),
+    (r"if let Some\(bsdf\) = &mut si\.bsdf \{", "if (si.bsdf.is_some()) { Bsdf& bsdf = *si.bsdf.unwrap();", 0),
+    (r"\.clamp\(", ".clamp_(", 0),
+    (r"std::f32::INFINITY as Float", "Float(INFINITY)", 0),
+    (r"Material::bump\(bump, si\);", "Material::bump(bump, si);", 0),
+    (r"TrowbridgeReitzDistribution \{\s*alpha_x: (.*?),\s*alpha_y: (.*?),\s*sample_visible_area,\s*\}", r"TrowbridgeReitzDistribution{\1, \2, sample_visible_area}", re.S),
+    (r"OrenNayar \{\s*r,\s*a: (.*?),\s*b: (.*?),\s*sc_opt,\s*\}", r"OrenNayar{r, \1, \2, sc_opt}", re.S),
+    (r"SpecularTransmission \{\s*t,\s*eta_a,\s*eta_b,\s*fresnel: (FresnelDielectric\{.*?\}),\s*mode,\s*sc_opt,\s*\}", r"SpecularTransmission{t, eta_a, eta_b, \1, mode, sc_opt}", re.S),
+    (r"MicrofacetTransmission \{\s*t,\s*distribution,\s*eta_a,\s*eta_b,\s*fresnel: (FresnelDielectric\{.*?\}),\s*mode,\s*sc_opt,\s*\}", r"MicrofacetTransmission{t, distribution, eta_a, eta_b, \1, mode, sc_opt}", re.S),
+    (r"Bsdf \{\s*eta,\s*ns: (.*?),\s*ng: (.*?),\s*ss,\s*ts: (.*?),\s*bxdfs: Vec::with_capacity\(8\),\s*\}", r"Bsdf{eta, \1, \2, ss, \3, Vec<Bxdf>()}", re.S),
+    (r"let (?:mut )?(\w+): (RGBSpectrum) = RGBSpectrum::default\(\);", r"Spectrum \1 = spectrum_default();", 0),
+    (r"let (\w+): usize = 3;", r"size_t \1 = 3;", 0),
+    (r"let mut (\w+): Float;", r"Float \1;", 0),
+]
 RULES_DL = [
     # F19 AOIntegrator: the pixel sample's slice of the 2-D array, a temporary ray handed to intersect_p
     (r"let (\w+): Option<&\[Point2f\]> = ", r"auto \1 = ", 0),
@@ -552,6 +607,18 @@ SOURCES = [
     ("accelerators/bvh.rs", r"^    pub fn init_interior\(", "init_interior", "BVHBuildNode#bvh", True),
     ("accelerators/bvh.rs", r"^    pub fn recursive_build<'a>\($", "recursive_build", "#bvh", True),
     ("accelerators/bvh.rs", r"^    pub fn flatten_bvh_tree\($", "flatten_bvh_tree", "#bvh", True),
+    ("core/pbrt.rs", r"^pub fn radians\(", "radians", "#mat", True),
+    ("core/spectrum.rs", ("^impl RGBSpectrum \\{", r"^    pub fn clamp\(&self, low: Float, high: Float\) -> RGBSpectrum \{"), "clamp_", "Spectrum#mat", False),
+    ("core/microfacet.rs", ("^impl TrowbridgeReitzDistribution \\{", r"^    pub fn new\(alpha_x: Float, alpha_y: Float, sample_visible_area: bool\) -> Self \{"), "tr_new", "#mat", True),
+    ("core/reflection.rs", ("^impl OrenNayar \\{", r"^    pub fn new\("), "new_", "OrenNayar#mat", True),
+    ("core/reflection.rs", ("^impl SpecularTransmission \\{", r"^    pub fn new\($"), "new_", "SpecularTransmission#mat", True),
+    ("core/reflection.rs", ("^impl MicrofacetTransmission \\{", r"^    pub fn new\($"), "new_", "MicrofacetTransmission#mat", True),
+    ("core/reflection.rs", ("^impl Bsdf \\{", r"^    pub fn new\(si: &SurfaceInteraction, eta: Float\) -> Self \{"), "new_", "mat::Bsdf#mat", True),
+    ("core/reflection.rs", ("^impl Bsdf \\{", r"^    pub fn add\(&mut self, b: Bxdf\) \{"), "add", "mat::Bsdf#mat", True),
+] + [
+    ("materials/%s.rs" % f, r"^    pub fn compute_scattering_functions\($", "compute_scattering_functions", "mat::%s#mat" % c, True)
+    for f, c in (("matte", "MatteMaterial"), ("plastic", "PlasticMaterial"), ("mirror", "MirrorMaterial"), ("glass", "GlassMaterial"), ("metal", "MetalMaterial"))
+] + [
     ("core/reflection.rs", r"^pub fn vec3_same_hemisphere_vec3\(", "vec3_same_hemisphere_vec3", None, False),
     ("core/reflection.rs", r"^fn pow5\(", "pow5", None, False),
     ("core/geometry.rs", r"^pub fn nrm_faceforward_vec3\(", "nrm_faceforward_vec3", None, False),
@@ -598,11 +665,20 @@ def _convert_parts():
     parts.insert(0, '#include <deque>\n#include "../orc_render.hpp"   // the oracle (header-only, namespace orc): the leaf functions the carriers below delegate to\n')
     parts.append(CARRIERS)
     geom.TYPES.update(TYPES); base.TYPES.update(TYPES)
+    snapshot = dict(TYPES)
     for fname, first_re, name, cls, in_flow in SOURCES:
+        TYPES.clear(); TYPES.update(snapshot); geom.TYPES.update(snapshot); base.TYPES.update(snapshot)      # (a source may switch a few entries: `Self`, which SurfaceInteraction a borrow means)
         after_re, first_re = first_re if isinstance(first_re, tuple) else (None, first_re)
         text, l0, l1 = geom.extract(fname, after_re, first_re, None)
         cam = bool(cls) and cls.endswith("#cam")
         bvh = bool(cls) and cls.endswith("#bvh")
+        mat = bool(cls) and cls.endswith("#mat")
+        if mat:
+            cls = cls[:-4] or None
+            TYPES["Self"] = geom.TYPES["Self"] = base.TYPES["Self"] = {"tr_new": "TrowbridgeReitzDistribution"}.get(name, (cls or "").lstrip("@") or "Float")
+            text = re.sub(r"\bself\s*\n\s*\.", "self.", text)
+            TYPES["&mut SurfaceInteraction"] = geom.TYPES["&mut SurfaceInteraction"] = base.TYPES["&mut SurfaceInteraction"] = "SurfaceInteraction&"
+            TYPES["&SurfaceInteraction"] = geom.TYPES["&SurfaceInteraction"] = base.TYPES["&SurfaceInteraction"] = "const mat::SurfaceInteraction&" if (cls or "").startswith("mat::") else "const SurfaceInteraction&"
         dl = bool(cls) and cls.endswith("#dl")
         cls = (cls[:-4] or None) if (cam or bvh) else ((cls[:-3] or None) if dl else cls)
         if dl:
@@ -643,7 +719,13 @@ def _convert_parts():
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
         if bvh and name in ("recursive_build", "flatten_bvh_tree", "init_interior"):
             body = re.sub(r"\b(node|c0|c1)\.", r"\1->", body)          # (these are `&BVHBuildNode` / `&mut BVHBuildNode`: pointers into the arena)
-        for pat, rep, flags in (RULES_DL + RULES_CAM if dl else []) + (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+        if mat:                                     # F21: the lobes whose `new` is their struct literal in argument order (reflection.rs:718-720, 851-866, 959-961, 1136-1148): `X::new( .. )` -> X{ .. }
+            for lobe in ("LambertianReflection", "SpecularReflection", "FresnelSpecular", "MicrofacetReflection"):
+                while lobe + "::new(" in body:
+                    i = body.index(lobe + "::new(")
+                    j = geom.matching(body, i + len(lobe) + 5)
+                    body = body[:i] + lobe + "{" + body[i + len(lobe) + 6:j] + "}" + body[j + 1:]
+        for pat, rep, flags in (RULES_MAT if mat else []) + (RULES_DL + RULES_CAM if dl else []) + (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -657,7 +739,8 @@ def _convert_parts():
         body = re.sub(r"\blet (\w+): (usize|Float);", lambda m: "%s %s;" % (TYPES[m.group(2)], m.group(1)), body)
         base.TYPES["T"] = "Float"
         body = base.shadowing(body, set(params) | set(geom.FN_NAMES) | {"li"})
-        body = geom.tail_value(body)
+        if not sig.startswith("void"):
+            body = geom.tail_value(body)
         code = "// %s%s:%d-%d\n%s%s" % (REF, fname, l0, l1, sig, body)
         parts.append("namespace flow {\n%s}\n" % code if in_flow else code)
         where.append("%s%s %s:%d-%d" % ((cls + "::") if cls else "", name, fname, l0, l1))
@@ -866,6 +949,43 @@ extern "C" int flow_render_direct(const rspt_scene_desc* sd, const rspt_render_d
     orc::render(sc, *rd, num_threads, film_xyzw, li_rgb, &out, orc::ORC_INTEGRATOR_DIRECT, strategy, n_light_samples);
     orc::g_direct_li_override = nullptr;
     return 0;
+}
+// Material::compute_scattering_functions of one recipe with constant parameters: kind 0 matte (kd, sigma) 1 plastic (kd, ks, roughness) 2 mirror (kr) 3 glass (kr, kt, uroughness, vroughness, index)
+// 4 metal (eta, k, roughness, uroughness, vroughness; a negative u / v roughness = not given).  flags: 1 remaproughness, 2 allow_multiple_lobes, 4 a MixMaterial scale (sc).  frame: n, shading n, shading dpdu.
+// out: the lobe list as rspt_bxdf records (what the oracle's / the library's material assembly produce); returns the lobe count, *eta = Bsdf.eta
+extern "C" int flow_material(int kind, const float* p, int flags, const float* sc, const float* frame, rspt_bxdf* out, float* eta) {
+    using namespace flow; using namespace flow::mat;
+    mat::SurfaceInteraction si;
+    si.common.n = Normal3f{Float(frame[0]), Float(frame[1]), Float(frame[2])}; si.shading.n = Normal3f{Float(frame[3]), Float(frame[4]), Float(frame[5])}; si.shading.dpdu = Vector3f{Float(frame[6]), Float(frame[7]), Float(frame[8])};
+    const OptSpectrum scale{(flags & 4) != 0, S3f(sc)};
+    const bool remap = flags & 1, allow = (flags & 2) != 0;
+    auto F = [](float v) { return Tex<Float>{Float(v)}; }; auto S = [](const float* v) { return Tex<Spectrum>{S3f(v)}; };
+    switch (kind) {
+        case 0: MatteMaterial{S(p), F(p[3]), NoBump{}}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+        case 1: PlasticMaterial{S(p), S(p + 3), F(p[6]), NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+        case 2: MirrorMaterial{S(p), NoBump{}}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+        case 3: GlassMaterial{S(p), S(p + 3), F(p[6]), F(p[7]), F(p[8]), NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+        default: MetalMaterial{S(p), S(p + 3), F(p[6]), Option<Tex<Float>>{p[7] >= 0.0f, F(p[7])}, Option<Tex<Float>>{p[8] >= 0.0f, F(p[8])}, NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+    }
+    const mat::Bsdf& b = *si.bsdf.unwrap();
+    *eta = b.eta.v;
+    auto put3 = [](float* d, const Spectrum& s) { d[0] = s.c[0].v; d[1] = s.c[1].v; d[2] = s.c[2].v; };
+    auto fres = [&](rspt_bxdf& o, const Fresnel& f) { o.fresnel = (uint32_t)f.kind; if (f.kind == 1) { o.eta_a = f.dielectric.eta_i.v; o.eta_b = f.dielectric.eta_t.v; } if (f.kind == 2) { put3(o.c1, f.conductor.eta_t); put3(o.c2, f.conductor.k); } };
+    auto scl = [&](rspt_bxdf& o, const OptSpectrum& s) { o.has_sc = s.some ? 1u : 0u; if (s.some) put3(o.sc, s.v); };
+    for (size_t i = 0; i < b.bxdfs.len(); i++) {
+        const mat::Bxdf& x = b.bxdfs[i]; rspt_bxdf o{}; o.type = x.kind;
+        switch (x.kind) {
+            case RSPT_BXDF_LAMBERT_R: put3(o.r, x.lr.r); scl(o, x.lr.sc_opt); break;
+            case RSPT_BXDF_OREN_NAYAR: put3(o.r, x.on.r); o.on_a = x.on.a.v; o.on_b = x.on.b.v; scl(o, x.on.sc_opt); break;
+            case RSPT_BXDF_SPECULAR_R: put3(o.r, x.sr.r); fres(o, x.sr.fresnel); scl(o, x.sr.sc_opt); break;
+            case RSPT_BXDF_SPECULAR_T: put3(o.r, x.st.t); o.eta_a = x.st.eta_a.v; o.eta_b = x.st.eta_b.v; scl(o, x.st.sc_opt); break;
+            case RSPT_BXDF_FRESNEL_SPEC: put3(o.r, x.fs.r); put3(o.t, x.fs.t); o.eta_a = x.fs.eta_a.v; o.eta_b = x.fs.eta_b.v; scl(o, x.fs.sc_opt); break;
+            case RSPT_BXDF_MICROFACET_R: put3(o.r, x.mr.r); o.alpha_x = x.mr.distribution.tr.alpha_x.v; o.alpha_y = x.mr.distribution.tr.alpha_y.v; fres(o, x.mr.fresnel); scl(o, x.mr.sc_opt); break;
+            case RSPT_BXDF_MICROFACET_T: put3(o.r, x.mt.t); o.alpha_x = x.mt.distribution.tr.alpha_x.v; o.alpha_y = x.mt.distribution.tr.alpha_y.v; o.eta_a = x.mt.eta_a.v; o.eta_b = x.mt.eta_b.v; scl(o, x.mt.sc_opt); break;
+        }
+        out[i] = o;
+    }
+    return (int)b.bxdfs.len();
 }
 extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd, int num_threads, float* film_xyzw, float* li_rgb, int use_text) {
     if (!sd || !rd) return -1;

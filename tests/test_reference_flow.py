@@ -280,3 +280,47 @@ def test_ao_li_text_equals_the_oracles(flow, oracle, cos_sample, sampler, n):
     _, li_t, _, li_o = both(flow, sc, rd)
     assert_same(li_t, li_o)
     assert 0.3 < li_t.mean() < 3.2
+
+
+def test_material_recipes_text_equals_the_oracles_lobe_lists(flow, oracle):
+    """MatteMaterial / PlasticMaterial / MirrorMaterial / GlassMaterial / MetalMaterial::compute_scattering_functions (materials/*.rs) over Bsdf::new / add, OrenNayar::new,
+    SpecularTransmission::new, MicrofacetTransmission::new, TrowbridgeReitzDistribution::new / roughness_to_alpha and Spectrum::clamp — the reference's text, with constant
+    parameters — against the oracle's material assembly (which the library's rspt_material_lobes is held to): the same lobes in the same order with the same parameters,
+    with both values of allow_multiple_lobes and remaproughness"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(17)
+    L.flow_material.restype = C.c_int
+    L.flow_material.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    frame = np.array([0, 0, 1, 0, 0, 1, 1, 0, 0], np.float32); sc3 = np.zeros(3, np.float32)
+    fields = ["type", "fresnel", "r", "t", "eta_a", "eta_b", "alpha_x", "alpha_y", "c1", "c2", "on_a", "on_b", "has_sc"]
+    n_checked = 0
+    for trial in range(200):
+        kind = trial % 5
+        remap = bool(rng.integers(0, 2)); allow = bool(rng.integers(0, 2))
+        c = lambda: tuple(float(np.float32(x)) for x in rng.uniform(0, 1, 3) * (rng.uniform(size=3) > 0.15))      # noqa: E731  (black channels / black colours drop lobes)
+        f = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))                                                  # noqa: E731
+        p = np.zeros(16, np.float32)
+        if kind == 0:
+            kd, sigma = c(), (0.0 if trial % 10 < 5 else f(0, 40)); m = scenes.matte(kd, sigma); p[:3] = kd; p[3] = sigma
+        elif kind == 1:
+            kd, ks, ro = c(), c(), f(0.001, 1.0); m = scenes.plastic(kd, ks, ro, remap); p[:3] = kd; p[3:6] = ks; p[6] = ro
+        elif kind == 2:
+            kr = c(); m = scenes.mirror(kr); p[:3] = kr
+        elif kind == 3:
+            kr, kt, idx = c(), c(), f(1.1, 2.5); ur, vr = (0.0, 0.0) if trial % 10 < 5 else (f(0.01, 0.8), f(0.01, 0.8))
+            m = scenes.glass(kr, kt, idx, ur, vr, remap); p[:3] = kr; p[3:6] = kt; p[6] = ur; p[7] = vr; p[8] = idx
+        else:
+            eta, k, ro = tuple(f(0.1, 3) for _ in range(3)), tuple(f(0, 6) for _ in range(3)), f(0.001, 0.8)
+            uv = (None, None) if trial % 10 < 5 else (f(0.01, 0.5), f(0.01, 0.5))
+            m = scenes.metal(eta, k, ro, remap, uv[0], uv[1]); p[:3] = eta; p[3:6] = k; p[6] = ro; p[7] = -1 if uv[0] is None else uv[0]; p[8] = -1 if uv[1] is None else uv[1]
+        sc, mi = scenes.material_scene(m)
+        eta_o, lob_o = oracle.material_lobes(sc, mi, allow)
+        out = np.zeros(8, abi.BXDF_DT); eta_t = C.c_float(0)
+        n = L.flow_material(kind, p.ctypes.data, (1 if remap else 0) | (2 if allow else 0), sc3.ctypes.data, frame.ctypes.data, out.ctypes.data, C.addressof(eta_t))
+        assert n == len(lob_o), (kind, trial, n, len(lob_o))
+        assert np.float32(eta_t.value) == np.float32(eta_o)
+        for fld in fields:
+            assert np.array_equal(np.ascontiguousarray(out[:n][fld]).view(np.uint32), np.ascontiguousarray(lob_o[fld]).view(np.uint32)), (kind, trial, fld, out[:n][fld], lob_o[fld])
+        n_checked += n
+    assert n_checked > 200
