@@ -298,7 +298,7 @@ struct DirectLightingIntegrator {               // integrators/directlighting.rs
     Spectrum specular_reflect(const Ray& ray, const SurfaceInteraction& isect, const Scene& scene, Sampler& sampler, int32_t depth) const;
     Spectrum specular_transmit(const Ray& ray, const SurfaceInteraction& isect, const Scene& scene, Sampler& sampler, int32_t depth) const;
 };
-// SpatialLightDistribution::compute_distribution (lightdistrib.rs:180-275): the voxel's light weights.  Carriers: the scene's bound and lights, the oracle's radical_inverse and light samplers
+// SpatialLightDistribution::compute_distribution (lightdistrib.rs:180-275): the voxel's light weights.  Carriers: the scene's bound and lights, the oracle's light samplers (radical_inverse is the reference's text)
 struct Point3i { int32_t x, y, z; int32_t operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); } };
 struct Bounds3fL { Point3f p_min, p_max; Point3f lerp(const Point3f& t) const; };
 struct SpatialScene {
@@ -314,7 +314,7 @@ struct SpatialScene {
             } };
         L operator[](size_t j) const { return L{s, (uint32_t)j}; } } lights;
 };
-static inline Float radical_inverse(uint16_t base_index, uint64_t a) { return Float(orc::radical_inverse((int)base_index, a)); }      // lowdiscrepancy.rs radical_inverse: the oracle's
+using ::radical_inverse;      // lowdiscrepancy.rs:1126-2162: the reference's text (compiled in the geometry batch)
 static inline Float spectrum_y(const Spectrum& s) { return s.y(); }
 struct SpatialLightDistribution { SpatialScene scene; int32_t n_voxels[3]; Distribution1D compute_distribution(const Point3i& pi) const; };
 // ---- the BVH BUILDER's carriers (accelerators/bvh.rs:27-75, 171-392): containers and the arena; every function body below them is the reference's text ----

@@ -40,7 +40,8 @@ OUT_DIR = base.OUT_DIR
 FIXTURE = os.path.join(ROOT, "tests", "golden", "geom_functions.npz")
 
 # ---- carriers added to the base prelude (no arithmetic: selectors, bit casts, constants) ----
-FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                             // `n as Float` from usize
+FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                             // `n as Float` from usize / u64
+    Float(uint16_t x) : v((float)x) {}                           // `base as Float` from u16
     explicit operator size_t() const { return (size_t)v; }       // `x as usize` (only met with small non-negative values here)
     explicit operator double() const { return (double)v; }      // `x as f64`
     Float ln() const { return Float(logf(v)); }                  // f32::ln is the platform libm's logf
@@ -59,6 +60,7 @@ PRELUDE2 = r"""
 #include <cstring>
 #include <vector>
 #include <array>
+#include <tuple>
 static const Float MACHINE_EPSILON(5.9604644775390625e-8f);                     // core/pbrt.rs:16: f32::EPSILON * 0.5 = 2^-24
 static const Float PI(3.14159265358979323846f), INV_PI(0.31830988618379067154f), INV_4_PI(0.07957747154594766788f);   // core/pbrt.rs:17-20
 static inline uint32_t float_to_bits(Float f) { uint32_t u; std::memcpy(&u, &f.v, 4); return u; }   // pbrt.rs:30-57: transmute_copy
@@ -150,11 +152,12 @@ struct LinearBVHNode { Bounds3f bounds; int32_t offset; uint16_t n_primitives; u
 struct BVHAccel { Slice<LinearBVHNode> nodes; Slice<GeometricPrimitive> primitives; bool intersect(const Ray& ray, SurfaceInteraction* isect) const; bool intersect_p(const Ray& ray) const; };
 // the Sobol' sampler's carriers (samplers/sobol.rs, core/sampler.rs, core/lowdiscrepancy.rs:1014-1050)
 enum class XYEnum { X, Y };
-struct Vector2i { int32_t x, y; };
+struct Vector2i { int32_t x, y; int32_t operator[](XYEnum i) const { return i == XYEnum::X ? x : y; } };      // impl Index<XYEnum> for Vector2i (geometry.rs:249-257)
 struct Point2i {
     int32_t x, y;
     static Point2i default_() { return Point2i{0, 0}; }
     int32_t operator[](XYEnum i) const { return i == XYEnum::X ? x : y; }      // impl Index<XYEnum> for Point2i (geometry.rs:914-923)
+    int32_t& operator[](XYEnum i) { return i == XYEnum::X ? x : y; }           // impl IndexMut<XYEnum> for Point2i (geometry.rs:933-940)
 };
 Vector2i operator-(const Point2i& a, const Point2i& b);
 Point2f operator+(const Point2f& a, const Point2f& b);
@@ -184,6 +187,33 @@ struct SobolSampler {
     uint64_t get_index_for_sample(uint64_t sample_num) const; Float sample_dimension(uint64_t index, int64_t dim) const;
     void start_pixel(Point2i p); Float get_1d(); Point2f get_2d(); bool start_next_sample(); bool set_sample_number(int64_t sample_num);
     CameraSample get_camera_sample(Point2i p_raster);      // Sampler::get_camera_sample (sampler.rs:85-95); the enum's Sobol arm forwards get_1d / get_2d
+};
+// the Halton sampler's carriers (samplers/halton.rs; the tables PRIMES / PRIME_SUMS come from the reference's text below, lowdiscrepancy.rs:20-150)
+static const uint16_t PRIME_TABLE_SIZE = 1000;                                     // lowdiscrepancy.rs:18
+static const int32_t K_MAX_RESOLUTION = 128;                                       // halton.rs:30
+enum class Ordering { Relaxed, SeqCst };
+template <class T> struct Atomic { mutable T v; static Atomic new_(T x) { return Atomic{x}; } T load(Ordering) const { return v; } void store(T x, Ordering) const { v = x; }
+                                   T fetch_add(T x, Ordering) const { const T o = v; v += x; return o; } };      // one thread here: the orderings carry no arithmetic
+typedef Atomic<int32_t> AtomicI32; typedef Atomic<uint64_t> AtomicU64;
+static Vec<uint16_t> RADICAL_INVERSE_PERMUTATIONS;     // lazy_static (halton.rs:19-26): filled once by g_halton_init, through the text's compute_radical_inverse_permutations
+static inline int32_t rs_min(int32_t a, int32_t b) { return a < b ? a : b; }                                   // Ord::min on i32
+uint32_t reverse_bits_32(uint32_t n); uint64_t reverse_bits_64(uint64_t n); uint64_t inverse_radical_inverse(uint8_t base, uint64_t inverse, uint64_t n_digits);
+Float radical_inverse(uint16_t base_index, uint64_t a); Float scrambled_radical_inverse(uint16_t base_index, uint64_t a, const uint16_t* perm);
+void shuffle(uint16_t* samp, int32_t count, int32_t n_dimensions, Rng& rng); Vec<uint16_t> compute_radical_inverse_permutations(Rng& rng);
+template <class T> T mod_t(T a, T b);
+uint64_t multiplicative_inverse(int64_t a, int64_t n); void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y);
+struct HaltonSampler {                                 // halton.rs:54-78, the fields in their declared order (the literal of HaltonSampler::new names them in this order)
+    int64_t samples_per_pixel; Point2i base_scales, base_exponents; uint64_t sample_stride; std::array<int64_t, 2> mult_inverse;
+    AtomicI32 pixel_for_offset_x, pixel_for_offset_y; AtomicU64 offset_for_current_pixel; bool sample_at_pixel_center;
+    int64_t dimension; uint64_t interval_sample_index; int64_t array_start_dim, array_end_dim;
+    Point2i current_pixel; int64_t current_pixel_sample_index;
+    Vec<int32_t> samples_1d_array_sizes, samples_2d_array_sizes; Vec<Vec<Float>> sample_array_1d; Vec<Vec<Point2f>> sample_array_2d;
+    size_t array_1d_offset, array_2d_offset;
+    static HaltonSampler new_(int64_t samples_per_pixel, const Bounds2i& sample_bounds, bool sample_at_pixel_center);
+    uint64_t get_index_for_sample(uint64_t sample_num) const; Float sample_dimension(uint64_t index, int64_t dim) const; const uint16_t* permutation_for_dimension(int64_t dim) const;
+    void start_pixel(Point2i p); Float get_1d(); Point2f get_2d(); Point2f get_2d_sample(size_t array_idx, size_t idx) const; void request_2d_array(int32_t n); int32_t round_count(int32_t count) const;
+    std::tuple<bool, size_t, size_t> get_2d_array_idxs(int32_t n); bool start_next_sample(); bool set_sample_number(int64_t sample_num);
+    CameraSample get_camera_sample(Point2i p_raster);      // Sampler::get_camera_sample (sampler.rs:85-95); the enum's Halton arm forwards get_1d / get_2d
 };
 // the film's carriers (core/film.rs)
 static const size_t FILTER_TABLE_WIDTH = 16;                                                          // film.rs:22
@@ -233,11 +263,13 @@ TYPES.update({"i64": "int64_t", "i32": "int32_t", "u64": "uint64_t", "usize": "s
               "Vector2f": "Vector2f", "Shading": "Shading", "Point2fArray3": "std::array<Point2f, 3>",
               "InteractionCommon": "InteractionCommon", "&InteractionCommon": "const InteractionCommon&", "&mut InteractionCommon": "InteractionCommon&",
               "&mut VisibilityTester": "VisibilityTester&", "&mut Float": "Float*",
-              "Point2i": "Point2i", "&Point2i": "const Point2i&", "Vector2i": "Vector2i", "CameraSample": "CameraSample", "XYEnum": "XYEnum", "&Point2f": "const Point2f&"})
+              "Point2i": "Point2i", "&Point2i": "const Point2i&", "Vector2i": "Vector2i", "CameraSample": "CameraSample", "XYEnum": "XYEnum", "&Point2f": "const Point2f&",
+              "u16": "uint16_t", "&[u16]": "const uint16_t*", "&mut [u16]": "uint16_t*", "&mut Rng": "Rng&", "Vec<u16>": "Vec<uint16_t>", "&mut i64": "int64_t*", "Tuple3": "std::tuple<bool, size_t, size_t>", "T": "T"})
 
 # (file, search-from regex or None, first-line regex, name, class or None, cut-before regex or None, explicit signature or None, appended epilogue or None, extra rule set)
 TRI_SIG = "bool Triangle::%s(const Ray& ray, Float* t_out, Float* b_out) const {\n"
 TRI_END = "    *t_out = t; b_out[0] = b0; b_out[1] = b1; b_out[2] = b2;   // (hand-written: the values the cut text has computed, handed back)\n    return true;\n}\n"
+MATCH_END = "    return Float(0.0f);   // (not reached: the reference panics for a base index its match has no arm for)\n}\n"
 SOURCES = [
     ("core/pbrt.rs", None, r"^pub fn gamma\(", "gamma", None, None, None, None, ()),
     ("core/pbrt.rs", None, r"^pub fn next_float_up\(", "next_float_up", None, None, None, None, ()),
@@ -341,6 +373,33 @@ SOURCES = [
     ("core/geometry.rs", None, r"^pub fn pnt2_min_pnt2i\(", "pnt2_min_pnt2i", None, None, None, None, ("film", "int")),
     ("core/geometry.rs", None, r"^pub fn pnt2_max_pnt2i\(", "pnt2_max_pnt2i", None, None, None, None, ("film", "int")),
     ("core/geometry.rs", None, r"^pub fn bnd2_intersect_bnd2i\(", "bnd2_intersect_bnd2i", None, None, None, None, ("film", "int")),
+    # the Halton sampler (the reference's default sampler): radical inverses, the digit permutations, the pixel offset, the sample stream
+    ("core/lowdiscrepancy.rs", None, r"^pub fn reverse_bits_32\(", "reverse_bits_32", None, None, None, None, ("int", "morton", "halton")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn reverse_bits_64\(", "reverse_bits_64", None, None, None, None, ("int", "halton")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn inverse_radical_inverse\(", "inverse_radical_inverse", None, None, None, None, ("int", "halton")),
+    ("core/lowdiscrepancy.rs", None, r"^fn radical_inverse_specialized\(", "radical_inverse_specialized", None, None, None, None, ("int", "halton")),
+    ("core/lowdiscrepancy.rs", None, r"^fn scrambled_radical_inverse_specialized\(", "scrambled_radical_inverse_specialized", None, None, None, None, ("int", "halton")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn radical_inverse\(", "radical_inverse", None, None, None, MATCH_END, ("int", "halton")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn scrambled_radical_inverse\(", "scrambled_radical_inverse", None, None, None, MATCH_END, ("int", "halton")),
+    ("core/sampling.rs", None, r"^pub fn shuffle<T>\(", "shuffle", None, None, None, None, ("int", "halton")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn compute_radical_inverse_permutations\(", "compute_radical_inverse_permutations", None, None, None, None, ("int", "halton")),
+    ("core/pbrt.rs", None, r"^pub fn mod_t<T>\(", "mod_t", None, None, "template <class T> T mod_t(T a, T b) {\n", None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^fn extended_gcd\(", "extended_gcd", None, None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^fn multiplicative_inverse\(", "multiplicative_inverse", None, None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn new\($", "new_", "HaltonSampler", None, "HaltonSampler HaltonSampler::new_(int64_t samples_per_pixel, const Bounds2i& sample_bounds, bool sample_at_pixel_center) {\n", None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn get_index_for_sample\(&self", "get_index_for_sample", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn sample_dimension\(&self", "sample_dimension", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    fn permutation_for_dimension\(&self", "permutation_for_dimension", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn start_pixel\(&mut self", "start_pixel", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn get_1d\(&mut self", "get_1d", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn get_2d\(&mut self", "get_2d", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn get_2d_sample\(&self", "get_2d_sample", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn request_2d_array\(&mut self", "request_2d_array", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn round_count\(&self", "round_count", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn get_2d_array_idxs\(&mut self", "get_2d_array_idxs", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn start_next_sample\(&mut self", "start_next_sample", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("samplers/halton.rs", None, r"^    pub fn set_sample_number\(&mut self", "set_sample_number", "HaltonSampler", None, None, None, ("int", "halton")),
+    ("core/sampler.rs", None, r"^    pub fn get_camera_sample\(&mut self", "get_camera_sample", "HaltonSampler", None, None, None, ("int",)),
     ("core/geometry.rs", None, r"^impl_op_ex!\(\+\|a: &Point2f, b: &Vector2f\| -> Point2f \{", "operator+", None, None, None, None, ("int",)),
     ("core/geometry.rs", None, r"^impl_op_ex!\(\+\|a: &Point2i, b: &Point2i\| -> Point2i \{", "operator+", None, None, None, None, ("int",)),
     ("core/geometry.rs", r"^impl Bounds2i \{", r"^    pub fn area\(&self\) -> i32 \{", "area", "Bounds2i", None, None, None, ("int",)),
@@ -558,6 +617,40 @@ RULES_FILM_POST = [
      r"FilmTile{pixel_bounds, filter_radius, \1, filter_table, filter_table_size, Vec<FilmTilePixel>::filled(\2), max_sample_luminance}", re.S),
     (r"Bounds2([fi]) \{\s*p_min: (.*?),\s*p_max: (.*?),?\s*\}(?=[;,)])", r"Bounds2\1{\2, \3}", re.S),
 ]
+RULES_HALTON = [
+    # G30 the match over the base index (radical_inverse / scrambled_radical_inverse): one arm per prime -> one case per prime; the block arm of base 2 holds one
+    #     expression between comment lines; the `_` arm panics
+    (r"match base_index \{", "switch (base_index) {", 0),
+    (r"^(\s*)(\d+) => (\w+\(\d+_u16, [\w, ]+\)),$", r"\1case \2: return \3;", re.M),
+    (r"^(\s*)0 => \{\n(?:\s*//.*\n)*\s*(\S.*)\n(?:\s*//.*\n)*\s*\}", r"\1case 0: return (\2);", re.M),
+    (r"^(\s*)_ => \{\s*panic!\(.*?\);\s*\}", r"\1default: break;", re.M | re.S),
+    (r"\b(\d+)_i64\b", r"\1ll", 0), (r"\)\n\s*as (i64)\b", r") as \1", 0),
+    (r"(\w+\(\w+\)) as Float", r"Float(\1)", 0),
+    (r"\b(\w+) as (u16|u8)\b", lambda m: "(%s)(%s)" % (TYPES[m.group(2)], m.group(1)), 0),
+    (r"^\s*assert_eq!\(.*?\);\s*$", "", re.M | re.S),
+    # G31 generic helpers instantiated where they are used: shuffle<T> at u16 (the permutation table), mod_t<T> as a template; `num::Zero::zero()` is T's zero
+    (r"let result: T = ", "const T result = ", 0), (r"num::Zero::zero\(\)", "T(0)", 0),
+    (r"samp\.swap\(\s*(.*?),\s*(.*?),?\s*\);", r"std::swap(samp[\1], samp[\2]);", re.S),
+    # G32 vectors and slices:  `vec![v; n]` (v is the type's zero in both uses);  `&mut perms[p..(p + n)]` -> the pointer to element p;  `&TABLE[k..]` -> the pointer to element k;  `Vec::new()`
+    (r"let (?:mut )?(\w+): Vec<(\w+)> = vec!\[(?:0_u16|Point2f::default\(\)); (\w+)\];", lambda m: "Vec<%s> %s = Vec<%s>::filled(%s);" % (TYPES[m.group(2)], m.group(1), TYPES[m.group(2)], m.group(3)), 0),
+    (r"&mut perms\[p\.\.\(p \+ PRIMES\[i as usize\] as usize\)\]", "perms.data() + p", 0),
+    (r"^(\s*)&(\w+)\[(.*)\.\.\]$", r"\1&\2[\3]", re.M),
+    (r"Vec::new\(\)", "{}", 0),
+    (r"\b(\d+)_u16\b", r"(uint16_t)\1", 0),
+    # G33 the two axes:  `for i in XYEnum::iter() {`;  `let base = if (i as u8) == 0 { 2 } else { 3 };`;  `res[i].min(K)` on i32;  `[i64; 2]` array literal
+    (r"\[XYEnum::X\]", ".x", 0), (r"\[XYEnum::Y\]", ".y", 0),      # (G8, needed in front of the casts)
+    (r"for (\w+) in XYEnum::iter\(\) \{", r"for (const XYEnum \1 : {XYEnum::X, XYEnum::Y}) {", 0),
+    (r"let (\w+) = if (.*?) \{ (\w+) \} else \{ (\w+) \};", r"const int32_t \1 = (\2) ? \3 : \4;", 0),
+    (r"(\w+\[\w+\])\.min\((\w+)\)", r"rs_min(\1, \2)", 0),
+    (r"let (\w+): \[i64; 2\] = \[(.*?)\];", r"std::array<int64_t, 2> \1 = {\2};", re.S),
+    # G34 HaltonSampler's literal: its fields are written in their declared order -> designated initialisers on one line
+    (r"^(\s*)HaltonSampler \{\n(.*?)\n\s*\}$", lambda m: m.group(1) + "HaltonSampler{" + ", ".join(
+        (".%s = %s" % (f.split(":", 1)[0].strip(), f.split(":", 1)[1].strip()) if ":" in f.replace("::", "") else ".%s = %s" % (f, f))
+        for f in [re.sub(r"\s*//.*$", "", l).strip().rstrip(",") for l in m.group(2).split("\n")] if f) + "}", re.M | re.S),
+    # G35 tuples:  `return (a, b, c);` and a tail `(a, b, c)`
+    (r"return \((\w+), (\w+), (\w+)\);", r"return std::make_tuple(\1, \2, \3);", 0),
+    (r"^(\s*)\((\w+), (\w+), (\w+)\)$", r"\1std::make_tuple(\2, \3, \4)", re.M),
+]
 RULES_RNG = [
     # G11 wrapping integer arithmetic (rng.rs):  `let (x, _overflow) = A.overflowing_OP(B);`  — C++ unsigned arithmetic wraps; Rust's overflowing shifts mask the count
     (r"let \((\w+), _overflow\) = ([\w.>\-]+)\.overflowing_mul\((.*?)\);", r"auto \1 = (\2) * (\3);", 0),
@@ -571,7 +664,8 @@ RULES_RNG = [
 
 def signature(text, name, cls):
     text = re.sub(r"<'a, 'b>", "", re.sub(r"&'[ab] ", "&", text)).replace("-> [Point2f; 3] {", "-> Point2fArray3 {").replace("p: (u32, u32)", "p: PairU32")
-    m = re.match(r"(?:pub )?fn (\w+)\((.*?)\)(?: -> ([\w:]+))?\s*\{\n", text, re.S)
+    text = re.sub(r"fn (\w+)<T>\(", r"fn \1(", text).replace("samp: &mut [T]", "samp: &mut [u16]").replace("-> (bool, usize, usize) {", "-> Tuple3 {")      # (generic helpers: see G31)
+    m = re.match(r"(?:pub )?fn (\w+)\((.*?)\)(?: -> ([\w:<>&\[\]]+))?\s*(?:where[^{]*)?\{\n", text, re.S)
     args, ret = m.group(2), m.group(3)
     out, params, const, refs = [], [], "", []
     is_static = True
@@ -674,7 +768,14 @@ def _convert_parts():
     assert anchor in pre
     pre = pre.replace(anchor, anchor + VEC3_EXTRA)
     # the base prelude ends with the Sobol' words; the carriers of this batch go between the base prelude and the base functions
-    parts = [pre, PRELUDE2] + parts[1:]
+    tables = []
+    for nm in ("PRIMES", "PRIME_SUMS"):      # G36: `pub const NAME: [u32; PRIME_TABLE_SIZE as usize] = [ .. ];` -> a C array of the same words
+        text = open(REF + "core/lowdiscrepancy.rs").read()
+        mo = re.search(r"^pub const %s: \[u32; PRIME_TABLE_SIZE as usize\] = \[\n(.*?)\n\];$" % nm, text, re.M | re.S)
+        l0 = text.count("\n", 0, mo.start()) + 1
+        tables.append("// %score/lowdiscrepancy.rs:%d-%d\nstatic const uint32_t %s[PRIME_TABLE_SIZE] = {\n%s\n};\n" % (REF, l0, l0 + mo.group(0).count("\n"), nm, re.sub(r"(?<=\d)_(?=\d)", "", re.sub(r"^\s*//.*$", "", mo.group(1), flags=re.M))))      # (digit separators: the base's R3)
+        where.append("%s core/lowdiscrepancy.rs:%d-%d" % (nm, l0, l0 + mo.group(0).count("\n")))
+    parts = [pre, PRELUDE2] + tables + parts[1:]
     base.TYPES.update(TYPES)          # (the base's declaration rule R11 looks types up in its own table; the base functions are already converted)
     TYPES["MinMaxEnum"] = base.TYPES["MinMaxEnum"] = "MinMaxEnum"
     for fname, after_re, first_re, name, cls, cut_re, sig_override, epilogue, extra in SOURCES:
@@ -694,12 +795,15 @@ def _convert_parts():
         if "full" in extra and name == "intersect_full":
             i0 = body.index("if let Some(alpha_mask) = &self.mesh.alpha_mask {") if "if let Some(alpha_mask) = &self.mesh.alpha_mask {" in body else body.index("if let Some(alpha_mask) = &this->mesh.alpha_mask {")
             body = body[:body.rfind("\n", 0, i0)] + body[matching(body, body.index("{", i0), "{", "}") + 1:]      # G22: the alpha-mask block (triangle.rs:313-331) is dropped
-        for pat, rep, flags in (RULES_DIFF if "diff" in extra else []) + (RULES_MORTON if "morton" in extra else []) + (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
+        for pat, rep, flags in (RULES_HALTON if "halton" in extra else []) + (RULES_DIFF if "diff" in extra else []) + (RULES_MORTON if "morton" in extra else []) + (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
             body = re.sub(pat, rep, body, flags=flags)
         body = cast_after_parens(body, "Float", "Float(%s)")
         body = cast_after_parens(body, "usize", "(size_t)(%s)")
-        if "full" in extra:
+        if "full" in extra or "halton" in extra:
             body = cast_after_brackets(body, "usize", "(size_t)(%s)")
+        if "halton" in extra:
+            for ty in ("i64", "i32", "u64", "u16"):
+                body = cast_after_brackets(body, ty, "(" + TYPES[ty] + ")(%s)")
         body = cast_after_parens(body, "u8", "(uint8_t)(%s)")
         if "int" in extra:
             for ty in ("i64", "i32", "u64", "u32"):
@@ -713,7 +817,7 @@ def _convert_parts():
             body = re.sub(r"(?<![\w)\]])\*%s\b" % nm, nm, body)
         body = base.shadowing(body, set(params) | set(FN_NAMES))
         if epilogue:
-            body = body.rstrip() + "\n" + epilogue
+            body = (body.rstrip() if cut_re else body.rstrip()[:-1].rstrip()) + "\n" + epilogue      # (an uncut text still ends with its closing brace)
         elif not sig.startswith("void"):
             body = tail_value(body)
         parts.append("// %s%s:%d-%d\n%s%s" % (REF, fname, l0, l1, sig, body))
@@ -906,6 +1010,53 @@ void g_sobol(const int64_t* spp, const int32_t* bounds, const int32_t* pixel, ui
         }
     }
 }
+// lazy_static RADICAL_INVERSE_PERMUTATIONS (halton.rs:19-26): `Rng::new()` (the default state and stream, rng.rs:24-31), then the text's compute_radical_inverse_permutations
+static void halton_init() { if (RADICAL_INVERSE_PERMUTATIONS.len() == 0) { Rng rng; RADICAL_INVERSE_PERMUTATIONS = compute_radical_inverse_permutations(rng); } }
+uint64_t g_halton_perms(uint16_t* out) { halton_init(); if (out) std::memcpy(out, RADICAL_INVERSE_PERMUTATIONS.data(), RADICAL_INVERSE_PERMUTATIONS.len() * sizeof(uint16_t)); return RADICAL_INVERSE_PERMUTATIONS.len(); }
+void g_radical(const uint16_t* bi, const uint64_t* a, uint64_t n, float* out, uint64_t* iout) {   // out: n x 2 (radical_inverse, scrambled_radical_inverse with that base's permutation); iout: n x 4
+    halton_init();
+    for (uint64_t i = 0; i < n; i++) {
+        out[2 * i] = radical_inverse(bi[i], a[i]).v;
+        out[2 * i + 1] = scrambled_radical_inverse(bi[i], a[i], &RADICAL_INVERSE_PERMUTATIONS[PRIME_SUMS[bi[i]]]).v;
+        iout[4 * i] = reverse_bits_32((uint32_t)a[i]); iout[4 * i + 1] = reverse_bits_64(a[i]);
+        iout[4 * i + 2] = inverse_radical_inverse(2, a[i] % 128, 7); iout[4 * i + 3] = inverse_radical_inverse(3, a[i] % 243, 5);
+    }
+}
+// the render loop's use of the sampler (integrator.rs:134-175) plus the 2-D sample arrays an integrator's preprocess requests (directlighting.rs:52-70): request_2d_array, start_pixel, then per
+// sample get_camera_sample, the path's draws, the arrays' first and last element (get_2d_array_idxs / get_2d_sample), start_next_sample
+void g_halton(const int64_t* spp, const int32_t* bounds, const int32_t* pixel, const uint8_t* center, const int32_t* arrays, uint64_t n, float* out, uint64_t* meta) {   // out: n x 4 samples x 34; meta: n x 12
+    halton_init();
+    for (uint64_t i = 0; i < n; i++) {
+        HaltonSampler s = HaltonSampler::new_(spp[i], Bounds2i{Point2i{bounds[4 * i], bounds[4 * i + 1]}, Point2i{bounds[4 * i + 2], bounds[4 * i + 3]}}, center[i] != 0);
+        for (int k = 0; k < 2; k++) if (arrays[2 * i + k] > 0) s.request_2d_array(arrays[2 * i + k]);
+        uint64_t* mt = meta + 12 * i;
+        mt[0] = (uint64_t)s.base_scales.x; mt[1] = (uint64_t)s.base_scales.y; mt[2] = (uint64_t)s.base_exponents.x; mt[3] = (uint64_t)s.base_exponents.y;
+        mt[4] = s.sample_stride; mt[5] = (uint64_t)s.mult_inverse[0]; mt[6] = (uint64_t)s.mult_inverse[1]; mt[7] = 0;
+        const Point2i p{pixel[2 * i], pixel[2 * i + 1]};
+        s.start_pixel(p);
+        for (int k = 0; k < 4; k++) {
+            float* o = out + (4 * i + k) * 34;
+            mt[8 + k] = s.interval_sample_index;
+            const CameraSample cs = s.get_camera_sample(p);
+            o[0] = cs.p_film.x.v; o[1] = cs.p_film.y.v; o[2] = cs.time.v; o[3] = cs.p_lens.x.v; o[4] = cs.p_lens.y.v;
+            for (int b = 0; b < 4; b++) {
+                o[5 + 5 * b] = s.get_1d().v;
+                const Point2f u = s.get_2d(), w = s.get_2d();
+                o[6 + 5 * b] = u.x.v; o[7 + 5 * b] = u.y.v; o[8 + 5 * b] = w.x.v; o[9 + 5 * b] = w.y.v;
+            }
+            for (int a = 0; a < 2; a++) {
+                o[25 + 4 * a] = o[26 + 4 * a] = o[27 + 4 * a] = o[28 + 4 * a] = -1.0f;
+                const int32_t na = arrays[2 * i + a];
+                if (na <= 0 || k >= spp[i]) continue;          // (past the last pixel sample the arrays hold nothing)
+                const std::tuple<bool, size_t, size_t> ix = s.get_2d_array_idxs(na);
+                if (std::get<0>(ix)) continue;
+                const Point2f f = s.get_2d_sample(std::get<1>(ix), std::get<2>(ix)), l = s.get_2d_sample(std::get<1>(ix), std::get<2>(ix) + (size_t)na - 1);
+                o[25 + 4 * a] = f.x.v; o[26 + 4 * a] = f.y.v; o[27 + 4 * a] = l.x.v; o[28 + 4 * a] = l.y.v;
+            }
+            o[33] = s.start_next_sample() ? 1.0f : 0.0f;
+        }
+    }
+}
 void g_morton(const uint32_t* xy, uint64_t n, uint32_t* out) { for (uint64_t i = 0; i < n; i++) out[i] = morton2(std::pair<uint32_t, uint32_t>{xy[2 * i], xy[2 * i + 1]}); }
 void g_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {   // per sequence: 4 words, 2 floats, 2 bounded draws
     for (uint64_t i = 0; i < n; i++) {
@@ -1028,6 +1179,21 @@ def inputs(n=1 << 12, seed=0x6E0A):
     px = x0 + rng.integers(0, 1 << 30, n) % w; py = y0 + rng.integers(0, 1 << 30, n) % h
     px[:8] = x0[:8]; py[:8] = y0[:8]; px[8:16] = (x0 + w - 1)[8:16]; py[8:16] = (y0 + h - 1)[8:16]
     d["sob_pixel"] = np.stack([px, py], 1).astype(np.int32)
+    # the Halton sampler the same way: any spp, resolutions below / at / above K_MAX_RESOLUTION = 128 (the base scales saturate at 128 / 243), negative pixel coordinates
+    # (mod_t), samplepixelcenter, and up to two requested 2-D arrays (directlighting's light / BSDF arrays);  the radical inverses over all 1000 bases
+    d["hal_spp"] = rng.choice(np.array([1, 3, 16, 64, 100], np.int64), n)
+    x0 = rng.integers(-40, 64, n) * (rng.uniform(size=n) < 0.5); y0 = rng.integers(-40, 64, n) * (rng.uniform(size=n) < 0.5)
+    w = rng.choice([1, 2, 16, 100, 128, 400, 1920], n); h = rng.choice([1, 3, 16, 100, 243, 400, 1080], n)
+    d["hal_bounds"] = np.stack([x0, y0, x0 + w, y0 + h], 1).astype(np.int32)
+    px = x0 + rng.integers(0, 1 << 30, n) % w; py = y0 + rng.integers(0, 1 << 30, n) % h
+    px[:8] = x0[:8]; py[:8] = y0[:8]; px[8:16] = (x0 + w - 1)[8:16]; py[8:16] = (y0 + h - 1)[8:16]
+    d["hal_pixel"] = np.stack([px, py], 1).astype(np.int32)
+    d["hal_center"] = (rng.uniform(size=n) < 0.25).astype(np.uint8)
+    d["hal_arrays"] = np.array([[0, 0], [4, 0], [1, 4], [2, 2]], np.int32)[rng.integers(0, 4, n)]
+    bi = rng.integers(0, 1000, n_all).astype(np.uint16); bi[:64] = np.arange(64); bi[64:72] = 999
+    a = rng.integers(0, 1 << 62, n_all, dtype=np.uint64) >> rng.integers(0, 62, n_all).astype(np.uint64)
+    a[:4] = [0, 1, 0xFFFFFFFFFFFFFFFF, 0x8000000000000000]
+    d["rad_bi"] = bi; d["rad_a"] = a
     n = n_all
     # DiffuseAreaLight::sample_li: emitting triangles of a scene of extent ~10, reference points in front of / behind / in the plane of / ON the triangle
     P0 = rng.uniform(-5, 5, (n, 3)); e1 = rng.normal(size=(n, 3)) * np.exp(rng.uniform(-3, 1, (n, 1))); e2 = rng.normal(size=(n, 3)) * np.exp(rng.uniform(-3, 1, (n, 1)))
@@ -1197,11 +1363,45 @@ def run_reference(L, d):
     L.keep_alive = keep
     out["sob_out"] = call("g_sobol", [d["sob_spp"], d["sob_bounds"], d["sob_pixel"]], (len(d["sob_spp"]), 4, 26), n=len(d["sob_spp"]))
     out["mor_out"] = call("g_morton", [d["mor_xy"]], n, dtype=np.uint32)
+    out.update(run_halton(L, d))
     ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
     L.g_rng.restype = None
     L.g_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.g_rng(P(d["rng_seq"]), P(d["rng_bound"]), n, ou.ctypes.data, of.ctypes.data)
     out["rng_u_out"] = ou; out["rng_f_out"] = of
+    return out
+
+
+def halton_permutations(L):
+    """RADICAL_INVERSE_PERMUTATIONS as the reference's text computes it (all 1000 bases)"""
+    L.g_halton_perms.restype = C.c_uint64
+    L.g_halton_perms.argtypes = [C.c_void_p]
+    perms = np.zeros(L.g_halton_perms(None), np.uint16)
+    L.g_halton_perms(perms.ctypes.data)
+    return perms
+
+
+def perm_digest(perms):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(perms, "<u2").tobytes()).digest(), np.uint64).copy()
+
+
+def run_halton(L, d):
+    out = {}
+    perms = halton_permutations(L)
+    out["hpc_out"] = np.array([len(perms)], np.uint64); out["hph_out"] = perms[:8192].copy(); out["hps_out"] = perm_digest(perms)
+    n = len(d["rad_bi"])
+    ro, ri = np.zeros((n, 2), np.float32), np.zeros((n, 4), np.uint64)
+    L.g_radical.restype = None
+    L.g_radical.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.g_radical(d["rad_bi"].ctypes.data, d["rad_a"].ctypes.data, n, ro.ctypes.data, ri.ctypes.data)
+    out["rad_out"], out["radi_out"] = ro, ri
+    n = len(d["hal_spp"])
+    ho, hm = np.zeros((n, 4, 34), np.float32), np.zeros((n, 12), np.uint64)
+    L.g_halton.restype = None
+    L.g_halton.argtypes = [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.g_halton(d["hal_spp"].ctypes.data, d["hal_bounds"].ctypes.data, d["hal_pixel"].ctypes.data, d["hal_center"].ctypes.data, d["hal_arrays"].ctypes.data, n, ho.ctypes.data, hm.ctypes.data)
+    out["hal_out"], out["halm_out"] = ho, hm
     return out
 
 

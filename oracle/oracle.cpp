@@ -544,6 +544,54 @@ void orc_geom_sobol(const rspt_sampler_tables* t, const int64_t* spp, const int3
         }
     }
 }
+// the radical inverses and the Halton sampler as the tile loop drives it (same layout as the reference text's g_radical / g_halton, oracle/make_geom_fixtures.py)
+void orc_geom_radical(const uint16_t* perms, const uint16_t* bi, const uint64_t* a, uint64_t n, float* out, uint64_t* iout) {
+    for (uint64_t i = 0; i < n; i++) {
+        out[2 * i] = radical_inverse((int)bi[i], a[i]);
+        out[2 * i + 1] = scrambled_radical_inverse((int)bi[i], a[i], perms + prime_tables().sums[bi[i]]);
+        iout[4 * i] = reverse_bits_32((uint32_t)a[i]); iout[4 * i + 1] = reverse_bits_64(a[i]);
+        iout[4 * i + 2] = inverse_radical_inverse(2, a[i] % 128, 7); iout[4 * i + 3] = inverse_radical_inverse(3, a[i] % 243, 5);
+    }
+}
+void orc_geom_halton(const uint16_t* perms, uint64_t n_perms, const int64_t* spp, const int32_t* bounds, const int32_t* pixel, const uint8_t* center, const int32_t* arrays, uint64_t n, float* out, uint64_t* meta) {
+    for (uint64_t i = 0; i < n; i++) {
+        rspt_render_desc rd{};
+        rd.sampler_kind = RSPT_SAMPLER_HALTON; rd.spp = spp[i]; rd.sample_at_pixel_center = center[i];
+        for (int k = 0; k < 4; k++) rd.sample_bounds[k] = bounds[4 * i + k];
+        rd.tables.halton_perms = perms; rd.tables.n_halton_perms = n_perms;
+        Sampler s(rd);
+        for (int k = 0; k < 2; k++) if (arrays[2 * i + k] > 0) s.request_2d_array(arrays[2 * i + k]);
+        uint64_t* mt = meta + 12 * i;
+        mt[0] = (uint64_t)s.halton.base_scales[0]; mt[1] = (uint64_t)s.halton.base_scales[1]; mt[2] = (uint64_t)s.halton.base_exponents[0]; mt[3] = (uint64_t)s.halton.base_exponents[1];
+        mt[4] = s.halton.sample_stride; mt[5] = s.halton.mult_inverse[0]; mt[6] = s.halton.mult_inverse[1]; mt[7] = 0;
+        const int32_t px = pixel[2 * i], py = pixel[2 * i + 1];
+        s.start_pixel(px, py);
+        for (int k = 0; k < 4; k++) {
+            float* o = out + (4 * i + k) * 34;
+            mt[8 + k] = s.halton.interval_sample_index;
+            const P2 f2 = s.get_2d();
+            o[0] = (Float)px + f2.x; o[1] = (Float)py + f2.y;   // sampler.rs:85-95
+            o[2] = s.get_1d();
+            const P2 lens = s.get_2d();
+            o[3] = lens.x; o[4] = lens.y;
+            for (int b = 0; b < 4; b++) {
+                o[5 + 5 * b] = s.get_1d();
+                const P2 u = s.get_2d(), w = s.get_2d();
+                o[6 + 5 * b] = u.x; o[7 + 5 * b] = u.y; o[8 + 5 * b] = w.x; o[9 + 5 * b] = w.y;
+            }
+            for (int a = 0; a < 2; a++) {
+                o[25 + 4 * a] = o[26 + 4 * a] = o[27 + 4 * a] = o[28 + 4 * a] = -1.0f;
+                const int32_t na = arrays[2 * i + a];
+                if (na <= 0 || k >= spp[i]) continue;
+                size_t idx; uint64_t start;
+                if (!s.get_2d_array(na, &idx, &start)) continue;
+                const P2 f = s.get_2d_sample(idx, start), l = s.get_2d_sample(idx, start + (uint64_t)na - 1);
+                o[25 + 4 * a] = f.x; o[26 + 4 * a] = f.y; o[27 + 4 * a] = l.x; o[28 + 4 * a] = l.y;
+            }
+            o[33] = s.start_next_sample() ? 1.0f : 0.0f;
+        }
+    }
+}
 void orc_geom_triangle_full(const float* tri, const float* nrm, const float* tan, const float* uvs, const int32_t* flags, const float* o, const float* d, const float* tmax, uint64_t n, float* out) {
     for (uint64_t i = 0; i < n; i++) {
         Scene sc{};

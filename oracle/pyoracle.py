@@ -331,6 +331,28 @@ def geom(d):
     spp, bounds, pixel = np.ascontiguousarray(d["sob_spp"], np.int64), np.ascontiguousarray(d["sob_bounds"], np.int32), np.ascontiguousarray(d["sob_pixel"], np.int32)
     L.orc_geom_sobol(C.addressof(tables), spp.ctypes.data, bounds.ctypes.data, pixel.ctypes.data, ns, so.ctypes.data)
     out["sob_out"] = so
+    # the Halton sampler: the digit permutations (all 1000 bases), the radical inverses, the sample stream
+    n_p = L.orc_halton_permutations(1000, None)
+    perms = np.zeros(n_p, np.uint16)
+    L.orc_halton_permutations(1000, perms.ctypes.data)
+    import hashlib
+    out["hpc_out"] = np.array([n_p], np.uint64); out["hph_out"] = perms[:8192].copy()
+    out["hps_out"] = np.frombuffer(hashlib.sha256(perms.astype("<u2").tobytes()).digest(), np.uint64).copy()
+    nr = len(d["rad_bi"])
+    ro, ri = np.zeros((nr, 2), np.float32), np.zeros((nr, 4), np.uint64)
+    bi, aa = np.ascontiguousarray(d["rad_bi"], np.uint16), np.ascontiguousarray(d["rad_a"], np.uint64)
+    L.orc_geom_radical.restype = None
+    L.orc_geom_radical.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.orc_geom_radical(perms.ctypes.data, bi.ctypes.data, aa.ctypes.data, nr, ro.ctypes.data, ri.ctypes.data)
+    out["rad_out"], out["radi_out"] = ro, ri
+    nh = len(d["hal_spp"])
+    ho, hm = np.zeros((nh, 4, 34), np.float32), np.zeros((nh, 12), np.uint64)
+    hs = [np.ascontiguousarray(d["hal_spp"], np.int64), np.ascontiguousarray(d["hal_bounds"], np.int32), np.ascontiguousarray(d["hal_pixel"], np.int32),
+          np.ascontiguousarray(d["hal_center"], np.uint8), np.ascontiguousarray(d["hal_arrays"], np.int32)]
+    L.orc_geom_halton.restype = None
+    L.orc_geom_halton.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.orc_geom_halton(perms.ctypes.data, n_p, *[x.ctypes.data for x in hs], nh, ho.ctypes.data, hm.ctypes.data)
+    out["hal_out"], out["halm_out"] = ho, hm
     out["trp_out"] = out["tri_out"]      # Triangle::intersect_p repeats intersect's watertight test (triangle.rs:450-591); the oracle shares one function
     ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
     L.orc_geom_rng.restype = None

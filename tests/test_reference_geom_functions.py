@@ -28,7 +28,12 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "mor_out": "morton2 / part1_by1 (the tile order of BlockQueue)",
          "dif_out": "SurfaceInteraction::compute_differentials over solve_linear_system_2x2",
          "al_out": "DiffuseAreaLight::sample_li / l over Triangle::sample / sample_with_ref_point",
-         "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample"}
+         "sob_out": "SobolSampler start_pixel / get_camera_sample / get_1d / get_2d / start_next_sample over sobol_interval_to_index, sobol_sample",
+         "hpc_out": "compute_radical_inverse_permutations (entry count)", "hph_out": "compute_radical_inverse_permutations over shuffle and Rng (first 8192 entries)",
+         "hps_out": "compute_radical_inverse_permutations (SHA-256 of all 3 682 913 entries)",
+         "rad_out": "radical_inverse / scrambled_radical_inverse over all 1000 prime bases", "radi_out": "reverse_bits_32 / reverse_bits_64 / inverse_radical_inverse",
+         "halm_out": "HaltonSampler::new (base scales / exponents, stride, multiplicative inverses over extended_gcd, mod_t) and get_index_for_sample per pixel sample",
+         "hal_out": "HaltonSampler start_pixel / get_camera_sample / get_1d / get_2d / request_2d_array / get_2d_array_idxs / get_2d_sample / start_next_sample"}
 
 
 def differing(a, b):
@@ -70,6 +75,13 @@ def test_oracle_equals_the_references_text_on_the_committed_fixture(oracle):
     sob = g["sob_out"]
     assert ((sob[:, :, 0] >= g["sob_pixel"][:, None, 0]) & (sob[:, :, 0] < g["sob_pixel"][:, None, 0] + 1)).all()     # the film sample lies in its pixel (the remap of dimensions 0 / 1)
     assert (sob[:, :, 25] == 0).any() and (sob[:, :, 25] == 1).any() and (g["sob_bounds"][:, :2] != 0).any()           # the last sample of a pixel; cropped sample bounds
+    hal, meta = g["hal_out"], g["halm_out"]
+    free = g["hal_center"] == 0
+    assert ((hal[free, :, 0] >= g["hal_pixel"][free, None, 0]) & (hal[free, :, 0] < g["hal_pixel"][free, None, 0] + 1)).all()       # the pixel's Halton offset puts the film sample in its pixel
+    assert (hal[~free, :, 0] == g["hal_pixel"][~free, None, 0] + 0.5).all() and (~free).sum() > 100                                    # samplepixelcenter
+    assert (meta[:, 0] == 128).any() and (meta[:, 1] == 243).any() and (meta[:, 4] == 1).any() and (g["hal_pixel"] < 0).any()          # saturated base scales (K_MAX_RESOLUTION), a 1 x 1 frame (stride 1), mod_t of a negative pixel
+    assert (hal[:, 0, 25] >= 0).sum() > 500 and (hal[:, 0, 29] >= 0).sum() > 300 and (hal[:, :, 25:33] == -1).any()                   # one and two requested arrays, and none
+    assert (g["rad_bi"] == 0).any() and (g["rad_bi"] == 999).any() and int(g["hpc_out"][0]) == 3682913                                # base 2 by bit reversal, the last base, the sum of the first 1000 primes
 
 
 def oracle_traversal(oracle, sc, o, d, tmax):
@@ -118,10 +130,11 @@ def test_committed_fixture_is_what_the_references_text_gives():
 def test_oracle_equals_the_compiled_reference_text_on_131072_fresh_cases_per_function(oracle):
     mk = generator()
     L, where = mk.convert()
-    assert len(where) == 18 + len(mk.SOURCES)
+    assert len(where) == 18 + 2 + len(mk.SOURCES)      # (the base batch, the two prime tables, this batch)
     lines = dict(w.rsplit(" ", 1) for w in where)
     assert lines["Bounds3f::intersect_p"] == "core/geometry.rs:2211-2268" and lines["Triangle::intersect"] == "shapes/triangle.rs:134-273"
     assert lines["BVHAccel::intersect"] == "accelerators/bvh.rs:401-462" and lines["BVHAccel::intersect_p"] == "accelerators/bvh.rs:463-514"
+    assert lines["radical_inverse"] == "core/lowdiscrepancy.rs:1126-2162" and lines["HaltonSampler::get_index_for_sample"] == "samplers/halton.rs:173-214" and lines["PRIMES"] == "core/lowdiscrepancy.rs:20-82"
     d = mk.inputs(n=1 << 17, seed=0x5EED7)
     ref = mk.run_reference(L, d)
     got = oracle.geom(d)
