@@ -42,6 +42,7 @@ FIXTURE = os.path.join(ROOT, "tests", "golden", "geom_functions.npz")
 # ---- carriers added to the base prelude (no arithmetic: selectors, bit casts, constants) ----
 FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                             // `n as Float` from usize / u64
     Float(uint16_t x) : v((float)x) {}                           // `base as Float` from u16
+    Float(int64_t x) : v((float)x) {}                            // `samples_per_pixel as Float` from i64
     explicit operator size_t() const { return (size_t)v; }       // `x as usize` (only met with small non-negative values here)
     explicit operator double() const { return (double)v; }      // `x as f64`
     Float ln() const { return Float(logf(v)); }                  // f32::ln is the platform libm's logf
@@ -134,6 +135,7 @@ static const uint64_t PCG32_DEFAULT_STATE = 0x853c49e6748fea9bull, PCG32_DEFAULT
 struct Rng {
     uint64_t state = PCG32_DEFAULT_STATE, inc = PCG32_DEFAULT_STREAM;
     void set_sequence(uint64_t initseq); uint32_t uniform_uint32(); uint32_t uniform_uint32_bounded(uint32_t b); Float uniform_float();
+    static Rng default_() { Rng r; r.state = 0; r.inc = 0; return r; }      // #[derive(Default)] (rng.rs:20): zeros, NOT Rng::new()'s constants
 };
 // the traversal's carriers (BVHAccel::intersect / intersect_p, bvh.rs:401-514): the containers index, the SurfaceInteraction keeps what a hit record of rspt_trace holds
 struct SurfaceInteraction { uint32_t prim; Float t, b0, b1, b2; };
@@ -168,6 +170,9 @@ static inline int32_t rs_leading_zeros(uint32_t v) { return v == 0 ? 32 : __buil
 static inline int32_t rs_max(int32_t a, int32_t b) { return a > b ? a : b; }                                   // Ord::max on i32
 template <class T> struct Vec : std::vector<T> { size_t len() const { return this->size(); } void push(const T& v) { this->push_back(v); } static Vec filled(size_t n) { Vec r; r.resize(n); return r; } };
 struct CameraSample { Point2f p_film; Float time; Point2f p_lens; };
+template <class T> struct MutSlice { T* p; MutSlice(T* q) : p(q) {} MutSlice(Vec<T>& v) : p(v.data()) {} T& operator[](size_t i) const { return p[i]; } MutSlice from(size_t k) const { return MutSlice(p + k); } };   // `&mut [T]`, `&mut s[k..]`
+template <class T> MutSlice<T> mut_slice(Vec<T>& v) { return MutSlice<T>(v); }
+template <class T> MutSlice<T> mut_slice(MutSlice<T> v) { return v; }
 int32_t round_up_pow2_32(int32_t v); int32_t log_2_int_u32(uint32_t v);
 uint64_t sobol_interval_to_index(uint32_t m, uint64_t frame, Point2i p); Float sobol_sample(int64_t index, int32_t dimension, uint64_t scramble);
 struct SobolSampler {
@@ -199,7 +204,7 @@ static Vec<uint16_t> RADICAL_INVERSE_PERMUTATIONS;     // lazy_static (halton.rs
 static inline int32_t rs_min(int32_t a, int32_t b) { return a < b ? a : b; }                                   // Ord::min on i32
 uint32_t reverse_bits_32(uint32_t n); uint64_t reverse_bits_64(uint64_t n); uint64_t inverse_radical_inverse(uint8_t base, uint64_t inverse, uint64_t n_digits);
 Float radical_inverse(uint16_t base_index, uint64_t a); Float scrambled_radical_inverse(uint16_t base_index, uint64_t a, const uint16_t* perm);
-void shuffle(uint16_t* samp, int32_t count, int32_t n_dimensions, Rng& rng); Vec<uint16_t> compute_radical_inverse_permutations(Rng& rng);
+Vec<uint16_t> compute_radical_inverse_permutations(Rng& rng);
 template <class T> T mod_t(T a, T b);
 uint64_t multiplicative_inverse(int64_t a, int64_t n); void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y);
 struct HaltonSampler {                                 // halton.rs:54-78, the fields in their declared order (the literal of HaltonSampler::new names them in this order)
@@ -215,6 +220,31 @@ struct HaltonSampler {                                 // halton.rs:54-78, the f
     std::tuple<bool, size_t, size_t> get_2d_array_idxs(int32_t n); bool start_next_sample(); bool set_sample_number(int64_t sample_num);
     CameraSample get_camera_sample(Point2i p_raster);      // Sampler::get_camera_sample (sampler.rs:85-95); the enum's Halton arm forwards get_1d / get_2d
 };
+// the pixel samplers' carriers (samplers/{zerotwosequence,maxmin,stratified,random}.rs): the fields in their declared order; C_MAX_MIN_DIST comes from the reference's text below
+static inline int32_t rs_leading_zeros(uint64_t v) { return v == 0 ? 64 : __builtin_clzll(v); }                        // u64::leading_zeros
+static inline uint32_t rs_trailing_zeros(size_t v) { return v == 0 ? 64 : (uint32_t)__builtin_ctzll(v); }     // usize::trailing_zeros
+template <class T> void shuffle(MutSlice<T> samp, int32_t count, int32_t n_dimensions, Rng& rng);
+template <class T> bool is_power_of_2(T v);
+int64_t log_2_int_u64(uint64_t v); int64_t log_2_int_i64(int64_t v); int64_t round_up_pow2_64(int64_t v);
+uint32_t multiply_generator(const uint32_t* c, uint32_t a); Float sample_generator_matrix(const uint32_t* c, uint32_t a, uint32_t scramble);
+void gray_code_sample_1d(const uint32_t* c, uint32_t n, uint32_t scramble, MutSlice<Float> p); void gray_code_sample_2d(const uint32_t* c0, const uint32_t* c1, uint32_t n, Point2i scramble, MutSlice<Point2f> p);
+void van_der_corput(int32_t n_samples_per_pixel_sample, int32_t n_pixel_samples, MutSlice<Float> samples, Rng& rng); void sobol_2d(int32_t n_samples_per_pixel_sample, int32_t n_pixel_samples, MutSlice<Point2f> samples, Rng& rng);
+void stratified_sample_1d(MutSlice<Float> samp, int32_t n_samples, Rng& rng, bool jitter); void stratified_sample_2d(MutSlice<Point2f> samp, int32_t nx, int32_t ny, Rng& rng, bool jitter);
+void latin_hypercube(MutSlice<Point2f> samples, uint32_t n_samples, Rng& rng);
+#define PIXEL_SAMPLER_TAIL \
+    Point2i current_pixel; int64_t current_pixel_sample_index; Vec<int32_t> samples_1d_array_sizes, samples_2d_array_sizes; Vec<Vec<Float>> sample_array_1d; Vec<Vec<Point2f>> sample_array_2d; \
+    size_t array_1d_offset, array_2d_offset; \
+    void start_pixel(Point2i p); Float get_1d(); Point2f get_2d(); Point2f get_2d_sample(size_t array_idx, size_t idx) const; void request_2d_array(int32_t n); int32_t round_count(int32_t count) const; \
+    std::tuple<bool, size_t, size_t> get_2d_array_idxs(int32_t n); bool start_next_sample(); void reseed(uint64_t seed); CameraSample get_camera_sample(Point2i p_raster);
+#define PIXEL_SAMPLER_VECTORS Vec<Vec<Float>> samples_1d; Vec<Vec<Point2f>> samples_2d; int32_t current_1d_dimension, current_2d_dimension; Rng rng;
+struct ZeroTwoSequenceSampler { int64_t samples_per_pixel, n_sampled_dimensions; PIXEL_SAMPLER_VECTORS PIXEL_SAMPLER_TAIL          // zerotwosequence.rs:12-31
+    static ZeroTwoSequenceSampler new_(int64_t samples_per_pixel, int64_t n_sampled_dimensions); };
+struct MaxMinDistSampler { int64_t samples_per_pixel; const uint32_t* c_pixel; PIXEL_SAMPLER_VECTORS PIXEL_SAMPLER_TAIL                 // maxmin.rs:14-33 (c_pixel: the row of C_MAX_MIN_DIST, not a copy)
+    static MaxMinDistSampler new_(int64_t samples_per_pixel, int64_t n_sampled_dimensions); };
+struct StratifiedSampler { int64_t samples_per_pixel; int32_t x_pixel_samples, y_pixel_samples; bool jitter_samples; PIXEL_SAMPLER_VECTORS PIXEL_SAMPLER_TAIL   // stratified.rs:9-30
+    static StratifiedSampler new_(int32_t x_pixel_samples, int32_t y_pixel_samples, bool jitter_samples, int64_t n_sampled_dimensions); };
+struct RandomSampler { int64_t samples_per_pixel; Rng rng; PIXEL_SAMPLER_TAIL                                                          // random.rs:10-22
+    static RandomSampler new_(int64_t samples_per_pixel); };
 // the film's carriers (core/film.rs)
 static const size_t FILTER_TABLE_WIDTH = 16;                                                          // film.rs:22
 struct Bounds2f { Point2f p_min, p_max; };
@@ -264,7 +294,8 @@ TYPES.update({"i64": "int64_t", "i32": "int32_t", "u64": "uint64_t", "usize": "s
               "InteractionCommon": "InteractionCommon", "&InteractionCommon": "const InteractionCommon&", "&mut InteractionCommon": "InteractionCommon&",
               "&mut VisibilityTester": "VisibilityTester&", "&mut Float": "Float*",
               "Point2i": "Point2i", "&Point2i": "const Point2i&", "Vector2i": "Vector2i", "CameraSample": "CameraSample", "XYEnum": "XYEnum", "&Point2f": "const Point2f&",
-              "u16": "uint16_t", "&[u16]": "const uint16_t*", "&mut [u16]": "uint16_t*", "&mut Rng": "Rng&", "Vec<u16>": "Vec<uint16_t>", "&mut i64": "int64_t*", "Tuple3": "std::tuple<bool, size_t, size_t>", "T": "T"})
+              "u16": "uint16_t", "&[u16]": "const uint16_t*", "&mut [u16]": "uint16_t*", "&mut Rng": "Rng&", "Vec<u16>": "Vec<uint16_t>", "&mut i64": "int64_t*", "Tuple3": "std::tuple<bool, size_t, size_t>", "T": "T",
+              "&mut [Float]": "MutSlice<Float>", "&mut [Point2f]": "MutSlice<Point2f>", "[u32; 32]": "const uint32_t*", "&[u32]": "const uint32_t*"})
 
 # (file, search-from regex or None, first-line regex, name, class or None, cut-before regex or None, explicit signature or None, appended epilogue or None, extra rule set)
 TRI_SIG = "bool Triangle::%s(const Ray& ray, Float* t_out, Float* b_out) const {\n"
@@ -381,7 +412,7 @@ SOURCES = [
     ("core/lowdiscrepancy.rs", None, r"^fn scrambled_radical_inverse_specialized\(", "scrambled_radical_inverse_specialized", None, None, None, None, ("int", "halton")),
     ("core/lowdiscrepancy.rs", None, r"^pub fn radical_inverse\(", "radical_inverse", None, None, None, MATCH_END, ("int", "halton")),
     ("core/lowdiscrepancy.rs", None, r"^pub fn scrambled_radical_inverse\(", "scrambled_radical_inverse", None, None, None, MATCH_END, ("int", "halton")),
-    ("core/sampling.rs", None, r"^pub fn shuffle<T>\(", "shuffle", None, None, None, None, ("int", "halton")),
+    ("core/sampling.rs", None, r"^pub fn shuffle<T>\(", "shuffle", None, None, "template <class T> void shuffle(MutSlice<T> samp, int32_t count, int32_t n_dimensions, Rng& rng) {\n", None, ("int", "halton")),
     ("core/lowdiscrepancy.rs", None, r"^pub fn compute_radical_inverse_permutations\(", "compute_radical_inverse_permutations", None, None, None, None, ("int", "halton")),
     ("core/pbrt.rs", None, r"^pub fn mod_t<T>\(", "mod_t", None, None, "template <class T> T mod_t(T a, T b) {\n", None, ("int", "halton")),
     ("samplers/halton.rs", None, r"^fn extended_gcd\(", "extended_gcd", None, None, None, None, ("int", "halton")),
@@ -400,6 +431,64 @@ SOURCES = [
     ("samplers/halton.rs", None, r"^    pub fn start_next_sample\(&mut self", "start_next_sample", "HaltonSampler", None, None, None, ("int", "halton")),
     ("samplers/halton.rs", None, r"^    pub fn set_sample_number\(&mut self", "set_sample_number", "HaltonSampler", None, None, None, ("int", "halton")),
     ("core/sampler.rs", None, r"^    pub fn get_camera_sample\(&mut self", "get_camera_sample", "HaltonSampler", None, None, None, ("int",)),
+    # the pixel samplers: (0,2)-sequence, max-min distance, stratified, random; their helpers
+    ("core/pbrt.rs", None, r"^pub fn log_2_int_u64\(", "log_2_int_u64", None, None, None, None, ("int", "halton", "pix")),
+    ("core/pbrt.rs", None, r"^pub fn log_2_int_i64\(", "log_2_int_i64", None, None, None, None, ("int", "halton", "pix")),
+    ("core/pbrt.rs", None, r"^pub fn is_power_of_2<T>\(", "is_power_of_2", None, None, "template <class T> bool is_power_of_2(T v) {\n", None, ("int", "halton", "pix")),
+    ("core/pbrt.rs", None, r"^pub fn round_up_pow2_64\(", "round_up_pow2_64", None, None, None, None, ("int", "halton", "pix")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn multiply_generator\(", "multiply_generator", None, None, None, None, ("int", "halton", "pix")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn sample_generator_matrix\(", "sample_generator_matrix", None, None, None, None, ("int", "halton", "pix")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn gray_code_sample_1d\(", "gray_code_sample_1d", None, None, None, None, ("int", "halton", "pix")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn gray_code_sample_2d\(", "gray_code_sample_2d", None, None, None, None, ("int", "halton", "pix")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn van_der_corput\($", "van_der_corput", None, None, None, None, ("int", "halton", "pix", "morton")),
+    ("core/lowdiscrepancy.rs", None, r"^pub fn sobol_2d\($", "sobol_2d", None, None, None, None, ("int", "halton", "pix", "morton")),
+    ("core/sampling.rs", None, r"^pub fn stratified_sample_1d\(", "stratified_sample_1d", None, None, None, None, ("int", "halton", "pix")),
+    ("core/sampling.rs", None, r"^pub fn stratified_sample_2d\(", "stratified_sample_2d", None, None, None, None, ("int", "halton", "pix")),
+    ("core/sampling.rs", None, r"^pub fn latin_hypercube\(", "latin_hypercube", None, None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", r"^impl ZeroTwoSequenceSampler \{", r"^    pub fn new\(", "new_", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn start_pixel\(&mut self", "start_pixel", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn get_1d\(&mut self", "get_1d", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn get_2d\(&mut self", "get_2d", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn get_2d_sample\(&self", "get_2d_sample", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn request_2d_array\(&mut self", "request_2d_array", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn round_count\(&self", "round_count", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn get_2d_array_idxs\(&mut self", "get_2d_array_idxs", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn start_next_sample\(&mut self", "start_next_sample", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/zerotwosequence.rs", None, r"^    pub fn reseed\(&mut self", "reseed", "ZeroTwoSequenceSampler", None, None, None, ("int", "halton", "pix")),
+    ("core/sampler.rs", None, r"^    pub fn get_camera_sample\(&mut self", "get_camera_sample", "ZeroTwoSequenceSampler", None, None, None, ("int",)),
+    ("samplers/maxmin.rs", r"^impl MaxMinDistSampler \{", r"^    pub fn new\(", "new_", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn start_pixel\(&mut self", "start_pixel", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn get_1d\(&mut self", "get_1d", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn get_2d\(&mut self", "get_2d", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn get_2d_sample\(&self", "get_2d_sample", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn request_2d_array\(&mut self", "request_2d_array", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn round_count\(&self", "round_count", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn get_2d_array_idxs\(&mut self", "get_2d_array_idxs", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn start_next_sample\(&mut self", "start_next_sample", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/maxmin.rs", None, r"^    pub fn reseed\(&mut self", "reseed", "MaxMinDistSampler", None, None, None, ("int", "halton", "pix")),
+    ("core/sampler.rs", None, r"^    pub fn get_camera_sample\(&mut self", "get_camera_sample", "MaxMinDistSampler", None, None, None, ("int",)),
+    ("samplers/stratified.rs", r"^impl StratifiedSampler \{", r"^    pub fn new\(", "new_", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn start_pixel\(&mut self", "start_pixel", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn get_1d\(&mut self", "get_1d", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn get_2d\(&mut self", "get_2d", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn get_2d_sample\(&self", "get_2d_sample", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn request_2d_array\(&mut self", "request_2d_array", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn round_count\(&self", "round_count", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn get_2d_array_idxs\(&mut self", "get_2d_array_idxs", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn start_next_sample\(&mut self", "start_next_sample", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/stratified.rs", None, r"^    pub fn reseed\(&mut self", "reseed", "StratifiedSampler", None, None, None, ("int", "halton", "pix")),
+    ("core/sampler.rs", None, r"^    pub fn get_camera_sample\(&mut self", "get_camera_sample", "StratifiedSampler", None, None, None, ("int",)),
+    ("samplers/random.rs", r"^impl RandomSampler \{", r"^    pub fn new\(", "new_", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn start_pixel\(&mut self", "start_pixel", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn get_1d\(&mut self", "get_1d", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn get_2d\(&mut self", "get_2d", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn get_2d_sample\(&self", "get_2d_sample", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn request_2d_array\(&mut self", "request_2d_array", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn round_count\(&self", "round_count", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn get_2d_array_idxs\(&mut self", "get_2d_array_idxs", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn start_next_sample\(&mut self", "start_next_sample", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("samplers/random.rs", None, r"^    pub fn reseed\(&mut self", "reseed", "RandomSampler", None, None, None, ("int", "halton", "pix")),
+    ("core/sampler.rs", None, r"^    pub fn get_camera_sample\(&mut self", "get_camera_sample", "RandomSampler", None, None, None, ("int",)),
     ("core/geometry.rs", None, r"^impl_op_ex!\(\+\|a: &Point2f, b: &Vector2f\| -> Point2f \{", "operator+", None, None, None, None, ("int",)),
     ("core/geometry.rs", None, r"^impl_op_ex!\(\+\|a: &Point2i, b: &Point2i\| -> Point2i \{", "operator+", None, None, None, None, ("int",)),
     ("core/geometry.rs", r"^impl Bounds2i \{", r"^    pub fn area\(&self\) -> i32 \{", "area", "Bounds2i", None, None, None, ("int",)),
@@ -633,7 +722,7 @@ RULES_HALTON = [
     (r"samp\.swap\(\s*(.*?),\s*(.*?),?\s*\);", r"std::swap(samp[\1], samp[\2]);", re.S),
     # G32 vectors and slices:  `vec![v; n]` (v is the type's zero in both uses);  `&mut perms[p..(p + n)]` -> the pointer to element p;  `&TABLE[k..]` -> the pointer to element k;  `Vec::new()`
     (r"let (?:mut )?(\w+): Vec<(\w+)> = vec!\[(?:0_u16|Point2f::default\(\)); (\w+)\];", lambda m: "Vec<%s> %s = Vec<%s>::filled(%s);" % (TYPES[m.group(2)], m.group(1), TYPES[m.group(2)], m.group(3)), 0),
-    (r"&mut perms\[p\.\.\(p \+ PRIMES\[i as usize\] as usize\)\]", "perms.data() + p", 0),
+    (r"&mut perms\[p\.\.\(p \+ PRIMES\[i as usize\] as usize\)\]", "MutSlice<uint16_t>(perms.data() + p)", 0),
     (r"^(\s*)&(\w+)\[(.*)\.\.\]$", r"\1&\2[\3]", re.M),
     (r"Vec::new\(\)", "{}", 0),
     (r"\b(\d+)_u16\b", r"(uint16_t)\1", 0),
@@ -650,6 +739,32 @@ RULES_HALTON = [
     # G35 tuples:  `return (a, b, c);` and a tail `(a, b, c)`
     (r"return \((\w+), (\w+), (\w+)\);", r"return std::make_tuple(\1, \2, \3);", 0),
     (r"^(\s*)\((\w+), (\w+), (\w+)\)$", r"\1std::make_tuple(\2, \3, \4)", re.M),
+]
+RULES_PIX = [
+    # G37 mutable slices: `for s in &mut self.v {` (each element as a slice); `let s: &mut [T] = E.as_mut_slice();`; `&mut E[(k)..]` -> the slice from k; `&mut s[..]` -> s; the generator's borrow
+    (r"for (\w+) in &mut ([\w.>\-]+) \{", r"for (auto& \1__v : \2) { auto \1 = mut_slice(\1__v);", 0),
+    (r"let (\w+): &mut \[\w+\] =\s*(.*?)\.as_mut_slice\(\);", r"auto \1 = mut_slice(\2);", 0),
+    (r"let (\w+): &mut \[\w+\] =\s*&mut ([\w.>\-\[\]]+)\[\((.*?)\)\.\.\];", r"auto \1 = mut_slice(\2).from(\3);", 0),
+    (r"&mut ([\w.>\-\[\]]+)\[\((.*?)\)\.\.\]", r"mut_slice(\1).from(\2)", 0),
+    (r"&mut (\w+)\[\.\.\]", r"\1", 0),
+    (r"&mut this->rng\b", "this->rng", 0),
+    # G38 generator matrices: `[u32; 32]` / `[[u32; 32]; 2]` literals (hex digits keep their value: G25), `[u32; 2]`; `(i + 1).trailing_zeros()`; `loop {`; `a & 1 != 0`
+    (r"(0x[0-9a-fA-F_]+?)_u32\b", r"\1", 0),
+    (r"let (\w+): \[u32; 32\] = \[(.*?)\];", r"const uint32_t \1[32] = {\2};", re.S),
+    (r"let (\w+): \[\[u32; 32\]; 2\] = \[\n(.*?)\n    \];", lambda m: "const uint32_t %s[2][32] = {\n%s\n    };" % (m.group(1), m.group(2).replace("[", "{").replace("]", "}")), re.S),
+    (r"let mut (\w+): \[u32; 2\] = \[(.*?)\];", r"uint32_t \1[2] = {\2};", 0),
+    (r"\((\w+ \+ 1)\)\.trailing_zeros\(\)", r"rs_trailing_zeros(\1)", 0),
+    (r"^(\s*)loop \{$", r"\1for (;;) {", re.M),
+    (r"\b(\w+) & (\w+) != 0", r"((\1 & \2) != 0)", 0),
+    (r"num::One::one\(\)", "T(1)", 0),
+    # G39 the samplers' literals (G34's rule for any `…Sampler { .. }`, with or without a binding); vectors of zeros; ranges from 1; `Point2i { x, y }`
+    (r"^(\s*)(?:let mut (\w+)(?:: \w+)? = )?(\w+Sampler) \{\n(.*?)\n\s*\}(;?)$", lambda m: m.group(1) + (("%s %s = " % (m.group(3), m.group(2))) if m.group(2) else "") + m.group(3) + "{" + ", ".join(
+        (".%s = %s" % (f.split(":", 1)[0].strip(), f.split(":", 1)[1].strip()) if ":" in f.replace("::", "") else ".%s = %s" % (f, f))
+        for f in [re.sub(r"\s*//.*$", "", l).strip().rstrip(",") for l in m.group(4).split("\n")] if f) + "}" + m.group(5), re.M | re.S),
+    (r"let (\w+): Vec<(\w+)> =\s*vec!\[(?:0\.0|Point2f::default\(\)); (.*?)\];", lambda m: "Vec<%s> %s = Vec<%s>::filled(%s);" % (TYPES[m.group(2)], m.group(1), TYPES[m.group(2)], m.group(3)), 0),
+    (r"for (\w+) in 1\.\.([^{]+?) \{", r"for (size_t \1 = 1; \1 < \2; \1++) {", 0),
+    (r"for (\w+) in 0\.\.([\w.>\-]+) as usize \{", r"for (size_t \1 = 0; \1 < (size_t)(\2); \1++) {", 0),
+    (r"\bPoint2i \{ x, y \}", "Point2i{x, y}", 0),
 ]
 RULES_RNG = [
     # G11 wrapping integer arithmetic (rng.rs):  `let (x, _overflow) = A.overflowing_OP(B);`  — C++ unsigned arithmetic wraps; Rust's overflowing shifts mask the count
@@ -775,11 +890,18 @@ def _convert_parts():
         l0 = text.count("\n", 0, mo.start()) + 1
         tables.append("// %score/lowdiscrepancy.rs:%d-%d\nstatic const uint32_t %s[PRIME_TABLE_SIZE] = {\n%s\n};\n" % (REF, l0, l0 + mo.group(0).count("\n"), nm, re.sub(r"(?<=\d)_(?=\d)", "", re.sub(r"^\s*//.*$", "", mo.group(1), flags=re.M))))      # (digit separators: the base's R3)
         where.append("%s core/lowdiscrepancy.rs:%d-%d" % (nm, l0, l0 + mo.group(0).count("\n")))
+    text = open(REF + "core/lowdiscrepancy.rs").read()      # G36b: `pub const C_MAX_MIN_DIST: [[u32; 32]; 17] = [ [ .. ], .. ];` -> the same words as a C array of rows
+    mo = re.search(r"^pub const C_MAX_MIN_DIST: \[\[u32; 32\]; 17\] = \[\n(.*?)\n\];$", text, re.M | re.S)
+    l0 = text.count("\n", 0, mo.start()) + 1
+    rows = re.sub(r"0x[0-9a-fA-F_]+", lambda m: m.group(0).replace("_", "") + "u", re.sub(r"^\s*//.*$", "", mo.group(1), flags=re.M)).replace("[", "{").replace("]", "}")
+    tables.append("// %score/lowdiscrepancy.rs:%d-%d\nstatic const uint32_t C_MAX_MIN_DIST[17][32] = {\n%s\n};\n" % (REF, l0, l0 + mo.group(0).count("\n"), rows))
+    where.append("C_MAX_MIN_DIST core/lowdiscrepancy.rs:%d-%d" % (l0, l0 + mo.group(0).count("\n")))
     parts = [pre, PRELUDE2] + tables + parts[1:]
     base.TYPES.update(TYPES)          # (the base's declaration rule R11 looks types up in its own table; the base functions are already converted)
     TYPES["MinMaxEnum"] = base.TYPES["MinMaxEnum"] = "MinMaxEnum"
     for fname, after_re, first_re, name, cls, cut_re, sig_override, epilogue, extra in SOURCES:
         text, l0, l1 = extract(fname, after_re, first_re, cut_re)
+        TYPES["Self"] = cls or "FilmTile"      # (`-> Self` of a constructor)
         if text.startswith("impl_op_ex!"):
             mo = re.match(r"impl_op_ex!\((.)\|(.*?)\| -> (\w+) \{\n", text)
             args = [x.strip().split(":") for x in mo.group(2).split(",")]
@@ -795,7 +917,7 @@ def _convert_parts():
         if "full" in extra and name == "intersect_full":
             i0 = body.index("if let Some(alpha_mask) = &self.mesh.alpha_mask {") if "if let Some(alpha_mask) = &self.mesh.alpha_mask {" in body else body.index("if let Some(alpha_mask) = &this->mesh.alpha_mask {")
             body = body[:body.rfind("\n", 0, i0)] + body[matching(body, body.index("{", i0), "{", "}") + 1:]      # G22: the alpha-mask block (triangle.rs:313-331) is dropped
-        for pat, rep, flags in (RULES_HALTON if "halton" in extra else []) + (RULES_DIFF if "diff" in extra else []) + (RULES_MORTON if "morton" in extra else []) + (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
+        for pat, rep, flags in (RULES_PIX if "pix" in extra else []) + (RULES_HALTON if "halton" in extra else []) + (RULES_DIFF if "diff" in extra else []) + (RULES_MORTON if "morton" in extra else []) + (RULES_FILM if "film" in extra else []) + (RULES_FULL if "full" in extra else []) + (RULES_INT if "int" in extra else []) + (RULES_LIGHT if "light" in extra else []) + RULES_PRE + (RULES_RNG if "rng" in extra else []):
             body = re.sub(pat, rep, body, flags=flags)
         body = cast_after_parens(body, "Float", "Float(%s)")
         body = cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -818,7 +940,7 @@ def _convert_parts():
         body = base.shadowing(body, set(params) | set(FN_NAMES))
         if epilogue:
             body = (body.rstrip() if cut_re else body.rstrip()[:-1].rstrip()) + "\n" + epilogue      # (an uncut text still ends with its closing brace)
-        elif not sig.startswith("void"):
+        elif not (sig.startswith("void") or " void " in sig.split("(")[0]):
             body = tail_value(body)
         parts.append("// %s%s:%d-%d\n%s%s" % (REF, fname, l0, l1, sig, body))
         where.append("%s%s %s:%d-%d" % ((cls + "::") if cls else "", name, fname, l0, l1))
@@ -1057,6 +1179,49 @@ void g_halton(const int64_t* spp, const int32_t* bounds, const int32_t* pixel, c
         }
     }
 }
+// the pixel samplers under the same loop (integrator.rs:134-175 with clone_with_seed's reseed): kind 0 (0,2)-sequence, 1 max-min distance, 2 stratified, 3 random.
+// par: n x 6 (spp, n_sampled_dimensions, x samples, y samples, jitter, -); out: n x 4 samples x 34 as g_halton (samples past spp stay zero); meta: n x 2 (spp after `new`, round_count(3))
+}      // extern "C" (a template cannot have C linkage)
+template <class S> static void pixel_case(S s, uint64_t seed, const int32_t* pixel, const int32_t* arrays, float* out, uint64_t* meta) {
+    for (int k = 0; k < 2; k++) if (arrays[k] > 0) s.request_2d_array(arrays[k]);
+    meta[0] = (uint64_t)s.samples_per_pixel; meta[1] = (uint64_t)s.round_count(3);
+    s.reseed(seed);
+    const Point2i p{pixel[0], pixel[1]};
+    s.start_pixel(p);
+    for (int k = 0; k < 4 && k < s.samples_per_pixel; k++) {
+        float* o = out + k * 34;
+        const CameraSample cs = s.get_camera_sample(p);
+        o[0] = cs.p_film.x.v; o[1] = cs.p_film.y.v; o[2] = cs.time.v; o[3] = cs.p_lens.x.v; o[4] = cs.p_lens.y.v;
+        for (int b = 0; b < 4; b++) {
+            o[5 + 5 * b] = s.get_1d().v;
+            const Point2f u = s.get_2d(), w = s.get_2d();
+            o[6 + 5 * b] = u.x.v; o[7 + 5 * b] = u.y.v; o[8 + 5 * b] = w.x.v; o[9 + 5 * b] = w.y.v;
+        }
+        for (int a = 0; a < 2; a++) {
+            o[25 + 4 * a] = o[26 + 4 * a] = o[27 + 4 * a] = o[28 + 4 * a] = -1.0f;
+            const int32_t na = arrays[a];
+            if (na <= 0) continue;
+            const std::tuple<bool, size_t, size_t> ix = s.get_2d_array_idxs(na);
+            if (std::get<0>(ix)) continue;
+            const Point2f f = s.get_2d_sample(std::get<1>(ix), std::get<2>(ix)), l = s.get_2d_sample(std::get<1>(ix), std::get<2>(ix) + (size_t)na - 1);
+            o[25 + 4 * a] = f.x.v; o[26 + 4 * a] = f.y.v; o[27 + 4 * a] = l.x.v; o[28 + 4 * a] = l.y.v;
+        }
+        o[33] = s.start_next_sample() ? 1.0f : 0.0f;
+    }
+}
+extern "C" {
+void g_pixel(const int32_t* kind, const int64_t* par, const uint64_t* seed, const int32_t* pixel, const int32_t* arrays, uint64_t n, float* out, uint64_t* meta) {
+    for (uint64_t i = 0; i < n; i++) {
+        const int64_t* q = par + 6 * i;
+        float* o = out + i * 4 * 34; uint64_t* mt = meta + 2 * i;
+        switch (kind[i]) {
+            case 0: pixel_case(ZeroTwoSequenceSampler::new_(q[0], q[1]), seed[i], pixel + 2 * i, arrays + 2 * i, o, mt); break;
+            case 1: pixel_case(MaxMinDistSampler::new_(q[0], q[1]), seed[i], pixel + 2 * i, arrays + 2 * i, o, mt); break;
+            case 2: pixel_case(StratifiedSampler::new_((int32_t)q[2], (int32_t)q[3], q[4] != 0, q[1]), seed[i], pixel + 2 * i, arrays + 2 * i, o, mt); break;
+            default: pixel_case(RandomSampler::new_(q[0]), seed[i], pixel + 2 * i, arrays + 2 * i, o, mt); break;
+        }
+    }
+}
 void g_morton(const uint32_t* xy, uint64_t n, uint32_t* out) { for (uint64_t i = 0; i < n; i++) out[i] = morton2(std::pair<uint32_t, uint32_t>{xy[2 * i], xy[2 * i + 1]}); }
 void g_rng(const uint64_t* seq, const uint32_t* bound, uint64_t n, uint32_t* out_u, float* out_f) {   // per sequence: 4 words, 2 floats, 2 bounded draws
     for (uint64_t i = 0; i < n; i++) {
@@ -1194,6 +1359,18 @@ def inputs(n=1 << 12, seed=0x6E0A):
     a = rng.integers(0, 1 << 62, n_all, dtype=np.uint64) >> rng.integers(0, 62, n_all).astype(np.uint64)
     a[:4] = [0, 1, 0xFFFFFFFFFFFFFFFF, 0x8000000000000000]
     d["rad_bi"] = bi; d["rad_a"] = a
+    # the pixel samplers: kind 0 (0,2)-sequence, 1 max-min distance (a power-of-two spp up to 2^16, and counts its `new` rounds up), 2 stratified (jittered and not), 3 random;
+    # 0 .. 5 sampled dimensions (the draws past them come from the generator), seeds as the tile loop derives them, up to two requested arrays of a power-of-two size
+    kind = rng.integers(0, 4, n).astype(np.int32); kind[:4] = [0, 1, 2, 3]
+    spp = np.where(kind == 1, 1 << rng.integers(0, 9, n), rng.choice([1, 2, 3, 4, 7, 16, 64], n)).astype(np.int64)
+    spp[(kind == 1) & (rng.uniform(size=n) < 0.2)] = 5; spp[4:8] = [65536, 3, 100, 1]; kind[4:8] = [1, 1, 1, 1]
+    nx = rng.integers(1, 5, n); ny = rng.integers(1, 5, n)
+    d["pix_kind"] = kind
+    dims = rng.integers(0, 6, n); dims[kind == 1] = np.maximum(dims[kind == 1], 1)      # (MaxMinDistSampler::start_pixel writes samples_2d[0]: the reference panics without a sampled dimension)
+    d["pix_par"] = np.stack([spp, dims, nx, ny, rng.uniform(size=n) < 0.7, np.zeros(n)], 1).astype(np.int64)
+    d["pix_seed"] = rng.integers(0, 1 << 40, n, dtype=np.uint64)
+    d["pix_pixel"] = rng.integers(-8, 2000, (n, 2)).astype(np.int32)
+    d["pix_arrays"] = np.array([[0, 0], [4, 0], [1, 4], [2, 2]], np.int32)[rng.integers(0, 4, n)]
     n = n_all
     # DiffuseAreaLight::sample_li: emitting triangles of a scene of extent ~10, reference points in front of / behind / in the plane of / ON the triangle
     P0 = rng.uniform(-5, 5, (n, 3)); e1 = rng.normal(size=(n, 3)) * np.exp(rng.uniform(-3, 1, (n, 1))); e2 = rng.normal(size=(n, 3)) * np.exp(rng.uniform(-3, 1, (n, 1)))
@@ -1402,6 +1579,12 @@ def run_halton(L, d):
     L.g_halton.argtypes = [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p, C.c_void_p]
     L.g_halton(d["hal_spp"].ctypes.data, d["hal_bounds"].ctypes.data, d["hal_pixel"].ctypes.data, d["hal_center"].ctypes.data, d["hal_arrays"].ctypes.data, n, ho.ctypes.data, hm.ctypes.data)
     out["hal_out"], out["halm_out"] = ho, hm
+    n = len(d["pix_kind"])
+    po, pm = np.zeros((n, 4, 34), np.float32), np.zeros((n, 2), np.uint64)
+    L.g_pixel.restype = None
+    L.g_pixel.argtypes = [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.g_pixel(d["pix_kind"].ctypes.data, d["pix_par"].ctypes.data, d["pix_seed"].ctypes.data, d["pix_pixel"].ctypes.data, d["pix_arrays"].ctypes.data, n, po.ctypes.data, pm.ctypes.data)
+    out["pix_out"], out["pixm_out"] = po, pm
     return out
 
 

@@ -592,6 +592,53 @@ void orc_geom_halton(const uint16_t* perms, uint64_t n_perms, const int64_t* spp
         }
     }
 }
+// the pixel samplers (same layout as the reference text's g_pixel); c_rows: C_MAX_MIN_DIST (17 x 32 words), spp already as MaxMinDistSampler::new leaves it
+void orc_geom_pixel(const uint32_t* c_rows, const int32_t* kind, const int64_t* par, const uint64_t* seed, const int32_t* pixel, const int32_t* arrays, uint64_t n, float* out, uint64_t* meta) {
+    static const int kinds[4] = {RSPT_SAMPLER_ZEROTWO, RSPT_SAMPLER_MAXMINDIST, RSPT_SAMPLER_STRATIFIED, RSPT_SAMPLER_RANDOM};
+    for (uint64_t i = 0; i < n; i++) {
+        const int64_t* q = par + 6 * i;
+        rspt_render_desc rd{};
+        rd.sampler_kind = (uint32_t)kinds[kind[i]]; rd.pixel_dimensions = (uint32_t)q[1];
+        rd.strat_x = (uint32_t)q[2]; rd.strat_y = (uint32_t)q[3]; rd.strat_jitter = (uint32_t)q[4];
+        int64_t spp = kind[i] == 2 ? q[2] * q[3] : q[0];
+        if (kind[i] == 1) {                                   // maxmin.rs:36-59 (the host's part: scenes.py make_sampler does the same): round up to a power of two, pick the matrix
+            int64_t r = 1; while (r < spp) r <<= 1;
+            spp = r;
+            int lg = 0; while ((1ll << lg) < spp) lg++;
+            rd.maxmin_c_pixel = c_rows + 32 * lg;
+        }
+        rd.spp = spp;
+        Sampler s(rd);
+        for (int k = 0; k < 2; k++) if (arrays[2 * i + k] > 0) s.request_2d_array(arrays[2 * i + k]);
+        meta[2 * i] = (uint64_t)spp; meta[2 * i + 1] = (uint64_t)s.round_count(3);
+        s.reseed(seed[i]);
+        const int32_t px = pixel[2 * i], py = pixel[2 * i + 1];
+        s.start_pixel(px, py);
+        for (int k = 0; k < 4 && k < spp; k++) {
+            float* o = out + (4 * i + k) * 34;
+            const P2 f2 = s.get_2d();
+            o[0] = (Float)px + f2.x; o[1] = (Float)py + f2.y;   // sampler.rs:85-95
+            o[2] = s.get_1d();
+            const P2 lens = s.get_2d();
+            o[3] = lens.x; o[4] = lens.y;
+            for (int b = 0; b < 4; b++) {
+                o[5 + 5 * b] = s.get_1d();
+                const P2 u = s.get_2d(), w = s.get_2d();
+                o[6 + 5 * b] = u.x; o[7 + 5 * b] = u.y; o[8 + 5 * b] = w.x; o[9 + 5 * b] = w.y;
+            }
+            for (int a = 0; a < 2; a++) {
+                o[25 + 4 * a] = o[26 + 4 * a] = o[27 + 4 * a] = o[28 + 4 * a] = -1.0f;
+                const int32_t na = arrays[2 * i + a];
+                if (na <= 0) continue;
+                size_t idx; uint64_t start;
+                if (!s.get_2d_array(na, &idx, &start)) continue;
+                const P2 f = s.get_2d_sample(idx, start), l = s.get_2d_sample(idx, start + (uint64_t)na - 1);
+                o[25 + 4 * a] = f.x; o[26 + 4 * a] = f.y; o[27 + 4 * a] = l.x; o[28 + 4 * a] = l.y;
+            }
+            o[33] = s.start_next_sample() ? 1.0f : 0.0f;
+        }
+    }
+}
 void orc_geom_triangle_full(const float* tri, const float* nrm, const float* tan, const float* uvs, const int32_t* flags, const float* o, const float* d, const float* tmax, uint64_t n, float* out) {
     for (uint64_t i = 0; i < n; i++) {
         Scene sc{};

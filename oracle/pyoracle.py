@@ -353,6 +353,15 @@ def geom(d):
     L.orc_geom_halton.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p, C.c_void_p]
     L.orc_geom_halton(perms.ctypes.data, n_p, *[x.ctypes.data for x in hs], nh, ho.ctypes.data, hm.ctypes.data)
     out["hal_out"], out["halm_out"] = ho, hm
+    npx = len(d["pix_kind"])
+    po, pm = np.zeros((npx, 4, 34), np.float32), np.zeros((npx, 2), np.uint64)
+    rows = np.ascontiguousarray(scenes.maxmin_tables(), np.uint32)
+    ps = [np.ascontiguousarray(d["pix_kind"], np.int32), np.ascontiguousarray(d["pix_par"], np.int64), np.ascontiguousarray(d["pix_seed"], np.uint64),
+          np.ascontiguousarray(d["pix_pixel"], np.int32), np.ascontiguousarray(d["pix_arrays"], np.int32)]
+    L.orc_geom_pixel.restype = None
+    L.orc_geom_pixel.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.orc_geom_pixel(rows.ctypes.data, *[x.ctypes.data for x in ps], npx, po.ctypes.data, pm.ctypes.data)
+    out["pix_out"], out["pixm_out"] = po, pm
     out["trp_out"] = out["tri_out"]      # Triangle::intersect_p repeats intersect's watertight test (triangle.rs:450-591); the oracle shares one function
     ou, of = np.zeros((n, 6), np.uint32), np.zeros((n, 2), np.float32)
     L.orc_geom_rng.restype = None

@@ -33,6 +33,9 @@ NAMES = {"gam_out": "gamma", "nfu_out": "next_float_up", "nfd_out": "next_float_
          "hps_out": "compute_radical_inverse_permutations (SHA-256 of all 3 682 913 entries)",
          "rad_out": "radical_inverse / scrambled_radical_inverse over all 1000 prime bases", "radi_out": "reverse_bits_32 / reverse_bits_64 / inverse_radical_inverse",
          "halm_out": "HaltonSampler::new (base scales / exponents, stride, multiplicative inverses over extended_gcd, mod_t) and get_index_for_sample per pixel sample",
+         "pix_out": "ZeroTwoSequence / MaxMinDist / Stratified / RandomSampler: new, reseed, start_pixel, get_camera_sample, get_1d / get_2d, the 2-D arrays, start_next_sample over van_der_corput, sobol_2d, "
+                    "gray_code_sample_1d / _2d, sample_generator_matrix, stratified_sample_1d / _2d, latin_hypercube, shuffle",
+         "pixm_out": "the samplers' spp after new (MaxMinDist rounds up to a power of two) and round_count",
          "hal_out": "HaltonSampler start_pixel / get_camera_sample / get_1d / get_2d / request_2d_array / get_2d_array_idxs / get_2d_sample / start_next_sample"}
 
 
@@ -81,6 +84,10 @@ def test_oracle_equals_the_references_text_on_the_committed_fixture(oracle):
     assert (hal[~free, :, 0] == g["hal_pixel"][~free, None, 0] + 0.5).all() and (~free).sum() > 100                                    # samplepixelcenter
     assert (meta[:, 0] == 128).any() and (meta[:, 1] == 243).any() and (meta[:, 4] == 1).any() and (g["hal_pixel"] < 0).any()          # saturated base scales (K_MAX_RESOLUTION), a 1 x 1 frame (stride 1), mod_t of a negative pixel
     assert (hal[:, 0, 25] >= 0).sum() > 500 and (hal[:, 0, 29] >= 0).sum() > 300 and (hal[:, :, 25:33] == -1).any()                   # one and two requested arrays, and none
+    pix, kind = g["pix_out"], g["pix_kind"]
+    assert all((kind == k).sum() > 100 for k in range(4)) and (g["pix_par"][kind == 2, 4] == 0).sum() > 30 and (g["pix_par"][:, 1] == 0).any()      # every sampler; unjittered strata; no sampled dimension at all
+    assert (g["pixm_out"][(kind == 1) & (g["pix_par"][:, 0] == 5), 0] == 8).all() and g["pixm_out"][4, 0] == 65536 and g["pixm_out"][6, 0] == 128   # MaxMinDistSampler::new rounds 5 -> 8, 100 -> 128
+    assert (g["pixm_out"][kind <= 1, 1] == 4).all() and (g["pixm_out"][kind >= 2, 1] == 3).all()                                                # round_count(3)
     assert (g["rad_bi"] == 0).any() and (g["rad_bi"] == 999).any() and int(g["hpc_out"][0]) == 3682913                                # base 2 by bit reversal, the last base, the sum of the first 1000 primes
 
 
@@ -130,11 +137,12 @@ def test_committed_fixture_is_what_the_references_text_gives():
 def test_oracle_equals_the_compiled_reference_text_on_131072_fresh_cases_per_function(oracle):
     mk = generator()
     L, where = mk.convert()
-    assert len(where) == 18 + 2 + len(mk.SOURCES)      # (the base batch, the two prime tables, this batch)
+    assert len(where) == 18 + 3 + len(mk.SOURCES)      # (the base batch; PRIMES, PRIME_SUMS, C_MAX_MIN_DIST; this batch)
     lines = dict(w.rsplit(" ", 1) for w in where)
     assert lines["Bounds3f::intersect_p"] == "core/geometry.rs:2211-2268" and lines["Triangle::intersect"] == "shapes/triangle.rs:134-273"
     assert lines["BVHAccel::intersect"] == "accelerators/bvh.rs:401-462" and lines["BVHAccel::intersect_p"] == "accelerators/bvh.rs:463-514"
     assert lines["radical_inverse"] == "core/lowdiscrepancy.rs:1126-2162" and lines["HaltonSampler::get_index_for_sample"] == "samplers/halton.rs:173-214" and lines["PRIMES"] == "core/lowdiscrepancy.rs:20-82"
+    assert lines["sobol_2d"] == "core/lowdiscrepancy.rs:919-1010" and lines["MaxMinDistSampler::start_pixel"] == "samplers/maxmin.rs:116-160" and lines["latin_hypercube"] == "core/sampling.rs:273-306"
     d = mk.inputs(n=1 << 17, seed=0x5EED7)
     ref = mk.run_reference(L, d)
     got = oracle.geom(d)
