@@ -65,6 +65,25 @@ static const Float INV_2_PI(0.15915494309189533577f);                      // co
 Bounds3f bnd3_union_bnd3f(const Bounds3f& b1, const Bounds3f& b2); Bounds3f bnd3_union_pnt3f(const Bounds3f& b, const Point3f& p);
 Float vec3_abs_dot_nrmf(const Vector3f& v1, const Normal3f& n2); bool vec3_same_hemisphere_vec3(const Vector3f& w, const Vector3f& wp); Float pow5(Float v);
 Normal3f nrm_faceforward_vec3(const Normal3f& n, const Vector3f& v); Vector3f spherical_direction(Float sin_theta, Float cos_theta, Float phi);
+// ---- SamplerIntegrator::render's tile loop (integrator.rs:108-190): carriers.  The Sampler enum (core/sampler.rs:18-203) forwards every method to its variant: here over the six
+// samplers whose bodies are the reference's text (the geometry batch) ----
+struct TileSampler {
+    int kind = RSPT_SAMPLER_SOBOL; SobolSampler sobol{}; HaltonSampler halton{}; ZeroTwoSequenceSampler zerotwo{}; MaxMinDistSampler maxmin{}; StratifiedSampler strat{}; RandomSampler random{};
+#define TS_FWD(call) switch (kind) { case RSPT_SAMPLER_HALTON: return halton.call; case RSPT_SAMPLER_ZEROTWO: return zerotwo.call; case RSPT_SAMPLER_MAXMINDIST: return maxmin.call; \
+                                     case RSPT_SAMPLER_STRATIFIED: return strat.call; case RSPT_SAMPLER_RANDOM: return random.call; default: return sobol.call; }
+    void start_pixel(Point2i p) { TS_FWD(start_pixel(p)) }
+    CameraSample get_camera_sample(Point2i p) { TS_FWD(get_camera_sample(p)) }
+    Float get_1d() { TS_FWD(get_1d()) }
+    Point2f get_2d() { TS_FWD(get_2d()) }
+    bool start_next_sample() { TS_FWD(start_next_sample()) }
+    int64_t get_samples_per_pixel() const { TS_FWD(samples_per_pixel) }
+    int64_t get_current_sample_number() const { TS_FWD(current_pixel_sample_index) }
+    void reseed(uint64_t seed) {                    // sobol.rs / halton.rs reseed: nothing to do
+        switch (kind) { case RSPT_SAMPLER_ZEROTWO: zerotwo.reseed(seed); break; case RSPT_SAMPLER_MAXMINDIST: maxmin.reseed(seed); break; case RSPT_SAMPLER_STRATIFIED: strat.reseed(seed); break;
+                        case RSPT_SAMPLER_RANDOM: random.reseed(seed); break; default: break; }
+    }
+#undef TS_FWD
+};
 namespace flow {
 static inline orc::V3 V(const Vector3f& v) { return orc::V3{v.x.v, v.y.v, v.z.v}; }
 static inline orc::V3 V(const Point3f& v) { return orc::V3{v.x.v, v.y.v, v.z.v}; }
@@ -274,9 +293,9 @@ struct LightDistribution {                      // LightDistribution::lookup: th
     Distribution1D lookup(const Point3f& p) const { return cx->scene->d.n_lights ? Distribution1D::from(*orc::light_lookup(*cx, V(p))) : Distribution1D{}; }
 };
 struct Sampler {
-    orc::Sampler* s;
-    Float get_1d() { return Float(s->get_1d()); }
-    Point2f get_2d() { const orc::P2 p = s->get_2d(); return Point2f{Float(p.x), Float(p.y)}; }
+    orc::Sampler* s; TileSampler* t = nullptr;      // the oracle's sampler, or (the tile-loop pin) the reference's text of the samplers: then no 2-D arrays (the path integrator requests none)
+    Float get_1d() { return t ? t->get_1d() : Float(s->get_1d()); }
+    Point2f get_2d() { if (t) return t->get_2d(); const orc::P2 p = s->get_2d(); return Point2f{Float(p.x), Float(p.y)}; }
     // the 2-D sample arrays an integrator's preprocess requested (sobol.rs:203-236, halton.rs): (used up, array, first element of this pixel sample)
     std::tuple<bool, size_t, size_t> get_2d_array_idxs(int32_t n) { size_t idx = 0; uint64_t start = 0; const bool ok = s->get_2d_array(n, &idx, &start); return {!ok, idx, (size_t)start}; }
     struct Slice2 { std::vector<Point2f> v; const Point2f& operator[](size_t i) const { return v[i]; } };
@@ -464,6 +483,20 @@ RULES_CAM = [
     (r"let (?:mut )?(\w+): (RayDifferential|Ray|Transform|Point3f|Point2f) = ", r"\2 \1 = ", 0),
     (r"Transform::default\(\)", "Transform::default_()", 0),
 ]
+RULES_TILE = [
+    # F22 the tile loop (integrator.rs:108-190) and its helpers: the optional differential; Ord::min / max; the field-init shorthand; `for pixel in &bounds`; a decimal literal with an
+    #     exponent under a cast; `(x.f() as Float)`; a comment behind an argument; `&mut l` handed to a `&mut Spectrum` parameter; Ray::default()
+    (r"if let Some\(d\) = this->differential\.iter_mut\(\)\.next\(\) \{", "if (this->differential.some) { RayDifferential& d = this->differential;", 0),
+    (r"std::cmp::(min|max)\(", r"rs_\1(", 0),
+    (r"Bounds2i \{ p_min, p_max \}", "Bounds2i{p_min, p_max}", 0),
+    (r"for (\w+) in &([\w.]+) \{", r"for (const auto \1 : \2) {", 0),
+    (r"(-?\d+\.\d+e-?\d+) as Float", r"Float(\1)", 0),
+    (r"\((\w+\.\w+\(\)) as Float\)", r"Float(\1)", 0),
+    (r",\s*//.*$", ",", re.M),
+    (r"&mut l\b", "l", 0),
+    (r"Ray::default\(\)", "ray_default()", 0),
+    (r"let (?:mut )?(\w+): (Point2i|Bounds2i|CameraSample|i32|bool) = ", lambda m: "%s %s = " % (geom.TYPES.get(m.group(2), m.group(2)), m.group(1)), 0),
+]
 RULES_FLOW = [
     # F15 SpatialLightDistribution::compute_distribution: the axis enum as an index, Bounds3f / InteractionCommon literals, Rc, vec![0; n], the enumerate().take(n) loop, iter().sum(), `for item in &mut v`
     (r"\[XYZEnum::X\]", "[0]", 0), (r"\[XYZEnum::Y\]", "[1]", 0), (r"\[XYZEnum::Z\]", "[2]", 0),
@@ -644,12 +677,125 @@ SOURCES = [
     ("core/geometry.rs", r"^pub fn nrm_cross_vec3\(", "nrm_cross_vec3", None, False),
     ("core/sampling.rs", r"^pub fn cosine_hemisphere_pdf\(", "cosine_hemisphere_pdf", None, False),
     ("core/sampling.rs", r"^pub fn uniform_hemisphere_pdf\(", "uniform_hemisphere_pdf", None, False),
+    # the helpers of SamplerIntegrator::render's tile loop (the loop body itself is converted by tile_loop_part below)
+    ("core/geometry.rs", ("^impl Ray \\{", r"^    pub fn scale_differentials\(&mut self, s: Float\) \{"), "scale_differentials", "Ray#til", False),
+    ("core/geometry.rs", r"^pub fn pnt2_inside_exclusivei\(", "pnt2_inside_exclusivei", "#til", False),
+    ("core/geometry.rs", ("^impl Bounds2i \\{", r"^    pub fn new\(p1: Point2i, p2: Point2i\) -> Self \{"), "new_", "Bounds2i#til", False),
+    ("core/spectrum.rs", r"^    pub fn has_nans\(&self\) -> bool \{", "has_nans", "Spectrum#til", False),
     ("integrators/ao.rs", r"^    pub fn li\($", "li", "AOIntegrator#dl", True),
     ("core/integrator.rs", r"^pub fn uniform_sample_all_lights\(", "uniform_sample_all_lights", "#dl", True),
     ("integrators/directlighting.rs", r"^    pub fn li\(", "li", "DirectLightingIntegrator#dl", True),
     ("integrators/directlighting.rs", r"^    pub fn specular_reflect\(", "specular_reflect", "DirectLightingIntegrator#dl", True),
     ("integrators/directlighting.rs", r"^    pub fn specular_transmit\(", "specular_transmit", "DirectLightingIntegrator#dl", True),
 ]
+
+
+TILE_CARRIERS = r"""
+static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
+struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
+struct TileCamera {                                 // the Camera enum's Perspective arm (camera.rs); CameraBase.clipping_start is 0 unless a Blender scene sets it
+    const PerspectiveCamera* cam;
+    Float generate_ray_differential(const CameraSample& s, Ray* ray) const { return cam->generate_ray_differential(s, *ray); }
+    Float get_clipping_start() const { return Float(0.0f); }
+    void adjust_to_clipping_start(const CameraSample&, Ray*) const { abort(); }
+};
+struct TileIntegrator {                             // SamplerIntegrator::Path's arm of li (integrator.rs:199-209) -> PathIntegrator::li, the reference's text (above)
+    Spectrum li(Ray* ray, const TileScene& ts, TileSampler* sampler, int32_t depth) const {
+        flow::Scene scene{ts.cx, ts.c, {}, {}};
+        for (uint32_t i = 0; i < ts.cx->scene->d.n_lights; i++) {
+            scene.lights.v.push_back(flow::LightRef{&scene, i});
+            if (ts.cx->scene->d.lights[i].kind == RSPT_LIGHT_INFINITE) scene.infinite_lights.v.push_back(flow::LightRef{&scene, i});
+        }
+        const flow::PathIntegrator integrator{ts.cx->rd->max_depth, Float(ts.cx->rd->rr_threshold), flow::Option<flow::LightDistribution>{true, flow::LightDistribution{ts.cx}}};
+        flow::Sampler s{nullptr, sampler};
+        return integrator.li(*ray, scene, s, depth);
+    }
+};
+"""
+
+TILE_HOOK = r"""
+// SamplerIntegrator::render with EVERY stage the reference's text: the tile counts (integrator.rs:75-79), BlockQueue::new's order (blockqueue/mod.rs:23-52: (i % nx, i / nx), a stable sort by
+// morton2 — the text's), then per tile the loop body above over the text's samplers, camera, li, FilmTile, and Film::merge_film_tile in queue order.  film_xyzw: Film.pixels (xyz + weight).
+extern "C" int flow_render_tiles(const rspt_scene_desc* sd, const rspt_render_desc* rd, float* film_xyzw) {
+    if (!sd || !rd || rd->integrator != RSPT_INTEGRATOR_PATH || rd->camera_animated) return -1;
+    orc::Scene sc{*sd};
+    sc.prepare_media();
+    orc::RenderCtx cx; cx.scene = &sc; cx.rd = rd;
+    for (uint32_t i = 0; i < sc.d.n_lights; i++) cx.n_light_samples.push_back(1);
+    orc::light_distrib_init(cx);
+    orc::Counters counters;
+    Film film;
+    film.cropped_pixel_bounds = Bounds2i{Point2i{rd->crop_px[0], rd->crop_px[1]}, Point2i{rd->crop_px[2], rd->crop_px[3]}};
+    film.filter.radius = Vector2f{Float(rd->filter_radius[0]), Float(rd->filter_radius[1])}; film.max_sample_luminance = Float(rd->max_sample_luminance);
+    for (int k = 0; k < 256; k++) film.filter_table[k] = Float(rd->filter_table[k]);
+    const size_t cw = (size_t)(rd->crop_px[2] - rd->crop_px[0]), ch = (size_t)(rd->crop_px[3] - rd->crop_px[1]);
+    film.pixels.v = Vec<Pixel>::filled(cw * ch);
+    PerspectiveCamera cam{};
+    auto M = [](const float* m) { Matrix4x4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = Float(m[4 * i + j]); return r; };
+    cam.camera_to_world.start_transform.m = M(rd->camera_to_world); cam.camera_to_world.end_transform.m = M(rd->camera_to_world); cam.camera_to_world.actually_animated = false;
+    cam.camera_to_world.start_time = Float(0.0f); cam.camera_to_world.end_time = Float(1.0f);
+    cam.shutter_open = Float(rd->shutter_open); cam.shutter_close = Float(rd->shutter_close); cam.medium = MediumRef{0};
+    cam.raster_to_camera.m = M(rd->raster_to_camera); cam.lens_radius = Float(rd->lens_radius); cam.focal_distance = Float(rd->focal_distance);
+    const Point3f c0 = cam.raster_to_camera.transform_point(Point3f{Float(0.0f), Float(0.0f), Float(0.0f)});      // PerspectiveCamera::new (perspective.rs:82-97)
+    cam.dx_camera = cam.raster_to_camera.transform_point(Point3f{Float(1.0f), Float(0.0f), Float(0.0f)}) - c0;
+    cam.dy_camera = cam.raster_to_camera.transform_point(Point3f{Float(0.0f), Float(1.0f), Float(0.0f)}) - c0;
+    const Bounds2i sample_bounds{Point2i{rd->sample_bounds[0], rd->sample_bounds[1]}, Point2i{rd->sample_bounds[2], rd->sample_bounds[3]}};
+    TileSampler smp; smp.kind = (int)rd->sampler_kind;
+    switch (smp.kind) {                             // make_sampler (api.rs:1690-1720): each sampler's `new`, the reference's text
+        case RSPT_SAMPLER_SOBOL: SOBOL_MATRICES_32 = rd->tables.sobol32; VD_C_SOBOL_MATRICES.p = rd->tables.vdc; VD_C_SOBOL_MATRICES_INV.p = rd->tables.vdc_inv; smp.sobol = SobolSampler::make(rd->spp, sample_bounds); break;
+        case RSPT_SAMPLER_HALTON: if (RADICAL_INVERSE_PERMUTATIONS.len() == 0) { Rng rng; RADICAL_INVERSE_PERMUTATIONS = compute_radical_inverse_permutations(rng); }      // lazy_static (halton.rs:19-26)
+                                  smp.halton = HaltonSampler::new_(rd->spp, sample_bounds, rd->sample_at_pixel_center != 0); break;
+        case RSPT_SAMPLER_ZEROTWO: smp.zerotwo = ZeroTwoSequenceSampler::new_(rd->spp, rd->pixel_dimensions); break;
+        case RSPT_SAMPLER_MAXMINDIST: smp.maxmin = MaxMinDistSampler::new_(rd->spp, rd->pixel_dimensions); break;
+        case RSPT_SAMPLER_STRATIFIED: smp.strat = StratifiedSampler::new_((int32_t)rd->strat_x, (int32_t)rd->strat_y, rd->strat_jitter != 0, rd->pixel_dimensions); break;
+        case RSPT_SAMPLER_RANDOM: smp.random = RandomSampler::new_(rd->spp); break;
+        default: return -2;
+    }
+    smp.reseed(0);                                  // clone_with_seed(0_u64) (integrator.rs:106)
+    const Vector2i sample_extent = sample_bounds.diagonal();
+    const int32_t tile_size = 16;                   // integrator.rs:75
+    if (rd->tile_size != 16) return -3;
+    const Point2i n_tiles{(sample_extent.x + tile_size - 1) / tile_size, (sample_extent.y + tile_size - 1) / tile_size};
+    std::vector<std::pair<uint32_t, uint32_t>> blocks;
+    for (uint32_t i = 0; i < (uint32_t)(n_tiles.x * n_tiles.y); i++) blocks.push_back({i % (uint32_t)n_tiles.x, i / (uint32_t)n_tiles.x});
+    std::stable_sort(blocks.begin(), blocks.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return morton2(a) < morton2(b); });
+    const TileIntegrator integrator{}; const TileScene scene{&cx, &counters}; const TileCamera camera{&cam};
+    for (const std::pair<uint32_t, uint32_t>& b : blocks) {
+        const FilmTile tile = render_tile(b.first, b.second, integrator, scene, smp, camera, film, sample_bounds, sample_bounds /* pixel_bounds: api.rs hands the integrator the film's sample bounds */, n_tiles, tile_size);
+        film.merge_film_tile(tile);
+    }
+    for (size_t k = 0; k < cw * ch; k++) { const Pixel& p = film.pixels.v[k]; film_xyzw[4 * k] = p.xyz[0].v; film_xyzw[4 * k + 1] = p.xyz[1].v; film_xyzw[4 * k + 2] = p.xyz[2].v; film_xyzw[4 * k + 3] = p.filter_weight_sum.v; }
+    return 0;
+}
+"""
+
+
+def tile_loop_part():
+    """the body of the worker closure of SamplerIntegrator::render — from `let tile` to the line in front of the channel send (integrator.rs:109-189) — as one function over the carriers above"""
+    lines = open(REF + "core/integrator.rs").read().split("\n")
+    i0 = next(k for k, l in enumerate(lines) if l.strip() == "let tile: Point2i = Point2i {")
+    i1 = next(k for k in range(i0, len(lines)) if lines[k].strip().startswith("// send the tile through the channel"))
+    indent = len(lines[i0]) - len(lines[i0].lstrip())
+    text = "\n".join(("    " + l[indent:]) if l.strip() else "" for l in lines[i0:i1])
+    text = re.sub(r"^\s*//.*\n", "", text, flags=re.M)
+    body = join_multiline_if(text + "\n}\n")
+    saved = (dict(TYPES), dict(geom.TYPES), dict(base.TYPES))
+    try:
+        for pat, rep, flags in RULES_TILE + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = geom.cast_after_parens(body, "Float", "Float(%s)")
+        for ty in ("i32", "u64", "u32"):
+            body = geom.cast_after_parens(body, ty, "(" + geom.TYPES[ty] + ")(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = re.sub(r"\blet (?:mut )?(\w+): (Float|Spectrum|Ray) = ", r"\2 \1 = ", body)
+        body = base.shadowing(body, {"x", "y", "integrator", "scene", "tile_sampler", "camera", "film", "sample_bounds", "pixel_bounds", "n_tiles", "tile_size"} | set(geom.FN_NAMES))
+    finally:
+        TYPES.clear(); TYPES.update(saved[0]); geom.TYPES.clear(); geom.TYPES.update(saved[1]); base.TYPES.clear(); base.TYPES.update(saved[2])
+    sig = ("static FilmTile render_tile(uint32_t x, uint32_t y, const TileIntegrator& integrator, const TileScene& scene, TileSampler& tile_sampler, const TileCamera& camera, const Film& film,\n"
+           "                            const Bounds2i& sample_bounds, const Bounds2i& pixel_bounds, Point2i n_tiles, int32_t tile_size) {\n")
+    body = body.rstrip()[:-1].rstrip() + "\n    return film_tile;      // (hand-written: the closure sends the tile through the channel)\n}\n"
+    return "// %score/integrator.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "SamplerIntegrator::render (tile loop) core/integrator.rs:%d-%d" % (i0 + 1, i1)
 
 
 def convert_parts():
@@ -679,6 +825,10 @@ def _convert_parts():
             text = re.sub(r"\bself\s*\n\s*\.", "self.", text)
             TYPES["&mut SurfaceInteraction"] = geom.TYPES["&mut SurfaceInteraction"] = base.TYPES["&mut SurfaceInteraction"] = "SurfaceInteraction&"
             TYPES["&SurfaceInteraction"] = geom.TYPES["&SurfaceInteraction"] = base.TYPES["&SurfaceInteraction"] = "const mat::SurfaceInteraction&" if (cls or "").startswith("mat::") else "const SurfaceInteraction&"
+        til = bool(cls) and cls.endswith("#til")
+        if til:
+            cls = cls[:-4] or None
+            TYPES["Self"] = geom.TYPES["Self"] = base.TYPES["Self"] = cls or "Float"
         dl = bool(cls) and cls.endswith("#dl")
         cls = (cls[:-4] or None) if (cam or bvh) else ((cls[:-3] or None) if dl else cls)
         if dl:
@@ -725,7 +875,7 @@ def _convert_parts():
                     i = body.index(lobe + "::new(")
                     j = geom.matching(body, i + len(lobe) + 5)
                     body = body[:i] + lobe + "{" + body[i + len(lobe) + 6:j] + "}" + body[j + 1:]
-        for pat, rep, flags in (RULES_MAT if mat else []) + (RULES_DL + RULES_CAM if dl else []) + (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+        for pat, rep, flags in (RULES_TILE if til else []) + (RULES_MAT if mat else []) + (RULES_DL + RULES_CAM if dl else []) + (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -997,6 +1147,9 @@ extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd
     return 0;
 }
 """)
+    tile_code, tile_where = tile_loop_part()
+    where.append(tile_where)
+    parts.append(TILE_CARRIERS + tile_code + TILE_HOOK)
     return parts, where
 
 
@@ -1022,6 +1175,18 @@ def render(L, scene, rd, use_text, threads=4):
     rc = L.flow_render(C.addressof(scene.desc), C.addressof(rd), threads, film.ctypes.data, li.ctypes.data, int(use_text))
     assert rc == 0
     return film, li
+
+
+def render_tiles(L, scene, rd):
+    """Film.pixels (cropped pixels x (xyz, weight)) of SamplerIntegrator::render with every stage the reference's text: tile loop, sampler, camera, li, film (flow_render_tiles)"""
+    import numpy as np
+    cw, ch = rd.crop_px[2] - rd.crop_px[0], rd.crop_px[3] - rd.crop_px[1]
+    film = np.zeros((cw * ch, 4), np.float32)
+    L.flow_render_tiles.restype = C.c_int
+    L.flow_render_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.flow_render_tiles(C.addressof(scene.desc), C.addressof(rd), film.ctypes.data)
+    assert rc == 0, rc
+    return film
 
 
 LOBE_FIXTURE = os.path.join(ROOT, "tests", "golden", "lobe_functions.npz")

@@ -77,7 +77,7 @@ static inline Vector3f Vector3f_from(const Normal3f& n) { return Vector3f{n.x, n
 struct Cell { mutable Float v; Float get() const { return v; } void set(Float x) const { v = x; } static Cell new_(Float x) { return Cell{x}; } Float* get_mut() { return &v; } };   // Cell<Float>
 struct RayDifferential { bool some; Point3f rx_origin, ry_origin; Vector3f rx_direction, ry_direction; };   // Option<RayDifferential> (geometry.rs:2408-2414): Copy
 struct MediumRef { uint32_t id; MediumRef clone() const { return *this; } };                               // Option<Arc<Medium>>
-struct Ray { Point3f o; Vector3f d; Cell t_max; Float time; RayDifferential differential; MediumRef medium; };   // geometry.rs:2378-2390
+struct Ray { Point3f o; Vector3f d; Cell t_max; Float time; RayDifferential differential; MediumRef medium; void scale_differentials(Float s); };   // geometry.rs:2378-2390
 enum class MinMaxEnum { Min, Max };
 struct Bounds3f {
     Point3f p_min, p_max;
@@ -163,7 +163,7 @@ struct Point2i {
 };
 Vector2i operator-(const Point2i& a, const Point2i& b);
 Point2f operator+(const Point2f& a, const Point2f& b);
-struct Bounds2i { Point2i p_min, p_max; Vector2i diagonal() const; int32_t area() const; };
+struct Bounds2i { Point2i p_min, p_max; Vector2i diagonal() const; int32_t area() const; static Bounds2i new_(Point2i p1, Point2i p2); };
 struct TableRows { const uint64_t* p; const uint64_t* operator[](size_t k) const { return p + 52 * k; } };   // [&[u64]; 25 / 26]: rows of at most 52 words (the committed blob pads them)
 static TableRows VD_C_SOBOL_MATRICES{nullptr}, VD_C_SOBOL_MATRICES_INV{nullptr};
 static inline int32_t rs_leading_zeros(uint32_t v) { return v == 0 ? 32 : __builtin_clz(v); }                 // u32::leading_zeros

@@ -324,3 +324,31 @@ def test_material_recipes_text_equals_the_oracles_lobe_lists(flow, oracle):
             assert np.array_equal(np.ascontiguousarray(out[:n][fld]).view(np.uint32), np.ascontiguousarray(lob_o[fld]).view(np.uint32)), (kind, trial, fld, out[:n][fld], lob_o[fld])
         n_checked += n
     assert n_checked > 200
+
+
+# ---- SamplerIntegrator::render: the tile loop's own text over the text of every stage it calls ----
+@pytest.mark.parametrize("sampler", ["sobol", "halton", "02sequence", "maxmindist", "stratified", "random"])
+def test_render_with_every_stage_from_the_references_text_equals_the_oracles_film(flow, oracle, sampler):
+    """the worker closure of SamplerIntegrator::render (integrator.rs:109-200: tile bounds, the per-tile seed, start_pixel, get_camera_sample, generate_ray_differential,
+    scale_differentials, li, the NaN test, add_sample, start_next_sample) compiled from the text and run over the TEXT of the sampler, the camera, PathIntegrator::li and the film,
+    tiles in BlockQueue's Morton order, merged by the text's Film::merge_film_tile: the oracle's render() must produce the same Film.pixels, bit for bit.
+    56 x 40 pixels = 3.5 x 2.5 tiles (partial tiles on two sides; the filter reaches across tile borders)."""
+    mk, L = flow
+    assert "SamplerIntegrator::render (tile loop) core/integrator.rs:109-200" in mk.convert_parts()[1]
+    sc = scenes.cornell_box(oracle.bvh_build, variant="mixed")
+    rd = scenes.make_render_desc(56, 40, 16 if sampler != "halton" else 5, scenes.CORNELL_LOOK_AT, scenes.CORNELL_FOV, max_depth=6, sampler=sampler, strat=(4, 4), filter_radius=(1.5, 1.5))
+    film_t = mk.render_tiles(L, sc, rd)
+    ref = oracle.render(sc, rd, threads=4)
+    a, b = film_t.view(np.uint32), np.ascontiguousarray(ref["film"], np.float32).view(np.uint32)
+    assert np.array_equal(a, b), "%d of %d film words differ" % (int((a != b).sum()), a.size)
+    assert film_t[:, 3].min() > 0 and film_t[:, 1].mean() > 0.05
+
+
+def test_render_text_on_the_gallery_with_cropped_sample_bounds(flow, oracle):
+    from tests.util import GALLERY_LOOK_AT, gallery
+    mk, L = flow
+    sc = gallery(oracle.bvh_build, "all")
+    rd = scenes.make_render_desc(64, 48, 4, GALLERY_LOOK_AT, 60, max_depth=5, crop=(0.25, 0.9, 0.1, 0.8))
+    film_t = mk.render_tiles(L, sc, rd)
+    ref = oracle.render(sc, rd, threads=4)
+    assert np.array_equal(film_t.view(np.uint32), np.ascontiguousarray(ref["film"], np.float32).view(np.uint32)) and (np.array(rd.sample_bounds[:2]) > 0).all()
