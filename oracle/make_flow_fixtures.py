@@ -355,7 +355,9 @@ size_t flatten_bvh_tree(const BVHBuildNode* node, Vec<LinearBVHNode>& nodes, siz
 // ---- the material recipes (materials/*.rs compute_scattering_functions): constant textures, no bump map; the Bsdf here collects the reference's own lobe structs ----
 namespace mat {
 struct Bxdf {                                   // enum Bxdf (reflection.rs:462-484): the arm that is set
-    uint32_t kind = 0; LambertianReflection lr; OrenNayar on; SpecularReflection sr; SpecularTransmission st; FresnelSpecular fs; MicrofacetReflection mr; MicrofacetTransmission mt;
+    uint32_t kind = 0; LambertianReflection lr; OrenNayar on; SpecularReflection sr; SpecularTransmission st; FresnelSpecular fs; MicrofacetReflection mr; MicrofacetTransmission mt; LambertianTransmission lt; FresnelBlend fb;
+    static Bxdf LambertianTrans(const LambertianTransmission& x) { Bxdf b; b.kind = RSPT_BXDF_LAMBERT_T; b.lt = x; return b; }
+    static Bxdf FresnelBlnd(const FresnelBlend& x) { Bxdf b; b.kind = RSPT_BXDF_FRESNEL_BLEND; b.fb = x; return b; }
     static Bxdf LambertianRefl(const LambertianReflection& x) { Bxdf b; b.kind = RSPT_BXDF_LAMBERT_R; b.lr = x; return b; }
     static Bxdf OrenNayarRefl(const OrenNayar& x) { Bxdf b; b.kind = RSPT_BXDF_OREN_NAYAR; b.on = x; return b; }
     static Bxdf SpecRefl(const SpecularReflection& x) { Bxdf b; b.kind = RSPT_BXDF_SPECULAR_R; b.sr = x; return b; }
@@ -381,6 +383,9 @@ struct PlasticMaterial { Tex<Spectrum> kd, ks; Tex<Float> roughness; NoBump bump
 struct MirrorMaterial { Tex<Spectrum> kr; NoBump bump_map; CSF };
 struct GlassMaterial { Tex<Spectrum> kr, kt; Tex<Float> u_roughness, v_roughness, index; NoBump bump_map; bool remap_roughness; CSF };
 struct MetalMaterial { Tex<Spectrum> eta, k; Tex<Float> roughness; Option<Tex<Float>> u_roughness, v_roughness; NoBump bump_map; bool remap_roughness; CSF };
+struct SubstrateMaterial { Tex<Spectrum> kd, ks; Tex<Float> nu, nv; NoBump bump_map; bool remap_roughness; CSF };                                                  // substrate.rs:16-23
+struct UberMaterial { Tex<Spectrum> kd, ks, kr, kt, opacity; Tex<Float> roughness; Option<Tex<Float>> u_roughness, v_roughness; Tex<Float> eta; NoBump bump_map; bool remap_roughness; CSF };   // uber.rs:17-30
+struct TranslucentMaterial { Tex<Spectrum> kd, ks; Tex<Float> roughness; Tex<Spectrum> reflect, transmit; NoBump bump_map; bool remap_roughness; CSF };                 // translucent.rs:17-25
 }
 Spectrum estimate_direct(const SurfaceInteraction& it, Point2f u_scattering, const LightRef& light, Point2f u_light, const Scene& scene, Sampler& sampler, bool handle_media, bool specular);
 Spectrum uniform_sample_one_light(const SurfaceInteraction& it, const Scene& scene, Sampler& sampler, bool handle_media, Option<Distribution1D> light_distrib);
@@ -400,6 +405,7 @@ TYPES.update({"Option<Spectrum>": "OptSpectrum", "Option<Arc<Material>>": "NoneA
 RULES_MAT = [
     # F20 the material recipes: enum constructors, struct literals of the lobes' pieces, `si.bsdf = Some(Bsdf::new(..))` (the Bsdf lives behind the interaction), constant textures
     (r"Bxdf::(LambertianRefl|OrenNayarRefl|SpecRefl|SpecTrans|FresnelSpec|MicrofacetRefl|MicrofacetTrans)\(", r"Bxdf::\1(", 0),
+    (r"let (\w+): Option<MicrofacetDistribution> =\s*", r"auto \1 = ", 0),
     (r"Fresnel::(Dielectric|Conductor|NoOp)\(", r"Fresnel_\1(", 0),
     (r"MicrofacetDistribution::TrowbridgeReitz\(", "MicrofacetDistribution_TrowbridgeReitz(", 0),
     (r"TrowbridgeReitzDistribution::new\(", "tr_new(", 0),
@@ -650,7 +656,8 @@ SOURCES = [
     ("core/reflection.rs", ("^impl Bsdf \\{", r"^    pub fn add\(&mut self, b: Bxdf\) \{"), "add", "mat::Bsdf#mat", True),
 ] + [
     ("materials/%s.rs" % f, r"^    pub fn compute_scattering_functions\($", "compute_scattering_functions", "mat::%s#mat" % c, True)
-    for f, c in (("matte", "MatteMaterial"), ("plastic", "PlasticMaterial"), ("mirror", "MirrorMaterial"), ("glass", "GlassMaterial"), ("metal", "MetalMaterial"))
+    for f, c in (("matte", "MatteMaterial"), ("plastic", "PlasticMaterial"), ("mirror", "MirrorMaterial"), ("glass", "GlassMaterial"), ("metal", "MetalMaterial"),
+                 ("substrate", "SubstrateMaterial"), ("uber", "UberMaterial"), ("translucent", "TranslucentMaterial"))
 ] + [
     ("core/reflection.rs", r"^pub fn vec3_same_hemisphere_vec3\(", "vec3_same_hemisphere_vec3", None, False),
     ("core/reflection.rs", r"^fn pow5\(", "pow5", None, False),
@@ -870,7 +877,7 @@ def _convert_parts():
         if bvh and name in ("recursive_build", "flatten_bvh_tree", "init_interior"):
             body = re.sub(r"\b(node|c0|c1)\.", r"\1->", body)          # (these are `&BVHBuildNode` / `&mut BVHBuildNode`: pointers into the arena)
         if mat:                                     # F21: the lobes whose `new` is their struct literal in argument order (reflection.rs:718-720, 851-866, 959-961, 1136-1148): `X::new( .. )` -> X{ .. }
-            for lobe in ("LambertianReflection", "SpecularReflection", "FresnelSpecular", "MicrofacetReflection"):
+            for lobe in ("LambertianReflection", "SpecularReflection", "FresnelSpecular", "MicrofacetReflection", "LambertianTransmission", "FresnelBlend"):      # (+ reflection.rs:1006-1009, 1381-1394)
                 while lobe + "::new(" in body:
                     i = body.index(lobe + "::new(")
                     j = geom.matching(body, i + len(lobe) + 5)
@@ -1101,7 +1108,7 @@ extern "C" int flow_render_direct(const rspt_scene_desc* sd, const rspt_render_d
     return 0;
 }
 // Material::compute_scattering_functions of one recipe with constant parameters: kind 0 matte (kd, sigma) 1 plastic (kd, ks, roughness) 2 mirror (kr) 3 glass (kr, kt, uroughness, vroughness, index)
-// 4 metal (eta, k, roughness, uroughness, vroughness; a negative u / v roughness = not given).  flags: 1 remaproughness, 2 allow_multiple_lobes, 4 a MixMaterial scale (sc).  frame: n, shading n, shading dpdu.
+// 4 metal (eta, k, roughness, uroughness, vroughness; a negative u / v roughness = not given) 5 substrate (kd, ks, nu, nv) 6 uber (kd, ks, kr, kt, opacity, roughness, u, v, index) 7 translucent (kd, ks, roughness, reflect, transmit).  flags: 1 remaproughness, 2 allow_multiple_lobes, 4 a MixMaterial scale (sc).  frame: n, shading n, shading dpdu.
 // out: the lobe list as rspt_bxdf records (what the oracle's / the library's material assembly produce); returns the lobe count, *eta = Bsdf.eta
 extern "C" int flow_material(int kind, const float* p, int flags, const float* sc, const float* frame, rspt_bxdf* out, float* eta) {
     using namespace flow; using namespace flow::mat;
@@ -1115,6 +1122,10 @@ extern "C" int flow_material(int kind, const float* p, int flags, const float* s
         case 1: PlasticMaterial{S(p), S(p + 3), F(p[6]), NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
         case 2: MirrorMaterial{S(p), NoBump{}}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
         case 3: GlassMaterial{S(p), S(p + 3), F(p[6]), F(p[7]), F(p[8]), NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+        case 5: SubstrateMaterial{S(p), S(p + 3), F(p[6]), F(p[7]), NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+        case 6: UberMaterial{S(p), S(p + 3), S(p + 6), S(p + 9), S(p + 12), F(p[15]), Option<Tex<Float>>{p[16] >= 0.0f, F(p[16])}, Option<Tex<Float>>{p[17] >= 0.0f, F(p[17])}, F(p[18]), NoBump{}, remap}
+                    .compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
+        case 7: TranslucentMaterial{S(p), S(p + 3), F(p[6]), S(p + 7), S(p + 10), NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
         default: MetalMaterial{S(p), S(p + 3), F(p[6]), Option<Tex<Float>>{p[7] >= 0.0f, F(p[7])}, Option<Tex<Float>>{p[8] >= 0.0f, F(p[8])}, NoBump{}, remap}.compute_scattering_functions(si, TransportMode::Radiance, allow, flow::NoneOpt, scale); break;
     }
     const mat::Bsdf& b = *si.bsdf.unwrap();
@@ -1131,6 +1142,8 @@ extern "C" int flow_material(int kind, const float* p, int flags, const float* s
             case RSPT_BXDF_SPECULAR_T: put3(o.r, x.st.t); o.eta_a = x.st.eta_a.v; o.eta_b = x.st.eta_b.v; scl(o, x.st.sc_opt); break;
             case RSPT_BXDF_FRESNEL_SPEC: put3(o.r, x.fs.r); put3(o.t, x.fs.t); o.eta_a = x.fs.eta_a.v; o.eta_b = x.fs.eta_b.v; scl(o, x.fs.sc_opt); break;
             case RSPT_BXDF_MICROFACET_R: put3(o.r, x.mr.r); o.alpha_x = x.mr.distribution.tr.alpha_x.v; o.alpha_y = x.mr.distribution.tr.alpha_y.v; fres(o, x.mr.fresnel); scl(o, x.mr.sc_opt); break;
+            case RSPT_BXDF_LAMBERT_T: put3(o.r, x.lt.t); scl(o, x.lt.sc_opt); break;
+            case RSPT_BXDF_FRESNEL_BLEND: put3(o.r, x.fb.rd); put3(o.t, x.fb.rs); o.alpha_x = x.fb.distribution.unwrap().tr.alpha_x.v; o.alpha_y = x.fb.distribution.unwrap().tr.alpha_y.v; scl(o, x.fb.sc_opt); break;
             case RSPT_BXDF_MICROFACET_T: put3(o.r, x.mt.t); o.alpha_x = x.mt.distribution.tr.alpha_x.v; o.alpha_y = x.mt.distribution.tr.alpha_y.v; o.eta_a = x.mt.eta_a.v; o.eta_b = x.mt.eta_b.v; scl(o, x.mt.sc_opt); break;
         }
         out[i] = o;

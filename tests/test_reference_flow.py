@@ -283,7 +283,7 @@ def test_ao_li_text_equals_the_oracles(flow, oracle, cos_sample, sampler, n):
 
 
 def test_material_recipes_text_equals_the_oracles_lobe_lists(flow, oracle):
-    """MatteMaterial / PlasticMaterial / MirrorMaterial / GlassMaterial / MetalMaterial::compute_scattering_functions (materials/*.rs) over Bsdf::new / add, OrenNayar::new,
+    """MatteMaterial / PlasticMaterial / MirrorMaterial / GlassMaterial / MetalMaterial / SubstrateMaterial / UberMaterial / TranslucentMaterial::compute_scattering_functions (materials/*.rs) over Bsdf::new / add, OrenNayar::new,
     SpecularTransmission::new, MicrofacetTransmission::new, TrowbridgeReitzDistribution::new / roughness_to_alpha and Spectrum::clamp — the reference's text, with constant
     parameters — against the oracle's material assembly (which the library's rspt_material_lobes is held to): the same lobes in the same order with the same parameters,
     with both values of allow_multiple_lobes and remaproughness"""
@@ -295,12 +295,12 @@ def test_material_recipes_text_equals_the_oracles_lobe_lists(flow, oracle):
     frame = np.array([0, 0, 1, 0, 0, 1, 1, 0, 0], np.float32); sc3 = np.zeros(3, np.float32)
     fields = ["type", "fresnel", "r", "t", "eta_a", "eta_b", "alpha_x", "alpha_y", "c1", "c2", "on_a", "on_b", "has_sc"]
     n_checked = 0
-    for trial in range(200):
-        kind = trial % 5
+    for trial in range(400):
+        kind = trial % 8
         remap = bool(rng.integers(0, 2)); allow = bool(rng.integers(0, 2))
         c = lambda: tuple(float(np.float32(x)) for x in rng.uniform(0, 1, 3) * (rng.uniform(size=3) > 0.15))      # noqa: E731  (black channels / black colours drop lobes)
         f = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))                                                  # noqa: E731
-        p = np.zeros(16, np.float32)
+        p = np.zeros(24, np.float32)
         if kind == 0:
             kd, sigma = c(), (0.0 if trial % 10 < 5 else f(0, 40)); m = scenes.matte(kd, sigma); p[:3] = kd; p[3] = sigma
         elif kind == 1:
@@ -310,6 +310,16 @@ def test_material_recipes_text_equals_the_oracles_lobe_lists(flow, oracle):
         elif kind == 3:
             kr, kt, idx = c(), c(), f(1.1, 2.5); ur, vr = (0.0, 0.0) if trial % 10 < 5 else (f(0.01, 0.8), f(0.01, 0.8))
             m = scenes.glass(kr, kt, idx, ur, vr, remap); p[:3] = kr; p[3:6] = kt; p[6] = ur; p[7] = vr; p[8] = idx
+        elif kind == 5:
+            kd, ks, nu, nv = c(), c(), f(0.001, 1.0), f(0.001, 1.0); m = scenes.substrate(kd, ks, nu, nv, remap); p[:3] = kd; p[3:6] = ks; p[6] = nu; p[7] = nv
+        elif kind == 6:
+            kd, ks, kr, kt, ro, idx = c(), c(), c(), c(), f(0.001, 1.0), f(1.1, 2.5)
+            op = (1.0, 1.0, 1.0) if trial % 16 < 8 else tuple(float(np.float32(x)) for x in rng.uniform(0, 1, 3))
+            uv = (None, None) if trial % 3 else (f(0.01, 0.5), f(0.01, 0.5))
+            m = scenes.uber(kd, ks, kr, kt, ro, uv[0], uv[1], op, idx, remap)
+            p[:3] = kd; p[3:6] = ks; p[6:9] = kr; p[9:12] = kt; p[12:15] = op; p[15] = ro; p[16] = -1 if uv[0] is None else uv[0]; p[17] = -1 if uv[1] is None else uv[1]; p[18] = idx
+        elif kind == 7:
+            kd, ks, refl, tran, ro = c(), c(), c(), c(), f(0.001, 1.0); m = scenes.translucent(kd, ks, refl, tran, ro, remap); p[:3] = kd; p[3:6] = ks; p[6] = ro; p[7:10] = refl; p[10:13] = tran
         else:
             eta, k, ro = tuple(f(0.1, 3) for _ in range(3)), tuple(f(0, 6) for _ in range(3)), f(0.001, 0.8)
             uv = (None, None) if trial % 10 < 5 else (f(0.01, 0.5), f(0.01, 0.5))
@@ -323,7 +333,7 @@ def test_material_recipes_text_equals_the_oracles_lobe_lists(flow, oracle):
         for fld in fields:
             assert np.array_equal(np.ascontiguousarray(out[:n][fld]).view(np.uint32), np.ascontiguousarray(lob_o[fld]).view(np.uint32)), (kind, trial, fld, out[:n][fld], lob_o[fld])
         n_checked += n
-    assert n_checked > 200
+    assert n_checked > 500
 
 
 # ---- SamplerIntegrator::render: the tile loop's own text over the text of every stage it calls ----
