@@ -394,6 +394,18 @@ struct PathIntegrator {
     Spectrum li(const Ray& r, const Scene& scene, Sampler& sampler, int32_t _depth) const;
 };
 }  // namespace flow
+// ---- the infinite light (lights/infinite.rs) over MipMap<Spectrum> (core/mipmap.rs): carriers.  The pyramid's levels are the host's (rspt_envmap.texels: level after level, each
+// max(1, w / 2) x max(1, h / 2) — MipMap::new's own resampling is the host's restatement, tools/ and rs_pbrt_amd/scenes.py); every lookup below is the reference's text ----
+enum class ImageWrap { Repeat, Black, Clamp };
+static inline int64_t f2isize(Float x) { return x.v != x.v ? 0 : (x.v >= 9223372036854775808.0f ? INT64_MAX : (x.v <= -9223372036854775808.0f ? INT64_MIN : (int64_t)x.v)); }   // `x as isize` from f32: saturating
+struct MipLevel { const float* p; size_t w, h; size_t u_size() const { return w; } size_t v_size() const { return h; }      // BlockedArray<Spectrum>: indexed (u, v)
+                  Spectrum at(size_t s, size_t t) const { Spectrum r; for (int k = 0; k < 3; k++) r.c[k] = Float(p[3 * (t * w + s) + k]); return r; } };
+struct MipMapS { Vec<MipLevel> pyramid; ImageWrap wrap_mode;
+                 size_t levels() const; Spectrum texel(size_t level, int64_t s, int64_t t) const; Spectrum lookup_pnt_flt(Point2f st, Float width) const; Spectrum triangle(size_t level, Point2f st) const; };
+Spectrum lerp(Float t, Spectrum a, Spectrum b); Float spherical_theta(const Vector3f& v); Float spherical_phi(const Vector3f& v);
+struct InfiniteAreaLight { MipMapS lmap; Float world_radius; const flow::Distribution2D& distribution; Transform light_to_world, world_to_light;
+    Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const;
+    Spectrum le(const Ray& ray) const; Float pdf_li(void* _iref, const Vector3f& w) const; };
 """
 
 TYPES = dict(geom.TYPES)
@@ -488,6 +500,22 @@ RULES_CAM = [
     (r"Vector3f::from\(([^()]+)\)", r"Vector3f_from(\1)", 0),
     (r"let (?:mut )?(\w+): (RayDifferential|Ray|Transform|Point3f|Point2f) = ", r"\2 \1 = ", 0),
     (r"Transform::default\(\)", "Transform::default_()", 0),
+]
+RULES_INF = [
+    # F23 MipMap<Spectrum>: a level by reference, the pair of sizes, the one reachable arm of `match self.wrap_mode` (the infinite light's map repeats: infinite.rs:150-160), the
+    #     BlockedArray index, `&T` results by value, isize, `x.f() as Float`, `let v: T`
+    (r"let l = &this->pyramid\[level\];", "const MipLevel& l = this->pyramid[level];", 0),
+    (r"let \((\w+), (\w+)\) = \((.*?) as isize, (.*?) as isize\);", r"const int64_t \1 = (int64_t)(\3), \2 = (int64_t)(\4);", 0),
+    (r"let \(ss, tt\): \(usize, usize\) = match this->wrap_mode \{\s*ImageWrap::Repeat => \(\n\s*([^\n]*),\n\s*([^\n]*),\n\s*\),.*?\n    \};", r"size_t ss = \1; size_t tt = \2;", re.S),
+    (r"\b0_usize\b", "(size_t)0", 0),
+    (r"\bclamp_t\(level, ", "flow::clamp_t(level, ", 0),      # (the usize instance of clamp_t lives with the distributions' batch)
+    (r"&l\[\(ss, tt\)\]", "l.at(ss, tt)", 0),
+    (r"\*this->texel\(", "this->texel(", 0),
+    (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
+    (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
+    (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
+    (r"let (\w+): T = ", r"Spectrum \1 = ", 0),
+    (r"let (?:mut )?(\w+): (Point2f|Vector3f) = ", r"\2 \1 = ", 0),
 ]
 RULES_TILE = [
     # F22 the tile loop (integrator.rs:108-190) and its helpers: the optional differential; Ord::min / max; the field-init shorthand; `for pixel in &bounds`; a decimal literal with an
@@ -684,6 +712,17 @@ SOURCES = [
     ("core/geometry.rs", r"^pub fn nrm_cross_vec3\(", "nrm_cross_vec3", None, False),
     ("core/sampling.rs", r"^pub fn cosine_hemisphere_pdf\(", "cosine_hemisphere_pdf", None, False),
     ("core/sampling.rs", r"^pub fn uniform_hemisphere_pdf\(", "uniform_hemisphere_pdf", None, False),
+    # the infinite light over the MIP map's trilinear lookup
+    ("core/geometry.rs", r"^pub fn spherical_theta\(", "spherical_theta", "#inf", False),
+    ("core/geometry.rs", r"^pub fn spherical_phi\(", "spherical_phi", "#inf", False),
+    ("core/pbrt.rs", r"^pub fn lerp<S, T>", "lerp@Spectrum", "#inf", False),
+    ("core/mipmap.rs", r"^    pub fn levels\(&self\) -> usize \{", "levels", "MipMapS#inf", False),
+    ("core/mipmap.rs", r"^    pub fn texel\(&self", "texel", "MipMapS#inf", False),
+    ("core/mipmap.rs", r"^    pub fn lookup_pnt_flt\(&self", "lookup_pnt_flt", "MipMapS#inf", False),
+    ("core/mipmap.rs", r"^    fn triangle\(&self", "triangle", "MipMapS#inf", False),
+    ("lights/infinite.rs", r"^    pub fn sample_li<'a, 'b>\($", "sample_li", "InfiniteAreaLight#inf", False),
+    ("lights/infinite.rs", r"^    pub fn le\(&self, ray: &Ray\) -> Spectrum \{", "le", "InfiniteAreaLight#inf", False),
+    ("lights/infinite.rs", r"^    pub fn pdf_li\(&self", "pdf_li", "InfiniteAreaLight#inf", False),
     # the helpers of SamplerIntegrator::render's tile loop (the loop body itself is converted by tile_loop_part below)
     ("core/geometry.rs", ("^impl Ray \\{", r"^    pub fn scale_differentials\(&mut self, s: Float\) \{"), "scale_differentials", "Ray#til", False),
     ("core/geometry.rs", r"^pub fn pnt2_inside_exclusivei\(", "pnt2_inside_exclusivei", "#til", False),
@@ -832,6 +871,14 @@ def _convert_parts():
             text = re.sub(r"\bself\s*\n\s*\.", "self.", text)
             TYPES["&mut SurfaceInteraction"] = geom.TYPES["&mut SurfaceInteraction"] = base.TYPES["&mut SurfaceInteraction"] = "SurfaceInteraction&"
             TYPES["&SurfaceInteraction"] = geom.TYPES["&SurfaceInteraction"] = base.TYPES["&SurfaceInteraction"] = "const mat::SurfaceInteraction&" if (cls or "").startswith("mat::") else "const SurfaceInteraction&"
+        inf = bool(cls) and cls.endswith("#inf")
+        if inf:
+            cls = cls[:-4] or None
+            for tab in (TYPES, geom.TYPES, base.TYPES):
+                tab.update({"T": "Spectrum", "&T": "Spectrum", "isize": "int64_t", "Self": cls or "Float", "&dyn Interaction": "void*"})
+            if name == "lerp@Spectrum":             # F12 again: the generic lerp instantiated at S = Float, T = Spectrum (MipMap::lookup_pnt_flt blends two levels)
+                text = re.sub(r"pub fn lerp<S, T>\(t: S, a: T, b: T\) -> T\nwhere.*?\{\n", "pub fn lerp(t: Float, a: Spectrum, b: Spectrum) -> Spectrum {\n", text, flags=re.S).replace("let one: S = num::One::one();", "let one: Float = 1.0 as Float;")
+                name = "lerp"
         til = bool(cls) and cls.endswith("#til")
         if til:
             cls = cls[:-4] or None
@@ -882,7 +929,7 @@ def _convert_parts():
                     i = body.index(lobe + "::new(")
                     j = geom.matching(body, i + len(lobe) + 5)
                     body = body[:i] + lobe + "{" + body[i + len(lobe) + 6:j] + "}" + body[j + 1:]
-        for pat, rep, flags in (RULES_TILE if til else []) + (RULES_MAT if mat else []) + (RULES_DL + RULES_CAM if dl else []) + (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if cam else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+        for pat, rep, flags in (RULES_INF if inf else []) + (RULES_TILE if til else []) + (RULES_MAT if mat else []) + (RULES_DL + RULES_CAM if dl else []) + (RULES_BVH if bvh else []) + (geom.RULES_LIGHT if "lights/" in fname else []) + (RULES_CAM if (cam or inf) else []) + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
@@ -1035,6 +1082,51 @@ extern "C" void flow_delta_lights(const rspt_scene_desc* sd, const rspt_light* l
         const orc::Spec os = orc::light_sample_li(sc, l, oref, orc::P2{0.5f, 0.5f}, &owi, &opdf, &oli);
         q[0] = opdf; q[1] = owi.x; q[2] = owi.y; q[3] = owi.z; q[4] = os.c[0]; q[5] = os.c[1]; q[6] = os.c[2]; q[7] = oli.p.x; q[8] = oli.p.y; q[9] = oli.p.z; q[10] = oli.time;
     }
+}
+// InfiniteAreaLight::{sample_li, le, pdf_li} over MipMap::lookup_pnt_flt / triangle / texel and Distribution2D, text next to the oracle's light_sample_li / infinite_le / infinite_pdf_li:
+// ref = reference points, u = the 2-D samples, dirs = directions for le / pdf_li.  out: pdf wi(3) L(3) p(3) | le(3) | pdf_li | lookup_pnt_flt(u, width = |ref.x| / 3: every pyramid level, as power() uses it) = 17 floats; returns the pyramid's level count
+extern "C" int flow_infinite(const rspt_scene_desc* sd, const float* ref, const float* u, const float* dirs, uint64_t n, float* out_text, float* out_oracle) {
+    orc::Scene sc{*sd};
+    const rspt_light* lt = nullptr;
+    for (uint32_t i = 0; i < sd->n_lights; i++) if (sd->lights[i].kind == RSPT_LIGHT_INFINITE) { lt = &sd->lights[i]; break; }
+    if (!lt) return -1;
+    const rspt_envmap& m = sd->envmaps[lt->prim];
+    MipMapS mm; mm.wrap_mode = ImageWrap::Repeat;                       // infinite.rs:150-160: the light's map repeats
+    { const float* p = m.texels; size_t w = m.width, h = m.height;
+      for (uint32_t l = 0; l < m.n_levels; l++) { mm.pyramid.push(MipLevel{p, w, h}); p += 3 * w * h; w = std::max<size_t>(1, w / 2); h = std::max<size_t>(1, h / 2); } }
+    flow::Distribution2D d2; Vec<Float> marg;                           // Distribution2D::new (sampling.rs:156-171) over the text's Distribution1D::new
+    for (uint32_t v = 0; v < m.dist_nv; v++) { Vec<Float> row; for (uint32_t k = 0; k < m.dist_nu; k++) row.push(Float(m.dist_func[v * m.dist_nu + k])); d2.p_conditional_v.push(flow::Distribution1D::new_(row)); marg.push(d2.p_conditional_v[v].func_int); }
+    d2.p_marginal = flow::Distribution1D::new_(marg);
+    Transform l2w{}, w2l{};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { l2w.m.m[r][c] = Float(lt->p[3 * r + c]); w2l.m.m[r][c] = Float(lt->p[9 + 3 * r + c]); }
+    l2w.m.m[3][3] = Float(1.0f); w2l.m.m[3][3] = Float(1.0f);
+    const InfiniteAreaLight il{mm, Float(orc::world_radius(sc)), d2, l2w, w2l};
+    for (uint64_t i = 0; i < n; i++) {
+        const InteractionCommon iref{Point3f{Float(ref[3 * i]), Float(ref[3 * i + 1]), Float(ref[3 * i + 2])}, Float(0.25f), Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)}, Vector3f{Float(0.0f), Float(0.0f), Float(0.0f)},
+                                     Normal3f{Float(0.0f), Float(0.0f), Float(0.0f)}, None};
+        InteractionCommon li = iref; li.time = Float(0.0f); Vector3f wi{Float(0.0f), Float(0.0f), Float(0.0f)}; Float pdf(0.0f); VisibilityTester vis{nullptr, nullptr};
+        const Spectrum s = il.sample_li(iref, li, Point2f{Float(u[2 * i]), Float(u[2 * i + 1])}, &wi, &pdf, vis);
+        float* t = out_text + 17 * i; float* q = out_oracle + 17 * i;
+        t[0] = pdf.v; t[1] = wi.x.v; t[2] = wi.y.v; t[3] = wi.z.v; t[4] = s.c[0].v; t[5] = s.c[1].v; t[6] = s.c[2].v; t[7] = li.p.x.v; t[8] = li.p.y.v; t[9] = li.p.z.v;
+        const Vector3f d{Float(dirs[3 * i]), Float(dirs[3 * i + 1]), Float(dirs[3 * i + 2])};
+        Ray r{}; r.d = d;
+        const Spectrum e = il.le(r);
+        t[10] = e.c[0].v; t[11] = e.c[1].v; t[12] = e.c[2].v; t[13] = il.pdf_li(nullptr, d).v;
+        orc::Interaction oref; oref.p = orc::V3{ref[3 * i], ref[3 * i + 1], ref[3 * i + 2]}; oref.time = 0.25f;
+        orc::Interaction oli; oli.p = oref.p; orc::V3 owi{0, 0, 0}; float opdf = 0.0f;
+        const orc::Spec os = orc::light_sample_li(sc, *lt, oref, orc::P2{u[2 * i], u[2 * i + 1]}, &owi, &opdf, &oli);
+        q[0] = opdf; q[1] = owi.x; q[2] = owi.y; q[3] = owi.z; q[4] = os.c[0]; q[5] = os.c[1]; q[6] = os.c[2]; q[7] = oli.p.x; q[8] = oli.p.y; q[9] = oli.p.z;
+        const orc::V3 od{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+        const orc::Spec oe = orc::infinite_le(sc, *lt, od);
+        q[10] = oe.c[0]; q[11] = oe.c[1]; q[12] = oe.c[2]; q[13] = orc::infinite_pdf_li(sc, *lt, od);
+        const float width = std::fabs(ref[3 * i]) / 3.0f;
+        const Spectrum lk = mm.lookup_pnt_flt(Point2f{Float(u[2 * i]), Float(u[2 * i + 1])}, Float(width));
+        const orc::Spec olk = orc::env_lookup(m, orc::P2{u[2 * i], u[2 * i + 1]}, width);
+        for (int k = 0; k < 3; k++) { t[14 + k] = lk.c[k].v; q[14 + k] = olk.c[k]; }
+        if (t[0] == 0.0f) for (int k = 1; k < 10; k++) t[k] = 0.0f;      // (a zero pdf: neither side defines the rest)
+        if (q[0] == 0.0f) for (int k = 1; k < 10; k++) q[k] = 0.0f;
+    }
+    return (int)m.n_levels;
 }
 // SpatialLightDistribution::compute_distribution for voxels pi (n x 3), text next to the oracle's spatial_compute: func (n_lights per voxel)
 extern "C" int flow_spatial(const rspt_scene_desc* sd, const rspt_render_desc* rd, const int32_t* pi, uint64_t n, float* out_text, float* out_oracle) {

@@ -50,6 +50,9 @@ FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                           
     Float ceil() const { return Float(ceilf(v)); }
     explicit operator int32_t() const { return v != v ? 0 : (v >= 2147483648.0f ? 2147483647 : (v <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)v)); }   // `x as i32` from f32: saturating, NaN -> 0
     Float tan() const { return Float(tanf(v)); }
+    Float log2() const { return Float(log2f(v)); }               // f32::log2 / acos / atan2: the platform libm's
+    Float acos() const { return Float(acosf(v)); }
+    Float atan2(Float o) const { return Float(atan2f(v, o.v)); }
     Float atan() const { return Float(atanf(v)); }
     Float& operator/=(Float o) { v = v / o.v; return *this; }
 """

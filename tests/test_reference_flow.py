@@ -362,3 +362,26 @@ def test_render_text_on_the_gallery_with_cropped_sample_bounds(flow, oracle):
     film_t = mk.render_tiles(L, sc, rd)
     ref = oracle.render(sc, rd, threads=4)
     assert np.array_equal(film_t.view(np.uint32), np.ascontiguousarray(ref["film"], np.float32).view(np.uint32)) and (np.array(rd.sample_bounds[:2]) > 0).all()
+
+
+@pytest.mark.parametrize("kind", ["constant", "image"])
+def test_infinite_light_text_equals_the_oracle(flow, oracle, kind):
+    """InfiniteAreaLight::{sample_li, le, pdf_li} (lights/infinite.rs:298-392) over MipMap::{lookup_pnt_flt, triangle, texel} (core/mipmap.rs, the Repeat arm), spherical_theta / _phi and the text's
+    Distribution2D, against the oracle's light_sample_li / infinite_le / infinite_pdf_li on the sky scenes (a constant map = one texel; an image map with its pyramid and a rotated light frame)"""
+    import ctypes as C
+    from tests.util import sky_scene
+    mk, L = flow
+    sc = sky_scene(oracle.bvh_build, kind, with_area=False)
+    rng = np.random.default_rng(23)
+    n = 1 << 15
+    ref = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32).clip(0, np.nextafter(np.float32(1), np.float32(0))); u[:64, 1] = 0.0; u[64:128, 0] = 0.0
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]; d = d.astype(np.float32); d[:32] = [0, 0, 1]; d[32:64] = [0, 0, -1]; d[64:96] = [1, 0, 0]      # the poles (sin theta = 0), the seam
+    t, q = np.zeros((n, 17), np.float32), np.zeros((n, 17), np.float32)
+    L.flow_infinite.restype = C.c_int
+    L.flow_infinite.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    levels = L.flow_infinite(C.addressof(sc.desc), ref.ctypes.data, u.ctypes.data, d.ctypes.data, n, t.ctypes.data, q.ctypes.data)
+    assert levels >= 1 and (kind == "constant" or levels > 3)
+    bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+    assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
+    assert (t[:, 0] > 0).mean() > 0.9 and (t[:, 13] > 0).mean() > 0.9 and t[:, 10:13].max() > 0
