@@ -400,8 +400,12 @@ enum class ImageWrap { Repeat, Black, Clamp };
 static inline int64_t f2isize(Float x) { return x.v != x.v ? 0 : (x.v >= 9223372036854775808.0f ? INT64_MAX : (x.v <= -9223372036854775808.0f ? INT64_MIN : (int64_t)x.v)); }   // `x as isize` from f32: saturating
 struct MipLevel { const float* p; size_t w, h; size_t u_size() const { return w; } size_t v_size() const { return h; }      // BlockedArray<Spectrum>: indexed (u, v)
                   Spectrum at(size_t s, size_t t) const { Spectrum r; for (int k = 0; k < 3; k++) r.c[k] = Float(p[3 * (t * w + s) + k]); return r; } };
-struct MipMapS { Vec<MipLevel> pyramid; ImageWrap wrap_mode;
+using flow::clamp_t;                                                                                  // (the i64 / usize instances of clamp_t live with the distributions' batch)
+static const size_t WEIGHT_LUT_SIZE = 128;                                                            // mipmap.rs:21
+struct MipMapS { Vec<MipLevel> pyramid; ImageWrap wrap_mode; bool do_trilinear = false; Float max_anisotropy = Float(8.0f); Float weight_lut[WEIGHT_LUT_SIZE] = {};
+                 Spectrum lookup_pnt_vec_vec(Point2f st, Vector2f& dst0, Vector2f& dst1) const; Spectrum ewa(size_t level, Point2f st, Vector2f dst0, Vector2f dst1) const;
                  size_t levels() const; Spectrum texel(size_t level, int64_t s, int64_t t) const; Spectrum lookup_pnt_flt(Point2f st, Float width) const; Spectrum triangle(size_t level, Point2f st) const; };
+void vec2_mul_assign(Vector2f& a, Float b);
 Spectrum lerp(Float t, Spectrum a, Spectrum b); Float spherical_theta(const Vector3f& v); Float spherical_phi(const Vector3f& v);
 struct InfiniteAreaLight { MipMapS lmap; Float world_radius; const flow::Distribution2D& distribution; Transform light_to_world, world_to_light;
     Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const;
@@ -506,16 +510,29 @@ RULES_INF = [
     #     BlockedArray index, `&T` results by value, isize, `x.f() as Float`, `let v: T`
     (r"let l = &this->pyramid\[level\];", "const MipLevel& l = this->pyramid[level];", 0),
     (r"let \((\w+), (\w+)\) = \((.*?) as isize, (.*?) as isize\);", r"const int64_t \1 = (int64_t)(\3), \2 = (int64_t)(\4);", 0),
-    (r"let \(ss, tt\): \(usize, usize\) = match this->wrap_mode \{\s*ImageWrap::Repeat => \(\n\s*([^\n]*),\n\s*([^\n]*),\n\s*\),.*?\n    \};", r"size_t ss = \1; size_t tt = \2;", re.S),
+    (r"let \(ss, tt\): \(usize, usize\) = match this->wrap_mode \{", "size_t ss, tt; switch (this->wrap_mode) {", 0),
+    (r"ImageWrap::(Repeat|Clamp) => \(\n\s*([^\n]*),\n\s*([^\n]*),\n\s*\),", r"case ImageWrap::\1: ss = \2; tt = \3; break;", 0),
+    (r"ImageWrap::Black => \{", "case ImageWrap::Black: {", 0),
+    (r"^(\s*)\(\n\s*([^\n]*),\n\s*([^\n]*),\n\s*\)(?:\s*//.*)?$", r"\1ss = \2; tt = \3;", re.M),
+    (r"^(\s*)\((s as usize), (t as usize)\)$", r"\1ss = \2; tt = \3;", re.M),
+    (r"\n        \}\n    \};", "\n        } break;\n    }", 0),
+    (r"\bclamp_t\((s|t), 0, ", r"clamp_t(\1, (int64_t)0, ", 0),
+    # F24 the EWA filter: `*dst1 *= scale` (the impl_op above), re-borrows of the two axes, `..=` ranges, Ord::min on usize, T::default(), a cast behind a method call
+    (r"\*?dst1 \*= scale;", "vec2_mul_assign(dst1, scale);", 0),
+    (r"\*(dst[01])\b", r"\1", 0),
+    (r"for (\w+) in (\w+)\.\.=(\w+) \{", r"for (int64_t \1 = \2; \1 <= \3; \1++) {", 0),
+    (r"std::cmp::min\(", "std::min<size_t>(", 0),
+    (r"T::default\(\)", "Spectrum::new_(Float(0.0f))", 0),
+    (r"(\w+\.log2\(\)) as Float", r"\1", 0),
+    (r"let (\w+): isize = (.*) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"\b0_usize\b", "(size_t)0", 0),
-    (r"\bclamp_t\(level, ", "flow::clamp_t(level, ", 0),      # (the usize instance of clamp_t lives with the distributions' batch)
     (r"&l\[\(ss, tt\)\]", "l.at(ss, tt)", 0),
     (r"\*this->texel\(", "this->texel(", 0),
     (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
     (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
-    (r"let (\w+): T = ", r"Spectrum \1 = ", 0),
-    (r"let (?:mut )?(\w+): (Point2f|Vector3f) = ", r"\2 \1 = ", 0),
+    (r"let (?:mut )?(\w+): T = ", r"Spectrum \1 = ", 0),
+    (r"let (?:mut )?(\w+): (Point2f|Vector3f|Vector2f) = ", r"\2 \1 = ", 0),
 ]
 RULES_TILE = [
     # F22 the tile loop (integrator.rs:108-190) and its helpers: the optional differential; Ord::min / max; the field-init shorthand; `for pixel in &bounds`; a decimal literal with an
@@ -720,6 +737,11 @@ SOURCES = [
     ("core/mipmap.rs", r"^    pub fn texel\(&self", "texel", "MipMapS#inf", False),
     ("core/mipmap.rs", r"^    pub fn lookup_pnt_flt\(&self", "lookup_pnt_flt", "MipMapS#inf", False),
     ("core/mipmap.rs", r"^    fn triangle\(&self", "triangle", "MipMapS#inf", False),
+    ("core/geometry.rs", ("^impl Vector2f \\{", r"^    pub fn length_squared\(&self\) -> Float \{"), "length_squared", "Vector2f#inf", False),
+    ("core/geometry.rs", ("^impl Vector2f \\{", r"^    pub fn length\(&self\) -> Float \{"), "length", "Vector2f#inf", False),
+    ("core/geometry.rs", r"^impl_op!\(\*= \|a: &mut Vector2f, b: Float\| \{", "vec2_mul_assign", "#inf", False),
+    ("core/mipmap.rs", r"^    pub fn lookup_pnt_vec_vec\(&self", "lookup_pnt_vec_vec", "MipMapS#inf", False),
+    ("core/mipmap.rs", r"^    fn ewa\(&self", "ewa", "MipMapS#inf", False),
     ("lights/infinite.rs", r"^    pub fn sample_li<'a, 'b>\($", "sample_li", "InfiniteAreaLight#inf", False),
     ("lights/infinite.rs", r"^    pub fn le\(&self, ray: &Ray\) -> Spectrum \{", "le", "InfiniteAreaLight#inf", False),
     ("lights/infinite.rs", r"^    pub fn pdf_li\(&self", "pdf_li", "InfiniteAreaLight#inf", False),
@@ -735,6 +757,23 @@ SOURCES = [
     ("integrators/directlighting.rs", r"^    pub fn specular_transmit\(", "specular_transmit", "DirectLightingIntegrator#dl", True),
 ]
 
+
+MIPMAP_HOOK = r"""
+// MipMap::lookup_pnt_vec_vec (trilinear or EWA) over ewa / triangle / texel in all three wrap modes, text next to the oracle's img_lookup: st, dst0, dst1 per lookup; out: 3 floats
+extern "C" void flow_mipmap(const rspt_image* img, const rspt_texture* tx, const float* st, const float* d0, const float* d1, uint64_t n, float* out_text, float* out_oracle) {
+    MipMapS mm; mm.wrap_mode = tx->wrap == RSPT_WRAP_REPEAT ? ImageWrap::Repeat : (tx->wrap == RSPT_WRAP_BLACK ? ImageWrap::Black : ImageWrap::Clamp);
+    mm.do_trilinear = tx->trilinear != 0; mm.max_anisotropy = Float(tx->max_aniso);
+    { const float* p = img->texels; size_t w = img->width, h = img->height;
+      for (uint32_t l = 0; l < img->n_levels; l++) { mm.pyramid.push(MipLevel{p, w, h}); p += 3 * w * h; w = std::max<size_t>(1, w / 2); h = std::max<size_t>(1, h / 2); } }
+    init_weight_lut(mm);
+    for (uint64_t i = 0; i < n; i++) {
+        Vector2f a{Float(d0[2 * i]), Float(d0[2 * i + 1])}, b{Float(d1[2 * i]), Float(d1[2 * i + 1])};
+        const Spectrum s = mm.lookup_pnt_vec_vec(Point2f{Float(st[2 * i]), Float(st[2 * i + 1])}, a, b);
+        const orc::Spec o = orc::img_lookup(*img, *tx, orc::P2{st[2 * i], st[2 * i + 1]}, orc::P2{d0[2 * i], d0[2 * i + 1]}, orc::P2{d1[2 * i], d1[2 * i + 1]});
+        for (int k = 0; k < 3; k++) { out_text[3 * i + k] = s.c[k].v; out_oracle[3 * i + k] = o.c[k]; }
+    }
+}
+"""
 
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
@@ -844,6 +883,26 @@ def tile_loop_part():
     return "// %score/integrator.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "SamplerIntegrator::render (tile loop) core/integrator.rs:%d-%d" % (i0 + 1, i1)
 
 
+def weight_lut_part():
+    """the block of MipMap::new that fills the EWA filter's weight table (mipmap.rs:186-193), as a function over the carrier"""
+    lines = open(REF + "core/mipmap.rs").read().split("\n")
+    i0 = next(k for k, l in enumerate(lines) if l.strip() == "if mipmap.weight_lut[0] == 0.0 as Float {")
+    indent = len(lines[i0]) - len(lines[i0].lstrip())
+    i1 = next(k for k in range(i0 + 1, len(lines)) if lines[k] == " " * indent + "}")
+    body = "\n".join("    " + l[indent:] for l in lines[i0:i1 + 1]) + "\n}\n"
+    saved = (dict(TYPES), dict(geom.TYPES), dict(base.TYPES))
+    try:
+        for pat, rep, flags in RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = geom.cast_after_parens(body, "Float", "Float(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = re.sub(r"\blet (?:mut )?(\w+): Float = ", r"Float \1 = ", body)
+    finally:
+        TYPES.clear(); TYPES.update(saved[0]); geom.TYPES.clear(); geom.TYPES.update(saved[1]); base.TYPES.clear(); base.TYPES.update(saved[2])
+    return "// %score/mipmap.rs:%d-%d\nstatic void init_weight_lut(MipMapS& mipmap) {\n%s" % (REF, i0 + 1, i1 + 1, body), "MipMap::new (EWA weight table) core/mipmap.rs:%d-%d" % (i0 + 1, i1 + 1)
+
+
 def convert_parts():
     saved = (dict(geom.TYPES), dict(base.TYPES))      # (the type tables are module state shared with the other two scripts: a test process runs all three)
     try:
@@ -876,6 +935,10 @@ def _convert_parts():
             cls = cls[:-4] or None
             for tab in (TYPES, geom.TYPES, base.TYPES):
                 tab.update({"T": "Spectrum", "&T": "Spectrum", "isize": "int64_t", "Self": cls or "Float", "&dyn Interaction": "void*"})
+            for tab in (TYPES, geom.TYPES, base.TYPES):
+                tab["&mut Vector2f"] = "Vector2f&"
+            if name == "vec2_mul_assign":           # `impl_op!(*= |a: &mut Vector2f, b: Float| { .. });` -> a function of that name (the call site's `*dst1 *= scale` names it, F23)
+                text = text.replace("impl_op!(*= |a: &mut Vector2f, b: Float| {", "fn vec2_mul_assign(a: &mut Vector2f, b: Float) {").replace("});", "}")
             if name == "lerp@Spectrum":             # F12 again: the generic lerp instantiated at S = Float, T = Spectrum (MipMap::lookup_pnt_flt blends two levels)
                 text = re.sub(r"pub fn lerp<S, T>\(t: S, a: T, b: T\) -> T\nwhere.*?\{\n", "pub fn lerp(t: Float, a: Spectrum, b: Spectrum) -> Spectrum {\n", text, flags=re.S).replace("let one: S = num::One::one();", "let one: Float = 1.0 as Float;")
                 name = "lerp"
@@ -1252,6 +1315,9 @@ extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd
     return 0;
 }
 """)
+    lut_code, lut_where = weight_lut_part()
+    where.append(lut_where)
+    parts.append(lut_code + MIPMAP_HOOK)
     tile_code, tile_where = tile_loop_part()
     where.append(tile_where)
     parts.append(TILE_CARRIERS + tile_code + TILE_HOOK)

@@ -52,6 +52,7 @@ FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                           
     Float tan() const { return Float(tanf(v)); }
     Float log2() const { return Float(log2f(v)); }               // f32::log2 / acos / atan2: the platform libm's
     Float acos() const { return Float(acosf(v)); }
+    Float exp() const { return Float(expf(v)); }
     Float atan2(Float o) const { return Float(atan2f(v, o.v)); }
     Float atan() const { return Float(atanf(v)); }
     Float& operator/=(Float o) { v = v / o.v; return *this; }

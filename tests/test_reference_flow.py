@@ -385,3 +385,38 @@ def test_infinite_light_text_equals_the_oracle(flow, oracle, kind):
     bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
     assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
     assert (t[:, 0] > 0).mean() > 0.9 and (t[:, 13] > 0).mean() > 0.9 and t[:, 10:13].max() > 0
+
+
+@pytest.mark.parametrize("wrap", [abi.WRAP_REPEAT, abi.WRAP_BLACK, abi.WRAP_CLAMP])
+@pytest.mark.parametrize("trilinear", [0, 1])
+def test_mipmap_lookup_text_equals_the_oracle(flow, oracle, wrap, trilinear):
+    """MipMap::lookup_pnt_vec_vec (mipmap.rs:253-297) — the trilinear width or the EWA path with the eccentricity clamp, the level of detail, the two-level blend — over ewa (:337-400, with the
+    weight table of MipMap::new :186-193), triangle, lookup_pnt_flt and texel in all three wrap modes, against the oracle's img_lookup (which the device's texture fetch is held to): footprints from a
+    fraction of a texel to tens of texels, degenerate (zero) axes, lookups across the image border"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(31 + wrap * 2 + trilinear)
+    w, h = 32, 16
+    levels = []
+    lw, lh = w, h
+    base = rng.uniform(0, 2, (h, w, 3)).astype(np.float32)
+    while True:
+        levels.append(rng.uniform(0, 2, (lh, lw, 3)).astype(np.float32) if levels else base)      # (any numbers: the lookups' arithmetic is what is compared)
+        if lw == 1 and lh == 1:
+            break
+        lw, lh = max(1, lw // 2), max(1, lh // 2)
+    tex = np.concatenate([l.reshape(-1) for l in levels])
+    img = abi.Image(); img.width, img.height, img.n_levels, img.channels = w, h, len(levels), 3; img.texels = tex.ctypes.data
+    tx = abi.Texture(); tx.wrap, tx.trilinear, tx.max_aniso = wrap, trilinear, 8.0
+    n = 1 << 14
+    st = rng.uniform(-0.5, 1.5, (n, 2)).astype(np.float32)
+    scale = np.exp(rng.uniform(np.log(1e-4), np.log(0.2), (n, 1)))
+    d0 = (rng.normal(size=(n, 2)) * scale).astype(np.float32); d1 = (rng.normal(size=(n, 2)) * scale * np.exp(rng.uniform(-3, 0, (n, 1)))).astype(np.float32)
+    d1[:64] = 0.0; d0[64:96] = 0.0; d1[64:96] = 0.0
+    t, q = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    L.flow_mipmap.restype = None
+    L.flow_mipmap.argtypes = [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.flow_mipmap(C.addressof(img), C.addressof(tx), st.ctypes.data, d0.ctypes.data, d1.ctypes.data, n, t.ctypes.data, q.ctypes.data)
+    bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+    assert not bad.any(), "%d of %d lookups differ" % (int(bad.any(axis=1).sum()), n)
+    assert np.isfinite(t).mean() > 0.99 and t.std() > 0.1
