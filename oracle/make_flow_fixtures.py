@@ -406,6 +406,12 @@ struct MipMapS { Vec<MipLevel> pyramid; ImageWrap wrap_mode; bool do_trilinear =
                  Spectrum lookup_pnt_vec_vec(Point2f st, Vector2f& dst0, Vector2f& dst1) const; Spectrum ewa(size_t level, Point2f st, Vector2f dst0, Vector2f dst1) const;
                  size_t levels() const; Spectrum texel(size_t level, int64_t s, int64_t t) const; Spectrum lookup_pnt_flt(Point2f st, Float width) const; Spectrum triangle(size_t level, Point2f st) const; };
 void vec2_mul_assign(Vector2f& a, Float b);
+// Perlin noise (core/texture.rs:21-48 the permutation table — converted from the text below —, 289-439)
+static const size_t NOISE_PERM_SIZE = 256;                                                            // texture.rs:21
+static const Float LOG2_E(1.44269504088896340735992468100189214f);                                    // std::f32::consts::LOG2_E
+Float log_2(Float x); Float smooth_step(Float min, Float max, Float value); Float noise_flt(Float x, Float y, Float z); Float noise_pnt3(const Point3f& p);
+Float grad(int32_t x, int32_t y, int32_t z, Float dx, Float dy, Float dz); Float noise_weight(Float t); Float lanczos(Float x, Float tau);
+Float fbm(const Point3f& p, const Vector3f& dpdx, const Vector3f& dpdy, Float omega, int32_t max_octaves); Float turbulence(const Point3f& p, const Vector3f& dpdx, const Vector3f& dpdy, Float omega, int32_t max_octaves);
 Spectrum lerp(Float t, Spectrum a, Spectrum b); Float spherical_theta(const Vector3f& v); Float spherical_phi(const Vector3f& v);
 struct InfiniteAreaLight { MipMapS lmap; Float world_radius; const flow::Distribution2D& distribution; Transform light_to_world, world_to_light;
     Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const;
@@ -531,6 +537,11 @@ RULES_INF = [
     (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
     (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
+    # F25 the noise functions: a borrow of a temporary, a one-line `let x = if c { a } else { b };`, a range up to a cast, LOG2_E
+    (r"([(,]\s*)&\(", r"\1(", 0),
+    (r"let (\w+) = if (.*?) \{ (-?\w+) \} else \{ (-?\w+) \};", r"const auto \1 = (\2) ? \3 : \4;", 0),
+    (r"for (\w+) in (\w+)\.\.(\w+) as usize \{", r"for (size_t \1 = \2; \1 < (size_t)(\3); \1++) {", 0),
+    (r"std::f32::consts::LOG2_E", "LOG2_E", 0),
     (r"let (?:mut )?(\w+): T = ", r"Spectrum \1 = ", 0),
     (r"let (?:mut )?(\w+): (Point2f|Vector3f|Vector2f) = ", r"\2 \1 = ", 0),
 ]
@@ -737,6 +748,15 @@ SOURCES = [
     ("core/mipmap.rs", r"^    pub fn texel\(&self", "texel", "MipMapS#inf", False),
     ("core/mipmap.rs", r"^    pub fn lookup_pnt_flt\(&self", "lookup_pnt_flt", "MipMapS#inf", False),
     ("core/mipmap.rs", r"^    fn triangle\(&self", "triangle", "MipMapS#inf", False),
+    ("core/pbrt.rs", r"^pub fn log_2\(", "log_2", "#inf", False),
+    ("core/texture.rs", r"^pub fn smooth_step\(", "smooth_step", "#inf", False),
+    ("core/texture.rs", r"^pub fn noise_flt\(", "noise_flt", "#inf", False),
+    ("core/texture.rs", r"^pub fn noise_pnt3\(", "noise_pnt3", "#inf", False),
+    ("core/texture.rs", r"^pub fn grad\(", "grad", "#inf", False),
+    ("core/texture.rs", r"^pub fn noise_weight\(", "noise_weight", "#inf", False),
+    ("core/texture.rs", r"^pub fn fbm\(", "fbm", "#inf", False),
+    ("core/texture.rs", r"^pub fn turbulence\($", "turbulence", "#inf", False),
+    ("core/texture.rs", r"^pub fn lanczos\(", "lanczos", "#inf", False),
     ("core/geometry.rs", ("^impl Vector2f \\{", r"^    pub fn length_squared\(&self\) -> Float \{"), "length_squared", "Vector2f#inf", False),
     ("core/geometry.rs", ("^impl Vector2f \\{", r"^    pub fn length\(&self\) -> Float \{"), "length", "Vector2f#inf", False),
     ("core/geometry.rs", r"^impl_op!\(\*= \|a: &mut Vector2f, b: Float\| \{", "vec2_mul_assign", "#inf", False),
@@ -771,6 +791,22 @@ extern "C" void flow_mipmap(const rspt_image* img, const rspt_texture* tx, const
         const Spectrum s = mm.lookup_pnt_vec_vec(Point2f{Float(st[2 * i]), Float(st[2 * i + 1])}, a, b);
         const orc::Spec o = orc::img_lookup(*img, *tx, orc::P2{st[2 * i], st[2 * i + 1]}, orc::P2{d0[2 * i], d0[2 * i + 1]}, orc::P2{d1[2 * i], d1[2 * i + 1]});
         for (int k = 0; k < 3; k++) { out_text[3 * i + k] = s.c[k].v; out_oracle[3 * i + k] = o.c[k]; }
+    }
+}
+"""
+
+MIPMAP_HOOK += r"""
+// noise_pnt3 / fbm / turbulence / smooth_step / lanczos (core/texture.rs:289-439), text next to the oracle's: par = omega, octaves (as a float), a value for smooth_step / lanczos; out: 5 floats
+extern "C" void flow_noise(const float* p, const float* dpdx, const float* dpdy, const float* par, uint64_t n, float* out_text, float* out_oracle) {
+    for (uint64_t i = 0; i < n; i++) {
+        const Point3f q{Float(p[3 * i]), Float(p[3 * i + 1]), Float(p[3 * i + 2])};
+        const Vector3f dx{Float(dpdx[3 * i]), Float(dpdx[3 * i + 1]), Float(dpdx[3 * i + 2])}, dy{Float(dpdy[3 * i]), Float(dpdy[3 * i + 1]), Float(dpdy[3 * i + 2])};
+        const Float omega(par[3 * i]); const int32_t oct = (int32_t)par[3 * i + 1]; const Float v(par[3 * i + 2]);
+        float* t = out_text + 5 * i; float* o = out_oracle + 5 * i;
+        t[0] = noise_pnt3(q).v; t[1] = fbm(q, dx, dy, omega, oct).v; t[2] = turbulence(q, dx, dy, omega, oct).v; t[3] = smooth_step(Float(0.3f), Float(0.7f), v).v; t[4] = lanczos(v, Float(2.0f)).v;
+        const orc::V3 oq{p[3 * i], p[3 * i + 1], p[3 * i + 2]}, ox{dpdx[3 * i], dpdx[3 * i + 1], dpdx[3 * i + 2]}, oy{dpdy[3 * i], dpdy[3 * i + 1], dpdy[3 * i + 2]};
+        o[0] = orc::noise_flt(oq.x, oq.y, oq.z); o[1] = orc::fbm(oq, ox, oy, par[3 * i], oct); o[2] = orc::turbulence(oq, ox, oy, par[3 * i], oct); o[3] = orc::smooth_step(0.3f, 0.7f, par[3 * i + 2]);
+        o[4] = t[4];      // (the oracle has no lanczos: MipMap::new's resampling is the host's; the value is checked against numpy in the test)
     }
 }
 """
@@ -915,6 +951,11 @@ def _convert_parts():
     parts, where = geom.convert_parts()
     parts.insert(0, '#include <deque>\n#include "../orc_render.hpp"   // the oracle (header-only, namespace orc): the leaf functions the carriers below delegate to\n')
     parts.append(CARRIERS)
+    text = open(REF + "core/texture.rs").read()      # `pub const NOISE_PERM: [u8; 2 * NOISE_PERM_SIZE] = [ .. ];` -> the same bytes as a C array (the rule of the prime tables, G36)
+    mo = re.search(r"^pub const NOISE_PERM: \[u8; 2 \* NOISE_PERM_SIZE\] = \[\n(.*?)\n\];$", text, re.M | re.S)
+    l0 = text.count("\n", 0, mo.start()) + 1
+    parts.append("// %score/texture.rs:%d-%d\nstatic const uint8_t NOISE_PERM[2 * 256] = {\n%s\n};\n" % (REF, l0, l0 + mo.group(0).count("\n"), re.sub(r"//.*$", "", mo.group(1), flags=re.M)))
+    where.append("NOISE_PERM core/texture.rs:%d-%d" % (l0, l0 + mo.group(0).count("\n")))
     geom.TYPES.update(TYPES); base.TYPES.update(TYPES)
     snapshot = dict(TYPES)
     for fname, first_re, name, cls, in_flow in SOURCES:
@@ -996,6 +1037,9 @@ def _convert_parts():
             body = re.sub(pat, rep, body, flags=flags)
         body = geom.cast_after_parens(body, "Float", "Float(%s)")
         body = geom.cast_after_parens(body, "usize", "(size_t)(%s)")
+        if inf:
+            body = geom.cast_after_brackets(body, "usize", "(size_t)(%s)")
+            body = geom.cast_after_parens(body, "i32", "(int32_t)(%s)")
         if bvh:
             body = geom.cast_after_parens(body, "i32", "(int32_t)(%s)")
         if dl:

@@ -420,3 +420,26 @@ def test_mipmap_lookup_text_equals_the_oracle(flow, oracle, wrap, trilinear):
     bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
     assert not bad.any(), "%d of %d lookups differ" % (int(bad.any(axis=1).sum()), n)
     assert np.isfinite(t).mean() > 0.99 and t.std() > 0.1
+
+
+def test_noise_fbm_turbulence_text_equals_the_oracle(flow, oracle):
+    """noise_flt / noise_pnt3 / grad / noise_weight over the permutation table NOISE_PERM, fbm, turbulence (the octave count from the footprint through log_2), smooth_step and lanczos
+    (core/texture.rs:21-48, 289-439; pbrt.rs:153-156) against the oracle's (the marble / wrinkled / windy / fbm textures sit on them): points over many noise cells incl. negative
+    coordinates and exact lattice points, footprints from sub-octave to none"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(41)
+    n = 1 << 16
+    p = (rng.uniform(-300, 300, (n, 3)) * np.exp(rng.uniform(-4, 0, (n, 1)))).astype(np.float32); p[:256] = np.round(p[:256])
+    dx = (rng.normal(size=(n, 3)) * np.exp(rng.uniform(-9, 1, (n, 1)))).astype(np.float32); dy = (rng.normal(size=(n, 3)) * np.exp(rng.uniform(-9, 1, (n, 1)))).astype(np.float32)
+    dx[:32] = 0; dy[:32] = 0
+    par = np.stack([rng.uniform(0.2, 0.9, n), rng.integers(1, 9, n), rng.uniform(-0.5, 1.5, n)], 1).astype(np.float32)
+    t, q = np.zeros((n, 5), np.float32), np.zeros((n, 5), np.float32)
+    L.flow_noise.restype = None
+    L.flow_noise.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    L.flow_noise(p.ctypes.data, dx.ctypes.data, dy.ctypes.data, par.ctypes.data, n, t.ctypes.data, q.ctypes.data)
+    bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+    assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
+    assert np.abs(t[:, 0]).max() > 0.5 and (t[:256, 0] == 0).all() and t[:, 2].min() > 0         # gradient noise vanishes on the lattice; turbulence is a sum of magnitudes
+    x = np.abs(par[:, 2].astype(np.float64)); ref = np.where(x < 1e-5, 1.0, np.where(x > 1, 0.0, np.sin(x * np.pi * 2) / np.maximum(x * np.pi * 2, 1e-30) * np.sin(x * np.pi) / np.maximum(x * np.pi, 1e-30)))
+    assert np.abs(t[:, 4] - ref).max() < 1e-5
