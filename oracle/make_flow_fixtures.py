@@ -406,6 +406,31 @@ struct MipMapS { Vec<MipLevel> pyramid; ImageWrap wrap_mode; bool do_trilinear =
                  Spectrum lookup_pnt_vec_vec(Point2f st, Vector2f& dst0, Vector2f& dst1) const; Spectrum ewa(size_t level, Point2f st, Vector2f dst0, Vector2f dst1) const;
                  size_t levels() const; Spectrum texel(size_t level, int64_t s, int64_t t) const; Spectrum lookup_pnt_flt(Point2f st, Float width) const; Spectrum triangle(size_t level, Point2f st) const; };
 void vec2_mul_assign(Vector2f& a, Float b);
+// the texture mappings (core/texture.rs:51-283) and the procedural textures over them (textures/*.rs): carriers.  The two mapping enums forward `map` to their variant (texture.rs:58-92);
+// a child texture is a ConstantTexture
+Vector2f operator/(const Vector2f& a, Float b);
+static inline Point3f& operator*=(Point3f& a, Float b) { a = a * b; return a; }                       // impl_op!(*= |a: &mut Point3f, b: Float|) (geometry.rs:1348-1352): the three products of `a * b`
+struct UVMapping2D { Float su, sv, du, dv; Point2f map(const FullInteraction& si, Vector2f& dstdx, Vector2f& dstdy) const; };
+struct SphericalMapping2D { Transform world_to_texture; Point2f sphere(const Point3f& p) const; Point2f map(const FullInteraction& si, Vector2f& dstdx, Vector2f& dstdy) const; };
+struct CylindricalMapping2D { Transform world_to_texture; Point2f cylinder(const Point3f& p) const; Point2f map(const FullInteraction& si, Vector2f& dstdx, Vector2f& dstdy) const; };
+struct PlanarMapping2D { Vector3f vs, vt; Float ds, dt; Point2f map(const FullInteraction& si, Vector2f& dstdx, Vector2f& dstdy) const; };
+struct IdentityMapping3D { Transform world_to_texture; Transform get_world_to_texture() const { return world_to_texture; } Point3f map(const FullInteraction& si, Vector3f* dpdx, Vector3f* dpdy) const; };
+struct TextureMapping2D { uint32_t kind; UVMapping2D uv; SphericalMapping2D sph; CylindricalMapping2D cyl; PlanarMapping2D pl;
+    Point2f map(const FullInteraction& si, Vector2f* dstdx, Vector2f* dstdy) const {
+        switch (kind) { case RSPT_MAP_PLANAR: return pl.map(si, *dstdx, *dstdy); case RSPT_MAP_SPHERICAL: return sph.map(si, *dstdx, *dstdy); case RSPT_MAP_CYLINDRICAL: return cyl.map(si, *dstdx, *dstdy); default: return uv.map(si, *dstdx, *dstdy); } } };
+struct TextureMapping3D { IdentityMapping3D id; Point3f map(const FullInteraction& si, Vector3f* dpdx, Vector3f* dpdy) const { return id.map(si, dpdx, dpdy); } };
+template <class T> struct TexConst { T value; T evaluate(const FullInteraction&) const { return value; } };
+static inline Vector2f vector2f_default() { return Vector2f{Float(0.0f), Float(0.0f)}; }
+struct WrinkledTexture;
+struct BumpTex { const WrinkledTexture* w; Float evaluate(const FullInteraction& si) const; };       // Arc<dyn Texture<Float>>: here a WrinkledTexture (its evaluate is the text's)
+void material_bump(const BumpTex& d, FullInteraction& si);
+struct MarbleTexture { TextureMapping3D mapping; int32_t octaves; Float omega, scale, variation; Spectrum evaluate(const FullInteraction& si) const; };      // marble.rs:14-21
+struct WindyTexture { TextureMapping3D mapping; Float evaluate(const FullInteraction& si) const; };
+struct WrinkledTexture { TextureMapping3D mapping; int32_t octaves; Float omega; Float evaluate(const FullInteraction& si) const; };
+inline Float BumpTex::evaluate(const FullInteraction& si) const { return w->evaluate(si); }
+struct FBmTexture { TextureMapping3D mapping; Float omega; int32_t octaves; Float evaluate(const FullInteraction& si) const; };
+struct Checkerboard2DTexture { TexConst<Spectrum> tex1, tex2; TextureMapping2D mapping; Spectrum evaluate(const FullInteraction& si) const; };
+struct DotsTexture { TextureMapping2D mapping; TexConst<Spectrum> outside_dot, inside_dot; Spectrum evaluate(const FullInteraction& si) const; };
 // Perlin noise (core/texture.rs:21-48 the permutation table — converted from the text below —, 289-439)
 static const size_t NOISE_PERM_SIZE = 256;                                                            // texture.rs:21
 static const Float LOG2_E(1.44269504088896340735992468100189214f);                                    // std::f32::consts::LOG2_E
@@ -537,6 +562,18 @@ RULES_INF = [
     (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
     (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
+    # F27 Material::bump: the evaluation copy of the interaction (the optional members a triangle's interaction does not carry are dropped), cells of vectors
+    (r"let mut si_eval: SurfaceInteraction = SurfaceInteraction::default\(\);", "FullInteraction si_eval{};", 0),
+    (r"if let Some\((?:ref )?\w+\) = &?si\.(?:common\.medium_interface|primitive|bsdf|shape) \{.*?\} else \{.*?\}", "", re.S),
+    (r"Cell::new\((si\.dpd[xy]\.get\(\))\)", r"CellV::new_(\1)", 0),
+    (r"Normal3f::from\(", "Normal3f_from(", 0),
+    # F26 mappings and procedural textures: the axis selector behind a parenthesis, the colour table, `T::from(x)` at T = Float, the defaults
+    (r"\[XYEnum::X\]", ".x", 0), (r"\[XYEnum::Y\]", ".y", 0),
+    (r"let c: \[\[Float; 3\]; 9\] = \[\n(.*?)\n\s*\];", lambda m: "const Float c[9][3] = {\n%s\n};" % m.group(1).replace("[", "{").replace("]", "}"), re.S),
+    (r"\bT::from\(", "Float(", 0),
+    (r"(\([^()]*(?:\([^()]*\)[^()]*)*\)\.(?:floor|ceil)\(\)) as (usize|i32)\b", lambda m: "(%s)(%s)" % (geom.TYPES[m.group(2)], m.group(1)), 0),
+    (r"Vector2f::default\(\)", "vector2f_default()", 0), (r"Vector3f::default\(\)", "vector3f_default()", 0),
+    (r"let (?:mut )?(\w+): (i32|u8) = ", lambda m: "%s %s = " % (geom.TYPES[m.group(2)], m.group(1)), 0),
     # F25 the noise functions: a borrow of a temporary, a one-line `let x = if c { a } else { b };`, a range up to a cast, LOG2_E
     (r"([(,]\s*)&\(", r"\1(", 0),
     (r"let (\w+) = if (.*?) \{ (-?\w+) \} else \{ (-?\w+) \};", r"const auto \1 = (\2) ? \3 : \4;", 0),
@@ -757,6 +794,23 @@ SOURCES = [
     ("core/texture.rs", r"^pub fn fbm\(", "fbm", "#inf", False),
     ("core/texture.rs", r"^pub fn turbulence\($", "turbulence", "#inf", False),
     ("core/texture.rs", r"^pub fn lanczos\(", "lanczos", "#inf", False),
+    ("core/geometry.rs", r"^impl_op_ex!\(/\|a: &Vector2f, b: Float\| -> Vector2f \{", "operator/", "#inf", False),
+    ("core/spectrum.rs", r"^    pub fn from_rgb\(rgb: &\[Float; 3\]\) -> RGBSpectrum \{", "from_rgb", "Spectrum#inf", False),
+    ("core/texture.rs", ("^impl UVMapping2D \\{", r"^    pub fn map\($"), "map", "UVMapping2D#inf", False),
+    ("core/texture.rs", ("^impl SphericalMapping2D \\{", r"^    pub fn sphere\(&self"), "sphere", "SphericalMapping2D#inf", False),
+    ("core/texture.rs", (r"^    pub fn sphere\(&self", r"^    pub fn map\($"), "map", "SphericalMapping2D#inf", False),
+    ("core/texture.rs", ("^impl CylindricalMapping2D \\{", r"^    pub fn cylinder\(&self"), "cylinder", "CylindricalMapping2D#inf", False),
+    ("core/texture.rs", (r"^    pub fn cylinder\(&self", r"^    pub fn map\($"), "map", "CylindricalMapping2D#inf", False),
+    ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
+    ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
+    ("core/interaction.rs", r"^    pub fn set_shading_geometry\($", "set_shading_geometry", "FullInteraction#inf", False),
+    ("core/material.rs", r"^    pub fn bump\(d: ", "material_bump", "#inf", False),
+    ("textures/marble.rs", r"^    fn evaluate\(&self", "evaluate", "MarbleTexture#inf", False),
+    ("textures/windy.rs", r"^    fn evaluate\(&self", "evaluate@Float", "WindyTexture#inf", False),
+    ("textures/wrinkled.rs", r"^    fn evaluate\(&self", "evaluate@Float", "WrinkledTexture#inf", False),
+    ("textures/fbm.rs", r"^    fn evaluate\(&self", "evaluate@Float", "FBmTexture#inf", False),
+    ("textures/checkerboard.rs", r"^    fn evaluate\(&self", "evaluate", "Checkerboard2DTexture#inf", False),
+    ("textures/dots.rs", r"^    fn evaluate\(&self", "evaluate", "DotsTexture#inf", False),
     ("core/geometry.rs", ("^impl Vector2f \\{", r"^    pub fn length_squared\(&self\) -> Float \{"), "length_squared", "Vector2f#inf", False),
     ("core/geometry.rs", ("^impl Vector2f \\{", r"^    pub fn length\(&self\) -> Float \{"), "length", "Vector2f#inf", False),
     ("core/geometry.rs", r"^impl_op!\(\*= \|a: &mut Vector2f, b: Float\| \{", "vec2_mul_assign", "#inf", False),
@@ -808,6 +862,93 @@ extern "C" void flow_noise(const float* p, const float* dpdx, const float* dpdy,
         o[0] = orc::noise_flt(oq.x, oq.y, oq.z); o[1] = orc::fbm(oq, ox, oy, par[3 * i], oct); o[2] = orc::turbulence(oq, ox, oy, par[3 * i], oct); o[3] = orc::smooth_step(0.3f, 0.7f, par[3 * i + 2]);
         o[4] = t[4];      // (the oracle has no lanczos: MipMap::new's resampling is the host's; the value is checked against numpy in the test)
     }
+}
+"""
+
+MIPMAP_HOOK += r"""
+// the texture mappings and the procedural textures, text next to the oracle's tex_map2d / tex_map3d / tex_eval: tx[0] = the texture (children tx[1], tx[2]: constants), si: p(3) uv(2) dpdx(3) dpdy(3)
+// dudx dvdx dudy dvdy; out: value(3) | st(2) dstdx(2) dstdy(2) - | or p(3) dpdx(3) dpdy(3)
+extern "C" int flow_textures(const rspt_texture* tx, const float* si_in, uint64_t n, float* out_text, float* out_oracle) {
+    rspt_scene_desc d{}; d.textures = tx; d.n_textures = 3;
+    orc::Scene sc{d};
+    auto T = [&](const float* m) { Transform t{}; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) t.m.m[r][c] = Float(m[4 * r + c]); return t; };
+    const rspt_texture& x = tx[0];
+    TextureMapping2D m2{x.mapping, UVMapping2D{Float(x.map[0]), Float(x.map[1]), Float(x.map[2]), Float(x.map[3])}, SphericalMapping2D{T(x.world_to_texture)}, CylindricalMapping2D{T(x.world_to_texture)},
+                        PlanarMapping2D{Vector3f{Float(x.map[0]), Float(x.map[1]), Float(x.map[2])}, Vector3f{Float(x.map[3]), Float(x.map[4]), Float(x.map[5])}, Float(x.map[6]), Float(x.map[7])}};
+    TextureMapping3D m3{IdentityMapping3D{T(x.world_to_texture)}};
+    const TexConst<Spectrum> c1{flow::S3f(tx[1].value)}, c2{flow::S3f(tx[2].value)};
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = si_in + 15 * i;
+        FullInteraction si{};
+        si.common.p = Point3f{Float(q[0]), Float(q[1]), Float(q[2])}; si.uv = Point2f{Float(q[3]), Float(q[4])};
+        si.dpdx.v = Vector3f{Float(q[5]), Float(q[6]), Float(q[7])}; si.dpdy.v = Vector3f{Float(q[8]), Float(q[9]), Float(q[10])};
+        si.dudx.v = Float(q[11]); si.dvdx.v = Float(q[12]); si.dudy.v = Float(q[13]); si.dvdy.v = Float(q[14]);
+        orc::Interaction oi{}; oi.p = orc::V3{q[0], q[1], q[2]}; oi.uv = orc::P2{q[3], q[4]}; oi.dpdx = orc::V3{q[5], q[6], q[7]}; oi.dpdy = orc::V3{q[8], q[9], q[10]};
+        oi.dudx = q[11]; oi.dvdx = q[12]; oi.dudy = q[13]; oi.dvdy = q[14];
+        float* t = out_text + 12 * i; float* o = out_oracle + 12 * i;
+        for (int k = 0; k < 12; k++) t[k] = o[k] = 0.0f;
+        Spectrum v = Spectrum::new_(Float(0.0f));
+        switch (x.kind) {
+            case RSPT_TEX_MARBLE: v = MarbleTexture{m3, x.octaves, Float(x.omega), Float(x.scale), Float(x.variation)}.evaluate(si); break;
+            case RSPT_TEX_WINDY: v = Spectrum::new_(WindyTexture{m3}.evaluate(si)); break;
+            case RSPT_TEX_WRINKLED: v = Spectrum::new_(WrinkledTexture{m3, x.octaves, Float(x.omega)}.evaluate(si)); break;
+            case RSPT_TEX_FBM: v = Spectrum::new_(FBmTexture{m3, Float(x.omega), x.octaves}.evaluate(si)); break;
+            case RSPT_TEX_CHECKERBOARD: v = Checkerboard2DTexture{c1, c2, m2}.evaluate(si); break;
+            case RSPT_TEX_DOTS: v = DotsTexture{m2, c1, c2}.evaluate(si); break;
+            default: return -1;
+        }
+        const orc::Spec ov = orc::tex_eval(sc, 0, oi);
+        for (int k = 0; k < 3; k++) { t[k] = v.c[k].v; o[k] = ov.c[k]; }
+        if (x.mapping == RSPT_MAP_IDENTITY3D) {
+            Vector3f dx = vector3f_default(), dy = vector3f_default();
+            const Point3f pp = m3.map(si, &dx, &dy);
+            t[3] = pp.x.v; t[4] = pp.y.v; t[5] = pp.z.v; t[6] = dx.x.v; t[7] = dx.y.v; t[8] = dx.z.v; t[9] = dy.x.v; t[10] = dy.y.v; t[11] = dy.z.v;
+            orc::V3 ox, oy; const orc::V3 op = orc::tex_map3d(x, oi, &ox, &oy);
+            o[3] = op.x; o[4] = op.y; o[5] = op.z; o[6] = ox.x; o[7] = ox.y; o[8] = ox.z; o[9] = oy.x; o[10] = oy.y; o[11] = oy.z;
+        } else {
+            Vector2f dx = vector2f_default(), dy = vector2f_default();
+            const Point2f st = m2.map(si, &dx, &dy);
+            t[3] = st.x.v; t[4] = st.y.v; t[5] = dx.x.v; t[6] = dx.y.v; t[7] = dy.x.v; t[8] = dy.y.v;
+            orc::P2 ox, oy; const orc::P2 ost = orc::tex_map2d(x, oi, &ox, &oy);
+            o[3] = ost.x; o[4] = ost.y; o[5] = ox.x; o[6] = ox.y; o[7] = oy.x; o[8] = oy.y;
+        }
+    }
+    return 0;
+}
+"""
+
+MIPMAP_HOOK += r"""
+// Material::bump over a WrinkledTexture displacement (tx[0]) and SurfaceInteraction::set_shading_geometry, text next to the oracle's bump: si as flow_textures' 15 floats, then n(3) and the shading
+// frame n dpdu dpdv dndu dndv (15); out: shading n, dpdu, dpdv
+extern "C" int flow_bump(const rspt_texture* tx, const float* si_in, uint64_t n, float* out_text, float* out_oracle) {
+    rspt_scene_desc d{}; d.textures = tx; d.n_textures = 1;
+    orc::Scene sc{d};
+    const rspt_texture& x = tx[0];
+    if (x.kind != RSPT_TEX_WRINKLED) return -1;
+    Transform w2t{}; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) w2t.m.m[r][c] = Float(x.world_to_texture[4 * r + c]);
+    const WrinkledTexture wr{TextureMapping3D{IdentityMapping3D{w2t}}, x.octaves, Float(x.omega)};
+    const BumpTex bt{&wr};
+    auto V3f = [](const float* q) { return Vector3f{Float(q[0]), Float(q[1]), Float(q[2])}; }; auto N3f = [](const float* q) { return Normal3f{Float(q[0]), Float(q[1]), Float(q[2])}; };
+    auto O3 = [](const float* q) { return orc::V3{q[0], q[1], q[2]}; };
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = si_in + 33 * i;
+        FullInteraction si{};
+        si.common.p = Point3f{Float(q[0]), Float(q[1]), Float(q[2])}; si.uv = Point2f{Float(q[3]), Float(q[4])};
+        si.dpdx.v = V3f(q + 5); si.dpdy.v = V3f(q + 8);
+        si.dudx.v = Float(q[11]); si.dvdx.v = Float(q[12]); si.dudy.v = Float(q[13]); si.dvdy.v = Float(q[14]);
+        si.common.n = N3f(q + 15); si.shading.n = N3f(q + 18); si.shading.dpdu = V3f(q + 21); si.shading.dpdv = V3f(q + 24); si.shading.dndu = N3f(q + 27); si.shading.dndv = N3f(q + 30);
+        si.dndu = Normal3f{Float(0.0f), Float(0.0f), Float(0.0f)}; si.dndv = si.dndu;      // (a triangle's geometric dndu / dndv: triangle.rs)
+        material_bump(bt, si);
+        orc::Interaction oi{}; oi.p = O3(q); oi.uv = orc::P2{q[3], q[4]}; oi.dpdx = O3(q + 5); oi.dpdy = O3(q + 8);
+        oi.dudx = q[11]; oi.dvdx = q[12]; oi.dudy = q[13]; oi.dvdy = q[14];
+        oi.n = O3(q + 15); oi.sh_n = O3(q + 18); oi.sh_dpdu = O3(q + 21); oi.sh_dpdv = O3(q + 24); oi.sh_dndu = O3(q + 27); oi.sh_dndv = O3(q + 30);
+        orc::bump(sc, 0, &oi);
+        float* t = out_text + 9 * i; float* o = out_oracle + 9 * i;
+        t[0] = si.shading.n.x.v; t[1] = si.shading.n.y.v; t[2] = si.shading.n.z.v; t[3] = si.shading.dpdu.x.v; t[4] = si.shading.dpdu.y.v; t[5] = si.shading.dpdu.z.v;
+        t[6] = si.shading.dpdv.x.v; t[7] = si.shading.dpdv.y.v; t[8] = si.shading.dpdv.z.v;
+        o[0] = oi.sh_n.x; o[1] = oi.sh_n.y; o[2] = oi.sh_n.z; o[3] = oi.sh_dpdu.x; o[4] = oi.sh_dpdu.y; o[5] = oi.sh_dpdu.z; o[6] = oi.sh_dpdv.x; o[7] = oi.sh_dpdv.y; o[8] = oi.sh_dpdv.z;
+    }
+    return 0;
 }
 """
 
@@ -978,6 +1119,15 @@ def _convert_parts():
                 tab.update({"T": "Spectrum", "&T": "Spectrum", "isize": "int64_t", "Self": cls or "Float", "&dyn Interaction": "void*"})
             for tab in (TYPES, geom.TYPES, base.TYPES):
                 tab["&mut Vector2f"] = "Vector2f&"
+                tab["&SurfaceInteraction"] = "const FullInteraction&"
+                tab["&mut SurfaceInteraction"] = "FullInteraction&"
+                tab["&Arc<dyn Texture<Float> + Send + Sync>"] = "const BumpTex&"
+                tab["RGBSpectrum"] = "Spectrum"
+                if name.endswith("@Float"):
+                    tab["T"] = "Float"
+            name = name.split("@Float")[0]
+            if "textures/" in fname:
+                text = re.sub(r"\s+// .*$", "", text, flags=re.M)                 # a comment behind an argument
             if name == "vec2_mul_assign":           # `impl_op!(*= |a: &mut Vector2f, b: Float| { .. });` -> a function of that name (the call site's `*dst1 *= scale` names it, F23)
                 text = text.replace("impl_op!(*= |a: &mut Vector2f, b: Float| {", "fn vec2_mul_assign(a: &mut Vector2f, b: Float) {").replace("});", "}")
             if name == "lerp@Spectrum":             # F12 again: the generic lerp instantiated at S = Float, T = Spectrum (MipMap::lookup_pnt_flt blends two levels)
@@ -1014,7 +1164,10 @@ def _convert_parts():
             sig, body, params = base.signature(text)
             name = "clamp_t"
         else:
-            sig, body, params = geom.signature(text.replace("/* TODO: Float *uRemapped = nullptr */", ""), name, cls)
+            if text.startswith("impl_op_ex!"):
+                sig, body, params = base.signature(text)
+            else:
+                sig, body, params = geom.signature(text.replace("/* TODO: Float *uRemapped = nullptr */", ""), name, cls)
         if self_type:
             body = body.replace("self.", "self_.")
         body = join_multiline_if(body)
@@ -1023,6 +1176,8 @@ def _convert_parts():
         for nm in re.findall(r"Vector3f\* (\w+)", sig):        # F9: field access through a `&mut Vector3f` auto-dereferences; handing it on as `&Vector3f` re-borrows
             body = re.sub(r"(?<![\w>.])%s\.(?=[xyz]\b)" % nm, nm + "->", body)
             body = re.sub(r"(this->(?:f|pdf)\(\w+, )%s\)" % nm, r"\1*%s)" % nm, body)
+        if name == "set_shading_geometry":          # F27: a triangle's interaction carries no shape (interaction.rs:355-359: the orientation flip is the shape's)
+            body = drop_block(body, "if let Some(shape) = this->shape {")
         if name == "li" and cls == "PathIntegrator":
             body = drop_block(body, "if let Some(ref bssrdf) = isect.bssrdf {")
         if bvh and name in ("recursive_build", "flatten_bvh_tree", "init_interior"):

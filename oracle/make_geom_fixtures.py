@@ -45,6 +45,7 @@ FLOAT_EXTRA = """    Float(size_t x) : v((float)x) {}                           
     Float(int64_t x) : v((float)x) {}                            // `samples_per_pixel as Float` from i64
     explicit operator size_t() const { return (size_t)v; }       // `x as usize` (only met with small non-negative values here)
     explicit operator double() const { return (double)v; }      // `x as f64`
+    explicit operator uint32_t() const { return v != v ? 0u : (v >= 4294967296.0f ? 4294967295u : (v <= 0.0f ? 0u : (uint32_t)v)); }   // `x as u32` from f32: saturating, NaN -> 0
     Float ln() const { return Float(logf(v)); }                  // f32::ln is the platform libm's logf
     Float floor() const { return Float(floorf(v)); }
     Float ceil() const { return Float(ceilf(v)); }
@@ -95,11 +96,12 @@ struct InteractionCommon { Point3f p; Float time; Vector3f p_error; Vector3f wo;
 struct NoneOpt { bool is_some() const { return false; } };                                                       // an Option that is None in every case of this batch
 struct TriangleMesh { const uint32_t* vertex_indices; const Point3f* p; Slice<Normal3f> n{nullptr, 0}; bool reverse_orientation = false, transform_swaps_handedness = false;
                       Slice<Vector3f> s{nullptr, 0}; Slice<Point2f> uv{nullptr, 0}; NoneOpt alpha_mask; };
-struct CellV { mutable Vector3f v; static CellV new_(const Vector3f& x) { return CellV{x}; } void set(const Vector3f& x) const { v = x; } };
+struct CellV { mutable Vector3f v; static CellV new_(const Vector3f& x) { return CellV{x}; } void set(const Vector3f& x) const { v = x; } Vector3f get() const { return v; } };
 struct Shading { Normal3f n; Vector3f dpdu, dpdv; Normal3f dndu, dndv; };                                            // interaction.rs:120-127
 struct FullInteraction {                                                                                             // SurfaceInteraction (interaction.rs:129-170): what Triangle::intersect fills
     InteractionCommon common; Point2f uv; Vector3f dpdu, dpdv; Normal3f dndu, dndv; CellV dpdx, dpdy; Cell dudx, dvdx, dudy, dvdy; NoneT primitive; Shading shading; NoneT bsdf, shape;
     void compute_differentials(const Ray& ray);
+    void set_shading_geometry(const Vector3f& dpdus, const Vector3f& dpdvs, const Normal3f& dndus, const Normal3f& dndvs, bool orientation_is_authoritative);
 };
 static inline Vector3f Vector3f_from(const Point3f& p) { return Vector3f{p.x, p.y, p.z}; }                     // impl From<Point3f> for Vector3f (geometry.rs:606-614)
 bool solve_linear_system_2x2(std::array<std::array<Float, 2>, 2> a, std::array<Float, 2> b, Float* x0, Float* x1);

@@ -255,21 +255,23 @@ static inline P2 tex_map2d(const rspt_texture& tx, const Interaction& si, P2* ds
     case RSPT_MAP_SPHERICAL: {
         P2 st = map_sphere(tx, si.p);
         const Float delta = 0.1f;
+        const Float inv = 1.0f / delta; // `Vector2f / Float` multiplies by the reciprocal (geometry.rs:1281-1288): not the same bits as a division (found by the text pin, round 6)
         P2 sx = map_sphere(tx, si.p + si.dpdx * delta);
-        *dstdx = P2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        *dstdx = P2{(sx.x - st.x) * inv, (sx.y - st.y) * inv};
         P2 sy = map_sphere(tx, si.p + si.dpdy * delta);
-        *dstdy = P2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        *dstdy = P2{(sy.x - st.x) * inv, (sy.y - st.y) * inv};
         wrap_dt(dstdx); wrap_dt(dstdy);
         return st;
     }
     case RSPT_MAP_CYLINDRICAL: {
         P2 st = map_cylinder(tx, si.p);
         const Float delta = 0.01f;
+        const Float inv = 1.0f / delta; // (as above)
         P2 sx = map_cylinder(tx, si.p + si.dpdx * delta);
-        *dstdx = P2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        *dstdx = P2{(sx.x - st.x) * inv, (sx.y - st.y) * inv};
         wrap_dt(dstdx);
         P2 sy = map_cylinder(tx, si.p + si.dpdy * delta);
-        *dstdy = P2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        *dstdy = P2{(sy.x - st.x) * inv, (sy.y - st.y) * inv};
         wrap_dt(dstdy);
         return st;
     }

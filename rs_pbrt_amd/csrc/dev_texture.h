@@ -245,21 +245,23 @@ __device__ __noinline__ f2 tex_map2d_round(const rspt_texture& tx, const TexSurf
     if (tx.mapping == RSPT_MAP_SPHERICAL) {
         f2 st = map_sphere(tx, si.p);
         const float delta = 0.1f;
+        const float inv = 1.0f / delta;   // `Vector2f / Float` multiplies by the reciprocal (geometry.rs:1281-1288): not the same bits as a division
         f2 sx = map_sphere(tx, si.p + si.dpdx * delta);
-        *dstdx = f2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        *dstdx = f2{(sx.x - st.x) * inv, (sx.y - st.y) * inv};
         f2 sy = map_sphere(tx, si.p + si.dpdy * delta);
-        *dstdy = f2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        *dstdy = f2{(sy.x - st.x) * inv, (sy.y - st.y) * inv};
         wrap_dt(dstdx); wrap_dt(dstdy);
         return st;
     }
     if (tx.mapping == RSPT_MAP_CYLINDRICAL) {
         f2 st = map_cylinder(tx, si.p);
         const float delta = 0.01f;
+        const float inv = 1.0f / delta;   // (as above)
         f2 sx = map_cylinder(tx, si.p + si.dpdx * delta);
-        *dstdx = f2{(sx.x - st.x) / delta, (sx.y - st.y) / delta};
+        *dstdx = f2{(sx.x - st.x) * inv, (sx.y - st.y) * inv};
         wrap_dt(dstdx);
         f2 sy = map_cylinder(tx, si.p + si.dpdy * delta);
-        *dstdy = f2{(sy.x - st.x) / delta, (sy.y - st.y) / delta};
+        *dstdy = f2{(sy.x - st.x) * inv, (sy.y - st.y) * inv};
         wrap_dt(dstdy);
         return st;
     }

@@ -443,3 +443,67 @@ def test_noise_fbm_turbulence_text_equals_the_oracle(flow, oracle):
     assert np.abs(t[:, 0]).max() > 0.5 and (t[:256, 0] == 0).all() and t[:, 2].min() > 0         # gradient noise vanishes on the lattice; turbulence is a sum of magnitudes
     x = np.abs(par[:, 2].astype(np.float64)); ref = np.where(x < 1e-5, 1.0, np.where(x > 1, 0.0, np.sin(x * np.pi * 2) / np.maximum(x * np.pi * 2, 1e-30) * np.sin(x * np.pi) / np.maximum(x * np.pi, 1e-30)))
     assert np.abs(t[:, 4] - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("kind,mapping", [(abi.TEX_CHECKERBOARD, abi.MAP_UV), (abi.TEX_CHECKERBOARD, abi.MAP_PLANAR), (abi.TEX_DOTS, abi.MAP_SPHERICAL), (abi.TEX_DOTS, abi.MAP_CYLINDRICAL),
+                                          (abi.TEX_MARBLE, abi.MAP_IDENTITY3D), (abi.TEX_WINDY, abi.MAP_IDENTITY3D), (abi.TEX_WRINKLED, abi.MAP_IDENTITY3D), (abi.TEX_FBM, abi.MAP_IDENTITY3D)])
+def test_texture_mappings_and_procedural_textures_text_equals_the_oracle(flow, oracle, kind, mapping):
+    """UVMapping2D / SphericalMapping2D / CylindricalMapping2D / PlanarMapping2D / IdentityMapping3D::map (texture.rs:101-283, with the finite differences and the wrap fix-ups of the two
+    angular mappings) and Checkerboard2DTexture / DotsTexture / MarbleTexture / WindyTexture / WrinkledTexture / FBmTexture::evaluate (textures/*.rs) against the oracle's tex_map2d / tex_map3d /
+    tex_eval (which the device's texture code is held to)"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(kind * 16 + mapping)
+    tx = (abi.Texture * 3)()
+    tx[0].kind, tx[0].mapping, tx[0].tex1, tx[0].tex2 = kind, mapping, 1, 2
+    mp = rng.uniform(-2, 2, 8).astype(np.float32) if mapping == abi.MAP_PLANAR else np.array([3.0, 2.5, 0.25, -0.5, 0, 0, 0, 0], np.float32)
+    for k in range(8):
+        tx[0].map[k] = float(mp[k])
+    rot = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    w2t = np.eye(4); w2t[:3, :3] = rot * 1.7; w2t[:3, 3] = [0.3, -0.2, 0.1]
+    for k in range(16):
+        tx[0].world_to_texture[k] = float(np.float32(w2t.reshape(-1)[k]))
+    tx[0].octaves, tx[0].omega, tx[0].scale, tx[0].variation = 6, 0.5, 1.3, 0.2
+    for j, v in ((1, (1.0, 0.5, 0.25)), (2, (0.1, 0.2, 0.9))):
+        tx[j].kind = abi.TEX_CONSTANT
+        for k in range(3):
+            tx[j].value[k] = v[k]
+    n = 1 << 14
+    si = np.concatenate([rng.uniform(-4, 4, (n, 3)), rng.uniform(-1, 2, (n, 2)), rng.normal(size=(n, 6)) * np.exp(rng.uniform(-8, -1, (n, 1))), rng.normal(size=(n, 4)) * 0.01], 1).astype(np.float32)
+    si[:16, 5:] = 0.0
+    t, q = np.zeros((n, 12), np.float32), np.zeros((n, 12), np.float32)
+    L.flow_textures.restype = C.c_int
+    L.flow_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    assert L.flow_textures(C.addressof(tx), si.ctypes.data, n, t.ctypes.data, q.ctypes.data) == 0
+    bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+    assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
+    assert t[:, :3].std() > 0.01
+
+
+def test_bump_mapping_text_equals_the_oracle(flow, oracle):
+    """Material::bump (material.rs:116-219: the two shifted evaluations of the displacement, the step sizes from the uv differentials with the 0.0005 fall-back, the displaced dpdu / dpdv) and
+    SurfaceInteraction::set_shading_geometry (interaction.rs:345-370: the new shading normal, turned to the geometric side), over a WrinkledTexture displacement, against the oracle's bump"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(77)
+    tx = (abi.Texture * 1)()
+    tx[0].kind, tx[0].mapping = abi.TEX_WRINKLED, abi.MAP_IDENTITY3D
+    w2t = np.eye(4) * 2.5; w2t[3, 3] = 1
+    for k in range(16):
+        tx[0].world_to_texture[k] = float(w2t.reshape(-1)[k])
+    tx[0].octaves, tx[0].omega = 5, 0.6
+    n = 1 << 14
+    def unit(k):
+        v = rng.normal(size=(k, 3)); return v / np.linalg.norm(v, axis=1)[:, None]
+    nn = unit(n); sn = nn + rng.normal(size=(n, 3)) * 0.2; sn /= np.linalg.norm(sn, axis=1)[:, None]; sn[: n // 4] *= -1      # shading normals on either side of the geometric one
+    du = np.cross(sn, unit(n)); dv = np.cross(sn, du) * rng.uniform(0.5, 2, (n, 1))
+    si = np.concatenate([rng.uniform(-4, 4, (n, 3)), rng.uniform(0, 1, (n, 2)), rng.normal(size=(n, 6)) * np.exp(rng.uniform(-8, -2, (n, 1))), rng.normal(size=(n, 4)) * np.exp(rng.uniform(-8, -2, (n, 1))),
+                         nn, sn, du, dv, rng.normal(size=(n, 6)) * 0.1], 1).astype(np.float32)
+    si[:64, 11:15] = 0.0                                                           # no differentials: the 0.0005 step
+    t, q = np.zeros((n, 9), np.float32), np.zeros((n, 9), np.float32)
+    L.flow_bump.restype = C.c_int
+    L.flow_bump.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    assert L.flow_bump(C.addressof(tx), si.ctypes.data, n, t.ctypes.data, q.ctypes.data) == 0
+    bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+    assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
+    assert (np.abs(t[:, :3] - si[:, 18:21]).max(axis=1) > 1e-3).mean() > 0.5          # the bump turns the shading normal
