@@ -431,6 +431,16 @@ inline Float BumpTex::evaluate(const FullInteraction& si) const { return w->eval
 struct FBmTexture { TextureMapping3D mapping; Float omega; int32_t octaves; Float evaluate(const FullInteraction& si) const; };
 struct Checkerboard2DTexture { TexConst<Spectrum> tex1, tex2; TextureMapping2D mapping; Spectrum evaluate(const FullInteraction& si) const; };
 struct DotsTexture { TextureMapping2D mapping; TexConst<Spectrum> outside_dot, inside_dot; Spectrum evaluate(const FullInteraction& si) const; };
+// participating media (media/homogeneous.rs, core/medium.rs:301-328): carriers.  A MediumInteraction keeps what the path reads (p, wo, time; its medium / phase function are the medium's own, g)
+static inline Spectrum operator-(const Spectrum& a) { Spectrum r; for (int k = 0; k < 3; k++) r.c[k] = -a.c[k]; return r; }      // impl Neg for RGBSpectrum (spectrum.rs:1775-1782)
+static inline Spectrum spectrum_rgb(Float r, Float g, Float b) { Spectrum s; s.c[0] = r; s.c[1] = g; s.c[2] = b; return s; }    // RGBSpectrum::rgb: the three channels
+static const Float F32_MAX(3.40282347e+38f);
+struct MediumInteraction { Point3f p; Vector3f wo; Float time; };
+struct UPair { Float u[2]; int k = 0; Float get_1d() { return u[k++]; } };                               // the two draws HomogeneousMedium::sample takes from the sampler
+struct HomogeneousMedium { Spectrum sigma_a, sigma_s, sigma_t; Float g;
+    Spectrum tr(const Ray& ray, UPair& _sampler) const; std::pair<Spectrum, flow::Option<MediumInteraction>> sample(const Ray& ray, UPair& sampler) const; };
+struct HenyeyGreenstein { Float g; Float p(const Vector3f& wo, const Vector3f& wi) const; Float sample_p(const Vector3f& wo, Vector3f* wi, Point2f u) const; };
+Vector3f spherical_direction_vec3(Float sin_theta, Float cos_theta, Float phi, const Vector3f& x, const Vector3f& y, const Vector3f& z);
 // Perlin noise (core/texture.rs:21-48 the permutation table — converted from the text below —, 289-439)
 static const size_t NOISE_PERM_SIZE = 256;                                                            // texture.rs:21
 static const Float LOG2_E(1.44269504088896340735992468100189214f);                                    // std::f32::consts::LOG2_E
@@ -562,6 +572,16 @@ RULES_INF = [
     (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
     (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
+    # F28 the homogeneous medium: RGBSpectrum::rgb, f32::MAX, the channel selector, the interaction of a sampled distance (its medium and phase function are the medium's own: dropped), the result pair
+    (r"RGBSpectrum::rgb\(", "spectrum_rgb(", 0), (r"\bf32::MAX\b", "F32_MAX", 0),
+    (r"\(\((sampler\.get_1d\(\) \* 3\.0 as Float)\) as usize\)\.min\(2_usize\)", r"std::min<size_t>((size_t)(\1), 2)", 0),
+    (r"let channel_rgb: RGBEnum = match channel \{.*?\};", "const size_t channel_rgb = channel;      // (0 => Red, 1 => Green, _ => Blue: the index itself)", re.S),
+    (r"let mi_opt = if sampled_medium \{\s*let mi: MediumInteraction = MediumInteraction::new\(\s*&(.*?),\s*&\((.*?)\),\s*(.*?),\s*Some\(.*?\n\s*\);\s*Some\(mi\)\s*\} else \{\s*None\s*\};",
+     r"const flow::Option<MediumInteraction> mi_opt = sampled_medium ? flow::Option<MediumInteraction>{true, MediumInteraction{\1, \2, \3}} : flow::Option<MediumInteraction>{false, MediumInteraction{}};", re.S),
+    (r"for (\w+) in RGBEnum::iter\(\) \{", r"for (size_t \1 = 0; \1 < 3; \1++) {", 0),
+    (r"^(\s*)\((.*), mi_opt\)$", r"\1std::make_pair(\2, mi_opt)", re.M),
+    (r"\bray\.position\(", "ray_position(ray, ", 0),
+    (r"\b(sigma_t|density)\[(\w+)\]", r"\1.c[\2]", 0),      # impl Index<RGBEnum> for RGBSpectrum: the channel
     # F27 Material::bump: the evaluation copy of the interaction (the optional members a triangle's interaction does not carry are dropped), cells of vectors
     (r"let mut si_eval: SurfaceInteraction = SurfaceInteraction::default\(\);", "FullInteraction si_eval{};", 0),
     (r"if let Some\((?:ref )?\w+\) = &?si\.(?:common\.medium_interface|primitive|bsdf|shape) \{.*?\} else \{.*?\}", "", re.S),
@@ -803,6 +823,12 @@ SOURCES = [
     ("core/texture.rs", (r"^    pub fn cylinder\(&self", r"^    pub fn map\($"), "map", "CylindricalMapping2D#inf", False),
     ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
     ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
+    ("core/spectrum.rs", r"^    pub fn exp\(&self\) -> RGBSpectrum \{", "exp", "Spectrum#inf", False),
+    ("core/geometry.rs", r"^pub fn spherical_direction_vec3\($", "spherical_direction_vec3", "#inf", False),
+    ("core/medium.rs", ("^impl HenyeyGreenstein \\{", r"^    pub fn p\(&self"), "p", "HenyeyGreenstein#inf", False),
+    ("core/medium.rs", ("^impl HenyeyGreenstein \\{", r"^    pub fn sample_p\(&self"), "sample_p", "HenyeyGreenstein#inf", False),
+    ("media/homogeneous.rs", r"^    pub fn tr\(&self", "tr", "HomogeneousMedium#inf", False),
+    ("media/homogeneous.rs", r"^    pub fn sample\($", "sample", "HomogeneousMedium#inf", False),
     ("core/interaction.rs", r"^    pub fn set_shading_geometry\($", "set_shading_geometry", "FullInteraction#inf", False),
     ("core/material.rs", r"^    pub fn bump\(d: ", "material_bump", "#inf", False),
     ("textures/marble.rs", r"^    fn evaluate\(&self", "evaluate", "MarbleTexture#inf", False),
@@ -949,6 +975,42 @@ extern "C" int flow_bump(const rspt_texture* tx, const float* si_in, uint64_t n,
         o[0] = oi.sh_n.x; o[1] = oi.sh_n.y; o[2] = oi.sh_n.z; o[3] = oi.sh_dpdu.x; o[4] = oi.sh_dpdu.y; o[5] = oi.sh_dpdu.z; o[6] = oi.sh_dpdv.x; o[7] = oi.sh_dpdv.y; o[8] = oi.sh_dpdv.z;
     }
     return 0;
+}
+"""
+
+MIPMAP_HOOK += r"""
+// HomogeneousMedium::{tr, sample} and HenyeyGreenstein::{p, sample_p}, text next to the oracle's homogeneous_tr / homogeneous_sample / phase_hg / hg_sample_p.
+// in: ray o(3) d(3) t_max | u(2) | wo(3) wi(3) = 15 floats; out: tr(3) | factor(3) sampled p(3) wo(3) | p | sample_p wi(3) = 18 floats
+extern "C" void flow_media(const rspt_medium* m, const float* in, uint64_t n, float* out_text, float* out_oracle) {
+    const Spectrum sa = flow::S3f(m->sigma_a), ss = flow::S3f(m->sigma_s);
+    const HomogeneousMedium hm{sa, ss, ss + sa, Float(m->g)};           // HomogeneousMedium::new (homogeneous.rs:24-31): sigma_t = sigma_s + sigma_a
+    const HenyeyGreenstein hg{Float(m->g)};
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = in + 15 * i; float* t = out_text + 18 * i; float* o = out_oracle + 18 * i;
+        for (int k = 0; k < 18; k++) t[k] = o[k] = 0.0f;
+        Ray r{}; r.o = Point3f{Float(q[0]), Float(q[1]), Float(q[2])}; r.d = Vector3f{Float(q[3]), Float(q[4]), Float(q[5])}; r.t_max.v = Float(q[6]); r.time = Float(0.5f);
+        UPair up{{Float(q[7]), Float(q[8])}};
+        const Spectrum tr = hm.tr(r, up);
+        const std::pair<Spectrum, flow::Option<MediumInteraction>> sm = hm.sample(r, up);
+        for (int k = 0; k < 3; k++) { t[k] = tr.c[k].v; t[3 + k] = sm.first.c[k].v; }
+        t[6] = sm.second.is_some() ? 1.0f : 0.0f;
+        if (sm.second.is_some()) { const MediumInteraction mi = sm.second.unwrap(); t[7] = mi.p.x.v; t[8] = mi.p.y.v; t[9] = mi.p.z.v; t[10] = mi.wo.x.v; t[11] = mi.wo.y.v; t[12] = mi.wo.z.v; }
+        const Vector3f wo{Float(q[9]), Float(q[10]), Float(q[11])}, wi{Float(q[12]), Float(q[13]), Float(q[14])};
+        t[13] = hg.p(wo, wi).v;
+        Vector3f w = vector3f_default();
+        t[14] = hg.sample_p(wo, &w, Point2f{Float(q[7]), Float(q[8])}).v; t[15] = w.x.v; t[16] = w.y.v; t[17] = w.z.v;
+        orc::Ray orr{orc::V3{q[0], q[1], q[2]}, orc::V3{q[3], q[4], q[5]}, q[6], 0.5f};
+        const orc::Spec otr = orc::homogeneous_tr(*m, orr);
+        orc::Interaction omi{}; bool sampled = false;
+        const orc::Spec of = orc::homogeneous_sample(*m, 1, orr, q[7], q[8], &omi, &sampled);
+        for (int k = 0; k < 3; k++) { o[k] = otr.c[k]; o[3 + k] = of.c[k]; }
+        o[6] = sampled ? 1.0f : 0.0f;
+        if (sampled) { o[7] = omi.p.x; o[8] = omi.p.y; o[9] = omi.p.z; o[10] = omi.wo.x; o[11] = omi.wo.y; o[12] = omi.wo.z; }
+        const orc::V3 owo{q[9], q[10], q[11]}, owi{q[12], q[13], q[14]};
+        o[13] = orc::phase_hg(orc::dot(owo, owi), m->g);
+        orc::V3 ow{0, 0, 0};
+        o[14] = orc::hg_sample_p(m->g, owo, &ow, orc::P2{q[7], q[8]}); o[15] = ow.x; o[16] = ow.y; o[17] = ow.z;
+    }
 }
 """
 
@@ -1121,11 +1183,14 @@ def _convert_parts():
                 tab["&mut Vector2f"] = "Vector2f&"
                 tab["&SurfaceInteraction"] = "const FullInteraction&"
                 tab["&mut SurfaceInteraction"] = "FullInteraction&"
+                tab["&mut Sampler"] = "UPair&"
+                tab["MediumPair"] = "std::pair<Spectrum, flow::Option<MediumInteraction>>"
                 tab["&Arc<dyn Texture<Float> + Send + Sync>"] = "const BumpTex&"
                 tab["RGBSpectrum"] = "Spectrum"
                 if name.endswith("@Float"):
                     tab["T"] = "Float"
             name = name.split("@Float")[0]
+            text = text.replace("-> (Spectrum, Option<MediumInteraction>) {", "-> MediumPair {")
             if "textures/" in fname:
                 text = re.sub(r"\s+// .*$", "", text, flags=re.M)                 # a comment behind an argument
             if name == "vec2_mul_assign":           # `impl_op!(*= |a: &mut Vector2f, b: Float| { .. });` -> a function of that name (the call site's `*dst1 *= scale` names it, F23)

@@ -507,3 +507,31 @@ def test_bump_mapping_text_equals_the_oracle(flow, oracle):
     bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
     assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
     assert (np.abs(t[:, :3] - si[:, 18:21]).max(axis=1) > 1e-3).mean() > 0.5          # the bump turns the shading normal
+
+
+@pytest.mark.parametrize("g", [0.0, 0.0005, 0.6, -0.85])
+def test_homogeneous_medium_and_henyey_greenstein_text_equals_the_oracle(flow, oracle, g):
+    """HomogeneousMedium::{tr, sample} (homogeneous.rs:33-91: the channel choice, the sampled distance, the medium interaction, transmittance / density / the throughput factor) and
+    HenyeyGreenstein::{p, sample_p} (medium.rs:301-328, both branches of |g| < 1e-3) with spherical_direction_vec3 and Spectrum::exp, against the oracle's (which VolPath on the device is held to)"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(int(abs(g) * 1000) + 3)
+    m = abi.Medium()
+    for k in range(3):
+        m.sigma_a[k] = float(np.float32(rng.uniform(0.0, 2.0))); m.sigma_s[k] = float(np.float32(rng.uniform(0.05, 4.0)))
+    m.sigma_a[1] = 0.0
+    m.g = g
+    n = 1 << 15
+    def unit(k):
+        v = rng.normal(size=(k, 3)); return v / np.linalg.norm(v, axis=1)[:, None]
+    d = unit(n) * np.exp(rng.uniform(-2, 2, (n, 1)))
+    tmax = np.exp(rng.uniform(-4, 3, n)); tmax[:64] = np.inf
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32).clip(0, np.nextafter(np.float32(1), np.float32(0))); u[:16, 1] = 0.0; u[16:32, 0] = 0.0
+    x = np.concatenate([rng.uniform(-3, 3, (n, 3)), d, tmax[:, None], u, unit(n), unit(n)], 1).astype(np.float32)
+    t, q = np.zeros((n, 18), np.float32), np.zeros((n, 18), np.float32)
+    L.flow_media.restype = None
+    L.flow_media.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.flow_media(C.addressof(m), x.ctypes.data, n, t.ctypes.data, q.ctypes.data)
+    bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+    assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
+    assert 0.1 < t[:, 6].mean() < 0.95 and t[:, 13].min() > 0
