@@ -43,9 +43,21 @@ struct Transform {
     Point3f transform_point(const Point3f& p) const; Vector3f transform_vector(const Vector3f& v) const; Point3f transform_point_with_error(const Point3f& p, Vector3f* p_error) const; Ray transform_ray(const Ray& r) const;
     static Transform default_() { return Transform{}; }
 };
-struct AnimatedTransform {                      // transform.rs:894-930: a camera that does not move has actually_animated = false
-    Transform start_transform, end_transform; Float start_time, end_time; bool actually_animated;
-    void interpolate(Float, Transform*) const { abort(); }
+struct Quaternion { Vector3f v; Float w; static Quaternion new_(Transform t); Transform to_transform() const; };      // quaternion.rs:27-31
+// impl Add / Sub / Mul<Float> / Div<Float> / Neg for Quaternion (quaternion.rs:111-166): component-wise through Vector3f's operators (the reference's text) and Float's
+static inline Quaternion operator+(const Quaternion& a, const Quaternion& b) { return Quaternion{a.v + b.v, a.w + b.w}; }
+static inline Quaternion operator-(const Quaternion& a, const Quaternion& b) { return Quaternion{a.v - b.v, a.w - b.w}; }
+static inline Quaternion operator*(const Quaternion& a, Float b) { return Quaternion{a.v * b, a.w * b}; }
+static inline Quaternion operator/(const Quaternion& a, Float b) { return Quaternion{a.v / b, a.w / b}; }
+static inline Quaternion operator-(const Quaternion& a) { return Quaternion{-a.v, -a.w}; }
+static inline Matrix4x4 matrix4x4_default() { return Matrix4x4::new_(1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0); }      // impl Default for Matrix4x4 (transform.rs:77-88): the identity
+Matrix4x4 matrix4x4_inverse(const Matrix4x4& m); Matrix4x4 matrix4x4_transpose(const Matrix4x4& m); Matrix4x4 mtx_mul(const Matrix4x4& m1, const Matrix4x4& m2);
+Transform transform_mul(Transform a, Transform rhs); Transform transform_translate(const Vector3f& delta);
+static inline Transform operator*(const Transform& a, const Transform& b) { return transform_mul(a, b); }      // impl Mul for Transform (transform.rs:869-877): the text's
+Float quat_dot_quat(const Quaternion& q1, const Quaternion& q2); Quaternion quat_normalize(const Quaternion& q); Quaternion quat_slerp(Float t, const Quaternion& q1, const Quaternion& q2);
+struct AnimatedTransform {                      // transform.rs:894-909 (without the derivative terms, pinned in round 5): a camera that does not move has actually_animated = false
+    Transform start_transform, end_transform; Float start_time, end_time; bool actually_animated; Vector3f t[2]; Quaternion r[2]; Matrix4x4 s[2]; bool has_rotation;
+    void interpolate(Float time, Transform* t) const; static void decompose(const Matrix4x4& m, Vector3f* t, Quaternion* rquat, Matrix4x4* s);
     Ray transform_ray(const Ray& r) const;
 };
 struct PerspectiveCamera {                      // perspective.rs:21-47 (with CameraBase's fields)
@@ -572,6 +584,18 @@ RULES_INF = [
     (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
     (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
+    # F29 the moving transform: static methods of Matrix4x4 / Transform as functions, the identity default, literals of Transform / Quaternion / a 4 x 4 array, `loop`, a zeroed float array
+    (r"Matrix4x4::transpose\(", "matrix4x4_transpose(", 0), (r"Matrix4x4::inverse\(", "matrix4x4_inverse(", 0), (r"Matrix4x4::default\(\)", "matrix4x4_default()", 0),
+    (r"Transform::translate\(", "transform_translate(", 0), (r"\.clone\(\)", "", 0),
+    (r"Matrix4x4 \{\s*m: \[\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\],\s*\}", r"Matrix4x4::new_(\1, \2, \3, \4)", re.S),
+    (r"Transform \{\s*m: (.*?),\s*m_inv: (.*?),\s*\}", r"Transform{\1, \2}", re.S),
+    (r"Quaternion \{\s*v: (Vector3f \{.*?\}),\s*w,\s*\}", r"Quaternion{\1, w}", re.S),
+    (r"^(\s*)loop \{$", r"\1for (;;) {", re.M),
+    (r"let mut (\w+): \[Float; 3\] = \[0\.0; 3\];", r"Float \1[3] = {};", 0),
+    (r"let mut (\w+) = if (.*?) \{ (\d+) \} else \{ (\d+) \};", r"size_t \1 = (\2) ? \3 : \4;", 0),
+    (r"let mut (\w+): Float;", r"Float \1;", 0),
+    (r"let (?:mut )?(\w+): (Matrix4x4|Quaternion|Transform) = ", r"\2 \1 = ", 0),
+    (r"\b(rquat|s)\b = ", r"\1 = ", 0),
     # F28 the homogeneous medium: RGBSpectrum::rgb, f32::MAX, the channel selector, the interaction of a sampled distance (its medium and phase function are the medium's own: dropped), the result pair
     (r"RGBSpectrum::rgb\(", "spectrum_rgb(", 0), (r"\bf32::MAX\b", "F32_MAX", 0),
     (r"\(\((sampler\.get_1d\(\) \* 3\.0 as Float)\) as usize\)\.min\(2_usize\)", r"std::min<size_t>((size_t)(\1), 2)", 0),
@@ -823,6 +847,18 @@ SOURCES = [
     ("core/texture.rs", (r"^    pub fn cylinder\(&self", r"^    pub fn map\($"), "map", "CylindricalMapping2D#inf", False),
     ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
     ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
+    # the moving transform: decomposition into T R S and the interpolation at a time
+    ("core/transform.rs", r"^pub fn mtx_mul\(", "mtx_mul", "#inf", False),
+    ("core/transform.rs", r"^    pub fn transpose\(m: &Matrix4x4\) -> Matrix4x4 \{", "matrix4x4_transpose", "#inf", False),
+    ("core/transform.rs", r"^    pub fn translate\(delta: &Vector3f\) -> Transform \{", "transform_translate", "#inf", False),
+    ("core/transform.rs", ("^impl Mul for Transform \\{", r"^    fn mul\(self, rhs: Transform\) -> Transform \{"), "transform_mul", "#inf", False),
+    ("core/quaternion.rs", r"^    pub fn new\(t: Transform\) -> Self \{", "new_", "Quaternion#inf", False),
+    ("core/quaternion.rs", r"^    pub fn to_transform\(&self\) -> Transform \{", "to_transform", "Quaternion#inf", False),
+    ("core/quaternion.rs", r"^pub fn quat_slerp\(", "quat_slerp", "#inf", False),
+    ("core/quaternion.rs", r"^pub fn quat_dot_quat\(", "quat_dot_quat", "#inf", False),
+    ("core/quaternion.rs", r"^pub fn quat_normalize\(", "quat_normalize", "#inf", False),
+    ("core/transform.rs", r"^    pub fn decompose\(m: &Matrix4x4", "decompose", "AnimatedTransform#inf", False),
+    ("core/transform.rs", r"^    pub fn interpolate\(&self, time: Float, t: &mut Transform\) \{", "interpolate", "AnimatedTransform#inf", False),
     ("core/spectrum.rs", r"^    pub fn exp\(&self\) -> RGBSpectrum \{", "exp", "Spectrum#inf", False),
     ("core/geometry.rs", r"^pub fn spherical_direction_vec3\($", "spherical_direction_vec3", "#inf", False),
     ("core/medium.rs", ("^impl HenyeyGreenstein \\{", r"^    pub fn p\(&self"), "p", "HenyeyGreenstein#inf", False),
@@ -1014,6 +1050,35 @@ extern "C" void flow_media(const rspt_medium* m, const float* in, uint64_t n, fl
 }
 """
 
+MIPMAP_HOOK += r"""
+// AnimatedTransform::new's decomposition (decompose twice, the quaternion flip, has_rotation: transform.rs:911-932) and interpolate, text next to the oracle's AnimatedTransform.
+// in: start(16) end(16) row major; times: n values in [t0 - , t1 + ]; out per time: m(16) m_inv(16); dec: t0(3) r0(4) s0(9) t1(3) r1(4) s1(9) has_rotation = 33
+extern "C" void flow_animated(const float* start, const float* end, float t0, float t1, const float* times, uint64_t n, float* out_text, float* out_oracle, float* dec_text, float* dec_oracle) {
+    auto M = [](const float* m) { Matrix4x4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = Float(m[4 * i + j]); return r; };
+    AnimatedTransform at{};
+    at.start_transform = Transform{M(start), matrix4x4_inverse(M(start))}; at.end_transform = Transform{M(end), matrix4x4_inverse(M(end))};
+    at.start_time = Float(t0); at.end_time = Float(t1); at.actually_animated = std::memcmp(start, end, 64) != 0;
+    AnimatedTransform::decompose(at.start_transform.m, &at.t[0], &at.r[0], &at.s[0]);
+    AnimatedTransform::decompose(at.end_transform.m, &at.t[1], &at.r[1], &at.s[1]);
+    if (quat_dot_quat(at.r[0], at.r[1]) < Float(0.0f)) at.r[1] = -at.r[1];      // transform.rs:927-930: the shortest path
+    at.has_rotation = quat_dot_quat(at.r[0], at.r[1]) < Float(0.9995f);
+    const orc::AnimatedTransform oa(start, t0, end, t1);
+    const orc::M44 osi = orc::m44_inverse(orc::m44_from(start)), oei = orc::m44_inverse(orc::m44_from(end));
+    for (int k = 0; k < 2; k++) {
+        float* d = dec_text + 16 * k; float* o = dec_oracle + 16 * k;
+        d[0] = at.t[k].x.v; d[1] = at.t[k].y.v; d[2] = at.t[k].z.v; d[3] = at.r[k].v.x.v; d[4] = at.r[k].v.y.v; d[5] = at.r[k].v.z.v; d[6] = at.r[k].w.v;
+        o[0] = oa.t[k].x; o[1] = oa.t[k].y; o[2] = oa.t[k].z; o[3] = oa.r[k].v.x; o[4] = oa.r[k].v.y; o[5] = oa.r[k].v.z; o[6] = oa.r[k].w;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { d[7 + 3 * i + j] = at.s[k].m[i][j].v; o[7 + 3 * i + j] = oa.s[k].m[i][j]; }
+    }
+    dec_text[32] = at.has_rotation ? 1.0f : 0.0f; dec_oracle[32] = oa.has_rotation ? 1.0f : 0.0f;
+    for (uint64_t i = 0; i < n; i++) {
+        Transform t{}; at.interpolate(Float(times[i]), &t);
+        orc::M44 om, oi; oa.interpolate_full(times[i], osi, oei, &om, &oi);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { out_text[32 * i + 4 * r + c] = t.m.m[r][c].v; out_text[32 * i + 16 + 4 * r + c] = t.m_inv.m[r][c].v; out_oracle[32 * i + 4 * r + c] = om.m[r][c]; out_oracle[32 * i + 16 + 4 * r + c] = oi.m[r][c]; }
+    }
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
@@ -1184,6 +1249,7 @@ def _convert_parts():
                 tab["&SurfaceInteraction"] = "const FullInteraction&"
                 tab["&mut SurfaceInteraction"] = "FullInteraction&"
                 tab["&mut Sampler"] = "UPair&"
+                tab.update({"Quaternion": "Quaternion", "&Quaternion": "const Quaternion&", "&mut Quaternion": "Quaternion*", "Matrix4x4": "Matrix4x4", "&Matrix4x4": "const Matrix4x4&", "&mut Matrix4x4": "Matrix4x4*"})
                 tab["MediumPair"] = "std::pair<Spectrum, flow::Option<MediumInteraction>>"
                 tab["&Arc<dyn Texture<Float> + Send + Sync>"] = "const BumpTex&"
                 tab["RGBSpectrum"] = "Spectrum"
@@ -1191,6 +1257,8 @@ def _convert_parts():
                     tab["T"] = "Float"
             name = name.split("@Float")[0]
             text = text.replace("-> (Spectrum, Option<MediumInteraction>) {", "-> MediumPair {")
+            if name == "transform_mul":              # `impl Mul for Transform { fn mul(self, rhs) }` -> a function of two transforms (the carrier's operator* names it)
+                text = text.replace("fn mul(self, rhs: Transform)", "fn transform_mul(a: Transform, rhs: Transform)").replace("self.", "a.")
             if "textures/" in fname:
                 text = re.sub(r"\s+// .*$", "", text, flags=re.M)                 # a comment behind an argument
             if name == "vec2_mul_assign":           # `impl_op!(*= |a: &mut Vector2f, b: Float| { .. });` -> a function of that name (the call site's `*dst1 *= scale` names it, F23)

@@ -535,3 +535,41 @@ def test_homogeneous_medium_and_henyey_greenstein_text_equals_the_oracle(flow, o
     bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
     assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
     assert 0.1 < t[:, 6].mean() < 0.95 and t[:, 13].min() > 0
+
+
+def test_animated_transform_decomposition_and_interpolation_text_equals_the_oracle(flow, oracle):
+    """AnimatedTransform::decompose (transform.rs:2032-2080: the polar iteration over Matrix4x4::inverse / transpose, Quaternion::new on either branch of the trace, the scale), the quaternion
+    flip and has_rotation of AnimatedTransform::new, and AnimatedTransform::interpolate (:2081-2113) over quat_slerp (both branches), Quaternion::to_transform, Transform::translate, the
+    Transform product and mtx_mul — against the oracle's AnimatedTransform (which the moving camera and the moving instances on the device are held to): the interpolated matrix AND its inverse"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(91)
+    L.flow_animated.restype = None
+    L.flow_animated.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
+
+    def rot(axis, ang):
+        axis = axis / np.linalg.norm(axis); x, y, z = axis; c, s_ = np.cos(ang), np.sin(ang); k = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+        return np.eye(3) + s_ * k + (1 - c) * (k @ k)
+    n_pairs, n_rot, n_small = 0, 0, 0
+    for trial in range(200):
+        def key(small):
+            m = np.eye(4)
+            ang = rng.uniform(0, 0.02) if small else rng.uniform(0, 3.1)
+            m[:3, :3] = rot(rng.normal(size=3), ang) @ np.diag(rng.uniform(0.3, 3, 3) if trial % 3 else np.ones(3) * rng.uniform(0.5, 2))
+            if trial % 7 == 0:
+                m[:3, :3] = m[:3, :3] @ (np.eye(3) + rng.normal(size=(3, 3)) * 0.1)          # shear: S is not diagonal
+            m[:3, 3] = rng.uniform(-5, 5, 3)
+            return m.astype(np.float32)
+        a = key(False); b = key(trial % 5 == 0) if trial % 11 else a.copy()
+        if trial % 5 == 0:
+            b[:3, :3] = (a[:3, :3].astype(np.float64) @ rot(rng.normal(size=3), rng.uniform(0, 0.02))).astype(np.float32)          # nearly the same rotation: the nlerp branch of quat_slerp
+        t0, t1 = 0.25, 1.5
+        times = np.concatenate([[0.0, 0.25, 1.5, 2.0], rng.uniform(t0, t1, 60)]).astype(np.float32)
+        n = len(times)
+        ot, oo = np.zeros((n, 32), np.float32), np.zeros((n, 32), np.float32); dt, do = np.zeros(33, np.float32), np.zeros(33, np.float32)
+        L.flow_animated(a.ctypes.data, b.ctypes.data, t0, t1, times.ctypes.data, n, ot.ctypes.data, oo.ctypes.data, dt.ctypes.data, do.ctypes.data)
+        assert np.array_equal(dt.view(np.uint32), do.view(np.uint32)), (trial, dt, do)
+        bad = (ot.view(np.uint32) != oo.view(np.uint32)) & ~(np.isnan(ot) & np.isnan(oo))
+        assert not bad.any(), (trial, int(bad.sum()))
+        n_pairs += 1; n_rot += int(dt[32]); n_small += int(dt[32] == 0)
+    assert n_rot > 100 and n_small > 20
