@@ -42,6 +42,7 @@ struct Transform {
     Matrix4x4 m, m_inv;
     Point3f transform_point(const Point3f& p) const; Vector3f transform_vector(const Vector3f& v) const; Point3f transform_point_with_error(const Point3f& p, Vector3f* p_error) const; Ray transform_ray(const Ray& r) const;
     static Transform default_() { return Transform{}; }
+    Point3f transform_point_with_abs_error(const Point3f& pt, const Vector3f& pt_error, Vector3f* abs_error) const; Normal3f transform_normal(const Normal3f& n) const; void transform_surface_interaction(FullInteraction& si) const;
 };
 struct Quaternion { Vector3f v; Float w; static Quaternion new_(Transform t); Transform to_transform() const; };      // quaternion.rs:27-31
 // impl Add / Sub / Mul<Float> / Div<Float> / Neg for Quaternion (quaternion.rs:111-166): component-wise through Vector3f's operators (the reference's text) and Float's
@@ -607,7 +608,10 @@ RULES_INF = [
     (r"\bray\.position\(", "ray_position(ray, ", 0),
     (r"\b(sigma_t|density)\[(\w+)\]", r"\1.c[\2]", 0),      # impl Index<RGBEnum> for RGBSpectrum: the channel
     # F27 Material::bump: the evaluation copy of the interaction (the optional members a triangle's interaction does not carry are dropped), cells of vectors
-    (r"let mut si_eval: SurfaceInteraction = SurfaceInteraction::default\(\);", "FullInteraction si_eval{};", 0),
+    (r"let mut (si_eval|ret): SurfaceInteraction = SurfaceInteraction::default\(\);", r"FullInteraction \1{};", 0),
+    (r"Cell::new\((si\.d[uv]d[xy]\.get\(\))\)", r"Cell::new_(\1)", 0),
+    (r"ret\.(shape|primitive) = None;", r"ret.\1 = NoneT{};", 0),
+    (r"\b(Normal3f|Point3f) \{\s*x: (.*?),\s*y: (.*?),\s*z: (.*?),?\s*\}", r"\1{\2, \3, \4}", re.S),
     (r"if let Some\((?:ref )?\w+\) = &?si\.(?:common\.medium_interface|primitive|bsdf|shape) \{.*?\} else \{.*?\}", "", re.S),
     (r"Cell::new\((si\.dpd[xy]\.get\(\))\)", r"CellV::new_(\1)", 0),
     (r"Normal3f::from\(", "Normal3f_from(", 0),
@@ -847,6 +851,10 @@ SOURCES = [
     ("core/texture.rs", (r"^    pub fn cylinder\(&self", r"^    pub fn map\($"), "map", "CylindricalMapping2D#inf", False),
     ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
     ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
+    # instancing: an instance's hit taken to world space
+    ("core/transform.rs", r"^    pub fn transform_point_with_abs_error\($", "transform_point_with_abs_error", "Transform#inf", False),
+    ("core/transform.rs", r"^    pub fn transform_normal\(&self, n: &Normal3f\) -> Normal3f \{", "transform_normal", "Transform#inf", False),
+    ("core/transform.rs", r"^    pub fn transform_surface_interaction\(&self, si: &mut SurfaceInteraction\) \{", "transform_surface_interaction", "Transform#inf", False),
     # the moving transform: decomposition into T R S and the interpolation at a time
     ("core/transform.rs", r"^pub fn mtx_mul\(", "mtx_mul", "#inf", False),
     ("core/transform.rs", r"^    pub fn transpose\(m: &Matrix4x4\) -> Matrix4x4 \{", "matrix4x4_transpose", "#inf", False),
@@ -1075,6 +1083,37 @@ extern "C" void flow_animated(const float* start, const float* end, float t0, fl
         Transform t{}; at.interpolate(Float(times[i]), &t);
         orc::M44 om, oi; oa.interpolate_full(times[i], osi, oei, &om, &oi);
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { out_text[32 * i + 4 * r + c] = t.m.m[r][c].v; out_text[32 * i + 16 + 4 * r + c] = t.m_inv.m[r][c].v; out_oracle[32 * i + 4 * r + c] = om.m[r][c]; out_oracle[32 * i + 16 + 4 * r + c] = oi.m[r][c]; }
+    }
+}
+"""
+
+MIPMAP_HOOK += r"""
+// Transform::transform_surface_interaction (an instance's hit taken to world space) over transform_point_with_abs_error / transform_normal / transform_vector, text next to the oracle's.
+// si: p p_error n wo (12) time uv(2) dpdu dpdv (6) sh: n dpdu dpdv dndu dndv (15) dudx dvdx dudy dvdy dpdx dpdy (10) = 46; out: p p_error n wo dpdu dpdv sh_n sh_dpdu sh_dpdv sh_dndu sh_dndv = 33
+extern "C" void flow_instance(const float* m, const float* mi, const float* si_in, uint64_t n, float* out_text, float* out_oracle) {
+    Transform tr{}; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { tr.m.m[r][c] = Float(m[4 * r + c]); tr.m_inv.m[r][c] = Float(mi[4 * r + c]); }
+    auto V3f = [](const float* q) { return Vector3f{Float(q[0]), Float(q[1]), Float(q[2])}; }; auto N3f = [](const float* q) { return Normal3f{Float(q[0]), Float(q[1]), Float(q[2])}; };
+    auto O3 = [](const float* q) { return orc::V3{q[0], q[1], q[2]}; };
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = si_in + 46 * i;
+        FullInteraction si{};
+        si.common.p = Point3f{Float(q[0]), Float(q[1]), Float(q[2])}; si.common.p_error = V3f(q + 3); si.common.n = N3f(q + 6); si.common.wo = V3f(q + 9); si.common.time = Float(q[12]);
+        si.uv = Point2f{Float(q[13]), Float(q[14])}; si.dpdu = V3f(q + 15); si.dpdv = V3f(q + 18);
+        si.shading.n = N3f(q + 21); si.shading.dpdu = V3f(q + 24); si.shading.dpdv = V3f(q + 27); si.shading.dndu = N3f(q + 30); si.shading.dndv = N3f(q + 33);
+        si.dudx.v = Float(q[36]); si.dvdx.v = Float(q[37]); si.dudy.v = Float(q[38]); si.dvdy.v = Float(q[39]); si.dpdx.v = V3f(q + 40); si.dpdy.v = V3f(q + 43);
+        si.dndu = Normal3f{Float(0.0f), Float(0.0f), Float(0.0f)}; si.dndv = si.dndu;
+        tr.transform_surface_interaction(si);
+        orc::Interaction oi{}; oi.p = O3(q); oi.p_error = O3(q + 3); oi.n = O3(q + 6); oi.wo = O3(q + 9); oi.time = q[12]; oi.uv = orc::P2{q[13], q[14]}; oi.dpdu = O3(q + 15); oi.dpdv = O3(q + 18);
+        oi.sh_n = O3(q + 21); oi.sh_dpdu = O3(q + 24); oi.sh_dpdv = O3(q + 27); oi.sh_dndu = O3(q + 30); oi.sh_dndv = O3(q + 33);
+        oi.dudx = q[36]; oi.dvdx = q[37]; oi.dudy = q[38]; oi.dvdy = q[39]; oi.dpdx = O3(q + 40); oi.dpdy = O3(q + 43);
+        orc::Scene::transform_surface_interaction(m, mi, &oi);
+        float* t = out_text + 33 * i; float* o = out_oracle + 33 * i;
+        auto put = [](float* d, const Vector3f& v) { d[0] = v.x.v; d[1] = v.y.v; d[2] = v.z.v; }; auto putn = [](float* d, const Normal3f& v) { d[0] = v.x.v; d[1] = v.y.v; d[2] = v.z.v; };
+        auto puto = [](float* d, const orc::V3& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; };
+        t[0] = si.common.p.x.v; t[1] = si.common.p.y.v; t[2] = si.common.p.z.v; put(t + 3, si.common.p_error); putn(t + 6, si.common.n); put(t + 9, si.common.wo); put(t + 12, si.dpdu); put(t + 15, si.dpdv);
+        putn(t + 18, si.shading.n); put(t + 21, si.shading.dpdu); put(t + 24, si.shading.dpdv); putn(t + 27, si.shading.dndu); putn(t + 30, si.shading.dndv);
+        puto(o, oi.p); puto(o + 3, oi.p_error); puto(o + 6, oi.n); puto(o + 9, oi.wo); puto(o + 12, oi.dpdu); puto(o + 15, oi.dpdv);
+        puto(o + 18, oi.sh_n); puto(o + 21, oi.sh_dpdu); puto(o + 24, oi.sh_dpdv); puto(o + 27, oi.sh_dndu); puto(o + 30, oi.sh_dndv);
     }
 }
 """

@@ -573,3 +573,28 @@ def test_animated_transform_decomposition_and_interpolation_text_equals_the_orac
         assert not bad.any(), (trial, int(bad.sum()))
         n_pairs += 1; n_rot += int(dt[32]); n_small += int(dt[32] == 0)
     assert n_rot > 100 and n_small > 20
+
+
+def test_transform_surface_interaction_text_equals_the_oracle(flow, oracle):
+    """Transform::transform_surface_interaction (transform.rs:815-860: what a TransformedPrimitive does to an instance's hit) over transform_point_with_abs_error (:709-760, the error bound
+    and the homogeneous divide), transform_normal (:528-537, the transposed inverse), transform_vector and nrm_faceforward_nrm, against the oracle's (which instancing on the device is held to)"""
+    import ctypes as C
+    mk, L = flow
+    rng = np.random.default_rng(57)
+    L.flow_instance.restype = None
+    L.flow_instance.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    n = 1 << 12
+    for trial in range(12):
+        a = np.eye(4); a[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0] @ np.diag(rng.uniform(0.3, 3, 3) * (1 if trial % 3 else -1)); a[:3, 3] = rng.uniform(-10, 10, 3)
+        if trial == 5:
+            a[3, :] = [0.01, -0.02, 0.005, 1.1]                                       # a projective row: the homogeneous divide
+        m = a.astype(np.float32); mi = np.linalg.inv(m.astype(np.float64)).astype(np.float32)
+        def unit(k):
+            v = rng.normal(size=(k, 3)); return v / np.linalg.norm(v, axis=1)[:, None]
+        nn = unit(n); sn = nn + rng.normal(size=(n, 3)) * 0.3; sn[: n // 3] *= -1
+        si = np.concatenate([rng.uniform(-5, 5, (n, 3)), np.abs(rng.normal(size=(n, 3))) * 1e-6, nn, unit(n), rng.uniform(0, 1, (n, 1)), rng.uniform(0, 1, (n, 2)), rng.normal(size=(n, 6)),
+                             sn, rng.normal(size=(n, 6)), rng.normal(size=(n, 6)) * 0.1, rng.normal(size=(n, 4)) * 0.01, rng.normal(size=(n, 6)) * 0.01], 1).astype(np.float32)
+        t, q = np.zeros((n, 33), np.float32), np.zeros((n, 33), np.float32)
+        L.flow_instance(m.ctypes.data, mi.ctypes.data, si.ctypes.data, n, t.ctypes.data, q.ctypes.data)
+        bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+        assert not bad.any(), (trial, int(bad.sum()), sorted(set(np.where(bad)[1].tolist())))
