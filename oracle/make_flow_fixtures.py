@@ -42,6 +42,7 @@ struct Transform {
     Matrix4x4 m, m_inv;
     Point3f transform_point(const Point3f& p) const; Vector3f transform_vector(const Vector3f& v) const; Point3f transform_point_with_error(const Point3f& p, Vector3f* p_error) const; Ray transform_ray(const Ray& r) const;
     static Transform default_() { return Transform{}; }
+    bool is_identity() const;
     Point3f transform_point_with_abs_error(const Point3f& pt, const Vector3f& pt_error, Vector3f* abs_error) const; Normal3f transform_normal(const Normal3f& n) const; void transform_surface_interaction(FullInteraction& si) const;
 };
 struct Quaternion { Vector3f v; Float w; static Quaternion new_(Transform t); Transform to_transform() const; };      // quaternion.rs:27-31
@@ -53,7 +54,7 @@ static inline Quaternion operator/(const Quaternion& a, Float b) { return Quater
 static inline Quaternion operator-(const Quaternion& a) { return Quaternion{-a.v, -a.w}; }
 static inline Matrix4x4 matrix4x4_default() { return Matrix4x4::new_(1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0); }      // impl Default for Matrix4x4 (transform.rs:77-88): the identity
 Matrix4x4 matrix4x4_inverse(const Matrix4x4& m); Matrix4x4 matrix4x4_transpose(const Matrix4x4& m); Matrix4x4 mtx_mul(const Matrix4x4& m1, const Matrix4x4& m2);
-Transform transform_mul(Transform a, Transform rhs); Transform transform_translate(const Vector3f& delta);
+Transform transform_mul(Transform a, Transform rhs); Transform transform_translate(const Vector3f& delta); Transform transform_inverse(const Transform& t);
 static inline Transform operator*(const Transform& a, const Transform& b) { return transform_mul(a, b); }      // impl Mul for Transform (transform.rs:869-877): the text's
 Float quat_dot_quat(const Quaternion& q1, const Quaternion& q2); Quaternion quat_normalize(const Quaternion& q); Quaternion quat_slerp(Float t, const Quaternion& q1, const Quaternion& q2);
 struct AnimatedTransform {                      // transform.rs:894-909 (without the derivative terms, pinned in round 5): a camera that does not move has actually_animated = false
@@ -407,6 +408,25 @@ struct PathIntegrator {
     Spectrum li(const Ray& r, const Scene& scene, Sampler& sampler, int32_t _depth) const;
 };
 }  // namespace flow
+// ---- instancing (core/primitive.rs:198-272): carriers.  The instanced object's aggregate is the oracle's (its traversal and the triangle's interaction are pinned by the geometry batch);
+// TransformedPrimitive::intersect / intersect_p themselves are the reference's text ----
+struct ObjectPrim { const orc::Scene* sc; const rspt_object* o; orc::Counters* c;
+    bool intersect(const Ray& ray, FullInteraction& isect) const {
+        orc::Ray r = flow::to_orc(ray); orc::Interaction oi{}; float t = 0.0f, b[3] = {0, 0, 0};
+        const bool hit = o->n_nodes ? sc->bvh_intersect((uint32_t)o->first_node, r, &oi, c, &t, b) : sc->prim_intersect((uint32_t)o->first_prim, r, &oi, c, &t, b);
+        if (!hit) return false;
+        ray.t_max.set(Float(r.t_max));
+        auto P = [](const orc::V3& v) { return Point3f{Float(v.x), Float(v.y), Float(v.z)}; }; auto V = [](const orc::V3& v) { return Vector3f{Float(v.x), Float(v.y), Float(v.z)}; };
+        auto N = [](const orc::V3& v) { return Normal3f{Float(v.x), Float(v.y), Float(v.z)}; };
+        isect = FullInteraction{};
+        isect.common.p = P(oi.p); isect.common.p_error = V(oi.p_error); isect.common.n = N(oi.n); isect.common.wo = V(oi.wo); isect.common.time = Float(oi.time);
+        isect.uv = Point2f{Float(oi.uv.x), Float(oi.uv.y)}; isect.dpdu = V(oi.dpdu); isect.dpdv = V(oi.dpdv);
+        isect.shading.n = N(oi.sh_n); isect.shading.dpdu = V(oi.sh_dpdu); isect.shading.dpdv = V(oi.sh_dpdv); isect.shading.dndu = N(oi.sh_dndu); isect.shading.dndv = N(oi.sh_dndv);
+        return true;
+    }
+    bool intersect_p(const Ray& ray) const { const orc::Ray r = flow::to_orc(ray); return o->n_nodes ? sc->bvh_intersect_p((uint32_t)o->first_node, r, c) : sc->prim_intersect_p((uint32_t)o->first_prim, r, c); }
+};
+struct TransformedPrimitive { ObjectPrim primitive; AnimatedTransform primitive_to_world; bool intersect(const Ray& r, FullInteraction& isect) const; bool intersect_p(const Ray& r) const; };
 // ---- the infinite light (lights/infinite.rs) over MipMap<Spectrum> (core/mipmap.rs): carriers.  The pyramid's levels are the host's (rspt_envmap.texels: level after level, each
 // max(1, w / 2) x max(1, h / 2) — MipMap::new's own resampling is the host's restatement, tools/ and rs_pbrt_amd/scenes.py); every lookup below is the reference's text ----
 enum class ImageWrap { Repeat, Black, Clamp };
@@ -587,7 +607,7 @@ RULES_INF = [
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
     # F29 the moving transform: static methods of Matrix4x4 / Transform as functions, the identity default, literals of Transform / Quaternion / a 4 x 4 array, `loop`, a zeroed float array
     (r"Matrix4x4::transpose\(", "matrix4x4_transpose(", 0), (r"Matrix4x4::inverse\(", "matrix4x4_inverse(", 0), (r"Matrix4x4::default\(\)", "matrix4x4_default()", 0),
-    (r"Transform::translate\(", "transform_translate(", 0), (r"\.clone\(\)", "", 0),
+    (r"Transform::translate\(", "transform_translate(", 0), (r"Transform::inverse\(", "transform_inverse(", 0), (r"\(& ray, ", "(ray, ", 0), (r"Transform::default\(\)", "Transform::default_()", 0), (r"\.clone\(\)", "", 0),
     (r"Matrix4x4 \{\s*m: \[\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\],\s*\}", r"Matrix4x4::new_(\1, \2, \3, \4)", re.S),
     (r"Transform \{\s*m: (.*?),\s*m_inv: (.*?),\s*\}", r"Transform{\1, \2}", re.S),
     (r"Quaternion \{\s*v: (Vector3f \{.*?\}),\s*w,\s*\}", r"Quaternion{\1, w}", re.S),
@@ -852,6 +872,10 @@ SOURCES = [
     ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
     ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
     # instancing: an instance's hit taken to world space
+    ("core/transform.rs", r"^    pub fn inverse\(t: &Transform\) -> Transform \{", "transform_inverse", "#inf", False),
+    ("core/transform.rs", r"^    pub fn is_identity\(&self\) -> bool \{", "is_identity", "Transform#inf", False),
+    ("core/primitive.rs", ("^impl TransformedPrimitive \\{", r"^    pub fn intersect\(&self, r: &Ray, isect: &mut SurfaceInteraction\) -> bool \{"), "intersect", "TransformedPrimitive#inf", False),
+    ("core/primitive.rs", ("^impl TransformedPrimitive \\{", r"^    pub fn intersect_p\(&self, r: &Ray\) -> bool \{"), "intersect_p", "TransformedPrimitive#inf", False),
     ("core/transform.rs", r"^    pub fn transform_point_with_abs_error\($", "transform_point_with_abs_error", "Transform#inf", False),
     ("core/transform.rs", r"^    pub fn transform_normal\(&self, n: &Normal3f\) -> Normal3f \{", "transform_normal", "Transform#inf", False),
     ("core/transform.rs", r"^    pub fn transform_surface_interaction\(&self, si: &mut SurfaceInteraction\) \{", "transform_surface_interaction", "Transform#inf", False),
@@ -1118,6 +1142,49 @@ extern "C" void flow_instance(const float* m, const float* mi, const float* si_i
 }
 """
 
+MIPMAP_HOOK += r"""
+// TransformedPrimitive::intersect / intersect_p (primitive.rs:215-265) of instance k, text next to the oracle's transformed_intersect / prim_intersect_p: rays o(3) d(3) t_max time;
+// out: hit, r.t_max afterwards, p(3) n(3) shading n(3) dpdu(3), occluded = 15
+extern "C" int flow_transformed(const rspt_scene_desc* sd, uint32_t k, const float* rays, uint64_t n, float* out_text, float* out_oracle) {
+    orc::Scene sc{*sd};
+    if (k >= sd->n_instances) return -1;
+    const rspt_instance& in = sd->instances[k];
+    auto M = [](const float* m) { Matrix4x4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = Float(m[4 * i + j]); return r; };
+    AnimatedTransform at{};                             // AnimatedTransform::new (transform.rs:911-932): the two keys, decomposed by the text
+    at.start_transform = Transform{M(in.to_world), M(in.from_world)};
+    at.end_transform = in.animated ? Transform{M(in.to_world_end), M(in.from_world_end)} : at.start_transform;
+    at.start_time = Float(in.animated ? in.time[0] : 0.0f); at.end_time = Float(in.animated ? in.time[1] : 1.0f); at.actually_animated = in.animated != 0;
+    AnimatedTransform::decompose(at.start_transform.m, &at.t[0], &at.r[0], &at.s[0]);
+    AnimatedTransform::decompose(at.end_transform.m, &at.t[1], &at.r[1], &at.s[1]);
+    if (quat_dot_quat(at.r[0], at.r[1]) < Float(0.0f)) at.r[1] = -at.r[1];
+    at.has_rotation = quat_dot_quat(at.r[0], at.r[1]) < Float(0.9995f);
+    orc::Counters c1, c2;
+    const TransformedPrimitive tp{ObjectPrim{&sc, &sd->objects[in.object], &c1}, at};
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = rays + 8 * i; float* t = out_text + 15 * i; float* o = out_oracle + 15 * i;
+        for (int j = 0; j < 15; j++) t[j] = o[j] = 0.0f;
+        Ray r{}; r.o = Point3f{Float(q[0]), Float(q[1]), Float(q[2])}; r.d = Vector3f{Float(q[3]), Float(q[4]), Float(q[5])}; r.t_max.v = Float(q[6]); r.time = Float(q[7]); r.medium = MediumRef{0};
+        FullInteraction si{};
+        const bool hit = tp.intersect(r, si);
+        t[0] = hit ? 1.0f : 0.0f; t[1] = r.t_max.get().v;
+        if (hit) { t[2] = si.common.p.x.v; t[3] = si.common.p.y.v; t[4] = si.common.p.z.v; t[5] = si.common.n.x.v; t[6] = si.common.n.y.v; t[7] = si.common.n.z.v;
+                   t[8] = si.shading.n.x.v; t[9] = si.shading.n.y.v; t[10] = si.shading.n.z.v; t[11] = si.dpdu.x.v; t[12] = si.dpdu.y.v; t[13] = si.dpdu.z.v; }
+        Ray r2{}; r2.o = r.o; r2.d = r.d; r2.t_max.v = Float(q[6]); r2.time = Float(q[7]); r2.medium = MediumRef{0};
+        t[14] = tp.intersect_p(r2) ? 1.0f : 0.0f;
+        orc::Ray orr{orc::V3{q[0], q[1], q[2]}, orc::V3{q[3], q[4], q[5]}, q[6], q[7]};
+        orc::Interaction oi{}; float ot = 0.0f, ob[3] = {0, 0, 0};
+        const bool ohit = sc.transformed_intersect(k, orr, &oi, &c2, &ot, ob);
+        o[0] = ohit ? 1.0f : 0.0f; o[1] = orr.t_max;
+        if (ohit) { o[2] = oi.p.x; o[3] = oi.p.y; o[4] = oi.p.z; o[5] = oi.n.x; o[6] = oi.n.y; o[7] = oi.n.z; o[8] = oi.sh_n.x; o[9] = oi.sh_n.y; o[10] = oi.sh_n.z; o[11] = oi.dpdu.x; o[12] = oi.dpdu.y; o[13] = oi.dpdu.z; }
+        // intersect_p: the top-level primitive of instance k
+        uint32_t pk = 0; for (uint64_t j = 0; j < sd->n_top_prims; j++) if (sd->prims[j].mesh == RSPT_MESH_INSTANCE && sd->prims[j].v[0] == k) pk = (uint32_t)j;
+        orc::Ray orr2{orc::V3{q[0], q[1], q[2]}, orc::V3{q[3], q[4], q[5]}, q[6], q[7]};
+        o[14] = sc.prim_intersect_p(pk, orr2, &c2) ? 1.0f : 0.0f;
+    }
+    return 0;
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
@@ -1288,6 +1355,7 @@ def _convert_parts():
                 tab["&SurfaceInteraction"] = "const FullInteraction&"
                 tab["&mut SurfaceInteraction"] = "FullInteraction&"
                 tab["&mut Sampler"] = "UPair&"
+                tab["&Transform"] = "const Transform&"
                 tab.update({"Quaternion": "Quaternion", "&Quaternion": "const Quaternion&", "&mut Quaternion": "Quaternion*", "Matrix4x4": "Matrix4x4", "&Matrix4x4": "const Matrix4x4&", "&mut Matrix4x4": "Matrix4x4*"})
                 tab["MediumPair"] = "std::pair<Spectrum, flow::Option<MediumInteraction>>"
                 tab["&Arc<dyn Texture<Float> + Send + Sync>"] = "const BumpTex&"

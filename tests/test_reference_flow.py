@@ -598,3 +598,32 @@ def test_transform_surface_interaction_text_equals_the_oracle(flow, oracle):
         L.flow_instance(m.ctypes.data, mi.ctypes.data, si.ctypes.data, n, t.ctypes.data, q.ctypes.data)
         bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
         assert not bad.any(), (trial, int(bad.sum()), sorted(set(np.where(bad)[1].tolist())))
+
+
+@pytest.mark.parametrize("moving", [False, True])
+def test_transformed_primitive_text_equals_the_oracle(flow, oracle, moving):
+    """TransformedPrimitive::intersect / intersect_p (primitive.rs:215-265: the interpolated primitive_to_world, Transform::inverse, the object-space ray, the t_max hand-back, the
+    identity test, the hit taken to world space) against the oracle's transformed_intersect / prim_intersect_p on the instanced landscape stand-in, static and moving trees"""
+    import ctypes as C
+    mk, L = flow
+    sc = scenes.landscape_standin(oracle.bvh_build, n_side=8, terrain=16, tree_grid=(4, 3), moving=moving)
+    assert sc.desc.n_instances >= 12
+    L.flow_transformed.restype = C.c_int
+    L.flow_transformed.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5 + moving)
+    n = 1 << 12
+    n_hit = 0
+    for k in (0, 5, 11):
+        tw = np.asarray(sc.instances[k]["to_world"], np.float64).reshape(-1)
+        centre = np.array([tw[3], tw[7], tw[11]], np.float64)
+        o = centre + rng.normal(size=(n, 3)) * 6 + [0, 4, 0]
+        tgt = centre + rng.normal(size=(n, 3)) * 1.0 + [0, 1.0, 0]
+        d = tgt - o; d /= np.linalg.norm(d, axis=1)[:, None]
+        tmax = np.where(rng.uniform(size=n) < 0.3, rng.uniform(1, 12, n), np.inf)
+        rays = np.concatenate([o, d, tmax[:, None], rng.uniform(-0.2, 1.2, (n, 1))], 1).astype(np.float32)
+        t, q = np.zeros((n, 15), np.float32), np.zeros((n, 15), np.float32)
+        assert L.flow_transformed(C.addressof(sc.desc), k, rays.ctypes.data, n, t.ctypes.data, q.ctypes.data) == 0
+        bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
+        assert not bad.any(), (k, int(bad.any(axis=1).sum()), sorted(set(np.where(bad)[1].tolist())))
+        n_hit += int(t[:, 0].sum())
+    assert n_hit > 300
