@@ -2,7 +2,7 @@
 // by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
 // Parity: pinned by the reference's own output on ONE scene family — the two Cornell-box renders of its documentation (path + Sobol' +
 // matte + area light + spatial light distribution + box filter: tests/test_reference_pin.py, 94 % of the 8-spp PNG's pixels byte for
-// byte).  Everything else (other materials, textures, lights, samplers, integrators, media, instances) is UNPINNED by the reference:
+// byte).  No other OUTPUT of the reference exists (the rest is held to its TEXT, below):
 // rs_pbrt ships no tests / golden vectors and cannot be built here (no Rust toolchain), so those parts rest on first-principles
 // known-answer tests (tests/test_oracle_*.py) until a dump of real rs_pbrt is committed (oracle/REFERENCE_FIXTURES.md).
 // Pinned by the reference's own TEXT since round 6 (compiled from the Rust sources by committed rewrite rules, oracle/make_leaf_fixtures.py; bit for bit):
@@ -10,7 +10,11 @@
 // AnimatedTransform's derivative polynomials (oracle/make_motion_fixture.py); third session of round 6 (oracle/make_geom_fixtures.py): Bounds3f::intersect_p, the
 // watertight test of Triangle::intersect / intersect_p, pnt3_offset_ray_origin (+ next_float_up / _down, gamma), vec3_cross_vec3, vec3_coordinate_system, reflect,
 // refract, power_heuristic, cosine_ / uniform_sample_hemisphere, TrowbridgeReitzDistribution::{roughness_to_alpha, d, lambda, g1, g, pdf}, phase_hg, RGBSpectrum::y,
-// Rng::{set_sequence, uniform_uint32, uniform_uint32_bounded, uniform_float}.  Control flow (dispatch, loops, traversal order) remains unpinned.
+// Rng::{set_sequence, uniform_uint32, uniform_uint32_bounded, uniform_float}.  Later sessions of round 6 (oracle/make_geom_fixtures.py, make_flow_fixtures.py; DESIGN.md §3a holds
+// the whole list, ~400 functions and tables): the whole Triangle::intersect, BVHAccel::intersect / _p and the builder, all six samplers, the camera, light sampling incl. the infinite
+// light, the film, all nine lobes and Bsdf's loop, eight material recipes, estimate_direct, PathIntegrator / DirectLighting / AO ::li, SamplerIntegrator::render's tile loop run over
+// the text of every stage it calls, the MIP map, the texture mappings and procedural textures, bump mapping, the homogeneous medium, AnimatedTransform::decompose / interpolate,
+// TransformedPrimitive::intersect.  Unpinned: MixMaterial's lobe copy, VolPathIntegrator::li's control flow, the grid medium, MipMap::new's resampling.
 #include "orc_render.hpp"
 #include "orc_motion.hpp"
 
