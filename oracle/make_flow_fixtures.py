@@ -457,6 +457,11 @@ static inline Vector2f vector2f_default() { return Vector2f{Float(0.0f), Float(0
 struct WrinkledTexture;
 struct BumpTex { const WrinkledTexture* w; Float evaluate(const FullInteraction& si) const; };       // Arc<dyn Texture<Float>>: here a WrinkledTexture (its evaluate is the text's)
 void material_bump(const BumpTex& d, FullInteraction& si);
+struct ScaleTexture { TexConst<Spectrum> tex1, tex2; Spectrum evaluate(const FullInteraction& si) const; };                                    // scale.rs:12-15
+struct MixTexture { TexConst<Spectrum> tex1, tex2; TexConst<Float> amount; Spectrum evaluate(const FullInteraction& si) const; };                 // mix.rs:14-18
+struct MipRef { const MipMapS* m; Spectrum lookup_pnt_vec_vec(Point2f st, Vector2f* a, Vector2f* b) const { return m->lookup_pnt_vec_vec(st, *a, *b); } };   // Arc<MipMap<Spectrum>>
+struct ImageTexture { TextureMapping2D mapping; MipRef mipmap; Spectrum evaluate(const FullInteraction& si) const; };                         // imagemap.rs:18-21
+void image_convert_out(const Spectrum& from, Spectrum& to);
 struct MarbleTexture { TextureMapping3D mapping; int32_t octaves; Float omega, scale, variation; Spectrum evaluate(const FullInteraction& si) const; };      // marble.rs:14-21
 struct WindyTexture { TextureMapping3D mapping; Float evaluate(const FullInteraction& si) const; };
 struct WrinkledTexture { TextureMapping3D mapping; int32_t octaves; Float omega; Float evaluate(const FullInteraction& si) const; };
@@ -638,6 +643,10 @@ RULES_INF = [
     # F26 mappings and procedural textures: the axis selector behind a parenthesis, the colour table, `T::from(x)` at T = Float, the defaults
     (r"\[XYEnum::X\]", ".x", 0), (r"\[XYEnum::Y\]", ".y", 0),
     (r"let c: \[\[Float; 3\]; 9\] = \[\n(.*?)\n\s*\];", lambda m: "const Float c[9][3] = {\n%s\n};" % m.group(1).replace("[", "{").replace("]", "}"), re.S),
+    (r"ImageTexture::<Spectrum>::convert_out\(&mem, &mut ret\);", "image_convert_out(mem, ret);", 0),
+    (r"let mut rgb: \[Float; 3\] = \[0\.0 as Float; 3\];", "Float rgb[3] = {};", 0),
+    (r"\*to = ", "to = ", 0),
+    (r"from\.to_rgb\(&mut rgb\);", "from.to_rgb(rgb);", 0),
     (r"\bT::from\(", "Float(", 0),
     (r"(\([^()]*(?:\([^()]*\)[^()]*)*\)\.(?:floor|ceil)\(\)) as (usize|i32)\b", lambda m: "(%s)(%s)" % (geom.TYPES[m.group(2)], m.group(1)), 0),
     (r"Vector2f::default\(\)", "vector2f_default()", 0), (r"Vector3f::default\(\)", "vector3f_default()", 0),
@@ -900,6 +909,11 @@ SOURCES = [
     ("core/interaction.rs", r"^    pub fn set_shading_geometry\($", "set_shading_geometry", "FullInteraction#inf", False),
     ("core/material.rs", r"^    pub fn bump\(d: ", "material_bump", "#inf", False),
     ("textures/marble.rs", r"^    fn evaluate\(&self", "evaluate", "MarbleTexture#inf", False),
+    ("textures/scale.rs", r"^    fn evaluate\(&self", "evaluate", "ScaleTexture#inf", False),
+    ("textures/mix.rs", r"^    fn evaluate\(&self", "evaluate", "MixTexture#inf", False),
+    ("core/spectrum.rs", r"^    pub fn to_rgb\(&self, rgb: &mut \[Float; 3\]\) \{", "to_rgb", "Spectrum#inf", False),
+    ("textures/imagemap.rs", ("^impl ImageTextureConvert<Spectrum> for ImageTexture<Spectrum> \\{", r"^    fn convert_out\(from: &Spectrum, to: &mut Spectrum\) \{"), "image_convert_out", "#inf", False),
+    ("textures/imagemap.rs", ("^impl Texture<Spectrum> for ImageTexture<Spectrum> \\{", r"^    fn evaluate\(&self"), "evaluate", "ImageTexture#inf", False),
     ("textures/windy.rs", r"^    fn evaluate\(&self", "evaluate@Float", "WindyTexture#inf", False),
     ("textures/wrinkled.rs", r"^    fn evaluate\(&self", "evaluate@Float", "WrinkledTexture#inf", False),
     ("textures/fbm.rs", r"^    fn evaluate\(&self", "evaluate@Float", "FBmTexture#inf", False),
@@ -962,8 +976,13 @@ extern "C" void flow_noise(const float* p, const float* dpdx, const float* dpdy,
 MIPMAP_HOOK += r"""
 // the texture mappings and the procedural textures, text next to the oracle's tex_map2d / tex_map3d / tex_eval: tx[0] = the texture (children tx[1], tx[2]: constants), si: p(3) uv(2) dpdx(3) dpdy(3)
 // dudx dvdx dudy dvdy; out: value(3) | st(2) dstdx(2) dstdy(2) - | or p(3) dpdx(3) dpdy(3)
-extern "C" int flow_textures(const rspt_texture* tx, const float* si_in, uint64_t n, float* out_text, float* out_oracle) {
-    rspt_scene_desc d{}; d.textures = tx; d.n_textures = 3;
+extern "C" int flow_textures(const rspt_texture* tx, const rspt_image* img, const float* si_in, uint64_t n, float* out_text, float* out_oracle) {
+    rspt_scene_desc d{}; d.textures = tx; d.n_textures = 3; d.images = img; d.n_images = img ? 1 : 0;
+    MipMapS mm; mm.wrap_mode = tx[0].wrap == RSPT_WRAP_REPEAT ? ImageWrap::Repeat : (tx[0].wrap == RSPT_WRAP_BLACK ? ImageWrap::Black : ImageWrap::Clamp);
+    mm.do_trilinear = tx[0].trilinear != 0; mm.max_anisotropy = Float(tx[0].max_aniso);
+    if (img) { const float* p = img->texels; size_t w = img->width, h = img->height;
+               for (uint32_t l = 0; l < img->n_levels; l++) { mm.pyramid.push(MipLevel{p, w, h}); p += 3 * w * h; w = std::max<size_t>(1, w / 2); h = std::max<size_t>(1, h / 2); } }
+    init_weight_lut(mm);
     orc::Scene sc{d};
     auto T = [&](const float* m) { Transform t{}; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) t.m.m[r][c] = Float(m[4 * r + c]); return t; };
     const rspt_texture& x = tx[0];
@@ -989,6 +1008,9 @@ extern "C" int flow_textures(const rspt_texture* tx, const float* si_in, uint64_
             case RSPT_TEX_FBM: v = Spectrum::new_(FBmTexture{m3, Float(x.omega), x.octaves}.evaluate(si)); break;
             case RSPT_TEX_CHECKERBOARD: v = Checkerboard2DTexture{c1, c2, m2}.evaluate(si); break;
             case RSPT_TEX_DOTS: v = DotsTexture{m2, c1, c2}.evaluate(si); break;
+            case RSPT_TEX_SCALE: v = ScaleTexture{c1, c2}.evaluate(si); break;
+            case RSPT_TEX_MIX: v = MixTexture{c1, c2, TexConst<Float>{Float(tx[tx[0].tex3].value[0])}}.evaluate(si); break;
+            case RSPT_TEX_IMAGE: v = ImageTexture{m2, MipRef{&mm}}.evaluate(si); break;
             default: return -1;
         }
         const orc::Spec ov = orc::tex_eval(sc, 0, oi);
@@ -1363,6 +1385,8 @@ def _convert_parts():
                 if name.endswith("@Float"):
                     tab["T"] = "Float"
             name = name.split("@Float")[0]
+            if "textures/mix.rs" in fname:
+                text = text.replace("T::from(", "Spectrum::new(")
             text = text.replace("-> (Spectrum, Option<MediumInteraction>) {", "-> MediumPair {")
             if name == "transform_mul":              # `impl Mul for Transform { fn mul(self, rhs) }` -> a function of two transforms (the carrier's operator* names it)
                 text = text.replace("fn mul(self, rhs: Transform)", "fn transform_mul(a: Transform, rhs: Transform)").replace("self.", "a.")

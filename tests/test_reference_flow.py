@@ -446,7 +446,8 @@ def test_noise_fbm_turbulence_text_equals_the_oracle(flow, oracle):
 
 
 @pytest.mark.parametrize("kind,mapping", [(abi.TEX_CHECKERBOARD, abi.MAP_UV), (abi.TEX_CHECKERBOARD, abi.MAP_PLANAR), (abi.TEX_DOTS, abi.MAP_SPHERICAL), (abi.TEX_DOTS, abi.MAP_CYLINDRICAL),
-                                          (abi.TEX_MARBLE, abi.MAP_IDENTITY3D), (abi.TEX_WINDY, abi.MAP_IDENTITY3D), (abi.TEX_WRINKLED, abi.MAP_IDENTITY3D), (abi.TEX_FBM, abi.MAP_IDENTITY3D)])
+                                          (abi.TEX_MARBLE, abi.MAP_IDENTITY3D), (abi.TEX_WINDY, abi.MAP_IDENTITY3D), (abi.TEX_WRINKLED, abi.MAP_IDENTITY3D), (abi.TEX_FBM, abi.MAP_IDENTITY3D),
+                                          (abi.TEX_SCALE, abi.MAP_UV), (abi.TEX_MIX, abi.MAP_UV), (abi.TEX_IMAGE, abi.MAP_UV), (abi.TEX_IMAGE, abi.MAP_SPHERICAL)])
 def test_texture_mappings_and_procedural_textures_text_equals_the_oracle(flow, oracle, kind, mapping):
     """UVMapping2D / SphericalMapping2D / CylindricalMapping2D / PlanarMapping2D / IdentityMapping3D::map (texture.rs:101-283, with the finite differences and the wrap fix-ups of the two
     angular mappings) and Checkerboard2DTexture / DotsTexture / MarbleTexture / WindyTexture / WrinkledTexture / FBmTexture::evaluate (textures/*.rs) against the oracle's tex_map2d / tex_map3d /
@@ -455,7 +456,7 @@ def test_texture_mappings_and_procedural_textures_text_equals_the_oracle(flow, o
     mk, L = flow
     rng = np.random.default_rng(kind * 16 + mapping)
     tx = (abi.Texture * 3)()
-    tx[0].kind, tx[0].mapping, tx[0].tex1, tx[0].tex2 = kind, mapping, 1, 2
+    tx[0].kind, tx[0].mapping, tx[0].tex1, tx[0].tex2, tx[0].tex3 = kind, mapping, 1, 2, 2
     mp = rng.uniform(-2, 2, 8).astype(np.float32) if mapping == abi.MAP_PLANAR else np.array([3.0, 2.5, 0.25, -0.5, 0, 0, 0, 0], np.float32)
     for k in range(8):
         tx[0].map[k] = float(mp[k])
@@ -473,11 +474,23 @@ def test_texture_mappings_and_procedural_textures_text_equals_the_oracle(flow, o
     si[:16, 5:] = 0.0
     t, q = np.zeros((n, 12), np.float32), np.zeros((n, 12), np.float32)
     L.flow_textures.restype = C.c_int
-    L.flow_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-    assert L.flow_textures(C.addressof(tx), si.ctypes.data, n, t.ctypes.data, q.ctypes.data) == 0
+    L.flow_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    img = None
+    if kind == abi.TEX_IMAGE:                                                    # a 16 x 8 map with its pyramid, EWA, wrap mode Clamp
+        levels, lw, lh = [], 16, 8
+        while True:
+            levels.append(rng.uniform(0, 2, (lh, lw, 3)).astype(np.float32))
+            if lw == 1 and lh == 1:
+                break
+            lw, lh = max(1, lw // 2), max(1, lh // 2)
+        texels = np.concatenate([l.reshape(-1) for l in levels])
+        img = abi.Image(); img.width, img.height, img.n_levels, img.channels = 16, 8, len(levels), 3; img.texels = texels.ctypes.data
+        tx[0].image, tx[0].trilinear, tx[0].max_aniso, tx[0].wrap = 0, 0, 8.0, abi.WRAP_CLAMP
+        si[:, 11:15] *= 3
+    assert L.flow_textures(C.addressof(tx), C.addressof(img) if img is not None else None, si.ctypes.data, n, t.ctypes.data, q.ctypes.data) == 0
     bad = (t.view(np.uint32) != q.view(np.uint32)) & ~(np.isnan(t) & np.isnan(q))
     assert not bad.any(), "%d of %d values differ (columns %s)" % (int(bad.sum()), bad.size, sorted(set(np.where(bad)[1].tolist())))
-    assert t[:, :3].std() > 0.01
+    assert t[:, :3].std() > 0.01 or kind in (abi.TEX_SCALE, abi.TEX_MIX)
 
 
 def test_bump_mapping_text_equals_the_oracle(flow, oracle):
