@@ -66,10 +66,10 @@ struct PerspectiveCamera {                      // perspective.rs:21-47 (with Ca
     AnimatedTransform camera_to_world; Float shutter_open, shutter_close; MediumRef medium; Transform raster_to_camera; Float lens_radius, focal_distance; Vector3f dx_camera, dy_camera;
     Float generate_ray_differential(const CameraSample& sample, Ray& ray) const;
 };
-struct PointLight { Point3f p_light; Spectrum i; Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f _u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const; };   // lights/point.rs
-struct SpotLight { Point3f p_light; Spectrum i; Float cos_total_width, cos_falloff_start; Transform world_to_light;                                                                         // lights/spot.rs
+struct PointLight { Point3f p_light; Spectrum i; Spectrum power() const; Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f _u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const; };   // lights/point.rs
+struct SpotLight { Point3f p_light; Spectrum i; Float cos_total_width, cos_falloff_start; Transform world_to_light; Spectrum power() const;                                                                         // lights/spot.rs
     Float falloff(const Vector3f& w) const; Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f _u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const; };
-struct DistantLight { Spectrum l; Vector3f w_light; Float world_radius;                                                                                                                  // lights/distant.rs (world_radius: what preprocess stored)
+struct DistantLight { Spectrum l; Vector3f w_light; Float world_radius; Spectrum power() const;                                                                                                                  // lights/distant.rs (world_radius: what preprocess stored)
     Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f _u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const; };
 static inline Point3f& operator+=(Point3f& a, const Vector3f& b) { a = a + b; return a; }          // impl AddAssign<Vector3f> for Point3f
 static inline Point3f point3f_default() { return Point3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }
@@ -488,7 +488,9 @@ Float fbm(const Point3f& p, const Vector3f& dpdx, const Vector3f& dpdy, Float om
 Spectrum lerp(Float t, Spectrum a, Spectrum b); Float spherical_theta(const Vector3f& v); Float spherical_phi(const Vector3f& v);
 struct InfiniteAreaLight { MipMapS lmap; Float world_radius; const flow::Distribution2D& distribution; Transform light_to_world, world_to_light;
     Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const;
-    Spectrum le(const Ray& ray) const; Float pdf_li(void* _iref, const Vector3f& w) const; };
+    Spectrum le(const Ray& ray) const; Float pdf_li(void* _iref, const Vector3f& w) const; Spectrum power() const; };
+Point3f operator/(const Point3f& a, Float b); Float pnt3_distancef(const Point3f& p1, const Point3f& p2); bool pnt3_inside_bnd3(const Point3f& p, const Bounds3f& b);
+void bounds3f_bounding_sphere(const Bounds3f& b, Point3f* center, Float* radius);
 """
 
 TYPES = dict(geom.TYPES)
@@ -610,6 +612,8 @@ RULES_INF = [
     (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
     (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
+    # F30 bounding_sphere: casts to the type a value already has
+    (r"\b(b\.p_m\w+) as Point3f", r"\1", 0), (r"\*center as Point3f", "*center", 0),
     # F29 the moving transform: static methods of Matrix4x4 / Transform as functions, the identity default, literals of Transform / Quaternion / a 4 x 4 array, `loop`, a zeroed float array
     (r"Matrix4x4::transpose\(", "matrix4x4_transpose(", 0), (r"Matrix4x4::inverse\(", "matrix4x4_inverse(", 0), (r"Matrix4x4::default\(\)", "matrix4x4_default()", 0),
     (r"Transform::translate\(", "transform_translate(", 0), (r"Transform::inverse\(", "transform_inverse(", 0), (r"\(& ray, ", "(ray, ", 0), (r"Transform::default\(\)", "Transform::default_()", 0), (r"\.clone\(\)", "", 0),
@@ -880,6 +884,16 @@ SOURCES = [
     ("core/texture.rs", (r"^    pub fn cylinder\(&self", r"^    pub fn map\($"), "map", "CylindricalMapping2D#inf", False),
     ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
     ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
+    # Light::power (the power light distribution) and the scene's bounding sphere
+    ("core/geometry.rs", r"^impl_op_ex!\(/\|a: &Point3f, b: Float\| -> Point3f \{", "operator/", "#inf", False),
+    ("core/geometry.rs", r"^pub fn pnt3_distancef\(", "pnt3_distancef", "#inf", False),
+    ("core/geometry.rs", r"^pub fn pnt3_inside_bnd3\(", "pnt3_inside_bnd3", "#inf", False),
+    ("core/geometry.rs", ("^impl Bounds3f \\{", r"^    pub fn bounding_sphere\("), "bounds3f_bounding_sphere", "#inf", False),
+    ("lights/diffuse.rs", r"^    pub fn power\(&self\) -> Spectrum \{", "power", "DiffuseAreaLight#inf", False),
+    ("lights/point.rs", r"^    pub fn power\(&self\) -> Spectrum \{", "power", "PointLight#inf", False),
+    ("lights/spot.rs", r"^    pub fn power\(&self\) -> Spectrum \{", "power", "SpotLight#inf", False),
+    ("lights/distant.rs", r"^    pub fn power\(&self\) -> Spectrum \{", "power", "DistantLight#inf", False),
+    ("lights/infinite.rs", r"^    pub fn power\(&self\) -> Spectrum \{", "power", "InfiniteAreaLight#inf", False),
     # instancing: an instance's hit taken to world space
     ("core/transform.rs", r"^    pub fn inverse\(t: &Transform\) -> Transform \{", "transform_inverse", "#inf", False),
     ("core/transform.rs", r"^    pub fn is_identity\(&self\) -> bool \{", "is_identity", "Transform#inf", False),
@@ -1207,6 +1221,50 @@ extern "C" int flow_transformed(const rspt_scene_desc* sd, uint32_t k, const flo
 }
 """
 
+MIPMAP_HOOK += r"""
+// Light::power of every light of the scene (diffuse.rs:85-93, point.rs:70-72, spot.rs:107-112, distant.rs:67-70, infinite.rs:344-349) over Bounds3f::bounding_sphere, Triangle::area and the MIP
+// map, and the distribution compute_light_power_distribution builds from their luminances (integrator.rs:574-584), text next to the oracle's light_power / Distribution1D.
+// out: n_lights x (power.y, cdf entry); radius: text, oracle
+extern "C" int flow_light_power(const rspt_scene_desc* sd, float* out_text, float* out_oracle, float* radius) {
+    orc::Scene sc{*sd};
+    const orc::Bounds3 wb = sc.world_bound();
+    Point3f center = point3f_default(); Float r(0.0f);
+    bounds3f_bounding_sphere(Bounds3f{Point3f{Float(wb.p_min.x), Float(wb.p_min.y), Float(wb.p_min.z)}, Point3f{Float(wb.p_max.x), Float(wb.p_max.y), Float(wb.p_max.z)}}, &center, &r);
+    radius[0] = r.v; radius[1] = orc::world_radius(sc);
+    Vec<Float> light_power; std::vector<float> opower;
+    static const uint32_t idx[3] = {0, 1, 2};
+    for (uint32_t i = 0; i < sd->n_lights; i++) {
+        const rspt_light& l = sd->lights[i];
+        Spectrum pw = Spectrum::new_(Float(0.0f));
+        switch (l.kind) {
+            case RSPT_LIGHT_POINT: pw = PointLight{Point3f{Float(l.p[0]), Float(l.p[1]), Float(l.p[2])}, flow::S3f(l.L)}.power(); break;
+            case RSPT_LIGHT_SPOT: { SpotLight sl{}; sl.i = flow::S3f(l.L); sl.cos_total_width = Float(l.p[12]); sl.cos_falloff_start = Float(l.p[13]); pw = sl.power(); break; }
+            case RSPT_LIGHT_DISTANT: { DistantLight dl{}; dl.l = flow::S3f(l.L); dl.world_radius = r; pw = dl.power(); break; }
+            case RSPT_LIGHT_INFINITE: {
+                const rspt_envmap& m = sd->envmaps[l.prim];
+                MipMapS mm; mm.wrap_mode = ImageWrap::Repeat;
+                { const float* p = m.texels; size_t w = m.width, h = m.height;
+                  for (uint32_t k = 0; k < m.n_levels; k++) { mm.pyramid.push(MipLevel{p, w, h}); p += 3 * w * h; w = std::max<size_t>(1, w / 2); h = std::max<size_t>(1, h / 2); } }
+                const flow::Distribution2D none{};
+                pw = InfiniteAreaLight{mm, r, none, Transform{}, Transform{}}.power(); break; }
+            default: {
+                const rspt_prim& pr = sd->prims[l.prim];
+                Point3f pts[3]; for (int k = 0; k < 3; k++) { const float* q = sd->P + 3 * (size_t)pr.v[k]; pts[k] = Point3f{Float(q[0]), Float(q[1]), Float(q[2])}; }
+                DiffuseAreaLight dl{}; dl.l_emit = flow::S3f(l.L); dl.two_sided = l.two_sided != 0; dl.shape.id = 0; dl.shape.mesh.vertex_indices = idx; dl.shape.mesh.p = pts;
+                dl.area = dl.shape.area();                      // DiffuseAreaLight::new (diffuse.rs:38-62): area = shape.area()
+                pw = dl.power(); break; }
+        }
+        light_power.push(pw.y());
+        opower.push_back(orc::light_power(sc, l).y());
+    }
+    if (sd->n_lights == 0) return 0;
+    const flow::Distribution1D d = flow::Distribution1D::new_(light_power);
+    const orc::Distribution1D od(opower);
+    for (uint32_t i = 0; i < sd->n_lights; i++) { out_text[2 * i] = light_power[i].v; out_text[2 * i + 1] = d.cdf[i + 1].v; out_oracle[2 * i] = opower[i]; out_oracle[2 * i + 1] = od.cdf[i + 1]; }
+    return (int)sd->n_lights;
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
@@ -1378,6 +1436,7 @@ def _convert_parts():
                 tab["&mut SurfaceInteraction"] = "FullInteraction&"
                 tab["&mut Sampler"] = "UPair&"
                 tab["&Transform"] = "const Transform&"
+                tab.update({"&mut Point3f": "Point3f*", "&Bounds3f": "const Bounds3f&"})
                 tab.update({"Quaternion": "Quaternion", "&Quaternion": "const Quaternion&", "&mut Quaternion": "Quaternion*", "Matrix4x4": "Matrix4x4", "&Matrix4x4": "const Matrix4x4&", "&mut Matrix4x4": "Matrix4x4*"})
                 tab["MediumPair"] = "std::pair<Spectrum, flow::Option<MediumInteraction>>"
                 tab["&Arc<dyn Texture<Float> + Send + Sync>"] = "const BumpTex&"

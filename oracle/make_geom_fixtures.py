@@ -117,6 +117,7 @@ struct DiffuseAreaLight {                                                       
     Spectrum l_emit; Triangle shape; bool two_sided;
     Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const;
     Spectrum l(const InteractionCommon& intr, const Vector3f& w) const;
+    Float area = Float(0.0f); Spectrum power() const;      // (area: what DiffuseAreaLight::new stores, shape.area(); power's body: the flow batch)
 };
 static inline Normal3f Normal3f_default() { return Normal3f{Float(0.0f), Float(0.0f), Float(0.0f)}; }                            // #[derive(Default)]
 Vector2f operator-(const Point2f& a, const Point2f& b); Vector3f operator-(const Vector3f& a, const Vector3f& b); Normal3f operator-(const Normal3f& a, const Normal3f& b);

@@ -640,3 +640,23 @@ def test_transformed_primitive_text_equals_the_oracle(flow, oracle, moving):
         assert not bad.any(), (k, int(bad.any(axis=1).sum()), sorted(set(np.where(bad)[1].tolist())))
         n_hit += int(t[:, 0].sum())
     assert n_hit > 300
+
+
+def test_light_power_and_the_power_distribution_text_equals_the_oracle(flow, oracle):
+    """Light::power of the five light kinds over Bounds3f::bounding_sphere (the scene's radius: distant and infinite lights), Triangle::area and MipMap::lookup_pnt_flt, and the Distribution1D
+    compute_light_power_distribution builds from their luminances, against the oracle's light_power (the `power` light strategy)"""
+    import ctypes as C
+    from tests.util import gallery, sky_scene
+    mk, L = flow
+    L.flow_light_power.restype = C.c_int
+    L.flow_light_power.argtypes = [C.c_void_p] * 4
+    kinds = set()
+    for sc in (gallery(oracle.bvh_build, "all"), sky_scene(oracle.bvh_build, "image", with_area=True), scenes.cornell_box(oracle.bvh_build)):
+        n = int(sc.desc.n_lights)
+        t, q, r = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32), np.zeros(2, np.float32)
+        assert L.flow_light_power(C.addressof(sc.desc), t.ctypes.data, q.ctypes.data, r.ctypes.data) == n
+        assert np.array_equal(r[:1].view(np.uint32), r[1:].view(np.uint32)) and r[0] > 0
+        assert np.array_equal(t.view(np.uint32), q.view(np.uint32)), (t, q)
+        assert (t[:, 0] > 0).all() and t[-1, 1] == 1.0
+        kinds |= {int(k) for k in sc.lights["kind"]}
+    assert kinds >= {abi.LIGHT_DIFFUSE_AREA, abi.LIGHT_POINT, abi.LIGHT_SPOT, abi.LIGHT_DISTANT, abi.LIGHT_INFINITE}
