@@ -479,6 +479,10 @@ struct HomogeneousMedium { Spectrum sigma_a, sigma_s, sigma_t; Float g;
     Spectrum tr(const Ray& ray, UPair& _sampler) const; std::pair<Spectrum, flow::Option<MediumInteraction>> sample(const Ray& ray, UPair& sampler) const; };
 struct HenyeyGreenstein { Float g; Float p(const Vector3f& wo, const Vector3f& wi) const; Float sample_p(const Vector3f& wo, Vector3f* wi, Point2f u) const; };
 Vector3f spherical_direction_vec3(Float sin_theta, Float cos_theta, Float phi, const Vector3f& x, const Vector3f& y, const Vector3f& z);
+// the film's set-up (core/film.rs:175-215 Film::new, :266-292 get_sample_bounds; filters/gaussian.rs, boxfilter.rs): the Filter enum forwards evaluate / get_radius to its variant
+struct GaussianFilter { Float alpha, exp_x, exp_y; Vector2f radius; Float gaussian(Float d, Float expv) const; Float evaluate(Point2f p) const; };
+struct FilterK { int kind; GaussianFilter g; Vector2f radius; Float evaluate(Point2f p) const { return kind == 1 ? g.evaluate(p) : Float(1.0f); }      // BoxFilter::evaluate (boxfilter.rs:30-32): 1
+                 Vector2f get_radius() const { return radius; } };
 // Perlin noise (core/texture.rs:21-48 the permutation table — converted from the text below —, 289-439)
 static const size_t NOISE_PERM_SIZE = 256;                                                            // texture.rs:21
 static const Float LOG2_E(1.44269504088896340735992468100189214f);                                    // std::f32::consts::LOG2_E
@@ -612,6 +616,12 @@ RULES_INF = [
     (r"\b(\d+)_isize\b", r"(int64_t)\1", 0),
     (r"let (\w+): isize = ([\w.]+\(\)) as isize;", r"int64_t \1 = f2isize(\2);", 0),
     (r"(this->pyramid\[\w+\]\.\w+\(\)) as Float", r"Float(\1)", 0),
+    # F31 the film's bounds: literals of the 2-D bounds
+    (r"let (\w+): Bounds2f = Bounds2f \{ p_min: (\w+), p_max: (\w+) \};", r"Bounds2f \1 = Bounds2f{\2, \3};", 0),
+    (r"\bPoint2i \{\s*x: ([^{}]*?),\s*y: ([^{}]*?),?\s*\}", r"Point2i{\1, \2}", re.S),
+    (r"\bBounds2i \{\s*p_min: (Point2i\{.*?\}),\s*p_max: (Point2i\{.*?\}),?\s*\}", r"Bounds2i{\1, \2}", re.S),
+    (r"let mut filter_table: \[Float; FILTER_TABLE_WIDTH \* FILTER_TABLE_WIDTH\] =\s*\[0\.0; FILTER_TABLE_WIDTH \* FILTER_TABLE_WIDTH\];", "Float filter_table[FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH] = {};", 0),
+    (r"let (?:mut )?(\w+): (Bounds2i|Vector2f) = ", r"\2 \1 = ", 0),
     # F30 bounding_sphere: casts to the type a value already has
     (r"\b(b\.p_m\w+) as Point3f", r"\1", 0), (r"\*center as Point3f", "*center", 0),
     # F29 the moving transform: static methods of Matrix4x4 / Transform as functions, the identity default, literals of Transform / Quaternion / a 4 x 4 array, `loop`, a zeroed float array
@@ -884,6 +894,10 @@ SOURCES = [
     ("core/texture.rs", (r"^    pub fn cylinder\(&self", r"^    pub fn map\($"), "map", "CylindricalMapping2D#inf", False),
     ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
     ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
+    # the film's set-up
+    ("filters/gaussian.rs", r"^    pub fn gaussian\(&self", "gaussian", "GaussianFilter#inf", False),
+    ("filters/gaussian.rs", r"^    pub fn evaluate\(&self, p: Point2f\) -> Float \{", "evaluate", "GaussianFilter#inf", False),
+    ("core/film.rs", r"^    pub fn get_sample_bounds\(&self\) -> Bounds2i \{", "get_sample_bounds", "Film#inf", False),
     # Light::power (the power light distribution) and the scene's bounding sphere
     ("core/geometry.rs", r"^impl_op_ex!\(/\|a: &Point3f, b: Float\| -> Point3f \{", "operator/", "#inf", False),
     ("core/geometry.rs", r"^pub fn pnt3_distancef\(", "pnt3_distancef", "#inf", False),
@@ -1265,6 +1279,24 @@ extern "C" int flow_light_power(const rspt_scene_desc* sd, float* out_text, floa
 }
 """
 
+FILM_HOOK = r"""
+// Film::new's cropped pixel bounds and filter table, Film::get_sample_bounds: in = xres yres | crop x0 x1 y0 y1 | filter kind (0 box, 1 gaussian) radius x y alpha; out: crop_px(4) sample_bounds(4) | table(256)
+extern "C" void flow_film_setup(const float* in, int32_t* bounds_out, float* table_out) {
+    const Vector2f radius{Float(in[7]), Float(in[8])};
+    const Float alpha(in[9]);
+    // GaussianFilter::create (gaussian.rs:20-37): exp_x / exp_y = exp(-alpha w w)
+    const GaussianFilter g{alpha, (-alpha * radius.x * radius.x).exp(), (-alpha * radius.y * radius.y).exp(), radius};
+    const FilterK fk{(int)in[6], g, radius};
+    Bounds2i cb{}; Float table[FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH];
+    film_new_block(Point2i{(int32_t)in[0], (int32_t)in[1]}, Bounds2f{Point2f{Float(in[2]), Float(in[4])}, Point2f{Float(in[3]), Float(in[5])}}, fk, &cb, table);
+    Film film; film.cropped_pixel_bounds = cb; film.filter.radius = radius;
+    const Bounds2i sb = film.get_sample_bounds();
+    bounds_out[0] = cb.p_min.x; bounds_out[1] = cb.p_min.y; bounds_out[2] = cb.p_max.x; bounds_out[3] = cb.p_max.y;
+    bounds_out[4] = sb.p_min.x; bounds_out[5] = sb.p_min.y; bounds_out[6] = sb.p_max.x; bounds_out[7] = sb.p_max.y;
+    for (size_t k = 0; k < 256; k++) table_out[k] = table[k].v;
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
@@ -1391,6 +1423,29 @@ def weight_lut_part():
     finally:
         TYPES.clear(); TYPES.update(saved[0]); geom.TYPES.clear(); geom.TYPES.update(saved[1]); base.TYPES.clear(); base.TYPES.update(saved[2])
     return "// %score/mipmap.rs:%d-%d\nstatic void init_weight_lut(MipMapS& mipmap) {\n%s" % (REF, i0 + 1, i1 + 1, body), "MipMap::new (EWA weight table) core/mipmap.rs:%d-%d" % (i0 + 1, i1 + 1)
+
+
+def film_new_part():
+    """the arithmetic of Film::new (film.rs:187-214): the cropped pixel bounds and the filter weight table, as a function over the carriers"""
+    lines = open(REF + "core/film.rs").read().split("\n")
+    i0 = next(k for k, l in enumerate(lines) if l.strip() == "let cropped_pixel_bounds: Bounds2i = Bounds2i {")
+    i1 = next(k for k in range(i0, len(lines)) if lines[k].strip() == "Film {")
+    indent = len(lines[i0]) - len(lines[i0].lstrip())
+    text = "\n".join(("    " + l[indent:]) if l.strip() else "" for l in lines[i0:i1])
+    body = re.sub(r"^\s*//.*\n", "", text, flags=re.M) + "\n}\n"
+    saved = (dict(TYPES), dict(geom.TYPES), dict(base.TYPES))
+    try:
+        for pat, rep, flags in RULES_INF + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = geom.cast_after_parens(body, "Float", "Float(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = re.sub(r"\blet (?:mut )?(\w+): (Float|Point2f|usize) = ", lambda m: "%s %s = " % (geom.TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+    finally:
+        TYPES.clear(); TYPES.update(saved[0]); geom.TYPES.clear(); geom.TYPES.update(saved[1]); base.TYPES.clear(); base.TYPES.update(saved[2])
+    sig = "static void film_new_block(Point2i resolution, Bounds2f crop_window, const FilterK& filter, Bounds2i* bounds_out, Float* table_out) {\n"
+    body = body.rstrip()[:-1].rstrip() + "\n    *bounds_out = cropped_pixel_bounds; for (size_t k = 0; k < FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH; k++) table_out[k] = filter_table[k];      // (hand-written: the two results handed back)\n}\n"
+    return "// %score/film.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "Film::new (bounds and filter table) core/film.rs:%d-%d" % (i0 + 1, i1)
 
 
 def convert_parts():
@@ -1840,6 +1895,9 @@ extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd
     lut_code, lut_where = weight_lut_part()
     where.append(lut_where)
     parts.append(lut_code + MIPMAP_HOOK)
+    film_code, film_where = film_new_part()
+    where.append(film_where)
+    parts.append(film_code + FILM_HOOK)
     tile_code, tile_where = tile_loop_part()
     where.append(tile_where)
     parts.append(TILE_CARRIERS + tile_code + TILE_HOOK)

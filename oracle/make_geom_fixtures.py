@@ -271,7 +271,7 @@ template <class T> struct WriteGuard { Vec<T>* v; WriteGuard& unwrap() { return 
 template <class T> struct RwLock { mutable Vec<T> v; WriteGuard<T> write() const { return WriteGuard<T>{&v}; } };
 struct Film {
     Bounds2i cropped_pixel_bounds; Filter filter; Float filter_table[256]; Float max_sample_luminance; RwLock<Pixel> pixels;
-    FilmTile get_film_tile(const Bounds2i& sample_bounds) const; void merge_film_tile(const FilmTile& tile) const;
+    FilmTile get_film_tile(const Bounds2i& sample_bounds) const; void merge_film_tile(const FilmTile& tile) const; Bounds2i get_sample_bounds() const;
 };
 static inline Spectrum& operator+=(Spectrum& a, const Spectrum& b) { a = a + b; return a; }             // impl AddAssign / MulAssign for RGBSpectrum: element-wise (spectrum.rs)
 static inline Spectrum& operator*=(Spectrum& a, const Spectrum& b) { a = a * b; return a; }

@@ -898,15 +898,30 @@ def box_filter_table(radius=(0.5, 0.5)):  # film.rs:198-211 with BoxFilter::eval
     return np.ones(256, F32)
 
 
-def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs, film.rs:198-211
-    rx, ry = F32(radius[0]), F32(radius[1])
-    ex, ey = F32(math.exp(-alpha * float(rx) * float(rx))), F32(math.exp(-alpha * float(ry) * float(ry)))
+_LIBM = None
+
+
+def _expf(x):
+    """f32::exp of the reference = the platform libm's expf (not a double exp rounded afterwards: the table's small entries differ by several ulps)"""
+    global _LIBM
+    if _LIBM is None:
+        import ctypes
+        import ctypes.util
+        _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _LIBM.expf.restype = ctypes.c_float
+        _LIBM.expf.argtypes = [ctypes.c_float]
+    return F32(_LIBM.expf(float(F32(x))))
+
+
+def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs:20-45, film.rs:198-211 — in f32 throughout, as the reference (tests/test_reference_flow.py holds it to the text)
+    rx, ry, a = F32(radius[0]), F32(radius[1]), F32(alpha)
+    ex, ey = _expf(F32(F32(-a * rx) * rx)), _expf(F32(F32(-a * ry) * ry))
     t = np.zeros(256, F32)
     for y in range(16):
         for x in range(16):
-            px = F32(F32(x + 0.5) * rx / F32(16)); py = F32(F32(y + 0.5) * ry / F32(16))
-            gx = max(F32(0), F32(math.exp(-alpha * float(px) * float(px))) - ex)
-            gy = max(F32(0), F32(math.exp(-alpha * float(py) * float(py))) - ey)
+            px = F32(F32(F32(x + 0.5) * rx) / F32(16)); py = F32(F32(F32(y + 0.5) * ry) / F32(16))
+            gx = max(F32(0), F32(_expf(F32(F32(-a * px) * px)) - ex))
+            gy = max(F32(0), F32(_expf(F32(F32(-a * py) * py)) - ey))
             t[y * 16 + x] = F32(gx * gy)
     return t
 

@@ -660,3 +660,29 @@ def test_light_power_and_the_power_distribution_text_equals_the_oracle(flow, ora
         assert (t[:, 0] > 0).all() and t[-1, 1] == 1.0
         kinds |= {int(k) for k in sc.lights["kind"]}
     assert kinds >= {abi.LIGHT_DIFFUSE_AREA, abi.LIGHT_POINT, abi.LIGHT_SPOT, abi.LIGHT_DISTANT, abi.LIGHT_INFINITE}
+
+
+def test_film_setup_text_equals_the_host(flow):
+    """Film::new's cropped pixel bounds and filter weight table (film.rs:187-214), GaussianFilter::evaluate / gaussian, and Film::get_sample_bounds (:266-292) against what the host side puts into
+    the render description (scenes.make_render_desc, scenes.gaussian_filter_table): resolutions, crop windows and filter radii incl. fractional ones"""
+    import ctypes as C
+    mk, L = flow
+    L.flow_film_setup.restype = None
+    L.flow_film_setup.argtypes = [C.c_void_p] * 3
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        xres, yres = int(rng.integers(1, 2000)), int(rng.integers(1, 1200))
+        crop = (0.0, 1.0, 0.0, 1.0) if trial % 3 == 0 else tuple(float(np.float32(v)) for v in (rng.uniform(0, 0.5), rng.uniform(0.5, 1), rng.uniform(0, 0.5), rng.uniform(0.5, 1)))
+        gauss = trial % 2 == 1
+        radius = (2.0, 2.0) if trial % 5 == 0 else tuple(float(np.float32(v)) for v in rng.uniform(0.3, 3.5, 2))
+        if not gauss and trial % 5 == 0:
+            radius = (0.5, 0.5)
+        alpha = 2.0 if trial % 4 else float(np.float32(rng.uniform(0.5, 3)))
+        inp = np.array([xres, yres, *crop, 1 if gauss else 0, *radius, alpha], np.float32)
+        b, t = np.zeros(8, np.int32), np.zeros(256, np.float32)
+        L.flow_film_setup(inp.ctypes.data, b.ctypes.data, t.ctypes.data)
+        table = scenes.gaussian_filter_table(radius, alpha) if gauss else None
+        rd = scenes.make_render_desc(xres, yres, 1, scenes.CORNELL_LOOK_AT, 40.0, crop=crop, filter_radius=radius, filter_table=table)
+        assert tuple(b[:4]) == tuple(rd.crop_px) and tuple(b[4:]) == tuple(rd.sample_bounds), (trial, xres, yres, crop, radius, b, tuple(rd.crop_px), tuple(rd.sample_bounds))
+        host = np.array(rd.filter_table[:], np.float32)
+        assert np.array_equal(t.view(np.uint32), host.view(np.uint32)), (trial, radius, alpha, int((t != host).sum()), np.abs(t - host).max())
