@@ -41,7 +41,7 @@ static inline Float spectrum_max_component_value(const Spectrum& s) { return s.c
 struct Transform {
     Matrix4x4 m, m_inv;
     Point3f transform_point(const Point3f& p) const; Vector3f transform_vector(const Vector3f& v) const; Point3f transform_point_with_error(const Point3f& p, Vector3f* p_error) const; Ray transform_ray(const Ray& r) const;
-    static Transform default_() { return Transform{}; }
+    static Transform default_();      // #[derive(Default)] over Matrix4x4's identity (transform.rs:77-88, 251-255)
     bool is_identity() const;
     Point3f transform_point_with_abs_error(const Point3f& pt, const Vector3f& pt_error, Vector3f* abs_error) const; Normal3f transform_normal(const Normal3f& n) const; void transform_surface_interaction(FullInteraction& si) const;
 };
@@ -55,6 +55,9 @@ static inline Quaternion operator-(const Quaternion& a) { return Quaternion{-a.v
 static inline Matrix4x4 matrix4x4_default() { return Matrix4x4::new_(1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0); }      // impl Default for Matrix4x4 (transform.rs:77-88): the identity
 Matrix4x4 matrix4x4_inverse(const Matrix4x4& m); Matrix4x4 matrix4x4_transpose(const Matrix4x4& m); Matrix4x4 mtx_mul(const Matrix4x4& m1, const Matrix4x4& m2);
 Transform transform_mul(Transform a, Transform rhs); Transform transform_translate(const Vector3f& delta); Transform transform_inverse(const Transform& t);
+inline Transform Transform::default_() { return Transform{matrix4x4_default(), matrix4x4_default()}; }
+Transform transform_look_at(const Point3f& pos, const Point3f& look, const Vector3f& up); Transform transform_scale(Float x, Float y, Float z); Transform transform_perspective(Float fov, Float n, Float f);
+struct FilmRes { Point2i full_resolution; };
 static inline Transform operator*(const Transform& a, const Transform& b) { return transform_mul(a, b); }      // impl Mul for Transform (transform.rs:869-877): the text's
 Float quat_dot_quat(const Quaternion& q1, const Quaternion& q2); Quaternion quat_normalize(const Quaternion& q); Quaternion quat_slerp(Float t, const Quaternion& q1, const Quaternion& q2);
 struct AnimatedTransform {                      // transform.rs:894-909 (without the derivative terms, pinned in round 5): a camera that does not move has actually_animated = false
@@ -433,6 +436,7 @@ enum class ImageWrap { Repeat, Black, Clamp };
 static inline int64_t f2isize(Float x) { return x.v != x.v ? 0 : (x.v >= 9223372036854775808.0f ? INT64_MAX : (x.v <= -9223372036854775808.0f ? INT64_MIN : (int64_t)x.v)); }   // `x as isize` from f32: saturating
 struct MipLevel { const float* p; size_t w, h; size_t u_size() const { return w; } size_t v_size() const { return h; }      // BlockedArray<Spectrum>: indexed (u, v)
                   Spectrum at(size_t s, size_t t) const { Spectrum r; for (int k = 0; k < 3; k++) r.c[k] = Float(p[3 * (t * w + s) + k]); return r; } };
+using flow::radians;
 using flow::clamp_t;                                                                                  // (the i64 / usize instances of clamp_t live with the distributions' batch)
 static const size_t WEIGHT_LUT_SIZE = 128;                                                            // mipmap.rs:21
 struct MipMapS { Vec<MipLevel> pyramid; ImageWrap wrap_mode; bool do_trilinear = false; Float max_anisotropy = Float(8.0f); Float weight_lut[WEIGHT_LUT_SIZE] = {};
@@ -626,6 +630,7 @@ RULES_INF = [
     (r"\b(b\.p_m\w+) as Point3f", r"\1", 0), (r"\*center as Point3f", "*center", 0),
     # F29 the moving transform: static methods of Matrix4x4 / Transform as functions, the identity default, literals of Transform / Quaternion / a 4 x 4 array, `loop`, a zeroed float array
     (r"Matrix4x4::transpose\(", "matrix4x4_transpose(", 0), (r"Matrix4x4::inverse\(", "matrix4x4_inverse(", 0), (r"Matrix4x4::default\(\)", "matrix4x4_default()", 0),
+    (r"Transform::scale\(", "transform_scale(", 0), (r"Transform::perspective\(", "transform_perspective(", 0), (r"let mut camera_to_world = ", "Matrix4x4 camera_to_world = ", 0), (r"let persp = ", "const Matrix4x4 persp = ", 0),
     (r"Transform::translate\(", "transform_translate(", 0), (r"Transform::inverse\(", "transform_inverse(", 0), (r"\(& ray, ", "(ray, ", 0), (r"Transform::default\(\)", "Transform::default_()", 0), (r"\.clone\(\)", "", 0),
     (r"Matrix4x4 \{\s*m: \[\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\],\s*\}", r"Matrix4x4::new_(\1, \2, \3, \4)", re.S),
     (r"Transform \{\s*m: (.*?),\s*m_inv: (.*?),\s*\}", r"Transform{\1, \2}", re.S),
@@ -894,6 +899,10 @@ SOURCES = [
     ("core/texture.rs", (r"^    pub fn cylinder\(&self", r"^    pub fn map\($"), "map", "CylindricalMapping2D#inf", False),
     ("core/texture.rs", ("^impl PlanarMapping2D \\{", r"^    pub fn map\($"), "map", "PlanarMapping2D#inf", False),
     ("core/texture.rs", ("^impl IdentityMapping3D \\{", r"^    pub fn map\($"), "map", "IdentityMapping3D#inf", False),
+    # the camera's set-up: LookAt, the perspective projection, the screen-to-raster chain
+    ("core/transform.rs", r"^    pub fn scale\(x: Float, y: Float, z: Float\) -> Transform \{", "transform_scale", "#inf", False),
+    ("core/transform.rs", r"^    pub fn look_at\(pos: &Point3f", "transform_look_at", "#inf", False),
+    ("core/transform.rs", r"^    pub fn perspective\(fov: Float, n: Float, f: Float\) -> Transform \{", "transform_perspective", "#inf", False),
     # the film's set-up
     ("filters/gaussian.rs", r"^    pub fn gaussian\(&self", "gaussian", "GaussianFilter#inf", False),
     ("filters/gaussian.rs", r"^    pub fn evaluate\(&self, p: Point2f\) -> Float \{", "evaluate", "GaussianFilter#inf", False),
@@ -1297,6 +1306,21 @@ extern "C" void flow_film_setup(const float* in, int32_t* bounds_out, float* tab
 }
 """
 
+CAMERA_HOOK = r"""
+// the camera matrices a scene file's LookAt / Camera "perspective" lines give: in = xres yres fov | pos(3) look(3) up(3); out: raster_to_camera(16), camera_to_world(16)
+extern "C" void flow_camera_setup(const float* in, float* out) {
+    const FilmRes film{Point2i{(int32_t)in[0], (int32_t)in[1]}};
+    // PerspectiveCamera::create (perspective.rs:148-163): the screen window from the frame's aspect ratio
+    const Float frame = Float(film.full_resolution.x) / Float(film.full_resolution.y);
+    Bounds2f screen{};
+    if (frame > Float(1.0f)) { screen.p_min.x = -frame; screen.p_max.x = frame; screen.p_min.y = Float(-1.0f); screen.p_max.y = Float(1.0f); }
+    else { screen.p_min.x = Float(-1.0f); screen.p_max.x = Float(1.0f); screen.p_min.y = Float(-1.0f) / frame; screen.p_max.y = Float(1.0f) / frame; }
+    const Transform r2c = camera_raster_to_camera(Float(in[2]), screen, film);
+    const Transform w2c = transform_look_at(Point3f{Float(in[3]), Float(in[4]), Float(in[5])}, Point3f{Float(in[6]), Float(in[7]), Float(in[8])}, Vector3f{Float(in[9]), Float(in[10]), Float(in[11])});
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { out[4 * r + c] = r2c.m.m[r][c].v; out[16 + 4 * r + c] = w2c.m_inv.m[r][c].v; }      // camera_to_world = the CTM's inverse (api.rs pbrt_camera)
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
@@ -1446,6 +1470,28 @@ def film_new_part():
     sig = "static void film_new_block(Point2i resolution, Bounds2f crop_window, const FilterK& filter, Bounds2i* bounds_out, Float* table_out) {\n"
     body = body.rstrip()[:-1].rstrip() + "\n    *bounds_out = cropped_pixel_bounds; for (size_t k = 0; k < FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH; k++) table_out[k] = filter_table[k];      // (hand-written: the two results handed back)\n}\n"
     return "// %score/film.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "Film::new (bounds and filter table) core/film.rs:%d-%d" % (i0 + 1, i1)
+
+
+def camera_new_part():
+    """the projective chain of PerspectiveCamera::new (perspective.rs:59-79): camera_to_screen, screen_to_raster, raster_to_camera, as a function over the carriers"""
+    lines = open(REF + "cameras/perspective.rs").read().split("\n")
+    i0 = next(k for k, l in enumerate(lines) if l.strip() == "let camera_to_screen: Transform = Transform::perspective(fov, 1e-2, 1000.0);")
+    i1 = next(k for k in range(i0, len(lines)) if lines[k].strip().startswith("let raster_to_camera = ")) + 1
+    indent = len(lines[i0]) - len(lines[i0].lstrip())
+    text = "\n".join(("    " + l[indent:]) if l.strip() else "" for l in lines[i0:i1])
+    body = re.sub(r"^\s*//.*\n", "", text, flags=re.M) + "\n}\n"
+    saved = (dict(TYPES), dict(geom.TYPES), dict(base.TYPES))
+    try:
+        for pat, rep, flags in RULES_INF + RULES_CAM + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = geom.cast_after_parens(body, "Float", "Float(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+    finally:
+        TYPES.clear(); TYPES.update(saved[0]); geom.TYPES.clear(); geom.TYPES.update(saved[1]); base.TYPES.clear(); base.TYPES.update(saved[2])
+    sig = "static Transform camera_raster_to_camera(Float fov, Bounds2f screen_window, const FilmRes& film) {\n"
+    body = body.rstrip()[:-1].rstrip() + "\n    return raster_to_camera;      // (hand-written: the value the constructor stores)\n}\n"
+    return "// %scameras/perspective.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "PerspectiveCamera::new (raster_to_camera) cameras/perspective.rs:%d-%d" % (i0 + 1, i1)
 
 
 def convert_parts():
@@ -1895,6 +1941,9 @@ extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd
     lut_code, lut_where = weight_lut_part()
     where.append(lut_where)
     parts.append(lut_code + MIPMAP_HOOK)
+    cam_code, cam_where = camera_new_part()
+    where.append(cam_where)
+    parts.append(cam_code + CAMERA_HOOK)
     film_code, film_where = film_new_part()
     where.append(film_where)
     parts.append(film_code + FILM_HOOK)

@@ -179,18 +179,25 @@ class Transform:
     def perspective(fov, n, f):  # transform.rs:461-489
         n, f = F32(n), F32(f)
         persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], F32)
-        inv_tan = F32(1) / F32(math.tan(float(F32(F32(F32(math.pi) / F32(180)) * F32(fov)) / F32(2))))
+        inv_tan = F32(1) / _libm_f32("tanf", F32(F32(F32(F32(math.pi) / F32(180)) * F32(fov)) / F32(2)))      # f32::tan = the platform libm's tanf, not a double tan rounded afterwards
         return Transform.scale(inv_tan, inv_tan, 1) * Transform(persp)
 
     @staticmethod
-    def look_at(pos, look, up):  # transform.rs:414-451 -> world_to_camera (m_inv = camera_to_world)
-        pos, look, up = (np.array(v, np.float64) for v in (pos, look, up))
-        d = (look - pos); d /= np.linalg.norm(d)
-        upn = up / np.linalg.norm(up)
-        left = np.cross(upn, d); left /= np.linalg.norm(left)
-        new_up = np.cross(d, left)
+    def look_at(pos, look, up):  # transform.rs:414-451 -> world_to_camera (m_inv = camera_to_world); every step in f32 as the reference (tests/test_reference_flow.py holds it to the text)
+        def normalize(v):   # Vector3f::normalize: v / length, and Vector3f / Float multiplies by the reciprocal (geometry.rs:1271-1279)
+            x, y, z = (F32(c) for c in v)
+            inv = F32(F32(1) / F32(np.sqrt(F32(F32(F32(x * x) + F32(y * y)) + F32(z * z)))))
+            return (F32(x * inv), F32(y * inv), F32(z * inv))
+
+        def cross(a, b):    # vec3_cross_vec3: the products and differences in f64, rounded once (geometry.rs:460-474)
+            ax, ay, az = (float(F32(c)) for c in a); bx, by, bz = (float(F32(c)) for c in b)
+            return (F32(ay * bz - az * by), F32(az * bx - ax * bz), F32(ax * by - ay * bx))
+        pos32 = tuple(F32(c) for c in pos)
+        d = normalize(tuple(F32(F32(l) - p) for l, p in zip(look, pos32)))
+        left = normalize(cross(normalize(up), d))
+        new_up = cross(d, left)
         c2w = np.eye(4, dtype=F32)
-        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = left.astype(F32), new_up.astype(F32), d.astype(F32), pos.astype(F32)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = np.array(left, F32), np.array(new_up, F32), np.array(d, F32), np.array(pos32, F32)
         return Transform(_mtx_inverse(c2w), c2w)
 
 
@@ -901,16 +908,22 @@ def box_filter_table(radius=(0.5, 0.5)):  # film.rs:198-211 with BoxFilter::eval
 _LIBM = None
 
 
-def _expf(x):
-    """f32::exp of the reference = the platform libm's expf (not a double exp rounded afterwards: the table's small entries differ by several ulps)"""
+def _libm_f32(fn, x):
+    """an f32 function of the platform libm (expf, tanf, ...): what Rust's f32 methods call"""
     global _LIBM
+    import ctypes
     if _LIBM is None:
-        import ctypes
         import ctypes.util
         _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
-        _LIBM.expf.restype = ctypes.c_float
-        _LIBM.expf.argtypes = [ctypes.c_float]
-    return F32(_LIBM.expf(float(F32(x))))
+    f = getattr(_LIBM, fn)
+    f.restype = ctypes.c_float
+    f.argtypes = [ctypes.c_float]
+    return F32(f(float(F32(x))))
+
+
+def _expf(x):
+    """f32::exp of the reference = the platform libm's expf (not a double exp rounded afterwards: the table's small entries differ by several ulps)"""
+    return _libm_f32("expf", x)
 
 
 def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs:20-45, film.rs:198-211 — in f32 throughout, as the reference (tests/test_reference_flow.py holds it to the text)

@@ -686,3 +686,27 @@ def test_film_setup_text_equals_the_host(flow):
         assert tuple(b[:4]) == tuple(rd.crop_px) and tuple(b[4:]) == tuple(rd.sample_bounds), (trial, xres, yres, crop, radius, b, tuple(rd.crop_px), tuple(rd.sample_bounds))
         host = np.array(rd.filter_table[:], np.float32)
         assert np.array_equal(t.view(np.uint32), host.view(np.uint32)), (trial, radius, alpha, int((t != host).sum()), np.abs(t - host).max())
+
+
+def test_camera_setup_text_equals_the_host(flow):
+    """Transform::look_at / perspective / scale / translate, the Transform product and inverse, and the projective chain of PerspectiveCamera::new (perspective.rs:59-79) against the matrices the
+    host side puts into the render description (scenes.make_render_desc: raster_to_camera, camera_to_world)"""
+    import ctypes as C
+    mk, L = flow
+    L.flow_camera_setup.restype = None
+    L.flow_camera_setup.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(8)
+    worst = 0
+    for trial in range(300):
+        xres, yres = (400, 400) if trial == 0 else (int(rng.integers(16, 2000)), int(rng.integers(16, 1200)))
+        fov = 40.0 if trial == 0 else float(np.float32(rng.uniform(10, 100)))
+        look = scenes.CORNELL_LOOK_AT if trial == 0 else (tuple(float(np.float32(v)) for v in rng.uniform(-10, 10, 3)), tuple(float(np.float32(v)) for v in rng.uniform(-10, 10, 3)),
+                                                            tuple(float(np.float32(v)) for v in rng.normal(size=3)))
+        inp = np.array([xres, yres, fov, *look[0], *look[1], *look[2]], np.float32)
+        out = np.zeros(32, np.float32)
+        L.flow_camera_setup(inp.ctypes.data, out.ctypes.data)
+        rd = scenes.make_render_desc(xres, yres, 1, look, fov)
+        host = np.array(list(rd.raster_to_camera) + list(rd.camera_to_world), np.float32)
+        bad = out.view(np.uint32) != host.view(np.uint32)
+        worst = max(worst, int(bad.sum()))
+        assert not bad.any(), (trial, xres, yres, fov, np.where(bad)[0], out[bad], host[bad])
