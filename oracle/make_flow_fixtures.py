@@ -1321,6 +1321,21 @@ extern "C" void flow_camera_setup(const float* in, float* out) {
 }
 """
 
+CAMERA_HOOK += r"""
+// LightSource "spot" / "distant" as api.rs:795-848, :889-918 set them up — composed here of the reference's text (Vector3f::normalize, vec3_coordinate_system, radians, f32::cos):
+// in = from(3) to(3) coneangle conedelta; out: du(3) dv(3) dir(3) cos_total_width cos_falloff_start | distant w_light(3)
+extern "C" void flow_light_setup(const float* in, float* out) {
+    const Point3f from{Float(in[0]), Float(in[1]), Float(in[2])}, to{Float(in[3]), Float(in[4]), Float(in[5])};
+    const Vector3f dir = (to - from).normalize();
+    Vector3f du = vector3f_default(), dv = vector3f_default();
+    vec3_coordinate_system(dir, &du, &dv);
+    out[0] = du.x.v; out[1] = du.y.v; out[2] = du.z.v; out[3] = dv.x.v; out[4] = dv.y.v; out[5] = dv.z.v; out[6] = dir.x.v; out[7] = dir.y.v; out[8] = dir.z.v;
+    out[9] = radians(Float(in[6])).cos().v; out[10] = radians(Float(in[6]) - Float(in[7])).cos().v;      // SpotLight::new (spot.rs:53-54) over coneangle, coneangle - conedelta (api.rs:843-844)
+    const Vector3f w = (from - to).normalize();                                                            // DistantLight::new (distant.rs:31-33) over dir = from - to (api.rs:903-906)
+    out[11] = w.x.v; out[12] = w.y.v; out[13] = w.z.v;
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };

@@ -142,6 +142,19 @@ def _mtx_inverse(m):  # Gauss-Jordan with full pivoting in f32, transform.rs:128
     return minv
 
 
+def _v3_normalize(v):
+    """Vector3f::normalize: v / length, and Vector3f / Float multiplies by the reciprocal (geometry.rs:1271-1279)"""
+    x, y, z = (F32(c) for c in v)
+    inv = F32(F32(1) / F32(np.sqrt(F32(F32(F32(x * x) + F32(y * y)) + F32(z * z)))))
+    return (F32(x * inv), F32(y * inv), F32(z * inv))
+
+
+def _v3_cross(a, b):
+    """vec3_cross_vec3: the products and differences in f64, rounded once (geometry.rs:680-692)"""
+    ax, ay, az = (float(F32(c)) for c in a); bx, by, bz = (float(F32(c)) for c in b)
+    return (F32(ay * bz - az * by), F32(az * bx - ax * bz), F32(ax * by - ay * bx))
+
+
 class Transform:
     def __init__(self, m, m_inv=None):
         self.m = np.array(m, F32)
@@ -686,27 +699,28 @@ class SceneBuilder:
 
     def add_spot_light(self, p_from, p_to, I, coneangle=30.0, conedelta=5.0):
         """LightSource "spot" (api.rs:795-848, spot.rs:30-66): world_to_light rotates `to - from` onto +z"""
-        d = np.array(p_to, np.float64) - np.array(p_from, np.float64)
-        d /= np.linalg.norm(d)
-        d32 = d.astype(F32)
-        if abs(d32[0]) > abs(d32[1]):  # vec3_coordinate_system geometry.rs:779-794
-            du = np.array([-d32[2], 0, d32[0]], np.float64) / math.sqrt(float(d32[0]) ** 2 + float(d32[2]) ** 2)
+        # every step in f32, as api.rs:822-829 / SpotLight::new do it (tests/test_reference_flow.py holds this to the reference's text)
+        d = _v3_normalize(tuple(F32(F32(t) - F32(f)) for t, f in zip(p_to, p_from)))
+        if abs(d[0]) > abs(d[1]):  # vec3_coordinate_system geometry.rs:779-794: v2 = (..) / sqrt(..) multiplies by the reciprocal, v3 = cross(v1, v2)
+            inv = F32(F32(1) / F32(np.sqrt(F32(F32(d[0] * d[0]) + F32(d[2] * d[2])))))
+            du = (F32(F32(-d[2]) * inv), F32(F32(0) * inv), F32(d[0] * inv))
         else:
-            du = np.array([0, d32[2], -d32[1]], np.float64) / math.sqrt(float(d32[1]) ** 2 + float(d32[2]) ** 2)
-        dv = np.cross(d, du)
+            inv = F32(F32(1) / F32(np.sqrt(F32(F32(d[1] * d[1]) + F32(d[2] * d[2])))))
+            du = (F32(F32(0) * inv), F32(d[2] * inv), F32(F32(-d[1]) * inv))
+        dv = _v3_cross(d, du)
         lt = np.zeros((), abi.LIGHT_DT)
         lt["kind"] = abi.LIGHT_SPOT; lt["L"] = np.array(I, F32); lt["p"][:3] = np.array(p_from, F32)
-        lt["p"][3:12] = np.stack([du, dv, d]).astype(F32).reshape(-1)
-        lt["p"][12] = F32(math.cos(math.radians(coneangle)))
-        lt["p"][13] = F32(math.cos(math.radians(coneangle - conedelta)))
+        lt["p"][3:12] = np.array([du, dv, d], F32).reshape(-1)
+        rad = lambda deg: F32(F32(F32(math.pi) / F32(180)) * F32(deg))      # noqa: E731  radians() pbrt.rs:143-146
+        lt["p"][12] = _libm_f32("cosf", rad(coneangle))
+        lt["p"][13] = _libm_f32("cosf", rad(F32(F32(coneangle) - F32(conedelta))))
         self.delta_lights.append(lt)
 
     def add_distant_light(self, p_from, p_to, L):
         """LightSource "distant" (api.rs:889-918, distant.rs:25-40): w_light = normalize(from - to)"""
-        w = np.array(p_from, np.float64) - np.array(p_to, np.float64)
-        w /= np.linalg.norm(w)
+        w = _v3_normalize(tuple(F32(F32(f) - F32(t)) for f, t in zip(p_from, p_to)))      # in f32 (api.rs:903-906, distant.rs:31-33)
         lt = np.zeros((), abi.LIGHT_DT)
-        lt["kind"] = abi.LIGHT_DISTANT; lt["L"] = np.array(L, F32); lt["p"][:3] = w.astype(F32)
+        lt["kind"] = abi.LIGHT_DISTANT; lt["L"] = np.array(L, F32); lt["p"][:3] = np.array(w, F32)
         self.delta_lights.append(lt)
 
     def add_infinite_light(self, L=(1.0, 1.0, 1.0), image=None, light_to_world=None):

@@ -710,3 +710,23 @@ def test_camera_setup_text_equals_the_host(flow):
         bad = out.view(np.uint32) != host.view(np.uint32)
         worst = max(worst, int(bad.sum()))
         assert not bad.any(), (trial, xres, yres, fov, np.where(bad)[0], out[bad], host[bad])
+
+
+def test_spot_and_distant_light_setup_text_equals_the_host(flow):
+    """what api.rs makes of LightSource "spot" / "distant" (the direction, vec3_coordinate_system's frame, the cone cosines) against the host side's light records (scenes.SceneBuilder)"""
+    import ctypes as C
+    mk, L = flow
+    L.flow_light_setup.restype = None
+    L.flow_light_setup.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(12)
+    for trial in range(300):
+        f = tuple(float(np.float32(v)) for v in rng.uniform(-10, 10, 3)); t = tuple(float(np.float32(v)) for v in rng.uniform(-10, 10, 3))
+        cone, delta = float(np.float32(rng.uniform(5, 80))), float(np.float32(rng.uniform(0, 5)))
+        out = np.zeros(14, np.float32)
+        inp = np.array([*f, *t, cone, delta], np.float32)
+        L.flow_light_setup(inp.ctypes.data, out.ctypes.data)
+        sb = scenes.SceneBuilder()
+        sb.add_spot_light(f, t, (1, 1, 1), cone, delta); sb.add_distant_light(f, t, (1, 1, 1))
+        spot, dist = sb.delta_lights[0], sb.delta_lights[1]
+        host = np.concatenate([spot["p"][3:14], dist["p"][:3]]).astype(np.float32)
+        assert np.array_equal(out.view(np.uint32), host.view(np.uint32)), (trial, out, host)
