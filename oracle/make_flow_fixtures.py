@@ -441,6 +441,7 @@ using flow::clamp_t;                                                            
 static const size_t WEIGHT_LUT_SIZE = 128;                                                            // mipmap.rs:21
 struct MipMapS { Vec<MipLevel> pyramid; ImageWrap wrap_mode; bool do_trilinear = false; Float max_anisotropy = Float(8.0f); Float weight_lut[WEIGHT_LUT_SIZE] = {};
                  Spectrum lookup_pnt_vec_vec(Point2f st, Vector2f& dst0, Vector2f& dst1) const; Spectrum ewa(size_t level, Point2f st, Vector2f dst0, Vector2f dst1) const;
+                 int32_t width() const { return (int32_t)pyramid[0].w; } int32_t height() const { return (int32_t)pyramid[0].h; }      // MipMap::width / height: the resolution (mipmap.rs:197-202)
                  size_t levels() const; Spectrum texel(size_t level, int64_t s, int64_t t) const; Spectrum lookup_pnt_flt(Point2f st, Float width) const; Spectrum triangle(size_t level, Point2f st) const; };
 void vec2_mul_assign(Vector2f& a, Float b);
 // the texture mappings (core/texture.rs:51-283) and the procedural textures over them (textures/*.rs): carriers.  The two mapping enums forward `map` to their variant (texture.rs:58-92);
@@ -1336,6 +1337,16 @@ extern "C" void flow_light_setup(const float* in, float* out) {
 }
 """
 
+ENV_HOOK = r"""
+// the scalar image of the infinite light's sampling distribution over a given pyramid (levels concatenated): out (2 h) x (2 w) floats
+extern "C" void flow_envmap_image(const float* texels, uint32_t w0, uint32_t h0, uint32_t n_levels, float* out) {
+    MipMapS mm; mm.wrap_mode = ImageWrap::Repeat;
+    { const float* p = texels; size_t w = w0, h = h0; for (uint32_t l = 0; l < n_levels; l++) { mm.pyramid.push(MipLevel{p, w, h}); p += 3 * w * h; w = std::max<size_t>(1, w / 2); h = std::max<size_t>(1, h / 2); } }
+    const Vec<Float> img = envmap_distribution_image(mm);
+    for (size_t k = 0; k < img.len(); k++) out[k] = img[k].v;
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
@@ -1507,6 +1518,30 @@ def camera_new_part():
     sig = "static Transform camera_raster_to_camera(Float fov, Bounds2f screen_window, const FilmRes& film) {\n"
     body = body.rstrip()[:-1].rstrip() + "\n    return raster_to_camera;      // (hand-written: the value the constructor stores)\n}\n"
     return "// %scameras/perspective.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "PerspectiveCamera::new (raster_to_camera) cameras/perspective.rs:%d-%d" % (i0 + 1, i1)
+
+
+def envmap_image_part():
+    """the block of InfiniteAreaLight::new that computes the scalar image of the sampling distribution (infinite.rs:133-146), as a function over the MIP map carrier"""
+    lines = open(REF + "lights/infinite.rs").read().split("\n")
+    i0 = next(k for k, l in enumerate(lines) if l.strip() == "let width: i32 = 2_i32 * lmap.width();")
+    i1 = next(k for k in range(i0, len(lines)) if lines[k].strip().startswith("let distribution: Arc<Distribution2D> ="))
+    indent = len(lines[i0]) - len(lines[i0].lstrip())
+    text = "\n".join(("    " + l[indent:]) if l.strip() else "" for l in lines[i0:i1])
+    body = re.sub(r"^\s*//.*\n", "", text, flags=re.M) + "\n}\n"
+    saved = (dict(TYPES), dict(geom.TYPES), dict(base.TYPES))
+    try:
+        body = body.replace("let mut img: Vec<Float> = Vec::new();", "Vec<Float> img;")
+        for pat, rep, flags in RULES_INF + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = geom.cast_after_parens(body, "Float", "Float(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = re.sub(r"\blet (?:mut )?(\w+): (Float|Point2f|i32) = ", lambda m: "%s %s = " % (geom.TYPES.get(m.group(2), m.group(2)), m.group(1)), body)
+    finally:
+        TYPES.clear(); TYPES.update(saved[0]); geom.TYPES.clear(); geom.TYPES.update(saved[1]); base.TYPES.clear(); base.TYPES.update(saved[2])
+    sig = "static Vec<Float> envmap_distribution_image(const MipMapS& lmap) {\n"
+    body = body.rstrip()[:-1].rstrip() + "\n    return img;      // (hand-written: the image Distribution2D::new receives)\n}\n"
+    return "// %slights/infinite.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "InfiniteAreaLight::new (distribution image) lights/infinite.rs:%d-%d" % (i0 + 1, i1)
 
 
 def convert_parts():
@@ -1956,6 +1991,9 @@ extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd
     lut_code, lut_where = weight_lut_part()
     where.append(lut_where)
     parts.append(lut_code + MIPMAP_HOOK)
+    env_code, env_where = envmap_image_part()
+    where.append(env_where)
+    parts.append(env_code + ENV_HOOK)
     cam_code, cam_where = camera_new_part()
     where.append(cam_where)
     parts.append(cam_code + CAMERA_HOOK)

@@ -378,7 +378,8 @@ def build_envmap(texels):
         il = int(math.floor(level)); delta = F32(level - F32(il))
         val = (_env_triangle(levels[il], up, vp) * (F32(1) - delta) + _env_triangle(levels[il + 1], up, vp) * delta).astype(F32)
     y = (F32(0.212671) * val[..., 0] + F32(0.715160) * val[..., 1]).astype(F32) + F32(0.072169) * val[..., 2]
-    sin_theta = np.sin((F32(math.pi) * (vv.astype(F32) + F32(0.5)) / F32(nv)).astype(F32)).astype(F32)
+    sin_row = np.array([_libm_f32("sinf", F32(F32(F32(math.pi) * F32(F32(v) + F32(0.5))) / F32(nv))) for v in range(nv)], F32)      # f32::sin = libm's sinf (numpy's float32 sin differs in the last bit on some rows)
+    sin_theta = sin_row[vv]
     dist = np.ascontiguousarray((y.astype(F32) * sin_theta).astype(F32))
     return dict(width=w, height=h, n_levels=n_levels, texels=np.ascontiguousarray(np.concatenate([l.reshape(-1) for l in levels]), F32),
                 dist_nu=nu, dist_nv=nv, dist_func=dist)

@@ -730,3 +730,21 @@ def test_spot_and_distant_light_setup_text_equals_the_host(flow):
         spot, dist = sb.delta_lights[0], sb.delta_lights[1]
         host = np.concatenate([spot["p"][3:14], dist["p"][:3]]).astype(np.float32)
         assert np.array_equal(out.view(np.uint32), host.view(np.uint32)), (trial, out, host)
+
+
+def test_envmap_distribution_image_text_equals_the_host(flow):
+    """the scalar image InfiniteAreaLight::new hands to Distribution2D::new (infinite.rs:133-146: a trilinear lookup at half a texel's width, luminance times sin theta) against the host's
+    scenes.build_envmap, on the host's own pyramid"""
+    import ctypes as C
+    mk, L = flow
+    L.flow_envmap_image.restype = None
+    L.flow_envmap_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(2)
+    for (h, w) in ((4, 8), (16, 32), (1, 1), (64, 64)):
+        img = rng.uniform(0.01, 3, (h, w, 3)).astype(np.float32); img[0, 0] = 40.0
+        e = scenes.build_envmap(img)
+        out = np.zeros(e["dist_nu"] * e["dist_nv"], np.float32)
+        L.flow_envmap_image(e["texels"].ctypes.data, w, h, e["n_levels"], out.ctypes.data)
+        host = np.ascontiguousarray(e["dist_func"], np.float32).reshape(-1)
+        bad = out.view(np.uint32) != host.view(np.uint32)
+        assert not bad.any(), ((h, w), int(bad.sum()), out[bad][:4], host[bad][:4])
