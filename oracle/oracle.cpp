@@ -11,7 +11,7 @@
 // watertight test of Triangle::intersect / intersect_p, pnt3_offset_ray_origin (+ next_float_up / _down, gamma), vec3_cross_vec3, vec3_coordinate_system, reflect,
 // refract, power_heuristic, cosine_ / uniform_sample_hemisphere, TrowbridgeReitzDistribution::{roughness_to_alpha, d, lambda, g1, g, pdf}, phase_hg, RGBSpectrum::y,
 // Rng::{set_sequence, uniform_uint32, uniform_uint32_bounded, uniform_float}.  Later sessions of round 6 (oracle/make_geom_fixtures.py, make_flow_fixtures.py; DESIGN.md §3a holds
-// the whole list, ~400 functions and tables): the whole Triangle::intersect, BVHAccel::intersect / _p and the builder, all six samplers, the camera, light sampling incl. the infinite
+// the whole list, ~420 functions, blocks and tables): the whole Triangle::intersect, BVHAccel::intersect / _p and the builder, all six samplers, the camera, light sampling incl. the infinite
 // light, the film, all nine lobes and Bsdf's loop, eight material recipes, estimate_direct, PathIntegrator / DirectLighting / AO ::li, SamplerIntegrator::render's tile loop run over
 // the text of every stage it calls, the MIP map, the texture mappings and procedural textures, bump mapping, the homogeneous medium, AnimatedTransform::decompose / interpolate,
 // TransformedPrimitive::intersect.  Unpinned: MixMaterial's lobe copy, VolPathIntegrator::li's control flow, the grid medium, MipMap::new's resampling.
