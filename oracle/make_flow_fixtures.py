@@ -56,7 +56,7 @@ static inline Matrix4x4 matrix4x4_default() { return Matrix4x4::new_(1.0, 0.0, 0
 Matrix4x4 matrix4x4_inverse(const Matrix4x4& m); Matrix4x4 matrix4x4_transpose(const Matrix4x4& m); Matrix4x4 mtx_mul(const Matrix4x4& m1, const Matrix4x4& m2);
 Transform transform_mul(Transform a, Transform rhs); Transform transform_translate(const Vector3f& delta); Transform transform_inverse(const Transform& t);
 inline Transform Transform::default_() { return Transform{matrix4x4_default(), matrix4x4_default()}; }
-Transform transform_look_at(const Point3f& pos, const Point3f& look, const Vector3f& up); Transform transform_scale(Float x, Float y, Float z); Transform transform_perspective(Float fov, Float n, Float f);
+Transform transform_look_at(const Point3f& pos, const Point3f& look, const Vector3f& up); Transform transform_rotate_y(Float theta); Transform transform_scale(Float x, Float y, Float z); Transform transform_perspective(Float fov, Float n, Float f);
 struct FilmRes { Point2i full_resolution; };
 static inline Transform operator*(const Transform& a, const Transform& b) { return transform_mul(a, b); }      // impl Mul for Transform (transform.rs:869-877): the text's
 Float quat_dot_quat(const Quaternion& q1, const Quaternion& q2); Quaternion quat_normalize(const Quaternion& q); Quaternion quat_slerp(Float t, const Quaternion& q1, const Quaternion& q2);
@@ -631,7 +631,7 @@ RULES_INF = [
     (r"\b(b\.p_m\w+) as Point3f", r"\1", 0), (r"\*center as Point3f", "*center", 0),
     # F29 the moving transform: static methods of Matrix4x4 / Transform as functions, the identity default, literals of Transform / Quaternion / a 4 x 4 array, `loop`, a zeroed float array
     (r"Matrix4x4::transpose\(", "matrix4x4_transpose(", 0), (r"Matrix4x4::inverse\(", "matrix4x4_inverse(", 0), (r"Matrix4x4::default\(\)", "matrix4x4_default()", 0),
-    (r"Transform::scale\(", "transform_scale(", 0), (r"Transform::perspective\(", "transform_perspective(", 0), (r"let mut camera_to_world = ", "Matrix4x4 camera_to_world = ", 0), (r"let persp = ", "const Matrix4x4 persp = ", 0),
+    (r"Transform::scale\(", "transform_scale(", 0), (r"Transform::perspective\(", "transform_perspective(", 0), (r"let mut camera_to_world = ", "Matrix4x4 camera_to_world = ", 0), (r"let persp = ", "const Matrix4x4 persp = ", 0), (r"let m = Matrix4x4::new", "const Matrix4x4 m = Matrix4x4::new", 0), (r"Transform \{\s*m,\s*m_inv: (.*?),\s*\}", r"Transform{m, \1}", re.S),
     (r"Transform::translate\(", "transform_translate(", 0), (r"Transform::inverse\(", "transform_inverse(", 0), (r"\(& ray, ", "(ray, ", 0), (r"Transform::default\(\)", "Transform::default_()", 0), (r"\.clone\(\)", "", 0),
     (r"Matrix4x4 \{\s*m: \[\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\[(.*?)\],\s*\],\s*\}", r"Matrix4x4::new_(\1, \2, \3, \4)", re.S),
     (r"Transform \{\s*m: (.*?),\s*m_inv: (.*?),\s*\}", r"Transform{\1, \2}", re.S),
@@ -903,6 +903,7 @@ SOURCES = [
     # the camera's set-up: LookAt, the perspective projection, the screen-to-raster chain
     ("core/transform.rs", r"^    pub fn scale\(x: Float, y: Float, z: Float\) -> Transform \{", "transform_scale", "#inf", False),
     ("core/transform.rs", r"^    pub fn look_at\(pos: &Point3f", "transform_look_at", "#inf", False),
+    ("core/transform.rs", r"^    pub fn rotate_y\(theta: Float\) -> Transform \{", "transform_rotate_y", "#inf", False),
     ("core/transform.rs", r"^    pub fn perspective\(fov: Float, n: Float, f: Float\) -> Transform \{", "transform_perspective", "#inf", False),
     # the film's set-up
     ("filters/gaussian.rs", r"^    pub fn gaussian\(&self", "gaussian", "GaussianFilter#inf", False),
@@ -1335,6 +1336,7 @@ extern "C" void flow_light_setup(const float* in, float* out) {
     const Vector3f w = (from - to).normalize();                                                            // DistantLight::new (distant.rs:31-33) over dir = from - to (api.rs:903-906)
     out[11] = w.x.v; out[12] = w.y.v; out[13] = w.z.v;
 }
+extern "C" void flow_rotate_y(float theta, float* out) { const Transform t = transform_rotate_y(Float(theta)); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { out[4 * r + c] = t.m.m[r][c].v; out[16 + 4 * r + c] = t.m_inv.m[r][c].v; } }
 """
 
 ENV_HOOK = r"""

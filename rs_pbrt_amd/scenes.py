@@ -179,8 +179,8 @@ class Transform:
 
     @staticmethod
     def rotate_y(theta_deg):  # transform.rs:355-367 (m_inv = transpose)
-        t = math.radians(float(F32(theta_deg)))
-        sn, cs = F32(math.sin(t)), F32(math.cos(t))
+        t = F32(F32(F32(math.pi) / F32(180)) * F32(theta_deg))      # radians() and f32::sin / cos in f32, as the reference (transform.rs:365-367)
+        sn, cs = _libm_f32("sinf", t), _libm_f32("cosf", t)
         m = np.array([[cs, 0, sn, 0], [0, 1, 0, 0], [-sn, 0, cs, 0], [0, 0, 0, 1]], F32)
         return Transform(m, m.T.copy())
 

@@ -730,6 +730,13 @@ def test_spot_and_distant_light_setup_text_equals_the_host(flow):
         spot, dist = sb.delta_lights[0], sb.delta_lights[1]
         host = np.concatenate([spot["p"][3:14], dist["p"][:3]]).astype(np.float32)
         assert np.array_equal(out.view(np.uint32), host.view(np.uint32)), (trial, out, host)
+    L.flow_rotate_y.restype = None
+    L.flow_rotate_y.argtypes = [C.c_float, C.c_void_p]
+    for theta in [0.0, 6.0, 90.0, 180.0] + [float(np.float32(v)) for v in rng.uniform(0, 360, 300)]:      # Transform::rotate_y (the instances of the landscape stand-in)
+        out = np.zeros(32, np.float32)
+        L.flow_rotate_y(theta, out.ctypes.data)
+        h = scenes.Transform.rotate_y(theta)
+        assert np.array_equal(out.view(np.uint32), np.concatenate([h.m.reshape(-1), h.m_inv.reshape(-1)]).astype(np.float32).view(np.uint32)), theta
 
 
 def test_envmap_distribution_image_text_equals_the_host(flow):
