@@ -494,6 +494,13 @@ static const Float LOG2_E(1.44269504088896340735992468100189214f);              
 Float log_2(Float x); Float smooth_step(Float min, Float max, Float value); Float noise_flt(Float x, Float y, Float z); Float noise_pnt3(const Point3f& p);
 Float grad(int32_t x, int32_t y, int32_t z, Float dx, Float dy, Float dz); Float noise_weight(Float t); Float lanczos(Float x, Float tau);
 Float fbm(const Point3f& p, const Vector3f& dpdx, const Vector3f& dpdy, Float omega, int32_t max_octaves); Float turbulence(const Point3f& p, const Vector3f& dpdx, const Vector3f& dpdy, Float omega, int32_t max_octaves);
+// MipMap::new's pyramid (mipmap.rs:166-185): a level that owns its texels (BlockedArray<Spectrum>::new), written through (u, v)
+static std::deque<std::vector<float>> g_level_store;
+struct BlockedArrayS { std::vector<float>* buf; size_t w, h;
+    static BlockedArrayS new_(size_t w, size_t h) { g_level_store.emplace_back(3 * w * h, 0.0f); return BlockedArrayS{&g_level_store.back(), w, h}; }
+    struct Ref { float* p; void operator=(const Spectrum& s) { p[0] = s.c[0].v; p[1] = s.c[1].v; p[2] = s.c[2].v; } };
+    Ref at(size_t s, size_t t) { return Ref{buf->data() + 3 * (t * w + s)}; }
+    operator MipLevel() const { return MipLevel{buf->data(), w, h}; } };
 Spectrum lerp(Float t, Spectrum a, Spectrum b); Float spherical_theta(const Vector3f& v); Float spherical_phi(const Vector3f& v);
 struct InfiniteAreaLight { MipMapS lmap; Float world_radius; const flow::Distribution2D& distribution; Transform light_to_world, world_to_light;
     Spectrum sample_li(const InteractionCommon& iref, InteractionCommon& light_intr, Point2f u, Vector3f* wi, Float* pdf, VisibilityTester& vis) const;
@@ -629,6 +636,12 @@ RULES_INF = [
     (r"let (?:mut )?(\w+): (Bounds2i|Vector2f) = ", r"\2 \1 = ", 0),
     # F30 bounding_sphere: casts to the type a value already has
     (r"\b(b\.p_m\w+) as Point3f", r"\1", 0), (r"\*center as Point3f", "*center", 0),
+    # F32 the pyramid: a level that is written, Ord::max on usize, ranges from 1, the identity cast `as T`
+    (r"let mut ba = BlockedArray::<T>::new\((\w+), (\w+)\);", r"BlockedArrayS ba = BlockedArrayS::new_(\1, \2);", 0),
+    (r"ba\[\((\w+), (\w+)\)\] = ", r"ba.at(\1, \2) = ", 0),
+    (r"\)\s*as T\b", ")", 0), (r"\*mipmap\.texel\(", "mipmap.texel(", 0),
+    (r"std::cmp::max\(1, ", "std::max<size_t>(1, ", 0),
+    (r"for (\w+) in 1\.\.(\w+) \{", r"for (size_t \1 = 1; \1 < \2; \1++) {", 0),
     # F29 the moving transform: static methods of Matrix4x4 / Transform as functions, the identity default, literals of Transform / Quaternion / a 4 x 4 array, `loop`, a zeroed float array
     (r"Matrix4x4::transpose\(", "matrix4x4_transpose(", 0), (r"Matrix4x4::inverse\(", "matrix4x4_inverse(", 0), (r"Matrix4x4::default\(\)", "matrix4x4_default()", 0),
     (r"Transform::scale\(", "transform_scale(", 0), (r"Transform::perspective\(", "transform_perspective(", 0), (r"let mut camera_to_world = ", "Matrix4x4 camera_to_world = ", 0), (r"let persp = ", "const Matrix4x4 persp = ", 0), (r"let m = Matrix4x4::new", "const Matrix4x4 m = Matrix4x4::new", 0), (r"Transform \{\s*m,\s*m_inv: (.*?),\s*\}", r"Transform{m, \1}", re.S),
@@ -1349,6 +1362,19 @@ extern "C" void flow_envmap_image(const float* texels, uint32_t w0, uint32_t h0,
 }
 """
 
+PYRAMID_HOOK = r"""
+// MipMap::new's levels from level 0 (w x h x 3, a power of two each side) under a wrap mode: out = levels 1 .. n - 1 concatenated; returns n_levels (mipmap.rs:155: 1 + log2(max(w, h)))
+extern "C" int flow_pyramid(const float* level0, uint32_t w, uint32_t h, uint32_t wrap, float* out) {
+    MipMapS mm; mm.wrap_mode = wrap == RSPT_WRAP_REPEAT ? ImageWrap::Repeat : (wrap == RSPT_WRAP_BLACK ? ImageWrap::Black : ImageWrap::Clamp);
+    mm.pyramid.push(MipLevel{level0, w, h});
+    const size_t n_levels = 1 + (size_t)Float((int32_t)std::max(w, h)).log2();      // `1 + (max(resolution.x, resolution.y) as Float).log2() as usize`
+    build_pyramid(mm, n_levels);
+    float* o = out;
+    for (size_t l = 1; l < mm.pyramid.len(); l++) { const MipLevel& lv = mm.pyramid[l]; std::memcpy(o, lv.p, sizeof(float) * 3 * lv.w * lv.h); o += 3 * lv.w * lv.h; }
+    return (int)mm.pyramid.len();
+}
+"""
+
 TILE_CARRIERS = r"""
 static inline Ray ray_default() { Ray r{}; r.t_max.v = Float(INFINITY); r.medium = MediumRef{0}; return r; }      // impl Default for Ray: generate_ray_differential overwrites every field
 struct TileScene { orc::RenderCtx* cx; orc::Counters* c; };
@@ -1544,6 +1570,26 @@ def envmap_image_part():
     sig = "static Vec<Float> envmap_distribution_image(const MipMapS& lmap) {\n"
     body = body.rstrip()[:-1].rstrip() + "\n    return img;      // (hand-written: the image Distribution2D::new receives)\n}\n"
     return "// %slights/infinite.rs:%d-%d\n%s%s" % (REF, i0 + 1, i1, sig, body), "InfiniteAreaLight::new (distribution image) lights/infinite.rs:%d-%d" % (i0 + 1, i1)
+
+
+def pyramid_part():
+    """the loop of MipMap::new that filters each level from the finer one (mipmap.rs:166-184), as a function over the carriers"""
+    lines = open(REF + "core/mipmap.rs").read().split("\n")
+    i0 = next(k for k, l in enumerate(lines) if l.strip() == "for i in 1..n_levels {")
+    indent = len(lines[i0]) - len(lines[i0].lstrip())
+    i1 = next(k for k in range(i0 + 1, len(lines)) if lines[k] == " " * indent + "}")
+    text = "\n".join(("    " + l[indent:]) if l.strip() else "" for l in lines[i0:i1 + 1])
+    body = re.sub(r"^\s*//.*\n", "", text, flags=re.M) + "\n}\n"
+    saved = (dict(TYPES), dict(geom.TYPES), dict(base.TYPES))
+    try:
+        for pat, rep, flags in RULES_INF + RULES_FLOW + geom.RULES_INT + geom.RULES_PRE:
+            body = re.sub(pat, rep, body, flags=flags)
+        body = geom.cast_after_parens(body, "Float", "Float(%s)")
+        for pat, rep, flags in base.RULES:
+            body = re.sub(pat, rep, body, flags=flags)
+    finally:
+        TYPES.clear(); TYPES.update(saved[0]); geom.TYPES.clear(); geom.TYPES.update(saved[1]); base.TYPES.clear(); base.TYPES.update(saved[2])
+    return "// %score/mipmap.rs:%d-%d\nstatic void build_pyramid(MipMapS& mipmap, size_t n_levels) {\n%s" % (REF, i0 + 1, i1 + 1, body), "MipMap::new (pyramid) core/mipmap.rs:%d-%d" % (i0 + 1, i1 + 1)
 
 
 def convert_parts():
@@ -1993,6 +2039,9 @@ extern "C" int flow_render(const rspt_scene_desc* sd, const rspt_render_desc* rd
     lut_code, lut_where = weight_lut_part()
     where.append(lut_where)
     parts.append(lut_code + MIPMAP_HOOK)
+    pyr_code, pyr_where = pyramid_part()
+    where.append(pyr_where)
+    parts.append(pyr_code + PYRAMID_HOOK)
     env_code, env_where = envmap_image_part()
     where.append(env_where)
     parts.append(env_code + ENV_HOOK)

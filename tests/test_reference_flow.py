@@ -755,3 +755,24 @@ def test_envmap_distribution_image_text_equals_the_host(flow):
         host = np.ascontiguousarray(e["dist_func"], np.float32).reshape(-1)
         bad = out.view(np.uint32) != host.view(np.uint32)
         assert not bad.any(), ((h, w), int(bad.sum()), out[bad][:4], host[bad][:4])
+
+
+@pytest.mark.parametrize("wrap", [abi.WRAP_REPEAT, abi.WRAP_BLACK, abi.WRAP_CLAMP])
+def test_mipmap_pyramid_text_equals_the_host(flow, wrap):
+    """the level-by-level box filter of MipMap::new (mipmap.rs:166-184, four texels of the finer level through texel()'s wrap mode) against the pyramids the host builds
+    (scenes.build_image / build_envmap)"""
+    import ctypes as C
+    mk, L = flow
+    L.flow_pyramid.restype = C.c_int
+    L.flow_pyramid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(6 + wrap)
+    for (h, w) in ((8, 8), (4, 32), (64, 16), (1, 1), (2, 1)):
+        img = rng.uniform(0, 2, (h, w, 3)).astype(np.float32)
+        e = scenes.build_image(img, wrap=wrap)
+        host = np.ascontiguousarray(e["texels"], np.float32).reshape(-1)
+        out = np.zeros(len(host), np.float32)
+        level0 = host[: img.size].copy()                                        # (the host's level 0: ImageTexture::new has flipped / scaled the file's texels)
+        n = L.flow_pyramid(level0.ctypes.data, w, h, wrap, out.ctypes.data)
+        assert n == e["n_levels"], ((h, w), n, e["n_levels"])
+        got = np.concatenate([level0, out[: len(host) - img.size]])
+        assert np.array_equal(got.view(np.uint32), host.view(np.uint32)), ((h, w), int((got != host).sum()))
